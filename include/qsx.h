@@ -1,0 +1,403 @@
+/*
+ * qsx.h — C ABI of the MI355X (gfx950) execution kernel for Quickstep's
+ * relational_operators hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI on
+ * this path: the five hot WorkOrder::execute() bodies call C++ templates in
+ * storage/ and expressions/ directly.  Each entry point below names the
+ * reference function (file:line under the Quickstep tree) whose inner loop it
+ * replaces; a GPU work order's execute() calls exactly these and nothing else
+ * (see INTEGRATION.md for the reference-side binding).
+ *
+ * Conventions
+ *   - every pointer named *_dev / documented "device" is HBM (or pinned,
+ *     device-visible host memory); "host" pointers are ordinary host memory;
+ *   - sizes are in rows (tuples) unless a name says _bytes;
+ *   - every call is ordered on `stream` (a hipStream_t passed as void*; NULL
+ *     is the default stream) and returns without synchronising unless its
+ *     comment says "synchronises";
+ *   - return value: QSX_OK (0) or a negative qsx_status_t; qsx_status_string()
+ *     describes it.  Nothing falls back to a CPU implementation: with no
+ *     usable GPU every compute entry point returns QSX_ERR_NO_DEVICE.
+ *   - bitmaps are TupleIdSequence-compatible: 64-bit words, bit i of the
+ *     sequence is  word[i >> 6] & (1ull << (63 - (i & 63)))  (MSB first,
+ *     utility/BitVector.hpp:893-935), trailing bits zero.
+ */
+#ifndef QSX_H_
+#define QSX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QSX_ABI_VERSION 1
+
+typedef void *qsx_stream_t;
+
+typedef enum qsx_status {
+  QSX_OK = 0,
+  QSX_ERR_INVALID_ARGUMENT = -1,
+  QSX_ERR_NO_DEVICE = -2,
+  QSX_ERR_OUT_OF_MEMORY = -3,
+  QSX_ERR_HIP = -4,
+  QSX_ERR_CAPACITY = -5,     /* caller-provided output / table too small */
+  QSX_ERR_UNSUPPORTED = -6,
+  QSX_ERR_TOO_MANY_GROUPS = -7
+} qsx_status_t;
+
+/* Value types; numbering follows types/TypeID.hpp:32-43 (kInt, kLong, kFloat,
+ * kDouble, kChar) so a reference TypeID can be passed through unchanged.
+ * QSX_CHAR columns are fixed-width byte strings of 1, 2, 4 or 8 bytes and are
+ * only legal as group-by key components (compact-key packing). */
+typedef enum qsx_type {
+  QSX_INT = 0,    /* int32 */
+  QSX_LONG = 1,   /* int64 */
+  QSX_FLOAT = 2,  /* float */
+  QSX_DOUBLE = 3, /* double */
+  QSX_CHAR = 4
+} qsx_type_t;
+
+/* Comparison ids; numbering follows types/operations/comparisons/ComparisonID.hpp:36-42. */
+typedef enum qsx_cmp {
+  QSX_EQ = 0, QSX_NE = 1, QSX_LT = 2, QSX_LE = 3, QSX_GT = 4, QSX_GE = 5
+} qsx_cmp_t;
+
+const char *qsx_status_string(int status);
+int qsx_abi_version(void);
+/* sizeof(qsx_agg_config_t) as compiled into the library: lets a foreign-language
+ * binding (ctypes, cgo, JNI) verify its struct mirror before the first call. */
+size_t qsx_abi_sizeof_agg_config(void);
+/* Number of usable gfx950 devices (0 when there is none). Never fails. */
+int qsx_device_count(void);
+/* Text of the last HIP error seen by this thread ("" if none). */
+const char *qsx_last_error(void);
+
+/* ---- device memory plumbing (used by the host StorageManager; tests and
+ * bench.py use torch allocations instead) ------------------------------- */
+int qsx_device_alloc(size_t bytes, void **out_dev);
+int qsx_device_free(void *dev);
+int qsx_copy_to_device(void *dst_dev, const void *src_host, size_t bytes, qsx_stream_t stream);
+int qsx_copy_to_host(void *dst_host, const void *src_dev, size_t bytes, qsx_stream_t stream);
+int qsx_memset_device(void *dst_dev, int byte, size_t bytes, qsx_stream_t stream);
+int qsx_stream_synchronize(qsx_stream_t stream);
+
+/* ======================================================================
+ * Select: predicate + projection
+ * ====================================================================== */
+
+/* K1.  out_bitmap[i] = (col[i] OP *literal) [AND filter[i]].
+ * Replaces LiteralUncheckedComparator::compareValueAccessorAndStaticValueHelper
+ * (types/operations/comparisons/LiteralComparators-inl.hpp:317-388) as reached
+ * from ComparisonPredicate::getAllMatches (expressions/predicate/
+ * ComparisonPredicate.cpp:115-334) and StorageBlock::getMatchesForPredicate
+ * (storage/StorageBlock.cpp:1053-1083).
+ *   type        QSX_INT / QSX_LONG / QSX_FLOAT / QSX_DOUBLE (column and literal share it)
+ *   col_dev     n values, densely packed (a BasicColumnStore stripe)
+ *   literal     host pointer to one value of `type`
+ *   filter_dev  optional existing TupleIdSequence (n bits) or NULL; only rows set
+ *               in it can be set in the output (short-circuit semantics,
+ *               LiteralComparators-inl.hpp:344-356)
+ *   out_bitmap_dev  (n+63)/64 words, fully overwritten
+ *   out_count_dev   optional int64 on device receiving popcount(out) (overwritten) */
+int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op,
+                   const void *literal, const uint64_t *filter_dev,
+                   uint64_t *out_bitmap_dev, int64_t *out_count_dev,
+                   qsx_stream_t stream);
+
+/* Bitmap algebra on TupleIdSequences of n bits (storage/TupleIdSequence.hpp:
+ * intersectWith / unionWith / invert). op: 0 = AND, 1 = OR, 2 = AND NOT,
+ * 3 = NOT a (b ignored). */
+int qsx_bitmap_combine(int op, const uint64_t *a_dev, const uint64_t *b_dev, int64_t n,
+                       uint64_t *out_dev, qsx_stream_t stream);
+int qsx_bitmap_count(const uint64_t *bitmap_dev, int64_t n, int64_t *out_count_dev,
+                     qsx_stream_t stream);
+
+/* Scratch bytes qsx_compact_gather / qsx_bitmap_to_tids need for n input rows. */
+size_t qsx_compact_workspace_bytes(int64_t n);
+
+/* K2.  Order-preserving compaction of the rows selected by `bitmap` for
+ * `ncols` columns at once.  Replaces StorageBlock::selectSimple ->
+ * BasicColumnStoreTupleStorageSubBlock::bulkInsertTuplesWithRemappedAttributes
+ * (storage/StorageBlock.cpp:390-399, storage/BasicColumnStoreTupleStorageSubBlock.cpp:339-425).
+ *   cols / out_cols  host arrays of ncols device pointers
+ *   widths           host array of value widths in bytes (1, 2, 4 or 8)
+ *   out_count_dev    int64 on device: number of rows written
+ * Output columns must have room for popcount(bitmap) rows. */
+int qsx_compact_gather(int ncols, const void *const *cols, const int32_t *widths,
+                       const uint64_t *bitmap_dev, int64_t n, void *const *out_cols,
+                       int64_t *out_count_dev, void *workspace_dev, size_t workspace_bytes,
+                       qsx_stream_t stream);
+
+/* TupleIdSequence -> ascending tuple-id list (base_tid + position). */
+int qsx_bitmap_to_tids(const uint64_t *bitmap_dev, int64_t n, int32_t base_tid,
+                       int32_t *out_tids_dev, int64_t *out_count_dev,
+                       void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
+
+/* K5.  dst[i] = src[tids[i]] for i < n (value width 1/2/4/8 bytes); tids < 0
+ * write zero bytes (outer-join NULL padding; the null bit is the caller's).
+ * Replaces ScalarAttribute::getAllValuesForJoin (expressions/scalar/
+ * ScalarAttribute.cpp:185-225) as used by HashInnerJoinWorkOrder
+ * (relational_operators/HashJoinOperator.cpp:527-539). */
+int qsx_gather(int width, const void *src_dev, const int32_t *tids_dev, int64_t n,
+               void *dst_dev, qsx_stream_t stream);
+
+/* ======================================================================
+ * Hash join
+ * ====================================================================== */
+
+typedef struct qsx_join_table qsx_join_table_t;
+
+/* JoinHashTable for one single-attribute INT or LONG key (the case
+ * SimplifyHashTableImplTypeProto reduces to SimpleScalarSeparateChaining,
+ * storage/HashTableFactory.cpp:58-68).  Duplicate keys are kept; the value is
+ * a 32-bit build-side tuple reference chosen by the caller (see base_tid).
+ * est_entries is the optimizer estimate (ExecutionGenerator.cpp:903-904); the
+ * table grows on its own when the estimate is exceeded (counterpart of
+ * HashTable::resize, storage/HashTable.hpp:1437-1440).  Synchronises. */
+int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **out);
+int qsx_join_table_destroy(qsx_join_table_t *table);
+/* Number of entries inserted so far.  Synchronises on `stream`. */
+int qsx_join_table_size(qsx_join_table_t *table, int64_t *out_entries, qsx_stream_t stream);
+
+/* K3.  Insert (keys[i] -> base_tid + i) for every row i < n that is set in
+ * filter (all rows when filter_dev is NULL).  Safe to call concurrently from
+ * several host threads / streams on the same table, like many
+ * BuildHashWorkOrders sharing one JoinHashTable.  Replaces
+ * HashTable::putValueAccessor (storage/HashTable.hpp:1358-1461) ->
+ * SimpleScalarSeparateChainingHashTable::putInternal / locateBucketForInsertion
+ * (storage/SimpleScalarSeparateChainingHashTable.hpp:1062-1113) as called from
+ * BuildHashWorkOrder::execute (relational_operators/BuildHashOperator.cpp:162-207).
+ * May synchronise when the table has to grow. */
+int qsx_join_build(qsx_join_table_t *table, const void *keys_dev, int64_t n,
+                   int32_t base_tid, const uint64_t *filter_dev, qsx_stream_t stream);
+
+/* K4.  Inner-join probe: for every probe row i < n (set in filter) and every
+ * table entry with an equal key, emit (probe_base_tid + i, build_tid).
+ * Replaces HashTable::getAllFromValueAccessorImpl (storage/HashTable.hpp:
+ * 2145-2181) + the pair collector (relational_operators/HashJoinOperator.cpp:
+ * 76-130) inside HashInnerJoinWorkOrder::execute (:450-541).
+ *   out_*_dev      arrays of `capacity` int32 each
+ *   out_count_dev  int64 on device: total number of matches (also when it
+ *                  exceeds capacity; pairs beyond capacity are not written —
+ *                  the caller compares and re-runs with a larger buffer)
+ * Pair order is unspecified (reference: unordered_map iteration order,
+ * HashJoinOperator.cpp:480). */
+int qsx_join_probe(qsx_join_table_t *table, const void *keys_dev, int64_t n,
+                   int32_t probe_base_tid, const uint64_t *filter_dev,
+                   int32_t *out_probe_tid_dev, int32_t *out_build_tid_dev,
+                   int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream);
+
+/* Number of matches only (no output written); same semantics as out_count_dev. */
+int qsx_join_probe_count(qsx_join_table_t *table, const void *keys_dev, int64_t n,
+                         const uint64_t *filter_dev, int64_t *out_count_dev,
+                         qsx_stream_t stream);
+
+/* Existence probe for semi / anti joins: out_bitmap bit i = filter[i] AND
+ * (key i found) when anti == 0, filter[i] AND NOT found when anti != 0.
+ * Replaces HashTable::runOverKeysFromValueAccessorIfMatch[Not]Found
+ * (storage/HashTable.hpp:1979-2062) as used by HashSemiJoinWorkOrder /
+ * HashAntiJoinWorkOrder (relational_operators/HashJoinOperator.cpp:795-816, 860-877). */
+int qsx_join_probe_exists(qsx_join_table_t *table, const void *keys_dev, int64_t n,
+                          const uint64_t *filter_dev, int anti,
+                          uint64_t *out_bitmap_dev, int64_t *out_count_dev,
+                          qsx_stream_t stream);
+
+/* ======================================================================
+ * Aggregation
+ * ====================================================================== */
+
+typedef struct qsx_agg_state qsx_agg_state_t;
+
+/* Strategy; chosen by the caller with the optimizer's rules
+ * (query_optimizer/ExecutionGenerator.cpp:1922-1965,
+ *  query_optimizer/cost_model/StarSchemaSimpleCostModel.cpp:614-776). */
+typedef enum qsx_agg_strategy {
+  QSX_AGG_SINGLE_STATE = 0,   /* no GROUP BY (AggregationOperationState.cpp:476-519) */
+  QSX_AGG_COMPACT_KEY = 1,    /* ThreadPrivateCompactKeyHashTable (.cpp:203-304) */
+  QSX_AGG_COLLISION_FREE = 2, /* CollisionFreeVectorTable (.hpp:530-645) */
+  QSX_AGG_GENERIC = 3         /* PackedPayloadHashTable (.hpp:838-909); keys <= 8 bytes packed */
+} qsx_agg_strategy_t;
+
+typedef enum qsx_agg_fn {
+  QSX_AGG_COUNT_STAR = 0, /* COUNT(*)            -> int64 */
+  QSX_AGG_SUM = 1,        /* SUM(int|long) -> int64 ; SUM(float|double|expr) -> double */
+  QSX_AGG_AVG = 2         /* sum / (double)count -> double (AggregationHandleAvg.cpp:144-155) */
+} qsx_agg_fn_t;
+
+/* Operand of an expression instruction or an aggregate argument. */
+typedef enum qsx_operand_kind {
+  QSX_OPD_COLUMN = 0, /* index = input column */
+  QSX_OPD_CONST = 1,  /* index = slot in consts[] */
+  QSX_OPD_TEMP = 2    /* index = result of an earlier instruction (its dst) */
+} qsx_operand_kind_t;
+
+typedef struct qsx_operand {
+  int32_t kind;
+  int32_t index;
+} qsx_operand_t;
+
+typedef enum qsx_expr_op {
+  QSX_EX_ADD = 0, QSX_EX_SUB = 1, QSX_EX_MUL = 2, QSX_EX_DIV = 3
+} qsx_expr_op_t;
+
+/* temp[dst] = a OP b, evaluated per row in IEEE double, operands converted
+ * to double first (Quickstep promotes INT/LONG/FLOAT op DOUBLE to DOUBLE,
+ * types/operations/binary_operations/ArithmeticBinaryOperators.hpp:203-340).
+ * This replaces the temporary NativeColumnVectors of
+ * ScalarBinaryExpression::getAllValues (expressions/scalar/
+ * ScalarBinaryExpression.cpp:100-195) — fused, nothing is materialised. */
+typedef struct qsx_expr_instr {
+  int32_t op;
+  int32_t dst; /* 0 .. QSX_MAX_TEMPS-1 */
+  qsx_operand_t a;
+  qsx_operand_t b;
+} qsx_expr_instr_t;
+
+typedef struct qsx_agg_desc {
+  int32_t fn;        /* qsx_agg_fn_t */
+  qsx_operand_t arg; /* ignored for COUNT(*); COLUMN or TEMP */
+} qsx_agg_desc_t;
+
+/* Comparison predicate held by the aggregation state (the reference keeps the
+ * predicate in AggregationOperationState, .cpp:440-445); conjunction of
+ * `column OP literal` terms evaluated inside the aggregation kernel. */
+typedef struct qsx_pred_term {
+  int32_t column;
+  int32_t op;           /* qsx_cmp_t */
+  union { int32_t i32; int64_t i64; float f32; double f64; } literal; /* typed like the column */
+} qsx_pred_term_t;
+
+#define QSX_MAX_COLUMNS 16
+#define QSX_MAX_KEYS 4
+#define QSX_MAX_AGGS 8
+#define QSX_MAX_INSTRS 16
+#define QSX_MAX_TEMPS 8
+#define QSX_MAX_CONSTS 8
+#define QSX_MAX_PRED_TERMS 4
+
+typedef struct qsx_agg_config {
+  int32_t strategy;                       /* qsx_agg_strategy_t */
+  int32_t num_columns;                    /* columns handed to every qsx_agg_update */
+  int32_t column_type[QSX_MAX_COLUMNS];   /* qsx_type_t */
+  int32_t column_width[QSX_MAX_COLUMNS];  /* bytes; 4/8/4/8 for INT/LONG/FLOAT/DOUBLE, 1/2/4/8 for CHAR */
+  int32_t num_keys;
+  int32_t key_column[QSX_MAX_KEYS];       /* GROUP BY order; packed little-endian at running
+                                             offsets into a 64-bit code (ThreadPrivateCompactKeyHashTable.cpp:216-232) */
+  int32_t num_instrs;
+  qsx_expr_instr_t instrs[QSX_MAX_INSTRS];
+  double consts[QSX_MAX_CONSTS];
+  int32_t num_aggs;
+  qsx_agg_desc_t aggs[QSX_MAX_AGGS];
+  int32_t num_pred_terms;
+  qsx_pred_term_t pred[QSX_MAX_PRED_TERMS];
+  int64_t est_groups;                     /* optimizer estimate; tables grow past it */
+  int64_t num_entries;                    /* COLLISION_FREE only: max_key + 1 (StarSchemaSimpleCostModel.cpp:707) */
+} qsx_agg_config_t;
+
+/* Counterpart of the AggregationOperationState constructor
+ * (storage/AggregationOperationState.cpp:74-252) + InitializeAggregation
+ * (zeroing; CollisionFreeVectorTable.hpp:136-143).  Synchronises. */
+int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out);
+int qsx_agg_state_destroy(qsx_agg_state_t *state);
+
+/* K6/K7/K8 (+K11 fused).  Accumulate n rows into the state.  Replaces
+ * AggregationOperationState::aggregateBlock (storage/AggregationOperationState.cpp:
+ * 428-474) and below: aggregateBlockSingleState (:476-519),
+ * ThreadPrivateCompactKeyHashTable::upsertValueAccessorCompositeKey (.cpp:203-304),
+ * CollisionFreeVectorTable::upsertValueAccessor* (.hpp:530-645),
+ * PackedPayloadHashTable::upsertValueAccessorCompositeKey (.hpp:838-909).
+ *   cols        host array of config.num_columns device pointers (n values each)
+ *   filter_dev  optional TupleIdSequence restricting the rows (e.g. a LIP result)
+ * Safe to call concurrently on one state from several host threads/streams,
+ * like many AggregationWorkOrders sharing one state. */
+int qsx_agg_update(qsx_agg_state_t *state, const void *const *cols, int64_t n,
+                   const uint64_t *filter_dev, qsx_stream_t stream);
+
+/* dst += src (same config).  Counterpart of
+ * ThreadPrivateCompactKeyHashTable::mergeFrom (.cpp:306-363) and
+ * AggregationOperationState::mergeGroupByHashTables (.cpp:831-843). */
+int qsx_agg_merge(qsx_agg_state_t *dst, const qsx_agg_state_t *src, qsx_stream_t stream);
+
+/* Raw partial state for transport between GPUs (RCCL all-gather /
+ * reduce-scatter of partial aggregates).  Layout per strategy is described in
+ * DESIGN.md; size is fixed once the state is created. */
+int qsx_agg_state_export_bytes(const qsx_agg_state_t *state, size_t *out_bytes);
+int qsx_agg_state_export(const qsx_agg_state_t *state, void *out_dev, qsx_stream_t stream);
+/* dst += exported image of a state with the same config. */
+int qsx_agg_state_import_merge(qsx_agg_state_t *dst, const void *image_dev, qsx_stream_t stream);
+
+/* Upper bound on the number of groups a finalize of partition p can emit.
+ * Synchronises on `stream`. */
+int qsx_agg_num_groups(qsx_agg_state_t *state, int64_t *out_groups, qsx_stream_t stream);
+
+/* K10.  Emit one row per group of finalize-partition `partition` of
+ * `num_partitions`: key columns (width = the key column's width) and one
+ * value column per aggregate (int64 for COUNT and SUM over INT/LONG, double
+ * otherwise).  Replaces AggregationOperationState::finalizeAggregate
+ * (storage/AggregationOperationState.cpp:641-948), incl.
+ * CollisionFreeVectorTable::finalizeKey/finalizeState (.hpp:647-727; ascending
+ * key order, partition = contiguous key range) and
+ * ThreadPrivateCompactKeyHashTable::finalize (.cpp:365-421).
+ *   out_null_dev  optional array of num_aggs byte columns; 1 = NULL result
+ *                 (SUM/AVG over zero rows in SINGLE_STATE, AggregationHandleSum.cpp:45-120)
+ *   out_groups_dev int64 on device: rows written. */
+int qsx_agg_finalize(qsx_agg_state_t *state, int partition, int num_partitions,
+                     void *const *out_key_cols, void *const *out_val_cols,
+                     uint8_t *const *out_null_cols, int64_t capacity,
+                     int64_t *out_groups_dev, qsx_stream_t stream);
+
+/* ======================================================================
+ * LIP filters (utility/lip_filter/)
+ * ====================================================================== */
+
+typedef struct qsx_lip_filter qsx_lip_filter_t;
+
+typedef enum qsx_lip_kind {
+  QSX_LIP_SINGLE_IDENTITY_HASH = 0, /* bit = value % cardinality (SingleIdentityHashFilter.hpp:156-169) */
+  QSX_LIP_BITVECTOR_EXACT = 1       /* bit = value - min, out of range = miss (BitVectorExactFilter.hpp:150-176) */
+} qsx_lip_kind_t;
+
+/* cardinality: filter bits (IDENTITY_HASH: max(64, 8*est build cardinality);
+ * EXACT: max - min + 1).  min_value only used by EXACT.  Synchronises. */
+int qsx_lip_filter_create(int kind, int64_t cardinality, int64_t min_value, int is_anti,
+                          qsx_lip_filter_t **out);
+int qsx_lip_filter_destroy(qsx_lip_filter_t *f);
+/* LIPFilterBuilder::insertValueAccessor (BuildHashOperator.cpp:187-190). */
+int qsx_lip_build(qsx_lip_filter_t *f, int key_type, const void *keys_dev, int64_t n,
+                  const uint64_t *filter_dev, qsx_stream_t stream);
+/* LIPFilterAdaptiveProber::filterValueAccessor (LIPFilterAdaptiveProber.hpp:83-90):
+ * out = in AND hit(filter, key).  in_bitmap_dev may be NULL (= all rows). */
+int qsx_lip_probe(const qsx_lip_filter_t *f, int key_type, const void *keys_dev, int64_t n,
+                  const uint64_t *in_bitmap_dev, uint64_t *out_bitmap_dev,
+                  int64_t *out_count_dev, qsx_stream_t stream);
+/* Raw bit array (for all-reduce(OR) across GPUs): 64-bit words, LSB-first. */
+int qsx_lip_filter_words(qsx_lip_filter_t *f, uint64_t **out_words_dev, int64_t *out_num_words);
+
+/* ======================================================================
+ * Hash partitioning (multi-GPU shuffle, partitioned aggregation)
+ * ====================================================================== */
+
+/* Partition id of a key = HashPartitionSchemeHeader::getPartitionId
+ * (catalog/PartitionSchemeHeader.hpp:200-214) with the identity hash of
+ * types/TypedValue.hpp:575-592: h = zero-extended bit pattern;
+ * pid = P power of two ? h & (P-1) : (h >= P ? h % P : h). */
+size_t qsx_partition_workspace_bytes(int64_t n, int num_partitions);
+
+/* K9.  Stable scatter of n rows into num_partitions contiguous regions by the
+ * partition id of keys[i]; moves `ncols` payload columns (the key column may
+ * be one of them).  out_offsets_dev receives num_partitions + 1 int64 row
+ * offsets (exclusive prefix of partition sizes).  Counterpart of
+ * PartitionAwareInsertDestination routing (storage/InsertDestination.hpp:490-660). */
+int qsx_partition_scatter(int key_type, const void *keys_dev, int64_t n, int num_partitions,
+                          int ncols, const void *const *cols, const int32_t *widths,
+                          void *const *out_cols, int64_t *out_offsets_dev,
+                          void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* QSX_H_ */

@@ -1,0 +1,331 @@
+"""ctypes binding of the CPU ORACLE (oracle/libqsx_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — importable from tests/, __graft_entry__.smoke() and
+the cpu_baseline leg of bench.py; nothing under quickstep_amd/ imports it.
+Works on numpy arrays in host memory.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from quickstep_amd import types as T  # noqa: E402  (descriptor structs only; loads no library)
+
+LIB_PATH = os.path.join(_HERE, "libqsx_oracle.so")
+REF_PIN = os.path.join(_HERE, "_ref", "ref_pin")
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+if not os.path.exists(LIB_PATH):
+    build()
+_lib = C.CDLL(LIB_PATH)
+
+_vp, _i64, _i32, _int, _u64, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_uint64, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+
+
+class JoinBenchResult(C.Structure):
+    _fields_ = [("build_seconds", C.c_double), ("probe_seconds", C.c_double), ("matches", C.c_int64),
+                ("checksum", C.c_uint64)]
+
+
+for _name, _res, _args in [
+    ("qso_sizeof_agg_config", _sz, []),
+    ("qso_hash_scalar", _u64, [_int, _vp]),
+    ("qso_combine_hashes", _u64, [_u64, _u64]),
+    ("qso_next_prime", _u64, [_u64]),
+    ("qso_prev_prime", _u64, [_u64]),
+    ("qso_partition_id", _u64, [_u64, _u64]),
+    ("qso_select_cmp", None, [_int, _vp, _i64, _int, _vp, _vp, _vp]),
+    ("qso_bitmap_count", _i64, [_vp, _i64]),
+    ("qso_compact_gather", _i64, [_int, _vp, _vp, _i64, _vp]),
+    ("qso_bitmap_to_tids", _i64, [_vp, _i64, _i32, _vp]),
+    ("qso_gather", None, [_int, _vp, _vp, _i64, _vp]),
+    ("qso_join_table_create", _vp, [_int, _i64]),
+    ("qso_join_table_destroy", None, [_vp]),
+    ("qso_join_table_info", None, [_vp, C.POINTER(_u64)]),
+    ("qso_join_build", None, [_vp, _vp, _i64, _u64, _i32, _vp]),
+    ("qso_join_probe", _i64, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64]),
+    ("qso_join_probe_exists", None, [_vp, _vp, _i64, _vp, _int, _vp]),
+    ("qso_agg_state_create", _vp, [C.POINTER(T.AggConfig)]),
+    ("qso_agg_state_destroy", None, [_vp]),
+    ("qso_agg_update", None, [_vp, _pp, _i64, _vp]),
+    ("qso_agg_merge", None, [_vp, _vp]),
+    ("qso_agg_num_groups", _i64, [_vp]),
+    ("qso_agg_finalize", _i64, [_vp, _int, _int, _pp, _pp, _pp, _i64]),
+    ("qso_lip_filter_create", _vp, [_int, _i64, _i64, _int]),
+    ("qso_lip_filter_destroy", None, [_vp]),
+    ("qso_lip_build", None, [_vp, _int, _vp, _i64, _vp]),
+    ("qso_lip_probe", None, [_vp, _int, _vp, _i64, _vp, _vp]),
+    ("qso_partition_offsets", None, [_int, _vp, _i64, _int, _vp]),
+    ("qso_partition_scatter_col", None, [_int, _vp, _i64, _int, _int, _vp, _vp]),
+    ("qso_bench_join", None, [_int, _vp, _i64, _vp, _i64, _i64, _int, C.POINTER(JoinBenchResult)]),
+    ("qso_bench_agg", C.c_double, [C.POINTER(T.AggConfig), _pp, _i64, _i64, _int, _pp]),
+    ("qso_bench_select", C.c_double, [_int, _vp, _i64, _int, _vp, _i64, _int, _vp, C.POINTER(_i64)]),
+]:
+    _f = getattr(_lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+
+assert _lib.qso_sizeof_agg_config() == C.sizeof(T.AggConfig)
+
+_NP_TYPE = {np.dtype(np.int32): T.INT, np.dtype(np.int64): T.LONG, np.dtype(np.float32): T.FLOAT,
+            np.dtype(np.float64): T.DOUBLE}
+_C_SCALAR = {T.INT: C.c_int32, T.LONG: C.c_int64, T.FLOAT: C.c_float, T.DOUBLE: C.c_double}
+
+
+def qtype(a):
+    return _NP_TYPE[a.dtype]
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+def _ptr_array(arrays):
+    arr = (C.c_void_p * max(len(arrays), 1))()
+    for i, a in enumerate(arrays):
+        arr[i] = None if a is None else a.ctypes.data
+    return arr
+
+
+def words(n):
+    return (n + 63) // 64
+
+
+# ---- scalar helpers ---------------------------------------------------------
+def hash_scalar(qt, value):
+    v = _C_SCALAR[qt](value)
+    return _lib.qso_hash_scalar(qt, C.byref(v))
+
+
+def combine_hashes(a, b):
+    return _lib.qso_combine_hashes(a, b)
+
+
+def next_prime(n):
+    return _lib.qso_next_prime(n)
+
+
+def prev_prime(n):
+    return _lib.qso_prev_prime(n)
+
+
+def partition_id(h, p):
+    return _lib.qso_partition_id(h, p)
+
+
+def ref_combine_hashes(pairs):
+    """CombineHashes evaluated by the REFERENCE's own utility/HashPair.hpp (oracle/_ref/ref_pin)."""
+    args = [REF_PIN]
+    for a, b in pairs:
+        args += [str(a), str(b)]
+    out = subprocess.run(args, check=True, capture_output=True, text=True).stdout.split()
+    return [int(x, 16) for x in out]
+
+
+# ---- select --------------------------------------------------------------------
+def select_cmp(col, op, literal, filter_bitmap=None):
+    n = col.size
+    out = np.zeros(max(words(n), 1), dtype=np.uint64)
+    lit = _C_SCALAR[qtype(col)](literal)
+    _lib.qso_select_cmp(qtype(col), _p(col), n, op, C.byref(lit), _p(filter_bitmap), _p(out))
+    return out
+
+
+def bitmap_count(bitmap, n):
+    return _lib.qso_bitmap_count(_p(bitmap), n)
+
+
+def compact_gather(col, bitmap):
+    out = np.empty_like(col)
+    k = _lib.qso_compact_gather(col.itemsize, _p(col), _p(bitmap), col.size, _p(out))
+    return out[:k]
+
+
+def bitmap_to_tids(bitmap, n, base_tid=0):
+    out = np.empty(max(n, 1), dtype=np.int32)
+    k = _lib.qso_bitmap_to_tids(_p(bitmap), n, base_tid, _p(out))
+    return out[:k]
+
+
+def gather(src, tids):
+    out = np.empty(tids.size, dtype=src.dtype)
+    _lib.qso_gather(src.itemsize, _p(src), _p(tids), tids.size, _p(out))
+    return out
+
+
+def bitmap_from_bools(bools):
+    """MSB-first TupleIdSequence words from a boolean array (test helper)."""
+    n = bools.size
+    padded = np.zeros(words(n) * 64, dtype=np.uint8)
+    padded[:n] = bools
+    return np.packbits(padded.reshape(-1, 64), axis=1, bitorder="big").view(">u8").astype(np.uint64).reshape(-1)
+
+
+def bools_from_bitmap(bitmap, n):
+    be = bitmap.astype(">u8").view(np.uint8)
+    return np.unpackbits(be, bitorder="big")[:n].astype(bool)
+
+
+# ---- join ------------------------------------------------------------------------
+class JoinTable:
+    def __init__(self, key_type, est_entries):
+        self._h = C.c_void_p(_lib.qso_join_table_create(key_type, est_entries))
+        assert self._h.value
+
+    def close(self):
+        if self._h is not None:
+            _lib.qso_join_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def info(self):
+        out = (C.c_uint64 * 4)()
+        _lib.qso_join_table_info(self._h, out)
+        return dict(num_slots=out[0], num_buckets=out[1], buckets_allocated=out[2], blob_bytes=out[3])
+
+    def build(self, keys, block_id=0, base_tid=0, filter_bitmap=None):
+        _lib.qso_join_build(self._h, _p(keys), keys.size, block_id, base_tid, _p(filter_bitmap))
+
+    def probe(self, keys, capacity=None, probe_base_tid=0, filter_bitmap=None, with_blocks=False):
+        n = keys.size
+        cap = n if capacity is None else capacity
+        while True:
+            op = np.empty(max(cap, 1), dtype=np.int32)
+            ob = np.empty(max(cap, 1), dtype=np.int32)
+            blocks = np.empty(max(cap, 1), dtype=np.uint64) if with_blocks else None
+            k = _lib.qso_join_probe(self._h, _p(keys), n, probe_base_tid, _p(filter_bitmap), _p(op), _p(ob),
+                                    _p(blocks), cap)
+            if k <= cap or capacity is not None:
+                break
+            cap = k
+        k = min(k, cap)
+        if with_blocks:
+            return op[:k], ob[:k], blocks[:k]
+        return op[:k], ob[:k]
+
+    def probe_exists(self, keys, anti=False, filter_bitmap=None):
+        out = np.zeros(max(words(keys.size), 1), dtype=np.uint64)
+        _lib.qso_join_probe_exists(self._h, _p(keys), keys.size, _p(filter_bitmap), 1 if anti else 0, _p(out))
+        return out
+
+
+# ---- aggregation --------------------------------------------------------------------
+class AggState:
+    def __init__(self, config, handle=None):
+        self.config = config
+        self._h = C.c_void_p(_lib.qso_agg_state_create(C.byref(config))) if handle is None else handle
+
+    def close(self):
+        if self._h is not None:
+            _lib.qso_agg_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def update(self, cols, n=None, filter_bitmap=None):
+        if n is None:
+            n = cols[0].size
+        _lib.qso_agg_update(self._h, _ptr_array(cols), n, _p(filter_bitmap))
+
+    def merge(self, other):
+        _lib.qso_agg_merge(self._h, other._h)
+
+    def num_groups(self):
+        return _lib.qso_agg_num_groups(self._h)
+
+    def finalize(self, partition=0, num_partitions=1):
+        cfg = self.config
+        cap = max(self.num_groups(), 1)
+        keys = []
+        for k in range(cfg.num_keys):
+            w = cfg.column_width[cfg.key_column[k]]
+            keys.append(np.zeros(cap, dtype={1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}[w]))
+        vals, nulls = [], []
+        for a in range(cfg.num_aggs):
+            vals.append(np.zeros(cap, dtype=np.int64 if T.agg_output_is_int(cfg, a) else np.float64))
+            nulls.append(np.zeros(cap, dtype=np.uint8))
+        rows = _lib.qso_agg_finalize(self._h, partition, num_partitions, _ptr_array(keys), _ptr_array(vals),
+                                     _ptr_array(nulls), cap)
+        return [k[:rows] for k in keys], [v[:rows] for v in vals], [z[:rows] for z in nulls]
+
+
+# ---- LIP -------------------------------------------------------------------------------
+class LipFilter:
+    def __init__(self, kind, cardinality, min_value=0, is_anti=False):
+        self._h = C.c_void_p(_lib.qso_lip_filter_create(kind, cardinality, min_value, 1 if is_anti else 0))
+
+    def close(self):
+        if self._h is not None:
+            _lib.qso_lip_filter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def build(self, keys, filter_bitmap=None):
+        _lib.qso_lip_build(self._h, qtype(keys), _p(keys), keys.size, _p(filter_bitmap))
+
+    def probe(self, keys, in_bitmap=None):
+        out = np.zeros(max(words(keys.size), 1), dtype=np.uint64)
+        _lib.qso_lip_probe(self._h, qtype(keys), _p(keys), keys.size, _p(in_bitmap), _p(out))
+        return out
+
+
+# ---- partition ----------------------------------------------------------------------------
+def partition_offsets(keys, num_partitions):
+    out = np.zeros(num_partitions + 1, dtype=np.int64)
+    _lib.qso_partition_offsets(qtype(keys), _p(keys), keys.size, num_partitions, _p(out))
+    return out
+
+
+def partition_scatter(keys, num_partitions, col):
+    out = np.empty_like(col)
+    _lib.qso_partition_scatter_col(qtype(keys), _p(keys), keys.size, num_partitions, col.itemsize, _p(col), _p(out))
+    return out
+
+
+# ---- CPU baseline drivers ---------------------------------------------------------------------
+def bench_join(build_keys, probe_keys, block_rows, num_threads):
+    r = JoinBenchResult()
+    _lib.qso_bench_join(qtype(build_keys), _p(build_keys), build_keys.size, _p(probe_keys), probe_keys.size,
+                        block_rows, num_threads, C.byref(r))
+    return dict(build_seconds=r.build_seconds, probe_seconds=r.probe_seconds, matches=r.matches, checksum=r.checksum)
+
+
+def bench_agg(config, cols, n, block_rows, num_threads):
+    h = C.c_void_p()
+    secs = _lib.qso_bench_agg(C.byref(config), _ptr_array(cols), n, block_rows, num_threads, C.byref(h))
+    return secs, AggState(config, handle=h)
+
+
+def bench_select(col, op, literal, block_rows, num_threads):
+    out = np.empty_like(col)
+    rows = C.c_int64()
+    lit = _C_SCALAR[qtype(col)](literal)
+    secs = _lib.qso_bench_select(qtype(col), _p(col), col.size, op, C.byref(lit), block_rows, num_threads, _p(out),
+                                 C.byref(rows))
+    return secs, out[:rows.value]

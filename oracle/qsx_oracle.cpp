@@ -1,0 +1,1080 @@
+// qsx_oracle.cpp — CPU ORACLE (test infrastructure; see qsx_oracle.h header
+// comment for what it is pinned against and who may call it).
+//
+// Every function is a restatement of the reference algorithm it cites
+// (paths relative to the Quickstep tree); nothing here is shared with the HIP
+// product path.  Build: see oracle/Makefile (g++ -O2 -ffp-contract=off).
+
+#include "qsx_oracle.h"
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <thread>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace {
+
+constexpr std::size_t kSlotSizeBytes = 0x200000;  // storage/StorageConstants.hpp:50
+constexpr std::uint64_t kSizeMax = ~static_cast<std::uint64_t>(0);
+
+// ---------------------------------------------------------------------------
+// BitVector<false> / TupleIdSequence bit order (utility/BitVector.hpp:893-935):
+// bit i lives in word i>>6 under mask (1<<63) >> (i & 63).
+// ---------------------------------------------------------------------------
+inline bool bit_get(const std::uint64_t *w, std::int64_t i) {
+  return (w[i >> 6] >> (63 - (i & 63))) & 1u;
+}
+inline void bit_set(std::uint64_t *w, std::int64_t i) {
+  w[i >> 6] |= (static_cast<std::uint64_t>(1) << 63) >> (i & 63);
+}
+inline std::int64_t bitmap_words(std::int64_t n) { return (n + 63) >> 6; }
+
+inline bool row_selected(const std::uint64_t *filter, std::int64_t i) {
+  return filter == nullptr || bit_get(filter, i);
+}
+
+// ---------------------------------------------------------------------------
+// Hashing (types/TypedValue.hpp:95-129 constructors, :575-592, :916-918).
+// ---------------------------------------------------------------------------
+inline std::uint64_t hash_int(std::int32_t v) { return static_cast<std::uint32_t>(v); }
+inline std::uint64_t hash_long(std::int64_t v) { return static_cast<std::uint64_t>(v); }
+inline std::uint64_t hash_float(float v) {
+  if (v == 0.0f) v = 0.0f;  // -0.0f canonicalised (TypedValue.hpp:113-120)
+  std::uint32_t bits;
+  std::memcpy(&bits, &v, 4);
+  return bits;
+}
+inline std::uint64_t hash_double(double v) {
+  if (v == 0.0) v = 0.0;  // TypedValue.hpp:125-129
+  std::uint64_t bits;
+  std::memcpy(&bits, &v, 8);
+  return bits;
+}
+
+inline std::uint64_t hash_typed(int type, const void *p) {
+  switch (type) {
+    case QSX_INT: { std::int32_t v; std::memcpy(&v, p, 4); return hash_int(v); }
+    case QSX_LONG: { std::int64_t v; std::memcpy(&v, p, 8); return hash_long(v); }
+    case QSX_FLOAT: { float v; std::memcpy(&v, p, 4); return hash_float(v); }
+    case QSX_DOUBLE: { double v; std::memcpy(&v, p, 8); return hash_double(v); }
+    default: std::abort();
+  }
+}
+
+inline int type_width(int type) {
+  switch (type) {
+    case QSX_INT: case QSX_FLOAT: return 4;
+    case QSX_LONG: case QSX_DOUBLE: return 8;
+    default: return 0;
+  }
+}
+
+// utility/HashPair.hpp:47-58 (64-bit specialisation).
+inline std::uint64_t combine_hashes(std::uint64_t first, std::uint64_t second) {
+  const std::uint64_t kMul = 0x9ddfea08eb382d69ULL;
+  std::uint64_t a = (first ^ second) * kMul;
+  a ^= (a >> 47);
+  std::uint64_t b = (second ^ a) * kMul;
+  b ^= (b >> 47);
+  b *= kMul;
+  return b;
+}
+
+bool is_prime(std::uint64_t n) {
+  if (n < 2) return false;
+  if (n < 4) return true;
+  if ((n & 1) == 0) return false;
+  for (std::uint64_t d = 3; d * d <= n; d += 2) {
+    if (n % d == 0) return false;
+  }
+  return true;
+}
+// utility/PrimeNumber.hpp:38 — least prime >= n.
+std::uint64_t next_prime(std::uint64_t n) {
+  if (n <= 2) return 2;
+  while (!is_prime(n)) ++n;
+  return n;
+}
+// utility/PrimeNumber.hpp:49 — greatest prime <= n, 0 if none.
+std::uint64_t prev_prime(std::uint64_t n) {
+  if (n < 2) return 0;
+  while (!is_prime(n)) --n;
+  return n;
+}
+
+// catalog/PartitionSchemeHeader.hpp:200-214.
+inline std::uint64_t partition_id(std::uint64_t h, std::uint64_t P) {
+  if ((P & (P - 1)) == 0) return h & (P - 1);
+  return h >= P ? h % P : h;
+}
+
+// ---------------------------------------------------------------------------
+// Comparison (types/operations/comparisons/LiteralComparators-inl.hpp:317-388).
+// ---------------------------------------------------------------------------
+template <typename T>
+inline bool compare(T a, int op, T b) {
+  switch (op) {
+    case QSX_EQ: return a == b;
+    case QSX_NE: return a != b;
+    case QSX_LT: return a < b;
+    case QSX_LE: return a <= b;
+    case QSX_GT: return a > b;
+    case QSX_GE: return a >= b;
+    default: return false;
+  }
+}
+
+template <typename T>
+void select_cmp_t(const T *col, std::int64_t n, int op, T lit, const std::uint64_t *filter,
+                  std::uint64_t *out) {
+  std::memset(out, 0, sizeof(std::uint64_t) * bitmap_words(n));
+  if (filter != nullptr) {
+    // short-circuit path (:344-356): evaluate only the rows of `filter`.
+    for (std::int64_t i = 0; i < n; ++i) {
+      if (bit_get(filter, i) && compare<T>(col[i], op, lit)) bit_set(out, i);
+    }
+  } else {
+    // :358-371 — per-row result->set(pos, cmp).
+    for (std::int64_t i = 0; i < n; ++i) {
+      if (compare<T>(col[i], op, lit)) bit_set(out, i);
+    }
+  }
+}
+
+}  // namespace
+
+// ===========================================================================
+// join hash table
+// ===========================================================================
+namespace {
+
+// storage/TupleReference.hpp:36-47
+struct TupleRef {
+  std::uint64_t block;
+  std::int32_t tuple;
+};
+// storage/SimpleScalarSeparateChainingHashTable.hpp:214-218 (32 bytes)
+struct Bucket {
+  std::atomic<std::uint64_t> next;
+  std::uint64_t hash;
+  TupleRef value;
+};
+static_assert(sizeof(Bucket) == 32, "bucket layout");
+constexpr std::size_t kHeaderBytes = 128;  // Header with a cache-line aligned atomic (:207-212)
+
+struct Storage {
+  std::uint64_t num_slots = 0;
+  std::uint64_t num_buckets = 0;
+  std::uint64_t blob_bytes = 0;
+  std::unique_ptr<std::atomic<std::uint64_t>[]> slots;
+  std::unique_ptr<Bucket[]> buckets;
+};
+
+// Sizing rule of the constructor (:283-397) and of resize (:838-895): take a
+// prime slot count, round the footprint up to whole 2 MiB storage slots, then
+// refit slots/buckets to the blob actually obtained.
+void size_storage(std::uint64_t wanted_slots, Storage *st) {
+  const std::uint64_t required = kHeaderBytes + wanted_slots * 8 + (wanted_slots * 32) / 2;
+  const std::uint64_t blob_slots = (required + kSlotSizeBytes - 1) / kSlotSizeBytes;
+  const std::uint64_t available = blob_slots * kSlotSizeBytes - kHeaderBytes;
+  std::uint64_t buckets = available / (2 * 8 + 32);
+  const std::uint64_t slots = prev_prime(buckets * 2);
+  buckets = slots / 2;
+  st->num_slots = slots;
+  st->num_buckets = buckets;
+  st->blob_bytes = blob_slots * kSlotSizeBytes;
+  st->slots.reset(new std::atomic<std::uint64_t>[slots]);
+  for (std::uint64_t i = 0; i < slots; ++i) st->slots[i].store(0, std::memory_order_relaxed);
+  st->buckets.reset(new Bucket[buckets]);
+  for (std::uint64_t i = 0; i < buckets; ++i) {
+    st->buckets[i].next.store(0, std::memory_order_relaxed);
+    st->buckets[i].hash = 0;
+    st->buckets[i].value = TupleRef{0, -1};
+  }
+}
+
+}  // namespace
+
+struct qso_join_table {
+  int key_type;
+  Storage st;
+  std::atomic<std::uint64_t> buckets_allocated{0};
+  std::shared_mutex resize_mutex;  // HashTable::resize_shared_mutex_ (storage/HashTable.hpp:1215)
+
+  inline std::uint64_t key_hash(const void *keys, std::int64_t i) const {
+    if (key_type == QSX_INT) return hash_int(static_cast<const std::int32_t *>(keys)[i]);
+    return hash_long(static_cast<const std::int64_t *>(keys)[i]);
+  }
+
+  // resize() (:820-985): grow to ~2x, copy the buckets, rebuild chains by
+  // pushing each bucket at the HEAD of its slot's chain (:968-981).
+  void resize(std::uint64_t extra_buckets) {
+    std::unique_lock<std::shared_mutex> lock(resize_mutex);
+    if (buckets_allocated.load() + extra_buckets < st.num_buckets) return;  // isFull (:241-244)
+    Storage bigger;
+    size_storage(next_prime((st.num_buckets + extra_buckets / 2) * 2 * 2), &bigger);
+    const std::uint64_t used = buckets_allocated.load();
+    for (std::uint64_t b = 0; b < used; ++b) {
+      bigger.buckets[b].hash = st.buckets[b].hash;
+      bigger.buckets[b].value = st.buckets[b].value;
+    }
+    st = std::move(bigger);
+    for (std::uint64_t b = 0; b < used; ++b) {
+      Bucket &bucket = st.buckets[b];
+      const std::uint64_t slot = bucket.hash % st.num_slots;
+      const std::uint64_t head = st.slots[slot].load(std::memory_order_relaxed);
+      bucket.next.store(head, std::memory_order_relaxed);  // 0 when the slot was empty
+      st.slots[slot].store(b + 1, std::memory_order_relaxed);
+    }
+  }
+
+  // preallocateForBulkInsert (:1003-1024).
+  bool preallocate(std::uint64_t total, std::uint64_t *position) {
+    std::uint64_t original = buckets_allocated.load(std::memory_order_relaxed);
+    std::uint64_t post = original + total;
+    while (post <= st.num_buckets &&
+           !buckets_allocated.compare_exchange_weak(original, post, std::memory_order_relaxed)) {
+      post = original + total;
+    }
+    if (post > st.num_buckets) return false;
+    *position = original;
+    return true;
+  }
+
+  // putInternal + locateBucketForInsertion with a preallocation state
+  // (:1062-1113): walk to the chain tail, CAS 0 -> pending, then publish.
+  void put_prealloc(std::uint64_t hash, const TupleRef &value, std::uint64_t *position) {
+    std::atomic<std::uint64_t> *pending = &st.slots[hash % st.num_slots];
+    for (;;) {
+      std::uint64_t existing = 0;
+      if (pending->compare_exchange_strong(existing, kSizeMax, std::memory_order_acq_rel)) {
+        const std::uint64_t bucket_num = (*position)++;
+        Bucket &bucket = st.buckets[bucket_num];
+        bucket.hash = hash;
+        bucket.value = value;
+        pending->store(bucket_num + 1, std::memory_order_release);
+        return;
+      }
+      while (existing == kSizeMax) existing = pending->load(std::memory_order_acquire);
+      if (existing == 0) continue;
+      pending = &st.buckets[existing - 1].next;
+    }
+  }
+
+  // putValueAccessor (storage/HashTable.hpp:1358-1461) for one block, with
+  // TupleReferenceGenerator values; NULL keys do not exist (non-nullable).
+  void put_block(const void *keys, std::int64_t n, std::uint64_t block_id, std::int32_t base_tid,
+                 const std::uint64_t *filter) {
+    std::uint64_t total = 0;
+    if (filter == nullptr) {
+      total = static_cast<std::uint64_t>(n);
+    } else {
+      for (std::int64_t i = 0; i < n; ++i) total += bit_get(filter, i);
+    }
+    std::uint64_t position = 0;
+    for (;;) {
+      bool ok;
+      {
+        std::shared_lock<std::shared_mutex> lock(resize_mutex);
+        ok = preallocate(total, &position);
+      }
+      if (ok) break;
+      resize(total);
+    }
+    std::shared_lock<std::shared_mutex> lock(resize_mutex);
+    for (std::int64_t i = 0; i < n; ++i) {
+      if (!row_selected(filter, i)) continue;
+      put_prealloc(key_hash(keys, i), TupleRef{block_id, static_cast<std::int32_t>(base_tid + i)},
+                   &position);
+    }
+  }
+};
+
+extern "C" {
+
+size_t qso_sizeof_agg_config(void) { return sizeof(qsx_agg_config_t); }
+uint64_t qso_hash_scalar(int type, const void *value) { return hash_typed(type, value); }
+uint64_t qso_combine_hashes(uint64_t a, uint64_t b) { return combine_hashes(a, b); }
+uint64_t qso_next_prime(uint64_t n) { return next_prime(n); }
+uint64_t qso_prev_prime(uint64_t n) { return prev_prime(n); }
+uint64_t qso_partition_id(uint64_t hash, uint64_t num_partitions) {
+  return partition_id(hash, num_partitions);
+}
+
+void qso_select_cmp(int type, const void *col, int64_t n, int op, const void *literal,
+                    const uint64_t *filter, uint64_t *out_bitmap) {
+  switch (type) {
+    case QSX_INT: {
+      std::int32_t lit; std::memcpy(&lit, literal, 4);
+      select_cmp_t<std::int32_t>(static_cast<const std::int32_t *>(col), n, op, lit, filter, out_bitmap);
+      break;
+    }
+    case QSX_LONG: {
+      std::int64_t lit; std::memcpy(&lit, literal, 8);
+      select_cmp_t<std::int64_t>(static_cast<const std::int64_t *>(col), n, op, lit, filter, out_bitmap);
+      break;
+    }
+    case QSX_FLOAT: {
+      float lit; std::memcpy(&lit, literal, 4);
+      select_cmp_t<float>(static_cast<const float *>(col), n, op, lit, filter, out_bitmap);
+      break;
+    }
+    case QSX_DOUBLE: {
+      double lit; std::memcpy(&lit, literal, 8);
+      select_cmp_t<double>(static_cast<const double *>(col), n, op, lit, filter, out_bitmap);
+      break;
+    }
+    default: std::abort();
+  }
+}
+
+int64_t qso_bitmap_count(const uint64_t *bitmap, int64_t n) {
+  int64_t c = 0;
+  for (int64_t w = 0; w < bitmap_words(n); ++w) c += __builtin_popcountll(bitmap[w]);
+  return c;
+}
+
+int64_t qso_compact_gather(int width, const void *src, const uint64_t *bitmap, int64_t n, void *dst) {
+  // bulkInsertTuplesWithRemappedAttributes: per selected row, memcpy(width)
+  // (storage/BasicColumnStoreTupleStorageSubBlock.cpp:339-425).
+  const char *s = static_cast<const char *>(src);
+  char *d = static_cast<char *>(dst);
+  int64_t out = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (bit_get(bitmap, i)) {
+      std::memcpy(d + out * width, s + i * width, width);
+      ++out;
+    }
+  }
+  return out;
+}
+
+int64_t qso_bitmap_to_tids(const uint64_t *bitmap, int64_t n, int32_t base_tid, int32_t *out) {
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (bit_get(bitmap, i)) out[c++] = static_cast<int32_t>(base_tid + i);
+  }
+  return c;
+}
+
+void qso_gather(int width, const void *src, const int32_t *tids, int64_t n, void *dst) {
+  // ScalarAttribute::getAllValuesForJoin (expressions/scalar/ScalarAttribute.cpp:185-225).
+  const char *s = static_cast<const char *>(src);
+  char *d = static_cast<char *>(dst);
+  for (int64_t i = 0; i < n; ++i) {
+    if (tids[i] < 0) {
+      std::memset(d + i * width, 0, width);
+    } else {
+      std::memcpy(d + i * width, s + static_cast<int64_t>(tids[i]) * width, width);
+    }
+  }
+}
+
+qso_join_table_t *qso_join_table_create(int key_type, int64_t est_entries) {
+  if (key_type != QSX_INT && key_type != QSX_LONG) return nullptr;
+  qso_join_table_t *t = new qso_join_table_t();
+  t->key_type = key_type;
+  // constructor (:283-397): num_slots_tmp = next_prime(num_entries * kHashTableLoadFactor)
+  size_storage(next_prime(static_cast<uint64_t>(est_entries < 0 ? 0 : est_entries) * 2), &t->st);
+  return t;
+}
+
+void qso_join_table_destroy(qso_join_table_t *t) { delete t; }
+
+void qso_join_table_info(const qso_join_table_t *t, uint64_t out[4]) {
+  out[0] = t->st.num_slots;
+  out[1] = t->st.num_buckets;
+  out[2] = t->buckets_allocated.load();
+  out[3] = t->st.blob_bytes;
+}
+
+void qso_join_build(qso_join_table_t *t, const void *keys, int64_t n, uint64_t block_id,
+                    int32_t base_tid, const uint64_t *filter) {
+  t->put_block(keys, n, block_id, base_tid, filter);
+}
+
+int64_t qso_join_probe(const qso_join_table_t *t, const void *keys, int64_t n,
+                       int32_t probe_base_tid, const uint64_t *filter, int32_t *out_probe_tid,
+                       int32_t *out_build_tid, uint64_t *out_build_block, int64_t capacity) {
+  // getAllFromValueAccessorImpl (storage/HashTable.hpp:2145-2181) with
+  // getNextEntryForKey (SimpleScalarSeparateChainingHashTable.hpp:751-781).
+  int64_t count = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!row_selected(filter, i)) continue;
+    const uint64_t hash = t->key_hash(keys, i);
+    uint64_t entry = t->st.slots[hash % t->st.num_slots].load(std::memory_order_relaxed);
+    while (entry != 0) {
+      const Bucket &bucket = t->st.buckets[entry - 1];
+      entry = bucket.next.load(std::memory_order_relaxed);
+      if (bucket.hash == hash) {
+        if (count < capacity) {
+          out_probe_tid[count] = static_cast<int32_t>(probe_base_tid + i);
+          out_build_tid[count] = bucket.value.tuple;
+          if (out_build_block != nullptr) out_build_block[count] = bucket.value.block;
+        }
+        ++count;
+      }
+    }
+  }
+  return count;
+}
+
+void qso_join_probe_exists(const qso_join_table_t *t, const void *keys, int64_t n,
+                           const uint64_t *filter, int anti, uint64_t *out_bitmap) {
+  // runOverKeysFromValueAccessorIfMatch[Not]Found (storage/HashTable.hpp:1979-2062).
+  std::memset(out_bitmap, 0, sizeof(uint64_t) * bitmap_words(n));
+  for (int64_t i = 0; i < n; ++i) {
+    if (!row_selected(filter, i)) continue;
+    const uint64_t hash = t->key_hash(keys, i);
+    uint64_t entry = t->st.slots[hash % t->st.num_slots].load(std::memory_order_relaxed);
+    bool found = false;
+    while (entry != 0 && !found) {
+      const Bucket &bucket = t->st.buckets[entry - 1];
+      entry = bucket.next.load(std::memory_order_relaxed);
+      found = (bucket.hash == hash);
+    }
+    if (found != (anti != 0)) bit_set(out_bitmap, i);
+  }
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// aggregation
+// ===========================================================================
+namespace {
+
+struct StateLayout {
+  // One "state column" per int64/double accumulator.  COUNT -> 1 int64;
+  // SUM -> 1 (int64 for INT/LONG arguments, double otherwise:
+  // expressions/aggregation/AggregationHandleSum.cpp:45-80); AVG -> sum + count
+  // (AggregationHandleAvg.cpp:45-93).
+  int num_states = 0;
+  bool state_is_int[2 * QSX_MAX_AGGS];
+  int agg_first_state[QSX_MAX_AGGS];
+  bool agg_arg_is_int[QSX_MAX_AGGS];
+};
+
+bool operand_is_int_column(const qsx_agg_config_t &c, const qsx_operand_t &o) {
+  return o.kind == QSX_OPD_COLUMN &&
+         (c.column_type[o.index] == QSX_INT || c.column_type[o.index] == QSX_LONG);
+}
+
+StateLayout make_layout(const qsx_agg_config_t &c) {
+  StateLayout L;
+  for (int a = 0; a < c.num_aggs; ++a) {
+    L.agg_first_state[a] = L.num_states;
+    const bool is_int = c.aggs[a].fn != QSX_AGG_COUNT_STAR && operand_is_int_column(c, c.aggs[a].arg);
+    L.agg_arg_is_int[a] = is_int;
+    switch (c.aggs[a].fn) {
+      case QSX_AGG_COUNT_STAR:
+        L.state_is_int[L.num_states++] = true;
+        break;
+      case QSX_AGG_SUM:
+        L.state_is_int[L.num_states++] = is_int;
+        break;
+      case QSX_AGG_AVG:
+        L.state_is_int[L.num_states++] = is_int;
+        L.state_is_int[L.num_states++] = true;
+        break;
+      default: std::abort();
+    }
+  }
+  return L;
+}
+
+union StateWord {
+  std::int64_t i;
+  double d;
+};
+
+// Per-row evaluation context: reads typed columns, evaluates the fused
+// expression program (ScalarBinaryExpression::getAllValues semantics: every
+// node is an IEEE double, expressions/scalar/ScalarBinaryExpression.cpp:100-195
+// over ArithmeticBinaryOperators.hpp:203-340) and the state's predicate.
+struct RowReader {
+  const qsx_agg_config_t &c;
+  const void *const *cols;
+  double temps[QSX_MAX_TEMPS];
+
+  RowReader(const qsx_agg_config_t &cfg, const void *const *columns) : c(cfg), cols(columns) {}
+
+  inline double col_as_double(int col, std::int64_t i) const {
+    switch (c.column_type[col]) {
+      case QSX_INT: return static_cast<const std::int32_t *>(cols[col])[i];
+      case QSX_LONG: return static_cast<double>(static_cast<const std::int64_t *>(cols[col])[i]);
+      case QSX_FLOAT: return static_cast<const float *>(cols[col])[i];
+      case QSX_DOUBLE: return static_cast<const double *>(cols[col])[i];
+      default: std::abort();
+    }
+  }
+  inline std::int64_t col_as_int(int col, std::int64_t i) const {
+    if (c.column_type[col] == QSX_INT) return static_cast<const std::int32_t *>(cols[col])[i];
+    return static_cast<const std::int64_t *>(cols[col])[i];
+  }
+  inline double operand(const qsx_operand_t &o, std::int64_t i) const {
+    switch (o.kind) {
+      case QSX_OPD_COLUMN: return col_as_double(o.index, i);
+      case QSX_OPD_CONST: return c.consts[o.index];
+      default: return temps[o.index];
+    }
+  }
+  inline void eval(std::int64_t i) {
+    for (int k = 0; k < c.num_instrs; ++k) {
+      const qsx_expr_instr_t &in = c.instrs[k];
+      const double a = operand(in.a, i), b = operand(in.b, i);
+      double r;
+      switch (in.op) {
+        case QSX_EX_ADD: r = a + b; break;
+        case QSX_EX_SUB: r = a - b; break;
+        case QSX_EX_MUL: r = a * b; break;
+        default: r = a / b; break;
+      }
+      temps[in.dst] = r;
+    }
+  }
+  inline bool predicate(std::int64_t i) const {
+    for (int t = 0; t < c.num_pred_terms; ++t) {
+      const qsx_pred_term_t &p = c.pred[t];
+      bool ok;
+      switch (c.column_type[p.column]) {
+        case QSX_INT: ok = compare<std::int32_t>(static_cast<const std::int32_t *>(cols[p.column])[i], p.op, p.literal.i32); break;
+        case QSX_LONG: ok = compare<std::int64_t>(static_cast<const std::int64_t *>(cols[p.column])[i], p.op, p.literal.i64); break;
+        case QSX_FLOAT: ok = compare<float>(static_cast<const float *>(cols[p.column])[i], p.op, p.literal.f32); break;
+        case QSX_DOUBLE: ok = compare<double>(static_cast<const double *>(cols[p.column])[i], p.op, p.literal.f64); break;
+        default: std::abort();
+      }
+      if (!ok) return false;
+    }
+    return true;
+  }
+  // Compact key code (storage/ThreadPrivateCompactKeyHashTable.cpp:216-232,
+  // .hpp:125-142): key bytes memcpy'd at running offsets into a zeroed uint64.
+  inline std::uint64_t key_code(std::int64_t i) const {
+    std::uint64_t code = 0;
+    int offset = 0;
+    for (int k = 0; k < c.num_keys; ++k) {
+      const int col = c.key_column[k];
+      const int w = c.column_width[col];
+      std::memcpy(reinterpret_cast<char *>(&code) + offset,
+                  static_cast<const char *>(cols[col]) + i * w, w);
+      offset += w;
+    }
+    return code;
+  }
+  // HashCompositeKey (utility/CompositeHash.hpp:39-48).
+  inline std::uint64_t composite_hash(std::int64_t i) const {
+    std::uint64_t h = 0;
+    for (int k = 0; k < c.num_keys; ++k) {
+      const int col = c.key_column[k];
+      const int w = c.column_width[col];
+      const std::uint64_t hk =
+          hash_typed(c.column_type[col], static_cast<const char *>(cols[col]) + i * w);
+      h = (k == 0) ? hk : combine_hashes(h, hk);
+    }
+    return h;
+  }
+};
+
+inline void accumulate(const qsx_agg_config_t &c, const StateLayout &L, const RowReader &rr,
+                       std::int64_t i, StateWord *st /* num_states words of one group */) {
+  for (int a = 0; a < c.num_aggs; ++a) {
+    StateWord *s = st + L.agg_first_state[a];
+    switch (c.aggs[a].fn) {
+      case QSX_AGG_COUNT_STAR:
+        s[0].i += 1;
+        break;
+      case QSX_AGG_SUM:
+      case QSX_AGG_AVG:
+        if (L.agg_arg_is_int[a]) {
+          s[0].i += rr.col_as_int(c.aggs[a].arg.index, i);
+        } else {
+          s[0].d += rr.operand(c.aggs[a].arg, i);
+        }
+        if (c.aggs[a].fn == QSX_AGG_AVG) s[1].i += 1;
+        break;
+    }
+  }
+}
+
+inline void merge_words(const StateLayout &L, StateWord *dst, const StateWord *src) {
+  for (int s = 0; s < L.num_states; ++s) {
+    if (L.state_is_int[s]) dst[s].i += src[s].i; else dst[s].d += src[s].d;
+  }
+}
+
+}  // namespace
+
+struct qso_agg_state {
+  qsx_agg_config_t c;
+  StateLayout L;
+  int key_bytes = 0;
+
+  // SINGLE_STATE (storage/AggregationOperationState.cpp:476-519)
+  std::vector<StateWord> single;
+  std::int64_t single_rows = 0;
+
+  // COMPACT_KEY (storage/ThreadPrivateCompactKeyHashTable.{hpp,cpp}) and
+  // GENERIC (PackedPayloadHashTable; insertion-ordered buckets + index).
+  std::unordered_map<std::uint64_t, std::uint32_t> index;
+  std::vector<std::uint64_t> keys;        // bucket -> key code
+  std::vector<std::uint64_t> key_hashes;  // GENERIC: composite hash per bucket
+  std::vector<StateWord> states;          // bucket-major: [bucket][state]
+
+  // COLLISION_FREE (storage/CollisionFreeVectorTable.hpp)
+  std::vector<std::uint64_t> existence;   // LSB-first bit array
+  std::vector<StateWord> dense;           // state-major: [state][key]
+
+  explicit qso_agg_state(const qsx_agg_config_t &cfg) : c(cfg), L(make_layout(cfg)) {
+    for (int k = 0; k < c.num_keys; ++k) key_bytes += c.column_width[c.key_column[k]];
+    if (c.strategy == QSX_AGG_SINGLE_STATE) {
+      single.assign(L.num_states, StateWord{0});
+    } else if (c.strategy == QSX_AGG_COLLISION_FREE) {
+      existence.assign((c.num_entries + 63) / 64, 0);
+      dense.assign(static_cast<std::size_t>(L.num_states) * c.num_entries, StateWord{0});
+    }
+  }
+
+  std::uint32_t bucket_for(std::uint64_t code, std::uint64_t hash) {
+    auto it = index.find(code);
+    if (it != index.end()) return it->second;
+    const std::uint32_t b = static_cast<std::uint32_t>(keys.size());
+    index.emplace(code, b);
+    keys.push_back(code);
+    key_hashes.push_back(hash);
+    states.resize(states.size() + L.num_states, StateWord{0});
+    return b;
+  }
+
+  void update(const void *const *cols, std::int64_t n, const std::uint64_t *filter) {
+    RowReader rr(c, cols);
+    if (c.strategy == QSX_AGG_SINGLE_STATE) {
+      // aggregateBlockSingleState: accumulate a block-local state, then merge
+      // into the global one (mergeStates under a mutex, :476-519).
+      std::vector<StateWord> local(L.num_states, StateWord{0});
+      std::int64_t rows = 0;
+      for (std::int64_t i = 0; i < n; ++i) {
+        if (!row_selected(filter, i) || !rr.predicate(i)) continue;
+        rr.eval(i);
+        accumulate(c, L, rr, i, local.data());
+        ++rows;
+      }
+      merge_words(L, single.data(), local.data());
+      single_rows += rows;
+      return;
+    }
+    for (std::int64_t i = 0; i < n; ++i) {
+      if (!row_selected(filter, i) || !rr.predicate(i)) continue;
+      rr.eval(i);
+      if (c.strategy == QSX_AGG_COLLISION_FREE) {
+        // upsertValueAccessor* (CollisionFreeVectorTable.hpp:530-645): loc = key.
+        const std::int64_t loc = rr.col_as_int(c.key_column[0], i);
+        existence[loc >> 6] |= (static_cast<std::uint64_t>(1) << (loc & 63));
+        StateWord group[2 * QSX_MAX_AGGS];
+        for (int s = 0; s < L.num_states; ++s) group[s] = dense[static_cast<std::size_t>(s) * c.num_entries + loc];
+        accumulate(c, L, rr, i, group);
+        for (int s = 0; s < L.num_states; ++s) dense[static_cast<std::size_t>(s) * c.num_entries + loc] = group[s];
+      } else {
+        const std::uint64_t code = rr.key_code(i);
+        const std::uint64_t h = (c.strategy == QSX_AGG_GENERIC) ? rr.composite_hash(i) : 0;
+        const std::uint32_t b = bucket_for(code, h);
+        accumulate(c, L, rr, i, &states[static_cast<std::size_t>(b) * L.num_states]);
+      }
+    }
+  }
+
+  void merge_from(const qso_agg_state &src) {
+    switch (c.strategy) {
+      case QSX_AGG_SINGLE_STATE:
+        merge_words(L, single.data(), src.single.data());
+        single_rows += src.single_rows;
+        break;
+      case QSX_AGG_COLLISION_FREE:
+        for (std::size_t w = 0; w < existence.size(); ++w) existence[w] |= src.existence[w];
+        for (int s = 0; s < L.num_states; ++s) {
+          for (std::int64_t k = 0; k < c.num_entries; ++k) {
+            const std::size_t p = static_cast<std::size_t>(s) * c.num_entries + k;
+            if (L.state_is_int[s]) dense[p].i += src.dense[p].i; else dense[p].d += src.dense[p].d;
+          }
+        }
+        break;
+      default:
+        // mergeFrom (ThreadPrivateCompactKeyHashTable.cpp:306-363): map source
+        // buckets to destination buckets (new keys appended), then add columns.
+        for (std::size_t b = 0; b < src.keys.size(); ++b) {
+          const std::uint32_t d = bucket_for(src.keys[b], src.key_hashes[b]);
+          merge_words(L, &states[static_cast<std::size_t>(d) * L.num_states],
+                      &src.states[b * L.num_states]);
+        }
+        break;
+    }
+  }
+};
+
+namespace {
+
+// Write one finalized group row.  SUM(int) -> int64, SUM(fp) -> double,
+// COUNT -> int64, AVG -> sum / (double)count (AggregationHandleAvg.cpp:144-155).
+void emit_values(const qsx_agg_config_t &c, const StateLayout &L, const StateWord *st, bool empty_group,
+                 std::int64_t row, void *const *out_val_cols, std::uint8_t *const *out_null_cols) {
+  for (int a = 0; a < c.num_aggs; ++a) {
+    const StateWord *s = st + L.agg_first_state[a];
+    bool is_null = false;
+    switch (c.aggs[a].fn) {
+      case QSX_AGG_COUNT_STAR:
+        static_cast<std::int64_t *>(out_val_cols[a])[row] = s[0].i;
+        break;
+      case QSX_AGG_SUM:
+        if (L.agg_arg_is_int[a]) static_cast<std::int64_t *>(out_val_cols[a])[row] = s[0].i;
+        else static_cast<double *>(out_val_cols[a])[row] = s[0].d;
+        is_null = empty_group;  // SUM over zero rows is NULL (AggregationHandleSum.cpp:100-120)
+        break;
+      case QSX_AGG_AVG: {
+        const double sum = L.agg_arg_is_int[a] ? static_cast<double>(s[0].i) : s[0].d;
+        is_null = (s[1].i == 0);
+        static_cast<double *>(out_val_cols[a])[row] = is_null ? 0.0 : sum / static_cast<double>(s[1].i);
+        break;
+      }
+    }
+    if (out_null_cols != nullptr && out_null_cols[a] != nullptr) out_null_cols[a][row] = is_null ? 1 : 0;
+  }
+}
+
+void emit_keys_from_code(const qsx_agg_config_t &c, std::uint64_t code, std::int64_t row,
+                         void *const *out_key_cols) {
+  // finalize (ThreadPrivateCompactKeyHashTable.cpp:365-421): memcpy width_i bytes from code+offset_i.
+  int offset = 0;
+  for (int k = 0; k < c.num_keys; ++k) {
+    const int w = c.column_width[c.key_column[k]];
+    std::memcpy(static_cast<char *>(out_key_cols[k]) + row * w,
+                reinterpret_cast<const char *>(&code) + offset, w);
+    offset += w;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+qso_agg_state_t *qso_agg_state_create(const qsx_agg_config_t *config) {
+  return new qso_agg_state(*config);
+}
+void qso_agg_state_destroy(qso_agg_state_t *s) { delete s; }
+
+void qso_agg_update(qso_agg_state_t *s, const void *const *cols, int64_t n, const uint64_t *filter) {
+  s->update(cols, n, filter);
+}
+void qso_agg_merge(qso_agg_state_t *dst, const qso_agg_state_t *src) { dst->merge_from(*src); }
+
+int64_t qso_agg_num_groups(const qso_agg_state_t *s) {
+  switch (s->c.strategy) {
+    case QSX_AGG_SINGLE_STATE: return 1;
+    case QSX_AGG_COLLISION_FREE: {
+      int64_t c = 0;
+      for (uint64_t w : s->existence) c += __builtin_popcountll(w);
+      return c;
+    }
+    default: return static_cast<int64_t>(s->keys.size());
+  }
+}
+
+int64_t qso_agg_finalize(const qso_agg_state_t *s, int partition, int num_partitions,
+                         void *const *out_key_cols, void *const *out_val_cols,
+                         uint8_t *const *out_null_cols, int64_t capacity) {
+  const qsx_agg_config_t &c = s->c;
+  const StateLayout &L = s->L;
+  int64_t row = 0;
+  switch (c.strategy) {
+    case QSX_AGG_SINGLE_STATE:
+      // finalizeSingleState (:652-670): always exactly one row (partition 0).
+      if (partition != 0 || capacity < 1) return 0;
+      emit_values(c, L, s->single.data(), s->single_rows == 0, 0, out_val_cols, out_null_cols);
+      return 1;
+    case QSX_AGG_COLLISION_FREE: {
+      // finalizeKey/finalizeState (CollisionFreeVectorTable.hpp:647-727) on the
+      // key range of this partition (:192-208): ascending key order.
+      const int64_t len = (c.num_entries + num_partitions - 1) / num_partitions;
+      const int64_t begin = static_cast<int64_t>(partition) * len;
+      const int64_t end = std::min<int64_t>(begin + len, c.num_entries);
+      const int kw = c.column_width[c.key_column[0]];
+      for (int64_t loc = begin; loc < end; ++loc) {
+        if (!((s->existence[loc >> 6] >> (loc & 63)) & 1u)) continue;
+        if (row >= capacity) return row;
+        if (kw == 4) static_cast<int32_t *>(out_key_cols[0])[row] = static_cast<int32_t>(loc);
+        else static_cast<int64_t *>(out_key_cols[0])[row] = loc;
+        StateWord group[2 * QSX_MAX_AGGS];
+        for (int st = 0; st < L.num_states; ++st) group[st] = s->dense[static_cast<size_t>(st) * c.num_entries + loc];
+        emit_values(c, L, group, false, row, out_val_cols, out_null_cols);
+        ++row;
+      }
+      return row;
+    }
+    default:
+      for (size_t b = 0; b < s->keys.size(); ++b) {
+        if (c.strategy == QSX_AGG_GENERIC) {
+          // partitioned mode routes a row to HashCompositeKey % P
+          // (storage/AggregationOperationState.cpp:576-583).
+          if (static_cast<int>(s->key_hashes[b] % static_cast<uint64_t>(num_partitions)) != partition) continue;
+        } else if (partition != 0) {
+          continue;  // compact-key tables finalize in one piece (:925-948)
+        }
+        if (row >= capacity) return row;
+        emit_keys_from_code(c, s->keys[b], row, out_key_cols);
+        emit_values(c, L, &s->states[b * L.num_states], false, row, out_val_cols, out_null_cols);
+        ++row;
+      }
+      return row;
+  }
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// LIP filters
+// ===========================================================================
+struct qso_lip_filter {
+  int kind;
+  std::int64_t cardinality;
+  std::int64_t min_value;
+  bool is_anti;
+  std::vector<std::uint64_t> bits;
+};
+
+namespace {
+inline std::int64_t key_as_i64(int key_type, const void *keys, std::int64_t i) {
+  if (key_type == QSX_INT) return static_cast<const std::int32_t *>(keys)[i];
+  return static_cast<const std::int64_t *>(keys)[i];
+}
+// SingleIdentityHashFilter (utility/lip_filter/SingleIdentityHashFilter.hpp:156-169):
+// hash = value % filter_cardinality_ with the value converted to size_t first.
+inline std::uint64_t identity_bit(std::int64_t v, std::int64_t card) {
+  return static_cast<std::uint64_t>(v) % static_cast<std::uint64_t>(card);
+}
+}  // namespace
+
+extern "C" {
+
+qso_lip_filter_t *qso_lip_filter_create(int kind, int64_t cardinality, int64_t min_value, int is_anti) {
+  qso_lip_filter_t *f = new qso_lip_filter_t();
+  f->kind = kind;
+  f->cardinality = cardinality;
+  f->min_value = min_value;
+  f->is_anti = is_anti != 0;
+  f->bits.assign((cardinality + 63) / 64, 0);
+  return f;
+}
+void qso_lip_filter_destroy(qso_lip_filter_t *f) { delete f; }
+
+void qso_lip_build(qso_lip_filter_t *f, int key_type, const void *keys, int64_t n, const uint64_t *filter) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (!row_selected(filter, i)) continue;
+    const int64_t v = key_as_i64(key_type, keys, i);
+    uint64_t bit;
+    if (f->kind == QSX_LIP_BITVECTOR_EXACT) {
+      bit = static_cast<uint64_t>(v - f->min_value);  // BitVectorExactFilter.hpp:150-156
+    } else {
+      bit = identity_bit(v, f->cardinality);
+    }
+    f->bits[bit >> 6] |= static_cast<uint64_t>(1) << (bit & 63);
+  }
+}
+
+void qso_lip_probe(const qso_lip_filter_t *f, int key_type, const void *keys, int64_t n,
+                   const uint64_t *in_bitmap, uint64_t *out_bitmap) {
+  std::memset(out_bitmap, 0, sizeof(uint64_t) * bitmap_words(n));
+  for (int64_t i = 0; i < n; ++i) {
+    if (!row_selected(in_bitmap, i)) continue;
+    const int64_t v = key_as_i64(key_type, keys, i);
+    bool hit;
+    if (f->kind == QSX_LIP_BITVECTOR_EXACT) {
+      // contains (BitVectorExactFilter.hpp:158-172)
+      if (v < f->min_value || v > f->min_value + f->cardinality - 1) {
+        hit = f->is_anti;
+      } else {
+        const uint64_t bit = static_cast<uint64_t>(v - f->min_value);
+        const bool set = (f->bits[bit >> 6] >> (bit & 63)) & 1u;
+        hit = f->is_anti ? !set : set;
+      }
+    } else {
+      const uint64_t bit = identity_bit(v, f->cardinality);
+      hit = (f->bits[bit >> 6] >> (bit & 63)) & 1u;
+    }
+    if (hit) bit_set(out_bitmap, i);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// partition scatter (PartitionAwareInsertDestination routing, storage/
+// InsertDestination.hpp:490-660, with HashPartitionSchemeHeader ids).
+// ---------------------------------------------------------------------------
+void qso_partition_offsets(int key_type, const void *keys, int64_t n, int num_partitions, int64_t *offsets) {
+  std::vector<int64_t> counts(num_partitions, 0);
+  const int w = type_width(key_type);
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t h = hash_typed(key_type, static_cast<const char *>(keys) + i * w);
+    ++counts[partition_id(h, num_partitions)];
+  }
+  offsets[0] = 0;
+  for (int p = 0; p < num_partitions; ++p) offsets[p + 1] = offsets[p] + counts[p];
+}
+
+void qso_partition_scatter_col(int key_type, const void *keys, int64_t n, int num_partitions,
+                               int width, const void *col, void *out_col) {
+  std::vector<int64_t> offsets(num_partitions + 1);
+  qso_partition_offsets(key_type, keys, n, num_partitions, offsets.data());
+  const int w = type_width(key_type);
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t h = hash_typed(key_type, static_cast<const char *>(keys) + i * w);
+    const int64_t pos = offsets[partition_id(h, num_partitions)]++;
+    std::memcpy(static_cast<char *>(out_col) + pos * width, static_cast<const char *>(col) + i * width, width);
+  }
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// CPU baseline drivers
+// ===========================================================================
+namespace {
+
+using Clock = std::chrono::steady_clock;
+inline double seconds_since(Clock::time_point t0) {
+  return std::chrono::duration<double>(Clock::now() - t0).count();
+}
+
+// Stand-in for Foreman/Worker (query_execution/ForemanSingleNode.cpp:102-178,
+// Worker.cpp:54-139): work orders = block indices, workers pull from a shared
+// atomic queue and run execute() until it is drained.
+template <typename Fn>
+void run_work_orders(std::int64_t num_blocks, int num_threads, Fn execute) {
+  std::atomic<std::int64_t> next{0};
+  std::vector<std::thread> workers;
+  for (int t = 0; t < num_threads; ++t) {
+    workers.emplace_back([&, t]() {
+      for (;;) {
+        const std::int64_t b = next.fetch_add(1, std::memory_order_relaxed);
+        if (b >= num_blocks) break;
+        execute(b, t);
+      }
+    });
+  }
+  for (auto &w : workers) w.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+void qso_bench_join(int key_type, const void *build_keys, int64_t n_build, const void *probe_keys,
+                    int64_t n_probe, int64_t block_rows, int num_threads,
+                    qso_join_bench_result_t *out) {
+  const int kw = type_width(key_type);
+  qso_join_table_t *table = qso_join_table_create(key_type, n_build);
+  const int64_t build_blocks = (n_build + block_rows - 1) / block_rows;
+  const int64_t probe_blocks = (n_probe + block_rows - 1) / block_rows;
+
+  Clock::time_point t0 = Clock::now();
+  run_work_orders(build_blocks, num_threads, [&](int64_t b, int) {
+    // BuildHashWorkOrder::execute (relational_operators/BuildHashOperator.cpp:162-207)
+    const int64_t begin = b * block_rows, rows = std::min(block_rows, n_build - begin);
+    table->put_block(static_cast<const char *>(build_keys) + begin * kw, rows,
+                     static_cast<uint64_t>(b), static_cast<int32_t>(begin), nullptr);
+  });
+  out->build_seconds = seconds_since(t0);
+
+  std::vector<int64_t> matches(num_threads, 0);
+  std::vector<uint64_t> checksums(num_threads, 0);
+  t0 = Clock::now();
+  run_work_orders(probe_blocks, num_threads, [&](int64_t b, int t) {
+    // HashInnerJoinWorkOrder::execute (relational_operators/HashJoinOperator.cpp:450-541):
+    // collect (probe_tid, build_tid) pairs per build block in an unordered_map
+    // of vectors (:76-102), then visit each build block's pair list.
+    const int64_t begin = b * block_rows, rows = std::min(block_rows, n_probe - begin);
+    const char *keys = static_cast<const char *>(probe_keys) + begin * kw;
+    std::unordered_map<uint64_t, std::vector<std::pair<int32_t, int32_t>>> joined;
+    for (int64_t i = 0; i < rows; ++i) {
+      const uint64_t hash = table->key_hash(keys, i);
+      uint64_t entry = table->st.slots[hash % table->st.num_slots].load(std::memory_order_relaxed);
+      while (entry != 0) {
+        const Bucket &bucket = table->st.buckets[entry - 1];
+        entry = bucket.next.load(std::memory_order_relaxed);
+        if (bucket.hash == hash) {
+          joined[bucket.value.block].emplace_back(static_cast<int32_t>(begin + i), bucket.value.tuple);
+        }
+      }
+    }
+    for (const auto &kv : joined) {
+      for (const auto &pr : kv.second) {
+        checksums[t] += static_cast<uint64_t>(static_cast<uint32_t>(pr.first)) * 1000003ULL +
+                        static_cast<uint64_t>(static_cast<uint32_t>(pr.second));
+      }
+      matches[t] += static_cast<int64_t>(kv.second.size());
+    }
+  });
+  out->probe_seconds = seconds_since(t0);
+  out->matches = 0;
+  out->checksum = 0;
+  for (int t = 0; t < num_threads; ++t) {
+    out->matches += matches[t];
+    out->checksum += checksums[t];
+  }
+  qso_join_table_destroy(table);
+}
+
+double qso_bench_agg(const qsx_agg_config_t *config, const void *const *cols, int64_t n,
+                     int64_t block_rows, int num_threads, qso_agg_state_t **out_state) {
+  const int64_t blocks = (n + block_rows - 1) / block_rows;
+  // One private state per worker (HashTablePool hands a returned table to the
+  // next work order; with T workers at most T tables exist), merged at
+  // finalize (storage/AggregationOperationState.cpp:925-948).
+  std::vector<qso_agg_state_t *> priv(num_threads, nullptr);
+  for (int t = 0; t < num_threads; ++t) priv[t] = qso_agg_state_create(config);
+  Clock::time_point t0 = Clock::now();
+  run_work_orders(blocks, num_threads, [&](int64_t b, int t) {
+    const int64_t begin = b * block_rows, rows = std::min(block_rows, n - begin);
+    const void *block_cols[QSX_MAX_COLUMNS];
+    for (int c = 0; c < config->num_columns; ++c) {
+      block_cols[c] = static_cast<const char *>(cols[c]) + begin * config->column_width[c];
+    }
+    priv[t]->update(block_cols, rows, nullptr);
+  });
+  for (int t = 1; t < num_threads; ++t) priv[0]->merge_from(*priv[t]);
+  const double elapsed = seconds_since(t0);
+  for (int t = 1; t < num_threads; ++t) qso_agg_state_destroy(priv[t]);
+  if (out_state != nullptr) *out_state = priv[0]; else qso_agg_state_destroy(priv[0]);
+  return elapsed;
+}
+
+double qso_bench_select(int type, const void *col, int64_t n, int op, const void *literal,
+                        int64_t block_rows, int num_threads, void *out_col, int64_t *out_rows) {
+  // SelectWorkOrder::execute (relational_operators/SelectOperator.cpp:161-195):
+  // predicate bitmap per block, then selectSimple into the destination.  The
+  // destination here is one contiguous column; each block's rows land at an
+  // offset reserved atomically (InsertDestination hands out blocks under a mutex).
+  const int w = type_width(type);
+  const int64_t blocks = (n + block_rows - 1) / block_rows;
+  std::atomic<int64_t> out_pos{0};
+  Clock::time_point t0 = Clock::now();
+  run_work_orders(blocks, num_threads, [&](int64_t b, int) {
+    const int64_t begin = b * block_rows, rows = std::min(block_rows, n - begin);
+    const char *c = static_cast<const char *>(col) + begin * w;
+    std::vector<uint64_t> bitmap(bitmap_words(rows));
+    qso_select_cmp(type, c, rows, op, literal, nullptr, bitmap.data());
+    const int64_t cnt = qso_bitmap_count(bitmap.data(), rows);
+    const int64_t at = out_pos.fetch_add(cnt);
+    qso_compact_gather(w, c, bitmap.data(), rows, static_cast<char *>(out_col) + at * w);
+  });
+  const double elapsed = seconds_since(t0);
+  *out_rows = out_pos.load();
+  return elapsed;
+}
+
+}  // extern "C"

@@ -1,0 +1,387 @@
+"""ctypes binding of the C ABI in include/qsx.h (quickstep_amd/lib/libqsx.so).
+
+This is the *product* path as seen from Python: tests marked ``gpu``, bench.py
+and ``__graft_entry__.smoke()`` all go through here, i.e. through the same
+``extern "C"`` entry points a Quickstep GPU work order would call.  There is no
+CPU implementation behind these functions; if the shared library is missing
+the import of this module fails, and on a machine without a gfx950 device
+every compute call raises ``QsxError(QSX_ERR_NO_DEVICE)``.
+
+Device memory, streams and collectives are torch's (plumbing): functions take
+``torch`` CUDA tensors and pass ``tensor.data_ptr()`` through.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (imported first so that libqsx binds to the HIP runtime torch already loaded)
+
+from . import types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libqsx.so")
+
+
+class QsxError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = _lib.qsx_status_string(status).decode()
+        detail = _lib.qsx_last_error().decode()
+        super().__init__(f"{where}: {msg} ({status})" + (f" — {detail}" if detail and status == T.ERR_HIP else ""))
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or make -C quickstep_amd/csrc). There is no CPU fallback for the HIP execution kernel.")
+    return C.CDLL(LIB_PATH)
+
+
+_lib = _load()
+
+_vp, _i64, _i32, _int, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+
+_SIGNATURES = {
+    "qsx_status_string": (C.c_char_p, [_int]),
+    "qsx_abi_version": (_int, []),
+    "qsx_abi_sizeof_agg_config": (_sz, []),
+    "qsx_device_count": (_int, []),
+    "qsx_last_error": (C.c_char_p, []),
+    "qsx_device_alloc": (_int, [_sz, _pp]),
+    "qsx_device_free": (_int, [_vp]),
+    "qsx_copy_to_device": (_int, [_vp, _vp, _sz, _vp]),
+    "qsx_copy_to_host": (_int, [_vp, _vp, _sz, _vp]),
+    "qsx_memset_device": (_int, [_vp, _int, _sz, _vp]),
+    "qsx_stream_synchronize": (_int, [_vp]),
+    "qsx_select_cmp": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "qsx_bitmap_combine": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_bitmap_count": (_int, [_vp, _i64, _vp, _vp]),
+    "qsx_compact_workspace_bytes": (_sz, [_i64]),
+    "qsx_compact_gather": (_int, [_int, _pp, C.POINTER(_i32), _vp, _i64, _pp, _vp, _vp, _sz, _vp]),
+    "qsx_bitmap_to_tids": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "qsx_gather": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_join_table_create": (_int, [_int, _i64, _pp]),
+    "qsx_join_table_destroy": (_int, [_vp]),
+    "qsx_join_table_size": (_int, [_vp, C.POINTER(_i64), _vp]),
+    "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_join_probe_count": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "qsx_join_probe_exists": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
+    "qsx_agg_state_create": (_int, [C.POINTER(T.AggConfig), _pp]),
+    "qsx_agg_state_destroy": (_int, [_vp]),
+    "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
+    "qsx_agg_merge": (_int, [_vp, _vp, _vp]),
+    "qsx_agg_state_export_bytes": (_int, [_vp, C.POINTER(_sz)]),
+    "qsx_agg_state_export": (_int, [_vp, _vp, _vp]),
+    "qsx_agg_state_import_merge": (_int, [_vp, _vp, _vp]),
+    "qsx_agg_num_groups": (_int, [_vp, C.POINTER(_i64), _vp]),
+    "qsx_agg_finalize": (_int, [_vp, _int, _int, _pp, _pp, _pp, _i64, _vp, _vp]),
+    "qsx_lip_filter_create": (_int, [_int, _i64, _i64, _int, _pp]),
+    "qsx_lip_filter_destroy": (_int, [_vp]),
+    "qsx_lip_build": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
+    "qsx_lip_probe": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "qsx_lip_filter_words": (_int, [_vp, _pp, C.POINTER(_i64)]),
+    "qsx_partition_workspace_bytes": (_sz, [_i64, _int]),
+    "qsx_partition_scatter": (_int, [_int, _vp, _i64, _int, _int, _pp, C.POINTER(_i32), _pp, _vp, _vp, _sz, _vp]),
+}
+
+# every symbol include/qsx.h declares must resolve (tests/test_abi.py checks the header against this table)
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(_lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if _lib.qsx_abi_sizeof_agg_config() != C.sizeof(T.AggConfig):
+    raise ImportError("quickstep_amd.types.AggConfig does not match qsx_agg_config_t of libqsx.so")
+
+lib = _lib
+EXPORTED = tuple(_SIGNATURES)
+
+
+def _check(status, where):
+    if status != T.OK:
+        raise QsxError(status, where)
+
+
+def device_count():
+    return _lib.qsx_device_count()
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(stream=None):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+_TORCH_TYPE = {torch.int32: T.INT, torch.int64: T.LONG, torch.float32: T.FLOAT, torch.float64: T.DOUBLE}
+_C_SCALAR = {T.INT: C.c_int32, T.LONG: C.c_int64, T.FLOAT: C.c_float, T.DOUBLE: C.c_double}
+
+
+def qsx_type_of(t):
+    return _TORCH_TYPE[t.dtype]
+
+
+def bitmap_words(n):
+    return (n + 63) // 64
+
+
+def new_bitmap(n, device):
+    return torch.empty(max(bitmap_words(n), 1), dtype=torch.int64, device=device)
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+# --------------------------------------------------------------------------- select
+def select_cmp(col, op, literal, filter_bitmap=None, out_bitmap=None, out_count=None, stream=None):
+    """K1: returns (bitmap int64[ceil(n/64)] MSB-first, count int64[1]) device tensors."""
+    n = col.numel()
+    qt = qsx_type_of(col)
+    lit = _C_SCALAR[qt](literal)
+    if out_bitmap is None:
+        out_bitmap = new_bitmap(n, col.device)
+    if out_count is None:
+        out_count = torch.zeros(1, dtype=torch.int64, device=col.device)
+    _check(_lib.qsx_select_cmp(qt, _ptr(col), n, op, C.byref(lit), _ptr(filter_bitmap), _ptr(out_bitmap),
+                               _ptr(out_count), _stream(stream)), "qsx_select_cmp")
+    return out_bitmap, out_count
+
+
+def bitmap_combine(op, a, b, n, out=None, stream=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _check(_lib.qsx_bitmap_combine(op, _ptr(a), _ptr(b), n, _ptr(out), _stream(stream)), "qsx_bitmap_combine")
+    return out
+
+
+def bitmap_count(bitmap, n, stream=None):
+    out = torch.zeros(1, dtype=torch.int64, device=bitmap.device)
+    _check(_lib.qsx_bitmap_count(_ptr(bitmap), n, _ptr(out), _stream(stream)), "qsx_bitmap_count")
+    return out
+
+
+def compact_gather(cols, bitmap, n, out_cols=None, stream=None):
+    """K2: returns (list of output columns sized n, count int64[1])."""
+    device = bitmap.device
+    if out_cols is None:
+        out_cols = [torch.empty_like(c) for c in cols]
+    widths = (C.c_int32 * max(len(cols), 1))(*[c.element_size() for c in cols])
+    ws_bytes = _lib.qsx_compact_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    count = torch.zeros(1, dtype=torch.int64, device=device)
+    _check(_lib.qsx_compact_gather(len(cols), _ptr_array(cols), widths, _ptr(bitmap), n, _ptr_array(out_cols),
+                                   _ptr(count), _ptr(ws), ws_bytes, _stream(stream)), "qsx_compact_gather")
+    return out_cols, count
+
+
+def bitmap_to_tids(bitmap, n, base_tid=0, stream=None):
+    device = bitmap.device
+    out = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+    ws_bytes = _lib.qsx_compact_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    count = torch.zeros(1, dtype=torch.int64, device=device)
+    _check(_lib.qsx_bitmap_to_tids(_ptr(bitmap), n, base_tid, _ptr(out), _ptr(count), _ptr(ws), ws_bytes,
+                                   _stream(stream)), "qsx_bitmap_to_tids")
+    return out, count
+
+
+def gather(src, tids, out=None, stream=None):
+    n = tids.numel()
+    if out is None:
+        out = torch.empty(n, dtype=src.dtype, device=src.device)
+    _check(_lib.qsx_gather(src.element_size(), _ptr(src), _ptr(tids), n, _ptr(out), _stream(stream)), "qsx_gather")
+    return out
+
+
+# --------------------------------------------------------------------------- join
+class JoinTable:
+    """JoinHashTable handle (qsx_join_table_t)."""
+
+    def __init__(self, key_type, est_entries):
+        self.key_type = key_type
+        h = C.c_void_p()
+        _check(_lib.qsx_join_table_create(key_type, est_entries, C.byref(h)), "qsx_join_table_create")
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            _lib.qsx_join_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self, stream=None):
+        v = C.c_int64()
+        _check(_lib.qsx_join_table_size(self._h, C.byref(v), _stream(stream)), "qsx_join_table_size")
+        return v.value
+
+    def build(self, keys, base_tid=0, filter_bitmap=None, stream=None):
+        _check(_lib.qsx_join_build(self._h, _ptr(keys), keys.numel(), base_tid, _ptr(filter_bitmap),
+                                   _stream(stream)), "qsx_join_build")
+
+    def probe(self, keys, capacity=None, probe_base_tid=0, filter_bitmap=None, out=None, stream=None):
+        """K4: returns (probe_tid int32[capacity], build_tid int32[capacity], count int64[1])."""
+        n = keys.numel()
+        if out is None:
+            capacity = n if capacity is None else capacity
+            out_p = torch.empty(max(capacity, 1), dtype=torch.int32, device=keys.device)
+            out_b = torch.empty(max(capacity, 1), dtype=torch.int32, device=keys.device)
+            count = torch.zeros(1, dtype=torch.int64, device=keys.device)
+        else:
+            out_p, out_b, count = out
+            capacity = out_p.numel() if capacity is None else capacity
+        _check(_lib.qsx_join_probe(self._h, _ptr(keys), n, probe_base_tid, _ptr(filter_bitmap), _ptr(out_p),
+                                   _ptr(out_b), capacity, _ptr(count), _stream(stream)), "qsx_join_probe")
+        return out_p, out_b, count
+
+    def probe_count(self, keys, filter_bitmap=None, stream=None):
+        count = torch.zeros(1, dtype=torch.int64, device=keys.device)
+        _check(_lib.qsx_join_probe_count(self._h, _ptr(keys), keys.numel(), _ptr(filter_bitmap), _ptr(count),
+                                         _stream(stream)), "qsx_join_probe_count")
+        return count
+
+    def probe_exists(self, keys, anti=False, filter_bitmap=None, stream=None):
+        n = keys.numel()
+        out = new_bitmap(n, keys.device)
+        count = torch.zeros(1, dtype=torch.int64, device=keys.device)
+        _check(_lib.qsx_join_probe_exists(self._h, _ptr(keys), n, _ptr(filter_bitmap), 1 if anti else 0, _ptr(out),
+                                          _ptr(count), _stream(stream)), "qsx_join_probe_exists")
+        return out, count
+
+
+# --------------------------------------------------------------------------- aggregation
+class AggState:
+    """AggregationOperationState handle (qsx_agg_state_t)."""
+
+    def __init__(self, config):
+        self.config = config
+        h = C.c_void_p()
+        _check(_lib.qsx_agg_state_create(C.byref(config), C.byref(h)), "qsx_agg_state_create")
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            _lib.qsx_agg_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, cols, n=None, filter_bitmap=None, stream=None):
+        if n is None:
+            n = cols[0].numel()
+        _check(_lib.qsx_agg_update(self._h, _ptr_array(cols), n, _ptr(filter_bitmap), _stream(stream)),
+               "qsx_agg_update")
+
+    def merge(self, other, stream=None):
+        _check(_lib.qsx_agg_merge(self._h, other._h, _stream(stream)), "qsx_agg_merge")
+
+    def export_bytes(self):
+        v = C.c_size_t()
+        _check(_lib.qsx_agg_state_export_bytes(self._h, C.byref(v)), "qsx_agg_state_export_bytes")
+        return v.value
+
+    def export(self, device, stream=None):
+        """Raw image as an int64 tensor (8-byte words)."""
+        nbytes = self.export_bytes()
+        out = torch.empty(nbytes // 8, dtype=torch.int64, device=device)
+        _check(_lib.qsx_agg_state_export(self._h, _ptr(out), _stream(stream)), "qsx_agg_state_export")
+        return out
+
+    def import_merge(self, image, stream=None):
+        _check(_lib.qsx_agg_state_import_merge(self._h, _ptr(image), _stream(stream)), "qsx_agg_state_import_merge")
+
+    def num_groups(self, stream=None):
+        v = C.c_int64()
+        _check(_lib.qsx_agg_num_groups(self._h, C.byref(v), _stream(stream)), "qsx_agg_num_groups")
+        return v.value
+
+    def finalize(self, device, partition=0, num_partitions=1, capacity=None, stream=None):
+        """K10: returns (key columns, value columns, null columns (uint8), groups int64[1])."""
+        cfg = self.config
+        if capacity is None:
+            capacity = max(self.num_groups(stream), 1)
+        keys = []
+        for k in range(cfg.num_keys):
+            w = cfg.column_width[cfg.key_column[k]]
+            dt = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[w]
+            keys.append(torch.zeros(capacity, dtype=dt, device=device))
+        vals, nulls = [], []
+        for a in range(cfg.num_aggs):
+            dt = torch.int64 if T.agg_output_is_int(cfg, a) else torch.float64
+            vals.append(torch.zeros(capacity, dtype=dt, device=device))
+            nulls.append(torch.zeros(capacity, dtype=torch.uint8, device=device))
+        groups = torch.zeros(1, dtype=torch.int64, device=device)
+        _check(_lib.qsx_agg_finalize(self._h, partition, num_partitions, _ptr_array(keys), _ptr_array(vals),
+                                     _ptr_array(nulls), capacity, _ptr(groups), _stream(stream)), "qsx_agg_finalize")
+        return keys, vals, nulls, groups
+
+
+# --------------------------------------------------------------------------- LIP
+class LipFilter:
+    def __init__(self, kind, cardinality, min_value=0, is_anti=False):
+        h = C.c_void_p()
+        _check(_lib.qsx_lip_filter_create(kind, cardinality, min_value, 1 if is_anti else 0, C.byref(h)),
+               "qsx_lip_filter_create")
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            _lib.qsx_lip_filter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build(self, keys, filter_bitmap=None, stream=None):
+        _check(_lib.qsx_lip_build(self._h, qsx_type_of(keys), _ptr(keys), keys.numel(), _ptr(filter_bitmap),
+                                  _stream(stream)), "qsx_lip_build")
+
+    def probe(self, keys, in_bitmap=None, stream=None):
+        n = keys.numel()
+        out = new_bitmap(n, keys.device)
+        count = torch.zeros(1, dtype=torch.int64, device=keys.device)
+        _check(_lib.qsx_lip_probe(self._h, qsx_type_of(keys), _ptr(keys), n, _ptr(in_bitmap), _ptr(out), _ptr(count),
+                                  _stream(stream)), "qsx_lip_probe")
+        return out, count
+
+    def words(self):
+        """(device pointer, number of 64-bit words) of the raw LSB-first bit array."""
+        p = C.c_void_p()
+        nw = C.c_int64()
+        _check(_lib.qsx_lip_filter_words(self._h, C.byref(p), C.byref(nw)), "qsx_lip_filter_words")
+        return p.value, nw.value
+
+
+# --------------------------------------------------------------------------- partition
+def partition_scatter(keys, num_partitions, cols, stream=None):
+    """K9: returns (scattered columns, offsets int64[P+1] on device)."""
+    n = keys.numel()
+    device = keys.device
+    out_cols = [torch.empty_like(c) for c in cols]
+    widths = (C.c_int32 * max(len(cols), 1))(*[c.element_size() for c in cols])
+    ws_bytes = _lib.qsx_partition_workspace_bytes(n, num_partitions)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    offsets = torch.zeros(num_partitions + 1, dtype=torch.int64, device=device)
+    _check(_lib.qsx_partition_scatter(qsx_type_of(keys), _ptr(keys), n, num_partitions, len(cols), _ptr_array(cols),
+                                      widths, _ptr_array(out_cols), _ptr(offsets), _ptr(ws), ws_bytes,
+                                      _stream(stream)), "qsx_partition_scatter")
+    return out_cols, offsets

@@ -1,0 +1,1191 @@
+// aggregate.hip — K6/K7/K8 group-by aggregation with fused K11 expression
+// evaluation and the state's predicate, K10 finalize, partial-state merge.
+//
+// Reference loops replaced (paths in the Quickstep tree):
+//   storage/AggregationOperationState.cpp:428-474 (aggregateBlock), :476-519,
+//   storage/ThreadPrivateCompactKeyHashTable.cpp:203-304 (+ .hpp:125-169),
+//   storage/CollisionFreeVectorTable.hpp:530-645,
+//   storage/PackedPayloadHashTable.hpp:838-909,
+//   expressions/scalar/ScalarBinaryExpression.cpp:100-195 (temp vectors -> fused),
+//   finalize: AggregationOperationState.cpp:641-948,
+//             ThreadPrivateCompactKeyHashTable.cpp:365-421,
+//             CollisionFreeVectorTable.hpp:647-727.
+//
+// State layout in HBM (one allocation per state, "image" = what
+// qsx_agg_state_export copies; all words 8 bytes):
+//   hash strategies (SINGLE_STATE / COMPACT_KEY / GENERIC), capacity C = 2^k:
+//     keys   [C + 1]            packed key code, ~0 = empty; slot C is reserved
+//                               for the one code that equals ~0
+//     col 0  [C + 1] int64      row count of the group
+//     col j  [C + 1] int64|f64  j-th SUM/AVG accumulator (j = 1..NS)
+//   COLLISION_FREE, E = num_entries (max_key + 1):
+//     exist  [ceil(E/64)]       existence bits, LSB-first (bit k of word k>>6)
+//     col 0  [E] int64          row count (only when some COUNT/AVG needs it)
+//     col j  [E] int64|f64      j-th accumulator
+//
+// Hash-strategy update kernel, per 256-thread workgroup:
+//   * the first R = 4 distinct groups a workgroup meets are "register groups":
+//     their codes sit in 4 LDS tag words, every thread keeps its own partial
+//     sums for them in VGPRs (predicated adds, no atomics at all) — this is
+//     the TPC-H Q1 regime (4 groups, 600 M rows);
+//   * further groups go to a workgroup-private open-addressing table in LDS
+//     (ds_cmpst_b64 claim, ds_add_u64 / ds_add_f64 accumulate);
+//   * groups that do not fit LDS go straight to the global table with global
+//     64-bit atomics;
+//   * at the end the workgroup folds registers -> LDS -> global table, so the
+//     global table sees one atomic per group per accumulator per workgroup.
+// Integer SUM/COUNT use integer atomics (exact, order-independent); double
+// sums are order-dependent in the last bits, the contract is 1e-6 relative.
+
+#include "common.hpp"
+#include "scan.hpp"
+
+#include <mutex>
+#include <vector>
+
+namespace qsx {
+
+constexpr int kABlock = 256;
+constexpr int kRegGroups = 4;
+constexpr int kRowsPerIter = 2;
+constexpr uint64_t kEmptyCode = ~0ull;
+constexpr int kMaxSums = QSX_MAX_AGGS;
+
+struct DevOperand {
+  int kind;
+  int index;
+};
+struct DevInstr {
+  int op;
+  int dst;
+  DevOperand a, b;
+};
+struct DevSum {
+  DevOperand arg;
+  int is_int;  // accumulate as int64 (argument is an INT/LONG column)
+};
+struct DevPred {
+  int column;
+  int op;
+  unsigned long long literal;  // raw bits, typed like the column
+};
+
+struct DevConfig {
+  int num_columns;
+  int column_type[QSX_MAX_COLUMNS];
+  int column_width[QSX_MAX_COLUMNS];
+  int num_keys;
+  int key_column[QSX_MAX_KEYS];
+  int key_width[QSX_MAX_KEYS];
+  int key_shift[QSX_MAX_KEYS];  // bit offset of the key inside the 64-bit code
+  int num_instrs;
+  DevInstr instrs[QSX_MAX_INSTRS];
+  double consts[QSX_MAX_CONSTS];
+  int num_sums;
+  DevSum sums[kMaxSums];
+  int num_pred;
+  DevPred pred[QSX_MAX_PRED_TERMS];
+  const void *cols[QSX_MAX_COLUMNS];
+};
+
+struct HashTableView {
+  unsigned long long *keys;    // [cap + 1]
+  unsigned long long *states;  // [(NS + 1)][cap + 1]
+  unsigned long long cap;      // power of two
+  int shift;                   // 64 - log2(cap)
+  unsigned long long *ngroups; // groups inserted (sentinel slot not counted)
+  int *overflow;               // set when an insert found the table full
+};
+
+struct DenseView {
+  unsigned long long *exist;
+  unsigned long long *states;  // [ncols][E]
+  long long num_entries;
+  int has_count;               // col 0 is the row count
+  int *error;                  // set when a key is outside [0, E)
+};
+
+// ---- per-row evaluation -----------------------------------------------------
+__device__ __forceinline__ double temp_get(const double (&t)[QSX_MAX_TEMPS], int i) {
+  switch (i) {  // wave-uniform index: scalar branches, temps stay in VGPRs
+    case 0: return t[0];
+    case 1: return t[1];
+    case 2: return t[2];
+    case 3: return t[3];
+    case 4: return t[4];
+    case 5: return t[5];
+    case 6: return t[6];
+    default: return t[7];
+  }
+}
+__device__ __forceinline__ void temp_set(double (&t)[QSX_MAX_TEMPS], int i, double v) {
+  switch (i) {
+    case 0: t[0] = v; break;
+    case 1: t[1] = v; break;
+    case 2: t[2] = v; break;
+    case 3: t[3] = v; break;
+    case 4: t[4] = v; break;
+    case 5: t[5] = v; break;
+    case 6: t[6] = v; break;
+    default: t[7] = v; break;
+  }
+}
+
+__device__ __forceinline__ double column_as_double(const DevConfig &c, int col, int64_t row) {
+  switch (c.column_type[col]) {
+    case QSX_INT: return static_cast<double>(static_cast<const int32_t *>(c.cols[col])[row]);
+    case QSX_LONG: return static_cast<double>(static_cast<const int64_t *>(c.cols[col])[row]);
+    case QSX_FLOAT: return static_cast<double>(static_cast<const float *>(c.cols[col])[row]);
+    default: return static_cast<const double *>(c.cols[col])[row];
+  }
+}
+__device__ __forceinline__ long long column_as_int(const DevConfig &c, int col, int64_t row) {
+  if (c.column_type[col] == QSX_INT) return static_cast<const int32_t *>(c.cols[col])[row];
+  return static_cast<const int64_t *>(c.cols[col])[row];
+}
+__device__ __forceinline__ double operand_value(const DevConfig &c, const DevOperand &o,
+                                                const double (&t)[QSX_MAX_TEMPS], int64_t row) {
+  switch (o.kind) {
+    case QSX_OPD_COLUMN: return column_as_double(c, o.index, row);
+    case QSX_OPD_CONST: return c.consts[o.index];
+    default: return temp_get(t, o.index);
+  }
+}
+
+// Expression program: every node an IEEE double, evaluated in program order
+// (compiled with -ffp-contract=off so that a*b+c is never fused: each
+// reference temp vector holds a rounded double).
+__device__ __forceinline__ void eval_program(const DevConfig &c, double (&t)[QSX_MAX_TEMPS], int64_t row) {
+  for (int k = 0; k < c.num_instrs; ++k) {
+    const DevInstr in = c.instrs[k];
+    const double a = operand_value(c, in.a, t, row);
+    const double b = operand_value(c, in.b, t, row);
+    double r;
+    switch (in.op) {
+      case QSX_EX_ADD: r = a + b; break;
+      case QSX_EX_SUB: r = a - b; break;
+      case QSX_EX_MUL: r = a * b; break;
+      default: r = a / b; break;
+    }
+    temp_set(t, in.dst, r);
+  }
+}
+
+__device__ __forceinline__ bool eval_predicate(const DevConfig &c, int64_t row) {
+  bool ok = true;
+  for (int p = 0; p < c.num_pred; ++p) {
+    const DevPred term = c.pred[p];
+    bool r;
+    switch (c.column_type[term.column]) {
+      case QSX_INT:
+        r = compare_op<int32_t>(static_cast<const int32_t *>(c.cols[term.column])[row], term.op,
+                                static_cast<int32_t>(term.literal));
+        break;
+      case QSX_LONG:
+        r = compare_op<int64_t>(static_cast<const int64_t *>(c.cols[term.column])[row], term.op,
+                                static_cast<int64_t>(term.literal));
+        break;
+      case QSX_FLOAT:
+        r = compare_op<float>(static_cast<const float *>(c.cols[term.column])[row], term.op,
+                              __uint_as_float(static_cast<uint32_t>(term.literal)));
+        break;
+      default:
+        r = compare_op<double>(static_cast<const double *>(c.cols[term.column])[row], term.op,
+                               __longlong_as_double(static_cast<long long>(term.literal)));
+        break;
+    }
+    ok = ok && r;
+  }
+  return ok;
+}
+
+// Compact key code: key bytes at running offsets of a zeroed 64-bit word,
+// little endian (storage/ThreadPrivateCompactKeyHashTable.cpp:216-232).
+__device__ __forceinline__ unsigned long long key_code(const DevConfig &c, int64_t row) {
+  unsigned long long code = 0;
+  for (int k = 0; k < c.num_keys; ++k) {
+    const void *col = c.cols[c.key_column[k]];
+    unsigned long long v;
+    switch (c.key_width[k]) {
+      case 1: v = static_cast<const uint8_t *>(col)[row]; break;
+      case 2: v = static_cast<const uint16_t *>(col)[row]; break;
+      case 4: v = static_cast<const uint32_t *>(col)[row]; break;
+      default: v = static_cast<const unsigned long long *>(col)[row]; break;
+    }
+    code |= v << c.key_shift[k];
+  }
+  return code;
+}
+
+// Value of sum j for this row as raw 64-bit accumulator increment.
+__device__ __forceinline__ unsigned long long sum_increment(const DevConfig &c, int j,
+                                                            const double (&t)[QSX_MAX_TEMPS], int64_t row) {
+  const DevSum s = c.sums[j];
+  if (s.is_int) return static_cast<unsigned long long>(column_as_int(c, s.arg.index, row));
+  return static_cast<unsigned long long>(__double_as_longlong(operand_value(c, s.arg, t, row)));
+}
+
+__device__ __forceinline__ unsigned long long acc_add(unsigned long long acc, unsigned long long inc, int is_int) {
+  if (is_int) return acc + inc;
+  return static_cast<unsigned long long>(__double_as_longlong(
+      __longlong_as_double(static_cast<long long>(acc)) + __longlong_as_double(static_cast<long long>(inc))));
+}
+
+__device__ __forceinline__ bool filter_bit(const uint64_t *filter, int64_t row) {
+  return filter == nullptr || msb_bit(filter[row >> 6], static_cast<int>(row & 63));
+}
+
+// ---- global hash table --------------------------------------------------------
+__device__ __forceinline__ unsigned long long code_slot(unsigned long long code, int shift) {
+  return (mix64(code) * 0x9E3779B97F4A7C15ull) >> shift;
+}
+
+// Returns the slot of `code` (inserting it if new), cap for the sentinel
+// code, or ~0 when the table is full (overflow flag raised).
+__device__ __forceinline__ unsigned long long global_find_or_insert(const HashTableView &g, unsigned long long code) {
+  if (code == kEmptyCode) return g.cap;
+  unsigned long long s = code_slot(code, g.shift);
+  for (unsigned long long probes = 0; probes < g.cap; ++probes) {
+    unsigned long long k = __hip_atomic_load(&g.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == code) return s;
+    if (k == kEmptyCode) {
+      k = atomicCAS(&g.keys[s], kEmptyCode, code);
+      if (k == kEmptyCode) {
+        atomicAdd(g.ngroups, 1ull);
+        return s;
+      }
+      if (k == code) return s;
+    }
+    s = (s + 1) & (g.cap - 1);
+  }
+  atomicExch(g.overflow, 1);
+  return ~0ull;
+}
+
+__device__ __forceinline__ void global_add(const HashTableView &g, int col, unsigned long long slot,
+                                           unsigned long long inc, int is_int) {
+  unsigned long long *p = g.states + static_cast<unsigned long long>(col) * (g.cap + 1) + slot;
+  if (is_int) {
+    if (inc != 0) atomicAdd(p, inc);
+  } else {
+    atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
+  }
+}
+
+// ---- LDS table ------------------------------------------------------------------
+__device__ __forceinline__ int lds_find_or_insert(unsigned long long *l_keys, int S, unsigned long long code) {
+  int s = static_cast<int>(mix64(code) >> 40) & (S - 1);
+  for (int probes = 0; probes < S; ++probes) {
+    unsigned long long k = __hip_atomic_load(&l_keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == code) return s;
+    if (k == kEmptyCode) {
+      k = atomicCAS(&l_keys[s], kEmptyCode, code);
+      if (k == kEmptyCode || k == code) return s;
+    }
+    s = (s + 1) & (S - 1);
+  }
+  return -1;
+}
+
+__device__ __forceinline__ void lds_add(unsigned long long *p, unsigned long long inc, int is_int) {
+  if (is_int) {
+    atomicAdd(p, inc);
+  } else {
+    unsafeAtomicAdd(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// hash-strategy update kernel.  NS = number of SUM/AVG accumulators.
+// Dynamic LDS: tags[R] | rstate[R][NS+1] | l_keys[S] | l_state[NS+1][S]
+// ---------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(kABlock) void agg_hash_kernel(DevConfig c, int64_t n,
+                                                          const uint64_t *__restrict__ filter,
+                                                          HashTableView g, int S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
+  unsigned long long *l_tags = smem;                                     // [R]
+  unsigned long long *l_rstate = l_tags + kRegGroups;                    // [R][NS + 1]
+  unsigned long long *l_keys = l_rstate + kRegGroups * (NS + 1);         // [S]
+  unsigned long long *l_state = l_keys + S;                              // [NS + 1][S]
+
+  for (int i = threadIdx.x; i < kRegGroups; i += kABlock) l_tags[i] = kEmptyCode;
+  for (int i = threadIdx.x; i < kRegGroups * (NS + 1); i += kABlock) l_rstate[i] = 0;
+  for (int i = threadIdx.x; i < S; i += kABlock) l_keys[i] = kEmptyCode;
+  for (int i = threadIdx.x; i < (NS + 1) * S; i += kABlock) l_state[i] = 0;
+  __syncthreads();
+
+  // Per-thread partial state of the register groups.
+  unsigned long long racc[kRegGroups][NS > 0 ? NS : 1];
+  unsigned int rcnt[kRegGroups];
+#pragma unroll
+  for (int r = 0; r < kRegGroups; ++r) {
+    rcnt[r] = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) racc[r][j] = 0;
+  }
+
+  const int64_t tile_rows = static_cast<int64_t>(kABlock) * kRowsPerIter;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * tile_rows; base < n;
+       base += static_cast<int64_t>(gridDim.x) * tile_rows) {
+    // Tags only ever go from empty to a code: a per-iteration snapshot is enough.
+    unsigned long long tag[kRegGroups];
+#pragma unroll
+    for (int r = 0; r < kRegGroups; ++r) {
+      tag[r] = __hip_atomic_load(&l_tags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int v = 0; v < kRowsPerIter; ++v) {
+      const int64_t row = base + static_cast<int64_t>(v) * kABlock + threadIdx.x;
+      bool live = row < n && filter_bit(filter, row);
+      if (live) live = eval_predicate(c, row);
+      double t[QSX_MAX_TEMPS];
+      unsigned long long code = 0;
+      unsigned long long inc[NS > 0 ? NS : 1];
+      if (live) {
+        eval_program(c, t, row);
+        code = key_code(c, row);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) inc[j] = sum_increment(c, j, t, row);
+      }
+      // which register group (if any)?
+      int sel = -1;
+      if (live && code != kEmptyCode) {
+#pragma unroll
+        for (int r = 0; r < kRegGroups; ++r) {
+          if (tag[r] == code) sel = r;
+        }
+        if (sel < 0) {
+          // Not in the snapshot: try to claim a free tag (first rows of a workgroup only).
+          for (int r = 0; r < kRegGroups && sel < 0; ++r) {
+            unsigned long long k = __hip_atomic_load(&l_tags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (k == kEmptyCode) k = atomicCAS(&l_tags[r], kEmptyCode, code);
+            if (k == kEmptyCode || k == code) sel = r;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kRegGroups; ++r) {
+        const bool hit = sel == r;
+        rcnt[r] += hit ? 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          // identity element: integer 0 and +0.0 share the all-zero bit pattern
+          racc[r][j] = acc_add(racc[r][j], hit ? inc[j] : 0ull, c.sums[j].is_int);
+        }
+      }
+      if (live && sel < 0) {
+        const int s = code == kEmptyCode ? -1 : lds_find_or_insert(l_keys, S, code);
+        if (s >= 0) {
+          atomicAdd(&l_state[s], 1ull);
+#pragma unroll
+          for (int j = 0; j < NS; ++j) lds_add(&l_state[(j + 1) * S + s], inc[j], c.sums[j].is_int);
+        } else {
+          const unsigned long long gs = global_find_or_insert(g, code);
+          if (gs != ~0ull) {
+            global_add(g, 0, gs, 1ull, 1);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, inc[j], c.sums[j].is_int);
+          }
+        }
+      }
+    }
+  }
+
+  // registers -> LDS (wave reduction first: one LDS atomic per wave per word)
+#pragma unroll
+  for (int r = 0; r < kRegGroups; ++r) {
+    const unsigned long long cnt = wave_reduce_add(static_cast<unsigned long long>(rcnt[r]));
+    if (cnt == 0) continue;  // wave-uniform
+    if (lane_id() == 0) atomicAdd(&l_rstate[r * (NS + 1)], cnt);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      unsigned long long v;
+      if (c.sums[j].is_int) {
+        v = wave_reduce_add(racc[r][j]);
+      } else {
+        v = static_cast<unsigned long long>(__double_as_longlong(
+            wave_reduce_add(__longlong_as_double(static_cast<long long>(racc[r][j])))));
+      }
+      if (lane_id() == 0) lds_add(&l_rstate[r * (NS + 1) + j + 1], v, c.sums[j].is_int);
+    }
+  }
+  __syncthreads();
+
+  // LDS -> global table: one atomic per group per accumulator per workgroup.
+  for (int i = threadIdx.x; i < kRegGroups + S; i += kABlock) {
+    unsigned long long code, cnt;
+    const unsigned long long *src;
+    int stride;
+    if (i < kRegGroups) {
+      code = l_tags[i];
+      src = &l_rstate[i * (NS + 1)];
+      stride = 1;
+    } else {
+      code = l_keys[i - kRegGroups];
+      src = &l_state[i - kRegGroups];
+      stride = S;
+    }
+    cnt = src[0];
+    if (code == kEmptyCode || cnt == 0) continue;
+    const unsigned long long gs = global_find_or_insert(g, code);
+    if (gs == ~0ull) continue;
+    global_add(g, 0, gs, cnt, 1);
+    for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, src[(j + 1) * stride], c.sums[j].is_int);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// COLLISION_FREE update kernel (K7): vec[key] += arg, existence bit.
+// ---------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(kABlock) void agg_dense_kernel(DevConfig c, int64_t n,
+                                                           const uint64_t *__restrict__ filter,
+                                                           DenseView d) {
+  const int first_sum_col = d.has_count ? 1 : 0;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * kABlock + threadIdx.x; row < n;
+       row += static_cast<int64_t>(gridDim.x) * kABlock) {
+    if (!filter_bit(filter, row) || !eval_predicate(c, row)) continue;
+    const long long loc = column_as_int(c, c.key_column[0], row);
+    if (loc < 0 || loc >= d.num_entries) {
+      atomicExch(d.error, 1);  // precondition min >= 0, max < num_entries violated
+      continue;
+    }
+    double t[QSX_MAX_TEMPS];
+    eval_program(c, t, row);
+    const unsigned long long bit = 1ull << (loc & 63);
+    unsigned long long *word = &d.exist[loc >> 6];
+    if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0) atomicOr(word, bit);
+    if (d.has_count) atomicAdd(&d.states[loc], 1ull);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      unsigned long long *p = d.states + static_cast<unsigned long long>(first_sum_col + j) * d.num_entries + loc;
+      const unsigned long long inc = sum_increment(c, j, t, row);
+      if (c.sums[j].is_int) {
+        atomicAdd(p, inc);
+      } else {
+        atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// merge of exported images
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kABlock) void merge_hash_kernel(const unsigned long long *__restrict__ image,
+                                                            unsigned long long src_cap, int num_cols,
+                                                            unsigned int int_col_mask, HashTableView g) {
+  const unsigned long long *src_keys = image;
+  const unsigned long long *src_states = image + (src_cap + 1);
+  for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * kABlock + threadIdx.x;
+       i <= src_cap; i += static_cast<unsigned long long>(gridDim.x) * kABlock) {
+    const unsigned long long cnt = src_states[i];
+    if (cnt == 0) continue;
+    const unsigned long long code = i == src_cap ? kEmptyCode : src_keys[i];
+    if (i != src_cap && code == kEmptyCode) continue;
+    const unsigned long long gs = global_find_or_insert(g, code);
+    if (gs == ~0ull) continue;
+    for (int col = 0; col < num_cols; ++col) {
+      global_add(g, col, gs, src_states[static_cast<unsigned long long>(col) * (src_cap + 1) + i],
+                 (int_col_mask >> col) & 1u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kABlock) void merge_dense_kernel(const unsigned long long *__restrict__ image,
+                                                             unsigned long long *__restrict__ dst,
+                                                             long long exist_words, long long num_entries,
+                                                             int num_cols, unsigned int int_col_mask) {
+  const long long total = exist_words + static_cast<long long>(num_cols) * num_entries;
+  for (long long i = static_cast<long long>(blockIdx.x) * kABlock + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * kABlock) {
+    const unsigned long long v = image[i];
+    if (v == 0) continue;
+    if (i < exist_words) {
+      atomicOr(&dst[i], v);
+    } else {
+      const int col = static_cast<int>((i - exist_words) / num_entries);
+      if ((int_col_mask >> col) & 1u) {
+        atomicAdd(&dst[i], v);
+      } else {
+        atomic_add_f64(reinterpret_cast<double *>(&dst[i]), __longlong_as_double(static_cast<long long>(v)));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// finalize
+// ---------------------------------------------------------------------------
+struct FinalizeDesc {
+  int num_aggs;
+  int fn[QSX_MAX_AGGS];
+  int sum_col[QSX_MAX_AGGS];  // state column of the aggregate's sum (>= 1), 0 for COUNT(*)
+  int is_int[QSX_MAX_AGGS];
+  int num_keys;
+  int key_width[QSX_MAX_KEYS];
+  int key_shift[QSX_MAX_KEYS];
+  int key_type[QSX_MAX_KEYS];
+  void *out_keys[QSX_MAX_KEYS];
+  void *out_vals[QSX_MAX_AGGS];
+  uint8_t *out_nulls[QSX_MAX_AGGS];
+};
+
+__device__ __forceinline__ void write_values(const FinalizeDesc &f, const unsigned long long *states,
+                                             unsigned long long col_stride, unsigned long long idx,
+                                             int count_col, bool empty_group, long long out_row) {
+  const long long cnt = count_col >= 0 ? static_cast<long long>(states[static_cast<unsigned long long>(count_col) * col_stride + idx]) : 0;
+  for (int a = 0; a < f.num_aggs; ++a) {
+    bool is_null = false;
+    if (f.fn[a] == QSX_AGG_COUNT_STAR) {
+      static_cast<long long *>(f.out_vals[a])[out_row] = cnt;
+    } else {
+      const unsigned long long raw = states[static_cast<unsigned long long>(f.sum_col[a]) * col_stride + idx];
+      if (f.fn[a] == QSX_AGG_SUM) {
+        // int64 and double results are both stored as their 8 raw bytes
+        static_cast<unsigned long long *>(f.out_vals[a])[out_row] = raw;
+        is_null = empty_group;
+      } else {
+        const double sum = f.is_int[a] ? static_cast<double>(static_cast<long long>(raw))
+                                       : __longlong_as_double(static_cast<long long>(raw));
+        is_null = cnt == 0;
+        static_cast<double *>(f.out_vals[a])[out_row] = is_null ? 0.0 : sum / static_cast<double>(cnt);
+      }
+    }
+    if (f.out_nulls[a] != nullptr) f.out_nulls[a][out_row] = is_null ? 1 : 0;
+  }
+}
+
+__device__ __forceinline__ void write_keys_from_code(const FinalizeDesc &f, unsigned long long code, long long out_row) {
+  for (int k = 0; k < f.num_keys; ++k) {
+    const unsigned long long v = code >> f.key_shift[k];
+    switch (f.key_width[k]) {
+      case 1: static_cast<uint8_t *>(f.out_keys[k])[out_row] = static_cast<uint8_t>(v); break;
+      case 2: static_cast<uint16_t *>(f.out_keys[k])[out_row] = static_cast<uint16_t>(v); break;
+      case 4: static_cast<uint32_t *>(f.out_keys[k])[out_row] = static_cast<uint32_t>(v); break;
+      default: static_cast<unsigned long long *>(f.out_keys[k])[out_row] = v; break;
+    }
+  }
+}
+
+// Reference hash of one key component (types/TypedValue.hpp:575-592): the
+// zero-extended bit pattern, -0.0 canonicalised for FLOAT/DOUBLE.
+__device__ __forceinline__ unsigned long long reference_scalar_hash(int type, unsigned long long bits) {
+  switch (type) {
+    case QSX_INT: return bits & 0xFFFFFFFFull;
+    case QSX_FLOAT: return (bits & 0xFFFFFFFFull) == 0x80000000ull ? 0ull : (bits & 0xFFFFFFFFull);
+    case QSX_DOUBLE: return bits == 0x8000000000000000ull ? 0ull : bits;
+    default: return bits;
+  }
+}
+// CombineHashes (utility/HashPair.hpp:47-58).
+__device__ __forceinline__ unsigned long long reference_combine(unsigned long long a, unsigned long long b) {
+  const unsigned long long kMul = 0x9ddfea08eb382d69ull;
+  unsigned long long x = (a ^ b) * kMul;
+  x ^= (x >> 47);
+  unsigned long long y = (b ^ x) * kMul;
+  y ^= (y >> 47);
+  y *= kMul;
+  return y;
+}
+
+// One output row per occupied slot whose reference partition matches.
+__global__ __launch_bounds__(kABlock) void finalize_hash_kernel(HashTableView g, FinalizeDesc f,
+                                                               int partition, int num_partitions,
+                                                               int partition_by_hash, long long capacity,
+                                                               unsigned long long *__restrict__ out_groups) {
+  const unsigned long long stride = g.cap + 1;
+  const unsigned long long total = g.cap + 1;
+  const unsigned long long rounded = (total + kWave - 1) / kWave * kWave;
+  for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * kABlock + threadIdx.x;
+       i < rounded; i += static_cast<unsigned long long>(gridDim.x) * kABlock) {
+    bool emit = false;
+    unsigned long long code = kEmptyCode;
+    if (i < total) {
+      code = i == g.cap ? kEmptyCode : g.keys[i];
+      const unsigned long long cnt = g.states[i];
+      emit = (i == g.cap) ? (cnt != 0) : (code != kEmptyCode);
+      if (emit && partition_by_hash) {
+        // partitioned aggregation routes a group to HashCompositeKey % P
+        // (storage/AggregationOperationState.cpp:576-583, utility/CompositeHash.hpp:39-48)
+        unsigned long long h = 0;
+        for (int k = 0; k < f.num_keys; ++k) {
+          unsigned long long bits = code >> f.key_shift[k];
+          if (f.key_width[k] < 8) bits &= (1ull << (8 * f.key_width[k])) - 1;
+          const unsigned long long hk = reference_scalar_hash(f.key_type[k], bits);
+          h = k == 0 ? hk : reference_combine(h, hk);
+        }
+        emit = static_cast<int>(h % static_cast<unsigned long long>(num_partitions)) == partition;
+      }
+    }
+    const uint64_t m = __ballot(emit);
+    if (m == 0) continue;
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    unsigned long long base = 0;
+    if (lane_id() == leader) base = atomicAdd(out_groups, static_cast<unsigned long long>(__popcll(m)));
+    base = __shfl(base, leader, kWave);
+    if (!emit) continue;
+    const long long out_row = static_cast<long long>(base) + rank_below(m);
+    if (out_row >= capacity) continue;
+    write_keys_from_code(f, code, out_row);
+    write_values(f, g.states, stride, i, 0, false, out_row);
+  }
+}
+
+// SINGLE_STATE: exactly one row, NULL sums when no row was aggregated
+// (storage/AggregationOperationState.cpp:652-670).
+__global__ void finalize_single_kernel(HashTableView g, FinalizeDesc f, unsigned long long *out_groups) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // the only possible code is 0
+  unsigned long long s = code_slot(0ull, g.shift);
+  unsigned long long found = ~0ull;
+  for (unsigned long long probes = 0; probes < g.cap; ++probes) {
+    const unsigned long long k = g.keys[s];
+    if (k == 0ull) { found = s; break; }
+    if (k == kEmptyCode) break;
+    s = (s + 1) & (g.cap - 1);
+  }
+  if (found == ~0ull) {
+    // nothing aggregated: COUNT = 0, SUM/AVG NULL. Slot `cap` is never used by
+    // code 0 and holds all-zero state words.
+    write_values(f, g.states, g.cap + 1, g.cap, 0, true, 0);
+  } else {
+    write_values(f, g.states, g.cap + 1, found, 0, false, 0);
+  }
+  *out_groups = 1;
+}
+
+// COLLISION_FREE finalize: ordered compaction of the existence bits of the
+// partition's key range [begin, end) (CollisionFreeVectorTable.hpp:192-208, 647-727).
+constexpr int kDenseTileWords = 64;
+
+__device__ __forceinline__ unsigned long long ranged_word(const unsigned long long *exist, long long w,
+                                                          long long begin, long long end) {
+  // bits of word w restricted to keys in [begin, end)
+  const long long lo = w * 64, hi = lo + 64;
+  if (hi <= begin || lo >= end) return 0;
+  unsigned long long v = exist[w];
+  if (begin > lo) v &= ~0ull << (begin - lo);
+  if (end < hi) v &= ~0ull >> (hi - end);
+  return v;
+}
+
+__global__ __launch_bounds__(kABlock) void dense_tile_count_kernel(const unsigned long long *__restrict__ exist,
+                                                                  long long first_word, long long num_words,
+                                                                  long long begin, long long end,
+                                                                  long long num_tiles,
+                                                                  int32_t *__restrict__ tile_counts) {
+  const int lane = lane_id();
+  for (long long tile = static_cast<long long>(blockIdx.x) * (kABlock / kWave) + (threadIdx.x >> 6);
+       tile < num_tiles; tile += static_cast<long long>(gridDim.x) * (kABlock / kWave)) {
+    const long long w = tile * kDenseTileWords + lane;
+    int c = w < num_words ? __popcll(ranged_word(exist, first_word + w, begin, end)) : 0;
+    c = wave_reduce_add(c);
+    if (lane == 0) tile_counts[tile] = c;
+  }
+}
+
+__global__ __launch_bounds__(kABlock) void finalize_dense_kernel(DenseView d, FinalizeDesc f,
+                                                                long long first_word, long long num_words,
+                                                                long long begin, long long end,
+                                                                long long num_tiles,
+                                                                const int64_t *__restrict__ tile_offsets,
+                                                                long long capacity) {
+  __shared__ unsigned long long s_words[kABlock / kWave][kDenseTileWords];
+  __shared__ int32_t s_prefix[kABlock / kWave][kDenseTileWords];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  for (long long tile = static_cast<long long>(blockIdx.x) * (kABlock / kWave) + wave; tile < num_tiles;
+       tile += static_cast<long long>(gridDim.x) * (kABlock / kWave)) {
+    const long long w = tile * kDenseTileWords + lane;
+    const unsigned long long mine = w < num_words ? ranged_word(d.exist, first_word + w, begin, end) : 0;
+    const int pc = __popcll(mine);
+    int incl = pc;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int up = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += up;
+    }
+    s_words[wave][lane] = mine;
+    s_prefix[wave][lane] = incl - pc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const long long tile_off = tile_offsets[tile];
+    for (int k = 0; k < kDenseTileWords; ++k) {
+      const unsigned long long word = s_words[wave][k];
+      if (word == 0) continue;
+      if ((word >> lane) & 1ull) {
+        const int before = __popcll(word & ((1ull << lane) - 1));
+        const long long out_row = tile_off + s_prefix[wave][k] + before;
+        const long long loc = (first_word + tile * kDenseTileWords + k) * 64 + lane;
+        if (out_row < capacity) {
+          if (f.key_width[0] == 4) static_cast<int32_t *>(f.out_keys[0])[out_row] = static_cast<int32_t>(loc);
+          else static_cast<long long *>(f.out_keys[0])[out_row] = loc;
+          write_values(f, d.states, static_cast<unsigned long long>(d.num_entries),
+                       static_cast<unsigned long long>(loc), d.has_count ? 0 : -1, false, out_row);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(kABlock) void popcount_words_kernel(const unsigned long long *__restrict__ words,
+                                                                long long num_words,
+                                                                unsigned long long *__restrict__ out) {
+  unsigned long long c = 0;
+  for (long long w = static_cast<long long>(blockIdx.x) * kABlock + threadIdx.x; w < num_words;
+       w += static_cast<long long>(gridDim.x) * kABlock) {
+    c += __popcll(words[w]);
+  }
+  c = wave_reduce_add(c);
+  if (lane_id() == 0 && c != 0) atomicAdd(out, c);
+}
+
+}  // namespace qsx
+
+using namespace qsx;
+
+// ===========================================================================
+// host side
+// ===========================================================================
+struct qsx_agg_state {
+  qsx_agg_config_t config;
+  DevConfig dev;            // everything but cols[]
+  FinalizeDesc fin;         // everything but the output pointers
+  int num_sums = 0;
+  int num_cols = 0;         // state columns in the image
+  unsigned int int_col_mask = 0;
+  bool dense = false;
+  bool dense_has_count = false;
+
+  // one allocation: the image
+  unsigned long long *image = nullptr;
+  size_t image_bytes = 0;
+  unsigned long long cap = 0;      // hash strategies
+  long long exist_words = 0;       // dense
+  // control words: [0] ngroups (u64), [1] overflow|error flag (int), [2] scratch counter
+  unsigned long long *control = nullptr;
+  // scratch for ordered dense finalize
+  int32_t *tile_counts = nullptr;
+  int64_t *tile_offsets = nullptr;
+  long long max_tiles = 0;
+  int lds_slots = 64;
+
+  HashTableView hash_view() const {
+    HashTableView g;
+    g.keys = image;
+    g.states = image + (cap + 1);
+    g.cap = cap;
+    int log2 = 0;
+    while ((1ull << log2) < cap) ++log2;
+    g.shift = 64 - log2;
+    g.ngroups = control;
+    g.overflow = reinterpret_cast<int *>(control + 1);
+    return g;
+  }
+  DenseView dense_view() const {
+    DenseView d;
+    d.exist = image;
+    d.states = image + exist_words;
+    d.num_entries = config.num_entries;
+    d.has_count = dense_has_count ? 1 : 0;
+    d.error = reinterpret_cast<int *>(control + 1);
+    return d;
+  }
+};
+
+static bool valid_operand(const qsx_agg_config_t &c, const qsx_operand_t &o, int num_defined_temps_mask) {
+  switch (o.kind) {
+    case QSX_OPD_COLUMN: {
+      if (o.index < 0 || o.index >= c.num_columns) return false;
+      const int t = c.column_type[o.index];
+      return t == QSX_INT || t == QSX_LONG || t == QSX_FLOAT || t == QSX_DOUBLE;
+    }
+    case QSX_OPD_CONST: return o.index >= 0 && o.index < QSX_MAX_CONSTS;
+    case QSX_OPD_TEMP: return o.index >= 0 && o.index < QSX_MAX_TEMPS && ((num_defined_temps_mask >> o.index) & 1);
+    default: return false;
+  }
+}
+
+static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
+  if (c.num_columns < 0 || c.num_columns > QSX_MAX_COLUMNS || c.num_keys < 0 || c.num_keys > QSX_MAX_KEYS ||
+      c.num_aggs < 0 || c.num_aggs > QSX_MAX_AGGS || c.num_instrs < 0 || c.num_instrs > QSX_MAX_INSTRS ||
+      c.num_pred_terms < 0 || c.num_pred_terms > QSX_MAX_PRED_TERMS) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  DevConfig &d = st->dev;
+  std::memset(&d, 0, sizeof(d));
+  d.num_columns = c.num_columns;
+  for (int i = 0; i < c.num_columns; ++i) {
+    const int t = c.column_type[i], w = c.column_width[i];
+    if (t == QSX_CHAR) {
+      if (w != 1 && w != 2 && w != 4 && w != 8) return QSX_ERR_UNSUPPORTED;
+    } else if (type_width(t) == 0 || w != type_width(t)) {
+      return QSX_ERR_INVALID_ARGUMENT;
+    }
+    d.column_type[i] = t;
+    d.column_width[i] = w;
+  }
+  // keys
+  switch (c.strategy) {
+    case QSX_AGG_SINGLE_STATE:
+      if (c.num_keys != 0) return QSX_ERR_INVALID_ARGUMENT;
+      break;
+    case QSX_AGG_COLLISION_FREE:
+      if (c.num_keys != 1 || c.num_entries <= 0) return QSX_ERR_INVALID_ARGUMENT;
+      break;
+    case QSX_AGG_COMPACT_KEY:
+    case QSX_AGG_GENERIC:
+      if (c.num_keys < 1) return QSX_ERR_INVALID_ARGUMENT;
+      break;
+    default: return QSX_ERR_INVALID_ARGUMENT;
+  }
+  d.num_keys = c.num_keys;
+  int offset_bytes = 0;
+  for (int k = 0; k < c.num_keys; ++k) {
+    const int col = c.key_column[k];
+    if (col < 0 || col >= c.num_columns) return QSX_ERR_INVALID_ARGUMENT;
+    const int t = c.column_type[col];
+    if (c.strategy == QSX_AGG_COLLISION_FREE && t != QSX_INT && t != QSX_LONG) return QSX_ERR_UNSUPPORTED;
+    if (c.strategy == QSX_AGG_GENERIC && t == QSX_CHAR) return QSX_ERR_UNSUPPORTED;  // FarmHash keys: out of scope
+    d.key_column[k] = col;
+    d.key_width[k] = c.column_width[col];
+    d.key_shift[k] = offset_bytes * 8;
+    offset_bytes += c.column_width[col];
+  }
+  // both hash strategies pack the whole key into one 64-bit code
+  if (offset_bytes > 8) return QSX_ERR_UNSUPPORTED;
+  // expression program
+  int defined = 0;
+  d.num_instrs = c.num_instrs;
+  for (int k = 0; k < c.num_instrs; ++k) {
+    const qsx_expr_instr_t &in = c.instrs[k];
+    if (in.op < QSX_EX_ADD || in.op > QSX_EX_DIV || in.dst < 0 || in.dst >= QSX_MAX_TEMPS) return QSX_ERR_INVALID_ARGUMENT;
+    if (!valid_operand(c, in.a, defined) || !valid_operand(c, in.b, defined)) return QSX_ERR_INVALID_ARGUMENT;
+    d.instrs[k].op = in.op;
+    d.instrs[k].dst = in.dst;
+    d.instrs[k].a = DevOperand{in.a.kind, in.a.index};
+    d.instrs[k].b = DevOperand{in.b.kind, in.b.index};
+    defined |= 1 << in.dst;
+  }
+  for (int k = 0; k < QSX_MAX_CONSTS; ++k) d.consts[k] = c.consts[k];
+  // aggregates -> state columns
+  FinalizeDesc &f = st->fin;
+  std::memset(&f, 0, sizeof(f));
+  f.num_aggs = c.num_aggs;
+  int ns = 0;
+  bool needs_count = false;
+  for (int a = 0; a < c.num_aggs; ++a) {
+    const qsx_agg_desc_t &ag = c.aggs[a];
+    f.fn[a] = ag.fn;
+    if (ag.fn == QSX_AGG_COUNT_STAR) {
+      needs_count = true;
+      f.sum_col[a] = 0;
+      continue;
+    }
+    if (ag.fn != QSX_AGG_SUM && ag.fn != QSX_AGG_AVG) return QSX_ERR_UNSUPPORTED;
+    if (ag.arg.kind == QSX_OPD_CONST || !valid_operand(c, ag.arg, defined)) return QSX_ERR_INVALID_ARGUMENT;
+    if (ag.fn == QSX_AGG_AVG) needs_count = true;
+    const bool is_int = ag.arg.kind == QSX_OPD_COLUMN &&
+                        (c.column_type[ag.arg.index] == QSX_INT || c.column_type[ag.arg.index] == QSX_LONG);
+    d.sums[ns].arg = DevOperand{ag.arg.kind, ag.arg.index};
+    d.sums[ns].is_int = is_int ? 1 : 0;
+    f.is_int[a] = is_int ? 1 : 0;
+    f.sum_col[a] = ns + 1;  // fixed up below for dense states without a count column
+    ++ns;
+  }
+  d.num_sums = ns;
+  st->num_sums = ns;
+  // predicate
+  d.num_pred = c.num_pred_terms;
+  for (int p = 0; p < c.num_pred_terms; ++p) {
+    const qsx_pred_term_t &t = c.pred[p];
+    if (t.column < 0 || t.column >= c.num_columns || t.op < QSX_EQ || t.op > QSX_GE) return QSX_ERR_INVALID_ARGUMENT;
+    d.pred[p].column = t.column;
+    d.pred[p].op = t.op;
+    unsigned long long bits = 0;
+    switch (c.column_type[t.column]) {
+      case QSX_INT: bits = static_cast<uint32_t>(t.literal.i32); break;
+      case QSX_LONG: bits = static_cast<unsigned long long>(t.literal.i64); break;
+      case QSX_FLOAT: { uint32_t b; std::memcpy(&b, &t.literal.f32, 4); bits = b; break; }
+      case QSX_DOUBLE: std::memcpy(&bits, &t.literal.f64, 8); break;
+      default: return QSX_ERR_UNSUPPORTED;
+    }
+    d.pred[p].literal = bits;
+  }
+  // finalize key description
+  f.num_keys = c.num_keys;
+  for (int k = 0; k < c.num_keys; ++k) {
+    f.key_width[k] = d.key_width[k];
+    f.key_shift[k] = d.key_shift[k];
+    f.key_type[k] = c.column_type[c.key_column[k]];
+  }
+  st->dense = c.strategy == QSX_AGG_COLLISION_FREE;
+  st->dense_has_count = needs_count;
+  if (st->dense && !needs_count) {
+    for (int a = 0; a < c.num_aggs; ++a) f.sum_col[a] -= 1;  // no count column in front
+  }
+  st->num_cols = st->dense ? ns + (needs_count ? 1 : 0) : ns + 1;
+  st->int_col_mask = 0;
+  {
+    int col = 0;
+    if (!st->dense || needs_count) st->int_col_mask |= 1u << col++;
+    for (int j = 0; j < ns; ++j, ++col) if (d.sums[j].is_int) st->int_col_mask |= 1u << col;
+  }
+  return QSX_OK;
+}
+
+template <int NS>
+static void launch_hash(const DevConfig &dc, int64_t n, const uint64_t *filter, const HashTableView &g, int S,
+                        hipStream_t stream) {
+  const size_t lds = sizeof(unsigned long long) * (kRegGroups + kRegGroups * (NS + 1) + S + static_cast<size_t>(NS + 1) * S);
+  const int grid = grid_for(n, kABlock * kRowsPerIter * 4);
+  hipLaunchKernelGGL((agg_hash_kernel<NS>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S);
+}
+template <int NS>
+static void launch_dense(const DevConfig &dc, int64_t n, const uint64_t *filter, const DenseView &d, hipStream_t stream) {
+  const int grid = grid_for(n, kABlock * 4);
+  hipLaunchKernelGGL((agg_dense_kernel<NS>), dim3(grid), dim3(kABlock), 0, stream, dc, n, filter, d);
+}
+
+#define QSX_DISPATCH_NS(ns, FN, ...)      \
+  switch (ns) {                           \
+    case 0: FN<0>(__VA_ARGS__); break;    \
+    case 1: FN<1>(__VA_ARGS__); break;    \
+    case 2: FN<2>(__VA_ARGS__); break;    \
+    case 3: FN<3>(__VA_ARGS__); break;    \
+    case 4: FN<4>(__VA_ARGS__); break;    \
+    case 5: FN<5>(__VA_ARGS__); break;    \
+    case 6: FN<6>(__VA_ARGS__); break;    \
+    case 7: FN<7>(__VA_ARGS__); break;    \
+    default: FN<8>(__VA_ARGS__); break;   \
+  }
+
+static int check_flags(qsx_agg_state *st, hipStream_t stream) {
+  unsigned long long control[2];
+  QSX_HIP_TRY(hipMemcpyAsync(control, st->control, sizeof(control), hipMemcpyDeviceToHost, stream));
+  QSX_HIP_TRY(hipStreamSynchronize(stream));
+  if (static_cast<int>(control[1] & 0xFFFFFFFFu) != 0) {
+    return st->dense ? QSX_ERR_INVALID_ARGUMENT : QSX_ERR_TOO_MANY_GROUPS;
+  }
+  return QSX_OK;
+}
+
+extern "C" {
+
+int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) {
+  QSX_REQUIRE_DEVICE();
+  if (config == nullptr || out == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  qsx_agg_state *st = new qsx_agg_state();
+  st->config = *config;
+  int rc = translate_config(*config, st);
+  if (rc != QSX_OK) { delete st; return rc; }
+  if (st->dense) {
+    st->exist_words = (config->num_entries + 63) / 64;
+    st->image_bytes = sizeof(unsigned long long) * (st->exist_words + static_cast<size_t>(st->num_cols) * config->num_entries);
+    st->max_tiles = (st->exist_words + kDenseTileWords - 1) / kDenseTileWords + 1;
+  } else {
+    const int64_t est = config->strategy == QSX_AGG_SINGLE_STATE ? 1 : (config->est_groups < 1 ? 1 : config->est_groups);
+    // generous head-room: the estimate comes from the optimizer and a full
+    // table cannot be grown in the middle of a kernel
+    st->cap = next_pow2(static_cast<uint64_t>(est) * 8 + 1024);
+    st->image_bytes = sizeof(unsigned long long) * (st->cap + 1) * (st->num_cols + 1);
+    // workgroup-private LDS table: up to 512 slots (<= 40 KiB at NS = 8)
+    uint64_t s = next_pow2(static_cast<uint64_t>(est) * 4);
+    if (s < 64) s = 64;
+    if (s > 512) s = 512;
+    st->lds_slots = static_cast<int>(s);
+  }
+  hipError_t err = hipMalloc(reinterpret_cast<void **>(&st->image), st->image_bytes);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->control), 4 * sizeof(unsigned long long));
+  if (err == hipSuccess && st->dense) {
+    err = hipMalloc(reinterpret_cast<void **>(&st->tile_counts), sizeof(int32_t) * st->max_tiles);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->tile_offsets), sizeof(int64_t) * (st->max_tiles + 1));
+  }
+  if (err == hipSuccess) err = hipMemset(st->control, 0, 4 * sizeof(unsigned long long));
+  if (err == hipSuccess) {
+    // InitializeAggregation: zero the state (CollisionFreeVectorTable.hpp:136-143)
+    if (st->dense) {
+      err = hipMemset(st->image, 0, st->image_bytes);
+    } else {
+      err = hipMemset(st->image, 0xFF, sizeof(unsigned long long) * (st->cap + 1));
+      if (err == hipSuccess) {
+        err = hipMemset(st->image + (st->cap + 1), 0, sizeof(unsigned long long) * (st->cap + 1) * st->num_cols);
+      }
+    }
+  }
+  if (err == hipSuccess) err = hipDeviceSynchronize();
+  if (err != hipSuccess) {
+    set_last_error("qsx_agg_state_create", err);
+    (void)hipFree(st->image); (void)hipFree(st->control); (void)hipFree(st->tile_counts); (void)hipFree(st->tile_offsets);
+    delete st;
+    return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
+  }
+  *out = st;
+  return QSX_OK;
+}
+
+int qsx_agg_state_destroy(qsx_agg_state_t *st) {
+  if (st == nullptr) return QSX_OK;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(st->image);
+  (void)hipFree(st->control);
+  (void)hipFree(st->tile_counts);
+  (void)hipFree(st->tile_offsets);
+  delete st;
+  return QSX_OK;
+}
+
+int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev,
+                   qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (st == nullptr || n < 0 || (n > 0 && st->config.num_columns > 0 && cols == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+  if (n == 0) return QSX_OK;
+  DevConfig dc = st->dev;
+  for (int i = 0; i < st->config.num_columns; ++i) dc.cols[i] = cols[i];
+  hipStream_t s = as_stream(stream);
+  if (st->dense) {
+    const DenseView d = st->dense_view();
+    QSX_DISPATCH_NS(st->num_sums, launch_dense, dc, n, filter_dev, d, s);
+  } else {
+    const HashTableView g = st->hash_view();
+    QSX_DISPATCH_NS(st->num_sums, launch_hash, dc, n, filter_dev, g, st->lds_slots, s);
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_agg_state_export_bytes(const qsx_agg_state_t *st, size_t *out_bytes) {
+  if (st == nullptr || out_bytes == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  *out_bytes = st->image_bytes;
+  return QSX_OK;
+}
+
+int qsx_agg_state_export(const qsx_agg_state_t *st, void *out_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (st == nullptr || out_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  QSX_HIP_TRY(hipMemcpyAsync(out_dev, st->image, st->image_bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+  return QSX_OK;
+}
+
+int qsx_agg_state_import_merge(qsx_agg_state_t *dst, const void *image_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (dst == nullptr || image_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  const unsigned long long *image = static_cast<const unsigned long long *>(image_dev);
+  hipStream_t s = as_stream(stream);
+  if (dst->dense) {
+    const long long total = dst->exist_words + static_cast<long long>(dst->num_cols) * dst->config.num_entries;
+    hipLaunchKernelGGL(merge_dense_kernel, dim3(grid_for(total, kABlock * 4)), dim3(kABlock), 0, s, image,
+                       dst->image, dst->exist_words, static_cast<long long>(dst->config.num_entries),
+                       dst->num_cols, dst->int_col_mask);
+  } else {
+    hipLaunchKernelGGL(merge_hash_kernel, dim3(grid_for(dst->cap + 1, kABlock)), dim3(kABlock), 0, s, image,
+                       dst->cap, dst->num_cols, dst->int_col_mask, dst->hash_view());
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_agg_merge(qsx_agg_state_t *dst, const qsx_agg_state_t *src, qsx_stream_t stream) {
+  if (dst == nullptr || src == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (dst->image_bytes != src->image_bytes || dst->num_cols != src->num_cols || dst->dense != src->dense) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  return qsx_agg_state_import_merge(dst, src->image, stream);
+}
+
+int qsx_agg_num_groups(qsx_agg_state_t *st, int64_t *out_groups, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (st == nullptr || out_groups == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  hipStream_t s = as_stream(stream);
+  int rc = check_flags(st, s);
+  if (rc != QSX_OK) return rc;
+  if (st->config.strategy == QSX_AGG_SINGLE_STATE) {
+    *out_groups = 1;
+    return QSX_OK;
+  }
+  unsigned long long v = 0;
+  if (st->dense) {
+    QSX_HIP_TRY(hipMemsetAsync(st->control + 2, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(popcount_words_kernel, dim3(grid_for(st->exist_words, kABlock * 4)), dim3(kABlock), 0, s,
+                       st->image, st->exist_words, st->control + 2);
+    QSX_CHECK_LAUNCH();
+    QSX_HIP_TRY(hipMemcpyAsync(&v, st->control + 2, sizeof(v), hipMemcpyDeviceToHost, s));
+    QSX_HIP_TRY(hipStreamSynchronize(s));
+    *out_groups = static_cast<int64_t>(v);
+  } else {
+    QSX_HIP_TRY(hipMemcpyAsync(&v, st->control, sizeof(v), hipMemcpyDeviceToHost, s));
+    QSX_HIP_TRY(hipStreamSynchronize(s));
+    *out_groups = static_cast<int64_t>(v) + 1;  // + the sentinel slot
+  }
+  return QSX_OK;
+}
+
+int qsx_agg_finalize(qsx_agg_state_t *st, int partition, int num_partitions, void *const *out_key_cols,
+                     void *const *out_val_cols, uint8_t *const *out_null_cols, int64_t capacity,
+                     int64_t *out_groups_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (st == nullptr || out_groups_dev == nullptr || num_partitions < 1 || partition < 0 ||
+      partition >= num_partitions || capacity < 0 || out_val_cols == nullptr) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  int rc = check_flags(st, s);
+  if (rc != QSX_OK) return rc;
+  FinalizeDesc f = st->fin;
+  for (int k = 0; k < f.num_keys; ++k) {
+    if (out_key_cols == nullptr || out_key_cols[k] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    f.out_keys[k] = out_key_cols[k];
+  }
+  for (int a = 0; a < f.num_aggs; ++a) {
+    f.out_vals[a] = out_val_cols[a];
+    f.out_nulls[a] = out_null_cols != nullptr ? out_null_cols[a] : nullptr;
+  }
+  unsigned long long *out_groups = reinterpret_cast<unsigned long long *>(out_groups_dev);
+  QSX_HIP_TRY(hipMemsetAsync(out_groups_dev, 0, sizeof(int64_t), s));
+  switch (st->config.strategy) {
+    case QSX_AGG_SINGLE_STATE:
+      if (partition != 0) return QSX_OK;
+      if (capacity < 1) return QSX_ERR_CAPACITY;
+      hipLaunchKernelGGL(finalize_single_kernel, dim3(1), dim3(64), 0, s, st->hash_view(), f, out_groups);
+      break;
+    case QSX_AGG_COMPACT_KEY:
+      // compact-key tables are finalized in one piece (AggregationOperationState.cpp:925-948)
+      if (partition != 0) return QSX_OK;
+      hipLaunchKernelGGL(finalize_hash_kernel, dim3(grid_for(st->cap + 1, kABlock)), dim3(kABlock), 0, s,
+                         st->hash_view(), f, 0, 1, 0, static_cast<long long>(capacity), out_groups);
+      break;
+    case QSX_AGG_GENERIC:
+      hipLaunchKernelGGL(finalize_hash_kernel, dim3(grid_for(st->cap + 1, kABlock)), dim3(kABlock), 0, s,
+                         st->hash_view(), f, partition, num_partitions, 1, static_cast<long long>(capacity),
+                         out_groups);
+      break;
+    default: {
+      const long long E = st->config.num_entries;
+      const long long len = (E + num_partitions - 1) / num_partitions;
+      const long long begin = static_cast<long long>(partition) * len;
+      const long long end = begin + len < E ? begin + len : E;
+      if (begin >= end) return QSX_OK;
+      const long long first_word = begin / 64;
+      const long long num_words = (end + 63) / 64 - first_word;
+      const long long num_tiles = (num_words + kDenseTileWords - 1) / kDenseTileWords;
+      const DenseView d = st->dense_view();
+      hipLaunchKernelGGL(dense_tile_count_kernel, dim3(grid_for(num_tiles, kABlock / kWave)), dim3(kABlock), 0, s,
+                         d.exist, first_word, num_words, begin, end, num_tiles, st->tile_counts);
+      QSX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, st->tile_counts,
+                         static_cast<int64_t>(num_tiles), st->tile_offsets, out_groups_dev);
+      QSX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(finalize_dense_kernel, dim3(grid_for(num_tiles, kABlock / kWave)), dim3(kABlock), 0, s,
+                         d, f, first_word, num_words, begin, end, num_tiles, st->tile_offsets,
+                         static_cast<long long>(capacity));
+      break;
+    }
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+}  // extern "C"

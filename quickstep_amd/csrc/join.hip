@@ -1,0 +1,532 @@
+// join.hip — K3 (hash-table build) and K4 (probe + match compaction).
+//
+// Reference loops replaced (paths in the Quickstep tree):
+//   K3  storage/HashTable.hpp:1358-1461 (putValueAccessor) ->
+//       storage/SimpleScalarSeparateChainingHashTable.hpp:1062-1113
+//   K4  storage/HashTable.hpp:2145-2181 (getAllFromValueAccessorImpl) +
+//       relational_operators/HashJoinOperator.cpp:76-130 (pair collectors),
+//       storage/HashTable.hpp:1979-2062 (existence probes for semi/anti)
+//
+// Device table (NOT the reference's 32-byte separate-chaining buckets): open
+// addressing, power-of-two capacity, load factor <= 1/2, 16-byte probe unit so
+// that one global_load_dwordx4 inspects a whole unit:
+//   INT keys : unit = two 8-byte entries {key:32 | tid:32}, empty = all ones
+//   LONG keys: unit = one 16-byte entry  {key:64, tid:32, pad:32}, empty tid = -1
+// Duplicate keys simply occupy further slots of the probe sequence (the
+// reference keeps duplicates too, allow_duplicate_keys = true), so the build
+// never compares keys: it only claims an empty slot with one CAS.  A probe
+// walks units from hash(key) until it meets an empty slot.
+//
+// Match compaction: a 256-thread workgroup stages the (probe_tid, build_tid)
+// pairs of a 4096-row tile in LDS (wave ballot + mbcnt prefix, one LDS atomic
+// per wave step), then reserves its output range with ONE global atomic and
+// streams the pairs out coalesced.
+
+#include "common.hpp"
+
+#include <mutex>
+#include <shared_mutex>
+
+namespace qsx {
+
+constexpr int kJBlock = 256;
+constexpr uint64_t kEmpty64 = ~0ull;
+constexpr uint32_t kEmptyTid = 0xFFFFFFFFu;
+
+struct alignas(16) LongEntry {
+  int64_t key;
+  uint32_t tid;
+  uint32_t pad;
+};
+
+struct TableView {
+  void *slots;    // uint64_t[capacity] (INT) or LongEntry[capacity] (LONG)
+  uint64_t mask;  // capacity - 1 (entries)
+  int shift;      // 64 - log2(capacity)
+};
+
+__device__ __forceinline__ uint64_t slot_of(int32_t key, const TableView &t) {
+  return (static_cast<uint64_t>(static_cast<uint32_t>(key)) * 0x9E3779B97F4A7C15ull) >> t.shift;
+}
+__device__ __forceinline__ uint64_t slot_of(int64_t key, const TableView &t) {
+  return (mix64(static_cast<uint64_t>(key)) * 0x9E3779B97F4A7C15ull) >> t.shift;
+}
+
+__device__ __forceinline__ bool row_in_filter(const uint64_t *filter, int64_t row) {
+  return filter == nullptr || ((filter[row >> 6] >> (63 - (row & 63))) & 1u);
+}
+
+__device__ __forceinline__ void insert_entry(const TableView &t, int32_t key, uint32_t tid) {
+  uint64_t *slots = static_cast<uint64_t *>(t.slots);
+  const uint64_t packed = (static_cast<uint64_t>(tid) << 32) | static_cast<uint32_t>(key);
+  // Home position = entry 0 of the key's 16-byte unit, so that a probe that
+  // starts at the unit boundary sees the sequence without gaps.
+  uint64_t s = slot_of(key, t) & ~1ull;
+  for (;;) {
+    const unsigned long long old =
+        atomicCAS(reinterpret_cast<unsigned long long *>(&slots[s]), kEmpty64, packed);
+    if (old == kEmpty64) return;
+    s = (s + 1) & t.mask;
+  }
+}
+
+__device__ __forceinline__ void insert_entry(const TableView &t, int64_t key, uint32_t tid) {
+  LongEntry *slots = static_cast<LongEntry *>(t.slots);
+  uint64_t s = slot_of(key, t);
+  for (;;) {
+    // Claim the slot through its tid word; the key is published with a plain
+    // store and only read by probe kernels launched after the build
+    // (BuildHash -> HashJoin is a pipeline breaker, ExecutionGenerator.cpp:1110-1124).
+    if (atomicCAS(&slots[s].tid, kEmptyTid, tid) == kEmptyTid) {
+      slots[s].key = key;
+      return;
+    }
+    s = (s + 1) & t.mask;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3 build
+// ---------------------------------------------------------------------------
+template <typename KeyT>
+__global__ __launch_bounds__(kJBlock) void build_kernel(TableView t, const KeyT *__restrict__ keys,
+                                                       int64_t n, int32_t base_tid,
+                                                       const uint64_t *__restrict__ filter,
+                                                       unsigned long long *__restrict__ entries) {
+  unsigned long long inserted = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kJBlock) {
+    if (!row_in_filter(filter, i)) continue;
+    insert_entry(t, keys[i], static_cast<uint32_t>(base_tid + i));
+    ++inserted;
+  }
+  inserted = wave_reduce_add(inserted);
+  if (lane_id() == 0 && inserted != 0) atomicAdd(entries, inserted);
+}
+
+// Re-insert every entry of an old table into a bigger one (resize).
+__global__ __launch_bounds__(kJBlock) void rehash_kernel(int is_long, TableView src, TableView dst) {
+  const int64_t cap = static_cast<int64_t>(src.mask) + 1;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < cap;
+       i += static_cast<int64_t>(gridDim.x) * kJBlock) {
+    if (is_long) {
+      const LongEntry e = static_cast<const LongEntry *>(src.slots)[i];
+      if (e.tid != kEmptyTid) insert_entry(dst, e.key, e.tid);
+    } else {
+      const uint64_t e = static_cast<const uint64_t *>(src.slots)[i];
+      if (e != kEmpty64) {
+        insert_entry(dst, static_cast<int32_t>(static_cast<uint32_t>(e)), static_cast<uint32_t>(e >> 32));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4 probe.  MODE 0: emit pairs, 1: count only, 2: existence bitmap.
+// ---------------------------------------------------------------------------
+constexpr int kRowsPerThread = 16;
+constexpr int kProbeTile = kJBlock * kRowsPerThread;  // 4096 rows per workgroup tile
+constexpr int kStage = kProbeTile;                    // staged pairs per tile (FK joins never exceed it)
+
+// What one 16-byte probe unit holds for a given key.
+struct UnitHits {
+  bool m0, m1;   // entry 0 / 1 matches
+  bool end;      // an empty slot was seen: the probe sequence stops here
+  int32_t t0, t1;
+};
+
+struct IntUnits {
+  using Key = int32_t;
+  using Raw = ulonglong2;
+  const ulonglong2 *units;
+  uint64_t unit_mask;
+  __device__ IntUnits(const TableView &t) : units(static_cast<const ulonglong2 *>(t.slots)), unit_mask(t.mask >> 1) {}
+  __device__ __forceinline__ uint64_t first_unit(Key k, const TableView &t) const { return slot_of(k, t) >> 1; }
+  __device__ __forceinline__ Raw load(uint64_t u) const { return units[u]; }
+  __device__ __forceinline__ UnitHits inspect(const Raw &u, Key k) const {
+    UnitHits h;
+    const bool e0 = u.x == kEmpty64;
+    const bool e1 = u.y == kEmpty64;
+    h.m0 = !e0 && static_cast<uint32_t>(u.x) == static_cast<uint32_t>(k);
+    // entry 1 is only part of this key's probe sequence if entry 0 is occupied
+    h.m1 = !e0 && !e1 && static_cast<uint32_t>(u.y) == static_cast<uint32_t>(k);
+    h.end = e0 || e1;
+    h.t0 = static_cast<int32_t>(u.x >> 32);
+    h.t1 = static_cast<int32_t>(u.y >> 32);
+    return h;
+  }
+};
+
+struct LongUnits {
+  using Key = int64_t;
+  using Raw = LongEntry;
+  const LongEntry *units;
+  uint64_t unit_mask;
+  __device__ LongUnits(const TableView &t) : units(static_cast<const LongEntry *>(t.slots)), unit_mask(t.mask) {}
+  __device__ __forceinline__ uint64_t first_unit(Key k, const TableView &t) const { return slot_of(k, t); }
+  __device__ __forceinline__ Raw load(uint64_t u) const { return units[u]; }
+  __device__ __forceinline__ UnitHits inspect(const Raw &u, Key k) const {
+    UnitHits h;
+    h.end = u.tid == kEmptyTid;
+    h.m0 = !h.end && u.key == k;
+    h.m1 = false;
+    h.t0 = static_cast<int32_t>(u.tid);
+    h.t1 = 0;
+    return h;
+  }
+};
+
+struct PairSink {
+  int32_t *stage_probe;  // LDS
+  int32_t *stage_build;  // LDS
+  int *stage_fill;       // LDS
+  int32_t *out_probe;    // global
+  int32_t *out_build;    // global
+  unsigned long long capacity;
+  unsigned long long *out_count;
+};
+
+// Append one match per matching lane of the wave: ballot, one LDS atomic for
+// the whole wave, mbcnt rank.  Pairs that do not fit the LDS stage (tiles with
+// many duplicate matches) take the slow path: a wave-aggregated reservation
+// straight on the global counter.
+__device__ __forceinline__ void emit_match(const PairSink &sink, bool match, int32_t probe_tid,
+                                           int32_t build_tid) {
+  const uint64_t m = __ballot(match);
+  if (m == 0) return;  // wave-uniform
+  const int leader = __ffsll(static_cast<long long>(m)) - 1;
+  int base = 0;
+  if (lane_id() == leader) base = atomicAdd(sink.stage_fill, __popcll(m));
+  base = __shfl(base, leader, kWave);
+  const int pos = base + rank_below(m);
+  const bool over = match && pos >= kStage;
+  if (match && !over) {
+    sink.stage_probe[pos] = probe_tid;
+    sink.stage_build[pos] = build_tid;
+  }
+  const uint64_t mo = __ballot(over);
+  if (mo != 0) {
+    const int leader2 = __ffsll(static_cast<long long>(mo)) - 1;
+    unsigned long long gbase = 0;
+    if (lane_id() == leader2) gbase = atomicAdd(sink.out_count, static_cast<unsigned long long>(__popcll(mo)));
+    gbase = __shfl(gbase, leader2, kWave);
+    if (over) {
+      const unsigned long long o = gbase + rank_below(mo);
+      if (o < sink.capacity) {
+        sink.out_probe[o] = probe_tid;
+        sink.out_build[o] = build_tid;
+      }
+    }
+  }
+}
+
+template <typename Units, int MODE>
+__global__ __launch_bounds__(kJBlock) void probe_kernel(
+    TableView t, const typename Units::Key *__restrict__ keys, int64_t n, int32_t probe_base_tid,
+    const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe,
+    int32_t *__restrict__ out_build, int64_t capacity, unsigned long long *__restrict__ out_count,
+    uint64_t *__restrict__ out_bitmap, int anti) {
+  using Key = typename Units::Key;
+  using Raw = typename Units::Raw;
+  __shared__ int32_t s_probe[MODE == 0 ? kStage : 1];
+  __shared__ int32_t s_build[MODE == 0 ? kStage : 1];
+  __shared__ int s_fill;
+  __shared__ unsigned long long s_base;
+  const Units table(t);
+  PairSink sink{s_probe, s_build, &s_fill, out_probe, out_build,
+                static_cast<unsigned long long>(capacity), out_count};
+  const int64_t num_tiles = (n + kProbeTile - 1) / kProbeTile;
+  unsigned long long local_count = 0;
+
+  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    if (MODE == 0) {
+      if (threadIdx.x == 0) s_fill = 0;
+      __syncthreads();
+    }
+    const int64_t tile_base = tile * kProbeTile;
+    // Row r of this thread: tile_base + r * 256 + tid.  A wave therefore owns
+    // 64 consecutive rows per r: coalesced key loads, and an existence ballot
+    // is exactly one TupleIdSequence word.
+    Key key[kRowsPerThread];
+    bool live[kRowsPerThread];
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const int64_t row = tile_base + r * kJBlock + threadIdx.x;
+      live[r] = row < n && row_in_filter(filter, row);
+      key[r] = row < n ? keys[row] : Key();
+    }
+    // First unit of every row: kRowsPerThread independent 16-byte loads in flight.
+    uint64_t unit[kRowsPerThread];
+    Raw first[kRowsPerThread];
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      unit[r] = table.first_unit(key[r], t);
+      first[r] = table.load(live[r] ? unit[r] : 0);
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const int64_t row = tile_base + r * kJBlock + threadIdx.x;
+      const int32_t probe_tid = static_cast<int32_t>(probe_base_tid + row);
+      bool walking = live[r];
+      Raw u = first[r];
+      uint64_t cur = unit[r];
+      bool found = false;
+      // Every lane of the wave stays in the loop until all are done, so that
+      // emit_match can use wave-wide ballots.
+      while (__any(walking)) {
+        const UnitHits h = table.inspect(u, key[r]);
+        const bool m0 = walking && h.m0;
+        const bool m1 = walking && h.m1;
+        if (MODE == 0) {
+          emit_match(sink, m0, probe_tid, h.t0);
+          emit_match(sink, m1, probe_tid, h.t1);
+        } else if (MODE == 1) {
+          local_count += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
+        } else {
+          found = found || m0 || m1;
+          if (found) walking = false;  // existence: the first hit is enough
+        }
+        if (h.end) walking = false;
+        if (walking) {
+          cur = (cur + 1) & table.unit_mask;
+          u = table.load(cur);
+        }
+      }
+      if (MODE == 2) {
+        const bool bit = live[r] && (found != (anti != 0));
+        const uint64_t word = msb_first(__ballot(bit));
+        if (lane_id() == 0 && row < n) {
+          out_bitmap[row >> 6] = word;
+          local_count += __popcll(word);
+        }
+      }
+    }
+    if (MODE == 0) {
+      __syncthreads();
+      const int produced = s_fill;
+      const int staged = produced < kStage ? produced : kStage;
+      if (threadIdx.x == 0) s_base = atomicAdd(out_count, static_cast<unsigned long long>(staged));
+      __syncthreads();
+      const unsigned long long base = s_base;
+      for (int i = threadIdx.x; i < staged; i += kJBlock) {
+        const unsigned long long o = base + i;
+        if (o < sink.capacity) {
+          out_probe[o] = s_probe[i];
+          out_build[o] = s_build[i];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (MODE != 0) {
+    local_count = wave_reduce_add(local_count);
+    if (lane_id() == 0 && local_count != 0 && out_count != nullptr) atomicAdd(out_count, local_count);
+  }
+}
+
+}  // namespace qsx
+
+using namespace qsx;
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct qsx_join_table {
+  int key_type = QSX_INT;
+  uint64_t capacity = 0;  // entries, power of two
+  void *slots = nullptr;
+  unsigned long long *entries_dev = nullptr;
+  int64_t reserved = 0;   // host-side upper bound of entries (rows handed to build so far)
+  // Builds/probes take it shared, growth takes it exclusive — the role of
+  // HashTable::resize_shared_mutex_ (storage/HashTable.hpp:1215).
+  std::shared_mutex mutex;
+
+  size_t entry_bytes() const { return key_type == QSX_INT ? 8 : 16; }
+  TableView view() const {
+    TableView v;
+    v.slots = slots;
+    v.mask = capacity - 1;
+    int log2 = 0;
+    while ((1ull << log2) < capacity) ++log2;
+    v.shift = 64 - log2;
+    return v;
+  }
+};
+
+static uint64_t capacity_for(int64_t entries) {
+  // kHashTableLoadFactor = 2 slots per entry (storage/StorageConstants.hpp:104),
+  // rounded up to a power of two for mask addressing.
+  const uint64_t want = static_cast<uint64_t>(entries < 512 ? 512 : entries) * 2;
+  return next_pow2(want);
+}
+
+static int allocate_slots(qsx_join_table *t, uint64_t capacity, void **out) {
+  QSX_HIP_TRY(hipMalloc(out, capacity * t->entry_bytes()));
+  QSX_HIP_TRY(hipMemset(*out, 0xFF, capacity * t->entry_bytes()));
+  return QSX_OK;
+}
+
+// Make room for `additional` more rows.  Counterpart of HashTable::resize
+// (storage/HashTable.hpp:1437-1440, SimpleScalarSeparateChainingHashTable.hpp:820-985).
+static int ensure_room(qsx_join_table *t, int64_t additional) {
+  std::unique_lock<std::shared_mutex> lock(t->mutex);
+  if (static_cast<uint64_t>(t->reserved + additional) * 2 <= t->capacity) {
+    t->reserved += additional;
+    return QSX_OK;
+  }
+  QSX_HIP_TRY(hipDeviceSynchronize());  // drain in-flight builds on every stream
+  unsigned long long actual = 0;
+  QSX_HIP_TRY(hipMemcpy(&actual, t->entries_dev, sizeof(actual), hipMemcpyDeviceToHost));
+  // rows filtered out by a bitmap never became entries: tighten the bound
+  t->reserved = static_cast<int64_t>(actual);
+  if (static_cast<uint64_t>(t->reserved + additional) * 2 <= t->capacity) {
+    t->reserved += additional;
+    return QSX_OK;
+  }
+  const uint64_t new_capacity = capacity_for(2 * (t->reserved + additional));
+  void *bigger = nullptr;
+  int rc = allocate_slots(t, new_capacity, &bigger);
+  if (rc != QSX_OK) return rc;
+  TableView src = t->view();
+  void *old_slots = t->slots;
+  t->slots = bigger;
+  t->capacity = new_capacity;
+  TableView dst = t->view();
+  hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(src.mask + 1, kJBlock)), dim3(kJBlock), 0, nullptr,
+                     t->key_type == QSX_LONG ? 1 : 0, src, dst);
+  QSX_CHECK_LAUNCH();
+  QSX_HIP_TRY(hipDeviceSynchronize());
+  QSX_HIP_TRY(hipFree(old_slots));
+  t->reserved += additional;
+  return QSX_OK;
+}
+
+extern "C" {
+
+int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **out) {
+  QSX_REQUIRE_DEVICE();
+  if (out == nullptr || est_entries < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (key_type != QSX_INT && key_type != QSX_LONG) return QSX_ERR_UNSUPPORTED;
+  qsx_join_table *t = new qsx_join_table();
+  t->key_type = key_type;
+  t->capacity = capacity_for(est_entries);
+  int rc = allocate_slots(t, t->capacity, &t->slots);
+  if (rc != QSX_OK) { delete t; return rc; }
+  hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, sizeof(unsigned long long));
+  if (err != hipSuccess) {
+    set_last_error("hipMalloc(entries)", err);
+    (void)hipFree(t->slots);
+    delete t;
+    return QSX_ERR_HIP;
+  }
+  *out = t;
+  return QSX_OK;
+}
+
+int qsx_join_table_destroy(qsx_join_table_t *t) {
+  if (t == nullptr) return QSX_OK;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(t->slots);
+  (void)hipFree(t->entries_dev);
+  delete t;
+  return QSX_OK;
+}
+
+int qsx_join_table_size(qsx_join_table_t *t, int64_t *out_entries, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || out_entries == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  unsigned long long v = 0;
+  QSX_HIP_TRY(hipMemcpyAsync(&v, t->entries_dev, sizeof(v), hipMemcpyDeviceToHost, as_stream(stream)));
+  QSX_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  *out_entries = static_cast<int64_t>(v);
+  return QSX_OK;
+}
+
+int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t base_tid,
+                   const uint64_t *filter_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || n < 0 || base_tid < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (n == 0) return QSX_OK;
+  if (keys_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (static_cast<int64_t>(base_tid) + n > INT32_MAX) return QSX_ERR_INVALID_ARGUMENT;
+  int rc = ensure_room(t, n);
+  if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(t->mutex);
+  const int grid = grid_for(n, kJBlock * 4);
+  if (t->key_type == QSX_INT) {
+    hipLaunchKernelGGL(build_kernel<int32_t>, dim3(grid), dim3(kJBlock), 0, as_stream(stream), t->view(),
+                       static_cast<const int32_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev);
+  } else {
+    hipLaunchKernelGGL(build_kernel<int64_t>, dim3(grid), dim3(kJBlock), 0, as_stream(stream), t->view(),
+                       static_cast<const int64_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev);
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+}  // extern "C"
+
+template <int MODE>
+static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_t probe_base_tid,
+                        const uint64_t *filter, int32_t *out_probe, int32_t *out_build,
+                        int64_t capacity, int64_t *out_count, uint64_t *out_bitmap, int anti,
+                        hipStream_t stream) {
+  if (out_count != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), stream));
+  if (n == 0) return QSX_OK;
+  std::shared_lock<std::shared_mutex> lock(t->mutex);
+  const int64_t num_tiles = (n + kProbeTile - 1) / kProbeTile;
+  // 4 workgroups per CU keep 128 KiB of the 160 KiB LDS busy in pair mode.
+  const int64_t max_grid = MODE == 0 ? 4 * kCUs : 8 * kCUs;
+  const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
+  unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count);
+  if (t->key_type == QSX_INT) {
+    hipLaunchKernelGGL((probe_kernel<IntUnits, MODE>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
+                       static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,
+                       out_build, capacity, count, out_bitmap, anti);
+  } else {
+    hipLaunchKernelGGL((probe_kernel<LongUnits, MODE>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
+                       static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe,
+                       out_build, capacity, count, out_bitmap, anti);
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+extern "C" {
+
+int qsx_join_probe(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t probe_base_tid,
+                   const uint64_t *filter_dev, int32_t *out_probe_tid_dev, int32_t *out_build_tid_dev,
+                   int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || n < 0 || capacity < 0 || out_count_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (keys_dev == nullptr || (capacity > 0 && (out_probe_tid_dev == nullptr || out_build_tid_dev == nullptr)))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (static_cast<int64_t>(probe_base_tid) + n > INT32_MAX) return QSX_ERR_INVALID_ARGUMENT;
+  return launch_probe<0>(t, keys_dev, n, probe_base_tid, filter_dev, out_probe_tid_dev,
+                         out_build_tid_dev, capacity, out_count_dev, nullptr, 0, as_stream(stream));
+}
+
+int qsx_join_probe_count(qsx_join_table_t *t, const void *keys_dev, int64_t n,
+                         const uint64_t *filter_dev, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || n < 0 || out_count_dev == nullptr || (n > 0 && keys_dev == nullptr)) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  return launch_probe<1>(t, keys_dev, n, 0, filter_dev, nullptr, nullptr, 0, out_count_dev, nullptr, 0,
+                         as_stream(stream));
+}
+
+int qsx_join_probe_exists(qsx_join_table_t *t, const void *keys_dev, int64_t n,
+                          const uint64_t *filter_dev, int anti, uint64_t *out_bitmap_dev,
+                          int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || n < 0 || (n > 0 && (keys_dev == nullptr || out_bitmap_dev == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  return launch_probe<2>(t, keys_dev, n, 0, filter_dev, nullptr, nullptr, 0, out_count_dev,
+                         out_bitmap_dev, anti, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// runtime.hip — status strings, device discovery and the memory plumbing of
+// the C ABI (include/qsx.h).  No compute here.
+#include "common.hpp"
+
+#include <mutex>
+
+namespace qsx {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const char *what, hipError_t err) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(err);
+}
+
+static int probe_devices() {
+  int count = 0;
+  hipError_t err = hipGetDeviceCount(&count);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int usable = 0;
+  for (int d = 0; d < count; ++d) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
+    // This library carries gfx950 code objects only.
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+  }
+  return usable;
+}
+
+static int usable_devices() {
+  static std::once_flag once;
+  static int usable = 0;
+  std::call_once(once, []() { usable = probe_devices(); });
+  return usable;
+}
+
+int device_ready() {
+  if (usable_devices() > 0) return QSX_OK;
+  g_last_error = "no gfx950 (MI355X) device is visible to HIP; the execution kernel has no CPU path";
+  return QSX_ERR_NO_DEVICE;
+}
+
+}  // namespace qsx
+
+extern "C" {
+
+const char *qsx_status_string(int status) {
+  switch (status) {
+    case QSX_OK: return "ok";
+    case QSX_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case QSX_ERR_NO_DEVICE: return "no gfx950 device available (no CPU fallback exists)";
+    case QSX_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case QSX_ERR_HIP: return "HIP runtime error (see qsx_last_error)";
+    case QSX_ERR_CAPACITY: return "caller-provided capacity too small";
+    case QSX_ERR_UNSUPPORTED: return "unsupported type / configuration";
+    case QSX_ERR_TOO_MANY_GROUPS: return "aggregation table overflow: more groups than the state can hold";
+    default: return "unknown status";
+  }
+}
+
+int qsx_abi_version(void) { return QSX_ABI_VERSION; }
+
+size_t qsx_abi_sizeof_agg_config(void) { return sizeof(qsx_agg_config_t); }
+
+int qsx_device_count(void) { return qsx::usable_devices(); }
+
+const char *qsx_last_error(void) { return qsx::g_last_error.c_str(); }
+
+int qsx_device_alloc(size_t bytes, void **out_dev) {
+  QSX_REQUIRE_DEVICE();
+  if (out_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  *out_dev = nullptr;
+  if (bytes == 0) return QSX_OK;
+  QSX_HIP_TRY(hipMalloc(out_dev, bytes));
+  return QSX_OK;
+}
+
+int qsx_device_free(void *dev) {
+  if (dev == nullptr) return QSX_OK;
+  QSX_REQUIRE_DEVICE();
+  QSX_HIP_TRY(hipFree(dev));
+  return QSX_OK;
+}
+
+int qsx_copy_to_device(void *dst_dev, const void *src_host, size_t bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (bytes == 0) return QSX_OK;
+  QSX_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, qsx::as_stream(stream)));
+  return QSX_OK;
+}
+
+int qsx_copy_to_host(void *dst_host, const void *src_dev, size_t bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (bytes == 0) return QSX_OK;
+  QSX_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, qsx::as_stream(stream)));
+  QSX_HIP_TRY(hipStreamSynchronize(qsx::as_stream(stream)));
+  return QSX_OK;
+}
+
+int qsx_memset_device(void *dst_dev, int byte, size_t bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (bytes == 0) return QSX_OK;
+  QSX_HIP_TRY(hipMemsetAsync(dst_dev, byte, bytes, qsx::as_stream(stream)));
+  return QSX_OK;
+}
+
+int qsx_stream_synchronize(qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  QSX_HIP_TRY(hipStreamSynchronize(qsx::as_stream(stream)));
+  return QSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,376 @@
+// select.hip — K1 (predicate -> TupleIdSequence bitmap), bitmap algebra,
+// K2 (order-preserving compaction / projection) and K5 (gather by tuple id).
+//
+// Reference loops replaced (paths in the Quickstep tree):
+//   K1  types/operations/comparisons/LiteralComparators-inl.hpp:317-388
+//   K2  storage/StorageBlock.cpp:363-399 ->
+//       storage/BasicColumnStoreTupleStorageSubBlock.cpp:339-425
+//   K5  expressions/scalar/ScalarAttribute.cpp:185-225
+//
+// Layout: a column is a dense stripe of n values in HBM (what
+// BasicColumnStoreTupleStorageSubBlock keeps per attribute).  A wave owns 64
+// consecutive rows per bitmap word: lane l loads row 64*w + l (coalesced
+// 256/512-byte wave loads), the comparison result of the whole word is one
+// v_cmp -> SGPR-pair ballot, and s_brev_b64 turns the LSB-first ballot into the
+// MSB-first word BitVector uses.  No shuffles, no LDS for K1.
+
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace qsx {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// ---------------------------------------------------------------------------
+// K1
+// ---------------------------------------------------------------------------
+template <typename T, int OP>
+__device__ __forceinline__ bool cmp_static(T a, T b) {
+  if (OP == QSX_EQ) return a == b;
+  if (OP == QSX_NE) return a != b;
+  if (OP == QSX_LT) return a < b;
+  if (OP == QSX_LE) return a <= b;
+  if (OP == QSX_GT) return a > b;
+  return a >= b;
+}
+
+// R = bitmap words (64-row groups) a wave keeps in flight per iteration.
+template <typename T, int OP, int R>
+__global__ __launch_bounds__(kBlock) void select_cmp_kernel(
+    const T *__restrict__ col, int64_t n, T lit, const uint64_t *__restrict__ filter,
+    uint64_t *__restrict__ out, unsigned long long *__restrict__ out_count) {
+  const int lane = lane_id();
+  const int64_t num_words = (n + 63) >> 6;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t num_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  unsigned long long count = 0;
+
+  for (int64_t w0 = wave * R; w0 < num_words; w0 += num_waves * R) {
+    T v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ((w0 + r) << 6) + lane;
+      v[r] = row < n ? col[row] : T();
+    }
+    uint64_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ((w0 + r) << 6) + lane;
+      bool pred = row < n && cmp_static<T, OP>(v[r], lit);
+      if (filter != nullptr && w0 + r < num_words) {
+        // short-circuit semantics (:344-356): only rows already selected can match.
+        const uint64_t fw = filter[w0 + r];  // wave-uniform address: one scalar load
+        pred = pred && msb_bit(fw, lane);
+      }
+      const uint64_t word = msb_first(__ballot(pred));
+      count += __popcll(word);
+      if (lane == r) mine = word;
+    }
+    if (lane < R && w0 + lane < num_words) out[w0 + lane] = mine;
+  }
+
+  if (out_count != nullptr) {
+    __shared__ unsigned long long block_count;
+    if (threadIdx.x == 0) block_count = 0;
+    __syncthreads();
+    if (lane == 0 && count != 0) atomicAdd(&block_count, count);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_count != 0) atomicAdd(out_count, block_count);
+  }
+}
+
+template <typename T, int OP>
+static int launch_select_cmp(const void *col, int64_t n, const void *literal, const uint64_t *filter,
+                             uint64_t *out, int64_t *out_count, hipStream_t stream) {
+  constexpr int R = sizeof(T) == 4 ? 8 : 4;
+  T lit;
+  std::memcpy(&lit, literal, sizeof(T));
+  const int64_t num_words = (n + 63) >> 6;
+  const int grid = grid_for(num_words, kWavesPerBlock * R);
+  hipLaunchKernelGGL((select_cmp_kernel<T, OP, R>), dim3(grid), dim3(kBlock), 0, stream,
+                     static_cast<const T *>(col), n, lit, filter, out,
+                     reinterpret_cast<unsigned long long *>(out_count));
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+template <typename T>
+static int dispatch_select_op(int op, const void *col, int64_t n, const void *literal,
+                              const uint64_t *filter, uint64_t *out, int64_t *out_count,
+                              hipStream_t stream) {
+  switch (op) {
+    case QSX_EQ: return launch_select_cmp<T, QSX_EQ>(col, n, literal, filter, out, out_count, stream);
+    case QSX_NE: return launch_select_cmp<T, QSX_NE>(col, n, literal, filter, out, out_count, stream);
+    case QSX_LT: return launch_select_cmp<T, QSX_LT>(col, n, literal, filter, out, out_count, stream);
+    case QSX_LE: return launch_select_cmp<T, QSX_LE>(col, n, literal, filter, out, out_count, stream);
+    case QSX_GT: return launch_select_cmp<T, QSX_GT>(col, n, literal, filter, out, out_count, stream);
+    case QSX_GE: return launch_select_cmp<T, QSX_GE>(col, n, literal, filter, out, out_count, stream);
+    default: return QSX_ERR_INVALID_ARGUMENT;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bitmap algebra
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void bitmap_combine_kernel(
+    int op, const uint64_t *__restrict__ a, const uint64_t *__restrict__ b, int64_t n,
+    uint64_t *__restrict__ out) {
+  const int64_t num_words = (n + 63) >> 6;
+  const int tail = static_cast<int>(n & 63);
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; w < num_words;
+       w += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint64_t x = a[w];
+    uint64_t r;
+    switch (op) {
+      case 0: r = x & b[w]; break;
+      case 1: r = x | b[w]; break;
+      case 2: r = x & ~b[w]; break;
+      default: r = ~x; break;
+    }
+    if (w == num_words - 1 && tail != 0) r &= ~0ull << (64 - tail);  // trailing bits stay zero
+    out[w] = r;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void bitmap_count_kernel(const uint64_t *__restrict__ bitmap,
+                                                              int64_t num_words,
+                                                              unsigned long long *__restrict__ out) {
+  unsigned long long c = 0;
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; w < num_words;
+       w += static_cast<int64_t>(gridDim.x) * kBlock) {
+    c += __popcll(bitmap[w]);
+  }
+  c = wave_reduce_add(c);
+  __shared__ unsigned long long block_count;
+  if (threadIdx.x == 0) block_count = 0;
+  __syncthreads();
+  if (lane_id() == 0 && c != 0) atomicAdd(&block_count, c);
+  __syncthreads();
+  if (threadIdx.x == 0 && block_count != 0) atomicAdd(out, block_count);
+}
+
+// ---------------------------------------------------------------------------
+// K2: order-preserving compaction.  Tile = 64 bitmap words = 4096 rows, one
+// wave per tile.  Pass 1 popcounts tiles, pass 2 scans the tile counts, pass 3
+// writes: within a tile the wave walks the 64 words; for a word, lane l owns
+// row l, its output slot is tile_offset + prefix(word) + popcount(bits before l).
+// ---------------------------------------------------------------------------
+constexpr int kTileWords = 64;
+
+__global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint64_t *__restrict__ bitmap,
+                                                            int64_t num_words, int64_t num_tiles,
+                                                            int32_t *__restrict__ tile_counts) {
+  const int lane = lane_id();
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+       tile < num_tiles; tile += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    const int64_t w = tile * kTileWords + lane;
+    int c = w < num_words ? __popcll(bitmap[w]) : 0;
+    c = wave_reduce_add(c);
+    if (lane == 0) tile_counts[tile] = c;
+  }
+}
+
+struct GatherArgs {
+  int ncols;
+  int width[QSX_MAX_COLUMNS];
+  const void *src[QSX_MAX_COLUMNS];
+  void *dst[QSX_MAX_COLUMNS];
+};
+
+__device__ __forceinline__ void copy_value(const void *src, int64_t si, void *dst, int64_t di, int width) {
+  switch (width) {
+    case 1: static_cast<uint8_t *>(dst)[di] = static_cast<const uint8_t *>(src)[si]; break;
+    case 2: static_cast<uint16_t *>(dst)[di] = static_cast<const uint16_t *>(src)[si]; break;
+    case 4: static_cast<uint32_t *>(dst)[di] = static_cast<const uint32_t *>(src)[si]; break;
+    default: static_cast<uint64_t *>(dst)[di] = static_cast<const uint64_t *>(src)[si]; break;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void compact_gather_kernel(
+    GatherArgs args, const uint64_t *__restrict__ bitmap, int64_t num_words, int64_t num_tiles,
+    const int64_t *__restrict__ tile_offsets, int32_t *__restrict__ out_tids, int32_t base_tid) {
+  __shared__ uint64_t s_words[kWavesPerBlock][kTileWords];
+  __shared__ int32_t s_prefix[kWavesPerBlock][kTileWords];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; tile < num_tiles;
+       tile += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    const int64_t w = tile * kTileWords + lane;
+    const uint64_t my_word = w < num_words ? bitmap[w] : 0;
+    const int pc = __popcll(my_word);
+    int incl = pc;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int up = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += up;
+    }
+    s_words[wave][lane] = my_word;
+    s_prefix[wave][lane] = incl - pc;
+    // Same-wave LDS hand-off: DS ops of one wave complete in order.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t tile_off = tile_offsets[tile];
+    for (int k = 0; k < kTileWords; ++k) {
+      const uint64_t word = s_words[wave][k];  // broadcast read
+      if (word == 0) continue;                 // wave-uniform
+      if (msb_bit(word, lane)) {
+        const int before = lane == 0 ? 0 : __popcll(word >> (64 - lane));
+        const int64_t di = tile_off + s_prefix[wave][k] + before;
+        const int64_t si = ((tile * kTileWords + k) << 6) + lane;
+        if (out_tids != nullptr) out_tids[di] = static_cast<int32_t>(base_tid + si);
+        for (int c = 0; c < args.ncols; ++c) copy_value(args.src[c], si, args.dst[c], di, args.width[c]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K5: gather by tuple id
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ src,
+                                                        const int32_t *__restrict__ tids, int64_t n,
+                                                        T *__restrict__ dst) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int32_t t = tids[i];
+    dst[i] = t < 0 ? T() : src[t];
+  }
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int run_compaction(const GatherArgs &args, const uint64_t *bitmap, int64_t n,
+                          int32_t *out_tids, int32_t base_tid, int64_t *out_count, void *workspace,
+                          size_t workspace_bytes, hipStream_t stream) {
+  const int64_t num_words = (n + 63) >> 6;
+  const int64_t num_tiles = (num_words + kTileWords - 1) / kTileWords;
+  if (workspace_bytes < qsx_compact_workspace_bytes(n)) return QSX_ERR_CAPACITY;
+  if (n == 0) {
+    if (out_count != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), stream));
+    return QSX_OK;
+  }
+  int64_t *tile_offsets = static_cast<int64_t *>(workspace);
+  int32_t *tile_counts = reinterpret_cast<int32_t *>(
+      static_cast<char *>(workspace) + align_up(sizeof(int64_t) * (num_tiles + 1), 256));
+  hipLaunchKernelGGL(tile_count_kernel, dim3(grid_for(num_tiles, kWavesPerBlock)), dim3(kBlock), 0,
+                     stream, bitmap, num_words, num_tiles, tile_counts);
+  QSX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, num_tiles,
+                     tile_offsets, out_count);
+  QSX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(compact_gather_kernel, dim3(grid_for(num_tiles, kWavesPerBlock)), dim3(kBlock),
+                     0, stream, args, bitmap, num_words, num_tiles, tile_offsets, out_tids, base_tid);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+}  // namespace qsx
+
+using namespace qsx;
+
+extern "C" {
+
+int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op, const void *literal,
+                   const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev,
+                   qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || literal == nullptr || (n > 0 && (col_dev == nullptr || out_bitmap_dev == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return QSX_OK;
+  switch (type) {
+    case QSX_INT: return dispatch_select_op<int32_t>(op, col_dev, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_LONG: return dispatch_select_op<int64_t>(op, col_dev, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_FLOAT: return dispatch_select_op<float>(op, col_dev, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_DOUBLE: return dispatch_select_op<double>(op, col_dev, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+}
+
+int qsx_bitmap_combine(int op, const uint64_t *a_dev, const uint64_t *b_dev, int64_t n,
+                       uint64_t *out_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || op < 0 || op > 3) return QSX_ERR_INVALID_ARGUMENT;
+  if (n == 0) return QSX_OK;
+  if (a_dev == nullptr || out_dev == nullptr || (op != 3 && b_dev == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+  const int64_t num_words = (n + 63) >> 6;
+  hipLaunchKernelGGL(bitmap_combine_kernel, dim3(grid_for(num_words, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), op, a_dev, b_dev, n, out_dev);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_bitmap_count(const uint64_t *bitmap_dev, int64_t n, int64_t *out_count_dev,
+                     qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || out_count_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  hipStream_t s = as_stream(stream);
+  QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return QSX_OK;
+  const int64_t num_words = (n + 63) >> 6;
+  hipLaunchKernelGGL(bitmap_count_kernel, dim3(grid_for(num_words, kBlock * 4)), dim3(kBlock), 0, s,
+                     bitmap_dev, num_words, reinterpret_cast<unsigned long long *>(out_count_dev));
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+size_t qsx_compact_workspace_bytes(int64_t n) {
+  const int64_t num_words = (n + 63) >> 6;
+  const int64_t num_tiles = (num_words + kTileWords - 1) / kTileWords;
+  return align_up(sizeof(int64_t) * (num_tiles + 1), 256) + align_up(sizeof(int32_t) * (num_tiles + 1), 256);
+}
+
+int qsx_compact_gather(int ncols, const void *const *cols, const int32_t *widths,
+                       const uint64_t *bitmap_dev, int64_t n, void *const *out_cols,
+                       int64_t *out_count_dev, void *workspace_dev, size_t workspace_bytes,
+                       qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || ncols < 0 || ncols > QSX_MAX_COLUMNS) return QSX_ERR_INVALID_ARGUMENT;
+  GatherArgs args;
+  args.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) {
+    const int w = widths[c];
+    if (w != 1 && w != 2 && w != 4 && w != 8) return QSX_ERR_UNSUPPORTED;
+    args.width[c] = w;
+    args.src[c] = cols[c];
+    args.dst[c] = out_cols[c];
+  }
+  return run_compaction(args, bitmap_dev, n, nullptr, 0, out_count_dev, workspace_dev,
+                        workspace_bytes, as_stream(stream));
+}
+
+int qsx_bitmap_to_tids(const uint64_t *bitmap_dev, int64_t n, int32_t base_tid,
+                       int32_t *out_tids_dev, int64_t *out_count_dev, void *workspace_dev,
+                       size_t workspace_bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || (n > 0 && out_tids_dev == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+  GatherArgs args;
+  args.ncols = 0;
+  return run_compaction(args, bitmap_dev, n, out_tids_dev, base_tid, out_count_dev, workspace_dev,
+                        workspace_bytes, as_stream(stream));
+}
+
+int qsx_gather(int width, const void *src_dev, const int32_t *tids_dev, int64_t n, void *dst_dev,
+               qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (n == 0) return QSX_OK;
+  const int grid = grid_for(n, kBlock * 4);
+  hipStream_t s = as_stream(stream);
+  switch (width) {
+    case 1: hipLaunchKernelGGL(gather_kernel<uint8_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint8_t *>(src_dev), tids_dev, n, static_cast<uint8_t *>(dst_dev)); break;
+    case 2: hipLaunchKernelGGL(gather_kernel<uint16_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint16_t *>(src_dev), tids_dev, n, static_cast<uint16_t *>(dst_dev)); break;
+    case 4: hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint32_t *>(src_dev), tids_dev, n, static_cast<uint32_t *>(dst_dev)); break;
+    case 8: hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint64_t *>(src_dev), tids_dev, n, static_cast<uint64_t *>(dst_dev)); break;
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+}  // extern "C"

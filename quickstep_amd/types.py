@@ -1,0 +1,141 @@
+"""ctypes mirror of the descriptor structs and enums of include/qsx.h.
+
+Shared by the product binding (quickstep_amd.capi) and by the test-only
+oracle binding (oracle/pyoracle.py) so that a test hands the *same* descriptor
+bytes to both sides.  Pure data definitions: no library is loaded here.
+"""
+import ctypes as C
+
+# qsx_type_t (numbering of types/TypeID.hpp:32-43 in the reference)
+INT, LONG, FLOAT, DOUBLE, CHAR = 0, 1, 2, 3, 4
+# qsx_cmp_t (types/operations/comparisons/ComparisonID.hpp:36-42)
+EQ, NE, LT, LE, GT, GE = range(6)
+# qsx_agg_strategy_t
+AGG_SINGLE_STATE, AGG_COMPACT_KEY, AGG_COLLISION_FREE, AGG_GENERIC = range(4)
+# qsx_agg_fn_t
+AGG_COUNT_STAR, AGG_SUM, AGG_AVG = range(3)
+# qsx_operand_kind_t
+OPD_COLUMN, OPD_CONST, OPD_TEMP = range(3)
+# qsx_expr_op_t
+EX_ADD, EX_SUB, EX_MUL, EX_DIV = range(4)
+# qsx_lip_kind_t
+LIP_SINGLE_IDENTITY_HASH, LIP_BITVECTOR_EXACT = range(2)
+
+MAX_COLUMNS, MAX_KEYS, MAX_AGGS, MAX_INSTRS, MAX_TEMPS, MAX_CONSTS, MAX_PRED_TERMS = 16, 4, 8, 16, 8, 8, 4
+
+TYPE_WIDTH = {INT: 4, LONG: 8, FLOAT: 4, DOUBLE: 8}
+
+# status codes
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_HIP = -1, -2, -3, -4
+ERR_CAPACITY, ERR_UNSUPPORTED, ERR_TOO_MANY_GROUPS = -5, -6, -7
+
+
+class Operand(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("index", C.c_int32)]
+
+
+class ExprInstr(C.Structure):
+    _fields_ = [("op", C.c_int32), ("dst", C.c_int32), ("a", Operand), ("b", Operand)]
+
+
+class AggDesc(C.Structure):
+    _fields_ = [("fn", C.c_int32), ("arg", Operand)]
+
+
+class PredLiteral(C.Union):
+    _fields_ = [("i32", C.c_int32), ("i64", C.c_int64), ("f32", C.c_float), ("f64", C.c_double)]
+
+
+class PredTerm(C.Structure):
+    _fields_ = [("column", C.c_int32), ("op", C.c_int32), ("literal", PredLiteral)]
+
+
+class AggConfig(C.Structure):
+    _fields_ = [
+        ("strategy", C.c_int32),
+        ("num_columns", C.c_int32),
+        ("column_type", C.c_int32 * MAX_COLUMNS),
+        ("column_width", C.c_int32 * MAX_COLUMNS),
+        ("num_keys", C.c_int32),
+        ("key_column", C.c_int32 * MAX_KEYS),
+        ("num_instrs", C.c_int32),
+        ("instrs", ExprInstr * MAX_INSTRS),
+        ("consts", C.c_double * MAX_CONSTS),
+        ("num_aggs", C.c_int32),
+        ("aggs", AggDesc * MAX_AGGS),
+        ("num_pred_terms", C.c_int32),
+        ("pred", PredTerm * MAX_PRED_TERMS),
+        ("est_groups", C.c_int64),
+        ("num_entries", C.c_int64),
+    ]
+
+
+def col(i):
+    return Operand(OPD_COLUMN, i)
+
+
+def const(i):
+    return Operand(OPD_CONST, i)
+
+
+def temp(i):
+    return Operand(OPD_TEMP, i)
+
+
+def make_agg_config(strategy, columns, keys=(), instrs=(), consts=(), aggs=(), pred=(),
+                    est_groups=0, num_entries=0):
+    """Build an AggConfig.
+
+    columns: list of (type, width) — width may be None for numeric types
+    keys:    list of column indices (GROUP BY order)
+    instrs:  list of (op, dst, Operand a, Operand b)
+    aggs:    list of (fn, Operand-or-None)
+    pred:    list of (column, cmp, literal)
+    """
+    cfg = AggConfig()
+    cfg.strategy = strategy
+    cfg.num_columns = len(columns)
+    for i, (t, w) in enumerate(columns):
+        cfg.column_type[i] = t
+        cfg.column_width[i] = TYPE_WIDTH[t] if w is None else w
+    cfg.num_keys = len(keys)
+    for i, k in enumerate(keys):
+        cfg.key_column[i] = k
+    cfg.num_instrs = len(instrs)
+    for i, (op, dst, a, b) in enumerate(instrs):
+        cfg.instrs[i] = ExprInstr(op, dst, a, b)
+    for i, v in enumerate(consts):
+        cfg.consts[i] = v
+    cfg.num_aggs = len(aggs)
+    for i, (fn, arg) in enumerate(aggs):
+        cfg.aggs[i] = AggDesc(fn, arg if arg is not None else Operand(OPD_COLUMN, 0))
+    cfg.num_pred_terms = len(pred)
+    for i, (column, op, literal) in enumerate(pred):
+        term = PredTerm()
+        term.column = column
+        term.op = op
+        t = columns[column][0]
+        if t == INT:
+            term.literal.i32 = int(literal)
+        elif t == LONG:
+            term.literal.i64 = int(literal)
+        elif t == FLOAT:
+            term.literal.f32 = float(literal)
+        else:
+            term.literal.f64 = float(literal)
+        cfg.pred[i] = term
+    cfg.est_groups = est_groups
+    cfg.num_entries = num_entries
+    return cfg
+
+
+def agg_output_is_int(cfg, a):
+    """True when aggregate `a` finalizes to int64 (COUNT, SUM over INT/LONG)."""
+    fn = cfg.aggs[a].fn
+    if fn == AGG_COUNT_STAR:
+        return True
+    if fn == AGG_AVG:
+        return False
+    arg = cfg.aggs[a].arg
+    return arg.kind == OPD_COLUMN and cfg.column_type[arg.index] in (INT, LONG)

@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library loads and exports every symbol include/qsx.h declares
+(no compute calls: there is no GPU here), and refuses to compute without one."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "qsx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qsx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    names = declared_functions()
+    assert len(names) >= 40
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/qsx.h but not exported by libqsx.so"
+    # and the Python binding table covers exactly the declared functions
+    assert sorted(capi.EXPORTED) == names
+
+
+def test_abi_version_and_struct_mirror(capi):
+    from quickstep_amd import types as T
+    assert capi.lib.qsx_abi_version() == 1
+    assert capi.lib.qsx_abi_sizeof_agg_config() == ctypes.sizeof(T.AggConfig)
+    assert capi.lib.qsx_status_string(0) == b"ok"
+    assert b"no CPU" in capi.lib.qsx_status_string(T.ERR_NO_DEVICE)
+
+
+def test_no_cpu_fallback_without_a_gpu(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from quickstep_amd import types as T
+    assert capi.device_count() == 0
+    h = ctypes.c_void_p()
+    assert capi.lib.qsx_join_table_create(T.INT, 16, ctypes.byref(h)) == T.ERR_NO_DEVICE
+    buf = np.zeros(4, dtype=np.int32)
+    lit = ctypes.c_int32(1)
+    rc = capi.lib.qsx_select_cmp(T.INT, buf.ctypes.data, 4, T.LT, ctypes.byref(lit), None, buf.ctypes.data, None, None)
+    assert rc == T.ERR_NO_DEVICE
+    cfg = T.make_agg_config(T.AGG_SINGLE_STATE, [(T.INT, None)], aggs=[(T.AGG_COUNT_STAR, None)])
+    assert capi.lib.qsx_agg_state_create(ctypes.byref(cfg), ctypes.byref(h)) == T.ERR_NO_DEVICE
+
+
+def test_product_code_never_touches_the_oracle():
+    """quickstep_amd/ (the product) must not import, include or link oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "quickstep_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"^\s*(import|from)\s+\S*oracle|#include\s*[\"<][^\">]*oracle|qso_|libqsx_oracle|pyoracle\s*\.",
+                             text, flags=re.M):
+                    bad.append(os.path.join(base, f))
+    assert bad == []

@@ -1,0 +1,302 @@
+"""GPU parity: K6/K7/K8 aggregation (+ fused K11 expressions, state predicate,
+K10 finalize, merge/export) through the C ABI against the oracle.
+
+Bar (BASELINE.json north_star): COUNT and SUM over INT/LONG bit-exact; SUM/AVG
+over FLOAT/DOUBLE within 1e-6 relative (summation order differs).  Group rows
+are compared as sorted sets: output order is the bucket order of whichever
+table survived and is unspecified in the reference."""
+import numpy as np
+import pytest
+import torch
+
+from quickstep_amd import types as T
+from helpers import bitmap_dev, to_dev
+
+pytestmark = pytest.mark.gpu
+
+FP_RTOL = 1e-6   # tolerance stated by north_star for FLOAT/DOUBLE SUM/AVG
+
+
+def run_hip(capi, dev, cfg, cols, blocks=1, filter_bitmap=None, partition=0, num_partitions=1, state=None):
+    st = capi.AggState(cfg) if state is None else state
+    n = cols[0].size if cols else 0
+    dcols = [to_dev(c, dev) for c in cols]
+    if blocks == 1:
+        st.update(dcols, n, filter_bitmap=None if filter_bitmap is None else bitmap_dev(filter_bitmap, dev))
+    else:
+        assert filter_bitmap is None
+        edges = np.linspace(0, n, blocks + 1).astype(np.int64)
+        for b in range(blocks):                            # one AggregationWorkOrder per block
+            st.update([c[edges[b]:edges[b + 1]] for c in dcols], int(edges[b + 1] - edges[b]))
+    return st
+
+
+def finalize_np(st, dev, partition=0, num_partitions=1):
+    keys, vals, nulls, groups = st.finalize(dev, partition, num_partitions)
+    g = int(groups.item())
+    return [k.cpu().numpy()[:g] for k in keys], [v.cpu().numpy()[:g] for v in vals], [z.cpu().numpy()[:g] for z in nulls]
+
+
+def assert_same_groups(got, ref):
+    gk, gv, gn = got
+    rk, rv, rn = ref
+    assert (gk[0].size if gk else gv[0].size) == (rk[0].size if rk else rv[0].size)
+    go = np.lexsort([np.asarray(k) for k in gk[::-1]]) if gk else np.arange(gv[0].size)
+    ro = np.lexsort([np.asarray(k) for k in rk[::-1]]) if rk else np.arange(rv[0].size)
+    for a, b in zip(gk, rk):
+        assert np.array_equal(a[go], b[ro])
+    for a, b, na, nb in zip(gv, rv, gn, rn):
+        assert np.array_equal(na[go], nb[ro])
+        if a.dtype == np.int64:
+            assert np.array_equal(a[go], b[ro])            # integer results: bit-exact
+        else:
+            assert np.allclose(a[go], b[ro], rtol=FP_RTOL, atol=0.0)
+
+
+def agg_rows(g):
+    val = np.arange(g["num_tuples"])
+    gid = val % g["group_by_width"]
+    return dict(gb0=(gid % g["group_by_1_size"]).astype(np.int32), gb1=(gid // g["group_by_1_size"]).astype(np.int32),
+                i=val.astype(np.int32), l=val.astype(np.int64), f=(0.1 * val).astype(np.float32), d=0.1 * val)
+
+
+def test_golden_scalar_aggregates(capi, dev, golden):
+    g = golden["agg_unittest"]
+    s = g["scalar"]
+    r = agg_rows(g)
+    cols = [r["i"], r["l"], r["f"], r["d"]]
+    layout = [(T.INT, None), (T.LONG, None), (T.FLOAT, None), (T.DOUBLE, None)]
+    aggs = [(T.AGG_SUM, T.col(0)), (T.AGG_SUM, T.col(1)), (T.AGG_SUM, T.col(3)), (T.AGG_AVG, T.col(0)),
+            (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(2))]
+    for pred, exp_sum, exp_cnt in ((None, s["sum_int_no_predicate"], s["count_no_predicate"]),
+                                   (s["predicate_less_than"], s["sum_int_with_predicate"], s["count_with_predicate"])):
+        cfg = T.make_agg_config(T.AGG_SINGLE_STATE, layout, aggs=aggs, pred=[] if pred is None else [(0, T.LT, pred)])
+        st = run_hip(capi, dev, cfg, cols, blocks=30)
+        _, vals, nulls = finalize_np(st, dev)
+        assert vals[0].tolist() == [exp_sum] and vals[1].tolist() == [exp_sum] and vals[4].tolist() == [exp_cnt]
+        assert vals[2][0] == pytest.approx(0.1 * exp_sum, rel=g["float_rel_tol"])
+        assert vals[5][0] == pytest.approx(0.1 * exp_sum, rel=g["float_rel_tol"])
+        assert vals[3][0] == pytest.approx(exp_sum / exp_cnt, rel=1e-12)
+        assert not any(z[0] for z in nulls)
+    cfg = T.make_agg_config(T.AGG_SINGLE_STATE, layout, aggs=aggs, pred=[(0, T.LT, s["zero_rows_predicate_less_than"])])
+    st = run_hip(capi, dev, cfg, cols)
+    _, vals, nulls = finalize_np(st, dev)
+    assert vals[4].tolist() == [0] and [int(z[0]) for z in nulls] == [1, 1, 1, 1, 0, 1]
+
+
+@pytest.mark.parametrize("strategy", [T.AGG_COMPACT_KEY, T.AGG_GENERIC])
+@pytest.mark.parametrize("with_pred", [False, True])
+def test_golden_group_by(capi, dev, golden, strategy, with_pred):
+    g = golden["agg_unittest"]
+    r = agg_rows(g)
+    e = g["group_by"]["with_predicate" if with_pred else "without_predicate"]
+    cols = [r["gb0"], r["gb1"], r["i"], r["d"], r["f"]]
+    cfg = T.make_agg_config(
+        strategy, [(T.INT, None), (T.INT, None), (T.INT, None), (T.DOUBLE, None), (T.FLOAT, None)], keys=[0, 1],
+        aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.col(3)), (T.AGG_AVG, T.col(2)), (T.AGG_COUNT_STAR, None),
+              (T.AGG_SUM, T.col(4))],
+        pred=[(2, T.LT, g["group_by_predicate_less_than"])] if with_pred else [], est_groups=20)
+    st = run_hip(capi, dev, cfg, cols, blocks=30)
+    keys, vals, _ = finalize_np(st, dev)
+    gid = keys[0] + keys[1] * g["group_by_1_size"]
+    order = np.argsort(gid)
+    assert gid[order].tolist() == list(range(20))
+    assert vals[0][order].tolist() == e["sum_int_per_group"]
+    assert vals[3][order].tolist() == e["count_per_group"]
+    assert np.allclose(vals[1][order], e["sum_float_per_group"], rtol=g["float_rel_tol"])
+    assert np.allclose(vals[4][order], e["sum_float_per_group"], rtol=g["float_rel_tol"])
+    assert np.allclose(vals[2][order], e["avg_int_per_group"], rtol=g["float_rel_tol"])
+
+
+def q1_config(with_date_pred=False, est_groups=6):
+    cols = [(T.CHAR, 1), (T.CHAR, 1), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None)]
+    pred = []
+    if with_date_pred:
+        cols.append((T.LONG, None))                       # stand-in for the 8-byte DateLit l_shipdate
+        pred = [(6, T.LE, 19980902)]
+    return T.make_agg_config(
+        T.AGG_COMPACT_KEY, cols, keys=[0, 1],
+        # t0 = 1 - disc ; t1 = price * t0 ; t2 = 1 + tax ; t3 = t1 * t2   (benchmarks/tpch/queries/01.sql)
+        instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0)),
+                (T.EX_ADD, 2, T.const(0), T.col(5)), (T.EX_MUL, 3, T.temp(1), T.temp(2))],
+        consts=[1.0],
+        aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.col(3)), (T.AGG_SUM, T.temp(1)), (T.AGG_SUM, T.temp(3)),
+              (T.AGG_AVG, T.col(2)), (T.AGG_AVG, T.col(3)), (T.AGG_AVG, T.col(4)), (T.AGG_COUNT_STAR, None)],
+        pred=pred, est_groups=est_groups)
+
+
+def q1_columns(rng, n, with_date=False):
+    combo = rng.choice(4, size=n, p=[0.2466, 0.0065, 0.5005, 0.2464])     # (A,F) (N,F) (N,O) (R,F)
+    k1 = np.frombuffer(b"ANNR", dtype=np.uint8)[combo]
+    k2 = np.frombuffer(b"FFOF", dtype=np.uint8)[combo]
+    cols = [k1, k2, rng.integers(1, 51, size=n).astype(np.float64), np.round(rng.uniform(900, 105000, size=n), 2),
+            rng.integers(0, 11, size=n) / 100.0, rng.integers(0, 9, size=n) / 100.0]
+    if with_date:
+        cols.append(rng.integers(19920101, 19981231, size=n).astype(np.int64))
+    return cols
+
+
+@pytest.mark.parametrize("n", [0, 1, 255, 70_001, 2_000_000])
+@pytest.mark.parametrize("with_date", [False, True])
+def test_q1_shape_matches_oracle(capi, oracle, dev, n, with_date):
+    rng = np.random.default_rng(n + 4)
+    cols = q1_columns(rng, n, with_date)
+    cfg = q1_config(with_date)
+    st = run_hip(capi, dev, cfg, cols, blocks=3 if n > 1000 else 1)
+    o = oracle.AggState(cfg)
+    o.update(cols, n)
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+
+
+@pytest.mark.parametrize("strategy,groups", [(T.AGG_COMPACT_KEY, 7), (T.AGG_COMPACT_KEY, 300), (T.AGG_COMPACT_KEY, 9000),
+                                             (T.AGG_GENERIC, 50_000)])
+def test_many_groups_two_int_keys(capi, oracle, dev, strategy, groups):
+    """BASELINE config 3 minimal variant: two INT32 keys + one DOUBLE value (16 B/row); group
+    counts beyond the register groups, beyond the LDS table and beyond LDS altogether."""
+    rng = np.random.default_rng(groups)
+    n = 400_000
+    side = int(np.ceil(np.sqrt(groups)))
+    k1 = rng.integers(-3, side - 3, size=n).astype(np.int32)            # negative key components too
+    k2 = rng.integers(0, side, size=n).astype(np.int32)
+    v = rng.normal(1000.0, 50.0, size=n)
+    w = rng.integers(-10**9, 10**9, size=n).astype(np.int64)
+    cfg = T.make_agg_config(strategy, [(T.INT, None), (T.INT, None), (T.DOUBLE, None), (T.LONG, None)], keys=[0, 1],
+                            aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None), (T.AGG_AVG, T.col(2)),
+                                  (T.AGG_SUM, T.col(3)), (T.AGG_AVG, T.col(3))], est_groups=groups)
+    filt = oracle.bitmap_from_bools(rng.random(n) < 0.9)
+    st = run_hip(capi, dev, cfg, [k1, k2, v, w], filter_bitmap=filt)
+    o = oracle.AggState(cfg)
+    o.update([k1, k2, v, w], n, filter_bitmap=filt)
+    assert st.num_groups() >= o.num_groups()
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+    if strategy == T.AGG_GENERIC:
+        # partitioned finalize: membership of every partition = reference's HashCompositeKey % P
+        P = 41                                               # --num_aggregation_partitions default
+        seen = 0
+        for p in range(0, P, 10):
+            assert_same_groups(finalize_np(st, dev, p, P), o.finalize(p, P))
+        for p in range(P):
+            seen += finalize_np(st, dev, p, P)[0][0].size
+        assert seen == o.num_groups()
+
+
+def test_sentinel_and_wide_keys(capi, oracle, dev):
+    """8-byte LONG key including -1 (bit pattern of the table's empty marker), INT64 extremes, and a
+    CHAR(2)+CHAR(4)+CHAR(2) = 8-byte compact key."""
+    rng = np.random.default_rng(8)
+    n = 50_000
+    k = rng.choice(np.array([-1, 0, 1, 2**63 - 1, -2**63, 123456789012], dtype=np.int64), size=n)
+    v = rng.integers(0, 100, size=n).astype(np.int32)
+    for strategy in (T.AGG_COMPACT_KEY, T.AGG_GENERIC):
+        cfg = T.make_agg_config(strategy, [(T.LONG, None), (T.INT, None)], keys=[0],
+                                aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None)], est_groups=8)
+        st = run_hip(capi, dev, cfg, [k, v], blocks=4)
+        o = oracle.AggState(cfg)
+        o.update([k, v])
+        assert_same_groups(finalize_np(st, dev), o.finalize())
+    c2 = rng.integers(0, 3, size=n).astype(np.int16)
+    c4 = rng.integers(-2, 2, size=n).astype(np.int32)
+    c2b = rng.integers(0, 2, size=n).astype(np.int16) - 1
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.CHAR, 2), (T.CHAR, 4), (T.CHAR, 2), (T.INT, None)], keys=[0, 1, 2],
+                            aggs=[(T.AGG_SUM, T.col(3)), (T.AGG_COUNT_STAR, None)], est_groups=30)
+    st = run_hip(capi, dev, cfg, [c2, c4, c2b, v])
+    o = oracle.AggState(cfg)
+    o.update([c2, c4, c2b, v])
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+
+
+@pytest.mark.parametrize("num_entries,partitions", [(1, 1), (700, 3), (100_000, 7), (1_000_000, 16)])
+def test_collision_free_vector(capi, oracle, dev, num_entries, partitions):
+    """Q3 group-by path: dense key, SUM(double expr) + COUNT + SUM(int); ascending keys per range partition."""
+    rng = np.random.default_rng(num_entries)
+    n = 500_000
+    key = np.sort(rng.integers(0, num_entries, size=n)).astype(np.int32)      # lineitem is clustered on orderkey
+    price = np.round(rng.uniform(900, 105000, size=n), 2)
+    disc = rng.integers(0, 11, size=n) / 100.0
+    qty = rng.integers(1, 51, size=n).astype(np.int32)
+    for aggs in ([(T.AGG_SUM, T.temp(1)), (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(3))], [(T.AGG_SUM, T.temp(1))]):
+        cfg = T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)],
+                                keys=[0], instrs=[(T.EX_SUB, 0, T.const(0), T.col(2)), (T.EX_MUL, 1, T.col(1), T.temp(0))],
+                                consts=[1.0], aggs=aggs, num_entries=num_entries)
+        st = run_hip(capi, dev, cfg, [key, price, disc, qty], blocks=5)
+        o = oracle.AggState(cfg)
+        o.update([key, price, disc, qty])
+        assert st.num_groups() == o.num_groups()
+        for p in range(partitions):
+            gk, gv, gn = finalize_np(st, dev, p, partitions)
+            rk, rv, rn = o.finalize(p, partitions)
+            assert np.array_equal(gk[0], rk[0])            # same keys in the same (ascending) order
+            for a, b in zip(gv, rv):
+                if a.dtype == np.int64:
+                    assert np.array_equal(a, b)
+                else:
+                    assert np.allclose(a, b, rtol=FP_RTOL, atol=0.0)
+
+
+def test_merge_and_export_import(capi, oracle, dev):
+    """Partial states of two 'GPUs' merged: mergeFrom semantics (ThreadPrivateCompactKeyHashTable.cpp:306-363)."""
+    rng = np.random.default_rng(21)
+    n = 120_000
+    for cfg, cols in (
+        (q1_config(), q1_columns(rng, n)),
+        (T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None), (T.LONG, None)], keys=[0],
+                           aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None)], num_entries=5000),
+         [rng.integers(0, 5000, size=n).astype(np.int32), rng.integers(-5, 5, size=n).astype(np.int64)]),
+        (T.make_agg_config(T.AGG_SINGLE_STATE, [(T.DOUBLE, None)], aggs=[(T.AGG_AVG, T.col(0)), (T.AGG_COUNT_STAR, None)]),
+         [rng.normal(size=n)]),
+    ):
+        half = n // 2
+        a = run_hip(capi, dev, cfg, [c[:half] for c in cols])
+        b = run_hip(capi, dev, cfg, [c[half:] for c in cols])
+        image = b.export(dev)
+        assert image.numel() * 8 == b.export_bytes()
+        c = capi.AggState(cfg)
+        c.merge(a)
+        c.import_merge(image)
+        o = oracle.AggState(cfg)
+        o.update(cols)
+        assert_same_groups(finalize_np(c, dev), o.finalize())
+
+
+def test_too_many_groups_is_reported_not_silently_dropped(capi, dev):
+    rng = np.random.default_rng(0)
+    k = rng.permutation(200_000).astype(np.int32)
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.INT, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None)], est_groups=4)
+    st = run_hip(capi, dev, cfg, [k])
+    with pytest.raises(capi.QsxError) as e:
+        st.num_groups()
+    assert e.value.status == T.ERR_TOO_MANY_GROUPS
+    cfg = T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None)], num_entries=10)
+    st = run_hip(capi, dev, cfg, [k])                       # keys outside [0, num_entries): precondition violated
+    with pytest.raises(capi.QsxError):
+        st.finalize(dev, capacity=16)
+
+
+def test_q1_at_scale_properties(capi, dev):
+    """C3 shape at 60 M rows (the full 600 M runs in bench.py): COUNT per group equals a bincount,
+    SUM(qty) is an integer-valued double and therefore exact, SUM(price*(1-disc)) within 1e-6 of a
+    torch float64 reduction over the same device data."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    n = 60_000_000
+    combo = torch.multinomial(torch.tensor([0.2466, 0.0065, 0.5005, 0.2464], device=dev), n, replacement=True, generator=g)
+    k1 = torch.tensor(list(b"ANNR"), dtype=torch.uint8, device=dev)[combo]
+    k2 = torch.tensor(list(b"FFOF"), dtype=torch.uint8, device=dev)[combo]
+    qty = torch.randint(1, 51, (n,), device=dev, generator=g).double()
+    price = (torch.rand(n, device=dev, generator=g, dtype=torch.float64) * 104100 + 900).mul(100).round().div(100)
+    disc = torch.randint(0, 11, (n,), device=dev, generator=g).double() / 100
+    tax = torch.randint(0, 9, (n,), device=dev, generator=g).double() / 100
+    st = capi.AggState(q1_config())
+    st.update([k1, k2, qty, price, disc, tax], n)
+    keys, vals, nulls, groups = st.finalize(dev)
+    gcount = int(groups.item())
+    assert gcount == 4
+    counts = torch.bincount(combo, minlength=4)
+    for row in range(gcount):
+        c = [i for i in range(4) if b"ANNR"[i] == int(keys[0][row]) and b"FFOF"[i] == int(keys[1][row])][0]
+        sel = combo == c
+        assert int(vals[7][row]) == int(counts[c])
+        assert float(vals[0][row]) == float(qty[sel].sum())
+        ref = (price[sel] * (1 - disc[sel])).sum().item()
+        assert abs(float(vals[2][row]) - ref) <= FP_RTOL * abs(ref)
+        assert abs(float(vals[6][row]) - disc[sel].mean().item()) <= FP_RTOL

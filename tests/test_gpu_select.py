@@ -1,0 +1,102 @@
+"""GPU parity: K1/K2/K5 through the C ABI against the oracle (bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from quickstep_amd import types as T
+from helpers import bitmap_dev, bitmap_np, to_dev
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [0, 1, 63, 64, 65, 4095, 4096, 4097, 100_003, 1_000_000]
+DTYPES = [np.int32, np.int64, np.float32, np.float64]
+
+
+def make_col(rng, dtype, n):
+    if np.issubdtype(dtype, np.integer):
+        return rng.integers(-50, 50, size=n).astype(dtype)
+    col = rng.integers(-50, 50, size=n).astype(dtype) / 4
+    if n > 10:
+        col[rng.integers(0, n, size=3)] = np.nan     # NaN compares false except !=
+    return col
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", SIZES)
+def test_select_cmp_bitmaps_are_bit_exact(capi, oracle, dev, dtype, n):
+    rng = np.random.default_rng(n + 17)
+    col = make_col(rng, dtype, n)
+    dcol = to_dev(col, dev)
+    for op in (T.EQ, T.NE, T.LT, T.LE, T.GT, T.GE):
+        bm, cnt = capi.select_cmp(dcol, op, 3)
+        ref = oracle.select_cmp(col, op, 3)
+        if n:
+            assert np.array_equal(bitmap_np(bm)[:ref.size], ref), (dtype, n, op)
+        assert int(cnt.item()) == oracle.bitmap_count(ref, n)
+
+
+@pytest.mark.parametrize("n", [1, 64, 1000, 250_001])
+def test_select_cmp_with_filter_and_bitmap_algebra(capi, oracle, dev, n):
+    rng = np.random.default_rng(n)
+    col = rng.integers(0, 1000, size=n).astype(np.int32)
+    dcol = to_dev(col, dev)
+    first, _ = capi.select_cmp(dcol, T.GE, 100)
+    second, cnt = capi.select_cmp(dcol, T.LT, 600, filter_bitmap=first)
+    rfirst = oracle.select_cmp(col, T.GE, 100)
+    rsecond = oracle.select_cmp(col, T.LT, 600, filter_bitmap=rfirst)
+    assert np.array_equal(bitmap_np(second), rsecond)
+    assert int(cnt.item()) == int(((col >= 100) & (col < 600)).sum())
+    other, _ = capi.select_cmp(dcol, T.LT, 300)
+    a, b = oracle.bools_from_bitmap(rfirst, n), col < 300
+    for op, want in ((0, a & b), (1, a | b), (2, a & ~b), (3, ~a)):
+        got = capi.bitmap_combine(op, first, other, n)
+        assert np.array_equal(bitmap_np(got), oracle.bitmap_from_bools(want)), op   # trailing bits stay zero
+        assert int(capi.bitmap_count(got, n).item()) == int(want.sum())
+
+
+def test_golden_bitvector_words(capi, dev, golden):
+    for case in golden["bitvector"]["cases"]:
+        col = np.zeros(case["n"], dtype=np.int32)
+        col[case["set_bits"]] = 1
+        bm, cnt = capi.select_cmp(to_dev(col, dev), T.EQ, 1)
+        assert [f"{w:016x}" for w in bitmap_np(bm)] == case["expected_words_hex"]
+        tids, c = capi.bitmap_to_tids(bm, case["n"])
+        assert tids.cpu().numpy()[:int(c.item())].tolist() == case["set_bits"]
+
+
+@pytest.mark.parametrize("n", [0, 1, 64, 4097, 300_007])
+@pytest.mark.parametrize("selectivity", [0.0, 0.01, 0.5, 1.0])
+def test_compact_gather_is_order_preserving(capi, oracle, dev, n, selectivity):
+    rng = np.random.default_rng(n + int(selectivity * 100))
+    keep = rng.random(n) < selectivity
+    words = oracle.bitmap_from_bools(keep) if n else np.zeros(1, dtype=np.uint64)
+    cols = [rng.integers(0, 255, size=n).astype(np.uint8), rng.integers(-2**15, 2**15, size=n).astype(np.int16),
+            rng.integers(-2**31, 2**31, size=n).astype(np.int32), rng.normal(size=n)]
+    out, cnt = capi.compact_gather([to_dev(c, dev) for c in cols], bitmap_dev(words, dev), n)
+    k = int(cnt.item())
+    assert k == int(keep.sum())
+    for o, c in zip(out, cols):
+        assert np.array_equal(o.cpu().numpy()[:k], oracle.compact_gather(c, words) if n else c[:0])
+    tids, c2 = capi.bitmap_to_tids(bitmap_dev(words, dev), n, base_tid=7)
+    assert np.array_equal(tids.cpu().numpy()[:int(c2.item())], np.nonzero(keep)[0].astype(np.int32) + 7)
+
+
+def test_gather_by_tuple_id(capi, oracle, dev):
+    rng = np.random.default_rng(2)
+    for dtype in (np.uint8, np.int16, np.int32, np.float64):
+        src = rng.integers(0, 100, size=5000).astype(dtype)
+        tids = rng.integers(-1, 5000, size=20_001).astype(np.int32)      # -1 = outer-join NULL padding
+        got = capi.gather(to_dev(src, dev), to_dev(tids, dev))
+        assert np.array_equal(got.cpu().numpy(), oracle.gather(src, tids))
+
+
+def test_select_config_c1_selectivities(capi, oracle, dev):
+    """BASELINE config 1 shape at 2 M rows: col < K for ~1 %, 10 %, 50 % then project col."""
+    rng = np.random.default_rng(1)
+    col = rng.integers(0, 2**31, size=2_000_000).astype(np.int32)
+    dcol = to_dev(col, dev)
+    for k in (21474836, 214748364, 1073741824):
+        bm, cnt = capi.select_cmp(dcol, T.LT, k)
+        (out,), c = capi.compact_gather([dcol], bm, col.size)
+        assert int(c.item()) == int(cnt.item()) == int((col < k).sum())
+        assert np.array_equal(out.cpu().numpy()[:int(c.item())], col[col < k])

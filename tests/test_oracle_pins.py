@@ -1,0 +1,324 @@
+"""CPU: pin the oracle (oracle/qsx_oracle.cpp) against the reference's own
+golden vectors (tests/golden/*.json, see make_golden.py for sources) and
+against oracle/_ref/ref_pin, the one piece of the reference that compiles here."""
+import os
+
+import numpy as np
+import pytest
+
+from quickstep_amd import types as T
+
+
+def test_combine_hashes_matches_reference_header(oracle, golden):
+    for case in golden["hash_partition"]["combine_hashes"]:
+        assert oracle.combine_hashes(case["a"], case["b"]) == int(case["expected_hex"], 16)
+    if not os.path.exists(oracle.REF_PIN):
+        pytest.skip("oracle/_ref/ref_pin not built (reference tree absent)")
+    rng = np.random.default_rng(1)
+    pairs = [(int(a), int(b)) for a, b in rng.integers(0, 2**63, size=(64, 2), dtype=np.int64)]
+    pairs += [(0, 0), (2**64 - 1, 2**64 - 1), (1, 2)]
+    ref = oracle.ref_combine_hashes(pairs)
+    assert ref == [oracle.combine_hashes(a, b) for a, b in pairs]
+
+
+def test_scalar_hash_is_zero_extended_bit_pattern(oracle, golden):
+    qt = {"int": T.INT, "long": T.LONG}
+    for case in golden["hash_partition"]["scalar_hash"]:
+        assert oracle.hash_scalar(qt[case["type"]], case["value"]) == int(case["expected_hex"], 16)
+    assert oracle.hash_scalar(T.DOUBLE, -0.0) == oracle.hash_scalar(T.DOUBLE, 0.0) == 0
+    assert oracle.hash_scalar(T.FLOAT, -0.0) == 0
+
+
+def test_partition_listing_of_partition_test(oracle, golden):
+    g = golden["hash_partition"]["partition_by_hash_4"]
+    parts = [[] for _ in range(4)]
+    for v in g["ids_inserted"]:
+        parts[oracle.partition_id(oracle.hash_scalar(T.INT, v), 4)].append(v)
+    assert parts == g["expected_partitions"]
+    # the scatter restatement gives the same membership, in insertion order
+    keys = np.array(g["ids_inserted"], dtype=np.int32)
+    offs = oracle.partition_offsets(keys, 4)
+    out = oracle.partition_scatter(keys, 4, keys)
+    for p in range(4):
+        assert out[offs[p]:offs[p + 1]].tolist() == g["expected_partitions"][p]
+    # non power of two: h >= P ? h % P : h
+    assert oracle.partition_id(7, 3) == 1 and oracle.partition_id(2, 3) == 2
+
+
+def test_primes(oracle):
+    assert [oracle.next_prime(n) for n in (0, 1, 2, 3, 4, 90, 2000000)] == [2, 2, 2, 3, 5, 97, 2000003]
+    assert [oracle.prev_prime(n) for n in (0, 1, 2, 3, 4, 100)] == [0, 0, 2, 3, 3, 97]
+
+
+def test_bitvector_is_msb_first(oracle, golden):
+    for case in golden["bitvector"]["cases"]:
+        bools = np.zeros(case["n"], dtype=bool)
+        bools[case["set_bits"]] = True
+        col = bools.astype(np.int32)
+        bm = oracle.select_cmp(col, T.EQ, 1)
+        assert [f"{w:016x}" for w in bm] == case["expected_words_hex"]
+        assert oracle.bitmap_count(bm, case["n"]) == len(case["set_bits"])
+        assert oracle.bitmap_to_tids(bm, case["n"]).tolist() == case["set_bits"]
+        assert np.array_equal(oracle.bitmap_from_bools(bools), bm)
+        assert np.array_equal(oracle.bools_from_bitmap(bm, case["n"]), bools)
+
+
+def test_select_filter_short_circuit(oracle):
+    rng = np.random.default_rng(3)
+    col = rng.integers(-100, 100, size=1000).astype(np.int64)
+    first = oracle.select_cmp(col, T.GT, -20)
+    both = oracle.select_cmp(col, T.LT, 30, filter_bitmap=first)
+    want = (col > -20) & (col < 30)
+    assert np.array_equal(oracle.bools_from_bitmap(both, col.size), want)
+    assert np.array_equal(oracle.compact_gather(col, both), col[want])
+
+
+def test_join_table_sizing_follows_reference_formula(oracle):
+    # storage/SimpleScalarSeparateChainingHashTable.hpp:283-397
+    info = oracle.JoinTable(T.INT, 1_000_000).info()
+    assert info["blob_bytes"] == 23 * 2 * 1024 * 1024          # ceil((128 + 24*2000003) / 2 MiB) slots
+    avail = info["blob_bytes"] - 128
+    buckets = avail // 48
+    assert info["num_slots"] == oracle.prev_prime(buckets * 2)
+    assert info["num_buckets"] == info["num_slots"] // 2
+    small = oracle.JoinTable(T.LONG, 10).info()
+    assert small["blob_bytes"] == 2 * 1024 * 1024 and small["num_slots"] == oracle.prev_prime(2 * ((2 * 1024 * 1024 - 128) // 48))
+
+
+def _join_unittest_tables(g):
+    dim_tid = np.arange(g["num_dim_tuples"])
+    fact_tid = np.arange(g["num_fact_tuples"])
+    return dim_tid, fact_tid
+
+
+def test_join_unittest_long_key(oracle, golden):
+    g = golden["join_unittest"]
+    dim_tid, fact_tid = _join_unittest_tables(g)
+    table = oracle.JoinTable(T.LONG, g["num_dim_tuples"])
+    bs = g["block_size"]
+    for b in range(0, g["num_dim_tuples"], bs):       # one BuildHashWorkOrder per 10-row block
+        table.build(dim_tid[b:b + bs].astype(np.int64), block_id=b // bs, base_tid=b)
+    counts = np.zeros(g["num_dim_tuples"], dtype=np.int64)
+    total = 0
+    for b in range(0, g["num_fact_tuples"], bs):      # one HashInnerJoinWorkOrder per probe block
+        p, d = table.probe(fact_tid[b:b + bs].astype(np.int64), probe_base_tid=b)
+        total += p.size
+        np.add.at(counts, dim_tid[d], 1)              # projected dim.long == dim tid
+        assert np.array_equal(dim_tid[d], fact_tid[p])
+    assert total == g["long_key"]["expected_num_results"]
+    assert (counts == g["long_key"]["expected_count_per_dim_long"]).all()
+
+
+def test_join_unittest_int_duplicate_key(oracle, golden):
+    g = golden["join_unittest"]
+    dim_tid, fact_tid = _join_unittest_tables(g)
+    bs = g["block_size"]
+    dim_int = (dim_tid % bs).astype(np.int32)
+    fact_int = fact_tid.astype(np.int32)
+    table = oracle.JoinTable(T.INT, g["num_dim_tuples"])
+    for b in range(0, g["num_dim_tuples"], bs):
+        table.build(dim_int[b:b + bs], block_id=b // bs, base_tid=b)
+    p, d, blocks = table.probe(fact_int, with_blocks=True)
+    e = g["int_duplicate_key"]
+    assert p.size == e["expected_num_results"]
+    assert (np.bincount(d, minlength=g["num_dim_tuples"]) == e["expected_count_per_dim_row"]).all()
+    fact_counts = np.bincount(p, minlength=g["num_fact_tuples"])
+    assert (fact_counts[:bs] == e["expected_fact_count_first_rows"]).all()
+    assert (fact_counts[bs:] == e["expected_fact_count_other_rows"]).all()
+    assert np.array_equal(blocks, (d // bs).astype(np.uint64))   # TupleReference.block of each match
+    # chain order = insertion order (tail append, SimpleScalarSeparateChainingHashTable.hpp:1062-1113)
+    assert np.array_equal(d[p == 3], np.arange(3, 200, 10))
+
+
+def test_join_table_resize_keeps_all_entries(oracle):
+    table = oracle.JoinTable(T.INT, 4)                     # tiny estimate: forces resize() under load
+    rng = np.random.default_rng(11)
+    keys = rng.integers(0, 50_000, size=200_000).astype(np.int32)
+    for b in range(0, keys.size, 50_000):
+        table.build(keys[b:b + 50_000], block_id=b // 50_000, base_tid=b)
+    assert table.info()["buckets_allocated"] == keys.size
+    probe = np.arange(0, 50_000, 7, dtype=np.int32)
+    p, d = table.probe(probe)
+    assert p.size == sum(np.count_nonzero(keys == k) for k in probe[:50]) + \
+        np.isin(keys, probe[50:]).sum()
+    assert np.array_equal(keys[d], probe[p])
+
+
+def _agg_rows(g):
+    val = np.arange(g["num_tuples"])
+    gid = val % g["group_by_width"]
+    return dict(gb0=(gid % g["group_by_1_size"]).astype(np.int32), gb1=(gid // g["group_by_1_size"]).astype(np.int32),
+                i=val.astype(np.int32), l=val.astype(np.int64), f=(0.1 * val).astype(np.float32), d=0.1 * val)
+
+
+def test_agg_unittest_scalar(oracle, golden):
+    g = golden["agg_unittest"]
+    rows = _agg_rows(g)
+    s = g["scalar"]
+    cols = [rows["i"], rows["l"], rows["f"], rows["d"]]
+    layout = [(T.INT, None), (T.LONG, None), (T.FLOAT, None), (T.DOUBLE, None)]
+    aggs = [(T.AGG_SUM, T.col(0)), (T.AGG_SUM, T.col(1)), (T.AGG_SUM, T.col(3)), (T.AGG_AVG, T.col(0)),
+            (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(2))]
+    for pred, exp_sum, exp_cnt in ((None, s["sum_int_no_predicate"], s["count_no_predicate"]),
+                                   (s["predicate_less_than"], s["sum_int_with_predicate"], s["count_with_predicate"])):
+        cfg = T.make_agg_config(T.AGG_SINGLE_STATE, layout, aggs=aggs,
+                                pred=[] if pred is None else [(0, T.LT, pred)])
+        st = oracle.AggState(cfg)
+        for b in range(0, g["num_tuples"], 10):          # 10 tuples per block (:107)
+            st.update([c[b:b + 10] for c in cols], 10)
+        _, vals, nulls = st.finalize()
+        assert vals[0][0] == exp_sum and vals[1][0] == exp_sum and vals[4][0] == exp_cnt
+        assert vals[0].dtype == np.int64                  # SUM(INT) is LONG (:593-602)
+        assert vals[2][0] == pytest.approx(0.1 * exp_sum, rel=g["float_rel_tol"])
+        assert vals[5][0] == pytest.approx(0.1 * exp_sum, rel=g["float_rel_tol"])
+        assert vals[3][0] == pytest.approx(exp_sum / exp_cnt, rel=1e-12)
+        assert not any(z[0] for z in nulls)
+    # zero rows: SUM / AVG NULL, COUNT 0, still exactly one row (:1160-1345)
+    cfg = T.make_agg_config(T.AGG_SINGLE_STATE, layout, aggs=aggs, pred=[(0, T.LT, s["zero_rows_predicate_less_than"])])
+    st = oracle.AggState(cfg)
+    st.update(cols)
+    keys, vals, nulls = st.finalize()
+    assert vals[4].tolist() == [0] and [int(z[0]) for z in nulls] == [1, 1, 1, 1, 0, 1]
+
+
+@pytest.mark.parametrize("strategy", [T.AGG_COMPACT_KEY, T.AGG_GENERIC])
+@pytest.mark.parametrize("with_pred", [False, True])
+def test_agg_unittest_group_by(oracle, golden, strategy, with_pred):
+    g = golden["agg_unittest"]
+    rows = _agg_rows(g)
+    e = g["group_by"]["with_predicate" if with_pred else "without_predicate"]
+    cols = [rows["gb0"], rows["gb1"], rows["i"], rows["d"], rows["f"]]
+    cfg = T.make_agg_config(
+        strategy, [(T.INT, None), (T.INT, None), (T.INT, None), (T.DOUBLE, None), (T.FLOAT, None)], keys=[0, 1],
+        aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.col(3)), (T.AGG_AVG, T.col(2)), (T.AGG_COUNT_STAR, None),
+              (T.AGG_SUM, T.col(4))],
+        pred=[(2, T.LT, g["group_by_predicate_less_than"])] if with_pred else [], est_groups=20)
+    st = oracle.AggState(cfg)
+    for b in range(0, g["num_tuples"], 10):
+        st.update([c[b:b + 10] for c in cols], 10)
+    keys, vals, _ = st.finalize()
+    assert keys[0].size == g["group_by_width"]
+    gid = keys[0] + keys[1] * g["group_by_1_size"]       # :517
+    order = np.argsort(gid)
+    assert gid[order].tolist() == list(range(20))
+    assert vals[0][order].tolist() == e["sum_int_per_group"]
+    assert vals[3][order].tolist() == e["count_per_group"]
+    assert np.allclose(vals[1][order], e["sum_float_per_group"], rtol=g["float_rel_tol"])
+    assert np.allclose(vals[4][order], e["sum_float_per_group"], rtol=g["float_rel_tol"])
+    assert np.allclose(vals[2][order], e["avg_int_per_group"], rtol=g["float_rel_tol"])
+
+
+def _test_table(golden):
+    rows = golden["sql_golden"]["test_table"]
+    keep = [r for r in rows if r["int_col"] is not None]
+    return rows, keep
+
+
+def test_sql_golden_select_group_by(oracle, golden):
+    rows, keep = _test_table(golden)
+    sel = golden["sql_golden"]["select"]
+    assert len(rows) == sel["count_star"]
+    # GROUP BY long_col/100 (integer division) over rows with non-NULL int_col contributions:
+    # SUM(int_col) skips NULLs, COUNT(*) counts all rows; HAVING MIN(float_col) > 0 drops the group holding x = 0.
+    g1 = np.array([r["long_col"] // 100 for r in rows], dtype=np.int64)
+    ints = np.array([0 if r["int_col"] is None else r["int_col"] for r in rows], dtype=np.int32)
+    cfg = T.make_agg_config(T.AGG_GENERIC, [(T.LONG, None), (T.INT, None)], keys=[0],
+                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1))], est_groups=8)
+    st = oracle.AggState(cfg)
+    st.update([g1, ints])
+    keys, vals, _ = st.finalize()
+    got = {int(k): (int(c), int(s)) for k, c, s in zip(keys[0], vals[0], vals[1])}
+    for e in sel["group_by_long_div_100"]:
+        assert got[e["g"]] == (e["count"], e["sum_int"])
+    # two keys, HAVING group_col2 > 5
+    g2 = np.array([r["long_col"] // 50 for r in rows], dtype=np.int64)
+    cfg2 = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.INT, None)], keys=[0, 1],
+                             aggs=[(T.AGG_COUNT_STAR, None)], est_groups=16)
+    st2 = oracle.AggState(cfg2)
+    st2.update([g1.astype(np.int32), g2.astype(np.int32)])
+    keys2, vals2, _ = st2.finalize()
+    got2 = sorted((int(c), int(a), int(b)) for a, b, c in zip(keys2[0], keys2[1], vals2[0]) if b > 5)
+    assert got2 == sorted((e["count"], e["g1"], e["g2"]) for e in sel["group_by_two_keys_gt5"])
+    # GROUP BY int_col (non-NULL rows): the distinct listing
+    ic = np.array([r["int_col"] for r in keep], dtype=np.int32)
+    cfg3 = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.INT, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None)], est_groups=32)
+    st3 = oracle.AggState(cfg3)
+    st3.update([ic])
+    keys3, _, _ = st3.finalize()
+    assert sorted(keys3[0].tolist()) == sel["distinct_int_col"]
+
+
+def test_sql_golden_lip(oracle, golden):
+    lip = golden["sql_golden"]["lip"]
+    x = np.arange(0, lip["limit"] + 1, lip["r_step"], dtype=np.int32)     # R.x = R.y
+    z = np.arange(0, lip["limit"] + 1, lip["s_step"], dtype=np.int32)     # S.z
+    # exact filter on [min, max] of S.z (AttachLIPFilters picks BitVectorExactFilter)
+    f = oracle.LipFilter(T.LIP_BITVECTOR_EXACT, int(z.max() - z.min() + 1), int(z.min()))
+    f.build(z)
+    hit = oracle.bools_from_bitmap(f.probe(x), x.size)
+    semi = x[hit]
+    assert semi[semi % 10000 == 0].tolist() == lip["semi_join_mod_10000"]
+    assert int(semi[semi % 5 == 0].sum()) + int(semi[semi % 7 == 0].sum()) == lip["sum_x_union_mod5_mod7"]
+    # same answer through the hash table's existence probe (FilterJoin == semi join)
+    t = oracle.JoinTable(T.INT, z.size)
+    t.build(z)
+    assert np.array_equal(oracle.bools_from_bitmap(t.probe_exists(x), x.size), hit)
+    # the approximate filter may only add false positives
+    g = oracle.LipFilter(T.LIP_SINGLE_IDENTITY_HASH, 1024)
+    g.build(z)
+    approx = oracle.bools_from_bitmap(g.probe(x), x.size)
+    assert (approx | ~hit).all()
+    # the SUM through the aggregation restatement (Long result)
+    both = np.concatenate([semi[semi % 5 == 0], semi[semi % 7 == 0]])
+    cfg = T.make_agg_config(T.AGG_SINGLE_STATE, [(T.INT, None)], aggs=[(T.AGG_SUM, T.col(0))])
+    st = oracle.AggState(cfg)
+    st.update([both])
+    assert st.finalize()[1][0].tolist() == [lip["sum_x_union_mod5_mod7"]]
+
+
+def test_sql_golden_three_way_join(oracle, golden):
+    j = golden["sql_golden"]["join"]
+    a = j["a"]
+    aw = np.array([r["w"] for r in a], dtype=np.int32)
+    ax = np.array([r["x"] for r in a], dtype=np.int64)
+    ay = np.array([r["y"] for r in a])
+    bsel = aw % 2 == 0
+    bw, bx = aw[bsel], ax[bsel] + (aw[bsel] // 2) % 2
+    csel = ax % 3 == 0
+    cx, cy = ax[csel], ay[csel] + (ax[csel] // 3) % 3 - 1
+    # a JOIN b ON a.w = b.w
+    tb = oracle.JoinTable(T.INT, bw.size)
+    tb.build(bw)
+    pa, pb = tb.probe(aw)
+    # JOIN c ON a.x = c.x
+    tc = oracle.JoinTable(T.LONG, cx.size)
+    tc.build(cx)
+    p2, pc = tc.probe(ax[pa])
+    rows = sorted((int(aw[pa][i]), int(bx[pb][i]), float(cy[k])) for i, k in zip(p2, pc))
+    # JOIN d ON a.y = d.y keeps every row (d = all y of a)
+    assert rows == [(e["w"], e["b_x"], e["c_y"]) for e in j["three_way_join_expected"]]
+
+
+def test_collision_free_matches_generic(oracle):
+    rng = np.random.default_rng(5)
+    n = 20000
+    key = rng.integers(0, 700, size=n).astype(np.int32)
+    val = rng.integers(-1000, 1000, size=n).astype(np.int64)
+    dbl = rng.normal(size=n)
+    layout = [(T.INT, None), (T.LONG, None), (T.DOUBLE, None)]
+    aggs = [(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(2))]
+    cf = oracle.AggState(T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], aggs=aggs, num_entries=701))
+    ge = oracle.AggState(T.make_agg_config(T.AGG_GENERIC, layout, keys=[0], aggs=aggs, est_groups=700))
+    for st in (cf, ge):
+        st.update([key, val, dbl])
+    parts = [cf.finalize(p, 3) for p in range(3)]
+    k = np.concatenate([p[0][0] for p in parts])
+    assert np.array_equal(k, np.unique(key))              # ascending key order across range partitions
+    gk, gv, _ = ge.finalize()
+    order = np.argsort(gk[0])
+    for a in range(3):
+        v = np.concatenate([p[1][a] for p in parts])
+        assert np.allclose(v, gv[a][order], rtol=1e-12)
+    # generic partitioned finalize covers every group exactly once
+    pk = np.concatenate([ge.finalize(p, 41)[0][0] for p in range(41)])
+    assert np.array_equal(np.sort(pk), np.unique(key))
