@@ -159,6 +159,10 @@ typedef struct qsx_join_table qsx_join_table_t;
  * HashTable::resize, storage/HashTable.hpp:1437-1440).  Synchronises. */
 int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **out);
 int qsx_join_table_destroy(qsx_join_table_t *table);
+/* Drop every entry, keep the allocation (a new query re-using the table;
+ * counterpart of DestroyHashOperator + re-creation, relational_operators/
+ * DestroyHashOperator.cpp:70-72).  Stream-ordered. */
+int qsx_join_table_clear(qsx_join_table_t *table, qsx_stream_t stream);
 /* Number of entries inserted so far.  Synchronises on `stream`. */
 int qsx_join_table_size(qsx_join_table_t *table, int64_t *out_entries, qsx_stream_t stream);
 
@@ -302,6 +306,10 @@ typedef struct qsx_agg_config {
  * (zeroing; CollisionFreeVectorTable.hpp:136-143).  Synchronises. */
 int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out);
 int qsx_agg_state_destroy(qsx_agg_state_t *state);
+/* Back to the freshly initialised state (InitializeAggregationOperator,
+ * relational_operators/InitializeAggregationOperator.cpp:91), keeping the
+ * allocation.  Stream-ordered. */
+int qsx_agg_state_clear(qsx_agg_state_t *state, qsx_stream_t stream);
 
 /* K6/K7/K8 (+K11 fused).  Accumulate n rows into the state.  Replaces
  * AggregationOperationState::aggregateBlock (storage/AggregationOperationState.cpp:

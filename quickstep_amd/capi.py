@@ -63,6 +63,7 @@ _SIGNATURES = {
     "qsx_gather": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_table_create": (_int, [_int, _i64, _pp]),
     "qsx_join_table_destroy": (_int, [_vp]),
+    "qsx_join_table_clear": (_int, [_vp, _vp]),
     "qsx_join_table_size": (_int, [_vp, C.POINTER(_i64), _vp]),
     "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -70,6 +71,7 @@ _SIGNATURES = {
     "qsx_join_probe_exists": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
     "qsx_agg_state_create": (_int, [C.POINTER(T.AggConfig), _pp]),
     "qsx_agg_state_destroy": (_int, [_vp]),
+    "qsx_agg_state_clear": (_int, [_vp, _vp]),
     "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
     "qsx_agg_merge": (_int, [_vp, _vp, _vp]),
     "qsx_agg_state_export_bytes": (_int, [_vp, C.POINTER(_sz)]),
@@ -222,6 +224,9 @@ class JoinTable:
         except Exception:
             pass
 
+    def clear(self, stream=None):
+        _check(_lib.qsx_join_table_clear(self._h, _stream(stream)), "qsx_join_table_clear")
+
     def size(self, stream=None):
         v = C.c_int64()
         _check(_lib.qsx_join_table_size(self._h, C.byref(v), _stream(stream)), "qsx_join_table_size")
@@ -281,6 +286,9 @@ class AggState:
             self.close()
         except Exception:
             pass
+
+    def clear(self, stream=None):
+        _check(_lib.qsx_agg_state_clear(self._h, _stream(stream)), "qsx_agg_state_clear")
 
     def update(self, cols, n=None, filter_bitmap=None, stream=None):
         if n is None:

@@ -1038,6 +1038,21 @@ int qsx_agg_state_destroy(qsx_agg_state_t *st) {
   return QSX_OK;
 }
 
+int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (st == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  hipStream_t s = as_stream(stream);
+  if (st->dense) {
+    QSX_HIP_TRY(hipMemsetAsync(st->image, 0, st->image_bytes, s));
+  } else {
+    QSX_HIP_TRY(hipMemsetAsync(st->image, 0xFF, sizeof(unsigned long long) * (st->cap + 1), s));
+    QSX_HIP_TRY(hipMemsetAsync(st->image + (st->cap + 1), 0,
+                               sizeof(unsigned long long) * (st->cap + 1) * st->num_cols, s));
+  }
+  QSX_HIP_TRY(hipMemsetAsync(st->control, 0, 4 * sizeof(unsigned long long), s));
+  return QSX_OK;
+}
+
 int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev,
                    qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();

@@ -433,6 +433,16 @@ int qsx_join_table_destroy(qsx_join_table_t *t) {
   return QSX_OK;
 }
 
+int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  std::unique_lock<std::shared_mutex> lock(t->mutex);
+  QSX_HIP_TRY(hipMemsetAsync(t->slots, 0xFF, t->capacity * t->entry_bytes(), as_stream(stream)));
+  QSX_HIP_TRY(hipMemsetAsync(t->entries_dev, 0, sizeof(unsigned long long), as_stream(stream)));
+  t->reserved = 0;
+  return QSX_OK;
+}
+
 int qsx_join_table_size(qsx_join_table_t *t, int64_t *out_entries, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (t == nullptr || out_entries == nullptr) return QSX_ERR_INVALID_ARGUMENT;

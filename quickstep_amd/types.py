@@ -1,8 +1,8 @@
 """ctypes mirror of the descriptor structs and enums of include/qsx.h.
 
-Shared by the product binding (quickstep_amd.capi) and by the test-only
-oracle binding (oracle/pyoracle.py) so that a test hands the *same* descriptor
-bytes to both sides.  Pure data definitions: no library is loaded here.
+Shared by the product binding (quickstep_amd.capi) and by the test-only CPU
+checker's binding so that a test hands the *same* descriptor bytes to both
+sides.  Pure data definitions: no library is loaded here.
 """
 import ctypes as C
 
