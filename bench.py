@@ -1,0 +1,336 @@
+#!/usr/bin/env python3
+"""bench.py — the headline measurement of BASELINE.json:
+"probe+aggregate rows/s at TPC-H SF100 (Q1,Q3); % HBM roofline @1/2/4/8 GPU".
+
+One step = one pass of the hot path over one batch of synthetic, HBM-resident
+input, through the C ABI (quickstep_amd.capi -> libqsx.so):
+
+  C2  hash join, Q3 customer⋈orders shape: clear + build a 1 M-key INT table,
+      probe it with 100 M INT keys (match rate 1.0), emit (probe_tid, build_tid);
+  C3  aggregation, Q1 lineitem shape: 600 M rows, GROUP BY two CHAR(1) keys,
+      SUM(qty), SUM(price), SUM(price*(1-disc)), SUM(price*(1-disc)*(1+tax)),
+      AVG(qty), AVG(price), AVG(disc), COUNT(*), then finalize.
+
+value = (probe rows + aggregated rows) of all ranks / wall time of the step.
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank holds the same per-GPU amount of rows (weak scaling); build and probe rows
+are shuffled on the join key across ranks (K9 scatter + RCCL all-to-all) and
+the partial Q1 states are merged across ranks (all-gather + import-merge).
+
+The line also carries `roofline` for the dominant kernel (the aggregation
+update kernel; algorithmic 34 B/row) with its duration measured
+by HIP events on the launch stream, and `cpu_baseline`: the CPU oracle (a port
+of the reference algorithms, oracle/) timed on this host's cores on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import quickstep_amd.capi as capi  # noqa: E402
+from quickstep_amd import types as T  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+Q1_BYTES_PER_ROW = 34          # 1 + 1 + 4 * 8
+
+
+def q1_config():
+    return T.make_agg_config(
+        T.AGG_COMPACT_KEY,
+        columns=[(T.CHAR, 1), (T.CHAR, 1), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None)],
+        keys=[0, 1],
+        instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0)),
+                (T.EX_ADD, 2, T.const(0), T.col(5)), (T.EX_MUL, 3, T.temp(1), T.temp(2))],
+        consts=[1.0],
+        aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.col(3)), (T.AGG_SUM, T.temp(1)), (T.AGG_SUM, T.temp(3)),
+              (T.AGG_AVG, T.col(2)), (T.AGG_AVG, T.col(3)), (T.AGG_AVG, T.col(4)), (T.AGG_COUNT_STAR, None)],
+        est_groups=6)
+
+
+def gen_q1_columns_gpu(n, dev, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    probs = torch.tensor([0.2466, 0.0065, 0.5005, 0.2464], device=dev)
+    chunk = 50_000_000
+    k1 = torch.empty(n, dtype=torch.uint8, device=dev)
+    k2 = torch.empty(n, dtype=torch.uint8, device=dev)
+    qty = torch.empty(n, dtype=torch.float64, device=dev)
+    price = torch.empty(n, dtype=torch.float64, device=dev)
+    disc = torch.empty(n, dtype=torch.float64, device=dev)
+    tax = torch.empty(n, dtype=torch.float64, device=dev)
+    m1 = torch.tensor(list(b"ANNR"), dtype=torch.uint8, device=dev)
+    m2 = torch.tensor(list(b"FFOF"), dtype=torch.uint8, device=dev)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        combo = torch.multinomial(probs, e - s, replacement=True, generator=g)
+        k1[s:e] = m1[combo]
+        k2[s:e] = m2[combo]
+        qty[s:e] = torch.randint(1, 51, (e - s,), device=dev, generator=g).double()
+        price[s:e] = (torch.rand(e - s, device=dev, generator=g, dtype=torch.float64) * 104100 + 900).mul(100).round().div(100)
+        disc[s:e] = torch.randint(0, 11, (e - s,), device=dev, generator=g).double() / 100
+        tax[s:e] = torch.randint(0, 9, (e - s,), device=dev, generator=g).double() / 100
+        del combo
+    return [k1, k2, qty, price, disc, tax]
+
+
+def gen_q1_columns_cpu(n, seed):
+    rng = np.random.default_rng(seed)
+    combo = rng.choice(4, size=n, p=[0.2466, 0.0065, 0.5005, 0.2464])
+    return [np.frombuffer(b"ANNR", dtype=np.uint8)[combo], np.frombuffer(b"FFOF", dtype=np.uint8)[combo],
+            rng.integers(1, 51, size=n).astype(np.float64), np.round(rng.uniform(900, 105000, size=n), 2),
+            rng.integers(0, 11, size=n) / 100.0, rng.integers(0, 9, size=n) / 100.0]
+
+
+def cpu_baseline(args):
+    """Oracle (port of the reference CPU algorithms) on a bounded sample, all host cores."""
+    from oracle import pyoracle as O
+    threads = os.cpu_count() or 1
+    rng = np.random.default_rng(3)
+    build = rng.permutation(args.build_rows).astype(np.int32)
+    block_join = 1_048_576           # 4 MB blocks of INT keys
+    block_agg = 4 * 1024 * 1024 // Q1_BYTES_PER_ROW
+    # calibrate on a small slice, then size the sample for ~8 s per operator
+    probe_small = rng.integers(0, int(args.build_rows / args.match), size=2_000_000).astype(np.int32)
+    r = O.bench_join(build, probe_small, block_join, threads)
+    rate_p = probe_small.size / max(r["probe_seconds"], 1e-6)
+    n_probe = int(min(args.probe_rows, max(4_000_000, rate_p * args.cpu_seconds)))
+    probe = rng.integers(0, int(args.build_rows / args.match), size=n_probe).astype(np.int32)
+    best = None
+    for _ in range(2):
+        r = O.bench_join(build, probe, block_join, threads)
+        best = r if best is None or r["probe_seconds"] < best["probe_seconds"] else best
+    rate_p = n_probe / best["probe_seconds"]
+    rate_b = args.build_rows / best["build_seconds"]
+    cfg = q1_config()
+    cols_small = gen_q1_columns_cpu(2_000_000, 4)
+    secs, st = O.bench_agg(cfg, cols_small, 2_000_000, block_agg, threads)
+    st.close()
+    rate_a = 2_000_000 / max(secs, 1e-6)
+    n_agg = int(min(args.agg_rows, max(4_000_000, rate_a * args.cpu_seconds), 60_000_000))
+    cols = gen_q1_columns_cpu(n_agg, 4)
+    best_a = None
+    for _ in range(2):
+        secs, st = O.bench_agg(cfg, cols, n_agg, block_agg, threads)
+        st.close()
+        best_a = secs if best_a is None else min(best_a, secs)
+    rate_a = n_agg / best_a
+    mix = (args.probe_rows + args.agg_rows) / (args.probe_rows / rate_p + args.agg_rows / rate_a)
+    return {
+        "value": mix, "unit": "rows/s", "cores": threads, "kind": "port",
+        "sample": f"oracle (CPU restatement of SimpleScalarSeparateChaining probe + ThreadPrivateCompactKey aggregation), "
+                  f"{threads} worker threads, block-at-a-time; join {args.build_rows} x {n_probe} probe rows, "
+                  f"aggregation {n_agg} rows; value = same probe:aggregate row mix as the GPU step",
+        "probe_rows_per_s": rate_p, "build_rows_per_s": rate_b, "aggregate_rows_per_s": rate_a,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--build-rows", type=int, default=1_000_000)
+    ap.add_argument("--probe-rows", type=int, default=100_000_000)
+    ap.add_argument("--agg-rows", type=int, default=600_000_000)
+    ap.add_argument("--match", type=float, default=1.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if capi.device_count() < 1:
+        raise SystemExit("libqsx.so sees no gfx950 device; there is no CPU path to benchmark")
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+        from quickstep_amd import distributed as qd
+
+    # ---- synthetic inputs, resident in HBM before the timed region -----------
+    g = torch.Generator(device=dev)
+    g.manual_seed(2 + rank)
+    key_space = args.build_rows * world
+    build_keys = (torch.randperm(args.build_rows, device=dev, generator=g, dtype=torch.int32) * world + rank
+                  if distributed else torch.randperm(args.build_rows, device=dev, generator=g, dtype=torch.int32))
+    g.manual_seed(3 + rank)
+    probe_keys = torch.randint(0, int(key_space / args.match), (args.probe_rows,), device=dev, generator=g,
+                               dtype=torch.int32)
+    agg_cols = gen_q1_columns_gpu(args.agg_rows, dev, 4 + rank)
+    torch.cuda.synchronize()
+
+    cfg = q1_config()
+    state = capi.AggState(cfg)
+    main_stream = torch.cuda.current_stream()
+    agg_stream = torch.cuda.Stream(device=dev) if distributed else main_stream
+    if distributed:
+        join = qd.PartitionedHashJoin(capi, T.INT, 2 * args.build_rows)
+        capacity = int(args.probe_rows * 1.25)
+    else:
+        table = capi.JoinTable(T.INT, args.build_rows)
+        capacity = args.probe_rows
+        out = (torch.empty(capacity, dtype=torch.int32, device=dev), torch.empty(capacity, dtype=torch.int32, device=dev),
+               torch.zeros(1, dtype=torch.int64, device=dev))
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    phase_ms = {"build": 0.0, "probe": 0.0, "aggregate_update": 0.0, "finalize": 0.0, "shuffle_build": 0.0,
+                "shuffle_probe": 0.0, "merge": 0.0}
+    results = {}
+
+    def step(timed):
+        if distributed:
+            # join on the main stream, aggregation on its own stream: the shuffle is xGMI-bound,
+            # the aggregation HBM-bound, so the two overlap.
+            agg_stream.wait_stream(main_stream)
+            with torch.cuda.stream(agg_stream):
+                a0, a1, a2 = ev(), ev(), ev()
+                a0.record()
+                state.clear()
+                state.update(agg_cols, args.agg_rows)
+                a1.record()
+                qd.merge_agg_state_images(capi, state)
+                fin = state.finalize(dev, capacity=16)
+                a2.record()
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+            nb = join.build(build_keys, rank * args.build_rows)
+            e1.record()
+            probe_tids, build_tids, op, ob, cnt = join.probe(probe_keys, 0, capacity=capacity)
+            e2.record()
+            main_stream.wait_stream(agg_stream)
+            results.update(matches=cnt, groups=fin[3], built=nb)
+            if timed:
+                torch.cuda.synchronize()
+                phase_ms["shuffle_build"] += e0.elapsed_time(e1)
+                phase_ms["shuffle_probe"] += e1.elapsed_time(e2)
+                phase_ms["aggregate_update"] += a0.elapsed_time(a1)
+                phase_ms["merge"] += a1.elapsed_time(a2)
+            return
+        e = [ev() for _ in range(6)]
+        e[0].record()
+        table.clear()
+        table.build(build_keys)
+        e[1].record()
+        _, _, cnt = table.probe(probe_keys, capacity=capacity, out=out)
+        e[2].record()
+        state.clear()
+        e[3].record()
+        state.update(agg_cols, args.agg_rows)
+        e[4].record()
+        fin = state.finalize(dev, capacity=16)
+        e[5].record()
+        results.update(matches=cnt, groups=fin[3], fin=fin)
+        if timed:
+            torch.cuda.synchronize()
+            phase_ms["build"] += e[0].elapsed_time(e[1])
+            phase_ms["probe"] += e[1].elapsed_time(e[2])
+            phase_ms["aggregate_update"] += e[3].elapsed_time(e[4])
+            phase_ms["finalize"] += e[4].elapsed_time(e[5])
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # per-phase durations: a second, instrumented pass (event reads synchronise, so it is kept out of the timed loop)
+    for _ in range(args.steps):
+        step(True)
+    for k in phase_ms:
+        phase_ms[k] /= args.steps
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        m = results["matches"].clone()
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+        matches = int(m.item())
+    else:
+        matches = int(results["matches"].item())
+
+    # ---- sanity: the timed work really produced the right shape of result ----
+    expected_matches = None
+    if args.match == 1.0:
+        expected_matches = args.probe_rows * world
+        assert matches == expected_matches, (matches, expected_matches)
+    assert int(results["groups"].item()) == 4
+
+    rows_per_step = (args.probe_rows + args.agg_rows) * world
+    value = rows_per_step * args.steps / elapsed
+    agg_s = phase_ms["aggregate_update"] / 1e3
+    agg_gbs = Q1_BYTES_PER_ROW * args.agg_rows / agg_s / 1e9
+    line = {
+        "metric": "probe+aggregate rows/s at TPC-H SF100 (Q1,Q3)",
+        "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "i32 keys / f64 sums", "data": "synthetic",
+        "config": {
+            "workload": f"C2 HashJoinOperator {args.build_rows} x {args.probe_rows} INTEGER inner equi-join (match rate "
+                        f"{args.match}) + C3 AggregationOperator Q1 shape over {args.agg_rows} rows, per GPU",
+            "build_rows": args.build_rows * world, "probe_rows": args.probe_rows * world,
+            "aggregate_rows": args.agg_rows * world, "matches": matches,
+            "parallelism": "1 GPU" if world == 1 else f"{world} GPUs, join-key all-to-all shuffle + partial-aggregate all-gather merge",
+        },
+        "roofline": {
+            "kernel": "agg_hash_kernel<5> (qsx_agg_update, Q1 shape)", "bound": "hbm",
+            "achieved": agg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg_gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_row": Q1_BYTES_PER_ROW, "rows_per_launch": args.agg_rows,
+            "avg_launch_ms": phase_ms["aggregate_update"], "traffic": None,
+        },
+        "phases_ms": phase_ms,
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            if tr.get("rows_per_launch") == args.agg_rows:
+                line["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+                line["roofline"]["traffic_source"] = tr.get("source")
+        except Exception:
+            pass
+    if not distributed:
+        probe_s = phase_ms["probe"] / 1e3
+        probe_bytes = 4 * args.probe_rows + 8 * matches
+        line["probe"] = {
+            "rows_per_s": args.probe_rows / probe_s, "ms": phase_ms["probe"],
+            "roofline": {"kernel": "probe_kernel<IntUnits,0> (qsx_join_probe)", "bound": "hbm",
+                         "achieved": probe_bytes / probe_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": probe_bytes / probe_s / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes": "4*N_probe + 8*N_match (hash-table traffic excluded)"},
+        }
+        line["build"] = {"rows_per_s": args.build_rows / (phase_ms["build"] / 1e3), "ms": phase_ms["build"]}
+        line["aggregate"] = {"rows_per_s": args.agg_rows / agg_s, "ms": phase_ms["aggregate_update"],
+                             "finalize_ms": phase_ms["finalize"]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

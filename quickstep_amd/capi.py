@@ -275,6 +275,7 @@ class AggState:
         h = C.c_void_p()
         _check(_lib.qsx_agg_state_create(C.byref(config), C.byref(h)), "qsx_agg_state_create")
         self._h = h
+        self.device = torch.device("cuda", torch.cuda.current_device())
 
     def close(self):
         if self._h is not None:

@@ -82,7 +82,10 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(const KeyT *
   const int lane = lane_id();
   const int64_t w = static_cast<int64_t>(blockIdx.x) * kPWaves + (threadIdx.x >> 6);
   if (w >= W) return;
-  if (w == 0 && lane <= P) out_offsets[lane] = lane < P ? starts[static_cast<int64_t>(lane) * W] : n;
+  if (w == 0) {
+    if (lane < P) out_offsets[lane] = starts[static_cast<int64_t>(lane) * W];
+    if (lane == 0) out_offsets[P] = n;
+  }
   const int64_t begin = w * rows_per_wave;
   const int64_t end = begin + rows_per_wave < n ? begin + rows_per_wave : n;
   int64_t my_offset = lane < P ? starts[static_cast<int64_t>(lane) * W + w] : 0;  // lane p: next slot of partition p

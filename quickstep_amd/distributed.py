@@ -1,0 +1,123 @@
+"""Multi-GPU execution of the hot path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI) for the two exchange steps the path has.
+
+The reference has no data-plane collective: single-node Quickstep
+shares memory, and its partitioned execution is purely logical — relation rows
+are routed to partition ``HashPartitionSchemeHeader::getPartitionId(key)``
+(catalog/PartitionSchemeHeader.hpp:200-214) by PartitionAwareInsertDestination
+(storage/InsertDestination.hpp:490-660), then each partition gets its own
+BuildHash / HashJoin / Aggregation work orders (BuildHashOperator.cpp:82-91,
+HashJoinOperator.cpp:220-231).  Here GPU g *is* partition g of P = world size:
+
+  * join-key shuffle  = local K9 partition scatter (qsx_partition_scatter)
+                        -> counts all-to-all -> all-to-all(v) of the key and
+                        payload columns -> local build / probe;
+  * partial aggregate merge (group keys not co-partitioned with the shuffle)
+                      = all-gather of the exported state images + local
+                        qsx_agg_state_import_merge for hash-table states,
+                        all-reduce (SUM / bit-OR per column type) for the dense
+                        CollisionFreeVector image.
+
+Everything numeric happens behind an ``ops`` object with the same surface as
+``quickstep_amd.capi``; the product passes ``quickstep_amd.capi`` itself.
+(The gloo/CPU tests pass an adapter over the CPU checker so that the rank
+logic — split sizes, offsets, merge order — is exercised without a GPU.)
+"""
+import torch
+import torch.distributed as dist
+
+
+def _splits(offsets_host):
+    return [int(offsets_host[i + 1] - offsets_host[i]) for i in range(len(offsets_host) - 1)]
+
+
+def exchange_counts(send_counts, group=None):
+    """send_counts: int64[P] on the compute device.  Returns int64[P] recv counts."""
+    recv = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv, send_counts, group=group)
+    return recv
+
+
+def shuffle_by_key(ops, keys, cols, group=None):
+    """Repartition rows across ranks by the hash partition of ``keys``.
+
+    cols: list of equally long 1-D tensors travelling with the rows (include
+    ``keys`` itself if the receiver needs it).  Returns (received columns,
+    recv_counts list).  Rows from rank r arrive before rows from rank r + 1 and
+    keep their local order (the scatter is stable)."""
+    world = dist.get_world_size(group)
+    scattered, offsets = ops.partition_scatter(keys, world, cols)
+    send_counts_dev = offsets[1:] - offsets[:-1]
+    recv_counts_dev = exchange_counts(send_counts_dev, group)
+    send_splits = send_counts_dev.cpu().tolist()          # host sync: all_to_all_single needs host split sizes
+    recv_splits = recv_counts_dev.cpu().tolist()
+    total = int(sum(recv_splits))
+    received = []
+    for col in scattered:
+        out = torch.empty(total, dtype=col.dtype, device=col.device)
+        dist.all_to_all_single(out, col, output_split_sizes=recv_splits, input_split_sizes=send_splits, group=group)
+        received.append(out)
+    return received, recv_splits
+
+
+class PartitionedHashJoin:
+    """lineitem ⋈ orders style partitioned join (BASELINE config 4).
+
+    Build rows and probe rows start block-round-robin on the ranks; both sides
+    are shuffled on the join key, then every rank joins its own partition.
+    Output pairs carry *global* tuple ids (rank-local tid + the rank's base)."""
+
+    def __init__(self, ops, key_type, est_build_rows_per_rank, group=None):
+        self.ops = ops
+        self.group = group
+        self.table = ops.JoinTable(key_type, est_build_rows_per_rank)
+
+    def build(self, keys, tid_base):
+        tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
+        (rkeys, rtids), _ = shuffle_by_key(self.ops, keys, [keys, tids], self.group)
+        self.build_tids = rtids                            # table stores positions into this column
+        self.table.clear()
+        self.table.build(rkeys)
+        return rkeys.numel()
+
+    def probe(self, keys, tid_base, capacity=None):
+        tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
+        (rkeys, rtids), _ = shuffle_by_key(self.ops, keys, [keys, tids], self.group)
+        out_p, out_b, count = self.table.probe(rkeys, capacity=capacity)
+        return rtids, self.build_tids, out_p, out_b, count
+
+    def materialize(self, probe_tids, build_tids, out_p, out_b, count):
+        """Global (probe_tid, build_tid) pairs of this partition (K5 gathers)."""
+        k = int(count.item())
+        return self.ops.gather(probe_tids, out_p[:k]), self.ops.gather(build_tids, out_b[:k])
+
+
+def merge_agg_state_images(ops, state, group=None):
+    """Merge the partial aggregation states of all ranks into every rank's state
+    (counterpart of merging the thread-private tables at finalize,
+    storage/AggregationOperationState.cpp:925-948).  Hash-table images are
+    all-gathered and merged locally (Q1-sized: a few KiB per rank)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    device = state.device if hasattr(state, "device") else None
+    image = state.export(device)
+    gathered = [torch.empty_like(image) for _ in range(world)]
+    dist.all_gather(gathered, image, group=group)
+    for r in range(world):
+        if r != rank:
+            state.import_merge(gathered[r])
+    return state
+
+
+def allreduce_dense_agg_image(image, exist_words, num_entries, int_col_mask, num_cols, group=None):
+    """All-reduce a CollisionFreeVector state image in place: bit-OR for the
+    existence words, integer SUM for count / integer columns, f64 SUM for the
+    rest.  image: int64[exist_words + num_cols * num_entries]."""
+    dist.all_reduce(image[:exist_words], op=dist.ReduceOp.BOR, group=group)
+    for col in range(num_cols):
+        seg = image[exist_words + col * num_entries: exist_words + (col + 1) * num_entries]
+        if (int_col_mask >> col) & 1:
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.all_reduce(seg.view(torch.float64), op=dist.ReduceOp.SUM, group=group)
+    return image
