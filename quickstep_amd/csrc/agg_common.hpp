@@ -1,0 +1,267 @@
+// agg_common.hpp — device-side descriptors and per-row helpers shared by the
+// aggregation kernels (aggregate.hip, agg_hash_update.hpp).
+#ifndef QSX_CSRC_AGG_COMMON_HPP_
+#define QSX_CSRC_AGG_COMMON_HPP_
+
+#include "common.hpp"
+
+namespace qsx {
+
+constexpr int kABlock = 256;
+constexpr int kRegGroups = 4;
+constexpr uint64_t kEmptyCode = ~0ull;
+constexpr int kMaxSums = QSX_MAX_AGGS;
+
+struct DevOperand {
+  int kind;
+  int index;
+};
+struct DevInstr {
+  int op;
+  int dst;
+  DevOperand a, b;
+};
+struct DevSum {
+  DevOperand arg;
+  int is_int;  // accumulate as int64 (argument is an INT/LONG column)
+};
+struct DevPred {
+  int column;
+  int op;
+  unsigned long long literal;  // raw bits, typed like the column
+};
+
+struct DevConfig {
+  int num_columns;
+  int column_type[QSX_MAX_COLUMNS];
+  int column_width[QSX_MAX_COLUMNS];
+  int num_keys;
+  int key_column[QSX_MAX_KEYS];
+  int key_width[QSX_MAX_KEYS];
+  int key_shift[QSX_MAX_KEYS];  // bit offset of the key inside the 64-bit code
+  int num_instrs;
+  DevInstr instrs[QSX_MAX_INSTRS];
+  double consts[QSX_MAX_CONSTS];
+  int num_sums;
+  DevSum sums[kMaxSums];
+  int num_pred;
+  DevPred pred[QSX_MAX_PRED_TERMS];
+  const void *cols[QSX_MAX_COLUMNS];
+  // LDS staging plan of the hash-strategy update kernel: byte offset of column
+  // c inside a staged tile (-1: column not referenced, not staged), of the
+  // filter words (-1: no filter) and the size of one tile buffer.
+  int lds_off[QSX_MAX_COLUMNS];
+  int filter_lds_off;
+  int tile_bytes;
+};
+
+struct HashTableView {
+  unsigned long long *keys;    // [cap + 1]
+  unsigned long long *states;  // [(NS + 1)][cap + 1]
+  unsigned long long cap;      // power of two
+  int shift;                   // 64 - log2(cap)
+  unsigned long long *ngroups; // groups inserted (sentinel slot not counted)
+  int *overflow;               // set when an insert found the table full
+};
+
+struct DenseView {
+  unsigned long long *exist;
+  unsigned long long *states;  // [ncols][E]
+  long long num_entries;
+  int has_count;               // col 0 is the row count
+  int *error;                  // set when a key is outside [0, E)
+};
+
+// ---- per-row evaluation -----------------------------------------------------
+__device__ __forceinline__ double temp_get(const double (&t)[QSX_MAX_TEMPS], int i) {
+  switch (i) {  // wave-uniform index: scalar branches, temps stay in VGPRs
+    case 0: return t[0];
+    case 1: return t[1];
+    case 2: return t[2];
+    case 3: return t[3];
+    case 4: return t[4];
+    case 5: return t[5];
+    case 6: return t[6];
+    default: return t[7];
+  }
+}
+__device__ __forceinline__ void temp_set(double (&t)[QSX_MAX_TEMPS], int i, double v) {
+  switch (i) {
+    case 0: t[0] = v; break;
+    case 1: t[1] = v; break;
+    case 2: t[2] = v; break;
+    case 3: t[3] = v; break;
+    case 4: t[4] = v; break;
+    case 5: t[5] = v; break;
+    case 6: t[6] = v; break;
+    default: t[7] = v; break;
+  }
+}
+
+__device__ __forceinline__ double column_as_double(const DevConfig &c, int col, int64_t row) {
+  switch (c.column_type[col]) {
+    case QSX_INT: return static_cast<double>(static_cast<const int32_t *>(c.cols[col])[row]);
+    case QSX_LONG: return static_cast<double>(static_cast<const int64_t *>(c.cols[col])[row]);
+    case QSX_FLOAT: return static_cast<double>(static_cast<const float *>(c.cols[col])[row]);
+    default: return static_cast<const double *>(c.cols[col])[row];
+  }
+}
+__device__ __forceinline__ long long column_as_int(const DevConfig &c, int col, int64_t row) {
+  if (c.column_type[col] == QSX_INT) return static_cast<const int32_t *>(c.cols[col])[row];
+  return static_cast<const int64_t *>(c.cols[col])[row];
+}
+__device__ __forceinline__ double operand_value(const DevConfig &c, const DevOperand &o,
+                                                const double (&t)[QSX_MAX_TEMPS], int64_t row) {
+  switch (o.kind) {
+    case QSX_OPD_COLUMN: return column_as_double(c, o.index, row);
+    case QSX_OPD_CONST: return c.consts[o.index];
+    default: return temp_get(t, o.index);
+  }
+}
+
+// Expression program: every node an IEEE double, evaluated in program order
+// (compiled with -ffp-contract=off so that a*b+c is never fused: each
+// reference temp vector holds a rounded double).
+__device__ __forceinline__ void eval_program(const DevConfig &c, double (&t)[QSX_MAX_TEMPS], int64_t row) {
+  for (int k = 0; k < c.num_instrs; ++k) {
+    const DevInstr in = c.instrs[k];
+    const double a = operand_value(c, in.a, t, row);
+    const double b = operand_value(c, in.b, t, row);
+    double r;
+    switch (in.op) {
+      case QSX_EX_ADD: r = a + b; break;
+      case QSX_EX_SUB: r = a - b; break;
+      case QSX_EX_MUL: r = a * b; break;
+      default: r = a / b; break;
+    }
+    temp_set(t, in.dst, r);
+  }
+}
+
+__device__ __forceinline__ bool eval_predicate(const DevConfig &c, int64_t row) {
+  bool ok = true;
+  for (int p = 0; p < c.num_pred; ++p) {
+    const DevPred term = c.pred[p];
+    bool r;
+    switch (c.column_type[term.column]) {
+      case QSX_INT:
+        r = compare_op<int32_t>(static_cast<const int32_t *>(c.cols[term.column])[row], term.op,
+                                static_cast<int32_t>(term.literal));
+        break;
+      case QSX_LONG:
+        r = compare_op<int64_t>(static_cast<const int64_t *>(c.cols[term.column])[row], term.op,
+                                static_cast<int64_t>(term.literal));
+        break;
+      case QSX_FLOAT:
+        r = compare_op<float>(static_cast<const float *>(c.cols[term.column])[row], term.op,
+                              __uint_as_float(static_cast<uint32_t>(term.literal)));
+        break;
+      default:
+        r = compare_op<double>(static_cast<const double *>(c.cols[term.column])[row], term.op,
+                               __longlong_as_double(static_cast<long long>(term.literal)));
+        break;
+    }
+    ok = ok && r;
+  }
+  return ok;
+}
+
+// Compact key code: key bytes at running offsets of a zeroed 64-bit word,
+// little endian (storage/ThreadPrivateCompactKeyHashTable.cpp:216-232).
+__device__ __forceinline__ unsigned long long key_code(const DevConfig &c, int64_t row) {
+  unsigned long long code = 0;
+  for (int k = 0; k < c.num_keys; ++k) {
+    const void *col = c.cols[c.key_column[k]];
+    unsigned long long v;
+    switch (c.key_width[k]) {
+      case 1: v = static_cast<const uint8_t *>(col)[row]; break;
+      case 2: v = static_cast<const uint16_t *>(col)[row]; break;
+      case 4: v = static_cast<const uint32_t *>(col)[row]; break;
+      default: v = static_cast<const unsigned long long *>(col)[row]; break;
+    }
+    code |= v << c.key_shift[k];
+  }
+  return code;
+}
+
+// Value of sum j for this row as raw 64-bit accumulator increment.
+__device__ __forceinline__ unsigned long long sum_increment(const DevConfig &c, int j,
+                                                            const double (&t)[QSX_MAX_TEMPS], int64_t row) {
+  const DevSum s = c.sums[j];
+  if (s.is_int) return static_cast<unsigned long long>(column_as_int(c, s.arg.index, row));
+  return static_cast<unsigned long long>(__double_as_longlong(operand_value(c, s.arg, t, row)));
+}
+
+__device__ __forceinline__ unsigned long long acc_add(unsigned long long acc, unsigned long long inc, int is_int) {
+  if (is_int) return acc + inc;
+  return static_cast<unsigned long long>(__double_as_longlong(
+      __longlong_as_double(static_cast<long long>(acc)) + __longlong_as_double(static_cast<long long>(inc))));
+}
+
+__device__ __forceinline__ bool filter_bit(const uint64_t *filter, int64_t row) {
+  return filter == nullptr || msb_bit(filter[row >> 6], static_cast<int>(row & 63));
+}
+
+// ---- global hash table --------------------------------------------------------
+__device__ __forceinline__ unsigned long long code_slot(unsigned long long code, int shift) {
+  return (mix64(code) * 0x9E3779B97F4A7C15ull) >> shift;
+}
+
+// Returns the slot of `code` (inserting it if new), cap for the sentinel
+// code, or ~0 when the table is full (overflow flag raised).
+__device__ __forceinline__ unsigned long long global_find_or_insert(const HashTableView &g, unsigned long long code) {
+  if (code == kEmptyCode) return g.cap;
+  unsigned long long s = code_slot(code, g.shift);
+  for (unsigned long long probes = 0; probes < g.cap; ++probes) {
+    unsigned long long k = __hip_atomic_load(&g.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == code) return s;
+    if (k == kEmptyCode) {
+      k = atomicCAS(&g.keys[s], kEmptyCode, code);
+      if (k == kEmptyCode) {
+        atomicAdd(g.ngroups, 1ull);
+        return s;
+      }
+      if (k == code) return s;
+    }
+    s = (s + 1) & (g.cap - 1);
+  }
+  atomicExch(g.overflow, 1);
+  return ~0ull;
+}
+
+__device__ __forceinline__ void global_add(const HashTableView &g, int col, unsigned long long slot,
+                                           unsigned long long inc, int is_int) {
+  unsigned long long *p = g.states + static_cast<unsigned long long>(col) * (g.cap + 1) + slot;
+  if (is_int) {
+    if (inc != 0) atomicAdd(p, inc);
+  } else {
+    atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
+  }
+}
+
+// ---- LDS table ------------------------------------------------------------------
+__device__ __forceinline__ int lds_find_or_insert(unsigned long long *l_keys, int S, unsigned long long code) {
+  int s = static_cast<int>(mix64(code) >> 40) & (S - 1);
+  for (int probes = 0; probes < S; ++probes) {
+    unsigned long long k = __hip_atomic_load(&l_keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == code) return s;
+    if (k == kEmptyCode) {
+      k = atomicCAS(&l_keys[s], kEmptyCode, code);
+      if (k == kEmptyCode || k == code) return s;
+    }
+    s = (s + 1) & (S - 1);
+  }
+  return -1;
+}
+
+__device__ __forceinline__ void lds_add(unsigned long long *p, unsigned long long inc, int is_int) {
+  if (is_int) {
+    atomicAdd(p, inc);
+  } else {
+    unsafeAtomicAdd(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
+  }
+}
+
+}  // namespace qsx
+
+#endif  // QSX_CSRC_AGG_COMMON_HPP_

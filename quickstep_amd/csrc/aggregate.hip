@@ -37,403 +37,16 @@
 // Integer SUM/COUNT use integer atomics (exact, order-independent); double
 // sums are order-dependent in the last bits, the contract is 1e-6 relative.
 
-#include "common.hpp"
+#include "agg_common.hpp"
+#include "agg_hash_update.hpp"
 #include "scan.hpp"
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
 namespace qsx {
 
-constexpr int kABlock = 256;
-constexpr int kRegGroups = 4;
-constexpr int kRowsPerIter = 2;
-constexpr uint64_t kEmptyCode = ~0ull;
-constexpr int kMaxSums = QSX_MAX_AGGS;
-
-struct DevOperand {
-  int kind;
-  int index;
-};
-struct DevInstr {
-  int op;
-  int dst;
-  DevOperand a, b;
-};
-struct DevSum {
-  DevOperand arg;
-  int is_int;  // accumulate as int64 (argument is an INT/LONG column)
-};
-struct DevPred {
-  int column;
-  int op;
-  unsigned long long literal;  // raw bits, typed like the column
-};
-
-struct DevConfig {
-  int num_columns;
-  int column_type[QSX_MAX_COLUMNS];
-  int column_width[QSX_MAX_COLUMNS];
-  int num_keys;
-  int key_column[QSX_MAX_KEYS];
-  int key_width[QSX_MAX_KEYS];
-  int key_shift[QSX_MAX_KEYS];  // bit offset of the key inside the 64-bit code
-  int num_instrs;
-  DevInstr instrs[QSX_MAX_INSTRS];
-  double consts[QSX_MAX_CONSTS];
-  int num_sums;
-  DevSum sums[kMaxSums];
-  int num_pred;
-  DevPred pred[QSX_MAX_PRED_TERMS];
-  const void *cols[QSX_MAX_COLUMNS];
-};
-
-struct HashTableView {
-  unsigned long long *keys;    // [cap + 1]
-  unsigned long long *states;  // [(NS + 1)][cap + 1]
-  unsigned long long cap;      // power of two
-  int shift;                   // 64 - log2(cap)
-  unsigned long long *ngroups; // groups inserted (sentinel slot not counted)
-  int *overflow;               // set when an insert found the table full
-};
-
-struct DenseView {
-  unsigned long long *exist;
-  unsigned long long *states;  // [ncols][E]
-  long long num_entries;
-  int has_count;               // col 0 is the row count
-  int *error;                  // set when a key is outside [0, E)
-};
-
-// ---- per-row evaluation -----------------------------------------------------
-__device__ __forceinline__ double temp_get(const double (&t)[QSX_MAX_TEMPS], int i) {
-  switch (i) {  // wave-uniform index: scalar branches, temps stay in VGPRs
-    case 0: return t[0];
-    case 1: return t[1];
-    case 2: return t[2];
-    case 3: return t[3];
-    case 4: return t[4];
-    case 5: return t[5];
-    case 6: return t[6];
-    default: return t[7];
-  }
-}
-__device__ __forceinline__ void temp_set(double (&t)[QSX_MAX_TEMPS], int i, double v) {
-  switch (i) {
-    case 0: t[0] = v; break;
-    case 1: t[1] = v; break;
-    case 2: t[2] = v; break;
-    case 3: t[3] = v; break;
-    case 4: t[4] = v; break;
-    case 5: t[5] = v; break;
-    case 6: t[6] = v; break;
-    default: t[7] = v; break;
-  }
-}
-
-__device__ __forceinline__ double column_as_double(const DevConfig &c, int col, int64_t row) {
-  switch (c.column_type[col]) {
-    case QSX_INT: return static_cast<double>(static_cast<const int32_t *>(c.cols[col])[row]);
-    case QSX_LONG: return static_cast<double>(static_cast<const int64_t *>(c.cols[col])[row]);
-    case QSX_FLOAT: return static_cast<double>(static_cast<const float *>(c.cols[col])[row]);
-    default: return static_cast<const double *>(c.cols[col])[row];
-  }
-}
-__device__ __forceinline__ long long column_as_int(const DevConfig &c, int col, int64_t row) {
-  if (c.column_type[col] == QSX_INT) return static_cast<const int32_t *>(c.cols[col])[row];
-  return static_cast<const int64_t *>(c.cols[col])[row];
-}
-__device__ __forceinline__ double operand_value(const DevConfig &c, const DevOperand &o,
-                                                const double (&t)[QSX_MAX_TEMPS], int64_t row) {
-  switch (o.kind) {
-    case QSX_OPD_COLUMN: return column_as_double(c, o.index, row);
-    case QSX_OPD_CONST: return c.consts[o.index];
-    default: return temp_get(t, o.index);
-  }
-}
-
-// Expression program: every node an IEEE double, evaluated in program order
-// (compiled with -ffp-contract=off so that a*b+c is never fused: each
-// reference temp vector holds a rounded double).
-__device__ __forceinline__ void eval_program(const DevConfig &c, double (&t)[QSX_MAX_TEMPS], int64_t row) {
-  for (int k = 0; k < c.num_instrs; ++k) {
-    const DevInstr in = c.instrs[k];
-    const double a = operand_value(c, in.a, t, row);
-    const double b = operand_value(c, in.b, t, row);
-    double r;
-    switch (in.op) {
-      case QSX_EX_ADD: r = a + b; break;
-      case QSX_EX_SUB: r = a - b; break;
-      case QSX_EX_MUL: r = a * b; break;
-      default: r = a / b; break;
-    }
-    temp_set(t, in.dst, r);
-  }
-}
-
-__device__ __forceinline__ bool eval_predicate(const DevConfig &c, int64_t row) {
-  bool ok = true;
-  for (int p = 0; p < c.num_pred; ++p) {
-    const DevPred term = c.pred[p];
-    bool r;
-    switch (c.column_type[term.column]) {
-      case QSX_INT:
-        r = compare_op<int32_t>(static_cast<const int32_t *>(c.cols[term.column])[row], term.op,
-                                static_cast<int32_t>(term.literal));
-        break;
-      case QSX_LONG:
-        r = compare_op<int64_t>(static_cast<const int64_t *>(c.cols[term.column])[row], term.op,
-                                static_cast<int64_t>(term.literal));
-        break;
-      case QSX_FLOAT:
-        r = compare_op<float>(static_cast<const float *>(c.cols[term.column])[row], term.op,
-                              __uint_as_float(static_cast<uint32_t>(term.literal)));
-        break;
-      default:
-        r = compare_op<double>(static_cast<const double *>(c.cols[term.column])[row], term.op,
-                               __longlong_as_double(static_cast<long long>(term.literal)));
-        break;
-    }
-    ok = ok && r;
-  }
-  return ok;
-}
-
-// Compact key code: key bytes at running offsets of a zeroed 64-bit word,
-// little endian (storage/ThreadPrivateCompactKeyHashTable.cpp:216-232).
-__device__ __forceinline__ unsigned long long key_code(const DevConfig &c, int64_t row) {
-  unsigned long long code = 0;
-  for (int k = 0; k < c.num_keys; ++k) {
-    const void *col = c.cols[c.key_column[k]];
-    unsigned long long v;
-    switch (c.key_width[k]) {
-      case 1: v = static_cast<const uint8_t *>(col)[row]; break;
-      case 2: v = static_cast<const uint16_t *>(col)[row]; break;
-      case 4: v = static_cast<const uint32_t *>(col)[row]; break;
-      default: v = static_cast<const unsigned long long *>(col)[row]; break;
-    }
-    code |= v << c.key_shift[k];
-  }
-  return code;
-}
-
-// Value of sum j for this row as raw 64-bit accumulator increment.
-__device__ __forceinline__ unsigned long long sum_increment(const DevConfig &c, int j,
-                                                            const double (&t)[QSX_MAX_TEMPS], int64_t row) {
-  const DevSum s = c.sums[j];
-  if (s.is_int) return static_cast<unsigned long long>(column_as_int(c, s.arg.index, row));
-  return static_cast<unsigned long long>(__double_as_longlong(operand_value(c, s.arg, t, row)));
-}
-
-__device__ __forceinline__ unsigned long long acc_add(unsigned long long acc, unsigned long long inc, int is_int) {
-  if (is_int) return acc + inc;
-  return static_cast<unsigned long long>(__double_as_longlong(
-      __longlong_as_double(static_cast<long long>(acc)) + __longlong_as_double(static_cast<long long>(inc))));
-}
-
-__device__ __forceinline__ bool filter_bit(const uint64_t *filter, int64_t row) {
-  return filter == nullptr || msb_bit(filter[row >> 6], static_cast<int>(row & 63));
-}
-
-// ---- global hash table --------------------------------------------------------
-__device__ __forceinline__ unsigned long long code_slot(unsigned long long code, int shift) {
-  return (mix64(code) * 0x9E3779B97F4A7C15ull) >> shift;
-}
-
-// Returns the slot of `code` (inserting it if new), cap for the sentinel
-// code, or ~0 when the table is full (overflow flag raised).
-__device__ __forceinline__ unsigned long long global_find_or_insert(const HashTableView &g, unsigned long long code) {
-  if (code == kEmptyCode) return g.cap;
-  unsigned long long s = code_slot(code, g.shift);
-  for (unsigned long long probes = 0; probes < g.cap; ++probes) {
-    unsigned long long k = __hip_atomic_load(&g.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == code) return s;
-    if (k == kEmptyCode) {
-      k = atomicCAS(&g.keys[s], kEmptyCode, code);
-      if (k == kEmptyCode) {
-        atomicAdd(g.ngroups, 1ull);
-        return s;
-      }
-      if (k == code) return s;
-    }
-    s = (s + 1) & (g.cap - 1);
-  }
-  atomicExch(g.overflow, 1);
-  return ~0ull;
-}
-
-__device__ __forceinline__ void global_add(const HashTableView &g, int col, unsigned long long slot,
-                                           unsigned long long inc, int is_int) {
-  unsigned long long *p = g.states + static_cast<unsigned long long>(col) * (g.cap + 1) + slot;
-  if (is_int) {
-    if (inc != 0) atomicAdd(p, inc);
-  } else {
-    atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
-  }
-}
-
-// ---- LDS table ------------------------------------------------------------------
-__device__ __forceinline__ int lds_find_or_insert(unsigned long long *l_keys, int S, unsigned long long code) {
-  int s = static_cast<int>(mix64(code) >> 40) & (S - 1);
-  for (int probes = 0; probes < S; ++probes) {
-    unsigned long long k = __hip_atomic_load(&l_keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (k == code) return s;
-    if (k == kEmptyCode) {
-      k = atomicCAS(&l_keys[s], kEmptyCode, code);
-      if (k == kEmptyCode || k == code) return s;
-    }
-    s = (s + 1) & (S - 1);
-  }
-  return -1;
-}
-
-__device__ __forceinline__ void lds_add(unsigned long long *p, unsigned long long inc, int is_int) {
-  if (is_int) {
-    atomicAdd(p, inc);
-  } else {
-    unsafeAtomicAdd(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
-  }
-}
-
-// ---------------------------------------------------------------------------
-// hash-strategy update kernel.  NS = number of SUM/AVG accumulators.
-// Dynamic LDS: tags[R] | rstate[R][NS+1] | l_keys[S] | l_state[NS+1][S]
-// ---------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(kABlock) void agg_hash_kernel(DevConfig c, int64_t n,
-                                                          const uint64_t *__restrict__ filter,
-                                                          HashTableView g, int S) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
-  unsigned long long *l_tags = smem;                                     // [R]
-  unsigned long long *l_rstate = l_tags + kRegGroups;                    // [R][NS + 1]
-  unsigned long long *l_keys = l_rstate + kRegGroups * (NS + 1);         // [S]
-  unsigned long long *l_state = l_keys + S;                              // [NS + 1][S]
-
-  for (int i = threadIdx.x; i < kRegGroups; i += kABlock) l_tags[i] = kEmptyCode;
-  for (int i = threadIdx.x; i < kRegGroups * (NS + 1); i += kABlock) l_rstate[i] = 0;
-  for (int i = threadIdx.x; i < S; i += kABlock) l_keys[i] = kEmptyCode;
-  for (int i = threadIdx.x; i < (NS + 1) * S; i += kABlock) l_state[i] = 0;
-  __syncthreads();
-
-  // Per-thread partial state of the register groups.
-  unsigned long long racc[kRegGroups][NS > 0 ? NS : 1];
-  unsigned int rcnt[kRegGroups];
-#pragma unroll
-  for (int r = 0; r < kRegGroups; ++r) {
-    rcnt[r] = 0;
-#pragma unroll
-    for (int j = 0; j < NS; ++j) racc[r][j] = 0;
-  }
-
-  const int64_t tile_rows = static_cast<int64_t>(kABlock) * kRowsPerIter;
-  for (int64_t base = static_cast<int64_t>(blockIdx.x) * tile_rows; base < n;
-       base += static_cast<int64_t>(gridDim.x) * tile_rows) {
-    // Tags only ever go from empty to a code: a per-iteration snapshot is enough.
-    unsigned long long tag[kRegGroups];
-#pragma unroll
-    for (int r = 0; r < kRegGroups; ++r) {
-      tag[r] = __hip_atomic_load(&l_tags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-#pragma unroll
-    for (int v = 0; v < kRowsPerIter; ++v) {
-      const int64_t row = base + static_cast<int64_t>(v) * kABlock + threadIdx.x;
-      bool live = row < n && filter_bit(filter, row);
-      if (live) live = eval_predicate(c, row);
-      double t[QSX_MAX_TEMPS];
-      unsigned long long code = 0;
-      unsigned long long inc[NS > 0 ? NS : 1];
-      if (live) {
-        eval_program(c, t, row);
-        code = key_code(c, row);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) inc[j] = sum_increment(c, j, t, row);
-      }
-      // which register group (if any)?
-      int sel = -1;
-      if (live && code != kEmptyCode) {
-#pragma unroll
-        for (int r = 0; r < kRegGroups; ++r) {
-          if (tag[r] == code) sel = r;
-        }
-        if (sel < 0) {
-          // Not in the snapshot: try to claim a free tag (first rows of a workgroup only).
-          for (int r = 0; r < kRegGroups && sel < 0; ++r) {
-            unsigned long long k = __hip_atomic_load(&l_tags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (k == kEmptyCode) k = atomicCAS(&l_tags[r], kEmptyCode, code);
-            if (k == kEmptyCode || k == code) sel = r;
-          }
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < kRegGroups; ++r) {
-        const bool hit = sel == r;
-        rcnt[r] += hit ? 1u : 0u;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          // identity element: integer 0 and +0.0 share the all-zero bit pattern
-          racc[r][j] = acc_add(racc[r][j], hit ? inc[j] : 0ull, c.sums[j].is_int);
-        }
-      }
-      if (live && sel < 0) {
-        const int s = code == kEmptyCode ? -1 : lds_find_or_insert(l_keys, S, code);
-        if (s >= 0) {
-          atomicAdd(&l_state[s], 1ull);
-#pragma unroll
-          for (int j = 0; j < NS; ++j) lds_add(&l_state[(j + 1) * S + s], inc[j], c.sums[j].is_int);
-        } else {
-          const unsigned long long gs = global_find_or_insert(g, code);
-          if (gs != ~0ull) {
-            global_add(g, 0, gs, 1ull, 1);
-#pragma unroll
-            for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, inc[j], c.sums[j].is_int);
-          }
-        }
-      }
-    }
-  }
-
-  // registers -> LDS (wave reduction first: one LDS atomic per wave per word)
-#pragma unroll
-  for (int r = 0; r < kRegGroups; ++r) {
-    const unsigned long long cnt = wave_reduce_add(static_cast<unsigned long long>(rcnt[r]));
-    if (cnt == 0) continue;  // wave-uniform
-    if (lane_id() == 0) atomicAdd(&l_rstate[r * (NS + 1)], cnt);
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      unsigned long long v;
-      if (c.sums[j].is_int) {
-        v = wave_reduce_add(racc[r][j]);
-      } else {
-        v = static_cast<unsigned long long>(__double_as_longlong(
-            wave_reduce_add(__longlong_as_double(static_cast<long long>(racc[r][j])))));
-      }
-      if (lane_id() == 0) lds_add(&l_rstate[r * (NS + 1) + j + 1], v, c.sums[j].is_int);
-    }
-  }
-  __syncthreads();
-
-  // LDS -> global table: one atomic per group per accumulator per workgroup.
-  for (int i = threadIdx.x; i < kRegGroups + S; i += kABlock) {
-    unsigned long long code, cnt;
-    const unsigned long long *src;
-    int stride;
-    if (i < kRegGroups) {
-      code = l_tags[i];
-      src = &l_rstate[i * (NS + 1)];
-      stride = 1;
-    } else {
-      code = l_keys[i - kRegGroups];
-      src = &l_state[i - kRegGroups];
-      stride = S;
-    }
-    cnt = src[0];
-    if (code == kEmptyCode || cnt == 0) continue;
-    const unsigned long long gs = global_find_or_insert(g, code);
-    if (gs == ~0ull) continue;
-    global_add(g, 0, gs, cnt, 1);
-    for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, src[(j + 1) * stride], c.sums[j].is_int);
-  }
-}
 
 // ---------------------------------------------------------------------------
 // COLLISION_FREE update kernel (K7): vec[key] += arg, existence bit.
@@ -772,6 +385,7 @@ struct qsx_agg_state {
   int64_t *tile_offsets = nullptr;
   long long max_tiles = 0;
   int lds_slots = 64;
+  unsigned used_columns = 0;
 
   HashTableView hash_view() const {
     HashTableView g;
@@ -890,11 +504,18 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
     if (ag.fn == QSX_AGG_AVG) needs_count = true;
     const bool is_int = ag.arg.kind == QSX_OPD_COLUMN &&
                         (c.column_type[ag.arg.index] == QSX_INT || c.column_type[ag.arg.index] == QSX_LONG);
-    d.sums[ns].arg = DevOperand{ag.arg.kind, ag.arg.index};
-    d.sums[ns].is_int = is_int ? 1 : 0;
     f.is_int[a] = is_int ? 1 : 0;
-    f.sum_col[a] = ns + 1;  // fixed up below for dense states without a count column
-    ++ns;
+    // SUM(x) and AVG(x) over the same argument share one accumulator (what
+    // ReuseAggregateExpressions does on the optimizer side,
+    // query_optimizer/rules/ReuseAggregateExpressions.hpp:43-80).
+    int j = 0;
+    while (j < ns && !(d.sums[j].arg.kind == ag.arg.kind && d.sums[j].arg.index == ag.arg.index)) ++j;
+    if (j == ns) {
+      d.sums[ns].arg = DevOperand{ag.arg.kind, ag.arg.index};
+      d.sums[ns].is_int = is_int ? 1 : 0;
+      ++ns;
+    }
+    f.sum_col[a] = j + 1;  // fixed up below for dense states without a count column
   }
   d.num_sums = ns;
   st->num_sums = ns;
@@ -922,6 +543,16 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
     f.key_shift[k] = d.key_shift[k];
     f.key_type[k] = c.column_type[c.key_column[k]];
   }
+  // columns the update kernel has to stage: keys, predicate, expression and aggregate operands
+  unsigned used = 0;
+  for (int k = 0; k < c.num_keys; ++k) used |= 1u << c.key_column[k];
+  for (int p = 0; p < c.num_pred_terms; ++p) used |= 1u << c.pred[p].column;
+  for (int k = 0; k < c.num_instrs; ++k) {
+    if (c.instrs[k].a.kind == QSX_OPD_COLUMN) used |= 1u << c.instrs[k].a.index;
+    if (c.instrs[k].b.kind == QSX_OPD_COLUMN) used |= 1u << c.instrs[k].b.index;
+  }
+  for (int j = 0; j < ns; ++j) if (d.sums[j].arg.kind == QSX_OPD_COLUMN) used |= 1u << d.sums[j].arg.index;
+  st->used_columns = used;
   st->dense = c.strategy == QSX_AGG_COLLISION_FREE;
   st->dense_has_count = needs_count;
   if (st->dense && !needs_count) {
@@ -937,12 +568,70 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
   return QSX_OK;
 }
 
+static size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+
+// Lays the referenced columns of one TR-row tile out in LDS and launches the
+// update kernel with two tile buffers (DMA double buffering).
+template <int NS, int V>
+static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter,
+                         const HashTableView &g, int S, hipStream_t stream, bool dry_run) {
+  constexpr int TR = kABlock * V;
+  size_t off = 0;
+  for (int col = 0; col < dc.num_columns; ++col) {
+    if ((used_columns >> col) & 1u) {
+      dc.lds_off[col] = static_cast<int>(off);
+      off += align16(static_cast<size_t>(TR) * dc.column_width[col]);
+    } else {
+      dc.lds_off[col] = -1;
+    }
+  }
+  dc.filter_lds_off = -1;
+  if (filter != nullptr) {
+    dc.filter_lds_off = static_cast<int>(off);
+    off += align16(TR / 64 * 8);
+  }
+  if (off == 0) off = 16;
+  dc.tile_bytes = static_cast<int>(off);
+  const size_t lds = 2 * off + sizeof(unsigned long long) *
+                                   (kRegGroups + kRegGroups * (NS + 1) + S + static_cast<size_t>(NS + 1) * S);
+  constexpr size_t kMaxLds = 160 * 1024;
+  if (lds > kMaxLds) return QSX_ERR_CAPACITY;
+  if (dry_run) return QSX_OK;
+  static bool attribute_set = false;  // per instantiation
+  if (!attribute_set) {
+    QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_update_kernel<NS, V>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
+    attribute_set = true;
+  }
+  // grid = what is resident at once (LDS-limited workgroups per CU), tiles are strided over it
+  int per_cu = static_cast<int>(kMaxLds / lds);
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t num_tiles = (n + TR - 1) / TR;
+  const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
+  const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
+  hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S);
+  return QSX_OK;
+}
+
+static int agg_rows_per_thread() {
+  static int v = []() {
+    const char *e = getenv("QSX_AGG_ROWS_PER_THREAD");
+    return e != nullptr && atoi(e) == 2 ? 2 : 4;
+  }();
+  return v;
+}
+
 template <int NS>
-static void launch_hash(const DevConfig &dc, int64_t n, const uint64_t *filter, const HashTableView &g, int S,
-                        hipStream_t stream) {
-  const size_t lds = sizeof(unsigned long long) * (kRegGroups + kRegGroups * (NS + 1) + S + static_cast<size_t>(NS + 1) * S);
-  const int grid = grid_for(n, kABlock * kRowsPerIter * 4);
-  hipLaunchKernelGGL((agg_hash_kernel<NS>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S);
+static int launch_hash(const DevConfig &dc, unsigned used_columns, int64_t n, const uint64_t *filter,
+                       const HashTableView &g, int S, hipStream_t stream) {
+  // 1024-row tiles when two of them (plus the group tables) fit the CU's LDS twice over, else 512-row tiles
+  if (agg_rows_per_thread() == 4 && launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, stream, true) == QSX_OK) {
+    return launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, stream, false);
+  }
+  int rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, S, stream, false);
+  if (rc == QSX_ERR_CAPACITY) rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, 64, stream, false);
+  return rc;
 }
 template <int NS>
 static void launch_dense(const DevConfig &dc, int64_t n, const uint64_t *filter, const DenseView &d, hipStream_t stream) {
@@ -1066,7 +755,9 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
     QSX_DISPATCH_NS(st->num_sums, launch_dense, dc, n, filter_dev, d, s);
   } else {
     const HashTableView g = st->hash_view();
-    QSX_DISPATCH_NS(st->num_sums, launch_hash, dc, n, filter_dev, g, st->lds_slots, s);
+    int rc = QSX_OK;
+    QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, st->lds_slots, s);
+    if (rc != QSX_OK) return rc;
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;
