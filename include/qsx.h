@@ -83,6 +83,10 @@ int qsx_copy_to_device(void *dst_dev, const void *src_host, size_t bytes, qsx_st
 int qsx_copy_to_host(void *dst_host, const void *src_dev, size_t bytes, qsx_stream_t stream);
 int qsx_memset_device(void *dst_dev, int byte, size_t bytes, qsx_stream_t stream);
 int qsx_stream_synchronize(qsx_stream_t stream);
+/* One stream per Worker thread (query_execution/Worker.cpp:54-99 runs work orders one at a
+ * time per worker; concurrent workers = concurrent streams). */
+int qsx_stream_create(qsx_stream_t *out_stream);
+int qsx_stream_destroy(qsx_stream_t stream);
 
 /* ======================================================================
  * Select: predicate + projection
@@ -143,6 +147,15 @@ int qsx_bitmap_to_tids(const uint64_t *bitmap_dev, int64_t n, int32_t base_tid,
  * (relational_operators/HashJoinOperator.cpp:527-539). */
 int qsx_gather(int width, const void *src_dev, const int32_t *tids_dev, int64_t n,
                void *dst_dev, qsx_stream_t stream);
+
+/* K5 over a relation stored as several blocks: tids are relation-global row
+ * numbers, segment s holds rows [segment_first_row[s], segment_first_row[s+1])
+ * (the last one is open-ended) at segment_ptrs[s].  At most 64 segments.
+ * Counterpart of the per-build-block loop of HashInnerJoinWorkOrder
+ * (relational_operators/HashJoinOperator.cpp:494-540). */
+int qsx_gather_segmented(int width, int num_segments, const void *const *segment_ptrs,
+                         const int64_t *segment_first_row, const int32_t *tids_dev, int64_t n,
+                         void *dst_dev, qsx_stream_t stream);
 
 /* ======================================================================
  * Hash join

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "qsx_copy_to_host": (_int, [_vp, _vp, _sz, _vp]),
     "qsx_memset_device": (_int, [_vp, _int, _sz, _vp]),
     "qsx_stream_synchronize": (_int, [_vp]),
+    "qsx_stream_create": (_int, [_pp]),
+    "qsx_stream_destroy": (_int, [_vp]),
     "qsx_select_cmp": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "qsx_bitmap_combine": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_bitmap_count": (_int, [_vp, _i64, _vp, _vp]),
@@ -61,6 +63,7 @@ _SIGNATURES = {
     "qsx_compact_gather": (_int, [_int, _pp, C.POINTER(_i32), _vp, _i64, _pp, _vp, _vp, _sz, _vp]),
     "qsx_bitmap_to_tids": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     "qsx_gather": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_gather_segmented": (_int, [_int, _int, _pp, C.POINTER(_i64), _vp, _i64, _vp, _vp]),
     "qsx_join_table_create": (_int, [_int, _i64, _pp]),
     "qsx_join_table_destroy": (_int, [_vp]),
     "qsx_join_table_clear": (_int, [_vp, _vp]),
@@ -200,6 +203,17 @@ def gather(src, tids, out=None, stream=None):
     if out is None:
         out = torch.empty(n, dtype=src.dtype, device=src.device)
     _check(_lib.qsx_gather(src.element_size(), _ptr(src), _ptr(tids), n, _ptr(out), _stream(stream)), "qsx_gather")
+    return out
+
+
+def gather_segmented(segments, first_rows, tids, out=None, stream=None):
+    """K5 over a relation stored as several blocks (tids = relation-global row numbers)."""
+    n = tids.numel()
+    if out is None:
+        out = torch.empty(n, dtype=segments[0].dtype, device=tids.device)
+    starts = (C.c_int64 * len(segments))(*first_rows)
+    _check(_lib.qsx_gather_segmented(segments[0].element_size(), len(segments), _ptr_array(segments), starts,
+                                     _ptr(tids), n, _ptr(out), _stream(stream)), "qsx_gather_segmented")
     return out
 
 

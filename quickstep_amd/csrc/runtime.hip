@@ -106,6 +106,22 @@ int qsx_memset_device(void *dst_dev, int byte, size_t bytes, qsx_stream_t stream
   return QSX_OK;
 }
 
+int qsx_stream_create(qsx_stream_t *out_stream) {
+  QSX_REQUIRE_DEVICE();
+  if (out_stream == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  hipStream_t s;
+  QSX_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *out_stream = reinterpret_cast<qsx_stream_t>(s);
+  return QSX_OK;
+}
+
+int qsx_stream_destroy(qsx_stream_t stream) {
+  if (stream == nullptr) return QSX_OK;
+  QSX_REQUIRE_DEVICE();
+  QSX_HIP_TRY(hipStreamDestroy(qsx::as_stream(stream)));
+  return QSX_OK;
+}
+
 int qsx_stream_synchronize(qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   QSX_HIP_TRY(hipStreamSynchronize(qsx::as_stream(stream)));

@@ -240,6 +240,32 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ sr
   }
 }
 
+constexpr int kMaxSegments = 64;
+struct SegmentTable {
+  int num;
+  const void *ptr[kMaxSegments];
+  int64_t first_row[kMaxSegments];
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_segmented_kernel(SegmentTable seg, const int32_t *__restrict__ tids,
+                                                                  int64_t n, T *__restrict__ dst) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int32_t t = tids[i];
+    if (t < 0) {
+      dst[i] = T();
+      continue;
+    }
+    int lo = 0, hi = seg.num - 1;  // last segment whose first_row <= t
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (seg.first_row[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    dst[i] = static_cast<const T *>(seg.ptr[lo])[t - seg.first_row[lo]];
+  }
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int run_compaction(const GatherArgs &args, const uint64_t *bitmap, int64_t n,
@@ -367,6 +393,32 @@ int qsx_gather(int width, const void *src_dev, const int32_t *tids_dev, int64_t 
     case 2: hipLaunchKernelGGL(gather_kernel<uint16_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint16_t *>(src_dev), tids_dev, n, static_cast<uint16_t *>(dst_dev)); break;
     case 4: hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint32_t *>(src_dev), tids_dev, n, static_cast<uint32_t *>(dst_dev)); break;
     case 8: hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint64_t *>(src_dev), tids_dev, n, static_cast<uint64_t *>(dst_dev)); break;
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_gather_segmented(int width, int num_segments, const void *const *segment_ptrs,
+                         const int64_t *segment_first_row, const int32_t *tids_dev, int64_t n, void *dst_dev,
+                         qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || num_segments < 1 || segment_ptrs == nullptr || segment_first_row == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (num_segments > kMaxSegments) return QSX_ERR_UNSUPPORTED;
+  if (n == 0) return QSX_OK;
+  SegmentTable seg;
+  seg.num = num_segments;
+  for (int i = 0; i < num_segments; ++i) {
+    seg.ptr[i] = segment_ptrs[i];
+    seg.first_row[i] = segment_first_row[i];
+  }
+  const int grid = grid_for(n, kBlock * 4);
+  hipStream_t s = as_stream(stream);
+  switch (width) {
+    case 1: hipLaunchKernelGGL(gather_segmented_kernel<uint8_t>, dim3(grid), dim3(kBlock), 0, s, seg, tids_dev, n, static_cast<uint8_t *>(dst_dev)); break;
+    case 2: hipLaunchKernelGGL(gather_segmented_kernel<uint16_t>, dim3(grid), dim3(kBlock), 0, s, seg, tids_dev, n, static_cast<uint16_t *>(dst_dev)); break;
+    case 4: hipLaunchKernelGGL(gather_segmented_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, seg, tids_dev, n, static_cast<uint32_t *>(dst_dev)); break;
+    case 8: hipLaunchKernelGGL(gather_segmented_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, s, seg, tids_dev, n, static_cast<uint64_t *>(dst_dev)); break;
     default: return QSX_ERR_UNSUPPORTED;
   }
   QSX_CHECK_LAUNCH();

@@ -1,0 +1,866 @@
+// quickstep_gpu.cpp — see quickstep_gpu.hpp.  Every GPU work order body is a
+// short sequence of C-ABI calls (include/qsx.h); INTEGRATION.md lists the same
+// sequences against the reference's own classes.
+#include "quickstep_gpu.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+namespace quickstep {
+
+// ---------------------------------------------------------------------------
+// errors / stream
+// ---------------------------------------------------------------------------
+ExecutionError::ExecutionError(const std::string &where, int status)
+    : std::runtime_error(where + ": " + qsx_status_string(status) + " [" + qsx_last_error() + "]"), status_(status) {}
+
+void CheckStatus(int status, const char *where) {
+  if (status != QSX_OK) throw ExecutionError(where, status);
+}
+
+namespace {
+thread_local qsx_stream_t tls_stream = nullptr;
+
+struct DeviceBuffer {  // scratch owned by one work order
+  void *ptr = nullptr;
+  explicit DeviceBuffer(std::size_t bytes) { CheckStatus(qsx_device_alloc(bytes ? bytes : 8, &ptr), "qsx_device_alloc"); }
+  ~DeviceBuffer() { qsx_device_free(ptr); }
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+};
+
+std::int64_t ReadCount(const void *dev_count) {
+  std::int64_t v = 0;
+  CheckStatus(qsx_copy_to_host(&v, dev_count, sizeof(v), CurrentStream()), "qsx_copy_to_host");
+  return v;
+}
+
+std::uint64_t NowMicros() {
+  return static_cast<std::uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(
+                                        std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+}  // namespace
+
+qsx_stream_t CurrentStream() { return tls_stream; }
+void SetCurrentStream(qsx_stream_t stream) { tls_stream = stream; }
+
+// ---------------------------------------------------------------------------
+// catalog + storage
+// ---------------------------------------------------------------------------
+attribute_id CatalogRelation::addAttribute(const std::string &name, Type type) {
+  names_.push_back(name);
+  types_.push_back(type);
+  return static_cast<attribute_id>(types_.size() - 1);
+}
+attribute_id CatalogRelation::getAttributeByName(const std::string &name) const {
+  for (std::size_t i = 0; i < names_.size(); ++i) {
+    if (names_[i] == name) return static_cast<attribute_id>(i);
+  }
+  return kInvalidAttributeID;
+}
+void CatalogRelation::addBlock(block_id b) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  blocks_.push_back(b);
+}
+std::vector<block_id> CatalogRelation::getBlocksSnapshot() const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  return blocks_;
+}
+
+namespace {
+bool g_host_memory = false;  // CPU plumbing mode (BASELINE config 1): blocks live in host memory
+}
+void UseHostMemoryForBlocks(bool on) { g_host_memory = on; }
+
+StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t capacity, std::int64_t first_row)
+    : relation_(relation), capacity_(capacity), num_tuples_(0), first_row_(first_row) {
+  for (std::size_t a = 0; a < relation.size(); ++a) {
+    void *p = nullptr;
+    const std::size_t bytes = static_cast<std::size_t>(capacity) * relation.getAttributeType(static_cast<attribute_id>(a)).width;
+    if (g_host_memory) {
+      p = std::malloc(bytes ? bytes : 8);
+    } else {
+      CheckStatus(qsx_device_alloc(bytes ? bytes : 8, &p), "qsx_device_alloc(stripe)");
+    }
+    stripes_.push_back(p);
+  }
+}
+StorageBlock::~StorageBlock() {
+  for (void *p : stripes_) {
+    if (g_host_memory) std::free(p); else qsx_device_free(p);
+  }
+}
+void StorageBlock::copyAttributeToHost(attribute_id a, void *dst) const {
+  const std::size_t bytes = static_cast<std::size_t>(num_tuples_) * relation_.getAttributeType(a).width;
+  if (g_host_memory) {
+    std::memcpy(dst, stripes_.at(a), bytes);
+  } else {
+    CheckStatus(qsx_copy_to_host(dst, stripes_.at(a), bytes, CurrentStream()), "qsx_copy_to_host");
+  }
+}
+
+block_id StorageManager::createBlock(CatalogRelation *relation, std::int64_t capacity) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  const block_id id = next_id_++;
+  // first_row is fixed when the block is registered with its final size (returnBlock / loadBlock)
+  blocks_[id] = std::make_shared<StorageBlock>(*relation, capacity, 0);
+  return id;
+}
+
+block_id StorageManager::loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns,
+                                   std::int64_t num_tuples) {
+  BlockReference block;
+  block_id id;
+  {
+    std::lock_guard<std::mutex> lock(mutex_);
+    id = next_id_++;
+    std::int64_t &rows = rows_in_relation_[relation->getID()];
+    block = std::make_shared<StorageBlock>(*relation, num_tuples, rows);
+    rows += num_tuples;
+    blocks_[id] = block;
+  }
+  for (std::size_t a = 0; a < relation->size(); ++a) {
+    const std::size_t bytes = static_cast<std::size_t>(num_tuples) * relation->getAttributeType(static_cast<attribute_id>(a)).width;
+    if (g_host_memory) {
+      std::memcpy(block->stripe(static_cast<attribute_id>(a)), host_columns.at(a), bytes);
+    } else {
+      CheckStatus(qsx_copy_to_device(block->stripe(static_cast<attribute_id>(a)), host_columns.at(a), bytes, nullptr),
+                  "qsx_copy_to_device");
+    }
+  }
+  if (!g_host_memory) CheckStatus(qsx_stream_synchronize(nullptr), "qsx_stream_synchronize");
+  block->setNumTuples(num_tuples);
+  relation->addBlock(id);
+  return id;
+}
+
+BlockReference StorageManager::getBlock(block_id id) const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  auto it = blocks_.find(id);
+  if (it == blocks_.end()) throw std::out_of_range("StorageManager::getBlock: unknown block");
+  return it->second;
+}
+
+std::int64_t StorageManager::reserveRows(relation_id relation, std::int64_t num_tuples) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  std::int64_t &rows = rows_in_relation_[relation];
+  const std::int64_t first = rows;
+  rows += num_tuples;
+  return first;
+}
+
+void StorageManager::deleteBlockOrBlobFile(block_id id) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  blocks_.erase(id);
+}
+
+// ---------------------------------------------------------------------------
+// Predicate
+// ---------------------------------------------------------------------------
+void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num_matches) const {
+  const std::int64_t n = block.numTuples();
+  const std::size_t words = static_cast<std::size_t>((n + 63) / 64);
+  void *current = nullptr, *next = nullptr, *count = nullptr;
+  CheckStatus(qsx_device_alloc(words * 8 + 8, &current), "qsx_device_alloc(bitmap)");
+  CheckStatus(qsx_device_alloc(words * 8 + 8, &next), "qsx_device_alloc(bitmap)");
+  CheckStatus(qsx_device_alloc(8, &count), "qsx_device_alloc(count)");
+  bool first = true;
+  for (const ComparisonPredicate &term : conjuncts) {
+    const Type &t = block.getRelation().getAttributeType(term.attribute);
+    // conjunctions chain the filter through their children (short-circuit)
+    CheckStatus(qsx_select_cmp(t.id, block.stripe(term.attribute), n, static_cast<int>(term.comparison), &term.literal.v,
+                               first ? nullptr : static_cast<const std::uint64_t *>(current),
+                               static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
+                "qsx_select_cmp");
+    std::swap(current, next);
+    first = false;
+  }
+  if (first) {  // empty conjunction: every tuple matches
+    CheckStatus(qsx_memset_device(next, 0xFF, words * 8, CurrentStream()), "qsx_memset_device");
+    CheckStatus(qsx_bitmap_combine(0, static_cast<const std::uint64_t *>(next), static_cast<const std::uint64_t *>(next), n,
+                                   static_cast<std::uint64_t *>(current), CurrentStream()), "qsx_bitmap_combine");
+    CheckStatus(qsx_bitmap_count(static_cast<const std::uint64_t *>(current), n, static_cast<std::int64_t *>(count),
+                                 CurrentStream()), "qsx_bitmap_count");
+  }
+  *num_matches = ReadCount(count);
+  qsx_device_free(next);
+  qsx_device_free(count);
+  return current;
+}
+
+// ---------------------------------------------------------------------------
+// InsertDestination
+// ---------------------------------------------------------------------------
+BlockReference InsertDestination::getBlockForInsertion(std::int64_t capacity, block_id *id) {
+  *id = storage_manager_->createBlock(relation_, capacity);
+  return storage_manager_->getBlock(*id);
+}
+void InsertDestination::returnBlock(block_id id, std::int64_t num_tuples) {
+  BlockReference block = storage_manager_->getBlock(id);
+  block->setNumTuples(num_tuples);
+  block->setFirstRow(storage_manager_->reserveRows(relation_->getID(), num_tuples));
+  std::lock_guard<std::mutex> lock(mutex_);
+  touched_.push_back(id);
+  relation_->addBlock(id);
+}
+std::vector<block_id> InsertDestination::getTouchedBlocks() const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  return touched_;
+}
+
+// ---------------------------------------------------------------------------
+// AggregationOperationState
+// ---------------------------------------------------------------------------
+AggregationOperationState::AggregationOperationState(const AggregationStateSpec &spec) : spec_(spec) {
+  std::memset(&config_, 0, sizeof(config_));
+  const CatalogRelation &rel = *spec.input_relation;
+  auto column_of = [&](attribute_id attr) -> int {
+    for (std::size_t i = 0; i < column_attr_.size(); ++i) {
+      if (column_attr_[i] == attr) return static_cast<int>(i);
+    }
+    if (column_attr_.size() >= QSX_MAX_COLUMNS) throw ExecutionError("AggregationOperationState: too many columns", QSX_ERR_UNSUPPORTED);
+    const Type &t = rel.getAttributeType(attr);
+    config_.column_type[column_attr_.size()] = t.id;
+    config_.column_width[column_attr_.size()] = t.width;
+    column_attr_.push_back(attr);
+    return static_cast<int>(column_attr_.size() - 1);
+  };
+  config_.strategy = spec.group_by.empty() ? QSX_AGG_SINGLE_STATE : spec.strategy;
+  config_.num_keys = static_cast<int>(spec.group_by.size());
+  for (std::size_t k = 0; k < spec.group_by.size(); ++k) config_.key_column[k] = column_of(spec.group_by[k]);
+  config_.num_aggs = static_cast<int>(spec.aggregates.size());
+  for (std::size_t a = 0; a < spec.aggregates.size(); ++a) {
+    const AggregateSpec &ag = spec.aggregates[a];
+    switch (ag.function) {
+      case AggregationID::kCount: config_.aggs[a].fn = QSX_AGG_COUNT_STAR; break;
+      case AggregationID::kSum: config_.aggs[a].fn = QSX_AGG_SUM; break;
+      case AggregationID::kAvg: config_.aggs[a].fn = QSX_AGG_AVG; break;
+    }
+    if (ag.function != AggregationID::kCount) {
+      config_.aggs[a].arg.kind = QSX_OPD_COLUMN;
+      config_.aggs[a].arg.index = column_of(ag.argument);
+    }
+  }
+  if (spec.predicate != nullptr) {
+    config_.num_pred_terms = static_cast<int>(spec.predicate->conjuncts.size());
+    for (std::size_t p = 0; p < spec.predicate->conjuncts.size(); ++p) {
+      const ComparisonPredicate &term = spec.predicate->conjuncts[p];
+      config_.pred[p].column = column_of(term.attribute);
+      config_.pred[p].op = static_cast<int>(term.comparison);
+      std::memcpy(&config_.pred[p].literal, &term.literal.v, sizeof(term.literal.v));
+    }
+  }
+  config_.num_columns = static_cast<int>(column_attr_.size());
+  config_.est_groups = spec.estimated_num_groups;
+  config_.num_entries = spec.collision_free_num_entries;
+  CheckStatus(qsx_agg_state_create(&config_, &state_), "qsx_agg_state_create");
+}
+
+AggregationOperationState::~AggregationOperationState() { qsx_agg_state_destroy(state_); }
+
+void AggregationOperationState::aggregateBlock(const StorageBlock &block) {
+  const void *cols[QSX_MAX_COLUMNS];
+  for (std::size_t i = 0; i < column_attr_.size(); ++i) cols[i] = block.stripe(column_attr_[i]);
+  CheckStatus(qsx_agg_update(state_, cols, block.numTuples(), nullptr, CurrentStream()), "qsx_agg_update");
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+}
+
+void AggregationOperationState::finalizeAggregate(std::size_t partition, std::size_t num_partitions, InsertDestination *dest) {
+  std::int64_t groups = 0;
+  CheckStatus(qsx_agg_num_groups(state_, &groups, CurrentStream()), "qsx_agg_num_groups");
+  block_id id;
+  BlockReference out = dest->getBlockForInsertion(groups > 0 ? groups : 1, &id);
+  void *key_cols[QSX_MAX_KEYS];
+  void *val_cols[QSX_MAX_AGGS];
+  for (int k = 0; k < config_.num_keys; ++k) key_cols[k] = out->stripe(k);
+  for (int a = 0; a < config_.num_aggs; ++a) val_cols[a] = out->stripe(config_.num_keys + a);
+  DeviceBuffer rows(8);
+  CheckStatus(qsx_agg_finalize(state_, static_cast<int>(partition), static_cast<int>(num_partitions), key_cols, val_cols,
+                               nullptr, out->capacity(), static_cast<std::int64_t *>(rows.ptr), CurrentStream()),
+              "qsx_agg_finalize");
+  dest->returnBlock(id, ReadCount(rows.ptr));
+}
+
+// ---------------------------------------------------------------------------
+// QueryContext
+// ---------------------------------------------------------------------------
+QueryContext::~QueryContext() {
+  for (auto &parts : join_tables_) {
+    for (qsx_join_table_t *t : parts) qsx_join_table_destroy(t);
+  }
+}
+QueryContext::predicate_id QueryContext::addPredicate(Predicate p) {
+  predicates_.push_back(std::move(p));
+  return static_cast<predicate_id>(predicates_.size() - 1);
+}
+QueryContext::scalar_group_id QueryContext::addScalarGroup(std::vector<attribute_id> attrs) {
+  scalar_groups_.push_back(std::move(attrs));
+  return static_cast<scalar_group_id>(scalar_groups_.size() - 1);
+}
+QueryContext::join_hash_table_id QueryContext::addJoinHashTable(TypeID key_type, std::int64_t estimated_entries,
+                                                                std::size_t num_partitions) {
+  std::vector<qsx_join_table_t *> parts(num_partitions, nullptr);
+  for (std::size_t p = 0; p < num_partitions; ++p) {
+    CheckStatus(qsx_join_table_create(key_type, estimated_entries, &parts[p]), "qsx_join_table_create");
+  }
+  join_tables_.push_back(std::move(parts));
+  return static_cast<join_hash_table_id>(join_tables_.size() - 1);
+}
+void QueryContext::destroyJoinHashTable(join_hash_table_id id, partition_id part) {
+  qsx_join_table_destroy(join_tables_.at(id).at(part));
+  join_tables_.at(id).at(part) = nullptr;
+}
+QueryContext::aggregation_state_id QueryContext::addAggregationState(const AggregationStateSpec &spec,
+                                                                     std::size_t num_partitions) {
+  std::vector<std::unique_ptr<AggregationOperationState>> parts;
+  for (std::size_t p = 0; p < num_partitions; ++p) parts.emplace_back(new AggregationOperationState(spec));
+  agg_states_.push_back(std::move(parts));
+  return static_cast<aggregation_state_id>(agg_states_.size() - 1);
+}
+QueryContext::insert_destination_id QueryContext::addInsertDestination(CatalogRelation *relation,
+                                                                       StorageManager *storage_manager) {
+  destinations_.emplace_back(new InsertDestination(relation, storage_manager));
+  return static_cast<insert_destination_id>(destinations_.size() - 1);
+}
+
+// ---------------------------------------------------------------------------
+// WorkOrdersContainer
+// ---------------------------------------------------------------------------
+void WorkOrdersContainer::addNormalWorkOrder(WorkOrder *workorder, std::size_t operator_index) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  queues_.at(operator_index).emplace_back(workorder);
+}
+bool WorkOrdersContainer::hasNormalWorkOrder(std::size_t operator_index) const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  return !queues_.at(operator_index).empty();
+}
+WorkOrder *WorkOrdersContainer::getNormalWorkOrder(std::size_t operator_index) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  auto &q = queues_.at(operator_index);
+  if (q.empty()) return nullptr;
+  WorkOrder *wo = q.front().release();
+  q.pop_front();
+  return wo;
+}
+std::size_t WorkOrdersContainer::getNumNormalWorkOrders(std::size_t operator_index) const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  return queues_.at(operator_index).size();
+}
+
+// ---------------------------------------------------------------------------
+// Select
+// ---------------------------------------------------------------------------
+SelectOperator::SelectOperator(std::size_t query_id, const CatalogRelation &input_relation, bool has_repartition,
+                               const CatalogRelation &output_relation,
+                               QueryContext::insert_destination_id output_destination_index,
+                               QueryContext::predicate_id predicate_index, std::vector<attribute_id> &&selection,
+                               bool input_relation_is_stored, bool on_gpu)
+    : RelationalOperator(query_id, 1, has_repartition), input_relation_(input_relation),
+      output_relation_(output_relation), output_destination_index_(output_destination_index),
+      predicate_index_(predicate_index), simple_selection_(std::move(selection)),
+      input_relation_is_stored_(input_relation_is_stored), on_gpu_(on_gpu) {
+  if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
+}
+
+bool SelectOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                      StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
+  // SelectOperator.cpp:47-107: one work order per input block; streaming inputs
+  // generate incrementally and finish when done_feeding_input_relation_.
+  const Predicate *predicate = query_context->getPredicate(predicate_index_);
+  InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
+  std::lock_guard<std::mutex> lock(mutex_);
+  while (num_workorders_generated_ < input_relation_block_ids_.size()) {
+    container->addNormalWorkOrder(new SelectWorkOrder(query_id_, input_relation_block_ids_[num_workorders_generated_],
+                                                      predicate, simple_selection_, dest, storage_manager, on_gpu_),
+                                  op_index_);
+    ++num_workorders_generated_;
+  }
+  return input_relation_is_stored_ || done_feeding_input_relation_;
+}
+
+void SelectWorkOrder::execute() {
+  if (!on_gpu_) {
+    executeOnHost();
+    return;
+  }
+  BlockReference block = storage_manager_->getBlock(input_block_id_);
+  const std::int64_t n = block->numTuples();
+  std::int64_t matches = 0;
+  Predicate all;
+  void *bitmap = (predicate_ != nullptr ? predicate_ : &all)->getMatchesForBlock(*block, &matches);  // getMatchesForPredicate
+  block_id out_id;
+  BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
+  // block->selectSimple(simple_selection_, matches, output_destination_) (StorageBlock.cpp:390-399)
+  std::vector<const void *> src;
+  std::vector<void *> dst;
+  std::vector<std::int32_t> widths;
+  for (std::size_t i = 0; i < simple_selection_.size(); ++i) {
+    src.push_back(block->stripe(simple_selection_[i]));
+    dst.push_back(out->stripe(static_cast<attribute_id>(i)));
+    widths.push_back(block->getRelation().getAttributeType(simple_selection_[i]).width);
+  }
+  const std::size_t ws_bytes = qsx_compact_workspace_bytes(n);
+  DeviceBuffer ws(ws_bytes), count(8);
+  CheckStatus(qsx_compact_gather(static_cast<int>(src.size()), src.data(), widths.data(),
+                                 static_cast<const std::uint64_t *>(bitmap), n, dst.data(),
+                                 static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
+              "qsx_compact_gather");
+  const std::int64_t written = ReadCount(count.ptr);  // synchronises the work order, like the reference's execute()
+  qsx_device_free(bitmap);
+  output_destination_->returnBlock(out_id, written);
+}
+
+// CPU work order of BASELINE config 1: the same plumbing with the loops on the
+// host (blocks in host memory).  Not a fallback: only built by operators that
+// were constructed with on_gpu = false.
+void SelectWorkOrder::executeOnHost() {
+  BlockReference block = storage_manager_->getBlock(input_block_id_);
+  const std::int64_t n = block->numTuples();
+  std::vector<bool> match(static_cast<std::size_t>(n), true);
+  if (predicate_ != nullptr) {
+    for (const ComparisonPredicate &term : predicate_->conjuncts) {
+      const Type &t = block->getRelation().getAttributeType(term.attribute);
+      const char *base = static_cast<const char *>(block->stripe(term.attribute));
+      for (std::int64_t i = 0; i < n; ++i) {
+        if (!match[i]) continue;
+        double a, b;
+        std::int64_t ia = 0, ib = 0;
+        bool is_int = true;
+        switch (t.id) {
+          case kInt: ia = reinterpret_cast<const std::int32_t *>(base)[i]; ib = term.literal.v.i32; break;
+          case kLong: ia = reinterpret_cast<const std::int64_t *>(base)[i]; ib = term.literal.v.i64; break;
+          case kFloat: is_int = false; a = reinterpret_cast<const float *>(base)[i]; b = term.literal.v.f32; break;
+          default: is_int = false; a = reinterpret_cast<const double *>(base)[i]; b = term.literal.v.f64; break;
+        }
+        bool r;
+        switch (term.comparison) {
+          case ComparisonID::kEqual: r = is_int ? ia == ib : a == b; break;
+          case ComparisonID::kNotEqual: r = is_int ? ia != ib : a != b; break;
+          case ComparisonID::kLess: r = is_int ? ia < ib : a < b; break;
+          case ComparisonID::kLessOrEqual: r = is_int ? ia <= ib : a <= b; break;
+          case ComparisonID::kGreater: r = is_int ? ia > ib : a > b; break;
+          default: r = is_int ? ia >= ib : a >= b; break;
+        }
+        match[i] = r;
+      }
+    }
+  }
+  std::int64_t matches = 0;
+  for (std::int64_t i = 0; i < n; ++i) matches += match[i];
+  block_id out_id;
+  BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
+  for (std::size_t c = 0; c < simple_selection_.size(); ++c) {
+    const int w = block->getRelation().getAttributeType(simple_selection_[c]).width;
+    const char *src = static_cast<const char *>(block->stripe(simple_selection_[c]));
+    char *dst = static_cast<char *>(out->stripe(static_cast<attribute_id>(c)));
+    std::int64_t o = 0;
+    for (std::int64_t i = 0; i < n; ++i) {
+      if (match[i]) std::memcpy(dst + (o++) * w, src + i * w, w);
+    }
+  }
+  output_destination_->returnBlock(out_id, matches);
+}
+
+// ---------------------------------------------------------------------------
+// BuildHash
+// ---------------------------------------------------------------------------
+BuildHashOperator::BuildHashOperator(std::size_t query_id, const CatalogRelation &input_relation,
+                                     bool input_relation_is_stored, const std::vector<attribute_id> &join_key_attributes,
+                                     bool, std::size_t num_partitions, QueryContext::join_hash_table_id hash_table_index,
+                                     QueryContext::predicate_id build_predicate_index)
+    : RelationalOperator(query_id, num_partitions), input_relation_(input_relation),
+      input_relation_is_stored_(input_relation_is_stored), join_key_attributes_(join_key_attributes),
+      hash_table_index_(hash_table_index), build_predicate_index_(build_predicate_index) {
+  if (join_key_attributes.size() != 1) {
+    throw ExecutionError("BuildHashOperator: only single-attribute INT/LONG keys are on the GPU path", QSX_ERR_UNSUPPORTED);
+  }
+  if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
+}
+
+bool BuildHashOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                         StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
+  const Predicate *predicate = query_context->getPredicate(build_predicate_index_);
+  qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, 0);
+  std::lock_guard<std::mutex> lock(mutex_);
+  while (num_workorders_generated_ < input_relation_block_ids_.size()) {
+    container->addNormalWorkOrder(new BuildHashWorkOrder(query_id_, input_relation_, join_key_attributes_.front(),
+                                                         input_relation_block_ids_[num_workorders_generated_], predicate,
+                                                         table, storage_manager),
+                                  op_index_);
+    ++num_workorders_generated_;
+  }
+  return input_relation_is_stored_ || done_feeding_input_relation_;
+}
+
+void BuildHashWorkOrder::execute() {
+  BlockReference block = storage_manager_->getBlock(build_block_id_);
+  void *bitmap = nullptr;
+  if (predicate_ != nullptr) {
+    std::int64_t matches = 0;
+    bitmap = predicate_->getMatchesForBlock(*block, &matches);
+  }
+  // hash_table_->putValueAccessor(accessor, key_attr, nullable, &TupleReferenceGenerator) (:192-203);
+  // the stored reference is the relation-global row number of the tuple.
+  CheckStatus(qsx_join_build(hash_table_, block->stripe(join_key_attribute_), block->numTuples(),
+                             static_cast<std::int32_t>(block->firstRow()), static_cast<const std::uint64_t *>(bitmap),
+                             CurrentStream()), "qsx_join_build");
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+  qsx_device_free(bitmap);
+}
+
+// ---------------------------------------------------------------------------
+// HashJoin
+// ---------------------------------------------------------------------------
+HashJoinOperator::HashJoinOperator(std::size_t query_id, const CatalogRelation &build_relation,
+                                   const CatalogRelation &probe_relation, bool probe_relation_is_stored,
+                                   const std::vector<attribute_id> &join_key_attributes, bool, std::size_t num_partitions,
+                                   bool has_repartition, const CatalogRelation &output_relation,
+                                   QueryContext::insert_destination_id output_destination_index,
+                                   QueryContext::join_hash_table_id hash_table_index, QueryContext::predicate_id,
+                                   QueryContext::scalar_group_id selection_index,
+                                   const std::vector<bool> *is_selection_on_build, JoinType join_type)
+    : RelationalOperator(query_id, num_partitions, has_repartition), build_relation_(build_relation),
+      probe_relation_(probe_relation), probe_relation_is_stored_(probe_relation_is_stored),
+      join_key_attributes_(join_key_attributes), output_relation_(output_relation),
+      output_destination_index_(output_destination_index), hash_table_index_(hash_table_index),
+      selection_index_(selection_index), join_type_(join_type) {
+  if (join_key_attributes.size() != 1) {
+    throw ExecutionError("HashJoinOperator: only single-attribute INT/LONG keys are on the GPU path", QSX_ERR_UNSUPPORTED);
+  }
+  if (is_selection_on_build != nullptr) is_selection_on_build_ = *is_selection_on_build;
+  if (probe_relation_is_stored) probe_relation_block_ids_ = probe_relation.getBlocksSnapshot();
+}
+
+bool HashJoinOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                        StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
+  const std::vector<attribute_id> &selection = query_context->getScalarGroup(selection_index_);
+  if (is_selection_on_build_.empty()) is_selection_on_build_.assign(selection.size(), false);
+  qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, 0);
+  InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
+  std::lock_guard<std::mutex> lock(mutex_);
+  while (num_workorders_generated_ < probe_relation_block_ids_.size()) {
+    container->addNormalWorkOrder(
+        new HashInnerJoinWorkOrder(query_id_, build_relation_, probe_relation_, join_key_attributes_.front(),
+                                   probe_relation_block_ids_[num_workorders_generated_], selection, is_selection_on_build_,
+                                   join_type_, table, dest, storage_manager),
+        op_index_);
+    ++num_workorders_generated_;
+  }
+  return probe_relation_is_stored_ || done_feeding_input_relation_;
+}
+
+void HashInnerJoinWorkOrder::execute() {
+  BlockReference probe = storage_manager_->getBlock(block_id_);
+  const std::int64_t n = probe->numTuples();
+  const void *keys = probe->stripe(join_key_attribute_);
+  DeviceBuffer count(8);
+  if (join_type_ != HashJoinOperator::JoinType::kInnerJoin) {
+    // HashSemiJoinWorkOrder / HashAntiJoinWorkOrder without residual predicate (:795-816, :860-877):
+    // existence bitmap over the probe block, then project the probe attributes.
+    DeviceBuffer bitmap(static_cast<std::size_t>((n + 63) / 64) * 8 + 8);
+    CheckStatus(qsx_join_probe_exists(hash_table_, keys, n, nullptr,
+                                      join_type_ == HashJoinOperator::JoinType::kLeftAntiJoin ? 1 : 0,
+                                      static_cast<std::uint64_t *>(bitmap.ptr), static_cast<std::int64_t *>(count.ptr),
+                                      CurrentStream()), "qsx_join_probe_exists");
+    const std::int64_t matches = ReadCount(count.ptr);
+    block_id out_id;
+    BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
+    std::vector<const void *> src;
+    std::vector<void *> dst;
+    std::vector<std::int32_t> widths;
+    for (std::size_t i = 0; i < selection_.size(); ++i) {
+      src.push_back(probe->stripe(selection_[i]));
+      dst.push_back(out->stripe(static_cast<attribute_id>(i)));
+      widths.push_back(probe_relation_.getAttributeType(selection_[i]).width);
+    }
+    const std::size_t ws_bytes = qsx_compact_workspace_bytes(n);
+    DeviceBuffer ws(ws_bytes);
+    CheckStatus(qsx_compact_gather(static_cast<int>(src.size()), src.data(), widths.data(),
+                                   static_cast<const std::uint64_t *>(bitmap.ptr), n, dst.data(),
+                                   static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
+                "qsx_compact_gather");
+    output_destination_->returnBlock(out_id, ReadCount(count.ptr));
+    return;
+  }
+  // hash_table_.getAllFromValueAccessor(accessor, key, nullable, &collector) (:480-485)
+  CheckStatus(qsx_join_probe_count(hash_table_, keys, n, nullptr, static_cast<std::int64_t *>(count.ptr), CurrentStream()),
+              "qsx_join_probe_count");
+  const std::int64_t matches = ReadCount(count.ptr);
+  DeviceBuffer probe_tids(static_cast<std::size_t>(matches) * 4 + 8), build_tids(static_cast<std::size_t>(matches) * 4 + 8);
+  CheckStatus(qsx_join_probe(hash_table_, keys, n, /*probe_base_tid=*/0, nullptr, static_cast<std::int32_t *>(probe_tids.ptr),
+                             static_cast<std::int32_t *>(build_tids.ptr), matches, static_cast<std::int64_t *>(count.ptr),
+                             CurrentStream()), "qsx_join_probe");
+  block_id out_id;
+  BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
+  // the build relation as gather segments (one per build block; :494-540 loops over build blocks instead)
+  std::vector<block_id> build_blocks = build_relation_.getBlocksSnapshot();
+  std::vector<BlockReference> build_refs;
+  for (block_id b : build_blocks) build_refs.push_back(storage_manager_->getBlock(b));
+  std::sort(build_refs.begin(), build_refs.end(),
+            [](const BlockReference &a, const BlockReference &b) { return a->firstRow() < b->firstRow(); });
+  std::vector<std::int64_t> first_rows;
+  for (const BlockReference &b : build_refs) first_rows.push_back(b->firstRow());
+  for (std::size_t i = 0; i < selection_.size(); ++i) {
+    // Scalar::getAllValuesForJoin (:529-536)
+    void *dst = out->stripe(static_cast<attribute_id>(i));
+    if (is_selection_on_build_[i]) {
+      std::vector<const void *> segs;
+      for (const BlockReference &b : build_refs) segs.push_back(b->stripe(selection_[i]));
+      CheckStatus(qsx_gather_segmented(build_relation_.getAttributeType(selection_[i]).width, static_cast<int>(segs.size()),
+                                       segs.data(), first_rows.data(), static_cast<const std::int32_t *>(build_tids.ptr),
+                                       matches, dst, CurrentStream()), "qsx_gather_segmented");
+    } else {
+      CheckStatus(qsx_gather(probe_relation_.getAttributeType(selection_[i]).width, probe->stripe(selection_[i]),
+                             static_cast<const std::int32_t *>(probe_tids.ptr), matches, dst, CurrentStream()),
+                  "qsx_gather");
+    }
+  }
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+  output_destination_->returnBlock(out_id, matches);  // output_destination_->bulkInsertTuples(&temp_result) (:539)
+}
+
+namespace {
+class DestroyHashWorkOrder : public WorkOrder {
+ public:
+  DestroyHashWorkOrder(std::size_t query_id, QueryContext::join_hash_table_id id, QueryContext *ctx)
+      : WorkOrder(query_id), id_(id), ctx_(ctx) {}
+  void execute() override { ctx_->destroyJoinHashTable(id_, 0); }  // DestroyHashOperator.cpp:70-72
+ private:
+  QueryContext::join_hash_table_id id_;
+  QueryContext *ctx_;
+};
+class AggregationWorkOrder : public WorkOrder {
+ public:
+  AggregationWorkOrder(std::size_t query_id, block_id input_block_id, AggregationOperationState *state,
+                       StorageManager *storage_manager)
+      : WorkOrder(query_id), input_block_id_(input_block_id), state_(state), storage_manager_(storage_manager) {}
+  void execute() override { state_->aggregateBlock(*storage_manager_->getBlock(input_block_id_)); }  // AggregationOperator.cpp:124-126
+ private:
+  block_id input_block_id_;
+  AggregationOperationState *state_;
+  StorageManager *storage_manager_;
+};
+class FinalizeAggregationWorkOrder : public WorkOrder {
+ public:
+  FinalizeAggregationWorkOrder(std::size_t query_id, std::size_t part, std::size_t num_parts,
+                               AggregationOperationState *state, InsertDestination *dest)
+      : WorkOrder(query_id), part_(part), num_parts_(num_parts), state_(state), dest_(dest) {}
+  void execute() override { state_->finalizeAggregate(part_, num_parts_, dest_); }  // FinalizeAggregationOperator.cpp:99-101
+ private:
+  std::size_t part_, num_parts_;
+  AggregationOperationState *state_;
+  InsertDestination *dest_;
+};
+class DestroyAggregationStateWorkOrder : public WorkOrder {
+ public:
+  DestroyAggregationStateWorkOrder(std::size_t query_id, QueryContext::aggregation_state_id id, QueryContext *ctx)
+      : WorkOrder(query_id), id_(id), ctx_(ctx) {}
+  void execute() override { ctx_->destroyAggregationState(id_, 0); }
+ private:
+  QueryContext::aggregation_state_id id_;
+  QueryContext *ctx_;
+};
+}  // namespace
+
+bool DestroyHashOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *,
+                                           const tmb::client_id, tmb::MessageBus *) {
+  if (!work_generated_) {
+    work_generated_ = true;
+    container->addNormalWorkOrder(new DestroyHashWorkOrder(query_id_, hash_table_index_, query_context), op_index_);
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// Aggregation
+// ---------------------------------------------------------------------------
+AggregationOperator::AggregationOperator(std::size_t query_id, const CatalogRelation &input_relation,
+                                         bool input_relation_is_stored, QueryContext::aggregation_state_id aggr_state_index,
+                                         std::size_t num_partitions)
+    : RelationalOperator(query_id, num_partitions), input_relation_(input_relation),
+      input_relation_is_stored_(input_relation_is_stored), aggr_state_index_(aggr_state_index) {
+  if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
+}
+
+bool AggregationOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                           StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
+  AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, 0);
+  std::lock_guard<std::mutex> lock(mutex_);
+  while (num_workorders_generated_ < input_relation_block_ids_.size()) {
+    container->addNormalWorkOrder(new AggregationWorkOrder(query_id_, input_relation_block_ids_[num_workorders_generated_],
+                                                           state, storage_manager), op_index_);
+    ++num_workorders_generated_;
+  }
+  return input_relation_is_stored_ || done_feeding_input_relation_;
+}
+
+bool FinalizeAggregationOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                                   StorageManager *, const tmb::client_id, tmb::MessageBus *) {
+  if (!started_) {
+    started_ = true;
+    AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, 0);
+    InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
+    // num_partitions x aggr_state_num_partitions work orders (FinalizeAggregationOperator.cpp:48-66)
+    for (std::size_t p = 0; p < aggr_state_num_partitions_; ++p) {
+      container->addNormalWorkOrder(new FinalizeAggregationWorkOrder(query_id_, p, aggr_state_num_partitions_, state, dest),
+                                    op_index_);
+    }
+  }
+  return true;
+}
+
+bool DestroyAggregationStateOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                                       StorageManager *, const tmb::client_id, tmb::MessageBus *) {
+  if (!work_generated_) {
+    work_generated_ = true;
+    container->addNormalWorkOrder(new DestroyAggregationStateWorkOrder(query_id_, aggr_state_index_, query_context), op_index_);
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// QueryPlan / Foreman / Worker
+// ---------------------------------------------------------------------------
+std::size_t QueryPlan::addRelationalOperator(RelationalOperator *op) {
+  operators_.emplace_back(op);
+  deps_.emplace_back();
+  op->setOperatorIndex(operators_.size() - 1);
+  return operators_.size() - 1;
+}
+void QueryPlan::addDirectDependency(std::size_t consumer, std::size_t producer, bool is_pipeline_breaker) {
+  deps_.at(consumer).push_back(Edge{producer, is_pipeline_breaker});
+}
+
+ForemanSingleNode::ForemanSingleNode(QueryPlan *plan, QueryContext *query_context, StorageManager *storage_manager,
+                                     std::size_t num_workers)
+    : plan_(plan), query_context_(query_context), storage_manager_(storage_manager),
+      num_workers_(num_workers ? num_workers : 1), outstanding_(plan->size(), 0) {}
+
+void ForemanSingleNode::workerMain(std::size_t worker_id) {
+  // Worker::run (query_execution/Worker.cpp:54-99): receive a work order, execute(), report completion.
+  qsx_stream_t stream = nullptr;
+  if (qsx_device_count() > 0) CheckStatus(qsx_stream_create(&stream), "qsx_stream_create");
+  SetCurrentStream(stream);
+  for (;;) {
+    Item item;
+    {
+      std::unique_lock<std::mutex> lock(mutex_);
+      cv_work_.wait(lock, [&] { return shutting_down_ || !ready_.empty(); });
+      if (ready_.empty()) break;
+      item = ready_.front();
+      ready_.pop_front();
+    }
+    std::unique_ptr<WorkOrder> wo(item.wo);
+    const std::uint64_t start = NowMicros();
+    std::string error;
+    try {
+      wo->execute();
+    } catch (const std::exception &e) {
+      error = e.what();
+    }
+    wo.reset();
+    const std::uint64_t end = NowMicros();
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      --outstanding_[item.op];
+      profile_.push_back(WorkOrderTimeEntry{worker_id, item.op, start, end});
+      if (!error.empty() && worker_error_.empty()) worker_error_ = error;
+    }
+    cv_done_.notify_all();
+  }
+  if (stream != nullptr) qsx_stream_destroy(stream);
+}
+
+void ForemanSingleNode::run() {
+  const std::size_t N = plan_->size();
+  WorkOrdersContainer container(N);
+  std::vector<bool> done_generating(N, false), finished(N, false);
+  std::vector<std::size_t> blocks_fed(N, 0);  // per producer: output blocks already fed downstream
+  std::vector<std::thread> workers;
+  for (std::size_t w = 0; w < num_workers_; ++w) workers.emplace_back(&ForemanSingleNode::workerMain, this, w);
+
+  auto shutdown = [&]() {
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      shutting_down_ = true;
+    }
+    cv_work_.notify_all();
+    for (auto &t : workers) t.join();
+  };
+
+  try {
+    for (;;) {
+      std::unique_lock<std::mutex> lock(mutex_);
+      if (!worker_error_.empty()) throw std::runtime_error("work order failed: " + worker_error_);
+      bool progress = false;
+      for (std::size_t op = 0; op < N; ++op) {
+        if (finished[op]) continue;
+        bool blocked = false, producers_finished = true;
+        for (const QueryPlan::Edge &e : plan_->dependencies(op)) {
+          if (!finished[e.producer]) {
+            producers_finished = false;
+            if (e.breaker) blocked = true;
+          }
+        }
+        if (!blocked && !done_generating[op]) {
+          // only the Foreman thread ever calls getAllWorkOrders (SURVEY §8b Threading)
+          lock.unlock();
+          const bool done = plan_->getOperator(op)->getAllWorkOrders(&container, query_context_, storage_manager_, 0, &bus_);
+          lock.lock();
+          while (WorkOrder *wo = container.getNormalWorkOrder(op)) {
+            ready_.push_back(Item{wo, op});
+            ++outstanding_[op];
+            progress = true;
+          }
+          if (done) done_generating[op] = true;
+        }
+        // pipelining: feed newly produced output blocks to streaming consumers (kDataPipelineMessage)
+        RelationalOperator *producer = plan_->getOperator(op);
+        const QueryContext::insert_destination_id dest_id = producer->getInsertDestinationID();
+        if (dest_id != QueryContext::kInvalidInsertDestinationId) {
+          const std::vector<block_id> touched = query_context_->getInsertDestination(dest_id)->getTouchedBlocks();
+          for (; blocks_fed[op] < touched.size(); ++blocks_fed[op]) {
+            for (std::size_t consumer = 0; consumer < N; ++consumer) {
+              for (const QueryPlan::Edge &e : plan_->dependencies(consumer)) {
+                if (e.producer == op && !e.breaker) {
+                  plan_->getOperator(consumer)->feedInputBlock(touched[blocks_fed[op]], producer->getOutputRelationID(), 0);
+                  progress = true;
+                }
+              }
+            }
+          }
+        }
+        if (done_generating[op] && outstanding_[op] == 0 && producers_finished && container.getNumNormalWorkOrders(op) == 0) {
+          // re-check that no block appeared between the scan above and now
+          if (dest_id == QueryContext::kInvalidInsertDestinationId ||
+              blocks_fed[op] == query_context_->getInsertDestination(dest_id)->getTouchedBlocks().size()) {
+            finished[op] = true;
+            progress = true;
+            for (std::size_t consumer = 0; consumer < N; ++consumer) {
+              for (const QueryPlan::Edge &e : plan_->dependencies(consumer)) {
+                if (e.producer == op && !e.breaker) {
+                  plan_->getOperator(consumer)->doneFeedingInputBlocks(producer->getOutputRelationID());
+                }
+              }
+            }
+          }
+        }
+      }
+      if (std::all_of(finished.begin(), finished.end(), [](bool f) { return f; })) break;
+      if (progress) {
+        lock.unlock();
+        cv_work_.notify_all();
+        continue;
+      }
+      cv_done_.wait_for(lock, std::chrono::milliseconds(50));
+    }
+  } catch (...) {
+    shutdown();
+    throw;
+  }
+  shutdown();
+}
+
+}  // namespace quickstep

@@ -1,0 +1,651 @@
+// quickstep_gpu.hpp — host side of the drop-in: the reference's operator /
+// work-order interface for the hot path, with work orders that call the HIP
+// execution kernel through the C ABI (include/qsx.h) and nothing else.
+//
+// Mirrors (same names, argument meaning and call protocol; paths in the Quickstep tree):
+//   RelationalOperator            relational_operators/RelationalOperator.hpp:55-334
+//   WorkOrder                     relational_operators/WorkOrder.hpp:53-335
+//   WorkOrdersContainer           query_execution/WorkOrdersContainer.hpp:243
+//   QueryContext                  query_execution/QueryContext.hpp:190-451
+//   SelectOperator/WorkOrder      relational_operators/SelectOperator.hpp:69-386
+//   BuildHashOperator/WorkOrder   relational_operators/BuildHashOperator.hpp:66-277
+//   HashJoinOperator/WorkOrder    relational_operators/HashJoinOperator.hpp:66-438
+//   AggregationOperator           relational_operators/AggregationOperator.hpp:53-187
+//   FinalizeAggregationOperator   relational_operators/FinalizeAggregationOperator.hpp:52-163
+//   DestroyHashOperator, DestroyAggregationStateOperator
+//   ForemanSingleNode / Worker    query_execution/ForemanSingleNode.cpp:102-178, Worker.cpp:54-139
+// What is NOT rebuilt: catalog persistence, buffer manager, TMB, protobuf
+// (de)serialisation, optimizer.  CatalogRelation / StorageManager /
+// InsertDestination here are the minimum those operators need: device-resident
+// column-store blocks.
+#ifndef QUICKSTEP_AMD_HOST_QUICKSTEP_GPU_HPP_
+#define QUICKSTEP_AMD_HOST_QUICKSTEP_GPU_HPP_
+
+#include <atomic>
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/qsx.h"
+
+namespace tmb {
+typedef std::uint32_t client_id;  // stand-in: scheduler messages never carry data
+class MessageBus {};
+}  // namespace tmb
+
+namespace quickstep {
+
+typedef int attribute_id;
+typedef int tuple_id;
+typedef int relation_id;
+typedef std::uint64_t block_id;
+typedef std::size_t partition_id;
+typedef int numa_node_id;
+
+constexpr attribute_id kInvalidAttributeID = -1;
+
+// types/TypeID.hpp:32-43 (numbering shared with qsx_type_t)
+enum TypeID { kInt = 0, kLong = 1, kFloat = 2, kDouble = 3, kChar = 4 };
+// types/operations/comparisons/ComparisonID.hpp:36-42
+enum class ComparisonID { kEqual = 0, kNotEqual, kLess, kLessOrEqual, kGreater, kGreaterOrEqual };
+// expressions/aggregation/AggregationID.hpp
+enum class AggregationID { kCount, kSum, kAvg };
+
+struct Type {
+  TypeID id;
+  int width;  // bytes
+  static Type Int() { return {kInt, 4}; }
+  static Type Long() { return {kLong, 8}; }
+  static Type Float() { return {kFloat, 4}; }
+  static Type Double() { return {kDouble, 8}; }
+  static Type Char(int n) { return {kChar, n}; }
+};
+
+// Error raised when the C ABI reports a failure: the reference aborts with
+// LOG(FATAL) on invariant violations (BuildHashOperator.cpp:205-206); an
+// exception keeps test processes alive.
+class ExecutionError : public std::runtime_error {
+ public:
+  ExecutionError(const std::string &where, int status);
+  int status() const { return status_; }
+ private:
+  int status_;
+};
+void CheckStatus(int status, const char *where);
+
+// CPU plumbing mode (BASELINE config 1: "CPU reference WorkOrder, no GPU"): blocks are kept in
+// host memory.  Set before any block is created; GPU work orders must not be used in this mode.
+void UseHostMemoryForBlocks(bool on);
+
+// The stream of the calling Worker thread (nullptr = default stream).
+qsx_stream_t CurrentStream();
+void SetCurrentStream(qsx_stream_t stream);
+
+// ---------------------------------------------------------------------------
+// catalog + storage (minimum)
+// ---------------------------------------------------------------------------
+class CatalogRelation {
+ public:
+  CatalogRelation(relation_id id, std::string name) : id_(id), name_(std::move(name)) {}
+  attribute_id addAttribute(const std::string &name, Type type);
+  relation_id getID() const { return id_; }
+  const std::string &getName() const { return name_; }
+  std::size_t size() const { return types_.size(); }
+  const Type &getAttributeType(attribute_id a) const { return types_.at(a); }
+  attribute_id getAttributeByName(const std::string &name) const;
+  void addBlock(block_id b);
+  std::vector<block_id> getBlocksSnapshot() const;
+
+ private:
+  relation_id id_;
+  std::string name_;
+  std::vector<std::string> names_;
+  std::vector<Type> types_;
+  mutable std::mutex mutex_;
+  std::vector<block_id> blocks_;
+};
+
+// One device-resident BasicColumnStore block: a dense stripe per attribute
+// (storage/BasicColumnStoreTupleStorageSubBlock.cpp:100-183).
+class StorageBlock {
+ public:
+  StorageBlock(const CatalogRelation &relation, std::int64_t capacity, std::int64_t first_row);
+  ~StorageBlock();
+  const CatalogRelation &getRelation() const { return relation_; }
+  std::int64_t numTuples() const { return num_tuples_; }
+  void setNumTuples(std::int64_t n) { num_tuples_ = n; }
+  std::int64_t capacity() const { return capacity_; }
+  std::int64_t firstRow() const { return first_row_; }  // relation-global row number of tuple 0
+  void setFirstRow(std::int64_t r) { first_row_ = r; }
+  void *stripe(attribute_id a) const { return stripes_.at(a); }
+  void copyAttributeToHost(attribute_id a, void *dst) const;
+
+ private:
+  const CatalogRelation &relation_;
+  std::int64_t capacity_;
+  std::int64_t num_tuples_;
+  std::int64_t first_row_;
+  std::vector<void *> stripes_;
+};
+typedef std::shared_ptr<StorageBlock> BlockReference;
+
+class StorageManager {
+ public:
+  StorageManager() = default;
+  // Create an empty block with room for `capacity` tuples; first_row = rows already in the relation.
+  block_id createBlock(CatalogRelation *relation, std::int64_t capacity);
+  // Create a block from host columns (one pointer per attribute), copy to HBM and add it to the relation.
+  block_id loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns, std::int64_t num_tuples);
+  BlockReference getBlock(block_id id) const;
+  void deleteBlockOrBlobFile(block_id id);
+  // Registers `num_tuples` more rows of `relation`; returns the relation-global row number of the first one.
+  std::int64_t reserveRows(relation_id relation, std::int64_t num_tuples);
+
+ private:
+  mutable std::mutex mutex_;
+  std::unordered_map<block_id, BlockReference> blocks_;
+  std::unordered_map<relation_id, std::int64_t> rows_in_relation_;
+  block_id next_id_ = 1;
+};
+
+// ---------------------------------------------------------------------------
+// expressions (attribute-vs-literal comparisons, attribute projections)
+// ---------------------------------------------------------------------------
+struct TypedLiteral {
+  TypeID type;
+  union { std::int32_t i32; std::int64_t i64; float f32; double f64; } v;
+  static TypedLiteral Int(std::int32_t x) { TypedLiteral l; l.type = kInt; l.v.i64 = 0; l.v.i32 = x; return l; }
+  static TypedLiteral Long(std::int64_t x) { TypedLiteral l; l.type = kLong; l.v.i64 = x; return l; }
+  static TypedLiteral Float(float x) { TypedLiteral l; l.type = kFloat; l.v.i64 = 0; l.v.f32 = x; return l; }
+  static TypedLiteral Double(double x) { TypedLiteral l; l.type = kDouble; l.v.f64 = x; return l; }
+};
+
+// ComparisonPredicate attr OP literal (expressions/predicate/ComparisonPredicate.cpp:115-334);
+// a Predicate is a conjunction of those.
+struct ComparisonPredicate {
+  attribute_id attribute;
+  ComparisonID comparison;
+  TypedLiteral literal;
+};
+struct Predicate {
+  std::vector<ComparisonPredicate> conjuncts;
+  // TupleIdSequence of the matching tuples of `block` (StorageBlock::getMatchesForPredicate).
+  // Returns a device bitmap owned by the caller (qsx_device_free) and the match count.
+  void *getMatchesForBlock(const StorageBlock &block, std::int64_t *num_matches) const;
+};
+
+// ---------------------------------------------------------------------------
+// InsertDestination (storage/InsertDestination.hpp:75-340): output sink
+// ---------------------------------------------------------------------------
+class InsertDestination {
+ public:
+  InsertDestination(CatalogRelation *relation, StorageManager *storage_manager)
+      : relation_(relation), storage_manager_(storage_manager) {}
+  const CatalogRelation &getRelation() const { return *relation_; }
+  // A block with room for `capacity` tuples; hand it back with returnBlock once filled.
+  BlockReference getBlockForInsertion(std::int64_t capacity, block_id *id);
+  void returnBlock(block_id id, std::int64_t num_tuples);
+  std::vector<block_id> getTouchedBlocks() const;
+
+ private:
+  CatalogRelation *relation_;
+  StorageManager *storage_manager_;
+  mutable std::mutex mutex_;
+  std::vector<block_id> touched_;
+};
+
+// ---------------------------------------------------------------------------
+// aggregation state description (storage/AggregationOperationState.cpp:74-252)
+// ---------------------------------------------------------------------------
+struct AggregateSpec {
+  AggregationID function;
+  attribute_id argument;  // kInvalidAttributeID for COUNT(*)
+};
+struct AggregationStateSpec {
+  const CatalogRelation *input_relation = nullptr;
+  std::vector<attribute_id> group_by;
+  std::vector<AggregateSpec> aggregates;
+  const Predicate *predicate = nullptr;  // the state owns the predicate in the reference (:440-445)
+  qsx_agg_strategy_t strategy = QSX_AGG_GENERIC;
+  std::int64_t estimated_num_groups = 16;
+  std::int64_t collision_free_num_entries = 0;
+};
+
+class AggregationOperationState {
+ public:
+  explicit AggregationOperationState(const AggregationStateSpec &spec);
+  ~AggregationOperationState();
+  void aggregateBlock(const StorageBlock &block);                       // :428-474
+  void finalizeAggregate(std::size_t partition, std::size_t num_partitions, InsertDestination *dest);  // :641-694
+  const AggregationStateSpec &spec() const { return spec_; }
+
+ private:
+  AggregationStateSpec spec_;
+  qsx_agg_config_t config_;
+  qsx_agg_state_t *state_ = nullptr;
+  std::vector<attribute_id> column_attr_;  // config column -> input attribute
+};
+
+// ---------------------------------------------------------------------------
+// QueryContext (query_execution/QueryContext.hpp:190-451)
+// ---------------------------------------------------------------------------
+class QueryContext {
+ public:
+  typedef std::uint32_t predicate_id;
+  typedef std::uint32_t scalar_group_id;
+  typedef std::uint32_t join_hash_table_id;
+  typedef std::uint32_t aggregation_state_id;
+  typedef std::uint32_t insert_destination_id;
+  static constexpr predicate_id kInvalidPredicateId = static_cast<predicate_id>(-1);
+  static constexpr insert_destination_id kInvalidInsertDestinationId = static_cast<insert_destination_id>(-1);
+
+  ~QueryContext();
+  predicate_id addPredicate(Predicate p);
+  scalar_group_id addScalarGroup(std::vector<attribute_id> attrs);  // attribute projections only
+  join_hash_table_id addJoinHashTable(TypeID key_type, std::int64_t estimated_entries, std::size_t num_partitions = 1);
+  aggregation_state_id addAggregationState(const AggregationStateSpec &spec, std::size_t num_partitions = 1);
+  insert_destination_id addInsertDestination(CatalogRelation *relation, StorageManager *storage_manager);
+
+  const Predicate *getPredicate(predicate_id id) const { return id == kInvalidPredicateId ? nullptr : &predicates_.at(id); }
+  const std::vector<attribute_id> &getScalarGroup(scalar_group_id id) const { return scalar_groups_.at(id); }
+  qsx_join_table_t *getJoinHashTable(join_hash_table_id id, partition_id part = 0) const { return join_tables_.at(id).at(part); }
+  void destroyJoinHashTable(join_hash_table_id id, partition_id part = 0);
+  AggregationOperationState *getAggregationState(aggregation_state_id id, partition_id part = 0) const {
+    return agg_states_.at(id).at(part).get();
+  }
+  void destroyAggregationState(aggregation_state_id id, partition_id part = 0) { agg_states_.at(id).at(part).reset(); }
+  InsertDestination *getInsertDestination(insert_destination_id id) const { return destinations_.at(id).get(); }
+
+ private:
+  std::vector<Predicate> predicates_;
+  std::vector<std::vector<attribute_id>> scalar_groups_;
+  std::vector<std::vector<qsx_join_table_t *>> join_tables_;
+  std::vector<std::vector<std::unique_ptr<AggregationOperationState>>> agg_states_;
+  std::vector<std::unique_ptr<InsertDestination>> destinations_;
+};
+
+// ---------------------------------------------------------------------------
+// WorkOrder / container / RelationalOperator
+// ---------------------------------------------------------------------------
+class WorkOrder {
+ public:
+  virtual ~WorkOrder() {}
+  virtual void execute() = 0;                                            // WorkOrder.hpp:251
+  const std::vector<int> &getPreferredNUMANodes() const { return preferred_numa_nodes_; }  // :260
+  std::size_t getQueryID() const { return query_id_; }
+  partition_id getPartitionId() const { return partition_id_; }
+
+ protected:
+  explicit WorkOrder(std::size_t query_id, partition_id part_id = 0) : query_id_(query_id), partition_id_(part_id) {}
+  const std::size_t query_id_;
+  const partition_id partition_id_;
+  std::vector<int> preferred_numa_nodes_;
+};
+
+class WorkOrdersContainer {
+ public:
+  explicit WorkOrdersContainer(std::size_t num_operators) : queues_(num_operators) {}
+  void addNormalWorkOrder(WorkOrder *workorder, std::size_t operator_index);  // WorkOrdersContainer.hpp:243
+  bool hasNormalWorkOrder(std::size_t operator_index) const;
+  WorkOrder *getNormalWorkOrder(std::size_t operator_index);                  // caller owns the result
+  std::size_t getNumNormalWorkOrders(std::size_t operator_index) const;
+
+ private:
+  mutable std::mutex mutex_;
+  std::vector<std::deque<std::unique_ptr<WorkOrder>>> queues_;
+};
+
+class RelationalOperator {
+ public:
+  enum OperatorType { kAggregation = 0, kBuildHash, kDestroyAggregationState, kDestroyHash, kFinalizeAggregation,
+                      kInnerJoin, kSelect, kMockOperator };
+  virtual ~RelationalOperator() {}
+  virtual OperatorType getOperatorType() const = 0;
+  virtual std::string getName() const = 0;
+  // Generates all work orders available right now; returns true when no more
+  // will ever be produced (RelationalOperator.hpp:111-136).  May be called repeatedly.
+  virtual bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                StorageManager *storage_manager, const tmb::client_id scheduler_client_id,
+                                tmb::MessageBus *bus) = 0;
+  virtual void feedInputBlock(const block_id input_block_id, const relation_id input_relation_id,
+                              const partition_id part_id) {}               // :174
+  virtual void doneFeedingInputBlocks(const relation_id rel_id) { done_feeding_input_relation_ = true; }  // :198
+  virtual QueryContext::insert_destination_id getInsertDestinationID() const {
+    return QueryContext::kInvalidInsertDestinationId;
+  }
+  virtual relation_id getOutputRelationID() const { return -1; }
+  void setOperatorIndex(std::size_t index) { op_index_ = index; }
+  std::size_t getOperatorIndex() const { return op_index_; }
+  std::size_t getQueryID() const { return query_id_; }
+  std::size_t getNumPartitions() const { return num_partitions_; }
+
+ protected:
+  explicit RelationalOperator(std::size_t query_id, std::size_t num_partitions = 1, bool has_repartition = false,
+                              std::size_t output_num_partitions = 1)
+      : query_id_(query_id), num_partitions_(num_partitions), has_repartition_(has_repartition),
+        output_num_partitions_(output_num_partitions) {}
+  const std::size_t query_id_;
+  const std::size_t num_partitions_;
+  const bool has_repartition_;
+  const std::size_t output_num_partitions_;
+  bool done_feeding_input_relation_ = false;
+  std::size_t op_index_ = 0;
+};
+
+// ---------------------------------------------------------------------------
+// SelectOperator (SelectOperator.hpp:90-98,149-157; simple projection form)
+// ---------------------------------------------------------------------------
+class SelectOperator : public RelationalOperator {
+ public:
+  // on_gpu = false builds the CPU work order of BASELINE config 1 (plumbing only, no HIP).
+  SelectOperator(std::size_t query_id, const CatalogRelation &input_relation, bool has_repartition,
+                 const CatalogRelation &output_relation, QueryContext::insert_destination_id output_destination_index,
+                 QueryContext::predicate_id predicate_index, std::vector<attribute_id> &&selection,
+                 bool input_relation_is_stored, bool on_gpu = true);
+  OperatorType getOperatorType() const override { return kSelect; }
+  std::string getName() const override { return "SelectOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    input_relation_block_ids_.push_back(input_block_id);
+  }
+  QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
+  relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+
+ private:
+  const CatalogRelation &input_relation_;
+  const CatalogRelation &output_relation_;
+  const QueryContext::insert_destination_id output_destination_index_;
+  const QueryContext::predicate_id predicate_index_;
+  const std::vector<attribute_id> simple_selection_;
+  const bool input_relation_is_stored_;
+  const bool on_gpu_;
+  std::mutex mutex_;
+  std::vector<block_id> input_relation_block_ids_;
+  std::size_t num_workorders_generated_ = 0;
+  bool started_ = false;
+};
+
+class SelectWorkOrder : public WorkOrder {
+ public:
+  SelectWorkOrder(std::size_t query_id, block_id input_block_id, const Predicate *predicate,
+                  const std::vector<attribute_id> &simple_selection, InsertDestination *output_destination,
+                  StorageManager *storage_manager, bool on_gpu)
+      : WorkOrder(query_id), input_block_id_(input_block_id), predicate_(predicate), simple_selection_(simple_selection),
+        output_destination_(output_destination), storage_manager_(storage_manager), on_gpu_(on_gpu) {}
+  void execute() override;  // SelectOperator.cpp:161-195
+
+ private:
+  void executeOnHost();
+  const block_id input_block_id_;
+  const Predicate *predicate_;
+  const std::vector<attribute_id> &simple_selection_;
+  InsertDestination *output_destination_;
+  StorageManager *storage_manager_;
+  const bool on_gpu_;
+};
+
+// ---------------------------------------------------------------------------
+// BuildHashOperator (BuildHashOperator.hpp:86-93)
+// ---------------------------------------------------------------------------
+class BuildHashOperator : public RelationalOperator {
+ public:
+  BuildHashOperator(std::size_t query_id, const CatalogRelation &input_relation, bool input_relation_is_stored,
+                    const std::vector<attribute_id> &join_key_attributes, bool any_join_key_attributes_nullable,
+                    std::size_t num_partitions, QueryContext::join_hash_table_id hash_table_index,
+                    QueryContext::predicate_id build_predicate_index = QueryContext::kInvalidPredicateId);
+  OperatorType getOperatorType() const override { return kBuildHash; }
+  std::string getName() const override { return "BuildHashOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    input_relation_block_ids_.push_back(input_block_id);
+  }
+
+ private:
+  const CatalogRelation &input_relation_;
+  const bool input_relation_is_stored_;
+  const std::vector<attribute_id> join_key_attributes_;
+  const QueryContext::join_hash_table_id hash_table_index_;
+  const QueryContext::predicate_id build_predicate_index_;
+  std::mutex mutex_;
+  std::vector<block_id> input_relation_block_ids_;
+  std::size_t num_workorders_generated_ = 0;
+  bool started_ = false;
+};
+
+class BuildHashWorkOrder : public WorkOrder {
+ public:
+  BuildHashWorkOrder(std::size_t query_id, const CatalogRelation &input_relation, attribute_id join_key_attribute,
+                     block_id build_block_id, const Predicate *predicate, qsx_join_table_t *hash_table,
+                     StorageManager *storage_manager)
+      : WorkOrder(query_id), input_relation_(input_relation), join_key_attribute_(join_key_attribute),
+        build_block_id_(build_block_id), predicate_(predicate), hash_table_(hash_table),
+        storage_manager_(storage_manager) {}
+  void execute() override;  // BuildHashOperator.cpp:162-207
+
+ private:
+  const CatalogRelation &input_relation_;
+  const attribute_id join_key_attribute_;
+  const block_id build_block_id_;
+  const Predicate *predicate_;
+  qsx_join_table_t *hash_table_;
+  StorageManager *storage_manager_;
+};
+
+// ---------------------------------------------------------------------------
+// HashJoinOperator, inner join (HashJoinOperator.hpp:126-141)
+// ---------------------------------------------------------------------------
+class HashJoinOperator : public RelationalOperator {
+ public:
+  enum class JoinType { kInnerJoin = 0, kLeftSemiJoin, kLeftAntiJoin };
+  // selection + is_selection_on_build: output attribute i is attribute selection[i] of the build
+  // relation when is_selection_on_build[i], else of the probe relation.
+  HashJoinOperator(std::size_t query_id, const CatalogRelation &build_relation, const CatalogRelation &probe_relation,
+                   bool probe_relation_is_stored, const std::vector<attribute_id> &join_key_attributes,
+                   bool any_join_key_attributes_nullable, std::size_t num_partitions, bool has_repartition,
+                   const CatalogRelation &output_relation, QueryContext::insert_destination_id output_destination_index,
+                   QueryContext::join_hash_table_id hash_table_index, QueryContext::predicate_id residual_predicate_index,
+                   QueryContext::scalar_group_id selection_index, const std::vector<bool> *is_selection_on_build = nullptr,
+                   JoinType join_type = JoinType::kInnerJoin);
+  OperatorType getOperatorType() const override { return kInnerJoin; }
+  std::string getName() const override { return "HashJoinOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    probe_relation_block_ids_.push_back(input_block_id);
+  }
+  QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
+  relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+
+ private:
+  const CatalogRelation &build_relation_;
+  const CatalogRelation &probe_relation_;
+  const bool probe_relation_is_stored_;
+  const std::vector<attribute_id> join_key_attributes_;
+  const CatalogRelation &output_relation_;
+  const QueryContext::insert_destination_id output_destination_index_;
+  const QueryContext::join_hash_table_id hash_table_index_;
+  const QueryContext::scalar_group_id selection_index_;
+  std::vector<bool> is_selection_on_build_;
+  const JoinType join_type_;
+  std::mutex mutex_;
+  std::vector<block_id> probe_relation_block_ids_;
+  std::size_t num_workorders_generated_ = 0;
+  bool started_ = false;
+};
+
+class HashInnerJoinWorkOrder : public WorkOrder {
+ public:
+  HashInnerJoinWorkOrder(std::size_t query_id, const CatalogRelation &build_relation,
+                         const CatalogRelation &probe_relation, attribute_id join_key_attribute, block_id lookup_block_id,
+                         const std::vector<attribute_id> &selection, const std::vector<bool> &is_selection_on_build,
+                         HashJoinOperator::JoinType join_type, qsx_join_table_t *hash_table,
+                         InsertDestination *output_destination, StorageManager *storage_manager)
+      : WorkOrder(query_id), build_relation_(build_relation), probe_relation_(probe_relation),
+        join_key_attribute_(join_key_attribute), block_id_(lookup_block_id), selection_(selection),
+        is_selection_on_build_(is_selection_on_build), join_type_(join_type), hash_table_(hash_table),
+        output_destination_(output_destination), storage_manager_(storage_manager) {}
+  void execute() override;  // HashJoinOperator.cpp:450-541 (inner), :795-877 (semi / anti)
+
+ private:
+  const CatalogRelation &build_relation_;
+  const CatalogRelation &probe_relation_;
+  const attribute_id join_key_attribute_;
+  const block_id block_id_;
+  const std::vector<attribute_id> &selection_;
+  const std::vector<bool> &is_selection_on_build_;
+  const HashJoinOperator::JoinType join_type_;
+  qsx_join_table_t *hash_table_;
+  InsertDestination *output_destination_;
+  StorageManager *storage_manager_;
+};
+
+class DestroyHashOperator : public RelationalOperator {
+ public:
+  DestroyHashOperator(std::size_t query_id, std::size_t num_partitions, QueryContext::join_hash_table_id hash_table_index)
+      : RelationalOperator(query_id, num_partitions), hash_table_index_(hash_table_index) {}
+  OperatorType getOperatorType() const override { return kDestroyHash; }
+  std::string getName() const override { return "DestroyHashOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+
+ private:
+  const QueryContext::join_hash_table_id hash_table_index_;
+  bool work_generated_ = false;
+};
+
+// ---------------------------------------------------------------------------
+// Aggregation (AggregationOperator.hpp:55-59, FinalizeAggregationOperator.hpp:54-61)
+// ---------------------------------------------------------------------------
+class AggregationOperator : public RelationalOperator {
+ public:
+  AggregationOperator(std::size_t query_id, const CatalogRelation &input_relation, bool input_relation_is_stored,
+                      QueryContext::aggregation_state_id aggr_state_index, std::size_t num_partitions = 1);
+  OperatorType getOperatorType() const override { return kAggregation; }
+  std::string getName() const override { return "AggregationOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    input_relation_block_ids_.push_back(input_block_id);
+  }
+
+ private:
+  const CatalogRelation &input_relation_;
+  const bool input_relation_is_stored_;
+  const QueryContext::aggregation_state_id aggr_state_index_;
+  std::mutex mutex_;
+  std::vector<block_id> input_relation_block_ids_;
+  std::size_t num_workorders_generated_ = 0;
+  bool started_ = false;
+};
+
+class FinalizeAggregationOperator : public RelationalOperator {
+ public:
+  FinalizeAggregationOperator(std::size_t query_id, QueryContext::aggregation_state_id aggr_state_index,
+                              std::size_t num_partitions, bool has_repartition, std::size_t aggr_state_num_partitions,
+                              const CatalogRelation &output_relation,
+                              QueryContext::insert_destination_id output_destination_index)
+      : RelationalOperator(query_id, num_partitions, has_repartition), aggr_state_index_(aggr_state_index),
+        aggr_state_num_partitions_(aggr_state_num_partitions), output_relation_(output_relation),
+        output_destination_index_(output_destination_index) {}
+  OperatorType getOperatorType() const override { return kFinalizeAggregation; }
+  std::string getName() const override { return "FinalizeAggregationOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+  QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
+  relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+
+ private:
+  const QueryContext::aggregation_state_id aggr_state_index_;
+  const std::size_t aggr_state_num_partitions_;
+  const CatalogRelation &output_relation_;
+  const QueryContext::insert_destination_id output_destination_index_;
+  bool started_ = false;
+};
+
+class DestroyAggregationStateOperator : public RelationalOperator {
+ public:
+  DestroyAggregationStateOperator(std::size_t query_id, QueryContext::aggregation_state_id aggr_state_index,
+                                  std::size_t num_partitions = 1)
+      : RelationalOperator(query_id, num_partitions), aggr_state_index_(aggr_state_index) {}
+  OperatorType getOperatorType() const override { return kDestroyAggregationState; }
+  std::string getName() const override { return "DestroyAggregationStateOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+
+ private:
+  const QueryContext::aggregation_state_id aggr_state_index_;
+  bool work_generated_ = false;
+};
+
+// ---------------------------------------------------------------------------
+// Scheduler: ForemanSingleNode + Worker (query_execution/ForemanSingleNode.cpp:102-178,
+// Worker.cpp:54-139), reduced to what the hot path needs: a DAG of operators,
+// pipeline-breaking and streaming edges, N worker threads with one HIP stream each.
+// ---------------------------------------------------------------------------
+class QueryPlan {
+ public:
+  std::size_t addRelationalOperator(RelationalOperator *op);  // takes ownership
+  // is_pipeline_breaker: consumer may not start before producer has finished entirely
+  // (BuildHash -> HashJoin, Aggregation -> Finalize; ExecutionGenerator.cpp:1110-1124, 2027-2046);
+  // otherwise the producer's filled output blocks are fed to the consumer as they appear.
+  void addDirectDependency(std::size_t consumer, std::size_t producer, bool is_pipeline_breaker);
+  std::size_t size() const { return operators_.size(); }
+  RelationalOperator *getOperator(std::size_t i) const { return operators_.at(i).get(); }
+  struct Edge { std::size_t producer; bool breaker; };
+  const std::vector<Edge> &dependencies(std::size_t consumer) const { return deps_.at(consumer); }
+
+ private:
+  std::vector<std::unique_ptr<RelationalOperator>> operators_;
+  std::vector<std::vector<Edge>> deps_;
+};
+
+struct WorkOrderTimeEntry {  // --profile_and_report_workorder_perf (PolicyEnforcerBase.cpp:66-68)
+  std::size_t worker_id;
+  std::size_t operator_index;
+  std::uint64_t start_us;
+  std::uint64_t end_us;
+};
+
+class ForemanSingleNode {
+ public:
+  ForemanSingleNode(QueryPlan *plan, QueryContext *query_context, StorageManager *storage_manager,
+                    std::size_t num_workers);
+  void run();  // admits the query, dispatches work orders until every operator has finished
+  const std::vector<WorkOrderTimeEntry> &getWorkOrderProfilingResults() const { return profile_; }
+
+ private:
+  void workerMain(std::size_t worker_id);
+  QueryPlan *plan_;
+  QueryContext *query_context_;
+  StorageManager *storage_manager_;
+  std::size_t num_workers_;
+  tmb::MessageBus bus_;
+
+  std::mutex mutex_;
+  std::condition_variable cv_work_;
+  std::condition_variable cv_done_;
+  struct Item { WorkOrder *wo; std::size_t op; };
+  std::deque<Item> ready_;
+  std::vector<std::size_t> outstanding_;  // dispatched but unfinished work orders per operator
+  bool shutting_down_ = false;
+  std::string worker_error_;
+  std::vector<WorkOrderTimeEntry> profile_;
+};
+
+}  // namespace quickstep
+
+#endif  // QUICKSTEP_AMD_HOST_QUICKSTEP_GPU_HPP_

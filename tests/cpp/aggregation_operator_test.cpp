@@ -1,0 +1,194 @@
+// Mirrors relational_operators/tests/AggregationOperator_unittest.cpp: 300 rows in 10-tuple blocks,
+// columns GroupBy-0/1, IntType, LongType, FloatType, DoubleType (:192-207); scalar SUM/AVG/COUNT with
+// and without predicate (:593-602, :877-886), zero-row behaviour (:1160-1345) and the GROUP BY checks
+// (:1349-1470), driven synchronously like the reference test and through Foreman/Worker with a
+// Select -> Aggregation streaming edge.  GPU work orders.
+#include <algorithm>
+#include <cstring>
+#include <map>
+
+#include "test_util.hpp"
+
+using namespace quickstep;
+
+namespace {
+constexpr tuple_id kNumTuples = 300;
+constexpr int kGroupByWidth = 20;
+constexpr int kGroupByRepeats = kNumTuples / kGroupByWidth;
+constexpr int kGroupBy1Size = 4;
+constexpr tuple_id kNumTuplesPerBlock = 10;
+
+std::int64_t Summation(int n) { return static_cast<std::int64_t>(n) * (n + 1) / 2; }
+std::int64_t ArithmeticSum(int a, int d, int n) { return static_cast<std::int64_t>(n) * (2 * a + (n - 1) * d) / 2; }
+
+struct Fixture {
+  CatalogRelation table{100, "aggregate_test"};
+  StorageManager storage;
+  Fixture() {
+    table.addAttribute("GroupBy-0", Type::Int());
+    table.addAttribute("GroupBy-1", Type::Int());
+    table.addAttribute("IntType-0", Type::Int());
+    table.addAttribute("LongType-0", Type::Long());
+    table.addAttribute("FloatType-0", Type::Float());
+    table.addAttribute("DoubleType-0", Type::Double());
+    for (tuple_id i = 0; i < kNumTuples; i += kNumTuplesPerBlock) {
+      std::int32_t g0[kNumTuplesPerBlock], g1[kNumTuplesPerBlock], iv[kNumTuplesPerBlock];
+      std::int64_t lv[kNumTuplesPerBlock];
+      float fv[kNumTuplesPerBlock];
+      double dv[kNumTuplesPerBlock];
+      for (tuple_id t = 0; t < kNumTuplesPerBlock; ++t) {
+        const int val = i + t, gid = val % kGroupByWidth;
+        g0[t] = gid % kGroupBy1Size; g1[t] = gid / kGroupBy1Size; iv[t] = val; lv[t] = val;
+        fv[t] = static_cast<float>(0.1 * val); dv[t] = 0.1 * val;
+      }
+      storage.loadBlock(&table, {g0, g1, iv, lv, fv, dv}, kNumTuplesPerBlock);
+    }
+  }
+};
+
+struct Rows {
+  std::vector<std::vector<std::int64_t>> ints;   // per output attribute (raw 8-byte words)
+  std::size_t n = 0;
+};
+
+// Output attributes are 4-byte keys or 8-byte values; read everything as raw words.
+std::vector<std::vector<unsigned char>> readAll(QueryContext &ctx, QueryContext::insert_destination_id dest,
+                                                StorageManager &storage, const CatalogRelation &rel, std::size_t *rows) {
+  std::vector<std::vector<unsigned char>> cols(rel.size());
+  *rows = 0;
+  for (block_id b : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+    BlockReference blk = storage.getBlock(b);
+    for (std::size_t a = 0; a < rel.size(); ++a) {
+      const std::size_t w = rel.getAttributeType(static_cast<attribute_id>(a)).width;
+      const std::size_t at = cols[a].size();
+      cols[a].resize(at + w * blk->numTuples());
+      blk->copyAttributeToHost(static_cast<attribute_id>(a), cols[a].data() + at);
+    }
+    *rows += static_cast<std::size_t>(blk->numTuples());
+  }
+  return cols;
+}
+template <typename T>
+T at(const std::vector<unsigned char> &col, std::size_t i) {
+  T v;
+  std::memcpy(&v, col.data() + i * sizeof(T), sizeof(T));
+  return v;
+}
+}  // namespace
+
+#include <cstring>
+
+int main() {
+  if (qsx_device_count() < 1) {
+    std::fprintf(stderr, "aggregation_operator_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
+    return 2;
+  }
+  // ---- scalar aggregates, synchronous driver ------------------------------------------------------
+  for (const int predicate_value : {-2, 30, -1}) {  // -2: no predicate; 30: IntType-0 < 30; -1: zero rows
+    Fixture f;
+    CatalogRelation result(101, "result");
+    result.addAttribute("sum_int", Type::Long());
+    result.addAttribute("sum_double", Type::Double());
+    result.addAttribute("avg_long", Type::Double());
+    result.addAttribute("count", Type::Long());
+    QueryContext ctx;
+    Predicate pred;
+    pred.conjuncts.push_back({2, ComparisonID::kLess, TypedLiteral::Int(predicate_value)});
+    const auto pred_id = ctx.addPredicate(pred);
+    AggregationStateSpec spec;
+    spec.input_relation = &f.table;
+    spec.aggregates = {{AggregationID::kSum, 2}, {AggregationID::kSum, 5}, {AggregationID::kAvg, 3}, {AggregationID::kCount, kInvalidAttributeID}};
+    spec.predicate = predicate_value == -2 ? nullptr : ctx.getPredicate(pred_id);
+    const auto state = ctx.addAggregationState(spec);
+    const auto dest = ctx.addInsertDestination(&result, &f.storage);
+    AggregationOperator op(0, f.table, true, state);
+    FinalizeAggregationOperator fin(0, state, 1, false, 1, result, dest);
+    DestroyAggregationStateOperator destroy(0, state);
+    fetchAndExecuteWorkOrders(&op, &ctx, &f.storage);
+    fetchAndExecuteWorkOrders(&fin, &ctx, &f.storage);
+    std::size_t rows;
+    auto cols = readAll(ctx, dest, f.storage, result, &rows);
+    EXPECT_EQ(rows, static_cast<std::size_t>(1));  // exactly one row, even for zero input rows (:1160-1345)
+    const int last = predicate_value == -2 ? 299 : predicate_value - 1;
+    const std::int64_t count = last + 1;
+    EXPECT_EQ(at<std::int64_t>(cols[3], 0), count);
+    if (count > 0) {
+      EXPECT_EQ(at<std::int64_t>(cols[0], 0), Summation(last));            // SUM(int) is LONG, exact
+      EXPECT_NEAR(at<double>(cols[1], 0), 0.1 * Summation(last), 1e-5 * 0.1 * Summation(last));
+      EXPECT_NEAR(at<double>(cols[2], 0), Summation(last) / static_cast<double>(count), 1e-9);
+    }
+    fetchAndExecuteWorkOrders(&destroy, &ctx, &f.storage);
+  }
+
+  // ---- GROUP BY, both drivers, both hash strategies -------------------------------------------------
+  for (const bool use_foreman : {false, true}) {
+    for (const qsx_agg_strategy_t strategy : {QSX_AGG_COMPACT_KEY, QSX_AGG_GENERIC}) {
+      for (const bool with_predicate : {false, true}) {
+        Fixture f;
+        CatalogRelation selected(102, "selected"), result(103, "result");
+        result.addAttribute("GroupBy-0", Type::Int());
+        result.addAttribute("GroupBy-1", Type::Int());
+        result.addAttribute("sum_int", Type::Long());
+        result.addAttribute("sum_double", Type::Double());
+        result.addAttribute("avg_int", Type::Double());
+        result.addAttribute("count", Type::Long());
+        QueryContext ctx;
+        Predicate pred;
+        pred.conjuncts.push_back({2, ComparisonID::kLess, TypedLiteral::Int(kGroupByWidth * (kGroupByRepeats >> 1))});  // :539
+        const auto pred_id = ctx.addPredicate(pred);
+        AggregationStateSpec spec;
+        spec.input_relation = &f.table;
+        spec.group_by = {0, 1};
+        spec.aggregates = {{AggregationID::kSum, 2}, {AggregationID::kSum, 5}, {AggregationID::kAvg, 2}, {AggregationID::kCount, kInvalidAttributeID}};
+        spec.predicate = with_predicate ? ctx.getPredicate(pred_id) : nullptr;
+        spec.strategy = strategy;
+        spec.estimated_num_groups = kGroupByWidth;
+        const auto dest = ctx.addInsertDestination(&result, &f.storage);
+        if (use_foreman) {
+          // Select(all columns, no predicate) --streaming--> Aggregation --breaker--> Finalize --breaker--> Destroy
+          for (const char *name : {"GroupBy-0", "GroupBy-1", "IntType-0", "LongType-0", "FloatType-0", "DoubleType-0"}) {
+            selected.addAttribute(name, f.table.getAttributeType(f.table.getAttributeByName(name)));
+          }
+          spec.input_relation = &selected;
+          const auto state = ctx.addAggregationState(spec);
+          const auto sel_dest = ctx.addInsertDestination(&selected, &f.storage);
+          QueryPlan plan;
+          const auto s = plan.addRelationalOperator(new SelectOperator(0, f.table, false, selected, sel_dest,
+                                                                       QueryContext::kInvalidPredicateId,
+                                                                       std::vector<attribute_id>{0, 1, 2, 3, 4, 5}, true));
+          const auto a = plan.addRelationalOperator(new AggregationOperator(0, selected, false, state));
+          const auto fz = plan.addRelationalOperator(new FinalizeAggregationOperator(0, state, 1, false, 1, result, dest));
+          const auto d = plan.addRelationalOperator(new DestroyAggregationStateOperator(0, state));
+          plan.addDirectDependency(a, s, false);
+          plan.addDirectDependency(fz, a, true);
+          plan.addDirectDependency(d, fz, true);
+          ForemanSingleNode foreman(&plan, &ctx, &f.storage, 4);
+          foreman.run();
+          EXPECT_EQ(foreman.getWorkOrderProfilingResults().size(), static_cast<std::size_t>(30 + 30 + 1 + 1));
+        } else {
+          const auto state = ctx.addAggregationState(spec);
+          AggregationOperator op(0, f.table, true, state);
+          FinalizeAggregationOperator fin(0, state, 1, false, 1, result, dest);
+          fetchAndExecuteWorkOrders(&op, &ctx, &f.storage);
+          fetchAndExecuteWorkOrders(&fin, &ctx, &f.storage);
+        }
+        std::size_t rows;
+        auto cols = readAll(ctx, dest, f.storage, result, &rows);
+        EXPECT_EQ(rows, static_cast<std::size_t>(kGroupByWidth));
+        const int repeats = with_predicate ? kGroupByRepeats >> 1 : kGroupByRepeats;
+        std::vector<bool> seen(kGroupByWidth, false);
+        for (std::size_t i = 0; i < rows; ++i) {
+          const int gid = at<std::int32_t>(cols[0], i) + at<std::int32_t>(cols[1], i) * kGroupBy1Size;  // :517
+          EXPECT_TRUE(gid >= 0 && gid < kGroupByWidth && !seen[gid]);
+          seen[gid] = true;
+          const std::int64_t sum = ArithmeticSum(gid, kGroupByWidth, repeats);
+          EXPECT_EQ(at<std::int64_t>(cols[2], i), sum);
+          EXPECT_NEAR(at<double>(cols[3], i), 0.1 * sum, 1e-5 * 0.1 * sum + 1e-12);
+          EXPECT_NEAR(at<double>(cols[4], i), sum / static_cast<double>(repeats), 1e-5 * sum / repeats + 1e-12);
+          EXPECT_EQ(at<std::int64_t>(cols[5], i), static_cast<std::int64_t>(repeats));
+        }
+      }
+    }
+  }
+  return finish("aggregation_operator_test");
+}

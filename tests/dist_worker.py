@@ -1,0 +1,109 @@
+"""Worker of tests/test_distributed_gloo.py: one rank of a 2-rank gloo job that runs the
+multi-GPU rank logic of quickstep_amd/distributed.py on CPU tensors, with the CPU checker
+plugged in as `ops` (tests may use the oracle; the product passes quickstep_amd.capi)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import pyoracle as O  # noqa: E402
+from quickstep_amd import distributed as qd  # noqa: E402
+from quickstep_amd import types as T  # noqa: E402
+
+
+class OracleJoinTable:
+    def __init__(self, key_type, est):
+        self.key_type, self.est = key_type, est
+        self.t = O.JoinTable(key_type, est)
+
+    def clear(self):
+        self.t = O.JoinTable(self.key_type, self.est)
+
+    def build(self, keys):
+        self.t.build(keys.numpy())
+
+    def probe(self, keys, capacity=None):
+        p, b = self.t.probe(keys.numpy())
+        return torch.from_numpy(p), torch.from_numpy(b), torch.tensor([p.size], dtype=torch.int64)
+
+
+class OracleOps:
+    """Same surface as quickstep_amd.capi for what distributed.py calls."""
+    JoinTable = OracleJoinTable
+
+    @staticmethod
+    def partition_scatter(keys, num_partitions, cols):
+        k = keys.numpy()
+        offs = O.partition_offsets(k, num_partitions)
+        return [torch.from_numpy(O.partition_scatter(k, num_partitions, c.numpy())) for c in cols], torch.from_numpy(offs)
+
+    @staticmethod
+    def gather(src, tids):
+        return torch.from_numpy(O.gather(src.numpy(), tids.numpy().astype(np.int32)))
+
+
+class FakeAggState:
+    """Dense per-group image [count, sum] over 16 groups: enough to exercise all-gather + merge order."""
+    device = None
+
+    def __init__(self, values):
+        self.image = torch.zeros(32, dtype=torch.int64)
+        for g, v in values:
+            self.image[g] += 1
+            self.image[16 + g] += v
+
+    def export(self, device):
+        return self.image.clone()
+
+    def import_merge(self, other):
+        self.image += other
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    out_dir = sys.argv[1]
+    n_build, n_probe = 5000, 40000
+    rng = np.random.default_rng(100 + rank)
+    # every rank holds a slice of both relations; keys collide across ranks and include negatives
+    build_keys = rng.integers(-2000, 2000, size=n_build).astype(np.int32)
+    probe_keys = rng.integers(-2500, 2500, size=n_probe).astype(np.int32)
+    join = qd.PartitionedHashJoin(OracleOps, T.INT, n_build * 2)
+    join.build(torch.from_numpy(build_keys), rank * n_build)
+    probe_tids, build_tids, op, ob, cnt = join.probe(torch.from_numpy(probe_keys), rank * n_probe)
+    gp, gb = join.materialize(probe_tids, build_tids, op, ob, cnt)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), build_keys=build_keys, probe_keys=probe_keys,
+             pairs_probe=gp.numpy(), pairs_build=gb.numpy())
+
+    # partial aggregate merge
+    vals = [(int(g), int(v)) for g, v in zip(rng.integers(0, 16, size=1000), rng.integers(0, 100, size=1000))]
+    st = FakeAggState(vals)
+    local = st.image.clone()
+    qd.merge_agg_state_images(OracleOps, st)
+    total = local.clone()
+    dist.all_reduce(total)
+    assert torch.equal(st.image, total)
+
+    # dense image all-reduce: existence bits OR, integer SUM, f64 SUM
+    exist_words, entries = 2, 5
+    img = torch.zeros(exist_words + 2 * entries, dtype=torch.int64)
+    img[0] = 1 << rank
+    img[1] = 0b1010 if rank == 0 else 0b0110
+    img[exist_words:exist_words + entries] = torch.arange(entries) + rank
+    img[exist_words + entries:] = (torch.arange(entries, dtype=torch.float64) * 0.5 + rank).view(torch.int64)
+    qd.allreduce_dense_agg_image(img, exist_words, entries, int_col_mask=0b01, num_cols=2)
+    assert int(img[0]) == (1 << world) - 1 and int(img[1]) == 0b1110
+    assert img[exist_words:exist_words + entries].tolist() == [world * i + sum(range(world)) for i in range(entries)]
+    assert np.allclose(img[exist_words + entries:].view(torch.float64).numpy(),
+                       np.arange(entries) * 0.5 * world + sum(range(world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

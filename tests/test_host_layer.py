@@ -1,0 +1,48 @@
+"""The C++ host layer (quickstep_amd/host): RelationalOperator / WorkOrder mirror driving the
+C ABI.  The C++ tests under tests/cpp mirror the reference's own operator unit tests; pytest
+builds (if needed) and runs them."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "bin")
+
+
+def _ensure_built():
+    if not all(os.path.exists(os.path.join(BIN, b)) for b in
+               ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
+
+
+def _run(name, *args, timeout=600):
+    _ensure_built()
+    r = subprocess.run([os.path.join(BIN, name), *args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "[  PASSED  ]" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_select_operator_cpu_workorder_plumbing():
+    """BASELINE config 1 (CPU WorkOrder through Foreman/Worker, no GPU), scaled to 1 M rows."""
+    out = _run("select_cpu_workorder_test", "1000000", "4")
+    assert out.count("M rows/s") == 3
+
+
+def test_gpu_operators_refuse_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _ensure_built()
+    r = subprocess.run([os.path.join(BIN, "hash_join_operator_test")], capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_hash_join_operator_unittest_mirror():
+    _run("hash_join_operator_test")
+
+
+@pytest.mark.gpu
+def test_aggregation_operator_unittest_mirror():
+    _run("aggregation_operator_test")
