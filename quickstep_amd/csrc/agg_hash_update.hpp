@@ -20,19 +20,20 @@
 //              per interpreted instruction (the program is wave-uniform: scalar
 //              branches, amortised over 64 * V rows).
 //   3. ACCUMULATE
-//              * the first R = 4 distinct groups the workgroup meets are "register
-//                groups": their codes sit in 4 LDS tag words and every thread keeps
-//                private partial sums for them in VGPRs (predicated adds, no
-//                atomics) — the TPC-H Q1 regime;
-//              * further groups: workgroup-private open-addressing table in LDS
-//                (ds_cmpst_b64 claim, ds_add_u64 / ds_add_f64);
+//              * groups live in a workgroup-private open-addressing table in LDS
+//                (ds_cmpst_b64 claim); every accumulator of a group is replicated
+//                REP times (REP = 64 for few groups: one bank column per lane), so
+//                a row costs one conflict-free ds_add_u64 / ds_add_f64 per
+//                accumulator and no VGPR state — the TPC-H Q1 regime (4 groups)
+//                and the thousands-of-groups regime run the same code;
 //              * groups that do not fit LDS: global table, 64-bit global atomics.
-//   4. FLUSH   registers -> LDS (wave reduction) -> global table: one global atomic
-//              per group per accumulator per workgroup.
+//   4. FLUSH   fold the REP partials -> global table: one global atomic per group
+//              per accumulator per workgroup.
 #ifndef QSX_CSRC_AGG_HASH_UPDATE_HPP_
 #define QSX_CSRC_AGG_HASH_UPDATE_HPP_
 
 #include "agg_common.hpp"
+#include "agg_translate.hpp"
 
 namespace qsx {
 
@@ -43,6 +44,21 @@ using glb_ptr_t = const __attribute__((address_space(1))) void *;
 // (wave-uniform LDS base) + 16 * l.
 __device__ __forceinline__ void dma16(const char *global_lane_addr, char *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((glb_ptr_t)global_lane_addr, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// Loop over a configuration-sized range.  kStatic = the configuration is a compile-time
+// constant (AOT plan shape, agg_shapes.hpp): unroll to the ABI maximum so that every
+// switch on a configuration field folds away; otherwise a plain run-time loop (interpreter).
+template <bool kStatic, int MAX, typename F>
+__device__ __forceinline__ void cfg_for(int count, F &&f) {
+  if constexpr (kStatic) {
+#pragma unroll
+    for (int k = 0; k < MAX; ++k) {
+      if (k < count) f(k);
+    }
+  } else {
+    for (int k = 0; k < count; ++k) f(k);
+  }
 }
 
 // Copy `count` elements of `width` bytes (1/2/4/8) with ordinary loads; used
@@ -59,15 +75,16 @@ __device__ __forceinline__ void copy_elements_to_lds(const char *src, char *dst,
 }
 
 // Issue the HBM -> LDS copy of one tile (rows [row0, row0 + rows)).
-__device__ __forceinline__ void stage_tile(const DevConfig &c, const uint64_t *filter, char *tile, int64_t row0,
-                                           int rows) {
+template <bool kStatic>
+__device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const *cols, const uint64_t *filter,
+                                           char *tile, int64_t row0, int rows) {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
-  for (int col = 0; col < c.num_columns; ++col) {
+  cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_columns, [&](int col) __attribute__((always_inline)) {
     const int off = c.lds_off[col];
-    if (off < 0) continue;  // column not referenced by keys / predicate / expressions
+    if (off < 0) return;  // column not referenced by keys / predicate / expressions
     const int w = c.column_width[col];
-    const char *src = static_cast<const char *>(c.cols[col]) + row0 * w;
+    const char *src = static_cast<const char *>(cols[col]) + row0 * w;
     char *dst = tile + off;
     const int bytes = rows * w;
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
@@ -81,7 +98,7 @@ __device__ __forceinline__ void stage_tile(const DevConfig &c, const uint64_t *f
     } else {
       copy_elements_to_lds(src, dst, rows, w);
     }
-  }
+  });
   if (c.filter_lds_off >= 0) {
     copy_elements_to_lds(reinterpret_cast<const char *>(filter + (row0 >> 6)), tile + c.filter_lds_off,
                          (rows + 63) >> 6, 8);
@@ -116,13 +133,13 @@ __device__ __forceinline__ void temps_get(const Temps<V> &s, int i, double (&out
 // out of VGPRs into scratch.
 #define QSX_TG(k) \
   case k:         \
-    _Pragma("unroll") for (int v = 0; v < V; ++v) { out[v] = s.t[k][v]; asm volatile("; temp get " #k : "+v"(out[v])); } \
+    _Pragma("unroll") for (int v = 0; v < V; ++v) { out[v] = s.t[k][v]; asm("; temp get " #k : "+v"(out[v])); } \
     break;
   switch (i) {  // wave-uniform index: scalar branches, the temps stay in VGPRs
     QSX_TG(0) QSX_TG(1) QSX_TG(2) QSX_TG(3) QSX_TG(4) QSX_TG(5) QSX_TG(6)
     default:
 #pragma unroll
-      for (int v = 0; v < V; ++v) { out[v] = s.t[7][v]; asm volatile("; temp get 7" : "+v"(out[v])); }
+      for (int v = 0; v < V; ++v) { out[v] = s.t[7][v]; asm("; temp get 7" : "+v"(out[v])); }
       break;
   }
 #undef QSX_TG
@@ -131,13 +148,13 @@ template <int V>
 __device__ __forceinline__ void temps_set(Temps<V> &s, int i, const double (&in)[V]) {
 #define QSX_TS(k) \
   case k:         \
-    _Pragma("unroll") for (int v = 0; v < V; ++v) { s.t[k][v] = in[v]; asm volatile("; temp set " #k : "+v"(s.t[k][v])); } \
+    _Pragma("unroll") for (int v = 0; v < V; ++v) { s.t[k][v] = in[v]; asm("; temp set " #k : "+v"(s.t[k][v])); } \
     break;
   switch (i) {
     QSX_TS(0) QSX_TS(1) QSX_TS(2) QSX_TS(3) QSX_TS(4) QSX_TS(5) QSX_TS(6)
     default:
 #pragma unroll
-      for (int v = 0; v < V; ++v) { s.t[7][v] = in[v]; asm volatile("; temp set 7" : "+v"(s.t[7][v])); }
+      for (int v = 0; v < V; ++v) { s.t[7][v] = in[v]; asm("; temp set 7" : "+v"(s.t[7][v])); }
       break;
   }
 #undef QSX_TS
@@ -161,9 +178,9 @@ __device__ __forceinline__ void operand_vec(const DevConfig &c, const DevOperand
   }
 }
 
-template <int V>
+template <bool kStatic, int V>
 __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *tile, bool (&live)[V]) {
-  for (int p = 0; p < c.num_pred; ++p) {
+  cfg_for<kStatic, QSX_MAX_PRED_TERMS>(c.num_pred, [&](int p) __attribute__((always_inline)) {
     const DevPred term = c.pred[p];
     const char *base = tile + c.lds_off[term.column];
 #pragma unroll
@@ -188,15 +205,15 @@ __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *ti
       }
       live[v] = live[v] && ok;
     }
-  }
+  });
 }
 
 // Compact key codes of V rows (ThreadPrivateCompactKeyHashTable.cpp:216-232).
-template <int V>
+template <bool kStatic, int V>
 __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *tile, unsigned long long (&code)[V]) {
 #pragma unroll
   for (int v = 0; v < V; ++v) code[v] = 0;
-  for (int k = 0; k < c.num_keys; ++k) {
+  cfg_for<kStatic, QSX_MAX_KEYS>(c.num_keys, [&](int k) __attribute__((always_inline)) {
     const char *base = tile + c.lds_off[c.key_column[k]];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -210,102 +227,79 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
       }
       code[v] |= x << c.key_shift[k];
     }
-  }
+  });
 }
 
-// Where a row that is not in a register group accumulates.
-enum : int { kDestNone = 0, kDestLds = 1, kDestGlobal = 2 };
-
-// Decide where one live row accumulates: a register group (sel >= 0), the
-// workgroup's LDS table or the global table; the row count of non-register
-// groups is bumped right here.
-__device__ __forceinline__ void classify_row(bool live, unsigned long long code,
-                                             const unsigned long long (&tag)[kRegGroups],
-                                             unsigned long long *l_tags, unsigned long long *l_keys,
-                                             unsigned long long *l_state, int S, const HashTableView &g,
-                                             int &sel, int &dest, long long &slot) {
-  sel = -1;
-  dest = kDestNone;
-  slot = 0;
+// Group of one row.  Every row gets an LDS accumulator index so that the
+// accumulate loop needs no branches: live rows whose group sits in the
+// workgroup's LDS table get that group's slot, all other rows (filtered out, or
+// routed to the global table because the LDS table is full / the code equals the
+// empty marker) get the trash slot S.  Global-table rows additionally report
+// their global slot (>= 0).  The group's row count is bumped right here.
+__device__ __forceinline__ void classify_row(bool live, unsigned long long code, unsigned long long *l_keys,
+                                             unsigned long long *l_acc, int S, int rep_shift, int lane_col,
+                                             const HashTableView &g, int &slot, long long &global_slot) {
+  slot = (S << rep_shift) + lane_col;  // trash
+  global_slot = -1;
   if (!live) return;
-  if (code != kEmptyCode) {
-#pragma unroll
-    for (int r = 0; r < kRegGroups; ++r) {
-      if (tag[r] == code) sel = r;
-    }
-    if (sel < 0) {
-      // Not in the snapshot: claim a free tag (first rows of a workgroup only).
-#pragma unroll
-      for (int r = 0; r < kRegGroups; ++r) {
-        if (sel < 0) {
-          unsigned long long k = __hip_atomic_load(&l_tags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (k == kEmptyCode) k = atomicCAS(&l_tags[r], kEmptyCode, code);
-          if (k == kEmptyCode || k == code) sel = r;
-        }
-      }
-    }
-  }
-  if (sel >= 0) return;
   const int s = code == kEmptyCode ? -1 : lds_find_or_insert(l_keys, S, code);
   if (s >= 0) {
-    dest = kDestLds;
-    slot = s;
-    atomicAdd(&l_state[s], 1ull);
+    slot = (s << rep_shift) + lane_col;  // index inside one accumulator plane
+    atomicAdd(&l_acc[slot], 1ull);       // plane 0 = row count
   } else {
     const unsigned long long gs = global_find_or_insert(g, code);
     if (gs != ~0ull) {
-      dest = kDestGlobal;
-      slot = static_cast<long long>(gs);
+      global_slot = static_cast<long long>(gs);
       global_add(g, 0, gs, 1ull, 1);
     }
   }
 }
 
-// Dynamic LDS: tile[2][tile_bytes] | tags[R] | rstate[R][NS+1] | l_keys[S] | l_state[NS+1][S]
-template <int NS, int V>
-__global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, int64_t n,
-                                                                 const uint64_t *__restrict__ filter,
-                                                                 HashTableView g, int S) {
+// Dynamic LDS: tile[nbuf][tile_bytes] | l_keys[S] | l_acc[NS + 1][S + 1][REP]   (slot S = trash)
+// l_acc holds, per accumulator plane and group slot, REP = 2^rep_shift partial
+// values; a lane adds into column (lane & (REP - 1)), so with REP = 64 every
+// lane owns its bank column and a wave's ds_add never conflicts (measured
+// ~6 ns per wave instruction per CU, tools/ubench/lds_atomic.hip).
+template <bool kStatic, int NS, int V>
+__device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, int64_t n,
+                                                     const uint64_t *__restrict__ filter, const HashTableView &g,
+                                                     int S, int rep_shift, int nbuf) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int TR = kABlock * V;
   char *tiles = reinterpret_cast<char *>(smem_raw);
-  unsigned long long *l_tags = reinterpret_cast<unsigned long long *>(smem_raw + 2 * c.tile_bytes);
-  unsigned long long *l_rstate = l_tags + kRegGroups;               // [R][NS + 1]
-  unsigned long long *l_keys = l_rstate + kRegGroups * (NS + 1);    // [S]
-  unsigned long long *l_state = l_keys + S;                         // [NS + 1][S]
+  unsigned long long *l_keys = reinterpret_cast<unsigned long long *>(smem_raw + nbuf * c.tile_bytes);  // [S]
+  unsigned long long *l_acc = l_keys + S;                                                           // [NS + 1][S << rep_shift]
+  const int plane = (S + 1) << rep_shift;
+  const int lane_col = lane_id() & ((1 << rep_shift) - 1);
 
-  for (int i = threadIdx.x; i < kRegGroups; i += kABlock) l_tags[i] = kEmptyCode;
-  for (int i = threadIdx.x; i < kRegGroups * (NS + 1); i += kABlock) l_rstate[i] = 0;
   for (int i = threadIdx.x; i < S; i += kABlock) l_keys[i] = kEmptyCode;
-  for (int i = threadIdx.x; i < (NS + 1) * S; i += kABlock) l_state[i] = 0;
+  for (int i = threadIdx.x; i < (NS + 1) * plane; i += kABlock) l_acc[i] = 0;
 
-  unsigned long long racc[kRegGroups][NS > 0 ? NS : 1];
-  unsigned int rcnt[kRegGroups];
-#pragma unroll
-  for (int r = 0; r < kRegGroups; ++r) {
-    rcnt[r] = 0;
-#pragma unroll
-    for (int j = 0; j < NS; ++j) racc[r][j] = 0;
-  }
-
+  // nbuf == 2: the DMA of tile i+1 overlaps the compute of tile i inside the workgroup;
+  // nbuf == 1: one buffer, overlap comes from the other workgroups resident on the CU.
   const int64_t num_tiles = (n + TR - 1) / TR;
   int buf = 0;
-  if (static_cast<int64_t>(blockIdx.x) < num_tiles) {
+  if (nbuf == 2 && static_cast<int64_t>(blockIdx.x) < num_tiles) {
     const int64_t row0 = static_cast<int64_t>(blockIdx.x) * TR;
-    stage_tile(c, filter, tiles, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
+    stage_tile<kStatic>(c, cols, filter, tiles, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
   }
   for (int64_t tile_id = blockIdx.x; tile_id < num_tiles; tile_id += gridDim.x) {
-    // The tile staged during the previous iteration has landed; every wave is
-    // done with the other buffer.
+    if (nbuf == 1) {
+      __syncthreads();  // every wave is done reading the previous tile
+      const int64_t row0 = tile_id * TR;
+      stage_tile<kStatic>(c, cols, filter, tiles, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
+    }
+    // The tile has landed (nbuf == 2: it was staged during the previous iteration and
+    // every wave is done with the other buffer).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int64_t next = tile_id + gridDim.x;
-    if (next < num_tiles) {
+    if (nbuf == 2 && next < num_tiles) {
       const int64_t row0 = next * TR;
-      stage_tile(c, filter, tiles + (buf ^ 1) * c.tile_bytes, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
+      stage_tile<kStatic>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
     }
     const char *tile = tiles + buf * c.tile_bytes;
-    buf ^= 1;
+    if (nbuf == 2) buf ^= 1;
     const int64_t row0 = tile_id * TR;
     const int rows = static_cast<int>(n - row0 < TR ? n - row0 : TR);
 
@@ -320,32 +314,24 @@ __global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, i
         live[v] = msb_bit(word, r & 63);
       }
     }
-    predicate_vec<V>(c, tile, live);
+    predicate_vec<kStatic, V>(c, tile, live);
 
     // ---- group of every row ----------------------------------------------------
     unsigned long long code[V];
-    key_codes_vec<V>(c, tile, code);
-    unsigned long long tag[kRegGroups];
-#pragma unroll
-    for (int r = 0; r < kRegGroups; ++r) {
-      tag[r] = __hip_atomic_load(&l_tags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    int sel[V];     // register group, or -1
-    int dest[V];    // for sel < 0: kDestLds / kDestGlobal / kDestNone
-    long long slot[V];
+    key_codes_vec<kStatic, V>(c, tile, code);
+    int slot[V];
+    long long global_slot[V];
+    bool any_global = false;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      classify_row(live[v], code[v], tag, l_tags, l_keys, l_state, S, g, sel[v], dest[v], slot[v]);
+      classify_row(live[v], code[v], l_keys, l_acc, S, rep_shift, lane_col, g, slot[v], global_slot[v]);
+      any_global = any_global || global_slot[v] >= 0;
     }
-#pragma unroll
-    for (int r = 0; r < kRegGroups; ++r) {
-#pragma unroll
-      for (int v = 0; v < V; ++v) rcnt[r] += sel[v] == r ? 1u : 0u;
-    }
+    const bool wave_has_global = __any(any_global);  // rare: groups that did not fit the LDS table
 
     // ---- expression program ------------------------------------------------------
     Temps<V> temps;
-    for (int k = 0; k < c.num_instrs; ++k) {
+    cfg_for<kStatic, QSX_MAX_INSTRS>(c.num_instrs, [&](int k) __attribute__((always_inline)) {
       const DevInstr in = c.instrs[k];
       double a[V], b[V], res[V];
       operand_vec<V>(c, in.a, temps, tile, a);
@@ -369,9 +355,9 @@ __global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, i
           break;
       }
       temps_set<V>(temps, in.dst, res);
-    }
+    });
 
-    // ---- accumulate ------------------------------------------------------------------
+    // ---- accumulate: one LDS atomic per row per accumulator ------------------------
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
       const DevSum s = c.sums[j];
@@ -381,76 +367,74 @@ __global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, i
         for (int v = 0; v < V; ++v) {
           inc[v] = static_cast<unsigned long long>(tile_int(c, tile, s.arg.index, threadIdx.x + v * kABlock));
         }
-#pragma unroll
-        for (int r = 0; r < kRegGroups; ++r) {
-#pragma unroll
-          for (int v = 0; v < V; ++v) racc[r][j] += sel[v] == r ? inc[v] : 0ull;
-        }
       } else {
         double x[V];
         operand_vec<V>(c, s.arg, temps, tile, x);
 #pragma unroll
-        for (int r = 0; r < kRegGroups; ++r) {
-          double acc = __longlong_as_double(static_cast<long long>(racc[r][j]));
-#pragma unroll
-          for (int v = 0; v < V; ++v) acc += sel[v] == r ? x[v] : 0.0;
-          racc[r][j] = static_cast<unsigned long long>(__double_as_longlong(acc));
-        }
-#pragma unroll
         for (int v = 0; v < V; ++v) inc[v] = static_cast<unsigned long long>(__double_as_longlong(x[v]));
       }
+      unsigned long long *acc_plane = l_acc + (j + 1) * plane;
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        if (dest[v] == kDestLds) {
-          lds_add(&l_state[(j + 1) * S + slot[v]], inc[v], s.is_int);
-        } else if (dest[v] == kDestGlobal) {
-          global_add(g, j + 1, static_cast<unsigned long long>(slot[v]), inc[v], s.is_int);
+      for (int v = 0; v < V; ++v) lds_add(&acc_plane[slot[v]], inc[v], s.is_int);  // unconditional (trash slot)
+      if (wave_has_global) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          if (global_slot[v] >= 0) global_add(g, j + 1, static_cast<unsigned long long>(global_slot[v]), inc[v], s.is_int);
         }
       }
-    }
-  }
-
-  // ---- registers -> LDS (wave reduction first: one LDS atomic per wave per word) ----
-#pragma unroll
-  for (int r = 0; r < kRegGroups; ++r) {
-    const unsigned long long cnt = wave_reduce_add(static_cast<unsigned long long>(rcnt[r]));
-    if (cnt == 0) continue;  // wave-uniform
-    if (lane_id() == 0) atomicAdd(&l_rstate[r * (NS + 1)], cnt);
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      unsigned long long v;
-      if (c.sums[j].is_int) {
-        v = wave_reduce_add(racc[r][j]);
-      } else {
-        v = static_cast<unsigned long long>(__double_as_longlong(
-            wave_reduce_add(__longlong_as_double(static_cast<long long>(racc[r][j])))));
-      }
-      if (lane_id() == 0) lds_add(&l_rstate[r * (NS + 1) + j + 1], v, c.sums[j].is_int);
     }
   }
   __syncthreads();
 
-  // ---- LDS -> global table: one atomic per group per accumulator per workgroup ------
-  for (int i = threadIdx.x; i < kRegGroups + S; i += kABlock) {
-    unsigned long long code;
-    const unsigned long long *src;
-    int stride;
-    if (i < kRegGroups) {
-      code = l_tags[i];
-      src = &l_rstate[i * (NS + 1)];
-      stride = 1;
-    } else {
-      code = l_keys[i - kRegGroups];
-      src = &l_state[i - kRegGroups];
-      stride = S;
-    }
-    const unsigned long long cnt = src[0];
-    if (code == kEmptyCode || cnt == 0) continue;
+  // ---- LDS -> global table: fold the REP partials, one global atomic per group per
+  // accumulator per workgroup --------------------------------------------------------
+  const int rep = 1 << rep_shift;
+  for (int s = threadIdx.x; s < S; s += kABlock) {
+    const unsigned long long code = l_keys[s];
+    if (code == kEmptyCode) continue;
+    unsigned long long cnt = 0;
+    for (int r = 0; r < rep; ++r) cnt += l_acc[(s << rep_shift) + r];
+    if (cnt == 0) continue;
     const unsigned long long gs = global_find_or_insert(g, code);
     if (gs == ~0ull) continue;
     global_add(g, 0, gs, cnt, 1);
-    for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, src[(j + 1) * stride], c.sums[j].is_int);
+    for (int j = 0; j < NS; ++j) {
+      const unsigned long long *p = l_acc + (j + 1) * plane + (s << rep_shift);
+      unsigned long long v;
+      if (c.sums[j].is_int) {
+        v = 0;
+        for (int r = 0; r < rep; ++r) v += p[r];
+      } else {
+        double d = 0.0;
+        for (int r = 0; r < rep; ++r) d += __longlong_as_double(static_cast<long long>(p[r]));
+        v = static_cast<unsigned long long>(__double_as_longlong(d));
+      }
+      global_add(g, j + 1, gs, v, c.sums[j].is_int);
+    }
   }
+}
+
+// Interpreter: the configuration arrives as a kernel argument.
+template <int NS, int V>
+__global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, int64_t n,
+                                                                 const uint64_t *__restrict__ filter,
+                                                                 HashTableView g, int S, int rep_shift, int nbuf) {
+  agg_hash_update_body<false, NS, V>(c, c.cols, n, filter, g, S, rep_shift, nbuf);
+}
+
+struct ColumnPointers {
+  const void *p[QSX_MAX_COLUMNS];
+};
+
+// AOT plan shape: the translated configuration is a function-local static constexpr
+// object, i.e. a true constant of the code object, so after the configuration loops are
+// unrolled every load from it constant-folds and the interpreter disappears: what is left
+// is the straight-line arithmetic of that plan.
+template <typename Shape, int V>
+__global__ __launch_bounds__(kABlock) void agg_hash_shape_kernel(ColumnPointers cols, int64_t n, HashTableView g, int S,
+                                                                int rep_shift, int nbuf) {
+  static constexpr Translated T = Shape::translated(kABlock * V);
+  agg_hash_update_body<true, T.num_sums, V>(T.dev, cols.p, n, nullptr, g, S, rep_shift, nbuf);
 }
 
 }  // namespace qsx

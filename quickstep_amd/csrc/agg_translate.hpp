@@ -1,0 +1,233 @@
+// agg_translate.hpp — qsx_agg_config_t (public descriptor) -> device-side plan.
+// constexpr so that the same code runs at state creation (host, run time) and
+// inside the ahead-of-time plan-shape specialisations (agg_shapes.hpp, compile time).
+#ifndef QSX_CSRC_AGG_TRANSLATE_HPP_
+#define QSX_CSRC_AGG_TRANSLATE_HPP_
+
+#include "agg_common.hpp"
+
+namespace qsx {
+
+struct FinalizeDesc {
+  int num_aggs;
+  int fn[QSX_MAX_AGGS];
+  int sum_col[QSX_MAX_AGGS];  // state column of the aggregate's sum (>= 1), 0 for COUNT(*)
+  int is_int[QSX_MAX_AGGS];
+  int num_keys;
+  int key_width[QSX_MAX_KEYS];
+  int key_shift[QSX_MAX_KEYS];
+  int key_type[QSX_MAX_KEYS];
+  void *out_keys[QSX_MAX_KEYS];
+  void *out_vals[QSX_MAX_AGGS];
+  uint8_t *out_nulls[QSX_MAX_AGGS];
+};
+
+struct Translated {
+  int status;
+  DevConfig dev;     // everything but cols[] and the LDS plan
+  FinalizeDesc fin;  // everything but the output pointers
+  int num_sums;
+  int num_cols;      // state columns in the image
+  unsigned int_col_mask;
+  unsigned used_columns;
+  bool dense;
+  bool dense_has_count;
+};
+
+constexpr int type_width_ce(int type) {
+  return (type == QSX_INT || type == QSX_FLOAT) ? 4 : ((type == QSX_LONG || type == QSX_DOUBLE) ? 8 : 0);
+}
+
+constexpr bool valid_operand(const qsx_agg_config_t &c, const qsx_operand_t &o, int defined_temps_mask) {
+  switch (o.kind) {
+    case QSX_OPD_COLUMN: {
+      if (o.index < 0 || o.index >= c.num_columns) return false;
+      const int t = c.column_type[o.index];
+      return t == QSX_INT || t == QSX_LONG || t == QSX_FLOAT || t == QSX_DOUBLE;
+    }
+    case QSX_OPD_CONST: return o.index >= 0 && o.index < QSX_MAX_CONSTS;
+    case QSX_OPD_TEMP: return o.index >= 0 && o.index < QSX_MAX_TEMPS && ((defined_temps_mask >> o.index) & 1);
+    default: return false;
+  }
+}
+
+constexpr Translated fail(Translated t, int status) {
+  t.status = status;
+  return t;
+}
+
+constexpr Translated translate(const qsx_agg_config_t &c) {
+  Translated t{};
+  t.status = QSX_OK;
+  if (c.num_columns < 0 || c.num_columns > QSX_MAX_COLUMNS || c.num_keys < 0 || c.num_keys > QSX_MAX_KEYS ||
+      c.num_aggs < 0 || c.num_aggs > QSX_MAX_AGGS || c.num_instrs < 0 || c.num_instrs > QSX_MAX_INSTRS ||
+      c.num_pred_terms < 0 || c.num_pred_terms > QSX_MAX_PRED_TERMS) {
+    return fail(t, QSX_ERR_INVALID_ARGUMENT);
+  }
+  DevConfig &d = t.dev;
+  d.num_columns = c.num_columns;
+  for (int i = 0; i < c.num_columns; ++i) {
+    const int ty = c.column_type[i], w = c.column_width[i];
+    if (ty == QSX_CHAR) {
+      if (w != 1 && w != 2 && w != 4 && w != 8) return fail(t, QSX_ERR_UNSUPPORTED);
+    } else if (type_width_ce(ty) == 0 || w != type_width_ce(ty)) {
+      return fail(t, QSX_ERR_INVALID_ARGUMENT);
+    }
+    d.column_type[i] = ty;
+    d.column_width[i] = w;
+  }
+  switch (c.strategy) {
+    case QSX_AGG_SINGLE_STATE:
+      if (c.num_keys != 0) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+      break;
+    case QSX_AGG_COLLISION_FREE:
+      if (c.num_keys != 1 || c.num_entries <= 0) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+      break;
+    case QSX_AGG_COMPACT_KEY:
+    case QSX_AGG_GENERIC:
+      if (c.num_keys < 1) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+      break;
+    default: return fail(t, QSX_ERR_INVALID_ARGUMENT);
+  }
+  d.num_keys = c.num_keys;
+  int offset_bytes = 0;
+  for (int k = 0; k < c.num_keys; ++k) {
+    const int col = c.key_column[k];
+    if (col < 0 || col >= c.num_columns) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+    const int ty = c.column_type[col];
+    if (c.strategy == QSX_AGG_COLLISION_FREE && ty != QSX_INT && ty != QSX_LONG) return fail(t, QSX_ERR_UNSUPPORTED);
+    if (c.strategy == QSX_AGG_GENERIC && ty == QSX_CHAR) return fail(t, QSX_ERR_UNSUPPORTED);  // FarmHash keys: out of scope
+    d.key_column[k] = col;
+    d.key_width[k] = c.column_width[col];
+    d.key_shift[k] = offset_bytes * 8;
+    offset_bytes += c.column_width[col];
+  }
+  // both hash strategies pack the whole key into one 64-bit code
+  if (offset_bytes > 8) return fail(t, QSX_ERR_UNSUPPORTED);
+  // expression program
+  int defined = 0;
+  d.num_instrs = c.num_instrs;
+  for (int k = 0; k < c.num_instrs; ++k) {
+    const qsx_expr_instr_t &in = c.instrs[k];
+    if (in.op < QSX_EX_ADD || in.op > QSX_EX_DIV || in.dst < 0 || in.dst >= QSX_MAX_TEMPS) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+    if (!valid_operand(c, in.a, defined) || !valid_operand(c, in.b, defined)) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+    d.instrs[k].op = in.op;
+    d.instrs[k].dst = in.dst;
+    d.instrs[k].a = DevOperand{in.a.kind, in.a.index};
+    d.instrs[k].b = DevOperand{in.b.kind, in.b.index};
+    defined |= 1 << in.dst;
+  }
+  for (int k = 0; k < QSX_MAX_CONSTS; ++k) d.consts[k] = c.consts[k];
+  // aggregates -> state columns
+  FinalizeDesc &f = t.fin;
+  f.num_aggs = c.num_aggs;
+  int ns = 0;
+  bool needs_count = false;
+  for (int a = 0; a < c.num_aggs; ++a) {
+    const qsx_agg_desc_t &ag = c.aggs[a];
+    f.fn[a] = ag.fn;
+    if (ag.fn == QSX_AGG_COUNT_STAR) {
+      needs_count = true;
+      f.sum_col[a] = 0;
+      continue;
+    }
+    if (ag.fn != QSX_AGG_SUM && ag.fn != QSX_AGG_AVG) return fail(t, QSX_ERR_UNSUPPORTED);
+    if (ag.arg.kind == QSX_OPD_CONST || !valid_operand(c, ag.arg, defined)) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+    if (ag.fn == QSX_AGG_AVG) needs_count = true;
+    const bool is_int = ag.arg.kind == QSX_OPD_COLUMN &&
+                        (c.column_type[ag.arg.index] == QSX_INT || c.column_type[ag.arg.index] == QSX_LONG);
+    f.is_int[a] = is_int ? 1 : 0;
+    // SUM(x) and AVG(x) over the same argument share one accumulator (what
+    // ReuseAggregateExpressions does on the optimizer side,
+    // query_optimizer/rules/ReuseAggregateExpressions.hpp:43-80).
+    int j = 0;
+    while (j < ns && !(d.sums[j].arg.kind == ag.arg.kind && d.sums[j].arg.index == ag.arg.index)) ++j;
+    if (j == ns) {
+      d.sums[ns].arg = DevOperand{ag.arg.kind, ag.arg.index};
+      d.sums[ns].is_int = is_int ? 1 : 0;
+      ++ns;
+    }
+    f.sum_col[a] = j + 1;  // fixed up below for dense states without a count column
+  }
+  d.num_sums = ns;
+  t.num_sums = ns;
+  // predicate
+  d.num_pred = c.num_pred_terms;
+  for (int p = 0; p < c.num_pred_terms; ++p) {
+    const qsx_pred_term_t &term = c.pred[p];
+    if (term.column < 0 || term.column >= c.num_columns || term.op < QSX_EQ || term.op > QSX_GE) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+    d.pred[p].column = term.column;
+    d.pred[p].op = term.op;
+    unsigned long long bits = 0;
+    switch (c.column_type[term.column]) {
+      case QSX_INT: bits = static_cast<uint32_t>(term.literal.i32); break;
+      case QSX_LONG: bits = static_cast<unsigned long long>(term.literal.i64); break;
+      case QSX_FLOAT: bits = __builtin_bit_cast(uint32_t, term.literal.f32); break;
+      case QSX_DOUBLE: bits = __builtin_bit_cast(unsigned long long, term.literal.f64); break;
+      default: return fail(t, QSX_ERR_UNSUPPORTED);
+    }
+    d.pred[p].literal = bits;
+  }
+  // finalize key description
+  f.num_keys = c.num_keys;
+  for (int k = 0; k < c.num_keys; ++k) {
+    f.key_width[k] = d.key_width[k];
+    f.key_shift[k] = d.key_shift[k];
+    f.key_type[k] = c.column_type[c.key_column[k]];
+  }
+  // columns the update kernel has to stage: keys, predicate, expression and aggregate operands
+  unsigned used = 0;
+  for (int k = 0; k < c.num_keys; ++k) used |= 1u << c.key_column[k];
+  for (int p = 0; p < c.num_pred_terms; ++p) used |= 1u << c.pred[p].column;
+  for (int k = 0; k < c.num_instrs; ++k) {
+    if (c.instrs[k].a.kind == QSX_OPD_COLUMN) used |= 1u << c.instrs[k].a.index;
+    if (c.instrs[k].b.kind == QSX_OPD_COLUMN) used |= 1u << c.instrs[k].b.index;
+  }
+  for (int j = 0; j < ns; ++j) {
+    if (d.sums[j].arg.kind == QSX_OPD_COLUMN) used |= 1u << d.sums[j].arg.index;
+  }
+  t.used_columns = used;
+  t.dense = c.strategy == QSX_AGG_COLLISION_FREE;
+  t.dense_has_count = needs_count;
+  if (t.dense && !needs_count) {
+    for (int a = 0; a < c.num_aggs; ++a) f.sum_col[a] -= 1;  // no count column in front
+  }
+  t.num_cols = t.dense ? ns + (needs_count ? 1 : 0) : ns + 1;
+  t.int_col_mask = 0;
+  {
+    int col = 0;
+    if (!t.dense || needs_count) t.int_col_mask |= 1u << col++;
+    for (int j = 0; j < ns; ++j, ++col) {
+      if (d.sums[j].is_int) t.int_col_mask |= 1u << col;
+    }
+  }
+  return t;
+}
+
+constexpr size_t align16_ce(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+
+// LDS layout of one tile of `tile_rows` rows: referenced columns back to back (16-byte
+// aligned), then the filter words.  Returns the tile size in bytes.
+constexpr int plan_tile(DevConfig &d, unsigned used_columns, int tile_rows, bool has_filter) {
+  size_t off = 0;
+  for (int col = 0; col < QSX_MAX_COLUMNS; ++col) {
+    if (col < d.num_columns && ((used_columns >> col) & 1u)) {
+      d.lds_off[col] = static_cast<int>(off);
+      off += align16_ce(static_cast<size_t>(tile_rows) * d.column_width[col]);
+    } else {
+      d.lds_off[col] = -1;
+    }
+  }
+  d.filter_lds_off = -1;
+  if (has_filter) {
+    d.filter_lds_off = static_cast<int>(off);
+    off += align16_ce(tile_rows / 64 * 8);
+  }
+  if (off == 0) off = 16;
+  d.tile_bytes = static_cast<int>(off);
+  return d.tile_bytes;
+}
+
+}  // namespace qsx
+
+#endif  // QSX_CSRC_AGG_TRANSLATE_HPP_

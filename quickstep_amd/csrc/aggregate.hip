@@ -38,7 +38,9 @@
 // sums are order-dependent in the last bits, the contract is 1e-6 relative.
 
 #include "agg_common.hpp"
+#include "agg_translate.hpp"
 #include "agg_hash_update.hpp"
+#include "agg_shapes.hpp"
 #include "scan.hpp"
 
 #include <cstdlib>
@@ -131,19 +133,6 @@ __global__ __launch_bounds__(kABlock) void merge_dense_kernel(const unsigned lon
 // ---------------------------------------------------------------------------
 // finalize
 // ---------------------------------------------------------------------------
-struct FinalizeDesc {
-  int num_aggs;
-  int fn[QSX_MAX_AGGS];
-  int sum_col[QSX_MAX_AGGS];  // state column of the aggregate's sum (>= 1), 0 for COUNT(*)
-  int is_int[QSX_MAX_AGGS];
-  int num_keys;
-  int key_width[QSX_MAX_KEYS];
-  int key_shift[QSX_MAX_KEYS];
-  int key_type[QSX_MAX_KEYS];
-  void *out_keys[QSX_MAX_KEYS];
-  void *out_vals[QSX_MAX_AGGS];
-  uint8_t *out_nulls[QSX_MAX_AGGS];
-};
 
 __device__ __forceinline__ void write_values(const FinalizeDesc &f, const unsigned long long *states,
                                              unsigned long long col_stride, unsigned long long idx,
@@ -386,6 +375,7 @@ struct qsx_agg_state {
   long long max_tiles = 0;
   int lds_slots = 64;
   unsigned used_columns = 0;
+  const struct ShapeEntry *shape = nullptr;  // AOT plan shape matching this configuration, if any
 
   HashTableView hash_view() const {
     HashTableView g;
@@ -410,165 +400,45 @@ struct qsx_agg_state {
   }
 };
 
-static bool valid_operand(const qsx_agg_config_t &c, const qsx_operand_t &o, int num_defined_temps_mask) {
-  switch (o.kind) {
-    case QSX_OPD_COLUMN: {
-      if (o.index < 0 || o.index >= c.num_columns) return false;
-      const int t = c.column_type[o.index];
-      return t == QSX_INT || t == QSX_LONG || t == QSX_FLOAT || t == QSX_DOUBLE;
-    }
-    case QSX_OPD_CONST: return o.index >= 0 && o.index < QSX_MAX_CONSTS;
-    case QSX_OPD_TEMP: return o.index >= 0 && o.index < QSX_MAX_TEMPS && ((num_defined_temps_mask >> o.index) & 1);
-    default: return false;
-  }
-}
-
+// Fills the state from the constexpr-capable translation shared with the AOT plan shapes.
 static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
-  if (c.num_columns < 0 || c.num_columns > QSX_MAX_COLUMNS || c.num_keys < 0 || c.num_keys > QSX_MAX_KEYS ||
-      c.num_aggs < 0 || c.num_aggs > QSX_MAX_AGGS || c.num_instrs < 0 || c.num_instrs > QSX_MAX_INSTRS ||
-      c.num_pred_terms < 0 || c.num_pred_terms > QSX_MAX_PRED_TERMS) {
-    return QSX_ERR_INVALID_ARGUMENT;
-  }
-  DevConfig &d = st->dev;
-  std::memset(&d, 0, sizeof(d));
-  d.num_columns = c.num_columns;
-  for (int i = 0; i < c.num_columns; ++i) {
-    const int t = c.column_type[i], w = c.column_width[i];
-    if (t == QSX_CHAR) {
-      if (w != 1 && w != 2 && w != 4 && w != 8) return QSX_ERR_UNSUPPORTED;
-    } else if (type_width(t) == 0 || w != type_width(t)) {
-      return QSX_ERR_INVALID_ARGUMENT;
-    }
-    d.column_type[i] = t;
-    d.column_width[i] = w;
-  }
-  // keys
-  switch (c.strategy) {
-    case QSX_AGG_SINGLE_STATE:
-      if (c.num_keys != 0) return QSX_ERR_INVALID_ARGUMENT;
-      break;
-    case QSX_AGG_COLLISION_FREE:
-      if (c.num_keys != 1 || c.num_entries <= 0) return QSX_ERR_INVALID_ARGUMENT;
-      break;
-    case QSX_AGG_COMPACT_KEY:
-    case QSX_AGG_GENERIC:
-      if (c.num_keys < 1) return QSX_ERR_INVALID_ARGUMENT;
-      break;
-    default: return QSX_ERR_INVALID_ARGUMENT;
-  }
-  d.num_keys = c.num_keys;
-  int offset_bytes = 0;
-  for (int k = 0; k < c.num_keys; ++k) {
-    const int col = c.key_column[k];
-    if (col < 0 || col >= c.num_columns) return QSX_ERR_INVALID_ARGUMENT;
-    const int t = c.column_type[col];
-    if (c.strategy == QSX_AGG_COLLISION_FREE && t != QSX_INT && t != QSX_LONG) return QSX_ERR_UNSUPPORTED;
-    if (c.strategy == QSX_AGG_GENERIC && t == QSX_CHAR) return QSX_ERR_UNSUPPORTED;  // FarmHash keys: out of scope
-    d.key_column[k] = col;
-    d.key_width[k] = c.column_width[col];
-    d.key_shift[k] = offset_bytes * 8;
-    offset_bytes += c.column_width[col];
-  }
-  // both hash strategies pack the whole key into one 64-bit code
-  if (offset_bytes > 8) return QSX_ERR_UNSUPPORTED;
-  // expression program
-  int defined = 0;
-  d.num_instrs = c.num_instrs;
-  for (int k = 0; k < c.num_instrs; ++k) {
-    const qsx_expr_instr_t &in = c.instrs[k];
-    if (in.op < QSX_EX_ADD || in.op > QSX_EX_DIV || in.dst < 0 || in.dst >= QSX_MAX_TEMPS) return QSX_ERR_INVALID_ARGUMENT;
-    if (!valid_operand(c, in.a, defined) || !valid_operand(c, in.b, defined)) return QSX_ERR_INVALID_ARGUMENT;
-    d.instrs[k].op = in.op;
-    d.instrs[k].dst = in.dst;
-    d.instrs[k].a = DevOperand{in.a.kind, in.a.index};
-    d.instrs[k].b = DevOperand{in.b.kind, in.b.index};
-    defined |= 1 << in.dst;
-  }
-  for (int k = 0; k < QSX_MAX_CONSTS; ++k) d.consts[k] = c.consts[k];
-  // aggregates -> state columns
-  FinalizeDesc &f = st->fin;
-  std::memset(&f, 0, sizeof(f));
-  f.num_aggs = c.num_aggs;
-  int ns = 0;
-  bool needs_count = false;
-  for (int a = 0; a < c.num_aggs; ++a) {
-    const qsx_agg_desc_t &ag = c.aggs[a];
-    f.fn[a] = ag.fn;
-    if (ag.fn == QSX_AGG_COUNT_STAR) {
-      needs_count = true;
-      f.sum_col[a] = 0;
-      continue;
-    }
-    if (ag.fn != QSX_AGG_SUM && ag.fn != QSX_AGG_AVG) return QSX_ERR_UNSUPPORTED;
-    if (ag.arg.kind == QSX_OPD_CONST || !valid_operand(c, ag.arg, defined)) return QSX_ERR_INVALID_ARGUMENT;
-    if (ag.fn == QSX_AGG_AVG) needs_count = true;
-    const bool is_int = ag.arg.kind == QSX_OPD_COLUMN &&
-                        (c.column_type[ag.arg.index] == QSX_INT || c.column_type[ag.arg.index] == QSX_LONG);
-    f.is_int[a] = is_int ? 1 : 0;
-    // SUM(x) and AVG(x) over the same argument share one accumulator (what
-    // ReuseAggregateExpressions does on the optimizer side,
-    // query_optimizer/rules/ReuseAggregateExpressions.hpp:43-80).
-    int j = 0;
-    while (j < ns && !(d.sums[j].arg.kind == ag.arg.kind && d.sums[j].arg.index == ag.arg.index)) ++j;
-    if (j == ns) {
-      d.sums[ns].arg = DevOperand{ag.arg.kind, ag.arg.index};
-      d.sums[ns].is_int = is_int ? 1 : 0;
-      ++ns;
-    }
-    f.sum_col[a] = j + 1;  // fixed up below for dense states without a count column
-  }
-  d.num_sums = ns;
-  st->num_sums = ns;
-  // predicate
-  d.num_pred = c.num_pred_terms;
-  for (int p = 0; p < c.num_pred_terms; ++p) {
-    const qsx_pred_term_t &t = c.pred[p];
-    if (t.column < 0 || t.column >= c.num_columns || t.op < QSX_EQ || t.op > QSX_GE) return QSX_ERR_INVALID_ARGUMENT;
-    d.pred[p].column = t.column;
-    d.pred[p].op = t.op;
-    unsigned long long bits = 0;
-    switch (c.column_type[t.column]) {
-      case QSX_INT: bits = static_cast<uint32_t>(t.literal.i32); break;
-      case QSX_LONG: bits = static_cast<unsigned long long>(t.literal.i64); break;
-      case QSX_FLOAT: { uint32_t b; std::memcpy(&b, &t.literal.f32, 4); bits = b; break; }
-      case QSX_DOUBLE: std::memcpy(&bits, &t.literal.f64, 8); break;
-      default: return QSX_ERR_UNSUPPORTED;
-    }
-    d.pred[p].literal = bits;
-  }
-  // finalize key description
-  f.num_keys = c.num_keys;
-  for (int k = 0; k < c.num_keys; ++k) {
-    f.key_width[k] = d.key_width[k];
-    f.key_shift[k] = d.key_shift[k];
-    f.key_type[k] = c.column_type[c.key_column[k]];
-  }
-  // columns the update kernel has to stage: keys, predicate, expression and aggregate operands
-  unsigned used = 0;
-  for (int k = 0; k < c.num_keys; ++k) used |= 1u << c.key_column[k];
-  for (int p = 0; p < c.num_pred_terms; ++p) used |= 1u << c.pred[p].column;
-  for (int k = 0; k < c.num_instrs; ++k) {
-    if (c.instrs[k].a.kind == QSX_OPD_COLUMN) used |= 1u << c.instrs[k].a.index;
-    if (c.instrs[k].b.kind == QSX_OPD_COLUMN) used |= 1u << c.instrs[k].b.index;
-  }
-  for (int j = 0; j < ns; ++j) if (d.sums[j].arg.kind == QSX_OPD_COLUMN) used |= 1u << d.sums[j].arg.index;
-  st->used_columns = used;
-  st->dense = c.strategy == QSX_AGG_COLLISION_FREE;
-  st->dense_has_count = needs_count;
-  if (st->dense && !needs_count) {
-    for (int a = 0; a < c.num_aggs; ++a) f.sum_col[a] -= 1;  // no count column in front
-  }
-  st->num_cols = st->dense ? ns + (needs_count ? 1 : 0) : ns + 1;
-  st->int_col_mask = 0;
-  {
-    int col = 0;
-    if (!st->dense || needs_count) st->int_col_mask |= 1u << col++;
-    for (int j = 0; j < ns; ++j, ++col) if (d.sums[j].is_int) st->int_col_mask |= 1u << col;
-  }
+  const Translated t = translate(c);
+  if (t.status != QSX_OK) return t.status;
+  st->dev = t.dev;
+  st->fin = t.fin;
+  st->num_sums = t.num_sums;
+  st->num_cols = t.num_cols;
+  st->int_col_mask = t.int_col_mask;
+  st->used_columns = t.used_columns;
+  st->dense = t.dense;
+  st->dense_has_count = t.dense_has_count;
   return QSX_OK;
 }
 
 static size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+
+// Launch geometry of the hash-strategy update kernel; the environment overrides exist for
+// tuning sweeps on the GPU box (tools/agg_probe.py), the defaults are the measured best.
+struct AggTuning {
+  int rows_per_thread;   // V of the interpreter kernel: 2 or 4 (tile = 256 * V rows)
+  int shape_rows_per_thread;  // V of the AOT plan-shape kernels
+  int buffers;           // 1 or 2 tile buffers per workgroup
+  int acc_kib;           // LDS budget of the replicated accumulators
+  int max_blocks_per_cu;
+};
+static const AggTuning &agg_tuning() {
+  static AggTuning t = []() {
+    // measured on MI355X (tools/agg_sweep.sh, 600 M Q1 rows): shape kernel V=4, 1 buffer, 16 KiB
+    // accumulators, 4 workgroups/CU = 3.47 ms; interpreter V=2 = 10.9 ms
+    AggTuning v{2, 4, 1, 16, 4};
+    if (const char *e = getenv("QSX_AGG_ROWS_PER_THREAD")) v.rows_per_thread = v.shape_rows_per_thread = atoi(e) == 4 ? 4 : 2;
+    if (const char *e = getenv("QSX_AGG_BUFFERS")) v.buffers = atoi(e) == 2 ? 2 : 1;
+    if (const char *e = getenv("QSX_AGG_ACC_KIB")) v.acc_kib = atoi(e) > 0 ? atoi(e) : 12;
+    if (const char *e = getenv("QSX_AGG_BLOCKS_PER_CU")) v.max_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 4;
+    return v;
+  }();
+  return t;
+}
 
 // Lays the referenced columns of one TR-row tile out in LDS and launches the
 // update kernel with two tile buffers (DMA double buffering).
@@ -592,8 +462,12 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   }
   if (off == 0) off = 16;
   dc.tile_bytes = static_cast<int>(off);
-  const size_t lds = 2 * off + sizeof(unsigned long long) *
-                                   (kRegGroups + kRegGroups * (NS + 1) + S + static_cast<size_t>(NS + 1) * S);
+  // replicate every accumulator as far as the budget allows (64 = one bank column per lane)
+  const AggTuning &tune = agg_tuning();
+  int rep_shift = 6;
+  while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * (S + 1) * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
+  const int nbuf = tune.buffers;
+  const size_t lds = nbuf * off + sizeof(unsigned long long) * (S + ((static_cast<size_t>(NS + 1) * (S + 1)) << rep_shift));
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   if (dry_run) return QSX_OK;
@@ -605,21 +479,77 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   }
   // grid = what is resident at once (LDS-limited workgroups per CU), tiles are strided over it
   int per_cu = static_cast<int>(kMaxLds / lds);
-  if (per_cu > 4) per_cu = 4;
+  if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
   if (per_cu < 1) per_cu = 1;
   const int64_t num_tiles = (n + TR - 1) / TR;
   const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
   const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
-  hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S);
+  hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S,
+                     rep_shift, nbuf);
   return QSX_OK;
 }
 
-static int agg_rows_per_thread() {
-  static int v = []() {
-    const char *e = getenv("QSX_AGG_ROWS_PER_THREAD");
-    return e != nullptr && atoi(e) == 2 ? 2 : 4;
-  }();
-  return v;
+static int agg_rows_per_thread() { return agg_tuning().rows_per_thread; }
+
+// ---- AOT plan shapes (agg_shapes.hpp) -------------------------------------------------
+typedef int (*ShapeLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
+                             hipStream_t stream);
+struct ShapeEntry {
+  const char *name;
+  qsx_agg_config_t config;
+  ShapeLauncher launch;
+};
+
+template <typename Shape, int V>
+static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
+                          hipStream_t stream) {
+  constexpr int TR = kABlock * V;
+  constexpr Translated T = Shape::translated(TR);
+  static_assert(T.status == QSX_OK, "plan shape does not translate");
+  constexpr int NS = T.num_sums;
+  const AggTuning &tune = agg_tuning();
+  int rep_shift = 6;
+  while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * (S + 1) * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
+  const int nbuf = tune.buffers;
+  const size_t lds = static_cast<size_t>(nbuf) * T.dev.tile_bytes +
+                     sizeof(unsigned long long) * (S + ((static_cast<size_t>(NS + 1) * (S + 1)) << rep_shift));
+  constexpr size_t kMaxLds = 160 * 1024;
+  if (lds > kMaxLds) return QSX_ERR_CAPACITY;
+  static bool attribute_set = false;
+  if (!attribute_set) {
+    QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_kernel<Shape, V>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
+    attribute_set = true;
+  }
+  int per_cu = static_cast<int>(kMaxLds / lds);
+  if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t num_tiles = (n + TR - 1) / TR;
+  const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
+  const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
+  ColumnPointers cp;
+  for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < num_columns ? cols[i] : nullptr;
+  hipLaunchKernelGGL((agg_hash_shape_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g, S, rep_shift, nbuf);
+  return QSX_OK;
+}
+
+template <typename Shape>
+static int launch_shape(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
+                        hipStream_t stream) {
+  if (agg_tuning().shape_rows_per_thread == 4) return launch_shape_v<Shape, 4>(cols, num_columns, n, g, S, stream);
+  return launch_shape_v<Shape, 2>(cols, num_columns, n, g, S, stream);
+}
+
+static const ShapeEntry *find_shape(const qsx_agg_config_t &c) {
+  static const ShapeEntry table[] = {
+      {"tpch_q1", ShapeTpchQ1::config(), &launch_shape<ShapeTpchQ1>},
+      {"two_int_keys_sum_count_avg", ShapeTwoIntKeysSumCountAvg::config(), &launch_shape<ShapeTwoIntKeysSumCountAvg>},
+  };
+  if (getenv("QSX_AGG_NO_SPECIALIZE") != nullptr && atoi(getenv("QSX_AGG_NO_SPECIALIZE")) != 0) return nullptr;
+  for (const ShapeEntry &e : table) {
+    if (same_plan(e.config, c)) return &e;
+  }
+  return nullptr;
 }
 
 template <int NS>
@@ -671,6 +601,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
   st->config = *config;
   int rc = translate_config(*config, st);
   if (rc != QSX_OK) { delete st; return rc; }
+  if (!st->dense) st->shape = find_shape(*config);
   if (st->dense) {
     st->exist_words = (config->num_entries + 63) / 64;
     st->image_bytes = sizeof(unsigned long long) * (st->exist_words + static_cast<size_t>(st->num_cols) * config->num_entries);
@@ -682,8 +613,8 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     st->cap = next_pow2(static_cast<uint64_t>(est) * 8 + 1024);
     st->image_bytes = sizeof(unsigned long long) * (st->cap + 1) * (st->num_cols + 1);
     // workgroup-private LDS table: up to 512 slots (<= 40 KiB at NS = 8)
-    uint64_t s = next_pow2(static_cast<uint64_t>(est) * 4);
-    if (s < 64) s = 64;
+    uint64_t s = next_pow2(static_cast<uint64_t>(est) * 2);
+    if (s < 8) s = 8;
     if (s > 512) s = 512;
     st->lds_slots = static_cast<int>(s);
   }
@@ -756,7 +687,11 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
   } else {
     const HashTableView g = st->hash_view();
     int rc = QSX_OK;
-    QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, st->lds_slots, s);
+    if (st->shape != nullptr && filter_dev == nullptr) {
+      rc = st->shape->launch(cols, st->config.num_columns, n, g, st->lds_slots, s);
+    } else {
+      QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, st->lds_slots, s);
+    }
     if (rc != QSX_OK) return rc;
   }
   QSX_CHECK_LAUNCH();

@@ -110,7 +110,7 @@ int main() {
     auto cols = readAll(ctx, dest, f.storage, result, &rows);
     EXPECT_EQ(rows, static_cast<std::size_t>(1));  // exactly one row, even for zero input rows (:1160-1345)
     const int last = predicate_value == -2 ? 299 : predicate_value - 1;
-    const std::int64_t count = last + 1;
+    const std::int64_t count = last + 1 > 0 ? last + 1 : 0;  // "< -1" selects nothing
     EXPECT_EQ(at<std::int64_t>(cols[3], 0), count);
     if (count > 0) {
       EXPECT_EQ(at<std::int64_t>(cols[0], 0), Summation(last));            // SUM(int) is LONG, exact

@@ -300,3 +300,31 @@ def test_q1_at_scale_properties(capi, dev):
         ref = (price[sel] * (1 - disc[sel])).sum().item()
         assert abs(float(vals[2][row]) - ref) <= FP_RTOL * abs(ref)
         assert abs(float(vals[6][row]) - disc[sel].mean().item()) <= FP_RTOL
+
+
+def test_plan_shape_and_interpreter_agree(capi, oracle, dev):
+    """The AOT plan-shape kernels (csrc/agg_shapes.hpp) and the interpreter kernel run the same body;
+    QSX_AGG_NO_SPECIALIZE=1 (read at state creation) forces the interpreter.  Both must match the oracle
+    and each other (integers bit-exact)."""
+    import os
+    rng = np.random.default_rng(77)
+    n = 500_003
+    for cfg, cols in ((q1_config(), q1_columns(rng, n)),
+                      (T.make_agg_config(T.AGG_COMPACT_KEY, [(T.INT, None), (T.INT, None), (T.DOUBLE, None)], keys=[0, 1],
+                                         aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None), (T.AGG_AVG, T.col(2))], est_groups=200),
+                       [rng.integers(0, 20, size=n).astype(np.int32), rng.integers(-5, 5, size=n).astype(np.int32),
+                        rng.normal(size=n)])):
+        results = []
+        for no_spec in ("0", "1"):
+            os.environ["QSX_AGG_NO_SPECIALIZE"] = no_spec
+            try:
+                st = run_hip(capi, dev, cfg, cols, blocks=2)
+            finally:
+                os.environ.pop("QSX_AGG_NO_SPECIALIZE", None)
+            results.append(finalize_np(st, dev))
+        o = oracle.AggState(cfg)
+        o.update(cols, n)
+        ref = o.finalize()
+        assert_same_groups(results[0], ref)
+        assert_same_groups(results[1], ref)
+        assert_same_groups(results[0], results[1])
