@@ -155,7 +155,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if capi.device_count() < 1:
         raise SystemExit("libqsx.so sees no gfx950 device; there is no CPU path to benchmark")
-    distributed = world > 1
+    # QSX_BENCH_FORCE_DISTRIBUTED=1 runs the multi-GPU code path (RCCL shuffle + merge) even with one rank:
+    # used to validate that path on the 1-GPU box (torch.distributed.run --nproc-per-node 1).
+    distributed = world > 1 or os.environ.get("QSX_BENCH_FORCE_DISTRIBUTED") == "1"
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
@@ -209,7 +211,7 @@ def main():
             e0.record()
             nb = join.build(build_keys, rank * args.build_rows)
             e1.record()
-            probe_tids, build_tids, op, ob, cnt = join.probe(probe_keys, 0, capacity=capacity)
+            probe_tids, build_tids, op, ob, cnt = join.probe(probe_keys, rank * args.probe_rows, capacity=capacity)
             e2.record()
             main_stream.wait_stream(agg_stream)
             results.update(matches=cnt, groups=fin[3], built=nb)
