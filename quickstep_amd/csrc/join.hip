@@ -23,7 +23,10 @@
 // streams the pairs out coalesced.
 
 #include "common.hpp"
+#include "join_radix.hpp"
+#include "scan.hpp"
 
+#include <cstdlib>
 #include <mutex>
 #include <shared_mutex>
 
@@ -43,6 +46,7 @@ struct TableView {
   void *slots;    // uint64_t[capacity] (INT) or LongEntry[capacity] (LONG)
   uint64_t mask;  // capacity - 1 (entries)
   int shift;      // 64 - log2(capacity)
+  unsigned int *max_disp;  // largest displacement from the home slot any insert saw (radix probe margin)
 };
 
 __device__ __forceinline__ uint64_t slot_of(int32_t key, const TableView &t) {
@@ -61,13 +65,16 @@ __device__ __forceinline__ void insert_entry(const TableView &t, int32_t key, ui
   const uint64_t packed = (static_cast<uint64_t>(tid) << 32) | static_cast<uint32_t>(key);
   // Home position = entry 0 of the key's 16-byte unit, so that a probe that
   // starts at the unit boundary sees the sequence without gaps.
-  uint64_t s = slot_of(key, t) & ~1ull;
+  const uint64_t home = slot_of(key, t) & ~1ull;
+  uint64_t s = home;
   for (;;) {
     const unsigned long long old =
         atomicCAS(reinterpret_cast<unsigned long long *>(&slots[s]), kEmpty64, packed);
-    if (old == kEmpty64) return;
+    if (old == kEmpty64) break;
     s = (s + 1) & t.mask;
   }
+  const unsigned int disp = static_cast<unsigned int>((s - home) & t.mask);
+  if (disp > __hip_atomic_load(t.max_disp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(t.max_disp, disp);
 }
 
 __device__ __forceinline__ void insert_entry(const TableView &t, int64_t key, uint32_t tid) {
@@ -341,6 +348,8 @@ struct qsx_join_table {
   // HashTable::resize_shared_mutex_ (storage/HashTable.hpp:1215).
   std::shared_mutex mutex;
 
+  unsigned int *max_disp_dev = nullptr;  // see TableView::max_disp (second word of the entries_dev allocation)
+
   size_t entry_bytes() const { return key_type == QSX_INT ? 8 : 16; }
   TableView view() const {
     TableView v;
@@ -349,6 +358,7 @@ struct qsx_join_table {
     int log2 = 0;
     while ((1ull << log2) < capacity) ++log2;
     v.shift = 64 - log2;
+    v.max_disp = max_disp_dev;
     return v;
   }
 };
@@ -392,6 +402,7 @@ static int ensure_room(qsx_join_table *t, int64_t additional) {
   t->slots = bigger;
   t->capacity = new_capacity;
   TableView dst = t->view();
+  QSX_HIP_TRY(hipMemset(t->max_disp_dev, 0, sizeof(unsigned int)));
   hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(src.mask + 1, kJBlock)), dim3(kJBlock), 0, nullptr,
                      t->key_type == QSX_LONG ? 1 : 0, src, dst);
   QSX_CHECK_LAUNCH();
@@ -412,8 +423,9 @@ int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **
   t->capacity = capacity_for(est_entries);
   int rc = allocate_slots(t, t->capacity, &t->slots);
   if (rc != QSX_OK) { delete t; return rc; }
-  hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, sizeof(unsigned long long));
+  hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), 2 * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, 2 * sizeof(unsigned long long));
+  t->max_disp_dev = reinterpret_cast<unsigned int *>(t->entries_dev + 1);
   if (err != hipSuccess) {
     set_last_error("hipMalloc(entries)", err);
     (void)hipFree(t->slots);
@@ -438,7 +450,7 @@ int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
   if (t == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   std::unique_lock<std::shared_mutex> lock(t->mutex);
   QSX_HIP_TRY(hipMemsetAsync(t->slots, 0xFF, t->capacity * t->entry_bytes(), as_stream(stream)));
-  QSX_HIP_TRY(hipMemsetAsync(t->entries_dev, 0, sizeof(unsigned long long), as_stream(stream)));
+  QSX_HIP_TRY(hipMemsetAsync(t->entries_dev, 0, 2 * sizeof(unsigned long long), as_stream(stream)));
   t->reserved = 0;
   return QSX_OK;
 }
@@ -477,6 +489,83 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
 
 }  // extern "C"
 
+// ---- radix-partitioned probe (join_radix.hpp) ---------------------------------------------------
+constexpr int64_t kRadixMinBuildRows = 131072;   // below this the table (<= 2 MiB) lives in every XCD's L2
+constexpr int64_t kRadixMinProbeRows = 1 << 20;
+
+// Opt-in (QSX_JOIN_RADIX=1): measured on MI355X for the C2 shape (1 M x 100 M) the partitioned path
+// is not yet faster than probing the 16 MiB table directly (2.4 ms vs 1.9 ms, profiles/README.md);
+// it stays selectable for parity tests and as the base of further tuning.
+static bool radix_enabled() {
+  static const bool on = []() {
+    const char *e = getenv("QSX_JOIN_RADIX");
+    return e != nullptr && atoi(e) != 0;
+  }();
+  return on;
+}
+
+template <int MODE>
+static int launch_probe_radix(qsx_join_table *t, const int32_t *keys, int64_t n, int32_t probe_base_tid,
+                              const uint64_t *filter, int32_t *out_probe, int32_t *out_build, int64_t capacity,
+                              unsigned long long *count, hipStream_t stream) {
+  const TableView v = t->view();
+  int log_cap = 64 - v.shift;
+  int log_p = 4;
+  while (log_p < 10 && (t->reserved >> log_p) > 2048) ++log_p;   // <= ~2 K entries per partition, P <= 1024
+  if (log_p > log_cap - 8) log_p = log_cap - 8;                  // at least 256 slots per partition
+  RadixGeom geom;
+  geom.table_shift = v.shift;
+  geom.part_shift = log_cap - log_p;
+  geom.log_p = log_p;
+  const int P = 1 << log_p;
+  // G workgroups, each owning one contiguous chunk of probe rows
+  int64_t G = (n + 4 * kRadixTile - 1) / (4 * kRadixTile);
+  if (G > 1024) G = 1024;
+  if (G < 1) G = 1;
+  int64_t rows_per_block = (n + G - 1) / G;
+  rows_per_block = (rows_per_block + kRadixTile - 1) / kRadixTile * kRadixTile;
+  G = (n + rows_per_block - 1) / rows_per_block;
+  const int64_t cells = static_cast<int64_t>(P) * G;
+  // stream-ordered scratch: concurrent probes (one per Worker stream) never share it
+  int32_t *pk = nullptr, *pt = nullptr, *hist_t = nullptr;
+  int64_t *starts = nullptr, *scan_ws = nullptr;
+  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&pk), static_cast<size_t>(n) * 4 + 16, stream));
+  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&pt), static_cast<size_t>(n) * 4 + 16, stream));
+  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&hist_t), static_cast<size_t>(cells) * 4 + 64, stream));
+  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&starts), static_cast<size_t>(cells + 1) * 8, stream));
+  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&scan_ws), scan_workspace_words(cells) * 8, stream));
+  hipLaunchKernelGGL(radix_probe_hist, dim3(static_cast<unsigned>(G)), dim3(kRBlock), P * sizeof(int32_t), stream, keys, n,
+                     filter, geom, rows_per_block, hist_t);
+  QSX_CHECK_LAUNCH();
+  QSX_HIP_TRY(launch_scan(hist_t, cells, starts, nullptr, scan_ws, stream));
+  const size_t scatter_lds = sizeof(int32_t) * (2 * kRadixTile + 2 * P + (P & 1)) + sizeof(int64_t) * P;
+  hipLaunchKernelGGL(radix_probe_scatter, dim3(static_cast<unsigned>(G)), dim3(kRBlock), scatter_lds, stream, keys, n, filter,
+                     probe_base_tid, geom, rows_per_block, starts, pk, pt);
+  QSX_CHECK_LAUNCH();
+  RadixJoinArgs a;
+  a.table_slots = static_cast<const unsigned long long *>(v.slots);
+  a.table_mask = v.mask;
+  a.max_disp = v.max_disp;
+  a.geom = geom;
+  a.probe_keys = pk;
+  a.probe_tids = pt;
+  a.probe_starts = starts;
+  a.probe_blocks = G;
+  int slices = static_cast<int>((static_cast<int64_t>(kCUs) * 6 + P - 1) / P);   // ~6 workgroups per CU in total
+  const int64_t per_partition = n / P + 1;
+  while (slices > 1 && per_partition / slices < 4 * kRadixJoinTile) --slices;
+  a.slices = slices;
+  hipLaunchKernelGGL((radix_join<MODE>), dim3(static_cast<unsigned>(P * slices)), dim3(kRBlock), 0, stream, a, out_probe,
+                     out_build, capacity, count);
+  QSX_CHECK_LAUNCH();
+  QSX_HIP_TRY(hipFreeAsync(pk, stream));
+  QSX_HIP_TRY(hipFreeAsync(pt, stream));
+  QSX_HIP_TRY(hipFreeAsync(hist_t, stream));
+  QSX_HIP_TRY(hipFreeAsync(starts, stream));
+  QSX_HIP_TRY(hipFreeAsync(scan_ws, stream));
+  return QSX_OK;
+}
+
 template <int MODE>
 static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_t probe_base_tid,
                         const uint64_t *filter, int32_t *out_probe, int32_t *out_build,
@@ -485,6 +574,11 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
   if (out_count != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), stream));
   if (n == 0) return QSX_OK;
   std::shared_lock<std::shared_mutex> lock(t->mutex);
+  if (MODE != 2 && t->key_type == QSX_INT && radix_enabled() && t->reserved >= kRadixMinBuildRows &&
+      n >= kRadixMinProbeRows) {
+    return launch_probe_radix<MODE>(t, static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build,
+                                    capacity, reinterpret_cast<unsigned long long *>(out_count), stream);
+  }
   const int64_t num_tiles = (n + kProbeTile - 1) / kProbeTile;
   // 4 workgroups per CU keep 128 KiB of the 160 KiB LDS busy in pair mode.
   const int64_t max_grid = MODE == 0 ? 4 * kCUs : 8 * kCUs;

@@ -165,3 +165,32 @@ def test_fk_join_at_scale_properties(capi, dev):
     k = int(cnt2.item())
     assert k == int((probe2 < n_build).sum().item())
     assert bool((build[b2[:k].long()] == probe2[p2[:k].long()]).all())
+
+
+@pytest.mark.parametrize("n_build,n_probe,key_range,hot", [(300_000, 2_000_000, 250_000, 0), (1_200_000, 3_000_001, 5_000_000, 0),
+                                                            (200_000, 1_500_000, 2_000_000, 6000)])
+def test_radix_partitioned_probe_matches_oracle(capi, oracle, dev, n_build, n_probe, key_range, hot):
+    """Build >= 128 K entries and probe >= 1 M rows take the radix-partitioned LDS-table path
+    (csrc/join_radix.hpp): duplicates, filters, negative keys, and (hot > 0) one key with thousands of
+    build duplicates so that its partition overflows the LDS table and falls back to the global table."""
+    rng = np.random.default_rng(n_build)
+    lo = -key_range // 2
+    build = rng.integers(lo, lo + key_range, size=n_build).astype(np.int32)
+    probe = rng.integers(lo - 10, lo + key_range + 10, size=n_probe).astype(np.int32)
+    if hot:
+        build[:hot] = 424242
+        probe[:20] = 424242                           # 20 probe rows x `hot` matches each
+    blocks = np.array_split(build, 3)
+    pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.8)
+    pf[0] |= np.uint64(0xFFFFF00000000000)            # keep the hot probe rows selected
+    table, p, d, total = hip_join(capi, dev, T.INT, blocks, probe, probe_filter=pf)
+    _, rp, rd = oracle_join(oracle, T.INT, blocks, probe, probe_filter=pf)
+    assert total == rp.size
+    assert np.array_equal(sorted_pairs(p, d), sorted_pairs(rp, rd))
+    # probing again (table unchanged) reuses the partitioned build side; a further build invalidates it
+    _, _, cnt = table.probe(to_dev(probe, dev), capacity=total, filter_bitmap=bitmap_dev(pf, dev))
+    assert int(cnt.item()) == total
+    extra = np.arange(7, dtype=np.int32) + lo
+    table.build(to_dev(extra, dev), base_tid=n_build)
+    want = total + int(np.isin(probe[oracle.bools_from_bitmap(pf, n_probe)], extra).sum())
+    assert int(table.probe_count(to_dev(probe, dev), filter_bitmap=bitmap_dev(pf, dev)).item()) == want
