@@ -12,5 +12,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/pass$i" -o p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > "$out/pass$i.json" 2> "$out/pass$i.err"
 done
-python3 tools/pmc_summary.py "$out" agg_hash_update probe_kernel build_kernel > "$out/summary.txt" 2>&1
+python3 tools/pmc_summary.py "$out" agg_hash probe_kernel build_kernel radix > "$out/summary.txt" 2>&1
 cat "$out/summary.txt"
