@@ -240,9 +240,14 @@ __device__ __forceinline__ void global_add(const HashTableView &g, int col, unsi
 }
 
 // ---- LDS table ------------------------------------------------------------------
+// Probing is bounded (a group lives within kLdsMaxProbes slots of its home or not in LDS at
+// all), so that a full table costs a miss 8 LDS reads, not S: rows of groups that do not fit
+// go to the global table.
+constexpr int kLdsMaxProbes = 8;
 __device__ __forceinline__ int lds_find_or_insert(unsigned long long *l_keys, int S, unsigned long long code) {
   int s = static_cast<int>(mix64(code) >> 40) & (S - 1);
-  for (int probes = 0; probes < S; ++probes) {
+  const int limit = S < kLdsMaxProbes ? S : kLdsMaxProbes;
+  for (int probes = 0; probes < limit; ++probes) {
     unsigned long long k = __hip_atomic_load(&l_keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (k == code) return s;
     if (k == kEmptyCode) {

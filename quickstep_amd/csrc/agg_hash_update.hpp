@@ -239,7 +239,7 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
 __device__ __forceinline__ void classify_row(bool live, unsigned long long code, unsigned long long *l_keys,
                                              unsigned long long *l_acc, int S, int rep_shift, int lane_col,
                                              const HashTableView &g, int &slot, long long &global_slot) {
-  slot = (S << rep_shift) + lane_col;  // trash
+  slot = (S << rep_shift) + lane_id();  // trash: one column per lane whatever REP is (no same-address pile-up)
   global_slot = -1;
   if (!live) return;
   const int s = code == kEmptyCode ? -1 : lds_find_or_insert(l_keys, S, code);
@@ -255,7 +255,7 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
   }
 }
 
-// Dynamic LDS: tile[nbuf][tile_bytes] | l_keys[S] | l_acc[NS + 1][S + 1][REP]   (slot S = trash)
+// Dynamic LDS: tile[nbuf][tile_bytes] | l_keys[S] | l_acc[NS + 1][S * REP + 64]   (last 64 = trash columns)
 // l_acc holds, per accumulator plane and group slot, REP = 2^rep_shift partial
 // values; a lane adds into column (lane & (REP - 1)), so with REP = 64 every
 // lane owns its bank column and a wave's ds_add never conflicts (measured
@@ -263,13 +263,13 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
 template <bool kStatic, int NS, int V>
 __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, int64_t n,
                                                      const uint64_t *__restrict__ filter, const HashTableView &g,
-                                                     int S, int rep_shift, int nbuf) {
+                                                     int S, int rep_shift, int nbuf, int ranges) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int TR = kABlock * V;
   char *tiles = reinterpret_cast<char *>(smem_raw);
   unsigned long long *l_keys = reinterpret_cast<unsigned long long *>(smem_raw + nbuf * c.tile_bytes);  // [S]
   unsigned long long *l_acc = l_keys + S;                                                           // [NS + 1][S << rep_shift]
-  const int plane = (S + 1) << rep_shift;
+  const int plane = (S << rep_shift) + kWave;  // + 64 trash columns
   const int lane_col = lane_id() & ((1 << rep_shift) - 1);
 
   for (int i = threadIdx.x; i < S; i += kABlock) l_keys[i] = kEmptyCode;
@@ -277,13 +277,20 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 
   // nbuf == 2: the DMA of tile i+1 overlaps the compute of tile i inside the workgroup;
   // nbuf == 1: one buffer, overlap comes from the other workgroups resident on the CU.
+  // ranges > 1 (more groups than one LDS table holds): the workgroups split into `ranges`
+  // families; family r walks ALL tiles but only aggregates the groups whose hash falls into
+  // range r, so each family's groups fit its LDS tables.  Costs `ranges` reads of the input
+  // instead of (NS + 1) global atomics per row.
+  const int my_range = ranges > 1 ? static_cast<int>(blockIdx.x % ranges) : 0;
+  const int64_t first_tile = ranges > 1 ? blockIdx.x / ranges : blockIdx.x;
+  const int64_t tile_step = ranges > 1 ? gridDim.x / ranges : gridDim.x;
   const int64_t num_tiles = (n + TR - 1) / TR;
   int buf = 0;
-  if (nbuf == 2 && static_cast<int64_t>(blockIdx.x) < num_tiles) {
-    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * TR;
+  if (nbuf == 2 && first_tile < num_tiles) {
+    const int64_t row0 = first_tile * TR;
     stage_tile<kStatic>(c, cols, filter, tiles, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
   }
-  for (int64_t tile_id = blockIdx.x; tile_id < num_tiles; tile_id += gridDim.x) {
+  for (int64_t tile_id = first_tile; tile_id < num_tiles; tile_id += tile_step) {
     if (nbuf == 1) {
       __syncthreads();  // every wave is done reading the previous tile
       const int64_t row0 = tile_id * TR;
@@ -293,7 +300,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     // every wave is done with the other buffer).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int64_t next = tile_id + gridDim.x;
+    const int64_t next = tile_id + tile_step;
     if (nbuf == 2 && next < num_tiles) {
       const int64_t row0 = next * TR;
       stage_tile<kStatic>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
@@ -319,6 +326,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     // ---- group of every row ----------------------------------------------------
     unsigned long long code[V];
     key_codes_vec<kStatic, V>(c, tile, code);
+    if (ranges > 1) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        live[v] = live[v] && static_cast<int>((mix64(code[v]) >> 20) % static_cast<unsigned>(ranges)) == my_range;
+      }
+    }
     int slot[V];
     long long global_slot[V];
     bool any_global = false;
@@ -418,8 +431,9 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 template <int NS, int V>
 __global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, int64_t n,
                                                                  const uint64_t *__restrict__ filter,
-                                                                 HashTableView g, int S, int rep_shift, int nbuf) {
-  agg_hash_update_body<false, NS, V>(c, c.cols, n, filter, g, S, rep_shift, nbuf);
+                                                                 HashTableView g, int S, int rep_shift, int nbuf,
+                                                                 int ranges) {
+  agg_hash_update_body<false, NS, V>(c, c.cols, n, filter, g, S, rep_shift, nbuf, ranges);
 }
 
 struct ColumnPointers {
@@ -432,9 +446,9 @@ struct ColumnPointers {
 // is the straight-line arithmetic of that plan.
 template <typename Shape, int V>
 __global__ __launch_bounds__(kABlock) void agg_hash_shape_kernel(ColumnPointers cols, int64_t n, HashTableView g, int S,
-                                                                int rep_shift, int nbuf) {
+                                                                int rep_shift, int nbuf, int ranges) {
   static constexpr Translated T = Shape::translated(kABlock * V);
-  agg_hash_update_body<true, T.num_sums, V>(T.dev, cols.p, n, nullptr, g, S, rep_shift, nbuf);
+  agg_hash_update_body<true, T.num_sums, V>(T.dev, cols.p, n, nullptr, g, S, rep_shift, nbuf, ranges);
 }
 
 }  // namespace qsx

@@ -374,6 +374,7 @@ struct qsx_agg_state {
   int64_t *tile_offsets = nullptr;
   long long max_tiles = 0;
   int lds_slots = 64;
+  int lds_ranges = 1;  // > 1: hash-range families of workgroups (agg_hash_update.hpp)
   unsigned used_columns = 0;
   const struct ShapeEntry *shape = nullptr;  // AOT plan shape matching this configuration, if any
 
@@ -444,7 +445,7 @@ static const AggTuning &agg_tuning() {
 // update kernel with two tile buffers (DMA double buffering).
 template <int NS, int V>
 static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter,
-                         const HashTableView &g, int S, hipStream_t stream, bool dry_run) {
+                         const HashTableView &g, int S, int ranges, hipStream_t stream, bool dry_run) {
   constexpr int TR = kABlock * V;
   size_t off = 0;
   for (int col = 0; col < dc.num_columns; ++col) {
@@ -465,9 +466,9 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   // replicate every accumulator as far as the budget allows (64 = one bank column per lane)
   const AggTuning &tune = agg_tuning();
   int rep_shift = 6;
-  while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * (S + 1) * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
+  while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * S * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
   const int nbuf = tune.buffers;
-  const size_t lds = nbuf * off + sizeof(unsigned long long) * (S + ((static_cast<size_t>(NS + 1) * (S + 1)) << rep_shift));
+  const size_t lds = nbuf * off + sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep_shift) + kWave));
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   if (dry_run) return QSX_OK;
@@ -483,9 +484,11 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   if (per_cu < 1) per_cu = 1;
   const int64_t num_tiles = (n + TR - 1) / TR;
   const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
-  const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
+  int grid = static_cast<int>(num_tiles * ranges < max_grid ? num_tiles * ranges : max_grid);
+  grid = grid / ranges * ranges;
+  if (grid < ranges) grid = ranges;
   hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S,
-                     rep_shift, nbuf);
+                     rep_shift, nbuf, ranges);
   return QSX_OK;
 }
 
@@ -493,7 +496,7 @@ static int agg_rows_per_thread() { return agg_tuning().rows_per_thread; }
 
 // ---- AOT plan shapes (agg_shapes.hpp) -------------------------------------------------
 typedef int (*ShapeLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
-                             hipStream_t stream);
+                             int ranges, hipStream_t stream);
 struct ShapeEntry {
   const char *name;
   qsx_agg_config_t config;
@@ -502,17 +505,17 @@ struct ShapeEntry {
 
 template <typename Shape, int V>
 static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
-                          hipStream_t stream) {
+                          int ranges, hipStream_t stream) {
   constexpr int TR = kABlock * V;
   constexpr Translated T = Shape::translated(TR);
   static_assert(T.status == QSX_OK, "plan shape does not translate");
   constexpr int NS = T.num_sums;
   const AggTuning &tune = agg_tuning();
   int rep_shift = 6;
-  while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * (S + 1) * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
+  while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * S * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
   const int nbuf = tune.buffers;
   const size_t lds = static_cast<size_t>(nbuf) * T.dev.tile_bytes +
-                     sizeof(unsigned long long) * (S + ((static_cast<size_t>(NS + 1) * (S + 1)) << rep_shift));
+                     sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep_shift) + kWave));
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   static bool attribute_set = false;
@@ -526,18 +529,21 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
   if (per_cu < 1) per_cu = 1;
   const int64_t num_tiles = (n + TR - 1) / TR;
   const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
-  const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
+  int grid = static_cast<int>(num_tiles * ranges < max_grid ? num_tiles * ranges : max_grid);
+  grid = grid / ranges * ranges;
+  if (grid < ranges) grid = ranges;
   ColumnPointers cp;
   for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < num_columns ? cols[i] : nullptr;
-  hipLaunchKernelGGL((agg_hash_shape_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g, S, rep_shift, nbuf);
+  hipLaunchKernelGGL((agg_hash_shape_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g, S, rep_shift, nbuf,
+                     ranges);
   return QSX_OK;
 }
 
 template <typename Shape>
 static int launch_shape(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
-                        hipStream_t stream) {
-  if (agg_tuning().shape_rows_per_thread == 4) return launch_shape_v<Shape, 4>(cols, num_columns, n, g, S, stream);
-  return launch_shape_v<Shape, 2>(cols, num_columns, n, g, S, stream);
+                        int ranges, hipStream_t stream) {
+  if (agg_tuning().shape_rows_per_thread == 4) return launch_shape_v<Shape, 4>(cols, num_columns, n, g, S, ranges, stream);
+  return launch_shape_v<Shape, 2>(cols, num_columns, n, g, S, ranges, stream);
 }
 
 static const ShapeEntry *find_shape(const qsx_agg_config_t &c) {
@@ -554,13 +560,13 @@ static const ShapeEntry *find_shape(const qsx_agg_config_t &c) {
 
 template <int NS>
 static int launch_hash(const DevConfig &dc, unsigned used_columns, int64_t n, const uint64_t *filter,
-                       const HashTableView &g, int S, hipStream_t stream) {
+                       const HashTableView &g, int S, int ranges, hipStream_t stream) {
   // 1024-row tiles when two of them (plus the group tables) fit the CU's LDS twice over, else 512-row tiles
-  if (agg_rows_per_thread() == 4 && launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, stream, true) == QSX_OK) {
-    return launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, stream, false);
+  if (agg_rows_per_thread() == 4 && launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, stream, true) == QSX_OK) {
+    return launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, stream, false);
   }
-  int rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, S, stream, false);
-  if (rc == QSX_ERR_CAPACITY) rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, 64, stream, false);
+  int rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, S, ranges, stream, false);
+  if (rc == QSX_ERR_CAPACITY) rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, 64, 1, stream, false);
   return rc;
 }
 template <int NS>
@@ -615,7 +621,20 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     // workgroup-private LDS table: up to 512 slots (<= 40 KiB at NS = 8)
     uint64_t s = next_pow2(static_cast<uint64_t>(est) * 2);
     if (s < 8) s = 8;
-    if (s > 512) s = 512;
+    if (s > 512) {
+      // More groups than a replicated 512-slot table holds: take the biggest unreplicated LDS
+      // table that fits 104 KiB and split the groups over up to 8 hash ranges (each range reads
+      // the whole input); beyond that, one range and the overflow goes to the global table.
+      uint64_t smax = 4096;
+      while (smax > 512 && 8 * (smax + static_cast<uint64_t>(st->num_sums + 1) * (smax + 64)) > 104 * 1024) smax >>= 1;
+      const uint64_t ranges = (static_cast<uint64_t>(est) * 10 + smax * 7 - 1) / (smax * 7);  // load <= 0.7
+      if (smax > 512 && ranges <= 8) {
+        s = smax;
+        st->lds_ranges = static_cast<int>(ranges < 1 ? 1 : ranges);
+      } else {
+        s = 512;
+      }
+    }
     st->lds_slots = static_cast<int>(s);
   }
   hipError_t err = hipMalloc(reinterpret_cast<void **>(&st->image), st->image_bytes);
@@ -688,9 +707,10 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
     const HashTableView g = st->hash_view();
     int rc = QSX_OK;
     if (st->shape != nullptr && filter_dev == nullptr) {
-      rc = st->shape->launch(cols, st->config.num_columns, n, g, st->lds_slots, s);
+      rc = st->shape->launch(cols, st->config.num_columns, n, g, st->lds_slots, st->lds_ranges, s);
     } else {
-      QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, st->lds_slots, s);
+      QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, st->lds_slots,
+                      st->lds_ranges, s);
     }
     if (rc != QSX_OK) return rc;
   }
