@@ -230,6 +230,38 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
   });
 }
 
+// Runs of equal ADJACENT keys inside a wave (clustered / sorted inputs, e.g. lineitem on
+// l_orderkey): run_start = lane where the run containing this lane begins (max-scan over the
+// head flags); the segmented sums below add lane (i - off) only while it is still inside the
+// run, so equal keys that are not adjacent are never merged.  The last lane of a run ends up
+// with the whole run's sum.
+__device__ __forceinline__ int wave_run_start(long long key) {
+  const long long prev = __shfl_up(key, 1, kWave);
+  int start = (lane_id() == 0 || prev != key) ? lane_id() : 0;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int up = __shfl_up(start, off, kWave);
+    if (lane_id() >= off && up > start) start = up;
+  }
+  return start;
+}
+__device__ __forceinline__ unsigned long long segmented_run_sum_u64(int run_start, unsigned long long v) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned long long v2 = __shfl_up(v, off, kWave);
+    if (lane_id() - off >= run_start) v += v2;
+  }
+  return v;
+}
+__device__ __forceinline__ double segmented_run_sum_f64(int run_start, double v) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const double v2 = __shfl_up(v, off, kWave);
+    if (lane_id() - off >= run_start) v += v2;
+  }
+  return v;
+}
+
 // Group of one row.  Every row gets an LDS accumulator index so that the
 // accumulate loop needs no branches: live rows whose group sits in the
 // workgroup's LDS table get that group's slot, all other rows (filtered out, or
@@ -260,10 +292,13 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
 // values; a lane adds into column (lane & (REP - 1)), so with REP = 64 every
 // lane owns its bank column and a wave's ds_add never conflicts (measured
 // ~6 ns per wave instruction per CU, tools/ubench/lds_atomic.hip).
-template <bool kStatic, int NS, int V>
+// kDense: COLLISION_FREE sink — the group of a row is its key value, accumulators are the dense
+// arrays in HBM (DenseView), adjacent equal keys of a wave are combined before the atomics.
+template <bool kStatic, bool kDense, int NS, int V>
 __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, int64_t n,
                                                      const uint64_t *__restrict__ filter, const HashTableView &g,
-                                                     int S, int rep_shift, int nbuf, int ranges) {
+                                                     const DenseView &dense, int S, int rep_shift, int nbuf,
+                                                     int ranges) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int TR = kABlock * V;
   char *tiles = reinterpret_cast<char *>(smem_raw);
@@ -335,12 +370,47 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     int slot[V];
     long long global_slot[V];
     bool any_global = false;
+    bool run_tail[V];   // kDense: this lane commits the run of equal adjacent keys ending here
+    if constexpr (kDense) {
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      classify_row(live[v], code[v], l_keys, l_acc, S, rep_shift, lane_col, g, slot[v], global_slot[v]);
-      any_global = any_global || global_slot[v] >= 0;
+      for (int v = 0; v < V; ++v) {
+        global_slot[v] = -1;
+        const long long loc = static_cast<long long>(tile_int(c, tile, c.key_column[0], threadIdx.x + v * kABlock));
+        if (live[v] && (loc < 0 || loc >= dense.num_entries)) {
+          atomicExch(dense.error, 1);  // precondition min >= 0, max < num_entries violated
+          live[v] = false;
+        }
+        // dead rows get a key no neighbour shares so that they never join a run
+        const long long run_key = live[v] ? loc : -1 - static_cast<long long>(lane_id());
+        const long long next_key = __shfl_down(run_key, 1, kWave);
+        run_tail[v] = live[v] && (lane_id() == kWave - 1 || next_key != run_key);
+        global_slot[v] = live[v] ? loc : -1;
+        slot[v] = wave_run_start(run_key);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        classify_row(live[v], code[v], l_keys, l_acc, S, rep_shift, lane_col, g, slot[v], global_slot[v]);
+        any_global = any_global || global_slot[v] >= 0;
+        run_tail[v] = false;
+      }
     }
     const bool wave_has_global = __any(any_global);  // rare: groups that did not fit the LDS table
+    if constexpr (kDense) {
+      // existence bit + row count of every run (CollisionFreeVectorTable.hpp:530-645)
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        unsigned long long run_len = live[v] ? 1ull : 0ull;
+        run_len = segmented_run_sum_u64(slot[v], run_len);
+        if (run_tail[v]) {
+          const long long loc = global_slot[v];
+          const unsigned long long bit = 1ull << (loc & 63);
+          unsigned long long *word = &dense.exist[loc >> 6];
+          if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0) atomicOr(word, bit);
+          if (dense.has_count) atomicAdd(&dense.states[loc], run_len);
+        }
+      }
+    }
 
     // ---- expression program ------------------------------------------------------
     Temps<V> temps;
@@ -386,17 +456,36 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 #pragma unroll
         for (int v = 0; v < V; ++v) inc[v] = static_cast<unsigned long long>(__double_as_longlong(x[v]));
       }
-      unsigned long long *acc_plane = l_acc + (j + 1) * plane;
-#pragma unroll
-      for (int v = 0; v < V; ++v) lds_add(&acc_plane[slot[v]], inc[v], s.is_int);  // unconditional (trash slot)
-      if (wave_has_global) {
+      if constexpr (kDense) {
+        unsigned long long *col = dense.states + static_cast<unsigned long long>((dense.has_count ? 1 : 0) + j) * dense.num_entries;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          if (global_slot[v] >= 0) global_add(g, j + 1, static_cast<unsigned long long>(global_slot[v]), inc[v], s.is_int);
+          unsigned long long run;
+          if (s.is_int) {
+            run = segmented_run_sum_u64(slot[v], live[v] ? inc[v] : 0ull);
+          } else {
+            run = static_cast<unsigned long long>(__double_as_longlong(segmented_run_sum_f64(
+                slot[v], live[v] ? __longlong_as_double(static_cast<long long>(inc[v])) : 0.0)));
+          }
+          if (run_tail[v]) {
+            if (s.is_int) atomicAdd(&col[global_slot[v]], run);
+            else atomic_add_f64(reinterpret_cast<double *>(&col[global_slot[v]]), __longlong_as_double(static_cast<long long>(run)));
+          }
+        }
+      } else {
+        unsigned long long *acc_plane = l_acc + (j + 1) * plane;
+#pragma unroll
+        for (int v = 0; v < V; ++v) lds_add(&acc_plane[slot[v]], inc[v], s.is_int);  // unconditional (trash slot)
+        if (wave_has_global) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            if (global_slot[v] >= 0) global_add(g, j + 1, static_cast<unsigned long long>(global_slot[v]), inc[v], s.is_int);
+          }
         }
       }
     }
   }
+  if constexpr (kDense) return;
   __syncthreads();
 
   // ---- LDS -> global table: fold the REP partials, one global atomic per group per
@@ -433,7 +522,15 @@ __global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, i
                                                                  const uint64_t *__restrict__ filter,
                                                                  HashTableView g, int S, int rep_shift, int nbuf,
                                                                  int ranges) {
-  agg_hash_update_body<false, NS, V>(c, c.cols, n, filter, g, S, rep_shift, nbuf, ranges);
+  agg_hash_update_body<false, false, NS, V>(c, c.cols, n, filter, g, DenseView{}, S, rep_shift, nbuf, ranges);
+}
+
+// COLLISION_FREE (K7) through the same staged-tile body with the dense sink.
+template <int NS, int V>
+__global__ __launch_bounds__(kABlock) void agg_dense_update_kernel(DevConfig c, int64_t n,
+                                                                  const uint64_t *__restrict__ filter, DenseView d,
+                                                                  int nbuf) {
+  agg_hash_update_body<false, true, NS, V>(c, c.cols, n, filter, HashTableView{}, d, 8, 0, nbuf, 1);
 }
 
 struct ColumnPointers {
@@ -448,7 +545,7 @@ template <typename Shape, int V>
 __global__ __launch_bounds__(kABlock) void agg_hash_shape_kernel(ColumnPointers cols, int64_t n, HashTableView g, int S,
                                                                 int rep_shift, int nbuf, int ranges) {
   static constexpr Translated T = Shape::translated(kABlock * V);
-  agg_hash_update_body<true, T.num_sums, V>(T.dev, cols.p, n, nullptr, g, S, rep_shift, nbuf, ranges);
+  agg_hash_update_body<true, false, T.num_sums, V>(T.dev, cols.p, n, nullptr, g, DenseView{}, S, rep_shift, nbuf, ranges);
 }
 
 }  // namespace qsx

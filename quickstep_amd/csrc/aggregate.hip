@@ -51,41 +51,6 @@ namespace qsx {
 
 
 // ---------------------------------------------------------------------------
-// COLLISION_FREE update kernel (K7): vec[key] += arg, existence bit.
-// ---------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(kABlock) void agg_dense_kernel(DevConfig c, int64_t n,
-                                                           const uint64_t *__restrict__ filter,
-                                                           DenseView d) {
-  const int first_sum_col = d.has_count ? 1 : 0;
-  for (int64_t row = static_cast<int64_t>(blockIdx.x) * kABlock + threadIdx.x; row < n;
-       row += static_cast<int64_t>(gridDim.x) * kABlock) {
-    if (!filter_bit(filter, row) || !eval_predicate(c, row)) continue;
-    const long long loc = column_as_int(c, c.key_column[0], row);
-    if (loc < 0 || loc >= d.num_entries) {
-      atomicExch(d.error, 1);  // precondition min >= 0, max < num_entries violated
-      continue;
-    }
-    double t[QSX_MAX_TEMPS];
-    eval_program(c, t, row);
-    const unsigned long long bit = 1ull << (loc & 63);
-    unsigned long long *word = &d.exist[loc >> 6];
-    if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0) atomicOr(word, bit);
-    if (d.has_count) atomicAdd(&d.states[loc], 1ull);
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      unsigned long long *p = d.states + static_cast<unsigned long long>(first_sum_col + j) * d.num_entries + loc;
-      const unsigned long long inc = sum_increment(c, j, t, row);
-      if (c.sums[j].is_int) {
-        atomicAdd(p, inc);
-      } else {
-        atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // merge of exported images
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kABlock) void merge_hash_kernel(const unsigned long long *__restrict__ image,
@@ -570,9 +535,29 @@ static int launch_hash(const DevConfig &dc, unsigned used_columns, int64_t n, co
   return rc;
 }
 template <int NS>
-static void launch_dense(const DevConfig &dc, int64_t n, const uint64_t *filter, const DenseView &d, hipStream_t stream) {
-  const int grid = grid_for(n, kABlock * 4);
-  hipLaunchKernelGGL((agg_dense_kernel<NS>), dim3(grid), dim3(kABlock), 0, stream, dc, n, filter, d);
+static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter, const DenseView &d,
+                        hipStream_t stream) {
+  constexpr int V = 4;
+  constexpr int TR = kABlock * V;
+  plan_tile(dc, used_columns, TR, filter != nullptr);
+  const int nbuf = 1;
+  const size_t lds = static_cast<size_t>(nbuf) * dc.tile_bytes + sizeof(unsigned long long) * (8 + static_cast<size_t>(NS + 1) * (8 + kWave));
+  constexpr size_t kMaxLds = 160 * 1024;
+  if (lds > kMaxLds) return QSX_ERR_CAPACITY;
+  static bool attribute_set = false;
+  if (!attribute_set) {
+    QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dense_update_kernel<NS, V>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
+    attribute_set = true;
+  }
+  int per_cu = static_cast<int>(kMaxLds / lds);
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t num_tiles = (n + TR - 1) / TR;
+  const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
+  const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
+  hipLaunchKernelGGL((agg_dense_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, d, nbuf);
+  return QSX_OK;
 }
 
 #define QSX_DISPATCH_NS(ns, FN, ...)      \
@@ -702,7 +687,9 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
   hipStream_t s = as_stream(stream);
   if (st->dense) {
     const DenseView d = st->dense_view();
-    QSX_DISPATCH_NS(st->num_sums, launch_dense, dc, n, filter_dev, d, s);
+    int rc = QSX_OK;
+    QSX_DISPATCH_NS(st->num_sums, rc = launch_dense, dc, st->used_columns, n, filter_dev, d, s);
+    if (rc != QSX_OK) return rc;
   } else {
     const HashTableView g = st->hash_view();
     int rc = QSX_OK;
