@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--probe-rows", type=int, default=100_000_000)
     ap.add_argument("--agg-rows", type=int, default=600_000_000)
     ap.add_argument("--match", type=float, default=1.0)
+    ap.add_argument("--join-table", choices=["dense", "hashed"], default="dense",
+                    help="dense: the build key (custkey) has exact min/max statistics -> directly addressed table "
+                         "(qsx_join_table_create_dense); hashed: open-addressing table (qsx_join_table_create)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -179,11 +182,13 @@ def main():
     state = capi.AggState(cfg)
     main_stream = torch.cuda.current_stream()
     agg_stream = torch.cuda.Stream(device=dev) if distributed else main_stream
+    dense = args.join_table == "dense"
     if distributed:
-        join = qd.PartitionedHashJoin(capi, T.INT, 2 * args.build_rows)
+        join = qd.PartitionedHashJoin(capi, T.INT, 2 * args.build_rows,
+                                      key_domain=(0, key_space - 1) if dense else None)
         capacity = int(args.probe_rows * 1.25)
     else:
-        table = capi.JoinTable(T.INT, args.build_rows)
+        table = capi.JoinTable(T.INT, args.build_rows, key_range=(0, args.build_rows - 1) if dense else None)
         capacity = args.probe_rows
         out = (torch.empty(capacity, dtype=torch.int32, device=dev), torch.empty(capacity, dtype=torch.int32, device=dev),
                torch.zeros(1, dtype=torch.int64, device=dev))
@@ -318,11 +323,26 @@ def main():
         probe_bytes = 4 * args.probe_rows + 8 * matches
         line["probe"] = {
             "rows_per_s": args.probe_rows / probe_s, "ms": phase_ms["probe"],
-            "roofline": {"kernel": "probe_kernel<IntUnits,0> (qsx_join_probe)", "bound": "hbm",
+            "table": "directly addressed (exact min/max statistics of the build key)" if dense else "hashed",
+            "roofline": {"kernel": "dense_probe_kernel<int,0> (qsx_join_probe)" if dense else
+                         "probe_kernel<IntUnits,0> (qsx_join_probe)", "bound": "hbm",
                          "achieved": probe_bytes / probe_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": probe_bytes / probe_s / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes": "4*N_probe + 8*N_match (hash-table traffic excluded)"},
         }
+        if dense:
+            # the same probe against the hashed table (what a build side without exact statistics gets), untimed leg
+            hashed = capi.JoinTable(T.INT, args.build_rows)
+            hashed.build(build_keys)
+            hashed.probe(probe_keys, capacity=capacity, out=out)
+            h0, h1 = ev(), ev()
+            h0.record()
+            for _ in range(3):
+                hashed.probe(probe_keys, capacity=capacity, out=out)
+            h1.record()
+            torch.cuda.synchronize()
+            line["probe"]["hashed_table_ms"] = h0.elapsed_time(h1) / 3
+            hashed.close()
         line["build"] = {"rows_per_s": args.build_rows / (phase_ms["build"] / 1e3), "ms": phase_ms["build"]}
         line["aggregate"] = {"rows_per_s": args.agg_rows / agg_s, "ms": phase_ms["aggregate_update"],
                              "finalize_ms": phase_ms["finalize"]}

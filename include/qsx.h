@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define QSX_ABI_VERSION 1
+#define QSX_ABI_VERSION 2
 
 typedef void *qsx_stream_t;
 
@@ -171,6 +171,26 @@ typedef struct qsx_join_table qsx_join_table_t;
  * table grows on its own when the estimate is exceeded (counterpart of
  * HashTable::resize, storage/HashTable.hpp:1437-1440).  Synchronises. */
 int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **out);
+/* Same table, addressed directly by (key - min_key): one 4-byte head word per
+ * key value instead of a hashed probe sequence, duplicates chained through an
+ * overflow list.  For the caller that knows the build-side join attribute lies
+ * exactly in [min_key, max_key] — the optimizer condition under which the
+ * reference swaps the hash table for a BitVectorExactFilter
+ * (query_optimizer/rules/InjectJoinFilters.cpp:130-150, exact min/max
+ * statistics and a bounded value range; kMaxFilterSize there = 1e9) — but the
+ * tuple references are kept, so every join flavour of this header works on it
+ * (inner joins with build-side outputs and duplicate keys included).
+ *   key_stride  1, or a power of two 2^s: the table holds the progression
+ *               min_key, min_key + 2^s, ... only — what one hash partition
+ *               (key & (P-1), catalog/PartitionSchemeHeader.hpp:200-214) of a
+ *               dense key domain looks like after the multi-GPU shuffle, so the
+ *               head array stays (max_key - min_key) / P words on every GPU.
+ * A build key that is not a member (outside the range / off the stride) is a
+ * broken precondition: the row is skipped and qsx_join_table_size reports
+ * QSX_ERR_INVALID_ARGUMENT.  Probe keys that are not members simply do not
+ * match.  Synchronises. */
+int qsx_join_table_create_dense(int key_type, int64_t min_key, int64_t max_key, int64_t key_stride,
+                                int64_t est_entries, qsx_join_table_t **out);
 int qsx_join_table_destroy(qsx_join_table_t *table);
 /* Drop every entry, keep the allocation (a new query re-using the table;
  * counterpart of DestroyHashOperator + re-creation, relational_operators/

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "qsx_gather": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_gather_segmented": (_int, [_int, _int, _pp, C.POINTER(_i64), _vp, _i64, _vp, _vp]),
     "qsx_join_table_create": (_int, [_int, _i64, _pp]),
+    "qsx_join_table_create_dense": (_int, [_int, _i64, _i64, _i64, _i64, _pp]),
     "qsx_join_table_destroy": (_int, [_vp]),
     "qsx_join_table_clear": (_int, [_vp, _vp]),
     "qsx_join_table_size": (_int, [_vp, C.POINTER(_i64), _vp]),
@@ -221,10 +222,18 @@ def gather_segmented(segments, first_rows, tids, out=None, stream=None):
 class JoinTable:
     """JoinHashTable handle (qsx_join_table_t)."""
 
-    def __init__(self, key_type, est_entries):
+    def __init__(self, key_type, est_entries, key_range=None, key_stride=1):
+        """key_range = (min_key, max_key): exact build-side statistics -> the directly addressed
+        flavour (qsx_join_table_create_dense; key_stride = P for one hash partition of a dense
+        domain); None -> the hashed table."""
         self.key_type = key_type
+        self._h = None
         h = C.c_void_p()
-        _check(_lib.qsx_join_table_create(key_type, est_entries, C.byref(h)), "qsx_join_table_create")
+        if key_range is None:
+            _check(_lib.qsx_join_table_create(key_type, est_entries, C.byref(h)), "qsx_join_table_create")
+        else:
+            _check(_lib.qsx_join_table_create_dense(key_type, int(key_range[0]), int(key_range[1]), int(key_stride),
+                                                    est_entries, C.byref(h)), "qsx_join_table_create_dense")
         self._h = h
 
     def close(self):

@@ -23,6 +23,7 @@
 // streams the pairs out coalesced.
 
 #include "common.hpp"
+#include "join_dense.hpp"
 #include "join_radix.hpp"
 #include "scan.hpp"
 
@@ -350,6 +351,27 @@ struct qsx_join_table {
 
   unsigned int *max_disp_dev = nullptr;  // see TableView::max_disp (second word of the entries_dev allocation)
 
+  // Directly addressed flavour (join_dense.hpp): head[] + overflow chain entries; `slots` unused.
+  bool dense = false;
+  int64_t min_key = 0;
+  int stride_shift = 0;
+  uint64_t range = 0;
+  uint32_t *head = nullptr;
+  uint2 *ov = nullptr;
+  unsigned int ov_capacity = 0;
+  DenseTableView dense_view() const {
+    DenseTableView v;
+    v.head = head;
+    v.ov = ov;
+    v.min_key = min_key;
+    v.stride_shift = stride_shift;
+    v.range = range;
+    v.ov_count = reinterpret_cast<unsigned int *>(entries_dev + 2);
+    v.ov_capacity = ov_capacity;
+    v.error = reinterpret_cast<int *>(entries_dev + 3);
+    return v;
+  }
+
   size_t entry_bytes() const { return key_type == QSX_INT ? 8 : 16; }
   TableView view() const {
     TableView v;
@@ -362,6 +384,9 @@ struct qsx_join_table {
     return v;
   }
 };
+
+// control words behind entries_dev: [0] entries, [1] max displacement, [2] overflow entries, [3] error flag (dense)
+constexpr int kControlWords = 4;
 
 static uint64_t capacity_for(int64_t entries) {
   // kHashTableLoadFactor = 2 slots per entry (storage/StorageConstants.hpp:104),
@@ -378,7 +403,31 @@ static int allocate_slots(qsx_join_table *t, uint64_t capacity, void **out) {
 
 // Make room for `additional` more rows.  Counterpart of HashTable::resize
 // (storage/HashTable.hpp:1437-1440, SimpleScalarSeparateChainingHashTable.hpp:820-985).
+// Dense flavour: every row could be a duplicate, so the overflow list has room for every row handed in.
+static int ensure_room_dense(qsx_join_table *t, int64_t additional) {
+  std::unique_lock<std::shared_mutex> lock(t->mutex);
+  if (static_cast<uint64_t>(t->reserved + additional) <= t->ov_capacity) {
+    t->reserved += additional;
+    return QSX_OK;
+  }
+  QSX_HIP_TRY(hipDeviceSynchronize());  // drain in-flight builds on every stream
+  uint64_t want = static_cast<uint64_t>(t->reserved + additional) * 2;
+  if (want > 0x7FFFFFFFull) want = 0x7FFFFFFFull;
+  if (want < static_cast<uint64_t>(t->reserved + additional)) return QSX_ERR_CAPACITY;
+  uint2 *bigger = nullptr;
+  QSX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&bigger), want * sizeof(uint2)));
+  if (t->ov_capacity != 0) {
+    QSX_HIP_TRY(hipMemcpy(bigger, t->ov, static_cast<size_t>(t->ov_capacity) * sizeof(uint2), hipMemcpyDeviceToDevice));
+  }
+  (void)hipFree(t->ov);
+  t->ov = bigger;
+  t->ov_capacity = static_cast<unsigned int>(want);
+  t->reserved += additional;
+  return QSX_OK;
+}
+
 static int ensure_room(qsx_join_table *t, int64_t additional) {
+  if (t->dense) return ensure_room_dense(t, additional);
   std::unique_lock<std::shared_mutex> lock(t->mutex);
   if (static_cast<uint64_t>(t->reserved + additional) * 2 <= t->capacity) {
     t->reserved += additional;
@@ -423,8 +472,8 @@ int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **
   t->capacity = capacity_for(est_entries);
   int rc = allocate_slots(t, t->capacity, &t->slots);
   if (rc != QSX_OK) { delete t; return rc; }
-  hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), 2 * sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, 2 * sizeof(unsigned long long));
+  hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, kControlWords * sizeof(unsigned long long));
   t->max_disp_dev = reinterpret_cast<unsigned int *>(t->entries_dev + 1);
   if (err != hipSuccess) {
     set_last_error("hipMalloc(entries)", err);
@@ -436,10 +485,49 @@ int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **
   return QSX_OK;
 }
 
+int qsx_join_table_create_dense(int key_type, int64_t min_key, int64_t max_key, int64_t key_stride,
+                                int64_t est_entries, qsx_join_table_t **out) {
+  QSX_REQUIRE_DEVICE();
+  if (out == nullptr || est_entries < 0 || max_key < min_key || key_stride < 1) return QSX_ERR_INVALID_ARGUMENT;
+  if (key_type != QSX_INT && key_type != QSX_LONG) return QSX_ERR_UNSUPPORTED;
+  if ((key_stride & (key_stride - 1)) != 0) return QSX_ERR_UNSUPPORTED;  // shift addressing only
+  int stride_shift = 0;
+  while ((1ll << stride_shift) < key_stride) ++stride_shift;
+  // unsigned: the span of [INT64_MIN, INT64_MAX] still fits
+  const uint64_t span = static_cast<uint64_t>(max_key) - static_cast<uint64_t>(min_key);
+  const uint64_t range = (span >> stride_shift) + 1;
+  if (range > (1ull << 32)) return QSX_ERR_CAPACITY;  // 16 GiB of head words
+  qsx_join_table *t = new qsx_join_table();
+  t->key_type = key_type;
+  t->dense = true;
+  t->min_key = min_key;
+  t->stride_shift = stride_shift;
+  t->range = range;
+  t->ov_capacity = static_cast<unsigned int>(est_entries < 1024 ? 1024 : (est_entries > 0x7FFFFFFF ? 0x7FFFFFFF : est_entries));
+  hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->head), range * sizeof(uint32_t));
+  if (err == hipSuccess) err = hipMemset(t->head, 0, range * sizeof(uint32_t));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&t->ov), static_cast<size_t>(t->ov_capacity) * sizeof(uint2));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, kControlWords * sizeof(unsigned long long));
+  if (err != hipSuccess) {
+    set_last_error("hipMalloc(dense join table)", err);
+    (void)hipFree(t->head);
+    (void)hipFree(t->ov);
+    (void)hipFree(t->entries_dev);
+    delete t;
+    return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
+  }
+  t->max_disp_dev = reinterpret_cast<unsigned int *>(t->entries_dev + 1);
+  *out = t;
+  return QSX_OK;
+}
+
 int qsx_join_table_destroy(qsx_join_table_t *t) {
   if (t == nullptr) return QSX_OK;
   (void)hipDeviceSynchronize();
   (void)hipFree(t->slots);
+  (void)hipFree(t->head);
+  (void)hipFree(t->ov);
   (void)hipFree(t->entries_dev);
   delete t;
   return QSX_OK;
@@ -449,8 +537,12 @@ int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (t == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   std::unique_lock<std::shared_mutex> lock(t->mutex);
-  QSX_HIP_TRY(hipMemsetAsync(t->slots, 0xFF, t->capacity * t->entry_bytes(), as_stream(stream)));
-  QSX_HIP_TRY(hipMemsetAsync(t->entries_dev, 0, 2 * sizeof(unsigned long long), as_stream(stream)));
+  if (t->dense) {
+    QSX_HIP_TRY(hipMemsetAsync(t->head, 0, t->range * sizeof(uint32_t), as_stream(stream)));
+  } else {
+    QSX_HIP_TRY(hipMemsetAsync(t->slots, 0xFF, t->capacity * t->entry_bytes(), as_stream(stream)));
+  }
+  QSX_HIP_TRY(hipMemsetAsync(t->entries_dev, 0, kControlWords * sizeof(unsigned long long), as_stream(stream)));
   t->reserved = 0;
   return QSX_OK;
 }
@@ -458,10 +550,12 @@ int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
 int qsx_join_table_size(qsx_join_table_t *t, int64_t *out_entries, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (t == nullptr || out_entries == nullptr) return QSX_ERR_INVALID_ARGUMENT;
-  unsigned long long v = 0;
-  QSX_HIP_TRY(hipMemcpyAsync(&v, t->entries_dev, sizeof(v), hipMemcpyDeviceToHost, as_stream(stream)));
+  unsigned long long v[kControlWords] = {0, 0, 0, 0};
+  QSX_HIP_TRY(hipMemcpyAsync(v, t->entries_dev, sizeof(v), hipMemcpyDeviceToHost, as_stream(stream)));
   QSX_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
-  *out_entries = static_cast<int64_t>(v);
+  *out_entries = static_cast<int64_t>(v[0]);
+  // dense flavour: a build key outside [min_key, max_key] was skipped — the caller's statistics were not exact
+  if (t->dense && static_cast<int>(v[3] & 0xFFFFFFFFu) != 0) return QSX_ERR_INVALID_ARGUMENT;
   return QSX_OK;
 }
 
@@ -476,6 +570,17 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   if (rc != QSX_OK) return rc;
   std::shared_lock<std::shared_mutex> lock(t->mutex);
   const int grid = grid_for(n, kJBlock * 4);
+  if (t->dense) {
+    if (t->key_type == QSX_INT) {
+      hipLaunchKernelGGL(dense_build_kernel<int32_t>, dim3(grid), dim3(kDBlock), 0, as_stream(stream), t->dense_view(),
+                         static_cast<const int32_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev);
+    } else {
+      hipLaunchKernelGGL(dense_build_kernel<int64_t>, dim3(grid), dim3(kDBlock), 0, as_stream(stream), t->dense_view(),
+                         static_cast<const int64_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev);
+    }
+    QSX_CHECK_LAUNCH();
+    return QSX_OK;
+  }
   if (t->key_type == QSX_INT) {
     hipLaunchKernelGGL(build_kernel<int32_t>, dim3(grid), dim3(kJBlock), 0, as_stream(stream), t->view(),
                        static_cast<const int32_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev);
@@ -574,6 +679,23 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
   if (out_count != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), stream));
   if (n == 0) return QSX_OK;
   std::shared_lock<std::shared_mutex> lock(t->mutex);
+  if (t->dense) {
+    const int64_t tiles = (n + kDenseTile - 1) / kDenseTile;
+    const int64_t limit = 8 * kCUs;  // no LDS: 8 workgroups (32 waves) per CU
+    const int dgrid = static_cast<int>(tiles < limit ? tiles : limit);
+    unsigned long long *dcount = reinterpret_cast<unsigned long long *>(out_count);
+    if (t->key_type == QSX_INT) {
+      hipLaunchKernelGGL((dense_probe_kernel<int32_t, MODE>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+                         static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
+                         dcount, out_bitmap, anti);
+    } else {
+      hipLaunchKernelGGL((dense_probe_kernel<int64_t, MODE>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+                         static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
+                         dcount, out_bitmap, anti);
+    }
+    QSX_CHECK_LAUNCH();
+    return QSX_OK;
+  }
   if (MODE != 2 && t->key_type == QSX_INT && radix_enabled() && t->reserved >= kRadixMinBuildRows &&
       n >= kRadixMinProbeRows) {
     return launch_probe_radix<MODE>(t, static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build,

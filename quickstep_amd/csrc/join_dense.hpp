@@ -1,0 +1,242 @@
+// join_dense.hpp — the directly addressed join table (qsx_join_table_create_dense).
+//
+// Same contract as the hashed table of join.hip (K3 build / K4 probe; reference loops:
+// storage/HashTable.hpp:1358-1461 and :2145-2181, :1979-2062), chosen by the caller when the
+// build-side join attribute has exact min/max statistics in a bounded range — the condition of
+// query_optimizer/rules/InjectJoinFilters.cpp:130-150.
+//
+// Layout in HBM:
+//   head[range]   uint32 per key value (key - min_key):
+//                   0                      no build row has this key
+//                   t + 1      (bit 31 = 0) exactly one build row, tuple reference t
+//                   0x80000000 | e          the chain of this key starts at overflow entry e
+//   ov[e]         {tid, next}  next has the format of a head word (0 terminates the chain)
+// A primary-key build side (TPC-H custkey / orderkey) never touches ov: a probe is ONE random
+// 4-byte read, and for the C2 shape (1 M keys) head[] is 4 MiB — it stays resident in every
+// XCD's L2 while the probe keys and the output pairs stream past it with non-temporal accesses.
+//
+// Match compaction (MODE 0): a wave owns 16 x 64 probe rows of a tile.  It ballots the 16 steps; the
+// four wave totals meet in LDS and the workgroup reserves the space of all first-level matches of
+// the 4096-row tile with ONE global atomic (the single output counter serialises same-address
+// atomics in L2: one per wave measured 1.25 ms / 100 M rows, of which 0.7 ms was the counter).
+// Every step's matches are then written as one contiguous run (mbcnt rank) straight to the output
+// arrays — no staging of the pairs.  Duplicate-key chains (rare) continue with one wave-aggregated
+// reservation per chain step.
+#ifndef QSX_CSRC_JOIN_DENSE_HPP_
+#define QSX_CSRC_JOIN_DENSE_HPP_
+
+#include "common.hpp"
+
+namespace qsx {
+
+constexpr int kDBlock = 256;
+constexpr int kDenseRowsPerThread = 16;
+constexpr int kDenseTile = kDBlock * kDenseRowsPerThread;
+constexpr uint32_t kChainBit = 0x80000000u;
+
+struct DenseTableView {
+  uint32_t *head;
+  uint2 *ov;
+  int64_t min_key;
+  int stride_shift;          // keys are min_key + i * 2^stride_shift (one hash partition of a dense key domain)
+  uint64_t range;            // number of head words: ((max_key - min_key) >> stride_shift) + 1
+  unsigned int *ov_count;    // overflow entries handed out
+  unsigned int ov_capacity;
+  int *error;                // set when a build key is outside the range (or ov ran out: host bug)
+};
+
+// Head index of a key, or ~0 when the key is not a member of the table's progression.
+template <typename KeyT>
+__device__ __forceinline__ uint64_t dense_index(const DenseTableView &t, KeyT key) {
+  const uint64_t d = static_cast<uint64_t>(static_cast<int64_t>(key) - t.min_key);
+  const uint64_t idx = d >> t.stride_shift;
+  return (idx << t.stride_shift) == d && idx < t.range ? idx : ~0ull;
+}
+
+__device__ __forceinline__ bool dense_row_in_filter(const uint64_t *filter, int64_t row) {
+  return filter == nullptr || ((filter[row >> 6] >> (63 - (row & 63))) & 1u);
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, const KeyT *__restrict__ keys, int64_t n,
+                                                             int32_t base_tid, const uint64_t *__restrict__ filter,
+                                                             unsigned long long *__restrict__ entries) {
+  unsigned long long inserted = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kDBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kDBlock) {
+    if (!dense_row_in_filter(filter, i)) continue;
+    const uint64_t idx = dense_index(t, keys[i]);
+    if (idx == ~0ull) {
+      atomicExch(t.error, 1);
+      continue;
+    }
+    const uint32_t tid = static_cast<uint32_t>(base_tid + i);
+    if (atomicCAS(&t.head[idx], 0u, tid + 1u) != 0u) {
+      // duplicate key: push an overflow entry in front of whatever the head holds now
+      const unsigned int e = atomicAdd(t.ov_count, 1u);
+      if (e >= t.ov_capacity) {
+        atomicExch(t.error, 2);
+        continue;
+      }
+      t.ov[e].x = tid;
+      // next is only read by probe kernels launched after the build (pipeline breaker)
+      t.ov[e].y = atomicExch(&t.head[idx], kChainBit | e);
+    }
+    ++inserted;
+  }
+  inserted = wave_reduce_add(inserted);
+  if (lane_id() == 0 && inserted != 0) atomicAdd(entries, inserted);
+}
+
+// One wave-aggregated append of the matching lanes straight to the global output.
+__device__ __forceinline__ void dense_emit_direct(bool match, int32_t probe_tid, int32_t build_tid,
+                                                  int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build,
+                                                  unsigned long long capacity, unsigned long long *out_count) {
+  const uint64_t m = __ballot(match);
+  if (m == 0) return;
+  unsigned long long base = 0;
+  if (lane_id() == __ffsll(static_cast<long long>(m)) - 1) {
+    base = atomicAdd(out_count, static_cast<unsigned long long>(__popcll(m)));
+  }
+  base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1, kWave);
+  const unsigned long long o = base + rank_below(m);
+  if (match && o < capacity) {
+    __builtin_nontemporal_store(probe_tid, &out_probe[o]);
+    __builtin_nontemporal_store(build_tid, &out_build[o]);
+  }
+}
+
+// MODE 0: emit pairs, 1: count only, 2: existence bitmap (as probe_kernel in join.hip).
+template <typename KeyT, int MODE>
+__global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
+    DenseTableView t, const KeyT *__restrict__ keys, int64_t n, int32_t probe_base_tid,
+    const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build,
+    int64_t capacity_signed, unsigned long long *__restrict__ out_count, uint64_t *__restrict__ out_bitmap, int anti) {
+  constexpr int R = kDenseRowsPerThread;
+  const unsigned long long capacity = static_cast<unsigned long long>(capacity_signed);
+  const int64_t num_tiles = (n + kDenseTile - 1) / kDenseTile;
+  unsigned long long local_count = 0;
+  __shared__ int s_wave_total[2][kDBlock / kWave];
+  __shared__ unsigned long long s_tile_base;
+  const int wave = threadIdx.x >> 6;
+  int parity = 0;
+
+  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, parity ^= 1) {
+    const int64_t tile_base = tile * kDenseTile;
+    // Row r of this thread: tile_base + r * 256 + tid; a wave owns 64 consecutive rows per r.
+    uint32_t h[R];
+    {
+      KeyT key[R];
+      bool live[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = tile_base + r * kDBlock + threadIdx.x;
+        live[r] = row < n && dense_row_in_filter(filter, row);
+        key[r] = row < n ? __builtin_nontemporal_load(&keys[row]) : KeyT();
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {  // R independent 4-byte reads in flight per lane
+        const uint64_t idx = dense_index(t, key[r]);
+        h[r] = (live[r] && idx != ~0ull) ? t.head[idx] : 0u;
+      }
+    }
+
+    if (MODE == 2) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = tile_base + r * kDBlock + threadIdx.x;
+        // live is folded into h (dead rows read 0); anti needs it back
+        const bool live = row < n && dense_row_in_filter(filter, row);
+        const bool bit = live && ((h[r] != 0u) != (anti != 0));
+        const uint64_t word = msb_first(__ballot(bit));
+        if (lane_id() == 0 && row < n) {
+          out_bitmap[row >> 6] = word;
+          local_count += __popcll(word);
+        }
+      }
+      continue;
+    }
+
+    // ---- first level: at most one match per row ---------------------------------------
+    uint64_t m[R];
+    int total = 0;
+    bool any_chain = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      m[r] = __ballot(h[r] != 0u);
+      total += __popcll(m[r]);
+      any_chain = any_chain || (h[r] & kChainBit) != 0u;
+    }
+    const bool wave_has_chain = __any(any_chain);
+    uint32_t next[R];
+    if (MODE == 1) {
+      if (lane_id() == 0) local_count += total;
+      if (wave_has_chain) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) next[r] = (h[r] & kChainBit) ? t.ov[h[r] & ~kChainBit].y : 0u;
+      }
+    } else {
+      // s_wave_total is double-buffered by tile parity, s_tile_base is rewritten only after the next
+      // tile's first barrier: two barriers per tile suffice.
+      if (lane_id() == 0) s_wave_total[parity][wave] = total;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int all = 0;
+#pragma unroll
+        for (int w = 0; w < kDBlock / kWave; ++w) all += s_wave_total[parity][w];
+        s_tile_base = all != 0 ? atomicAdd(out_count, static_cast<unsigned long long>(all)) : 0ull;
+      }
+      __syncthreads();
+      unsigned long long base = s_tile_base;
+      for (int w = 0; w < wave; ++w) base += s_wave_total[parity][w];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = tile_base + r * kDBlock + threadIdx.x;
+        uint32_t tid = h[r] - 1u;
+        next[r] = 0u;
+        if (wave_has_chain && (h[r] & kChainBit)) {
+          const uint2 e = t.ov[h[r] & ~kChainBit];
+          tid = e.x;
+          next[r] = e.y;
+        }
+        const unsigned long long o = base + rank_below(m[r]);
+        if (h[r] != 0u && o < capacity) {
+          __builtin_nontemporal_store(static_cast<int32_t>(probe_base_tid + row), &out_probe[o]);
+          __builtin_nontemporal_store(static_cast<int32_t>(tid), &out_build[o]);
+        }
+        base += __popcll(m[r]);
+      }
+    }
+    // ---- duplicate build keys: walk the chains ------------------------------------------
+    if (wave_has_chain) {
+#pragma unroll 1
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = tile_base + r * kDBlock + threadIdx.x;
+        uint32_t cur = next[r];
+        while (__any(cur != 0u)) {
+          uint32_t tid = cur - 1u, nxt = 0u;
+          if (cur & kChainBit) {
+            const uint2 e = t.ov[cur & ~kChainBit];
+            tid = e.x;
+            nxt = e.y;
+          }
+          if (MODE == 1) {
+            local_count += cur != 0u ? 1u : 0u;
+          } else {
+            dense_emit_direct(cur != 0u, static_cast<int32_t>(probe_base_tid + row), static_cast<int32_t>(tid), out_probe,
+                              out_build, capacity, out_count);
+          }
+          cur = nxt;
+        }
+      }
+    }
+  }
+  if (MODE != 0) {
+    local_count = wave_reduce_add(local_count);
+    if (lane_id() == 0 && local_count != 0 && out_count != nullptr) atomicAdd(out_count, local_count);
+  }
+}
+
+}  // namespace qsx
+
+#endif  // QSX_CSRC_JOIN_DENSE_HPP_

@@ -60,6 +60,20 @@ def shuffle_by_key(ops, keys, cols, group=None):
     return received, recv_splits
 
 
+def rank_progression(key_domain, world, rank):
+    """(first, last) of the keys k in [min, max] with k & (world-1) == rank, or None when the dense
+    flavour does not apply (no statistics, world not a power of two, negative keys — their
+    zero-extended hash is not the key value — or an empty partition)."""
+    if key_domain is None or world & (world - 1):
+        return None
+    lo, hi = int(key_domain[0]), int(key_domain[1])
+    if lo < 0 or hi < lo:
+        return None
+    first = lo + ((rank - lo) % world)
+    last = hi - ((hi - rank) % world)
+    return (first, last) if first <= last else None
+
+
 class PartitionedHashJoin:
     """lineitem ⋈ orders style partitioned join (BASELINE config 4).
 
@@ -67,10 +81,20 @@ class PartitionedHashJoin:
     are shuffled on the join key, then every rank joins its own partition.
     Output pairs carry *global* tuple ids (rank-local tid + the rank's base)."""
 
-    def __init__(self, ops, key_type, est_build_rows_per_rank, group=None):
+    def __init__(self, ops, key_type, est_build_rows_per_rank, group=None, key_domain=None):
+        """key_domain = (min, max): exact statistics of the build-side join attribute (TPC-H keys are
+        dense).  With a power-of-two world the partition of this rank, key & (P-1) == rank, is the
+        progression first, first + P, ... so the rank's table is the strided directly addressed
+        flavour (qsx_join_table_create_dense); otherwise the hashed table."""
         self.ops = ops
         self.group = group
-        self.table = ops.JoinTable(key_type, est_build_rows_per_rank)
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        progression = rank_progression(key_domain, world, rank)
+        if progression is None:
+            self.table = ops.JoinTable(key_type, est_build_rows_per_rank)
+        else:
+            self.table = ops.JoinTable(key_type, est_build_rows_per_rank, key_range=progression, key_stride=world)
 
     def build(self, keys, tid_base):
         tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)

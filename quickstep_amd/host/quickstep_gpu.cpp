@@ -300,10 +300,18 @@ QueryContext::scalar_group_id QueryContext::addScalarGroup(std::vector<attribute
   return static_cast<scalar_group_id>(scalar_groups_.size() - 1);
 }
 QueryContext::join_hash_table_id QueryContext::addJoinHashTable(TypeID key_type, std::int64_t estimated_entries,
-                                                                std::size_t num_partitions) {
+                                                                std::size_t num_partitions,
+                                                                const ExactKeyRange *exact_key_range) {
   std::vector<qsx_join_table_t *> parts(num_partitions, nullptr);
   for (std::size_t p = 0; p < num_partitions; ++p) {
-    CheckStatus(qsx_join_table_create(key_type, estimated_entries, &parts[p]), "qsx_join_table_create");
+    if (exact_key_range != nullptr) {
+      // every partition addresses the whole range: the single-node partition function is not a stride of the key
+      CheckStatus(qsx_join_table_create_dense(key_type, exact_key_range->min_value, exact_key_range->max_value, 1,
+                                              estimated_entries, &parts[p]),
+                  "qsx_join_table_create_dense");
+    } else {
+      CheckStatus(qsx_join_table_create(key_type, estimated_entries, &parts[p]), "qsx_join_table_create");
+    }
   }
   join_tables_.push_back(std::move(parts));
   return static_cast<join_hash_table_id>(join_tables_.size() - 1);

@@ -250,7 +250,12 @@ class QueryContext {
   ~QueryContext();
   predicate_id addPredicate(Predicate p);
   scalar_group_id addScalarGroup(std::vector<attribute_id> attrs);  // attribute projections only
-  join_hash_table_id addJoinHashTable(TypeID key_type, std::int64_t estimated_entries, std::size_t num_partitions = 1);
+  // exact_key_range: exact min/max statistics of the build-side join attribute when the optimizer has them
+  // (the condition of query_optimizer/rules/InjectJoinFilters.cpp:130-150) -> the directly addressed table
+  // flavour (qsx_join_table_create_dense); nullptr -> the hashed table.
+  struct ExactKeyRange { std::int64_t min_value, max_value; };
+  join_hash_table_id addJoinHashTable(TypeID key_type, std::int64_t estimated_entries, std::size_t num_partitions = 1,
+                                      const ExactKeyRange *exact_key_range = nullptr);
   aggregation_state_id addAggregationState(const AggregationStateSpec &spec, std::size_t num_partitions = 1);
   insert_destination_id addInsertDestination(CatalogRelation *relation, StorageManager *storage_manager);
 

@@ -56,11 +56,16 @@ Result collect(QueryContext &ctx, QueryContext::insert_destination_id dest_id, S
   return r;
 }
 
+// exact_stats: the optimizer knows the exact min/max of the build key (dim.long = 0..199, dim.int = 0..9):
+// the join table is the directly addressed flavour.
+bool g_exact_stats = false;
+
 void runJoin(attribute_id key_attr, TypeID key_type, bool use_foreman, HashJoinOperator::JoinType join_type, Result *out) {
   Fixture f;
   CatalogRelation result(3, "result");
   QueryContext ctx;
-  const auto table = ctx.addJoinHashTable(key_type, kNumDimTuples);
+  const QueryContext::ExactKeyRange range{0, key_type == kLong ? kNumDimTuples - 1 : kBlockSize - 1};
+  const auto table = ctx.addJoinHashTable(key_type, kNumDimTuples, 1, g_exact_stats ? &range : nullptr);
   const auto dest = ctx.addInsertDestination(&result, &f.storage);
   std::vector<bool> on_build;
   QueryContext::scalar_group_id selection;
@@ -107,7 +112,9 @@ int main() {
     std::fprintf(stderr, "hash_join_operator_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
     return 2;
   }
-  for (const bool use_foreman : {false, true}) {
+  for (const int variant : {0, 1, 2, 3}) {
+    const bool use_foreman = (variant & 1) != 0;
+    g_exact_stats = (variant & 2) != 0;
     {  // LongKeyHashJoinTest: 200 results, every dim.long exactly once (:510-514)
       Result r;
       runJoin(0, kLong, use_foreman, HashJoinOperator::JoinType::kInnerJoin, &r);

@@ -17,15 +17,21 @@ from quickstep_amd import types as T  # noqa: E402
 
 
 class OracleJoinTable:
-    def __init__(self, key_type, est):
+    def __init__(self, key_type, est, key_range=None, key_stride=1):
         self.key_type, self.est = key_type, est
+        self.key_range, self.key_stride = key_range, key_stride
         self.t = O.JoinTable(key_type, est)
 
     def clear(self):
         self.t = O.JoinTable(self.key_type, self.est)
 
     def build(self, keys):
-        self.t.build(keys.numpy())
+        k = keys.numpy()
+        if self.key_range is not None and k.size:
+            # the dense flavour's precondition: every build key is a member of the rank's progression
+            assert k.min() >= self.key_range[0] and k.max() <= self.key_range[1]
+            assert ((k.astype(np.int64) - self.key_range[0]) % self.key_stride == 0).all()
+        self.t.build(k)
 
     def probe(self, keys, capacity=None):
         p, b = self.t.probe(keys.numpy())
@@ -79,6 +85,21 @@ def main():
     gp, gb = join.materialize(probe_tids, build_tids, op, ob, cnt)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), build_keys=build_keys, probe_keys=probe_keys,
              pairs_probe=gp.numpy(), pairs_build=gb.numpy())
+
+    # the same with exact statistics of a dense, non-negative key domain: every rank's table is the
+    # strided directly addressed flavour; the wrapper asserts the progression precondition
+    dom = (3, 4001)
+    bk = rng.integers(dom[0], dom[1] + 1, size=n_build).astype(np.int32)
+    pk = rng.integers(0, 4500, size=n_probe).astype(np.int32)
+    join2 = qd.PartitionedHashJoin(OracleOps, T.INT, n_build * 2, key_domain=dom)
+    assert join2.table.key_range is not None and join2.table.key_stride == world
+    join2.build(torch.from_numpy(bk), rank * n_build)
+    pt2, bt2, op2, ob2, cnt2 = join2.probe(torch.from_numpy(pk), rank * n_probe)
+    gp2, gb2 = join2.materialize(pt2, bt2, op2, ob2, cnt2)
+    np.savez(os.path.join(out_dir, f"dense_rank{rank}.npz"), build_keys=bk, probe_keys=pk,
+             pairs_probe=gp2.numpy(), pairs_build=gb2.numpy())
+    assert qd.rank_progression((0, 10), 3, 1) is None and qd.rank_progression((-4, 10), 2, 1) is None
+    assert qd.rank_progression((5, 6), 4, 0) is None and qd.rank_progression((5, 17), 4, 2) == (6, 14)
 
     # partial aggregate merge
     vals = [(int(g), int(v)) for g, v in zip(rng.integers(0, 16, size=1000), rng.integers(0, 100, size=1000))]

@@ -28,7 +28,12 @@ def test_partitioned_join_and_merge_two_ranks(tmp_path, oracle):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    ranks = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    for prefix in ("rank", "dense_rank"):
+        _check_partitioned_join(oracle, tmp_path, world, prefix)
+
+
+def _check_partitioned_join(oracle, tmp_path, world, prefix):
+    ranks = [np.load(tmp_path / f"{prefix}{i}.npz") for i in range(world)]
     build = np.concatenate([d["build_keys"] for d in ranks])      # global tid = rank * n + local row
     probe = np.concatenate([d["probe_keys"] for d in ranks])
     got = np.concatenate([np.stack([d["pairs_probe"], d["pairs_build"]], 1) for d in ranks])

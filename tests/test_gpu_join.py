@@ -12,10 +12,17 @@ from helpers import bitmap_dev, bitmap_np, sorted_pairs, to_dev
 pytestmark = pytest.mark.gpu
 
 
+FLAVOURS = ["hashed", "dense"]
+
+
 def hip_join(capi, dev, key_type, build_blocks, probe_keys, est=None, capacity=None, build_filters=None,
-             probe_filter=None):
+             probe_filter=None, flavour="hashed"):
     total_build = sum(b.size for b in build_blocks)
-    table = capi.JoinTable(key_type, total_build if est is None else est)
+    key_range = None
+    if flavour == "dense":   # exact min/max statistics of the build side, as the optimizer would hold them
+        allk = np.concatenate(build_blocks) if total_build else np.zeros(1, np.int64)
+        key_range = (int(allk.min()), int(allk.max()))
+    table = capi.JoinTable(key_type, total_build if est is None else est, key_range=key_range)
     base = 0
     for i, b in enumerate(build_blocks):
         f = None if build_filters is None else bitmap_dev(build_filters[i], dev)
@@ -41,24 +48,27 @@ def oracle_join(oracle, key_type, build_blocks, probe_keys, build_filters=None, 
     return t, p, b
 
 
-def test_golden_long_key_join(capi, dev, golden):
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_golden_long_key_join(capi, dev, golden, flavour):
     g = golden["join_unittest"]
     bs = g["block_size"]
     dim = np.arange(g["num_dim_tuples"], dtype=np.int64)
     fact = np.arange(g["num_fact_tuples"], dtype=np.int64)
     blocks = [dim[b:b + bs] for b in range(0, dim.size, bs)]        # one build work order per 10-row block
-    _, p, d, total = hip_join(capi, dev, T.LONG, blocks, fact)
+    _, p, d, total = hip_join(capi, dev, T.LONG, blocks, fact, flavour=flavour)
     assert total == g["long_key"]["expected_num_results"]
     assert (np.bincount(d, minlength=dim.size) == g["long_key"]["expected_count_per_dim_long"]).all()
     assert np.array_equal(dim[d], fact[p])
 
 
-def test_golden_int_duplicate_key_join(capi, dev, golden):
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_golden_int_duplicate_key_join(capi, dev, golden, flavour):
     g = golden["join_unittest"]
     bs = g["block_size"]
     dim_int = (np.arange(g["num_dim_tuples"]) % bs).astype(np.int32)
     fact_int = np.arange(g["num_fact_tuples"], dtype=np.int32)
-    _, p, d, total = hip_join(capi, dev, T.INT, [dim_int[b:b + bs] for b in range(0, dim_int.size, bs)], fact_int)
+    _, p, d, total = hip_join(capi, dev, T.INT, [dim_int[b:b + bs] for b in range(0, dim_int.size, bs)], fact_int,
+                              flavour=flavour)
     e = g["int_duplicate_key"]
     assert total == e["expected_num_results"]
     assert (np.bincount(d, minlength=dim_int.size) == e["expected_count_per_dim_row"]).all()
@@ -66,13 +76,14 @@ def test_golden_int_duplicate_key_join(capi, dev, golden):
     assert (fc[:bs] == e["expected_fact_count_first_rows"]).all() and (fc[bs:] == 0).all()
 
 
-def test_cartesian_product_key(capi, oracle, dev):
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_cartesian_product_key(capi, oracle, dev, flavour):
     """CharKeyCartesianProductHashJoinTest shape (HashJoinOperator_unittest.cpp:692-826): one
     constant key on both sides, every dim row joins every fact row (200 x 300).  The
     constant stands in for the CHAR(\"100\") key; this drives the LDS-stage overflow path."""
     dim = np.full(200, 100, dtype=np.int32)
     fact = np.full(300, 100, dtype=np.int32)
-    _, p, d, total = hip_join(capi, dev, T.INT, [dim], fact)
+    _, p, d, total = hip_join(capi, dev, T.INT, [dim], fact, flavour=flavour)
     assert total == 200 * 300
     assert (np.bincount(d, minlength=200) == 300).all() and (np.bincount(p, minlength=300) == 200).all()
     _, rp, rd = oracle_join(oracle, T.INT, [dim], fact)
@@ -82,18 +93,23 @@ def test_cartesian_product_key(capi, oracle, dev):
 @pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
 @pytest.mark.parametrize("n_build,n_probe,key_range", [(1, 1, 1), (1000, 5000, 300), (50_000, 400_000, 100_000),
                                                          (200_000, 1_000_003, 150_000)])
-def test_random_join_matches_oracle(capi, oracle, dev, key_type, dtype, n_build, n_probe, key_range):
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_random_join_matches_oracle(capi, oracle, dev, key_type, dtype, n_build, n_probe, key_range, flavour):
     rng = np.random.default_rng(n_build + n_probe)
     lo = -key_range // 2                                  # negative keys: hash is the zero-extended pattern
     build = rng.integers(lo, lo + key_range, size=n_build).astype(dtype)
     probe = rng.integers(lo - 10, lo + key_range + 10, size=n_probe).astype(dtype)
-    if dtype == np.int64:
+    if dtype == np.int64 and flavour == "hashed":
         build[::7] += 2**40                               # keys beyond 32 bits
         probe[::5] += 2**40
+    elif dtype == np.int64:
+        build += 2**40                                    # dense: a bounded range far from zero
+        probe += 2**40
+        probe[::11] = -probe[::11]                        # far outside the range: no match
     blocks = np.array_split(build, 3)
     bf = [oracle.bitmap_from_bools(rng.random(b.size) < 0.8) if b.size else np.zeros(1, np.uint64) for b in blocks]
     pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.7)
-    table, p, d, total = hip_join(capi, dev, key_type, blocks, probe, build_filters=bf, probe_filter=pf)
+    table, p, d, total = hip_join(capi, dev, key_type, blocks, probe, build_filters=bf, probe_filter=pf, flavour=flavour)
     otable, rp, rd = oracle_join(oracle, key_type, blocks, probe, build_filters=bf, probe_filter=pf)
     assert total == rp.size
     assert table.size() == otable.info()["buckets_allocated"]
@@ -121,29 +137,76 @@ def test_empty_inputs(capi, dev):
     assert int(c.item()) == 100
 
 
-def test_table_grows_past_its_estimate(capi, oracle, dev):
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_table_grows_past_its_estimate(capi, oracle, dev, flavour):
     """est_entries = 4 but 300 k rows arrive in 6 build work orders: the table must
     resize like HashTable::resize (storage/HashTable.hpp:1437-1440) without losing entries."""
     rng = np.random.default_rng(9)
     build = rng.integers(0, 40_000, size=300_000).astype(np.int32)
     probe = rng.integers(0, 45_000, size=100_000).astype(np.int32)
     blocks = np.array_split(build, 6)
-    table, p, d, total = hip_join(capi, dev, T.INT, blocks, probe, est=4)
+    table, p, d, total = hip_join(capi, dev, T.INT, blocks, probe, est=4, flavour=flavour)
     assert table.size() == build.size
     _, rp, rd = oracle_join(oracle, T.INT, blocks, probe)
     assert total == rp.size
     assert np.array_equal(sorted_pairs(p, d), sorted_pairs(rp, rd))
 
 
-def test_capacity_smaller_than_matches_reports_full_count(capi, dev):
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_capacity_smaller_than_matches_reports_full_count(capi, dev, flavour):
     build = np.arange(10_000, dtype=np.int32)
     probe = np.arange(10_000, dtype=np.int32)
-    table, p, d, total = hip_join(capi, dev, T.INT, [build], probe, capacity=1234)
+    table, p, d, total = hip_join(capi, dev, T.INT, [build], probe, capacity=1234, flavour=flavour)
     assert total == 10_000 and p.size == 1234
     assert np.array_equal(build[d], probe[p])             # what was written is still valid pairs
 
 
-def test_fk_join_at_scale_properties(capi, dev):
+def test_dense_table_rejects_build_keys_outside_its_range(capi, dev):
+    """The dense flavour's precondition (exact min/max statistics, InjectJoinFilters.cpp:130-150): a build key
+    outside the range is skipped and reported by the next synchronising call; probe keys outside simply miss."""
+    table = capi.JoinTable(T.INT, 16, key_range=(10, 19))
+    table.build(to_dev(np.array([10, 15, 19, 15], dtype=np.int32), dev))
+    assert table.size() == 4
+    p, b, cnt = table.probe(to_dev(np.array([9, 10, 15, 20, -5, 2**31 - 1], dtype=np.int32), dev))
+    k = int(cnt.item())
+    assert sorted(zip(p.cpu().numpy()[:k].tolist(), b.cpu().numpy()[:k].tolist())) == [(1, 0), (2, 1), (2, 3)]
+    table.build(to_dev(np.array([20], dtype=np.int32), dev), base_tid=4)
+    with pytest.raises(capi.QsxError):
+        table.size()
+    table.clear()
+    assert table.size() == 0
+    with pytest.raises(capi.QsxError):
+        capi.JoinTable(T.LONG, 16, key_range=(0, 2**40))     # range too large for head words
+    with pytest.raises(capi.QsxError):
+        capi.JoinTable(T.INT, 16, key_range=(0, 100), key_stride=3)   # shift addressing: powers of two only
+
+
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+def test_dense_table_over_one_hash_partition(capi, oracle, dev, key_type, dtype):
+    """After the multi-GPU shuffle a rank holds the keys with key & (P-1) == rank of a dense domain
+    (PartitionSchemeHeader.hpp:200-214): the strided dense table addresses them with (key - min) / P.
+    Probe keys of other partitions (a mis-routed row would be one) must not match."""
+    rng = np.random.default_rng(31)
+    P, rank, domain = 8, 5, 400_000
+    mine = np.arange(rank, domain, P)
+    build = rng.choice(mine, size=60_000, replace=True).astype(dtype)      # duplicates included
+    probe = rng.integers(-50, domain + 50, size=500_000).astype(dtype)     # all partitions + out of range
+    table = capi.JoinTable(key_type, build.size, key_range=(int(mine[0]), int(mine[-1])), key_stride=P)
+    table.build(to_dev(build, dev))
+    assert table.size() == build.size
+    dp = to_dev(probe, dev)
+    total = int(table.probe_count(dp).item())
+    p, b, cnt = table.probe(dp, capacity=total)
+    _, rp, rd = oracle_join(oracle, key_type, [build], probe)
+    assert total == rp.size == int(cnt.item())
+    assert np.array_equal(sorted_pairs(p.cpu().numpy(), b.cpu().numpy()), sorted_pairs(rp, rd))
+    table.build(to_dev(np.array([rank + 1], dtype=dtype), dev), base_tid=build.size)   # off the stride
+    with pytest.raises(capi.QsxError):
+        table.size()
+
+
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_fk_join_at_scale_properties(capi, dev, flavour):
     """C2 shape scaled to 1 M x 20 M (full 100 M runs in bench.py): every probe key hits
     exactly one build row, so pairs must be a permutation of the probe tids and satisfy the
     join condition; checked on device with size-independent reductions."""
@@ -152,7 +215,7 @@ def test_fk_join_at_scale_properties(capi, dev):
     n_build, n_probe = 1_000_000, 20_000_000
     build = torch.randperm(n_build, device=dev, generator=g, dtype=torch.int32)
     probe = torch.randint(0, n_build, (n_probe,), device=dev, generator=g, dtype=torch.int32)
-    table = capi.JoinTable(T.INT, n_build)
+    table = capi.JoinTable(T.INT, n_build, key_range=(0, n_build - 1) if flavour == "dense" else None)
     table.build(build)
     p, b, cnt = table.probe(probe)
     assert int(cnt.item()) == n_probe

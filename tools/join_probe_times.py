@@ -19,6 +19,8 @@ match = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 probe = torch.randint(0, int(nb / match), (npr,), device=dev, generator=g, dtype=torch.int32)
 table = capi.JoinTable(T.INT, nb)
 table.build(build)
+dense = capi.JoinTable(T.INT, nb, key_range=(0, nb - 1))
+dense.build(build)
 out = (torch.empty(npr, dtype=torch.int32, device=dev), torch.empty(npr, dtype=torch.int32, device=dev),
        torch.zeros(1, dtype=torch.int64, device=dev))
 
@@ -35,6 +37,11 @@ def timed(name, fn, reps=3):
     print(f"{name:32s} {e0.elapsed_time(e1) / reps:8.3f} ms")
 
 
+timed("dense build (clear + 1 M)", lambda: (dense.clear(), dense.build(build)))
+timed("hashed build (clear + 1 M)", lambda: (table.clear(), table.build(build)))
+timed("dense probe pairs", lambda: dense.probe(probe, capacity=npr, out=out))
+timed("dense probe count only", lambda: dense.probe_count(probe))
+timed("dense probe exists bitmap", lambda: dense.probe_exists(probe))
 timed("probe pairs", lambda: table.probe(probe, capacity=npr, out=out))
 timed("probe count only", lambda: table.probe_count(probe))
 timed("probe exists bitmap", lambda: table.probe_exists(probe))
