@@ -111,6 +111,20 @@ int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op,
                    uint64_t *out_bitmap_dev, int64_t *out_count_dev,
                    qsx_stream_t stream);
 
+/* K1 with a second column as right operand: out_bitmap[i] = (lhs[i] OP rhs[i])
+ * [AND filter[i]].  Replaces LiteralUncheckedComparator::compareColumnVectors
+ * (types/operations/comparisons/LiteralComparators-inl.hpp:52-125) as reached from
+ * ComparisonPredicate::getAllMatches for attribute-vs-attribute predicates
+ * (expressions/predicate/ComparisonPredicate.cpp:300-334).  With the operands
+ * gathered for a list of joined pairs (qsx_gather) it evaluates a residual join
+ * predicate on all pairs at once — what HashInnerJoinWorkOrder does pair by pair
+ * through Predicate::matchesForJoinedTuples (relational_operators/
+ * HashJoinOperator.cpp:510-524) — and the component check of a hashed composite
+ * key (qsx_join_key_pack). */
+int qsx_select_cmp_columns(int type, const void *lhs_dev, const void *rhs_dev, int64_t n, int op,
+                           const uint64_t *filter_dev, uint64_t *out_bitmap_dev,
+                           int64_t *out_count_dev, qsx_stream_t stream);
+
 /* Bitmap algebra on TupleIdSequences of n bits (storage/TupleIdSequence.hpp:
  * intersectWith / unionWith / invert). op: 0 = AND, 1 = OR, 2 = AND NOT,
  * 3 = NOT a (b ignored). */
@@ -139,6 +153,15 @@ int qsx_compact_gather(int ncols, const void *const *cols, const int32_t *widths
 int qsx_bitmap_to_tids(const uint64_t *bitmap_dev, int64_t n, int32_t base_tid,
                        int32_t *out_tids_dev, int64_t *out_count_dev,
                        void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
+
+/* Tuple-id list -> TupleIdSequence of num_bits bits: bit (tids[i] - base_tid) is
+ * set for every i < n (duplicates allowed); the bitmap is fully overwritten.
+ * The semi/anti join with a residual predicate collects the probe tuples that
+ * kept at least one pair this way (TupleIdSequence filter of
+ * HashSemiJoinWorkOrder::executeWithResidualPredicate, relational_operators/
+ * HashJoinOperator.cpp:735-760). */
+int qsx_tids_to_bitmap(const int32_t *tids_dev, int64_t n, int32_t base_tid, int64_t num_bits,
+                       uint64_t *out_bitmap_dev, qsx_stream_t stream);
 
 /* K5.  dst[i] = src[tids[i]] for i < n (value width 1/2/4/8 bytes); tids < 0
  * write zero bytes (outer-join NULL padding; the null bit is the caller's).
@@ -192,6 +215,25 @@ int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **
 int qsx_join_table_create_dense(int key_type, int64_t min_key, int64_t max_key, int64_t key_stride,
                                 int64_t est_entries, qsx_join_table_t **out);
 int qsx_join_table_destroy(qsx_join_table_t *table);
+
+/* Composite join keys.  The reference keeps the key components in the bucket,
+ * hashes them with a CombineHashes fold and compares hash + components on lookup
+ * (HashTable::putValueAccessorCompositeKey / getAllFromValueAccessorCompositeKey,
+ * storage/HashTable.hpp:1463-1575, 1835-1880; hashCompositeKey :2109-2119;
+ * SeparateChainingHashTable::getNextEntryForCompositeKey .hpp:1033-1060).
+ * Here the components are folded into ONE LONG key per row, which then goes
+ * through the single-key table above:
+ *   sum of widths <= 8 bytes: the components' bytes at running offsets of a zeroed
+ *     64-bit word (little endian) — equal words <=> equal composite keys,
+ *     *out_exact = 1;
+ *   wider: the reference's composite hash (identity hash of every component,
+ *     CombineHashes fold, utility/HashPair.hpp:47-58), *out_exact = 0: the pairs
+ *     the table returns must be verified component by component
+ *     (qsx_gather + qsx_select_cmp_columns(QSX_EQ) + qsx_compact_gather).
+ *   types   host array: QSX_INT or QSX_LONG per component (at most QSX_MAX_KEYS)
+ *   out_dev n int64 on device;  out_exact  host int */
+int qsx_join_key_pack(int ncols, const void *const *cols, const int32_t *types, int64_t n,
+                      int64_t *out_dev, int *out_exact, qsx_stream_t stream);
 /* Drop every entry, keep the allocation (a new query re-using the table;
  * counterpart of DestroyHashOperator + re-creation, relational_operators/
  * DestroyHashOperator.cpp:70-72).  Stream-ordered. */

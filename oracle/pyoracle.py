@@ -54,6 +54,13 @@ for _name, _res, _args in [
     ("qso_join_build", None, [_vp, _vp, _i64, _u64, _i32, _vp]),
     ("qso_join_probe", _i64, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64]),
     ("qso_join_probe_exists", None, [_vp, _vp, _i64, _vp, _int, _vp]),
+    ("qso_cjoin_table_create", _vp, [_int, C.POINTER(_i32), _i64]),
+    ("qso_cjoin_table_destroy", None, [_vp]),
+    ("qso_cjoin_build", None, [_vp, _pp, _i64, _u64, _i32, _vp]),
+    ("qso_cjoin_probe", _i64, [_vp, _pp, _i64, _i32, _vp, _vp, _vp, _i64]),
+    ("qso_cjoin_hash_row", _u64, [_vp, _pp, _i64]),
+    ("qso_select_cmp_columns", None, [_int, _vp, _vp, _i64, _int, _vp, _vp]),
+    ("qso_tids_to_bitmap", None, [_vp, _i64, _i32, _i64, _vp]),
     ("qso_agg_state_create", _vp, [C.POINTER(T.AggConfig)]),
     ("qso_agg_state_destroy", None, [_vp]),
     ("qso_agg_update", None, [_vp, _pp, _i64, _vp]),
@@ -224,6 +231,61 @@ class JoinTable:
         out = np.zeros(max(words(keys.size), 1), dtype=np.uint64)
         _lib.qso_join_probe_exists(self._h, _p(keys), keys.size, _p(filter_bitmap), 1 if anti else 0, _p(out))
         return out
+
+
+class CompositeJoinTable:
+    """Join table over several fixed-width key components (SeparateChainingHashTable restated)."""
+
+    def __init__(self, key_types, est_entries):
+        self.key_types = list(key_types)
+        arr = (C.c_int32 * len(self.key_types))(*self.key_types)
+        self._h = C.c_void_p(_lib.qso_cjoin_table_create(len(self.key_types), arr, est_entries))
+        assert self._h.value
+
+    def close(self):
+        if self._h is not None:
+            _lib.qso_cjoin_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    @staticmethod
+    def _cols(cols):
+        keep = [np.ascontiguousarray(c) for c in cols]
+        return keep, (C.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
+
+    def build(self, cols, block_id=0, base_tid=0, filter_bitmap=None):
+        keep, ptrs = self._cols(cols)
+        _lib.qso_cjoin_build(self._h, ptrs, keep[0].size, block_id, base_tid, _p(filter_bitmap))
+
+    def probe(self, cols, probe_base_tid=0, filter_bitmap=None):
+        keep, ptrs = self._cols(cols)
+        n = keep[0].size
+        k = _lib.qso_cjoin_probe(self._h, ptrs, n, probe_base_tid, _p(filter_bitmap), None, None, 0)
+        op = np.empty(max(k, 1), dtype=np.int32)
+        ob = np.empty(max(k, 1), dtype=np.int32)
+        _lib.qso_cjoin_probe(self._h, ptrs, n, probe_base_tid, _p(filter_bitmap), _p(op), _p(ob), k)
+        return op[:k], ob[:k]
+
+    def hash_rows(self, cols):
+        keep, ptrs = self._cols(cols)
+        return np.array([_lib.qso_cjoin_hash_row(self._h, ptrs, i) for i in range(keep[0].size)], dtype=np.uint64)
+
+
+def select_cmp_columns(lhs, rhs, op, filter_bitmap=None):
+    out = np.zeros(max(words(lhs.size), 1), dtype=np.uint64)
+    _lib.qso_select_cmp_columns(_NP_TYPE[lhs.dtype], _p(lhs), _p(rhs), lhs.size, op, _p(filter_bitmap), _p(out))
+    return out
+
+
+def tids_to_bitmap(tids, num_bits, base_tid=0):
+    out = np.zeros(max(words(num_bits), 1), dtype=np.uint64)
+    _lib.qso_tids_to_bitmap(_p(tids), tids.size, base_tid, num_bits, _p(out))
+    return out
 
 
 # ---- aggregation --------------------------------------------------------------------

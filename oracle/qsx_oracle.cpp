@@ -23,6 +23,7 @@
 namespace {
 
 constexpr std::size_t kSlotSizeBytes = 0x200000;  // storage/StorageConstants.hpp:50
+constexpr std::uint64_t kHashTableLoadFactor = 2;   // slots per entry (storage/StorageConstants.hpp:104)
 constexpr std::uint64_t kSizeMax = ~static_cast<std::uint64_t>(0);
 
 // ---------------------------------------------------------------------------
@@ -442,6 +443,138 @@ void qso_join_probe_exists(const qso_join_table_t *t, const void *keys, int64_t 
       found = (bucket.hash == hash);
     }
     if (found != (anti != 0)) bit_set(out_bitmap, i);
+  }
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// composite-key join table: SeparateChainingHashTable restated for fixed-width
+// components.  Bucket = {next, hash, value, key components} (storage/
+// SeparateChainingHashTable.hpp:166, kValueOffset/key layout via HashTableKeyManager);
+// hash = CombineHashes fold over the component hashes (storage/HashTable.hpp:2109-2119);
+// put appends at the chain tail (putCompositeKeyInternal -> locateBucketForInsertion,
+// .hpp:743-792, 1339-1374); lookup compares hash AND components
+// (getNextEntryForCompositeKey, .hpp:1033-1060).  Single-threaded; growth re-chains like
+// resize (.hpp:1080-1240) but is not restated step by step (chain order never shows in a result).
+// ---------------------------------------------------------------------------
+struct qso_cjoin_table {
+  int nkeys = 0;
+  int key_types[QSX_MAX_KEYS];
+  std::uint64_t num_slots = 0;
+  std::vector<std::uint64_t> slots;            // 0 = empty, else bucket + 1
+  struct CBucket {
+    std::uint64_t next;
+    std::uint64_t hash;
+    TupleRef value;
+    std::int64_t key[QSX_MAX_KEYS];
+  };
+  std::vector<CBucket> buckets;
+
+  std::int64_t component(const void *const *cols, int k, std::int64_t i) const {
+    if (key_types[k] == QSX_INT) return static_cast<const std::int32_t *>(cols[k])[i];
+    return static_cast<const std::int64_t *>(cols[k])[i];
+  }
+  std::uint64_t hash_row(const void *const *cols, std::int64_t i) const {
+    std::uint64_t h = 0;
+    for (int k = 0; k < nkeys; ++k) {
+      const std::uint64_t hk = key_types[k] == QSX_INT
+                                   ? hash_int(static_cast<const std::int32_t *>(cols[k])[i])
+                                   : hash_long(static_cast<const std::int64_t *>(cols[k])[i]);
+      h = k == 0 ? hk : combine_hashes(h, hk);
+    }
+    return h;
+  }
+  void rechain(std::uint64_t wanted_slots) {
+    num_slots = next_prime(wanted_slots);
+    slots.assign(num_slots, 0);
+    for (std::uint64_t b = 0; b < buckets.size(); ++b) {
+      std::uint64_t *pending = &slots[buckets[b].hash % num_slots];
+      while (*pending != 0) pending = &buckets[*pending - 1].next;
+      buckets[b].next = 0;
+      *pending = b + 1;
+    }
+  }
+};
+
+extern "C" {
+
+qso_cjoin_table_t *qso_cjoin_table_create(int nkeys, const int32_t *key_types, int64_t est_entries) {
+  if (nkeys < 1 || nkeys > QSX_MAX_KEYS) return nullptr;
+  qso_cjoin_table *t = new qso_cjoin_table();
+  t->nkeys = nkeys;
+  for (int k = 0; k < nkeys; ++k) t->key_types[k] = key_types[k];
+  t->rechain(static_cast<std::uint64_t>(est_entries < 1 ? 1 : est_entries) * kHashTableLoadFactor);
+  return t;
+}
+void qso_cjoin_table_destroy(qso_cjoin_table_t *t) { delete t; }
+
+void qso_cjoin_build(qso_cjoin_table_t *t, const void *const *cols, int64_t n, uint64_t block_id, int32_t base_tid,
+                     const uint64_t *filter) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (!row_selected(filter, i)) continue;
+    if ((t->buckets.size() + 1) * kHashTableLoadFactor > t->num_slots) t->rechain(t->num_slots * 2);
+    qso_cjoin_table::CBucket b;
+    b.next = 0;
+    b.hash = t->hash_row(cols, i);
+    b.value = TupleRef{block_id, static_cast<std::int32_t>(base_tid + i)};
+    for (int k = 0; k < QSX_MAX_KEYS; ++k) b.key[k] = k < t->nkeys ? t->component(cols, k, i) : 0;
+    t->buckets.push_back(b);
+    std::uint64_t *pending = &t->slots[b.hash % t->num_slots];
+    while (*pending != 0) pending = &t->buckets[*pending - 1].next;  // chain tail
+    *pending = t->buckets.size();
+  }
+}
+
+int64_t qso_cjoin_probe(const qso_cjoin_table_t *t, const void *const *cols, int64_t n, int32_t probe_base_tid,
+                        const uint64_t *filter, int32_t *out_probe_tid, int32_t *out_build_tid, int64_t capacity) {
+  int64_t count = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!row_selected(filter, i)) continue;
+    const uint64_t hash = t->hash_row(cols, i);
+    uint64_t entry = t->slots[hash % t->num_slots];
+    while (entry != 0) {
+      const qso_cjoin_table::CBucket &bucket = t->buckets[entry - 1];
+      entry = bucket.next;
+      if (bucket.hash != hash) continue;
+      bool same = true;  // compositeKeyCollisionCheck
+      for (int k = 0; k < t->nkeys && same; ++k) same = bucket.key[k] == t->component(cols, k, i);
+      if (!same) continue;
+      if (count < capacity) {
+        out_probe_tid[count] = static_cast<int32_t>(probe_base_tid + i);
+        out_build_tid[count] = bucket.value.tuple;
+      }
+      ++count;
+    }
+  }
+  return count;
+}
+
+// CombineHashes fold of one row's components (what a hashed composite key of the device path must equal).
+uint64_t qso_cjoin_hash_row(const qso_cjoin_table_t *t, const void *const *cols, int64_t i) { return t->hash_row(cols, i); }
+
+// LiteralUncheckedComparator::compareColumnVectors (LiteralComparators-inl.hpp:52-125).
+void qso_select_cmp_columns(int type, const void *lhs, const void *rhs, int64_t n, int op, const uint64_t *filter,
+                            uint64_t *out_bitmap) {
+  std::memset(out_bitmap, 0, sizeof(uint64_t) * bitmap_words(n));
+  for (int64_t i = 0; i < n; ++i) {
+    if (filter != nullptr && !bit_get(filter, i)) continue;
+    bool r;
+    switch (type) {
+      case QSX_INT: r = compare<std::int32_t>(static_cast<const std::int32_t *>(lhs)[i], op, static_cast<const std::int32_t *>(rhs)[i]); break;
+      case QSX_LONG: r = compare<std::int64_t>(static_cast<const std::int64_t *>(lhs)[i], op, static_cast<const std::int64_t *>(rhs)[i]); break;
+      case QSX_FLOAT: r = compare<float>(static_cast<const float *>(lhs)[i], op, static_cast<const float *>(rhs)[i]); break;
+      default: r = compare<double>(static_cast<const double *>(lhs)[i], op, static_cast<const double *>(rhs)[i]); break;
+    }
+    if (r) bit_set(out_bitmap, i);
+  }
+}
+
+void qso_tids_to_bitmap(const int32_t *tids, int64_t n, int32_t base_tid, int64_t num_bits, uint64_t *out_bitmap) {
+  std::memset(out_bitmap, 0, sizeof(uint64_t) * bitmap_words(num_bits));
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t bit = static_cast<int64_t>(tids[i]) - base_tid;
+    if (bit >= 0 && bit < num_bits) bit_set(out_bitmap, bit);
   }
 }
 

@@ -57,16 +57,19 @@ _SIGNATURES = {
     "qsx_stream_create": (_int, [_pp]),
     "qsx_stream_destroy": (_int, [_vp]),
     "qsx_select_cmp": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "qsx_select_cmp_columns": (_int, [_int, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "qsx_bitmap_combine": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_bitmap_count": (_int, [_vp, _i64, _vp, _vp]),
     "qsx_compact_workspace_bytes": (_sz, [_i64]),
     "qsx_compact_gather": (_int, [_int, _pp, C.POINTER(_i32), _vp, _i64, _pp, _vp, _vp, _sz, _vp]),
     "qsx_bitmap_to_tids": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "qsx_tids_to_bitmap": (_int, [_vp, _i64, _i32, _i64, _vp, _vp]),
     "qsx_gather": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_gather_segmented": (_int, [_int, _int, _pp, C.POINTER(_i64), _vp, _i64, _vp, _vp]),
     "qsx_join_table_create": (_int, [_int, _i64, _pp]),
     "qsx_join_table_create_dense": (_int, [_int, _i64, _i64, _i64, _i64, _pp]),
     "qsx_join_table_destroy": (_int, [_vp]),
+    "qsx_join_key_pack": (_int, [_int, _pp, C.POINTER(_i32), _i64, _vp, C.POINTER(_int), _vp]),
     "qsx_join_table_clear": (_int, [_vp, _vp]),
     "qsx_join_table_size": (_int, [_vp, C.POINTER(_i64), _vp]),
     "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -161,6 +164,17 @@ def select_cmp(col, op, literal, filter_bitmap=None, out_bitmap=None, out_count=
     return out_bitmap, out_count
 
 
+def select_cmp_columns(lhs, rhs, op, filter_bitmap=None, stream=None):
+    """K1, attribute OP attribute: returns (bitmap, count) like select_cmp."""
+    n = lhs.numel()
+    assert rhs.numel() == n and rhs.dtype == lhs.dtype
+    out_bitmap = new_bitmap(n, lhs.device)
+    out_count = torch.zeros(1, dtype=torch.int64, device=lhs.device)
+    _check(_lib.qsx_select_cmp_columns(qsx_type_of(lhs), _ptr(lhs), _ptr(rhs), n, op, _ptr(filter_bitmap),
+                                       _ptr(out_bitmap), _ptr(out_count), _stream(stream)), "qsx_select_cmp_columns")
+    return out_bitmap, out_count
+
+
 def bitmap_combine(op, a, b, n, out=None, stream=None):
     if out is None:
         out = torch.empty_like(a)
@@ -197,6 +211,25 @@ def bitmap_to_tids(bitmap, n, base_tid=0, stream=None):
     _check(_lib.qsx_bitmap_to_tids(_ptr(bitmap), n, base_tid, _ptr(out), _ptr(count), _ptr(ws), ws_bytes,
                                    _stream(stream)), "qsx_bitmap_to_tids")
     return out, count
+
+
+def tids_to_bitmap(tids, num_bits, base_tid=0, stream=None):
+    out = new_bitmap(num_bits, tids.device)
+    _check(_lib.qsx_tids_to_bitmap(_ptr(tids), tids.numel(), base_tid, num_bits, _ptr(out), _stream(stream)),
+           "qsx_tids_to_bitmap")
+    return out
+
+
+def join_key_pack(cols, stream=None):
+    """Composite join key -> (int64 key per row, exact flag); see qsx_join_key_pack."""
+    n = cols[0].numel()
+    out = torch.empty(n, dtype=torch.int64, device=cols[0].device)
+    ptrs = (C.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
+    types = (C.c_int32 * len(cols))(*[qsx_type_of(c) for c in cols])
+    exact = C.c_int(0)
+    _check(_lib.qsx_join_key_pack(len(cols), ptrs, types, n, _ptr(out), C.byref(exact), _stream(stream)),
+           "qsx_join_key_pack")
+    return out, bool(exact.value)
 
 
 def gather(src, tids, out=None, stream=None):

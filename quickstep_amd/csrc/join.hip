@@ -332,6 +332,43 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// composite keys -> one LONG key (qsx_join_key_pack)
+// ---------------------------------------------------------------------------
+struct KeyPackArgs {
+  const void *cols[QSX_MAX_KEYS];
+  int is_long[QSX_MAX_KEYS];
+  int shift[QSX_MAX_KEYS];  // exact packing: bit offset of the component
+  int ncols;
+  int exact;
+};
+
+// utility/HashPair.hpp:47-58 (64-bit CombineHashes)
+__device__ __forceinline__ uint64_t combine_hashes(uint64_t first, uint64_t second) {
+  const uint64_t kMul = 0x9ddfea08eb382d69ull;
+  uint64_t a = (first ^ second) * kMul;
+  a ^= (a >> 47);
+  uint64_t b = (second ^ a) * kMul;
+  b ^= (b >> 47);
+  b *= kMul;
+  return b;
+}
+
+__global__ __launch_bounds__(kJBlock) void key_pack_kernel(KeyPackArgs a, int64_t n, int64_t *__restrict__ out) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kJBlock) {
+    uint64_t acc = 0;
+    for (int k = 0; k < a.ncols; ++k) {
+      // identity hash = the zero-extended bit pattern (types/TypedValue.hpp:575-592)
+      const uint64_t v = a.is_long[k] ? static_cast<uint64_t>(static_cast<const int64_t *>(a.cols[k])[i])
+                                      : static_cast<uint64_t>(static_cast<const uint32_t *>(a.cols[k])[i]);
+      if (a.exact) acc |= v << a.shift[k];
+      else acc = k == 0 ? v : combine_hashes(acc, v);
+    }
+    out[i] = static_cast<int64_t>(acc);
+  }
+}
+
 }  // namespace qsx
 
 using namespace qsx;
@@ -519,6 +556,32 @@ int qsx_join_table_create_dense(int key_type, int64_t min_key, int64_t max_key, 
   }
   t->max_disp_dev = reinterpret_cast<unsigned int *>(t->entries_dev + 1);
   *out = t;
+  return QSX_OK;
+}
+
+int qsx_join_key_pack(int ncols, const void *const *cols, const int32_t *types, int64_t n, int64_t *out_dev,
+                      int *out_exact, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (ncols < 1 || ncols > QSX_MAX_KEYS || cols == nullptr || types == nullptr || n < 0 || out_exact == nullptr ||
+      (n > 0 && out_dev == nullptr)) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  KeyPackArgs a;
+  a.ncols = ncols;
+  int bits = 0;
+  for (int k = 0; k < ncols; ++k) {
+    if (types[k] != QSX_INT && types[k] != QSX_LONG) return QSX_ERR_UNSUPPORTED;
+    if (n > 0 && cols[k] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    a.cols[k] = cols[k];
+    a.is_long[k] = types[k] == QSX_LONG;
+    a.shift[k] = bits < 64 ? bits : 0;
+    bits += types[k] == QSX_LONG ? 64 : 32;
+  }
+  a.exact = bits <= 64;
+  *out_exact = a.exact;
+  if (n == 0) return QSX_OK;
+  hipLaunchKernelGGL(key_pack_kernel, dim3(grid_for(n, kJBlock * 4)), dim3(kJBlock), 0, as_stream(stream), a, n, out_dev);
+  QSX_CHECK_LAUNCH();
   return QSX_OK;
 }
 

@@ -36,9 +36,11 @@ __device__ __forceinline__ bool cmp_static(T a, T b) {
 }
 
 // R = bitmap words (64-row groups) a wave keeps in flight per iteration.
-template <typename T, int OP, int R>
+// COLS: the right operand is a second column (attribute OP attribute,
+// ComparisonPredicate.cpp:214-334 -> compareColumnVectors / compareValueAccessors) instead of the literal.
+template <typename T, int OP, int R, bool COLS>
 __global__ __launch_bounds__(kBlock) void select_cmp_kernel(
-    const T *__restrict__ col, int64_t n, T lit, const uint64_t *__restrict__ filter,
+    const T *__restrict__ col, const T *__restrict__ rhs, int64_t n, T lit, const uint64_t *__restrict__ filter,
     uint64_t *__restrict__ out, unsigned long long *__restrict__ out_count) {
   const int lane = lane_id();
   const int64_t num_words = (n + 63) >> 6;
@@ -47,17 +49,18 @@ __global__ __launch_bounds__(kBlock) void select_cmp_kernel(
   unsigned long long count = 0;
 
   for (int64_t w0 = wave * R; w0 < num_words; w0 += num_waves * R) {
-    T v[R];
+    T v[R], u[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((w0 + r) << 6) + lane;
       v[r] = row < n ? col[row] : T();
+      u[r] = COLS ? (row < n ? rhs[row] : T()) : lit;
     }
     uint64_t mine = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((w0 + r) << 6) + lane;
-      bool pred = row < n && cmp_static<T, OP>(v[r], lit);
+      bool pred = row < n && cmp_static<T, OP>(v[r], u[r]);
       if (filter != nullptr && w0 + r < num_words) {
         // short-circuit semantics (:344-356): only rows already selected can match.
         const uint64_t fw = filter[w0 + r];  // wave-uniform address: one scalar load
@@ -80,32 +83,41 @@ __global__ __launch_bounds__(kBlock) void select_cmp_kernel(
   }
 }
 
+// rhs_col == nullptr: compare with *literal; else with the second column.
 template <typename T, int OP>
-static int launch_select_cmp(const void *col, int64_t n, const void *literal, const uint64_t *filter,
+static int launch_select_cmp(const void *col, const void *rhs_col, int64_t n, const void *literal, const uint64_t *filter,
                              uint64_t *out, int64_t *out_count, hipStream_t stream) {
   constexpr int R = sizeof(T) == 4 ? 8 : 4;
-  T lit;
-  std::memcpy(&lit, literal, sizeof(T));
+  T lit = T();
+  if (literal != nullptr) std::memcpy(&lit, literal, sizeof(T));
   const int64_t num_words = (n + 63) >> 6;
-  const int grid = grid_for(num_words, kWavesPerBlock * R);
-  hipLaunchKernelGGL((select_cmp_kernel<T, OP, R>), dim3(grid), dim3(kBlock), 0, stream,
-                     static_cast<const T *>(col), n, lit, filter, out,
-                     reinterpret_cast<unsigned long long *>(out_count));
+  if (rhs_col == nullptr) {
+    const int grid = grid_for(num_words, kWavesPerBlock * R);
+    hipLaunchKernelGGL((select_cmp_kernel<T, OP, R, false>), dim3(grid), dim3(kBlock), 0, stream,
+                       static_cast<const T *>(col), static_cast<const T *>(nullptr), n, lit, filter, out,
+                       reinterpret_cast<unsigned long long *>(out_count));
+  } else {
+    constexpr int R2 = R / 2;  // two loads per row
+    const int grid = grid_for(num_words, kWavesPerBlock * R2);
+    hipLaunchKernelGGL((select_cmp_kernel<T, OP, R2, true>), dim3(grid), dim3(kBlock), 0, stream,
+                       static_cast<const T *>(col), static_cast<const T *>(rhs_col), n, lit, filter, out,
+                       reinterpret_cast<unsigned long long *>(out_count));
+  }
   QSX_CHECK_LAUNCH();
   return QSX_OK;
 }
 
 template <typename T>
-static int dispatch_select_op(int op, const void *col, int64_t n, const void *literal,
+static int dispatch_select_op(int op, const void *col, const void *rhs_col, int64_t n, const void *literal,
                               const uint64_t *filter, uint64_t *out, int64_t *out_count,
                               hipStream_t stream) {
   switch (op) {
-    case QSX_EQ: return launch_select_cmp<T, QSX_EQ>(col, n, literal, filter, out, out_count, stream);
-    case QSX_NE: return launch_select_cmp<T, QSX_NE>(col, n, literal, filter, out, out_count, stream);
-    case QSX_LT: return launch_select_cmp<T, QSX_LT>(col, n, literal, filter, out, out_count, stream);
-    case QSX_LE: return launch_select_cmp<T, QSX_LE>(col, n, literal, filter, out, out_count, stream);
-    case QSX_GT: return launch_select_cmp<T, QSX_GT>(col, n, literal, filter, out, out_count, stream);
-    case QSX_GE: return launch_select_cmp<T, QSX_GE>(col, n, literal, filter, out, out_count, stream);
+    case QSX_EQ: return launch_select_cmp<T, QSX_EQ>(col, rhs_col, n, literal, filter, out, out_count, stream);
+    case QSX_NE: return launch_select_cmp<T, QSX_NE>(col, rhs_col, n, literal, filter, out, out_count, stream);
+    case QSX_LT: return launch_select_cmp<T, QSX_LT>(col, rhs_col, n, literal, filter, out, out_count, stream);
+    case QSX_LE: return launch_select_cmp<T, QSX_LE>(col, rhs_col, n, literal, filter, out, out_count, stream);
+    case QSX_GT: return launch_select_cmp<T, QSX_GT>(col, rhs_col, n, literal, filter, out, out_count, stream);
+    case QSX_GE: return launch_select_cmp<T, QSX_GE>(col, rhs_col, n, literal, filter, out, out_count, stream);
     default: return QSX_ERR_INVALID_ARGUMENT;
   }
 }
@@ -293,6 +305,19 @@ static int run_compaction(const GatherArgs &args, const uint64_t *bitmap, int64_
   return QSX_OK;
 }
 
+// tuple-id list -> TupleIdSequence (bit = tid - base): one atomicOr per tid, skipped when the bit is already set
+__global__ __launch_bounds__(kBlock) void tids_to_bitmap_kernel(const int32_t *__restrict__ tids, int64_t n, int32_t base_tid,
+                                                               int64_t num_bits, unsigned long long *__restrict__ out) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t bit = static_cast<int64_t>(tids[i]) - base_tid;
+    if (bit < 0 || bit >= num_bits) continue;
+    const unsigned long long mask = 1ull << (63 - (bit & 63));
+    unsigned long long *word = &out[bit >> 6];
+    if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) == 0) atomicOr(word, mask);
+  }
+}
+
 }  // namespace qsx
 
 using namespace qsx;
@@ -310,12 +335,47 @@ int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op, const void 
   if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
   if (n == 0) return QSX_OK;
   switch (type) {
-    case QSX_INT: return dispatch_select_op<int32_t>(op, col_dev, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
-    case QSX_LONG: return dispatch_select_op<int64_t>(op, col_dev, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
-    case QSX_FLOAT: return dispatch_select_op<float>(op, col_dev, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
-    case QSX_DOUBLE: return dispatch_select_op<double>(op, col_dev, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_INT: return dispatch_select_op<int32_t>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_LONG: return dispatch_select_op<int64_t>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_FLOAT: return dispatch_select_op<float>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_DOUBLE: return dispatch_select_op<double>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
     default: return QSX_ERR_UNSUPPORTED;
   }
+}
+
+int qsx_select_cmp_columns(int type, const void *lhs_dev, const void *rhs_dev, int64_t n, int op,
+                           const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev,
+                           qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || (n > 0 && (lhs_dev == nullptr || rhs_dev == nullptr || out_bitmap_dev == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return QSX_OK;
+  switch (type) {
+    case QSX_INT: return dispatch_select_op<int32_t>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_LONG: return dispatch_select_op<int64_t>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_FLOAT: return dispatch_select_op<float>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_DOUBLE: return dispatch_select_op<double>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+}
+
+int qsx_tids_to_bitmap(const int32_t *tids_dev, int64_t n, int32_t base_tid, int64_t num_bits,
+                       uint64_t *out_bitmap_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || num_bits < 0 || (num_bits > 0 && out_bitmap_dev == nullptr) || (n > 0 && tids_dev == nullptr)) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (num_bits == 0) return QSX_OK;
+  hipStream_t s = as_stream(stream);
+  QSX_HIP_TRY(hipMemsetAsync(out_bitmap_dev, 0, static_cast<size_t>((num_bits + 63) >> 6) * 8, s));
+  if (n == 0) return QSX_OK;
+  hipLaunchKernelGGL(tids_to_bitmap_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, s, tids_dev, n, base_tid,
+                     num_bits, reinterpret_cast<unsigned long long *>(out_bitmap_dev));
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
 }
 
 int qsx_bitmap_combine(int op, const uint64_t *a_dev, const uint64_t *b_dev, int64_t n,

@@ -85,11 +85,36 @@ StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t capacit
       CheckStatus(qsx_device_alloc(bytes ? bytes : 8, &p), "qsx_device_alloc(stripe)");
     }
     stripes_.push_back(p);
+    void *nulls = nullptr;
+    if (relation.getAttributeType(static_cast<attribute_id>(a)).nullable) {
+      const std::size_t nbytes = static_cast<std::size_t>((capacity + 63) / 64) * 8 + 8;
+      if (g_host_memory) {
+        nulls = std::calloc(nbytes, 1);
+      } else {
+        CheckStatus(qsx_device_alloc(nbytes, &nulls), "qsx_device_alloc(null bitmap)");
+        CheckStatus(qsx_memset_device(nulls, 0, nbytes, CurrentStream()), "qsx_memset_device(null bitmap)");
+      }
+    }
+    null_bitmaps_.push_back(nulls);
   }
 }
 StorageBlock::~StorageBlock() {
   for (void *p : stripes_) {
     if (g_host_memory) std::free(p); else qsx_device_free(p);
+  }
+  for (void *p : null_bitmaps_) {
+    if (p == nullptr) continue;
+    if (g_host_memory) std::free(p); else qsx_device_free(p);
+  }
+}
+void StorageBlock::copyNullBitmapToHost(attribute_id a, std::uint64_t *dst) const {
+  const std::size_t bytes = static_cast<std::size_t>((num_tuples_ + 63) / 64) * 8;
+  if (null_bitmaps_.at(a) == nullptr) {
+    std::memset(dst, 0, bytes);
+  } else if (g_host_memory) {
+    std::memcpy(dst, null_bitmaps_.at(a), bytes);
+  } else {
+    CheckStatus(qsx_copy_to_host(dst, null_bitmaps_.at(a), bytes, CurrentStream()), "qsx_copy_to_host(null bitmap)");
   }
 }
 void StorageBlock::copyAttributeToHost(attribute_id a, void *dst) const {
@@ -481,8 +506,8 @@ BuildHashOperator::BuildHashOperator(std::size_t query_id, const CatalogRelation
     : RelationalOperator(query_id, num_partitions), input_relation_(input_relation),
       input_relation_is_stored_(input_relation_is_stored), join_key_attributes_(join_key_attributes),
       hash_table_index_(hash_table_index), build_predicate_index_(build_predicate_index) {
-  if (join_key_attributes.size() != 1) {
-    throw ExecutionError("BuildHashOperator: only single-attribute INT/LONG keys are on the GPU path", QSX_ERR_UNSUPPORTED);
+  if (join_key_attributes.empty() || join_key_attributes.size() > QSX_MAX_KEYS) {
+    throw ExecutionError("BuildHashOperator: 1 to 4 INT/LONG join key attributes are on the GPU path", QSX_ERR_UNSUPPORTED);
   }
   if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
 }
@@ -492,8 +517,12 @@ bool BuildHashOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCo
   const Predicate *predicate = query_context->getPredicate(build_predicate_index_);
   qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, 0);
   std::lock_guard<std::mutex> lock(mutex_);
+  if (!started_) {
+    query_context->setJoinHashTableBuildKeyAttributes(hash_table_index_, join_key_attributes_);
+    started_ = true;
+  }
   while (num_workorders_generated_ < input_relation_block_ids_.size()) {
-    container->addNormalWorkOrder(new BuildHashWorkOrder(query_id_, input_relation_, join_key_attributes_.front(),
+    container->addNormalWorkOrder(new BuildHashWorkOrder(query_id_, input_relation_, join_key_attributes_,
                                                          input_relation_block_ids_[num_workorders_generated_], predicate,
                                                          table, storage_manager),
                                   op_index_);
@@ -502,6 +531,37 @@ bool BuildHashOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCo
   return input_relation_is_stored_ || done_feeding_input_relation_;
 }
 
+namespace {
+// The single key column the join table sees for one block: the attribute's stripe, or — for a
+// composite key — the LONG fold of the components (qsx_join_key_pack; the QueryContext creates
+// the table of a composite key with key type kLong).  `exact` is false when the fold is the
+// reference's composite hash and joined pairs still need their components compared.
+struct JoinKeys {
+  const void *ptr = nullptr;
+  bool exact = true;
+  std::unique_ptr<DeviceBuffer> packed;
+  JoinKeys(const StorageBlock &block, const std::vector<attribute_id> &attrs) {
+    if (attrs.size() == 1) {
+      ptr = block.stripe(attrs.front());
+      return;
+    }
+    std::vector<const void *> cols;
+    std::vector<std::int32_t> types;
+    for (attribute_id a : attrs) {
+      cols.push_back(block.stripe(a));
+      types.push_back(block.getRelation().getAttributeType(a).id);
+    }
+    packed.reset(new DeviceBuffer(static_cast<std::size_t>(block.numTuples()) * 8 + 8));
+    int is_exact = 0;
+    CheckStatus(qsx_join_key_pack(static_cast<int>(cols.size()), cols.data(), types.data(), block.numTuples(),
+                                  static_cast<std::int64_t *>(packed->ptr), &is_exact, CurrentStream()),
+                "qsx_join_key_pack");
+    ptr = packed->ptr;
+    exact = is_exact != 0;
+  }
+};
+}  // namespace
+
 void BuildHashWorkOrder::execute() {
   BlockReference block = storage_manager_->getBlock(build_block_id_);
   void *bitmap = nullptr;
@@ -509,9 +569,10 @@ void BuildHashWorkOrder::execute() {
     std::int64_t matches = 0;
     bitmap = predicate_->getMatchesForBlock(*block, &matches);
   }
-  // hash_table_->putValueAccessor(accessor, key_attr, nullable, &TupleReferenceGenerator) (:192-203);
+  // hash_table_->putValueAccessor[CompositeKey](accessor, key_attr(s), nullable, &TupleReferenceGenerator) (:192-203);
   // the stored reference is the relation-global row number of the tuple.
-  CheckStatus(qsx_join_build(hash_table_, block->stripe(join_key_attribute_), block->numTuples(),
+  JoinKeys keys(*block, join_key_attributes_);
+  CheckStatus(qsx_join_build(hash_table_, keys.ptr, block->numTuples(),
                              static_cast<std::int32_t>(block->firstRow()), static_cast<const std::uint64_t *>(bitmap),
                              CurrentStream()), "qsx_join_build");
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
@@ -526,16 +587,21 @@ HashJoinOperator::HashJoinOperator(std::size_t query_id, const CatalogRelation &
                                    const std::vector<attribute_id> &join_key_attributes, bool, std::size_t num_partitions,
                                    bool has_repartition, const CatalogRelation &output_relation,
                                    QueryContext::insert_destination_id output_destination_index,
-                                   QueryContext::join_hash_table_id hash_table_index, QueryContext::predicate_id,
+                                   QueryContext::join_hash_table_id hash_table_index,
+                                   QueryContext::predicate_id residual_predicate_index,
                                    QueryContext::scalar_group_id selection_index,
                                    const std::vector<bool> *is_selection_on_build, JoinType join_type)
     : RelationalOperator(query_id, num_partitions, has_repartition), build_relation_(build_relation),
       probe_relation_(probe_relation), probe_relation_is_stored_(probe_relation_is_stored),
       join_key_attributes_(join_key_attributes), output_relation_(output_relation),
       output_destination_index_(output_destination_index), hash_table_index_(hash_table_index),
-      selection_index_(selection_index), join_type_(join_type) {
-  if (join_key_attributes.size() != 1) {
-    throw ExecutionError("HashJoinOperator: only single-attribute INT/LONG keys are on the GPU path", QSX_ERR_UNSUPPORTED);
+      residual_predicate_index_(residual_predicate_index), selection_index_(selection_index), join_type_(join_type) {
+  if (join_key_attributes.empty() || join_key_attributes.size() > QSX_MAX_KEYS) {
+    throw ExecutionError("HashJoinOperator: 1 to 4 INT/LONG join key attributes are on the GPU path", QSX_ERR_UNSUPPORTED);
+  }
+  if (join_type == JoinType::kLeftOuterJoin && residual_predicate_index != QueryContext::kInvalidPredicateId) {
+    // as in the reference: HashOuterJoinWorkOrder takes no residual predicate (HashJoinOperator.hpp:571-640)
+    throw ExecutionError("HashJoinOperator: outer joins take no residual predicate", QSX_ERR_UNSUPPORTED);
   }
   if (is_selection_on_build != nullptr) is_selection_on_build_ = *is_selection_on_build;
   if (probe_relation_is_stored) probe_relation_block_ids_ = probe_relation.getBlocksSnapshot();
@@ -548,10 +614,19 @@ bool HashJoinOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCon
   qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, 0);
   InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
   std::lock_guard<std::mutex> lock(mutex_);
+  if (!started_) {
+    // the build operator is a blocking dependency: it has published its key attributes by now
+    build_key_attributes_ = query_context->getJoinHashTableBuildKeyAttributes(hash_table_index_);
+    if (build_key_attributes_.size() != join_key_attributes_.size()) {
+      throw ExecutionError("HashJoinOperator: build and probe sides have different numbers of key attributes", QSX_ERR_INVALID_ARGUMENT);
+    }
+    started_ = true;
+  }
   while (num_workorders_generated_ < probe_relation_block_ids_.size()) {
     container->addNormalWorkOrder(
-        new HashInnerJoinWorkOrder(query_id_, build_relation_, probe_relation_, join_key_attributes_.front(),
-                                   probe_relation_block_ids_[num_workorders_generated_], selection, is_selection_on_build_,
+        new HashInnerJoinWorkOrder(query_id_, build_relation_, probe_relation_, join_key_attributes_, build_key_attributes_,
+                                   probe_relation_block_ids_[num_workorders_generated_],
+                                   query_context->getPredicate(residual_predicate_index_), selection, is_selection_on_build_,
                                    join_type_, table, dest, storage_manager),
         op_index_);
     ++num_workorders_generated_;
@@ -559,19 +634,145 @@ bool HashJoinOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCon
   return probe_relation_is_stored_ || done_feeding_input_relation_;
 }
 
+namespace {
+// The build relation as gather segments (one per build block; the reference loops over build
+// blocks instead, HashJoinOperator.cpp:494-540).
+struct BuildSegments {
+  std::vector<BlockReference> refs;
+  std::vector<std::int64_t> first_rows;
+  BuildSegments(const CatalogRelation &build_relation, StorageManager *storage_manager) {
+    for (block_id b : build_relation.getBlocksSnapshot()) refs.push_back(storage_manager->getBlock(b));
+    std::sort(refs.begin(), refs.end(),
+              [](const BlockReference &a, const BlockReference &b) { return a->firstRow() < b->firstRow(); });
+    for (const BlockReference &b : refs) first_rows.push_back(b->firstRow());
+  }
+  void gather(attribute_id attr, int width, const void *build_tids, std::int64_t n, void *dst) const {
+    std::vector<const void *> segs;
+    for (const BlockReference &b : refs) segs.push_back(b->stripe(attr));
+    CheckStatus(qsx_gather_segmented(width, static_cast<int>(segs.size()), segs.data(), first_rows.data(),
+                                     static_cast<const std::int32_t *>(build_tids), n, dst, CurrentStream()),
+                "qsx_gather_segmented");
+  }
+};
+
+// Joined pairs of one probe block, on device.
+struct JoinedPairs {
+  std::unique_ptr<DeviceBuffer> probe_tids, build_tids;
+  std::int64_t count = 0;
+};
+
+// Keep the pairs set in `bitmap` (order preserving).
+void CompactPairs(JoinedPairs *pairs, const void *bitmap) {
+  const std::int64_t n = pairs->count;
+  std::unique_ptr<DeviceBuffer> p(new DeviceBuffer(static_cast<std::size_t>(n) * 4 + 8)), b(new DeviceBuffer(static_cast<std::size_t>(n) * 4 + 8));
+  const void *src[2] = {pairs->probe_tids->ptr, pairs->build_tids->ptr};
+  void *dst[2] = {p->ptr, b->ptr};
+  const std::int32_t widths[2] = {4, 4};
+  const std::size_t ws_bytes = qsx_compact_workspace_bytes(n);
+  DeviceBuffer ws(ws_bytes), count(8);
+  CheckStatus(qsx_compact_gather(2, src, widths, static_cast<const std::uint64_t *>(bitmap), n, dst,
+                                 static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
+              "qsx_compact_gather(pairs)");
+  pairs->count = ReadCount(count.ptr);
+  pairs->probe_tids = std::move(p);
+  pairs->build_tids = std::move(b);
+}
+}  // namespace
+
 void HashInnerJoinWorkOrder::execute() {
+  using JoinType = HashJoinOperator::JoinType;
   BlockReference probe = storage_manager_->getBlock(block_id_);
   const std::int64_t n = probe->numTuples();
-  const void *keys = probe->stripe(join_key_attribute_);
+  JoinKeys keys(*probe, join_key_attributes_);
   DeviceBuffer count(8);
-  if (join_type_ != HashJoinOperator::JoinType::kInnerJoin) {
-    // HashSemiJoinWorkOrder / HashAntiJoinWorkOrder without residual predicate (:795-816, :860-877):
-    // existence bitmap over the probe block, then project the probe attributes.
-    DeviceBuffer bitmap(static_cast<std::size_t>((n + 63) / 64) * 8 + 8);
-    CheckStatus(qsx_join_probe_exists(hash_table_, keys, n, nullptr,
-                                      join_type_ == HashJoinOperator::JoinType::kLeftAntiJoin ? 1 : 0,
-                                      static_cast<std::uint64_t *>(bitmap.ptr), static_cast<std::int64_t *>(count.ptr),
-                                      CurrentStream()), "qsx_join_probe_exists");
+  const std::size_t bitmap_bytes = static_cast<std::size_t>((n + 63) / 64) * 8 + 8;
+  const bool pairs_needed = join_type_ == JoinType::kInnerJoin || join_type_ == JoinType::kLeftOuterJoin ||
+                            residual_predicate_ != nullptr || !keys.exact;
+
+  JoinedPairs pairs;
+  std::unique_ptr<BuildSegments> build;
+  if (pairs_needed) {
+    // hash_table_.getAllFromValueAccessor[CompositeKey](accessor, key(s), nullable, &collector) (:480-485)
+    CheckStatus(qsx_join_probe_count(hash_table_, keys.ptr, n, nullptr, static_cast<std::int64_t *>(count.ptr), CurrentStream()),
+                "qsx_join_probe_count");
+    pairs.count = ReadCount(count.ptr);
+    pairs.probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
+    pairs.build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
+    CheckStatus(qsx_join_probe(hash_table_, keys.ptr, n, /*probe_base_tid=*/0, nullptr,
+                               static_cast<std::int32_t *>(pairs.probe_tids->ptr), static_cast<std::int32_t *>(pairs.build_tids->ptr),
+                               pairs.count, static_cast<std::int64_t *>(count.ptr), CurrentStream()), "qsx_join_probe");
+    build.reset(new BuildSegments(build_relation_, storage_manager_));
+
+    // Terms evaluated on the pairs: the component equalities of a hashed composite key
+    // (compositeKeyCollisionCheck, SeparateChainingHashTable.hpp:1046) and the residual predicate
+    // (matchesForJoinedTuples, :510-524), chained through the filter bitmap like a conjunction.
+    std::vector<ComparisonPredicate> terms;
+    if (!keys.exact) {
+      for (std::size_t k = 0; k < join_key_attributes_.size(); ++k) {
+        terms.push_back(ComparisonPredicate::Attributes(join_key_attributes_[k], false, ComparisonID::kEqual,
+                                                        build_key_attributes_[k], true));
+      }
+    }
+    if (residual_predicate_ != nullptr) {
+      terms.insert(terms.end(), residual_predicate_->conjuncts.begin(), residual_predicate_->conjuncts.end());
+    }
+    if (!terms.empty() && pairs.count > 0) {
+      const std::int64_t m = pairs.count;
+      const std::size_t pair_bitmap_bytes = static_cast<std::size_t>((m + 63) / 64) * 8 + 8;
+      DeviceBuffer current(pair_bitmap_bytes), next(pair_bitmap_bytes), lhs(static_cast<std::size_t>(m) * 8 + 8),
+          rhs(static_cast<std::size_t>(m) * 8 + 8);
+      void *cur = current.ptr, *nxt = next.ptr;
+      bool first = true;
+      auto gather_side = [&](attribute_id attr, bool on_build, void *dst) -> Type {
+        const Type t = (on_build ? build_relation_ : probe_relation_).getAttributeType(attr);
+        if (on_build) {
+          build->gather(attr, t.width, pairs.build_tids->ptr, m, dst);
+        } else {
+          CheckStatus(qsx_gather(t.width, probe->stripe(attr), static_cast<const std::int32_t *>(pairs.probe_tids->ptr), m, dst,
+                                 CurrentStream()), "qsx_gather");
+        }
+        return t;
+      };
+      for (const ComparisonPredicate &term : terms) {
+        const Type t = gather_side(term.attribute, term.on_build_side, lhs.ptr);
+        if (term.rhs_attribute != kInvalidAttributeID) {
+          const Type rt = gather_side(term.rhs_attribute, term.rhs_on_build_side, rhs.ptr);
+          if (rt.id != t.id) throw ExecutionError("join predicate compares attributes of different types", QSX_ERR_UNSUPPORTED);
+          CheckStatus(qsx_select_cmp_columns(t.id, lhs.ptr, rhs.ptr, m, static_cast<int>(term.comparison),
+                                             first ? nullptr : static_cast<const std::uint64_t *>(cur),
+                                             static_cast<std::uint64_t *>(nxt), nullptr, CurrentStream()),
+                      "qsx_select_cmp_columns");
+        } else {
+          CheckStatus(qsx_select_cmp(t.id, lhs.ptr, m, static_cast<int>(term.comparison), &term.literal.v,
+                                     first ? nullptr : static_cast<const std::uint64_t *>(cur),
+                                     static_cast<std::uint64_t *>(nxt), nullptr, CurrentStream()), "qsx_select_cmp");
+        }
+        std::swap(cur, nxt);
+        first = false;
+      }
+      CompactPairs(&pairs, cur);
+    }
+  }
+
+  if (join_type_ == JoinType::kLeftSemiJoin || join_type_ == JoinType::kLeftAntiJoin) {
+    // HashSemiJoinWorkOrder / HashAntiJoinWorkOrder (:680-877, :880-1000): the probe tuples with
+    // (semi) / without (anti) a surviving match, projected on the probe attributes.
+    const bool anti = join_type_ == JoinType::kLeftAntiJoin;
+    DeviceBuffer bitmap(bitmap_bytes);
+    if (pairs_needed) {
+      CheckStatus(qsx_tids_to_bitmap(static_cast<const std::int32_t *>(pairs.probe_tids->ptr), pairs.count, 0, n,
+                                     static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_tids_to_bitmap");
+      if (anti) {
+        CheckStatus(qsx_bitmap_combine(3, static_cast<const std::uint64_t *>(bitmap.ptr), nullptr, n,
+                                       static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_bitmap_combine");
+      }
+      CheckStatus(qsx_bitmap_count(static_cast<const std::uint64_t *>(bitmap.ptr), n, static_cast<std::int64_t *>(count.ptr),
+                                   CurrentStream()), "qsx_bitmap_count");
+    } else {
+      CheckStatus(qsx_join_probe_exists(hash_table_, keys.ptr, n, nullptr, anti ? 1 : 0,
+                                        static_cast<std::uint64_t *>(bitmap.ptr), static_cast<std::int64_t *>(count.ptr),
+                                        CurrentStream()), "qsx_join_probe_exists");
+    }
     const std::int64_t matches = ReadCount(count.ptr);
     block_id out_id;
     BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
@@ -592,41 +793,60 @@ void HashInnerJoinWorkOrder::execute() {
     output_destination_->returnBlock(out_id, ReadCount(count.ptr));
     return;
   }
-  // hash_table_.getAllFromValueAccessor(accessor, key, nullable, &collector) (:480-485)
-  CheckStatus(qsx_join_probe_count(hash_table_, keys, n, nullptr, static_cast<std::int64_t *>(count.ptr), CurrentStream()),
-              "qsx_join_probe_count");
-  const std::int64_t matches = ReadCount(count.ptr);
-  DeviceBuffer probe_tids(static_cast<std::size_t>(matches) * 4 + 8), build_tids(static_cast<std::size_t>(matches) * 4 + 8);
-  CheckStatus(qsx_join_probe(hash_table_, keys, n, /*probe_base_tid=*/0, nullptr, static_cast<std::int32_t *>(probe_tids.ptr),
-                             static_cast<std::int32_t *>(build_tids.ptr), matches, static_cast<std::int64_t *>(count.ptr),
-                             CurrentStream()), "qsx_join_probe");
+
+  // Inner / left outer: matched pairs first, then (outer) the probe tuples without a match with
+  // NULL build-side attributes (HashOuterJoinWorkOrder, :1026-1099).
+  const std::int64_t matches = pairs.count;
+  std::int64_t unmatched = 0;
+  std::unique_ptr<DeviceBuffer> unmatched_tids;
+  if (join_type_ == JoinType::kLeftOuterJoin) {
+    DeviceBuffer bitmap(bitmap_bytes);
+    CheckStatus(qsx_tids_to_bitmap(static_cast<const std::int32_t *>(pairs.probe_tids->ptr), matches, 0, n,
+                                   static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_tids_to_bitmap");
+    CheckStatus(qsx_bitmap_combine(3, static_cast<const std::uint64_t *>(bitmap.ptr), nullptr, n,
+                                   static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_bitmap_combine");
+    unmatched_tids.reset(new DeviceBuffer(static_cast<std::size_t>(n) * 4 + 8));
+    const std::size_t ws_bytes = qsx_compact_workspace_bytes(n);
+    DeviceBuffer ws(ws_bytes);
+    CheckStatus(qsx_bitmap_to_tids(static_cast<const std::uint64_t *>(bitmap.ptr), n, 0, static_cast<std::int32_t *>(unmatched_tids->ptr),
+                                   static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()), "qsx_bitmap_to_tids");
+    unmatched = ReadCount(count.ptr);
+  }
+  const std::int64_t total = matches + unmatched;
   block_id out_id;
-  BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
-  // the build relation as gather segments (one per build block; :494-540 loops over build blocks instead)
-  std::vector<block_id> build_blocks = build_relation_.getBlocksSnapshot();
-  std::vector<BlockReference> build_refs;
-  for (block_id b : build_blocks) build_refs.push_back(storage_manager_->getBlock(b));
-  std::sort(build_refs.begin(), build_refs.end(),
-            [](const BlockReference &a, const BlockReference &b) { return a->firstRow() < b->firstRow(); });
-  std::vector<std::int64_t> first_rows;
-  for (const BlockReference &b : build_refs) first_rows.push_back(b->firstRow());
+  BlockReference out = output_destination_->getBlockForInsertion(total > 0 ? total : 1, &out_id);
   for (std::size_t i = 0; i < selection_.size(); ++i) {
     // Scalar::getAllValuesForJoin (:529-536)
-    void *dst = out->stripe(static_cast<attribute_id>(i));
-    if (is_selection_on_build_[i]) {
-      std::vector<const void *> segs;
-      for (const BlockReference &b : build_refs) segs.push_back(b->stripe(selection_[i]));
-      CheckStatus(qsx_gather_segmented(build_relation_.getAttributeType(selection_[i]).width, static_cast<int>(segs.size()),
-                                       segs.data(), first_rows.data(), static_cast<const std::int32_t *>(build_tids.ptr),
-                                       matches, dst, CurrentStream()), "qsx_gather_segmented");
+    char *dst = static_cast<char *>(out->stripe(static_cast<attribute_id>(i)));
+    const bool on_build = is_selection_on_build_[i];
+    const int width = (on_build ? build_relation_ : probe_relation_).getAttributeType(selection_[i]).width;
+    if (on_build) {
+      build->gather(selection_[i], width, pairs.build_tids->ptr, matches, dst);
     } else {
-      CheckStatus(qsx_gather(probe_relation_.getAttributeType(selection_[i]).width, probe->stripe(selection_[i]),
-                             static_cast<const std::int32_t *>(probe_tids.ptr), matches, dst, CurrentStream()),
-                  "qsx_gather");
+      CheckStatus(qsx_gather(width, probe->stripe(selection_[i]), static_cast<const std::int32_t *>(pairs.probe_tids->ptr), matches,
+                             dst, CurrentStream()), "qsx_gather");
+    }
+    if (unmatched > 0) {
+      char *tail = dst + static_cast<std::size_t>(matches) * width;
+      if (on_build) {
+        // result->fillWithNulls() (:1077-1080): zero bytes + the null bits of rows [matches, total)
+        CheckStatus(qsx_memset_device(tail, 0, static_cast<std::size_t>(unmatched) * width, CurrentStream()), "qsx_memset_device");
+        std::uint64_t *nulls = out->nullBitmap(static_cast<attribute_id>(i));
+        if (nulls == nullptr) {
+          throw ExecutionError("outer join output attribute taken from the build side must be nullable", QSX_ERR_INVALID_ARGUMENT);
+        }
+        std::vector<std::uint64_t> words(static_cast<std::size_t>((total + 63) / 64), 0);
+        for (std::int64_t r = matches; r < total; ++r) words[r >> 6] |= 1ull << (63 - (r & 63));
+        CheckStatus(qsx_copy_to_device(nulls, words.data(), words.size() * 8, CurrentStream()), "qsx_copy_to_device(null bitmap)");
+        CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");  // `words` is a local
+      } else {
+        CheckStatus(qsx_gather(width, probe->stripe(selection_[i]), static_cast<const std::int32_t *>(unmatched_tids->ptr), unmatched,
+                               tail, CurrentStream()), "qsx_gather");
+      }
     }
   }
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
-  output_destination_->returnBlock(out_id, matches);  // output_destination_->bulkInsertTuples(&temp_result) (:539)
+  output_destination_->returnBlock(out_id, total);  // output_destination_->bulkInsertTuples(&temp_result) (:539)
 }
 
 namespace {

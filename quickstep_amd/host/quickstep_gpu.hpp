@@ -62,11 +62,13 @@ enum class AggregationID { kCount, kSum, kAvg };
 struct Type {
   TypeID id;
   int width;  // bytes
+  bool nullable = false;  // blocks keep a null bitmap for the attribute (BasicColumnStoreTupleStorageSubBlock.cpp:131-147)
   static Type Int() { return {kInt, 4}; }
   static Type Long() { return {kLong, 8}; }
   static Type Float() { return {kFloat, 4}; }
   static Type Double() { return {kDouble, 8}; }
   static Type Char(int n) { return {kChar, n}; }
+  Type getNullableVersion() const { Type t = *this; t.nullable = true; return t; }
 };
 
 // Error raised when the C ABI reports a failure: the reference aborts with
@@ -127,6 +129,11 @@ class StorageBlock {
   void setFirstRow(std::int64_t r) { first_row_ = r; }
   void *stripe(attribute_id a) const { return stripes_.at(a); }
   void copyAttributeToHost(attribute_id a, void *dst) const;
+  // Null bitmap of a nullable attribute (TupleIdSequence bit order, 1 = NULL; zeroed at creation),
+  // nullptr for non-nullable attributes.
+  std::uint64_t *nullBitmap(attribute_id a) const { return static_cast<std::uint64_t *>(null_bitmaps_.at(a)); }
+  // dst: (numTuples() + 63) / 64 words; all zero for a non-nullable attribute.
+  void copyNullBitmapToHost(attribute_id a, std::uint64_t *dst) const;
 
  private:
   const CatalogRelation &relation_;
@@ -134,6 +141,7 @@ class StorageBlock {
   std::int64_t num_tuples_;
   std::int64_t first_row_;
   std::vector<void *> stripes_;
+  std::vector<void *> null_bitmaps_;
 };
 typedef std::shared_ptr<StorageBlock> BlockReference;
 
@@ -169,11 +177,25 @@ struct TypedLiteral {
 };
 
 // ComparisonPredicate attr OP literal (expressions/predicate/ComparisonPredicate.cpp:115-334);
-// a Predicate is a conjunction of those.
+// a Predicate is a conjunction of those.  As the residual predicate of a join
+// (HashJoinOperator.cpp:510-524, Predicate::matchesForJoinedTuples) a term also says which side each
+// attribute comes from (Scalar::kLeftSide = probe, kRightSide = build) and may compare two attributes.
 struct ComparisonPredicate {
   attribute_id attribute;
   ComparisonID comparison;
   TypedLiteral literal;
+  bool on_build_side = false;                          // join residuals only: `attribute` is of the build relation
+  attribute_id rhs_attribute = kInvalidAttributeID;    // != invalid: attribute OP rhs_attribute (literal unused)
+  bool rhs_on_build_side = false;
+  ComparisonPredicate() = default;
+  ComparisonPredicate(attribute_id a, ComparisonID c, TypedLiteral l, bool build_side = false)
+      : attribute(a), comparison(c), literal(l), on_build_side(build_side) {}
+  static ComparisonPredicate Attributes(attribute_id lhs, bool lhs_on_build, ComparisonID c, attribute_id rhs, bool rhs_on_build) {
+    ComparisonPredicate p(lhs, c, TypedLiteral::Long(0), lhs_on_build);
+    p.rhs_attribute = rhs;
+    p.rhs_on_build_side = rhs_on_build;
+    return p;
+  }
 };
 struct Predicate {
   std::vector<ComparisonPredicate> conjuncts;
@@ -263,6 +285,16 @@ class QueryContext {
   const std::vector<attribute_id> &getScalarGroup(scalar_group_id id) const { return scalar_groups_.at(id); }
   qsx_join_table_t *getJoinHashTable(join_hash_table_id id, partition_id part = 0) const { return join_tables_.at(id).at(part); }
   void destroyJoinHashTable(join_hash_table_id id, partition_id part = 0);
+  // The build operator records which build attributes form the key (the reference keeps the key
+  // values inside the table's buckets; here a hashed composite key is verified against the build
+  // relation's columns, so the probe side has to know them).
+  void setJoinHashTableBuildKeyAttributes(join_hash_table_id id, const std::vector<attribute_id> &attrs) {
+    if (join_table_build_keys_.size() <= id) join_table_build_keys_.resize(id + 1);
+    join_table_build_keys_[id] = attrs;
+  }
+  const std::vector<attribute_id> &getJoinHashTableBuildKeyAttributes(join_hash_table_id id) const {
+    return join_table_build_keys_.at(id);
+  }
   AggregationOperationState *getAggregationState(aggregation_state_id id, partition_id part = 0) const {
     return agg_states_.at(id).at(part).get();
   }
@@ -273,6 +305,7 @@ class QueryContext {
   std::vector<Predicate> predicates_;
   std::vector<std::vector<attribute_id>> scalar_groups_;
   std::vector<std::vector<qsx_join_table_t *>> join_tables_;
+  std::vector<std::vector<attribute_id>> join_table_build_keys_;
   std::vector<std::vector<std::unique_ptr<AggregationOperationState>>> agg_states_;
   std::vector<std::unique_ptr<InsertDestination>> destinations_;
 };
@@ -431,17 +464,17 @@ class BuildHashOperator : public RelationalOperator {
 
 class BuildHashWorkOrder : public WorkOrder {
  public:
-  BuildHashWorkOrder(std::size_t query_id, const CatalogRelation &input_relation, attribute_id join_key_attribute,
-                     block_id build_block_id, const Predicate *predicate, qsx_join_table_t *hash_table,
-                     StorageManager *storage_manager)
-      : WorkOrder(query_id), input_relation_(input_relation), join_key_attribute_(join_key_attribute),
+  BuildHashWorkOrder(std::size_t query_id, const CatalogRelation &input_relation,
+                     const std::vector<attribute_id> &join_key_attributes, block_id build_block_id,
+                     const Predicate *predicate, qsx_join_table_t *hash_table, StorageManager *storage_manager)
+      : WorkOrder(query_id), input_relation_(input_relation), join_key_attributes_(join_key_attributes),
         build_block_id_(build_block_id), predicate_(predicate), hash_table_(hash_table),
         storage_manager_(storage_manager) {}
   void execute() override;  // BuildHashOperator.cpp:162-207
 
  private:
   const CatalogRelation &input_relation_;
-  const attribute_id join_key_attribute_;
+  const std::vector<attribute_id> &join_key_attributes_;
   const block_id build_block_id_;
   const Predicate *predicate_;
   qsx_join_table_t *hash_table_;
@@ -453,7 +486,7 @@ class BuildHashWorkOrder : public WorkOrder {
 // ---------------------------------------------------------------------------
 class HashJoinOperator : public RelationalOperator {
  public:
-  enum class JoinType { kInnerJoin = 0, kLeftSemiJoin, kLeftAntiJoin };
+  enum class JoinType { kInnerJoin = 0, kLeftSemiJoin, kLeftAntiJoin, kLeftOuterJoin };
   // selection + is_selection_on_build: output attribute i is attribute selection[i] of the build
   // relation when is_selection_on_build[i], else of the probe relation.
   HashJoinOperator(std::size_t query_id, const CatalogRelation &build_relation, const CatalogRelation &probe_relation,
@@ -482,8 +515,10 @@ class HashJoinOperator : public RelationalOperator {
   const CatalogRelation &output_relation_;
   const QueryContext::insert_destination_id output_destination_index_;
   const QueryContext::join_hash_table_id hash_table_index_;
+  const QueryContext::predicate_id residual_predicate_index_;
   const QueryContext::scalar_group_id selection_index_;
   std::vector<bool> is_selection_on_build_;
+  std::vector<attribute_id> build_key_attributes_;
   const JoinType join_type_;
   std::mutex mutex_;
   std::vector<block_id> probe_relation_block_ids_;
@@ -491,24 +526,31 @@ class HashJoinOperator : public RelationalOperator {
   bool started_ = false;
 };
 
+// One work order class for the four join types (the reference has HashInnerJoinWorkOrder,
+// HashSemiJoinWorkOrder, HashAntiJoinWorkOrder, HashOuterJoinWorkOrder; HashJoinOperator.cpp:450-1099).
 class HashInnerJoinWorkOrder : public WorkOrder {
  public:
   HashInnerJoinWorkOrder(std::size_t query_id, const CatalogRelation &build_relation,
-                         const CatalogRelation &probe_relation, attribute_id join_key_attribute, block_id lookup_block_id,
+                         const CatalogRelation &probe_relation, const std::vector<attribute_id> &join_key_attributes,
+                         const std::vector<attribute_id> &build_key_attributes,
+                         block_id lookup_block_id, const Predicate *residual_predicate,
                          const std::vector<attribute_id> &selection, const std::vector<bool> &is_selection_on_build,
                          HashJoinOperator::JoinType join_type, qsx_join_table_t *hash_table,
                          InsertDestination *output_destination, StorageManager *storage_manager)
       : WorkOrder(query_id), build_relation_(build_relation), probe_relation_(probe_relation),
-        join_key_attribute_(join_key_attribute), block_id_(lookup_block_id), selection_(selection),
-        is_selection_on_build_(is_selection_on_build), join_type_(join_type), hash_table_(hash_table),
-        output_destination_(output_destination), storage_manager_(storage_manager) {}
-  void execute() override;  // HashJoinOperator.cpp:450-541 (inner), :795-877 (semi / anti)
+        join_key_attributes_(join_key_attributes), build_key_attributes_(build_key_attributes),
+        block_id_(lookup_block_id), residual_predicate_(residual_predicate),
+        selection_(selection), is_selection_on_build_(is_selection_on_build), join_type_(join_type),
+        hash_table_(hash_table), output_destination_(output_destination), storage_manager_(storage_manager) {}
+  void execute() override;  // HashJoinOperator.cpp:450-541 (inner), :680-877 (semi / anti), :960-1099 (outer)
 
  private:
   const CatalogRelation &build_relation_;
   const CatalogRelation &probe_relation_;
-  const attribute_id join_key_attribute_;
+  const std::vector<attribute_id> &join_key_attributes_;
+  const std::vector<attribute_id> &build_key_attributes_;
   const block_id block_id_;
+  const Predicate *residual_predicate_;
   const std::vector<attribute_id> &selection_;
   const std::vector<bool> &is_selection_on_build_;
   const HashJoinOperator::JoinType join_type_;

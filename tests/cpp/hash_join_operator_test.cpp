@@ -1,6 +1,7 @@
 // Mirrors relational_operators/tests/HashJoinOperator_unittest.cpp: dim (200 rows) / fact (300 rows)
 // tables in 10-tuple blocks (:196-270), LongKeyHashJoinTest (:379-514), IntDuplicateKeyHashJoinTest
-// (:516-690), plus semi/anti variants and a Foreman/Worker run of the same plan.  GPU work orders.
+// (:516-690), CompositeKeyHashJoinTest (:999-1177), CompositeKeyHashJoinWithResidualPredicateTest (:1187-1375),
+// plus semi/anti/outer variants and a Foreman/Worker run of the same plans.  GPU work orders.
 #include <algorithm>
 #include <map>
 
@@ -20,19 +21,27 @@ struct Fixture {
     for (CatalogRelation *r : {&dim, &fact}) {
       r->addAttribute("long", Type::Long());
       r->addAttribute("int", Type::Int());
+      // the VARCHAR column of the reference (digits of tid/2*2 resp. tid) carried as integers,
+      // once LONG (composite key wider than 8 bytes: hashed fold) and once INT next to an INT copy
+      // of tid (8 bytes: exact packing)
+      r->addAttribute("varchar_as_long", Type::Long());
+      r->addAttribute("varchar_as_int", Type::Int());
+      r->addAttribute("tid_int", Type::Int());
     }
-    // dim: long = tid, int = tid % kBlockSize ; fact: long = tid, int = tid   (:196-270)
+    // dim: long = tid, int = tid % kBlockSize, varchar = tid / 2 * 2 ; fact: long = int = varchar = tid   (:196-270)
     for (tuple_id i = 0; i < kNumDimTuples; i += kBlockSize) {
-      std::int64_t l[kBlockSize];
-      std::int32_t v[kBlockSize];
-      for (tuple_id t = 0; t < kBlockSize; ++t) { l[t] = i + t; v[t] = (i + t) % kBlockSize; }
-      storage.loadBlock(&dim, {l, v}, kBlockSize);
+      std::int64_t l[kBlockSize], vl[kBlockSize];
+      std::int32_t v[kBlockSize], vi[kBlockSize], ti[kBlockSize];
+      for (tuple_id t = 0; t < kBlockSize; ++t) {
+        l[t] = i + t; v[t] = (i + t) % kBlockSize; vl[t] = (i + t) / 2 * 2; vi[t] = (i + t) / 2 * 2; ti[t] = i + t;
+      }
+      storage.loadBlock(&dim, {l, v, vl, vi, ti}, kBlockSize);
     }
     for (tuple_id i = 0; i < kNumFactTuples; i += kBlockSize) {
-      std::int64_t l[kBlockSize];
-      std::int32_t v[kBlockSize];
-      for (tuple_id t = 0; t < kBlockSize; ++t) { l[t] = i + t; v[t] = i + t; }
-      storage.loadBlock(&fact, {l, v}, kBlockSize);
+      std::int64_t l[kBlockSize], vl[kBlockSize];
+      std::int32_t v[kBlockSize], vi[kBlockSize], ti[kBlockSize];
+      for (tuple_id t = 0; t < kBlockSize; ++t) { l[t] = i + t; v[t] = i + t; vl[t] = i + t; vi[t] = i + t; ti[t] = i + t; }
+      storage.loadBlock(&fact, {l, v, vl, vi, ti}, kBlockSize);
     }
   }
 };
@@ -105,6 +114,73 @@ void runJoin(attribute_id key_attr, TypeID key_type, bool use_foreman, HashJoinO
   }
   *out = collect(ctx, dest, f.storage, inner);
 }
+
+// Composite keys / residual predicate / outer join.  Output: (dim.long [build side], fact.long [probe side]) for
+// inner and outer joins, fact.long for semi and anti joins.
+struct JoinedRows {
+  std::vector<std::int64_t> dim_long, fact_long;
+  std::vector<bool> dim_is_null;
+};
+
+JoinedRows runGeneralJoin(const std::vector<attribute_id> &keys, TypeID table_key_type, const Predicate *residual,
+                          HashJoinOperator::JoinType join_type, bool use_foreman) {
+  Fixture f;
+  CatalogRelation result(4, "result");
+  QueryContext ctx;
+  const auto table = ctx.addJoinHashTable(table_key_type, kNumDimTuples);
+  const auto dest = ctx.addInsertDestination(&result, &f.storage);
+  const bool pairs = join_type == HashJoinOperator::JoinType::kInnerJoin || join_type == HashJoinOperator::JoinType::kLeftOuterJoin;
+  std::vector<bool> on_build;
+  QueryContext::scalar_group_id selection;
+  if (pairs) {
+    result.addAttribute("dim_long", Type::Long().getNullableVersion());
+    result.addAttribute("fact_long", Type::Long());
+    selection = ctx.addScalarGroup({0, 0});
+    on_build = {true, false};
+  } else {
+    result.addAttribute("fact_long", Type::Long());
+    selection = ctx.addScalarGroup({0});
+    on_build = {false};
+  }
+  const auto residual_id = residual != nullptr ? ctx.addPredicate(*residual) : QueryContext::kInvalidPredicateId;
+  auto *builder = new BuildHashOperator(0, f.dim, true, keys, false, 1, table);
+  auto *prober = new HashJoinOperator(0, f.dim, f.fact, true, keys, false, 1, false, result, dest, table, residual_id, selection,
+                                      &on_build, join_type);
+  auto *cleaner = new DestroyHashOperator(0, 1, table);
+  std::unique_ptr<RelationalOperator> b, p, c;
+  if (use_foreman) {
+    QueryPlan plan;
+    const auto bi = plan.addRelationalOperator(builder);
+    const auto pi = plan.addRelationalOperator(prober);
+    const auto ci = plan.addRelationalOperator(cleaner);
+    plan.addDirectDependency(pi, bi, true);
+    plan.addDirectDependency(ci, pi, true);
+    ForemanSingleNode foreman(&plan, &ctx, &f.storage, 4);
+    foreman.run();
+  } else {
+    b.reset(builder); p.reset(prober); c.reset(cleaner);
+    fetchAndExecuteWorkOrders(b.get(), &ctx, &f.storage);
+    fetchAndExecuteWorkOrders(p.get(), &ctx, &f.storage);
+  }
+  JoinedRows rows;
+  for (block_id blk_id : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+    BlockReference blk = f.storage.getBlock(blk_id);
+    const std::size_t at = rows.fact_long.size(), k = static_cast<std::size_t>(blk->numTuples());
+    rows.fact_long.resize(at + k);
+    if (pairs) {
+      rows.dim_long.resize(at + k);
+      blk->copyAttributeToHost(0, rows.dim_long.data() + at);
+      blk->copyAttributeToHost(1, rows.fact_long.data() + at);
+      std::vector<std::uint64_t> nulls((k + 63) / 64 + 1, 0);
+      blk->copyNullBitmapToHost(0, nulls.data());
+      for (std::size_t i = 0; i < k; ++i) rows.dim_is_null.push_back((nulls[i >> 6] >> (63 - (i & 63))) & 1u);
+    } else {
+      blk->copyAttributeToHost(0, rows.fact_long.data() + at);
+    }
+  }
+  if (!use_foreman) fetchAndExecuteWorkOrders(c.get(), &ctx, &f.storage);
+  return rows;
+}
 }  // namespace
 
 int main() {
@@ -149,6 +225,70 @@ int main() {
       EXPECT_EQ(anti.dim_long.size(), static_cast<std::size_t>(kNumFactTuples - kNumDimTuples));
       for (std::size_t i = 0; i < semi.dim_long.size(); ++i) EXPECT_EQ(semi.dim_long[i], static_cast<std::int64_t>(i));
       for (std::size_t i = 0; i < anti.dim_long.size(); ++i) EXPECT_EQ(anti.dim_long[i], static_cast<std::int64_t>(kNumDimTuples + i));
+    }
+  }
+  // ---- composite keys, residual predicates, outer join -------------------------------------------------------------
+  using JT = HashJoinOperator::JoinType;
+  Predicate dim_long_lt_15;   // residual of CompositeKeyHashJoinWithResidualPredicateTest (:1268-1272): dim.long < 15
+  dim_long_lt_15.conjuncts.push_back(ComparisonPredicate(0, ComparisonID::kLess, TypedLiteral::Long(15), /*build_side=*/true));
+  const std::vector<std::vector<attribute_id>> composite_keys = {{0, 2} /* (LONG, LONG): hashed fold + component check */,
+                                                                 {4, 3} /* (INT, INT): exact 8-byte packing */};
+  for (const bool use_foreman : {false, true}) {
+    for (const auto &keys : composite_keys) {
+      {  // CompositeKeyHashJoinTest: 100 results, the even tids below 200, each once on both sides (:1159-1177)
+        JoinedRows r = runGeneralJoin(keys, kLong, nullptr, JT::kInnerJoin, use_foreman);
+        EXPECT_EQ(r.dim_long.size(), static_cast<std::size_t>(100));
+        std::vector<int> seen(kNumDimTuples, 0);
+        for (std::size_t i = 0; i < r.dim_long.size(); ++i) {
+          EXPECT_EQ(r.dim_long[i], r.fact_long[i]);
+          EXPECT_TRUE(r.dim_long[i] >= 0 && r.dim_long[i] < kNumDimTuples && (r.dim_long[i] & 1) == 0);
+          if (r.dim_long[i] >= 0 && r.dim_long[i] < kNumDimTuples) ++seen[r.dim_long[i]];
+          EXPECT_TRUE(!r.dim_is_null[i]);
+        }
+        for (tuple_id i = 0; i < kNumDimTuples; ++i) EXPECT_EQ(seen[i], (i & 1) ? 0 : 1);
+      }
+      {  // ... WithResidualPredicateTest: 8 results, tids 0, 2, ..., 14 (:1350-1368)
+        JoinedRows r = runGeneralJoin(keys, kLong, &dim_long_lt_15, JT::kInnerJoin, use_foreman);
+        EXPECT_EQ(r.dim_long.size(), static_cast<std::size_t>(8));
+        std::sort(r.dim_long.begin(), r.dim_long.end());
+        std::sort(r.fact_long.begin(), r.fact_long.end());
+        for (std::size_t i = 0; i < r.dim_long.size(); ++i) {
+          EXPECT_EQ(r.dim_long[i], static_cast<std::int64_t>(2 * i));
+          EXPECT_EQ(r.fact_long[i], static_cast<std::int64_t>(2 * i));
+        }
+      }
+      {  // semi / anti with the residual (HashJoinOperator.cpp:680-793, :880-1000): 8 resp. 292 fact rows
+        JoinedRows semi = runGeneralJoin(keys, kLong, &dim_long_lt_15, JT::kLeftSemiJoin, use_foreman);
+        JoinedRows anti = runGeneralJoin(keys, kLong, &dim_long_lt_15, JT::kLeftAntiJoin, use_foreman);
+        EXPECT_EQ(semi.fact_long.size(), static_cast<std::size_t>(8));
+        EXPECT_EQ(anti.fact_long.size(), static_cast<std::size_t>(kNumFactTuples - 8));
+        std::sort(semi.fact_long.begin(), semi.fact_long.end());
+        for (std::size_t i = 0; i < semi.fact_long.size(); ++i) EXPECT_EQ(semi.fact_long[i], static_cast<std::int64_t>(2 * i));
+        std::vector<int> seen(kNumFactTuples, 0);
+        for (std::int64_t v : anti.fact_long) ++seen[v];
+        for (tuple_id i = 0; i < kNumFactTuples; ++i) EXPECT_EQ(seen[i], (i < 15 && (i & 1) == 0) ? 0 : 1);
+      }
+      {  // left outer join (HashOuterJoinWorkOrder, :960-1099): 100 matched rows + 200 fact rows with NULL dim.long
+        JoinedRows r = runGeneralJoin(keys, kLong, nullptr, JT::kLeftOuterJoin, use_foreman);
+        EXPECT_EQ(r.fact_long.size(), static_cast<std::size_t>(kNumFactTuples));
+        std::vector<int> seen(kNumFactTuples, 0);
+        for (std::size_t i = 0; i < r.fact_long.size(); ++i) {
+          const std::int64_t fl = r.fact_long[i];
+          ++seen[fl];
+          const bool matched = fl < kNumDimTuples && (fl & 1) == 0;
+          EXPECT_EQ(static_cast<int>(r.dim_is_null[i]), matched ? 0 : 1);
+          if (matched) EXPECT_EQ(r.dim_long[i], fl);
+        }
+        for (tuple_id i = 0; i < kNumFactTuples; ++i) EXPECT_EQ(seen[i], 1);
+      }
+    }
+    {  // attribute-vs-attribute residual on the LONG key join: fact.int == dim.int holds for tids 0..9 only
+      Predicate same_int;
+      same_int.conjuncts.push_back(ComparisonPredicate::Attributes(1, /*lhs_on_build=*/false, ComparisonID::kEqual, 1, /*rhs_on_build=*/true));
+      JoinedRows r = runGeneralJoin({0}, kLong, &same_int, JT::kInnerJoin, use_foreman);
+      EXPECT_EQ(r.dim_long.size(), static_cast<std::size_t>(kBlockSize));
+      std::sort(r.dim_long.begin(), r.dim_long.end());
+      for (std::size_t i = 0; i < r.dim_long.size(); ++i) EXPECT_EQ(r.dim_long[i], static_cast<std::int64_t>(i));
     }
   }
   return finish("hash_join_operator_test");

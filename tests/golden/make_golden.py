@@ -75,7 +75,8 @@ dump("hash_partition", {
 dump("join_unittest", {
     "source": [
         "relational_operators/tests/HashJoinOperator_unittest.cpp:97-99 (sizes), :196-270 (data), "
-        ":379-514 (LongKeyHashJoinTest), :516-690 (IntDuplicateKeyHashJoinTest)",
+        ":379-514 (LongKeyHashJoinTest), :516-690 (IntDuplicateKeyHashJoinTest), "
+        ":999-1177 (CompositeKeyHashJoinTest), :1187-1375 (CompositeKeyHashJoinWithResidualPredicateTest)",
     ],
     "num_dim_tuples": 200,
     "num_fact_tuples": 300,
@@ -91,6 +92,18 @@ dump("join_unittest", {
         "expected_count_per_dim_row": 1,            # every dim row appears exactly once
         "expected_fact_count_first_rows": 20,       # fact rows 0..9 match 200/10 dim rows each
         "expected_fact_count_other_rows": 0,        # fact rows >= 10 never match
+    },
+    # keys (long, varchar): dim.varchar = tid / 2 * 2, fact.varchar = tid, so only even tids join (:1159-1177)
+    "composite_key": {
+        "expected_num_results": 100,
+        "second_component_dim": "tid // 2 * 2",
+        "second_component_fact": "tid",
+        "matching_tids": "even tids below num_dim_tuples, each once on both sides",
+    },
+    # + residual predicate dim.long < 15 (:1268-1272): tids 0, 2, ..., 14 (:1350-1368)
+    "composite_key_residual": {
+        "residual_dim_long_less_than": 15,
+        "expected_num_results": 8,
     },
 })
 

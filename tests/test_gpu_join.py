@@ -257,3 +257,100 @@ def test_radix_partitioned_probe_matches_oracle(capi, oracle, dev, n_build, n_pr
     table.build(to_dev(extra, dev), base_tid=n_build)
     want = total + int(np.isin(probe[oracle.bools_from_bitmap(pf, n_probe)], extra).sum())
     assert int(table.probe_count(to_dev(probe, dev), filter_bitmap=bitmap_dev(pf, dev)).item()) == want
+
+
+# ---- composite keys, residual predicates (HashJoinOperator_unittest.cpp:999-1375) -----------------------------
+def hip_composite_join(capi, dev, build_cols, probe_cols):
+    """Composite-key inner join through the C ABI: fold the components into one LONG key
+    (qsx_join_key_pack), single-key table, and — when the fold is a hash, not an exact packing —
+    verify the components of every returned pair (gather + attribute-vs-attribute K1 + K2)."""
+    bd = [to_dev(c, dev) for c in build_cols]
+    pd = [to_dev(c, dev) for c in probe_cols]
+    bk, exact = capi.join_key_pack(bd)
+    pk, exact2 = capi.join_key_pack(pd)
+    assert exact == exact2
+    table = capi.JoinTable(T.LONG, bk.numel())
+    table.build(bk)
+    total = int(table.probe_count(pk).item())
+    p, b, cnt = table.probe(pk, capacity=total)
+    assert int(cnt.item()) == total
+    p, b = p[:total], b[:total]
+    if not exact and total > 0:
+        bm = None
+        for pc, bc in zip(pd, bd):
+            bm, _ = capi.select_cmp_columns(capi.gather(pc, p), capi.gather(bc, b), T.EQ, filter_bitmap=bm)
+        (p, b), k = capi.compact_gather([p, b], bm, total)
+        p, b = p[:int(k.item())], b[:int(k.item())]
+    return p, b, exact
+
+
+@pytest.mark.parametrize("second_type", [np.int32, np.int64])
+def test_golden_composite_key_join_and_residual(capi, dev, golden, second_type):
+    """CompositeKeyHashJoinTest (:999-1177) and ...WithResidualPredicateTest (:1187-1375): keys
+    (long, varchar) where the VARCHAR holds tid/2*2 (dim) and tid (fact) as digits; the second
+    component is carried as an integer here.  (LONG, INT) needs 12 bytes -> hashed fold + component
+    verification; with both components narrowed to INT the fold is an exact packing — both run."""
+    g = golden["join_unittest"]
+    dim = np.arange(g["num_dim_tuples"])
+    fact = np.arange(g["num_fact_tuples"])
+    first = np.int64 if second_type == np.int64 else np.int32
+    build_cols = [dim.astype(first), (dim // 2 * 2).astype(second_type)]
+    probe_cols = [fact.astype(first), fact.astype(second_type)]
+    p, b, exact = hip_composite_join(capi, dev, build_cols, probe_cols)
+    assert exact == (second_type == np.int32)
+    p, b = p.cpu().numpy(), b.cpu().numpy()
+    assert p.size == g["composite_key"]["expected_num_results"]
+    assert np.array_equal(np.sort(b), np.arange(0, dim.size, 2)) and np.array_equal(np.sort(p), np.arange(0, dim.size, 2))
+    # residual predicate dim.long < 15 evaluated on the joined pairs (HashJoinOperator.cpp:510-524)
+    pt, bt = to_dev(p, dev), to_dev(b, dev)
+    dim_long = capi.gather(to_dev(dim.astype(np.int64), dev), bt)
+    bm, cnt = capi.select_cmp(dim_long, T.LT, g["composite_key_residual"]["residual_dim_long_less_than"])
+    assert int(cnt.item()) == g["composite_key_residual"]["expected_num_results"]
+    (fp, fb), k = capi.compact_gather([pt, bt], bm, p.size)
+    k = int(k.item())
+    assert sorted(fb[:k].cpu().tolist()) == list(range(0, 15, 2)) == sorted(fp[:k].cpu().tolist())
+
+
+@pytest.mark.parametrize("types", [(np.int32, np.int32), (np.int64, np.int32), (np.int64, np.int64, np.int32)])
+def test_random_composite_join_matches_oracle(capi, oracle, dev, types):
+    rng = np.random.default_rng(len(types) * 17 + 3)
+    n_build, n_probe = 30_000, 200_000
+    # small component domains: plenty of duplicate composite keys and, for the hashed fold,
+    # rows that agree in one component only
+    build_cols = [rng.integers(-20, 20, size=n_build).astype(t) for t in types]
+    probe_cols = [rng.integers(-22, 22, size=n_probe).astype(t) for t in types]
+    p, b, exact = hip_composite_join(capi, dev, build_cols, probe_cols)
+    assert exact == (sum(np.dtype(t).itemsize for t in types) <= 8)
+    ot = oracle.CompositeJoinTable([T.INT if t == np.int32 else T.LONG for t in types], n_build)
+    ot.build(build_cols)
+    rp, rb = ot.probe(probe_cols)
+    assert p.numel() == rp.size
+    assert np.array_equal(sorted_pairs(p.cpu().numpy(), b.cpu().numpy()), sorted_pairs(rp, rb))
+    if not exact:
+        # the device fold is the reference's composite hash (HashTable.hpp:2109-2119)
+        keys, _ = capi.join_key_pack([to_dev(c[:64], dev) for c in build_cols])
+        assert np.array_equal(keys.cpu().numpy().view(np.uint64), ot.hash_rows([c[:64] for c in build_cols]))
+
+
+def test_semi_join_with_residual_predicate(capi, oracle, dev):
+    """HashSemiJoinWorkOrder::executeWithResidualPredicate (HashJoinOperator.cpp:680-793): a probe row
+    qualifies when at least one of its pairs passes the residual (here probe.v < build.w)."""
+    rng = np.random.default_rng(5)
+    n_build, n_probe = 20_000, 150_000
+    bk = rng.integers(0, 5000, size=n_build).astype(np.int32)
+    bw = rng.integers(0, 100, size=n_build).astype(np.int64)
+    pk = rng.integers(0, 6000, size=n_probe).astype(np.int32)
+    pv = rng.integers(0, 100, size=n_probe).astype(np.int64)
+    table, p, b, total = hip_join(capi, dev, T.INT, [bk], pk)
+    pt, bt = to_dev(p, dev), to_dev(b, dev)
+    bm, _ = capi.select_cmp_columns(capi.gather(to_dev(pv, dev), pt), capi.gather(to_dev(bw, dev), bt), T.LT)
+    (kept, ), k = capi.compact_gather([pt], bm, total)
+    got = bitmap_np(capi.tids_to_bitmap(kept[:int(k.item())], n_probe))
+    _, rp, rb = oracle_join(oracle, T.INT, [bk], pk)
+    keep = pv[rp] < bw[rb]
+    want = oracle.tids_to_bitmap(rp[keep], n_probe)
+    assert np.array_equal(got, want)
+    assert np.array_equal(want, oracle.bitmap_from_bools(np.isin(np.arange(n_probe), rp[keep])))
+    # the anti join is the complement within the probe block (:860-877 with residual :930-1000)
+    anti = bitmap_np(capi.bitmap_combine(3, capi.tids_to_bitmap(kept[:int(k.item())], n_probe), None, n_probe))
+    assert oracle.bitmap_count(anti, n_probe) == n_probe - oracle.bitmap_count(want, n_probe)

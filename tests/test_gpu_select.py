@@ -100,3 +100,38 @@ def test_select_config_c1_selectivities(capi, oracle, dev):
         (out,), c = capi.compact_gather([dcol], bm, col.size)
         assert int(c.item()) == int(cnt.item()) == int((col < k).sum())
         assert np.array_equal(out.cpu().numpy()[:int(c.item())], col[col < k])
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64, np.float32, np.float64])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 100_003])
+def test_select_cmp_columns_is_bit_exact(capi, oracle, dev, dtype, n):
+    """attribute OP attribute (LiteralComparators-inl.hpp:52-125), with and without a filter."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(-5, 5, size=n).astype(dtype)
+    b = rng.integers(-5, 5, size=n).astype(dtype)
+    f = oracle.bitmap_from_bools(rng.random(n) < 0.6)
+    da, db = to_dev(a, dev), to_dev(b, dev)
+    for op in range(6):
+        bm, cnt = capi.select_cmp_columns(da, db, op)
+        want = oracle.select_cmp_columns(a, b, op)
+        assert np.array_equal(bitmap_np(bm), want)
+        assert int(cnt.item()) == oracle.bitmap_count(want, n)
+        bm, cnt = capi.select_cmp_columns(da, db, op, filter_bitmap=bitmap_dev(f, dev))
+        want = oracle.select_cmp_columns(a, b, op, filter_bitmap=f)
+        assert np.array_equal(bitmap_np(bm), want)
+        assert int(cnt.item()) == oracle.bitmap_count(want, n)
+
+
+def test_tids_to_bitmap_round_trip(capi, oracle, dev):
+    rng = np.random.default_rng(12)
+    n_bits = 70_001
+    tids = rng.integers(1000, 1000 + n_bits, size=200_000).astype(np.int32)     # duplicates on purpose
+    tids[::1000] = 5                                                            # below base: ignored
+    got = bitmap_np(capi.tids_to_bitmap(to_dev(tids, dev), n_bits, base_tid=1000))
+    want = oracle.tids_to_bitmap(tids, n_bits, base_tid=1000)
+    assert np.array_equal(got, want)
+    back, cnt = capi.bitmap_to_tids(capi.tids_to_bitmap(to_dev(tids, dev), n_bits, base_tid=1000), n_bits, base_tid=1000)
+    uniq = np.unique(tids[tids >= 1000])
+    assert np.array_equal(back[:int(cnt.item())].cpu().numpy(), uniq)
+    empty = capi.tids_to_bitmap(torch.empty(0, dtype=torch.int32, device=dev), 130)
+    assert not bitmap_np(empty).any()

@@ -322,3 +322,35 @@ def test_collision_free_matches_generic(oracle):
     # generic partitioned finalize covers every group exactly once
     pk = np.concatenate([ge.finalize(p, 41)[0][0] for p in range(41)])
     assert np.array_equal(np.sort(pk), np.unique(key))
+
+
+def test_join_unittest_composite_key_and_residual(oracle, golden):
+    """CompositeKeyHashJoinTest / ...WithResidualPredicateTest (HashJoinOperator_unittest.cpp:999-1375)
+    on the composite-key restatement: 100 results (even tids), 8 with the residual dim.long < 15."""
+    g = golden["join_unittest"]
+    dim = np.arange(g["num_dim_tuples"], dtype=np.int64)
+    fact = np.arange(g["num_fact_tuples"], dtype=np.int64)
+    t = oracle.CompositeJoinTable([T.LONG, T.LONG], dim.size)
+    for b in range(0, dim.size, g["block_size"]):                 # one build work order per block
+        blk = dim[b:b + g["block_size"]]
+        t.build([blk, blk // 2 * 2], block_id=b // g["block_size"], base_tid=b)
+    p, d = t.probe([fact, fact])
+    assert p.size == g["composite_key"]["expected_num_results"]
+    assert np.array_equal(np.sort(d), np.arange(0, dim.size, 2)) and np.array_equal(np.sort(p), np.sort(d))
+    keep = dim[d] < g["composite_key_residual"]["residual_dim_long_less_than"]
+    assert int(keep.sum()) == g["composite_key_residual"]["expected_num_results"]
+    assert sorted(d[keep].tolist()) == list(range(0, 15, 2))
+
+
+def test_composite_hash_is_the_combine_hashes_fold(oracle):
+    """hashCompositeKey (storage/HashTable.hpp:2109-2119): fold of CombineHashes over the components'
+    identity hashes; CombineHashes itself is pinned against the reference header above."""
+    t = oracle.CompositeJoinTable([T.LONG, T.INT, T.LONG], 4)
+    a = np.array([7, -1], dtype=np.int64)
+    b = np.array([3, -2], dtype=np.int32)
+    c = np.array([1 << 40, 0], dtype=np.int64)
+    got = t.hash_rows([a, b, c])
+    for i in range(2):
+        h = oracle.combine_hashes(oracle.hash_scalar(T.LONG, a[i]), oracle.hash_scalar(T.INT, b[i]))
+        h = oracle.combine_hashes(h, oracle.hash_scalar(T.LONG, c[i]))
+        assert int(got[i]) == h
