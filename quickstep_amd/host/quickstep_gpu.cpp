@@ -63,10 +63,27 @@ attribute_id CatalogRelation::getAttributeByName(const std::string &name) const 
 void CatalogRelation::addBlock(block_id b) {
   std::lock_guard<std::mutex> lock(mutex_);
   blocks_.push_back(b);
+  if (num_partitions_ > 0) partition_blocks_.at(0).push_back(b);
 }
 std::vector<block_id> CatalogRelation::getBlocksSnapshot() const {
   std::lock_guard<std::mutex> lock(mutex_);
   return blocks_;
+}
+void CatalogRelation::setPartitionScheme(std::size_t num_partitions, attribute_id partition_attribute) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  num_partitions_ = num_partitions;
+  partition_attribute_ = partition_attribute;
+  partition_blocks_.assign(num_partitions, {});
+}
+void CatalogRelation::addBlockToPartition(block_id b, partition_id part) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  blocks_.push_back(b);
+  if (num_partitions_ > 0) partition_blocks_.at(part).push_back(b);
+}
+std::vector<block_id> CatalogRelation::getBlocksInPartition(partition_id part) const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  if (num_partitions_ == 0) return part == 0 ? blocks_ : std::vector<block_id>();
+  return partition_blocks_.at(part);
 }
 
 namespace {
@@ -135,7 +152,7 @@ block_id StorageManager::createBlock(CatalogRelation *relation, std::int64_t cap
 }
 
 block_id StorageManager::loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns,
-                                   std::int64_t num_tuples) {
+                                   std::int64_t num_tuples, partition_id part) {
   BlockReference block;
   block_id id;
   {
@@ -157,7 +174,7 @@ block_id StorageManager::loadBlock(CatalogRelation *relation, const std::vector<
   }
   if (!g_host_memory) CheckStatus(qsx_stream_synchronize(nullptr), "qsx_stream_synchronize");
   block->setNumTuples(num_tuples);
-  relation->addBlock(id);
+  relation->addBlockToPartition(id, part);
   return id;
 }
 
@@ -505,28 +522,39 @@ BuildHashOperator::BuildHashOperator(std::size_t query_id, const CatalogRelation
                                      QueryContext::predicate_id build_predicate_index)
     : RelationalOperator(query_id, num_partitions), input_relation_(input_relation),
       input_relation_is_stored_(input_relation_is_stored), join_key_attributes_(join_key_attributes),
-      hash_table_index_(hash_table_index), build_predicate_index_(build_predicate_index) {
+      is_broadcast_join_(num_partitions > 1u && !input_relation.hasPartitionScheme()),
+      hash_table_index_(hash_table_index), build_predicate_index_(build_predicate_index), input_(num_partitions) {
   if (join_key_attributes.empty() || join_key_attributes.size() > QSX_MAX_KEYS) {
     throw ExecutionError("BuildHashOperator: 1 to 4 INT/LONG join key attributes are on the GPU path", QSX_ERR_UNSUPPORTED);
   }
-  if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
+  if (input_relation_is_stored) {
+    // BuildHashOperator.hpp:105-119: per-partition blocks, or every block for every partition (broadcast)
+    if (input_relation.hasPartitionScheme() && input_relation.getNumPartitions() != num_partitions) {
+      throw ExecutionError("BuildHashOperator: num_partitions differs from the input relation's partition scheme", QSX_ERR_INVALID_ARGUMENT);
+    }
+    for (partition_id part = 0; part < num_partitions; ++part) {
+      input_.ids[part] = is_broadcast_join_ ? input_relation.getBlocksSnapshot() : input_relation.getBlocksInPartition(part);
+    }
+  }
 }
 
 bool BuildHashOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
                                          StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
   const Predicate *predicate = query_context->getPredicate(build_predicate_index_);
-  qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, 0);
   std::lock_guard<std::mutex> lock(mutex_);
   if (!started_) {
     query_context->setJoinHashTableBuildKeyAttributes(hash_table_index_, join_key_attributes_);
     started_ = true;
   }
-  while (num_workorders_generated_ < input_relation_block_ids_.size()) {
-    container->addNormalWorkOrder(new BuildHashWorkOrder(query_id_, input_relation_, join_key_attributes_,
-                                                         input_relation_block_ids_[num_workorders_generated_], predicate,
-                                                         table, storage_manager),
-                                  op_index_);
-    ++num_workorders_generated_;
+  for (partition_id part = 0; part < num_partitions_; ++part) {   // BuildHashOperator.cpp:82-110
+    qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, part);
+    while (input_.generated[part] < input_.ids[part].size()) {
+      container->addNormalWorkOrder(new BuildHashWorkOrder(query_id_, input_relation_, join_key_attributes_,
+                                                           input_.ids[part][input_.generated[part]], predicate, table,
+                                                           storage_manager, part),
+                                    op_index_);
+      ++input_.generated[part];
+    }
   }
   return input_relation_is_stored_ || done_feeding_input_relation_;
 }
@@ -595,7 +623,8 @@ HashJoinOperator::HashJoinOperator(std::size_t query_id, const CatalogRelation &
       probe_relation_(probe_relation), probe_relation_is_stored_(probe_relation_is_stored),
       join_key_attributes_(join_key_attributes), output_relation_(output_relation),
       output_destination_index_(output_destination_index), hash_table_index_(hash_table_index),
-      residual_predicate_index_(residual_predicate_index), selection_index_(selection_index), join_type_(join_type) {
+      residual_predicate_index_(residual_predicate_index), selection_index_(selection_index), join_type_(join_type),
+      probe_(num_partitions) {
   if (join_key_attributes.empty() || join_key_attributes.size() > QSX_MAX_KEYS) {
     throw ExecutionError("HashJoinOperator: 1 to 4 INT/LONG join key attributes are on the GPU path", QSX_ERR_UNSUPPORTED);
   }
@@ -604,14 +633,20 @@ HashJoinOperator::HashJoinOperator(std::size_t query_id, const CatalogRelation &
     throw ExecutionError("HashJoinOperator: outer joins take no residual predicate", QSX_ERR_UNSUPPORTED);
   }
   if (is_selection_on_build != nullptr) is_selection_on_build_ = *is_selection_on_build;
-  if (probe_relation_is_stored) probe_relation_block_ids_ = probe_relation.getBlocksSnapshot();
+  if (probe_relation_is_stored) {
+    if (num_partitions > 1 && probe_relation.getNumPartitions() != num_partitions) {
+      throw ExecutionError("HashJoinOperator: num_partitions differs from the probe relation's partition scheme", QSX_ERR_INVALID_ARGUMENT);
+    }
+    for (partition_id part = 0; part < num_partitions; ++part) {
+      probe_.ids[part] = num_partitions > 1 ? probe_relation.getBlocksInPartition(part) : probe_relation.getBlocksSnapshot();
+    }
+  }
 }
 
 bool HashJoinOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
                                         StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
   const std::vector<attribute_id> &selection = query_context->getScalarGroup(selection_index_);
   if (is_selection_on_build_.empty()) is_selection_on_build_.assign(selection.size(), false);
-  qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, 0);
   InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
   std::lock_guard<std::mutex> lock(mutex_);
   if (!started_) {
@@ -622,14 +657,17 @@ bool HashJoinOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCon
     }
     started_ = true;
   }
-  while (num_workorders_generated_ < probe_relation_block_ids_.size()) {
-    container->addNormalWorkOrder(
-        new HashInnerJoinWorkOrder(query_id_, build_relation_, probe_relation_, join_key_attributes_, build_key_attributes_,
-                                   probe_relation_block_ids_[num_workorders_generated_],
-                                   query_context->getPredicate(residual_predicate_index_), selection, is_selection_on_build_,
-                                   join_type_, table, dest, storage_manager),
-        op_index_);
-    ++num_workorders_generated_;
+  for (partition_id part = 0; part < num_partitions_; ++part) {   // HashJoinOperator.cpp:220-250
+    qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, part);
+    while (probe_.generated[part] < probe_.ids[part].size()) {
+      container->addNormalWorkOrder(
+          new HashInnerJoinWorkOrder(query_id_, build_relation_, probe_relation_, join_key_attributes_, build_key_attributes_,
+                                     probe_.ids[part][probe_.generated[part]],
+                                     query_context->getPredicate(residual_predicate_index_), selection, is_selection_on_build_,
+                                     join_type_, table, dest, storage_manager, part),
+          op_index_);
+      ++probe_.generated[part];
+    }
   }
   return probe_relation_is_stored_ || done_feeding_input_relation_;
 }
@@ -852,9 +890,9 @@ void HashInnerJoinWorkOrder::execute() {
 namespace {
 class DestroyHashWorkOrder : public WorkOrder {
  public:
-  DestroyHashWorkOrder(std::size_t query_id, QueryContext::join_hash_table_id id, QueryContext *ctx)
-      : WorkOrder(query_id), id_(id), ctx_(ctx) {}
-  void execute() override { ctx_->destroyJoinHashTable(id_, 0); }  // DestroyHashOperator.cpp:70-72
+  DestroyHashWorkOrder(std::size_t query_id, QueryContext::join_hash_table_id id, QueryContext *ctx, partition_id part)
+      : WorkOrder(query_id, part), id_(id), ctx_(ctx) {}
+  void execute() override { ctx_->destroyJoinHashTable(id_, partition_id_); }  // DestroyHashOperator.cpp:70-72
  private:
   QueryContext::join_hash_table_id id_;
   QueryContext *ctx_;
@@ -862,8 +900,8 @@ class DestroyHashWorkOrder : public WorkOrder {
 class AggregationWorkOrder : public WorkOrder {
  public:
   AggregationWorkOrder(std::size_t query_id, block_id input_block_id, AggregationOperationState *state,
-                       StorageManager *storage_manager)
-      : WorkOrder(query_id), input_block_id_(input_block_id), state_(state), storage_manager_(storage_manager) {}
+                       StorageManager *storage_manager, partition_id part = 0)
+      : WorkOrder(query_id, part), input_block_id_(input_block_id), state_(state), storage_manager_(storage_manager) {}
   void execute() override { state_->aggregateBlock(*storage_manager_->getBlock(input_block_id_)); }  // AggregationOperator.cpp:124-126
  private:
   block_id input_block_id_;
@@ -883,9 +921,10 @@ class FinalizeAggregationWorkOrder : public WorkOrder {
 };
 class DestroyAggregationStateWorkOrder : public WorkOrder {
  public:
-  DestroyAggregationStateWorkOrder(std::size_t query_id, QueryContext::aggregation_state_id id, QueryContext *ctx)
-      : WorkOrder(query_id), id_(id), ctx_(ctx) {}
-  void execute() override { ctx_->destroyAggregationState(id_, 0); }
+  DestroyAggregationStateWorkOrder(std::size_t query_id, QueryContext::aggregation_state_id id, QueryContext *ctx,
+                                   partition_id part)
+      : WorkOrder(query_id, part), id_(id), ctx_(ctx) {}
+  void execute() override { ctx_->destroyAggregationState(id_, partition_id_); }
  private:
   QueryContext::aggregation_state_id id_;
   QueryContext *ctx_;
@@ -896,7 +935,9 @@ bool DestroyHashOperator::getAllWorkOrders(WorkOrdersContainer *container, Query
                                            const tmb::client_id, tmb::MessageBus *) {
   if (!work_generated_) {
     work_generated_ = true;
-    container->addNormalWorkOrder(new DestroyHashWorkOrder(query_id_, hash_table_index_, query_context), op_index_);
+    for (partition_id part = 0; part < num_partitions_; ++part) {   // DestroyHashOperator.cpp:40-50
+      container->addNormalWorkOrder(new DestroyHashWorkOrder(query_id_, hash_table_index_, query_context, part), op_index_);
+    }
   }
   return true;
 }
@@ -908,18 +949,27 @@ AggregationOperator::AggregationOperator(std::size_t query_id, const CatalogRela
                                          bool input_relation_is_stored, QueryContext::aggregation_state_id aggr_state_index,
                                          std::size_t num_partitions)
     : RelationalOperator(query_id, num_partitions), input_relation_(input_relation),
-      input_relation_is_stored_(input_relation_is_stored), aggr_state_index_(aggr_state_index) {
-  if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
+      input_relation_is_stored_(input_relation_is_stored), aggr_state_index_(aggr_state_index), input_(num_partitions) {
+  if (input_relation_is_stored) {
+    if (num_partitions > 1 && input_relation.getNumPartitions() != num_partitions) {
+      throw ExecutionError("AggregationOperator: num_partitions differs from the input relation's partition scheme", QSX_ERR_INVALID_ARGUMENT);
+    }
+    for (partition_id part = 0; part < num_partitions; ++part) {
+      input_.ids[part] = num_partitions > 1 ? input_relation.getBlocksInPartition(part) : input_relation.getBlocksSnapshot();
+    }
+  }
 }
 
 bool AggregationOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
                                            StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
-  AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, 0);
   std::lock_guard<std::mutex> lock(mutex_);
-  while (num_workorders_generated_ < input_relation_block_ids_.size()) {
-    container->addNormalWorkOrder(new AggregationWorkOrder(query_id_, input_relation_block_ids_[num_workorders_generated_],
-                                                           state, storage_manager), op_index_);
-    ++num_workorders_generated_;
+  for (partition_id part = 0; part < num_partitions_; ++part) {   // AggregationOperator.cpp:49-61
+    AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, part);
+    while (input_.generated[part] < input_.ids[part].size()) {
+      container->addNormalWorkOrder(new AggregationWorkOrder(query_id_, input_.ids[part][input_.generated[part]], state,
+                                                             storage_manager, part), op_index_);
+      ++input_.generated[part];
+    }
   }
   return input_relation_is_stored_ || done_feeding_input_relation_;
 }
@@ -928,12 +978,14 @@ bool FinalizeAggregationOperator::getAllWorkOrders(WorkOrdersContainer *containe
                                                    StorageManager *, const tmb::client_id, tmb::MessageBus *) {
   if (!started_) {
     started_ = true;
-    AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, 0);
     InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
     // num_partitions x aggr_state_num_partitions work orders (FinalizeAggregationOperator.cpp:48-66)
-    for (std::size_t p = 0; p < aggr_state_num_partitions_; ++p) {
-      container->addNormalWorkOrder(new FinalizeAggregationWorkOrder(query_id_, p, aggr_state_num_partitions_, state, dest),
-                                    op_index_);
+    for (partition_id part = 0; part < num_partitions_; ++part) {
+      AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, part);
+      for (std::size_t p = 0; p < aggr_state_num_partitions_; ++p) {
+        container->addNormalWorkOrder(new FinalizeAggregationWorkOrder(query_id_, p, aggr_state_num_partitions_, state, dest),
+                                      op_index_);
+      }
     }
   }
   return true;
@@ -943,7 +995,9 @@ bool DestroyAggregationStateOperator::getAllWorkOrders(WorkOrdersContainer *cont
                                                        StorageManager *, const tmb::client_id, tmb::MessageBus *) {
   if (!work_generated_) {
     work_generated_ = true;
-    container->addNormalWorkOrder(new DestroyAggregationStateWorkOrder(query_id_, aggr_state_index_, query_context), op_index_);
+    for (partition_id part = 0; part < num_partitions_; ++part) {
+      container->addNormalWorkOrder(new DestroyAggregationStateWorkOrder(query_id_, aggr_state_index_, query_context, part), op_index_);
+    }
   }
   return true;
 }

@@ -103,8 +103,16 @@ class CatalogRelation {
   std::size_t size() const { return types_.size(); }
   const Type &getAttributeType(attribute_id a) const { return types_.at(a); }
   attribute_id getAttributeByName(const std::string &name) const;
-  void addBlock(block_id b);
+  void addBlock(block_id b);   // unpartitioned relations; partition 0 of partitioned ones
   std::vector<block_id> getBlocksSnapshot() const;
+  // HashPartitionSchemeHeader(num_partitions, {attribute}) + PartitionScheme (catalog/PartitionScheme.hpp,
+  // PartitionSchemeHeader.hpp:200-214): blocks are registered per partition; the loader routes tuples.
+  void setPartitionScheme(std::size_t num_partitions, attribute_id partition_attribute);
+  bool hasPartitionScheme() const { return num_partitions_ > 0; }
+  std::size_t getNumPartitions() const { return num_partitions_ > 0 ? num_partitions_ : 1; }
+  attribute_id getPartitionAttribute() const { return partition_attribute_; }
+  void addBlockToPartition(block_id b, partition_id part);
+  std::vector<block_id> getBlocksInPartition(partition_id part) const;
 
  private:
   relation_id id_;
@@ -113,6 +121,17 @@ class CatalogRelation {
   std::vector<Type> types_;
   mutable std::mutex mutex_;
   std::vector<block_id> blocks_;
+  std::size_t num_partitions_ = 0;  // 0: no partition scheme
+  attribute_id partition_attribute_ = kInvalidAttributeID;
+  std::vector<std::vector<block_id>> partition_blocks_;
+};
+
+// Block ids of an operator's input, per partition, with the per-partition count of work orders
+// already generated (input_relation_block_ids_ / num_workorders_generated_ of the reference operators).
+struct PartitionedBlockIds {
+  std::vector<std::vector<block_id>> ids;
+  std::vector<std::size_t> generated;
+  explicit PartitionedBlockIds(std::size_t parts) : ids(parts), generated(parts, 0) {}
 };
 
 // One device-resident BasicColumnStore block: a dense stripe per attribute
@@ -151,7 +170,8 @@ class StorageManager {
   // Create an empty block with room for `capacity` tuples; first_row = rows already in the relation.
   block_id createBlock(CatalogRelation *relation, std::int64_t capacity);
   // Create a block from host columns (one pointer per attribute), copy to HBM and add it to the relation.
-  block_id loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns, std::int64_t num_tuples);
+  block_id loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns, std::int64_t num_tuples,
+                     partition_id part = 0);
   BlockReference getBlock(block_id id) const;
   void deleteBlockOrBlobFile(block_id id);
   // Registers `num_tuples` more rows of `relation`; returns the relation-global row number of the first one.
@@ -445,20 +465,24 @@ class BuildHashOperator : public RelationalOperator {
   std::string getName() const override { return "BuildHashOperator"; }
   bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
                         const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
-  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id) override {
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id part_id) override {
     std::lock_guard<std::mutex> lock(mutex_);
-    input_relation_block_ids_.push_back(input_block_id);
+    if (is_broadcast_join_) {  // BuildHashOperator.hpp:146-152
+      for (auto &ids : input_.ids) ids.push_back(input_block_id);
+    } else {
+      input_.ids.at(part_id).push_back(input_block_id);
+    }
   }
 
  private:
   const CatalogRelation &input_relation_;
   const bool input_relation_is_stored_;
   const std::vector<attribute_id> join_key_attributes_;
+  const bool is_broadcast_join_;  // build side unpartitioned, probe side partitioned (BuildHashOperator.hpp:99)
   const QueryContext::join_hash_table_id hash_table_index_;
   const QueryContext::predicate_id build_predicate_index_;
   std::mutex mutex_;
-  std::vector<block_id> input_relation_block_ids_;
-  std::size_t num_workorders_generated_ = 0;
+  PartitionedBlockIds input_;
   bool started_ = false;
 };
 
@@ -466,8 +490,9 @@ class BuildHashWorkOrder : public WorkOrder {
  public:
   BuildHashWorkOrder(std::size_t query_id, const CatalogRelation &input_relation,
                      const std::vector<attribute_id> &join_key_attributes, block_id build_block_id,
-                     const Predicate *predicate, qsx_join_table_t *hash_table, StorageManager *storage_manager)
-      : WorkOrder(query_id), input_relation_(input_relation), join_key_attributes_(join_key_attributes),
+                     const Predicate *predicate, qsx_join_table_t *hash_table, StorageManager *storage_manager,
+                     partition_id part_id = 0)
+      : WorkOrder(query_id, part_id), input_relation_(input_relation), join_key_attributes_(join_key_attributes),
         build_block_id_(build_block_id), predicate_(predicate), hash_table_(hash_table),
         storage_manager_(storage_manager) {}
   void execute() override;  // BuildHashOperator.cpp:162-207
@@ -500,9 +525,9 @@ class HashJoinOperator : public RelationalOperator {
   std::string getName() const override { return "HashJoinOperator"; }
   bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
                         const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
-  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id) override {
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id part_id) override {
     std::lock_guard<std::mutex> lock(mutex_);
-    probe_relation_block_ids_.push_back(input_block_id);
+    probe_.ids.at(part_id).push_back(input_block_id);
   }
   QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
   relation_id getOutputRelationID() const override { return output_relation_.getID(); }
@@ -521,8 +546,7 @@ class HashJoinOperator : public RelationalOperator {
   std::vector<attribute_id> build_key_attributes_;
   const JoinType join_type_;
   std::mutex mutex_;
-  std::vector<block_id> probe_relation_block_ids_;
-  std::size_t num_workorders_generated_ = 0;
+  PartitionedBlockIds probe_;
   bool started_ = false;
 };
 
@@ -536,8 +560,8 @@ class HashInnerJoinWorkOrder : public WorkOrder {
                          block_id lookup_block_id, const Predicate *residual_predicate,
                          const std::vector<attribute_id> &selection, const std::vector<bool> &is_selection_on_build,
                          HashJoinOperator::JoinType join_type, qsx_join_table_t *hash_table,
-                         InsertDestination *output_destination, StorageManager *storage_manager)
-      : WorkOrder(query_id), build_relation_(build_relation), probe_relation_(probe_relation),
+                         InsertDestination *output_destination, StorageManager *storage_manager, partition_id part_id = 0)
+      : WorkOrder(query_id, part_id), build_relation_(build_relation), probe_relation_(probe_relation),
         join_key_attributes_(join_key_attributes), build_key_attributes_(build_key_attributes),
         block_id_(lookup_block_id), residual_predicate_(residual_predicate),
         selection_(selection), is_selection_on_build_(is_selection_on_build), join_type_(join_type),
@@ -584,9 +608,9 @@ class AggregationOperator : public RelationalOperator {
   std::string getName() const override { return "AggregationOperator"; }
   bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
                         const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
-  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id) override {
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id part_id) override {
     std::lock_guard<std::mutex> lock(mutex_);
-    input_relation_block_ids_.push_back(input_block_id);
+    input_.ids.at(part_id).push_back(input_block_id);
   }
 
  private:
@@ -594,8 +618,7 @@ class AggregationOperator : public RelationalOperator {
   const bool input_relation_is_stored_;
   const QueryContext::aggregation_state_id aggr_state_index_;
   std::mutex mutex_;
-  std::vector<block_id> input_relation_block_ids_;
-  std::size_t num_workorders_generated_ = 0;
+  PartitionedBlockIds input_;
   bool started_ = false;
 };
 

@@ -14,20 +14,49 @@ constexpr tuple_id kNumDimTuples = 200;
 constexpr tuple_id kNumFactTuples = 300;
 constexpr tuple_id kBlockSize = 10;
 
+constexpr std::size_t kMultiplePartitions = 4;   // HashJoinOperator_unittest.cpp:101
+
+// partitioned = insertTuplesWithSingleAttributePartitions (:272-339): HashPartitionSchemeHeader(4, {long}) on both
+// tables, tuple tid lives in partition tid % 4 (= long & 3, PartitionSchemeHeader.hpp:207-214), one block per partition.
+// dim_partitioned = false with partitioned = true is the broadcast build (BuildHashOperator.hpp:99, 146-152).
 struct Fixture {
   CatalogRelation dim{1, "dim_table"}, fact{2, "fact_table"};
   StorageManager storage;
-  Fixture() {
-    for (CatalogRelation *r : {&dim, &fact}) {
-      r->addAttribute("long", Type::Long());
-      r->addAttribute("int", Type::Int());
-      // the VARCHAR column of the reference (digits of tid/2*2 resp. tid) carried as integers,
-      // once LONG (composite key wider than 8 bytes: hashed fold) and once INT next to an INT copy
-      // of tid (8 bytes: exact packing)
-      r->addAttribute("varchar_as_long", Type::Long());
-      r->addAttribute("varchar_as_int", Type::Int());
-      r->addAttribute("tid_int", Type::Int());
+  explicit Fixture(bool partitioned = false, bool dim_partitioned = true) {
+    if (partitioned) {
+      loadPartitioned(&fact, kNumFactTuples, false, true);
+      loadPartitioned(&dim, kNumDimTuples, true, dim_partitioned);
+      return;
     }
+    loadUnpartitioned();
+  }
+  void addAttributes(CatalogRelation *r) {
+    r->addAttribute("long", Type::Long());
+    r->addAttribute("int", Type::Int());
+    r->addAttribute("varchar_as_long", Type::Long());
+    r->addAttribute("varchar_as_int", Type::Int());
+    r->addAttribute("tid_int", Type::Int());
+  }
+  void loadPartitioned(CatalogRelation *r, tuple_id num_tuples, bool is_dim, bool with_scheme) {
+    addAttributes(r);
+    const std::size_t parts = with_scheme ? kMultiplePartitions : 1;
+    if (with_scheme) r->setPartitionScheme(kMultiplePartitions, 0);
+    for (std::size_t part = 0; part < parts; ++part) {
+      std::vector<std::int64_t> l, vl;
+      std::vector<std::int32_t> v, vi, ti;
+      for (tuple_id tid = 0; tid < num_tuples; ++tid) {
+        if (with_scheme && static_cast<std::size_t>(tid) % kMultiplePartitions != part) continue;
+        l.push_back(tid); v.push_back(is_dim ? tid % kBlockSize : tid);
+        vl.push_back(is_dim ? tid / 2 * 2 : tid); vi.push_back(is_dim ? tid / 2 * 2 : tid); ti.push_back(tid);
+      }
+      storage.loadBlock(r, {l.data(), v.data(), vl.data(), vi.data(), ti.data()}, static_cast<std::int64_t>(l.size()), part);
+    }
+  }
+  void loadUnpartitioned() {
+    // the VARCHAR column of the reference (digits of tid/2*2 resp. tid) is carried as integers,
+    // once LONG (composite key wider than 8 bytes: hashed fold) and once INT next to an INT copy
+    // of tid (8 bytes: exact packing)
+    for (CatalogRelation *r : {&dim, &fact}) addAttributes(r);
     // dim: long = tid, int = tid % kBlockSize, varchar = tid / 2 * 2 ; fact: long = int = varchar = tid   (:196-270)
     for (tuple_id i = 0; i < kNumDimTuples; i += kBlockSize) {
       std::int64_t l[kBlockSize], vl[kBlockSize];
@@ -68,13 +97,17 @@ Result collect(QueryContext &ctx, QueryContext::insert_destination_id dest_id, S
 // exact_stats: the optimizer knows the exact min/max of the build key (dim.long = 0..199, dim.int = 0..9):
 // the join table is the directly addressed flavour.
 bool g_exact_stats = false;
+// 0: unpartitioned; 1: both tables hash-partitioned 4 ways on `long` (the ...WithSingleAttributePartitions tests,
+// :1379-1875); 2: only the probe side partitioned — broadcast build into all 4 tables.
+int g_partitioning = 0;
 
 void runJoin(attribute_id key_attr, TypeID key_type, bool use_foreman, HashJoinOperator::JoinType join_type, Result *out) {
-  Fixture f;
+  Fixture f(g_partitioning != 0, g_partitioning == 1);
+  const std::size_t parts = g_partitioning != 0 ? kMultiplePartitions : 1;
   CatalogRelation result(3, "result");
   QueryContext ctx;
   const QueryContext::ExactKeyRange range{0, key_type == kLong ? kNumDimTuples - 1 : kBlockSize - 1};
-  const auto table = ctx.addJoinHashTable(key_type, kNumDimTuples, 1, g_exact_stats ? &range : nullptr);
+  const auto table = ctx.addJoinHashTable(key_type, kNumDimTuples, parts, g_exact_stats ? &range : nullptr);
   const auto dest = ctx.addInsertDestination(&result, &f.storage);
   std::vector<bool> on_build;
   QueryContext::scalar_group_id selection;
@@ -89,10 +122,10 @@ void runJoin(attribute_id key_attr, TypeID key_type, bool use_foreman, HashJoinO
     selection = ctx.addScalarGroup({0});
     on_build = {false};
   }
-  auto *builder = new BuildHashOperator(0, f.dim, true, {key_attr}, false, 1, table);
-  auto *prober = new HashJoinOperator(0, f.dim, f.fact, true, {key_attr}, false, 1, false, result, dest, table,
+  auto *builder = new BuildHashOperator(0, f.dim, true, {key_attr}, false, parts, table);
+  auto *prober = new HashJoinOperator(0, f.dim, f.fact, true, {key_attr}, false, parts, false, result, dest, table,
                                       QueryContext::kInvalidPredicateId, selection, &on_build, join_type);
-  auto *cleaner = new DestroyHashOperator(0, 1, table);
+  auto *cleaner = new DestroyHashOperator(0, parts, table);
   if (use_foreman) {
     QueryPlan plan;
     const auto b = plan.addRelationalOperator(builder);
@@ -102,8 +135,10 @@ void runJoin(attribute_id key_attr, TypeID key_type, bool use_foreman, HashJoinO
     plan.addDirectDependency(c, p, true);
     ForemanSingleNode foreman(&plan, &ctx, &f.storage, 4);
     foreman.run();
-    EXPECT_EQ(foreman.getWorkOrderProfilingResults().size(),
-              static_cast<std::size_t>(kNumDimTuples / kBlockSize + kNumFactTuples / kBlockSize + 1));
+    const std::size_t build_orders = g_partitioning == 0 ? kNumDimTuples / kBlockSize
+                                     : g_partitioning == 1 ? kMultiplePartitions : kMultiplePartitions /* 1 block x 4 tables */;
+    const std::size_t probe_orders = g_partitioning == 0 ? kNumFactTuples / kBlockSize : kMultiplePartitions;
+    EXPECT_EQ(foreman.getWorkOrderProfilingResults().size(), build_orders + probe_orders + parts);
   } else {
     std::unique_ptr<RelationalOperator> b(builder), p(prober), c(cleaner);
     fetchAndExecuteWorkOrders(b.get(), &ctx, &f.storage);
@@ -124,10 +159,13 @@ struct JoinedRows {
 
 JoinedRows runGeneralJoin(const std::vector<attribute_id> &keys, TypeID table_key_type, const Predicate *residual,
                           HashJoinOperator::JoinType join_type, bool use_foreman) {
-  Fixture f;
+  // g_partitioning == 1: SingleAttributePartitionedCompositeKeyHashJoin[WithResidualPredicate]Test (:1524-1875) —
+  // every composite key here contains the tuple id, so equal keys share a partition
+  Fixture f(g_partitioning != 0, g_partitioning == 1);
+  const std::size_t parts = g_partitioning != 0 ? kMultiplePartitions : 1;
   CatalogRelation result(4, "result");
   QueryContext ctx;
-  const auto table = ctx.addJoinHashTable(table_key_type, kNumDimTuples);
+  const auto table = ctx.addJoinHashTable(table_key_type, kNumDimTuples, parts);
   const auto dest = ctx.addInsertDestination(&result, &f.storage);
   const bool pairs = join_type == HashJoinOperator::JoinType::kInnerJoin || join_type == HashJoinOperator::JoinType::kLeftOuterJoin;
   std::vector<bool> on_build;
@@ -143,10 +181,10 @@ JoinedRows runGeneralJoin(const std::vector<attribute_id> &keys, TypeID table_ke
     on_build = {false};
   }
   const auto residual_id = residual != nullptr ? ctx.addPredicate(*residual) : QueryContext::kInvalidPredicateId;
-  auto *builder = new BuildHashOperator(0, f.dim, true, keys, false, 1, table);
-  auto *prober = new HashJoinOperator(0, f.dim, f.fact, true, keys, false, 1, false, result, dest, table, residual_id, selection,
+  auto *builder = new BuildHashOperator(0, f.dim, true, keys, false, parts, table);
+  auto *prober = new HashJoinOperator(0, f.dim, f.fact, true, keys, false, parts, false, result, dest, table, residual_id, selection,
                                       &on_build, join_type);
-  auto *cleaner = new DestroyHashOperator(0, 1, table);
+  auto *cleaner = new DestroyHashOperator(0, parts, table);
   std::unique_ptr<RelationalOperator> b, p, c;
   if (use_foreman) {
     QueryPlan plan;
@@ -188,9 +226,10 @@ int main() {
     std::fprintf(stderr, "hash_join_operator_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
     return 2;
   }
-  for (const int variant : {0, 1, 2, 3}) {
+  for (const int variant : {0, 1, 2, 3, 4, 5, 6, 7, 8, 9}) {
     const bool use_foreman = (variant & 1) != 0;
     g_exact_stats = (variant & 2) != 0;
+    g_partitioning = variant < 4 ? 0 : (variant < 8 ? 1 : 2);   // 8, 9: broadcast build, hashed tables
     {  // LongKeyHashJoinTest: 200 results, every dim.long exactly once (:510-514)
       Result r;
       runJoin(0, kLong, use_foreman, HashJoinOperator::JoinType::kInnerJoin, &r);
@@ -203,6 +242,7 @@ int main() {
       }
       for (int c : counts) EXPECT_EQ(c, 1);
     }
+    if (g_partitioning != 1)   // dim.int is not the partitioning attribute: equal keys sit in different partitions
     {  // IntDuplicateKeyHashJoinTest: 200 results, each dim row once, fact rows 0..9 twenty times (:673-690)
       Result r;
       runJoin(1, kInt, use_foreman, HashJoinOperator::JoinType::kInnerJoin, &r);
@@ -233,7 +273,9 @@ int main() {
   dim_long_lt_15.conjuncts.push_back(ComparisonPredicate(0, ComparisonID::kLess, TypedLiteral::Long(15), /*build_side=*/true));
   const std::vector<std::vector<attribute_id>> composite_keys = {{0, 2} /* (LONG, LONG): hashed fold + component check */,
                                                                  {4, 3} /* (INT, INT): exact 8-byte packing */};
-  for (const bool use_foreman : {false, true}) {
+  for (const int variant : {0, 1, 2, 3, 4, 5}) {
+    const bool use_foreman = (variant & 1) != 0;
+    g_partitioning = variant / 2;
     for (const auto &keys : composite_keys) {
       {  // CompositeKeyHashJoinTest: 100 results, the even tids below 200, each once on both sides (:1159-1177)
         JoinedRows r = runGeneralJoin(keys, kLong, nullptr, JT::kInnerJoin, use_foreman);
