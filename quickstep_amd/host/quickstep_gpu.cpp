@@ -201,7 +201,7 @@ void StorageManager::deleteBlockOrBlobFile(block_id id) {
 // ---------------------------------------------------------------------------
 // Predicate
 // ---------------------------------------------------------------------------
-void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num_matches) const {
+void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num_matches, const std::uint64_t *filter) const {
   const std::int64_t n = block.numTuples();
   const std::size_t words = static_cast<std::size_t>((n + 63) / 64);
   void *current = nullptr, *next = nullptr, *count = nullptr;
@@ -213,15 +213,16 @@ void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num
     const Type &t = block.getRelation().getAttributeType(term.attribute);
     // conjunctions chain the filter through their children (short-circuit)
     CheckStatus(qsx_select_cmp(t.id, block.stripe(term.attribute), n, static_cast<int>(term.comparison), &term.literal.v,
-                               first ? nullptr : static_cast<const std::uint64_t *>(current),
+                               first ? filter : static_cast<const std::uint64_t *>(current),
                                static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
                 "qsx_select_cmp");
     std::swap(current, next);
     first = false;
   }
-  if (first) {  // empty conjunction: every tuple matches
+  if (first) {  // empty conjunction: every tuple (of the filter) matches
     CheckStatus(qsx_memset_device(next, 0xFF, words * 8, CurrentStream()), "qsx_memset_device");
-    CheckStatus(qsx_bitmap_combine(0, static_cast<const std::uint64_t *>(next), static_cast<const std::uint64_t *>(next), n,
+    CheckStatus(qsx_bitmap_combine(0, static_cast<const std::uint64_t *>(next),
+                                   filter != nullptr ? filter : static_cast<const std::uint64_t *>(next), n,
                                    static_cast<std::uint64_t *>(current), CurrentStream()), "qsx_bitmap_combine");
     CheckStatus(qsx_bitmap_count(static_cast<const std::uint64_t *>(current), n, static_cast<std::int64_t *>(count),
                                  CurrentStream()), "qsx_bitmap_count");
@@ -302,10 +303,10 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
 
 AggregationOperationState::~AggregationOperationState() { qsx_agg_state_destroy(state_); }
 
-void AggregationOperationState::aggregateBlock(const StorageBlock &block) {
+void AggregationOperationState::aggregateBlock(const StorageBlock &block, const std::uint64_t *lip_filter) {
   const void *cols[QSX_MAX_COLUMNS];
   for (std::size_t i = 0; i < column_attr_.size(); ++i) cols[i] = block.stripe(column_attr_[i]);
-  CheckStatus(qsx_agg_update(state_, cols, block.numTuples(), nullptr, CurrentStream()), "qsx_agg_update");
+  CheckStatus(qsx_agg_update(state_, cols, block.numTuples(), lip_filter, CurrentStream()), "qsx_agg_update");
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
 }
 
@@ -332,6 +333,67 @@ QueryContext::~QueryContext() {
   for (auto &parts : join_tables_) {
     for (qsx_join_table_t *t : parts) qsx_join_table_destroy(t);
   }
+  for (qsx_lip_filter_t *f : lip_filters_) qsx_lip_filter_destroy(f);
+}
+QueryContext::lip_filter_id QueryContext::addLIPFilter(qsx_lip_kind_t kind, std::int64_t cardinality, std::int64_t min_value,
+                                                       bool is_anti) {
+  qsx_lip_filter_t *f = nullptr;
+  CheckStatus(qsx_lip_filter_create(kind, cardinality, min_value, is_anti ? 1 : 0, &f), "qsx_lip_filter_create");
+  lip_filters_.push_back(f);
+  return static_cast<lip_filter_id>(lip_filters_.size() - 1);
+}
+void QueryContext::destroyLIPFilter(lip_filter_id id) {
+  qsx_lip_filter_destroy(lip_filters_.at(id));
+  lip_filters_.at(id) = nullptr;
+}
+QueryContext::lip_deployment_id QueryContext::addLIPDeployment(LIPFilterDeployment deployment) {
+  lip_deployments_.push_back(std::move(deployment));
+  return static_cast<lip_deployment_id>(lip_deployments_.size() - 1);
+}
+
+// ---------------------------------------------------------------------------
+// LIP filter builder / prober
+// ---------------------------------------------------------------------------
+LIPFilterBuilder::LIPFilterBuilder(const QueryContext::LIPFilterDeployment &deployment, const QueryContext &query_context) {
+  for (const auto &e : deployment.build_entries) entries_.emplace_back(query_context.getLIPFilterMutable(e.lip_filter), e.attribute);
+}
+void LIPFilterBuilder::insertValueAccessor(const StorageBlock &block, const std::uint64_t *filter) const {
+  for (const auto &e : entries_) {
+    CheckStatus(qsx_lip_build(e.first, block.getRelation().getAttributeType(e.second).id, block.stripe(e.second),
+                              block.numTuples(), filter, CurrentStream()), "qsx_lip_build");
+  }
+}
+LIPFilterAdaptiveProber::LIPFilterAdaptiveProber(const QueryContext::LIPFilterDeployment &deployment,
+                                                 const QueryContext &query_context) {
+  for (const auto &e : deployment.probe_entries) entries_.emplace_back(query_context.getLIPFilterMutable(e.lip_filter), e.attribute);
+}
+void *LIPFilterAdaptiveProber::filterValueAccessor(const StorageBlock &block, const std::uint64_t *filter,
+                                                   std::int64_t *num_hits) const {
+  const std::int64_t n = block.numTuples();
+  const std::size_t bytes = static_cast<std::size_t>((n + 63) / 64) * 8 + 8;
+  void *current = nullptr, *next = nullptr;
+  CheckStatus(qsx_device_alloc(bytes, &current), "qsx_device_alloc(bitmap)");
+  CheckStatus(qsx_device_alloc(bytes, &next), "qsx_device_alloc(bitmap)");
+  DeviceBuffer count(8);
+  const std::uint64_t *in = filter;
+  for (const auto &e : entries_) {
+    CheckStatus(qsx_lip_probe(e.first, block.getRelation().getAttributeType(e.second).id, block.stripe(e.second), n, in,
+                              static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count.ptr), CurrentStream()),
+                "qsx_lip_probe");
+    std::swap(current, next);
+    in = static_cast<const std::uint64_t *>(current);
+  }
+  if (num_hits != nullptr) *num_hits = ReadCount(count.ptr);
+  qsx_device_free(next);
+  return current;
+}
+LIPFilterBuilder *CreateLIPFilterBuilderHelper(QueryContext::lip_deployment_id id, const QueryContext *query_context) {
+  const QueryContext::LIPFilterDeployment *d = query_context->getLIPDeployment(id);
+  return d == nullptr || d->build_entries.empty() ? nullptr : new LIPFilterBuilder(*d, *query_context);
+}
+LIPFilterAdaptiveProber *CreateLIPFilterAdaptiveProberHelper(QueryContext::lip_deployment_id id, const QueryContext *query_context) {
+  const QueryContext::LIPFilterDeployment *d = query_context->getLIPDeployment(id);
+  return d == nullptr || d->probe_entries.empty() ? nullptr : new LIPFilterAdaptiveProber(*d, *query_context);
 }
 QueryContext::predicate_id QueryContext::addPredicate(Predicate p) {
   predicates_.push_back(std::move(p));
@@ -423,7 +485,8 @@ bool SelectOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryConte
   std::lock_guard<std::mutex> lock(mutex_);
   while (num_workorders_generated_ < input_relation_block_ids_.size()) {
     container->addNormalWorkOrder(new SelectWorkOrder(query_id_, input_relation_block_ids_[num_workorders_generated_],
-                                                      predicate, simple_selection_, dest, storage_manager, on_gpu_),
+                                                      predicate, simple_selection_, dest, storage_manager, on_gpu_,
+                                                      CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context)),
                                   op_index_);
     ++num_workorders_generated_;
   }
@@ -439,7 +502,13 @@ void SelectWorkOrder::execute() {
   const std::int64_t n = block->numTuples();
   std::int64_t matches = 0;
   Predicate all;
-  void *bitmap = (predicate_ != nullptr ? predicate_ : &all)->getMatchesForBlock(*block, &matches);  // getMatchesForPredicate
+  // SelectOperator.cpp:161-195: predicate matches, then the LIP filters on what is left; the filters run
+  // first here and the predicate only evaluates their survivors (same conjunction)
+  void *lip = nullptr;
+  if (lip_filter_adaptive_prober_ != nullptr) lip = lip_filter_adaptive_prober_->filterValueAccessor(*block, nullptr, nullptr);
+  void *bitmap = (predicate_ != nullptr ? predicate_ : &all)
+                     ->getMatchesForBlock(*block, &matches, static_cast<const std::uint64_t *>(lip));  // getMatchesForPredicate
+  qsx_device_free(lip);
   block_id out_id;
   BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
   // block->selectSimple(simple_selection_, matches, output_destination_) (StorageBlock.cpp:390-399)
@@ -551,7 +620,8 @@ bool BuildHashOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCo
     while (input_.generated[part] < input_.ids[part].size()) {
       container->addNormalWorkOrder(new BuildHashWorkOrder(query_id_, input_relation_, join_key_attributes_,
                                                            input_.ids[part][input_.generated[part]], predicate, table,
-                                                           storage_manager, part),
+                                                           storage_manager, part,
+                                                           CreateLIPFilterBuilderHelper(lip_deployment_index_, query_context)),
                                     op_index_);
       ++input_.generated[part];
     }
@@ -599,6 +669,9 @@ void BuildHashWorkOrder::execute() {
   }
   // hash_table_->putValueAccessor[CompositeKey](accessor, key_attr(s), nullable, &TupleReferenceGenerator) (:192-203);
   // the stored reference is the relation-global row number of the tuple.
+  if (lip_filter_builder_ != nullptr) {
+    lip_filter_builder_->insertValueAccessor(*block, static_cast<const std::uint64_t *>(bitmap));  // :187-190
+  }
   JoinKeys keys(*block, join_key_attributes_);
   CheckStatus(qsx_join_build(hash_table_, keys.ptr, block->numTuples(),
                              static_cast<std::int32_t>(block->firstRow()), static_cast<const std::uint64_t *>(bitmap),
@@ -664,7 +737,8 @@ bool HashJoinOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCon
           new HashInnerJoinWorkOrder(query_id_, build_relation_, probe_relation_, join_key_attributes_, build_key_attributes_,
                                      probe_.ids[part][probe_.generated[part]],
                                      query_context->getPredicate(residual_predicate_index_), selection, is_selection_on_build_,
-                                     join_type_, table, dest, storage_manager, part),
+                                     join_type_, table, dest, storage_manager, part,
+                                     CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context)),
           op_index_);
       ++probe_.generated[part];
     }
@@ -724,6 +798,13 @@ void HashInnerJoinWorkOrder::execute() {
   JoinKeys keys(*probe, join_key_attributes_);
   DeviceBuffer count(8);
   const std::size_t bitmap_bytes = static_cast<std::size_t>((n + 63) / 64) * 8 + 8;
+  // existence_map of the LIPFilterAdaptiveProber (:462-470): the probe tuples this work order looks at
+  struct LipBitmap {
+    void *ptr = nullptr;
+    ~LipBitmap() { qsx_device_free(ptr); }
+  } lip_holder;
+  if (lip_filter_adaptive_prober_ != nullptr) lip_holder.ptr = lip_filter_adaptive_prober_->filterValueAccessor(*probe, nullptr, nullptr);
+  const std::uint64_t *lip = static_cast<const std::uint64_t *>(lip_holder.ptr);
   const bool pairs_needed = join_type_ == JoinType::kInnerJoin || join_type_ == JoinType::kLeftOuterJoin ||
                             residual_predicate_ != nullptr || !keys.exact;
 
@@ -731,12 +812,12 @@ void HashInnerJoinWorkOrder::execute() {
   std::unique_ptr<BuildSegments> build;
   if (pairs_needed) {
     // hash_table_.getAllFromValueAccessor[CompositeKey](accessor, key(s), nullable, &collector) (:480-485)
-    CheckStatus(qsx_join_probe_count(hash_table_, keys.ptr, n, nullptr, static_cast<std::int64_t *>(count.ptr), CurrentStream()),
+    CheckStatus(qsx_join_probe_count(hash_table_, keys.ptr, n, lip, static_cast<std::int64_t *>(count.ptr), CurrentStream()),
                 "qsx_join_probe_count");
     pairs.count = ReadCount(count.ptr);
     pairs.probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
     pairs.build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
-    CheckStatus(qsx_join_probe(hash_table_, keys.ptr, n, /*probe_base_tid=*/0, nullptr,
+    CheckStatus(qsx_join_probe(hash_table_, keys.ptr, n, /*probe_base_tid=*/0, lip,
                                static_cast<std::int32_t *>(pairs.probe_tids->ptr), static_cast<std::int32_t *>(pairs.build_tids->ptr),
                                pairs.count, static_cast<std::int64_t *>(count.ptr), CurrentStream()), "qsx_join_probe");
     build.reset(new BuildSegments(build_relation_, storage_manager_));
@@ -803,11 +884,15 @@ void HashInnerJoinWorkOrder::execute() {
       if (anti) {
         CheckStatus(qsx_bitmap_combine(3, static_cast<const std::uint64_t *>(bitmap.ptr), nullptr, n,
                                        static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_bitmap_combine");
+        if (lip != nullptr) {
+          CheckStatus(qsx_bitmap_combine(0, static_cast<const std::uint64_t *>(bitmap.ptr), lip, n,
+                                         static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_bitmap_combine");
+        }
       }
       CheckStatus(qsx_bitmap_count(static_cast<const std::uint64_t *>(bitmap.ptr), n, static_cast<std::int64_t *>(count.ptr),
                                    CurrentStream()), "qsx_bitmap_count");
     } else {
-      CheckStatus(qsx_join_probe_exists(hash_table_, keys.ptr, n, nullptr, anti ? 1 : 0,
+      CheckStatus(qsx_join_probe_exists(hash_table_, keys.ptr, n, lip, anti ? 1 : 0,
                                         static_cast<std::uint64_t *>(bitmap.ptr), static_cast<std::int64_t *>(count.ptr),
                                         CurrentStream()), "qsx_join_probe_exists");
     }
@@ -843,6 +928,10 @@ void HashInnerJoinWorkOrder::execute() {
                                    static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_tids_to_bitmap");
     CheckStatus(qsx_bitmap_combine(3, static_cast<const std::uint64_t *>(bitmap.ptr), nullptr, n,
                                    static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_bitmap_combine");
+    if (lip != nullptr) {
+      CheckStatus(qsx_bitmap_combine(0, static_cast<const std::uint64_t *>(bitmap.ptr), lip, n,
+                                     static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_bitmap_combine");
+    }
     unmatched_tids.reset(new DeviceBuffer(static_cast<std::size_t>(n) * 4 + 8));
     const std::size_t ws_bytes = qsx_compact_workspace_bytes(n);
     DeviceBuffer ws(ws_bytes);
@@ -900,13 +989,21 @@ class DestroyHashWorkOrder : public WorkOrder {
 class AggregationWorkOrder : public WorkOrder {
  public:
   AggregationWorkOrder(std::size_t query_id, block_id input_block_id, AggregationOperationState *state,
-                       StorageManager *storage_manager, partition_id part = 0)
-      : WorkOrder(query_id, part), input_block_id_(input_block_id), state_(state), storage_manager_(storage_manager) {}
-  void execute() override { state_->aggregateBlock(*storage_manager_->getBlock(input_block_id_)); }  // AggregationOperator.cpp:124-126
+                       StorageManager *storage_manager, partition_id part = 0, LIPFilterAdaptiveProber *prober = nullptr)
+      : WorkOrder(query_id, part), input_block_id_(input_block_id), state_(state), storage_manager_(storage_manager),
+        lip_filter_adaptive_prober_(prober) {}
+  void execute() override {  // AggregationOperator.cpp:124-126
+    BlockReference block = storage_manager_->getBlock(input_block_id_);
+    void *lip = nullptr;
+    if (lip_filter_adaptive_prober_ != nullptr) lip = lip_filter_adaptive_prober_->filterValueAccessor(*block, nullptr, nullptr);
+    state_->aggregateBlock(*block, static_cast<const std::uint64_t *>(lip));
+    qsx_device_free(lip);
+  }
  private:
   block_id input_block_id_;
   AggregationOperationState *state_;
   StorageManager *storage_manager_;
+  std::unique_ptr<LIPFilterAdaptiveProber> lip_filter_adaptive_prober_;
 };
 class FinalizeAggregationWorkOrder : public WorkOrder {
  public:
@@ -967,7 +1064,9 @@ bool AggregationOperator::getAllWorkOrders(WorkOrdersContainer *container, Query
     AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, part);
     while (input_.generated[part] < input_.ids[part].size()) {
       container->addNormalWorkOrder(new AggregationWorkOrder(query_id_, input_.ids[part][input_.generated[part]], state,
-                                                             storage_manager, part), op_index_);
+                                                             storage_manager, part,
+                                                             CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context)),
+                                    op_index_);
       ++input_.generated[part];
     }
   }

@@ -219,9 +219,9 @@ struct ComparisonPredicate {
 };
 struct Predicate {
   std::vector<ComparisonPredicate> conjuncts;
-  // TupleIdSequence of the matching tuples of `block` (StorageBlock::getMatchesForPredicate).
-  // Returns a device bitmap owned by the caller (qsx_device_free) and the match count.
-  void *getMatchesForBlock(const StorageBlock &block, std::int64_t *num_matches) const;
+  // TupleIdSequence of the matching tuples of `block` (StorageBlock::getMatchesForPredicate), restricted to
+  // `filter` when given.  Returns a device bitmap owned by the caller (qsx_device_free) and the match count.
+  void *getMatchesForBlock(const StorageBlock &block, std::int64_t *num_matches, const std::uint64_t *filter = nullptr) const;
 };
 
 // ---------------------------------------------------------------------------
@@ -265,7 +265,8 @@ class AggregationOperationState {
  public:
   explicit AggregationOperationState(const AggregationStateSpec &spec);
   ~AggregationOperationState();
-  void aggregateBlock(const StorageBlock &block);                       // :428-474
+  // :428-474; lip_filter = TupleIdSequence left by the LIPFilterAdaptiveProber (:440-460), or nullptr
+  void aggregateBlock(const StorageBlock &block, const std::uint64_t *lip_filter = nullptr);
   void finalizeAggregate(std::size_t partition, std::size_t num_partitions, InsertDestination *dest);  // :641-694
   const AggregationStateSpec &spec() const { return spec_; }
 
@@ -286,10 +287,27 @@ class QueryContext {
   typedef std::uint32_t join_hash_table_id;
   typedef std::uint32_t aggregation_state_id;
   typedef std::uint32_t insert_destination_id;
+  typedef std::uint32_t lip_filter_id;
+  typedef std::uint32_t lip_deployment_id;
+  static constexpr lip_deployment_id kInvalidLIPDeploymentId = static_cast<lip_deployment_id>(-1);
   static constexpr predicate_id kInvalidPredicateId = static_cast<predicate_id>(-1);
   static constexpr insert_destination_id kInvalidInsertDestinationId = static_cast<insert_destination_id>(-1);
 
   ~QueryContext();
+  // LIP filters and their deployments (QueryContext.hpp:338-395, utility/lip_filter/LIPFilterDeployment.hpp,
+  // LIPFilter.proto:24-63): a deployment names, for one operator, the filters it builds or probes and
+  // the attribute each one sees.
+  struct LIPFilterDeploymentEntry { lip_filter_id lip_filter; attribute_id attribute; };
+  struct LIPFilterDeployment {
+    std::vector<LIPFilterDeploymentEntry> build_entries, probe_entries;
+  };
+  lip_filter_id addLIPFilter(qsx_lip_kind_t kind, std::int64_t cardinality, std::int64_t min_value = 0, bool is_anti = false);
+  qsx_lip_filter_t *getLIPFilterMutable(lip_filter_id id) const { return lip_filters_.at(id); }
+  void destroyLIPFilter(lip_filter_id id);
+  lip_deployment_id addLIPDeployment(LIPFilterDeployment deployment);
+  const LIPFilterDeployment *getLIPDeployment(lip_deployment_id id) const {
+    return id == kInvalidLIPDeploymentId ? nullptr : &lip_deployments_.at(id);
+  }
   predicate_id addPredicate(Predicate p);
   scalar_group_id addScalarGroup(std::vector<attribute_id> attrs);  // attribute projections only
   // exact_key_range: exact min/max statistics of the build-side join attribute when the optimizer has them
@@ -324,11 +342,40 @@ class QueryContext {
  private:
   std::vector<Predicate> predicates_;
   std::vector<std::vector<attribute_id>> scalar_groups_;
+  std::vector<qsx_lip_filter_t *> lip_filters_;
+  std::vector<LIPFilterDeployment> lip_deployments_;
   std::vector<std::vector<qsx_join_table_t *>> join_tables_;
   std::vector<std::vector<attribute_id>> join_table_build_keys_;
   std::vector<std::vector<std::unique_ptr<AggregationOperationState>>> agg_states_;
   std::vector<std::unique_ptr<InsertDestination>> destinations_;
 };
+
+// LIPFilterBuilder (utility/lip_filter/LIPFilterBuilder.hpp): inserts the build attributes of a block
+// into the deployment's filters; owned by the work order that got it (BuildHashOperator.hpp:274).
+class LIPFilterBuilder {
+ public:
+  LIPFilterBuilder(const QueryContext::LIPFilterDeployment &deployment, const QueryContext &query_context);
+  // tuples of `block` selected by `filter` (nullptr = all)  (BuildHashOperator.cpp:187-190)
+  void insertValueAccessor(const StorageBlock &block, const std::uint64_t *filter) const;
+ private:
+  std::vector<std::pair<qsx_lip_filter_t *, attribute_id>> entries_;
+};
+// LIPFilterAdaptiveProber (utility/lip_filter/LIPFilterAdaptiveProber.hpp:60-243): the tuples of a block
+// that pass every probe filter of the deployment, as a TupleIdSequence.  The reference reorders the
+// filters by observed selectivity between batches; on the device every filter is one pass over a
+// column and the order does not change the result, so they run in deployment order.
+class LIPFilterAdaptiveProber {
+ public:
+  LIPFilterAdaptiveProber(const QueryContext::LIPFilterDeployment &deployment, const QueryContext &query_context);
+  // Returns a device bitmap owned by the caller (qsx_device_free): `filter` AND all probes.  (:83-90)
+  void *filterValueAccessor(const StorageBlock &block, const std::uint64_t *filter, std::int64_t *num_hits) const;
+ private:
+  std::vector<std::pair<qsx_lip_filter_t *, attribute_id>> entries_;
+};
+// CreateLIPFilter{Builder,AdaptiveProber}Helper (utility/lip_filter/LIPFilterUtil.hpp): nullptr without a
+// deployment or without entries of that kind.
+LIPFilterBuilder *CreateLIPFilterBuilderHelper(QueryContext::lip_deployment_id id, const QueryContext *query_context);
+LIPFilterAdaptiveProber *CreateLIPFilterAdaptiveProberHelper(QueryContext::lip_deployment_id id, const QueryContext *query_context);
 
 // ---------------------------------------------------------------------------
 // WorkOrder / container / RelationalOperator
@@ -380,6 +427,8 @@ class RelationalOperator {
     return QueryContext::kInvalidInsertDestinationId;
   }
   virtual relation_id getOutputRelationID() const { return -1; }
+  // RelationalOperator.hpp:294-297
+  void deployLIPFilters(const QueryContext::lip_deployment_id lip_deployment_index) { lip_deployment_index_ = lip_deployment_index; }
   void setOperatorIndex(std::size_t index) { op_index_ = index; }
   std::size_t getOperatorIndex() const { return op_index_; }
   std::size_t getQueryID() const { return query_id_; }
@@ -396,6 +445,7 @@ class RelationalOperator {
   const std::size_t output_num_partitions_;
   bool done_feeding_input_relation_ = false;
   std::size_t op_index_ = 0;
+  QueryContext::lip_deployment_id lip_deployment_index_ = QueryContext::kInvalidLIPDeploymentId;
 };
 
 // ---------------------------------------------------------------------------
@@ -437,9 +487,10 @@ class SelectWorkOrder : public WorkOrder {
  public:
   SelectWorkOrder(std::size_t query_id, block_id input_block_id, const Predicate *predicate,
                   const std::vector<attribute_id> &simple_selection, InsertDestination *output_destination,
-                  StorageManager *storage_manager, bool on_gpu)
+                  StorageManager *storage_manager, bool on_gpu, LIPFilterAdaptiveProber *lip_filter_adaptive_prober = nullptr)
       : WorkOrder(query_id), input_block_id_(input_block_id), predicate_(predicate), simple_selection_(simple_selection),
-        output_destination_(output_destination), storage_manager_(storage_manager), on_gpu_(on_gpu) {}
+        output_destination_(output_destination), storage_manager_(storage_manager), on_gpu_(on_gpu),
+        lip_filter_adaptive_prober_(lip_filter_adaptive_prober) {}
   void execute() override;  // SelectOperator.cpp:161-195
 
  private:
@@ -450,6 +501,7 @@ class SelectWorkOrder : public WorkOrder {
   InsertDestination *output_destination_;
   StorageManager *storage_manager_;
   const bool on_gpu_;
+  std::unique_ptr<LIPFilterAdaptiveProber> lip_filter_adaptive_prober_;  // SelectOperator.hpp:383
 };
 
 // ---------------------------------------------------------------------------
@@ -491,10 +543,10 @@ class BuildHashWorkOrder : public WorkOrder {
   BuildHashWorkOrder(std::size_t query_id, const CatalogRelation &input_relation,
                      const std::vector<attribute_id> &join_key_attributes, block_id build_block_id,
                      const Predicate *predicate, qsx_join_table_t *hash_table, StorageManager *storage_manager,
-                     partition_id part_id = 0)
+                     partition_id part_id = 0, LIPFilterBuilder *lip_filter_builder = nullptr)
       : WorkOrder(query_id, part_id), input_relation_(input_relation), join_key_attributes_(join_key_attributes),
         build_block_id_(build_block_id), predicate_(predicate), hash_table_(hash_table),
-        storage_manager_(storage_manager) {}
+        storage_manager_(storage_manager), lip_filter_builder_(lip_filter_builder) {}
   void execute() override;  // BuildHashOperator.cpp:162-207
 
  private:
@@ -504,6 +556,7 @@ class BuildHashWorkOrder : public WorkOrder {
   const Predicate *predicate_;
   qsx_join_table_t *hash_table_;
   StorageManager *storage_manager_;
+  std::unique_ptr<LIPFilterBuilder> lip_filter_builder_;  // BuildHashOperator.hpp:274
 };
 
 // ---------------------------------------------------------------------------
@@ -560,8 +613,10 @@ class HashInnerJoinWorkOrder : public WorkOrder {
                          block_id lookup_block_id, const Predicate *residual_predicate,
                          const std::vector<attribute_id> &selection, const std::vector<bool> &is_selection_on_build,
                          HashJoinOperator::JoinType join_type, qsx_join_table_t *hash_table,
-                         InsertDestination *output_destination, StorageManager *storage_manager, partition_id part_id = 0)
-      : WorkOrder(query_id, part_id), build_relation_(build_relation), probe_relation_(probe_relation),
+                         InsertDestination *output_destination, StorageManager *storage_manager, partition_id part_id = 0,
+                         LIPFilterAdaptiveProber *lip_filter_adaptive_prober = nullptr)
+      : WorkOrder(query_id, part_id), lip_filter_adaptive_prober_(lip_filter_adaptive_prober),
+        build_relation_(build_relation), probe_relation_(probe_relation),
         join_key_attributes_(join_key_attributes), build_key_attributes_(build_key_attributes),
         block_id_(lookup_block_id), residual_predicate_(residual_predicate),
         selection_(selection), is_selection_on_build_(is_selection_on_build), join_type_(join_type),
@@ -569,6 +624,7 @@ class HashInnerJoinWorkOrder : public WorkOrder {
   void execute() override;  // HashJoinOperator.cpp:450-541 (inner), :680-877 (semi / anti), :960-1099 (outer)
 
  private:
+  std::unique_ptr<LIPFilterAdaptiveProber> lip_filter_adaptive_prober_;
   const CatalogRelation &build_relation_;
   const CatalogRelation &probe_relation_;
   const std::vector<attribute_id> &join_key_attributes_;

@@ -12,7 +12,8 @@ BIN = os.path.join(ROOT, "tests", "cpp", "bin")
 
 def _ensure_built():
     if not all(os.path.exists(os.path.join(BIN, b)) for b in
-               ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test")):
+               ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
+                "lip_filter_operator_test")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -46,3 +47,10 @@ def test_hash_join_operator_unittest_mirror():
 @pytest.mark.gpu
 def test_aggregation_operator_unittest_mirror():
     _run("aggregation_operator_test")
+
+
+@pytest.mark.gpu
+def test_lip_filter_deployments_through_the_operators():
+    """LIP.test data (R even, S multiples of 3): BuildHash builds the filter, Select / Aggregation /
+    HashJoin(semi) probe it — sync driver and Foreman/Worker, exact and identity-hash filters."""
+    _run("lip_filter_operator_test")
