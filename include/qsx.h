@@ -303,7 +303,9 @@ typedef enum qsx_agg_strategy {
 typedef enum qsx_agg_fn {
   QSX_AGG_COUNT_STAR = 0, /* COUNT(*)            -> int64 */
   QSX_AGG_SUM = 1,        /* SUM(int|long) -> int64 ; SUM(float|double|expr) -> double */
-  QSX_AGG_AVG = 2         /* sum / (double)count -> double (AggregationHandleAvg.cpp:144-155) */
+  QSX_AGG_AVG = 2,        /* sum / (double)count -> double (AggregationHandleAvg.cpp:144-155) */
+  QSX_AGG_MIN = 3,        /* AggregationHandleMin.cpp:45-120: result has the argument's type   */
+  QSX_AGG_MAX = 4         /* AggregationHandleMax.cpp:45-120  (DOUBLE for an expression)       */
 } qsx_agg_fn_t;
 
 /* Operand of an expression instruction or an aggregate argument. */
@@ -418,8 +420,9 @@ int qsx_agg_num_groups(qsx_agg_state_t *state, int64_t *out_groups, qsx_stream_t
 
 /* K10.  Emit one row per group of finalize-partition `partition` of
  * `num_partitions`: key columns (width = the key column's width) and one
- * value column per aggregate (int64 for COUNT and SUM over INT/LONG, double
- * otherwise).  Replaces AggregationOperationState::finalizeAggregate
+ * value column per aggregate (int64 for COUNT and SUM over INT/LONG, double for
+ * the other SUMs and AVG; a MIN/MAX column has the argument's own type and
+ * width, DOUBLE for an expression).  Replaces AggregationOperationState::finalizeAggregate
  * (storage/AggregationOperationState.cpp:641-948), incl.
  * CollisionFreeVectorTable::finalizeKey/finalizeState (.hpp:647-727; ascending
  * key order, partition = contiguous key range) and

@@ -325,7 +325,7 @@ class AggState:
             keys.append(np.zeros(cap, dtype={1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}[w]))
         vals, nulls = [], []
         for a in range(cfg.num_aggs):
-            vals.append(np.zeros(cap, dtype=np.int64 if T.agg_output_is_int(cfg, a) else np.float64))
+            vals.append(np.zeros(cap, dtype=np.dtype(T.agg_output_dtype(cfg, a))))
             nulls.append(np.zeros(cap, dtype=np.uint8))
         rows = _lib.qso_agg_finalize(self._h, partition, num_partitions, _ptr_array(keys), _ptr_array(vals),
                                      _ptr_array(nulls), cap)

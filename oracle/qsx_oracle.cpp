@@ -590,8 +590,12 @@ struct StateLayout {
   // SUM -> 1 (int64 for INT/LONG arguments, double otherwise:
   // expressions/aggregation/AggregationHandleSum.cpp:45-80); AVG -> sum + count
   // (AggregationHandleAvg.cpp:45-93).
+  // MIN / MAX -> current extremum + "has a value" (the reference keeps a nullable TypedValue and
+  // compares with the type's less / greater comparator: AggregationHandleMin.hpp:190-215,
+  // AggregationHandleMax.hpp:190-215).
   int num_states = 0;
   bool state_is_int[2 * QSX_MAX_AGGS];
+  int state_op[2 * QSX_MAX_AGGS];     // 0 add, 1 min, 2 max; a min/max word is followed by its has-value word
   int agg_first_state[QSX_MAX_AGGS];
   bool agg_arg_is_int[QSX_MAX_AGGS];
 };
@@ -603,6 +607,7 @@ bool operand_is_int_column(const qsx_agg_config_t &c, const qsx_operand_t &o) {
 
 StateLayout make_layout(const qsx_agg_config_t &c) {
   StateLayout L;
+  for (int s = 0; s < 2 * QSX_MAX_AGGS; ++s) L.state_op[s] = 0;
   for (int a = 0; a < c.num_aggs; ++a) {
     L.agg_first_state[a] = L.num_states;
     const bool is_int = c.aggs[a].fn != QSX_AGG_COUNT_STAR && operand_is_int_column(c, c.aggs[a].arg);
@@ -617,6 +622,12 @@ StateLayout make_layout(const qsx_agg_config_t &c) {
       case QSX_AGG_AVG:
         L.state_is_int[L.num_states++] = is_int;
         L.state_is_int[L.num_states++] = true;
+        break;
+      case QSX_AGG_MIN:
+      case QSX_AGG_MAX:
+        L.state_op[L.num_states] = c.aggs[a].fn == QSX_AGG_MIN ? 1 : 2;
+        L.state_is_int[L.num_states++] = is_int;
+        L.state_is_int[L.num_states++] = true;   // has-value flag (adds like a count)
         break;
       default: std::abort();
     }
@@ -734,14 +745,42 @@ inline void accumulate(const qsx_agg_config_t &c, const StateLayout &L, const Ro
         }
         if (c.aggs[a].fn == QSX_AGG_AVG) s[1].i += 1;
         break;
+      case QSX_AGG_MIN:
+      case QSX_AGG_MAX: {
+        // iterateUnaryInl: take the value when the state is NULL or the value compares less / greater
+        const bool want_less = c.aggs[a].fn == QSX_AGG_MIN;
+        if (L.agg_arg_is_int[a]) {
+          const std::int64_t v = rr.col_as_int(c.aggs[a].arg.index, i);
+          if (s[1].i == 0 || (want_less ? v < s[0].i : v > s[0].i)) s[0].i = v;
+        } else {
+          const double v = rr.operand(c.aggs[a].arg, i);
+          if (s[1].i == 0 || (want_less ? v < s[0].d : v > s[0].d)) s[0].d = v;
+        }
+        s[1].i += 1;
+        break;
+      }
     }
   }
 }
 
-inline void merge_words(const StateLayout &L, StateWord *dst, const StateWord *src) {
-  for (int s = 0; s < L.num_states; ++s) {
+// dst (op)= src for one state word; min/max words come with their has-value word at s + 1.
+inline void merge_word(const StateLayout &L, int s, StateWord *dst, const StateWord *src) {
+  if (L.state_op[s] == 0) {
     if (L.state_is_int[s]) dst[s].i += src[s].i; else dst[s].d += src[s].d;
+    return;
   }
+  if (src[s + 1].i == 0) return;   // mergeStates: a NULL source state changes nothing
+  const bool want_less = L.state_op[s] == 1;
+  if (L.state_is_int[s]) {
+    if (dst[s + 1].i == 0 || (want_less ? src[s].i < dst[s].i : src[s].i > dst[s].i)) dst[s].i = src[s].i;
+  } else {
+    if (dst[s + 1].i == 0 || (want_less ? src[s].d < dst[s].d : src[s].d > dst[s].d)) dst[s].d = src[s].d;
+  }
+}
+inline void merge_words(const StateLayout &L, StateWord *dst, const StateWord *src) {
+  // extrema first: they look at dst's has-value word before the add below changes it
+  for (int s = 0; s < L.num_states; ++s) if (L.state_op[s] != 0) merge_word(L, s, dst, src);
+  for (int s = 0; s < L.num_states; ++s) if (L.state_op[s] == 0) merge_word(L, s, dst, src);
 }
 
 }  // namespace
@@ -832,11 +871,14 @@ struct qso_agg_state {
         break;
       case QSX_AGG_COLLISION_FREE:
         for (std::size_t w = 0; w < existence.size(); ++w) existence[w] |= src.existence[w];
-        for (int s = 0; s < L.num_states; ++s) {
-          for (std::int64_t k = 0; k < c.num_entries; ++k) {
-            const std::size_t p = static_cast<std::size_t>(s) * c.num_entries + k;
-            if (L.state_is_int[s]) dense[p].i += src.dense[p].i; else dense[p].d += src.dense[p].d;
+        for (std::int64_t k = 0; k < c.num_entries; ++k) {
+          StateWord d[2 * QSX_MAX_AGGS], r[2 * QSX_MAX_AGGS];
+          for (int s = 0; s < L.num_states; ++s) {
+            d[s] = dense[static_cast<std::size_t>(s) * c.num_entries + k];
+            r[s] = src.dense[static_cast<std::size_t>(s) * c.num_entries + k];
           }
+          merge_words(L, d, r);
+          for (int s = 0; s < L.num_states; ++s) dense[static_cast<std::size_t>(s) * c.num_entries + k] = d[s];
         }
         break;
       default:
@@ -874,6 +916,20 @@ void emit_values(const qsx_agg_config_t &c, const StateLayout &L, const StateWor
         const double sum = L.agg_arg_is_int[a] ? static_cast<double>(s[0].i) : s[0].d;
         is_null = (s[1].i == 0);
         static_cast<double *>(out_val_cols[a])[row] = is_null ? 0.0 : sum / static_cast<double>(s[1].i);
+        break;
+      }
+      case QSX_AGG_MIN:
+      case QSX_AGG_MAX: {
+        // finalize: the extremum, typed like the argument; NULL when no value was seen
+        // (AggregationHandleMin.cpp:100-120)
+        is_null = (s[1].i == 0);
+        const int vt = c.aggs[a].arg.kind == QSX_OPD_COLUMN ? c.column_type[c.aggs[a].arg.index] : QSX_DOUBLE;
+        switch (vt) {
+          case QSX_INT: static_cast<std::int32_t *>(out_val_cols[a])[row] = is_null ? 0 : static_cast<std::int32_t>(s[0].i); break;
+          case QSX_LONG: static_cast<std::int64_t *>(out_val_cols[a])[row] = is_null ? 0 : s[0].i; break;
+          case QSX_FLOAT: static_cast<float *>(out_val_cols[a])[row] = is_null ? 0.0f : static_cast<float>(s[0].d); break;
+          default: static_cast<double *>(out_val_cols[a])[row] = is_null ? 0.0 : s[0].d; break;
+        }
         break;
       }
     }

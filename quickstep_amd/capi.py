@@ -388,7 +388,7 @@ class AggState:
             keys.append(torch.zeros(capacity, dtype=dt, device=device))
         vals, nulls = [], []
         for a in range(cfg.num_aggs):
-            dt = torch.int64 if T.agg_output_is_int(cfg, a) else torch.float64
+            dt = getattr(torch, T.agg_output_dtype(cfg, a))
             vals.append(torch.zeros(capacity, dtype=dt, device=device))
             nulls.append(torch.zeros(capacity, dtype=torch.uint8, device=device))
         groups = torch.zeros(1, dtype=torch.int64, device=device)

@@ -21,10 +21,25 @@ struct DevInstr {
   int dst;
   DevOperand a, b;
 };
+// How an accumulator word combines (state columns hold 8-byte words).  MIN/MAX always work on
+// int64: an INT/LONG argument as it is, a FLOAT/DOUBLE/expression argument through the
+// order-preserving map of ordered_from_double(), so that one ds_min_i64 / global_atomic_smin_x2
+// serves every type.
+enum AccKind { kAccSumF64 = 0, kAccSumI64 = 1, kAccMinI64 = 2, kAccMaxI64 = 3 };
+
 struct DevSum {
   DevOperand arg;
-  int is_int;  // accumulate as int64 (argument is an INT/LONG column)
+  int is_int;   // the argument is an INT/LONG column (read as integer)
+  int kind;     // AccKind
 };
+
+// double <-> int64 with the same ordering (IEEE sign-magnitude -> two's complement)
+__host__ __device__ constexpr long long ordered_from_bits(long long bits) {
+  return bits < 0 ? bits ^ 0x7FFFFFFFFFFFFFFFll : bits;
+}
+__host__ __device__ constexpr long long acc_identity(int kind) {
+  return kind == kAccMinI64 ? 0x7FFFFFFFFFFFFFFFll : (kind == kAccMaxI64 ? static_cast<long long>(0x8000000000000000ull) : 0ll);
+}
 struct DevPred {
   int column;
   int op;
@@ -184,18 +199,16 @@ __device__ __forceinline__ unsigned long long key_code(const DevConfig &c, int64
   return code;
 }
 
-// Value of sum j for this row as raw 64-bit accumulator increment.
-__device__ __forceinline__ unsigned long long sum_increment(const DevConfig &c, int j,
-                                                            const double (&t)[QSX_MAX_TEMPS], int64_t row) {
-  const DevSum s = c.sums[j];
-  if (s.is_int) return static_cast<unsigned long long>(column_as_int(c, s.arg.index, row));
-  return static_cast<unsigned long long>(__double_as_longlong(operand_value(c, s.arg, t, row)));
-}
-
-__device__ __forceinline__ unsigned long long acc_add(unsigned long long acc, unsigned long long inc, int is_int) {
-  if (is_int) return acc + inc;
-  return static_cast<unsigned long long>(__double_as_longlong(
-      __longlong_as_double(static_cast<long long>(acc)) + __longlong_as_double(static_cast<long long>(inc))));
+// Combine two accumulator words.
+__device__ __forceinline__ unsigned long long acc_combine(unsigned long long acc, unsigned long long inc, int kind) {
+  switch (kind) {
+    case kAccSumI64: return acc + inc;
+    case kAccMinI64: return static_cast<long long>(inc) < static_cast<long long>(acc) ? inc : acc;
+    case kAccMaxI64: return static_cast<long long>(inc) > static_cast<long long>(acc) ? inc : acc;
+    default:
+      return static_cast<unsigned long long>(__double_as_longlong(
+          __longlong_as_double(static_cast<long long>(acc)) + __longlong_as_double(static_cast<long long>(inc))));
+  }
 }
 
 __device__ __forceinline__ bool filter_bit(const uint64_t *filter, int64_t row) {
@@ -229,14 +242,20 @@ __device__ __forceinline__ unsigned long long global_find_or_insert(const HashTa
   return ~0ull;
 }
 
-__device__ __forceinline__ void global_add(const HashTableView &g, int col, unsigned long long slot,
-                                           unsigned long long inc, int is_int) {
-  unsigned long long *p = g.states + static_cast<unsigned long long>(col) * (g.cap + 1) + slot;
-  if (is_int) {
-    if (inc != 0) atomicAdd(p, inc);
-  } else {
-    atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
+// One 64-bit global atomic on an accumulator word.
+__device__ __forceinline__ void global_accumulate(unsigned long long *p, unsigned long long inc, int kind) {
+  switch (kind) {
+    case kAccSumI64:
+      if (inc != 0) atomicAdd(p, inc);
+      break;
+    case kAccMinI64: atomicMin(reinterpret_cast<long long *>(p), static_cast<long long>(inc)); break;
+    case kAccMaxI64: atomicMax(reinterpret_cast<long long *>(p), static_cast<long long>(inc)); break;
+    default: atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc))); break;
   }
+}
+__device__ __forceinline__ void global_add(const HashTableView &g, int col, unsigned long long slot,
+                                           unsigned long long inc, int kind) {
+  global_accumulate(g.states + static_cast<unsigned long long>(col) * (g.cap + 1) + slot, inc, kind);
 }
 
 // ---- LDS table ------------------------------------------------------------------
@@ -259,11 +278,12 @@ __device__ __forceinline__ int lds_find_or_insert(unsigned long long *l_keys, in
   return -1;
 }
 
-__device__ __forceinline__ void lds_add(unsigned long long *p, unsigned long long inc, int is_int) {
-  if (is_int) {
-    atomicAdd(p, inc);
-  } else {
-    unsafeAtomicAdd(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc)));
+__device__ __forceinline__ void lds_add(unsigned long long *p, unsigned long long inc, int kind) {
+  switch (kind) {
+    case kAccSumI64: atomicAdd(p, inc); break;
+    case kAccMinI64: atomicMin(reinterpret_cast<long long *>(p), static_cast<long long>(inc)); break;
+    case kAccMaxI64: atomicMax(reinterpret_cast<long long *>(p), static_cast<long long>(inc)); break;
+    default: unsafeAtomicAdd(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc))); break;
   }
 }
 

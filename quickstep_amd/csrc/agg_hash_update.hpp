@@ -261,6 +261,15 @@ __device__ __forceinline__ double segmented_run_sum_f64(int run_start, double v)
   }
   return v;
 }
+// Same scan with the accumulator's own combine (MIN / MAX / integer SUM); dead lanes carry the identity.
+__device__ __forceinline__ unsigned long long segmented_run_combine(int run_start, unsigned long long v, int kind) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned long long v2 = __shfl_up(v, off, kWave);
+    if (lane_id() - off >= run_start) v = acc_combine(v, v2, kind);
+  }
+  return v;
+}
 
 // Group of one row.  Every row gets an LDS accumulator index so that the
 // accumulate loop needs no branches: live rows whose group sits in the
@@ -282,7 +291,7 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
     const unsigned long long gs = global_find_or_insert(g, code);
     if (gs != ~0ull) {
       global_slot = static_cast<long long>(gs);
-      global_add(g, 0, gs, 1ull, 1);
+      global_add(g, 0, gs, 1ull, kAccSumI64);
     }
   }
 }
@@ -308,7 +317,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   const int lane_col = lane_id() & ((1 << rep_shift) - 1);
 
   for (int i = threadIdx.x; i < S; i += kABlock) l_keys[i] = kEmptyCode;
-  for (int i = threadIdx.x; i < (NS + 1) * plane; i += kABlock) l_acc[i] = 0;
+  for (int i = threadIdx.x; i < plane; i += kABlock) l_acc[i] = 0;  // row counts
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const unsigned long long identity = static_cast<unsigned long long>(acc_identity(c.sums[j].kind));
+    for (int i = threadIdx.x; i < plane; i += kABlock) l_acc[(j + 1) * plane + i] = identity;
+  }
 
   // nbuf == 2: the DMA of tile i+1 overlaps the compute of tile i inside the workgroup;
   // nbuf == 1: one buffer, overlap comes from the other workgroups resident on the CU.
@@ -454,32 +468,32 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         double x[V];
         operand_vec<V>(c, s.arg, temps, tile, x);
 #pragma unroll
-        for (int v = 0; v < V; ++v) inc[v] = static_cast<unsigned long long>(__double_as_longlong(x[v]));
+        for (int v = 0; v < V; ++v) {
+          const long long bits = __double_as_longlong(x[v]);
+          inc[v] = static_cast<unsigned long long>(s.kind >= kAccMinI64 ? ordered_from_bits(bits) : bits);
+        }
       }
       if constexpr (kDense) {
         unsigned long long *col = dense.states + static_cast<unsigned long long>((dense.has_count ? 1 : 0) + j) * dense.num_entries;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           unsigned long long run;
-          if (s.is_int) {
-            run = segmented_run_sum_u64(slot[v], live[v] ? inc[v] : 0ull);
-          } else {
+          if (s.kind == kAccSumF64) {
             run = static_cast<unsigned long long>(__double_as_longlong(segmented_run_sum_f64(
                 slot[v], live[v] ? __longlong_as_double(static_cast<long long>(inc[v])) : 0.0)));
+          } else {
+            run = segmented_run_combine(slot[v], live[v] ? inc[v] : static_cast<unsigned long long>(acc_identity(s.kind)), s.kind);
           }
-          if (run_tail[v]) {
-            if (s.is_int) atomicAdd(&col[global_slot[v]], run);
-            else atomic_add_f64(reinterpret_cast<double *>(&col[global_slot[v]]), __longlong_as_double(static_cast<long long>(run)));
-          }
+          if (run_tail[v]) global_accumulate(&col[global_slot[v]], run, s.kind);
         }
       } else {
         unsigned long long *acc_plane = l_acc + (j + 1) * plane;
 #pragma unroll
-        for (int v = 0; v < V; ++v) lds_add(&acc_plane[slot[v]], inc[v], s.is_int);  // unconditional (trash slot)
+        for (int v = 0; v < V; ++v) lds_add(&acc_plane[slot[v]], inc[v], s.kind);  // unconditional (trash slot)
         if (wave_has_global) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            if (global_slot[v] >= 0) global_add(g, j + 1, static_cast<unsigned long long>(global_slot[v]), inc[v], s.is_int);
+            if (global_slot[v] >= 0) global_add(g, j + 1, static_cast<unsigned long long>(global_slot[v]), inc[v], s.kind);
           }
         }
       }
@@ -499,19 +513,13 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     if (cnt == 0) continue;
     const unsigned long long gs = global_find_or_insert(g, code);
     if (gs == ~0ull) continue;
-    global_add(g, 0, gs, cnt, 1);
+    global_add(g, 0, gs, cnt, kAccSumI64);
     for (int j = 0; j < NS; ++j) {
       const unsigned long long *p = l_acc + (j + 1) * plane + (s << rep_shift);
-      unsigned long long v;
-      if (c.sums[j].is_int) {
-        v = 0;
-        for (int r = 0; r < rep; ++r) v += p[r];
-      } else {
-        double d = 0.0;
-        for (int r = 0; r < rep; ++r) d += __longlong_as_double(static_cast<long long>(p[r]));
-        v = static_cast<unsigned long long>(__double_as_longlong(d));
-      }
-      global_add(g, j + 1, gs, v, c.sums[j].is_int);
+      const int kind = c.sums[j].kind;
+      unsigned long long v = static_cast<unsigned long long>(acc_identity(kind));
+      for (int r = 0; r < rep; ++r) v = acc_combine(v, p[r], kind);
+      global_add(g, j + 1, gs, v, kind);
     }
   }
 }

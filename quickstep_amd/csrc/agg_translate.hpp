@@ -11,8 +11,9 @@ namespace qsx {
 struct FinalizeDesc {
   int num_aggs;
   int fn[QSX_MAX_AGGS];
-  int sum_col[QSX_MAX_AGGS];  // state column of the aggregate's sum (>= 1), 0 for COUNT(*)
-  int is_int[QSX_MAX_AGGS];
+  int sum_col[QSX_MAX_AGGS];  // state column of the aggregate's accumulator (>= 1), 0 for COUNT(*)
+  int is_int[QSX_MAX_AGGS];   // the accumulator word is a plain int64 (INT/LONG argument)
+  int val_type[QSX_MAX_AGGS]; // MIN/MAX: type of the output column (= the argument's; DOUBLE for expressions)
   int num_keys;
   int key_width[QSX_MAX_KEYS];
   int key_shift[QSX_MAX_KEYS];
@@ -28,7 +29,8 @@ struct Translated {
   FinalizeDesc fin;  // everything but the output pointers
   int num_sums;
   int num_cols;      // state columns in the image
-  unsigned int_col_mask;
+  int col_kind[QSX_MAX_AGGS + 1];  // AccKind of every state column (merge / all-reduce operator)
+  unsigned int_col_mask;           // columns that combine as integers (everything but kAccSumF64)
   unsigned used_columns;
   bool dense;
   bool dense_has_count;
@@ -131,20 +133,23 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
       f.sum_col[a] = 0;
       continue;
     }
-    if (ag.fn != QSX_AGG_SUM && ag.fn != QSX_AGG_AVG) return fail(t, QSX_ERR_UNSUPPORTED);
+    if (ag.fn != QSX_AGG_SUM && ag.fn != QSX_AGG_AVG && ag.fn != QSX_AGG_MIN && ag.fn != QSX_AGG_MAX) return fail(t, QSX_ERR_UNSUPPORTED);
     if (ag.arg.kind == QSX_OPD_CONST || !valid_operand(c, ag.arg, defined)) return fail(t, QSX_ERR_INVALID_ARGUMENT);
     if (ag.fn == QSX_AGG_AVG) needs_count = true;
     const bool is_int = ag.arg.kind == QSX_OPD_COLUMN &&
                         (c.column_type[ag.arg.index] == QSX_INT || c.column_type[ag.arg.index] == QSX_LONG);
     f.is_int[a] = is_int ? 1 : 0;
+    f.val_type[a] = ag.arg.kind == QSX_OPD_COLUMN ? c.column_type[ag.arg.index] : QSX_DOUBLE;
+    const int kind = ag.fn == QSX_AGG_MIN ? kAccMinI64 : (ag.fn == QSX_AGG_MAX ? kAccMaxI64 : (is_int ? kAccSumI64 : kAccSumF64));
     // SUM(x) and AVG(x) over the same argument share one accumulator (what
     // ReuseAggregateExpressions does on the optimizer side,
-    // query_optimizer/rules/ReuseAggregateExpressions.hpp:43-80).
+    // query_optimizer/rules/ReuseAggregateExpressions.hpp:43-80); so do repeated MIN(x) / MAX(x).
     int j = 0;
-    while (j < ns && !(d.sums[j].arg.kind == ag.arg.kind && d.sums[j].arg.index == ag.arg.index)) ++j;
+    while (j < ns && !(d.sums[j].arg.kind == ag.arg.kind && d.sums[j].arg.index == ag.arg.index && d.sums[j].kind == kind)) ++j;
     if (j == ns) {
       d.sums[ns].arg = DevOperand{ag.arg.kind, ag.arg.index};
       d.sums[ns].is_int = is_int ? 1 : 0;
+      d.sums[ns].kind = kind;
       ++ns;
     }
     f.sum_col[a] = j + 1;  // fixed up below for dense states without a count column
@@ -196,9 +201,13 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
   t.int_col_mask = 0;
   {
     int col = 0;
-    if (!t.dense || needs_count) t.int_col_mask |= 1u << col++;
+    if (!t.dense || needs_count) {
+      t.col_kind[col] = kAccSumI64;
+      t.int_col_mask |= 1u << col++;
+    }
     for (int j = 0; j < ns; ++j, ++col) {
-      if (d.sums[j].is_int) t.int_col_mask |= 1u << col;
+      t.col_kind[col] = d.sums[j].kind;
+      if (d.sums[j].kind != kAccSumF64) t.int_col_mask |= 1u << col;
     }
   }
   return t;

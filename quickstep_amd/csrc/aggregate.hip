@@ -49,13 +49,31 @@
 
 namespace qsx {
 
+// AccKind of every state column, by value into the kernels that combine whole columns.
+struct ColKinds {
+  int kind[QSX_MAX_AGGS + 1];
+};
+
+// Columns whose identity is not the all-zero word (MIN / MAX) are filled after the state's memset.
+__global__ __launch_bounds__(kABlock) void fill_identity_kernel(unsigned long long *__restrict__ states, long long col_stride,
+                                                               long long col_words, int num_cols, ColKinds kinds) {
+  for (int col = 0; col < num_cols; ++col) {
+    if (kinds.kind[col] < kAccMinI64) continue;
+    const unsigned long long identity = static_cast<unsigned long long>(acc_identity(kinds.kind[col]));
+    unsigned long long *p = states + static_cast<long long>(col) * col_stride;
+    for (long long i = static_cast<long long>(blockIdx.x) * kABlock + threadIdx.x; i < col_words;
+         i += static_cast<long long>(gridDim.x) * kABlock) {
+      p[i] = identity;
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------
 // merge of exported images
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kABlock) void merge_hash_kernel(const unsigned long long *__restrict__ image,
                                                             unsigned long long src_cap, int num_cols,
-                                                            unsigned int int_col_mask, HashTableView g) {
+                                                            ColKinds kinds, HashTableView g) {
   const unsigned long long *src_keys = image;
   const unsigned long long *src_states = image + (src_cap + 1);
   for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * kABlock + threadIdx.x;
@@ -67,8 +85,7 @@ __global__ __launch_bounds__(kABlock) void merge_hash_kernel(const unsigned long
     const unsigned long long gs = global_find_or_insert(g, code);
     if (gs == ~0ull) continue;
     for (int col = 0; col < num_cols; ++col) {
-      global_add(g, col, gs, src_states[static_cast<unsigned long long>(col) * (src_cap + 1) + i],
-                 (int_col_mask >> col) & 1u);
+      global_add(g, col, gs, src_states[static_cast<unsigned long long>(col) * (src_cap + 1) + i], kinds.kind[col]);
     }
   }
 }
@@ -76,21 +93,17 @@ __global__ __launch_bounds__(kABlock) void merge_hash_kernel(const unsigned long
 __global__ __launch_bounds__(kABlock) void merge_dense_kernel(const unsigned long long *__restrict__ image,
                                                              unsigned long long *__restrict__ dst,
                                                              long long exist_words, long long num_entries,
-                                                             int num_cols, unsigned int int_col_mask) {
+                                                             int num_cols, ColKinds kinds) {
   const long long total = exist_words + static_cast<long long>(num_cols) * num_entries;
   for (long long i = static_cast<long long>(blockIdx.x) * kABlock + threadIdx.x; i < total;
        i += static_cast<long long>(gridDim.x) * kABlock) {
     const unsigned long long v = image[i];
-    if (v == 0) continue;
     if (i < exist_words) {
-      atomicOr(&dst[i], v);
+      if (v != 0) atomicOr(&dst[i], v);
     } else {
-      const int col = static_cast<int>((i - exist_words) / num_entries);
-      if ((int_col_mask >> col) & 1u) {
-        atomicAdd(&dst[i], v);
-      } else {
-        atomic_add_f64(reinterpret_cast<double *>(&dst[i]), __longlong_as_double(static_cast<long long>(v)));
-      }
+      const int kind = kinds.kind[static_cast<int>((i - exist_words) / num_entries)];
+      if (v == static_cast<unsigned long long>(acc_identity(kind))) continue;
+      global_accumulate(&dst[i], v, kind);
     }
   }
 }
@@ -113,6 +126,20 @@ __device__ __forceinline__ void write_values(const FinalizeDesc &f, const unsign
         // int64 and double results are both stored as their 8 raw bytes
         static_cast<unsigned long long *>(f.out_vals[a])[out_row] = raw;
         is_null = empty_group;
+      } else if (f.fn[a] == QSX_AGG_MIN || f.fn[a] == QSX_AGG_MAX) {
+        // typed like the argument; the accumulator is the int value or the order-mapped double
+        is_null = empty_group;
+        const long long word = static_cast<long long>(raw);
+        switch (f.val_type[a]) {
+          case QSX_INT: static_cast<int32_t *>(f.out_vals[a])[out_row] = is_null ? 0 : static_cast<int32_t>(word); break;
+          case QSX_LONG: static_cast<long long *>(f.out_vals[a])[out_row] = is_null ? 0 : word; break;
+          case QSX_FLOAT:
+            static_cast<float *>(f.out_vals[a])[out_row] = is_null ? 0.0f : static_cast<float>(__longlong_as_double(ordered_from_bits(word)));
+            break;
+          default:
+            static_cast<double *>(f.out_vals[a])[out_row] = is_null ? 0.0 : __longlong_as_double(ordered_from_bits(word));
+            break;
+        }
       } else {
         const double sum = f.is_int[a] ? static_cast<double>(static_cast<long long>(raw))
                                        : __longlong_as_double(static_cast<long long>(raw));
@@ -324,6 +351,8 @@ struct qsx_agg_state {
   int num_sums = 0;
   int num_cols = 0;         // state columns in the image
   unsigned int int_col_mask = 0;
+  ColKinds col_kinds{};
+  bool has_min_max = false;  // some state column needs a non-zero identity
   bool dense = false;
   bool dense_has_count = false;
 
@@ -375,6 +404,10 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
   st->num_sums = t.num_sums;
   st->num_cols = t.num_cols;
   st->int_col_mask = t.int_col_mask;
+  for (int col = 0; col < t.num_cols; ++col) {
+    st->col_kinds.kind[col] = t.col_kind[col];
+    if (t.col_kind[col] >= kAccMinI64) st->has_min_max = true;
+  }
   st->used_columns = t.used_columns;
   st->dense = t.dense;
   st->dense_has_count = t.dense_has_count;
@@ -382,6 +415,17 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
 }
 
 static size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+
+// After the zeroing memset: MIN / MAX columns start from their identity.
+static int fill_identities(qsx_agg_state *st, hipStream_t stream) {
+  if (!st->has_min_max) return QSX_OK;
+  const long long words = st->dense ? st->config.num_entries : static_cast<long long>(st->cap + 1);
+  unsigned long long *states = st->dense ? st->image + st->exist_words : st->image + (st->cap + 1);
+  hipLaunchKernelGGL(fill_identity_kernel, dim3(grid_for(words, kABlock * 4)), dim3(kABlock), 0, stream, states, words, words,
+                     st->num_cols, st->col_kinds);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
 
 // Launch geometry of the hash-strategy update kernel; the environment overrides exist for
 // tuning sweeps on the GPU box (tools/agg_probe.py), the defaults are the measured best.
@@ -640,6 +684,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
       }
     }
   }
+  if (err == hipSuccess && fill_identities(st, nullptr) != QSX_OK) err = hipErrorUnknown;
   if (err == hipSuccess) err = hipDeviceSynchronize();
   if (err != hipSuccess) {
     set_last_error("qsx_agg_state_create", err);
@@ -674,7 +719,7 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
                                sizeof(unsigned long long) * (st->cap + 1) * st->num_cols, s));
   }
   QSX_HIP_TRY(hipMemsetAsync(st->control, 0, 4 * sizeof(unsigned long long), s));
-  return QSX_OK;
+  return fill_identities(st, s);
 }
 
 int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev,
@@ -727,10 +772,10 @@ int qsx_agg_state_import_merge(qsx_agg_state_t *dst, const void *image_dev, qsx_
     const long long total = dst->exist_words + static_cast<long long>(dst->num_cols) * dst->config.num_entries;
     hipLaunchKernelGGL(merge_dense_kernel, dim3(grid_for(total, kABlock * 4)), dim3(kABlock), 0, s, image,
                        dst->image, dst->exist_words, static_cast<long long>(dst->config.num_entries),
-                       dst->num_cols, dst->int_col_mask);
+                       dst->num_cols, dst->col_kinds);
   } else {
     hipLaunchKernelGGL(merge_hash_kernel, dim3(grid_for(dst->cap + 1, kABlock)), dim3(kABlock), 0, s, image,
-                       dst->cap, dst->num_cols, dst->int_col_mask, dst->hash_view());
+                       dst->cap, dst->num_cols, dst->col_kinds, dst->hash_view());
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;

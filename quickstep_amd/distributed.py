@@ -133,14 +133,18 @@ def merge_agg_state_images(ops, state, group=None):
     return state
 
 
-def allreduce_dense_agg_image(image, exist_words, num_entries, int_col_mask, num_cols, group=None):
+def allreduce_dense_agg_image(image, exist_words, num_entries, int_col_mask, num_cols, group=None, min_max_cols=None):
     """All-reduce a CollisionFreeVector state image in place: bit-OR for the
     existence words, integer SUM for count / integer columns, f64 SUM for the
-    rest.  image: int64[exist_words + num_cols * num_entries]."""
+    rest.  image: int64[exist_words + num_cols * num_entries].
+    min_max_cols: {column: "min" | "max"} for MIN / MAX accumulators — those columns hold int64 words
+    (the value itself or the order-preserving image of a double) and reduce with integer MIN / MAX."""
     dist.all_reduce(image[:exist_words], op=dist.ReduceOp.BOR, group=group)
     for col in range(num_cols):
         seg = image[exist_words + col * num_entries: exist_words + (col + 1) * num_entries]
-        if (int_col_mask >> col) & 1:
+        if min_max_cols and col in min_max_cols:
+            dist.all_reduce(seg, op=dist.ReduceOp.MIN if min_max_cols[col] == "min" else dist.ReduceOp.MAX, group=group)
+        elif (int_col_mask >> col) & 1:
             dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=group)
         else:
             dist.all_reduce(seg.view(torch.float64), op=dist.ReduceOp.SUM, group=group)

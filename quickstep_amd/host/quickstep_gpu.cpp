@@ -280,6 +280,8 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
       case AggregationID::kCount: config_.aggs[a].fn = QSX_AGG_COUNT_STAR; break;
       case AggregationID::kSum: config_.aggs[a].fn = QSX_AGG_SUM; break;
       case AggregationID::kAvg: config_.aggs[a].fn = QSX_AGG_AVG; break;
+      case AggregationID::kMin: config_.aggs[a].fn = QSX_AGG_MIN; break;
+      case AggregationID::kMax: config_.aggs[a].fn = QSX_AGG_MAX; break;
     }
     if (ag.function != AggregationID::kCount) {
       config_.aggs[a].arg.kind = QSX_OPD_COLUMN;

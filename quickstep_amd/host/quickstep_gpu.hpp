@@ -57,7 +57,7 @@ enum TypeID { kInt = 0, kLong = 1, kFloat = 2, kDouble = 3, kChar = 4 };
 // types/operations/comparisons/ComparisonID.hpp:36-42
 enum class ComparisonID { kEqual = 0, kNotEqual, kLess, kLessOrEqual, kGreater, kGreaterOrEqual };
 // expressions/aggregation/AggregationID.hpp
-enum class AggregationID { kCount, kSum, kAvg };
+enum class AggregationID { kCount, kSum, kAvg, kMin, kMax };
 
 struct Type {
   TypeID id;

@@ -13,7 +13,7 @@ EQ, NE, LT, LE, GT, GE = range(6)
 # qsx_agg_strategy_t
 AGG_SINGLE_STATE, AGG_COMPACT_KEY, AGG_COLLISION_FREE, AGG_GENERIC = range(4)
 # qsx_agg_fn_t
-AGG_COUNT_STAR, AGG_SUM, AGG_AVG = range(3)
+AGG_COUNT_STAR, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX = range(5)
 # qsx_operand_kind_t
 OPD_COLUMN, OPD_CONST, OPD_TEMP = range(3)
 # qsx_expr_op_t
@@ -128,6 +128,18 @@ def make_agg_config(strategy, columns, keys=(), instrs=(), consts=(), aggs=(), p
     cfg.est_groups = est_groups
     cfg.num_entries = num_entries
     return cfg
+
+
+def agg_output_dtype(cfg, a):
+    """numpy dtype name of the value column qsx_agg_finalize writes for aggregate `a`: int64 for COUNT
+    and SUM over INT/LONG, float64 for the other SUMs and AVG, the argument's own type for MIN/MAX."""
+    fn = cfg.aggs[a].fn
+    if fn in (AGG_MIN, AGG_MAX):
+        arg = cfg.aggs[a].arg
+        if arg.kind != OPD_COLUMN:
+            return "float64"
+        return {INT: "int32", LONG: "int64", FLOAT: "float32", DOUBLE: "float64"}[cfg.column_type[arg.index]]
+    return "int64" if agg_output_is_int(cfg, a) else "float64"
 
 
 def agg_output_is_int(cfg, a):

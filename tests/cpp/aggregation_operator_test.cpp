@@ -190,5 +190,44 @@ int main() {
       }
     }
   }
+  // ---- MIN / MAX (GroupBy_{Max,Min}_*: :1550-1680; ScalarAttribute_*_{Max,Min}_*: :675-712) ---------------------------
+  for (const bool with_predicate : {false, true}) {
+    Fixture f;
+    CatalogRelation result(104, "result");
+    result.addAttribute("GroupBy-0", Type::Int());
+    result.addAttribute("GroupBy-1", Type::Int());
+    result.addAttribute("max_int", Type::Int());       // MIN / MAX keep the argument's type
+    result.addAttribute("min_long", Type::Long());
+    result.addAttribute("max_float", Type::Float());
+    result.addAttribute("min_double", Type::Double());
+    QueryContext ctx;
+    Predicate pred;
+    pred.conjuncts.push_back({2, ComparisonID::kLess, TypedLiteral::Int(kGroupByWidth * (kGroupByRepeats >> 1))});
+    const auto pred_id = ctx.addPredicate(pred);
+    AggregationStateSpec spec;
+    spec.input_relation = &f.table;
+    spec.group_by = {0, 1};
+    spec.aggregates = {{AggregationID::kMax, 2}, {AggregationID::kMin, 3}, {AggregationID::kMax, 4}, {AggregationID::kMin, 5}};
+    spec.predicate = with_predicate ? ctx.getPredicate(pred_id) : nullptr;
+    spec.estimated_num_groups = kGroupByWidth;
+    const auto state = ctx.addAggregationState(spec);
+    const auto dest = ctx.addInsertDestination(&result, &f.storage);
+    AggregationOperator op(0, f.table, true, state);
+    FinalizeAggregationOperator fin(0, state, 1, false, 1, result, dest);
+    fetchAndExecuteWorkOrders(&op, &ctx, &f.storage);
+    fetchAndExecuteWorkOrders(&fin, &ctx, &f.storage);
+    std::size_t rows;
+    auto cols = readAll(ctx, dest, f.storage, result, &rows);
+    EXPECT_EQ(rows, static_cast<std::size_t>(kGroupByWidth));
+    const int repeats = with_predicate ? kGroupByRepeats >> 1 : kGroupByRepeats;
+    for (std::size_t i = 0; i < rows; ++i) {
+      const int gid = at<std::int32_t>(cols[0], i) + at<std::int32_t>(cols[1], i) * kGroupBy1Size;
+      const int max = kGroupByWidth * (repeats - 1) + gid;                  // :1555
+      EXPECT_EQ(at<std::int32_t>(cols[2], i), max);
+      EXPECT_EQ(at<std::int64_t>(cols[3], i), static_cast<std::int64_t>(gid));  // :1648
+      EXPECT_TRUE(at<float>(cols[4], i) == static_cast<float>(0.1 * max));
+      EXPECT_TRUE(at<double>(cols[5], i) == 0.1 * gid);
+    }
+  }
   return finish("aggregation_operator_test");
 }

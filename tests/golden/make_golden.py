@@ -131,7 +131,8 @@ for with_pred, repeats in (("without_predicate", 15), ("with_predicate", 15 >> 1
 dump("agg_unittest", {
     "source": [
         "relational_operators/tests/AggregationOperator_unittest.cpp:93-97 (sizes), :192-207 (row generator), "
-        ":215-219,:492,:539 (predicates), :571-602,:877-886 (scalar sums), :1349-1470 (group-by checks), "
+        ":215-219,:492,:539 (predicates), :571-602,:877-886 (scalar sums), :675-712,:807-864,:959-996 (scalar MIN/MAX), "
+        ":1349-1470 (group-by checks), :1550-1680 (group-by MIN/MAX checks), "
         ":585-587 (float tolerance 1e-5 relative)",
     ],
     "num_tuples": 300,
@@ -148,6 +149,18 @@ dump("agg_unittest", {
         "sum_int_with_predicate": summation(29),                # 435
         "count_with_predicate": 30,
         "zero_rows_predicate_less_than": -1,                    # SUM/AVG -> NULL, COUNT -> 0 (:1160-1345)
+        # MIN / MAX of the attribute (:675-712, :959-996); FloatType/DoubleType hold 0.1 * val
+        "max_no_predicate": 299, "max_with_predicate": 29, "min": 0,
+        # ... and of the expressions the reference tests build (:807-864): attr + attr, attr * attr
+        "max_expr_add_no_predicate": 2 * 299, "max_expr_mul_no_predicate": 299 * 299,
+    },
+    # GROUP BY MAX / MIN (:1550-1582, :1647-1680): max = 20 * (repeats - 1) + gid, min = gid, with
+    # repeats = 15 without and 15 >> 1 with the predicate; float/double columns 0.1 * that
+    "group_by_min_max": {
+        "without_predicate": {"max_int_per_group": [20 * (15 - 1) + g for g in range(20)],
+                              "min_int_per_group": list(range(20))},
+        "with_predicate": {"max_int_per_group": [20 * ((15 >> 1) - 1) + g for g in range(20)],
+                           "min_int_per_group": list(range(20))},
     },
     "group_by_predicate_less_than": 20 * (15 >> 1),             # IntType < 140
     "group_by": groupby,

@@ -328,3 +328,99 @@ def test_plan_shape_and_interpreter_agree(capi, oracle, dev):
         assert_same_groups(results[0], ref)
         assert_same_groups(results[1], ref)
         assert_same_groups(results[0], results[1])
+
+
+# ---- MIN / MAX (AggregationHandleMin/Max; AggregationOperator_unittest.cpp:675-712, :1550-1680) -----------------
+@pytest.mark.parametrize("with_pred", [False, True])
+def test_golden_scalar_min_max(capi, dev, golden, with_pred):
+    g = golden["agg_unittest"]
+    r = agg_rows(g)
+    e = g["scalar"]
+    cols = [r["i"], r["l"], r["f"], r["d"]]
+    aggs = []
+    for c in range(4):
+        aggs += [(T.AGG_MAX, T.col(c)), (T.AGG_MIN, T.col(c))]
+    cfg = T.make_agg_config(T.AGG_SINGLE_STATE, [(T.INT, None), (T.LONG, None), (T.FLOAT, None), (T.DOUBLE, None)], aggs=aggs,
+                            pred=[(0, T.LT, e["predicate_less_than"])] if with_pred else [])
+    st = run_hip(capi, dev, cfg, cols, blocks=30)
+    _, vals, nulls = finalize_np(st, dev)
+    mx = e["max_with_predicate"] if with_pred else e["max_no_predicate"]
+    assert [v.dtype for v in vals] == [np.int32, np.int32, np.int64, np.int64, np.float32, np.float32, np.float64, np.float64]
+    assert vals[0][0] == mx and vals[2][0] == mx and vals[1][0] == e["min"] and vals[3][0] == e["min"]
+    assert vals[4][0] == np.float32(0.1 * mx) and vals[6][0] == 0.1 * mx          # exactly the stored values
+    assert vals[5][0] == 0.0 and vals[7][0] == 0.0
+    assert not any(z[0] for z in nulls)
+
+
+def test_golden_scalar_min_max_of_expressions_and_zero_rows(capi, dev, golden):
+    g = golden["agg_unittest"]
+    r = agg_rows(g)
+    e = g["scalar"]
+    cfg = T.make_agg_config(T.AGG_SINGLE_STATE, [(T.INT, None)],
+                            instrs=[(T.EX_ADD, 0, T.col(0), T.col(0)), (T.EX_MUL, 1, T.col(0), T.col(0))],
+                            aggs=[(T.AGG_MAX, T.temp(0)), (T.AGG_MAX, T.temp(1)), (T.AGG_MIN, T.temp(0))])
+    _, vals, nulls = finalize_np(run_hip(capi, dev, cfg, [r["i"]], blocks=7), dev)
+    assert vals[0][0] == e["max_expr_add_no_predicate"] and vals[1][0] == e["max_expr_mul_no_predicate"] and vals[2][0] == 0.0
+    # no row passes: MIN / MAX are NULL like SUM (AggregationHandleMin.cpp:100-120)
+    cfg = T.make_agg_config(T.AGG_SINGLE_STATE, [(T.INT, None)], aggs=[(T.AGG_MAX, T.col(0)), (T.AGG_MIN, T.col(0)), (T.AGG_COUNT_STAR, None)],
+                            pred=[(0, T.LT, e["zero_rows_predicate_less_than"])])
+    _, vals, nulls = finalize_np(run_hip(capi, dev, cfg, [r["i"]]), dev)
+    assert nulls[0][0] == 1 and nulls[1][0] == 1 and vals[2][0] == 0
+
+
+@pytest.mark.parametrize("strategy", [T.AGG_COMPACT_KEY, T.AGG_GENERIC])
+@pytest.mark.parametrize("with_pred", [False, True])
+def test_golden_group_by_min_max(capi, dev, golden, strategy, with_pred):
+    g = golden["agg_unittest"]
+    r = agg_rows(g)
+    e = g["group_by_min_max"]["with_predicate" if with_pred else "without_predicate"]
+    cfg = T.make_agg_config(
+        strategy, [(T.INT, None), (T.INT, None), (T.INT, None), (T.DOUBLE, None), (T.FLOAT, None), (T.LONG, None)], keys=[0, 1],
+        aggs=[(T.AGG_MAX, T.col(2)), (T.AGG_MIN, T.col(2)), (T.AGG_MAX, T.col(3)), (T.AGG_MIN, T.col(3)),
+              (T.AGG_MAX, T.col(4)), (T.AGG_MIN, T.col(5)), (T.AGG_SUM, T.col(2))],
+        pred=[(2, T.LT, g["group_by_predicate_less_than"])] if with_pred else [], est_groups=20)
+    st = run_hip(capi, dev, cfg, [r["gb0"], r["gb1"], r["i"], r["d"], r["f"], r["l"]], blocks=30)
+    keys, vals, _ = finalize_np(st, dev)
+    order = np.argsort(keys[0] + keys[1] * g["group_by_1_size"])
+    mx, mn = np.array(e["max_int_per_group"]), np.array(e["min_int_per_group"])
+    assert vals[0][order].tolist() == mx.tolist() and vals[1][order].tolist() == mn.tolist()
+    assert np.array_equal(vals[2][order], 0.1 * mx) and np.array_equal(vals[3][order], 0.1 * mn)
+    assert np.array_equal(vals[4][order], (0.1 * mx).astype(np.float32)) and vals[5][order].tolist() == mn.tolist()
+
+
+@pytest.mark.parametrize("strategy,n_groups", [(T.AGG_COMPACT_KEY, 7), (T.AGG_GENERIC, 3000), (T.AGG_COLLISION_FREE, 40_000),
+                                                (T.AGG_SINGLE_STATE, 1)])
+def test_random_min_max_matches_oracle(capi, oracle, dev, strategy, n_groups):
+    """Negative values, -0.0 / +0.0, huge magnitudes, filters, merge of two partial states: MIN/MAX are
+    exact for every type (no rounding is involved), so everything compares bit for bit."""
+    rng = np.random.default_rng(n_groups)
+    n = 300_000
+    key = (np.sort(rng.integers(0, n_groups, size=n)) if strategy == T.AGG_COLLISION_FREE else rng.integers(0, n_groups, size=n)).astype(np.int32)
+    iv = rng.integers(-2**31, 2**31 - 1, size=n).astype(np.int32)
+    lv = rng.integers(-2**62, 2**62, size=n).astype(np.int64)
+    fv = rng.normal(size=n).astype(np.float32) * np.float32(1e20)
+    dv = rng.normal(size=n) * 1e-300
+    dv[::97] = 0.0
+    keys = [] if strategy == T.AGG_SINGLE_STATE else [0]
+    cfg = T.make_agg_config(strategy, [(T.INT, None), (T.INT, None), (T.LONG, None), (T.FLOAT, None), (T.DOUBLE, None)], keys=keys,
+                            instrs=[(T.EX_MUL, 0, T.col(4), T.col(3))],
+                            aggs=[(T.AGG_MIN, T.col(1)), (T.AGG_MAX, T.col(1)), (T.AGG_MIN, T.col(2)), (T.AGG_MAX, T.col(2)),
+                                  (T.AGG_MIN, T.col(3)), (T.AGG_MAX, T.col(4)), (T.AGG_MAX, T.temp(0)), (T.AGG_SUM, T.col(1))],
+                            est_groups=n_groups, num_entries=n_groups)
+    cols = [key, iv, lv, fv, dv]
+    f = oracle.bitmap_from_bools(rng.random(n) < 0.7)
+    half = n // 2
+    a = run_hip(capi, dev, cfg, [c[:half] for c in cols], filter_bitmap=oracle.bitmap_from_bools(oracle.bools_from_bitmap(f, n)[:half]))
+    b = run_hip(capi, dev, cfg, [c[half:] for c in cols], filter_bitmap=oracle.bitmap_from_bools(oracle.bools_from_bitmap(f, n)[half:]))
+    a.import_merge(b.export(dev))
+    o = oracle.AggState(cfg)
+    o.update(cols, filter_bitmap=f)
+    gk, gv, gn = finalize_np(a, dev)
+    rk, rv, rn = o.finalize()
+    go = np.argsort(gk[0], kind="stable") if gk else np.arange(1)
+    ro = np.argsort(rk[0], kind="stable") if rk else np.arange(1)
+    if gk:
+        assert np.array_equal(gk[0][go], rk[0][ro])
+    for x, y in zip(gv, rv):
+        assert x.dtype == y.dtype
+        assert np.array_equal(x[go], y[ro])

@@ -354,3 +354,37 @@ def test_composite_hash_is_the_combine_hashes_fold(oracle):
         h = oracle.combine_hashes(oracle.hash_scalar(T.LONG, a[i]), oracle.hash_scalar(T.INT, b[i]))
         h = oracle.combine_hashes(h, oracle.hash_scalar(T.LONG, c[i]))
         assert int(got[i]) == h
+
+
+def test_agg_unittest_min_max(oracle, golden):
+    """ScalarAttribute_*_{Max,Min}_* (:675-712, :959-996) and GroupBy_{Max,Min}_* (:1550-1680)."""
+    g = golden["agg_unittest"]
+    val = np.arange(g["num_tuples"])
+    gid = val % g["group_by_width"]
+    cols = [(gid % g["group_by_1_size"]).astype(np.int32), (gid // g["group_by_1_size"]).astype(np.int32),
+            val.astype(np.int32), 0.1 * val, (0.1 * val).astype(np.float32)]
+    layout = [(T.INT, None), (T.INT, None), (T.INT, None), (T.DOUBLE, None), (T.FLOAT, None)]
+    aggs = [(T.AGG_MAX, T.col(2)), (T.AGG_MIN, T.col(2)), (T.AGG_MAX, T.col(3)), (T.AGG_MAX, T.col(4))]
+    for with_pred in (False, True):
+        s = g["scalar"]
+        st = oracle.AggState(T.make_agg_config(T.AGG_SINGLE_STATE, layout, aggs=aggs,
+                                               pred=[(2, T.LT, s["predicate_less_than"])] if with_pred else []))
+        st.update(cols)
+        _, vals, nulls = st.finalize()
+        mx = s["max_with_predicate"] if with_pred else s["max_no_predicate"]
+        assert vals[0][0] == mx and vals[1][0] == s["min"] and vals[2][0] == 0.1 * mx and vals[3][0] == np.float32(0.1 * mx)
+        assert vals[0].dtype == np.int32 and vals[3].dtype == np.float32 and not any(z[0] for z in nulls)
+        e = g["group_by_min_max"]["with_predicate" if with_pred else "without_predicate"]
+        for strategy in (T.AGG_COMPACT_KEY, T.AGG_GENERIC):
+            st = oracle.AggState(T.make_agg_config(strategy, layout, keys=[0, 1], aggs=aggs, est_groups=20,
+                                                   pred=[(2, T.LT, g["group_by_predicate_less_than"])] if with_pred else []))
+            for b in range(0, val.size, 10):
+                st.update([c[b:b + 10] for c in cols])
+            keys, vals, _ = st.finalize()
+            order = np.argsort(keys[0] + keys[1] * g["group_by_1_size"])
+            assert vals[0][order].tolist() == e["max_int_per_group"] and vals[1][order].tolist() == e["min_int_per_group"]
+            assert np.array_equal(vals[2][order], 0.1 * np.array(e["max_int_per_group"]))
+    # zero rows: NULL
+    st = oracle.AggState(T.make_agg_config(T.AGG_SINGLE_STATE, layout, aggs=aggs, pred=[(2, T.LT, -1)]))
+    st.update(cols)
+    assert all(z[0] == 1 for z in st.finalize()[2])
