@@ -46,6 +46,27 @@ struct DevPred {
   unsigned long long literal;  // raw bits, typed like the column
 };
 
+// Interpreter plan (run-time configurations only; AOT plan shapes keep their temps in registers):
+// operands pre-resolved to LDS byte offsets so that an interpreted instruction is one scalar
+// decode + V ds_read_b64 per operand + V ds_write_b64, with no per-row type dispatch and no VGPR
+// array of temps (which capped the interpreter at V = 2 rows per thread).
+enum PlanMode { kPlanTileF64 = 0, kPlanTempF64 = 1, kPlanImm = 2, kPlanTileI32 = 3, kPlanTileI64 = 4, kPlanTileF32 = 5 };
+struct PlanOperand {
+  int mode;    // PlanMode
+  int off;     // byte offset inside the staged tile / the temps area
+  double imm;
+};
+struct PlanInstr {
+  int op;
+  int dst_off;  // byte offset of the result's slot in the temps area; -1: result never read
+  PlanOperand a, b;
+};
+struct PlanSum {
+  int is_int;   // integer column argument: read `width` bytes at tile + arg.off
+  int width;
+  PlanOperand arg;
+};
+
 struct DevConfig {
   int num_columns;
   int column_type[QSX_MAX_COLUMNS];
@@ -68,6 +89,10 @@ struct DevConfig {
   int lds_off[QSX_MAX_COLUMNS];
   int filter_lds_off;
   int tile_bytes;
+  // interpreter plan (plan_interpreter() in aggregate.hip); temps_bytes == 0 for AOT shapes
+  int temps_bytes;
+  PlanInstr plan_instrs[QSX_MAX_INSTRS];
+  PlanSum plan_sums[kMaxSums];
 };
 
 struct HashTableView {

@@ -162,11 +162,11 @@ __device__ __forceinline__ void temps_set(Temps<V> &s, int i, const double (&in)
 
 template <int V>
 __device__ __forceinline__ void operand_vec(const DevConfig &c, const DevOperand &o, const Temps<V> &s,
-                                            const char *tile, double (&out)[V]) {
+                                            const char *tile, int trow, double (&out)[V]) {
   switch (o.kind) {
     case QSX_OPD_COLUMN:
 #pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = tile_double(c, tile, o.index, threadIdx.x + v * kABlock);
+      for (int v = 0; v < V; ++v) out[v] = tile_double(c, tile, o.index, trow + v * kABlock);
       break;
     case QSX_OPD_CONST:
 #pragma unroll
@@ -178,14 +178,50 @@ __device__ __forceinline__ void operand_vec(const DevConfig &c, const DevOperand
   }
 }
 
+// Interpreter operand: everything is resolved to (mode, LDS byte offset | immediate).
+template <int V>
+__device__ __forceinline__ void plan_operand_vec(const PlanOperand &o, const char *tile, const char *temps, int trow,
+                                                 double (&out)[V]) {
+  switch (o.mode) {
+    case kPlanImm:
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = o.imm;
+      break;
+    case kPlanTileI32: {
+      const int32_t *p = reinterpret_cast<const int32_t *>(tile + o.off);
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = static_cast<double>(p[trow + v * kABlock]);
+      break;
+    }
+    case kPlanTileI64: {
+      const long long *p = reinterpret_cast<const long long *>(tile + o.off);
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = static_cast<double>(p[trow + v * kABlock]);
+      break;
+    }
+    case kPlanTileF32: {
+      const float *p = reinterpret_cast<const float *>(tile + o.off);
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = static_cast<double>(p[trow + v * kABlock]);
+      break;
+    }
+    default: {  // f64 column of the tile or f64 temp slot: same load, different base
+      const double *p = reinterpret_cast<const double *>((o.mode == kPlanTempF64 ? temps : tile) + o.off);
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = p[trow + v * kABlock];
+      break;
+    }
+  }
+}
+
 template <bool kStatic, int V>
-__device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *tile, bool (&live)[V]) {
+__device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *tile, int trow, bool (&live)[V]) {
   cfg_for<kStatic, QSX_MAX_PRED_TERMS>(c.num_pred, [&](int p) __attribute__((always_inline)) {
     const DevPred term = c.pred[p];
     const char *base = tile + c.lds_off[term.column];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int r = threadIdx.x + v * kABlock;
+      const int r = trow + v * kABlock;
       bool ok;
       switch (c.column_type[term.column]) {
         case QSX_INT:
@@ -210,14 +246,14 @@ __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *ti
 
 // Compact key codes of V rows (ThreadPrivateCompactKeyHashTable.cpp:216-232).
 template <bool kStatic, int V>
-__device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *tile, unsigned long long (&code)[V]) {
+__device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *tile, int trow, unsigned long long (&code)[V]) {
 #pragma unroll
   for (int v = 0; v < V; ++v) code[v] = 0;
   cfg_for<kStatic, QSX_MAX_KEYS>(c.num_keys, [&](int k) __attribute__((always_inline)) {
     const char *base = tile + c.lds_off[c.key_column[k]];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int r = threadIdx.x + v * kABlock;
+      const int r = trow + v * kABlock;
       unsigned long long x;
       switch (c.key_width[k]) {
         case 1: x = reinterpret_cast<const uint8_t *>(base)[r]; break;
@@ -296,7 +332,9 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
   }
 }
 
-// Dynamic LDS: tile[nbuf][tile_bytes] | l_keys[S] | l_acc[NS + 1][S * REP + 64]   (last 64 = trash columns)
+// Dynamic LDS: tile[nbuf][tile_bytes] | temps[temps_bytes] | l_keys[S] | l_acc[NS + 1][S * REP + 64]   (last 64 = trash columns)
+// temps = the interpreter's expression values, one f64 column of TR rows per live value (a thread only
+// ever touches its own rows, so no barrier separates the interpreted instructions).
 // l_acc holds, per accumulator plane and group slot, REP = 2^rep_shift partial
 // values; a lane adds into column (lane & (REP - 1)), so with REP = 64 every
 // lane owns its bank column and a wave's ds_add never conflicts (measured
@@ -311,7 +349,8 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int TR = kABlock * V;
   char *tiles = reinterpret_cast<char *>(smem_raw);
-  unsigned long long *l_keys = reinterpret_cast<unsigned long long *>(smem_raw + nbuf * c.tile_bytes);  // [S]
+  char *lds_temps = reinterpret_cast<char *>(smem_raw) + nbuf * c.tile_bytes;
+  unsigned long long *l_keys = reinterpret_cast<unsigned long long *>(smem_raw + nbuf * c.tile_bytes + c.temps_bytes);  // [S]
   unsigned long long *l_acc = l_keys + S;                                                           // [NS + 1][S << rep_shift]
   const int plane = (S << rep_shift) + kWave;  // + 64 trash columns
   const int lane_col = lane_id() & ((1 << rep_shift) - 1);
@@ -359,22 +398,29 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const int64_t row0 = tile_id * TR;
     const int rows = static_cast<int>(n - row0 < TR ? n - row0 : TR);
 
+    // This thread's first row of the tile.  Opaque to the optimizer on purpose: every LDS address of
+    // the tile loop is (uniform offset) + trow * width, all loop-invariant, and with the interpreter
+    // unrolled LICM would otherwise park one precomputed address per operand in VGPRs (256 VGPRs,
+    // occupancy 1); recomputing them costs one v_add / v_lshl_add per access.
+    int trow = threadIdx.x;
+    asm volatile("; per-tile row index" : "+v"(trow));
+
     // ---- which rows are live -------------------------------------------------
     bool live[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int r = threadIdx.x + v * kABlock;
+      const int r = trow + v * kABlock;
       live[v] = r < rows;
       if (c.filter_lds_off >= 0 && live[v]) {
         const uint64_t word = reinterpret_cast<const uint64_t *>(tile + c.filter_lds_off)[r >> 6];
         live[v] = msb_bit(word, r & 63);
       }
     }
-    predicate_vec<kStatic, V>(c, tile, live);
+    predicate_vec<kStatic, V>(c, tile, trow, live);
 
     // ---- group of every row ----------------------------------------------------
     unsigned long long code[V];
-    key_codes_vec<kStatic, V>(c, tile, code);
+    key_codes_vec<kStatic, V>(c, tile, trow, code);
     if (ranges > 1) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
@@ -389,7 +435,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         global_slot[v] = -1;
-        const long long loc = static_cast<long long>(tile_int(c, tile, c.key_column[0], threadIdx.x + v * kABlock));
+        const long long loc = static_cast<long long>(tile_int(c, tile, c.key_column[0], trow + v * kABlock));
         if (live[v] && (loc < 0 || loc >= dense.num_entries)) {
           atomicExch(dense.error, 1);  // precondition min >= 0, max < num_entries violated
           live[v] = false;
@@ -428,11 +474,43 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 
     // ---- expression program ------------------------------------------------------
     Temps<V> temps;
-    cfg_for<kStatic, QSX_MAX_INSTRS>(c.num_instrs, [&](int k) __attribute__((always_inline)) {
+    if constexpr (!kStatic) {
+      // interpreter: operands and results live in LDS (plan_instrs), nothing of the program in VGPRs
+      for (int k = 0; k < c.num_instrs; ++k) {
+        const PlanInstr in = c.plan_instrs[k];
+        double a[V], b[V], res[V];
+        plan_operand_vec<V>(in.a, tile, lds_temps, trow, a);
+        plan_operand_vec<V>(in.b, tile, lds_temps, trow, b);
+        switch (in.op) {
+          case QSX_EX_ADD:
+#pragma unroll
+            for (int v = 0; v < V; ++v) res[v] = a[v] + b[v];
+            break;
+          case QSX_EX_SUB:
+#pragma unroll
+            for (int v = 0; v < V; ++v) res[v] = a[v] - b[v];
+            break;
+          case QSX_EX_MUL:
+#pragma unroll
+            for (int v = 0; v < V; ++v) res[v] = a[v] * b[v];
+            break;
+          default:
+#pragma unroll
+            for (int v = 0; v < V; ++v) res[v] = a[v] / b[v];
+            break;
+        }
+        if (in.dst_off >= 0) {
+          double *dst = reinterpret_cast<double *>(lds_temps + in.dst_off);
+#pragma unroll
+          for (int v = 0; v < V; ++v) dst[trow + v * kABlock] = res[v];
+        }
+      }
+    }
+    cfg_for<kStatic, QSX_MAX_INSTRS>(kStatic ? c.num_instrs : 0, [&](int k) __attribute__((always_inline)) {
       const DevInstr in = c.instrs[k];
       double a[V], b[V], res[V];
-      operand_vec<V>(c, in.a, temps, tile, a);
-      operand_vec<V>(c, in.b, temps, tile, b);
+      operand_vec<V>(c, in.a, temps, tile, trow, a);
+      operand_vec<V>(c, in.b, temps, tile, trow, b);
       switch (in.op) {
         case QSX_EX_ADD:
 #pragma unroll
@@ -460,13 +538,28 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       const DevSum s = c.sums[j];
       unsigned long long inc[V];
       if (s.is_int) {
+        if constexpr (kStatic) {
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-          inc[v] = static_cast<unsigned long long>(tile_int(c, tile, s.arg.index, threadIdx.x + v * kABlock));
+          for (int v = 0; v < V; ++v) {
+            inc[v] = static_cast<unsigned long long>(tile_int(c, tile, s.arg.index, trow + v * kABlock));
+          }
+        } else {
+          const PlanSum ps = c.plan_sums[j];
+          const char *p = tile + ps.arg.off;
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const int r = trow + v * kABlock;
+            inc[v] = static_cast<unsigned long long>(ps.width == 4 ? static_cast<long long>(reinterpret_cast<const int32_t *>(p)[r])
+                                                                    : reinterpret_cast<const long long *>(p)[r]);
+          }
         }
       } else {
         double x[V];
-        operand_vec<V>(c, s.arg, temps, tile, x);
+        if constexpr (kStatic) {
+          operand_vec<V>(c, s.arg, temps, tile, trow, x);
+        } else {
+          plan_operand_vec<V>(c.plan_sums[j].arg, tile, lds_temps, trow, x);
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           const long long bits = __double_as_longlong(x[v]);

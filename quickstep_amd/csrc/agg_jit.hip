@@ -1,0 +1,207 @@
+// agg_jit.hip — see agg_jit.hpp.
+#include "agg_jit.hpp"
+
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+
+namespace qsx {
+
+struct JitKernel {
+  hipModule_t module = nullptr;
+  hipFunction_t function = nullptr;
+};
+
+namespace {
+
+const char *const kBundle =
+#include "jit_bundle.inc"
+    ;
+
+// hipRTC has the HIP device built-ins but no libc headers.
+const char *const kPrelude = R"(
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long int64_t;
+typedef unsigned long uint64_t;
+typedef unsigned long size_t;
+typedef unsigned long uintptr_t;
+)";
+
+void emit_operand(std::ostringstream &o, const char *lhs, const DevOperand &v) {
+  o << "  " << lhs << ".kind = " << v.kind << "; " << lhs << ".index = " << v.index << ";\n";
+}
+
+// The translated configuration as the body of a constexpr function (non-zero fields only; doubles as
+// hex-float literals so that they are bit-exact).
+std::string emit_dev_config(const DevConfig &d) {
+  std::ostringstream o;
+  char buf[64];
+  o << "  d.num_columns = " << d.num_columns << ";\n";
+  for (int i = 0; i < d.num_columns; ++i) {
+    o << "  d.column_type[" << i << "] = " << d.column_type[i] << "; d.column_width[" << i << "] = " << d.column_width[i]
+      << "; d.lds_off[" << i << "] = " << d.lds_off[i] << ";\n";
+  }
+  for (int i = d.num_columns; i < QSX_MAX_COLUMNS; ++i) o << "  d.lds_off[" << i << "] = -1;\n";
+  o << "  d.num_keys = " << d.num_keys << ";\n";
+  for (int k = 0; k < d.num_keys; ++k) {
+    o << "  d.key_column[" << k << "] = " << d.key_column[k] << "; d.key_width[" << k << "] = " << d.key_width[k]
+      << "; d.key_shift[" << k << "] = " << d.key_shift[k] << ";\n";
+  }
+  o << "  d.num_instrs = " << d.num_instrs << ";\n";
+  for (int k = 0; k < d.num_instrs; ++k) {
+    o << "  d.instrs[" << k << "].op = " << d.instrs[k].op << "; d.instrs[" << k << "].dst = " << d.instrs[k].dst << ";\n";
+    std::snprintf(buf, sizeof(buf), "d.instrs[%d].a", k);
+    emit_operand(o, buf, d.instrs[k].a);
+    std::snprintf(buf, sizeof(buf), "d.instrs[%d].b", k);
+    emit_operand(o, buf, d.instrs[k].b);
+  }
+  for (int k = 0; k < QSX_MAX_CONSTS; ++k) {
+    if (d.consts[k] == 0.0 && !std::signbit(d.consts[k])) continue;
+    if (d.consts[k] != d.consts[k] || d.consts[k] - d.consts[k] != 0.0) {   // NaN / inf have no literal
+      unsigned long long bits;
+      std::memcpy(&bits, &d.consts[k], 8);
+      o << "  d.consts[" << k << "] = __builtin_bit_cast(double, " << bits << "ull);\n";
+    } else {
+      std::snprintf(buf, sizeof(buf), "%a", d.consts[k]);
+      o << "  d.consts[" << k << "] = " << buf << ";\n";
+    }
+  }
+  o << "  d.num_sums = " << d.num_sums << ";\n";
+  for (int j = 0; j < d.num_sums; ++j) {
+    std::snprintf(buf, sizeof(buf), "d.sums[%d].arg", j);
+    emit_operand(o, buf, d.sums[j].arg);
+    o << "  d.sums[" << j << "].is_int = " << d.sums[j].is_int << "; d.sums[" << j << "].kind = " << d.sums[j].kind << ";\n";
+  }
+  o << "  d.num_pred = " << d.num_pred << ";\n";
+  for (int p = 0; p < d.num_pred; ++p) {
+    o << "  d.pred[" << p << "].column = " << d.pred[p].column << "; d.pred[" << p << "].op = " << d.pred[p].op << "; d.pred["
+      << p << "].literal = " << d.pred[p].literal << "ull;\n";
+  }
+  o << "  d.filter_lds_off = " << d.filter_lds_off << "; d.tile_bytes = " << d.tile_bytes << ";\n";
+  return o.str();
+}
+
+std::string make_source(const DevConfig &dev, int num_sums, bool dense) {
+  std::ostringstream o;
+  o << kPrelude << kBundle << "\nnamespace qsx {\nconstexpr DevConfig jit_make_dev() {\n  DevConfig d{};\n"
+    << emit_dev_config(dev) << "  return d;\n}\n"
+    << "extern \"C\" __global__ __launch_bounds__(" << kABlock << ") void qsx_jit_agg(ColumnPointers cols, int64_t n,\n"
+    << "    const uint64_t *filter, HashTableView g, DenseView dense, int S, int rep_shift, int nbuf, int ranges) {\n"
+    << "  static constexpr DevConfig D = jit_make_dev();\n"
+    << "  agg_hash_update_body<true, " << (dense ? "true" : "false") << ", " << num_sums << ", " << kJitRowsPerThread
+    << ">(D, cols.p, n, filter, g, dense, S, rep_shift, nbuf, ranges);\n}\n}  // namespace qsx\n";
+  return o.str();
+}
+
+bool jit_enabled() {
+  static const bool on = []() {
+    const char *e = getenv("QSX_AGG_JIT");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return on;
+}
+
+std::mutex g_mutex;
+std::map<std::string, JitKernel *> g_cache;   // by source text; nullptr = tried and failed
+
+JitKernel *compile(const std::string &source) {
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, source.c_str(), "qsx_jit_agg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return nullptr;
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics"};
+  const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t log_size = 0;
+    hiprtcGetProgramLogSize(prog, &log_size);
+    std::string log(log_size, '\0');
+    if (log_size != 0) hiprtcGetProgramLog(prog, &log[0]);
+    std::fprintf(stderr, "[qsx] run-time plan shape: hipRTC failed (%s); the interpreter kernel is used.\n%.2000s\n",
+                 hiprtcGetErrorString(rc), log.c_str());
+    hiprtcDestroyProgram(&prog);
+    return nullptr;
+  }
+  size_t code_size = 0;
+  hiprtcGetCodeSize(prog, &code_size);
+  std::string code(code_size, '\0');
+  hiprtcGetCode(prog, &code[0]);
+  hiprtcDestroyProgram(&prog);
+  JitKernel *k = new JitKernel();
+  if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
+      hipModuleGetFunction(&k->function, k->module, "qsx_jit_agg") != hipSuccess) {
+    (void)hipGetLastError();
+    std::fprintf(stderr, "[qsx] run-time plan shape: loading the code object failed; the interpreter kernel is used.\n");
+    delete k;
+    return nullptr;
+  }
+  // up to the CU's 160 KiB of dynamic LDS (same opt-in as the AOT kernels; harmless if the runtime ignores it)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k->function), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipGetLastError();
+  return k;
+}
+
+}  // namespace
+
+// Source text only (tests / offline inspection; needs no device).
+std::string jit_agg_source(const DevConfig &dev, int num_sums, bool dense) { return make_source(dev, num_sums, dense); }
+
+const JitKernel *jit_agg_kernel(const DevConfig &dev, int num_sums, bool dense, bool /*has_filter*/) {
+  if (!jit_enabled()) return nullptr;
+  const std::string source = make_source(dev, num_sums, dense);   // has_filter is part of dev (filter_lds_off)
+  std::lock_guard<std::mutex> lock(g_mutex);
+  auto it = g_cache.find(source);
+  if (it != g_cache.end()) return it->second;
+  JitKernel *k = compile(source);
+  g_cache.emplace(source, k);
+  return k;
+}
+
+int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols, int64_t n,
+                   const uint64_t *filter, const HashTableView &g, const DenseView &dense, int S, int rep_shift, int nbuf,
+                   int ranges) {
+  ColumnPointers a_cols = cols;
+  int64_t a_n = n;
+  const uint64_t *a_filter = filter;
+  HashTableView a_g = g;
+  DenseView a_dense = dense;
+  void *args[] = {&a_cols, &a_n, &a_filter, &a_g, &a_dense, &S, &rep_shift, &nbuf, &ranges};
+  QSX_HIP_TRY(hipModuleLaunchKernel(k->function, static_cast<unsigned>(grid), 1, 1, kABlock, 1, 1,
+                                    static_cast<unsigned>(lds_bytes), stream, args, nullptr));
+  return QSX_OK;
+}
+
+}  // namespace qsx
+
+// Test hook (not part of include/qsx.h): compiles the plan shape of a configuration with hipRTC and
+// reports whether that worked — runs without a GPU, so the CPU test suite covers the generator.
+extern "C" int qsx_debug_jit_compile(const qsx_agg_config_t *config, int with_filter, size_t *out_code_bytes) {
+  using namespace qsx;
+  if (config == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  Translated t = translate(*config);
+  if (t.status != QSX_OK) return t.status;
+  plan_tile(t.dev, t.used_columns, kABlock * kJitRowsPerThread, with_filter != 0);
+  const std::string source = jit_agg_source(t.dev, t.num_sums, t.dense);
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, source.c_str(), "qsx_jit_agg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return QSX_ERR_HIP;
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics"};
+  const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+  size_t code_size = 0;
+  if (rc == HIPRTC_SUCCESS) {
+    hiprtcGetCodeSize(prog, &code_size);
+  } else {
+    size_t log_size = 0;
+    hiprtcGetProgramLogSize(prog, &log_size);
+    std::string log(log_size, '\0');
+    if (log_size != 0) hiprtcGetProgramLog(prog, &log[0]);
+    std::fprintf(stderr, "%.4000s\n", log.c_str());
+  }
+  hiprtcDestroyProgram(&prog);
+  if (out_code_bytes != nullptr) *out_code_bytes = code_size;
+  return rc == HIPRTC_SUCCESS ? QSX_OK : QSX_ERR_HIP;
+}

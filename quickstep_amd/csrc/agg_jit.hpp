@@ -1,0 +1,37 @@
+// agg_jit.hpp — run-time plan shapes: the aggregation update kernel specialised for one
+// configuration with hipRTC when the state is created.
+//
+// The AOT plan shapes (agg_shapes.hpp) show what specialisation buys: with the translated
+// configuration a compile-time constant the interpreter folds away and the same kernel body runs
+// ~3x fewer instructions (Q1: 1.25 vs 3.3-3.7 ms / 200 M rows; the interpreter is bound by
+// instruction issue — 711 scalar instructions per 128-row wave tile — not by HBM).  A query
+// processor does not know its plans at build time, so the shape is compiled when the state is
+// created: the translated DevConfig is printed as a constexpr object into a ~30-line wrapper around
+// the bundled kernel sources (jit_bundle.inc) and built for gfx950 by hipRTC (2-3 s, cached per
+// process by source text).  The role of the reference's per-query code path selection
+// (AggregationOperationState's strategy dispatch) taken one step further; QSX_AGG_JIT=0 disables it,
+// any hipRTC failure falls back to the interpreter kernel (same body, same results).
+#ifndef QSX_CSRC_AGG_JIT_HPP_
+#define QSX_CSRC_AGG_JIT_HPP_
+
+#include "agg_common.hpp"
+#include "agg_hash_update.hpp"
+
+namespace qsx {
+
+struct JitKernel;
+
+// Specialised kernel for `dev` (translated configuration with its tile plan for 1024-row tiles
+// already filled in), or nullptr when run-time compilation is off or failed.
+const JitKernel *jit_agg_kernel(const DevConfig &dev, int num_sums, bool dense, bool has_filter);
+
+// Launches it: the argument list of agg_hash_update_body.
+int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols, int64_t n,
+                   const uint64_t *filter, const HashTableView &g, const DenseView &dense, int S, int rep_shift, int nbuf,
+                   int ranges);
+
+constexpr int kJitRowsPerThread = 4;
+
+}  // namespace qsx
+
+#endif  // QSX_CSRC_AGG_JIT_HPP_

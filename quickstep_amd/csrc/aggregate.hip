@@ -41,8 +41,10 @@
 #include "agg_translate.hpp"
 #include "agg_hash_update.hpp"
 #include "agg_shapes.hpp"
+#include "agg_jit.hpp"
 #include "scan.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -371,6 +373,13 @@ struct qsx_agg_state {
   int lds_ranges = 1;  // > 1: hash-range families of workgroups (agg_hash_update.hpp)
   unsigned used_columns = 0;
   const struct ShapeEntry *shape = nullptr;  // AOT plan shape matching this configuration, if any
+  // Run-time plan shapes (agg_jit.hpp), one per filter variant; compiled once the state has seen enough
+  // rows to pay for the 1-2 s of hipRTC.
+  std::mutex jit_mutex;
+  const JitKernel *jit[2] = {nullptr, nullptr};
+  bool jit_tried[2] = {false, false};
+  int jit_tile_bytes[2] = {0, 0};
+  std::atomic<long long> rows_seen{0};
 
   HashTableView hash_view() const {
     HashTableView g;
@@ -450,6 +459,86 @@ static const AggTuning &agg_tuning() {
   return t;
 }
 
+// Resolves the expression program and the aggregate arguments of a run-time configuration to LDS
+// offsets (PlanInstr / PlanSum) for tiles of `tile_rows` rows whose column offsets (lds_off) are set.
+// Temps get slots by liveness: a value's slot is free again after its last reader, and the reader
+// itself may reuse it for its result (a thread reads its rows before it writes them).
+static void plan_interpreter(DevConfig &dc, int tile_rows) {
+  auto resolve = [&](const DevOperand &o, const int (&slot_of_temp)[QSX_MAX_TEMPS]) {
+    PlanOperand p{};
+    switch (o.kind) {
+      case QSX_OPD_CONST:
+        p.mode = kPlanImm;
+        p.imm = dc.consts[o.index];
+        break;
+      case QSX_OPD_TEMP:
+        p.mode = kPlanTempF64;
+        p.off = slot_of_temp[o.index] * tile_rows * 8;
+        break;
+      default:
+        p.off = dc.lds_off[o.index];
+        switch (dc.column_type[o.index]) {
+          case QSX_INT: p.mode = kPlanTileI32; break;
+          case QSX_LONG: p.mode = kPlanTileI64; break;
+          case QSX_FLOAT: p.mode = kPlanTileF32; break;
+          default: p.mode = kPlanTileF64; break;
+        }
+        break;
+    }
+    return p;
+  };
+  const int n = dc.num_instrs;
+  // last reader of the value defined by instruction k (n = an aggregate argument reads it; -1 = nobody)
+  int last_use[QSX_MAX_INSTRS];
+  for (int k = 0; k < n; ++k) {
+    last_use[k] = -1;
+    const int temp = dc.instrs[k].dst;
+    for (int j = k + 1; j < n; ++j) {
+      if ((dc.instrs[j].a.kind == QSX_OPD_TEMP && dc.instrs[j].a.index == temp) ||
+          (dc.instrs[j].b.kind == QSX_OPD_TEMP && dc.instrs[j].b.index == temp)) {
+        last_use[k] = j;
+      }
+      if (dc.instrs[j].dst == temp) break;  // redefined: later readers see the new value
+    }
+    bool redefined = false;
+    for (int j = k + 1; j < n; ++j) redefined = redefined || dc.instrs[j].dst == temp;
+    if (!redefined) {
+      for (int j = 0; j < dc.num_sums; ++j) {
+        if (dc.sums[j].arg.kind == QSX_OPD_TEMP && dc.sums[j].arg.index == temp) last_use[k] = n;
+      }
+    }
+  }
+  int slot_of_temp[QSX_MAX_TEMPS];   // slot currently holding temp t
+  int slot_free_after[QSX_MAX_INSTRS];  // per slot: instruction index after which it is free (-1 = free)
+  int num_slots = 0;
+  for (int t = 0; t < QSX_MAX_TEMPS; ++t) slot_of_temp[t] = 0;
+  for (int k = 0; k < n; ++k) {
+    PlanInstr &pi = dc.plan_instrs[k];
+    pi.op = dc.instrs[k].op;
+    pi.a = resolve(dc.instrs[k].a, slot_of_temp);   // operands see the slots before this result is placed
+    pi.b = resolve(dc.instrs[k].b, slot_of_temp);
+    if (last_use[k] < 0) {
+      pi.dst_off = -1;
+      continue;
+    }
+    int slot = -1;
+    for (int s2 = 0; s2 < num_slots && slot < 0; ++s2) {
+      if (slot_free_after[s2] <= k) slot = s2;   // free, or its last reader is this very instruction
+    }
+    if (slot < 0) slot = num_slots++;
+    slot_free_after[slot] = last_use[k];
+    slot_of_temp[dc.instrs[k].dst] = slot;
+    pi.dst_off = slot * tile_rows * 8;
+  }
+  dc.temps_bytes = num_slots * tile_rows * 8;
+  for (int j = 0; j < dc.num_sums; ++j) {
+    PlanSum &ps = dc.plan_sums[j];
+    ps.is_int = dc.sums[j].is_int;
+    ps.arg = resolve(dc.sums[j].arg, slot_of_temp);
+    ps.width = dc.sums[j].arg.kind == QSX_OPD_COLUMN ? dc.column_width[dc.sums[j].arg.index] : 8;
+  }
+}
+
 // Lays the referenced columns of one TR-row tile out in LDS and launches the
 // update kernel with two tile buffers (DMA double buffering).
 template <int NS, int V>
@@ -472,12 +561,14 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   }
   if (off == 0) off = 16;
   dc.tile_bytes = static_cast<int>(off);
+  plan_interpreter(dc, TR);
   // replicate every accumulator as far as the budget allows (64 = one bank column per lane)
   const AggTuning &tune = agg_tuning();
   int rep_shift = 6;
   while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * S * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
   const int nbuf = tune.buffers;
-  const size_t lds = nbuf * off + sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep_shift) + kWave));
+  const size_t lds = nbuf * off + dc.temps_bytes +
+                     sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep_shift) + kWave));
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   if (dry_run) return QSX_OK;
@@ -567,6 +658,66 @@ static const ShapeEntry *find_shape(const qsx_agg_config_t &c) {
   return nullptr;
 }
 
+// ---- run-time plan shapes (agg_jit.hpp) ---------------------------------------------------------
+static long long jit_min_rows() {
+  const char *e = getenv("QSX_AGG_JIT_MIN_ROWS");   // read per call: tests switch it at run time
+  return e != nullptr ? atoll(e) : 16ll * 1024 * 1024;   // below this the interpreter costs less than the compile
+}
+
+// The specialised kernel of this state for the filter variant, compiling it on first use once the state
+// has aggregated jit_min_rows() rows; nullptr -> use the interpreter.
+static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, int64_t n) {
+  const long long seen = st->rows_seen.fetch_add(n) + n;
+  const int v = has_filter ? 1 : 0;
+  std::lock_guard<std::mutex> lock(st->jit_mutex);
+  if (!st->jit_tried[v]) {
+    if (seen < jit_min_rows()) return nullptr;
+    if (getenv("QSX_AGG_NO_SPECIALIZE") != nullptr && atoi(getenv("QSX_AGG_NO_SPECIALIZE")) != 0) {
+      st->jit_tried[v] = true;
+      return nullptr;
+    }
+    DevConfig dev = st->dev;
+    plan_tile(dev, st->used_columns, kABlock * kJitRowsPerThread, has_filter);
+    st->jit_tile_bytes[v] = dev.tile_bytes;
+    st->jit[v] = jit_agg_kernel(dev, st->num_sums, st->dense, has_filter);
+    st->jit_tried[v] = true;
+  }
+  return st->jit[v];
+}
+
+static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, const void *const *cols, int64_t n,
+                      const uint64_t *filter, hipStream_t stream) {
+  constexpr int TR = kABlock * kJitRowsPerThread;
+  constexpr size_t kMaxLds = 160 * 1024;
+  const int NS = st->num_sums;
+  const AggTuning &tune = agg_tuning();
+  int S = st->dense ? 8 : st->lds_slots, ranges = st->dense ? 1 : st->lds_ranges, rep_shift = 0, nbuf = 1;
+  size_t lds;
+  const int tile_bytes = st->jit_tile_bytes[has_filter ? 1 : 0];
+  if (st->dense) {
+    lds = static_cast<size_t>(tile_bytes) + sizeof(unsigned long long) * (8 + static_cast<size_t>(NS + 1) * (8 + kWave));
+  } else {
+    rep_shift = 6;
+    while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * S * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
+    nbuf = tune.buffers;
+    lds = static_cast<size_t>(nbuf) * tile_bytes +
+          sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep_shift) + kWave));
+  }
+  if (lds > kMaxLds) return QSX_ERR_CAPACITY;
+  int per_cu = static_cast<int>(kMaxLds / lds);
+  if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t num_tiles = (n + TR - 1) / TR;
+  const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
+  int grid = static_cast<int>(num_tiles * ranges < max_grid ? num_tiles * ranges : max_grid);
+  grid = grid / ranges * ranges;
+  if (grid < ranges) grid = ranges;
+  ColumnPointers cp;
+  for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < st->config.num_columns ? cols[i] : nullptr;
+  return jit_agg_launch(k, grid, lds, stream, cp, n, filter, st->dense ? HashTableView{} : st->hash_view(),
+                        st->dense ? st->dense_view() : DenseView{}, S, rep_shift, nbuf, ranges);
+}
+
 template <int NS>
 static int launch_hash(const DevConfig &dc, unsigned used_columns, int64_t n, const uint64_t *filter,
                        const HashTableView &g, int S, int ranges, hipStream_t stream) {
@@ -584,8 +735,10 @@ static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const ui
   constexpr int V = 4;
   constexpr int TR = kABlock * V;
   plan_tile(dc, used_columns, TR, filter != nullptr);
+  plan_interpreter(dc, TR);
   const int nbuf = 1;
-  const size_t lds = static_cast<size_t>(nbuf) * dc.tile_bytes + sizeof(unsigned long long) * (8 + static_cast<size_t>(NS + 1) * (8 + kWave));
+  const size_t lds = static_cast<size_t>(nbuf) * dc.tile_bytes + dc.temps_bytes +
+                     sizeof(unsigned long long) * (8 + static_cast<size_t>(NS + 1) * (8 + kWave));
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   static bool attribute_set = false;
@@ -730,6 +883,17 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
   DevConfig dc = st->dev;
   for (int i = 0; i < st->config.num_columns; ++i) dc.cols[i] = cols[i];
   hipStream_t s = as_stream(stream);
+  // specialised kernels first: AOT plan shape, then the run-time one; CAPACITY (the tile does not fit
+  // LDS next to the group tables) and compile failures fall through to the interpreter
+  const bool aot = !st->dense && st->shape != nullptr && filter_dev == nullptr;
+  const JitKernel *jk = aot ? nullptr : state_jit_kernel(st, filter_dev != nullptr, n);
+  if (jk != nullptr) {
+    int rc = launch_jit(st, jk, filter_dev != nullptr, cols, n, filter_dev, s);
+    if (rc == QSX_OK && hipGetLastError() == hipSuccess) return QSX_OK;
+    // the specialised kernel could not be launched: keep going with the interpreter from now on
+    std::lock_guard<std::mutex> lock(st->jit_mutex);
+    st->jit[filter_dev != nullptr ? 1 : 0] = nullptr;
+  }
   if (st->dense) {
     const DenseView d = st->dense_view();
     int rc = QSX_OK;
@@ -738,7 +902,7 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
   } else {
     const HashTableView g = st->hash_view();
     int rc = QSX_OK;
-    if (st->shape != nullptr && filter_dev == nullptr) {
+    if (aot) {
       rc = st->shape->launch(cols, st->config.num_columns, n, g, st->lds_slots, st->lds_ranges, s);
     } else {
       QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, st->lds_slots,

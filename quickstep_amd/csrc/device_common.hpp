@@ -1,0 +1,75 @@
+// device_common.hpp — device-side helpers shared by every kernel.  Kept free of host / libc++
+// includes on purpose: this file is also part of the source bundle the run-time plan-shape
+// compiler hands to hipRTC (agg_jit.hip), where only the HIP device built-ins exist.
+#ifndef QSX_CSRC_DEVICE_COMMON_HPP_
+#define QSX_CSRC_DEVICE_COMMON_HPP_
+
+namespace qsx {
+
+constexpr int kWave = 64;
+constexpr int kCUs = 256;            // MI355X
+constexpr int kMaxGridBlocks = 2048; // 8 x 256-thread blocks per CU: grid-stride above this
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// TupleIdSequence words are MSB-first (utility/BitVector.hpp:893-935); a wave
+// ballot is LSB-first (bit l = lane l).  One s_brev_b64 converts either way.
+__device__ __forceinline__ uint64_t msb_first(uint64_t ballot_mask) { return __brevll(ballot_mask); }
+
+// Bit of row (64*w + lane) in an MSB-first word.
+__device__ __forceinline__ bool msb_bit(uint64_t word, int lane) { return (word >> (63 - lane)) & 1u; }
+
+// Number of set bits of an LSB-first wave mask strictly below the calling lane
+// (v_mbcnt_lo/hi: no lane-id arithmetic needed).
+__device__ __forceinline__ int rank_below(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_add(T v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+__device__ __forceinline__ uint64_t wave_broadcast_first(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+template <typename T>
+__device__ __forceinline__ bool compare_op(T a, int op, T b) {
+  switch (op) {
+    case QSX_EQ: return a == b;
+    case QSX_NE: return a != b;
+    case QSX_LT: return a < b;
+    case QSX_LE: return a <= b;
+    case QSX_GT: return a > b;
+    default: return a >= b;
+  }
+}
+
+// Multiplicative (Fibonacci) hashes for the device tables.  Hash values never
+// show in results (only row order depends on them and that is unspecified,
+// relational_operators/tests/HashJoinOperator_unittest.cpp:480), so the device
+// tables are free not to use the reference's identity hash.
+__device__ __forceinline__ uint32_t mix32(uint32_t k) { return k * 0x9E3779B1u; }
+__device__ __forceinline__ uint64_t mix64(uint64_t k) {
+  k ^= k >> 32;
+  k *= 0x9E3779B97F4A7C15ull;
+  k ^= k >> 29;
+  return k;
+}
+
+// 64-bit global atomics (native on gfx950: global_atomic_add_x2 / _add_f64).
+__device__ __forceinline__ void atomic_add_i64(int64_t *p, int64_t v) {
+  atomicAdd(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(v));
+}
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+
+}  // namespace qsx
+
+#endif  // QSX_CSRC_DEVICE_COMMON_HPP_

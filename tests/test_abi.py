@@ -61,3 +61,22 @@ def test_product_code_never_touches_the_oracle():
                              text, flags=re.M):
                     bad.append(os.path.join(base, f))
     assert bad == []
+
+
+def test_run_time_plan_shape_generator_compiles_without_a_gpu(capi):
+    """csrc/agg_jit.hip: the source generator + hipRTC build of a plan shape (gfx950 code object) needs no
+    device, so the CPU suite covers it: hash, dense and filter variants, MIN/MAX, predicates."""
+    import ctypes as C
+    from quickstep_amd import types as T
+    fn = capi.lib.qsx_debug_jit_compile
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(T.AggConfig), C.c_int, C.POINTER(C.c_size_t)]
+    layout = [(T.INT, None), (T.LONG, None), (T.FLOAT, None), (T.DOUBLE, None)]
+    kw = dict(instrs=[(T.EX_MUL, 0, T.col(3), T.col(2)), (T.EX_DIV, 1, T.temp(0), T.const(0))], consts=[-0.75],
+              aggs=[(T.AGG_SUM, T.temp(1)), (T.AGG_MIN, T.col(2)), (T.AGG_MAX, T.col(1)), (T.AGG_AVG, T.col(0)), (T.AGG_COUNT_STAR, None)],
+              pred=[(1, T.GT, -5), (3, T.LE, 2.5)])
+    for cfg, with_filter in ((T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], **kw), 0),
+                             (T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], num_entries=100, **kw), 1)):
+        size = C.c_size_t(0)
+        assert fn(C.byref(cfg), with_filter, C.byref(size)) == 0
+        assert size.value > 1000

@@ -1,0 +1,79 @@
+"""Run-time plan shapes (csrc/agg_jit.hip): the aggregation kernel specialised by hipRTC for the state's
+configuration must give the interpreter's results — same body, configuration folded in — on every
+strategy, with filters, predicates, MIN/MAX, and when groups overflow LDS.  QSX_AGG_JIT_MIN_ROWS=0 makes
+the states compile on their first update (the default waits for 16 Mi rows)."""
+import os
+
+import numpy as np
+import pytest
+
+from quickstep_amd import types as T
+from helpers import bitmap_dev, to_dev
+from test_gpu_agg import FP_RTOL, assert_same_groups, finalize_np, q1_columns, q1_config, run_hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def jit_now(monkeypatch):
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0")
+    monkeypatch.delenv("QSX_AGG_NO_SPECIALIZE", raising=False)
+    monkeypatch.delenv("QSX_AGG_JIT", raising=False)
+
+
+def configs(rng, n):
+    key = rng.integers(0, 50, size=n).astype(np.int32)
+    key2 = rng.integers(0, 300, size=n).astype(np.int32)
+    iv = rng.integers(-1000, 1000, size=n).astype(np.int32)
+    lv = rng.integers(-2**40, 2**40, size=n).astype(np.int64)
+    fv = rng.normal(size=n).astype(np.float32)
+    dv = rng.uniform(900, 105000, size=n)
+    layout = [(T.INT, None), (T.INT, None), (T.INT, None), (T.LONG, None), (T.FLOAT, None), (T.DOUBLE, None)]
+    cols = [key, key2, iv, lv, fv, dv]
+    instrs = [(T.EX_MUL, 0, T.col(5), T.col(4)), (T.EX_ADD, 1, T.temp(0), T.col(2)), (T.EX_DIV, 2, T.temp(1), T.const(0)),
+              (T.EX_SUB, 0, T.temp(2), T.col(3))]                       # temp 0 is redefined on purpose
+    aggs = [(T.AGG_SUM, T.temp(0)), (T.AGG_MIN, T.col(4)), (T.AGG_MAX, T.temp(2)), (T.AGG_AVG, T.col(2)), (T.AGG_SUM, T.col(3)),
+            (T.AGG_COUNT_STAR, None), (T.AGG_MAX, T.col(3))]
+    kw = dict(instrs=instrs, consts=[3.0], aggs=aggs)
+    yield "compact 2 keys + predicate", T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0, 1], est_groups=15000,
+                                                          pred=[(2, T.GE, -900), (5, T.LT, 100000.0)], **kw), cols
+    yield "generic 15 k groups (LDS overflow / hash ranges)", T.make_agg_config(T.AGG_GENERIC, layout, keys=[1, 0], est_groups=15000, **kw), cols
+    yield "single state", T.make_agg_config(T.AGG_SINGLE_STATE, layout, **kw), cols
+    skey = np.sort(rng.integers(0, 5000, size=n)).astype(np.int32)
+    yield "collision free", T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], num_entries=5000, **kw), [skey] + cols[1:]
+    yield "q1 with date predicate", q1_config(with_date_pred=True), q1_columns(rng, n, with_date=True)
+
+
+@pytest.mark.parametrize("with_filter", [False, True])
+def test_run_time_plan_shapes_match_interpreter_and_oracle(capi, oracle, dev, jit_now, monkeypatch, with_filter):
+    rng = np.random.default_rng(77)
+    n = 400_003
+    for name, cfg, cols in configs(rng, n):
+        f = oracle.bitmap_from_bools(rng.random(n) < 0.6) if with_filter else None
+        jit = run_hip(capi, dev, cfg, cols, filter_bitmap=f)
+        got = finalize_np(jit, dev)
+        monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", str(1 << 60))           # this state: interpreter only
+        interp = finalize_np(run_hip(capi, dev, cfg, cols, filter_bitmap=f), dev)
+        monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0")
+        o = oracle.AggState(cfg)
+        o.update(cols, filter_bitmap=f)
+        ref = o.finalize()
+        assert_same_groups(got, ref), name
+        assert_same_groups(got, interp), name
+        # two more blocks through the (now cached) specialised kernel + a merge of partial states
+        again = run_hip(capi, dev, cfg, [c[: n // 2] for c in cols],
+                        filter_bitmap=None if f is None else oracle.bitmap_from_bools(oracle.bools_from_bitmap(f, n)[: n // 2]))
+        rest = run_hip(capi, dev, cfg, [c[n // 2:] for c in cols],
+                       filter_bitmap=None if f is None else oracle.bitmap_from_bools(oracle.bools_from_bitmap(f, n)[n // 2:]))
+        again.import_merge(rest.export(dev))
+        assert_same_groups(finalize_np(again, dev), ref), name
+
+
+def test_jit_disabled_by_environment_still_correct(capi, oracle, dev, monkeypatch):
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0")
+    monkeypatch.setenv("QSX_AGG_NO_SPECIALIZE", "1")
+    rng = np.random.default_rng(5)
+    name, cfg, cols = next(configs(rng, 50_000))
+    o = oracle.AggState(cfg)
+    o.update(cols)
+    assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols), dev), o.finalize())
