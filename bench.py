@@ -145,6 +145,10 @@ def main():
     ap.add_argument("--join-table", choices=["dense", "hashed"], default="dense",
                     help="dense: the build key (custkey) has exact min/max statistics -> directly addressed table "
                          "(qsx_join_table_create_dense); hashed: open-addressing table (qsx_join_table_create)")
+    ap.add_argument("--join-plan", choices=["auto", "shuffle", "broadcast"], default="auto",
+                    help="N > 1: shuffle = both sides repartitioned on the join key (K9 + RCCL all-to-all); broadcast = "
+                         "all-gather of the build side, probe rows stay where they are (the reference's broadcast join, "
+                         "BuildHashOperator.hpp:99,146-152); auto = broadcast while the gathered build side has <= 16 Mi rows")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -183,9 +187,15 @@ def main():
     main_stream = torch.cuda.current_stream()
     agg_stream = torch.cuda.Stream(device=dev) if distributed else main_stream
     dense = args.join_table == "dense"
+    plan = args.join_plan
+    if plan == "auto":
+        plan = "broadcast" if args.build_rows * world <= 16 * 1024 * 1024 else "shuffle"
     if distributed:
-        join = qd.PartitionedHashJoin(capi, T.INT, 2 * args.build_rows,
-                                      key_domain=(0, key_space - 1) if dense else None)
+        def make_join(which):
+            if which == "broadcast":
+                return qd.BroadcastHashJoin(capi, T.INT, args.build_rows * world, key_domain=(0, key_space - 1) if dense else None)
+            return qd.PartitionedHashJoin(capi, T.INT, 2 * args.build_rows, key_domain=(0, key_space - 1) if dense else None)
+        join = make_join(plan)
         capacity = int(args.probe_rows * 1.25)
     else:
         table = capi.JoinTable(T.INT, args.build_rows, key_range=(0, args.build_rows - 1) if dense else None)
@@ -268,6 +278,19 @@ def main():
     for k in phase_ms:
         phase_ms[k] /= args.steps
 
+    other_plan_ms = None
+    if distributed and world > 1:
+        # the plan the rule above did not pick, untimed leg (2 runs, second one measured): what the shuffle costs here
+        other = make_join("shuffle" if plan == "broadcast" else "broadcast")
+        for it in range(2):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            other.build(build_keys, rank * args.build_rows)
+            other.probe(probe_keys, rank * args.probe_rows, capacity=capacity)
+            torch.cuda.synchronize()
+            other_plan_ms = (time.perf_counter() - t1) * 1e3
+        del other
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -299,7 +322,9 @@ def main():
                         f"{args.match}) + C3 AggregationOperator Q1 shape over {args.agg_rows} rows, per GPU",
             "build_rows": args.build_rows * world, "probe_rows": args.probe_rows * world,
             "aggregate_rows": args.agg_rows * world, "matches": matches,
-            "parallelism": "1 GPU" if world == 1 else f"{world} GPUs, join-key all-to-all shuffle + partial-aggregate all-gather merge",
+            "parallelism": "1 GPU" if world == 1 else (
+                f"{world} GPUs, " + ("broadcast join (all-gather of the build side, local probe)" if plan == "broadcast"
+                                     else "join-key all-to-all shuffle of both sides") + " + partial-aggregate all-gather merge"),
         },
         "roofline": {
             "kernel": "agg_hash_shape_kernel<ShapeTpchQ1,4> (qsx_agg_update; AOT plan shape of the Q1 aggregation, same body as the interpreter kernel)", "bound": "hbm",
@@ -309,6 +334,8 @@ def main():
         },
         "phases_ms": phase_ms,
     }
+    if other_plan_ms is not None:
+        line["join_plan"] = {"used": plan, "other_plan_build_plus_probe_ms": other_plan_ms}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:

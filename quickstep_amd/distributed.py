@@ -116,6 +116,47 @@ class PartitionedHashJoin:
         return self.ops.gather(probe_tids, out_p[:k]), self.ops.gather(build_tids, out_b[:k])
 
 
+class BroadcastHashJoin:
+    """Broadcast join: the build side is small, so every rank all-gathers ALL build rows and probes its
+    own probe rows locally — no probe-side shuffle.  The reference's plan for a build relation without
+    a partition scheme under a partitioned probe (BuildHashOperator.hpp:99, 146-152:
+    is_broadcast_join_ inserts every build block into every partition's table).  Same result surface
+    as PartitionedHashJoin: pairs carry global tuple ids."""
+
+    def __init__(self, ops, key_type, est_build_rows_total, group=None, key_domain=None):
+        self.ops = ops
+        self.group = group
+        self.table = ops.JoinTable(key_type, est_build_rows_total, key_range=key_domain) if key_domain is not None \
+            else ops.JoinTable(key_type, est_build_rows_total)
+
+    def build(self, keys, tid_base):
+        world = dist.get_world_size(self.group)
+        n = torch.tensor([keys.numel()], dtype=torch.int64, device=keys.device)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(x.item()) for x in sizes]
+        bases = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(bases, torch.tensor([tid_base], dtype=torch.int64, device=keys.device), group=self.group)
+        pad = max(sizes)
+        mine = torch.zeros(pad, dtype=keys.dtype, device=keys.device)
+        mine[:keys.numel()] = keys
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=self.group)
+        self.table.clear()
+        for r in range(world):                              # the stored reference is the GLOBAL build tid
+            if sizes[r]:
+                self.table.build(gathered[r][:sizes[r]], base_tid=int(bases[r].item()))
+        return sum(sizes)
+
+    def probe(self, keys, tid_base, capacity=None):
+        out_p, out_b, count = self.table.probe(keys, capacity=capacity, probe_base_tid=tid_base)
+        return None, None, out_p, out_b, count
+
+    def materialize(self, probe_tids, build_tids, out_p, out_b, count):
+        k = int(count.item())
+        return out_p[:k], out_b[:k]                         # already global
+
+
 def merge_agg_state_images(ops, state, group=None):
     """Merge the partial aggregation states of all ranks into every rank's state
     (counterpart of merging the thread-private tables at finalize,

@@ -25,16 +25,16 @@ class OracleJoinTable:
     def clear(self):
         self.t = O.JoinTable(self.key_type, self.est)
 
-    def build(self, keys):
+    def build(self, keys, base_tid=0):
         k = keys.numpy()
         if self.key_range is not None and k.size:
             # the dense flavour's precondition: every build key is a member of the rank's progression
             assert k.min() >= self.key_range[0] and k.max() <= self.key_range[1]
             assert ((k.astype(np.int64) - self.key_range[0]) % self.key_stride == 0).all()
-        self.t.build(k)
+        self.t.build(k, base_tid=base_tid)
 
-    def probe(self, keys, capacity=None):
-        p, b = self.t.probe(keys.numpy())
+    def probe(self, keys, capacity=None, probe_base_tid=0):
+        p, b = self.t.probe(keys.numpy(), probe_base_tid=probe_base_tid)
         return torch.from_numpy(p), torch.from_numpy(b), torch.tensor([p.size], dtype=torch.int64)
 
 
@@ -100,6 +100,14 @@ def main():
              pairs_probe=gp2.numpy(), pairs_build=gb2.numpy())
     assert qd.rank_progression((0, 10), 3, 1) is None and qd.rank_progression((-4, 10), 2, 1) is None
     assert qd.rank_progression((5, 6), 4, 0) is None and qd.rank_progression((5, 17), 4, 2) == (6, 14)
+
+    # broadcast join (small build side): all-gather of the build rows, local probe, no probe shuffle
+    join3 = qd.BroadcastHashJoin(OracleOps, T.INT, n_build * world)
+    assert join3.build(torch.from_numpy(build_keys), rank * n_build) == n_build * world
+    _, _, op3, ob3, cnt3 = join3.probe(torch.from_numpy(probe_keys), rank * n_probe)
+    gp3, gb3 = join3.materialize(None, None, op3, ob3, cnt3)
+    np.savez(os.path.join(out_dir, f"bcast_rank{rank}.npz"), build_keys=build_keys, probe_keys=probe_keys,
+             pairs_probe=gp3.numpy(), pairs_build=gb3.numpy())
 
     # partial aggregate merge
     vals = [(int(g), int(v)) for g, v in zip(rng.integers(0, 16, size=1000), rng.integers(0, 100, size=1000))]

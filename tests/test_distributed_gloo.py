@@ -28,11 +28,11 @@ def test_partitioned_join_and_merge_two_ranks(tmp_path, oracle):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    for prefix in ("rank", "dense_rank"):
-        _check_partitioned_join(oracle, tmp_path, world, prefix)
+    for prefix in ("rank", "dense_rank", "bcast_rank"):
+        _check_partitioned_join(oracle, tmp_path, world, prefix, on_owner_rank=prefix != "bcast_rank")
 
 
-def _check_partitioned_join(oracle, tmp_path, world, prefix):
+def _check_partitioned_join(oracle, tmp_path, world, prefix, on_owner_rank=True):
     ranks = [np.load(tmp_path / f"{prefix}{i}.npz") for i in range(world)]
     build = np.concatenate([d["build_keys"] for d in ranks])      # global tid = rank * n + local row
     probe = np.concatenate([d["probe_keys"] for d in ranks])
@@ -41,7 +41,11 @@ def _check_partitioned_join(oracle, tmp_path, world, prefix):
     assert (build[got[:, 1]] == probe[got[:, 0]]).all()
     for i, d in enumerate(ranks):
         keys = probe[d["pairs_probe"]]
-        assert ((keys.astype(np.uint32) & (world - 1)) == i).all()
+        if on_owner_rank:
+            assert ((keys.astype(np.uint32) & (world - 1)) == i).all()
+        else:   # broadcast join: a pair is produced by the rank that holds the probe row
+            n_probe = d["probe_keys"].size
+            assert ((d["pairs_probe"] // n_probe) == i).all()
     # and the union over ranks is exactly the single-node join
     t = oracle.JoinTable(T.INT, build.size)
     t.build(build)
