@@ -398,12 +398,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const int64_t row0 = tile_id * TR;
     const int rows = static_cast<int>(n - row0 < TR ? n - row0 : TR);
 
-    // This thread's first row of the tile.  Opaque to the optimizer on purpose: every LDS address of
-    // the tile loop is (uniform offset) + trow * width, all loop-invariant, and with the interpreter
-    // unrolled LICM would otherwise park one precomputed address per operand in VGPRs (256 VGPRs,
-    // occupancy 1); recomputing them costs one v_add / v_lshl_add per access.
-    int trow = threadIdx.x;
-    asm volatile("; per-tile row index" : "+v"(trow));
+    const int trow = threadIdx.x;  // this thread's first row of the tile
 
     // ---- which rows are live -------------------------------------------------
     bool live[V];
