@@ -44,42 +44,73 @@ __global__ __launch_bounds__(kLBlock) void lip_build_kernel(LipView f, const Key
   }
 }
 
-template <typename KeyT>
-__global__ __launch_bounds__(kLBlock) void lip_probe_kernel(LipView f, const KeyT *__restrict__ keys, int64_t n,
+// Filter membership of one key: index of the filter bit, or -1 when the key is outside an exact
+// filter's range (then `out_of_range_hit` decides, BitVectorExactFilter.hpp:158-172).
+__device__ __forceinline__ long long lip_bit_index(const LipView &f, long long v) {
+  if (f.exact) {
+    const long long off = v - f.min_value;
+    return (off < 0 || off >= f.cardinality) ? -1 : off;
+  }
+  return static_cast<long long>(static_cast<unsigned long long>(v) % static_cast<unsigned long long>(f.cardinality));
+}
+
+// R bitmap words (64-row groups) per wave iteration: R independent key loads, then R independent
+// 4-byte reads of the filter in flight per lane (one dependent pair per iteration left the probe
+// latency-bound: 0.52 ms / 100 M rows).  Filters of up to kLipLdsWords 32-bit words are copied into
+// LDS first (a 1 M-key exact filter is 128 KiB): the random reads then never leave the CU.
+constexpr int kLipLdsWords = 32 * 1024;  // 128 KiB
+template <typename KeyT, int R, bool kInLds>
+__global__ __launch_bounds__(kInLds ? 1024 : kLBlock) void lip_probe_kernel(LipView f, const KeyT *__restrict__ keys, int64_t n,
                                                            const uint64_t *__restrict__ in_bitmap,
                                                            uint64_t *__restrict__ out_bitmap,
                                                            unsigned long long *__restrict__ out_count) {
+  extern __shared__ uint32_t s_filter[];
+  const uint32_t *__restrict__ bits32 = reinterpret_cast<const uint32_t *>(f.words);
+  if (kInLds) {
+    const long long words32 = (f.cardinality + 31) >> 5;
+    for (long long i = threadIdx.x; i < words32; i += blockDim.x) s_filter[i] = bits32[i];
+    __syncthreads();
+  }
   const int lane = lane_id();
   const int64_t num_words = (n + 63) >> 6;
+  const int waves_per_block = static_cast<int>(blockDim.x) / kWave;   // LDS variant: 16 waves share one copy of the filter
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * waves_per_block + (threadIdx.x >> 6);
+  const int64_t num_waves = static_cast<int64_t>(gridDim.x) * waves_per_block;
   unsigned long long count = 0;
-  for (int64_t w = static_cast<int64_t>(blockIdx.x) * (kLBlock / kWave) + (threadIdx.x >> 6); w < num_words;
-       w += static_cast<int64_t>(gridDim.x) * (kLBlock / kWave)) {
-    const int64_t row = (w << 6) + lane;
-    bool live = row < n;
-    if (live && in_bitmap != nullptr) live = msb_bit(in_bitmap[w], lane);
-    bool hit = false;
-    if (live) {
-      const long long v = static_cast<long long>(keys[row]);
-      if (f.exact) {
-        const long long off = v - f.min_value;
-        if (off < 0 || off >= f.cardinality) {
-          hit = f.is_anti != 0;  // BitVectorExactFilter.hpp:158-172
-        } else {
-          const bool set = (f.words[off >> 6] >> (off & 63)) & 1ull;
-          hit = f.is_anti ? !set : set;
-        }
+  for (int64_t w0 = wave * R; w0 < num_words; w0 += num_waves * R) {
+    long long bit[R];
+    bool live[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ((w0 + r) << 6) + lane;
+      live[r] = row < n;
+      if (live[r] && in_bitmap != nullptr) live[r] = msb_bit(in_bitmap[w0 + r], lane);
+      bit[r] = live[r] ? lip_bit_index(f, static_cast<long long>(keys[row])) : -1;
+    }
+    uint32_t word[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      word[r] = 0;
+      if (bit[r] >= 0) word[r] = kInLds ? s_filter[bit[r] >> 5] : bits32[bit[r] >> 5];
+    }
+    uint64_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      bool hit;
+      if (bit[r] < 0) {
+        hit = f.exact && f.is_anti != 0;            // outside the exact range (or a dead row, masked below)
       } else {
-        const unsigned long long bit = static_cast<unsigned long long>(v) % static_cast<unsigned long long>(f.cardinality);
-        hit = (f.words[bit >> 6] >> (bit & 63)) & 1ull;
+        const bool set = (word[r] >> (bit[r] & 31)) & 1u;
+        hit = f.is_anti ? !set : set;
       }
+      const uint64_t out = msb_first(__ballot(live[r] && hit));
+      count += __popcll(out);
+      if (lane == r) mine = out;
     }
-    const uint64_t word = msb_first(__ballot(live && hit));
-    if (lane == 0) {
-      out_bitmap[w] = word;
-      count += __popcll(word);
-    }
+    if (lane < R && w0 + lane < num_words) out_bitmap[w0 + lane] = mine;
   }
   if (out_count != nullptr) {
+    if (lane != 0) count = 0;   // every lane counted the same wave-uniform ballots
     count = wave_reduce_add(count);
     if (lane == 0 && count != 0) atomicAdd(out_count, count);
   }
@@ -168,16 +199,37 @@ int qsx_lip_probe(const qsx_lip_filter_t *f, int key_type, const void *keys_dev,
   if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
   if (n == 0) return QSX_OK;
   const int64_t num_words = (n + 63) >> 6;
-  const int grid = grid_for(num_words, (kLBlock / kWave) * 4);
   unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count_dev);
-  if (key_type == QSX_INT) {
-    hipLaunchKernelGGL(lip_probe_kernel<int32_t>, dim3(grid), dim3(kLBlock), 0, s, f->view(),
-                       static_cast<const int32_t *>(keys_dev), n, in_bitmap_dev, out_bitmap_dev, count);
-  } else if (key_type == QSX_LONG) {
-    hipLaunchKernelGGL(lip_probe_kernel<int64_t>, dim3(grid), dim3(kLBlock), 0, s, f->view(),
-                       static_cast<const int64_t *>(keys_dev), n, in_bitmap_dev, out_bitmap_dev, count);
+  if (key_type != QSX_INT && key_type != QSX_LONG) return QSX_ERR_UNSUPPORTED;
+  constexpr int R = 8;
+  const long long words32 = (f->cardinality + 31) >> 5;
+  // LDS copy pays when every workgroup amortises it over enough rows: one workgroup per CU, >= 64 K rows each
+  const bool in_lds = words32 <= kLipLdsWords && n >= static_cast<int64_t>(kCUs) * 65536;
+  if (in_lds) {
+    const size_t lds = static_cast<size_t>(words32) * 4;
+    const int grid = kCUs;
+#define QSX_LIP_LAUNCH_LDS(KeyT)                                                                                      \
+    do {                                                                                                              \
+      static bool attribute_set = false;                                                                              \
+      if (!attribute_set) {                                                                                           \
+        QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&lip_probe_kernel<KeyT, R, true>),             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLipLdsWords * 4));              \
+        attribute_set = true;                                                                                         \
+      }                                                                                                               \
+      hipLaunchKernelGGL((lip_probe_kernel<KeyT, R, true>), dim3(grid), dim3(1024), lds, s, f->view(),                \
+                         static_cast<const KeyT *>(keys_dev), n, in_bitmap_dev, out_bitmap_dev, count);               \
+    } while (0)
+    if (key_type == QSX_INT) QSX_LIP_LAUNCH_LDS(int32_t); else QSX_LIP_LAUNCH_LDS(int64_t);
+#undef QSX_LIP_LAUNCH_LDS
   } else {
-    return QSX_ERR_UNSUPPORTED;
+    const int grid = grid_for(num_words, (kLBlock / kWave) * R);
+    if (key_type == QSX_INT) {
+      hipLaunchKernelGGL((lip_probe_kernel<int32_t, R, false>), dim3(grid), dim3(kLBlock), 0, s, f->view(),
+                         static_cast<const int32_t *>(keys_dev), n, in_bitmap_dev, out_bitmap_dev, count);
+    } else {
+      hipLaunchKernelGGL((lip_probe_kernel<int64_t, R, false>), dim3(grid), dim3(kLBlock), 0, s, f->view(),
+                         static_cast<const int64_t *>(keys_dev), n, in_bitmap_dev, out_bitmap_dev, count);
+    }
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;
