@@ -8,7 +8,6 @@
 namespace qsx {
 
 constexpr int kABlock = 256;
-constexpr int kRegGroups = 4;
 constexpr uint64_t kEmptyCode = ~0ull;
 constexpr int kMaxSums = QSX_MAX_AGGS;
 
@@ -112,118 +111,6 @@ struct DenseView {
   int *error;                  // set when a key is outside [0, E)
 };
 
-// ---- per-row evaluation -----------------------------------------------------
-__device__ __forceinline__ double temp_get(const double (&t)[QSX_MAX_TEMPS], int i) {
-  switch (i) {  // wave-uniform index: scalar branches, temps stay in VGPRs
-    case 0: return t[0];
-    case 1: return t[1];
-    case 2: return t[2];
-    case 3: return t[3];
-    case 4: return t[4];
-    case 5: return t[5];
-    case 6: return t[6];
-    default: return t[7];
-  }
-}
-__device__ __forceinline__ void temp_set(double (&t)[QSX_MAX_TEMPS], int i, double v) {
-  switch (i) {
-    case 0: t[0] = v; break;
-    case 1: t[1] = v; break;
-    case 2: t[2] = v; break;
-    case 3: t[3] = v; break;
-    case 4: t[4] = v; break;
-    case 5: t[5] = v; break;
-    case 6: t[6] = v; break;
-    default: t[7] = v; break;
-  }
-}
-
-__device__ __forceinline__ double column_as_double(const DevConfig &c, int col, int64_t row) {
-  switch (c.column_type[col]) {
-    case QSX_INT: return static_cast<double>(static_cast<const int32_t *>(c.cols[col])[row]);
-    case QSX_LONG: return static_cast<double>(static_cast<const int64_t *>(c.cols[col])[row]);
-    case QSX_FLOAT: return static_cast<double>(static_cast<const float *>(c.cols[col])[row]);
-    default: return static_cast<const double *>(c.cols[col])[row];
-  }
-}
-__device__ __forceinline__ long long column_as_int(const DevConfig &c, int col, int64_t row) {
-  if (c.column_type[col] == QSX_INT) return static_cast<const int32_t *>(c.cols[col])[row];
-  return static_cast<const int64_t *>(c.cols[col])[row];
-}
-__device__ __forceinline__ double operand_value(const DevConfig &c, const DevOperand &o,
-                                                const double (&t)[QSX_MAX_TEMPS], int64_t row) {
-  switch (o.kind) {
-    case QSX_OPD_COLUMN: return column_as_double(c, o.index, row);
-    case QSX_OPD_CONST: return c.consts[o.index];
-    default: return temp_get(t, o.index);
-  }
-}
-
-// Expression program: every node an IEEE double, evaluated in program order
-// (compiled with -ffp-contract=off so that a*b+c is never fused: each
-// reference temp vector holds a rounded double).
-__device__ __forceinline__ void eval_program(const DevConfig &c, double (&t)[QSX_MAX_TEMPS], int64_t row) {
-  for (int k = 0; k < c.num_instrs; ++k) {
-    const DevInstr in = c.instrs[k];
-    const double a = operand_value(c, in.a, t, row);
-    const double b = operand_value(c, in.b, t, row);
-    double r;
-    switch (in.op) {
-      case QSX_EX_ADD: r = a + b; break;
-      case QSX_EX_SUB: r = a - b; break;
-      case QSX_EX_MUL: r = a * b; break;
-      default: r = a / b; break;
-    }
-    temp_set(t, in.dst, r);
-  }
-}
-
-__device__ __forceinline__ bool eval_predicate(const DevConfig &c, int64_t row) {
-  bool ok = true;
-  for (int p = 0; p < c.num_pred; ++p) {
-    const DevPred term = c.pred[p];
-    bool r;
-    switch (c.column_type[term.column]) {
-      case QSX_INT:
-        r = compare_op<int32_t>(static_cast<const int32_t *>(c.cols[term.column])[row], term.op,
-                                static_cast<int32_t>(term.literal));
-        break;
-      case QSX_LONG:
-        r = compare_op<int64_t>(static_cast<const int64_t *>(c.cols[term.column])[row], term.op,
-                                static_cast<int64_t>(term.literal));
-        break;
-      case QSX_FLOAT:
-        r = compare_op<float>(static_cast<const float *>(c.cols[term.column])[row], term.op,
-                              __uint_as_float(static_cast<uint32_t>(term.literal)));
-        break;
-      default:
-        r = compare_op<double>(static_cast<const double *>(c.cols[term.column])[row], term.op,
-                               __longlong_as_double(static_cast<long long>(term.literal)));
-        break;
-    }
-    ok = ok && r;
-  }
-  return ok;
-}
-
-// Compact key code: key bytes at running offsets of a zeroed 64-bit word,
-// little endian (storage/ThreadPrivateCompactKeyHashTable.cpp:216-232).
-__device__ __forceinline__ unsigned long long key_code(const DevConfig &c, int64_t row) {
-  unsigned long long code = 0;
-  for (int k = 0; k < c.num_keys; ++k) {
-    const void *col = c.cols[c.key_column[k]];
-    unsigned long long v;
-    switch (c.key_width[k]) {
-      case 1: v = static_cast<const uint8_t *>(col)[row]; break;
-      case 2: v = static_cast<const uint16_t *>(col)[row]; break;
-      case 4: v = static_cast<const uint32_t *>(col)[row]; break;
-      default: v = static_cast<const unsigned long long *>(col)[row]; break;
-    }
-    code |= v << c.key_shift[k];
-  }
-  return code;
-}
-
 // Combine two accumulator words.
 __device__ __forceinline__ unsigned long long acc_combine(unsigned long long acc, unsigned long long inc, int kind) {
   switch (kind) {
@@ -234,10 +121,6 @@ __device__ __forceinline__ unsigned long long acc_combine(unsigned long long acc
       return static_cast<unsigned long long>(__double_as_longlong(
           __longlong_as_double(static_cast<long long>(acc)) + __longlong_as_double(static_cast<long long>(inc))));
   }
-}
-
-__device__ __forceinline__ bool filter_bit(const uint64_t *filter, int64_t row) {
-  return filter == nullptr || msb_bit(filter[row >> 6], static_cast<int>(row & 63));
 }
 
 // ---- global hash table --------------------------------------------------------

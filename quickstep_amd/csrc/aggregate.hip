@@ -17,24 +17,17 @@
 //     keys   [C + 1]            packed key code, ~0 = empty; slot C is reserved
 //                               for the one code that equals ~0
 //     col 0  [C + 1] int64      row count of the group
-//     col j  [C + 1] int64|f64  j-th SUM/AVG accumulator (j = 1..NS)
+//     col j  [C + 1] int64|f64  j-th accumulator (j = 1..NS): SUM as int64 / f64, MIN / MAX as int64
+//                               (doubles through the order-preserving map of agg_common.hpp)
 //   COLLISION_FREE, E = num_entries (max_key + 1):
 //     exist  [ceil(E/64)]       existence bits, LSB-first (bit k of word k>>6)
 //     col 0  [E] int64          row count (only when some COUNT/AVG needs it)
 //     col j  [E] int64|f64      j-th accumulator
 //
-// Hash-strategy update kernel, per 256-thread workgroup:
-//   * the first R = 4 distinct groups a workgroup meets are "register groups":
-//     their codes sit in 4 LDS tag words, every thread keeps its own partial
-//     sums for them in VGPRs (predicated adds, no atomics at all) — this is
-//     the TPC-H Q1 regime (4 groups, 600 M rows);
-//   * further groups go to a workgroup-private open-addressing table in LDS
-//     (ds_cmpst_b64 claim, ds_add_u64 / ds_add_f64 accumulate);
-//   * groups that do not fit LDS go straight to the global table with global
-//     64-bit atomics;
-//   * at the end the workgroup folds registers -> LDS -> global table, so the
-//     global table sees one atomic per group per accumulator per workgroup.
-// Integer SUM/COUNT use integer atomics (exact, order-independent); double
+// The update kernel itself lives in agg_hash_update.hpp (one body for the hash strategies and the
+// dense sink); this file holds the host side: state, translation, launch geometry, the choice
+// between AOT plan shape / run-time plan shape (agg_jit.hip) / interpreter, merge and finalize.
+// Integer SUM/COUNT/MIN/MAX use integer atomics (exact, order-independent); double
 // sums are order-dependent in the last bits, the contract is 1e-6 relative.
 
 #include "agg_common.hpp"
