@@ -7,29 +7,68 @@
 // itself is what PartitionAwareInsertDestination does per output row
 // (storage/InsertDestination.hpp:490-660).
 //
-// Three passes, every wave owns one contiguous row range so that the scatter
-// is stable (rows keep their relative order inside a partition):
-//   1. per-wave histograms, written partition-major  hist[p * W + w]
-//   2. exclusive scan of that array  ->  absolute start of (partition p, wave w)
-//   3. scatter: per 64-row batch the wave walks the partition ids present
-//      (readfirstlane loop), ranks the rows of one partition with ballot +
-//      mbcnt and bumps that partition's running offset, held by lane p.
+// Three passes; every workgroup owns one contiguous row range and walks it in 2048-row tiles, so
+// the scatter is stable (rows keep their relative order inside a partition):
+//   1. per-workgroup histograms, written partition-major  hist[p * G + b]
+//   2. exclusive scan of that array  ->  absolute start of (partition p, workgroup b)
+//   3. scatter: a tile's rows are ranked per partition (ballot + mbcnt inside a wave, a wave
+//      scan per partition over the tile's (step, wave) cells), staged in LDS in partition
+//      order and copied out as contiguous runs — one run per partition per tile, so the writes
+//      are coalesced whatever P is (the first version wrote one 64-row batch at a time: 32-byte
+//      fragments at P = 8, 1.24 ms / 100 M (key, tid) rows).
 // Limits: at most 64 partitions (lane p owns partition p).
 
 #include "common.hpp"
+#include "partition.hpp"
 #include "scan.hpp"
+
+#include <type_traits>
 
 namespace qsx {
 
 constexpr int kPBlock = 256;
 constexpr int kPWaves = kPBlock / kWave;
+constexpr int kPSteps = 8;                        // rows per thread per tile
+constexpr int kPTile = kPBlock * kPSteps;         // 2048 rows
+constexpr int kPCells = kPSteps * kPWaves;        // 32 (step, wave) cells per tile: scanned by one wave
 
-template <typename KeyT>
+// MODE 0: the reference's partition function (identity hash); MODE 1: the top bits of a mixing hash
+// (internal re-partitioning: aggregation groups, join table slices) — P must be a power of two there.
+template <typename KeyT, int MODE>
 __device__ __forceinline__ int partition_of(KeyT key, int P, int pow2) {
   unsigned long long h;
   if (sizeof(KeyT) == 4) h = static_cast<uint32_t>(key); else h = static_cast<unsigned long long>(key);
+  if (MODE == 1) return static_cast<int>((mix64(h) * 0x9E3779B97F4A7C15ull) >> (64 - pow2));   // pow2 = log2(P) here
   if (pow2) return static_cast<int>(h & static_cast<unsigned long long>(P - 1));
   return static_cast<int>(h >= static_cast<unsigned long long>(P) ? h % static_cast<unsigned long long>(P) : h);
+}
+
+// One 64-row step of a wave: rank of every row among the rows of its partition (row order) and, in
+// lane p, the number of rows of partition p.  kSmallP (P <= 8): P independent ballots, no dependent
+// chain (the general loop walks the partitions present one at a time through a shuffle).
+template <bool kSmallP>
+__device__ __forceinline__ void step_ranks(int pid, int P, int &rank, int &count_in_lane) {
+  const int lane = lane_id();
+  rank = 0;
+  count_in_lane = 0;
+  if (kSmallP) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint64_t m = __ballot(pid == p);
+      if (pid == p) rank = rank_below(m);
+      if (lane == p) count_in_lane = __popcll(m);
+    }
+  } else {
+    uint64_t remaining = __ballot(pid >= 0);
+    while (remaining != 0) {
+      const int leader = __ffsll(static_cast<long long>(remaining)) - 1;
+      const int cur = __shfl(pid, leader, kWave);
+      const uint64_t m = __ballot(pid == cur);
+      if (pid == cur) rank = rank_below(m);
+      if (lane == cur) count_in_lane = __popcll(m);
+      remaining &= ~m;
+    }
+  }
 }
 
 struct ScatterArgs {
@@ -39,114 +78,217 @@ struct ScatterArgs {
   void *dst[QSX_MAX_COLUMNS];
 };
 
-template <typename KeyT>
+template <typename KeyT, int MODE, bool kSmallP>
 __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(const KeyT *__restrict__ keys, int64_t n, int P,
-                                                                int pow2, int64_t rows_per_wave, int64_t W,
+                                                                int pow2, int64_t rows_per_block, int64_t G,
                                                                 int32_t *__restrict__ hist) {
+  __shared__ int s_total[kWave];
   const int lane = lane_id();
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * kPWaves + (threadIdx.x >> 6);
-  if (w >= W) return;
-  const int64_t begin = w * rows_per_wave;
-  const int64_t end = begin + rows_per_wave < n ? begin + rows_per_wave : n;
+  if (threadIdx.x < kWave) s_total[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  const int64_t end = begin + rows_per_block < n ? begin + rows_per_block : n;
   int my_count = 0;  // lane p counts partition p
-  for (int64_t base = begin; base < end; base += kWave) {
-    const int64_t row = base + lane;
-    const int pid = row < end ? partition_of<KeyT>(keys[row], P, pow2) : -1;
-    uint64_t remaining = __ballot(pid >= 0);
-    while (remaining != 0) {
-      const int leader = __ffsll(static_cast<long long>(remaining)) - 1;
-      const int cur = __shfl(pid, leader, kWave);
-      const uint64_t m = __ballot(pid == cur);
-      if (lane == cur) my_count += __popcll(m);
-      remaining &= ~m;
+  for (int64_t tile = begin; tile < end; tile += kPTile) {
+    int pid[kPSteps];
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
+      const int64_t row = tile + j * kPBlock + threadIdx.x;
+      pid[j] = row < end ? partition_of<KeyT, MODE>(keys[row], P, pow2) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
+      int rank, count;
+      step_ranks<kSmallP>(pid[j], P, rank, count);
+      my_count += count;
     }
   }
-  if (lane < P) hist[static_cast<int64_t>(lane) * W + w] = my_count;
+  if (lane < P && my_count != 0) atomicAdd(&s_total[lane], my_count);
+  __syncthreads();
+  if (threadIdx.x < P) hist[static_cast<int64_t>(threadIdx.x) * G + blockIdx.x] = s_total[threadIdx.x];
 }
 
-__device__ __forceinline__ void move_value(const void *src, int64_t si, void *dst, int64_t di, int width) {
-  switch (width) {
-    case 1: static_cast<uint8_t *>(dst)[di] = static_cast<const uint8_t *>(src)[si]; break;
-    case 2: static_cast<uint16_t *>(dst)[di] = static_cast<const uint16_t *>(src)[si]; break;
-    case 4: static_cast<uint32_t *>(dst)[di] = static_cast<const uint32_t *>(src)[si]; break;
-    default: static_cast<uint64_t *>(dst)[di] = static_cast<const uint64_t *>(src)[si]; break;
+template <int W>
+__device__ __forceinline__ void stage_and_copy(const void *src, void *dst, unsigned char *stage, const int64_t (&row)[kPSteps],
+                                               const int (&pos)[kPSteps], const int (&pid)[kPSteps],
+                                               const unsigned char *s_pid, const int *s_part_start,
+                                               const long long *s_glob, int tile_rows) {
+  using V = typename std::conditional<W == 1, uint8_t, typename std::conditional<W == 2, uint16_t,
+            typename std::conditional<W == 4, uint32_t, uint64_t>::type>::type>::type;
+  V v[kPSteps];
+#pragma unroll
+  for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? static_cast<const V *>(src)[row[j]] : V();
+#pragma unroll
+  for (int j = 0; j < kPSteps; ++j) {
+    if (pid[j] >= 0) reinterpret_cast<V *>(stage)[pos[j]] = v[j];
   }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kPSteps; ++j) {   // fixed trip count: the 16 slot reads / stores of a thread are independent
+    const int i = j * kPBlock + threadIdx.x;
+    if (i < tile_rows) {
+      const int p = s_pid[i];
+      static_cast<V *>(dst)[s_glob[p] + (i - s_part_start[p])] = reinterpret_cast<const V *>(stage)[i];
+    }
+  }
+  __syncthreads();
 }
 
-template <typename KeyT>
+template <typename KeyT, int MODE, bool kSmallP>
 __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(const KeyT *__restrict__ keys, int64_t n, int P,
-                                                                   int pow2, int64_t rows_per_wave, int64_t W,
+                                                                   int pow2, int64_t rows_per_block, int64_t G,
                                                                    const int64_t *__restrict__ starts,
-                                                                   ScatterArgs args,
+                                                                   ScatterArgs args, int stage_width,
                                                                    int64_t *__restrict__ out_offsets) {
+  // dynamic LDS: stage[kPTile * widest column] | cnt[kPCells * P] — sized by the launch so that small
+  // P / narrow columns leave room for more workgroups per CU (the tile loop is a chain of
+  // load -> LDS -> barrier -> store phases: occupancy is what hides their latencies)
+  extern __shared__ __attribute__((aligned(8))) unsigned char s_dyn[];
+  unsigned char *s_stage = s_dyn;
+  int *s_cnt = reinterpret_cast<int *>(s_dyn + static_cast<size_t>(kPTile) * stage_width);  // [cell][partition]
+  __shared__ int s_part_start[kWave + 1];         // tile-local start of every partition's run
+  __shared__ long long s_glob[kWave];             // next global row of (partition, this workgroup)
+  __shared__ unsigned char s_pid[kPTile];         // partition of every staged slot
   const int lane = lane_id();
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * kPWaves + (threadIdx.x >> 6);
-  if (w >= W) return;
-  if (w == 0) {
-    if (lane < P) out_offsets[lane] = starts[static_cast<int64_t>(lane) * W];
-    if (lane == 0) out_offsets[P] = n;
+  const int wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < P) out_offsets[threadIdx.x] = starts[static_cast<int64_t>(threadIdx.x) * G];
+    if (threadIdx.x == 0) out_offsets[P] = n;
   }
-  const int64_t begin = w * rows_per_wave;
-  const int64_t end = begin + rows_per_wave < n ? begin + rows_per_wave : n;
-  int64_t my_offset = lane < P ? starts[static_cast<int64_t>(lane) * W + w] : 0;  // lane p: next slot of partition p
-  for (int64_t base = begin; base < end; base += kWave) {
-    const int64_t row = base + lane;
-    const int pid = row < end ? partition_of<KeyT>(keys[row], P, pow2) : -1;
-    uint64_t remaining = __ballot(pid >= 0);
-    int64_t dst_row = -1;
-    while (remaining != 0) {
-      const int leader = __ffsll(static_cast<long long>(remaining)) - 1;
-      const int cur = __shfl(pid, leader, kWave);
-      const uint64_t m = __ballot(pid == cur);
-      const int64_t part_base = __shfl(my_offset, cur, kWave);
-      if (pid == cur) dst_row = part_base + rank_below(m);
-      if (lane == cur) my_offset += __popcll(m);
-      remaining &= ~m;
+  if (threadIdx.x < P) s_glob[threadIdx.x] = starts[static_cast<int64_t>(threadIdx.x) * G + blockIdx.x];
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  const int64_t end = begin + rows_per_block < n ? begin + rows_per_block : n;
+  for (int64_t tile = begin; tile < end; tile += kPTile) {
+    const int tile_rows = static_cast<int>(end - tile < kPTile ? end - tile : kPTile);
+    int64_t row[kPSteps];
+    int pid[kPSteps], pos[kPSteps];
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
+      row[j] = tile + j * kPBlock + threadIdx.x;
+      pid[j] = row[j] < end ? partition_of<KeyT, MODE>(keys[row[j]], P, pow2) : -1;
     }
-    if (dst_row >= 0) {
-      for (int c = 0; c < args.ncols; ++c) move_value(args.src[c], row, args.dst[c], dst_row, args.width[c]);
+    // rank inside the wave + the cell's count per partition
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
+      int count;
+      step_ranks<kSmallP>(pid[j], P, pos[j], count);
+      if (lane < P) s_cnt[(j * kPWaves + wave) * P + lane] = count;   // every cell is written: no zeroing pass
     }
+    __syncthreads();
+    // per partition: exclusive scan over the 64 cells (lane = cell), total into s_part_start[p + 1]
+    for (int p = wave; p < P; p += kPWaves) {
+      const int c = lane < kPCells ? s_cnt[lane * P + p] : 0;
+      int incl = c;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const int up = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += up;
+      }
+      if (lane < kPCells) s_cnt[lane * P + p] = incl - c;
+      if (lane == kWave - 1) s_part_start[p + 1] = incl;
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive scan of the partition totals (lane = partition)
+      const int c = lane < P ? s_part_start[lane + 1] : 0;
+      int incl = c;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const int up = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += up;
+      }
+      if (lane < P) s_part_start[lane + 1] = incl;
+      if (lane == 0) s_part_start[0] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
+      if (pid[j] >= 0) {
+        pos[j] += s_part_start[pid[j]] + s_cnt[(j * kPWaves + wave) * P + pid[j]];
+        s_pid[pos[j]] = static_cast<unsigned char>(pid[j]);
+      }
+    }
+    __syncthreads();
+    for (int c = 0; c < args.ncols; ++c) {
+      switch (args.width[c]) {
+        case 1: stage_and_copy<1>(args.src[c], args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
+        case 2: stage_and_copy<2>(args.src[c], args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
+        case 4: stage_and_copy<4>(args.src[c], args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
+        default: stage_and_copy<8>(args.src[c], args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
+      }
+    }
+    if (threadIdx.x < P) s_glob[threadIdx.x] += s_part_start[threadIdx.x + 1] - s_part_start[threadIdx.x];
+    __syncthreads();
   }
 }
 
 static size_t p_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static int64_t waves_for(int64_t n) {
-  // at least 512 rows per wave, at most 8192 waves (2048 workgroups)
-  int64_t W = (n + 511) / 512;
-  if (W < 1) W = 1;
-  if (W > static_cast<int64_t>(kMaxGridBlocks) * kPWaves) W = static_cast<int64_t>(kMaxGridBlocks) * kPWaves;
-  return W;
+static int64_t blocks_for(int64_t n) {
+  // whole 4096-row tiles per workgroup, at most 2048 workgroups
+  int64_t G = (n + kPTile - 1) / kPTile;
+  if (G < 1) G = 1;
+  if (G > kMaxGridBlocks) G = kMaxGridBlocks;
+  return G;
 }
 
-}  // namespace qsx
-
-using namespace qsx;
-
-extern "C" {
-
-size_t qsx_partition_workspace_bytes(int64_t n, int num_partitions) {
-  const int64_t W = waves_for(n);
-  const int64_t cells = W * num_partitions;
-  return p_align_up(sizeof(int64_t) * (cells + 1), 256) + p_align_up(sizeof(int32_t) * cells, 256);
+size_t partition_workspace_bytes(int64_t n, int num_partitions) {
+  const int64_t cells = blocks_for(n) * num_partitions;
+  return p_align_up(sizeof(int64_t) * (cells + 1), 256) + p_align_up(sizeof(int32_t) * cells, 256) +
+         scan_workspace_words(cells) * sizeof(int64_t);
 }
 
-int qsx_partition_scatter(int key_type, const void *keys_dev, int64_t n, int num_partitions, int ncols,
-                          const void *const *cols, const int32_t *widths, void *const *out_cols,
-                          int64_t *out_offsets_dev, void *workspace_dev, size_t workspace_bytes,
-                          qsx_stream_t stream) {
-  QSX_REQUIRE_DEVICE();
+template <typename KeyT, int MODE>
+static int launch_partition_t(const KeyT *keys, int64_t n, int P, int pow2, const ScatterArgs &args, int64_t *out_offsets,
+                              void *workspace, hipStream_t s) {
+  const int64_t G = blocks_for(n);
+  int64_t rows_per_block = (n + G - 1) / G;
+  rows_per_block = (rows_per_block + kPTile - 1) / kPTile * kPTile;
+  const int64_t cells = G * P;
+  int64_t *starts = static_cast<int64_t *>(workspace);
+  char *after = static_cast<char *>(workspace) + p_align_up(sizeof(int64_t) * (cells + 1), 256);
+  int32_t *hist = reinterpret_cast<int32_t *>(after);
+  int64_t *scan_ws = reinterpret_cast<int64_t *>(after + p_align_up(sizeof(int32_t) * cells, 256));
+  if (P <= 8) {
+    hipLaunchKernelGGL((partition_hist_kernel<KeyT, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys, n, P,
+                       pow2, rows_per_block, G, hist);
+  } else {
+    hipLaunchKernelGGL((partition_hist_kernel<KeyT, MODE, false>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys, n, P,
+                       pow2, rows_per_block, G, hist);
+  }
+  QSX_CHECK_LAUNCH();
+  QSX_HIP_TRY(launch_scan(hist, cells, starts, nullptr, scan_ws, s));
+  int stage_width = 1;
+  for (int c = 0; c < args.ncols; ++c) stage_width = args.width[c] > stage_width ? args.width[c] : stage_width;
+  const size_t lds = static_cast<size_t>(kPTile) * stage_width + sizeof(int) * kPCells * P;
+  if (P <= 8) {
+    hipLaunchKernelGGL((partition_scatter_kernel<KeyT, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
+                       n, P, pow2, rows_per_block, G, starts, args, stage_width, out_offsets);
+  } else {
+    hipLaunchKernelGGL((partition_scatter_kernel<KeyT, MODE, false>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
+                       n, P, pow2, rows_per_block, G, starts, args, stage_width, out_offsets);
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+// mode 0: reference partition function (qsx_partition_scatter); mode 1: mixing-hash partitions for
+// internal use (P a power of two).  Shared by the C entry point, the partitioned aggregation and
+// the partitioned probe.
+int partition_scatter_impl(int mode, int key_type, const void *keys_dev, int64_t n, int num_partitions, int ncols,
+                           const void *const *cols, const int32_t *widths, void *const *out_cols, int64_t *out_offsets_dev,
+                           void *workspace_dev, size_t workspace_bytes, hipStream_t s) {
   if (n < 0 || num_partitions < 1 || ncols < 0 || ncols > QSX_MAX_COLUMNS || out_offsets_dev == nullptr) {
     return QSX_ERR_INVALID_ARGUMENT;
   }
   if (num_partitions > kWave) return QSX_ERR_UNSUPPORTED;
   if (key_type != QSX_INT && key_type != QSX_LONG) return QSX_ERR_UNSUPPORTED;
-  hipStream_t s = as_stream(stream);
+  const bool is_pow2 = (num_partitions & (num_partitions - 1)) == 0;
+  if (mode == 1 && !is_pow2) return QSX_ERR_UNSUPPORTED;
   if (n == 0) {
     QSX_HIP_TRY(hipMemsetAsync(out_offsets_dev, 0, sizeof(int64_t) * (num_partitions + 1), s));
     return QSX_OK;
   }
-  if (workspace_bytes < qsx_partition_workspace_bytes(n, num_partitions) || workspace_dev == nullptr) return QSX_ERR_CAPACITY;
+  if (workspace_bytes < partition_workspace_bytes(n, num_partitions) || workspace_dev == nullptr) return QSX_ERR_CAPACITY;
   ScatterArgs args;
   args.ncols = ncols;
   for (int c = 0; c < ncols; ++c) {
@@ -156,36 +298,40 @@ int qsx_partition_scatter(int key_type, const void *keys_dev, int64_t n, int num
     args.src[c] = cols[c];
     args.dst[c] = out_cols[c];
   }
-  const int64_t W = waves_for(n);
-  int64_t rows_per_wave = (n + W - 1) / W;
-  rows_per_wave = (rows_per_wave + kWave - 1) / kWave * kWave;
-  const int64_t cells = W * num_partitions;
-  int64_t *starts = static_cast<int64_t *>(workspace_dev);
-  int32_t *hist = reinterpret_cast<int32_t *>(static_cast<char *>(workspace_dev) +
-                                              p_align_up(sizeof(int64_t) * (cells + 1), 256));
-  const int pow2 = (num_partitions & (num_partitions - 1)) == 0 ? 1 : 0;
-  const int grid = static_cast<int>((W + kPWaves - 1) / kPWaves);
-  if (key_type == QSX_INT) {
-    hipLaunchKernelGGL(partition_hist_kernel<int32_t>, dim3(grid), dim3(kPBlock), 0, s,
-                       static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, rows_per_wave, W, hist);
-  } else {
-    hipLaunchKernelGGL(partition_hist_kernel<int64_t>, dim3(grid), dim3(kPBlock), 0, s,
-                       static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, rows_per_wave, W, hist);
+  int pow2 = is_pow2 ? 1 : 0;
+  if (mode == 1) {
+    pow2 = 0;
+    while ((1 << pow2) < num_partitions) ++pow2;   // log2(P): the hash shift
+    if (pow2 == 0) pow2 = 0;
   }
-  QSX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, hist, cells, starts, static_cast<int64_t *>(nullptr));
-  QSX_CHECK_LAUNCH();
-  if (key_type == QSX_INT) {
-    hipLaunchKernelGGL(partition_scatter_kernel<int32_t>, dim3(grid), dim3(kPBlock), 0, s,
-                       static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, rows_per_wave, W, starts, args,
-                       out_offsets_dev);
-  } else {
-    hipLaunchKernelGGL(partition_scatter_kernel<int64_t>, dim3(grid), dim3(kPBlock), 0, s,
-                       static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, rows_per_wave, W, starts, args,
-                       out_offsets_dev);
+  if (mode == 1 && num_partitions == 1) {
+    // one partition: a plain copy keeps the contract (shift by 64 would be undefined)
+    mode = 0;
+    pow2 = 1;
   }
-  QSX_CHECK_LAUNCH();
-  return QSX_OK;
+  if (key_type == QSX_INT) {
+    return mode == 0 ? launch_partition_t<int32_t, 0>(static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, s)
+                     : launch_partition_t<int32_t, 1>(static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, s);
+  }
+  return mode == 0 ? launch_partition_t<int64_t, 0>(static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, s)
+                   : launch_partition_t<int64_t, 1>(static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, s);
+}
+
+}  // namespace qsx
+
+using namespace qsx;
+
+extern "C" {
+
+size_t qsx_partition_workspace_bytes(int64_t n, int num_partitions) { return partition_workspace_bytes(n, num_partitions); }
+
+int qsx_partition_scatter(int key_type, const void *keys_dev, int64_t n, int num_partitions, int ncols,
+                          const void *const *cols, const int32_t *widths, void *const *out_cols,
+                          int64_t *out_offsets_dev, void *workspace_dev, size_t workspace_bytes,
+                          qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  return partition_scatter_impl(0, key_type, keys_dev, n, num_partitions, ncols, cols, widths, out_cols, out_offsets_dev,
+                                workspace_dev, workspace_bytes, as_stream(stream));
 }
 
 }  // extern "C"
