@@ -207,6 +207,7 @@ def main():
     phase_ms = {"build": 0.0, "probe": 0.0, "aggregate_update": 0.0, "finalize": 0.0, "shuffle_build": 0.0,
                 "shuffle_probe": 0.0, "merge": 0.0}
     results = {}
+    recorded = []   # per timed step: (phase, start event, end event) on the stream the kernels were launched on
 
     def step(timed):
         if distributed:
@@ -230,12 +231,9 @@ def main():
             e2.record()
             main_stream.wait_stream(agg_stream)
             results.update(matches=cnt, groups=fin[3], built=nb)
-            if timed:
-                torch.cuda.synchronize()
-                phase_ms["shuffle_build"] += e0.elapsed_time(e1)
-                phase_ms["shuffle_probe"] += e1.elapsed_time(e2)
-                phase_ms["aggregate_update"] += a0.elapsed_time(a1)
-                phase_ms["merge"] += a1.elapsed_time(a2)
+            if timed:   # events are only READ after the timed loop (reading synchronises)
+                recorded.append((("shuffle_build", e0, e1), ("shuffle_probe", e1, e2), ("aggregate_update", a0, a1),
+                                 ("merge", a1, a2)))
             return
         e = [ev() for _ in range(6)]
         e[0].record()
@@ -252,11 +250,8 @@ def main():
         e[5].record()
         results.update(matches=cnt, groups=fin[3], fin=fin)
         if timed:
-            torch.cuda.synchronize()
-            phase_ms["build"] += e[0].elapsed_time(e[1])
-            phase_ms["probe"] += e[1].elapsed_time(e[2])
-            phase_ms["aggregate_update"] += e[3].elapsed_time(e[4])
-            phase_ms["finalize"] += e[4].elapsed_time(e[5])
+            recorded.append((("build", e[0], e[1]), ("probe", e[1], e[2]), ("aggregate_update", e[3], e[4]),
+                             ("finalize", e[4], e[5])))
 
     for _ in range(args.warmup):
         step(False)
@@ -266,15 +261,15 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(False)
+        step(True)      # HIP events are recorded inside the timed region, read below
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    # per-phase durations: a second, instrumented pass (event reads synchronise, so it is kept out of the timed loop)
-    for _ in range(args.steps):
-        step(True)
+    for per_step in recorded:
+        for name, start, end in per_step:
+            phase_ms[name] += start.elapsed_time(end)
     for k in phase_ms:
         phase_ms[k] /= args.steps
 
