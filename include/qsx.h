@@ -125,6 +125,37 @@ int qsx_select_cmp_columns(int type, const void *lhs_dev, const void *rhs_dev, i
                            const uint64_t *filter_dev, uint64_t *out_bitmap_dev,
                            int64_t *out_count_dev, qsx_stream_t stream);
 
+/* ---- compressed attributes (CompressedColumnStoreTupleStorageSubBlock) ----------------------
+ * An attribute of a compressed column-store block is a stripe of 1/2/4-byte unsigned CODES: the value
+ * itself for a truncated INT/LONG attribute, or an index into a sorted dictionary
+ * (storage/CompressedBlockBuilder.cpp:508-566, 590-650; compression/CompressionDictionary.hpp).
+ * A comparison with a literal is first rewritten into a comparison on codes by the caller
+ * (CompressedAttributePredicateTransformer::TransformPredicateOnCompressedAttribute,
+ * storage/CompressedStoreUtil.cpp:51-140, 425-616: ALL / NONE / {=, !=, <, >=} code / code range) and
+ * then evaluated on the code stripe — a quarter to an eighth of the bytes of the uncompressed column. */
+typedef enum qsx_code_cmp {
+  QSX_CODE_EQ = 0,    /* getEqualCodes           code == first            */
+  QSX_CODE_NE = 1,    /* getNotEqualCodes        code != first            */
+  QSX_CODE_LT = 2,    /* getLessCodes            code <  first            */
+  QSX_CODE_GE = 3,    /* getGreaterOrEqualCodes  code >= first            */
+  QSX_CODE_RANGE = 4  /* getCodesInRange         first <= code < second   */
+} qsx_code_cmp_t;
+
+/* K1 on a code stripe.  Replaces the scan loops of storage/
+ * CompressedColumnStoreTupleStorageSubBlock.cpp:420-760 (attributes other than the sort column).
+ * filter / out_bitmap / out_count as in qsx_select_cmp. */
+int qsx_select_codes(int code_width, const void *codes_dev, int64_t n, int op, uint32_t first,
+                     uint32_t second, const uint64_t *filter_dev, uint64_t *out_bitmap_dev,
+                     int64_t *out_count_dev, qsx_stream_t stream);
+
+/* Decode a code stripe into values of value_width (4 or 8) bytes: out[i] = dictionary[codes[i]], or the
+ * zero-extended code when dictionary_dev is NULL (truncated attribute).  What
+ * CompressedTupleStorageSubBlock::getAttributeValue does per tuple (storage/
+ * CompressedTupleStorageSubBlock.hpp:225-300) for operators that consume values (joins, aggregates,
+ * projections). */
+int qsx_decode_codes(int code_width, const void *codes_dev, int64_t n, const void *dictionary_dev,
+                     int value_width, void *out_dev, qsx_stream_t stream);
+
 /* Bitmap algebra on TupleIdSequences of n bits (storage/TupleIdSequence.hpp:
  * intersectWith / unionWith / invert). op: 0 = AND, 1 = OR, 2 = AND NOT,
  * 3 = NOT a (b ignored). */

@@ -31,6 +31,14 @@ _vp, _i64, _i32, _int, _u64, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.
 _pp = C.POINTER(C.c_void_p)
 
 
+class CompressedInfo(C.Structure):
+    _fields_ = [("kind", C.c_int), ("code_width", C.c_int), ("num_codes", C.c_uint32)]
+
+
+class CodePredicate(C.Structure):
+    _fields_ = [("result", C.c_int), ("comp", C.c_int), ("first", C.c_uint32), ("second", C.c_uint32)]
+
+
 class JoinBenchResult(C.Structure):
     _fields_ = [("build_seconds", C.c_double), ("probe_seconds", C.c_double), ("matches", C.c_int64),
                 ("checksum", C.c_uint64)]
@@ -61,6 +69,10 @@ for _name, _res, _args in [
     ("qso_cjoin_hash_row", _u64, [_vp, _pp, _i64]),
     ("qso_select_cmp_columns", None, [_int, _vp, _vp, _i64, _int, _vp, _vp]),
     ("qso_tids_to_bitmap", None, [_vp, _i64, _i32, _i64, _vp]),
+    ("qso_compress_column", None, [_int, _vp, _i64, C.POINTER(CompressedInfo), _vp, _vp]),
+    ("qso_transform_predicate", None, [C.POINTER(CompressedInfo), _int, _vp, _int, _vp, C.POINTER(CodePredicate)]),
+    ("qso_select_codes", None, [_int, _vp, _i64, _int, C.c_uint32, C.c_uint32, _vp, _vp]),
+    ("qso_decode_codes", None, [_int, _vp, _i64, _vp, _int, _vp]),
     ("qso_agg_state_create", _vp, [C.POINTER(T.AggConfig)]),
     ("qso_agg_state_destroy", None, [_vp]),
     ("qso_agg_update", None, [_vp, _pp, _i64, _vp]),
@@ -285,6 +297,62 @@ def select_cmp_columns(lhs, rhs, op, filter_bitmap=None):
 def tids_to_bitmap(tids, num_bits, base_tid=0):
     out = np.zeros(max(words(num_bits), 1), dtype=np.uint64)
     _lib.qso_tids_to_bitmap(_p(tids), tids.size, base_tid, num_bits, _p(out))
+    return out
+
+
+# ---- compressed attributes --------------------------------------------------------------
+PRED_ALL, PRED_NONE, PRED_BASIC, PRED_RANGE = range(4)
+_CODE_DTYPE = {1: np.uint8, 2: np.uint16, 4: np.uint32}
+
+
+class CompressedColumn:
+    """One attribute of a CompressedColumnStore block as CompressedBlockBuilder would store it:
+    kind 0 uncompressed (codes = the values), 1 truncated, 2 dictionary-coded."""
+
+    def __init__(self, values):
+        values = np.ascontiguousarray(values)
+        self.type = _NP_TYPE[values.dtype]
+        self.dtype = values.dtype
+        self.n = values.size
+        self.info = CompressedInfo()
+        raw = np.zeros(max(values.size, 1) * 8, dtype=np.uint8)
+        dictionary = np.zeros(max(values.size, 1), dtype=values.dtype)
+        _lib.qso_compress_column(self.type, _p(values), values.size, C.byref(self.info), _p(raw), _p(dictionary))
+        self.kind, self.code_width = self.info.kind, self.info.code_width
+        if self.kind == 0:
+            self.codes = raw[: values.size * values.dtype.itemsize].view(values.dtype).copy()
+            self.dictionary = None
+        else:
+            self.codes = raw[: values.size * self.code_width].view(_CODE_DTYPE[self.code_width]).copy()
+            self.dictionary = dictionary[: self.info.num_codes].copy() if self.kind == 2 else None
+
+    def transform(self, op, literal):
+        """TransformPredicateOnCompressedAttribute -> CodePredicate (kinds 1 and 2 only)."""
+        lit = np.array([literal], dtype=self.dtype)
+        out = CodePredicate()
+        _lib.qso_transform_predicate(C.byref(self.info), self.type, _p(self.dictionary), op, _p(lit), C.byref(out))
+        return out
+
+    def matches(self, op, literal, filter_bitmap=None):
+        """getMatchesForPredicate on the code stripe (CompressedTupleStorageSubBlock.cpp:160-250)."""
+        pred = self.transform(op, literal)
+        if pred.result == PRED_NONE:
+            return np.zeros(max(words(self.n), 1), dtype=np.uint64)
+        if pred.result == PRED_ALL:
+            return bitmap_from_bools(np.ones(self.n, dtype=bool)) if filter_bitmap is None else filter_bitmap.copy()
+        return select_codes(self.codes, pred.comp, pred.first, pred.second, filter_bitmap)
+
+    def decode(self):
+        if self.kind == 0:
+            return self.codes.copy()
+        out = np.zeros(self.n, dtype=self.dtype)
+        _lib.qso_decode_codes(self.code_width, _p(self.codes), self.n, _p(self.dictionary), self.dtype.itemsize, _p(out))
+        return out
+
+
+def select_codes(codes, op, first, second=0, filter_bitmap=None):
+    out = np.zeros(max(words(codes.size), 1), dtype=np.uint64)
+    _lib.qso_select_codes(codes.dtype.itemsize, _p(codes), codes.size, op, first, second, _p(filter_bitmap), _p(out))
     return out
 
 

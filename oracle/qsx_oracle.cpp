@@ -7,6 +7,7 @@
 
 #include "qsx_oracle.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -1264,6 +1265,236 @@ double qso_bench_select(int type, const void *col, int64_t n, int op, const void
   const double elapsed = seconds_since(t0);
   *out_rows = out_pos.load();
   return elapsed;
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// compressed attributes
+// ===========================================================================
+namespace {
+
+template <typename T>
+void compress_column_t(int type, const T *values, std::int64_t n, qso_compressed_info_t *info, void *out_codes,
+                       void *out_dictionary) {
+  const std::size_t width = sizeof(T);
+  // CompressionDictionaryBuilder: distinct values, code length in bits grows when the count passes a
+  // power of two (compression/CompressionDictionaryBuilder.cpp:128-134), padded to 1/2/4 bytes (.hpp:87-95),
+  // dictionary = 2 uint32 header words + the values (.hpp:103-110); values sorted at build time.
+  std::vector<T> dict(values, values + n);
+  std::sort(dict.begin(), dict.end());
+  dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
+  unsigned code_bits = 0;
+  for (std::size_t num_values = 1; num_values <= dict.size(); ++num_values) {
+    if (code_bits == 0 || num_values == (1ull << code_bits) + 1) ++code_bits;
+  }
+  const std::size_t dict_code_bytes = code_bits < 9 ? 1 : (code_bits < 17 ? 2 : 4);
+  const std::size_t dictionary_bytes = 2 * sizeof(std::uint32_t) + dict.size() * width + static_cast<std::size_t>(n) * dict_code_bytes;
+  // computeTruncatedByteLengthForAttribute (storage/CompressedBlockBuilder.cpp:508-566): INT/LONG only, no
+  // negative value, by the leading zeros of the maximum; LONG maximum == UINT32_MAX is not truncated.
+  std::size_t truncated_width = width;
+  if ((type == QSX_INT || type == QSX_LONG) && n > 0) {
+    bool negative = false;
+    std::int64_t mx = 0;
+    for (std::int64_t i = 0; i < n; ++i) {
+      const std::int64_t v = static_cast<std::int64_t>(values[i]);
+      negative = negative || v < 0;
+      mx = v > mx ? v : mx;
+    }
+    if (!negative && !(type == QSX_LONG && mx == 0xFFFFFFFFll)) {
+      unsigned needed_bits = 0;
+      while (needed_bits < 64 && (static_cast<std::uint64_t>(mx) >> needed_bits) != 0) ++needed_bits;
+      if (needed_bits < 9) truncated_width = 1;
+      else if (needed_bits < 17) truncated_width = 2;
+      else if (needed_bits < 33) truncated_width = 4;
+    }
+  }
+  const std::size_t truncated_bytes = static_cast<std::size_t>(n) * truncated_width;
+  // buildCompressionInfo (:590-650): the smaller representation wins, ties go to the dictionary
+  if (truncated_bytes < dictionary_bytes) {
+    info->kind = truncated_width < width ? 1 : 0;
+    info->code_width = static_cast<int>(truncated_width);
+    info->num_codes = 0;
+    for (std::int64_t i = 0; i < n; ++i) {
+      const std::uint64_t v = static_cast<std::uint64_t>(static_cast<std::int64_t>(values[i]));
+      switch (truncated_width) {
+        case 1: static_cast<std::uint8_t *>(out_codes)[i] = static_cast<std::uint8_t>(v); break;
+        case 2: static_cast<std::uint16_t *>(out_codes)[i] = static_cast<std::uint16_t>(v); break;
+        default:
+          if (truncated_width == 4 && info->kind == 1) static_cast<std::uint32_t *>(out_codes)[i] = static_cast<std::uint32_t>(v);
+          else std::memcpy(static_cast<char *>(out_codes) + i * width, &values[i], width);   // uncompressed: as it is
+          break;
+      }
+    }
+    return;
+  }
+  info->kind = 2;
+  info->code_width = static_cast<int>(dict_code_bytes);
+  info->num_codes = static_cast<std::uint32_t>(dict.size());
+  std::memcpy(out_dictionary, dict.data(), dict.size() * width);
+  for (std::int64_t i = 0; i < n; ++i) {
+    const std::uint32_t code = static_cast<std::uint32_t>(std::lower_bound(dict.begin(), dict.end(), values[i]) - dict.begin());
+    switch (dict_code_bytes) {
+      case 1: static_cast<std::uint8_t *>(out_codes)[i] = static_cast<std::uint8_t>(code); break;
+      case 2: static_cast<std::uint16_t *>(out_codes)[i] = static_cast<std::uint16_t>(code); break;
+      default: static_cast<std::uint32_t *>(out_codes)[i] = code; break;
+    }
+  }
+}
+
+constexpr std::uint32_t kU32Max = 0xFFFFFFFFu;
+
+// TransformPredicateOnCompressedAttribute for a literal of the attribute's own type, no NULLs
+// (storage/CompressedStoreUtil.cpp:51-140, 425-616).
+template <typename T>
+void transform_predicate_t(const qso_compressed_info_t &info, const T *dict, int op, T lit, qso_code_predicate_t *out) {
+  out->result = 1;  // NONE
+  out->comp = QSX_CODE_EQ;
+  out->first = out->second = 0;
+  auto basic = [&](int comp, std::uint32_t code) { out->result = 2; out->comp = comp; out->first = code; };
+  std::pair<std::uint32_t, std::uint32_t> range(0, 0);
+  if (info.kind == 2) {
+    const T *end = dict + info.num_codes;
+    const std::uint32_t lower = static_cast<std::uint32_t>(std::lower_bound(dict, end, lit) - dict);
+    const std::uint32_t upper = static_cast<std::uint32_t>(std::upper_bound(dict, end, lit) - dict);
+    const bool present = lower != upper;
+    if (op == QSX_EQ) {        // TransformEqualPredicate... (:425-470)
+      if (present) basic(QSX_CODE_EQ, lower);
+      return;
+    }
+    if (op == QSX_NE) {        // TransformNotEqualPredicate... (:472-535), dictionary without a null code
+      if (!present) { out->result = 0; return; }
+      basic(QSX_CODE_NE, lower);
+      return;
+    }
+    // getLimitCodesForComparisonTyped (compression/CompressionDictionary.cpp:276-305)
+    switch (op) {
+      case QSX_LT: range = {0, lower}; break;
+      case QSX_LE: range = {0, upper}; break;
+      case QSX_GT: range = {upper, info.num_codes}; break;
+      default: range = {lower, info.num_codes}; break;
+    }
+    if (range.first >= range.second) return;                       // NONE
+    if (range.second == info.num_codes) range.second = kU32Max;    // skips one comparison (:553-556)
+  } else {
+    // truncated attribute: TruncationHelper (:144-236) + always-true / always-false tests (:266-420)
+    const std::int64_t max_truncated = info.code_width == 4 ? 0xFFFFFFFFll : (1ll << (8 * info.code_width)) - 1;
+    const double as_double = static_cast<double>(lit);
+    const bool long_exact = std::is_integral<T>::value || as_double == static_cast<double>(static_cast<std::int64_t>(as_double));
+    const std::int64_t as_long = static_cast<std::int64_t>(lit);
+    const bool in_range = as_long >= 0 && as_long <= max_truncated;
+    if (op == QSX_EQ) {
+      if (long_exact && in_range) basic(QSX_CODE_EQ, static_cast<std::uint32_t>(as_long));
+      return;
+    }
+    if (op == QSX_NE) {
+      if (!long_exact || !in_range) { out->result = 0; return; }
+      basic(QSX_CODE_NE, static_cast<std::uint32_t>(as_long));
+      return;
+    }
+    std::int64_t eff = as_long;   // GetEffectiveLiteralForComparison (:208-230): round towards the matching side
+    if (!long_exact) eff = (op == QSX_LT || op == QSX_GE) ? static_cast<std::int64_t>(std::ceil(as_double)) : static_cast<std::int64_t>(std::floor(as_double));
+    bool always_true = false, always_false = false;
+    switch (op) {
+      case QSX_LT: always_true = eff > max_truncated; always_false = eff <= 0; break;
+      case QSX_LE: always_true = eff >= max_truncated; always_false = eff < 0; break;
+      case QSX_GT: always_true = eff < 0; always_false = eff >= max_truncated; break;
+      default: always_true = eff <= 0; always_false = eff > max_truncated; break;
+    }
+    if (always_true) { out->result = 0; return; }
+    if (always_false) return;
+    switch (op) {
+      case QSX_LT: range = {0, static_cast<std::uint32_t>(eff)}; break;
+      case QSX_LE: range = {0, static_cast<std::uint32_t>(eff + 1)}; break;
+      case QSX_GT: range = {static_cast<std::uint32_t>(eff + 1), kU32Max}; break;
+      default: range = {static_cast<std::uint32_t>(eff), kU32Max}; break;
+    }
+  }
+  // :590-612
+  if (range.first == 0) {
+    if (range.second == kU32Max) out->result = 0;
+    else basic(QSX_CODE_LT, range.second);
+  } else if (range.second == kU32Max) {
+    basic(QSX_CODE_GE, range.first);
+  } else {
+    out->result = 3;
+    out->comp = QSX_CODE_RANGE;
+    out->first = range.first;
+    out->second = range.second;
+  }
+}
+
+template <typename C>
+void select_codes_t(const C *codes, std::int64_t n, int op, std::uint32_t first, std::uint32_t second,
+                    const std::uint64_t *filter, std::uint64_t *out) {
+  // getEqualCodes / getNotEqualCodes / getCodesSatisfyingComparison / getCodesInRange
+  // (storage/CompressedColumnStoreTupleStorageSubBlock.cpp:420-760); the short-circuit variants only
+  // visit the filter's tuples, the others intersect afterwards: same result.
+  std::memset(out, 0, sizeof(std::uint64_t) * bitmap_words(n));
+  for (std::int64_t i = 0; i < n; ++i) {
+    if (filter != nullptr && !bit_get(filter, i)) continue;
+    const std::uint32_t c = codes[i];
+    bool m;
+    switch (op) {
+      case QSX_CODE_EQ: m = c == first; break;
+      case QSX_CODE_NE: m = c != first; break;
+      case QSX_CODE_LT: m = c < first; break;
+      case QSX_CODE_GE: m = c >= first; break;
+      default: m = c >= first && c < second; break;
+    }
+    if (m) bit_set(out, i);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void qso_compress_column(int type, const void *values, int64_t n, qso_compressed_info_t *info, void *out_codes,
+                         void *out_dictionary) {
+  switch (type) {
+    case QSX_INT: compress_column_t(type, static_cast<const std::int32_t *>(values), n, info, out_codes, out_dictionary); break;
+    case QSX_LONG: compress_column_t(type, static_cast<const std::int64_t *>(values), n, info, out_codes, out_dictionary); break;
+    case QSX_FLOAT: compress_column_t(type, static_cast<const float *>(values), n, info, out_codes, out_dictionary); break;
+    default: compress_column_t(type, static_cast<const double *>(values), n, info, out_codes, out_dictionary); break;
+  }
+}
+
+void qso_transform_predicate(const qso_compressed_info_t *info, int type, const void *dictionary, int op, const void *literal,
+                             qso_code_predicate_t *out) {
+  switch (type) {
+    case QSX_INT: { std::int32_t l; std::memcpy(&l, literal, 4); transform_predicate_t(*info, static_cast<const std::int32_t *>(dictionary), op, l, out); break; }
+    case QSX_LONG: { std::int64_t l; std::memcpy(&l, literal, 8); transform_predicate_t(*info, static_cast<const std::int64_t *>(dictionary), op, l, out); break; }
+    case QSX_FLOAT: { float l; std::memcpy(&l, literal, 4); transform_predicate_t(*info, static_cast<const float *>(dictionary), op, l, out); break; }
+    default: { double l; std::memcpy(&l, literal, 8); transform_predicate_t(*info, static_cast<const double *>(dictionary), op, l, out); break; }
+  }
+}
+
+void qso_select_codes(int code_width, const void *codes, int64_t n, int op, uint32_t first, uint32_t second, const uint64_t *filter,
+                      uint64_t *out_bitmap) {
+  switch (code_width) {
+    case 1: select_codes_t(static_cast<const std::uint8_t *>(codes), n, op, first, second, filter, out_bitmap); break;
+    case 2: select_codes_t(static_cast<const std::uint16_t *>(codes), n, op, first, second, filter, out_bitmap); break;
+    default: select_codes_t(static_cast<const std::uint32_t *>(codes), n, op, first, second, filter, out_bitmap); break;
+  }
+}
+
+void qso_decode_codes(int code_width, const void *codes, int64_t n, const void *dictionary, int value_width, void *out) {
+  for (int64_t i = 0; i < n; ++i) {
+    std::uint32_t c;
+    switch (code_width) {
+      case 1: c = static_cast<const std::uint8_t *>(codes)[i]; break;
+      case 2: c = static_cast<const std::uint16_t *>(codes)[i]; break;
+      default: c = static_cast<const std::uint32_t *>(codes)[i]; break;
+    }
+    if (dictionary != nullptr) {
+      std::memcpy(static_cast<char *>(out) + i * value_width, static_cast<const char *>(dictionary) + static_cast<size_t>(c) * value_width, value_width);
+    } else if (value_width == 4) {
+      static_cast<std::uint32_t *>(out)[i] = c;
+    } else {
+      static_cast<std::uint64_t *>(out)[i] = c;
+    }
+  }
 }
 
 }  // extern "C"

@@ -58,6 +58,8 @@ _SIGNATURES = {
     "qsx_stream_destroy": (_int, [_vp]),
     "qsx_select_cmp": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "qsx_select_cmp_columns": (_int, [_int, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
+    "qsx_select_codes": (_int, [_int, _vp, _i64, _int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "qsx_decode_codes": (_int, [_int, _vp, _i64, _vp, _int, _vp, _vp]),
     "qsx_bitmap_combine": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_bitmap_count": (_int, [_vp, _i64, _vp, _vp]),
     "qsx_compact_workspace_bytes": (_sz, [_i64]),
@@ -173,6 +175,24 @@ def select_cmp_columns(lhs, rhs, op, filter_bitmap=None, stream=None):
     _check(_lib.qsx_select_cmp_columns(qsx_type_of(lhs), _ptr(lhs), _ptr(rhs), n, op, _ptr(filter_bitmap),
                                        _ptr(out_bitmap), _ptr(out_count), _stream(stream)), "qsx_select_cmp_columns")
     return out_bitmap, out_count
+
+
+def select_codes(codes, op, first, second=0, filter_bitmap=None, stream=None):
+    """K1 on a compressed attribute's code stripe (uint8 / int16 / int32 tensors holding unsigned codes)."""
+    n = codes.numel()
+    out_bitmap = new_bitmap(n, codes.device)
+    out_count = torch.zeros(1, dtype=torch.int64, device=codes.device)
+    _check(_lib.qsx_select_codes(codes.element_size(), _ptr(codes), n, op, first, second, _ptr(filter_bitmap),
+                                 _ptr(out_bitmap), _ptr(out_count), _stream(stream)), "qsx_select_codes")
+    return out_bitmap, out_count
+
+
+def decode_codes(codes, dictionary, value_dtype, stream=None):
+    """codes -> values: dictionary lookup, or zero-extension when dictionary is None (truncated attribute)."""
+    out = torch.empty(codes.numel(), dtype=value_dtype, device=codes.device)
+    _check(_lib.qsx_decode_codes(codes.element_size(), _ptr(codes), codes.numel(), _ptr(dictionary), out.element_size(),
+                                 _ptr(out), _stream(stream)), "qsx_decode_codes")
+    return out
 
 
 def bitmap_combine(op, a, b, n, out=None, stream=None):

@@ -305,6 +305,91 @@ static int run_compaction(const GatherArgs &args, const uint64_t *bitmap, int64_
   return QSX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// K1 on compressed attributes: comparisons on the code stripe (1/2/4-byte unsigned codes of a
+// dictionary-coded or truncated attribute), storage/CompressedColumnStoreTupleStorageSubBlock.cpp:
+// getEqualCodes / getNotEqualCodes / getLessCodes / getGreaterOrEqualCodes / getCodesInRange.
+// Same wave layout as select_cmp_kernel; a 1-byte code column moves a quarter of the bytes of the INT
+// column it stands for.
+// ---------------------------------------------------------------------------
+template <typename T, int R>
+__global__ __launch_bounds__(kBlock) void select_codes_kernel(const T *__restrict__ codes, int64_t n, int op, uint32_t first,
+                                                             uint32_t second, const uint64_t *__restrict__ filter,
+                                                             uint64_t *__restrict__ out,
+                                                             unsigned long long *__restrict__ out_count) {
+  const int lane = lane_id();
+  const int64_t num_words = (n + 63) >> 6;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t num_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  // every operator is one range test lo <= code < hi on 64-bit bounds, NE its complement
+  // (selects, not a switch: the switch form left `lo` undefined on the RANGE path in the generated code)
+  const unsigned long long lo = op == QSX_CODE_LT ? 0ull : first;
+  const unsigned long long hi = (op == QSX_CODE_EQ || op == QSX_CODE_NE) ? static_cast<unsigned long long>(first) + 1
+                                : op == QSX_CODE_LT ? first
+                                : op == QSX_CODE_GE ? (1ull << 32)
+                                                    : second;   // QSX_CODE_RANGE: [first, second)
+  const bool negate = op == QSX_CODE_NE;
+  unsigned long long count = 0;
+  for (int64_t w0 = wave * R; w0 < num_words; w0 += num_waves * R) {
+    T v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ((w0 + r) << 6) + lane;
+      v[r] = row < n ? codes[row] : T();
+    }
+    uint64_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ((w0 + r) << 6) + lane;
+      const unsigned long long c = v[r];
+      bool pred = row < n && ((c >= lo && c < hi) != negate);
+      if (filter != nullptr && w0 + r < num_words) pred = pred && msb_bit(filter[w0 + r], lane);
+      const uint64_t word = msb_first(__ballot(pred));
+      count += __popcll(word);
+      if (lane == r) mine = word;
+    }
+    if (lane < R && w0 + lane < num_words) out[w0 + lane] = mine;
+  }
+  if (out_count != nullptr) {
+    __shared__ unsigned long long block_count;
+    if (threadIdx.x == 0) block_count = 0;
+    __syncthreads();
+    if (lane == 0 && count != 0) atomicAdd(&block_count, count);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_count != 0) atomicAdd(out_count, block_count);
+  }
+}
+
+// Decode a code stripe: dictionary lookup (codes index a dictionary of `value_width`-byte values that
+// stays in L2 / L1) or zero-extension of a truncated value.
+template <typename C, typename V>
+__global__ __launch_bounds__(kBlock) void decode_codes_kernel(const C *__restrict__ codes, int64_t n,
+                                                             const V *__restrict__ dictionary, V *__restrict__ out) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const C c = codes[i];
+    out[i] = dictionary != nullptr ? dictionary[c] : static_cast<V>(c);
+  }
+}
+
+template <typename C>
+static int launch_decode(const void *codes, int64_t n, const void *dictionary, int value_width, void *out, hipStream_t s) {
+  const int grid = grid_for(n, kBlock * 4);
+  switch (value_width) {
+    case 4:
+      hipLaunchKernelGGL((decode_codes_kernel<C, uint32_t>), dim3(grid), dim3(kBlock), 0, s, static_cast<const C *>(codes), n,
+                         static_cast<const uint32_t *>(dictionary), static_cast<uint32_t *>(out));
+      break;
+    case 8:
+      hipLaunchKernelGGL((decode_codes_kernel<C, uint64_t>), dim3(grid), dim3(kBlock), 0, s, static_cast<const C *>(codes), n,
+                         static_cast<const uint64_t *>(dictionary), static_cast<uint64_t *>(out));
+      break;
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
 // tuple-id list -> TupleIdSequence (bit = tid - base): one atomicOr per tid, skipped when the bit is already set
 __global__ __launch_bounds__(kBlock) void tids_to_bitmap_kernel(const int32_t *__restrict__ tids, int64_t n, int32_t base_tid,
                                                                int64_t num_bits, unsigned long long *__restrict__ out) {
@@ -358,6 +443,52 @@ int qsx_select_cmp_columns(int type, const void *lhs_dev, const void *rhs_dev, i
     case QSX_LONG: return dispatch_select_op<int64_t>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
     case QSX_FLOAT: return dispatch_select_op<float>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
     case QSX_DOUBLE: return dispatch_select_op<double>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+}
+
+int qsx_select_codes(int code_width, const void *codes_dev, int64_t n, int op, uint32_t first, uint32_t second,
+                     const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || op < QSX_CODE_EQ || op > QSX_CODE_RANGE || (n > 0 && (codes_dev == nullptr || out_bitmap_dev == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return QSX_OK;
+  const int64_t num_words = (n + 63) >> 6;
+  constexpr int R = 8;
+  const int grid = grid_for(num_words, kWavesPerBlock * R);
+  unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count_dev);
+  switch (code_width) {
+    case 1:
+      hipLaunchKernelGGL((select_codes_kernel<uint8_t, R>), dim3(grid), dim3(kBlock), 0, s, static_cast<const uint8_t *>(codes_dev),
+                         n, op, first, second, filter_dev, out_bitmap_dev, count);
+      break;
+    case 2:
+      hipLaunchKernelGGL((select_codes_kernel<uint16_t, R>), dim3(grid), dim3(kBlock), 0, s, static_cast<const uint16_t *>(codes_dev),
+                         n, op, first, second, filter_dev, out_bitmap_dev, count);
+      break;
+    case 4:
+      hipLaunchKernelGGL((select_codes_kernel<uint32_t, R>), dim3(grid), dim3(kBlock), 0, s, static_cast<const uint32_t *>(codes_dev),
+                         n, op, first, second, filter_dev, out_bitmap_dev, count);
+      break;
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_decode_codes(int code_width, const void *codes_dev, int64_t n, const void *dictionary_dev, int value_width,
+                     void *out_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || (n > 0 && (codes_dev == nullptr || out_dev == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
+  if (n == 0) return QSX_OK;
+  hipStream_t s = as_stream(stream);
+  switch (code_width) {
+    case 1: return launch_decode<uint8_t>(codes_dev, n, dictionary_dev, value_width, out_dev, s);
+    case 2: return launch_decode<uint16_t>(codes_dev, n, dictionary_dev, value_width, out_dev, s);
+    case 4: return launch_decode<uint32_t>(codes_dev, n, dictionary_dev, value_width, out_dev, s);
     default: return QSX_ERR_UNSUPPORTED;
   }
 }

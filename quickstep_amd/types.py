@@ -10,6 +10,7 @@ import ctypes as C
 INT, LONG, FLOAT, DOUBLE, CHAR = 0, 1, 2, 3, 4
 # qsx_cmp_t (types/operations/comparisons/ComparisonID.hpp:36-42)
 EQ, NE, LT, LE, GT, GE = range(6)
+CODE_EQ, CODE_NE, CODE_LT, CODE_GE, CODE_RANGE = range(5)            # qsx_code_cmp_t
 # qsx_agg_strategy_t
 AGG_SINGLE_STATE, AGG_COMPACT_KEY, AGG_COLLISION_FREE, AGG_GENERIC = range(4)
 # qsx_agg_fn_t

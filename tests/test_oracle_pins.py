@@ -388,3 +388,77 @@ def test_agg_unittest_min_max(oracle, golden):
     st = oracle.AggState(T.make_agg_config(T.AGG_SINGLE_STATE, layout, aggs=aggs, pred=[(2, T.LT, -1)]))
     st.update(cols)
     assert all(z[0] == 1 for z in st.finalize()[2])
+
+
+def _compressed_cases():
+    rng = np.random.default_rng(9)
+    yield "int truncated to 1 byte", rng.integers(0, 200, size=5000).astype(np.int32), 1, 1
+    yield "long truncated to 2 bytes", rng.integers(0, 60000, size=5000).astype(np.int64), 1, 2
+    yield "long truncated to 4 bytes", rng.integers(0, 2**31, size=5000).astype(np.int64), 1, 4
+    yield "int dictionary (negative values, few distinct)", rng.choice(np.array([-7, -1, 3, 900, 10**6], dtype=np.int32), size=5000), 2, 1
+    yield "double dictionary (TPC-H discount)", rng.integers(0, 11, size=5000) / 100.0, 2, 1
+    yield "float dictionary, 2-byte codes", (rng.integers(0, 700, size=20000) * 0.5).astype(np.float32), 2, 2
+    yield "int incompressible", rng.integers(-2**31, 2**31 - 1, size=3000).astype(np.int32), 0, 4
+
+
+def test_compression_choice_follows_the_block_builder(oracle):
+    """CompressedBlockBuilder (storage/CompressedBlockBuilder.cpp:508-566, 590-650): truncation by the leading zeros of the
+    maximum (non-negative INT/LONG only), dictionary code width by the number of distinct values, the smaller wins."""
+    for name, values, kind, width in _compressed_cases():
+        col = oracle.CompressedColumn(values)
+        assert (col.kind, col.code_width) == (kind, width), name
+        assert np.array_equal(col.decode(), values), name
+        if kind == 2:
+            assert np.array_equal(col.dictionary, np.unique(values)), name
+    # LONG maximum == UINT32_MAX must not be truncated (:538-542); one negative value forbids truncation
+    assert oracle.CompressedColumn(np.array([5, 2**32 - 1] * 300, dtype=np.int64)).kind == 2
+    assert oracle.CompressedColumn(np.arange(-1, 4000, dtype=np.int64)).kind != 1
+
+
+def test_predicates_on_codes_equal_predicates_on_values(oracle):
+    """TransformPredicateOnCompressedAttribute + the code-stripe scans (CompressedStoreUtil.cpp:51-140, 425-616;
+    CompressedColumnStoreTupleStorageSubBlock.cpp:420-760): for every comparison and literals below, inside, between and
+    above the stored values the matches on codes are the matches of the comparison on the decoded values."""
+    rng = np.random.default_rng(10)
+    for name, values, kind, width in _compressed_cases():
+        if kind == 0:
+            continue
+        col = oracle.CompressedColumn(values)
+        lits = [values.min(), values.max(), np.sort(values)[values.size // 2], values.min() - 1, values.max() + 1]
+        if values.dtype.kind == "f":
+            lits += [np.sort(np.unique(values))[3] + values.dtype.type(0.001), values.dtype.type(-0.5)]
+        else:
+            lits += [0, 1, 255, 256, 65535, 65536]
+        f = oracle.bitmap_from_bools(rng.random(values.size) < 0.5)
+        for lit in lits:
+            if values.dtype.kind != "f" and not (np.iinfo(values.dtype).min <= int(lit) <= np.iinfo(values.dtype).max):
+                continue
+            lit = values.dtype.type(lit)
+            for op in range(6):
+                want = oracle.select_cmp(values, op, lit)
+                assert np.array_equal(col.matches(op, lit), want), (name, op, lit)
+                assert np.array_equal(col.matches(op, lit, filter_bitmap=f), oracle.select_cmp(values, op, lit, filter_bitmap=f)), (name, op, lit)
+
+
+def test_predicate_transformer_result_kinds(oracle):
+    """The shapes the transformer produces (CompressedStoreUtil.cpp:548-612): range ends at the code count -> >=,
+    starts at 0 -> <, covers everything -> ALL, empty -> NONE; literals absent from the dictionary."""
+    d = oracle.CompressedColumn(np.array([10, 20, 30, 40] * 100, dtype=np.int32) - 25)      # dictionary: -15 -5 5 15
+    assert d.kind == 2
+    t = d.transform(T.EQ, 5)
+    assert (t.result, t.comp, t.first) == (oracle.PRED_BASIC, T.CODE_EQ, 2)
+    assert d.transform(T.EQ, 6).result == oracle.PRED_NONE and d.transform(T.NE, 6).result == oracle.PRED_ALL
+    t = d.transform(T.LT, 5)
+    assert (t.result, t.comp, t.first) == (oracle.PRED_BASIC, T.CODE_LT, 2)
+    t = d.transform(T.GT, -5)
+    assert (t.result, t.comp, t.first) == (oracle.PRED_BASIC, T.CODE_GE, 2)
+    assert d.transform(T.GE, -100).result == oracle.PRED_ALL and d.transform(T.GT, 15).result == oracle.PRED_NONE
+    tr = oracle.CompressedColumn(np.arange(0, 200, dtype=np.int64))                          # truncated to 1 byte
+    assert tr.kind == 1 and tr.code_width == 1
+    assert tr.transform(T.LT, 0).result == oracle.PRED_NONE and tr.transform(T.GE, 0).result == oracle.PRED_ALL
+    assert tr.transform(T.EQ, 300).result == oracle.PRED_NONE and tr.transform(T.NE, -1).result == oracle.PRED_ALL
+    t = tr.transform(T.LE, 7)
+    assert (t.result, t.comp, t.first) == (oracle.PRED_BASIC, T.CODE_LT, 8)
+    t = tr.transform(T.GT, 7)
+    assert (t.result, t.comp, t.first) == (oracle.PRED_BASIC, T.CODE_GE, 8)
+    assert tr.transform(T.LE, 255).result == oracle.PRED_ALL                                  # >= the largest 1-byte code
