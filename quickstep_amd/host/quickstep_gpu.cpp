@@ -4,6 +4,7 @@
 #include "quickstep_gpu.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -123,6 +124,10 @@ StorageBlock::~StorageBlock() {
     if (p == nullptr) continue;
     if (g_host_memory) std::free(p); else qsx_device_free(p);
   }
+  for (CompressedAttribute &c : compressed_) {
+    qsx_device_free(c.codes);
+    qsx_device_free(c.dictionary);
+  }
 }
 void StorageBlock::copyNullBitmapToHost(attribute_id a, std::uint64_t *dst) const {
   const std::size_t bytes = static_cast<std::size_t>((num_tuples_ + 63) / 64) * 8;
@@ -139,8 +144,203 @@ void StorageBlock::copyAttributeToHost(attribute_id a, void *dst) const {
   if (g_host_memory) {
     std::memcpy(dst, stripes_.at(a), bytes);
   } else {
-    CheckStatus(qsx_copy_to_host(dst, stripes_.at(a), bytes, CurrentStream()), "qsx_copy_to_host");
+    CheckStatus(qsx_copy_to_host(dst, stripe(a), bytes, CurrentStream()), "qsx_copy_to_host");
   }
+}
+
+void *StorageBlock::stripe(attribute_id a) const {
+  if (compressed_.empty() || compressed_.at(a).kind == CompressedAttribute::kUncompressed) return stripes_.at(a);
+  std::lock_guard<std::mutex> lock(decode_mutex_);
+  if (stripes_.at(a) == nullptr) {
+    const CompressedAttribute &c = compressed_.at(a);
+    const int width = relation_.getAttributeType(a).width;
+    void *values = nullptr;
+    CheckStatus(qsx_device_alloc(static_cast<std::size_t>(capacity_ ? capacity_ : 1) * width, &values), "qsx_device_alloc(decoded stripe)");
+    CheckStatus(qsx_decode_codes(c.code_width, c.codes, num_tuples_, c.dictionary, width, values, CurrentStream()), "qsx_decode_codes");
+    CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // other workers' streams read it next
+    stripes_.at(a) = values;
+  }
+  return stripes_.at(a);
+}
+
+namespace {
+// CompressedBlockBuilder's per-attribute decision for fixed-width numeric attributes without NULLs
+// (storage/CompressedBlockBuilder.cpp:508-566 truncated width, :590-650 truncation vs dictionary;
+// compression/CompressionDictionaryBuilder.{hpp:87-110,cpp:128-134} code length and dictionary size).
+template <typename T>
+void BuildCompressedAttribute(TypeID type, const T *values, std::int64_t n, CompressedAttribute *out,
+                              std::vector<unsigned char> *codes_host) {
+  std::vector<T> dict(values, values + n);
+  std::sort(dict.begin(), dict.end());
+  dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
+  unsigned code_bits = 0;
+  for (std::size_t num_values = 1; num_values <= dict.size(); ++num_values) {
+    if (code_bits == 0 || num_values == (1ull << code_bits) + 1) ++code_bits;
+  }
+  const std::size_t dict_code_bytes = code_bits < 9 ? 1 : (code_bits < 17 ? 2 : 4);
+  const std::size_t dictionary_bytes = 2 * sizeof(std::uint32_t) + dict.size() * sizeof(T) + static_cast<std::size_t>(n) * dict_code_bytes;
+  std::size_t truncated_width = sizeof(T);
+  if ((type == kInt || type == kLong) && n > 0) {
+    bool negative = false;
+    std::int64_t mx = 0;
+    for (std::int64_t i = 0; i < n; ++i) {
+      const std::int64_t v = static_cast<std::int64_t>(values[i]);
+      negative = negative || v < 0;
+      mx = std::max(mx, v);
+    }
+    if (!negative && !(type == kLong && mx == 0xFFFFFFFFll)) {
+      unsigned needed_bits = 0;
+      while (needed_bits < 64 && (static_cast<std::uint64_t>(mx) >> needed_bits) != 0) ++needed_bits;
+      if (needed_bits < 9) truncated_width = 1;
+      else if (needed_bits < 17) truncated_width = 2;
+      else if (needed_bits < 33) truncated_width = 4;
+    }
+  }
+  auto put_code = [&](std::int64_t i, std::uint64_t code, std::size_t width) {
+    switch (width) {
+      case 1: (*codes_host)[i] = static_cast<unsigned char>(code); break;
+      case 2: reinterpret_cast<std::uint16_t *>(codes_host->data())[i] = static_cast<std::uint16_t>(code); break;
+      default: reinterpret_cast<std::uint32_t *>(codes_host->data())[i] = static_cast<std::uint32_t>(code); break;
+    }
+  };
+  if (static_cast<std::size_t>(n) * truncated_width < dictionary_bytes) {
+    if (truncated_width == sizeof(T)) {
+      out->kind = CompressedAttribute::kUncompressed;
+      return;
+    }
+    out->kind = CompressedAttribute::kTruncated;
+    out->code_width = static_cast<int>(truncated_width);
+    codes_host->assign(static_cast<std::size_t>(n) * truncated_width, 0);
+    for (std::int64_t i = 0; i < n; ++i) put_code(i, static_cast<std::uint64_t>(static_cast<std::int64_t>(values[i])), truncated_width);
+    return;
+  }
+  out->kind = CompressedAttribute::kDictionary;
+  out->code_width = static_cast<int>(dict_code_bytes);
+  out->num_codes = static_cast<std::uint32_t>(dict.size());
+  out->dictionary_host.assign(reinterpret_cast<const unsigned char *>(dict.data()),
+                              reinterpret_cast<const unsigned char *>(dict.data() + dict.size()));
+  codes_host->assign(static_cast<std::size_t>(n) * dict_code_bytes, 0);
+  for (std::int64_t i = 0; i < n; ++i) {
+    put_code(i, static_cast<std::uint64_t>(std::lower_bound(dict.begin(), dict.end(), values[i]) - dict.begin()), dict_code_bytes);
+  }
+}
+
+template <typename T>
+PredicateTransformResult TransformT(const CompressedAttribute &attr, ComparisonID comparison, T lit) {
+  PredicateTransformResult r;   // kNone
+  auto basic = [&](qsx_code_cmp_t comp, std::uint32_t code) {
+    r.type = PredicateTransformResult::kBasicComparison;
+    r.comp = comp;
+    r.first_literal = code;
+  };
+  constexpr std::uint32_t kMax = 0xFFFFFFFFu;
+  std::pair<std::uint32_t, std::uint32_t> range(0, 0);
+  if (attr.kind == CompressedAttribute::kDictionary) {
+    const T *dict = reinterpret_cast<const T *>(attr.dictionary_host.data());
+    const T *end = dict + attr.num_codes;
+    const std::uint32_t lower = static_cast<std::uint32_t>(std::lower_bound(dict, end, lit) - dict);
+    const std::uint32_t upper = static_cast<std::uint32_t>(std::upper_bound(dict, end, lit) - dict);
+    if (comparison == ComparisonID::kEqual) {           // TransformEqualPredicateOnCompressedAttribute (:425-470)
+      if (lower != upper) basic(QSX_CODE_EQ, lower);
+      return r;
+    }
+    if (comparison == ComparisonID::kNotEqual) {        // TransformNotEqualPredicate... (:472-535), no null code
+      if (lower == upper) r.type = PredicateTransformResult::kAll;
+      else basic(QSX_CODE_NE, lower);
+      return r;
+    }
+    switch (comparison) {                               // getLimitCodesForComparisonTyped (CompressionDictionary.cpp:276-305)
+      case ComparisonID::kLess: range = {0, lower}; break;
+      case ComparisonID::kLessOrEqual: range = {0, upper}; break;
+      case ComparisonID::kGreater: range = {upper, attr.num_codes}; break;
+      default: range = {lower, attr.num_codes}; break;
+    }
+    if (range.first >= range.second) return r;
+    if (range.second == attr.num_codes) range.second = kMax;
+  } else {
+    // truncated attribute (:144-236 TruncationHelper, :266-420 always-true / always-false)
+    const std::int64_t max_truncated = attr.code_width == 4 ? 0xFFFFFFFFll : (1ll << (8 * attr.code_width)) - 1;
+    const double as_double = static_cast<double>(lit);
+    const bool long_exact = std::is_integral<T>::value || as_double == static_cast<double>(static_cast<std::int64_t>(as_double));
+    const std::int64_t as_long = static_cast<std::int64_t>(lit);
+    const bool in_range = as_long >= 0 && as_long <= max_truncated;
+    if (comparison == ComparisonID::kEqual) {
+      if (long_exact && in_range) basic(QSX_CODE_EQ, static_cast<std::uint32_t>(as_long));
+      return r;
+    }
+    if (comparison == ComparisonID::kNotEqual) {
+      if (!long_exact || !in_range) r.type = PredicateTransformResult::kAll;
+      else basic(QSX_CODE_NE, static_cast<std::uint32_t>(as_long));
+      return r;
+    }
+    const bool lower_side = comparison == ComparisonID::kLess || comparison == ComparisonID::kGreaterOrEqual;
+    const std::int64_t eff = long_exact ? as_long
+                                        : static_cast<std::int64_t>(lower_side ? std::ceil(as_double) : std::floor(as_double));
+    bool always_true = false, always_false = false;
+    switch (comparison) {
+      case ComparisonID::kLess: always_true = eff > max_truncated; always_false = eff <= 0; break;
+      case ComparisonID::kLessOrEqual: always_true = eff >= max_truncated; always_false = eff < 0; break;
+      case ComparisonID::kGreater: always_true = eff < 0; always_false = eff >= max_truncated; break;
+      default: always_true = eff <= 0; always_false = eff > max_truncated; break;
+    }
+    if (always_true) { r.type = PredicateTransformResult::kAll; return r; }
+    if (always_false) return r;
+    switch (comparison) {
+      case ComparisonID::kLess: range = {0, static_cast<std::uint32_t>(eff)}; break;
+      case ComparisonID::kLessOrEqual: range = {0, static_cast<std::uint32_t>(eff + 1)}; break;
+      case ComparisonID::kGreater: range = {static_cast<std::uint32_t>(eff + 1), kMax}; break;
+      default: range = {static_cast<std::uint32_t>(eff), kMax}; break;
+    }
+  }
+  if (range.first == 0) {                                // :590-612
+    if (range.second == kMax) r.type = PredicateTransformResult::kAll;
+    else basic(QSX_CODE_LT, range.second);
+  } else if (range.second == kMax) {
+    basic(QSX_CODE_GE, range.first);
+  } else {
+    r.type = PredicateTransformResult::kRangeComparison;
+    r.comp = QSX_CODE_RANGE;
+    r.first_literal = range.first;
+    r.second_literal = range.second;
+  }
+  return r;
+}
+}  // namespace
+
+PredicateTransformResult TransformPredicateOnCompressedAttribute(const CompressedAttribute &attribute, TypeID type,
+                                                                 ComparisonID comparison, const TypedLiteral &literal) {
+  switch (type) {
+    case kInt: return TransformT<std::int32_t>(attribute, comparison, literal.v.i32);
+    case kLong: return TransformT<std::int64_t>(attribute, comparison, literal.v.i64);
+    case kFloat: return TransformT<float>(attribute, comparison, literal.v.f32);
+    case kDouble: return TransformT<double>(attribute, comparison, literal.v.f64);
+    default: throw ExecutionError("compressed attributes: numeric types only", QSX_ERR_UNSUPPORTED);
+  }
+}
+
+void StorageBlock::compressAttribute(attribute_id a, const void *host_values) {
+  if (g_host_memory) return;   // CPU plumbing mode keeps plain stripes
+  const Type &t = relation_.getAttributeType(a);
+  if (compressed_.empty()) compressed_.resize(relation_.size());
+  CompressedAttribute &c = compressed_.at(a);
+  std::vector<unsigned char> codes_host;
+  switch (t.id) {
+    case kInt: BuildCompressedAttribute(t.id, static_cast<const std::int32_t *>(host_values), num_tuples_, &c, &codes_host); break;
+    case kLong: BuildCompressedAttribute(t.id, static_cast<const std::int64_t *>(host_values), num_tuples_, &c, &codes_host); break;
+    case kFloat: BuildCompressedAttribute(t.id, static_cast<const float *>(host_values), num_tuples_, &c, &codes_host); break;
+    case kDouble: BuildCompressedAttribute(t.id, static_cast<const double *>(host_values), num_tuples_, &c, &codes_host); break;
+    default: return;
+  }
+  if (c.kind == CompressedAttribute::kUncompressed) return;
+  CheckStatus(qsx_device_alloc(codes_host.size() + 8, &c.codes), "qsx_device_alloc(codes)");
+  CheckStatus(qsx_copy_to_device(c.codes, codes_host.data(), codes_host.size(), nullptr), "qsx_copy_to_device(codes)");
+  if (c.kind == CompressedAttribute::kDictionary) {
+    CheckStatus(qsx_device_alloc(c.dictionary_host.size() + 8, &c.dictionary), "qsx_device_alloc(dictionary)");
+    CheckStatus(qsx_copy_to_device(c.dictionary, c.dictionary_host.data(), c.dictionary_host.size(), nullptr), "qsx_copy_to_device(dictionary)");
+  }
+  CheckStatus(qsx_stream_synchronize(nullptr), "qsx_stream_synchronize");
+  qsx_device_free(stripes_.at(a));      // the values are gone until somebody asks for them (stripe())
+  stripes_.at(a) = nullptr;
 }
 
 block_id StorageManager::createBlock(CatalogRelation *relation, std::int64_t capacity) {
@@ -152,7 +352,7 @@ block_id StorageManager::createBlock(CatalogRelation *relation, std::int64_t cap
 }
 
 block_id StorageManager::loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns,
-                                   std::int64_t num_tuples, partition_id part) {
+                                   std::int64_t num_tuples, partition_id part, const std::vector<bool> *compress) {
   BlockReference block;
   block_id id;
   {
@@ -174,6 +374,11 @@ block_id StorageManager::loadBlock(CatalogRelation *relation, const std::vector<
   }
   if (!g_host_memory) CheckStatus(qsx_stream_synchronize(nullptr), "qsx_stream_synchronize");
   block->setNumTuples(num_tuples);
+  if (compress != nullptr) {
+    for (std::size_t a = 0; a < relation->size() && a < compress->size(); ++a) {
+      if ((*compress)[a]) block->compressAttribute(static_cast<attribute_id>(a), host_columns.at(a));
+    }
+  }
   relation->addBlockToPartition(id, part);
   return id;
 }
@@ -211,11 +416,27 @@ void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num
   bool first = true;
   for (const ComparisonPredicate &term : conjuncts) {
     const Type &t = block.getRelation().getAttributeType(term.attribute);
+    const std::uint64_t *in = first ? filter : static_cast<const std::uint64_t *>(current);
     // conjunctions chain the filter through their children (short-circuit)
-    CheckStatus(qsx_select_cmp(t.id, block.stripe(term.attribute), n, static_cast<int>(term.comparison), &term.literal.v,
-                               first ? filter : static_cast<const std::uint64_t *>(current),
-                               static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
-                "qsx_select_cmp");
+    if (const CompressedAttribute *c = block.compressedAttribute(term.attribute)) {
+      // CompressedTupleStorageSubBlock::getMatchesForPredicate (storage/CompressedTupleStorageSubBlock.cpp:160-250):
+      // rewrite to a comparison on codes, scan the code stripe
+      const PredicateTransformResult r = TransformPredicateOnCompressedAttribute(*c, t.id, term.comparison, term.literal);
+      if (r.type == PredicateTransformResult::kAll || r.type == PredicateTransformResult::kNone) {
+        // every code / no code: code >= 0 resp. code < 0
+        CheckStatus(qsx_select_codes(c->code_width, c->codes, n, r.type == PredicateTransformResult::kAll ? QSX_CODE_GE : QSX_CODE_LT, 0, 0,
+                                     in, static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
+                    "qsx_select_codes");
+      } else {
+        CheckStatus(qsx_select_codes(c->code_width, c->codes, n, r.comp, r.first_literal, r.second_literal, in,
+                                     static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
+                    "qsx_select_codes");
+      }
+    } else {
+      CheckStatus(qsx_select_cmp(t.id, block.stripe(term.attribute), n, static_cast<int>(term.comparison), &term.literal.v, in,
+                                 static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
+                  "qsx_select_cmp");
+    }
     std::swap(current, next);
     first = false;
   }

@@ -134,8 +134,35 @@ struct PartitionedBlockIds {
   explicit PartitionedBlockIds(std::size_t parts) : ids(parts), generated(parts, 0) {}
 };
 
-// One device-resident BasicColumnStore block: a dense stripe per attribute
-// (storage/BasicColumnStoreTupleStorageSubBlock.cpp:100-183).
+// How one attribute of a compressed column-store block is stored (CompressedBlockBuilder's choice,
+// storage/CompressedBlockBuilder.cpp:508-566, 590-650): a stripe of 1/2/4-byte unsigned codes that are the
+// values themselves (truncated non-negative INT/LONG) or indexes into a sorted dictionary.
+struct CompressedAttribute {
+  enum Kind { kUncompressed = 0, kTruncated = 1, kDictionary = 2 };
+  Kind kind = kUncompressed;
+  int code_width = 0;
+  std::uint32_t num_codes = 0;          // dictionary entries
+  void *codes = nullptr;                // device: num_tuples codes
+  void *dictionary = nullptr;           // device copy of the dictionary (decode)
+  std::vector<unsigned char> dictionary_host;  // sorted values, attribute width each (predicate transformation)
+};
+
+// Result of rewriting `attribute OP literal` into a comparison on codes
+// (CompressedAttributePredicateTransformer::TransformPredicateOnCompressedAttribute,
+// storage/CompressedStoreUtil.cpp:51-140, 425-616).
+struct PredicateTransformResult {
+  enum Type { kAll, kNone, kBasicComparison, kRangeComparison };
+  Type type = kNone;
+  qsx_code_cmp_t comp = QSX_CODE_EQ;    // kBasicComparison: =, !=, <, >= on codes
+  std::uint32_t first_literal = 0, second_literal = 0;
+};
+struct TypedLiteral;
+PredicateTransformResult TransformPredicateOnCompressedAttribute(const CompressedAttribute &attribute, TypeID type,
+                                                                 ComparisonID comparison, const TypedLiteral &literal);
+
+// One device-resident column-store block: a dense stripe per attribute
+// (storage/BasicColumnStoreTupleStorageSubBlock.cpp:100-183), optionally compressed per attribute
+// (storage/CompressedColumnStoreTupleStorageSubBlock.cpp).
 class StorageBlock {
  public:
   StorageBlock(const CatalogRelation &relation, std::int64_t capacity, std::int64_t first_row);
@@ -146,8 +173,16 @@ class StorageBlock {
   std::int64_t capacity() const { return capacity_; }
   std::int64_t firstRow() const { return first_row_; }  // relation-global row number of tuple 0
   void setFirstRow(std::int64_t r) { first_row_ = r; }
-  void *stripe(attribute_id a) const { return stripes_.at(a); }
+  // The attribute's VALUES as a dense stripe.  A compressed attribute is decoded on first use (operators
+  // that consume values: joins, aggregates, projections); predicates on it never come here, they scan the codes.
+  void *stripe(attribute_id a) const;
   void copyAttributeToHost(attribute_id a, void *dst) const;
+  const CompressedAttribute *compressedAttribute(attribute_id a) const {
+    return compressed_.empty() || compressed_.at(a).kind == CompressedAttribute::kUncompressed ? nullptr : &compressed_.at(a);
+  }
+  // Replaces attribute a's stripe by its compressed form when CompressedBlockBuilder would (values on the host).
+  void compressAttribute(attribute_id a, const void *host_values);
+  bool valuesMaterialized(attribute_id a) const { return stripes_.at(a) != nullptr; }
   // Null bitmap of a nullable attribute (TupleIdSequence bit order, 1 = NULL; zeroed at creation),
   // nullptr for non-nullable attributes.
   std::uint64_t *nullBitmap(attribute_id a) const { return static_cast<std::uint64_t *>(null_bitmaps_.at(a)); }
@@ -159,8 +194,10 @@ class StorageBlock {
   std::int64_t capacity_;
   std::int64_t num_tuples_;
   std::int64_t first_row_;
-  std::vector<void *> stripes_;
+  mutable std::vector<void *> stripes_;          // nullptr: compressed and not decoded yet
   std::vector<void *> null_bitmaps_;
+  std::vector<CompressedAttribute> compressed_;  // empty or one per attribute
+  mutable std::mutex decode_mutex_;
 };
 typedef std::shared_ptr<StorageBlock> BlockReference;
 
@@ -170,8 +207,10 @@ class StorageManager {
   // Create an empty block with room for `capacity` tuples; first_row = rows already in the relation.
   block_id createBlock(CatalogRelation *relation, std::int64_t capacity);
   // Create a block from host columns (one pointer per attribute), copy to HBM and add it to the relation.
+  // compress: per attribute, try to store it compressed (the attribute list of the block layout's
+  // CompressedColumnStore description, storage/StorageBlockLayout.proto); nullptr = plain column store.
   block_id loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns, std::int64_t num_tuples,
-                     partition_id part = 0);
+                     partition_id part = 0, const std::vector<bool> *compress = nullptr);
   BlockReference getBlock(block_id id) const;
   void deleteBlockOrBlobFile(block_id id);
   // Registers `num_tuples` more rows of `relation`; returns the relation-global row number of the first one.

@@ -1,0 +1,183 @@
+// Compressed column-store blocks through the operators (the reference's TPC-H DDL stores lineitem,
+// orders and partsupp as compressed column stores, benchmarks/tpch/create.sql:69-121).  The same plan — Select with a
+// conjunction on compressed attributes, then a grouped aggregation over compressed inputs — runs over a relation loaded
+// with compression and over a plain copy; results must be identical, and the blocks must really hold codes
+// (truncation for small non-negative integers, dictionaries for few distinct values: CompressedBlockBuilder's choice).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "test_util.hpp"
+
+using namespace quickstep;
+
+namespace {
+constexpr std::int64_t kRows = 200000;
+constexpr std::int64_t kBlockRows = 50000;
+
+struct Lineitem {
+  std::vector<std::int32_t> linenumber, shipdate, partkey;
+  std::vector<std::int64_t> orderkey;
+  std::vector<double> quantity, discount, price;
+  Lineitem() {
+    std::uint64_t x = 88172645463325252ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (std::int64_t i = 0; i < kRows; ++i) {
+      linenumber.push_back(static_cast<std::int32_t>(rnd() % 7 + 1));            // truncated to 1 byte
+      shipdate.push_back(static_cast<std::int32_t>(19920101 + rnd() % 2500));     // 2500 distinct: 2-byte dictionary
+      partkey.push_back(static_cast<std::int32_t>(rnd() % 2000000) - 1000000);    // negative values, many distinct: stays plain
+      orderkey.push_back(static_cast<std::int64_t>(i / 4));                       // truncated to 2 or 4 bytes per block
+      quantity.push_back(static_cast<double>(rnd() % 50 + 1));                    // 50 distinct doubles: 1-byte dictionary
+      discount.push_back(static_cast<double>(rnd() % 11) / 100.0);                // 11 distinct: 1-byte dictionary
+      price.push_back(900.0 + static_cast<double>(rnd() % 10000000) / 100.0);     // ~all distinct: plain
+    }
+  }
+};
+
+void load(const Lineitem &li, CatalogRelation *rel, StorageManager *storage, bool compressed) {
+  for (const char *name : {"l_linenumber", "l_shipdate", "l_partkey"}) rel->addAttribute(name, Type::Int());
+  rel->addAttribute("l_orderkey", Type::Long());
+  for (const char *name : {"l_quantity", "l_discount", "l_extendedprice"}) rel->addAttribute(name, Type::Double());
+  const std::vector<bool> all(7, true);
+  for (std::int64_t at = 0; at < kRows; at += kBlockRows) {
+    storage->loadBlock(rel, {li.linenumber.data() + at, li.shipdate.data() + at, li.partkey.data() + at, li.orderkey.data() + at,
+                             li.quantity.data() + at, li.discount.data() + at, li.price.data() + at},
+                       kBlockRows, 0, compressed ? &all : nullptr);
+  }
+}
+
+struct Output {
+  std::vector<std::int32_t> linenumber;
+  std::vector<double> quantity, price;
+  std::vector<std::int64_t> agg_key_count;   // per l_linenumber group: count
+  std::vector<double> agg_sum_disc_price, agg_min_qty;
+};
+
+Output run(const Lineitem &li, bool compressed, bool use_foreman) {
+  CatalogRelation lineitem(1, "lineitem"), selected(2, "selected"), result(3, "result");
+  StorageManager storage;
+  load(li, &lineitem, &storage, compressed);
+  if (compressed) {
+    // what CompressedBlockBuilder decides for these columns
+    BlockReference b = storage.getBlock(lineitem.getBlocksSnapshot().front());
+    EXPECT_TRUE(b->compressedAttribute(0) != nullptr && b->compressedAttribute(0)->kind == CompressedAttribute::kTruncated &&
+                b->compressedAttribute(0)->code_width == 1);
+    EXPECT_TRUE(b->compressedAttribute(1) != nullptr && b->compressedAttribute(1)->kind == CompressedAttribute::kDictionary &&
+                b->compressedAttribute(1)->code_width == 2);
+    EXPECT_TRUE(b->compressedAttribute(2) == nullptr);
+    EXPECT_TRUE(b->compressedAttribute(3) != nullptr && b->compressedAttribute(3)->kind == CompressedAttribute::kTruncated);
+    EXPECT_TRUE(b->compressedAttribute(4) != nullptr && b->compressedAttribute(4)->kind == CompressedAttribute::kDictionary &&
+                b->compressedAttribute(4)->code_width == 1 && b->compressedAttribute(4)->num_codes == 50);
+    EXPECT_TRUE(b->compressedAttribute(5) != nullptr && b->compressedAttribute(5)->num_codes == 11);
+    EXPECT_TRUE(b->compressedAttribute(6) == nullptr);
+    EXPECT_TRUE(!b->valuesMaterialized(4));   // nothing decoded before an operator asks for the values
+  }
+  selected.addAttribute("l_linenumber", Type::Int());
+  selected.addAttribute("l_quantity", Type::Double());
+  selected.addAttribute("l_extendedprice", Type::Double());
+  result.addAttribute("l_linenumber", Type::Int());
+  result.addAttribute("count", Type::Long());
+  result.addAttribute("sum_disc", Type::Double());
+  result.addAttribute("min_qty", Type::Double());
+  QueryContext ctx;
+  Predicate pred;   // l_shipdate <= 19980902-ish AND l_quantity < 24 AND l_discount >= 0.045 AND l_orderkey >= 10
+  pred.conjuncts.push_back({1, ComparisonID::kLessOrEqual, TypedLiteral::Int(19920101 + 2000)});
+  pred.conjuncts.push_back({4, ComparisonID::kLess, TypedLiteral::Double(24.0)});
+  pred.conjuncts.push_back({5, ComparisonID::kGreaterOrEqual, TypedLiteral::Double(0.045)});   // between two dictionary values
+  pred.conjuncts.push_back({3, ComparisonID::kGreaterOrEqual, TypedLiteral::Long(10)});
+  const auto pred_id = ctx.addPredicate(pred);   // (the aggregation state takes at most QSX_MAX_PRED_TERMS = 4 terms)
+  const auto sel_dest = ctx.addInsertDestination(&selected, &storage);
+  const auto agg_dest = ctx.addInsertDestination(&result, &storage);
+  AggregationStateSpec spec;
+  spec.input_relation = &lineitem;
+  spec.group_by = {0};
+  spec.aggregates = {{AggregationID::kCount, kInvalidAttributeID}, {AggregationID::kSum, 5}, {AggregationID::kMin, 4}};
+  spec.predicate = ctx.getPredicate(pred_id);
+  spec.strategy = QSX_AGG_COMPACT_KEY;
+  spec.estimated_num_groups = 8;
+  const auto state = ctx.addAggregationState(spec);
+  auto *select = new SelectOperator(0, lineitem, false, selected, sel_dest, pred_id, std::vector<attribute_id>{0, 4, 6}, true);
+  auto *aggregate = new AggregationOperator(0, lineitem, true, state);
+  auto *finalize = new FinalizeAggregationOperator(0, state, 1, false, 1, result, agg_dest);
+  std::vector<std::unique_ptr<RelationalOperator>> owned;
+  if (use_foreman) {
+    QueryPlan plan;
+    plan.addRelationalOperator(select);
+    const auto a = plan.addRelationalOperator(aggregate);
+    const auto z = plan.addRelationalOperator(finalize);
+    plan.addDirectDependency(z, a, true);
+    ForemanSingleNode foreman(&plan, &ctx, &storage, 4);
+    foreman.run();
+  } else {
+    for (RelationalOperator *op : {static_cast<RelationalOperator *>(select), static_cast<RelationalOperator *>(aggregate),
+                                   static_cast<RelationalOperator *>(finalize)}) {
+      owned.emplace_back(op);
+      fetchAndExecuteWorkOrders(op, &ctx, &storage);
+    }
+  }
+  Output out;
+  for (block_id b : ctx.getInsertDestination(sel_dest)->getTouchedBlocks()) {
+    BlockReference blk = storage.getBlock(b);
+    const std::size_t at = out.linenumber.size(), k = static_cast<std::size_t>(blk->numTuples());
+    out.linenumber.resize(at + k); out.quantity.resize(at + k); out.price.resize(at + k);
+    blk->copyAttributeToHost(0, out.linenumber.data() + at);
+    blk->copyAttributeToHost(1, out.quantity.data() + at);
+    blk->copyAttributeToHost(2, out.price.data() + at);
+  }
+  out.agg_key_count.assign(8, 0);
+  out.agg_sum_disc_price.assign(8, 0.0);
+  out.agg_min_qty.assign(8, 0.0);
+  for (block_id b : ctx.getInsertDestination(agg_dest)->getTouchedBlocks()) {
+    BlockReference blk = storage.getBlock(b);
+    const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+    std::vector<std::int32_t> key(k);
+    std::vector<std::int64_t> cnt(k);
+    std::vector<double> sum(k), mn(k);
+    blk->copyAttributeToHost(0, key.data()); blk->copyAttributeToHost(1, cnt.data());
+    blk->copyAttributeToHost(2, sum.data()); blk->copyAttributeToHost(3, mn.data());
+    for (std::size_t i = 0; i < k; ++i) {
+      out.agg_key_count[key[i]] = cnt[i]; out.agg_sum_disc_price[key[i]] = sum[i]; out.agg_min_qty[key[i]] = mn[i];
+    }
+  }
+  return out;
+}
+}  // namespace
+
+int main() {
+  if (qsx_device_count() < 1) {
+    std::fprintf(stderr, "compressed_block_operator_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
+    return 2;
+  }
+  const Lineitem li;
+  // expected, straight from the host columns
+  std::vector<std::int64_t> want_count(8, 0);
+  std::vector<double> want_sum(8, 0.0), want_min(8, 1e300);
+  std::vector<std::int64_t> want_rows;
+  for (std::int64_t i = 0; i < kRows; ++i) {
+    if (li.shipdate[i] <= 19920101 + 2000 && li.quantity[i] < 24.0 && li.discount[i] >= 0.045 && li.orderkey[i] >= 10) {
+      want_rows.push_back(i);
+      ++want_count[li.linenumber[i]];
+      want_sum[li.linenumber[i]] += li.discount[i];
+      want_min[li.linenumber[i]] = std::min(want_min[li.linenumber[i]], li.quantity[i]);
+    }
+  }
+  for (const bool use_foreman : {false, true}) {
+    const Output plain = run(li, false, use_foreman);
+    const Output comp = run(li, true, use_foreman);
+    for (const Output *o : {&plain, &comp}) {
+      EXPECT_EQ(o->linenumber.size(), want_rows.size());
+      if (!use_foreman && o->linenumber.size() == want_rows.size()) {   // the synchronous driver keeps block order
+        for (std::size_t i = 0; i < want_rows.size(); ++i) {
+          EXPECT_EQ(o->linenumber[i], li.linenumber[want_rows[i]]);
+          EXPECT_TRUE(o->quantity[i] == li.quantity[want_rows[i]] && o->price[i] == li.price[want_rows[i]]);
+        }
+      }
+      for (int g = 1; g <= 7; ++g) {
+        EXPECT_EQ(o->agg_key_count[g], want_count[g]);
+        EXPECT_NEAR(o->agg_sum_disc_price[g], want_sum[g], 1e-9 * want_sum[g] + 1e-12);
+        if (want_count[g] > 0) EXPECT_TRUE(o->agg_min_qty[g] == want_min[g]);
+      }
+    }
+  }
+  return finish("compressed_block_operator_test");
+}

@@ -13,7 +13,7 @@ BIN = os.path.join(ROOT, "tests", "cpp", "bin")
 def _ensure_built():
     if not all(os.path.exists(os.path.join(BIN, b)) for b in
                ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
-                "lip_filter_operator_test")):
+                "lip_filter_operator_test", "compressed_block_operator_test")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -54,3 +54,10 @@ def test_lip_filter_deployments_through_the_operators():
     """LIP.test data (R even, S multiples of 3): BuildHash builds the filter, Select / Aggregation /
     HashJoin(semi) probe it — sync driver and Foreman/Worker, exact and identity-hash filters."""
     _run("lip_filter_operator_test")
+
+
+@pytest.mark.gpu
+def test_compressed_column_store_blocks_through_the_operators():
+    """CompressedBlockBuilder's choice per attribute, predicates rewritten to code comparisons and scanned on the code
+    stripes, values decoded on demand for projections and aggregates: same results as over plain blocks."""
+    _run("compressed_block_operator_test")
