@@ -83,6 +83,13 @@ __global__ __launch_bounds__(kBlock) void select_cmp_kernel(
   }
 }
 
+template <typename T, typename Pred>
+static int launch_select_packed(const void *col, int64_t n, Pred pred, const uint64_t *filter, uint64_t *out, int64_t *out_count,
+                                hipStream_t stream);
+static bool aligned16(const void *p);
+template <typename T, int OP>
+struct LiteralPred;
+
 // rhs_col == nullptr: compare with *literal; else with the second column.
 template <typename T, int OP>
 static int launch_select_cmp(const void *col, const void *rhs_col, int64_t n, const void *literal, const uint64_t *filter,
@@ -91,6 +98,10 @@ static int launch_select_cmp(const void *col, const void *rhs_col, int64_t n, co
   T lit = T();
   if (literal != nullptr) std::memcpy(&lit, literal, sizeof(T));
   const int64_t num_words = (n + 63) >> 6;
+  if (rhs_col == nullptr && aligned16(col)) {
+    // 16 bytes per lane per load (select_packed_kernel below); unaligned slices keep the row-per-lane kernel
+    return launch_select_packed<T>(col, n, LiteralPred<T, OP>{lit}, filter, out, out_count, stream);
+  }
   if (rhs_col == nullptr) {
     const int grid = grid_for(num_words, kWavesPerBlock * R);
     hipLaunchKernelGGL((select_cmp_kernel<T, OP, R, false>), dim3(grid), dim3(kBlock), 0, stream,
@@ -360,6 +371,106 @@ __global__ __launch_bounds__(kBlock) void select_codes_kernel(const T *__restric
   }
 }
 
+// ---------------------------------------------------------------------------
+// K1, packed variant: every lane loads 16 bytes = K = 16 / sizeof(T) consecutive rows, so one wave load
+// covers 64 * K rows (16 bitmap words for 1-byte codes) instead of 64 — a byte-wide column with one row
+// per lane is bound by the number of memory instructions, not by HBM (0.138 ms / 100 M 1-byte codes against
+// 0.10 ms for the 4x larger INT column).  A lane turns its K rows into a K-bit MSB-first mask; the 64 / K
+// lanes that share a bitmap word merge their masks with log2(64 / K) xor-shuffles, the group's first lane
+// ANDs the filter word and stores.  Needs a 16-byte aligned stripe (the callers fall back otherwise).
+// ---------------------------------------------------------------------------
+struct CodeRangePred {   // lo <= code < hi, optionally negated (the five comparisons of qsx_select_codes)
+  unsigned long long lo, hi;
+  bool negate;
+  template <typename T>
+  __device__ __forceinline__ bool operator()(T v) const {
+    const unsigned long long c = v;
+    return (c >= lo && c < hi) != negate;
+  }
+};
+template <typename T, int OP>
+struct LiteralPred {     // value OP literal
+  T lit;
+  __device__ __forceinline__ bool operator()(T v) const { return cmp_static<T, OP>(v, lit); }
+};
+
+template <typename T, typename Pred, int R>
+__global__ __launch_bounds__(kBlock) void select_packed_kernel(const T *__restrict__ col, int64_t n, Pred pred,
+                                                              const uint64_t *__restrict__ filter,
+                                                              uint64_t *__restrict__ out,
+                                                              unsigned long long *__restrict__ out_count) {
+  constexpr int K = 16 / sizeof(T);        // rows per lane per load
+  constexpr int G = kWave / K;             // lanes per bitmap word
+  constexpr int kRowsPerLoad = kWave * K;  // rows per wave load = K bitmap words
+  const int lane = lane_id();
+  const int64_t num_loads = (n + kRowsPerLoad - 1) / kRowsPerLoad;
+  const int64_t num_words = (n + 63) >> 6;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t num_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  unsigned long long count = 0;
+  for (int64_t l0 = wave * R; l0 < num_loads; l0 += num_waves * R) {
+    uint4 raw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row0 = (l0 + r) * kRowsPerLoad + static_cast<int64_t>(lane) * K;
+      raw[r] = make_uint4(0, 0, 0, 0);
+      if (row0 + K <= n) {
+        raw[r] = *reinterpret_cast<const uint4 *>(col + row0);
+      } else if (row0 < n) {               // the last, partial 16 bytes of the stripe: element by element
+        T tmp[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) tmp[i] = row0 + i < n ? col[row0 + i] : T();
+        raw[r] = *reinterpret_cast<const uint4 *>(tmp);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row0 = (l0 + r) * kRowsPerLoad + static_cast<int64_t>(lane) * K;
+      T v[K];
+      *reinterpret_cast<uint4 *>(v) = raw[r];
+      unsigned long long m = 0;            // K-bit mask, first row = most significant bit
+#pragma unroll
+      for (int i = 0; i < K; ++i) m = (m << 1) | ((row0 + i < n && pred(v[i])) ? 1ull : 0ull);
+      // merge the G lanes of a word: after step d the lower lane of every 2d-group holds 2d * K bits
+#pragma unroll
+      for (int d = 1; d < G; d <<= 1) {
+        const unsigned long long other = __shfl_xor(m, d, kWave);
+        m = (m << (d * K)) | other;        // only meaningful in lanes whose bit d is clear; those are the ones kept
+      }
+      const int64_t word = (l0 + r) * K + lane / G;
+      if ((lane % G) == 0 && word < num_words) {
+        if (filter != nullptr) m &= filter[word];
+        out[word] = m;
+        count += __popcll(m);
+      }
+    }
+  }
+  if (out_count != nullptr) {
+    __shared__ unsigned long long block_count;
+    if (threadIdx.x == 0) block_count = 0;
+    __syncthreads();
+    count = wave_reduce_add(count);
+    if (lane == 0 && count != 0) atomicAdd(&block_count, count);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_count != 0) atomicAdd(out_count, block_count);
+  }
+}
+
+template <typename T, typename Pred>
+static int launch_select_packed(const void *col, int64_t n, Pred pred, const uint64_t *filter, uint64_t *out, int64_t *out_count,
+                                hipStream_t stream) {
+  constexpr int R = 4;
+  constexpr int kRowsPerLoad = kWave * (16 / static_cast<int>(sizeof(T)));
+  const int64_t num_loads = (n + kRowsPerLoad - 1) / kRowsPerLoad;
+  const int grid = grid_for(num_loads, kWavesPerBlock * R);
+  hipLaunchKernelGGL((select_packed_kernel<T, Pred, R>), dim3(grid), dim3(kBlock), 0, stream, static_cast<const T *>(col), n, pred,
+                     filter, out, reinterpret_cast<unsigned long long *>(out_count));
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // Decode a code stripe: dictionary lookup (codes index a dictionary of `value_width`-byte values that
 // stays in L2 / L1) or zero-extension of a truncated value.
 template <typename C, typename V>
@@ -456,6 +567,19 @@ int qsx_select_codes(int code_width, const void *codes_dev, int64_t n, int op, u
   hipStream_t s = as_stream(stream);
   if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
   if (n == 0) return QSX_OK;
+  if (aligned16(codes_dev)) {
+    CodeRangePred pred;
+    pred.lo = op == QSX_CODE_LT ? 0ull : first;
+    pred.hi = (op == QSX_CODE_EQ || op == QSX_CODE_NE) ? static_cast<unsigned long long>(first) + 1
+              : op == QSX_CODE_LT ? first : op == QSX_CODE_GE ? (1ull << 32) : second;
+    pred.negate = op == QSX_CODE_NE;
+    switch (code_width) {
+      case 1: return launch_select_packed<uint8_t>(codes_dev, n, pred, filter_dev, out_bitmap_dev, out_count_dev, s);
+      case 2: return launch_select_packed<uint16_t>(codes_dev, n, pred, filter_dev, out_bitmap_dev, out_count_dev, s);
+      case 4: return launch_select_packed<uint32_t>(codes_dev, n, pred, filter_dev, out_bitmap_dev, out_count_dev, s);
+      default: return QSX_ERR_UNSUPPORTED;
+    }
+  }
   const int64_t num_words = (n + 63) >> 6;
   constexpr int R = 8;
   const int grid = grid_for(num_words, kWavesPerBlock * R);

@@ -135,3 +135,25 @@ def test_tids_to_bitmap_round_trip(capi, oracle, dev):
     assert np.array_equal(back[:int(cnt.item())].cpu().numpy(), uniq)
     empty = capi.tids_to_bitmap(torch.empty(0, dtype=torch.int32, device=dev), 130)
     assert not bitmap_np(empty).any()
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64, np.float32, np.float64])
+def test_select_cmp_aligned_and_unaligned_stripes_agree(capi, oracle, dev, dtype):
+    """16-byte aligned stripes take the packed kernel (16 bytes per lane per load), slices that start inside a 16-byte
+    chunk the row-per-lane kernel; both must give the oracle's words for every offset and ragged length."""
+    rng = np.random.default_rng(8)
+    base = rng.integers(-20, 20, size=70_000).astype(dtype)
+    dbase = to_dev(base, dev)
+    f_all = rng.random(70_000) < 0.7
+    for start in (0, 1, 2, 3, 4, 5, 7, 8):
+        for n in (1, 15, 16, 17, 63, 64, 65, 1023, 1025, 4097, 33_333):
+            sl, dsl = base[start:start + n], dbase[start:start + n]
+            f = oracle.bitmap_from_bools(f_all[:n])
+            for op in (T.LT, T.EQ, T.GE):
+                bm, cnt = capi.select_cmp(dsl, op, 3)
+                want = oracle.select_cmp(sl, op, dtype(3))
+                assert np.array_equal(bitmap_np(bm), want), (start, n, op)
+                assert int(cnt.item()) == oracle.bitmap_count(want, n)
+                bm, cnt = capi.select_cmp(dsl, op, 3, filter_bitmap=bitmap_dev(f, dev))
+                want = oracle.select_cmp(sl, op, dtype(3), filter_bitmap=f)
+                assert np.array_equal(bitmap_np(bm), want), (start, n, op, "filter")

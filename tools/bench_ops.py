@@ -54,6 +54,14 @@ dcol = torch.rand(N, device=dev, generator=g, dtype=torch.float64)
 ms = timed(lambda: capi.select_cmp(dcol, T.LE, 0.98, out_bitmap=bm, out_count=cnt))
 report("K1 select_cmp DOUBLE col<=K", ms, N, 8 * N)
 
+# compressed attribute: the same predicate on a 1-byte code stripe (dictionary / truncated column), and the decode
+codes = torch.randint(0, 50, (N,), device=dev, generator=g, dtype=torch.uint8)
+ms = timed(lambda: capi.select_codes(codes, T.CODE_LT, 24))
+report("K1 select_codes 1-byte codes, code<K (stands for a DOUBLE column)", ms, N, N, "bytes of the code stripe; the DOUBLE column would be 8x")
+dictionary = torch.arange(1, 51, device=dev, dtype=torch.float64)
+ms = timed(lambda: capi.decode_codes(codes, dictionary, torch.float64))
+report("decode 1-byte dictionary codes -> DOUBLE", ms, N, 9 * N)
+
 # ---- K3 build / K5 gather ------------------------------------------------------------------------
 nb = int(1_000_000 * max(scale, 0.1))
 build = torch.randperm(nb, device=dev, generator=g, dtype=torch.int32)
@@ -64,6 +72,13 @@ probe = torch.randint(0, nb, (N,), device=dev, generator=g, dtype=torch.int32)
 outs = (torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
 ms = timed(lambda: table.probe(probe, capacity=N, out=outs))
 report("K4 join_probe pairs (m=1.0)", ms, N, 12 * N)
+dense = capi.JoinTable(T.INT, nb, key_range=(0, nb - 1))
+ms = timed(lambda: (dense.clear(), dense.build(build)))
+report("K3 dense join_build 1 M INT keys (clear + build)", ms, nb, 4 * nb)
+ms = timed(lambda: dense.probe(probe, capacity=N, out=outs))
+report("K4 dense join_probe pairs (m=1.0; exact min/max statistics)", ms, N, 12 * N)
+ms = timed(lambda: dense.probe_count(probe))
+report("K4 dense join_probe count only", ms, N, 4 * N)
 payload = torch.rand(nb, device=dev, generator=g, dtype=torch.float64)
 gout = torch.empty(N, dtype=torch.float64, device=dev)
 ms = timed(lambda: capi.gather(payload, outs[1], out=gout))
