@@ -149,6 +149,8 @@ def main():
                     help="N > 1: shuffle = both sides repartitioned on the join key (K9 + RCCL all-to-all); broadcast = "
                          "all-gather of the build side, probe rows stay where they are (the reference's broadcast join, "
                          "BuildHashOperator.hpp:99,146-152); auto = broadcast while the gathered build side has <= 16 Mi rows")
+    ap.add_argument("--other-plan-leg", action="store_true",
+                    help="N > 1: after the timed region also run the join plan that was NOT picked, untimed, and report its cost")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -274,18 +276,22 @@ def main():
         phase_ms[k] /= args.steps
 
     other_plan_ms = None
-    if distributed and world > 1:
-        # the plan the rule above did not pick, untimed leg (2 runs, second one measured): what the shuffle costs here
-        other = make_join("shuffle" if plan == "broadcast" else "broadcast")
-        for it in range(2):
-            torch.cuda.synchronize()
-            dist.barrier()
-            t1 = time.perf_counter()
-            other.build(build_keys, rank * args.build_rows)
-            other.probe(probe_keys, rank * args.probe_rows, capacity=capacity)
-            torch.cuda.synchronize()
-            other_plan_ms = (time.perf_counter() - t1) * 1e3
-        del other
+    if distributed and world > 1 and args.other_plan_leg:
+        # the plan the rule above did not pick, untimed leg (2 runs, second one measured): what the shuffle costs here.
+        # Never allowed to take the headline measurement down with it.
+        try:
+            other = make_join("shuffle" if plan == "broadcast" else "broadcast")
+            for it in range(2):
+                torch.cuda.synchronize()
+                dist.barrier()
+                t1 = time.perf_counter()
+                other.build(build_keys, rank * args.build_rows)
+                other.probe(probe_keys, rank * args.probe_rows, capacity=capacity)
+                torch.cuda.synchronize()
+                other_plan_ms = (time.perf_counter() - t1) * 1e3
+            del other
+        except Exception as exc:  # noqa: BLE001
+            other_plan_ms = f"failed: {exc!r}"[:200]
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
