@@ -234,15 +234,60 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int64_t tile_off = tile_offsets[tile];
-    for (int k = 0; k < kTileWords; ++k) {
-      const uint64_t word = s_words[wave][k];  // broadcast read
-      if (word == 0) continue;                 // wave-uniform
-      if (msb_bit(word, lane)) {
+    // 8 bitmap words per step: the 8 loads of a lane are issued back to back and their stores follow —
+    // one word at a time left a single load -> store dependency in flight per wave (0.24 ms / 100 M rows at 50 %).
+    constexpr int kBatch = 8;
+    for (int k0 = 0; k0 < kTileWords; k0 += kBatch) {
+      bool take[kBatch];
+      int64_t si[kBatch], di[kBatch];
+      bool any = false;
+#pragma unroll
+      for (int b = 0; b < kBatch; ++b) {
+        const uint64_t word = s_words[wave][k0 + b];  // broadcast read
+        take[b] = msb_bit(word, lane);
         const int before = lane == 0 ? 0 : __popcll(word >> (64 - lane));
-        const int64_t di = tile_off + s_prefix[wave][k] + before;
-        const int64_t si = ((tile * kTileWords + k) << 6) + lane;
-        if (out_tids != nullptr) out_tids[di] = static_cast<int32_t>(base_tid + si);
-        for (int c = 0; c < args.ncols; ++c) copy_value(args.src[c], si, args.dst[c], di, args.width[c]);
+        di[b] = tile_off + s_prefix[wave][k0 + b] + before;
+        si[b] = ((tile * kTileWords + k0 + b) << 6) + lane;
+        any = any || word != 0;
+      }
+      if (!any) continue;                      // wave-uniform: 512 unselected rows
+      if (out_tids != nullptr) {
+#pragma unroll
+        for (int b = 0; b < kBatch; ++b) {
+          if (take[b]) out_tids[di[b]] = static_cast<int32_t>(base_tid + si[b]);
+        }
+      }
+      for (int c = 0; c < args.ncols; ++c) {
+        const void *src = args.src[c];
+        void *dst = args.dst[c];
+        switch (args.width[c]) {               // wave-uniform
+          case 4: {
+            uint32_t v[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) v[b] = take[b] ? static_cast<const uint32_t *>(src)[si[b]] : 0u;
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+              if (take[b]) static_cast<uint32_t *>(dst)[di[b]] = v[b];
+            }
+            break;
+          }
+          case 8: {
+            uint64_t v[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) v[b] = take[b] ? static_cast<const uint64_t *>(src)[si[b]] : 0ull;
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+              if (take[b]) static_cast<uint64_t *>(dst)[di[b]] = v[b];
+            }
+            break;
+          }
+          default:
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+              if (take[b]) copy_value(src, si[b], dst, di[b], args.width[c]);
+            }
+            break;
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
