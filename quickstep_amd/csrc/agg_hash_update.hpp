@@ -345,7 +345,7 @@ template <bool kStatic, bool kDense, int NS, int V>
 __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, int64_t n,
                                                      const uint64_t *__restrict__ filter, const HashTableView &g,
                                                      const DenseView &dense, int S, int rep_shift, int nbuf,
-                                                     int ranges) {
+                                                     int ranges, const long long *__restrict__ pieces = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int TR = kABlock * V;
   char *tiles = reinterpret_cast<char *>(smem_raw);
@@ -369,20 +369,26 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   // families; family r walks ALL tiles but only aggregates the groups whose hash falls into
   // range r, so each family's groups fit its LDS tables.  Costs `ranges` reads of the input
   // instead of (NS + 1) global atomics per row.
+  // pieces != nullptr (partitioned aggregation, aggregate.hip): the input was hash-partitioned on the key code into
+  // `ranges` pieces; family r walks only piece r = rows [pieces[r], pieces[r] + pieces[ranges + r]) — its groups are
+  // its own by construction, no hash test, every row is read once.
   const int my_range = ranges > 1 ? static_cast<int>(blockIdx.x % ranges) : 0;
   const int64_t first_tile = ranges > 1 ? blockIdx.x / ranges : blockIdx.x;
   const int64_t tile_step = ranges > 1 ? gridDim.x / ranges : gridDim.x;
-  const int64_t num_tiles = (n + TR - 1) / TR;
+  const bool by_piece = pieces != nullptr;
+  const int64_t row_begin = by_piece ? pieces[my_range] : 0;
+  const int64_t row_end = by_piece ? row_begin + pieces[ranges + my_range] : n;
+  const int64_t num_tiles = (row_end - row_begin + TR - 1) / TR;
+  auto tile_row0 = [&](int64_t t) { return row_begin + t * TR; };
+  auto tile_rows = [&](int64_t t) { return static_cast<int>(row_end - tile_row0(t) < TR ? row_end - tile_row0(t) : TR); };
   int buf = 0;
   if (nbuf == 2 && first_tile < num_tiles) {
-    const int64_t row0 = first_tile * TR;
-    stage_tile<kStatic>(c, cols, filter, tiles, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
+    stage_tile<kStatic>(c, cols, filter, tiles, tile_row0(first_tile), tile_rows(first_tile));
   }
   for (int64_t tile_id = first_tile; tile_id < num_tiles; tile_id += tile_step) {
     if (nbuf == 1) {
       __syncthreads();  // every wave is done reading the previous tile
-      const int64_t row0 = tile_id * TR;
-      stage_tile<kStatic>(c, cols, filter, tiles, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
+      stage_tile<kStatic>(c, cols, filter, tiles, tile_row0(tile_id), tile_rows(tile_id));
     }
     // The tile has landed (nbuf == 2: it was staged during the previous iteration and
     // every wave is done with the other buffer).
@@ -390,13 +396,11 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     __syncthreads();
     const int64_t next = tile_id + tile_step;
     if (nbuf == 2 && next < num_tiles) {
-      const int64_t row0 = next * TR;
-      stage_tile<kStatic>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, row0, static_cast<int>(n - row0 < TR ? n - row0 : TR));
+      stage_tile<kStatic>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, tile_row0(next), tile_rows(next));
     }
     const char *tile = tiles + buf * c.tile_bytes;
     if (nbuf == 2) buf ^= 1;
-    const int64_t row0 = tile_id * TR;
-    const int rows = static_cast<int>(n - row0 < TR ? n - row0 : TR);
+    const int rows = tile_rows(tile_id);
 
     const int trow = threadIdx.x;  // this thread's first row of the tile
 
@@ -416,7 +420,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     // ---- group of every row ----------------------------------------------------
     unsigned long long code[V];
     key_codes_vec<kStatic, V>(c, tile, trow, code);
-    if (ranges > 1) {
+    if (ranges > 1 && !by_piece) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         live[v] = live[v] && static_cast<int>((mix64(code[v]) >> 20) % static_cast<unsigned>(ranges)) == my_range;
@@ -617,8 +621,8 @@ template <int NS, int V>
 __global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, int64_t n,
                                                                  const uint64_t *__restrict__ filter,
                                                                  HashTableView g, int S, int rep_shift, int nbuf,
-                                                                 int ranges) {
-  agg_hash_update_body<false, false, NS, V>(c, c.cols, n, filter, g, DenseView{}, S, rep_shift, nbuf, ranges);
+                                                                 int ranges, const long long *__restrict__ pieces) {
+  agg_hash_update_body<false, false, NS, V>(c, c.cols, n, filter, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces);
 }
 
 // COLLISION_FREE (K7) through the same staged-tile body with the dense sink.
@@ -639,9 +643,10 @@ struct ColumnPointers {
 // is the straight-line arithmetic of that plan.
 template <typename Shape, int V>
 __global__ __launch_bounds__(kABlock) void agg_hash_shape_kernel(ColumnPointers cols, int64_t n, HashTableView g, int S,
-                                                                int rep_shift, int nbuf, int ranges) {
+                                                                int rep_shift, int nbuf, int ranges,
+                                                                const long long *__restrict__ pieces) {
   static constexpr Translated T = Shape::translated(kABlock * V);
-  agg_hash_update_body<true, false, T.num_sums, V>(T.dev, cols.p, n, nullptr, g, DenseView{}, S, rep_shift, nbuf, ranges);
+  agg_hash_update_body<true, false, T.num_sums, V>(T.dev, cols.p, n, nullptr, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces);
 }
 
 }  // namespace qsx

@@ -94,10 +94,11 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense) {
   o << kPrelude << kBundle << "\nnamespace qsx {\nconstexpr DevConfig jit_make_dev() {\n  DevConfig d{};\n"
     << emit_dev_config(dev) << "  return d;\n}\n"
     << "extern \"C\" __global__ __launch_bounds__(" << kABlock << ") void qsx_jit_agg(ColumnPointers cols, int64_t n,\n"
-    << "    const uint64_t *filter, HashTableView g, DenseView dense, int S, int rep_shift, int nbuf, int ranges) {\n"
+    << "    const uint64_t *filter, HashTableView g, DenseView dense, int S, int rep_shift, int nbuf, int ranges,\n"
+    << "    const long long *pieces) {\n"
     << "  static constexpr DevConfig D = jit_make_dev();\n"
     << "  agg_hash_update_body<true, " << (dense ? "true" : "false") << ", " << num_sums << ", " << kJitRowsPerThread
-    << ">(D, cols.p, n, filter, g, dense, S, rep_shift, nbuf, ranges);\n}\n}  // namespace qsx\n";
+    << ">(D, cols.p, n, filter, g, dense, S, rep_shift, nbuf, ranges, pieces);\n}\n}  // namespace qsx\n";
   return o.str();
 }
 
@@ -164,13 +165,14 @@ const JitKernel *jit_agg_kernel(const DevConfig &dev, int num_sums, bool dense, 
 
 int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols, int64_t n,
                    const uint64_t *filter, const HashTableView &g, const DenseView &dense, int S, int rep_shift, int nbuf,
-                   int ranges) {
+                   int ranges, const long long *pieces) {
   ColumnPointers a_cols = cols;
   int64_t a_n = n;
   const uint64_t *a_filter = filter;
   HashTableView a_g = g;
   DenseView a_dense = dense;
-  void *args[] = {&a_cols, &a_n, &a_filter, &a_g, &a_dense, &S, &rep_shift, &nbuf, &ranges};
+  const long long *a_pieces = pieces;
+  void *args[] = {&a_cols, &a_n, &a_filter, &a_g, &a_dense, &S, &rep_shift, &nbuf, &ranges, &a_pieces};
   QSX_HIP_TRY(hipModuleLaunchKernel(k->function, static_cast<unsigned>(grid), 1, 1, kABlock, 1, 1,
                                     static_cast<unsigned>(lds_bytes), stream, args, nullptr));
   return QSX_OK;

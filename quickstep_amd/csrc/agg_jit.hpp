@@ -28,7 +28,7 @@ const JitKernel *jit_agg_kernel(const DevConfig &dev, int num_sums, bool dense, 
 // Launches it: the argument list of agg_hash_update_body.
 int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols, int64_t n,
                    const uint64_t *filter, const HashTableView &g, const DenseView &dense, int S, int rep_shift, int nbuf,
-                   int ranges);
+                   int ranges, const long long *pieces);
 
 constexpr int kJitRowsPerThread = 4;
 

@@ -35,6 +35,7 @@
 #include "agg_hash_update.hpp"
 #include "agg_shapes.hpp"
 #include "agg_jit.hpp"
+#include "partition.hpp"
 #include "scan.hpp"
 
 #include <atomic>
@@ -43,6 +44,27 @@
 #include <vector>
 
 namespace qsx {
+
+// Packed key code of every row straight from the key columns (ThreadPrivateCompactKeyHashTable.cpp:216-232):
+// the routing key of the partitioned aggregation (aggregate.hip, update_partitioned).
+__global__ __launch_bounds__(kABlock) void agg_key_codes_kernel(DevConfig c, int64_t n, long long *__restrict__ codes) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kABlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kABlock) {
+    unsigned long long code = 0;
+    for (int k = 0; k < c.num_keys; ++k) {
+      const void *col = c.cols[c.key_column[k]];
+      unsigned long long v;
+      switch (c.key_width[k]) {
+        case 1: v = static_cast<const uint8_t *>(col)[i]; break;
+        case 2: v = static_cast<const uint16_t *>(col)[i]; break;
+        case 4: v = static_cast<const uint32_t *>(col)[i]; break;
+        default: v = static_cast<const unsigned long long *>(col)[i]; break;
+      }
+      code |= v << c.key_shift[k];
+    }
+    codes[i] = static_cast<long long>(code);
+  }
+}
 
 // AccKind of every state column, by value into the kernels that combine whole columns.
 struct ColKinds {
@@ -364,6 +386,12 @@ struct qsx_agg_state {
   long long max_tiles = 0;
   int lds_slots = 64;
   int lds_ranges = 1;  // > 1: hash-range families of workgroups (agg_hash_update.hpp)
+  // More groups than one workgroup-private LDS table holds: big inputs are first hash-partitioned on the
+  // key code (K9, mixing-hash mode) into part_count pieces whose groups fit a part_slots-slot table, then
+  // aggregated piece by piece — one read + one write + one read of the used columns instead of
+  // lds_ranges reads of the whole input at one workgroup per CU.
+  int part_count = 1;
+  int part_slots = 64;
   unsigned used_columns = 0;
   const struct ShapeEntry *shape = nullptr;  // AOT plan shape matching this configuration, if any
   // Run-time plan shapes (agg_jit.hpp), one per filter variant; compiled once the state has seen enough
@@ -536,7 +564,7 @@ static void plan_interpreter(DevConfig &dc, int tile_rows) {
 // update kernel with two tile buffers (DMA double buffering).
 template <int NS, int V>
 static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter,
-                         const HashTableView &g, int S, int ranges, hipStream_t stream, bool dry_run) {
+                         const HashTableView &g, int S, int ranges, const long long *pieces, hipStream_t stream, bool dry_run) {
   constexpr int TR = kABlock * V;
   size_t off = 0;
   for (int col = 0; col < dc.num_columns; ++col) {
@@ -581,7 +609,7 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   grid = grid / ranges * ranges;
   if (grid < ranges) grid = ranges;
   hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S,
-                     rep_shift, nbuf, ranges);
+                     rep_shift, nbuf, ranges, pieces);
   return QSX_OK;
 }
 
@@ -589,7 +617,7 @@ static int agg_rows_per_thread() { return agg_tuning().rows_per_thread; }
 
 // ---- AOT plan shapes (agg_shapes.hpp) -------------------------------------------------
 typedef int (*ShapeLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
-                             int ranges, hipStream_t stream);
+                             int ranges, const long long *pieces, hipStream_t stream);
 struct ShapeEntry {
   const char *name;
   qsx_agg_config_t config;
@@ -598,7 +626,7 @@ struct ShapeEntry {
 
 template <typename Shape, int V>
 static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
-                          int ranges, hipStream_t stream) {
+                          int ranges, const long long *pieces, hipStream_t stream) {
   constexpr int TR = kABlock * V;
   constexpr Translated T = Shape::translated(TR);
   static_assert(T.status == QSX_OK, "plan shape does not translate");
@@ -628,15 +656,15 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
   ColumnPointers cp;
   for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < num_columns ? cols[i] : nullptr;
   hipLaunchKernelGGL((agg_hash_shape_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g, S, rep_shift, nbuf,
-                     ranges);
+                     ranges, pieces);
   return QSX_OK;
 }
 
 template <typename Shape>
 static int launch_shape(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
-                        int ranges, hipStream_t stream) {
-  if (agg_tuning().shape_rows_per_thread == 4) return launch_shape_v<Shape, 4>(cols, num_columns, n, g, S, ranges, stream);
-  return launch_shape_v<Shape, 2>(cols, num_columns, n, g, S, ranges, stream);
+                        int ranges, const long long *pieces, hipStream_t stream) {
+  if (agg_tuning().shape_rows_per_thread == 4) return launch_shape_v<Shape, 4>(cols, num_columns, n, g, S, ranges, pieces, stream);
+  return launch_shape_v<Shape, 2>(cols, num_columns, n, g, S, ranges, pieces, stream);
 }
 
 static const ShapeEntry *find_shape(const qsx_agg_config_t &c) {
@@ -679,12 +707,12 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, int
 }
 
 static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, const void *const *cols, int64_t n,
-                      const uint64_t *filter, hipStream_t stream) {
+                      const uint64_t *filter, int slots, int num_ranges, const long long *pieces, hipStream_t stream) {
   constexpr int TR = kABlock * kJitRowsPerThread;
   constexpr size_t kMaxLds = 160 * 1024;
   const int NS = st->num_sums;
   const AggTuning &tune = agg_tuning();
-  int S = st->dense ? 8 : st->lds_slots, ranges = st->dense ? 1 : st->lds_ranges, rep_shift = 0, nbuf = 1;
+  int S = st->dense ? 8 : slots, ranges = st->dense ? 1 : num_ranges, rep_shift = 0, nbuf = 1;
   size_t lds;
   const int tile_bytes = st->jit_tile_bytes[has_filter ? 1 : 0];
   if (st->dense) {
@@ -708,18 +736,19 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, co
   ColumnPointers cp;
   for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < st->config.num_columns ? cols[i] : nullptr;
   return jit_agg_launch(k, grid, lds, stream, cp, n, filter, st->dense ? HashTableView{} : st->hash_view(),
-                        st->dense ? st->dense_view() : DenseView{}, S, rep_shift, nbuf, ranges);
+                        st->dense ? st->dense_view() : DenseView{}, S, rep_shift, nbuf, ranges, pieces);
 }
 
 template <int NS>
 static int launch_hash(const DevConfig &dc, unsigned used_columns, int64_t n, const uint64_t *filter,
-                       const HashTableView &g, int S, int ranges, hipStream_t stream) {
+                       const HashTableView &g, int S, int ranges, const long long *pieces, hipStream_t stream) {
   // 1024-row tiles when two of them (plus the group tables) fit the CU's LDS twice over, else 512-row tiles
-  if (agg_rows_per_thread() == 4 && launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, stream, true) == QSX_OK) {
-    return launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, stream, false);
+  if (agg_rows_per_thread() == 4 && launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, pieces, stream, true) == QSX_OK) {
+    return launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, pieces, stream, false);
   }
-  int rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, S, ranges, stream, false);
-  if (rc == QSX_ERR_CAPACITY) rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, 64, 1, stream, false);
+  int rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, S, ranges, pieces, stream, false);
+  // (with pieces the family count is fixed by the partitioning: keep it, only shrink the table)
+  if (rc == QSX_ERR_CAPACITY) rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, 64, pieces != nullptr ? ranges : 1, pieces, stream, false);
   return rc;
 }
 template <int NS>
@@ -811,6 +840,18 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
       }
     }
     st->lds_slots = static_cast<int>(s);
+    if (st->lds_ranges > 1 || (static_cast<uint64_t>(est) * 10 > s * 7 && est > 256)) {
+      // ~350 groups per piece -> a 1024-slot table at load <= 0.35 with room for replication
+      uint64_t pieces = next_pow2((static_cast<uint64_t>(est) + 349) / 350);
+      if (pieces > 64) pieces = 64;
+      if (pieces > 1) {
+        st->part_count = static_cast<int>(pieces);
+        uint64_t ps = next_pow2((static_cast<uint64_t>(est) / pieces + 1) * 3);
+        if (ps < 64) ps = 64;
+        if (ps > 4096) ps = 4096;
+        st->part_slots = static_cast<int>(ps);
+      }
+    }
   }
   hipError_t err = hipMalloc(reinterpret_cast<void **>(&st->image), st->image_bytes);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->control), 4 * sizeof(unsigned long long));
@@ -868,20 +909,17 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
   return fill_identities(st, s);
 }
 
-int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev,
-                   qsx_stream_t stream) {
-  QSX_REQUIRE_DEVICE();
-  if (st == nullptr || n < 0 || (n > 0 && st->config.num_columns > 0 && cols == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
-  if (n == 0) return QSX_OK;
+// One launch of the update kernel over n rows with the given LDS table geometry: AOT plan shape, then the
+// run-time one, then the interpreter (CAPACITY — the tile does not fit LDS next to the group tables — and
+// compile failures fall through).
+static int update_slice(qsx_agg_state *st, const void *const *cols, int64_t n, const uint64_t *filter_dev, int slots,
+                        int ranges, const long long *pieces, hipStream_t s) {
   DevConfig dc = st->dev;
   for (int i = 0; i < st->config.num_columns; ++i) dc.cols[i] = cols[i];
-  hipStream_t s = as_stream(stream);
-  // specialised kernels first: AOT plan shape, then the run-time one; CAPACITY (the tile does not fit
-  // LDS next to the group tables) and compile failures fall through to the interpreter
   const bool aot = !st->dense && st->shape != nullptr && filter_dev == nullptr;
   const JitKernel *jk = aot ? nullptr : state_jit_kernel(st, filter_dev != nullptr, n);
   if (jk != nullptr) {
-    int rc = launch_jit(st, jk, filter_dev != nullptr, cols, n, filter_dev, s);
+    int rc = launch_jit(st, jk, filter_dev != nullptr, cols, n, filter_dev, slots, ranges, pieces, s);
     if (rc == QSX_OK && hipGetLastError() == hipSuccess) return QSX_OK;
     // the specialised kernel could not be launched: keep going with the interpreter from now on
     std::lock_guard<std::mutex> lock(st->jit_mutex);
@@ -896,15 +934,78 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
     const HashTableView g = st->hash_view();
     int rc = QSX_OK;
     if (aot) {
-      rc = st->shape->launch(cols, st->config.num_columns, n, g, st->lds_slots, st->lds_ranges, s);
+      rc = st->shape->launch(cols, st->config.num_columns, n, g, slots, ranges, pieces, s);
     } else {
-      QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, st->lds_slots,
-                      st->lds_ranges, s);
+      QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, slots, ranges, pieces, s);
     }
     if (rc != QSX_OK) return rc;
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;
+}
+
+static long long partition_min_rows() {
+  const char *e = getenv("QSX_AGG_PARTITION_MIN_ROWS");
+  return e != nullptr ? atoll(e) : 4ll * 1024 * 1024;
+}
+
+// Mid-size group counts: partition the used columns on the key code (pieces aligned to 16 rows so that the update
+// kernel's 16-byte DMA works on every column of every piece), then ONE launch in which workgroup family p aggregates
+// piece p with a small LDS table.  No host synchronisation: the piece boundaries stay on the device.
+static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_t n, hipStream_t s) {
+  const int P = st->part_count;
+  const int ncols = st->config.num_columns;
+  constexpr int kAlignRows = 16;
+  const int64_t padded = n + static_cast<int64_t>(kAlignRows) * P;
+  long long *codes = nullptr;
+  int64_t *pieces = nullptr;
+  void *ws = nullptr;
+  const size_t ws_bytes = partition_workspace_bytes(n, P);
+  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&codes), static_cast<size_t>(n) * 8, s));
+  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&pieces), sizeof(int64_t) * 2 * P, s));
+  QSX_HIP_TRY(hipMallocAsync(&ws, ws_bytes, s));
+  const void *src[QSX_MAX_COLUMNS];
+  void *dst[QSX_MAX_COLUMNS];
+  void *part_cols[QSX_MAX_COLUMNS];
+  int32_t widths[QSX_MAX_COLUMNS];
+  int moved = 0;
+  for (int c = 0; c < ncols; ++c) {
+    part_cols[c] = nullptr;
+    if (!((st->used_columns >> c) & 1u)) continue;
+    QSX_HIP_TRY(hipMallocAsync(&part_cols[c], static_cast<size_t>(padded) * st->dev.column_width[c] + 16, s));
+    src[moved] = cols[c];
+    dst[moved] = part_cols[c];
+    widths[moved] = st->dev.column_width[c];
+    ++moved;
+  }
+  DevConfig dc = st->dev;
+  for (int i = 0; i < ncols; ++i) dc.cols[i] = cols[i];
+  hipLaunchKernelGGL(agg_key_codes_kernel, dim3(grid_for(n, kABlock * 4)), dim3(kABlock), 0, s, dc, n, codes);
+  QSX_CHECK_LAUNCH();
+  int rc = partition_scatter_impl(1, QSX_LONG, codes, n, P, moved, src, widths, dst, pieces, ws, ws_bytes, s, kAlignRows);
+  if (rc == QSX_OK) {
+    // n only sizes the grid here (an upper bound of every piece); the kernel reads its piece from `pieces`
+    rc = update_slice(st, part_cols, n, nullptr, st->part_slots, P, reinterpret_cast<const long long *>(pieces), s);
+  }
+  for (int c = 0; c < ncols; ++c) {
+    if (part_cols[c] != nullptr) QSX_HIP_TRY(hipFreeAsync(part_cols[c], s));
+  }
+  QSX_HIP_TRY(hipFreeAsync(ws, s));
+  QSX_HIP_TRY(hipFreeAsync(pieces, s));
+  QSX_HIP_TRY(hipFreeAsync(codes, s));
+  return rc;
+}
+
+int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev,
+                   qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (st == nullptr || n < 0 || (n > 0 && st->config.num_columns > 0 && cols == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+  if (n == 0) return QSX_OK;
+  hipStream_t s = as_stream(stream);
+  if (!st->dense && st->part_count > 1 && filter_dev == nullptr && n >= partition_min_rows()) {
+    return update_partitioned(st, cols, n, s);
+  }
+  return update_slice(st, cols, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s);
 }
 
 int qsx_agg_state_export_bytes(const qsx_agg_state_t *st, size_t *out_bytes) {

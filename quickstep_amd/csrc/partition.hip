@@ -96,11 +96,19 @@ __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(const KeyT *__r
       const int64_t row = tile + j * kPBlock + threadIdx.x;
       pid[j] = row < end ? partition_of<KeyT, MODE>(keys[row], P, pow2) : -1;
     }
+    if (MODE == 1 && !kSmallP) {
+      // internal re-partitioning needs no row order: one LDS atomic per row instead of the ranking loop
 #pragma unroll
-    for (int j = 0; j < kPSteps; ++j) {
-      int rank, count;
-      step_ranks<kSmallP>(pid[j], P, rank, count);
-      my_count += count;
+      for (int j = 0; j < kPSteps; ++j) {
+        if (pid[j] >= 0) atomicAdd(&s_total[pid[j]], 1);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kPSteps; ++j) {
+        int rank, count;
+        step_ranks<kSmallP>(pid[j], P, rank, count);
+        my_count += count;
+      }
     }
   }
   if (lane < P && my_count != 0) atomicAdd(&s_total[lane], my_count);
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(const KeyT *
   __shared__ unsigned char s_pid[kPTile];         // partition of every staged slot
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == 0 && out_offsets != nullptr) {
     if (threadIdx.x < P) out_offsets[threadIdx.x] = starts[static_cast<int64_t>(threadIdx.x) * G];
     if (threadIdx.x == 0) out_offsets[P] = n;
   }
@@ -167,6 +175,16 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(const KeyT *
       row[j] = tile + j * kPBlock + threadIdx.x;
       pid[j] = row[j] < end ? partition_of<KeyT, MODE>(keys[row[j]], P, pow2) : -1;
     }
+    constexpr bool kUnordered = MODE == 1 && !kSmallP;
+    if (kUnordered) {
+      // no row order to keep: the rank inside the tile is an LDS fetch-add on the partition's counter
+      if (threadIdx.x < P) s_cnt[threadIdx.x] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < kPSteps; ++j) pos[j] = pid[j] >= 0 ? atomicAdd(&s_cnt[pid[j]], 1) : 0;
+      __syncthreads();
+      if (threadIdx.x < P) s_part_start[threadIdx.x + 1] = s_cnt[threadIdx.x];
+    } else {
     // rank inside the wave + the cell's count per partition
 #pragma unroll
     for (int j = 0; j < kPSteps; ++j) {
@@ -187,6 +205,7 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(const KeyT *
       if (lane < kPCells) s_cnt[lane * P + p] = incl - c;
       if (lane == kWave - 1) s_part_start[p + 1] = incl;
     }
+    }
     __syncthreads();
     if (wave == 0) {  // exclusive scan of the partition totals (lane = partition)
       const int c = lane < P ? s_part_start[lane + 1] : 0;
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(const KeyT *
 #pragma unroll
     for (int j = 0; j < kPSteps; ++j) {
       if (pid[j] >= 0) {
-        pos[j] += s_part_start[pid[j]] + s_cnt[(j * kPWaves + wave) * P + pid[j]];
+        pos[j] += s_part_start[pid[j]] + (kUnordered ? 0 : s_cnt[(j * kPWaves + wave) * P + pid[j]]);
         s_pid[pos[j]] = static_cast<unsigned char>(pid[j]);
       }
     }
@@ -219,6 +238,28 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(const KeyT *
     if (threadIdx.x < P) s_glob[threadIdx.x] += s_part_start[threadIdx.x + 1] - s_part_start[threadIdx.x];
     __syncthreads();
   }
+}
+
+// Internal re-partitioning with aligned pieces: every partition's run starts at a multiple of `align` rows of the
+// output (so that a consumer can DMA 16-byte chunks of any column straight out of a piece); the gaps are never
+// read.  Rewrites the (partition, workgroup) start cells in place and publishes pieces[p] = start row,
+// pieces[P + p] = row count.
+__global__ __launch_bounds__(kPBlock) void align_starts_kernel(int64_t *__restrict__ starts, int P, int64_t G, int64_t n, int align,
+                                                              int64_t *__restrict__ pieces) {
+  __shared__ long long s_shift[kWave];
+  if (threadIdx.x == 0) {
+    long long next = 0;
+    for (int p = 0; p < P; ++p) {
+      const long long begin = starts[static_cast<int64_t>(p) * G];
+      const long long end = p + 1 < P ? starts[static_cast<int64_t>(p + 1) * G] : n;
+      s_shift[p] = next - begin;
+      pieces[p] = next;
+      pieces[P + p] = end - begin;
+      next = (next + (end - begin) + align - 1) / align * align;
+    }
+  }
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < static_cast<int64_t>(P) * G; i += kPBlock) starts[i] += s_shift[i / G];
 }
 
 static size_t p_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -239,7 +280,7 @@ size_t partition_workspace_bytes(int64_t n, int num_partitions) {
 
 template <typename KeyT, int MODE>
 static int launch_partition_t(const KeyT *keys, int64_t n, int P, int pow2, const ScatterArgs &args, int64_t *out_offsets,
-                              void *workspace, hipStream_t s) {
+                              void *workspace, int align_rows, hipStream_t s) {
   const int64_t G = blocks_for(n);
   int64_t rows_per_block = (n + G - 1) / G;
   rows_per_block = (rows_per_block + kPTile - 1) / kPTile * kPTile;
@@ -257,15 +298,21 @@ static int launch_partition_t(const KeyT *keys, int64_t n, int P, int pow2, cons
   }
   QSX_CHECK_LAUNCH();
   QSX_HIP_TRY(launch_scan(hist, cells, starts, nullptr, scan_ws, s));
+  int64_t *block0_offsets = out_offsets;
+  if (align_rows > 0) {
+    hipLaunchKernelGGL(align_starts_kernel, dim3(1), dim3(kPBlock), 0, s, starts, P, G, n, align_rows, out_offsets);
+    QSX_CHECK_LAUNCH();
+    block0_offsets = nullptr;   // out_offsets holds the pieces (start, count) instead of P + 1 boundaries
+  }
   int stage_width = 1;
   for (int c = 0; c < args.ncols; ++c) stage_width = args.width[c] > stage_width ? args.width[c] : stage_width;
   const size_t lds = static_cast<size_t>(kPTile) * stage_width + sizeof(int) * kPCells * P;
   if (P <= 8) {
     hipLaunchKernelGGL((partition_scatter_kernel<KeyT, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
-                       n, P, pow2, rows_per_block, G, starts, args, stage_width, out_offsets);
+                       n, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
   } else {
     hipLaunchKernelGGL((partition_scatter_kernel<KeyT, MODE, false>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
-                       n, P, pow2, rows_per_block, G, starts, args, stage_width, out_offsets);
+                       n, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;
@@ -276,7 +323,7 @@ static int launch_partition_t(const KeyT *keys, int64_t n, int P, int pow2, cons
 // the partitioned probe.
 int partition_scatter_impl(int mode, int key_type, const void *keys_dev, int64_t n, int num_partitions, int ncols,
                            const void *const *cols, const int32_t *widths, void *const *out_cols, int64_t *out_offsets_dev,
-                           void *workspace_dev, size_t workspace_bytes, hipStream_t s) {
+                           void *workspace_dev, size_t workspace_bytes, hipStream_t s, int align_rows) {
   if (n < 0 || num_partitions < 1 || ncols < 0 || ncols > QSX_MAX_COLUMNS || out_offsets_dev == nullptr) {
     return QSX_ERR_INVALID_ARGUMENT;
   }
@@ -310,11 +357,11 @@ int partition_scatter_impl(int mode, int key_type, const void *keys_dev, int64_t
     pow2 = 1;
   }
   if (key_type == QSX_INT) {
-    return mode == 0 ? launch_partition_t<int32_t, 0>(static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, s)
-                     : launch_partition_t<int32_t, 1>(static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, s);
+    return mode == 0 ? launch_partition_t<int32_t, 0>(static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s)
+                     : launch_partition_t<int32_t, 1>(static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s);
   }
-  return mode == 0 ? launch_partition_t<int64_t, 0>(static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, s)
-                   : launch_partition_t<int64_t, 1>(static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, s);
+  return mode == 0 ? launch_partition_t<int64_t, 0>(static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s)
+                   : launch_partition_t<int64_t, 1>(static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s);
 }
 
 }  // namespace qsx
@@ -331,7 +378,7 @@ int qsx_partition_scatter(int key_type, const void *keys_dev, int64_t n, int num
                           qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   return partition_scatter_impl(0, key_type, keys_dev, n, num_partitions, ncols, cols, widths, out_cols, out_offsets_dev,
-                                workspace_dev, workspace_bytes, as_stream(stream));
+                                workspace_dev, workspace_bytes, as_stream(stream), 0);
 }
 
 }  // extern "C"

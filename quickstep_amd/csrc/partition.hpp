@@ -11,9 +11,12 @@ size_t partition_workspace_bytes(int64_t n, int num_partitions);
 // mode 0: the reference's partition function (identity hash, catalog/PartitionSchemeHeader.hpp:200-214);
 // mode 1: top bits of a mixing hash, P a power of two (internal re-partitioning).  Stable; writes
 // num_partitions + 1 row offsets to out_offsets_dev.
+// align_rows > 0 (mode 1): every partition's run starts at a multiple of align_rows output rows (the output columns need
+// room for n + align_rows * num_partitions rows) and out_offsets_dev receives 2 * num_partitions values instead:
+// [p] = first row of piece p, [num_partitions + p] = its row count.
 int partition_scatter_impl(int mode, int key_type, const void *keys_dev, int64_t n, int num_partitions, int ncols,
                            const void *const *cols, const int32_t *widths, void *const *out_cols, int64_t *out_offsets_dev,
-                           void *workspace_dev, size_t workspace_bytes, hipStream_t stream);
+                           void *workspace_dev, size_t workspace_bytes, hipStream_t stream, int align_rows = 0);
 
 }  // namespace qsx
 

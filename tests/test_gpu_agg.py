@@ -424,3 +424,31 @@ def test_random_min_max_matches_oracle(capi, oracle, dev, strategy, n_groups):
     for x, y in zip(gv, rv):
         assert x.dtype == y.dtype
         assert np.array_equal(x[go], y[ro])
+
+
+@pytest.mark.parametrize("strategy", [T.AGG_COMPACT_KEY, T.AGG_GENERIC])
+@pytest.mark.parametrize("n_groups", [3_000, 40_000])
+def test_partitioned_aggregation_for_mid_size_group_counts(capi, oracle, dev, monkeypatch, strategy, n_groups):
+    """More groups than a workgroup-private LDS table holds: inputs above QSX_AGG_PARTITION_MIN_ROWS are
+    hash-partitioned on the key code first (csrc/aggregate.hip, update_partitioned) and aggregated piece by piece.
+    Forced here on 600 k rows; several update calls accumulate into the same state, with MIN/MAX and a predicate."""
+    monkeypatch.setenv("QSX_AGG_PARTITION_MIN_ROWS", "0")
+    rng = np.random.default_rng(n_groups)
+    n = 600_000
+    k1 = rng.integers(0, 200, size=n).astype(np.int32)
+    k2 = rng.integers(0, n_groups // 200, size=n).astype(np.int32)
+    val = rng.normal(size=n) * 1000
+    iv = rng.integers(-5, 5, size=n).astype(np.int32)
+    cfg = T.make_agg_config(strategy, [(T.INT, None), (T.INT, None), (T.DOUBLE, None), (T.INT, None)], keys=[0, 1],
+                            instrs=[(T.EX_MUL, 0, T.col(2), T.col(3))],
+                            aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None), (T.AGG_AVG, T.temp(0)), (T.AGG_MIN, T.col(2)),
+                                  (T.AGG_MAX, T.col(3)), (T.AGG_SUM, T.col(3))],
+                            pred=[(3, T.GE, -4)], est_groups=n_groups)
+    cols = [k1, k2, val, iv]
+    st = run_hip(capi, dev, cfg, cols, blocks=3)
+    o = oracle.AggState(cfg)
+    o.update(cols)
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+    # the same rows without partitioning (hash-range families / global table) agree as well
+    monkeypatch.setenv("QSX_AGG_PARTITION_MIN_ROWS", str(1 << 60))
+    assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols, blocks=3), dev), o.finalize())
