@@ -45,27 +45,6 @@
 
 namespace qsx {
 
-// Packed key code of every row straight from the key columns (ThreadPrivateCompactKeyHashTable.cpp:216-232):
-// the routing key of the partitioned aggregation (aggregate.hip, update_partitioned).
-__global__ __launch_bounds__(kABlock) void agg_key_codes_kernel(DevConfig c, int64_t n, long long *__restrict__ codes) {
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kABlock + threadIdx.x; i < n;
-       i += static_cast<int64_t>(gridDim.x) * kABlock) {
-    unsigned long long code = 0;
-    for (int k = 0; k < c.num_keys; ++k) {
-      const void *col = c.cols[c.key_column[k]];
-      unsigned long long v;
-      switch (c.key_width[k]) {
-        case 1: v = static_cast<const uint8_t *>(col)[i]; break;
-        case 2: v = static_cast<const uint16_t *>(col)[i]; break;
-        case 4: v = static_cast<const uint32_t *>(col)[i]; break;
-        default: v = static_cast<const unsigned long long *>(col)[i]; break;
-      }
-      code |= v << c.key_shift[k];
-    }
-    codes[i] = static_cast<long long>(code);
-  }
-}
-
 // AccKind of every state column, by value into the kernels that combine whole columns.
 struct ColKinds {
   int kind[QSX_MAX_AGGS + 1];
@@ -957,11 +936,9 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   const int ncols = st->config.num_columns;
   constexpr int kAlignRows = 16;
   const int64_t padded = n + static_cast<int64_t>(kAlignRows) * P;
-  long long *codes = nullptr;
   int64_t *pieces = nullptr;
   void *ws = nullptr;
   const size_t ws_bytes = partition_workspace_bytes(n, P);
-  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&codes), static_cast<size_t>(n) * 8, s));
   QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&pieces), sizeof(int64_t) * 2 * P, s));
   QSX_HIP_TRY(hipMallocAsync(&ws, ws_bytes, s));
   const void *src[QSX_MAX_COLUMNS];
@@ -978,11 +955,11 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
     widths[moved] = st->dev.column_width[c];
     ++moved;
   }
-  DevConfig dc = st->dev;
-  for (int i = 0; i < ncols; ++i) dc.cols[i] = cols[i];
-  hipLaunchKernelGGL(agg_key_codes_kernel, dim3(grid_for(n, kABlock * 4)), dim3(kABlock), 0, s, dc, n, codes);
-  QSX_CHECK_LAUNCH();
-  int rc = partition_scatter_impl(1, QSX_LONG, codes, n, P, moved, src, widths, dst, pieces, ws, ws_bytes, s, kAlignRows);
+  // the routing key is the packed key code, computed from the key columns inside K9 (never materialised)
+  const void *key_cols[QSX_MAX_KEYS];
+  for (int k = 0; k < st->dev.num_keys; ++k) key_cols[k] = cols[st->dev.key_column[k]];
+  int rc = partition_scatter_packed_keys(st->dev.num_keys, key_cols, st->dev.key_width, st->dev.key_shift, n, P, moved, src, widths,
+                                         dst, pieces, ws, ws_bytes, s, kAlignRows);
   if (rc == QSX_OK) {
     // n only sizes the grid here (an upper bound of every piece); the kernel reads its piece from `pieces`
     rc = update_slice(st, part_cols, n, nullptr, st->part_slots, P, reinterpret_cast<const long long *>(pieces), s);
@@ -992,7 +969,6 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   }
   QSX_HIP_TRY(hipFreeAsync(ws, s));
   QSX_HIP_TRY(hipFreeAsync(pieces, s));
-  QSX_HIP_TRY(hipFreeAsync(codes, s));
   return rc;
 }
 

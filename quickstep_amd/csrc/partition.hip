@@ -34,10 +34,42 @@ constexpr int kPCells = kPSteps * kPWaves;        // 32 (step, wave) cells per t
 
 // MODE 0: the reference's partition function (identity hash); MODE 1: the top bits of a mixing hash
 // (internal re-partitioning: aggregation groups, join table slices) — P must be a power of two there.
-template <typename KeyT, int MODE>
-__device__ __forceinline__ int partition_of(KeyT key, int P, int pow2) {
-  unsigned long long h;
-  if (sizeof(KeyT) == 4) h = static_cast<uint32_t>(key); else h = static_cast<unsigned long long>(key);
+// Where a row's key comes from: one INT / LONG column (zero-extended bit pattern = the identity hash), or several
+// key columns packed into one 64-bit code on the fly (the aggregation's key code; saves materialising it).
+template <typename KeyT>
+struct ColumnKey {
+  const KeyT *keys;
+  __device__ __forceinline__ unsigned long long operator()(int64_t row) const {
+    if (sizeof(KeyT) == 4) return static_cast<uint32_t>(keys[row]);
+    return static_cast<unsigned long long>(keys[row]);
+  }
+};
+struct PackedKey {
+  const void *col[QSX_MAX_KEYS];
+  int width[QSX_MAX_KEYS];
+  int shift[QSX_MAX_KEYS];
+  int num;
+  __device__ __forceinline__ unsigned long long operator()(int64_t row) const {
+    unsigned long long code = 0;
+#pragma unroll
+    for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+      if (k < num) {
+        unsigned long long v;
+        switch (width[k]) {
+          case 1: v = static_cast<const uint8_t *>(col[k])[row]; break;
+          case 2: v = static_cast<const uint16_t *>(col[k])[row]; break;
+          case 4: v = static_cast<const uint32_t *>(col[k])[row]; break;
+          default: v = static_cast<const unsigned long long *>(col[k])[row]; break;
+        }
+        code |= v << shift[k];
+      }
+    }
+    return code;
+  }
+};
+
+template <int MODE>
+__device__ __forceinline__ int partition_of(unsigned long long h, int P, int pow2) {
   if (MODE == 1) return static_cast<int>((mix64(h) * 0x9E3779B97F4A7C15ull) >> (64 - pow2));   // pow2 = log2(P) here
   if (pow2) return static_cast<int>(h & static_cast<unsigned long long>(P - 1));
   return static_cast<int>(h >= static_cast<unsigned long long>(P) ? h % static_cast<unsigned long long>(P) : h);
@@ -78,8 +110,8 @@ struct ScatterArgs {
   void *dst[QSX_MAX_COLUMNS];
 };
 
-template <typename KeyT, int MODE, bool kSmallP>
-__global__ __launch_bounds__(kPBlock) void partition_hist_kernel(const KeyT *__restrict__ keys, int64_t n, int P,
+template <typename Loader, int MODE, bool kSmallP>
+__global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key, int64_t n, int P,
                                                                 int pow2, int64_t rows_per_block, int64_t G,
                                                                 int32_t *__restrict__ hist) {
   __shared__ int s_total[kWave];
@@ -94,7 +126,7 @@ __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(const KeyT *__r
 #pragma unroll
     for (int j = 0; j < kPSteps; ++j) {
       const int64_t row = tile + j * kPBlock + threadIdx.x;
-      pid[j] = row < end ? partition_of<KeyT, MODE>(keys[row], P, pow2) : -1;
+      pid[j] = row < end ? partition_of<MODE>(load_key(row), P, pow2) : -1;
     }
     if (MODE == 1 && !kSmallP) {
       // internal re-partitioning needs no row order: one LDS atomic per row instead of the ranking loop
@@ -142,8 +174,8 @@ __device__ __forceinline__ void stage_and_copy(const void *src, void *dst, unsig
   __syncthreads();
 }
 
-template <typename KeyT, int MODE, bool kSmallP>
-__global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(const KeyT *__restrict__ keys, int64_t n, int P,
+template <typename Loader, int MODE, bool kSmallP>
+__global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(Loader load_key, int64_t n, int P,
                                                                    int pow2, int64_t rows_per_block, int64_t G,
                                                                    const int64_t *__restrict__ starts,
                                                                    ScatterArgs args, int stage_width,
@@ -173,7 +205,7 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(const KeyT *
 #pragma unroll
     for (int j = 0; j < kPSteps; ++j) {
       row[j] = tile + j * kPBlock + threadIdx.x;
-      pid[j] = row[j] < end ? partition_of<KeyT, MODE>(keys[row[j]], P, pow2) : -1;
+      pid[j] = row[j] < end ? partition_of<MODE>(load_key(row[j]), P, pow2) : -1;
     }
     constexpr bool kUnordered = MODE == 1 && !kSmallP;
     if (kUnordered) {
@@ -278,8 +310,8 @@ size_t partition_workspace_bytes(int64_t n, int num_partitions) {
          scan_workspace_words(cells) * sizeof(int64_t);
 }
 
-template <typename KeyT, int MODE>
-static int launch_partition_t(const KeyT *keys, int64_t n, int P, int pow2, const ScatterArgs &args, int64_t *out_offsets,
+template <typename Loader, int MODE>
+static int launch_partition_t(Loader keys, int64_t n, int P, int pow2, const ScatterArgs &args, int64_t *out_offsets,
                               void *workspace, int align_rows, hipStream_t s) {
   const int64_t G = blocks_for(n);
   int64_t rows_per_block = (n + G - 1) / G;
@@ -290,10 +322,10 @@ static int launch_partition_t(const KeyT *keys, int64_t n, int P, int pow2, cons
   int32_t *hist = reinterpret_cast<int32_t *>(after);
   int64_t *scan_ws = reinterpret_cast<int64_t *>(after + p_align_up(sizeof(int32_t) * cells, 256));
   if (P <= 8) {
-    hipLaunchKernelGGL((partition_hist_kernel<KeyT, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys, n, P,
+    hipLaunchKernelGGL((partition_hist_kernel<Loader, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys, n, P,
                        pow2, rows_per_block, G, hist);
   } else {
-    hipLaunchKernelGGL((partition_hist_kernel<KeyT, MODE, false>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys, n, P,
+    hipLaunchKernelGGL((partition_hist_kernel<Loader, MODE, false>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys, n, P,
                        pow2, rows_per_block, G, hist);
   }
   QSX_CHECK_LAUNCH();
@@ -308,10 +340,10 @@ static int launch_partition_t(const KeyT *keys, int64_t n, int P, int pow2, cons
   for (int c = 0; c < args.ncols; ++c) stage_width = args.width[c] > stage_width ? args.width[c] : stage_width;
   const size_t lds = static_cast<size_t>(kPTile) * stage_width + sizeof(int) * kPCells * P;
   if (P <= 8) {
-    hipLaunchKernelGGL((partition_scatter_kernel<KeyT, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
+    hipLaunchKernelGGL((partition_scatter_kernel<Loader, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
                        n, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
   } else {
-    hipLaunchKernelGGL((partition_scatter_kernel<KeyT, MODE, false>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
+    hipLaunchKernelGGL((partition_scatter_kernel<Loader, MODE, false>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
                        n, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
   }
   QSX_CHECK_LAUNCH();
@@ -357,11 +389,42 @@ int partition_scatter_impl(int mode, int key_type, const void *keys_dev, int64_t
     pow2 = 1;
   }
   if (key_type == QSX_INT) {
-    return mode == 0 ? launch_partition_t<int32_t, 0>(static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s)
-                     : launch_partition_t<int32_t, 1>(static_cast<const int32_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s);
+    const ColumnKey<int32_t> k{static_cast<const int32_t *>(keys_dev)};
+    return mode == 0 ? launch_partition_t<ColumnKey<int32_t>, 0>(k, n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s)
+                     : launch_partition_t<ColumnKey<int32_t>, 1>(k, n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s);
   }
-  return mode == 0 ? launch_partition_t<int64_t, 0>(static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s)
-                   : launch_partition_t<int64_t, 1>(static_cast<const int64_t *>(keys_dev), n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s);
+  const ColumnKey<int64_t> k{static_cast<const int64_t *>(keys_dev)};
+  return mode == 0 ? launch_partition_t<ColumnKey<int64_t>, 0>(k, n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s)
+                   : launch_partition_t<ColumnKey<int64_t>, 1>(k, n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s);
+}
+
+// Mixing-hash partitioning on a key code packed on the fly from up to QSX_MAX_KEYS key columns (mode 1 only).
+int partition_scatter_packed_keys(int num_keys, const void *const *key_cols, const int *key_widths, const int *key_shifts,
+                                  int64_t n, int num_partitions, int ncols, const void *const *cols, const int32_t *widths,
+                                  void *const *out_cols, int64_t *out_offsets_dev, void *workspace_dev, size_t workspace_bytes,
+                                  hipStream_t s, int align_rows) {
+  if (n <= 0 || num_keys < 1 || num_keys > QSX_MAX_KEYS || num_partitions < 2 || num_partitions > kWave ||
+      (num_partitions & (num_partitions - 1)) != 0 || ncols < 0 || ncols > QSX_MAX_COLUMNS || out_offsets_dev == nullptr) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (workspace_bytes < partition_workspace_bytes(n, num_partitions) || workspace_dev == nullptr) return QSX_ERR_CAPACITY;
+  ScatterArgs args;
+  args.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) {
+    args.width[c] = widths[c];
+    args.src[c] = cols[c];
+    args.dst[c] = out_cols[c];
+  }
+  PackedKey k;
+  k.num = num_keys;
+  for (int i = 0; i < QSX_MAX_KEYS; ++i) {
+    k.col[i] = i < num_keys ? key_cols[i] : nullptr;
+    k.width[i] = i < num_keys ? key_widths[i] : 0;
+    k.shift[i] = i < num_keys ? key_shifts[i] : 0;
+  }
+  int log2p = 0;
+  while ((1 << log2p) < num_partitions) ++log2p;
+  return launch_partition_t<PackedKey, 1>(k, n, num_partitions, log2p, args, out_offsets_dev, workspace_dev, align_rows, s);
 }
 
 }  // namespace qsx

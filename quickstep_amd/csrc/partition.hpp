@@ -18,6 +18,13 @@ int partition_scatter_impl(int mode, int key_type, const void *keys_dev, int64_t
                            const void *const *cols, const int32_t *widths, void *const *out_cols, int64_t *out_offsets_dev,
                            void *workspace_dev, size_t workspace_bytes, hipStream_t stream, int align_rows = 0);
 
+// Same, routing on the key code packed on the fly from several key columns (little-endian at bit offsets key_shifts,
+// ThreadPrivateCompactKeyHashTable.cpp:216-232): mode 1 only, num_partitions a power of two >= 2.
+int partition_scatter_packed_keys(int num_keys, const void *const *key_cols, const int *key_widths, const int *key_shifts,
+                                  int64_t n, int num_partitions, int ncols, const void *const *cols, const int32_t *widths,
+                                  void *const *out_cols, int64_t *out_offsets_dev, void *workspace_dev, size_t workspace_bytes,
+                                  hipStream_t stream, int align_rows);
+
 }  // namespace qsx
 
 #endif  // QSX_CSRC_PARTITION_HPP_
