@@ -318,19 +318,25 @@ PredicateTransformResult TransformPredicateOnCompressedAttribute(const Compresse
   }
 }
 
+void CompressValues(TypeID type, const void *values, std::int64_t n, CompressedAttribute *out,
+                    std::vector<unsigned char> *codes_host) {
+  codes_host->clear();
+  switch (type) {
+    case kInt: BuildCompressedAttribute(type, static_cast<const std::int32_t *>(values), n, out, codes_host); break;
+    case kLong: BuildCompressedAttribute(type, static_cast<const std::int64_t *>(values), n, out, codes_host); break;
+    case kFloat: BuildCompressedAttribute(type, static_cast<const float *>(values), n, out, codes_host); break;
+    case kDouble: BuildCompressedAttribute(type, static_cast<const double *>(values), n, out, codes_host); break;
+    default: out->kind = CompressedAttribute::kUncompressed; break;
+  }
+}
+
 void StorageBlock::compressAttribute(attribute_id a, const void *host_values) {
   if (g_host_memory) return;   // CPU plumbing mode keeps plain stripes
   const Type &t = relation_.getAttributeType(a);
   if (compressed_.empty()) compressed_.resize(relation_.size());
   CompressedAttribute &c = compressed_.at(a);
   std::vector<unsigned char> codes_host;
-  switch (t.id) {
-    case kInt: BuildCompressedAttribute(t.id, static_cast<const std::int32_t *>(host_values), num_tuples_, &c, &codes_host); break;
-    case kLong: BuildCompressedAttribute(t.id, static_cast<const std::int64_t *>(host_values), num_tuples_, &c, &codes_host); break;
-    case kFloat: BuildCompressedAttribute(t.id, static_cast<const float *>(host_values), num_tuples_, &c, &codes_host); break;
-    case kDouble: BuildCompressedAttribute(t.id, static_cast<const double *>(host_values), num_tuples_, &c, &codes_host); break;
-    default: return;
-  }
+  CompressValues(t.id, host_values, num_tuples_, &c, &codes_host);
   if (c.kind == CompressedAttribute::kUncompressed) return;
   CheckStatus(qsx_device_alloc(codes_host.size() + 8, &c.codes), "qsx_device_alloc(codes)");
   CheckStatus(qsx_copy_to_device(c.codes, codes_host.data(), codes_host.size(), nullptr), "qsx_copy_to_device(codes)");

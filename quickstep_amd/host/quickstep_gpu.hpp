@@ -157,6 +157,11 @@ struct PredicateTransformResult {
   std::uint32_t first_literal = 0, second_literal = 0;
 };
 struct TypedLiteral;
+// CompressedBlockBuilder's per-attribute decision for n host values of a numeric type without NULLs: fills kind,
+// code_width, num_codes and dictionary_host of *out and the code stripe (empty when the attribute stays
+// uncompressed).  Pure host logic (storage/CompressedBlockBuilder.cpp:508-566, 590-650).
+void CompressValues(TypeID type, const void *values, std::int64_t n, CompressedAttribute *out,
+                    std::vector<unsigned char> *codes_host);
 PredicateTransformResult TransformPredicateOnCompressedAttribute(const CompressedAttribute &attribute, TypeID type,
                                                                  ComparisonID comparison, const TypedLiteral &literal);
 

@@ -13,7 +13,7 @@ BIN = os.path.join(ROOT, "tests", "cpp", "bin")
 def _ensure_built():
     if not all(os.path.exists(os.path.join(BIN, b)) for b in
                ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
-                "lip_filter_operator_test", "compressed_block_operator_test")):
+                "lip_filter_operator_test", "compressed_block_operator_test", "host_logic_test")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -28,6 +28,12 @@ def test_select_operator_cpu_workorder_plumbing():
     """BASELINE config 1 (CPU WorkOrder through Foreman/Worker, no GPU), scaled to 1 M rows."""
     out = _run("select_cpu_workorder_test", "1000000", "4")
     assert out.count("M rows/s") == 3
+
+
+def test_host_logic_without_a_device():
+    """Compression choice + predicate rewriting on codes (row by row against the comparison on values), partition
+    scheme bookkeeping, work-order container order: pure host logic of the operator layer."""
+    _run("host_logic_test")
 
 
 def test_gpu_operators_refuse_to_run_without_a_gpu():
