@@ -513,6 +513,24 @@ int qsx_partition_scatter(int key_type, const void *keys_dev, int64_t n, int num
                           void *const *out_cols, int64_t *out_offsets_dev,
                           void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
 
+/* ======================================================================
+ * ORDER BY (the step after the aggregate in Q1 / Q3)
+ * ====================================================================== */
+
+size_t qsx_sort_workspace_bytes(int64_t n);
+
+/* Stable sort permutation: out_tids[j] = row number (0-based) of the j-th row in ORDER BY order over
+ * nkeys key columns (key 0 most significant; descending[k] != 0 = DESC; INT / LONG / FLOAT / DOUBLE).
+ * Replaces the comparator sort of SortRunGenerationWorkOrder::execute (relational_operators/
+ * SortRunGenerationOperator.cpp:88-105 -> StorageBlock::sort, storage/StorageBlock.cpp:561-640, ordering
+ * from utility/SortConfiguration.hpp:51-130) and — applied to the concatenation of the runs, truncated
+ * to top_k by the caller — the merge tree of SortMergeRunOperator (relational_operators/
+ * SortMergeRunOperatorHelpers.cpp).  Rows with equal keys keep their input order.  The caller
+ * materialises columns with qsx_gather(col, out_tids).  NULL ordering is out of scope (no NULL inputs). */
+int qsx_sort_permutation(int nkeys, const void *const *key_cols, const int32_t *key_types,
+                         const int32_t *descending, int64_t n, int32_t *out_tids_dev,
+                         void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -73,6 +73,7 @@ for _name, _res, _args in [
     ("qso_transform_predicate", None, [C.POINTER(CompressedInfo), _int, _vp, _int, _vp, C.POINTER(CodePredicate)]),
     ("qso_select_codes", None, [_int, _vp, _i64, _int, C.c_uint32, C.c_uint32, _vp, _vp]),
     ("qso_decode_codes", None, [_int, _vp, _i64, _vp, _int, _vp]),
+    ("qso_sort_permutation", None, [_int, _pp, C.POINTER(_i32), C.POINTER(_i32), _i64, _vp]),
     ("qso_agg_state_create", _vp, [C.POINTER(T.AggConfig)]),
     ("qso_agg_state_destroy", None, [_vp]),
     ("qso_agg_update", None, [_vp, _pp, _i64, _vp]),
@@ -354,6 +355,18 @@ def select_codes(codes, op, first, second=0, filter_bitmap=None):
     out = np.zeros(max(words(codes.size), 1), dtype=np.uint64)
     _lib.qso_select_codes(codes.dtype.itemsize, _p(codes), codes.size, op, first, second, _p(filter_bitmap), _p(out))
     return out
+
+
+def sort_permutation(key_cols, descending=None):
+    """ORDER BY key_cols[0], key_cols[1], ...: stable, comparator semantics of SortConfiguration."""
+    keep = [np.ascontiguousarray(c) for c in key_cols]
+    n = keep[0].size
+    ptrs = (C.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
+    types = (C.c_int32 * len(keep))(*[_NP_TYPE[c.dtype] for c in keep])
+    desc = (C.c_int32 * len(keep))(*[1 if (descending and descending[i]) else 0 for i in range(len(keep))])
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    _lib.qso_sort_permutation(len(keep), ptrs, types, desc, n, _p(out))
+    return out[:n]
 
 
 # ---- aggregation --------------------------------------------------------------------

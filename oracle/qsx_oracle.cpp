@@ -1498,3 +1498,34 @@ void qso_decode_codes(int code_width, const void *codes, int64_t n, const void *
 }
 
 }  // extern "C"
+
+// ===========================================================================
+// ORDER BY
+// ===========================================================================
+extern "C" {
+
+// Stable sort of the row numbers by the comparator chain of a SortConfiguration (utility/SortConfiguration.hpp:51-130;
+// StorageBlock::sort, storage/StorageBlock.cpp:561-640): key 0 is the most significant, descending[k] flips key k.
+void qso_sort_permutation(int nkeys, const void *const *key_cols, const int32_t *key_types, const int32_t *descending, int64_t n,
+                          int32_t *out_tids) {
+  std::vector<int32_t> order(static_cast<size_t>(n));
+  for (int64_t i = 0; i < n; ++i) order[static_cast<size_t>(i)] = static_cast<int32_t>(i);
+  auto less = [&](int32_t a, int32_t b) {
+    for (int k = 0; k < nkeys; ++k) {
+      int cmp = 0;
+      switch (key_types[k]) {
+        case QSX_INT: { const auto *c = static_cast<const std::int32_t *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        case QSX_LONG: { const auto *c = static_cast<const std::int64_t *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        case QSX_FLOAT: { const auto *c = static_cast<const float *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        default: { const auto *c = static_cast<const double *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+      }
+      if (descending != nullptr && descending[k]) cmp = -cmp;
+      if (cmp != 0) return cmp < 0;
+    }
+    return false;
+  };
+  std::stable_sort(order.begin(), order.end(), less);
+  std::memcpy(out_tids, order.data(), sizeof(int32_t) * static_cast<size_t>(n));
+}
+
+}  // extern "C"

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "qsx_tids_to_bitmap": (_int, [_vp, _i64, _i32, _i64, _vp, _vp]),
     "qsx_gather": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_gather_segmented": (_int, [_int, _int, _pp, C.POINTER(_i64), _vp, _i64, _vp, _vp]),
+    "qsx_sort_workspace_bytes": (_sz, [_i64]),
+    "qsx_sort_permutation": (_int, [_int, _pp, C.POINTER(_i32), C.POINTER(_i32), _i64, _vp, _vp, _sz, _vp]),
     "qsx_join_table_create": (_int, [_int, _i64, _pp]),
     "qsx_join_table_create_dense": (_int, [_int, _i64, _i64, _i64, _i64, _pp]),
     "qsx_join_table_destroy": (_int, [_vp]),
@@ -250,6 +252,21 @@ def join_key_pack(cols, stream=None):
     _check(_lib.qsx_join_key_pack(len(cols), ptrs, types, n, _ptr(out), C.byref(exact), _stream(stream)),
            "qsx_join_key_pack")
     return out, bool(exact.value)
+
+
+def sort_permutation(key_cols, descending=None, stream=None):
+    """ORDER BY key_cols[0], key_cols[1], ... -> int32 row numbers in output order (stable)."""
+    n = key_cols[0].numel()
+    device = key_cols[0].device
+    out = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+    ws_bytes = _lib.qsx_sort_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    ptrs = (C.c_void_p * len(key_cols))(*[c.data_ptr() for c in key_cols])
+    types = (C.c_int32 * len(key_cols))(*[qsx_type_of(c) for c in key_cols])
+    desc = (C.c_int32 * len(key_cols))(*[1 if (descending and descending[i]) else 0 for i in range(len(key_cols))])
+    _check(_lib.qsx_sort_permutation(len(key_cols), ptrs, types, desc, n, _ptr(out), _ptr(ws), ws_bytes, _stream(stream)),
+           "qsx_sort_permutation")
+    return out[:n]
 
 
 def gather(src, tids, out=None, stream=None):

@@ -33,7 +33,8 @@ constexpr int kPTile = kPBlock * kPSteps;         // 2048 rows
 constexpr int kPCells = kPSteps * kPWaves;        // 32 (step, wave) cells per tile: scanned by one wave
 
 // MODE 0: the reference's partition function (identity hash); MODE 1: the top bits of a mixing hash
-// (internal re-partitioning: aggregation groups, join table slices) — P must be a power of two there.
+// (internal re-partitioning: aggregation groups, join table slices) — P must be a power of two there;
+// MODE 2: a 6-bit radix digit of a 64-bit sort key (stable: one LSD radix sort pass, sort.hip).
 // Where a row's key comes from: one INT / LONG column (zero-extended bit pattern = the identity hash), or several
 // key columns packed into one 64-bit code on the fly (the aggregation's key code; saves materialising it).
 template <typename KeyT>
@@ -70,6 +71,7 @@ struct PackedKey {
 
 template <int MODE>
 __device__ __forceinline__ int partition_of(unsigned long long h, int P, int pow2) {
+  if (MODE == 2) return static_cast<int>((h >> pow2) & static_cast<unsigned long long>(P - 1));   // radix digit, pow2 = bit shift
   if (MODE == 1) return static_cast<int>((mix64(h) * 0x9E3779B97F4A7C15ull) >> (64 - pow2));   // pow2 = log2(P) here
   if (pow2) return static_cast<int>(h & static_cast<unsigned long long>(P - 1));
   return static_cast<int>(h >= static_cast<unsigned long long>(P) ? h % static_cast<unsigned long long>(P) : h);
@@ -396,6 +398,23 @@ int partition_scatter_impl(int mode, int key_type, const void *keys_dev, int64_t
   const ColumnKey<int64_t> k{static_cast<const int64_t *>(keys_dev)};
   return mode == 0 ? launch_partition_t<ColumnKey<int64_t>, 0>(k, n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s)
                    : launch_partition_t<ColumnKey<int64_t>, 1>(k, n, num_partitions, pow2, args, out_offsets_dev, workspace_dev, align_rows, s);
+}
+
+// One stable LSD radix pass: rows ordered by the 6-bit digit (keys64 >> shift) & 63, ties in input order.
+int partition_scatter_digit(const unsigned long long *keys64_dev, int64_t n, int shift, int ncols, const void *const *cols,
+                            const int32_t *widths, void *const *out_cols, int64_t *out_offsets_dev, void *workspace_dev,
+                            size_t workspace_bytes, hipStream_t s) {
+  if (n <= 0 || ncols < 0 || ncols > QSX_MAX_COLUMNS || out_offsets_dev == nullptr || shift < 0 || shift > 63) return QSX_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < partition_workspace_bytes(n, kWave) || workspace_dev == nullptr) return QSX_ERR_CAPACITY;
+  ScatterArgs args;
+  args.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) {
+    args.width[c] = widths[c];
+    args.src[c] = cols[c];
+    args.dst[c] = out_cols[c];
+  }
+  const ColumnKey<int64_t> k{reinterpret_cast<const int64_t *>(keys64_dev)};
+  return launch_partition_t<ColumnKey<int64_t>, 2>(k, n, kWave, shift, args, out_offsets_dev, workspace_dev, 0, s);
 }
 
 // Mixing-hash partitioning on a key code packed on the fly from up to QSX_MAX_KEYS key columns (mode 1 only).

@@ -25,6 +25,12 @@ int partition_scatter_packed_keys(int num_keys, const void *const *key_cols, con
                                   void *const *out_cols, int64_t *out_offsets_dev, void *workspace_dev, size_t workspace_bytes,
                                   hipStream_t stream, int align_rows);
 
+// One stable LSD radix-sort pass over 64-bit keys: 64 buckets by the digit (key >> shift) & 63, ties keep their order.
+// out_offsets_dev: 65 int64.  Workspace: partition_workspace_bytes(n, 64).
+int partition_scatter_digit(const unsigned long long *keys64_dev, int64_t n, int shift, int ncols, const void *const *cols,
+                            const int32_t *widths, void *const *out_cols, int64_t *out_offsets_dev, void *workspace_dev,
+                            size_t workspace_bytes, hipStream_t stream);
+
 }  // namespace qsx
 
 #endif  // QSX_CSRC_PARTITION_HPP_
