@@ -81,6 +81,7 @@ int qsx_device_alloc(size_t bytes, void **out_dev);
 int qsx_device_free(void *dev);
 int qsx_copy_to_device(void *dst_dev, const void *src_host, size_t bytes, qsx_stream_t stream);
 int qsx_copy_to_host(void *dst_host, const void *src_dev, size_t bytes, qsx_stream_t stream);
+int qsx_copy_on_device(void *dst_dev, const void *src_dev, size_t bytes, qsx_stream_t stream);
 int qsx_memset_device(void *dst_dev, int byte, size_t bytes, qsx_stream_t stream);
 int qsx_stream_synchronize(qsx_stream_t stream);
 /* One stream per Worker thread (query_execution/Worker.cpp:54-99 runs work orders one at a

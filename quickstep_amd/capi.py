@@ -52,6 +52,7 @@ _SIGNATURES = {
     "qsx_device_free": (_int, [_vp]),
     "qsx_copy_to_device": (_int, [_vp, _vp, _sz, _vp]),
     "qsx_copy_to_host": (_int, [_vp, _vp, _sz, _vp]),
+    "qsx_copy_on_device": (_int, [_vp, _vp, _sz, _vp]),
     "qsx_memset_device": (_int, [_vp, _int, _sz, _vp]),
     "qsx_stream_synchronize": (_int, [_vp]),
     "qsx_stream_create": (_int, [_pp]),

@@ -91,6 +91,13 @@ int qsx_copy_to_device(void *dst_dev, const void *src_host, size_t bytes, qsx_st
   return QSX_OK;
 }
 
+int qsx_copy_on_device(void *dst_dev, const void *src_dev, size_t bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (bytes == 0) return QSX_OK;
+  QSX_HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, qsx::as_stream(stream)));
+  return QSX_OK;
+}
+
 int qsx_copy_to_host(void *dst_host, const void *src_dev, size_t bytes, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (bytes == 0) return QSX_OK;

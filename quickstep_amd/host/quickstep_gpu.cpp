@@ -1331,6 +1331,110 @@ bool DestroyAggregationStateOperator::getAllWorkOrders(WorkOrdersContainer *cont
 }
 
 // ---------------------------------------------------------------------------
+// ORDER BY
+// ---------------------------------------------------------------------------
+namespace {
+// Sorts the concatenation of `blocks` by `config` and writes the first `limit` tuples (0 = all) into one output block.
+void SortBlocksInto(const std::vector<BlockReference> &blocks, const CatalogRelation &relation,
+                    const QueryContext::SortConfiguration &config, std::size_t limit, InsertDestination *dest) {
+  std::int64_t n = 0;
+  for (const BlockReference &b : blocks) n += b->numTuples();
+  const std::int64_t out_rows = limit != 0 && static_cast<std::int64_t>(limit) < n ? static_cast<std::int64_t>(limit) : n;
+  block_id out_id;
+  BlockReference out = dest->getBlockForInsertion(out_rows > 0 ? out_rows : 1, &out_id);
+  if (n == 0) {
+    dest->returnBlock(out_id, 0);
+    return;
+  }
+  // one contiguous stripe per attribute (a single input block is used in place)
+  std::vector<std::unique_ptr<DeviceBuffer>> owned;
+  std::vector<const void *> stripes(relation.size(), nullptr);
+  for (std::size_t a = 0; a < relation.size(); ++a) {
+    const int width = relation.getAttributeType(static_cast<attribute_id>(a)).width;
+    if (blocks.size() == 1) {
+      stripes[a] = blocks.front()->stripe(static_cast<attribute_id>(a));
+      continue;
+    }
+    owned.emplace_back(new DeviceBuffer(static_cast<std::size_t>(n) * width + 16));
+    char *at = static_cast<char *>(owned.back()->ptr);
+    for (const BlockReference &b : blocks) {
+      const std::size_t bytes = static_cast<std::size_t>(b->numTuples()) * width;
+      CheckStatus(qsx_copy_on_device(at, b->stripe(static_cast<attribute_id>(a)), bytes, CurrentStream()), "qsx_copy_on_device");
+      at += bytes;
+    }
+    stripes[a] = owned.back()->ptr;
+  }
+  std::vector<const void *> key_cols;
+  std::vector<std::int32_t> key_types, descending;
+  for (std::size_t k = 0; k < config.order_by.size(); ++k) {
+    key_cols.push_back(stripes.at(config.order_by[k]));
+    key_types.push_back(relation.getAttributeType(config.order_by[k]).id);
+    descending.push_back(config.ordering.at(k) ? 0 : 1);
+  }
+  const std::size_t ws_bytes = qsx_sort_workspace_bytes(n);
+  DeviceBuffer ws(ws_bytes), tids(static_cast<std::size_t>(n) * 4 + 16);
+  CheckStatus(qsx_sort_permutation(static_cast<int>(key_cols.size()), key_cols.data(), key_types.data(), descending.data(), n,
+                                   static_cast<std::int32_t *>(tids.ptr), ws.ptr, ws_bytes, CurrentStream()),
+              "qsx_sort_permutation");
+  for (std::size_t a = 0; a < relation.size(); ++a) {
+    CheckStatus(qsx_gather(relation.getAttributeType(static_cast<attribute_id>(a)).width, stripes[a],
+                           static_cast<const std::int32_t *>(tids.ptr), out_rows, out->stripe(static_cast<attribute_id>(a)),
+                           CurrentStream()), "qsx_gather");
+  }
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+  dest->returnBlock(out_id, out_rows);
+}
+
+class SortWorkOrder : public WorkOrder {
+ public:
+  SortWorkOrder(std::size_t query_id, std::vector<block_id> blocks, const CatalogRelation &relation,
+                const QueryContext::SortConfiguration &config, std::size_t limit, InsertDestination *dest,
+                StorageManager *storage_manager)
+      : WorkOrder(query_id), blocks_(std::move(blocks)), relation_(relation), config_(config), limit_(limit), dest_(dest),
+        storage_manager_(storage_manager) {}
+  void execute() override {   // SortRunGenerationOperator.cpp:88-105 / SortMergeRunOperator.cpp:150-200
+    std::vector<BlockReference> refs;
+    for (block_id b : blocks_) refs.push_back(storage_manager_->getBlock(b));
+    SortBlocksInto(refs, relation_, config_, limit_, dest_);
+  }
+ private:
+  std::vector<block_id> blocks_;
+  const CatalogRelation &relation_;
+  const QueryContext::SortConfiguration &config_;
+  const std::size_t limit_;
+  InsertDestination *dest_;
+  StorageManager *storage_manager_;
+};
+}  // namespace
+
+bool SortRunGenerationOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                                 StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
+  const QueryContext::SortConfiguration &config = query_context->getSortConfig(sort_config_index_);
+  InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
+  std::lock_guard<std::mutex> lock(mutex_);
+  while (num_workorders_generated_ < input_relation_block_ids_.size()) {   // one sorted run per input block
+    container->addNormalWorkOrder(new SortWorkOrder(query_id_, {input_relation_block_ids_[num_workorders_generated_]}, input_relation_,
+                                                    config, 0, dest, storage_manager), op_index_);
+    ++num_workorders_generated_;
+  }
+  return input_relation_is_stored_ || done_feeding_input_relation_;
+}
+
+bool SortMergeRunOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                            StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  if (!input_relation_is_stored_ && !done_feeding_input_relation_) return false;   // every run must have arrived
+  if (!work_generated_) {
+    work_generated_ = true;
+    container->addNormalWorkOrder(new SortWorkOrder(query_id_, input_relation_block_ids_, input_relation_,
+                                                    query_context->getSortConfig(sort_config_index_), top_k_,
+                                                    query_context->getInsertDestination(output_destination_index_), storage_manager),
+                                  op_index_);
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
 // QueryPlan / Foreman / Worker
 // ---------------------------------------------------------------------------
 std::size_t QueryPlan::addRelationalOperator(RelationalOperator *op) {

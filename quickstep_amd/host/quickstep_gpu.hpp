@@ -358,6 +358,18 @@ class QueryContext {
   // (the condition of query_optimizer/rules/InjectJoinFilters.cpp:130-150) -> the directly addressed table
   // flavour (qsx_join_table_create_dense); nullptr -> the hashed table.
   struct ExactKeyRange { std::int64_t min_value, max_value; };
+  // utility/SortConfiguration.hpp:51-130: ORDER BY attributes, ordering[i] true = ascending (no NULL inputs here, so
+  // the null_ordering vector of the reference has nothing to order)
+  struct SortConfiguration {
+    std::vector<attribute_id> order_by;
+    std::vector<bool> ordering;
+  };
+  typedef std::uint32_t sort_config_id;
+  sort_config_id addSortConfig(SortConfiguration config) {
+    sort_configs_.push_back(std::move(config));
+    return static_cast<sort_config_id>(sort_configs_.size() - 1);
+  }
+  const SortConfiguration &getSortConfig(sort_config_id id) const { return sort_configs_.at(id); }
   join_hash_table_id addJoinHashTable(TypeID key_type, std::int64_t estimated_entries, std::size_t num_partitions = 1,
                                       const ExactKeyRange *exact_key_range = nullptr);
   aggregation_state_id addAggregationState(const AggregationStateSpec &spec, std::size_t num_partitions = 1);
@@ -386,6 +398,7 @@ class QueryContext {
  private:
   std::vector<Predicate> predicates_;
   std::vector<std::vector<attribute_id>> scalar_groups_;
+  std::vector<SortConfiguration> sort_configs_;
   std::vector<qsx_lip_filter_t *> lip_filters_;
   std::vector<LIPFilterDeployment> lip_deployments_;
   std::vector<std::vector<qsx_join_table_t *>> join_tables_;
@@ -455,7 +468,7 @@ class WorkOrdersContainer {
 class RelationalOperator {
  public:
   enum OperatorType { kAggregation = 0, kBuildHash, kDestroyAggregationState, kDestroyHash, kFinalizeAggregation,
-                      kInnerJoin, kSelect, kMockOperator };
+                      kInnerJoin, kSelect, kSortMergeRun, kSortRunGeneration, kMockOperator };
   virtual ~RelationalOperator() {}
   virtual OperatorType getOperatorType() const = 0;
   virtual std::string getName() const = 0;
@@ -758,6 +771,81 @@ class DestroyAggregationStateOperator : public RelationalOperator {
 
  private:
   const QueryContext::aggregation_state_id aggr_state_index_;
+  bool work_generated_ = false;
+};
+
+// ---------------------------------------------------------------------------
+// ORDER BY: SortRunGenerationOperator (SortRunGenerationOperator.hpp:86-108) sorts every input block into a run,
+// SortMergeRunOperator (SortMergeRunOperator.hpp:99-133) merges the runs into the output relation, optionally only
+// the first top_k tuples.  On the device a merge of sorted runs is the same radix sort over their concatenation
+// (qsx_sort_permutation), so the merge operator issues ONE work order once all runs have arrived; merge_factor and
+// the intermediate run relation of the reference's multi-pass merge tree are accepted and unused.
+// ---------------------------------------------------------------------------
+class SortRunGenerationOperator : public RelationalOperator {
+ public:
+  SortRunGenerationOperator(std::size_t query_id, const CatalogRelation &input_relation, const CatalogRelation &output_relation,
+                            QueryContext::insert_destination_id output_destination_index,
+                            QueryContext::sort_config_id sort_config_index, bool input_relation_is_stored)
+      : RelationalOperator(query_id), input_relation_(input_relation), output_relation_(output_relation),
+        output_destination_index_(output_destination_index), sort_config_index_(sort_config_index),
+        input_relation_is_stored_(input_relation_is_stored) {
+    if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
+  }
+  OperatorType getOperatorType() const override { return kSortRunGeneration; }
+  std::string getName() const override { return "SortRunGenerationOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    input_relation_block_ids_.push_back(input_block_id);
+  }
+  QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
+  relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+
+ private:
+  const CatalogRelation &input_relation_;
+  const CatalogRelation &output_relation_;
+  const QueryContext::insert_destination_id output_destination_index_;
+  const QueryContext::sort_config_id sort_config_index_;
+  const bool input_relation_is_stored_;
+  std::mutex mutex_;
+  std::vector<block_id> input_relation_block_ids_;
+  std::size_t num_workorders_generated_ = 0;
+};
+
+class SortMergeRunOperator : public RelationalOperator {
+ public:
+  SortMergeRunOperator(std::size_t query_id, const CatalogRelation &input_relation, const CatalogRelation &output_relation,
+                       QueryContext::insert_destination_id output_destination_index, const CatalogRelation &run_relation,
+                       QueryContext::insert_destination_id run_block_destination_index,
+                       QueryContext::sort_config_id sort_config_index, std::size_t merge_factor, std::size_t top_k,
+                       bool input_relation_is_stored)
+      : RelationalOperator(query_id), input_relation_(input_relation), output_relation_(output_relation),
+        output_destination_index_(output_destination_index), sort_config_index_(sort_config_index), top_k_(top_k),
+        input_relation_is_stored_(input_relation_is_stored) {
+    (void)run_relation; (void)run_block_destination_index; (void)merge_factor;
+    if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
+  }
+  OperatorType getOperatorType() const override { return kSortMergeRun; }
+  std::string getName() const override { return "SortMergeRunOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    input_relation_block_ids_.push_back(input_block_id);
+  }
+  QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
+  relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+
+ private:
+  const CatalogRelation &input_relation_;
+  const CatalogRelation &output_relation_;
+  const QueryContext::insert_destination_id output_destination_index_;
+  const QueryContext::sort_config_id sort_config_index_;
+  const std::size_t top_k_;    // 0 = all tuples
+  const bool input_relation_is_stored_;
+  std::mutex mutex_;
+  std::vector<block_id> input_relation_block_ids_;
   bool work_generated_ = false;
 };
 

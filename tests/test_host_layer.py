@@ -13,7 +13,8 @@ BIN = os.path.join(ROOT, "tests", "cpp", "bin")
 def _ensure_built():
     if not all(os.path.exists(os.path.join(BIN, b)) for b in
                ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
-                "lip_filter_operator_test", "compressed_block_operator_test", "host_logic_test")):
+                "lip_filter_operator_test", "compressed_block_operator_test", "host_logic_test",
+                "sort_operator_test")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -67,3 +68,10 @@ def test_compressed_column_store_blocks_through_the_operators():
     """CompressedBlockBuilder's choice per attribute, predicates rewritten to code comparisons and scanned on the code
     stripes, values decoded on demand for projections and aggregates: same results as over plain blocks."""
     _run("compressed_block_operator_test")
+
+
+@pytest.mark.gpu
+def test_sort_run_generation_and_merge_operators():
+    """SortRunGenerationOperator / SortMergeRunOperator mirrors (1 and 3 ORDER BY columns, ASC/DESC/mixed, top-k),
+    synchronous driver and Foreman/Worker with runs streaming into the merge."""
+    _run("sort_operator_test")
