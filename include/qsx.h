@@ -532,6 +532,16 @@ int qsx_sort_permutation(int nkeys, const void *const *key_cols, const int32_t *
                          const int32_t *descending, int64_t n, int32_t *out_tids_dev,
                          void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
 
+/* ORDER BY ... LIMIT k: the first min(k, n) entries of qsx_sort_permutation's output, written to
+ * out_tids_dev (k entries), same tie order.  Replaces the top_k path of SortMergeRunOperator
+ * (relational_operators/SortMergeRunOperator.hpp:92-118 `top_k`, SortMergeRunOperatorHelpers.cpp: the
+ * merge stops after top_k tuples).  For k << n a histogram of the leading bits of key 0 selects the
+ * candidate rows and only those are sorted.  Workspace = qsx_sort_workspace_bytes(n).  Synchronises the
+ * stream once (candidate count). */
+int qsx_sort_top_k(int nkeys, const void *const *key_cols, const int32_t *key_types,
+                   const int32_t *descending, int64_t n, int64_t k, int32_t *out_tids_dev,
+                   void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

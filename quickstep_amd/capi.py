@@ -71,6 +71,7 @@ _SIGNATURES = {
     "qsx_gather_segmented": (_int, [_int, _int, _pp, C.POINTER(_i64), _vp, _i64, _vp, _vp]),
     "qsx_sort_workspace_bytes": (_sz, [_i64]),
     "qsx_sort_permutation": (_int, [_int, _pp, C.POINTER(_i32), C.POINTER(_i32), _i64, _vp, _vp, _sz, _vp]),
+    "qsx_sort_top_k": (_int, [_int, _pp, C.POINTER(_i32), C.POINTER(_i32), _i64, _i64, _vp, _vp, _sz, _vp]),
     "qsx_join_table_create": (_int, [_int, _i64, _pp]),
     "qsx_join_table_create_dense": (_int, [_int, _i64, _i64, _i64, _i64, _pp]),
     "qsx_join_table_destroy": (_int, [_vp]),
@@ -268,6 +269,22 @@ def sort_permutation(key_cols, descending=None, stream=None):
     _check(_lib.qsx_sort_permutation(len(key_cols), ptrs, types, desc, n, _ptr(out), _ptr(ws), ws_bytes, _stream(stream)),
            "qsx_sort_permutation")
     return out[:n]
+
+
+def sort_top_k(key_cols, k, descending=None, stream=None):
+    """ORDER BY ... LIMIT k -> the first min(k, n) row numbers of sort_permutation's output."""
+    n = key_cols[0].numel()
+    k = min(int(k), n)
+    device = key_cols[0].device
+    out = torch.empty(max(k, 1), dtype=torch.int32, device=device)
+    ws_bytes = _lib.qsx_sort_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    ptrs = (C.c_void_p * len(key_cols))(*[c.data_ptr() for c in key_cols])
+    types = (C.c_int32 * len(key_cols))(*[qsx_type_of(c) for c in key_cols])
+    desc = (C.c_int32 * len(key_cols))(*[1 if (descending and descending[i]) else 0 for i in range(len(key_cols))])
+    _check(_lib.qsx_sort_top_k(len(key_cols), ptrs, types, desc, n, k, _ptr(out), _ptr(ws), ws_bytes, _stream(stream)),
+           "qsx_sort_top_k")
+    return out[:k]
 
 
 def gather(src, tids, out=None, stream=None):

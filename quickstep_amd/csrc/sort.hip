@@ -22,22 +22,79 @@ __global__ __launch_bounds__(kSBlock) void iota_kernel(int32_t *__restrict__ out
   }
 }
 
+// Order-preserving unsigned image of a value given as raw bits (T = uint32_t for INT / FLOAT, uint64 for LONG / DOUBLE).
+template <typename T>
+__device__ __forceinline__ unsigned long long ordered_image(T b, int type, int descending) {
+  constexpr T kSign = static_cast<T>(1) << (sizeof(T) * 8 - 1);
+  unsigned long long k;
+  if (type == QSX_INT || type == QSX_LONG) {
+    k = b ^ kSign;                                   // two's complement: flip the sign bit
+  } else {
+    const T z = (b & static_cast<T>(~kSign)) == 0 ? static_cast<T>(0) : b;   // -0.0 compares equal to +0.0: same image
+    k = (z & kSign) ? static_cast<T>(~z) : (z | kSign);   // IEEE sign-magnitude: negatives reversed below the positives
+  }
+  if (descending) k = sizeof(T) == 4 ? (static_cast<uint32_t>(~k)) : ~k;
+  return k;
+}
+
 // keys64[i] = ordered image of col[tids[i]]
 template <typename T>
 __global__ __launch_bounds__(kSBlock) void sort_keys_kernel(const T *__restrict__ col, const int32_t *__restrict__ tids, int64_t n,
                                                            int type, int descending, unsigned long long *__restrict__ keys64) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kSBlock) {
-    const T b = col[tids[i]];      // raw bits of the value (T = uint32_t for INT / FLOAT, uint64 for LONG / DOUBLE)
-    constexpr T kSign = static_cast<T>(1) << (sizeof(T) * 8 - 1);
-    unsigned long long k;
-    if (type == QSX_INT || type == QSX_LONG) {
-      k = b ^ kSign;                                   // two's complement: flip the sign bit
-    } else {
-      const T z = (b & static_cast<T>(~kSign)) == 0 ? static_cast<T>(0) : b;   // -0.0 compares equal to +0.0: same image
-      k = (z & kSign) ? static_cast<T>(~z) : (z | kSign);   // IEEE sign-magnitude: negatives reversed below the positives
-    }
-    if (descending) k = sizeof(T) == 4 ? (static_cast<uint32_t>(~k)) : ~k;
-    keys64[i] = k;
+    keys64[i] = ordered_image<T>(col[tids[i]], type, descending);
+  }
+}
+
+// ---- top-k: threshold selection on the most significant key -------------------------------------------------------
+// LIMIT k after ORDER BY needs the k first rows only.  A 4096-bin histogram of the leading 12 bits of the first key's
+// image locates the bin in which the k-th row falls; the rows up to that bin (k + one bin's population, in input
+// order) are the only candidates, and only they are sorted.  One pass over the key column + a pass writing a bitmap,
+// instead of 6-11 scatter passes over all rows per key.
+constexpr int kTopBins = 4096;
+
+template <typename T>
+__global__ __launch_bounds__(kSBlock) void topk_hist_kernel(const T *__restrict__ col, int64_t n, int type, int descending,
+                                                           unsigned long long *__restrict__ hist) {
+  __shared__ unsigned int s_hist[kTopBins];
+  for (int i = threadIdx.x; i < kTopBins; i += kSBlock) s_hist[i] = 0;
+  __syncthreads();
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kSBlock) {
+    const unsigned long long k = ordered_image<T>(col[i], type, descending);
+    atomicAdd(&s_hist[k >> (sizeof(T) * 8 - 12)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kTopBins; i += kSBlock) {
+    if (s_hist[i] != 0) atomicAdd(&hist[i], static_cast<unsigned long long>(s_hist[i]));
+  }
+}
+
+// control[0] = threshold bin (smallest t with count(bins <= t) >= k), control[1] = that count
+__global__ void topk_threshold_kernel(const unsigned long long *__restrict__ hist, long long k, long long *__restrict__ control) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned long long cum = 0;
+  int t = 0;
+  for (; t < kTopBins; ++t) {
+    cum += hist[t];
+    if (cum >= static_cast<unsigned long long>(k)) break;
+  }
+  control[0] = t < kTopBins ? t : kTopBins - 1;
+  control[1] = static_cast<long long>(cum);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSBlock) void topk_mark_kernel(const T *__restrict__ col, int64_t n, int type, int descending,
+                                                           const long long *__restrict__ control, uint64_t *__restrict__ bitmap) {
+  const unsigned long long threshold = static_cast<unsigned long long>(control[0]);
+  const int64_t num_words = (n + 63) >> 6;
+  const int lane = lane_id();
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * (kSBlock / kWave) + (threadIdx.x >> 6); w < num_words;
+       w += static_cast<int64_t>(gridDim.x) * (kSBlock / kWave)) {
+    const int64_t row = (w << 6) + lane;
+    bool keep = false;
+    if (row < n) keep = (ordered_image<T>(col[row], type, descending) >> (sizeof(T) * 8 - 12)) <= threshold;
+    const uint64_t word = msb_first(__ballot(keep));
+    if (lane == 0) bitmap[w] = word;
   }
 }
 
@@ -47,40 +104,46 @@ static size_t s_align(size_t v) { return (v + 255) / 256 * 256; }
 
 using namespace qsx;
 
-extern "C" {
+// Sizes of the pieces of the sort workspace for n rows.
+struct SortWorkspace {
+  size_t keys, tids, offsets, part, hist, bitmap, compact, total;
+  explicit SortWorkspace(int64_t n) {
+    if (n < 0) n = 0;
+    const size_t rows = static_cast<size_t>(n) + 16;
+    keys = s_align(rows * 8);
+    tids = s_align(rows * 4);
+    offsets = s_align(65 * 8);
+    part = s_align(partition_workspace_bytes(n, kWave));
+    hist = s_align(kTopBins * 8 + 64);
+    bitmap = s_align(((n + 63) / 64 + 2) * 8);
+    compact = s_align(qsx_compact_workspace_bytes(n) + 64);
+    total = 2 * keys + 2 * tids + offsets + part + hist + bitmap + compact + 256;
+  }
+};
 
-size_t qsx_sort_workspace_bytes(int64_t n) {
-  if (n < 0) n = 0;
-  const size_t rows = static_cast<size_t>(n) + 16;
-  return 2 * s_align(rows * 8) + s_align(rows * 4) + s_align(65 * 8) + partition_workspace_bytes(n, kWave) + 256;
-}
-
-int qsx_sort_permutation(int nkeys, const void *const *key_cols, const int32_t *key_types, const int32_t *descending, int64_t n,
-                         int32_t *out_tids_dev, void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream) {
-  QSX_REQUIRE_DEVICE();
+static int validate_sort_args(int nkeys, const void *const *key_cols, const int32_t *key_types, int64_t n, const void *out) {
   if (nkeys < 1 || nkeys > QSX_MAX_KEYS || key_cols == nullptr || key_types == nullptr || n < 0 || n > INT32_MAX ||
-      (n > 0 && out_tids_dev == nullptr)) {
+      (n > 0 && out == nullptr)) {
     return QSX_ERR_INVALID_ARGUMENT;
   }
   for (int k = 0; k < nkeys; ++k) {
     if (key_types[k] < QSX_INT || key_types[k] > QSX_DOUBLE) return QSX_ERR_UNSUPPORTED;
     if (n > 0 && key_cols[k] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   }
-  if (n == 0) return QSX_OK;
-  if (workspace_dev == nullptr || workspace_bytes < qsx_sort_workspace_bytes(n)) return QSX_ERR_CAPACITY;
-  hipStream_t s = as_stream(stream);
-  const size_t rows = static_cast<size_t>(n) + 16;
-  char *w = static_cast<char *>(workspace_dev);
+  return QSX_OK;
+}
+
+// Stable sort of the m row numbers in tids_a (in place semantically: the result lands in *result, one of the two tid
+// buffers) by the keys; tids_a must hold the rows in input order.
+static int sort_tids(int nkeys, const void *const *key_cols, const int32_t *key_types, const int32_t *descending, int64_t m,
+                     int32_t *tids_a, int32_t *tids_b, char *w, const SortWorkspace &ws, int32_t **result, hipStream_t s) {
   unsigned long long *keys_a = reinterpret_cast<unsigned long long *>(w);
-  unsigned long long *keys_b = reinterpret_cast<unsigned long long *>(w + s_align(rows * 8));
-  int32_t *tids_b = reinterpret_cast<int32_t *>(w + 2 * s_align(rows * 8));
-  int64_t *offsets = reinterpret_cast<int64_t *>(w + 2 * s_align(rows * 8) + s_align(rows * 4));
-  void *part_ws = w + 2 * s_align(rows * 8) + s_align(rows * 4) + s_align(65 * 8);
-  const size_t part_ws_bytes = partition_workspace_bytes(n, kWave);
-  int32_t *tids_a = out_tids_dev;
+  unsigned long long *keys_b = reinterpret_cast<unsigned long long *>(w + ws.keys);
+  int64_t *offsets = reinterpret_cast<int64_t *>(w + 2 * ws.keys + 2 * ws.tids);
+  void *part_ws = w + 2 * ws.keys + 2 * ws.tids + ws.offsets;
+  const size_t part_ws_bytes = ws.part;
+  const int64_t n = m;
   const int grid = grid_for(n, kSBlock * 4);
-  hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(kSBlock), 0, s, tids_a, n);
-  QSX_CHECK_LAUNCH();
   for (int k = nkeys - 1; k >= 0; --k) {
     const int type = key_types[k];
     const int desc = descending != nullptr && descending[k] != 0 ? 1 : 0;
@@ -103,9 +166,91 @@ int qsx_sort_permutation(int nkeys, const void *const *key_cols, const int32_t *
       int32_t *tt = tids_a; tids_a = tids_b; tids_b = tt;
     }
   }
-  if (tids_a != out_tids_dev) {
-    QSX_HIP_TRY(hipMemcpyAsync(out_tids_dev, tids_a, static_cast<size_t>(n) * 4, hipMemcpyDeviceToDevice, s));
+  *result = tids_a;
+  return QSX_OK;
+}
+
+extern "C" {
+
+size_t qsx_sort_workspace_bytes(int64_t n) { return SortWorkspace(n).total; }
+
+int qsx_sort_permutation(int nkeys, const void *const *key_cols, const int32_t *key_types, const int32_t *descending, int64_t n,
+                         int32_t *out_tids_dev, void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  int rc = validate_sort_args(nkeys, key_cols, key_types, n, out_tids_dev);
+  if (rc != QSX_OK) return rc;
+  if (n == 0) return QSX_OK;
+  const SortWorkspace ws(n);
+  if (workspace_dev == nullptr || workspace_bytes < ws.total) return QSX_ERR_CAPACITY;
+  hipStream_t s = as_stream(stream);
+  char *w = static_cast<char *>(workspace_dev);
+  int32_t *tids_b = reinterpret_cast<int32_t *>(w + 2 * ws.keys);
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, kSBlock * 4)), dim3(kSBlock), 0, s, out_tids_dev, n);
+  QSX_CHECK_LAUNCH();
+  int32_t *result = nullptr;
+  rc = sort_tids(nkeys, key_cols, key_types, descending, n, out_tids_dev, tids_b, w, ws, &result, s);
+  if (rc != QSX_OK) return rc;
+  if (result != out_tids_dev) QSX_HIP_TRY(hipMemcpyAsync(out_tids_dev, result, static_cast<size_t>(n) * 4, hipMemcpyDeviceToDevice, s));
+  return QSX_OK;
+}
+
+int qsx_sort_top_k(int nkeys, const void *const *key_cols, const int32_t *key_types, const int32_t *descending, int64_t n,
+                   int64_t k, int32_t *out_tids_dev, void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  int rc = validate_sort_args(nkeys, key_cols, key_types, n, out_tids_dev);
+  if (rc != QSX_OK) return rc;
+  if (k < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (k > n) k = n;
+  if (n == 0 || k == 0) return QSX_OK;
+  const SortWorkspace ws(n);
+  if (workspace_dev == nullptr || workspace_bytes < ws.total) return QSX_ERR_CAPACITY;
+  hipStream_t s = as_stream(stream);
+  char *w = static_cast<char *>(workspace_dev);
+  int32_t *tids_a = reinterpret_cast<int32_t *>(w + 2 * ws.keys + ws.tids);   // second tid buffer: candidates / iota
+  int32_t *tids_b = reinterpret_cast<int32_t *>(w + 2 * ws.keys);
+  char *extra = w + 2 * ws.keys + 2 * ws.tids + ws.offsets + ws.part;
+  unsigned long long *hist = reinterpret_cast<unsigned long long *>(extra);
+  long long *control = reinterpret_cast<long long *>(extra + kTopBins * 8);   // inside the hist piece (64 spare bytes)
+  uint64_t *bitmap = reinterpret_cast<uint64_t *>(extra + ws.hist);
+  void *compact_ws = extra + ws.hist + ws.bitmap;
+  int64_t m = n;
+  bool selected = false;
+  if (n >= 65536 && k <= n / 64) {
+    // threshold selection on key 0
+    const int type = key_types[0];
+    const int desc = descending != nullptr && descending[0] != 0 ? 1 : 0;
+    const int grid = grid_for(n, kSBlock * 8);
+    QSX_HIP_TRY(hipMemsetAsync(hist, 0, kTopBins * 8 + 64, s));
+    if (type == QSX_INT || type == QSX_FLOAT) {
+      hipLaunchKernelGGL(topk_hist_kernel<uint32_t>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const uint32_t *>(key_cols[0]), n, type, desc, hist);
+      hipLaunchKernelGGL(topk_threshold_kernel, dim3(1), dim3(64), 0, s, hist, static_cast<long long>(k), control);
+      hipLaunchKernelGGL(topk_mark_kernel<uint32_t>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const uint32_t *>(key_cols[0]), n, type, desc, control, bitmap);
+    } else {
+      hipLaunchKernelGGL(topk_hist_kernel<unsigned long long>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const unsigned long long *>(key_cols[0]), n, type, desc, hist);
+      hipLaunchKernelGGL(topk_threshold_kernel, dim3(1), dim3(64), 0, s, hist, static_cast<long long>(k), control);
+      hipLaunchKernelGGL(topk_mark_kernel<unsigned long long>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const unsigned long long *>(key_cols[0]), n, type, desc, control, bitmap);
+    }
+    QSX_CHECK_LAUNCH();
+    long long host_control[2] = {0, 0};
+    QSX_HIP_TRY(hipMemcpyAsync(host_control, control, sizeof(host_control), hipMemcpyDeviceToHost, s));
+    QSX_HIP_TRY(hipStreamSynchronize(s));
+    if (host_control[1] >= k && host_control[1] <= n / 2) {
+      // candidates in input order (ties of the final sort keep the input order, like a stable sort of everything)
+      int64_t *count_dev = reinterpret_cast<int64_t *>(control + 2);
+      rc = qsx_bitmap_to_tids(bitmap, n, 0, tids_a, count_dev, compact_ws, ws.compact, stream);
+      if (rc != QSX_OK) return rc;
+      m = host_control[1];
+      selected = true;
+    }
   }
+  if (!selected) {
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, kSBlock * 4)), dim3(kSBlock), 0, s, tids_a, n);
+    QSX_CHECK_LAUNCH();
+  }
+  int32_t *result = nullptr;
+  rc = sort_tids(nkeys, key_cols, key_types, descending, m, tids_a, tids_b, w, SortWorkspace(n), &result, s);
+  if (rc != QSX_OK) return rc;
+  QSX_HIP_TRY(hipMemcpyAsync(out_tids_dev, result, static_cast<size_t>(k) * 4, hipMemcpyDeviceToDevice, s));
   return QSX_OK;
 }
 

@@ -1373,9 +1373,15 @@ void SortBlocksInto(const std::vector<BlockReference> &blocks, const CatalogRela
   }
   const std::size_t ws_bytes = qsx_sort_workspace_bytes(n);
   DeviceBuffer ws(ws_bytes), tids(static_cast<std::size_t>(n) * 4 + 16);
-  CheckStatus(qsx_sort_permutation(static_cast<int>(key_cols.size()), key_cols.data(), key_types.data(), descending.data(), n,
-                                   static_cast<std::int32_t *>(tids.ptr), ws.ptr, ws_bytes, CurrentStream()),
-              "qsx_sort_permutation");
+  if (out_rows < n) {   // top_k: only the leading rows are wanted
+    CheckStatus(qsx_sort_top_k(static_cast<int>(key_cols.size()), key_cols.data(), key_types.data(), descending.data(), n, out_rows,
+                               static_cast<std::int32_t *>(tids.ptr), ws.ptr, ws_bytes, CurrentStream()),
+                "qsx_sort_top_k");
+  } else {
+    CheckStatus(qsx_sort_permutation(static_cast<int>(key_cols.size()), key_cols.data(), key_types.data(), descending.data(), n,
+                                     static_cast<std::int32_t *>(tids.ptr), ws.ptr, ws_bytes, CurrentStream()),
+                "qsx_sort_permutation");
+  }
   for (std::size_t a = 0; a < relation.size(); ++a) {
     CheckStatus(qsx_gather(relation.getAttributeType(static_cast<attribute_id>(a)).width, stripes[a],
                            static_cast<const std::int32_t *>(tids.ptr), out_rows, out->stripe(static_cast<attribute_id>(a)),

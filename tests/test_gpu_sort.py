@@ -54,3 +54,22 @@ def test_q3_order_by_revenue_desc_orderdate_limit_10(capi, oracle, dev):
     want = oracle.sort_permutation([revenue, orderdate], [True, False])[:10]
     assert np.array_equal(got_key, orderkey[want]) and np.array_equal(got_rev, revenue[want])
     assert (np.diff(got_rev) <= 0).all()
+
+
+@pytest.mark.parametrize("n,k", [(10, 3), (10, 50), (70_000, 10), (70_000, 1), (1_500_000, 10), (1_500_000, 20_000), (300_000, 0)])
+def test_top_k_is_the_head_of_the_full_sort(capi, oracle, dev, n, k):
+    """qsx_sort_top_k = first k rows of the stable sort (SortMergeRunOperator's top_k), for every key type, including
+    skewed keys where one histogram bin holds most rows (fallback to the full sort) and heavy ties at the threshold."""
+    rng = np.random.default_rng(n + k)
+    cols = {
+        "uniform double": np.round(rng.uniform(1000, 500000, size=n), 4),
+        "skewed int": np.where(rng.random(n) < 0.9, 7, rng.integers(-1000, 1000, size=n)).astype(np.int32),
+        "ties int64": rng.integers(0, 5, size=n).astype(np.int64) * (1 << 40),
+        "float32 signed": (rng.normal(size=n) * 1e3).astype(np.float32),
+    }
+    second = rng.integers(0, 100, size=n).astype(np.int32)
+    for name, col in cols.items():
+        for desc in (False, True):
+            got = capi.sort_top_k([to_dev(col, dev), to_dev(second, dev)], k, [desc, False]).cpu().numpy()
+            want = oracle.sort_permutation([col, second], [desc, False])[:k]
+            assert np.array_equal(got, want), (name, desc)
