@@ -433,6 +433,16 @@ int qsx_agg_state_clear(qsx_agg_state_t *state, qsx_stream_t stream);
 int qsx_agg_update(qsx_agg_state_t *state, const void *const *cols, int64_t n,
                    const uint64_t *filter_dev, qsx_stream_t stream);
 
+/* BuildAggregationExistenceMapWorkOrder::execute (relational_operators/
+ * BuildAggregationExistenceMapOperator.cpp:50-67, 177-208): sets the existence bit of every (selected)
+ * key of a block in a COLLISION_FREE state, without touching the aggregate states — the left side of a
+ * CrossReferenceCoalesceAggregate (query_optimizer/ExecutionGenerator.cpp:2054-2210: left outer join +
+ * group-by fused; keys without right-side rows finalize as COUNT 0 / SUM 0,
+ * CollisionFreeVectorTable.hpp:700-727).  key_type QSX_INT or QSX_LONG; other strategies:
+ * QSX_ERR_UNSUPPORTED. */
+int qsx_agg_mark_existence(qsx_agg_state_t *state, int key_type, const void *keys_dev, int64_t n,
+                           const uint64_t *filter_dev, qsx_stream_t stream);
+
 /* dst += src (same config).  Counterpart of
  * ThreadPrivateCompactKeyHashTable::mergeFrom (.cpp:306-363) and
  * AggregationOperationState::mergeGroupByHashTables (.cpp:831-843). */

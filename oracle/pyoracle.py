@@ -77,6 +77,7 @@ for _name, _res, _args in [
     ("qso_agg_state_create", _vp, [C.POINTER(T.AggConfig)]),
     ("qso_agg_state_destroy", None, [_vp]),
     ("qso_agg_update", None, [_vp, _pp, _i64, _vp]),
+    ("qso_agg_mark_existence", None, [_vp, _int, _vp, _i64, _vp]),
     ("qso_agg_merge", None, [_vp, _vp]),
     ("qso_agg_num_groups", _i64, [_vp]),
     ("qso_agg_finalize", _i64, [_vp, _int, _int, _pp, _pp, _pp, _i64]),
@@ -390,6 +391,9 @@ class AggState:
         if n is None:
             n = cols[0].size
         _lib.qso_agg_update(self._h, _ptr_array(cols), n, _p(filter_bitmap))
+
+    def mark_existence(self, keys, filter_bitmap=None):
+        _lib.qso_agg_mark_existence(self._h, qtype(keys), _p(keys), len(keys), _p(filter_bitmap))
 
     def merge(self, other):
         _lib.qso_agg_merge(self._h, other._h)

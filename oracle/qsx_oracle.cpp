@@ -962,6 +962,15 @@ void qso_agg_state_destroy(qso_agg_state_t *s) { delete s; }
 void qso_agg_update(qso_agg_state_t *s, const void *const *cols, int64_t n, const uint64_t *filter) {
   s->update(cols, n, filter);
 }
+void qso_agg_mark_existence(qso_agg_state_t *s, int key_type, const void *keys, int64_t n, const uint64_t *filter) {
+  // ExecuteBuild (BuildAggregationExistenceMapOperator.cpp:50-67): setBit(value) for every tuple of the accessor
+  for (int64_t i = 0; i < n; ++i) {
+    if (!row_selected(filter, i)) continue;
+    const int64_t loc = key_type == QSX_INT ? static_cast<const int32_t *>(keys)[i] : static_cast<const int64_t *>(keys)[i];
+    if (loc < 0 || loc >= static_cast<int64_t>(s->c.num_entries)) continue;
+    s->existence[loc >> 6] |= (static_cast<uint64_t>(1) << (loc & 63));
+  }
+}
 void qso_agg_merge(qso_agg_state_t *dst, const qso_agg_state_t *src) { dst->merge_from(*src); }
 
 int64_t qso_agg_num_groups(const qso_agg_state_t *s) {

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "qsx_agg_state_destroy": (_int, [_vp]),
     "qsx_agg_state_clear": (_int, [_vp, _vp]),
     "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
+    "qsx_agg_mark_existence": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "qsx_agg_merge": (_int, [_vp, _vp, _vp]),
     "qsx_agg_state_export_bytes": (_int, [_vp, C.POINTER(_sz)]),
     "qsx_agg_state_export": (_int, [_vp, _vp, _vp]),
@@ -407,6 +408,10 @@ class AggState:
             n = cols[0].numel()
         _check(_lib.qsx_agg_update(self._h, _ptr_array(cols), n, _ptr(filter_bitmap), _stream(stream)),
                "qsx_agg_update")
+
+    def mark_existence(self, keys, filter_bitmap=None, stream=None):
+        _check(_lib.qsx_agg_mark_existence(self._h, qsx_type_of(keys), _ptr(keys), keys.numel(), _ptr(filter_bitmap),
+                                           _stream(stream)), "qsx_agg_mark_existence")
 
     def merge(self, other, stream=None):
         _check(_lib.qsx_agg_merge(self._h, other._h, _stream(stream)), "qsx_agg_merge")

@@ -135,7 +135,7 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
     }
     if (ag.fn != QSX_AGG_SUM && ag.fn != QSX_AGG_AVG && ag.fn != QSX_AGG_MIN && ag.fn != QSX_AGG_MAX) return fail(t, QSX_ERR_UNSUPPORTED);
     if (ag.arg.kind == QSX_OPD_CONST || !valid_operand(c, ag.arg, defined)) return fail(t, QSX_ERR_INVALID_ARGUMENT);
-    if (ag.fn == QSX_AGG_AVG) needs_count = true;
+    if (ag.fn == QSX_AGG_AVG || ag.fn == QSX_AGG_MIN || ag.fn == QSX_AGG_MAX) needs_count = true;   // NULL over zero rows
     const bool is_int = ag.arg.kind == QSX_OPD_COLUMN &&
                         (c.column_type[ag.arg.index] == QSX_INT || c.column_type[ag.arg.index] == QSX_LONG);
     f.is_int[a] = is_int ? 1 : 0;

@@ -123,8 +123,9 @@ __device__ __forceinline__ void write_values(const FinalizeDesc &f, const unsign
         static_cast<unsigned long long *>(f.out_vals[a])[out_row] = raw;
         is_null = empty_group;
       } else if (f.fn[a] == QSX_AGG_MIN || f.fn[a] == QSX_AGG_MAX) {
-        // typed like the argument; the accumulator is the int value or the order-mapped double
-        is_null = empty_group;
+        // typed like the argument; the accumulator is the int value or the order-mapped double.  A dense-table key
+        // that only has its existence bit (BuildAggregationExistenceMapOperator) saw no value: NULL.
+        is_null = empty_group || (count_col >= 0 && cnt == 0);
         const long long word = static_cast<long long>(raw);
         switch (f.val_type[a]) {
           case QSX_INT: static_cast<int32_t *>(f.out_vals[a])[out_row] = is_null ? 0 : static_cast<int32_t>(word); break;
@@ -318,6 +319,23 @@ __global__ __launch_bounds__(kABlock) void finalize_dense_kernel(DenseView d, Fi
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// BuildAggregationExistenceMapWorkOrder::execute (relational_operators/BuildAggregationExistenceMapOperator.cpp:50-67):
+// existence_map->setBit(key) for every (selected) row.  Most keys of a block hit distinct words, so the bit is tested
+// before the atomic; keys outside [0, num_entries) are skipped (the reference would write out of bounds).
+template <typename KeyT>
+__global__ __launch_bounds__(kABlock) void mark_existence_kernel(const KeyT *__restrict__ keys, int64_t n,
+                                                                const uint64_t *__restrict__ filter,
+                                                                unsigned long long *__restrict__ exist, long long num_entries) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kABlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kABlock) {
+    if (filter != nullptr && !msb_bit(filter[i >> 6], static_cast<int>(i & 63))) continue;
+    const long long loc = static_cast<long long>(keys[i]);
+    if (loc < 0 || loc >= num_entries) continue;
+    const unsigned long long bit = 1ull << (loc & 63);
+    unsigned long long *word = &exist[loc >> 6];
+    if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0) atomicOr(word, bit);
   }
 }
 
@@ -982,6 +1000,25 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
     return update_partitioned(st, cols, n, s);
   }
   return update_slice(st, cols, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s);
+}
+
+int qsx_agg_mark_existence(qsx_agg_state_t *st, int key_type, const void *keys_dev, int64_t n, const uint64_t *filter_dev,
+                           qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (st == nullptr || n < 0 || (n > 0 && keys_dev == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+  if (!st->dense || (key_type != QSX_INT && key_type != QSX_LONG)) return QSX_ERR_UNSUPPORTED;
+  if (n == 0) return QSX_OK;
+  hipStream_t s = as_stream(stream);
+  const int grid = grid_for(n, kABlock * 4);
+  if (key_type == QSX_INT) {
+    hipLaunchKernelGGL(mark_existence_kernel<int32_t>, dim3(grid), dim3(kABlock), 0, s, static_cast<const int32_t *>(keys_dev), n,
+                       filter_dev, st->image, static_cast<long long>(st->config.num_entries));
+  } else {
+    hipLaunchKernelGGL(mark_existence_kernel<long long>, dim3(grid), dim3(kABlock), 0, s, static_cast<const long long *>(keys_dev), n,
+                       filter_dev, st->image, static_cast<long long>(st->config.num_entries));
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
 }
 
 int qsx_agg_state_export_bytes(const qsx_agg_state_t *st, size_t *out_bytes) {

@@ -539,6 +539,15 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
 }
 
+void AggregationOperationState::buildExistenceMap(const StorageBlock &block, attribute_id build_attribute, const Type &type) {
+  if (type.id != kInt && type.id != kLong) {   // LOG(FATAL) "Build attribute type not supported" (:203-206)
+    throw ExecutionError("BuildAggregationExistenceMapOperator: build attribute must be INT or LONG", QSX_ERR_UNSUPPORTED);
+  }
+  CheckStatus(qsx_agg_mark_existence(state_, type.id, block.stripe(build_attribute), block.numTuples(), nullptr, CurrentStream()),
+              "qsx_agg_mark_existence");
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+}
+
 void AggregationOperationState::finalizeAggregate(std::size_t partition, std::size_t num_partitions, InsertDestination *dest) {
   std::int64_t groups = 0;
   CheckStatus(qsx_agg_num_groups(state_, &groups, CurrentStream()), "qsx_agg_num_groups");
@@ -1234,6 +1243,24 @@ class AggregationWorkOrder : public WorkOrder {
   StorageManager *storage_manager_;
   std::unique_ptr<LIPFilterAdaptiveProber> lip_filter_adaptive_prober_;
 };
+class BuildAggregationExistenceMapWorkOrder : public WorkOrder {
+ public:
+  BuildAggregationExistenceMapWorkOrder(std::size_t query_id, const CatalogRelation &input_relation, partition_id part,
+                                        block_id build_block_id, attribute_id build_attribute, AggregationOperationState *state,
+                                        StorageManager *storage_manager)
+      : WorkOrder(query_id, part), input_relation_(input_relation), build_block_id_(build_block_id),
+        build_attribute_(build_attribute), state_(state), storage_manager_(storage_manager) {}
+  void execute() override {   // BuildAggregationExistenceMapOperator.cpp:177-208
+    BlockReference block = storage_manager_->getBlock(build_block_id_);
+    state_->buildExistenceMap(*block, build_attribute_, input_relation_.getAttributeType(build_attribute_));
+  }
+ private:
+  const CatalogRelation &input_relation_;
+  block_id build_block_id_;
+  attribute_id build_attribute_;
+  AggregationOperationState *state_;
+  StorageManager *storage_manager_;
+};
 class FinalizeAggregationWorkOrder : public WorkOrder {
  public:
   FinalizeAggregationWorkOrder(std::size_t query_id, std::size_t part, std::size_t num_parts,
@@ -1295,6 +1322,35 @@ bool AggregationOperator::getAllWorkOrders(WorkOrdersContainer *container, Query
       container->addNormalWorkOrder(new AggregationWorkOrder(query_id_, input_.ids[part][input_.generated[part]], state,
                                                              storage_manager, part,
                                                              CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context)),
+                                    op_index_);
+      ++input_.generated[part];
+    }
+  }
+  return input_relation_is_stored_ || done_feeding_input_relation_;
+}
+
+BuildAggregationExistenceMapOperator::BuildAggregationExistenceMapOperator(
+    std::size_t query_id, const CatalogRelation &input_relation, attribute_id build_attribute, bool input_relation_is_stored,
+    QueryContext::aggregation_state_id aggr_state_index, std::size_t num_partitions)
+    : RelationalOperator(query_id, num_partitions), input_relation_(input_relation), build_attribute_(build_attribute),
+      input_relation_is_stored_(input_relation_is_stored), aggr_state_index_(aggr_state_index), input_(num_partitions) {
+  if (input_relation_is_stored) {
+    for (partition_id part = 0; part < num_partitions; ++part) {
+      input_.ids[part] = num_partitions > 1 ? input_relation.getBlocksInPartition(part) : input_relation.getBlocksSnapshot();
+    }
+  }
+}
+
+bool BuildAggregationExistenceMapOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
+                                                            StorageManager *storage_manager, const tmb::client_id,
+                                                            tmb::MessageBus *) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  for (partition_id part = 0; part < num_partitions_; ++part) {   // BuildAggregationExistenceMapOperator.cpp:82-128
+    AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, part);
+    while (input_.generated[part] < input_.ids[part].size()) {
+      container->addNormalWorkOrder(new BuildAggregationExistenceMapWorkOrder(query_id_, input_relation_, part,
+                                                                              input_.ids[part][input_.generated[part]],
+                                                                              build_attribute_, state, storage_manager),
                                     op_index_);
       ++input_.generated[part];
     }

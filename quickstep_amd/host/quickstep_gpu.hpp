@@ -312,6 +312,9 @@ class AggregationOperationState {
   // :428-474; lip_filter = TupleIdSequence left by the LIPFilterAdaptiveProber (:440-460), or nullptr
   void aggregateBlock(const StorageBlock &block, const std::uint64_t *lip_filter = nullptr);
   void finalizeAggregate(std::size_t partition, std::size_t num_partitions, InsertDestination *dest);  // :641-694
+  // getCollisionFreeVectorTable()->getExistenceMap()->setBit(key) for every tuple of the block
+  // (BuildAggregationExistenceMapOperator.cpp:177-208); the state must use QSX_AGG_COLLISION_FREE
+  void buildExistenceMap(const StorageBlock &block, attribute_id build_attribute, const Type &type);
   const AggregationStateSpec &spec() const { return spec_; }
 
  private:
@@ -467,7 +470,7 @@ class WorkOrdersContainer {
 
 class RelationalOperator {
  public:
-  enum OperatorType { kAggregation = 0, kBuildHash, kDestroyAggregationState, kDestroyHash, kFinalizeAggregation,
+  enum OperatorType { kAggregation = 0, kBuildAggregationExistenceMap, kBuildHash, kDestroyAggregationState, kDestroyHash, kFinalizeAggregation,
                       kInnerJoin, kSelect, kSortMergeRun, kSortRunGeneration, kMockOperator };
   virtual ~RelationalOperator() {}
   virtual OperatorType getOperatorType() const = 0;
@@ -733,6 +736,32 @@ class AggregationOperator : public RelationalOperator {
   std::mutex mutex_;
   PartitionedBlockIds input_;
   bool started_ = false;
+};
+
+// relational_operators/BuildAggregationExistenceMapOperator.hpp:57-140: marks the keys of the left relation of a
+// CrossReferenceCoalesceAggregate in the collision-free table of the aggregation state, so that keys without
+// right-side rows still finalize (COUNT 0).  Runs after InitializeAggregation, before the AggregationOperator.
+class BuildAggregationExistenceMapOperator : public RelationalOperator {
+ public:
+  BuildAggregationExistenceMapOperator(std::size_t query_id, const CatalogRelation &input_relation, attribute_id build_attribute,
+                                       bool input_relation_is_stored, QueryContext::aggregation_state_id aggr_state_index,
+                                       std::size_t num_partitions = 1);
+  OperatorType getOperatorType() const override { return kBuildAggregationExistenceMap; }
+  std::string getName() const override { return "BuildAggregationExistenceMapOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id part_id) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    input_.ids.at(part_id).push_back(input_block_id);
+  }
+
+ private:
+  const CatalogRelation &input_relation_;
+  const attribute_id build_attribute_;
+  const bool input_relation_is_stored_;
+  const QueryContext::aggregation_state_id aggr_state_index_;
+  std::mutex mutex_;
+  PartitionedBlockIds input_;
 };
 
 class FinalizeAggregationOperator : public RelationalOperator {

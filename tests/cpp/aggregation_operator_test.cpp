@@ -229,5 +229,81 @@ int main() {
       EXPECT_TRUE(at<double>(cols[5], i) == 0.1 * gid);
     }
   }
+  // ---- CrossReferenceCoalesceAggregate (ExecutionGenerator.cpp:2054-2210): customer LEFT OUTER JOIN orders GROUP BY
+  // c_custkey fused into  InitializeAggregation -> BuildAggregationExistenceMap(customer.c_custkey) -> Aggregation(orders
+  // GROUP BY o_custkey, collision-free vector) -> Finalize.  Customers without orders come out with COUNT 0 / SUM 0
+  // (CollisionFreeVectorTable.hpp:700-727), the shape of TPC-H Q13.
+  for (const bool use_foreman : {false, true}) {
+    constexpr int kCustomers = 50, kWithOrders = 40;
+    Fixture f;   // "orders": IntType-0 = val; o_custkey := GroupBy-0 replaced below by a dedicated relation
+    CatalogRelation customer(110, "customer"), orders(111, "orders"), result(112, "result");
+    customer.addAttribute("c_custkey", Type::Int());
+    orders.addAttribute("o_custkey", Type::Int());
+    orders.addAttribute("o_totalprice", Type::Long());
+    for (int b = 0; b < kCustomers; b += kNumTuplesPerBlock) {
+      std::int32_t k[kNumTuplesPerBlock];
+      for (tuple_id t = 0; t < kNumTuplesPerBlock; ++t) k[t] = kCustomers - 1 - (b + t);   // not sorted
+      f.storage.loadBlock(&customer, {k}, kNumTuplesPerBlock);
+    }
+    std::vector<std::int64_t> want_sum(kCustomers, 0), want_count(kCustomers, 0);
+    for (tuple_id i = 0; i < kNumTuples; i += kNumTuplesPerBlock) {
+      std::int32_t k[kNumTuplesPerBlock];
+      std::int64_t v[kNumTuplesPerBlock];
+      for (tuple_id t = 0; t < kNumTuplesPerBlock; ++t) {
+        k[t] = ((i + t) * 7) % kWithOrders;
+        v[t] = i + t;
+        if (v[t] >= 20) { want_sum[k[t]] += v[t]; ++want_count[k[t]]; }
+      }
+      f.storage.loadBlock(&orders, {k, v}, kNumTuplesPerBlock);
+    }
+    result.addAttribute("c_custkey", Type::Int());
+    result.addAttribute("count", Type::Long());
+    result.addAttribute("sum", Type::Long());
+    QueryContext ctx;
+    Predicate pred;   // the right child's filter predicate is fused into the state (:2096-2100)
+    pred.conjuncts.push_back({1, ComparisonID::kGreaterOrEqual, TypedLiteral::Long(20)});
+    const auto pred_id = ctx.addPredicate(pred);
+    AggregationStateSpec spec;
+    spec.input_relation = &orders;
+    spec.group_by = {0};
+    spec.aggregates = {{AggregationID::kCount, kInvalidAttributeID}, {AggregationID::kSum, 1}};
+    spec.predicate = ctx.getPredicate(pred_id);
+    spec.strategy = QSX_AGG_COLLISION_FREE;
+    spec.collision_free_num_entries = kCustomers;
+    const auto state = ctx.addAggregationState(spec);
+    const auto dest = ctx.addInsertDestination(&result, &f.storage);
+    if (use_foreman) {
+      QueryPlan plan;
+      const auto e = plan.addRelationalOperator(new BuildAggregationExistenceMapOperator(0, customer, 0, true, state));
+      const auto a = plan.addRelationalOperator(new AggregationOperator(0, orders, true, state));
+      const auto fz = plan.addRelationalOperator(new FinalizeAggregationOperator(0, state, 1, false, 2, result, dest));
+      const auto d = plan.addRelationalOperator(new DestroyAggregationStateOperator(0, state));
+      plan.addDirectDependency(a, e, true);    // "Start aggregation after building existence map" (:2176-2179)
+      plan.addDirectDependency(fz, a, true);
+      plan.addDirectDependency(d, fz, true);
+      ForemanSingleNode foreman(&plan, &ctx, &f.storage, 4);
+      foreman.run();
+      EXPECT_EQ(foreman.getWorkOrderProfilingResults().size(), static_cast<std::size_t>(5 + 30 + 2 + 1));
+    } else {
+      BuildAggregationExistenceMapOperator exist(0, customer, 0, true, state);
+      EXPECT_TRUE(exist.getOperatorType() == RelationalOperator::kBuildAggregationExistenceMap);
+      AggregationOperator op(0, orders, true, state);
+      FinalizeAggregationOperator fin(0, state, 1, false, 1, result, dest);
+      fetchAndExecuteWorkOrders(&exist, &ctx, &f.storage);
+      fetchAndExecuteWorkOrders(&op, &ctx, &f.storage);
+      fetchAndExecuteWorkOrders(&fin, &ctx, &f.storage);
+    }
+    std::size_t rows;
+    auto cols = readAll(ctx, dest, f.storage, result, &rows);
+    EXPECT_EQ(rows, static_cast<std::size_t>(kCustomers));    // every customer, with or without orders
+    std::vector<bool> seen(kCustomers, false);
+    for (std::size_t i = 0; i < rows; ++i) {
+      const int key = at<std::int32_t>(cols[0], i);
+      EXPECT_TRUE(key >= 0 && key < kCustomers && !seen[key]);
+      seen[key] = true;
+      EXPECT_EQ(at<std::int64_t>(cols[1], i), want_count[key]);
+      EXPECT_EQ(at<std::int64_t>(cols[2], i), want_sum[key]);
+    }
+  }
   return finish("aggregation_operator_test");
 }

@@ -452,3 +452,46 @@ def test_partitioned_aggregation_for_mid_size_group_counts(capi, oracle, dev, mo
     # the same rows without partitioning (hash-range families / global table) agree as well
     monkeypatch.setenv("QSX_AGG_PARTITION_MIN_ROWS", str(1 << 60))
     assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols, blocks=3), dev), o.finalize())
+
+
+@pytest.mark.parametrize("key_dtype", [np.int32, np.int64])
+def test_existence_map_then_aggregate_q13_shape(capi, oracle, dev, key_dtype):
+    """CrossReferenceCoalesceAggregate (ExecutionGenerator.cpp:2054-2210): BuildAggregationExistenceMap over the left
+    relation's unique keys, then the right relation aggregated into the same collision-free table.  Left keys
+    without right rows finalize with COUNT 0 / SUM 0 / AVG, MIN, MAX NULL; the Q13 histogram follows."""
+    rng = np.random.default_rng(13)
+    customers, n_orders = 150_000, 1_500_000
+    c_custkey = rng.permutation(customers).astype(key_dtype)
+    o_custkey = rng.integers(0, customers * 2 // 3, size=n_orders).astype(key_dtype)     # a third has no orders
+    o_total = rng.integers(1, 500_000, size=n_orders).astype(np.int64)
+    o_price = np.round(rng.uniform(1, 1000, size=n_orders), 2)
+    kt = T.INT if key_dtype == np.int32 else T.LONG
+    cfg = T.make_agg_config(T.AGG_COLLISION_FREE, [(kt, None), (T.LONG, None), (T.DOUBLE, None)], keys=[0],
+                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1)), (T.AGG_AVG, T.col(2)), (T.AGG_MIN, T.col(1)),
+                                  (T.AGG_MAX, T.col(2))],
+                            pred=[(1, T.GE, 1000)], num_entries=customers)
+    keep = rng.random(customers) < 0.9                        # existence map built under a filter, in 3 blocks
+    filt = oracle.bitmap_from_bools(keep)
+    st = capi.AggState(cfg)
+    o = oracle.AggState(cfg)
+    st.mark_existence(to_dev(c_custkey, dev), to_dev(filt, dev))
+    o.mark_existence(c_custkey, filt)
+    assert st.num_groups() == o.num_groups() == int(keep.sum())
+    for lo in range(0, n_orders, n_orders // 3):
+        hi = min(lo + n_orders // 3, n_orders)
+        st.update([to_dev(c[lo:hi], dev) for c in (o_custkey, o_total, o_price)], hi - lo)
+    o.update([o_custkey, o_total, o_price])
+    got, ref = finalize_np(st, dev), o.finalize()
+    assert np.array_equal(got[0][0], ref[0][0])                                   # ascending keys, same set
+    assert_same_groups(got, ref)
+    counts = got[1][0]
+    assert (counts == 0).sum() > 0 and got[2][3][counts == 0].all() and not got[2][3][counts > 0].any()
+    # Q13's outer query: customers per order count
+    assert np.array_equal(np.bincount(counts), np.bincount(ref[1][0]))
+
+
+def test_existence_map_rejects_hash_strategies(capi, dev):
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.INT, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None)], est_groups=8)
+    with pytest.raises(capi.QsxError) as e:
+        capi.AggState(cfg).mark_existence(torch.zeros(4, dtype=torch.int32, device=dev))
+    assert e.value.status == T.ERR_UNSUPPORTED

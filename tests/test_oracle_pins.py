@@ -324,6 +324,29 @@ def test_collision_free_matches_generic(oracle):
     assert np.array_equal(np.sort(pk), np.unique(key))
 
 
+def test_existence_map_equals_left_outer_join_then_group_by(oracle):
+    """CrossReferenceCoalesceAggregate is the fusion of `left LEFT OUTER JOIN right GROUP BY left.key` with aggregates
+    over the right side (rules/FuseAggregateJoin.cpp:60-160): existence bits from the left keys, states from the right
+    rows.  Checked against the unfused plan written with numpy: every left key appears, COUNT = number of matching
+    right rows passing the fused filter, SUM over no rows = 0 (CollisionFreeVectorTable.hpp:700-727)."""
+    rng = np.random.default_rng(8)
+    left = rng.permutation(500).astype(np.int32)[:400]                  # unique left keys
+    right_key = rng.choice(left[:300], size=5000).astype(np.int32)      # FK into the left relation; 100 keys unmatched
+    right_val = rng.integers(-50, 50, size=5000).astype(np.int64)
+    cfg = T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None), (T.LONG, None)], keys=[0],
+                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1))], pred=[(1, T.GT, -10)], num_entries=500)
+    st = oracle.AggState(cfg)
+    st.mark_existence(left)
+    st.update([right_key, right_val])
+    keys, vals, _ = st.finalize()
+    assert np.array_equal(keys[0], np.sort(left))
+    sel = right_val > -10
+    want_count = np.bincount(right_key[sel], minlength=500)[keys[0]]
+    want_sum = np.bincount(right_key[sel], weights=right_val[sel], minlength=500)[keys[0]].astype(np.int64)
+    assert np.array_equal(vals[0], want_count) and np.array_equal(vals[1], want_sum)
+    assert (vals[0] == 0).sum() >= 100
+
+
 def test_join_unittest_composite_key_and_residual(oracle, golden):
     """CompositeKeyHashJoinTest / ...WithResidualPredicateTest (HashJoinOperator_unittest.cpp:999-1375)
     on the composite-key restatement: 100 results (even tids), 8 with the residual dim.long < 15."""
