@@ -552,6 +552,21 @@ int qsx_sort_top_k(int nkeys, const void *const *key_cols, const int32_t *key_ty
                    const int32_t *descending, int64_t n, int64_t k, int32_t *out_tids_dev,
                    void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
 
+/* Distinctify: out_tids = row number of the first occurrence of every distinct tuple over ncols columns
+ * (QSX_INT / LONG / FLOAT / DOUBLE, or 1-byte QSX_CHAR; at most QSX_MAX_KEYS), restricted to the rows of
+ * filter_dev when non-NULL, listed in tuple order; *out_count_dev = number of distinct tuples.
+ * Replaces the distinctify hash table of a DISTINCT aggregate — AggregationOperationState.cpp:172-207
+ * (one table per DISTINCT aggregate, key = group-by values + argument), filled per block by
+ * AggregationConcreteHandle::insertValueAccessorIntoDistinctifyHashTable (AggregationConcreteHandle.hpp:
+ * 120-140, called at AggregationOperationState.cpp:522-528, 600-628) and drained at finalize by
+ * aggregateOnDistinctifyHashTableFor{Single,GroupBy} (:652-670, :720-760) — by sort + run heads: the caller
+ * gathers the tuples (qsx_gather) and feeds them to qsx_agg_update of the state that computes the
+ * aggregate over distinct values.  Sort keys of type QSX_CHAR (1 byte) are also accepted by
+ * qsx_sort_permutation / qsx_sort_top_k.  Workspace = qsx_sort_workspace_bytes(n).  Synchronises the stream. */
+int qsx_distinct_rows(int ncols, const void *const *cols, const int32_t *types, int64_t n,
+                      const uint64_t *filter_dev, int32_t *out_tids_dev, int64_t *out_count_dev,
+                      void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

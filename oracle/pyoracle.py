@@ -74,6 +74,7 @@ for _name, _res, _args in [
     ("qso_select_codes", None, [_int, _vp, _i64, _int, C.c_uint32, C.c_uint32, _vp, _vp]),
     ("qso_decode_codes", None, [_int, _vp, _i64, _vp, _int, _vp]),
     ("qso_sort_permutation", None, [_int, _pp, C.POINTER(_i32), C.POINTER(_i32), _i64, _vp]),
+    ("qso_distinct_rows", _i64, [_int, _pp, C.POINTER(_i32), _i64, _vp, _vp]),
     ("qso_agg_state_create", _vp, [C.POINTER(T.AggConfig)]),
     ("qso_agg_state_destroy", None, [_vp]),
     ("qso_agg_update", None, [_vp, _pp, _i64, _vp]),
@@ -98,7 +99,7 @@ for _name, _res, _args in [
 assert _lib.qso_sizeof_agg_config() == C.sizeof(T.AggConfig)
 
 _NP_TYPE = {np.dtype(np.int32): T.INT, np.dtype(np.int64): T.LONG, np.dtype(np.float32): T.FLOAT,
-            np.dtype(np.float64): T.DOUBLE}
+            np.dtype(np.float64): T.DOUBLE, np.dtype(np.uint8): T.CHAR}   # CHAR(1)
 _C_SCALAR = {T.INT: C.c_int32, T.LONG: C.c_int64, T.FLOAT: C.c_float, T.DOUBLE: C.c_double}
 
 
@@ -368,6 +369,17 @@ def sort_permutation(key_cols, descending=None):
     out = np.zeros(max(n, 1), dtype=np.int32)
     _lib.qso_sort_permutation(len(keep), ptrs, types, desc, n, _p(out))
     return out[:n]
+
+
+def distinct_rows(cols, filter_bitmap=None):
+    """Row numbers of the first occurrence of every distinct tuple, in tuple order (the distinctify table)."""
+    keep = [np.ascontiguousarray(c) for c in cols]
+    n = keep[0].size
+    ptrs = (C.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
+    types = (C.c_int32 * len(keep))(*[_NP_TYPE[c.dtype] for c in keep])
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    count = _lib.qso_distinct_rows(len(keep), ptrs, types, n, _p(filter_bitmap), _p(out))
+    return out[:count]
 
 
 # ---- aggregation --------------------------------------------------------------------

@@ -19,6 +19,7 @@
 #include <thread>
 #include <unordered_map>
 #include <utility>
+#include <set>
 #include <vector>
 
 namespace {
@@ -1526,6 +1527,7 @@ void qso_sort_permutation(int nkeys, const void *const *key_cols, const int32_t 
         case QSX_INT: { const auto *c = static_cast<const std::int32_t *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
         case QSX_LONG: { const auto *c = static_cast<const std::int64_t *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
         case QSX_FLOAT: { const auto *c = static_cast<const float *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        case QSX_CHAR: { const auto *c = static_cast<const std::uint8_t *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
         default: { const auto *c = static_cast<const double *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
       }
       if (descending != nullptr && descending[k]) cmp = -cmp;
@@ -1535,6 +1537,37 @@ void qso_sort_permutation(int nkeys, const void *const *key_cols, const int32_t 
   };
   std::stable_sort(order.begin(), order.end(), less);
   std::memcpy(out_tids, order.data(), sizeof(int32_t) * static_cast<size_t>(n));
+}
+
+// The distinctify hash table of a DISTINCT aggregate (AggregationOperationState.cpp:172-207; insert
+// AggregationConcreteHandle::insertValueAccessorIntoDistinctifyHashTable, AggregationConcreteHandle.hpp:120-140) keeps
+// one entry per distinct (group-by..., argument) tuple.  Restated as a set of tuples: the result is the row number of
+// the first occurrence of every distinct tuple, listed in tuple order (the table's own iteration order is unspecified).
+int64_t qso_distinct_rows(int ncols, const void *const *cols, const int32_t *types, int64_t n, const uint64_t *filter,
+                          int32_t *out_tids) {
+  auto cmp_rows = [&](int32_t a, int32_t b) {
+    for (int k = 0; k < ncols; ++k) {
+      int cmp = 0;
+      switch (types[k]) {
+        case QSX_INT: { const auto *c = static_cast<const std::int32_t *>(cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        case QSX_LONG: { const auto *c = static_cast<const std::int64_t *>(cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        case QSX_FLOAT: { const auto *c = static_cast<const float *>(cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        case QSX_CHAR: { const auto *c = static_cast<const std::uint8_t *>(cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        default: { const auto *c = static_cast<const double *>(cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+      }
+      if (cmp != 0) return cmp;
+    }
+    return 0;
+  };
+  auto less = [&](int32_t a, int32_t b) { return cmp_rows(a, b) < 0; };
+  std::set<int32_t, decltype(less)> seen(less);       // keyed by tuple value; holds the first row seen with it
+  for (int64_t i = 0; i < n; ++i) {
+    if (!row_selected(filter, i)) continue;
+    seen.insert(static_cast<int32_t>(i));             // insert() keeps the existing (earlier) row on a duplicate
+  }
+  int64_t out = 0;
+  for (int32_t row : seen) out_tids[out++] = row;
+  return out;
 }
 
 }  // extern "C"

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "qsx_gather_segmented": (_int, [_int, _int, _pp, C.POINTER(_i64), _vp, _i64, _vp, _vp]),
     "qsx_sort_workspace_bytes": (_sz, [_i64]),
     "qsx_sort_permutation": (_int, [_int, _pp, C.POINTER(_i32), C.POINTER(_i32), _i64, _vp, _vp, _sz, _vp]),
+    "qsx_distinct_rows": (_int, [_int, _pp, C.POINTER(_i32), _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "qsx_sort_top_k": (_int, [_int, _pp, C.POINTER(_i32), C.POINTER(_i32), _i64, _i64, _vp, _vp, _sz, _vp]),
     "qsx_join_table_create": (_int, [_int, _i64, _pp]),
     "qsx_join_table_create_dense": (_int, [_int, _i64, _i64, _i64, _i64, _pp]),
@@ -133,7 +134,8 @@ def _stream(stream=None):
     return C.c_void_p(s.cuda_stream)
 
 
-_TORCH_TYPE = {torch.int32: T.INT, torch.int64: T.LONG, torch.float32: T.FLOAT, torch.float64: T.DOUBLE}
+_TORCH_TYPE = {torch.int32: T.INT, torch.int64: T.LONG, torch.float32: T.FLOAT, torch.float64: T.DOUBLE,
+               torch.uint8: T.CHAR}   # CHAR(1)
 _C_SCALAR = {T.INT: C.c_int32, T.LONG: C.c_int64, T.FLOAT: C.c_float, T.DOUBLE: C.c_double}
 
 
@@ -270,6 +272,21 @@ def sort_permutation(key_cols, descending=None, stream=None):
     _check(_lib.qsx_sort_permutation(len(key_cols), ptrs, types, desc, n, _ptr(out), _ptr(ws), ws_bytes, _stream(stream)),
            "qsx_sort_permutation")
     return out[:n]
+
+
+def distinct_rows(cols, filter_bitmap=None, stream=None):
+    """First row of every distinct tuple over cols (restricted to filter_bitmap), in tuple order."""
+    n = cols[0].numel()
+    device = cols[0].device
+    out = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+    count = torch.zeros(1, dtype=torch.int64, device=device)
+    ws_bytes = _lib.qsx_sort_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    ptrs = (C.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
+    types = (C.c_int32 * len(cols))(*[qsx_type_of(c) for c in cols])
+    _check(_lib.qsx_distinct_rows(len(cols), ptrs, types, n, _ptr(filter_bitmap), _ptr(out), _ptr(count), _ptr(ws), ws_bytes,
+                                  _stream(stream)), "qsx_distinct_rows")
+    return out[:int(count.item())]
 
 
 def sort_top_k(key_cols, k, descending=None, stream=None):

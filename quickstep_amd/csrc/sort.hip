@@ -27,13 +27,15 @@ template <typename T>
 __device__ __forceinline__ unsigned long long ordered_image(T b, int type, int descending) {
   constexpr T kSign = static_cast<T>(1) << (sizeof(T) * 8 - 1);
   unsigned long long k;
-  if (type == QSX_INT || type == QSX_LONG) {
+  if (type == QSX_CHAR) {
+    k = b;                                           // unsigned byte
+  } else if (type == QSX_INT || type == QSX_LONG) {
     k = b ^ kSign;                                   // two's complement: flip the sign bit
   } else {
     const T z = (b & static_cast<T>(~kSign)) == 0 ? static_cast<T>(0) : b;   // -0.0 compares equal to +0.0: same image
     k = (z & kSign) ? static_cast<T>(~z) : (z | kSign);   // IEEE sign-magnitude: negatives reversed below the positives
   }
-  if (descending) k = sizeof(T) == 4 ? (static_cast<uint32_t>(~k)) : ~k;
+  if (descending) k = sizeof(T) == 8 ? ~k : (~k & ((1ull << (sizeof(T) * 8)) - 1));
   return k;
 }
 
@@ -104,6 +106,42 @@ static size_t s_align(size_t v) { return (v + 255) / 256 * 256; }
 
 using namespace qsx;
 
+// ---- DISTINCT: first row of every run of equal tuples in the sorted order ---------------------------------------
+struct TupleColumns {
+  int ncols;
+  const void *col[QSX_MAX_KEYS];
+  int type[QSX_MAX_KEYS];
+};
+
+__device__ __forceinline__ unsigned long long tuple_image(const TupleColumns &t, int c, int32_t row) {
+  const int type = t.type[c];
+  if (type == QSX_CHAR) return static_cast<const uint8_t *>(t.col[c])[row];
+  if (type == QSX_INT || type == QSX_FLOAT) return ordered_image<uint32_t>(static_cast<const uint32_t *>(t.col[c])[row], type, 0);
+  return ordered_image<unsigned long long>(static_cast<const unsigned long long *>(t.col[c])[row], type, 0);
+}
+
+// bit i = tuple of row tids[i] differs from the tuple of row tids[i-1] (bit 0 always set); equality is the sort's
+// (the ordered images: -0.0 == +0.0)
+__global__ __launch_bounds__(kSBlock) void run_heads_kernel(TupleColumns t, const int32_t *__restrict__ tids, int64_t m,
+                                                           uint64_t *__restrict__ bitmap) {
+  const int64_t num_words = (m + 63) >> 6;
+  const int lane = lane_id();
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * (kSBlock / kWave) + (threadIdx.x >> 6); w < num_words;
+       w += static_cast<int64_t>(gridDim.x) * (kSBlock / kWave)) {
+    const int64_t i = (w << 6) + lane;
+    bool head = false;
+    if (i < m) {
+      head = i == 0;
+      if (!head) {
+        const int32_t row = tids[i], prev = tids[i - 1];
+        for (int c = 0; c < t.ncols; ++c) head = head || tuple_image(t, c, row) != tuple_image(t, c, prev);
+      }
+    }
+    const uint64_t word = msb_first(__ballot(head));
+    if (lane == 0) bitmap[w] = word;
+  }
+}
+
 // Sizes of the pieces of the sort workspace for n rows.
 struct SortWorkspace {
   size_t keys, tids, offsets, part, hist, bitmap, compact, total;
@@ -127,7 +165,7 @@ static int validate_sort_args(int nkeys, const void *const *key_cols, const int3
     return QSX_ERR_INVALID_ARGUMENT;
   }
   for (int k = 0; k < nkeys; ++k) {
-    if (key_types[k] < QSX_INT || key_types[k] > QSX_DOUBLE) return QSX_ERR_UNSUPPORTED;
+    if (key_types[k] < QSX_INT || key_types[k] > QSX_CHAR) return QSX_ERR_UNSUPPORTED;
     if (n > 0 && key_cols[k] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   }
   return QSX_OK;
@@ -147,7 +185,10 @@ static int sort_tids(int nkeys, const void *const *key_cols, const int32_t *key_
   for (int k = nkeys - 1; k >= 0; --k) {
     const int type = key_types[k];
     const int desc = descending != nullptr && descending[k] != 0 ? 1 : 0;
-    if (type == QSX_INT || type == QSX_FLOAT) {
+    if (type == QSX_CHAR) {
+      hipLaunchKernelGGL(sort_keys_kernel<uint8_t>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const uint8_t *>(key_cols[k]), tids_a, n,
+                         type, desc, keys_a);
+    } else if (type == QSX_INT || type == QSX_FLOAT) {
       hipLaunchKernelGGL(sort_keys_kernel<uint32_t>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const uint32_t *>(key_cols[k]), tids_a, n,
                          type, desc, keys_a);
     } else {
@@ -155,7 +196,7 @@ static int sort_tids(int nkeys, const void *const *key_cols, const int32_t *key_
                          static_cast<const unsigned long long *>(key_cols[k]), tids_a, n, type, desc, keys_a);
     }
     QSX_CHECK_LAUNCH();
-    const int bits = (type == QSX_INT || type == QSX_FLOAT) ? 32 : 64;
+    const int bits = type == QSX_CHAR ? 8 : ((type == QSX_INT || type == QSX_FLOAT) ? 32 : 64);
     for (int shift = 0; shift < bits; shift += 6) {
       const void *src[2] = {keys_a, tids_a};
       void *dst[2] = {keys_b, tids_b};
@@ -215,7 +256,7 @@ int qsx_sort_top_k(int nkeys, const void *const *key_cols, const int32_t *key_ty
   void *compact_ws = extra + ws.hist + ws.bitmap;
   int64_t m = n;
   bool selected = false;
-  if (n >= 65536 && k <= n / 64) {
+  if (n >= 65536 && k <= n / 64 && key_types[0] != QSX_CHAR) {
     // threshold selection on key 0
     const int type = key_types[0];
     const int desc = descending != nullptr && descending[0] != 0 ? 1 : 0;
@@ -252,6 +293,54 @@ int qsx_sort_top_k(int nkeys, const void *const *key_cols, const int32_t *key_ty
   if (rc != QSX_OK) return rc;
   QSX_HIP_TRY(hipMemcpyAsync(out_tids_dev, result, static_cast<size_t>(k) * 4, hipMemcpyDeviceToDevice, s));
   return QSX_OK;
+}
+
+int qsx_distinct_rows(int ncols, const void *const *cols, const int32_t *types, int64_t n, const uint64_t *filter_dev,
+                      int32_t *out_tids_dev, int64_t *out_count_dev, void *workspace_dev, size_t workspace_bytes,
+                      qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  int rc = validate_sort_args(ncols, cols, types, n, out_tids_dev);
+  if (rc != QSX_OK) return rc;
+  if (out_count_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  hipStream_t s = as_stream(stream);
+  QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return QSX_OK;
+  const SortWorkspace ws(n);
+  if (workspace_dev == nullptr || workspace_bytes < ws.total) return QSX_ERR_CAPACITY;
+  char *w = static_cast<char *>(workspace_dev);
+  int32_t *tids_a = reinterpret_cast<int32_t *>(w + 2 * ws.keys + ws.tids);
+  int32_t *tids_b = reinterpret_cast<int32_t *>(w + 2 * ws.keys);
+  char *extra = w + 2 * ws.keys + 2 * ws.tids + ws.offsets + ws.part;
+  int64_t *count_dev = reinterpret_cast<int64_t *>(extra);                  // inside the hist piece
+  uint64_t *bitmap = reinterpret_cast<uint64_t *>(extra + ws.hist);
+  void *compact_ws = extra + ws.hist + ws.bitmap;
+  int64_t m = n;
+  if (filter_dev != nullptr) {   // the selected rows, in input order
+    rc = qsx_bitmap_to_tids(filter_dev, n, 0, tids_a, count_dev, compact_ws, ws.compact, stream);
+    if (rc != QSX_OK) return rc;
+    QSX_HIP_TRY(hipMemcpyAsync(&m, count_dev, sizeof(m), hipMemcpyDeviceToHost, s));
+    QSX_HIP_TRY(hipStreamSynchronize(s));
+    if (m == 0) return QSX_OK;
+  } else {
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, kSBlock * 4)), dim3(kSBlock), 0, s, tids_a, n);
+    QSX_CHECK_LAUNCH();
+  }
+  int32_t *sorted = nullptr;
+  rc = sort_tids(ncols, cols, types, nullptr, m, tids_a, tids_b, w, ws, &sorted, s);
+  if (rc != QSX_OK) return rc;
+  TupleColumns t{};
+  t.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) { t.col[c] = cols[c]; t.type[c] = types[c]; }
+  hipLaunchKernelGGL(run_heads_kernel, dim3(grid_for(m, kSBlock * 4)), dim3(kSBlock), 0, s, t, sorted, m, bitmap);
+  QSX_CHECK_LAUNCH();
+  // positions of the run heads -> their row numbers
+  int32_t *positions = sorted == tids_a ? tids_b : tids_a;
+  rc = qsx_bitmap_to_tids(bitmap, m, 0, positions, out_count_dev, compact_ws, ws.compact, stream);
+  if (rc != QSX_OK) return rc;
+  int64_t distinct = 0;
+  QSX_HIP_TRY(hipMemcpyAsync(&distinct, out_count_dev, sizeof(distinct), hipMemcpyDeviceToHost, s));
+  QSX_HIP_TRY(hipStreamSynchronize(s));
+  return qsx_gather(4, sorted, positions, distinct, out_tids_dev, stream);
 }
 
 }  // extern "C"

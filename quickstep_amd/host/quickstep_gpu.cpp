@@ -483,6 +483,39 @@ std::vector<block_id> InsertDestination::getTouchedBlocks() const {
 // ---------------------------------------------------------------------------
 // AggregationOperationState
 // ---------------------------------------------------------------------------
+struct AggregationOperationState::Distinctify {
+  std::size_t agg_index = 0;            // position in spec.aggregates
+  std::vector<attribute_id> attrs;      // group-by..., argument
+  std::vector<Type> types;
+  std::mutex mutex;                     // many AggregationWorkOrders append concurrently
+  struct Chunk {
+    std::vector<std::unique_ptr<DeviceBuffer>> cols;
+    std::int64_t rows = 0;
+  };
+  std::vector<Chunk> chunks;
+};
+
+namespace {
+qsx_agg_fn_t AggFn(AggregationID id) {
+  switch (id) {
+    case AggregationID::kCount: return QSX_AGG_COUNT_STAR;
+    case AggregationID::kSum: return QSX_AGG_SUM;
+    case AggregationID::kAvg: return QSX_AGG_AVG;
+    case AggregationID::kMin: return QSX_AGG_MIN;
+    default: return QSX_AGG_MAX;
+  }
+}
+// Result type of an aggregate (AggregationHandle{Count,Sum,Avg,Min,Max}::getResultType).
+Type AggResultType(AggregationID id, const Type &argument) {
+  switch (id) {
+    case AggregationID::kCount: return Type::Long();
+    case AggregationID::kSum: return (argument.id == kInt || argument.id == kLong) ? Type::Long() : Type::Double();
+    case AggregationID::kAvg: return Type::Double();
+    default: return argument;
+  }
+}
+}  // namespace
+
 AggregationOperationState::AggregationOperationState(const AggregationStateSpec &spec) : spec_(spec) {
   std::memset(&config_, 0, sizeof(config_));
   const CatalogRelation &rel = *spec.input_relation;
@@ -500,21 +533,31 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
   config_.strategy = spec.group_by.empty() ? QSX_AGG_SINGLE_STATE : spec.strategy;
   config_.num_keys = static_cast<int>(spec.group_by.size());
   for (std::size_t k = 0; k < spec.group_by.size(); ++k) config_.key_column[k] = column_of(spec.group_by[k]);
-  config_.num_aggs = static_cast<int>(spec.aggregates.size());
+  int num_main = 0;
   for (std::size_t a = 0; a < spec.aggregates.size(); ++a) {
     const AggregateSpec &ag = spec.aggregates[a];
-    switch (ag.function) {
-      case AggregationID::kCount: config_.aggs[a].fn = QSX_AGG_COUNT_STAR; break;
-      case AggregationID::kSum: config_.aggs[a].fn = QSX_AGG_SUM; break;
-      case AggregationID::kAvg: config_.aggs[a].fn = QSX_AGG_AVG; break;
-      case AggregationID::kMin: config_.aggs[a].fn = QSX_AGG_MIN; break;
-      case AggregationID::kMax: config_.aggs[a].fn = QSX_AGG_MAX; break;
+    if (ag.is_distinct) {
+      // "Initialize the corresponding distinctify hash table if this is a DISTINCT aggregation" (:172-207):
+      // key types = group-by types + argument types
+      if (ag.argument == kInvalidAttributeID) throw ExecutionError("DISTINCT aggregate without an argument", QSX_ERR_INVALID_ARGUMENT);
+      if (spec.group_by.size() + 1 > QSX_MAX_KEYS) throw ExecutionError("DISTINCT aggregate: too many group-by attributes", QSX_ERR_UNSUPPORTED);
+      std::unique_ptr<Distinctify> d(new Distinctify);
+      d->agg_index = a;
+      d->attrs = spec.group_by;
+      d->attrs.push_back(ag.argument);
+      for (attribute_id attr : d->attrs) d->types.push_back(rel.getAttributeType(attr));
+      distinctify_.push_back(std::move(d));
+      main_agg_.push_back(-1);
+      continue;
     }
+    config_.aggs[num_main].fn = AggFn(ag.function);
     if (ag.function != AggregationID::kCount) {
-      config_.aggs[a].arg.kind = QSX_OPD_COLUMN;
-      config_.aggs[a].arg.index = column_of(ag.argument);
+      config_.aggs[num_main].arg.kind = QSX_OPD_COLUMN;
+      config_.aggs[num_main].arg.index = column_of(ag.argument);
     }
+    main_agg_.push_back(num_main++);
   }
+  config_.num_aggs = num_main;
   if (spec.predicate != nullptr) {
     config_.num_pred_terms = static_cast<int>(spec.predicate->conjuncts.size());
     for (std::size_t p = 0; p < spec.predicate->conjuncts.size(); ++p) {
@@ -527,16 +570,214 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
   config_.num_columns = static_cast<int>(column_attr_.size());
   config_.est_groups = spec.estimated_num_groups;
   config_.num_entries = spec.collision_free_num_entries;
-  CheckStatus(qsx_agg_state_create(&config_, &state_), "qsx_agg_state_create");
+  // all_distinct_ (:126-127, 620-628): no upsert into the final table per block, it is filled from the distinctify tables
+  if (num_main > 0 || distinctify_.empty()) CheckStatus(qsx_agg_state_create(&config_, &state_), "qsx_agg_state_create");
 }
 
-AggregationOperationState::~AggregationOperationState() { qsx_agg_state_destroy(state_); }
+AggregationOperationState::~AggregationOperationState() {
+  if (state_ != nullptr) qsx_agg_state_destroy(state_);
+}
 
 void AggregationOperationState::aggregateBlock(const StorageBlock &block, const std::uint64_t *lip_filter) {
+  const std::int64_t n = block.numTuples();
+  if (!distinctify_.empty() && n > 0) {
+    // insertValueAccessorIntoDistinctifyHashTable per DISTINCT aggregate (:522-528, 600-628), on the tuples that pass
+    // the state's predicate and the LIP filters: the block's distinct (group-by..., argument) tuples are appended
+    std::int64_t matches = n;
+    void *selected = nullptr;
+    if (spec_.predicate != nullptr) selected = spec_.predicate->getMatchesForBlock(block, &matches, lip_filter);
+    const std::uint64_t *filter = selected != nullptr ? static_cast<const std::uint64_t *>(selected) : lip_filter;
+    const std::size_t ws_bytes = qsx_sort_workspace_bytes(n);
+    DeviceBuffer ws(ws_bytes), tids(static_cast<std::size_t>(n) * 4 + 16), count(8);
+    for (auto &d : distinctify_) {
+      const void *cols[QSX_MAX_KEYS];
+      std::int32_t types[QSX_MAX_KEYS];
+      for (std::size_t c = 0; c < d->attrs.size(); ++c) {
+        cols[c] = block.stripe(d->attrs[c]);
+        types[c] = d->types[c].id;
+      }
+      CheckStatus(qsx_distinct_rows(static_cast<int>(d->attrs.size()), cols, types, n, filter, static_cast<std::int32_t *>(tids.ptr),
+                                    static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()), "qsx_distinct_rows");
+      Distinctify::Chunk chunk;
+      chunk.rows = ReadCount(count.ptr);
+      if (chunk.rows == 0) continue;
+      for (std::size_t c = 0; c < d->attrs.size(); ++c) {
+        chunk.cols.emplace_back(new DeviceBuffer(static_cast<std::size_t>(chunk.rows) * d->types[c].width + 16));
+        CheckStatus(qsx_gather(d->types[c].width, cols[c], static_cast<const std::int32_t *>(tids.ptr), chunk.rows,
+                               chunk.cols.back()->ptr, CurrentStream()), "qsx_gather");
+      }
+      CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+      std::lock_guard<std::mutex> lock(d->mutex);
+      d->chunks.push_back(std::move(chunk));
+    }
+    qsx_device_free(selected);
+  }
+  if (state_ == nullptr) return;
   const void *cols[QSX_MAX_COLUMNS];
   for (std::size_t i = 0; i < column_attr_.size(); ++i) cols[i] = block.stripe(column_attr_[i]);
-  CheckStatus(qsx_agg_update(state_, cols, block.numTuples(), lip_filter, CurrentStream()), "qsx_agg_update");
+  CheckStatus(qsx_agg_update(state_, cols, n, lip_filter, CurrentStream()), "qsx_agg_update");
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+}
+
+// finalizeAggregate with DISTINCT aggregates: every distinctify table is reduced to its distinct tuples, which are
+// aggregated once each into a table keyed like the final one (aggregateOnDistinctifyHashTableFor{Single,GroupBy},
+// AggregationOperationState.cpp:652-670, 720-760); the per-aggregate results are then lined up on the group key.
+void AggregationOperationState::finalizeWithDistinct(InsertDestination *dest) {
+  const CatalogRelation &rel = *spec_.input_relation;
+  const int nk = config_.num_keys;
+  struct ResultSet {
+    std::vector<std::unique_ptr<DeviceBuffer>> keys, vals;
+    std::int64_t rows = 0;
+    std::unique_ptr<DeviceBuffer> order;      // row numbers in ascending key order
+  };
+  auto finalize_into = [&](qsx_agg_state_t *state, const qsx_agg_config_t &cfg, const std::vector<Type> &val_types, ResultSet *out) {
+    std::int64_t groups = 0;
+    CheckStatus(qsx_agg_num_groups(state, &groups, CurrentStream()), "qsx_agg_num_groups");
+    const std::int64_t cap = groups > 0 ? groups : 1;
+    void *key_cols[QSX_MAX_KEYS];
+    void *val_cols[QSX_MAX_AGGS];
+    for (int k = 0; k < cfg.num_keys; ++k) {
+      out->keys.emplace_back(new DeviceBuffer(static_cast<std::size_t>(cap) * cfg.column_width[cfg.key_column[k]] + 16));
+      key_cols[k] = out->keys.back()->ptr;
+    }
+    for (int a = 0; a < cfg.num_aggs; ++a) {
+      out->vals.emplace_back(new DeviceBuffer(static_cast<std::size_t>(cap) * val_types[a].width + 16));
+      val_cols[a] = out->vals.back()->ptr;
+    }
+    DeviceBuffer rows(8);
+    CheckStatus(qsx_agg_finalize(state, 0, 1, key_cols, val_cols, nullptr, cap, static_cast<std::int64_t *>(rows.ptr), CurrentStream()),
+                "qsx_agg_finalize");
+    out->rows = ReadCount(rows.ptr);
+    if (cfg.num_keys > 0 && out->rows > 0) {   // ascending key order: the common order of all result sets
+      const void *cols[QSX_MAX_KEYS];
+      std::int32_t types[QSX_MAX_KEYS];
+      for (int k = 0; k < cfg.num_keys; ++k) {
+        cols[k] = out->keys[k]->ptr;
+        types[k] = cfg.column_type[cfg.key_column[k]];
+        if (types[k] == kChar && cfg.column_width[cfg.key_column[k]] != 1) {
+          throw ExecutionError("DISTINCT aggregate: CHAR group-by keys wider than one byte", QSX_ERR_UNSUPPORTED);
+        }
+      }
+      const std::size_t ws_bytes = qsx_sort_workspace_bytes(out->rows);
+      DeviceBuffer ws(ws_bytes);
+      out->order.reset(new DeviceBuffer(static_cast<std::size_t>(out->rows) * 4 + 16));
+      CheckStatus(qsx_sort_permutation(cfg.num_keys, cols, types, nullptr, out->rows, static_cast<std::int32_t *>(out->order->ptr), ws.ptr,
+                                       ws_bytes, CurrentStream()), "qsx_sort_permutation");
+    }
+  };
+
+  // the non-DISTINCT aggregates
+  ResultSet main;
+  std::vector<Type> main_types;
+  if (state_ != nullptr) {
+    for (std::size_t a = 0; a < spec_.aggregates.size(); ++a) {
+      if (main_agg_[a] < 0) continue;
+      const AggregateSpec &ag = spec_.aggregates[a];
+      main_types.push_back(AggResultType(ag.function, ag.argument == kInvalidAttributeID ? Type::Long() : rel.getAttributeType(ag.argument)));
+    }
+    finalize_into(state_, config_, main_types, &main);
+  }
+  // one result set per DISTINCT aggregate
+  std::vector<ResultSet> distinct(distinctify_.size());
+  for (std::size_t i = 0; i < distinctify_.size(); ++i) {
+    Distinctify &d = *distinctify_[i];
+    const AggregateSpec &ag = spec_.aggregates[d.agg_index];
+    const std::size_t ncols = d.attrs.size();
+    std::int64_t total = 0;
+    for (const auto &chunk : d.chunks) total += chunk.rows;
+    // all block-level tuples side by side, then distinct over the whole input
+    std::vector<std::unique_ptr<DeviceBuffer>> all, tuples;
+    for (std::size_t c = 0; c < ncols; ++c) {
+      all.emplace_back(new DeviceBuffer(static_cast<std::size_t>(total) * d.types[c].width + 16));
+      char *at = static_cast<char *>(all.back()->ptr);
+      for (const auto &chunk : d.chunks) {
+        const std::size_t bytes = static_cast<std::size_t>(chunk.rows) * d.types[c].width;
+        CheckStatus(qsx_copy_on_device(at, chunk.cols[c]->ptr, bytes, CurrentStream()), "qsx_copy_on_device");
+        at += bytes;
+      }
+    }
+    std::int64_t rows = 0;
+    if (total > 0) {
+      const void *cols[QSX_MAX_KEYS];
+      std::int32_t types[QSX_MAX_KEYS];
+      for (std::size_t c = 0; c < ncols; ++c) { cols[c] = all[c]->ptr; types[c] = d.types[c].id; }
+      const std::size_t ws_bytes = qsx_sort_workspace_bytes(total);
+      DeviceBuffer ws(ws_bytes), tids(static_cast<std::size_t>(total) * 4 + 16), count(8);
+      CheckStatus(qsx_distinct_rows(static_cast<int>(ncols), cols, types, total, nullptr, static_cast<std::int32_t *>(tids.ptr),
+                                    static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()), "qsx_distinct_rows");
+      rows = ReadCount(count.ptr);
+      for (std::size_t c = 0; c < ncols; ++c) {
+        tuples.emplace_back(new DeviceBuffer(static_cast<std::size_t>(rows) * d.types[c].width + 16));
+        CheckStatus(qsx_gather(d.types[c].width, cols[c], static_cast<const std::int32_t *>(tids.ptr), rows, tuples.back()->ptr,
+                               CurrentStream()), "qsx_gather");
+      }
+    }
+    // the aggregate over the distinct tuples, keyed like the final table
+    qsx_agg_config_t cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.strategy = config_.strategy;
+    cfg.num_columns = static_cast<int>(ncols);
+    for (std::size_t c = 0; c < ncols; ++c) {
+      cfg.column_type[c] = d.types[c].id;
+      cfg.column_width[c] = d.types[c].width;
+    }
+    cfg.num_keys = nk;
+    for (int k = 0; k < nk; ++k) cfg.key_column[k] = k;
+    cfg.num_aggs = 1;
+    cfg.aggs[0].fn = AggFn(ag.function);             // COUNT(DISTINCT x) = COUNT(*) over the distinct tuples (no NULLs)
+    if (ag.function != AggregationID::kCount) {
+      cfg.aggs[0].arg.kind = QSX_OPD_COLUMN;
+      cfg.aggs[0].arg.index = nk;
+    }
+    cfg.est_groups = config_.est_groups;
+    cfg.num_entries = config_.num_entries;
+    qsx_agg_state_t *state = nullptr;
+    CheckStatus(qsx_agg_state_create(&cfg, &state), "qsx_agg_state_create");
+    try {
+      if (rows > 0) {
+        const void *cols[QSX_MAX_KEYS];
+        for (std::size_t c = 0; c < ncols; ++c) cols[c] = tuples[c]->ptr;
+        CheckStatus(qsx_agg_update(state, cols, rows, nullptr, CurrentStream()), "qsx_agg_update");
+      }
+      finalize_into(state, cfg, {AggResultType(ag.function, d.types.back())}, &distinct[i]);
+    } catch (...) {
+      qsx_agg_state_destroy(state);
+      throw;
+    }
+    CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+    qsx_agg_state_destroy(state);
+  }
+  // every result set holds the same groups (each group has at least one tuple in every table)
+  const ResultSet &first = state_ != nullptr ? main : distinct.front();
+  for (const ResultSet &r : distinct) {
+    if (r.rows != first.rows) throw ExecutionError("DISTINCT aggregate: group sets differ", QSX_ERR_INVALID_ARGUMENT);
+  }
+  block_id id;
+  BlockReference out = dest->getBlockForInsertion(first.rows > 0 ? first.rows : 1, &id);
+  auto emit = [&](const ResultSet &r, const void *src, int width, attribute_id out_attr) {
+    if (r.rows == 0) return;
+    if (r.order != nullptr) {
+      CheckStatus(qsx_gather(width, src, static_cast<const std::int32_t *>(r.order->ptr), r.rows, out->stripe(out_attr), CurrentStream()),
+                  "qsx_gather");
+    } else {
+      CheckStatus(qsx_copy_on_device(out->stripe(out_attr), src, static_cast<std::size_t>(r.rows) * width, CurrentStream()),
+                  "qsx_copy_on_device");
+    }
+  };
+  for (int k = 0; k < nk; ++k) emit(first, first.keys[k]->ptr, config_.column_width[config_.key_column[k]], k);
+  std::size_t next_distinct = 0;
+  for (std::size_t a = 0; a < spec_.aggregates.size(); ++a) {
+    const attribute_id out_attr = static_cast<attribute_id>(nk + a);
+    if (main_agg_[a] >= 0) {
+      emit(main, main.vals[main_agg_[a]]->ptr, main_types[main_agg_[a]].width, out_attr);
+    } else {
+      const ResultSet &r = distinct[next_distinct];
+      emit(r, r.vals[0]->ptr, AggResultType(spec_.aggregates[a].function, distinctify_[next_distinct]->types.back()).width, out_attr);
+      ++next_distinct;
+    }
+  }
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+  dest->returnBlock(id, first.rows);
 }
 
 void AggregationOperationState::buildExistenceMap(const StorageBlock &block, attribute_id build_attribute, const Type &type) {
@@ -549,6 +790,11 @@ void AggregationOperationState::buildExistenceMap(const StorageBlock &block, att
 }
 
 void AggregationOperationState::finalizeAggregate(std::size_t partition, std::size_t num_partitions, InsertDestination *dest) {
+  if (!distinctify_.empty()) {
+    // the distinctify tables are drained by one work order; the others of a partitioned finalize have nothing to emit
+    if (partition == 0) finalizeWithDistinct(dest);
+    return;
+  }
   std::int64_t groups = 0;
   CheckStatus(qsx_agg_num_groups(state_, &groups, CurrentStream()), "qsx_agg_num_groups");
   block_id id;

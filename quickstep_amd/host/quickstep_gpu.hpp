@@ -294,6 +294,7 @@ class InsertDestination {
 struct AggregateSpec {
   AggregationID function;
   attribute_id argument;  // kInvalidAttributeID for COUNT(*)
+  bool is_distinct = false;   // serialization::Aggregate::is_distinct (AggregationOperationState.proto)
 };
 struct AggregationStateSpec {
   const CatalogRelation *input_relation = nullptr;
@@ -320,8 +321,14 @@ class AggregationOperationState {
  private:
   AggregationStateSpec spec_;
   qsx_agg_config_t config_;
-  qsx_agg_state_t *state_ = nullptr;
+  qsx_agg_state_t *state_ = nullptr;       // the non-DISTINCT aggregates; nullptr when every aggregate is DISTINCT (all_distinct_)
   std::vector<attribute_id> column_attr_;  // config column -> input attribute
+  std::vector<int> main_agg_;              // spec aggregate -> aggregate of config_ (-1: DISTINCT)
+  // one per DISTINCT aggregate: distinctify_hashtables_ (AggregationOperationState.cpp:172-207), kept as the distinct
+  // (group-by..., argument) tuples of the blocks seen so far
+  struct Distinctify;
+  std::vector<std::unique_ptr<Distinctify>> distinctify_;
+  void finalizeWithDistinct(InsertDestination *dest);
 };
 
 // ---------------------------------------------------------------------------

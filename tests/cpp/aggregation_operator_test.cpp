@@ -4,6 +4,7 @@
 // (:1349-1470), driven synchronously like the reference test and through Foreman/Worker with a
 // Select -> Aggregation streaming edge.  GPU work orders.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 
@@ -303,6 +304,127 @@ int main() {
       seen[key] = true;
       EXPECT_EQ(at<std::int64_t>(cols[1], i), want_count[key]);
       EXPECT_EQ(at<std::int64_t>(cols[2], i), want_sum[key]);
+    }
+  }
+  // ---- DISTINCT aggregates: query_optimizer/tests/execution_generator/Distinct.test -----------------------------------
+  // foo(x INT, y DOUBLE, z INT) = (i, (i + 0.5) % 100, i % 3) for i in 0..29999 (:18-24); w = x % y stands in for the
+  // scalar argument of the third query.  30 blocks of 1000 tuples, 4 workers.
+  {
+    constexpr int kRows = 30000, kBlock = 1000;
+    StorageManager storage;
+    CatalogRelation foo(120, "foo");
+    foo.addAttribute("x", Type::Int());
+    foo.addAttribute("y", Type::Double());
+    foo.addAttribute("z", Type::Int());
+    foo.addAttribute("w", Type::Double());
+    for (int b = 0; b < kRows; b += kBlock) {
+      std::vector<std::int32_t> x(kBlock), z(kBlock);
+      std::vector<double> y(kBlock), w(kBlock);
+      for (int t = 0; t < kBlock; ++t) {
+        const int i = b + t;
+        x[t] = i; y[t] = std::fmod(i + 0.5, 100.0); z[t] = i % 3; w[t] = std::fmod(static_cast<double>(i), y[t]);
+      }
+      storage.loadBlock(&foo, {x.data(), y.data(), z.data(), w.data()}, kBlock);
+    }
+    auto distinct = [](AggregationID fn, attribute_id arg) { AggregateSpec a{fn, arg}; a.is_distinct = true; return a; };
+    {  // SELECT COUNT(*), COUNT(DISTINCT x), COUNT(DISTINCT y), COUNT(DISTINCT z) FROM foo  (:27-37)
+      CatalogRelation result(121, "result");
+      for (const char *name : {"count", "dx", "dy", "dz"}) result.addAttribute(name, Type::Long());
+      QueryContext ctx;
+      AggregationStateSpec spec;
+      spec.input_relation = &foo;
+      spec.aggregates = {{AggregationID::kCount, kInvalidAttributeID}, distinct(AggregationID::kCount, 0),
+                         distinct(AggregationID::kCount, 1), distinct(AggregationID::kCount, 2)};
+      const auto state = ctx.addAggregationState(spec);
+      const auto dest = ctx.addInsertDestination(&result, &storage);
+      QueryPlan plan;
+      const auto a = plan.addRelationalOperator(new AggregationOperator(0, foo, true, state));
+      const auto fz = plan.addRelationalOperator(new FinalizeAggregationOperator(0, state, 1, false, 1, result, dest));
+      plan.addDirectDependency(fz, a, true);
+      ForemanSingleNode foreman(&plan, &ctx, &storage, 4);
+      foreman.run();
+      std::size_t rows;
+      auto cols = readAll(ctx, dest, storage, result, &rows);
+      EXPECT_EQ(rows, static_cast<std::size_t>(1));
+      EXPECT_EQ(at<std::int64_t>(cols[0], 0), static_cast<std::int64_t>(30000));
+      EXPECT_EQ(at<std::int64_t>(cols[1], 0), static_cast<std::int64_t>(30000));
+      EXPECT_EQ(at<std::int64_t>(cols[2], 0), static_cast<std::int64_t>(100));
+      EXPECT_EQ(at<std::int64_t>(cols[3], 0), static_cast<std::int64_t>(3));
+    }
+    for (const qsx_agg_strategy_t strategy : {QSX_AGG_COMPACT_KEY, QSX_AGG_GENERIC, QSX_AGG_COLLISION_FREE}) {
+      // SELECT SUM(y), SUM(DISTINCT y), COUNT(DISTINCT y), AVG(DISTINCT y), z FROM foo GROUP BY z ORDER BY z  (:40-56)
+      // SELECT MAX(x) * SUM(DISTINCT y), COUNT(DISTINCT x % y) + z, z FROM foo GROUP BY z ORDER BY z        (:58-72)
+      CatalogRelation result(122, "result");
+      result.addAttribute("z", Type::Int());
+      result.addAttribute("sum_y", Type::Double());
+      result.addAttribute("sum_distinct_y", Type::Double());
+      result.addAttribute("count_distinct_y", Type::Long());
+      result.addAttribute("avg_distinct_y", Type::Double());
+      result.addAttribute("max_x", Type::Int());
+      result.addAttribute("count_distinct_w", Type::Long());
+      QueryContext ctx;
+      AggregationStateSpec spec;
+      spec.input_relation = &foo;
+      spec.group_by = {2};
+      spec.aggregates = {{AggregationID::kSum, 1}, distinct(AggregationID::kSum, 1), distinct(AggregationID::kCount, 1),
+                         distinct(AggregationID::kAvg, 1), {AggregationID::kMax, 0}, distinct(AggregationID::kCount, 3)};
+      spec.strategy = strategy;
+      spec.estimated_num_groups = 3;
+      spec.collision_free_num_entries = 3;
+      const auto state = ctx.addAggregationState(spec);
+      const auto dest = ctx.addInsertDestination(&result, &storage);
+      AggregationOperator op(0, foo, true, state);
+      FinalizeAggregationOperator fin(0, state, 1, false, 2, result, dest);   // two finalize work orders, one emits
+      fetchAndExecuteWorkOrders(&op, &ctx, &storage);
+      fetchAndExecuteWorkOrders(&fin, &ctx, &storage);
+      std::size_t rows;
+      auto cols = readAll(ctx, dest, storage, result, &rows);
+      EXPECT_EQ(rows, static_cast<std::size_t>(3));
+      const std::int64_t want_product[3] = {149985000, 149990000, 149995000};
+      const std::int64_t want_count_plus_z[3] = {196, 197, 195};
+      for (std::size_t i = 0; i < rows && i < 3; ++i) {
+        const int z = at<std::int32_t>(cols[0], i);
+        EXPECT_EQ(z, static_cast<int>(i));                                     // groups come out in key order
+        EXPECT_NEAR(at<double>(cols[1], i), 500000.0, 1e-6 * 500000.0);
+        EXPECT_TRUE(at<double>(cols[2], i) == 5000.0);                         // 0.5 + 1.5 + ... + 99.5, exact in double
+        EXPECT_EQ(at<std::int64_t>(cols[3], i), static_cast<std::int64_t>(100));
+        EXPECT_TRUE(at<double>(cols[4], i) == 50.0);
+        EXPECT_EQ(static_cast<std::int64_t>(at<std::int32_t>(cols[5], i) * at<double>(cols[2], i)), want_product[z]);
+        EXPECT_EQ(at<std::int64_t>(cols[6], i) + z, want_count_plus_z[z]);
+      }
+    }
+    {  // every aggregate DISTINCT, with the state's predicate: x < 150 leaves y in {0.5 .. 99.5} for 150 rows
+      CatalogRelation result(123, "result");
+      result.addAttribute("z", Type::Int());
+      result.addAttribute("count_distinct_y", Type::Long());
+      result.addAttribute("min_distinct_x", Type::Int());
+      QueryContext ctx;
+      Predicate pred;
+      pred.conjuncts.push_back({0, ComparisonID::kLess, TypedLiteral::Int(150)});
+      const auto pred_id = ctx.addPredicate(pred);
+      AggregationStateSpec spec;
+      spec.input_relation = &foo;
+      spec.group_by = {2};
+      spec.aggregates = {distinct(AggregationID::kCount, 1), distinct(AggregationID::kMin, 0)};
+      spec.predicate = ctx.getPredicate(pred_id);
+      spec.strategy = QSX_AGG_GENERIC;
+      spec.estimated_num_groups = 3;
+      const auto state = ctx.addAggregationState(spec);
+      const auto dest = ctx.addInsertDestination(&result, &storage);
+      AggregationOperator op(0, foo, true, state);
+      FinalizeAggregationOperator fin(0, state, 1, false, 1, result, dest);
+      fetchAndExecuteWorkOrders(&op, &ctx, &storage);
+      fetchAndExecuteWorkOrders(&fin, &ctx, &storage);
+      std::size_t rows;
+      auto cols = readAll(ctx, dest, storage, result, &rows);
+      EXPECT_EQ(rows, static_cast<std::size_t>(3));
+      for (std::size_t i = 0; i < rows && i < 3; ++i) {
+        // rows 0..149 of residue z: i = z, z+3, ...; y = i + 0.5 for i < 100, i - 99.5 beyond -> 50 rows, values of
+        // i mod 100 distinct unless i and i-100 share the residue mod 3 (never: 100 % 3 == 1)
+        EXPECT_EQ(at<std::int32_t>(cols[0], i), static_cast<int>(i));
+        EXPECT_EQ(at<std::int64_t>(cols[1], i), static_cast<std::int64_t>(50));
+        EXPECT_EQ(at<std::int32_t>(cols[2], i), static_cast<int>(i));
+      }
     }
   }
   return finish("aggregation_operator_test");

@@ -73,3 +73,60 @@ def test_top_k_is_the_head_of_the_full_sort(capi, oracle, dev, n, k):
             got = capi.sort_top_k([to_dev(col, dev), to_dev(second, dev)], k, [desc, False]).cpu().numpy()
             want = oracle.sort_permutation([col, second], [desc, False])[:k]
             assert np.array_equal(got, want), (name, desc)
+
+
+def test_char_sort_keys(capi, oracle, dev):
+    """1-byte CHAR keys (Q1's l_returnflag, l_linestatus) order as unsigned bytes, ASC and DESC, with a numeric tiebreak."""
+    rng = np.random.default_rng(12)
+    n = 200_000
+    flag = rng.choice(np.frombuffer(b"ANR\xf0", dtype=np.uint8), size=n)
+    status = rng.choice(np.frombuffer(b"FO", dtype=np.uint8), size=n)
+    qty = rng.integers(1, 51, size=n).astype(np.int32)
+    for desc in ([False, False, False], [True, False, True]):
+        got = capi.sort_permutation([to_dev(flag, dev), to_dev(status, dev), to_dev(qty, dev)], desc).cpu().numpy()
+        assert np.array_equal(got, oracle.sort_permutation([flag, status, qty], desc))
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 5000, 400_000])
+def test_distinct_rows_matches_the_distinctify_table(capi, oracle, dev, n):
+    """qsx_distinct_rows = first occurrence of every distinct (group-by..., argument) tuple, in tuple order, with and
+    without a filter; tuples over every key type incl. -0.0 / +0.0 (one value) and CHAR."""
+    rng = np.random.default_rng(n)
+    g1 = rng.integers(0, 3, size=n).astype(np.int32)
+    g2 = rng.choice(np.frombuffer(b"AB", dtype=np.uint8), size=n)
+    cases = {
+        "int arg": [g1, rng.integers(-20, 20, size=n).astype(np.int32)],
+        "long arg": [g1, g2, rng.integers(-2**40, 2**40, size=n).astype(np.int64) // (1 << 37)],
+        "double arg": [g2, rng.choice(np.array([0.0, -0.0, 0.5, -7.25, 1e300]), size=n)],
+        "float alone": [rng.choice(np.array([0.0, -0.0, 2.5, -2.5], dtype=np.float32), size=n)],
+        "all distinct": [np.arange(n, dtype=np.int64)[::-1].copy()],
+    }
+    keep = rng.random(n) < 0.6
+    filt = oracle.bitmap_from_bools(keep)
+    for name, cols in cases.items():
+        dcols = [to_dev(c, dev) for c in cols]
+        got = capi.distinct_rows(dcols).cpu().numpy()
+        assert np.array_equal(got, oracle.distinct_rows(cols)), name
+        got = capi.distinct_rows(dcols, to_dev(filt, dev)).cpu().numpy()
+        assert np.array_equal(got, oracle.distinct_rows(cols, filt)), name
+    none = oracle.bitmap_from_bools(np.zeros(n, dtype=bool))
+    assert capi.distinct_rows([to_dev(g1, dev)], to_dev(none, dev)).numel() == 0
+
+
+def test_count_distinct_at_scale_q16_shape(capi, dev):
+    """COUNT(DISTINCT ps_suppkey) GROUP BY a 3-attribute key (TPC-H Q16 shape) on 20 M rows: distinct tuples fed to a
+    COUNT(*) group-by equal a torch unique on the same device data."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(16)
+    n = 20_000_000
+    brand = torch.randint(0, 25, (n,), device=dev, generator=g, dtype=torch.int32)
+    size = torch.randint(1, 51, (n,), device=dev, generator=g, dtype=torch.int32)
+    supp = torch.randint(0, 1000, (n,), device=dev, generator=g, dtype=torch.int32)
+    rows = capi.distinct_rows([brand, size, supp])
+    packed = (brand.long() * 64 + size.long()) * 1024 + supp.long()
+    uniq = torch.unique(packed)
+    assert rows.numel() == uniq.numel()
+    assert torch.equal(packed[rows.long()], uniq)                      # tuple order = packed order, one row per tuple
+    first = torch.full((int(packed.max()) + 1,), n, dtype=torch.int64, device=dev)
+    first.scatter_reduce_(0, packed, torch.arange(n, device=dev), reduce="amin")
+    assert torch.equal(first[uniq], rows.long())                        # the representative is the first occurrence

@@ -347,6 +347,39 @@ def test_existence_map_equals_left_outer_join_then_group_by(oracle):
     assert (vals[0] == 0).sum() >= 100
 
 
+def test_sql_golden_distinct(oracle):
+    """query_optimizer/tests/execution_generator/Distinct.test:18-72: foo(x, y, z) = (i, (i + 0.5) % 100, i % 3), i < 30000.
+    The distinctify table (oracle.distinct_rows) feeding the aggregate over the distinct tuples reproduces the three
+    result tables of the reference."""
+    i = np.arange(30000)
+    x, y, z = i.astype(np.int32), np.fmod(i + 0.5, 100.0), (i % 3).astype(np.int32)
+    # COUNT(*), COUNT(DISTINCT x), COUNT(DISTINCT y), COUNT(DISTINCT z)  ->  30000, 30000, 100, 3
+    assert [oracle.distinct_rows([c]).size for c in (x, y, z)] == [30000, 100, 3]
+    # SUM(y), SUM(DISTINCT y), COUNT(DISTINCT y), AVG(DISTINCT y), z GROUP BY z  ->  500000, 5000, 100, 50 per z
+    rows = oracle.distinct_rows([z, y])
+    cfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None)], keys=[0],
+                            aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None), (T.AGG_AVG, T.col(1))], est_groups=3)
+    st = oracle.AggState(cfg)
+    st.update([z[rows], y[rows]])
+    keys, vals, _ = st.finalize()
+    order = np.argsort(keys[0])
+    assert keys[0][order].tolist() == [0, 1, 2]
+    assert vals[0][order].tolist() == [5000.0] * 3 and vals[1][order].tolist() == [100] * 3 and vals[2][order].tolist() == [50.0] * 3
+    plain = oracle.AggState(T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None)], keys=[0],
+                                              aggs=[(T.AGG_SUM, T.col(1))], est_groups=3))
+    plain.update([z, y])
+    assert np.allclose(plain.finalize()[1][0], 500000.0, rtol=1e-12)
+    # MAX(x) * SUM(DISTINCT y), COUNT(DISTINCT x % y) + z  ->  149985000 | 196, 149990000 | 197, 149995000 | 195
+    w = np.fmod(x.astype(np.float64), y)
+    rows = oracle.distinct_rows([z, w])
+    counts = np.bincount(z[rows], minlength=3)
+    assert (counts + np.arange(3)).tolist() == [196, 197, 195]
+    assert [int(x[z == g].max() * 5000.0) for g in range(3)] == [149985000, 149990000, 149995000]
+    # the representative of a tuple is its first occurrence, listed in tuple order
+    rows = oracle.distinct_rows([z])
+    assert rows.tolist() == [0, 1, 2]
+
+
 def test_join_unittest_composite_key_and_residual(oracle, golden):
     """CompositeKeyHashJoinTest / ...WithResidualPredicateTest (HashJoinOperator_unittest.cpp:999-1375)
     on the composite-key restatement: 100 results (even tids), 8 with the residual dim.long < 15."""
