@@ -734,6 +734,14 @@ static int launch_probe_radix(qsx_join_table *t, const int32_t *keys, int64_t n,
   return QSX_OK;
 }
 
+// The two-pass dense probe pays a second read of the keys and wins when the lookups are cheap and the tiles many: with
+// a filter (LIP / predicate bitmap: few live rows) by default; QSX_JOIN_TWO_PASS=1 / 0 forces it on / off.
+static bool dense_two_pass(const uint64_t *filter) {
+  const char *e = getenv("QSX_JOIN_TWO_PASS");
+  if (e != nullptr && e[0] != '\0') return e[0] != '0';
+  return filter != nullptr;
+}
+
 template <int MODE>
 static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_t probe_base_tid,
                         const uint64_t *filter, int32_t *out_probe, int32_t *out_build,
@@ -747,6 +755,40 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
     const int64_t limit = 8 * kCUs;  // no LDS: 8 workgroups (32 waves) per CU
     const int dgrid = static_cast<int>(tiles < limit ? tiles : limit);
     unsigned long long *dcount = reinterpret_cast<unsigned long long *>(out_count);
+    if (MODE == 0 && dense_two_pass(filter)) {
+      // count per (tile, wave) -> scan -> write: see join_dense.hpp
+      const int64_t units = tiles * (kDBlock / kWave);
+      int32_t *unit_counts = nullptr;
+      int64_t *unit_offsets = nullptr, *scan_ws = nullptr;
+      QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&unit_counts), static_cast<size_t>(units) * 4, stream));
+      QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&unit_offsets), static_cast<size_t>(units + 1) * 8, stream));
+      QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&scan_ws), scan_workspace_words(units) * 8, stream));
+      if (t->key_type == QSX_INT) {
+        hipLaunchKernelGGL((dense_probe_kernel<int32_t, 3>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+                           static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
+                           dcount, out_bitmap, anti, unit_counts, unit_offsets);
+      } else {
+        hipLaunchKernelGGL((dense_probe_kernel<int64_t, 3>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+                           static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
+                           dcount, out_bitmap, anti, unit_counts, unit_offsets);
+      }
+      QSX_CHECK_LAUNCH();
+      QSX_HIP_TRY(launch_scan(unit_counts, units, unit_offsets, out_count, scan_ws, stream));
+      if (t->key_type == QSX_INT) {
+        hipLaunchKernelGGL((dense_probe_kernel<int32_t, 4>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+                           static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
+                           dcount, out_bitmap, anti, unit_counts, unit_offsets);
+      } else {
+        hipLaunchKernelGGL((dense_probe_kernel<int64_t, 4>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+                           static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
+                           dcount, out_bitmap, anti, unit_counts, unit_offsets);
+      }
+      QSX_CHECK_LAUNCH();
+      QSX_HIP_TRY(hipFreeAsync(unit_counts, stream));
+      QSX_HIP_TRY(hipFreeAsync(unit_offsets, stream));
+      QSX_HIP_TRY(hipFreeAsync(scan_ws, stream));
+      return QSX_OK;
+    }
     if (t->key_type == QSX_INT) {
       hipLaunchKernelGGL((dense_probe_kernel<int32_t, MODE>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
                          static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,

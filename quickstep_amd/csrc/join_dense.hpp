@@ -15,10 +15,10 @@
 // 4-byte read, and for the C2 shape (1 M keys) head[] is 4 MiB — it stays resident in every
 // XCD's L2 while the probe keys and the output pairs stream past it with non-temporal accesses.
 //
-// Match compaction (MODE 0): a wave owns 16 x 64 probe rows of a tile.  It ballots the 16 steps; the
-// four wave totals meet in LDS and the workgroup reserves the space of all first-level matches of
-// the 4096-row tile with ONE global atomic (the single output counter serialises same-address
-// atomics in L2: one per wave measured 1.25 ms / 100 M rows, of which 0.7 ms was the counter).
+// Match compaction (MODE 0): a wave owns 16 x 64 probe rows of a tile.  It ballots the 16 steps and
+// reserves the space of all its first-level matches with ONE global atomic (the single output counter
+// serialises same-address atomics in L2: one per 64-row step measured 1.25 ms / 100 M rows, of which
+// 0.7 ms was the counter; one per 1024 rows is 1/16 of that and needs no workgroup barrier).
 // Every step's matches are then written as one contiguous run (mbcnt rank) straight to the output
 // arrays — no staging of the pairs.  Duplicate-key chains (rare) continue with one wave-aggregated
 // reservation per chain step.
@@ -106,50 +106,75 @@ __device__ __forceinline__ void dense_emit_direct(bool match, int32_t probe_tid,
   }
 }
 
-// MODE 0: emit pairs, 1: count only, 2: existence bitmap (as probe_kernel in join.hip).
+// MODE 0: emit pairs (one reservation per tile on the output counter), 1: count only, 2: existence bitmap (as
+// probe_kernel in join.hip); 3 + 4: the two-pass form of 0 — 3 counts the matches of every (tile, wave) unit, a scan turns
+// the counts into offsets, 4 writes every unit's pairs at its offset.  No atomics on the output counter (which takes
+// ~12 ns each: with sparse matches over clustered keys the one-pass form is bound by them, 146 K tiles = 1.7 ms for
+// 600 M rows) and the pairs come out in probe-row order.
 template <typename KeyT, int MODE>
 __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
     DenseTableView t, const KeyT *__restrict__ keys, int64_t n, int32_t probe_base_tid,
     const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build,
-    int64_t capacity_signed, unsigned long long *__restrict__ out_count, uint64_t *__restrict__ out_bitmap, int anti) {
+    int64_t capacity_signed, unsigned long long *__restrict__ out_count, uint64_t *__restrict__ out_bitmap, int anti,
+    int32_t *__restrict__ unit_counts = nullptr, const int64_t *__restrict__ unit_offsets = nullptr) {
   constexpr int R = kDenseRowsPerThread;
   const unsigned long long capacity = static_cast<unsigned long long>(capacity_signed);
   const int64_t num_tiles = (n + kDenseTile - 1) / kDenseTile;
   unsigned long long local_count = 0;
   __shared__ int s_wave_total[2][kDBlock / kWave];
   __shared__ unsigned long long s_tile_base;
-  const int wave = threadIdx.x >> 6;
   int parity = 0;
+  const int wave = threadIdx.x >> 6;
+
+  // The keys and the filter words of the NEXT tile are requested before the head words of the current one are read:
+  // one memory round trip per tile instead of filter -> keys -> head.  The 16 filter words a wave needs for a tile
+  // (rows r * 256 + wave * 64 ..) come with one load, lane r holding word r.
+  const int lane = lane_id();
+  const int64_t num_filter_words = (n + 63) >> 6;
+  KeyT key[R], next_key[R];
+  uint64_t filter_words = ~0ull, next_filter_words = ~0ull;
+  auto request = [&](int64_t tile, KeyT (&k)[R], uint64_t &words) {
+    const int64_t base = tile * kDenseTile;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = base + r * kDBlock + threadIdx.x;
+      k[r] = row < n ? __builtin_nontemporal_load(&keys[row]) : KeyT();
+    }
+    words = ~0ull;
+    if (filter != nullptr && lane < R) {
+      const int64_t w = (base >> 6) + lane * (kDBlock / kWave) + wave;
+      if (w < num_filter_words) words = filter[w];
+    }
+  };
+  if (static_cast<int64_t>(blockIdx.x) < num_tiles) request(blockIdx.x, key, filter_words);
 
   for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, parity ^= 1) {
     const int64_t tile_base = tile * kDenseTile;
+    if (tile + gridDim.x < num_tiles) request(tile + gridDim.x, next_key, next_filter_words);
     // Row r of this thread: tile_base + r * 256 + tid; a wave owns 64 consecutive rows per r.
     uint32_t h[R];
-    {
-      KeyT key[R];
-      bool live[R];
+    uint32_t live_mask = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t row = tile_base + r * kDBlock + threadIdx.x;
-        live[r] = row < n && dense_row_in_filter(filter, row);
-        key[r] = row < n ? __builtin_nontemporal_load(&keys[row]) : KeyT();
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {  // R independent 4-byte reads in flight per lane
-        const uint64_t idx = dense_index(t, key[r]);
-        h[r] = (live[r] && idx != ~0ull) ? t.head[idx] : 0u;
-      }
+    for (int r = 0; r < R; ++r) {  // R independent 4-byte reads in flight per lane
+      const int64_t row = tile_base + r * kDBlock + threadIdx.x;
+      const uint64_t filter_word = __shfl(filter_words, r, kWave);   // before the branch: every lane must take part
+      const bool live = row < n && msb_bit(filter_word, lane);
+      live_mask |= live ? (1u << r) : 0u;
+      const uint64_t idx = dense_index(t, key[r]);
+      h[r] = (live && idx != ~0ull) ? t.head[idx] : 0u;
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r) key[r] = next_key[r];
+    filter_words = next_filter_words;
 
     if (MODE == 2) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int64_t row = tile_base + r * kDBlock + threadIdx.x;
         // live is folded into h (dead rows read 0); anti needs it back
-        const bool live = row < n && dense_row_in_filter(filter, row);
-        const bool bit = live && ((h[r] != 0u) != (anti != 0));
+        const bool bit = ((live_mask >> r) & 1u) && ((h[r] != 0u) != (anti != 0));
         const uint64_t word = msb_first(__ballot(bit));
-        if (lane_id() == 0 && row < n) {
+        if (lane == 0 && row < n) {
           out_bitmap[row >> 6] = word;
           local_count += __popcll(word);
         }
@@ -169,26 +194,31 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
     }
     const bool wave_has_chain = __any(any_chain);
     uint32_t next[R];
-    if (MODE == 1) {
-      if (lane_id() == 0) local_count += total;
+    unsigned long long base = 0;   // MODE 0 / 4: where this wave's next pair goes
+    if (MODE == 1 || MODE == 3) {
+      if (lane == 0) local_count += total;
       if (wave_has_chain) {
 #pragma unroll
         for (int r = 0; r < R; ++r) next[r] = (h[r] & kChainBit) ? t.ov[h[r] & ~kChainBit].y : 0u;
       }
     } else {
-      // s_wave_total is double-buffered by tile parity, s_tile_base is rewritten only after the next
-      // tile's first barrier: two barriers per tile suffice.
-      if (lane_id() == 0) s_wave_total[parity][wave] = total;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        int all = 0;
+      if (MODE == 0) {
+        // s_wave_total is double-buffered by tile parity, s_tile_base is rewritten only after the next
+        // tile's first barrier: two barriers per tile suffice.
+        if (lane == 0) s_wave_total[parity][wave] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          int all = 0;
 #pragma unroll
-        for (int w = 0; w < kDBlock / kWave; ++w) all += s_wave_total[parity][w];
-        s_tile_base = all != 0 ? atomicAdd(out_count, static_cast<unsigned long long>(all)) : 0ull;
+          for (int w = 0; w < kDBlock / kWave; ++w) all += s_wave_total[parity][w];
+          s_tile_base = all != 0 ? atomicAdd(out_count, static_cast<unsigned long long>(all)) : 0ull;
+        }
+        __syncthreads();
+        base = s_tile_base;
+        for (int w = 0; w < wave; ++w) base += s_wave_total[parity][w];
+      } else {
+        base = static_cast<unsigned long long>(unit_offsets[tile * (kDBlock / kWave) + wave]);   // from the counting pass
       }
-      __syncthreads();
-      unsigned long long base = s_tile_base;
-      for (int w = 0; w < wave; ++w) base += s_wave_total[parity][w];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int64_t row = tile_base + r * kDBlock + threadIdx.x;
@@ -220,20 +250,33 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
             tid = e.x;
             nxt = e.y;
           }
-          if (MODE == 1) {
+          if (MODE == 1 || MODE == 3) {
             local_count += cur != 0u ? 1u : 0u;
-          } else {
+          } else if (MODE == 0) {
             dense_emit_direct(cur != 0u, static_cast<int32_t>(probe_base_tid + row), static_cast<int32_t>(tid), out_probe,
                               out_build, capacity, out_count);
+          } else {   // the wave's run continues behind its first-level matches, in the order the counting pass saw
+            const uint64_t cm = __ballot(cur != 0u);
+            const unsigned long long o = base + rank_below(cm);
+            if (cur != 0u && o < capacity) {
+              __builtin_nontemporal_store(static_cast<int32_t>(probe_base_tid + row), &out_probe[o]);
+              __builtin_nontemporal_store(static_cast<int32_t>(tid), &out_build[o]);
+            }
+            base += __popcll(cm);
           }
           cur = nxt;
         }
       }
     }
+    if (MODE == 3) {   // matches of this wave in this tile, for the scan between the two passes
+      const unsigned long long unit = wave_reduce_add(local_count);
+      if (lane == 0) unit_counts[tile * (kDBlock / kWave) + wave] = static_cast<int32_t>(unit);
+      local_count = 0;
+    }
   }
-  if (MODE != 0) {
+  if (MODE == 1 || MODE == 2) {
     local_count = wave_reduce_add(local_count);
-    if (lane_id() == 0 && local_count != 0 && out_count != nullptr) atomicAdd(out_count, local_count);
+    if (lane == 0 && local_count != 0 && out_count != nullptr) atomicAdd(out_count, local_count);
   }
 }
 

@@ -77,15 +77,33 @@ __global__ __launch_bounds__(kInLds ? 1024 : kLBlock) void lip_probe_kernel(LipV
   const int64_t wave = static_cast<int64_t>(blockIdx.x) * waves_per_block + (threadIdx.x >> 6);
   const int64_t num_waves = static_cast<int64_t>(gridDim.x) * waves_per_block;
   unsigned long long count = 0;
-  for (int64_t w0 = wave * R; w0 < num_words; w0 += num_waves * R) {
+  // One group = R bitmap words = R x 64 rows.  The keys and the input-bitmap words of the NEXT group are requested
+  // before the filter words of the current one are read, so a wave has one memory round trip per group instead of
+  // three (bitmap -> keys -> filter); the R input-bitmap words come with one load (lane r holds word r).
+  KeyT key[R], next_key[R];
+  uint64_t in_words = ~0ull, next_in_words = ~0ull;
+  auto request = [&](int64_t w0, KeyT (&k)[R], uint64_t &words) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ((w0 + r) << 6) + lane;
+      k[r] = row < n ? keys[row] : KeyT();
+    }
+    words = ~0ull;
+    if (in_bitmap != nullptr && lane < R && w0 + lane < num_words) words = in_bitmap[w0 + lane];
+  };
+  int64_t w0 = wave * R;
+  if (w0 < num_words) request(w0, key, in_words);
+  for (; w0 < num_words; w0 += num_waves * R) {
+    const int64_t w_next = w0 + num_waves * R;
+    if (w_next < num_words) request(w_next, next_key, next_in_words);
     long long bit[R];
     bool live[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((w0 + r) << 6) + lane;
-      live[r] = row < n;
-      if (live[r] && in_bitmap != nullptr) live[r] = msb_bit(in_bitmap[w0 + r], lane);
-      bit[r] = live[r] ? lip_bit_index(f, static_cast<long long>(keys[row])) : -1;
+      const uint64_t in_word = __shfl(in_words, r, kWave);
+      live[r] = row < n && msb_bit(in_word, lane);
+      bit[r] = live[r] ? lip_bit_index(f, static_cast<long long>(key[r])) : -1;
     }
     uint32_t word[R];
 #pragma unroll
@@ -108,6 +126,9 @@ __global__ __launch_bounds__(kInLds ? 1024 : kLBlock) void lip_probe_kernel(LipV
       if (lane == r) mine = out;
     }
     if (lane < R && w0 + lane < num_words) out_bitmap[w0 + lane] = mine;
+#pragma unroll
+    for (int r = 0; r < R; ++r) key[r] = next_key[r];
+    in_words = next_in_words;
   }
   if (out_count != nullptr) {
     if (lane != 0) count = 0;   // every lane counted the same wave-uniform ballots

@@ -67,10 +67,14 @@ def run(timed):
     lip_o.build(o_orderkey, filter_bitmap=o_ok)
     mark("orders: select + LIP probe + semi probe + build + LIP build")
     l_sel, _ = capi.select_cmp(l_shipdate, T.GT, DATE)
-    l_lip, _ = lip_o.probe(l_orderkey, in_bitmap=l_sel)
-    total = int(t_o.probe_count(l_orderkey, filter_bitmap=l_lip).item())
-    p, b, cnt = t_o.probe(l_orderkey, capacity=total, filter_bitmap=l_lip)
-    mark("lineitem: select + LIP probe + count + inner probe")
+    mark("lineitem: select l_shipdate > DATE")
+    l_lip, l_live = lip_o.probe(l_orderkey, in_bitmap=l_sel)
+    mark("lineitem: LIP probe on l_orderkey")
+    # o_orderkey is the primary key of the build side: at most one match per probe row, so the rows that pass the LIP
+    # filter bound the output (the reference sizes from the same uniqueness fact, impliesUniqueAttributes)
+    p, b, cnt = t_o.probe(l_orderkey, capacity=int(l_live.item()), filter_bitmap=l_lip)
+    total = int(cnt.item())
+    mark("lineitem: inner probe")
     key = capi.gather(l_orderkey, p[:total])
     price = capi.gather(l_extendedprice, p[:total])
     disc = capi.gather(l_discount, p[:total])
