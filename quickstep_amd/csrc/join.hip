@@ -246,22 +246,42 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
   const int64_t num_tiles = (n + kProbeTile - 1) / kProbeTile;
   unsigned long long local_count = 0;
 
+  // Row r of a thread in a tile: tile_base + r * 256 + tid.  A wave therefore owns 64 consecutive rows per r:
+  // coalesced key loads, and an existence ballot is exactly one TupleIdSequence word.  The keys and the 16 filter words
+  // (one load, lane r holds word r) of the NEXT tile are requested before the table units of the current one are read.
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t num_filter_words = (n + 63) >> 6;
+  Key key[kRowsPerThread], next_key[kRowsPerThread];
+  uint64_t filter_words = ~0ull, next_filter_words = ~0ull;
+  auto request = [&](int64_t tile, Key (&k)[kRowsPerThread], uint64_t &words) {
+    const int64_t base = tile * kProbeTile;
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const int64_t row = base + r * kJBlock + threadIdx.x;
+      k[r] = row < n ? keys[row] : Key();
+    }
+    words = ~0ull;
+    if (filter != nullptr && lane < kRowsPerThread) {
+      const int64_t w = (base >> 6) + lane * (kJBlock / kWave) + wave;
+      if (w < num_filter_words) words = filter[w];
+    }
+  };
+  if (static_cast<int64_t>(blockIdx.x) < num_tiles) request(blockIdx.x, key, filter_words);
+
   for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     if (MODE == 0) {
       if (threadIdx.x == 0) s_fill = 0;
       __syncthreads();
     }
     const int64_t tile_base = tile * kProbeTile;
-    // Row r of this thread: tile_base + r * 256 + tid.  A wave therefore owns
-    // 64 consecutive rows per r: coalesced key loads, and an existence ballot
-    // is exactly one TupleIdSequence word.
-    Key key[kRowsPerThread];
+    if (tile + gridDim.x < num_tiles) request(tile + gridDim.x, next_key, next_filter_words);
     bool live[kRowsPerThread];
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
       const int64_t row = tile_base + r * kJBlock + threadIdx.x;
-      live[r] = row < n && row_in_filter(filter, row);
-      key[r] = row < n ? keys[row] : Key();
+      const uint64_t filter_word = __shfl(filter_words, r, kWave);   // before the branch: every lane takes part
+      live[r] = row < n && msb_bit(filter_word, lane);
     }
     // First unit of every row: kRowsPerThread independent 16-byte loads in flight.
     uint64_t unit[kRowsPerThread];
@@ -309,6 +329,9 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
         }
       }
     }
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) key[r] = next_key[r];
+    filter_words = next_filter_words;
     if (MODE == 0) {
       __syncthreads();
       const int produced = s_fill;
@@ -634,11 +657,12 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   std::shared_lock<std::shared_mutex> lock(t->mutex);
   const int grid = grid_for(n, kJBlock * 4);
   if (t->dense) {
+    const int dgrid = grid_for((n + 63) >> 6, (kDBlock / kWave) * kBuildR);
     if (t->key_type == QSX_INT) {
-      hipLaunchKernelGGL(dense_build_kernel<int32_t>, dim3(grid), dim3(kDBlock), 0, as_stream(stream), t->dense_view(),
+      hipLaunchKernelGGL(dense_build_kernel<int32_t>, dim3(dgrid), dim3(kDBlock), 0, as_stream(stream), t->dense_view(),
                          static_cast<const int32_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev);
     } else {
-      hipLaunchKernelGGL(dense_build_kernel<int64_t>, dim3(grid), dim3(kDBlock), 0, as_stream(stream), t->dense_view(),
+      hipLaunchKernelGGL(dense_build_kernel<int64_t>, dim3(dgrid), dim3(kDBlock), 0, as_stream(stream), t->dense_view(),
                          static_cast<const int64_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev);
     }
     QSX_CHECK_LAUNCH();

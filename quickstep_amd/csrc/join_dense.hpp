@@ -57,35 +57,68 @@ __device__ __forceinline__ bool dense_row_in_filter(const uint64_t *filter, int6
   return filter == nullptr || ((filter[row >> 6] >> (63 - (row & 63))) & 1u);
 }
 
+// A wave owns groups of kBuildR x 64 rows: filter words with one load per group, next group's keys requested before the
+// current group's head words are claimed (the structure of dense_probe_kernel).
+constexpr int kBuildR = 8;
 template <typename KeyT>
 __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, const KeyT *__restrict__ keys, int64_t n,
                                                              int32_t base_tid, const uint64_t *__restrict__ filter,
                                                              unsigned long long *__restrict__ entries) {
+  constexpr int R = kBuildR;
+  const int lane = lane_id();
+  const int64_t num_words = (n + 63) >> 6;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kDBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t num_waves = static_cast<int64_t>(gridDim.x) * (kDBlock / kWave);
   unsigned long long inserted = 0;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kDBlock + threadIdx.x; i < n;
-       i += static_cast<int64_t>(gridDim.x) * kDBlock) {
-    if (!dense_row_in_filter(filter, i)) continue;
-    const uint64_t idx = dense_index(t, keys[i]);
-    if (idx == ~0ull) {
-      atomicExch(t.error, 1);
-      continue;
+  KeyT key[R], next_key[R];
+  uint64_t words = ~0ull, next_words = ~0ull;
+  auto request = [&](int64_t w0, KeyT (&k)[R], uint64_t &fw) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ((w0 + r) << 6) + lane;
+      k[r] = row < n ? keys[row] : KeyT();
     }
-    const uint32_t tid = static_cast<uint32_t>(base_tid + i);
-    if (atomicCAS(&t.head[idx], 0u, tid + 1u) != 0u) {
-      // duplicate key: push an overflow entry in front of whatever the head holds now
-      const unsigned int e = atomicAdd(t.ov_count, 1u);
-      if (e >= t.ov_capacity) {
-        atomicExch(t.error, 2);
-        continue;
+    fw = ~0ull;
+    if (filter != nullptr && lane < R && w0 + lane < num_words) fw = filter[w0 + lane];
+  };
+  int64_t w0 = wave * R;
+  if (w0 < num_words) request(w0, key, words);
+  for (; w0 < num_words; w0 += num_waves * R) {
+    const int64_t w_next = w0 + num_waves * R;
+    if (w_next < num_words) request(w_next, next_key, next_words);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t i = ((w0 + r) << 6) + lane;
+      const uint64_t fw = __shfl(words, r, kWave);   // before any branch: every lane takes part
+      if (i < n && msb_bit(fw, lane)) {
+        const uint64_t idx = dense_index(t, key[r]);
+        if (idx == ~0ull) {
+          atomicExch(t.error, 1);
+        } else {
+          const uint32_t tid = static_cast<uint32_t>(base_tid + i);
+          bool ok = true;
+          if (atomicCAS(&t.head[idx], 0u, tid + 1u) != 0u) {
+            // duplicate key: push an overflow entry in front of whatever the head holds now
+            const unsigned int e = atomicAdd(t.ov_count, 1u);
+            if (e >= t.ov_capacity) {
+              atomicExch(t.error, 2);
+              ok = false;
+            } else {
+              t.ov[e].x = tid;
+              // next is only read by probe kernels launched after the build (pipeline breaker)
+              t.ov[e].y = atomicExch(&t.head[idx], kChainBit | e);
+            }
+          }
+          if (ok) ++inserted;
+        }
       }
-      t.ov[e].x = tid;
-      // next is only read by probe kernels launched after the build (pipeline breaker)
-      t.ov[e].y = atomicExch(&t.head[idx], kChainBit | e);
     }
-    ++inserted;
+#pragma unroll
+    for (int r = 0; r < R; ++r) key[r] = next_key[r];
+    words = next_words;
   }
   inserted = wave_reduce_add(inserted);
-  if (lane_id() == 0 && inserted != 0) atomicAdd(entries, inserted);
+  if (lane == 0 && inserted != 0) atomicAdd(entries, inserted);
 }
 
 // One wave-aggregated append of the matching lanes straight to the global output.

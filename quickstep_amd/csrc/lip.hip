@@ -22,25 +22,57 @@ struct LipView {
   int is_anti;
 };
 
-template <typename KeyT>
+// A wave owns groups of R x 64 rows; the R filter words of a group come with one load (lane r holds word r) and the
+// keys of the next group are requested before the bits of the current one are set (as in lip_probe_kernel below).
+template <typename KeyT, int R>
 __global__ __launch_bounds__(kLBlock) void lip_build_kernel(LipView f, const KeyT *__restrict__ keys, int64_t n,
                                                            const uint64_t *__restrict__ filter) {
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kLBlock + threadIdx.x; i < n;
-       i += static_cast<int64_t>(gridDim.x) * kLBlock) {
-    if (filter != nullptr && !msb_bit(filter[i >> 6], static_cast<int>(i & 63))) continue;
-    const long long v = static_cast<long long>(keys[i]);
-    unsigned long long bit;
-    if (f.exact) {
-      const long long off = v - f.min_value;
-      if (off < 0 || off >= f.cardinality) continue;  // outside the declared [min, max]: cannot be represented
-      bit = static_cast<unsigned long long>(off);
-    } else {
-      // value converted to size_t first: a negative key sign-extends (SingleIdentityHashFilter.hpp:156-169)
-      bit = static_cast<unsigned long long>(v) % static_cast<unsigned long long>(f.cardinality);
+  const int lane = lane_id();
+  const int64_t num_words = (n + 63) >> 6;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kLBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t num_waves = static_cast<int64_t>(gridDim.x) * (kLBlock / kWave);
+  KeyT key[R], next_key[R];
+  uint64_t words = ~0ull, next_words = ~0ull;
+  auto request = [&](int64_t w0, KeyT (&k)[R], uint64_t &fw) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ((w0 + r) << 6) + lane;
+      k[r] = row < n ? keys[row] : KeyT();
     }
-    const unsigned long long mask = 1ull << (bit & 63);
-    unsigned long long *w = &f.words[bit >> 6];
-    if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) == 0) atomicOr(w, mask);
+    fw = ~0ull;
+    if (filter != nullptr && lane < R && w0 + lane < num_words) fw = filter[w0 + lane];
+  };
+  int64_t w0 = wave * R;
+  if (w0 < num_words) request(w0, key, words);
+  for (; w0 < num_words; w0 += num_waves * R) {
+    const int64_t w_next = w0 + num_waves * R;
+    if (w_next < num_words) request(w_next, next_key, next_words);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ((w0 + r) << 6) + lane;
+      const uint64_t fw = __shfl(words, r, kWave);   // before any branch: every lane takes part
+      if (row < n && msb_bit(fw, lane)) {
+        const long long v = static_cast<long long>(key[r]);
+        unsigned long long bit = 0;
+        bool ok = true;
+        if (f.exact) {
+          const long long off = v - f.min_value;
+          ok = off >= 0 && off < f.cardinality;      // outside the declared [min, max]: cannot be represented
+          bit = static_cast<unsigned long long>(off);
+        } else {
+          // value converted to size_t first: a negative key sign-extends (SingleIdentityHashFilter.hpp:156-169)
+          bit = static_cast<unsigned long long>(v) % static_cast<unsigned long long>(f.cardinality);
+        }
+        if (ok) {
+          const unsigned long long mask = 1ull << (bit & 63);
+          unsigned long long *w = &f.words[bit >> 6];
+          if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) == 0) atomicOr(w, mask);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) key[r] = next_key[r];
+    words = next_words;
   }
 }
 
@@ -197,12 +229,12 @@ int qsx_lip_build(qsx_lip_filter_t *f, int key_type, const void *keys_dev, int64
   QSX_REQUIRE_DEVICE();
   if (f == nullptr || n < 0 || (n > 0 && keys_dev == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
   if (n == 0) return QSX_OK;
-  const int grid = grid_for(n, kLBlock * 4);
+  const int grid = grid_for((n + 63) >> 6, (kLBlock / kWave) * 8);
   if (key_type == QSX_INT) {
-    hipLaunchKernelGGL(lip_build_kernel<int32_t>, dim3(grid), dim3(kLBlock), 0, as_stream(stream), f->view(),
+    hipLaunchKernelGGL((lip_build_kernel<int32_t, 8>), dim3(grid), dim3(kLBlock), 0, as_stream(stream), f->view(),
                        static_cast<const int32_t *>(keys_dev), n, filter_dev);
   } else if (key_type == QSX_LONG) {
-    hipLaunchKernelGGL(lip_build_kernel<int64_t>, dim3(grid), dim3(kLBlock), 0, as_stream(stream), f->view(),
+    hipLaunchKernelGGL((lip_build_kernel<int64_t, 8>), dim3(grid), dim3(kLBlock), 0, as_stream(stream), f->view(),
                        static_cast<const int64_t *>(keys_dev), n, filter_dev);
   } else {
     return QSX_ERR_UNSUPPORTED;

@@ -71,17 +71,38 @@ __global__ __launch_bounds__(kSBlock) void topk_hist_kernel(const T *__restrict_
   }
 }
 
-// control[0] = threshold bin (smallest t with count(bins <= t) >= k), control[1] = that count
-__global__ void topk_threshold_kernel(const unsigned long long *__restrict__ hist, long long k, long long *__restrict__ control) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  unsigned long long cum = 0;
-  int t = 0;
-  for (; t < kTopBins; ++t) {
-    cum += hist[t];
-    if (cum >= static_cast<unsigned long long>(k)) break;
+// control[0] = threshold bin (smallest t with count(bins <= t) >= k), control[1] = that count.  One wave: lane L sums
+// bins [64 L, 64 L + 64), a wave scan finds the lane whose range holds the k-th row, that lane walks its 64 bins.
+__global__ __launch_bounds__(kWave) void topk_threshold_kernel(const unsigned long long *__restrict__ hist, long long k,
+                                                              long long *__restrict__ control) {
+  constexpr int kPerLane = kTopBins / kWave;
+  const int lane = lane_id();
+  unsigned long long mine = 0;
+#pragma unroll 8
+  for (int i = 0; i < kPerLane; ++i) mine += hist[lane * kPerLane + i];
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned long long up = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += up;
   }
-  control[0] = t < kTopBins ? t : kTopBins - 1;
-  control[1] = static_cast<long long>(cum);
+  const unsigned long long want = static_cast<unsigned long long>(k);
+  const unsigned long long before = incl - mine;
+  const uint64_t reached = __ballot(incl >= want);
+  if (reached == 0) {   // k exceeds the row count: everything is a candidate
+    if (lane == kWave - 1) { control[0] = kTopBins - 1; control[1] = static_cast<long long>(incl); }
+    return;
+  }
+  if (lane == __ffsll(static_cast<long long>(reached)) - 1) {
+    unsigned long long cum = before;
+    int t = lane * kPerLane;
+    for (; t < (lane + 1) * kPerLane; ++t) {
+      cum += hist[t];
+      if (cum >= want) break;
+    }
+    control[0] = t;
+    control[1] = static_cast<long long>(cum);
+  }
 }
 
 template <typename T>

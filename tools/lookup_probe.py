@@ -62,4 +62,9 @@ out2 = (torch.empty(100_000_000, dtype=torch.int32, device=dev), torch.empty(100
 res["C2 probe_count"] = timed(lambda: t2.probe_count(p2))
 res["C2 probe"] = timed(lambda: t2.probe(p2, capacity=100_000_000, out=out2))
 res["C2 probe_exists"] = timed(lambda: t2.probe_exists(p2))
+t3 = capi.JoinTable(T.INT, 1_000_000)          # hashed flavour, same inputs
+t3.build(b2)
+res["C2 hashed probe_count"] = timed(lambda: t3.probe_count(p2))
+res["C2 hashed probe"] = timed(lambda: t3.probe(p2, capacity=100_000_000, out=out2))
+res["C2 hashed probe_exists"] = timed(lambda: t3.probe_exists(p2))
 print(json.dumps(res))
