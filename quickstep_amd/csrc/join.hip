@@ -277,6 +277,7 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
     const int64_t tile_base = tile * kProbeTile;
     if (tile + gridDim.x < num_tiles) request(tile + gridDim.x, next_key, next_filter_words);
     bool live[kRowsPerThread];
+    uint64_t exists_word = 0;
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
       const int64_t row = tile_base + r * kJBlock + threadIdx.x;
@@ -323,11 +324,13 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
       if (MODE == 2) {
         const bool bit = live[r] && (found != (anti != 0));
         const uint64_t word = msb_first(__ballot(bit));
-        if (lane_id() == 0 && row < n) {
-          out_bitmap[row >> 6] = word;
-          local_count += __popcll(word);
-        }
+        if (lane == r) exists_word = word;
+        if (lane == 0) local_count += __popcll(word);
       }
+    }
+    if (MODE == 2) {   // lane r holds the word of step r: one store instruction per tile and wave
+      const int64_t w = (tile_base >> 6) + lane * (kJBlock / kWave) + wave;
+      if (lane < kRowsPerThread && w < num_filter_words) out_bitmap[w] = exists_word;
     }
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) key[r] = next_key[r];

@@ -51,6 +51,9 @@ res["lip_probe no in_bitmap"] = timed(lambda: lip.probe(l_orderkey))
 res["probe_count filter=5%"] = timed(lambda: table.probe_count(l_orderkey, filter_bitmap=l_lip))
 res["probe filter=5%"] = timed(lambda: table.probe(l_orderkey, capacity=live, filter_bitmap=l_lip, out=out))
 res["probe_exists filter=54%"] = timed(lambda: table.probe_exists(l_orderkey, filter_bitmap=l_sel))
+res["probe_exists filter=5%"] = timed(lambda: table.probe_exists(l_orderkey, filter_bitmap=l_lip))
+res["probe_exists no filter"] = timed(lambda: table.probe_exists(l_orderkey))
+res["probe_count filter=54%"] = timed(lambda: table.probe_count(l_orderkey, filter_bitmap=l_sel))
 res["probe_count no filter"] = timed(lambda: table.probe_count(l_orderkey))
 # C2 shape: 1 M unique build keys, 100 M uniformly random probe keys, every probe row matches
 b2 = torch.randperm(1_000_000, device=dev, generator=g, dtype=torch.int32)
