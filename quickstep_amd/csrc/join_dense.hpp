@@ -87,32 +87,36 @@ __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, 
   for (; w0 < num_words; w0 += num_waves * R) {
     const int64_t w_next = w0 + num_waves * R;
     if (w_next < num_words) request(w_next, next_key, next_words);
+    // the R compare-and-swaps of a group are all issued before the first result is looked at
+    uint64_t idx[R];
+    uint32_t old[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t i = ((w0 + r) << 6) + lane;
       const uint64_t fw = __shfl(words, r, kWave);   // before any branch: every lane takes part
-      if (i < n && msb_bit(fw, lane)) {
-        const uint64_t idx = dense_index(t, key[r]);
-        if (idx == ~0ull) {
-          atomicExch(t.error, 1);
-        } else {
-          const uint32_t tid = static_cast<uint32_t>(base_tid + i);
-          bool ok = true;
-          if (atomicCAS(&t.head[idx], 0u, tid + 1u) != 0u) {
-            // duplicate key: push an overflow entry in front of whatever the head holds now
-            const unsigned int e = atomicAdd(t.ov_count, 1u);
-            if (e >= t.ov_capacity) {
-              atomicExch(t.error, 2);
-              ok = false;
-            } else {
-              t.ov[e].x = tid;
-              // next is only read by probe kernels launched after the build (pipeline breaker)
-              t.ov[e].y = atomicExch(&t.head[idx], kChainBit | e);
-            }
-          }
-          if (ok) ++inserted;
+      const bool live = i < n && msb_bit(fw, lane);
+      idx[r] = live ? dense_index(t, key[r]) : ~1ull;     // ~0: outside the range (an error), ~1: dead row
+      if (idx[r] == ~0ull) atomicExch(t.error, 1);
+      old[r] = 0u;
+      if (idx[r] < ~1ull) old[r] = atomicCAS(&t.head[idx[r]], 0u, static_cast<uint32_t>(base_tid + i) + 1u);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (idx[r] >= ~1ull) continue;
+      const int64_t i = ((w0 + r) << 6) + lane;
+      const uint32_t tid = static_cast<uint32_t>(base_tid + i);
+      if (old[r] != 0u) {
+        // duplicate key: push an overflow entry in front of whatever the head holds now
+        const unsigned int e = atomicAdd(t.ov_count, 1u);
+        if (e >= t.ov_capacity) {
+          atomicExch(t.error, 2);
+          continue;
         }
+        t.ov[e].x = tid;
+        // next is only read by probe kernels launched after the build (pipeline breaker)
+        t.ov[e].y = atomicExch(&t.head[idx[r]], kChainBit | e);
       }
+      ++inserted;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) key[r] = next_key[r];

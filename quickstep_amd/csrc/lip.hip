@@ -47,28 +47,34 @@ __global__ __launch_bounds__(kLBlock) void lip_build_kernel(LipView f, const Key
   for (; w0 < num_words; w0 += num_waves * R) {
     const int64_t w_next = w0 + num_waves * R;
     if (w_next < num_words) request(w_next, next_key, next_words);
+    // all R filter words are read first (unconditionally: dead lanes read word 0), then the missing bits are set with
+    // fire-and-forget atomics: one round trip per group instead of one per row
+    unsigned long long bit[R];
+    bool set_it[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((w0 + r) << 6) + lane;
       const uint64_t fw = __shfl(words, r, kWave);   // before any branch: every lane takes part
-      if (row < n && msb_bit(fw, lane)) {
-        const long long v = static_cast<long long>(key[r]);
-        unsigned long long bit = 0;
-        bool ok = true;
-        if (f.exact) {
-          const long long off = v - f.min_value;
-          ok = off >= 0 && off < f.cardinality;      // outside the declared [min, max]: cannot be represented
-          bit = static_cast<unsigned long long>(off);
-        } else {
-          // value converted to size_t first: a negative key sign-extends (SingleIdentityHashFilter.hpp:156-169)
-          bit = static_cast<unsigned long long>(v) % static_cast<unsigned long long>(f.cardinality);
-        }
-        if (ok) {
-          const unsigned long long mask = 1ull << (bit & 63);
-          unsigned long long *w = &f.words[bit >> 6];
-          if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) == 0) atomicOr(w, mask);
-        }
+      const long long v = static_cast<long long>(key[r]);
+      bool ok = row < n && msb_bit(fw, lane);
+      if (f.exact) {
+        const long long off = v - f.min_value;
+        ok = ok && off >= 0 && off < f.cardinality;      // outside the declared [min, max]: cannot be represented
+        bit[r] = static_cast<unsigned long long>(off);
+      } else {
+        // value converted to size_t first: a negative key sign-extends (SingleIdentityHashFilter.hpp:156-169)
+        bit[r] = static_cast<unsigned long long>(v) % static_cast<unsigned long long>(f.cardinality);
       }
+      if (!ok) bit[r] = 0;
+      set_it[r] = ok;
+    }
+    unsigned long long have[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) have[r] = __hip_atomic_load(&f.words[bit[r] >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const unsigned long long mask = 1ull << (bit[r] & 63);
+      if (set_it[r] && (have[r] & mask) == 0) atomicOr(&f.words[bit[r] >> 6], mask);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) key[r] = next_key[r];
