@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define QSX_ABI_VERSION 2
+#define QSX_ABI_VERSION 3
 
 typedef void *qsx_stream_t;
 
@@ -408,6 +408,10 @@ typedef struct qsx_agg_config {
   qsx_pred_term_t pred[QSX_MAX_PRED_TERMS];
   int64_t est_groups;                     /* optimizer estimate; tables grow past it */
   int64_t num_entries;                    /* COLLISION_FREE only: max_key + 1 (StarSchemaSimpleCostModel.cpp:707) */
+  int32_t column_code_width[QSX_MAX_COLUMNS]; /* 0: the column arrives as values.  1 / 2 / 4: it arrives as a stripe of
+                                             unsigned codes of that width (a compressed attribute of a
+                                             CompressedColumnStoreTupleStorageSubBlock) and qsx_agg_update_coded decodes it
+                                             while reading: INT / LONG / FLOAT / DOUBLE columns only */
 } qsx_agg_config_t;
 
 /* Counterpart of the AggregationOperationState constructor
@@ -432,6 +436,17 @@ int qsx_agg_state_clear(qsx_agg_state_t *state, qsx_stream_t stream);
  * like many AggregationWorkOrders sharing one state. */
 int qsx_agg_update(qsx_agg_state_t *state, const void *const *cols, int64_t n,
                    const uint64_t *filter_dev, qsx_stream_t stream);
+
+/* qsx_agg_update on a block whose attributes with column_code_width != 0 are compressed: cols[c] is the code
+ * stripe, dictionaries_dev[c] the block's dictionary for that attribute (values of the column's type, indexed by
+ * code; storage/CompressedTupleStorageSubBlock.hpp:60-110 compression dictionaries) or NULL when the attribute is
+ * truncation-compressed (value = code).  Replaces the per-value decode of CompressedColumnStoreValueAccessor::
+ * getUntypedValue (storage/CompressedColumnStoreValueAccessor.hpp:90-150) in front of aggregateBlock: HBM is read
+ * at the code width (Q1 over lineitem's compressed quantity / discount / tax: 13 instead of 34 bytes per row).
+ * Entries of dictionaries_dev for plain columns are ignored; dictionaries_dev may be NULL when no coded column
+ * uses a dictionary. */
+int qsx_agg_update_coded(qsx_agg_state_t *state, const void *const *cols, const void *const *dictionaries_dev,
+                         int64_t n, const uint64_t *filter_dev, qsx_stream_t stream);
 
 /* BuildAggregationExistenceMapWorkOrder::execute (relational_operators/
  * BuildAggregationExistenceMapOperator.cpp:50-67, 177-208): sets the existence bit of every (selected)

@@ -79,6 +79,7 @@ for _name, _res, _args in [
     ("qso_agg_state_destroy", None, [_vp]),
     ("qso_agg_update", None, [_vp, _pp, _i64, _vp]),
     ("qso_agg_mark_existence", None, [_vp, _int, _vp, _i64, _vp]),
+    ("qso_agg_update_coded", None, [_vp, _pp, _pp, _i64, _vp]),
     ("qso_agg_merge", None, [_vp, _vp]),
     ("qso_agg_num_groups", _i64, [_vp]),
     ("qso_agg_finalize", _i64, [_vp, _int, _int, _pp, _pp, _pp, _i64]),
@@ -403,6 +404,13 @@ class AggState:
         if n is None:
             n = cols[0].size
         _lib.qso_agg_update(self._h, _ptr_array(cols), n, _p(filter_bitmap))
+
+    def update_coded(self, cols, dictionaries, n=None, filter_bitmap=None):
+        if n is None:
+            n = len(cols[0])
+        keep = [np.ascontiguousarray(d) if d is not None else None for d in dictionaries]
+        dicts = (C.c_void_p * len(cols))(*[d.ctypes.data if d is not None else None for d in keep])
+        _lib.qso_agg_update_coded(self._h, _ptr_array(cols), dicts, n, _p(filter_bitmap))
 
     def mark_existence(self, keys, filter_bitmap=None):
         _lib.qso_agg_mark_existence(self._h, qtype(keys), _p(keys), len(keys), _p(filter_bitmap))

@@ -972,6 +972,38 @@ void qso_agg_mark_existence(qso_agg_state_t *s, int key_type, const void *keys, 
     s->existence[loc >> 6] |= (static_cast<uint64_t>(1) << (loc & 63));
   }
 }
+void qso_agg_update_coded(qso_agg_state_t *s, const void *const *cols, const void *const *dictionaries, int64_t n,
+                          const uint64_t *filter) {
+  // CompressedColumnStoreValueAccessor::getUntypedValue (storage/CompressedColumnStoreValueAccessor.hpp:90-150): a
+  // dictionary-coded attribute returns dictionary[code], a truncated one the code widened to the attribute's type.
+  const qsx_agg_config_t &c = s->c;
+  std::vector<std::vector<unsigned char>> decoded(c.num_columns);
+  std::vector<const void *> plain(c.num_columns);
+  for (int col = 0; col < c.num_columns; ++col) {
+    const int cw = c.column_code_width[col];
+    plain[col] = cols[col];
+    if (cw == 0) continue;
+    const int w = c.column_width[col];
+    decoded[col].resize(static_cast<size_t>(n) * w);
+    for (int64_t i = 0; i < n; ++i) {
+      uint32_t code = 0;
+      std::memcpy(&code, static_cast<const char *>(cols[col]) + i * cw, cw);
+      unsigned char *out = decoded[col].data() + i * w;
+      if (dictionaries != nullptr && dictionaries[col] != nullptr) {
+        std::memcpy(out, static_cast<const char *>(dictionaries[col]) + static_cast<size_t>(code) * w, w);
+      } else {
+        switch (c.column_type[col]) {
+          case QSX_INT: { const int32_t v = static_cast<int32_t>(code); std::memcpy(out, &v, 4); break; }
+          case QSX_LONG: { const int64_t v = static_cast<int64_t>(code); std::memcpy(out, &v, 8); break; }
+          case QSX_FLOAT: { const float v = static_cast<float>(code); std::memcpy(out, &v, 4); break; }
+          default: { const double v = static_cast<double>(code); std::memcpy(out, &v, 8); break; }
+        }
+      }
+    }
+    plain[col] = decoded[col].data();
+  }
+  s->update(plain.data(), n, filter);
+}
 void qso_agg_merge(qso_agg_state_t *dst, const qso_agg_state_t *src) { dst->merge_from(*src); }
 
 int64_t qso_agg_num_groups(const qso_agg_state_t *s) {

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "qsx_agg_state_clear": (_int, [_vp, _vp]),
     "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
     "qsx_agg_mark_existence": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
+    "qsx_agg_update_coded": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
     "qsx_agg_merge": (_int, [_vp, _vp, _vp]),
     "qsx_agg_state_export_bytes": (_int, [_vp, C.POINTER(_sz)]),
     "qsx_agg_state_export": (_int, [_vp, _vp, _vp]),
@@ -425,6 +426,14 @@ class AggState:
             n = cols[0].numel()
         _check(_lib.qsx_agg_update(self._h, _ptr_array(cols), n, _ptr(filter_bitmap), _stream(stream)),
                "qsx_agg_update")
+
+    def update_coded(self, cols, dictionaries, n=None, filter_bitmap=None, stream=None):
+        """cols[c] = code stripe for columns with column_code_width != 0; dictionaries[c] = dictionary tensor or None."""
+        if n is None:
+            n = cols[0].numel()
+        dicts = (C.c_void_p * len(cols))(*[d.data_ptr() if d is not None else None for d in dictionaries])
+        _check(_lib.qsx_agg_update_coded(self._h, _ptr_array(cols), dicts, n, _ptr(filter_bitmap), _stream(stream)),
+               "qsx_agg_update_coded")
 
     def mark_existence(self, keys, filter_bitmap=None, stream=None):
         _check(_lib.qsx_agg_mark_existence(self._h, qsx_type_of(keys), _ptr(keys), keys.numel(), _ptr(filter_bitmap),

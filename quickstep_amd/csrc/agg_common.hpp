@@ -82,6 +82,14 @@ struct DevConfig {
   int num_pred;
   DevPred pred[QSX_MAX_PRED_TERMS];
   const void *cols[QSX_MAX_COLUMNS];
+  // Compressed attributes (CompressedColumnStore): column c arrives as a stripe of code_width[c]-byte unsigned codes
+  // (0 = plain values).  The codes are staged like any column (same DMA, code_off[c]); once the tile has landed
+  // every thread decodes the codes of ITS rows into the column's value slots (lds_off[c]) — through dicts[c]
+  // (dictionary of column_type values; per block, so per call) or, when that is null, as the value itself
+  // (truncation).  HBM moves the codes, the value slots look like a plain column to everything downstream.
+  int code_width[QSX_MAX_COLUMNS];
+  const void *dicts[QSX_MAX_COLUMNS];
+  int code_off[QSX_MAX_COLUMNS];   // byte offset of the staged codes inside a tile (-1: plain column)
   // LDS staging plan of the hash-strategy update kernel: byte offset of column
   // c inside a staged tile (-1: column not referenced, not staged), of the
   // filter words (-1: no filter) and the size of one tile buffer.

@@ -76,16 +76,18 @@ __device__ __forceinline__ void copy_elements_to_lds(const char *src, char *dst,
 
 // Issue the HBM -> LDS copy of one tile (rows [row0, row0 + rows)).
 template <bool kStatic>
-__device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const *cols, const uint64_t *filter,
-                                           char *tile, int64_t row0, int rows) {
+__device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const *cols, const uint64_t *filter, char *tile,
+                                           int64_t row0, int rows) {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_columns, [&](int col) __attribute__((always_inline)) {
     const int off = c.lds_off[col];
     if (off < 0) return;  // column not referenced by keys / predicate / expressions
-    const int w = c.column_width[col];
+    // a compressed attribute is staged as its code stripe (decode_tile_codes fills the value slots afterwards)
+    const bool coded = c.code_width[col] != 0;
+    const int w = coded ? c.code_width[col] : c.column_width[col];
     const char *src = static_cast<const char *>(cols[col]) + row0 * w;
-    char *dst = tile + off;
+    char *dst = tile + (coded ? c.code_off[col] : off);
     const int bytes = rows * w;
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
       const int full = bytes & ~15;
@@ -103,6 +105,49 @@ __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const
     copy_elements_to_lds(reinterpret_cast<const char *>(filter + (row0 >> 6)), tile + c.filter_lds_off,
                          (rows + 63) >> 6, 8);
   }
+}
+
+// Compressed attributes: every thread turns the staged codes of its V rows into values (dictionary entry, or the code
+// itself for truncation) in the column's value slots.  Only the thread itself reads those slots afterwards (rows are
+// owned per thread), so no barrier follows; with a static configuration the dictionary reads of all coded columns are
+// in flight together.
+template <bool kStatic, int V>
+__device__ __forceinline__ void decode_tile_codes(const DevConfig &c, const void *const *dicts, char *tile, int trow, int rows) {
+  cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_columns, [&](int col) __attribute__((always_inline)) {
+    if (c.code_width[col] == 0 || c.lds_off[col] < 0) return;
+    const char *codes = tile + c.code_off[col];
+    char *slots = tile + c.lds_off[col];
+    const void *dict = dicts != nullptr ? dicts[col] : nullptr;
+    uint32_t code[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int r = trow + v * kABlock;
+      switch (c.code_width[col]) {
+        case 1: code[v] = reinterpret_cast<const uint8_t *>(codes)[r]; break;
+        case 2: code[v] = reinterpret_cast<const uint16_t *>(codes)[r]; break;
+        default: code[v] = reinterpret_cast<const uint32_t *>(codes)[r]; break;
+      }
+      if (r >= rows) code[v] = 0;   // stale LDS behind a partial tile must not index the dictionary
+    }
+    switch (c.column_type[col]) {
+      case QSX_INT:
+#pragma unroll
+        for (int v = 0; v < V; ++v) reinterpret_cast<int32_t *>(slots)[trow + v * kABlock] = dict != nullptr ? static_cast<const int32_t *>(dict)[code[v]] : static_cast<int32_t>(code[v]);
+        break;
+      case QSX_FLOAT:
+#pragma unroll
+        for (int v = 0; v < V; ++v) reinterpret_cast<float *>(slots)[trow + v * kABlock] = dict != nullptr ? static_cast<const float *>(dict)[code[v]] : static_cast<float>(code[v]);
+        break;
+      case QSX_LONG:
+#pragma unroll
+        for (int v = 0; v < V; ++v) reinterpret_cast<long long *>(slots)[trow + v * kABlock] = dict != nullptr ? static_cast<const long long *>(dict)[code[v]] : static_cast<long long>(code[v]);
+        break;
+      default:
+#pragma unroll
+        for (int v = 0; v < V; ++v) reinterpret_cast<double *>(slots)[trow + v * kABlock] = dict != nullptr ? static_cast<const double *>(dict)[code[v]] : static_cast<double>(code[v]);
+        break;
+    }
+  });
 }
 
 // ---- typed reads of a staged column ---------------------------------------------
@@ -342,7 +387,7 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
 // kDense: COLLISION_FREE sink — the group of a row is its key value, accumulators are the dense
 // arrays in HBM (DenseView), adjacent equal keys of a wave are combined before the atomics.
 template <bool kStatic, bool kDense, int NS, int V>
-__device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, int64_t n,
+__device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, const void *const *dicts, int64_t n,
                                                      const uint64_t *__restrict__ filter, const HashTableView &g,
                                                      const DenseView &dense, int S, int rep_shift, int nbuf,
                                                      int ranges, const long long *__restrict__ pieces = nullptr) {
@@ -398,11 +443,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     if (nbuf == 2 && next < num_tiles) {
       stage_tile<kStatic>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, tile_row0(next), tile_rows(next));
     }
-    const char *tile = tiles + buf * c.tile_bytes;
+    char *tile = tiles + buf * c.tile_bytes;
     if (nbuf == 2) buf ^= 1;
     const int rows = tile_rows(tile_id);
 
     const int trow = threadIdx.x;  // this thread's first row of the tile
+    decode_tile_codes<kStatic, V>(c, dicts, tile, trow, rows);
 
     // ---- which rows are live -------------------------------------------------
     bool live[V];
@@ -622,7 +668,7 @@ __global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, i
                                                                  const uint64_t *__restrict__ filter,
                                                                  HashTableView g, int S, int rep_shift, int nbuf,
                                                                  int ranges, const long long *__restrict__ pieces) {
-  agg_hash_update_body<false, false, NS, V>(c, c.cols, n, filter, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces);
+  agg_hash_update_body<false, false, NS, V>(c, c.cols, c.dicts, n, filter, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces);
 }
 
 // COLLISION_FREE (K7) through the same staged-tile body with the dense sink.
@@ -630,12 +676,13 @@ template <int NS, int V>
 __global__ __launch_bounds__(kABlock) void agg_dense_update_kernel(DevConfig c, int64_t n,
                                                                   const uint64_t *__restrict__ filter, DenseView d,
                                                                   int nbuf) {
-  agg_hash_update_body<false, true, NS, V>(c, c.cols, n, filter, HashTableView{}, d, 8, 0, nbuf, 1);
+  agg_hash_update_body<false, true, NS, V>(c, c.cols, c.dicts, n, filter, HashTableView{}, d, 8, 0, nbuf, 1);
 }
 
 struct ColumnPointers {
   const void *p[QSX_MAX_COLUMNS];
 };
+
 
 // AOT plan shape: the translated configuration is a function-local static constexpr
 // object, i.e. a true constant of the code object, so after the configuration loops are
@@ -646,7 +693,7 @@ __global__ __launch_bounds__(kABlock) void agg_hash_shape_kernel(ColumnPointers 
                                                                 int rep_shift, int nbuf, int ranges,
                                                                 const long long *__restrict__ pieces) {
   static constexpr Translated T = Shape::translated(kABlock * V);
-  agg_hash_update_body<true, false, T.num_sums, V>(T.dev, cols.p, n, nullptr, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces);
+  agg_hash_update_body<true, false, T.num_sums, V>(T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces);
 }
 
 }  // namespace qsx

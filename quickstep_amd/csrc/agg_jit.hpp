@@ -26,9 +26,9 @@ struct JitKernel;
 const JitKernel *jit_agg_kernel(const DevConfig &dev, int num_sums, bool dense, bool has_filter);
 
 // Launches it: the argument list of agg_hash_update_body.
-int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols, int64_t n,
-                   const uint64_t *filter, const HashTableView &g, const DenseView &dense, int S, int rep_shift, int nbuf,
-                   int ranges, const long long *pieces);
+int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
+                   const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g,
+                   const DenseView &dense, bool is_dense, int S, int rep_shift, int nbuf, int ranges, const long long *pieces);
 
 constexpr int kJitRowsPerThread = 4;
 

@@ -104,7 +104,10 @@ inline bool same_plan(const qsx_agg_config_t &a, const qsx_agg_config_t &b) {
     return false;
   }
   for (int i = 0; i < a.num_columns; ++i) {
-    if (a.column_type[i] != b.column_type[i] || a.column_width[i] != b.column_width[i]) return false;
+    if (a.column_type[i] != b.column_type[i] || a.column_width[i] != b.column_width[i] ||
+        a.column_code_width[i] != b.column_code_width[i]) {
+      return false;
+    }
   }
   for (int i = 0; i < a.num_keys; ++i) {
     if (a.key_column[i] != b.key_column[i]) return false;

@@ -77,6 +77,11 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
     }
     d.column_type[i] = ty;
     d.column_width[i] = w;
+    const int cw = c.column_code_width[i];
+    if (cw != 0) {   // compressed attribute: 1 / 2 / 4-byte codes of a numeric column
+      if ((cw != 1 && cw != 2 && cw != 4) || ty == QSX_CHAR) return fail(t, QSX_ERR_UNSUPPORTED);
+      d.code_width[i] = cw;
+    }
   }
   switch (c.strategy) {
     case QSX_AGG_SINGLE_STATE:
@@ -223,8 +228,14 @@ constexpr int plan_tile(DevConfig &d, unsigned used_columns, int tile_rows, bool
     if (col < d.num_columns && ((used_columns >> col) & 1u)) {
       d.lds_off[col] = static_cast<int>(off);
       off += align16_ce(static_cast<size_t>(tile_rows) * d.column_width[col]);
+      d.code_off[col] = -1;
+      if (d.code_width[col] != 0) {   // compressed attribute: the codes are staged, the slots above receive the values
+        d.code_off[col] = static_cast<int>(off);
+        off += align16_ce(static_cast<size_t>(tile_rows) * d.code_width[col]);
+      }
     } else {
       d.lds_off[col] = -1;
+      d.code_off[col] = -1;
     }
   }
   d.filter_lds_off = -1;

@@ -373,6 +373,7 @@ using namespace qsx;
 // ===========================================================================
 struct qsx_agg_state {
   qsx_agg_config_t config;
+  bool has_coded_columns = false;   // some column arrives as codes of a compressed attribute
   DevConfig dev;            // everything but cols[]
   FinalizeDesc fin;         // everything but the output pointers
   int num_sums = 0;
@@ -449,6 +450,7 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
     if (t.col_kind[col] >= kAccMinI64) st->has_min_max = true;
   }
   st->used_columns = t.used_columns;
+  for (int i = 0; i < t.dev.num_columns; ++i) st->has_coded_columns = st->has_coded_columns || t.dev.code_width[i] != 0;
   st->dense = t.dense;
   st->dense_has_count = t.dense_has_count;
   return QSX_OK;
@@ -576,22 +578,7 @@ template <int NS, int V>
 static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter,
                          const HashTableView &g, int S, int ranges, const long long *pieces, hipStream_t stream, bool dry_run) {
   constexpr int TR = kABlock * V;
-  size_t off = 0;
-  for (int col = 0; col < dc.num_columns; ++col) {
-    if ((used_columns >> col) & 1u) {
-      dc.lds_off[col] = static_cast<int>(off);
-      off += align16(static_cast<size_t>(TR) * dc.column_width[col]);
-    } else {
-      dc.lds_off[col] = -1;
-    }
-  }
-  dc.filter_lds_off = -1;
-  if (filter != nullptr) {
-    dc.filter_lds_off = static_cast<int>(off);
-    off += align16(TR / 64 * 8);
-  }
-  if (off == 0) off = 16;
-  dc.tile_bytes = static_cast<int>(off);
+  const size_t off = static_cast<size_t>(plan_tile(dc, used_columns, TR, filter != nullptr));
   plan_interpreter(dc, TR);
   // replicate every accumulator as far as the budget allows (64 = one bank column per lane)
   const AggTuning &tune = agg_tuning();
@@ -664,7 +651,11 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
   grid = grid / ranges * ranges;
   if (grid < ranges) grid = ranges;
   ColumnPointers cp;
-  for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < num_columns ? cols[i] : nullptr;
+  for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < num_columns ? cols[i] : nullptr;   // (AOT shapes: plain columns only)
+  if (getenv("QSX_DEBUG_LAUNCH") != nullptr) {
+    std::fprintf(stderr, "[qsx] shape launch grid=%d lds=%zu S=%d rep_shift=%d nbuf=%d ranges=%d tile_bytes=%d n=%lld\n", grid, lds, S,
+                 rep_shift, nbuf, ranges, T.dev.tile_bytes, static_cast<long long>(n));
+  }
   hipLaunchKernelGGL((agg_hash_shape_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g, S, rep_shift, nbuf,
                      ranges, pieces);
   return QSX_OK;
@@ -716,7 +707,7 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, int
   return st->jit[v];
 }
 
-static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, const void *const *cols, int64_t n,
+static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, const void *const *cols, const void *const *dicts, int64_t n,
                       const uint64_t *filter, int slots, int num_ranges, const long long *pieces, hipStream_t stream) {
   constexpr int TR = kABlock * kJitRowsPerThread;
   constexpr size_t kMaxLds = 160 * 1024;
@@ -745,8 +736,18 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, co
   if (grid < ranges) grid = ranges;
   ColumnPointers cp;
   for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < st->config.num_columns ? cols[i] : nullptr;
-  return jit_agg_launch(k, grid, lds, stream, cp, n, filter, st->dense ? HashTableView{} : st->hash_view(),
-                        st->dense ? st->dense_view() : DenseView{}, S, rep_shift, nbuf, ranges, pieces);
+  // the dictionaries of this call (per block) go behind a pointer: see make_source on the kernarg size
+  const void **dict_table = nullptr;
+  if (st->has_coded_columns) {
+    const void *host_table[QSX_MAX_COLUMNS];
+    for (int i = 0; i < QSX_MAX_COLUMNS; ++i) host_table[i] = i < st->config.num_columns ? dicts[i] : nullptr;
+    QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&dict_table), sizeof(host_table), stream));
+    QSX_HIP_TRY(hipMemcpyAsync(dict_table, host_table, sizeof(host_table), hipMemcpyHostToDevice, stream));
+  }
+  const int rc = jit_agg_launch(k, grid, lds, stream, cp, dict_table, n, filter, st->dense ? HashTableView{} : st->hash_view(),
+                                st->dense ? st->dense_view() : DenseView{}, st->dense, S, rep_shift, nbuf, ranges, pieces);
+  if (dict_table != nullptr) QSX_HIP_TRY(hipFreeAsync(dict_table, stream));
+  return rc;
 }
 
 template <int NS>
@@ -922,14 +923,17 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
 // One launch of the update kernel over n rows with the given LDS table geometry: AOT plan shape, then the
 // run-time one, then the interpreter (CAPACITY — the tile does not fit LDS next to the group tables — and
 // compile failures fall through).
-static int update_slice(qsx_agg_state *st, const void *const *cols, int64_t n, const uint64_t *filter_dev, int slots,
-                        int ranges, const long long *pieces, hipStream_t s) {
+static int update_slice(qsx_agg_state *st, const void *const *cols, const void *const *dicts, int64_t n,
+                        const uint64_t *filter_dev, int slots, int ranges, const long long *pieces, hipStream_t s) {
   DevConfig dc = st->dev;
-  for (int i = 0; i < st->config.num_columns; ++i) dc.cols[i] = cols[i];
+  for (int i = 0; i < st->config.num_columns; ++i) {
+    dc.cols[i] = cols[i];
+    dc.dicts[i] = (dicts != nullptr && dc.code_width[i] != 0) ? dicts[i] : nullptr;
+  }
   const bool aot = !st->dense && st->shape != nullptr && filter_dev == nullptr;
   const JitKernel *jk = aot ? nullptr : state_jit_kernel(st, filter_dev != nullptr, n);
   if (jk != nullptr) {
-    int rc = launch_jit(st, jk, filter_dev != nullptr, cols, n, filter_dev, slots, ranges, pieces, s);
+    int rc = launch_jit(st, jk, filter_dev != nullptr, cols, dc.dicts, n, filter_dev, slots, ranges, pieces, s);
     if (rc == QSX_OK && hipGetLastError() == hipSuccess) return QSX_OK;
     // the specialised kernel could not be launched: keep going with the interpreter from now on
     std::lock_guard<std::mutex> lock(st->jit_mutex);
@@ -993,7 +997,7 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
                                          dst, pieces, ws, ws_bytes, s, kAlignRows);
   if (rc == QSX_OK) {
     // n only sizes the grid here (an upper bound of every piece); the kernel reads its piece from `pieces`
-    rc = update_slice(st, part_cols, n, nullptr, st->part_slots, P, reinterpret_cast<const long long *>(pieces), s);
+    rc = update_slice(st, part_cols, nullptr, n, nullptr, st->part_slots, P, reinterpret_cast<const long long *>(pieces), s);
   }
   for (int c = 0; c < ncols; ++c) {
     if (part_cols[c] != nullptr) QSX_HIP_TRY(hipFreeAsync(part_cols[c], s));
@@ -1003,16 +1007,29 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   return rc;
 }
 
-int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev,
-                   qsx_stream_t stream) {
+static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *const *dicts, int64_t n,
+                      const uint64_t *filter_dev, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (st == nullptr || n < 0 || (n > 0 && st->config.num_columns > 0 && cols == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
   if (n == 0) return QSX_OK;
   hipStream_t s = as_stream(stream);
-  if (!st->dense && st->part_count > 1 && filter_dev == nullptr && n >= partition_min_rows()) {
+  // (the partitioned path scatters value columns: states over compressed attributes take the tile path)
+  if (!st->dense && st->part_count > 1 && filter_dev == nullptr && !st->has_coded_columns && n >= partition_min_rows()) {
     return update_partitioned(st, cols, n, s);
   }
-  return update_slice(st, cols, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s);
+  return update_slice(st, cols, dicts, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s);
+}
+
+int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev,
+                   qsx_stream_t stream) {
+  // a state declared over compressed attributes needs the dictionaries / code stripes: qsx_agg_update_coded
+  if (st != nullptr && st->has_coded_columns) return QSX_ERR_INVALID_ARGUMENT;
+  return agg_update(st, cols, nullptr, n, filter_dev, stream);
+}
+
+int qsx_agg_update_coded(qsx_agg_state_t *st, const void *const *cols, const void *const *dictionaries_dev, int64_t n,
+                         const uint64_t *filter_dev, qsx_stream_t stream) {
+  return agg_update(st, cols, dictionaries_dev, n, filter_dev, stream);
 }
 
 int qsx_agg_mark_existence(qsx_agg_state_t *st, int key_type, const void *keys_dev, int64_t n, const uint64_t *filter_dev,

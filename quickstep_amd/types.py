@@ -69,6 +69,7 @@ class AggConfig(C.Structure):
         ("pred", PredTerm * MAX_PRED_TERMS),
         ("est_groups", C.c_int64),
         ("num_entries", C.c_int64),
+        ("column_code_width", C.c_int32 * MAX_COLUMNS),
     ]
 
 
@@ -85,7 +86,7 @@ def temp(i):
 
 
 def make_agg_config(strategy, columns, keys=(), instrs=(), consts=(), aggs=(), pred=(),
-                    est_groups=0, num_entries=0):
+                    est_groups=0, num_entries=0, code_widths=None):
     """Build an AggConfig.
 
     columns: list of (type, width) — width may be None for numeric types
@@ -128,6 +129,8 @@ def make_agg_config(strategy, columns, keys=(), instrs=(), consts=(), aggs=(), p
         cfg.pred[i] = term
     cfg.est_groups = est_groups
     cfg.num_entries = num_entries
+    for i, w in enumerate(code_widths or ()):      # 0 = plain column, 1 / 2 / 4 = compressed attribute (codes)
+        cfg.column_code_width[i] = w
     return cfg
 
 

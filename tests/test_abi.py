@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(capi):
 
 def test_abi_version_and_struct_mirror(capi):
     from quickstep_amd import types as T
-    assert capi.lib.qsx_abi_version() == 2
+    assert capi.lib.qsx_abi_version() == 3
     assert capi.lib.qsx_abi_sizeof_agg_config() == ctypes.sizeof(T.AggConfig)
     assert capi.lib.qsx_status_string(0) == b"ok"
     assert b"no CPU" in capi.lib.qsx_status_string(T.ERR_NO_DEVICE)

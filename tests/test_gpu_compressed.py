@@ -87,3 +87,85 @@ def test_q1_style_aggregation_over_decoded_dictionary_columns(capi, oracle, dev)
     sel = qty < 24
     assert int(vals[1][0].item()) == int(sel.sum())
     assert np.isclose(vals[0][0].item(), (price[sel] * disc[sel]).sum(), rtol=1e-9)
+
+
+def _q1_coded_inputs(oracle, rng, n):
+    """Q1's lineitem columns as CompressedBlockBuilder would store them: quantity / discount / tax dictionary-coded in
+    one byte, the keys plain CHAR(1), extendedprice left as DOUBLE (too many distinct values), plus a truncated INT."""
+    combo = rng.choice(4, size=n, p=[0.2466, 0.0065, 0.5005, 0.2464])
+    k1 = np.frombuffer(b"ANNR", dtype=np.uint8)[combo]
+    k2 = np.frombuffer(b"FFOF", dtype=np.uint8)[combo]
+    qty = rng.integers(1, 51, size=n).astype(np.float64)
+    price = np.round(rng.uniform(900, 105000, size=n), 2)
+    disc = rng.integers(0, 11, size=n) / 100.0
+    tax = rng.integers(0, 9, size=n) / 100.0
+    lineno = rng.integers(1, 8, size=n).astype(np.int32)            # truncation-compressed: value = code
+    cols = [k1, k2, qty, price, disc, tax, lineno]
+    comp = [None, None] + [oracle.CompressedColumn(c) for c in (qty, price, disc, tax, lineno)]
+    return cols, comp
+
+
+@pytest.mark.parametrize("jit", [False, True])
+def test_q1_over_compressed_attributes_matches_oracle(capi, oracle, dev, jit, monkeypatch):
+    """qsx_agg_update_coded: the aggregation reads the code stripes (13 instead of 34 bytes per row for Q1) and decodes
+    while staging; results equal the oracle aggregating the decoded columns (and the plain-column GPU path) —
+    interpreter and run-time plan shape."""
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if jit else str(1 << 60))
+    rng = np.random.default_rng(77)
+    n = 400_003
+    cols, comp = _q1_coded_inputs(oracle, rng, n)
+    widths = [0 if c is None or c.kind == 0 else c.code_width for c in comp]
+    assert widths[2] == widths[4] == widths[5] == 1 and widths[3] == 0 and widths[6] == 1
+    assert comp[2].dictionary is not None and comp[6].dictionary is None          # dictionary vs truncation
+    layout = [(T.CHAR, 1), (T.CHAR, 1), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)]
+    kw = dict(keys=[0, 1],
+              instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0)),
+                      (T.EX_ADD, 2, T.const(0), T.col(5)), (T.EX_MUL, 3, T.temp(1), T.temp(2))],
+              consts=[1.0],
+              aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.col(3)), (T.AGG_SUM, T.temp(1)), (T.AGG_SUM, T.temp(3)),
+                    (T.AGG_AVG, T.col(4)), (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(6)), (T.AGG_MAX, T.col(4))],
+              pred=[(6, T.LT, 7)], est_groups=6)
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=widths, **kw)
+    plain_cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, **kw)
+    code_cols = [cols[i] if widths[i] == 0 else comp[i].codes for i in range(len(cols))]
+    dicts = [None if widths[i] == 0 else comp[i].dictionary for i in range(len(cols))]
+    st = capi.AggState(cfg)
+    filt = oracle.bitmap_from_bools(rng.random(n) < 0.8)
+    for lo, hi in ((0, 150_000), (150_000, n)):                    # two "blocks"; the second one under a filter
+        f = None if lo == 0 else oracle.bitmap_from_bools(oracle.bools_from_bitmap(filt, n)[lo:hi])
+        st.update_coded([to_dev(np.ascontiguousarray(c[lo:hi]), dev) for c in code_cols],
+                        [None if d is None else to_dev(d, dev) for d in dicts], hi - lo,
+                        filter_bitmap=None if f is None else bitmap_dev(f, dev))
+    o = oracle.AggState(cfg)
+    o.update_coded([np.ascontiguousarray(c[:150_000]) for c in code_cols], dicts, 150_000)
+    o.update_coded([np.ascontiguousarray(c[150_000:]) for c in code_cols], dicts, n - 150_000,
+                   filter_bitmap=oracle.bitmap_from_bools(oracle.bools_from_bitmap(filt, n)[150_000:]))
+    from test_gpu_agg import assert_same_groups, finalize_np
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+    # the decoded columns through the plain entry point give the same groups
+    o2 = oracle.AggState(plain_cfg)
+    o2.update([c[:150_000] for c in cols])
+    o2.update([c[150_000:] for c in cols], filter_bitmap=oracle.bitmap_from_bools(oracle.bools_from_bitmap(filt, n)[150_000:]))
+    assert_same_groups(o.finalize(), o2.finalize())
+    with pytest.raises(capi.QsxError):                               # a coded state needs the coded entry point
+        st.update([to_dev(c[:10], dev) for c in code_cols], 10)
+
+
+def test_dense_group_by_over_a_truncated_key(capi, oracle, dev):
+    """COLLISION_FREE state whose key attribute is truncation-compressed (2-byte codes of an INT) and whose argument is
+    dictionary-coded: keys are decoded while staging like every other column."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    key = rng.integers(0, 40_000, size=n).astype(np.int32)
+    val = rng.choice(np.array([0.25, 1.5, -3.0, 1e6, 7.0]), size=n)
+    ck, cv = oracle.CompressedColumn(key), oracle.CompressedColumn(val)
+    assert ck.code_width == 2 and ck.dictionary is None and cv.code_width == 1 and cv.dictionary is not None
+    cfg = T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None), (T.DOUBLE, None)], keys=[0],
+                            aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None), (T.AGG_MIN, T.col(1))], num_entries=40_000,
+                            code_widths=[2, 1])
+    st = capi.AggState(cfg)
+    st.update_coded([codes_dev(ck, dev), codes_dev(cv, dev)], [None, to_dev(cv.dictionary, dev)], n)
+    o = oracle.AggState(cfg)
+    o.update_coded([ck.codes, cv.codes], [None, cv.dictionary], n)
+    from test_gpu_agg import assert_same_groups, finalize_np
+    assert_same_groups(finalize_np(st, dev), o.finalize())

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Q1 aggregation over lineitem as the reference's TPC-H DDL stores it (CompressedColumnStore: quantity / discount / tax
+dictionary-coded in one byte each) against the same aggregation over plain DOUBLE columns.  usage: agg_coded_probe.py [rows_millions]"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("QSX_AGG_JIT_MIN_ROWS", "0")
+import quickstep_amd.capi as capi  # noqa: E402
+from quickstep_amd import types as T  # noqa: E402
+import bench  # noqa: E402
+
+dev = torch.device("cuda", 0)
+n = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 600_000_000
+g = torch.Generator(device=dev)
+g.manual_seed(4)
+combo = torch.multinomial(torch.tensor([0.2466, 0.0065, 0.5005, 0.2464], device=dev), n, replacement=True, generator=g)
+k1 = torch.tensor(list(b"ANNR"), dtype=torch.uint8, device=dev)[combo]
+k2 = torch.tensor(list(b"FFOF"), dtype=torch.uint8, device=dev)[combo]
+del combo
+qty_c = torch.randint(0, 50, (n,), device=dev, generator=g, dtype=torch.uint8)
+disc_c = torch.randint(0, 11, (n,), device=dev, generator=g, dtype=torch.uint8)
+tax_c = torch.randint(0, 9, (n,), device=dev, generator=g, dtype=torch.uint8)
+price = (torch.rand(n, device=dev, generator=g, dtype=torch.float64) * 104100 + 900).mul(100).round().div(100)
+qty_d = torch.arange(1, 51, device=dev, dtype=torch.float64)
+disc_d = torch.arange(0, 11, device=dev, dtype=torch.float64) / 100
+tax_d = torch.arange(0, 9, device=dev, dtype=torch.float64) / 100
+
+plain_cfg = bench.q1_config()
+coded_cfg = bench.q1_config()
+for c in (2, 4, 5):
+    coded_cfg.column_code_width[c] = 1
+
+
+def timed(fn, reps=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+res = {"rows": n}
+coded = capi.AggState(coded_cfg)
+cols_c = [k1, k2, qty_c, price, disc_c, tax_c]
+dicts = [None, None, qty_d, None, disc_d, tax_d]
+
+
+def run_coded():
+    coded.clear()
+    coded.update_coded(cols_c, dicts, n)
+
+
+res["coded_ms (13 B/row)"] = timed(run_coded)
+ck, cv, _, cg = coded.finalize(dev, capacity=16)
+qty, disc, tax = qty_d[qty_c.long()], disc_d[disc_c.long()], tax_d[tax_c.long()]
+del qty_c, disc_c, tax_c
+plain = capi.AggState(plain_cfg)
+cols_p = [k1, k2, qty, price, disc, tax]
+
+
+def run_plain():
+    plain.clear()
+    plain.update(cols_p, n)
+
+
+res["plain_ms (34 B/row)"] = timed(run_plain)
+pk, pv, _, pg = plain.finalize(dev, capacity=16)
+groups = int(pg.item())
+same = int(cg.item()) == groups
+for a in range(len(pv)):
+    x, y = cv[a][:groups].double(), pv[a][:groups].double()
+    order_x, order_y = torch.argsort(ck[0][:groups].long() * 256 + ck[1][:groups].long()), torch.argsort(pk[0][:groups].long() * 256 + pk[1][:groups].long())
+    same = same and bool(torch.allclose(x[order_x], y[order_y], rtol=1e-9, atol=0))
+res["same_result_as_plain"] = same
+res["coded_GBps_of_codes"] = 13 * n / res["coded_ms (13 B/row)"] / 1e6
+res["coded_rows_per_s"] = n / res["coded_ms (13 B/row)"] * 1e3
+res["plain_rows_per_s"] = n / res["plain_ms (34 B/row)"] * 1e3
+print(json.dumps(res))
