@@ -40,6 +40,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -343,6 +344,32 @@ __global__ __launch_bounds__(kABlock) void mark_existence_kernel(const KeyT *__r
   }
 }
 
+// A by-value kernel argument -> device memory.  The update kernels read their configuration / dictionary table through a
+// pointer (large kernarg segments slow them down); the runtime owns the lifetime of a kernel argument, unlike that of
+// a pageable host buffer handed to hipMemcpyAsync, so this is the stream-ordered way to get a host struct there.
+template <typename T>
+__global__ void store_struct_kernel(T value, T *__restrict__ dst) {
+  static_assert(sizeof(T) % 4 == 0, "word copy");
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&value);
+  uint32_t *out = reinterpret_cast<uint32_t *>(dst);
+  for (unsigned i = threadIdx.x; i < sizeof(T) / 4; i += blockDim.x) out[i] = src[i];
+}
+struct DictTable {
+  const void *p[QSX_MAX_COLUMNS];
+};
+// One device slot per (host thread, stream) for such a struct: work on one stream is ordered, so the store of the next
+// call cannot overtake the kernel still reading the slot, and no allocator is involved on the update path.
+template <typename T>
+static T *device_slot(hipStream_t stream) {
+  thread_local std::map<hipStream_t, T *> slots;
+  auto it = slots.find(stream);
+  if (it != slots.end()) return it->second;
+  T *p = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(T)) != hipSuccess) return nullptr;
+  slots.emplace(stream, p);
+  return p;
+}
+
 __global__ __launch_bounds__(kABlock) void popcount_words_kernel(const unsigned long long *__restrict__ words,
                                                                 long long num_words,
                                                                 unsigned long long *__restrict__ out) {
@@ -605,7 +632,10 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   int grid = static_cast<int>(num_tiles * ranges < max_grid ? num_tiles * ranges : max_grid);
   grid = grid / ranges * ranges;
   if (grid < ranges) grid = ranges;
-  hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S,
+  DevConfig *dc_dev = device_slot<DevConfig>(stream);   // this call's configuration (column pointers included)
+  if (dc_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  hipLaunchKernelGGL(store_struct_kernel<DevConfig>, dim3(1), dim3(256), 0, stream, dc, dc_dev);
+  hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc_dev, n, filter, g, S,
                      rep_shift, nbuf, ranges, pieces);
   return QSX_OK;
 }
@@ -739,14 +769,15 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, co
   // the dictionaries of this call (per block) go behind a pointer: see make_source on the kernarg size
   const void **dict_table = nullptr;
   if (st->has_coded_columns) {
-    const void *host_table[QSX_MAX_COLUMNS];
-    for (int i = 0; i < QSX_MAX_COLUMNS; ++i) host_table[i] = i < st->config.num_columns ? dicts[i] : nullptr;
-    QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&dict_table), sizeof(host_table), stream));
-    QSX_HIP_TRY(hipMemcpyAsync(dict_table, host_table, sizeof(host_table), hipMemcpyHostToDevice, stream));
+    DictTable host_table;
+    for (int i = 0; i < QSX_MAX_COLUMNS; ++i) host_table.p[i] = i < st->config.num_columns ? dicts[i] : nullptr;
+    DictTable *slot = device_slot<DictTable>(stream);
+    if (slot == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+    hipLaunchKernelGGL(store_struct_kernel<DictTable>, dim3(1), dim3(64), 0, stream, host_table, slot);
+    dict_table = slot->p;
   }
   const int rc = jit_agg_launch(k, grid, lds, stream, cp, dict_table, n, filter, st->dense ? HashTableView{} : st->hash_view(),
                                 st->dense ? st->dense_view() : DenseView{}, st->dense, S, rep_shift, nbuf, ranges, pieces);
-  if (dict_table != nullptr) QSX_HIP_TRY(hipFreeAsync(dict_table, stream));
   return rc;
 }
 
@@ -786,7 +817,10 @@ static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const ui
   const int64_t num_tiles = (n + TR - 1) / TR;
   const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
   const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
-  hipLaunchKernelGGL((agg_dense_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, d, nbuf);
+  DevConfig *dc_dev = device_slot<DevConfig>(stream);
+  if (dc_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  hipLaunchKernelGGL(store_struct_kernel<DevConfig>, dim3(1), dim3(256), 0, stream, dc, dc_dev);
+  hipLaunchKernelGGL((agg_dense_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc_dev, n, filter, d, nbuf);
   return QSX_OK;
 }
 

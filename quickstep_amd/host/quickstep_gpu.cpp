@@ -517,6 +517,10 @@ Type AggResultType(AggregationID id, const Type &argument) {
 }  // namespace
 
 AggregationOperationState::AggregationOperationState(const AggregationStateSpec &spec) : spec_(spec) {
+  // the library must have been built from the header this file was compiled against
+  if (qsx_abi_version() != QSX_ABI_VERSION || qsx_abi_sizeof_agg_config() != sizeof(qsx_agg_config_t)) {
+    throw ExecutionError("libqsx.so and include/qsx.h disagree on the ABI version / qsx_agg_config_t", QSX_ERR_INVALID_ARGUMENT);
+  }
   std::memset(&config_, 0, sizeof(config_));
   const CatalogRelation &rel = *spec.input_relation;
   auto column_of = [&](attribute_id attr) -> int {
