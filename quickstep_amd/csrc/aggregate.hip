@@ -344,16 +344,6 @@ __global__ __launch_bounds__(kABlock) void mark_existence_kernel(const KeyT *__r
   }
 }
 
-// A by-value kernel argument -> device memory.  The update kernels read their configuration / dictionary table through a
-// pointer (large kernarg segments slow them down); the runtime owns the lifetime of a kernel argument, unlike that of
-// a pageable host buffer handed to hipMemcpyAsync, so this is the stream-ordered way to get a host struct there.
-template <typename T>
-__global__ void store_struct_kernel(T value, T *__restrict__ dst) {
-  static_assert(sizeof(T) % 4 == 0, "word copy");
-  const uint32_t *src = reinterpret_cast<const uint32_t *>(&value);
-  uint32_t *out = reinterpret_cast<uint32_t *>(dst);
-  for (unsigned i = threadIdx.x; i < sizeof(T) / 4; i += blockDim.x) out[i] = src[i];
-}
 struct DictTable {
   const void *p[QSX_MAX_COLUMNS];
 };
