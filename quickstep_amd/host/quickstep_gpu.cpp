@@ -580,6 +580,7 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
 
 AggregationOperationState::~AggregationOperationState() {
   if (state_ != nullptr) qsx_agg_state_destroy(state_);
+  if (coded_state_ != nullptr) qsx_agg_state_destroy(coded_state_);
 }
 
 void AggregationOperationState::aggregateBlock(const StorageBlock &block, const std::uint64_t *lip_filter) {
@@ -617,6 +618,46 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
     qsx_device_free(selected);
   }
   if (state_ == nullptr) return;
+  // A block with compressed operand attributes whose values have not been materialised: aggregate on the codes.
+  // (Key and predicate columns of the state take the value path here: stripe() decodes them once per block.)
+  int code_width[QSX_MAX_COLUMNS] = {};
+  bool any_coded = false;
+  for (std::size_t i = 0; i < column_attr_.size(); ++i) {
+    const CompressedAttribute *ca = block.compressedAttribute(column_attr_[i]);
+    const int type = config_.column_type[i];
+    if (ca != nullptr && type != kChar && !block.valuesMaterialized(column_attr_[i])) {
+      code_width[i] = ca->code_width;
+      any_coded = true;
+    }
+  }
+  if (any_coded && n > 0) {
+    bool use_coded = false;
+    {
+      std::lock_guard<std::mutex> lock(coded_mutex_);
+      if (coded_state_ == nullptr && !coded_merged_) {
+        coded_config_ = config_;
+        for (std::size_t i = 0; i < column_attr_.size(); ++i) coded_config_.column_code_width[i] = code_width[i];
+        CheckStatus(qsx_agg_state_create(&coded_config_, &coded_state_), "qsx_agg_state_create");
+      }
+      if (coded_state_ != nullptr && !coded_merged_) {
+        use_coded = true;
+        for (std::size_t i = 0; i < column_attr_.size(); ++i) use_coded = use_coded && coded_config_.column_code_width[i] == code_width[i];
+      }
+    }
+    if (use_coded) {
+      const void *cols[QSX_MAX_COLUMNS];
+      const void *dicts[QSX_MAX_COLUMNS];
+      for (std::size_t i = 0; i < column_attr_.size(); ++i) {
+        const CompressedAttribute *ca = code_width[i] != 0 ? block.compressedAttribute(column_attr_[i]) : nullptr;
+        cols[i] = ca != nullptr ? ca->codes : block.stripe(column_attr_[i]);
+        dicts[i] = ca != nullptr && ca->kind == CompressedAttribute::kDictionary ? ca->dictionary : nullptr;
+      }
+      CheckStatus(qsx_agg_update_coded(coded_state_, cols, dicts, n, lip_filter, CurrentStream()), "qsx_agg_update_coded");
+      ++coded_blocks_;
+      CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+      return;
+    }
+  }
   const void *cols[QSX_MAX_COLUMNS];
   for (std::size_t i = 0; i < column_attr_.size(); ++i) cols[i] = block.stripe(column_attr_[i]);
   CheckStatus(qsx_agg_update(state_, cols, n, lip_filter, CurrentStream()), "qsx_agg_update");
@@ -794,6 +835,14 @@ void AggregationOperationState::buildExistenceMap(const StorageBlock &block, att
 }
 
 void AggregationOperationState::finalizeAggregate(std::size_t partition, std::size_t num_partitions, InsertDestination *dest) {
+  {   // the state fed by compressed blocks joins the other one (same image layout: mergeFrom semantics)
+    std::lock_guard<std::mutex> lock(coded_mutex_);
+    if (coded_state_ != nullptr && !coded_merged_) {
+      CheckStatus(qsx_agg_merge(state_, coded_state_, CurrentStream()), "qsx_agg_merge");
+      CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+    }
+    coded_merged_ = true;
+  }
   if (!distinctify_.empty()) {
     // the distinctify tables are drained by one work order; the others of a partitioned finalize have nothing to emit
     if (partition == 0) finalizeWithDistinct(dest);

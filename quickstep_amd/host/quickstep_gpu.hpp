@@ -317,11 +317,21 @@ class AggregationOperationState {
   // (BuildAggregationExistenceMapOperator.cpp:177-208); the state must use QSX_AGG_COLLISION_FREE
   void buildExistenceMap(const StorageBlock &block, attribute_id build_attribute, const Type &type);
   const AggregationStateSpec &spec() const { return spec_; }
+  // blocks aggregated on their code stripes (qsx_agg_update_coded) rather than on decoded values
+  std::int64_t numBlocksAggregatedOnCodes() const { return coded_blocks_.load(); }
 
  private:
   AggregationStateSpec spec_;
   qsx_agg_config_t config_;
   qsx_agg_state_t *state_ = nullptr;       // the non-DISTINCT aggregates; nullptr when every aggregate is DISTINCT (all_distinct_)
+  // Blocks of a compressed column store: a second state of the same shape whose operand columns are declared as code
+  // stripes (qsx_agg_update_coded reads the codes and decodes on the fly); created for the coding of the first such
+  // block, blocks coded differently take the value path; merged into state_ before the first finalize.
+  qsx_agg_state_t *coded_state_ = nullptr;
+  qsx_agg_config_t coded_config_;
+  bool coded_merged_ = false;
+  std::mutex coded_mutex_;
+  std::atomic<std::int64_t> coded_blocks_{0};
   std::vector<attribute_id> column_attr_;  // config column -> input attribute
   std::vector<int> main_agg_;              // spec aggregate -> aggregate of config_ (-1: DISTINCT)
   // one per DISTINCT aggregate: distinctify_hashtables_ (AggregationOperationState.cpp:172-207), kept as the distinct

@@ -115,6 +115,8 @@ Output run(const Lineitem &li, bool compressed, bool use_foreman) {
       fetchAndExecuteWorkOrders(op, &ctx, &storage);
     }
   }
+  // compressed blocks are aggregated on their code stripes (key, predicate and argument attributes all coded here)
+  EXPECT_TRUE((ctx.getAggregationState(state, 0)->numBlocksAggregatedOnCodes() > 0) == compressed);
   Output out;
   for (block_id b : ctx.getInsertDestination(sel_dest)->getTouchedBlocks()) {
     BlockReference blk = storage.getBlock(b);
