@@ -18,7 +18,7 @@ import torch  # noqa: F401  (imported first so that libqsx binds to the HIP runt
 from . import types as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqsx.so")
+LIB_PATH = os.environ.get("QSX_LIB_PATH") or os.path.join(_HERE, "lib", "libqsx.so")   # override: A/B runs of two builds
 
 
 class QsxError(RuntimeError):

@@ -622,10 +622,7 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   int grid = static_cast<int>(num_tiles * ranges < max_grid ? num_tiles * ranges : max_grid);
   grid = grid / ranges * ranges;
   if (grid < ranges) grid = ranges;
-  DevConfig *dc_dev = device_slot<DevConfig>(stream);   // this call's configuration (column pointers included)
-  if (dc_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
-  hipLaunchKernelGGL(store_struct_kernel<DevConfig>, dim3(1), dim3(256), 0, stream, dc, dc_dev);
-  hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc_dev, n, filter, g, S,
+  hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S,
                      rep_shift, nbuf, ranges, pieces);
   return QSX_OK;
 }
@@ -807,10 +804,7 @@ static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const ui
   const int64_t num_tiles = (n + TR - 1) / TR;
   const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
   const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
-  DevConfig *dc_dev = device_slot<DevConfig>(stream);
-  if (dc_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
-  hipLaunchKernelGGL(store_struct_kernel<DevConfig>, dim3(1), dim3(256), 0, stream, dc, dc_dev);
-  hipLaunchKernelGGL((agg_dense_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc_dev, n, filter, d, nbuf);
+  hipLaunchKernelGGL((agg_dense_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, d, nbuf);
   return QSX_OK;
 }
 

@@ -28,14 +28,24 @@ def timed(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
-for label, env in (("plan shape", None), ("interpreter", "1")):
-    if env:
-        os.environ["QSX_AGG_NO_SPECIALIZE"] = env
-    st = capi.AggState(q1_config())
+for label, env in (("plan shape", None), ("interpreter", "1"), ("run-time shape", "jit")):
+    # NO_SPECIALIZE must stay set while the state is UPDATED: it also gates the run-time plan shape (an earlier version
+    # of this script dropped it after creation and its "interpreter" line timed the hipRTC kernel)
     os.environ.pop("QSX_AGG_NO_SPECIALIZE", None)
+    os.environ.pop("QSX_AGG_JIT_MIN_ROWS", None)
+    if env == "1":
+        os.environ["QSX_AGG_NO_SPECIALIZE"] = "1"
+    st = capi.AggState(q1_config()) if env != "jit" else None
+    if env == "jit":
+        os.environ["QSX_AGG_NO_SPECIALIZE"] = "1"
+        st = capi.AggState(q1_config())          # no AOT shape picked at creation ...
+        os.environ.pop("QSX_AGG_NO_SPECIALIZE", None)
+        os.environ["QSX_AGG_JIT_MIN_ROWS"] = "0"  # ... and the hipRTC shape from the first update
     ms = timed(lambda: st.update(cols, n))
     print(f"Q1 {label:12s} {ms:8.3f} ms  {34 * n / ms / 1e6:8.1f} GB/s  {34 * n / ms / 1e6 / 80:5.1f} % of 8 TB/s")
-# Q1 with MIN/MAX instead of two of the sums (no plan shape exists: always the interpreter)
+# Q1 with MIN/MAX instead of two of the sums (no AOT plan shape exists), interpreted
+os.environ.pop("QSX_AGG_JIT_MIN_ROWS", None)
+os.environ["QSX_AGG_NO_SPECIALIZE"] = "1"
 cfg = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.CHAR, 1), (T.CHAR, 1)] + [(T.DOUBLE, None)] * 4, keys=[0, 1],
                         instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0))], consts=[1.0],
                         aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_MIN, T.col(3)), (T.AGG_MAX, T.temp(1)), (T.AGG_AVG, T.col(5)),
