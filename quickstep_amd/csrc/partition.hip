@@ -200,14 +200,29 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(Loader load_
   if (threadIdx.x < P) s_glob[threadIdx.x] = starts[static_cast<int64_t>(threadIdx.x) * G + blockIdx.x];
   const int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
   const int64_t end = begin + rows_per_block < n ? begin + rows_per_block : n;
+  // the keys of the NEXT tile are requested before the current tile goes through its rank / stage / copy phases (each
+  // of them ends in a barrier): one exposed round trip less per tile
+  using KeyValue = decltype(load_key(static_cast<int64_t>(0)));
+  KeyValue key[kPSteps], next_key[kPSteps];
+#pragma unroll
+  for (int j = 0; j < kPSteps; ++j) {
+    const int64_t r = begin + j * kPBlock + threadIdx.x;
+    key[j] = r < end ? load_key(r) : KeyValue();
+  }
   for (int64_t tile = begin; tile < end; tile += kPTile) {
     const int tile_rows = static_cast<int>(end - tile < kPTile ? end - tile : kPTile);
     int64_t row[kPSteps];
     int pid[kPSteps], pos[kPSteps];
 #pragma unroll
     for (int j = 0; j < kPSteps; ++j) {
+      const int64_t r = tile + kPTile + j * kPBlock + threadIdx.x;
+      next_key[j] = r < end ? load_key(r) : KeyValue();
+    }
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
       row[j] = tile + j * kPBlock + threadIdx.x;
-      pid[j] = row[j] < end ? partition_of<MODE>(load_key(row[j]), P, pow2) : -1;
+      pid[j] = row[j] < end ? partition_of<MODE>(key[j], P, pow2) : -1;
+      key[j] = next_key[j];
     }
     constexpr bool kUnordered = MODE == 1 && !kSmallP;
     if (kUnordered) {
