@@ -82,27 +82,23 @@ __device__ __forceinline__ int partition_of(unsigned long long h, int P, int pow
 // chain (the general loop walks the partitions present one at a time through a shuffle).
 template <bool kSmallP>
 __device__ __forceinline__ void step_ranks(int pid, int P, int &rank, int &count_in_lane) {
+  // Bit-sliced match: one ballot per bit of the partition number.  A lane's peers are the lanes that agree with it on
+  // every bit; lane p counts partition p by agreeing with its own lane number instead.  log2(P) ballots whatever the
+  // number of partitions present (the previous general path walked them one by one: 3.15 ms per 100 M rows at P = 64).
   const int lane = lane_id();
-  rank = 0;
-  count_in_lane = 0;
-  if (kSmallP) {
+  const uint64_t live = __ballot(pid >= 0);
+  uint64_t peers = live, mine = live;
+  const int bits = kSmallP ? 3 : (P <= 16 ? 4 : (P <= 32 ? 5 : 6));
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const uint64_t m = __ballot(pid == p);
-      if (pid == p) rank = rank_below(m);
-      if (lane == p) count_in_lane = __popcll(m);
-    }
-  } else {
-    uint64_t remaining = __ballot(pid >= 0);
-    while (remaining != 0) {
-      const int leader = __ffsll(static_cast<long long>(remaining)) - 1;
-      const int cur = __shfl(pid, leader, kWave);
-      const uint64_t m = __ballot(pid == cur);
-      if (pid == cur) rank = rank_below(m);
-      if (lane == cur) count_in_lane = __popcll(m);
-      remaining &= ~m;
+  for (int b = 0; b < 6; ++b) {
+    if (b < bits) {
+      const uint64_t set = __ballot(pid >= 0 && ((pid >> b) & 1));
+      peers &= ((pid >> b) & 1) ? set : ~set;
+      mine &= ((lane >> b) & 1) ? set : ~set;
     }
   }
+  rank = pid >= 0 ? rank_below(peers) : 0;
+  count_in_lane = lane < P ? __popcll(mine) : 0;
 }
 
 struct ScatterArgs {
