@@ -10,6 +10,8 @@
 // A merge of sorted runs is the same sort over their concatenation (a radix pass costs what a merge pass costs).
 
 #include "common.hpp"
+
+#include <algorithm>
 #include "partition.hpp"
 
 namespace qsx {
@@ -55,15 +57,21 @@ __global__ __launch_bounds__(kSBlock) void sort_keys_kernel(const T *__restrict_
 // instead of 6-11 scatter passes over all rows per key.
 constexpr int kTopBins = 4096;
 
+// Histogram of the next `bits` bits (below the `prefix_bits` leading bits already fixed) of key 0's image, over the
+// rows whose leading bits equal `prefix`.
 template <typename T>
 __global__ __launch_bounds__(kSBlock) void topk_hist_kernel(const T *__restrict__ col, int64_t n, int type, int descending,
+                                                           int prefix_bits, unsigned long long prefix, int bits,
                                                            unsigned long long *__restrict__ hist) {
   __shared__ unsigned int s_hist[kTopBins];
   for (int i = threadIdx.x; i < kTopBins; i += kSBlock) s_hist[i] = 0;
   __syncthreads();
+  constexpr int kWidth = static_cast<int>(sizeof(T)) * 8;
+  const int shift = kWidth - prefix_bits - bits;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kSBlock) {
     const unsigned long long k = ordered_image<T>(col[i], type, descending);
-    atomicAdd(&s_hist[k >> (sizeof(T) * 8 - 12)], 1u);
+    const bool in_prefix = prefix_bits == 0 || (k >> (kWidth - prefix_bits)) == prefix;
+    if (in_prefix) atomicAdd(&s_hist[(k >> shift) & ((1u << bits) - 1u)], 1u);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kTopBins; i += kSBlock) {
@@ -71,10 +79,12 @@ __global__ __launch_bounds__(kSBlock) void topk_hist_kernel(const T *__restrict_
   }
 }
 
-// control[0] = threshold bin (smallest t with count(bins <= t) >= k), control[1] = that count.  One wave: lane L sums
-// bins [64 L, 64 L + 64), a wave scan finds the lane whose range holds the k-th row, that lane walks its 64 bins.
+// `below` rows sort before every row of the prefix.  control[0] = threshold bin t (smallest with below + count(bins <= t)
+// >= k), control[1] = below + count(bins <= t) (the candidates when the selection stops here), control[2] = below +
+// count(bins < t) (the rows in front of bin t: `below` of the next level).  One wave: lane L sums bins [64 L, 64 L + 64),
+// a wave scan finds the lane whose range holds the k-th row, that lane walks its 64 bins.
 __global__ __launch_bounds__(kWave) void topk_threshold_kernel(const unsigned long long *__restrict__ hist, long long k,
-                                                              long long *__restrict__ control) {
+                                                              long long below, long long *__restrict__ control) {
   constexpr int kPerLane = kTopBins / kWave;
   const int lane = lane_id();
   unsigned long long mine = 0;
@@ -86,36 +96,37 @@ __global__ __launch_bounds__(kWave) void topk_threshold_kernel(const unsigned lo
     const unsigned long long up = __shfl_up(incl, off, kWave);
     if (lane >= off) incl += up;
   }
-  const unsigned long long want = static_cast<unsigned long long>(k);
+  const unsigned long long want = static_cast<unsigned long long>(k - below);   // >= 1: the k-th row lies in this prefix
   const unsigned long long before = incl - mine;
   const uint64_t reached = __ballot(incl >= want);
-  if (reached == 0) {   // k exceeds the row count: everything is a candidate
-    if (lane == kWave - 1) { control[0] = kTopBins - 1; control[1] = static_cast<long long>(incl); }
+  if (reached == 0) {   // cannot happen for k <= n; keep everything
+    if (lane == kWave - 1) { control[0] = kTopBins - 1; control[1] = below + static_cast<long long>(incl); control[2] = below; }
     return;
   }
   if (lane == __ffsll(static_cast<long long>(reached)) - 1) {
     unsigned long long cum = before;
     int t = lane * kPerLane;
     for (; t < (lane + 1) * kPerLane; ++t) {
+      if (cum + hist[t] >= want) break;
       cum += hist[t];
-      if (cum >= want) break;
     }
     control[0] = t;
-    control[1] = static_cast<long long>(cum);
+    control[1] = below + static_cast<long long>(cum + hist[t]);
+    control[2] = below + static_cast<long long>(cum);
   }
 }
 
+// keep = the leading `bits` bits of the image are <= limit
 template <typename T>
 __global__ __launch_bounds__(kSBlock) void topk_mark_kernel(const T *__restrict__ col, int64_t n, int type, int descending,
-                                                           const long long *__restrict__ control, uint64_t *__restrict__ bitmap) {
-  const unsigned long long threshold = static_cast<unsigned long long>(control[0]);
+                                                           int bits, unsigned long long limit, uint64_t *__restrict__ bitmap) {
   const int64_t num_words = (n + 63) >> 6;
   const int lane = lane_id();
   for (int64_t w = static_cast<int64_t>(blockIdx.x) * (kSBlock / kWave) + (threadIdx.x >> 6); w < num_words;
        w += static_cast<int64_t>(gridDim.x) * (kSBlock / kWave)) {
     const int64_t row = (w << 6) + lane;
     bool keep = false;
-    if (row < n) keep = (ordered_image<T>(col[row], type, descending) >> (sizeof(T) * 8 - 12)) <= threshold;
+    if (row < n) keep = (ordered_image<T>(col[row], type, descending) >> (sizeof(T) * 8 - bits)) <= limit;
     const uint64_t word = msb_first(__ballot(keep));
     if (lane == 0) bitmap[w] = word;
   }
@@ -278,27 +289,50 @@ int qsx_sort_top_k(int nkeys, const void *const *key_cols, const int32_t *key_ty
   int64_t m = n;
   bool selected = false;
   if (n >= 65536 && k <= n / 64 && key_types[0] != QSX_CHAR) {
-    // threshold selection on key 0
+    // threshold selection on key 0, refined 12 bits at a time while the threshold bin still holds too many rows
+    // (keys that share their leading bits: doubles in [0, 1), small integers)
     const int type = key_types[0];
     const int desc = descending != nullptr && descending[0] != 0 ? 1 : 0;
+    const bool narrow = type == QSX_INT || type == QSX_FLOAT;
+    const int width = narrow ? 32 : 64;
     const int grid = grid_for(n, kSBlock * 8);
-    QSX_HIP_TRY(hipMemsetAsync(hist, 0, kTopBins * 8 + 64, s));
-    if (type == QSX_INT || type == QSX_FLOAT) {
-      hipLaunchKernelGGL(topk_hist_kernel<uint32_t>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const uint32_t *>(key_cols[0]), n, type, desc, hist);
-      hipLaunchKernelGGL(topk_threshold_kernel, dim3(1), dim3(64), 0, s, hist, static_cast<long long>(k), control);
-      hipLaunchKernelGGL(topk_mark_kernel<uint32_t>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const uint32_t *>(key_cols[0]), n, type, desc, control, bitmap);
-    } else {
-      hipLaunchKernelGGL(topk_hist_kernel<unsigned long long>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const unsigned long long *>(key_cols[0]), n, type, desc, hist);
-      hipLaunchKernelGGL(topk_threshold_kernel, dim3(1), dim3(64), 0, s, hist, static_cast<long long>(k), control);
-      hipLaunchKernelGGL(topk_mark_kernel<unsigned long long>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const unsigned long long *>(key_cols[0]), n, type, desc, control, bitmap);
+    const int64_t good_enough = std::max<int64_t>(std::max<int64_t>(4 * k, 65536), n / 1024);
+    int prefix_bits = 0;
+    unsigned long long prefix = 0;
+    long long below = 0;
+    long long host_control[3] = {0, 0, 0};
+    for (int level = 0; level < 5 && prefix_bits < width; ++level) {
+      const int bits = width - prefix_bits < 12 ? width - prefix_bits : 12;
+      QSX_HIP_TRY(hipMemsetAsync(hist, 0, kTopBins * 8 + 64, s));
+      if (narrow) {
+        hipLaunchKernelGGL(topk_hist_kernel<uint32_t>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const uint32_t *>(key_cols[0]), n,
+                           type, desc, prefix_bits, prefix, bits, hist);
+      } else {
+        hipLaunchKernelGGL(topk_hist_kernel<unsigned long long>, dim3(grid), dim3(kSBlock), 0, s,
+                           static_cast<const unsigned long long *>(key_cols[0]), n, type, desc, prefix_bits, prefix, bits, hist);
+      }
+      hipLaunchKernelGGL(topk_threshold_kernel, dim3(1), dim3(64), 0, s, hist, static_cast<long long>(k), below, control);
+      QSX_CHECK_LAUNCH();
+      QSX_HIP_TRY(hipMemcpyAsync(host_control, control, sizeof(host_control), hipMemcpyDeviceToHost, s));
+      QSX_HIP_TRY(hipStreamSynchronize(s));
+      prefix = (prefix << bits) | static_cast<unsigned long long>(host_control[0]);
+      prefix_bits += bits;
+      below = host_control[2];
+      if (host_control[1] <= good_enough) break;
     }
-    QSX_CHECK_LAUNCH();
-    long long host_control[2] = {0, 0};
-    QSX_HIP_TRY(hipMemcpyAsync(host_control, control, sizeof(host_control), hipMemcpyDeviceToHost, s));
-    QSX_HIP_TRY(hipStreamSynchronize(s));
+    if (host_control[1] >= k && host_control[1] <= n / 2) {
+      if (narrow) {
+        hipLaunchKernelGGL(topk_mark_kernel<uint32_t>, dim3(grid), dim3(kSBlock), 0, s, static_cast<const uint32_t *>(key_cols[0]), n,
+                           type, desc, prefix_bits, prefix, bitmap);
+      } else {
+        hipLaunchKernelGGL(topk_mark_kernel<unsigned long long>, dim3(grid), dim3(kSBlock), 0, s,
+                           static_cast<const unsigned long long *>(key_cols[0]), n, type, desc, prefix_bits, prefix, bitmap);
+      }
+      QSX_CHECK_LAUNCH();
+    }
     if (host_control[1] >= k && host_control[1] <= n / 2) {
       // candidates in input order (ties of the final sort keep the input order, like a stable sort of everything)
-      int64_t *count_dev = reinterpret_cast<int64_t *>(control + 2);
+      int64_t *count_dev = reinterpret_cast<int64_t *>(control + 4);
       rc = qsx_bitmap_to_tids(bitmap, n, 0, tids_a, count_dev, compact_ws, ws.compact, stream);
       if (rc != QSX_OK) return rc;
       m = host_control[1];

@@ -66,6 +66,8 @@ def test_top_k_is_the_head_of_the_full_sort(capi, oracle, dev, n, k):
         "skewed int": np.where(rng.random(n) < 0.9, 7, rng.integers(-1000, 1000, size=n)).astype(np.int32),
         "ties int64": rng.integers(0, 5, size=n).astype(np.int64) * (1 << 40),
         "float32 signed": (rng.normal(size=n) * 1e3).astype(np.float32),
+        "doubles in [0, 1) (shared leading bits: refined threshold)": rng.random(n),
+        "small int64 (leading 40 bits equal)": rng.integers(0, 1 << 20, size=n).astype(np.int64),
     }
     second = rng.integers(0, 100, size=n).astype(np.int32)
     for name, col in cols.items():
