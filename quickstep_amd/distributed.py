@@ -137,15 +137,24 @@ class BroadcastHashJoin:
         sizes = [int(x.item()) for x in sizes]
         bases = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(bases, torch.tensor([tid_base], dtype=torch.int64, device=keys.device), group=self.group)
+        bases = [int(b.item()) for b in bases]
+        self.table.clear()
+        contiguous = len(set(sizes)) == 1 and all(bases[r] == bases[0] + r * sizes[0] for r in range(world))
+        if contiguous and sizes[0] > 0:
+            # equal shares whose global tids follow one another (the block-round-robin layout): the gathered buffer IS
+            # the build relation in tid order -> one gather into one tensor, one build
+            everything = torch.empty(world * sizes[0], dtype=keys.dtype, device=keys.device)
+            dist.all_gather_into_tensor(everything, keys.contiguous(), group=self.group)
+            self.table.build(everything, base_tid=bases[0])
+            return sum(sizes)
         pad = max(sizes)
         mine = torch.zeros(pad, dtype=keys.dtype, device=keys.device)
         mine[:keys.numel()] = keys
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine, group=self.group)
-        self.table.clear()
         for r in range(world):                              # the stored reference is the GLOBAL build tid
             if sizes[r]:
-                self.table.build(gathered[r][:sizes[r]], base_tid=int(bases[r].item()))
+                self.table.build(gathered[r][:sizes[r]], base_tid=bases[r])
         return sum(sizes)
 
     def probe(self, keys, tid_base, capacity=None):

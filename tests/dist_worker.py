@@ -109,6 +109,15 @@ def main():
     np.savez(os.path.join(out_dir, f"bcast_rank{rank}.npz"), build_keys=build_keys, probe_keys=probe_keys,
              pairs_probe=gp3.numpy(), pairs_build=gb3.numpy())
 
+    # uneven shares (the general path: padded all-gather, one build per source rank with its own tid base)
+    mine = build_keys[: n_build - 37 * rank]
+    join4 = qd.BroadcastHashJoin(OracleOps, T.INT, n_build * world)
+    assert join4.build(torch.from_numpy(mine), rank * n_build) == sum(n_build - 37 * r for r in range(world))
+    _, _, op4, ob4, cnt4 = join4.probe(torch.from_numpy(probe_keys), rank * n_probe)
+    gp4, gb4 = join4.materialize(None, None, op4, ob4, cnt4)
+    np.savez(os.path.join(out_dir, f"bcast_uneven_rank{rank}.npz"), build_keys=mine, probe_keys=probe_keys,
+             pairs_probe=gp4.numpy(), pairs_build=gb4.numpy())
+
     # partial aggregate merge
     vals = [(int(g), int(v)) for g, v in zip(rng.integers(0, 16, size=1000), rng.integers(0, 100, size=1000))]
     st = FakeAggState(vals)

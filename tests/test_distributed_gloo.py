@@ -30,6 +30,24 @@ def test_partitioned_join_and_merge_two_ranks(tmp_path, oracle):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for prefix in ("rank", "dense_rank", "bcast_rank"):
         _check_partitioned_join(oracle, tmp_path, world, prefix, on_owner_rank=prefix != "bcast_rank")
+    _check_uneven_broadcast(oracle, tmp_path, world)
+
+
+def _check_uneven_broadcast(oracle, tmp_path, world):
+    """Ranks hold different numbers of build rows: global build tid = rank * 5000 + local row (the tid base each rank passed)."""
+    ranks = [np.load(tmp_path / f"bcast_uneven_rank{i}.npz") for i in range(world)]
+    stride = 5000
+    probe = np.concatenate([d["probe_keys"] for d in ranks])
+    got = np.concatenate([np.stack([d["pairs_probe"], d["pairs_build"]], 1) for d in ranks])
+    want = []
+    for r, d in enumerate(ranks):                      # the single-node join, one build slice at a time
+        t = oracle.JoinTable(T.INT, d["build_keys"].size)
+        t.build(d["build_keys"])
+        p, b = t.probe(probe)
+        want.append(np.stack([p, b + r * stride], 1))
+    want = np.concatenate(want)
+    key = lambda a: a[np.lexsort((a[:, 1], a[:, 0]))]  # noqa: E731
+    assert np.array_equal(key(got), key(want))
 
 
 def _check_partitioned_join(oracle, tmp_path, world, prefix, on_owner_rank=True):
