@@ -131,13 +131,12 @@ class BroadcastHashJoin:
 
     def build(self, keys, tid_base):
         world = dist.get_world_size(self.group)
-        n = torch.tensor([keys.numel()], dtype=torch.int64, device=keys.device)
-        sizes = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(sizes, n, group=self.group)
-        sizes = [int(x.item()) for x in sizes]
-        bases = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(bases, torch.tensor([tid_base], dtype=torch.int64, device=keys.device), group=self.group)
-        bases = [int(b.item()) for b in bases]
+        # (row count, tid base) of every rank: one collective, one host synchronisation
+        mine_meta = torch.tensor([keys.numel(), tid_base], dtype=torch.int64, device=keys.device)
+        meta = torch.empty(2 * world, dtype=torch.int64, device=keys.device)
+        dist.all_gather_into_tensor(meta, mine_meta, group=self.group)
+        meta = meta.cpu().tolist()
+        sizes, bases = meta[0::2], meta[1::2]
         self.table.clear()
         contiguous = len(set(sizes)) == 1 and all(bases[r] == bases[0] + r * sizes[0] for r in range(world))
         if contiguous and sizes[0] > 0:
