@@ -295,7 +295,12 @@ int qsx_join_build(qsx_join_table_t *table, const void *keys_dev, int64_t n,
  *                  exceeds capacity; pairs beyond capacity are not written —
  *                  the caller compares and re-runs with a larger buffer)
  * Pair order is unspecified (reference: unordered_map iteration order,
- * HashJoinOperator.cpp:480). */
+ * HashJoinOperator.cpp:480).  (A directly addressed table probed under a filter
+ * runs count / scan / write passes and happens to emit the pairs in probe-row
+ * order; QSX_JOIN_TWO_PASS=1 / 0 forces that form on / off.)  When the build key
+ * is unique — what impliesUniqueAttributes tells the reference's optimizer — the
+ * number of probe rows that pass the filter bounds the output, so no counting
+ * call is needed to size the arrays. */
 int qsx_join_probe(qsx_join_table_t *table, const void *keys_dev, int64_t n,
                    int32_t probe_base_tid, const uint64_t *filter_dev,
                    int32_t *out_probe_tid_dev, int32_t *out_build_tid_dev,
