@@ -289,22 +289,37 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(Loader load_
 // output (so that a consumer can DMA 16-byte chunks of any column straight out of a piece); the gaps are never
 // read.  Rewrites the (partition, workgroup) start cells in place and publishes pieces[p] = start row,
 // pieces[P + p] = row count.
-__global__ __launch_bounds__(kPBlock) void align_starts_kernel(int64_t *__restrict__ starts, int P, int64_t G, int64_t n, int align,
+__global__ __launch_bounds__(1024) void align_starts_kernel(int64_t *__restrict__ starts, int P, int64_t G, int64_t n, int align,
                                                               int64_t *__restrict__ pieces) {
   __shared__ long long s_shift[kWave];
-  if (threadIdx.x == 0) {
-    long long next = 0;
-    for (int p = 0; p < P; ++p) {
-      const long long begin = starts[static_cast<int64_t>(p) * G];
+  if (threadIdx.x < kWave) {   // wave 0: lane p owns partition p; aligned starts = exclusive scan of the padded sizes
+    const int p = threadIdx.x;
+    long long begin = 0, size = 0;
+    if (p < P) {
+      begin = starts[static_cast<int64_t>(p) * G];
       const long long end = p + 1 < P ? starts[static_cast<int64_t>(p + 1) * G] : n;
+      size = end - begin;
+    }
+    const long long padded = (size + align - 1) / align * align;
+    long long incl = padded;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const long long up = __shfl_up(incl, off, kWave);
+      if (p >= off) incl += up;
+    }
+    const long long next = incl - padded;
+    if (p < P) {
       s_shift[p] = next - begin;
       pieces[p] = next;
-      pieces[P + p] = end - begin;
-      next = (next + (end - begin) + align - 1) / align * align;
+      pieces[P + p] = size;
     }
   }
   __syncthreads();
-  for (int64_t i = threadIdx.x; i < static_cast<int64_t>(P) * G; i += kPBlock) starts[i] += s_shift[i / G];
+  // (one workgroup: every shift depends on the unshifted first cell of two partitions)
+  for (int p = 0; p < P; ++p) {
+    const long long shift = s_shift[p];
+    for (int64_t g = threadIdx.x; g < G; g += blockDim.x) starts[static_cast<int64_t>(p) * G + g] += shift;
+  }
 }
 
 static size_t p_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -345,7 +360,7 @@ static int launch_partition_t(Loader keys, int64_t n, int P, int pow2, const Sca
   QSX_HIP_TRY(launch_scan(hist, cells, starts, nullptr, scan_ws, s));
   int64_t *block0_offsets = out_offsets;
   if (align_rows > 0) {
-    hipLaunchKernelGGL(align_starts_kernel, dim3(1), dim3(kPBlock), 0, s, starts, P, G, n, align_rows, out_offsets);
+    hipLaunchKernelGGL(align_starts_kernel, dim3(1), dim3(1024), 0, s, starts, P, G, n, align_rows, out_offsets);
     QSX_CHECK_LAUNCH();
     block0_offsets = nullptr;   // out_offsets holds the pieces (start, count) instead of P + 1 boundaries
   }
