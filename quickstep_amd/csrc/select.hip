@@ -210,17 +210,20 @@ __device__ __forceinline__ void copy_value(const void *src, int64_t si, void *ds
   }
 }
 
+// One wave per 4096-row tile.  Every lane expands the set bits of its bitmap word into a tile-local position list in LDS
+// (at its prefix offset: the list is in row order); the wave then handles 64 selected rows per step with every lane busy
+// and contiguous stores — at 1 % selectivity the previous form (8 words per step, lanes = rows of a word) had ~1 of
+// 64 lanes working.  Reads are unconditional and batched (4 steps in flight per lane).
 __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
     GatherArgs args, const uint64_t *__restrict__ bitmap, int64_t num_words, int64_t num_tiles,
     const int64_t *__restrict__ tile_offsets, int32_t *__restrict__ out_tids, int32_t base_tid) {
-  __shared__ uint64_t s_words[kWavesPerBlock][kTileWords];
-  __shared__ int32_t s_prefix[kWavesPerBlock][kTileWords];
+  __shared__ uint16_t s_pos[kWavesPerBlock][kTileWords * 64];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; tile < num_tiles;
        tile += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
     const int64_t w = tile * kTileWords + lane;
-    const uint64_t my_word = w < num_words ? bitmap[w] : 0;
+    uint64_t my_word = w < num_words ? bitmap[w] : 0;
     const int pc = __popcll(my_word);
     int incl = pc;
 #pragma unroll
@@ -228,33 +231,34 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
       const int up = __shfl_up(incl, off, kWave);
       if (lane >= off) incl += up;
     }
-    s_words[wave][lane] = my_word;
-    s_prefix[wave][lane] = incl - pc;
+    const int total = __shfl(incl, kWave - 1, kWave);
+    if (total == 0) continue;                    // wave-uniform: 4096 unselected rows
+    int at = incl - pc;
+    while (my_word != 0) {                       // MSB-first: bit 63 is row 0 of the word
+      const int row_in_word = __clzll(static_cast<long long>(my_word));
+      s_pos[wave][at++] = static_cast<uint16_t>(lane * 64 + row_in_word);
+      my_word &= ~(1ull << (63 - row_in_word));
+    }
     // Same-wave LDS hand-off: DS ops of one wave complete in order.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int64_t tile_off = tile_offsets[tile];
-    // 8 bitmap words per step: the 8 loads of a lane are issued back to back and their stores follow —
-    // one word at a time left a single load -> store dependency in flight per wave (0.24 ms / 100 M rows at 50 %).
-    constexpr int kBatch = 8;
-    for (int k0 = 0; k0 < kTileWords; k0 += kBatch) {
-      bool take[kBatch];
-      int64_t si[kBatch], di[kBatch];
-      bool any = false;
+    const int64_t tile_row0 = tile * kTileWords * 64;
+    constexpr int kBatch = 4;
+    for (int i0 = lane; i0 < total; i0 += kWave * kBatch) {
+      int64_t si[kBatch];
+      bool live[kBatch];
 #pragma unroll
       for (int b = 0; b < kBatch; ++b) {
-        const uint64_t word = s_words[wave][k0 + b];  // broadcast read
-        take[b] = msb_bit(word, lane);
-        const int before = lane == 0 ? 0 : __popcll(word >> (64 - lane));
-        di[b] = tile_off + s_prefix[wave][k0 + b] + before;
-        si[b] = ((tile * kTileWords + k0 + b) << 6) + lane;
-        any = any || word != 0;
+        const int i = i0 + b * kWave;
+        live[b] = i < total;
+        si[b] = tile_row0 + (live[b] ? s_pos[wave][i] : s_pos[wave][0]);   // a valid row either way
       }
-      if (!any) continue;                      // wave-uniform: 512 unselected rows
       if (out_tids != nullptr) {
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
-          if (take[b]) out_tids[di[b]] = static_cast<int32_t>(base_tid + si[b]);
+          if (live[b]) out_tids[tile_off + i0 + b * kWave] = static_cast<int32_t>(base_tid + si[b]);
         }
       }
       for (int c = 0; c < args.ncols; ++c) {
@@ -264,33 +268,33 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
           case 4: {
             uint32_t v[kBatch];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) v[b] = take[b] ? static_cast<const uint32_t *>(src)[si[b]] : 0u;
+            for (int b = 0; b < kBatch; ++b) v[b] = static_cast<const uint32_t *>(src)[si[b]];
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
-              if (take[b]) static_cast<uint32_t *>(dst)[di[b]] = v[b];
+              if (live[b]) static_cast<uint32_t *>(dst)[tile_off + i0 + b * kWave] = v[b];
             }
             break;
           }
           case 8: {
             uint64_t v[kBatch];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) v[b] = take[b] ? static_cast<const uint64_t *>(src)[si[b]] : 0ull;
+            for (int b = 0; b < kBatch; ++b) v[b] = static_cast<const uint64_t *>(src)[si[b]];
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
-              if (take[b]) static_cast<uint64_t *>(dst)[di[b]] = v[b];
+              if (live[b]) static_cast<uint64_t *>(dst)[tile_off + i0 + b * kWave] = v[b];
             }
             break;
           }
           default:
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
-              if (take[b]) copy_value(src, si[b], dst, di[b], args.width[c]);
+              if (live[b]) copy_value(src, si[b], dst, tile_off + i0 + b * kWave, args.width[c]);
             }
             break;
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();             // the list is rewritten by the next tile
   }
 }
 
