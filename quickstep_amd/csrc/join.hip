@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
       const int64_t row = base + r * kJBlock + threadIdx.x;
-      k[r] = row < n ? keys[row] : Key();
+      k[r] = keys[row < n ? row : n - 1];   // clamped, not guarded: no branch around the read
     }
     words = ~0ull;
     if (filter != nullptr && lane < kRowsPerThread) {

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((w0 + r) << 6) + lane;
-      k[r] = row < n ? keys[row] : KeyT();
+      k[r] = keys[row < n ? row : n - 1];   // clamped, not guarded: no branch around the read
     }
     fw = ~0ull;
     if (filter != nullptr && lane < R && w0 + lane < num_words) fw = filter[w0 + lane];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = base + r * kDBlock + threadIdx.x;
-      k[r] = row < n ? __builtin_nontemporal_load(&keys[row]) : KeyT();
+      k[r] = __builtin_nontemporal_load(&keys[row < n ? row : n - 1]);   // clamped, not guarded
     }
     words = ~0ull;
     if (filter != nullptr && lane < R) {

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kLBlock) void lip_build_kernel(LipView f, const Key
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((w0 + r) << 6) + lane;
-      k[r] = row < n ? keys[row] : KeyT();
+      k[r] = keys[row < n ? row : n - 1];   // clamped, not guarded: no branch around the read
     }
     fw = ~0ull;
     if (filter != nullptr && lane < R && w0 + lane < num_words) fw = filter[w0 + lane];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kInLds ? 1024 : kLBlock) void lip_probe_kernel(LipV
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = base + static_cast<int64_t>(r) * blockDim.x + threadIdx.x;
-      k[r] = row < n ? __builtin_nontemporal_load(&keys[row]) : KeyT();
+      k[r] = __builtin_nontemporal_load(&keys[row < n ? row : n - 1]);   // clamped, not guarded
     }
     words = ~0ull;
     if (in_bitmap != nullptr && lane < R) {

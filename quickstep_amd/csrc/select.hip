@@ -53,8 +53,8 @@ __global__ __launch_bounds__(kBlock) void select_cmp_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((w0 + r) << 6) + lane;
-      v[r] = row < n ? col[row] : T();
-      u[r] = COLS ? (row < n ? rhs[row] : T()) : lit;
+      v[r] = col[row < n ? row : n - 1];   // clamped, not guarded (rows past n are masked out of the ballot)
+      u[r] = COLS ? rhs[row < n ? row : n - 1] : lit;
     }
     uint64_t mine = 0;
 #pragma unroll
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void select_codes_kernel(const T *__restric
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((w0 + r) << 6) + lane;
-      v[r] = row < n ? codes[row] : T();
+      v[r] = codes[row < n ? row : n - 1];   // clamped, not guarded
     }
     uint64_t mine = 0;
 #pragma unroll
