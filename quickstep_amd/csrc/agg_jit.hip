@@ -102,7 +102,8 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense) {
     << "    int S, int rep_shift, int nbuf, int ranges, const long long *pieces) {\n"
     << "  static constexpr DevConfig D = jit_make_dev();\n"
     << "  agg_hash_update_body<true, " << (dense ? "true" : "false") << ", " << num_sums << ", " << kJitRowsPerThread
-    << ">(D, cols.p, dicts, n, filter, " << (dense ? "HashTableView{}, view" : "view, DenseView{}")
+    << ">(D, cols.p, dicts, n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", "
+    << (dense ? "HashTableView{}, view" : "view, DenseView{}")
     << ", S, rep_shift, nbuf, ranges, pieces);\n}\n}  // namespace qsx\n";
   return o.str();
 }
@@ -121,8 +122,9 @@ std::map<std::string, JitKernel *> g_cache;   // by source text; nullptr = tried
 JitKernel *compile(const std::string &source) {
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, source.c_str(), "qsx_jit_agg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return nullptr;
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics"};
-  const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
+                        "-mllvm", "-amdgpu-internalize-symbols"};   // the last two: what hipcc passes for device code
+  const hiprtcResult rc = hiprtcCompileProgram(prog, 7, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t log_size = 0;
     hiprtcGetProgramLogSize(prog, &log_size);
@@ -196,13 +198,28 @@ extern "C" int qsx_debug_jit_compile(const qsx_agg_config_t *config, int with_fi
   if (t.status != QSX_OK) return t.status;
   plan_tile(t.dev, t.used_columns, kABlock * kJitRowsPerThread, with_filter != 0);
   const std::string source = jit_agg_source(t.dev, t.num_sums, t.dense);
+  if (const char *dump = getenv("QSX_JIT_DUMP")) {   // the generated translation unit, for offline inspection with hipcc -S
+    if (FILE *f = std::fopen(dump, "w")) {
+      std::fwrite(source.data(), 1, source.size(), f);
+      std::fclose(f);
+    }
+  }
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, source.c_str(), "qsx_jit_agg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return QSX_ERR_HIP;
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics"};
-  const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
+                        "-mllvm", "-amdgpu-internalize-symbols"};   // the last two: what hipcc passes for device code
+  const hiprtcResult rc = hiprtcCompileProgram(prog, 7, opts);
   size_t code_size = 0;
   if (rc == HIPRTC_SUCCESS) {
     hiprtcGetCodeSize(prog, &code_size);
+    if (const char *dump = getenv("QSX_JIT_DUMP_CODE")) {   // the code object, for llvm-objdump / llvm-readelf --notes
+      std::string code(code_size, '\0');
+      hiprtcGetCode(prog, &code[0]);
+      if (FILE *f = std::fopen(dump, "wb")) {
+        std::fwrite(code.data(), 1, code.size(), f);
+        std::fclose(f);
+      }
+    }
   } else {
     size_t log_size = 0;
     hiprtcGetProgramLogSize(prog, &log_size);

@@ -751,6 +751,10 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, co
   int grid = static_cast<int>(num_tiles * ranges < max_grid ? num_tiles * ranges : max_grid);
   grid = grid / ranges * ranges;
   if (grid < ranges) grid = ranges;
+  if (getenv("QSX_DEBUG_LAUNCH") != nullptr) {
+    std::fprintf(stderr, "[qsx] jit launch grid=%d lds=%zu S=%d rep_shift=%d nbuf=%d ranges=%d tile_bytes=%d n=%lld\n", grid, lds, S,
+                 rep_shift, nbuf, ranges, tile_bytes, static_cast<long long>(n));
+  }
   ColumnPointers cp;
   for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < st->config.num_columns ? cols[i] : nullptr;
   // the dictionaries of this call (per block) go behind a pointer: see make_source on the kernarg size
