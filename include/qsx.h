@@ -509,7 +509,9 @@ typedef enum qsx_lip_kind {
 } qsx_lip_kind_t;
 
 /* cardinality: filter bits (IDENTITY_HASH: max(64, 8*est build cardinality);
- * EXACT: max - min + 1).  min_value only used by EXACT.  Synchronises. */
+ * EXACT: max - min + 1).  min_value only used by EXACT.  At most 2^32 - 2 bits
+ * (QSX_ERR_UNSUPPORTED beyond: bit positions are 32-bit in the probe kernel).
+ * Synchronises. */
 int qsx_lip_filter_create(int kind, int64_t cardinality, int64_t min_value, int is_anti,
                           qsx_lip_filter_t **out);
 int qsx_lip_filter_destroy(qsx_lip_filter_t *f);
