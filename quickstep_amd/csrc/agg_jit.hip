@@ -93,6 +93,8 @@ std::string emit_dev_config(const DevConfig &d) {
 
 std::string make_source(const DevConfig &dev, int num_sums, bool dense) {
   std::ostringstream o;
+  bool any_coded = false;   // unused pointers are passed as literals: every live scalar argument costs SGPRs in the tile loop
+  for (int i = 0; i < dev.num_columns; ++i) any_coded = any_coded || dev.code_width[i] != 0;
   o << kPrelude << kBundle << "\nnamespace qsx {\nconstexpr DevConfig jit_make_dev() {\n  DevConfig d{};\n"
     << emit_dev_config(dev) << "  return d;\n}\n"
     // explicit arguments are kept under 256 bytes (one view, the dictionaries behind a pointer): with the 256 hidden
@@ -102,7 +104,7 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense) {
     << "    int S, int rep_shift, int nbuf, int ranges, const long long *pieces) {\n"
     << "  static constexpr DevConfig D = jit_make_dev();\n"
     << "  agg_hash_update_body<true, " << (dense ? "true" : "false") << ", " << num_sums << ", " << kJitRowsPerThread
-    << ">(D, cols.p, dicts, n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", "
+    << ">(D, cols.p, " << (any_coded ? "dicts" : "nullptr") << ", n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", "
     << (dense ? "HashTableView{}, view" : "view, DenseView{}")
     << ", S, rep_shift, nbuf, ranges, pieces);\n}\n}  // namespace qsx\n";
   return o.str();
