@@ -112,6 +112,16 @@ int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op,
                    uint64_t *out_bitmap_dev, int64_t *out_count_dev,
                    qsx_stream_t stream);
 
+/* qsx_select_cmp on the SORT COLUMN of a sorted column store (ascending, no NULLs in the first n rows): the matches are
+ * one row range found by two searches, not a scan.  Replaces SortColumnPredicateEvaluator::
+ * EvaluatePredicateForUncompressedSortColumn (storage/ColumnStoreUtil.cpp:40-280) as called from
+ * BasicColumnStoreTupleStorageSubBlock::getMatchesForPredicate (storage/BasicColumnStoreTupleStorageSubBlock.cpp:
+ * 587-610; predicate_cost::kBinarySearch) and CompressedColumnStoreTupleStorageSubBlock.cpp:381.  Same arguments and
+ * result as qsx_select_cmp. */
+int qsx_select_cmp_sorted(int type, const void *col_dev, int64_t n, int op, const void *literal,
+                          const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev,
+                          qsx_stream_t stream);
+
 /* K1 with a second column as right operand: out_bitmap[i] = (lhs[i] OP rhs[i])
  * [AND filter[i]].  Replaces LiteralUncheckedComparator::compareColumnVectors
  * (types/operations/comparisons/LiteralComparators-inl.hpp:52-125) as reached from

@@ -52,6 +52,7 @@ for _name, _res, _args in [
     ("qso_prev_prime", _u64, [_u64]),
     ("qso_partition_id", _u64, [_u64, _u64]),
     ("qso_select_cmp", None, [_int, _vp, _i64, _int, _vp, _vp, _vp]),
+    ("qso_select_cmp_sorted", None, [_int, _vp, _i64, _int, _vp, _vp, _vp]),
     ("qso_bitmap_count", _i64, [_vp, _i64]),
     ("qso_compact_gather", _i64, [_int, _vp, _vp, _i64, _vp]),
     ("qso_bitmap_to_tids", _i64, [_vp, _i64, _i32, _vp]),
@@ -163,6 +164,15 @@ def select_cmp(col, op, literal, filter_bitmap=None):
     out = np.zeros(max(words(n), 1), dtype=np.uint64)
     lit = _C_SCALAR[qtype(col)](literal)
     _lib.qso_select_cmp(qtype(col), _p(col), n, op, C.byref(lit), _p(filter_bitmap), _p(out))
+    return out
+
+
+def select_cmp_sorted(col, op, literal, filter_bitmap=None):
+    """The same predicate evaluated by binary search on a sorted stripe (SortColumnPredicateEvaluator)."""
+    n = col.size
+    out = np.zeros(max(words(n), 1), dtype=np.uint64)
+    lit = _C_SCALAR[qtype(col)](literal)
+    _lib.qso_select_cmp_sorted(qtype(col), _p(col), n, op, C.byref(lit), _p(filter_bitmap), _p(out))
     return out
 
 

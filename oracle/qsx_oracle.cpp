@@ -301,6 +301,32 @@ struct qso_join_table {
   }
 };
 
+namespace {
+// EvaluatePredicateForUncompressedSortColumn (storage/ColumnStoreUtil.cpp:40-280): std::lower_bound / std::upper_bound on
+// the sorted stripe give [min_match, max_match_bound); != takes the complement; the filter is intersected afterwards
+// (BasicColumnStoreTupleStorageSubBlock.cpp:603-606).
+template <typename T>
+void select_cmp_sorted_t(const T *col, std::int64_t n, int op, T lit, const std::uint64_t *filter, std::uint64_t *out) {
+  const std::int64_t lower = std::lower_bound(col, col + n, lit) - col;
+  const std::int64_t upper = std::upper_bound(col, col + n, lit) - col;
+  std::int64_t min_match = 0, max_match_bound = n;
+  switch (op) {
+    case QSX_EQ: case QSX_NE: min_match = lower; max_match_bound = upper; break;
+    case QSX_LT: max_match_bound = lower; break;
+    case QSX_LE: max_match_bound = upper; break;
+    case QSX_GT: min_match = upper; break;
+    default: min_match = lower; break;
+  }
+  for (std::int64_t w = 0; w < bitmap_words(n); ++w) out[w] = 0;
+  for (std::int64_t i = 0; i < n; ++i) {
+    bool match = i >= min_match && i < max_match_bound;
+    if (op == QSX_NE) match = !match;
+    if (match && row_selected(filter, i)) out[i >> 6] |= (static_cast<std::uint64_t>(1) << 63) >> (i & 63);
+  }
+}
+}  // namespace
+
+
 extern "C" {
 
 size_t qso_sizeof_agg_config(void) { return sizeof(qsx_agg_config_t); }
@@ -335,6 +361,17 @@ void qso_select_cmp(int type, const void *col, int64_t n, int op, const void *li
       select_cmp_t<double>(static_cast<const double *>(col), n, op, lit, filter, out_bitmap);
       break;
     }
+    default: std::abort();
+  }
+}
+
+void qso_select_cmp_sorted(int type, const void *col, int64_t n, int op, const void *literal, const uint64_t *filter,
+                           uint64_t *out_bitmap) {
+  switch (type) {
+    case QSX_INT: { std::int32_t lit; std::memcpy(&lit, literal, 4); select_cmp_sorted_t(static_cast<const std::int32_t *>(col), n, op, lit, filter, out_bitmap); break; }
+    case QSX_LONG: { std::int64_t lit; std::memcpy(&lit, literal, 8); select_cmp_sorted_t(static_cast<const std::int64_t *>(col), n, op, lit, filter, out_bitmap); break; }
+    case QSX_FLOAT: { float lit; std::memcpy(&lit, literal, 4); select_cmp_sorted_t(static_cast<const float *>(col), n, op, lit, filter, out_bitmap); break; }
+    case QSX_DOUBLE: { double lit; std::memcpy(&lit, literal, 8); select_cmp_sorted_t(static_cast<const double *>(col), n, op, lit, filter, out_bitmap); break; }
     default: std::abort();
   }
 }

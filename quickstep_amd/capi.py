@@ -58,6 +58,7 @@ _SIGNATURES = {
     "qsx_stream_create": (_int, [_pp]),
     "qsx_stream_destroy": (_int, [_vp]),
     "qsx_select_cmp": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "qsx_select_cmp_sorted": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "qsx_select_cmp_columns": (_int, [_int, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "qsx_select_codes": (_int, [_int, _vp, _i64, _int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "qsx_decode_codes": (_int, [_int, _vp, _i64, _vp, _int, _vp, _vp]),
@@ -171,6 +172,18 @@ def select_cmp(col, op, literal, filter_bitmap=None, out_bitmap=None, out_count=
         out_count = torch.zeros(1, dtype=torch.int64, device=col.device)
     _check(_lib.qsx_select_cmp(qt, _ptr(col), n, op, C.byref(lit), _ptr(filter_bitmap), _ptr(out_bitmap),
                                _ptr(out_count), _stream(stream)), "qsx_select_cmp")
+    return out_bitmap, out_count
+
+
+def select_cmp_sorted(col, op, literal, filter_bitmap=None, stream=None):
+    """K1 on the sort column of a sorted column store (binary search): same result surface as select_cmp."""
+    n = col.numel()
+    qt = qsx_type_of(col)
+    lit = _C_SCALAR[qt](literal)
+    out_bitmap = new_bitmap(n, col.device)
+    out_count = torch.zeros(1, dtype=torch.int64, device=col.device)
+    _check(_lib.qsx_select_cmp_sorted(qt, _ptr(col), n, op, C.byref(lit), _ptr(filter_bitmap), _ptr(out_bitmap),
+                                      _ptr(out_count), _stream(stream)), "qsx_select_cmp_sorted")
     return out_bitmap, out_count
 
 

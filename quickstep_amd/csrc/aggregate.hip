@@ -347,19 +347,6 @@ __global__ __launch_bounds__(kABlock) void mark_existence_kernel(const KeyT *__r
 struct DictTable {
   const void *p[QSX_MAX_COLUMNS];
 };
-// One device slot per (host thread, stream) for such a struct: work on one stream is ordered, so the store of the next
-// call cannot overtake the kernel still reading the slot, and no allocator is involved on the update path.
-template <typename T>
-static T *device_slot(hipStream_t stream) {
-  thread_local std::map<hipStream_t, T *> slots;
-  auto it = slots.find(stream);
-  if (it != slots.end()) return it->second;
-  T *p = nullptr;
-  if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(T)) != hipSuccess) return nullptr;
-  slots.emplace(stream, p);
-  return p;
-}
-
 __global__ __launch_bounds__(kABlock) void popcount_words_kernel(const unsigned long long *__restrict__ words,
                                                                 long long num_words,
                                                                 unsigned long long *__restrict__ out) {

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
+
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -70,6 +72,19 @@ __global__ void store_struct_kernel(T value, T *__restrict__ dst) {
   uint32_t *out = reinterpret_cast<uint32_t *>(dst);
   for (unsigned i = threadIdx.x; i < sizeof(T) / 4; i += blockDim.x) out[i] = src[i];
 }
+// One device slot per (host thread, stream) for such a struct: work on one stream is ordered, so the store of the next
+// call cannot overtake the kernel still reading the slot, and no allocator is involved on the update path.
+template <typename T>
+static T *device_slot(hipStream_t stream) {
+  thread_local std::map<hipStream_t, T *> slots;
+  auto it = slots.find(stream);
+  if (it != slots.end()) return it->second;
+  T *p = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(T)) != hipSuccess) return nullptr;
+  slots.emplace(stream, p);
+  return p;
+}
+
 }  // namespace qsx
 
 #endif  // QSX_CSRC_COMMON_HPP_

@@ -299,6 +299,90 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// K1 on the sort column of a sorted column store: the matches of `col OP literal` are one row range (its complement for
+// !=), found by two searches instead of a scan — SortColumnPredicateEvaluator::EvaluatePredicateForUncompressedSortColumn
+// (storage/ColumnStoreUtil.cpp:40-280: lower_bound / upper_bound on the stripe, then a range of the TupleIdSequence).
+// One wave searches 64-ary (lane l probes the l-th of 64 cut points of the current interval: 5 steps for 1 G rows), a
+// second kernel writes the bitmap words of the range ANDed with the filter.
+// ---------------------------------------------------------------------------
+struct SortedBounds {
+  long long lower;   // first row with value >= literal
+  long long upper;   // first row with value >  literal
+};
+
+template <typename T>
+__global__ __launch_bounds__(kWave) void sorted_bounds_kernel(const T *__restrict__ col, int64_t n, T literal,
+                                                             SortedBounds *__restrict__ out) {
+  const int lane = lane_id();
+  long long result[2];
+  for (int which = 0; which < 2; ++which) {   // 0: lower bound (value < literal goes left), 1: upper bound (value <= literal)
+    long long lo = 0, hi = n;                 // the bound lies in [lo, hi]
+    while (hi - lo > 0) {
+      const long long span = hi - lo;
+      const long long step = (span + kWave) / (kWave + 1);              // >= 1
+      const long long at = lo + step * (lane + 1) - 1;                   // cut point of this lane (may pass hi - 1)
+      bool left = false;                                                 // col[at] sorts before the bound
+      if (at < hi) {
+        const T v = col[at];
+        left = which == 0 ? v < literal : v <= literal;
+      }
+      const uint64_t m = __ballot(left);
+      const int passed = __popcll(m);                                    // cut points left of the bound: a prefix of the lanes
+      const long long new_lo = passed == 0 ? lo : lo + step * passed;
+      const long long new_hi = passed == kWave ? hi : (lo + step * (passed + 1) - 1 < hi ? lo + step * (passed + 1) - 1 : hi);
+      lo = new_lo < hi ? new_lo : hi;
+      hi = new_hi;
+    }
+    result[which] = lo;
+  }
+  if (lane == 0) {
+    out->lower = result[0];
+    out->upper = result[1];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sorted_range_bitmap_kernel(const SortedBounds *__restrict__ bounds, int64_t n, int op,
+                                                                    const uint64_t *__restrict__ filter,
+                                                                    uint64_t *__restrict__ out,
+                                                                    unsigned long long *__restrict__ out_count) {
+  // [begin, end) = rows matching, or (QSX_NE) rows NOT matching
+  long long begin = 0, end = n;
+  switch (op) {
+    case QSX_EQ: case QSX_NE: begin = bounds->lower; end = bounds->upper; break;
+    case QSX_LT: end = bounds->lower; break;
+    case QSX_LE: end = bounds->upper; break;
+    case QSX_GT: begin = bounds->upper; break;
+    default: begin = bounds->lower; break;   // QSX_GE
+  }
+  const int64_t num_words = (n + 63) >> 6;
+  unsigned long long count = 0;
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; w < num_words; w += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const long long first = w << 6;
+    // rows first .. first + 63 of this word that lie in [begin, end), MSB-first
+    uint64_t word = 0;
+    const long long a = begin > first ? begin - first : 0, b = end < first + 64 ? end - first : 64;
+    if (a < b) word = (b - a == 64 ? ~0ull : ((~0ull) >> (64 - (b - a))) << (64 - b));
+    if (op == QSX_NE) word = ~word;
+    const long long valid = n - first >= 64 ? 64 : n - first;            // trailing bits of the last word stay zero
+    if (valid < 64) word &= ~0ull << (64 - valid);
+    if (filter != nullptr) word &= filter[w];
+    out[w] = word;
+    count += __popcll(word);
+  }
+  if (out_count != nullptr) {   // one atomic per workgroup (same-address atomics are ~12 ns each)
+    __shared__ unsigned long long s_part[kBlock / kWave];
+    count = wave_reduce_add(count);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long all = 0;
+      for (int w = 0; w < kBlock / kWave; ++w) all += s_part[w];
+      if (all != 0) atomicAdd(out_count, all);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K5: gather by tuple id
 // ---------------------------------------------------------------------------
 // 8 row numbers per thread and step: the 8 tid loads are issued together, then the 8 source reads (unconditional: a
@@ -602,6 +686,43 @@ int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op, const void 
     case QSX_DOUBLE: return dispatch_select_op<double>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
     default: return QSX_ERR_UNSUPPORTED;
   }
+}
+
+int qsx_select_cmp_sorted(int type, const void *col_dev, int64_t n, int op, const void *literal, const uint64_t *filter_dev,
+                          uint64_t *out_bitmap_dev, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || literal == nullptr || op < QSX_EQ || op > QSX_GE || (n > 0 && (col_dev == nullptr || out_bitmap_dev == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return QSX_OK;
+  SortedBounds *bounds = device_slot<SortedBounds>(s);
+  if (bounds == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  switch (type) {
+    case QSX_INT:
+      hipLaunchKernelGGL(sorted_bounds_kernel<int32_t>, dim3(1), dim3(kWave), 0, s, static_cast<const int32_t *>(col_dev), n,
+                         *static_cast<const int32_t *>(literal), bounds);
+      break;
+    case QSX_LONG:
+      hipLaunchKernelGGL(sorted_bounds_kernel<int64_t>, dim3(1), dim3(kWave), 0, s, static_cast<const int64_t *>(col_dev), n,
+                         *static_cast<const int64_t *>(literal), bounds);
+      break;
+    case QSX_FLOAT:
+      hipLaunchKernelGGL(sorted_bounds_kernel<float>, dim3(1), dim3(kWave), 0, s, static_cast<const float *>(col_dev), n,
+                         *static_cast<const float *>(literal), bounds);
+      break;
+    case QSX_DOUBLE:
+      hipLaunchKernelGGL(sorted_bounds_kernel<double>, dim3(1), dim3(kWave), 0, s, static_cast<const double *>(col_dev), n,
+                         *static_cast<const double *>(literal), bounds);
+      break;
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+  QSX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sorted_range_bitmap_kernel, dim3(grid_for((n + 63) >> 6, kBlock * 8) < 2 * kCUs ? grid_for((n + 63) >> 6, kBlock * 8) : 2 * kCUs), dim3(kBlock), 0, s, bounds, n, op, filter_dev,
+                     out_bitmap_dev, reinterpret_cast<unsigned long long *>(out_count_dev));
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
 }
 
 int qsx_select_cmp_columns(int type, const void *lhs_dev, const void *rhs_dev, int64_t n, int op,

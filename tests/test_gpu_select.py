@@ -157,3 +157,29 @@ def test_select_cmp_aligned_and_unaligned_stripes_agree(capi, oracle, dev, dtype
                 bm, cnt = capi.select_cmp(dsl, op, 3, filter_bitmap=bitmap_dev(f, dev))
                 want = oracle.select_cmp(sl, op, dtype(3), filter_bitmap=f)
                 assert np.array_equal(bitmap_np(bm), want), (start, n, op, "filter")
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4097, 1_000_003])
+def test_sort_column_predicate_by_binary_search(capi, oracle, dev, n):
+    """qsx_select_cmp_sorted on a sorted stripe = the scan's answer (qsx_select_cmp) = the oracle's lower/upper bound
+    restatement of SortColumnPredicateEvaluator, for every comparison, type, literal position and with a filter."""
+    rng = np.random.default_rng(n)
+    filt = oracle.bitmap_from_bools(rng.random(n) < 0.7)
+    cols = {
+        "int32 with ties": np.sort(rng.integers(-50, 50, size=n)).astype(np.int32),
+        "int64": np.sort(rng.integers(-2**40, 2**40, size=n)).astype(np.int64),
+        "float32": np.sort((rng.normal(size=n) * 100).astype(np.float32)),
+        "float64 ties": np.sort(np.round(rng.normal(size=n), 1)),
+    }
+    for name, col in cols.items():
+        d = to_dev(col, dev)
+        lits = [col[0], col[-1], col[n // 2], col[0] - 1, col[-1] + 1, (col[n // 3] + col[2 * n // 3]) / 2]
+        for lit in lits:
+            lit = col.dtype.type(lit).item()
+            for op in range(6):
+                for f in (None, filt):
+                    got, cnt = capi.select_cmp_sorted(d, op, lit, filter_bitmap=None if f is None else bitmap_dev(f, dev))
+                    want = oracle.select_cmp_sorted(col, op, lit, f)
+                    assert np.array_equal(bitmap_np(got), want), (name, op, lit)
+                    assert np.array_equal(want, oracle.select_cmp(col, op, lit, f))       # the scan agrees
+                    assert int(cnt.item()) == oracle.bitmap_count(want, n)
