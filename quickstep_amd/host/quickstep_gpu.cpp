@@ -438,6 +438,11 @@ void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num
                                      static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
                     "qsx_select_codes");
       }
+    } else if (term.attribute == block.sortColumn() && t.id != kChar) {
+      // the block is sorted on this attribute: SortColumnPredicateEvaluator (storage/ColumnStoreUtil.cpp:40-280)
+      CheckStatus(qsx_select_cmp_sorted(t.id, block.stripe(term.attribute), n, static_cast<int>(term.comparison), &term.literal.v, in,
+                                        static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
+                  "qsx_select_cmp_sorted");
     } else {
       CheckStatus(qsx_select_cmp(t.id, block.stripe(term.attribute), n, static_cast<int>(term.comparison), &term.literal.v, in,
                                  static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),

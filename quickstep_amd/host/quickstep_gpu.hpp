@@ -188,6 +188,11 @@ class StorageBlock {
   // Replaces attribute a's stripe by its compressed form when CompressedBlockBuilder would (values on the host).
   void compressAttribute(attribute_id a, const void *host_values);
   bool valuesMaterialized(attribute_id a) const { return stripes_.at(a) != nullptr; }
+  // Sort column of a sorted column store (TupleStorageSubBlockDescription sort_attribute_id; the tuples of the block are
+  // in ascending order of it): predicates on it are evaluated by binary search (predicate_cost::kBinarySearch).
+  // kInvalidAttributeID = unsorted.  The loader of the block vouches for the order.
+  void setSortColumn(attribute_id a) { sort_column_ = a; }
+  attribute_id sortColumn() const { return sort_column_; }
   // Null bitmap of a nullable attribute (TupleIdSequence bit order, 1 = NULL; zeroed at creation),
   // nullptr for non-nullable attributes.
   std::uint64_t *nullBitmap(attribute_id a) const { return static_cast<std::uint64_t *>(null_bitmaps_.at(a)); }
@@ -199,6 +204,7 @@ class StorageBlock {
   std::int64_t capacity_;
   std::int64_t num_tuples_;
   std::int64_t first_row_;
+  attribute_id sort_column_ = kInvalidAttributeID;
   mutable std::vector<void *> stripes_;          // nullptr: compressed and not decoded yet
   std::vector<void *> null_bitmaps_;
   std::vector<CompressedAttribute> compressed_;  // empty or one per attribute

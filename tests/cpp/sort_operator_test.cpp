@@ -143,5 +143,67 @@ int main() {
       runCase(rows, {0, 2, 1}, {true, false, true}, top_k, use_foreman);       // mixed ordering (:754-800 without NULLs)
     }
   }
+  // ---- predicates on the sort column of a sorted block: binary search (qsx_select_cmp_sorted) == scan ----------------
+  {
+    StorageManager storage;
+    CatalogRelation sorted(130, "sorted"), plain(131, "plain"), out_a(132, "out_a"), out_b(133, "out_b");
+    for (CatalogRelation *r : {&sorted, &plain, &out_a, &out_b}) {
+      r->addAttribute("a", Type::Int());
+      r->addAttribute("b", Type::Double());
+    }
+    std::vector<Row> by_b = rows;
+    std::sort(by_b.begin(), by_b.end(), [](const Row &x, const Row &y) { return x.b < y.b; });
+    std::vector<std::int32_t> a;
+    std::vector<double> b;
+    for (const Row &r : by_b) { a.push_back(r.a); b.push_back(r.b); }
+    const block_id sorted_id = storage.loadBlock(&sorted, {a.data(), b.data()}, static_cast<std::int64_t>(a.size()));
+    storage.loadBlock(&plain, {a.data(), b.data()}, static_cast<std::int64_t>(a.size()));
+    storage.getBlock(sorted_id)->setSortColumn(1);
+    for (const ComparisonID cmp : {ComparisonID::kEqual, ComparisonID::kNotEqual, ComparisonID::kLess, ComparisonID::kLessOrEqual,
+                                   ComparisonID::kGreater, ComparisonID::kGreaterOrEqual}) {
+      for (const double lit : {-60.0, 12.5, 12.55, 64.875, 1000.0}) {
+        QueryContext ctx;
+        Predicate pred;
+        pred.conjuncts.push_back({1, cmp, TypedLiteral::Double(lit)});
+        pred.conjuncts.push_back({0, ComparisonID::kLess, TypedLiteral::Int(50)});   // a second term: the range is a filter for it
+        const auto pred_id = ctx.addPredicate(pred);
+        const auto dest_a = ctx.addInsertDestination(&out_a, &storage);
+        const auto dest_b = ctx.addInsertDestination(&out_b, &storage);
+        SelectOperator on_sorted(0, sorted, false, out_a, dest_a, pred_id, std::vector<attribute_id>{0, 1}, true);
+        SelectOperator on_plain(0, plain, false, out_b, dest_b, pred_id, std::vector<attribute_id>{0, 1}, true);
+        fetchAndExecuteWorkOrders(&on_sorted, &ctx, &storage);
+        fetchAndExecuteWorkOrders(&on_plain, &ctx, &storage);
+        auto collect = [&](QueryContext::insert_destination_id d) {
+          std::vector<std::pair<std::int32_t, double>> v;
+          for (block_id id : ctx.getInsertDestination(d)->getTouchedBlocks()) {
+            BlockReference blk = storage.getBlock(id);
+            const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+            std::vector<std::int32_t> ca(k);
+            std::vector<double> cb(k);
+            blk->copyAttributeToHost(0, ca.data());
+            blk->copyAttributeToHost(1, cb.data());
+            for (std::size_t i = 0; i < k; ++i) v.emplace_back(ca[i], cb[i]);
+          }
+          return v;
+        };
+        const auto got = collect(dest_a), want = collect(dest_b);
+        EXPECT_TRUE(got == want);
+        std::size_t expected = 0;
+        for (const Row &r : by_b) {
+          bool m = false;
+          switch (cmp) {
+            case ComparisonID::kEqual: m = r.b == lit; break;
+            case ComparisonID::kNotEqual: m = r.b != lit; break;
+            case ComparisonID::kLess: m = r.b < lit; break;
+            case ComparisonID::kLessOrEqual: m = r.b <= lit; break;
+            case ComparisonID::kGreater: m = r.b > lit; break;
+            default: m = r.b >= lit; break;
+          }
+          if (m && r.a < 50) ++expected;
+        }
+        EXPECT_EQ(got.size(), expected);
+      }
+    }
+  }
   return finish("sort_operator_test");
 }
