@@ -459,7 +459,11 @@ int qsx_agg_update(qsx_agg_state_t *state, const void *const *cols, int64_t n,
  * getUntypedValue (storage/CompressedColumnStoreValueAccessor.hpp:90-150) in front of aggregateBlock: HBM is read
  * at the code width (Q1 over lineitem's compressed quantity / discount / tax: 13 instead of 34 bytes per row).
  * Entries of dictionaries_dev for plain columns are ignored; dictionaries_dev may be NULL when no coded column
- * uses a dictionary. */
+ * uses a dictionary.
+ * The same mechanism reads a column THROUGH a list of row numbers: declare code width 4, pass the row numbers (the
+ * probe or build tids of a join) as the "codes" and the column itself as the "dictionary" — an aggregation right
+ * behind a join then never materialises the join's output (Scalar::getAllValuesForJoin + bulkInsertTuples,
+ * relational_operators/HashJoinOperator.cpp:529-541, followed by aggregateBlock). */
 int qsx_agg_update_coded(qsx_agg_state_t *state, const void *const *cols, const void *const *dictionaries_dev,
                          int64_t n, const uint64_t *filter_dev, qsx_stream_t stream);
 

@@ -169,3 +169,25 @@ def test_dense_group_by_over_a_truncated_key(capi, oracle, dev):
     o.update_coded([ck.codes, cv.codes], [None, cv.dictionary], n)
     from test_gpu_agg import assert_same_groups, finalize_np
     assert_same_groups(finalize_np(st, dev), o.finalize())
+
+
+def test_aggregation_through_a_pair_list(capi, oracle, dev):
+    """The coded entry point doubles as a selection vector: a column handed over as 4-byte "codes" = row numbers (the
+    probe tids of a join) with the column itself as dictionary is read through the pair list — the join output is never
+    materialised.  Same groups as gather-then-aggregate (bit-exact: same values in the same order per group)."""
+    rng = np.random.default_rng(33)
+    n_rows, n_pairs = 500_000, 120_000
+    orderkey = np.sort(rng.integers(0, 60_000, size=n_rows)).astype(np.int32)
+    price = np.round(rng.uniform(900, 105000, size=n_rows), 2)
+    disc = rng.integers(0, 11, size=n_rows) / 100.0
+    tids = np.sort(rng.choice(n_rows, size=n_pairs, replace=False)).astype(np.int32)      # ascending, like the two-pass probe emits
+    layout = [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None)]
+    kw = dict(keys=[0], instrs=[(T.EX_SUB, 0, T.const(0), T.col(2)), (T.EX_MUL, 1, T.col(1), T.temp(0))], consts=[1.0],
+              aggs=[(T.AGG_SUM, T.temp(1)), (T.AGG_COUNT_STAR, None)], num_entries=60_000)
+    through = capi.AggState(T.make_agg_config(T.AGG_COLLISION_FREE, layout, code_widths=[4, 4, 4], **kw))
+    d_tids = to_dev(tids, dev)
+    through.update_coded([d_tids, d_tids, d_tids], [to_dev(orderkey, dev), to_dev(price, dev), to_dev(disc, dev)], n_pairs)
+    o = oracle.AggState(T.make_agg_config(T.AGG_COLLISION_FREE, layout, **kw))
+    o.update([orderkey[tids], price[tids], disc[tids]])
+    from test_gpu_agg import assert_same_groups, finalize_np
+    assert_same_groups(finalize_np(through, dev), o.finalize())
