@@ -578,6 +578,28 @@ static void plan_interpreter(DevConfig &dc, int tile_rows) {
 
 // Lays the referenced columns of one TR-row tile out in LDS and launches the
 // update kernel with two tile buffers (DMA double buffering).
+// Replication of the LDS accumulators vs workgroups per CU.  More replication = fewer same-address LDS atomics, but the
+// planes compete with the tile for the 160 KiB of a CU, and what decides the kernel's speed is first of all how many
+// workgroups are resident (their stage / compute phases overlap each other).  Measured on the Q1 shape (tools/agg_sweep*.sh,
+// ms per 200 M rows): 64 KiB-ish allocations are granted in 1 KiB steps; rep 16 with 3 workgroups 1.28, with 2 workgroups
+// 1.52; rep 8 with 3 workgroups 1.44, with 4 workgroups 1.44; rep 4: 1.92.  Start from the budgeted replication and give
+// one step of it up when that admits one more workgroup below three per CU.
+static int choose_replication(int NS, int S, size_t fixed_bytes, const AggTuning &tune, size_t *lds_out) {
+  constexpr size_t kMaxLds = 160 * 1024;
+  auto lds_of = [&](int rep) {
+    return fixed_bytes + sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep) + kWave));
+  };
+  auto per_cu_of = [&](size_t lds) {
+    const size_t granted = (lds + 1023) / 1024 * 1024;
+    return granted > kMaxLds ? 0 : static_cast<int>(kMaxLds / granted);
+  };
+  int rep_shift = 6;
+  while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * S * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
+  if (rep_shift > 0 && per_cu_of(lds_of(rep_shift)) < 3 && per_cu_of(lds_of(rep_shift - 1)) > per_cu_of(lds_of(rep_shift))) --rep_shift;
+  *lds_out = lds_of(rep_shift);
+  return rep_shift;
+}
+
 template <int NS, int V>
 static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter,
                          const HashTableView &g, int S, int ranges, const long long *pieces, hipStream_t stream, bool dry_run) {
@@ -586,11 +608,9 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   plan_interpreter(dc, TR);
   // replicate every accumulator as far as the budget allows (64 = one bank column per lane)
   const AggTuning &tune = agg_tuning();
-  int rep_shift = 6;
-  while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * S * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
   const int nbuf = tune.buffers;
-  const size_t lds = nbuf * off + dc.temps_bytes +
-                     sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep_shift) + kWave));
+  size_t lds = 0;
+  const int rep_shift = choose_replication(NS, S, nbuf * off + dc.temps_bytes, tune, &lds);
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   if (dry_run) return QSX_OK;
@@ -601,7 +621,7 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
     attribute_set = true;
   }
   // grid = what is resident at once (LDS-limited workgroups per CU), tiles are strided over it
-  int per_cu = static_cast<int>(kMaxLds / lds);
+  int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
   if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
   if (per_cu < 1) per_cu = 1;
   const int64_t num_tiles = (n + TR - 1) / TR;
@@ -633,11 +653,9 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
   static_assert(T.status == QSX_OK, "plan shape does not translate");
   constexpr int NS = T.num_sums;
   const AggTuning &tune = agg_tuning();
-  int rep_shift = 6;
-  while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * S * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
   const int nbuf = tune.buffers;
-  const size_t lds = static_cast<size_t>(nbuf) * T.dev.tile_bytes +
-                     sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep_shift) + kWave));
+  size_t lds = 0;
+  const int rep_shift = choose_replication(NS, S, static_cast<size_t>(nbuf) * T.dev.tile_bytes, tune, &lds);
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   static bool attribute_set = false;
@@ -646,7 +664,7 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
     attribute_set = true;
   }
-  int per_cu = static_cast<int>(kMaxLds / lds);
+  int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
   if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
   if (per_cu < 1) per_cu = 1;
   const int64_t num_tiles = (n + TR - 1) / TR;
@@ -723,14 +741,11 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, co
   if (st->dense) {
     lds = static_cast<size_t>(tile_bytes) + sizeof(unsigned long long) * (8 + static_cast<size_t>(NS + 1) * (8 + kWave));
   } else {
-    rep_shift = 6;
-    while (rep_shift > 0 && (static_cast<size_t>(NS + 1) * S * 8) << rep_shift > static_cast<size_t>(tune.acc_kib) * 1024) --rep_shift;
     nbuf = tune.buffers;
-    lds = static_cast<size_t>(nbuf) * tile_bytes +
-          sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep_shift) + kWave));
+    rep_shift = choose_replication(NS, S, static_cast<size_t>(nbuf) * tile_bytes, tune, &lds);
   }
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
-  int per_cu = static_cast<int>(kMaxLds / lds);
+  int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
   if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
   if (per_cu < 1) per_cu = 1;
   const int64_t num_tiles = (n + TR - 1) / TR;
@@ -789,7 +804,7 @@ static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const ui
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
     attribute_set = true;
   }
-  int per_cu = static_cast<int>(kMaxLds / lds);
+  int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
   const int64_t num_tiles = (n + TR - 1) / TR;
