@@ -98,12 +98,17 @@ report("K9 partition_scatter P=8, key + tid", ms, N, 4 * N * 2 + 8 * N * 2, "key
 # ---- aggregation family --------------------------------------------------------------------------------
 na = 2 * N
 cols = gen_q1_columns_gpu(na, dev, 4)
-for label, env in (("plan shape", None), ("interpreter", "1")):
-    if env:
-        os.environ["QSX_AGG_NO_SPECIALIZE"] = env
+for label, create_env, update_env in (("AOT plan shape", None, None), ("run-time plan shape (hipRTC)", "1", None),
+                                      ("interpreter", "1", "1")):
+    # QSX_AGG_NO_SPECIALIZE at creation: no AOT shape; still set at update: no run-time shape either
+    if create_env:
+        os.environ["QSX_AGG_NO_SPECIALIZE"] = create_env
     st = capi.AggState(q1_config())
     os.environ.pop("QSX_AGG_NO_SPECIALIZE", None)
+    if update_env:
+        os.environ["QSX_AGG_NO_SPECIALIZE"] = update_env
     ms = timed(lambda: st.update(cols, na), reps=3)
+    os.environ.pop("QSX_AGG_NO_SPECIALIZE", None)
     report(f"K6 aggregate Q1 shape ({label})", ms, na, 34 * na)
 k1 = torch.randint(0, 100, (na,), device=dev, generator=g, dtype=torch.int32)
 k2 = torch.randint(0, 100, (na,), device=dev, generator=g, dtype=torch.int32)
@@ -117,7 +122,7 @@ gencfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.INT, None), (T.DOUB
                            aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None)], est_groups=10_000)
 st = capi.AggState(gencfg)
 ms = timed(lambda: st.update([k1, k2, val], na), reps=3)
-report("K8 aggregate GENERIC 2 INT keys, 10 k groups (interpreter)", ms, na, 16 * na)
+report("K8 aggregate GENERIC 2 INT keys, 10 k groups (partitioned; run-time plan shape)", ms, na, 16 * na)
 # Q3 group-by shape: dense key (orders at SF100: 150 M keys for 600 M lineitems -> 4 rows per key, clustered)
 ne = na // 4
 okey = (torch.arange(na, device=dev, dtype=torch.int64) // 4).to(torch.int32)
