@@ -6,6 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <vector>
+#include <thread>
+#include <chrono>
+#include <atomic>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -118,8 +122,30 @@ bool jit_enabled() {
   return on;
 }
 
-std::mutex g_mutex;
-std::map<std::string, JitKernel *> g_cache;   // by source text; nullptr = tried and failed
+}  // namespace
+
+// One per distinct source text.  state: 0 = compiling, 1 = ready, -1 = failed.
+struct JitRequest {
+  std::atomic<int> state{0};
+  JitKernel *kernel = nullptr;
+};
+
+namespace {
+// The cache, its lock and the compile threads are never destroyed: a compile may still be running when the process
+// tears its statics down; an atexit hook waits for the threads instead.
+std::mutex &cache_mutex() { static std::mutex *m = new std::mutex; return *m; }
+std::map<std::string, JitRequest *> &cache() { static auto *c = new std::map<std::string, JitRequest *>; return *c; }
+std::vector<std::thread> &compile_threads() { static auto *t = new std::vector<std::thread>; return *t; }
+void join_compile_threads() {
+  std::vector<std::thread> threads;
+  {
+    std::lock_guard<std::mutex> lock(cache_mutex());
+    threads.swap(compile_threads());
+  }
+  for (std::thread &t : threads) {
+    if (t.joinable()) t.join();
+  }
+}
 
 JitKernel *compile(const std::string &source) {
   hiprtcProgram prog = nullptr;
@@ -161,15 +187,52 @@ JitKernel *compile(const std::string &source) {
 // Source text only (tests / offline inspection; needs no device).
 std::string jit_agg_source(const DevConfig &dev, int num_sums, bool dense) { return make_source(dev, num_sums, dense); }
 
-const JitKernel *jit_agg_kernel(const DevConfig &dev, int num_sums, bool dense, bool /*has_filter*/) {
+JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, bool synchronous) {
   if (!jit_enabled()) return nullptr;
-  const std::string source = make_source(dev, num_sums, dense);   // has_filter is part of dev (filter_lds_off)
-  std::lock_guard<std::mutex> lock(g_mutex);
-  auto it = g_cache.find(source);
-  if (it != g_cache.end()) return it->second;
-  JitKernel *k = compile(source);
-  g_cache.emplace(source, k);
-  return k;
+  const std::string source = make_source(dev, num_sums, dense);   // a filter is part of dev (filter_lds_off)
+  JitRequest *r = nullptr;
+  bool mine = false;
+  {
+    std::lock_guard<std::mutex> lock(cache_mutex());
+    auto it = cache().find(source);
+    if (it != cache().end()) {
+      r = it->second;
+    } else {
+      r = new JitRequest();
+      cache().emplace(source, r);
+      mine = true;
+      if (!synchronous) {
+        // hipRTC takes 1-2 s: the caller keeps using the interpreter kernel and picks the shape up when it is ready
+        static bool hooked = false;
+        if (!hooked) {
+          std::atexit(join_compile_threads);
+          hooked = true;
+        }
+        int device = 0;
+        (void)hipGetDevice(&device);
+        compile_threads().emplace_back([r, source, device]() {
+          (void)hipSetDevice(device);
+          JitKernel *k = compile(source);
+          r->kernel = k;
+          r->state.store(k != nullptr ? 1 : -1, std::memory_order_release);
+        });
+      }
+    }
+  }
+  if (mine && synchronous) {
+    JitKernel *k = compile(source);
+    r->kernel = k;
+    r->state.store(k != nullptr ? 1 : -1, std::memory_order_release);
+  } else if (synchronous) {
+    while (r->state.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::milliseconds(1));   // someone else compiles it
+  }
+  return r;
+}
+
+int jit_request_state(JitRequest *r, const JitKernel **kernel) {
+  const int state = r->state.load(std::memory_order_acquire);
+  if (kernel != nullptr) *kernel = state == 1 ? r->kernel : nullptr;
+  return state;
 }
 
 int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,

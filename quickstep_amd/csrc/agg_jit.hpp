@@ -21,9 +21,13 @@ namespace qsx {
 
 struct JitKernel;
 
-// Specialised kernel for `dev` (translated configuration with its tile plan for 1024-row tiles
-// already filled in), or nullptr when run-time compilation is off or failed.
-const JitKernel *jit_agg_kernel(const DevConfig &dev, int num_sums, bool dense, bool has_filter);
+// Request for the specialised kernel of `dev` (translated configuration with its tile plan for 1024-row tiles already
+// filled in); nullptr when run-time compilation is off.  Requests are cached by source text.  synchronous = compile
+// (or wait for whoever compiles it) before returning; otherwise a background thread compiles and the caller polls.
+struct JitRequest;
+JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, bool synchronous);
+// 0: still compiling, 1: ready (*kernel set), -1: failed (hipRTC error: the interpreter stays in use)
+int jit_request_state(JitRequest *request, const JitKernel **kernel);
 
 // Launches it: the argument list of agg_hash_update_body.
 int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,

@@ -378,6 +378,7 @@ using namespace qsx;
 struct qsx_agg_state {
   qsx_agg_config_t config;
   bool has_coded_columns = false;   // some column arrives as codes of a compressed attribute
+  JitRequest *jit_request[2] = {nullptr, nullptr};   // run-time plan shapes asked for (no filter / filter); owned by the cache
   DevConfig dev;            // everything but cols[]
   FinalizeDesc fin;         // everything but the output pointers
   int num_sums = 0;
@@ -714,8 +715,10 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, int
   const long long seen = st->rows_seen.fetch_add(n) + n;
   const int v = has_filter ? 1 : 0;
   std::lock_guard<std::mutex> lock(st->jit_mutex);
-  if (!st->jit_tried[v]) {
-    if (seen < jit_min_rows()) return nullptr;
+  if (st->jit_tried[v]) return st->jit[v];          // settled: ready or given up
+  if (st->jit_request[v] == nullptr) {
+    const long long min_rows = jit_min_rows();
+    if (seen < min_rows) return nullptr;
     if (getenv("QSX_AGG_NO_SPECIALIZE") != nullptr && atoi(getenv("QSX_AGG_NO_SPECIALIZE")) != 0) {
       st->jit_tried[v] = true;
       return nullptr;
@@ -723,10 +726,23 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, int
     DevConfig dev = st->dev;
     plan_tile(dev, st->used_columns, kABlock * kJitRowsPerThread, has_filter);
     st->jit_tile_bytes[v] = dev.tile_bytes;
-    st->jit[v] = jit_agg_kernel(dev, st->num_sums, st->dense, has_filter);
-    st->jit_tried[v] = true;
+    // hipRTC takes 1-2 s — three orders of magnitude more than interpreting the 16 Mi rows that trigger it — so the
+    // compile runs in the background and the interpreter stays in use until the shape is ready.  QSX_AGG_JIT_MIN_ROWS=0
+    // (compile at first use: tests, tools) or QSX_AGG_JIT_SYNC=1 wait for it instead.
+    const char *sync_env = getenv("QSX_AGG_JIT_SYNC");
+    const bool synchronous = min_rows == 0 || (sync_env != nullptr && atoi(sync_env) != 0);
+    st->jit_request[v] = jit_agg_request(dev, st->num_sums, st->dense, synchronous);
+    if (st->jit_request[v] == nullptr) {             // run-time compilation is off
+      st->jit_tried[v] = true;
+      return nullptr;
+    }
   }
-  return st->jit[v];
+  const JitKernel *k = nullptr;
+  const int state = jit_request_state(st->jit_request[v], &k);
+  if (state == 0) return nullptr;                    // still compiling
+  st->jit[v] = k;
+  st->jit_tried[v] = true;
+  return k;
 }
 
 static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, const void *const *cols, const void *const *dicts, int64_t n,
@@ -1054,6 +1070,17 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
 int qsx_agg_update_coded(qsx_agg_state_t *st, const void *const *cols, const void *const *dictionaries_dev, int64_t n,
                          const uint64_t *filter_dev, qsx_stream_t stream) {
   return agg_update(st, cols, dictionaries_dev, n, filter_dev, stream);
+}
+
+// Test hook (not part of include/qsx.h): where the run-time plan shape of a state stands.
+// -2: not requested yet, 0: compiling in the background, 1: in use, -1: given up (off / failed).
+int qsx_debug_agg_jit_state(qsx_agg_state_t *st, int with_filter) {
+  if (st == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  const int v = with_filter != 0 ? 1 : 0;
+  std::lock_guard<std::mutex> lock(st->jit_mutex);
+  if (st->jit_tried[v]) return st->jit[v] != nullptr ? 1 : -1;
+  if (st->jit_request[v] == nullptr) return -2;
+  return jit_request_state(st->jit_request[v], nullptr) == 0 ? 0 : (jit_request_state(st->jit_request[v], nullptr) == 1 ? 1 : -1);
 }
 
 int qsx_agg_mark_existence(qsx_agg_state_t *st, int key_type, const void *keys_dev, int64_t n, const uint64_t *filter_dev,

@@ -77,3 +77,46 @@ def test_jit_disabled_by_environment_still_correct(capi, oracle, dev, monkeypatc
     o = oracle.AggState(cfg)
     o.update(cols)
     assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols), dev), o.finalize())
+
+
+def test_background_compile_does_not_stall_and_takes_over(capi, oracle, dev, monkeypatch):
+    """With a non-zero row threshold the hipRTC compile runs in a background thread: the update that triggers it returns on
+    the interpreter (state 0 = compiling or already 1), later updates pick the shape up (state 1), and the groups are
+    the oracle's whichever kernel served which block."""
+    import ctypes
+    import time
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "1000")
+    monkeypatch.delenv("QSX_AGG_JIT_SYNC", raising=False)
+    monkeypatch.delenv("QSX_AGG_NO_SPECIALIZE", raising=False)
+    rng = np.random.default_rng(123)
+    n = 50_000
+    key = rng.integers(0, 37, size=n).astype(np.int32)
+    val = rng.normal(size=n)
+    odd = rng.integers(0, 1000, size=n).astype(np.int64)
+    # a configuration nothing else in the suite compiles (the cache is per process and keyed by source text)
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.INT, None), (T.DOUBLE, None), (T.LONG, None)], keys=[0],
+                            instrs=[(T.EX_MUL, 0, T.col(1), T.const(0))], consts=[1.0009765625],
+                            aggs=[(T.AGG_SUM, T.temp(0)), (T.AGG_MAX, T.col(2)), (T.AGG_COUNT_STAR, None)], est_groups=64)
+    state_of = capi.lib.qsx_debug_agg_jit_state
+    state_of.restype = ctypes.c_int
+    st = capi.AggState(cfg)
+    o = oracle.AggState(cfg)
+    cols = [to_dev(key, dev), to_dev(val, dev), to_dev(odd, dev)]
+    assert state_of(st._h, 0) == -2                                   # nothing requested yet
+    t0 = time.perf_counter()
+    st.update(cols, n)
+    first_call = time.perf_counter() - t0
+    o.update([key, val, odd])
+    assert state_of(st._h, 0) in (0, 1)
+    blocks = 1
+    deadline = time.time() + 60
+    while state_of(st._h, 0) == 0 and time.time() < deadline:
+        time.sleep(0.05)
+        st.update(cols, n)                                            # served by the interpreter meanwhile
+        o.update([key, val, odd])
+        blocks += 1
+    assert state_of(st._h, 0) == 1, "the run-time plan shape never became ready"
+    st.update(cols, n)                                                # served by the compiled shape
+    o.update([key, val, odd])
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+    assert first_call < 0.5 or blocks == 1, f"the triggering update stalled for {first_call:.2f} s"

@@ -6,6 +6,8 @@ import sys
 
 import torch
 
+os.environ.setdefault("QSX_AGG_JIT_SYNC", "1")   # time the run-time plan shape, not the interpreter that covers its compile
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import quickstep_amd.capi as capi  # noqa: E402
 from quickstep_amd import types as T  # noqa: E402
