@@ -95,7 +95,7 @@ std::string emit_dev_config(const DevConfig &d) {
   return o.str();
 }
 
-std::string make_source(const DevConfig &dev, int num_sums, bool dense) {
+std::string make_source(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geo) {
   std::ostringstream o;
   bool any_coded = false;   // unused pointers are passed as literals: every live scalar argument costs SGPRs in the tile loop
   for (int i = 0; i < dev.num_columns; ++i) any_coded = any_coded || dev.code_width[i] != 0;
@@ -107,10 +107,12 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense) {
     << "    const void *const *dicts, int64_t n, const uint64_t *filter, " << (dense ? "DenseView" : "HashTableView") << " view,\n"
     << "    int S, int rep_shift, int nbuf, int ranges, const long long *pieces) {\n"
     << "  static constexpr DevConfig D = jit_make_dev();\n"
+    // the geometry arguments stay in the signature (one launch path for every shape) but the body gets the constants
+    << "  (void)S; (void)rep_shift; (void)nbuf; (void)ranges;\n"
     << "  agg_hash_update_body<true, " << (dense ? "true" : "false") << ", " << num_sums << ", " << kJitRowsPerThread
     << ">(D, cols.p, " << (any_coded ? "dicts" : "nullptr") << ", n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", "
     << (dense ? "HashTableView{}, view" : "view, DenseView{}")
-    << ", S, rep_shift, nbuf, ranges, pieces);\n}\n}  // namespace qsx\n";
+    << ", " << geo.S << ", " << geo.rep_shift << ", " << geo.nbuf << ", " << geo.ranges << ", pieces);\n}\n}  // namespace qsx\n";
   return o.str();
 }
 
@@ -185,11 +187,13 @@ JitKernel *compile(const std::string &source) {
 }  // namespace
 
 // Source text only (tests / offline inspection; needs no device).
-std::string jit_agg_source(const DevConfig &dev, int num_sums, bool dense) { return make_source(dev, num_sums, dense); }
+std::string jit_agg_source(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geometry) {
+  return make_source(dev, num_sums, dense, geometry);
+}
 
-JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, bool synchronous) {
+JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geometry, bool synchronous) {
   if (!jit_enabled()) return nullptr;
-  const std::string source = make_source(dev, num_sums, dense);   // a filter is part of dev (filter_lds_off)
+  const std::string source = make_source(dev, num_sums, dense, geometry);   // a filter is part of dev (filter_lds_off)
   JitRequest *r = nullptr;
   bool mine = false;
   {
@@ -262,7 +266,8 @@ extern "C" int qsx_debug_jit_compile(const qsx_agg_config_t *config, int with_fi
   Translated t = translate(*config);
   if (t.status != QSX_OK) return t.status;
   plan_tile(t.dev, t.used_columns, kABlock * kJitRowsPerThread, with_filter != 0);
-  const std::string source = jit_agg_source(t.dev, t.num_sums, t.dense);
+  const JitGeometry geometry{t.dense ? 8 : 16, t.dense ? 0 : 4, 1, 1};   // a plausible geometry: this hook only checks that the shape compiles
+  const std::string source = jit_agg_source(t.dev, t.num_sums, t.dense, geometry);
   if (const char *dump = getenv("QSX_JIT_DUMP")) {   // the generated translation unit, for offline inspection with hipcc -S
     if (FILE *f = std::fopen(dump, "w")) {
       std::fwrite(source.data(), 1, source.size(), f);

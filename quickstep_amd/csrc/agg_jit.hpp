@@ -25,7 +25,13 @@ struct JitKernel;
 // filled in); nullptr when run-time compilation is off.  Requests are cached by source text.  synchronous = compile
 // (or wait for whoever compiles it) before returning; otherwise a background thread compiles and the caller polls.
 struct JitRequest;
-JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, bool synchronous);
+// Launch geometry folded into the shape as constants (table slots, log2 of the accumulator replication, tile buffers,
+// workgroup families): they are fixed per state and path, and as constants they fold the plane / slot arithmetic of the
+// tile loop instead of occupying scalar registers.
+struct JitGeometry {
+  int S, rep_shift, nbuf, ranges;
+};
+JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geometry, bool synchronous);
 // 0: still compiling, 1: ready (*kernel set), -1: failed (hipRTC error: the interpreter stays in use)
 int jit_request_state(JitRequest *request, const JitKernel **kernel);
 

@@ -378,7 +378,10 @@ using namespace qsx;
 struct qsx_agg_state {
   qsx_agg_config_t config;
   bool has_coded_columns = false;   // some column arrives as codes of a compressed attribute
-  JitRequest *jit_request[2] = {nullptr, nullptr};   // run-time plan shapes asked for (no filter / filter); owned by the cache
+  // run-time plan shapes asked for, owned by the cache: index = (filter ? 1 : 0) + (partitioned input ? 2 : 0)
+  JitRequest *jit_request[4] = {nullptr, nullptr, nullptr, nullptr};
+  JitGeometry jit_geometry[4] = {};
+  size_t jit_lds[4] = {0, 0, 0, 0};
   DevConfig dev;            // everything but cols[]
   FinalizeDesc fin;         // everything but the output pointers
   int num_sums = 0;
@@ -413,9 +416,9 @@ struct qsx_agg_state {
   // Run-time plan shapes (agg_jit.hpp), one per filter variant; compiled once the state has seen enough
   // rows to pay for the 1-2 s of hipRTC.
   std::mutex jit_mutex;
-  const JitKernel *jit[2] = {nullptr, nullptr};
-  bool jit_tried[2] = {false, false};
-  int jit_tile_bytes[2] = {0, 0};
+  const JitKernel *jit[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool jit_tried[4] = {false, false, false, false};
+  int jit_tile_bytes[4] = {0, 0, 0, 0};
   std::atomic<long long> rows_seen{0};
 
   HashTableView hash_view() const {
@@ -711,9 +714,30 @@ static long long jit_min_rows() {
 
 // The specialised kernel of this state for the filter variant, compiling it on first use once the state
 // has aggregated jit_min_rows() rows; nullptr -> use the interpreter.
-static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, int64_t n) {
+// Geometry of a shape launch for a state: the same numbers launch_hash_v / launch_shape_v derive, fixed per state and path.
+static JitGeometry jit_geometry_for(const qsx_agg_state *st, int tile_bytes, int slots, int num_ranges, size_t *lds) {
+  const int NS = st->num_sums;
+  JitGeometry g{};
+  if (st->dense) {
+    g = JitGeometry{8, 0, 1, 1};
+    *lds = static_cast<size_t>(tile_bytes) + sizeof(unsigned long long) * (8 + static_cast<size_t>(NS + 1) * (8 + kWave));
+    return g;
+  }
+  const AggTuning &tune = agg_tuning();
+  g.S = slots;
+  g.ranges = num_ranges;
+  g.nbuf = tune.buffers;
+  g.rep_shift = choose_replication(NS, g.S, static_cast<size_t>(g.nbuf) * tile_bytes, tune, lds);
+  return g;
+}
+
+// The specialised kernel of this state for the (filter, partitioned) variant, requested once the state has aggregated
+// jit_min_rows() rows; nullptr -> use the interpreter (not requested yet, still compiling, or given up).
+static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, bool partitioned, int slots, int num_ranges, int64_t n,
+                                         int *variant) {
   const long long seen = st->rows_seen.fetch_add(n) + n;
-  const int v = has_filter ? 1 : 0;
+  const int v = (has_filter ? 1 : 0) + (partitioned ? 2 : 0);
+  *variant = v;
   std::lock_guard<std::mutex> lock(st->jit_mutex);
   if (st->jit_tried[v]) return st->jit[v];          // settled: ready or given up
   if (st->jit_request[v] == nullptr) {
@@ -726,12 +750,17 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, int
     DevConfig dev = st->dev;
     plan_tile(dev, st->used_columns, kABlock * kJitRowsPerThread, has_filter);
     st->jit_tile_bytes[v] = dev.tile_bytes;
+    st->jit_geometry[v] = jit_geometry_for(st, dev.tile_bytes, slots, num_ranges, &st->jit_lds[v]);
+    if (st->jit_lds[v] > 160 * 1024) {               // the shape would not fit a CU: the interpreter's smaller tiles stay in use
+      st->jit_tried[v] = true;
+      return nullptr;
+    }
     // hipRTC takes 1-2 s — three orders of magnitude more than interpreting the 16 Mi rows that trigger it — so the
     // compile runs in the background and the interpreter stays in use until the shape is ready.  QSX_AGG_JIT_MIN_ROWS=0
     // (compile at first use: tests, tools) or QSX_AGG_JIT_SYNC=1 wait for it instead.
     const char *sync_env = getenv("QSX_AGG_JIT_SYNC");
     const bool synchronous = min_rows == 0 || (sync_env != nullptr && atoi(sync_env) != 0);
-    st->jit_request[v] = jit_agg_request(dev, st->num_sums, st->dense, synchronous);
+    st->jit_request[v] = jit_agg_request(dev, st->num_sums, st->dense, st->jit_geometry[v], synchronous);
     if (st->jit_request[v] == nullptr) {             // run-time compilation is off
       st->jit_tried[v] = true;
       return nullptr;
@@ -745,21 +774,17 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, int
   return k;
 }
 
-static int launch_jit(qsx_agg_state *st, const JitKernel *k, bool has_filter, const void *const *cols, const void *const *dicts, int64_t n,
+static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const void *const *cols, const void *const *dicts, int64_t n,
                       const uint64_t *filter, int slots, int num_ranges, const long long *pieces, hipStream_t stream) {
   constexpr int TR = kABlock * kJitRowsPerThread;
   constexpr size_t kMaxLds = 160 * 1024;
-  const int NS = st->num_sums;
   const AggTuning &tune = agg_tuning();
-  int S = st->dense ? 8 : slots, ranges = st->dense ? 1 : num_ranges, rep_shift = 0, nbuf = 1;
-  size_t lds;
-  const int tile_bytes = st->jit_tile_bytes[has_filter ? 1 : 0];
-  if (st->dense) {
-    lds = static_cast<size_t>(tile_bytes) + sizeof(unsigned long long) * (8 + static_cast<size_t>(NS + 1) * (8 + kWave));
-  } else {
-    nbuf = tune.buffers;
-    rep_shift = choose_replication(NS, S, static_cast<size_t>(nbuf) * tile_bytes, tune, &lds);
-  }
+  // the geometry the shape was compiled for (constants inside it); a call with another one cannot use it
+  const JitGeometry &geo = st->jit_geometry[variant];
+  if (!st->dense && (geo.S != slots || geo.ranges != num_ranges)) return QSX_ERR_UNSUPPORTED;
+  int S = geo.S, ranges = geo.ranges, rep_shift = geo.rep_shift, nbuf = geo.nbuf;
+  const size_t lds = st->jit_lds[variant];
+  const int tile_bytes = st->jit_tile_bytes[variant];
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
   if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
@@ -971,13 +996,14 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
     dc.dicts[i] = (dicts != nullptr && dc.code_width[i] != 0) ? dicts[i] : nullptr;
   }
   const bool aot = !st->dense && st->shape != nullptr && filter_dev == nullptr;
-  const JitKernel *jk = aot ? nullptr : state_jit_kernel(st, filter_dev != nullptr, n);
+  int variant = 0;
+  const JitKernel *jk = aot ? nullptr : state_jit_kernel(st, filter_dev != nullptr, pieces != nullptr, slots, ranges, n, &variant);
   if (jk != nullptr) {
-    int rc = launch_jit(st, jk, filter_dev != nullptr, cols, dc.dicts, n, filter_dev, slots, ranges, pieces, s);
+    int rc = launch_jit(st, jk, variant, cols, dc.dicts, n, filter_dev, slots, ranges, pieces, s);
     if (rc == QSX_OK && hipGetLastError() == hipSuccess) return QSX_OK;
     // the specialised kernel could not be launched: keep going with the interpreter from now on
     std::lock_guard<std::mutex> lock(st->jit_mutex);
-    st->jit[filter_dev != nullptr ? 1 : 0] = nullptr;
+    st->jit[variant] = nullptr;
   }
   if (st->dense) {
     const DenseView d = st->dense_view();
