@@ -682,6 +682,16 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
     std::fprintf(stderr, "[qsx] shape launch grid=%d lds=%zu S=%d rep_shift=%d nbuf=%d ranges=%d tile_bytes=%d n=%lld\n", grid, lds, S,
                  rep_shift, nbuf, ranges, T.dev.tile_bytes, static_cast<long long>(n));
   }
+  if (S == 16 && rep_shift == 4 && nbuf == 1 && ranges == 1 && pieces == nullptr) {   // the default small-group geometry
+    static bool fixed_attribute_set = false;
+    if (!fixed_attribute_set) {
+      QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_kernel<Shape, V, 16, 4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
+      fixed_attribute_set = true;
+    }
+    hipLaunchKernelGGL((agg_hash_shape_fixed_kernel<Shape, V, 16, 4>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g);
+    return QSX_OK;
+  }
   hipLaunchKernelGGL((agg_hash_shape_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g, S, rep_shift, nbuf,
                      ranges, pieces);
   return QSX_OK;
