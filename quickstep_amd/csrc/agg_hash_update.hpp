@@ -701,10 +701,11 @@ __global__ __launch_bounds__(kABlock) void agg_hash_shape_kernel(ColumnPointers 
 // The same with the launch geometry of the common small-group case (one tile buffer, one workgroup family) as constants:
 // the plane / slot arithmetic of the tile loop folds instead of occupying scalar registers (what made the run-time shapes
 // 10 % faster once they got their geometry as constants).
-template <typename Shape, int V, int S_, int REP_SHIFT_>
-__global__ __launch_bounds__(kABlock) void agg_hash_shape_fixed_kernel(ColumnPointers cols, int64_t n, HashTableView g) {
+template <typename Shape, int V, int S_, int REP_SHIFT_, int RANGES_>
+__global__ __launch_bounds__(kABlock) void agg_hash_shape_fixed_kernel(ColumnPointers cols, int64_t n, HashTableView g,
+                                                                      const long long *__restrict__ pieces) {
   static constexpr Translated T = Shape::translated(kABlock * V);
-  agg_hash_update_body<true, false, T.num_sums, V>(T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, S_, REP_SHIFT_, 1, 1, nullptr);
+  agg_hash_update_body<true, false, T.num_sums, V>(T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, S_, REP_SHIFT_, 1, RANGES_, pieces);
 }
 
 }  // namespace qsx

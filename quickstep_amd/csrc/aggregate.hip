@@ -682,16 +682,23 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
     std::fprintf(stderr, "[qsx] shape launch grid=%d lds=%zu S=%d rep_shift=%d nbuf=%d ranges=%d tile_bytes=%d n=%lld\n", grid, lds, S,
                  rep_shift, nbuf, ranges, T.dev.tile_bytes, static_cast<long long>(n));
   }
-  if (S == 16 && rep_shift == 4 && nbuf == 1 && ranges == 1 && pieces == nullptr) {   // the default small-group geometry
-    static bool fixed_attribute_set = false;
-    if (!fixed_attribute_set) {
-      QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_kernel<Shape, V, 16, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
-      fixed_attribute_set = true;
-    }
-    hipLaunchKernelGGL((agg_hash_shape_fixed_kernel<Shape, V, 16, 4>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g);
-    return QSX_OK;
-  }
+  // the two geometries the defaults produce — a handful of groups in one family (Q1), and the partitioned path's 32 pieces
+  // with 1024-slot tables (10 k groups) — have kernels with those numbers as constants
+#define QSX_LAUNCH_FIXED(S_, REP_, RANGES_)                                                                                        \
+  do {                                                                                                                             \
+    static bool fixed_attribute_set = false;                                                                                       \
+    if (!fixed_attribute_set) {                                                                                                    \
+      QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_kernel<Shape, V, S_, REP_, RANGES_>),   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));                    \
+      fixed_attribute_set = true;                                                                                                  \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((agg_hash_shape_fixed_kernel<Shape, V, S_, REP_, RANGES_>), dim3(grid), dim3(kABlock), lds, stream, cp, n,  \
+                       g, pieces);                                                                                                 \
+    return QSX_OK;                                                                                                                 \
+  } while (0)
+  if (nbuf == 1 && S == 16 && rep_shift == 4 && ranges == 1 && pieces == nullptr) QSX_LAUNCH_FIXED(16, 4, 1);
+  if (nbuf == 1 && S == 1024 && rep_shift == 0 && ranges == 32 && pieces != nullptr) QSX_LAUNCH_FIXED(1024, 0, 32);
+#undef QSX_LAUNCH_FIXED
   hipLaunchKernelGGL((agg_hash_shape_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g, S, rep_shift, nbuf,
                      ranges, pieces);
   return QSX_OK;
