@@ -108,10 +108,12 @@ struct ScatterArgs {
   void *dst[QSX_MAX_COLUMNS];
 };
 
-template <typename Loader, int MODE, bool kSmallP>
-__global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key, int64_t n, int P,
+// PT > 0: the partition count as a constant (8 = one partition per GPU of a node, the shuffle's case); 0 = run-time P.
+template <typename Loader, int MODE, bool kSmallP, int PT = 0>
+__global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key, int64_t n, int P_arg,
                                                                 int pow2, int64_t rows_per_block, int64_t G,
                                                                 int32_t *__restrict__ hist) {
+  const int P = PT > 0 ? PT : P_arg;
   __shared__ int s_total[kWave];
   const int lane = lane_id();
   if (threadIdx.x < kWave) s_total[threadIdx.x] = 0;
@@ -172,8 +174,8 @@ __device__ __forceinline__ void stage_and_copy(const void *src, void *dst, unsig
   __syncthreads();
 }
 
-template <typename Loader, int MODE, bool kSmallP>
-__global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(Loader load_key, int64_t n, int P,
+template <typename Loader, int MODE, bool kSmallP, int PT = 0>
+__global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(Loader load_key, int64_t n, int P_arg,
                                                                    int pow2, int64_t rows_per_block, int64_t G,
                                                                    const int64_t *__restrict__ starts,
                                                                    ScatterArgs args, int stage_width,
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(Loader load_
   // dynamic LDS: stage[kPTile * widest column] | cnt[kPCells * P] — sized by the launch so that small
   // P / narrow columns leave room for more workgroups per CU (the tile loop is a chain of
   // load -> LDS -> barrier -> store phases: occupancy is what hides their latencies)
+  const int P = PT > 0 ? PT : P_arg;
   extern __shared__ __attribute__((aligned(8))) unsigned char s_dyn[];
   unsigned char *s_stage = s_dyn;
   int *s_cnt = reinterpret_cast<int *>(s_dyn + static_cast<size_t>(kPTile) * stage_width);  // [cell][partition]
@@ -349,7 +352,10 @@ static int launch_partition_t(Loader keys, int64_t n, int P, int pow2, const Sca
   char *after = static_cast<char *>(workspace) + p_align_up(sizeof(int64_t) * (cells + 1), 256);
   int32_t *hist = reinterpret_cast<int32_t *>(after);
   int64_t *scan_ws = reinterpret_cast<int64_t *>(after + p_align_up(sizeof(int32_t) * cells, 256));
-  if (P <= 8) {
+  if (P == 8) {
+    hipLaunchKernelGGL((partition_hist_kernel<Loader, MODE, true, 8>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys, n, P,
+                       pow2, rows_per_block, G, hist);
+  } else if (P <= 8) {
     hipLaunchKernelGGL((partition_hist_kernel<Loader, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys, n, P,
                        pow2, rows_per_block, G, hist);
   } else {
@@ -367,7 +373,10 @@ static int launch_partition_t(Loader keys, int64_t n, int P, int pow2, const Sca
   int stage_width = 1;
   for (int c = 0; c < args.ncols; ++c) stage_width = args.width[c] > stage_width ? args.width[c] : stage_width;
   const size_t lds = static_cast<size_t>(kPTile) * stage_width + sizeof(int) * kPCells * P;
-  if (P <= 8) {
+  if (P == 8) {
+    hipLaunchKernelGGL((partition_scatter_kernel<Loader, MODE, true, 8>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
+                       n, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
+  } else if (P <= 8) {
     hipLaunchKernelGGL((partition_scatter_kernel<Loader, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
                        n, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
   } else {
