@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define QSX_ABI_VERSION 3
+#define QSX_ABI_VERSION 4
 
 typedef void *qsx_stream_t;
 
@@ -421,7 +421,16 @@ typedef struct qsx_agg_config {
   qsx_agg_desc_t aggs[QSX_MAX_AGGS];
   int32_t num_pred_terms;
   qsx_pred_term_t pred[QSX_MAX_PRED_TERMS];
-  int64_t est_groups;                     /* optimizer estimate; tables grow past it */
+  int64_t est_groups;                     /* optimizer estimate (ExecutionGenerator.cpp:1922-1965).  The table is created with
+                                             8x head-room and GROWS past it like the reference's tables
+                                             (PackedPayloadHashTable::resize, ThreadPrivateCompactKeyHashTable::resize): groups
+                                             that find no slot during an update go to a spill log inside the state (1 Mi
+                                             records) instead of being dropped, and the table is enlarged 4x or more and the
+                                             log folded back in before the next update launch that sees it and before every
+                                             num_groups / finalize / export / merge.  Only when one update call spills more than
+                                             the log holds (an estimate several orders of magnitude too low on a call of
+                                             millions of rows) are rows lost: num_groups / finalize / export then return
+                                             QSX_ERR_TOO_MANY_GROUPS and the caller re-runs with a larger estimate. */
   int64_t num_entries;                    /* COLLISION_FREE only: max_key + 1 (StarSchemaSimpleCostModel.cpp:707) */
   int32_t column_code_width[QSX_MAX_COLUMNS]; /* 0: the column arrives as values.  1 / 2 / 4: it arrives as a stripe of
                                              unsigned codes of that width (a compressed attribute of a
@@ -477,18 +486,22 @@ int qsx_agg_update_coded(qsx_agg_state_t *state, const void *const *cols, const 
 int qsx_agg_mark_existence(qsx_agg_state_t *state, int key_type, const void *keys_dev, int64_t n,
                            const uint64_t *filter_dev, qsx_stream_t stream);
 
-/* dst += src (same config).  Counterpart of
+/* dst += src (same config; the two tables may have grown to different capacities).  Counterpart of
  * ThreadPrivateCompactKeyHashTable::mergeFrom (.cpp:306-363) and
- * AggregationOperationState::mergeGroupByHashTables (.cpp:831-843). */
-int qsx_agg_merge(qsx_agg_state_t *dst, const qsx_agg_state_t *src, qsx_stream_t stream);
+ * AggregationOperationState::mergeGroupByHashTables (.cpp:831-843).  Synchronises on `stream` (the source is
+ * brought to rest first). */
+int qsx_agg_merge(qsx_agg_state_t *dst, qsx_agg_state_t *src, qsx_stream_t stream);
 
 /* Raw partial state for transport between GPUs (RCCL all-gather /
  * reduce-scatter of partial aggregates).  Layout per strategy is described in
- * DESIGN.md; size is fixed once the state is created. */
-int qsx_agg_state_export_bytes(const qsx_agg_state_t *state, size_t *out_bytes);
-int qsx_agg_state_export(const qsx_agg_state_t *state, void *out_dev, qsx_stream_t stream);
-/* dst += exported image of a state with the same config. */
-int qsx_agg_state_import_merge(qsx_agg_state_t *dst, const void *image_dev, qsx_stream_t stream);
+ * DESIGN.md.  The image of a hash strategy grows with its table: ask for the size (synchronises on `stream`, folds
+ * spilled rows in) right before exporting; the size stays valid until the next update / merge into the state.
+ * COLLISION_FREE and SINGLE_STATE images never change size. */
+int qsx_agg_state_export_bytes(qsx_agg_state_t *state, size_t *out_bytes, qsx_stream_t stream);
+/* QSX_ERR_CAPACITY when the image no longer fits capacity_bytes. */
+int qsx_agg_state_export(qsx_agg_state_t *state, void *out_dev, size_t capacity_bytes, qsx_stream_t stream);
+/* dst += exported image (image_bytes long) of a state with the same config.  Stream-ordered. */
+int qsx_agg_state_import_merge(qsx_agg_state_t *dst, const void *image_dev, size_t image_bytes, qsx_stream_t stream);
 
 /* Upper bound on the number of groups a finalize of partition p can emit.
  * Synchronises on `stream`. */

@@ -91,9 +91,9 @@ _SIGNATURES = {
     "qsx_agg_mark_existence": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "qsx_agg_update_coded": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
     "qsx_agg_merge": (_int, [_vp, _vp, _vp]),
-    "qsx_agg_state_export_bytes": (_int, [_vp, C.POINTER(_sz)]),
-    "qsx_agg_state_export": (_int, [_vp, _vp, _vp]),
-    "qsx_agg_state_import_merge": (_int, [_vp, _vp, _vp]),
+    "qsx_agg_state_export_bytes": (_int, [_vp, C.POINTER(_sz), _vp]),
+    "qsx_agg_state_export": (_int, [_vp, _vp, _sz, _vp]),
+    "qsx_agg_state_import_merge": (_int, [_vp, _vp, _sz, _vp]),
     "qsx_agg_num_groups": (_int, [_vp, C.POINTER(_i64), _vp]),
     "qsx_agg_finalize": (_int, [_vp, _int, _int, _pp, _pp, _pp, _i64, _vp, _vp]),
     "qsx_lip_filter_create": (_int, [_int, _i64, _i64, _int, _pp]),
@@ -455,20 +455,23 @@ class AggState:
     def merge(self, other, stream=None):
         _check(_lib.qsx_agg_merge(self._h, other._h, _stream(stream)), "qsx_agg_merge")
 
-    def export_bytes(self):
+    def export_bytes(self, stream=None):
+        """Size of the image right now (a hash-strategy table may have grown); synchronises."""
         v = C.c_size_t()
-        _check(_lib.qsx_agg_state_export_bytes(self._h, C.byref(v)), "qsx_agg_state_export_bytes")
+        _check(_lib.qsx_agg_state_export_bytes(self._h, C.byref(v), _stream(stream)), "qsx_agg_state_export_bytes")
         return v.value
 
     def export(self, device, stream=None):
         """Raw image as an int64 tensor (8-byte words)."""
-        nbytes = self.export_bytes()
+        nbytes = self.export_bytes(stream)
         out = torch.empty(nbytes // 8, dtype=torch.int64, device=device)
-        _check(_lib.qsx_agg_state_export(self._h, _ptr(out), _stream(stream)), "qsx_agg_state_export")
+        _check(_lib.qsx_agg_state_export(self._h, _ptr(out), nbytes, _stream(stream)), "qsx_agg_state_export")
         return out
 
     def import_merge(self, image, stream=None):
-        _check(_lib.qsx_agg_state_import_merge(self._h, _ptr(image), _stream(stream)), "qsx_agg_state_import_merge")
+        """image: int64 tensor holding exactly one exported image (its length tells the source table's capacity)."""
+        _check(_lib.qsx_agg_state_import_merge(self._h, _ptr(image), image.numel() * image.element_size(), _stream(stream)),
+               "qsx_agg_state_import_merge")
 
     def num_groups(self, stream=None):
         v = C.c_int64()

@@ -108,7 +108,16 @@ struct HashTableView {
   unsigned long long cap;      // power of two
   int shift;                   // 64 - log2(cap)
   unsigned long long *ngroups; // groups inserted (sentinel slot not counted)
-  int *overflow;               // set when an insert found the table full
+  int *overflow;               // set when a group found room neither in the table nor in the spill log
+  // Spill log (growable states; log_cap == 0 otherwise): a group whose probe sequence is exhausted — the optimizer's
+  // estimate was too low and the table has not been grown yet — gets a private record {code, col 0 .. col NC-1} here
+  // instead of being dropped.  The host grows the table and folds the records back in before the next launch that sees
+  // them and before every finalize / export (aggregate.hip: settle); the reference resizes in place under an exclusive
+  // lock (storage/PackedPayloadHashTable.cpp:232-288, ThreadPrivateCompactKeyHashTable.cpp:159-201).
+  unsigned long long *log;     // [log_cap][log_stride], every record pre-initialised with the columns' identities
+  unsigned int *log_count;
+  unsigned int log_cap;
+  int log_stride;              // NC + 1 words
 };
 
 struct DenseView {
@@ -136,12 +145,19 @@ __device__ __forceinline__ unsigned long long code_slot(unsigned long long code,
   return (mix64(code) * 0x9E3779B97F4A7C15ull) >> shift;
 }
 
-// Returns the slot of `code` (inserting it if new), cap for the sentinel
-// code, or ~0 when the table is full (overflow flag raised).
+// Probing is bounded: below the load the host keeps the table at (<= 1/4 once it has seen the group count, aggregate.hip)
+// a run of kGlobalMaxProbes occupied slots does not happen, and a table that filled up behind the host's back costs a
+// miss 128 reads instead of cap.  A code that fails once fails every time (slots never free up), so its rows
+// consistently go to the spill log.
+constexpr unsigned long long kGlobalMaxProbes = 128;
+
+// Returns where `code` accumulates: its slot (inserting it if new), cap for the sentinel code, cap + 1 + r for
+// a fresh record r of the spill log, or ~0 when neither has room (overflow flag raised).
 __device__ __forceinline__ unsigned long long global_find_or_insert(const HashTableView &g, unsigned long long code) {
   if (code == kEmptyCode) return g.cap;
   unsigned long long s = code_slot(code, g.shift);
-  for (unsigned long long probes = 0; probes < g.cap; ++probes) {
+  const unsigned long long limit = g.cap < kGlobalMaxProbes ? g.cap : kGlobalMaxProbes;
+  for (unsigned long long probes = 0; probes < limit; ++probes) {
     unsigned long long k = __hip_atomic_load(&g.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == code) return s;
     if (k == kEmptyCode) {
@@ -153,6 +169,13 @@ __device__ __forceinline__ unsigned long long global_find_or_insert(const HashTa
       if (k == code) return s;
     }
     s = (s + 1) & (g.cap - 1);
+  }
+  if (g.log_cap != 0) {
+    const unsigned int r = atomicAdd(g.log_count, 1u);
+    if (r < g.log_cap) {
+      g.log[static_cast<unsigned long long>(r) * g.log_stride] = code;
+      return g.cap + 1 + r;
+    }
   }
   atomicExch(g.overflow, 1);
   return ~0ull;
@@ -171,7 +194,9 @@ __device__ __forceinline__ void global_accumulate(unsigned long long *p, unsigne
 }
 __device__ __forceinline__ void global_add(const HashTableView &g, int col, unsigned long long slot,
                                            unsigned long long inc, int kind) {
-  global_accumulate(g.states + static_cast<unsigned long long>(col) * (g.cap + 1) + slot, inc, kind);
+  unsigned long long *p = slot <= g.cap ? g.states + static_cast<unsigned long long>(col) * (g.cap + 1) + slot
+                                        : g.log + (slot - g.cap - 1) * g.log_stride + 1 + col;
+  global_accumulate(p, inc, kind);
 }
 
 // ---- LDS table ------------------------------------------------------------------

@@ -42,6 +42,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 namespace qsx {
@@ -103,6 +104,47 @@ __global__ __launch_bounds__(kABlock) void merge_dense_kernel(const unsigned lon
       global_accumulate(&dst[i], v, kind);
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// growth of the hash-strategy table: spill log + published control words
+// ---------------------------------------------------------------------------
+// Records [first, first + count) of a spill log back to "unused": every column word holds its identity (the record's
+// owner accumulates into it without initialising anything).  count = *count_dev when that is given (clear: only the
+// records a previous run touched are rewritten).
+__global__ __launch_bounds__(kABlock) void init_log_kernel(unsigned long long *__restrict__ log, int stride,
+                                                          unsigned long long count, const unsigned int *__restrict__ count_dev,
+                                                          unsigned int log_cap, ColKinds kinds) {
+  if (count_dev != nullptr) count = *count_dev < log_cap ? *count_dev : log_cap;
+  const unsigned long long words = count * stride;
+  for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * kABlock + threadIdx.x; i < words;
+       i += static_cast<unsigned long long>(gridDim.x) * kABlock) {
+    const int w = static_cast<int>(i % stride);
+    log[i] = w == 0 ? kEmptyCode : static_cast<unsigned long long>(acc_identity(kinds.kind[w - 1]));
+  }
+}
+
+// Fold spill records into the (grown) table; a record that still finds no slot is appended to `g`'s own log.
+__global__ __launch_bounds__(kABlock) void drain_log_kernel(const unsigned long long *__restrict__ records, unsigned int count,
+                                                           int stride, int num_cols, ColKinds kinds, HashTableView g) {
+  for (unsigned int r = blockIdx.x * kABlock + threadIdx.x; r < count; r += gridDim.x * kABlock) {
+    const unsigned long long *rec = records + static_cast<unsigned long long>(r) * stride;
+    const unsigned long long gs = global_find_or_insert(g, rec[0]);
+    if (gs == ~0ull) continue;
+    for (int col = 0; col < num_cols; ++col) global_add(g, col, gs, rec[1 + col], kinds.kind[col]);
+  }
+}
+
+// One lane copies the control words to host-visible memory behind an update: {groups, spilled records, overflow flag,
+// sequence}.  The host reads them without synchronising (maybe_grow), so a table that is filling up grows between two
+// update calls instead of failing at finalize.
+__global__ void publish_control_kernel(const unsigned long long *__restrict__ control, unsigned long long *host_slot,
+                                       unsigned long long seq) {
+  if (threadIdx.x != 0) return;
+  __hip_atomic_store(&host_slot[0], control[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&host_slot[1], control[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&host_slot[2], control[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&host_slot[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------
@@ -375,6 +417,10 @@ using namespace qsx;
 // ===========================================================================
 // host side
 // ===========================================================================
+// Spill-log records per growable state: what one update call may leave outside the table before the host grows it
+// (a 0.5 M-row block whose groups the estimate missed entirely still fits).
+constexpr unsigned int kLogRecords = 1u << 20;
+
 struct qsx_agg_state {
   qsx_agg_config_t config;
   bool has_coded_columns = false;   // some column arrives as codes of a compressed attribute
@@ -397,8 +443,19 @@ struct qsx_agg_state {
   size_t image_bytes = 0;
   unsigned long long cap = 0;      // hash strategies
   long long exist_words = 0;       // dense
-  // control words: [0] ngroups (u64), [1] overflow|error flag (int), [2] scratch counter
+  // control words: [0] ngroups (u64), [1] overflow|error flag (int), [2] scratch counter, [3] spilled records (u32)
   unsigned long long *control = nullptr;
+  // ---- growth (COMPACT_KEY / GENERIC) ----
+  // Update / merge launches hold `table_mutex` shared (they read image, cap, geometry); growth holds it exclusive after
+  // draining the device — the role of the reference's resize lock (storage/HashTable.hpp:1215 for the join table,
+  // PackedPayloadHashTable::resize for this one).
+  bool growable = false;
+  mutable std::shared_mutex table_mutex;
+  unsigned long long *log = nullptr;          // spill log, kLogRecords records of (num_cols + 1) words
+  unsigned long long *published = nullptr;    // host-visible copy of {ngroups, spilled, overflow, seq} (publish_control_kernel)
+  unsigned long long *published_dev = nullptr;
+  std::atomic<unsigned long long> publish_seq{0};
+  int64_t geometry_est = 1;                   // the group count the LDS geometry below was derived for
   // scratch for ordered dense finalize
   int32_t *tile_counts = nullptr;
   int64_t *tile_offsets = nullptr;
@@ -431,6 +488,10 @@ struct qsx_agg_state {
     g.shift = 64 - log2;
     g.ngroups = control;
     g.overflow = reinterpret_cast<int *>(control + 1);
+    g.log = log;
+    g.log_count = reinterpret_cast<unsigned int *>(control + 3);
+    g.log_cap = log != nullptr ? kLogRecords : 0u;
+    g.log_stride = num_cols + 1;
     return g;
   }
   DenseView dense_view() const {
@@ -885,12 +946,168 @@ static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const ui
     default: FN<8>(__VA_ARGS__); break;   \
   }
 
-static int check_flags(qsx_agg_state *st, hipStream_t stream) {
-  unsigned long long control[2];
+// LDS-table geometry of the update kernel for `est` groups (launch_hash_v / launch_shape_v / the run-time shapes).
+static void derive_geometry(qsx_agg_state *st, int64_t est) {
+  st->geometry_est = est;
+  st->lds_ranges = 1;
+  st->part_count = 1;
+  st->part_slots = 64;
+  // workgroup-private LDS table: up to 512 slots (<= 40 KiB at NS = 8)
+  uint64_t s = next_pow2(static_cast<uint64_t>(est) * 2);
+  if (s < 8) s = 8;
+  if (s > 512) {
+    // More groups than a replicated 512-slot table holds: take the biggest unreplicated LDS
+    // table that fits 104 KiB and split the groups over up to 8 hash ranges (each range reads
+    // the whole input); beyond that, one range and the overflow goes to the global table.
+    uint64_t smax = 4096;
+    while (smax > 512 && 8 * (smax + static_cast<uint64_t>(st->num_sums + 1) * (smax + 64)) > 104 * 1024) smax >>= 1;
+    const uint64_t ranges = (static_cast<uint64_t>(est) * 10 + smax * 7 - 1) / (smax * 7);  // load <= 0.7
+    if (smax > 512 && ranges <= 8) {
+      s = smax;
+      st->lds_ranges = static_cast<int>(ranges < 1 ? 1 : ranges);
+    } else {
+      s = 512;
+    }
+  }
+  st->lds_slots = static_cast<int>(s);
+  if (st->lds_ranges > 1 || (static_cast<uint64_t>(est) * 10 > s * 7 && est > 256)) {
+    // ~350 groups per piece -> a 1024-slot table at load <= 0.35 with room for replication
+    uint64_t pieces = next_pow2((static_cast<uint64_t>(est) + 349) / 350);
+    if (pieces > 64) pieces = 64;
+    if (pieces > 1) {
+      st->part_count = static_cast<int>(pieces);
+      uint64_t ps = next_pow2((static_cast<uint64_t>(est) / pieces + 1) * 3);
+      if (ps < 64) ps = 64;
+      if (ps > 4096) ps = 4096;
+      st->part_slots = static_cast<int>(ps);
+    }
+  }
+}
+
+static hipError_t init_hash_image(qsx_agg_state *st, unsigned long long *image, unsigned long long cap, hipStream_t s) {
+  hipError_t err = hipMemsetAsync(image, 0xFF, sizeof(unsigned long long) * (cap + 1), s);
+  if (err == hipSuccess) err = hipMemsetAsync(image + (cap + 1), 0, sizeof(unsigned long long) * (cap + 1) * st->num_cols, s);
+  if (err == hipSuccess && st->has_min_max) {
+    hipLaunchKernelGGL(fill_identity_kernel, dim3(grid_for(static_cast<long long>(cap + 1), kABlock * 4)), dim3(kABlock), 0, s,
+                       image + (cap + 1), static_cast<long long>(cap + 1), static_cast<long long>(cap + 1), st->num_cols, st->col_kinds);
+    err = hipGetLastError();
+  }
+  return err;
+}
+
+static int init_log(qsx_agg_state *st, unsigned long long *log, unsigned long long count, const unsigned int *count_dev, hipStream_t s) {
+  // (count on the device: normally 0 — a small grid that strides over whatever it finds)
+  const unsigned long long words = count_dev != nullptr ? 256ull * kABlock * 8 : count * (st->num_cols + 1);
+  hipLaunchKernelGGL(init_log_kernel, dim3(grid_for(static_cast<int64_t>(words), kABlock * 8)), dim3(kABlock), 0, s, log, st->num_cols + 1,
+                     count, count_dev, kLogRecords, st->col_kinds);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+// Grow the table until it holds its groups at load <= 1/4 and the spill log is empty.  Caller holds table_mutex
+// exclusively.  Counterpart of PackedPayloadHashTable::resize (storage/PackedPayloadHashTable.cpp:232-288) and
+// ThreadPrivateCompactKeyHashTable::resize (.cpp:159-201), which double in place under the table's lock.
+static int grow_and_drain(qsx_agg_state *st) {
+  QSX_HIP_TRY(hipDeviceSynchronize());   // drain in-flight updates on every stream
+  for (int round = 0; round < 40; ++round) {
+    unsigned long long control[4];
+    QSX_HIP_TRY(hipMemcpy(control, st->control, sizeof(control), hipMemcpyDeviceToHost));
+    const unsigned long long groups = control[0];
+    const unsigned long long spilled = control[3] & 0xFFFFFFFFull;
+    if (static_cast<int>(control[1] & 0xFFFFFFFFu) != 0) return QSX_ERR_TOO_MANY_GROUPS;   // the log itself overflowed: rows were lost
+    if (spilled == 0 && groups * 4 <= st->cap) break;
+    unsigned long long new_cap = st->cap * 4;
+    while (new_cap < 16 * groups) new_cap <<= 1;
+    const size_t new_bytes = sizeof(unsigned long long) * (new_cap + 1) * (st->num_cols + 1);
+    unsigned long long *bigger = nullptr, *old_log = nullptr;
+    QSX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&bigger), new_bytes));
+    hipError_t err = init_hash_image(st, bigger, new_cap, nullptr);
+    if (err == hipSuccess && spilled != 0) {
+      // the spilled records are re-inserted from a copy: what still finds no slot goes to the (reset) log again
+      err = hipMalloc(reinterpret_cast<void **>(&old_log), sizeof(unsigned long long) * spilled * (st->num_cols + 1));
+      if (err == hipSuccess) err = hipMemcpy(old_log, st->log, sizeof(unsigned long long) * spilled * (st->num_cols + 1), hipMemcpyDeviceToDevice);
+    }
+    if (err != hipSuccess) {
+      set_last_error("grow_and_drain", err);
+      (void)hipFree(bigger);
+      (void)hipFree(old_log);
+      return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
+    }
+    unsigned long long *old_image = st->image;
+    const unsigned long long old_cap = st->cap;
+    if (spilled != 0) {
+      int rc = init_log(st, st->log, spilled, nullptr, nullptr);
+      if (rc != QSX_OK) return rc;
+    }
+    QSX_HIP_TRY(hipMemset(st->control, 0, 4 * sizeof(unsigned long long)));   // the merge below recounts the groups
+    st->image = bigger;
+    st->cap = new_cap;
+    st->image_bytes = new_bytes;
+    const HashTableView g = st->hash_view();
+    hipLaunchKernelGGL(merge_hash_kernel, dim3(grid_for(old_cap + 1, kABlock)), dim3(kABlock), 0, nullptr, old_image, old_cap,
+                       st->num_cols, st->col_kinds, g);
+    QSX_CHECK_LAUNCH();
+    if (spilled != 0) {
+      hipLaunchKernelGGL(drain_log_kernel, dim3(grid_for(static_cast<int64_t>(spilled), kABlock)), dim3(kABlock), 0, nullptr, old_log,
+                         static_cast<unsigned int>(spilled), st->num_cols + 1, st->num_cols, st->col_kinds, g);
+      QSX_CHECK_LAUNCH();
+    }
+    QSX_HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(old_image);
+    (void)hipFree(old_log);
+  }
+  unsigned long long groups = 0;
+  QSX_HIP_TRY(hipMemcpy(&groups, st->control, sizeof(groups), hipMemcpyDeviceToHost));
+  st->published[0] = groups;
+  st->published[1] = 0;
+  // The estimate was off: give the update kernel the LDS geometry of the group count actually seen (a table sized for 6
+  // groups sends nearly every row of a 10 k-group input down the per-row global path).
+  if (static_cast<int64_t>(groups) > 2 * st->geometry_est) {
+    derive_geometry(st, static_cast<int64_t>(groups) * 2);
+    std::lock_guard<std::mutex> lock(st->jit_mutex);   // run-time shapes carry the geometry as constants: ask again
+    for (int v = 0; v < 4; ++v) {
+      st->jit_request[v] = nullptr;
+      st->jit[v] = nullptr;
+      st->jit_tried[v] = false;
+    }
+  }
+  return QSX_OK;
+}
+
+// Before an update launch: grow when the control words published behind the previous launches say the table is past
+// load 1/4 or rows went to the spill log.  Never waits for the device unless it grows.
+static int maybe_grow(qsx_agg_state *st) {
+  if (!st->growable) return QSX_OK;
+  const unsigned long long groups = __atomic_load_n(&st->published[0], __ATOMIC_ACQUIRE);
+  const unsigned long long spilled = __atomic_load_n(&st->published[1], __ATOMIC_ACQUIRE);
+  {
+    std::shared_lock<std::shared_mutex> lock(st->table_mutex);
+    if (spilled == 0 && groups * 4 <= st->cap) return QSX_OK;
+  }
+  std::unique_lock<std::shared_mutex> lock(st->table_mutex);
+  return grow_and_drain(st);
+}
+
+// Behind an update launch (same stream): refresh the published control words.
+static int publish_control(qsx_agg_state *st, hipStream_t s) {
+  if (!st->growable) return QSX_OK;
+  hipLaunchKernelGGL(publish_control_kernel, dim3(1), dim3(64), 0, s, st->control, st->published_dev, st->publish_seq.fetch_add(1) + 1);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+// In front of everything that reads the state as a whole (group count, finalize, export, merge source): wait for the
+// stream, fold spilled rows back in, report lost rows.
+static int settle(qsx_agg_state *st, hipStream_t stream) {
+  unsigned long long control[4];
   QSX_HIP_TRY(hipMemcpyAsync(control, st->control, sizeof(control), hipMemcpyDeviceToHost, stream));
   QSX_HIP_TRY(hipStreamSynchronize(stream));
   if (static_cast<int>(control[1] & 0xFFFFFFFFu) != 0) {
     return st->dense ? QSX_ERR_INVALID_ARGUMENT : QSX_ERR_TOO_MANY_GROUPS;
+  }
+  if (st->growable && ((control[3] & 0xFFFFFFFFull) != 0 || control[0] * 4 > st->cap)) {
+    std::unique_lock<std::shared_mutex> lock(st->table_mutex);
+    return grow_and_drain(st);
   }
   return QSX_OK;
 }
@@ -911,46 +1128,27 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     st->max_tiles = (st->exist_words + kDenseTileWords - 1) / kDenseTileWords + 1;
   } else {
     const int64_t est = config->strategy == QSX_AGG_SINGLE_STATE ? 1 : (config->est_groups < 1 ? 1 : config->est_groups);
-    // generous head-room: the estimate comes from the optimizer and a full
-    // table cannot be grown in the middle of a kernel
+    // generous head-room: the estimate comes from the optimizer and a table cannot be grown in the middle of a
+    // kernel — groups beyond it land in the spill log and the table grows before the next launch (maybe_grow / settle)
     st->cap = next_pow2(static_cast<uint64_t>(est) * 8 + 1024);
     st->image_bytes = sizeof(unsigned long long) * (st->cap + 1) * (st->num_cols + 1);
-    // workgroup-private LDS table: up to 512 slots (<= 40 KiB at NS = 8)
-    uint64_t s = next_pow2(static_cast<uint64_t>(est) * 2);
-    if (s < 8) s = 8;
-    if (s > 512) {
-      // More groups than a replicated 512-slot table holds: take the biggest unreplicated LDS
-      // table that fits 104 KiB and split the groups over up to 8 hash ranges (each range reads
-      // the whole input); beyond that, one range and the overflow goes to the global table.
-      uint64_t smax = 4096;
-      while (smax > 512 && 8 * (smax + static_cast<uint64_t>(st->num_sums + 1) * (smax + 64)) > 104 * 1024) smax >>= 1;
-      const uint64_t ranges = (static_cast<uint64_t>(est) * 10 + smax * 7 - 1) / (smax * 7);  // load <= 0.7
-      if (smax > 512 && ranges <= 8) {
-        s = smax;
-        st->lds_ranges = static_cast<int>(ranges < 1 ? 1 : ranges);
-      } else {
-        s = 512;
-      }
-    }
-    st->lds_slots = static_cast<int>(s);
-    if (st->lds_ranges > 1 || (static_cast<uint64_t>(est) * 10 > s * 7 && est > 256)) {
-      // ~350 groups per piece -> a 1024-slot table at load <= 0.35 with room for replication
-      uint64_t pieces = next_pow2((static_cast<uint64_t>(est) + 349) / 350);
-      if (pieces > 64) pieces = 64;
-      if (pieces > 1) {
-        st->part_count = static_cast<int>(pieces);
-        uint64_t ps = next_pow2((static_cast<uint64_t>(est) / pieces + 1) * 3);
-        if (ps < 64) ps = 64;
-        if (ps > 4096) ps = 4096;
-        st->part_slots = static_cast<int>(ps);
-      }
-    }
+    derive_geometry(st, est);
+    st->growable = config->strategy != QSX_AGG_SINGLE_STATE;
   }
   hipError_t err = hipMalloc(reinterpret_cast<void **>(&st->image), st->image_bytes);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->control), 4 * sizeof(unsigned long long));
   if (err == hipSuccess && st->dense) {
     err = hipMalloc(reinterpret_cast<void **>(&st->tile_counts), sizeof(int32_t) * st->max_tiles);
     if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->tile_offsets), sizeof(int64_t) * (st->max_tiles + 1));
+  }
+  if (err == hipSuccess && st->growable) {
+    err = hipMalloc(reinterpret_cast<void **>(&st->log), sizeof(unsigned long long) * kLogRecords * (st->num_cols + 1));
+    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void **>(&st->published), 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    if (err == hipSuccess) {
+      std::memset(st->published, 0, 4 * sizeof(unsigned long long));
+      err = hipHostGetDevicePointer(reinterpret_cast<void **>(&st->published_dev), st->published, 0);
+    }
+    if (err == hipSuccess && init_log(st, st->log, kLogRecords, nullptr, nullptr) != QSX_OK) err = hipErrorUnknown;
   }
   if (err == hipSuccess) err = hipMemset(st->control, 0, 4 * sizeof(unsigned long long));
   if (err == hipSuccess) {
@@ -969,6 +1167,8 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
   if (err != hipSuccess) {
     set_last_error("qsx_agg_state_create", err);
     (void)hipFree(st->image); (void)hipFree(st->control); (void)hipFree(st->tile_counts); (void)hipFree(st->tile_offsets);
+    (void)hipFree(st->log);
+    if (st->published != nullptr) (void)hipHostFree(st->published);
     delete st;
     return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
   }
@@ -983,6 +1183,8 @@ int qsx_agg_state_destroy(qsx_agg_state_t *st) {
   (void)hipFree(st->control);
   (void)hipFree(st->tile_counts);
   (void)hipFree(st->tile_offsets);
+  (void)hipFree(st->log);
+  if (st->published != nullptr) (void)hipHostFree(st->published);
   delete st;
   return QSX_OK;
 }
@@ -991,6 +1193,14 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (st == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   hipStream_t s = as_stream(stream);
+  std::unique_lock<std::shared_mutex> lock(st->table_mutex);
+  if (st->growable) {
+    // records a previous run left in the spill log go back to their identities (before the count is zeroed below)
+    int rc = init_log(st, st->log, 0, reinterpret_cast<const unsigned int *>(st->control + 3), s);
+    if (rc != QSX_OK) return rc;
+    __atomic_store_n(&st->published[0], 0ull, __ATOMIC_RELEASE);
+    __atomic_store_n(&st->published[1], 0ull, __ATOMIC_RELEASE);
+  }
   if (st->dense) {
     QSX_HIP_TRY(hipMemsetAsync(st->image, 0, st->image_bytes, s));
   } else {
@@ -1054,11 +1264,25 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   const int ncols = st->config.num_columns;
   constexpr int kAlignRows = 16;
   const int64_t padded = n + static_cast<int64_t>(kAlignRows) * P;
+  // every stream-ordered allocation of this call, released (stream-ordered) on every way out
+  struct AsyncAllocations {
+    hipStream_t stream;
+    std::vector<void *> ptrs;
+    ~AsyncAllocations() {
+      for (void *p : ptrs) (void)hipFreeAsync(p, stream);
+    }
+    int alloc(void **out, size_t bytes) {
+      QSX_HIP_TRY(hipMallocAsync(out, bytes, stream));
+      ptrs.push_back(*out);
+      return QSX_OK;
+    }
+  } scratch{s, {}};
   int64_t *pieces = nullptr;
   void *ws = nullptr;
   const size_t ws_bytes = partition_workspace_bytes(n, P);
-  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&pieces), sizeof(int64_t) * 2 * P, s));
-  QSX_HIP_TRY(hipMallocAsync(&ws, ws_bytes, s));
+  int rc = scratch.alloc(reinterpret_cast<void **>(&pieces), sizeof(int64_t) * 2 * P);
+  if (rc == QSX_OK) rc = scratch.alloc(&ws, ws_bytes);
+  if (rc != QSX_OK) return rc;
   const void *src[QSX_MAX_COLUMNS];
   void *dst[QSX_MAX_COLUMNS];
   void *part_cols[QSX_MAX_COLUMNS];
@@ -1067,7 +1291,8 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   for (int c = 0; c < ncols; ++c) {
     part_cols[c] = nullptr;
     if (!((st->used_columns >> c) & 1u)) continue;
-    QSX_HIP_TRY(hipMallocAsync(&part_cols[c], static_cast<size_t>(padded) * st->dev.column_width[c] + 16, s));
+    rc = scratch.alloc(&part_cols[c], static_cast<size_t>(padded) * st->dev.column_width[c] + 16);
+    if (rc != QSX_OK) return rc;
     src[moved] = cols[c];
     dst[moved] = part_cols[c];
     widths[moved] = st->dev.column_width[c];
@@ -1076,18 +1301,11 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   // the routing key is the packed key code, computed from the key columns inside K9 (never materialised)
   const void *key_cols[QSX_MAX_KEYS];
   for (int k = 0; k < st->dev.num_keys; ++k) key_cols[k] = cols[st->dev.key_column[k]];
-  int rc = partition_scatter_packed_keys(st->dev.num_keys, key_cols, st->dev.key_width, st->dev.key_shift, n, P, moved, src, widths,
-                                         dst, pieces, ws, ws_bytes, s, kAlignRows);
-  if (rc == QSX_OK) {
-    // n only sizes the grid here (an upper bound of every piece); the kernel reads its piece from `pieces`
-    rc = update_slice(st, part_cols, nullptr, n, nullptr, st->part_slots, P, reinterpret_cast<const long long *>(pieces), s);
-  }
-  for (int c = 0; c < ncols; ++c) {
-    if (part_cols[c] != nullptr) QSX_HIP_TRY(hipFreeAsync(part_cols[c], s));
-  }
-  QSX_HIP_TRY(hipFreeAsync(ws, s));
-  QSX_HIP_TRY(hipFreeAsync(pieces, s));
-  return rc;
+  rc = partition_scatter_packed_keys(st->dev.num_keys, key_cols, st->dev.key_width, st->dev.key_shift, n, P, moved, src, widths,
+                                     dst, pieces, ws, ws_bytes, s, kAlignRows);
+  if (rc != QSX_OK) return rc;
+  // n only sizes the grid here (an upper bound of every piece); the kernel reads its piece from `pieces`
+  return update_slice(st, part_cols, nullptr, n, nullptr, st->part_slots, P, reinterpret_cast<const long long *>(pieces), s);
 }
 
 static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *const *dicts, int64_t n,
@@ -1096,11 +1314,17 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
   if (st == nullptr || n < 0 || (n > 0 && st->config.num_columns > 0 && cols == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
   if (n == 0) return QSX_OK;
   hipStream_t s = as_stream(stream);
+  int rc = maybe_grow(st);
+  if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
   // (the partitioned path scatters value columns: states over compressed attributes take the tile path)
   if (!st->dense && st->part_count > 1 && filter_dev == nullptr && !st->has_coded_columns && n >= partition_min_rows()) {
-    return update_partitioned(st, cols, n, s);
+    rc = update_partitioned(st, cols, n, s);
+  } else {
+    rc = update_slice(st, cols, dicts, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s);
   }
-  return update_slice(st, cols, dicts, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s);
+  if (rc != QSX_OK) return rc;
+  return publish_control(st, s);
 }
 
 int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev,
@@ -1145,51 +1369,74 @@ int qsx_agg_mark_existence(qsx_agg_state_t *st, int key_type, const void *keys_d
   return QSX_OK;
 }
 
-int qsx_agg_state_export_bytes(const qsx_agg_state_t *st, size_t *out_bytes) {
+int qsx_agg_state_export_bytes(qsx_agg_state_t *st, size_t *out_bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
   if (st == nullptr || out_bytes == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  // a table that grew has a bigger image: bring it to rest first (spilled rows folded in), then the size is final
+  // until the next update
+  int rc = settle(st, as_stream(stream));
+  if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
   *out_bytes = st->image_bytes;
   return QSX_OK;
 }
 
-int qsx_agg_state_export(const qsx_agg_state_t *st, void *out_dev, qsx_stream_t stream) {
+int qsx_agg_state_export(qsx_agg_state_t *st, void *out_dev, size_t capacity_bytes, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (st == nullptr || out_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  int rc = settle(st, as_stream(stream));
+  if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
+  if (capacity_bytes < st->image_bytes) return QSX_ERR_CAPACITY;
   QSX_HIP_TRY(hipMemcpyAsync(out_dev, st->image, st->image_bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
   return QSX_OK;
 }
 
-int qsx_agg_state_import_merge(qsx_agg_state_t *dst, const void *image_dev, qsx_stream_t stream) {
+int qsx_agg_state_import_merge(qsx_agg_state_t *dst, const void *image_dev, size_t image_bytes, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (dst == nullptr || image_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   const unsigned long long *image = static_cast<const unsigned long long *>(image_dev);
   hipStream_t s = as_stream(stream);
+  int rc = maybe_grow(dst);
+  if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(dst->table_mutex);
   if (dst->dense) {
+    if (image_bytes != dst->image_bytes) return QSX_ERR_INVALID_ARGUMENT;
     const long long total = dst->exist_words + static_cast<long long>(dst->num_cols) * dst->config.num_entries;
     hipLaunchKernelGGL(merge_dense_kernel, dim3(grid_for(total, kABlock * 4)), dim3(kABlock), 0, s, image,
                        dst->image, dst->exist_words, static_cast<long long>(dst->config.num_entries),
                        dst->num_cols, dst->col_kinds);
   } else {
-    hipLaunchKernelGGL(merge_hash_kernel, dim3(grid_for(dst->cap + 1, kABlock)), dim3(kABlock), 0, s, image,
-                       dst->cap, dst->num_cols, dst->col_kinds, dst->hash_view());
+    // the source table may have grown differently: its capacity follows from the image size
+    const size_t row_bytes = sizeof(unsigned long long) * (dst->num_cols + 1);
+    if (image_bytes == 0 || image_bytes % row_bytes != 0) return QSX_ERR_INVALID_ARGUMENT;
+    const unsigned long long src_cap = image_bytes / row_bytes - 1;
+    if (src_cap == 0 || (src_cap & (src_cap - 1)) != 0) return QSX_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(merge_hash_kernel, dim3(grid_for(src_cap + 1, kABlock)), dim3(kABlock), 0, s, image,
+                       src_cap, dst->num_cols, dst->col_kinds, dst->hash_view());
   }
   QSX_CHECK_LAUNCH();
-  return QSX_OK;
+  return publish_control(dst, s);
 }
 
-int qsx_agg_merge(qsx_agg_state_t *dst, const qsx_agg_state_t *src, qsx_stream_t stream) {
-  if (dst == nullptr || src == nullptr) return QSX_ERR_INVALID_ARGUMENT;
-  if (dst->image_bytes != src->image_bytes || dst->num_cols != src->num_cols || dst->dense != src->dense) {
+int qsx_agg_merge(qsx_agg_state_t *dst, qsx_agg_state_t *src, qsx_stream_t stream) {
+  if (dst == nullptr || src == nullptr || dst == src) return QSX_ERR_INVALID_ARGUMENT;
+  if (dst->num_cols != src->num_cols || dst->dense != src->dense || (dst->dense && dst->image_bytes != src->image_bytes)) {
     return QSX_ERR_INVALID_ARGUMENT;
   }
-  return qsx_agg_state_import_merge(dst, src->image, stream);
+  int rc = settle(src, as_stream(stream));   // the source's spilled rows are part of what is merged
+  if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(src->table_mutex);
+  return qsx_agg_state_import_merge(dst, src->image, src->image_bytes, stream);
 }
 
 int qsx_agg_num_groups(qsx_agg_state_t *st, int64_t *out_groups, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (st == nullptr || out_groups == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   hipStream_t s = as_stream(stream);
-  int rc = check_flags(st, s);
+  int rc = settle(st, s);
   if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
   if (st->config.strategy == QSX_AGG_SINGLE_STATE) {
     *out_groups = 1;
     return QSX_OK;
@@ -1220,8 +1467,9 @@ int qsx_agg_finalize(qsx_agg_state_t *st, int partition, int num_partitions, voi
     return QSX_ERR_INVALID_ARGUMENT;
   }
   hipStream_t s = as_stream(stream);
-  int rc = check_flags(st, s);
+  int rc = settle(st, s);
   if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
   FinalizeDesc f = st->fin;
   for (int k = 0; k < f.num_keys; ++k) {
     if (out_key_cols == nullptr || out_key_cols[k] == nullptr) return QSX_ERR_INVALID_ARGUMENT;

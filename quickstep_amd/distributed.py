@@ -174,11 +174,19 @@ def merge_agg_state_images(ops, state, group=None):
     rank = dist.get_rank(group)
     device = state.device if hasattr(state, "device") else None
     image = state.export(device)
-    gathered = [torch.empty_like(image) for _ in range(world)]
-    dist.all_gather(gathered, image, group=group)
+    # a table that outgrew its estimate has a bigger image than its peers': exchange the sizes, pad to the largest
+    words = torch.tensor([image.numel()], dtype=torch.int64, device=image.device)
+    all_words = torch.empty(world, dtype=torch.int64, device=image.device)
+    dist.all_gather_into_tensor(all_words, words, group=group)
+    all_words = all_words.cpu().tolist()
+    pad = max(all_words)
+    if image.numel() < pad:
+        image = torch.cat([image, image.new_zeros(pad - image.numel())])
+    gathered = torch.empty(world * pad, dtype=image.dtype, device=image.device)
+    dist.all_gather_into_tensor(gathered, image, group=group)
     for r in range(world):
         if r != rank:
-            state.import_merge(gathered[r])
+            state.import_merge(gathered[r * pad: r * pad + all_words[r]])
     return state
 
 

@@ -7,7 +7,7 @@ sides.  Pure data definitions: no library is loaded here.
 import ctypes as C
 
 # qsx_type_t (numbering of types/TypeID.hpp:32-43 in the reference)
-ABI_VERSION = 3                                                     # QSX_ABI_VERSION of include/qsx.h
+ABI_VERSION = 4                                                     # QSX_ABI_VERSION of include/qsx.h
 INT, LONG, FLOAT, DOUBLE, CHAR = 0, 1, 2, 3, 4
 # qsx_cmp_t (types/operations/comparisons/ComparisonID.hpp:36-42)
 EQ, NE, LT, LE, GT, GE = range(6)

@@ -258,14 +258,51 @@ def test_merge_and_export_import(capi, oracle, dev):
         assert_same_groups(finalize_np(c, dev), o.finalize())
 
 
-def test_too_many_groups_is_reported_not_silently_dropped(capi, dev):
+def test_table_grows_past_the_optimizer_estimate(capi, oracle, dev):
+    """An estimate orders of magnitude too low must not lose a group (the reference's tables resize:
+    PackedPayloadHashTable::resize, ThreadPrivateCompactKeyHashTable::resize): block-at-a-time the table grows between
+    update calls; inside one call the groups that find no slot wait in the state's spill log."""
     rng = np.random.default_rng(0)
-    k = rng.permutation(200_000).astype(np.int32)
+    n = 400_000
+    k = rng.integers(0, 50_000, size=n).astype(np.int32)
+    v = rng.integers(-1000, 1000, size=n).astype(np.int64)
+    d = rng.normal(size=n)
+    layout = [(T.INT, None), (T.LONG, None), (T.DOUBLE, None)]
+    aggs = [(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1)), (T.AGG_MIN, T.col(2)), (T.AGG_MAX, T.col(1)), (T.AGG_AVG, T.col(2))]
+    for strategy in (T.AGG_COMPACT_KEY, T.AGG_GENERIC):
+        cfg = T.make_agg_config(strategy, layout, keys=[0], aggs=aggs, est_groups=4)
+        o = oracle.AggState(cfg)
+        o.update([k, v, d])
+        ref = o.finalize()
+        for blocks in (1, 40):
+            st = run_hip(capi, dev, cfg, [k, v, d], blocks=blocks)
+            assert st.num_groups() >= ref[0][0].size
+            assert_same_groups(finalize_np(st, dev), ref)
+        # a state that has grown keeps working: clear + second run, and its (bigger) image merges into a small table
+        st.clear()
+        st.update([to_dev(c, dev) for c in (k, v, d)], n)
+        assert_same_groups(finalize_np(st, dev), ref)
+        image = st.export(dev)
+        small = capi.AggState(cfg)
+        assert image.numel() * 8 == st.export_bytes() > small.export_bytes()
+        small.import_merge(image)
+        assert_same_groups(finalize_np(small, dev), ref)
+        other = capi.AggState(cfg)
+        other.merge(st)
+        assert_same_groups(finalize_np(other, dev), ref)
+
+
+def test_lost_rows_are_reported_not_silently_dropped(capi, dev):
+    """One call that spills more groups than the state's log holds (1 Mi records): the error surfaces at
+    num_groups / finalize / export, never as a silently smaller result."""
+    rng = np.random.default_rng(0)
+    k = rng.permutation(3_000_000).astype(np.int32)
     cfg = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.INT, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None)], est_groups=4)
     st = run_hip(capi, dev, cfg, [k])
-    with pytest.raises(capi.QsxError) as e:
-        st.num_groups()
-    assert e.value.status == T.ERR_TOO_MANY_GROUPS
+    for call in (st.num_groups, lambda: st.finalize(dev, capacity=16), lambda: st.export(dev)):
+        with pytest.raises(capi.QsxError) as e:
+            call()
+        assert e.value.status == T.ERR_TOO_MANY_GROUPS
     cfg = T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None)], num_entries=10)
     st = run_hip(capi, dev, cfg, [k])                       # keys outside [0, num_entries): precondition violated
     with pytest.raises(capi.QsxError):
