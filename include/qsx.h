@@ -222,6 +222,17 @@ int qsx_gather_segmented(int width, int num_segments, const void *const *segment
                          const int64_t *segment_first_row, const int32_t *tids_dev, int64_t n,
                          void *dst_dev, qsx_stream_t stream);
 
+/* The null bits that travel with gathered values (NativeColumnVector's null BitVector,
+ * types/containers/ColumnVector.hpp:130-401, filled by ScalarAttribute::getAllValuesForJoin / by
+ * bulkInsertTuplesWithRemappedAttributes for nullable attributes): bit i of out_bitmap (TupleIdSequence bit order,
+ * 1 = NULL, trailing bits zero) = the null bit of row tids[i]; segment_bitmaps[s] is the null bitmap of segment s
+ * (NULL pointer: the segment has no NULLs); a negative tid yields 1 (outer-join padding,
+ * HashOuterJoinWorkOrder's fillWithNulls, relational_operators/HashJoinOperator.cpp:1077-1080).  One segment with
+ * first row 0 = a plain block. */
+int qsx_bitmap_gather_segmented(int num_segments, const uint64_t *const *segment_bitmaps,
+                                const int64_t *segment_first_row, const int32_t *tids_dev, int64_t n,
+                                uint64_t *out_bitmap_dev, qsx_stream_t stream);
+
 /* ======================================================================
  * Hash join
  * ====================================================================== */
@@ -352,7 +363,9 @@ typedef enum qsx_agg_fn {
   QSX_AGG_SUM = 1,        /* SUM(int|long) -> int64 ; SUM(float|double|expr) -> double */
   QSX_AGG_AVG = 2,        /* sum / (double)count -> double (AggregationHandleAvg.cpp:144-155) */
   QSX_AGG_MIN = 3,        /* AggregationHandleMin.cpp:45-120: result has the argument's type   */
-  QSX_AGG_MAX = 4         /* AggregationHandleMax.cpp:45-120  (DOUBLE for an expression)       */
+  QSX_AGG_MAX = 4,        /* AggregationHandleMax.cpp:45-120  (DOUBLE for an expression)       */
+  QSX_AGG_COUNT = 5       /* COUNT(x): rows whose argument is not NULL -> int64 (AggregationHandleCount.hpp:98-118,
+                             the count_star = false, nullable_type = true instantiation) */
 } qsx_agg_fn_t;
 
 /* Operand of an expression instruction or an aggregate argument. */
@@ -436,6 +449,16 @@ typedef struct qsx_agg_config {
                                              unsigned codes of that width (a compressed attribute of a
                                              CompressedColumnStoreTupleStorageSubBlock) and qsx_agg_update_coded decodes it
                                              while reading: INT / LONG / FLOAT / DOUBLE columns only */
+  int32_t column_nullable[QSX_MAX_COLUMNS];  /* != 0: the attribute's type is nullable; qsx_agg_update_nullable hands its null
+                                             bitmap in with every block.  Semantics are the reference's, applied inside the
+                                             update kernel: a tuple with a NULL group-by key is skipped
+                                             (PackedPayloadHashTable.hpp:861-867); a comparison with NULL is not true, so a NULL
+                                             in a predicate column drops the tuple; an aggregate skips the tuples whose argument
+                                             — or any operand of the expression it aggregates — is NULL while COUNT(*) still
+                                             counts them (AggregationHandleSum.hpp:105-120 iterateUnaryInl,
+                                             AggregationHandleCount.hpp:98-118); SUM / AVG / MIN / MAX of a group that saw no
+                                             non-NULL argument finalize as NULL (AggregationHandleSum.cpp:100-120,
+                                             AggregationHandleAvg.cpp:144-155) */
 } qsx_agg_config_t;
 
 /* Counterpart of the AggregationOperationState constructor
@@ -460,6 +483,13 @@ int qsx_agg_state_clear(qsx_agg_state_t *state, qsx_stream_t stream);
  * like many AggregationWorkOrders sharing one state. */
 int qsx_agg_update(qsx_agg_state_t *state, const void *const *cols, int64_t n,
                    const uint64_t *filter_dev, qsx_stream_t stream);
+
+/* qsx_agg_update on a block with NULLs: null_bitmaps_dev[c] is the null bitmap of column c (TupleIdSequence bit
+ * order, bit i set = tuple i is NULL, n bits; storage/BasicColumnStoreTupleStorageSubBlock.cpp:131-147 keeps one per
+ * nullable attribute) or NULL when the block holds no NULL in that attribute; entries of columns not declared
+ * column_nullable must be NULL.  qsx_agg_update on such a state = a block without NULLs. */
+int qsx_agg_update_nullable(qsx_agg_state_t *state, const void *const *cols, const uint64_t *const *null_bitmaps_dev,
+                            int64_t n, const uint64_t *filter_dev, qsx_stream_t stream);
 
 /* qsx_agg_update on a block whose attributes with column_code_width != 0 are compressed: cols[c] is the code
  * stripe, dictionaries_dev[c] the block's dictionary for that attribute (values of the column's type, indexed by

@@ -81,6 +81,7 @@ for _name, _res, _args in [
     ("qso_agg_update", None, [_vp, _pp, _i64, _vp]),
     ("qso_agg_mark_existence", None, [_vp, _int, _vp, _i64, _vp]),
     ("qso_agg_update_coded", None, [_vp, _pp, _pp, _i64, _vp]),
+    ("qso_agg_update_nullable", None, [_vp, _pp, _pp, _i64, _vp]),
     ("qso_agg_merge", None, [_vp, _vp]),
     ("qso_agg_num_groups", _i64, [_vp]),
     ("qso_agg_finalize", _i64, [_vp, _int, _int, _pp, _pp, _pp, _i64]),
@@ -414,6 +415,14 @@ class AggState:
         if n is None:
             n = cols[0].size
         _lib.qso_agg_update(self._h, _ptr_array(cols), n, _p(filter_bitmap))
+
+    def update_nullable(self, cols, null_bitmaps, n=None, filter_bitmap=None):
+        """null_bitmaps[c]: uint64 MSB-first null bitmap of column c, or None."""
+        if n is None:
+            n = cols[0].size
+        keep = [np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None for b in null_bitmaps]
+        ptrs = (C.c_void_p * len(cols))(*[b.ctypes.data if b is not None else None for b in keep])
+        _lib.qso_agg_update_nullable(self._h, _ptr_array(cols), ptrs, n, _p(filter_bitmap))
 
     def update_coded(self, cols, dictionaries, n=None, filter_bitmap=None):
         if n is None:

@@ -655,8 +655,12 @@ StateLayout make_layout(const qsx_agg_config_t &c) {
       case QSX_AGG_COUNT_STAR:
         L.state_is_int[L.num_states++] = true;
         break;
+      case QSX_AGG_COUNT:
+        L.state_is_int[L.num_states++] = true;
+        break;
       case QSX_AGG_SUM:
         L.state_is_int[L.num_states++] = is_int;
+        L.state_is_int[L.num_states++] = true;   // non-NULL arguments seen (AggregationStateSum::null_, AggregationHandleSum.hpp:58-62)
         break;
       case QSX_AGG_AVG:
         L.state_is_int[L.num_states++] = is_int;
@@ -686,9 +690,32 @@ union StateWord {
 struct RowReader {
   const qsx_agg_config_t &c;
   const void *const *cols;
+  const std::uint64_t *const *nulls;   // per column: null bitmap of the block (MSB-first) or nullptr
   double temps[QSX_MAX_TEMPS];
+  bool temp_null[QSX_MAX_TEMPS];
 
-  RowReader(const qsx_agg_config_t &cfg, const void *const *columns) : c(cfg), cols(columns) {}
+  RowReader(const qsx_agg_config_t &cfg, const void *const *columns, const std::uint64_t *const *null_bitmaps = nullptr)
+      : c(cfg), cols(columns), nulls(null_bitmaps) {
+    for (bool &t : temp_null) t = false;
+  }
+
+  // getUntypedValue<true>() == nullptr of the reference's nullable accessors
+  inline bool col_is_null(int col, std::int64_t i) const {
+    return nulls != nullptr && nulls[col] != nullptr && ((nulls[col][i >> 6] >> (63 - (i & 63))) & 1u) != 0;
+  }
+  // NULL propagates through arithmetic (ArithmeticBinaryOperators.hpp: the nullable applyToColumnVectors variants
+  // produce NULL when either operand is NULL)
+  inline bool operand_is_null(const qsx_operand_t &o, std::int64_t i) const {
+    return o.kind == QSX_OPD_COLUMN ? col_is_null(o.index, i) : (o.kind == QSX_OPD_TEMP ? temp_null[o.index] : false);
+  }
+  // a tuple with a NULL group-by key is not aggregated (PackedPayloadHashTable.hpp:861-867); a comparison with NULL
+  // is not true, so neither is one with a NULL predicate operand
+  inline bool row_has_null_key_or_predicate_operand(std::int64_t i) const {
+    if (nulls == nullptr) return false;
+    for (int k = 0; k < c.num_keys; ++k) if (col_is_null(c.key_column[k], i)) return true;
+    for (int t = 0; t < c.num_pred_terms; ++t) if (col_is_null(c.pred[t].column, i)) return true;
+    return false;
+  }
 
   inline double col_as_double(int col, std::int64_t i) const {
     switch (c.column_type[col]) {
@@ -714,6 +741,7 @@ struct RowReader {
     for (int k = 0; k < c.num_instrs; ++k) {
       const qsx_expr_instr_t &in = c.instrs[k];
       const double a = operand(in.a, i), b = operand(in.b, i);
+      temp_null[in.dst] = operand_is_null(in.a, i) || operand_is_null(in.b, i);
       double r;
       switch (in.op) {
         case QSX_EX_ADD: r = a + b; break;
@@ -771,8 +799,12 @@ inline void accumulate(const qsx_agg_config_t &c, const StateLayout &L, const Ro
                        std::int64_t i, StateWord *st /* num_states words of one group */) {
   for (int a = 0; a < c.num_aggs; ++a) {
     StateWord *s = st + L.agg_first_state[a];
+    // every handle but COUNT(*) skips a NULL argument (iterateUnaryInl, AggregationHandleSum.hpp:105-120;
+    // AggregationHandleCount.hpp:98-118 for COUNT(x))
+    if (c.aggs[a].fn != QSX_AGG_COUNT_STAR && rr.operand_is_null(c.aggs[a].arg, i)) continue;
     switch (c.aggs[a].fn) {
       case QSX_AGG_COUNT_STAR:
+      case QSX_AGG_COUNT:
         s[0].i += 1;
         break;
       case QSX_AGG_SUM:
@@ -782,7 +814,7 @@ inline void accumulate(const qsx_agg_config_t &c, const StateLayout &L, const Ro
         } else {
           s[0].d += rr.operand(c.aggs[a].arg, i);
         }
-        if (c.aggs[a].fn == QSX_AGG_AVG) s[1].i += 1;
+        s[1].i += 1;
         break;
       case QSX_AGG_MIN:
       case QSX_AGG_MAX: {
@@ -865,15 +897,15 @@ struct qso_agg_state {
     return b;
   }
 
-  void update(const void *const *cols, std::int64_t n, const std::uint64_t *filter) {
-    RowReader rr(c, cols);
+  void update(const void *const *cols, std::int64_t n, const std::uint64_t *filter, const std::uint64_t *const *nulls = nullptr) {
+    RowReader rr(c, cols, nulls);
     if (c.strategy == QSX_AGG_SINGLE_STATE) {
       // aggregateBlockSingleState: accumulate a block-local state, then merge
       // into the global one (mergeStates under a mutex, :476-519).
       std::vector<StateWord> local(L.num_states, StateWord{0});
       std::int64_t rows = 0;
       for (std::int64_t i = 0; i < n; ++i) {
-        if (!row_selected(filter, i) || !rr.predicate(i)) continue;
+        if (!row_selected(filter, i) || rr.row_has_null_key_or_predicate_operand(i) || !rr.predicate(i)) continue;
         rr.eval(i);
         accumulate(c, L, rr, i, local.data());
         ++rows;
@@ -883,7 +915,7 @@ struct qso_agg_state {
       return;
     }
     for (std::int64_t i = 0; i < n; ++i) {
-      if (!row_selected(filter, i) || !rr.predicate(i)) continue;
+      if (!row_selected(filter, i) || rr.row_has_null_key_or_predicate_operand(i) || !rr.predicate(i)) continue;
       rr.eval(i);
       if (c.strategy == QSX_AGG_COLLISION_FREE) {
         // upsertValueAccessor* (CollisionFreeVectorTable.hpp:530-645): loc = key.
@@ -944,13 +976,23 @@ void emit_values(const qsx_agg_config_t &c, const StateLayout &L, const StateWor
     bool is_null = false;
     switch (c.aggs[a].fn) {
       case QSX_AGG_COUNT_STAR:
+      case QSX_AGG_COUNT:
         static_cast<std::int64_t *>(out_val_cols[a])[row] = s[0].i;
         break;
-      case QSX_AGG_SUM:
-        if (L.agg_arg_is_int[a]) static_cast<std::int64_t *>(out_val_cols[a])[row] = s[0].i;
-        else static_cast<double *>(out_val_cols[a])[row] = s[0].d;
-        is_null = empty_group;  // SUM over zero rows is NULL (AggregationHandleSum.cpp:100-120)
+      case QSX_AGG_SUM: {
+        // SUM over zero rows is NULL (AggregationHandleSum.cpp:100-120); so is the SUM of a group whose nullable
+        // argument was NULL in every row.  (A non-nullable argument: the compact-key and collision-free tables keep
+        // no null flag — a key that only has its existence bit finalizes as 0, CollisionFreeVectorTable.hpp:700-727.)
+        bool temp_nullable[QSX_MAX_TEMPS] = {};
+        auto nullable = [&](const qsx_operand_t &o) {
+          return o.kind == QSX_OPD_COLUMN ? c.column_nullable[o.index] != 0 : (o.kind == QSX_OPD_TEMP && temp_nullable[o.index]);
+        };
+        for (int k = 0; k < c.num_instrs; ++k) temp_nullable[c.instrs[k].dst] = nullable(c.instrs[k].a) || nullable(c.instrs[k].b);
+        is_null = empty_group || (nullable(c.aggs[a].arg) && s[1].i == 0);
+        if (L.agg_arg_is_int[a]) static_cast<std::int64_t *>(out_val_cols[a])[row] = is_null ? 0 : s[0].i;
+        else static_cast<double *>(out_val_cols[a])[row] = is_null ? 0.0 : s[0].d;
         break;
+      }
       case QSX_AGG_AVG: {
         const double sum = L.agg_arg_is_int[a] ? static_cast<double>(s[0].i) : s[0].d;
         is_null = (s[1].i == 0);
@@ -999,6 +1041,10 @@ void qso_agg_state_destroy(qso_agg_state_t *s) { delete s; }
 
 void qso_agg_update(qso_agg_state_t *s, const void *const *cols, int64_t n, const uint64_t *filter) {
   s->update(cols, n, filter);
+}
+void qso_agg_update_nullable(qso_agg_state_t *s, const void *const *cols, const uint64_t *const *null_bitmaps, int64_t n,
+                             const uint64_t *filter) {
+  s->update(cols, n, filter, null_bitmaps);
 }
 void qso_agg_mark_existence(qso_agg_state_t *s, int key_type, const void *keys, int64_t n, const uint64_t *filter) {
   // ExecuteBuild (BuildAggregationExistenceMapOperator.cpp:50-67): setBit(value) for every tuple of the accessor

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "qsx_tids_to_bitmap": (_int, [_vp, _i64, _i32, _i64, _vp, _vp]),
     "qsx_gather": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_gather_segmented": (_int, [_int, _int, _pp, C.POINTER(_i64), _vp, _i64, _vp, _vp]),
+    "qsx_bitmap_gather_segmented": (_int, [_int, _pp, C.POINTER(_i64), _vp, _i64, _vp, _vp]),
     "qsx_sort_workspace_bytes": (_sz, [_i64]),
     "qsx_sort_permutation": (_int, [_int, _pp, C.POINTER(_i32), C.POINTER(_i32), _i64, _vp, _vp, _sz, _vp]),
     "qsx_distinct_rows": (_int, [_int, _pp, C.POINTER(_i32), _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -90,6 +91,7 @@ _SIGNATURES = {
     "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
     "qsx_agg_mark_existence": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "qsx_agg_update_coded": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
+    "qsx_agg_update_nullable": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
     "qsx_agg_merge": (_int, [_vp, _vp, _vp]),
     "qsx_agg_state_export_bytes": (_int, [_vp, C.POINTER(_sz), _vp]),
     "qsx_agg_state_export": (_int, [_vp, _vp, _sz, _vp]),
@@ -338,6 +340,18 @@ def gather_segmented(segments, first_rows, tids, out=None, stream=None):
     return out
 
 
+def bitmap_gather_segmented(segment_bitmaps, first_rows, tids, stream=None):
+    """Null bits of the rows `tids` (relation-global; negative = NULL padding) as a TupleIdSequence-ordered bitmap.
+    segment_bitmaps[s]: int64 tensor (the segment's null bitmap words) or None (no NULLs in that segment)."""
+    n = tids.numel()
+    out = torch.zeros((n + 63) // 64 + 1, dtype=torch.int64, device=tids.device)
+    ptrs = (C.c_void_p * len(segment_bitmaps))(*[b.data_ptr() if b is not None else None for b in segment_bitmaps])
+    starts = (C.c_int64 * len(segment_bitmaps))(*first_rows)
+    _check(_lib.qsx_bitmap_gather_segmented(len(segment_bitmaps), ptrs, starts, _ptr(tids), n, _ptr(out), _stream(stream)),
+           "qsx_bitmap_gather_segmented")
+    return out[:(n + 63) // 64]
+
+
 # --------------------------------------------------------------------------- join
 class JoinTable:
     """JoinHashTable handle (qsx_join_table_t)."""
@@ -439,6 +453,14 @@ class AggState:
             n = cols[0].numel()
         _check(_lib.qsx_agg_update(self._h, _ptr_array(cols), n, _ptr(filter_bitmap), _stream(stream)),
                "qsx_agg_update")
+
+    def update_nullable(self, cols, null_bitmaps, n=None, filter_bitmap=None, stream=None):
+        """null_bitmaps[c]: int64 tensor with the null bitmap words of column c (TupleIdSequence bit order) or None."""
+        if n is None:
+            n = cols[0].numel()
+        nulls = (C.c_void_p * len(cols))(*[b.data_ptr() if b is not None else None for b in null_bitmaps])
+        _check(_lib.qsx_agg_update_nullable(self._h, _ptr_array(cols), nulls, n, _ptr(filter_bitmap), _stream(stream)),
+               "qsx_agg_update_nullable")
 
     def update_coded(self, cols, dictionaries, n=None, filter_bitmap=None, stream=None):
         """cols[c] = code stripe for columns with column_code_width != 0; dictionaries[c] = dictionary tensor or None."""

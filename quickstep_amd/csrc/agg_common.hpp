@@ -30,6 +30,11 @@ struct DevSum {
   DevOperand arg;
   int is_int;   // the argument is an INT/LONG column (read as integer)
   int kind;     // AccKind
+  // Nullable inputs: bit s set = the argument is NULL when null slot s (DevConfig::null_column) is NULL in the row; the
+  // row then contributes the accumulator's identity.  count_valid: this accumulator counts the rows whose mask is
+  // clear (COUNT(x), the denominator of AVG(x), the "saw a value" test of SUM / MIN / MAX) instead of adding `arg`.
+  unsigned null_mask;
+  int count_valid;
 };
 
 // double <-> int64 with the same ordering (IEEE sign-magnitude -> two's complement)
@@ -96,6 +101,14 @@ struct DevConfig {
   int lds_off[QSX_MAX_COLUMNS];
   int filter_lds_off;
   int tile_bytes;
+  // Nullable columns (qsx_agg_config_t::column_nullable) that the plan reads: slot s = column null_column[s]; its
+  // null words of a tile are staged at null_lds_off[s] like the filter words.  row_null_mask: slots of the group-by key
+  // and predicate columns — a row with one of them NULL is not aggregated at all.
+  int num_null_cols;
+  int null_column[QSX_MAX_COLUMNS];
+  int null_lds_off[QSX_MAX_COLUMNS];
+  unsigned row_null_mask;
+  const unsigned long long *nulls[QSX_MAX_COLUMNS];   // per call, by slot; nullptr = no NULL in this block
   // interpreter plan (plan_interpreter() in aggregate.hip); temps_bytes == 0 for AOT shapes
   int temps_bytes;
   PlanInstr plan_instrs[QSX_MAX_INSTRS];

@@ -77,7 +77,7 @@ __device__ __forceinline__ void copy_elements_to_lds(const char *src, char *dst,
 // Issue the HBM -> LDS copy of one tile (rows [row0, row0 + rows)).
 template <bool kStatic>
 __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const *cols, const uint64_t *filter, char *tile,
-                                           int64_t row0, int rows) {
+                                           int64_t row0, int rows, const unsigned long long *const *nulls = nullptr) {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_columns, [&](int col) __attribute__((always_inline)) {
@@ -105,6 +105,17 @@ __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const
     copy_elements_to_lds(reinterpret_cast<const char *>(filter + (row0 >> 6)), tile + c.filter_lds_off,
                          (rows + 63) >> 6, 8);
   }
+  // null words of the nullable columns the plan reads (zeros for a block without NULLs in that attribute)
+  cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_null_cols, [&](int s) __attribute__((always_inline)) {
+    const unsigned long long *src = nulls != nullptr ? nulls[s] : nullptr;
+    char *dst = tile + c.null_lds_off[s];
+    const int words = (rows + 63) >> 6;
+    if (src != nullptr) {
+      copy_elements_to_lds(reinterpret_cast<const char *>(src + (row0 >> 6)), dst, words, 8);
+    } else {
+      for (int i = threadIdx.x; i < words; i += kABlock) reinterpret_cast<uint64_t *>(dst)[i] = 0;
+    }
+  });
 }
 
 // Compressed attributes: every thread turns the staged codes of its V rows into values (dictionary entry, or the code
@@ -390,7 +401,8 @@ template <bool kStatic, bool kDense, int NS, int V>
 __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, const void *const *dicts, int64_t n,
                                                      const uint64_t *__restrict__ filter, const HashTableView &g,
                                                      const DenseView &dense, int S, int rep_shift, int nbuf,
-                                                     int ranges, const long long *__restrict__ pieces = nullptr) {
+                                                     int ranges, const long long *__restrict__ pieces = nullptr,
+                                                     const unsigned long long *const *nulls = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int TR = kABlock * V;
   char *tiles = reinterpret_cast<char *>(smem_raw);
@@ -428,12 +440,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   auto tile_rows = [&](int64_t t) { return static_cast<int>(row_end - tile_row0(t) < TR ? row_end - tile_row0(t) : TR); };
   int buf = 0;
   if (nbuf == 2 && first_tile < num_tiles) {
-    stage_tile<kStatic>(c, cols, filter, tiles, tile_row0(first_tile), tile_rows(first_tile));
+    stage_tile<kStatic>(c, cols, filter, tiles, tile_row0(first_tile), tile_rows(first_tile), nulls);
   }
   for (int64_t tile_id = first_tile; tile_id < num_tiles; tile_id += tile_step) {
     if (nbuf == 1) {
       __syncthreads();  // every wave is done reading the previous tile
-      stage_tile<kStatic>(c, cols, filter, tiles, tile_row0(tile_id), tile_rows(tile_id));
+      stage_tile<kStatic>(c, cols, filter, tiles, tile_row0(tile_id), tile_rows(tile_id), nulls);
     }
     // The tile has landed (nbuf == 2: it was staged during the previous iteration and
     // every wave is done with the other buffer).
@@ -441,7 +453,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     __syncthreads();
     const int64_t next = tile_id + tile_step;
     if (nbuf == 2 && next < num_tiles) {
-      stage_tile<kStatic>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, tile_row0(next), tile_rows(next));
+      stage_tile<kStatic>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, tile_row0(next), tile_rows(next), nulls);
     }
     char *tile = tiles + buf * c.tile_bytes;
     if (nbuf == 2) buf ^= 1;
@@ -460,6 +472,23 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         const uint64_t word = reinterpret_cast<const uint64_t *>(tile + c.filter_lds_off)[r >> 6];
         live[v] = msb_bit(word, r & 63);
       }
+    }
+    // NULLs: bit s of nullbits = the row is NULL in null slot s; a NULL group-by key or predicate operand drops the row
+    // (PackedPayloadHashTable.hpp:861-867; a comparison with NULL is not true)
+    unsigned nullbits[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) nullbits[v] = 0;
+    if (c.num_null_cols != 0) {
+      cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_null_cols, [&](int s) __attribute__((always_inline)) {
+        const uint64_t *words = reinterpret_cast<const uint64_t *>(tile + c.null_lds_off[s]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const int r = trow + v * kABlock;
+          if (msb_bit(words[r >> 6], r & 63)) nullbits[v] |= 1u << s;
+        }
+      });
+#pragma unroll
+      for (int v = 0; v < V; ++v) live[v] = live[v] && (nullbits[v] & c.row_null_mask) == 0;
     }
     predicate_vec<kStatic, V>(c, tile, trow, live);
 
@@ -582,7 +611,11 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     for (int j = 0; j < NS; ++j) {
       const DevSum s = c.sums[j];
       unsigned long long inc[V];
-      if (s.is_int) {
+      if (s.count_valid) {
+        // rows with a non-NULL argument (COUNT(x), AVG's denominator, "saw a value")
+#pragma unroll
+        for (int v = 0; v < V; ++v) inc[v] = (nullbits[v] & s.null_mask) == 0 ? 1ull : 0ull;
+      } else if (s.is_int) {
         if constexpr (kStatic) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
@@ -609,6 +642,13 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         for (int v = 0; v < V; ++v) {
           const long long bits = __double_as_longlong(x[v]);
           inc[v] = static_cast<unsigned long long>(s.kind >= kAccMinI64 ? ordered_from_bits(bits) : bits);
+        }
+      }
+      if (s.count_valid == 0 && s.null_mask != 0) {
+        // a NULL argument leaves the accumulator alone (iterateUnaryInl skips it, AggregationHandleSum.hpp:105-120)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          if ((nullbits[v] & s.null_mask) != 0) inc[v] = static_cast<unsigned long long>(acc_identity(s.kind));
         }
       }
       if constexpr (kDense) {
@@ -670,7 +710,7 @@ __global__ __launch_bounds__(kABlock) void agg_hash_update_kernel(DevConfig c, i
                                                                  const uint64_t *__restrict__ filter,
                                                                  HashTableView g, int S, int rep_shift, int nbuf,
                                                                  int ranges, const long long *__restrict__ pieces) {
-  agg_hash_update_body<false, false, NS, V>(c, c.cols, c.dicts, n, filter, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces);
+  agg_hash_update_body<false, false, NS, V>(c, c.cols, c.dicts, n, filter, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces, c.nulls);
 }
 
 // COLLISION_FREE (K7) through the same staged-tile body with the dense sink.
@@ -678,7 +718,7 @@ template <int NS, int V>
 __global__ __launch_bounds__(kABlock) void agg_dense_update_kernel(DevConfig c, int64_t n,
                                                                   const uint64_t *__restrict__ filter, DenseView d,
                                                                   int nbuf) {
-  agg_hash_update_body<false, true, NS, V>(c, c.cols, c.dicts, n, filter, HashTableView{}, d, 8, 0, nbuf, 1);
+  agg_hash_update_body<false, true, NS, V>(c, c.cols, c.dicts, n, filter, HashTableView{}, d, 8, 0, nbuf, 1, nullptr, c.nulls);
 }
 
 struct ColumnPointers {

@@ -105,7 +105,7 @@ inline bool same_plan(const qsx_agg_config_t &a, const qsx_agg_config_t &b) {
   }
   for (int i = 0; i < a.num_columns; ++i) {
     if (a.column_type[i] != b.column_type[i] || a.column_width[i] != b.column_width[i] ||
-        a.column_code_width[i] != b.column_code_width[i]) {
+        a.column_code_width[i] != b.column_code_width[i] || (a.column_nullable[i] != 0) != (b.column_nullable[i] != 0)) {
       return false;
     }
   }

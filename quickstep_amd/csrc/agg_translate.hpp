@@ -12,6 +12,8 @@ struct FinalizeDesc {
   int num_aggs;
   int fn[QSX_MAX_AGGS];
   int sum_col[QSX_MAX_AGGS];  // state column of the aggregate's accumulator (>= 1), 0 for COUNT(*)
+  int nn_col[QSX_MAX_AGGS];   // state column counting the rows with a non-NULL argument (nullable arguments only), else -1:
+                              // the row count stands for it
   int is_int[QSX_MAX_AGGS];   // the accumulator word is a plain int64 (INT/LONG argument)
   int val_type[QSX_MAX_AGGS]; // MIN/MAX: type of the output column (= the argument's; DOUBLE for expressions)
   int num_keys;
@@ -125,6 +127,29 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
     defined |= 1 << in.dst;
   }
   for (int k = 0; k < QSX_MAX_CONSTS; ++k) d.consts[k] = c.consts[k];
+  // nullable columns -> null slots; which temps are NULL when which slot is
+  unsigned col_null_mask[QSX_MAX_COLUMNS] = {};
+  d.num_null_cols = 0;
+  d.row_null_mask = 0;
+  auto null_slot_mask = [&](int col) constexpr -> unsigned {
+    if (c.column_nullable[col] == 0) return 0u;
+    if (col_null_mask[col] == 0) {
+      d.null_column[d.num_null_cols] = col;
+      col_null_mask[col] = 1u << d.num_null_cols++;
+    }
+    return col_null_mask[col];
+  };
+  for (int k = 0; k < c.num_keys; ++k) d.row_null_mask |= null_slot_mask(c.key_column[k]);
+  for (int p = 0; p < c.num_pred_terms; ++p) {
+    if (c.pred[p].column >= 0 && c.pred[p].column < c.num_columns) d.row_null_mask |= null_slot_mask(c.pred[p].column);
+  }
+  unsigned temp_null_mask[QSX_MAX_TEMPS] = {};
+  auto operand_null_mask = [&](const qsx_operand_t &o) constexpr -> unsigned {
+    return o.kind == QSX_OPD_COLUMN ? null_slot_mask(o.index) : (o.kind == QSX_OPD_TEMP ? temp_null_mask[o.index] : 0u);
+  };
+  for (int k = 0; k < c.num_instrs; ++k) {
+    temp_null_mask[c.instrs[k].dst] = operand_null_mask(c.instrs[k].a) | operand_null_mask(c.instrs[k].b);
+  }
   // aggregates -> state columns
   FinalizeDesc &f = t.fin;
   f.num_aggs = c.num_aggs;
@@ -133,13 +158,35 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
   for (int a = 0; a < c.num_aggs; ++a) {
     const qsx_agg_desc_t &ag = c.aggs[a];
     f.fn[a] = ag.fn;
+    f.nn_col[a] = -1;
     if (ag.fn == QSX_AGG_COUNT_STAR) {
       needs_count = true;
       f.sum_col[a] = 0;
       continue;
     }
-    if (ag.fn != QSX_AGG_SUM && ag.fn != QSX_AGG_AVG && ag.fn != QSX_AGG_MIN && ag.fn != QSX_AGG_MAX) return fail(t, QSX_ERR_UNSUPPORTED);
+    if (ag.fn != QSX_AGG_SUM && ag.fn != QSX_AGG_AVG && ag.fn != QSX_AGG_MIN && ag.fn != QSX_AGG_MAX && ag.fn != QSX_AGG_COUNT) return fail(t, QSX_ERR_UNSUPPORTED);
     if (ag.arg.kind == QSX_OPD_CONST || !valid_operand(c, ag.arg, defined)) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+    const unsigned arg_nulls = operand_null_mask(ag.arg);
+    if (arg_nulls != 0) {
+      // the rows this aggregate sees = the rows with a non-NULL argument: one counting accumulator per distinct mask
+      int j = 0;
+      while (j < ns && !(d.sums[j].count_valid != 0 && d.sums[j].null_mask == arg_nulls)) ++j;
+      if (j == ns) {
+        if (ns == kMaxSums) return fail(t, QSX_ERR_UNSUPPORTED);
+        d.sums[ns].arg = DevOperand{QSX_OPD_CONST, 0};
+        d.sums[ns].is_int = 1;
+        d.sums[ns].kind = kAccSumI64;
+        d.sums[ns].null_mask = arg_nulls;
+        d.sums[ns].count_valid = 1;
+        ++ns;
+      }
+      f.nn_col[a] = j + 1;
+    }
+    if (ag.fn == QSX_AGG_COUNT) {
+      needs_count = true;
+      f.sum_col[a] = 0;   // COUNT(x) over a non-nullable x is the row count; else nn_col
+      continue;
+    }
     if (ag.fn == QSX_AGG_AVG || ag.fn == QSX_AGG_MIN || ag.fn == QSX_AGG_MAX) needs_count = true;   // NULL over zero rows
     const bool is_int = ag.arg.kind == QSX_OPD_COLUMN &&
                         (c.column_type[ag.arg.index] == QSX_INT || c.column_type[ag.arg.index] == QSX_LONG);
@@ -150,11 +197,14 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
     // ReuseAggregateExpressions does on the optimizer side,
     // query_optimizer/rules/ReuseAggregateExpressions.hpp:43-80); so do repeated MIN(x) / MAX(x).
     int j = 0;
-    while (j < ns && !(d.sums[j].arg.kind == ag.arg.kind && d.sums[j].arg.index == ag.arg.index && d.sums[j].kind == kind)) ++j;
+    while (j < ns && !(d.sums[j].count_valid == 0 && d.sums[j].arg.kind == ag.arg.kind && d.sums[j].arg.index == ag.arg.index && d.sums[j].kind == kind)) ++j;
     if (j == ns) {
+      if (ns == kMaxSums) return fail(t, QSX_ERR_UNSUPPORTED);
       d.sums[ns].arg = DevOperand{ag.arg.kind, ag.arg.index};
       d.sums[ns].is_int = is_int ? 1 : 0;
       d.sums[ns].kind = kind;
+      d.sums[ns].null_mask = arg_nulls;
+      d.sums[ns].count_valid = 0;
       ++ns;
     }
     f.sum_col[a] = j + 1;  // fixed up below for dense states without a count column
@@ -194,13 +244,16 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
     if (c.instrs[k].b.kind == QSX_OPD_COLUMN) used |= 1u << c.instrs[k].b.index;
   }
   for (int j = 0; j < ns; ++j) {
-    if (d.sums[j].arg.kind == QSX_OPD_COLUMN) used |= 1u << d.sums[j].arg.index;
+    if (d.sums[j].count_valid == 0 && d.sums[j].arg.kind == QSX_OPD_COLUMN) used |= 1u << d.sums[j].arg.index;
   }
   t.used_columns = used;
   t.dense = c.strategy == QSX_AGG_COLLISION_FREE;
   t.dense_has_count = needs_count;
   if (t.dense && !needs_count) {
-    for (int a = 0; a < c.num_aggs; ++a) f.sum_col[a] -= 1;  // no count column in front
+    for (int a = 0; a < c.num_aggs; ++a) {   // no count column in front
+      f.sum_col[a] -= 1;
+      if (f.nn_col[a] >= 0) f.nn_col[a] -= 1;
+    }
   }
   t.num_cols = t.dense ? ns + (needs_count ? 1 : 0) : ns + 1;
   t.int_col_mask = 0;
@@ -242,6 +295,13 @@ constexpr int plan_tile(DevConfig &d, unsigned used_columns, int tile_rows, bool
   if (has_filter) {
     d.filter_lds_off = static_cast<int>(off);
     off += align16_ce(tile_rows / 64 * 8);
+  }
+  for (int s = 0; s < QSX_MAX_COLUMNS; ++s) {
+    d.null_lds_off[s] = -1;
+    if (s < d.num_null_cols) {
+      d.null_lds_off[s] = static_cast<int>(off);
+      off += align16_ce(tile_rows / 64 * 8);
+    }
   }
   if (off == 0) off = 16;
   d.tile_bytes = static_cast<int>(off);

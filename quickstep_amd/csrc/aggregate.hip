@@ -157,18 +157,24 @@ __device__ __forceinline__ void write_values(const FinalizeDesc &f, const unsign
   const long long cnt = count_col >= 0 ? static_cast<long long>(states[static_cast<unsigned long long>(count_col) * col_stride + idx]) : 0;
   for (int a = 0; a < f.num_aggs; ++a) {
     bool is_null = false;
+    // rows this aggregate saw: those with a non-NULL argument when the argument is nullable, else every row of the group
+    const bool has_nn = f.nn_col[a] >= 0;
+    const long long seen = has_nn ? static_cast<long long>(states[static_cast<unsigned long long>(f.nn_col[a]) * col_stride + idx]) : cnt;
     if (f.fn[a] == QSX_AGG_COUNT_STAR) {
       static_cast<long long *>(f.out_vals[a])[out_row] = cnt;
+    } else if (f.fn[a] == QSX_AGG_COUNT) {
+      static_cast<long long *>(f.out_vals[a])[out_row] = seen;
     } else {
       const unsigned long long raw = states[static_cast<unsigned long long>(f.sum_col[a]) * col_stride + idx];
       if (f.fn[a] == QSX_AGG_SUM) {
-        // int64 and double results are both stored as their 8 raw bytes
-        static_cast<unsigned long long *>(f.out_vals[a])[out_row] = raw;
-        is_null = empty_group;
+        // int64 and double results are both stored as their 8 raw bytes; NULL when no non-NULL argument was seen
+        // (AggregationHandleSum.cpp:100-120)
+        is_null = empty_group || (has_nn && seen == 0);
+        static_cast<unsigned long long *>(f.out_vals[a])[out_row] = is_null ? 0ull : raw;
       } else if (f.fn[a] == QSX_AGG_MIN || f.fn[a] == QSX_AGG_MAX) {
         // typed like the argument; the accumulator is the int value or the order-mapped double.  A dense-table key
         // that only has its existence bit (BuildAggregationExistenceMapOperator) saw no value: NULL.
-        is_null = empty_group || (count_col >= 0 && cnt == 0);
+        is_null = empty_group || (has_nn ? seen == 0 : (count_col >= 0 && cnt == 0));
         const long long word = static_cast<long long>(raw);
         switch (f.val_type[a]) {
           case QSX_INT: static_cast<int32_t *>(f.out_vals[a])[out_row] = is_null ? 0 : static_cast<int32_t>(word); break;
@@ -183,8 +189,8 @@ __device__ __forceinline__ void write_values(const FinalizeDesc &f, const unsign
       } else {
         const double sum = f.is_int[a] ? static_cast<double>(static_cast<long long>(raw))
                                        : __longlong_as_double(static_cast<long long>(raw));
-        is_null = cnt == 0;
-        static_cast<double *>(f.out_vals[a])[out_row] = is_null ? 0.0 : sum / static_cast<double>(cnt);
+        is_null = seen == 0;
+        static_cast<double *>(f.out_vals[a])[out_row] = is_null ? 0.0 : sum / static_cast<double>(seen);
       }
     }
     if (f.out_nulls[a] != nullptr) f.out_nulls[a][out_row] = is_null ? 1 : 0;
@@ -1216,15 +1222,22 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
 // run-time one, then the interpreter (CAPACITY — the tile does not fit LDS next to the group tables — and
 // compile failures fall through).
 static int update_slice(qsx_agg_state *st, const void *const *cols, const void *const *dicts, int64_t n,
-                        const uint64_t *filter_dev, int slots, int ranges, const long long *pieces, hipStream_t s) {
+                        const uint64_t *filter_dev, int slots, int ranges, const long long *pieces, hipStream_t s,
+                        const uint64_t *const *nulls = nullptr) {
   DevConfig dc = st->dev;
   for (int i = 0; i < st->config.num_columns; ++i) {
     dc.cols[i] = cols[i];
     dc.dicts[i] = (dicts != nullptr && dc.code_width[i] != 0) ? dicts[i] : nullptr;
   }
-  const bool aot = !st->dense && st->shape != nullptr && filter_dev == nullptr;
+  for (int sl = 0; sl < dc.num_null_cols; ++sl) {
+    dc.nulls[sl] = nulls != nullptr ? reinterpret_cast<const unsigned long long *>(nulls[dc.null_column[sl]]) : nullptr;
+  }
+  const bool aot = !st->dense && st->shape != nullptr && filter_dev == nullptr && dc.num_null_cols == 0;
   int variant = 0;
-  const JitKernel *jk = aot ? nullptr : state_jit_kernel(st, filter_dev != nullptr, pieces != nullptr, slots, ranges, n, &variant);
+  // (states over nullable columns run the interpreter: the null bitmaps of a call travel in its configuration argument)
+  const JitKernel *jk = (aot || dc.num_null_cols != 0)
+                            ? nullptr
+                            : state_jit_kernel(st, filter_dev != nullptr, pieces != nullptr, slots, ranges, n, &variant);
   if (jk != nullptr) {
     int rc = launch_jit(st, jk, variant, cols, dc.dicts, n, filter_dev, slots, ranges, pieces, s);
     if (rc == QSX_OK && hipGetLastError() == hipSuccess) return QSX_OK;
@@ -1309,7 +1322,7 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
 }
 
 static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *const *dicts, int64_t n,
-                      const uint64_t *filter_dev, qsx_stream_t stream) {
+                      const uint64_t *filter_dev, qsx_stream_t stream, const uint64_t *const *nulls = nullptr) {
   QSX_REQUIRE_DEVICE();
   if (st == nullptr || n < 0 || (n > 0 && st->config.num_columns > 0 && cols == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
   if (n == 0) return QSX_OK;
@@ -1318,10 +1331,12 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
   if (rc != QSX_OK) return rc;
   std::shared_lock<std::shared_mutex> lock(st->table_mutex);
   // (the partitioned path scatters value columns: states over compressed attributes take the tile path)
-  if (!st->dense && st->part_count > 1 && filter_dev == nullptr && !st->has_coded_columns && n >= partition_min_rows()) {
+  // (and so do states over nullable columns: a null bitmap cannot be scattered like a value column)
+  if (!st->dense && st->part_count > 1 && filter_dev == nullptr && !st->has_coded_columns && st->dev.num_null_cols == 0 &&
+      n >= partition_min_rows()) {
     rc = update_partitioned(st, cols, n, s);
   } else {
-    rc = update_slice(st, cols, dicts, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s);
+    rc = update_slice(st, cols, dicts, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s, nulls);
   }
   if (rc != QSX_OK) return rc;
   return publish_control(st, s);
@@ -1332,6 +1347,17 @@ int qsx_agg_update(qsx_agg_state_t *st, const void *const *cols, int64_t n, cons
   // a state declared over compressed attributes needs the dictionaries / code stripes: qsx_agg_update_coded
   if (st != nullptr && st->has_coded_columns) return QSX_ERR_INVALID_ARGUMENT;
   return agg_update(st, cols, nullptr, n, filter_dev, stream);
+}
+
+int qsx_agg_update_nullable(qsx_agg_state_t *st, const void *const *cols, const uint64_t *const *null_bitmaps_dev, int64_t n,
+                            const uint64_t *filter_dev, qsx_stream_t stream) {
+  if (st != nullptr && st->has_coded_columns) return QSX_ERR_INVALID_ARGUMENT;
+  if (st != nullptr && null_bitmaps_dev != nullptr) {
+    for (int i = 0; i < st->config.num_columns; ++i) {
+      if (null_bitmaps_dev[i] != nullptr && st->config.column_nullable[i] == 0) return QSX_ERR_INVALID_ARGUMENT;
+    }
+  }
+  return agg_update(st, cols, nullptr, n, filter_dev, stream, null_bitmaps_dev);
 }
 
 int qsx_agg_update_coded(qsx_agg_state_t *st, const void *const *cols, const void *const *dictionaries_dev, int64_t n,

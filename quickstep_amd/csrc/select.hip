@@ -438,6 +438,37 @@ __global__ __launch_bounds__(kBlock) void gather_segmented_kernel(SegmentTable s
   }
 }
 
+// Null bits travelling with gathered values: bit i of the output = the null bit of row tids[i] in the segment holding it
+// (a segment without a bitmap has no NULLs), 1 for a negative tid (outer-join padding).  One row per lane, the wave's
+// ballot is the output word.
+__global__ __launch_bounds__(kBlock) void bitmap_gather_segmented_kernel(SegmentTable seg, const int32_t *__restrict__ tids,
+                                                                        int64_t n, uint64_t *__restrict__ out) {
+  const int64_t rounded = (n + kWave - 1) / kWave * kWave;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < rounded;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    bool is_null = false;
+    if (i < n) {
+      const int32_t t = tids[i];
+      if (t < 0) {
+        is_null = true;
+      } else {
+        int lo = 0, hi = seg.num - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (seg.first_row[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const uint64_t *bits = static_cast<const uint64_t *>(seg.ptr[lo]);
+        if (bits != nullptr) {
+          const int64_t r = t - seg.first_row[lo];
+          is_null = msb_bit(bits[r >> 6], static_cast<int>(r & 63));
+        }
+      }
+    }
+    const uint64_t word = msb_first(__ballot(is_null));
+    if (lane_id() == 0) out[i >> 6] = word;
+  }
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int run_compaction(const GatherArgs &args, const uint64_t *bitmap, int64_t n,
@@ -952,6 +983,25 @@ int qsx_gather_segmented(int width, int num_segments, const void *const *segment
     case 8: hipLaunchKernelGGL(gather_segmented_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, s, seg, tids_dev, n, static_cast<uint64_t *>(dst_dev)); break;
     default: return QSX_ERR_UNSUPPORTED;
   }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_bitmap_gather_segmented(int num_segments, const uint64_t *const *segment_bitmaps, const int64_t *segment_first_row,
+                                 const int32_t *tids_dev, int64_t n, uint64_t *out_bitmap_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || num_segments < 1 || segment_bitmaps == nullptr || segment_first_row == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (num_segments > kMaxSegments) return QSX_ERR_UNSUPPORTED;
+  if (n == 0) return QSX_OK;
+  if (tids_dev == nullptr || out_bitmap_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  SegmentTable seg;
+  seg.num = num_segments;
+  for (int i = 0; i < num_segments; ++i) {
+    seg.ptr[i] = segment_bitmaps[i];
+    seg.first_row[i] = segment_first_row[i];
+  }
+  hipLaunchKernelGGL(bitmap_gather_segmented_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, as_stream(stream), seg,
+                     tids_dev, n, out_bitmap_dev);
   QSX_CHECK_LAUNCH();
   return QSX_OK;
 }

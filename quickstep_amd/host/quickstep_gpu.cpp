@@ -358,7 +358,8 @@ block_id StorageManager::createBlock(CatalogRelation *relation, std::int64_t cap
 }
 
 block_id StorageManager::loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns,
-                                   std::int64_t num_tuples, partition_id part, const std::vector<bool> *compress) {
+                                   std::int64_t num_tuples, partition_id part, const std::vector<bool> *compress,
+                                   const std::vector<const std::uint64_t *> *null_bitmaps) {
   BlockReference block;
   block_id id;
   {
@@ -376,6 +377,17 @@ block_id StorageManager::loadBlock(CatalogRelation *relation, const std::vector<
     } else {
       CheckStatus(qsx_copy_to_device(block->stripe(static_cast<attribute_id>(a)), host_columns.at(a), bytes, nullptr),
                   "qsx_copy_to_device");
+    }
+  }
+  for (std::size_t a = 0; null_bitmaps != nullptr && a < relation->size() && a < null_bitmaps->size(); ++a) {
+    if ((*null_bitmaps)[a] == nullptr) continue;
+    std::uint64_t *dst = block->nullBitmap(static_cast<attribute_id>(a));
+    if (dst == nullptr) throw ExecutionError("loadBlock: null bitmap given for a non-nullable attribute", QSX_ERR_INVALID_ARGUMENT);
+    const std::size_t bytes = static_cast<std::size_t>((num_tuples + 63) / 64) * 8;
+    if (g_host_memory) {
+      std::memcpy(dst, (*null_bitmaps)[a], bytes);
+    } else {
+      CheckStatus(qsx_copy_to_device(dst, (*null_bitmaps)[a], bytes, nullptr), "qsx_copy_to_device(null bitmap)");
     }
   }
   if (!g_host_memory) CheckStatus(qsx_stream_synchronize(nullptr), "qsx_stream_synchronize");
@@ -409,6 +421,64 @@ void StorageManager::deleteBlockOrBlobFile(block_id id) {
   blocks_.erase(id);
 }
 
+namespace {
+// The tuples of `block` selected by `filter` (nullptr = all) whose attributes `attrs` are all non-NULL, as a device
+// bitmap — or nullptr when no attribute is nullable (the caller keeps using `filter`).  This is the reference's
+// check_for_null_keys skip (HashTable.hpp:1409-1418, 2158-2160) and the NULL argument skip of the aggregate handles
+// (AggregationHandleSum.hpp:105-120), done once per block on the TupleIdSequence instead of per value.
+std::unique_ptr<DeviceBuffer> NotNullFilter(const StorageBlock &block, const std::vector<attribute_id> &attrs, const std::uint64_t *filter) {
+  const std::int64_t n = block.numTuples();
+  std::unique_ptr<DeviceBuffer> out;
+  for (attribute_id a : attrs) {
+    const std::uint64_t *nulls = block.nullBitmap(a);
+    if (nulls == nullptr) continue;
+    const bool first = out == nullptr;
+    if (first) out.reset(new DeviceBuffer(static_cast<std::size_t>((n + 63) / 64) * 8 + 8));
+    if (n == 0) continue;
+    if (first && filter == nullptr) {
+      CheckStatus(qsx_bitmap_combine(3, nulls, nullptr, n, static_cast<std::uint64_t *>(out->ptr), CurrentStream()), "qsx_bitmap_combine");
+    } else {
+      CheckStatus(qsx_bitmap_combine(2, first ? filter : static_cast<const std::uint64_t *>(out->ptr), nulls, n,
+                                     static_cast<std::uint64_t *>(out->ptr), CurrentStream()), "qsx_bitmap_combine");
+    }
+  }
+  return out;
+}
+
+// Null bits of the rows `tids` of one block's attribute -> dst (an output block's null bitmap).
+void GatherBlockNulls(const StorageBlock &block, attribute_id attr, const void *tids, std::int64_t n, std::uint64_t *dst) {
+  const std::uint64_t *seg = block.nullBitmap(attr);
+  const std::int64_t zero = 0;
+  CheckStatus(qsx_bitmap_gather_segmented(1, &seg, &zero, static_cast<const std::int32_t *>(tids), n, dst, CurrentStream()),
+              "qsx_bitmap_gather_segmented");
+}
+
+// The null bits of the selected tuples of `block` follow the values of a projection: output attribute i takes the
+// bits of input attribute selection[i] at the tuples set in `bitmap` (bulkInsertTuplesWithRemappedAttributes copies
+// value and null bit together, storage/BasicColumnStoreTupleStorageSubBlock.cpp:339-425).
+void ProjectNullBitmaps(const StorageBlock &block, const std::vector<attribute_id> &selection, const void *bitmap,
+                        std::int64_t num_selected, StorageBlock *out) {
+  const std::int64_t n = block.numTuples();
+  std::unique_ptr<DeviceBuffer> tids;
+  for (std::size_t i = 0; i < selection.size(); ++i) {
+    if (block.nullBitmap(selection[i]) == nullptr) continue;   // the output bitmap stays all-zero
+    std::uint64_t *dst = out->nullBitmap(static_cast<attribute_id>(i));
+    if (dst == nullptr) throw ExecutionError("projection of a nullable attribute into a non-nullable one", QSX_ERR_INVALID_ARGUMENT);
+    if (num_selected == 0) continue;
+    if (tids == nullptr) {
+      tids.reset(new DeviceBuffer(static_cast<std::size_t>(n) * 4 + 16));
+      const std::size_t ws_bytes = qsx_compact_workspace_bytes(n);
+      DeviceBuffer ws(ws_bytes), count(8);
+      CheckStatus(qsx_bitmap_to_tids(static_cast<const std::uint64_t *>(bitmap), n, 0, static_cast<std::int32_t *>(tids->ptr),
+                                     static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()), "qsx_bitmap_to_tids");
+      CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // ws / count are locals
+    }
+    GatherBlockNulls(block, selection[i], tids->ptr, num_selected, dst);
+  }
+  if (tids != nullptr) CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------
 // Predicate
 // ---------------------------------------------------------------------------
@@ -420,6 +490,7 @@ void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num
   CheckStatus(qsx_device_alloc(words * 8 + 8, &next), "qsx_device_alloc(bitmap)");
   CheckStatus(qsx_device_alloc(8, &count), "qsx_device_alloc(count)");
   bool first = true;
+  bool recount = false;
   for (const ComparisonPredicate &term : conjuncts) {
     const Type &t = block.getRelation().getAttributeType(term.attribute);
     const std::uint64_t *in = first ? filter : static_cast<const std::uint64_t *>(current);
@@ -448,8 +519,19 @@ void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num
                                  static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
                   "qsx_select_cmp");
     }
+    if (block.nullBitmap(term.attribute) != nullptr && n > 0) {
+      // a comparison with NULL is not true (LiteralComparators-inl.hpp:330-370: the nullable variants test the value
+      // pointer first): the stripe holds an arbitrary value under a NULL, so its match is taken back
+      CheckStatus(qsx_bitmap_combine(2, static_cast<const std::uint64_t *>(next), block.nullBitmap(term.attribute), n,
+                                     static_cast<std::uint64_t *>(next), CurrentStream()), "qsx_bitmap_combine");
+      recount = true;
+    }
     std::swap(current, next);
     first = false;
+  }
+  if (recount) {
+    CheckStatus(qsx_bitmap_count(static_cast<const std::uint64_t *>(current), n, static_cast<std::int64_t *>(count), CurrentStream()),
+                "qsx_bitmap_count");
   }
   if (first) {  // empty conjunction: every tuple (of the filter) matches
     CheckStatus(qsx_memset_device(next, 0xFF, words * 8, CurrentStream()), "qsx_memset_device");
@@ -536,6 +618,7 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
     const Type &t = rel.getAttributeType(attr);
     config_.column_type[column_attr_.size()] = t.id;
     config_.column_width[column_attr_.size()] = t.width;
+    config_.column_nullable[column_attr_.size()] = t.nullable ? 1 : 0;
     column_attr_.push_back(attr);
     return static_cast<int>(column_attr_.size() - 1);
   };
@@ -561,6 +644,12 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
     }
     config_.aggs[num_main].fn = AggFn(ag.function);
     if (ag.function != AggregationID::kCount) {
+      config_.aggs[num_main].arg.kind = QSX_OPD_COLUMN;
+      config_.aggs[num_main].arg.index = column_of(ag.argument);
+    } else if (ag.argument != kInvalidAttributeID && rel.getAttributeType(ag.argument).nullable) {
+      // COUNT(x) over a nullable x counts the non-NULL values (AggregationHandleCount<false, true>); over a
+      // non-nullable x it is COUNT(*)
+      config_.aggs[num_main].fn = QSX_AGG_COUNT;
       config_.aggs[num_main].arg.kind = QSX_OPD_COLUMN;
       config_.aggs[num_main].arg.index = column_of(ag.argument);
     }
@@ -606,7 +695,11 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
         cols[c] = block.stripe(d->attrs[c]);
         types[c] = d->types[c].id;
       }
-      CheckStatus(qsx_distinct_rows(static_cast<int>(d->attrs.size()), cols, types, n, filter, static_cast<std::int32_t *>(tids.ptr),
+      // the distinctify table is keyed by (group-by..., argument): a tuple with a NULL in any of them is not inserted
+      // (PackedPayloadHashTable.hpp:861-867)
+      const std::unique_ptr<DeviceBuffer> not_null = NotNullFilter(block, d->attrs, filter);
+      const std::uint64_t *distinct_filter = not_null != nullptr ? static_cast<const std::uint64_t *>(not_null->ptr) : filter;
+      CheckStatus(qsx_distinct_rows(static_cast<int>(d->attrs.size()), cols, types, n, distinct_filter, static_cast<std::int32_t *>(tids.ptr),
                                     static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()), "qsx_distinct_rows");
       Distinctify::Chunk chunk;
       chunk.rows = ReadCount(count.ptr);
@@ -625,9 +718,16 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
   if (state_ == nullptr) return;
   // A block with compressed operand attributes whose values have not been materialised: aggregate on the codes.
   // (Key and predicate columns of the state take the value path here: stripe() decodes them once per block.)
+  // null bitmaps of the nullable operand attributes (a block may hold none: loadBlock without bitmaps)
+  const std::uint64_t *nulls[QSX_MAX_COLUMNS] = {};
+  bool any_nulls = false;
+  for (std::size_t i = 0; i < column_attr_.size(); ++i) {
+    nulls[i] = config_.column_nullable[i] != 0 ? block.nullBitmap(column_attr_[i]) : nullptr;
+    any_nulls = any_nulls || nulls[i] != nullptr;
+  }
   int code_width[QSX_MAX_COLUMNS] = {};
   bool any_coded = false;
-  for (std::size_t i = 0; i < column_attr_.size(); ++i) {
+  for (std::size_t i = 0; i < column_attr_.size() && !any_nulls; ++i) {
     const CompressedAttribute *ca = block.compressedAttribute(column_attr_[i]);
     const int type = config_.column_type[i];
     if (ca != nullptr && type != kChar && !block.valuesMaterialized(column_attr_[i])) {
@@ -665,7 +765,11 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
   }
   const void *cols[QSX_MAX_COLUMNS];
   for (std::size_t i = 0; i < column_attr_.size(); ++i) cols[i] = block.stripe(column_attr_[i]);
-  CheckStatus(qsx_agg_update(state_, cols, n, lip_filter, CurrentStream()), "qsx_agg_update");
+  if (any_nulls) {
+    CheckStatus(qsx_agg_update_nullable(state_, cols, nulls, n, lip_filter, CurrentStream()), "qsx_agg_update_nullable");
+  } else {
+    CheckStatus(qsx_agg_update(state_, cols, n, lip_filter, CurrentStream()), "qsx_agg_update");
+  }
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
 }
 
@@ -859,13 +963,33 @@ void AggregationOperationState::finalizeAggregate(std::size_t partition, std::si
   BlockReference out = dest->getBlockForInsertion(groups > 0 ? groups : 1, &id);
   void *key_cols[QSX_MAX_KEYS];
   void *val_cols[QSX_MAX_AGGS];
+  std::uint8_t *null_cols[QSX_MAX_AGGS] = {};
+  std::vector<std::unique_ptr<DeviceBuffer>> null_flags;
   for (int k = 0; k < config_.num_keys; ++k) key_cols[k] = out->stripe(k);
-  for (int a = 0; a < config_.num_aggs; ++a) val_cols[a] = out->stripe(config_.num_keys + a);
+  for (int a = 0; a < config_.num_aggs; ++a) {
+    val_cols[a] = out->stripe(config_.num_keys + a);
+    // result types of SUM / AVG / MIN / MAX are nullable (AggregationHandleSum::getResultType ...->getNullableVersion()):
+    // an output attribute declared nullable receives the NULL flags as its null bitmap
+    if (out->nullBitmap(static_cast<attribute_id>(config_.num_keys + a)) != nullptr) {
+      null_flags.emplace_back(new DeviceBuffer(static_cast<std::size_t>(out->capacity()) + 16));
+      null_cols[a] = static_cast<std::uint8_t *>(null_flags.back()->ptr);
+    }
+  }
   DeviceBuffer rows(8);
   CheckStatus(qsx_agg_finalize(state_, static_cast<int>(partition), static_cast<int>(num_partitions), key_cols, val_cols,
-                               nullptr, out->capacity(), static_cast<std::int64_t *>(rows.ptr), CurrentStream()),
+                               null_flags.empty() ? nullptr : null_cols, out->capacity(), static_cast<std::int64_t *>(rows.ptr),
+                               CurrentStream()),
               "qsx_agg_finalize");
-  dest->returnBlock(id, ReadCount(rows.ptr));
+  const std::int64_t written = ReadCount(rows.ptr);
+  for (int a = 0; a < config_.num_aggs && written > 0; ++a) {
+    if (null_cols[a] == nullptr) continue;
+    // byte flags -> TupleIdSequence-ordered bitmap: a scan of 1-byte "codes" for flag >= 1
+    CheckStatus(qsx_select_codes(1, null_cols[a], written, QSX_CODE_GE, 1, 0, nullptr,
+                                 out->nullBitmap(static_cast<attribute_id>(config_.num_keys + a)), static_cast<std::int64_t *>(rows.ptr),
+                                 CurrentStream()), "qsx_select_codes(null flags)");
+  }
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+  dest->returnBlock(id, written);
 }
 
 // ---------------------------------------------------------------------------
@@ -901,8 +1025,12 @@ LIPFilterBuilder::LIPFilterBuilder(const QueryContext::LIPFilterDeployment &depl
 }
 void LIPFilterBuilder::insertValueAccessor(const StorageBlock &block, const std::uint64_t *filter) const {
   for (const auto &e : entries_) {
+    // a NULL is never inserted (SingleIdentityHashFilter.hpp:115-126, BitVectorExactFilter.hpp:115-128)
+    std::unique_ptr<DeviceBuffer> not_null = NotNullFilter(block, {e.second}, filter);
     CheckStatus(qsx_lip_build(e.first, block.getRelation().getAttributeType(e.second).id, block.stripe(e.second),
-                              block.numTuples(), filter, CurrentStream()), "qsx_lip_build");
+                              block.numTuples(), not_null != nullptr ? static_cast<const std::uint64_t *>(not_null->ptr) : filter,
+                              CurrentStream()), "qsx_lip_build");
+    if (not_null != nullptr) CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
   }
 }
 LIPFilterAdaptiveProber::LIPFilterAdaptiveProber(const QueryContext::LIPFilterDeployment &deployment,
@@ -919,9 +1047,13 @@ void *LIPFilterAdaptiveProber::filterValueAccessor(const StorageBlock &block, co
   DeviceBuffer count(8);
   const std::uint64_t *in = filter;
   for (const auto &e : entries_) {
+    // a NULL never passes a filter (SingleIdentityHashFilter.hpp:133-152)
+    std::unique_ptr<DeviceBuffer> not_null = NotNullFilter(block, {e.second}, in);
+    if (not_null != nullptr) in = static_cast<const std::uint64_t *>(not_null->ptr);
     CheckStatus(qsx_lip_probe(e.first, block.getRelation().getAttributeType(e.second).id, block.stripe(e.second), n, in,
                               static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count.ptr), CurrentStream()),
                 "qsx_lip_probe");
+    if (not_null != nullptr) CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
     std::swap(current, next);
     in = static_cast<const std::uint64_t *>(current);
   }
@@ -1069,6 +1201,7 @@ void SelectWorkOrder::execute() {
                                  static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
               "qsx_compact_gather");
   const std::int64_t written = ReadCount(count.ptr);  // synchronises the work order, like the reference's execute()
+  ProjectNullBitmaps(*block, simple_selection_, bitmap, written, out.get());
   qsx_device_free(bitmap);
   output_destination_->returnBlock(out_id, written);
 }
@@ -1215,8 +1348,12 @@ void BuildHashWorkOrder::execute() {
     lip_filter_builder_->insertValueAccessor(*block, static_cast<const std::uint64_t *>(bitmap));  // :187-190
   }
   JoinKeys keys(*block, join_key_attributes_);
+  // check_for_null_keys: tuples with a NULL key component are not inserted (HashTable.hpp:1409-1418, 1505-1518)
+  std::unique_ptr<DeviceBuffer> not_null = NotNullFilter(*block, join_key_attributes_, static_cast<const std::uint64_t *>(bitmap));
+  const std::uint64_t *build_filter = not_null != nullptr ? static_cast<const std::uint64_t *>(not_null->ptr)
+                                                          : static_cast<const std::uint64_t *>(bitmap);
   CheckStatus(qsx_join_build(hash_table_, keys.ptr, block->numTuples(),
-                             static_cast<std::int32_t>(block->firstRow()), static_cast<const std::uint64_t *>(bitmap),
+                             static_cast<std::int32_t>(block->firstRow()), build_filter,
                              CurrentStream()), "qsx_join_build");
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
   qsx_device_free(bitmap);
@@ -1307,6 +1444,14 @@ struct BuildSegments {
                                      static_cast<const std::int32_t *>(build_tids), n, dst, CurrentStream()),
                 "qsx_gather_segmented");
   }
+  // null bits of a build attribute for the joined pairs (negative tid = outer-join padding = NULL)
+  void gatherNulls(attribute_id attr, const void *build_tids, std::int64_t n, std::uint64_t *dst) const {
+    std::vector<const std::uint64_t *> segs;
+    for (const BlockReference &b : refs) segs.push_back(b->nullBitmap(attr));
+    CheckStatus(qsx_bitmap_gather_segmented(static_cast<int>(segs.size()), segs.data(), first_rows.data(),
+                                            static_cast<const std::int32_t *>(build_tids), n, dst, CurrentStream()),
+                "qsx_bitmap_gather_segmented");
+  }
 };
 
 // Joined pairs of one probe block, on device.
@@ -1347,6 +1492,11 @@ void HashInnerJoinWorkOrder::execute() {
   } lip_holder;
   if (lip_filter_adaptive_prober_ != nullptr) lip_holder.ptr = lip_filter_adaptive_prober_->filterValueAccessor(*probe, nullptr, nullptr);
   const std::uint64_t *lip = static_cast<const std::uint64_t *>(lip_holder.ptr);
+  // check_for_null_keys: a probe tuple with a NULL key component is not looked up (HashTable.hpp:2158-2160, 1855-1865):
+  // it matches nothing — out of an inner / semi join, NULL-padded in an outer join, kept by an anti join.
+  // `lookup` = the tuples that are looked up, `lip` stays the set of tuples this work order is about.
+  const std::unique_ptr<DeviceBuffer> not_null_keys = NotNullFilter(*probe, join_key_attributes_, lip);
+  const std::uint64_t *lookup = not_null_keys != nullptr ? static_cast<const std::uint64_t *>(not_null_keys->ptr) : lip;
   const bool pairs_needed = join_type_ == JoinType::kInnerJoin || join_type_ == JoinType::kLeftOuterJoin ||
                             residual_predicate_ != nullptr || !keys.exact;
 
@@ -1354,12 +1504,12 @@ void HashInnerJoinWorkOrder::execute() {
   std::unique_ptr<BuildSegments> build;
   if (pairs_needed) {
     // hash_table_.getAllFromValueAccessor[CompositeKey](accessor, key(s), nullable, &collector) (:480-485)
-    CheckStatus(qsx_join_probe_count(hash_table_, keys.ptr, n, lip, static_cast<std::int64_t *>(count.ptr), CurrentStream()),
+    CheckStatus(qsx_join_probe_count(hash_table_, keys.ptr, n, lookup, static_cast<std::int64_t *>(count.ptr), CurrentStream()),
                 "qsx_join_probe_count");
     pairs.count = ReadCount(count.ptr);
     pairs.probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
     pairs.build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
-    CheckStatus(qsx_join_probe(hash_table_, keys.ptr, n, /*probe_base_tid=*/0, lip,
+    CheckStatus(qsx_join_probe(hash_table_, keys.ptr, n, /*probe_base_tid=*/0, lookup,
                                static_cast<std::int32_t *>(pairs.probe_tids->ptr), static_cast<std::int32_t *>(pairs.build_tids->ptr),
                                pairs.count, static_cast<std::int64_t *>(count.ptr), CurrentStream()), "qsx_join_probe");
     build.reset(new BuildSegments(build_relation_, storage_manager_));
@@ -1433,8 +1583,20 @@ void HashInnerJoinWorkOrder::execute() {
       }
       CheckStatus(qsx_bitmap_count(static_cast<const std::uint64_t *>(bitmap.ptr), n, static_cast<std::int64_t *>(count.ptr),
                                    CurrentStream()), "qsx_bitmap_count");
+    } else if (anti && lookup != lip) {
+      // NULL keys are not looked up and therefore survive the anti join: tuples \ (looked-up tuples with a match)
+      CheckStatus(qsx_join_probe_exists(hash_table_, keys.ptr, n, lookup, 0, static_cast<std::uint64_t *>(bitmap.ptr),
+                                        static_cast<std::int64_t *>(count.ptr), CurrentStream()), "qsx_join_probe_exists");
+      CheckStatus(qsx_bitmap_combine(3, static_cast<const std::uint64_t *>(bitmap.ptr), nullptr, n,
+                                     static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_bitmap_combine");
+      if (lip != nullptr) {
+        CheckStatus(qsx_bitmap_combine(0, static_cast<const std::uint64_t *>(bitmap.ptr), lip, n,
+                                       static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_bitmap_combine");
+      }
+      CheckStatus(qsx_bitmap_count(static_cast<const std::uint64_t *>(bitmap.ptr), n, static_cast<std::int64_t *>(count.ptr),
+                                   CurrentStream()), "qsx_bitmap_count");
     } else {
-      CheckStatus(qsx_join_probe_exists(hash_table_, keys.ptr, n, lip, anti ? 1 : 0,
+      CheckStatus(qsx_join_probe_exists(hash_table_, keys.ptr, n, lookup, anti ? 1 : 0,
                                         static_cast<std::uint64_t *>(bitmap.ptr), static_cast<std::int64_t *>(count.ptr),
                                         CurrentStream()), "qsx_join_probe_exists");
     }
@@ -1455,7 +1617,9 @@ void HashInnerJoinWorkOrder::execute() {
                                    static_cast<const std::uint64_t *>(bitmap.ptr), n, dst.data(),
                                    static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
                 "qsx_compact_gather");
-    output_destination_->returnBlock(out_id, ReadCount(count.ptr));
+    const std::int64_t written = ReadCount(count.ptr);
+    ProjectNullBitmaps(*probe, selection_, bitmap.ptr, written, out.get());
+    output_destination_->returnBlock(out_id, written);
     return;
   }
 
@@ -1484,6 +1648,26 @@ void HashInnerJoinWorkOrder::execute() {
   const std::int64_t total = matches + unmatched;
   block_id out_id;
   BlockReference out = output_destination_->getBlockForInsertion(total > 0 ? total : 1, &out_id);
+  // Row numbers of all `total` output rows per side, for the null bits: pairs first, then (outer) the unmatched probe
+  // tuples next to build tid -1 = NULL padding.  Only materialised when some output attribute can be NULL.
+  std::unique_ptr<DeviceBuffer> all_probe_tids, all_build_tids;
+  auto all_tids = [&](bool on_build) -> const void * {
+    std::unique_ptr<DeviceBuffer> &buf = on_build ? all_build_tids : all_probe_tids;
+    if (unmatched == 0) return on_build ? pairs.build_tids->ptr : pairs.probe_tids->ptr;
+    if (buf == nullptr) {
+      buf.reset(new DeviceBuffer(static_cast<std::size_t>(total) * 4 + 8));
+      char *tail = static_cast<char *>(buf->ptr) + static_cast<std::size_t>(matches) * 4;
+      CheckStatus(qsx_copy_on_device(buf->ptr, on_build ? pairs.build_tids->ptr : pairs.probe_tids->ptr,
+                                     static_cast<std::size_t>(matches) * 4, CurrentStream()), "qsx_copy_on_device");
+      if (on_build) {
+        CheckStatus(qsx_memset_device(tail, 0xFF, static_cast<std::size_t>(unmatched) * 4, CurrentStream()), "qsx_memset_device");
+      } else {
+        CheckStatus(qsx_copy_on_device(tail, unmatched_tids->ptr, static_cast<std::size_t>(unmatched) * 4, CurrentStream()),
+                    "qsx_copy_on_device");
+      }
+    }
+    return buf->ptr;
+  };
   for (std::size_t i = 0; i < selection_.size(); ++i) {
     // Scalar::getAllValuesForJoin (:529-536)
     char *dst = static_cast<char *>(out->stripe(static_cast<attribute_id>(i)));
@@ -1498,19 +1682,25 @@ void HashInnerJoinWorkOrder::execute() {
     if (unmatched > 0) {
       char *tail = dst + static_cast<std::size_t>(matches) * width;
       if (on_build) {
-        // result->fillWithNulls() (:1077-1080): zero bytes + the null bits of rows [matches, total)
+        // result->fillWithNulls() (:1077-1080): zero bytes here, the null bits of rows [matches, total) below
         CheckStatus(qsx_memset_device(tail, 0, static_cast<std::size_t>(unmatched) * width, CurrentStream()), "qsx_memset_device");
-        std::uint64_t *nulls = out->nullBitmap(static_cast<attribute_id>(i));
-        if (nulls == nullptr) {
+        if (out->nullBitmap(static_cast<attribute_id>(i)) == nullptr) {
           throw ExecutionError("outer join output attribute taken from the build side must be nullable", QSX_ERR_INVALID_ARGUMENT);
         }
-        std::vector<std::uint64_t> words(static_cast<std::size_t>((total + 63) / 64), 0);
-        for (std::int64_t r = matches; r < total; ++r) words[r >> 6] |= 1ull << (63 - (r & 63));
-        CheckStatus(qsx_copy_to_device(nulls, words.data(), words.size() * 8, CurrentStream()), "qsx_copy_to_device(null bitmap)");
-        CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");  // `words` is a local
       } else {
         CheckStatus(qsx_gather(width, probe->stripe(selection_[i]), static_cast<const std::int32_t *>(unmatched_tids->ptr), unmatched,
                                tail, CurrentStream()), "qsx_gather");
+      }
+    }
+    // null bits of the output attribute: the source attribute's bits at the joined rows, 1 under the outer join's padding
+    const bool source_nullable = (on_build ? build_relation_ : probe_relation_).getAttributeType(selection_[i]).nullable;
+    if (total > 0 && (source_nullable || (on_build && unmatched > 0))) {
+      std::uint64_t *nulls = out->nullBitmap(static_cast<attribute_id>(i));
+      if (nulls == nullptr) throw ExecutionError("join output of a nullable attribute must be nullable", QSX_ERR_INVALID_ARGUMENT);
+      if (on_build) {
+        build->gatherNulls(selection_[i], all_tids(true), total, nulls);
+      } else {
+        GatherBlockNulls(*probe, selection_[i], all_tids(false), total, nulls);
       }
     }
   }

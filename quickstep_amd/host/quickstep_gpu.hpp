@@ -220,8 +220,11 @@ class StorageManager {
   // Create a block from host columns (one pointer per attribute), copy to HBM and add it to the relation.
   // compress: per attribute, try to store it compressed (the attribute list of the block layout's
   // CompressedColumnStore description, storage/StorageBlockLayout.proto); nullptr = plain column store.
+  // null_bitmaps: per attribute, the host null bitmap of a nullable attribute (TupleIdSequence bit order, 1 = NULL,
+  // (num_tuples + 63) / 64 words) or nullptr = no NULLs in this block; the vector itself may be nullptr.
   block_id loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns, std::int64_t num_tuples,
-                     partition_id part = 0, const std::vector<bool> *compress = nullptr);
+                     partition_id part = 0, const std::vector<bool> *compress = nullptr,
+                     const std::vector<const std::uint64_t *> *null_bitmaps = nullptr);
   BlockReference getBlock(block_id id) const;
   void deleteBlockOrBlobFile(block_id id);
   // Registers `num_tuples` more rows of `relation`; returns the relation-global row number of the first one.

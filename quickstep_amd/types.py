@@ -15,7 +15,7 @@ CODE_EQ, CODE_NE, CODE_LT, CODE_GE, CODE_RANGE = range(5)            # qsx_code_
 # qsx_agg_strategy_t
 AGG_SINGLE_STATE, AGG_COMPACT_KEY, AGG_COLLISION_FREE, AGG_GENERIC = range(4)
 # qsx_agg_fn_t
-AGG_COUNT_STAR, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX = range(5)
+AGG_COUNT_STAR, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX, AGG_COUNT = range(6)
 # qsx_operand_kind_t
 OPD_COLUMN, OPD_CONST, OPD_TEMP = range(3)
 # qsx_expr_op_t
@@ -71,6 +71,7 @@ class AggConfig(C.Structure):
         ("est_groups", C.c_int64),
         ("num_entries", C.c_int64),
         ("column_code_width", C.c_int32 * MAX_COLUMNS),
+        ("column_nullable", C.c_int32 * MAX_COLUMNS),
     ]
 
 
@@ -87,7 +88,7 @@ def temp(i):
 
 
 def make_agg_config(strategy, columns, keys=(), instrs=(), consts=(), aggs=(), pred=(),
-                    est_groups=0, num_entries=0, code_widths=None):
+                    est_groups=0, num_entries=0, code_widths=None, nullable=()):
     """Build an AggConfig.
 
     columns: list of (type, width) — width may be None for numeric types
@@ -95,6 +96,7 @@ def make_agg_config(strategy, columns, keys=(), instrs=(), consts=(), aggs=(), p
     instrs:  list of (op, dst, Operand a, Operand b)
     aggs:    list of (fn, Operand-or-None)
     pred:    list of (column, cmp, literal)
+    nullable: column indices whose attribute type is nullable (their null bitmaps go to update_nullable)
     """
     cfg = AggConfig()
     cfg.strategy = strategy
@@ -132,6 +134,8 @@ def make_agg_config(strategy, columns, keys=(), instrs=(), consts=(), aggs=(), p
     cfg.num_entries = num_entries
     for i, w in enumerate(code_widths or ()):      # 0 = plain column, 1 / 2 / 4 = compressed attribute (codes)
         cfg.column_code_width[i] = w
+    for i in nullable:
+        cfg.column_nullable[i] = 1
     return cfg
 
 
@@ -150,7 +154,7 @@ def agg_output_dtype(cfg, a):
 def agg_output_is_int(cfg, a):
     """True when aggregate `a` finalizes to int64 (COUNT, SUM over INT/LONG)."""
     fn = cfg.aggs[a].fn
-    if fn == AGG_COUNT_STAR:
+    if fn in (AGG_COUNT_STAR, AGG_COUNT):
         return True
     if fn == AGG_AVG:
         return False

@@ -174,7 +174,7 @@ a_rows = [{"w": i, "x": 10 * i, "y": 100.0 * i} for i in range(20)]
 dump("sql_golden", {
     "source": [
         "query_optimizer/tests/execution_generator/LIP.test:20-29,39-75,77-146",
-        "query_optimizer/tests/execution_generator/Join.test:17-74",
+        "query_optimizer/tests/execution_generator/Join.test:17-74, 136-196 (LEFT JOIN chains: NULL join keys)",
         "query_optimizer/tests/execution_generator/Select.test:582-679 (aggregates over the 25-row test table)",
         "query_optimizer/tests/TestDatabaseLoader.cpp:118-170 (test table)",
     ],
@@ -196,6 +196,23 @@ dump("sql_golden", {
             {"w": 12, "b_x": 120, "c_y": 1200.0},
             {"w": 18, "b_x": 181, "c_y": 1799.0},
         ],
+        # Join.test:136-165: a LEFT JOIN b ON a.w = b.w LEFT JOIN c ON a.x = c.x LEFT JOIN d ON a.y = d.y
+        # (d.z = 'C<w>' for every row: d holds every a.y); None = NULL.  Columns a.w, b.x, c.y, row w = index.
+        "left_join_on_a": {
+            "b_x": [0, None, 21, None, 40, None, 61, None, 80, None, 101, None, 120, None, 141, None, 160, None, 181, None],
+            "c_y": [-1.0, None, None, 300.0, None, None, 601.0, None, None, 899.0, None, None, 1200.0, None, None, 1501.0,
+                    None, None, 1799.0, None],
+        },
+        # Join.test:167-196: a LEFT JOIN b ON a.w = b.w LEFT JOIN c ON b.x = c.x LEFT JOIN d ON c.y = d.y — the second
+        # and third joins probe with NULL keys (b.x / c.y of the padded rows): a NULL key matches nothing.
+        # d_z_w: the w of the matching d row ('C<w>'), None = NULL.
+        "left_join_chained": {
+            "b_x": [0, None, 21, None, 40, None, 61, None, 80, None, 101, None, 120, None, 141, None, 160, None, 181, None],
+            "c_y": [-1.0, None, None, None, None, None, None, None, None, None, None, None, 1200.0, None, None, None,
+                    None, None, None, None],
+            "d_z_w": [None, None, None, None, None, None, None, None, None, None, None, None, 12, None, None, None,
+                      None, None, None, None],
+        },
     },
     "test_table": test_table_rows(),
     "select": {
@@ -214,6 +231,12 @@ dump("sql_golden", {
             {"count": 2, "g1": 4, "g2": 8}, {"count": 1, "g1": 4, "g2": 9},
             {"count": 1, "g1": 5, "g2": 10}, {"count": 1, "g1": 5, "g2": 11},
         ],
+        # Select.test:609-623: SELECT COUNT(*), COUNT(1), COUNT(0), SUM(int_col) / COUNT(*), AVG(int_col+0) * COUNT(1),
+        # MAX(double_col+100), MIN(float_col+1) FROM test — int_col and double_col are NULL in rows 0, 10, 20
+        "scalar_with_nulls": {
+            "count_star": 25, "sum_int_div_count": 0, "avg_int_plus_0_times_count": -20.454545454545457,
+            "max_double_plus_100": 217.57550765359252, "min_float_plus_1": 1.0,
+        },
         # SELECT int_col FROM test GROUP BY int_col ORDER BY int_col  (NULL group not printed)
         "distinct_int_col": [-23, -21, -19, -17, -15, -13, -11, -9, -7, -5, -3, -1,
                              2, 4, 6, 8, 12, 14, 16, 18, 22, 24],

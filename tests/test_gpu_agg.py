@@ -532,3 +532,83 @@ def test_existence_map_rejects_hash_strategies(capi, dev):
     with pytest.raises(capi.QsxError) as e:
         capi.AggState(cfg).mark_existence(torch.zeros(4, dtype=torch.int32, device=dev))
     assert e.value.status == T.ERR_UNSUPPORTED
+
+
+# ---- nullable inputs -----------------------------------------------------------------------------------------------
+def test_sql_golden_scalar_aggregates_skip_nulls(capi, oracle, dev, golden):
+    """Select.test:609-623 on the device: int_col / double_col are NULL in rows 0, 10, 20 (TestDatabaseLoader.cpp:118-170)."""
+    from test_oracle_pins import check_select_scalar_with_nulls, nullable_test_table, select_scalar_with_nulls_config
+    cols, nulls = nullable_test_table(oracle, golden)
+    st = capi.AggState(select_scalar_with_nulls_config())
+    st.update_nullable([to_dev(c, dev) for c in cols], [None if b is None else bitmap_dev(b, dev) for b in nulls])
+    _, vals, flags = finalize_np(st, dev)
+    check_select_scalar_with_nulls(vals, flags, golden["sql_golden"]["select"]["scalar_with_nulls"])
+    all_null = bitmap_dev(oracle.bitmap_from_bools(np.ones(25, dtype=bool)), dev)
+    st = capi.AggState(select_scalar_with_nulls_config())
+    st.update_nullable([to_dev(c, dev) for c in cols], [all_null, None, None, all_null])
+    _, vals, flags = finalize_np(st, dev)
+    assert int(vals[0][0]) == 25 and int(vals[5][0]) == 0 and [int(z[0]) for z in flags] == [0, 1, 1, 1, 0, 0]
+
+
+@pytest.mark.parametrize("strategy", [T.AGG_SINGLE_STATE, T.AGG_COMPACT_KEY, T.AGG_GENERIC, T.AGG_COLLISION_FREE])
+def test_nullable_columns_match_the_oracle(capi, oracle, dev, strategy):
+    """NULL group-by keys drop the tuple, NULL predicate operands fail the predicate, every aggregate skips the tuples whose
+    argument (or an operand of its expression) is NULL, COUNT(*) does not; groups whose argument was always NULL finalize
+    as NULL.  Blocks with and without bitmaps, with and without a filter."""
+    rng = np.random.default_rng(77 + strategy)
+    n = 150_000
+    key = rng.integers(0, 300, size=n).astype(np.int32)
+    key[40_064:100_032][key[40_064:100_032] == 7] = 8      # (the block that comes without bitmaps has no row of group 7)
+    x = rng.integers(-50, 50, size=n).astype(np.int32)
+    y = rng.normal(size=n)
+    z = rng.integers(0, 1000, size=n).astype(np.int64)
+    p = rng.uniform(size=n).astype(np.float32)
+    # group 7 never has a non-NULL x; about a fifth of every nullable column is NULL
+    null_key = rng.uniform(size=n) < 0.1
+    null_x = (rng.uniform(size=n) < 0.2) | (key == 7)
+    null_y = rng.uniform(size=n) < 0.2
+    null_p = rng.uniform(size=n) < 0.05
+    layout = [(T.INT, None), (T.INT, None), (T.DOUBLE, None), (T.LONG, None), (T.FLOAT, None)]
+    keys = [] if strategy == T.AGG_SINGLE_STATE else [0]
+    cfg = T.make_agg_config(
+        strategy, layout, keys=keys,
+        instrs=[(T.EX_MUL, 0, T.col(1), T.col(2)), (T.EX_ADD, 1, T.temp(0), T.col(3))],     # x * y + z
+        aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_COUNT, T.col(1)), (T.AGG_SUM, T.col(1)), (T.AGG_AVG, T.col(2)),
+              (T.AGG_MIN, T.temp(1)), (T.AGG_MAX, T.col(1)), (T.AGG_SUM, T.col(3))],
+        pred=[(4, T.LT, 0.9)], est_groups=512, num_entries=300, nullable=[0, 1, 2, 4])
+    cols = [key, x, y, z, p]
+    null_bools = [null_key, null_x, null_y, None, null_p]
+    keep = rng.uniform(size=n) < 0.7
+    edges = [0, 40_000, 40_064, 100_032, n]      # block boundaries at multiples of 64 (bitmaps are sliced by word)
+    for with_filter in (False, True):
+        st = capi.AggState(cfg)
+        o = oracle.AggState(cfg)
+        for b in range(len(edges) - 1):
+            lo, hi = edges[b], edges[b + 1]
+            part = [c[lo:hi] for c in cols]
+            # the third block comes without bitmaps (an attribute may hold no NULL in a block)
+            bitmaps = [None if (nb is None or b == 2) else oracle.bitmap_from_bools(nb[lo:hi]) for nb in null_bools]
+            filt = oracle.bitmap_from_bools(keep[lo:hi]) if with_filter else None
+            o.update_nullable(part, bitmaps, filter_bitmap=filt)
+            st.update_nullable([to_dev(c, dev) for c in part], [None if m is None else bitmap_dev(m, dev) for m in bitmaps],
+                               filter_bitmap=None if filt is None else bitmap_dev(filt, dev))
+        got, ref = finalize_np(st, dev), o.finalize()
+        assert_same_groups(got, ref)
+        if strategy != T.AGG_SINGLE_STATE:
+            row = int(np.nonzero(got[0][0] == 7)[0][0])
+            assert [int(z_[row]) for z_ in got[2]] == [0, 0, 1, 0, 1, 1, 0] and int(got[1][1][row]) == 0
+
+
+def test_bitmap_gather_segmented(capi, oracle, dev):
+    """Null bits follow gathered values: bit i = null bit of row tids[i] in its segment, 1 for the outer join's padding."""
+    rng = np.random.default_rng(5)
+    sizes = [1000, 64, 3001]
+    first = [0, 1000, 1064]
+    bools = [rng.uniform(size=s) < 0.3 for s in sizes]
+    segs = [bitmap_dev(oracle.bitmap_from_bools(bools[0]), dev), None, bitmap_dev(oracle.bitmap_from_bools(bools[2]), dev)]
+    whole = np.concatenate([bools[0], np.zeros(64, dtype=bool), bools[2]])
+    for count in (0, 1, 63, 64, 65, 5000):
+        tids = rng.integers(-1, sum(sizes), size=count).astype(np.int32)
+        out = capi.bitmap_gather_segmented(segs, first, to_dev(tids, dev))
+        want = oracle.bitmap_from_bools(np.where(tids < 0, True, whole[np.maximum(tids, 0)]))
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want[:(count + 63) // 64])

@@ -14,7 +14,7 @@ def _ensure_built():
     if not all(os.path.exists(os.path.join(BIN, b)) for b in
                ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
                 "lip_filter_operator_test", "compressed_block_operator_test", "host_logic_test",
-                "sort_operator_test")):
+                "sort_operator_test", "nullable_operator_test")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -75,3 +75,10 @@ def test_sort_run_generation_and_merge_operators():
     """SortRunGenerationOperator / SortMergeRunOperator mirrors (1 and 3 ORDER BY columns, ASC/DESC/mixed, top-k),
     synchronous driver and Foreman/Worker with runs streaming into the merge."""
     _run("sort_operator_test")
+
+
+@pytest.mark.gpu
+def test_nulls_through_the_operators():
+    """Join.test's LEFT JOIN chains (NULL join keys), Select.test's aggregates over the test table's NULLs, semi / anti joins
+    and selections over nullable attributes — synchronous driver and Foreman/Worker."""
+    _run("nullable_operator_test")

@@ -221,11 +221,13 @@ def test_sql_golden_select_group_by(oracle, golden):
     # GROUP BY long_col/100 (integer division) over rows with non-NULL int_col contributions:
     # SUM(int_col) skips NULLs, COUNT(*) counts all rows; HAVING MIN(float_col) > 0 drops the group holding x = 0.
     g1 = np.array([r["long_col"] // 100 for r in rows], dtype=np.int64)
-    ints = np.array([0 if r["int_col"] is None else r["int_col"] for r in rows], dtype=np.int32)
+    # the stripe holds an arbitrary value under a NULL (here: a large one that would show in every sum)
+    ints = np.array([1 << 30 if r["int_col"] is None else r["int_col"] for r in rows], dtype=np.int32)
+    int_nulls = oracle.bitmap_from_bools(np.array([r["int_col"] is None for r in rows]))
     cfg = T.make_agg_config(T.AGG_GENERIC, [(T.LONG, None), (T.INT, None)], keys=[0],
-                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1))], est_groups=8)
+                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1))], est_groups=8, nullable=[1])
     st = oracle.AggState(cfg)
-    st.update([g1, ints])
+    st.update_nullable([g1, ints], [None, int_nulls])
     keys, vals, _ = st.finalize()
     got = {int(k): (int(c), int(s)) for k, c, s in zip(keys[0], vals[0], vals[1])}
     for e in sel["group_by_long_div_100"]:
@@ -239,13 +241,105 @@ def test_sql_golden_select_group_by(oracle, golden):
     keys2, vals2, _ = st2.finalize()
     got2 = sorted((int(c), int(a), int(b)) for a, b, c in zip(keys2[0], keys2[1], vals2[0]) if b > 5)
     assert got2 == sorted((e["count"], e["g1"], e["g2"]) for e in sel["group_by_two_keys_gt5"])
-    # GROUP BY int_col (non-NULL rows): the distinct listing
-    ic = np.array([r["int_col"] for r in keep], dtype=np.int32)
-    cfg3 = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.INT, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None)], est_groups=32)
+    # GROUP BY int_col: tuples with a NULL key form no group (the listing has 22 rows, PackedPayloadHashTable.hpp:861-867)
+    cfg3 = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None)], est_groups=32, nullable=[0])
     st3 = oracle.AggState(cfg3)
-    st3.update([ic])
-    keys3, _, _ = st3.finalize()
-    assert sorted(keys3[0].tolist()) == sel["distinct_int_col"]
+    st3.update_nullable([ints], [int_nulls])
+    keys3, vals3, _ = st3.finalize()
+    assert sorted(keys3[0].tolist()) == sel["distinct_int_col"] and vals3[0].tolist() == [1] * len(sel["distinct_int_col"])
+
+
+def nullable_test_table(oracle, golden):
+    """(columns, null bitmaps, config columns) of the 25-row test table with its NULLs as NULLs."""
+    rows = golden["sql_golden"]["test_table"]
+    ints = np.array([-77 if r["int_col"] is None else r["int_col"] for r in rows], dtype=np.int32)
+    longs = np.array([r["long_col"] for r in rows], dtype=np.int64)
+    floats = np.array([r["float_col"] for r in rows], dtype=np.float32)
+    doubles = np.array([1e300 if r["double_col"] is None else r["double_col"] for r in rows], dtype=np.float64)
+    int_nulls = oracle.bitmap_from_bools(np.array([r["int_col"] is None for r in rows]))
+    double_nulls = oracle.bitmap_from_bools(np.array([r["double_col"] is None for r in rows]))
+    return [ints, longs, floats, doubles], [int_nulls, None, None, double_nulls]
+
+
+def select_scalar_with_nulls_config():
+    # SELECT COUNT(*), SUM(int_col), AVG(int_col+0), MAX(double_col+100), MIN(float_col+1), COUNT(int_col) FROM test
+    return T.make_agg_config(
+        T.AGG_SINGLE_STATE, [(T.INT, None), (T.LONG, None), (T.FLOAT, None), (T.DOUBLE, None)],
+        instrs=[(T.EX_ADD, 0, T.col(0), T.const(0)), (T.EX_ADD, 1, T.col(3), T.const(1)), (T.EX_ADD, 2, T.col(2), T.const(2))],
+        consts=[0.0, 100.0, 1.0],
+        aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(0)), (T.AGG_AVG, T.temp(0)), (T.AGG_MAX, T.temp(1)),
+              (T.AGG_MIN, T.temp(2)), (T.AGG_COUNT, T.col(0))],
+        nullable=[0, 3])
+
+
+def check_select_scalar_with_nulls(vals, nulls, e):
+    count_star = int(vals[0][0])
+    assert count_star == e["count_star"] and int(vals[5][0]) == 22
+    assert int(vals[1][0] / count_star) == e["sum_int_div_count"]          # integer division of -18 by 25
+    assert vals[2][0] * count_star == pytest.approx(e["avg_int_plus_0_times_count"], rel=1e-12)
+    assert vals[3][0] == pytest.approx(e["max_double_plus_100"], rel=1e-12)
+    assert vals[4][0] == pytest.approx(e["min_float_plus_1"], rel=1e-6)
+    assert not any(int(z[0]) for z in nulls)
+
+
+def test_sql_golden_select_scalar_aggregates_skip_nulls(oracle, golden):
+    """Select.test:609-623: aggregates over a table whose int_col / double_col are NULL in rows 0, 10, 20."""
+    cols, nulls = nullable_test_table(oracle, golden)
+    st = oracle.AggState(select_scalar_with_nulls_config())
+    st.update_nullable(cols, nulls)
+    _, vals, flags = st.finalize()
+    check_select_scalar_with_nulls(vals, flags, golden["sql_golden"]["select"]["scalar_with_nulls"])
+    # every argument NULL: SUM / AVG / MIN / MAX are NULL, COUNT(x) is 0, COUNT(*) counts the rows
+    all_null = oracle.bitmap_from_bools(np.ones(25, dtype=bool))
+    st = oracle.AggState(select_scalar_with_nulls_config())
+    st.update_nullable(cols, [all_null, None, None, all_null])
+    _, vals, flags = st.finalize()
+    assert int(vals[0][0]) == 25 and int(vals[5][0]) == 0
+    assert [int(z[0]) for z in flags] == [0, 1, 1, 1, 0, 0]
+
+
+def left_outer_join_unique(oracle, probe_keys, probe_is_null, build_keys):
+    """Build tid (or -1) per probe row for a build side with unique keys; NULL probe keys are not looked up
+    (HashTable.hpp:2158-2160)."""
+    t = oracle.JoinTable(T.LONG, build_keys.size)
+    t.build(build_keys)
+    lookup = oracle.bitmap_from_bools(~probe_is_null)
+    p, b = t.probe(probe_keys, filter_bitmap=lookup)
+    out = np.full(probe_keys.size, -1, dtype=np.int64)
+    out[p] = b
+    return out
+
+
+def test_sql_golden_left_join_chains_with_null_keys(oracle, golden):
+    """Join.test:136-196."""
+    j = golden["sql_golden"]["join"]
+    a = j["a"]
+    aw = np.array([r["w"] for r in a], dtype=np.int64)
+    ax = np.array([r["x"] for r in a], dtype=np.int64)
+    ay = np.array([r["y"] for r in a], dtype=np.int64)          # whole numbers: joined as LONG images
+    bw = aw[aw % 2 == 0]
+    bx = (ax + (aw // 2) % 2)[aw % 2 == 0]
+    cx = ax[ax % 3 == 0]
+    cy = (ay + (ax // 3) % 3 - 1)[ax % 3 == 0]
+    never = np.zeros(aw.size, dtype=bool)
+
+    def column(values, tids):
+        return [None if t < 0 else int(values[t]) for t in tids]
+
+    # a LEFT JOIN b ON a.w = b.w LEFT JOIN c ON a.x = c.x
+    e = j["left_join_on_a"]
+    tb = left_outer_join_unique(oracle, aw, never, bw)
+    tc = left_outer_join_unique(oracle, ax, never, cx)
+    assert column(bx, tb) == e["b_x"] and column(cy, tc) == [None if v is None else int(v) for v in e["c_y"]]
+    # ... LEFT JOIN c ON b.x = c.x LEFT JOIN d ON c.y = d.y: the padded rows probe with NULL keys
+    e = j["left_join_chained"]
+    b_x = np.where(tb < 0, 123456, bx[np.maximum(tb, 0)])      # arbitrary value under the NULLs
+    tc2 = left_outer_join_unique(oracle, b_x, tb < 0, cx)
+    c_y = np.where(tc2 < 0, 1200, cy[np.maximum(tc2, 0)])      # 1200 would match d if it were looked up
+    td = left_outer_join_unique(oracle, c_y, tc2 < 0, ay)
+    assert column(bx, tb) == e["b_x"]
+    assert column(cy, tc2) == [None if v is None else int(v) for v in e["c_y"]]
+    assert column(aw, td) == e["d_z_w"]
 
 
 def test_sql_golden_lip(oracle, golden):
