@@ -633,6 +633,7 @@ struct StateLayout {
   // compares with the type's less / greater comparator: AggregationHandleMin.hpp:190-215,
   // AggregationHandleMax.hpp:190-215).
   int num_states = 0;
+  bool any_nullable = false;          // some column is nullable: SUM keeps its "saw a value" count
   bool state_is_int[2 * QSX_MAX_AGGS];
   int state_op[2 * QSX_MAX_AGGS];     // 0 add, 1 min, 2 max; a min/max word is followed by its has-value word
   int agg_first_state[QSX_MAX_AGGS];
@@ -646,6 +647,7 @@ bool operand_is_int_column(const qsx_agg_config_t &c, const qsx_operand_t &o) {
 
 StateLayout make_layout(const qsx_agg_config_t &c) {
   StateLayout L;
+  for (int col = 0; col < c.num_columns; ++col) L.any_nullable = L.any_nullable || c.column_nullable[col] != 0;
   for (int s = 0; s < 2 * QSX_MAX_AGGS; ++s) L.state_op[s] = 0;
   for (int a = 0; a < c.num_aggs; ++a) {
     L.agg_first_state[a] = L.num_states;
@@ -741,7 +743,7 @@ struct RowReader {
     for (int k = 0; k < c.num_instrs; ++k) {
       const qsx_expr_instr_t &in = c.instrs[k];
       const double a = operand(in.a, i), b = operand(in.b, i);
-      temp_null[in.dst] = operand_is_null(in.a, i) || operand_is_null(in.b, i);
+      if (nulls != nullptr) temp_null[in.dst] = operand_is_null(in.a, i) || operand_is_null(in.b, i);
       double r;
       switch (in.op) {
         case QSX_EX_ADD: r = a + b; break;
@@ -801,7 +803,7 @@ inline void accumulate(const qsx_agg_config_t &c, const StateLayout &L, const Ro
     StateWord *s = st + L.agg_first_state[a];
     // every handle but COUNT(*) skips a NULL argument (iterateUnaryInl, AggregationHandleSum.hpp:105-120;
     // AggregationHandleCount.hpp:98-118 for COUNT(x))
-    if (c.aggs[a].fn != QSX_AGG_COUNT_STAR && rr.operand_is_null(c.aggs[a].arg, i)) continue;
+    if (rr.nulls != nullptr && c.aggs[a].fn != QSX_AGG_COUNT_STAR && rr.operand_is_null(c.aggs[a].arg, i)) continue;
     switch (c.aggs[a].fn) {
       case QSX_AGG_COUNT_STAR:
       case QSX_AGG_COUNT:
@@ -814,7 +816,8 @@ inline void accumulate(const qsx_agg_config_t &c, const StateLayout &L, const Ro
         } else {
           s[0].d += rr.operand(c.aggs[a].arg, i);
         }
-        s[1].i += 1;
+        // (SUM's "saw a value" word is only read for nullable arguments; AVG's second word is its count)
+        if (L.any_nullable || c.aggs[a].fn == QSX_AGG_AVG) s[1].i += 1;
         break;
       case QSX_AGG_MIN:
       case QSX_AGG_MAX: {
