@@ -136,7 +136,12 @@ namespace {
 // The cache, its lock and the compile threads are never destroyed: a compile may still be running when the process
 // tears its statics down; an atexit hook waits for the threads instead.
 std::mutex &cache_mutex() { static std::mutex *m = new std::mutex; return *m; }
-std::map<std::string, JitRequest *> &cache() { static auto *c = new std::map<std::string, JitRequest *>; return *c; }
+// keyed by (device, source text): hipModuleLoadData loads the code object on the device that is current in the loading
+// thread, and a hipFunction_t of one device's module must not be launched on another
+std::map<std::pair<int, std::string>, JitRequest *> &cache() {
+  static auto *c = new std::map<std::pair<int, std::string>, JitRequest *>;
+  return *c;
+}
 std::vector<std::thread> &compile_threads() { static auto *t = new std::vector<std::thread>; return *t; }
 void join_compile_threads() {
   std::vector<std::thread> threads;
@@ -196,14 +201,17 @@ JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, cons
   const std::string source = make_source(dev, num_sums, dense, geometry);   // a filter is part of dev (filter_lds_off)
   JitRequest *r = nullptr;
   bool mine = false;
+  int device = 0;
+  (void)hipGetDevice(&device);
   {
     std::lock_guard<std::mutex> lock(cache_mutex());
-    auto it = cache().find(source);
+    const std::pair<int, std::string> key(device, source);
+    auto it = cache().find(key);
     if (it != cache().end()) {
       r = it->second;
     } else {
       r = new JitRequest();
-      cache().emplace(source, r);
+      cache().emplace(key, r);
       mine = true;
       if (!synchronous) {
         // hipRTC takes 1-2 s: the caller keeps using the interpreter kernel and picks the shape up when it is ready
@@ -212,8 +220,6 @@ JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, cons
           std::atexit(join_compile_threads);
           hooked = true;
         }
-        int device = 0;
-        (void)hipGetDevice(&device);
         compile_threads().emplace_back([r, source, device]() {
           (void)hipSetDevice(device);
           JitKernel *k = compile(source);

@@ -533,6 +533,25 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
 
 static size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): one flag per device behind a lock —
+// AggregationWorkOrders of several worker threads reach the launchers concurrently.
+constexpr int kMaxDevices = 64;
+struct PerDeviceOnce {
+  std::mutex mutex;
+  bool done[kMaxDevices] = {};
+};
+template <typename F>
+static int once_per_device(PerDeviceOnce &flags, F &&set_attribute) {
+  int device = 0;
+  QSX_HIP_TRY(hipGetDevice(&device));
+  if (device < 0 || device >= kMaxDevices) return QSX_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(flags.mutex);
+  if (flags.done[device]) return QSX_OK;
+  QSX_HIP_TRY(set_attribute());
+  flags.done[device] = true;
+  return QSX_OK;
+}
+
 // After the zeroing memset: MIN / MAX columns start from their identity.
 static int fill_identities(qsx_agg_state *st, hipStream_t stream) {
   if (!st->has_min_max) return QSX_OK;
@@ -685,11 +704,13 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   if (dry_run) return QSX_OK;
-  static bool attribute_set = false;  // per instantiation
-  if (!attribute_set) {
-    QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_update_kernel<NS, V>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
-    attribute_set = true;
+  static PerDeviceOnce attribute_set;  // per instantiation
+  {
+    const int rc = once_per_device(attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_update_kernel<NS, V>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
   }
   // grid = what is resident at once (LDS-limited workgroups per CU), tiles are strided over it
   int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
@@ -729,11 +750,13 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
   const int rep_shift = choose_replication(NS, S, static_cast<size_t>(nbuf) * T.dev.tile_bytes, tune, &lds);
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
-  static bool attribute_set = false;
-  if (!attribute_set) {
-    QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_kernel<Shape, V>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
-    attribute_set = true;
+  static PerDeviceOnce attribute_set;
+  {
+    const int rc = once_per_device(attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_kernel<Shape, V>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
   }
   int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
   if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
@@ -753,12 +776,12 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
   // with 1024-slot tables (10 k groups) — have kernels with those numbers as constants
 #define QSX_LAUNCH_FIXED(S_, REP_, RANGES_)                                                                                        \
   do {                                                                                                                             \
-    static bool fixed_attribute_set = false;                                                                                       \
-    if (!fixed_attribute_set) {                                                                                                    \
-      QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_kernel<Shape, V, S_, REP_, RANGES_>),   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));                    \
-      fixed_attribute_set = true;                                                                                                  \
-    }                                                                                                                              \
+    static PerDeviceOnce fixed_attribute_set;                                                                                      \
+    const int attr_rc = once_per_device(fixed_attribute_set, [] {                                                                  \
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_kernel<Shape, V, S_, REP_, RANGES_>),        \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));                          \
+    });                                                                                                                            \
+    if (attr_rc != QSX_OK) return attr_rc;                                                                                         \
     hipLaunchKernelGGL((agg_hash_shape_fixed_kernel<Shape, V, S_, REP_, RANGES_>), dim3(grid), dim3(kABlock), lds, stream, cp, n,  \
                        g, pieces);                                                                                                 \
     return QSX_OK;                                                                                                                 \
@@ -923,11 +946,13 @@ static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const ui
                      sizeof(unsigned long long) * (8 + static_cast<size_t>(NS + 1) * (8 + kWave));
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
-  static bool attribute_set = false;
-  if (!attribute_set) {
-    QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dense_update_kernel<NS, V>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds)));
-    attribute_set = true;
+  static PerDeviceOnce attribute_set;
+  {
+    const int rc = once_per_device(attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dense_update_kernel<NS, V>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
   }
   int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
   if (per_cu > 4) per_cu = 4;

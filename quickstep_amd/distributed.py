@@ -60,6 +60,17 @@ def shuffle_by_key(ops, keys, cols, group=None):
     return received, recv_splits
 
 
+def _checked_count(count, out_pairs):
+    """qsx_join_probe keeps counting past the capacity it was given and only guards the writes: a count above the
+    buffer means pairs were dropped (duplicate build keys, capacity sized for a foreign-key join) — an error, not a
+    shorter result."""
+    k = int(count.item())
+    if k > out_pairs.numel():
+        raise RuntimeError(f"join produced {k} pairs but the output buffer holds {out_pairs.numel()}: "
+                           "probe again with capacity >= that count (or count first with probe_count)")
+    return k
+
+
 def rank_progression(key_domain, world, rank):
     """(first, last) of the keys k in [min, max] with k & (world-1) == rank, or None when the dense
     flavour does not apply (no statistics, world not a power of two, negative keys — their
@@ -107,12 +118,16 @@ class PartitionedHashJoin:
     def probe(self, keys, tid_base, capacity=None):
         tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
         (rkeys, rtids), _ = shuffle_by_key(self.ops, keys, [keys, tids], self.group)
+        # how many rows arrive depends on the data: a foreign-key probe (every key matches at most one build row)
+        # needs room for all of them, never less
+        if capacity is not None:
+            capacity = max(int(capacity), rkeys.numel())
         out_p, out_b, count = self.table.probe(rkeys, capacity=capacity)
         return rtids, self.build_tids, out_p, out_b, count
 
     def materialize(self, probe_tids, build_tids, out_p, out_b, count):
         """Global (probe_tid, build_tid) pairs of this partition (K5 gathers)."""
-        k = int(count.item())
+        k = _checked_count(count, out_p)
         return self.ops.gather(probe_tids, out_p[:k]), self.ops.gather(build_tids, out_b[:k])
 
 
@@ -161,7 +176,7 @@ class BroadcastHashJoin:
         return None, None, out_p, out_b, count
 
     def materialize(self, probe_tids, build_tids, out_p, out_b, count):
-        k = int(count.item())
+        k = _checked_count(count, out_p)
         return out_p[:k], out_b[:k]                         # already global
 
 

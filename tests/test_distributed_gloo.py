@@ -71,3 +71,13 @@ def _check_partitioned_join(oracle, tmp_path, world, prefix, on_owner_rank=True)
     want = np.stack([p, b], 1)
     key = lambda a: a[np.lexsort((a[:, 1], a[:, 0]))]  # noqa: E731
     assert np.array_equal(key(got.astype(np.int64)), key(want.astype(np.int64)))
+
+
+def test_truncated_pair_lists_are_an_error():
+    """qsx_join_probe counts past its capacity: materialize() must not hand back the shorter list."""
+    import pytest
+    import torch
+    from quickstep_amd import distributed as qd
+    assert qd._checked_count(torch.tensor([4]), torch.empty(4)) == 4
+    with pytest.raises(RuntimeError):
+        qd._checked_count(torch.tensor([5]), torch.empty(4))
