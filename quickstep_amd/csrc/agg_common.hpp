@@ -212,6 +212,118 @@ __device__ __forceinline__ void global_add(const HashTableView &g, int col, unsi
   global_accumulate(p, inc, kind);
 }
 
+// ---- group directory (mid-size group counts) ---------------------------------------
+// Thousands of groups do not fit a replicated workgroup-private LDS *hash table* (keys + states), but their accumulators
+// alone do when they are addressed by a dense group number: 10 k groups x (4-byte count + one 8-byte sum) = 120 KiB.
+// The key -> group number mapping lives in this directory in HBM — 16-byte entries {key code, gid}, a few hundred KiB,
+// L2-resident — and is read-mostly: after the first rows of an input every lookup is one 16-byte read.  gids are handed
+// out in order of first insertion and stay valid for the life of the state, so every workgroup of every update call
+// agrees on them.  The directory only accelerates: the global table (HashTableView) stays the state's content, rows
+// whose group gets no gid below lds_gids take the per-row global path.
+struct DirView {
+  unsigned long long *entries;        // [dcap][2]: {code (kEmptyCode = free), gid (kEmptyCode = not published yet)}
+  unsigned long long dmask;           // dcap - 1
+  int dshift;                         // 64 - log2(dcap)
+  unsigned long long *codes_by_gid;   // [lds_gids]
+  unsigned int *ngids;
+  unsigned int lds_gids;              // gids with an LDS accumulator
+  // Key bounds of the build pass's rows (zeroed before every build pass): bounds[2k] = max of the k-th key's
+  // order-preserving unsigned image, bounds[2k + 1] = max of that image's complement (i.e. ~min) — both grow from 0, so
+  // one memset resets them and one atomicMax per wave updates them.  When the box they span has at most lds_gids cells the
+  // accumulate pass numbers the groups by their position in the box (no directory read at all); rows outside the box —
+  // the build pass only samples the input — take the per-row global path like rows without a gid.
+  unsigned long long *bounds;         // [2 * QSX_MAX_KEYS]
+  // The build pass reads every sample_stride-th tile, starting with tile sample_phase: a group that a sample of several
+  // million rows misses has few rows, and those are aggregated through the global table.
+  int sample_stride;
+  int sample_phase;
+};
+constexpr unsigned long long kSignBias = 1ull << 63;
+
+// Position of a row's group inside the key box of the build pass (dense numbering).
+struct KeyBox {
+  bool usable;                         // the box has at most lds_gids cells
+  int cells;
+  long long lo[QSX_MAX_KEYS];
+  unsigned long long range[QSX_MAX_KEYS];
+  unsigned int mult[QSX_MAX_KEYS];
+};
+__device__ __forceinline__ KeyBox key_box_of(const DirView &d, int num_keys) {
+  KeyBox b;
+  b.usable = d.bounds != nullptr && num_keys > 0;
+  unsigned long long cells = 1;
+#pragma unroll
+  for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+    b.lo[k] = 0;
+    b.range[k] = 1;
+    b.mult[k] = 0;
+    if (k < num_keys && b.usable) {
+      const unsigned long long hi_image = d.bounds[2 * k];
+      const unsigned long long lo_image = ~d.bounds[2 * k + 1];
+      // an empty sample leaves both words 0: lo_image = ~0 > hi_image
+      if (lo_image > hi_image || hi_image - lo_image >= d.lds_gids) {
+        b.usable = false;
+      } else {
+        b.lo[k] = static_cast<long long>(lo_image ^ kSignBias);
+        b.range[k] = hi_image - lo_image + 1;
+        b.mult[k] = static_cast<unsigned int>(cells);
+        cells *= b.range[k];
+        if (cells > d.lds_gids) b.usable = false;
+      }
+    }
+  }
+  b.cells = b.usable ? static_cast<int>(cells) : 0;
+  return b;
+}
+constexpr int kDirMaxProbes = 64;
+
+// Within one update call the directory is written by one kernel and read by the next: on a multi-XCD part a
+// device-coherent load (agent scope, sc1) bypasses the XCD's L2 — measured 59 ms per 200 M lookups against 1 ms for
+// plain loads — and a plain load may return a stale line while another XCD inserts.  So an update call is two launches:
+// the build pass collects the distinct key codes of its rows in a workgroup-private LDS set (agg_hash_update_body,
+// kDirBuild) and inserts them here with device-scope atomics — a few thousand per workgroup, not one per row — and after
+// the kernel boundary (which makes the directory visible to every L2) the accumulate pass only reads it.
+// Update calls of other streams may overlap either pass.  That costs speed, not rows: an entry is never changed once its
+// gid is published, a reader that sees it half-written or not at all (stale line) sends the row down the global path,
+// and the flush fetches a gid's code with a device-scope load behind the release store that published the gid.
+
+// Insert `code` if new (device-scope atomics; called per distinct code of a workgroup, not per row).
+__device__ __forceinline__ void dir_insert(const DirView &d, unsigned long long code) {
+  unsigned long long s = (mix64(code) * 0x9E3779B97F4A7C15ull) >> d.dshift;
+  for (int probes = 0; probes < kDirMaxProbes; ++probes) {
+    unsigned long long *entry = d.entries + 2 * s;
+    unsigned long long k = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmptyCode) {
+      k = atomicCAS(entry, kEmptyCode, code);
+      if (k == kEmptyCode) {
+        // the gid is read by the NEXT kernel only: no publication protocol inside this one
+        const unsigned int g = atomicAdd(d.ngids, 1u);
+        if (g < d.lds_gids) __hip_atomic_store(&d.codes_by_gid[g], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // release: whoever sees the gid (an accumulate pass of ANOTHER stream's call may run next to this build pass) finds
+        // the code behind it with a device-scope load
+        __hip_atomic_store(entry + 1, static_cast<unsigned long long>(g), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
+    if (k == code) return;
+    s = (s + 1) & d.dmask;
+  }
+  // no room near the code's home: its rows take the global path in the accumulate pass
+}
+
+// gid of `code` (plain cached loads: the directory is read-only in this launch), or -1: not in the directory
+// (full around its home) or without an LDS accumulator.
+__device__ __forceinline__ int dir_lookup(const DirView &d, unsigned long long code) {
+  unsigned long long s = (mix64(code) * 0x9E3779B97F4A7C15ull) >> d.dshift;
+  for (int probes = 0; probes < kDirMaxProbes; ++probes) {
+    const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(d.entries + 2 * s);
+    if (e.x == code) return e.y < d.lds_gids ? static_cast<int>(e.y) : -1;
+    if (e.x == kEmptyCode) return -1;
+    s = (s + 1) & d.dmask;
+  }
+  return -1;
+}
+
 // ---- LDS table ------------------------------------------------------------------
 // Probing is bounded (a group lives within kLdsMaxProbes slots of its home or not in LDS at
 // all), so that a full table costs a miss 8 LDS reads, not S: rows of groups that do not fit

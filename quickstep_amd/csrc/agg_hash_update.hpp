@@ -63,8 +63,9 @@ __device__ __forceinline__ void cfg_for(int count, F &&f) {
 
 // Copy `count` elements of `width` bytes (1/2/4/8) with ordinary loads; used
 // for stripes that are not 16-byte aligned and for sub-16-byte tails.
+template <int BLOCK = kABlock>
 __device__ __forceinline__ void copy_elements_to_lds(const char *src, char *dst, int count, int width) {
-  for (int i = threadIdx.x; i < count; i += kABlock) {
+  for (int i = threadIdx.x; i < count; i += BLOCK) {
     switch (width) {
       case 1: reinterpret_cast<uint8_t *>(dst)[i] = reinterpret_cast<const uint8_t *>(src)[i]; break;
       case 2: reinterpret_cast<uint16_t *>(dst)[i] = reinterpret_cast<const uint16_t *>(src)[i]; break;
@@ -75,7 +76,7 @@ __device__ __forceinline__ void copy_elements_to_lds(const char *src, char *dst,
 }
 
 // Issue the HBM -> LDS copy of one tile (rows [row0, row0 + rows)).
-template <bool kStatic>
+template <bool kStatic, int BLOCK = kABlock>
 __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const *cols, const uint64_t *filter, char *tile,
                                            int64_t row0, int rows, const unsigned long long *const *nulls = nullptr) {
   const int lane = lane_id();
@@ -92,17 +93,17 @@ __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
       const int full = bytes & ~15;
       const int chunks = (full + 1023) >> 10;
-      for (int k = wave; k < chunks; k += kABlock / kWave) {
+      for (int k = wave; k < chunks; k += BLOCK / kWave) {
         const int o = (k << 10) + (lane << 4);
         if (o < full) dma16(src + o, dst + (k << 10));
       }
-      if (full != bytes) copy_elements_to_lds(src + full, dst + full, (bytes - full) / w, w);
+      if (full != bytes) copy_elements_to_lds<BLOCK>(src + full, dst + full, (bytes - full) / w, w);
     } else {
-      copy_elements_to_lds(src, dst, rows, w);
+      copy_elements_to_lds<BLOCK>(src, dst, rows, w);
     }
   });
   if (c.filter_lds_off >= 0) {
-    copy_elements_to_lds(reinterpret_cast<const char *>(filter + (row0 >> 6)), tile + c.filter_lds_off,
+    copy_elements_to_lds<BLOCK>(reinterpret_cast<const char *>(filter + (row0 >> 6)), tile + c.filter_lds_off,
                          (rows + 63) >> 6, 8);
   }
   // null words of the nullable columns the plan reads (zeros for a block without NULLs in that attribute)
@@ -111,9 +112,9 @@ __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const
     char *dst = tile + c.null_lds_off[s];
     const int words = (rows + 63) >> 6;
     if (src != nullptr) {
-      copy_elements_to_lds(reinterpret_cast<const char *>(src + (row0 >> 6)), dst, words, 8);
+      copy_elements_to_lds<BLOCK>(reinterpret_cast<const char *>(src + (row0 >> 6)), dst, words, 8);
     } else {
-      for (int i = threadIdx.x; i < words; i += kABlock) reinterpret_cast<uint64_t *>(dst)[i] = 0;
+      for (int i = threadIdx.x; i < words; i += BLOCK) reinterpret_cast<uint64_t *>(dst)[i] = 0;
     }
   });
 }
@@ -122,7 +123,7 @@ __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const
 // itself for truncation) in the column's value slots.  Only the thread itself reads those slots afterwards (rows are
 // owned per thread), so no barrier follows; with a static configuration the dictionary reads of all coded columns are
 // in flight together.
-template <bool kStatic, int V>
+template <bool kStatic, int V, int BLOCK = kABlock>
 __device__ __forceinline__ void decode_tile_codes(const DevConfig &c, const void *const *dicts, char *tile, int trow, int rows) {
   cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_columns, [&](int col) __attribute__((always_inline)) {
     if (c.code_width[col] == 0 || c.lds_off[col] < 0) return;
@@ -132,7 +133,7 @@ __device__ __forceinline__ void decode_tile_codes(const DevConfig &c, const void
     uint32_t code[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int r = trow + v * kABlock;
+      const int r = trow + v * BLOCK;
       switch (c.code_width[col]) {
         case 1: code[v] = reinterpret_cast<const uint8_t *>(codes)[r]; break;
         case 2: code[v] = reinterpret_cast<const uint16_t *>(codes)[r]; break;
@@ -143,19 +144,19 @@ __device__ __forceinline__ void decode_tile_codes(const DevConfig &c, const void
     switch (c.column_type[col]) {
       case QSX_INT:
 #pragma unroll
-        for (int v = 0; v < V; ++v) reinterpret_cast<int32_t *>(slots)[trow + v * kABlock] = dict != nullptr ? static_cast<const int32_t *>(dict)[code[v]] : static_cast<int32_t>(code[v]);
+        for (int v = 0; v < V; ++v) reinterpret_cast<int32_t *>(slots)[trow + v * BLOCK] = dict != nullptr ? static_cast<const int32_t *>(dict)[code[v]] : static_cast<int32_t>(code[v]);
         break;
       case QSX_FLOAT:
 #pragma unroll
-        for (int v = 0; v < V; ++v) reinterpret_cast<float *>(slots)[trow + v * kABlock] = dict != nullptr ? static_cast<const float *>(dict)[code[v]] : static_cast<float>(code[v]);
+        for (int v = 0; v < V; ++v) reinterpret_cast<float *>(slots)[trow + v * BLOCK] = dict != nullptr ? static_cast<const float *>(dict)[code[v]] : static_cast<float>(code[v]);
         break;
       case QSX_LONG:
 #pragma unroll
-        for (int v = 0; v < V; ++v) reinterpret_cast<long long *>(slots)[trow + v * kABlock] = dict != nullptr ? static_cast<const long long *>(dict)[code[v]] : static_cast<long long>(code[v]);
+        for (int v = 0; v < V; ++v) reinterpret_cast<long long *>(slots)[trow + v * BLOCK] = dict != nullptr ? static_cast<const long long *>(dict)[code[v]] : static_cast<long long>(code[v]);
         break;
       default:
 #pragma unroll
-        for (int v = 0; v < V; ++v) reinterpret_cast<double *>(slots)[trow + v * kABlock] = dict != nullptr ? static_cast<const double *>(dict)[code[v]] : static_cast<double>(code[v]);
+        for (int v = 0; v < V; ++v) reinterpret_cast<double *>(slots)[trow + v * BLOCK] = dict != nullptr ? static_cast<const double *>(dict)[code[v]] : static_cast<double>(code[v]);
         break;
     }
   });
@@ -216,13 +217,13 @@ __device__ __forceinline__ void temps_set(Temps<V> &s, int i, const double (&in)
 #undef QSX_TS
 }
 
-template <int V>
+template <int V, int BLOCK = kABlock>
 __device__ __forceinline__ void operand_vec(const DevConfig &c, const DevOperand &o, const Temps<V> &s,
                                             const char *tile, int trow, double (&out)[V]) {
   switch (o.kind) {
     case QSX_OPD_COLUMN:
 #pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = tile_double(c, tile, o.index, trow + v * kABlock);
+      for (int v = 0; v < V; ++v) out[v] = tile_double(c, tile, o.index, trow + v * BLOCK);
       break;
     case QSX_OPD_CONST:
 #pragma unroll
@@ -235,7 +236,7 @@ __device__ __forceinline__ void operand_vec(const DevConfig &c, const DevOperand
 }
 
 // Interpreter operand: everything is resolved to (mode, LDS byte offset | immediate).
-template <int V>
+template <int V, int BLOCK = kABlock>
 __device__ __forceinline__ void plan_operand_vec(const PlanOperand &o, const char *tile, const char *temps, int trow,
                                                  double (&out)[V]) {
   switch (o.mode) {
@@ -246,38 +247,38 @@ __device__ __forceinline__ void plan_operand_vec(const PlanOperand &o, const cha
     case kPlanTileI32: {
       const int32_t *p = reinterpret_cast<const int32_t *>(tile + o.off);
 #pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = static_cast<double>(p[trow + v * kABlock]);
+      for (int v = 0; v < V; ++v) out[v] = static_cast<double>(p[trow + v * BLOCK]);
       break;
     }
     case kPlanTileI64: {
       const long long *p = reinterpret_cast<const long long *>(tile + o.off);
 #pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = static_cast<double>(p[trow + v * kABlock]);
+      for (int v = 0; v < V; ++v) out[v] = static_cast<double>(p[trow + v * BLOCK]);
       break;
     }
     case kPlanTileF32: {
       const float *p = reinterpret_cast<const float *>(tile + o.off);
 #pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = static_cast<double>(p[trow + v * kABlock]);
+      for (int v = 0; v < V; ++v) out[v] = static_cast<double>(p[trow + v * BLOCK]);
       break;
     }
     default: {  // f64 column of the tile or f64 temp slot: same load, different base
       const double *p = reinterpret_cast<const double *>((o.mode == kPlanTempF64 ? temps : tile) + o.off);
 #pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = p[trow + v * kABlock];
+      for (int v = 0; v < V; ++v) out[v] = p[trow + v * BLOCK];
       break;
     }
   }
 }
 
-template <bool kStatic, int V>
+template <bool kStatic, int V, int BLOCK = kABlock>
 __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *tile, int trow, bool (&live)[V]) {
   cfg_for<kStatic, QSX_MAX_PRED_TERMS>(c.num_pred, [&](int p) __attribute__((always_inline)) {
     const DevPred term = c.pred[p];
     const char *base = tile + c.lds_off[term.column];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int r = trow + v * kABlock;
+      const int r = trow + v * BLOCK;
       bool ok;
       switch (c.column_type[term.column]) {
         case QSX_INT:
@@ -301,7 +302,7 @@ __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *ti
 }
 
 // Compact key codes of V rows (ThreadPrivateCompactKeyHashTable.cpp:216-232).
-template <bool kStatic, int V>
+template <bool kStatic, int V, int BLOCK = kABlock>
 __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *tile, int trow, unsigned long long (&code)[V]) {
 #pragma unroll
   for (int v = 0; v < V; ++v) code[v] = 0;
@@ -309,7 +310,7 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
     const char *base = tile + c.lds_off[c.key_column[k]];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int r = trow + v * kABlock;
+      const int r = trow + v * BLOCK;
       unsigned long long x;
       switch (c.key_width[k]) {
         case 1: x = reinterpret_cast<const uint8_t *>(base)[r]; break;
@@ -320,6 +321,20 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
       code[v] |= x << c.key_shift[k];
     }
   });
+}
+
+// k-th group-by key of tile row r as a number: INT / LONG sign-extended, everything else (CHAR bytes, FLOAT / DOUBLE bit
+// patterns) as the unsigned field.  Any injective image serves the key box of the group directory (DirView::bounds).
+__device__ __forceinline__ long long key_field(const DevConfig &c, const char *tile, int k, int r) {
+  const char *base = tile + c.lds_off[c.key_column[k]];
+  switch (c.key_width[k]) {
+    case 1: return reinterpret_cast<const uint8_t *>(base)[r];
+    case 2: return reinterpret_cast<const uint16_t *>(base)[r];
+    case 4:
+      return c.column_type[c.key_column[k]] == QSX_INT ? static_cast<long long>(reinterpret_cast<const int32_t *>(base)[r])
+                                                       : static_cast<long long>(reinterpret_cast<const uint32_t *>(base)[r]);
+    default: return reinterpret_cast<const long long *>(base)[r];
+  }
 }
 
 // Runs of equal ADJACENT keys inside a wave (clustered / sorted inputs, e.g. lineitem on
@@ -397,27 +412,44 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
 // ~6 ns per wave instruction per CU, tools/ubench/lds_atomic.hip).
 // kDense: COLLISION_FREE sink — the group of a row is its key value, accumulators are the dense
 // arrays in HBM (DenseView), adjacent equal keys of a wave are combined before the atomics.
-template <bool kStatic, bool kDense, int NS, int V>
+template <bool kStatic, bool kDense, int NS, int V, bool kDir = false, int BLOCK = kABlock, bool kDirBuild = false>
 __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, const void *const *dicts, int64_t n,
                                                      const uint64_t *__restrict__ filter, const HashTableView &g,
                                                      const DenseView &dense, int S, int rep_shift, int nbuf,
                                                      int ranges, const long long *__restrict__ pieces = nullptr,
-                                                     const unsigned long long *const *nulls = nullptr) {
+                                                     const unsigned long long *const *nulls = nullptr,
+                                                     const DirView *dir = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int TR = kABlock * V;
+  constexpr int TR = BLOCK * V;
   char *tiles = reinterpret_cast<char *>(smem_raw);
   char *lds_temps = reinterpret_cast<char *>(smem_raw) + nbuf * c.tile_bytes;
   unsigned long long *l_keys = reinterpret_cast<unsigned long long *>(smem_raw + nbuf * c.tile_bytes + c.temps_bytes);  // [S]
   unsigned long long *l_acc = l_keys + S;                                                           // [NS + 1][S << rep_shift]
   const int plane = (S << rep_shift) + kWave;  // + 64 trash columns
   const int lane_col = lane_id() & ((1 << rep_shift) - 1);
+  // kDir (group directory, agg_common.hpp): S = gids with an accumulator here, no replication, no key table — the
+  // accumulator of gid g is word g of its plane; the row counts are 32-bit words behind the NS planes
+  // (a workgroup sees < 2^32 rows of one group between two flushes: it flushes once, at its end, after < 2^32 rows in all
+  // — the launcher bounds the rows per workgroup).
+  // Dynamic LDS: tile[nbuf][tile_bytes] | temps | l_sum[NS][S + 64] u64 | l_cnt[S + 64] u32
+  unsigned long long *l_sum = l_keys;
+  unsigned int *l_cnt = reinterpret_cast<unsigned int *>(l_keys + static_cast<size_t>(NS) * plane);
+  auto acc_plane_of = [&](int j) { return kDir ? l_sum + static_cast<size_t>(j) * plane : l_acc + static_cast<size_t>(j + 1) * plane; };
 
-  for (int i = threadIdx.x; i < S; i += kABlock) l_keys[i] = kEmptyCode;
-  for (int i = threadIdx.x; i < plane; i += kABlock) l_acc[i] = 0;  // row counts
+  if constexpr (kDirBuild) {
+    // build pass of the group directory: only the set of key codes this workgroup sees, S slots
+    for (int i = threadIdx.x; i < S; i += BLOCK) l_keys[i] = kEmptyCode;
+  } else if constexpr (kDir) {
+    for (int i = threadIdx.x; i < plane; i += BLOCK) l_cnt[i] = 0;
+  } else {
+    for (int i = threadIdx.x; i < S; i += BLOCK) l_keys[i] = kEmptyCode;
+    for (int i = threadIdx.x; i < plane; i += BLOCK) l_acc[i] = 0;  // row counts
+  }
 #pragma unroll
-  for (int j = 0; j < NS; ++j) {
+  for (int j = 0; j < (kDirBuild ? 0 : NS); ++j) {
     const unsigned long long identity = static_cast<unsigned long long>(acc_identity(c.sums[j].kind));
-    for (int i = threadIdx.x; i < plane; i += kABlock) l_acc[(j + 1) * plane + i] = identity;
+    unsigned long long *p = acc_plane_of(j);
+    for (int i = threadIdx.x; i < plane; i += BLOCK) p[i] = identity;
   }
 
   // nbuf == 2: the DMA of tile i+1 overlaps the compute of tile i inside the workgroup;
@@ -430,8 +462,18 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   // `ranges` pieces; family r walks only piece r = rows [pieces[r], pieces[r] + pieces[ranges + r]) — its groups are
   // its own by construction, no hash test, every row is read once.
   const int my_range = ranges > 1 ? static_cast<int>(blockIdx.x % ranges) : 0;
-  const int64_t first_tile = ranges > 1 ? blockIdx.x / ranges : blockIdx.x;
-  const int64_t tile_step = ranges > 1 ? gridDim.x / ranges : gridDim.x;
+  // (build pass of the group directory: every sample_stride-th tile only)
+  const int64_t first_tile = kDirBuild ? static_cast<int64_t>(blockIdx.x) * dir->sample_stride + dir->sample_phase
+                                       : (ranges > 1 ? blockIdx.x / ranges : blockIdx.x);
+  const int64_t tile_step = kDirBuild ? static_cast<int64_t>(gridDim.x) * dir->sample_stride
+                                      : (ranges > 1 ? gridDim.x / ranges : gridDim.x);
+  // kDirBuild: per-thread bounds of the keys seen (order-preserving unsigned images; DirView::bounds)
+  unsigned long long seen_hi[QSX_MAX_KEYS], seen_nlo[QSX_MAX_KEYS];
+#pragma unroll
+  for (int k = 0; k < QSX_MAX_KEYS; ++k) seen_hi[k] = seen_nlo[k] = 0;
+  KeyBox box;
+  box.usable = false;
+  if constexpr (kDir) box = key_box_of(*dir, c.num_keys);
   const bool by_piece = pieces != nullptr;
   const int64_t row_begin = by_piece ? pieces[my_range] : 0;
   const int64_t row_end = by_piece ? row_begin + pieces[ranges + my_range] : n;
@@ -440,12 +482,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   auto tile_rows = [&](int64_t t) { return static_cast<int>(row_end - tile_row0(t) < TR ? row_end - tile_row0(t) : TR); };
   int buf = 0;
   if (nbuf == 2 && first_tile < num_tiles) {
-    stage_tile<kStatic>(c, cols, filter, tiles, tile_row0(first_tile), tile_rows(first_tile), nulls);
+    stage_tile<kStatic, BLOCK>(c, cols, filter, tiles, tile_row0(first_tile), tile_rows(first_tile), nulls);
   }
   for (int64_t tile_id = first_tile; tile_id < num_tiles; tile_id += tile_step) {
     if (nbuf == 1) {
       __syncthreads();  // every wave is done reading the previous tile
-      stage_tile<kStatic>(c, cols, filter, tiles, tile_row0(tile_id), tile_rows(tile_id), nulls);
+      stage_tile<kStatic, BLOCK>(c, cols, filter, tiles, tile_row0(tile_id), tile_rows(tile_id), nulls);
     }
     // The tile has landed (nbuf == 2: it was staged during the previous iteration and
     // every wave is done with the other buffer).
@@ -453,20 +495,20 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     __syncthreads();
     const int64_t next = tile_id + tile_step;
     if (nbuf == 2 && next < num_tiles) {
-      stage_tile<kStatic>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, tile_row0(next), tile_rows(next), nulls);
+      stage_tile<kStatic, BLOCK>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, tile_row0(next), tile_rows(next), nulls);
     }
     char *tile = tiles + buf * c.tile_bytes;
     if (nbuf == 2) buf ^= 1;
     const int rows = tile_rows(tile_id);
 
     const int trow = threadIdx.x;  // this thread's first row of the tile
-    decode_tile_codes<kStatic, V>(c, dicts, tile, trow, rows);
+    decode_tile_codes<kStatic, V, BLOCK>(c, dicts, tile, trow, rows);
 
     // ---- which rows are live -------------------------------------------------
     bool live[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int r = trow + v * kABlock;
+      const int r = trow + v * BLOCK;
       live[v] = r < rows;
       if (c.filter_lds_off >= 0 && live[v]) {
         const uint64_t word = reinterpret_cast<const uint64_t *>(tile + c.filter_lds_off)[r >> 6];
@@ -483,23 +525,41 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         const uint64_t *words = reinterpret_cast<const uint64_t *>(tile + c.null_lds_off[s]);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          const int r = trow + v * kABlock;
+          const int r = trow + v * BLOCK;
           if (msb_bit(words[r >> 6], r & 63)) nullbits[v] |= 1u << s;
         }
       });
 #pragma unroll
       for (int v = 0; v < V; ++v) live[v] = live[v] && (nullbits[v] & c.row_null_mask) == 0;
     }
-    predicate_vec<kStatic, V>(c, tile, trow, live);
+    predicate_vec<kStatic, V, BLOCK>(c, tile, trow, live);
 
     // ---- group of every row ----------------------------------------------------
     unsigned long long code[V];
-    key_codes_vec<kStatic, V>(c, tile, trow, code);
+    key_codes_vec<kStatic, V, BLOCK>(c, tile, trow, code);
     if (ranges > 1 && !by_piece) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         live[v] = live[v] && static_cast<int>((mix64(code[v]) >> 20) % static_cast<unsigned>(ranges)) == my_range;
       }
+    }
+    if constexpr (kDirBuild) {
+      // distinct codes of the live rows -> LDS set; what does not fit there goes to the directory right away
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        if (live[v] && code[v] != kEmptyCode) {
+          if (lds_find_or_insert(l_keys, S, code[v]) < 0) dir_insert(*dir, code[v]);
+#pragma unroll
+          for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+            if (k < c.num_keys) {
+              const unsigned long long image = static_cast<unsigned long long>(key_field(c, tile, k, trow + v * BLOCK)) ^ kSignBias;
+              seen_hi[k] = image > seen_hi[k] ? image : seen_hi[k];
+              seen_nlo[k] = ~image > seen_nlo[k] ? ~image : seen_nlo[k];
+            }
+          }
+        }
+      }
+      continue;
     }
     int slot[V];
     long long global_slot[V];
@@ -509,7 +569,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         global_slot[v] = -1;
-        const long long loc = static_cast<long long>(tile_int(c, tile, c.key_column[0], trow + v * kABlock));
+        const long long loc = static_cast<long long>(tile_int(c, tile, c.key_column[0], trow + v * BLOCK));
         if (live[v] && (loc < 0 || loc >= dense.num_entries)) {
           atomicExch(dense.error, 1);  // precondition min >= 0, max < num_entries violated
           live[v] = false;
@@ -520,6 +580,44 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         run_tail[v] = live[v] && (lane_id() == kWave - 1 || next_key != run_key);
         global_slot[v] = live[v] ? loc : -1;
         slot[v] = wave_run_start(run_key);
+      }
+    } else if constexpr (kDir) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        run_tail[v] = false;
+        slot[v] = S + lane_id();   // trash
+        global_slot[v] = -1;
+        int gid = -1;
+        if (live[v] && code[v] != kEmptyCode) {
+          if (box.usable) {
+            // group number = position in the key box of the build pass; a key outside the box (the build pass samples) has none
+            unsigned int cell = 0;
+            bool inside = true;
+#pragma unroll
+            for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+              if (k < c.num_keys) {
+                const unsigned long long d = static_cast<unsigned long long>(key_field(c, tile, k, trow + v * BLOCK) - box.lo[k]);
+                inside = inside && d < box.range[k];
+                cell += static_cast<unsigned int>(d) * box.mult[k];
+              }
+            }
+            gid = inside ? static_cast<int>(cell) : -1;
+          } else {
+            gid = dir_lookup(*dir, code[v]);
+          }
+        }
+        if (gid >= 0) {
+          slot[v] = gid;
+          atomicAdd(&l_cnt[gid], 1u);
+        } else if (live[v]) {
+          // no gid with an accumulator here (more groups than the directory was sized for, or the sentinel code)
+          const unsigned long long gs = global_find_or_insert(g, code[v]);
+          if (gs != ~0ull) {
+            global_slot[v] = static_cast<long long>(gs);
+            global_add(g, 0, gs, 1ull, kAccSumI64);
+          }
+        }
+        any_global = any_global || global_slot[v] >= 0;
       }
     } else {
 #pragma unroll
@@ -553,8 +651,8 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       for (int k = 0; k < c.num_instrs; ++k) {
         const PlanInstr in = c.plan_instrs[k];
         double a[V], b[V], res[V];
-        plan_operand_vec<V>(in.a, tile, lds_temps, trow, a);
-        plan_operand_vec<V>(in.b, tile, lds_temps, trow, b);
+        plan_operand_vec<V, BLOCK>(in.a, tile, lds_temps, trow, a);
+        plan_operand_vec<V, BLOCK>(in.b, tile, lds_temps, trow, b);
         switch (in.op) {
           case QSX_EX_ADD:
 #pragma unroll
@@ -576,15 +674,15 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         if (in.dst_off >= 0) {
           double *dst = reinterpret_cast<double *>(lds_temps + in.dst_off);
 #pragma unroll
-          for (int v = 0; v < V; ++v) dst[trow + v * kABlock] = res[v];
+          for (int v = 0; v < V; ++v) dst[trow + v * BLOCK] = res[v];
         }
       }
     }
     cfg_for<kStatic, QSX_MAX_INSTRS>(kStatic ? c.num_instrs : 0, [&](int k) __attribute__((always_inline)) {
       const DevInstr in = c.instrs[k];
       double a[V], b[V], res[V];
-      operand_vec<V>(c, in.a, temps, tile, trow, a);
-      operand_vec<V>(c, in.b, temps, tile, trow, b);
+      operand_vec<V, BLOCK>(c, in.a, temps, tile, trow, a);
+      operand_vec<V, BLOCK>(c, in.b, temps, tile, trow, b);
       switch (in.op) {
         case QSX_EX_ADD:
 #pragma unroll
@@ -619,14 +717,14 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         if constexpr (kStatic) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            inc[v] = static_cast<unsigned long long>(tile_int(c, tile, s.arg.index, trow + v * kABlock));
+            inc[v] = static_cast<unsigned long long>(tile_int(c, tile, s.arg.index, trow + v * BLOCK));
           }
         } else {
           const PlanSum ps = c.plan_sums[j];
           const char *p = tile + ps.arg.off;
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            const int r = trow + v * kABlock;
+            const int r = trow + v * BLOCK;
             inc[v] = static_cast<unsigned long long>(ps.width == 4 ? static_cast<long long>(reinterpret_cast<const int32_t *>(p)[r])
                                                                     : reinterpret_cast<const long long *>(p)[r]);
           }
@@ -634,9 +732,9 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       } else {
         double x[V];
         if constexpr (kStatic) {
-          operand_vec<V>(c, s.arg, temps, tile, trow, x);
+          operand_vec<V, BLOCK>(c, s.arg, temps, tile, trow, x);
         } else {
-          plan_operand_vec<V>(c.plan_sums[j].arg, tile, lds_temps, trow, x);
+          plan_operand_vec<V, BLOCK>(c.plan_sums[j].arg, tile, lds_temps, trow, x);
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -665,7 +763,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
           if (run_tail[v]) global_accumulate(&col[global_slot[v]], run, s.kind);
         }
       } else {
-        unsigned long long *acc_plane = l_acc + (j + 1) * plane;
+        unsigned long long *acc_plane = acc_plane_of(j);
 #pragma unroll
         for (int v = 0; v < V; ++v) lds_add(&acc_plane[slot[v]], inc[v], s.kind);  // unconditional (trash slot)
         if (wave_has_global) {
@@ -679,11 +777,62 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   }
   if constexpr (kDense) return;
   __syncthreads();
+  if constexpr (kDirBuild) {
+    for (int i = threadIdx.x; i < S; i += BLOCK) {
+      const unsigned long long code = l_keys[i];
+      if (code != kEmptyCode) dir_insert(*dir, code);
+    }
+#pragma unroll
+    for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+      if (k < c.num_keys) {
+        unsigned long long hi = seen_hi[k], nlo = seen_nlo[k];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+          const unsigned long long h2 = __shfl_xor(hi, off, kWave), n2 = __shfl_xor(nlo, off, kWave);
+          hi = h2 > hi ? h2 : hi;
+          nlo = n2 > nlo ? n2 : nlo;
+        }
+        if (lane_id() == 0 && (hi | nlo) != 0) {
+          atomicMax(&dir->bounds[2 * k], hi);
+          atomicMax(&dir->bounds[2 * k + 1], nlo);
+        }
+      }
+    }
+    return;
+  }
+  if constexpr (kDir) {
+    // one global atomic per group this workgroup saw, per accumulator
+    const int gids = box.usable ? box.cells : static_cast<int>(dir->lds_gids);
+    for (int gid = threadIdx.x; gid < gids; gid += BLOCK) {
+      const unsigned long long cnt = l_cnt[gid];
+      if (cnt == 0) continue;
+      unsigned long long code;
+      if (box.usable) {
+        code = 0;
+#pragma unroll
+        for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+          if (k < c.num_keys) {
+            const unsigned long long field = static_cast<unsigned long long>(
+                box.lo[k] + static_cast<long long>((static_cast<unsigned int>(gid) / box.mult[k]) % box.range[k]));
+            const unsigned long long mask = c.key_width[k] >= 8 ? ~0ull : (1ull << (8 * c.key_width[k])) - 1;
+            code |= (field & mask) << c.key_shift[k];
+          }
+        }
+      } else {
+        code = __hip_atomic_load(&dir->codes_by_gid[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned long long gs = global_find_or_insert(g, code);
+      if (gs == ~0ull) continue;
+      global_add(g, 0, gs, cnt, kAccSumI64);
+      for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, acc_plane_of(j)[gid], c.sums[j].kind);
+    }
+    return;
+  }
 
   // ---- LDS -> global table: fold the REP partials, one global atomic per group per
   // accumulator per workgroup --------------------------------------------------------
   const int rep = 1 << rep_shift;
-  for (int s = threadIdx.x; s < S; s += kABlock) {
+  for (int s = threadIdx.x; s < S; s += BLOCK) {
     const unsigned long long code = l_keys[s];
     if (code == kEmptyCode) continue;
     unsigned long long cnt = 0;
@@ -724,6 +873,30 @@ __global__ __launch_bounds__(kABlock) void agg_dense_update_kernel(DevConfig c, 
 struct ColumnPointers {
   const void *p[QSX_MAX_COLUMNS];
 };
+
+// Group-directory variant (agg_common.hpp DirView): ONE workgroup of 1024 threads per CU owns the CU's LDS — `gids`
+// accumulators per aggregate, unreplicated — and 16 waves hide the directory's L2 round trip.  One row per thread and tile.
+constexpr int kDirBlock = 1024;
+template <int NS>
+__global__ __launch_bounds__(kDirBlock) void agg_dir_update_kernel(DevConfig c, int64_t n, const uint64_t *__restrict__ filter,
+                                                                  HashTableView g, DirView d, int gids, int nbuf) {
+  agg_hash_update_body<false, false, NS, 1, true, kDirBlock>(c, c.cols, c.dicts, n, filter, g, DenseView{}, gids, 0, nbuf, 1, nullptr,
+                                                             c.nulls, &d);
+}
+// Build pass: key (and predicate) columns only, `set_slots` LDS slots for the workgroup's distinct codes.
+template <int kUnused>   // (a template only so that the header can be included by several translation units)
+__global__ __launch_bounds__(kDirBlock) void agg_dir_build_kernel(DevConfig c, int64_t n, const uint64_t *__restrict__ filter, DirView d,
+                                                                 int set_slots, int nbuf) {
+  agg_hash_update_body<false, false, 0, 1, false, kDirBlock, true>(c, c.cols, c.dicts, n, filter, HashTableView{}, DenseView{}, set_slots, 0,
+                                                                   nbuf, 1, nullptr, c.nulls, &d);
+}
+template <typename Shape>
+__global__ __launch_bounds__(kDirBlock) void agg_dir_shape_kernel(ColumnPointers cols, int64_t n, HashTableView g, DirView d, int gids,
+                                                                 int nbuf) {
+  static constexpr Translated T = Shape::translated(kDirBlock);
+  agg_hash_update_body<true, false, T.num_sums, 1, true, kDirBlock>(T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, gids, 0, nbuf, 1,
+                                                                    nullptr, nullptr, &d);
+}
 
 
 // AOT plan shape: the translated configuration is a function-local static constexpr

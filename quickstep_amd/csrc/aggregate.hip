@@ -427,6 +427,8 @@ using namespace qsx;
 // (a 0.5 M-row block whose groups the estimate missed entirely still fits).
 constexpr unsigned int kLogRecords = 1u << 20;
 
+constexpr int kDirBoundSlots = 32;
+constexpr size_t kDirControlBytes = 16 + sizeof(unsigned long long) * 2 * QSX_MAX_KEYS * kDirBoundSlots;
 struct qsx_agg_state {
   qsx_agg_config_t config;
   bool has_coded_columns = false;   // some column arrives as codes of a compressed attribute
@@ -462,6 +464,44 @@ struct qsx_agg_state {
   unsigned long long *published_dev = nullptr;
   std::atomic<unsigned long long> publish_seq{0};
   int64_t geometry_est = 1;                   // the group count the LDS geometry below was derived for
+  // Group directory (agg_common.hpp DirView): mid-size group counts whose accumulators fit one CU's LDS when addressed by
+  // a dense group number.  dir_gids == 0: not in use.
+  int dir_gids = 0;
+  int dir_nbuf = 2;
+  unsigned long long *dir_entries = nullptr;
+  unsigned long long dir_cap = 0;
+  unsigned long long *dir_codes = nullptr;
+  int dir_codes_len = 0;
+  unsigned int *dir_ngids = nullptr;          // [4] counter words, then the key bounds (kDirControlBytes in all)
+  std::atomic<unsigned> dir_calls{0};         // rotates the build pass's sample
+  // The key bounds belong to ONE update call (build pass writes, accumulate pass reads): calls on the same stream are
+  // ordered, calls on different streams (worker threads) are not, so every stream gets its own bounds words.
+  std::mutex dir_mutex;
+  std::vector<hipStream_t> dir_streams;
+  int dir_bounds_slot(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(dir_mutex);
+    for (size_t i = 0; i < dir_streams.size(); ++i) {
+      if (dir_streams[i] == s) return static_cast<int>(i);
+    }
+    if (dir_streams.size() >= static_cast<size_t>(kDirBoundSlots)) return -1;   // that stream's calls take the other paths
+    dir_streams.push_back(s);
+    return static_cast<int>(dir_streams.size()) - 1;
+  }
+  DirView dir_view(int bounds_slot = 0) const {
+    DirView d;
+    d.entries = dir_entries;
+    d.dmask = dir_cap - 1;
+    int log2 = 0;
+    while ((1ull << log2) < dir_cap) ++log2;
+    d.dshift = 64 - log2;
+    d.codes_by_gid = dir_codes;
+    d.ngids = dir_ngids;
+    d.lds_gids = static_cast<unsigned int>(dir_gids);
+    d.bounds = reinterpret_cast<unsigned long long *>(dir_ngids + 4) + 2 * QSX_MAX_KEYS * bounds_slot;   // same allocation, 16 bytes in
+    d.sample_stride = 1;
+    d.sample_phase = 0;
+    return d;
+  }
   // scratch for ordered dense finalize
   int32_t *tile_counts = nullptr;
   int64_t *tile_offsets = nullptr;
@@ -731,11 +771,98 @@ static int agg_rows_per_thread() { return agg_tuning().rows_per_thread; }
 // ---- AOT plan shapes (agg_shapes.hpp) -------------------------------------------------
 typedef int (*ShapeLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
                              int ranges, const long long *pieces, hipStream_t stream);
+typedef int (*ShapeDirLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, const DirView &d, int gids,
+                                int nbuf, hipStream_t stream);
 struct ShapeEntry {
   const char *name;
   qsx_agg_config_t config;
   ShapeLauncher launch;
+  ShapeDirLauncher launch_dir;
 };
+
+// Group-directory launch: one 1024-thread workgroup per CU, tiles strided over them.
+static int dir_grid(int64_t n) {
+  const int64_t num_tiles = (n + kDirBlock - 1) / kDirBlock;
+  return static_cast<int>(num_tiles < kCUs ? num_tiles : kCUs);
+}
+static size_t dir_lds_bytes(int tile_bytes, int temps_bytes, int num_sums, int gids, int nbuf) {
+  return static_cast<size_t>(nbuf) * tile_bytes + temps_bytes + static_cast<size_t>(gids + kWave) * (8 * static_cast<size_t>(num_sums) + 4) + 16;
+}
+
+template <typename Shape>
+static int launch_shape_dir(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, const DirView &d, int gids,
+                            int nbuf, hipStream_t stream) {
+  constexpr Translated T = Shape::translated(kDirBlock);
+  static_assert(T.status == QSX_OK, "plan shape does not translate");
+  constexpr size_t kMaxLds = 160 * 1024;
+  const size_t lds = dir_lds_bytes(T.dev.tile_bytes, 0, T.num_sums, gids, nbuf);
+  if (lds > kMaxLds) return QSX_ERR_CAPACITY;
+  static PerDeviceOnce attribute_set;
+  {
+    const int rc = once_per_device(attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_shape_kernel<Shape>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
+  }
+  ColumnPointers cp;
+  for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < num_columns ? cols[i] : nullptr;
+  hipLaunchKernelGGL((agg_dir_shape_kernel<Shape>), dim3(dir_grid(n)), dim3(kDirBlock), lds, stream, cp, n, g, d, gids, nbuf);
+  return QSX_OK;
+}
+
+// Build pass of the group directory: stages the key and predicate columns only.
+static int launch_dir_build(DevConfig dc, unsigned key_columns, int64_t n, const uint64_t *filter, DirView d, int gids,
+                            unsigned call, hipStream_t stream) {
+  // the sample: every stride-th tile, at least ~8 M rows of a large input (all of a small one), another phase every call
+  const char *e = getenv("QSX_AGG_DIR_SAMPLE_ROWS");   // tests shrink the sample
+  const int64_t sample_rows = e != nullptr && atoll(e) > 0 ? atoll(e) : (8 << 20);
+  const int64_t stride = std::max<int64_t>(1, std::min<int64_t>(64, n / sample_rows));
+  d.sample_stride = static_cast<int>(stride);
+  d.sample_phase = static_cast<int>(call % stride);
+  QSX_HIP_TRY(hipMemsetAsync(d.bounds, 0, sizeof(unsigned long long) * 2 * QSX_MAX_KEYS, stream));
+  plan_tile(dc, key_columns, kDirBlock, filter != nullptr);
+  dc.temps_bytes = 0;
+  constexpr size_t kMaxLds = 160 * 1024;
+  // LDS set of the workgroup's distinct codes: twice the gids, what the CU has room for at most
+  int slots = static_cast<int>(next_pow2(static_cast<uint64_t>(gids) * 2));
+  int nbuf = 2;
+  while (slots > 1024 && static_cast<size_t>(nbuf) * dc.tile_bytes + 8 * static_cast<size_t>(slots) + 16 > kMaxLds) slots >>= 1;
+  const size_t lds = static_cast<size_t>(nbuf) * dc.tile_bytes + 8 * static_cast<size_t>(slots) + 16;
+  if (lds > kMaxLds) return QSX_ERR_CAPACITY;
+  static PerDeviceOnce attribute_set;
+  {
+    const int rc = once_per_device(attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_build_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
+  }
+  const int64_t sampled_tiles = ((n + kDirBlock - 1) / kDirBlock - d.sample_phase + stride - 1) / stride;
+  const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(sampled_tiles, kCUs)));
+  hipLaunchKernelGGL(agg_dir_build_kernel<0>, dim3(grid), dim3(kDirBlock), lds, stream, dc, n, filter, d, slots, nbuf);
+  return QSX_OK;
+}
+
+template <int NS>
+static int launch_dir(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d,
+                      int gids, int nbuf, hipStream_t stream) {
+  plan_tile(dc, used_columns, kDirBlock, filter != nullptr);
+  plan_interpreter(dc, kDirBlock);
+  constexpr size_t kMaxLds = 160 * 1024;
+  const size_t lds = dir_lds_bytes(dc.tile_bytes, dc.temps_bytes, NS, gids, nbuf);
+  if (lds > kMaxLds) return QSX_ERR_CAPACITY;
+  static PerDeviceOnce attribute_set;
+  {
+    const int rc = once_per_device(attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_update_kernel<NS>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
+  }
+  hipLaunchKernelGGL((agg_dir_update_kernel<NS>), dim3(dir_grid(n)), dim3(kDirBlock), lds, stream, dc, n, filter, g, d, gids, nbuf);
+  return QSX_OK;
+}
 
 template <typename Shape, int V>
 static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
@@ -803,8 +930,9 @@ static int launch_shape(const void *const *cols, int num_columns, int64_t n, con
 
 static const ShapeEntry *find_shape(const qsx_agg_config_t &c) {
   static const ShapeEntry table[] = {
-      {"tpch_q1", ShapeTpchQ1::config(), &launch_shape<ShapeTpchQ1>},
-      {"two_int_keys_sum_count_avg", ShapeTwoIntKeysSumCountAvg::config(), &launch_shape<ShapeTwoIntKeysSumCountAvg>},
+      {"tpch_q1", ShapeTpchQ1::config(), &launch_shape<ShapeTpchQ1>, &launch_shape_dir<ShapeTpchQ1>},
+      {"two_int_keys_sum_count_avg", ShapeTwoIntKeysSumCountAvg::config(), &launch_shape<ShapeTwoIntKeysSumCountAvg>,
+       &launch_shape_dir<ShapeTwoIntKeysSumCountAvg>},
   };
   if (getenv("QSX_AGG_NO_SPECIALIZE") != nullptr && atoi(getenv("QSX_AGG_NO_SPECIALIZE")) != 0) return nullptr;
   for (const ShapeEntry &e : table) {
@@ -977,6 +1105,11 @@ static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const ui
     default: FN<8>(__VA_ARGS__); break;   \
   }
 
+static bool dir_enabled() {
+  const char *e = getenv("QSX_AGG_DIRECTORY");   // read per call: tests and tools compare the paths
+  return e == nullptr || atoi(e) != 0;
+}
+
 // LDS-table geometry of the update kernel for `est` groups (launch_hash_v / launch_shape_v / the run-time shapes).
 static void derive_geometry(qsx_agg_state *st, int64_t est) {
   st->geometry_est = est;
@@ -1013,6 +1146,52 @@ static void derive_geometry(qsx_agg_state *st, int64_t est) {
       st->part_slots = static_cast<int>(ps);
     }
   }
+  // More groups than the replicated LDS tables hold, but few enough that one CU's LDS holds an accumulator per group
+  // (4 + 8 NS bytes each) next to the tile buffers: the group directory replaces the partition pass / the hash ranges.
+  st->dir_gids = 0;
+  if ((st->lds_ranges > 1 || st->part_count > 1) && dir_enabled()) {
+    DevConfig dev = st->dev;
+    const size_t tile = static_cast<size_t>(plan_tile(dev, st->used_columns, kDirBlock, true));
+    plan_interpreter(dev, kDirBlock);
+    // (a little head-room: the estimate is an estimate; groups beyond the accumulators take the global path, and the
+    // table's growth re-derives the geometry when the estimate was far off)
+    const size_t want = (static_cast<size_t>(est) + static_cast<size_t>(est) / 16 + 63) / 64 * 64;
+    const size_t per_gid = 8 * static_cast<size_t>(st->num_sums) + 4;
+    for (int nbuf = 2; nbuf >= 1 && st->dir_gids == 0; --nbuf) {
+      const size_t fixed = nbuf * tile + dev.temps_bytes + kWave * per_gid + 16;
+      if (fixed + want * per_gid <= 160 * 1024) {
+        // all the accumulators the CU has room for (capped: the flush walks them): a key box (DirView::bounds) may span
+        // more cells than there are groups
+        const size_t fit = (160 * 1024 - fixed) / per_gid / 64 * 64;
+        st->dir_gids = static_cast<int>(std::min<size_t>(fit, std::max<size_t>(want, 16384)));
+        st->dir_nbuf = nbuf;
+      }
+    }
+  }
+}
+
+// (Re)creates the directory for st->dir_gids.  Only between launches: caller holds table_mutex exclusively (or is the
+// constructor) and the device is idle.  gids start over — they only have to be stable within the directory's life.
+static hipError_t ensure_directory(qsx_agg_state *st) {
+  if (st->dir_gids == 0) return hipSuccess;
+  const unsigned long long want_cap = next_pow2(static_cast<uint64_t>(st->dir_gids) * 4);
+  hipError_t err = hipSuccess;
+  if (st->dir_ngids == nullptr) err = hipMalloc(reinterpret_cast<void **>(&st->dir_ngids), kDirControlBytes);
+  if (err == hipSuccess && st->dir_cap != want_cap) {
+    (void)hipFree(st->dir_entries);
+    st->dir_entries = nullptr;
+    st->dir_cap = want_cap;
+    err = hipMalloc(reinterpret_cast<void **>(&st->dir_entries), want_cap * 16);
+  }
+  if (err == hipSuccess && st->dir_codes_len < st->dir_gids) {
+    (void)hipFree(st->dir_codes);
+    st->dir_codes = nullptr;
+    st->dir_codes_len = st->dir_gids;
+    err = hipMalloc(reinterpret_cast<void **>(&st->dir_codes), sizeof(unsigned long long) * st->dir_gids);
+  }
+  if (err == hipSuccess) err = hipMemset(st->dir_entries, 0xFF, st->dir_cap * 16);
+  if (err == hipSuccess) err = hipMemset(st->dir_ngids, 0, kDirControlBytes);
+  return err;
 }
 
 static hipError_t init_hash_image(qsx_agg_state *st, unsigned long long *image, unsigned long long cap, hipStream_t s) {
@@ -1095,6 +1274,7 @@ static int grow_and_drain(qsx_agg_state *st) {
   // groups sends nearly every row of a 10 k-group input down the per-row global path).
   if (static_cast<int64_t>(groups) > 2 * st->geometry_est) {
     derive_geometry(st, static_cast<int64_t>(groups) * 2);
+    QSX_HIP_TRY(ensure_directory(st));
     std::lock_guard<std::mutex> lock(st->jit_mutex);   // run-time shapes carry the geometry as constants: ask again
     for (int v = 0; v < 4; ++v) {
       st->jit_request[v] = nullptr;
@@ -1172,6 +1352,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     err = hipMalloc(reinterpret_cast<void **>(&st->tile_counts), sizeof(int32_t) * st->max_tiles);
     if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->tile_offsets), sizeof(int64_t) * (st->max_tiles + 1));
   }
+  if (err == hipSuccess && !st->dense) err = ensure_directory(st);
   if (err == hipSuccess && st->growable) {
     err = hipMalloc(reinterpret_cast<void **>(&st->log), sizeof(unsigned long long) * kLogRecords * (st->num_cols + 1));
     if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void **>(&st->published), 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
@@ -1199,6 +1380,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     set_last_error("qsx_agg_state_create", err);
     (void)hipFree(st->image); (void)hipFree(st->control); (void)hipFree(st->tile_counts); (void)hipFree(st->tile_offsets);
     (void)hipFree(st->log);
+    (void)hipFree(st->dir_entries); (void)hipFree(st->dir_codes); (void)hipFree(st->dir_ngids);
     if (st->published != nullptr) (void)hipHostFree(st->published);
     delete st;
     return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
@@ -1215,6 +1397,9 @@ int qsx_agg_state_destroy(qsx_agg_state_t *st) {
   (void)hipFree(st->tile_counts);
   (void)hipFree(st->tile_offsets);
   (void)hipFree(st->log);
+  (void)hipFree(st->dir_entries);
+  (void)hipFree(st->dir_codes);
+  (void)hipFree(st->dir_ngids);
   if (st->published != nullptr) (void)hipHostFree(st->published);
   delete st;
   return QSX_OK;
@@ -1231,6 +1416,10 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
     if (rc != QSX_OK) return rc;
     __atomic_store_n(&st->published[0], 0ull, __ATOMIC_RELEASE);
     __atomic_store_n(&st->published[1], 0ull, __ATOMIC_RELEASE);
+  }
+  if (st->dir_gids != 0) {
+    QSX_HIP_TRY(hipMemsetAsync(st->dir_entries, 0xFF, st->dir_cap * 16, s));
+    QSX_HIP_TRY(hipMemsetAsync(st->dir_ngids, 0, 16, s));
   }
   if (st->dense) {
     QSX_HIP_TRY(hipMemsetAsync(st->image, 0, st->image_bytes, s));
@@ -1356,6 +1545,34 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
   if (rc != QSX_OK) return rc;
   std::shared_lock<std::shared_mutex> lock(st->table_mutex);
   // (the partitioned path scatters value columns: states over compressed attributes take the tile path)
+  const int bounds_slot = !st->dense && st->dir_gids != 0 ? st->dir_bounds_slot(s) : -1;
+  if (bounds_slot >= 0) {
+    // mid-size group count: group directory + one accumulator per group in LDS (derive_geometry)
+    const DirView dir = st->dir_view(bounds_slot);
+    DevConfig dc = st->dev;
+    for (int i = 0; i < st->config.num_columns; ++i) {
+      dc.cols[i] = cols[i];
+      dc.dicts[i] = (dicts != nullptr && dc.code_width[i] != 0) ? dicts[i] : nullptr;
+    }
+    for (int sl = 0; sl < dc.num_null_cols; ++sl) {
+      dc.nulls[sl] = nulls != nullptr ? reinterpret_cast<const unsigned long long *>(nulls[dc.null_column[sl]]) : nullptr;
+    }
+    st->rows_seen.fetch_add(n);
+    // two launches (agg_common.hpp): the distinct key codes of these rows enter the directory, then the rows are aggregated
+    unsigned key_columns = 0;
+    for (int k = 0; k < dc.num_keys; ++k) key_columns |= 1u << dc.key_column[k];
+    for (int p = 0; p < dc.num_pred; ++p) key_columns |= 1u << dc.pred[p].column;
+    rc = launch_dir_build(dc, key_columns, n, filter_dev, dir, st->dir_gids, st->dir_calls.fetch_add(1), s);
+    if (rc != QSX_OK) return rc;
+    QSX_CHECK_LAUNCH();
+    if (st->shape != nullptr && filter_dev == nullptr && dc.num_null_cols == 0) {
+      rc = st->shape->launch_dir(cols, st->config.num_columns, n, st->hash_view(), dir, st->dir_gids, st->dir_nbuf, s);
+    } else {
+      QSX_DISPATCH_NS(st->num_sums, rc = launch_dir, dc, st->used_columns, n, filter_dev, st->hash_view(), dir, st->dir_gids,
+                      st->dir_nbuf, s);
+    }
+    if (rc == QSX_OK) QSX_CHECK_LAUNCH();
+  } else
   // (and so do states over nullable columns: a null bitmap cannot be scattered like a value column)
   if (!st->dense && st->part_count > 1 && filter_dev == nullptr && !st->has_coded_columns && st->dev.num_null_cols == 0 &&
       n >= partition_min_rows()) {

@@ -612,3 +612,78 @@ def test_bitmap_gather_segmented(capi, oracle, dev):
         out = capi.bitmap_gather_segmented(segs, first, to_dev(tids, dev))
         want = oracle.bitmap_from_bools(np.where(tids < 0, True, whole[np.maximum(tids, 0)]))
         assert np.array_equal(out.cpu().numpy().view(np.uint64), want[:(count + 63) // 64])
+
+
+# ---- mid-size group counts: the group directory ------------------------------------------------------------------------
+@pytest.mark.parametrize("directory", ["1", "0"])
+def test_thousands_of_groups_directory_and_partitioned_paths(capi, oracle, dev, directory, monkeypatch):
+    """Thousands of groups: one accumulator per group in LDS behind the key -> group-number directory (default), or the
+    partition pass (QSX_AGG_DIRECTORY=0).  AOT shape (two INT keys SUM/COUNT/AVG), the interpreter with MIN/MAX, a state
+    predicate and a filter, and an estimate that the real group count overruns (rows without an accumulator take the
+    global path; the table grows)."""
+    monkeypatch.setenv("QSX_AGG_DIRECTORY", directory)
+    monkeypatch.setenv("QSX_AGG_PARTITION_MIN_ROWS", "100000")
+    rng = np.random.default_rng(31)
+    n = 2_000_000
+    k1 = rng.integers(0, 95, size=n).astype(np.int32)
+    k2 = rng.integers(-50, 50, size=n).astype(np.int32)
+    val = rng.normal(size=n)
+    ival = rng.integers(-1000, 1000, size=n).astype(np.int64)
+    layout = [(T.INT, None), (T.INT, None), (T.DOUBLE, None), (T.LONG, None)]
+    shape_cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout[:3], keys=[0, 1],
+                                  aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None), (T.AGG_AVG, T.col(2))], est_groups=10_000)
+    o = oracle.AggState(shape_cfg)
+    o.update([k1, k2, val])
+    ref = o.finalize()
+    for blocks in (1, 7):
+        assert_same_groups(finalize_np(run_hip(capi, dev, shape_cfg, [k1, k2, val], blocks=blocks), dev), ref)
+    keep = rng.uniform(size=n) < 0.6
+    filt = oracle.bitmap_from_bools(keep)
+    for est in (10_000, 2_000):
+        cfg = T.make_agg_config(T.AGG_GENERIC, layout, keys=[0, 1],
+                                instrs=[(T.EX_MUL, 0, T.col(2), T.col(3))],
+                                aggs=[(T.AGG_MIN, T.col(2)), (T.AGG_MAX, T.col(3)), (T.AGG_SUM, T.temp(0)), (T.AGG_COUNT_STAR, None),
+                                      (T.AGG_SUM, T.col(3))],
+                                pred=[(3, T.GE, -900)], est_groups=est)
+        for filter_bitmap in (None, filt):
+            o = oracle.AggState(cfg)
+            o.update([k1, k2, val, ival], filter_bitmap=filter_bitmap)
+            st = run_hip(capi, dev, cfg, [k1, k2, val, ival], filter_bitmap=filter_bitmap)
+            st.update([to_dev(c[:1000], dev) for c in (k1, k2, val, ival)], 1000)      # a second, small call on the same state
+            o.update([c[:1000] for c in (k1, k2, val, ival)])
+            assert_same_groups(finalize_np(st, dev), o.finalize())
+            st.clear()                                                                    # the directory starts over with the state
+            st.update([to_dev(c, dev) for c in (k1, k2, val, ival)], n)
+            o2 = oracle.AggState(cfg)
+            o2.update([k1, k2, val, ival])
+            assert_same_groups(finalize_np(st, dev), o2.finalize())
+
+
+@pytest.mark.parametrize("layout_kind", ["box", "sparse", "clustered_sample"])
+def test_group_directory_numbering_modes(capi, oracle, dev, layout_kind, monkeypatch):
+    """The three ways a row of a mid-size group-by finds its LDS accumulator: position in the key box of the build pass
+    (small key ranges), directory lookup (sparse keys: the box has too many cells), and — the build pass only samples a
+    large input — neither: groups and keys the sample missed are aggregated through the global table."""
+    monkeypatch.setenv("QSX_AGG_DIRECTORY", "1")
+    rng = np.random.default_rng(47)
+    n = 1_500_000
+    k1 = rng.integers(0, 90, size=n).astype(np.int32)
+    k2 = rng.integers(-40, 40, size=n).astype(np.int32)
+    if layout_kind == "sparse":
+        k1 = (k1 * 100_003).astype(np.int32)
+        k2 = (k2 * 7_919 - 5).astype(np.int32)
+    if layout_kind == "clustered_sample":
+        monkeypatch.setenv("QSX_AGG_DIR_SAMPLE_ROWS", "40000")    # every 37th tile of 1024 rows
+        order = np.argsort(k1, kind="stable")                      # clustered on k1: the sampled tiles miss whole key ranges
+        k1, k2 = k1[order], k2[order]
+        k1[-5:] = 5_000_000                                        # and keys far outside any sampled box
+    val = rng.normal(size=n)
+    layout = [(T.INT, None), (T.INT, None), (T.DOUBLE, None)]
+    for strategy, aggs in ((T.AGG_COMPACT_KEY, [(T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None), (T.AGG_AVG, T.col(2))]),
+                           (T.AGG_GENERIC, [(T.AGG_MIN, T.col(2)), (T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None)])):
+        cfg = T.make_agg_config(strategy, layout, keys=[0, 1], aggs=aggs, est_groups=8_000)
+        o = oracle.AggState(cfg)
+        o.update([k1, k2, val])
+        ref = o.finalize()
+        for blocks in (1, 3):
+            assert_same_groups(finalize_np(run_hip(capi, dev, cfg, [k1, k2, val], blocks=blocks), dev), ref)
