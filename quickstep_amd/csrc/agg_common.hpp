@@ -237,6 +237,9 @@ struct DirView {
   // million rows misses has few rows, and those are aggregated through the global table.
   int sample_stride;
   int sample_phase;
+  // The build pass is two launches over the same sample: 0 = key bounds only; 1 = the directory itself — which returns at
+  // once when the bounds span a usable box (the accumulate pass will not look anything up).
+  int build_step;
 };
 constexpr unsigned long long kSignBias = 1ull << 63;
 

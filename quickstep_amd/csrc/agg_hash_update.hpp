@@ -438,7 +438,10 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 
   if constexpr (kDirBuild) {
     // build pass of the group directory: only the set of key codes this workgroup sees, S slots
-    for (int i = threadIdx.x; i < S; i += BLOCK) l_keys[i] = kEmptyCode;
+    if (dir->build_step == 1) {
+      if (key_box_of(*dir, c.num_keys).usable) return;   // (uniform) groups will be numbered by their place in the key box
+      for (int i = threadIdx.x; i < S; i += BLOCK) l_keys[i] = kEmptyCode;
+    }
   } else if constexpr (kDir) {
     for (int i = threadIdx.x; i < plane; i += BLOCK) l_cnt[i] = 0;
   } else {
@@ -548,7 +551,10 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         if (live[v] && code[v] != kEmptyCode) {
-          if (lds_find_or_insert(l_keys, S, code[v]) < 0) dir_insert(*dir, code[v]);
+          if (dir->build_step == 1) {
+            if (lds_find_or_insert(l_keys, S, code[v]) < 0) dir_insert(*dir, code[v]);
+            continue;
+          }
 #pragma unroll
           for (int k = 0; k < QSX_MAX_KEYS; ++k) {
             if (k < c.num_keys) {
@@ -778,9 +784,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   if constexpr (kDense) return;
   __syncthreads();
   if constexpr (kDirBuild) {
-    for (int i = threadIdx.x; i < S; i += BLOCK) {
-      const unsigned long long code = l_keys[i];
-      if (code != kEmptyCode) dir_insert(*dir, code);
+    if (dir->build_step == 1) {
+      for (int i = threadIdx.x; i < S; i += BLOCK) {
+        const unsigned long long code = l_keys[i];
+        if (code != kEmptyCode) dir_insert(*dir, code);
+      }
+      return;
     }
 #pragma unroll
     for (int k = 0; k < QSX_MAX_KEYS; ++k) {
@@ -792,12 +801,26 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
           hi = h2 > hi ? h2 : hi;
           nlo = n2 > nlo ? n2 : nlo;
         }
-        if (lane_id() == 0 && (hi | nlo) != 0) {
-          atomicMax(&dir->bounds[2 * k], hi);
-          atomicMax(&dir->bounds[2 * k + 1], nlo);
+        seen_hi[k] = hi;
+        seen_nlo[k] = nlo;
+      }
+    }
+    // the workgroup's waves meet in LDS (the tile buffers are free now): one global atomic per word and workgroup — same-
+    // address atomics complete one at a time device-wide, 16 waves x 256 workgroups x 4 words of them took 0.2 ms
+    unsigned long long *wg_bounds = reinterpret_cast<unsigned long long *>(tiles);
+    if (threadIdx.x < 2 * QSX_MAX_KEYS) wg_bounds[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane_id() == 0) {
+#pragma unroll
+      for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+        if (k < c.num_keys && (seen_hi[k] | seen_nlo[k]) != 0) {
+          atomicMax(&wg_bounds[2 * k], seen_hi[k]);
+          atomicMax(&wg_bounds[2 * k + 1], seen_nlo[k]);
         }
       }
     }
+    __syncthreads();
+    if (threadIdx.x < 2 * c.num_keys && wg_bounds[threadIdx.x] != 0) atomicMax(&dir->bounds[threadIdx.x], wg_bounds[threadIdx.x]);
     return;
   }
   if constexpr (kDir) {

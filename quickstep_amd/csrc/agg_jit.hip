@@ -100,7 +100,18 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
   bool any_coded = false;   // unused pointers are passed as literals: every live scalar argument costs SGPRs in the tile loop
   for (int i = 0; i < dev.num_columns; ++i) any_coded = any_coded || dev.code_width[i] != 0;
   o << kPrelude << kBundle << "\nnamespace qsx {\nconstexpr DevConfig jit_make_dev() {\n  DevConfig d{};\n"
-    << emit_dev_config(dev) << "  return d;\n}\n"
+    << emit_dev_config(dev) << "  return d;\n}\n";
+  if (geo.dir_gids != 0) {
+    // group-directory variant: the body of agg_dir_update_kernel with the configuration and the geometry as constants
+    o << "extern \"C\" __global__ __launch_bounds__(" << kDirBlock << ") void qsx_jit_agg(ColumnPointers cols,\n"
+      << "    const void *const *dicts, int64_t n, const uint64_t *filter, HashTableView view, DirView d) {\n"
+      << "  static constexpr DevConfig D = jit_make_dev();\n"
+      << "  agg_hash_update_body<true, false, " << num_sums << ", 1, true, " << kDirBlock << ">(D, cols.p, "
+      << (any_coded ? "dicts" : "nullptr") << ", n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr")
+      << ", view, DenseView{}, " << geo.dir_gids << ", 0, " << geo.nbuf << ", 1, nullptr, nullptr, &d);\n}\n}  // namespace qsx\n";
+    return o.str();
+  }
+  o
     // explicit arguments are kept under 256 bytes (one view, the dictionaries behind a pointer): with the 256 hidden
     // bytes a kernarg segment beyond 512 bytes made the same code 2.4x slower (3.5 -> 8.3 ms, Q1 over 600 M rows)
     << "extern \"C\" __global__ __launch_bounds__(" << kABlock << ") void qsx_jit_agg(ColumnPointers cols,\n"
@@ -262,6 +273,20 @@ int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t s
   return QSX_OK;
 }
 
+int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
+                       const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d) {
+  ColumnPointers a_cols = cols;
+  const void *const *a_dicts = dict_table_dev;
+  int64_t a_n = n;
+  const uint64_t *a_filter = filter;
+  HashTableView a_g = g;
+  DirView a_d = d;
+  void *args[] = {&a_cols, &a_dicts, &a_n, &a_filter, &a_g, &a_d};
+  QSX_HIP_TRY(hipModuleLaunchKernel(k->function, static_cast<unsigned>(grid), 1, 1, kDirBlock, 1, 1,
+                                    static_cast<unsigned>(lds_bytes), stream, args, nullptr));
+  return QSX_OK;
+}
+
 }  // namespace qsx
 
 // Test hook (not part of include/qsx.h): compiles the plan shape of a configuration with hipRTC and
@@ -271,8 +296,11 @@ extern "C" int qsx_debug_jit_compile(const qsx_agg_config_t *config, int with_fi
   if (config == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   Translated t = translate(*config);
   if (t.status != QSX_OK) return t.status;
-  plan_tile(t.dev, t.used_columns, kABlock * kJitRowsPerThread, with_filter != 0);
-  const JitGeometry geometry{t.dense ? 8 : 16, t.dense ? 0 : 4, 1, 1};   // a plausible geometry: this hook only checks that the shape compiles
+  const bool directory = (with_filter & 2) != 0 && !t.dense;   // bit 1: the group-directory variant
+  with_filter &= 1;
+  plan_tile(t.dev, t.used_columns, directory ? kDirBlock : kABlock * kJitRowsPerThread, with_filter != 0);
+  // a plausible geometry: this hook only checks that the shape compiles
+  const JitGeometry geometry = directory ? JitGeometry{4096, 0, 2, 1, 4096} : JitGeometry{t.dense ? 8 : 16, t.dense ? 0 : 4, 1, 1, 0};
   const std::string source = jit_agg_source(t.dev, t.num_sums, t.dense, geometry);
   if (const char *dump = getenv("QSX_JIT_DUMP")) {   // the generated translation unit, for offline inspection with hipcc -S
     if (FILE *f = std::fopen(dump, "w")) {

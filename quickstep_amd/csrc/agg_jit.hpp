@@ -30,6 +30,7 @@ struct JitRequest;
 // tile loop instead of occupying scalar registers.
 struct JitGeometry {
   int S, rep_shift, nbuf, ranges;
+  int dir_gids;   // != 0: the group-directory variant (agg_common.hpp DirView) with that many LDS accumulators per aggregate
 };
 JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geometry, bool synchronous);
 // 0: still compiling, 1: ready (*kernel set), -1: failed (hipRTC error: the interpreter stays in use)
@@ -39,6 +40,10 @@ int jit_request_state(JitRequest *request, const JitKernel **kernel);
 int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
                    const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g,
                    const DenseView &dense, bool is_dense, int S, int rep_shift, int nbuf, int ranges, const long long *pieces);
+
+// The group-directory variant (geometry.dir_gids != 0): the argument list of agg_dir_update_kernel.
+int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
+                       const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d);
 
 constexpr int kJitRowsPerThread = 4;
 

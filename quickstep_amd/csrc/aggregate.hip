@@ -427,15 +427,16 @@ using namespace qsx;
 // (a 0.5 M-row block whose groups the estimate missed entirely still fits).
 constexpr unsigned int kLogRecords = 1u << 20;
 
+constexpr int kJitVariants = 6;   // (filter) x (tile path, partitioned path, group directory)
 constexpr int kDirBoundSlots = 32;
 constexpr size_t kDirControlBytes = 16 + sizeof(unsigned long long) * 2 * QSX_MAX_KEYS * kDirBoundSlots;
 struct qsx_agg_state {
   qsx_agg_config_t config;
   bool has_coded_columns = false;   // some column arrives as codes of a compressed attribute
   // run-time plan shapes asked for, owned by the cache: index = (filter ? 1 : 0) + (partitioned input ? 2 : 0)
-  JitRequest *jit_request[4] = {nullptr, nullptr, nullptr, nullptr};
-  JitGeometry jit_geometry[4] = {};
-  size_t jit_lds[4] = {0, 0, 0, 0};
+  JitRequest *jit_request[kJitVariants] = {};
+  JitGeometry jit_geometry[kJitVariants] = {};
+  size_t jit_lds[kJitVariants] = {};
   DevConfig dev;            // everything but cols[]
   FinalizeDesc fin;         // everything but the output pointers
   int num_sums = 0;
@@ -500,6 +501,7 @@ struct qsx_agg_state {
     d.bounds = reinterpret_cast<unsigned long long *>(dir_ngids + 4) + 2 * QSX_MAX_KEYS * bounds_slot;   // same allocation, 16 bytes in
     d.sample_stride = 1;
     d.sample_phase = 0;
+    d.build_step = 0;
     return d;
   }
   // scratch for ordered dense finalize
@@ -519,9 +521,9 @@ struct qsx_agg_state {
   // Run-time plan shapes (agg_jit.hpp), one per filter variant; compiled once the state has seen enough
   // rows to pay for the 1-2 s of hipRTC.
   std::mutex jit_mutex;
-  const JitKernel *jit[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool jit_tried[4] = {false, false, false, false};
-  int jit_tile_bytes[4] = {0, 0, 0, 0};
+  const JitKernel *jit[kJitVariants] = {};
+  bool jit_tried[kJitVariants] = {};
+  int jit_tile_bytes[kJitVariants] = {};
   std::atomic<long long> rows_seen{0};
 
   HashTableView hash_view() const {
@@ -814,9 +816,9 @@ static int launch_shape_dir(const void *const *cols, int num_columns, int64_t n,
 // Build pass of the group directory: stages the key and predicate columns only.
 static int launch_dir_build(DevConfig dc, unsigned key_columns, int64_t n, const uint64_t *filter, DirView d, int gids,
                             unsigned call, hipStream_t stream) {
-  // the sample: every stride-th tile, at least ~8 M rows of a large input (all of a small one), another phase every call
+  // the sample: every stride-th tile, at least ~4 M rows of a large input (all of a small one), another phase every call
   const char *e = getenv("QSX_AGG_DIR_SAMPLE_ROWS");   // tests shrink the sample
-  const int64_t sample_rows = e != nullptr && atoll(e) > 0 ? atoll(e) : (8 << 20);
+  const int64_t sample_rows = e != nullptr && atoll(e) > 0 ? atoll(e) : (4 << 20);
   const int64_t stride = std::max<int64_t>(1, std::min<int64_t>(64, n / sample_rows));
   d.sample_stride = static_cast<int>(stride);
   d.sample_phase = static_cast<int>(call % stride);
@@ -839,7 +841,13 @@ static int launch_dir_build(DevConfig dc, unsigned key_columns, int64_t n, const
     if (rc != QSX_OK) return rc;
   }
   const int64_t sampled_tiles = ((n + kDirBlock - 1) / kDirBlock - d.sample_phase + stride - 1) / stride;
+  // (all CUs: the pass is bound by the LDS compare-and-swaps of the workgroups' code sets — 2.7 us per 1024-row tile —
+  // not by the inserts at its end: 64 workgroups took 0.54 ms for the sample that 256 read in 0.32 ms)
   const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(sampled_tiles, kCUs)));
+  d.build_step = 0;
+  hipLaunchKernelGGL(agg_dir_build_kernel<0>, dim3(grid), dim3(kDirBlock), static_cast<size_t>(nbuf) * dc.tile_bytes + 16, stream, dc, n,
+                     filter, d, slots, nbuf);
+  d.build_step = 1;
   hipLaunchKernelGGL(agg_dir_build_kernel<0>, dim3(grid), dim3(kDirBlock), lds, stream, dc, n, filter, d, slots, nbuf);
   return QSX_OK;
 }
@@ -969,9 +977,9 @@ static JitGeometry jit_geometry_for(const qsx_agg_state *st, int tile_bytes, int
 // The specialised kernel of this state for the (filter, partitioned) variant, requested once the state has aggregated
 // jit_min_rows() rows; nullptr -> use the interpreter (not requested yet, still compiling, or given up).
 static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, bool partitioned, int slots, int num_ranges, int64_t n,
-                                         int *variant) {
+                                         int *variant, bool directory = false) {
   const long long seen = st->rows_seen.fetch_add(n) + n;
-  const int v = (has_filter ? 1 : 0) + (partitioned ? 2 : 0);
+  const int v = (has_filter ? 1 : 0) + (directory ? 4 : (partitioned ? 2 : 0));
   *variant = v;
   std::lock_guard<std::mutex> lock(st->jit_mutex);
   if (st->jit_tried[v]) return st->jit[v];          // settled: ready or given up
@@ -983,9 +991,14 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
       return nullptr;
     }
     DevConfig dev = st->dev;
-    plan_tile(dev, st->used_columns, kABlock * kJitRowsPerThread, has_filter);
+    plan_tile(dev, st->used_columns, directory ? kDirBlock : kABlock * kJitRowsPerThread, has_filter);
     st->jit_tile_bytes[v] = dev.tile_bytes;
-    st->jit_geometry[v] = jit_geometry_for(st, dev.tile_bytes, slots, num_ranges, &st->jit_lds[v]);
+    if (directory) {
+      st->jit_geometry[v] = JitGeometry{st->dir_gids, 0, st->dir_nbuf, 1, st->dir_gids};
+      st->jit_lds[v] = dir_lds_bytes(dev.tile_bytes, 0, st->num_sums, st->dir_gids, st->dir_nbuf);
+    } else {
+      st->jit_geometry[v] = jit_geometry_for(st, dev.tile_bytes, slots, num_ranges, &st->jit_lds[v]);
+    }
     if (st->jit_lds[v] > 160 * 1024) {               // the shape would not fit a CU: the interpreter's smaller tiles stay in use
       st->jit_tried[v] = true;
       return nullptr;
@@ -1048,6 +1061,26 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const 
   const int rc = jit_agg_launch(k, grid, lds, stream, cp, dict_table, n, filter, st->dense ? HashTableView{} : st->hash_view(),
                                 st->dense ? st->dense_view() : DenseView{}, st->dense, S, rep_shift, nbuf, ranges, pieces);
   return rc;
+}
+
+static int launch_jit_dir(qsx_agg_state *st, const JitKernel *k, int variant, const void *const *cols, const void *const *dicts, int64_t n,
+                          const uint64_t *filter, const DirView &dir, hipStream_t stream) {
+  const size_t lds = st->jit_lds[variant];
+  if (lds > 160 * 1024) return QSX_ERR_CAPACITY;
+  ColumnPointers cp;
+  for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < st->config.num_columns ? cols[i] : nullptr;
+  const void **dict_table = nullptr;
+  if (st->has_coded_columns) {
+    DictTable host_table;
+    for (int i = 0; i < QSX_MAX_COLUMNS; ++i) host_table.p[i] = i < st->config.num_columns ? dicts[i] : nullptr;
+    DictTable *slot = device_slot<DictTable>(stream);
+    if (slot == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+    hipLaunchKernelGGL(store_struct_kernel<DictTable>, dim3(1), dim3(64), 0, stream, host_table, slot);
+    dict_table = slot->p;
+  }
+  const int rc = jit_agg_launch_dir(k, dir_grid(n), lds, stream, cp, dict_table, n, filter, st->hash_view(), dir);
+  if (rc != QSX_OK || hipGetLastError() != hipSuccess) return QSX_ERR_HIP;
+  return QSX_OK;
 }
 
 template <int NS>
@@ -1276,7 +1309,7 @@ static int grow_and_drain(qsx_agg_state *st) {
     derive_geometry(st, static_cast<int64_t>(groups) * 2);
     QSX_HIP_TRY(ensure_directory(st));
     std::lock_guard<std::mutex> lock(st->jit_mutex);   // run-time shapes carry the geometry as constants: ask again
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < kJitVariants; ++v) {
       st->jit_request[v] = nullptr;
       st->jit[v] = nullptr;
       st->jit_tried[v] = false;
@@ -1557,7 +1590,6 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
     for (int sl = 0; sl < dc.num_null_cols; ++sl) {
       dc.nulls[sl] = nulls != nullptr ? reinterpret_cast<const unsigned long long *>(nulls[dc.null_column[sl]]) : nullptr;
     }
-    st->rows_seen.fetch_add(n);
     // two launches (agg_common.hpp): the distinct key codes of these rows enter the directory, then the rows are aggregated
     unsigned key_columns = 0;
     for (int k = 0; k < dc.num_keys; ++k) key_columns |= 1u << dc.key_column[k];
@@ -1565,9 +1597,23 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
     rc = launch_dir_build(dc, key_columns, n, filter_dev, dir, st->dir_gids, st->dir_calls.fetch_add(1), s);
     if (rc != QSX_OK) return rc;
     QSX_CHECK_LAUNCH();
+    int variant = 0;
+    const JitKernel *jk = nullptr;
     if (st->shape != nullptr && filter_dev == nullptr && dc.num_null_cols == 0) {
+      st->rows_seen.fetch_add(n);
       rc = st->shape->launch_dir(cols, st->config.num_columns, n, st->hash_view(), dir, st->dir_gids, st->dir_nbuf, s);
+    } else if (dc.num_null_cols == 0 &&
+               (jk = state_jit_kernel(st, filter_dev != nullptr, false, st->dir_gids, 1, n, &variant, true)) != nullptr &&
+               st->jit_geometry[variant].dir_gids == st->dir_gids && launch_jit_dir(st, jk, variant, cols, dc.dicts, n, filter_dev, dir, s) == QSX_OK) {
+      rc = QSX_OK;   // run-time plan shape of the directory kernel
     } else {
+      if (jk != nullptr) {   // the specialised kernel could not be launched: the interpreter from now on
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> jit_lock(st->jit_mutex);
+        st->jit[variant] = nullptr;
+      } else if (dc.num_null_cols != 0) {
+        st->rows_seen.fetch_add(n);
+      }
       QSX_DISPATCH_NS(st->num_sums, rc = launch_dir, dc, st->used_columns, n, filter_dev, st->hash_view(), dir, st->dir_gids,
                       st->dir_nbuf, s);
     }

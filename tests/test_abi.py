@@ -77,8 +77,11 @@ def test_run_time_plan_shape_generator_compiles_without_a_gpu(capi):
     kw = dict(instrs=[(T.EX_MUL, 0, T.col(3), T.col(2)), (T.EX_DIV, 1, T.temp(0), T.const(0))], consts=[-0.75],
               aggs=[(T.AGG_SUM, T.temp(1)), (T.AGG_MIN, T.col(2)), (T.AGG_MAX, T.col(1)), (T.AGG_AVG, T.col(0)), (T.AGG_COUNT_STAR, None)],
               pred=[(1, T.GT, -5), (3, T.LE, 2.5)])
+    # (bit 1 of the second argument: the group-directory variant of a hash strategy)
     for cfg, with_filter in ((T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], **kw), 0),
-                             (T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], num_entries=100, **kw), 1)):
+                             (T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], num_entries=100, **kw), 1),
+                             (T.make_agg_config(T.AGG_GENERIC, layout, keys=[0, 2], **kw), 2),
+                             (T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], **kw), 3)):
         size = C.c_size_t(0)
         assert fn(C.byref(cfg), with_filter, C.byref(size)) == 0
         assert size.value > 1000

@@ -659,12 +659,14 @@ def test_thousands_of_groups_directory_and_partitioned_paths(capi, oracle, dev, 
             assert_same_groups(finalize_np(st, dev), o2.finalize())
 
 
+@pytest.mark.parametrize("run_time_shape", [False, True])
 @pytest.mark.parametrize("layout_kind", ["box", "sparse", "clustered_sample"])
-def test_group_directory_numbering_modes(capi, oracle, dev, layout_kind, monkeypatch):
+def test_group_directory_numbering_modes(capi, oracle, dev, layout_kind, run_time_shape, monkeypatch):
     """The three ways a row of a mid-size group-by finds its LDS accumulator: position in the key box of the build pass
     (small key ranges), directory lookup (sparse keys: the box has too many cells), and — the build pass only samples a
     large input — neither: groups and keys the sample missed are aggregated through the global table."""
     monkeypatch.setenv("QSX_AGG_DIRECTORY", "1")
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if run_time_shape else str(1 << 60))   # hipRTC shape of the directory kernel / interpreter
     rng = np.random.default_rng(47)
     n = 1_500_000
     k1 = rng.integers(0, 90, size=n).astype(np.int32)
