@@ -769,6 +769,17 @@ static bool dense_two_pass(const uint64_t *filter) {
   return filter != nullptr;
 }
 
+// The XCD-sliced dense probe (join_dense.hpp) pays 8 visits of every probe row for lookups that all hit L2.  Measured
+// (tools/probe_sliced.py, 100 M probes, plain -> sliced): counting 4 M keys 1.27 -> 0.82 ms, 8 M 1.57 -> 0.98, 16 M
+// 1.74 -> 1.44, 64 M 1.86 -> 1.94; emitting pairs 8 M keys 1.71 -> 1.81 ms — eight times the tile visits, each one memory
+// round trip, cost what the L2 hits save once pairs have to be staged.  So: count mode only, head arrays of 12..128 MiB.
+// QSX_JOIN_SLICED=1 / 0 forces it on (both modes) / off.
+static bool dense_sliced(uint64_t range, int64_t n, int mode) {
+  const char *e = getenv("QSX_JOIN_SLICED");
+  if (e != nullptr && e[0] != '\0') return e[0] != '0' && range >= 64;
+  return mode == 1 && range * 4 >= (12ull << 20) && range * 4 <= (128ull << 20) && n >= (4 << 20);
+}
+
 template <int MODE>
 static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_t probe_base_tid,
                         const uint64_t *filter, int32_t *out_probe, int32_t *out_build,
@@ -815,6 +826,24 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
       QSX_HIP_TRY(hipFreeAsync(unit_offsets, stream));
       QSX_HIP_TRY(hipFreeAsync(scan_ws, stream));
       return QSX_OK;
+    }
+    if constexpr (MODE == 0 || MODE == 1) {
+      if (dense_sliced(t->dense_view().range, n, MODE) && dcount != nullptr) {
+        // head[] does not fit an XCD's L2: every XCD looks up one key range of it (join_dense.hpp)
+        const int64_t limit_s = (MODE == 0 ? 5 : 8) * kCUs;   // MODE 0 stages pairs in 32 KiB of LDS
+        const int64_t stiles = (n + kSlicedTile - 1) / kSlicedTile;
+        int sgrid = static_cast<int>(stiles * kSlices < limit_s ? stiles * kSlices : limit_s);
+        sgrid = sgrid / kSlices * kSlices;
+        if (t->key_type == QSX_INT) {
+          hipLaunchKernelGGL((dense_probe_sliced_kernel<int32_t, MODE>), dim3(sgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+                             static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity, dcount);
+        } else {
+          hipLaunchKernelGGL((dense_probe_sliced_kernel<int64_t, MODE>), dim3(sgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+                             static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity, dcount);
+        }
+        QSX_CHECK_LAUNCH();
+        return QSX_OK;
+      }
     }
     if (t->key_type == QSX_INT) {
       hipLaunchKernelGGL((dense_probe_kernel<int32_t, MODE>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),

@@ -205,6 +205,60 @@ def test_dense_table_over_one_hash_partition(capi, oracle, dev, key_type, dtype)
         table.size()
 
 
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+def test_xcd_sliced_dense_probe_matches_oracle(capi, oracle, dev, key_type, dtype, monkeypatch):
+    """The XCD-sliced probe of a directly addressed table (join_dense.hpp: workgroup b looks up key range b % 8, pairs
+    staged in LDS across tile visits) against the oracle: duplicates (chains), a probe filter, keys outside the range, a
+    strided table, a range that does not divide by 8, skewed keys (one slice gets nearly every match: the stage must flush
+    inside the loop), and a capacity smaller than the match count."""
+    monkeypatch.setenv("QSX_JOIN_SLICED", "1")
+    rng = np.random.default_rng(77)
+    for stride, n_build, span, n_probe, hot in ((1, 90_000, 100_003, 700_001, 0.0), (4, 30_000, 200_001, 300_000, 0.0),
+                                                (1, 50_000, 64_000, 600_000, 0.9)):
+        lo = 1_000 if dtype == np.int32 else 2**40
+        domain = lo + np.arange(0, span * stride, stride)
+        build = rng.choice(domain, size=n_build, replace=True).astype(dtype)
+        probe = (lo + rng.integers(-20, span * stride + 20, size=n_probe)).astype(dtype)
+        if hot:
+            probe[rng.random(n_probe) < hot] = build[7]          # one key range takes nearly all matches
+        table = capi.JoinTable(key_type, n_build, key_range=(int(domain[0]), int(domain[-1])), key_stride=stride)
+        table.build(to_dev(build, dev))
+        dp = to_dev(probe, dev)
+        pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.7)
+        for filt in (None, pf):
+            fdev = None if filt is None else bitmap_dev(filt, dev)
+            _, rp, rd = oracle_join(oracle, key_type, [build], probe, probe_filter=filt)
+            total = int(table.probe_count(dp, filter_bitmap=fdev).item())
+            assert total == rp.size
+            monkeypatch.setenv("QSX_JOIN_TWO_PASS", "0")         # (with a filter the two-pass kernels would take the call)
+            p, b, cnt = table.probe(dp, capacity=total, filter_bitmap=fdev)
+            assert int(cnt.item()) == total
+            assert np.array_equal(sorted_pairs(p.cpu().numpy()[:total], b.cpu().numpy()[:total]), sorted_pairs(rp, rd))
+        p, b, cnt = table.probe(dp, capacity=1000)               # more matches than room: full count, no write past the end
+        assert int(cnt.item()) == int(table.probe_count(dp).item())
+        table.close()
+
+
+def test_xcd_sliced_probe_at_scale_properties(capi, dev, monkeypatch):
+    """8 M-key table (32 MiB of head words: the broadcast join's table at 8 GPUs) probed by 30 M keys through the sliced
+    kernels (by default only the count takes them at this size) and the plain ones: pairs are a permutation of the probe
+    tids and satisfy the join condition."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    n_build, n_probe = 8_000_000, 30_000_000
+    build = torch.randperm(n_build, device=dev, generator=g, dtype=torch.int32)
+    probe = torch.randint(0, n_build, (n_probe,), device=dev, generator=g, dtype=torch.int32)
+    table = capi.JoinTable(T.INT, n_build, key_range=(0, n_build - 1))
+    table.build(build)
+    for sliced in ("1", "0"):
+        monkeypatch.setenv("QSX_JOIN_SLICED", sliced)
+        p, b, cnt = table.probe(probe)
+        assert int(cnt.item()) == n_probe == int(table.probe_count(probe).item())
+        assert bool((build[b.long()] == probe[p.long()]).all())
+        assert int(p.long().sum().item()) == n_probe * (n_probe - 1) // 2
+        assert int(torch.bincount(p.long(), minlength=n_probe).max().item()) == 1
+
+
 @pytest.mark.parametrize("flavour", FLAVOURS)
 def test_fk_join_at_scale_properties(capi, dev, flavour):
     """C2 shape scaled to 1 M x 20 M (full 100 M runs in bench.py): every probe key hits
