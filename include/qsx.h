@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define QSX_ABI_VERSION 4
+#define QSX_ABI_VERSION 5
 
 typedef void *qsx_stream_t;
 
@@ -45,7 +45,8 @@ typedef enum qsx_status {
   QSX_ERR_HIP = -4,
   QSX_ERR_CAPACITY = -5,     /* caller-provided output / table too small */
   QSX_ERR_UNSUPPORTED = -6,
-  QSX_ERR_TOO_MANY_GROUPS = -7
+  QSX_ERR_TOO_MANY_GROUPS = -7,
+  QSX_ERR_HASH_COLLISION = -8  /* wide group-by key: two keys shared a 64-bit hash (see QSX_GROUPS_HASH_COLLISION) */
 } qsx_status_t;
 
 /* Value types; numbering follows types/TypeID.hpp:32-43 (kInt, kLong, kFloat,
@@ -426,7 +427,12 @@ typedef struct qsx_agg_config {
   int32_t column_width[QSX_MAX_COLUMNS];  /* bytes; 4/8/4/8 for INT/LONG/FLOAT/DOUBLE, 1/2/4/8 for CHAR */
   int32_t num_keys;
   int32_t key_column[QSX_MAX_KEYS];       /* GROUP BY order; packed little-endian at running
-                                             offsets into a 64-bit code (ThreadPrivateCompactKeyHashTable.cpp:216-232) */
+                                             offsets into a 64-bit code (ThreadPrivateCompactKeyHashTable.cpp:216-232).
+                                             A key wider than 8 bytes (hash strategies; up to 3 words of 8 bytes,
+                                             PackedPayloadHashTable.hpp:499-521 takes any composite key) is grouped by a
+                                             64-bit hash of its packed words and verified exactly: every word costs two
+                                             of the QSX_MAX_AGGS accumulators of the state (QSX_ERR_UNSUPPORTED when
+                                             they do not fit), see QSX_GROUPS_HASH_COLLISION */
   int32_t num_instrs;
   qsx_expr_instr_t instrs[QSX_MAX_INSTRS];
   double consts[QSX_MAX_CONSTS];
@@ -548,7 +554,11 @@ int qsx_agg_num_groups(qsx_agg_state_t *state, int64_t *out_groups, qsx_stream_t
  * ThreadPrivateCompactKeyHashTable::finalize (.cpp:365-421).
  *   out_null_dev  optional array of num_aggs byte columns; 1 = NULL result
  *                 (SUM/AVG over zero rows in SINGLE_STATE, AggregationHandleSum.cpp:45-120)
- *   out_groups_dev int64 on device: rows written. */
+ *   out_groups_dev int64 on device: rows written — or QSX_GROUPS_HASH_COLLISION: the state groups by a key wider
+ *                 than 8 bytes and two different keys shared their 64-bit hash (every group carries MIN and MAX of its
+ *                 packed key words, MIN != MAX somewhere proves it).  Nothing of the output may be used then; the
+ *                 caller reports QSX_ERR_HASH_COLLISION / re-runs the operator.  Expected once in ~2^64 / groups^2 states. */
+#define QSX_GROUPS_HASH_COLLISION (-1ll)
 int qsx_agg_finalize(qsx_agg_state_t *state, int partition, int num_partitions,
                      void *const *out_key_cols, void *const *out_val_cols,
                      uint8_t *const *out_null_cols, int64_t capacity,

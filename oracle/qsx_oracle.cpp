@@ -689,6 +689,19 @@ union StateWord {
 // expression program (ScalarBinaryExpression::getAllValues semantics: every
 // node is an IEEE double, expressions/scalar/ScalarBinaryExpression.cpp:100-195
 // over ArithmeticBinaryOperators.hpp:203-340) and the state's predicate.
+// Group-by key of more than 8 bytes: 32 bytes, components at running offsets, rest zero.
+struct WideKey {
+  std::uint64_t w[4];
+  bool operator==(const WideKey &o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+};
+struct WideKeyHash {
+  std::size_t operator()(const WideKey &k) const {
+    std::uint64_t h = k.w[0];
+    for (int i = 1; i < 4; ++i) h = combine_hashes(h, k.w[i]);
+    return static_cast<std::size_t>(h);
+  }
+};
+
 struct RowReader {
   const qsx_agg_config_t &c;
   const void *const *cols;
@@ -783,6 +796,19 @@ struct RowReader {
     }
     return code;
   }
+  // A key wider than 8 bytes (PackedPayloadHashTable keeps the key components in the bucket,
+  // storage/PackedPayloadHashTable.hpp:499-521, HashTableKeyManager): the same memcpy at running offsets into 32 zeroed bytes.
+  inline WideKey wide_key(std::int64_t i) const {
+    WideKey key{};
+    int offset = 0;
+    for (int k = 0; k < c.num_keys; ++k) {
+      const int col = c.key_column[k];
+      const int w = c.column_width[col];
+      std::memcpy(reinterpret_cast<char *>(key.w) + offset, static_cast<const char *>(cols[col]) + i * w, w);
+      offset += w;
+    }
+    return key;
+  }
   // HashCompositeKey (utility/CompositeHash.hpp:39-48).
   inline std::uint64_t composite_hash(std::int64_t i) const {
     std::uint64_t h = 0;
@@ -873,6 +899,9 @@ struct qso_agg_state {
   std::unordered_map<std::uint64_t, std::uint32_t> index;
   std::vector<std::uint64_t> keys;        // bucket -> key code
   std::vector<std::uint64_t> key_hashes;  // GENERIC: composite hash per bucket
+  // keys wider than 8 bytes: the same bucket numbering through these two instead of index / keys
+  std::unordered_map<WideKey, std::uint32_t, WideKeyHash> wide_index;
+  std::vector<WideKey> wide_keys;
   std::vector<StateWord> states;          // bucket-major: [bucket][state]
 
   // COLLISION_FREE (storage/CollisionFreeVectorTable.hpp)
@@ -899,6 +928,18 @@ struct qso_agg_state {
     states.resize(states.size() + L.num_states, StateWord{0});
     return b;
   }
+
+  std::uint32_t bucket_for_wide(const WideKey &key, std::uint64_t hash) {
+    auto it = wide_index.find(key);
+    if (it != wide_index.end()) return it->second;
+    const std::uint32_t b = static_cast<std::uint32_t>(wide_keys.size());
+    wide_index.emplace(key, b);
+    wide_keys.push_back(key);
+    key_hashes.push_back(hash);
+    states.resize(states.size() + L.num_states, StateWord{0});
+    return b;
+  }
+  std::size_t num_buckets() const { return key_bytes > 8 ? wide_keys.size() : keys.size(); }
 
   void update(const void *const *cols, std::int64_t n, const std::uint64_t *filter, const std::uint64_t *const *nulls = nullptr) {
     RowReader rr(c, cols, nulls);
@@ -929,9 +970,8 @@ struct qso_agg_state {
         accumulate(c, L, rr, i, group);
         for (int s = 0; s < L.num_states; ++s) dense[static_cast<std::size_t>(s) * c.num_entries + loc] = group[s];
       } else {
-        const std::uint64_t code = rr.key_code(i);
         const std::uint64_t h = (c.strategy == QSX_AGG_GENERIC) ? rr.composite_hash(i) : 0;
-        const std::uint32_t b = bucket_for(code, h);
+        const std::uint32_t b = key_bytes > 8 ? bucket_for_wide(rr.wide_key(i), h) : bucket_for(rr.key_code(i), h);
         accumulate(c, L, rr, i, &states[static_cast<std::size_t>(b) * L.num_states]);
       }
     }
@@ -958,8 +998,9 @@ struct qso_agg_state {
       default:
         // mergeFrom (ThreadPrivateCompactKeyHashTable.cpp:306-363): map source
         // buckets to destination buckets (new keys appended), then add columns.
-        for (std::size_t b = 0; b < src.keys.size(); ++b) {
-          const std::uint32_t d = bucket_for(src.keys[b], src.key_hashes[b]);
+        for (std::size_t b = 0; b < src.num_buckets(); ++b) {
+          const std::uint32_t d = key_bytes > 8 ? bucket_for_wide(src.wide_keys[b], src.key_hashes[b])
+                                                : bucket_for(src.keys[b], src.key_hashes[b]);
           merge_words(L, &states[static_cast<std::size_t>(d) * L.num_states],
                       &src.states[b * L.num_states]);
         }
@@ -1021,16 +1062,18 @@ void emit_values(const qsx_agg_config_t &c, const StateLayout &L, const StateWor
   }
 }
 
-void emit_keys_from_code(const qsx_agg_config_t &c, std::uint64_t code, std::int64_t row,
-                         void *const *out_key_cols) {
-  // finalize (ThreadPrivateCompactKeyHashTable.cpp:365-421): memcpy width_i bytes from code+offset_i.
+void emit_keys_from_bytes(const qsx_agg_config_t &c, const char *key_bytes, std::int64_t row, void *const *out_key_cols) {
   int offset = 0;
   for (int k = 0; k < c.num_keys; ++k) {
     const int w = c.column_width[c.key_column[k]];
-    std::memcpy(static_cast<char *>(out_key_cols[k]) + row * w,
-                reinterpret_cast<const char *>(&code) + offset, w);
+    std::memcpy(static_cast<char *>(out_key_cols[k]) + row * w, key_bytes + offset, w);
     offset += w;
   }
+}
+void emit_keys_from_code(const qsx_agg_config_t &c, std::uint64_t code, std::int64_t row,
+                         void *const *out_key_cols) {
+  // finalize (ThreadPrivateCompactKeyHashTable.cpp:365-421): memcpy width_i bytes from code+offset_i.
+  emit_keys_from_bytes(c, reinterpret_cast<const char *>(&code), row, out_key_cols);
 }
 
 }  // namespace
@@ -1100,7 +1143,7 @@ int64_t qso_agg_num_groups(const qso_agg_state_t *s) {
       for (uint64_t w : s->existence) c += __builtin_popcountll(w);
       return c;
     }
-    default: return static_cast<int64_t>(s->keys.size());
+    default: return static_cast<int64_t>(s->num_buckets());
   }
 }
 
@@ -1136,7 +1179,7 @@ int64_t qso_agg_finalize(const qso_agg_state_t *s, int partition, int num_partit
       return row;
     }
     default:
-      for (size_t b = 0; b < s->keys.size(); ++b) {
+      for (size_t b = 0; b < s->num_buckets(); ++b) {
         if (c.strategy == QSX_AGG_GENERIC) {
           // partitioned mode routes a row to HashCompositeKey % P
           // (storage/AggregationOperationState.cpp:576-583).
@@ -1145,7 +1188,8 @@ int64_t qso_agg_finalize(const qso_agg_state_t *s, int partition, int num_partit
           continue;  // compact-key tables finalize in one piece (:925-948)
         }
         if (row >= capacity) return row;
-        emit_keys_from_code(c, s->keys[b], row, out_key_cols);
+        if (s->key_bytes > 8) emit_keys_from_bytes(c, reinterpret_cast<const char *>(s->wide_keys[b].w), row, out_key_cols);
+        else emit_keys_from_code(c, s->keys[b], row, out_key_cols);
         emit_values(c, L, &s->states[b * L.num_states], false, row, out_val_cols, out_null_cols);
         ++row;
       }

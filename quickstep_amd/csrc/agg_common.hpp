@@ -15,6 +15,9 @@ struct DevOperand {
   int kind;
   int index;
 };
+// Internal operand kind (never in a qsx_agg_config_t): word `index` of a wide group-by key, see DevConfig::wide_words.
+constexpr int kOpdKeyWord = 100;
+constexpr int kMaxKeyWords = 3;
 struct DevInstr {
   int op;
   int dst;
@@ -78,7 +81,16 @@ struct DevConfig {
   int num_keys;
   int key_column[QSX_MAX_KEYS];
   int key_width[QSX_MAX_KEYS];
-  int key_shift[QSX_MAX_KEYS];  // bit offset of the key inside the 64-bit code
+  int key_shift[QSX_MAX_KEYS];  // bit offset of the key inside its 64-bit word (the code itself unless wide_words != 0)
+  // Group-by keys wider than 8 packed bytes (PackedPayloadHashTable takes any composite key,
+  // storage/PackedPayloadHashTable.hpp:499-521): the components are packed into wide_words 64-bit words (key k in word
+  // key_word[k]; a component never straddles two words), the table is keyed by a 64-bit mixing hash of the words, and
+  // every word gets two hidden accumulators, MIN and MAX of the word over the group's rows.  Finalize reads the key back
+  // from the MIN columns; MIN == MAX for every word of every group proves that no two keys shared a hash (anything else
+  // is reported, never returned as a result).  wide_hash_mask: test hook that forces such collisions.
+  int wide_words;
+  int key_word[QSX_MAX_KEYS];
+  unsigned long long wide_hash_mask;
   int num_instrs;
   DevInstr instrs[QSX_MAX_INSTRS];
   double consts[QSX_MAX_CONSTS];

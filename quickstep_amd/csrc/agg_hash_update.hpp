@@ -301,9 +301,42 @@ __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *ti
   });
 }
 
-// Compact key codes of V rows (ThreadPrivateCompactKeyHashTable.cpp:216-232).
+// Word w of the packed wide key of tile row r (DevConfig::wide_words).
+__device__ __forceinline__ unsigned long long key_word_of(const DevConfig &c, const char *tile, int w, int r) {
+  unsigned long long word = 0;
+#pragma unroll
+  for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+    if (k < c.num_keys && c.key_word[k] == w) {
+      const char *base = tile + c.lds_off[c.key_column[k]];
+      unsigned long long x;
+      switch (c.key_width[k]) {
+        case 1: x = reinterpret_cast<const uint8_t *>(base)[r]; break;
+        case 2: x = reinterpret_cast<const uint16_t *>(base)[r]; break;
+        case 4: x = reinterpret_cast<const uint32_t *>(base)[r]; break;
+        default: x = reinterpret_cast<const unsigned long long *>(base)[r]; break;
+      }
+      word |= x << c.key_shift[k];
+    }
+  }
+  return word;
+}
+
+// Compact key codes of V rows (ThreadPrivateCompactKeyHashTable.cpp:216-232); for a wide key the 64-bit mixing hash of
+// its words.
 template <bool kStatic, int V, int BLOCK = kABlock>
 __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *tile, int trow, unsigned long long (&code)[V]) {
+  if (c.wide_words != 0) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      unsigned long long h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+      for (int w = 0; w < kMaxKeyWords; ++w) {
+        if (w < c.wide_words) h = mix64(h ^ key_word_of(c, tile, w, trow + v * BLOCK)) * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull;
+      }
+      code[v] = mix64(h) & c.wide_hash_mask;
+    }
+    return;
+  }
 #pragma unroll
   for (int v = 0; v < V; ++v) code[v] = 0;
   cfg_for<kStatic, QSX_MAX_KEYS>(c.num_keys, [&](int k) __attribute__((always_inline)) {
@@ -439,7 +472,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   if constexpr (kDirBuild) {
     // build pass of the group directory: only the set of key codes this workgroup sees, S slots
     if (dir->build_step == 1) {
-      if (key_box_of(*dir, c.num_keys).usable) return;   // (uniform) groups will be numbered by their place in the key box
+      if (key_box_of(*dir, c.wide_words != 0 ? 0 : c.num_keys).usable) return;   // (uniform) groups will be numbered by their place in the key box
       for (int i = threadIdx.x; i < S; i += BLOCK) l_keys[i] = kEmptyCode;
     }
   } else if constexpr (kDir) {
@@ -476,7 +509,8 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   for (int k = 0; k < QSX_MAX_KEYS; ++k) seen_hi[k] = seen_nlo[k] = 0;
   KeyBox box;
   box.usable = false;
-  if constexpr (kDir) box = key_box_of(*dir, c.num_keys);
+  // (a wide key's code is a hash: its groups cannot be numbered by position, the directory is looked up)
+  if constexpr (kDir) box = key_box_of(*dir, c.wide_words != 0 ? 0 : c.num_keys);
   const bool by_piece = pieces != nullptr;
   const int64_t row_begin = by_piece ? pieces[my_range] : 0;
   const int64_t row_end = by_piece ? row_begin + pieces[ranges + my_range] : n;
@@ -719,6 +753,10 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         // rows with a non-NULL argument (COUNT(x), AVG's denominator, "saw a value")
 #pragma unroll
         for (int v = 0; v < V; ++v) inc[v] = (nullbits[v] & s.null_mask) == 0 ? 1ull : 0ull;
+      } else if (s.arg.kind == kOpdKeyWord) {
+        // hidden accumulators of a wide key: MIN / MAX of the packed key words (DevConfig::wide_words)
+#pragma unroll
+        for (int v = 0; v < V; ++v) inc[v] = key_word_of(c, tile, s.arg.index, trow + v * BLOCK);
       } else if (s.is_int) {
         if constexpr (kStatic) {
 #pragma unroll

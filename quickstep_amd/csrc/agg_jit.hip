@@ -61,6 +61,10 @@ std::string emit_dev_config(const DevConfig &d) {
     o << "  d.key_column[" << k << "] = " << d.key_column[k] << "; d.key_width[" << k << "] = " << d.key_width[k]
       << "; d.key_shift[" << k << "] = " << d.key_shift[k] << ";\n";
   }
+  if (d.wide_words != 0) {
+    o << "  d.wide_words = " << d.wide_words << "; d.wide_hash_mask = " << d.wide_hash_mask << "ull;\n";
+    for (int k = 0; k < d.num_keys; ++k) o << "  d.key_word[" << k << "] = " << d.key_word[k] << ";\n";
+  }
   o << "  d.num_instrs = " << d.num_instrs << ";\n";
   for (int k = 0; k < d.num_instrs; ++k) {
     o << "  d.instrs[" << k << "].op = " << d.instrs[k].op << "; d.instrs[" << k << "].dst = " << d.instrs[k].dst << ";\n";

@@ -20,6 +20,13 @@ struct FinalizeDesc {
   int key_width[QSX_MAX_KEYS];
   int key_shift[QSX_MAX_KEYS];
   int key_type[QSX_MAX_KEYS];
+  // wide keys (DevConfig::wide_words): key k sits in word key_word[k]; word w is state column wide_min_col[w], and must
+  // equal column wide_max_col[w]
+  int wide_words;
+  int key_word[QSX_MAX_KEYS];
+  int wide_min_col[kMaxKeyWords];
+  int wide_max_col[kMaxKeyWords];
+  int *collision;   // set by finalize when MIN != MAX somewhere
   void *out_keys[QSX_MAX_KEYS];
   void *out_vals[QSX_MAX_AGGS];
   uint8_t *out_nulls[QSX_MAX_AGGS];
@@ -99,20 +106,38 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
     default: return fail(t, QSX_ERR_INVALID_ARGUMENT);
   }
   d.num_keys = c.num_keys;
-  int offset_bytes = 0;
+  int offset_bytes = 0, total_key_bytes = 0;
   for (int k = 0; k < c.num_keys; ++k) {
     const int col = c.key_column[k];
     if (col < 0 || col >= c.num_columns) return fail(t, QSX_ERR_INVALID_ARGUMENT);
+    total_key_bytes += c.column_width[col];
+  }
+  // Both hash strategies pack a key of up to 8 bytes into one 64-bit code (ThreadPrivateCompactKeyHashTable's KeyCode);
+  // a wider key is packed into several words and hashed (DevConfig::wide_words).
+  const bool wide = total_key_bytes > 8;
+  int word_bytes[QSX_MAX_KEYS] = {};   // wide: first fit, a component never straddles two words
+  int words = 0;
+  for (int k = 0; k < c.num_keys; ++k) {
+    const int col = c.key_column[k];
     const int ty = c.column_type[col];
     if (c.strategy == QSX_AGG_COLLISION_FREE && ty != QSX_INT && ty != QSX_LONG) return fail(t, QSX_ERR_UNSUPPORTED);
     if (c.strategy == QSX_AGG_GENERIC && ty == QSX_CHAR) return fail(t, QSX_ERR_UNSUPPORTED);  // FarmHash keys: out of scope
+    int word = 0;
+    if (wide) {
+      while (word < words && word_bytes[word] + c.column_width[col] > 8) ++word;
+      if (word == words) ++words;
+      offset_bytes = word_bytes[word];
+      word_bytes[word] += c.column_width[col];
+    }
     d.key_column[k] = col;
     d.key_width[k] = c.column_width[col];
     d.key_shift[k] = offset_bytes * 8;
-    offset_bytes += c.column_width[col];
+    d.key_word[k] = word;
+    if (!wide) offset_bytes += c.column_width[col];
   }
-  // both hash strategies pack the whole key into one 64-bit code
-  if (offset_bytes > 8) return fail(t, QSX_ERR_UNSUPPORTED);
+  d.wide_words = wide ? words : 0;
+  d.wide_hash_mask = ~0ull;
+  if (wide && (c.strategy == QSX_AGG_COLLISION_FREE || d.wide_words > kMaxKeyWords)) return fail(t, QSX_ERR_UNSUPPORTED);
   // expression program
   int defined = 0;
   d.num_instrs = c.num_instrs;
@@ -209,6 +234,21 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
     }
     f.sum_col[a] = j + 1;  // fixed up below for dense states without a count column
   }
+  // wide keys: MIN and MAX of every key word, behind the aggregates' accumulators
+  f.wide_words = d.wide_words;
+  for (int w = 0; w < d.wide_words; ++w) {
+    if (ns + 2 > kMaxSums) return fail(t, QSX_ERR_UNSUPPORTED);   // (accumulators per state are limited: fewer aggregates or a narrower key)
+    for (int which = 0; which < 2; ++which) {
+      d.sums[ns].arg = DevOperand{kOpdKeyWord, w};
+      d.sums[ns].is_int = 1;
+      d.sums[ns].kind = which == 0 ? kAccMinI64 : kAccMaxI64;
+      d.sums[ns].null_mask = 0;
+      d.sums[ns].count_valid = 0;
+      ++ns;
+    }
+    f.wide_min_col[w] = ns - 1;   // state column = accumulator index + 1
+    f.wide_max_col[w] = ns;
+  }
   d.num_sums = ns;
   t.num_sums = ns;
   // predicate
@@ -234,6 +274,7 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
     f.key_width[k] = d.key_width[k];
     f.key_shift[k] = d.key_shift[k];
     f.key_type[k] = c.column_type[c.key_column[k]];
+    f.key_word[k] = d.key_word[k];
   }
   // columns the update kernel has to stage: keys, predicate, expression and aggregate operands
   unsigned used = 0;

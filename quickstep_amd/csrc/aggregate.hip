@@ -197,9 +197,23 @@ __device__ __forceinline__ void write_values(const FinalizeDesc &f, const unsign
   }
 }
 
-__device__ __forceinline__ void write_keys_from_code(const FinalizeDesc &f, unsigned long long code, long long out_row) {
+// Key word `w` of the group in slot i: the code itself, or for a wide key the MIN column of that word — which must
+// equal its MAX column, or two different keys met under one hash (DevConfig::wide_words).
+__device__ __forceinline__ unsigned long long group_key_word(const FinalizeDesc &f, unsigned long long code,
+                                                             const unsigned long long *states, unsigned long long stride,
+                                                             unsigned long long i, int w) {
+  if (f.wide_words == 0) return code;
+  const unsigned long long lo = states[static_cast<unsigned long long>(f.wide_min_col[w]) * stride + i];
+  const unsigned long long hi = states[static_cast<unsigned long long>(f.wide_max_col[w]) * stride + i];
+  if (lo != hi) atomicExch(f.collision, 1);
+  return lo;
+}
+
+__device__ __forceinline__ void write_keys_from_code(const FinalizeDesc &f, unsigned long long code, long long out_row,
+                                                     const unsigned long long *states = nullptr, unsigned long long stride = 0,
+                                                     unsigned long long slot = 0) {
   for (int k = 0; k < f.num_keys; ++k) {
-    const unsigned long long v = code >> f.key_shift[k];
+    const unsigned long long v = group_key_word(f, code, states, stride, slot, f.key_word[k]) >> f.key_shift[k];
     switch (f.key_width[k]) {
       case 1: static_cast<uint8_t *>(f.out_keys[k])[out_row] = static_cast<uint8_t>(v); break;
       case 2: static_cast<uint16_t *>(f.out_keys[k])[out_row] = static_cast<uint16_t>(v); break;
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(kABlock) void finalize_hash_kernel(HashTableView g,
         // (storage/AggregationOperationState.cpp:576-583, utility/CompositeHash.hpp:39-48)
         unsigned long long h = 0;
         for (int k = 0; k < f.num_keys; ++k) {
-          unsigned long long bits = code >> f.key_shift[k];
+          unsigned long long bits = group_key_word(f, code, g.states, stride, i, f.key_word[k]) >> f.key_shift[k];
           if (f.key_width[k] < 8) bits &= (1ull << (8 * f.key_width[k])) - 1;
           const unsigned long long hk = reference_scalar_hash(f.key_type[k], bits);
           h = k == 0 ? hk : reference_combine(h, hk);
@@ -268,9 +282,14 @@ __global__ __launch_bounds__(kABlock) void finalize_hash_kernel(HashTableView g,
     if (!emit) continue;
     const long long out_row = static_cast<long long>(base) + rank_below(m);
     if (out_row >= capacity) continue;
-    write_keys_from_code(f, code, out_row);
+    write_keys_from_code(f, code, out_row, g.states, stride, i);
     write_values(f, g.states, stride, i, 0, false, out_row);
   }
+}
+
+// A wide-key state whose finalize saw MIN != MAX in a key word reports it in the group count (include/qsx.h).
+__global__ void report_collision_kernel(const int *collision, unsigned long long *out_groups) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *collision != 0) *out_groups = static_cast<unsigned long long>(QSX_GROUPS_HASH_COLLISION);
 }
 
 // SINGLE_STATE: exactly one row, NULL sums when no row was aggregated
@@ -558,6 +577,10 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
   const Translated t = translate(c);
   if (t.status != QSX_OK) return t.status;
   st->dev = t.dev;
+  if (const char *e = getenv("QSX_AGG_WIDE_HASH_BITS")) {   // test hook: a short hash makes different wide keys collide
+    const int bits = atoi(e);
+    if (bits > 0 && bits < 64) st->dev.wide_hash_mask = (1ull << bits) - 1;
+  }
   st->fin = t.fin;
   st->num_sums = t.num_sums;
   st->num_cols = t.num_cols;
@@ -703,6 +726,11 @@ static void plan_interpreter(DevConfig &dc, int tile_rows) {
   for (int j = 0; j < dc.num_sums; ++j) {
     PlanSum &ps = dc.plan_sums[j];
     ps.is_int = dc.sums[j].is_int;
+    if (dc.sums[j].arg.kind == kOpdKeyWord) {   // hidden accumulator of a wide key: the kernel packs the word itself
+      ps.arg = PlanOperand{};
+      ps.width = 8;
+      continue;
+    }
     ps.arg = resolve(dc.sums[j].arg, slot_of_temp);
     ps.width = dc.sums[j].arg.kind == QSX_OPD_COLUMN ? dc.column_width[dc.sums[j].arg.index] : 8;
   }
@@ -1380,7 +1408,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     st->growable = config->strategy != QSX_AGG_SINGLE_STATE;
   }
   hipError_t err = hipMalloc(reinterpret_cast<void **>(&st->image), st->image_bytes);
-  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->control), 4 * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->control), 8 * sizeof(unsigned long long));   // [4]: wide-key collision flag
   if (err == hipSuccess && st->dense) {
     err = hipMalloc(reinterpret_cast<void **>(&st->tile_counts), sizeof(int32_t) * st->max_tiles);
     if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->tile_offsets), sizeof(int64_t) * (st->max_tiles + 1));
@@ -1395,7 +1423,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     }
     if (err == hipSuccess && init_log(st, st->log, kLogRecords, nullptr, nullptr) != QSX_OK) err = hipErrorUnknown;
   }
-  if (err == hipSuccess) err = hipMemset(st->control, 0, 4 * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(st->control, 0, 8 * sizeof(unsigned long long));
   if (err == hipSuccess) {
     // InitializeAggregation: zero the state (CollisionFreeVectorTable.hpp:136-143)
     if (st->dense) {
@@ -1461,7 +1489,7 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
     QSX_HIP_TRY(hipMemsetAsync(st->image + (st->cap + 1), 0,
                                sizeof(unsigned long long) * (st->cap + 1) * st->num_cols, s));
   }
-  QSX_HIP_TRY(hipMemsetAsync(st->control, 0, 4 * sizeof(unsigned long long), s));
+  QSX_HIP_TRY(hipMemsetAsync(st->control, 0, 8 * sizeof(unsigned long long), s));
   return fill_identities(st, s);
 }
 
@@ -1620,8 +1648,9 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
     if (rc == QSX_OK) QSX_CHECK_LAUNCH();
   } else
   // (and so do states over nullable columns: a null bitmap cannot be scattered like a value column)
+  // (and states with a wide key: K9 packs the key code itself, it does not know the hashed form)
   if (!st->dense && st->part_count > 1 && filter_dev == nullptr && !st->has_coded_columns && st->dev.num_null_cols == 0 &&
-      n >= partition_min_rows()) {
+      st->dev.wide_words == 0 && n >= partition_min_rows()) {
     rc = update_partitioned(st, cols, n, s);
   } else {
     rc = update_slice(st, cols, dicts, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s, nulls);
@@ -1795,6 +1824,7 @@ int qsx_agg_finalize(qsx_agg_state_t *st, int partition, int num_partitions, voi
   }
   unsigned long long *out_groups = reinterpret_cast<unsigned long long *>(out_groups_dev);
   QSX_HIP_TRY(hipMemsetAsync(out_groups_dev, 0, sizeof(int64_t), s));
+  f.collision = reinterpret_cast<int *>(st->control + 4);
   switch (st->config.strategy) {
     case QSX_AGG_SINGLE_STATE:
       if (partition != 0) return QSX_OK;
@@ -1835,6 +1865,10 @@ int qsx_agg_finalize(qsx_agg_state_t *st, int partition, int num_partitions, voi
     }
   }
   QSX_CHECK_LAUNCH();
+  if (f.wide_words != 0) {
+    hipLaunchKernelGGL(report_collision_kernel, dim3(1), dim3(64), 0, s, f.collision, out_groups);
+    QSX_CHECK_LAUNCH();
+  }
   return QSX_OK;
 }
 

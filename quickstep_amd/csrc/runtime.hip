@@ -56,6 +56,7 @@ const char *qsx_status_string(int status) {
     case QSX_ERR_CAPACITY: return "caller-provided capacity too small";
     case QSX_ERR_UNSUPPORTED: return "unsupported type / configuration";
     case QSX_ERR_TOO_MANY_GROUPS: return "aggregation table overflow: more groups than the state can hold";
+    case QSX_ERR_HASH_COLLISION: return "wide group-by key: two keys shared a 64-bit hash, the result is void (re-run the operator)";
     default: return "unknown status";
   }
 }

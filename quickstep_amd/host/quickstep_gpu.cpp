@@ -802,6 +802,7 @@ void AggregationOperationState::finalizeWithDistinct(InsertDestination *dest) {
     CheckStatus(qsx_agg_finalize(state, 0, 1, key_cols, val_cols, nullptr, cap, static_cast<std::int64_t *>(rows.ptr), CurrentStream()),
                 "qsx_agg_finalize");
     out->rows = ReadCount(rows.ptr);
+    if (out->rows == QSX_GROUPS_HASH_COLLISION) throw ExecutionError("qsx_agg_finalize: wide group-by key", QSX_ERR_HASH_COLLISION);
     if (cfg.num_keys > 0 && out->rows > 0) {   // ascending key order: the common order of all result sets
       const void *cols[QSX_MAX_KEYS];
       std::int32_t types[QSX_MAX_KEYS];
@@ -981,6 +982,8 @@ void AggregationOperationState::finalizeAggregate(std::size_t partition, std::si
                                CurrentStream()),
               "qsx_agg_finalize");
   const std::int64_t written = ReadCount(rows.ptr);
+  // a key wider than 8 bytes is grouped by its 64-bit hash and verified: two keys under one hash void the result
+  if (written == QSX_GROUPS_HASH_COLLISION) throw ExecutionError("qsx_agg_finalize: wide group-by key", QSX_ERR_HASH_COLLISION);
   for (int a = 0; a < config_.num_aggs && written > 0; ++a) {
     if (null_cols[a] == nullptr) continue;
     // byte flags -> TupleIdSequence-ordered bitmap: a scan of 1-byte "codes" for flag >= 1

@@ -7,7 +7,7 @@ sides.  Pure data definitions: no library is loaded here.
 import ctypes as C
 
 # qsx_type_t (numbering of types/TypeID.hpp:32-43 in the reference)
-ABI_VERSION = 4                                                     # QSX_ABI_VERSION of include/qsx.h
+ABI_VERSION = 5                                                     # QSX_ABI_VERSION of include/qsx.h
 INT, LONG, FLOAT, DOUBLE, CHAR = 0, 1, 2, 3, 4
 # qsx_cmp_t (types/operations/comparisons/ComparisonID.hpp:36-42)
 EQ, NE, LT, LE, GT, GE = range(6)
@@ -30,7 +30,8 @@ TYPE_WIDTH = {INT: 4, LONG: 8, FLOAT: 4, DOUBLE: 8}
 # status codes
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_HIP = -1, -2, -3, -4
-ERR_CAPACITY, ERR_UNSUPPORTED, ERR_TOO_MANY_GROUPS = -5, -6, -7
+ERR_CAPACITY, ERR_UNSUPPORTED, ERR_TOO_MANY_GROUPS, ERR_HASH_COLLISION = -5, -6, -7, -8
+GROUPS_HASH_COLLISION = -1   # qsx_agg_finalize's group count when a wide-key state saw two keys under one hash
 
 
 class Operand(C.Structure):

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <tuple>
 
 #include "test_util.hpp"
 
@@ -426,6 +427,70 @@ int main() {
         EXPECT_EQ(at<std::int32_t>(cols[2], i), static_cast<int>(i));
       }
     }
+  }
+  // ---- GROUP BY a key wider than 8 bytes: (GroupBy-0 INT, LongType-0 / 20 LONG, GroupBy-1 INT) = 16 bytes ---------------
+  // (the reference's PackedPayloadHashTable takes any composite key; the device groups by a hash of the packed key words
+  // and proves the grouping, include/qsx.h QSX_GROUPS_HASH_COLLISION).  Same data as above: val = tid, gid = val % 20,
+  // the LONG key val / 20 is the "repeat" number, so every (g0, repeat, g1) is one row and (g0, g1) x repeat = 300 groups.
+  for (const bool partitioned_finalize : {false, true}) {
+    Fixture f;
+    CatalogRelation wide(110, "wide_input"), result(111, "result");
+    wide.addAttribute("GroupBy-0", Type::Int());
+    wide.addAttribute("repeat", Type::Long());
+    wide.addAttribute("GroupBy-1", Type::Int());
+    wide.addAttribute("DoubleType-0", Type::Double());
+    StorageManager storage;
+    for (tuple_id i = 0; i < kNumTuples; i += 50) {
+      std::int32_t g0[50], g1[50];
+      std::int64_t rep[50];
+      double dv[50];
+      for (tuple_id t = 0; t < 50; ++t) {
+        const int val = i + t, gid = val % kGroupByWidth;
+        g0[t] = gid % kGroupBy1Size; g1[t] = gid / kGroupBy1Size;
+        rep[t] = (static_cast<std::int64_t>(val / kGroupByWidth) % 5) << 40;   // 5 distinct LONG values beyond 32 bits
+        dv[t] = 0.1 * val;
+      }
+      storage.loadBlock(&wide, {g0, rep, g1, dv}, 50);
+    }
+    result.addAttribute("GroupBy-0", Type::Int());
+    result.addAttribute("repeat", Type::Long());
+    result.addAttribute("GroupBy-1", Type::Int());
+    result.addAttribute("sum_double", Type::Double());
+    result.addAttribute("count", Type::Long());
+    QueryContext ctx;
+    AggregationStateSpec spec;
+    spec.input_relation = &wide;
+    spec.group_by = {0, 1, 2};
+    spec.aggregates = {{AggregationID::kSum, 3}, {AggregationID::kCount, kInvalidAttributeID}};
+    spec.strategy = QSX_AGG_GENERIC;
+    spec.estimated_num_groups = 16;     // 100 groups: the table grows
+    const auto state = ctx.addAggregationState(spec);
+    const auto dest = ctx.addInsertDestination(&result, &storage);
+    AggregationOperator op(0, wide, true, state);
+    const std::size_t parts = partitioned_finalize ? 3 : 1;
+    FinalizeAggregationOperator fin(0, state, 1, false, parts, result, dest);
+    fetchAndExecuteWorkOrders(&op, &ctx, &storage);
+    fetchAndExecuteWorkOrders(&fin, &ctx, &storage);
+    std::size_t rows;
+    auto cols = readAll(ctx, dest, storage, result, &rows);
+    EXPECT_EQ(rows, static_cast<std::size_t>(kGroupByWidth * 5));
+    std::map<std::tuple<int, std::int64_t, int>, std::pair<double, std::int64_t>> want;
+    for (int val = 0; val < kNumTuples; ++val) {
+      const int gid = val % kGroupByWidth;
+      auto &w = want[{gid % kGroupBy1Size, (static_cast<std::int64_t>(val / kGroupByWidth) % 5) << 40, gid / kGroupBy1Size}];
+      w.first += 0.1 * val;
+      w.second += 1;
+    }
+    std::size_t matched = 0;
+    for (std::size_t i = 0; i < rows; ++i) {
+      const auto it = want.find({at<std::int32_t>(cols[0], i), at<std::int64_t>(cols[1], i), at<std::int32_t>(cols[2], i)});
+      EXPECT_TRUE(it != want.end());
+      if (it == want.end()) continue;
+      EXPECT_NEAR(at<double>(cols[3], i), it->second.first, 1e-9 * it->second.first + 1e-12);
+      EXPECT_EQ(at<std::int64_t>(cols[4], i), it->second.second);
+      ++matched;
+    }
+    EXPECT_EQ(matched, want.size());
   }
   return finish("aggregation_operator_test");
 }

@@ -34,6 +34,8 @@ def run_hip(capi, dev, cfg, cols, blocks=1, filter_bitmap=None, partition=0, num
 def finalize_np(st, dev, partition=0, num_partitions=1):
     keys, vals, nulls, groups = st.finalize(dev, partition, num_partitions)
     g = int(groups.item())
+    if g == T.GROUPS_HASH_COLLISION:
+        raise RuntimeError("QSX_GROUPS_HASH_COLLISION")
     return [k.cpu().numpy()[:g] for k in keys], [v.cpu().numpy()[:g] for v in vals], [z.cpu().numpy()[:g] for z in nulls]
 
 
@@ -689,3 +691,83 @@ def test_group_directory_numbering_modes(capi, oracle, dev, layout_kind, run_tim
         ref = o.finalize()
         for blocks in (1, 3):
             assert_same_groups(finalize_np(run_hip(capi, dev, cfg, [k1, k2, val], blocks=blocks), dev), ref)
+
+
+# ---- group-by keys wider than 8 bytes ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", ["long_long", "int_long_int", "double_long_thousands"])
+def test_wide_group_keys_match_oracle(capi, oracle, dev, shape, monkeypatch):
+    """PackedPayloadHashTable takes any composite key (storage/PackedPayloadHashTable.hpp:499-521); the device packs a key
+    of up to 24 bytes into words, groups by a 64-bit hash of them and proves the grouping with MIN / MAX of every word
+    (DevConfig::wide_words).  Checked against the oracle's component-wise keys: several blocks, a filter, a predicate, an
+    estimate the group count overruns (growth), partitioned finalize, thousands of groups (group directory), the
+    interpreter and the run-time plan shape."""
+    rng = np.random.default_rng(53)
+    n = 400_000
+    if shape == "long_long":
+        layout = [(T.LONG, None), (T.LONG, None), (T.DOUBLE, None), (T.INT, None)]
+        cols = [rng.integers(-3, 4, size=n).astype(np.int64) * (2**40 + 17), rng.integers(0, 9, size=n).astype(np.int64) - 2**62,
+                rng.normal(size=n), rng.integers(-100, 100, size=n).astype(np.int32)]
+        keys, est = [0, 1], 8
+    elif shape == "int_long_int":
+        layout = [(T.INT, None), (T.LONG, None), (T.INT, None), (T.DOUBLE, None)]
+        cols = [rng.integers(-5, 5, size=n).astype(np.int32), rng.integers(0, 6, size=n).astype(np.int64) * 2**33,
+                rng.integers(2**30, 2**30 + 4, size=n).astype(np.int32), rng.normal(size=n)]
+        keys, est = [0, 1, 2], 300
+    else:
+        layout = [(T.DOUBLE, None), (T.LONG, None), (T.DOUBLE, None), (T.INT, None)]
+        cols = [rng.integers(0, 70, size=n) * 0.25 - 3.0, rng.integers(0, 60, size=n).astype(np.int64) * 1_000_003,
+                rng.normal(size=n), rng.integers(-100, 100, size=n).astype(np.int32)]
+        keys, est = [0, 1], 4200
+    val = 3 if shape == "int_long_int" else 2
+    aggs = [(T.AGG_SUM, T.col(val)), (T.AGG_COUNT_STAR, None), (T.AGG_AVG, T.col(val)), (T.AGG_MIN, T.col(val))]
+    keep = oracle.bitmap_from_bools(rng.uniform(size=n) < 0.7)
+    for jit in (False, True):
+        monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if jit else str(1 << 60))
+        for pred in ([], [(val, T.GT, -1.0)]):
+            cfg = T.make_agg_config(T.AGG_GENERIC, layout, keys=keys, aggs=aggs, pred=pred, est_groups=est)
+            o = oracle.AggState(cfg)
+            o.update(cols)
+            for blocks in (1, 3):
+                st = run_hip(capi, dev, cfg, cols, blocks=blocks)
+                for P in (1, 3):
+                    for part in range(P):
+                        assert_same_groups(finalize_np(st, dev, part, P), o.finalize(part, P))
+            of = oracle.AggState(cfg)
+            of.update(cols, filter_bitmap=keep)
+            assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols, filter_bitmap=keep), dev), of.finalize())
+    # partial states of two "ranks" merged through their exported images
+    cfg = T.make_agg_config(T.AGG_GENERIC, layout, keys=keys, aggs=aggs, est_groups=est)
+    a = run_hip(capi, dev, cfg, [c[:n // 2] for c in cols])
+    b = run_hip(capi, dev, cfg, [c[n // 2:] for c in cols])
+    a.import_merge(b.export(dev))
+    o = oracle.AggState(cfg)
+    o.update(cols)
+    assert_same_groups(finalize_np(a, dev), o.finalize())
+
+
+def test_wide_group_key_hash_collision_is_reported_not_returned(capi, dev, monkeypatch):
+    """Two different wide keys under one hash: finalize must say so (QSX_GROUPS_HASH_COLLISION) instead of returning merged
+    groups.  A 5-bit hash (test hook) over 40 keys forces it; with the full hash the same input finalizes normally."""
+    rng = np.random.default_rng(59)
+    n = 50_000
+    cols = [rng.integers(0, 5, size=n).astype(np.int64), rng.integers(0, 8, size=n).astype(np.int64), rng.normal(size=n)]
+    cfg = T.make_agg_config(T.AGG_GENERIC, [(T.LONG, None), (T.LONG, None), (T.DOUBLE, None)], keys=[0, 1],
+                            aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None)], est_groups=64)
+    monkeypatch.setenv("QSX_AGG_WIDE_HASH_BITS", "5")
+    with pytest.raises(RuntimeError, match="QSX_GROUPS_HASH_COLLISION"):
+        finalize_np(run_hip(capi, dev, cfg, cols), dev)
+    monkeypatch.delenv("QSX_AGG_WIDE_HASH_BITS")
+    keys, vals, nulls = finalize_np(run_hip(capi, dev, cfg, cols), dev)
+    assert keys[0].size == 40
+
+
+def test_wide_group_key_limits(capi):
+    """Every key word costs two accumulators of the state: what does not fit is refused at creation."""
+    layout = [(T.LONG, None)] * 4 + [(T.DOUBLE, None)]
+    with pytest.raises(capi.QsxError):     # 32 bytes: four words
+        capi.AggState(T.make_agg_config(T.AGG_GENERIC, layout, keys=[0, 1, 2, 3], aggs=[(T.AGG_COUNT_STAR, None)], est_groups=8))
+    with pytest.raises(capi.QsxError):     # three words + three more accumulators > 8
+        capi.AggState(T.make_agg_config(T.AGG_GENERIC, layout, keys=[0, 1, 2],
+                                        aggs=[(T.AGG_SUM, T.col(4)), (T.AGG_MIN, T.col(4)), (T.AGG_MAX, T.col(4))], est_groups=8))
+    capi.AggState(T.make_agg_config(T.AGG_GENERIC, layout, keys=[0, 1, 2], aggs=[(T.AGG_SUM, T.col(4)), (T.AGG_COUNT_STAR, None)],
+                                    est_groups=8)).close()
