@@ -50,15 +50,21 @@ typedef enum qsx_status {
 } qsx_status_t;
 
 /* Value types; numbering follows types/TypeID.hpp:32-43 (kInt, kLong, kFloat,
- * kDouble, kChar) so a reference TypeID can be passed through unchanged.
- * QSX_CHAR columns are fixed-width byte strings of 1, 2, 4 or 8 bytes and are
- * only legal as group-by key components (compact-key packing). */
+ * kDouble, kChar, kVarChar, kDate) so a reference TypeID can be passed through unchanged.
+ * QSX_CHAR columns are fixed-width byte strings; 1, 2, 4 or 8 bytes wide they are legal as
+ * group-by key components (compact-key packing), any width as the left side of
+ * qsx_select_cmp_char.
+ * QSX_DATE values are the reference's 8-byte DateLit {int32 year; uint8 month; uint8 day;
+ * 2 bytes of padding} (types/DatetimeLit.hpp:38-43), compared year, month, day
+ * (:65-90); the padding bytes are never looked at.  Legal in qsx_select_cmp[_sorted|_columns],
+ * as an aggregation state's predicate column and group-by key, and as a sort / distinct key. */
 typedef enum qsx_type {
   QSX_INT = 0,    /* int32 */
   QSX_LONG = 1,   /* int64 */
   QSX_FLOAT = 2,  /* float */
   QSX_DOUBLE = 3, /* double */
-  QSX_CHAR = 4
+  QSX_CHAR = 4,
+  QSX_DATE = 6
 } qsx_type_t;
 
 /* Comparison ids; numbering follows types/operations/comparisons/ComparisonID.hpp:36-42. */
@@ -100,7 +106,7 @@ int qsx_stream_destroy(qsx_stream_t stream);
  * from ComparisonPredicate::getAllMatches (expressions/predicate/
  * ComparisonPredicate.cpp:115-334) and StorageBlock::getMatchesForPredicate
  * (storage/StorageBlock.cpp:1053-1083).
- *   type        QSX_INT / QSX_LONG / QSX_FLOAT / QSX_DOUBLE (column and literal share it)
+ *   type        QSX_INT / QSX_LONG / QSX_FLOAT / QSX_DOUBLE / QSX_DATE (column and literal share it)
  *   col_dev     n values, densely packed (a BasicColumnStore stripe)
  *   literal     host pointer to one value of `type`
  *   filter_dev  optional existing TupleIdSequence (n bits) or NULL; only rows set
@@ -112,6 +118,17 @@ int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op,
                    const void *literal, const uint64_t *filter_dev,
                    uint64_t *out_bitmap_dev, int64_t *out_count_dev,
                    qsx_stream_t stream);
+
+/* K1 on a CHAR(width) attribute: out_bitmap[i] = (col[i] OP literal) [AND filter[i]] with the reference's string
+ * comparison — both sides are C strings that end at their first NUL byte or at their maximum length, compared byte
+ * by byte as unsigned chars, a proper prefix being smaller (AsciiStringUncheckedComparator::strcmpHelper,
+ * types/operations/comparisons/AsciiStringComparators.hpp:218-251).
+ *   col_dev      n values of `width` bytes each (1..255), densely packed (a column-store stripe of a CHAR(width) attribute)
+ *   literal      host pointer to literal_length (0..64) bytes; a NUL inside ends the literal
+ * Other arguments as qsx_select_cmp.  (TPC-H: c_mktsegment = 'BUILDING', l_shipmode IN (...), ...) */
+#define QSX_MAX_CHAR_LITERAL 64
+int qsx_select_cmp_char(const void *col_dev, int width, int64_t n, int op, const void *literal, int literal_length,
+                        const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev, qsx_stream_t stream);
 
 /* qsx_select_cmp on the SORT COLUMN of a sorted column store (ascending, no NULLs in the first n rows): the matches are
  * one row range found by two searches, not a scan.  Replaces SortColumnPredicateEvaluator::
@@ -409,7 +426,7 @@ typedef struct qsx_agg_desc {
 typedef struct qsx_pred_term {
   int32_t column;
   int32_t op;           /* qsx_cmp_t */
-  union { int32_t i32; int64_t i64; float f32; double f64; } literal; /* typed like the column */
+  union { int32_t i32; int64_t i64; float f32; double f64; } literal; /* typed like the column (QSX_DATE: the 8 DateLit bytes in i64) */
 } qsx_pred_term_t;
 
 #define QSX_MAX_COLUMNS 16

@@ -53,6 +53,7 @@ for _name, _res, _args in [
     ("qso_partition_id", _u64, [_u64, _u64]),
     ("qso_select_cmp", None, [_int, _vp, _i64, _int, _vp, _vp, _vp]),
     ("qso_select_cmp_sorted", None, [_int, _vp, _i64, _int, _vp, _vp, _vp]),
+    ("qso_select_cmp_char", None, [_vp, _int, _i64, _int, C.c_char_p, _int, _vp, _vp]),
     ("qso_bitmap_count", _i64, [_vp, _i64]),
     ("qso_compact_gather", _i64, [_int, _vp, _vp, _i64, _vp]),
     ("qso_bitmap_to_tids", _i64, [_vp, _i64, _i32, _vp]),
@@ -160,20 +161,35 @@ def ref_combine_hashes(pairs):
 
 
 # ---- select --------------------------------------------------------------------
-def select_cmp(col, op, literal, filter_bitmap=None):
+def _literal(qt, literal):
+    return C.c_int64(literal) if qt == T.DATE else _C_SCALAR[qt](literal)
+
+
+def select_cmp(col, op, literal, filter_bitmap=None, qt=None):
+    """qt=T.DATE: col holds raw DateLit bytes as int64, literal = T.date_raw(...)."""
     n = col.size
     out = np.zeros(max(words(n), 1), dtype=np.uint64)
-    lit = _C_SCALAR[qtype(col)](literal)
-    _lib.qso_select_cmp(qtype(col), _p(col), n, op, C.byref(lit), _p(filter_bitmap), _p(out))
+    qt = qtype(col) if qt is None else qt
+    lit = _literal(qt, literal)
+    _lib.qso_select_cmp(qt, _p(col), n, op, C.byref(lit), _p(filter_bitmap), _p(out))
     return out
 
 
-def select_cmp_sorted(col, op, literal, filter_bitmap=None):
+def select_cmp_char(col, op, literal, filter_bitmap=None):
+    """CHAR(width) column (uint8 array of shape (n, width)) OP literal (bytes): strcmpHelper semantics."""
+    n, width = col.shape
+    out = np.zeros(max(words(n), 1), dtype=np.uint64)
+    _lib.qso_select_cmp_char(_p(col), width, n, op, C.c_char_p(literal), len(literal), _p(filter_bitmap), _p(out))
+    return out
+
+
+def select_cmp_sorted(col, op, literal, filter_bitmap=None, qt=None):
     """The same predicate evaluated by binary search on a sorted stripe (SortColumnPredicateEvaluator)."""
     n = col.size
     out = np.zeros(max(words(n), 1), dtype=np.uint64)
-    lit = _C_SCALAR[qtype(col)](literal)
-    _lib.qso_select_cmp_sorted(qtype(col), _p(col), n, op, C.byref(lit), _p(filter_bitmap), _p(out))
+    qt = qtype(col) if qt is None else qt
+    lit = _literal(qt, literal)
+    _lib.qso_select_cmp_sorted(qt, _p(col), n, op, C.byref(lit), _p(filter_bitmap), _p(out))
     return out
 
 
@@ -303,9 +319,9 @@ class CompositeJoinTable:
         return np.array([_lib.qso_cjoin_hash_row(self._h, ptrs, i) for i in range(keep[0].size)], dtype=np.uint64)
 
 
-def select_cmp_columns(lhs, rhs, op, filter_bitmap=None):
+def select_cmp_columns(lhs, rhs, op, filter_bitmap=None, qt=None):
     out = np.zeros(max(words(lhs.size), 1), dtype=np.uint64)
-    _lib.qso_select_cmp_columns(_NP_TYPE[lhs.dtype], _p(lhs), _p(rhs), lhs.size, op, _p(filter_bitmap), _p(out))
+    _lib.qso_select_cmp_columns(_NP_TYPE[lhs.dtype] if qt is None else qt, _p(lhs), _p(rhs), lhs.size, op, _p(filter_bitmap), _p(out))
     return out
 
 
@@ -371,24 +387,24 @@ def select_codes(codes, op, first, second=0, filter_bitmap=None):
     return out
 
 
-def sort_permutation(key_cols, descending=None):
+def sort_permutation(key_cols, descending=None, types=None):
     """ORDER BY key_cols[0], key_cols[1], ...: stable, comparator semantics of SortConfiguration."""
     keep = [np.ascontiguousarray(c) for c in key_cols]
     n = keep[0].size
     ptrs = (C.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
-    types = (C.c_int32 * len(keep))(*[_NP_TYPE[c.dtype] for c in keep])
+    types = (C.c_int32 * len(keep))(*(types if types is not None else [_NP_TYPE[c.dtype] for c in keep]))
     desc = (C.c_int32 * len(keep))(*[1 if (descending and descending[i]) else 0 for i in range(len(keep))])
     out = np.zeros(max(n, 1), dtype=np.int32)
     _lib.qso_sort_permutation(len(keep), ptrs, types, desc, n, _p(out))
     return out[:n]
 
 
-def distinct_rows(cols, filter_bitmap=None):
+def distinct_rows(cols, filter_bitmap=None, types=None):
     """Row numbers of the first occurrence of every distinct tuple, in tuple order (the distinctify table)."""
     keep = [np.ascontiguousarray(c) for c in cols]
     n = keep[0].size
     ptrs = (C.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
-    types = (C.c_int32 * len(keep))(*[_NP_TYPE[c.dtype] for c in keep])
+    types = (C.c_int32 * len(keep))(*(types if types is not None else [_NP_TYPE[c.dtype] for c in keep]))
     out = np.zeros(max(n, 1), dtype=np.int32)
     count = _lib.qso_distinct_rows(len(keep), ptrs, types, n, _p(filter_bitmap), _p(out))
     return out[:count]

@@ -68,6 +68,9 @@ inline std::uint64_t hash_typed(int type, const void *p) {
     case QSX_LONG: { std::int64_t v; std::memcpy(&v, p, 8); return hash_long(v); }
     case QSX_FLOAT: { float v; std::memcpy(&v, p, 4); return hash_float(v); }
     case QSX_DOUBLE: { double v; std::memcpy(&v, p, 8); return hash_double(v); }
+    // a DATE hashes as the 8 bytes of its TypedValue (getHashScalarLiteral, TypedValue.hpp:575-592, 916-918); the padding
+    // bytes of the DateLit are taken as zero
+    case QSX_DATE: { std::uint64_t v; std::memcpy(&v, p, 8); return v & 0x0000FFFFFFFFFFFFull; }
     default: std::abort();
   }
 }
@@ -75,7 +78,7 @@ inline std::uint64_t hash_typed(int type, const void *p) {
 inline int type_width(int type) {
   switch (type) {
     case QSX_INT: case QSX_FLOAT: return 4;
-    case QSX_LONG: case QSX_DOUBLE: return 8;
+    case QSX_LONG: case QSX_DOUBLE: case QSX_DATE: return 8;
     default: return 0;
   }
 }
@@ -133,6 +136,42 @@ inline bool compare(T a, int op, T b) {
     case QSX_GE: return a >= b;
     default: return false;
   }
+}
+
+// DateLit (types/DatetimeLit.hpp:38-90): {int32 year; uint8 month, day} in 8 bytes, ordered by year, then month, then
+// day; the two padding bytes take no part in anything.
+struct DateLit {
+  std::int32_t year;
+  std::uint8_t month, day;
+  std::uint8_t padding[2];
+  bool operator<(const DateLit &r) const { return year != r.year ? year < r.year : (month != r.month ? month < r.month : day < r.day); }
+  bool operator>(const DateLit &r) const { return r < *this; }
+  bool operator<=(const DateLit &r) const { return !(*this > r); }
+  bool operator>=(const DateLit &r) const { return !(*this < r); }
+  bool operator==(const DateLit &r) const { return year == r.year && month == r.month && day == r.day; }
+  bool operator!=(const DateLit &r) const { return !(*this == r); }
+};
+static_assert(sizeof(DateLit) == 8, "DateLit occupies 8 bytes of a column stripe");
+inline DateLit date_at(const void *col, std::int64_t i) {
+  DateLit d;
+  std::memcpy(&d, static_cast<const char *>(col) + i * 8, 8);
+  return d;
+}
+constexpr std::uint64_t kDateValueMask = 0x0000FFFFFFFFFFFFull;
+
+// AsciiStringUncheckedComparator::strcmpHelper (types/operations/comparisons/AsciiStringComparators.hpp:218-251) for a
+// CHAR(left_length) value against a literal of right_length bytes, neither necessarily NUL-terminated.
+inline int strcmp_helper(const char *left, std::size_t left_length, const char *right, std::size_t right_length) {
+  if (right_length > left_length) {
+    const int res = std::strncmp(left, right, left_length);
+    if (res) return res;
+    return strnlen(right, right_length) > left_length ? -1 : res;
+  } else if (left_length > right_length) {
+    const int res = std::strncmp(left, right, right_length);
+    if (res) return res;
+    return strnlen(left, left_length) > right_length ? 1 : res;
+  }
+  return std::strncmp(left, right, left_length);
 }
 
 template <typename T>
@@ -361,7 +400,23 @@ void qso_select_cmp(int type, const void *col, int64_t n, int op, const void *li
       select_cmp_t<double>(static_cast<const double *>(col), n, op, lit, filter, out_bitmap);
       break;
     }
+    case QSX_DATE: {
+      DateLit lit; std::memcpy(&lit, literal, 8);
+      select_cmp_t<DateLit>(static_cast<const DateLit *>(col), n, op, lit, filter, out_bitmap);
+      break;
+    }
     default: std::abort();
+  }
+}
+
+void qso_select_cmp_char(const void *col, int width, int64_t n, int op, const void *literal, int literal_length,
+                         const uint64_t *filter, uint64_t *out_bitmap) {
+  std::memset(out_bitmap, 0, sizeof(uint64_t) * bitmap_words(n));
+  for (int64_t i = 0; i < n; ++i) {
+    if (filter != nullptr && !bit_get(filter, i)) continue;
+    const int res = strcmp_helper(static_cast<const char *>(col) + i * width, static_cast<std::size_t>(width),
+                                  static_cast<const char *>(literal), static_cast<std::size_t>(literal_length));
+    if (compare<int>(res, op, 0)) bit_set(out_bitmap, i);
   }
 }
 
@@ -372,6 +427,7 @@ void qso_select_cmp_sorted(int type, const void *col, int64_t n, int op, const v
     case QSX_LONG: { std::int64_t lit; std::memcpy(&lit, literal, 8); select_cmp_sorted_t(static_cast<const std::int64_t *>(col), n, op, lit, filter, out_bitmap); break; }
     case QSX_FLOAT: { float lit; std::memcpy(&lit, literal, 4); select_cmp_sorted_t(static_cast<const float *>(col), n, op, lit, filter, out_bitmap); break; }
     case QSX_DOUBLE: { double lit; std::memcpy(&lit, literal, 8); select_cmp_sorted_t(static_cast<const double *>(col), n, op, lit, filter, out_bitmap); break; }
+    case QSX_DATE: { DateLit lit; std::memcpy(&lit, literal, 8); select_cmp_sorted_t(static_cast<const DateLit *>(col), n, op, lit, filter, out_bitmap); break; }
     default: std::abort();
   }
 }
@@ -603,6 +659,7 @@ void qso_select_cmp_columns(int type, const void *lhs, const void *rhs, int64_t 
       case QSX_INT: r = compare<std::int32_t>(static_cast<const std::int32_t *>(lhs)[i], op, static_cast<const std::int32_t *>(rhs)[i]); break;
       case QSX_LONG: r = compare<std::int64_t>(static_cast<const std::int64_t *>(lhs)[i], op, static_cast<const std::int64_t *>(rhs)[i]); break;
       case QSX_FLOAT: r = compare<float>(static_cast<const float *>(lhs)[i], op, static_cast<const float *>(rhs)[i]); break;
+      case QSX_DATE: r = compare<DateLit>(date_at(lhs, i), op, date_at(rhs, i)); break;
       default: r = compare<double>(static_cast<const double *>(lhs)[i], op, static_cast<const double *>(rhs)[i]); break;
     }
     if (r) bit_set(out_bitmap, i);
@@ -776,6 +833,7 @@ struct RowReader {
         case QSX_LONG: ok = compare<std::int64_t>(static_cast<const std::int64_t *>(cols[p.column])[i], p.op, p.literal.i64); break;
         case QSX_FLOAT: ok = compare<float>(static_cast<const float *>(cols[p.column])[i], p.op, p.literal.f32); break;
         case QSX_DOUBLE: ok = compare<double>(static_cast<const double *>(cols[p.column])[i], p.op, p.literal.f64); break;
+        case QSX_DATE: { DateLit lit; std::memcpy(&lit, &p.literal.i64, 8); ok = compare<DateLit>(date_at(cols[p.column], i), p.op, lit); break; }
         default: std::abort();
       }
       if (!ok) return false;
@@ -791,7 +849,7 @@ struct RowReader {
       const int col = c.key_column[k];
       const int w = c.column_width[col];
       std::memcpy(reinterpret_cast<char *>(&code) + offset,
-                  static_cast<const char *>(cols[col]) + i * w, w);
+                  static_cast<const char *>(cols[col]) + i * w, c.column_type[col] == QSX_DATE ? 6 : w);   // not the padding of a DateLit
       offset += w;
     }
     return code;
@@ -804,7 +862,7 @@ struct RowReader {
     for (int k = 0; k < c.num_keys; ++k) {
       const int col = c.key_column[k];
       const int w = c.column_width[col];
-      std::memcpy(reinterpret_cast<char *>(key.w) + offset, static_cast<const char *>(cols[col]) + i * w, w);
+      std::memcpy(reinterpret_cast<char *>(key.w) + offset, static_cast<const char *>(cols[col]) + i * w, c.column_type[col] == QSX_DATE ? 6 : w);
       offset += w;
     }
     return key;
@@ -1690,6 +1748,7 @@ void qso_sort_permutation(int nkeys, const void *const *key_cols, const int32_t 
         case QSX_LONG: { const auto *c = static_cast<const std::int64_t *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
         case QSX_FLOAT: { const auto *c = static_cast<const float *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
         case QSX_CHAR: { const auto *c = static_cast<const std::uint8_t *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        case QSX_DATE: { const DateLit x = date_at(key_cols[k], a), y = date_at(key_cols[k], b); cmp = x < y ? -1 : (x > y ? 1 : 0); break; }
         default: { const auto *c = static_cast<const double *>(key_cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
       }
       if (descending != nullptr && descending[k]) cmp = -cmp;
@@ -1715,6 +1774,7 @@ int64_t qso_distinct_rows(int ncols, const void *const *cols, const int32_t *typ
         case QSX_LONG: { const auto *c = static_cast<const std::int64_t *>(cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
         case QSX_FLOAT: { const auto *c = static_cast<const float *>(cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
         case QSX_CHAR: { const auto *c = static_cast<const std::uint8_t *>(cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
+        case QSX_DATE: { const DateLit x = date_at(cols[k], a), y = date_at(cols[k], b); cmp = x < y ? -1 : (x > y ? 1 : 0); break; }
         default: { const auto *c = static_cast<const double *>(cols[k]); cmp = c[a] < c[b] ? -1 : (c[a] > c[b] ? 1 : 0); break; }
       }
       if (cmp != 0) return cmp;

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "qsx_stream_destroy": (_int, [_vp]),
     "qsx_select_cmp": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "qsx_select_cmp_sorted": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "qsx_select_cmp_char": (_int, [_vp, _int, _i64, _int, C.c_char_p, _int, _vp, _vp, _vp, _vp]),
     "qsx_select_cmp_columns": (_int, [_int, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "qsx_select_codes": (_int, [_int, _vp, _i64, _int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "qsx_decode_codes": (_int, [_int, _vp, _i64, _vp, _int, _vp, _vp]),
@@ -163,11 +164,16 @@ def _ptr_array(tensors):
 
 
 # --------------------------------------------------------------------------- select
-def select_cmp(col, op, literal, filter_bitmap=None, out_bitmap=None, out_count=None, stream=None):
-    """K1: returns (bitmap int64[ceil(n/64)] MSB-first, count int64[1]) device tensors."""
+def _literal(qt, literal):
+    return C.c_int64(literal) if qt == T.DATE else _C_SCALAR[qt](literal)
+
+
+def select_cmp(col, op, literal, filter_bitmap=None, out_bitmap=None, out_count=None, stream=None, qtype=None):
+    """K1: returns (bitmap int64[ceil(n/64)] MSB-first, count int64[1]) device tensors.  qtype=T.DATE: col is an int64
+    tensor of raw DateLit bytes, literal = T.date_raw(...)."""
     n = col.numel()
-    qt = qsx_type_of(col)
-    lit = _C_SCALAR[qt](literal)
+    qt = qsx_type_of(col) if qtype is None else qtype
+    lit = _literal(qt, literal)
     if out_bitmap is None:
         out_bitmap = new_bitmap(n, col.device)
     if out_count is None:
@@ -177,11 +183,22 @@ def select_cmp(col, op, literal, filter_bitmap=None, out_bitmap=None, out_count=
     return out_bitmap, out_count
 
 
-def select_cmp_sorted(col, op, literal, filter_bitmap=None, stream=None):
+def select_cmp_char(col, op, literal, filter_bitmap=None, stream=None):
+    """K1 on a CHAR(width) stripe: col is a uint8 tensor of shape (n, width), literal a bytes object."""
+    n, width = col.shape
+    assert col.dtype == torch.uint8 and col.is_contiguous()
+    out_bitmap = new_bitmap(n, col.device)
+    out_count = torch.zeros(1, dtype=torch.int64, device=col.device)
+    _check(_lib.qsx_select_cmp_char(_ptr(col), width, n, op, C.c_char_p(literal), len(literal), _ptr(filter_bitmap), _ptr(out_bitmap),
+                                    _ptr(out_count), _stream(stream)), "qsx_select_cmp_char")
+    return out_bitmap, out_count
+
+
+def select_cmp_sorted(col, op, literal, filter_bitmap=None, stream=None, qtype=None):
     """K1 on the sort column of a sorted column store (binary search): same result surface as select_cmp."""
     n = col.numel()
-    qt = qsx_type_of(col)
-    lit = _C_SCALAR[qt](literal)
+    qt = qsx_type_of(col) if qtype is None else qtype
+    lit = _literal(qt, literal)
     out_bitmap = new_bitmap(n, col.device)
     out_count = torch.zeros(1, dtype=torch.int64, device=col.device)
     _check(_lib.qsx_select_cmp_sorted(qt, _ptr(col), n, op, C.byref(lit), _ptr(filter_bitmap), _ptr(out_bitmap),
@@ -189,13 +206,13 @@ def select_cmp_sorted(col, op, literal, filter_bitmap=None, stream=None):
     return out_bitmap, out_count
 
 
-def select_cmp_columns(lhs, rhs, op, filter_bitmap=None, stream=None):
+def select_cmp_columns(lhs, rhs, op, filter_bitmap=None, stream=None, qtype=None):
     """K1, attribute OP attribute: returns (bitmap, count) like select_cmp."""
     n = lhs.numel()
     assert rhs.numel() == n and rhs.dtype == lhs.dtype
     out_bitmap = new_bitmap(n, lhs.device)
     out_count = torch.zeros(1, dtype=torch.int64, device=lhs.device)
-    _check(_lib.qsx_select_cmp_columns(qsx_type_of(lhs), _ptr(lhs), _ptr(rhs), n, op, _ptr(filter_bitmap),
+    _check(_lib.qsx_select_cmp_columns(qsx_type_of(lhs) if qtype is None else qtype, _ptr(lhs), _ptr(rhs), n, op, _ptr(filter_bitmap),
                                        _ptr(out_bitmap), _ptr(out_count), _stream(stream)), "qsx_select_cmp_columns")
     return out_bitmap, out_count
 
@@ -268,14 +285,14 @@ def join_key_pack(cols, stream=None):
     n = cols[0].numel()
     out = torch.empty(n, dtype=torch.int64, device=cols[0].device)
     ptrs = (C.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
-    types = (C.c_int32 * len(cols))(*[qsx_type_of(c) for c in cols])
+    types = (C.c_int32 * len(cols))(*(types if types is not None else [qsx_type_of(c) for c in cols]))
     exact = C.c_int(0)
     _check(_lib.qsx_join_key_pack(len(cols), ptrs, types, n, _ptr(out), C.byref(exact), _stream(stream)),
            "qsx_join_key_pack")
     return out, bool(exact.value)
 
 
-def sort_permutation(key_cols, descending=None, stream=None):
+def sort_permutation(key_cols, descending=None, stream=None, types=None):
     """ORDER BY key_cols[0], key_cols[1], ... -> int32 row numbers in output order (stable)."""
     n = key_cols[0].numel()
     device = key_cols[0].device
@@ -283,14 +300,14 @@ def sort_permutation(key_cols, descending=None, stream=None):
     ws_bytes = _lib.qsx_sort_workspace_bytes(n)
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
     ptrs = (C.c_void_p * len(key_cols))(*[c.data_ptr() for c in key_cols])
-    types = (C.c_int32 * len(key_cols))(*[qsx_type_of(c) for c in key_cols])
+    types = (C.c_int32 * len(key_cols))(*(types if types is not None else [qsx_type_of(c) for c in key_cols]))
     desc = (C.c_int32 * len(key_cols))(*[1 if (descending and descending[i]) else 0 for i in range(len(key_cols))])
     _check(_lib.qsx_sort_permutation(len(key_cols), ptrs, types, desc, n, _ptr(out), _ptr(ws), ws_bytes, _stream(stream)),
            "qsx_sort_permutation")
     return out[:n]
 
 
-def distinct_rows(cols, filter_bitmap=None, stream=None):
+def distinct_rows(cols, filter_bitmap=None, stream=None, types=None):
     """First row of every distinct tuple over cols (restricted to filter_bitmap), in tuple order."""
     n = cols[0].numel()
     device = cols[0].device
@@ -299,13 +316,13 @@ def distinct_rows(cols, filter_bitmap=None, stream=None):
     ws_bytes = _lib.qsx_sort_workspace_bytes(n)
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
     ptrs = (C.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
-    types = (C.c_int32 * len(cols))(*[qsx_type_of(c) for c in cols])
+    types = (C.c_int32 * len(cols))(*(types if types is not None else [qsx_type_of(c) for c in cols]))
     _check(_lib.qsx_distinct_rows(len(cols), ptrs, types, n, _ptr(filter_bitmap), _ptr(out), _ptr(count), _ptr(ws), ws_bytes,
                                   _stream(stream)), "qsx_distinct_rows")
     return out[:int(count.item())]
 
 
-def sort_top_k(key_cols, k, descending=None, stream=None):
+def sort_top_k(key_cols, k, descending=None, stream=None, types=None):
     """ORDER BY ... LIMIT k -> the first min(k, n) row numbers of sort_permutation's output."""
     n = key_cols[0].numel()
     k = min(int(k), n)
@@ -314,7 +331,7 @@ def sort_top_k(key_cols, k, descending=None, stream=None):
     ws_bytes = _lib.qsx_sort_workspace_bytes(n)
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
     ptrs = (C.c_void_p * len(key_cols))(*[c.data_ptr() for c in key_cols])
-    types = (C.c_int32 * len(key_cols))(*[qsx_type_of(c) for c in key_cols])
+    types = (C.c_int32 * len(key_cols))(*(types if types is not None else [qsx_type_of(c) for c in key_cols]))
     desc = (C.c_int32 * len(key_cols))(*[1 if (descending and descending[i]) else 0 for i in range(len(key_cols))])
     _check(_lib.qsx_sort_top_k(len(key_cols), ptrs, types, desc, n, k, _ptr(out), _ptr(ws), ws_bytes, _stream(stream)),
            "qsx_sort_top_k")

@@ -291,6 +291,10 @@ __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *ti
           ok = compare_op<float>(reinterpret_cast<const float *>(base)[r], term.op,
                                  __uint_as_float(static_cast<uint32_t>(term.literal)));
           break;
+        case QSX_DATE:   // year, month, day (types/DatetimeLit.hpp:65-90)
+          ok = compare_op<long long>(date_ordered(reinterpret_cast<const unsigned long long *>(base)[r]), term.op,
+                                     date_ordered(term.literal));
+          break;
         default:
           ok = compare_op<double>(reinterpret_cast<const double *>(base)[r], term.op,
                                   __longlong_as_double(static_cast<long long>(term.literal)));
@@ -315,6 +319,7 @@ __device__ __forceinline__ unsigned long long key_word_of(const DevConfig &c, co
         case 4: x = reinterpret_cast<const uint32_t *>(base)[r]; break;
         default: x = reinterpret_cast<const unsigned long long *>(base)[r]; break;
       }
+      if (c.column_type[c.key_column[k]] == QSX_DATE) x &= kDateValueMask;   // the padding bytes of a DateLit are not part of the key
       word |= x << c.key_shift[k];
     }
   }
@@ -351,6 +356,7 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
         case 4: x = reinterpret_cast<const uint32_t *>(base)[r]; break;
         default: x = reinterpret_cast<const unsigned long long *>(base)[r]; break;
       }
+      if (c.column_type[c.key_column[k]] == QSX_DATE) x &= kDateValueMask;
       code[v] |= x << c.key_shift[k];
     }
   });
@@ -366,7 +372,10 @@ __device__ __forceinline__ long long key_field(const DevConfig &c, const char *t
     case 4:
       return c.column_type[c.key_column[k]] == QSX_INT ? static_cast<long long>(reinterpret_cast<const int32_t *>(base)[r])
                                                        : static_cast<long long>(reinterpret_cast<const uint32_t *>(base)[r]);
-    default: return reinterpret_cast<const long long *>(base)[r];
+    default:
+      return c.column_type[c.key_column[k]] == QSX_DATE
+                 ? static_cast<long long>(reinterpret_cast<const unsigned long long *>(base)[r] & kDateValueMask)
+                 : reinterpret_cast<const long long *>(base)[r];
   }
 }
 

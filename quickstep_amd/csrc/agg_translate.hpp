@@ -46,7 +46,7 @@ struct Translated {
 };
 
 constexpr int type_width_ce(int type) {
-  return (type == QSX_INT || type == QSX_FLOAT) ? 4 : ((type == QSX_LONG || type == QSX_DOUBLE) ? 8 : 0);
+  return (type == QSX_INT || type == QSX_FLOAT) ? 4 : ((type == QSX_LONG || type == QSX_DOUBLE || type == QSX_DATE) ? 8 : 0);
 }
 
 constexpr bool valid_operand(const qsx_agg_config_t &c, const qsx_operand_t &o, int defined_temps_mask) {
@@ -88,7 +88,7 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
     d.column_width[i] = w;
     const int cw = c.column_code_width[i];
     if (cw != 0) {   // compressed attribute: 1 / 2 / 4-byte codes of a numeric column
-      if ((cw != 1 && cw != 2 && cw != 4) || ty == QSX_CHAR) return fail(t, QSX_ERR_UNSUPPORTED);
+      if ((cw != 1 && cw != 2 && cw != 4) || ty == QSX_CHAR) return fail(t, QSX_ERR_UNSUPPORTED);   // (a DATE always has a dictionary)
       d.code_width[i] = cw;
     }
   }
@@ -264,6 +264,7 @@ constexpr Translated translate(const qsx_agg_config_t &c) {
       case QSX_LONG: bits = static_cast<unsigned long long>(term.literal.i64); break;
       case QSX_FLOAT: bits = __builtin_bit_cast(uint32_t, term.literal.f32); break;
       case QSX_DOUBLE: bits = __builtin_bit_cast(unsigned long long, term.literal.f64); break;
+      case QSX_DATE: bits = static_cast<unsigned long long>(term.literal.i64); break;   // the DateLit bytes
       default: return fail(t, QSX_ERR_UNSUPPORTED);
     }
     d.pred[p].literal = bits;

@@ -452,6 +452,7 @@ constexpr size_t kDirControlBytes = 16 + sizeof(unsigned long long) * 2 * QSX_MA
 struct qsx_agg_state {
   qsx_agg_config_t config;
   bool has_coded_columns = false;   // some column arrives as codes of a compressed attribute
+  bool has_date_key = false;        // a group-by key is a DATE: its padding bytes are masked when the key is packed
   // run-time plan shapes asked for, owned by the cache: index = (filter ? 1 : 0) + (partitioned input ? 2 : 0)
   JitRequest *jit_request[kJitVariants] = {};
   JitGeometry jit_geometry[kJitVariants] = {};
@@ -591,6 +592,7 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
   }
   st->used_columns = t.used_columns;
   for (int i = 0; i < t.dev.num_columns; ++i) st->has_coded_columns = st->has_coded_columns || t.dev.code_width[i] != 0;
+  for (int k = 0; k < t.dev.num_keys; ++k) st->has_date_key = st->has_date_key || t.dev.column_type[t.dev.key_column[k]] == QSX_DATE;
   st->dense = t.dense;
   st->dense_has_count = t.dense_has_count;
   return QSX_OK;
@@ -1650,7 +1652,7 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
   // (and so do states over nullable columns: a null bitmap cannot be scattered like a value column)
   // (and states with a wide key: K9 packs the key code itself, it does not know the hashed form)
   if (!st->dense && st->part_count > 1 && filter_dev == nullptr && !st->has_coded_columns && st->dev.num_null_cols == 0 &&
-      st->dev.wide_words == 0 && n >= partition_min_rows()) {
+      st->dev.wide_words == 0 && !st->has_date_key && n >= partition_min_rows()) {
     rc = update_partitioned(st, cols, n, s);
   } else {
     rc = update_slice(st, cols, dicts, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s, nulls);

@@ -51,7 +51,7 @@ inline int grid_for(int64_t work_items, int items_per_block) {
 inline int type_width(int type) {
   switch (type) {
     case QSX_INT: case QSX_FLOAT: return 4;
-    case QSX_LONG: case QSX_DOUBLE: return 8;
+    case QSX_LONG: case QSX_DOUBLE: case QSX_DATE: return 8;
     default: return 0;
   }
 }

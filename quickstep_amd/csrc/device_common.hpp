@@ -39,6 +39,25 @@ __device__ __forceinline__ uint64_t wave_broadcast_first(uint64_t v) {
   return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
+// QSX_DATE: the reference's DateLit {int32 year; uint8 month; uint8 day; 2 bytes of padding}
+// (types/DatetimeLit.hpp:38-43) as the 8 bytes it occupies in a column stripe.  Ordered by year, month, day (:65-90);
+// the padding is never looked at.
+__host__ __device__ constexpr long long date_ordered(unsigned long long raw) {
+  return static_cast<long long>(static_cast<int>(raw & 0xFFFFFFFFull)) * 65536 +
+         static_cast<long long>(((raw >> 32) & 0xFFull) << 8 | ((raw >> 40) & 0xFFull));
+}
+constexpr unsigned long long kDateValueMask = 0x0000FFFFFFFFFFFFull;   // year, month, day
+struct DateValue {
+  unsigned long long raw;
+  __host__ __device__ constexpr long long key() const { return date_ordered(raw); }
+  __host__ __device__ constexpr bool operator==(const DateValue &o) const { return key() == o.key(); }
+  __host__ __device__ constexpr bool operator!=(const DateValue &o) const { return key() != o.key(); }
+  __host__ __device__ constexpr bool operator<(const DateValue &o) const { return key() < o.key(); }
+  __host__ __device__ constexpr bool operator<=(const DateValue &o) const { return key() <= o.key(); }
+  __host__ __device__ constexpr bool operator>(const DateValue &o) const { return key() > o.key(); }
+  __host__ __device__ constexpr bool operator>=(const DateValue &o) const { return key() >= o.key(); }
+};
+
 template <typename T>
 __device__ __forceinline__ bool compare_op(T a, int op, T b) {
   switch (op) {

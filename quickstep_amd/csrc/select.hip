@@ -681,6 +681,78 @@ static int launch_select_packed(const void *col, int64_t n, Pred pred, const uin
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---------------------------------------------------------------------------
+// K1 on a CHAR(width) stripe (qsx_select_cmp_char): a tile of tile_rows x width bytes is copied to LDS with 16-byte
+// reads (a row per lane straight from HBM would read `width`-strided bytes), then every lane compares its row with the
+// literal the way AsciiStringUncheckedComparator::strcmpHelper does (AsciiStringComparators.hpp:218-251): C strings
+// ending at the first NUL or at their maximum length, unsigned bytes, a proper prefix is smaller.
+// ---------------------------------------------------------------------------
+struct CharLiteral {
+  unsigned char bytes[QSX_MAX_CHAR_LITERAL];
+  int length;   // bytes before the first NUL
+};
+__global__ __launch_bounds__(kBlock) void select_char_kernel(const unsigned char *__restrict__ col, int width, int64_t n, int op,
+                                                            CharLiteral lit, const uint64_t *__restrict__ filter,
+                                                            uint64_t *__restrict__ out, unsigned long long *__restrict__ out_count,
+                                                            int tile_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_tile[];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t num_tiles = (n + tile_rows - 1) / tile_rows;
+  unsigned long long count = 0;
+  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * tile_rows;
+    const int rows = static_cast<int>(n - row0 < tile_rows ? n - row0 : tile_rows);
+    const unsigned char *src = col + row0 * width;
+    const int bytes = rows * width;
+    __syncthreads();   // every wave is done with the previous tile
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const int full = bytes & ~15;
+      for (int o = threadIdx.x * 16; o < full; o += kBlock * 16) {
+        *reinterpret_cast<uint4 *>(s_tile + o) = *reinterpret_cast<const uint4 *>(src + o);
+      }
+      for (int o = full + threadIdx.x; o < bytes; o += kBlock) s_tile[o] = src[o];
+    } else {
+      for (int o = threadIdx.x; o < bytes; o += kBlock) s_tile[o] = src[o];
+    }
+    __syncthreads();
+    for (int w = wave; w * 64 < rows; w += kWavesPerBlock) {
+      const int r = w * 64 + lane;
+      bool pred = false;
+      if (r < rows) {
+        const unsigned char *v = s_tile + r * width;
+        int res = 0;
+        const int longest = width > lit.length ? width : lit.length;
+        for (int i = 0; i < longest; ++i) {
+          const unsigned char a = i < width ? v[i] : 0;
+          const unsigned char b = i < lit.length ? lit.bytes[i] : 0;
+          if (a != b) {
+            res = a < b ? -1 : 1;
+            break;
+          }
+          if (a == 0) break;
+        }
+        pred = compare_op<int>(res, op, 0);
+      }
+      uint64_t word = msb_first(__ballot(pred));
+      const int64_t word_index = (row0 >> 6) + w;
+      if (filter != nullptr) word &= filter[word_index];
+      if (lane == 0) {
+        out[word_index] = word;
+        count += __popcll(word);
+      }
+    }
+  }
+  if (out_count != nullptr) {
+    __shared__ unsigned long long block_count;
+    if (threadIdx.x == 0) block_count = 0;
+    __syncthreads();
+    if (lane == 0 && count != 0) atomicAdd(&block_count, count);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_count != 0) atomicAdd(out_count, block_count);
+  }
+}
+
 // Decode a code stripe: dictionary lookup (codes index a dictionary of `value_width`-byte values that
 // stays in L2 / L1) or zero-extension of a truncated value.
 template <typename C, typename V>
@@ -730,6 +802,36 @@ using namespace qsx;
 
 extern "C" {
 
+int qsx_select_cmp_char(const void *col_dev, int width, int64_t n, int op, const void *literal, int literal_length,
+                        const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || width < 1 || width > 255 || literal_length < 0 || (literal_length > 0 && literal == nullptr) || op < QSX_EQ ||
+      op > QSX_GE || (n > 0 && (col_dev == nullptr || out_bitmap_dev == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (literal_length > QSX_MAX_CHAR_LITERAL) return QSX_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return QSX_OK;
+  CharLiteral lit{};
+  lit.length = 0;
+  while (lit.length < literal_length && static_cast<const unsigned char *>(literal)[lit.length] != 0) {   // a NUL ends it
+    lit.bytes[lit.length] = static_cast<const unsigned char *>(literal)[lit.length];
+    ++lit.length;
+  }
+  // rows per tile: a multiple of 64 (whole bitmap words), at most 48 KiB of LDS
+  int tile_rows = (48 * 1024 / width) / 64 * 64;
+  if (tile_rows > 1024) tile_rows = 1024;
+  if (tile_rows < 64) tile_rows = 64;
+  const int64_t tiles = (n + tile_rows - 1) / tile_rows;
+  const int grid = static_cast<int>(tiles < 4 * kCUs ? tiles : 4 * kCUs);
+  const size_t lds = (static_cast<size_t>(tile_rows) * width + 15) / 16 * 16;
+  hipLaunchKernelGGL(select_char_kernel, dim3(grid), dim3(kBlock), lds, s, static_cast<const unsigned char *>(col_dev), width, n, op,
+                     lit, filter_dev, out_bitmap_dev, reinterpret_cast<unsigned long long *>(out_count_dev), tile_rows);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
 int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op, const void *literal,
                    const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev,
                    qsx_stream_t stream) {
@@ -745,6 +847,7 @@ int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op, const void 
     case QSX_LONG: return dispatch_select_op<int64_t>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
     case QSX_FLOAT: return dispatch_select_op<float>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
     case QSX_DOUBLE: return dispatch_select_op<double>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_DATE: return dispatch_select_op<DateValue>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
     default: return QSX_ERR_UNSUPPORTED;
   }
 }
@@ -777,6 +880,10 @@ int qsx_select_cmp_sorted(int type, const void *col_dev, int64_t n, int op, cons
       hipLaunchKernelGGL(sorted_bounds_kernel<double>, dim3(1), dim3(kWave), 0, s, static_cast<const double *>(col_dev), n,
                          *static_cast<const double *>(literal), bounds);
       break;
+    case QSX_DATE:
+      hipLaunchKernelGGL(sorted_bounds_kernel<DateValue>, dim3(1), dim3(kWave), 0, s, static_cast<const DateValue *>(col_dev), n,
+                         *static_cast<const DateValue *>(literal), bounds);
+      break;
     default: return QSX_ERR_UNSUPPORTED;
   }
   QSX_CHECK_LAUNCH();
@@ -801,6 +908,7 @@ int qsx_select_cmp_columns(int type, const void *lhs_dev, const void *rhs_dev, i
     case QSX_LONG: return dispatch_select_op<int64_t>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
     case QSX_FLOAT: return dispatch_select_op<float>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
     case QSX_DOUBLE: return dispatch_select_op<double>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
+    case QSX_DATE: return dispatch_select_op<DateValue>(op, lhs_dev, rhs_dev, n, nullptr, filter_dev, out_bitmap_dev, out_count_dev, s);
     default: return QSX_ERR_UNSUPPORTED;
   }
 }

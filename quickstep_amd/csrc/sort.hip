@@ -31,6 +31,8 @@ __device__ __forceinline__ unsigned long long ordered_image(T b, int type, int d
   unsigned long long k;
   if (type == QSX_CHAR) {
     k = b;                                           // unsigned byte
+  } else if (type == QSX_DATE) {
+    k = static_cast<unsigned long long>(date_ordered(static_cast<unsigned long long>(b))) ^ (1ull << 63);   // year, month, day
   } else if (type == QSX_INT || type == QSX_LONG) {
     k = b ^ kSign;                                   // two's complement: flip the sign bit
   } else {
@@ -197,7 +199,7 @@ static int validate_sort_args(int nkeys, const void *const *key_cols, const int3
     return QSX_ERR_INVALID_ARGUMENT;
   }
   for (int k = 0; k < nkeys; ++k) {
-    if (key_types[k] < QSX_INT || key_types[k] > QSX_CHAR) return QSX_ERR_UNSUPPORTED;
+    if ((key_types[k] < QSX_INT || key_types[k] > QSX_CHAR) && key_types[k] != QSX_DATE) return QSX_ERR_UNSUPPORTED;
     if (n > 0 && key_cols[k] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   }
   return QSX_OK;

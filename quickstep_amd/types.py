@@ -9,6 +9,7 @@ import ctypes as C
 # qsx_type_t (numbering of types/TypeID.hpp:32-43 in the reference)
 ABI_VERSION = 5                                                     # QSX_ABI_VERSION of include/qsx.h
 INT, LONG, FLOAT, DOUBLE, CHAR = 0, 1, 2, 3, 4
+DATE = 6   # the reference's 8-byte DateLit {int32 year; uint8 month, day; 2 bytes padding}, carried as int64 raw bytes
 # qsx_cmp_t (types/operations/comparisons/ComparisonID.hpp:36-42)
 EQ, NE, LT, LE, GT, GE = range(6)
 CODE_EQ, CODE_NE, CODE_LT, CODE_GE, CODE_RANGE = range(5)            # qsx_code_cmp_t
@@ -25,7 +26,13 @@ LIP_SINGLE_IDENTITY_HASH, LIP_BITVECTOR_EXACT = range(2)
 
 MAX_COLUMNS, MAX_KEYS, MAX_AGGS, MAX_INSTRS, MAX_TEMPS, MAX_CONSTS, MAX_PRED_TERMS = 16, 4, 8, 16, 8, 8, 4
 
-TYPE_WIDTH = {INT: 4, LONG: 8, FLOAT: 4, DOUBLE: 8}
+TYPE_WIDTH = {INT: 4, LONG: 8, FLOAT: 4, DOUBLE: 8, DATE: 8}
+
+
+def date_raw(year, month, day, padding=0):
+    """The 8 bytes of a DateLit as a (signed) 64-bit integer; `padding` fills the two unused bytes."""
+    v = (int(year) & 0xFFFFFFFF) | (int(month) & 0xFF) << 32 | (int(day) & 0xFF) << 40 | (int(padding) & 0xFFFF) << 48
+    return v - (1 << 64) if v >= 1 << 63 else v
 
 # status codes
 OK = 0
@@ -124,7 +131,7 @@ def make_agg_config(strategy, columns, keys=(), instrs=(), consts=(), aggs=(), p
         t = columns[column][0]
         if t == INT:
             term.literal.i32 = int(literal)
-        elif t == LONG:
+        elif t in (LONG, DATE):
             term.literal.i64 = int(literal)
         elif t == FLOAT:
             term.literal.f32 = float(literal)

@@ -253,4 +253,37 @@ dump("bitvector", {
         {"n": 5, "set_bits": [4], "expected_words_hex": ["0800000000000000"]},
     ],
 })
+# --------------------------------------------------------------------------
+# 6. DATE and CHAR comparisons (types/operations/comparisons/tests/Comparison_unittest.cpp)
+# --------------------------------------------------------------------------
+# The test compares every pair of its sample values under all six comparisons and expects what the literals' own
+# operators / strncmp-then-length give (:547-558, :604-641 dates; :665-742 strings).  Stored: the sample values and, per
+# comparison, the expected truth table over all ordered pairs.
+_DATES = [[2016, 7, 15], [-18017, 4, 13], [99999, 12, 31], [-99999, 1, 1]]           # :153-156
+_SHORT = "foo"                                                                       # :58
+_LONG = ("Space is big. You just won't believe how vastly, hugely, mind-bogglingly "
+         "big it is. I mean, you may think it's a long way down the road to the "
+         "chemist's, but that's just peanuts to space.")                            # :60-63 (the test's sample text, data)
+# CHAR values as (text, field width): exact width (no NUL), width + 1, width + 5 (NUL padded)   :240-254, :303-317
+_STRINGS = [[_SHORT, len(_SHORT)], [_SHORT, len(_SHORT) + 1], [_SHORT, len(_SHORT) + 5],
+            [_LONG, len(_LONG)], [_LONG, len(_LONG) + 1], [_LONG, len(_LONG) + 5]]
+_OPS = ["eq", "ne", "lt", "le", "gt", "ge"]
+
+
+def _cmp_table(values, key):
+    def holds(op, a, b):
+        return {"eq": a == b, "ne": a != b, "lt": a < b, "le": a <= b, "gt": a > b, "ge": a >= b}[op]
+    return {op: [[holds(op, key(a), key(b)) for b in values] for a in values] for op in _OPS}
+
+
+dump("comparison_unittest", {
+    "source": ["types/operations/comparisons/tests/Comparison_unittest.cpp:58-63, 153-156, 240-254, 303-317 (samples), "
+               ":547-558, 604-641 (dates: the DateLit operators, types/DatetimeLit.hpp:65-90), "
+               ":665-742 (strings: strncmp over the shorter ASCII length, then the lengths)"],
+    "dates": _DATES,
+    "date_tables": _cmp_table(_DATES, key=lambda d: tuple(d)),
+    "strings": _STRINGS,
+    # strncmp(min length) then length == ordering of the NUL-trimmed byte strings
+    "string_tables": _cmp_table(_STRINGS, key=lambda s: s[0].encode()),
+})
 print("golden fixtures written to", HERE)

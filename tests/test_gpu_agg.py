@@ -771,3 +771,43 @@ def test_wide_group_key_limits(capi):
                                         aggs=[(T.AGG_SUM, T.col(4)), (T.AGG_MIN, T.col(4)), (T.AGG_MAX, T.col(4))], est_groups=8))
     capi.AggState(T.make_agg_config(T.AGG_GENERIC, layout, keys=[0, 1, 2], aggs=[(T.AGG_SUM, T.col(4)), (T.AGG_COUNT_STAR, None)],
                                     est_groups=8)).close()
+
+
+# ---- DATE columns: predicate and group-by key ---------------------------------------------------------------------------
+def test_date_predicate_and_date_group_keys(capi, oracle, dev, monkeypatch):
+    """TPC-H Q1's `l_shipdate <= DATE` inside the aggregation state and Q3's GROUP BY l_orderkey, o_orderdate,
+    o_shippriority (INT + DATE + INT = 16 bytes: a wide key): DateLit columns with garbage in their padding bytes; the
+    padding takes no part in the comparison, the key or the output."""
+    rng = np.random.default_rng(61)
+    n = 300_000
+    years, months, days = rng.integers(1992, 1999, size=n), rng.integers(1, 13, size=n), rng.integers(1, 29, size=n)
+    pad = rng.integers(0, 1 << 16, size=n)
+    dates = ((years.astype(np.int64) & 0xFFFFFFFF) | (months.astype(np.int64) << 32) | (days.astype(np.int64) << 40) |
+             (pad.astype(np.int64) << 48)).astype(np.int64)
+    flag = rng.choice(np.frombuffer(b"ANR", dtype=np.uint8), size=n)
+    qty = rng.integers(1, 51, size=n).astype(np.float64)
+    cutoff = T.date_raw(1998, 9, 2)
+    for jit in (False, True):
+        monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if jit else str(1 << 60))
+        # Q1 shape: CHAR(1) key, DATE predicate
+        cfg = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.CHAR, 1), (T.DOUBLE, None), (T.DATE, None)], keys=[0],
+                                aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None)], pred=[(2, T.LE, cutoff)], est_groups=4)
+        o = oracle.AggState(cfg)
+        o.update([flag, qty, dates])
+        assert_same_groups(finalize_np(run_hip(capi, dev, cfg, [flag, qty, dates], blocks=2), dev), o.finalize())
+        # GROUP BY a DATE (month granularity keeps the group count moderate): narrow key (8 bytes) and the Q3-shaped wide key
+        month_dates = ((years.astype(np.int64) & 0xFFFFFFFF) | (months.astype(np.int64) << 32) | (np.int64(1) << 40) |
+                       (pad.astype(np.int64) << 48)).astype(np.int64)
+        okey = rng.integers(0, 40, size=n).astype(np.int32)
+        prio = rng.integers(0, 2, size=n).astype(np.int32)
+        for keys, layout, cols in (([0], [(T.DATE, None), (T.DOUBLE, None)], [month_dates, qty]),
+                                   ([0, 1, 2], [(T.INT, None), (T.DATE, None), (T.INT, None), (T.DOUBLE, None)], [okey, month_dates, prio, qty])):
+            cfg = T.make_agg_config(T.AGG_GENERIC, layout, keys=keys, aggs=[(T.AGG_SUM, T.col(len(layout) - 1)), (T.AGG_COUNT_STAR, None)],
+                                    est_groups=128)
+            o = oracle.AggState(cfg)
+            o.update(cols)
+            ref = o.finalize()
+            got = finalize_np(run_hip(capi, dev, cfg, cols, blocks=3), dev)
+            assert_same_groups(got, ref)
+            date_key = got[0][keys.index(0) if len(keys) == 1 else 1]
+            assert int((date_key.view(np.uint64) >> np.uint64(48)).max()) == 0     # output dates carry zero padding

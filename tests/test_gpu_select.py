@@ -183,3 +183,84 @@ def test_sort_column_predicate_by_binary_search(capi, oracle, dev, n):
                     assert np.array_equal(bitmap_np(got), want), (name, op, lit)
                     assert np.array_equal(want, oracle.select_cmp(col, op, lit, f))       # the scan agrees
                     assert int(cnt.item()) == oracle.bitmap_count(want, n)
+
+
+# ---- DATE and CHAR(n) predicates (the predicate types of TPC-H Q1 / Q3 beside the numeric ones) ----------------------------
+def make_dates(rng, n, padding=True):
+    """Raw DateLit bytes as int64: years around the TPC-H range plus a few far-away ones, garbage in the padding bytes."""
+    years = rng.integers(1992, 1999, size=n)
+    if n > 10:
+        years[rng.integers(0, n, size=3)] = [-18017, 99999, -99999]
+    months = rng.integers(1, 13, size=n)
+    days = rng.integers(1, 29, size=n)
+    pad = rng.integers(0, 1 << 16, size=n) if padding else np.zeros(n, dtype=np.int64)
+    raw = (years.astype(np.int64) & 0xFFFFFFFF) | (months.astype(np.int64) << 32) | (days.astype(np.int64) << 40) | (pad.astype(np.int64) << 48)
+    return raw.astype(np.int64)
+
+
+@pytest.mark.parametrize("n", [0, 1, 65, 4097, 300_001])
+def test_date_predicates_are_bit_exact(capi, oracle, dev, n, golden):
+    rng = np.random.default_rng(n + 5)
+    col = make_dates(rng, n)
+    dcol = to_dev(col, dev)
+    keep = oracle.bitmap_from_bools(rng.random(n) < 0.6) if n else None
+    for y, m, d in [(1995, 3, 15), (1998, 9, 2), (1992, 1, 1)] + [tuple(x) for x in golden["comparison_unittest"]["dates"]]:
+        lit = T.date_raw(y, m, d)
+        for op in (T.EQ, T.NE, T.LT, T.LE, T.GT, T.GE):
+            for filt in (None, keep):
+                bm, cnt = capi.select_cmp(dcol, op, lit, qtype=T.DATE, filter_bitmap=None if filt is None else bitmap_dev(filt, dev))
+                ref = oracle.select_cmp(col, op, lit, filter_bitmap=filt, qt=T.DATE)
+                if n:
+                    assert np.array_equal(bitmap_np(bm)[:ref.size], ref), (n, op, y, m, d)
+                assert int(cnt.item()) == oracle.bitmap_count(ref, n)
+    if n:
+        other = make_dates(rng, n)
+        for op in (T.EQ, T.LT, T.GE):
+            bm, cnt = capi.select_cmp_columns(dcol, to_dev(other, dev), op, qtype=T.DATE)
+            ref = oracle.select_cmp_columns(col, other, op, qt=T.DATE)
+            assert np.array_equal(bitmap_np(bm)[:ref.size], ref)
+        # the sort-column path: order the stripe by (year, month, day) first
+        order = oracle.sort_permutation([col], types=[T.DATE])
+        sorted_col = np.ascontiguousarray(col[order])
+        for op in (T.EQ, T.NE, T.LT, T.LE, T.GT, T.GE):
+            lit = int(sorted_col[n // 2])
+            bm, cnt = capi.select_cmp_sorted(to_dev(sorted_col, dev), op, lit, qtype=T.DATE)
+            ref = oracle.select_cmp(sorted_col, op, lit, qt=T.DATE)
+            assert np.array_equal(bitmap_np(bm)[:ref.size], ref)
+            assert np.array_equal(oracle.select_cmp_sorted(sorted_col, op, lit, qt=T.DATE), ref)
+
+
+@pytest.mark.parametrize("width,n", [(1, 1000), (10, 0), (10, 1), (10, 150_001), (25, 70_000), (15, 4096), (255, 5_000), (7, 64)])
+def test_char_predicates_follow_strcmp_helper(capi, oracle, dev, width, n):
+    """CHAR(width) OP literal: strings end at the first NUL or at the field width, unsigned bytes, a prefix is smaller
+    (AsciiStringComparators.hpp:218-251).  TPC-H shaped values (c_mktsegment CHAR(10), l_shipinstruct CHAR(25), ...), values
+    that fill the field exactly, bytes >= 0x80, an unaligned slice of the stripe, a filter."""
+    rng = np.random.default_rng(width * 1000 + n)
+    words = [b"BUILDING", b"AUTOMOBILE", b"MACHINERY", b"HOUSEHOLD", b"FURNITURE", b"BUILD", b"BUILDINGS", b"", b"\xc3\xa9t\xc3\xa9",
+             b"DELIVER IN PERSON", b"TAKE BACK RETURN", b"COLLECT COD", b"NONE", b"x" * width]
+    col = np.zeros((n, width), dtype=np.uint8)
+    pick = rng.integers(0, len(words), size=n)
+    for i in range(n):
+        w = words[pick[i]][:width]
+        col[i, :len(w)] = np.frombuffer(w, dtype=np.uint8)
+        if len(w) + 1 < width and rng.random() < 0.2:
+            col[i, len(w) + 1:] = rng.integers(1, 255, size=width - len(w) - 1)   # bytes behind the terminator are not part of the string
+    dcol = to_dev(col, dev)
+    keep = oracle.bitmap_from_bools(rng.random(n) < 0.5) if n else None
+    literals = [b"BUILDING", b"BUILD", b"BUILDINGS", b"", b"MACHINERY", b"NONE\0junk", b"x" * min(width, 64), b"\xc3\xa9t\xc3\xa9", b"TAKE BACK RETURN"]
+    for lit in literals:
+        for op in (T.EQ, T.NE, T.LT, T.LE, T.GT, T.GE):
+            for filt in (None, keep):
+                bm, cnt = capi.select_cmp_char(dcol, op, lit, filter_bitmap=None if filt is None else bitmap_dev(filt, dev))
+                ref = oracle.select_cmp_char(col, op, lit, filter_bitmap=filt)
+                if n:
+                    assert np.array_equal(bitmap_np(bm)[:ref.size], ref), (width, n, lit, op)
+                assert int(cnt.item()) == oracle.bitmap_count(ref, n)
+    if n > 200:
+        # a slice that starts at row 3: not 16-byte aligned for most widths
+        sl = dcol[3:3 + (n - 3) // 64 * 64]
+        bm, cnt = capi.select_cmp_char(sl, T.EQ, b"BUILDING")
+        ref = oracle.select_cmp_char(np.ascontiguousarray(col[3:3 + (n - 3) // 64 * 64]), T.EQ, b"BUILDING")
+        assert np.array_equal(bitmap_np(bm)[:ref.size], ref)
+    with pytest.raises(capi.QsxError):
+        capi.select_cmp_char(to_dev(np.zeros((4, 10), dtype=np.uint8), dev), T.EQ, b"y" * 65)     # literal beyond QSX_MAX_CHAR_LITERAL

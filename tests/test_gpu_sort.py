@@ -132,3 +132,28 @@ def test_count_distinct_at_scale_q16_shape(capi, dev):
     first = torch.full((int(packed.max()) + 1,), n, dtype=torch.int64, device=dev)
     first.scatter_reduce_(0, packed, torch.arange(n, device=dev), reduce="amin")
     assert torch.equal(first[uniq], rows.long())                        # the representative is the first occurrence
+
+
+def test_date_sort_keys_and_distinct_dates(capi, oracle, dev):
+    """ORDER BY revenue DESC, o_orderdate with o_orderdate a real DateLit column (Q3), top-k of the same, and DISTINCT over a
+    DATE: ordered by year, month, day whatever the padding bytes hold."""
+    from quickstep_amd import types as T
+    rng = np.random.default_rng(71)
+    n = 120_000
+    years = rng.integers(1992, 1999, size=n)
+    years[:3] = [-18017, 99999, -99999]
+    months, days, pad = rng.integers(1, 13, size=n), rng.integers(1, 29, size=n), rng.integers(0, 1 << 16, size=n)
+    dates = ((years.astype(np.int64) & 0xFFFFFFFF) | (months.astype(np.int64) << 32) | (days.astype(np.int64) << 40) |
+             (pad.astype(np.int64) << 48)).astype(np.int64)
+    revenue = np.round(rng.uniform(0, 50, size=n), 0)            # many ties: the date decides
+    for desc in ([False], [True]):
+        got = capi.sort_permutation([to_dev(dates, dev)], desc, types=[T.DATE]).cpu().numpy()
+        assert np.array_equal(got, oracle.sort_permutation([dates], desc, types=[T.DATE]))
+    keys, types, desc = [revenue, dates], [T.DOUBLE, T.DATE], [True, False]
+    want = oracle.sort_permutation(keys, desc, types=types)
+    assert np.array_equal(capi.sort_permutation([to_dev(k, dev) for k in keys], desc, types=types).cpu().numpy(), want)
+    assert np.array_equal(capi.sort_top_k([to_dev(k, dev) for k in keys], 10, desc, types=types).cpu().numpy(), want[:10])
+    month_dates = ((years.astype(np.int64) & 0xFFFFFFFF) | (months.astype(np.int64) << 32) | (np.int64(1) << 40) |
+                   (pad.astype(np.int64) << 48)).astype(np.int64)
+    got = capi.distinct_rows([to_dev(month_dates, dev)], types=[T.DATE]).cpu().numpy()
+    assert np.array_equal(got, oracle.distinct_rows([month_dates], types=[T.DATE]))

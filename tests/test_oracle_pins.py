@@ -612,3 +612,34 @@ def test_predicate_transformer_result_kinds(oracle):
     t = tr.transform(T.GT, 7)
     assert (t.result, t.comp, t.first) == (oracle.PRED_BASIC, T.CODE_GE, 8)
     assert tr.transform(T.LE, 255).result == oracle.PRED_ALL                                  # >= the largest 1-byte code
+
+
+def test_comparison_unittest_dates_and_strings(oracle, golden):
+    """Comparison_unittest.cpp's DATE and CHAR samples under all six comparisons: the oracle's DateLit comparison (year,
+    month, day; padding bytes ignored) and its strcmpHelper restatement against the expected truth tables."""
+    g = golden["comparison_unittest"]
+    ops = {"eq": T.EQ, "ne": T.NE, "lt": T.LT, "le": T.LE, "gt": T.GT, "ge": T.GE}
+    dates = g["dates"]
+    col = np.array([T.date_raw(y, m, d, padding=0xBEEF) for y, m, d in dates], dtype=np.int64)   # garbage in the padding bytes
+    for name, op in ops.items():
+        for j, (y, m, d) in enumerate(dates):
+            bm = oracle.select_cmp(col, op, T.date_raw(y, m, d), qt=T.DATE)
+            got = [bool((int(bm[0]) >> (63 - i)) & 1) for i in range(len(dates))]
+            assert got == [row[j] for row in g["date_tables"][name]], (name, j)
+        # attribute OP attribute, every pair at once
+        lhs = np.repeat(col, len(dates))
+        rhs = np.tile(np.array([T.date_raw(y, m, d) for y, m, d in dates], dtype=np.int64), len(dates))
+        bm = oracle.select_cmp_columns(lhs, rhs, op, qt=T.DATE)
+        want = [v for row in g["date_tables"][name] for v in row]
+        assert [bool((int(bm[i >> 6]) >> (63 - (i & 63))) & 1) for i in range(len(want))] == want
+    strings = g["strings"]
+    for name, op in ops.items():
+        for i, (ltext, lwidth) in enumerate(strings):
+            stripe = np.zeros((1, lwidth), dtype=np.uint8)
+            stripe[0, :len(ltext)] = np.frombuffer(ltext.encode(), dtype=np.uint8)
+            for j, (rtext, rwidth) in enumerate(strings):
+                if rwidth > 64:
+                    continue                      # (the device ABI takes literals of up to 64 bytes; the long sample is a left side only)
+                literal = rtext.encode() + b"\0" * (rwidth - len(rtext))
+                bm = oracle.select_cmp_char(stripe, op, literal)
+                assert bool(int(bm[0]) >> 63) == g["string_tables"][name][i][j], (name, i, j)
