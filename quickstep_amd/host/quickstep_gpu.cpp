@@ -305,6 +305,134 @@ PredicateTransformResult TransformT(const CompressedAttribute &attr, ComparisonI
   }
   return r;
 }
+
+// ---- DATE and CHAR(n) attributes: dictionaries of fixed-width byte values under the type's own order -------------------
+// (CompressionDictionaryBuilder keeps its values in a set ordered by the type's less comparison,
+// compression/CompressionDictionaryBuilder.cpp:40-90; there is no truncation for these types.)
+// strcmpHelper of the reference (types/operations/comparisons/AsciiStringComparators.hpp:218-251)
+int CompareAsciiStrings(const char *left, std::size_t left_length, const char *right, std::size_t right_length) {
+  if (right_length > left_length) {
+    const int res = std::strncmp(left, right, left_length);
+    if (res) return res;
+    return strnlen(right, right_length) > left_length ? -1 : res;
+  } else if (left_length > right_length) {
+    const int res = std::strncmp(left, right, right_length);
+    if (res) return res;
+    return strnlen(left, left_length) > right_length ? 1 : res;
+  }
+  return std::strncmp(left, right, left_length);
+}
+// <0, 0, >0: value (value_width bytes) against the literal
+int CompareBytesWithLiteral(TypeID type, const unsigned char *value, int value_width, const void *literal, std::size_t literal_length) {
+  if (type == kDate) {
+    DateLit a, b;
+    std::memcpy(&a, value, 8);
+    std::memcpy(&b, literal, 8);
+    return a < b ? -1 : (b < a ? 1 : 0);
+  }
+  return CompareAsciiStrings(reinterpret_cast<const char *>(value), static_cast<std::size_t>(value_width),
+                             static_cast<const char *>(literal), literal_length);
+}
+
+void BuildByteDictionary(TypeID type, int width, const unsigned char *values, std::int64_t n, CompressedAttribute *out,
+                         std::vector<unsigned char> *codes_host) {
+  auto less = [&](const unsigned char *a, const unsigned char *b) { return CompareBytesWithLiteral(type, a, width, b, width) < 0; };
+  std::vector<const unsigned char *> dict(static_cast<std::size_t>(n));
+  for (std::int64_t i = 0; i < n; ++i) dict[static_cast<std::size_t>(i)] = values + i * width;
+  std::sort(dict.begin(), dict.end(), less);
+  dict.erase(std::unique(dict.begin(), dict.end(), [&](const unsigned char *a, const unsigned char *b) { return !less(a, b) && !less(b, a); }),
+             dict.end());
+  unsigned code_bits = 0;
+  for (std::size_t num_values = 1; num_values <= dict.size(); ++num_values) {
+    if (code_bits == 0 || num_values == (1ull << code_bits) + 1) ++code_bits;
+  }
+  const std::size_t code_bytes = code_bits < 9 ? 1 : (code_bits < 17 ? 2 : 4);
+  const std::size_t dictionary_bytes = 2 * sizeof(std::uint32_t) + dict.size() * width + static_cast<std::size_t>(n) * code_bytes;
+  if (static_cast<std::size_t>(n) * width < dictionary_bytes) {   // CompressedBlockBuilder.cpp:590-650: compress only if it is smaller
+    out->kind = CompressedAttribute::kUncompressed;
+    return;
+  }
+  out->kind = CompressedAttribute::kDictionary;
+  out->code_width = static_cast<int>(code_bytes);
+  out->num_codes = static_cast<std::uint32_t>(dict.size());
+  out->value_width = width;
+  out->dictionary_host.assign(dict.size() * width, 0);
+  for (std::size_t e = 0; e < dict.size(); ++e) {
+    // a DATE entry keeps year, month, day only; a CHAR entry ends at its terminator (what follows is not part of the value)
+    const std::size_t keep = type == kDate ? 6 : strnlen(reinterpret_cast<const char *>(dict[e]), static_cast<std::size_t>(width));
+    std::memcpy(out->dictionary_host.data() + e * width, dict[e], keep);
+  }
+  codes_host->assign(static_cast<std::size_t>(n) * code_bytes, 0);
+  for (std::int64_t i = 0; i < n; ++i) {
+    const std::uint32_t code = static_cast<std::uint32_t>(std::lower_bound(dict.begin(), dict.end(), values + i * width, less) - dict.begin());
+    switch (code_bytes) {
+      case 1: (*codes_host)[static_cast<std::size_t>(i)] = static_cast<unsigned char>(code); break;
+      case 2: reinterpret_cast<std::uint16_t *>(codes_host->data())[i] = static_cast<std::uint16_t>(code); break;
+      default: reinterpret_cast<std::uint32_t *>(codes_host->data())[i] = code; break;
+    }
+  }
+}
+
+// The dictionary branch of TransformT for byte dictionaries (same rules: CompressedStoreUtil.cpp:425-616,
+// CompressionDictionary.cpp:276-305).
+PredicateTransformResult TransformBytes(const CompressedAttribute &attr, TypeID type, ComparisonID comparison, const void *literal,
+                                        std::size_t literal_length) {
+  PredicateTransformResult r;
+  const int width = attr.value_width;
+  std::uint32_t lower = 0, upper = attr.num_codes;   // first entry >= literal, first entry > literal
+  {
+    std::uint32_t lo = 0, hi = attr.num_codes;
+    while (lo < hi) {
+      const std::uint32_t mid = lo + (hi - lo) / 2;
+      if (CompareBytesWithLiteral(type, attr.dictionary_host.data() + static_cast<std::size_t>(mid) * width, width, literal, literal_length) < 0) lo = mid + 1;
+      else hi = mid;
+    }
+    lower = lo;
+    hi = attr.num_codes;
+    while (lo < hi) {
+      const std::uint32_t mid = lo + (hi - lo) / 2;
+      if (CompareBytesWithLiteral(type, attr.dictionary_host.data() + static_cast<std::size_t>(mid) * width, width, literal, literal_length) <= 0) lo = mid + 1;
+      else hi = mid;
+    }
+    upper = lo;
+  }
+  auto basic = [&](qsx_code_cmp_t comp, std::uint32_t code) {
+    r.type = PredicateTransformResult::kBasicComparison;
+    r.comp = comp;
+    r.first_literal = code;
+  };
+  constexpr std::uint32_t kMax = 0xFFFFFFFFu;
+  if (comparison == ComparisonID::kEqual) {
+    if (lower != upper) basic(QSX_CODE_EQ, lower);
+    return r;
+  }
+  if (comparison == ComparisonID::kNotEqual) {
+    if (lower == upper) r.type = PredicateTransformResult::kAll;
+    else basic(QSX_CODE_NE, lower);
+    return r;
+  }
+  std::pair<std::uint32_t, std::uint32_t> range(0, 0);
+  switch (comparison) {
+    case ComparisonID::kLess: range = {0, lower}; break;
+    case ComparisonID::kLessOrEqual: range = {0, upper}; break;
+    case ComparisonID::kGreater: range = {upper, attr.num_codes}; break;
+    default: range = {lower, attr.num_codes}; break;
+  }
+  if (range.first >= range.second) return r;
+  if (range.second == attr.num_codes) range.second = kMax;
+  if (range.first == 0) {
+    if (range.second == kMax) r.type = PredicateTransformResult::kAll;
+    else basic(QSX_CODE_LT, range.second);
+  } else if (range.second == kMax) {
+    basic(QSX_CODE_GE, range.first);
+  } else {
+    r.type = PredicateTransformResult::kRangeComparison;
+    r.comp = QSX_CODE_RANGE;
+    r.first_literal = range.first;
+    r.second_literal = range.second;
+  }
+  return r;
+}
 }  // namespace
 
 PredicateTransformResult TransformPredicateOnCompressedAttribute(const CompressedAttribute &attribute, TypeID type,
@@ -314,14 +442,21 @@ PredicateTransformResult TransformPredicateOnCompressedAttribute(const Compresse
     case kLong: return TransformT<std::int64_t>(attribute, comparison, literal.v.i64);
     case kFloat: return TransformT<float>(attribute, comparison, literal.v.f32);
     case kDouble: return TransformT<double>(attribute, comparison, literal.v.f64);
-    default: throw ExecutionError("compressed attributes: numeric types only", QSX_ERR_UNSUPPORTED);
+    case kDate: return TransformBytes(attribute, type, comparison, &literal.v.i64, 8);
+    case kChar: return TransformBytes(attribute, type, comparison, literal.text.data(), literal.text.size());
+    default: throw ExecutionError("compressed attributes: INT / LONG / FLOAT / DOUBLE / DATE / CHAR(n)", QSX_ERR_UNSUPPORTED);
   }
 }
 
 void CompressValues(TypeID type, const void *values, std::int64_t n, CompressedAttribute *out,
-                    std::vector<unsigned char> *codes_host) {
+                    std::vector<unsigned char> *codes_host, int value_width) {
   codes_host->clear();
   switch (type) {
+    case kDate: BuildByteDictionary(type, 8, static_cast<const unsigned char *>(values), n, out, codes_host); break;
+    case kChar:
+      if (value_width > 0) BuildByteDictionary(type, value_width, static_cast<const unsigned char *>(values), n, out, codes_host);
+      else out->kind = CompressedAttribute::kUncompressed;
+      break;
     case kInt: BuildCompressedAttribute(type, static_cast<const std::int32_t *>(values), n, out, codes_host); break;
     case kLong: BuildCompressedAttribute(type, static_cast<const std::int64_t *>(values), n, out, codes_host); break;
     case kFloat: BuildCompressedAttribute(type, static_cast<const float *>(values), n, out, codes_host); break;
@@ -336,7 +471,7 @@ void StorageBlock::compressAttribute(attribute_id a, const void *host_values) {
   if (compressed_.empty()) compressed_.resize(relation_.size());
   CompressedAttribute &c = compressed_.at(a);
   std::vector<unsigned char> codes_host;
-  CompressValues(t.id, host_values, num_tuples_, &c, &codes_host);
+  CompressValues(t.id, host_values, num_tuples_, &c, &codes_host, t.width);
   if (c.kind == CompressedAttribute::kUncompressed) return;
   CheckStatus(qsx_device_alloc(codes_host.size() + 8, &c.codes), "qsx_device_alloc(codes)");
   CheckStatus(qsx_copy_to_device(c.codes, codes_host.data(), codes_host.size(), nullptr), "qsx_copy_to_device(codes)");
@@ -509,7 +644,12 @@ void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num
                                      static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
                     "qsx_select_codes");
       }
-    } else if (term.attribute == block.sortColumn() && t.id != kChar) {
+    } else if (t.id == kChar) {
+      // CHAR(n) OP string literal (AsciiStringUncheckedComparator, AsciiStringComparators.hpp:218-251)
+      CheckStatus(qsx_select_cmp_char(block.stripe(term.attribute), t.width, n, static_cast<int>(term.comparison), term.literal.text.data(),
+                                      static_cast<int>(term.literal.text.size()), in, static_cast<std::uint64_t *>(next),
+                                      static_cast<std::int64_t *>(count), CurrentStream()), "qsx_select_cmp_char");
+    } else if (term.attribute == block.sortColumn()) {
       // the block is sorted on this attribute: SortColumnPredicateEvaluator (storage/ColumnStoreUtil.cpp:40-280)
       CheckStatus(qsx_select_cmp_sorted(t.id, block.stripe(term.attribute), n, static_cast<int>(term.comparison), &term.literal.v, in,
                                         static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
@@ -657,13 +797,19 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
   }
   config_.num_aggs = num_main;
   if (spec.predicate != nullptr) {
-    config_.num_pred_terms = static_cast<int>(spec.predicate->conjuncts.size());
-    for (std::size_t p = 0; p < spec.predicate->conjuncts.size(); ++p) {
-      const ComparisonPredicate &term = spec.predicate->conjuncts[p];
-      config_.pred[p].column = column_of(term.attribute);
-      config_.pred[p].op = static_cast<int>(term.comparison);
-      std::memcpy(&config_.pred[p].literal, &term.literal.v, sizeof(term.literal.v));
+    int in_state = 0;
+    for (const ComparisonPredicate &term : spec.predicate->conjuncts) {
+      const Type &t = rel.getAttributeType(term.attribute);
+      if (t.id == kChar || term.rhs_attribute != kInvalidAttributeID || in_state == QSX_MAX_PRED_TERMS) {
+        external_predicate_.conjuncts.push_back(term);   // string comparisons, attribute-vs-attribute, overflow
+        continue;
+      }
+      config_.pred[in_state].column = column_of(term.attribute);
+      config_.pred[in_state].op = static_cast<int>(term.comparison);
+      std::memcpy(&config_.pred[in_state].literal, &term.literal.v, sizeof(term.literal.v));
+      ++in_state;
     }
+    config_.num_pred_terms = in_state;
   }
   config_.num_columns = static_cast<int>(column_attr_.size());
   config_.est_groups = spec.estimated_num_groups;
@@ -716,6 +862,16 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
     qsx_device_free(selected);
   }
   if (state_ == nullptr) return;
+  // the conjuncts the kernel does not evaluate: a TupleIdSequence like the one a SelectOperator computes, used as the filter
+  struct OwnedBitmap {
+    void *ptr = nullptr;
+    ~OwnedBitmap() { if (ptr != nullptr) qsx_device_free(ptr); }
+  } external_matches;
+  if (!external_predicate_.conjuncts.empty() && n > 0) {
+    std::int64_t matches = 0;
+    external_matches.ptr = external_predicate_.getMatchesForBlock(block, &matches, lip_filter);
+    lip_filter = static_cast<const std::uint64_t *>(external_matches.ptr);
+  }
   // A block with compressed operand attributes whose values have not been materialised: aggregate on the codes.
   // (Key and predicate columns of the state take the value path here: stripe() decodes them once per block.)
   // null bitmaps of the nullable operand attributes (a block may hold none: loadBlock without bitmaps)

@@ -25,6 +25,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -53,7 +54,18 @@ typedef int numa_node_id;
 constexpr attribute_id kInvalidAttributeID = -1;
 
 // types/TypeID.hpp:32-43 (numbering shared with qsx_type_t)
-enum TypeID { kInt = 0, kLong = 1, kFloat = 2, kDouble = 3, kChar = 4 };
+enum TypeID { kInt = 0, kLong = 1, kFloat = 2, kDouble = 3, kChar = 4, kVarChar = 5, kDate = 6 };
+
+// types/DatetimeLit.hpp:38-90: the value of a DATE attribute, 8 bytes in a column stripe; ordered by year, month, day.
+struct DateLit {
+  std::int32_t year;
+  std::uint8_t month, day;
+  std::uint8_t unused[2];
+  static DateLit Create(std::int32_t year, std::uint8_t month, std::uint8_t day) { return DateLit{year, month, day, {0, 0}}; }
+  bool operator<(const DateLit &r) const { return year != r.year ? year < r.year : (month != r.month ? month < r.month : day < r.day); }
+  bool operator==(const DateLit &r) const { return year == r.year && month == r.month && day == r.day; }
+};
+static_assert(sizeof(DateLit) == 8, "DateLit occupies 8 bytes");
 // types/operations/comparisons/ComparisonID.hpp:36-42
 enum class ComparisonID { kEqual = 0, kNotEqual, kLess, kLessOrEqual, kGreater, kGreaterOrEqual };
 // expressions/aggregation/AggregationID.hpp
@@ -68,6 +80,7 @@ struct Type {
   static Type Float() { return {kFloat, 4}; }
   static Type Double() { return {kDouble, 8}; }
   static Type Char(int n) { return {kChar, n}; }
+  static Type Date() { return {kDate, 8}; }
   Type getNullableVersion() const { Type t = *this; t.nullable = true; return t; }
 };
 
@@ -145,6 +158,7 @@ struct CompressedAttribute {
   void *codes = nullptr;                // device: num_tuples codes
   void *dictionary = nullptr;           // device copy of the dictionary (decode)
   std::vector<unsigned char> dictionary_host;  // sorted values, attribute width each (predicate transformation)
+  int value_width = 0;                  // CHAR(n) / DATE dictionaries: bytes per entry
 };
 
 // Result of rewriting `attribute OP literal` into a comparison on codes
@@ -161,7 +175,7 @@ struct TypedLiteral;
 // code_width, num_codes and dictionary_host of *out and the code stripe (empty when the attribute stays
 // uncompressed).  Pure host logic (storage/CompressedBlockBuilder.cpp:508-566, 590-650).
 void CompressValues(TypeID type, const void *values, std::int64_t n, CompressedAttribute *out,
-                    std::vector<unsigned char> *codes_host);
+                    std::vector<unsigned char> *codes_host, int value_width = 0);   // value_width: CHAR(n) only
 PredicateTransformResult TransformPredicateOnCompressedAttribute(const CompressedAttribute &attribute, TypeID type,
                                                                  ComparisonID comparison, const TypedLiteral &literal);
 
@@ -247,6 +261,16 @@ struct TypedLiteral {
   static TypedLiteral Long(std::int64_t x) { TypedLiteral l; l.type = kLong; l.v.i64 = x; return l; }
   static TypedLiteral Float(float x) { TypedLiteral l; l.type = kFloat; l.v.i64 = 0; l.v.f32 = x; return l; }
   static TypedLiteral Double(double x) { TypedLiteral l; l.type = kDouble; l.v.f64 = x; return l; }
+  static TypedLiteral Date(std::int32_t year, int month, int day) {   // the DateLit bytes, padding zero
+    TypedLiteral l;
+    l.type = kDate;
+    const DateLit d = DateLit::Create(year, static_cast<std::uint8_t>(month), static_cast<std::uint8_t>(day));
+    std::memcpy(&l.v.i64, &d, 8);
+    return l;
+  }
+  // a string literal for a CHAR(n) attribute (compared like the reference's strcmpHelper: AsciiStringComparators.hpp:218-251)
+  static TypedLiteral Char(const std::string &text) { TypedLiteral l; l.type = kChar; l.v.i64 = 0; l.text = text; return l; }
+  std::string text;
 };
 
 // ComparisonPredicate attr OP literal (expressions/predicate/ComparisonPredicate.cpp:115-334);
@@ -342,6 +366,9 @@ class AggregationOperationState {
   std::mutex coded_mutex_;
   std::atomic<std::int64_t> coded_blocks_{0};
   std::vector<attribute_id> column_attr_;  // config column -> input attribute
+  // conjuncts the state's kernel does not evaluate itself (CHAR(n) comparisons, terms beyond QSX_MAX_PRED_TERMS): they are
+  // evaluated per block like a SelectOperator's predicate and handed to the update as its filter
+  Predicate external_predicate_;
   std::vector<int> main_agg_;              // spec aggregate -> aggregate of config_ (-1: DISTINCT)
   // one per DISTINCT aggregate: distinctify_hashtables_ (AggregationOperationState.cpp:172-207), kept as the distinct
   // (group-by..., argument) tuples of the blocks seen so far

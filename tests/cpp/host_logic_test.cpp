@@ -110,6 +110,68 @@ int main() {
     CheckColumn<float>("float dictionary, 2-byte codes", kFloat, halves, CompressedAttribute::kDictionary, 2,
                        {-1.0f, 0.0f, 0.25f, 100.5f, 349.5f, 1000.0f}, TypedLiteral::Float);
   }
+  // ---- DATE and CHAR(n) attributes: dictionaries under the type's own order ---------------------------------------------
+  // (TPC-H: l_shipdate / o_orderdate DATE, l_shipmode CHAR(10), l_shipinstruct CHAR(25) of the compressed column stores,
+  // benchmarks/tpch/create.sql:73-121).  Every comparison on codes must select the rows the comparison on values selects.
+  {
+    const int n = 6000;
+    std::vector<DateLit> dates;
+    for (int i = 0; i < n; ++i) {
+      DateLit d = DateLit::Create(1992 + static_cast<int>(rnd() % 7), static_cast<std::uint8_t>(1 + rnd() % 12), static_cast<std::uint8_t>(1 + rnd() % 28));
+      d.unused[0] = static_cast<std::uint8_t>(rnd());   // garbage in the padding bytes: not part of the value
+      d.unused[1] = static_cast<std::uint8_t>(rnd());
+      dates.push_back(d);
+    }
+    CompressedAttribute c;
+    std::vector<unsigned char> codes;
+    CompressValues(kDate, dates.data(), n, &c, &codes);
+    EXPECT_TRUE(c.kind == CompressedAttribute::kDictionary && c.code_width == 2 && c.value_width == 8);
+    const DateLit *dict = reinterpret_cast<const DateLit *>(c.dictionary_host.data());
+    for (int i = 0; i < n; ++i) EXPECT_TRUE(dict[CodeAt(c, codes, i)] == dates[i] && dict[CodeAt(c, codes, i)].unused[0] == 0);
+    const int probes[][3] = {{1991, 12, 31}, {1992, 1, 1}, {1995, 3, 15}, {1998, 9, 2}, {1998, 12, 28}, {1999, 1, 1}, {-18017, 4, 13}, {99999, 12, 31}};
+    for (const auto &p : probes) {
+      const DateLit lit = DateLit::Create(p[0], static_cast<std::uint8_t>(p[1]), static_cast<std::uint8_t>(p[2]));
+      for (const ComparisonID comp : {ComparisonID::kEqual, ComparisonID::kNotEqual, ComparisonID::kLess, ComparisonID::kLessOrEqual,
+                                      ComparisonID::kGreater, ComparisonID::kGreaterOrEqual}) {
+        const PredicateTransformResult r = TransformPredicateOnCompressedAttribute(c, kDate, comp, TypedLiteral::Date(p[0], p[1], p[2]));
+        for (int i = 0; i < n; ++i) {
+          const int order = dates[i] < lit ? -1 : (lit < dates[i] ? 1 : 0);
+          if (CodeMatches(r, CodeAt(c, codes, i)) != Compare(order, comp, 0)) {
+            std::fprintf(stderr, "date dictionary: comparison %d with %d-%d-%d differs at row %d\n", static_cast<int>(comp), p[0], p[1], p[2], i);
+            ++g_failures;
+            break;
+          }
+        }
+      }
+    }
+    // CHAR(10): five words, one of them filling the field exactly, bytes behind a terminator are junk
+    const char *words[] = {"BUILDING", "AUTOMOBILE", "MACHINERY", "HOUSEHOLD", "FURNITURE"};
+    std::vector<char> column(static_cast<std::size_t>(n) * 10, 0);
+    for (int i = 0; i < n; ++i) {
+      const char *w = words[rnd() % 5];
+      std::strncpy(&column[static_cast<std::size_t>(i) * 10], w, 10);
+      if (std::strlen(w) < 9 && rnd() % 4 == 0) column[static_cast<std::size_t>(i) * 10 + 9] = 'x';
+    }
+    CompressedAttribute cc;
+    CompressValues(kChar, column.data(), n, &cc, &codes, 10);
+    EXPECT_TRUE(cc.kind == CompressedAttribute::kDictionary && cc.code_width == 1 && cc.num_codes == 5 && cc.value_width == 10);
+    for (const char *lit : {"BUILDING", "BUILD", "BUILDINGS", "AUTOMOBILE", "AUTOMOBILES", "", "ZZZ", "HOUSEHOLD", "MACHINERZ"}) {
+      for (const ComparisonID comp : {ComparisonID::kEqual, ComparisonID::kNotEqual, ComparisonID::kLess, ComparisonID::kLessOrEqual,
+                                      ComparisonID::kGreater, ComparisonID::kGreaterOrEqual}) {
+        const PredicateTransformResult r = TransformPredicateOnCompressedAttribute(cc, kChar, comp, TypedLiteral::Char(lit));
+        for (int i = 0; i < n; ++i) {
+          // the field as a C string (ends at its terminator or at 10 bytes) against the literal
+          const std::string value(&column[static_cast<std::size_t>(i) * 10], strnlen(&column[static_cast<std::size_t>(i) * 10], 10));
+          const int order = value.compare(lit);
+          if (CodeMatches(r, CodeAt(cc, codes, i)) != Compare(order < 0 ? -1 : (order > 0 ? 1 : 0), comp, 0)) {
+            std::fprintf(stderr, "char dictionary: comparison %d with '%s' differs at row %d ('%s')\n", static_cast<int>(comp), lit, i, value.c_str());
+            ++g_failures;
+            break;
+          }
+        }
+      }
+    }
+  }
   // ---- partition scheme bookkeeping -----------------------------------------------------------------------------------
   {
     CatalogRelation rel(1, "r");

@@ -14,7 +14,7 @@ def _ensure_built():
     if not all(os.path.exists(os.path.join(BIN, b)) for b in
                ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
                 "lip_filter_operator_test", "compressed_block_operator_test", "host_logic_test",
-                "sort_operator_test", "nullable_operator_test")):
+                "sort_operator_test", "nullable_operator_test", "tpch_types_operator_test")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -82,3 +82,10 @@ def test_nulls_through_the_operators():
     """Join.test's LEFT JOIN chains (NULL join keys), Select.test's aggregates over the test table's NULLs, semi / anti joins
     and selections over nullable attributes — synchronous driver and Foreman/Worker."""
     _run("nullable_operator_test")
+
+
+@pytest.mark.gpu
+def test_tpch_schema_types_through_the_operators():
+    """CHAR(10) / CHAR(1) / DATE attributes of the reference's TPC-H schema in the predicates and group-by keys of Q1 and Q3,
+    over plain and over dictionary-compressed blocks."""
+    _run("tpch_types_operator_test")
