@@ -90,10 +90,33 @@ def gen_q1_columns_cpu(n, seed):
             rng.integers(0, 11, size=n) / 100.0, rng.integers(0, 9, size=n) / 100.0]
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask and the cgroup CPU quota bound os.cpu_count() (a box that
+    shows 256 CPUs but grants a fraction of them runs 256 compute-bound threads at that fraction's speed)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = text[0], int(text[1])
+            else:
+                quota, period = text[0], int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and int(quota) > 0:
+                n = min(n, max(1, int(quota) // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(args):
-    """Oracle (port of the reference CPU algorithms) on a bounded sample, all host cores."""
+    """Oracle (port of the reference CPU algorithms) on a bounded sample, all usable host cores."""
     from oracle import pyoracle as O
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     rng = np.random.default_rng(3)
     build = rng.permutation(args.build_rows).astype(np.int32)
     block_join = 1_048_576           # 4 MB blocks of INT keys (BASELINE.md §4)

@@ -285,7 +285,7 @@ def join_key_pack(cols, stream=None):
     n = cols[0].numel()
     out = torch.empty(n, dtype=torch.int64, device=cols[0].device)
     ptrs = (C.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
-    types = (C.c_int32 * len(cols))(*(types if types is not None else [qsx_type_of(c) for c in cols]))
+    types = (C.c_int32 * len(cols))(*[qsx_type_of(c) for c in cols])
     exact = C.c_int(0)
     _check(_lib.qsx_join_key_pack(len(cols), ptrs, types, n, _ptr(out), C.byref(exact), _stream(stream)),
            "qsx_join_key_pack")

@@ -107,4 +107,5 @@ def test_tuple_id_range_and_argument_errors(capi, dev):
     with pytest.raises(capi.QsxError):
         capi.partition_scatter(keys, 65, [keys])       # more partitions than a wave has lanes
     with pytest.raises(capi.QsxError):
-        capi.AggState(T.make_agg_config(T.AGG_COMPACT_KEY, [(T.LONG, None), (T.LONG, None)], keys=[0, 1], aggs=[]))   # 16-byte key code
+        capi.AggState(T.make_agg_config(T.AGG_COMPACT_KEY, [(T.LONG, None)] * 4, keys=[0, 1, 2, 3], aggs=[]))   # 32-byte key: four words
+    capi.AggState(T.make_agg_config(T.AGG_COMPACT_KEY, [(T.LONG, None), (T.LONG, None)], keys=[0, 1], aggs=[])).close()   # 16 bytes: a wide key
