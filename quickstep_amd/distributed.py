@@ -15,8 +15,10 @@ HashJoinOperator.cpp:220-231).  Here GPU g *is* partition g of P = world size:
   * partial aggregate merge (group keys not co-partitioned with the shuffle)
                       = all-gather of the exported state images + local
                         qsx_agg_state_import_merge for hash-table states,
-                        all-reduce (SUM / bit-OR per column type) for the dense
-                        CollisionFreeVector image.
+                        reduce-scatter (SUM / MIN / MAX per column, bit-OR of the
+                        existence words) of the dense CollisionFreeVector image:
+                        rank r keeps the merged keys of finalize partition r
+                        (all-reduce variant for callers that want the whole table).
 
 Everything numeric happens behind an ``ops`` object with the same surface as
 ``quickstep_amd.capi``; the product passes ``quickstep_amd.capi`` itself.
@@ -205,13 +207,99 @@ def merge_agg_state_images(ops, state, group=None):
     return state
 
 
+def _allreduce_or(words, group=None):
+    """Bit-OR all-reduce of an int64 tensor in place.  RCCL has no bitwise reductions (SUM / PROD / MIN / MAX / AVG only:
+    ReduceOp.BOR raises on the "nccl" backend), so there the words are all-gathered and OR-ed locally; the existence map
+    of a CollisionFreeVector is 1 bit per key, a sixty-fourth of one state column."""
+    if dist.get_backend(group) != "nccl":
+        dist.all_reduce(words, op=dist.ReduceOp.BOR, group=group)
+        return words
+    world = dist.get_world_size(group)
+    gathered = torch.empty(world * words.numel(), dtype=words.dtype, device=words.device)
+    dist.all_gather_into_tensor(gathered, words.contiguous(), group=group)
+    gathered = gathered.view(world, words.numel())
+    acc = gathered[0].clone()
+    for r in range(1, world):
+        acc |= gathered[r]
+    words.copy_(acc)
+    return words
+
+
+def dense_partition_range(num_entries, world, rank):
+    """Key range [begin, end) that finalize partition `rank` of `world` owns in a CollisionFreeVector state
+    (CollisionFreeVectorTable.hpp:192-208; qsx_agg_finalize uses the same split)."""
+    length = (num_entries + world - 1) // world
+    begin = min(rank * length, num_entries)
+    return begin, min(begin + length, num_entries)
+
+
+def reduce_scatter_dense_agg_image(image, exist_words, num_entries, int_col_mask, num_cols, group=None, min_max_cols=None):
+    """Reduce-scatter of the ranks' CollisionFreeVector images: afterwards rank r holds the MERGED state of the keys of
+    finalize partition r (dense_partition_range) and nothing else — the returned image is zero / identity outside that
+    range — so every rank finalizes ITS partition of the result (qsx_agg_finalize(partition=rank, num_partitions=world))
+    and no rank ever holds, or receives, the whole merged table.  Per rank this moves 1/world of what the all-reduce
+    moves.  Columns: reduce_scatter_tensor with SUM (int64 / f64) or MIN / MAX; existence bits: every rank sends each
+    peer the words covering that peer's key range (all_to_all_single), the receiver ORs them.
+
+    image: int64[exist_words + num_cols * num_entries] as exported by the state.  Returns a new image of the same layout
+    to be imported into a CLEARED state (state.clear(); state.import_merge(result))."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    length = (num_entries + world - 1) // world
+    begin, end = dense_partition_range(num_entries, world, rank)
+    out = torch.zeros_like(image)
+    padded = world * length
+    for col in range(num_cols):
+        seg = image[exist_words + col * num_entries: exist_words + (col + 1) * num_entries]
+        is_int = bool((int_col_mask >> col) & 1) or bool(min_max_cols and col in min_max_cols)
+        op = dist.ReduceOp.SUM
+        fill = 0
+        if min_max_cols and col in min_max_cols:
+            op = dist.ReduceOp.MIN if min_max_cols[col] == "min" else dist.ReduceOp.MAX
+            fill = torch.iinfo(torch.int64).max if min_max_cols[col] == "min" else torch.iinfo(torch.int64).min
+        src = seg if is_int else seg.view(torch.float64)
+        send = src.new_full((padded,), fill) if is_int else src.new_zeros(padded)
+        send[:num_entries] = src
+        mine = torch.empty(length, dtype=send.dtype, device=send.device)
+        dist.reduce_scatter_tensor(mine, send, op=op, group=group)
+        dst = out[exist_words + col * num_entries + begin: exist_words + col * num_entries + end]
+        if end > begin:
+            dst.copy_((mine if is_int else mine.view(torch.int64))[: end - begin])
+        if min_max_cols and col in min_max_cols:
+            # outside the owned range: the accumulator's identity, what a cleared state holds
+            full = out[exist_words + col * num_entries: exist_words + (col + 1) * num_entries]
+            full[:begin] = fill
+            full[end:] = fill
+    # existence words covering every peer's range (the same word may go to two neighbours: their ranges share it)
+    def word_range(r):
+        b, e = dense_partition_range(num_entries, world, r)
+        return (b // 64, (e + 63) // 64) if e > b else (0, 0)
+    splits = [word_range(r)[1] - word_range(r)[0] for r in range(world)]
+    send = torch.cat([image[word_range(r)[0]: word_range(r)[1]] for r in range(world)]) if sum(splits) else image[:0]
+    my_words = splits[rank]
+    recv = torch.empty(world * my_words, dtype=image.dtype, device=image.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[my_words] * world, input_split_sizes=splits, group=group)
+    if my_words:
+        acc = recv[:my_words].clone()
+        for r in range(1, world):
+            acc |= recv[r * my_words: (r + 1) * my_words]
+        first_word, last_word = word_range(rank)
+        # bits of neighbouring partitions that share the boundary words are dropped: the range is exactly [begin, end)
+        bit = torch.arange(first_word * 64, last_word * 64, device=image.device, dtype=torch.int64)
+        inside = ((bit >= begin) & (bit < end)).view(-1, 64)
+        weights = (torch.ones(64, dtype=torch.int64, device=image.device) << torch.arange(64, device=image.device, dtype=torch.int64))
+        mask = (inside.to(torch.int64) * weights).sum(dim=1)      # LSB-first existence words (DESIGN.md section 2)
+        out[first_word:last_word] = acc & mask
+    return out
+
+
 def allreduce_dense_agg_image(image, exist_words, num_entries, int_col_mask, num_cols, group=None, min_max_cols=None):
     """All-reduce a CollisionFreeVector state image in place: bit-OR for the
     existence words, integer SUM for count / integer columns, f64 SUM for the
     rest.  image: int64[exist_words + num_cols * num_entries].
     min_max_cols: {column: "min" | "max"} for MIN / MAX accumulators — those columns hold int64 words
     (the value itself or the order-preserving image of a double) and reduce with integer MIN / MAX."""
-    dist.all_reduce(image[:exist_words], op=dist.ReduceOp.BOR, group=group)
+    _allreduce_or(image[:exist_words], group)
     for col in range(num_cols):
         seg = image[exist_words + col * num_entries: exist_words + (col + 1) * num_entries]
         if min_max_cols and col in min_max_cols:

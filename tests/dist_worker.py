@@ -139,6 +139,46 @@ def main():
     assert img[exist_words:exist_words + entries].tolist() == [world * i + sum(range(world)) for i in range(entries)]
     assert np.allclose(img[exist_words + entries:].view(torch.float64).numpy(),
                        np.arange(entries) * 0.5 * world + sum(range(world)))
+    # the bit-OR as RCCL has to do it (no bitwise reductions there): all-gather + local OR
+    real_backend = dist.get_backend
+    dist.get_backend = lambda group=None: "nccl"
+    try:
+        bits = torch.tensor([1 << rank, 0b1010 if rank == 0 else 0b0110, -1 if rank == 1 else 0], dtype=torch.int64)
+        qd._allreduce_or(bits)
+        assert bits.tolist() == [(1 << world) - 1, 0b1110, -1]
+    finally:
+        dist.get_backend = real_backend
+    # dense image reduce-scatter: rank r ends up with the merged keys of finalize partition r only
+    entries = 150                                   # not a multiple of 64 * world: partitions share boundary words
+    exist_words = (entries + 63) // 64
+    r2 = np.random.default_rng(7 + rank)
+    present = r2.random(entries) < 0.4
+    cnt = np.where(present, r2.integers(1, 5, size=entries), 0).astype(np.int64)
+    sm = np.where(present, r2.normal(size=entries), 0.0)
+    mn = np.where(present, r2.integers(-50, 50, size=entries), np.iinfo(np.int64).max).astype(np.int64)
+    words = np.zeros(exist_words, dtype=np.uint64)
+    for k in np.nonzero(present)[0]:
+        words[k >> 6] |= np.uint64(1) << np.uint64(k & 63)
+    img = torch.from_numpy(np.concatenate([words.view(np.int64), cnt, sm.view(np.int64), mn]))
+    got = qd.reduce_scatter_dense_agg_image(img.clone(), exist_words, entries, int_col_mask=0b001, num_cols=3,
+                                            min_max_cols={2: "min"})
+    # what the all-reduce of the same images holds, restricted to this rank's partition
+    ref = img.clone()
+    qd.allreduce_dense_agg_image(ref, exist_words, entries, int_col_mask=0b001, num_cols=3, min_max_cols={2: "min"})
+    begin, end = qd.dense_partition_range(entries, world, rank)
+    ref_bits = [(int(ref[k >> 6]) >> (k & 63)) & 1 for k in range(entries)]
+    got_bits = [(int(got[k >> 6]) >> (k & 63)) & 1 for k in range(entries)]
+    assert got_bits == [b if begin <= k < end else 0 for k, b in enumerate(ref_bits)]
+    for col in range(3):
+        a = got[exist_words + col * entries: exist_words + (col + 1) * entries]
+        b = ref[exist_words + col * entries: exist_words + (col + 1) * entries]
+        if col == 1:
+            assert np.allclose(a.view(torch.float64)[begin:end].numpy(), b.view(torch.float64)[begin:end].numpy(), rtol=1e-12)
+            assert float(a.view(torch.float64)[:begin].abs().sum() + a.view(torch.float64)[end:].abs().sum()) == 0.0
+        else:
+            assert torch.equal(a[begin:end], b[begin:end])
+            outside = torch.cat([a[:begin], a[end:]])
+            assert bool((outside == (np.iinfo(np.int64).max if col == 2 else 0)).all())
     dist.barrier()
     dist.destroy_process_group()
 

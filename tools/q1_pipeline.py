@@ -23,13 +23,22 @@ n = int(6_000_000 * SF)
 cols = bench.gen_q1_columns_gpu(n, dev, 4)
 g = torch.Generator(device=dev)
 g.manual_seed(11)
-shipdate = torch.randint(19920101, 19981201, (n,), device=dev, generator=g, dtype=torch.int32)
-DATE = 19980902   # ~98 % of the rows qualify
+# l_shipdate as the reference stores it: DATE = 8-byte DateLit (year | month << 32 | day << 40), uniform over 1992-01-01 .. 1998-12-28;
+# `l_shipdate <= DATE '1998-09-02'` keeps ~95 % of the rows.  argv[2] = "int": the 4-byte integer stand-in of round 1.
+AS_INT = len(sys.argv) > 2 and sys.argv[2] == "int"
+if AS_INT:
+    shipdate = torch.randint(19920101, 19981201, (n,), device=dev, generator=g, dtype=torch.int32)
+    DATE, DATE_TYPE = 19980902, T.INT
+else:
+    shipdate = (torch.randint(1992, 1999, (n,), device=dev, generator=g, dtype=torch.int64) |
+                (torch.randint(1, 13, (n,), device=dev, generator=g, dtype=torch.int64) << 32) |
+                (torch.randint(1, 29, (n,), device=dev, generator=g, dtype=torch.int64) << 40))
+    DATE, DATE_TYPE = T.date_raw(1998, 9, 2), T.DATE
 
 q1 = bench.q1_config()
 with_pred = T.make_agg_config(
     T.AGG_COMPACT_KEY,
-    columns=[(T.CHAR, 1), (T.CHAR, 1), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)],
+    columns=[(T.CHAR, 1), (T.CHAR, 1), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (DATE_TYPE, None)],
     keys=[0, 1],
     instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0)),
             (T.EX_ADD, 2, T.const(0), T.col(5)), (T.EX_MUL, 3, T.temp(1), T.temp(2))],
@@ -50,7 +59,7 @@ def plan_state_predicate():
 
 
 def plan_select_then_aggregate():
-    bm, _ = capi.select_cmp(shipdate, T.LE, DATE)
+    bm, _ = capi.select_cmp(shipdate, T.LE, DATE, qtype=DATE_TYPE)
     s_filter.clear()
     s_filter.update(cols, n, filter_bitmap=bm)
     keys, vals, _, groups = s_filter.finalize(dev, capacity=16)
@@ -72,7 +81,7 @@ def timed(fn, reps=3):
 ms_a, (va, ka) = timed(plan_state_predicate)
 ms_b, (vb, kb) = timed(plan_select_then_aggregate)
 same = ka == kb and all(torch.allclose(x.double(), y.double(), rtol=1e-9) for x, y in zip(va, vb))
-print(json.dumps({"query": "TPC-H Q1 (synthetic, 1 GPU)", "SF": SF, "lineitem": n, "groups": ka,
+print(json.dumps({"query": "TPC-H Q1 (synthetic, 1 GPU), l_shipdate " + ("INT stand-in" if AS_INT else "DATE (8-byte DateLit)"), "SF": SF, "lineitem": n, "groups": ka,
                   "predicate in the aggregation state: ms": ms_a, "rows_per_s": n / ms_a * 1e3,
                   "select (K1) then aggregate under the bitmap: ms": ms_b, "rows_per_s (select + aggregate)": n / ms_b * 1e3,
                   "plans agree": bool(same), "count_order": [int(c) for c in va[7].tolist()]}))
