@@ -52,3 +52,23 @@ def test_partitioned_join_equals_single_table_join(capi, oracle, dev, P, dense):
     assert np.array_equal(sorted_pairs(got_l, got_o), sorted_pairs(rp, rb))
     assert np.array_equal(np.concatenate(out_lp), l_payload[got_l]) and np.array_equal(np.concatenate(out_op), o_payload[got_o])
     assert np.array_equal(o_orderkey[got_o], l_orderkey[got_l])
+
+
+def test_distributed_surface_over_rccl():
+    """Every collective of quickstep_amd/distributed.py through the real backend (RCCL) with the product's ops, one rank
+    (tests/dist_worker_rccl.py): shuffle joins (dense and hashed tables), broadcast join, hash-state merge, dense-state
+    reduce-scatter and all-reduce with SUM / MIN / bit-OR."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_worker_rccl.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_SURFACE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
