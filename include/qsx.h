@@ -177,6 +177,15 @@ int qsx_select_codes(int code_width, const void *codes_dev, int64_t n, int op, u
                      uint32_t second, const uint64_t *filter_dev, uint64_t *out_bitmap_dev,
                      int64_t *out_count_dev, qsx_stream_t stream);
 
+/* qsx_select_codes on the code stripe of the block's SORT column (codes ascend with the values: truncation keeps the
+ * order, dictionaries are sorted): the matching rows are one range found by two searches instead of a scan — the
+ * sort-column branches of CompressedColumnStoreTupleStorageSubBlock::get{Equal,NotEqual,Less,GreaterOrEqual}Codes /
+ * getCodesInRange (storage/CompressedColumnStoreTupleStorageSubBlock.cpp:420-760).  lineitem, orders and partsupp
+ * are sorted on their key in the reference's TPC-H DDL (benchmarks/tpch/create.sql:57-121).  Same arguments and result. */
+int qsx_select_codes_sorted(int code_width, const void *codes_dev, int64_t n, int op, uint32_t first, uint32_t second,
+                            const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev,
+                            qsx_stream_t stream);
+
 /* Decode a code stripe into values of value_width (4 or 8) bytes: out[i] = dictionary[codes[i]], or the
  * zero-extended code when dictionary_dev is NULL (truncated attribute).  What
  * CompressedTupleStorageSubBlock::getAttributeValue does per tuple (storage/

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "qsx_select_cmp_char": (_int, [_vp, _int, _i64, _int, C.c_char_p, _int, _vp, _vp, _vp, _vp]),
     "qsx_select_cmp_columns": (_int, [_int, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "qsx_select_codes": (_int, [_int, _vp, _i64, _int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "qsx_select_codes_sorted": (_int, [_int, _vp, _i64, _int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "qsx_decode_codes": (_int, [_int, _vp, _i64, _vp, _int, _vp, _vp]),
     "qsx_bitmap_combine": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_bitmap_count": (_int, [_vp, _i64, _vp, _vp]),
@@ -224,6 +225,16 @@ def select_codes(codes, op, first, second=0, filter_bitmap=None, stream=None):
     out_count = torch.zeros(1, dtype=torch.int64, device=codes.device)
     _check(_lib.qsx_select_codes(codes.element_size(), _ptr(codes), n, op, first, second, _ptr(filter_bitmap),
                                  _ptr(out_bitmap), _ptr(out_count), _stream(stream)), "qsx_select_codes")
+    return out_bitmap, out_count
+
+
+def select_codes_sorted(codes, op, first, second=0, filter_bitmap=None, stream=None):
+    """K1 on the code stripe of a compressed SORT column (ascending codes): binary search instead of a scan."""
+    n = codes.numel()
+    out_bitmap = new_bitmap(n, codes.device)
+    out_count = torch.zeros(1, dtype=torch.int64, device=codes.device)
+    _check(_lib.qsx_select_codes_sorted(codes.element_size(), _ptr(codes), n, op, first, second, _ptr(filter_bitmap),
+                                        _ptr(out_bitmap), _ptr(out_count), _stream(stream)), "qsx_select_codes_sorted")
     return out_bitmap, out_count
 
 

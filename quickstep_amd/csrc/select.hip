@@ -341,6 +341,35 @@ __global__ __launch_bounds__(kWave) void sorted_bounds_kernel(const T *__restric
   }
 }
 
+// The same search on the code stripe of a compressed SORT column (codes ascend with the values: truncation keeps the
+// order, a dictionary is sorted): rows with lo <= code < hi are [lower_bound(lo), lower_bound(hi)).
+template <typename T>
+__global__ __launch_bounds__(kWave) void sorted_code_bounds_kernel(const T *__restrict__ codes, int64_t n, unsigned long long lo_code,
+                                                                  unsigned long long hi_code, SortedBounds *__restrict__ out) {
+  const int lane = lane_id();
+  long long result[2];
+  for (int which = 0; which < 2; ++which) {
+    const unsigned long long target = which == 0 ? lo_code : hi_code;   // first row with code >= target
+    long long lo = 0, hi = n;
+    while (hi - lo > 0) {
+      const long long span = hi - lo;
+      const long long step = (span + kWave) / (kWave + 1);
+      const long long at = lo + step * (lane + 1) - 1;
+      const bool left = at < hi && static_cast<unsigned long long>(codes[at < hi ? at : hi - 1]) < target;
+      const int passed = __popcll(__ballot(left));
+      const long long new_lo = passed == 0 ? lo : lo + step * passed;
+      const long long new_hi = passed == kWave ? hi : (lo + step * (passed + 1) - 1 < hi ? lo + step * (passed + 1) - 1 : hi);
+      lo = new_lo < hi ? new_lo : hi;
+      hi = new_hi;
+    }
+    result[which] = lo;
+  }
+  if (lane == 0) {
+    out->lower = result[0];
+    out->upper = result[1] > result[0] ? result[1] : result[0];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void sorted_range_bitmap_kernel(const SortedBounds *__restrict__ bounds, int64_t n, int op,
                                                                     const uint64_t *__restrict__ filter,
                                                                     uint64_t *__restrict__ out,
@@ -954,6 +983,41 @@ int qsx_select_codes(int code_width, const void *codes_dev, int64_t n, int op, u
       break;
     default: return QSX_ERR_UNSUPPORTED;
   }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_select_codes_sorted(int code_width, const void *codes_dev, int64_t n, int op, uint32_t first, uint32_t second,
+                            const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || op < QSX_CODE_EQ || op > QSX_CODE_RANGE || (n > 0 && (codes_dev == nullptr || out_bitmap_dev == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (code_width != 1 && code_width != 2 && code_width != 4) return QSX_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return QSX_OK;
+  // the comparison as a code range [lo, hi), != as its complement (as qsx_select_codes)
+  const unsigned long long lo = op == QSX_CODE_LT ? 0ull : first;
+  const unsigned long long hi = (op == QSX_CODE_EQ || op == QSX_CODE_NE) ? static_cast<unsigned long long>(first) + 1
+                                : op == QSX_CODE_LT ? first : op == QSX_CODE_GE ? (1ull << 32) : second;
+  SortedBounds *bounds = device_slot<SortedBounds>(s);
+  if (bounds == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  switch (code_width) {
+    case 1:
+      hipLaunchKernelGGL(sorted_code_bounds_kernel<uint8_t>, dim3(1), dim3(kWave), 0, s, static_cast<const uint8_t *>(codes_dev), n, lo, hi, bounds);
+      break;
+    case 2:
+      hipLaunchKernelGGL(sorted_code_bounds_kernel<uint16_t>, dim3(1), dim3(kWave), 0, s, static_cast<const uint16_t *>(codes_dev), n, lo, hi, bounds);
+      break;
+    default:
+      hipLaunchKernelGGL(sorted_code_bounds_kernel<uint32_t>, dim3(1), dim3(kWave), 0, s, static_cast<const uint32_t *>(codes_dev), n, lo, hi, bounds);
+      break;
+  }
+  QSX_CHECK_LAUNCH();
+  const int grid = grid_for((n + 63) >> 6, kBlock * 8) < 2 * kCUs ? grid_for((n + 63) >> 6, kBlock * 8) : 2 * kCUs;
+  hipLaunchKernelGGL(sorted_range_bitmap_kernel, dim3(grid), dim3(kBlock), 0, s, bounds, n, op == QSX_CODE_NE ? QSX_NE : QSX_EQ, filter_dev,
+                     out_bitmap_dev, reinterpret_cast<unsigned long long *>(out_count_dev));
   QSX_CHECK_LAUNCH();
   return QSX_OK;
 }

@@ -639,6 +639,12 @@ void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num
         CheckStatus(qsx_select_codes(c->code_width, c->codes, n, r.type == PredicateTransformResult::kAll ? QSX_CODE_GE : QSX_CODE_LT, 0, 0,
                                      in, static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
                     "qsx_select_codes");
+      } else if (term.attribute == block.sortColumn()) {
+        // the sort column of a compressed store: the codes ascend, the matches are one range (the sort-column branches of
+        // CompressedColumnStoreTupleStorageSubBlock.cpp:420-760)
+        CheckStatus(qsx_select_codes_sorted(c->code_width, c->codes, n, r.comp, r.first_literal, r.second_literal, in,
+                                            static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),
+                    "qsx_select_codes_sorted");
       } else {
         CheckStatus(qsx_select_codes(c->code_width, c->codes, n, r.comp, r.first_literal, r.second_literal, in,
                                      static_cast<std::uint64_t *>(next), static_cast<std::int64_t *>(count), CurrentStream()),

@@ -138,6 +138,46 @@ int main() {
       EXPECT_EQ(got.size(), want.size());
       EXPECT_TRUE(got == want);
     }
+    // ---- a compressed store's SORT column: customer is sorted on c_custkey (1 .. kRows); in the compressed run the key is
+    // truncated to 4-byte codes... per 40 000-row block to 2- or 4-byte codes, and the predicate is answered by two searches
+    {
+      CatalogRelation sorted_rel(20, "sorted_customer"), out(21, "out");
+      sorted_rel.addAttribute("c_custkey", Type::Int());
+      out.addAttribute("c_custkey", Type::Int());
+      const std::vector<bool> flags{true};
+      for (std::int64_t at = 0; at < kRows; at += kBlockRows) {
+        const block_id id = storage.loadBlock(&sorted_rel, {t.c_custkey.data() + at}, kBlockRows, 0, compressed ? &flags : nullptr);
+        storage.getBlock(id)->setSortColumn(0);
+      }
+      for (const auto &probe : std::vector<std::pair<ComparisonID, int>>{{ComparisonID::kLess, 50000}, {ComparisonID::kGreaterOrEqual, 100001},
+                                                                         {ComparisonID::kEqual, 40001}, {ComparisonID::kNotEqual, 7}}) {
+        QueryContext ctx;
+        Predicate pred;
+        pred.conjuncts.push_back({0, probe.first, TypedLiteral::Int(probe.second)});
+        const auto pred_id = ctx.addPredicate(pred);
+        const auto dest = ctx.addInsertDestination(&out, &storage);
+        SelectOperator select(0, sorted_rel, false, out, dest, pred_id, std::vector<attribute_id>{0}, true);
+        fetchAndExecuteWorkOrders(&select, &ctx, &storage);
+        std::int64_t got = 0, sum = 0;
+        for (block_id b : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+          BlockReference blk = storage.getBlock(b);
+          std::vector<std::int32_t> keys(static_cast<std::size_t>(blk->numTuples()));
+          blk->copyAttributeToHost(0, keys.data());
+          got += blk->numTuples();
+          for (std::int32_t k : keys) sum += k;
+        }
+        std::int64_t want = 0, want_sum = 0;
+        for (std::int64_t i = 0; i < kRows; ++i) {
+          const int k = t.c_custkey[i];
+          const bool keep = probe.first == ComparisonID::kLess ? k < probe.second
+                            : probe.first == ComparisonID::kGreaterOrEqual ? k >= probe.second
+                            : probe.first == ComparisonID::kEqual ? k == probe.second : k != probe.second;
+          if (keep) { ++want; want_sum += k; }
+        }
+        EXPECT_EQ(got, want);
+        EXPECT_EQ(sum, want_sum);
+      }
+    }
     // ---- Q3: orders WHERE o_orderdate < DATE '1995-03-15', GROUP BY o_orderkey, o_orderdate, o_shippriority --------------
     {
       CatalogRelation result(11, "result");

@@ -37,6 +37,28 @@ def test_code_stripe_scans_are_bit_exact(capi, oracle, dev, n):
                 assert int(cnt.item()) == oracle.bitmap_count(want, n)
 
 
+@pytest.mark.parametrize("n", [1, 65, 5000, 400_003])
+def test_sorted_code_stripe_by_binary_search(capi, oracle, dev, n):
+    """The sort column of a compressed column store (lineitem / orders / partsupp in the reference's TPC-H DDL): ascending
+    codes, every code comparison answered by two searches — must equal the scan of the same stripe."""
+    rng = np.random.default_rng(n + 3)
+    f = oracle.bitmap_from_bools(rng.random(n) < 0.5)
+    for width, np_t, hi in ((1, np.uint8, 256), (2, np.uint16, 65536), (4, np.uint32, 2**32)):
+        codes = np.sort(rng.integers(0, min(hi, max(4, n // 3)), size=n, dtype=np.uint64)).astype(np_t)   # runs of equal codes
+        if n > 100 and width == 4:
+            codes[-3:] = hi - 1                                                                            # the largest code
+        d = torch.from_numpy(codes.view({1: np.uint8, 2: np.int16, 4: np.int32}[width]).copy()).to(dev)
+        picks = sorted({int(codes[0]), int(codes[n // 2]), int(codes[-1]), 0, min(hi - 1, int(codes[-1]) + 1)})
+        for a in picks:
+            for op, b in ((T.CODE_EQ, 0), (T.CODE_NE, 0), (T.CODE_LT, 0), (T.CODE_GE, 0), (T.CODE_RANGE, min(hi - 1, a + 7)),
+                          (T.CODE_RANGE, max(a - 1, 0))):
+                for filt in (None, f):
+                    bm, cnt = capi.select_codes_sorted(d, op, a, b, filter_bitmap=None if filt is None else bitmap_dev(filt, dev))
+                    want = oracle.select_codes(codes, op, a, b, filt)
+                    assert np.array_equal(bitmap_np(bm), want), (n, width, op, a, b)
+                    assert int(cnt.item()) == oracle.bitmap_count(want, n)
+
+
 def test_compressed_columns_select_and_decode(capi, oracle, dev):
     """getMatchesForPredicate on compressed attributes: the caller's transform (oracle restatement here, the C++
     host layer in the product) + qsx_select_codes == the comparison on the uncompressed values through qsx_select_cmp;
