@@ -1650,9 +1650,11 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
     if (rc == QSX_OK) QSX_CHECK_LAUNCH();
   } else
   // (and so do states over nullable columns: a null bitmap cannot be scattered like a value column)
-  // (and states with a wide key: K9 packs the key code itself, it does not know the hashed form)
+  // (and states with a DATE key: K9 packs the key columns itself and would take the DateLit padding bytes along.  A wide
+  // key is fine: K9 ORs the components at their in-word shifts — equal keys still meet in one piece, which is all the
+  // pieces have to guarantee; the per-piece tables are keyed by the hashed code like everything else)
   if (!st->dense && st->part_count > 1 && filter_dev == nullptr && !st->has_coded_columns && st->dev.num_null_cols == 0 &&
-      st->dev.wide_words == 0 && !st->has_date_key && n >= partition_min_rows()) {
+      !st->has_date_key && n >= partition_min_rows()) {
     rc = update_partitioned(st, cols, n, s);
   } else {
     rc = update_slice(st, cols, dicts, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s, nulls);

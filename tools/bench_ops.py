@@ -56,6 +56,21 @@ dcol = torch.rand(N, device=dev, generator=g, dtype=torch.float64)
 ms = timed(lambda: capi.select_cmp(dcol, T.LE, 0.98, out_bitmap=bm, out_count=cnt))
 report("K1 select_cmp DOUBLE col<=K", ms, N, 8 * N)
 
+# the reference's DATE (8-byte DateLit: year, month, day) and CHAR(10) attributes: l_shipdate <= DATE, c_mktsegment = 'BUILDING'
+dates = (torch.randint(1992, 1999, (N,), device=dev, generator=g, dtype=torch.int64) |
+         (torch.randint(1, 13, (N,), device=dev, generator=g, dtype=torch.int64) << 32) |
+         (torch.randint(1, 29, (N,), device=dev, generator=g, dtype=torch.int64) << 40))
+ms = timed(lambda: capi.select_cmp(dates, T.LE, T.date_raw(1998, 9, 2), out_bitmap=bm, out_count=cnt, qtype=T.DATE))
+report("K1 select_cmp DATE col<=K", ms, N, 8 * N)
+del dates
+nchar = N // 4
+words = torch.tensor([list(w.ljust(10, b"\0")) for w in (b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD")],
+                     dtype=torch.uint8, device=dev)
+segment = words[torch.randint(0, 5, (nchar,), device=dev, generator=g)].contiguous()
+ms = timed(lambda: capi.select_cmp_char(segment, T.EQ, b"BUILDING"))
+report("K1 select_cmp_char CHAR(10) = 'BUILDING'", ms, nchar, 10 * nchar)
+del segment
+
 # compressed attribute: the same predicate on a 1-byte code stripe (dictionary / truncated column), and the decode
 codes = torch.randint(0, 50, (N,), device=dev, generator=g, dtype=torch.uint8)
 ms = timed(lambda: capi.select_codes(codes, T.CODE_LT, 24))
@@ -124,7 +139,24 @@ gencfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.INT, None), (T.DOUB
                            aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None)], est_groups=10_000)
 st = capi.AggState(gencfg)
 ms = timed(lambda: st.update([k1, k2, val], na), reps=3)
-report("K8 aggregate GENERIC 2 INT keys, 10 k groups (partitioned; run-time plan shape)", ms, na, 16 * na)
+report("K8 aggregate GENERIC 2 INT keys, 10 k groups (group directory: key box; run-time plan shape)", ms, na, 16 * na)
+st = capi.AggState(gencfg)
+s1, s2 = k1 * 1_000_003, k2 * 7_919 - 11
+ms = timed(lambda: st.update([s1, s2, val], na), reps=3)
+del s1, s2
+report("K8 aggregate GENERIC 2 INT keys spread over the INT range, 10 k groups (group directory: looked up)", ms, na, 16 * na)
+os.environ["QSX_AGG_DIRECTORY"] = "0"
+st = capi.AggState(gencfg)
+ms = timed(lambda: st.update([k1, k2, val], na), reps=3)
+os.environ.pop("QSX_AGG_DIRECTORY")
+report("K8 the same without the group directory (K9 on the key code + per-piece tables: round 1)", ms, na, 16 * na)
+widecfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.LONG, None), (T.INT, None), (T.DOUBLE, None)], keys=[0, 1, 2],
+                            aggs=[(T.AGG_SUM, T.col(3)), (T.AGG_COUNT_STAR, None)], est_groups=10_000)
+st = capi.AggState(widecfg)
+k_long, k_bit = k2.long() << 33, k1 & 1
+ms = timed(lambda: st.update([k1, k_long, k_bit, val], na), reps=3)
+report("K8 aggregate 16-byte key (INT, LONG, INT), 10 k groups (hashed words + MIN/MAX proof)", ms, na, 24 * na)
+del k_long, k_bit
 # Q3 group-by shape: dense key (orders at SF100: 150 M keys for 600 M lineitems -> 4 rows per key, clustered)
 ne = na // 4
 okey = (torch.arange(na, device=dev, dtype=torch.int64) // 4).to(torch.int32)
