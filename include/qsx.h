@@ -446,6 +446,19 @@ typedef struct qsx_pred_term {
 #define QSX_MAX_CONSTS 8
 #define QSX_MAX_PRED_TERMS 4
 
+/* K11 on its own: out[i] = value of `result` after running the program over row i — the projection of a scalar
+ * expression by a SelectWorkOrder / HashJoinWorkOrder (Scalar::getAllValues:
+ * expressions/scalar/ScalarBinaryExpression.cpp:100-195, ScalarAttribute.cpp:171-226, ScalarLiteral), one fused pass instead
+ * of a NativeColumnVector per expression node.  Inside an aggregation the same program runs fused with the accumulation
+ * (qsx_agg_config_t::instrs) and never comes here.
+ *   cols / types  the num_columns input stripes (INT / LONG / FLOAT / DOUBLE), n rows each
+ *   instrs        host array, at most QSX_MAX_INSTRS; consts: host array of QSX_MAX_CONSTS doubles (or NULL)
+ *   result        the operand whose value is written (a column: its conversion to DOUBLE; a constant; a temp)
+ *   out_dev       n doubles */
+int qsx_eval_expression(int num_columns, const void *const *cols, const int32_t *types, int num_instrs,
+                        const qsx_expr_instr_t *instrs, const double *consts, qsx_operand_t result, int64_t n,
+                        double *out_dev, qsx_stream_t stream);
+
 typedef struct qsx_agg_config {
   int32_t strategy;                       /* qsx_agg_strategy_t */
   int32_t num_columns;                    /* columns handed to every qsx_agg_update */

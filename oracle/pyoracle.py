@@ -53,6 +53,7 @@ for _name, _res, _args in [
     ("qso_partition_id", _u64, [_u64, _u64]),
     ("qso_select_cmp", None, [_int, _vp, _i64, _int, _vp, _vp, _vp]),
     ("qso_select_cmp_sorted", None, [_int, _vp, _i64, _int, _vp, _vp, _vp]),
+    ("qso_eval_expression", None, [_int, _pp, C.POINTER(_i32), _int, C.POINTER(T.ExprInstr), C.POINTER(C.c_double), T.Operand, _i64, _vp]),
     ("qso_select_cmp_char", None, [_vp, _int, _i64, _int, C.c_char_p, _int, _vp, _vp]),
     ("qso_bitmap_count", _i64, [_vp, _i64]),
     ("qso_compact_gather", _i64, [_int, _vp, _vp, _i64, _vp]),
@@ -173,6 +174,18 @@ def select_cmp(col, op, literal, filter_bitmap=None, qt=None):
     lit = _literal(qt, literal)
     _lib.qso_select_cmp(qt, _p(col), n, op, C.byref(lit), _p(filter_bitmap), _p(out))
     return out
+
+
+def eval_expression(cols, instrs, consts, result):
+    keep = [np.ascontiguousarray(c) for c in cols]
+    n = keep[0].size
+    out = np.zeros(max(n, 1), dtype=np.float64)
+    ptrs = (C.c_void_p * max(len(keep), 1))(*[c.ctypes.data for c in keep])
+    types = (C.c_int32 * max(len(keep), 1))(*[_NP_TYPE[c.dtype] for c in keep])
+    prog = (T.ExprInstr * max(len(instrs), 1))(*[T.ExprInstr(op, dst, a, b) for op, dst, a, b in instrs])
+    cs = (C.c_double * T.MAX_CONSTS)(*list(consts))
+    _lib.qso_eval_expression(len(keep), ptrs, types, len(instrs), prog, cs, result, n, _p(out))
+    return out[:n]
 
 
 def select_cmp_char(col, op, literal, filter_bitmap=None):

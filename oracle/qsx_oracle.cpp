@@ -1138,6 +1138,41 @@ void emit_keys_from_code(const qsx_agg_config_t &c, std::uint64_t code, std::int
 
 extern "C" {
 
+// ScalarBinaryExpression::getAllValues (expressions/scalar/ScalarBinaryExpression.cpp:100-195): every node evaluated into
+// its own vector in IEEE double, left to right as written; here row by row with the same per-node rounding.
+void qso_eval_expression(int num_columns, const void *const *cols, const int32_t *types, int num_instrs,
+                         const qsx_expr_instr_t *instrs, const double *consts, qsx_operand_t result, int64_t n, double *out) {
+  (void)num_columns;
+  for (int64_t i = 0; i < n; ++i) {
+    double temps[QSX_MAX_TEMPS] = {};
+    auto operand = [&](const qsx_operand_t &o) -> double {
+      switch (o.kind) {
+        case QSX_OPD_COLUMN:
+          switch (types[o.index]) {
+            case QSX_INT: return static_cast<double>(static_cast<const std::int32_t *>(cols[o.index])[i]);
+            case QSX_LONG: return static_cast<double>(static_cast<const std::int64_t *>(cols[o.index])[i]);
+            case QSX_FLOAT: return static_cast<double>(static_cast<const float *>(cols[o.index])[i]);
+            default: return static_cast<const double *>(cols[o.index])[i];
+          }
+        case QSX_OPD_CONST: return consts[o.index];
+        default: return temps[o.index];
+      }
+    };
+    for (int k = 0; k < num_instrs; ++k) {
+      const double a = operand(instrs[k].a), b = operand(instrs[k].b);
+      double r;
+      switch (instrs[k].op) {
+        case QSX_EX_ADD: r = a + b; break;
+        case QSX_EX_SUB: r = a - b; break;
+        case QSX_EX_MUL: r = a * b; break;
+        default: r = a / b; break;
+      }
+      temps[instrs[k].dst] = r;
+    }
+    out[i] = operand(result);
+  }
+}
+
 qso_agg_state_t *qso_agg_state_create(const qsx_agg_config_t *config) {
   return new qso_agg_state(*config);
 }

@@ -87,6 +87,7 @@ _SIGNATURES = {
     "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_probe_count": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "qsx_join_probe_exists": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
+    "qsx_eval_expression": (_int, [_int, _pp, C.POINTER(_i32), _int, C.POINTER(T.ExprInstr), C.POINTER(C.c_double), T.Operand, _i64, _vp, _vp]),
     "qsx_agg_state_create": (_int, [C.POINTER(T.AggConfig), _pp]),
     "qsx_agg_state_destroy": (_int, [_vp]),
     "qsx_agg_state_clear": (_int, [_vp, _vp]),
@@ -226,6 +227,19 @@ def select_codes(codes, op, first, second=0, filter_bitmap=None, stream=None):
     _check(_lib.qsx_select_codes(codes.element_size(), _ptr(codes), n, op, first, second, _ptr(filter_bitmap),
                                  _ptr(out_bitmap), _ptr(out_count), _stream(stream)), "qsx_select_codes")
     return out_bitmap, out_count
+
+
+def eval_expression(cols, instrs, consts, result, stream=None):
+    """K11 standalone: the value of `result` (T.col / T.const / T.temp) after the program, per row, as float64."""
+    n = cols[0].numel()
+    out = torch.empty(n, dtype=torch.float64, device=cols[0].device)
+    ptrs = (C.c_void_p * max(len(cols), 1))(*[c.data_ptr() for c in cols])
+    types = (C.c_int32 * max(len(cols), 1))(*[qsx_type_of(c) for c in cols])
+    prog = (T.ExprInstr * max(len(instrs), 1))(*[T.ExprInstr(op, dst, a, b) for op, dst, a, b in instrs])
+    cs = (C.c_double * T.MAX_CONSTS)(*list(consts))
+    _check(_lib.qsx_eval_expression(len(cols), ptrs, types, len(instrs), prog, cs, result, n, _ptr(out), _stream(stream)),
+           "qsx_eval_expression")
+    return out
 
 
 def select_codes_sorted(codes, op, first, second=0, filter_bitmap=None, stream=None):

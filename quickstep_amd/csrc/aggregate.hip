@@ -287,6 +287,77 @@ __global__ __launch_bounds__(kABlock) void finalize_hash_kernel(HashTableView g,
   }
 }
 
+// ---- K11 standalone: a scalar expression projected into a column (qsx_eval_expression) --------------------------------
+// The expression program of the aggregation kernel over global stripes instead of a staged tile: kExprRows rows per
+// thread, every node rounded on its own (-ffp-contract=off) like the reference's materialised temp vectors.
+constexpr int kExprRows = 2;
+struct ExprProgram {
+  const void *cols[QSX_MAX_COLUMNS];
+  int types[QSX_MAX_COLUMNS];
+  int num_instrs;
+  DevInstr instrs[QSX_MAX_INSTRS];
+  double consts[QSX_MAX_CONSTS];
+  DevOperand result;
+};
+static_assert(sizeof(ExprProgram) % 4 == 0, "store_struct_kernel copies words");
+__device__ __forceinline__ void expr_operand(const ExprProgram &p, const DevOperand &o, const Temps<kExprRows> &t, const int64_t (&row)[kExprRows],
+                                             double (&out)[kExprRows]) {
+  switch (o.kind) {
+    case QSX_OPD_COLUMN: {
+      const void *col = p.cols[o.index];
+#pragma unroll
+      for (int v = 0; v < kExprRows; ++v) {
+        switch (p.types[o.index]) {
+          case QSX_INT: out[v] = static_cast<double>(static_cast<const int32_t *>(col)[row[v]]); break;
+          case QSX_LONG: out[v] = static_cast<double>(static_cast<const long long *>(col)[row[v]]); break;
+          case QSX_FLOAT: out[v] = static_cast<double>(static_cast<const float *>(col)[row[v]]); break;
+          default: out[v] = static_cast<const double *>(col)[row[v]]; break;
+        }
+      }
+      break;
+    }
+    case QSX_OPD_CONST:
+#pragma unroll
+      for (int v = 0; v < kExprRows; ++v) out[v] = p.consts[o.index];
+      break;
+    default:
+      temps_get<kExprRows>(t, o.index, out);
+      break;
+  }
+}
+__global__ __launch_bounds__(kABlock) void eval_expression_kernel(const ExprProgram *__restrict__ program, int64_t n, double *__restrict__ out) {
+  const ExprProgram &p = *program;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kABlock;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kABlock + threadIdx.x; base < n; base += stride * kExprRows) {
+    int64_t row[kExprRows];
+#pragma unroll
+    for (int v = 0; v < kExprRows; ++v) row[v] = base + v * stride < n ? base + v * stride : n - 1;   // clamped, stores are guarded
+    Temps<kExprRows> temps;
+    for (int k = 0; k < p.num_instrs; ++k) {
+      const DevInstr in = p.instrs[k];
+      double a[kExprRows], b[kExprRows], r[kExprRows];
+      expr_operand(p, in.a, temps, row, a);
+      expr_operand(p, in.b, temps, row, b);
+#pragma unroll
+      for (int v = 0; v < kExprRows; ++v) {
+        switch (in.op) {
+          case QSX_EX_ADD: r[v] = a[v] + b[v]; break;
+          case QSX_EX_SUB: r[v] = a[v] - b[v]; break;
+          case QSX_EX_MUL: r[v] = a[v] * b[v]; break;
+          default: r[v] = a[v] / b[v]; break;
+        }
+      }
+      temps_set<kExprRows>(temps, in.dst, r);
+    }
+    double value[kExprRows];
+    expr_operand(p, p.result, temps, row, value);
+#pragma unroll
+    for (int v = 0; v < kExprRows; ++v) {
+      if (base + v * stride < n) out[base + v * stride] = value[v];
+    }
+  }
+}
+
 // A wide-key state whose finalize saw MIN != MAX in a key word reports it in the group count (include/qsx.h).
 __global__ void report_collision_kernel(const int *collision, unsigned long long *out_groups) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && *collision != 0) *out_groups = static_cast<unsigned long long>(QSX_GROUPS_HASH_COLLISION);
@@ -1802,6 +1873,58 @@ int qsx_agg_num_groups(qsx_agg_state_t *st, int64_t *out_groups, qsx_stream_t st
     QSX_HIP_TRY(hipStreamSynchronize(s));
     *out_groups = static_cast<int64_t>(v) + 1;  // + the sentinel slot
   }
+  return QSX_OK;
+}
+
+int qsx_eval_expression(int num_columns, const void *const *cols, const int32_t *types, int num_instrs,
+                        const qsx_expr_instr_t *instrs, const double *consts, qsx_operand_t result, int64_t n, double *out_dev,
+                        qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (num_columns < 0 || num_columns > QSX_MAX_COLUMNS || num_instrs < 0 || num_instrs > QSX_MAX_INSTRS || n < 0 ||
+      (num_columns > 0 && (cols == nullptr || types == nullptr)) || (num_instrs > 0 && instrs == nullptr) ||
+      (n > 0 && out_dev == nullptr)) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  ExprProgram prog{};
+  prog.num_instrs = num_instrs;
+  for (int c = 0; c < num_columns; ++c) {
+    if (types[c] != QSX_INT && types[c] != QSX_LONG && types[c] != QSX_FLOAT && types[c] != QSX_DOUBLE) return QSX_ERR_UNSUPPORTED;
+    if (n > 0 && cols[c] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    prog.cols[c] = cols[c];
+    prog.types[c] = types[c];
+  }
+  int defined = 0;
+  auto valid = [&](const qsx_operand_t &o) {
+    switch (o.kind) {
+      case QSX_OPD_COLUMN: return o.index >= 0 && o.index < num_columns;
+      case QSX_OPD_CONST: return o.index >= 0 && o.index < QSX_MAX_CONSTS && consts != nullptr;
+      case QSX_OPD_TEMP: return o.index >= 0 && o.index < QSX_MAX_TEMPS && ((defined >> o.index) & 1) != 0;
+      default: return false;
+    }
+  };
+  for (int k = 0; k < num_instrs; ++k) {
+    const qsx_expr_instr_t &in = instrs[k];
+    if (in.op < QSX_EX_ADD || in.op > QSX_EX_DIV || in.dst < 0 || in.dst >= QSX_MAX_TEMPS || !valid(in.a) || !valid(in.b)) {
+      return QSX_ERR_INVALID_ARGUMENT;
+    }
+    prog.instrs[k].op = in.op;
+    prog.instrs[k].dst = in.dst;
+    prog.instrs[k].a = DevOperand{in.a.kind, in.a.index};
+    prog.instrs[k].b = DevOperand{in.b.kind, in.b.index};
+    defined |= 1 << in.dst;
+  }
+  if (!valid(result)) return QSX_ERR_INVALID_ARGUMENT;
+  prog.result = DevOperand{result.kind, result.index};
+  for (int k = 0; k < QSX_MAX_CONSTS; ++k) prog.consts[k] = consts != nullptr ? consts[k] : 0.0;
+  if (n == 0) return QSX_OK;
+  hipStream_t s = as_stream(stream);
+  // the program travels through a device slot, not the kernarg segment (DESIGN.md "Kernel arguments")
+  ExprProgram *slot = device_slot<ExprProgram>(s);
+  if (slot == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  hipLaunchKernelGGL(store_struct_kernel<ExprProgram>, dim3(1), dim3(64), 0, s, prog, slot);
+  QSX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(eval_expression_kernel, dim3(grid_for(n, kABlock * kExprRows)), dim3(kABlock), 0, s, slot, n, out_dev);
+  QSX_CHECK_LAUNCH();
   return QSX_OK;
 }
 

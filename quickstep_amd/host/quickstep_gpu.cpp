@@ -596,6 +596,7 @@ void ProjectNullBitmaps(const StorageBlock &block, const std::vector<attribute_i
   const std::int64_t n = block.numTuples();
   std::unique_ptr<DeviceBuffer> tids;
   for (std::size_t i = 0; i < selection.size(); ++i) {
+    if (selection[i] == kInvalidAttributeID) continue;          // an expression's value: no bitmap to carry over
     if (block.nullBitmap(selection[i]) == nullptr) continue;   // the output bitmap stays all-zero
     std::uint64_t *dst = out->nullBitmap(static_cast<attribute_id>(i));
     if (dst == nullptr) throw ExecutionError("projection of a nullable attribute into a non-nullable one", QSX_ERR_INVALID_ARGUMENT);
@@ -718,8 +719,9 @@ std::vector<block_id> InsertDestination::getTouchedBlocks() const {
 // ---------------------------------------------------------------------------
 struct AggregationOperationState::Distinctify {
   std::size_t agg_index = 0;            // position in spec.aggregates
-  std::vector<attribute_id> attrs;      // group-by..., argument
+  std::vector<attribute_id> attrs;      // group-by..., argument (kInvalidAttributeID: the argument is `expression`)
   std::vector<Type> types;
+  ScalarPtr expression;                 // DISTINCT over an arithmetic expression: evaluated per block into a DOUBLE column
   std::mutex mutex;                     // many AggregationWorkOrders append concurrently
   struct Chunk {
     std::vector<std::unique_ptr<DeviceBuffer>> cols;
@@ -749,6 +751,41 @@ Type AggResultType(AggregationID id, const Type &argument) {
 }
 }  // namespace
 
+qsx_operand_t ExpressionFlattener::add(const ScalarPtr &scalar) {
+  if (scalar == nullptr) throw ExecutionError("ExpressionFlattener: null scalar", QSX_ERR_INVALID_ARGUMENT);
+  switch (scalar->kind) {
+    case Scalar::kAttribute:
+      return qsx_operand_t{QSX_OPD_COLUMN, column_of_(scalar->attribute)};
+    case Scalar::kLiteral: {
+      for (std::size_t i = 0; i < consts_.size(); ++i) {
+        if (std::memcmp(&consts_[i], &scalar->literal, sizeof(double)) == 0) return qsx_operand_t{QSX_OPD_CONST, static_cast<std::int32_t>(i)};
+      }
+      if (consts_.size() >= QSX_MAX_CONSTS) throw ExecutionError("expression: too many distinct literals", QSX_ERR_UNSUPPORTED);
+      consts_.push_back(scalar->literal);
+      return qsx_operand_t{QSX_OPD_CONST, static_cast<std::int32_t>(consts_.size() - 1)};
+    }
+    default: {
+      const qsx_operand_t a = add(scalar->left), b = add(scalar->right);
+      const std::int32_t op = static_cast<std::int32_t>(scalar->operation);   // kAdd .. kDivide = QSX_EX_ADD .. QSX_EX_DIV
+      for (const qsx_expr_instr_t &in : instrs_) {   // the same node again (shared subexpression): its temp
+        if (in.op == op && in.a.kind == a.kind && in.a.index == a.index && in.b.kind == b.kind && in.b.index == b.index) {
+          return qsx_operand_t{QSX_OPD_TEMP, in.dst};
+        }
+      }
+      if (instrs_.size() >= QSX_MAX_INSTRS || instrs_.size() >= QSX_MAX_TEMPS) {
+        throw ExecutionError("expression: more nodes than the kernel's program holds", QSX_ERR_UNSUPPORTED);
+      }
+      qsx_expr_instr_t in;
+      in.op = op;
+      in.dst = static_cast<std::int32_t>(instrs_.size());   // one temp per node
+      in.a = a;
+      in.b = b;
+      instrs_.push_back(in);
+      return qsx_operand_t{QSX_OPD_TEMP, in.dst};
+    }
+  }
+}
+
 AggregationOperationState::AggregationOperationState(const AggregationStateSpec &spec) : spec_(spec) {
   // the library must have been built from the header this file was compiled against
   if (qsx_abi_version() != QSX_ABI_VERSION || qsx_abi_sizeof_agg_config() != sizeof(qsx_agg_config_t)) {
@@ -772,8 +809,38 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
   config_.num_keys = static_cast<int>(spec.group_by.size());
   for (std::size_t k = 0; k < spec.group_by.size(); ++k) config_.key_column[k] = column_of(spec.group_by[k]);
   int num_main = 0;
-  for (std::size_t a = 0; a < spec.aggregates.size(); ++a) {
-    const AggregateSpec &ag = spec.aggregates[a];
+  ExpressionFlattener flattener(column_of);
+  for (std::size_t a = 0; a < spec_.aggregates.size(); ++a) {
+    if (spec_.aggregates[a].argument_expression != nullptr && spec_.aggregates[a].argument_expression->kind == Scalar::kAttribute) {
+      spec_.aggregates[a].argument = spec_.aggregates[a].argument_expression->attribute;   // ScalarAttribute: the plain form
+      spec_.aggregates[a].argument_expression = nullptr;
+    }
+    const AggregateSpec &ag = spec_.aggregates[a];
+    if (ag.argument_expression != nullptr && ag.is_distinct) {
+      // DISTINCT over an arithmetic expression (Distinct.test:58-72 COUNT(DISTINCT x % y) is such a query): the distinctify
+      // key is (group-by..., value of the expression); the value column is computed per block (qsx_eval_expression)
+      if (spec.group_by.size() + 1 > QSX_MAX_KEYS) throw ExecutionError("DISTINCT aggregate: too many group-by attributes", QSX_ERR_UNSUPPORTED);
+      std::unique_ptr<Distinctify> d(new Distinctify);
+      d->agg_index = a;
+      d->attrs = spec.group_by;
+      d->attrs.push_back(kInvalidAttributeID);
+      for (attribute_id attr : spec.group_by) d->types.push_back(rel.getAttributeType(attr));
+      d->types.push_back(Type::Double());
+      d->expression = ag.argument_expression;
+      distinctify_.push_back(std::move(d));
+      main_agg_.push_back(-1);
+      continue;
+    }
+    if (ag.argument_expression != nullptr) {
+      // an arithmetic expression as the aggregate's argument: part of the state's expression program
+      if (ag.function == AggregationID::kCount) throw ExecutionError("COUNT over an expression: pass COUNT(*)", QSX_ERR_UNSUPPORTED);
+      const qsx_operand_t value = flattener.add(ag.argument_expression);
+      if (value.kind == QSX_OPD_CONST) throw ExecutionError("aggregate over a literal", QSX_ERR_UNSUPPORTED);
+      config_.aggs[num_main].fn = AggFn(ag.function);
+      config_.aggs[num_main].arg = value;
+      main_agg_.push_back(num_main++);
+      continue;
+    }
     if (ag.is_distinct) {
       // "Initialize the corresponding distinctify hash table if this is a DISTINCT aggregation" (:172-207):
       // key types = group-by types + argument types
@@ -802,6 +869,9 @@ AggregationOperationState::AggregationOperationState(const AggregationStateSpec 
     main_agg_.push_back(num_main++);
   }
   config_.num_aggs = num_main;
+  config_.num_instrs = static_cast<int>(flattener.instrs().size());
+  for (std::size_t k = 0; k < flattener.instrs().size(); ++k) config_.instrs[k] = flattener.instrs()[k];
+  for (std::size_t k = 0; k < flattener.consts().size(); ++k) config_.consts[k] = flattener.consts()[k];
   if (spec.predicate != nullptr) {
     int in_state = 0;
     for (const ComparisonPredicate &term : spec.predicate->conjuncts) {
@@ -843,13 +913,41 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
     for (auto &d : distinctify_) {
       const void *cols[QSX_MAX_KEYS];
       std::int32_t types[QSX_MAX_KEYS];
+      std::unique_ptr<DeviceBuffer> expression_values;
+      std::vector<attribute_id> nullable_sources;   // attributes whose NULLs keep a tuple out of the table
       for (std::size_t c = 0; c < d->attrs.size(); ++c) {
-        cols[c] = block.stripe(d->attrs[c]);
         types[c] = d->types[c].id;
+        if (d->attrs[c] != kInvalidAttributeID) {
+          cols[c] = block.stripe(d->attrs[c]);
+          nullable_sources.push_back(d->attrs[c]);
+          continue;
+        }
+        std::vector<attribute_id> attrs;
+        ExpressionFlattener flattener([&](attribute_id a) {
+          for (std::size_t k = 0; k < attrs.size(); ++k) if (attrs[k] == a) return static_cast<int>(k);
+          attrs.push_back(a);
+          return static_cast<int>(attrs.size() - 1);
+        });
+        const qsx_operand_t result = flattener.add(d->expression);
+        const void *in_cols[QSX_MAX_COLUMNS];
+        std::int32_t in_types[QSX_MAX_COLUMNS];
+        if (attrs.size() > QSX_MAX_COLUMNS) throw ExecutionError("DISTINCT: expression over too many attributes", QSX_ERR_UNSUPPORTED);
+        for (std::size_t k = 0; k < attrs.size(); ++k) {
+          in_cols[k] = block.stripe(attrs[k]);
+          in_types[k] = block.getRelation().getAttributeType(attrs[k]).id;
+          nullable_sources.push_back(attrs[k]);   // a NULL operand makes the value NULL
+        }
+        double consts[QSX_MAX_CONSTS] = {};
+        for (std::size_t k = 0; k < flattener.consts().size(); ++k) consts[k] = flattener.consts()[k];
+        expression_values.reset(new DeviceBuffer(static_cast<std::size_t>(n) * 8 + 8));
+        CheckStatus(qsx_eval_expression(static_cast<int>(attrs.size()), in_cols, in_types, static_cast<int>(flattener.instrs().size()),
+                                        flattener.instrs().data(), consts, result, n, static_cast<double *>(expression_values->ptr),
+                                        CurrentStream()), "qsx_eval_expression");
+        cols[c] = expression_values->ptr;
       }
       // the distinctify table is keyed by (group-by..., argument): a tuple with a NULL in any of them is not inserted
       // (PackedPayloadHashTable.hpp:861-867)
-      const std::unique_ptr<DeviceBuffer> not_null = NotNullFilter(block, d->attrs, filter);
+      const std::unique_ptr<DeviceBuffer> not_null = NotNullFilter(block, nullable_sources, filter);
       const std::uint64_t *distinct_filter = not_null != nullptr ? static_cast<const std::uint64_t *>(not_null->ptr) : filter;
       CheckStatus(qsx_distinct_rows(static_cast<int>(d->attrs.size()), cols, types, n, distinct_filter, static_cast<std::int32_t *>(tids.ptr),
                                     static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()), "qsx_distinct_rows");
@@ -990,7 +1088,8 @@ void AggregationOperationState::finalizeWithDistinct(InsertDestination *dest) {
     for (std::size_t a = 0; a < spec_.aggregates.size(); ++a) {
       if (main_agg_[a] < 0) continue;
       const AggregateSpec &ag = spec_.aggregates[a];
-      main_types.push_back(AggResultType(ag.function, ag.argument == kInvalidAttributeID ? Type::Long() : rel.getAttributeType(ag.argument)));
+      main_types.push_back(AggResultType(ag.function, ag.argument_expression != nullptr ? Type::Double()   // expressions evaluate in DOUBLE
+                                                      : ag.argument == kInvalidAttributeID ? Type::Long() : rel.getAttributeType(ag.argument)));
     }
     finalize_into(state_, config_, main_types, &main);
   }
@@ -1315,6 +1414,27 @@ SelectOperator::SelectOperator(std::size_t query_id, const CatalogRelation &inpu
   if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
 }
 
+SelectOperator::SelectOperator(std::size_t query_id, const CatalogRelation &input_relation, bool has_repartition,
+                               const CatalogRelation &output_relation,
+                               QueryContext::insert_destination_id output_destination_index,
+                               QueryContext::predicate_id predicate_index, std::vector<ScalarPtr> &&selection,
+                               bool input_relation_is_stored)
+    : RelationalOperator(query_id, 1, has_repartition), input_relation_(input_relation),
+      output_relation_(output_relation), output_destination_index_(output_destination_index),
+      predicate_index_(predicate_index), selection_(std::move(selection)),
+      input_relation_is_stored_(input_relation_is_stored), on_gpu_(true) {
+  if (selection_.size() != output_relation.size()) {
+    throw ExecutionError("SelectOperator: one Scalar per output attribute", QSX_ERR_INVALID_ARGUMENT);
+  }
+  for (std::size_t i = 0; i < selection_.size(); ++i) {
+    if (selection_[i] == nullptr) throw ExecutionError("SelectOperator: null Scalar", QSX_ERR_INVALID_ARGUMENT);
+    if (selection_[i]->kind != Scalar::kAttribute && output_relation.getAttributeType(static_cast<attribute_id>(i)).id != kDouble) {
+      throw ExecutionError("SelectOperator: an arithmetic expression yields a DOUBLE attribute", QSX_ERR_INVALID_ARGUMENT);
+    }
+  }
+  if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
+}
+
 bool SelectOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context,
                                       StorageManager *storage_manager, const tmb::client_id, tmb::MessageBus *) {
   // SelectOperator.cpp:47-107: one work order per input block; streaming inputs
@@ -1325,7 +1445,8 @@ bool SelectOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryConte
   while (num_workorders_generated_ < input_relation_block_ids_.size()) {
     container->addNormalWorkOrder(new SelectWorkOrder(query_id_, input_relation_block_ids_[num_workorders_generated_],
                                                       predicate, simple_selection_, dest, storage_manager, on_gpu_,
-                                                      CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context)),
+                                                      CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context),
+                                                      selection_.empty() ? nullptr : &selection_),
                                   op_index_);
     ++num_workorders_generated_;
   }
@@ -1350,14 +1471,55 @@ void SelectWorkOrder::execute() {
   qsx_device_free(lip);
   block_id out_id;
   BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
-  // block->selectSimple(simple_selection_, matches, output_destination_) (StorageBlock.cpp:390-399)
+  // block->selectSimple(simple_selection_, matches, output_destination_) (StorageBlock.cpp:390-399), or block->select(
+  // selection_, ...) (:363-388): every Scalar's values for the block, then the matching rows of each
   std::vector<const void *> src;
   std::vector<void *> dst;
   std::vector<std::int32_t> widths;
-  for (std::size_t i = 0; i < simple_selection_.size(); ++i) {
-    src.push_back(block->stripe(simple_selection_[i]));
-    dst.push_back(out->stripe(static_cast<attribute_id>(i)));
-    widths.push_back(block->getRelation().getAttributeType(simple_selection_[i]).width);
+  std::vector<std::unique_ptr<DeviceBuffer>> expression_values;
+  std::vector<attribute_id> null_sources;   // per output attribute: the input attribute whose null bitmap it inherits
+  if (selection_ != nullptr && !selection_->empty()) {
+    for (std::size_t i = 0; i < selection_->size(); ++i) {
+      const ScalarPtr &scalar = (*selection_)[i];
+      dst.push_back(out->stripe(static_cast<attribute_id>(i)));
+      if (scalar->kind == Scalar::kAttribute) {
+        src.push_back(block->stripe(scalar->attribute));
+        widths.push_back(block->getRelation().getAttributeType(scalar->attribute).width);
+        null_sources.push_back(scalar->attribute);
+        continue;
+      }
+      // ScalarBinaryExpression / ScalarLiteral: one fused pass over the operand stripes (qsx_eval_expression)
+      std::vector<attribute_id> attrs;
+      ExpressionFlattener flattener([&](attribute_id a) {
+        for (std::size_t c = 0; c < attrs.size(); ++c) if (attrs[c] == a) return static_cast<int>(c);
+        attrs.push_back(a);
+        return static_cast<int>(attrs.size() - 1);
+      });
+      const qsx_operand_t result = flattener.add(scalar);
+      const void *cols[QSX_MAX_COLUMNS];
+      std::int32_t types[QSX_MAX_COLUMNS];
+      if (attrs.size() > QSX_MAX_COLUMNS) throw ExecutionError("SelectWorkOrder: expression over too many attributes", QSX_ERR_UNSUPPORTED);
+      for (std::size_t c = 0; c < attrs.size(); ++c) {
+        cols[c] = block->stripe(attrs[c]);
+        types[c] = block->getRelation().getAttributeType(attrs[c]).id;
+      }
+      double consts[QSX_MAX_CONSTS] = {};
+      for (std::size_t c = 0; c < flattener.consts().size(); ++c) consts[c] = flattener.consts()[c];
+      expression_values.emplace_back(new DeviceBuffer(static_cast<std::size_t>(n > 0 ? n : 1) * 8));
+      CheckStatus(qsx_eval_expression(static_cast<int>(attrs.size()), cols, types, static_cast<int>(flattener.instrs().size()),
+                                      flattener.instrs().data(), consts, result, n, static_cast<double *>(expression_values.back()->ptr),
+                                      CurrentStream()), "qsx_eval_expression");
+      src.push_back(expression_values.back()->ptr);
+      widths.push_back(8);
+      null_sources.push_back(kInvalidAttributeID);
+    }
+  } else {
+    for (std::size_t i = 0; i < simple_selection_.size(); ++i) {
+      src.push_back(block->stripe(simple_selection_[i]));
+      dst.push_back(out->stripe(static_cast<attribute_id>(i)));
+      widths.push_back(block->getRelation().getAttributeType(simple_selection_[i]).width);
+      null_sources.push_back(simple_selection_[i]);
+    }
   }
   const std::size_t ws_bytes = qsx_compact_workspace_bytes(n);
   DeviceBuffer ws(ws_bytes), count(8);
@@ -1366,7 +1528,7 @@ void SelectWorkOrder::execute() {
                                  static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
               "qsx_compact_gather");
   const std::int64_t written = ReadCount(count.ptr);  // synchronises the work order, like the reference's execute()
-  ProjectNullBitmaps(*block, simple_selection_, bitmap, written, out.get());
+  ProjectNullBitmaps(*block, null_sources, bitmap, written, out.get());
   qsx_device_free(bitmap);
   output_destination_->returnBlock(out_id, written);
 }

@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -322,12 +323,58 @@ class InsertDestination {
 };
 
 // ---------------------------------------------------------------------------
+// scalar expressions (expressions/scalar/): ScalarAttribute, ScalarLiteral, ScalarBinaryExpression over the four
+// arithmetic operations (types/operations/binary_operations/ArithmeticBinaryOperators.hpp).  Evaluated per row in IEEE
+// double, every node rounded on its own — what ScalarBinaryExpression::getAllValues produces for DOUBLE operands
+// (ScalarBinaryExpression.cpp:100-195); TPC-H's DECIMAL columns are DOUBLE in the reference (parser/SqlParser.ypp:791-793).
+// ---------------------------------------------------------------------------
+enum class BinaryOperationID { kAdd = 0, kSubtract, kMultiply, kDivide };
+class Scalar;
+typedef std::shared_ptr<const Scalar> ScalarPtr;
+class Scalar {
+ public:
+  enum Kind { kAttribute, kLiteral, kBinaryExpression };
+  Kind kind = kAttribute;
+  attribute_id attribute = kInvalidAttributeID;
+  double literal = 0.0;
+  BinaryOperationID operation = BinaryOperationID::kAdd;
+  ScalarPtr left, right;
+  static ScalarPtr Attribute(attribute_id a) { auto s = std::make_shared<Scalar>(); s->kind = kAttribute; s->attribute = a; return s; }
+  static ScalarPtr Literal(double v) { auto s = std::make_shared<Scalar>(); s->kind = kLiteral; s->literal = v; return s; }
+  static ScalarPtr Binary(BinaryOperationID op, ScalarPtr l, ScalarPtr r) {
+    auto s = std::make_shared<Scalar>();
+    s->kind = kBinaryExpression; s->operation = op; s->left = std::move(l); s->right = std::move(r);
+    return s;
+  }
+};
+// Scalar trees flattened into one expression program (qsx_expr_instr_t[]): one instruction per distinct binary node —
+// a subexpression shared by several scalars is computed once, the role of the reference's ColumnVectorCache — input
+// attributes mapped to program columns through `column_of`.
+class ExpressionFlattener {
+ public:
+  explicit ExpressionFlattener(std::function<int(attribute_id)> column_of) : column_of_(std::move(column_of)) {}
+  qsx_operand_t add(const ScalarPtr &scalar);   // the operand holding the scalar's value
+  const std::vector<qsx_expr_instr_t> &instrs() const { return instrs_; }
+  const std::vector<double> &consts() const { return consts_; }
+ private:
+  std::function<int(attribute_id)> column_of_;
+  std::vector<qsx_expr_instr_t> instrs_;
+  std::vector<double> consts_;
+};
+
+// ---------------------------------------------------------------------------
 // aggregation state description (storage/AggregationOperationState.cpp:74-252)
 // ---------------------------------------------------------------------------
 struct AggregateSpec {
   AggregationID function;
   attribute_id argument;  // kInvalidAttributeID for COUNT(*)
   bool is_distinct = false;   // serialization::Aggregate::is_distinct (AggregationOperationState.proto)
+  // serialization::Aggregate::argument as a Scalar tree (AggregationOperationState.cpp:100-130); when set it replaces
+  // `argument`: SUM(l_extendedprice * (1 - l_discount))
+  ScalarPtr argument_expression;
+  AggregateSpec() : function(AggregationID::kCount), argument(kInvalidAttributeID) {}
+  AggregateSpec(AggregationID f, attribute_id a, bool distinct = false) : function(f), argument(a), is_distinct(distinct) {}
+  AggregateSpec(AggregationID f, ScalarPtr expression) : function(f), argument(kInvalidAttributeID), argument_expression(std::move(expression)) {}
 };
 struct AggregationStateSpec {
   const CatalogRelation *input_relation = nullptr;
@@ -571,6 +618,11 @@ class SelectOperator : public RelationalOperator {
                  const CatalogRelation &output_relation, QueryContext::insert_destination_id output_destination_index,
                  QueryContext::predicate_id predicate_index, std::vector<attribute_id> &&selection,
                  bool input_relation_is_stored, bool on_gpu = true);
+  // The general form (SelectOperator.hpp:90-98: selection = a group of Scalars): attributes and arithmetic expressions;
+  // an expression's output attribute is DOUBLE.
+  SelectOperator(std::size_t query_id, const CatalogRelation &input_relation, bool has_repartition,
+                 const CatalogRelation &output_relation, QueryContext::insert_destination_id output_destination_index,
+                 QueryContext::predicate_id predicate_index, std::vector<ScalarPtr> &&selection, bool input_relation_is_stored);
   OperatorType getOperatorType() const override { return kSelect; }
   std::string getName() const override { return "SelectOperator"; }
   bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
@@ -588,6 +640,7 @@ class SelectOperator : public RelationalOperator {
   const QueryContext::insert_destination_id output_destination_index_;
   const QueryContext::predicate_id predicate_index_;
   const std::vector<attribute_id> simple_selection_;
+  const std::vector<ScalarPtr> selection_;   // non-empty: the general form
   const bool input_relation_is_stored_;
   const bool on_gpu_;
   std::mutex mutex_;
@@ -600,9 +653,10 @@ class SelectWorkOrder : public WorkOrder {
  public:
   SelectWorkOrder(std::size_t query_id, block_id input_block_id, const Predicate *predicate,
                   const std::vector<attribute_id> &simple_selection, InsertDestination *output_destination,
-                  StorageManager *storage_manager, bool on_gpu, LIPFilterAdaptiveProber *lip_filter_adaptive_prober = nullptr)
+                  StorageManager *storage_manager, bool on_gpu, LIPFilterAdaptiveProber *lip_filter_adaptive_prober = nullptr,
+                  const std::vector<ScalarPtr> *selection = nullptr)
       : WorkOrder(query_id), input_block_id_(input_block_id), predicate_(predicate), simple_selection_(simple_selection),
-        output_destination_(output_destination), storage_manager_(storage_manager), on_gpu_(on_gpu),
+        selection_(selection), output_destination_(output_destination), storage_manager_(storage_manager), on_gpu_(on_gpu),
         lip_filter_adaptive_prober_(lip_filter_adaptive_prober) {}
   void execute() override;  // SelectOperator.cpp:161-195
 
@@ -611,6 +665,7 @@ class SelectWorkOrder : public WorkOrder {
   const block_id input_block_id_;
   const Predicate *predicate_;
   const std::vector<attribute_id> &simple_selection_;
+  const std::vector<ScalarPtr> *selection_;   // nullptr / empty: simple_selection_
   InsertDestination *output_destination_;
   StorageManager *storage_manager_;
   const bool on_gpu_;

@@ -394,6 +394,44 @@ int main() {
         EXPECT_EQ(at<std::int64_t>(cols[6], i) + z, want_count_plus_z[z]);
       }
     }
+    {  // DISTINCT over a scalar expression argument (the shape of Distinct.test:58-72's COUNT(DISTINCT x % y)): the distinctify
+       // key is (z, value); y + y takes the 100 values 1, 3, .. 199 in every group, x - x is 0 everywhere, and a plain
+       // SUM(y * 2) runs next to them in the state's own expression program
+      CatalogRelation result(124, "result");
+      result.addAttribute("z", Type::Int());
+      result.addAttribute("count_distinct_2y", Type::Long());
+      result.addAttribute("sum_distinct_2y", Type::Double());
+      result.addAttribute("count_distinct_zero", Type::Long());
+      result.addAttribute("sum_2y", Type::Double());
+      QueryContext ctx;
+      const ScalarPtr y = Scalar::Attribute(1), x = Scalar::Attribute(0);
+      const ScalarPtr two_y = Scalar::Binary(BinaryOperationID::kAdd, y, y);
+      auto distinct_expr = [](AggregationID fn, ScalarPtr e) { AggregateSpec a(fn, std::move(e)); a.is_distinct = true; return a; };
+      AggregationStateSpec spec;
+      spec.input_relation = &foo;
+      spec.group_by = {2};
+      spec.aggregates = {distinct_expr(AggregationID::kCount, two_y), distinct_expr(AggregationID::kSum, two_y),
+                         distinct_expr(AggregationID::kCount, Scalar::Binary(BinaryOperationID::kSubtract, x, x)),
+                         AggregateSpec(AggregationID::kSum, Scalar::Binary(BinaryOperationID::kMultiply, y, Scalar::Literal(2.0)))};
+      spec.strategy = QSX_AGG_GENERIC;
+      spec.estimated_num_groups = 3;
+      const auto state = ctx.addAggregationState(spec);
+      const auto dest = ctx.addInsertDestination(&result, &storage);
+      AggregationOperator op(0, foo, true, state);
+      FinalizeAggregationOperator fin(0, state, 1, false, 1, result, dest);
+      fetchAndExecuteWorkOrders(&op, &ctx, &storage);
+      fetchAndExecuteWorkOrders(&fin, &ctx, &storage);
+      std::size_t rows;
+      auto cols = readAll(ctx, dest, storage, result, &rows);
+      EXPECT_EQ(rows, static_cast<std::size_t>(3));
+      for (std::size_t i = 0; i < rows && i < 3; ++i) {
+        EXPECT_EQ(at<std::int32_t>(cols[0], i), static_cast<int>(i));
+        EXPECT_EQ(at<std::int64_t>(cols[1], i), static_cast<std::int64_t>(100));
+        EXPECT_TRUE(at<double>(cols[2], i) == 10000.0);                       // 1 + 3 + ... + 199
+        EXPECT_EQ(at<std::int64_t>(cols[3], i), static_cast<std::int64_t>(1));
+        EXPECT_NEAR(at<double>(cols[4], i), 1000000.0, 1e-6 * 1000000.0);     // 10 000 rows x mean 50 x 2
+      }
+    }
     {  // every aggregate DISTINCT, with the state's predicate: x < 150 leaves y in {0.5 .. 99.5} for 150 rows
       CatalogRelation result(123, "result");
       result.addAttribute("z", Type::Int());

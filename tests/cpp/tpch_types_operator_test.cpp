@@ -6,6 +6,7 @@
 // blocks and over compressed ones (dictionary codes for the CHAR(10) and DATE attributes: predicates scan the codes,
 // CompressedStoreUtil.cpp:51-140) and is checked against the same computation on the host columns.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -29,7 +30,7 @@ struct Tables {
   // lineitem
   std::vector<unsigned char> l_returnflag, l_linestatus;
   std::vector<DateLit> l_shipdate;
-  std::vector<double> l_quantity;
+  std::vector<double> l_quantity, l_extendedprice, l_discount, l_tax;
   std::vector<char> l_shipmode;     // CHAR(10)
   Tables() {
     std::uint64_t x = 0x2545F4914F6CDD1Dull;
@@ -53,6 +54,9 @@ struct Tables {
       s.unused[1] = static_cast<std::uint8_t>(rnd());
       l_shipdate.push_back(s);
       l_quantity.push_back(static_cast<double>(rnd() % 50 + 1));
+      l_extendedprice.push_back(900.0 + static_cast<double>(rnd() % 10000000) / 100.0);
+      l_discount.push_back(static_cast<double>(rnd() % 11) / 100.0);
+      l_tax.push_back(static_cast<double>(rnd() % 9) / 100.0);
       std::strncpy(&l_shipmode[i * 10], modes[rnd() % 7], 10);
     }
   }
@@ -82,13 +86,17 @@ int main() {
     lineitem.addAttribute("l_shipdate", Type::Date());
     lineitem.addAttribute("l_quantity", Type::Double());
     lineitem.addAttribute("l_shipmode", Type::Char(10));
-    const std::vector<bool> c_flags{false, true}, o_flags{false, true, false}, l_flags{false, false, true, true, true};
+    lineitem.addAttribute("l_extendedprice", Type::Double());
+    lineitem.addAttribute("l_discount", Type::Double());
+    lineitem.addAttribute("l_tax", Type::Double());
+    const std::vector<bool> c_flags{false, true}, o_flags{false, true, false}, l_flags{false, false, true, true, true, true, true, true};
     for (std::int64_t at = 0; at < kRows; at += kBlockRows) {
       storage.loadBlock(&customer, {t.c_custkey.data() + at, t.c_mktsegment.data() + at * 10}, kBlockRows, 0, compressed ? &c_flags : nullptr);
       storage.loadBlock(&orders, {t.o_orderkey.data() + at, t.o_orderdate.data() + at, t.o_shippriority.data() + at}, kBlockRows, 0,
                         compressed ? &o_flags : nullptr);
       storage.loadBlock(&lineitem, {t.l_returnflag.data() + at, t.l_linestatus.data() + at, t.l_shipdate.data() + at, t.l_quantity.data() + at,
-                                    t.l_shipmode.data() + at * 10}, kBlockRows, 0, compressed ? &l_flags : nullptr);
+                                    t.l_shipmode.data() + at * 10, t.l_extendedprice.data() + at, t.l_discount.data() + at, t.l_tax.data() + at},
+                        kBlockRows, 0, compressed ? &l_flags : nullptr);
     }
     if (compressed) {   // the CHAR(10) and DATE attributes really are dictionary-coded
       BlockReference c = storage.getBlock(customer.getBlocksSnapshot().front());
@@ -276,6 +284,112 @@ int main() {
         EXPECT_NEAR(it->second.first, kv.second.first, 1e-9 * kv.second.first);
       }
     }
+  }
+  // ---- Q1 as benchmarks/tpch/queries/01.sql writes it: every aggregate, the two arithmetic expressions as Scalar trees ----
+  // sum(l_quantity), sum(l_extendedprice), sum(l_extendedprice * (1 - l_discount)), sum(l_extendedprice * (1 - l_discount) *
+  // (1 + l_tax)), avg(l_quantity), avg(l_extendedprice), avg(l_discount), count(*) WHERE l_shipdate <= DATE GROUP BY flags;
+  // and the projection of an expression by a SelectOperator (ScalarBinaryExpression::getAllValues on its own).
+  for (const bool compressed : {false, true}) {
+    StorageManager storage;
+    CatalogRelation lineitem(30, "lineitem"), result(31, "q1"), projected(32, "projected");
+    lineitem.addAttribute("l_returnflag", Type::Char(1));
+    lineitem.addAttribute("l_linestatus", Type::Char(1));
+    lineitem.addAttribute("l_shipdate", Type::Date());
+    lineitem.addAttribute("l_quantity", Type::Double());
+    lineitem.addAttribute("l_extendedprice", Type::Double());
+    lineitem.addAttribute("l_discount", Type::Double());
+    lineitem.addAttribute("l_tax", Type::Double());
+    const std::vector<bool> flags{false, false, true, true, false, true, true};
+    for (std::int64_t at = 0; at < kRows; at += kBlockRows) {
+      storage.loadBlock(&lineitem, {t.l_returnflag.data() + at, t.l_linestatus.data() + at, t.l_shipdate.data() + at, t.l_quantity.data() + at,
+                                    t.l_extendedprice.data() + at, t.l_discount.data() + at, t.l_tax.data() + at},
+                        kBlockRows, 0, compressed ? &flags : nullptr);
+    }
+    for (const char *name : {"l_returnflag", "l_linestatus"}) result.addAttribute(name, Type::Char(1));
+    for (const char *name : {"sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"}) {
+      result.addAttribute(name, Type::Double());
+    }
+    result.addAttribute("count_order", Type::Long());
+    const ScalarPtr price = Scalar::Attribute(4), disc = Scalar::Attribute(5), tax = Scalar::Attribute(6), one = Scalar::Literal(1.0);
+    const ScalarPtr disc_price = Scalar::Binary(BinaryOperationID::kMultiply, price, Scalar::Binary(BinaryOperationID::kSubtract, one, disc));
+    const ScalarPtr charge = Scalar::Binary(BinaryOperationID::kMultiply, disc_price, Scalar::Binary(BinaryOperationID::kAdd, one, tax));
+    QueryContext ctx;
+    Predicate pred;
+    pred.conjuncts.push_back({2, ComparisonID::kLessOrEqual, TypedLiteral::Date(1998, 9, 2)});
+    const auto pred_id = ctx.addPredicate(pred);
+    AggregationStateSpec spec;
+    spec.input_relation = &lineitem;
+    spec.group_by = {0, 1};
+    spec.aggregates = {AggregateSpec(AggregationID::kSum, 3), AggregateSpec(AggregationID::kSum, Scalar::Attribute(4)),
+                       AggregateSpec(AggregationID::kSum, disc_price), AggregateSpec(AggregationID::kSum, charge),
+                       AggregateSpec(AggregationID::kAvg, 3), AggregateSpec(AggregationID::kAvg, 4), AggregateSpec(AggregationID::kAvg, 5),
+                       AggregateSpec(AggregationID::kCount, kInvalidAttributeID)};
+    spec.predicate = ctx.getPredicate(pred_id);
+    spec.strategy = QSX_AGG_COMPACT_KEY;
+    spec.estimated_num_groups = 6;
+    const auto state = ctx.addAggregationState(spec);
+    const auto dest = ctx.addInsertDestination(&result, &storage);
+    AggregationOperator op(0, lineitem, true, state);
+    FinalizeAggregationOperator fin(0, state, 1, false, 1, result, dest);
+    fetchAndExecuteWorkOrders(&op, &ctx, &storage);
+    fetchAndExecuteWorkOrders(&fin, &ctx, &storage);
+    struct Row { double v[7] = {}; std::int64_t count = 0; };
+    std::map<std::pair<char, char>, Row> want;
+    const DateLit cut = DateLit::Create(1998, 9, 2);
+    for (std::int64_t i = 0; i < kRows; ++i) {
+      if (cut < t.l_shipdate[i]) continue;
+      Row &w = want[{static_cast<char>(t.l_returnflag[i]), static_cast<char>(t.l_linestatus[i])}];
+      const double dp = t.l_extendedprice[i] * (1.0 - t.l_discount[i]);
+      w.v[0] += t.l_quantity[i]; w.v[1] += t.l_extendedprice[i]; w.v[2] += dp; w.v[3] += dp * (1.0 + t.l_tax[i]);
+      w.v[4] += t.l_quantity[i]; w.v[5] += t.l_extendedprice[i]; w.v[6] += t.l_discount[i];
+      ++w.count;
+    }
+    std::size_t groups = 0;
+    for (block_id b : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+      BlockReference blk = storage.getBlock(b);
+      const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+      std::vector<char> f(k), s(k);
+      std::vector<std::vector<double>> vals(7, std::vector<double>(k));
+      std::vector<std::int64_t> cnt(k);
+      blk->copyAttributeToHost(0, f.data()); blk->copyAttributeToHost(1, s.data());
+      for (int a = 0; a < 7; ++a) blk->copyAttributeToHost(static_cast<attribute_id>(2 + a), vals[a].data());
+      blk->copyAttributeToHost(9, cnt.data());
+      for (std::size_t i = 0; i < k; ++i, ++groups) {
+        const auto it = want.find({f[i], s[i]});
+        EXPECT_TRUE(it != want.end());
+        if (it == want.end()) continue;
+        EXPECT_EQ(cnt[i], it->second.count);
+        for (int a = 0; a < 7; ++a) {
+          const double expect = a < 4 ? it->second.v[a] : it->second.v[a] / static_cast<double>(it->second.count);
+          EXPECT_NEAR(vals[a][i], expect, 1e-9 * std::fabs(expect));   // (north star: 1e-6 relative; summation order is all that differs)
+        }
+      }
+    }
+    EXPECT_EQ(groups, want.size());
+    // SELECT l_quantity, l_extendedprice * (1 - l_discount) * (1 + l_tax) FROM lineitem WHERE l_shipdate <= DATE
+    projected.addAttribute("l_quantity", Type::Double());
+    projected.addAttribute("charge", Type::Double());
+    const auto pdest = ctx.addInsertDestination(&projected, &storage);
+    SelectOperator select(0, lineitem, false, projected, pdest, pred_id, std::vector<ScalarPtr>{Scalar::Attribute(3), charge}, true);
+    fetchAndExecuteWorkOrders(&select, &ctx, &storage);
+    std::vector<double> got_qty, got_charge;
+    for (block_id b : ctx.getInsertDestination(pdest)->getTouchedBlocks()) {
+      BlockReference blk = storage.getBlock(b);
+      const std::size_t at = got_qty.size(), k = static_cast<std::size_t>(blk->numTuples());
+      got_qty.resize(at + k); got_charge.resize(at + k);
+      blk->copyAttributeToHost(0, got_qty.data() + at);
+      blk->copyAttributeToHost(1, got_charge.data() + at);
+    }
+    std::size_t at = 0;
+    bool same = true;
+    for (std::int64_t i = 0; i < kRows; ++i) {
+      if (cut < t.l_shipdate[i]) continue;
+      const double dp = t.l_extendedprice[i] * (1.0 - t.l_discount[i]);
+      same = same && at < got_qty.size() && got_qty[at] == t.l_quantity[i] && got_charge[at] == dp * (1.0 + t.l_tax[i]);   // bit-equal: same roundings
+      ++at;
+    }
+    EXPECT_EQ(at, got_qty.size());
+    EXPECT_TRUE(same);
   }
   return finish("tpch_types_operator_test");
 }

@@ -812,3 +812,28 @@ def test_date_predicate_and_date_group_keys(capi, oracle, dev, monkeypatch):
             assert_same_groups(got, ref)
             date_key = got[0][keys.index(0) if len(keys) == 1 else 1]
             assert int((date_key.view(np.uint64) >> np.uint64(48)).max()) == 0     # output dates carry zero padding
+
+
+def test_expression_projection_is_bit_equal_to_the_oracle(capi, oracle, dev):
+    """qsx_eval_expression (ScalarBinaryExpression::getAllValues on its own): Q1's charge expression and a mixed-type one;
+    every node is rounded on its own in IEEE double on both sides, so the columns are bit-equal."""
+    rng = np.random.default_rng(83)
+    for n in (1, 63, 100_003):
+        price = np.round(rng.uniform(900, 105000, size=n), 2)
+        disc = rng.integers(0, 11, size=n) / 100.0
+        tax = rng.integers(0, 9, size=n) / 100.0
+        qty = rng.integers(1, 51, size=n).astype(np.int32)
+        big = rng.integers(-2**40, 2**40, size=n).astype(np.int64)
+        f32 = rng.normal(size=n).astype(np.float32)
+        cols = [price, disc, tax, qty, big, f32]
+        programs = [
+            ([(T.EX_SUB, 0, T.const(0), T.col(1)), (T.EX_MUL, 1, T.col(0), T.temp(0)), (T.EX_ADD, 2, T.const(0), T.col(2)),
+              (T.EX_MUL, 3, T.temp(1), T.temp(2))], [1.0], T.temp(3)),
+            ([(T.EX_DIV, 0, T.col(4), T.col(3)), (T.EX_ADD, 1, T.temp(0), T.col(5)), (T.EX_MUL, 0, T.temp(1), T.const(1))], [0.0, -0.75], T.temp(0)),
+            ([], [2.5], T.col(3)),            # a bare attribute: its conversion to DOUBLE
+            ([], [2.5], T.const(0)),          # a literal
+        ]
+        for instrs, consts, result in programs:
+            got = capi.eval_expression([to_dev(c, dev) for c in cols], instrs, consts + [0.0] * (T.MAX_CONSTS - len(consts)), result).cpu().numpy()
+            want = oracle.eval_expression(cols, instrs, consts + [0.0] * (T.MAX_CONSTS - len(consts)), result)
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
