@@ -14,7 +14,7 @@ def _ensure_built():
     if not all(os.path.exists(os.path.join(BIN, b)) for b in
                ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
                 "lip_filter_operator_test", "compressed_block_operator_test", "host_logic_test",
-                "sort_operator_test", "nullable_operator_test", "tpch_types_operator_test")):
+                "sort_operator_test", "nullable_operator_test", "tpch_types_operator_test", "tpch_q3_plan_test")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -89,3 +89,11 @@ def test_tpch_schema_types_through_the_operators():
     """CHAR(10) / CHAR(1) / DATE attributes of the reference's TPC-H schema in the predicates and group-by keys of Q1 and Q3,
     over plain and over dictionary-compressed blocks."""
     _run("tpch_types_operator_test")
+
+
+@pytest.mark.gpu
+def test_tpch_q3_as_one_query_plan():
+    """benchmarks/tpch/queries/03.sql as one operator DAG under ForemanSingleNode / four workers: three Selects, two
+    BuildHash / HashJoin pairs, Aggregation over a 16-byte key with an expression argument, Finalize, SortRunGeneration,
+    SortMergeRun with LIMIT 10 — streaming edges and pipeline breakers included."""
+    _run("tpch_q3_plan_test")
