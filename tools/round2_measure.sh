@@ -12,4 +12,6 @@ python3 tools/q1_pipeline.py 100 int >> $o/q1_pipeline.jsonl 2>&1
 python3 tools/q3_pipeline.py 100 nolip fused types > $o/q3_pipeline.jsonl 2>&1
 python3 tools/q3_pipeline.py 100 nolip fused >> $o/q3_pipeline.jsonl 2>&1
 python3 tools/q3_pipeline.py 100 lip fused types >> $o/q3_pipeline.jsonl 2>&1
-grep -h "^{" $o/*.jsonl | cut -c1-260
+
+python3 tools/agg_large_groups.py > $o/agg_large_groups.jsonl 2>&1
+grep -h "^{" $o/*.jsonl | cut -c1-200 | tail -30
