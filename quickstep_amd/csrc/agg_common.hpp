@@ -344,6 +344,7 @@ __device__ __forceinline__ int dir_lookup(const DirView &d, unsigned long long c
 // all), so that a full table costs a miss 8 LDS reads, not S: rows of groups that do not fit
 // go to the global table.
 constexpr int kLdsMaxProbes = 8;
+constexpr int kHashCtlWords = 8;   // control words behind the LDS accumulator planes of the hash update kernel
 __device__ __forceinline__ int lds_find_or_insert(unsigned long long *l_keys, int S, unsigned long long code) {
   int s = static_cast<int>(mix64(code) >> 40) & (S - 1);
   const int limit = S < kLdsMaxProbes ? S : kLdsMaxProbes;

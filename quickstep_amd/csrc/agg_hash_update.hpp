@@ -527,10 +527,54 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   auto tile_row0 = [&](int64_t t) { return row_begin + t * TR; };
   auto tile_rows = [&](int64_t t) { return static_cast<int>(row_end - tile_row0(t) < TR ? row_end - tile_row0(t) : TR); };
   int buf = 0;
+  // (tables at their largest size only: a table sized for its estimate — Q1's 16 slots — never comes under pressure, and
+  // with S a compile-time constant of the fixed-geometry shapes the whole mechanism folds away there)
+  const bool can_flush = !kDense && !kDir && !kDirBuild && S >= 512;
+  bool flush_enabled = true;
+  // kHashCtlWords words behind the accumulator planes (dynamic LDS, counted by the launchers — a static __shared__ or a
+  // __syncthreads_or would add static LDS the occupancy calculations do not see): [0..2] pressure flags, written during tile
+  // i into slot i % 3, read by everyone at the barrier of tile i + 1, cleared by thread 0 one tile before their next use
+  // (three slots: no reader and no writer of a slot can meet its clearing); [3], [4] statistics of the flush in progress
+  unsigned long long *l_ctl = l_acc + static_cast<size_t>(NS + 1) * plane;
+  unsigned long long *s_flush_stat = l_ctl + 3;
+  if (can_flush && threadIdx.x < kHashCtlWords) l_ctl[threadIdx.x] = 0;
+  int tile_count = 0;
+  // LDS -> global table: fold the REP partials, one global atomic per group per accumulator per workgroup
+  auto flush_table = [&](bool with_stats) {
+    const int rep = 1 << rep_shift;
+    unsigned long long occupied = 0, absorbed = 0;
+    for (int sl = threadIdx.x; sl < S; sl += BLOCK) {
+      const unsigned long long code = l_keys[sl];
+      if (code == kEmptyCode) continue;
+      unsigned long long cnt = 0;
+      for (int r = 0; r < rep; ++r) cnt += l_acc[(sl << rep_shift) + r];
+      if (cnt == 0) continue;
+      ++occupied;
+      absorbed += cnt;
+      const unsigned long long gs = global_find_or_insert(g, code);
+      if (gs == ~0ull) continue;
+      global_add(g, 0, gs, cnt, kAccSumI64);
+      for (int j = 0; j < NS; ++j) {
+        const unsigned long long *p = l_acc + (j + 1) * plane + (sl << rep_shift);
+        const int kind = c.sums[j].kind;
+        unsigned long long v = static_cast<unsigned long long>(acc_identity(kind));
+        for (int r = 0; r < rep; ++r) v = acc_combine(v, p[r], kind);
+        global_add(g, j + 1, gs, v, kind);
+      }
+    }
+    if (with_stats) {
+      occupied = wave_reduce_add(occupied);
+      absorbed = wave_reduce_add(absorbed);
+      if (lane_id() == 0 && occupied != 0) {
+        atomicAdd(&s_flush_stat[0], occupied);
+        atomicAdd(&s_flush_stat[1], absorbed);
+      }
+    }
+  };
   if (nbuf == 2 && first_tile < num_tiles) {
     stage_tile<kStatic, BLOCK>(c, cols, filter, tiles, tile_row0(first_tile), tile_rows(first_tile), nulls);
   }
-  for (int64_t tile_id = first_tile; tile_id < num_tiles; tile_id += tile_step) {
+  for (int64_t tile_id = first_tile; tile_id < num_tiles; tile_id += tile_step, ++tile_count) {
     if (nbuf == 1) {
       __syncthreads();  // every wave is done reading the previous tile
       stage_tile<kStatic, BLOCK>(c, cols, filter, tiles, tile_row0(tile_id), tile_rows(tile_id), nulls);
@@ -538,7 +582,34 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     // The tile has landed (nbuf == 2: it was staged during the previous iteration and
     // every wave is done with the other buffer).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (can_flush) {
+      // Pressure on the LDS table (rows of the previous tile found no slot and paid global atomics): write the table out
+      // and start over.  The table then works as a write-combining cache: with clustered keys (lineitem on l_orderkey) a
+      // flushed group never comes back and every group costs one global update instead of one per row.  A flush that
+      // absorbed fewer than two rows per group (keys in random order, far more groups than slots) switches the
+      // mechanism off for this workgroup: it would only move the atomics around.
+      __syncthreads();
+      const bool pressure = tile_count > 0 && l_ctl[(tile_count - 1) % 3] != 0;
+      if (threadIdx.x == 0) l_ctl[(tile_count + 1) % 3] = 0;
+      if (pressure && flush_enabled) {
+        flush_table(true);
+        __syncthreads();
+        const unsigned long long occupied = s_flush_stat[0], absorbed = s_flush_stat[1];
+        flush_enabled = absorbed >= 2 * occupied;
+        __syncthreads();
+        if (threadIdx.x == 0) s_flush_stat[0] = s_flush_stat[1] = 0;
+        for (int i = threadIdx.x; i < S; i += BLOCK) l_keys[i] = kEmptyCode;
+        for (int i = threadIdx.x; i < plane; i += BLOCK) l_acc[i] = 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          const unsigned long long identity = static_cast<unsigned long long>(acc_identity(c.sums[j].kind));
+          for (int i = threadIdx.x; i < plane; i += BLOCK) l_acc[(j + 1) * plane + i] = identity;
+        }
+        __syncthreads();
+      }
+    } else {
+      __syncthreads();
+    }
     const int64_t next = tile_id + tile_step;
     if (nbuf == 2 && next < num_tiles) {
       stage_tile<kStatic, BLOCK>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, tile_row0(next), tile_rows(next), nulls);
@@ -677,6 +748,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       }
     }
     const bool wave_has_global = __any(any_global);  // rare: groups that did not fit the LDS table
+    if (can_flush && any_global) l_ctl[tile_count % 3] = 1;   // (benign race: everyone stores the same value)
     if constexpr (kDense) {
       // existence bit + row count of every run (CollisionFreeVectorTable.hpp:530-645)
 #pragma unroll
@@ -899,26 +971,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     return;
   }
 
-  // ---- LDS -> global table: fold the REP partials, one global atomic per group per
-  // accumulator per workgroup --------------------------------------------------------
-  const int rep = 1 << rep_shift;
-  for (int s = threadIdx.x; s < S; s += BLOCK) {
-    const unsigned long long code = l_keys[s];
-    if (code == kEmptyCode) continue;
-    unsigned long long cnt = 0;
-    for (int r = 0; r < rep; ++r) cnt += l_acc[(s << rep_shift) + r];
-    if (cnt == 0) continue;
-    const unsigned long long gs = global_find_or_insert(g, code);
-    if (gs == ~0ull) continue;
-    global_add(g, 0, gs, cnt, kAccSumI64);
-    for (int j = 0; j < NS; ++j) {
-      const unsigned long long *p = l_acc + (j + 1) * plane + (s << rep_shift);
-      const int kind = c.sums[j].kind;
-      unsigned long long v = static_cast<unsigned long long>(acc_identity(kind));
-      for (int r = 0; r < rep; ++r) v = acc_combine(v, p[r], kind);
-      global_add(g, j + 1, gs, v, kind);
-    }
-  }
+  flush_table(false);
 }
 
 // Interpreter: the configuration arrives as a kernel argument (A/B against a pointer to a device copy: no difference,

@@ -820,7 +820,8 @@ static void plan_interpreter(DevConfig &dc, int tile_rows) {
 static int choose_replication(int NS, int S, size_t fixed_bytes, const AggTuning &tune, size_t *lds_out) {
   constexpr size_t kMaxLds = 160 * 1024;
   auto lds_of = [&](int rep) {
-    return fixed_bytes + sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep) + kWave));
+    // (+ kHashCtlWords behind the planes: pressure flags and flush statistics of the write-combining mode, agg_hash_update.hpp)
+    return fixed_bytes + sizeof(unsigned long long) * (S + static_cast<size_t>(NS + 1) * ((static_cast<size_t>(S) << rep) + kWave) + kHashCtlWords);
   };
   auto per_cu_of = [&](size_t lds) {
     const size_t granted = (lds + 1023) / 1024 * 1024;

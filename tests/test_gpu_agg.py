@@ -837,3 +837,36 @@ def test_expression_projection_is_bit_equal_to_the_oracle(capi, oracle, dev):
             got = capi.eval_expression([to_dev(c, dev) for c in cols], instrs, consts + [0.0] * (T.MAX_CONSTS - len(consts)), result).cpu().numpy()
             want = oracle.eval_expression(cols, instrs, consts + [0.0] * (T.MAX_CONSTS - len(consts)), result)
             assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.parametrize("order", ["clustered", "random", "clustered_then_random"])
+def test_lds_table_flushes_under_pressure(capi, oracle, dev, order, monkeypatch):
+    """More groups than the workgroup's LDS table holds (est 100 k: 512 slots): the table is written out and restarted when
+    rows start missing it — clustered keys (lineitem on l_orderkey: a flushed group never returns) — and the mechanism
+    switches itself off where a flush absorbs nothing (random order).  Every accumulator kind, a predicate, a filter, the
+    interpreter and the run-time plan shape; multiset of groups against the oracle."""
+    rng = np.random.default_rng(97)
+    n, groups = 1_500_000, 150_000
+    if order == "clustered":
+        key = np.sort(rng.integers(0, groups, size=n)).astype(np.int32)
+    elif order == "random":
+        key = rng.integers(0, groups, size=n).astype(np.int32)
+    else:
+        key = np.concatenate([np.sort(rng.integers(0, groups, size=n // 2)), rng.integers(0, groups, size=n - n // 2)]).astype(np.int32)
+    val = rng.normal(size=n)
+    ival = rng.integers(-1000, 1000, size=n).astype(np.int64)
+    layout = [(T.INT, None), (T.DOUBLE, None), (T.LONG, None)]
+    keep = oracle.bitmap_from_bools(rng.uniform(size=n) < 0.8)
+    for jit in (False, True):
+        monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if jit else str(1 << 60))
+        cfg = T.make_agg_config(T.AGG_GENERIC, layout, keys=[0],
+                                aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_SUM, T.col(2)), (T.AGG_MIN, T.col(1)), (T.AGG_MAX, T.col(2)),
+                                      (T.AGG_AVG, T.col(1)), (T.AGG_COUNT_STAR, None)],
+                                pred=[(2, T.GE, -900)], est_groups=100_000)
+        for filt in (None, keep):
+            o = oracle.AggState(cfg)
+            o.update([key, val, ival], filter_bitmap=filt)
+            assert_same_groups(finalize_np(run_hip(capi, dev, cfg, [key, val, ival], filter_bitmap=filt), dev), o.finalize())
+        o = oracle.AggState(cfg)
+        o.update([key, val, ival])
+        assert_same_groups(finalize_np(run_hip(capi, dev, cfg, [key, val, ival], blocks=4), dev), o.finalize())
