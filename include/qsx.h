@@ -529,6 +529,19 @@ int qsx_agg_state_clear(qsx_agg_state_t *state, qsx_stream_t stream);
 int qsx_agg_update(qsx_agg_state_t *state, const void *const *cols, int64_t n,
                    const uint64_t *filter_dev, qsx_stream_t stream);
 
+/* qsx_agg_update over a RUN of blocks in one launch.  The reference issues one AggregationWorkOrder per 2-4 MB storage
+ * block (relational_operators/AggregationOperator.cpp:38-79) — about 120 K Q1 rows, half a microsecond of HBM time
+ * behind ~16 us of launch; the GPU operator hands a run of blocks to ONE work order instead (the operator decides
+ * work-order granularity, RelationalOperator.hpp:117-119), every block keeping its own stripes.
+ *   block_rows     host array [num_blocks]: rows of each block (0 allowed)
+ *   block_cols     host array [num_blocks * num_columns]: device stripe of column c of block b at [b * num_columns + c]
+ *   block_filters  host array [num_blocks] of TupleIdSequence bitmaps (bit 0 = the block's first row; NULL entry = every
+ *                  row of that block), or NULL: no block has one
+ * States over compressed or nullable attributes: QSX_ERR_UNSUPPORTED (their per-block dictionaries / null bitmaps go
+ * through qsx_agg_update_coded / qsx_agg_update_nullable, one call per block). */
+int qsx_agg_update_blocks(qsx_agg_state_t *state, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
+                          const uint64_t *const *block_filters, qsx_stream_t stream);
+
 /* qsx_agg_update on a block with NULLs: null_bitmaps_dev[c] is the null bitmap of column c (TupleIdSequence bit
  * order, bit i set = tuple i is NULL, n bits; storage/BasicColumnStoreTupleStorageSubBlock.cpp:131-147 keeps one per
  * nullable attribute) or NULL when the block holds no NULL in that attribute; entries of columns not declared

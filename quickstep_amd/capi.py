@@ -92,6 +92,7 @@ _SIGNATURES = {
     "qsx_agg_state_destroy": (_int, [_vp]),
     "qsx_agg_state_clear": (_int, [_vp, _vp]),
     "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
+    "qsx_agg_update_blocks": (_int, [_vp, _int, C.POINTER(_i64), _pp, _pp, _vp]),
     "qsx_agg_mark_existence": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "qsx_agg_update_coded": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
     "qsx_agg_update_nullable": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
@@ -495,6 +496,20 @@ class AggState:
             n = cols[0].numel()
         _check(_lib.qsx_agg_update(self._h, _ptr_array(cols), n, _ptr(filter_bitmap), _stream(stream)),
                "qsx_agg_update")
+
+    def update_blocks(self, blocks, filters=None, stream=None):
+        """One launch over a run of blocks: blocks = list of per-block column lists (every block its own stripes); filters =
+        per-block bitmaps (None entries allowed) or None."""
+        nb, ncols = len(blocks), self.config.num_columns
+        rows = (C.c_int64 * max(nb, 1))(*[b[0].numel() if b else 0 for b in blocks])
+        ptrs = (C.c_void_p * max(nb * ncols, 1))()
+        for i, b in enumerate(blocks):
+            for c in range(ncols):
+                ptrs[i * ncols + c] = b[c].data_ptr() if c < len(b) and b[c] is not None else None
+        fptr = None
+        if filters is not None:
+            fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None else None for f in filters])
+        _check(_lib.qsx_agg_update_blocks(self._h, nb, rows, ptrs, fptr, _stream(stream)), "qsx_agg_update_blocks")
 
     def update_nullable(self, cols, null_bitmaps, n=None, filter_bitmap=None, stream=None):
         """null_bitmaps[c]: int64 tensor with the null bitmap words of column c (TupleIdSequence bit order) or None."""

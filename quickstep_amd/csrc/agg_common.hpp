@@ -345,6 +345,50 @@ __device__ __forceinline__ int dir_lookup(const DirView &d, unsigned long long c
 // go to the global table.
 constexpr int kLdsMaxProbes = 8;
 constexpr int kHashCtlWords = 8;   // control words behind the LDS accumulator planes of the hash update kernel
+
+// ---- a run of blocks in ONE launch (qsx_agg_update_blocks) ------------------------------------------------------------
+// The reference issues one work order per 2-4 MB storage block (~120 K Q1 rows: half a microsecond of HBM time behind
+// ~16 us of launch): a GPU work order takes a RUN of blocks, each with its own stripes.  The update kernels walk the
+// tiles of the run; a tile never straddles two blocks (every block's last tile is short).  The table travels through the
+// kernels' `pieces` argument — every kernel family already has it — and announces itself with a magic first word.
+// Layout in device memory (8-byte words): [0] kBlockRunMagic, [1] number of blocks, then the word offsets (from word 0) of
+// [2] first_tile for 1024-row tiles (num_blocks + 1 words: tiles before block b), [3] the same for 512-row tiles,
+// [4] rows per block, [5] column base pointers [block * QSX_MAX_COLUMNS + column], [6] filter bitmap per block (0: none),
+// [7] tiles per block when all blocks but the last have the same number of 1024-row tiles (0: ragged run, binary search).
+constexpr long long kBlockRunMagic = -0x424C4B52554E31ll;
+constexpr int kBlockRunHeaderWords = 8;
+struct BlockRunView {
+  long long uniform_tiles;   // > 0: every block but the last has this many tiles — block of tile t = t / uniform_tiles, no search
+  long long num_blocks;
+  const long long *first_tile;
+  const long long *rows;
+  const void *const *cols;
+  const unsigned long long *const *filters;
+};
+__device__ __forceinline__ bool is_block_run(const long long *pieces) { return pieces != nullptr && pieces[0] == kBlockRunMagic; }
+__device__ __forceinline__ BlockRunView block_run_view(const long long *table, int tile_rows) {
+  BlockRunView v;
+  v.num_blocks = table[1];
+  v.uniform_tiles = tile_rows >= 1024 ? table[7] : 0;
+  // (word offsets from the table's own start, not addresses: every read then goes through the kernel's const __restrict__
+  // argument and can be a scalar load — through a pointer that was itself loaded from memory the compiler issues vector
+  // loads + readfirstlane, a ~1.5 us dependent chain in front of every tile's stage: Q1 5.3 instead of 3.4 ms per 600 M rows)
+  v.first_tile = table + (tile_rows >= 1024 ? table[2] : table[3]);
+  v.rows = table + table[4];
+  v.cols = reinterpret_cast<const void *const *>(table + table[5]);
+  v.filters = table[6] != 0 ? reinterpret_cast<const unsigned long long *const *>(table + table[6]) : nullptr;
+  return v;
+}
+// Block of tile t: the last b with first_tile[b] <= t (workgroup-uniform: ~10 scalar steps for a thousand blocks).
+__device__ __forceinline__ long long block_of_tile(const BlockRunView &v, long long t) {
+  if (v.uniform_tiles > 0) return t / v.uniform_tiles;
+  long long lo = 0, hi = v.num_blocks;   // first_tile[lo] <= t < first_tile[hi]
+  while (hi - lo > 1) {
+    const long long mid = (lo + hi) >> 1;
+    if (v.first_tile[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
 __device__ __forceinline__ int lds_find_or_insert(unsigned long long *l_keys, int S, unsigned long long code) {
   int s = static_cast<int>(mix64(code) >> 40) & (S - 1);
   const int limit = S < kLdsMaxProbes ? S : kLdsMaxProbes;

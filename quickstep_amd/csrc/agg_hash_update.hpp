@@ -76,18 +76,25 @@ __device__ __forceinline__ void copy_elements_to_lds(const char *src, char *dst,
 }
 
 // Issue the HBM -> LDS copy of one tile (rows [row0, row0 + rows)).
-template <bool kStatic, int BLOCK = kABlock>
+// A block's column base pointers held in registers (run of blocks): loaded together, one tile ahead of their use.  Read one
+// by one from the table at stage time they are six dependent vector loads in front of the tile's DMA (Q1: 5.0 instead of
+// 3.4 ms per 600 M rows).
+struct ColumnBases {
+  const void *p[QSX_MAX_COLUMNS];
+};
+template <bool kStatic, int BLOCK = kABlock, bool kRuns = false>
 __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const *cols, const uint64_t *filter, char *tile,
-                                           int64_t row0, int rows, const unsigned long long *const *nulls = nullptr) {
+                                           int64_t row0, int rows, const unsigned long long *const *nulls = nullptr,
+                                           const ColumnBases *bases = nullptr) {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
-  cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_columns, [&](int col) __attribute__((always_inline)) {
+  auto stage_column = [&](int col, const void *base) __attribute__((always_inline)) {
     const int off = c.lds_off[col];
     if (off < 0) return;  // column not referenced by keys / predicate / expressions
     // a compressed attribute is staged as its code stripe (decode_tile_codes fills the value slots afterwards)
     const bool coded = c.code_width[col] != 0;
     const int w = coded ? c.code_width[col] : c.column_width[col];
-    const char *src = static_cast<const char *>(cols[col]) + row0 * w;
+    const char *src = static_cast<const char *>(base) + row0 * w;
     char *dst = tile + (coded ? c.code_off[col] : off);
     const int bytes = rows * w;
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
@@ -101,10 +108,24 @@ __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const
     } else {
       copy_elements_to_lds<BLOCK>(src, dst, rows, w);
     }
-  });
+  };
+  if constexpr (kRuns && kStatic) {
+    // (plan shapes: the referenced columns are known, their bases sit in registers.  The interpreter reads the bases from
+    // the table column by column: unrolling its loop over all 16 possible columns costs 200 VGPRs and scratch)
+#pragma unroll
+    for (int col = 0; col < QSX_MAX_COLUMNS; ++col) {
+      if (col < c.num_columns) stage_column(col, bases->p[col]);
+    }
+  } else {
+    cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_columns, [&](int col) __attribute__((always_inline)) { stage_column(col, cols[col]); });
+  }
   if (c.filter_lds_off >= 0) {
-    copy_elements_to_lds<BLOCK>(reinterpret_cast<const char *>(filter + (row0 >> 6)), tile + c.filter_lds_off,
-                         (rows + 63) >> 6, 8);
+    if (filter != nullptr) {
+      copy_elements_to_lds<BLOCK>(reinterpret_cast<const char *>(filter + (row0 >> 6)), tile + c.filter_lds_off,
+                           (rows + 63) >> 6, 8);
+    } else {   // (a block of a run without a filter of its own: every row)
+      for (int i = threadIdx.x; i < ((rows + 63) >> 6); i += BLOCK) reinterpret_cast<uint64_t *>(tile + c.filter_lds_off)[i] = ~0ull;
+    }
   }
   // null words of the nullable columns the plan reads (zeros for a block without NULLs in that attribute)
   cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_null_cols, [&](int s) __attribute__((always_inline)) {
@@ -454,7 +475,10 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
 // ~6 ns per wave instruction per CU, tools/ubench/lds_atomic.hip).
 // kDense: COLLISION_FREE sink — the group of a row is its key value, accumulators are the dense
 // arrays in HBM (DenseView), adjacent equal keys of a wave are combined before the atomics.
-template <bool kStatic, bool kDense, int NS, int V, bool kDir = false, int BLOCK = kABlock, bool kDirBuild = false>
+// kRuns: the rows are a run of blocks (agg_common.hpp BlockRunView in `pieces`; cols / filter unused).  A compile-time
+// flavour, not a run-time test: with both sources in one kernel the by-value column table has its address taken and moves
+// to scratch (136 bytes per lane, Q1 3.3 -> 4.9 ms per 600 M rows).
+template <bool kStatic, bool kDense, int NS, int V, bool kDir = false, int BLOCK = kABlock, bool kDirBuild = false, bool kRuns = false>
 __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, const void *const *dicts, int64_t n,
                                                      const uint64_t *__restrict__ filter, const HashTableView &g,
                                                      const DenseView &dense, int S, int rep_shift, int nbuf,
@@ -520,12 +544,47 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   box.usable = false;
   // (a wide key's code is a hash: its groups cannot be numbered by position, the directory is looked up)
   if constexpr (kDir) box = key_box_of(*dir, c.wide_words != 0 ? 0 : c.num_keys);
-  const bool by_piece = pieces != nullptr;
+  // a run of blocks (agg_common.hpp BlockRunView): the tiles of all blocks, each block with its own stripes
+  constexpr bool batched = kRuns;
+  BlockRunView run{};
+  if constexpr (batched) run = block_run_view(pieces, TR);
+  const bool by_piece = pieces != nullptr && !batched;
   const int64_t row_begin = by_piece ? pieces[my_range] : 0;
   const int64_t row_end = by_piece ? row_begin + pieces[ranges + my_range] : n;
-  const int64_t num_tiles = (row_end - row_begin + TR - 1) / TR;
+  const int64_t num_tiles = batched ? run.first_tile[run.num_blocks] : (row_end - row_begin + TR - 1) / TR;
   auto tile_row0 = [&](int64_t t) { return row_begin + t * TR; };
   auto tile_rows = [&](int64_t t) { return static_cast<int>(row_end - tile_row0(t) < TR ? row_end - tile_row0(t) : TR); };
+  // where tile t's rows are: stripes, filter, first row inside the stripes, row count
+  struct TileSource {
+    const void *const *cols;
+    ColumnBases bases;       // kRuns only
+    const uint64_t *filter;
+    int64_t row0;
+    int rows;
+  };
+  auto locate = [&](int64_t t) {
+    TileSource src;
+    if constexpr (batched) {
+      const long long b = block_of_tile(run, t);
+      src.cols = run.cols + b * QSX_MAX_COLUMNS;
+      if constexpr (kStatic) {
+#pragma unroll
+        for (int col = 0; col < QSX_MAX_COLUMNS; ++col) {
+          src.bases.p[col] = (col < c.num_columns && c.lds_off[col] >= 0) ? src.cols[col] : nullptr;
+        }
+      }
+      src.filter = run.filters != nullptr ? reinterpret_cast<const uint64_t *>(run.filters[b]) : nullptr;
+      src.row0 = (t - run.first_tile[b]) * TR;
+      const long long left = run.rows[b] - src.row0;
+      src.rows = static_cast<int>(left < TR ? left : TR);
+    } else {
+      src.cols = cols;
+      src.filter = filter;
+      src.row0 = tile_row0(t);
+      src.rows = tile_rows(t);
+    }
+    return src;
+  };
   int buf = 0;
   // (tables at their largest size only: a table sized for its estimate — Q1's 16 slots — never comes under pressure, and
   // with S a compile-time constant of the fixed-geometry shapes the whole mechanism folds away there)
@@ -572,12 +631,18 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     }
   };
   if (nbuf == 2 && first_tile < num_tiles) {
-    stage_tile<kStatic, BLOCK>(c, cols, filter, tiles, tile_row0(first_tile), tile_rows(first_tile), nulls);
+    const TileSource src = locate(first_tile);
+    stage_tile<kStatic, BLOCK, kRuns>(c, src.cols, src.filter, tiles, src.row0, src.rows, nulls, &src.bases);
   }
+  // (a run of blocks: the next tile's source is looked up while the current tile is computed — the table reads are a
+  // dependent chain of scalar loads that would otherwise sit in front of every stage)
+  TileSource carried{};
+  if (first_tile < num_tiles) carried = locate(first_tile);
   for (int64_t tile_id = first_tile; tile_id < num_tiles; tile_id += tile_step, ++tile_count) {
+    const TileSource here = carried;
     if (nbuf == 1) {
       __syncthreads();  // every wave is done reading the previous tile
-      stage_tile<kStatic, BLOCK>(c, cols, filter, tiles, tile_row0(tile_id), tile_rows(tile_id), nulls);
+      stage_tile<kStatic, BLOCK, kRuns>(c, here.cols, here.filter, tiles, here.row0, here.rows, nulls, &here.bases);
     }
     // The tile has landed (nbuf == 2: it was staged during the previous iteration and
     // every wave is done with the other buffer).
@@ -611,12 +676,14 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       __syncthreads();
     }
     const int64_t next = tile_id + tile_step;
+    if (next < num_tiles) carried = locate(next);
     if (nbuf == 2 && next < num_tiles) {
-      stage_tile<kStatic, BLOCK>(c, cols, filter, tiles + (buf ^ 1) * c.tile_bytes, tile_row0(next), tile_rows(next), nulls);
+      stage_tile<kStatic, BLOCK, kRuns>(c, carried.cols, carried.filter, tiles + (buf ^ 1) * c.tile_bytes, carried.row0, carried.rows, nulls,
+                                        &carried.bases);
     }
     char *tile = tiles + buf * c.tile_bytes;
     if (nbuf == 2) buf ^= 1;
-    const int rows = tile_rows(tile_id);
+    const int rows = here.rows;
 
     const int trow = threadIdx.x;  // this thread's first row of the tile
     decode_tile_codes<kStatic, V, BLOCK>(c, dicts, tile, trow, rows);
@@ -997,6 +1064,21 @@ struct ColumnPointers {
   const void *p[QSX_MAX_COLUMNS];
 };
 
+// The same kernels over a run of blocks (qsx_agg_update_blocks): stripes and filters come from the table, has_filter only
+// says that the plan stages filter words (c.filter_lds_off).
+template <int NS, int V>
+__global__ __launch_bounds__(kABlock) void agg_hash_update_runs_kernel(DevConfig c, int64_t n, HashTableView g, int S, int rep_shift, int nbuf,
+                                                                      int ranges, const long long *__restrict__ block_run) {
+  agg_hash_update_body<false, false, NS, V, false, kABlock, false, true>(c, nullptr, nullptr, n, nullptr, g, DenseView{}, S, rep_shift, nbuf,
+                                                                         ranges, block_run, nullptr);
+}
+template <int NS, int V>
+__global__ __launch_bounds__(kABlock) void agg_dense_update_runs_kernel(DevConfig c, int64_t n, DenseView d, int nbuf,
+                                                                       const long long *__restrict__ block_run) {
+  agg_hash_update_body<false, true, NS, V, false, kABlock, false, true>(c, nullptr, nullptr, n, nullptr, HashTableView{}, d, 8, 0, nbuf, 1,
+                                                                        block_run, nullptr);
+}
+
 // Group-directory variant (agg_common.hpp DirView): ONE workgroup of 1024 threads per CU owns the CU's LDS — `gids`
 // accumulators per aggregate, unreplicated — and 16 waves hide the directory's L2 round trip.  One row per thread and tile.
 constexpr int kDirBlock = 1024;
@@ -1032,6 +1114,21 @@ __global__ __launch_bounds__(kABlock) void agg_hash_shape_kernel(ColumnPointers 
                                                                 const long long *__restrict__ pieces) {
   static constexpr Translated T = Shape::translated(kABlock * V);
   agg_hash_update_body<true, false, T.num_sums, V>(T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces);
+}
+
+template <typename Shape, int V>
+__global__ __launch_bounds__(kABlock) void agg_hash_shape_runs_kernel(int64_t n, HashTableView g, int S, int rep_shift, int nbuf, int ranges,
+                                                                     const long long *__restrict__ block_run) {
+  static constexpr Translated T = Shape::translated(kABlock * V);
+  agg_hash_update_body<true, false, T.num_sums, V, false, kABlock, false, true>(T.dev, nullptr, nullptr, n, nullptr, g, DenseView{}, S, rep_shift,
+                                                                                nbuf, ranges, block_run);
+}
+
+template <typename Shape, int V, int S_, int REP_SHIFT_, int RANGES_>
+__global__ __launch_bounds__(kABlock) void agg_hash_shape_fixed_runs_kernel(int64_t n, HashTableView g, const long long *__restrict__ block_run) {
+  static constexpr Translated T = Shape::translated(kABlock * V);
+  agg_hash_update_body<true, false, T.num_sums, V, false, kABlock, false, true>(T.dev, nullptr, nullptr, n, nullptr, g, DenseView{}, S_, REP_SHIFT_, 1,
+                                                                                RANGES_, block_run);
 }
 
 // The same with the launch geometry of the common small-group case (one tile buffer, one workgroup family) as constants:

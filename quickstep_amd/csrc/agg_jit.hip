@@ -128,6 +128,17 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
     << ">(D, cols.p, " << (any_coded ? "dicts" : "nullptr") << ", n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", "
     << (dense ? "HashTableView{}, view" : "view, DenseView{}")
     << ", " << geo.S << ", " << geo.rep_shift << ", " << geo.nbuf << ", " << geo.ranges << ", pieces);\n}\n}  // namespace qsx\n";
+  if (geo.runs != 0) {
+    // the run-of-blocks flavour of the body: same signature (the table arrives as `pieces`), stripes from the table
+    std::string src = o.str();
+    const std::string from = "agg_hash_update_body<true, " + std::string(dense ? "true" : "false") + ", " + std::to_string(num_sums) + ", " +
+                             std::to_string(kJitRowsPerThread) + ">(D, cols.p, ";
+    const std::string to = "agg_hash_update_body<true, " + std::string(dense ? "true" : "false") + ", " + std::to_string(num_sums) + ", " +
+                           std::to_string(kJitRowsPerThread) + ", false, " + std::to_string(kABlock) + ", false, true>(D, nullptr, ";
+    const size_t at = src.find(from);
+    if (at != std::string::npos) src.replace(at, from.size(), to);
+    return src;
+  }
   return o.str();
 }
 

@@ -31,6 +31,7 @@ struct JitRequest;
 struct JitGeometry {
   int S, rep_shift, nbuf, ranges;
   int dir_gids;   // != 0: the group-directory variant (agg_common.hpp DirView) with that many LDS accumulators per aggregate
+  int runs;       // != 0: the rows are a run of blocks (agg_common.hpp BlockRunView behind the `pieces` argument)
 };
 JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geometry, bool synchronous);
 // 0: still compiling, 1: ready (*kernel set), -1: failed (hipRTC error: the interpreter stays in use)

@@ -517,7 +517,7 @@ using namespace qsx;
 // (a 0.5 M-row block whose groups the estimate missed entirely still fits).
 constexpr unsigned int kLogRecords = 1u << 20;
 
-constexpr int kJitVariants = 6;   // (filter) x (tile path, partitioned path, group directory)
+constexpr int kJitVariants = 8;   // (filter) x (tile path, partitioned path, group directory, run of blocks)
 constexpr int kDirBoundSlots = 32;
 constexpr size_t kDirControlBytes = 16 + sizeof(unsigned long long) * 2 * QSX_MAX_KEYS * kDirBoundSlots;
 struct qsx_agg_state {
@@ -836,7 +836,8 @@ static int choose_replication(int NS, int S, size_t fixed_bytes, const AggTuning
 
 template <int NS, int V>
 static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter,
-                         const HashTableView &g, int S, int ranges, const long long *pieces, hipStream_t stream, bool dry_run) {
+                         const HashTableView &g, int S, int ranges, const long long *pieces, hipStream_t stream, bool dry_run,
+                         bool runs = false) {
   constexpr int TR = kABlock * V;
   const size_t off = static_cast<size_t>(plan_tile(dc, used_columns, TR, filter != nullptr));
   plan_interpreter(dc, TR);
@@ -848,9 +849,12 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   constexpr size_t kMaxLds = 160 * 1024;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   if (dry_run) return QSX_OK;
-  static PerDeviceOnce attribute_set;  // per instantiation
+  static PerDeviceOnce attribute_set, runs_attribute_set;  // per instantiation
   {
-    const int rc = once_per_device(attribute_set, [] {
+    const int rc = runs ? once_per_device(runs_attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_update_runs_kernel<NS, V>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    }) : once_per_device(attribute_set, [] {
       return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_update_kernel<NS, V>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
     });
@@ -865,6 +869,10 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   int grid = static_cast<int>(num_tiles * ranges < max_grid ? num_tiles * ranges : max_grid);
   grid = grid / ranges * ranges;
   if (grid < ranges) grid = ranges;
+  if (runs) {   // (pieces = the block-run table)
+    hipLaunchKernelGGL((agg_hash_update_runs_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, g, S, rep_shift, nbuf, ranges, pieces);
+    return QSX_OK;
+  }
   hipLaunchKernelGGL((agg_hash_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, g, S,
                      rep_shift, nbuf, ranges, pieces);
   return QSX_OK;
@@ -874,7 +882,7 @@ static int agg_rows_per_thread() { return agg_tuning().rows_per_thread; }
 
 // ---- AOT plan shapes (agg_shapes.hpp) -------------------------------------------------
 typedef int (*ShapeLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
-                             int ranges, const long long *pieces, hipStream_t stream);
+                             int ranges, const long long *pieces, hipStream_t stream, bool runs);
 typedef int (*ShapeDirLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, const DirView &d, int gids,
                                 int nbuf, hipStream_t stream);
 struct ShapeEntry {
@@ -976,7 +984,7 @@ static int launch_dir(DevConfig dc, unsigned used_columns, int64_t n, const uint
 
 template <typename Shape, int V>
 static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
-                          int ranges, const long long *pieces, hipStream_t stream) {
+                          int ranges, const long long *pieces, hipStream_t stream, bool runs) {
   constexpr int TR = kABlock * V;
   constexpr Translated T = Shape::translated(TR);
   static_assert(T.status == QSX_OK, "plan shape does not translate");
@@ -1023,6 +1031,26 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
                        g, pieces);                                                                                                 \
     return QSX_OK;                                                                                                                 \
   } while (0)
+  if (runs && nbuf == 1 && S == 16 && rep_shift == 4 && ranges == 1) {   // the default small-group geometry as constants (Q1)
+    static PerDeviceOnce fixed_runs_attribute_set;
+    const int rc = once_per_device(fixed_runs_attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_runs_kernel<Shape, V, 16, 4, 1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
+    hipLaunchKernelGGL((agg_hash_shape_fixed_runs_kernel<Shape, V, 16, 4, 1>), dim3(grid), dim3(kABlock), lds, stream, n, g, pieces);
+    return QSX_OK;
+  }
+  if (runs) {   // a run of blocks (pieces = its table): stripes come from the table, not from the argument list
+    static PerDeviceOnce runs_attribute_set;
+    const int rc = once_per_device(runs_attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_runs_kernel<Shape, V>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
+    hipLaunchKernelGGL((agg_hash_shape_runs_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, n, g, S, rep_shift, nbuf, ranges, pieces);
+    return QSX_OK;
+  }
   if (nbuf == 1 && S == 16 && rep_shift == 4 && ranges == 1 && pieces == nullptr) QSX_LAUNCH_FIXED(16, 4, 1);
   if (nbuf == 1 && S == 1024 && rep_shift == 0 && ranges == 32 && pieces != nullptr) QSX_LAUNCH_FIXED(1024, 0, 32);
 #undef QSX_LAUNCH_FIXED
@@ -1033,9 +1061,9 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
 
 template <typename Shape>
 static int launch_shape(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
-                        int ranges, const long long *pieces, hipStream_t stream) {
-  if (agg_tuning().shape_rows_per_thread == 4) return launch_shape_v<Shape, 4>(cols, num_columns, n, g, S, ranges, pieces, stream);
-  return launch_shape_v<Shape, 2>(cols, num_columns, n, g, S, ranges, pieces, stream);
+                        int ranges, const long long *pieces, hipStream_t stream, bool runs) {
+  if (agg_tuning().shape_rows_per_thread == 4) return launch_shape_v<Shape, 4>(cols, num_columns, n, g, S, ranges, pieces, stream, runs);
+  return launch_shape_v<Shape, 2>(cols, num_columns, n, g, S, ranges, pieces, stream, runs);
 }
 
 static const ShapeEntry *find_shape(const qsx_agg_config_t &c) {
@@ -1079,9 +1107,9 @@ static JitGeometry jit_geometry_for(const qsx_agg_state *st, int tile_bytes, int
 // The specialised kernel of this state for the (filter, partitioned) variant, requested once the state has aggregated
 // jit_min_rows() rows; nullptr -> use the interpreter (not requested yet, still compiling, or given up).
 static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, bool partitioned, int slots, int num_ranges, int64_t n,
-                                         int *variant, bool directory = false) {
+                                         int *variant, bool directory = false, bool runs = false) {
   const long long seen = st->rows_seen.fetch_add(n) + n;
-  const int v = (has_filter ? 1 : 0) + (directory ? 4 : (partitioned ? 2 : 0));
+  const int v = (has_filter ? 1 : 0) + (runs ? 6 : (directory ? 4 : (partitioned ? 2 : 0)));
   *variant = v;
   std::lock_guard<std::mutex> lock(st->jit_mutex);
   if (st->jit_tried[v]) return st->jit[v];          // settled: ready or given up
@@ -1100,6 +1128,7 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
       st->jit_lds[v] = dir_lds_bytes(dev.tile_bytes, 0, st->num_sums, st->dir_gids, st->dir_nbuf);
     } else {
       st->jit_geometry[v] = jit_geometry_for(st, dev.tile_bytes, slots, num_ranges, &st->jit_lds[v]);
+      st->jit_geometry[v].runs = runs ? 1 : 0;
     }
     if (st->jit_lds[v] > 160 * 1024) {               // the shape would not fit a CU: the interpreter's smaller tiles stay in use
       st->jit_tried[v] = true;
@@ -1187,19 +1216,21 @@ static int launch_jit_dir(qsx_agg_state *st, const JitKernel *k, int variant, co
 
 template <int NS>
 static int launch_hash(const DevConfig &dc, unsigned used_columns, int64_t n, const uint64_t *filter,
-                       const HashTableView &g, int S, int ranges, const long long *pieces, hipStream_t stream) {
+                       const HashTableView &g, int S, int ranges, const long long *pieces, hipStream_t stream, bool runs = false) {
   // 1024-row tiles when two of them (plus the group tables) fit the CU's LDS twice over, else 512-row tiles
-  if (agg_rows_per_thread() == 4 && launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, pieces, stream, true) == QSX_OK) {
-    return launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, pieces, stream, false);
+  if (agg_rows_per_thread() == 4 && launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, pieces, stream, true, runs) == QSX_OK) {
+    return launch_hash_v<NS, 4>(dc, used_columns, n, filter, g, S, ranges, pieces, stream, false, runs);
   }
-  int rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, S, ranges, pieces, stream, false);
+  int rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, S, ranges, pieces, stream, false, runs);
   // (with pieces the family count is fixed by the partitioning: keep it, only shrink the table)
-  if (rc == QSX_ERR_CAPACITY) rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, 64, pieces != nullptr ? ranges : 1, pieces, stream, false);
+  if (rc == QSX_ERR_CAPACITY) {
+    rc = launch_hash_v<NS, 2>(dc, used_columns, n, filter, g, 64, pieces != nullptr && !runs ? ranges : 1, pieces, stream, false, runs);
+  }
   return rc;
 }
 template <int NS>
 static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter, const DenseView &d,
-                        hipStream_t stream) {
+                        hipStream_t stream, const long long *block_run = nullptr) {   // block_run: the rows are a run of blocks
   constexpr int V = 4;
   constexpr int TR = kABlock * V;
   plan_tile(dc, used_columns, TR, filter != nullptr);
@@ -1223,6 +1254,16 @@ static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const ui
   const int64_t num_tiles = (n + TR - 1) / TR;
   const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;
   const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
+  if (block_run != nullptr) {
+    static PerDeviceOnce runs_attribute_set;
+    const int rc = once_per_device(runs_attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dense_update_runs_kernel<NS, V>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
+    hipLaunchKernelGGL((agg_dense_update_runs_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, d, nbuf, block_run);
+    return QSX_OK;
+  }
   hipLaunchKernelGGL((agg_dense_update_kernel<NS, V>), dim3(grid), dim3(kABlock), lds, stream, dc, n, filter, d, nbuf);
   return QSX_OK;
 }
@@ -1570,9 +1611,14 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
 // One launch of the update kernel over n rows with the given LDS table geometry: AOT plan shape, then the
 // run-time one, then the interpreter (CAPACITY — the tile does not fit LDS next to the group tables — and
 // compile failures fall through).
+// block_run != nullptr: the rows are a run of blocks described by that device table (agg_common.hpp BlockRunView; cols /
+// filter_dev then only say which columns and whether a filter exist); it travels in the kernels' `pieces` argument.
 static int update_slice(qsx_agg_state *st, const void *const *cols, const void *const *dicts, int64_t n,
                         const uint64_t *filter_dev, int slots, int ranges, const long long *pieces, hipStream_t s,
-                        const uint64_t *const *nulls = nullptr) {
+                        const uint64_t *const *nulls = nullptr, const long long *block_run = nullptr) {
+  const bool partitioned = pieces != nullptr;
+  const bool runs = block_run != nullptr;
+  if (runs) pieces = block_run;
   DevConfig dc = st->dev;
   for (int i = 0; i < st->config.num_columns; ++i) {
     dc.cols[i] = cols[i];
@@ -1586,7 +1632,7 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
   // (states over nullable columns run the interpreter: the null bitmaps of a call travel in its configuration argument)
   const JitKernel *jk = (aot || dc.num_null_cols != 0)
                             ? nullptr
-                            : state_jit_kernel(st, filter_dev != nullptr, pieces != nullptr, slots, ranges, n, &variant);
+                            : state_jit_kernel(st, filter_dev != nullptr, partitioned, slots, ranges, n, &variant, false, runs);
   if (jk != nullptr) {
     int rc = launch_jit(st, jk, variant, cols, dc.dicts, n, filter_dev, slots, ranges, pieces, s);
     if (rc == QSX_OK && hipGetLastError() == hipSuccess) return QSX_OK;
@@ -1597,15 +1643,15 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
   if (st->dense) {
     const DenseView d = st->dense_view();
     int rc = QSX_OK;
-    QSX_DISPATCH_NS(st->num_sums, rc = launch_dense, dc, st->used_columns, n, filter_dev, d, s);
+    QSX_DISPATCH_NS(st->num_sums, rc = launch_dense, dc, st->used_columns, n, filter_dev, d, s, block_run);
     if (rc != QSX_OK) return rc;
   } else {
     const HashTableView g = st->hash_view();
     int rc = QSX_OK;
     if (aot) {
-      rc = st->shape->launch(cols, st->config.num_columns, n, g, slots, ranges, pieces, s);
+      rc = st->shape->launch(cols, st->config.num_columns, n, g, slots, ranges, pieces, s, runs);
     } else {
-      QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, slots, ranges, pieces, s);
+      QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, slots, ranges, pieces, s, runs);
     }
     if (rc != QSX_OK) return rc;
   }
@@ -1751,6 +1797,85 @@ int qsx_agg_update_nullable(qsx_agg_state_t *st, const void *const *cols, const 
     }
   }
   return agg_update(st, cols, nullptr, n, filter_dev, stream, null_bitmaps_dev);
+}
+
+int qsx_agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
+                          const uint64_t *const *block_filters, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (st == nullptr || num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_cols == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
+  // (compressed and nullable inputs carry per-block dictionaries / null bitmaps: one call per block, qsx_agg_update_coded /
+  // qsx_agg_update_nullable)
+  if (st->has_coded_columns || st->dev.num_null_cols != 0) return QSX_ERR_UNSUPPORTED;
+  const int ncols = st->config.num_columns;
+  // the table (agg_common.hpp): header, first_tile for 1024- and 512-row tiles, rows, column pointers, filters
+  std::vector<long long> table(kBlockRunHeaderWords);
+  std::vector<long long> tiles1024, tiles512, rows, filters;
+  std::vector<long long> cols;
+  int64_t total = 0;
+  bool any_filter = false;
+  const void *first_cols[QSX_MAX_COLUMNS] = {};
+  const uint64_t *first_filter = nullptr;
+  for (int b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0) return QSX_ERR_INVALID_ARGUMENT;
+    if (block_rows[b] == 0) continue;
+    if (rows.empty()) {
+      for (int c = 0; c < ncols; ++c) first_cols[c] = block_cols[static_cast<size_t>(b) * ncols + c];
+    }
+    tiles1024.push_back(tiles1024.empty() ? 0 : tiles1024.back() + (rows.back() + 1023) / 1024);
+    tiles512.push_back(tiles512.empty() ? 0 : tiles512.back() + (rows.back() + 511) / 512);
+    rows.push_back(block_rows[b]);
+    for (int c = 0; c < QSX_MAX_COLUMNS; ++c) {
+      const void *p = c < ncols ? block_cols[static_cast<size_t>(b) * ncols + c] : nullptr;
+      if (c < ncols && ((st->used_columns >> c) & 1u) != 0 && p == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+      cols.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(p)));
+    }
+    const uint64_t *f = block_filters != nullptr ? block_filters[b] : nullptr;
+    if (f != nullptr && first_filter == nullptr) first_filter = f;
+    any_filter = any_filter || f != nullptr;
+    filters.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(f)));
+    total += block_rows[b];
+  }
+  if (rows.empty()) return QSX_OK;
+  tiles1024.push_back(tiles1024.back() + (rows.back() + 1023) / 1024);
+  tiles512.push_back(tiles512.back() + (rows.back() + 511) / 512);
+  const size_t nb = rows.size();
+  const size_t off1024 = kBlockRunHeaderWords, off512 = off1024 + nb + 1, off_rows = off512 + nb + 1, off_cols = off_rows + nb,
+               off_filters = off_cols + nb * QSX_MAX_COLUMNS, words = off_filters + nb;
+  table.resize(words);
+  std::copy(tiles1024.begin(), tiles1024.end(), table.begin() + off1024);
+  std::copy(tiles512.begin(), tiles512.end(), table.begin() + off512);
+  std::copy(rows.begin(), rows.end(), table.begin() + off_rows);
+  std::copy(cols.begin(), cols.end(), table.begin() + off_cols);
+  std::copy(filters.begin(), filters.end(), table.begin() + off_filters);
+  hipStream_t s = as_stream(stream);
+  long long *dev_table = static_cast<long long *>(staged_device_buffer(s, words * sizeof(long long)));
+  if (dev_table == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  table[0] = kBlockRunMagic;
+  table[1] = static_cast<long long>(nb);
+  table[2] = static_cast<long long>(off1024);
+  table[3] = static_cast<long long>(off512);
+  table[4] = static_cast<long long>(off_rows);
+  table[5] = static_cast<long long>(off_cols);
+  table[6] = any_filter ? static_cast<long long>(off_filters) : 0;
+  table[7] = 0;
+  {   // equal-sized blocks (a relation's blocks all hold the same number of tuples but the last): no search per tile
+    const long long per_block = (rows[0] + 1023) / 1024;
+    bool uniform = per_block > 0;
+    for (size_t b = 0; b + 1 < nb && uniform; ++b) uniform = (rows[b] + 1023) / 1024 == per_block;
+    if (uniform && nb > 1 && (rows[nb - 1] + 1023) / 1024 > per_block) uniform = false;
+    if (uniform) table[7] = per_block;
+  }
+  int rc = staged_upload(s, table.data(), words * sizeof(long long));
+  if (rc != QSX_OK) return rc;
+  rc = maybe_grow(st);
+  if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
+  // one launch over the tiles of all blocks.  (The group directory and the partition pass want one stripe per column: a
+  // mid-size group count takes the hash-range families here.)
+  rc = update_slice(st, first_cols, nullptr, total, any_filter ? first_filter : nullptr, st->lds_slots, st->lds_ranges, nullptr, s, nullptr,
+                    dev_table);
+  if (rc != QSX_OK) return rc;
+  return publish_control(st, s);
 }
 
 int qsx_agg_update_coded(qsx_agg_state_t *st, const void *const *cols, const void *const *dictionaries_dev, int64_t n,

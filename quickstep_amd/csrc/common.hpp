@@ -85,6 +85,56 @@ static T *device_slot(hipStream_t stream) {
   return p;
 }
 
+// Host tables of a call -> device memory, stream-ordered, without handing pageable memory to hipMemcpyAsync: one pinned
+// staging buffer and one device buffer per (host thread, stream), grown on demand.  The pinned buffer is rewritten only
+// after the event recorded behind its last copy has completed; the device buffer is rewritten by a copy that the stream
+// orders behind the kernels of the previous call that read it.
+struct StagedBuffer {
+  void *pinned = nullptr;
+  void *device = nullptr;
+  size_t capacity = 0;
+  hipEvent_t copied = nullptr;
+};
+static StagedBuffer *staged_buffer_for(hipStream_t stream, size_t bytes) {
+  thread_local std::map<hipStream_t, StagedBuffer> buffers;
+  StagedBuffer &b = buffers[stream];
+  if (b.capacity >= bytes) return &b;
+  if (b.copied != nullptr) (void)hipEventSynchronize(b.copied);
+  if (b.device != nullptr) {
+    (void)hipStreamSynchronize(stream);   // kernels of earlier calls may still read the old table
+    (void)hipFree(b.device);
+    (void)hipHostFree(b.pinned);
+    b.device = b.pinned = nullptr;
+    b.capacity = 0;
+  }
+  size_t cap = 64 * 1024;
+  while (cap < bytes) cap *= 2;
+  if (b.copied == nullptr && hipEventCreateWithFlags(&b.copied, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&b.pinned, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (hipMalloc(&b.device, cap) != hipSuccess) {
+    (void)hipHostFree(b.pinned);
+    b.pinned = nullptr;
+    return nullptr;
+  }
+  b.capacity = cap;
+  return &b;
+}
+// The device address the next staged_upload of this (thread, stream) will fill: tables that hold their own addresses need
+// it before they are complete.
+static void *staged_device_buffer(hipStream_t stream, size_t bytes) {
+  StagedBuffer *b = staged_buffer_for(stream, bytes);
+  return b != nullptr ? b->device : nullptr;
+}
+static int staged_upload(hipStream_t stream, const void *host_src, size_t bytes) {
+  StagedBuffer *b = staged_buffer_for(stream, bytes);
+  if (b == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  QSX_HIP_TRY(hipEventSynchronize(b->copied));   // the previous copy out of the pinned buffer (a fresh event is complete)
+  std::memcpy(b->pinned, host_src, bytes);
+  QSX_HIP_TRY(hipMemcpyAsync(b->device, b->pinned, bytes, hipMemcpyHostToDevice, stream));
+  QSX_HIP_TRY(hipEventRecord(b->copied, stream));
+  return QSX_OK;
+}
+
 }  // namespace qsx
 
 #endif  // QSX_CSRC_COMMON_HPP_

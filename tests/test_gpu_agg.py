@@ -870,3 +870,58 @@ def test_lds_table_flushes_under_pressure(capi, oracle, dev, order, monkeypatch)
         o = oracle.AggState(cfg)
         o.update([key, val, ival])
         assert_same_groups(finalize_np(run_hip(capi, dev, cfg, [key, val, ival], blocks=4), dev), o.finalize())
+
+
+# ---- a run of blocks in one launch -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["q1_aot", "generic_interpreter", "generic_jit", "dense", "hash_ranges"])
+def test_update_blocks_equals_one_update_per_block(capi, oracle, dev, kind, monkeypatch):
+    """qsx_agg_update_blocks: ONE launch over a run of blocks, every block with its own stripes (the reference's 2-4 MB
+    blocks are ~120 K rows: a launch per block is launch-bound by 20x).  Ragged block sizes — empty blocks, single rows,
+    sizes that are no multiple of a tile — per-block filters with gaps; AOT shape, interpreter, run-time shape, dense state,
+    hash-range families.  Must equal the oracle fed block by block."""
+    rng = np.random.default_rng(101)
+    sizes = [0, 1, 1023, 1024, 1025, 70_000, 0, 333, 120_000, 512, 5, 48_321]
+    n = sum(sizes)
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if kind in ("generic_jit", "dense", "hash_ranges") else str(1 << 60))
+    if kind == "q1_aot":
+        import bench
+        cfg = bench.q1_config()
+        cols = bench.gen_q1_columns_cpu(n, 5)
+    elif kind == "dense":
+        cols = [rng.integers(0, 5000, size=n).astype(np.int32), rng.normal(size=n), rng.integers(-9, 9, size=n).astype(np.int64)]
+        cfg = T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None), (T.DOUBLE, None), (T.LONG, None)], keys=[0],
+                                aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None), (T.AGG_MAX, T.col(2))], num_entries=5000)
+    else:
+        groups = 40 if kind != "hash_ranges" else 3000
+        cols = [rng.integers(0, groups, size=n).astype(np.int32), rng.normal(size=n), rng.integers(-9, 9, size=n).astype(np.int64)]
+        cfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None), (T.LONG, None)], keys=[0],
+                                instrs=[(T.EX_MUL, 0, T.col(1), T.col(2))],
+                                aggs=[(T.AGG_SUM, T.temp(0)), (T.AGG_MIN, T.col(1)), (T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None)],
+                                pred=[(2, T.GE, -8)], est_groups=groups)
+    edges = np.concatenate([[0], np.cumsum(sizes)])
+    host_blocks = [[c[edges[b]:edges[b + 1]] for c in cols] for b in range(len(sizes))]
+    dev_blocks = [[to_dev(c, dev) for c in blk] for blk in host_blocks]      # separate allocations per block and column
+    o = oracle.AggState(cfg)
+    for blk in host_blocks:
+        if blk[0].size:
+            o.update(blk)
+    st = capi.AggState(cfg)
+    st.update_blocks(dev_blocks)
+    st.update_blocks([])                                                      # an empty run is a no-op
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+    if kind == "q1_aot":
+        return                                                                # (the AOT shape takes no filter)
+    # per-block filters; blocks 3 and 8 have none (= every row)
+    masks = [rng.uniform(size=s) < 0.6 if s else np.zeros(0, dtype=bool) for s in sizes]
+    filters = [None if (b in (3, 8) or sizes[b] == 0) else bitmap_dev(oracle.bitmap_from_bools(masks[b]), dev) for b in range(len(sizes))]
+    o = oracle.AggState(cfg)
+    for b, blk in enumerate(host_blocks):
+        if blk[0].size:
+            o.update(blk, filter_bitmap=None if filters[b] is None else oracle.bitmap_from_bools(masks[b]))
+    st = capi.AggState(cfg)
+    st.update_blocks(dev_blocks, filters=filters)
+    st.update_blocks(dev_blocks[:2], filters=filters[:2])                     # a second, tiny run on the same state
+    for blk, f, m in list(zip(host_blocks, filters, masks))[:2]:
+        if blk[0].size:
+            o.update(blk, filter_bitmap=None if f is None else oracle.bitmap_from_bools(m))
+    assert_same_groups(finalize_np(st, dev), o.finalize())

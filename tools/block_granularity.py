@@ -52,5 +52,11 @@ for block in (n, 10_000_000, 1_000_000, 120_000):
             e = min(n, s + block)
             capi.select_cmp(cols[2][s:e], T.LT, 24.0)
 
+    def agg_run():                       # the same blocks as ONE work order: qsx_agg_update_blocks
+        st.clear()
+        st.update_blocks(run_blocks)
+
+    run_blocks = [[c[s0:min(n, s0 + block)] for c in cols] for s0 in range(0, n, block)]
     print(json.dumps({"rows": n, "block_rows": block, "calls": (n + block - 1) // block, "aggregate_ms": round(timed(agg), 3),
+                      "aggregate_as_one_run_of_blocks_ms": round(timed(agg_run), 3),
                       "probe_ms": round(timed(probe), 3), "select_ms": round(timed(select), 3)}), flush=True)
