@@ -1033,6 +1033,37 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
 }
 
+void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference> &blocks,
+                                                const std::vector<const std::uint64_t *> &lip_filters) {
+  std::vector<std::int64_t> rows;
+  std::vector<const void *> cols;
+  std::vector<const std::uint64_t *> filters;
+  bool any_filter = false;
+  const bool state_allows = state_ != nullptr && distinctify_.empty() && external_predicate_.conjuncts.empty();
+  for (std::size_t i = 0; i < blocks.size(); ++i) {
+    const StorageBlock &block = *blocks[i];
+    const std::uint64_t *filter = i < lip_filters.size() ? lip_filters[i] : nullptr;
+    bool in_run = state_allows && block.numTuples() > 0;
+    for (std::size_t c = 0; c < column_attr_.size() && in_run; ++c) {
+      // per-block dictionaries and null bitmaps travel with single-block calls (qsx_agg_update_coded / _nullable)
+      if (block.nullBitmap(column_attr_[c]) != nullptr) in_run = false;
+      if (block.compressedAttribute(column_attr_[c]) != nullptr && !block.valuesMaterialized(column_attr_[c])) in_run = false;
+    }
+    if (!in_run) {
+      aggregateBlock(block, filter);
+      continue;
+    }
+    rows.push_back(block.numTuples());
+    for (std::size_t c = 0; c < column_attr_.size(); ++c) cols.push_back(block.stripe(column_attr_[c]));
+    filters.push_back(filter);
+    any_filter = any_filter || filter != nullptr;
+  }
+  if (rows.empty()) return;
+  CheckStatus(qsx_agg_update_blocks(state_, static_cast<int>(rows.size()), rows.data(), cols.data(), any_filter ? filters.data() : nullptr,
+                                    CurrentStream()), "qsx_agg_update_blocks");
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+}
+
 // finalizeAggregate with DISTINCT aggregates: every distinctify table is reduced to its distinct tuples, which are
 // aggregated once each into a table keyed like the final one (aggregateOnDistinctifyHashTableFor{Single,GroupBy},
 // AggregationOperationState.cpp:652-670, 720-760); the per-aggregate results are then lined up on the group key.
@@ -2051,7 +2082,27 @@ class AggregationWorkOrder : public WorkOrder {
                        StorageManager *storage_manager, partition_id part = 0, LIPFilterAdaptiveProber *prober = nullptr)
       : WorkOrder(query_id, part), input_block_id_(input_block_id), state_(state), storage_manager_(storage_manager),
         lip_filter_adaptive_prober_(prober) {}
+  // a run of blocks (AggregationOperator::setBlocksPerWorkOrder)
+  AggregationWorkOrder(std::size_t query_id, std::vector<block_id> input_block_ids, AggregationOperationState *state,
+                       StorageManager *storage_manager, partition_id part, LIPFilterAdaptiveProber *prober)
+      : WorkOrder(query_id, part), input_block_id_(input_block_ids.front()), more_block_ids_(input_block_ids.begin() + 1, input_block_ids.end()),
+        state_(state), storage_manager_(storage_manager), lip_filter_adaptive_prober_(prober) {}
   void execute() override {  // AggregationOperator.cpp:124-126
+    if (!more_block_ids_.empty()) {
+      std::vector<BlockReference> blocks{storage_manager_->getBlock(input_block_id_)};
+      for (block_id id : more_block_ids_) blocks.push_back(storage_manager_->getBlock(id));
+      std::vector<const std::uint64_t *> filters(blocks.size(), nullptr);
+      std::vector<void *> owned;
+      if (lip_filter_adaptive_prober_ != nullptr) {
+        for (std::size_t i = 0; i < blocks.size(); ++i) {
+          owned.push_back(lip_filter_adaptive_prober_->filterValueAccessor(*blocks[i], nullptr, nullptr));
+          filters[i] = static_cast<const std::uint64_t *>(owned.back());
+        }
+      }
+      state_->aggregateBlocks(blocks, filters);
+      for (void *p : owned) qsx_device_free(p);
+      return;
+    }
     BlockReference block = storage_manager_->getBlock(input_block_id_);
     void *lip = nullptr;
     if (lip_filter_adaptive_prober_ != nullptr) lip = lip_filter_adaptive_prober_->filterValueAccessor(*block, nullptr, nullptr);
@@ -2060,6 +2111,7 @@ class AggregationWorkOrder : public WorkOrder {
   }
  private:
   block_id input_block_id_;
+  std::vector<block_id> more_block_ids_;
   AggregationOperationState *state_;
   StorageManager *storage_manager_;
   std::unique_ptr<LIPFilterAdaptiveProber> lip_filter_adaptive_prober_;
@@ -2140,11 +2192,21 @@ bool AggregationOperator::getAllWorkOrders(WorkOrdersContainer *container, Query
   for (partition_id part = 0; part < num_partitions_; ++part) {   // AggregationOperator.cpp:49-61
     AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, part);
     while (input_.generated[part] < input_.ids[part].size()) {
-      container->addNormalWorkOrder(new AggregationWorkOrder(query_id_, input_.ids[part][input_.generated[part]], state,
-                                                             storage_manager, part,
-                                                             CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context)),
-                                    op_index_);
-      ++input_.generated[part];
+      // every block that has arrived, in runs of blocks_per_work_order_ (1: the reference's one work order per block)
+      const std::size_t take = std::min(blocks_per_work_order_, input_.ids[part].size() - input_.generated[part]);
+      if (take > 1) {
+        std::vector<block_id> run(input_.ids[part].begin() + static_cast<std::ptrdiff_t>(input_.generated[part]),
+                                  input_.ids[part].begin() + static_cast<std::ptrdiff_t>(input_.generated[part] + take));
+        container->addNormalWorkOrder(new AggregationWorkOrder(query_id_, std::move(run), state, storage_manager, part,
+                                                               CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context)),
+                                      op_index_);
+      } else {
+        container->addNormalWorkOrder(new AggregationWorkOrder(query_id_, input_.ids[part][input_.generated[part]], state,
+                                                               storage_manager, part,
+                                                               CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context)),
+                                      op_index_);
+      }
+      input_.generated[part] += take;
     }
   }
   return input_relation_is_stored_ || done_feeding_input_relation_;

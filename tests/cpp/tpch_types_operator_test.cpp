@@ -6,6 +6,7 @@
 // blocks and over compressed ones (dictionary codes for the CHAR(10) and DATE attributes: predicates scan the codes,
 // CompressedStoreUtil.cpp:51-140) and is checked against the same computation on the host columns.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -390,6 +391,86 @@ int main() {
     }
     EXPECT_EQ(at, got_qty.size());
     EXPECT_TRUE(same);
+  }
+  // ---- work-order granularity: Q1 over blocks of the reference's size (4 MB of Q1 columns = 120 K rows), one
+  // AggregationWorkOrder per block against one per run of 64 blocks (qsx_agg_update_blocks) — same result, and the run
+  // form must not be slower (on the GPU box it is several times faster: the per-block form is launch-bound)
+  {
+    constexpr std::int64_t kBig = 6000000, kBigBlock = 120000;
+    std::vector<unsigned char> flag(kBig), status(kBig);
+    std::vector<double> qty(kBig), price(kBig), disc(kBig), tax(kBig);
+    std::uint64_t x = 0x853C49E6748FEA9Bull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (std::int64_t i = 0; i < kBig; ++i) {
+      flag[i] = "ANR"[rnd() % 3]; status[i] = "FO"[rnd() % 2];
+      qty[i] = static_cast<double>(rnd() % 50 + 1); price[i] = 900.0 + static_cast<double>(rnd() % 10000000) / 100.0;
+      disc[i] = static_cast<double>(rnd() % 11) / 100.0; tax[i] = static_cast<double>(rnd() % 9) / 100.0;
+    }
+    StorageManager storage;
+    CatalogRelation lineitem(40, "lineitem");
+    lineitem.addAttribute("l_returnflag", Type::Char(1));
+    lineitem.addAttribute("l_linestatus", Type::Char(1));
+    for (const char *name : {"l_quantity", "l_extendedprice", "l_discount", "l_tax"}) lineitem.addAttribute(name, Type::Double());
+    for (std::int64_t at = 0; at < kBig; at += kBigBlock) {
+      storage.loadBlock(&lineitem, {flag.data() + at, status.data() + at, qty.data() + at, price.data() + at, disc.data() + at, tax.data() + at}, kBigBlock);
+    }
+    const ScalarPtr p = Scalar::Attribute(3), d = Scalar::Attribute(4), tx = Scalar::Attribute(5), one = Scalar::Literal(1.0);
+    const ScalarPtr disc_price = Scalar::Binary(BinaryOperationID::kMultiply, p, Scalar::Binary(BinaryOperationID::kSubtract, one, d));
+    const ScalarPtr charge = Scalar::Binary(BinaryOperationID::kMultiply, disc_price, Scalar::Binary(BinaryOperationID::kAdd, one, tx));
+    std::map<std::pair<char, char>, std::vector<double>> results[2];
+    double millis[2] = {0, 0};
+    for (int runs = 0; runs < 2; ++runs) {
+      for (int rep = 0; rep < 3; ++rep) {   // the last repetition is the one compared and timed
+        CatalogRelation result(41 + runs, "q1");
+        for (const char *name : {"l_returnflag", "l_linestatus"}) result.addAttribute(name, Type::Char(1));
+        for (const char *name : {"sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "avg_disc"}) result.addAttribute(name, Type::Double());
+        result.addAttribute("count_order", Type::Long());
+        QueryContext ctx;
+        AggregationStateSpec spec;
+        spec.input_relation = &lineitem;
+        spec.group_by = {0, 1};
+        spec.aggregates = {AggregateSpec(AggregationID::kSum, 2), AggregateSpec(AggregationID::kSum, 3), AggregateSpec(AggregationID::kSum, disc_price),
+                           AggregateSpec(AggregationID::kSum, charge), AggregateSpec(AggregationID::kAvg, 4),
+                           AggregateSpec(AggregationID::kCount, kInvalidAttributeID)};
+        spec.strategy = QSX_AGG_COMPACT_KEY;
+        spec.estimated_num_groups = 6;
+        const auto state = ctx.addAggregationState(spec);
+        const auto dest = ctx.addInsertDestination(&result, &storage);
+        AggregationOperator op(0, lineitem, true, state);
+        if (runs == 1) op.setBlocksPerWorkOrder(64);
+        FinalizeAggregationOperator fin(0, state, 1, false, 1, result, dest);
+        const auto t0 = std::chrono::steady_clock::now();
+        fetchAndExecuteWorkOrders(&op, &ctx, &storage);
+        millis[runs] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        fetchAndExecuteWorkOrders(&fin, &ctx, &storage);
+        results[runs].clear();
+        for (block_id b : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+          BlockReference blk = storage.getBlock(b);
+          const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+          std::vector<char> f(k), s2(k);
+          std::vector<std::vector<double>> vals(5, std::vector<double>(k));
+          std::vector<std::int64_t> cnt(k);
+          blk->copyAttributeToHost(0, f.data()); blk->copyAttributeToHost(1, s2.data());
+          for (int a = 0; a < 5; ++a) blk->copyAttributeToHost(static_cast<attribute_id>(2 + a), vals[a].data());
+          blk->copyAttributeToHost(7, cnt.data());
+          for (std::size_t i = 0; i < k; ++i) {
+            results[runs][{f[i], s2[i]}] = {vals[0][i], vals[1][i], vals[2][i], vals[3][i], vals[4][i], static_cast<double>(cnt[i])};
+          }
+        }
+      }
+    }
+    EXPECT_EQ(results[0].size(), static_cast<std::size_t>(6));
+    EXPECT_EQ(results[1].size(), results[0].size());
+    for (const auto &kv : results[0]) {
+      const auto it = results[1].find(kv.first);
+      EXPECT_TRUE(it != results[1].end());
+      if (it == results[1].end()) continue;
+      EXPECT_TRUE(it->second[5] == kv.second[5]);                                                       // counts: exact
+      for (int a = 0; a < 5; ++a) EXPECT_NEAR(it->second[a], kv.second[a], 1e-9 * std::fabs(kv.second[a]));
+    }
+    std::printf("Q1 over %lld rows in %lld blocks: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n",
+                static_cast<long long>(kBig), static_cast<long long>(kBig / kBigBlock), millis[0], millis[1]);
+    EXPECT_TRUE(millis[1] < millis[0] * 1.5);
   }
   return finish("tpch_types_operator_test");
 }
