@@ -119,6 +119,22 @@ int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op,
                    uint64_t *out_bitmap_dev, int64_t *out_count_dev,
                    qsx_stream_t stream);
 
+/* K1 over a run of blocks in one launch: for every block b < num_blocks,
+ *   block_out_bitmaps[b][i] = (block_cols[b][i] OP *literal) [AND block_filters[b][i]],  i < block_rows[b],
+ * exactly what num_blocks calls of qsx_select_cmp produce.  The operator decides how many blocks a work order covers
+ * (RelationalOperator::getAllWorkOrders, relational_operators/RelationalOperator.hpp:117-119; SelectOperator.cpp:83-150
+ * makes one SelectWorkOrder per block): at the reference's 2-4 MB blocks a launch per block is launch-bound on this
+ * device, a run of blocks is not (DESIGN.md "Work-order granularity").
+ *   block_rows         host array: rows of each block (>= 0)
+ *   block_cols         host array of device pointers: each block's stripe of the attribute
+ *   block_filters      NULL, or host array of device pointers (an entry may be NULL): existing TupleIdSequences
+ *   block_out_bitmaps  host array of device pointers: (block_rows[b]+63)/64 words each, fully overwritten
+ *   out_counts_dev     optional device array of num_blocks int64: popcount of every block's bitmap (overwritten)
+ * The host arrays are consumed before the call returns. */
+int qsx_select_cmp_blocks(int type, int64_t num_blocks, const int64_t *block_rows, const void *const *block_cols, int op,
+                          const void *literal, const uint64_t *const *block_filters, uint64_t *const *block_out_bitmaps,
+                          int64_t *out_counts_dev, qsx_stream_t stream);
+
 /* K1 on a CHAR(width) attribute: out_bitmap[i] = (col[i] OP literal) [AND filter[i]] with the reference's string
  * comparison — both sides are C strings that end at their first NUL byte or at their maximum length, compared byte
  * by byte as unsigned chars, a proper prefix being smaller (AsciiStringUncheckedComparator::strcmpHelper,
@@ -217,6 +233,21 @@ int qsx_compact_gather(int ncols, const void *const *cols, const int32_t *widths
                        const uint64_t *bitmap_dev, int64_t n, void *const *out_cols,
                        int64_t *out_count_dev, void *workspace_dev, size_t workspace_bytes,
                        qsx_stream_t stream);
+
+/* K2 over a run of blocks in one launch: the rows selected by block_bitmaps[b] in every block b, block after block
+ * and in row order, land in ONE output stripe per column — the way consecutive SelectWorkOrders fill the blocks of an
+ * InsertDestination (relational_operators/SelectOperator.cpp:161-195, storage/InsertDestination.cpp:222-260).
+ *   block_cols       host array [b * ncols + c] of device pointers: block b's stripe of column c
+ *   block_bitmaps    host array of device pointers: (block_rows[b]+63)/64 words each
+ *   block_base_tids  host array or NULL (run-global row numbers); only used for out_tids_dev
+ *   out_tids_dev     optional: the tuple id (base + row) of every output row
+ *   out_count_dev    int64 on device: rows written
+ * workspace: qsx_compact_blocks_workspace_bytes(num_blocks, block_rows).  Host arrays are consumed before return. */
+size_t qsx_compact_blocks_workspace_bytes(int64_t num_blocks, const int64_t *block_rows);
+int qsx_compact_gather_blocks(int ncols, const int32_t *widths, int64_t num_blocks, const int64_t *block_rows,
+                              const void *const *block_cols, const uint64_t *const *block_bitmaps,
+                              const int32_t *block_base_tids, void *const *out_cols, int32_t *out_tids_dev,
+                              int64_t *out_count_dev, void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
 
 /* TupleIdSequence -> ascending tuple-id list (base_tid + position). */
 int qsx_bitmap_to_tids(const uint64_t *bitmap_dev, int64_t n, int32_t base_tid,
@@ -359,6 +390,19 @@ int qsx_join_probe_count(qsx_join_table_t *table, const void *keys_dev, int64_t 
                          const uint64_t *filter_dev, int64_t *out_count_dev,
                          qsx_stream_t stream);
 
+/* K4 over a run of probe blocks in one launch: the pairs of num_blocks calls of qsx_join_probe (block b probed with
+ * probe_base_tid = block_base_tids[b]) in one pair list with one counter.  HashJoinOperator makes one probe work order per
+ * probe block (relational_operators/HashJoinOperator.cpp:203-260); how many blocks a work order covers is the operator's
+ * decision (RelationalOperator.hpp:117-119) and a launch per 2-4 MB block is launch-bound on this device.
+ *   block_rows / block_keys   host arrays: rows and key stripe (device pointer) of each block
+ *   block_base_tids  host array, or NULL: block b's rows are then numbered from the rows of the blocks before it
+ *                    (run-global row numbers — what qsx_gather_segmented takes); base + rows must fit int32
+ *   block_filters    NULL, or host array of device pointers (entries may be NULL)
+ * Other arguments and the capacity / count contract as qsx_join_probe.  The host arrays are consumed before return. */
+int qsx_join_probe_blocks(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                          const int32_t *block_base_tids, const uint64_t *const *block_filters, int32_t *out_probe_tid_dev,
+                          int32_t *out_build_tid_dev, int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream);
+
 /* Existence probe for semi / anti joins: out_bitmap bit i = filter[i] AND
  * (key i found) when anti == 0, filter[i] AND NOT found when anti != 0.
  * Replaces HashTable::runOverKeysFromValueAccessorIfMatch[Not]Found
@@ -368,6 +412,14 @@ int qsx_join_probe_exists(qsx_join_table_t *table, const void *keys_dev, int64_t
                           const uint64_t *filter_dev, int anti,
                           uint64_t *out_bitmap_dev, int64_t *out_count_dev,
                           qsx_stream_t stream);
+
+/* qsx_join_probe_exists over a run of probe blocks in one launch: block b's bitmap goes to block_out_bitmaps[b]
+ * ((block_rows[b]+63)/64 words, fully overwritten); out_count_dev (optional) receives the number of set bits of the
+ * whole run.  (One HashSemiJoinWorkOrder / HashAntiJoinWorkOrder per probe block in the reference,
+ * relational_operators/HashJoinOperator.cpp:262-330.) */
+int qsx_join_probe_exists_blocks(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows,
+                                 const void *const *block_keys, const uint64_t *const *block_filters, int anti,
+                                 uint64_t *const *block_out_bitmaps, int64_t *out_count_dev, qsx_stream_t stream);
 
 /* ======================================================================
  * Aggregation

@@ -67,6 +67,9 @@ _SIGNATURES = {
     "qsx_bitmap_combine": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_bitmap_count": (_int, [_vp, _i64, _vp, _vp]),
     "qsx_compact_workspace_bytes": (_sz, [_i64]),
+    "qsx_compact_blocks_workspace_bytes": (_sz, [_i64, C.POINTER(_i64)]),
+    "qsx_compact_gather_blocks": (_int, [_int, C.POINTER(_i32), _i64, C.POINTER(_i64), _pp, _pp, C.POINTER(_i32), _pp, _vp, _vp, _vp,
+                                         _sz, _vp]),
     "qsx_compact_gather": (_int, [_int, _pp, C.POINTER(_i32), _vp, _i64, _pp, _vp, _vp, _sz, _vp]),
     "qsx_bitmap_to_tids": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     "qsx_tids_to_bitmap": (_int, [_vp, _i64, _i32, _i64, _vp, _vp]),
@@ -85,11 +88,14 @@ _SIGNATURES = {
     "qsx_join_table_size": (_int, [_vp, C.POINTER(_i64), _vp]),
     "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_join_probe_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_join_probe_exists_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _int, _pp, _vp, _vp]),
     "qsx_join_probe_count": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "qsx_join_probe_exists": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
     "qsx_eval_expression": (_int, [_int, _pp, C.POINTER(_i32), _int, C.POINTER(T.ExprInstr), C.POINTER(C.c_double), T.Operand, _i64, _vp, _vp]),
     "qsx_agg_state_create": (_int, [C.POINTER(T.AggConfig), _pp]),
     "qsx_agg_state_destroy": (_int, [_vp]),
+    "qsx_select_cmp_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, _int, _vp, _pp, _pp, _vp, _vp]),
     "qsx_agg_state_clear": (_int, [_vp, _vp]),
     "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
     "qsx_agg_update_blocks": (_int, [_vp, _int, C.POINTER(_i64), _pp, _pp, _vp]),
@@ -184,6 +190,25 @@ def select_cmp(col, op, literal, filter_bitmap=None, out_bitmap=None, out_count=
     _check(_lib.qsx_select_cmp(qt, _ptr(col), n, op, C.byref(lit), _ptr(filter_bitmap), _ptr(out_bitmap),
                                _ptr(out_count), _stream(stream)), "qsx_select_cmp")
     return out_bitmap, out_count
+
+
+def select_cmp_blocks(cols, op, literal, filters=None, stream=None, qtype=None, out_bitmaps=None):
+    """K1 over a run of blocks in one launch: cols = one stripe per block; returns (list of per-block bitmaps, counts int64[nb])."""
+    nb = len(cols)
+    qt = qsx_type_of(cols[0]) if qtype is None else qtype
+    lit = _literal(qt, literal)
+    dev = cols[0].device
+    outs = out_bitmaps if out_bitmaps is not None else [new_bitmap(c.numel(), dev) for c in cols]
+    counts = torch.zeros(max(nb, 1), dtype=torch.int64, device=dev)
+    rows = (C.c_int64 * max(nb, 1))(*[c.numel() for c in cols])
+    cptr = (C.c_void_p * max(nb, 1))(*[c.data_ptr() if c.numel() else None for c in cols])
+    optr = (C.c_void_p * max(nb, 1))(*[o.data_ptr() if o.numel() else None for o in outs])
+    fptr = None
+    if filters is not None:
+        fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+    _check(_lib.qsx_select_cmp_blocks(qt, nb, rows, cptr, op, C.byref(lit), fptr, optr, _ptr(counts), _stream(stream)),
+           "qsx_select_cmp_blocks")
+    return outs, counts[:nb]
 
 
 def select_cmp_char(col, op, literal, filter_bitmap=None, stream=None):
@@ -286,6 +311,33 @@ def compact_gather(cols, bitmap, n, out_cols=None, stream=None):
     _check(_lib.qsx_compact_gather(len(cols), _ptr_array(cols), widths, _ptr(bitmap), n, _ptr_array(out_cols),
                                    _ptr(count), _ptr(ws), ws_bytes, _stream(stream)), "qsx_compact_gather")
     return out_cols, count
+
+
+def compact_gather_blocks(blocks, bitmaps, base_tids=None, want_tids=False, stream=None):
+    """K2 over a run of blocks in one launch: blocks = per-block column lists, bitmaps = per-block TupleIdSequences.  Returns
+    (output columns sized for all rows of the run, tids int32 or None, count int64[1]); the selected rows of block 0 come
+    first, then block 1's, ... in row order."""
+    nb = len(blocks)
+    ncols = len(blocks[0]) if nb else 0
+    device = bitmaps[0].device if nb else torch.device("cuda:0")
+    total = sum(b[0].numel() if ncols else 0 for b in blocks) if ncols else 0
+    rows_list = [b[0].numel() for b in blocks] if ncols else [0] * nb
+    out_cols = [torch.empty(max(total, 1), dtype=blocks[0][c].dtype, device=device) for c in range(ncols)]
+    widths = (C.c_int32 * max(ncols, 1))(*[blocks[0][c].element_size() for c in range(ncols)])
+    rows = (C.c_int64 * max(nb, 1))(*rows_list)
+    cptr = (C.c_void_p * max(nb * ncols, 1))()
+    for i, b in enumerate(blocks):
+        for c in range(ncols):
+            cptr[i * ncols + c] = b[c].data_ptr() if b[c].numel() else None
+    bptr = (C.c_void_p * max(nb, 1))(*[m.data_ptr() if m is not None and m.numel() else None for m in bitmaps])
+    tptr = None if base_tids is None else (C.c_int32 * max(nb, 1))(*base_tids)
+    tids = torch.empty(max(total, 1), dtype=torch.int32, device=device) if want_tids else None
+    ws_bytes = _lib.qsx_compact_blocks_workspace_bytes(nb, rows)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    count = torch.zeros(1, dtype=torch.int64, device=device)
+    _check(_lib.qsx_compact_gather_blocks(ncols, widths, nb, rows, cptr, bptr, tptr, _ptr_array(out_cols), _ptr(tids), _ptr(count),
+                                          _ptr(ws), ws_bytes, _stream(stream)), "qsx_compact_gather_blocks")
+    return out_cols, tids, count
 
 
 def bitmap_to_tids(bitmap, n, base_tid=0, stream=None):
@@ -464,6 +516,46 @@ class JoinTable:
         _check(_lib.qsx_join_probe_exists(self._h, _ptr(keys), n, _ptr(filter_bitmap), 1 if anti else 0, _ptr(out),
                                           _ptr(count), _stream(stream)), "qsx_join_probe_exists")
         return out, count
+
+    def probe_blocks(self, key_blocks, capacity=None, base_tids=None, filters=None, out=None, stream=None):
+        """K4 over a run of probe blocks in one launch: key_blocks = one key stripe per block.  Probe tids are
+        base_tids[b] + row, or run-global row numbers when base_tids is None."""
+        nb = len(key_blocks)
+        dev = key_blocks[0].device if nb else torch.device("cuda:0")
+        total = sum(k.numel() for k in key_blocks)
+        if out is None:
+            capacity = total if capacity is None else capacity
+            out_p = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+            out_b = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+            count = torch.zeros(1, dtype=torch.int64, device=dev)
+        else:
+            out_p, out_b, count = out
+            capacity = out_p.numel() if capacity is None else capacity
+        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
+        bptr = None if base_tids is None else (C.c_int32 * max(nb, 1))(*base_tids)
+        fptr = None
+        if filters is not None:
+            fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        _check(_lib.qsx_join_probe_blocks(self._h, nb, rows, kptr, bptr, fptr, _ptr(out_p), _ptr(out_b), capacity, _ptr(count),
+                                          _stream(stream)), "qsx_join_probe_blocks")
+        return out_p, out_b, count
+
+    def probe_exists_blocks(self, key_blocks, anti=False, filters=None, out_bitmaps=None, stream=None):
+        """Semi / anti probe over a run of blocks: returns (per-block bitmaps, total count int64[1])."""
+        nb = len(key_blocks)
+        dev = key_blocks[0].device if nb else torch.device("cuda:0")
+        outs = out_bitmaps if out_bitmaps is not None else [new_bitmap(k.numel(), dev) for k in key_blocks]
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
+        optr = (C.c_void_p * max(nb, 1))(*[o.data_ptr() if o.numel() else None for o in outs])
+        fptr = None
+        if filters is not None:
+            fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        _check(_lib.qsx_join_probe_exists_blocks(self._h, nb, rows, kptr, fptr, 1 if anti else 0, optr, _ptr(count),
+                                                 _stream(stream)), "qsx_join_probe_exists_blocks")
+        return outs, count
 
 
 # --------------------------------------------------------------------------- aggregation

@@ -28,6 +28,7 @@
 #include "scan.hpp"
 
 #include <cstdlib>
+#include <vector>
 #include <mutex>
 #include <shared_mutex>
 
@@ -228,14 +229,16 @@ __device__ __forceinline__ void emit_match(const PairSink &sink, bool match, int
   }
 }
 
-template <typename Units, int MODE>
+// kRuns: the probe side is a run of blocks, as in dense_probe_kernel (join_dense.hpp).
+template <typename Units, int MODE, bool kRuns = false>
 __global__ __launch_bounds__(kJBlock) void probe_kernel(
     TableView t, const typename Units::Key *__restrict__ keys, int64_t n, int32_t probe_base_tid,
     const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe,
     int32_t *__restrict__ out_build, int64_t capacity, unsigned long long *__restrict__ out_count,
-    uint64_t *__restrict__ out_bitmap, int anti) {
+    uint64_t *__restrict__ out_bitmap, int anti, const long long *__restrict__ runs = nullptr) {
   using Key = typename Units::Key;
   using Raw = typename Units::Raw;
+  using Source = ProbeTileSource<Key>;
   __shared__ int32_t s_probe[MODE == 0 ? kStage : 1];
   __shared__ int32_t s_build[MODE == 0 ? kStage : 1];
   __shared__ int s_fill;
@@ -243,7 +246,10 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
   const Units table(t);
   PairSink sink{s_probe, s_build, &s_fill, out_probe, out_build,
                 static_cast<unsigned long long>(capacity), out_count};
-  const int64_t num_tiles = (n + kProbeTile - 1) / kProbeTile;
+  const int64_t num_tiles = kRuns ? runs[2] : (n + kProbeTile - 1) / kProbeTile;
+  auto source_of = [&](int64_t tile) {
+    return probe_tile_source<Key, kProbeTile, kRuns>(runs, tile, keys, n, probe_base_tid, filter, out_bitmap);
+  };
   unsigned long long local_count = 0;
 
   // Row r of a thread in a tile: tile_base + r * 256 + tid.  A wave therefore owns 64 consecutive rows per r:
@@ -251,38 +257,47 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
   // (one load, lane r holds word r) of the NEXT tile are requested before the table units of the current one are read.
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
-  const int64_t num_filter_words = (n + 63) >> 6;
   Key key[kRowsPerThread], next_key[kRowsPerThread];
   uint64_t filter_words = ~0ull, next_filter_words = ~0ull;
-  auto request = [&](int64_t tile, Key (&k)[kRowsPerThread], uint64_t &words) {
-    const int64_t base = tile * kProbeTile;
+  auto request = [&](const Source &src, Key (&k)[kRowsPerThread], uint64_t &words) {
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
-      const int64_t row = base + r * kJBlock + threadIdx.x;
-      k[r] = keys[row < n ? row : n - 1];   // clamped, not guarded: no branch around the read
+      const int64_t row = src.base + r * kJBlock + threadIdx.x;
+      k[r] = src.keys[row < src.n ? row : src.n - 1];   // clamped, not guarded: no branch around the read
     }
     words = ~0ull;
-    if (filter != nullptr && lane < kRowsPerThread) {
-      const int64_t w = (base >> 6) + lane * (kJBlock / kWave) + wave;
-      if (w < num_filter_words) words = filter[w];
+    if (src.filter != nullptr && lane < kRowsPerThread) {
+      const int64_t w = (src.base >> 6) + lane * (kJBlock / kWave) + wave;
+      if (w < ((src.n + 63) >> 6)) words = src.filter[w];
     }
   };
-  if (static_cast<int64_t>(blockIdx.x) < num_tiles) request(blockIdx.x, key, filter_words);
+  Source cur = Source(), next = Source();
+  if (static_cast<int64_t>(blockIdx.x) < num_tiles) {
+    cur = source_of(blockIdx.x);
+    request(cur, key, filter_words);
+  }
 
   for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     if (MODE == 0) {
       if (threadIdx.x == 0) s_fill = 0;
       __syncthreads();
     }
-    const int64_t tile_base = tile * kProbeTile;
-    if (tile + gridDim.x < num_tiles) request(tile + gridDim.x, next_key, next_filter_words);
+    if (tile + gridDim.x < num_tiles) {
+      next = source_of(tile + gridDim.x);
+      request(next, next_key, next_filter_words);
+    }
+    const int64_t tile_base = cur.base;
+    const int64_t n_rows = cur.n;
+    const int32_t base_tid = cur.base_tid;
+    uint64_t *const tile_bitmap = cur.out_bitmap;
+    cur = next;
     bool live[kRowsPerThread];
     uint64_t exists_word = 0;
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
       const int64_t row = tile_base + r * kJBlock + threadIdx.x;
       const uint64_t filter_word = __shfl(filter_words, r, kWave);   // before the branch: every lane takes part
-      live[r] = row < n && msb_bit(filter_word, lane);
+      live[r] = row < n_rows && msb_bit(filter_word, lane);
     }
     // First unit of every row: kRowsPerThread independent 16-byte loads in flight.
     uint64_t unit[kRowsPerThread];
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
       const int64_t row = tile_base + r * kJBlock + threadIdx.x;
-      const int32_t probe_tid = static_cast<int32_t>(probe_base_tid + row);
+      const int32_t probe_tid = static_cast<int32_t>(base_tid + row);
       bool walking = live[r];
       Raw u = first[r];
       uint64_t cur = unit[r];
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
     }
     if (MODE == 2) {   // lane r holds the word of step r: one store instruction per tile and wave
       const int64_t w = (tile_base >> 6) + lane * (kJBlock / kWave) + wave;
-      if (lane < kRowsPerThread && w < num_filter_words) out_bitmap[w] = exists_word;
+      if (lane < kRowsPerThread && w < ((n_rows + 63) >> 6)) tile_bitmap[w] = exists_word;
     }
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) key[r] = next_key[r];
@@ -780,16 +795,20 @@ static bool dense_sliced(uint64_t range, int64_t n, int mode) {
   return mode == 1 && range * 4 >= (12ull << 20) && range * 4 <= (128ull << 20) && n >= (4 << 20);
 }
 
-template <int MODE>
+// kRuns: the probe side is a run of blocks — runs_dev is its table (block_runs.hpp, tiles of 4096 rows), run_tiles its tile
+// count, n the rows of all blocks together and `filter` non-NULL when any block has one; keys / probe_base_tid /
+// out_bitmap come from the table.
+template <int MODE, bool kRuns = false>
 static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_t probe_base_tid,
                         const uint64_t *filter, int32_t *out_probe, int32_t *out_build,
                         int64_t capacity, int64_t *out_count, uint64_t *out_bitmap, int anti,
-                        hipStream_t stream) {
+                        hipStream_t stream, const long long *runs_dev = nullptr, int64_t run_tiles = 0) {
+  static_assert(kDenseTile == kProbeTile, "one run table serves both table kinds");
   if (out_count != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), stream));
   if (n == 0) return QSX_OK;
   std::shared_lock<std::shared_mutex> lock(t->mutex);
   if (t->dense) {
-    const int64_t tiles = (n + kDenseTile - 1) / kDenseTile;
+    const int64_t tiles = kRuns ? run_tiles : (n + kDenseTile - 1) / kDenseTile;
     const int64_t limit = 8 * kCUs;  // no LDS: 8 workgroups (32 waves) per CU
     const int dgrid = static_cast<int>(tiles < limit ? tiles : limit);
     unsigned long long *dcount = reinterpret_cast<unsigned long long *>(out_count);
@@ -802,24 +821,24 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
       QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&unit_offsets), static_cast<size_t>(units + 1) * 8, stream));
       QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&scan_ws), scan_workspace_words(units) * 8, stream));
       if (t->key_type == QSX_INT) {
-        hipLaunchKernelGGL((dense_probe_kernel<int32_t, 3>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+        hipLaunchKernelGGL((dense_probe_kernel<int32_t, 3, kRuns>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
                            static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
-                           dcount, out_bitmap, anti, unit_counts, unit_offsets);
+                           dcount, out_bitmap, anti, unit_counts, unit_offsets, runs_dev);
       } else {
-        hipLaunchKernelGGL((dense_probe_kernel<int64_t, 3>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+        hipLaunchKernelGGL((dense_probe_kernel<int64_t, 3, kRuns>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
                            static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
-                           dcount, out_bitmap, anti, unit_counts, unit_offsets);
+                           dcount, out_bitmap, anti, unit_counts, unit_offsets, runs_dev);
       }
       QSX_CHECK_LAUNCH();
       QSX_HIP_TRY(launch_scan(unit_counts, units, unit_offsets, out_count, scan_ws, stream));
       if (t->key_type == QSX_INT) {
-        hipLaunchKernelGGL((dense_probe_kernel<int32_t, 4>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+        hipLaunchKernelGGL((dense_probe_kernel<int32_t, 4, kRuns>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
                            static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
-                           dcount, out_bitmap, anti, unit_counts, unit_offsets);
+                           dcount, out_bitmap, anti, unit_counts, unit_offsets, runs_dev);
       } else {
-        hipLaunchKernelGGL((dense_probe_kernel<int64_t, 4>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+        hipLaunchKernelGGL((dense_probe_kernel<int64_t, 4, kRuns>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
                            static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
-                           dcount, out_bitmap, anti, unit_counts, unit_offsets);
+                           dcount, out_bitmap, anti, unit_counts, unit_offsets, runs_dev);
       }
       QSX_CHECK_LAUNCH();
       QSX_HIP_TRY(hipFreeAsync(unit_counts, stream));
@@ -827,7 +846,7 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
       QSX_HIP_TRY(hipFreeAsync(scan_ws, stream));
       return QSX_OK;
     }
-    if constexpr (MODE == 0 || MODE == 1) {
+    if constexpr (!kRuns && (MODE == 0 || MODE == 1)) {
       if (dense_sliced(t->dense_view().range, n, MODE) && dcount != nullptr) {
         // head[] does not fit an XCD's L2: every XCD looks up one key range of it (join_dense.hpp)
         const int64_t limit_s = (MODE == 0 ? 5 : 8) * kCUs;   // MODE 0 stages pairs in 32 KiB of LDS
@@ -846,38 +865,66 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
       }
     }
     if (t->key_type == QSX_INT) {
-      hipLaunchKernelGGL((dense_probe_kernel<int32_t, MODE>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+      hipLaunchKernelGGL((dense_probe_kernel<int32_t, MODE, kRuns>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
                          static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
-                         dcount, out_bitmap, anti);
+                         dcount, out_bitmap, anti, nullptr, nullptr, runs_dev);
     } else {
-      hipLaunchKernelGGL((dense_probe_kernel<int64_t, MODE>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
+      hipLaunchKernelGGL((dense_probe_kernel<int64_t, MODE, kRuns>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
                          static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
-                         dcount, out_bitmap, anti);
+                         dcount, out_bitmap, anti, nullptr, nullptr, runs_dev);
     }
     QSX_CHECK_LAUNCH();
     return QSX_OK;
   }
-  if (MODE != 2 && t->key_type == QSX_INT && radix_enabled() && t->reserved >= kRadixMinBuildRows &&
+  if (!kRuns && MODE != 2 && t->key_type == QSX_INT && radix_enabled() && t->reserved >= kRadixMinBuildRows &&
       n >= kRadixMinProbeRows) {
     return launch_probe_radix<MODE>(t, static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build,
                                     capacity, reinterpret_cast<unsigned long long *>(out_count), stream);
   }
-  const int64_t num_tiles = (n + kProbeTile - 1) / kProbeTile;
+  const int64_t num_tiles = kRuns ? run_tiles : (n + kProbeTile - 1) / kProbeTile;
   // 4 workgroups per CU keep 128 KiB of the 160 KiB LDS busy in pair mode.
   const int64_t max_grid = MODE == 0 ? 4 * kCUs : 8 * kCUs;
   const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
   unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count);
   if (t->key_type == QSX_INT) {
-    hipLaunchKernelGGL((probe_kernel<IntUnits, MODE>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
+    hipLaunchKernelGGL((probe_kernel<IntUnits, MODE, kRuns>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
                        static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,
-                       out_build, capacity, count, out_bitmap, anti);
+                       out_build, capacity, count, out_bitmap, anti, runs_dev);
   } else {
-    hipLaunchKernelGGL((probe_kernel<LongUnits, MODE>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
+    hipLaunchKernelGGL((probe_kernel<LongUnits, MODE, kRuns>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
                        static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe,
-                       out_build, capacity, count, out_bitmap, anti);
+                       out_build, capacity, count, out_bitmap, anti, runs_dev);
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;
+}
+
+// The table of a run of probe blocks on the device (staged_upload: stream-ordered, pinned); *rows_total = rows of the run,
+// *any_filter = some block has a filter.  Tuple ids: block_base_tids[b] + row, or run-global row numbers when it is NULL.
+static int upload_probe_run(int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                            const int32_t *block_base_tids, const uint64_t *const *block_filters, uint64_t *const *block_out,
+                            hipStream_t stream, const long long **runs_dev, int64_t *tiles, int64_t *rows_total, bool *any_filter) {
+  std::vector<int64_t> base(static_cast<size_t>(num_blocks));
+  int64_t total = 0;
+  *any_filter = false;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0 || (block_rows[b] > 0 && block_keys[b] == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+    if (block_rows[b] > 0 && block_out != nullptr && block_out[b] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    base[b] = block_base_tids != nullptr ? block_base_tids[b] : total;
+    if (base[b] < 0 || base[b] + block_rows[b] > INT32_MAX) return QSX_ERR_INVALID_ARGUMENT;
+    total += block_rows[b];
+    if (block_filters != nullptr && block_filters[b] != nullptr) *any_filter = true;
+  }
+  std::vector<long long> table;
+  *tiles = build_run_table(kDenseTile, num_blocks, block_rows, block_keys, reinterpret_cast<const void *const *>(block_filters),
+                           reinterpret_cast<void *const *>(block_out), base.data(), &table);
+  *rows_total = total;
+  if (*tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (*tiles == 0) return QSX_OK;
+  const size_t bytes = table.size() * sizeof(long long);
+  *runs_dev = static_cast<const long long *>(staged_device_buffer(stream, bytes));
+  if (*runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  return staged_upload(stream, table.data(), bytes);
 }
 
 extern "C" {
@@ -914,6 +961,45 @@ int qsx_join_probe_exists(qsx_join_table_t *t, const void *keys_dev, int64_t n,
   }
   return launch_probe<2>(t, keys_dev, n, 0, filter_dev, nullptr, nullptr, 0, out_count_dev,
                          out_bitmap_dev, anti, as_stream(stream));
+}
+
+int qsx_join_probe_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                          const int32_t *block_base_tids, const uint64_t *const *block_filters, int32_t *out_probe_tid_dev,
+                          int32_t *out_build_tid_dev, int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || num_blocks < 0 || capacity < 0 || out_count_dev == nullptr ||
+      (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr)) ||
+      (capacity > 0 && (out_probe_tid_dev == nullptr || out_build_tid_dev == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  const long long *runs_dev = nullptr;
+  int64_t tiles = 0, rows = 0;
+  bool any_filter = false;
+  const int rc = upload_probe_run(num_blocks, block_rows, block_keys, block_base_tids, block_filters, nullptr, s, &runs_dev, &tiles,
+                                  &rows, &any_filter);
+  if (rc != QSX_OK) return rc;
+  const uint64_t *filter_mark = any_filter ? reinterpret_cast<const uint64_t *>(runs_dev) : nullptr;   // only tested against NULL
+  return launch_probe<0, true>(t, nullptr, rows, 0, filter_mark, out_probe_tid_dev, out_build_tid_dev, capacity, out_count_dev,
+                               nullptr, 0, s, runs_dev, tiles);
+}
+
+int qsx_join_probe_exists_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                 const uint64_t *const *block_filters, int anti, uint64_t *const *block_out_bitmaps,
+                                 int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || num_blocks < 0 ||
+      (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr || block_out_bitmaps == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  const long long *runs_dev = nullptr;
+  int64_t tiles = 0, rows = 0;
+  bool any_filter = false;
+  const int rc = upload_probe_run(num_blocks, block_rows, block_keys, nullptr, block_filters, block_out_bitmaps, s, &runs_dev,
+                                  &tiles, &rows, &any_filter);
+  if (rc != QSX_OK) return rc;
+  return launch_probe<2, true>(t, nullptr, rows, 0, nullptr, nullptr, nullptr, 0, out_count_dev, nullptr, anti, s, runs_dev, tiles);
 }
 
 }  // extern "C"

@@ -25,6 +25,7 @@
 #ifndef QSX_CSRC_JOIN_DENSE_HPP_
 #define QSX_CSRC_JOIN_DENSE_HPP_
 
+#include "block_runs.hpp"
 #include "common.hpp"
 
 namespace qsx {
@@ -149,15 +150,44 @@ __device__ __forceinline__ void dense_emit_direct(bool match, int32_t probe_tid,
 // the counts into offsets, 4 writes every unit's pairs at its offset.  No atomics on the output counter (which takes
 // ~12 ns each: with sparse matches over clustered keys the one-pass form is bound by them, 146 K tiles = 1.7 ms for
 // 600 M rows) and the pairs come out in probe-row order.
-template <typename KeyT, int MODE>
+//
+// kRuns: the probe side is a run of blocks (qsx_join_probe_blocks, block_runs.hpp) — `runs` is the table, a tile belongs to
+// one block and takes that block's key stripe, row count, filter, base tuple id and (MODE 2) output bitmap; the output
+// pair list and its counter are the run's.
+template <typename KeyT>
+struct ProbeTileSource {
+  const KeyT *keys;
+  int64_t n;                 // rows of the block
+  int64_t base;              // first row of the tile within the block
+  int32_t base_tid;
+  const uint64_t *filter;
+  uint64_t *out_bitmap;
+};
+template <typename KeyT, int kTileRows, bool kRuns>
+__device__ __forceinline__ ProbeTileSource<KeyT> probe_tile_source(const long long *__restrict__ runs, int64_t tile,
+                                                                   const KeyT *keys, int64_t n, int32_t base_tid,
+                                                                   const uint64_t *filter, uint64_t *out_bitmap) {
+  if (!kRuns) return ProbeTileSource<KeyT>{keys, n, tile * kTileRows, base_tid, filter, out_bitmap};
+  const RunTile at = run_locate(runs, static_cast<int>(tile));
+  return ProbeTileSource<KeyT>{run_in<KeyT>(runs, at.block), run_rows(runs, at.block),
+                               static_cast<int64_t>(at.tile_in_block) * kTileRows, static_cast<int32_t>(run_base(runs, at.block)),
+                               run_filter(runs, at.block), run_out<uint64_t>(runs, at.block)};
+}
+
+template <typename KeyT, int MODE, bool kRuns = false>
 __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
     DenseTableView t, const KeyT *__restrict__ keys, int64_t n, int32_t probe_base_tid,
     const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build,
     int64_t capacity_signed, unsigned long long *__restrict__ out_count, uint64_t *__restrict__ out_bitmap, int anti,
-    int32_t *__restrict__ unit_counts = nullptr, const int64_t *__restrict__ unit_offsets = nullptr) {
+    int32_t *__restrict__ unit_counts = nullptr, const int64_t *__restrict__ unit_offsets = nullptr,
+    const long long *__restrict__ runs = nullptr) {
   constexpr int R = kDenseRowsPerThread;
+  using Source = ProbeTileSource<KeyT>;
   const unsigned long long capacity = static_cast<unsigned long long>(capacity_signed);
-  const int64_t num_tiles = (n + kDenseTile - 1) / kDenseTile;
+  const int64_t num_tiles = kRuns ? runs[2] : (n + kDenseTile - 1) / kDenseTile;
+  auto source_of = [&](int64_t tile) {
+    return probe_tile_source<KeyT, kDenseTile, kRuns>(runs, tile, keys, n, probe_base_tid, filter, out_bitmap);
+  };
   unsigned long long local_count = 0;
   __shared__ int2 s_sparse[(MODE == 0 || MODE == 4) ? kDBlock / kWave : 1][(MODE == 0 || MODE == 4) ? kDenseSparsePairs : 1];
   __shared__ int s_wave_total[2][kDBlock / kWave];
@@ -169,27 +199,36 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
   // one memory round trip per tile instead of filter -> keys -> head.  The 16 filter words a wave needs for a tile
   // (rows r * 256 + wave * 64 ..) come with one load, lane r holding word r.
   const int lane = lane_id();
-  const int64_t num_filter_words = (n + 63) >> 6;
   KeyT key[R], next_key[R];
   uint64_t filter_words = ~0ull, next_filter_words = ~0ull;
-  auto request = [&](int64_t tile, KeyT (&k)[R], uint64_t &words) {
-    const int64_t base = tile * kDenseTile;
+  auto request = [&](const Source &src, KeyT (&k)[R], uint64_t &words) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t row = base + r * kDBlock + threadIdx.x;
-      k[r] = __builtin_nontemporal_load(&keys[row < n ? row : n - 1]);   // clamped, not guarded
+      const int64_t row = src.base + r * kDBlock + threadIdx.x;
+      k[r] = __builtin_nontemporal_load(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded
     }
     words = ~0ull;
-    if (filter != nullptr && lane < R) {
-      const int64_t w = (base >> 6) + lane * (kDBlock / kWave) + wave;
-      if (w < num_filter_words) words = filter[w];
+    if (src.filter != nullptr && lane < R) {
+      const int64_t w = (src.base >> 6) + lane * (kDBlock / kWave) + wave;
+      if (w < ((src.n + 63) >> 6)) words = src.filter[w];
     }
   };
-  if (static_cast<int64_t>(blockIdx.x) < num_tiles) request(blockIdx.x, key, filter_words);
+  Source cur = Source(), next = Source();
+  if (static_cast<int64_t>(blockIdx.x) < num_tiles) {
+    cur = source_of(blockIdx.x);
+    request(cur, key, filter_words);
+  }
 
   for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, parity ^= 1) {
-    const int64_t tile_base = tile * kDenseTile;
-    if (tile + gridDim.x < num_tiles) request(tile + gridDim.x, next_key, next_filter_words);
+    if (tile + gridDim.x < num_tiles) {
+      next = source_of(tile + gridDim.x);
+      request(next, next_key, next_filter_words);
+    }
+    const int64_t tile_base = cur.base;
+    const int64_t n_rows = cur.n;
+    const int32_t base_tid = cur.base_tid;
+    uint64_t *const tile_bitmap = cur.out_bitmap;
+    cur = next;
     // Row r of this thread: tile_base + r * 256 + tid; a wave owns 64 consecutive rows per r (the workgroup reads 1 KiB
     // contiguous per step: the wave-contiguous mapping measured 8 % slower).
     uint32_t h[R];
@@ -198,7 +237,7 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
     for (int r = 0; r < R; ++r) {  // R independent 4-byte reads in flight per lane
       const int64_t row = tile_base + r * kDBlock + threadIdx.x;
       const uint64_t filter_word = __shfl(filter_words, r, kWave);   // before the branch: every lane must take part
-      const bool live = row < n && msb_bit(filter_word, lane);
+      const bool live = row < n_rows && msb_bit(filter_word, lane);
       live_mask |= live ? (1u << r) : 0u;
       const uint64_t idx = dense_index(t, key[r]);
       // unconditional read (dead lanes read word 0): a guarded read compiles to branch + load + wait per step, which
@@ -223,7 +262,7 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
       }
       // lane r holds the word of step r: one store instruction per tile and wave
       const int64_t w = (tile_base >> 6) + lane * (kDBlock / kWave) + wave;
-      if (lane < R && w < num_filter_words) out_bitmap[w] = mine;
+      if (lane < R && w < ((n_rows + 63) >> 6)) tile_bitmap[w] = mine;
       continue;
     }
 
@@ -281,13 +320,13 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
         }
         if (sparse) {
           if (m[r] != 0) {
-            if (h[r] != 0u) s_sparse[wave][staged + rank_below(m[r])] = make_int2(static_cast<int32_t>(probe_base_tid + row), static_cast<int32_t>(tid));
+            if (h[r] != 0u) s_sparse[wave][staged + rank_below(m[r])] = make_int2(static_cast<int32_t>(base_tid + row), static_cast<int32_t>(tid));
             staged += __popcll(m[r]);
           }
         } else {
           const unsigned long long o = base + rank_below(m[r]);
           if (h[r] != 0u && o < capacity) {
-            __builtin_nontemporal_store(static_cast<int32_t>(probe_base_tid + row), &out_probe[o]);
+            __builtin_nontemporal_store(static_cast<int32_t>(base_tid + row), &out_probe[o]);
             __builtin_nontemporal_store(static_cast<int32_t>(tid), &out_build[o]);
           }
           base += __popcll(m[r]);
@@ -325,13 +364,13 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
           if (MODE == 1 || MODE == 3) {
             local_count += cur != 0u ? 1u : 0u;
           } else if (MODE == 0) {
-            dense_emit_direct(cur != 0u, static_cast<int32_t>(probe_base_tid + row), static_cast<int32_t>(tid), out_probe,
+            dense_emit_direct(cur != 0u, static_cast<int32_t>(base_tid + row), static_cast<int32_t>(tid), out_probe,
                               out_build, capacity, out_count);
           } else {   // the wave's run continues behind its first-level matches, in the order the counting pass saw
             const uint64_t cm = __ballot(cur != 0u);
             const unsigned long long o = base + rank_below(cm);
             if (cur != 0u && o < capacity) {
-              __builtin_nontemporal_store(static_cast<int32_t>(probe_base_tid + row), &out_probe[o]);
+              __builtin_nontemporal_store(static_cast<int32_t>(base_tid + row), &out_probe[o]);
               __builtin_nontemporal_store(static_cast<int32_t>(tid), &out_build[o]);
             }
             base += __popcll(cm);

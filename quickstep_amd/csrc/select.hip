@@ -14,7 +14,10 @@
 // v_cmp -> SGPR-pair ballot, and s_brev_b64 turns the LSB-first ballot into the
 // MSB-first word BitVector uses.  No shuffles, no LDS for K1.
 
+#include <vector>
+
 #include "common.hpp"
+#include "block_runs.hpp"
 #include "scan.hpp"
 
 namespace qsx {
@@ -214,14 +217,16 @@ __device__ __forceinline__ void copy_value(const void *src, int64_t si, void *ds
 // (at its prefix offset: the list is in row order); the wave then handles 64 selected rows per step with every lane busy
 // and contiguous stores — at 1 % selectivity the previous form (8 words per step, lanes = rows of a word) had ~1 of
 // 64 lanes working.  Reads are unconditional and batched (4 steps in flight per lane).
-__global__ __launch_bounds__(kBlock) void compact_gather_kernel(
-    GatherArgs args, const uint64_t *__restrict__ bitmap, int64_t num_words, int64_t num_tiles,
-    const int64_t *__restrict__ tile_offsets, int32_t *__restrict__ out_tids, int32_t base_tid) {
-  __shared__ uint16_t s_pos[kWavesPerBlock][kTileWords * 64];
+//
+// compact_tile is one such tile: `tile` counts within the stripe the bitmap belongs to, tile_off is where the tile's rows
+// go in the output.  block_cols (kRuns): the column addresses of the block the tile belongs to, instead of args.src.
+template <bool kRuns>
+__device__ __forceinline__ void compact_tile(const GatherArgs &args, const long long *__restrict__ block_cols,
+                                             const uint64_t *__restrict__ bitmap, int64_t num_words, int64_t tile,
+                                             int64_t tile_off, int32_t *__restrict__ out_tids, int32_t base_tid,
+                                             uint16_t *__restrict__ s_pos_wave) {
   const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; tile < num_tiles;
-       tile += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+  {
     const int64_t w = tile * kTileWords + lane;
     uint64_t my_word = w < num_words ? bitmap[w] : 0;
     const int pc = __popcll(my_word);
@@ -232,18 +237,17 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
       if (lane >= off) incl += up;
     }
     const int total = __shfl(incl, kWave - 1, kWave);
-    if (total == 0) continue;                    // wave-uniform: 4096 unselected rows
+    if (total == 0) return;                      // wave-uniform: 4096 unselected rows
     int at = incl - pc;
     while (my_word != 0) {                       // MSB-first: bit 63 is row 0 of the word
       const int row_in_word = __clzll(static_cast<long long>(my_word));
-      s_pos[wave][at++] = static_cast<uint16_t>(lane * 64 + row_in_word);
+      s_pos_wave[at++] = static_cast<uint16_t>(lane * 64 + row_in_word);
       my_word &= ~(1ull << (63 - row_in_word));
     }
     // Same-wave LDS hand-off: DS ops of one wave complete in order.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int64_t tile_off = tile_offsets[tile];
     const int64_t tile_row0 = tile * kTileWords * 64;
     constexpr int kBatch = 4;
     for (int i0 = lane; i0 < total; i0 += kWave * kBatch) {
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
       for (int b = 0; b < kBatch; ++b) {
         const int i = i0 + b * kWave;
         live[b] = i < total;
-        si[b] = tile_row0 + (live[b] ? s_pos[wave][i] : s_pos[wave][0]);   // a valid row either way
+        si[b] = tile_row0 + (live[b] ? s_pos_wave[i] : s_pos_wave[0]);   // a valid row either way
       }
       if (out_tids != nullptr) {
 #pragma unroll
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
         }
       }
       for (int c = 0; c < args.ncols; ++c) {
-        const void *src = args.src[c];
+        const void *src = kRuns ? reinterpret_cast<const void *>(block_cols[c]) : args.src[c];
         void *dst = args.dst[c];
         switch (args.width[c]) {               // wave-uniform
           case 4: {
@@ -297,6 +301,50 @@ __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
     __builtin_amdgcn_wave_barrier();             // the list is rewritten by the next tile
   }
 }
+
+__global__ __launch_bounds__(kBlock) void compact_gather_kernel(
+    GatherArgs args, const uint64_t *__restrict__ bitmap, int64_t num_words, int64_t num_tiles,
+    const int64_t *__restrict__ tile_offsets, int32_t *__restrict__ out_tids, int32_t base_tid) {
+  __shared__ uint16_t s_pos[kWavesPerBlock][kTileWords * 64];
+  const int wave = threadIdx.x >> 6;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; tile < num_tiles;
+       tile += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    compact_tile<false>(args, nullptr, bitmap, num_words, tile, tile_offsets[tile], out_tids, base_tid, s_pos[wave]);
+  }
+}
+
+// K2 over a run of blocks (qsx_compact_gather_blocks): the tiles of all blocks are counted and scanned together, so the
+// selected rows of the run land in ONE output stripe per column, block after block, in row order — the way consecutive
+// SelectWorkOrders fill an InsertDestination block.  The run table's `filter` column holds each block's bitmap; the
+// blocks' column addresses follow the table at word cols_offset ([block * ncols + column]).
+__global__ __launch_bounds__(kBlock) void tile_count_runs_kernel(const long long *__restrict__ runs, int32_t *__restrict__ tile_counts) {
+  const int lane = lane_id();
+  const int num_tiles = static_cast<int>(runs[2]);
+  for (int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+       tile < num_tiles; tile += static_cast<int>(gridDim.x) * kWavesPerBlock) {
+    const RunTile at = run_locate(runs, tile);
+    const int64_t num_words = (run_rows(runs, at.block) + 63) >> 6;
+    const int64_t w = static_cast<int64_t>(at.tile_in_block) * kTileWords + lane;
+    int c = w < num_words ? __popcll(run_filter(runs, at.block)[w]) : 0;
+    c = wave_reduce_add(c);
+    if (lane == 0) tile_counts[tile] = c;
+  }
+}
+__global__ __launch_bounds__(kBlock) void compact_gather_runs_kernel(
+    GatherArgs args, const long long *__restrict__ runs, long long cols_offset, const int64_t *__restrict__ tile_offsets,
+    int32_t *__restrict__ out_tids) {
+  __shared__ uint16_t s_pos[kWavesPerBlock][kTileWords * 64];
+  const int wave = threadIdx.x >> 6;
+  const int num_tiles = static_cast<int>(runs[2]);
+  for (int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + wave); tile < num_tiles;
+       tile += static_cast<int>(gridDim.x) * kWavesPerBlock) {
+    const RunTile at = run_locate(runs, tile);
+    compact_tile<true>(args, runs + cols_offset + static_cast<long long>(at.block) * args.ncols, run_filter(runs, at.block),
+                       (run_rows(runs, at.block) + 63) >> 6, at.tile_in_block, tile_offsets[tile], out_tids,
+                       static_cast<int32_t>(run_base(runs, at.block)), s_pos[wave]);
+  }
+}
+
 
 // ---------------------------------------------------------------------------
 // K1 on the sort column of a sorted column store: the matches of `col OP literal` are one row range (its complement for
@@ -603,86 +651,95 @@ struct LiteralPred {     // value OP literal
   __device__ __forceinline__ bool operator()(T v) const { return cmp_static<T, OP>(v, lit); }
 };
 
+// One group of R wave loads starting at load l0 of a stripe (col, n): the rows' bits go to out, the matches are added to count.
 template <typename T, typename Pred, int R>
-__global__ __launch_bounds__(kBlock) void select_packed_kernel(const T *__restrict__ col, int64_t n, Pred pred,
-                                                              const uint64_t *__restrict__ filter,
-                                                              uint64_t *__restrict__ out,
-                                                              unsigned long long *__restrict__ out_count) {
+__device__ __forceinline__ void select_packed_group(const T *__restrict__ col, int64_t n, const Pred &pred,
+                                                    const uint64_t *__restrict__ filter, uint64_t *__restrict__ out,
+                                                    int64_t l0, int lane, unsigned long long &count) {
   constexpr int K = 16 / sizeof(T);        // rows per lane per load
   constexpr int G = kWave / K;             // lanes per bitmap word
   constexpr int kRowsPerLoad = kWave * K;  // rows per wave load = K bitmap words
-  const int lane = lane_id();
-  const int64_t num_loads = (n + kRowsPerLoad - 1) / kRowsPerLoad;
   const int64_t num_words = (n + 63) >> 6;
-  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t num_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  unsigned long long count = 0;
-  for (int64_t l0 = wave * R; l0 < num_loads; l0 += num_waves * R) {
-    uint4 raw[R];
-    if (sizeof(T) <= 2 && (l0 + R) * kRowsPerLoad <= n) {
-      // code stripes (8 / 16 rows per 16-byte read): every row of the group exists (all groups but the last), so R unguarded
-      // reads and no per-row bounds test — 0.059 -> 0.043 ms per 100 M one-byte codes; for 4 / 8-byte values the same split
-      // measured slower (0.082 -> 0.094 ms), so they keep the single guarded form
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t row0 = (l0 + r) * kRowsPerLoad + static_cast<int64_t>(lane) * K;
-        raw[r] = *reinterpret_cast<const uint4 *>(col + row0);
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        T v[K];
-        *reinterpret_cast<uint4 *>(v) = raw[r];
-        unsigned long long m = 0;            // K-bit mask, first row = most significant bit
-#pragma unroll
-        for (int i = 0; i < K; ++i) m = (m << 1) | (pred(v[i]) ? 1ull : 0ull);
-#pragma unroll
-        for (int d = 1; d < G; d <<= 1) {
-          const unsigned long long other = __shfl_xor(m, d, kWave);
-          m = (m << (d * K)) | other;
-        }
-        const int64_t word = (l0 + r) * K + lane / G;
-        if ((lane % G) == 0) {
-          if (filter != nullptr) m &= filter[word];
-          out[word] = m;
-          count += __popcll(m);
-        }
-      }
-      continue;
-    }
+  uint4 raw[R];
+  if (sizeof(T) <= 2 && (l0 + R) * kRowsPerLoad <= n) {
+    // code stripes (8 / 16 rows per 16-byte read): every row of the group exists (all groups but the last), so R unguarded
+    // reads and no per-row bounds test — 0.059 -> 0.043 ms per 100 M one-byte codes; for 4 / 8-byte values the same split
+    // measured slower (0.082 -> 0.094 ms), so they keep the single guarded form
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row0 = (l0 + r) * kRowsPerLoad + static_cast<int64_t>(lane) * K;
-      raw[r] = make_uint4(0, 0, 0, 0);
-      if (row0 + K <= n) {
-        raw[r] = *reinterpret_cast<const uint4 *>(col + row0);
-      } else if (row0 < n) {               // the last, partial 16 bytes of the stripe: element by element
-        T tmp[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) tmp[i] = row0 + i < n ? col[row0 + i] : T();
-        raw[r] = *reinterpret_cast<const uint4 *>(tmp);
-      }
+      raw[r] = *reinterpret_cast<const uint4 *>(col + row0);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t row0 = (l0 + r) * kRowsPerLoad + static_cast<int64_t>(lane) * K;
       T v[K];
       *reinterpret_cast<uint4 *>(v) = raw[r];
       unsigned long long m = 0;            // K-bit mask, first row = most significant bit
 #pragma unroll
-      for (int i = 0; i < K; ++i) m = (m << 1) | ((row0 + i < n && pred(v[i])) ? 1ull : 0ull);
-      // merge the G lanes of a word: after step d the lower lane of every 2d-group holds 2d * K bits
+      for (int i = 0; i < K; ++i) m = (m << 1) | (pred(v[i]) ? 1ull : 0ull);
 #pragma unroll
       for (int d = 1; d < G; d <<= 1) {
         const unsigned long long other = __shfl_xor(m, d, kWave);
-        m = (m << (d * K)) | other;        // only meaningful in lanes whose bit d is clear; those are the ones kept
+        m = (m << (d * K)) | other;
       }
       const int64_t word = (l0 + r) * K + lane / G;
-      if ((lane % G) == 0 && word < num_words) {
+      if ((lane % G) == 0) {
         if (filter != nullptr) m &= filter[word];
         out[word] = m;
         count += __popcll(m);
       }
     }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row0 = (l0 + r) * kRowsPerLoad + static_cast<int64_t>(lane) * K;
+    raw[r] = make_uint4(0, 0, 0, 0);
+    if (row0 + K <= n) {
+      raw[r] = *reinterpret_cast<const uint4 *>(col + row0);
+    } else if (row0 < n) {               // the last, partial 16 bytes of the stripe: element by element
+      T tmp[K];
+#pragma unroll
+      for (int i = 0; i < K; ++i) tmp[i] = row0 + i < n ? col[row0 + i] : T();
+      raw[r] = *reinterpret_cast<const uint4 *>(tmp);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row0 = (l0 + r) * kRowsPerLoad + static_cast<int64_t>(lane) * K;
+    T v[K];
+    *reinterpret_cast<uint4 *>(v) = raw[r];
+    unsigned long long m = 0;            // K-bit mask, first row = most significant bit
+#pragma unroll
+    for (int i = 0; i < K; ++i) m = (m << 1) | ((row0 + i < n && pred(v[i])) ? 1ull : 0ull);
+    // merge the G lanes of a word: after step d the lower lane of every 2d-group holds 2d * K bits
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+      const unsigned long long other = __shfl_xor(m, d, kWave);
+      m = (m << (d * K)) | other;        // only meaningful in lanes whose bit d is clear; those are the ones kept
+    }
+    const int64_t word = (l0 + r) * K + lane / G;
+    if ((lane % G) == 0 && word < num_words) {
+      if (filter != nullptr) m &= filter[word];
+      out[word] = m;
+      count += __popcll(m);
+    }
+  }
+}
+
+template <typename T, typename Pred, int R>
+__global__ __launch_bounds__(kBlock) void select_packed_kernel(const T *__restrict__ col, int64_t n, Pred pred,
+                                                              const uint64_t *__restrict__ filter,
+                                                              uint64_t *__restrict__ out,
+                                                              unsigned long long *__restrict__ out_count) {
+  constexpr int kRowsPerLoad = kWave * (16 / static_cast<int>(sizeof(T)));
+  const int lane = lane_id();
+  const int64_t num_loads = (n + kRowsPerLoad - 1) / kRowsPerLoad;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t num_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  unsigned long long count = 0;
+  for (int64_t l0 = wave * R; l0 < num_loads; l0 += num_waves * R) {
+    select_packed_group<T, Pred, R>(col, n, pred, filter, out, l0, lane, count);
   }
   if (out_count != nullptr) {
     __shared__ unsigned long long block_count;
@@ -693,6 +750,50 @@ __global__ __launch_bounds__(kBlock) void select_packed_kernel(const T *__restri
     __syncthreads();
     if (threadIdx.x == 0 && block_count != 0) atomicAdd(out_count, block_count);
   }
+}
+
+// K1 over a run of blocks (qsx_select_cmp_blocks): a wave's unit of work is one group of R loads of ONE block — the
+// table (block_runs.hpp) counts "tiles" of R * kRowsPerLoad rows — and every block keeps its own stripe, filter and output
+// bitmap.  A workgroup takes a contiguous range of the run's tiles (its waves interleaved inside it), so it meets few
+// blocks: a wave adds its matches to a block's counter when it moves on to another block, and the counts of the range's
+// last block meet in LDS first — about one atomic per workgroup plus four per block.  (Counters of neighbouring blocks
+// share a cache line and same-line atomics serialise in L2: one atomic per wave and tile visit made 12 blocks of 10 M rows
+// take 0.89 ms instead of 0.25.)
+template <typename T, typename Pred, int R>
+__global__ __launch_bounds__(kBlock) void select_packed_runs_kernel(const long long *__restrict__ runs, Pred pred,
+                                                                   unsigned long long *__restrict__ out_counts) {
+  __shared__ unsigned long long s_last_count;
+  const int lane = lane_id();
+  const long long num_tiles = runs[2];
+  const int first = static_cast<int>(num_tiles * blockIdx.x / gridDim.x);
+  const int end = static_cast<int>(num_tiles * (blockIdx.x + 1) / gridDim.x);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  if (threadIdx.x == 0) s_last_count = 0;
+  unsigned long long count = 0;
+  int counted_block = -1;
+  for (int tile = first + wave; tile < end; tile += kWavesPerBlock) {
+    const RunTile at = run_locate(runs, tile);
+    if (at.block != counted_block) {
+      if (out_counts != nullptr && counted_block >= 0) {
+        count = wave_reduce_add(count);
+        if (lane == 0 && count != 0) atomicAdd(&out_counts[counted_block], count);
+      }
+      count = 0;
+      counted_block = at.block;
+    }
+    select_packed_group<T, Pred, R>(run_in<T>(runs, at.block), run_rows(runs, at.block), pred, run_filter(runs, at.block),
+                                    run_out<uint64_t>(runs, at.block), static_cast<int64_t>(at.tile_in_block) * R, lane, count);
+  }
+  if (out_counts == nullptr) return;
+  const int last_block = end > first ? run_locate(runs, end - 1).block : -1;
+  __syncthreads();                       // s_last_count is zero
+  count = wave_reduce_add(count);
+  if (lane == 0 && count != 0 && counted_block >= 0) {
+    if (counted_block == last_block) atomicAdd(&s_last_count, count);
+    else atomicAdd(&out_counts[counted_block], count);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && last_block >= 0 && s_last_count != 0) atomicAdd(&out_counts[last_block], s_last_count);
 }
 
 template <typename T, typename Pred>
@@ -709,6 +810,31 @@ static int launch_select_packed(const void *col, int64_t n, Pred pred, const uin
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T, int OP>
+static int launch_select_runs(const long long *runs_dev, long long tiles, const void *literal, int64_t *out_counts, hipStream_t stream) {
+  constexpr int R = 4;
+  T lit = T();
+  std::memcpy(&lit, literal, sizeof(T));
+  const int grid = grid_for(tiles, kWavesPerBlock);
+  hipLaunchKernelGGL((select_packed_runs_kernel<T, LiteralPred<T, OP>, R>), dim3(grid), dim3(kBlock), 0, stream, runs_dev,
+                     LiteralPred<T, OP>{lit}, reinterpret_cast<unsigned long long *>(out_counts));
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+template <typename T>
+static int dispatch_select_runs(int op, const long long *runs_dev, long long tiles, const void *literal, int64_t *out_counts,
+                                hipStream_t stream) {
+  switch (op) {
+    case QSX_EQ: return launch_select_runs<T, QSX_EQ>(runs_dev, tiles, literal, out_counts, stream);
+    case QSX_NE: return launch_select_runs<T, QSX_NE>(runs_dev, tiles, literal, out_counts, stream);
+    case QSX_LT: return launch_select_runs<T, QSX_LT>(runs_dev, tiles, literal, out_counts, stream);
+    case QSX_LE: return launch_select_runs<T, QSX_LE>(runs_dev, tiles, literal, out_counts, stream);
+    case QSX_GT: return launch_select_runs<T, QSX_GT>(runs_dev, tiles, literal, out_counts, stream);
+    case QSX_GE: return launch_select_runs<T, QSX_GE>(runs_dev, tiles, literal, out_counts, stream);
+    default: return QSX_ERR_INVALID_ARGUMENT;
+  }
+}
 
 // ---------------------------------------------------------------------------
 // K1 on a CHAR(width) stripe (qsx_select_cmp_char): a tile of tile_rows x width bytes is copied to LDS with 16-byte
@@ -877,6 +1003,58 @@ int qsx_select_cmp(int type, const void *col_dev, int64_t n, int op, const void 
     case QSX_FLOAT: return dispatch_select_op<float>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
     case QSX_DOUBLE: return dispatch_select_op<double>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
     case QSX_DATE: return dispatch_select_op<DateValue>(op, col_dev, nullptr, n, literal, filter_dev, out_bitmap_dev, out_count_dev, s);
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+}
+
+int qsx_select_cmp_blocks(int type, int64_t num_blocks, const int64_t *block_rows, const void *const *block_cols, int op,
+                          const void *literal, const uint64_t *const *block_filters, uint64_t *const *block_out_bitmaps,
+                          int64_t *out_counts_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  const int width = type_width(type);
+  if (width == 0) return QSX_ERR_UNSUPPORTED;
+  if (num_blocks < 0 || literal == nullptr || op < QSX_EQ || op > QSX_GE ||
+      (num_blocks > 0 && (block_rows == nullptr || block_cols == nullptr || block_out_bitmaps == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  bool aligned = true;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0 || (block_rows[b] > 0 && (block_cols[b] == nullptr || block_out_bitmaps[b] == nullptr))) {
+      return QSX_ERR_INVALID_ARGUMENT;
+    }
+    aligned = aligned && aligned16(block_cols[b]);
+  }
+  hipStream_t s = as_stream(stream);
+  if (num_blocks == 0) return QSX_OK;
+  if (!aligned) {
+    // a stripe that does not start on a 16-byte boundary takes the row-per-lane kernel: block by block
+    for (int64_t b = 0; b < num_blocks; ++b) {
+      const int rc = qsx_select_cmp(type, block_cols[b], block_rows[b], op, literal, block_filters != nullptr ? block_filters[b] : nullptr,
+                                    block_out_bitmaps[b], out_counts_dev != nullptr ? out_counts_dev + b : nullptr, stream);
+      if (rc != QSX_OK) return rc;
+    }
+    return QSX_OK;
+  }
+  if (out_counts_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_counts_dev, 0, sizeof(int64_t) * static_cast<size_t>(num_blocks), s));
+  constexpr int kLoadsPerTile = 4;                                   // R of select_packed_runs_kernel
+  const long long tile_rows = static_cast<long long>(kWave) * (16 / width) * kLoadsPerTile;
+  std::vector<long long> table;
+  const long long tiles = build_run_table(tile_rows, num_blocks, block_rows, block_cols,
+                                          reinterpret_cast<const void *const *>(block_filters),
+                                          reinterpret_cast<void *const *>(block_out_bitmaps), nullptr, &table);
+  if (tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (tiles == 0) return QSX_OK;
+  const size_t bytes = table.size() * sizeof(long long);
+  const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
+  if (runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  const int rc = staged_upload(s, table.data(), bytes);
+  if (rc != QSX_OK) return rc;
+  switch (type) {
+    case QSX_INT: return dispatch_select_runs<int32_t>(op, runs_dev, tiles, literal, out_counts_dev, s);
+    case QSX_LONG: return dispatch_select_runs<int64_t>(op, runs_dev, tiles, literal, out_counts_dev, s);
+    case QSX_FLOAT: return dispatch_select_runs<float>(op, runs_dev, tiles, literal, out_counts_dev, s);
+    case QSX_DOUBLE: return dispatch_select_runs<double>(op, runs_dev, tiles, literal, out_counts_dev, s);
+    case QSX_DATE: return dispatch_select_runs<DateValue>(op, runs_dev, tiles, literal, out_counts_dev, s);
     default: return QSX_ERR_UNSUPPORTED;
   }
 }
@@ -1102,6 +1280,74 @@ int qsx_compact_gather(int ncols, const void *const *cols, const int32_t *widths
   }
   return run_compaction(args, bitmap_dev, n, nullptr, 0, out_count_dev, workspace_dev,
                         workspace_bytes, as_stream(stream));
+}
+
+size_t qsx_compact_blocks_workspace_bytes(int64_t num_blocks, const int64_t *block_rows) {
+  int64_t tiles = 0;
+  for (int64_t b = 0; b < num_blocks; ++b) tiles += (block_rows[b] + kTileWords * 64 - 1) / (kTileWords * 64);
+  return align_up(sizeof(int64_t) * (tiles + 1), 256) + align_up(sizeof(int32_t) * (tiles + 1), 256);
+}
+
+int qsx_compact_gather_blocks(int ncols, const int32_t *widths, int64_t num_blocks, const int64_t *block_rows,
+                              const void *const *block_cols, const uint64_t *const *block_bitmaps,
+                              const int32_t *block_base_tids, void *const *out_cols, int32_t *out_tids_dev,
+                              int64_t *out_count_dev, void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (ncols < 0 || ncols > QSX_MAX_COLUMNS || num_blocks < 0 || (ncols > 0 && (widths == nullptr || out_cols == nullptr)) ||
+      (num_blocks > 0 && (block_rows == nullptr || block_bitmaps == nullptr || (ncols > 0 && block_cols == nullptr)))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  GatherArgs args;
+  args.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) {
+    const int w = widths[c];
+    if (w != 1 && w != 2 && w != 4 && w != 8) return QSX_ERR_UNSUPPORTED;
+    args.width[c] = w;
+    args.src[c] = nullptr;
+    args.dst[c] = out_cols[c];
+  }
+  hipStream_t s = as_stream(stream);
+  std::vector<int64_t> base(static_cast<size_t>(num_blocks));
+  int64_t total = 0;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0 || (block_rows[b] > 0 && block_bitmaps[b] == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+    base[b] = block_base_tids != nullptr ? block_base_tids[b] : total;
+    if (out_tids_dev != nullptr && (base[b] < 0 || base[b] + block_rows[b] > INT32_MAX)) return QSX_ERR_INVALID_ARGUMENT;
+    total += block_rows[b];
+  }
+  if (workspace_bytes < qsx_compact_blocks_workspace_bytes(num_blocks, block_rows)) return QSX_ERR_CAPACITY;
+  std::vector<long long> table;
+  std::vector<const void *> no_input(static_cast<size_t>(num_blocks), nullptr);
+  const long long tiles = build_run_table(kTileWords * 64, num_blocks, block_rows, no_input.data(),
+                                          reinterpret_cast<const void *const *>(block_bitmaps), nullptr, base.data(), &table);
+  if (tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (tiles == 0) {
+    if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+    return QSX_OK;
+  }
+  const long long cols_offset = static_cast<long long>(table.size());
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    for (int c = 0; c < ncols; ++c) {
+      const void *col = block_cols[b * ncols + c];
+      if (block_rows[b] > 0 && col == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+      table.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(col)));
+    }
+  }
+  const size_t bytes = table.size() * sizeof(long long);
+  const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
+  if (runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  const int rc = staged_upload(s, table.data(), bytes);
+  if (rc != QSX_OK) return rc;
+  int64_t *tile_offsets = static_cast<int64_t *>(workspace_dev);
+  int32_t *tile_counts = reinterpret_cast<int32_t *>(static_cast<char *>(workspace_dev) + align_up(sizeof(int64_t) * (tiles + 1), 256));
+  hipLaunchKernelGGL(tile_count_runs_kernel, dim3(grid_for(tiles, kWavesPerBlock)), dim3(kBlock), 0, s, runs_dev, tile_counts);
+  QSX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tile_counts, static_cast<int64_t>(tiles), tile_offsets, out_count_dev);
+  QSX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(compact_gather_runs_kernel, dim3(grid_for(tiles, kWavesPerBlock)), dim3(kBlock), 0, s, args, runs_dev,
+                     cols_offset, tile_offsets, out_tids_dev);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
 }
 
 int qsx_bitmap_to_tids(const uint64_t *bitmap_dev, int64_t n, int32_t base_tid,

@@ -408,3 +408,64 @@ def test_semi_join_with_residual_predicate(capi, oracle, dev):
     # the anti join is the complement within the probe block (:860-877 with residual :930-1000)
     anti = bitmap_np(capi.bitmap_combine(3, capi.tids_to_bitmap(kept[:int(k.item())], n_probe), None, n_probe))
     assert oracle.bitmap_count(anti, n_probe) == n_probe - oracle.bitmap_count(want, n_probe)
+
+
+PROBE_RUNS = {
+    "ragged": [5000, 0, 1, 4095, 4096, 4097, 70_001, 0, 33],
+    "equal": [12_288] * 7,
+    "equal_short_last": [8192] * 5 + [77],
+    "one": [300_001],
+}
+
+
+@pytest.mark.parametrize("shape", sorted(PROBE_RUNS))
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_probe_over_a_run_of_blocks_equals_block_by_block(capi, oracle, dev, flavour, key_type, dtype, shape, monkeypatch):
+    """qsx_join_probe_blocks / qsx_join_probe_exists_blocks: one launch over a run of probe blocks gives the pairs and
+    bitmaps of one probe per block (duplicate build keys, per-block filters with gaps, explicit and run-global tids)."""
+    rows = PROBE_RUNS[shape]
+    rng = np.random.default_rng(len(rows) * 7 + rows[0])
+    build = rng.integers(0, 3000, size=9000).astype(dtype)          # ~3 entries per key: chains / multi-unit buckets
+    blocks = [rng.integers(-5, 3300, size=n).astype(dtype) for n in rows]
+    filters = [oracle.bitmap_from_bools(rng.random(n) < 0.5) if (i % 3 != 2 and n) else None for i, n in enumerate(rows)]
+    key_range = (0, 2999) if flavour == "dense" else None
+    table = capi.JoinTable(key_type, build.size, key_range=key_range)
+    table.build(to_dev(build, dev))
+    ot = oracle.JoinTable(key_type, build.size)
+    ot.build(build, block_id=0, base_tid=0)
+    dblocks = [to_dev(b, dev) for b in blocks]
+    dfilters = [None if f is None else bitmap_dev(f, dev) for f in filters]
+    bases = [int(x) for x in np.cumsum([0] + rows[:-1]) * 2 + 11]      # explicit tids: gaps between the blocks
+    for use_filters in (False, True):
+        for two_pass in ("0", "1"):
+            monkeypatch.setenv("QSX_JOIN_TWO_PASS", two_pass)
+            for base_tids in (None, bases):
+                want_p, want_b = [], []
+                start = 0
+                for i, blk in enumerate(blocks):
+                    rp, rb = ot.probe(blk, filter_bitmap=filters[i] if use_filters else None)
+                    want_p.append(rp + (start if base_tids is None else base_tids[i]))
+                    want_b.append(rb)
+                    start += blk.size
+                want_p, want_b = np.concatenate(want_p), np.concatenate(want_b)
+                p, b, cnt = table.probe_blocks(dblocks, capacity=want_p.size + 5, base_tids=base_tids,
+                                               filters=dfilters if use_filters else None)
+                k = int(cnt.item())
+                assert k == want_p.size, (shape, use_filters, two_pass)
+                assert np.array_equal(sorted_pairs(p.cpu().numpy()[:k], b.cpu().numpy()[:k]), sorted_pairs(want_p, want_b))
+        monkeypatch.delenv("QSX_JOIN_TWO_PASS")
+        for anti in (False, True):
+            outs, cnt = table.probe_exists_blocks(dblocks, anti=anti, filters=dfilters if use_filters else None)
+            total = 0
+            for i, blk in enumerate(blocks):
+                ref = ot.probe_exists(blk, anti=anti, filter_bitmap=filters[i] if use_filters else None)
+                if blk.size:
+                    assert np.array_equal(bitmap_np(outs[i]), ref), (shape, i, anti, use_filters)
+                total += oracle.bitmap_count(ref, blk.size)
+            assert int(cnt.item()) == total
+    # a pair list that is too small still reports the full count
+    p, b, cnt = table.probe_blocks(dblocks, capacity=3)
+    assert int(cnt.item()) == sum(ot.probe(blk)[0].size for blk in blocks)
+    p, b, cnt = table.probe_blocks([])
+    assert int(cnt.item()) == 0

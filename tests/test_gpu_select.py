@@ -264,3 +264,82 @@ def test_char_predicates_follow_strcmp_helper(capi, oracle, dev, width, n):
         assert np.array_equal(bitmap_np(bm)[:ref.size], ref)
     with pytest.raises(capi.QsxError):
         capi.select_cmp_char(to_dev(np.zeros((4, 10), dtype=np.uint8), dev), T.EQ, b"y" * 65)     # literal beyond QSX_MAX_CHAR_LITERAL
+
+
+RUN_SHAPES = {
+    "ragged": [5000, 0, 1, 63, 64, 65, 1023, 1024, 1025, 4096, 100_003, 0, 17],
+    "equal": [20_000] * 9,
+    "equal_short_last": [8192] * 6 + [100],
+    "one": [250_001],
+    "empty_only": [0, 0],
+}
+
+
+@pytest.mark.parametrize("shape", sorted(RUN_SHAPES))
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_select_cmp_blocks_equals_block_by_block(capi, oracle, dev, dtype, shape):
+    """One launch over a run of blocks (every block its own stripe, filter and bitmap) = the oracle block by block."""
+    rows = RUN_SHAPES[shape]
+    rng = np.random.default_rng(len(rows) + rows[0])
+    cols = [make_col(rng, dtype, n) for n in rows]
+    dcols = [to_dev(c, dev) for c in cols]
+    filters = [oracle.bitmap_from_bools(rng.random(n) < 0.6) if (i % 3 != 1 and n) else None for i, n in enumerate(rows)]
+    dfilters = [None if f is None else bitmap_dev(f, dev) for f in filters]
+    for op in (T.EQ, T.NE, T.LT, T.LE, T.GT, T.GE):
+        for use_filters in (False, True):
+            outs, counts = capi.select_cmp_blocks(dcols, op, 3, filters=dfilters if use_filters else None)
+            for b, n in enumerate(rows):
+                ref = oracle.select_cmp(cols[b], op, dtype(3), filter_bitmap=filters[b] if use_filters else None)
+                if n:
+                    assert np.array_equal(bitmap_np(outs[b])[:ref.size], ref), (shape, b, n, op, use_filters)
+                assert int(counts[b].item()) == oracle.bitmap_count(ref, n), (shape, b, op)
+
+
+def test_select_cmp_blocks_unaligned_stripes_and_dates(capi, oracle, dev):
+    rng = np.random.default_rng(21)
+    base = rng.integers(-20, 20, size=50_000).astype(np.int32)
+    dbase = to_dev(base, dev)
+    cuts = [(0, 4000), (4001, 9000), (9003, 9003), (9003, 30_001), (30_002, 50_000)]     # stripes starting inside a 16-byte chunk
+    outs, counts = capi.select_cmp_blocks([dbase[a:b] for a, b in cuts], T.LT, 3)
+    for i, (a, b) in enumerate(cuts):
+        ref = oracle.select_cmp(base[a:b], T.LT, np.int32(3))
+        if b > a:
+            assert np.array_equal(bitmap_np(outs[i])[:ref.size], ref)
+        assert int(counts[i].item()) == oracle.bitmap_count(ref, b - a)
+    dates = [make_dates(rng, n) for n in (3000, 70_001, 5)]
+    lit = T.date_raw(1995, 3, 15)
+    for op in (T.EQ, T.LT, T.GE):
+        outs, counts = capi.select_cmp_blocks([to_dev(d, dev) for d in dates], op, lit, qtype=T.DATE)
+        for i, d in enumerate(dates):
+            ref = oracle.select_cmp(d, op, lit, qt=T.DATE)
+            assert np.array_equal(bitmap_np(outs[i])[:ref.size], ref)
+            assert int(counts[i].item()) == oracle.bitmap_count(ref, d.size)
+
+
+@pytest.mark.parametrize("shape", sorted(RUN_SHAPES))
+@pytest.mark.parametrize("selectivity", [0.0, 0.02, 0.6, 1.0])
+def test_compact_gather_blocks_concatenates_in_block_and_row_order(capi, oracle, dev, shape, selectivity):
+    """K2 over a run: the selected rows of every block, block after block, as the oracle's per-block compaction gives them."""
+    rows = RUN_SHAPES[shape]
+    rng = np.random.default_rng(len(rows) + int(selectivity * 50))
+    blocks, keeps = [], []
+    for n in rows:
+        blocks.append([rng.integers(0, 255, size=n).astype(np.uint8), rng.integers(-2**15, 2**15, size=n).astype(np.int16),
+                       rng.integers(-2**31, 2**31, size=n).astype(np.int32), rng.normal(size=n)])
+        keeps.append(rng.random(n) < selectivity)
+    words = [oracle.bitmap_from_bools(k) if k.size else np.zeros(1, dtype=np.uint64) for k in keeps]
+    dblocks = [[to_dev(c, dev) for c in b] for b in blocks]
+    dwords = [bitmap_dev(w, dev) for w in words]
+    bases = [int(x) for x in np.cumsum([0] + rows[:-1]) + 100 * np.arange(len(rows))]
+    for base_tids in (None, bases):
+        out, tids, cnt = capi.compact_gather_blocks(dblocks, dwords, base_tids=base_tids, want_tids=True)
+        k = int(cnt.item())
+        assert k == sum(int(x.sum()) for x in keeps)
+        for c in range(4):
+            want = np.concatenate([oracle.compact_gather(blocks[b][c], words[b]) if rows[b] else blocks[b][c][:0] for b in range(len(rows))])
+            assert np.array_equal(out[c].cpu().numpy()[:k], want), (shape, c)
+        start, want_tids = 0, []
+        for b, n in enumerate(rows):
+            want_tids.append(np.nonzero(keeps[b])[0] + (start if base_tids is None else base_tids[b]))
+            start += n
+        assert np.array_equal(tids.cpu().numpy()[:k], np.concatenate(want_tids).astype(np.int32))

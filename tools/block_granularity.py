@@ -56,7 +56,17 @@ for block in (n, 10_000_000, 1_000_000, 120_000):
         st.clear()
         st.update_blocks(run_blocks)
 
+    def select_run():                    # qsx_select_cmp_blocks
+        capi.select_cmp_blocks(select_blocks, T.LT, 24.0, out_bitmaps=select_outs)
+
+    def probe_run():                     # qsx_join_probe_blocks
+        table.probe_blocks(key_blocks, out=out)
+
+    key_blocks = [keys[s0:min(n, s0 + block)] for s0 in range(0, n, block)]
+    select_blocks = [cols[2][s0:min(n, s0 + block)] for s0 in range(0, n, block)]
+    select_outs = [capi.new_bitmap(c.numel(), dev) for c in select_blocks]
     run_blocks = [[c[s0:min(n, s0 + block)] for c in cols] for s0 in range(0, n, block)]
     print(json.dumps({"rows": n, "block_rows": block, "calls": (n + block - 1) // block, "aggregate_ms": round(timed(agg), 3),
                       "aggregate_as_one_run_of_blocks_ms": round(timed(agg_run), 3),
-                      "probe_ms": round(timed(probe), 3), "select_ms": round(timed(select), 3)}), flush=True)
+                      "probe_ms": round(timed(probe), 3), "probe_as_one_run_of_blocks_ms": round(timed(probe_run), 3), "select_ms": round(timed(select), 3),
+                      "select_as_one_run_of_blocks_ms": round(timed(select_run), 3)}), flush=True)
