@@ -273,7 +273,8 @@ int qsx_gather(int width, const void *src_dev, const int32_t *tids_dev, int64_t 
 
 /* K5 over a relation stored as several blocks: tids are relation-global row
  * numbers, segment s holds rows [segment_first_row[s], segment_first_row[s+1])
- * (the last one is open-ended) at segment_ptrs[s].  At most 64 segments.
+ * (the last one is open-ended) at segment_ptrs[s].  At most 16384 segments (beyond 64 the table
+ * travels through device memory) — the blocks of a relation, or of a run handed to qsx_join_probe_blocks.
  * Counterpart of the per-build-block loop of HashInnerJoinWorkOrder
  * (relational_operators/HashJoinOperator.cpp:494-540). */
 int qsx_gather_segmented(int width, int num_segments, const void *const *segment_ptrs,

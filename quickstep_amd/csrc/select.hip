@@ -515,6 +515,65 @@ __global__ __launch_bounds__(kBlock) void gather_segmented_kernel(SegmentTable s
   }
 }
 
+// More than kMaxSegments segments (a long run of blocks): the table lives in device memory — first rows as 32-bit words
+// (tuple ids are int32), then the segment addresses — and every workgroup copies the first rows to LDS for the search.
+constexpr int kMaxTableSegments = 16384;   // 64 KiB of LDS
+__device__ __forceinline__ int segment_of(const int32_t *__restrict__ s_first, int num, int32_t t) {
+  int lo = 0, hi = num - 1;                // last segment whose first row <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (s_first[mid] <= t) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_segmented_table_kernel(const int32_t *__restrict__ first_rows,
+                                                                        const long long *__restrict__ ptrs, int num,
+                                                                        const int32_t *__restrict__ tids, int64_t n,
+                                                                        T *__restrict__ dst) {
+  extern __shared__ int32_t s_first[];
+  for (int i = threadIdx.x; i < num; i += kBlock) s_first[i] = first_rows[i];
+  __syncthreads();
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int32_t t = tids[i];
+    if (t < 0) {
+      dst[i] = T();
+      continue;
+    }
+    const int seg = segment_of(s_first, num, t);
+    dst[i] = reinterpret_cast<const T *>(ptrs[seg])[t - s_first[seg]];
+  }
+}
+__global__ __launch_bounds__(kBlock) void bitmap_gather_segmented_table_kernel(const int32_t *__restrict__ first_rows,
+                                                                               const long long *__restrict__ ptrs, int num,
+                                                                               const int32_t *__restrict__ tids, int64_t n,
+                                                                               uint64_t *__restrict__ out) {
+  extern __shared__ int32_t s_first[];
+  for (int i = threadIdx.x; i < num; i += kBlock) s_first[i] = first_rows[i];
+  __syncthreads();
+  const int64_t rounded = (n + kWave - 1) / kWave * kWave;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < rounded;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    bool is_null = false;
+    if (i < n) {
+      const int32_t t = tids[i];
+      if (t < 0) {
+        is_null = true;
+      } else {
+        const int seg = segment_of(s_first, num, t);
+        const uint64_t *bits = reinterpret_cast<const uint64_t *>(ptrs[seg]);
+        if (bits != nullptr) {
+          const int64_t r = t - s_first[seg];
+          is_null = msb_bit(bits[r >> 6], static_cast<int>(r & 63));
+        }
+      }
+    }
+    const uint64_t word = msb_first(__ballot(is_null));
+    if (lane_id() == 0) out[i >> 6] = word;
+  }
+}
+
 // Null bits travelling with gathered values: bit i of the output = the null bit of row tids[i] in the segment holding it
 // (a segment without a bitmap has no NULLs), 1 for a negative tid (outer-join padding).  One row per lane, the wave's
 // ballot is the output word.
@@ -1379,13 +1438,52 @@ int qsx_gather(int width, const void *src_dev, const int32_t *tids_dev, int64_t 
   return QSX_OK;
 }
 
+// The segment table of a long run in device memory: [first rows as int32, padded to 8 bytes | addresses].
+static int upload_segment_table(int num_segments, const void *const *ptrs, const int64_t *first_row, hipStream_t stream,
+                                const int32_t **first_dev, const long long **ptrs_dev) {
+  const size_t first_words = (static_cast<size_t>(num_segments) + 1) / 2;     // 64-bit words holding the int32 first rows
+  std::vector<long long> table(first_words + static_cast<size_t>(num_segments), 0);
+  int32_t *first = reinterpret_cast<int32_t *>(table.data());
+  for (int i = 0; i < num_segments; ++i) {
+    if (first_row[i] < 0 || first_row[i] > INT32_MAX) return QSX_ERR_INVALID_ARGUMENT;
+    first[i] = static_cast<int32_t>(first_row[i]);
+    table[first_words + i] = static_cast<long long>(reinterpret_cast<uintptr_t>(ptrs[i]));
+  }
+  const size_t bytes = table.size() * sizeof(long long);
+  const long long *dev = static_cast<const long long *>(staged_device_buffer(stream, bytes));
+  if (dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  const int rc = staged_upload(stream, table.data(), bytes);
+  if (rc != QSX_OK) return rc;
+  *first_dev = reinterpret_cast<const int32_t *>(dev);
+  *ptrs_dev = dev + first_words;
+  return QSX_OK;
+}
+
 int qsx_gather_segmented(int width, int num_segments, const void *const *segment_ptrs,
                          const int64_t *segment_first_row, const int32_t *tids_dev, int64_t n, void *dst_dev,
                          qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (n < 0 || num_segments < 1 || segment_ptrs == nullptr || segment_first_row == nullptr) return QSX_ERR_INVALID_ARGUMENT;
-  if (num_segments > kMaxSegments) return QSX_ERR_UNSUPPORTED;
+  if (num_segments > kMaxTableSegments) return QSX_ERR_UNSUPPORTED;
   if (n == 0) return QSX_OK;
+  if (num_segments > kMaxSegments) {
+    hipStream_t s = as_stream(stream);
+    const int32_t *first_dev = nullptr;
+    const long long *ptrs_dev = nullptr;
+    const int rc = upload_segment_table(num_segments, segment_ptrs, segment_first_row, s, &first_dev, &ptrs_dev);
+    if (rc != QSX_OK) return rc;
+    const int grid = grid_for(n, kBlock * 16);      // every workgroup pays the copy of the first rows to LDS
+    const size_t lds = static_cast<size_t>(num_segments) * sizeof(int32_t);
+    switch (width) {
+      case 1: hipLaunchKernelGGL(gather_segmented_table_kernel<uint8_t>, dim3(grid), dim3(kBlock), lds, s, first_dev, ptrs_dev, num_segments, tids_dev, n, static_cast<uint8_t *>(dst_dev)); break;
+      case 2: hipLaunchKernelGGL(gather_segmented_table_kernel<uint16_t>, dim3(grid), dim3(kBlock), lds, s, first_dev, ptrs_dev, num_segments, tids_dev, n, static_cast<uint16_t *>(dst_dev)); break;
+      case 4: hipLaunchKernelGGL(gather_segmented_table_kernel<uint32_t>, dim3(grid), dim3(kBlock), lds, s, first_dev, ptrs_dev, num_segments, tids_dev, n, static_cast<uint32_t *>(dst_dev)); break;
+      case 8: hipLaunchKernelGGL(gather_segmented_table_kernel<uint64_t>, dim3(grid), dim3(kBlock), lds, s, first_dev, ptrs_dev, num_segments, tids_dev, n, static_cast<uint64_t *>(dst_dev)); break;
+      default: return QSX_ERR_UNSUPPORTED;
+    }
+    QSX_CHECK_LAUNCH();
+    return QSX_OK;
+  }
   SegmentTable seg;
   seg.num = num_segments;
   for (int i = 0; i < num_segments; ++i) {
@@ -1409,9 +1507,22 @@ int qsx_bitmap_gather_segmented(int num_segments, const uint64_t *const *segment
                                  const int32_t *tids_dev, int64_t n, uint64_t *out_bitmap_dev, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (n < 0 || num_segments < 1 || segment_bitmaps == nullptr || segment_first_row == nullptr) return QSX_ERR_INVALID_ARGUMENT;
-  if (num_segments > kMaxSegments) return QSX_ERR_UNSUPPORTED;
+  if (num_segments > kMaxTableSegments) return QSX_ERR_UNSUPPORTED;
   if (n == 0) return QSX_OK;
   if (tids_dev == nullptr || out_bitmap_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (num_segments > kMaxSegments) {
+    hipStream_t s = as_stream(stream);
+    const int32_t *first_dev = nullptr;
+    const long long *ptrs_dev = nullptr;
+    const int rc = upload_segment_table(num_segments, reinterpret_cast<const void *const *>(segment_bitmaps), segment_first_row, s,
+                                        &first_dev, &ptrs_dev);
+    if (rc != QSX_OK) return rc;
+    hipLaunchKernelGGL(bitmap_gather_segmented_table_kernel, dim3(grid_for(n, kBlock * 16)), dim3(kBlock),
+                       static_cast<size_t>(num_segments) * sizeof(int32_t), s, first_dev, ptrs_dev, num_segments, tids_dev, n,
+                       out_bitmap_dev);
+    QSX_CHECK_LAUNCH();
+    return QSX_OK;
+  }
   SegmentTable seg;
   seg.num = num_segments;
   for (int i = 0; i < num_segments; ++i) {

@@ -469,3 +469,38 @@ def test_probe_over_a_run_of_blocks_equals_block_by_block(capi, oracle, dev, fla
     assert int(cnt.item()) == sum(ot.probe(blk)[0].size for blk in blocks)
     p, b, cnt = table.probe_blocks([])
     assert int(cnt.item()) == 0
+
+
+@pytest.mark.parametrize("num_blocks", [3, 64, 65, 700])
+def test_run_global_tids_feed_the_segmented_gathers(capi, oracle, dev, num_blocks):
+    """The pair list of qsx_join_probe_blocks numbers probe rows through the run; qsx_gather_segmented /
+    qsx_bitmap_gather_segmented (device-resident segment table beyond 64 segments) fetch the probe side's values and null
+    bits from the blocks' own stripes."""
+    rng = np.random.default_rng(num_blocks)
+    rows = [int(x) for x in rng.integers(0, 900, size=num_blocks)]
+    rows[0] = 5000
+    build = rng.permutation(4000).astype(np.int32)
+    table = capi.JoinTable(T.INT, build.size, key_range=(0, 3999))
+    table.build(to_dev(build, dev))
+    keys = [rng.integers(0, 8000, size=n).astype(np.int32) for n in rows]
+    payload = [rng.normal(size=n) for n in rows]
+    narrow = [rng.integers(0, 200, size=n).astype(np.uint8) for n in rows]
+    nulls = [rng.random(n) < 0.2 if b % 3 else None for b, n in enumerate(rows)]
+    p, b, cnt = table.probe_blocks([to_dev(k, dev) for k in keys])
+    k = int(cnt.item())
+    allk = np.concatenate(keys)
+    assert k == int((allk < 4000).sum())
+    first = [int(x) for x in np.cumsum([0] + rows[:-1])]
+    pt = p[:k].contiguous()
+    got_pay = capi.gather_segmented([to_dev(x, dev) for x in payload], first, pt).cpu().numpy()
+    got_narrow = capi.gather_segmented([to_dev(x, dev) for x in narrow], first, pt).cpu().numpy()
+    got_key = capi.gather_segmented([to_dev(x, dev) for x in keys], first, pt).cpu().numpy()
+    hp, hb = pt.cpu().numpy(), b[:k].cpu().numpy()
+    assert np.array_equal(got_key, allk[hp]) and np.array_equal(build[hb], allk[hp])
+    assert np.array_equal(got_pay, np.concatenate(payload)[hp]) and np.array_equal(got_narrow, np.concatenate(narrow)[hp])
+    segs = [None if m is None or m.size == 0 else bitmap_dev(oracle.bitmap_from_bools(m), dev) for m in nulls]
+    whole = np.concatenate([np.zeros(n, dtype=bool) if m is None else m for m, n in zip(nulls, rows)])
+    with_padding = torch.cat([pt, torch.full((3,), -1, dtype=torch.int32, device=pt.device)])
+    out = capi.bitmap_gather_segmented(segs, first, with_padding)
+    want = oracle.bitmap_from_bools(np.concatenate([whole[hp], np.ones(3, dtype=bool)]))
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want[:(k + 3 + 63) // 64])
