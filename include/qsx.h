@@ -404,6 +404,11 @@ int qsx_join_probe_blocks(qsx_join_table_t *table, int64_t num_blocks, const int
                           const int32_t *block_base_tids, const uint64_t *const *block_filters, int32_t *out_probe_tid_dev,
                           int32_t *out_build_tid_dev, int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream);
 
+/* qsx_join_probe_count over a run of probe blocks: the number of pairs qsx_join_probe_blocks would emit. */
+int qsx_join_probe_count_blocks(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows,
+                                const void *const *block_keys, const uint64_t *const *block_filters,
+                                int64_t *out_count_dev, qsx_stream_t stream);
+
 /* Existence probe for semi / anti joins: out_bitmap bit i = filter[i] AND
  * (key i found) when anti == 0, filter[i] AND NOT found when anti != 0.
  * Replaces HashTable::runOverKeysFromValueAccessorIfMatch[Not]Found

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_probe_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_join_probe_count_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _vp, _vp]),
     "qsx_join_probe_exists_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _int, _pp, _vp, _vp]),
     "qsx_join_probe_count": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "qsx_join_probe_exists": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
@@ -540,6 +541,18 @@ class JoinTable:
         _check(_lib.qsx_join_probe_blocks(self._h, nb, rows, kptr, bptr, fptr, _ptr(out_p), _ptr(out_b), capacity, _ptr(count),
                                           _stream(stream)), "qsx_join_probe_blocks")
         return out_p, out_b, count
+
+    def probe_count_blocks(self, key_blocks, filters=None, stream=None):
+        nb = len(key_blocks)
+        dev = key_blocks[0].device if nb else torch.device("cuda:0")
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
+        fptr = None
+        if filters is not None:
+            fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        _check(_lib.qsx_join_probe_count_blocks(self._h, nb, rows, kptr, fptr, _ptr(count), _stream(stream)), "qsx_join_probe_count_blocks")
+        return count
 
     def probe_exists_blocks(self, key_blocks, anti=False, filters=None, out_bitmaps=None, stream=None):
         """Semi / anti probe over a run of blocks: returns (per-block bitmaps, total count int64[1])."""

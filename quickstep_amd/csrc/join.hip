@@ -984,6 +984,22 @@ int qsx_join_probe_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
                                nullptr, 0, s, runs_dev, tiles);
 }
 
+int qsx_join_probe_count_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                const uint64_t *const *block_filters, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || num_blocks < 0 || out_count_dev == nullptr || (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  const long long *runs_dev = nullptr;
+  int64_t tiles = 0, rows = 0;
+  bool any_filter = false;
+  const int rc = upload_probe_run(num_blocks, block_rows, block_keys, nullptr, block_filters, nullptr, s, &runs_dev, &tiles, &rows,
+                                  &any_filter);
+  if (rc != QSX_OK) return rc;
+  return launch_probe<1, true>(t, nullptr, rows, 0, nullptr, nullptr, nullptr, 0, out_count_dev, nullptr, 0, s, runs_dev, tiles);
+}
+
 int qsx_join_probe_exists_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
                                  const uint64_t *const *block_filters, int anti, uint64_t *const *block_out_bitmaps,
                                  int64_t *out_count_dev, qsx_stream_t stream) {

@@ -1474,12 +1474,23 @@ bool SelectOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryConte
   InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
   std::lock_guard<std::mutex> lock(mutex_);
   while (num_workorders_generated_ < input_relation_block_ids_.size()) {
-    container->addNormalWorkOrder(new SelectWorkOrder(query_id_, input_relation_block_ids_[num_workorders_generated_],
-                                                      predicate, simple_selection_, dest, storage_manager, on_gpu_,
-                                                      CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context),
-                                                      selection_.empty() ? nullptr : &selection_),
-                                  op_index_);
-    ++num_workorders_generated_;
+    // every block that has arrived, in runs of blocks_per_work_order_ (1: the reference's one work order per block)
+    const std::size_t take = on_gpu_ ? std::min(blocks_per_work_order_, input_relation_block_ids_.size() - num_workorders_generated_) : 1;
+    if (take > 1) {
+      std::vector<block_id> run(input_relation_block_ids_.begin() + static_cast<std::ptrdiff_t>(num_workorders_generated_),
+                                input_relation_block_ids_.begin() + static_cast<std::ptrdiff_t>(num_workorders_generated_ + take));
+      container->addNormalWorkOrder(new SelectWorkOrder(query_id_, std::move(run), predicate, simple_selection_, dest, storage_manager,
+                                                        CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context),
+                                                        selection_.empty() ? nullptr : &selection_),
+                                    op_index_);
+    } else {
+      container->addNormalWorkOrder(new SelectWorkOrder(query_id_, input_relation_block_ids_[num_workorders_generated_],
+                                                        predicate, simple_selection_, dest, storage_manager, on_gpu_,
+                                                        CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context),
+                                                        selection_.empty() ? nullptr : &selection_),
+                                    op_index_);
+    }
+    num_workorders_generated_ += take;
   }
   return input_relation_is_stored_ || done_feeding_input_relation_;
 }
@@ -1489,7 +1500,99 @@ void SelectWorkOrder::execute() {
     executeOnHost();
     return;
   }
-  BlockReference block = storage_manager_->getBlock(input_block_id_);
+  if (run_block_ids_.empty()) {
+    executeBlock(input_block_id_);
+    return;
+  }
+  if (executeRun()) return;
+  for (block_id id : run_block_ids_) executeBlock(id);
+}
+
+// A run of blocks as one unit: every predicate term is one launch over all blocks (per-block bitmaps chained through the
+// terms like a conjunction), then the selected tuples of the run, block after block, are compacted into ONE output block
+// — what consecutive SelectWorkOrders do to an InsertDestination's current block (InsertDestination.cpp:222-260).
+bool SelectWorkOrder::executeRun() {
+  if (lip_filter_adaptive_prober_ != nullptr || predicate_ == nullptr || predicate_->conjuncts.empty()) return false;
+  std::vector<attribute_id> selection;
+  if (selection_ != nullptr && !selection_->empty()) {
+    for (const ScalarPtr &scalar : *selection_) {
+      if (scalar->kind != Scalar::kAttribute) return false;
+      selection.push_back(scalar->attribute);
+    }
+  } else {
+    selection = simple_selection_;
+  }
+  if (selection.size() > QSX_MAX_COLUMNS) return false;
+  std::vector<BlockReference> blocks;
+  std::vector<std::int64_t> rows;
+  std::int64_t total_rows = 0;
+  std::size_t bitmap_words = 0;
+  for (block_id id : run_block_ids_) {
+    blocks.push_back(storage_manager_->getBlock(id));
+    const StorageBlock &b = *blocks.back();
+    for (const ComparisonPredicate &term : predicate_->conjuncts) {
+      const Type &t = b.getRelation().getAttributeType(term.attribute);
+      if (term.rhs_attribute != kInvalidAttributeID || b.compressedAttribute(term.attribute) != nullptr || t.id == kChar ||
+          term.attribute == b.sortColumn() || b.nullBitmap(term.attribute) != nullptr) {
+        return false;
+      }
+    }
+    for (attribute_id a : selection) {
+      if (b.nullBitmap(a) != nullptr || b.compressedAttribute(a) != nullptr) return false;
+    }
+    rows.push_back(b.numTuples());
+    total_rows += b.numTuples();
+    bitmap_words += static_cast<std::size_t>((b.numTuples() + 63) / 64) + 1;
+  }
+  const std::size_t nb = blocks.size();
+  // two sets of per-block bitmaps in two allocations, the terms ping-pong between them
+  DeviceBuffer set_a(bitmap_words * 8 + 8), set_b(bitmap_words * 8 + 8), counts(nb * 8 + 8);
+  std::vector<std::uint64_t *> cur(nb), nxt(nb);
+  std::size_t at = 0;
+  for (std::size_t b = 0; b < nb; ++b) {
+    cur[b] = static_cast<std::uint64_t *>(set_a.ptr) + at;
+    nxt[b] = static_cast<std::uint64_t *>(set_b.ptr) + at;
+    at += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
+  }
+  std::vector<const void *> stripes(nb);
+  bool first = true;
+  for (const ComparisonPredicate &term : predicate_->conjuncts) {
+    const Type &t = blocks.front()->getRelation().getAttributeType(term.attribute);
+    for (std::size_t b = 0; b < nb; ++b) stripes[b] = blocks[b]->stripe(term.attribute);
+    CheckStatus(qsx_select_cmp_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
+                                      &term.literal.v, first ? nullptr : reinterpret_cast<const std::uint64_t *const *>(cur.data()),
+                                      nxt.data(), static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_cmp_blocks");
+    std::swap(cur, nxt);
+    first = false;
+  }
+  std::vector<std::int64_t> block_matches(nb);
+  CheckStatus(qsx_copy_to_host(block_matches.data(), counts.ptr, nb * 8, CurrentStream()), "qsx_copy_to_host");
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+  std::int64_t matches = 0;
+  for (std::int64_t m : block_matches) matches += m;
+  block_id out_id;
+  BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
+  std::vector<const void *> src(nb * selection.size());
+  std::vector<void *> dst;
+  std::vector<std::int32_t> widths;
+  for (std::size_t i = 0; i < selection.size(); ++i) {
+    dst.push_back(out->stripe(static_cast<attribute_id>(i)));
+    widths.push_back(blocks.front()->getRelation().getAttributeType(selection[i]).width);
+    for (std::size_t b = 0; b < nb; ++b) src[b * selection.size() + i] = blocks[b]->stripe(selection[i]);
+  }
+  const std::size_t ws_bytes = qsx_compact_blocks_workspace_bytes(static_cast<std::int64_t>(nb), rows.data());
+  DeviceBuffer ws(ws_bytes + 8), count(8);
+  CheckStatus(qsx_compact_gather_blocks(static_cast<int>(selection.size()), widths.data(), static_cast<std::int64_t>(nb), rows.data(),
+                                        src.data(), reinterpret_cast<const std::uint64_t *const *>(cur.data()), nullptr, dst.data(),
+                                        nullptr, static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
+              "qsx_compact_gather_blocks");
+  const std::int64_t written = ReadCount(count.ptr);   // synchronises the work order, like the reference's execute()
+  output_destination_->returnBlock(out_id, written);
+  return true;
+}
+
+void SelectWorkOrder::executeBlock(block_id input_block_id) {
+  BlockReference block = storage_manager_->getBlock(input_block_id);
   const std::int64_t n = block->numTuples();
   std::int64_t matches = 0;
   Predicate all;
@@ -1770,14 +1873,20 @@ bool HashJoinOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCon
   for (partition_id part = 0; part < num_partitions_; ++part) {   // HashJoinOperator.cpp:220-250
     qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, part);
     while (probe_.generated[part] < probe_.ids[part].size()) {
-      container->addNormalWorkOrder(
+      // every probe block that has arrived, in runs of blocks_per_work_order_ (1: one work order per block)
+      const std::size_t take = std::min(blocks_per_work_order_, probe_.ids[part].size() - probe_.generated[part]);
+      HashInnerJoinWorkOrder *order =
           new HashInnerJoinWorkOrder(query_id_, build_relation_, probe_relation_, join_key_attributes_, build_key_attributes_,
                                      probe_.ids[part][probe_.generated[part]],
                                      query_context->getPredicate(residual_predicate_index_), selection, is_selection_on_build_,
                                      join_type_, table, dest, storage_manager, part,
-                                     CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context)),
-          op_index_);
-      ++probe_.generated[part];
+                                     CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context));
+      if (take > 1) {
+        order->setRun(std::vector<block_id>(probe_.ids[part].begin() + static_cast<std::ptrdiff_t>(probe_.generated[part]),
+                                            probe_.ids[part].begin() + static_cast<std::ptrdiff_t>(probe_.generated[part] + take)));
+      }
+      container->addNormalWorkOrder(order, op_index_);
+      probe_.generated[part] += take;
     }
   }
   return probe_relation_is_stored_ || done_feeding_input_relation_;
@@ -1837,8 +1946,79 @@ void CompactPairs(JoinedPairs *pairs, const void *bitmap) {
 }  // namespace
 
 void HashInnerJoinWorkOrder::execute() {
+  if (run_block_ids_.empty()) {
+    executeBlock(block_id_);
+    return;
+  }
+  if (executeRun()) return;
+  for (block_id id : run_block_ids_) executeBlock(id);
+}
+
+// A run of probe blocks as one unit: one counting and one pair-emitting launch over all blocks (probe tuple ids are
+// run-global row numbers), then every output attribute is one segmented gather — the probe side from the run's own
+// stripes, the build side from the build relation's blocks — into ONE output block.
+bool HashInnerJoinWorkOrder::executeRun() {
   using JoinType = HashJoinOperator::JoinType;
-  BlockReference probe = storage_manager_->getBlock(block_id_);
+  if (join_type_ != JoinType::kInnerJoin || residual_predicate_ != nullptr || lip_filter_adaptive_prober_ != nullptr ||
+      join_key_attributes_.size() != 1) {
+    return false;
+  }
+  std::vector<BlockReference> blocks;
+  std::vector<std::int64_t> rows, first_rows;
+  std::vector<const void *> keys;
+  std::int64_t total_rows = 0;
+  for (block_id id : run_block_ids_) {
+    blocks.push_back(storage_manager_->getBlock(id));
+    const StorageBlock &b = *blocks.back();
+    if (b.nullBitmap(join_key_attributes_.front()) != nullptr || b.compressedAttribute(join_key_attributes_.front()) != nullptr) return false;
+    for (std::size_t i = 0; i < selection_.size(); ++i) {
+      if (!is_selection_on_build_[i] && (b.nullBitmap(selection_[i]) != nullptr || b.compressedAttribute(selection_[i]) != nullptr)) return false;
+    }
+    rows.push_back(b.numTuples());
+    first_rows.push_back(total_rows);
+    keys.push_back(b.stripe(join_key_attributes_.front()));
+    total_rows += b.numTuples();
+  }
+  if (total_rows > INT32_MAX || blocks.size() > 16384) return false;
+  const std::int64_t nb = static_cast<std::int64_t>(blocks.size());
+  DeviceBuffer count(8);
+  CheckStatus(qsx_join_probe_count_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, static_cast<std::int64_t *>(count.ptr),
+                                          CurrentStream()), "qsx_join_probe_count_blocks");
+  const std::int64_t matches = ReadCount(count.ptr);
+  DeviceBuffer probe_tids(static_cast<std::size_t>(matches) * 4 + 8), build_tids(static_cast<std::size_t>(matches) * 4 + 8);
+  CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, nullptr, static_cast<std::int32_t *>(probe_tids.ptr),
+                                    static_cast<std::int32_t *>(build_tids.ptr), matches, static_cast<std::int64_t *>(count.ptr),
+                                    CurrentStream()), "qsx_join_probe_blocks");
+  BuildSegments build(build_relation_, storage_manager_);
+  block_id out_id;
+  BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
+  std::vector<const void *> segments(blocks.size());
+  for (std::size_t i = 0; i < selection_.size(); ++i) {
+    void *dst = out->stripe(static_cast<attribute_id>(i));
+    const bool on_build = is_selection_on_build_[i];
+    const Type &t = (on_build ? build_relation_ : probe_relation_).getAttributeType(selection_[i]);
+    if (on_build) {
+      build.gather(selection_[i], t.width, build_tids.ptr, matches, dst);
+      if (t.nullable && matches > 0) {
+        std::uint64_t *nulls = out->nullBitmap(static_cast<attribute_id>(i));
+        if (nulls == nullptr) throw ExecutionError("join output of a nullable attribute must be nullable", QSX_ERR_INVALID_ARGUMENT);
+        build.gatherNulls(selection_[i], build_tids.ptr, matches, nulls);
+      }
+    } else {
+      for (std::size_t b = 0; b < blocks.size(); ++b) segments[b] = blocks[b]->stripe(selection_[i]);
+      CheckStatus(qsx_gather_segmented(t.width, static_cast<int>(segments.size()), segments.data(), first_rows.data(),
+                                       static_cast<const std::int32_t *>(probe_tids.ptr), matches, dst, CurrentStream()),
+                  "qsx_gather_segmented");
+    }
+  }
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+  output_destination_->returnBlock(out_id, matches);
+  return true;
+}
+
+void HashInnerJoinWorkOrder::executeBlock(block_id probe_block_id) {
+  using JoinType = HashJoinOperator::JoinType;
+  BlockReference probe = storage_manager_->getBlock(probe_block_id);
   const std::int64_t n = probe->numTuples();
   JoinKeys keys(*probe, join_key_attributes_);
   DeviceBuffer count(8);

@@ -636,8 +636,14 @@ class SelectOperator : public RelationalOperator {
   }
   QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
   relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+  // How many input blocks one SelectWorkOrder covers (1 = the reference's one work order per block,
+  // SelectOperator.cpp:83-150).  A run of blocks is one launch per predicate term plus one compaction into ONE output
+  // block (qsx_select_cmp_blocks / qsx_compact_gather_blocks); blocks the run form does not cover (compressed, sorted,
+  // CHAR or nullable attributes, expressions, LIP filters) are executed one by one inside the work order.
+  void setBlocksPerWorkOrder(std::size_t blocks) { blocks_per_work_order_ = blocks > 0 ? blocks : 1; }
 
  private:
+  std::size_t blocks_per_work_order_ = 1;
   const CatalogRelation &input_relation_;
   const CatalogRelation &output_relation_;
   const QueryContext::insert_destination_id output_destination_index_;
@@ -661,11 +667,23 @@ class SelectWorkOrder : public WorkOrder {
       : WorkOrder(query_id), input_block_id_(input_block_id), predicate_(predicate), simple_selection_(simple_selection),
         selection_(selection), output_destination_(output_destination), storage_manager_(storage_manager), on_gpu_(on_gpu),
         lip_filter_adaptive_prober_(lip_filter_adaptive_prober) {}
+  // A run of input blocks (SelectOperator::setBlocksPerWorkOrder).
+  SelectWorkOrder(std::size_t query_id, std::vector<block_id> &&input_block_ids, const Predicate *predicate,
+                  const std::vector<attribute_id> &simple_selection, InsertDestination *output_destination,
+                  StorageManager *storage_manager, LIPFilterAdaptiveProber *lip_filter_adaptive_prober = nullptr,
+                  const std::vector<ScalarPtr> *selection = nullptr)
+      : WorkOrder(query_id), input_block_id_(input_block_ids.front()), run_block_ids_(std::move(input_block_ids)),
+        predicate_(predicate), simple_selection_(simple_selection), selection_(selection),
+        output_destination_(output_destination), storage_manager_(storage_manager), on_gpu_(true),
+        lip_filter_adaptive_prober_(lip_filter_adaptive_prober) {}
   void execute() override;  // SelectOperator.cpp:161-195
 
  private:
   void executeOnHost();
+  void executeBlock(block_id input_block_id);
+  bool executeRun();          // false: the run form does not cover these blocks
   const block_id input_block_id_;
+  const std::vector<block_id> run_block_ids_;   // empty: the single block input_block_id_
   const Predicate *predicate_;
   const std::vector<attribute_id> &simple_selection_;
   const std::vector<ScalarPtr> *selection_;   // nullptr / empty: simple_selection_
@@ -755,8 +773,14 @@ class HashJoinOperator : public RelationalOperator {
   }
   QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
   relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+  // How many probe blocks one work order covers (1 = the reference's one probe work order per block,
+  // HashJoinOperator.cpp:203-260).  A run is probed with one launch (qsx_join_probe_blocks) and its joined tuples go to
+  // ONE output block; an inner join on one non-nullable key attribute without residual predicate or LIP filter takes the
+  // run form, everything else is executed block by block inside the work order.
+  void setBlocksPerWorkOrder(std::size_t blocks) { blocks_per_work_order_ = blocks > 0 ? blocks : 1; }
 
  private:
+  std::size_t blocks_per_work_order_ = 1;
   const CatalogRelation &build_relation_;
   const CatalogRelation &probe_relation_;
   const bool probe_relation_is_stored_;
@@ -793,8 +817,13 @@ class HashInnerJoinWorkOrder : public WorkOrder {
         selection_(selection), is_selection_on_build_(is_selection_on_build), join_type_(join_type),
         hash_table_(hash_table), output_destination_(output_destination), storage_manager_(storage_manager) {}
   void execute() override;  // HashJoinOperator.cpp:450-541 (inner), :680-877 (semi / anti), :960-1099 (outer)
+  // A run of probe blocks (HashJoinOperator::setBlocksPerWorkOrder): lookup_block_id is the first of them.
+  void setRun(std::vector<block_id> &&probe_block_ids) { run_block_ids_ = std::move(probe_block_ids); }
 
  private:
+  void executeBlock(block_id probe_block_id);
+  bool executeRun();          // false: the run form does not cover this join
+  std::vector<block_id> run_block_ids_;
   std::unique_ptr<LIPFilterAdaptiveProber> lip_filter_adaptive_prober_;
   const CatalogRelation &build_relation_;
   const CatalogRelation &probe_relation_;

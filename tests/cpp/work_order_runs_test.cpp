@@ -1,0 +1,183 @@
+// Work orders over runs of blocks (SelectOperator / HashJoinOperator / AggregationOperator::setBlocksPerWorkOrder): the
+// operator decides how many blocks a work order covers (relational_operators/RelationalOperator.hpp:117-119; the
+// reference makes one per block, SelectOperator.cpp:83-150, HashJoinOperator.cpp:203-260).  The run forms must give the
+// tuples of the block-by-block forms — the same multiset for the join, the same sequence for the select (output order =
+// block order, row order) — including the shapes the run form hands back to the per-block path (a nullable attribute).
+#include <algorithm>
+#include <chrono>
+#include <random>
+
+#include "test_util.hpp"
+
+using namespace quickstep;
+
+namespace {
+constexpr int kBlocks = 150;
+constexpr std::int64_t kBlockRows = 40000;       // ragged: block b holds kBlockRows - 13 * (b % 7) rows, block 5 none
+
+struct Lineitem {
+  CatalogRelation rel{1, "lineitem"};
+  std::vector<std::int32_t> orderkey, quantity;
+  std::vector<double> price;
+  std::vector<std::int64_t> block_rows;
+  Lineitem(StorageManager *storage, bool nullable_quantity) {
+    rel.addAttribute("l_orderkey", Type::Int());
+    rel.addAttribute("l_quantity", nullable_quantity ? Type::Int().getNullableVersion() : Type::Int());
+    rel.addAttribute("l_extendedprice", Type::Double());
+    std::mt19937_64 rng(11);
+    for (int b = 0; b < kBlocks; ++b) {
+      const std::int64_t n = b == 5 ? 0 : kBlockRows - 13 * (b % 7);
+      std::vector<std::int32_t> k(n), q(n);
+      std::vector<double> p(n);
+      for (std::int64_t i = 0; i < n; ++i) {
+        k[i] = static_cast<std::int32_t>(rng() % 300000);
+        q[i] = static_cast<std::int32_t>(rng() % 50) + 1;
+        p[i] = static_cast<double>(rng() % 10000000) / 100.0;
+      }
+      std::vector<std::uint64_t> nulls(static_cast<std::size_t>((n + 63) / 64) + 1, 0);
+      for (std::int64_t i = 0; i < n; i += 17) nulls[i >> 6] |= 1ull << (63 - (i & 63));
+      const std::vector<const std::uint64_t *> null_bitmaps = {nullptr, nullable_quantity ? nulls.data() : nullptr, nullptr};
+      storage->loadBlock(&rel, {k.data(), q.data(), p.data()}, n, 0, nullptr, &null_bitmaps);
+      orderkey.insert(orderkey.end(), k.begin(), k.end());
+      quantity.insert(quantity.end(), q.begin(), q.end());
+      price.insert(price.end(), p.begin(), p.end());
+      block_rows.push_back(n);
+    }
+  }
+};
+
+struct Rows {
+  std::vector<std::int32_t> key;
+  std::vector<double> price;
+};
+
+Rows collect(QueryContext &ctx, QueryContext::insert_destination_id dest, StorageManager &storage, std::size_t *blocks_out) {
+  Rows r;
+  const std::vector<block_id> touched = ctx.getInsertDestination(dest)->getTouchedBlocks();
+  *blocks_out = touched.size();
+  for (block_id b : touched) {
+    BlockReference blk = storage.getBlock(b);
+    const std::size_t at = r.key.size(), k = static_cast<std::size_t>(blk->numTuples());
+    r.key.resize(at + k);
+    r.price.resize(at + k);
+    if (k == 0) continue;
+    blk->copyAttributeToHost(0, r.key.data() + at);
+    blk->copyAttributeToHost(1, r.price.data() + at);
+  }
+  return r;
+}
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// select l_orderkey, l_extendedprice from lineitem where l_quantity < 24 and l_extendedprice >= 20000.0
+Rows runSelect(bool nullable_quantity, std::size_t blocks_per_order, std::size_t *out_blocks, double *ms) {
+  StorageManager storage;
+  Lineitem li(&storage, nullable_quantity);
+  CatalogRelation out(2, "selected");
+  out.addAttribute("l_orderkey", Type::Int());
+  out.addAttribute("l_extendedprice", Type::Double());
+  QueryContext ctx;
+  Predicate p;
+  p.conjuncts.push_back(ComparisonPredicate(1, ComparisonID::kLess, TypedLiteral::Int(24)));
+  p.conjuncts.push_back(ComparisonPredicate(2, ComparisonID::kGreaterOrEqual, TypedLiteral::Double(20000.0)));
+  const auto pred = ctx.addPredicate(p);
+  const auto dest = ctx.addInsertDestination(&out, &storage);
+  SelectOperator op(0, li.rel, false, out, dest, pred, std::vector<attribute_id>{0, 2}, true);
+  op.setBlocksPerWorkOrder(blocks_per_order);
+  const double t0 = now_ms();
+  fetchAndExecuteWorkOrders(&op, &ctx, &storage);
+  *ms = now_ms() - t0;
+  Rows got = collect(ctx, dest, storage, out_blocks);
+  // the oracle is plain arithmetic here
+  Rows want;
+  std::size_t row = 0;
+  for (std::int64_t n : li.block_rows) {
+    for (std::int64_t i = 0; i < n; ++i, ++row) {
+      const bool is_null = nullable_quantity && i % 17 == 0;
+      if (!is_null && li.quantity[row] < 24 && li.price[row] >= 20000.0) {
+        want.key.push_back(li.orderkey[row]);
+        want.price.push_back(li.price[row]);
+      }
+    }
+  }
+  EXPECT_EQ(got.key.size(), want.key.size());
+  EXPECT_TRUE(got.key == want.key);        // block order, row order
+  EXPECT_TRUE(got.price == want.price);
+  return got;
+}
+
+// select l_orderkey [build side: o_orderkey], l_extendedprice from orders join lineitem on o_orderkey = l_orderkey,
+// orders = the even keys below 200000, each once, in 40 blocks
+Rows runJoin(bool exact_stats, std::size_t blocks_per_order, std::size_t *out_blocks, double *ms) {
+  StorageManager storage;
+  Lineitem li(&storage, false);
+  CatalogRelation orders(3, "orders");
+  orders.addAttribute("o_orderkey", Type::Int());
+  std::vector<std::int32_t> okeys;
+  for (std::int32_t k = 0; k < 200000; k += 2) okeys.push_back(k);
+  std::shuffle(okeys.begin(), okeys.end(), std::mt19937_64(3));
+  for (std::size_t at = 0; at < okeys.size(); at += 2500) storage.loadBlock(&orders, {okeys.data() + at}, 2500);
+  CatalogRelation out(4, "joined");
+  out.addAttribute("o_orderkey", Type::Int());
+  out.addAttribute("l_extendedprice", Type::Double());
+  QueryContext ctx;
+  const QueryContext::ExactKeyRange range{0, 199998};
+  const auto table = ctx.addJoinHashTable(kInt, 100000, 1, exact_stats ? &range : nullptr);
+  const auto dest = ctx.addInsertDestination(&out, &storage);
+  const auto selection = ctx.addScalarGroup({0, 2});
+  const std::vector<bool> on_build = {true, false};
+  BuildHashOperator builder(0, orders, true, {0}, false, 1, table);
+  HashJoinOperator prober(0, orders, li.rel, true, {0}, false, 1, false, out, dest, table, QueryContext::kInvalidPredicateId, selection,
+                          &on_build, HashJoinOperator::JoinType::kInnerJoin);
+  prober.setBlocksPerWorkOrder(blocks_per_order);
+  fetchAndExecuteWorkOrders(&builder, &ctx, &storage);
+  const double t0 = now_ms();
+  fetchAndExecuteWorkOrders(&prober, &ctx, &storage);
+  *ms = now_ms() - t0;
+  Rows got = collect(ctx, dest, storage, out_blocks);
+  std::vector<std::pair<std::int32_t, double>> g, w;
+  for (std::size_t i = 0; i < got.key.size(); ++i) g.emplace_back(got.key[i], got.price[i]);
+  for (std::size_t i = 0; i < li.orderkey.size(); ++i) {
+    if (li.orderkey[i] < 200000 && (li.orderkey[i] & 1) == 0) w.emplace_back(li.orderkey[i], li.price[i]);
+  }
+  std::sort(g.begin(), g.end());
+  std::sort(w.begin(), w.end());
+  EXPECT_EQ(g.size(), w.size());
+  EXPECT_TRUE(g == w);
+  return got;
+}
+}  // namespace
+
+int main() {
+  if (qsx_device_count() < 1) {
+    std::fprintf(stderr, "work_order_runs_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
+    return 2;
+  }
+  std::size_t blocks_one = 0, blocks_run = 0;
+  double ms_one = 0, ms_run = 0;
+  for (int rep = 0; rep < 2; ++rep) {   // second repetition: warm allocator / modules
+    runSelect(false, 1, &blocks_one, &ms_one);
+    runSelect(false, 64, &blocks_run, &ms_run);
+  }
+  EXPECT_EQ(blocks_one, static_cast<std::size_t>(kBlocks));
+  EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));      // one output block per run
+  std::printf("select over %d blocks of ~%lld rows: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n", kBlocks,
+              static_cast<long long>(kBlockRows), ms_one, ms_run);
+  // a nullable predicate attribute: the run work order executes its blocks one by one
+  runSelect(true, 1, &blocks_one, &ms_one);
+  runSelect(true, 64, &blocks_run, &ms_run);
+  EXPECT_EQ(blocks_run, static_cast<std::size_t>(kBlocks));
+  for (const bool exact_stats : {true, false}) {
+    for (int rep = 0; rep < 2; ++rep) {
+      runJoin(exact_stats, 1, &blocks_one, &ms_one);
+      runJoin(exact_stats, 64, &blocks_run, &ms_run);
+    }
+    EXPECT_EQ(blocks_one, static_cast<std::size_t>(kBlocks));
+    EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
+    std::printf("hash join (%s table) probing %d blocks: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n",
+                exact_stats ? "directly addressed" : "hashed", kBlocks, ms_one, ms_run);
+  }
+  return finish("work_order_runs_test");
+}

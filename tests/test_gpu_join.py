@@ -453,6 +453,7 @@ def test_probe_over_a_run_of_blocks_equals_block_by_block(capi, oracle, dev, fla
                                                filters=dfilters if use_filters else None)
                 k = int(cnt.item())
                 assert k == want_p.size, (shape, use_filters, two_pass)
+                assert int(table.probe_count_blocks(dblocks, filters=dfilters if use_filters else None).item()) == k
                 assert np.array_equal(sorted_pairs(p.cpu().numpy()[:k], b.cpu().numpy()[:k]), sorted_pairs(want_p, want_b))
         monkeypatch.delenv("QSX_JOIN_TWO_PASS")
         for anti in (False, True):

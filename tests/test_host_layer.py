@@ -14,7 +14,7 @@ def _ensure_built():
     if not all(os.path.exists(os.path.join(BIN, b)) for b in
                ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
                 "lip_filter_operator_test", "compressed_block_operator_test", "host_logic_test",
-                "sort_operator_test", "nullable_operator_test", "tpch_types_operator_test", "tpch_q3_plan_test")):
+                "sort_operator_test", "nullable_operator_test", "tpch_types_operator_test", "tpch_q3_plan_test", "work_order_runs_test")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -97,3 +97,12 @@ def test_tpch_q3_as_one_query_plan():
     BuildHash / HashJoin pairs, Aggregation over a 16-byte key with an expression argument, Finalize, SortRunGeneration,
     SortMergeRun with LIMIT 10 — streaming edges and pipeline breakers included."""
     _run("tpch_q3_plan_test")
+
+
+@pytest.mark.gpu
+def test_work_orders_over_runs_of_blocks():
+    """SelectOperator / HashJoinOperator::setBlocksPerWorkOrder: a work order per run of blocks gives the tuples of a work
+    order per block (select: same sequence, one output block per run; join: same multiset), and shapes the run form does
+    not cover are executed block by block inside the work order."""
+    out = _run("work_order_runs_test")
+    assert "per run of 64 blocks" in out
