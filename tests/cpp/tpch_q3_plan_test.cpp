@@ -70,14 +70,10 @@ void loadBlocks(StorageManager *storage, CatalogRelation *rel, std::int64_t rows
     storage->loadBlock(rel, ptrs, std::min<std::int64_t>(kBlock, rows - at));
   }
 }
-}  // namespace
 
-int main() {
-  if (qsx_device_count() < 1) {
-    std::fprintf(stderr, "tpch_q3_plan_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
-    return 2;
-  }
-  const Db db;
+// blocks_per_work_order > 1: Select, HashJoin and Aggregation work orders cover runs of the blocks that have arrived
+// (setBlocksPerWorkOrder) — streaming edges deliver blocks one by one, so runs of every length up to the limit occur.
+void runQ3(const Db &db, std::size_t blocks_per_work_order) {
   const std::int64_t lines = static_cast<std::int64_t>(db.l_orderkey.size());
   StorageManager storage;
   CatalogRelation customer(1, "customer"), orders(2, "orders"), lineitem(3, "lineitem");
@@ -150,18 +146,27 @@ int main() {
   const auto sort_config = ctx.addSortConfig({{3, 1}, {false, true}});   // revenue DESC, o_orderdate ASC
 
   QueryPlan plan;
-  const auto s_cust = plan.addRelationalOperator(new SelectOperator(0, customer, false, cust_sel, d_cust, pid_cust, std::vector<attribute_id>{0}, true));
+  SelectOperator *op_s_cust = new SelectOperator(0, customer, false, cust_sel, d_cust, pid_cust, std::vector<attribute_id>{0}, true);
+  SelectOperator *op_s_ord = new SelectOperator(0, orders, false, ord_sel, d_ord, pid_ord, std::vector<attribute_id>{0, 1, 2, 3}, true);
+  SelectOperator *op_s_line = new SelectOperator(0, lineitem, false, li_sel, d_li, pid_line, std::vector<attribute_id>{0, 1, 2}, true);
+  HashJoinOperator *op_j_ord = new HashJoinOperator(0, cust_sel, ord_sel, false, {1}, false, 1, false, ord_join, d_ordjoin, t_cust,
+                                                    QueryContext::kInvalidPredicateId, sel_ord, &sel_ord_on_build,
+                                                    HashJoinOperator::JoinType::kInnerJoin);
+  HashJoinOperator *op_j_line = new HashJoinOperator(0, ord_join, li_sel, false, {0}, false, 1, false, joined, d_joined, t_ord,
+                                                     QueryContext::kInvalidPredicateId, sel_joined, &sel_joined_on_build,
+                                                     HashJoinOperator::JoinType::kInnerJoin);
+  AggregationOperator *op_agg = new AggregationOperator(0, joined, false, state);
+  for (SelectOperator *op : {op_s_cust, op_s_ord, op_s_line}) op->setBlocksPerWorkOrder(blocks_per_work_order);
+  for (HashJoinOperator *op : {op_j_ord, op_j_line}) op->setBlocksPerWorkOrder(blocks_per_work_order);
+  op_agg->setBlocksPerWorkOrder(blocks_per_work_order);
+  const auto s_cust = plan.addRelationalOperator(op_s_cust);
   const auto b_cust = plan.addRelationalOperator(new BuildHashOperator(0, cust_sel, false, {0}, false, 1, t_cust));
-  const auto s_ord = plan.addRelationalOperator(new SelectOperator(0, orders, false, ord_sel, d_ord, pid_ord, std::vector<attribute_id>{0, 1, 2, 3}, true));
-  const auto j_ord = plan.addRelationalOperator(new HashJoinOperator(0, cust_sel, ord_sel, false, {1}, false, 1, false, ord_join, d_ordjoin, t_cust,
-                                                                     QueryContext::kInvalidPredicateId, sel_ord, &sel_ord_on_build,
-                                                                     HashJoinOperator::JoinType::kInnerJoin));
+  const auto s_ord = plan.addRelationalOperator(op_s_ord);
+  const auto j_ord = plan.addRelationalOperator(op_j_ord);
   const auto b_ord = plan.addRelationalOperator(new BuildHashOperator(0, ord_join, false, {0}, false, 1, t_ord));
-  const auto s_line = plan.addRelationalOperator(new SelectOperator(0, lineitem, false, li_sel, d_li, pid_line, std::vector<attribute_id>{0, 1, 2}, true));
-  const auto j_line = plan.addRelationalOperator(new HashJoinOperator(0, ord_join, li_sel, false, {0}, false, 1, false, joined, d_joined, t_ord,
-                                                                      QueryContext::kInvalidPredicateId, sel_joined, &sel_joined_on_build,
-                                                                      HashJoinOperator::JoinType::kInnerJoin));
-  const auto agg = plan.addRelationalOperator(new AggregationOperator(0, joined, false, state));
+  const auto s_line = plan.addRelationalOperator(op_s_line);
+  const auto j_line = plan.addRelationalOperator(op_j_line);
+  const auto agg = plan.addRelationalOperator(op_agg);
   const auto fin = plan.addRelationalOperator(new FinalizeAggregationOperator(0, state, 1, false, 1, agg_out, d_agg));
   const auto gen = plan.addRelationalOperator(new SortRunGenerationOperator(0, agg_out, runs, d_runs, sort_config, false));
   const auto merge = plan.addRelationalOperator(new SortMergeRunOperator(0, runs, top, d_top, runs, d_runs, sort_config, 4, /*top_k=*/10, false));
@@ -225,5 +230,16 @@ int main() {
     EXPECT_EQ(got[i].prio, want[i].prio);
     EXPECT_NEAR(got[i].revenue, want[i].revenue, 1e-9 * want[i].revenue);
   }
+}
+}  // namespace
+
+int main() {
+  if (qsx_device_count() < 1) {
+    std::fprintf(stderr, "tpch_q3_plan_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
+    return 2;
+  }
+  const Db db;
+  runQ3(db, 1);
+  runQ3(db, 4);     // work orders over runs of up to four blocks
   return finish("tpch_q3_plan_test");
 }
