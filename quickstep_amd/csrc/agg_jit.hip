@@ -5,6 +5,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <unistd.h>
 #include <map>
 #include <vector>
 #include <thread>
@@ -180,27 +183,106 @@ void join_compile_threads() {
   }
 }
 
-JitKernel *compile(const std::string &source) {
+// ---- the code objects on disk (QSX_JIT_CACHE_DIR) ---------------------------------------------------------------------
+// hipRTC takes 1-2 s per plan shape — longer than most queries run — so within one process a new shape is served by the
+// interpreter kernel until its compile finishes.  A server that sees the same plan shapes after every restart sets
+// QSX_JIT_CACHE_DIR: code objects are kept there, one file per (compiler version, source text), and a shape found on
+// disk is loaded before the first update call returns.  A file holds the full source text in front of the code object
+// and is only used when that text matches (the file name is a hash); files are written to a temporary name and renamed,
+// so concurrent processes see whole files or none.  Unset (the default): no file is read or written.
+constexpr char kCacheMagic[8] = {'Q', 'S', 'X', 'J', 'I', 'T', '0', '1'};
+std::string cache_stamp() {
+  int major = 0, minor = 0;
+  (void)hiprtcVersion(&major, &minor);
+  return "hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics\n";
+}
+std::string cache_path(const std::string &stamped_source) {
+  const char *dir = getenv("QSX_JIT_CACHE_DIR");
+  if (dir == nullptr || dir[0] == '\0') return std::string();
+  unsigned long long h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;   // two FNV-1a walks with different offsets
+  for (unsigned char c : stamped_source) {
+    h1 = (h1 ^ c) * 0x100000001b3ull;
+    h2 = (h2 ^ (c + 0x9Eu)) * 0x100000001b3ull;
+  }
+  char name[64];
+  std::snprintf(name, sizeof(name), "/qsx_%016llx%016llx.hsaco", h1, h2);
+  return std::string(dir) + name;
+}
+bool load_cached_code(const std::string &source, std::string *code) {
+  const std::string stamped = cache_stamp() + source;
+  const std::string path = cache_path(stamped);
+  if (path.empty()) return false;
+  FILE *f = std::fopen(path.c_str(), "rb");
+  if (f == nullptr) return false;
+  bool ok = false;
+  char magic[8];
+  unsigned long long source_len = 0, code_len = 0;
+  if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, kCacheMagic, 8) == 0 && std::fread(&source_len, 8, 1, f) == 1 &&
+      std::fread(&code_len, 8, 1, f) == 1 && source_len == stamped.size() && code_len > 0 && code_len < (1ull << 30)) {
+    std::string text(source_len, '\0');
+    code->assign(code_len, '\0');
+    ok = std::fread(&text[0], 1, source_len, f) == source_len && text == stamped &&
+         std::fread(&(*code)[0], 1, code_len, f) == code_len;
+  }
+  std::fclose(f);
+  return ok;
+}
+void store_cached_code(const std::string &source, const std::string &code) {
+  const std::string stamped = cache_stamp() + source;
+  const std::string path = cache_path(stamped);
+  if (path.empty()) return;
+  char suffix[48];
+  std::snprintf(suffix, sizeof(suffix), ".tmp.%ld.%llx", static_cast<long>(getpid()),
+                static_cast<unsigned long long>(std::hash<std::thread::id>()(std::this_thread::get_id())));
+  const std::string tmp = path + suffix;
+  FILE *f = std::fopen(tmp.c_str(), "wb");
+  if (f == nullptr) return;                       // an unwritable directory only costs the next process a compile
+  const unsigned long long source_len = stamped.size(), code_len = code.size();
+  const bool ok = std::fwrite(kCacheMagic, 1, 8, f) == 8 && std::fwrite(&source_len, 8, 1, f) == 1 && std::fwrite(&code_len, 8, 1, f) == 1 &&
+                  std::fwrite(stamped.data(), 1, stamped.size(), f) == stamped.size() &&
+                  std::fwrite(code.data(), 1, code.size(), f) == code.size();
+  if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+
+// Source text -> gfx950 code object: from QSX_JIT_CACHE_DIR when it is there, else hipRTC (and then into the directory).
+// log (optional) receives the compiler's messages on failure.
+bool compile_to_code(const std::string &source, std::string *code, std::string *log) {
+  if (load_cached_code(source, code)) return true;
   hiprtcProgram prog = nullptr;
-  if (hiprtcCreateProgram(&prog, source.c_str(), "qsx_jit_agg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return nullptr;
+  if (hiprtcCreateProgram(&prog, source.c_str(), "qsx_jit_agg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
                         "-mllvm", "-amdgpu-internalize-symbols"};   // the last two: what hipcc passes for device code
   const hiprtcResult rc = hiprtcCompileProgram(prog, 7, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t log_size = 0;
     hiprtcGetProgramLogSize(prog, &log_size);
-    std::string log(log_size, '\0');
-    if (log_size != 0) hiprtcGetProgramLog(prog, &log[0]);
-    std::fprintf(stderr, "[qsx] run-time plan shape: hipRTC failed (%s); the interpreter kernel is used.\n%.2000s\n",
-                 hiprtcGetErrorString(rc), log.c_str());
+    std::string text(log_size, '\0');
+    if (log_size != 0) hiprtcGetProgramLog(prog, &text[0]);
+    if (log != nullptr) *log = std::string(hiprtcGetErrorString(rc)) + "\n" + text;
     hiprtcDestroyProgram(&prog);
-    return nullptr;
+    return false;
   }
   size_t code_size = 0;
   hiprtcGetCodeSize(prog, &code_size);
-  std::string code(code_size, '\0');
-  hiprtcGetCode(prog, &code[0]);
+  code->assign(code_size, '\0');
+  hiprtcGetCode(prog, &(*code)[0]);
   hiprtcDestroyProgram(&prog);
+  store_cached_code(source, *code);
+  return true;
+}
+
+JitKernel *load_code(const std::string &code);
+
+JitKernel *compile(const std::string &source) {
+  std::string code, log;
+  if (!compile_to_code(source, &code, &log)) {
+    std::fprintf(stderr, "[qsx] run-time plan shape: hipRTC failed; the interpreter kernel is used.\n%.2000s\n", log.c_str());
+    return nullptr;
+  }
+  return load_code(code);
+}
+
+JitKernel *load_code(const std::string &code) {
   JitKernel *k = new JitKernel();
   if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
       hipModuleGetFunction(&k->function, k->module, "qsx_jit_agg") != hipSuccess) {
@@ -239,7 +321,14 @@ JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, cons
       r = new JitRequest();
       cache().emplace(key, r);
       mine = true;
-      if (!synchronous) {
+      std::string cached;
+      if (!synchronous && load_cached_code(source, &cached)) {
+        // on disk (QSX_JIT_CACHE_DIR): a file read and a module load, milliseconds — ready before the first launch
+        JitKernel *k = load_code(cached);
+        r->kernel = k;
+        r->state.store(k != nullptr ? 1 : -1, std::memory_order_release);
+        mine = false;
+      } else if (!synchronous) {
         // hipRTC takes 1-2 s: the caller keeps using the interpreter kernel and picks the shape up when it is ready
         static bool hooked = false;
         if (!hooked) {
@@ -323,30 +412,19 @@ extern "C" int qsx_debug_jit_compile(const qsx_agg_config_t *config, int with_fi
       std::fclose(f);
     }
   }
-  hiprtcProgram prog = nullptr;
-  if (hiprtcCreateProgram(&prog, source.c_str(), "qsx_jit_agg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return QSX_ERR_HIP;
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
-                        "-mllvm", "-amdgpu-internalize-symbols"};   // the last two: what hipcc passes for device code
-  const hiprtcResult rc = hiprtcCompileProgram(prog, 7, opts);
-  size_t code_size = 0;
-  if (rc == HIPRTC_SUCCESS) {
-    hiprtcGetCodeSize(prog, &code_size);
+  std::string code, log;
+  const bool compiled = compile_to_code(source, &code, &log);
+  const size_t code_size = code.size();
+  if (compiled) {
     if (const char *dump = getenv("QSX_JIT_DUMP_CODE")) {   // the code object, for llvm-objdump / llvm-readelf --notes
-      std::string code(code_size, '\0');
-      hiprtcGetCode(prog, &code[0]);
       if (FILE *f = std::fopen(dump, "wb")) {
         std::fwrite(code.data(), 1, code.size(), f);
         std::fclose(f);
       }
     }
   } else {
-    size_t log_size = 0;
-    hiprtcGetProgramLogSize(prog, &log_size);
-    std::string log(log_size, '\0');
-    if (log_size != 0) hiprtcGetProgramLog(prog, &log[0]);
     std::fprintf(stderr, "%.4000s\n", log.c_str());
   }
-  hiprtcDestroyProgram(&prog);
   if (out_code_bytes != nullptr) *out_code_bytes = code_size;
-  return rc == HIPRTC_SUCCESS ? QSX_OK : QSX_ERR_HIP;
+  return compiled ? QSX_OK : QSX_ERR_HIP;
 }

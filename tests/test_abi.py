@@ -85,3 +85,39 @@ def test_run_time_plan_shape_generator_compiles_without_a_gpu(capi):
         size = C.c_size_t(0)
         assert fn(C.byref(cfg), with_filter, C.byref(size)) == 0
         assert size.value > 1000
+
+
+def test_plan_shape_code_objects_are_kept_in_the_cache_directory(capi, tmp_path, monkeypatch):
+    """QSX_JIT_CACHE_DIR: the first build of a plan shape leaves one file there (source text + code object), the second
+    takes the code object from it (same bytes, no compile); a damaged or foreign file is ignored and replaced."""
+    import ctypes as C
+    import time
+    from quickstep_amd import types as T
+    fn = capi.lib.qsx_debug_jit_compile
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(T.AggConfig), C.c_int, C.POINTER(C.c_size_t)]
+    layout = [(T.INT, None), (T.DOUBLE, None)]
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None)])
+    monkeypatch.setenv("QSX_JIT_CACHE_DIR", str(tmp_path))
+    size = C.c_size_t(0)
+    t0 = time.perf_counter()
+    assert fn(C.byref(cfg), 0, C.byref(size)) == 0
+    compile_s = time.perf_counter() - t0
+    files = sorted(p for p in tmp_path.iterdir())
+    assert len(files) == 1 and files[0].name.startswith("qsx_") and files[0].suffix == ".hsaco"
+    blob = files[0].read_bytes()
+    assert blob[:8] == b"QSXJIT01" and b"qsx_jit_agg" in blob and len(blob) > size.value
+    first = size.value
+    t0 = time.perf_counter()
+    assert fn(C.byref(cfg), 0, C.byref(size)) == 0
+    cached_s = time.perf_counter() - t0
+    assert size.value == first and cached_s < compile_s / 3, (compile_s, cached_s)
+    assert sorted(p for p in tmp_path.iterdir()) == files
+    # another plan shape: another file
+    other = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], aggs=[(T.AGG_MIN, T.col(1))])
+    assert fn(C.byref(other), 0, C.byref(size)) == 0
+    assert len(list(tmp_path.iterdir())) == 2
+    # a truncated file is not trusted: recompiled and rewritten whole
+    files[0].write_bytes(blob[:len(blob) // 2])
+    assert fn(C.byref(cfg), 0, C.byref(size)) == 0 and size.value == first
+    assert files[0].read_bytes() == blob

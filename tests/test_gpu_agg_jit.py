@@ -120,3 +120,59 @@ def test_background_compile_does_not_stall_and_takes_over(capi, oracle, dev, mon
     o.update([key, val, odd])
     assert_same_groups(finalize_np(st, dev), o.finalize())
     assert first_call < 0.5 or blocks == 1, f"the triggering update stalled for {first_call:.2f} s"
+
+
+_CACHE_SCRIPT = r"""
+import ctypes, json, sys, time
+import numpy as np, torch
+import quickstep_amd.capi as capi
+from quickstep_amd import types as T
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(7)
+n = 200_000
+key = rng.integers(0, 23, size=n).astype(np.int32)
+val = rng.integers(0, 1000, size=n).astype(np.float64)
+cfg = T.make_agg_config(T.AGG_COMPACT_KEY, [(T.INT, None), (T.DOUBLE, None)], keys=[0],
+                        instrs=[(T.EX_MUL, 0, T.col(1), T.const(0))], consts=[1.5],
+                        aggs=[(T.AGG_SUM, T.temp(0)), (T.AGG_COUNT_STAR, None)], est_groups=64)
+state_of = capi.lib.qsx_debug_agg_jit_state
+state_of.restype = ctypes.c_int
+st = capi.AggState(cfg)
+cols = [torch.from_numpy(key).to(dev), torch.from_numpy(val).to(dev)]
+st.update(cols, n)
+after_first = state_of(st._h, 0)
+deadline = time.time() + 60
+while state_of(st._h, 0) == 0 and time.time() < deadline:
+    time.sleep(0.05)
+st.update(cols, n)
+keys, vals, nulls, groups = st.finalize(dev, capacity=64)
+g = int(groups.item())
+order = torch.argsort(keys[0][:g])
+print(json.dumps({"after_first_update": after_first, "final": state_of(st._h, 0),
+                  "sums": [float(x) for x in vals[0][:g][order].cpu()], "keys": [int(x) for x in keys[0][:g][order].cpu()]}))
+"""
+
+
+def test_plan_shape_from_the_cache_directory_serves_the_first_update(tmp_path):
+    """QSX_JIT_CACHE_DIR across processes: the first process compiles the shape in the background (its first update runs on the
+    interpreter) and leaves the code object on disk; the second process loads it before its first update returns.  Both
+    give the same sums (integer-valued doubles: exact in any order)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, QSX_JIT_CACHE_DIR=str(tmp_path), QSX_AGG_JIT_MIN_ROWS="1000")
+    env.pop("QSX_AGG_JIT_SYNC", None)
+    env.pop("QSX_AGG_NO_SPECIALIZE", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", _CACHE_SCRIPT], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert runs[0]["final"] == 1 and runs[1]["final"] == 1
+    assert runs[0]["after_first_update"] in (0, 1)
+    assert runs[1]["after_first_update"] == 1, "the cached code object was not picked up before the first update returned"
+    assert len([p for p in tmp_path.iterdir() if p.suffix == ".hsaco"]) >= 1
+    assert runs[0]["keys"] == runs[1]["keys"] == list(range(23)) and runs[0]["sums"] == runs[1]["sums"]
