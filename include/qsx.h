@@ -365,6 +365,13 @@ int qsx_join_table_size(qsx_join_table_t *table, int64_t *out_entries, qsx_strea
 int qsx_join_build(qsx_join_table_t *table, const void *keys_dev, int64_t n,
                    int32_t base_tid, const uint64_t *filter_dev, qsx_stream_t stream);
 
+/* K3 over a run of build blocks in one launch: num_blocks calls of qsx_join_build (block b with base_tid =
+ * block_base_tids[b], its own key stripe and filter) as one.  BuildHashOperator makes one BuildHashWorkOrder per block
+ * (relational_operators/BuildHashOperator.cpp:70-130); how many blocks a work order covers is the operator's decision
+ * (RelationalOperator.hpp:117-119).  Host arrays are consumed before return; may synchronise when the table grows. */
+int qsx_join_build_blocks(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                          const int32_t *block_base_tids, const uint64_t *const *block_filters, qsx_stream_t stream);
+
 /* K4.  Inner-join probe: for every probe row i < n (set in filter) and every
  * table entry with an equal key, emit (probe_base_tid + i, build_tid).
  * Replaces HashTable::getAllFromValueAccessorImpl (storage/HashTable.hpp:

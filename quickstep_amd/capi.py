@@ -88,6 +88,7 @@ _SIGNATURES = {
     "qsx_join_table_size": (_int, [_vp, C.POINTER(_i64), _vp]),
     "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_join_build_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp]),
     "qsx_join_probe_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_probe_count_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _vp, _vp]),
     "qsx_join_probe_exists_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _int, _pp, _vp, _vp]),
@@ -488,6 +489,17 @@ class JoinTable:
     def build(self, keys, base_tid=0, filter_bitmap=None, stream=None):
         _check(_lib.qsx_join_build(self._h, _ptr(keys), keys.numel(), base_tid, _ptr(filter_bitmap),
                                    _stream(stream)), "qsx_join_build")
+
+    def build_blocks(self, key_blocks, base_tids, filters=None, stream=None):
+        """K3 over a run of build blocks in one launch."""
+        nb = len(key_blocks)
+        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
+        bptr = (C.c_int32 * max(nb, 1))(*base_tids)
+        fptr = None
+        if filters is not None:
+            fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        _check(_lib.qsx_join_build_blocks(self._h, nb, rows, kptr, bptr, fptr, _stream(stream)), "qsx_join_build_blocks")
 
     def probe(self, keys, capacity=None, probe_base_tid=0, filter_bitmap=None, out=None, stream=None):
         """K4: returns (probe_tid int32[capacity], build_tid int32[capacity], count int64[1])."""

@@ -112,6 +112,31 @@ __global__ __launch_bounds__(kJBlock) void build_kernel(TableView t, const KeyT 
   inserted = wave_reduce_add(inserted);
   if (lane_id() == 0 && inserted != 0) atomicAdd(entries, inserted);
 }
+// The build side as a run of blocks (qsx_join_build_blocks): a wave takes groups of kBuildTile rows of ONE block.
+template <typename KeyT>
+__global__ __launch_bounds__(kJBlock) void build_runs_kernel(TableView t, const long long *__restrict__ runs,
+                                                            unsigned long long *__restrict__ entries) {
+  unsigned long long inserted = 0;
+  const int lane = lane_id();
+  const int num_groups = static_cast<int>(runs[2]);
+  for (int group = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (kJBlock / kWave) + (threadIdx.x >> 6)));
+       group < num_groups; group += static_cast<int>(gridDim.x) * (kJBlock / kWave)) {
+    const RunTile at = run_locate(runs, group);
+    const KeyT *keys = run_in<KeyT>(runs, at.block);
+    const uint64_t *filter = run_filter(runs, at.block);
+    const int64_t n = run_rows(runs, at.block);
+    const uint32_t base_tid = static_cast<uint32_t>(run_base(runs, at.block));
+#pragma unroll 2
+    for (int r = 0; r < kBuildR; ++r) {
+      const int64_t i = static_cast<int64_t>(at.tile_in_block) * kBuildTile + r * kWave + lane;
+      if (i >= n || !row_in_filter(filter, i)) continue;
+      insert_entry(t, keys[i], base_tid + static_cast<uint32_t>(i));
+      ++inserted;
+    }
+  }
+  inserted = wave_reduce_add(inserted);
+  if (lane == 0 && inserted != 0) atomicAdd(entries, inserted);
+}
 
 // Re-insert every entry of an old table into a bigger one (resize).
 __global__ __launch_bounds__(kJBlock) void rehash_kernel(int is_long, TableView src, TableView dst) {
@@ -692,6 +717,57 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   } else {
     hipLaunchKernelGGL(build_kernel<int64_t>, dim3(grid), dim3(kJBlock), 0, as_stream(stream), t->view(),
                        static_cast<const int64_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev);
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                          const int32_t *block_base_tids, const uint64_t *const *block_filters, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr || block_base_tids == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  std::vector<int64_t> base(static_cast<size_t>(num_blocks));
+  int64_t total = 0;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0 || (block_rows[b] > 0 && block_keys[b] == nullptr) || block_base_tids[b] < 0 ||
+        static_cast<int64_t>(block_base_tids[b]) + block_rows[b] > INT32_MAX) {
+      return QSX_ERR_INVALID_ARGUMENT;
+    }
+    base[b] = block_base_tids[b];
+    total += block_rows[b];
+  }
+  if (total == 0) return QSX_OK;
+  int rc = ensure_room(t, total);
+  if (rc != QSX_OK) return rc;
+  hipStream_t s = as_stream(stream);
+  std::vector<long long> table;
+  const long long groups = build_run_table(kBuildTile, num_blocks, block_rows, block_keys,
+                                           reinterpret_cast<const void *const *>(block_filters), nullptr, base.data(), &table);
+  if (groups < 0) return QSX_ERR_INVALID_ARGUMENT;
+  const size_t bytes = table.size() * sizeof(long long);
+  const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
+  if (runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  rc = staged_upload(s, table.data(), bytes);
+  if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(t->mutex);
+  if (t->dense) {
+    const int dgrid = grid_for(groups, kDBlock / kWave);
+    if (t->key_type == QSX_INT) {
+      hipLaunchKernelGGL((dense_build_kernel<int32_t, true>), dim3(dgrid), dim3(kDBlock), 0, s, t->dense_view(),
+                         static_cast<const int32_t *>(nullptr), total, 0, static_cast<const uint64_t *>(nullptr), t->entries_dev, runs_dev);
+    } else {
+      hipLaunchKernelGGL((dense_build_kernel<int64_t, true>), dim3(dgrid), dim3(kDBlock), 0, s, t->dense_view(),
+                         static_cast<const int64_t *>(nullptr), total, 0, static_cast<const uint64_t *>(nullptr), t->entries_dev, runs_dev);
+    }
+  } else {
+    const int grid = grid_for(groups, kJBlock / kWave);
+    if (t->key_type == QSX_INT) {
+      hipLaunchKernelGGL(build_runs_kernel<int32_t>, dim3(grid), dim3(kJBlock), 0, s, t->view(), runs_dev, t->entries_dev);
+    } else {
+      hipLaunchKernelGGL(build_runs_kernel<int64_t>, dim3(grid), dim3(kJBlock), 0, s, t->view(), runs_dev, t->entries_dev);
+    }
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;

@@ -59,35 +59,75 @@ __device__ __forceinline__ bool dense_row_in_filter(const uint64_t *filter, int6
   return filter == nullptr || ((filter[row >> 6] >> (63 - (row & 63))) & 1u);
 }
 
+// ---- a tile of a stripe, or of a run of blocks (block_runs.hpp) -----------------------------------------------------------
+template <typename KeyT>
+struct ProbeTileSource {
+  const KeyT *keys;
+  int64_t n;                 // rows of the block
+  int64_t base;              // first row of the tile within the block
+  int32_t base_tid;
+  const uint64_t *filter;
+  uint64_t *out_bitmap;
+};
+template <typename KeyT, int kTileRows, bool kRuns>
+__device__ __forceinline__ ProbeTileSource<KeyT> probe_tile_source(const long long *__restrict__ runs, int64_t tile,
+                                                                   const KeyT *keys, int64_t n, int32_t base_tid,
+                                                                   const uint64_t *filter, uint64_t *out_bitmap) {
+  if (!kRuns) return ProbeTileSource<KeyT>{keys, n, tile * kTileRows, base_tid, filter, out_bitmap};
+  const RunTile at = run_locate(runs, static_cast<int>(tile));
+  return ProbeTileSource<KeyT>{run_in<KeyT>(runs, at.block), run_rows(runs, at.block),
+                               static_cast<int64_t>(at.tile_in_block) * kTileRows, static_cast<int32_t>(run_base(runs, at.block)),
+                               run_filter(runs, at.block), run_out<uint64_t>(runs, at.block)};
+}
+
 // A wave owns groups of kBuildR x 64 rows: filter words with one load per group, next group's keys requested before the
 // current group's head words are claimed (the structure of dense_probe_kernel).
+// kRuns: the build side is a run of blocks (qsx_join_build_blocks): a group belongs to one block and takes its key stripe,
+// row count, filter and base tuple id from the run table.
 constexpr int kBuildR = 8;
-template <typename KeyT>
+constexpr int kBuildTile = kBuildR * kWave;   // rows of a group
+template <typename KeyT, bool kRuns = false>
 __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, const KeyT *__restrict__ keys, int64_t n,
-                                                             int32_t base_tid, const uint64_t *__restrict__ filter,
-                                                             unsigned long long *__restrict__ entries) {
+                                                             int32_t base_tid_arg, const uint64_t *__restrict__ filter,
+                                                             unsigned long long *__restrict__ entries,
+                                                             const long long *__restrict__ runs = nullptr) {
   constexpr int R = kBuildR;
+  using Source = ProbeTileSource<KeyT>;
   const int lane = lane_id();
-  const int64_t num_words = (n + 63) >> 6;
-  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kDBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t num_groups = kRuns ? runs[2] : (((n + 63) >> 6) + R - 1) / R;
+  const int64_t wave = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (kDBlock / kWave) + (threadIdx.x >> 6)));
   const int64_t num_waves = static_cast<int64_t>(gridDim.x) * (kDBlock / kWave);
   unsigned long long inserted = 0;
   KeyT key[R], next_key[R];
   uint64_t words = ~0ull, next_words = ~0ull;
-  auto request = [&](int64_t w0, KeyT (&k)[R], uint64_t &fw) {
+  auto source_of = [&](int64_t group) {
+    return probe_tile_source<KeyT, kBuildTile, kRuns>(runs, group, keys, n, base_tid_arg, filter, nullptr);
+  };
+  auto request = [&](const Source &src, KeyT (&k)[R], uint64_t &fw) {
+    const int64_t sw0 = src.base >> 6;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t row = ((w0 + r) << 6) + lane;
-      k[r] = keys[row < n ? row : n - 1];   // clamped, not guarded: no branch around the read
+      const int64_t row = ((sw0 + r) << 6) + lane;
+      k[r] = src.keys[row < src.n ? row : src.n - 1];   // clamped, not guarded: no branch around the read
     }
     fw = ~0ull;
-    if (filter != nullptr && lane < R && w0 + lane < num_words) fw = filter[w0 + lane];
+    if (src.filter != nullptr && lane < R && sw0 + lane < ((src.n + 63) >> 6)) fw = src.filter[sw0 + lane];
   };
-  int64_t w0 = wave * R;
-  if (w0 < num_words) request(w0, key, words);
-  for (; w0 < num_words; w0 += num_waves * R) {
-    const int64_t w_next = w0 + num_waves * R;
-    if (w_next < num_words) request(w_next, next_key, next_words);
+  Source cur = Source(), next = Source();
+  int64_t group = wave;
+  if (group < num_groups) {
+    cur = source_of(group);
+    request(cur, key, words);
+  }
+  for (; group < num_groups; group += num_waves) {
+    if (group + num_waves < num_groups) {
+      next = source_of(group + num_waves);
+      request(next, next_key, next_words);
+    }
+    const int64_t w0 = cur.base >> 6;
+    const int64_t n = cur.n;               // (shadows the argument: the rows of this group's stripe)
+    const int32_t base_tid = cur.base_tid;
+    cur = next;
     // the R compare-and-swaps of a group are all issued before the first result is looked at
     uint64_t idx[R];
     uint32_t old[R];
@@ -154,26 +194,6 @@ __device__ __forceinline__ void dense_emit_direct(bool match, int32_t probe_tid,
 // kRuns: the probe side is a run of blocks (qsx_join_probe_blocks, block_runs.hpp) — `runs` is the table, a tile belongs to
 // one block and takes that block's key stripe, row count, filter, base tuple id and (MODE 2) output bitmap; the output
 // pair list and its counter are the run's.
-template <typename KeyT>
-struct ProbeTileSource {
-  const KeyT *keys;
-  int64_t n;                 // rows of the block
-  int64_t base;              // first row of the tile within the block
-  int32_t base_tid;
-  const uint64_t *filter;
-  uint64_t *out_bitmap;
-};
-template <typename KeyT, int kTileRows, bool kRuns>
-__device__ __forceinline__ ProbeTileSource<KeyT> probe_tile_source(const long long *__restrict__ runs, int64_t tile,
-                                                                   const KeyT *keys, int64_t n, int32_t base_tid,
-                                                                   const uint64_t *filter, uint64_t *out_bitmap) {
-  if (!kRuns) return ProbeTileSource<KeyT>{keys, n, tile * kTileRows, base_tid, filter, out_bitmap};
-  const RunTile at = run_locate(runs, static_cast<int>(tile));
-  return ProbeTileSource<KeyT>{run_in<KeyT>(runs, at.block), run_rows(runs, at.block),
-                               static_cast<int64_t>(at.tile_in_block) * kTileRows, static_cast<int32_t>(run_base(runs, at.block)),
-                               run_filter(runs, at.block), run_out<uint64_t>(runs, at.block)};
-}
-
 template <typename KeyT, int MODE, bool kRuns = false>
 __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
     DenseTableView t, const KeyT *__restrict__ keys, int64_t n, int32_t probe_base_tid,

@@ -1754,12 +1754,17 @@ bool BuildHashOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCo
   for (partition_id part = 0; part < num_partitions_; ++part) {   // BuildHashOperator.cpp:82-110
     qsx_join_table_t *table = query_context->getJoinHashTable(hash_table_index_, part);
     while (input_.generated[part] < input_.ids[part].size()) {
-      container->addNormalWorkOrder(new BuildHashWorkOrder(query_id_, input_relation_, join_key_attributes_,
-                                                           input_.ids[part][input_.generated[part]], predicate, table,
-                                                           storage_manager, part,
-                                                           CreateLIPFilterBuilderHelper(lip_deployment_index_, query_context)),
-                                    op_index_);
-      ++input_.generated[part];
+      const std::size_t take = std::min(blocks_per_work_order_, input_.ids[part].size() - input_.generated[part]);
+      BuildHashWorkOrder *order = new BuildHashWorkOrder(query_id_, input_relation_, join_key_attributes_,
+                                                         input_.ids[part][input_.generated[part]], predicate, table,
+                                                         storage_manager, part,
+                                                         CreateLIPFilterBuilderHelper(lip_deployment_index_, query_context));
+      if (take > 1) {
+        order->setRun(std::vector<block_id>(input_.ids[part].begin() + static_cast<std::ptrdiff_t>(input_.generated[part]),
+                                            input_.ids[part].begin() + static_cast<std::ptrdiff_t>(input_.generated[part] + take)));
+      }
+      container->addNormalWorkOrder(order, op_index_);
+      input_.generated[part] += take;
     }
   }
   return input_relation_is_stored_ || done_feeding_input_relation_;
@@ -1797,7 +1802,37 @@ struct JoinKeys {
 }  // namespace
 
 void BuildHashWorkOrder::execute() {
-  BlockReference block = storage_manager_->getBlock(build_block_id_);
+  if (run_block_ids_.empty()) {
+    executeBlock(build_block_id_);
+    return;
+  }
+  if (executeRun()) return;
+  for (block_id id : run_block_ids_) executeBlock(id);
+}
+
+bool BuildHashWorkOrder::executeRun() {
+  if (predicate_ != nullptr || lip_filter_builder_ != nullptr || join_key_attributes_.size() != 1) return false;
+  std::vector<BlockReference> blocks;
+  std::vector<std::int64_t> rows;
+  std::vector<const void *> keys;
+  std::vector<std::int32_t> bases;
+  for (block_id id : run_block_ids_) {
+    blocks.push_back(storage_manager_->getBlock(id));
+    const StorageBlock &b = *blocks.back();
+    if (b.nullBitmap(join_key_attributes_.front()) != nullptr || b.compressedAttribute(join_key_attributes_.front()) != nullptr) return false;
+    if (b.firstRow() + b.numTuples() > INT32_MAX) return false;
+    rows.push_back(b.numTuples());
+    keys.push_back(b.stripe(join_key_attributes_.front()));
+    bases.push_back(static_cast<std::int32_t>(b.firstRow()));   // the stored reference: relation-global row number
+  }
+  CheckStatus(qsx_join_build_blocks(hash_table_, static_cast<std::int64_t>(blocks.size()), rows.data(), keys.data(), bases.data(), nullptr,
+                                    CurrentStream()), "qsx_join_build_blocks");
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+  return true;
+}
+
+void BuildHashWorkOrder::executeBlock(block_id build_block_id) {
+  BlockReference block = storage_manager_->getBlock(build_block_id);
   void *bitmap = nullptr;
   if (predicate_ != nullptr) {
     std::int64_t matches = 0;

@@ -714,8 +714,13 @@ class BuildHashOperator : public RelationalOperator {
       input_.ids.at(part_id).push_back(input_block_id);
     }
   }
+  // How many build blocks one BuildHashWorkOrder covers (1 = the reference's one per block, BuildHashOperator.cpp:70-130).
+  // A run is inserted with one launch (qsx_join_build_blocks) when the key is one non-nullable attribute and the
+  // operator has neither a build predicate nor a LIP filter to fill; otherwise block by block inside the work order.
+  void setBlocksPerWorkOrder(std::size_t blocks) { blocks_per_work_order_ = blocks > 0 ? blocks : 1; }
 
  private:
+  std::size_t blocks_per_work_order_ = 1;
   const CatalogRelation &input_relation_;
   const bool input_relation_is_stored_;
   const std::vector<attribute_id> join_key_attributes_;
@@ -737,8 +742,13 @@ class BuildHashWorkOrder : public WorkOrder {
         build_block_id_(build_block_id), predicate_(predicate), hash_table_(hash_table),
         storage_manager_(storage_manager), lip_filter_builder_(lip_filter_builder) {}
   void execute() override;  // BuildHashOperator.cpp:162-207
+  // A run of build blocks (BuildHashOperator::setBlocksPerWorkOrder): build_block_id is the first of them.
+  void setRun(std::vector<block_id> &&build_block_ids) { run_block_ids_ = std::move(build_block_ids); }
 
  private:
+  void executeBlock(block_id build_block_id);
+  bool executeRun();
+  std::vector<block_id> run_block_ids_;
   const CatalogRelation &input_relation_;
   const std::vector<attribute_id> &join_key_attributes_;
   const block_id build_block_id_;

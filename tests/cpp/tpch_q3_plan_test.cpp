@@ -160,10 +160,13 @@ void runQ3(const Db &db, std::size_t blocks_per_work_order) {
   for (HashJoinOperator *op : {op_j_ord, op_j_line}) op->setBlocksPerWorkOrder(blocks_per_work_order);
   op_agg->setBlocksPerWorkOrder(blocks_per_work_order);
   const auto s_cust = plan.addRelationalOperator(op_s_cust);
-  const auto b_cust = plan.addRelationalOperator(new BuildHashOperator(0, cust_sel, false, {0}, false, 1, t_cust));
+  BuildHashOperator *op_b_cust = new BuildHashOperator(0, cust_sel, false, {0}, false, 1, t_cust);
+  BuildHashOperator *op_b_ord = new BuildHashOperator(0, ord_join, false, {0}, false, 1, t_ord);
+  for (BuildHashOperator *op : {op_b_cust, op_b_ord}) op->setBlocksPerWorkOrder(blocks_per_work_order);
+  const auto b_cust = plan.addRelationalOperator(op_b_cust);
   const auto s_ord = plan.addRelationalOperator(op_s_ord);
   const auto j_ord = plan.addRelationalOperator(op_j_ord);
-  const auto b_ord = plan.addRelationalOperator(new BuildHashOperator(0, ord_join, false, {0}, false, 1, t_ord));
+  const auto b_ord = plan.addRelationalOperator(op_b_ord);
   const auto s_line = plan.addRelationalOperator(op_s_line);
   const auto j_line = plan.addRelationalOperator(op_j_line);
   const auto agg = plan.addRelationalOperator(op_agg);

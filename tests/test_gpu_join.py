@@ -505,3 +505,31 @@ def test_run_global_tids_feed_the_segmented_gathers(capi, oracle, dev, num_block
     out = capi.bitmap_gather_segmented(segs, first, with_padding)
     want = oracle.bitmap_from_bools(np.concatenate([whole[hp], np.ones(3, dtype=bool)]))
     assert np.array_equal(out.cpu().numpy().view(np.uint64), want[:(k + 3 + 63) // 64])
+
+
+@pytest.mark.parametrize("shape", sorted(PROBE_RUNS))
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_build_over_a_run_of_blocks_equals_block_by_block(capi, oracle, dev, flavour, key_type, dtype, shape):
+    """qsx_join_build_blocks: one launch over a run of build blocks (own stripes, filters with gaps, relation-global base
+    tids) leaves the table of one build per block — same entry count, same pairs for any probe; the hashed table also
+    grows past its estimate inside the call."""
+    rows = PROBE_RUNS[shape]
+    rng = np.random.default_rng(len(rows) * 3 + rows[0])
+    blocks = [rng.integers(0, 5000, size=n).astype(dtype) for n in rows]      # duplicates within and across blocks
+    filters = [oracle.bitmap_from_bools(rng.random(n) < 0.7) if (i % 2 == 0 and n) else None for i, n in enumerate(rows)]
+    bases = [int(x) for x in np.cumsum([0] + rows[:-1])]
+    probe = rng.integers(-3, 5200, size=40_000).astype(dtype)
+    for use_filters in (False, True):
+        table = capi.JoinTable(key_type, 64 if flavour == "hashed" else sum(rows), key_range=(0, 4999) if flavour == "dense" else None)
+        table.build_blocks([to_dev(b, dev) for b in blocks], bases,
+                           filters=[None if f is None else bitmap_dev(f, dev) for f in filters] if use_filters else None)
+        ot = oracle.JoinTable(key_type, sum(rows))
+        for i, b in enumerate(blocks):
+            ot.build(b, block_id=i, base_tid=bases[i], filter_bitmap=filters[i] if use_filters else None)
+        assert table.size() == ot.info()["buckets_allocated"]
+        rp, rb = ot.probe(probe)
+        p, b, cnt = table.probe(to_dev(probe, dev), capacity=rp.size + 1)
+        k = int(cnt.item())
+        assert k == rp.size
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:k], b.cpu().numpy()[:k]), sorted_pairs(rp, rb))
