@@ -1672,25 +1672,17 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   const int ncols = st->config.num_columns;
   constexpr int kAlignRows = 16;
   const int64_t padded = n + static_cast<int64_t>(kAlignRows) * P;
-  // every stream-ordered allocation of this call, released (stream-ordered) on every way out
-  struct AsyncAllocations {
-    hipStream_t stream;
-    std::vector<void *> ptrs;
-    ~AsyncAllocations() {
-      for (void *p : ptrs) (void)hipFreeAsync(p, stream);
-    }
-    int alloc(void **out, size_t bytes) {
-      QSX_HIP_TRY(hipMallocAsync(out, bytes, stream));
-      ptrs.push_back(*out);
-      return QSX_OK;
-    }
-  } scratch{s, {}};
-  int64_t *pieces = nullptr;
-  void *ws = nullptr;
+  // the scratch of this call: piece table, K9 workspace, one partitioned copy of every used column
   const size_t ws_bytes = partition_workspace_bytes(n, P);
-  int rc = scratch.alloc(reinterpret_cast<void **>(&pieces), sizeof(int64_t) * 2 * P);
-  if (rc == QSX_OK) rc = scratch.alloc(&ws, ws_bytes);
+  size_t total = CallScratch::padded(sizeof(int64_t) * 2 * P) + CallScratch::padded(ws_bytes);
+  for (int c = 0; c < ncols; ++c) {
+    if ((st->used_columns >> c) & 1u) total += CallScratch::padded(static_cast<size_t>(padded) * st->dev.column_width[c] + 16);
+  }
+  CallScratch scratch(s);
+  int rc = scratch.reserve(total);
   if (rc != QSX_OK) return rc;
+  int64_t *pieces = static_cast<int64_t *>(scratch.take(sizeof(int64_t) * 2 * P));
+  void *ws = scratch.take(ws_bytes);
   const void *src[QSX_MAX_COLUMNS];
   void *dst[QSX_MAX_COLUMNS];
   void *part_cols[QSX_MAX_COLUMNS];
@@ -1699,8 +1691,8 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   for (int c = 0; c < ncols; ++c) {
     part_cols[c] = nullptr;
     if (!((st->used_columns >> c) & 1u)) continue;
-    rc = scratch.alloc(&part_cols[c], static_cast<size_t>(padded) * st->dev.column_width[c] + 16);
-    if (rc != QSX_OK) return rc;
+    part_cols[c] = scratch.take(static_cast<size_t>(padded) * st->dev.column_width[c] + 16);
+    if (part_cols[c] == nullptr) return QSX_ERR_OUT_OF_MEMORY;
     src[moved] = cols[c];
     dst[moved] = part_cols[c];
     widths[moved] = st->dev.column_width[c];

@@ -135,6 +135,76 @@ static int staged_upload(hipStream_t stream, const void *host_src, size_t bytes)
   return QSX_OK;
 }
 
+// Device scratch of ONE API call.  The stream-ordered allocator (hipMallocAsync / hipFreeAsync) is not used for it: on this
+// stack a plain hipFree issued while stream-ordered allocations are in use occasionally leaves a kernel's writes to such an
+// allocation lost (tools/ubench/pool_readback.hip: ~1 in 40 000 iterations read back zeros, with one host thread or four,
+// any allocation size, release threshold raised or not; never without the interleaved hipFree, never with plain
+// allocations) — and a library cannot keep its callers, or torch's allocator, from calling hipFree.
+// Instead every (host thread, stream) owns one grow-only arena: calls issued by one thread on one stream are ordered on
+// the device, so the next call may reuse the arena while the previous call's kernels are still queued.  Requests beyond
+// kScratchKeepBytes are one-off plain allocations, released when the call's work has finished.
+constexpr size_t kScratchKeepBytes = size_t(4) << 30;
+struct ScratchArena {
+  void *base = nullptr;
+  size_t capacity = 0;
+};
+class CallScratch {
+ public:
+  explicit CallScratch(hipStream_t stream) : stream_(stream) {}
+  CallScratch(const CallScratch &) = delete;
+  CallScratch &operator=(const CallScratch &) = delete;
+  ~CallScratch() {
+    if (one_off_ != nullptr) {
+      (void)hipStreamSynchronize(stream_);
+      (void)hipFree(one_off_);
+    }
+  }
+  // Bytes a take() of `bytes` consumes of the reservation.
+  static size_t padded(size_t bytes) { return (bytes + 255) / 256 * 256; }
+  // All the scratch of the call at once (sum of padded() sizes); QSX_OK or an error status.
+  int reserve(size_t total) {
+    total = padded(total ? total : 1);
+    used_ = 0;
+    if (total > kScratchKeepBytes) {
+      QSX_HIP_TRY(hipMalloc(&one_off_, total));
+      base_ = static_cast<char *>(one_off_);
+      capacity_ = total;
+      return QSX_OK;
+    }
+    thread_local std::map<hipStream_t, ScratchArena> arenas;
+    ScratchArena &a = arenas[stream_];
+    if (a.capacity < total) {
+      if (a.base != nullptr) {
+        QSX_HIP_TRY(hipStreamSynchronize(stream_));   // kernels of earlier calls may still use the old arena
+        QSX_HIP_TRY(hipFree(a.base));
+        a.base = nullptr;
+        a.capacity = 0;
+      }
+      size_t cap = 1 << 20;
+      while (cap < total) cap *= 2;
+      QSX_HIP_TRY(hipMalloc(&a.base, cap));
+      a.capacity = cap;
+    }
+    base_ = static_cast<char *>(a.base);
+    capacity_ = a.capacity;
+    return QSX_OK;
+  }
+  // The next piece of the reservation (256-byte aligned), nullptr when the reservation is exhausted.
+  void *take(size_t bytes) {
+    const size_t need = padded(bytes ? bytes : 1);
+    if (base_ == nullptr || used_ + need > capacity_) return nullptr;
+    void *p = base_ + used_;
+    used_ += need;
+    return p;
+  }
+
+ private:
+  hipStream_t stream_;
+  void *one_off_ = nullptr;
+  char *base_ = nullptr;
+  size_t capacity_ = 0, used_ = 0;
+};
+
 }  // namespace qsx
 
 #endif  // QSX_CSRC_COMMON_HPP_

@@ -812,14 +812,16 @@ static int launch_probe_radix(qsx_join_table *t, const int32_t *keys, int64_t n,
   rows_per_block = (rows_per_block + kRadixTile - 1) / kRadixTile * kRadixTile;
   G = (n + rows_per_block - 1) / rows_per_block;
   const int64_t cells = static_cast<int64_t>(P) * G;
-  // stream-ordered scratch: concurrent probes (one per Worker stream) never share it
-  int32_t *pk = nullptr, *pt = nullptr, *hist_t = nullptr;
-  int64_t *starts = nullptr, *scan_ws = nullptr;
-  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&pk), static_cast<size_t>(n) * 4 + 16, stream));
-  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&pt), static_cast<size_t>(n) * 4 + 16, stream));
-  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&hist_t), static_cast<size_t>(cells) * 4 + 64, stream));
-  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&starts), static_cast<size_t>(cells + 1) * 8, stream));
-  QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&scan_ws), scan_workspace_words(cells) * 8, stream));
+  // scratch of this call (per host thread and stream: concurrent probes, one per Worker stream, never share it)
+  CallScratch scratch(stream);
+  const size_t bytes_pk = static_cast<size_t>(n) * 4 + 16, bytes_hist = static_cast<size_t>(cells) * 4 + 64,
+               bytes_starts = static_cast<size_t>(cells + 1) * 8, bytes_scan = scan_workspace_words(cells) * 8;
+  int rc_scratch = scratch.reserve(2 * CallScratch::padded(bytes_pk) + CallScratch::padded(bytes_hist) + CallScratch::padded(bytes_starts) +
+                                   CallScratch::padded(bytes_scan));
+  if (rc_scratch != QSX_OK) return rc_scratch;
+  int32_t *pk = static_cast<int32_t *>(scratch.take(bytes_pk)), *pt = static_cast<int32_t *>(scratch.take(bytes_pk)),
+          *hist_t = static_cast<int32_t *>(scratch.take(bytes_hist));
+  int64_t *starts = static_cast<int64_t *>(scratch.take(bytes_starts)), *scan_ws = static_cast<int64_t *>(scratch.take(bytes_scan));
   hipLaunchKernelGGL(radix_probe_hist, dim3(static_cast<unsigned>(G)), dim3(kRBlock), P * sizeof(int32_t), stream, keys, n,
                      filter, geom, rows_per_block, hist_t);
   QSX_CHECK_LAUNCH();
@@ -844,11 +846,6 @@ static int launch_probe_radix(qsx_join_table *t, const int32_t *keys, int64_t n,
   hipLaunchKernelGGL((radix_join<MODE>), dim3(static_cast<unsigned>(P * slices)), dim3(kRBlock), 0, stream, a, out_probe,
                      out_build, capacity, count);
   QSX_CHECK_LAUNCH();
-  QSX_HIP_TRY(hipFreeAsync(pk, stream));
-  QSX_HIP_TRY(hipFreeAsync(pt, stream));
-  QSX_HIP_TRY(hipFreeAsync(hist_t, stream));
-  QSX_HIP_TRY(hipFreeAsync(starts, stream));
-  QSX_HIP_TRY(hipFreeAsync(scan_ws, stream));
   return QSX_OK;
 }
 
@@ -891,11 +888,13 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
     if (MODE == 0 && dense_two_pass(filter)) {
       // count per (tile, wave) -> scan -> write: see join_dense.hpp
       const int64_t units = tiles * (kDBlock / kWave);
-      int32_t *unit_counts = nullptr;
-      int64_t *unit_offsets = nullptr, *scan_ws = nullptr;
-      QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&unit_counts), static_cast<size_t>(units) * 4, stream));
-      QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&unit_offsets), static_cast<size_t>(units + 1) * 8, stream));
-      QSX_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&scan_ws), scan_workspace_words(units) * 8, stream));
+      CallScratch scratch(stream);
+      const size_t bytes_counts = static_cast<size_t>(units) * 4, bytes_offsets = static_cast<size_t>(units + 1) * 8,
+                   bytes_scan = scan_workspace_words(units) * 8;
+      const int rc_scratch = scratch.reserve(CallScratch::padded(bytes_counts) + CallScratch::padded(bytes_offsets) + CallScratch::padded(bytes_scan));
+      if (rc_scratch != QSX_OK) return rc_scratch;
+      int32_t *unit_counts = static_cast<int32_t *>(scratch.take(bytes_counts));
+      int64_t *unit_offsets = static_cast<int64_t *>(scratch.take(bytes_offsets)), *scan_ws = static_cast<int64_t *>(scratch.take(bytes_scan));
       if (t->key_type == QSX_INT) {
         hipLaunchKernelGGL((dense_probe_kernel<int32_t, 3, kRuns>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
                            static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
@@ -917,9 +916,6 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
                            dcount, out_bitmap, anti, unit_counts, unit_offsets, runs_dev);
       }
       QSX_CHECK_LAUNCH();
-      QSX_HIP_TRY(hipFreeAsync(unit_counts, stream));
-      QSX_HIP_TRY(hipFreeAsync(unit_offsets, stream));
-      QSX_HIP_TRY(hipFreeAsync(scan_ws, stream));
       return QSX_OK;
     }
     if constexpr (!kRuns && (MODE == 0 || MODE == 1)) {

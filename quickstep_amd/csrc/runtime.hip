@@ -1,5 +1,6 @@
 // runtime.hip — status strings, device discovery and the memory plumbing of
 // the C ABI (include/qsx.h).  No compute here.
+#include <cstdlib>
 #include "common.hpp"
 
 #include <mutex>

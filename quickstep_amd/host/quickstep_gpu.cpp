@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 namespace quickstep {
 
@@ -24,10 +25,57 @@ void CheckStatus(int status, const char *where) {
 namespace {
 thread_local qsx_stream_t tls_stream = nullptr;
 
-struct DeviceBuffer {  // scratch owned by one work order
+// Scratch owned by one work order.  A device allocation of a few MB costs ~170 us (hipMalloc + hipFree, whatever the
+// size; 0.7 us up to 64 KiB: tools/ubench/alloc_cost.hip) — more than the kernels of a work order over a 4 MB block take —
+// and the stream-ordered pool is not an option on this stack (csrc/common.hpp, CallScratch).  So buffers above 64 KiB come
+// from a per-thread cache of plain allocations in power-of-two size classes: a worker thread issues all its work on one
+// stream, so a buffer handed back while its last kernel is still queued can be handed out again to the same thread —
+// the next use is ordered behind it.  (A buffer built by one thread and consumed by another — DISTINCT chunks — is
+// published after a stream synchronisation, like a storage block.)  The cache keeps at most kCacheBytes per thread.
+struct DeviceBuffer {
+  static constexpr std::size_t kCacheFrom = 64 * 1024 + 1;
+  static constexpr std::size_t kCacheBytes = std::size_t(2) << 30;
+  struct Cache {
+    std::map<std::size_t, std::vector<void *>> free_by_class;
+    std::size_t bytes = 0;
+    ~Cache() {
+      for (auto &cls : free_by_class) for (void *p : cls.second) qsx_device_free(p);
+    }
+  };
+  static Cache &cache() {
+    thread_local Cache c;
+    return c;
+  }
   void *ptr = nullptr;
-  explicit DeviceBuffer(std::size_t bytes) { CheckStatus(qsx_device_alloc(bytes ? bytes : 8, &ptr), "qsx_device_alloc"); }
-  ~DeviceBuffer() { qsx_device_free(ptr); }
+  std::size_t size_class = 0;   // 0: a plain allocation of its own
+  explicit DeviceBuffer(std::size_t bytes) {
+    if (bytes >= kCacheFrom) {
+      size_class = 128 * 1024;
+      while (size_class < bytes) size_class *= 2;
+      Cache &c = cache();
+      auto it = c.free_by_class.find(size_class);
+      if (it != c.free_by_class.end() && !it->second.empty()) {
+        ptr = it->second.back();
+        it->second.pop_back();
+        c.bytes -= size_class;
+        return;
+      }
+      CheckStatus(qsx_device_alloc(size_class, &ptr), "qsx_device_alloc");
+      return;
+    }
+    CheckStatus(qsx_device_alloc(bytes ? bytes : 8, &ptr), "qsx_device_alloc");
+  }
+  ~DeviceBuffer() {
+    if (size_class != 0) {
+      Cache &c = cache();
+      if (c.bytes + size_class <= kCacheBytes) {
+        c.free_by_class[size_class].push_back(ptr);
+        c.bytes += size_class;
+        return;
+      }
+    }
+    qsx_device_free(ptr);
+  }
   DeviceBuffer(const DeviceBuffer &) = delete;
   DeviceBuffer &operator=(const DeviceBuffer &) = delete;
 };
@@ -92,8 +140,36 @@ bool g_host_memory = false;  // CPU plumbing mode (BASELINE config 1): blocks li
 }
 void UseHostMemoryForBlocks(bool on) { g_host_memory = on; }
 
-StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t capacity, std::int64_t first_row)
+StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t capacity, std::int64_t first_row, bool one_allocation)
     : relation_(relation), capacity_(capacity), num_tuples_(0), first_row_(first_row) {
+  if (one_allocation && !g_host_memory) {
+    // an output block: all stripes and null bitmaps in one allocation (a device allocation of a few MB costs ~170 us
+    // whatever its size, and a block has one per attribute otherwise)
+    auto round_up = [](std::size_t v) { return (v + 255) / 256 * 256; };
+    std::size_t total = 0, null_bytes = 0;
+    for (std::size_t a = 0; a < relation.size(); ++a) {
+      const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
+      total += round_up(static_cast<std::size_t>(capacity) * t.width + 8);
+      if (t.nullable) null_bytes += round_up(static_cast<std::size_t>((capacity + 63) / 64) * 8 + 8);
+    }
+    slab_bytes_ = total + null_bytes;
+    CheckStatus(qsx_device_alloc(slab_bytes_, &slab_), "qsx_device_alloc(block)");
+    char *at = static_cast<char *>(slab_);
+    char *nulls_at = at + total;
+    if (null_bytes != 0) CheckStatus(qsx_memset_device(nulls_at, 0, null_bytes, CurrentStream()), "qsx_memset_device(null bitmaps)");
+    for (std::size_t a = 0; a < relation.size(); ++a) {
+      const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
+      stripes_.push_back(at);
+      at += round_up(static_cast<std::size_t>(capacity) * t.width + 8);
+      void *nulls = nullptr;
+      if (t.nullable) {
+        nulls = nulls_at;
+        nulls_at += round_up(static_cast<std::size_t>((capacity + 63) / 64) * 8 + 8);
+      }
+      null_bitmaps_.push_back(nulls);
+    }
+    return;
+  }
   for (std::size_t a = 0; a < relation.size(); ++a) {
     void *p = nullptr;
     const std::size_t bytes = static_cast<std::size_t>(capacity) * relation.getAttributeType(static_cast<attribute_id>(a)).width;
@@ -117,6 +193,13 @@ StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t capacit
   }
 }
 StorageBlock::~StorageBlock() {
+  if (slab_ != nullptr) {
+    // (a stripe outside the slab was materialised later, stripe(): freed on its own below)
+    auto in_slab = [&](void *p) { return p >= slab_ && p < static_cast<char *>(slab_) + slab_bytes_; };
+    for (void *&p : stripes_) if (in_slab(p)) p = nullptr;
+    for (void *&p : null_bitmaps_) if (in_slab(p)) p = nullptr;
+    qsx_device_free(slab_);
+  }
   for (void *p : stripes_) {
     if (g_host_memory) std::free(p); else qsx_device_free(p);
   }
@@ -480,7 +563,7 @@ void StorageBlock::compressAttribute(attribute_id a, const void *host_values) {
     CheckStatus(qsx_copy_to_device(c.dictionary, c.dictionary_host.data(), c.dictionary_host.size(), nullptr), "qsx_copy_to_device(dictionary)");
   }
   CheckStatus(qsx_stream_synchronize(nullptr), "qsx_stream_synchronize");
-  qsx_device_free(stripes_.at(a));      // the values are gone until somebody asks for them (stripe())
+  if (slab_ == nullptr) qsx_device_free(stripes_.at(a));      // the values are gone until somebody asks for them (stripe())
   stripes_.at(a) = nullptr;
 }
 
@@ -488,7 +571,7 @@ block_id StorageManager::createBlock(CatalogRelation *relation, std::int64_t cap
   std::lock_guard<std::mutex> lock(mutex_);
   const block_id id = next_id_++;
   // first_row is fixed when the block is registered with its final size (returnBlock / loadBlock)
-  blocks_[id] = std::make_shared<StorageBlock>(*relation, capacity, 0);
+  blocks_[id] = std::make_shared<StorageBlock>(*relation, capacity, 0, /*one_allocation=*/true);
   return id;
 }
 

@@ -185,7 +185,7 @@ PredicateTransformResult TransformPredicateOnCompressedAttribute(const Compresse
 // (storage/CompressedColumnStoreTupleStorageSubBlock.cpp).
 class StorageBlock {
  public:
-  StorageBlock(const CatalogRelation &relation, std::int64_t capacity, std::int64_t first_row);
+  StorageBlock(const CatalogRelation &relation, std::int64_t capacity, std::int64_t first_row, bool one_allocation = false);
   ~StorageBlock();
   const CatalogRelation &getRelation() const { return relation_; }
   std::int64_t numTuples() const { return num_tuples_; }
@@ -220,6 +220,8 @@ class StorageBlock {
   std::int64_t num_tuples_;
   std::int64_t first_row_;
   attribute_id sort_column_ = kInvalidAttributeID;
+  void *slab_ = nullptr;                         // != nullptr: the one allocation all stripes and null bitmaps live in
+  std::size_t slab_bytes_ = 0;
   mutable std::vector<void *> stripes_;          // nullptr: compressed and not decoded yet
   std::vector<void *> null_bitmaps_;
   std::vector<CompressedAttribute> compressed_;  // empty or one per attribute
