@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 
 namespace quickstep {
@@ -2695,11 +2696,75 @@ ForemanSingleNode::ForemanSingleNode(QueryPlan *plan, QueryContext *query_contex
     : plan_(plan), query_context_(query_context), storage_manager_(storage_manager),
       num_workers_(num_workers ? num_workers : 1), outstanding_(plan->size(), 0) {}
 
+namespace {
+// The Worker threads of the process (query_execution/Worker.hpp: created once at start-up, they outlive every query).
+// Thread i keeps its HIP stream and with it everything that is cached per (thread, stream): the scratch arenas and staging
+// buffers inside libqsx.so, this layer's cache of scratch allocations — a query does not pay for them again (creating
+// four threads, streams and their first pinned / device buffers cost ~8 ms per query when the Foreman did it per run()).
+// The threads are never joined: they sleep on their queues when the process exits.
+class WorkerThreads {
+ public:
+  static WorkerThreads &instance() {
+    static WorkerThreads *pool = new WorkerThreads;
+    return *pool;
+  }
+  // fn(i) on worker thread i for every i < n; returns when all have returned.
+  void run(std::size_t n, const std::function<void(std::size_t)> &fn) {
+    std::mutex done_mutex;
+    std::condition_variable done_cv;
+    std::size_t remaining = n;
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      while (slots_.size() < n) {
+        slots_.emplace_back(new Slot);
+        Slot *slot = slots_.back().get();
+        std::thread([slot]() { threadMain(slot); }).detach();
+      }
+    }
+    for (std::size_t i = 0; i < n; ++i) {
+      Slot *slot = slots_[i].get();
+      {
+        std::lock_guard<std::mutex> lock(slot->mutex);
+        slot->tasks.push_back([&, i]() {
+          fn(i);
+          std::lock_guard<std::mutex> done_lock(done_mutex);
+          if (--remaining == 0) done_cv.notify_all();
+        });
+      }
+      slot->cv.notify_one();
+    }
+    std::unique_lock<std::mutex> lock(done_mutex);
+    done_cv.wait(lock, [&] { return remaining == 0; });
+  }
+
+ private:
+  struct Slot {
+    std::mutex mutex;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> tasks;
+  };
+  static void threadMain(Slot *slot) {
+    qsx_stream_t stream = nullptr;
+    if (qsx_device_count() > 0 && qsx_stream_create(&stream) != QSX_OK) stream = nullptr;   // (the default stream then)
+    SetCurrentStream(stream);
+    for (;;) {
+      std::function<void()> task;
+      {
+        std::unique_lock<std::mutex> lock(slot->mutex);
+        slot->cv.wait(lock, [&] { return !slot->tasks.empty(); });
+        task = std::move(slot->tasks.front());
+        slot->tasks.pop_front();
+      }
+      task();
+    }
+  }
+  std::mutex mutex_;
+  std::vector<std::unique_ptr<Slot>> slots_;
+};
+}  // namespace
+
 void ForemanSingleNode::workerMain(std::size_t worker_id) {
   // Worker::run (query_execution/Worker.cpp:54-99): receive a work order, execute(), report completion.
-  qsx_stream_t stream = nullptr;
-  if (qsx_device_count() > 0) CheckStatus(qsx_stream_create(&stream), "qsx_stream_create");
-  SetCurrentStream(stream);
   for (;;) {
     Item item;
     {
@@ -2727,7 +2792,6 @@ void ForemanSingleNode::workerMain(std::size_t worker_id) {
     }
     cv_done_.notify_all();
   }
-  if (stream != nullptr) qsx_stream_destroy(stream);
 }
 
 void ForemanSingleNode::run() {
@@ -2735,8 +2799,8 @@ void ForemanSingleNode::run() {
   WorkOrdersContainer container(N);
   std::vector<bool> done_generating(N, false), finished(N, false);
   std::vector<std::size_t> blocks_fed(N, 0);  // per producer: output blocks already fed downstream
-  std::vector<std::thread> workers;
-  for (std::size_t w = 0; w < num_workers_; ++w) workers.emplace_back(&ForemanSingleNode::workerMain, this, w);
+  // the process-wide Worker threads serve this query until it shuts them out again (one more thread drives them and waits)
+  std::thread workers([this]() { WorkerThreads::instance().run(num_workers_, [this](std::size_t w) { workerMain(w); }); });
 
   auto shutdown = [&]() {
     {
@@ -2744,7 +2808,7 @@ void ForemanSingleNode::run() {
       shutting_down_ = true;
     }
     cv_work_.notify_all();
-    for (auto &t : workers) t.join();
+    workers.join();
   };
 
   try {

@@ -11,6 +11,8 @@
 // The group-by key is 16 bytes (INT, DATE, INT: a wide key), the aggregate's argument a Scalar tree, c_mktsegment a CHAR(10)
 // attribute, the dates 8-byte DateLits.  Checked against the same query computed on the host columns.
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -21,8 +23,8 @@
 using namespace quickstep;
 
 namespace {
-constexpr int kCustomers = 3000, kOrders = 30000;
-constexpr std::int64_t kBlock = 8192;
+int kCustomers = 3000, kOrders = 30000;       // usage: tpch_q3_plan_test [orders [block rows]] (customers = orders / 10)
+std::int64_t kBlock = 8192;
 
 struct Db {
   std::vector<std::int32_t> c_custkey;
@@ -190,7 +192,24 @@ void runQ3(const Db &db, std::size_t blocks_per_work_order) {
   plan.addDirectDependency(drop_ord, j_line, true);
   plan.addDirectDependency(drop_state, fin, true);
   ForemanSingleNode foreman(&plan, &ctx, &storage, 4);
+  const auto t0 = std::chrono::steady_clock::now();
   foreman.run();
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("Q3 plan, %d orders / %lld lineitems in blocks of %lld rows, %zu block(s) per work order: %.2f ms, %zu work orders\n", kOrders,
+              static_cast<long long>(lines), static_cast<long long>(kBlock), blocks_per_work_order, ms,
+              foreman.getWorkOrderProfilingResults().size());
+  if (std::getenv("QSX_TEST_PROFILE") != nullptr) {   // --profile_and_report_workorder_perf: time per operator
+    std::map<std::size_t, std::pair<double, int>> per_op;
+    std::uint64_t first = ~0ull, last = 0;
+    for (const WorkOrderTimeEntry &e : foreman.getWorkOrderProfilingResults()) {
+      per_op[e.operator_index].first += static_cast<double>(e.end_us - e.start_us) / 1e3;
+      per_op[e.operator_index].second += 1;
+      first = std::min(first, e.start_us);
+      last = std::max(last, e.end_us);
+    }
+    for (const auto &kv : per_op) std::printf("  operator %zu: %d work orders, %.2f ms in total\n", kv.first, kv.second.second, kv.second.first);
+    std::printf("  first work order start .. last end: %.2f ms\n", static_cast<double>(last - first) / 1e3);
+  }
 
   // the same query on the host columns
   const DateLit cut = DateLit::Create(1995, 3, 15);
@@ -236,13 +255,23 @@ void runQ3(const Db &db, std::size_t blocks_per_work_order) {
 }
 }  // namespace
 
-int main() {
+int main(int argc, char **argv) {
   if (qsx_device_count() < 1) {
     std::fprintf(stderr, "tpch_q3_plan_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
     return 2;
   }
+  if (argc > 1) {
+    kOrders = std::atoi(argv[1]);
+    kCustomers = kOrders / 10;
+    if (argc > 2) kBlock = std::atoll(argv[2]);
+  }
   const Db db;
   runQ3(db, 1);
   runQ3(db, 4);     // work orders over runs of up to four blocks
+  if (argc > 1) {   // a timing run: warm repetitions, then runs of 64
+    runQ3(db, 1);
+    runQ3(db, 64);
+    runQ3(db, 64);
+  }
   return finish("tpch_q3_plan_test");
 }
