@@ -64,7 +64,8 @@ __device__ __forceinline__ void cfg_for(int count, F &&f) {
 // Copy `count` elements of `width` bytes (1/2/4/8) with ordinary loads; used
 // for stripes that are not 16-byte aligned and for sub-16-byte tails.
 template <int BLOCK = kABlock>
-__device__ __forceinline__ void copy_elements_to_lds(const char *src, char *dst, int count, int width) {
+__device__ __forceinline__ void copy_elements_to_lds(const char *src_generic, char *dst, int count, int width) {
+  const char *src = as_global(src_generic);
   for (int i = threadIdx.x; i < count; i += BLOCK) {
     switch (width) {
       case 1: reinterpret_cast<uint8_t *>(dst)[i] = reinterpret_cast<const uint8_t *>(src)[i]; break;
@@ -120,7 +121,7 @@ __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const
     cfg_for<kStatic, QSX_MAX_COLUMNS>(c.num_columns, [&](int col) __attribute__((always_inline)) { stage_column(col, cols[col]); });
   }
   if (c.filter_lds_off >= 0) {
-    if (filter != nullptr) {
+    if (!kRuns || filter != nullptr) {
       copy_elements_to_lds<BLOCK>(reinterpret_cast<const char *>(filter + (row0 >> 6)), tile + c.filter_lds_off,
                            (rows + 63) >> 6, 8);
     } else {   // (a block of a run without a filter of its own: every row)
@@ -632,7 +633,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   };
   if (nbuf == 2 && first_tile < num_tiles) {
     const TileSource src = locate(first_tile);
-    stage_tile<kStatic, BLOCK, kRuns>(c, src.cols, src.filter, tiles, src.row0, src.rows, nulls, &src.bases);
+    stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? src.cols : cols, kRuns ? src.filter : filter, tiles, src.row0, src.rows, nulls, &src.bases);
   }
   // (a run of blocks: the next tile's source is looked up while the current tile is computed — the table reads are a
   // dependent chain of scalar loads that would otherwise sit in front of every stage)
@@ -642,7 +643,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const TileSource here = carried;
     if (nbuf == 1) {
       __syncthreads();  // every wave is done reading the previous tile
-      stage_tile<kStatic, BLOCK, kRuns>(c, here.cols, here.filter, tiles, here.row0, here.rows, nulls, &here.bases);
+      stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? here.cols : cols, kRuns ? here.filter : filter, tiles, here.row0, here.rows, nulls, &here.bases);
     }
     // The tile has landed (nbuf == 2: it was staged during the previous iteration and
     // every wave is done with the other buffer).
@@ -678,8 +679,8 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const int64_t next = tile_id + tile_step;
     if (next < num_tiles) carried = locate(next);
     if (nbuf == 2 && next < num_tiles) {
-      stage_tile<kStatic, BLOCK, kRuns>(c, carried.cols, carried.filter, tiles + (buf ^ 1) * c.tile_bytes, carried.row0, carried.rows, nulls,
-                                        &carried.bases);
+      stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? carried.cols : cols, kRuns ? carried.filter : filter, tiles + (buf ^ 1) * c.tile_bytes,
+                                        carried.row0, carried.rows, nulls, &carried.bases);
     }
     char *tile = tiles + buf * c.tile_bytes;
     if (nbuf == 2) buf ^= 1;

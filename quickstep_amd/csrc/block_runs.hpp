@@ -47,14 +47,14 @@ __device__ __forceinline__ long long run_rows(const long long *__restrict__ t, i
 }
 template <typename T>
 __device__ __forceinline__ const T *run_in(const long long *__restrict__ t, int b) {
-  return reinterpret_cast<const T *>(t[kRunHeaderWords + (t[0] + 1) + t[0] + b]);
+  return as_global(reinterpret_cast<const T *>(t[kRunHeaderWords + (t[0] + 1) + t[0] + b]));
 }
 __device__ __forceinline__ const uint64_t *run_filter(const long long *__restrict__ t, int b) {
-  return reinterpret_cast<const uint64_t *>(t[kRunHeaderWords + (t[0] + 1) + 2 * t[0] + b]);
+  return as_global(reinterpret_cast<const uint64_t *>(t[kRunHeaderWords + (t[0] + 1) + 2 * t[0] + b]));
 }
 template <typename T>
 __device__ __forceinline__ T *run_out(const long long *__restrict__ t, int b) {
-  return reinterpret_cast<T *>(t[kRunHeaderWords + (t[0] + 1) + 3 * t[0] + b]);
+  return as_global(reinterpret_cast<T *>(t[kRunHeaderWords + (t[0] + 1) + 3 * t[0] + b]));
 }
 __device__ __forceinline__ long long run_base(const long long *__restrict__ t, int b) {
   return t[kRunHeaderWords + (t[0] + 1) + 4 * t[0] + b];

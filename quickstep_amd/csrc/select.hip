@@ -266,7 +266,7 @@ __device__ __forceinline__ void compact_tile(const GatherArgs &args, const long 
         }
       }
       for (int c = 0; c < args.ncols; ++c) {
-        const void *src = kRuns ? reinterpret_cast<const void *>(block_cols[c]) : args.src[c];
+        const void *src = kRuns ? as_global(reinterpret_cast<const void *>(block_cols[c])) : args.src[c];
         void *dst = args.dst[c];
         switch (args.width[c]) {               // wave-uniform
           case 4: {

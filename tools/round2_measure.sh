@@ -14,4 +14,13 @@ python3 tools/q3_pipeline.py 100 nolip fused >> $o/q3_pipeline.jsonl 2>&1
 python3 tools/q3_pipeline.py 100 lip fused types >> $o/q3_pipeline.jsonl 2>&1
 
 python3 tools/agg_large_groups.py > $o/agg_large_groups.jsonl 2>&1
+# the operator layer: work orders per block against work orders per run of blocks; allocation costs; the allocator finding
+tests/cpp/bin/work_order_runs_test > $o/work_order_runs.txt 2>&1
+tests/cpp/bin/tpch_types_operator_test 2>&1 | grep "work order" >> $o/work_order_runs.txt
+tests/cpp/bin/tpch_q3_plan_test 1500000 120000 2>&1 | grep "Q3 plan" >> $o/work_order_runs.txt
+tests/cpp/bin/tpch_q3_plan_test 15000000 120000 2>&1 | grep "Q3 plan" >> $o/work_order_runs.txt
+tools/ubench/alloc_cost > $o/alloc_cost.jsonl 2>&1
+for b in 8 4096 1000000; do timeout 200 tools/ubench/pool_readback 4 40000 $b 1 1 0 1 >> $o/pool_readback.txt 2>&1; done
+timeout 200 tools/ubench/pool_readback 4 40000 8 1 0 0 1 >> $o/pool_readback.txt 2>&1
+timeout 200 tools/ubench/pool_readback 4 40000 8 0 1 0 1 >> $o/pool_readback.txt 2>&1
 grep -h "^{" $o/*.jsonl | cut -c1-200 | tail -30
