@@ -707,6 +707,19 @@ int qsx_lip_build(qsx_lip_filter_t *f, int key_type, const void *keys_dev, int64
 int qsx_lip_probe(const qsx_lip_filter_t *f, int key_type, const void *keys_dev, int64_t n,
                   const uint64_t *in_bitmap_dev, uint64_t *out_bitmap_dev,
                   int64_t *out_count_dev, qsx_stream_t stream);
+/* qsx_lip_build / qsx_lip_probe over a run of blocks in one launch each (every block its own key stripe and bitmaps): what
+ * num_blocks calls produce.  LIPFilterBuilder::insertValueAccessor / LIPFilterAdaptiveProber::filterValueAccessor run once
+ * per block inside the work orders (relational_operators/BuildHashOperator.cpp:187-190, SelectOperator.cpp:170-180); a work
+ * order over a run of blocks (DESIGN.md "Work-order granularity") calls these instead.
+ *   block_filters / block_in_bitmaps   NULL, or host arrays of device pointers (entries may be NULL = every row)
+ *   block_out_bitmaps                  host array of device pointers, (block_rows[b]+63)/64 words each, fully overwritten
+ *   out_count_dev                      optional: set bits of all output bitmaps together */
+int qsx_lip_build_blocks(qsx_lip_filter_t *filter, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                         const void *const *block_keys, const uint64_t *const *block_filters, qsx_stream_t stream);
+int qsx_lip_probe_blocks(const qsx_lip_filter_t *filter, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                         const void *const *block_keys, const uint64_t *const *block_in_bitmaps,
+                         uint64_t *const *block_out_bitmaps, int64_t *out_count_dev, qsx_stream_t stream);
+
 /* Raw bit array (for all-reduce(OR) across GPUs): 64-bit words, LSB-first. */
 int qsx_lip_filter_words(qsx_lip_filter_t *f, uint64_t **out_words_dev, int64_t *out_num_words);
 

@@ -114,6 +114,8 @@ _SIGNATURES = {
     "qsx_lip_filter_destroy": (_int, [_vp]),
     "qsx_lip_build": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "qsx_lip_probe": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "qsx_lip_build_blocks": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _pp, _vp]),
+    "qsx_lip_probe_blocks": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _pp, _pp, _vp, _vp]),
     "qsx_lip_filter_words": (_int, [_vp, _pp, C.POINTER(_i64)]),
     "qsx_partition_workspace_bytes": (_sz, [_i64, _int]),
     "qsx_partition_scatter": (_int, [_int, _vp, _i64, _int, _int, _pp, C.POINTER(_i32), _pp, _vp, _vp, _sz, _vp]),
@@ -725,6 +727,33 @@ class LipFilter:
         _check(_lib.qsx_lip_probe(self._h, qsx_type_of(keys), _ptr(keys), n, _ptr(in_bitmap), _ptr(out), _ptr(count),
                                   _stream(stream)), "qsx_lip_probe")
         return out, count
+
+    def build_blocks(self, key_blocks, filters=None, stream=None):
+        """qsx_lip_build over a run of blocks in one launch."""
+        nb = len(key_blocks)
+        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
+        fptr = None
+        if filters is not None:
+            fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        _check(_lib.qsx_lip_build_blocks(self._h, qsx_type_of(key_blocks[0]) if nb else T.INT, nb, rows, kptr, fptr, _stream(stream)),
+               "qsx_lip_build_blocks")
+
+    def probe_blocks(self, key_blocks, in_bitmaps=None, stream=None):
+        """qsx_lip_probe over a run of blocks in one launch: (per-block output bitmaps, total count int64[1])."""
+        nb = len(key_blocks)
+        dev = key_blocks[0].device if nb else torch.device("cuda:0")
+        outs = [new_bitmap(k.numel(), dev) for k in key_blocks]
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
+        optr = (C.c_void_p * max(nb, 1))(*[o.data_ptr() if o.numel() else None for o in outs])
+        iptr = None
+        if in_bitmaps is not None:
+            iptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in in_bitmaps])
+        _check(_lib.qsx_lip_probe_blocks(self._h, qsx_type_of(key_blocks[0]) if nb else T.INT, nb, rows, kptr, iptr, optr, _ptr(count),
+                                         _stream(stream)), "qsx_lip_probe_blocks")
+        return outs, count
 
     def words(self):
         """(device pointer, number of 64-bit words) of the raw LSB-first bit array."""

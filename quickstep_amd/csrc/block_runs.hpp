@@ -60,6 +60,27 @@ __device__ __forceinline__ long long run_base(const long long *__restrict__ t, i
   return t[kRunHeaderWords + (t[0] + 1) + 4 * t[0] + b];
 }
 
+// ---- a tile of a stripe, or of a run of blocks (block_runs.hpp) -----------------------------------------------------------
+template <typename KeyT>
+struct ProbeTileSource {
+  const KeyT *keys;
+  int64_t n;                 // rows of the block
+  int64_t base;              // first row of the tile within the block
+  int32_t base_tid;
+  const uint64_t *filter;
+  uint64_t *out_bitmap;
+};
+template <typename KeyT, int kTileRows, bool kRuns>
+__device__ __forceinline__ ProbeTileSource<KeyT> probe_tile_source(const long long *__restrict__ runs, int64_t tile,
+                                                                   const KeyT *keys, int64_t n, int32_t base_tid,
+                                                                   const uint64_t *filter, uint64_t *out_bitmap) {
+  if (!kRuns) return ProbeTileSource<KeyT>{keys, n, tile * kTileRows, base_tid, filter, out_bitmap};
+  const RunTile at = run_locate(runs, static_cast<int>(tile));
+  return ProbeTileSource<KeyT>{run_in<KeyT>(runs, at.block), run_rows(runs, at.block),
+                               static_cast<int64_t>(at.tile_in_block) * kTileRows, static_cast<int32_t>(run_base(runs, at.block)),
+                               run_filter(runs, at.block), run_out<uint64_t>(runs, at.block)};
+}
+
 }  // namespace qsx
 
 #ifndef __HIPCC_RTC__

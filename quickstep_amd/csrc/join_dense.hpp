@@ -59,27 +59,6 @@ __device__ __forceinline__ bool dense_row_in_filter(const uint64_t *filter, int6
   return filter == nullptr || ((filter[row >> 6] >> (63 - (row & 63))) & 1u);
 }
 
-// ---- a tile of a stripe, or of a run of blocks (block_runs.hpp) -----------------------------------------------------------
-template <typename KeyT>
-struct ProbeTileSource {
-  const KeyT *keys;
-  int64_t n;                 // rows of the block
-  int64_t base;              // first row of the tile within the block
-  int32_t base_tid;
-  const uint64_t *filter;
-  uint64_t *out_bitmap;
-};
-template <typename KeyT, int kTileRows, bool kRuns>
-__device__ __forceinline__ ProbeTileSource<KeyT> probe_tile_source(const long long *__restrict__ runs, int64_t tile,
-                                                                   const KeyT *keys, int64_t n, int32_t base_tid,
-                                                                   const uint64_t *filter, uint64_t *out_bitmap) {
-  if (!kRuns) return ProbeTileSource<KeyT>{keys, n, tile * kTileRows, base_tid, filter, out_bitmap};
-  const RunTile at = run_locate(runs, static_cast<int>(tile));
-  return ProbeTileSource<KeyT>{run_in<KeyT>(runs, at.block), run_rows(runs, at.block),
-                               static_cast<int64_t>(at.tile_in_block) * kTileRows, static_cast<int32_t>(run_base(runs, at.block)),
-                               run_filter(runs, at.block), run_out<uint64_t>(runs, at.block)};
-}
-
 // A wave owns groups of kBuildR x 64 rows: filter words with one load per group, next group's keys requested before the
 // current group's head words are claimed (the structure of dense_probe_kernel).
 // kRuns: the build side is a run of blocks (qsx_join_build_blocks): a group belongs to one block and takes its key stripe,

@@ -9,6 +9,9 @@
 // set; here each filter is one pass that ANDs into a bitmap.
 
 #include "common.hpp"
+#include "block_runs.hpp"
+
+#include <vector>
 
 namespace qsx {
 
@@ -24,29 +27,42 @@ struct LipView {
 
 // A wave owns groups of R x 64 rows; the R filter words of a group come with one load (lane r holds word r) and the
 // keys of the next group are requested before the bits of the current one are set (as in lip_probe_kernel below).
-template <typename KeyT, int R>
-__global__ __launch_bounds__(kLBlock) void lip_build_kernel(LipView f, const KeyT *__restrict__ keys, int64_t n,
-                                                           const uint64_t *__restrict__ filter) {
+// kRuns: the rows are a run of blocks (qsx_lip_build_blocks; block_runs.hpp), a group belongs to one block.
+template <typename KeyT, int R, bool kRuns = false>
+__global__ __launch_bounds__(kLBlock) void lip_build_kernel(LipView f, const KeyT *__restrict__ keys, int64_t n_arg,
+                                                           const uint64_t *__restrict__ filter, const long long *__restrict__ runs = nullptr) {
+  using Source = ProbeTileSource<KeyT>;
   const int lane = lane_id();
-  const int64_t num_words = (n + 63) >> 6;
-  const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kLBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t num_groups = kRuns ? runs[2] : (((n_arg + 63) >> 6) + R - 1) / R;
+  const int64_t wave = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (kLBlock / kWave) + (threadIdx.x >> 6)));
   const int64_t num_waves = static_cast<int64_t>(gridDim.x) * (kLBlock / kWave);
   KeyT key[R], next_key[R];
   uint64_t words = ~0ull, next_words = ~0ull;
-  auto request = [&](int64_t w0, KeyT (&k)[R], uint64_t &fw) {
+  auto source_of = [&](int64_t group) { return probe_tile_source<KeyT, R * kWave, kRuns>(runs, group, keys, n_arg, 0, filter, nullptr); };
+  auto request = [&](const Source &src, KeyT (&k)[R], uint64_t &fw) {
+    const int64_t sw0 = src.base >> 6;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t row = ((w0 + r) << 6) + lane;
-      k[r] = keys[row < n ? row : n - 1];   // clamped, not guarded: no branch around the read
+      const int64_t row = ((sw0 + r) << 6) + lane;
+      k[r] = src.keys[row < src.n ? row : src.n - 1];   // clamped, not guarded: no branch around the read
     }
     fw = ~0ull;
-    if (filter != nullptr && lane < R && w0 + lane < num_words) fw = filter[w0 + lane];
+    if (src.filter != nullptr && lane < R && sw0 + lane < ((src.n + 63) >> 6)) fw = src.filter[sw0 + lane];
   };
-  int64_t w0 = wave * R;
-  if (w0 < num_words) request(w0, key, words);
-  for (; w0 < num_words; w0 += num_waves * R) {
-    const int64_t w_next = w0 + num_waves * R;
-    if (w_next < num_words) request(w_next, next_key, next_words);
+  Source cur = Source(), next = Source();
+  int64_t group = wave;
+  if (group < num_groups) {
+    cur = source_of(group);
+    request(cur, key, words);
+  }
+  for (; group < num_groups; group += num_waves) {
+    if (group + num_waves < num_groups) {
+      next = source_of(group + num_waves);
+      request(next, next_key, next_words);
+    }
+    const int64_t w0 = cur.base >> 6;
+    const int64_t n = cur.n;
+    cur = next;
     // all R filter words are read first (unconditionally: dead lanes read word 0), then the missing bits are set with
     // fire-and-forget atomics: one round trip per group instead of one per row
     unsigned long long bit[R];
@@ -97,11 +113,15 @@ __device__ __forceinline__ long long lip_bit_index(const LipView &f, long long v
 // latency-bound: 0.52 ms / 100 M rows).  Filters of up to kLipLdsWords 32-bit words are copied into
 // LDS first (a 1 M-key exact filter is 128 KiB): the random reads then never leave the CU.
 constexpr int kLipLdsWords = 32 * 1024;  // 128 KiB
-template <typename KeyT, int R, bool kInLds>
-__global__ __launch_bounds__(kInLds ? 1024 : kLBlock) void lip_probe_kernel(LipView f, const KeyT *__restrict__ keys, int64_t n,
-                                                           const uint64_t *__restrict__ in_bitmap,
-                                                           uint64_t *__restrict__ out_bitmap,
-                                                           unsigned long long *__restrict__ out_count) {
+// kRuns: the rows are a run of blocks (qsx_lip_probe_blocks): a tile belongs to one block and takes its key stripe, row
+// count, input and output bitmap from the run table (whose tiles are R x blockDim.x rows); the counter is the run's.
+template <typename KeyT, int R, bool kInLds, bool kRuns = false>
+__global__ __launch_bounds__(kInLds ? 1024 : kLBlock) void lip_probe_kernel(LipView f, const KeyT *__restrict__ keys, int64_t n_arg,
+                                                           const uint64_t *__restrict__ in_bitmap_arg,
+                                                           uint64_t *__restrict__ out_bitmap_arg,
+                                                           unsigned long long *__restrict__ out_count,
+                                                           const long long *__restrict__ runs = nullptr) {
+  using Source = ProbeTileSource<KeyT>;
   extern __shared__ uint32_t s_filter[];
   const uint32_t *__restrict__ bits32 = reinterpret_cast<const uint32_t *>(f.words);
   if (kInLds) {
@@ -110,7 +130,6 @@ __global__ __launch_bounds__(kInLds ? 1024 : kLBlock) void lip_probe_kernel(LipV
     __syncthreads();
   }
   const int lane = lane_id();
-  const int64_t num_words = (n + 63) >> 6;
   const int waves_per_block = static_cast<int>(blockDim.x) / kWave;   // LDS variant: 16 waves share one copy of the filter
   const int wave = threadIdx.x >> 6;
   unsigned long long count = 0;
@@ -118,27 +137,40 @@ __global__ __launch_bounds__(kInLds ? 1024 : kLBlock) void lip_probe_kernel(LipV
   // workgroup reads blockDim.x consecutive keys per step and a wave's ballot is one bitmap word (index
   // tile_word0 + r * waves_per_block + wave; lane r loads / stores word r: one load and one store per tile and wave).
   // The keys and input words of the NEXT tile are requested before the filter words of the current one are read.
-  const int64_t tile_rows = static_cast<int64_t>(R) * blockDim.x;
-  const int64_t num_tiles = (n + tile_rows - 1) / tile_rows;
+  constexpr int kTileRows = R * (kInLds ? 1024 : kLBlock);   // = R * blockDim.x
+  const int64_t num_tiles = kRuns ? runs[2] : (n_arg + kTileRows - 1) / kTileRows;
   KeyT key[R], next_key[R];
   uint64_t in_words = ~0ull, next_in_words = ~0ull;
-  auto request = [&](int64_t tile, KeyT (&k)[R], uint64_t &words) {
-    const int64_t base = tile * tile_rows;
+  auto source_of = [&](int64_t tile) {
+    return probe_tile_source<KeyT, kTileRows, kRuns>(runs, tile, keys, n_arg, 0, in_bitmap_arg, out_bitmap_arg);
+  };
+  auto request = [&](const Source &src, KeyT (&k)[R], uint64_t &words) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t row = base + static_cast<int64_t>(r) * blockDim.x + threadIdx.x;
-      k[r] = __builtin_nontemporal_load(&keys[row < n ? row : n - 1]);   // clamped, not guarded
+      const int64_t row = src.base + static_cast<int64_t>(r) * blockDim.x + threadIdx.x;
+      k[r] = __builtin_nontemporal_load(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded
     }
     words = ~0ull;
-    if (in_bitmap != nullptr && lane < R) {
-      const int64_t w = (base >> 6) + lane * waves_per_block + wave;
-      if (w < num_words) words = in_bitmap[w];
+    if (src.filter != nullptr && lane < R) {
+      const int64_t w = (src.base >> 6) + lane * waves_per_block + wave;
+      if (w < ((src.n + 63) >> 6)) words = src.filter[w];
     }
   };
-  if (static_cast<int64_t>(blockIdx.x) < num_tiles) request(blockIdx.x, key, in_words);
+  Source cur = Source(), next = Source();
+  if (static_cast<int64_t>(blockIdx.x) < num_tiles) {
+    cur = source_of(blockIdx.x);
+    request(cur, key, in_words);
+  }
   for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-    const int64_t tile_base = tile * tile_rows;
-    if (tile + gridDim.x < num_tiles) request(tile + gridDim.x, next_key, next_in_words);
+    if (tile + gridDim.x < num_tiles) {
+      next = source_of(tile + gridDim.x);
+      request(next, next_key, next_in_words);
+    }
+    const int64_t tile_base = cur.base;
+    const int64_t n = cur.n;
+    uint64_t *const out_bitmap = cur.out_bitmap;
+    const int64_t num_words = (n + 63) >> 6;
+    cur = next;
     // bit position in 32 bits (filters have fewer than 2^32 bits: checked at creation); kNoBit = not representable
     constexpr uint32_t kNoBit = 0xFFFFFFFFu;
     uint32_t pos[R];
@@ -296,6 +328,101 @@ int qsx_lip_probe(const qsx_lip_filter_t *f, int key_type, const void *keys_dev,
     } else {
       hipLaunchKernelGGL((lip_probe_kernel<int64_t, RG, false>), dim3(grid), dim3(kLBlock), 0, s, f->view(),
                          static_cast<const int64_t *>(keys_dev), n, in_bitmap_dev, out_bitmap_dev, count);
+    }
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+// The table of a run (block_runs.hpp) on the device; *tiles = its tile count (0: nothing to do).
+static int upload_lip_run(long long tile_rows, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                          const uint64_t *const *block_in, uint64_t *const *block_out, hipStream_t s, const long long **runs_dev,
+                          long long *tiles) {
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0 || (block_rows[b] > 0 && (block_keys[b] == nullptr || (block_out != nullptr && block_out[b] == nullptr)))) {
+      return QSX_ERR_INVALID_ARGUMENT;
+    }
+  }
+  std::vector<long long> table;
+  *tiles = build_run_table(tile_rows, num_blocks, block_rows, block_keys, reinterpret_cast<const void *const *>(block_in),
+                           reinterpret_cast<void *const *>(block_out), nullptr, &table);
+  if (*tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (*tiles == 0) return QSX_OK;
+  const size_t bytes = table.size() * sizeof(long long);
+  *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
+  if (*runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  return staged_upload(s, table.data(), bytes);
+}
+
+int qsx_lip_build_blocks(qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                         const void *const *block_keys, const uint64_t *const *block_filters, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (f == nullptr || num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
+  if (key_type != QSX_INT && key_type != QSX_LONG) return QSX_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const long long *runs_dev = nullptr;
+  long long groups = 0;
+  const int rc = upload_lip_run(8 * kWave, num_blocks, block_rows, block_keys, block_filters, nullptr, s, &runs_dev, &groups);
+  if (rc != QSX_OK || groups == 0) return rc;
+  const int grid = grid_for(groups, kLBlock / kWave);
+  if (key_type == QSX_INT) {
+    hipLaunchKernelGGL((lip_build_kernel<int32_t, 8, true>), dim3(grid), dim3(kLBlock), 0, s, f->view(), static_cast<const int32_t *>(nullptr),
+                       int64_t{0}, static_cast<const uint64_t *>(nullptr), runs_dev);
+  } else {
+    hipLaunchKernelGGL((lip_build_kernel<int64_t, 8, true>), dim3(grid), dim3(kLBlock), 0, s, f->view(), static_cast<const int64_t *>(nullptr),
+                       int64_t{0}, static_cast<const uint64_t *>(nullptr), runs_dev);
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_lip_probe_blocks(const qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                         const void *const *block_keys, const uint64_t *const *block_in_bitmaps, uint64_t *const *block_out_bitmaps,
+                         int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (f == nullptr || num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr || block_out_bitmaps == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (key_type != QSX_INT && key_type != QSX_LONG) return QSX_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count_dev);
+  int64_t total = 0;
+  for (int64_t b = 0; b < num_blocks; ++b) total += block_rows[b] > 0 ? block_rows[b] : 0;
+  constexpr int R = 8;
+  const long long words32 = (f->cardinality + 31) >> 5;
+  const bool in_lds = words32 <= kLipLdsWords && total >= static_cast<int64_t>(kCUs) * 65536;
+  const long long *runs_dev = nullptr;
+  long long tiles = 0;
+  const int rc = upload_lip_run(static_cast<long long>(R) * (in_lds ? 1024 : kLBlock), num_blocks, block_rows, block_keys, block_in_bitmaps,
+                                block_out_bitmaps, s, &runs_dev, &tiles);
+  if (rc != QSX_OK || tiles == 0) return rc;
+  if (in_lds) {
+    const size_t lds = static_cast<size_t>(words32) * 4;
+#define QSX_LIP_LAUNCH_LDS_RUNS(KeyT)                                                                                 \
+    do {                                                                                                              \
+      static bool attribute_set = false;                                                                              \
+      if (!attribute_set) {                                                                                           \
+        QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&lip_probe_kernel<KeyT, R, true, true>),       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLipLdsWords * 4));              \
+        attribute_set = true;                                                                                         \
+      }                                                                                                               \
+      hipLaunchKernelGGL((lip_probe_kernel<KeyT, R, true, true>), dim3(kCUs), dim3(1024), lds, s, f->view(),         \
+                         static_cast<const KeyT *>(nullptr), int64_t{0}, static_cast<const uint64_t *>(nullptr),     \
+                         static_cast<uint64_t *>(nullptr), count, runs_dev);                                         \
+    } while (0)
+    if (key_type == QSX_INT) QSX_LIP_LAUNCH_LDS_RUNS(int32_t); else QSX_LIP_LAUNCH_LDS_RUNS(int64_t);
+#undef QSX_LIP_LAUNCH_LDS_RUNS
+  } else {
+    const int grid = static_cast<int>(tiles < 8 * kCUs ? tiles : 8 * kCUs);
+    if (key_type == QSX_INT) {
+      hipLaunchKernelGGL((lip_probe_kernel<int32_t, R, false, true>), dim3(grid), dim3(kLBlock), 0, s, f->view(),
+                         static_cast<const int32_t *>(nullptr), int64_t{0}, static_cast<const uint64_t *>(nullptr),
+                         static_cast<uint64_t *>(nullptr), count, runs_dev);
+    } else {
+      hipLaunchKernelGGL((lip_probe_kernel<int64_t, R, false, true>), dim3(grid), dim3(kLBlock), 0, s, f->view(),
+                         static_cast<const int64_t *>(nullptr), int64_t{0}, static_cast<const uint64_t *>(nullptr),
+                         static_cast<uint64_t *>(nullptr), count, runs_dev);
     }
   }
   QSX_CHECK_LAUNCH();

@@ -1412,6 +1412,23 @@ void LIPFilterBuilder::insertValueAccessor(const StorageBlock &block, const std:
     if (not_null != nullptr) CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
   }
 }
+bool LIPFilterBuilder::insertBlocks(const std::vector<BlockReference> &blocks) const {
+  for (const auto &e : entries_) {
+    for (const BlockReference &b : blocks) {
+      if (b->nullBitmap(e.second) != nullptr || b->compressedAttribute(e.second) != nullptr) return false;
+    }
+  }
+  std::vector<std::int64_t> rows;
+  for (const BlockReference &b : blocks) rows.push_back(b->numTuples());
+  std::vector<const void *> keys(blocks.size());
+  for (const auto &e : entries_) {
+    for (std::size_t b = 0; b < blocks.size(); ++b) keys[b] = blocks[b]->stripe(e.second);
+    CheckStatus(qsx_lip_build_blocks(e.first, blocks.front()->getRelation().getAttributeType(e.second).id,
+                                     static_cast<std::int64_t>(blocks.size()), rows.data(), keys.data(), nullptr, CurrentStream()),
+                "qsx_lip_build_blocks");
+  }
+  return true;
+}
 LIPFilterAdaptiveProber::LIPFilterAdaptiveProber(const QueryContext::LIPFilterDeployment &deployment,
                                                  const QueryContext &query_context) {
   for (const auto &e : deployment.probe_entries) entries_.emplace_back(query_context.getLIPFilterMutable(e.lip_filter), e.attribute);
@@ -1439,6 +1456,51 @@ void *LIPFilterAdaptiveProber::filterValueAccessor(const StorageBlock &block, co
   if (num_hits != nullptr) *num_hits = ReadCount(count.ptr);
   qsx_device_free(next);
   return current;
+}
+bool LIPFilterAdaptiveProber::filterBlocks(const std::vector<BlockReference> &blocks, void **storage,
+                                           std::vector<const std::uint64_t *> *bitmaps) const {
+  *storage = nullptr;
+  for (const auto &e : entries_) {
+    for (const BlockReference &b : blocks) {
+      if (b->nullBitmap(e.second) != nullptr || b->compressedAttribute(e.second) != nullptr) return false;
+    }
+  }
+  const std::size_t nb = blocks.size();
+  std::vector<std::int64_t> rows;
+  std::size_t words = 0;
+  for (const BlockReference &b : blocks) {
+    rows.push_back(b->numTuples());
+    words += static_cast<std::size_t>((b->numTuples() + 63) / 64) + 1;
+  }
+  // two sets of per-block bitmaps in one allocation; the filters ping-pong between them and the result ends in the first
+  CheckStatus(qsx_device_alloc(2 * words * 8 + 8, storage), "qsx_device_alloc(bitmaps)");
+  std::vector<std::uint64_t *> cur(nb), nxt(nb);
+  std::size_t at = 0;
+  for (std::size_t b = 0; b < nb; ++b) {
+    cur[b] = static_cast<std::uint64_t *>(*storage) + at;
+    nxt[b] = static_cast<std::uint64_t *>(*storage) + words + at;
+    at += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
+  }
+  std::vector<const void *> keys(nb);
+  bool first = true;
+  for (const auto &e : entries_) {
+    for (std::size_t b = 0; b < nb; ++b) keys[b] = blocks[b]->stripe(e.second);
+    CheckStatus(qsx_lip_probe_blocks(e.first, blocks.front()->getRelation().getAttributeType(e.second).id, static_cast<std::int64_t>(nb),
+                                     rows.data(), keys.data(), first ? nullptr : reinterpret_cast<const std::uint64_t *const *>(cur.data()),
+                                     nxt.data(), nullptr, CurrentStream()), "qsx_lip_probe_blocks");
+    std::swap(cur, nxt);
+    first = false;
+  }
+  if (first) {   // no filter attached: every tuple
+    for (std::size_t b = 0; b < nb; ++b) {
+      CheckStatus(qsx_memset_device(nxt[b], 0xFF, static_cast<std::size_t>((rows[b] + 63) / 64) * 8, CurrentStream()), "qsx_memset_device");
+      if (rows[b] > 0) {
+        CheckStatus(qsx_bitmap_combine(0, nxt[b], nxt[b], rows[b], cur[b], CurrentStream()), "qsx_bitmap_combine");   // clears the tail bits
+      }
+    }
+  }
+  bitmaps->assign(cur.begin(), cur.end());
+  return true;
 }
 LIPFilterBuilder *CreateLIPFilterBuilderHelper(QueryContext::lip_deployment_id id, const QueryContext *query_context) {
   const QueryContext::LIPFilterDeployment *d = query_context->getLIPDeployment(id);
@@ -1596,7 +1658,7 @@ void SelectWorkOrder::execute() {
 // terms like a conjunction), then the selected tuples of the run, block after block, are compacted into ONE output block
 // — what consecutive SelectWorkOrders do to an InsertDestination's current block (InsertDestination.cpp:222-260).
 bool SelectWorkOrder::executeRun() {
-  if (lip_filter_adaptive_prober_ != nullptr || predicate_ == nullptr || predicate_->conjuncts.empty()) return false;
+  if (predicate_ == nullptr || predicate_->conjuncts.empty()) return false;
   std::vector<attribute_id> selection;
   if (selection_ != nullptr && !selection_->empty()) {
     for (const ScalarPtr &scalar : *selection_) {
@@ -1639,13 +1701,23 @@ bool SelectWorkOrder::executeRun() {
     at += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
   }
   std::vector<const void *> stripes(nb);
+  // SelectOperator.cpp:161-195: predicate matches, then the LIP filters on what is left — here the filters run first and
+  // the predicate only looks at their survivors (the same conjunction, as in the single-block form)
+  struct OwnedStorage {
+    void *ptr = nullptr;
+    ~OwnedStorage() { qsx_device_free(ptr); }
+  } lip_storage;
+  std::vector<const std::uint64_t *> lip_bitmaps;
+  if (lip_filter_adaptive_prober_ != nullptr && !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps)) return false;
   bool first = true;
   for (const ComparisonPredicate &term : predicate_->conjuncts) {
     const Type &t = blocks.front()->getRelation().getAttributeType(term.attribute);
     for (std::size_t b = 0; b < nb; ++b) stripes[b] = blocks[b]->stripe(term.attribute);
+    const std::uint64_t *const *in = first ? (lip_bitmaps.empty() ? nullptr : lip_bitmaps.data())
+                                           : reinterpret_cast<const std::uint64_t *const *>(cur.data());
     CheckStatus(qsx_select_cmp_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
-                                      &term.literal.v, first ? nullptr : reinterpret_cast<const std::uint64_t *const *>(cur.data()),
-                                      nxt.data(), static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_cmp_blocks");
+                                      &term.literal.v, in, nxt.data(), static_cast<std::int64_t *>(counts.ptr), CurrentStream()),
+                "qsx_select_cmp_blocks");
     std::swap(cur, nxt);
     first = false;
   }
@@ -1895,7 +1967,7 @@ void BuildHashWorkOrder::execute() {
 }
 
 bool BuildHashWorkOrder::executeRun() {
-  if (predicate_ != nullptr || lip_filter_builder_ != nullptr || join_key_attributes_.size() != 1) return false;
+  if (predicate_ != nullptr || join_key_attributes_.size() != 1) return false;
   std::vector<BlockReference> blocks;
   std::vector<std::int64_t> rows;
   std::vector<const void *> keys;
@@ -1909,6 +1981,7 @@ bool BuildHashWorkOrder::executeRun() {
     keys.push_back(b.stripe(join_key_attributes_.front()));
     bases.push_back(static_cast<std::int32_t>(b.firstRow()));   // the stored reference: relation-global row number
   }
+  if (lip_filter_builder_ != nullptr && !lip_filter_builder_->insertBlocks(blocks)) return false;   // BuildHashOperator.cpp:187-190
   CheckStatus(qsx_join_build_blocks(hash_table_, static_cast<std::int64_t>(blocks.size()), rows.data(), keys.data(), bases.data(), nullptr,
                                     CurrentStream()), "qsx_join_build_blocks");
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
@@ -2078,10 +2151,7 @@ void HashInnerJoinWorkOrder::execute() {
 // stripes, the build side from the build relation's blocks — into ONE output block.
 bool HashInnerJoinWorkOrder::executeRun() {
   using JoinType = HashJoinOperator::JoinType;
-  if (join_type_ != JoinType::kInnerJoin || residual_predicate_ != nullptr || lip_filter_adaptive_prober_ != nullptr ||
-      join_key_attributes_.size() != 1) {
-    return false;
-  }
+  if (join_type_ != JoinType::kInnerJoin || residual_predicate_ != nullptr || join_key_attributes_.size() != 1) return false;
   std::vector<BlockReference> blocks;
   std::vector<std::int64_t> rows, first_rows;
   std::vector<const void *> keys;
@@ -2100,12 +2170,20 @@ bool HashInnerJoinWorkOrder::executeRun() {
   }
   if (total_rows > INT32_MAX || blocks.size() > 16384) return false;
   const std::int64_t nb = static_cast<std::int64_t>(blocks.size());
+  // existence_map of the LIPFilterAdaptiveProber (:462-470): the probe tuples this work order looks up
+  struct OwnedStorage {
+    void *ptr = nullptr;
+    ~OwnedStorage() { qsx_device_free(ptr); }
+  } lip_storage;
+  std::vector<const std::uint64_t *> lip_bitmaps;
+  if (lip_filter_adaptive_prober_ != nullptr && !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps)) return false;
+  const std::uint64_t *const *lookup = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();
   DeviceBuffer count(8);
-  CheckStatus(qsx_join_probe_count_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, static_cast<std::int64_t *>(count.ptr),
+  CheckStatus(qsx_join_probe_count_blocks(hash_table_, nb, rows.data(), keys.data(), lookup, static_cast<std::int64_t *>(count.ptr),
                                           CurrentStream()), "qsx_join_probe_count_blocks");
   const std::int64_t matches = ReadCount(count.ptr);
   DeviceBuffer probe_tids(static_cast<std::size_t>(matches) * 4 + 8), build_tids(static_cast<std::size_t>(matches) * 4 + 8);
-  CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, nullptr, static_cast<std::int32_t *>(probe_tids.ptr),
+  CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, lookup, static_cast<std::int32_t *>(probe_tids.ptr),
                                     static_cast<std::int32_t *>(build_tids.ptr), matches, static_cast<std::int64_t *>(count.ptr),
                                     CurrentStream()), "qsx_join_probe_blocks");
   BuildSegments build(build_relation_, storage_manager_);
@@ -2393,9 +2471,15 @@ class AggregationWorkOrder : public WorkOrder {
       std::vector<const std::uint64_t *> filters(blocks.size(), nullptr);
       std::vector<void *> owned;
       if (lip_filter_adaptive_prober_ != nullptr) {
-        for (std::size_t i = 0; i < blocks.size(); ++i) {
-          owned.push_back(lip_filter_adaptive_prober_->filterValueAccessor(*blocks[i], nullptr, nullptr));
-          filters[i] = static_cast<const std::uint64_t *>(owned.back());
+        void *storage = nullptr;
+        if (lip_filter_adaptive_prober_->filterBlocks(blocks, &storage, &filters)) {   // one launch per filter over the run
+          owned.push_back(storage);
+        } else {
+          filters.assign(blocks.size(), nullptr);
+          for (std::size_t i = 0; i < blocks.size(); ++i) {
+            owned.push_back(lip_filter_adaptive_prober_->filterValueAccessor(*blocks[i], nullptr, nullptr));
+            filters[i] = static_cast<const std::uint64_t *>(owned.back());
+          }
         }
       }
       state_->aggregateBlocks(blocks, filters);

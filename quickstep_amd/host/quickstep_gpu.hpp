@@ -522,6 +522,9 @@ class LIPFilterBuilder {
   LIPFilterBuilder(const QueryContext::LIPFilterDeployment &deployment, const QueryContext &query_context);
   // tuples of `block` selected by `filter` (nullptr = all)  (BuildHashOperator.cpp:187-190)
   void insertValueAccessor(const StorageBlock &block, const std::uint64_t *filter) const;
+  // A run of blocks, one launch per filter (qsx_lip_build_blocks); false when an inserted attribute is nullable or
+  // compressed in one of the blocks (nothing inserted: the caller goes block by block).
+  bool insertBlocks(const std::vector<BlockReference> &blocks) const;
  private:
   std::vector<std::pair<qsx_lip_filter_t *, attribute_id>> entries_;
 };
@@ -534,6 +537,10 @@ class LIPFilterAdaptiveProber {
   LIPFilterAdaptiveProber(const QueryContext::LIPFilterDeployment &deployment, const QueryContext &query_context);
   // Returns a device bitmap owned by the caller (qsx_device_free): `filter` AND all probes.  (:83-90)
   void *filterValueAccessor(const StorageBlock &block, const std::uint64_t *filter, std::int64_t *num_hits) const;
+  // The same for a run of blocks, one launch per filter (qsx_lip_probe_blocks): bitmaps[b] receives block b's TupleIdSequence.
+  // All bitmaps live in *storage (a device allocation owned by the caller: qsx_device_free).  Returns false — nothing
+  // allocated — when a probed attribute is nullable or compressed in one of the blocks (the caller goes block by block).
+  bool filterBlocks(const std::vector<BlockReference> &blocks, void **storage, std::vector<const std::uint64_t *> *bitmaps) const;
  private:
   std::vector<std::pair<qsx_lip_filter_t *, attribute_id>> entries_;
 };

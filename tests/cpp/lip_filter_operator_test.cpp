@@ -64,7 +64,9 @@ int main() {
     std::fprintf(stderr, "lip_filter_operator_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
     return 2;
   }
-  for (const bool use_foreman : {false, true}) {
+  for (const int variant : {0, 1, 2, 3}) {
+    const bool use_foreman = (variant & 1) != 0;
+    const std::size_t blocks_per_work_order = (variant & 2) != 0 ? 4 : 1;   // 4: work orders over runs of blocks
     for (const qsx_lip_kind_t kind : {QSX_LIP_BITVECTOR_EXACT, QSX_LIP_SINGLE_IDENTITY_HASH}) {
       Fixture f;
       CatalogRelation selected(3, "selected"), semi(4, "semi"), sums(5, "sums");
@@ -106,6 +108,10 @@ int main() {
                                           QueryContext::kInvalidPredicateId, semi_selection, &on_build,
                                           HashJoinOperator::JoinType::kLeftSemiJoin);
       prober->deployLIPFilters(probe_dep_id);
+      builder->setBlocksPerWorkOrder(blocks_per_work_order);
+      select->setBlocksPerWorkOrder(blocks_per_work_order);
+      aggregate->setBlocksPerWorkOrder(blocks_per_work_order);
+      prober->setBlocksPerWorkOrder(blocks_per_work_order);
       std::vector<std::unique_ptr<RelationalOperator>> owned;
       if (use_foreman) {
         QueryPlan plan;

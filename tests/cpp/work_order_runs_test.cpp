@@ -73,10 +73,34 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// A LIP filter over l_orderkey holding the keys below kLipLimit, built by a BuildHashOperator over a relation of those keys
+// (in 10 blocks; the build runs in the run form too).
+constexpr std::int32_t kLipLimit = 150000;
+QueryContext::lip_deployment_id deployLip(QueryContext *ctx, StorageManager *storage, CatalogRelation *small, std::size_t blocks_per_order) {
+  small->addAttribute("k", Type::Int());
+  std::vector<std::int32_t> ks(kLipLimit);
+  for (std::int32_t i = 0; i < kLipLimit; ++i) ks[i] = i;
+  for (std::size_t at = 0; at < ks.size(); at += 15000) storage->loadBlock(small, {ks.data() + at}, 15000);
+  const auto filter = ctx->addLIPFilter(QSX_LIP_BITVECTOR_EXACT, kLipLimit, 0);
+  QueryContext::LIPFilterDeployment build_dep, probe_dep;
+  build_dep.build_entries.push_back({filter, 0});
+  probe_dep.probe_entries.push_back({filter, 0});   // l_orderkey
+  const auto build_id = ctx->addLIPDeployment(build_dep);
+  const auto probe_id = ctx->addLIPDeployment(probe_dep);
+  const auto table = ctx->addJoinHashTable(kInt, kLipLimit);
+  BuildHashOperator builder(0, *small, true, {0}, false, 1, table);
+  builder.deployLIPFilters(build_id);
+  builder.setBlocksPerWorkOrder(blocks_per_order);
+  fetchAndExecuteWorkOrders(&builder, ctx, storage);
+  return probe_id;
+}
+
 // select l_orderkey, l_extendedprice from lineitem where l_quantity < 24 and l_extendedprice >= 20000.0
-Rows runSelect(bool nullable_quantity, std::size_t blocks_per_order, std::size_t *out_blocks, double *ms) {
+// [with_lip: and l_orderkey passes the LIP filter]
+Rows runSelect(bool nullable_quantity, std::size_t blocks_per_order, std::size_t *out_blocks, double *ms, bool with_lip = false) {
   StorageManager storage;
   Lineitem li(&storage, nullable_quantity);
+  CatalogRelation small(7, "small");
   CatalogRelation out(2, "selected");
   out.addAttribute("l_orderkey", Type::Int());
   out.addAttribute("l_extendedprice", Type::Double());
@@ -87,6 +111,7 @@ Rows runSelect(bool nullable_quantity, std::size_t blocks_per_order, std::size_t
   const auto pred = ctx.addPredicate(p);
   const auto dest = ctx.addInsertDestination(&out, &storage);
   SelectOperator op(0, li.rel, false, out, dest, pred, std::vector<attribute_id>{0, 2}, true);
+  if (with_lip) op.deployLIPFilters(deployLip(&ctx, &storage, &small, blocks_per_order));
   op.setBlocksPerWorkOrder(blocks_per_order);
   const double t0 = now_ms();
   fetchAndExecuteWorkOrders(&op, &ctx, &storage);
@@ -98,7 +123,7 @@ Rows runSelect(bool nullable_quantity, std::size_t blocks_per_order, std::size_t
   for (std::int64_t n : li.block_rows) {
     for (std::int64_t i = 0; i < n; ++i, ++row) {
       const bool is_null = nullable_quantity && i % 17 == 0;
-      if (!is_null && li.quantity[row] < 24 && li.price[row] >= 20000.0) {
+      if (!is_null && li.quantity[row] < 24 && li.price[row] >= 20000.0 && (!with_lip || li.orderkey[row] < kLipLimit)) {
         want.key.push_back(li.orderkey[row]);
         want.price.push_back(li.price[row]);
       }
@@ -112,9 +137,10 @@ Rows runSelect(bool nullable_quantity, std::size_t blocks_per_order, std::size_t
 
 // select l_orderkey [build side: o_orderkey], l_extendedprice from orders join lineitem on o_orderkey = l_orderkey,
 // orders = the even keys below 200000, each once, in 40 blocks
-Rows runJoin(bool exact_stats, std::size_t blocks_per_order, std::size_t *out_blocks, double *ms) {
+Rows runJoin(bool exact_stats, std::size_t blocks_per_order, std::size_t *out_blocks, double *ms, bool with_lip = false) {
   StorageManager storage;
   Lineitem li(&storage, false);
+  CatalogRelation small(7, "small");
   CatalogRelation orders(3, "orders");
   orders.addAttribute("o_orderkey", Type::Int());
   std::vector<std::int32_t> okeys;
@@ -133,6 +159,7 @@ Rows runJoin(bool exact_stats, std::size_t blocks_per_order, std::size_t *out_bl
   BuildHashOperator builder(0, orders, true, {0}, false, 1, table);
   HashJoinOperator prober(0, orders, li.rel, true, {0}, false, 1, false, out, dest, table, QueryContext::kInvalidPredicateId, selection,
                           &on_build, HashJoinOperator::JoinType::kInnerJoin);
+  if (with_lip) prober.deployLIPFilters(deployLip(&ctx, &storage, &small, blocks_per_order));
   prober.setBlocksPerWorkOrder(blocks_per_order);
   builder.setBlocksPerWorkOrder(blocks_per_order);
   const double tb = now_ms();
@@ -145,7 +172,7 @@ Rows runJoin(bool exact_stats, std::size_t blocks_per_order, std::size_t *out_bl
   std::vector<std::pair<std::int32_t, double>> g, w;
   for (std::size_t i = 0; i < got.key.size(); ++i) g.emplace_back(got.key[i], got.price[i]);
   for (std::size_t i = 0; i < li.orderkey.size(); ++i) {
-    if (li.orderkey[i] < 200000 && (li.orderkey[i] & 1) == 0) w.emplace_back(li.orderkey[i], li.price[i]);
+    if (li.orderkey[i] < (with_lip ? kLipLimit : 200000) && (li.orderkey[i] & 1) == 0) w.emplace_back(li.orderkey[i], li.price[i]);
   }
   std::sort(g.begin(), g.end());
   std::sort(w.begin(), w.end());
@@ -192,5 +219,14 @@ int main() {
                 "building from 40 blocks: %.2f ms / %.2f ms\n",
                 exact_stats ? "directly addressed" : "hashed", kBlocks, ms_one, ms_run, build_one, build_run);
   }
+  // LIP filters in the run forms: one qsx_lip_probe_blocks per filter in front of the predicate terms / the probe
+  runSelect(false, 1, &blocks_one, &ms_one, true);
+  runSelect(false, 64, &blocks_run, &ms_run, true);
+  EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
+  std::printf("select under a LIP filter: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n", ms_one, ms_run);
+  runJoin(true, 1, &blocks_one, &ms_one, true);
+  runJoin(true, 64, &blocks_run, &ms_run, true);
+  EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
+  std::printf("hash join under a LIP filter: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n", ms_one, ms_run);
   return finish("work_order_runs_test");
 }

@@ -93,3 +93,35 @@ def test_lip_probe_at_scale_lds_resident_filter(capi, oracle, dev, kind, anti, c
         # the same rows through the small-input path (sliced below the LDS threshold) give the same words
         bm2, _ = f.probe(probe[:m], in_bitmap=None if in_bitmap is None else in_bitmap[: m // 64])
         assert torch.equal(bm2[: m // 64], bm[: m // 64])
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("kind,anti", [(T.LIP_SINGLE_IDENTITY_HASH, False), (T.LIP_BITVECTOR_EXACT, False),
+                                       (T.LIP_BITVECTOR_EXACT, True)])
+@pytest.mark.parametrize("rows", [[5000, 0, 1, 2047, 2048, 2049, 70_001, 0, 33], [8192] * 6 + [100], [20_000_000, 5]])
+def test_lip_build_and_probe_over_runs_of_blocks(capi, oracle, dev, dtype, kind, anti, rows):
+    """qsx_lip_build_blocks / qsx_lip_probe_blocks: one launch over a run of blocks (own key stripes and bitmaps, gaps in the
+    bitmap lists) leaves the filter / gives the bitmaps of one call per block — also where the probe copies the filter to
+    LDS (a run of >= 16 M rows)."""
+    rng = np.random.default_rng(len(rows) + rows[0] % 97)
+    build_blocks = [rng.integers(100, 5000, size=n).astype(dtype) for n in (3000, 0, 1, 513, 4096)]
+    build_filters = [oracle.bitmap_from_bools(rng.random(b.size) < 0.9) if (i % 2 == 0 and b.size) else None for i, b in enumerate(build_blocks)]
+    allb = np.concatenate(build_blocks)
+    card, mn = (4099, 0) if kind == T.LIP_SINGLE_IDENTITY_HASH else (int(allb.max() - allb.min() + 1), int(allb.min()))
+    f = capi.LipFilter(kind, card, mn, anti)
+    o = oracle.LipFilter(kind, card, mn, anti)
+    f.build_blocks([to_dev(b, dev) for b in build_blocks], filters=[None if m is None else bitmap_dev(m, dev) for m in build_filters])
+    for b, m in zip(build_blocks, build_filters):
+        o.build(b, filter_bitmap=m)
+    probe_blocks = [rng.integers(-200, 6000, size=n).astype(dtype) for n in rows]
+    in_bitmaps = [oracle.bitmap_from_bools(rng.random(n) < 0.6) if (i % 3 != 1 and n) else None for i, n in enumerate(rows)]
+    dblocks = [to_dev(p, dev) for p in probe_blocks]
+    for use_in in (False, True):
+        outs, cnt = f.probe_blocks(dblocks, in_bitmaps=[None if m is None else bitmap_dev(m, dev) for m in in_bitmaps] if use_in else None)
+        total = 0
+        for i, p in enumerate(probe_blocks):
+            ref = o.probe(p, in_bitmap=in_bitmaps[i] if use_in else None)
+            if p.size:
+                assert np.array_equal(bitmap_np(outs[i]), ref), (i, p.size, use_in)
+            total += oracle.bitmap_count(ref, p.size)
+        assert int(cnt.item()) == total
