@@ -1458,7 +1458,7 @@ void *LIPFilterAdaptiveProber::filterValueAccessor(const StorageBlock &block, co
   return current;
 }
 bool LIPFilterAdaptiveProber::filterBlocks(const std::vector<BlockReference> &blocks, void **storage,
-                                           std::vector<const std::uint64_t *> *bitmaps) const {
+                                           std::vector<const std::uint64_t *> *bitmaps, std::int64_t *num_hits) const {
   *storage = nullptr;
   for (const auto &e : entries_) {
     for (const BlockReference &b : blocks) {
@@ -1482,14 +1482,23 @@ bool LIPFilterAdaptiveProber::filterBlocks(const std::vector<BlockReference> &bl
     at += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
   }
   std::vector<const void *> keys(nb);
+  DeviceBuffer count(8);
   bool first = true;
   for (const auto &e : entries_) {
     for (std::size_t b = 0; b < nb; ++b) keys[b] = blocks[b]->stripe(e.second);
     CheckStatus(qsx_lip_probe_blocks(e.first, blocks.front()->getRelation().getAttributeType(e.second).id, static_cast<std::int64_t>(nb),
                                      rows.data(), keys.data(), first ? nullptr : reinterpret_cast<const std::uint64_t *const *>(cur.data()),
-                                     nxt.data(), nullptr, CurrentStream()), "qsx_lip_probe_blocks");
+                                     nxt.data(), static_cast<std::int64_t *>(count.ptr), CurrentStream()), "qsx_lip_probe_blocks");
     std::swap(cur, nxt);
     first = false;
+  }
+  if (num_hits != nullptr) {
+    *num_hits = 0;
+    if (first) {
+      for (std::int64_t r : rows) *num_hits += r;
+    } else {
+      *num_hits = ReadCount(count.ptr);
+    }
   }
   if (first) {   // no filter attached: every tuple
     for (std::size_t b = 0; b < nb; ++b) {
@@ -1658,7 +1667,10 @@ void SelectWorkOrder::execute() {
 // terms like a conjunction), then the selected tuples of the run, block after block, are compacted into ONE output block
 // — what consecutive SelectWorkOrders do to an InsertDestination's current block (InsertDestination.cpp:222-260).
 bool SelectWorkOrder::executeRun() {
-  if (predicate_ == nullptr || predicate_->conjuncts.empty()) return false;
+  const bool has_terms = predicate_ != nullptr && !predicate_->conjuncts.empty();
+  if (!has_terms && lip_filter_adaptive_prober_ == nullptr) return false;   // a plain copy: block by block
+  static const Predicate no_terms;
+  const Predicate &predicate = has_terms ? *predicate_ : no_terms;
   std::vector<attribute_id> selection;
   if (selection_ != nullptr && !selection_->empty()) {
     for (const ScalarPtr &scalar : *selection_) {
@@ -1676,7 +1688,7 @@ bool SelectWorkOrder::executeRun() {
   for (block_id id : run_block_ids_) {
     blocks.push_back(storage_manager_->getBlock(id));
     const StorageBlock &b = *blocks.back();
-    for (const ComparisonPredicate &term : predicate_->conjuncts) {
+    for (const ComparisonPredicate &term : predicate.conjuncts) {
       const Type &t = b.getRelation().getAttributeType(term.attribute);
       if (term.rhs_attribute != kInvalidAttributeID || b.compressedAttribute(term.attribute) != nullptr || t.id == kChar ||
           term.attribute == b.sortColumn() || b.nullBitmap(term.attribute) != nullptr) {
@@ -1708,9 +1720,13 @@ bool SelectWorkOrder::executeRun() {
     ~OwnedStorage() { qsx_device_free(ptr); }
   } lip_storage;
   std::vector<const std::uint64_t *> lip_bitmaps;
-  if (lip_filter_adaptive_prober_ != nullptr && !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps)) return false;
+  std::int64_t lip_hits = 0;
+  if (lip_filter_adaptive_prober_ != nullptr &&
+      !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps, has_terms ? nullptr : &lip_hits)) {
+    return false;
+  }
   bool first = true;
-  for (const ComparisonPredicate &term : predicate_->conjuncts) {
+  for (const ComparisonPredicate &term : predicate.conjuncts) {
     const Type &t = blocks.front()->getRelation().getAttributeType(term.attribute);
     for (std::size_t b = 0; b < nb; ++b) stripes[b] = blocks[b]->stripe(term.attribute);
     const std::uint64_t *const *in = first ? (lip_bitmaps.empty() ? nullptr : lip_bitmaps.data())
@@ -1721,11 +1737,16 @@ bool SelectWorkOrder::executeRun() {
     std::swap(cur, nxt);
     first = false;
   }
-  std::vector<std::int64_t> block_matches(nb);
-  CheckStatus(qsx_copy_to_host(block_matches.data(), counts.ptr, nb * 8, CurrentStream()), "qsx_copy_to_host");
-  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
-  std::int64_t matches = 0;
-  for (std::int64_t m : block_matches) matches += m;
+  std::int64_t matches = lip_hits;
+  const std::uint64_t *const *selected = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();   // only LIP filters: their bitmaps
+  if (has_terms) {
+    std::vector<std::int64_t> block_matches(nb);
+    CheckStatus(qsx_copy_to_host(block_matches.data(), counts.ptr, nb * 8, CurrentStream()), "qsx_copy_to_host");
+    CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+    matches = 0;
+    for (std::int64_t m : block_matches) matches += m;
+    selected = reinterpret_cast<const std::uint64_t *const *>(cur.data());
+  }
   block_id out_id;
   BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
   std::vector<const void *> src(nb * selection.size());
@@ -1739,7 +1760,7 @@ bool SelectWorkOrder::executeRun() {
   const std::size_t ws_bytes = qsx_compact_blocks_workspace_bytes(static_cast<std::int64_t>(nb), rows.data());
   DeviceBuffer ws(ws_bytes + 8), count(8);
   CheckStatus(qsx_compact_gather_blocks(static_cast<int>(selection.size()), widths.data(), static_cast<std::int64_t>(nb), rows.data(),
-                                        src.data(), reinterpret_cast<const std::uint64_t *const *>(cur.data()), nullptr, dst.data(),
+                                        src.data(), selected, nullptr, dst.data(),
                                         nullptr, static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
               "qsx_compact_gather_blocks");
   const std::int64_t written = ReadCount(count.ptr);   // synchronises the work order, like the reference's execute()
@@ -2151,7 +2172,8 @@ void HashInnerJoinWorkOrder::execute() {
 // stripes, the build side from the build relation's blocks — into ONE output block.
 bool HashInnerJoinWorkOrder::executeRun() {
   using JoinType = HashJoinOperator::JoinType;
-  if (join_type_ != JoinType::kInnerJoin || residual_predicate_ != nullptr || join_key_attributes_.size() != 1) return false;
+  const bool existence = join_type_ == JoinType::kLeftSemiJoin || join_type_ == JoinType::kLeftAntiJoin;
+  if ((join_type_ != JoinType::kInnerJoin && !existence) || residual_predicate_ != nullptr || join_key_attributes_.size() != 1) return false;
   std::vector<BlockReference> blocks;
   std::vector<std::int64_t> rows, first_rows;
   std::vector<const void *> keys;
@@ -2179,6 +2201,42 @@ bool HashInnerJoinWorkOrder::executeRun() {
   if (lip_filter_adaptive_prober_ != nullptr && !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps)) return false;
   const std::uint64_t *const *lookup = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();
   DeviceBuffer count(8);
+  if (existence) {
+    // HashSemiJoinWorkOrder / HashAntiJoinWorkOrder without residual (:795-816, :860-877): the probe tuples with / without a
+    // match, projected on the probe attributes — one existence probe and one compaction over the run
+    std::size_t words = 0;
+    for (std::int64_t r : rows) words += static_cast<std::size_t>((r + 63) / 64) + 1;
+    DeviceBuffer bitmap_storage(words * 8 + 8);
+    std::vector<std::uint64_t *> bitmaps(blocks.size());
+    std::size_t at = 0;
+    for (std::size_t b = 0; b < blocks.size(); ++b) {
+      bitmaps[b] = static_cast<std::uint64_t *>(bitmap_storage.ptr) + at;
+      at += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
+    }
+    CheckStatus(qsx_join_probe_exists_blocks(hash_table_, nb, rows.data(), keys.data(), lookup, join_type_ == JoinType::kLeftAntiJoin ? 1 : 0,
+                                             bitmaps.data(), static_cast<std::int64_t *>(count.ptr), CurrentStream()),
+                "qsx_join_probe_exists_blocks");
+    const std::int64_t selected = ReadCount(count.ptr);
+    block_id out_id;
+    BlockReference out = output_destination_->getBlockForInsertion(selected > 0 ? selected : 1, &out_id);
+    std::vector<const void *> src(blocks.size() * selection_.size());
+    std::vector<void *> dst;
+    std::vector<std::int32_t> widths;
+    for (std::size_t i = 0; i < selection_.size(); ++i) {
+      dst.push_back(out->stripe(static_cast<attribute_id>(i)));
+      widths.push_back(probe_relation_.getAttributeType(selection_[i]).width);
+      for (std::size_t b = 0; b < blocks.size(); ++b) src[b * selection_.size() + i] = blocks[b]->stripe(selection_[i]);
+    }
+    const std::size_t ws_bytes = qsx_compact_blocks_workspace_bytes(nb, rows.data());
+    DeviceBuffer ws(ws_bytes + 8);
+    CheckStatus(qsx_compact_gather_blocks(static_cast<int>(selection_.size()), widths.data(), nb, rows.data(), src.data(),
+                                          reinterpret_cast<const std::uint64_t *const *>(bitmaps.data()), nullptr, dst.data(), nullptr,
+                                          static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
+                "qsx_compact_gather_blocks");
+    const std::int64_t written = ReadCount(count.ptr);
+    output_destination_->returnBlock(out_id, written);
+    return true;
+  }
   CheckStatus(qsx_join_probe_count_blocks(hash_table_, nb, rows.data(), keys.data(), lookup, static_cast<std::int64_t *>(count.ptr),
                                           CurrentStream()), "qsx_join_probe_count_blocks");
   const std::int64_t matches = ReadCount(count.ptr);

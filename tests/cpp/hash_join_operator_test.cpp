@@ -100,6 +100,8 @@ bool g_exact_stats = false;
 // 0: unpartitioned; 1: both tables hash-partitioned 4 ways on `long` (the ...WithSingleAttributePartitions tests,
 // :1379-1875); 2: only the probe side partitioned — broadcast build into all 4 tables.
 int g_partitioning = 0;
+// > 1: BuildHash and HashJoin work orders cover runs of this many blocks (setBlocksPerWorkOrder)
+std::size_t g_blocks_per_work_order = 1;
 
 void runJoin(attribute_id key_attr, TypeID key_type, bool use_foreman, HashJoinOperator::JoinType join_type, Result *out) {
   Fixture f(g_partitioning != 0, g_partitioning == 1);
@@ -126,6 +128,8 @@ void runJoin(attribute_id key_attr, TypeID key_type, bool use_foreman, HashJoinO
   auto *prober = new HashJoinOperator(0, f.dim, f.fact, true, {key_attr}, false, parts, false, result, dest, table,
                                       QueryContext::kInvalidPredicateId, selection, &on_build, join_type);
   auto *cleaner = new DestroyHashOperator(0, parts, table);
+  builder->setBlocksPerWorkOrder(g_blocks_per_work_order);
+  prober->setBlocksPerWorkOrder(g_blocks_per_work_order);
   if (use_foreman) {
     QueryPlan plan;
     const auto b = plan.addRelationalOperator(builder);
@@ -138,7 +142,7 @@ void runJoin(attribute_id key_attr, TypeID key_type, bool use_foreman, HashJoinO
     const std::size_t build_orders = g_partitioning == 0 ? kNumDimTuples / kBlockSize
                                      : g_partitioning == 1 ? kMultiplePartitions : kMultiplePartitions /* 1 block x 4 tables */;
     const std::size_t probe_orders = g_partitioning == 0 ? kNumFactTuples / kBlockSize : kMultiplePartitions;
-    EXPECT_EQ(foreman.getWorkOrderProfilingResults().size(), build_orders + probe_orders + parts);
+    if (g_blocks_per_work_order == 1) EXPECT_EQ(foreman.getWorkOrderProfilingResults().size(), build_orders + probe_orders + parts);
   } else {
     std::unique_ptr<RelationalOperator> b(builder), p(prober), c(cleaner);
     fetchAndExecuteWorkOrders(b.get(), &ctx, &f.storage);
@@ -185,6 +189,8 @@ JoinedRows runGeneralJoin(const std::vector<attribute_id> &keys, TypeID table_ke
   auto *prober = new HashJoinOperator(0, f.dim, f.fact, true, keys, false, parts, false, result, dest, table, residual_id, selection,
                                       &on_build, join_type);
   auto *cleaner = new DestroyHashOperator(0, parts, table);
+  builder->setBlocksPerWorkOrder(g_blocks_per_work_order);
+  prober->setBlocksPerWorkOrder(g_blocks_per_work_order);
   std::unique_ptr<RelationalOperator> b, p, c;
   if (use_foreman) {
     QueryPlan plan;
@@ -226,10 +232,11 @@ int main() {
     std::fprintf(stderr, "hash_join_operator_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
     return 2;
   }
-  for (const int variant : {0, 1, 2, 3, 4, 5, 6, 7, 8, 9}) {
+  for (const int variant : {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13}) {
     const bool use_foreman = (variant & 1) != 0;
     g_exact_stats = (variant & 2) != 0;
-    g_partitioning = variant < 4 ? 0 : (variant < 8 ? 1 : 2);   // 8, 9: broadcast build, hashed tables
+    g_partitioning = variant >= 10 || variant < 4 ? 0 : (variant < 8 ? 1 : 2);   // 8, 9: broadcast build, hashed tables
+    g_blocks_per_work_order = variant >= 10 ? 7 : 1;                              // 10..13: runs of 7 of the 10-tuple blocks
     {  // LongKeyHashJoinTest: 200 results, every dim.long exactly once (:510-514)
       Result r;
       runJoin(0, kLong, use_foreman, HashJoinOperator::JoinType::kInnerJoin, &r);
@@ -267,15 +274,17 @@ int main() {
       for (std::size_t i = 0; i < anti.dim_long.size(); ++i) EXPECT_EQ(anti.dim_long[i], static_cast<std::int64_t>(kNumDimTuples + i));
     }
   }
+  g_blocks_per_work_order = 1;
   // ---- composite keys, residual predicates, outer join -------------------------------------------------------------
   using JT = HashJoinOperator::JoinType;
   Predicate dim_long_lt_15;   // residual of CompositeKeyHashJoinWithResidualPredicateTest (:1268-1272): dim.long < 15
   dim_long_lt_15.conjuncts.push_back(ComparisonPredicate(0, ComparisonID::kLess, TypedLiteral::Long(15), /*build_side=*/true));
   const std::vector<std::vector<attribute_id>> composite_keys = {{0, 2} /* (LONG, LONG): hashed fold + component check */,
                                                                  {4, 3} /* (INT, INT): exact 8-byte packing */};
-  for (const int variant : {0, 1, 2, 3, 4, 5}) {
+  for (const int variant : {0, 1, 2, 3, 4, 5, 6, 7}) {
     const bool use_foreman = (variant & 1) != 0;
-    g_partitioning = variant / 2;
+    g_partitioning = variant >= 6 ? 0 : variant / 2;
+    g_blocks_per_work_order = variant >= 6 ? 7 : 1;   // 6, 7: run work orders (these joins fall back to block by block inside them)
     for (const auto &keys : composite_keys) {
       {  // CompositeKeyHashJoinTest: 100 results, the even tids below 200, each once on both sides (:1159-1177)
         JoinedRows r = runGeneralJoin(keys, kLong, nullptr, JT::kInnerJoin, use_foreman);
