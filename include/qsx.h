@@ -607,6 +607,15 @@ int qsx_agg_update(qsx_agg_state_t *state, const void *const *cols, int64_t n,
 int qsx_agg_update_blocks(qsx_agg_state_t *state, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
                           const uint64_t *const *block_filters, qsx_stream_t stream);
 
+/* qsx_agg_update_coded over a run of blocks in one launch: every block its own code stripes / value stripes and its own
+ * dictionaries (the reference compresses block by block: CompressedBlockBuilder picks dictionary or truncation per block and
+ * attribute, storage/CompressedBlockBuilder.cpp:120-260 — the state's column_code_width fixes the code width of a column for
+ * all blocks it is handed; blocks that chose differently go through another state).
+ *   block_cols           [b * num_columns + c]: code stripe where column_code_width[c] != 0, else the value stripe
+ *   block_dictionaries   [b * num_columns + c]: dictionary of block b's column c (NULL: truncated or uncompressed) */
+int qsx_agg_update_coded_blocks(qsx_agg_state_t *state, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
+                                const void *const *block_dictionaries, const uint64_t *const *block_filters, qsx_stream_t stream);
+
 /* qsx_agg_update on a block with NULLs: null_bitmaps_dev[c] is the null bitmap of column c (TupleIdSequence bit
  * order, bit i set = tuple i is NULL, n bits; storage/BasicColumnStoreTupleStorageSubBlock.cpp:131-147 keeps one per
  * nullable attribute) or NULL when the block holds no NULL in that attribute; entries of columns not declared

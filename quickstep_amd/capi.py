@@ -101,6 +101,7 @@ _SIGNATURES = {
     "qsx_agg_state_clear": (_int, [_vp, _vp]),
     "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
     "qsx_agg_update_blocks": (_int, [_vp, _int, C.POINTER(_i64), _pp, _pp, _vp]),
+    "qsx_agg_update_coded_blocks": (_int, [_vp, _int, C.POINTER(_i64), _pp, _pp, _pp, _vp]),
     "qsx_agg_mark_existence": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "qsx_agg_update_coded": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
     "qsx_agg_update_nullable": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
@@ -629,6 +630,22 @@ class AggState:
         if filters is not None:
             fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None else None for f in filters])
         _check(_lib.qsx_agg_update_blocks(self._h, nb, rows, ptrs, fptr, _stream(stream)), "qsx_agg_update_blocks")
+
+    def update_coded_blocks(self, blocks, dictionaries, filters=None, stream=None):
+        """qsx_agg_update_coded over a run of blocks: blocks[b][c] = code / value stripe, dictionaries[b][c] = dictionary or None."""
+        nb, ncols = len(blocks), self.config.num_columns
+        rows = (C.c_int64 * max(nb, 1))(*[b[0].numel() if b else 0 for b in blocks])
+        ptrs = (C.c_void_p * max(nb * ncols, 1))()
+        dptr = (C.c_void_p * max(nb * ncols, 1))()
+        for i, b in enumerate(blocks):
+            for c in range(ncols):
+                ptrs[i * ncols + c] = b[c].data_ptr() if c < len(b) and b[c] is not None else None
+                d = dictionaries[i][c] if c < len(dictionaries[i]) else None
+                dptr[i * ncols + c] = d.data_ptr() if d is not None else None
+        fptr = None
+        if filters is not None:
+            fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None else None for f in filters])
+        _check(_lib.qsx_agg_update_coded_blocks(self._h, nb, rows, ptrs, dptr, fptr, _stream(stream)), "qsx_agg_update_coded_blocks")
 
     def update_nullable(self, cols, null_bitmaps, n=None, filter_bitmap=None, stream=None):
         """null_bitmaps[c]: int64 tensor with the null bitmap words of column c (TupleIdSequence bit order) or None."""

@@ -354,9 +354,11 @@ constexpr int kHashCtlWords = 8;   // control words behind the LDS accumulator p
 // Layout in device memory (8-byte words): [0] kBlockRunMagic, [1] number of blocks, then the word offsets (from word 0) of
 // [2] first_tile for 1024-row tiles (num_blocks + 1 words: tiles before block b), [3] the same for 512-row tiles,
 // [4] rows per block, [5] column base pointers [block * QSX_MAX_COLUMNS + column], [6] filter bitmap per block (0: none),
-// [7] tiles per block when all blocks but the last have the same number of 1024-row tiles (0: ragged run, binary search).
+// [7] tiles per block when all blocks but the last have the same number of 1024-row tiles (0: ragged run, binary search),
+// [8] dictionaries of the compressed columns [block * QSX_MAX_COLUMNS + column] (0: the state has none; an entry is 0 for a
+// truncated or uncompressed column).
 constexpr long long kBlockRunMagic = -0x424C4B52554E31ll;
-constexpr int kBlockRunHeaderWords = 8;
+constexpr int kBlockRunHeaderWords = 10;
 struct BlockRunView {
   long long uniform_tiles;   // > 0: every block but the last has this many tiles — block of tile t = t / uniform_tiles, no search
   long long num_blocks;
@@ -364,6 +366,7 @@ struct BlockRunView {
   const long long *rows;
   const void *const *cols;
   const unsigned long long *const *filters;
+  const void *const *dicts;
 };
 __device__ __forceinline__ bool is_block_run(const long long *pieces) { return pieces != nullptr && pieces[0] == kBlockRunMagic; }
 __device__ __forceinline__ BlockRunView block_run_view(const long long *table, int tile_rows) {
@@ -377,6 +380,7 @@ __device__ __forceinline__ BlockRunView block_run_view(const long long *table, i
   v.rows = table + table[4];
   v.cols = reinterpret_cast<const void *const *>(table + table[5]);
   v.filters = table[6] != 0 ? reinterpret_cast<const unsigned long long *const *>(table + table[6]) : nullptr;
+  v.dicts = table[8] != 0 ? reinterpret_cast<const void *const *>(table + table[8]) : nullptr;
   return v;
 }
 // Block of tile t: the last b with first_tile[b] <= t (workgroup-uniform: ~10 scalar steps for a thousand blocks).

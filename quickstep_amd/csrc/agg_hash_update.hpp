@@ -151,7 +151,7 @@ __device__ __forceinline__ void decode_tile_codes(const DevConfig &c, const void
     if (c.code_width[col] == 0 || c.lds_off[col] < 0) return;
     const char *codes = tile + c.code_off[col];
     char *slots = tile + c.lds_off[col];
-    const void *dict = dicts != nullptr ? dicts[col] : nullptr;
+    const void *dict = dicts != nullptr ? as_global(dicts[col]) : nullptr;   // (from a table of a run: tell the compiler it is device memory)
     uint32_t code[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -560,6 +560,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const void *const *cols;
     ColumnBases bases;       // kRuns only
     const uint64_t *filter;
+    const void *const *dicts;   // kRuns only: the block's dictionaries
     int64_t row0;
     int rows;
   };
@@ -575,12 +576,14 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         }
       }
       src.filter = run.filters != nullptr ? reinterpret_cast<const uint64_t *>(run.filters[b]) : nullptr;
+      src.dicts = run.dicts != nullptr ? run.dicts + b * QSX_MAX_COLUMNS : nullptr;
       src.row0 = (t - run.first_tile[b]) * TR;
       const long long left = run.rows[b] - src.row0;
       src.rows = static_cast<int>(left < TR ? left : TR);
     } else {
       src.cols = cols;
       src.filter = filter;
+      src.dicts = dicts;
       src.row0 = tile_row0(t);
       src.rows = tile_rows(t);
     }
@@ -687,7 +690,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const int rows = here.rows;
 
     const int trow = threadIdx.x;  // this thread's first row of the tile
-    decode_tile_codes<kStatic, V, BLOCK>(c, dicts, tile, trow, rows);
+    decode_tile_codes<kStatic, V, BLOCK>(c, kRuns ? here.dicts : dicts, tile, trow, rows);
 
     // ---- which rows are live -------------------------------------------------
     bool live[V];

@@ -1791,18 +1791,19 @@ int qsx_agg_update_nullable(qsx_agg_state_t *st, const void *const *cols, const 
   return agg_update(st, cols, nullptr, n, filter_dev, stream, null_bitmaps_dev);
 }
 
-int qsx_agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
-                          const uint64_t *const *block_filters, qsx_stream_t stream) {
+// block_dicts: the dictionaries of a state over compressed attributes, [block * num_columns + column] (nullptr otherwise).
+static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
+                             const void *const *block_dicts, const uint64_t *const *block_filters, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (st == nullptr || num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_cols == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
-  // (compressed and nullable inputs carry per-block dictionaries / null bitmaps: one call per block, qsx_agg_update_coded /
-  // qsx_agg_update_nullable)
-  if (st->has_coded_columns || st->dev.num_null_cols != 0) return QSX_ERR_UNSUPPORTED;
+  // (nullable inputs carry per-block null bitmaps: one call per block, qsx_agg_update_nullable)
+  if (st->dev.num_null_cols != 0) return QSX_ERR_UNSUPPORTED;
+  if (st->has_coded_columns != (block_dicts != nullptr)) return st->has_coded_columns ? QSX_ERR_INVALID_ARGUMENT : QSX_ERR_UNSUPPORTED;
   const int ncols = st->config.num_columns;
   // the table (agg_common.hpp): header, first_tile for 1024- and 512-row tiles, rows, column pointers, filters
   std::vector<long long> table(kBlockRunHeaderWords);
   std::vector<long long> tiles1024, tiles512, rows, filters;
-  std::vector<long long> cols;
+  std::vector<long long> cols, dicts;
   int64_t total = 0;
   bool any_filter = false;
   const void *first_cols[QSX_MAX_COLUMNS] = {};
@@ -1820,6 +1821,10 @@ int qsx_agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *bl
       const void *p = c < ncols ? block_cols[static_cast<size_t>(b) * ncols + c] : nullptr;
       if (c < ncols && ((st->used_columns >> c) & 1u) != 0 && p == nullptr) return QSX_ERR_INVALID_ARGUMENT;
       cols.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(p)));
+      if (block_dicts != nullptr) {
+        const void *d = c < ncols && st->dev.code_width[c] != 0 ? block_dicts[static_cast<size_t>(b) * ncols + c] : nullptr;
+        dicts.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(d)));
+      }
     }
     const uint64_t *f = block_filters != nullptr ? block_filters[b] : nullptr;
     if (f != nullptr && first_filter == nullptr) first_filter = f;
@@ -1832,8 +1837,10 @@ int qsx_agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *bl
   tiles512.push_back(tiles512.back() + (rows.back() + 511) / 512);
   const size_t nb = rows.size();
   const size_t off1024 = kBlockRunHeaderWords, off512 = off1024 + nb + 1, off_rows = off512 + nb + 1, off_cols = off_rows + nb,
-               off_filters = off_cols + nb * QSX_MAX_COLUMNS, words = off_filters + nb;
+               off_filters = off_cols + nb * QSX_MAX_COLUMNS, off_dicts = off_filters + nb,
+               words = off_dicts + (block_dicts != nullptr ? nb * QSX_MAX_COLUMNS : 0);
   table.resize(words);
+  std::copy(dicts.begin(), dicts.end(), table.begin() + off_dicts);
   std::copy(tiles1024.begin(), tiles1024.end(), table.begin() + off1024);
   std::copy(tiles512.begin(), tiles512.end(), table.begin() + off512);
   std::copy(rows.begin(), rows.end(), table.begin() + off_rows);
@@ -1850,6 +1857,7 @@ int qsx_agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *bl
   table[5] = static_cast<long long>(off_cols);
   table[6] = any_filter ? static_cast<long long>(off_filters) : 0;
   table[7] = 0;
+  table[8] = block_dicts != nullptr ? static_cast<long long>(off_dicts) : 0;
   {   // equal-sized blocks (a relation's blocks all hold the same number of tuples but the last): no search per tile
     const long long per_block = (rows[0] + 1023) / 1024;
     bool uniform = per_block > 0;
@@ -1868,6 +1876,18 @@ int qsx_agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *bl
                     dev_table);
   if (rc != QSX_OK) return rc;
   return publish_control(st, s);
+}
+
+int qsx_agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
+                          const uint64_t *const *block_filters, qsx_stream_t stream) {
+  return agg_update_blocks(st, num_blocks, block_rows, block_cols, nullptr, block_filters, stream);
+}
+
+int qsx_agg_update_coded_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
+                                const void *const *block_dictionaries, const uint64_t *const *block_filters, qsx_stream_t stream) {
+  if (num_blocks > 0 && block_dictionaries == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  static const void *const no_dictionaries[1] = {nullptr};
+  return agg_update_blocks(st, num_blocks, block_rows, block_cols, num_blocks > 0 ? block_dictionaries : no_dictionaries, block_filters, stream);
 }
 
 int qsx_agg_update_coded(qsx_agg_state_t *st, const void *const *cols, const void *const *dictionaries_dev, int64_t n,

@@ -1123,15 +1123,55 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
   std::vector<const void *> cols;
   std::vector<const std::uint64_t *> filters;
   bool any_filter = false;
+  std::vector<std::int64_t> coded_rows;
+  std::vector<const void *> coded_cols, coded_dicts;
+  std::vector<const std::uint64_t *> coded_filters;
+  bool any_coded_filter = false;
   const bool state_allows = state_ != nullptr && distinctify_.empty() && external_predicate_.conjuncts.empty();
   for (std::size_t i = 0; i < blocks.size(); ++i) {
     const StorageBlock &block = *blocks[i];
     const std::uint64_t *filter = i < lip_filters.size() ? lip_filters[i] : nullptr;
     bool in_run = state_allows && block.numTuples() > 0;
+    int code_width[QSX_MAX_COLUMNS] = {};
+    bool any_coded = false;
     for (std::size_t c = 0; c < column_attr_.size() && in_run; ++c) {
-      // per-block dictionaries and null bitmaps travel with single-block calls (qsx_agg_update_coded / _nullable)
+      // null bitmaps travel with single-block calls (qsx_agg_update_nullable)
       if (block.nullBitmap(column_attr_[c]) != nullptr) in_run = false;
-      if (block.compressedAttribute(column_attr_[c]) != nullptr && !block.valuesMaterialized(column_attr_[c])) in_run = false;
+      const CompressedAttribute *ca = block.compressedAttribute(column_attr_[c]);
+      if (ca != nullptr && config_.column_type[c] != kChar && !block.valuesMaterialized(column_attr_[c])) {
+        code_width[c] = ca->code_width;          // aggregated on its codes, like aggregateBlock does
+        any_coded = true;
+      }
+    }
+    if (in_run && any_coded) {
+      // compressed blocks: one run through the state over code stripes (created by the first such block, which fixes the code
+      // widths; a block that compressed differently goes block by block)
+      bool use_coded = false;
+      {
+        std::lock_guard<std::mutex> lock(coded_mutex_);
+        if (coded_state_ == nullptr && !coded_merged_) {
+          coded_config_ = config_;
+          for (std::size_t c = 0; c < column_attr_.size(); ++c) coded_config_.column_code_width[c] = code_width[c];
+          CheckStatus(qsx_agg_state_create(&coded_config_, &coded_state_), "qsx_agg_state_create");
+        }
+        if (coded_state_ != nullptr && !coded_merged_) {
+          use_coded = true;
+          for (std::size_t c = 0; c < column_attr_.size(); ++c) use_coded = use_coded && coded_config_.column_code_width[c] == code_width[c];
+        }
+      }
+      if (!use_coded) {
+        aggregateBlock(block, filter);
+        continue;
+      }
+      coded_rows.push_back(block.numTuples());
+      for (std::size_t c = 0; c < column_attr_.size(); ++c) {
+        const CompressedAttribute *ca = code_width[c] != 0 ? block.compressedAttribute(column_attr_[c]) : nullptr;
+        coded_cols.push_back(ca != nullptr ? ca->codes : block.stripe(column_attr_[c]));
+        coded_dicts.push_back(ca != nullptr && ca->kind == CompressedAttribute::kDictionary ? ca->dictionary : nullptr);
+      }
+      coded_filters.push_back(filter);
+      any_coded_filter = any_coded_filter || filter != nullptr;
+      continue;
     }
     if (!in_run) {
       aggregateBlock(block, filter);
@@ -1141,6 +1181,13 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
     for (std::size_t c = 0; c < column_attr_.size(); ++c) cols.push_back(block.stripe(column_attr_[c]));
     filters.push_back(filter);
     any_filter = any_filter || filter != nullptr;
+  }
+  if (!coded_rows.empty()) {
+    CheckStatus(qsx_agg_update_coded_blocks(coded_state_, static_cast<int>(coded_rows.size()), coded_rows.data(), coded_cols.data(),
+                                            coded_dicts.data(), any_coded_filter ? coded_filters.data() : nullptr, CurrentStream()),
+                "qsx_agg_update_coded_blocks");
+    coded_blocks_ += static_cast<int>(coded_rows.size());
+    CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
   }
   if (rows.empty()) return;
   CheckStatus(qsx_agg_update_blocks(state_, static_cast<int>(rows.size()), rows.data(), cols.data(), any_filter ? filters.data() : nullptr,
@@ -1415,7 +1462,7 @@ void LIPFilterBuilder::insertValueAccessor(const StorageBlock &block, const std:
 bool LIPFilterBuilder::insertBlocks(const std::vector<BlockReference> &blocks) const {
   for (const auto &e : entries_) {
     for (const BlockReference &b : blocks) {
-      if (b->nullBitmap(e.second) != nullptr || b->compressedAttribute(e.second) != nullptr) return false;
+      if (b->nullBitmap(e.second) != nullptr) return false;   // (a compressed attribute is read through stripe(): decoded once)
     }
   }
   std::vector<std::int64_t> rows;
@@ -1462,7 +1509,7 @@ bool LIPFilterAdaptiveProber::filterBlocks(const std::vector<BlockReference> &bl
   *storage = nullptr;
   for (const auto &e : entries_) {
     for (const BlockReference &b : blocks) {
-      if (b->nullBitmap(e.second) != nullptr || b->compressedAttribute(e.second) != nullptr) return false;
+      if (b->nullBitmap(e.second) != nullptr) return false;   // (a compressed attribute is read through stripe(): decoded once)
     }
   }
   const std::size_t nb = blocks.size();
@@ -1696,7 +1743,7 @@ bool SelectWorkOrder::executeRun() {
       }
     }
     for (attribute_id a : selection) {
-      if (b.nullBitmap(a) != nullptr || b.compressedAttribute(a) != nullptr) return false;
+      if (b.nullBitmap(a) != nullptr) return false;   // (projected values of a compressed attribute: stripe() decodes once)
     }
     rows.push_back(b.numTuples());
     total_rows += b.numTuples();
@@ -1996,7 +2043,7 @@ bool BuildHashWorkOrder::executeRun() {
   for (block_id id : run_block_ids_) {
     blocks.push_back(storage_manager_->getBlock(id));
     const StorageBlock &b = *blocks.back();
-    if (b.nullBitmap(join_key_attributes_.front()) != nullptr || b.compressedAttribute(join_key_attributes_.front()) != nullptr) return false;
+    if (b.nullBitmap(join_key_attributes_.front()) != nullptr) return false;   // (compressed key: stripe() decodes once)
     if (b.firstRow() + b.numTuples() > INT32_MAX) return false;
     rows.push_back(b.numTuples());
     keys.push_back(b.stripe(join_key_attributes_.front()));
@@ -2181,9 +2228,9 @@ bool HashInnerJoinWorkOrder::executeRun() {
   for (block_id id : run_block_ids_) {
     blocks.push_back(storage_manager_->getBlock(id));
     const StorageBlock &b = *blocks.back();
-    if (b.nullBitmap(join_key_attributes_.front()) != nullptr || b.compressedAttribute(join_key_attributes_.front()) != nullptr) return false;
+    if (b.nullBitmap(join_key_attributes_.front()) != nullptr) return false;   // (compressed key: stripe() decodes once)
     for (std::size_t i = 0; i < selection_.size(); ++i) {
-      if (!is_selection_on_build_[i] && (b.nullBitmap(selection_[i]) != nullptr || b.compressedAttribute(selection_[i]) != nullptr)) return false;
+      if (!is_selection_on_build_[i] && b.nullBitmap(selection_[i]) != nullptr) return false;
     }
     rows.push_back(b.numTuples());
     first_rows.push_back(total_rows);

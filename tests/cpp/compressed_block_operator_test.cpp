@@ -53,6 +53,8 @@ struct Output {
   std::vector<double> agg_sum_disc_price, agg_min_qty;
 };
 
+std::size_t g_blocks_per_work_order = 1;
+
 Output run(const Lineitem &li, bool compressed, bool use_foreman) {
   CatalogRelation lineitem(1, "lineitem"), selected(2, "selected"), result(3, "result");
   StorageManager storage;
@@ -99,6 +101,8 @@ Output run(const Lineitem &li, bool compressed, bool use_foreman) {
   auto *select = new SelectOperator(0, lineitem, false, selected, sel_dest, pred_id, std::vector<attribute_id>{0, 4, 6}, true);
   auto *aggregate = new AggregationOperator(0, lineitem, true, state);
   auto *finalize = new FinalizeAggregationOperator(0, state, 1, false, 1, result, agg_dest);
+  select->setBlocksPerWorkOrder(g_blocks_per_work_order);      // (predicates on codes: the Select goes block by block inside)
+  aggregate->setBlocksPerWorkOrder(g_blocks_per_work_order);   // compressed blocks: one qsx_agg_update_coded_blocks per run
   std::vector<std::unique_ptr<RelationalOperator>> owned;
   if (use_foreman) {
     QueryPlan plan;
@@ -163,7 +167,9 @@ int main() {
       want_min[li.linenumber[i]] = std::min(want_min[li.linenumber[i]], li.quantity[i]);
     }
   }
-  for (const bool use_foreman : {false, true}) {
+  for (const int variant : {0, 1, 2, 3}) {
+    const bool use_foreman = (variant & 1) != 0;
+    g_blocks_per_work_order = (variant & 2) != 0 ? 3 : 1;
     const Output plain = run(li, false, use_foreman);
     const Output comp = run(li, true, use_foreman);
     for (const Output *o : {&plain, &comp}) {

@@ -213,3 +213,48 @@ def test_aggregation_through_a_pair_list(capi, oracle, dev):
     o.update([orderkey[tids], price[tids], disc[tids]])
     from test_gpu_agg import assert_same_groups, finalize_np
     assert_same_groups(finalize_np(through, dev), o.finalize())
+
+
+@pytest.mark.parametrize("jit", [False, True])
+def test_q1_over_a_run_of_compressed_blocks(capi, oracle, dev, jit, monkeypatch):
+    """qsx_agg_update_coded_blocks: one launch over a run of compressed blocks, every block compressed on its own (its own
+    dictionaries: a block that holds fewer distinct values has a different code assignment), ragged sizes, filters with gaps —
+    equal to the oracle aggregating the decoded blocks one by one."""
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if jit else str(1 << 60))
+    rng = np.random.default_rng(78)
+    rows = [70_001, 0, 20_513, 31_024, 150_000, 9_005]
+    layout = [(T.CHAR, 1), (T.CHAR, 1), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)]
+    kw = dict(keys=[0, 1],
+              instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0)),
+                      (T.EX_ADD, 2, T.const(0), T.col(5)), (T.EX_MUL, 3, T.temp(1), T.temp(2))],
+              consts=[1.0],
+              aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.col(3)), (T.AGG_SUM, T.temp(1)), (T.AGG_SUM, T.temp(3)),
+                    (T.AGG_AVG, T.col(4)), (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(6)), (T.AGG_MAX, T.col(4))],
+              pred=[(6, T.LT, 7)], est_groups=6)
+    widths = [0, 0, 1, 0, 1, 1, 1]
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=widths, **kw)
+    plain_cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, **kw)
+    st = capi.AggState(cfg)
+    o = oracle.AggState(plain_cfg)
+    blocks, dicts, filters = [], [], []
+    for b, n in enumerate(rows):
+        cols, comp = _q1_coded_inputs(oracle, rng, n) if n else ([np.zeros(0, dtype=t) for t in (np.uint8, np.uint8, np.float64, np.float64, np.float64, np.float64, np.int32)], None)
+        if n:
+            if b % 2 == 0:
+                cols[2] = np.where(cols[2] > 25, 25.0, cols[2])      # fewer distinct quantities in this block: another dictionary
+                comp[2] = oracle.CompressedColumn(cols[2])
+            assert [0 if c is None or c.kind == 0 else c.code_width for c in comp] == widths
+            blocks.append([to_dev(cols[i] if widths[i] == 0 else comp[i].codes, dev) for i in range(7)])
+            dicts.append([None if widths[i] == 0 or comp[i].dictionary is None else to_dev(comp[i].dictionary, dev) for i in range(7)])
+        else:
+            blocks.append([to_dev(c, dev) for c in cols])
+            dicts.append([None] * 7)
+        f = oracle.bitmap_from_bools(rng.random(n) < 0.8) if (b % 3 == 0 and n) else None
+        filters.append(None if f is None else bitmap_dev(f, dev))
+        if n:
+            o.update(cols, filter_bitmap=f)
+    st.update_coded_blocks(blocks, dicts, filters)
+    from test_gpu_agg import assert_same_groups, finalize_np
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+    with pytest.raises(capi.QsxError):                               # a coded state needs the coded entry point
+        st.update_blocks(blocks)
