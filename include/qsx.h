@@ -202,6 +202,24 @@ int qsx_select_codes_sorted(int code_width, const void *codes_dev, int64_t n, in
                             const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev,
                             qsx_stream_t stream);
 
+/* K1 on the sort column of sorted column-store blocks, over a run of blocks in one launch: every block is sorted on its
+ * own, so every block's matches are its own row range (one wave per block searches the bounds, then the bitmaps of the run
+ * are written).  Same results as qsx_select_cmp_sorted / qsx_select_codes_sorted block by block.  The reference's TPC-H layout
+ * sorts lineitem on l_shipdate and orders on o_orderdate (benchmarks/tpch/create.sql:69-121): the predicates of Q1 and Q3 are
+ * of this kind.
+ *   qsx_select_cmp_sorted_blocks      uncompressed sort column: block_cols = value stripes, one literal for all blocks
+ *   qsx_select_codes_sorted_blocks    compressed sort column: block_codes = code stripes of `code_width` bytes, the comparison
+ *                                     rewritten per block (QSX_CODE_* op, first, second as for qsx_select_codes: the
+ *                                     dictionaries differ from block to block)
+ *   out_counts_dev                    optional device array of num_blocks int64: matches per block */
+int qsx_select_cmp_sorted_blocks(int type, int64_t num_blocks, const int64_t *block_rows, const void *const *block_cols, int op,
+                                 const void *literal, const uint64_t *const *block_filters, uint64_t *const *block_out_bitmaps,
+                                 int64_t *out_counts_dev, qsx_stream_t stream);
+int qsx_select_codes_sorted_blocks(int code_width, int64_t num_blocks, const int64_t *block_rows, const void *const *block_codes,
+                                   const int32_t *block_ops, const uint32_t *block_first, const uint32_t *block_second,
+                                   const uint64_t *const *block_filters, uint64_t *const *block_out_bitmaps, int64_t *out_counts_dev,
+                                   qsx_stream_t stream);
+
 /* Decode a code stripe into values of value_width (4 or 8) bytes: out[i] = dictionary[codes[i]], or the
  * zero-extended code when dictionary_dev is NULL (truncated attribute).  What
  * CompressedTupleStorageSubBlock::getAttributeValue does per tuple (storage/

@@ -97,6 +97,9 @@ _SIGNATURES = {
     "qsx_eval_expression": (_int, [_int, _pp, C.POINTER(_i32), _int, C.POINTER(T.ExprInstr), C.POINTER(C.c_double), T.Operand, _i64, _vp, _vp]),
     "qsx_agg_state_create": (_int, [C.POINTER(T.AggConfig), _pp]),
     "qsx_agg_state_destroy": (_int, [_vp]),
+    "qsx_select_cmp_sorted_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, _int, _vp, _pp, _pp, _vp, _vp]),
+    "qsx_select_codes_sorted_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _pp, _pp,
+                                              _vp, _vp]),
     "qsx_select_cmp_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, _int, _vp, _pp, _pp, _vp, _vp]),
     "qsx_agg_state_clear": (_int, [_vp, _vp]),
     "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
@@ -213,6 +216,39 @@ def select_cmp_blocks(cols, op, literal, filters=None, stream=None, qtype=None, 
         fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
     _check(_lib.qsx_select_cmp_blocks(qt, nb, rows, cptr, op, C.byref(lit), fptr, optr, _ptr(counts), _stream(stream)),
            "qsx_select_cmp_blocks")
+    return outs, counts[:nb]
+
+
+def _run_outputs(cols, filters):
+    nb = len(cols)
+    dev = cols[0].device
+    outs = [new_bitmap(c.numel(), dev) for c in cols]
+    counts = torch.zeros(max(nb, 1), dtype=torch.int64, device=dev)
+    rows = (C.c_int64 * max(nb, 1))(*[c.numel() for c in cols])
+    cptr = (C.c_void_p * max(nb, 1))(*[c.data_ptr() if c.numel() else None for c in cols])
+    optr = (C.c_void_p * max(nb, 1))(*[o.data_ptr() if o.numel() else None for o in outs])
+    fptr = None
+    if filters is not None:
+        fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+    return nb, outs, counts, rows, cptr, optr, fptr
+
+
+def select_cmp_sorted_blocks(cols, op, literal, filters=None, stream=None, qtype=None):
+    """K1 on the sort column of a run of sorted blocks (every block sorted on its own): (per-block bitmaps, counts int64[nb])."""
+    qt = qsx_type_of(cols[0]) if qtype is None else qtype
+    lit = _literal(qt, literal)
+    nb, outs, counts, rows, cptr, optr, fptr = _run_outputs(cols, filters)
+    _check(_lib.qsx_select_cmp_sorted_blocks(qt, nb, rows, cptr, op, C.byref(lit), fptr, optr, _ptr(counts), _stream(stream)),
+           "qsx_select_cmp_sorted_blocks")
+    return outs, counts[:nb]
+
+
+def select_codes_sorted_blocks(code_blocks, ops, firsts, seconds, filters=None, stream=None):
+    """K1 on the compressed sort column of a run of blocks: per-block code comparison (QSX_CODE_* op, first, second)."""
+    nb, outs, counts, rows, cptr, optr, fptr = _run_outputs(code_blocks, filters)
+    _check(_lib.qsx_select_codes_sorted_blocks(code_blocks[0].element_size(), nb, rows, cptr, (C.c_int32 * max(nb, 1))(*ops),
+                                               (C.c_uint32 * max(nb, 1))(*firsts), (C.c_uint32 * max(nb, 1))(*seconds), fptr, optr,
+                                               _ptr(counts), _stream(stream)), "qsx_select_codes_sorted_blocks")
     return outs, counts[:nb]
 
 

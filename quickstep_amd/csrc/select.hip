@@ -459,6 +459,98 @@ __global__ __launch_bounds__(kBlock) void sorted_range_bitmap_kernel(const Sorte
   }
 }
 
+// ---- the same over a run of blocks (qsx_select_cmp_sorted_blocks / qsx_select_codes_sorted_blocks) ---------------------------
+// Every block of a sorted column store is sorted on its own, so every block has its own bounds: one wave per block searches
+// them (64-ary, as above), a second kernel walks the bitmap tiles of the run (64 words per wave, block_runs.hpp) and writes
+// each block's range.  For code stripes the per-block code range and comparison (the dictionaries differ from block to
+// block: the host rewrites the predicate per block) follow the run table at word `extra`: [3 b] lo, [3 b + 1] hi, [3 b + 2] op.
+template <typename T>
+__device__ __forceinline__ long long sorted_first_not_before(const T *__restrict__ col, long long n, T literal, bool or_equal) {
+  // first row whose value is >= literal (or_equal = false) / > literal (or_equal = true)
+  const int lane = lane_id();
+  long long lo = 0, hi = n;
+  while (hi - lo > 0) {
+    const long long span = hi - lo;
+    const long long step = (span + kWave) / (kWave + 1);
+    const long long at = lo + step * (lane + 1) - 1;
+    bool left = false;
+    if (at < hi) {
+      const T v = col[at];
+      left = or_equal ? v <= literal : v < literal;
+    }
+    const int passed = __popcll(__ballot(left));
+    const long long new_lo = passed == 0 ? lo : lo + step * passed;
+    const long long new_hi = passed == kWave ? hi : (lo + step * (passed + 1) - 1 < hi ? lo + step * (passed + 1) - 1 : hi);
+    lo = new_lo < hi ? new_lo : hi;
+    hi = new_hi;
+  }
+  return lo;
+}
+template <typename T, bool kCodes>
+__global__ __launch_bounds__(kBlock) void sorted_bounds_runs_kernel(const long long *__restrict__ runs, T literal, long long extra,
+                                                                   SortedBounds *__restrict__ bounds) {
+  const int b = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+  if (b >= static_cast<int>(runs[0])) return;
+  const T *col = run_in<T>(runs, b);
+  const long long n = run_rows(runs, b);
+  long long lower, upper;
+  if constexpr (kCodes) {
+    // rows with lo <= code < hi: [first code >= lo, first code >= hi)
+    const unsigned long long lo_code = static_cast<unsigned long long>(runs[extra + 3 * b]);
+    const unsigned long long hi_code = static_cast<unsigned long long>(runs[extra + 3 * b + 1]);
+    const unsigned long long max_code = static_cast<T>(~static_cast<T>(0));
+    lower = lo_code > max_code ? n : sorted_first_not_before<T>(col, n, static_cast<T>(lo_code), false);
+    upper = hi_code > max_code ? n : sorted_first_not_before<T>(col, n, static_cast<T>(hi_code), false);
+    if (upper < lower) upper = lower;
+  } else {
+    lower = sorted_first_not_before<T>(col, n, literal, false);
+    upper = sorted_first_not_before<T>(col, n, literal, true);
+  }
+  if (lane_id() == 0) {
+    bounds[b].lower = lower;
+    bounds[b].upper = upper;
+  }
+}
+__global__ __launch_bounds__(kBlock) void sorted_range_bitmap_runs_kernel(const long long *__restrict__ runs, const SortedBounds *__restrict__ bounds,
+                                                                         int op_all, long long extra,
+                                                                         unsigned long long *__restrict__ out_counts) {
+  const int lane = lane_id();
+  const int num_tiles = static_cast<int>(runs[2]);
+  for (int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+       tile < num_tiles; tile += static_cast<int>(gridDim.x) * kWavesPerBlock) {
+    const RunTile at = run_locate(runs, tile);
+    const long long n = run_rows(runs, at.block);
+    const int op = extra != 0 ? (static_cast<int>(runs[extra + 3 * at.block + 2]) == QSX_CODE_NE ? QSX_NE : QSX_EQ) : op_all;
+    long long begin = 0, end = n;
+    switch (op) {
+      case QSX_EQ: case QSX_NE: begin = bounds[at.block].lower; end = bounds[at.block].upper; break;
+      case QSX_LT: end = bounds[at.block].lower; break;
+      case QSX_LE: end = bounds[at.block].upper; break;
+      case QSX_GT: begin = bounds[at.block].upper; break;
+      default: begin = bounds[at.block].lower; break;   // QSX_GE
+    }
+    const long long w = static_cast<long long>(at.tile_in_block) * kTileWords + lane;
+    unsigned long long count = 0;
+    if (w < ((n + 63) >> 6)) {
+      const long long first = w << 6;
+      uint64_t word = 0;
+      const long long a = begin > first ? begin - first : 0, b = end < first + 64 ? end - first : 64;
+      if (a < b) word = (b - a == 64 ? ~0ull : ((~0ull) >> (64 - (b - a))) << (64 - b));
+      if (op == QSX_NE) word = ~word;
+      const long long valid = n - first >= 64 ? 64 : n - first;            // trailing bits of the last word stay zero
+      if (valid < 64) word &= ~0ull << (64 - valid);
+      const uint64_t *filter = run_filter(runs, at.block);
+      if (filter != nullptr) word &= filter[w];
+      run_out<uint64_t>(runs, at.block)[w] = word;
+      count = __popcll(word);
+    }
+    if (out_counts != nullptr) {
+      count = wave_reduce_add(count);
+      if (lane == 0 && count != 0) atomicAdd(&out_counts[at.block], count);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K5: gather by tuple id
 // ---------------------------------------------------------------------------
@@ -1014,6 +1106,40 @@ __global__ __launch_bounds__(kBlock) void tids_to_bitmap_kernel(const int32_t *_
 
 using namespace qsx;
 
+// Shared back end of the two sorted-column run entry points.  extra_words (codes): 3 words per block behind the run table.
+template <typename T, bool kCodes>
+static int sorted_runs(int64_t num_blocks, const int64_t *block_rows, const void *const *block_cols, T literal, int op,
+                       const std::vector<long long> &extra_words, const uint64_t *const *block_filters, uint64_t *const *block_out_bitmaps,
+                       int64_t *out_counts_dev, hipStream_t s) {
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0 || (block_rows[b] > 0 && (block_cols[b] == nullptr || block_out_bitmaps[b] == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (out_counts_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_counts_dev, 0, sizeof(int64_t) * static_cast<size_t>(num_blocks), s));
+  std::vector<long long> table;
+  const long long tiles = build_run_table(kTileWords * 64, num_blocks, block_rows, block_cols, reinterpret_cast<const void *const *>(block_filters),
+                                          reinterpret_cast<void *const *>(block_out_bitmaps), nullptr, &table);
+  if (tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (tiles == 0) return QSX_OK;
+  const long long extra = kCodes ? static_cast<long long>(table.size()) : 0;
+  table.insert(table.end(), extra_words.begin(), extra_words.end());
+  const size_t bytes = table.size() * sizeof(long long);
+  const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
+  if (runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  int rc = staged_upload(s, table.data(), bytes);
+  if (rc != QSX_OK) return rc;
+  CallScratch scratch(s);
+  rc = scratch.reserve(sizeof(SortedBounds) * static_cast<size_t>(num_blocks));
+  if (rc != QSX_OK) return rc;
+  SortedBounds *bounds = static_cast<SortedBounds *>(scratch.take(sizeof(SortedBounds) * static_cast<size_t>(num_blocks)));
+  hipLaunchKernelGGL((sorted_bounds_runs_kernel<T, kCodes>), dim3(grid_for(num_blocks, kWavesPerBlock)), dim3(kBlock), 0, s, runs_dev, literal,
+                     extra, bounds);
+  QSX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sorted_range_bitmap_runs_kernel, dim3(grid_for(tiles, kWavesPerBlock)), dim3(kBlock), 0, s, runs_dev, bounds, op, extra,
+                     reinterpret_cast<unsigned long long *>(out_counts_dev));
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
 extern "C" {
 
 int qsx_select_cmp_char(const void *col_dev, int width, int64_t n, int op, const void *literal, int literal_length,
@@ -1257,6 +1383,61 @@ int qsx_select_codes_sorted(int code_width, const void *codes_dev, int64_t n, in
                      out_bitmap_dev, reinterpret_cast<unsigned long long *>(out_count_dev));
   QSX_CHECK_LAUNCH();
   return QSX_OK;
+}
+
+int qsx_select_cmp_sorted_blocks(int type, int64_t num_blocks, const int64_t *block_rows, const void *const *block_cols, int op,
+                                 const void *literal, const uint64_t *const *block_filters, uint64_t *const *block_out_bitmaps,
+                                 int64_t *out_counts_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (num_blocks < 0 || literal == nullptr || op < QSX_EQ || op > QSX_GE ||
+      (num_blocks > 0 && (block_rows == nullptr || block_cols == nullptr || block_out_bitmaps == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (num_blocks == 0) return QSX_OK;
+  hipStream_t s = as_stream(stream);
+  const std::vector<long long> none;
+  switch (type) {
+    case QSX_INT: return sorted_runs<int32_t, false>(num_blocks, block_rows, block_cols, *static_cast<const int32_t *>(literal), op, none, block_filters, block_out_bitmaps, out_counts_dev, s);
+    case QSX_LONG: return sorted_runs<int64_t, false>(num_blocks, block_rows, block_cols, *static_cast<const int64_t *>(literal), op, none, block_filters, block_out_bitmaps, out_counts_dev, s);
+    case QSX_FLOAT: return sorted_runs<float, false>(num_blocks, block_rows, block_cols, *static_cast<const float *>(literal), op, none, block_filters, block_out_bitmaps, out_counts_dev, s);
+    case QSX_DOUBLE: return sorted_runs<double, false>(num_blocks, block_rows, block_cols, *static_cast<const double *>(literal), op, none, block_filters, block_out_bitmaps, out_counts_dev, s);
+    case QSX_DATE: {
+      DateValue d;
+      std::memcpy(&d, literal, sizeof(d));
+      return sorted_runs<DateValue, false>(num_blocks, block_rows, block_cols, d, op, none, block_filters, block_out_bitmaps, out_counts_dev, s);
+    }
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+}
+
+int qsx_select_codes_sorted_blocks(int code_width, int64_t num_blocks, const int64_t *block_rows, const void *const *block_codes,
+                                   const int32_t *block_ops, const uint32_t *block_first, const uint32_t *block_second,
+                                   const uint64_t *const *block_filters, uint64_t *const *block_out_bitmaps, int64_t *out_counts_dev,
+                                   qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_codes == nullptr || block_ops == nullptr || block_first == nullptr ||
+                                            block_second == nullptr || block_out_bitmaps == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (code_width != 1 && code_width != 2 && code_width != 4) return QSX_ERR_UNSUPPORTED;
+  if (num_blocks == 0) return QSX_OK;
+  std::vector<long long> extra(static_cast<size_t>(num_blocks) * 3);
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    const int op = block_ops[b];
+    if (op < QSX_CODE_EQ || op > QSX_CODE_RANGE) return QSX_ERR_INVALID_ARGUMENT;
+    // the comparison as a code range [lo, hi), != as its complement (as qsx_select_codes_sorted)
+    const unsigned long long first = block_first[b], second = block_second[b];
+    extra[3 * b] = static_cast<long long>(op == QSX_CODE_LT ? 0ull : first);
+    extra[3 * b + 1] = static_cast<long long>((op == QSX_CODE_EQ || op == QSX_CODE_NE) ? first + 1 : op == QSX_CODE_LT ? first
+                                              : op == QSX_CODE_GE ? (1ull << 32) : second);
+    extra[3 * b + 2] = op;
+  }
+  hipStream_t s = as_stream(stream);
+  switch (code_width) {
+    case 1: return sorted_runs<uint8_t, true>(num_blocks, block_rows, block_codes, 0, QSX_EQ, extra, block_filters, block_out_bitmaps, out_counts_dev, s);
+    case 2: return sorted_runs<uint16_t, true>(num_blocks, block_rows, block_codes, 0, QSX_EQ, extra, block_filters, block_out_bitmaps, out_counts_dev, s);
+    default: return sorted_runs<uint32_t, true>(num_blocks, block_rows, block_codes, 0, QSX_EQ, extra, block_filters, block_out_bitmaps, out_counts_dev, s);
+  }
 }
 
 int qsx_decode_codes(int code_width, const void *codes_dev, int64_t n, const void *dictionary_dev, int value_width,

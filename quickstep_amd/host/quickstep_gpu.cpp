@@ -1732,15 +1732,22 @@ bool SelectWorkOrder::executeRun() {
   std::vector<std::int64_t> rows;
   std::int64_t total_rows = 0;
   std::size_t bitmap_words = 0;
+  const StorageBlock *reference_block = nullptr;   // the first non-empty block: what the others have to agree with
   for (block_id id : run_block_ids_) {
     blocks.push_back(storage_manager_->getBlock(id));
     const StorageBlock &b = *blocks.back();
     for (const ComparisonPredicate &term : predicate.conjuncts) {
       const Type &t = b.getRelation().getAttributeType(term.attribute);
-      if (term.rhs_attribute != kInvalidAttributeID || b.compressedAttribute(term.attribute) != nullptr || t.id == kChar ||
-          term.attribute == b.sortColumn() || b.nullBitmap(term.attribute) != nullptr) {
-        return false;
-      }
+      if (term.rhs_attribute != kInvalidAttributeID || t.id == kChar || b.nullBitmap(term.attribute) != nullptr) return false;
+      // a term on the blocks' sort column is a per-block binary search (also on the code stripe of a compressed sort column);
+      // a scan of code stripes has no run form yet
+      if (b.compressedAttribute(term.attribute) != nullptr && term.attribute != b.sortColumn()) return false;
+      if (b.numTuples() == 0) continue;                 // (an empty block has neither codes nor an order to agree on)
+      if (reference_block == nullptr) reference_block = &b;
+      const StorageBlock &f = *reference_block;
+      if ((term.attribute == b.sortColumn()) != (term.attribute == f.sortColumn())) return false;
+      const CompressedAttribute *cb = b.compressedAttribute(term.attribute), *cf = f.compressedAttribute(term.attribute);
+      if ((cb != nullptr) != (cf != nullptr) || (cb != nullptr && cb->code_width != cf->code_width)) return false;
     }
     for (attribute_id a : selection) {
       if (b.nullBitmap(a) != nullptr) return false;   // (projected values of a compressed attribute: stripe() decodes once)
@@ -1775,12 +1782,50 @@ bool SelectWorkOrder::executeRun() {
   bool first = true;
   for (const ComparisonPredicate &term : predicate.conjuncts) {
     const Type &t = blocks.front()->getRelation().getAttributeType(term.attribute);
-    for (std::size_t b = 0; b < nb; ++b) stripes[b] = blocks[b]->stripe(term.attribute);
+    const StorageBlock &ref = reference_block != nullptr ? *reference_block : *blocks.front();
+    if (ref.compressedAttribute(term.attribute) == nullptr) {   // (a compressed sort column is searched on its codes)
+      for (std::size_t b = 0; b < nb; ++b) stripes[b] = blocks[b]->stripe(term.attribute);
+    }
     const std::uint64_t *const *in = first ? (lip_bitmaps.empty() ? nullptr : lip_bitmaps.data())
                                            : reinterpret_cast<const std::uint64_t *const *>(cur.data());
-    CheckStatus(qsx_select_cmp_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
-                                      &term.literal.v, in, nxt.data(), static_cast<std::int64_t *>(counts.ptr), CurrentStream()),
-                "qsx_select_cmp_blocks");
+    const bool on_sort_column = term.attribute == ref.sortColumn();
+    if (on_sort_column && ref.compressedAttribute(term.attribute) != nullptr) {
+      // the sort column of compressed blocks: the comparison rewritten on every block's own codes
+      // (CompressedTupleStorageSubBlock::getMatchesForPredicate), then one search per block on the code stripes
+      std::vector<std::int32_t> ops(nb);
+      std::vector<std::uint32_t> firsts(nb), seconds(nb);
+      for (std::size_t b = 0; b < nb; ++b) {
+        const CompressedAttribute *c = blocks[b]->compressedAttribute(term.attribute);
+        if (c == nullptr) {   // an empty block
+          stripes[b] = nullptr;
+          ops[b] = QSX_CODE_LT;
+          firsts[b] = seconds[b] = 0;
+          continue;
+        }
+        const PredicateTransformResult r = TransformPredicateOnCompressedAttribute(*c, t.id, term.comparison, term.literal);
+        stripes[b] = c->codes;
+        if (r.type == PredicateTransformResult::kAll || r.type == PredicateTransformResult::kNone) {
+          ops[b] = r.type == PredicateTransformResult::kAll ? QSX_CODE_GE : QSX_CODE_LT;   // every code / no code
+          firsts[b] = seconds[b] = 0;
+        } else {
+          ops[b] = r.comp;
+          firsts[b] = r.first_literal;
+          seconds[b] = r.second_literal;
+        }
+      }
+      CheckStatus(qsx_select_codes_sorted_blocks(ref.compressedAttribute(term.attribute)->code_width, static_cast<std::int64_t>(nb),
+                                                 rows.data(), stripes.data(), ops.data(), firsts.data(), seconds.data(), in, nxt.data(),
+                                                 static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_codes_sorted_blocks");
+    } else if (on_sort_column) {
+      // SortColumnPredicateEvaluator (storage/ColumnStoreUtil.cpp:40-280), one search per block
+      CheckStatus(qsx_select_cmp_sorted_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
+                                               &term.literal.v, in, nxt.data(), static_cast<std::int64_t *>(counts.ptr), CurrentStream()),
+                  "qsx_select_cmp_sorted_blocks");
+    } else {
+      CheckStatus(qsx_select_cmp_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
+                                        &term.literal.v, in, nxt.data(), static_cast<std::int64_t *>(counts.ptr), CurrentStream()),
+                  "qsx_select_cmp_blocks");
+    }
     std::swap(cur, nxt);
     first = false;
   }

@@ -20,7 +20,8 @@ struct Lineitem {
   std::vector<std::int32_t> orderkey, quantity;
   std::vector<double> price;
   std::vector<std::int64_t> block_rows;
-  Lineitem(StorageManager *storage, bool nullable_quantity) {
+  // sorted_mode 1: every block sorted on l_quantity and declared so (sort column); 2: the sort column also compressed
+  Lineitem(StorageManager *storage, bool nullable_quantity, int sorted_mode = 0) {
     rel.addAttribute("l_orderkey", Type::Int());
     rel.addAttribute("l_quantity", nullable_quantity ? Type::Int().getNullableVersion() : Type::Int());
     rel.addAttribute("l_extendedprice", Type::Double());
@@ -34,10 +35,22 @@ struct Lineitem {
         q[i] = static_cast<std::int32_t>(rng() % 50) + 1;
         p[i] = static_cast<double>(rng() % 10000000) / 100.0;
       }
+      if (sorted_mode != 0) {
+        std::vector<std::int64_t> order(n);
+        for (std::int64_t i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](std::int64_t x, std::int64_t y) { return q[x] < q[y]; });
+        std::vector<std::int32_t> k2(n), q2(n);
+        std::vector<double> p2(n);
+        for (std::int64_t i = 0; i < n; ++i) { k2[i] = k[order[i]]; q2[i] = q[order[i]]; p2[i] = p[order[i]]; }
+        k.swap(k2); q.swap(q2); p.swap(p2);
+      }
       std::vector<std::uint64_t> nulls(static_cast<std::size_t>((n + 63) / 64) + 1, 0);
       for (std::int64_t i = 0; i < n; i += 17) nulls[i >> 6] |= 1ull << (63 - (i & 63));
       const std::vector<const std::uint64_t *> null_bitmaps = {nullptr, nullable_quantity ? nulls.data() : nullptr, nullptr};
-      storage->loadBlock(&rel, {k.data(), q.data(), p.data()}, n, 0, nullptr, &null_bitmaps);
+      const std::vector<bool> compress = {false, sorted_mode == 2, false};
+      const block_id id = storage->loadBlock(&rel, {k.data(), q.data(), p.data()}, n, 0, &compress, &null_bitmaps);
+      if (sorted_mode != 0) storage->getBlock(id)->setSortColumn(1);
+      if (sorted_mode == 2 && n > 1000) EXPECT_TRUE(storage->getBlock(id)->compressedAttribute(1) != nullptr);
       orderkey.insert(orderkey.end(), k.begin(), k.end());
       quantity.insert(quantity.end(), q.begin(), q.end());
       price.insert(price.end(), p.begin(), p.end());
@@ -97,9 +110,10 @@ QueryContext::lip_deployment_id deployLip(QueryContext *ctx, StorageManager *sto
 
 // select l_orderkey, l_extendedprice from lineitem where l_quantity < 24 and l_extendedprice >= 20000.0
 // [with_lip: and l_orderkey passes the LIP filter]
-Rows runSelect(bool nullable_quantity, std::size_t blocks_per_order, std::size_t *out_blocks, double *ms, bool with_lip = false) {
+Rows runSelect(bool nullable_quantity, std::size_t blocks_per_order, std::size_t *out_blocks, double *ms, bool with_lip = false,
+               int sorted_mode = 0) {
   StorageManager storage;
-  Lineitem li(&storage, nullable_quantity);
+  Lineitem li(&storage, nullable_quantity, sorted_mode);
   CatalogRelation small(7, "small");
   CatalogRelation out(2, "selected");
   out.addAttribute("l_orderkey", Type::Int());
@@ -218,6 +232,15 @@ int main() {
     std::printf("hash join (%s table) probing %d blocks: one work order per block %.2f ms, per run of 64 blocks %.2f ms; "
                 "building from 40 blocks: %.2f ms / %.2f ms\n",
                 exact_stats ? "directly addressed" : "hashed", kBlocks, ms_one, ms_run, build_one, build_run);
+  }
+  // blocks sorted on l_quantity: the first predicate term is a binary search per block — on the values, or on the code
+  // stripe of the compressed sort column (the reference's TPC-H layout: lineitem SORT l_shipdate, COMPRESS ALL)
+  for (const int sorted_mode : {1, 2}) {
+    runSelect(false, 1, &blocks_one, &ms_one, false, sorted_mode);
+    runSelect(false, 64, &blocks_run, &ms_run, false, sorted_mode);
+    EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
+    std::printf("select on the %ssort column: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n",
+                sorted_mode == 2 ? "compressed " : "", ms_one, ms_run);
   }
   // LIP filters in the run forms: one qsx_lip_probe_blocks per filter in front of the predicate terms / the probe
   runSelect(false, 1, &blocks_one, &ms_one, true);

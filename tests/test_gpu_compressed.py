@@ -258,3 +258,50 @@ def test_q1_over_a_run_of_compressed_blocks(capi, oracle, dev, jit, monkeypatch)
     assert_same_groups(finalize_np(st, dev), o.finalize())
     with pytest.raises(capi.QsxError):                               # a coded state needs the coded entry point
         st.update_blocks(blocks)
+
+
+def test_sort_column_predicates_over_runs_of_blocks(capi, oracle, dev):
+    """qsx_select_cmp_sorted_blocks / qsx_select_codes_sorted_blocks: every block sorted on its own, one launch for the run,
+    per-block comparisons on the code stripes of a compressed sort column — equal to the scan of every block."""
+    rng = np.random.default_rng(31)
+    rows = [5000, 0, 1, 63, 64, 65, 4096, 4097, 70_001, 0, 33]
+    # uncompressed sort column, every type
+    for np_t, qt in ((np.int32, None), (np.int64, None), (np.float32, None), (np.float64, None)):
+        blocks = [np.sort(rng.integers(-50, 50, size=n)).astype(np_t) for n in rows]
+        filters = [oracle.bitmap_from_bools(rng.random(n) < 0.6) if (i % 3 != 1 and n) else None for i, n in enumerate(rows)]
+        dblocks = [to_dev(b, dev) for b in blocks]
+        for op in (T.EQ, T.NE, T.LT, T.LE, T.GT, T.GE):
+            for lit in (3, 60):
+                for use_filters in (False, True):
+                    outs, counts = capi.select_cmp_sorted_blocks(dblocks, op, lit, filters=[None if f is None else bitmap_dev(f, dev) for f in filters] if use_filters else None)
+                    for b, n in enumerate(rows):
+                        want = oracle.select_cmp(blocks[b], op, np_t(lit), filter_bitmap=filters[b] if use_filters else None)
+                        if n:
+                            assert np.array_equal(bitmap_np(outs[b])[:want.size], want), (np_t, op, lit, b, n)
+                        assert int(counts[b].item()) == oracle.bitmap_count(want, n)
+    # DATE sort column
+    from test_gpu_select import make_dates
+    dates = [make_dates(rng, n) for n in (3000, 0, 70_001, 5)]
+    dates = [np.ascontiguousarray(d[oracle.sort_permutation([d], types=[T.DATE])]) if d.size else d for d in dates]
+    lit = T.date_raw(1995, 3, 15)
+    for op in (T.EQ, T.LT, T.GE, T.NE):
+        outs, counts = capi.select_cmp_sorted_blocks([to_dev(d, dev) for d in dates], op, lit, qtype=T.DATE)
+        for i, d in enumerate(dates):
+            want = oracle.select_cmp(d, op, lit, qt=T.DATE)
+            if d.size:
+                assert np.array_equal(bitmap_np(outs[i])[:want.size], want)
+            assert int(counts[i].item()) == oracle.bitmap_count(want, d.size)
+    # compressed sort column: per-block comparisons on the code stripes
+    for width, np_t, hi in ((1, np.uint8, 256), (2, np.uint16, 65536), (4, np.uint32, 2**32)):
+        code_blocks = [np.sort(rng.integers(0, min(hi, max(4, n // 3 + 4)), size=n, dtype=np.uint64)).astype(np_t) for n in rows]
+        dcodes = [torch.from_numpy(c.view({1: np.uint8, 2: np.int16, 4: np.int32}[width]).copy()).to(dev) for c in code_blocks]
+        ops = [(T.CODE_EQ, T.CODE_NE, T.CODE_LT, T.CODE_GE, T.CODE_RANGE)[i % 5] for i in range(len(rows))]
+        firsts = [int(c[c.size // 2]) if c.size else 0 for c in code_blocks]
+        seconds = [min(hi - 1, f + 5) for f in firsts]
+        filters = [oracle.bitmap_from_bools(rng.random(n) < 0.6) if (i % 2 == 0 and n) else None for i, n in enumerate(rows)]
+        outs, counts = capi.select_codes_sorted_blocks(dcodes, ops, firsts, seconds, filters=[None if f is None else bitmap_dev(f, dev) for f in filters])
+        for b, n in enumerate(rows):
+            want = oracle.select_codes(code_blocks[b], ops[b], firsts[b], seconds[b], filters[b])
+            if n:
+                assert np.array_equal(bitmap_np(outs[b])[:want.size], want), (width, b, n, ops[b])
+            assert int(counts[b].item()) == oracle.bitmap_count(want, n)
