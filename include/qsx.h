@@ -202,6 +202,15 @@ int qsx_select_codes_sorted(int code_width, const void *codes_dev, int64_t n, in
                             const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev,
                             qsx_stream_t stream);
 
+/* qsx_select_codes over a run of blocks in one launch: the comparison rewritten on every block's own codes (the dictionaries
+ * differ from block to block: CompressedTupleStorageSubBlock::getMatchesForPredicate, storage/CompressedTupleStorageSubBlock.cpp:
+ * 160-250, runs per block), one code width for the run.  block_ops / block_first / block_second: QSX_CODE_* comparison and its
+ * literals per block, as for qsx_select_codes ("every code" = QSX_CODE_GE 0, "no code" = QSX_CODE_LT 0). */
+int qsx_select_codes_blocks(int code_width, int64_t num_blocks, const int64_t *block_rows, const void *const *block_codes,
+                            const int32_t *block_ops, const uint32_t *block_first, const uint32_t *block_second,
+                            const uint64_t *const *block_filters, uint64_t *const *block_out_bitmaps, int64_t *out_counts_dev,
+                            qsx_stream_t stream);
+
 /* K1 on the sort column of sorted column-store blocks, over a run of blocks in one launch: every block is sorted on its
  * own, so every block's matches are its own row range (one wave per block searches the bounds, then the bitmaps of the run
  * are written).  Same results as qsx_select_cmp_sorted / qsx_select_codes_sorted block by block.  The reference's TPC-H layout

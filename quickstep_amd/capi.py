@@ -98,6 +98,8 @@ _SIGNATURES = {
     "qsx_agg_state_create": (_int, [C.POINTER(T.AggConfig), _pp]),
     "qsx_agg_state_destroy": (_int, [_vp]),
     "qsx_select_cmp_sorted_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, _int, _vp, _pp, _pp, _vp, _vp]),
+    "qsx_select_codes_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _pp, _pp,
+                                       _vp, _vp]),
     "qsx_select_codes_sorted_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _pp, _pp,
                                               _vp, _vp]),
     "qsx_select_cmp_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, _int, _vp, _pp, _pp, _vp, _vp]),
@@ -240,6 +242,15 @@ def select_cmp_sorted_blocks(cols, op, literal, filters=None, stream=None, qtype
     nb, outs, counts, rows, cptr, optr, fptr = _run_outputs(cols, filters)
     _check(_lib.qsx_select_cmp_sorted_blocks(qt, nb, rows, cptr, op, C.byref(lit), fptr, optr, _ptr(counts), _stream(stream)),
            "qsx_select_cmp_sorted_blocks")
+    return outs, counts[:nb]
+
+
+def select_codes_blocks(code_blocks, ops, firsts, seconds, filters=None, stream=None):
+    """K1 on the code stripes of a run of compressed blocks: per-block code comparison (QSX_CODE_* op, first, second)."""
+    nb, outs, counts, rows, cptr, optr, fptr = _run_outputs(code_blocks, filters)
+    _check(_lib.qsx_select_codes_blocks(code_blocks[0].element_size(), nb, rows, cptr, (C.c_int32 * max(nb, 1))(*ops),
+                                        (C.c_uint32 * max(nb, 1))(*firsts), (C.c_uint32 * max(nb, 1))(*seconds), fptr, optr,
+                                        _ptr(counts), _stream(stream)), "qsx_select_codes_blocks")
     return outs, counts[:nb]
 
 

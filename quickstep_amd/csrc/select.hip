@@ -14,6 +14,7 @@
 // v_cmp -> SGPR-pair ballot, and s_brev_b64 turns the LSB-first ballot into the
 // MSB-first word BitVector uses.  No shuffles, no LDS for K1.
 
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -910,9 +911,11 @@ __global__ __launch_bounds__(kBlock) void select_packed_kernel(const T *__restri
 // last block meet in LDS first — about one atomic per workgroup plus four per block.  (Counters of neighbouring blocks
 // share a cache line and same-line atomics serialise in L2: one atomic per wave and tile visit made 12 blocks of 10 M rows
 // take 0.89 ms instead of 0.25.)
+// extra != 0 (qsx_select_codes_blocks, Pred = CodeRangePred): the predicate of block b — the comparison rewritten on that block's
+// own codes — sits behind the run table at word extra + 3 b: lo, hi, negate.
 template <typename T, typename Pred, int R>
-__global__ __launch_bounds__(kBlock) void select_packed_runs_kernel(const long long *__restrict__ runs, Pred pred,
-                                                                   unsigned long long *__restrict__ out_counts) {
+__global__ __launch_bounds__(kBlock) void select_packed_runs_kernel(const long long *__restrict__ runs, Pred pred_all,
+                                                                   unsigned long long *__restrict__ out_counts, long long extra = 0) {
   __shared__ unsigned long long s_last_count;
   const int lane = lane_id();
   const long long num_tiles = runs[2];
@@ -931,6 +934,14 @@ __global__ __launch_bounds__(kBlock) void select_packed_runs_kernel(const long l
       }
       count = 0;
       counted_block = at.block;
+    }
+    Pred pred = pred_all;
+    if constexpr (std::is_same<Pred, CodeRangePred>::value) {
+      if (extra != 0) {
+        pred.lo = static_cast<unsigned long long>(runs[extra + 3 * at.block]);
+        pred.hi = static_cast<unsigned long long>(runs[extra + 3 * at.block + 1]);
+        pred.negate = runs[extra + 3 * at.block + 2] != 0;
+      }
     }
     select_packed_group<T, Pred, R>(run_in<T>(runs, at.block), run_rows(runs, at.block), pred, run_filter(runs, at.block),
                                     run_out<uint64_t>(runs, at.block), static_cast<int64_t>(at.tile_in_block) * R, lane, count);
@@ -1345,6 +1356,68 @@ int qsx_select_codes(int code_width, const void *codes_dev, int64_t n, int op, u
                          n, op, first, second, filter_dev, out_bitmap_dev, count);
       break;
     default: return QSX_ERR_UNSUPPORTED;
+  }
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_select_codes_blocks(int code_width, int64_t num_blocks, const int64_t *block_rows, const void *const *block_codes,
+                            const int32_t *block_ops, const uint32_t *block_first, const uint32_t *block_second,
+                            const uint64_t *const *block_filters, uint64_t *const *block_out_bitmaps, int64_t *out_counts_dev,
+                            qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_codes == nullptr || block_ops == nullptr || block_first == nullptr ||
+                                            block_second == nullptr || block_out_bitmaps == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (code_width != 1 && code_width != 2 && code_width != 4) return QSX_ERR_UNSUPPORTED;
+  if (num_blocks == 0) return QSX_OK;
+  bool aligned = true;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0 || (block_rows[b] > 0 && (block_codes[b] == nullptr || block_out_bitmaps[b] == nullptr)) ||
+        block_ops[b] < QSX_CODE_EQ || block_ops[b] > QSX_CODE_RANGE) {
+      return QSX_ERR_INVALID_ARGUMENT;
+    }
+    aligned = aligned && aligned16(block_codes[b]);
+  }
+  if (!aligned) {   // a stripe that does not start on a 16-byte boundary takes the row-per-lane kernel: block by block
+    for (int64_t b = 0; b < num_blocks; ++b) {
+      const int rc = qsx_select_codes(code_width, block_codes[b], block_rows[b], block_ops[b], block_first[b], block_second[b],
+                                      block_filters != nullptr ? block_filters[b] : nullptr, block_out_bitmaps[b],
+                                      out_counts_dev != nullptr ? out_counts_dev + b : nullptr, stream);
+      if (rc != QSX_OK) return rc;
+    }
+    return QSX_OK;
+  }
+  hipStream_t s = as_stream(stream);
+  if (out_counts_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_counts_dev, 0, sizeof(int64_t) * static_cast<size_t>(num_blocks), s));
+  constexpr int kLoadsPerTile = 4;                                   // R of select_packed_runs_kernel
+  const long long tile_rows = static_cast<long long>(kWave) * (16 / code_width) * kLoadsPerTile;
+  std::vector<long long> table;
+  const long long tiles = build_run_table(tile_rows, num_blocks, block_rows, block_codes, reinterpret_cast<const void *const *>(block_filters),
+                                          reinterpret_cast<void *const *>(block_out_bitmaps), nullptr, &table);
+  if (tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (tiles == 0) return QSX_OK;
+  const long long extra = static_cast<long long>(table.size());
+  for (int64_t b = 0; b < num_blocks; ++b) {   // the comparison as a code range [lo, hi), != as its complement (as qsx_select_codes)
+    const int op = block_ops[b];
+    const unsigned long long first = block_first[b], second = block_second[b];
+    table.push_back(static_cast<long long>(op == QSX_CODE_LT ? 0ull : first));
+    table.push_back(static_cast<long long>((op == QSX_CODE_EQ || op == QSX_CODE_NE) ? first + 1 : op == QSX_CODE_LT ? first
+                                           : op == QSX_CODE_GE ? (1ull << 32) : second));
+    table.push_back(op == QSX_CODE_NE ? 1 : 0);
+  }
+  const size_t bytes = table.size() * sizeof(long long);
+  const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
+  if (runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  const int rc = staged_upload(s, table.data(), bytes);
+  if (rc != QSX_OK) return rc;
+  const int grid = grid_for(tiles, kWavesPerBlock);
+  unsigned long long *counts = reinterpret_cast<unsigned long long *>(out_counts_dev);
+  switch (code_width) {
+    case 1: hipLaunchKernelGGL((select_packed_runs_kernel<uint8_t, CodeRangePred, kLoadsPerTile>), dim3(grid), dim3(kBlock), 0, s, runs_dev, CodeRangePred{}, counts, extra); break;
+    case 2: hipLaunchKernelGGL((select_packed_runs_kernel<uint16_t, CodeRangePred, kLoadsPerTile>), dim3(grid), dim3(kBlock), 0, s, runs_dev, CodeRangePred{}, counts, extra); break;
+    default: hipLaunchKernelGGL((select_packed_runs_kernel<uint32_t, CodeRangePred, kLoadsPerTile>), dim3(grid), dim3(kBlock), 0, s, runs_dev, CodeRangePred{}, counts, extra); break;
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;

@@ -1738,11 +1738,12 @@ bool SelectWorkOrder::executeRun() {
     const StorageBlock &b = *blocks.back();
     for (const ComparisonPredicate &term : predicate.conjuncts) {
       const Type &t = b.getRelation().getAttributeType(term.attribute);
-      if (term.rhs_attribute != kInvalidAttributeID || t.id == kChar || b.nullBitmap(term.attribute) != nullptr) return false;
-      // a term on the blocks' sort column is a per-block binary search (also on the code stripe of a compressed sort column);
-      // a scan of code stripes has no run form yet
-      if (b.compressedAttribute(term.attribute) != nullptr && term.attribute != b.sortColumn()) return false;
+      if (term.rhs_attribute != kInvalidAttributeID || b.nullBitmap(term.attribute) != nullptr) return false;
       if (b.numTuples() == 0) continue;                 // (an empty block has neither codes nor an order to agree on)
+      // a term on the blocks' sort column is a per-block binary search (also on the code stripe of a compressed sort column), a
+      // term on a compressed attribute a scan of the code stripes with the comparison rewritten per block; CHAR(n) values
+      // are only compared through their codes here
+      if (t.id == kChar && b.compressedAttribute(term.attribute) == nullptr) return false;
       if (reference_block == nullptr) reference_block = &b;
       const StorageBlock &f = *reference_block;
       if ((term.attribute == b.sortColumn()) != (term.attribute == f.sortColumn())) return false;
@@ -1816,6 +1817,32 @@ bool SelectWorkOrder::executeRun() {
       CheckStatus(qsx_select_codes_sorted_blocks(ref.compressedAttribute(term.attribute)->code_width, static_cast<std::int64_t>(nb),
                                                  rows.data(), stripes.data(), ops.data(), firsts.data(), seconds.data(), in, nxt.data(),
                                                  static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_codes_sorted_blocks");
+    } else if (ref.compressedAttribute(term.attribute) != nullptr) {
+      // a compressed attribute: every block's code stripe scanned with the comparison rewritten on that block's codes
+      std::vector<std::int32_t> ops(nb);
+      std::vector<std::uint32_t> firsts(nb), seconds(nb);
+      for (std::size_t b = 0; b < nb; ++b) {
+        const CompressedAttribute *c = blocks[b]->compressedAttribute(term.attribute);
+        if (c == nullptr) {   // an empty block
+          stripes[b] = nullptr;
+          ops[b] = QSX_CODE_LT;
+          firsts[b] = seconds[b] = 0;
+          continue;
+        }
+        const PredicateTransformResult r = TransformPredicateOnCompressedAttribute(*c, t.id, term.comparison, term.literal);
+        stripes[b] = c->codes;
+        if (r.type == PredicateTransformResult::kAll || r.type == PredicateTransformResult::kNone) {
+          ops[b] = r.type == PredicateTransformResult::kAll ? QSX_CODE_GE : QSX_CODE_LT;
+          firsts[b] = seconds[b] = 0;
+        } else {
+          ops[b] = r.comp;
+          firsts[b] = r.first_literal;
+          seconds[b] = r.second_literal;
+        }
+      }
+      CheckStatus(qsx_select_codes_blocks(ref.compressedAttribute(term.attribute)->code_width, static_cast<std::int64_t>(nb), rows.data(),
+                                          stripes.data(), ops.data(), firsts.data(), seconds.data(), in, nxt.data(),
+                                          static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_codes_blocks");
     } else if (on_sort_column) {
       // SortColumnPredicateEvaluator (storage/ColumnStoreUtil.cpp:40-280), one search per block
       CheckStatus(qsx_select_cmp_sorted_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),

@@ -305,3 +305,29 @@ def test_sort_column_predicates_over_runs_of_blocks(capi, oracle, dev):
             if n:
                 assert np.array_equal(bitmap_np(outs[b])[:want.size], want), (width, b, n, ops[b])
             assert int(counts[b].item()) == oracle.bitmap_count(want, n)
+
+
+def test_code_stripe_scans_over_runs_of_blocks(capi, oracle, dev):
+    """qsx_select_codes_blocks: one launch over the code stripes of a run of blocks with the comparison given per block
+    (every block has its own dictionary) — equal to qsx_select_codes' scan block by block, also for unaligned stripes."""
+    rng = np.random.default_rng(32)
+    rows = [5000, 0, 1, 63, 64, 65, 4095, 4096, 4097, 70_001, 0, 33]
+    all_ops = (T.CODE_EQ, T.CODE_NE, T.CODE_LT, T.CODE_GE, T.CODE_RANGE)
+    for width, np_t, hi in ((1, np.uint8, 256), (2, np.uint16, 65536), (4, np.uint32, 2**32)):
+        torch_view = {1: np.uint8, 2: np.int16, 4: np.int32}[width]
+        for shift in (0, 1):                                            # 1: every stripe starts inside a 16-byte chunk
+            blocks = [rng.integers(0, min(hi, 40), size=n + shift, dtype=np.uint64).astype(np_t) for n in rows]
+            dcodes = [torch.from_numpy(c.view(torch_view).copy()).to(dev)[shift:] for c in blocks]
+            blocks = [c[shift:] for c in blocks]
+            for rot in range(2):
+                ops = [all_ops[(i + rot) % 5] for i in range(len(rows))]
+                firsts = [int(rng.integers(0, 40)) for _ in rows]
+                seconds = [f + int(rng.integers(0, 9)) for f in firsts]
+                filters = [oracle.bitmap_from_bools(rng.random(n) < 0.6) if (i % 2 == rot and n) else None for i, n in enumerate(rows)]
+                outs, counts = capi.select_codes_blocks(dcodes, ops, firsts, seconds,
+                                                        filters=[None if f is None else bitmap_dev(f, dev) for f in filters])
+                for b, n in enumerate(rows):
+                    want = oracle.select_codes(blocks[b], ops[b], firsts[b], seconds[b], filters[b])
+                    if n:
+                        assert np.array_equal(bitmap_np(outs[b])[:want.size], want), (width, shift, b, n, ops[b])
+                    assert int(counts[b].item()) == oracle.bitmap_count(want, n)
