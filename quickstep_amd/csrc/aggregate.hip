@@ -1524,10 +1524,6 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
   }
   hipError_t err = hipMalloc(reinterpret_cast<void **>(&st->image), st->image_bytes);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->control), 8 * sizeof(unsigned long long));   // [4]: wide-key collision flag
-  if (err == hipSuccess && st->dense) {
-    err = hipMalloc(reinterpret_cast<void **>(&st->tile_counts), sizeof(int32_t) * st->max_tiles);
-    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->tile_offsets), sizeof(int64_t) * (st->max_tiles + 1));
-  }
   if (err == hipSuccess && !st->dense) err = ensure_directory(st);
   if (err == hipSuccess && st->growable) {
     err = hipMalloc(reinterpret_cast<void **>(&st->log), sizeof(unsigned long long) * kLogRecords * (st->num_cols + 1));
@@ -1999,11 +1995,17 @@ int qsx_agg_num_groups(qsx_agg_state_t *st, int64_t *out_groups, qsx_stream_t st
   }
   unsigned long long v = 0;
   if (st->dense) {
-    QSX_HIP_TRY(hipMemsetAsync(st->control + 2, 0, sizeof(unsigned long long), s));
+    // the counter belongs to this call: the partitions of a state are finalized by concurrent work orders, each asking
+    // for the group count first — a counter in the state (zeroed, added to, read) gave two of them each other's halves
+    CallScratch scratch(s);
+    const int rc_scratch = scratch.reserve(CallScratch::padded(sizeof(unsigned long long)));
+    if (rc_scratch != QSX_OK) return rc_scratch;
+    unsigned long long *counter = static_cast<unsigned long long *>(scratch.take(sizeof(unsigned long long)));
+    QSX_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), s));
     hipLaunchKernelGGL(popcount_words_kernel, dim3(grid_for(st->exist_words, kABlock * 32) < 2 * kCUs ? grid_for(st->exist_words, kABlock * 32) : 2 * kCUs), dim3(kABlock), 0, s,
-                       st->image, st->exist_words, st->control + 2);
+                       st->image, st->exist_words, counter);
     QSX_CHECK_LAUNCH();
-    QSX_HIP_TRY(hipMemcpyAsync(&v, st->control + 2, sizeof(v), hipMemcpyDeviceToHost, s));
+    QSX_HIP_TRY(hipMemcpyAsync(&v, counter, sizeof(v), hipMemcpyDeviceToHost, s));
     QSX_HIP_TRY(hipStreamSynchronize(s));
     *out_groups = static_cast<int64_t>(v);
   } else {
@@ -2117,14 +2119,24 @@ int qsx_agg_finalize(qsx_agg_state_t *st, int partition, int num_partitions, voi
       const long long num_words = (end + 63) / 64 - first_word;
       const long long num_tiles = (num_words + kDenseTileWords - 1) / kDenseTileWords;
       const DenseView d = st->dense_view();
+      // the tile counts / offsets of THIS call: the partitions of a state are finalized by concurrent work orders
+      // (FinalizeAggregationOperator makes one per partition), each on its own stream — scratch owned by the state was a race
+      // between them (two partitions interleaving their scans: groups with their sums missing, seen once the host layer's
+      // worker threads stopped being created per query and really ran the two work orders at the same time)
+      CallScratch scratch(s);
+      const size_t counts_bytes = sizeof(int32_t) * static_cast<size_t>(num_tiles + 1), offsets_bytes = sizeof(int64_t) * static_cast<size_t>(num_tiles + 2);
+      const int rc_scratch = scratch.reserve(CallScratch::padded(counts_bytes) + CallScratch::padded(offsets_bytes));
+      if (rc_scratch != QSX_OK) return rc_scratch;
+      int32_t *tile_counts = static_cast<int32_t *>(scratch.take(counts_bytes));
+      int64_t *tile_offsets = static_cast<int64_t *>(scratch.take(offsets_bytes));
       hipLaunchKernelGGL(dense_tile_count_kernel, dim3(grid_for(num_tiles, kABlock / kWave)), dim3(kABlock), 0, s,
-                         d.exist, first_word, num_words, begin, end, num_tiles, st->tile_counts);
+                         d.exist, first_word, num_words, begin, end, num_tiles, tile_counts);
       QSX_CHECK_LAUNCH();
-      hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, st->tile_counts,
-                         static_cast<int64_t>(num_tiles), st->tile_offsets, out_groups_dev);
+      hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tile_counts,
+                         static_cast<int64_t>(num_tiles), tile_offsets, out_groups_dev);
       QSX_CHECK_LAUNCH();
       hipLaunchKernelGGL(finalize_dense_kernel, dim3(grid_for(num_tiles, kABlock / kWave)), dim3(kABlock), 0, s,
-                         d, f, first_word, num_words, begin, end, num_tiles, st->tile_offsets,
+                         d, f, first_word, num_words, begin, end, num_tiles, tile_offsets,
                          static_cast<long long>(capacity));
       break;
     }

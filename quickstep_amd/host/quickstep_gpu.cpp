@@ -49,8 +49,15 @@ struct DeviceBuffer {
   }
   void *ptr = nullptr;
   std::size_t size_class = 0;   // 0: a plain allocation of its own
+  static bool cacheEnabled() {   // QSX_HOST_SCRATCH_CACHE=0: every buffer a plain allocation (debugging)
+    static const bool on = []() {
+      const char *e = std::getenv("QSX_HOST_SCRATCH_CACHE");
+      return e == nullptr || e[0] != '0';
+    }();
+    return on;
+  }
   explicit DeviceBuffer(std::size_t bytes) {
-    if (bytes >= kCacheFrom) {
+    if (bytes >= kCacheFrom && cacheEnabled()) {
       size_class = 128 * 1024;
       while (size_class < bytes) size_class *= 2;
       Cache &c = cache();
@@ -143,7 +150,7 @@ void UseHostMemoryForBlocks(bool on) { g_host_memory = on; }
 
 StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t capacity, std::int64_t first_row, bool one_allocation)
     : relation_(relation), capacity_(capacity), num_tuples_(0), first_row_(first_row) {
-  if (one_allocation && !g_host_memory) {
+  if (one_allocation && !g_host_memory && std::getenv("QSX_HOST_BLOCK_SLAB_OFF") == nullptr) {
     // an output block: all stripes and null bitmaps in one allocation (a device allocation of a few MB costs ~170 us
     // whatever its size, and a block has one per attribute otherwise)
     auto round_up = [](std::size_t v) { return (v + 255) / 256 * 256; };
@@ -1407,6 +1414,7 @@ void AggregationOperationState::finalizeAggregate(std::size_t partition, std::si
   const std::int64_t written = ReadCount(rows.ptr);
   // a key wider than 8 bytes is grouped by its 64-bit hash and verified: two keys under one hash void the result
   if (written == QSX_GROUPS_HASH_COLLISION) throw ExecutionError("qsx_agg_finalize: wide group-by key", QSX_ERR_HASH_COLLISION);
+  if (written > out->capacity()) throw ExecutionError("qsx_agg_finalize: more groups than the output block holds", QSX_ERR_CAPACITY);
   for (int a = 0; a < config_.num_aggs && written > 0; ++a) {
     if (null_cols[a] == nullptr) continue;
     // byte flags -> TupleIdSequence-ordered bitmap: a scan of 1-byte "codes" for flag >= 1
@@ -3026,6 +3034,19 @@ class WorkerThreads {
 
 void ForemanSingleNode::workerMain(std::size_t worker_id) {
   // Worker::run (query_execution/Worker.cpp:54-99): receive a work order, execute(), report completion.
+  struct FreshStream {   // QSX_HOST_FRESH_STREAMS (debugging): a stream of this query only on the persistent thread
+    qsx_stream_t previous = CurrentStream(), mine = nullptr;
+    FreshStream() {
+      if (std::getenv("QSX_HOST_FRESH_STREAMS") != nullptr && qsx_device_count() > 0 && qsx_stream_create(&mine) == QSX_OK) SetCurrentStream(mine);
+    }
+    ~FreshStream() {
+      if (mine != nullptr) {
+        qsx_stream_synchronize(mine);
+        SetCurrentStream(previous);
+        qsx_stream_destroy(mine);
+      }
+    }
+  } fresh_stream;
   for (;;) {
     Item item;
     {
@@ -3061,7 +3082,23 @@ void ForemanSingleNode::run() {
   std::vector<bool> done_generating(N, false), finished(N, false);
   std::vector<std::size_t> blocks_fed(N, 0);  // per producer: output blocks already fed downstream
   // the process-wide Worker threads serve this query until it shuts them out again (one more thread drives them and waits)
-  std::thread workers([this]() { WorkerThreads::instance().run(num_workers_, [this](std::size_t w) { workerMain(w); }); });
+  std::thread workers([this]() {
+    if (std::getenv("QSX_HOST_EPHEMERAL_WORKERS") != nullptr) {   // (debugging: threads and streams of this run() only)
+      std::vector<std::thread> own;
+      for (std::size_t w = 0; w < num_workers_; ++w) {
+        own.emplace_back([this, w]() {
+          qsx_stream_t stream = nullptr;
+          if (qsx_device_count() > 0) (void)qsx_stream_create(&stream);
+          SetCurrentStream(stream);
+          workerMain(w);
+          if (stream != nullptr) qsx_stream_destroy(stream);
+        });
+      }
+      for (auto &t : own) t.join();
+      return;
+    }
+    WorkerThreads::instance().run(num_workers_, [this](std::size_t w) { workerMain(w); });
+  });
 
   auto shutdown = [&]() {
     {

@@ -925,3 +925,46 @@ def test_update_blocks_equals_one_update_per_block(capi, oracle, dev, kind, monk
         if blk[0].size:
             o.update(blk, filter_bitmap=None if f is None else oracle.bitmap_from_bools(m))
     assert_same_groups(finalize_np(st, dev), o.finalize())
+
+
+def test_partitions_of_a_dense_state_are_finalized_concurrently(capi, oracle, dev):
+    """FinalizeAggregationOperator makes one work order per partition of a state and Workers run them at the same time,
+    each on its own stream: qsx_agg_num_groups + qsx_agg_finalize(partition p of P) from P host threads must give what one
+    thread gives partition by partition (the state used to keep the scratch of these calls: two callers got each other's
+    counts)."""
+    import threading
+    rng = np.random.default_rng(91)
+    entries, n, P = 300_000, 400_000, 4
+    keys = rng.integers(0, entries, size=n).astype(np.int32)
+    vals = rng.integers(0, 1000, size=n).astype(np.int64)
+    cfg = T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None), (T.LONG, None)], keys=[0], num_entries=entries,
+                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1))])
+    st = capi.AggState(cfg)
+    st.update([to_dev(keys, dev), to_dev(vals, dev)], n)
+    torch.cuda.synchronize()
+    want_groups = int(np.unique(keys).size)
+    want_sum = int(vals.sum())
+    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+    for _ in range(25):
+        results, errors = [None] * P, []
+
+        def work(p):
+            try:
+                g = st.num_groups(stream=streams[p])
+                k, v, _, groups = st.finalize(dev, partition=p, num_partitions=P, capacity=g, stream=streams[p])
+                streams[p].synchronize()
+                m = int(groups.item())
+                results[p] = (g, m, k[0][:m].cpu().numpy(), v[0][:m].cpu().numpy(), v[1][:m].cpu().numpy())
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        threads = [threading.Thread(target=work, args=(p,)) for p in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert all(r[0] == want_groups for r in results), [r[0] for r in results]       # every caller sees the whole state's count
+        all_keys = np.concatenate([r[2] for r in results])
+        assert all_keys.size == want_groups and np.unique(all_keys).size == want_groups
+        assert int(sum(r[3].sum() for r in results)) == n and int(sum(r[4].sum() for r in results)) == want_sum
