@@ -20,7 +20,8 @@ tests/cpp/bin/tpch_types_operator_test 2>&1 | grep "work order" >> $o/work_order
 tests/cpp/bin/tpch_q3_plan_test 1500000 120000 2>&1 | grep "Q3 plan" >> $o/work_order_runs.txt
 tests/cpp/bin/tpch_q3_plan_test 15000000 120000 2>&1 | grep "Q3 plan" >> $o/work_order_runs.txt
 tools/ubench/alloc_cost > $o/alloc_cost.jsonl 2>&1
-for b in 8 4096 1000000; do timeout 200 tools/ubench/pool_readback 4 40000 $b 1 1 0 1 >> $o/pool_readback.txt 2>&1; done
-timeout 200 tools/ubench/pool_readback 4 40000 8 1 0 0 1 >> $o/pool_readback.txt 2>&1
-timeout 200 tools/ubench/pool_readback 4 40000 8 0 1 0 1 >> $o/pool_readback.txt 2>&1
+(for b in 8 65536 4194304; do timeout 300 tools/ubench/pool_readback 4 100000 $b 1 1 0 0; done
+ echo "no plain hipMalloc/hipFree next to it:"; timeout 300 tools/ubench/pool_readback 4 100000 8 1 0 0 0
+ echo "plain allocations instead of the pool:"; timeout 300 tools/ubench/pool_readback 4 100000 8 0 1 0 0
+ echo "release threshold raised:"; timeout 300 tools/ubench/pool_readback 4 100000 8 1 1 0 1) > $o/pool_readback.txt 2>&1
 grep -h "^{" $o/*.jsonl | cut -c1-200 | tail -30
