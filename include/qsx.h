@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define QSX_ABI_VERSION 5
+/* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
+#define QSX_ABI_VERSION 6
 
 typedef void *qsx_stream_t;
 

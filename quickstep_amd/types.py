@@ -7,7 +7,7 @@ sides.  Pure data definitions: no library is loaded here.
 import ctypes as C
 
 # qsx_type_t (numbering of types/TypeID.hpp:32-43 in the reference)
-ABI_VERSION = 5                                                     # QSX_ABI_VERSION of include/qsx.h
+ABI_VERSION = 6                                                     # QSX_ABI_VERSION of include/qsx.h
 INT, LONG, FLOAT, DOUBLE, CHAR = 0, 1, 2, 3, 4
 DATE = 6   # the reference's 8-byte DateLit {int32 year; uint8 month, day; 2 bytes padding}, carried as int64 raw bytes
 # qsx_cmp_t (types/operations/comparisons/ComparisonID.hpp:36-42)
