@@ -968,3 +968,53 @@ def test_partitions_of_a_dense_state_are_finalized_concurrently(capi, oracle, de
         all_keys = np.concatenate([r[2] for r in results])
         assert all_keys.size == want_groups and np.unique(all_keys).size == want_groups
         assert int(sum(r[3].sum() for r in results)) == n and int(sum(r[4].sum() for r in results)) == want_sum
+
+
+def test_runs_of_blocks_at_scale_equal_one_stripe(capi, dev):
+    """C3 shape at 120 M rows cut into 1000 ragged blocks: qsx_agg_update_blocks (one launch), with and without per-block
+    filter bitmaps, gives the groups of qsx_agg_update over the same rows as one stripe — COUNT and the integer-valued SUM
+    exactly, the others within the floating-point tolerance; select + probe over the same cut agree with their stripe forms."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    n = 120_000_000
+    combo = torch.multinomial(torch.tensor([0.2466, 0.0065, 0.5005, 0.2464], device=dev), n, replacement=True, generator=g)
+    k1 = torch.tensor(list(b"ANNR"), dtype=torch.uint8, device=dev)[combo]
+    k2 = torch.tensor(list(b"FFOF"), dtype=torch.uint8, device=dev)[combo]
+    qty = torch.randint(1, 51, (n,), device=dev, generator=g).double()
+    price = (torch.rand(n, device=dev, generator=g, dtype=torch.float64) * 104100 + 900).mul(100).round().div(100)
+    disc = torch.randint(0, 11, (n,), device=dev, generator=g).double() / 100
+    tax = torch.randint(0, 9, (n,), device=dev, generator=g).double() / 100
+    cols = [k1, k2, qty, price, disc, tax]
+    cuts = sorted(set([0, n] + [int(x) // 64 * 64 for x in torch.randint(0, n, (999,), generator=torch.Generator().manual_seed(1)).tolist()]))
+    blocks = [[c[a:b] for c in cols] for a, b in zip(cuts[:-1], cuts[1:])]
+    bm, cnt = capi.select_cmp(qty, T.LE, 40.0)
+    filters = [bm[a // 64:(b + 63) // 64] for a, b in zip(cuts[:-1], cuts[1:])]
+
+    def groups_of(state):
+        keys, vals, _, groups = state.finalize(dev, capacity=16)
+        k = int(groups.item())
+        order = torch.argsort(keys[0][:k].to(torch.int64) * 256 + keys[1][:k].to(torch.int64))
+        return [v[:k][order] for v in vals]
+
+    for use_filter in (False, True):
+        one, run = capi.AggState(q1_config()), capi.AggState(q1_config())
+        one.update(cols, n, filter_bitmap=bm if use_filter else None)
+        run.update_blocks(blocks, filters if use_filter else None)
+        a, b = groups_of(one), groups_of(run)
+        assert torch.equal(a[7], b[7]) and torch.equal(a[0], b[0])            # COUNT(*), SUM(qty): exact
+        assert int(a[7].sum().item()) == (int(cnt.item()) if use_filter else n)
+        for x, y in zip(a[1:7], b[1:7]):
+            assert torch.allclose(x, y, rtol=FP_RTOL, atol=0.0)
+    # K1 and the probe over the same cut
+    outs, counts = capi.select_cmp_blocks([blk[2] for blk in blocks], T.LE, 40.0)
+    assert int(counts.sum().item()) == int(cnt.item())
+    assert torch.equal(torch.cat([o[:(blk[2].numel() + 63) // 64] for o, blk in zip(outs, blocks)]), bm[:(n + 63) // 64])
+    keys32 = torch.randint(0, 2_000_000, (n,), device=dev, generator=g, dtype=torch.int32)
+    table = capi.JoinTable(T.INT, 1_000_000, key_range=(0, 999_999))
+    table.build(torch.randperm(1_000_000, device=dev, dtype=torch.int32))
+    total = int(table.probe_count(keys32).item())
+    assert int(table.probe_count_blocks([keys32[a:b] for a, b in zip(cuts[:-1], cuts[1:])]).item()) == total == int((keys32 < 1_000_000).sum().item())
+    p, b_, c = table.probe_blocks([keys32[a:b] for a, b in zip(cuts[:-1], cuts[1:])], capacity=total)
+    assert int(c.item()) == total
+    assert bool((keys32[p[:total].long()] < 1_000_000).all())                 # run-global probe row numbers
+    assert int(torch.unique(p[:total]).numel()) == total                      # every matching row exactly once (unique build keys)
