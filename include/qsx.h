@@ -147,6 +147,11 @@ int qsx_select_cmp_blocks(int type, int64_t num_blocks, const int64_t *block_row
 int qsx_select_cmp_char(const void *col_dev, int width, int64_t n, int op, const void *literal, int literal_length,
                         const uint64_t *filter_dev, uint64_t *out_bitmap_dev, int64_t *out_count_dev, qsx_stream_t stream);
 
+/* qsx_select_cmp_char over a run of blocks in one launch (arguments as qsx_select_cmp_blocks / qsx_select_cmp_char). */
+int qsx_select_cmp_char_blocks(int width, int64_t num_blocks, const int64_t *block_rows, const void *const *block_cols, int op,
+                               const void *literal, int literal_length, const uint64_t *const *block_filters,
+                               uint64_t *const *block_out_bitmaps, int64_t *out_counts_dev, qsx_stream_t stream);
+
 /* qsx_select_cmp on the SORT COLUMN of a sorted column store (ascending, no NULLs in the first n rows): the matches are
  * one row range found by two searches, not a scan.  Replaces SortColumnPredicateEvaluator::
  * EvaluatePredicateForUncompressedSortColumn (storage/ColumnStoreUtil.cpp:40-280) as called from

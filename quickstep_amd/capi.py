@@ -98,6 +98,7 @@ _SIGNATURES = {
     "qsx_agg_state_create": (_int, [C.POINTER(T.AggConfig), _pp]),
     "qsx_agg_state_destroy": (_int, [_vp]),
     "qsx_select_cmp_sorted_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, _int, _vp, _pp, _pp, _vp, _vp]),
+    "qsx_select_cmp_char_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, _int, _vp, _int, _pp, _pp, _vp, _vp]),
     "qsx_select_codes_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _pp, _pp,
                                        _vp, _vp]),
     "qsx_select_codes_sorted_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _pp, _pp,
@@ -242,6 +243,25 @@ def select_cmp_sorted_blocks(cols, op, literal, filters=None, stream=None, qtype
     nb, outs, counts, rows, cptr, optr, fptr = _run_outputs(cols, filters)
     _check(_lib.qsx_select_cmp_sorted_blocks(qt, nb, rows, cptr, op, C.byref(lit), fptr, optr, _ptr(counts), _stream(stream)),
            "qsx_select_cmp_sorted_blocks")
+    return outs, counts[:nb]
+
+
+def select_cmp_char_blocks(cols, op, literal, filters=None, stream=None):
+    """K1 on CHAR(width) stripes of a run of blocks: cols = uint8 tensors of shape (n_b, width), literal a bytes object."""
+    width = cols[0].shape[1]
+    flat = [c.reshape(-1) for c in cols]
+    nb = len(cols)
+    dev = cols[0].device
+    outs = [new_bitmap(c.shape[0], dev) for c in cols]
+    counts = torch.zeros(max(nb, 1), dtype=torch.int64, device=dev)
+    rows = (C.c_int64 * max(nb, 1))(*[c.shape[0] for c in cols])
+    cptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f.numel() else None for f in flat])
+    optr = (C.c_void_p * max(nb, 1))(*[o.data_ptr() if o.numel() else None for o in outs])
+    fptr = None
+    if filters is not None:
+        fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+    _check(_lib.qsx_select_cmp_char_blocks(width, nb, rows, cptr, op, C.c_char_p(literal), len(literal), fptr, optr, _ptr(counts),
+                                           _stream(stream)), "qsx_select_cmp_char_blocks")
     return outs, counts[:nb]
 
 

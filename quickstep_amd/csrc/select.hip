@@ -1008,57 +1008,64 @@ struct CharLiteral {
   unsigned char bytes[QSX_MAX_CHAR_LITERAL];
   int length;   // bytes before the first NUL
 };
+// One tile (rows [row0, row0 + tile_rows) of a stripe) of the CHAR comparison; lane 0 of every wave adds its words' bits to count.
+__device__ __forceinline__ void select_char_tile(const unsigned char *__restrict__ col, int width, int64_t n, int op, const CharLiteral &lit,
+                                                 const uint64_t *__restrict__ filter, uint64_t *__restrict__ out, int64_t row0,
+                                                 int tile_rows, unsigned char *s_tile, unsigned long long &count) {
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int rows = static_cast<int>(n - row0 < tile_rows ? n - row0 : tile_rows);
+  const unsigned char *src = col + row0 * width;
+  const int bytes = rows * width;
+  __syncthreads();   // every wave is done with the previous tile
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const int full = bytes & ~15;
+    for (int o = threadIdx.x * 16; o < full; o += kBlock * 16) {
+      *reinterpret_cast<uint4 *>(s_tile + o) = *reinterpret_cast<const uint4 *>(src + o);
+    }
+    for (int o = full + threadIdx.x; o < bytes; o += kBlock) s_tile[o] = src[o];
+  } else {
+    for (int o = threadIdx.x; o < bytes; o += kBlock) s_tile[o] = src[o];
+  }
+  __syncthreads();
+  for (int w = wave; w * 64 < rows; w += kWavesPerBlock) {
+    const int r = w * 64 + lane;
+    bool pred = false;
+    if (r < rows) {
+      const unsigned char *v = s_tile + r * width;
+      int res = 0;
+      const int longest = width > lit.length ? width : lit.length;
+      for (int i = 0; i < longest; ++i) {
+        const unsigned char a = i < width ? v[i] : 0;
+        const unsigned char b = i < lit.length ? lit.bytes[i] : 0;
+        if (a != b) {
+          res = a < b ? -1 : 1;
+          break;
+        }
+        if (a == 0) break;
+      }
+      pred = compare_op<int>(res, op, 0);
+    }
+    uint64_t word = msb_first(__ballot(pred));
+    const int64_t word_index = (row0 >> 6) + w;
+    if (filter != nullptr) word &= filter[word_index];
+    if (lane == 0) {
+      out[word_index] = word;
+      count += __popcll(word);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void select_char_kernel(const unsigned char *__restrict__ col, int width, int64_t n, int op,
                                                             CharLiteral lit, const uint64_t *__restrict__ filter,
                                                             uint64_t *__restrict__ out, unsigned long long *__restrict__ out_count,
                                                             int tile_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_tile[];
   const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
   const int64_t num_tiles = (n + tile_rows - 1) / tile_rows;
   unsigned long long count = 0;
   for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-    const int64_t row0 = tile * tile_rows;
-    const int rows = static_cast<int>(n - row0 < tile_rows ? n - row0 : tile_rows);
-    const unsigned char *src = col + row0 * width;
-    const int bytes = rows * width;
-    __syncthreads();   // every wave is done with the previous tile
-    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-      const int full = bytes & ~15;
-      for (int o = threadIdx.x * 16; o < full; o += kBlock * 16) {
-        *reinterpret_cast<uint4 *>(s_tile + o) = *reinterpret_cast<const uint4 *>(src + o);
-      }
-      for (int o = full + threadIdx.x; o < bytes; o += kBlock) s_tile[o] = src[o];
-    } else {
-      for (int o = threadIdx.x; o < bytes; o += kBlock) s_tile[o] = src[o];
-    }
-    __syncthreads();
-    for (int w = wave; w * 64 < rows; w += kWavesPerBlock) {
-      const int r = w * 64 + lane;
-      bool pred = false;
-      if (r < rows) {
-        const unsigned char *v = s_tile + r * width;
-        int res = 0;
-        const int longest = width > lit.length ? width : lit.length;
-        for (int i = 0; i < longest; ++i) {
-          const unsigned char a = i < width ? v[i] : 0;
-          const unsigned char b = i < lit.length ? lit.bytes[i] : 0;
-          if (a != b) {
-            res = a < b ? -1 : 1;
-            break;
-          }
-          if (a == 0) break;
-        }
-        pred = compare_op<int>(res, op, 0);
-      }
-      uint64_t word = msb_first(__ballot(pred));
-      const int64_t word_index = (row0 >> 6) + w;
-      if (filter != nullptr) word &= filter[word_index];
-      if (lane == 0) {
-        out[word_index] = word;
-        count += __popcll(word);
-      }
-    }
+    select_char_tile(col, width, n, op, lit, filter, out, tile * tile_rows, tile_rows, s_tile, count);
   }
   if (out_count != nullptr) {
     __shared__ unsigned long long block_count;
@@ -1068,6 +1075,30 @@ __global__ __launch_bounds__(kBlock) void select_char_kernel(const unsigned char
     __syncthreads();
     if (threadIdx.x == 0 && block_count != 0) atomicAdd(out_count, block_count);
   }
+}
+
+// The same over a run of blocks (qsx_select_cmp_char_blocks): a workgroup takes a contiguous range of the run's tiles, a wave
+// adds its matches to a block's counter when the workgroup moves on to another block (as select_packed_runs_kernel).
+__global__ __launch_bounds__(kBlock) void select_char_runs_kernel(const long long *__restrict__ runs, int width, int op, CharLiteral lit,
+                                                                 unsigned long long *__restrict__ out_counts, int tile_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_tile[];
+  const int lane = lane_id();
+  const long long num_tiles = runs[2];
+  const int first = static_cast<int>(num_tiles * blockIdx.x / gridDim.x);
+  const int end = static_cast<int>(num_tiles * (blockIdx.x + 1) / gridDim.x);
+  unsigned long long count = 0;
+  int counted_block = -1;
+  for (int tile = first; tile < end; ++tile) {
+    const RunTile at = run_locate(runs, tile);
+    if (at.block != counted_block) {
+      if (out_counts != nullptr && counted_block >= 0 && lane == 0 && count != 0) atomicAdd(&out_counts[counted_block], count);
+      count = 0;
+      counted_block = at.block;
+    }
+    select_char_tile(run_in<unsigned char>(runs, at.block), width, run_rows(runs, at.block), op, lit, run_filter(runs, at.block),
+                     run_out<uint64_t>(runs, at.block), static_cast<int64_t>(at.tile_in_block) * tile_rows, tile_rows, s_tile, count);
+  }
+  if (out_counts != nullptr && counted_block >= 0 && lane == 0 && count != 0) atomicAdd(&out_counts[counted_block], count);
 }
 
 // Decode a code stripe: dictionary lookup (codes index a dictionary of `value_width`-byte values that
@@ -1179,6 +1210,48 @@ int qsx_select_cmp_char(const void *col_dev, int width, int64_t n, int op, const
   const size_t lds = (static_cast<size_t>(tile_rows) * width + 15) / 16 * 16;
   hipLaunchKernelGGL(select_char_kernel, dim3(grid), dim3(kBlock), lds, s, static_cast<const unsigned char *>(col_dev), width, n, op,
                      lit, filter_dev, out_bitmap_dev, reinterpret_cast<unsigned long long *>(out_count_dev), tile_rows);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_select_cmp_char_blocks(int width, int64_t num_blocks, const int64_t *block_rows, const void *const *block_cols, int op,
+                               const void *literal, int literal_length, const uint64_t *const *block_filters,
+                               uint64_t *const *block_out_bitmaps, int64_t *out_counts_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (num_blocks < 0 || width < 1 || width > 255 || literal_length < 0 || (literal_length > 0 && literal == nullptr) || op < QSX_EQ || op > QSX_GE ||
+      (num_blocks > 0 && (block_rows == nullptr || block_cols == nullptr || block_out_bitmaps == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (literal_length > QSX_MAX_CHAR_LITERAL) return QSX_ERR_UNSUPPORTED;
+  if (num_blocks == 0) return QSX_OK;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0 || (block_rows[b] > 0 && (block_cols[b] == nullptr || block_out_bitmaps[b] == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  if (out_counts_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_counts_dev, 0, sizeof(int64_t) * static_cast<size_t>(num_blocks), s));
+  CharLiteral lit{};
+  lit.length = 0;
+  while (lit.length < literal_length && static_cast<const unsigned char *>(literal)[lit.length] != 0) {   // a NUL ends it
+    lit.bytes[lit.length] = static_cast<const unsigned char *>(literal)[lit.length];
+    ++lit.length;
+  }
+  int tile_rows = (48 * 1024 / width) / 64 * 64;   // as qsx_select_cmp_char
+  if (tile_rows > 1024) tile_rows = 1024;
+  if (tile_rows < 64) tile_rows = 64;
+  std::vector<long long> table;
+  const long long tiles = build_run_table(tile_rows, num_blocks, block_rows, block_cols, reinterpret_cast<const void *const *>(block_filters),
+                                          reinterpret_cast<void *const *>(block_out_bitmaps), nullptr, &table);
+  if (tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
+  if (tiles == 0) return QSX_OK;
+  const size_t bytes = table.size() * sizeof(long long);
+  const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
+  if (runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  const int rc = staged_upload(s, table.data(), bytes);
+  if (rc != QSX_OK) return rc;
+  const int grid = static_cast<int>(tiles < 4 * kCUs ? tiles : 4 * kCUs);
+  const size_t lds = (static_cast<size_t>(tile_rows) * width + 15) / 16 * 16;
+  hipLaunchKernelGGL(select_char_runs_kernel, dim3(grid), dim3(kBlock), lds, s, runs_dev, width, op, lit,
+                     reinterpret_cast<unsigned long long *>(out_counts_dev), tile_rows);
   QSX_CHECK_LAUNCH();
   return QSX_OK;
 }

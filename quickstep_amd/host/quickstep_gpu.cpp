@@ -1749,9 +1749,8 @@ bool SelectWorkOrder::executeRun() {
       if (term.rhs_attribute != kInvalidAttributeID || b.nullBitmap(term.attribute) != nullptr) return false;
       if (b.numTuples() == 0) continue;                 // (an empty block has neither codes nor an order to agree on)
       // a term on the blocks' sort column is a per-block binary search (also on the code stripe of a compressed sort column), a
-      // term on a compressed attribute a scan of the code stripes with the comparison rewritten per block; CHAR(n) values
-      // are only compared through their codes here
-      if (t.id == kChar && b.compressedAttribute(term.attribute) == nullptr) return false;
+      // term on a compressed attribute a scan of the code stripes with the comparison rewritten per block
+      if (t.id == kChar && b.compressedAttribute(term.attribute) == nullptr && term.attribute == b.sortColumn()) return false;
       if (reference_block == nullptr) reference_block = &b;
       const StorageBlock &f = *reference_block;
       if ((term.attribute == b.sortColumn()) != (term.attribute == f.sortColumn())) return false;
@@ -1851,6 +1850,11 @@ bool SelectWorkOrder::executeRun() {
       CheckStatus(qsx_select_codes_blocks(ref.compressedAttribute(term.attribute)->code_width, static_cast<std::int64_t>(nb), rows.data(),
                                           stripes.data(), ops.data(), firsts.data(), seconds.data(), in, nxt.data(),
                                           static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_codes_blocks");
+    } else if (t.id == kChar) {
+      // CHAR(n) OP string literal on plain stripes (AsciiStringUncheckedComparator, AsciiStringComparators.hpp:218-251)
+      CheckStatus(qsx_select_cmp_char_blocks(t.width, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
+                                             term.literal.text.data(), static_cast<int>(term.literal.text.size()), in, nxt.data(),
+                                             static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_cmp_char_blocks");
     } else if (on_sort_column) {
       // SortColumnPredicateEvaluator (storage/ColumnStoreUtil.cpp:40-280), one search per block
       CheckStatus(qsx_select_cmp_sorted_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),

@@ -343,3 +343,31 @@ def test_compact_gather_blocks_concatenates_in_block_and_row_order(capi, oracle,
             want_tids.append(np.nonzero(keeps[b])[0] + (start if base_tids is None else base_tids[b]))
             start += n
         assert np.array_equal(tids.cpu().numpy()[:k], np.concatenate(want_tids).astype(np.int32))
+
+
+@pytest.mark.parametrize("width", [1, 10, 25, 255])
+def test_char_predicates_over_runs_of_blocks(capi, oracle, dev, width):
+    """qsx_select_cmp_char_blocks: one launch over the CHAR(width) stripes of a run of blocks = the comparison block by block."""
+    rng = np.random.default_rng(width)
+    words = [b"BUILDING", b"AUTOMOBILE", b"MACHINERY", b"BUILD", b"BUILDINGS", b"", b"x" * width]
+    rows = [3000, 0, 1, 63, 64, 65, 1024, 1025, 20_001, 0, 33]
+    blocks = []
+    for n in rows:
+        col = np.zeros((n, width), dtype=np.uint8)
+        pick = rng.integers(0, len(words), size=n)
+        for i in range(n):
+            w = words[pick[i]][:width]
+            col[i, :len(w)] = np.frombuffer(w, dtype=np.uint8)
+        blocks.append(col)
+    dblocks = [to_dev(b, dev) for b in blocks]
+    filters = [oracle.bitmap_from_bools(rng.random(n) < 0.5) if (i % 3 != 1 and n) else None for i, n in enumerate(rows)]
+    for lit in (b"BUILDING", b"BUILD", b"", b"x" * min(width, 64)):
+        for op in (T.EQ, T.NE, T.LT, T.GE):
+            for use_filters in (False, True):
+                outs, counts = capi.select_cmp_char_blocks(dblocks, op, lit,
+                                                           filters=[None if f is None else bitmap_dev(f, dev) for f in filters] if use_filters else None)
+                for b, n in enumerate(rows):
+                    ref = oracle.select_cmp_char(blocks[b], op, lit, filter_bitmap=filters[b] if use_filters else None)
+                    if n:
+                        assert np.array_equal(bitmap_np(outs[b])[:ref.size], ref), (width, b, n, lit, op)
+                    assert int(counts[b].item()) == oracle.bitmap_count(ref, n)
