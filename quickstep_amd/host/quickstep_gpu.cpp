@@ -88,6 +88,61 @@ struct DeviceBuffer {
   DeviceBuffer &operator=(const DeviceBuffer &) = delete;
 };
 
+// The allocations of output blocks (one per block: stripes + null bitmaps), kept for the next block of their size class instead
+// of going back to the runtime: a device allocation of a few MB costs 170-250 us (tools/ubench/alloc_cost.hip) — as much as
+// all the kernels of a work order over a run of blocks.  A block is destroyed when its last BlockReference goes, and every
+// work order waits for its stream before it returns, so no queued work can still use a slab that comes back here.
+class BlockSlabPool {
+ public:
+  static BlockSlabPool &instance() {
+    static BlockSlabPool *pool = new BlockSlabPool;   // never destroyed: it outlives the HIP runtime's own teardown order
+    return *pool;
+  }
+  static constexpr std::size_t kPoolFrom = 256 * 1024, kKeepBytes = std::size_t(8) << 30;
+  // *granted = the bytes to hand back with give()
+  void *take(std::size_t bytes, std::size_t *granted) {
+    if (bytes < kPoolFrom || std::getenv("QSX_HOST_BLOCK_POOL_OFF") != nullptr) {
+      *granted = 0;
+      void *p = nullptr;
+      CheckStatus(qsx_device_alloc(bytes ? bytes : 8, &p), "qsx_device_alloc(block)");
+      return p;
+    }
+    std::size_t cls = kPoolFrom;
+    while (cls < bytes) cls *= 2;
+    *granted = cls;
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      auto it = free_.find(cls);
+      if (it != free_.end() && !it->second.empty()) {
+        void *p = it->second.back();
+        it->second.pop_back();
+        kept_ -= cls;
+        return p;
+      }
+    }
+    void *p = nullptr;
+    CheckStatus(qsx_device_alloc(cls, &p), "qsx_device_alloc(block)");
+    return p;
+  }
+  void give(void *p, std::size_t granted) {
+    if (p == nullptr) return;
+    if (granted != 0) {
+      std::lock_guard<std::mutex> lock(mutex_);
+      if (kept_ + granted <= kKeepBytes) {
+        free_[granted].push_back(p);
+        kept_ += granted;
+        return;
+      }
+    }
+    qsx_device_free(p);
+  }
+
+ private:
+  std::mutex mutex_;
+  std::map<std::size_t, std::vector<void *>> free_;
+  std::size_t kept_ = 0;
+};
+
 std::int64_t ReadCount(const void *dev_count) {
   std::int64_t v = 0;
   CheckStatus(qsx_copy_to_host(&v, dev_count, sizeof(v), CurrentStream()), "qsx_copy_to_host");
@@ -161,7 +216,7 @@ StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t capacit
       if (t.nullable) null_bytes += round_up(static_cast<std::size_t>((capacity + 63) / 64) * 8 + 8);
     }
     slab_bytes_ = total + null_bytes;
-    CheckStatus(qsx_device_alloc(slab_bytes_, &slab_), "qsx_device_alloc(block)");
+    slab_ = BlockSlabPool::instance().take(slab_bytes_, &slab_granted_);
     char *at = static_cast<char *>(slab_);
     char *nulls_at = at + total;
     if (null_bytes != 0) CheckStatus(qsx_memset_device(nulls_at, 0, null_bytes, CurrentStream()), "qsx_memset_device(null bitmaps)");
@@ -206,7 +261,7 @@ StorageBlock::~StorageBlock() {
     auto in_slab = [&](void *p) { return p >= slab_ && p < static_cast<char *>(slab_) + slab_bytes_; };
     for (void *&p : stripes_) if (in_slab(p)) p = nullptr;
     for (void *&p : null_bitmaps_) if (in_slab(p)) p = nullptr;
-    qsx_device_free(slab_);
+    BlockSlabPool::instance().give(slab_, slab_granted_);
   }
   for (void *p : stripes_) {
     if (g_host_memory) std::free(p); else qsx_device_free(p);

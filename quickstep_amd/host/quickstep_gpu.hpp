@@ -221,7 +221,7 @@ class StorageBlock {
   std::int64_t first_row_;
   attribute_id sort_column_ = kInvalidAttributeID;
   void *slab_ = nullptr;                         // != nullptr: the one allocation all stripes and null bitmaps live in
-  std::size_t slab_bytes_ = 0;
+  std::size_t slab_bytes_ = 0, slab_granted_ = 0;   // granted: the pool's size class (0: a plain allocation)
   mutable std::vector<void *> stripes_;          // nullptr: compressed and not decoded yet
   std::vector<void *> null_bitmaps_;
   std::vector<CompressedAttribute> compressed_;  // empty or one per attribute
