@@ -3041,6 +3041,7 @@ class WorkerThreads {
     std::mutex done_mutex;
     std::condition_variable done_cv;
     std::size_t remaining = n;
+    std::vector<Slot *> mine;   // (taken under the lock: another Foreman may be growing slots_ right now)
     {
       std::lock_guard<std::mutex> lock(mutex_);
       while (slots_.size() < n) {
@@ -3048,9 +3049,10 @@ class WorkerThreads {
         Slot *slot = slots_.back().get();
         std::thread([slot]() { threadMain(slot); }).detach();
       }
+      for (std::size_t i = 0; i < n; ++i) mine.push_back(slots_[i].get());
     }
     for (std::size_t i = 0; i < n; ++i) {
-      Slot *slot = slots_[i].get();
+      Slot *slot = mine[i];
       {
         std::lock_guard<std::mutex> lock(slot->mutex);
         slot->tasks.push_back([&, i]() {
