@@ -2359,7 +2359,8 @@ void HashInnerJoinWorkOrder::execute() {
 bool HashInnerJoinWorkOrder::executeRun() {
   using JoinType = HashJoinOperator::JoinType;
   const bool existence = join_type_ == JoinType::kLeftSemiJoin || join_type_ == JoinType::kLeftAntiJoin;
-  if ((join_type_ != JoinType::kInnerJoin && !existence) || residual_predicate_ != nullptr || join_key_attributes_.size() != 1) return false;
+  if ((join_type_ != JoinType::kInnerJoin && !existence) || join_key_attributes_.size() != 1) return false;
+  if (residual_predicate_ != nullptr && existence) return false;   // (semi / anti with a residual go through the pairs: block by block)
   std::vector<BlockReference> blocks;
   std::vector<std::int64_t> rows, first_rows;
   std::vector<const void *> keys;
@@ -2425,15 +2426,59 @@ bool HashInnerJoinWorkOrder::executeRun() {
   }
   CheckStatus(qsx_join_probe_count_blocks(hash_table_, nb, rows.data(), keys.data(), lookup, static_cast<std::int64_t *>(count.ptr),
                                           CurrentStream()), "qsx_join_probe_count_blocks");
-  const std::int64_t matches = ReadCount(count.ptr);
-  DeviceBuffer probe_tids(static_cast<std::size_t>(matches) * 4 + 8), build_tids(static_cast<std::size_t>(matches) * 4 + 8);
-  CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, lookup, static_cast<std::int32_t *>(probe_tids.ptr),
-                                    static_cast<std::int32_t *>(build_tids.ptr), matches, static_cast<std::int64_t *>(count.ptr),
+  JoinedPairs pairs;
+  pairs.count = ReadCount(count.ptr);
+  pairs.probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
+  pairs.build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
+  CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, lookup, static_cast<std::int32_t *>(pairs.probe_tids->ptr),
+                                    static_cast<std::int32_t *>(pairs.build_tids->ptr), pairs.count, static_cast<std::int64_t *>(count.ptr),
                                     CurrentStream()), "qsx_join_probe_blocks");
   BuildSegments build(build_relation_, storage_manager_);
+  std::vector<const void *> segments(blocks.size());
+  if (residual_predicate_ != nullptr && pairs.count > 0) {
+    // matchesForJoinedTuples (:510-524) on the pairs of the run: each term's operands gathered by the pair lists (the probe
+    // side through the run's own stripes), compared, chained through the filter bitmap like a conjunction
+    const std::int64_t m = pairs.count;
+    const std::size_t pair_bitmap_bytes = static_cast<std::size_t>((m + 63) / 64) * 8 + 8;
+    DeviceBuffer current(pair_bitmap_bytes), next(pair_bitmap_bytes), lhs(static_cast<std::size_t>(m) * 8 + 8), rhs(static_cast<std::size_t>(m) * 8 + 8);
+    void *cur = current.ptr, *nxt = next.ptr;
+    bool first = true;
+    auto gather_side = [&](attribute_id attr, bool on_build, void *dst) -> Type {
+      const Type t = (on_build ? build_relation_ : probe_relation_).getAttributeType(attr);
+      if (on_build) {
+        build.gather(attr, t.width, pairs.build_tids->ptr, m, dst);
+      } else {
+        for (std::size_t b = 0; b < blocks.size(); ++b) segments[b] = blocks[b]->stripe(attr);
+        CheckStatus(qsx_gather_segmented(t.width, static_cast<int>(segments.size()), segments.data(), first_rows.data(),
+                                         static_cast<const std::int32_t *>(pairs.probe_tids->ptr), m, dst, CurrentStream()),
+                    "qsx_gather_segmented");
+      }
+      return t;
+    };
+    for (const ComparisonPredicate &term : residual_predicate_->conjuncts) {
+      const Type t = gather_side(term.attribute, term.on_build_side, lhs.ptr);
+      if (t.nullable || t.id == kChar) return false;   // (NULL operands / string operands: the block-by-block form)
+      if (term.rhs_attribute != kInvalidAttributeID) {
+        const Type rt = gather_side(term.rhs_attribute, term.rhs_on_build_side, rhs.ptr);
+        if (rt.id != t.id) throw ExecutionError("join predicate compares attributes of different types", QSX_ERR_UNSUPPORTED);
+        if (rt.nullable) return false;
+        CheckStatus(qsx_select_cmp_columns(t.id, lhs.ptr, rhs.ptr, m, static_cast<int>(term.comparison),
+                                           first ? nullptr : static_cast<const std::uint64_t *>(cur), static_cast<std::uint64_t *>(nxt), nullptr,
+                                           CurrentStream()), "qsx_select_cmp_columns");
+      } else {
+        CheckStatus(qsx_select_cmp(t.id, lhs.ptr, m, static_cast<int>(term.comparison), &term.literal.v,
+                                   first ? nullptr : static_cast<const std::uint64_t *>(cur), static_cast<std::uint64_t *>(nxt), nullptr,
+                                   CurrentStream()), "qsx_select_cmp");
+      }
+      std::swap(cur, nxt);
+      first = false;
+    }
+    if (!first) CompactPairs(&pairs, cur);
+  }
+  const std::int64_t matches = pairs.count;
+  DeviceBuffer &probe_tids = *pairs.probe_tids, &build_tids = *pairs.build_tids;
   block_id out_id;
   BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
-  std::vector<const void *> segments(blocks.size());
   for (std::size_t i = 0; i < selection_.size(); ++i) {
     void *dst = out->stripe(static_cast<attribute_id>(i));
     const bool on_build = is_selection_on_build_[i];
