@@ -379,6 +379,12 @@ int qsx_join_table_destroy(qsx_join_table_t *table);
  *   out_dev n int64 on device;  out_exact  host int */
 int qsx_join_key_pack(int ncols, const void *const *cols, const int32_t *types, int64_t n,
                       int64_t *out_dev, int *out_exact, qsx_stream_t stream);
+/* qsx_join_key_pack over a run of blocks in one launch: the packed keys of all blocks in ONE stripe, block after block
+ * (out_dev: sum of block_rows values) — what the run forms of build and probe then take as a single key stripe.
+ *   block_cols   host array [b * ncols + k] of device pointers: block b's stripe of key component k */
+int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks, const int64_t *block_rows,
+                             const void *const *block_cols, int64_t *out_dev, int *out_exact, qsx_stream_t stream);
+
 /* Drop every entry, keep the allocation (a new query re-using the table;
  * counterpart of DestroyHashOperator + re-creation, relational_operators/
  * DestroyHashOperator.cpp:70-72).  Stream-ordered. */

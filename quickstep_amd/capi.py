@@ -88,6 +88,7 @@ _SIGNATURES = {
     "qsx_join_table_size": (_int, [_vp, C.POINTER(_i64), _vp]),
     "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_join_key_pack_blocks": (_int, [_int, C.POINTER(_i32), _i64, C.POINTER(_i64), _pp, _vp, C.POINTER(_int), _vp]),
     "qsx_join_build_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp]),
     "qsx_join_probe_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_probe_count_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _vp, _vp]),
@@ -440,6 +441,23 @@ def join_key_pack(cols, stream=None):
     _check(_lib.qsx_join_key_pack(len(cols), ptrs, types, n, _ptr(out), C.byref(exact), _stream(stream)),
            "qsx_join_key_pack")
     return out, bool(exact.value)
+
+
+def join_key_pack_blocks(blocks, stream=None):
+    """Composite join keys of a run of blocks (blocks[b] = the key component stripes of block b) -> (one int64 stripe of all
+    blocks' packed keys, exact flag)."""
+    nb, ncols = len(blocks), len(blocks[0])
+    total = sum(b[0].numel() for b in blocks)
+    out = torch.empty(max(total, 1), dtype=torch.int64, device=blocks[0][0].device)
+    rows = (C.c_int64 * max(nb, 1))(*[b[0].numel() for b in blocks])
+    ptrs = (C.c_void_p * max(nb * ncols, 1))()
+    for i, b in enumerate(blocks):
+        for k in range(ncols):
+            ptrs[i * ncols + k] = b[k].data_ptr() if b[k].numel() else None
+    types = (C.c_int32 * ncols)(*[qsx_type_of(c) for c in blocks[0]])
+    exact = C.c_int(0)
+    _check(_lib.qsx_join_key_pack_blocks(ncols, types, nb, rows, ptrs, _ptr(out), C.byref(exact), _stream(stream)), "qsx_join_key_pack_blocks")
+    return out[:total], bool(exact.value)
 
 
 def sort_permutation(key_cols, descending=None, stream=None, types=None):

@@ -435,6 +435,36 @@ __global__ __launch_bounds__(kJBlock) void key_pack_kernel(KeyPackArgs a, int64_
   }
 }
 
+// The composite keys of a run of blocks -> ONE stripe of packed keys, block after block (qsx_join_key_pack_blocks): a wave
+// takes tiles of 512 rows of one block; the blocks' key columns follow the run table at word cols_offset
+// ([block * ncols + component]), the table's `base` is the block's first row in the output.
+__global__ __launch_bounds__(kJBlock) void key_pack_runs_kernel(KeyPackArgs a, const long long *__restrict__ runs, long long cols_offset,
+                                                               int64_t *__restrict__ out) {
+  constexpr int kTileRows = 512;
+  const int lane = lane_id();
+  const int num_tiles = static_cast<int>(runs[2]);
+  for (int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (kJBlock / kWave) + (threadIdx.x >> 6))); tile < num_tiles;
+       tile += static_cast<int>(gridDim.x) * (kJBlock / kWave)) {
+    const RunTile at = run_locate(runs, tile);
+    const long long n = run_rows(runs, at.block);
+    const long long out_first = run_base(runs, at.block);
+    const long long *cols = runs + cols_offset + static_cast<long long>(at.block) * a.ncols;
+    for (int r = lane; r < kTileRows; r += kWave) {
+      const long long i = static_cast<long long>(at.tile_in_block) * kTileRows + r;
+      if (i >= n) break;
+      uint64_t acc = 0;
+      for (int k = 0; k < a.ncols; ++k) {
+        const void *col = as_global(reinterpret_cast<const void *>(cols[k]));
+        const uint64_t v = a.is_long[k] ? static_cast<uint64_t>(static_cast<const int64_t *>(col)[i])
+                                        : static_cast<uint64_t>(static_cast<const uint32_t *>(col)[i]);
+        if (a.exact) acc |= v << a.shift[k];
+        else acc = k == 0 ? v : combine_hashes(acc, v);
+      }
+      out[out_first + i] = static_cast<int64_t>(acc);
+    }
+  }
+}
+
 }  // namespace qsx
 
 using namespace qsx;
@@ -647,6 +677,57 @@ int qsx_join_key_pack(int ncols, const void *const *cols, const int32_t *types, 
   *out_exact = a.exact;
   if (n == 0) return QSX_OK;
   hipLaunchKernelGGL(key_pack_kernel, dim3(grid_for(n, kJBlock * 4)), dim3(kJBlock), 0, as_stream(stream), a, n, out_dev);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks, const int64_t *block_rows,
+                             const void *const *block_cols, int64_t *out_dev, int *out_exact, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (ncols < 1 || ncols > QSX_MAX_KEYS || types == nullptr || num_blocks < 0 || out_exact == nullptr ||
+      (num_blocks > 0 && (block_rows == nullptr || block_cols == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  KeyPackArgs a;
+  a.ncols = ncols;
+  int bits = 0;
+  for (int k = 0; k < ncols; ++k) {
+    if (types[k] != QSX_INT && types[k] != QSX_LONG) return QSX_ERR_UNSUPPORTED;
+    a.cols[k] = nullptr;
+    a.is_long[k] = types[k] == QSX_LONG;
+    a.shift[k] = bits < 64 ? bits : 0;
+    bits += types[k] == QSX_LONG ? 64 : 32;
+  }
+  a.exact = bits <= 64;
+  *out_exact = a.exact;
+  std::vector<int64_t> first(static_cast<size_t>(num_blocks));
+  std::vector<const void *> none(static_cast<size_t>(num_blocks), nullptr);
+  int64_t total = 0;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0) return QSX_ERR_INVALID_ARGUMENT;
+    first[b] = total;
+    total += block_rows[b];
+  }
+  if (total == 0) return QSX_OK;
+  if (out_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  std::vector<long long> table;
+  const long long tiles = build_run_table(512, num_blocks, block_rows, none.data(), nullptr, nullptr, first.data(), &table);
+  if (tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
+  const long long cols_offset = static_cast<long long>(table.size());
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    for (int k = 0; k < ncols; ++k) {
+      const void *col = block_cols[b * ncols + k];
+      if (block_rows[b] > 0 && col == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+      table.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(col)));
+    }
+  }
+  hipStream_t s = as_stream(stream);
+  const size_t bytes = table.size() * sizeof(long long);
+  const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
+  if (runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  const int rc = staged_upload(s, table.data(), bytes);
+  if (rc != QSX_OK) return rc;
+  hipLaunchKernelGGL(key_pack_runs_kernel, dim3(grid_for(tiles, kJBlock / kWave)), dim3(kJBlock), 0, s, a, runs_dev, cols_offset, out_dev);
   QSX_CHECK_LAUNCH();
   return QSX_OK;
 }

@@ -2164,6 +2164,41 @@ struct JoinKeys {
 };
 }  // namespace
 
+namespace {
+// The key stripes of a run of blocks as the join table sees them: the attribute's stripes, or — composite key — one stripe of
+// packed keys for the whole run (qsx_join_key_pack_blocks), block b's keys at row first_rows[b] of it.
+struct RunJoinKeys {
+  std::vector<const void *> ptr;          // per block
+  bool exact = true;
+  std::unique_ptr<DeviceBuffer> packed;
+  RunJoinKeys(const std::vector<BlockReference> &blocks, const std::vector<attribute_id> &attrs, const std::vector<std::int64_t> &rows) {
+    if (attrs.size() == 1) {
+      for (const BlockReference &b : blocks) ptr.push_back(b->stripe(attrs.front()));
+      return;
+    }
+    std::vector<const void *> cols;
+    std::vector<std::int32_t> types;
+    for (attribute_id a : attrs) types.push_back(blocks.front()->getRelation().getAttributeType(a).id);
+    std::int64_t total = 0;
+    for (std::size_t b = 0; b < blocks.size(); ++b) {
+      for (attribute_id a : attrs) cols.push_back(blocks[b]->stripe(a));
+      total += rows[b];
+    }
+    packed.reset(new DeviceBuffer(static_cast<std::size_t>(total) * 8 + 8));
+    int is_exact = 0;
+    CheckStatus(qsx_join_key_pack_blocks(static_cast<int>(attrs.size()), types.data(), static_cast<std::int64_t>(blocks.size()), rows.data(),
+                                         cols.data(), static_cast<std::int64_t *>(packed->ptr), &is_exact, CurrentStream()),
+                "qsx_join_key_pack_blocks");
+    exact = is_exact != 0;
+    std::int64_t at = 0;
+    for (std::size_t b = 0; b < blocks.size(); ++b) {
+      ptr.push_back(static_cast<const std::int64_t *>(packed->ptr) + at);
+      at += rows[b];
+    }
+  }
+};
+}  // namespace
+
 void BuildHashWorkOrder::execute() {
   if (run_block_ids_.empty()) {
     executeBlock(build_block_id_);
@@ -2174,21 +2209,23 @@ void BuildHashWorkOrder::execute() {
 }
 
 bool BuildHashWorkOrder::executeRun() {
-  if (predicate_ != nullptr || join_key_attributes_.size() != 1) return false;
+  if (predicate_ != nullptr) return false;
   std::vector<BlockReference> blocks;
   std::vector<std::int64_t> rows;
-  std::vector<const void *> keys;
   std::vector<std::int32_t> bases;
   for (block_id id : run_block_ids_) {
     blocks.push_back(storage_manager_->getBlock(id));
     const StorageBlock &b = *blocks.back();
-    if (b.nullBitmap(join_key_attributes_.front()) != nullptr) return false;   // (compressed key: stripe() decodes once)
+    for (attribute_id a : join_key_attributes_) {
+      if (b.nullBitmap(a) != nullptr) return false;   // (compressed key: stripe() decodes once)
+    }
     if (b.firstRow() + b.numTuples() > INT32_MAX) return false;
     rows.push_back(b.numTuples());
-    keys.push_back(b.stripe(join_key_attributes_.front()));
     bases.push_back(static_cast<std::int32_t>(b.firstRow()));   // the stored reference: relation-global row number
   }
   if (lip_filter_builder_ != nullptr && !lip_filter_builder_->insertBlocks(blocks)) return false;   // BuildHashOperator.cpp:187-190
+  const RunJoinKeys run_keys(blocks, join_key_attributes_, rows);
+  const std::vector<const void *> &keys = run_keys.ptr;
   CheckStatus(qsx_join_build_blocks(hash_table_, static_cast<std::int64_t>(blocks.size()), rows.data(), keys.data(), bases.data(), nullptr,
                                     CurrentStream()), "qsx_join_build_blocks");
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
@@ -2359,26 +2396,32 @@ void HashInnerJoinWorkOrder::execute() {
 bool HashInnerJoinWorkOrder::executeRun() {
   using JoinType = HashJoinOperator::JoinType;
   const bool existence = join_type_ == JoinType::kLeftSemiJoin || join_type_ == JoinType::kLeftAntiJoin;
-  if ((join_type_ != JoinType::kInnerJoin && !existence) || join_key_attributes_.size() != 1) return false;
+  if (join_type_ != JoinType::kInnerJoin && !existence) return false;
   if (residual_predicate_ != nullptr && existence) return false;   // (semi / anti with a residual go through the pairs: block by block)
+  int key_bits = 0;
+  for (attribute_id a : join_key_attributes_) key_bits += probe_relation_.getAttributeType(a).width * 8;
+  const bool hashed_key = join_key_attributes_.size() > 1 && key_bits > 64;   // the fold is a hash: pairs need their components compared
+  if (hashed_key && existence) return false;
   std::vector<BlockReference> blocks;
   std::vector<std::int64_t> rows, first_rows;
-  std::vector<const void *> keys;
   std::int64_t total_rows = 0;
   for (block_id id : run_block_ids_) {
     blocks.push_back(storage_manager_->getBlock(id));
     const StorageBlock &b = *blocks.back();
-    if (b.nullBitmap(join_key_attributes_.front()) != nullptr) return false;   // (compressed key: stripe() decodes once)
+    for (attribute_id a : join_key_attributes_) {
+      if (b.nullBitmap(a) != nullptr) return false;   // (compressed key: stripe() decodes once)
+    }
     for (std::size_t i = 0; i < selection_.size(); ++i) {
       if (!is_selection_on_build_[i] && b.nullBitmap(selection_[i]) != nullptr) return false;
     }
     rows.push_back(b.numTuples());
     first_rows.push_back(total_rows);
-    keys.push_back(b.stripe(join_key_attributes_.front()));
     total_rows += b.numTuples();
   }
   if (total_rows > INT32_MAX || blocks.size() > 16384) return false;
   const std::int64_t nb = static_cast<std::int64_t>(blocks.size());
+  const RunJoinKeys run_keys(blocks, join_key_attributes_, rows);   // composite key: one launch packs the run's keys
+  const std::vector<const void *> &keys = run_keys.ptr;
   // existence_map of the LIPFilterAdaptiveProber (:462-470): the probe tuples this work order looks up
   struct OwnedStorage {
     void *ptr = nullptr;
@@ -2435,7 +2478,14 @@ bool HashInnerJoinWorkOrder::executeRun() {
                                     CurrentStream()), "qsx_join_probe_blocks");
   BuildSegments build(build_relation_, storage_manager_);
   std::vector<const void *> segments(blocks.size());
-  if (residual_predicate_ != nullptr && pairs.count > 0) {
+  std::vector<ComparisonPredicate> terms;
+  if (!run_keys.exact) {   // compositeKeyCollisionCheck (SeparateChainingHashTable.hpp:1046): equal folds, equal components?
+    for (std::size_t k = 0; k < join_key_attributes_.size(); ++k) {
+      terms.push_back(ComparisonPredicate::Attributes(join_key_attributes_[k], false, ComparisonID::kEqual, build_key_attributes_[k], true));
+    }
+  }
+  if (residual_predicate_ != nullptr) terms.insert(terms.end(), residual_predicate_->conjuncts.begin(), residual_predicate_->conjuncts.end());
+  if (!terms.empty() && pairs.count > 0) {
     // matchesForJoinedTuples (:510-524) on the pairs of the run: each term's operands gathered by the pair lists (the probe
     // side through the run's own stripes), compared, chained through the filter bitmap like a conjunction
     const std::int64_t m = pairs.count;
@@ -2455,7 +2505,7 @@ bool HashInnerJoinWorkOrder::executeRun() {
       }
       return t;
     };
-    for (const ComparisonPredicate &term : residual_predicate_->conjuncts) {
+    for (const ComparisonPredicate &term : terms) {
       const Type t = gather_side(term.attribute, term.on_build_side, lhs.ptr);
       if (t.nullable || t.id == kChar) return false;   // (NULL operands / string operands: the block-by-block form)
       if (term.rhs_attribute != kInvalidAttributeID) {

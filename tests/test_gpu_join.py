@@ -533,3 +533,16 @@ def test_build_over_a_run_of_blocks_equals_block_by_block(capi, oracle, dev, fla
         k = int(cnt.item())
         assert k == rp.size
         assert np.array_equal(sorted_pairs(p.cpu().numpy()[:k], b.cpu().numpy()[:k]), sorted_pairs(rp, rb))
+
+
+@pytest.mark.parametrize("types", [(np.int32, np.int32), (np.int64, np.int32), (np.int64, np.int64), (np.int32, np.int32, np.int32)])
+def test_composite_keys_of_a_run_of_blocks_pack_like_block_by_block(capi, dev, types):
+    """qsx_join_key_pack_blocks: the packed keys of a run (one stripe, block after block) = qsx_join_key_pack per block
+    (exact 8-byte packing and the reference's CombineHashes fold for wider keys)."""
+    rng = np.random.default_rng(len(types) * 10 + types[0]().itemsize)
+    rows = [3000, 0, 1, 511, 512, 513, 70_001, 5]
+    blocks = [[to_dev(rng.integers(-1000, 1000, size=n).astype(t), dev) for t in types] for n in rows]
+    packed, exact = capi.join_key_pack_blocks(blocks)
+    want = torch.cat([capi.join_key_pack(b)[0] for b in blocks if b[0].numel()])
+    assert exact == capi.join_key_pack([b for b in blocks if b[0].numel()][0])[1]
+    assert torch.equal(packed, want)
