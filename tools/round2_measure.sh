@@ -19,6 +19,7 @@ tests/cpp/bin/work_order_runs_test > $o/work_order_runs.txt 2>&1
 tests/cpp/bin/tpch_types_operator_test 2>&1 | grep "work order" >> $o/work_order_runs.txt
 tests/cpp/bin/tpch_q3_plan_test 1500000 120000 2>&1 | grep "Q3 plan" >> $o/work_order_runs.txt
 tests/cpp/bin/tpch_q3_plan_test 15000000 120000 2>&1 | grep "Q3 plan" >> $o/work_order_runs.txt
+for u in alloc_cost pool_readback; do [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/ubench/$u tools/ubench/$u.hip -lpthread; done
 tools/ubench/alloc_cost > $o/alloc_cost.jsonl 2>&1
 (for b in 8 65536 4194304; do timeout 300 tools/ubench/pool_readback 4 100000 $b 1 1 0 0; done
  echo "no plain hipMalloc/hipFree next to it:"; timeout 300 tools/ubench/pool_readback 4 100000 8 1 0 0 0
