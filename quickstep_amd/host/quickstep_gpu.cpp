@@ -33,6 +33,7 @@ thread_local qsx_stream_t tls_stream = nullptr;
 // stream, so a buffer handed back while its last kernel is still queued can be handed out again to the same thread —
 // the next use is ordered behind it.  (A buffer built by one thread and consumed by another — DISTINCT chunks — is
 // published after a stream synchronisation, like a storage block.)  The cache keeps at most kCacheBytes per thread.
+void TrimBlockSlabPool();   // (defined behind BlockSlabPool)
 struct DeviceBuffer {
   static constexpr std::size_t kCacheFrom = 64 * 1024 + 1;
   static constexpr std::size_t kCacheBytes = std::size_t(2) << 30;
@@ -68,7 +69,15 @@ struct DeviceBuffer {
         c.bytes -= size_class;
         return;
       }
-      CheckStatus(qsx_device_alloc(size_class, &ptr), "qsx_device_alloc");
+      if (qsx_device_alloc(size_class, &ptr) != QSX_OK) {
+        for (auto &cls : c.free_by_class) {     // this thread's cached buffers and the pooled block allocations go back first
+          for (void *q : cls.second) qsx_device_free(q);
+          cls.second.clear();
+        }
+        c.bytes = 0;
+        TrimBlockSlabPool();
+        CheckStatus(qsx_device_alloc(size_class, &ptr), "qsx_device_alloc");
+      }
       return;
     }
     CheckStatus(qsx_device_alloc(bytes ? bytes : 8, &ptr), "qsx_device_alloc");
@@ -121,8 +130,19 @@ class BlockSlabPool {
       }
     }
     void *p = nullptr;
-    CheckStatus(qsx_device_alloc(cls, &p), "qsx_device_alloc(block)");
+    if (qsx_device_alloc(cls, &p) != QSX_OK) {
+      trim();                                    // what the pool keeps goes back to the device before giving up
+      CheckStatus(qsx_device_alloc(cls, &p), "qsx_device_alloc(block)");
+    }
     return p;
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (auto &cls : free_) {
+      for (void *q : cls.second) qsx_device_free(q);
+      cls.second.clear();
+    }
+    kept_ = 0;
   }
   void give(void *p, std::size_t granted) {
     if (p == nullptr) return;
@@ -142,6 +162,8 @@ class BlockSlabPool {
   std::map<std::size_t, std::vector<void *>> free_;
   std::size_t kept_ = 0;
 };
+
+void TrimBlockSlabPool() { BlockSlabPool::instance().trim(); }
 
 std::int64_t ReadCount(const void *dev_count) {
   std::int64_t v = 0;
