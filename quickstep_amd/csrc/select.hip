@@ -184,15 +184,17 @@ __global__ __launch_bounds__(kBlock) void bitmap_count_kernel(const uint64_t *__
 // row l, its output slot is tile_offset + prefix(word) + popcount(bits before l).
 // ---------------------------------------------------------------------------
 constexpr int kTileWords = 64;
+constexpr int kSmallTileWords = 16;   // 1024-row tiles: four times the waves for an input of few tiles (a 2-4 MB block)
 
+// tile_words: bitmap words of a tile — kTileWords, or kSmallTileWords for inputs of few tiles (run_compaction).
 __global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint64_t *__restrict__ bitmap,
                                                             int64_t num_words, int64_t num_tiles,
-                                                            int32_t *__restrict__ tile_counts) {
+                                                            int32_t *__restrict__ tile_counts, int tile_words = kTileWords) {
   const int lane = lane_id();
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
        tile < num_tiles; tile += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
-    const int64_t w = tile * kTileWords + lane;
-    int c = w < num_words ? __popcll(bitmap[w]) : 0;
+    const int64_t w = tile * tile_words + lane;
+    int c = lane < tile_words && w < num_words ? __popcll(bitmap[w]) : 0;
     c = wave_reduce_add(c);
     if (lane == 0) tile_counts[tile] = c;
   }
@@ -225,11 +227,11 @@ template <bool kRuns>
 __device__ __forceinline__ void compact_tile(const GatherArgs &args, const long long *__restrict__ block_cols,
                                              const uint64_t *__restrict__ bitmap, int64_t num_words, int64_t tile,
                                              int64_t tile_off, int32_t *__restrict__ out_tids, int32_t base_tid,
-                                             uint16_t *__restrict__ s_pos_wave) {
+                                             uint16_t *__restrict__ s_pos_wave, int tile_words = kTileWords) {
   const int lane = lane_id();
   {
-    const int64_t w = tile * kTileWords + lane;
-    uint64_t my_word = w < num_words ? bitmap[w] : 0;
+    const int64_t w = tile * tile_words + lane;
+    uint64_t my_word = lane < tile_words && w < num_words ? bitmap[w] : 0;
     const int pc = __popcll(my_word);
     int incl = pc;
 #pragma unroll
@@ -249,7 +251,7 @@ __device__ __forceinline__ void compact_tile(const GatherArgs &args, const long 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int64_t tile_row0 = tile * kTileWords * 64;
+    const int64_t tile_row0 = tile * tile_words * 64;
     constexpr int kBatch = 4;
     for (int i0 = lane; i0 < total; i0 += kWave * kBatch) {
       int64_t si[kBatch];
@@ -305,12 +307,12 @@ __device__ __forceinline__ void compact_tile(const GatherArgs &args, const long 
 
 __global__ __launch_bounds__(kBlock) void compact_gather_kernel(
     GatherArgs args, const uint64_t *__restrict__ bitmap, int64_t num_words, int64_t num_tiles,
-    const int64_t *__restrict__ tile_offsets, int32_t *__restrict__ out_tids, int32_t base_tid) {
+    const int64_t *__restrict__ tile_offsets, int32_t *__restrict__ out_tids, int32_t base_tid, int tile_words = kTileWords) {
   __shared__ uint16_t s_pos[kWavesPerBlock][kTileWords * 64];
   const int wave = threadIdx.x >> 6;
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; tile < num_tiles;
        tile += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
-    compact_tile<false>(args, nullptr, bitmap, num_words, tile, tile_offsets[tile], out_tids, base_tid, s_pos[wave]);
+    compact_tile<false>(args, nullptr, bitmap, num_words, tile, tile_offsets[tile], out_tids, base_tid, s_pos[wave], tile_words);
   }
 }
 
@@ -704,7 +706,11 @@ static int run_compaction(const GatherArgs &args, const uint64_t *bitmap, int64_
                           int32_t *out_tids, int32_t base_tid, int64_t *out_count, void *workspace,
                           size_t workspace_bytes, hipStream_t stream) {
   const int64_t num_words = (n + 63) >> 6;
-  const int64_t num_tiles = (num_words + kTileWords - 1) / kTileWords;
+  // A wave walks its tile's selected rows 256 at a time and column by column: ~2 us of memory latency per step that only other
+  // waves can hide.  A 2-4 MB block is 30 tiles of 4096 rows — 30 waves on 256 CUs, 30 us per call — so inputs of few tiles
+  // are cut into 1024-row tiles instead (four times the waves, a quarter of the steps each).
+  const int tile_words = (num_words + kTileWords - 1) / kTileWords < 8 * kCUs ? kSmallTileWords : kTileWords;
+  const int64_t num_tiles = (num_words + tile_words - 1) / tile_words;
   if (workspace_bytes < qsx_compact_workspace_bytes(n)) return QSX_ERR_CAPACITY;
   if (n == 0) {
     if (out_count != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), stream));
@@ -714,13 +720,13 @@ static int run_compaction(const GatherArgs &args, const uint64_t *bitmap, int64_
   int32_t *tile_counts = reinterpret_cast<int32_t *>(
       static_cast<char *>(workspace) + align_up(sizeof(int64_t) * (num_tiles + 1), 256));
   hipLaunchKernelGGL(tile_count_kernel, dim3(grid_for(num_tiles, kWavesPerBlock)), dim3(kBlock), 0,
-                     stream, bitmap, num_words, num_tiles, tile_counts);
+                     stream, bitmap, num_words, num_tiles, tile_counts, tile_words);
   QSX_CHECK_LAUNCH();
   hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, num_tiles,
                      tile_offsets, out_count);
   QSX_CHECK_LAUNCH();
   hipLaunchKernelGGL(compact_gather_kernel, dim3(grid_for(num_tiles, kWavesPerBlock)), dim3(kBlock),
-                     0, stream, args, bitmap, num_words, num_tiles, tile_offsets, out_tids, base_tid);
+                     0, stream, args, bitmap, num_words, num_tiles, tile_offsets, out_tids, base_tid, tile_words);
   QSX_CHECK_LAUNCH();
   return QSX_OK;
 }
@@ -1708,7 +1714,7 @@ int qsx_bitmap_count(const uint64_t *bitmap_dev, int64_t n, int64_t *out_count_d
 
 size_t qsx_compact_workspace_bytes(int64_t n) {
   const int64_t num_words = (n + 63) >> 6;
-  const int64_t num_tiles = (num_words + kTileWords - 1) / kTileWords;
+  const int64_t num_tiles = (num_words + kSmallTileWords - 1) / kSmallTileWords;   // (room for the small tiles of run_compaction)
   return align_up(sizeof(int64_t) * (num_tiles + 1), 256) + align_up(sizeof(int32_t) * (num_tiles + 1), 256);
 }
 
