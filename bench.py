@@ -1,29 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py — the headline measurement of BASELINE.json:
+"""bench.py — the measurements of BASELINE.json:
 "probe+aggregate rows/s at TPC-H SF100 (Q1,Q3); % HBM roofline @1/2/4/8 GPU".
 
-One step = one pass of the hot path over one batch of synthetic, HBM-resident
-input, through the C ABI (quickstep_amd.capi -> libqsx.so):
+--config headline (default): one step = one pass of the hot path over one batch of synthetic, HBM-resident input,
+through the C ABI (quickstep_amd.capi -> libqsx.so):
 
-  C2  hash join, Q3 customer⋈orders shape: clear + build a 1 M-key INT table,
-      probe it with 100 M INT keys (match rate 1.0), emit (probe_tid, build_tid);
-  C3  aggregation, Q1 lineitem shape: 600 M rows, GROUP BY two CHAR(1) keys,
-      SUM(qty), SUM(price), SUM(price*(1-disc)), SUM(price*(1-disc)*(1+tax)),
-      AVG(qty), AVG(price), AVG(disc), COUNT(*), then finalize.
+  C2  hash join, Q3 customer⋈orders shape: clear + build a 1 M-key INT table, probe it with 100 M INT keys (match
+      rate 1.0), emit (probe_tid, build_tid);
+  C3  aggregation, Q1 lineitem shape: 600 M rows, GROUP BY two CHAR(1) keys, SUM(qty), SUM(price),
+      SUM(price*(1-disc)), SUM(price*(1-disc)*(1+tax)), AVG(qty), AVG(price), AVG(disc), COUNT(*), then finalize.
 
-value = (probe rows + aggregated rows) of all ranks / wall time of the step.
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank holds the same per-GPU amount of rows (weak scaling); build and probe rows
-are shuffled on the join key across ranks (K9 scatter + RCCL all-to-all) and
-the partial Q1 states are merged across ranks (all-gather + import-merge).
+value = (probe rows + aggregated rows) of all ranks / wall time of the step.  With --gpus N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank holds the same per-GPU amount of rows (weak scaling); build and probe
+rows are SHUFFLED on the join key across ranks (K9 scatter + RCCL all-to-all(v), the exchange north_star names; --join-plan
+broadcast = all-gather of the build side instead) and the partial Q1 states are merged (all-gather + import-merge).
 
-The line also carries `roofline` for the dominant kernel (the aggregation
-update kernel; algorithmic 34 B/row) with its duration measured
-by HIP events on the launch stream, and `cpu_baseline`: the CPU oracle (a port
-of the reference algorithms, oracle/) timed on this host's cores on a bounded
-sample of the same workload.
+--config c4: BASELINE config 4, the partitioned join orders ⋈ lineitem with one 8-byte payload column per side
+(quickstep_amd/plans.py PartitionedJoin): per rank 18.75 M orders and ~75 M lineitems (SF100 over 8 ranks), shuffle forced.
+--config c5: BASELINE config 5, TPC-H Q3 with LIP filters, broadcast build sides, dense group-by and a reduce-scatter of
+the partial aggregates (plans.DistributedQ3): SF 37.5 per rank (SF300 over 8 ranks).
+Per-rank sizes are fixed, so one rank on the 1-GPU box runs the same code path (every collective over one rank).
+
+After the timed region the results of the last step are CHECKED (pair validity, permutation of the probe rows, COUNT /
+SUM values against independent torch reductions) — a wrong result fails the run instead of printing a number.
+
+The line carries `roofline` for the dominant kernel with its duration measured by HIP events on the launch stream, and
+`cpu_baseline`: the CPU oracle (a port of the reference algorithms, oracle/) timed on this host's cores on a bounded sample
+of the same workload — 5 trials, mean of trials 2-4 in run order (benchmarks/tpch/process.py:11-45).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -40,7 +46,9 @@ import quickstep_amd.capi as capi  # noqa: E402
 from quickstep_amd import types as T  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+XGMI_PEAK_GBS = 7 * 153.0      # per GPU: 7 links x ~153 GB/s
 Q1_BYTES_PER_ROW = 34          # 1 + 1 + 4 * 8
+METRIC = "probe+aggregate rows/s at TPC-H SF100 (Q1,Q3)"
 
 
 def q1_config():
@@ -113,6 +121,22 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def trials_2_to_4(run, trials=5):
+    """5 trials, mean of trials 2-4 in run order (first = warm-up, last dropped)."""
+    times = [run() for _ in range(trials)]
+    return sum(times[1:4]) / 3.0, times
+
+
 def cpu_baseline(args):
     """Oracle (port of the reference CPU algorithms) on a bounded sample, all usable host cores."""
     from oracle import pyoracle as O
@@ -121,81 +145,149 @@ def cpu_baseline(args):
     build = rng.permutation(args.build_rows).astype(np.int32)
     block_join = 1_048_576           # 4 MB blocks of INT keys
     block_agg = 4 * 1024 * 1024 // Q1_BYTES_PER_ROW
-    # calibrate on a small slice, then size the sample for ~8 s per operator
+    # calibrate on a small slice, then size the sample so that the five trials of an operator take ~cpu_seconds in all
+    per_trial = args.cpu_seconds / 5.0
     probe_small = rng.integers(0, int(args.build_rows / args.match), size=2_000_000).astype(np.int32)
     r = O.bench_join(build, probe_small, block_join, threads)
     rate_p = probe_small.size / max(r["probe_seconds"], 1e-6)
-    n_probe = int(min(args.probe_rows, max(4_000_000, rate_p * args.cpu_seconds)))
+    n_probe = int(min(args.probe_rows, max(4_000_000, rate_p * per_trial)))
     probe = rng.integers(0, int(args.build_rows / args.match), size=n_probe).astype(np.int32)
-    best = None
-    for _ in range(2):
+    builds = []
+
+    def one_join():
         r = O.bench_join(build, probe, block_join, threads)
-        best = r if best is None or r["probe_seconds"] < best["probe_seconds"] else best
-    rate_p = n_probe / best["probe_seconds"]
-    rate_b = args.build_rows / best["build_seconds"]
+        builds.append(r["build_seconds"])
+        return r["probe_seconds"]
+    probe_s, probe_trials = trials_2_to_4(one_join)
+    rate_p = n_probe / probe_s
+    rate_b = args.build_rows / (sum(builds[1:4]) / 3.0)
     cfg = q1_config()
     cols_small = gen_q1_columns_cpu(2_000_000, 4)
     secs, st = O.bench_agg(cfg, cols_small, 2_000_000, block_agg, threads)
     st.close()
     rate_a = 2_000_000 / max(secs, 1e-6)
-    n_agg = int(min(args.agg_rows, max(4_000_000, rate_a * args.cpu_seconds), 60_000_000))
+    n_agg = int(min(args.agg_rows, max(4_000_000, rate_a * per_trial), 60_000_000))
     cols = gen_q1_columns_cpu(n_agg, 4)
-    best_a = None
-    for _ in range(2):
+
+    def one_agg():
         secs, st = O.bench_agg(cfg, cols, n_agg, block_agg, threads)
         st.close()
-        best_a = secs if best_a is None else min(best_a, secs)
-    rate_a = n_agg / best_a
+        return secs
+    agg_s, agg_trials = trials_2_to_4(one_agg)
+    rate_a = n_agg / agg_s
     mix = (args.probe_rows + args.agg_rows) / (args.probe_rows / rate_p + args.agg_rows / rate_a)
     return {
-        "value": mix, "unit": "rows/s", "cores": threads, "kind": "port",
+        "value": mix, "unit": "rows/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
         "sample": f"oracle (CPU restatement of SimpleScalarSeparateChaining probe + ThreadPrivateCompactKey aggregation), "
                   f"{threads} worker threads, block-at-a-time; join {args.build_rows} x {n_probe} probe rows, "
-                  f"aggregation {n_agg} rows; value = same probe:aggregate row mix as the GPU step",
+                  f"aggregation {n_agg} rows; 5 trials each, mean of trials 2-4 in run order; value = same "
+                  f"probe:aggregate row mix as the GPU step",
         "probe_rows_per_s": rate_p, "build_rows_per_s": rate_b, "aggregate_rows_per_s": rate_a,
+        "probe_trials_s": probe_trials, "aggregate_trials_s": agg_trials,
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--build-rows", type=int, default=1_000_000)
-    ap.add_argument("--probe-rows", type=int, default=100_000_000)
-    ap.add_argument("--agg-rows", type=int, default=600_000_000)
-    ap.add_argument("--match", type=float, default=1.0)
-    ap.add_argument("--join-table", choices=["dense", "hashed"], default="dense",
-                    help="dense: the build key (custkey) has exact min/max statistics -> directly addressed table "
-                         "(qsx_join_table_create_dense); hashed: open-addressing table (qsx_join_table_create)")
-    ap.add_argument("--join-plan", choices=["auto", "shuffle", "broadcast"], default="auto",
-                    help="N > 1: shuffle = both sides repartitioned on the join key (K9 + RCCL all-to-all); broadcast = "
-                         "all-gather of the build side, probe rows stay where they are (the reference's broadcast join, "
-                         "BuildHashOperator.hpp:99,146-152); auto = broadcast while the gathered build side has <= 16 Mi rows")
-    ap.add_argument("--other-plan-leg", action="store_true",
-                    help="N > 1: after the timed region also run the join plan that was NOT picked, untimed, and report its cost")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def kernel_source_digest():
+    """sha256 over the device sources of the aggregation kernel: profiles/traffic.json is only quoted while it matches."""
+    h = hashlib.sha256()
+    for name in ("agg_hash_update.hpp", "agg_common.hpp", "agg_shapes.hpp", "agg_translate.hpp", "device_common.hpp", "aggregate.hip"):
+        with open(os.path.join(ROOT, "quickstep_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if capi.device_count() < 1:
-        raise SystemExit("libqsx.so sees no gfx950 device; there is no CPU path to benchmark")
-    # QSX_BENCH_FORCE_DISTRIBUTED=1 runs the multi-GPU code path (RCCL shuffle + merge) even with one rank:
-    # used to validate that path on the 1-GPU box (torch.distributed.run --nproc-per-node 1).
-    distributed = world > 1 or os.environ.get("QSX_BENCH_FORCE_DISTRIBUTED") == "1"
+
+# ------------------------------------------------------------------------------------------------------------------------
+class Ctx:
+    pass
+
+
+def ev():
+    return torch.cuda.Event(enable_timing=True)
+
+
+def timed_loop(ctx, step, args):
+    """W untimed steps, then exactly K timed steps between barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if ctx.distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)      # HIP events are recorded inside the timed region, read afterwards
+    torch.cuda.synchronize()
+    if ctx.distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if ctx.distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def phase_means(recorded, steps):
+    out = {}
+    for per_step in recorded:
+        for name, start, end in per_step:
+            out[name] = out.get(name, 0.0) + start.elapsed_time(end)
+    return {k: v / steps for k, v in out.items()}
+
+
+def all_sum(ctx, value):
+    if not ctx.distributed:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=ctx.dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def check_pairs(probe_keys, build_keys, out_p, out_b, count, key_space, build_base=0, probe_base=0):
+    """Exact, any size: (1) every pair satisfies the join condition, (2) the probe tids are exactly the probe rows whose
+    key has a build row, each once (the build keys are unique)."""
+    k = int(count)
+    p, b = out_p[:k].long() - probe_base, out_b[:k].long() - build_base
+    assert bool((build_keys[b] == probe_keys[p]).all()), "a pair violates the join condition"
+    expect = torch.nonzero(probe_keys < key_space).flatten() if key_space is not None else None
+    got = torch.sort(p).values
+    if expect is not None:
+        assert got.numel() == expect.numel() and bool((got == expect).all()), "probe tids are not the matching probe rows, once each"
+    return k
+
+
+def check_q1(agg_cols, fin, rows):
+    """COUNT(*) per group exact against the number of rows with the group's key; SUM(qty) exact (integer-valued doubles: every
+    partial sum is an integer below 2^53); SUM(price), SUM(price*(1-disc)) within 1e-6 of a torch f64 reduction."""
+    keys, vals, _, groups = fin
+    g = int(groups.item())
+    k1, k2, qty, price, disc, _tax = agg_cols
+    combo = k1.long() * 256 + k2.long()
+    got_combo = keys[0][:g].long() * 256 + keys[1][:g].long()
+    assert int(vals[7][:g].sum().item()) == rows, "COUNT(*) does not add up to the rows aggregated"
+    assert torch.unique(got_combo).numel() == g, "a group appears twice"
+    # per group: masked torch reductions (a handful of groups; index_add_ would be 1.8 G atomics on four addresses)
+    for i in range(g):
+        mask = combo == got_combo[i]
+        zero = torch.zeros((), dtype=torch.float64, device=qty.device)
+        # COUNT(*) exact: with the counts adding up to the row count (above) no group is missing either
+        assert vals[7][i].item() == int(mask.sum().item()), "COUNT(*) of a group differs from the rows with its key"
+        assert vals[0][i].item() == torch.where(mask, qty, zero).sum().item(), "SUM(l_quantity) is not exact"
+        for a, ref in ((1, torch.where(mask, price, zero).sum().item()),
+                       (2, torch.where(mask, price * (1.0 - disc), zero).sum().item())):
+            rel = abs(vals[a][i].item() - ref) / abs(ref)
+            assert rel <= 1e-6, f"aggregate {a} of group {i}: relative error {rel}"
+        del mask
+    return g
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def run_headline(ctx, args):
+    dev, rank, world, distributed = ctx.dev, ctx.rank, ctx.world, ctx.distributed
     if distributed:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
         from quickstep_amd import distributed as qd
-
-    # ---- synthetic inputs, resident in HBM before the timed region -----------
     g = torch.Generator(device=dev)
     g.manual_seed(2 + rank)
     key_space = args.build_rows * world
@@ -213,7 +305,7 @@ def main():
     dense = args.join_table == "dense"
     plan = args.join_plan
     if plan == "auto":
-        plan = "broadcast" if args.build_rows * world <= 16 * 1024 * 1024 else "shuffle"
+        plan = "shuffle"       # the exchange BASELINE.json names; broadcast is the cheaper plan for a 1 M-row build side
     # A second stream for the aggregation only pays next to the xGMI-bound shuffle.  Next to a local probe (broadcast
     # plan) the two kernels fight over L2: measured 6.5 ms per step side by side against 4.4 ms back to back on one GPU.
     agg_stream = torch.cuda.Stream(device=dev) if distributed and plan == "shuffle" else main_stream
@@ -230,9 +322,6 @@ def main():
         out = (torch.empty(capacity, dtype=torch.int32, device=dev), torch.empty(capacity, dtype=torch.int32, device=dev),
                torch.zeros(1, dtype=torch.int64, device=dev))
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-    phase_ms = {"build": 0.0, "probe": 0.0, "aggregate_update": 0.0, "finalize": 0.0, "shuffle_build": 0.0,
-                "shuffle_probe": 0.0, "merge": 0.0}
     results = {}
     recorded = []   # per timed step: (phase, start event, end event) on the stream the kernels were launched on
 
@@ -257,7 +346,7 @@ def main():
             probe_tids, build_tids, op, ob, cnt = join.probe(probe_keys, rank * args.probe_rows, capacity=capacity)
             e2.record()
             main_stream.wait_stream(agg_stream)
-            results.update(matches=cnt, groups=fin[3], built=nb)
+            results.update(matches=cnt, groups=fin[3], fin=fin, built=nb, pairs=(probe_tids, build_tids, op, ob))
             if timed:   # events are only READ after the timed loop (reading synchronises)
                 recorded.append((("shuffle_build", e0, e1), ("shuffle_probe", e1, e2), ("aggregate_update", a0, a1),
                                  ("merge", a1, a2)))
@@ -280,30 +369,12 @@ def main():
             recorded.append((("build", e[0], e[1]), ("probe", e[1], e[2]), ("aggregate_update", e[3], e[4]),
                              ("finalize", e[4], e[5])))
 
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)      # HIP events are recorded inside the timed region, read below
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    for per_step in recorded:
-        for name, start, end in per_step:
-            phase_ms[name] += start.elapsed_time(end)
-    for k in phase_ms:
-        phase_ms[k] /= args.steps
+    elapsed = timed_loop(ctx, step, args)
+    phase_ms = phase_means(recorded, args.steps)
 
     other_plan_ms = None
     if distributed and world > 1 and args.other_plan_leg:
-        # the plan the rule above did not pick, untimed leg (2 runs, second one measured): what the shuffle costs here.
-        # Never allowed to take the headline measurement down with it.
+        # the plan that was not timed, untimed leg (2 runs, second one measured).  Never allowed to take the headline down.
         try:
             other = make_join("shuffle" if plan == "broadcast" else "broadcast")
             for it in range(2):
@@ -317,21 +388,35 @@ def main():
             del other
         except Exception as exc:  # noqa: BLE001
             other_plan_ms = f"failed: {exc!r}"[:200]
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        m = results["matches"].clone()
-        dist.all_reduce(m, op=dist.ReduceOp.SUM)
-        matches = int(m.item())
-    else:
-        matches = int(results["matches"].item())
+    matches = all_sum(ctx, results["matches"].item())
 
-    # ---- sanity: the timed work really produced the right shape of result ----
-    expected_matches = None
-    if args.match == 1.0:
-        expected_matches = args.probe_rows * world
-        assert matches == expected_matches, (matches, expected_matches)
+    # ---- the timed work produced the right RESULT (last step), not just the right shape ----------------------------------
+    checks = {}
+    if not args.no_check:
+        if not distributed:
+            checks["pairs"] = check_pairs(probe_keys, build_keys, out[0], out[1], results["matches"].item(), key_space)
+        else:
+            # shuffled join: the pairs index the rows that arrived on this rank — every pair must satisfy the join condition
+            # on the keys that arrived, and sit on the rank that owns its key; the pairs of all ranks together are one per
+            # probe row that has a build row
+            probe_tids, build_tids, op, ob = results["pairs"]
+            k = int(results["matches"].item())
+            if plan == "shuffle":
+                pk, bk = join.probe_keys[op[:k].long()], join.build_keys[ob[:k].long()]
+                assert bool((pk == bk).all()), "a pair violates the join condition"
+                assert world & (world - 1) or bool(((pk & (world - 1)) == rank).all()), "a pair sits on the wrong rank"
+            expected = all_sum(ctx, int((probe_keys < key_space).sum().item()))
+            assert matches == expected, (matches, expected)
+            checks["pairs"] = matches
+        if args.match == 1.0:
+            assert matches == args.probe_rows * world, (matches, args.probe_rows * world)
+        if not distributed:
+            checks["q1_groups"] = check_q1(agg_cols, results["fin"], args.agg_rows)
+        else:
+            fin = results["fin"]
+            g_ = int(fin[3].item())
+            assert all_sum(ctx, args.agg_rows) == int(fin[1][7][:g_].sum().item()), "merged COUNT(*) != rows of all ranks"
+            checks["q1_groups"] = g_
     assert int(results["groups"].item()) == 4
 
     rows_per_step = (args.probe_rows + args.agg_rows) * world
@@ -339,7 +424,7 @@ def main():
     agg_s = phase_ms["aggregate_update"] / 1e3
     agg_gbs = Q1_BYTES_PER_ROW * args.agg_rows / agg_s / 1e9
     line = {
-        "metric": "probe+aggregate rows/s at TPC-H SF100 (Q1,Q3)",
+        "metric": METRIC,
         "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "i32 keys / f64 sums", "data": "synthetic",
@@ -359,16 +444,26 @@ def main():
             "avg_launch_ms": phase_ms["aggregate_update"], "traffic": None,
         },
         "phases_ms": phase_ms,
+        "checked": checks,
     }
     if other_plan_ms is not None:
         line["join_plan"] = {"used": plan, "other_plan_build_plus_probe_ms": other_plan_ms}
+    if distributed and plan == "shuffle":
+        moved = join.shuffled_bytes * (world - 1) / max(world, 1)
+        sh_s = (phase_ms["shuffle_build"] + phase_ms["shuffle_probe"]) / 1e3
+        line["alltoall"] = {"bytes_per_rank_per_step": moved, "GBps_per_rank_over_shuffle_phases": moved / sh_s / 1e9,
+                            "peak_GBps_per_rank": XGMI_PEAK_GBS,
+                            "note": "phases include K9 scatter, counts exchange, build / probe kernels"}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
             if tr.get("rows_per_launch") == args.agg_rows:
-                line["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
-                line["roofline"]["traffic_source"] = tr.get("source")
+                if tr.get("kernel_source_digest") in (None, kernel_source_digest()):
+                    line["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+                    line["roofline"]["traffic_source"] = tr.get("source")
+                else:
+                    line["roofline"]["traffic_source"] = "profiles/traffic.json is for other kernel sources: stale, not quoted"
         except Exception:
             pass
     if not distributed:
@@ -383,27 +478,239 @@ def main():
                          "frac": probe_bytes / probe_s / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes": "4*N_probe + 8*N_match (hash-table traffic excluded)"},
         }
-        if dense:
-            # the same probe against the hashed table (what a build side without exact statistics gets), untimed leg
-            hashed = capi.JoinTable(T.INT, args.build_rows)
-            hashed.build(build_keys)
-            hashed.probe(probe_keys, capacity=capacity, out=out)
-            h0, h1 = ev(), ev()
-            h0.record()
-            for _ in range(3):
-                hashed.probe(probe_keys, capacity=capacity, out=out)
-            h1.record()
-            torch.cuda.synchronize()
-            line["probe"]["hashed_table_ms"] = h0.elapsed_time(h1) / 3
-            hashed.close()
+        line["probe"]["variants"] = probe_variants(ctx, args, build_keys, probe_keys, out)
         line["build"] = {"rows_per_s": args.build_rows / (phase_ms["build"] / 1e3), "ms": phase_ms["build"]}
         line["aggregate"] = {"rows_per_s": args.agg_rows / agg_s, "ms": phase_ms["aggregate_update"],
                              "finalize_ms": phase_ms["finalize"]}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    return line
+
+
+def probe_variants(ctx, args, build_keys, probe_keys, out):
+    """The other §8(d) C2 legs, each timed with HIP events over 3 launches after one warm-up: the hashed table (a build side
+    without statistics), match rate 0.2 (Q3's c_mktsegment filter), and the materialised join (+ one 8-byte payload
+    gathered from each side, +16 B per match)."""
+    dev = ctx.dev
+    n = args.probe_rows
+    res = {}
+
+    def timed(fn, reps=3):
+        fn()
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(33)
+    keys_02 = torch.randint(0, args.build_rows * 5, (n,), device=dev, generator=g, dtype=torch.int32)
+    for name, dense in (("dense", True), ("hashed", False)):
+        t = capi.JoinTable(T.INT, args.build_rows, key_range=(0, args.build_rows - 1) if dense else None)
+        t.build(build_keys)
+        for m, keys in ((1.0, probe_keys), (0.2, keys_02)):
+            ms = timed(lambda: t.probe(keys, capacity=n, out=out))
+            matches = int(out[2].item())
+            check_pairs(keys, build_keys, out[0], out[1], matches, args.build_rows)
+            byts = 4 * n + 8 * matches
+            res[f"{name}_m{m}"] = {"ms": ms, "matches": matches, "rows_per_s": n / ms * 1e3, "GBps": byts / ms / 1e6,
+                                   "frac_of_hbm_peak": byts / ms / 1e6 / HBM_PEAK_GBS}
+        if dense:
+            # materialised: one 8-byte payload column from each side, gathered by the pair list (K5)
+            pay_b = build_keys.long() * 3 + 1
+            pay_p = probe_keys.long() * 7 + 2
+            t.probe(probe_keys, capacity=n, out=out)
+            k = int(out[2].item())
+            ob = torch.empty(k, dtype=torch.int64, device=dev)
+            op = torch.empty(k, dtype=torch.int64, device=dev)
+
+            def materialise():
+                t.probe(probe_keys, capacity=n, out=out)
+                capi.gather(pay_b, out[1][:k], out=ob)
+                capi.gather(pay_p, out[0][:k], out=op)
+            ms = timed(materialise)
+            assert bool((ob == probe_keys[out[0][:k].long()].long() * 3 + 1).all()) and bool((op == probe_keys[out[0][:k].long()].long() * 7 + 2).all())
+            byts = 4 * n + 8 * k + 16 * k
+            res["dense_m1.0_materialised"] = {"ms": ms, "matches": k, "GBps": byts / ms / 1e6,
+                                              "frac_of_hbm_peak": byts / ms / 1e6 / HBM_PEAK_GBS}
+            del pay_b, pay_p, ob, op
+        t.close()
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def run_c4(ctx, args):
+    from quickstep_amd import plans
+    dev, rank, world = ctx.dev, ctx.rank, ctx.world
+    n_o = args.c4_orders_per_rank
+    inputs = plans.generate_c4_inputs(dev, n_o, rank)
+    n_l = inputs["l_orderkey"].numel()
+    torch.cuda.synchronize()
+    pj = plans.PartitionedJoin(capi, n_o * world, n_o, dense=args.join_table == "dense")
+    recorded, results = [], {}
+
+    def step(timed):
+        e0, e1 = ev(), ev()
+        e0.record()
+        cols, moved = pj.step(inputs, rank * n_o, 0)
+        e1.record()
+        results.update(cols=cols, moved=moved)
+        if timed:
+            recorded.append((("partitioned_join", e0, e1),))
+
+    elapsed = timed_loop(ctx, step, args)
+    phase_ms = phase_means(recorded, args.steps)
+    cols = results["cols"]
+    out_rows = all_sum(ctx, cols[0].numel())
+    total_lines = all_sum(ctx, n_l)
+    if not args.no_check:
+        assert plans.PartitionedJoin.check(cols), "a joined row violates the join condition"
+        assert bool(((cols[0] & (world - 1)) == rank).all()) or world & (world - 1)
+        assert out_rows == total_lines, (out_rows, total_lines)          # every lineitem row has exactly one order
+    rows = (n_o * world + total_lines)
+    moved = results["moved"] * (world - 1) / world                       # bytes this rank really sent to peers
+    # HBM algorithmic bytes per rank: scan both relations once (4 + 8 B/row), write the join output (4 + 8 + 8 B/row)
+    algo = (4 + 8) * (n_o + n_l) + (4 + 8 + 8) * cols[0].numel()
+    step_s = elapsed / args.steps
+    return {
+        "metric": METRIC, "value": rows * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32 keys / 8-byte payloads", "data": "synthetic",
+        "config": {"workload": f"C4 partitioned hash join orders ⋈ lineitem, {n_o} orders + {n_l} lineitems per GPU, one 8-byte "
+                               "payload column per side, both sides shuffled on orderkey (K9 scatter + all-to-all(v))",
+                   "orders": n_o * world, "lineitems": total_lines, "output_rows": out_rows,
+                   "parallelism": f"{world} GPU(s), hash partition = orderkey & (P-1)"},
+        "roofline": {"kernel": "whole step (K9 partition_scatter x2, build, probe, K5 gathers)", "bound": "hbm",
+                     "achieved": algo / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / step_s / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_step": algo, "traffic": None},
+        "alltoall": {"bytes_sent_per_rank_per_step": moved, "GBps_per_rank_over_step": moved / step_s / 1e9,
+                     "peak_GBps_per_rank": XGMI_PEAK_GBS},
+        "phases_ms": phase_ms,
+    }
+
+
+def run_c5(ctx, args):
+    from quickstep_amd import plans
+    dev, rank, world = ctx.dev, ctx.rank, ctx.world
+    inputs = plans.generate_q3_inputs(dev, args.c5_sf_per_rank, rank, world)
+    torch.cuda.synchronize()
+    os.environ.setdefault("QSX_AGG_JIT_MIN_ROWS", "0")
+    q3 = plans.DistributedQ3(capi, inputs["customers_total"], inputs["orders_total"], use_lip=not args.no_lip, fused=True)
+    recorded, results = [], {}
+
+    def step(timed):
+        e0, e1 = ev(), ev()
+        e0.record()
+        res = q3.run(inputs, tid_base_orders=rank * inputs["o_orderkey"].numel())
+        e1.record()
+        results.update(res)
+        if timed:
+            recorded.append((("q3", e0, e1),))
+
+    elapsed = timed_loop(ctx, step, args)
+    phase_ms = phase_means(recorded, args.steps)
+    rows_rank = inputs["c_custkey"].numel() + inputs["o_orderkey"].numel() + inputs["l_orderkey"].numel()
+    rows = all_sum(ctx, rows_rank)
+    pairs = all_sum(ctx, results["pairs"])
+    groups = all_sum(ctx, results["groups"])
+    if not args.no_check:
+        # independent torch evaluation of the query on this rank's lineitems against the GLOBAL qualifying-order set
+        c_ok = torch.zeros(inputs["customers_total"] + 1, dtype=torch.bool, device=dev)
+        mine = inputs["c_custkey"][inputs["c_mktsegment"] == plans.SEG_BUILDING].long()
+        c_ok[mine] = True
+        if ctx.distributed:
+            t = c_ok.to(torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c_ok = t.bool()
+        o_ok = torch.zeros(inputs["orders_total"] + 1, dtype=torch.bool, device=dev)
+        sel = (inputs["o_orderdate"] < plans.DATE_CUT) & c_ok[inputs["o_custkey"].long()]
+        o_ok[inputs["o_orderkey"][sel].long()] = True
+        if ctx.distributed:
+            t = o_ok.to(torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            o_ok = t.bool()
+        l_sel = (inputs["l_shipdate"] > plans.DATE_CUT) & o_ok[inputs["l_orderkey"].long()]
+        assert all_sum(ctx, int(l_sel.sum().item())) == pairs, "joined pairs differ from the torch evaluation"
+        revenue = torch.zeros(inputs["orders_total"] + 1, dtype=torch.float64, device=dev)
+        revenue.index_add_(0, inputs["l_orderkey"][l_sel].long(), (inputs["l_extendedprice"] * (1.0 - inputs["l_discount"]))[l_sel])
+        if ctx.distributed:
+            dist.all_reduce(revenue, op=dist.ReduceOp.SUM)
+        assert int((revenue != 0).sum().item()) == groups, "group count differs from the torch evaluation"
+        top = torch.topk(revenue, 10).values
+        rel = ((results["top_revenue"] - top).abs() / top).max().item()
+        assert rel <= 1e-6, f"top-10 revenue differs from the torch evaluation: {rel}"
+        del revenue, c_ok, o_ok
+    algo = plans.q3_input_bytes(inputs)
+    step_s = elapsed / args.steps
+    return {
+        "metric": METRIC, "value": rows * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32 keys / f64 sums", "data": "synthetic",
+        "config": {"workload": f"C5 TPC-H Q3 pipeline (3-way join + LIP filters + group-by l_orderkey + top 10) at SF "
+                               f"{args.c5_sf_per_rank} per GPU, input rows = customer + orders + lineitem",
+                   "input_rows": rows, "joined_pairs": pairs, "groups": groups,
+                   "parallelism": f"{world} GPU(s): broadcast build sides (all-gather), LIP bit vectors OR-ed across ranks, dense "
+                                  "partial aggregates merged by reduce-scatter, every rank finalizes its key range"},
+        "roofline": {"kernel": "whole query (K1 selects, LIP, K3/K4 joins, K7 dense aggregation through the pair list, K10, top-k)",
+                     "bound": "hbm", "achieved": algo / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": algo / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": algo, "traffic": None},
+        "collectives": {"bytes_per_rank_per_step": q3.comm_bytes, "GBps_per_rank_over_step": q3.comm_bytes / step_s / 1e9,
+                        "peak_GBps_per_rank": XGMI_PEAK_GBS},
+        "phases_ms": phase_ms,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=["headline", "c4", "c5"], default="headline")
+    ap.add_argument("--build-rows", type=int, default=1_000_000)
+    ap.add_argument("--probe-rows", type=int, default=100_000_000)
+    ap.add_argument("--agg-rows", type=int, default=600_000_000)
+    ap.add_argument("--match", type=float, default=1.0)
+    ap.add_argument("--c4-orders-per-rank", type=int, default=18_750_000, help="150 M orders of SF100 over 8 ranks")
+    ap.add_argument("--c5-sf-per-rank", type=float, default=37.5, help="SF300 over 8 ranks")
+    ap.add_argument("--no-lip", action="store_true", help="c5: no LIP filters")
+    ap.add_argument("--join-table", choices=["dense", "hashed"], default="dense",
+                    help="dense: the build key (custkey) has exact min/max statistics -> directly addressed table "
+                         "(qsx_join_table_create_dense); hashed: open-addressing table (qsx_join_table_create)")
+    ap.add_argument("--join-plan", choices=["auto", "shuffle", "broadcast"], default="auto",
+                    help="N > 1: shuffle = both sides repartitioned on the join key (K9 + RCCL all-to-all); broadcast = "
+                         "all-gather of the build side, probe rows stay where they are (the reference's broadcast join, "
+                         "BuildHashOperator.hpp:99,146-152); auto = shuffle (the exchange BASELINE.json names)")
+    ap.add_argument("--other-plan-leg", action="store_true",
+                    help="N > 1: after the timed region also run the join plan that was NOT picked, untimed, and report its cost")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU time budget per operator for the cpu_baseline trials")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the result checks after the timed region")
+    args = ap.parse_args()
+
+    ctx = Ctx()
+    ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    ctx.dev = dev = torch.device("cuda", local_rank)
+    if capi.device_count() < 1:
+        raise SystemExit("libqsx.so sees no gfx950 device; there is no CPU path to benchmark")
+    # QSX_BENCH_FORCE_DISTRIBUTED=1 runs the multi-GPU code path (RCCL shuffle + merge) even with one rank:
+    # used to validate that path on the 1-GPU box (torch.distributed.run --nproc-per-node 1).
+    ctx.distributed = world > 1 or os.environ.get("QSX_BENCH_FORCE_DISTRIBUTED") == "1"
+    if ctx.distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    line = {"headline": run_headline, "c4": run_c4, "c5": run_c5}[args.config](ctx, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "headline":
         line["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(line))
-    if distributed:
+    if ctx.distributed:
         dist.destroy_process_group()
 
 

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
-#define QSX_ABI_VERSION 6
+#define QSX_ABI_VERSION 7
 
 typedef void *qsx_stream_t;
 
@@ -699,6 +699,18 @@ int qsx_agg_merge(qsx_agg_state_t *dst, qsx_agg_state_t *src, qsx_stream_t strea
  * spilled rows in) right before exporting; the size stays valid until the next update / merge into the state.
  * COLLISION_FREE and SINGLE_STATE images never change size. */
 int qsx_agg_state_export_bytes(qsx_agg_state_t *state, size_t *out_bytes, qsx_stream_t stream);
+/* How the image is laid out, for whoever reduces images across GPUs column by column (reduce-scatter of the dense
+ * CollisionFreeVector state, storage/CollisionFreeVectorTable.hpp:192-208's key ranges): the image is `header_words`
+ * 8-byte words (dense: the LSB-first existence bits; hash strategies: the key slots) followed by `num_columns` columns of
+ * `words_per_column` words.  column_kinds[c] says how two partial values of column c combine:
+ * QSX_ACC_SUM_F64 (0) f64 +, QSX_ACC_SUM_I64 (1) int64 +, QSX_ACC_MIN_I64 (2), QSX_ACC_MAX_I64 (3) on the int64 words
+ * (MIN / MAX of doubles are stored as order-preserving int64 images).  Host-only, no device work. */
+#define QSX_ACC_SUM_F64 0
+#define QSX_ACC_SUM_I64 1
+#define QSX_ACC_MIN_I64 2
+#define QSX_ACC_MAX_I64 3
+int qsx_agg_state_image_layout(qsx_agg_state_t *state, int *out_dense, int64_t *out_header_words, int64_t *out_words_per_column,
+                               int *out_num_columns, int32_t *out_column_kinds, int kinds_capacity);
 /* QSX_ERR_CAPACITY when the image no longer fits capacity_bytes. */
 int qsx_agg_state_export(qsx_agg_state_t *state, void *out_dev, size_t capacity_bytes, qsx_stream_t stream);
 /* dst += exported image (image_bytes long) of a state with the same config.  Stream-ordered. */

@@ -115,6 +115,7 @@ _SIGNATURES = {
     "qsx_agg_merge": (_int, [_vp, _vp, _vp]),
     "qsx_agg_state_export_bytes": (_int, [_vp, C.POINTER(_sz), _vp]),
     "qsx_agg_state_export": (_int, [_vp, _vp, _sz, _vp]),
+    "qsx_agg_state_image_layout": (_int, [_vp, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int), C.POINTER(_i32), _int]),
     "qsx_agg_state_import_merge": (_int, [_vp, _vp, _sz, _vp]),
     "qsx_agg_num_groups": (_int, [_vp, C.POINTER(_i64), _vp]),
     "qsx_agg_finalize": (_int, [_vp, _int, _int, _pp, _pp, _pp, _i64, _vp, _vp]),
@@ -768,6 +769,15 @@ class AggState:
         _check(_lib.qsx_agg_state_export(self._h, _ptr(out), nbytes, _stream(stream)), "qsx_agg_state_export")
         return out
 
+    def image_layout(self):
+        """(dense, header_words, words_per_column, column_kinds): how an exported image is laid out and how two partial values
+        of each column combine (T.ACC_SUM_F64 / ACC_SUM_I64 / ACC_MIN_I64 / ACC_MAX_I64)."""
+        dense, header, per_col, ncols = C.c_int(), C.c_int64(), C.c_int64(), C.c_int()
+        kinds = (C.c_int32 * 32)()
+        _check(_lib.qsx_agg_state_image_layout(self._h, C.byref(dense), C.byref(header), C.byref(per_col), C.byref(ncols), kinds, 32),
+               "qsx_agg_state_image_layout")
+        return bool(dense.value), header.value, per_col.value, [int(kinds[i]) for i in range(ncols.value)]
+
     def import_merge(self, image, stream=None):
         """image: int64 tensor holding exactly one exported image (its length tells the source table's capacity)."""
         _check(_lib.qsx_agg_state_import_merge(self._h, _ptr(image), image.numel() * image.element_size(), _stream(stream)),
@@ -863,6 +873,24 @@ class LipFilter:
         nw = C.c_int64()
         _check(_lib.qsx_lip_filter_words(self._h, C.byref(p), C.byref(nw)), "qsx_lip_filter_words")
         return p.value, nw.value
+
+    def clear(self, stream=None):
+        p, nw = self.words()
+        _check(_lib.qsx_memset_device(C.c_void_p(p), 0, nw * 8, _stream(stream)), "qsx_memset_device")
+
+    def export(self, device, stream=None):
+        """Copy of the raw bit array as an int64 tensor (what a multi-GPU plan all-reduces with OR)."""
+        p, nw = self.words()
+        out = torch.empty(nw, dtype=torch.int64, device=device)
+        _check(_lib.qsx_copy_on_device(_ptr(out), C.c_void_p(p), nw * 8, _stream(stream)), "qsx_copy_on_device")
+        return out
+
+    def merge_or(self, words, stream=None):
+        """filter |= words (an exported image of a filter of the same kind and cardinality: another rank's bits)."""
+        p, nw = self.words()
+        assert words.numel() == nw and words.element_size() == 8
+        _check(_lib.qsx_bitmap_combine(1, C.c_void_p(p), _ptr(words), nw * 64, C.c_void_p(p), _stream(stream)),
+               "qsx_bitmap_combine")
 
 
 # --------------------------------------------------------------------------- partition

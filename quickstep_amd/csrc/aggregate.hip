@@ -1933,6 +1933,22 @@ int qsx_agg_state_export_bytes(qsx_agg_state_t *st, size_t *out_bytes, qsx_strea
   return QSX_OK;
 }
 
+int qsx_agg_state_image_layout(qsx_agg_state_t *st, int *out_dense, int64_t *out_header_words, int64_t *out_words_per_column,
+                               int *out_num_columns, int32_t *out_column_kinds, int kinds_capacity) {
+  if (st == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
+  if (out_dense != nullptr) *out_dense = st->dense ? 1 : 0;
+  // dense: [existence words][num_cols columns of num_entries words]; hash: [cap + 1 key words][num_cols columns of cap + 1]
+  if (out_header_words != nullptr) *out_header_words = st->dense ? st->exist_words : static_cast<int64_t>(st->cap + 1);
+  if (out_words_per_column != nullptr) *out_words_per_column = st->dense ? st->config.num_entries : static_cast<int64_t>(st->cap + 1);
+  if (out_num_columns != nullptr) *out_num_columns = st->num_cols;
+  if (out_column_kinds != nullptr) {
+    if (kinds_capacity < st->num_cols) return QSX_ERR_CAPACITY;
+    for (int c = 0; c < st->num_cols; ++c) out_column_kinds[c] = st->col_kinds.kind[c];
+  }
+  return QSX_OK;
+}
+
 int qsx_agg_state_export(qsx_agg_state_t *st, void *out_dev, size_t capacity_bytes, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (st == nullptr || out_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;

@@ -49,6 +49,7 @@ struct TableView {
   uint64_t mask;  // capacity - 1 (entries)
   int shift;      // 64 - log2(capacity)
   unsigned int *max_disp;  // largest displacement from the home slot any insert saw (radix probe margin)
+  unsigned int *dup_flag;  // set when an insert of an INT key met an occupant with the same key: the build side is not unique
 };
 
 __device__ __forceinline__ uint64_t slot_of(int32_t key, const TableView &t) {
@@ -73,6 +74,9 @@ __device__ __forceinline__ void insert_entry(const TableView &t, int32_t key, ui
     const unsigned long long old =
         atomicCAS(reinterpret_cast<unsigned long long *>(&slots[s]), kEmpty64, packed);
     if (old == kEmpty64) break;
+    // an occupant with this key: probes may no longer stop at their first match (join_sliced.hpp).  Every pair of equal
+    // keys is seen by the later of the two inserts, which walks over the earlier one's slot.
+    if (static_cast<uint32_t>(old) == static_cast<uint32_t>(key)) *t.dup_flag = 1u;
     s = (s + 1) & t.mask;
   }
   const unsigned int disp = static_cast<unsigned int>((s - home) & t.mask);
@@ -209,6 +213,10 @@ struct LongUnits {
     return h;
   }
 };
+
+}  // namespace qsx
+#include "join_sliced.hpp"
+namespace qsx {
 
 struct PairSink {
   int32_t *stage_probe;  // LDS
@@ -514,11 +522,13 @@ struct qsx_join_table {
     while ((1ull << log2) < capacity) ++log2;
     v.shift = 64 - log2;
     v.max_disp = max_disp_dev;
+    v.dup_flag = reinterpret_cast<unsigned int *>(entries_dev + 2);
     return v;
   }
 };
 
-// control words behind entries_dev: [0] entries, [1] max displacement, [2] overflow entries, [3] error flag (dense)
+// control words behind entries_dev: [0] entries, [1] max displacement, [2] overflow entries (dense) / duplicate-key flag
+// (hashed), [3] error flag (dense)
 constexpr int kControlWords = 4;
 
 static uint64_t capacity_for(int64_t entries) {
@@ -938,15 +948,40 @@ static bool dense_two_pass(const uint64_t *filter) {
   return filter != nullptr;
 }
 
-// The XCD-sliced dense probe (join_dense.hpp) pays 8 visits of every probe row for lookups that all hit L2.  Measured
-// (tools/probe_sliced.py, 100 M probes, plain -> sliced): counting 4 M keys 1.27 -> 0.82 ms, 8 M 1.57 -> 0.98, 16 M
-// 1.74 -> 1.44, 64 M 1.86 -> 1.94; emitting pairs 8 M keys 1.71 -> 1.81 ms — eight times the tile visits, each one memory
-// round trip, cost what the L2 hits save once pairs have to be staged.  So: count mode only, head arrays of 12..128 MiB.
-// QSX_JOIN_SLICED=1 / 0 forces it on (both modes) / off.
-static bool dense_sliced(uint64_t range, int64_t n, int mode) {
+// The XCD-sliced, compacting probe (join_sliced.hpp) for tables beyond one XCD's L2: how many slices, 0 = not this call.
+// A slice should stay <= ~3 MiB (the 4 MiB L2 also streams the keys and the pairs); more than 8 slices do not exist (8 XCDs),
+// so beyond 8 x 16 MiB the lookups miss anyway and the plain kernels are used.  QSX_JOIN_SLICED=0 switches it off, =1 forces
+// it for any table and input size (tests), QSX_JOIN_SLICES=2|4|8 fixes the slice count.
+static int sliced_probe_slices(uint64_t table_bytes, uint64_t sliceable_units, int64_t n, const void *keys) {
+  if ((reinterpret_cast<uintptr_t>(keys) & 15u) != 0) return 0;   // the scan reads 16-byte key vectors
   const char *e = getenv("QSX_JOIN_SLICED");
-  if (e != nullptr && e[0] != '\0') return e[0] != '0' && range >= 64;
-  return mode == 1 && range * 4 >= (12ull << 20) && range * 4 <= (128ull << 20) && n >= (4 << 20);
+  const bool forced = e != nullptr && e[0] == '1';
+  if (e != nullptr && e[0] == '0') return 0;
+  if (!forced && (table_bytes <= (7ull << 19) || table_bytes > (128ull << 20) || n < (1 << 20))) return 0;
+  int slices = 2;
+  while (slices < 8 && table_bytes / slices > (3ull << 20)) slices *= 2;
+  const char *fixed = getenv("QSX_JOIN_SLICES");
+  if (fixed != nullptr && (atoi(fixed) == 2 || atoi(fixed) == 4 || atoi(fixed) == 8)) slices = atoi(fixed);
+  while (slices > 1 && sliceable_units < static_cast<uint64_t>(slices)) slices /= 2;
+  return slices >= 2 ? slices : 0;
+}
+
+template <typename P, int MODE>
+static int launch_sliced(const P &policy, const typename P::Key *keys, int64_t n, int32_t probe_base_tid, const uint64_t *filter,
+                         int32_t *out_probe, int32_t *out_build, int64_t capacity, unsigned long long *count, int slices,
+                         hipStream_t stream) {
+  int per_cu = 0;
+  QSX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sliced_probe_kernel<P, MODE>, kSBlock, 0));
+  if (per_cu < 1) per_cu = 1;
+  const int64_t chunks = (n + P::kChunk - 1) / P::kChunk;
+  int64_t grid = static_cast<int64_t>(per_cu) * kCUs;
+  if (grid > chunks * slices) grid = chunks * slices;
+  grid = grid / slices * slices;
+  if (grid < slices) grid = slices;
+  hipLaunchKernelGGL((sliced_probe_kernel<P, MODE>), dim3(static_cast<unsigned>(grid)), dim3(kSBlock), 0, stream, policy, keys, n,
+                     probe_base_tid, filter, out_probe, out_build, capacity, count, slices);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
 }
 
 // kRuns: the probe side is a run of blocks — runs_dev is its table (block_runs.hpp, tiles of 4096 rows), run_tiles its tile
@@ -1000,21 +1035,19 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
       return QSX_OK;
     }
     if constexpr (!kRuns && (MODE == 0 || MODE == 1)) {
-      if (dense_sliced(t->dense_view().range, n, MODE) && dcount != nullptr) {
-        // head[] does not fit an XCD's L2: every XCD looks up one key range of it (join_dense.hpp)
-        const int64_t limit_s = (MODE == 0 ? 5 : 8) * kCUs;   // MODE 0 stages pairs in 32 KiB of LDS
-        const int64_t stiles = (n + kSlicedTile - 1) / kSlicedTile;
-        int sgrid = static_cast<int>(stiles * kSlices < limit_s ? stiles * kSlices : limit_s);
-        sgrid = sgrid / kSlices * kSlices;
+      const DenseTableView dv = t->dense_view();
+      const int slices = dcount != nullptr ? sliced_probe_slices(dv.range * sizeof(uint32_t), dv.range, n, keys) : 0;
+      if (slices != 0) {
         if (t->key_type == QSX_INT) {
-          hipLaunchKernelGGL((dense_probe_sliced_kernel<int32_t, MODE>), dim3(sgrid), dim3(kDBlock), 0, stream, t->dense_view(),
-                             static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity, dcount);
-        } else {
-          hipLaunchKernelGGL((dense_probe_sliced_kernel<int64_t, MODE>), dim3(sgrid), dim3(kDBlock), 0, stream, t->dense_view(),
-                             static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity, dcount);
+          DenseSlices<int32_t> policy;
+          policy.t = dv;
+          return launch_sliced<DenseSlices<int32_t>, MODE>(policy, static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,
+                                                           out_build, capacity, dcount, slices, stream);
         }
-        QSX_CHECK_LAUNCH();
-        return QSX_OK;
+        DenseSlices<int64_t> policy;
+        policy.t = dv;
+        return launch_sliced<DenseSlices<int64_t>, MODE>(policy, static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe,
+                                                         out_build, capacity, dcount, slices, stream);
       }
     }
     if (t->key_type == QSX_INT) {
@@ -1033,6 +1066,26 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
       n >= kRadixMinProbeRows) {
     return launch_probe_radix<MODE>(t, static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build,
                                     capacity, reinterpret_cast<unsigned long long *>(out_count), stream);
+  }
+  if constexpr (!kRuns && (MODE == 0 || MODE == 1)) {
+    const TableView hv = t->view();
+    const uint64_t units = t->key_type == QSX_INT ? t->capacity / 2 : t->capacity;
+    const int slices = out_count != nullptr ? sliced_probe_slices(t->capacity * t->entry_bytes(), units, n, keys) : 0;
+    if (slices != 0) {
+      unsigned long long *hcount = reinterpret_cast<unsigned long long *>(out_count);
+      if (t->key_type == QSX_INT) {
+        HashedSlices<IntUnits> policy;
+        policy.t = hv;
+        policy.dup_flag = hv.dup_flag;
+        return launch_sliced<HashedSlices<IntUnits>, MODE>(policy, static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,
+                                                           out_build, capacity, hcount, slices, stream);
+      }
+      HashedSlices<LongUnits> policy;
+      policy.t = hv;
+      policy.dup_flag = hv.dup_flag;
+      return launch_sliced<HashedSlices<LongUnits>, MODE>(policy, static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe,
+                                                          out_build, capacity, hcount, slices, stream);
+    }
   }
   const int64_t num_tiles = kRuns ? run_tiles : (n + kProbeTile - 1) / kProbeTile;
   // 4 workgroups per CU keep 128 KiB of the 160 KiB LDS busy in pair mode.

@@ -390,167 +390,6 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
   }
 }
 
-// ---- head[] larger than an XCD's L2: the XCD-sliced probe ---------------------------------------------------------------
-// With N million build keys head[] is 4 N MB.  Beyond the 4 MiB of one XCD's L2 a random 4-byte read turns into a
-// 128-byte line fetched over the fabric (100 M probes of an 8 M-key table: 1.7 ms against 0.6 ms for 1 M keys — the
-// broadcast join at 8 GPUs).  The table is cut into kSlices = 8 key ranges and workgroup b only looks up the keys of slice
-// b % 8: blocks are dealt to the XCDs round-robin (observed, relied upon for speed only — any placement gives the same
-// result), so every XCD's L2 holds one 1/8 of head[] and every lookup hits it.  The price: every slice's workgroups
-// stream ALL the probe keys (8 x 4 B per row instead of 4 B, the repeats served by the MALL/L2 side of the fabric, in
-// lines that are fully used) and run 8x the compares — cheap next to a line fetch per row.
-// A tile visit finds 1/8 of the tile's matches on average, so pairs are collected in LDS across tile visits and leave
-// with ONE reservation on the output counter per ~8 K pairs (one per visit would be 8x the atomics of the plain kernel,
-// which are what bounds it).  MODE 0: pairs, 1: count.
-constexpr int kSlices = 8;
-constexpr int kSlicedRows = 8;                          // rows per thread and tile visit
-constexpr int kSlicedTile = kDBlock * kSlicedRows;
-constexpr int kSlicedStage = 2 * kSlicedTile;           // one tile visit always fits an empty stage; 32 KiB: 5 workgroups per CU
-template <typename KeyT, int MODE>
-__global__ __launch_bounds__(kDBlock) void dense_probe_sliced_kernel(
-    DenseTableView t, const KeyT *__restrict__ keys, int64_t n, int32_t probe_base_tid, const uint64_t *__restrict__ filter,
-    int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build, int64_t capacity_signed,
-    unsigned long long *__restrict__ out_count) {
-  constexpr int R = kSlicedRows;
-  constexpr int kWaves = kDBlock / kWave;
-  const unsigned long long capacity = static_cast<unsigned long long>(capacity_signed);
-  const int64_t num_tiles = (n + kSlicedTile - 1) / kSlicedTile;
-  const int slice = static_cast<int>(blockIdx.x % kSlices);
-  const int64_t first = blockIdx.x / kSlices, step = gridDim.x / kSlices;
-  const uint64_t lo = t.range / kSlices * slice;
-  const uint64_t width = (slice == kSlices - 1 ? t.range : t.range / kSlices * (slice + 1)) - lo;
-  __shared__ int2 s_pairs[MODE == 0 ? kSlicedStage : 1];
-  __shared__ int s_wave_total[2][kWaves];
-  __shared__ unsigned long long s_base;
-  unsigned long long local_count = 0;
-  int fill = 0;      // pairs staged (the same number in every thread)
-  int parity = 0;
-  const int wave = threadIdx.x >> 6;
-  const int lane = lane_id();
-  const int64_t num_filter_words = (n + 63) >> 6;
-  KeyT key[R], next_key[R];
-  uint64_t filter_words = ~0ull, next_filter_words = ~0ull;
-  auto request = [&](int64_t tile, KeyT (&k)[R], uint64_t &words) {
-    const int64_t base = tile * kSlicedTile;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t row = base + r * kDBlock + threadIdx.x;
-      k[r] = keys[row < n ? row : n - 1];   // plain loads: the other slices' workgroups read the same lines
-    }
-    words = ~0ull;
-    if (filter != nullptr && lane < R) {
-      const int64_t w = (base >> 6) + lane * kWaves + wave;
-      if (w < num_filter_words) words = filter[w];
-    }
-  };
-  auto flush = [&]() {   // workgroup-uniform
-    if (threadIdx.x == 0) s_base = atomicAdd(out_count, static_cast<unsigned long long>(fill));
-    __syncthreads();
-    const unsigned long long base = s_base;
-    for (int i = threadIdx.x; i < fill; i += kDBlock) {
-      const int2 pair = s_pairs[i];
-      if (base + i < capacity) {
-        __builtin_nontemporal_store(pair.x, &out_probe[base + i]);
-        __builtin_nontemporal_store(pair.y, &out_build[base + i]);
-      }
-    }
-    __syncthreads();
-    fill = 0;
-  };
-  if (first < num_tiles) request(first, key, filter_words);
-  for (int64_t tile = first; tile < num_tiles; tile += step, parity ^= 1) {
-    const int64_t tile_base = tile * kSlicedTile;
-    if (tile + step < num_tiles) request(tile + step, next_key, next_filter_words);
-    uint32_t h[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t row = tile_base + r * kDBlock + threadIdx.x;
-      const uint64_t filter_word = __shfl(filter_words, r, kWave);
-      const bool live = row < n && msb_bit(filter_word, lane);
-      const uint64_t idx = dense_index(t, key[r]);                 // ~0: not a member
-      const bool lookup = live && idx - lo < width;                // (~0 - lo >= width: range < 2^63)
-      const uint32_t word = t.head[lookup ? idx : lo];             // unconditional, dead lanes share one word of the slice
-      h[r] = lookup ? word : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) key[r] = next_key[r];
-    filter_words = next_filter_words;
-
-    uint64_t m[R];
-    int total = 0;
-    bool any_chain = false;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      m[r] = __ballot(h[r] != 0u);
-      total += __popcll(m[r]);
-      any_chain = any_chain || (h[r] & kChainBit) != 0u;
-    }
-    const bool wave_has_chain = __any(any_chain);
-    uint32_t next[R];
-    if (MODE == 1) {
-      if (lane == 0) local_count += total;
-      if (wave_has_chain) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) next[r] = (h[r] & kChainBit) ? t.ov[h[r] & ~kChainBit].y : 0u;
-      }
-    } else {
-      if (lane == 0) s_wave_total[parity][wave] = total;
-      __syncthreads();   // also: the previous visit's pairs are in LDS
-      int all = 0, before = 0;
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w) {
-        const int c = s_wave_total[parity][w];
-        all += c;
-        before += w < wave ? c : 0;
-      }
-      if (fill + all > kSlicedStage) flush();
-      int at = fill + before;
-      fill += all;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t row = tile_base + r * kDBlock + threadIdx.x;
-        uint32_t tid = h[r] - 1u;
-        next[r] = 0u;
-        if (wave_has_chain && (h[r] & kChainBit)) {
-          const uint2 e = t.ov[h[r] & ~kChainBit];
-          tid = e.x;
-          next[r] = e.y;
-        }
-        if (h[r] != 0u) s_pairs[at + rank_below(m[r])] = make_int2(static_cast<int32_t>(probe_base_tid + row), static_cast<int32_t>(tid));
-        at += __popcll(m[r]);
-      }
-    }
-    if (wave_has_chain) {   // duplicate build keys (rare): the rest of every chain goes out directly
-#pragma unroll 1
-      for (int r = 0; r < R; ++r) {
-        const int64_t row = tile_base + r * kDBlock + threadIdx.x;
-        uint32_t cur = next[r];
-        while (__any(cur != 0u)) {
-          uint32_t tid = cur - 1u, nxt = 0u;
-          if (cur & kChainBit) {
-            const uint2 e = t.ov[cur & ~kChainBit];
-            tid = e.x;
-            nxt = e.y;
-          }
-          if (MODE == 1) {
-            local_count += cur != 0u ? 1u : 0u;
-          } else {
-            dense_emit_direct(cur != 0u, static_cast<int32_t>(probe_base_tid + row), static_cast<int32_t>(tid), out_probe, out_build,
-                              capacity, out_count);
-          }
-          cur = nxt;
-        }
-      }
-    }
-  }
-  if (MODE == 1) {
-    local_count = wave_reduce_add(local_count);
-    if (lane == 0 && local_count != 0) atomicAdd(out_count, local_count);
-  } else {
-    __syncthreads();
-    if (fill != 0) flush();
-  }
-}
-
 }  // namespace qsx
 
 #endif  // QSX_CSRC_JOIN_DENSE_HPP_

@@ -28,15 +28,79 @@ logic — split sizes, offsets, merge order — is exercised without a GPU.)
 import torch
 import torch.distributed as dist
 
+from . import types as T
+
 
 def _splits(offsets_host):
     return [int(offsets_host[i + 1] - offsets_host[i]) for i in range(len(offsets_host) - 1)]
 
 
+class _Transport:
+    """The collectives this file issues, by where the tensors live and what the process group can move.
+
+    Product: backend "nccl" (= RCCL over xGMI) on device tensors, handed through unchanged.  A process group that cannot
+    take device memory (gloo) gets *host staging*: device tensor -> host copy -> collective -> device copy.  That is how
+    the rank logic runs with the real kernels when ranks cannot have a GPU each (two rank processes sharing the one GPU
+    of a test box, where RCCL refuses the duplicate device); it moves the same bytes in the same order, only slower."""
+
+    @staticmethod
+    def _staged(tensor, group):
+        return tensor.is_cuda and dist.get_backend(group) != "nccl"
+
+    @classmethod
+    def all_to_all_single(cls, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        if not cls._staged(inp, group):
+            dist.all_to_all_single(out, inp, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+            return
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+        out.copy_(host)
+
+    @classmethod
+    def all_gather_into_tensor(cls, out, inp, group=None):
+        if not cls._staged(inp, group):
+            dist.all_gather_into_tensor(out, inp, group=group)
+            return
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu().contiguous(), group=group)
+        out.copy_(host)
+
+    @classmethod
+    def all_gather(cls, outs, inp, group=None):
+        if not cls._staged(inp, group):
+            dist.all_gather(outs, inp, group=group)
+            return
+        hosts = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(hosts, inp.cpu(), group=group)
+        for o, h in zip(outs, hosts):
+            o.copy_(h)
+
+    @classmethod
+    def reduce_scatter_tensor(cls, out, inp, op=dist.ReduceOp.SUM, group=None):
+        if not cls._staged(inp, group):
+            dist.reduce_scatter_tensor(out, inp, op=op, group=group)
+            return
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.reduce_scatter_tensor(host, inp.cpu(), op=op, group=group)
+        out.copy_(host)
+
+    @classmethod
+    def all_reduce(cls, tensor, op=dist.ReduceOp.SUM, group=None):
+        if not cls._staged(tensor, group):
+            dist.all_reduce(tensor, op=op, group=group)
+            return
+        host = tensor.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        tensor.copy_(host)
+
+
+xfer = _Transport
+
+
 def exchange_counts(send_counts, group=None):
     """send_counts: int64[P] on the compute device.  Returns int64[P] recv counts."""
     recv = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv, send_counts, group=group)
+    xfer.all_to_all_single(recv, send_counts, group=group)
     return recv
 
 
@@ -57,7 +121,7 @@ def shuffle_by_key(ops, keys, cols, group=None):
     received = []
     for col in scattered:
         out = torch.empty(total, dtype=col.dtype, device=col.device)
-        dist.all_to_all_single(out, col, output_split_sizes=recv_splits, input_split_sizes=send_splits, group=group)
+        xfer.all_to_all_single(out, col, output_split_sizes=recv_splits, input_split_sizes=send_splits, group=group)
         received.append(out)
     return received, recv_splits
 
@@ -109,23 +173,45 @@ class PartitionedHashJoin:
         else:
             self.table = ops.JoinTable(key_type, est_build_rows_per_rank, key_range=progression, key_stride=world)
 
-    def build(self, keys, tid_base):
+    def build(self, keys, tid_base, payload=()):
+        """payload: further columns of the build relation that travel with the rows (BASELINE config 4: one 8-byte
+        column per side); they end up in self.build_payload, in the order of the rows of this rank's partition."""
         tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
-        (rkeys, rtids), _ = shuffle_by_key(self.ops, keys, [keys, tids], self.group)
+        received, _ = shuffle_by_key(self.ops, keys, [keys, tids, *payload], self.group)
+        rkeys, rtids = received[0], received[1]
         self.build_tids = rtids                            # table stores positions into this column
+        self.build_keys = rkeys
+        self.build_payload = received[2:]
+        self.shuffled_bytes = sum(c.numel() * c.element_size() for c in received)
         self.table.clear()
         self.table.build(rkeys)
         return rkeys.numel()
 
-    def probe(self, keys, tid_base, capacity=None):
+    def probe(self, keys, tid_base, capacity=None, payload=()):
         tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
-        (rkeys, rtids), _ = shuffle_by_key(self.ops, keys, [keys, tids], self.group)
+        received, _ = shuffle_by_key(self.ops, keys, [keys, tids, *payload], self.group)
+        rkeys, rtids = received[0], received[1]
+        self.probe_keys = rkeys
+        self.probe_payload = received[2:]
+        self.shuffled_bytes += sum(c.numel() * c.element_size() for c in received)
         # how many rows arrive depends on the data: a foreign-key probe (every key matches at most one build row)
-        # needs room for all of them, never less
+        # needs room for all of them, never less; without a bound from the caller the pairs are counted first
+        # (duplicate build keys can yield more pairs than probe rows)
         if capacity is not None:
             capacity = max(int(capacity), rkeys.numel())
+        else:
+            capacity = max(int(self.table.probe_count(rkeys).item()), 1)
         out_p, out_b, count = self.table.probe(rkeys, capacity=capacity)
         return rtids, self.build_tids, out_p, out_b, count
+
+    def materialize_payload(self, out_p, out_b, count):
+        """The join's output relation on this rank: (join key, build payload columns..., probe payload columns...) of
+        every pair — K5 gathers on the columns that arrived with the shuffle (HashJoinOperator.cpp:526-541 builds the
+        same columns through ScalarAttribute::getAllValuesForJoin)."""
+        k = _checked_count(count, out_p)
+        p, b = out_p[:k], out_b[:k]
+        return ([self.ops.gather(self.probe_keys, p)] + [self.ops.gather(c, b) for c in self.build_payload]
+                + [self.ops.gather(c, p) for c in self.probe_payload])
 
     def materialize(self, probe_tids, build_tids, out_p, out_b, count):
         """Global (probe_tid, build_tid) pairs of this partition (K5 gathers)."""
@@ -151,7 +237,7 @@ class BroadcastHashJoin:
         # (row count, tid base) of every rank: one collective, one host synchronisation
         mine_meta = torch.tensor([keys.numel(), tid_base], dtype=torch.int64, device=keys.device)
         meta = torch.empty(2 * world, dtype=torch.int64, device=keys.device)
-        dist.all_gather_into_tensor(meta, mine_meta, group=self.group)
+        xfer.all_gather_into_tensor(meta, mine_meta, group=self.group)
         meta = meta.cpu().tolist()
         sizes, bases = meta[0::2], meta[1::2]
         self.table.clear()
@@ -160,14 +246,14 @@ class BroadcastHashJoin:
             # equal shares whose global tids follow one another (the block-round-robin layout): the gathered buffer IS
             # the build relation in tid order -> one gather into one tensor, one build
             everything = torch.empty(world * sizes[0], dtype=keys.dtype, device=keys.device)
-            dist.all_gather_into_tensor(everything, keys.contiguous(), group=self.group)
+            xfer.all_gather_into_tensor(everything, keys.contiguous(), group=self.group)
             self.table.build(everything, base_tid=bases[0])
             return sum(sizes)
         pad = max(sizes)
         mine = torch.zeros(pad, dtype=keys.dtype, device=keys.device)
         mine[:keys.numel()] = keys
         gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine, group=self.group)
+        xfer.all_gather(gathered, mine, group=self.group)
         for r in range(world):                              # the stored reference is the GLOBAL build tid
             if sizes[r]:
                 self.table.build(gathered[r][:sizes[r]], base_tid=bases[r])
@@ -194,13 +280,13 @@ def merge_agg_state_images(ops, state, group=None):
     # a table that outgrew its estimate has a bigger image than its peers': exchange the sizes, pad to the largest
     words = torch.tensor([image.numel()], dtype=torch.int64, device=image.device)
     all_words = torch.empty(world, dtype=torch.int64, device=image.device)
-    dist.all_gather_into_tensor(all_words, words, group=group)
+    xfer.all_gather_into_tensor(all_words, words, group=group)
     all_words = all_words.cpu().tolist()
     pad = max(all_words)
     if image.numel() < pad:
         image = torch.cat([image, image.new_zeros(pad - image.numel())])
     gathered = torch.empty(world * pad, dtype=image.dtype, device=image.device)
-    dist.all_gather_into_tensor(gathered, image, group=group)
+    xfer.all_gather_into_tensor(gathered, image, group=group)
     for r in range(world):
         if r != rank:
             state.import_merge(gathered[r * pad: r * pad + all_words[r]])
@@ -212,11 +298,11 @@ def _allreduce_or(words, group=None):
     ReduceOp.BOR raises on the "nccl" backend), so there the words are all-gathered and OR-ed locally; the existence map
     of a CollisionFreeVector is 1 bit per key, a sixty-fourth of one state column."""
     if dist.get_backend(group) != "nccl":
-        dist.all_reduce(words, op=dist.ReduceOp.BOR, group=group)
+        xfer.all_reduce(words, op=dist.ReduceOp.BOR, group=group)
         return words
     world = dist.get_world_size(group)
     gathered = torch.empty(world * words.numel(), dtype=words.dtype, device=words.device)
-    dist.all_gather_into_tensor(gathered, words.contiguous(), group=group)
+    xfer.all_gather_into_tensor(gathered, words.contiguous(), group=group)
     gathered = gathered.view(world, words.numel())
     acc = gathered[0].clone()
     for r in range(1, world):
@@ -261,7 +347,7 @@ def reduce_scatter_dense_agg_image(image, exist_words, num_entries, int_col_mask
         send = src.new_full((padded,), fill) if is_int else src.new_zeros(padded)
         send[:num_entries] = src
         mine = torch.empty(length, dtype=send.dtype, device=send.device)
-        dist.reduce_scatter_tensor(mine, send, op=op, group=group)
+        xfer.reduce_scatter_tensor(mine, send, op=op, group=group)
         dst = out[exist_words + col * num_entries + begin: exist_words + col * num_entries + end]
         if end > begin:
             dst.copy_((mine if is_int else mine.view(torch.int64))[: end - begin])
@@ -278,7 +364,7 @@ def reduce_scatter_dense_agg_image(image, exist_words, num_entries, int_col_mask
     send = torch.cat([image[word_range(r)[0]: word_range(r)[1]] for r in range(world)]) if sum(splits) else image[:0]
     my_words = splits[rank]
     recv = torch.empty(world * my_words, dtype=image.dtype, device=image.device)
-    dist.all_to_all_single(recv, send, output_split_sizes=[my_words] * world, input_split_sizes=splits, group=group)
+    xfer.all_to_all_single(recv, send, output_split_sizes=[my_words] * world, input_split_sizes=splits, group=group)
     if my_words:
         acc = recv[:my_words].clone()
         for r in range(1, world):
@@ -293,6 +379,29 @@ def reduce_scatter_dense_agg_image(image, exist_words, num_entries, int_col_mask
     return out
 
 
+def reduce_scatter_dense_state(state, device, group=None):
+    """Merge the dense (CollisionFreeVector) states of all ranks so that rank r holds — and can finalize — the groups of key
+    range r: export, reduce-scatter every column the way ITS accumulator combines (qsx_agg_state_image_layout: f64 +,
+    int64 +, MIN, MAX), OR the existence bits of the owned range, clear, import.  Returns the bytes a ring reduce-scatter
+    moves per rank.  The caller finalizes with partition = rank, num_partitions = world."""
+    dense, exist_words, entries, kinds = state.image_layout()
+    if not dense:
+        raise ValueError("reduce_scatter_dense_state needs a COLLISION_FREE state (hash states: merge_agg_state_images)")
+    world = dist.get_world_size(group)
+    int_mask, min_max = 0, {}
+    for c, kind in enumerate(kinds):
+        if kind != T.ACC_SUM_F64:
+            int_mask |= 1 << c
+        if kind in (T.ACC_MIN_I64, T.ACC_MAX_I64):
+            min_max[c] = "min" if kind == T.ACC_MIN_I64 else "max"
+    image = state.export(device)
+    reduced = reduce_scatter_dense_agg_image(image, exist_words, entries, int_mask, len(kinds), group=group, min_max_cols=min_max or None)
+    del image
+    state.clear()
+    state.import_merge(reduced)
+    return (len(kinds) * entries * 8 + exist_words * 8) * (world - 1) // world
+
+
 def allreduce_dense_agg_image(image, exist_words, num_entries, int_col_mask, num_cols, group=None, min_max_cols=None):
     """All-reduce a CollisionFreeVector state image in place: bit-OR for the
     existence words, integer SUM for count / integer columns, f64 SUM for the
@@ -303,9 +412,9 @@ def allreduce_dense_agg_image(image, exist_words, num_entries, int_col_mask, num
     for col in range(num_cols):
         seg = image[exist_words + col * num_entries: exist_words + (col + 1) * num_entries]
         if min_max_cols and col in min_max_cols:
-            dist.all_reduce(seg, op=dist.ReduceOp.MIN if min_max_cols[col] == "min" else dist.ReduceOp.MAX, group=group)
+            xfer.all_reduce(seg, op=dist.ReduceOp.MIN if min_max_cols[col] == "min" else dist.ReduceOp.MAX, group=group)
         elif (int_col_mask >> col) & 1:
-            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=group)
+            xfer.all_reduce(seg, op=dist.ReduceOp.SUM, group=group)
         else:
-            dist.all_reduce(seg.view(torch.float64), op=dist.ReduceOp.SUM, group=group)
+            xfer.all_reduce(seg.view(torch.float64), op=dist.ReduceOp.SUM, group=group)
     return image

@@ -11,46 +11,12 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from oracle import pyoracle as O  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle_ops import OracleOps  # noqa: E402
 from quickstep_amd import distributed as qd  # noqa: E402
+from quickstep_amd import plans  # noqa: E402
 from quickstep_amd import types as T  # noqa: E402
-
-
-class OracleJoinTable:
-    def __init__(self, key_type, est, key_range=None, key_stride=1):
-        self.key_type, self.est = key_type, est
-        self.key_range, self.key_stride = key_range, key_stride
-        self.t = O.JoinTable(key_type, est)
-
-    def clear(self):
-        self.t = O.JoinTable(self.key_type, self.est)
-
-    def build(self, keys, base_tid=0):
-        k = keys.numpy()
-        if self.key_range is not None and k.size:
-            # the dense flavour's precondition: every build key is a member of the rank's progression
-            assert k.min() >= self.key_range[0] and k.max() <= self.key_range[1]
-            assert ((k.astype(np.int64) - self.key_range[0]) % self.key_stride == 0).all()
-        self.t.build(k, base_tid=base_tid)
-
-    def probe(self, keys, capacity=None, probe_base_tid=0):
-        p, b = self.t.probe(keys.numpy(), probe_base_tid=probe_base_tid)
-        return torch.from_numpy(p), torch.from_numpy(b), torch.tensor([p.size], dtype=torch.int64)
-
-
-class OracleOps:
-    """Same surface as quickstep_amd.capi for what distributed.py calls."""
-    JoinTable = OracleJoinTable
-
-    @staticmethod
-    def partition_scatter(keys, num_partitions, cols):
-        k = keys.numpy()
-        offs = O.partition_offsets(k, num_partitions)
-        return [torch.from_numpy(O.partition_scatter(k, num_partitions, c.numpy())) for c in cols], torch.from_numpy(offs)
-
-    @staticmethod
-    def gather(src, tids):
-        return torch.from_numpy(O.gather(src.numpy(), tids.numpy().astype(np.int32)))
 
 
 class FakeAggState:
@@ -179,6 +145,28 @@ def main():
             assert torch.equal(a[begin:end], b[begin:end])
             outside = torch.cat([a[:begin], a[end:]])
             assert bool((outside == (np.iinfo(np.int64).max if col == 2 else 0)).all())
+    # BASELINE config 4: partitioned join with one 8-byte payload column per side (strided directly addressed tables)
+    cpu = torch.device("cpu")
+    orders_per_rank = 3000
+    c4 = plans.generate_c4_inputs(cpu, orders_per_rank, rank)
+    pj = plans.PartitionedJoin(OracleOps, orders_per_rank * world, orders_per_rank, dense=True)
+    cols, moved = pj.step(c4, rank * orders_per_rank, 0)
+    assert plans.PartitionedJoin.check(cols) and bool(((cols[0] & (world - 1)) == rank).all())
+    np.savez(os.path.join(out_dir, f"c4_rank{rank}.npz"), l_key=c4["l_orderkey"].numpy(), l_pay=c4["l_payload"].numpy(),
+             out_key=cols[0].numpy(), out_o=cols[1].numpy(), out_l=cols[2].numpy())
+
+    # BASELINE config 5: the distributed Q3 plan (LIP OR, broadcast builds, dense-state reduce-scatter, global top 10)
+    q3_in = plans.generate_q3_inputs(cpu, 0.004, rank, world)
+    saved = {"in_" + k: v.numpy() for k, v in q3_in.items() if torch.is_tensor(v)}
+    for fused in (True, False):
+        q3 = plans.DistributedQ3(OracleOps, q3_in["customers_total"], q3_in["orders_total"], use_lip=True, fused=fused)
+        res = q3.run(q3_in, tid_base_orders=rank * q3_in["o_orderkey"].numel())
+        keys_r, vals_r, _, groups_r = q3.state.finalize(cpu, partition=rank, num_partitions=world)
+        tag = "f" if fused else "g"
+        saved.update({f"{tag}_keys": keys_r[0].numpy(), f"{tag}_rev": vals_r[0].numpy(), f"{tag}_pairs": np.int64(res["pairs"]),
+                      f"{tag}_top_keys": res["top_keys"].numpy(), f"{tag}_top_rev": res["top_revenue"].numpy()})
+        assert q3.comm_bytes > 0
+    np.savez(os.path.join(out_dir, f"q3_rank{rank}.npz"), **saved)
     dist.barrier()
     dist.destroy_process_group()
 

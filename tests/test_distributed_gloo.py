@@ -31,6 +31,39 @@ def test_partitioned_join_and_merge_two_ranks(tmp_path, oracle):
     for prefix in ("rank", "dense_rank", "bcast_rank"):
         _check_partitioned_join(oracle, tmp_path, world, prefix, on_owner_rank=prefix != "bcast_rank")
     _check_uneven_broadcast(oracle, tmp_path, world)
+    _check_config4(tmp_path, world)
+    _check_config5(tmp_path, world)
+
+
+def _check_config4(tmp_path, world):
+    """(key, o_payload, l_payload) rows of the partitioned join: one per lineitem row, the payloads of the right rows."""
+    ranks = [np.load(tmp_path / f"c4_rank{i}.npz") for i in range(world)]
+    l_key = np.concatenate([d["l_key"] for d in ranks]).astype(np.int64)
+    l_pay = np.concatenate([d["l_pay"] for d in ranks])
+    out_key = np.concatenate([d["out_key"] for d in ranks]).astype(np.int64)
+    out_o = np.concatenate([d["out_o"] for d in ranks])
+    out_l = np.concatenate([d["out_l"] for d in ranks])
+    assert out_key.size == l_key.size and np.array_equal(out_o, out_key * 3 + 1)
+    a, b = np.stack([out_key, out_l], 1), np.stack([l_key, l_pay], 1)
+    assert np.array_equal(a[np.lexsort((a[:, 1], a[:, 0]))], b[np.lexsort((b[:, 1], b[:, 0]))])
+
+
+def _check_config5(tmp_path, world):
+    from helpers import q3_reference_numpy
+    ranks = [np.load(tmp_path / f"q3_rank{i}.npz") for i in range(world)]
+    inputs = [{k[3:]: d[k] for k in d.files if k.startswith("in_")} for d in ranks]
+    keys, sums, pairs = q3_reference_numpy(inputs)
+    assert keys.size > 50
+    top = np.argsort(-sums, kind="stable")[:10]
+    for tag in ("f", "g"):
+        assert sum(int(d[f"{tag}_pairs"]) for d in ranks) == pairs
+        got_keys = np.concatenate([d[f"{tag}_keys"] for d in ranks])
+        got_rev = np.concatenate([d[f"{tag}_rev"] for d in ranks])
+        order = np.argsort(got_keys)
+        assert np.array_equal(got_keys[order], keys) and np.allclose(got_rev[order], sums, rtol=1e-9, atol=0.0)
+        for d in ranks:
+            assert np.allclose(d[f"{tag}_top_rev"], sums[top], rtol=1e-9, atol=0.0)
+            assert np.array_equal(np.sort(d[f"{tag}_top_keys"]), np.sort(keys[top]))
 
 
 def _check_uneven_broadcast(oracle, tmp_path, world):

@@ -205,23 +205,30 @@ def test_dense_table_over_one_hash_partition(capi, oracle, dev, key_type, dtype)
         table.size()
 
 
+@pytest.mark.parametrize("slices", ["2", "8"])
+@pytest.mark.parametrize("flavour", FLAVOURS)
 @pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
-def test_xcd_sliced_dense_probe_matches_oracle(capi, oracle, dev, key_type, dtype, monkeypatch):
-    """The XCD-sliced probe of a directly addressed table (join_dense.hpp: workgroup b looks up key range b % 8, pairs
-    staged in LDS across tile visits) against the oracle: duplicates (chains), a probe filter, keys outside the range, a
-    strided table, a range that does not divide by 8, skewed keys (one slice gets nearly every match: the stage must flush
-    inside the loop), and a capacity smaller than the match count."""
+def test_xcd_sliced_probe_matches_oracle(capi, oracle, dev, key_type, dtype, flavour, slices, monkeypatch):
+    """The XCD-sliced, compacting probe (join_sliced.hpp: workgroup b serves table slice b % S, survivors of the key scan
+    meet in an LDS ring, full rounds of lookups) against the oracle, for both table kinds: duplicates (dense: chains; hashed:
+    walks that go back into the ring), a probe filter, keys outside the range, a strided table, a range that does not divide
+    by the slice count, row counts that are not a multiple of the scan chunk, skewed keys (one slice gets nearly every
+    match), and a capacity smaller than the match count."""
     monkeypatch.setenv("QSX_JOIN_SLICED", "1")
+    monkeypatch.setenv("QSX_JOIN_SLICES", slices)
     rng = np.random.default_rng(77)
     for stride, n_build, span, n_probe, hot in ((1, 90_000, 100_003, 700_001, 0.0), (4, 30_000, 200_001, 300_000, 0.0),
-                                                (1, 50_000, 64_000, 600_000, 0.9)):
+                                                (1, 50_000, 64_000, 600_000, 0.9), (1, 40_000, 1_000_000, 123_457, 0.0)):
         lo = 1_000 if dtype == np.int32 else 2**40
         domain = lo + np.arange(0, span * stride, stride)
-        build = rng.choice(domain, size=n_build, replace=True).astype(dtype)
+        build = rng.choice(domain, size=n_build, replace=span < 500_000).astype(dtype)   # last case: unique build keys
         probe = (lo + rng.integers(-20, span * stride + 20, size=n_probe)).astype(dtype)
         if hot:
             probe[rng.random(n_probe) < hot] = build[7]          # one key range takes nearly all matches
-        table = capi.JoinTable(key_type, n_build, key_range=(int(domain[0]), int(domain[-1])), key_stride=stride)
+        if flavour == "dense":
+            table = capi.JoinTable(key_type, n_build, key_range=(int(domain[0]), int(domain[-1])), key_stride=stride)
+        else:
+            table = capi.JoinTable(key_type, n_build)
         table.build(to_dev(build, dev))
         dp = to_dev(probe, dev)
         pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.7)
@@ -236,22 +243,49 @@ def test_xcd_sliced_dense_probe_matches_oracle(capi, oracle, dev, key_type, dtyp
             assert np.array_equal(sorted_pairs(p.cpu().numpy()[:total], b.cpu().numpy()[:total]), sorted_pairs(rp, rd))
         p, b, cnt = table.probe(dp, capacity=1000)               # more matches than room: full count, no write past the end
         assert int(cnt.item()) == int(table.probe_count(dp).item())
+        # a key stripe that does not start on a 16-byte boundary takes the plain kernels: same result
+        p, b, cnt = table.probe(dp[1:], capacity=total)
+        _, rp1, rd1 = oracle_join(oracle, key_type, [build], probe[1:])
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp1.size], b.cpu().numpy()[:rp1.size]), sorted_pairs(rp1, rd1))
         table.close()
 
 
-def test_xcd_sliced_probe_at_scale_properties(capi, dev, monkeypatch):
-    """8 M-key table (32 MiB of head words: the broadcast join's table at 8 GPUs) probed by 30 M keys through the sliced
-    kernels (by default only the count takes them at this size) and the plain ones: pairs are a permutation of the probe
-    tids and satisfy the join condition."""
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+def test_xcd_sliced_hashed_probe_walks_hundreds_of_duplicates(capi, oracle, dev, key_type, dtype, monkeypatch):
+    """One build key occurs 1500 times (a walk of 750+ units: beyond the 8-bit displacement a ring entry carries, finished
+    lane by lane), next to ordinary keys."""
+    monkeypatch.setenv("QSX_JOIN_SLICED", "1")
+    rng = np.random.default_rng(78)
+    build = rng.integers(0, 50_000, size=60_000).astype(dtype)
+    build[rng.choice(build.size, size=1500, replace=False)] = 424_242
+    probe = rng.integers(0, 60_000, size=200_003).astype(dtype)
+    probe[rng.choice(probe.size, size=40, replace=False)] = 424_242
+    table = capi.JoinTable(key_type, build.size)
+    table.build(to_dev(build, dev))
+    dp = to_dev(probe, dev)
+    _, rp, rd = oracle_join(oracle, key_type, [build], probe)
+    total = int(table.probe_count(dp).item())
+    assert total == rp.size
+    p, b, cnt = table.probe(dp, capacity=total)
+    assert int(cnt.item()) == total
+    assert np.array_equal(sorted_pairs(p.cpu().numpy()[:total], b.cpu().numpy()[:total]), sorted_pairs(rp, rd))
+
+
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_xcd_sliced_probe_at_scale_properties(capi, dev, monkeypatch, flavour):
+    """8 M-key table (32 MiB of head words — the broadcast join's table at 8 GPUs — or 128 MiB of hashed slots) probed by
+    30 M keys through the sliced kernels (their default at this size) and the plain ones: pairs are a permutation of the
+    probe tids and satisfy the join condition."""
     g = torch.Generator(device=dev)
     g.manual_seed(5)
     n_build, n_probe = 8_000_000, 30_000_000
     build = torch.randperm(n_build, device=dev, generator=g, dtype=torch.int32)
     probe = torch.randint(0, n_build, (n_probe,), device=dev, generator=g, dtype=torch.int32)
-    table = capi.JoinTable(T.INT, n_build, key_range=(0, n_build - 1))
+    table = capi.JoinTable(T.INT, n_build, key_range=(0, n_build - 1) if flavour == "dense" else None)
     table.build(build)
-    for sliced in ("1", "0"):
-        monkeypatch.setenv("QSX_JOIN_SLICED", sliced)
+    for sliced in (None, "0"):
+        if sliced is not None:
+            monkeypatch.setenv("QSX_JOIN_SLICED", sliced)
         p, b, cnt = table.probe(probe)
         assert int(cnt.item()) == n_probe == int(table.probe_count(probe).item())
         assert bool((build[b.long()] == probe[p.long()]).all())

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Dense probe of tables beyond one XCD's L2: plain kernel vs the XCD-sliced kernel (join_dense.hpp), 100 M probe keys,
-pairs and count-only.  usage: python tools/probe_sliced.py [probe_rows]"""
+"""Probe of join tables by table kind and size: plain kernels vs the XCD-sliced, compacting kernel (join_sliced.hpp),
+100 M probe keys, pairs and count-only, match rate 1.0 and 0.2.  One JSON line per (table kind, build rows).
+usage: python tools/probe_sliced.py [probe_rows] [build_rows ...]"""
 import json
 import os
 import sys
@@ -15,6 +16,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+sizes = [int(a) for a in sys.argv[2:]] or [1_000_000, 2_000_000, 4_000_000, 8_000_000, 16_000_000]
 
 
 def timed(fn, reps=5):
@@ -31,15 +33,29 @@ def timed(fn, reps=5):
 
 out = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev),
        torch.zeros(1, dtype=torch.int64, device=dev))
-for nb in (1_000_000, 2_000_000, 4_000_000, 8_000_000, 16_000_000, 64_000_000):
+for nb in sizes:
     b = torch.randperm(nb, device=dev, generator=g, dtype=torch.int32)
-    p = torch.randint(0, nb, (n,), device=dev, generator=g, dtype=torch.int32)
-    t = capi.JoinTable(T.INT, nb, key_range=(0, nb - 1))
-    t.build(b)
-    line = {"build_keys": nb, "head_MiB": nb * 4 / 2**20, "probe_rows": n}
-    for sliced in ("0", "1"):
-        os.environ["QSX_JOIN_SLICED"] = sliced
-        line["pairs_ms_sliced" if sliced == "1" else "pairs_ms_plain"] = round(timed(lambda: t.probe(p, capacity=n, out=out)), 3)
-        line["count_ms_sliced" if sliced == "1" else "count_ms_plain"] = round(timed(lambda: t.probe_count(p)), 3)
-    print(json.dumps(line), flush=True)
-    t.close()
+    # sparse keys for the hashed table: the same permutation spread over the INT range by an odd multiplier (unique, no
+    # statistics that would allow direct addressing)
+    spread = (b.long() * 2039 % (2**31 - 1)).to(torch.int32)
+    p10 = torch.randint(0, nb, (n,), device=dev, generator=g, dtype=torch.int32)
+    p02 = torch.randint(0, 5 * nb, (n,), device=dev, generator=g, dtype=torch.int32)
+    for kind in ("dense", "hashed", "hashed_sparse_keys"):
+        build = spread if kind == "hashed_sparse_keys" else b
+        t = capi.JoinTable(T.INT, nb, key_range=(0, nb - 1) if kind == "dense" else None)
+        t.build(build)
+        line = {"table": kind, "build_keys": nb, "table_MiB": nb * (4 if kind == "dense" else 16) / 2**20, "probe_rows": n}
+        for m, probe in (("m1.0", p10), ("m0.2", p02)):
+            if kind == "hashed_sparse_keys":
+                probe = (probe.long() * 2039 % (2**31 - 1)).to(torch.int32)
+            for sliced in ("0", "auto"):
+                if sliced == "auto":
+                    os.environ.pop("QSX_JOIN_SLICED", None)
+                else:
+                    os.environ["QSX_JOIN_SLICED"] = sliced
+                tag = "plain" if sliced == "0" else "auto"
+                line[f"pairs_ms_{m}_{tag}"] = round(timed(lambda: t.probe(probe, capacity=n, out=out)), 3)
+                line[f"matches_{m}"] = int(out[2].item())
+                line[f"count_ms_{m}_{tag}"] = round(timed(lambda: t.probe_count(probe)), 3)
+        print(json.dumps(line), flush=True)
+        t.close()
