@@ -486,9 +486,10 @@ def run_headline(ctx, args):
 
 
 def probe_variants(ctx, args, build_keys, probe_keys, out):
-    """The other §8(d) C2 legs, each timed with HIP events over 3 launches after one warm-up: the hashed table (a build side
-    without statistics), match rate 0.2 (Q3's c_mktsegment filter), and the materialised join (+ one 8-byte payload
-    gathered from each side, +16 B per match)."""
+    """The other §8(d) C2 legs, each timed with HIP events over 3 launches after one warm-up: hashed tables (a build side
+    without statistics: over the dense keys, with and without the directly addressed shadow, and over sparse keys), match
+    rate 0.2 (Q3's c_mktsegment filter), and the materialised join (+ one 8-byte payload gathered from each side, +16 B per
+    match).  Every leg's pairs are checked against the join condition and the expected count."""
     dev = ctx.dev
     n = args.probe_rows
     res = {}
@@ -506,16 +507,34 @@ def probe_variants(ctx, args, build_keys, probe_keys, out):
     g = torch.Generator(device=dev)
     g.manual_seed(33)
     keys_02 = torch.randint(0, args.build_rows * 5, (n,), device=dev, generator=g, dtype=torch.int32)
-    for name, dense in (("dense", True), ("hashed", False)):
+    spread = lambda k: (k.long() * 2039 % (2**31 - 1)).to(torch.int32)   # noqa: E731  (a bijection: unique, sparse keys)
+    legs = (("dense", True, "1", False),              # exact statistics from the optimizer
+            ("hashed", False, "1", False),            # no statistics: the first probe gives the table a directly addressed shadow
+            ("hashed_no_shadow", False, "0", False),  # QSX_JOIN_ADAPTIVE=0: the hashed kernels themselves on the same keys
+            ("hashed_sparse_keys", False, "1", True))  # keys spread over the INT range: no shadow possible
+    for name, dense, adaptive, sparse in legs:
+        os.environ["QSX_JOIN_ADAPTIVE"] = adaptive
+        bk = spread(build_keys) if sparse else build_keys
         t = capi.JoinTable(T.INT, args.build_rows, key_range=(0, args.build_rows - 1) if dense else None)
-        t.build(build_keys)
+        t.build(bk)
         for m, keys in ((1.0, probe_keys), (0.2, keys_02)):
+            if sparse:
+                keys = spread(keys)
             ms = timed(lambda: t.probe(keys, capacity=n, out=out))
             matches = int(out[2].item())
-            check_pairs(keys, build_keys, out[0], out[1], matches, args.build_rows)
+            k = int(out[2].item())
+            assert bool((bk[out[1][:k].long()] == keys[out[0][:k].long()]).all()), "a pair violates the join condition"
+            assert matches == int((keys_02 < args.build_rows).sum().item()) if m == 0.2 else matches == n
             byts = 4 * n + 8 * matches
             res[f"{name}_m{m}"] = {"ms": ms, "matches": matches, "rows_per_s": n / ms * 1e3, "GBps": byts / ms / 1e6,
                                    "frac_of_hbm_peak": byts / ms / 1e6 / HBM_PEAK_GBS}
+        if not dense:
+            # clear + build + first probe: what the shadow costs a query that builds the table once
+            def cycle():
+                t.clear()
+                t.build(bk)
+                t.probe(probe_keys if not sparse else spread(probe_keys), capacity=n, out=out)
+            res[f"{name}_clear_build_probe_ms"] = timed(cycle)
         if dense:
             # materialised: one 8-byte payload column from each side, gathered by the pair list (K5)
             pay_b = build_keys.long() * 3 + 1
@@ -536,6 +555,7 @@ def probe_variants(ctx, args, build_keys, probe_keys, out):
                                               "frac_of_hbm_peak": byts / ms / 1e6 / HBM_PEAK_GBS}
             del pay_b, pay_p, ob, op
         t.close()
+    os.environ.pop("QSX_JOIN_ADAPTIVE", None)
     return res
 
 
@@ -661,6 +681,29 @@ def run_c5(ctx, args):
     }
 
 
+def operators_leg(args, raw_value):
+    """The same workload through the operator boundary: BuildHash / HashJoin / Aggregation / FinalizeAggregation operators
+    of quickstep_amd/host under ForemanSingleNode + Workers on reference-sized 4 MB blocks, work orders over runs of 64
+    blocks (tests/cpp/headline_operators_bench.cpp, a child process with its own copy of the relations).  Reported next to
+    the raw-ABI value, never instead of it."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "headline_operators_bench")
+    if not os.path.exists(exe):
+        return {"error": "tests/cpp/bin/headline_operators_bench is not built (make -C quickstep_amd/host)"}
+    cmd = [exe, str(args.build_rows), str(args.probe_rows), str(args.agg_rows), str(args.steps), str(args.warmup),
+           str(args.operator_workers), str(args.blocks_per_work_order)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"exit code {r.returncode}", "stderr": r.stderr[-1500:]}
+    out = json.loads(lines[-1])
+    out["fraction_of_raw_abi_value"] = out["rows_per_s"] / raw_value
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -686,6 +729,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU time budget per operator for the cpu_baseline trials")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the result checks after the timed region")
+    ap.add_argument("--no-operators", action="store_true", help="N = 1: skip the leg that runs the workload through the C++ operator layer")
+    ap.add_argument("--operator-workers", type=int, default=4)
+    ap.add_argument("--blocks-per-work-order", type=int, default=64)
     args = ap.parse_args()
 
     ctx = Ctx()
@@ -706,6 +752,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     line = {"headline": run_headline, "c4": run_c4, "c5": run_c5}[args.config](ctx, args)
+    if rank == 0 and world == 1 and args.config == "headline" and not args.no_operators:
+        line["operators"] = operators_leg(args, line["value"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "headline":
         line["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -96,6 +96,12 @@ int qsx_stream_synchronize(qsx_stream_t stream);
  * time per worker; concurrent workers = concurrent streams). */
 int qsx_stream_create(qsx_stream_t *out_stream);
 int qsx_stream_destroy(qsx_stream_t stream);
+/* The library keeps, per (calling host thread, stream), a scratch arena, a pinned + device staging pair for host tables and
+ * a few device slots, so that no allocator runs on the hot path.  They are given back when the thread exits, when the
+ * stream goes through qsx_stream_destroy (the calling thread's entries for it) and here: everything the CALLING thread
+ * holds, after waiting for its streams — the call an engine makes on its out-of-memory path before retrying an allocation
+ * (the library does the same before it gives up on an allocation of its own).  out_bytes_released may be NULL. */
+int qsx_trim_scratch(size_t *out_bytes_released);
 
 /* ======================================================================
  * Select: predicate + projection
@@ -296,7 +302,8 @@ int qsx_bitmap_to_tids(const uint64_t *bitmap_dev, int64_t n, int32_t base_tid,
 int qsx_tids_to_bitmap(const int32_t *tids_dev, int64_t n, int32_t base_tid, int64_t num_bits,
                        uint64_t *out_bitmap_dev, qsx_stream_t stream);
 
-/* K5.  dst[i] = src[tids[i]] for i < n (value width 1/2/4/8 bytes); tids < 0
+/* K5.  dst[i] = src[tids[i]] for i < n (value width 1/2/4/8 bytes: one element per thread; any other width up to
+ * 4096 — CHAR(n) — byte by byte); tids < 0
  * write zero bytes (outer-join NULL padding; the null bit is the caller's).
  * Replaces ScalarAttribute::getAllValuesForJoin (expressions/scalar/
  * ScalarAttribute.cpp:185-225) as used by HashInnerJoinWorkOrder

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "qsx_stream_synchronize": (_int, [_vp]),
     "qsx_stream_create": (_int, [_pp]),
     "qsx_stream_destroy": (_int, [_vp]),
+    "qsx_trim_scratch": (_int, [C.POINTER(_sz)]),
     "qsx_select_cmp": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "qsx_select_cmp_sorted": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "qsx_select_cmp_char": (_int, [_vp, _int, _i64, _int, C.c_char_p, _int, _vp, _vp, _vp, _vp]),
@@ -146,6 +147,13 @@ EXPORTED = tuple(_SIGNATURES)
 def _check(status, where):
     if status != T.OK:
         raise QsxError(status, where)
+
+
+def trim_scratch():
+    """Release what the calling thread keeps inside libqsx.so between calls (qsx_trim_scratch); returns the bytes."""
+    v = C.c_size_t()
+    _check(_lib.qsx_trim_scratch(C.byref(v)), "qsx_trim_scratch")
+    return v.value
 
 
 def device_count():

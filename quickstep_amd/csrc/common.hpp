@@ -72,32 +72,57 @@ __global__ void store_struct_kernel(T value, T *__restrict__ dst) {
   uint32_t *out = reinterpret_cast<uint32_t *>(dst);
   for (unsigned i = threadIdx.x; i < sizeof(T) / 4; i += blockDim.x) out[i] = src[i];
 }
-// One device slot per (host thread, stream) for such a struct: work on one stream is ordered, so the store of the next
-// call cannot overtake the kernel still reading the slot, and no allocator is involved on the update path.
-template <typename T>
-static T *device_slot(hipStream_t stream) {
-  thread_local std::map<hipStream_t, T *> slots;
-  auto it = slots.find(stream);
-  if (it != slots.end()) return it->second;
-  T *p = nullptr;
-  if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(T)) != hipSuccess) return nullptr;
-  slots.emplace(stream, p);
-  return p;
-}
-
-// Host tables of a call -> device memory, stream-ordered, without handing pageable memory to hipMemcpyAsync: one pinned
-// staging buffer and one device buffer per (host thread, stream), grown on demand.  The pinned buffer is rewritten only
-// after the event recorded behind its last copy has completed; the device buffer is rewritten by a copy that the stream
-// orders behind the kernels of the previous call that read it.
+// ---- per-(host thread, stream) device resources --------------------------------------------------------------------------
+// Calls issued by one thread on one stream are ordered on the device, so such a pair can own buffers that every call
+// reuses without an allocator on the hot path: a grow-only scratch arena, a pinned + device staging pair for host tables,
+// small device slots for by-value structs.  ONE registry for the whole library (runtime.hip) holds them — per thread, so no
+// lock on the hot path — and gives them back:
+//   * when the thread exits (the registry's destructor),
+//   * when the stream is destroyed through qsx_stream_destroy (the calling thread's entries for it),
+//   * on qsx_trim_scratch() (everything the calling thread holds; the host layer calls it on its out-of-memory path),
+//   * before a failed allocation inside the library is retried once.
+struct ScratchArena {
+  void *base = nullptr;
+  size_t capacity = 0;
+};
 struct StagedBuffer {
   void *pinned = nullptr;
   void *device = nullptr;
   size_t capacity = 0;
   hipEvent_t copied = nullptr;
 };
+ScratchArena &thread_scratch_arena(hipStream_t stream);
+StagedBuffer &thread_staged_buffer(hipStream_t stream);
+void *&thread_device_slot(hipStream_t stream, const void *type_tag);
+void release_thread_stream(hipStream_t stream);     // this thread's entries for `stream` (the stream is idle or being destroyed)
+size_t trim_thread_resources();                      // everything this thread holds; returns the device bytes released
+
+// One device slot per (host thread, stream) for a by-value struct: work on one stream is ordered, so the store of the next
+// call cannot overtake the kernel still reading the slot, and no allocator is involved on the update path.
+template <typename T>
+static T *device_slot(hipStream_t stream) {
+  static const char tag = 0;
+  void *&p = thread_device_slot(stream, &tag);
+  if (p != nullptr) return static_cast<T *>(p);
+  if (hipMalloc(&p, sizeof(T)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)trim_thread_resources();
+    void *&q = thread_device_slot(stream, &tag);   // (the trim dropped the entry)
+    if (hipMalloc(&q, sizeof(T)) != hipSuccess) {
+      q = nullptr;
+      return nullptr;
+    }
+    return static_cast<T *>(q);
+  }
+  return static_cast<T *>(p);
+}
+
+// Host tables of a call -> device memory, stream-ordered, without handing pageable memory to hipMemcpyAsync: one pinned
+// staging buffer and one device buffer per (host thread, stream), grown on demand.  The pinned buffer is rewritten only
+// after the event recorded behind its last copy has completed; the device buffer is rewritten by a copy that the stream
+// orders behind the kernels of the previous call that read it.
 static StagedBuffer *staged_buffer_for(hipStream_t stream, size_t bytes) {
-  thread_local std::map<hipStream_t, StagedBuffer> buffers;
-  StagedBuffer &b = buffers[stream];
+  StagedBuffer &b = thread_staged_buffer(stream);
   if (b.capacity >= bytes) return &b;
   if (b.copied != nullptr) (void)hipEventSynchronize(b.copied);
   if (b.device != nullptr) {
@@ -112,6 +137,7 @@ static StagedBuffer *staged_buffer_for(hipStream_t stream, size_t bytes) {
   if (b.copied == nullptr && hipEventCreateWithFlags(&b.copied, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipHostMalloc(&b.pinned, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
   if (hipMalloc(&b.device, cap) != hipSuccess) {
+    (void)hipGetLastError();
     (void)hipHostFree(b.pinned);
     b.pinned = nullptr;
     return nullptr;
@@ -141,13 +167,11 @@ static int staged_upload(hipStream_t stream, const void *host_src, size_t bytes)
 // any allocation size, release threshold raised or not; never without the interleaved hipFree, never with plain
 // allocations) — and a library cannot keep its callers, or torch's allocator, from calling hipFree.
 // Instead every (host thread, stream) owns one grow-only arena: calls issued by one thread on one stream are ordered on
-// the device, so the next call may reuse the arena while the previous call's kernels are still queued.  Requests beyond
-// kScratchKeepBytes are one-off plain allocations, released when the call's work has finished.
-constexpr size_t kScratchKeepBytes = size_t(4) << 30;
-struct ScratchArena {
-  void *base = nullptr;
-  size_t capacity = 0;
-};
+// the device, so the next call may reuse the arena while the previous call's kernels are still queued.  An arena is a
+// power of two up to 256 MiB and the request rounded to 64 MiB beyond (a 2.1 GB request keeps 2.1 GB, not 4 GiB); requests
+// beyond kScratchKeepBytes are one-off plain allocations, released when the call's work has finished.
+constexpr size_t kScratchKeepBytes = size_t(1) << 30;
+constexpr size_t kScratchPow2Bytes = size_t(256) << 20;
 class CallScratch {
  public:
   explicit CallScratch(hipStream_t stream) : stream_(stream) {}
@@ -166,27 +190,37 @@ class CallScratch {
     total = padded(total ? total : 1);
     used_ = 0;
     if (total > kScratchKeepBytes) {
-      QSX_HIP_TRY(hipMalloc(&one_off_, total));
+      if (hipMalloc(&one_off_, total) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)trim_thread_resources();   // what this thread keeps for later calls goes first
+        QSX_HIP_TRY(hipMalloc(&one_off_, total));
+      }
       base_ = static_cast<char *>(one_off_);
       capacity_ = total;
       return QSX_OK;
     }
-    thread_local std::map<hipStream_t, ScratchArena> arenas;
-    ScratchArena &a = arenas[stream_];
-    if (a.capacity < total) {
-      if (a.base != nullptr) {
+    ScratchArena *a = &thread_scratch_arena(stream_);
+    if (a->capacity < total) {
+      if (a->base != nullptr) {
         QSX_HIP_TRY(hipStreamSynchronize(stream_));   // kernels of earlier calls may still use the old arena
-        QSX_HIP_TRY(hipFree(a.base));
-        a.base = nullptr;
-        a.capacity = 0;
+        QSX_HIP_TRY(hipFree(a->base));
+        a->base = nullptr;
+        a->capacity = 0;
       }
       size_t cap = 1 << 20;
-      while (cap < total) cap *= 2;
-      QSX_HIP_TRY(hipMalloc(&a.base, cap));
-      a.capacity = cap;
+      while (cap < total && cap < kScratchPow2Bytes) cap *= 2;
+      if (cap < total) cap = (total + (size_t(64) << 20) - 1) / (size_t(64) << 20) * (size_t(64) << 20);
+      if (hipMalloc(&a->base, cap) != hipSuccess) {
+        (void)hipGetLastError();
+        a->base = nullptr;
+        (void)trim_thread_resources();
+        a = &thread_scratch_arena(stream_);
+        QSX_HIP_TRY(hipMalloc(&a->base, cap));
+      }
+      a->capacity = cap;
     }
-    base_ = static_cast<char *>(a.base);
-    capacity_ = a.capacity;
+    base_ = static_cast<char *>(a->base);
+    capacity_ = a->capacity;
     return QSX_OK;
   }
   // The next piece of the reservation (256-byte aligned), nullptr when the reservation is exhausted.

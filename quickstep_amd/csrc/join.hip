@@ -24,9 +24,9 @@
 
 #include "common.hpp"
 #include "join_dense.hpp"
-#include "join_radix.hpp"
 #include "scan.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <vector>
 #include <mutex>
@@ -48,12 +48,14 @@ struct TableView {
   void *slots;    // uint64_t[capacity] (INT) or LongEntry[capacity] (LONG)
   uint64_t mask;  // capacity - 1 (entries)
   int shift;      // 64 - log2(capacity)
-  unsigned int *max_disp;  // largest displacement from the home slot any insert saw (radix probe margin)
   unsigned int *dup_flag;  // set when an insert of an INT key met an occupant with the same key: the build side is not unique
 };
 
+// INT keys: 32-bit multiplicative (Fibonacci) hashing — one v_mul_lo_u32 and a shift; the sliced probe evaluates it for
+// every (key, slice) pair.  capacity <= 2^32 slots for 32-bit keys (at most 2^31 entries, two slots per entry).
 __device__ __forceinline__ uint64_t slot_of(int32_t key, const TableView &t) {
-  return (static_cast<uint64_t>(static_cast<uint32_t>(key)) * 0x9E3779B97F4A7C15ull) >> t.shift;
+  const uint32_t h = static_cast<uint32_t>(key) * 0x9E3779B9u;
+  return t.shift > 32 ? (h >> (t.shift - 32)) : h;
 }
 __device__ __forceinline__ uint64_t slot_of(int64_t key, const TableView &t) {
   return (mix64(static_cast<uint64_t>(key)) * 0x9E3779B97F4A7C15ull) >> t.shift;
@@ -79,8 +81,6 @@ __device__ __forceinline__ void insert_entry(const TableView &t, int32_t key, ui
     if (static_cast<uint32_t>(old) == static_cast<uint32_t>(key)) *t.dup_flag = 1u;
     s = (s + 1) & t.mask;
   }
-  const unsigned int disp = static_cast<unsigned int>((s - home) & t.mask);
-  if (disp > __hip_atomic_load(t.max_disp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(t.max_disp, disp);
 }
 
 __device__ __forceinline__ void insert_entry(const TableView &t, int64_t key, uint32_t tid) {
@@ -101,26 +101,55 @@ __device__ __forceinline__ void insert_entry(const TableView &t, int64_t key, ui
 // ---------------------------------------------------------------------------
 // K3 build
 // ---------------------------------------------------------------------------
+// Bounds of the inserted keys, kept next to the entry count: [4] = min (key + 2^63 as unsigned), [5] = ~(max + 2^63) — both
+// shrink under atomicMin and both start from all ones (one memset).  The first probe reads them: a build side whose keys
+// span a small range gets a directly addressed shadow (seal_table).
+struct KeyBounds {
+  unsigned long long lo = ~0ull, hi_inv = ~0ull;
+  __device__ __forceinline__ void add(int64_t key) {
+    const unsigned long long u = static_cast<unsigned long long>(key) ^ 0x8000000000000000ull;
+    lo = u < lo ? u : lo;
+    hi_inv = ~u < hi_inv ? ~u : hi_inv;
+  }
+  __device__ __forceinline__ void publish(unsigned long long *control) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long a = __shfl_xor(lo, o, kWave), b = __shfl_xor(hi_inv, o, kWave);
+      lo = a < lo ? a : lo;
+      hi_inv = b < hi_inv ? b : hi_inv;
+    }
+    if (lane_id() == 0 && lo != ~0ull) {
+      atomicMin(control + 4, lo);
+      atomicMin(control + 5, hi_inv);
+    }
+  }
+};
+
 template <typename KeyT>
 __global__ __launch_bounds__(kJBlock) void build_kernel(TableView t, const KeyT *__restrict__ keys,
                                                        int64_t n, int32_t base_tid,
                                                        const uint64_t *__restrict__ filter,
                                                        unsigned long long *__restrict__ entries) {
   unsigned long long inserted = 0;
+  KeyBounds bounds;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * kJBlock) {
     if (!row_in_filter(filter, i)) continue;
-    insert_entry(t, keys[i], static_cast<uint32_t>(base_tid + i));
+    const KeyT key = keys[i];
+    insert_entry(t, key, static_cast<uint32_t>(base_tid + i));
+    bounds.add(key);
     ++inserted;
   }
   inserted = wave_reduce_add(inserted);
   if (lane_id() == 0 && inserted != 0) atomicAdd(entries, inserted);
+  bounds.publish(entries);
 }
 // The build side as a run of blocks (qsx_join_build_blocks): a wave takes groups of kBuildTile rows of ONE block.
 template <typename KeyT>
 __global__ __launch_bounds__(kJBlock) void build_runs_kernel(TableView t, const long long *__restrict__ runs,
                                                             unsigned long long *__restrict__ entries) {
   unsigned long long inserted = 0;
+  KeyBounds bounds;
   const int lane = lane_id();
   const int num_groups = static_cast<int>(runs[2]);
   for (int group = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (kJBlock / kWave) + (threadIdx.x >> 6)));
@@ -134,12 +163,15 @@ __global__ __launch_bounds__(kJBlock) void build_runs_kernel(TableView t, const 
     for (int r = 0; r < kBuildR; ++r) {
       const int64_t i = static_cast<int64_t>(at.tile_in_block) * kBuildTile + r * kWave + lane;
       if (i >= n || !row_in_filter(filter, i)) continue;
-      insert_entry(t, keys[i], base_tid + static_cast<uint32_t>(i));
+      const KeyT key = keys[i];
+      insert_entry(t, key, base_tid + static_cast<uint32_t>(i));
+      bounds.add(key);
       ++inserted;
     }
   }
   inserted = wave_reduce_add(inserted);
   if (lane == 0 && inserted != 0) atomicAdd(entries, inserted);
+  bounds.publish(entries);
 }
 
 // Re-insert every entry of an old table into a bigger one (resize).
@@ -155,6 +187,42 @@ __global__ __launch_bounds__(kJBlock) void rehash_kernel(int is_long, TableView 
       if (e != kEmpty64) {
         insert_entry(dst, static_cast<int32_t>(static_cast<uint32_t>(e)), static_cast<uint32_t>(e >> 32));
       }
+    }
+  }
+}
+
+// Every entry of a hashed table into a directly addressed one (seal_table): what dense_build_kernel does per build row.
+__global__ __launch_bounds__(kJBlock) void dense_build_from_slots_kernel(int is_long, TableView src, DenseTableView d) {
+  const int64_t cap = static_cast<int64_t>(src.mask) + 1;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < cap;
+       i += static_cast<int64_t>(gridDim.x) * kJBlock) {
+    int64_t key;
+    uint32_t tid;
+    if (is_long) {
+      const LongEntry e = static_cast<const LongEntry *>(src.slots)[i];
+      if (e.tid == kEmptyTid) continue;
+      key = e.key;
+      tid = e.tid;
+    } else {
+      const uint64_t e = static_cast<const uint64_t *>(src.slots)[i];
+      if (e == kEmpty64) continue;
+      key = static_cast<int32_t>(static_cast<uint32_t>(e));
+      tid = static_cast<uint32_t>(e >> 32);
+    }
+    const uint64_t idx = dense_index(d, key);
+    if (idx == ~0ull) {
+      atomicExch(d.error, 1);
+      continue;
+    }
+    const uint32_t old = atomicCAS(&d.head[idx], 0u, tid + 1u);
+    if (old != 0u) {
+      const unsigned int e = atomicAdd(d.ov_count, 1u);
+      if (e >= d.ov_capacity) {
+        atomicExch(d.error, 2);
+        continue;
+      }
+      d.ov[e].x = tid;
+      d.ov[e].y = atomicExch(&d.head[idx], kChainBit | e);
     }
   }
 }
@@ -277,6 +345,8 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
   __shared__ int s_fill;
   __shared__ unsigned long long s_base;
   const Units table(t);
+  // no build key occurs twice (the build compared keys on every failed claim): a probe ends at its first match
+  const bool unique = sizeof(Key) == 4 && *t.dup_flag == 0u;
   PairSink sink{s_probe, s_build, &s_fill, out_probe, out_build,
                 static_cast<unsigned long long>(capacity), out_count};
   const int64_t num_tiles = kRuns ? runs[2] : (n + kProbeTile - 1) / kProbeTile;
@@ -363,7 +433,7 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
           found = found || m0 || m1;
           if (found) walking = false;  // existence: the first hit is enough
         }
-        if (h.end) walking = false;
+        if (h.end || (unique && (m0 || m1))) walking = false;
         if (walking) {
           cur = (cur + 1) & table.unit_mask;
           u = table.load(cur);
@@ -490,7 +560,13 @@ struct qsx_join_table {
   // HashTable::resize_shared_mutex_ (storage/HashTable.hpp:1215).
   std::shared_mutex mutex;
 
-  unsigned int *max_disp_dev = nullptr;  // see TableView::max_disp (second word of the entries_dev allocation)
+
+  // Hashed flavour: a directly addressed shadow of the entries, made by the first probe after the builds when the keys
+  // turned out to span a small range (seal_table).  0 = not looked at since the last build / clear, 1 = stays hashed,
+  // 2 = `shadow` answers the probes.
+  std::mutex seal_mutex;
+  std::atomic<int> seal_state{0};
+  qsx_join_table *shadow = nullptr;
 
   // Directly addressed flavour (join_dense.hpp): head[] + overflow chain entries; `slots` unused.
   bool dense = false;
@@ -521,15 +597,19 @@ struct qsx_join_table {
     int log2 = 0;
     while ((1ull << log2) < capacity) ++log2;
     v.shift = 64 - log2;
-    v.max_disp = max_disp_dev;
     v.dup_flag = reinterpret_cast<unsigned int *>(entries_dev + 2);
     return v;
   }
 };
 
-// control words behind entries_dev: [0] entries, [1] max displacement, [2] overflow entries (dense) / duplicate-key flag
-// (hashed), [3] error flag (dense)
-constexpr int kControlWords = 4;
+// control words behind entries_dev: [0] entries, [1] unused, [2] overflow entries (dense) / duplicate-key flag
+// (hashed), [3] error flag (dense), [4] [5] bounds of the inserted keys (KeyBounds; all ones = none)
+constexpr int kControlWords = 6;
+static int reset_control_words(unsigned long long *control, hipStream_t stream) {
+  QSX_HIP_TRY(hipMemsetAsync(control, 0, 4 * sizeof(unsigned long long), stream));
+  QSX_HIP_TRY(hipMemsetAsync(control + 4, 0xFF, 2 * sizeof(unsigned long long), stream));
+  return QSX_OK;
+}
 
 static uint64_t capacity_for(int64_t entries) {
   // kHashTableLoadFactor = 2 slots per entry (storage/StorageConstants.hpp:104),
@@ -594,7 +674,6 @@ static int ensure_room(qsx_join_table *t, int64_t additional) {
   t->slots = bigger;
   t->capacity = new_capacity;
   TableView dst = t->view();
-  QSX_HIP_TRY(hipMemset(t->max_disp_dev, 0, sizeof(unsigned int)));
   hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(src.mask + 1, kJBlock)), dim3(kJBlock), 0, nullptr,
                      t->key_type == QSX_LONG ? 1 : 0, src, dst);
   QSX_CHECK_LAUNCH();
@@ -616,8 +695,8 @@ int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **
   int rc = allocate_slots(t, t->capacity, &t->slots);
   if (rc != QSX_OK) { delete t; return rc; }
   hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, kControlWords * sizeof(unsigned long long));
-  t->max_disp_dev = reinterpret_cast<unsigned int *>(t->entries_dev + 1);
+  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, 4 * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(t->entries_dev + 4, 0xFF, 2 * sizeof(unsigned long long));
   if (err != hipSuccess) {
     set_last_error("hipMalloc(entries)", err);
     (void)hipFree(t->slots);
@@ -651,7 +730,8 @@ int qsx_join_table_create_dense(int key_type, int64_t min_key, int64_t max_key, 
   if (err == hipSuccess) err = hipMemset(t->head, 0, range * sizeof(uint32_t));
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&t->ov), static_cast<size_t>(t->ov_capacity) * sizeof(uint2));
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, kControlWords * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, 4 * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(t->entries_dev + 4, 0xFF, 2 * sizeof(unsigned long long));
   if (err != hipSuccess) {
     set_last_error("hipMalloc(dense join table)", err);
     (void)hipFree(t->head);
@@ -660,7 +740,6 @@ int qsx_join_table_create_dense(int key_type, int64_t min_key, int64_t max_key, 
     delete t;
     return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
   }
-  t->max_disp_dev = reinterpret_cast<unsigned int *>(t->entries_dev + 1);
   *out = t;
   return QSX_OK;
 }
@@ -745,6 +824,7 @@ int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks
 int qsx_join_table_destroy(qsx_join_table_t *t) {
   if (t == nullptr) return QSX_OK;
   (void)hipDeviceSynchronize();
+  if (t->shadow != nullptr) (void)qsx_join_table_destroy(t->shadow);
   (void)hipFree(t->slots);
   (void)hipFree(t->head);
   (void)hipFree(t->ov);
@@ -762,15 +842,17 @@ int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
   } else {
     QSX_HIP_TRY(hipMemsetAsync(t->slots, 0xFF, t->capacity * t->entry_bytes(), as_stream(stream)));
   }
-  QSX_HIP_TRY(hipMemsetAsync(t->entries_dev, 0, kControlWords * sizeof(unsigned long long), as_stream(stream)));
+  const int rc_control = reset_control_words(t->entries_dev, as_stream(stream));
+  if (rc_control != QSX_OK) return rc_control;
   t->reserved = 0;
+  t->seal_state.store(0);
   return QSX_OK;
 }
 
 int qsx_join_table_size(qsx_join_table_t *t, int64_t *out_entries, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (t == nullptr || out_entries == nullptr) return QSX_ERR_INVALID_ARGUMENT;
-  unsigned long long v[kControlWords] = {0, 0, 0, 0};
+  unsigned long long v[kControlWords] = {0, 0, 0, 0, 0, 0};
   QSX_HIP_TRY(hipMemcpyAsync(v, t->entries_dev, sizeof(v), hipMemcpyDeviceToHost, as_stream(stream)));
   QSX_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
   *out_entries = static_cast<int64_t>(v[0]);
@@ -788,6 +870,7 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   if (static_cast<int64_t>(base_tid) + n > INT32_MAX) return QSX_ERR_INVALID_ARGUMENT;
   int rc = ensure_room(t, n);
   if (rc != QSX_OK) return rc;
+  t->seal_state.store(0);
   std::shared_lock<std::shared_mutex> lock(t->mutex);
   const int grid = grid_for(n, kJBlock * 4);
   if (t->dense) {
@@ -832,6 +915,7 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
   if (total == 0) return QSX_OK;
   int rc = ensure_room(t, total);
   if (rc != QSX_OK) return rc;
+  t->seal_state.store(0);
   hipStream_t s = as_stream(stream);
   std::vector<long long> table;
   const long long groups = build_run_table(kBuildTile, num_blocks, block_rows, block_keys,
@@ -866,80 +950,6 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
 
 }  // extern "C"
 
-// ---- radix-partitioned probe (join_radix.hpp) ---------------------------------------------------
-constexpr int64_t kRadixMinBuildRows = 131072;   // below this the table (<= 2 MiB) lives in every XCD's L2
-constexpr int64_t kRadixMinProbeRows = 1 << 20;
-
-// Opt-in (QSX_JOIN_RADIX=1): measured on MI355X for the C2 shape (1 M x 100 M) the partitioned path
-// is not yet faster than probing the 16 MiB table directly (2.4 ms vs 1.9 ms, profiles/README.md);
-// it stays selectable for parity tests and as the base of further tuning.
-static bool radix_enabled() {
-  static const bool on = []() {
-    const char *e = getenv("QSX_JOIN_RADIX");
-    return e != nullptr && atoi(e) != 0;
-  }();
-  return on;
-}
-
-template <int MODE>
-static int launch_probe_radix(qsx_join_table *t, const int32_t *keys, int64_t n, int32_t probe_base_tid,
-                              const uint64_t *filter, int32_t *out_probe, int32_t *out_build, int64_t capacity,
-                              unsigned long long *count, hipStream_t stream) {
-  const TableView v = t->view();
-  int log_cap = 64 - v.shift;
-  int log_p = 4;
-  while (log_p < 10 && (t->reserved >> log_p) > 2048) ++log_p;   // <= ~2 K entries per partition, P <= 1024
-  if (log_p > log_cap - 8) log_p = log_cap - 8;                  // at least 256 slots per partition
-  RadixGeom geom;
-  geom.table_shift = v.shift;
-  geom.part_shift = log_cap - log_p;
-  geom.log_p = log_p;
-  const int P = 1 << log_p;
-  // G workgroups, each owning one contiguous chunk of probe rows
-  int64_t G = (n + 4 * kRadixTile - 1) / (4 * kRadixTile);
-  if (G > 1024) G = 1024;
-  if (G < 1) G = 1;
-  int64_t rows_per_block = (n + G - 1) / G;
-  rows_per_block = (rows_per_block + kRadixTile - 1) / kRadixTile * kRadixTile;
-  G = (n + rows_per_block - 1) / rows_per_block;
-  const int64_t cells = static_cast<int64_t>(P) * G;
-  // scratch of this call (per host thread and stream: concurrent probes, one per Worker stream, never share it)
-  CallScratch scratch(stream);
-  const size_t bytes_pk = static_cast<size_t>(n) * 4 + 16, bytes_hist = static_cast<size_t>(cells) * 4 + 64,
-               bytes_starts = static_cast<size_t>(cells + 1) * 8, bytes_scan = scan_workspace_words(cells) * 8;
-  int rc_scratch = scratch.reserve(2 * CallScratch::padded(bytes_pk) + CallScratch::padded(bytes_hist) + CallScratch::padded(bytes_starts) +
-                                   CallScratch::padded(bytes_scan));
-  if (rc_scratch != QSX_OK) return rc_scratch;
-  int32_t *pk = static_cast<int32_t *>(scratch.take(bytes_pk)), *pt = static_cast<int32_t *>(scratch.take(bytes_pk)),
-          *hist_t = static_cast<int32_t *>(scratch.take(bytes_hist));
-  int64_t *starts = static_cast<int64_t *>(scratch.take(bytes_starts)), *scan_ws = static_cast<int64_t *>(scratch.take(bytes_scan));
-  hipLaunchKernelGGL(radix_probe_hist, dim3(static_cast<unsigned>(G)), dim3(kRBlock), P * sizeof(int32_t), stream, keys, n,
-                     filter, geom, rows_per_block, hist_t);
-  QSX_CHECK_LAUNCH();
-  QSX_HIP_TRY(launch_scan(hist_t, cells, starts, nullptr, scan_ws, stream));
-  const size_t scatter_lds = sizeof(int32_t) * (2 * kRadixTile + 2 * P + (P & 1)) + sizeof(int64_t) * P;
-  hipLaunchKernelGGL(radix_probe_scatter, dim3(static_cast<unsigned>(G)), dim3(kRBlock), scatter_lds, stream, keys, n, filter,
-                     probe_base_tid, geom, rows_per_block, starts, pk, pt);
-  QSX_CHECK_LAUNCH();
-  RadixJoinArgs a;
-  a.table_slots = static_cast<const unsigned long long *>(v.slots);
-  a.table_mask = v.mask;
-  a.max_disp = v.max_disp;
-  a.geom = geom;
-  a.probe_keys = pk;
-  a.probe_tids = pt;
-  a.probe_starts = starts;
-  a.probe_blocks = G;
-  int slices = static_cast<int>((static_cast<int64_t>(kCUs) * 6 + P - 1) / P);   // ~6 workgroups per CU in total
-  const int64_t per_partition = n / P + 1;
-  while (slices > 1 && per_partition / slices < 4 * kRadixJoinTile) --slices;
-  a.slices = slices;
-  hipLaunchKernelGGL((radix_join<MODE>), dim3(static_cast<unsigned>(P * slices)), dim3(kRBlock), 0, stream, a, out_probe,
-                     out_build, capacity, count);
-  QSX_CHECK_LAUNCH();
-  return QSX_OK;
-}
-
 // The two-pass dense probe pays a second read of the keys and wins when the lookups are cheap and the tiles many: with
 // a filter (LIP / predicate bitmap: few live rows) by default; QSX_JOIN_TWO_PASS=1 / 0 forces it on / off.
 static bool dense_two_pass(const uint64_t *filter) {
@@ -950,14 +960,16 @@ static bool dense_two_pass(const uint64_t *filter) {
 
 // The XCD-sliced, compacting probe (join_sliced.hpp) for tables beyond one XCD's L2: how many slices, 0 = not this call.
 // A slice should stay <= ~3 MiB (the 4 MiB L2 also streams the keys and the pairs); more than 8 slices do not exist (8 XCDs),
-// so beyond 8 x 16 MiB the lookups miss anyway and the plain kernels are used.  QSX_JOIN_SLICED=0 switches it off, =1 forces
-// it for any table and input size (tests), QSX_JOIN_SLICES=2|4|8 fixes the slice count.
+// so beyond 8 x 16 MiB the lookups miss anyway.  OPT-IN (QSX_JOIN_SLICED=1; QSX_JOIN_SLICES=2|4|8 fixes the slice count):
+// every XCD has to pull all probe keys through its own fabric port, and that — about 1.1 ms per 100 M keys at eight slices,
+// whatever the scan costs in instructions — is what the L2 hits save on a 16 MiB hashed table (1.52 ms plain, 1.64 ms
+// sliced) and far more than they save on a selective probe.
 static int sliced_probe_slices(uint64_t table_bytes, uint64_t sliceable_units, int64_t n, const void *keys) {
   if ((reinterpret_cast<uintptr_t>(keys) & 15u) != 0) return 0;   // the scan reads 16-byte key vectors
   const char *e = getenv("QSX_JOIN_SLICED");
   const bool forced = e != nullptr && e[0] == '1';
   if (e != nullptr && e[0] == '0') return 0;
-  if (!forced && (table_bytes <= (7ull << 19) || table_bytes > (128ull << 20) || n < (1 << 20))) return 0;
+  if (!forced) return 0;   // measured (profiles/r03_probe_sliced.jsonl): streaming the keys S times costs what the L2 hits save
   int slices = 2;
   while (slices < 8 && table_bytes / slices > (3ull << 20)) slices *= 2;
   const char *fixed = getenv("QSX_JOIN_SLICES");
@@ -973,15 +985,79 @@ static int launch_sliced(const P &policy, const typename P::Key *keys, int64_t n
   int per_cu = 0;
   QSX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sliced_probe_kernel<P, MODE>, kSBlock, 0));
   if (per_cu < 1) per_cu = 1;
-  const int64_t chunks = (n + P::kChunk - 1) / P::kChunk;
+  const int64_t chunks = (n + kSChunk - 1) / kSChunk;
+  int row_bits = 1;
+  while (row_bits < 32 && (1ll << row_bits) < n) ++row_bits;   // rows of this call fit row_bits bits
   int64_t grid = static_cast<int64_t>(per_cu) * kCUs;
   if (grid > chunks * slices) grid = chunks * slices;
   grid = grid / slices * slices;
   if (grid < slices) grid = slices;
   hipLaunchKernelGGL((sliced_probe_kernel<P, MODE>), dim3(static_cast<unsigned>(grid)), dim3(kSBlock), 0, stream, policy, keys, n,
-                     probe_base_tid, filter, out_probe, out_build, capacity, count, slices);
+                     probe_base_tid, filter, out_probe, out_build, capacity, count, slices, row_bits);
   QSX_CHECK_LAUNCH();
   return QSX_OK;
+}
+
+// ---- hashed table -> directly addressed shadow ------------------------------------------------------------------------------
+// The reference's hash of an INT / LONG key is the key itself (types/TypedValue.hpp:575-592) modulo a prime slot count, so
+// over a dense key domain — every TPC-H key — its table is directly addressed in all but name.  This table hashes
+// multiplicatively (sparse domains must not cluster) and pays for it with a 16 MiB table per million keys that no L2 holds.
+// So the first probe after the builds looks at the bounds of the inserted keys (KeyBounds, kept by the build kernels): when
+// they span at most 8 slots per entry the entries are copied into a directly addressed table (join_dense.hpp: one 4-byte word
+// per key value, duplicates chained) and probes go there — no statistics from the optimizer needed.  A build or clear makes
+// the next probe look again.  QSX_JOIN_ADAPTIVE=0 switches it off (the hashed kernels' own tests and measurements).
+constexpr int64_t kAdaptiveMinRows = 1 << 16;
+static bool adaptive_enabled() {
+  const char *e = getenv("QSX_JOIN_ADAPTIVE");
+  return e == nullptr || e[0] != '0';
+}
+
+static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream) {
+  int state = t->seal_state.load(std::memory_order_acquire);
+  if (state == 2) return t->shadow;
+  if (state == 1 || t->reserved < kAdaptiveMinRows || !adaptive_enabled()) return nullptr;
+  std::lock_guard<std::mutex> lock(t->seal_mutex);
+  state = t->seal_state.load(std::memory_order_acquire);
+  if (state != 0) return state == 2 ? t->shadow : nullptr;
+  // probes start after every build work order has finished (pipeline breaker); builds issued on other streams included
+  if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+  unsigned long long v[kControlWords];
+  if (hipMemcpy(v, t->entries_dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+  const uint64_t entries = v[0];
+  const int64_t lo = static_cast<int64_t>(v[4] ^ 0x8000000000000000ull), hi = static_cast<int64_t>(~v[5] ^ 0x8000000000000000ull);
+  const uint64_t span = static_cast<uint64_t>(hi) - static_cast<uint64_t>(lo);
+  if (v[4] == ~0ull || entries < static_cast<uint64_t>(kAdaptiveMinRows) || span >= 8 * entries || span >= (1ull << 32) ||
+      entries > 0x7FFFFFFFull) {
+    t->seal_state.store(1, std::memory_order_release);
+    return nullptr;
+  }
+  qsx_join_table *shadow = t->shadow;
+  if (shadow != nullptr && (shadow->min_key != lo || shadow->range != span + 1 || shadow->ov_capacity < entries)) {
+    (void)qsx_join_table_destroy(shadow);
+    shadow = t->shadow = nullptr;
+  }
+  if (shadow == nullptr) {
+    if (qsx_join_table_create_dense(t->key_type, lo, hi, 1, static_cast<int64_t>(entries), &shadow) != QSX_OK) {
+      (void)hipGetLastError();
+      t->seal_state.store(1, std::memory_order_release);   // no room for the shadow: the hashed table answers
+      return nullptr;
+    }
+    t->shadow = shadow;
+  } else if (qsx_join_table_clear(shadow, reinterpret_cast<qsx_stream_t>(stream)) != QSX_OK) {
+    return nullptr;
+  }
+  shadow->reserved = static_cast<int64_t>(entries);
+  const TableView src = t->view();
+  hipLaunchKernelGGL(dense_build_from_slots_kernel, dim3(grid_for(static_cast<int64_t>(src.mask) + 1, kJBlock * 4)), dim3(kJBlock), 0, stream,
+                     t->key_type == QSX_LONG ? 1 : 0, src, shadow->dense_view());
+  int error = 0;
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess ||
+      hipMemcpy(&error, shadow->entries_dev + 3, sizeof(error), hipMemcpyDeviceToHost) != hipSuccess || error != 0) {
+    t->seal_state.store(1, std::memory_order_release);
+    return nullptr;
+  }
+  t->seal_state.store(2, std::memory_order_release);   // other threads' probes (their own streams) may use it from here on
+  return shadow;
 }
 
 // kRuns: the probe side is a run of blocks — runs_dev is its table (block_runs.hpp, tiles of 4096 rows), run_tiles its tile
@@ -993,6 +1069,13 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
                         int64_t capacity, int64_t *out_count, uint64_t *out_bitmap, int anti,
                         hipStream_t stream, const long long *runs_dev = nullptr, int64_t run_tiles = 0) {
   static_assert(kDenseTile == kProbeTile, "one run table serves both table kinds");
+  if (!t->dense && n != 0) {
+    qsx_join_table *shadow = sealed_shadow(t, stream);
+    if (shadow != nullptr) {
+      return launch_probe<MODE, kRuns>(shadow, keys, n, probe_base_tid, filter, out_probe, out_build, capacity, out_count, out_bitmap,
+                                       anti, stream, runs_dev, run_tiles);
+    }
+  }
   if (out_count != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), stream));
   if (n == 0) return QSX_OK;
   std::shared_lock<std::shared_mutex> lock(t->mutex);
@@ -1036,7 +1119,8 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
     }
     if constexpr (!kRuns && (MODE == 0 || MODE == 1)) {
       const DenseTableView dv = t->dense_view();
-      const int slices = dcount != nullptr ? sliced_probe_slices(dv.range * sizeof(uint32_t), dv.range, n, keys) : 0;
+      const bool min_fits = t->key_type != QSX_INT || (dv.min_key >= INT32_MIN && dv.min_key <= INT32_MAX);
+      const int slices = dcount != nullptr && min_fits ? sliced_probe_slices(dv.range * sizeof(uint32_t), dv.range, n, keys) : 0;
       if (slices != 0) {
         if (t->key_type == QSX_INT) {
           DenseSlices<int32_t> policy;
@@ -1061,11 +1145,6 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
     }
     QSX_CHECK_LAUNCH();
     return QSX_OK;
-  }
-  if (!kRuns && MODE != 2 && t->key_type == QSX_INT && radix_enabled() && t->reserved >= kRadixMinBuildRows &&
-      n >= kRadixMinProbeRows) {
-    return launch_probe_radix<MODE>(t, static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build,
-                                    capacity, reinterpret_cast<unsigned long long *>(out_count), stream);
   }
   if constexpr (!kRuns && (MODE == 0 || MODE == 1)) {
     const TableView hv = t->view();

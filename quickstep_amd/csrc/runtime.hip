@@ -3,7 +3,9 @@
 #include <cstdlib>
 #include "common.hpp"
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 namespace qsx {
 
@@ -36,6 +38,77 @@ static int usable_devices() {
   std::call_once(once, []() { usable = probe_devices(); });
   return usable;
 }
+
+// ---- the per-(host thread, stream) resources of common.hpp -----------------------------------------------------------------
+namespace {
+struct ThreadResources {
+  std::map<hipStream_t, ScratchArena> arenas;
+  std::map<hipStream_t, StagedBuffer> staged;
+  std::map<std::pair<hipStream_t, const void *>, void *> slots;
+
+  static size_t drop(ScratchArena &a) {
+    const size_t bytes = a.capacity;
+    if (a.base != nullptr) (void)hipFree(a.base);
+    a = ScratchArena();
+    return bytes;
+  }
+  static size_t drop(StagedBuffer &b) {
+    const size_t bytes = b.capacity;
+    if (b.copied != nullptr) {
+      (void)hipEventSynchronize(b.copied);
+      (void)hipEventDestroy(b.copied);
+    }
+    if (b.device != nullptr) (void)hipFree(b.device);
+    if (b.pinned != nullptr) (void)hipHostFree(b.pinned);
+    b = StagedBuffer();
+    return bytes;
+  }
+  // Entries of `stream` (all streams when match_all).  The stream's queued work still uses them: wait for it first.
+  size_t release(hipStream_t stream, bool match_all) {
+    size_t bytes = 0;
+    for (auto it = arenas.begin(); it != arenas.end();) {
+      if (match_all || it->first == stream) {
+        (void)hipStreamSynchronize(it->first);
+        bytes += drop(it->second);
+        it = arenas.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    for (auto it = staged.begin(); it != staged.end();) {
+      if (match_all || it->first == stream) {
+        (void)hipStreamSynchronize(it->first);
+        bytes += drop(it->second);
+        it = staged.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    for (auto it = slots.begin(); it != slots.end();) {
+      if (match_all || it->first.first == stream) {
+        (void)hipStreamSynchronize(it->first.first);
+        if (it->second != nullptr) (void)hipFree(it->second);
+        it = slots.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    (void)hipGetLastError();   // (a stream destroyed behind the library's back: its synchronize fails, the buffers still go)
+    return bytes;
+  }
+  ~ThreadResources() { (void)release(nullptr, true); }   // thread exit
+};
+ThreadResources &thread_resources() {
+  thread_local ThreadResources r;
+  return r;
+}
+}  // namespace
+
+ScratchArena &thread_scratch_arena(hipStream_t stream) { return thread_resources().arenas[stream]; }
+StagedBuffer &thread_staged_buffer(hipStream_t stream) { return thread_resources().staged[stream]; }
+void *&thread_device_slot(hipStream_t stream, const void *type_tag) { return thread_resources().slots[std::make_pair(stream, type_tag)]; }
+void release_thread_stream(hipStream_t stream) { (void)thread_resources().release(stream, false); }
+size_t trim_thread_resources() { return thread_resources().release(nullptr, true); }
 
 int device_ready() {
   if (usable_devices() > 0) return QSX_OK;
@@ -127,7 +200,15 @@ int qsx_stream_create(qsx_stream_t *out_stream) {
 int qsx_stream_destroy(qsx_stream_t stream) {
   if (stream == nullptr) return QSX_OK;
   QSX_REQUIRE_DEVICE();
+  qsx::release_thread_stream(qsx::as_stream(stream));   // the scratch arena, staging buffers and slots this thread kept for it
   QSX_HIP_TRY(hipStreamDestroy(qsx::as_stream(stream)));
+  return QSX_OK;
+}
+
+int qsx_trim_scratch(size_t *out_bytes_released) {
+  QSX_REQUIRE_DEVICE();
+  const size_t bytes = qsx::trim_thread_resources();
+  if (out_bytes_released != nullptr) *out_bytes_released = bytes;
   return QSX_OK;
 }
 

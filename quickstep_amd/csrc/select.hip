@@ -584,6 +584,19 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ sr
   }
 }
 
+// Attributes of any other width (CHAR(n)): one thread per output byte — consecutive threads write consecutive bytes and
+// read the bytes of one source row.
+__global__ __launch_bounds__(kBlock) void gather_bytes_kernel(const uint8_t *__restrict__ src, int width, const int32_t *__restrict__ tids,
+                                                              int64_t n, uint8_t *__restrict__ dst) {
+  const int64_t total = n * width;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; j < total; j += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t row = j / width;
+    const int off = static_cast<int>(j - row * width);
+    const int32_t t = tids[row];
+    dst[j] = t < 0 ? uint8_t(0) : src[static_cast<int64_t>(t) * width + off];
+  }
+}
+
 constexpr int kMaxSegments = 64;
 struct SegmentTable {
   int num;
@@ -607,6 +620,26 @@ __global__ __launch_bounds__(kBlock) void gather_segmented_kernel(SegmentTable s
       if (seg.first_row[mid] <= t) lo = mid; else hi = mid - 1;
     }
     dst[i] = static_cast<const T *>(seg.ptr[lo])[t - seg.first_row[lo]];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_segmented_bytes_kernel(SegmentTable seg, int width, const int32_t *__restrict__ tids,
+                                                                        int64_t n, uint8_t *__restrict__ dst) {
+  const int64_t total = n * width;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; j < total; j += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t row = j / width;
+    const int off = static_cast<int>(j - row * width);
+    const int32_t t = tids[row];
+    if (t < 0) {
+      dst[j] = 0;
+      continue;
+    }
+    int lo = 0, hi = seg.num - 1;  // last segment whose first_row <= t
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (seg.first_row[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    dst[j] = static_cast<const uint8_t *>(seg.ptr[lo])[(t - seg.first_row[lo]) * width + off];
   }
 }
 
@@ -638,6 +671,26 @@ __global__ __launch_bounds__(kBlock) void gather_segmented_table_kernel(const in
     }
     const int seg = segment_of(s_first, num, t);
     dst[i] = reinterpret_cast<const T *>(ptrs[seg])[t - s_first[seg]];
+  }
+}
+__global__ __launch_bounds__(kBlock) void gather_segmented_table_bytes_kernel(const int32_t *__restrict__ first_rows,
+                                                                              const long long *__restrict__ ptrs, int num, int width,
+                                                                              const int32_t *__restrict__ tids, int64_t n,
+                                                                              uint8_t *__restrict__ dst) {
+  extern __shared__ int32_t s_first[];
+  for (int i = threadIdx.x; i < num; i += kBlock) s_first[i] = first_rows[i];
+  __syncthreads();
+  const int64_t total = n * width;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; j < total; j += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t row = j / width;
+    const int off = static_cast<int>(j - row * width);
+    const int32_t t = tids[row];
+    if (t < 0) {
+      dst[j] = 0;
+      continue;
+    }
+    const int seg = segment_of(s_first, num, t);
+    dst[j] = reinterpret_cast<const uint8_t *>(ptrs[seg])[static_cast<int64_t>(t - s_first[seg]) * width + off];
   }
 }
 __global__ __launch_bounds__(kBlock) void bitmap_gather_segmented_table_kernel(const int32_t *__restrict__ first_rows,
@@ -1828,7 +1881,11 @@ int qsx_gather(int width, const void *src_dev, const int32_t *tids_dev, int64_t 
     case 2: hipLaunchKernelGGL(gather_kernel<uint16_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint16_t *>(src_dev), tids_dev, n, static_cast<uint16_t *>(dst_dev)); break;
     case 4: hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint32_t *>(src_dev), tids_dev, n, static_cast<uint32_t *>(dst_dev)); break;
     case 8: hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint64_t *>(src_dev), tids_dev, n, static_cast<uint64_t *>(dst_dev)); break;
-    default: return QSX_ERR_UNSUPPORTED;
+    default:
+      if (width < 1 || width > 4096) return QSX_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL(gather_bytes_kernel, dim3(grid_for(n * width, kBlock * 8)), dim3(kBlock), 0, s, static_cast<const uint8_t *>(src_dev), width,
+                         tids_dev, n, static_cast<uint8_t *>(dst_dev));
+      break;
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;
@@ -1875,7 +1932,11 @@ int qsx_gather_segmented(int width, int num_segments, const void *const *segment
       case 2: hipLaunchKernelGGL(gather_segmented_table_kernel<uint16_t>, dim3(grid), dim3(kBlock), lds, s, first_dev, ptrs_dev, num_segments, tids_dev, n, static_cast<uint16_t *>(dst_dev)); break;
       case 4: hipLaunchKernelGGL(gather_segmented_table_kernel<uint32_t>, dim3(grid), dim3(kBlock), lds, s, first_dev, ptrs_dev, num_segments, tids_dev, n, static_cast<uint32_t *>(dst_dev)); break;
       case 8: hipLaunchKernelGGL(gather_segmented_table_kernel<uint64_t>, dim3(grid), dim3(kBlock), lds, s, first_dev, ptrs_dev, num_segments, tids_dev, n, static_cast<uint64_t *>(dst_dev)); break;
-      default: return QSX_ERR_UNSUPPORTED;
+      default:
+        if (width < 1 || width > 4096) return QSX_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(gather_segmented_table_bytes_kernel, dim3(grid_for(n * width, kBlock * 16)), dim3(kBlock), lds, s, first_dev, ptrs_dev,
+                           num_segments, width, tids_dev, n, static_cast<uint8_t *>(dst_dev));
+        break;
     }
     QSX_CHECK_LAUNCH();
     return QSX_OK;
@@ -1893,7 +1954,11 @@ int qsx_gather_segmented(int width, int num_segments, const void *const *segment
     case 2: hipLaunchKernelGGL(gather_segmented_kernel<uint16_t>, dim3(grid), dim3(kBlock), 0, s, seg, tids_dev, n, static_cast<uint16_t *>(dst_dev)); break;
     case 4: hipLaunchKernelGGL(gather_segmented_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, seg, tids_dev, n, static_cast<uint32_t *>(dst_dev)); break;
     case 8: hipLaunchKernelGGL(gather_segmented_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, s, seg, tids_dev, n, static_cast<uint64_t *>(dst_dev)); break;
-    default: return QSX_ERR_UNSUPPORTED;
+    default:
+      if (width < 1 || width > 4096) return QSX_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL(gather_segmented_bytes_kernel, dim3(grid_for(n * width, kBlock * 4)), dim3(kBlock), 0, s, seg, width, tids_dev, n,
+                         static_cast<uint8_t *>(dst_dev));
+      break;
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;

@@ -2442,6 +2442,28 @@ bool HashInnerJoinWorkOrder::executeRun() {
   }
   if (total_rows > INT32_MAX || blocks.size() > 16384) return false;
   const std::int64_t nb = static_cast<std::int64_t>(blocks.size());
+  // The terms evaluated on the pair list (component equalities of a hashed composite key, residual conjuncts): the run form
+  // gathers their operands with widths of 1 / 2 / 4 / 8 bytes and compares numeric types — a nullable or CHAR(n) operand
+  // sends the whole work order to the block-by-block form BEFORE any device work is done for the run.
+  {
+    auto operand_ok = [&](attribute_id attr, bool on_build, bool against_literal) {
+      const Type &t = (on_build ? build_relation_ : probe_relation_).getAttributeType(attr);
+      // (a CHAR(n) attribute against a literal is compared by qsx_select_cmp_char; attribute against attribute is numeric)
+      return !t.nullable && t.id != kVarChar && (t.id != kChar || against_literal);
+    };
+    if (hashed_key) {
+      for (std::size_t k = 0; k < join_key_attributes_.size(); ++k) {
+        if (!operand_ok(join_key_attributes_[k], false, false) || !operand_ok(build_key_attributes_[k], true, false)) return false;
+      }
+    }
+    if (residual_predicate_ != nullptr) {
+      for (const ComparisonPredicate &term : residual_predicate_->conjuncts) {
+        const bool literal = term.rhs_attribute == kInvalidAttributeID;
+        if (!operand_ok(term.attribute, term.on_build_side, literal)) return false;
+        if (!literal && !operand_ok(term.rhs_attribute, term.rhs_on_build_side, false)) return false;
+      }
+    }
+  }
   const RunJoinKeys run_keys(blocks, join_key_attributes_, rows);   // composite key: one launch packs the run's keys
   const std::vector<const void *> &keys = run_keys.ptr;
   // existence_map of the LIPFilterAdaptiveProber (:462-470): the probe tuples this work order looks up
@@ -2512,7 +2534,11 @@ bool HashInnerJoinWorkOrder::executeRun() {
     // side through the run's own stripes), compared, chained through the filter bitmap like a conjunction
     const std::int64_t m = pairs.count;
     const std::size_t pair_bitmap_bytes = static_cast<std::size_t>((m + 63) / 64) * 8 + 8;
-    DeviceBuffer current(pair_bitmap_bytes), next(pair_bitmap_bytes), lhs(static_cast<std::size_t>(m) * 8 + 8), rhs(static_cast<std::size_t>(m) * 8 + 8);
+    std::size_t widest = 8;
+    for (const ComparisonPredicate &term : terms) {
+      widest = std::max<std::size_t>(widest, (term.on_build_side ? build_relation_ : probe_relation_).getAttributeType(term.attribute).width);
+    }
+    DeviceBuffer current(pair_bitmap_bytes), next(pair_bitmap_bytes), lhs(static_cast<std::size_t>(m) * widest + 8), rhs(static_cast<std::size_t>(m) * 8 + 8);
     void *cur = current.ptr, *nxt = next.ptr;
     bool first = true;
     auto gather_side = [&](attribute_id attr, bool on_build, void *dst) -> Type {
@@ -2528,15 +2554,17 @@ bool HashInnerJoinWorkOrder::executeRun() {
       return t;
     };
     for (const ComparisonPredicate &term : terms) {
-      const Type t = gather_side(term.attribute, term.on_build_side, lhs.ptr);
-      if (t.nullable || t.id == kChar) return false;   // (NULL operands / string operands: the block-by-block form)
+      const Type t = gather_side(term.attribute, term.on_build_side, lhs.ptr);   // (operand types were vetted above)
       if (term.rhs_attribute != kInvalidAttributeID) {
         const Type rt = gather_side(term.rhs_attribute, term.rhs_on_build_side, rhs.ptr);
         if (rt.id != t.id) throw ExecutionError("join predicate compares attributes of different types", QSX_ERR_UNSUPPORTED);
-        if (rt.nullable) return false;
         CheckStatus(qsx_select_cmp_columns(t.id, lhs.ptr, rhs.ptr, m, static_cast<int>(term.comparison),
                                            first ? nullptr : static_cast<const std::uint64_t *>(cur), static_cast<std::uint64_t *>(nxt), nullptr,
                                            CurrentStream()), "qsx_select_cmp_columns");
+      } else if (t.id == kChar) {
+        CheckStatus(qsx_select_cmp_char(lhs.ptr, t.width, m, static_cast<int>(term.comparison), term.literal.text.data(),
+                                        static_cast<int>(term.literal.text.size()), first ? nullptr : static_cast<const std::uint64_t *>(cur),
+                                        static_cast<std::uint64_t *>(nxt), nullptr, CurrentStream()), "qsx_select_cmp_char");
       } else {
         CheckStatus(qsx_select_cmp(t.id, lhs.ptr, m, static_cast<int>(term.comparison), &term.literal.v,
                                    first ? nullptr : static_cast<const std::uint64_t *>(cur), static_cast<std::uint64_t *>(nxt), nullptr,
@@ -2626,7 +2654,11 @@ void HashInnerJoinWorkOrder::executeBlock(block_id probe_block_id) {
     if (!terms.empty() && pairs.count > 0) {
       const std::int64_t m = pairs.count;
       const std::size_t pair_bitmap_bytes = static_cast<std::size_t>((m + 63) / 64) * 8 + 8;
-      DeviceBuffer current(pair_bitmap_bytes), next(pair_bitmap_bytes), lhs(static_cast<std::size_t>(m) * 8 + 8),
+      std::size_t widest = 8;
+      for (const ComparisonPredicate &term : terms) {
+        widest = std::max<std::size_t>(widest, (term.on_build_side ? build_relation_ : probe_relation_).getAttributeType(term.attribute).width);
+      }
+      DeviceBuffer current(pair_bitmap_bytes), next(pair_bitmap_bytes), lhs(static_cast<std::size_t>(m) * widest + 8),
           rhs(static_cast<std::size_t>(m) * 8 + 8);
       void *cur = current.ptr, *nxt = next.ptr;
       bool first = true;
@@ -2643,12 +2675,19 @@ void HashInnerJoinWorkOrder::executeBlock(block_id probe_block_id) {
       for (const ComparisonPredicate &term : terms) {
         const Type t = gather_side(term.attribute, term.on_build_side, lhs.ptr);
         if (term.rhs_attribute != kInvalidAttributeID) {
+          if (t.id == kChar || t.id == kVarChar) {
+            throw ExecutionError("join predicate compares two string attributes (only string = literal is supported)", QSX_ERR_UNSUPPORTED);
+          }
           const Type rt = gather_side(term.rhs_attribute, term.rhs_on_build_side, rhs.ptr);
           if (rt.id != t.id) throw ExecutionError("join predicate compares attributes of different types", QSX_ERR_UNSUPPORTED);
           CheckStatus(qsx_select_cmp_columns(t.id, lhs.ptr, rhs.ptr, m, static_cast<int>(term.comparison),
                                              first ? nullptr : static_cast<const std::uint64_t *>(cur),
                                              static_cast<std::uint64_t *>(nxt), nullptr, CurrentStream()),
                       "qsx_select_cmp_columns");
+        } else if (t.id == kChar) {
+          CheckStatus(qsx_select_cmp_char(lhs.ptr, t.width, m, static_cast<int>(term.comparison), term.literal.text.data(),
+                                          static_cast<int>(term.literal.text.size()), first ? nullptr : static_cast<const std::uint64_t *>(cur),
+                                          static_cast<std::uint64_t *>(nxt), nullptr, CurrentStream()), "qsx_select_cmp_char");
         } else {
           CheckStatus(qsx_select_cmp(t.id, lhs.ptr, m, static_cast<int>(term.comparison), &term.literal.v,
                                      first ? nullptr : static_cast<const std::uint64_t *>(cur),

@@ -1,0 +1,276 @@
+// The headline workload of bench.py (BASELINE.json configs 2 + 3) through the OPERATOR BOUNDARY instead of the raw C ABI:
+//
+//   BuildHashOperator(customer.c_custkey)  --breaker-->  HashJoinOperator(orders.o_custkey = c_custkey) -> output relation
+//   AggregationOperator(lineitem: Q1's GROUP BY l_returnflag, l_linestatus + its eight aggregates)
+//       --breaker--> FinalizeAggregationOperator -> output relation
+//   DestroyHashOperator, DestroyAggregationStateOperator
+//
+// scheduled by ForemanSingleNode on process-wide Worker threads (query_execution/Worker.cpp:119-148), the relations stored
+// as reference-sized 4 MB column-store blocks (1 M INT rows; 123 361 rows of the six Q1 attributes), work orders over runs
+// of blocks (setBlocksPerWorkOrder, RelationalOperator.hpp:117-119).  One step = one such query; the operators allocate
+// their join table, aggregation state and output blocks inside the step like the reference's query admission does.
+//
+// The blocks are loaded from a handful of host templates (no 20 GB host copy of lineitem): every template block recurs
+// n / templates times, so the expected result of any number of blocks is known exactly (counts) or to rounding (sums).
+//
+// usage: headline_operators_bench [build_rows probe_rows agg_rows [steps warmup workers blocks_per_work_order]]
+// prints one JSON line {"rows_per_s": ..., "ms_per_step": ..., ...}; exit code 0 only when every step's results check out.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <tuple>
+
+#include "test_util.hpp"
+
+using namespace quickstep;
+
+namespace {
+constexpr std::int64_t kBlockBytes = 4ll << 20;
+constexpr int kTemplates = 8;
+
+struct Xorshift {
+  std::uint64_t x;
+  explicit Xorshift(std::uint64_t seed) : x(seed * 0x9E3779B97F4A7C15ull + 1) {}
+  std::uint64_t next() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; }
+};
+
+struct Q1Template {
+  std::vector<char> flag, status;
+  std::vector<double> qty, price, disc, tax;
+  std::map<std::pair<char, char>, std::int64_t> count;
+  std::map<std::pair<char, char>, double> sum_qty, sum_price, sum_disc_price;
+};
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (qsx_device_count() < 1) {
+    std::fprintf(stderr, "headline_operators_bench needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
+    return 2;
+  }
+  const std::int64_t build_rows = argc > 1 ? std::atoll(argv[1]) : 1000000, probe_rows = argc > 2 ? std::atoll(argv[2]) : 100000000,
+                     agg_rows = argc > 3 ? std::atoll(argv[3]) : 600000000;
+  const int steps = argc > 4 ? std::atoi(argv[4]) : 5, warmup = argc > 5 ? std::atoi(argv[5]) : 2;
+  const std::size_t workers = argc > 6 ? static_cast<std::size_t>(std::atoi(argv[6])) : 4;
+  const std::size_t run_blocks = argc > 7 ? static_cast<std::size_t>(std::atoi(argv[7])) : 64;
+
+  StorageManager storage;
+  CatalogRelation customer(1, "customer"), orders(2, "orders"), lineitem(3, "lineitem");
+  customer.addAttribute("c_custkey", Type::Int());
+  orders.addAttribute("o_custkey", Type::Int());
+  lineitem.addAttribute("l_returnflag", Type::Char(1));
+  lineitem.addAttribute("l_linestatus", Type::Char(1));
+  for (const char *n : {"l_quantity", "l_extendedprice", "l_discount", "l_tax"}) lineitem.addAttribute(n, Type::Double());
+
+  // ---- customer: a permutation of [0, build_rows) in 4 MB blocks ----------------------------------------------------------
+  const std::int64_t int_block = kBlockBytes / 4;
+  {
+    std::vector<std::int32_t> keys(static_cast<std::size_t>(build_rows));
+    for (std::int64_t i = 0; i < build_rows; ++i) keys[i] = static_cast<std::int32_t>(i);
+    Xorshift rng(2);
+    for (std::int64_t i = build_rows - 1; i > 0; --i) std::swap(keys[i], keys[rng.next() % static_cast<std::uint64_t>(i + 1)]);
+    for (std::int64_t at = 0; at < build_rows; at += int_block) {
+      storage.loadBlock(&customer, {keys.data() + at}, std::min(int_block, build_rows - at));
+    }
+  }
+  // ---- orders: uniform foreign keys, kTemplates distinct blocks --------------------------------------------------------------
+  {
+    std::vector<std::vector<std::int32_t>> tmpl(kTemplates, std::vector<std::int32_t>(static_cast<std::size_t>(int_block)));
+    Xorshift rng(3);
+    for (auto &t : tmpl) for (auto &k : t) k = static_cast<std::int32_t>(rng.next() % static_cast<std::uint64_t>(build_rows));
+    int b = 0;
+    for (std::int64_t at = 0; at < probe_rows; at += int_block, ++b) {
+      storage.loadBlock(&orders, {tmpl[b % kTemplates].data()}, std::min(int_block, probe_rows - at));
+    }
+  }
+  // ---- lineitem: Q1 attributes, 4 MB = 123 361 rows of 34 bytes ---------------------------------------------------------------
+  const std::int64_t q1_block = kBlockBytes / 34;
+  std::vector<Q1Template> q1(kTemplates);
+  std::vector<std::int64_t> q1_uses(kTemplates, 0);
+  std::int64_t last_block_rows = 0;
+  int last_template = 0;
+  {
+    Xorshift rng(4);
+    for (Q1Template &t : q1) {
+      for (std::int64_t i = 0; i < q1_block; ++i) {
+        const double u = static_cast<double>(rng.next() % 1000000) / 1e6;
+        const char f = u < 0.2466 ? 'A' : (u < 0.2531 ? 'N' : (u < 0.7536 ? 'N' : 'R'));
+        const char s = u < 0.2466 ? 'F' : (u < 0.2531 ? 'F' : (u < 0.7536 ? 'O' : 'F'));
+        t.flag.push_back(f);
+        t.status.push_back(s);
+        t.qty.push_back(static_cast<double>(1 + rng.next() % 50));
+        t.price.push_back(std::round((900.0 + static_cast<double>(rng.next() % 10410000) / 100.0) * 100.0) / 100.0);
+        t.disc.push_back(static_cast<double>(rng.next() % 11) / 100.0);
+        t.tax.push_back(static_cast<double>(rng.next() % 9) / 100.0);
+      }
+    }
+    int b = 0;
+    for (std::int64_t at = 0; at < agg_rows; at += q1_block, ++b) {
+      const Q1Template &t = q1[b % kTemplates];
+      const std::int64_t rows = std::min(q1_block, agg_rows - at);
+      storage.loadBlock(&lineitem, {t.flag.data(), t.status.data(), t.qty.data(), t.price.data(), t.disc.data(), t.tax.data()}, rows);
+      if (rows == q1_block) {
+        ++q1_uses[b % kTemplates];
+      } else {
+        last_block_rows = rows;
+        last_template = b % kTemplates;
+      }
+    }
+  }
+  // expected Q1 groups from the templates
+  std::map<std::pair<char, char>, std::int64_t> want_count;
+  std::map<std::pair<char, char>, double> want_qty, want_price, want_disc_price;
+  for (int ti = 0; ti < kTemplates; ++ti) {
+    const Q1Template &t = q1[ti];
+    auto add = [&](std::int64_t rows, std::int64_t times) {
+      std::map<std::pair<char, char>, std::int64_t> c;
+      std::map<std::pair<char, char>, double> sq, sp, sd;
+      for (std::int64_t i = 0; i < rows; ++i) {
+        const auto k = std::make_pair(t.flag[i], t.status[i]);
+        c[k] += 1;
+        sq[k] += t.qty[i];
+        sp[k] += t.price[i];
+        sd[k] += t.price[i] * (1.0 - t.disc[i]);
+      }
+      for (const auto &kv : c) {
+        want_count[kv.first] += kv.second * times;
+        want_qty[kv.first] += sq[kv.first] * static_cast<double>(times);
+        want_price[kv.first] += sp[kv.first] * static_cast<double>(times);
+        want_disc_price[kv.first] += sd[kv.first] * static_cast<double>(times);
+      }
+    };
+    if (q1_uses[ti] > 0) add(q1_block, q1_uses[ti]);
+    if (last_block_rows > 0 && ti == last_template) add(last_block_rows, 1);
+  }
+
+  CatalogRelation joined(10, "joined"), agg_out(11, "agg_out");
+  joined.addAttribute("o_custkey", Type::Int());
+  joined.addAttribute("c_custkey", Type::Int());
+  agg_out.addAttribute("l_returnflag", Type::Char(1));
+  agg_out.addAttribute("l_linestatus", Type::Char(1));
+  for (const char *n : {"sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"}) agg_out.addAttribute(n, Type::Double());
+  agg_out.addAttribute("count_order", Type::Long());
+
+  double total_ms = 0.0, best_ms = 1e30;
+  std::size_t work_orders = 0;
+  for (int it = 0; it < warmup + steps; ++it) {
+    const auto t0 = std::chrono::steady_clock::now();
+    QueryContext ctx;
+    const auto d_join = ctx.addInsertDestination(&joined, &storage), d_agg = ctx.addInsertDestination(&agg_out, &storage);
+    const QueryContext::ExactKeyRange key_range{0, build_rows - 1};   // exact statistics of the primary key
+    const auto table = ctx.addJoinHashTable(kInt, build_rows, 1, &key_range);
+    const auto selection = ctx.addScalarGroup({0, 0});                  // o_custkey of the probe side, c_custkey of the build side
+    const std::vector<bool> on_build{false, true};
+    AggregationStateSpec spec;
+    spec.input_relation = &lineitem;
+    spec.group_by = {0, 1};
+    const ScalarPtr disc_price = Scalar::Binary(BinaryOperationID::kMultiply, Scalar::Attribute(3),
+                                                Scalar::Binary(BinaryOperationID::kSubtract, Scalar::Literal(1.0), Scalar::Attribute(4)));
+    const ScalarPtr charge = Scalar::Binary(BinaryOperationID::kMultiply, disc_price,
+                                            Scalar::Binary(BinaryOperationID::kAdd, Scalar::Literal(1.0), Scalar::Attribute(5)));
+    spec.aggregates = {AggregateSpec(AggregationID::kSum, 2), AggregateSpec(AggregationID::kSum, 3), AggregateSpec(AggregationID::kSum, disc_price),
+                       AggregateSpec(AggregationID::kSum, charge), AggregateSpec(AggregationID::kAvg, 2), AggregateSpec(AggregationID::kAvg, 3),
+                       AggregateSpec(AggregationID::kAvg, 4), AggregateSpec(AggregationID::kCount, kInvalidAttributeID)};
+    spec.strategy = QSX_AGG_COMPACT_KEY;
+    spec.estimated_num_groups = 6;
+    const auto state = ctx.addAggregationState(spec);
+
+    QueryPlan plan;
+    BuildHashOperator *op_build = new BuildHashOperator(0, customer, true, {0}, false, 1, table);
+    HashJoinOperator *op_join = new HashJoinOperator(0, customer, orders, true, {0}, false, 1, false, joined, d_join, table,
+                                                     QueryContext::kInvalidPredicateId, selection, &on_build, HashJoinOperator::JoinType::kInnerJoin);
+    AggregationOperator *op_agg = new AggregationOperator(0, lineitem, true, state);
+    op_build->setBlocksPerWorkOrder(run_blocks);
+    op_join->setBlocksPerWorkOrder(run_blocks);
+    op_agg->setBlocksPerWorkOrder(run_blocks);
+    const auto i_build = plan.addRelationalOperator(op_build);
+    const auto i_join = plan.addRelationalOperator(op_join);
+    const auto i_agg = plan.addRelationalOperator(op_agg);
+    const auto i_fin = plan.addRelationalOperator(new FinalizeAggregationOperator(0, state, 1, false, 1, agg_out, d_agg));
+    const auto i_drop_table = plan.addRelationalOperator(new DestroyHashOperator(0, 1, table));
+    const auto i_drop_state = plan.addRelationalOperator(new DestroyAggregationStateOperator(0, state));
+    plan.addDirectDependency(i_join, i_build, true);
+    plan.addDirectDependency(i_fin, i_agg, true);
+    plan.addDirectDependency(i_drop_table, i_join, true);
+    plan.addDirectDependency(i_drop_state, i_fin, true);
+    ForemanSingleNode foreman(&plan, &ctx, &storage, workers);
+    foreman.run();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (it >= warmup) {
+      total_ms += ms;
+      best_ms = std::min(best_ms, ms);
+    }
+    work_orders = foreman.getWorkOrderProfilingResults().size();
+    if (std::getenv("QSX_TEST_PROFILE") != nullptr && it == warmup + steps - 1) {   // --profile_and_report_workorder_perf
+      const std::uint64_t t0_us = static_cast<std::uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(t0.time_since_epoch()).count());
+      std::map<std::size_t, std::tuple<double, int, std::uint64_t, std::uint64_t>> per_op;
+      for (const WorkOrderTimeEntry &e : foreman.getWorkOrderProfilingResults()) {
+        auto &p = per_op[e.operator_index];
+        if (std::get<1>(p) == 0) std::get<2>(p) = ~0ull;
+        std::get<0>(p) += static_cast<double>(e.end_us - e.start_us) / 1e3;
+        std::get<1>(p) += 1;
+        std::get<2>(p) = std::min(std::get<2>(p), e.start_us);
+        std::get<3>(p) = std::max(std::get<3>(p), e.end_us);
+      }
+      for (const auto &kv : per_op) {
+        std::fprintf(stderr, "  %-34s %3d work orders, %7.3f ms summed, first start %+8.3f ms, last end %+8.3f ms\n",
+                     plan.getOperator(kv.first)->getName().c_str(), std::get<1>(kv.second), std::get<0>(kv.second),
+                     (static_cast<double>(std::get<2>(kv.second)) - static_cast<double>(t0_us)) / 1e3,
+                     (static_cast<double>(std::get<3>(kv.second)) - static_cast<double>(t0_us)) / 1e3);
+      }
+      std::fprintf(stderr, "  step wall %.3f ms\n", ms);
+    }
+
+    // ---- results of this step ----------------------------------------------------------------------------------------------
+    std::int64_t joined_rows = 0;
+    bool join_ok = true;
+    const bool verify_columns = it == warmup + steps - 1;   // the join condition on every output row: last step only
+    for (block_id b : ctx.getInsertDestination(d_join)->getTouchedBlocks()) {
+      BlockReference blk = storage.getBlock(b);
+      joined_rows += blk->numTuples();
+      if (verify_columns) {
+        const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+        std::vector<std::int32_t> o(k), c(k);
+        blk->copyAttributeToHost(0, o.data());
+        blk->copyAttributeToHost(1, c.data());
+        for (std::size_t i = 0; i < k; ++i) join_ok = join_ok && o[i] == c[i];
+      }
+      storage.deleteBlockOrBlobFile(b);
+    }
+    EXPECT_EQ(joined_rows, probe_rows);   // every foreign key has exactly one customer
+    EXPECT_TRUE(join_ok);
+    std::size_t groups = 0;
+    for (block_id b : ctx.getInsertDestination(d_agg)->getTouchedBlocks()) {
+      BlockReference blk = storage.getBlock(b);
+      const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+      std::vector<char> f(k), s(k);
+      std::vector<double> sq(k), sp(k), sd(k), aq(k);
+      std::vector<std::int64_t> cnt(k);
+      blk->copyAttributeToHost(0, f.data()); blk->copyAttributeToHost(1, s.data());
+      blk->copyAttributeToHost(2, sq.data()); blk->copyAttributeToHost(3, sp.data()); blk->copyAttributeToHost(4, sd.data());
+      blk->copyAttributeToHost(6, aq.data()); blk->copyAttributeToHost(9, cnt.data());
+      for (std::size_t i = 0; i < k; ++i, ++groups) {
+        const auto key = std::make_pair(f[i], s[i]);
+        EXPECT_EQ(cnt[i], want_count[key]);                                   // COUNT(*): exact
+        EXPECT_EQ(static_cast<std::int64_t>(sq[i]), static_cast<std::int64_t>(want_qty[key]));   // integer-valued doubles: exact
+        EXPECT_NEAR(sp[i], want_price[key], 1e-6 * want_price[key]);
+        EXPECT_NEAR(sd[i], want_disc_price[key], 1e-6 * want_disc_price[key]);
+        EXPECT_NEAR(aq[i], want_qty[key] / static_cast<double>(want_count[key]), 1e-6 * aq[i]);
+      }
+      storage.deleteBlockOrBlobFile(b);
+    }
+    EXPECT_EQ(groups, want_count.size());
+  }
+  const double ms_per_step = total_ms / steps;
+  std::printf("{\"path\": \"operators (BuildHash / HashJoin / Aggregation / FinalizeAggregation under ForemanSingleNode)\", "
+              "\"rows_per_s\": %.6g, \"ms_per_step\": %.4f, \"best_ms\": %.4f, \"steps\": %d, \"warmup\": %d, \"workers\": %zu, "
+              "\"blocks_per_work_order\": %zu, \"block_bytes\": %lld, \"probe_blocks\": %lld, \"aggregate_blocks\": %lld, \"work_orders_per_step\": %zu, "
+              "\"build_rows\": %lld, \"probe_rows\": %lld, \"aggregate_rows\": %lld, \"checked\": %s}\n",
+              static_cast<double>(probe_rows + agg_rows) / (ms_per_step / 1e3), ms_per_step, best_ms, steps, warmup, workers, run_blocks,
+              static_cast<long long>(kBlockBytes), static_cast<long long>((probe_rows + int_block - 1) / int_block),
+              static_cast<long long>((agg_rows + q1_block - 1) / q1_block), work_orders, static_cast<long long>(build_rows),
+              static_cast<long long>(probe_rows), static_cast<long long>(agg_rows), g_failures == 0 ? "true" : "false");
+  return g_failures == 0 ? 0 : 1;
+}

@@ -5,6 +5,7 @@
 // block order, row order) — including the shapes the run form hands back to the per-block path (a nullable attribute).
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <random>
 
 #include "test_util.hpp"
@@ -194,6 +195,69 @@ Rows runJoin(bool exact_stats, std::size_t blocks_per_order, std::size_t *out_bl
   EXPECT_TRUE(g == w);
   return got;
 }
+
+// select o_orderkey, l_extendedprice, o_flag from orders join lineitem on o_orderkey = l_orderkey where o_flag = 'KEEP':
+// a CHAR(10) attribute of the build side in the residual predicate (compared on the pair list by qsx_select_cmp_char) and in
+// the projection (gathered byte by byte) — the run form and the block-by-block form
+void runJoinCharResidual(std::size_t blocks_per_order, std::size_t *out_blocks) {
+  StorageManager storage;
+  Lineitem li(&storage, false);
+  CatalogRelation orders(3, "orders");
+  orders.addAttribute("o_orderkey", Type::Int());
+  orders.addAttribute("o_flag", Type::Char(10));
+  std::vector<std::int32_t> okeys;
+  for (std::int32_t k = 0; k < 200000; k += 2) okeys.push_back(k);
+  std::shuffle(okeys.begin(), okeys.end(), std::mt19937_64(5));
+  std::vector<char> flags(okeys.size() * 10, 0);
+  for (std::size_t i = 0; i < okeys.size(); ++i) std::strncpy(&flags[i * 10], okeys[i] % 3 == 0 ? "KEEP" : "KEEPER", 10);
+  for (std::size_t at = 0; at < okeys.size(); at += 2500) storage.loadBlock(&orders, {okeys.data() + at, flags.data() + at * 10}, 2500);
+  CatalogRelation out(4, "joined");
+  out.addAttribute("o_orderkey", Type::Int());
+  out.addAttribute("l_extendedprice", Type::Double());
+  out.addAttribute("o_flag", Type::Char(10));
+  QueryContext ctx;
+  const auto table = ctx.addJoinHashTable(kInt, 100000);
+  const auto dest = ctx.addInsertDestination(&out, &storage);
+  const auto selection = ctx.addScalarGroup({0, 2, 1});
+  const std::vector<bool> on_build = {true, false, true};
+  Predicate residual;
+  residual.conjuncts.push_back(ComparisonPredicate(1, ComparisonID::kEqual, TypedLiteral::Char("KEEP"), /*build_side=*/true));
+  const auto pred = ctx.addPredicate(residual);
+  BuildHashOperator builder(0, orders, true, {0}, false, 1, table);
+  HashJoinOperator prober(0, orders, li.rel, true, {0}, false, 1, false, out, dest, table, pred, selection, &on_build,
+                          HashJoinOperator::JoinType::kInnerJoin);
+  prober.setBlocksPerWorkOrder(blocks_per_order);
+  fetchAndExecuteWorkOrders(&builder, &ctx, &storage);
+  fetchAndExecuteWorkOrders(&prober, &ctx, &storage);
+  std::vector<std::pair<std::int32_t, double>> g, w;
+  const std::vector<block_id> touched = ctx.getInsertDestination(dest)->getTouchedBlocks();
+  *out_blocks = touched.size();
+  bool flags_ok = true;
+  for (block_id b : touched) {
+    BlockReference blk = storage.getBlock(b);
+    const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+    if (k == 0) continue;
+    std::vector<std::int32_t> key(k);
+    std::vector<double> price(k);
+    std::vector<char> flag(k * 10);
+    blk->copyAttributeToHost(0, key.data());
+    blk->copyAttributeToHost(1, price.data());
+    blk->copyAttributeToHost(2, flag.data());
+    for (std::size_t i = 0; i < k; ++i) {
+      g.emplace_back(key[i], price[i]);
+      flags_ok = flags_ok && std::strncmp(&flag[i * 10], "KEEP", 10) == 0;
+    }
+  }
+  for (std::size_t i = 0; i < li.orderkey.size(); ++i) {
+    if (li.orderkey[i] < 200000 && (li.orderkey[i] & 1) == 0 && li.orderkey[i] % 3 == 0) w.emplace_back(li.orderkey[i], li.price[i]);
+  }
+  std::sort(g.begin(), g.end());
+  std::sort(w.begin(), w.end());
+  EXPECT_TRUE(flags_ok);
+  EXPECT_TRUE(w.size() > 10000);
+  EXPECT_EQ(g.size(), w.size());
+  EXPECT_TRUE(g == w);
+}
 }  // namespace
 
 int main() {
@@ -251,5 +315,10 @@ int main() {
   runJoin(true, 64, &blocks_run, &ms_run, true);
   EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
   std::printf("hash join under a LIP filter: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n", ms_one, ms_run);
+  // a CHAR(10) build attribute in the residual predicate and in the projection: both forms
+  runJoinCharResidual(1, &blocks_one);
+  runJoinCharResidual(64, &blocks_run);
+  EXPECT_EQ(blocks_one, static_cast<std::size_t>(kBlocks));
+  EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
   return finish("work_order_runs_test");
 }

@@ -244,8 +244,9 @@ def test_xcd_sliced_probe_matches_oracle(capi, oracle, dev, key_type, dtype, fla
         p, b, cnt = table.probe(dp, capacity=1000)               # more matches than room: full count, no write past the end
         assert int(cnt.item()) == int(table.probe_count(dp).item())
         # a key stripe that does not start on a 16-byte boundary takes the plain kernels: same result
-        p, b, cnt = table.probe(dp[1:], capacity=total)
         _, rp1, rd1 = oracle_join(oracle, key_type, [build], probe[1:])
+        p, b, cnt = table.probe(dp[1:], capacity=rp1.size)
+        assert int(cnt.item()) == rp1.size
         assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp1.size], b.cpu().numpy()[:rp1.size]), sorted_pairs(rp1, rd1))
         table.close()
 
@@ -293,8 +294,8 @@ def test_xcd_sliced_probe_at_scale_properties(capi, dev, monkeypatch, flavour):
         assert int(torch.bincount(p.long(), minlength=n_probe).max().item()) == 1
 
 
-@pytest.mark.parametrize("flavour", FLAVOURS)
-def test_fk_join_at_scale_properties(capi, dev, flavour):
+@pytest.mark.parametrize("flavour", FLAVOURS + ["hashed_no_shadow"])
+def test_fk_join_at_scale_properties(capi, dev, flavour, monkeypatch):
     """C2 shape scaled to 1 M x 20 M (full 100 M runs in bench.py): every probe key hits
     exactly one build row, so pairs must be a permutation of the probe tids and satisfy the
     join condition; checked on device with size-independent reductions."""
@@ -303,6 +304,8 @@ def test_fk_join_at_scale_properties(capi, dev, flavour):
     n_build, n_probe = 1_000_000, 20_000_000
     build = torch.randperm(n_build, device=dev, generator=g, dtype=torch.int32)
     probe = torch.randint(0, n_build, (n_probe,), device=dev, generator=g, dtype=torch.int32)
+    if flavour == "hashed_no_shadow":
+        monkeypatch.setenv("QSX_JOIN_ADAPTIVE", "0")      # the hashed kernels themselves (dense keys would get a shadow)
     table = capi.JoinTable(T.INT, n_build, key_range=(0, n_build - 1) if flavour == "dense" else None)
     table.build(build)
     p, b, cnt = table.probe(probe)
@@ -318,36 +321,53 @@ def test_fk_join_at_scale_properties(capi, dev, flavour):
     assert bool((build[b2[:k].long()] == probe2[p2[:k].long()]).all())
 
 
-@pytest.mark.parametrize("n_build,n_probe,key_range,hot", [(300_000, 2_000_000, 250_000, 0), (1_200_000, 3_000_001, 5_000_000, 0),
-                                                            (200_000, 1_500_000, 2_000_000, 6000)])
-def test_radix_partitioned_probe_matches_oracle(capi, oracle, dev, n_build, n_probe, key_range, hot):
-    """Build >= 128 K entries and probe >= 1 M rows take the radix-partitioned LDS-table path
-    (csrc/join_radix.hpp): duplicates, filters, negative keys, and (hot > 0) one key with thousands of
-    build duplicates so that its partition overflows the LDS table and falls back to the global table."""
-    rng = np.random.default_rng(n_build)
-    lo = -key_range // 2
-    build = rng.integers(lo, lo + key_range, size=n_build).astype(np.int32)
-    probe = rng.integers(lo - 10, lo + key_range + 10, size=n_probe).astype(np.int32)
-    if hot:
-        build[:hot] = 424242
-        probe[:20] = 424242                           # 20 probe rows x `hot` matches each
-    blocks = np.array_split(build, 3)
-    pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.8)
-    pf[0] |= np.uint64(0xFFFFF00000000000)            # keep the hot probe rows selected
-    table, p, d, total = hip_join(capi, dev, T.INT, blocks, probe, probe_filter=pf)
-    _, rp, rd = oracle_join(oracle, T.INT, blocks, probe, probe_filter=pf)
-    assert total == rp.size
-    assert np.array_equal(sorted_pairs(p, d), sorted_pairs(rp, rd))
-    # probing again (table unchanged) reuses the partitioned build side; a further build invalidates it
-    _, _, cnt = table.probe(to_dev(probe, dev), capacity=total, filter_bitmap=bitmap_dev(pf, dev))
-    assert int(cnt.item()) == total
-    extra = np.arange(7, dtype=np.int32) + lo
-    table.build(to_dev(extra, dev), base_tid=n_build)
-    want = total + int(np.isin(probe[oracle.bools_from_bitmap(pf, n_probe)], extra).sum())
-    assert int(table.probe_count(to_dev(probe, dev), filter_bitmap=bitmap_dev(pf, dev)).item()) == want
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+def test_hashed_table_over_a_dense_key_domain_answers_from_its_shadow(capi, oracle, dev, key_type, dtype, monkeypatch):
+    """A hashed table (no statistics from the optimizer) whose build keys turn out to span a small range copies its entries
+    into a directly addressed shadow at the first probe (join.hip sealed_shadow).  Same pairs, counts and existence bitmaps
+    with the shadow and without (QSX_JOIN_ADAPTIVE=0), with duplicates and filters, over runs of blocks, and again after
+    further builds and after a clear (the shadow must not survive either)."""
+    rng = np.random.default_rng(91)
+    lo = -5_000 if dtype == np.int32 else 2**41
+    n_build, n_probe = 120_000, 900_001
+    build = (lo + rng.integers(0, 300_000, size=n_build)).astype(dtype)          # duplicates, range / entries = 2.5
+    more = (lo + rng.integers(100_000, 420_000, size=70_000)).astype(dtype)      # a later build widens the range
+    probe = (lo + rng.integers(-1000, 430_000, size=n_probe)).astype(dtype)
+    pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.6)
+    dp = to_dev(probe, dev)
+
+    def check(table, build_blocks):
+        for filt in (None, pf):
+            fdev = None if filt is None else bitmap_dev(filt, dev)
+            _, rp, rd = oracle_join(oracle, key_type, build_blocks, probe, probe_filter=filt)
+            assert int(table.probe_count(dp, filter_bitmap=fdev).item()) == rp.size
+            p, b, cnt = table.probe(dp, capacity=rp.size, filter_bitmap=fdev)
+            assert int(cnt.item()) == rp.size
+            assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rd))
+            bm, c = table.probe_exists(dp, filter_bitmap=fdev)
+            want = np.zeros(n_probe, dtype=bool)
+            want[rp] = True
+            assert np.array_equal(bitmap_np(bm), oracle.bitmap_from_bools(want)) and int(c.item()) == int(want.sum())
+        cuts = [0, 100_000, 100_000, 512_345, n_probe]
+        blocks = [dp[a:b_] for a, b_ in zip(cuts[:-1], cuts[1:])]
+        _, rp, rd = oracle_join(oracle, key_type, build_blocks, probe)
+        p, b, cnt = table.probe_blocks(blocks, capacity=rp.size)
+        assert int(cnt.item()) == rp.size
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rd))
+
+    for adaptive in ("1", "0"):
+        monkeypatch.setenv("QSX_JOIN_ADAPTIVE", adaptive)
+        table = capi.JoinTable(key_type, n_build)
+        table.build(to_dev(build, dev))
+        check(table, [build])
+        table.build(to_dev(more, dev), base_tid=n_build)          # after a probe: the next probe looks at the bounds again
+        check(table, [build, more])
+        table.clear()
+        table.build(to_dev(more, dev))
+        check(table, [more])
+        table.close()
 
 
-# ---- composite keys, residual predicates (HashJoinOperator_unittest.cpp:999-1375) -----------------------------
 def hip_composite_join(capi, dev, build_cols, probe_cols):
     """Composite-key inner join through the C ABI: fold the components into one LONG key
     (qsx_join_key_pack), single-key table, and — when the fold is a hash, not an exact packing —
