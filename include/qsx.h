@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
-#define QSX_ABI_VERSION 7
+#define QSX_ABI_VERSION 8
 
 typedef void *qsx_stream_t;
 
@@ -47,7 +47,8 @@ typedef enum qsx_status {
   QSX_ERR_CAPACITY = -5,     /* caller-provided output / table too small */
   QSX_ERR_UNSUPPORTED = -6,
   QSX_ERR_TOO_MANY_GROUPS = -7,
-  QSX_ERR_HASH_COLLISION = -8  /* wide group-by key: two keys shared a 64-bit hash (see QSX_GROUPS_HASH_COLLISION) */
+  QSX_ERR_HASH_COLLISION = -8, /* wide group-by key: two keys shared a 64-bit hash (see QSX_GROUPS_HASH_COLLISION) */
+  QSX_ERR_COMM = -9            /* RCCL missing or a collective failed (see qsx_last_error) */
 } qsx_status_t;
 
 /* Value types; numbering follows types/TypeID.hpp:32-43 (kInt, kLong, kFloat,
@@ -102,6 +103,11 @@ int qsx_stream_destroy(qsx_stream_t stream);
  * holds, after waiting for its streams — the call an engine makes on its out-of-memory path before retrying an allocation
  * (the library does the same before it gives up on an allocation of its own).  out_bytes_released may be NULL. */
 int qsx_trim_scratch(size_t *out_bytes_released);
+/* The other direction: when a device allocation INSIDE the library fails for lack of memory, `hook(user)` is called — from the
+ * failing thread, with no library lock held — and the allocation is attempted once more.  The engine's buffer manager gives
+ * back what it pools there (the host layer of this repo: its output-block slabs and scratch caches).  NULL removes the hook.
+ * The hook may call qsx_device_free and qsx_trim_scratch; it must not call back into the operation that is failing. */
+int qsx_set_out_of_memory_hook(void (*hook)(void *user), void *user);
 
 /* ======================================================================
  * Select: predicate + projection
@@ -852,6 +858,42 @@ int qsx_sort_top_k(int nkeys, const void *const *key_cols, const int32_t *key_ty
 int qsx_distinct_rows(int ncols, const void *const *cols, const int32_t *types, int64_t n,
                       const uint64_t *filter_dev, int32_t *out_tids_dev, int64_t *out_count_dev,
                       void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, GPU g = hash partition g of P = world (catalog/PartitionSchemeHeader.hpp:200-214),
+ * RCCL over xGMI bound at run time (librccl.so.1).  The reference has no data-plane collective — its partitions share an
+ * address space (storage/InsertDestination.hpp:490-660, BuildHashOperator.cpp:82-91, HashJoinOperator.cpp:220-231) — so
+ * these are the two exchange steps the path gains when a partition becomes a GPU:
+ *   join-key shuffle   qsx_partition_scatter (K9) -> qsx_exchange_counts -> qsx_alltoallv per column -> local build / probe
+ *   partial aggregates qsx_agg_reduce_scatter (dense states) / qsx_agg_allgather_merge (hash states) before finalize
+ * plus qsx_bitmap_allreduce_or for LIP filters (qsx_lip_filter_words) and qsx_allgather for broadcast build sides.
+ * Bootstrap: rank 0 calls qsx_comm_unique_id, the engine carries the 128 bytes to the other processes (its own control
+ * plane: TMB messages in the reference's distributed mode), every rank calls qsx_comm_create on its own device.
+ * All collectives are stream-ordered; counts arrays of qsx_alltoallv are HOST arrays (rows per peer).
+ * --------------------------------------------------------------------------- */
+#define QSX_COMM_ID_BYTES 128
+typedef struct qsx_comm qsx_comm_t;
+int qsx_comm_unique_id(void *out_id_bytes);
+int qsx_comm_create(int world, int rank, const void *id_bytes, qsx_comm_t **out);
+int qsx_comm_destroy(qsx_comm_t *comm);
+int qsx_comm_rank(const qsx_comm_t *comm, int *out_world, int *out_rank);
+/* recv_counts_dev[p] = send_counts_dev[p] of rank p's call (int64[world] device arrays): the row counts of a shuffle */
+int qsx_exchange_counts(qsx_comm_t *comm, const int64_t *send_counts_dev, int64_t *recv_counts_dev, qsx_stream_t stream);
+/* Rows of `width` bytes: send_rows[p] rows go to rank p (taken back to back from send_dev in rank order — the layout
+ * qsx_partition_scatter leaves), recv_rows[p] rows arrive from rank p (placed back to back in rank order). */
+int qsx_alltoallv(qsx_comm_t *comm, int width, const void *send_dev, const int64_t *send_rows, void *recv_dev,
+                  const int64_t *recv_rows, qsx_stream_t stream);
+/* recv_dev = the `bytes` of every rank, in rank order (world * bytes). */
+int qsx_allgather(qsx_comm_t *comm, const void *send_dev, size_t bytes, void *recv_dev, qsx_stream_t stream);
+/* words |= the words of every other rank (LIP bit vectors; RCCL has no bitwise reduction: gather + local OR). */
+int qsx_bitmap_allreduce_or(qsx_comm_t *comm, uint64_t *words_dev, int64_t num_words, qsx_stream_t stream);
+/* COLLISION_FREE state: afterwards this rank holds the MERGED groups of finalize partition `rank` of `world` and nothing
+ * else — finalize with qsx_agg_finalize(state, rank, world, ...).  Replaces the shared atomics of
+ * CollisionFreeVectorTable (storage/CollisionFreeVectorTable.hpp:530-645) across address spaces. */
+int qsx_agg_reduce_scatter(qsx_comm_t *comm, qsx_agg_state_t *state, qsx_stream_t stream);
+/* Hash-strategy state: afterwards every rank holds the whole merged table (AggregationOperationState.cpp:925-948's merge
+ * of the thread-private tables, across ranks).  Synchronises on `stream`. */
+int qsx_agg_allgather_merge(qsx_comm_t *comm, qsx_agg_state_t *state, qsx_stream_t stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

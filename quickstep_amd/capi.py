@@ -58,6 +58,7 @@ _SIGNATURES = {
     "qsx_stream_create": (_int, [_pp]),
     "qsx_stream_destroy": (_int, [_vp]),
     "qsx_trim_scratch": (_int, [C.POINTER(_sz)]),
+    "qsx_set_out_of_memory_hook": (_int, [_vp, _vp]),
     "qsx_select_cmp": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "qsx_select_cmp_sorted": (_int, [_int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "qsx_select_cmp_char": (_int, [_vp, _int, _i64, _int, C.c_char_p, _int, _vp, _vp, _vp, _vp]),
@@ -127,6 +128,16 @@ _SIGNATURES = {
     "qsx_lip_build_blocks": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _pp, _vp]),
     "qsx_lip_probe_blocks": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _pp, _pp, _vp, _vp]),
     "qsx_lip_filter_words": (_int, [_vp, _pp, C.POINTER(_i64)]),
+    "qsx_comm_unique_id": (_int, [_vp]),
+    "qsx_comm_create": (_int, [_int, _int, _vp, _pp]),
+    "qsx_comm_destroy": (_int, [_vp]),
+    "qsx_comm_rank": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    "qsx_exchange_counts": (_int, [_vp, _vp, _vp, _vp]),
+    "qsx_alltoallv": (_int, [_vp, _int, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _vp]),
+    "qsx_allgather": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "qsx_bitmap_allreduce_or": (_int, [_vp, _vp, _i64, _vp]),
+    "qsx_agg_reduce_scatter": (_int, [_vp, _vp, _vp]),
+    "qsx_agg_allgather_merge": (_int, [_vp, _vp, _vp]),
     "qsx_partition_workspace_bytes": (_sz, [_i64, _int]),
     "qsx_partition_scatter": (_int, [_int, _vp, _i64, _int, _int, _pp, C.POINTER(_i32), _pp, _vp, _vp, _sz, _vp]),
 }
@@ -915,3 +926,55 @@ def partition_scatter(keys, num_partitions, cols, stream=None):
                                       widths, _ptr_array(out_cols), _ptr(offsets), _ptr(ws), ws_bytes,
                                       _stream(stream)), "qsx_partition_scatter")
     return out_cols, offsets
+
+
+# --------------------------------------------------------------------------- multi-GPU (RCCL behind the C ABI)
+class Comm:
+    """qsx_comm_t: one per rank.  unique_id() on rank 0, carried to the other ranks by the caller's control plane
+    (torch.distributed's store, an engine's message bus), then Comm(world, rank, id_bytes) on every rank's own device."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(_lib.qsx_comm_unique_id(buf), "qsx_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, world, rank, id_bytes):
+        h = C.c_void_p()
+        self._h = None
+        _check(_lib.qsx_comm_create(world, rank, C.c_char_p(id_bytes), C.byref(h)), "qsx_comm_create")
+        self._h = h
+        self.world, self.rank = world, rank
+
+    def close(self):
+        if self._h is not None:
+            _lib.qsx_comm_destroy(self._h)
+            self._h = None
+
+    def exchange_counts(self, send_counts, stream=None):
+        recv = torch.empty_like(send_counts)
+        _check(_lib.qsx_exchange_counts(self._h, _ptr(send_counts), _ptr(recv), _stream(stream)), "qsx_exchange_counts")
+        return recv
+
+    def alltoallv(self, col, send_rows, recv_rows, stream=None):
+        """col: rows for rank 0, then rank 1, ... (qsx_partition_scatter's layout); returns the rows received, in rank order."""
+        out = torch.empty(int(sum(recv_rows)), dtype=col.dtype, device=col.device)
+        sr = (C.c_int64 * self.world)(*[int(x) for x in send_rows])
+        rr = (C.c_int64 * self.world)(*[int(x) for x in recv_rows])
+        _check(_lib.qsx_alltoallv(self._h, col.element_size(), _ptr(col), sr, _ptr(out), rr, _stream(stream)), "qsx_alltoallv")
+        return out
+
+    def allgather(self, t, stream=None):
+        out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+        _check(_lib.qsx_allgather(self._h, _ptr(t), t.numel() * t.element_size(), _ptr(out), _stream(stream)), "qsx_allgather")
+        return out
+
+    def bitmap_allreduce_or(self, words, stream=None):
+        _check(_lib.qsx_bitmap_allreduce_or(self._h, _ptr(words), words.numel(), _stream(stream)), "qsx_bitmap_allreduce_or")
+        return words
+
+    def agg_reduce_scatter(self, state, stream=None):
+        _check(_lib.qsx_agg_reduce_scatter(self._h, state._h, _stream(stream)), "qsx_agg_reduce_scatter")
+
+    def agg_allgather_merge(self, state, stream=None):
+        _check(_lib.qsx_agg_allgather_merge(self._h, state._h, _stream(stream)), "qsx_agg_allgather_merge")

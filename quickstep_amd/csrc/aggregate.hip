@@ -35,6 +35,7 @@
 #include "agg_hash_update.hpp"
 #include "agg_shapes.hpp"
 #include "agg_jit.hpp"
+#include "comm.hpp"
 #include "partition.hpp"
 #include "scan.hpp"
 
@@ -1352,18 +1353,18 @@ static hipError_t ensure_directory(qsx_agg_state *st) {
   if (st->dir_gids == 0) return hipSuccess;
   const unsigned long long want_cap = next_pow2(static_cast<uint64_t>(st->dir_gids) * 4);
   hipError_t err = hipSuccess;
-  if (st->dir_ngids == nullptr) err = hipMalloc(reinterpret_cast<void **>(&st->dir_ngids), kDirControlBytes);
+  if (st->dir_ngids == nullptr) err = device_malloc(reinterpret_cast<void **>(&st->dir_ngids), kDirControlBytes);
   if (err == hipSuccess && st->dir_cap != want_cap) {
-    (void)hipFree(st->dir_entries);
+    (void)device_free(st->dir_entries);
     st->dir_entries = nullptr;
     st->dir_cap = want_cap;
-    err = hipMalloc(reinterpret_cast<void **>(&st->dir_entries), want_cap * 16);
+    err = device_malloc(reinterpret_cast<void **>(&st->dir_entries), want_cap * 16);
   }
   if (err == hipSuccess && st->dir_codes_len < st->dir_gids) {
-    (void)hipFree(st->dir_codes);
+    (void)device_free(st->dir_codes);
     st->dir_codes = nullptr;
     st->dir_codes_len = st->dir_gids;
-    err = hipMalloc(reinterpret_cast<void **>(&st->dir_codes), sizeof(unsigned long long) * st->dir_gids);
+    err = device_malloc(reinterpret_cast<void **>(&st->dir_codes), sizeof(unsigned long long) * st->dir_gids);
   }
   if (err == hipSuccess) err = hipMemset(st->dir_entries, 0xFF, st->dir_cap * 16);
   if (err == hipSuccess) err = hipMemset(st->dir_ngids, 0, kDirControlBytes);
@@ -1406,17 +1407,17 @@ static int grow_and_drain(qsx_agg_state *st) {
     while (new_cap < 16 * groups) new_cap <<= 1;
     const size_t new_bytes = sizeof(unsigned long long) * (new_cap + 1) * (st->num_cols + 1);
     unsigned long long *bigger = nullptr, *old_log = nullptr;
-    QSX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&bigger), new_bytes));
+    QSX_HIP_TRY(device_malloc(reinterpret_cast<void **>(&bigger), new_bytes));
     hipError_t err = init_hash_image(st, bigger, new_cap, nullptr);
     if (err == hipSuccess && spilled != 0) {
       // the spilled records are re-inserted from a copy: what still finds no slot goes to the (reset) log again
-      err = hipMalloc(reinterpret_cast<void **>(&old_log), sizeof(unsigned long long) * spilled * (st->num_cols + 1));
+      err = device_malloc(reinterpret_cast<void **>(&old_log), sizeof(unsigned long long) * spilled * (st->num_cols + 1));
       if (err == hipSuccess) err = hipMemcpy(old_log, st->log, sizeof(unsigned long long) * spilled * (st->num_cols + 1), hipMemcpyDeviceToDevice);
     }
     if (err != hipSuccess) {
       set_last_error("grow_and_drain", err);
-      (void)hipFree(bigger);
-      (void)hipFree(old_log);
+      (void)device_free(bigger);
+      (void)device_free(old_log);
       return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
     }
     unsigned long long *old_image = st->image;
@@ -1439,8 +1440,8 @@ static int grow_and_drain(qsx_agg_state *st) {
       QSX_CHECK_LAUNCH();
     }
     QSX_HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(old_image);
-    (void)hipFree(old_log);
+    (void)device_free(old_image);
+    (void)device_free(old_log);
   }
   unsigned long long groups = 0;
   QSX_HIP_TRY(hipMemcpy(&groups, st->control, sizeof(groups), hipMemcpyDeviceToHost));
@@ -1522,11 +1523,11 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     derive_geometry(st, est);
     st->growable = config->strategy != QSX_AGG_SINGLE_STATE;
   }
-  hipError_t err = hipMalloc(reinterpret_cast<void **>(&st->image), st->image_bytes);
-  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&st->control), 8 * sizeof(unsigned long long));   // [4]: wide-key collision flag
+  hipError_t err = device_malloc(reinterpret_cast<void **>(&st->image), st->image_bytes);
+  if (err == hipSuccess) err = device_malloc(reinterpret_cast<void **>(&st->control), 8 * sizeof(unsigned long long));   // [4]: wide-key collision flag
   if (err == hipSuccess && !st->dense) err = ensure_directory(st);
   if (err == hipSuccess && st->growable) {
-    err = hipMalloc(reinterpret_cast<void **>(&st->log), sizeof(unsigned long long) * kLogRecords * (st->num_cols + 1));
+    err = device_malloc(reinterpret_cast<void **>(&st->log), sizeof(unsigned long long) * kLogRecords * (st->num_cols + 1));
     if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void **>(&st->published), 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
     if (err == hipSuccess) {
       std::memset(st->published, 0, 4 * sizeof(unsigned long long));
@@ -1550,9 +1551,9 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
   if (err == hipSuccess) err = hipDeviceSynchronize();
   if (err != hipSuccess) {
     set_last_error("qsx_agg_state_create", err);
-    (void)hipFree(st->image); (void)hipFree(st->control); (void)hipFree(st->tile_counts); (void)hipFree(st->tile_offsets);
-    (void)hipFree(st->log);
-    (void)hipFree(st->dir_entries); (void)hipFree(st->dir_codes); (void)hipFree(st->dir_ngids);
+    (void)device_free(st->image); (void)device_free(st->control); (void)device_free(st->tile_counts); (void)device_free(st->tile_offsets);
+    (void)device_free(st->log);
+    (void)device_free(st->dir_entries); (void)device_free(st->dir_codes); (void)device_free(st->dir_ngids);
     if (st->published != nullptr) (void)hipHostFree(st->published);
     delete st;
     return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
@@ -1564,14 +1565,14 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
 int qsx_agg_state_destroy(qsx_agg_state_t *st) {
   if (st == nullptr) return QSX_OK;
   (void)hipDeviceSynchronize();
-  (void)hipFree(st->image);
-  (void)hipFree(st->control);
-  (void)hipFree(st->tile_counts);
-  (void)hipFree(st->tile_offsets);
-  (void)hipFree(st->log);
-  (void)hipFree(st->dir_entries);
-  (void)hipFree(st->dir_codes);
-  (void)hipFree(st->dir_ngids);
+  (void)device_free_idle(st->image);
+  (void)device_free_idle(st->control);
+  (void)device_free_idle(st->tile_counts);
+  (void)device_free_idle(st->tile_offsets);
+  (void)device_free_idle(st->log);
+  (void)device_free_idle(st->dir_entries);
+  (void)device_free_idle(st->dir_codes);
+  (void)device_free_idle(st->dir_ngids);
   if (st->published != nullptr) (void)hipHostFree(st->published);
   delete st;
   return QSX_OK;
@@ -1996,6 +1997,145 @@ int qsx_agg_merge(qsx_agg_state_t *dst, qsx_agg_state_t *src, qsx_stream_t strea
   if (rc != QSX_OK) return rc;
   std::shared_lock<std::shared_mutex> lock(src->table_mutex);
   return qsx_agg_state_import_merge(dst, src->image, src->image_bytes, stream);
+}
+
+// ---- partial aggregates across GPUs ------------------------------------------------------------------------------------------
+// Dense (CollisionFreeVector) states: reduce-scatter.  Rank r ends up holding — and finalizes with partition = r,
+// num_partitions = world — the merged groups of key range r (CollisionFreeVectorTable.hpp:192-208's contiguous ranges), and
+// nothing else; per rank this moves 1 / world of what an all-reduce moves.  Every state column is reduced the way its
+// accumulator combines (f64 +, int64 +, MIN, MAX); the existence bits of the owned range are the OR of what every rank holds
+// for it (RCCL has no bitwise reduction: each rank sends every peer the words covering that peer's range).
+int qsx_agg_reduce_scatter(qsx_comm_t *comm, qsx_agg_state_t *st, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (comm == nullptr || st == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (!st->dense) return QSX_ERR_UNSUPPORTED;   // hash states: qsx_agg_allgather_merge
+  const int world = comm->world, rank = comm->rank;
+  if (world == 1) return QSX_OK;
+  const RcclApi *api = rccl();
+  if (api == nullptr) return QSX_ERR_COMM;
+  hipStream_t s = as_stream(stream);
+  const long long entries = st->config.num_entries, exist_words = st->exist_words;
+  const long long length = (entries + world - 1) / world, padded = length * world;
+  auto range_of = [&](int r, long long *begin, long long *end) {
+    *begin = static_cast<long long>(r) * length < entries ? static_cast<long long>(r) * length : entries;
+    *end = *begin + length < entries ? *begin + length : entries;
+  };
+  auto words_of = [&](int r, long long *first, long long *last) {
+    long long b, e;
+    range_of(r, &b, &e);
+    *first = e > b ? b / 64 : 0;
+    *last = e > b ? (e + 63) / 64 : 0;
+  };
+  long long begin, end, my_first, my_last;
+  range_of(rank, &begin, &end);
+  words_of(rank, &my_first, &my_last);
+  const long long my_words = my_last - my_first;
+  CallScratch scratch(s);
+  const size_t bytes_send = static_cast<size_t>(padded) * 8, bytes_mine = static_cast<size_t>(length) * 8,
+               bytes_parts = static_cast<size_t>(my_words > 0 ? my_words : 1) * 8 * world;
+  int rc = scratch.reserve(CallScratch::padded(bytes_send) + CallScratch::padded(bytes_mine) + CallScratch::padded(bytes_parts) +
+                           CallScratch::padded(st->image_bytes));
+  if (rc != QSX_OK) return rc;
+  unsigned long long *send = static_cast<unsigned long long *>(scratch.take(bytes_send));
+  unsigned long long *mine = static_cast<unsigned long long *>(scratch.take(bytes_mine));
+  unsigned long long *parts = static_cast<unsigned long long *>(scratch.take(bytes_parts));
+  unsigned long long *reduced = static_cast<unsigned long long *>(scratch.take(st->image_bytes));
+  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
+  // the reduced image: zero / identity everywhere, the owned key range filled in below
+  QSX_HIP_TRY(hipMemsetAsync(reduced, 0, st->image_bytes, s));
+  if (st->has_min_max) {
+    hipLaunchKernelGGL(fill_identity_kernel, dim3(grid_for(entries, kABlock * 4)), dim3(kABlock), 0, s, reduced + exist_words, entries, entries,
+                       st->num_cols, st->col_kinds);
+    QSX_CHECK_LAUNCH();
+  }
+  for (int col = 0; col < st->num_cols; ++col) {
+    const int kind = st->col_kinds.kind[col];
+    const unsigned long long *column = st->image + exist_words + static_cast<long long>(col) * entries;
+    QSX_HIP_TRY(hipMemcpyAsync(send, column, static_cast<size_t>(entries) * 8, hipMemcpyDeviceToDevice, s));
+    if (padded > entries) {   // the tail of the last range: the accumulator's identity
+      if (kind >= kAccMinI64) {
+        ColKinds one{};
+        one.kind[0] = kind;
+        hipLaunchKernelGGL(fill_identity_kernel, dim3(1), dim3(kABlock), 0, s, send + entries, padded - entries, padded - entries, 1, one);
+        QSX_CHECK_LAUNCH();
+      } else {
+        QSX_HIP_TRY(hipMemsetAsync(send + entries, 0, static_cast<size_t>(padded - entries) * 8, s));
+      }
+    }
+    const ncclDataType_t type = kind == kAccSumF64 ? ncclFloat64 : ncclInt64;
+    const ncclRedOp_t op = kind == kAccMinI64 ? ncclMin : (kind == kAccMaxI64 ? ncclMax : ncclSum);
+    QSX_RCCL_TRY(api->ReduceScatter(send, mine, static_cast<size_t>(length), type, op, comm->comm, s), "ncclReduceScatter");
+    if (end > begin) {
+      QSX_HIP_TRY(hipMemcpyAsync(reduced + exist_words + static_cast<long long>(col) * entries + begin, mine, static_cast<size_t>(end - begin) * 8,
+                                 hipMemcpyDeviceToDevice, s));
+    }
+  }
+  // existence words of every peer's range -> that peer; the owner ORs them
+  QSX_RCCL_TRY(api->GroupStart(), "ncclGroupStart");
+  for (int p = 0; p < world; ++p) {
+    long long first, last;
+    words_of(p, &first, &last);
+    if (last > first) QSX_RCCL_TRY(api->Send(st->image + first, static_cast<size_t>(last - first), ncclUint64, p, comm->comm, s), "ncclSend");
+    if (my_words > 0) QSX_RCCL_TRY(api->Recv(parts + static_cast<long long>(p) * my_words, static_cast<size_t>(my_words), ncclUint64, p, comm->comm, s), "ncclRecv");
+  }
+  QSX_RCCL_TRY(api->GroupEnd(), "ncclGroupEnd");
+  if (my_words > 0) {
+    // LSB-first existence words: keep bits [begin, end) only
+    const unsigned long long first_mask = ~0ull << (begin & 63);
+    const unsigned long long last_mask = (end & 63) != 0 ? ~0ull >> (64 - (end & 63)) : ~0ull;
+    hipLaunchKernelGGL(or_words_kernel, dim3(grid_for(my_words, 256)), dim3(256), 0, s, parts, world, my_words, first_mask, last_mask,
+                       reduced + my_first);
+    QSX_CHECK_LAUNCH();
+  }
+  // the state becomes the reduced image
+  QSX_HIP_TRY(hipMemcpyAsync(st->image, reduced, st->image_bytes, hipMemcpyDeviceToDevice, s));
+  return QSX_OK;
+}
+
+// Hash-table states (Q1-sized: a few KiB): every rank gathers every image and merges the others' into its own — afterwards
+// all ranks hold the whole merged table (the counterpart of merging the thread-private tables at finalize,
+// storage/AggregationOperationState.cpp:925-948).  Images may differ in size (a table that grew): sizes first.
+int qsx_agg_allgather_merge(qsx_comm_t *comm, qsx_agg_state_t *st, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (comm == nullptr || st == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (st->dense) return QSX_ERR_UNSUPPORTED;    // dense states: qsx_agg_reduce_scatter
+  const int world = comm->world, rank = comm->rank;
+  if (world == 1) return QSX_OK;
+  const RcclApi *api = rccl();
+  if (api == nullptr) return QSX_ERR_COMM;
+  hipStream_t s = as_stream(stream);
+  size_t my_bytes = 0;
+  int rc = qsx_agg_state_export_bytes(st, &my_bytes, stream);
+  if (rc != QSX_OK) return rc;
+  // sizes: through device memory (one word per rank)
+  unsigned long long *sizes_dev = nullptr;
+  QSX_HIP_TRY(device_malloc(&sizes_dev, sizeof(unsigned long long) * (world + 1)));
+  const unsigned long long mine_size = my_bytes;
+  QSX_HIP_TRY(hipMemcpyAsync(sizes_dev + world, &mine_size, 8, hipMemcpyHostToDevice, s));
+  int status = rccl_status(api->AllGather(sizes_dev + world, sizes_dev, 1, ncclUint64, comm->comm, s), "ncclAllGather");
+  std::vector<unsigned long long> sizes(static_cast<size_t>(world));
+  if (status == QSX_OK && (hipMemcpyAsync(sizes.data(), sizes_dev, 8 * world, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) {
+    status = QSX_ERR_HIP;
+  }
+  (void)device_free(sizes_dev);
+  if (status != QSX_OK) return status;
+  size_t pad = 0;
+  for (unsigned long long v : sizes) pad = v > pad ? static_cast<size_t>(v) : pad;
+  unsigned char *gathered = nullptr, *padded_image = nullptr;
+  QSX_HIP_TRY(device_malloc(&gathered, pad * world));
+  if (device_malloc(&padded_image, pad) != hipSuccess) {
+    (void)device_free(gathered);
+    return QSX_ERR_OUT_OF_MEMORY;
+  }
+  status = qsx_agg_state_export(st, padded_image, my_bytes, stream);
+  if (status == QSX_OK) status = rccl_status(api->AllGather(padded_image, gathered, pad, ncclUint8, comm->comm, s), "ncclAllGather");
+  for (int r = 0; r < world && status == QSX_OK; ++r) {
+    if (r != rank) status = qsx_agg_state_import_merge(st, gathered + static_cast<size_t>(r) * pad, static_cast<size_t>(sizes[r]), stream);
+  }
+  if (hipStreamSynchronize(s) != hipSuccess && status == QSX_OK) status = QSX_ERR_HIP;
+  (void)device_free(gathered);
+  (void)device_free(padded_image);
+  return status;
 }
 
 int qsx_agg_num_groups(qsx_agg_state_t *st, int64_t *out_groups, qsx_stream_t stream) {

@@ -1,0 +1,185 @@
+// comm.hip — the exchange steps of the multi-GPU path behind the C ABI (include/qsx.h "multi-GPU"): one process per GPU,
+// RCCL over xGMI.  The reference has no data-plane collective — its partitions share one address space
+// (storage/InsertDestination.hpp:490-660 routes tuples, BuildHashOperator.cpp:82-91 / HashJoinOperator.cpp:220-231 make
+// per-partition work orders) — so these entry points are this repo's design: what a C++ host needs to turn "partition p" into
+// "GPU p" (quickstep_amd/distributed.py does the same through torch.distributed for the Python callers).
+#include "comm.hpp"
+
+#include <dlfcn.h>
+
+#include <mutex>
+#include <vector>
+
+namespace qsx {
+
+void set_last_error(const char *what, hipError_t err);
+
+const RcclApi *rccl() {
+  static RcclApi api;
+  static bool ok = false;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // the copy the process already holds, if any
+    if (lib == nullptr) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (lib == nullptr) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (lib == nullptr) {
+      set_last_error_text("librccl.so.1 not found (multi-GPU entry points need RCCL)");
+      return;
+    }
+    bool all = true;
+    auto bind = [&](auto &slot, const char *name) {
+      slot = reinterpret_cast<std::remove_reference_t<decltype(slot)>>(dlsym(lib, name));
+      all = all && slot != nullptr;
+    };
+    bind(api.GetUniqueId, "ncclGetUniqueId");
+    bind(api.CommInitRank, "ncclCommInitRank");
+    bind(api.CommDestroy, "ncclCommDestroy");
+    bind(api.GroupStart, "ncclGroupStart");
+    bind(api.GroupEnd, "ncclGroupEnd");
+    bind(api.Send, "ncclSend");
+    bind(api.Recv, "ncclRecv");
+    bind(api.AllGather, "ncclAllGather");
+    bind(api.ReduceScatter, "ncclReduceScatter");
+    bind(api.AllReduce, "ncclAllReduce");
+    bind(api.GetErrorString, "ncclGetErrorString");
+    if (!all) set_last_error_text("librccl.so.1 lacks a symbol the multi-GPU entry points need");
+    ok = all;
+  });
+  return ok ? &api : nullptr;
+}
+
+int rccl_status(ncclResult_t r, const char *what) {
+  if (r == ncclSuccess) return QSX_OK;
+  const RcclApi *api = rccl();
+  std::string text = std::string(what) + ": " + (api != nullptr ? api->GetErrorString(r) : "RCCL error");
+  set_last_error_text(text.c_str());
+  return QSX_ERR_COMM;
+}
+
+}  // namespace qsx
+
+using namespace qsx;
+
+extern "C" {
+
+int qsx_comm_unique_id(void *out_id) {
+  QSX_REQUIRE_DEVICE();
+  if (out_id == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  const RcclApi *api = rccl();
+  if (api == nullptr) return QSX_ERR_COMM;
+  static_assert(sizeof(ncclUniqueId) == QSX_COMM_ID_BYTES, "QSX_COMM_ID_BYTES mirrors NCCL_UNIQUE_ID_BYTES");
+  ncclUniqueId id;
+  QSX_RCCL_TRY(api->GetUniqueId(&id), "ncclGetUniqueId");
+  std::memcpy(out_id, &id, sizeof(id));
+  return QSX_OK;
+}
+
+int qsx_comm_create(int world, int rank, const void *id_bytes, qsx_comm_t **out) {
+  QSX_REQUIRE_DEVICE();
+  if (out == nullptr || id_bytes == nullptr || world < 1 || rank < 0 || rank >= world) return QSX_ERR_INVALID_ARGUMENT;
+  const RcclApi *api = rccl();
+  if (api == nullptr) return QSX_ERR_COMM;
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof(id));
+  qsx_comm *c = new qsx_comm;
+  c->world = world;
+  c->rank = rank;
+  const int rc = rccl_status(api->CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
+  if (rc != QSX_OK) {
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return QSX_OK;
+}
+
+int qsx_comm_destroy(qsx_comm_t *c) {
+  if (c == nullptr) return QSX_OK;
+  const RcclApi *api = rccl();
+  if (api != nullptr && c->comm != nullptr) (void)api->CommDestroy(c->comm);
+  delete c;
+  return QSX_OK;
+}
+
+int qsx_comm_rank(const qsx_comm_t *c, int *out_world, int *out_rank) {
+  if (c == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (out_world != nullptr) *out_world = c->world;
+  if (out_rank != nullptr) *out_rank = c->rank;
+  return QSX_OK;
+}
+
+int qsx_exchange_counts(qsx_comm_t *c, const int64_t *send_counts_dev, int64_t *recv_counts_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (c == nullptr || send_counts_dev == nullptr || recv_counts_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  const RcclApi *api = rccl();
+  if (api == nullptr) return QSX_ERR_COMM;
+  hipStream_t s = as_stream(stream);
+  QSX_RCCL_TRY(api->GroupStart(), "ncclGroupStart");
+  for (int p = 0; p < c->world; ++p) {
+    QSX_RCCL_TRY(api->Send(send_counts_dev + p, 1, ncclInt64, p, c->comm, s), "ncclSend");
+    QSX_RCCL_TRY(api->Recv(recv_counts_dev + p, 1, ncclInt64, p, c->comm, s), "ncclRecv");
+  }
+  QSX_RCCL_TRY(api->GroupEnd(), "ncclGroupEnd");
+  return QSX_OK;
+}
+
+int qsx_alltoallv(qsx_comm_t *c, int width, const void *send_dev, const int64_t *send_rows, void *recv_dev, const int64_t *recv_rows,
+                  qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (c == nullptr || width < 1 || send_rows == nullptr || recv_rows == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  const RcclApi *api = rccl();
+  if (api == nullptr) return QSX_ERR_COMM;
+  hipStream_t s = as_stream(stream);
+  const char *send = static_cast<const char *>(send_dev);
+  char *recv = static_cast<char *>(recv_dev);
+  int64_t send_at = 0, recv_at = 0;
+  QSX_RCCL_TRY(api->GroupStart(), "ncclGroupStart");
+  for (int p = 0; p < c->world; ++p) {
+    if (send_rows[p] < 0 || recv_rows[p] < 0) {
+      (void)api->GroupEnd();
+      return QSX_ERR_INVALID_ARGUMENT;
+    }
+    if (send_rows[p] > 0) {
+      QSX_RCCL_TRY(api->Send(send + send_at * width, static_cast<size_t>(send_rows[p]) * width, ncclUint8, p, c->comm, s), "ncclSend");
+    }
+    if (recv_rows[p] > 0) {
+      QSX_RCCL_TRY(api->Recv(recv + recv_at * width, static_cast<size_t>(recv_rows[p]) * width, ncclUint8, p, c->comm, s), "ncclRecv");
+    }
+    send_at += send_rows[p];
+    recv_at += recv_rows[p];
+  }
+  QSX_RCCL_TRY(api->GroupEnd(), "ncclGroupEnd");
+  return QSX_OK;
+}
+
+int qsx_allgather(qsx_comm_t *c, const void *send_dev, size_t bytes, void *recv_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (c == nullptr || (bytes > 0 && (send_dev == nullptr || recv_dev == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
+  if (bytes == 0) return QSX_OK;
+  const RcclApi *api = rccl();
+  if (api == nullptr) return QSX_ERR_COMM;
+  QSX_RCCL_TRY(api->AllGather(send_dev, recv_dev, bytes, ncclUint8, c->comm, as_stream(stream)), "ncclAllGather");
+  return QSX_OK;
+}
+
+int qsx_bitmap_allreduce_or(qsx_comm_t *c, uint64_t *words_dev, int64_t num_words, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (c == nullptr || num_words < 0 || (num_words > 0 && words_dev == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+  if (num_words == 0 || c->world == 1) return QSX_OK;
+  const RcclApi *api = rccl();
+  if (api == nullptr) return QSX_ERR_COMM;
+  // RCCL reduces with SUM / PROD / MIN / MAX / AVG only: the words are gathered and OR-ed here
+  hipStream_t s = as_stream(stream);
+  CallScratch scratch(s);
+  const size_t bytes = static_cast<size_t>(num_words) * 8 * c->world;
+  const int rc = scratch.reserve(CallScratch::padded(bytes));
+  if (rc != QSX_OK) return rc;
+  unsigned long long *all = static_cast<unsigned long long *>(scratch.take(bytes));
+  QSX_RCCL_TRY(api->AllGather(words_dev, all, static_cast<size_t>(num_words), ncclUint64, c->comm, s), "ncclAllGather");
+  hipLaunchKernelGGL(or_words_kernel, dim3(grid_for(num_words, 256)), dim3(256), 0, s, all, c->world, static_cast<long long>(num_words), ~0ull, ~0ull,
+                     reinterpret_cast<unsigned long long *>(words_dev));
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+}  // extern "C"

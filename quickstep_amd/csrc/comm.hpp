@@ -1,0 +1,59 @@
+// comm.hpp — RCCL, bound at run time (dlopen of librccl.so.1): libqsx.so carries no link-time dependency on it, a process
+// that never shards never loads it, and inside a process that already holds a copy (PyTorch ships one under the same
+// SONAME) the loader hands back that copy instead of a second one.
+#ifndef QSX_CSRC_COMM_HPP_
+#define QSX_CSRC_COMM_HPP_
+
+#include <rccl/rccl.h>
+
+#include "common.hpp"
+
+namespace qsx {
+
+struct RcclApi {
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+// nullptr (and qsx_last_error set) when the library or one of the symbols is missing.
+const RcclApi *rccl();
+int rccl_status(ncclResult_t r, const char *what);   // QSX_OK or QSX_ERR_COMM with qsx_last_error set
+void set_last_error_text(const char *text);
+
+// out[w] = OR over r of parts[r * words + w], AND mask of the first / last word (bits of the neighbouring key ranges that
+// share a boundary word are dropped)
+static __global__ __launch_bounds__(256) void or_words_kernel(const unsigned long long *__restrict__ parts, int num_parts, long long words,
+                                                       unsigned long long first_mask, unsigned long long last_mask,
+                                                       unsigned long long *__restrict__ out) {
+  for (long long w = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; w < words; w += static_cast<long long>(gridDim.x) * 256) {
+    unsigned long long v = 0;
+    for (int r = 0; r < num_parts; ++r) v |= parts[static_cast<long long>(r) * words + w];
+    if (w == 0) v &= first_mask;
+    if (w == words - 1) v &= last_mask;
+    out[w] = v;
+  }
+}
+
+}  // namespace qsx
+
+struct qsx_comm {
+  ncclComm_t comm = nullptr;
+  int world = 1;
+  int rank = 0;
+};
+
+#define QSX_RCCL_TRY(call, what)                              \
+  do {                                                         \
+    const int rc_rccl__ = qsx::rccl_status((call), what);      \
+    if (rc_rccl__ != QSX_OK) return rc_rccl__;                 \
+  } while (0)
+
+#endif  // QSX_CSRC_COMM_HPP_

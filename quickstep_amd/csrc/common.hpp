@@ -72,6 +72,22 @@ __global__ void store_struct_kernel(T value, T *__restrict__ dst) {
   uint32_t *out = reinterpret_cast<uint32_t *>(dst);
   for (unsigned i = threadIdx.x; i < sizeof(T) / 4; i += blockDim.x) out[i] = src[i];
 }
+// Every device allocation of the library: hipMalloc, and on hipErrorOutOfMemory the engine's relief hook
+// (qsx_set_out_of_memory_hook: the host layer gives back its pooled output-block allocations and scratch caches) before one
+// more attempt.  The library's own per-thread buffers are trimmed by the call sites that can afford it (CallScratch,
+// device_slot): a call that has uploaded a table into its staging buffer must not lose it to a nested allocation.
+hipError_t device_malloc(void **ptr, size_t bytes);
+template <typename T>
+inline hipError_t device_malloc(T **ptr, size_t bytes) { return device_malloc(reinterpret_cast<void **>(ptr), bytes); }
+// The counterpart.  device_free_idle: no queued work uses the memory any more (the destroy entry points have waited for the
+// device) — the allocation is kept for the next device_malloc of exactly its size instead of going back to the runtime:
+// an engine creates and destroys a join table and an aggregation state per query, and a hipMalloc / hipFree pair of a few MB
+// costs 0.2-0.5 ms (tools/ubench/alloc_cost.hip; the DestroyHash / DestroyAggregationState work orders of the operator bench
+// took 1 ms each).  At most kIdleKeepBytes are kept; qsx_trim_scratch and an out-of-memory condition release them.
+hipError_t device_free(void *ptr);
+hipError_t device_free_idle(void *ptr);
+size_t trim_idle_allocations();
+
 // ---- per-(host thread, stream) device resources --------------------------------------------------------------------------
 // Calls issued by one thread on one stream are ordered on the device, so such a pair can own buffers that every call
 // reuses without an allocator on the hot path: a grow-only scratch arena, a pinned + device staging pair for host tables,
@@ -104,11 +120,11 @@ static T *device_slot(hipStream_t stream) {
   static const char tag = 0;
   void *&p = thread_device_slot(stream, &tag);
   if (p != nullptr) return static_cast<T *>(p);
-  if (hipMalloc(&p, sizeof(T)) != hipSuccess) {
+  if (device_malloc(&p, sizeof(T)) != hipSuccess) {
     (void)hipGetLastError();
     (void)trim_thread_resources();
     void *&q = thread_device_slot(stream, &tag);   // (the trim dropped the entry)
-    if (hipMalloc(&q, sizeof(T)) != hipSuccess) {
+    if (device_malloc(&q, sizeof(T)) != hipSuccess) {
       q = nullptr;
       return nullptr;
     }
@@ -127,7 +143,7 @@ static StagedBuffer *staged_buffer_for(hipStream_t stream, size_t bytes) {
   if (b.copied != nullptr) (void)hipEventSynchronize(b.copied);
   if (b.device != nullptr) {
     (void)hipStreamSynchronize(stream);   // kernels of earlier calls may still read the old table
-    (void)hipFree(b.device);
+    (void)device_free(b.device);
     (void)hipHostFree(b.pinned);
     b.device = b.pinned = nullptr;
     b.capacity = 0;
@@ -136,7 +152,7 @@ static StagedBuffer *staged_buffer_for(hipStream_t stream, size_t bytes) {
   while (cap < bytes) cap *= 2;
   if (b.copied == nullptr && hipEventCreateWithFlags(&b.copied, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipHostMalloc(&b.pinned, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
-  if (hipMalloc(&b.device, cap) != hipSuccess) {
+  if (device_malloc(&b.device, cap) != hipSuccess) {
     (void)hipGetLastError();
     (void)hipHostFree(b.pinned);
     b.pinned = nullptr;
@@ -180,7 +196,7 @@ class CallScratch {
   ~CallScratch() {
     if (one_off_ != nullptr) {
       (void)hipStreamSynchronize(stream_);
-      (void)hipFree(one_off_);
+      (void)device_free(one_off_);
     }
   }
   // Bytes a take() of `bytes` consumes of the reservation.
@@ -190,10 +206,10 @@ class CallScratch {
     total = padded(total ? total : 1);
     used_ = 0;
     if (total > kScratchKeepBytes) {
-      if (hipMalloc(&one_off_, total) != hipSuccess) {
+      if (device_malloc(&one_off_, total) != hipSuccess) {
         (void)hipGetLastError();
         (void)trim_thread_resources();   // what this thread keeps for later calls goes first
-        QSX_HIP_TRY(hipMalloc(&one_off_, total));
+        QSX_HIP_TRY(device_malloc(&one_off_, total));
       }
       base_ = static_cast<char *>(one_off_);
       capacity_ = total;
@@ -203,19 +219,19 @@ class CallScratch {
     if (a->capacity < total) {
       if (a->base != nullptr) {
         QSX_HIP_TRY(hipStreamSynchronize(stream_));   // kernels of earlier calls may still use the old arena
-        QSX_HIP_TRY(hipFree(a->base));
+        QSX_HIP_TRY(device_free(a->base));
         a->base = nullptr;
         a->capacity = 0;
       }
       size_t cap = 1 << 20;
       while (cap < total && cap < kScratchPow2Bytes) cap *= 2;
       if (cap < total) cap = (total + (size_t(64) << 20) - 1) / (size_t(64) << 20) * (size_t(64) << 20);
-      if (hipMalloc(&a->base, cap) != hipSuccess) {
+      if (device_malloc(&a->base, cap) != hipSuccess) {
         (void)hipGetLastError();
         a->base = nullptr;
         (void)trim_thread_resources();
         a = &thread_scratch_arena(stream_);
-        QSX_HIP_TRY(hipMalloc(&a->base, cap));
+        QSX_HIP_TRY(device_malloc(&a->base, cap));
       }
       a->capacity = cap;
     }

@@ -619,7 +619,7 @@ static uint64_t capacity_for(int64_t entries) {
 }
 
 static int allocate_slots(qsx_join_table *t, uint64_t capacity, void **out) {
-  QSX_HIP_TRY(hipMalloc(out, capacity * t->entry_bytes()));
+  QSX_HIP_TRY(device_malloc(out, capacity * t->entry_bytes()));
   QSX_HIP_TRY(hipMemset(*out, 0xFF, capacity * t->entry_bytes()));
   return QSX_OK;
 }
@@ -638,11 +638,11 @@ static int ensure_room_dense(qsx_join_table *t, int64_t additional) {
   if (want > 0x7FFFFFFFull) want = 0x7FFFFFFFull;
   if (want < static_cast<uint64_t>(t->reserved + additional)) return QSX_ERR_CAPACITY;
   uint2 *bigger = nullptr;
-  QSX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&bigger), want * sizeof(uint2)));
+  QSX_HIP_TRY(device_malloc(reinterpret_cast<void **>(&bigger), want * sizeof(uint2)));
   if (t->ov_capacity != 0) {
     QSX_HIP_TRY(hipMemcpy(bigger, t->ov, static_cast<size_t>(t->ov_capacity) * sizeof(uint2), hipMemcpyDeviceToDevice));
   }
-  (void)hipFree(t->ov);
+  (void)device_free(t->ov);
   t->ov = bigger;
   t->ov_capacity = static_cast<unsigned int>(want);
   t->reserved += additional;
@@ -678,7 +678,7 @@ static int ensure_room(qsx_join_table *t, int64_t additional) {
                      t->key_type == QSX_LONG ? 1 : 0, src, dst);
   QSX_CHECK_LAUNCH();
   QSX_HIP_TRY(hipDeviceSynchronize());
-  QSX_HIP_TRY(hipFree(old_slots));
+  QSX_HIP_TRY(device_free(old_slots));
   t->reserved += additional;
   return QSX_OK;
 }
@@ -694,12 +694,12 @@ int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **
   t->capacity = capacity_for(est_entries);
   int rc = allocate_slots(t, t->capacity, &t->slots);
   if (rc != QSX_OK) { delete t; return rc; }
-  hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
+  hipError_t err = device_malloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
   if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, 4 * sizeof(unsigned long long));
   if (err == hipSuccess) err = hipMemset(t->entries_dev + 4, 0xFF, 2 * sizeof(unsigned long long));
   if (err != hipSuccess) {
-    set_last_error("hipMalloc(entries)", err);
-    (void)hipFree(t->slots);
+    set_last_error("device_malloc(entries)", err);
+    (void)device_free(t->slots);
     delete t;
     return QSX_ERR_HIP;
   }
@@ -726,17 +726,17 @@ int qsx_join_table_create_dense(int key_type, int64_t min_key, int64_t max_key, 
   t->stride_shift = stride_shift;
   t->range = range;
   t->ov_capacity = static_cast<unsigned int>(est_entries < 1024 ? 1024 : (est_entries > 0x7FFFFFFF ? 0x7FFFFFFF : est_entries));
-  hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->head), range * sizeof(uint32_t));
+  hipError_t err = device_malloc(reinterpret_cast<void **>(&t->head), range * sizeof(uint32_t));
   if (err == hipSuccess) err = hipMemset(t->head, 0, range * sizeof(uint32_t));
-  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&t->ov), static_cast<size_t>(t->ov_capacity) * sizeof(uint2));
-  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
+  if (err == hipSuccess) err = device_malloc(reinterpret_cast<void **>(&t->ov), static_cast<size_t>(t->ov_capacity) * sizeof(uint2));
+  if (err == hipSuccess) err = device_malloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
   if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, 4 * sizeof(unsigned long long));
   if (err == hipSuccess) err = hipMemset(t->entries_dev + 4, 0xFF, 2 * sizeof(unsigned long long));
   if (err != hipSuccess) {
-    set_last_error("hipMalloc(dense join table)", err);
-    (void)hipFree(t->head);
-    (void)hipFree(t->ov);
-    (void)hipFree(t->entries_dev);
+    set_last_error("device_malloc(dense join table)", err);
+    (void)device_free(t->head);
+    (void)device_free(t->ov);
+    (void)device_free(t->entries_dev);
     delete t;
     return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
   }
@@ -825,10 +825,10 @@ int qsx_join_table_destroy(qsx_join_table_t *t) {
   if (t == nullptr) return QSX_OK;
   (void)hipDeviceSynchronize();
   if (t->shadow != nullptr) (void)qsx_join_table_destroy(t->shadow);
-  (void)hipFree(t->slots);
-  (void)hipFree(t->head);
-  (void)hipFree(t->ov);
-  (void)hipFree(t->entries_dev);
+  (void)device_free_idle(t->slots);
+  (void)device_free_idle(t->head);
+  (void)device_free_idle(t->ov);
+  (void)device_free_idle(t->entries_dev);
   delete t;
   return QSX_OK;
 }

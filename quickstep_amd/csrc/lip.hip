@@ -249,7 +249,7 @@ int qsx_lip_filter_create(int kind, int64_t cardinality, int64_t min_value, int 
   f->min_value = min_value;
   f->is_anti = is_anti ? 1 : 0;
   f->num_words = (cardinality + 63) / 64;
-  hipError_t err = hipMalloc(reinterpret_cast<void **>(&f->words), sizeof(unsigned long long) * f->num_words);
+  hipError_t err = device_malloc(reinterpret_cast<void **>(&f->words), sizeof(unsigned long long) * f->num_words);
   if (err == hipSuccess) err = hipMemset(f->words, 0, sizeof(unsigned long long) * f->num_words);
   if (err == hipSuccess) err = hipDeviceSynchronize();
   if (err != hipSuccess) {
@@ -264,7 +264,7 @@ int qsx_lip_filter_create(int kind, int64_t cardinality, int64_t min_value, int 
 int qsx_lip_filter_destroy(qsx_lip_filter_t *f) {
   if (f == nullptr) return QSX_OK;
   (void)hipDeviceSynchronize();
-  (void)hipFree(f->words);
+  (void)device_free_idle(f->words);
   delete f;
   return QSX_OK;
 }

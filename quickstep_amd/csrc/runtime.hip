@@ -6,10 +6,13 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 namespace qsx {
 
 static thread_local std::string g_last_error;
+
+void set_last_error_text(const char *text) { g_last_error = text; }
 
 void set_last_error(const char *what, hipError_t err) {
   g_last_error = std::string(what) + ": " + hipGetErrorString(err);
@@ -48,7 +51,7 @@ struct ThreadResources {
 
   static size_t drop(ScratchArena &a) {
     const size_t bytes = a.capacity;
-    if (a.base != nullptr) (void)hipFree(a.base);
+    if (a.base != nullptr) (void)device_free(a.base);
     a = ScratchArena();
     return bytes;
   }
@@ -58,7 +61,7 @@ struct ThreadResources {
       (void)hipEventSynchronize(b.copied);
       (void)hipEventDestroy(b.copied);
     }
-    if (b.device != nullptr) (void)hipFree(b.device);
+    if (b.device != nullptr) (void)device_free(b.device);
     if (b.pinned != nullptr) (void)hipHostFree(b.pinned);
     b = StagedBuffer();
     return bytes;
@@ -87,7 +90,7 @@ struct ThreadResources {
     for (auto it = slots.begin(); it != slots.end();) {
       if (match_all || it->first.first == stream) {
         (void)hipStreamSynchronize(it->first.first);
-        if (it->second != nullptr) (void)hipFree(it->second);
+        if (it->second != nullptr) (void)device_free(it->second);
         it = slots.erase(it);
       } else {
         ++it;
@@ -110,6 +113,112 @@ void *&thread_device_slot(hipStream_t stream, const void *type_tag) { return thr
 void release_thread_stream(hipStream_t stream) { (void)thread_resources().release(stream, false); }
 size_t trim_thread_resources() { return thread_resources().release(nullptr, true); }
 
+namespace {
+std::mutex g_hook_mutex;
+void (*g_oom_hook)(void *) = nullptr;
+void *g_oom_hook_user = nullptr;
+}  // namespace
+
+namespace {
+constexpr size_t kIdleKeepBytes = size_t(2) << 30;
+struct Allocations {
+  std::mutex mutex;
+  std::map<void *, size_t> size_of;                       // every live device_malloc
+  std::map<size_t, std::vector<void *>> idle;             // given back by device_free_idle, by exact size
+  size_t idle_bytes = 0;
+};
+Allocations &allocations() {
+  static Allocations *a = new Allocations;   // never destroyed: frees may arrive during process teardown
+  return *a;
+}
+}  // namespace
+
+size_t trim_idle_allocations() {
+  Allocations &a = allocations();
+  std::vector<void *> doomed;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lock(a.mutex);
+    for (auto &cls : a.idle) {
+      for (void *p : cls.second) doomed.push_back(p);
+    }
+    a.idle.clear();
+    bytes = a.idle_bytes;
+    a.idle_bytes = 0;
+  }
+  for (void *p : doomed) (void)hipFree(p);
+  return bytes;
+}
+
+hipError_t device_free(void *ptr) {
+  if (ptr == nullptr) return hipSuccess;
+  {
+    Allocations &a = allocations();
+    std::lock_guard<std::mutex> lock(a.mutex);
+    a.size_of.erase(ptr);
+  }
+  return hipFree(ptr);
+}
+
+hipError_t device_free_idle(void *ptr) {
+  if (ptr == nullptr) return hipSuccess;
+  {
+    Allocations &a = allocations();
+    std::lock_guard<std::mutex> lock(a.mutex);
+    auto it = a.size_of.find(ptr);
+    if (it != a.size_of.end() && a.idle_bytes + it->second <= kIdleKeepBytes) {
+      a.idle[it->second].push_back(ptr);
+      a.idle_bytes += it->second;
+      a.size_of.erase(it);
+      return hipSuccess;
+    }
+    if (it != a.size_of.end()) a.size_of.erase(it);
+  }
+  return hipFree(ptr);
+}
+
+hipError_t device_malloc(void **ptr, size_t bytes) {
+  Allocations &a = allocations();
+  {
+    std::lock_guard<std::mutex> lock(a.mutex);
+    auto it = a.idle.find(bytes);
+    if (it != a.idle.end() && !it->second.empty()) {
+      *ptr = it->second.back();
+      it->second.pop_back();
+      a.idle_bytes -= bytes;
+      a.size_of[*ptr] = bytes;
+      return hipSuccess;
+    }
+  }
+  hipError_t err = hipMalloc(ptr, bytes);
+  if (err == hipErrorOutOfMemory && trim_idle_allocations() != 0) {
+    (void)hipGetLastError();
+    err = hipMalloc(ptr, bytes);
+  }
+  if (err == hipSuccess) {
+    std::lock_guard<std::mutex> lock(a.mutex);
+    a.size_of[*ptr] = bytes;
+    return err;
+  }
+  if (err != hipErrorOutOfMemory) return err;
+  (void)hipGetLastError();
+  void (*hook)(void *) = nullptr;
+  void *user = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_hook_mutex);
+    hook = g_oom_hook;
+    user = g_oom_hook_user;
+  }
+  if (hook == nullptr) return err;
+  hook(user);
+  err = hipMalloc(ptr, bytes);
+  if (err == hipSuccess) {
+    std::lock_guard<std::mutex> lock(a.mutex);
+    a.size_of[*ptr] = bytes;
+  }
+  return err;
+}
+
 int device_ready() {
   if (usable_devices() > 0) return QSX_OK;
   g_last_error = "no gfx950 (MI355X) device is visible to HIP; the execution kernel has no CPU path";
@@ -131,6 +240,7 @@ const char *qsx_status_string(int status) {
     case QSX_ERR_UNSUPPORTED: return "unsupported type / configuration";
     case QSX_ERR_TOO_MANY_GROUPS: return "aggregation table overflow: more groups than the state can hold";
     case QSX_ERR_HASH_COLLISION: return "wide group-by key: two keys shared a 64-bit hash, the result is void (re-run the operator)";
+    case QSX_ERR_COMM: return "RCCL unavailable or a collective failed (see qsx_last_error)";
     default: return "unknown status";
   }
 }
@@ -148,14 +258,21 @@ int qsx_device_alloc(size_t bytes, void **out_dev) {
   if (out_dev == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   *out_dev = nullptr;
   if (bytes == 0) return QSX_OK;
-  QSX_HIP_TRY(hipMalloc(out_dev, bytes));
+  QSX_HIP_TRY(qsx::device_malloc(out_dev, bytes));
+  return QSX_OK;
+}
+
+int qsx_set_out_of_memory_hook(void (*hook)(void *user), void *user) {
+  std::lock_guard<std::mutex> lock(qsx::g_hook_mutex);
+  qsx::g_oom_hook = hook;
+  qsx::g_oom_hook_user = user;
   return QSX_OK;
 }
 
 int qsx_device_free(void *dev) {
   if (dev == nullptr) return QSX_OK;
   QSX_REQUIRE_DEVICE();
-  QSX_HIP_TRY(hipFree(dev));
+  QSX_HIP_TRY(qsx::device_free(dev));
   return QSX_OK;
 }
 
@@ -207,7 +324,7 @@ int qsx_stream_destroy(qsx_stream_t stream) {
 
 int qsx_trim_scratch(size_t *out_bytes_released) {
   QSX_REQUIRE_DEVICE();
-  const size_t bytes = qsx::trim_thread_resources();
+  const size_t bytes = qsx::trim_thread_resources() + qsx::trim_idle_allocations();
   if (out_bytes_released != nullptr) *out_bytes_released = bytes;
   return QSX_OK;
 }

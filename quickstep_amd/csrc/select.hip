@@ -212,7 +212,13 @@ __device__ __forceinline__ void copy_value(const void *src, int64_t si, void *ds
     case 1: static_cast<uint8_t *>(dst)[di] = static_cast<const uint8_t *>(src)[si]; break;
     case 2: static_cast<uint16_t *>(dst)[di] = static_cast<const uint16_t *>(src)[si]; break;
     case 4: static_cast<uint32_t *>(dst)[di] = static_cast<const uint32_t *>(src)[si]; break;
-    default: static_cast<uint64_t *>(dst)[di] = static_cast<const uint64_t *>(src)[si]; break;
+    case 8: static_cast<uint64_t *>(dst)[di] = static_cast<const uint64_t *>(src)[si]; break;
+    default: {   // CHAR(n): byte by byte
+      const uint8_t *from = static_cast<const uint8_t *>(src) + si * width;
+      uint8_t *to = static_cast<uint8_t *>(dst) + di * width;
+      for (int b = 0; b < width; ++b) to[b] = from[b];
+      break;
+    }
   }
 }
 
@@ -640,6 +646,36 @@ __global__ __launch_bounds__(kBlock) void gather_segmented_bytes_kernel(SegmentT
       if (seg.first_row[mid] <= t) lo = mid; else hi = mid - 1;
     }
     dst[j] = static_cast<const uint8_t *>(seg.ptr[lo])[(t - seg.first_row[lo]) * width + off];
+  }
+}
+
+// Segments of equal length (the blocks of a relation, all but the last full): segment = tid / rows_per_segment, no search.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_uniform_segments_kernel(const long long *__restrict__ ptrs, int num, int32_t rows_per_segment,
+                                                                         int shift, const int32_t *__restrict__ tids, int64_t n,
+                                                                         T *__restrict__ dst) {
+  constexpr int R = 4;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i0 < n; i0 += stride * R) {
+    int32_t t[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t i = i0 + r * stride;
+      t[r] = i < n ? tids[i] : -1;
+    }
+    T v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int32_t tt = t[r] < 0 ? 0 : t[r];
+      int seg = shift >= 0 ? tt >> shift : tt / rows_per_segment;
+      seg = seg < num ? seg : num - 1;
+      v[r] = as_global(reinterpret_cast<const T *>(ptrs[seg]))[tt - seg * rows_per_segment];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t i = i0 + r * stride;
+      if (i < n) dst[i] = t[r] < 0 ? T() : v[r];
+    }
   }
 }
 
@@ -1781,7 +1817,7 @@ int qsx_compact_gather(int ncols, const void *const *cols, const int32_t *widths
   args.ncols = ncols;
   for (int c = 0; c < ncols; ++c) {
     const int w = widths[c];
-    if (w != 1 && w != 2 && w != 4 && w != 8) return QSX_ERR_UNSUPPORTED;
+    if (w < 1 || w > 4096) return QSX_ERR_UNSUPPORTED;   // 1 / 2 / 4 / 8: one load and store per value; other widths (CHAR(n)) byte by byte
     args.width[c] = w;
     args.src[c] = cols[c];
     args.dst[c] = out_cols[c];
@@ -1809,7 +1845,7 @@ int qsx_compact_gather_blocks(int ncols, const int32_t *widths, int64_t num_bloc
   args.ncols = ncols;
   for (int c = 0; c < ncols; ++c) {
     const int w = widths[c];
-    if (w != 1 && w != 2 && w != 4 && w != 8) return QSX_ERR_UNSUPPORTED;
+    if (w < 1 || w > 4096) return QSX_ERR_UNSUPPORTED;   // 1 / 2 / 4 / 8: one load and store per value; other widths (CHAR(n)) byte by byte
     args.width[c] = w;
     args.src[c] = nullptr;
     args.dst[c] = out_cols[c];
@@ -1919,6 +1955,32 @@ int qsx_gather_segmented(int width, int num_segments, const void *const *segment
   if (n < 0 || num_segments < 1 || segment_ptrs == nullptr || segment_first_row == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   if (num_segments > kMaxTableSegments) return QSX_ERR_UNSUPPORTED;
   if (n == 0) return QSX_OK;
+  // equal-length segments (every block of a relation but the last is full): the segment of a tuple id is a division
+  bool uniform = num_segments > 1 && segment_first_row[0] == 0 && segment_first_row[1] > 0 && segment_first_row[1] <= INT32_MAX &&
+                 (width == 1 || width == 2 || width == 4 || width == 8);
+  for (int i = 2; uniform && i < num_segments; ++i) uniform = segment_first_row[i] == segment_first_row[1] * i;
+  if (uniform) {
+    hipStream_t s = as_stream(stream);
+    const int32_t *first_dev = nullptr;
+    const long long *ptrs_dev = nullptr;
+    const int rc = upload_segment_table(num_segments, segment_ptrs, segment_first_row, s, &first_dev, &ptrs_dev);
+    if (rc != QSX_OK) return rc;
+    const int32_t rows = static_cast<int32_t>(segment_first_row[1]);
+    int shift = -1;
+    if ((rows & (rows - 1)) == 0) {
+      shift = 0;
+      while ((1 << shift) < rows) ++shift;
+    }
+    const int grid = grid_for(n, kBlock * 8);
+    switch (width) {
+      case 1: hipLaunchKernelGGL(gather_uniform_segments_kernel<uint8_t>, dim3(grid), dim3(kBlock), 0, s, ptrs_dev, num_segments, rows, shift, tids_dev, n, static_cast<uint8_t *>(dst_dev)); break;
+      case 2: hipLaunchKernelGGL(gather_uniform_segments_kernel<uint16_t>, dim3(grid), dim3(kBlock), 0, s, ptrs_dev, num_segments, rows, shift, tids_dev, n, static_cast<uint16_t *>(dst_dev)); break;
+      case 4: hipLaunchKernelGGL(gather_uniform_segments_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, ptrs_dev, num_segments, rows, shift, tids_dev, n, static_cast<uint32_t *>(dst_dev)); break;
+      default: hipLaunchKernelGGL(gather_uniform_segments_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, s, ptrs_dev, num_segments, rows, shift, tids_dev, n, static_cast<uint64_t *>(dst_dev)); break;
+    }
+    QSX_CHECK_LAUNCH();
+    return QSX_OK;
+  }
   if (num_segments > kMaxSegments) {
     hipStream_t s = as_stream(stream);
     const int32_t *first_dev = nullptr;

@@ -34,6 +34,8 @@ thread_local qsx_stream_t tls_stream = nullptr;
 // the next use is ordered behind it.  (A buffer built by one thread and consumed by another — DISTINCT chunks — is
 // published after a stream synchronisation, like a storage block.)  The cache keeps at most kCacheBytes per thread.
 void TrimBlockSlabPool();   // (defined behind BlockSlabPool)
+void *TakePooled(std::size_t bytes, std::size_t *granted);
+void GivePooled(void *p, std::size_t granted);
 struct DeviceBuffer {
   static constexpr std::size_t kCacheFrom = 64 * 1024 + 1;
   static constexpr std::size_t kCacheBytes = std::size_t(2) << 30;
@@ -48,8 +50,18 @@ struct DeviceBuffer {
     thread_local Cache c;
     return c;
   }
+  static void trimThisThread() {
+    Cache &c = cache();
+    for (auto &cls : c.free_by_class) {
+      for (void *q : cls.second) qsx_device_free(q);
+      cls.second.clear();
+    }
+    c.bytes = 0;
+  }
   void *ptr = nullptr;
   std::size_t size_class = 0;   // 0: a plain allocation of its own
+  std::size_t pooled = 0;       // != 0: from the shared pool (its size class there)
+  static constexpr std::size_t kSharedFrom = std::size_t(32) << 20;
   static bool cacheEnabled() {   // QSX_HOST_SCRATCH_CACHE=0: every buffer a plain allocation (debugging)
     static const bool on = []() {
       const char *e = std::getenv("QSX_HOST_SCRATCH_CACHE");
@@ -58,6 +70,12 @@ struct DeviceBuffer {
     return on;
   }
   explicit DeviceBuffer(std::size_t bytes) {
+    if (bytes >= kSharedFrom && cacheEnabled()) {
+      // pair lists / operand columns of a run of blocks: hundreds of MB — from the process-wide pool of the output blocks,
+      // not one cached copy per Worker thread (whichever thread happens to pick the join next would allocate its own)
+      ptr = TakePooled(bytes, &pooled);
+      return;
+    }
     if (bytes >= kCacheFrom && cacheEnabled()) {
       size_class = 128 * 1024;
       while (size_class < bytes) size_class *= 2;
@@ -70,12 +88,11 @@ struct DeviceBuffer {
         return;
       }
       if (qsx_device_alloc(size_class, &ptr) != QSX_OK) {
-        for (auto &cls : c.free_by_class) {     // this thread's cached buffers and the pooled block allocations go back first
-          for (void *q : cls.second) qsx_device_free(q);
-          cls.second.clear();
-        }
-        c.bytes = 0;
+        // this thread's cached buffers, the pooled block allocations and what libqsx.so keeps for this thread go back first
+        // (the library has already called HostOutOfMemoryHook once from inside qsx_device_alloc)
+        trimThisThread();
         TrimBlockSlabPool();
+        (void)qsx_trim_scratch(nullptr);
         CheckStatus(qsx_device_alloc(size_class, &ptr), "qsx_device_alloc");
       }
       return;
@@ -83,6 +100,11 @@ struct DeviceBuffer {
     CheckStatus(qsx_device_alloc(bytes ? bytes : 8, &ptr), "qsx_device_alloc");
   }
   ~DeviceBuffer() {
+    if (pooled != 0) {
+      (void)qsx_stream_synchronize(CurrentStream());   // another thread may take it next: this thread's queued work first
+      GivePooled(ptr, pooled);
+      return;
+    }
     if (size_class != 0) {
       Cache &c = cache();
       if (c.bytes + size_class <= kCacheBytes) {
@@ -132,6 +154,8 @@ class BlockSlabPool {
     void *p = nullptr;
     if (qsx_device_alloc(cls, &p) != QSX_OK) {
       trim();                                    // what the pool keeps goes back to the device before giving up
+      DeviceBuffer::trimThisThread();
+      (void)qsx_trim_scratch(nullptr);           // and what libqsx.so keeps for this thread between calls
       CheckStatus(qsx_device_alloc(cls, &p), "qsx_device_alloc(block)");
     }
     return p;
@@ -164,6 +188,18 @@ class BlockSlabPool {
 };
 
 void TrimBlockSlabPool() { BlockSlabPool::instance().trim(); }
+void *TakePooled(std::size_t bytes, std::size_t *granted) { return BlockSlabPool::instance().take(bytes, granted); }
+void GivePooled(void *p, std::size_t granted) { BlockSlabPool::instance().give(p, granted); }
+
+// qsx_set_out_of_memory_hook: a device allocation inside libqsx.so (a join table, an aggregation state, a scratch arena)
+// found no memory — the pooled output-block allocations and the failing thread's scratch cache go back before its retry.
+void HostOutOfMemoryHook(void *) {
+  TrimBlockSlabPool();
+  DeviceBuffer::trimThisThread();
+}
+struct RegisterOutOfMemoryHook {
+  RegisterOutOfMemoryHook() { (void)qsx_set_out_of_memory_hook(&HostOutOfMemoryHook, nullptr); }
+} g_register_out_of_memory_hook;
 
 std::int64_t ReadCount(const void *dev_count) {
   std::int64_t v = 0;
@@ -176,6 +212,8 @@ std::uint64_t NowMicros() {
                                         std::chrono::steady_clock::now().time_since_epoch()).count());
 }
 }  // namespace
+
+void CheckRepartition(const char *op, bool has_repartition, const InsertDestination *dest);   // (behind QueryContext)
 
 qsx_stream_t CurrentStream() { return tls_stream; }
 void SetCurrentStream(qsx_stream_t stream) { tls_stream = stream; }
@@ -277,7 +315,41 @@ StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t capacit
     null_bitmaps_.push_back(nulls);
   }
 }
+StorageBlock::StorageBlock(std::shared_ptr<StorageBlock> parent, std::int64_t first_tuple, std::int64_t num_tuples)
+    : relation_(parent->relation_), capacity_(num_tuples), num_tuples_(num_tuples), first_row_(0), view_parent_(std::move(parent)) {
+  for (std::size_t a = 0; a < relation_.size(); ++a) {
+    const Type &t = relation_.getAttributeType(static_cast<attribute_id>(a));
+    stripes_.push_back(static_cast<char *>(view_parent_->stripe(static_cast<attribute_id>(a))) + first_tuple * t.width);
+    void *nulls = nullptr;
+    if (t.nullable) {
+      const std::size_t nbytes = static_cast<std::size_t>((num_tuples + 63) / 64) * 8 + 8;
+      if (g_host_memory) {
+        nulls = std::calloc(nbytes, 1);
+      } else {
+        CheckStatus(qsx_device_alloc(nbytes, &nulls), "qsx_device_alloc(null bitmap)");
+        CheckStatus(qsx_memset_device(nulls, 0, nbytes, CurrentStream()), "qsx_memset_device(null bitmap)");
+      }
+    }
+    null_bitmaps_.push_back(nulls);
+  }
+}
+StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t num_tuples, const std::vector<void *> &stripes,
+                           const std::vector<void *> &null_bitmaps)
+    : relation_(relation), capacity_(num_tuples), num_tuples_(num_tuples), first_row_(0), external_memory_(true),
+      stripes_(stripes), null_bitmaps_(null_bitmaps) {}
+
 StorageBlock::~StorageBlock() {
+  if (external_memory_) {
+    for (void *&p : stripes_) p = nullptr;
+    for (void *&p : null_bitmaps_) p = nullptr;
+  }
+  // A block that dies while an exception unwinds a work order may still be the target of kernels that work order has
+  // queued: they must finish before its memory goes back to a pool another Worker takes from (the regular path has
+  // synchronised its stream before the last reference goes).
+  if (std::uncaught_exceptions() > 0 && !g_host_memory) (void)qsx_stream_synchronize(CurrentStream());
+  if (view_parent_ != nullptr) {
+    for (void *&p : stripes_) p = nullptr;   // the parent's
+  }
   if (slab_ != nullptr) {
     // (a stripe outside the slab was materialised later, stripe(): freed on its own below)
     auto in_slab = [&](void *p) { return p >= slab_ && p < static_cast<char *>(slab_) + slab_bytes_; };
@@ -719,6 +791,182 @@ std::int64_t StorageManager::reserveRows(relation_id relation, std::int64_t num_
   return first;
 }
 
+// ---- reference block images ------------------------------------------------------------------------------------------------
+namespace {
+// protobuf wire format, as far as a StorageBlockHeader needs it (varints, fixed64 / fixed32, length-delimited fields)
+struct WireReader {
+  const unsigned char *at, *end;
+  bool ok = true;
+  std::uint64_t varint() {
+    std::uint64_t v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      if (at >= end) { ok = false; return 0; }
+      const unsigned char b = *at++;
+      v |= static_cast<std::uint64_t>(b & 0x7F) << shift;
+      if ((b & 0x80) == 0) return v;
+    }
+    ok = false;
+    return 0;
+  }
+  std::uint64_t fixed(int bytes) {
+    if (end - at < bytes) { ok = false; return 0; }
+    std::uint64_t v = 0;
+    std::memcpy(&v, at, static_cast<std::size_t>(bytes));
+    at += bytes;
+    return v;
+  }
+  WireReader sub() {   // a length-delimited field
+    const std::uint64_t len = varint();
+    if (!ok || static_cast<std::uint64_t>(end - at) < len) { ok = false; return WireReader{at, at}; }
+    WireReader r{at, at + len};
+    at += len;
+    return r;
+  }
+  void skip(int wire_type) {
+    switch (wire_type) {
+      case 0: (void)varint(); break;
+      case 1: (void)fixed(8); break;
+      case 2: (void)sub(); break;
+      case 5: (void)fixed(4); break;
+      default: ok = false;
+    }
+  }
+};
+[[noreturn]] void Malformed(const char *what) {
+  throw ExecutionError(std::string("malformed block image: ") + what, QSX_ERR_INVALID_ARGUMENT);
+}
+}  // namespace
+
+ReferenceBlockLayout ParseReferenceBlockImage(const CatalogRelation &relation, const void *prefix, std::size_t prefix_bytes,
+                                              std::size_t image_bytes) {
+  const unsigned char *bytes = static_cast<const unsigned char *>(prefix);
+  if (prefix_bytes < sizeof(std::int32_t) || prefix_bytes > image_bytes) Malformed("shorter than its length word");
+  std::int32_t header_length = 0;
+  std::memcpy(&header_length, bytes, sizeof(header_length));
+  if (header_length <= 0 || static_cast<std::size_t>(header_length) + sizeof(std::int32_t) > image_bytes) Malformed("header length");   // StorageBlock.cpp:112-117
+  if (static_cast<std::size_t>(header_length) + sizeof(std::int32_t) + 8 > prefix_bytes) Malformed("the prefix handed in does not cover the block header");
+  // StorageBlockHeader { layout = 1 (StorageBlockLayoutDescription { num_slots = 1; tuple_store_description = 2 {
+  //   sub_block_type = 1; [sort_attribute_id = 64] }; index_description = 3 }); fixed64 tuple_store_size = 2; ... }
+  WireReader header{bytes + sizeof(std::int32_t), bytes + sizeof(std::int32_t) + header_length};
+  ReferenceBlockLayout out;
+  bool have_layout = false, have_size = false;
+  std::uint64_t sub_block_type = ~0ull;
+  while (header.ok && header.at < header.end) {
+    const std::uint64_t tag = header.varint();
+    const int field = static_cast<int>(tag >> 3), wire = static_cast<int>(tag & 7);
+    if (field == 1 && wire == 2) {
+      WireReader layout = header.sub();
+      have_layout = true;
+      while (layout.ok && layout.at < layout.end) {
+        const std::uint64_t ltag = layout.varint();
+        if ((ltag >> 3) == 2 && (ltag & 7) == 2) {
+          WireReader store = layout.sub();
+          while (store.ok && store.at < store.end) {
+            const std::uint64_t stag = store.varint();
+            if ((stag >> 3) == 1 && (stag & 7) == 0) sub_block_type = store.varint();
+            else if ((stag >> 3) == 64 && (stag & 7) == 0) out.sort_attribute = static_cast<attribute_id>(static_cast<std::int32_t>(store.varint()));
+            else store.skip(static_cast<int>(stag & 7));
+          }
+          if (!store.ok) Malformed("tuple store description");
+        } else {
+          layout.skip(static_cast<int>(ltag & 7));
+        }
+      }
+      if (!layout.ok) Malformed("layout description");
+    } else if (field == 2 && wire == 1) {
+      out.tuple_store_size = static_cast<std::size_t>(header.fixed(8));
+      have_size = true;
+    } else {
+      header.skip(wire);
+    }
+  }
+  if (!header.ok || !have_layout || !have_size || sub_block_type == ~0ull) Malformed("block header");   // !IsInitialized()
+  if (sub_block_type != 0) {   // TupleStorageSubBlockDescription::BASIC_COLUMN_STORE
+    throw ExecutionError("block image: the tuple store is not a BasicColumnStore (compressed / row stores are not adopted in place)", QSX_ERR_UNSUPPORTED);
+  }
+  out.tuple_store_offset = sizeof(std::int32_t) + static_cast<std::size_t>(header_length);
+  if (out.tuple_store_offset + out.tuple_store_size > image_bytes) Malformed("sub-block sizes exceed the block");   // :141-143
+  if (out.tuple_store_size < 8) Malformed("tuple store smaller than its header");   // BlockMemoryTooSmall
+  // BasicColumnStoreTupleStorageSubBlock.cpp:131-147
+  std::size_t row_bytes = 0, nullable = 0;
+  for (std::size_t a = 0; a < relation.size(); ++a) {
+    const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
+    row_bytes += static_cast<std::size_t>(t.width);
+    nullable += t.nullable ? 1 : 0;
+  }
+  if (row_bytes == 0) Malformed("relation without attributes");
+  auto bitmap_bytes = [](std::size_t bits) { return (bits + 63) / 64 * 8; };   // BitVector<false>::BytesNeeded
+  std::size_t max_tuples = ((out.tuple_store_size - 8) << 3) / ((row_bytes << 3) + nullable);
+  if (max_tuples == 0) Malformed("no room for one tuple");
+  if (nullable * bitmap_bytes(max_tuples) + 8 > out.tuple_store_size) Malformed("no room for the null bitmaps");
+  max_tuples = (out.tuple_store_size - 8 - nullable * bitmap_bytes(max_tuples)) / row_bytes;
+  if (max_tuples == 0) Malformed("no room for one tuple");
+  const std::size_t per_bitmap = bitmap_bytes(max_tuples);
+  out.max_tuples = static_cast<std::int64_t>(max_tuples);
+  std::int32_t num_tuples = 0;
+  std::memcpy(&num_tuples, bytes + out.tuple_store_offset, sizeof(num_tuples));
+  if (num_tuples < 0 || static_cast<std::size_t>(num_tuples) > max_tuples) Malformed("num_tuples");
+  out.num_tuples = num_tuples;
+  std::size_t at = out.tuple_store_offset + 8;
+  for (std::size_t a = 0; a < relation.size(); ++a) {
+    if (relation.getAttributeType(static_cast<attribute_id>(a)).nullable) {
+      out.null_bitmap_offset.push_back(at);
+      at += per_bitmap;
+    } else {
+      out.null_bitmap_offset.push_back(static_cast<std::size_t>(-1));
+    }
+  }
+  for (std::size_t a = 0; a < relation.size(); ++a) {
+    out.stripe_offset.push_back(at);
+    at += max_tuples * static_cast<std::size_t>(relation.getAttributeType(static_cast<attribute_id>(a)).width);
+  }
+  if (at > out.tuple_store_offset + out.tuple_store_size) Malformed("stripes exceed the tuple store");
+  if (out.sort_attribute != kInvalidAttributeID && (out.sort_attribute < 0 || static_cast<std::size_t>(out.sort_attribute) >= relation.size())) {
+    Malformed("sort attribute");
+  }
+  return out;
+}
+
+block_id StorageManager::adoptBlockImage(CatalogRelation *relation, void *image_dev, std::size_t image_bytes, partition_id part) {
+  // the block header is a few hundred bytes: fetch a prefix, parse on the host
+  const std::size_t prefix_bytes = std::min<std::size_t>(image_bytes, 16384);
+  std::vector<unsigned char> prefix(prefix_bytes);
+  if (g_host_memory) {
+    std::memcpy(prefix.data(), image_dev, prefix_bytes);
+  } else {
+    CheckStatus(qsx_copy_to_host(prefix.data(), image_dev, prefix_bytes, CurrentStream()), "qsx_copy_to_host(block header)");
+  }
+  const ReferenceBlockLayout layout = ParseReferenceBlockImage(*relation, prefix.data(), prefix_bytes, image_bytes);
+  std::vector<void *> stripes, nulls;
+  char *base = static_cast<char *>(image_dev);
+  for (std::size_t a = 0; a < relation->size(); ++a) {
+    stripes.push_back(base + layout.stripe_offset[a]);
+    nulls.push_back(layout.null_bitmap_offset[a] == static_cast<std::size_t>(-1) ? nullptr : base + layout.null_bitmap_offset[a]);
+  }
+  BlockReference block = std::make_shared<StorageBlock>(*relation, layout.num_tuples, stripes, nulls);
+  block->setSortColumn(layout.sort_attribute);
+  block_id id;
+  {
+    std::lock_guard<std::mutex> lock(mutex_);
+    id = next_id_++;
+    std::int64_t &rows = rows_in_relation_[relation->getID()];
+    block->setFirstRow(rows);
+    rows += layout.num_tuples;
+    blocks_[id] = block;
+  }
+  relation->addBlockToPartition(id, part);
+  return id;
+}
+
+block_id StorageManager::createViewBlock(block_id parent, std::int64_t first_tuple, std::int64_t num_tuples) {
+  BlockReference p = getBlock(parent);
+  BlockReference view = std::make_shared<StorageBlock>(p, first_tuple, num_tuples);
+  std::lock_guard<std::mutex> lock(mutex_);
+  const block_id id = next_id_++;
+  blocks_[id] = view;
+  return id;
+}
+
 void StorageManager::deleteBlockOrBlobFile(block_id id) {
   std::lock_guard<std::mutex> lock(mutex_);
   blocks_.erase(id);
@@ -869,15 +1117,123 @@ BlockReference InsertDestination::getBlockForInsertion(std::int64_t capacity, bl
   *id = storage_manager_->createBlock(relation_, capacity);
   return storage_manager_->getBlock(*id);
 }
-void InsertDestination::returnBlock(block_id id, std::int64_t num_tuples) {
+void InsertDestination::returnBlock(block_id id, std::int64_t num_tuples, partition_id input_partition) {
+  if (isPartitionAware()) {
+    repartitionBlock(id, num_tuples);
+    return;
+  }
   BlockReference block = storage_manager_->getBlock(id);
   block->setNumTuples(num_tuples);
   block->setFirstRow(storage_manager_->reserveRows(relation_->getID(), num_tuples));
   std::lock_guard<std::mutex> lock(mutex_);
-  touched_.push_back(id);
-  relation_->addBlock(id);
+  touched_.push_back(TouchedBlock{id, input_partition});
+  if (relation_->hasPartitionScheme()) {
+    relation_->addBlockToPartition(id, input_partition);   // the output keeps the input's partitioning (no repartition)
+  } else {
+    relation_->addBlock(id);
+  }
+}
+
+// bulkInsertTuples of a PartitionAwareInsertDestination (storage/InsertDestination.hpp:560-660), on a whole block at once:
+// K9 scatters the columns of 1 / 2 / 4 / 8 bytes and a row-number column by the partition of the partition attribute; wider
+// columns (CHAR(n)) and the null bits follow through the scattered row numbers; the scattered block is then cut into one
+// block per partition (views: no copy).
+void InsertDestination::repartitionBlock(block_id id, std::int64_t num_tuples) {
+  BlockReference src = storage_manager_->getBlock(id);
+  src->setNumTuples(num_tuples);
+  const std::size_t P = num_partitions_;
+  const Type &key_type = relation_->getAttributeType(partition_attribute_);
+  if (key_type.id != kInt && key_type.id != kLong) {
+    throw ExecutionError("PartitionAwareInsertDestination: the partition attribute must be INT or LONG", QSX_ERR_UNSUPPORTED);
+  }
+  if (P > 64) throw ExecutionError("PartitionAwareInsertDestination: more than 64 partitions", QSX_ERR_UNSUPPORTED);
+  if (num_tuples == 0) {
+    storage_manager_->deleteBlockOrBlobFile(id);
+    return;
+  }
+  block_id scattered_id;
+  BlockReference scattered = getBlockForInsertion(num_tuples, &scattered_id);
+  scattered->setNumTuples(num_tuples);
+  bool need_rows = false;
+  std::vector<const void *> cols;
+  std::vector<void *> outs;
+  std::vector<std::int32_t> widths;
+  for (std::size_t a = 0; a < relation_->size(); ++a) {
+    const Type &t = relation_->getAttributeType(static_cast<attribute_id>(a));
+    if (t.nullable) need_rows = true;
+    if (t.width == 1 || t.width == 2 || t.width == 4 || t.width == 8) {
+      cols.push_back(src->stripe(static_cast<attribute_id>(a)));
+      outs.push_back(scattered->stripe(static_cast<attribute_id>(a)));
+      widths.push_back(t.width);
+    } else {
+      need_rows = true;
+    }
+  }
+  std::unique_ptr<DeviceBuffer> rows, rows_scattered;
+  if (need_rows) {
+    // row numbers 0 .. n-1: the tuple ids of an all-ones TupleIdSequence (NOT of a zeroed one: trailing bits stay zero)
+    const std::size_t words = static_cast<std::size_t>((num_tuples + 63) / 64) + 1;
+    DeviceBuffer zero(words * 8), ones(words * 8), count(8);
+    CheckStatus(qsx_memset_device(zero.ptr, 0, words * 8, CurrentStream()), "qsx_memset_device");
+    CheckStatus(qsx_bitmap_combine(3, static_cast<const std::uint64_t *>(zero.ptr), nullptr, num_tuples, static_cast<std::uint64_t *>(ones.ptr),
+                                   CurrentStream()), "qsx_bitmap_combine");
+    rows.reset(new DeviceBuffer(static_cast<std::size_t>(num_tuples) * 4 + 8));
+    rows_scattered.reset(new DeviceBuffer(static_cast<std::size_t>(num_tuples) * 4 + 8));
+    const std::size_t tws = qsx_compact_workspace_bytes(num_tuples);
+    DeviceBuffer tw(tws + 8);
+    CheckStatus(qsx_bitmap_to_tids(static_cast<const std::uint64_t *>(ones.ptr), num_tuples, 0, static_cast<std::int32_t *>(rows->ptr),
+                                   static_cast<std::int64_t *>(count.ptr), tw.ptr, tws, CurrentStream()), "qsx_bitmap_to_tids");
+    cols.push_back(rows->ptr);
+    outs.push_back(rows_scattered->ptr);
+    widths.push_back(4);
+    CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // (zero / ones / tw go out of scope)
+  }
+  const std::size_t ws_bytes = qsx_partition_workspace_bytes(num_tuples, static_cast<int>(P));
+  DeviceBuffer ws(ws_bytes + 8), offsets_dev((P + 1) * 8);
+  CheckStatus(qsx_partition_scatter(key_type.id, src->stripe(partition_attribute_), num_tuples, static_cast<int>(P), static_cast<int>(cols.size()),
+                                    cols.data(), widths.data(), outs.data(), static_cast<std::int64_t *>(offsets_dev.ptr), ws.ptr, ws_bytes,
+                                    CurrentStream()), "qsx_partition_scatter");
+  std::vector<std::int64_t> offsets(P + 1);
+  CheckStatus(qsx_copy_to_host(offsets.data(), offsets_dev.ptr, (P + 1) * 8, CurrentStream()), "qsx_copy_to_host");
+  for (std::size_t a = 0; a < relation_->size(); ++a) {
+    const Type &t = relation_->getAttributeType(static_cast<attribute_id>(a));
+    if (t.width == 1 || t.width == 2 || t.width == 4 || t.width == 8) continue;
+    CheckStatus(qsx_gather(t.width, src->stripe(static_cast<attribute_id>(a)), static_cast<const std::int32_t *>(rows_scattered->ptr), num_tuples,
+                           scattered->stripe(static_cast<attribute_id>(a)), CurrentStream()), "qsx_gather");
+  }
+  std::vector<std::pair<block_id, partition_id>> made;
+  for (std::size_t p = 0; p < P; ++p) {
+    const std::int64_t first = offsets[p], rows_p = offsets[p + 1] - offsets[p];
+    if (rows_p == 0) continue;
+    const block_id view_id = storage_manager_->createViewBlock(scattered_id, first, rows_p);
+    BlockReference view = storage_manager_->getBlock(view_id);
+    for (std::size_t a = 0; a < relation_->size(); ++a) {
+      std::uint64_t *dst = view->nullBitmap(static_cast<attribute_id>(a));
+      if (dst == nullptr) continue;
+      const std::uint64_t *bits = src->nullBitmap(static_cast<attribute_id>(a));
+      const std::int64_t zero_row = 0;
+      CheckStatus(qsx_bitmap_gather_segmented(1, &bits, &zero_row, static_cast<const std::int32_t *>(rows_scattered->ptr) + first, rows_p, dst,
+                                              CurrentStream()), "qsx_bitmap_gather_segmented");
+    }
+    view->setFirstRow(storage_manager_->reserveRows(relation_->getID(), rows_p));
+    made.emplace_back(view_id, p);
+  }
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // before the source block goes
+  storage_manager_->deleteBlockOrBlobFile(id);
+  storage_manager_->deleteBlockOrBlobFile(scattered_id);      // (the views keep the scattered block alive)
+  std::lock_guard<std::mutex> lock(mutex_);
+  for (const auto &m : made) {
+    touched_.push_back(TouchedBlock{m.first, m.second});
+    relation_->addBlockToPartition(m.first, m.second);
+  }
 }
 std::vector<block_id> InsertDestination::getTouchedBlocks() const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  std::vector<block_id> ids;
+  for (const TouchedBlock &t : touched_) ids.push_back(t.id);
+  return ids;
+}
+std::vector<InsertDestination::TouchedBlock> InsertDestination::getTouchedBlocksWithPartitions() const {
   std::lock_guard<std::mutex> lock(mutex_);
   return touched_;
 }
@@ -1692,6 +2048,23 @@ QueryContext::insert_destination_id QueryContext::addInsertDestination(CatalogRe
   destinations_.emplace_back(new InsertDestination(relation, storage_manager));
   return static_cast<insert_destination_id>(destinations_.size() - 1);
 }
+QueryContext::insert_destination_id QueryContext::addPartitionAwareInsertDestination(CatalogRelation *relation,
+                                                                                     StorageManager *storage_manager) {
+  if (!relation->hasPartitionScheme()) {
+    throw ExecutionError("addPartitionAwareInsertDestination: the output relation has no partition scheme", QSX_ERR_INVALID_ARGUMENT);
+  }
+  destinations_.emplace_back(new InsertDestination(relation, storage_manager, relation->getNumPartitions(), relation->getPartitionAttribute()));
+  return static_cast<insert_destination_id>(destinations_.size() - 1);
+}
+
+// has_repartition of an operator (RelationalOperator.hpp:311-320) and the kind of its InsertDestination must agree: a
+// repartitioning operator whose destination would drop the partition scheme is a plan error, never silently accepted.
+void CheckRepartition(const char *op, bool has_repartition, const InsertDestination *dest) {
+  if (dest == nullptr || has_repartition == dest->isPartitionAware()) return;
+  throw ExecutionError(std::string(op) + (has_repartition ? ": has_repartition needs a PartitionAwareInsertDestination (QueryContext::addPartitionAwareInsertDestination)"
+                                                          : ": a PartitionAwareInsertDestination needs has_repartition = true"),
+                       QSX_ERR_INVALID_ARGUMENT);
+}
 
 // ---------------------------------------------------------------------------
 // WorkOrdersContainer
@@ -1759,6 +2132,7 @@ bool SelectOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryConte
   // generate incrementally and finish when done_feeding_input_relation_.
   const Predicate *predicate = query_context->getPredicate(predicate_index_);
   InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
+  CheckRepartition("SelectOperator", has_repartition_, dest);
   std::lock_guard<std::mutex> lock(mutex_);
   while (num_workorders_generated_ < input_relation_block_ids_.size()) {
     // every block that has arrived, in runs of blocks_per_work_order_ (1: the reference's one work order per block)
@@ -1972,7 +2346,7 @@ bool SelectWorkOrder::executeRun() {
                                         nullptr, static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
               "qsx_compact_gather_blocks");
   const std::int64_t written = ReadCount(count.ptr);   // synchronises the work order, like the reference's execute()
-  output_destination_->returnBlock(out_id, written);
+  output_destination_->returnBlock(out_id, written, getPartitionId());
   return true;
 }
 
@@ -2049,7 +2423,7 @@ void SelectWorkOrder::executeBlock(block_id input_block_id) {
   const std::int64_t written = ReadCount(count.ptr);  // synchronises the work order, like the reference's execute()
   ProjectNullBitmaps(*block, null_sources, bitmap, written, out.get());
   qsx_device_free(bitmap);
-  output_destination_->returnBlock(out_id, written);
+  output_destination_->returnBlock(out_id, written, getPartitionId());
 }
 
 // CPU work order of BASELINE config 1: the same plumbing with the loops on the
@@ -2100,7 +2474,7 @@ void SelectWorkOrder::executeOnHost() {
       if (match[i]) std::memcpy(dst + (o++) * w, src + i * w, w);
     }
   }
-  output_destination_->returnBlock(out_id, matches);
+  output_destination_->returnBlock(out_id, matches, getPartitionId());
 }
 
 // ---------------------------------------------------------------------------
@@ -2319,6 +2693,7 @@ bool HashJoinOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCon
   const std::vector<attribute_id> &selection = query_context->getScalarGroup(selection_index_);
   if (is_selection_on_build_.empty()) is_selection_on_build_.assign(selection.size(), false);
   InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
+  CheckRepartition("HashJoinOperator", has_repartition_, dest);
   std::lock_guard<std::mutex> lock(mutex_);
   if (!started_) {
     // the build operator is a blocking dependency: it has published its key attributes by now
@@ -2508,18 +2883,26 @@ bool HashInnerJoinWorkOrder::executeRun() {
                                           static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
                 "qsx_compact_gather_blocks");
     const std::int64_t written = ReadCount(count.ptr);
-    output_destination_->returnBlock(out_id, written);
+    output_destination_->returnBlock(out_id, written, getPartitionId());
     return true;
   }
-  CheckStatus(qsx_join_probe_count_blocks(hash_table_, nb, rows.data(), keys.data(), lookup, static_cast<std::int64_t *>(count.ptr),
-                                          CurrentStream()), "qsx_join_probe_count_blocks");
+  // No counting pass: the pair lists get room for one match per probe tuple — what a foreign-key probe of a primary-key
+  // build side produces at most (the reference sizes from the same uniqueness fact, impliesUniqueAttributes).  The probe
+  // counts every match it finds, also those that did not fit: a build side with duplicate keys makes this work order probe
+  // once more with the exact capacity.
   JoinedPairs pairs;
-  pairs.count = ReadCount(count.ptr);
-  pairs.probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
-  pairs.build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(pairs.count) * 4 + 8));
-  CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, lookup, static_cast<std::int32_t *>(pairs.probe_tids->ptr),
-                                    static_cast<std::int32_t *>(pairs.build_tids->ptr), pairs.count, static_cast<std::int64_t *>(count.ptr),
-                                    CurrentStream()), "qsx_join_probe_blocks");
+  std::int64_t room = total_rows > 0 ? total_rows : 1;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    pairs.probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(room) * 4 + 8));
+    pairs.build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(room) * 4 + 8));
+    CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, lookup, static_cast<std::int32_t *>(pairs.probe_tids->ptr),
+                                      static_cast<std::int32_t *>(pairs.build_tids->ptr), room, static_cast<std::int64_t *>(count.ptr),
+                                      CurrentStream()), "qsx_join_probe_blocks");
+    pairs.count = ReadCount(count.ptr);
+    if (pairs.count <= room) break;
+    if (attempt == 1) throw ExecutionError("HashJoinOperator: the match count changed between two probes of one run", QSX_ERR_CAPACITY);
+    room = pairs.count;
+  }
   BuildSegments build(build_relation_, storage_manager_);
   std::vector<const void *> segments(blocks.size());
   std::vector<ComparisonPredicate> terms;
@@ -2598,7 +2981,7 @@ bool HashInnerJoinWorkOrder::executeRun() {
     }
   }
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
-  output_destination_->returnBlock(out_id, matches);
+  output_destination_->returnBlock(out_id, matches, getPartitionId());
   return true;
 }
 
@@ -2754,7 +3137,7 @@ void HashInnerJoinWorkOrder::executeBlock(block_id probe_block_id) {
                 "qsx_compact_gather");
     const std::int64_t written = ReadCount(count.ptr);
     ProjectNullBitmaps(*probe, selection_, bitmap.ptr, written, out.get());
-    output_destination_->returnBlock(out_id, written);
+    output_destination_->returnBlock(out_id, written, getPartitionId());
     return;
   }
 
@@ -2840,7 +3223,7 @@ void HashInnerJoinWorkOrder::executeBlock(block_id probe_block_id) {
     }
   }
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
-  output_destination_->returnBlock(out_id, total);  // output_destination_->bulkInsertTuples(&temp_result) (:539)
+  output_destination_->returnBlock(out_id, total, getPartitionId());  // output_destination_->bulkInsertTuples(&temp_result) (:539)
 }
 
 namespace {
@@ -3029,6 +3412,7 @@ bool FinalizeAggregationOperator::getAllWorkOrders(WorkOrdersContainer *containe
   if (!started_) {
     started_ = true;
     InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
+    CheckRepartition("FinalizeAggregationOperator", has_repartition_, dest);
     // num_partitions x aggr_state_num_partitions work orders (FinalizeAggregationOperator.cpp:48-66)
     for (partition_id part = 0; part < num_partitions_; ++part) {
       AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, part);
@@ -3178,7 +3562,7 @@ void QueryPlan::addDirectDependency(std::size_t consumer, std::size_t producer, 
 ForemanSingleNode::ForemanSingleNode(QueryPlan *plan, QueryContext *query_context, StorageManager *storage_manager,
                                      std::size_t num_workers)
     : plan_(plan), query_context_(query_context), storage_manager_(storage_manager),
-      num_workers_(num_workers ? num_workers : 1), outstanding_(plan->size(), 0) {}
+      num_workers_(num_workers ? num_workers : 1), outstanding_(plan->size(), 0), executing_(plan->size(), 0) {}
 
 namespace {
 // The Worker threads of the process (query_execution/Worker.hpp: created once at start-up, they outlive every query).
@@ -3249,7 +3633,14 @@ class WorkerThreads {
 };
 }  // namespace
 
+namespace {
+thread_local bool tls_on_worker_thread = false;
+}
 void ForemanSingleNode::workerMain(std::size_t worker_id) {
+  struct OnWorker {
+    OnWorker() { tls_on_worker_thread = true; }
+    ~OnWorker() { tls_on_worker_thread = false; }
+  } on_worker;
   // Worker::run (query_execution/Worker.cpp:54-99): receive a work order, execute(), report completion.
   struct FreshStream {   // QSX_HOST_FRESH_STREAMS (debugging): a stream of this query only on the persistent thread
     qsx_stream_t previous = CurrentStream(), mine = nullptr;
@@ -3270,8 +3661,17 @@ void ForemanSingleNode::workerMain(std::size_t worker_id) {
       std::unique_lock<std::mutex> lock(mutex_);
       cv_work_.wait(lock, [&] { return shutting_down_ || !ready_.empty(); });
       if (ready_.empty()) break;
-      item = ready_.front();
-      ready_.pop_front();
+      // The next work order: of the operator with the fewest work orders on Workers right now (first in the queue among
+      // equals).  A probe whose build has just finished then starts next to an aggregation that queued seventy work orders
+      // before it, instead of behind them: its host-side steps (counts read back, output blocks) overlap the other
+      // operator's kernels.  (The reference's PolicyEnforcer picks per query; within one query it is FIFO.)
+      std::size_t pick = 0;
+      for (std::size_t i = 1; i < ready_.size() && executing_[ready_[pick].op] != 0; ++i) {
+        if (executing_[ready_[i].op] < executing_[ready_[pick].op]) pick = i;
+      }
+      item = ready_[pick];
+      ready_.erase(ready_.begin() + static_cast<std::ptrdiff_t>(pick));
+      ++executing_[item.op];
     }
     std::unique_ptr<WorkOrder> wo(item.wo);
     const std::uint64_t start = NowMicros();
@@ -3286,6 +3686,7 @@ void ForemanSingleNode::workerMain(std::size_t worker_id) {
     {
       std::lock_guard<std::mutex> lock(mutex_);
       --outstanding_[item.op];
+      --executing_[item.op];
       profile_.push_back(WorkOrderTimeEntry{worker_id, item.op, start, end});
       if (!error.empty() && worker_error_.empty()) worker_error_ = error;
     }
@@ -3294,6 +3695,12 @@ void ForemanSingleNode::workerMain(std::size_t worker_id) {
 }
 
 void ForemanSingleNode::run() {
+  // The process-wide Worker threads run one Foreman's workerMain at a time each: queries admitted concurrently from
+  // different threads are served one after the other (the reference's Workers interleave the work orders of admitted
+  // queries), and a Foreman started from INSIDE a work order would wait for the very thread it runs on.
+  if (tls_on_worker_thread) {
+    throw ExecutionError("ForemanSingleNode::run() called from a work order: nested query execution is not supported", QSX_ERR_UNSUPPORTED);
+  }
   const std::size_t N = plan_->size();
   WorkOrdersContainer container(N);
   std::vector<bool> done_generating(N, false), finished(N, false);
@@ -3356,12 +3763,14 @@ void ForemanSingleNode::run() {
         RelationalOperator *producer = plan_->getOperator(op);
         const QueryContext::insert_destination_id dest_id = producer->getInsertDestinationID();
         if (dest_id != QueryContext::kInvalidInsertDestinationId) {
-          const std::vector<block_id> touched = query_context_->getInsertDestination(dest_id)->getTouchedBlocks();
+          const std::vector<InsertDestination::TouchedBlock> touched = query_context_->getInsertDestination(dest_id)->getTouchedBlocksWithPartitions();
           for (; blocks_fed[op] < touched.size(); ++blocks_fed[op]) {
             for (std::size_t consumer = 0; consumer < N; ++consumer) {
               for (const QueryPlan::Edge &e : plan_->dependencies(consumer)) {
                 if (e.producer == op && !e.breaker) {
-                  plan_->getOperator(consumer)->feedInputBlock(touched[blocks_fed[op]], producer->getOutputRelationID(), 0);
+                  // kDataPipelineMessage carries the partition id of the block (InsertDestination.cpp:424-470)
+                  plan_->getOperator(consumer)->feedInputBlock(touched[blocks_fed[op]].id, producer->getOutputRelationID(),
+                                                               touched[blocks_fed[op]].partition);
                   progress = true;
                 }
               }

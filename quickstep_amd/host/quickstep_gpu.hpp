@@ -186,6 +186,13 @@ PredicateTransformResult TransformPredicateOnCompressedAttribute(const Compresse
 class StorageBlock {
  public:
   StorageBlock(const CatalogRelation &relation, std::int64_t capacity, std::int64_t first_row, bool one_allocation = false);
+  // A block that IS rows [first_tuple, first_tuple + num_tuples) of `parent` (one partition of a block that a
+  // PartitionAwareInsertDestination has scattered): its stripes point into the parent's, which it keeps alive; null bitmaps
+  // of nullable attributes are its own (zeroed; bit positions do not carry over from an unaligned row offset).
+  StorageBlock(std::shared_ptr<StorageBlock> parent, std::int64_t first_tuple, std::int64_t num_tuples);
+  // A block over memory that belongs to someone else (StorageManager::adoptBlockImage): nothing is freed with the block.
+  StorageBlock(const CatalogRelation &relation, std::int64_t num_tuples, const std::vector<void *> &stripes,
+               const std::vector<void *> &null_bitmaps);
   ~StorageBlock();
   const CatalogRelation &getRelation() const { return relation_; }
   std::int64_t numTuples() const { return num_tuples_; }
@@ -222,6 +229,8 @@ class StorageBlock {
   attribute_id sort_column_ = kInvalidAttributeID;
   void *slab_ = nullptr;                         // != nullptr: the one allocation all stripes and null bitmaps live in
   std::size_t slab_bytes_ = 0, slab_granted_ = 0;   // granted: the pool's size class (0: a plain allocation)
+  std::shared_ptr<StorageBlock> view_parent_;    // != nullptr: the stripes belong to it
+  bool external_memory_ = false;                 // stripes and null bitmaps belong to the caller (an adopted block image)
   mutable std::vector<void *> stripes_;          // nullptr: compressed and not decoded yet
   std::vector<void *> null_bitmaps_;
   std::vector<CompressedAttribute> compressed_;  // empty or one per attribute
@@ -229,9 +238,36 @@ class StorageBlock {
 };
 typedef std::shared_ptr<StorageBlock> BlockReference;
 
+// Where the pieces of a reference block image lie (byte offsets from the start of the image).  The image is what the
+// reference's StorageManager holds per block (storage/StorageBlock.cpp:81-195):
+//   [int32 header length][StorageBlockHeader, protobuf wire format (StorageBlockLayout.proto:96-124)]
+//   [tuple store sub-block of header.tuple_store_size bytes][index sub-blocks]
+// with a BasicColumnStoreTupleStorageSubBlock as tuple store (storage/BasicColumnStoreTupleStorageSubBlock.cpp:100-183):
+//   {int32 num_tuples; int32 nulls_in_sort_column}  (.hpp:188-191)
+//   one null bitmap per nullable attribute, BitVector<false>::BytesNeeded(max_tuples) bytes each, MSB-first, 1 = NULL
+//   one stripe per attribute at max_tuples * width bytes
+//   max_tuples = (tuple_store_size - 8 - nullable_attributes * bitmap_bytes) / sum of the attribute widths   (:131-147)
+struct ReferenceBlockLayout {
+  std::int64_t num_tuples = 0, max_tuples = 0;
+  attribute_id sort_attribute = kInvalidAttributeID;   // BasicColumnStoreTupleStorageSubBlockDescription::sort_attribute_id
+  std::size_t tuple_store_offset = 0, tuple_store_size = 0;
+  std::vector<std::size_t> null_bitmap_offset;          // per attribute; SIZE_MAX: not nullable
+  std::vector<std::size_t> stripe_offset;               // per attribute
+};
+// Pure host logic: `prefix` = the first prefix_bytes of the image (the block header and the 8-byte sub-block header must lie
+// inside), image_bytes = its full size.  Throws ExecutionError(QSX_ERR_INVALID_ARGUMENT) for a malformed image
+// (StorageBlock.cpp:108-131 MalformedBlock) and QSX_ERR_UNSUPPORTED for a tuple store that is not a basic column store.
+ReferenceBlockLayout ParseReferenceBlockImage(const CatalogRelation &relation, const void *prefix, std::size_t prefix_bytes,
+                                              std::size_t image_bytes);
+
 class StorageManager {
  public:
   StorageManager() = default;
+  // A reference block image that already lies in device memory (the engine's buffer pool in HBM) becomes a block of
+  // `relation` IN PLACE: the stripes and null bitmaps of the new block point into the image, nothing is copied; the image
+  // belongs to the caller and must outlive the block.  What every kernel entry point then sees is (stripe, num_tuples) —
+  // max_tuples only shows in the distance between two stripes.
+  block_id adoptBlockImage(CatalogRelation *relation, void *image_dev, std::size_t image_bytes, partition_id part = 0);
   // Create an empty block with room for `capacity` tuples; first_row = rows already in the relation.
   block_id createBlock(CatalogRelation *relation, std::int64_t capacity);
   // Create a block from host columns (one pointer per attribute), copy to HBM and add it to the relation.
@@ -242,6 +278,8 @@ class StorageManager {
   block_id loadBlock(CatalogRelation *relation, const std::vector<const void *> &host_columns, std::int64_t num_tuples,
                      partition_id part = 0, const std::vector<bool> *compress = nullptr,
                      const std::vector<const std::uint64_t *> *null_bitmaps = nullptr);
+  // Registers a view of rows [first_tuple, first_tuple + num_tuples) of block `parent` as a block of its own.
+  block_id createViewBlock(block_id parent, std::int64_t first_tuple, std::int64_t num_tuples);
   BlockReference getBlock(block_id id) const;
   void deleteBlockOrBlobFile(block_id id);
   // Registers `num_tuples` more rows of `relation`; returns the relation-global row number of the first one.
@@ -311,18 +349,35 @@ class InsertDestination {
  public:
   InsertDestination(CatalogRelation *relation, StorageManager *storage_manager)
       : relation_(relation), storage_manager_(storage_manager) {}
+  // PartitionAwareInsertDestination (storage/InsertDestination.hpp:490-660): every tuple goes to the partition
+  // HashPartitionSchemeHeader::getPartitionId names for its value of `partition_attribute`
+  // (catalog/PartitionSchemeHeader.hpp:200-214: identity hash of the INT / LONG value, h & (P - 1) for a power of two,
+  // else h >= P ? h % P : h).  A work order still fills ONE block; returnBlock scatters it (K9, qsx_partition_scatter) and
+  // registers one block per non-empty partition — what the reference's per-partition bulk inserts leave behind.
+  InsertDestination(CatalogRelation *relation, StorageManager *storage_manager, std::size_t num_partitions, attribute_id partition_attribute)
+      : relation_(relation), storage_manager_(storage_manager), num_partitions_(num_partitions), partition_attribute_(partition_attribute) {}
+  bool isPartitionAware() const { return num_partitions_ > 0; }
+  std::size_t getNumPartitions() const { return num_partitions_ > 0 ? num_partitions_ : 1; }
   const CatalogRelation &getRelation() const { return *relation_; }
   // A block with room for `capacity` tuples; hand it back with returnBlock once filled.
   BlockReference getBlockForInsertion(std::int64_t capacity, block_id *id);
-  void returnBlock(block_id id, std::int64_t num_tuples);
+  // input_partition: the partition of the work order that filled the block — the partition of the output block when the
+  // destination does not repartition (the output relation keeps the input's scheme, RelationalOperator.hpp:311-320).
+  void returnBlock(block_id id, std::int64_t num_tuples, partition_id input_partition = 0);
   std::vector<block_id> getTouchedBlocks() const;
+  struct TouchedBlock { block_id id; partition_id partition; };
+  std::vector<TouchedBlock> getTouchedBlocksWithPartitions() const;
 
  private:
+  void repartitionBlock(block_id id, std::int64_t num_tuples);
   CatalogRelation *relation_;
   StorageManager *storage_manager_;
+  std::size_t num_partitions_ = 0;                        // 0: not partition-aware
+  attribute_id partition_attribute_ = kInvalidAttributeID;
   mutable std::mutex mutex_;
-  std::vector<block_id> touched_;
+  std::vector<TouchedBlock> touched_;
 };
+typedef InsertDestination PartitionAwareInsertDestination;   // (one class: the second constructor makes it partition-aware)
 
 // ---------------------------------------------------------------------------
 // scalar expressions (expressions/scalar/): ScalarAttribute, ScalarLiteral, ScalarBinaryExpression over the four
@@ -482,6 +537,8 @@ class QueryContext {
                                       const ExactKeyRange *exact_key_range = nullptr);
   aggregation_state_id addAggregationState(const AggregationStateSpec &spec, std::size_t num_partitions = 1);
   insert_destination_id addInsertDestination(CatalogRelation *relation, StorageManager *storage_manager);
+  // A PartitionAwareInsertDestination for an output relation with a hash partition scheme (relation->setPartitionScheme).
+  insert_destination_id addPartitionAwareInsertDestination(CatalogRelation *relation, StorageManager *storage_manager);
 
   const Predicate *getPredicate(predicate_id id) const { return id == kInvalidPredicateId ? nullptr : &predicates_.at(id); }
   const std::vector<attribute_id> &getScalarGroup(scalar_group_id id) const { return scalar_groups_.at(id); }
@@ -1094,6 +1151,7 @@ class ForemanSingleNode {
   struct Item { WorkOrder *wo; std::size_t op; };
   std::deque<Item> ready_;
   std::vector<std::size_t> outstanding_;  // dispatched but unfinished work orders per operator
+  std::vector<std::size_t> executing_;    // of those: on a Worker right now
   bool shutting_down_ = false;
   std::string worker_error_;
   std::vector<WorkOrderTimeEntry> profile_;

@@ -8,7 +8,7 @@ import ctypes as C
 
 # qsx_type_t (numbering of types/TypeID.hpp:32-43 in the reference)
 ACC_SUM_F64, ACC_SUM_I64, ACC_MIN_I64, ACC_MAX_I64 = 0, 1, 2, 3      # qsx_agg_state_image_layout column kinds
-ABI_VERSION = 7                                                     # QSX_ABI_VERSION of include/qsx.h
+ABI_VERSION = 8                                                     # QSX_ABI_VERSION of include/qsx.h
 INT, LONG, FLOAT, DOUBLE, CHAR = 0, 1, 2, 3, 4
 DATE = 6   # the reference's 8-byte DateLit {int32 year; uint8 month, day; 2 bytes padding}, carried as int64 raw bytes
 # qsx_cmp_t (types/operations/comparisons/ComparisonID.hpp:36-42)
@@ -38,7 +38,7 @@ def date_raw(year, month, day, padding=0):
 # status codes
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_HIP = -1, -2, -3, -4
-ERR_CAPACITY, ERR_UNSUPPORTED, ERR_TOO_MANY_GROUPS, ERR_HASH_COLLISION = -5, -6, -7, -8
+ERR_CAPACITY, ERR_UNSUPPORTED, ERR_TOO_MANY_GROUPS, ERR_HASH_COLLISION, ERR_COMM = -5, -6, -7, -8, -9
 GROUPS_HASH_COLLISION = -1   # qsx_agg_finalize's group count when a wide-key state saw two keys under one hash
 
 

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "block_image_util.hpp"
 #include "test_util.hpp"
 
 using namespace quickstep;
@@ -82,7 +83,100 @@ void CheckColumn(const char *name, TypeID type, const std::vector<T> &values, Co
 }
 }  // namespace
 
+// Reference block images (host memory mode: no device needed): header parsing, max_tuples, stripe and null bitmap offsets.
+void CheckBlockImages() {
+  UseHostMemoryForBlocks(true);
+  {
+    CatalogRelation rel(40, "plain");
+    rel.addAttribute("k", Type::Int());
+    rel.addAttribute("p", Type::Double());
+    rel.addAttribute("c", Type::Char(7));
+    const std::int64_t n = 1000;
+    std::vector<std::int32_t> k(n);
+    std::vector<double> pcol(n);
+    std::vector<char> c(n * 7);
+    for (std::int64_t i = 0; i < n; ++i) { k[i] = static_cast<std::int32_t>(i * 3); pcol[i] = i * 0.5; std::snprintf(&c[i * 7], 7, "r%lld", static_cast<long long>(i)); }
+    std::int64_t max_tuples = 0;
+    std::vector<unsigned char> image = block_image::Build(rel, {k.data(), pcol.data(), c.data()}, {{}, {}, {}}, n, 2u << 20, 1, &max_tuples);
+    const ReferenceBlockLayout layout = ParseReferenceBlockImage(rel, image.data(), 4096, image.size());
+    EXPECT_EQ(layout.num_tuples, n);
+    EXPECT_EQ(layout.max_tuples, max_tuples);
+    EXPECT_EQ(layout.sort_attribute, 1);
+    // 2 MB - 4 - header - 8 bytes over 19-byte rows
+    EXPECT_EQ(layout.max_tuples, static_cast<std::int64_t>((layout.tuple_store_size - 8) / 19));
+    EXPECT_EQ(layout.stripe_offset[1] - layout.stripe_offset[0], static_cast<std::size_t>(max_tuples) * 4);
+    EXPECT_EQ(layout.stripe_offset[2] - layout.stripe_offset[1], static_cast<std::size_t>(max_tuples) * 8);
+    EXPECT_TRUE(layout.null_bitmap_offset[0] == static_cast<std::size_t>(-1));
+    StorageManager storage;
+    const block_id id = storage.adoptBlockImage(&rel, image.data(), image.size());
+    BlockReference blk = storage.getBlock(id);
+    EXPECT_EQ(blk->numTuples(), n);
+    EXPECT_EQ(blk->sortColumn(), 1);
+    EXPECT_TRUE(blk->stripe(0) == image.data() + layout.stripe_offset[0]);      // in place: no copy
+    std::vector<double> got(n);
+    blk->copyAttributeToHost(1, got.data());
+    EXPECT_TRUE(got == pcol);
+  }
+  {
+    CatalogRelation rel(41, "nullable");
+    rel.addAttribute("k", Type::Long());
+    rel.addAttribute("q", Type::Int().getNullableVersion());
+    rel.addAttribute("v", Type::Double().getNullableVersion());
+    const std::int64_t n = 12345;
+    std::vector<std::int64_t> k(n);
+    std::vector<std::int32_t> q(n);
+    std::vector<double> v(n);
+    std::vector<bool> qn(n), vn(n);
+    for (std::int64_t i = 0; i < n; ++i) { k[i] = i; q[i] = static_cast<std::int32_t>(i % 50); v[i] = i * 0.25; qn[i] = i % 17 == 0; vn[i] = i % 5 == 2; }
+    std::int64_t max_tuples = 0;
+    std::vector<unsigned char> image = block_image::Build(rel, {k.data(), q.data(), v.data()}, {{}, qn, vn}, n, 4u << 20, -1, &max_tuples);
+    const ReferenceBlockLayout layout = ParseReferenceBlockImage(rel, image.data(), 8192, image.size());
+    EXPECT_EQ(layout.max_tuples, max_tuples);
+    EXPECT_EQ(layout.sort_attribute, kInvalidAttributeID);
+    const std::size_t bitmap_bytes = static_cast<std::size_t>((max_tuples + 63) / 64 * 8);
+    EXPECT_EQ(layout.null_bitmap_offset[1], layout.tuple_store_offset + 8);
+    EXPECT_EQ(layout.null_bitmap_offset[2], layout.tuple_store_offset + 8 + bitmap_bytes);
+    EXPECT_EQ(layout.stripe_offset[0], layout.tuple_store_offset + 8 + 2 * bitmap_bytes);
+    // the two-step max_tuples of the reference: the bitmaps' rounding to whole words must still fit
+    EXPECT_TRUE(8 + 2 * bitmap_bytes + static_cast<std::size_t>(max_tuples) * 20 <= layout.tuple_store_size);
+    EXPECT_TRUE(8 + 2 * bitmap_bytes + static_cast<std::size_t>(max_tuples + 1) * 20 > layout.tuple_store_size - 16);
+    StorageManager storage;
+    BlockReference blk = storage.getBlock(storage.adoptBlockImage(&rel, image.data(), image.size()));
+    std::vector<std::uint64_t> nulls(static_cast<std::size_t>((n + 63) / 64));
+    blk->copyNullBitmapToHost(2, nulls.data());
+    bool same = true;
+    for (std::int64_t i = 0; i < n; ++i) same = same && (((nulls[i >> 6] >> (63 - (i & 63))) & 1u) != 0) == vn[i];
+    EXPECT_TRUE(same);
+    // malformed images are refused (StorageBlock.cpp:108-131), other tuple stores reported as unsupported
+    auto refused = [&](std::vector<unsigned char> bad, std::size_t bytes, int want_status) {
+      try {
+        (void)ParseReferenceBlockImage(rel, bad.data(), std::min<std::size_t>(bytes, 8192), bytes);
+      } catch (const ExecutionError &e) {
+        return e.status() == want_status;
+      }
+      return false;
+    };
+    std::vector<unsigned char> bad = image;
+    const std::int32_t negative = -5;
+    std::memcpy(bad.data(), &negative, 4);
+    EXPECT_TRUE(refused(bad, bad.size(), QSX_ERR_INVALID_ARGUMENT));
+    EXPECT_TRUE(refused(image, 100, QSX_ERR_INVALID_ARGUMENT));                          // sub-block sizes exceed the block
+    bad = image;
+    const std::int32_t too_many = static_cast<std::int32_t>(max_tuples + 1);
+    std::memcpy(bad.data() + layout.tuple_store_offset, &too_many, 4);
+    EXPECT_TRUE(refused(bad, bad.size(), QSX_ERR_INVALID_ARGUMENT));
+    std::vector<unsigned char> split_row = block_image::Header(2, 1000, -1, /*SPLIT_ROW_STORE=*/3);
+    std::vector<unsigned char> other(4096, 0);
+    const std::int32_t len = static_cast<std::int32_t>(split_row.size());
+    std::memcpy(other.data(), &len, 4);
+    std::memcpy(other.data() + 4, split_row.data(), split_row.size());
+    EXPECT_TRUE(refused(other, other.size(), QSX_ERR_UNSUPPORTED));
+  }
+  UseHostMemoryForBlocks(false);
+}
+
 int main() {
+  CheckBlockImages();
   // ---- compressed attributes -----------------------------------------------------------------------------------------
   {
     std::vector<std::int32_t> small, dict, wide;

@@ -14,7 +14,8 @@ def _ensure_built():
     if not all(os.path.exists(os.path.join(BIN, b)) for b in
                ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
                 "lip_filter_operator_test", "compressed_block_operator_test", "host_logic_test",
-                "sort_operator_test", "nullable_operator_test", "tpch_types_operator_test", "tpch_q3_plan_test", "work_order_runs_test")):
+                "sort_operator_test", "nullable_operator_test", "tpch_types_operator_test", "tpch_q3_plan_test", "work_order_runs_test",
+                "partition_operator_test", "headline_operators_bench", "block_image_test")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -106,3 +107,30 @@ def test_work_orders_over_runs_of_blocks():
     not cover are executed block by block inside the work order."""
     out = _run("work_order_runs_test")
     assert "per run of 64 blocks" in out
+
+
+@pytest.mark.gpu
+def test_partition_test_known_answers_through_the_operators():
+    """Partition.test: the 4-way hash partition listing produced by a repartitioning Select into a
+    PartitionAwareInsertDestination (K9 scatter), partitioned / broadcast / REPARTITIONED hash joins, partitioned aggregation;
+    has_repartition and the destination kind must agree (an error, never ignored)."""
+    _run("partition_operator_test")
+
+
+@pytest.mark.gpu
+def test_headline_workload_through_the_operator_boundary():
+    """BASELINE configs 2 + 3 as BuildHash / HashJoin / Aggregation / FinalizeAggregation operators under ForemanSingleNode on
+    4 MB blocks with work orders over runs of blocks, scaled to 1 M x 20 M + 60 M rows; every step's results are checked
+    (join condition on every output row, COUNT / SUM(qty) exact, sums to 1e-6)."""
+    _ensure_built()
+    r = subprocess.run([os.path.join(BIN, "headline_operators_bench"), "1000000", "20000000", "60000000", "2", "1", "4", "16"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '"checked": true' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_reference_block_images_are_adopted_in_place():
+    """Block images in the reference's layout ([int32 header length][StorageBlockHeader][{num_tuples, nulls_in_sort_column}]
+    [null bitmaps][stripes at max_tuples x width]) copied to device memory as they are: Select / Aggregation / HashJoin over
+    the adopted blocks equal the same operators over blocks loaded column by column (nullable and non-nullable relations)."""
+    _run("block_image_test")
