@@ -581,6 +581,12 @@ def run_c4(ctx, args):
 
     elapsed = timed_loop(ctx, step, args)
     phase_ms = phase_means(recorded, args.steps)
+    # one more (untimed) step with HIP events around the device phases of the plan
+    from quickstep_amd import distributed as qd
+    qd.phases.enabled = True
+    step(False)
+    phase_ms.update({"  " + k: v for k, v in qd.phases.read().items()})
+    qd.phases.enabled = False
     cols = results["cols"]
     out_rows = all_sum(ctx, cols[0].numel())
     total_lines = all_sum(ctx, n_l)
@@ -630,6 +636,11 @@ def run_c5(ctx, args):
 
     elapsed = timed_loop(ctx, step, args)
     phase_ms = phase_means(recorded, args.steps)
+    from quickstep_amd import distributed as qd
+    qd.phases.enabled = True          # one more (untimed) step with HIP events around the phases of the plan
+    step(False)
+    phase_ms.update({"  " + k: v for k, v in qd.phases.read().items()})
+    qd.phases.enabled = False
     rows_rank = inputs["c_custkey"].numel() + inputs["o_orderkey"].numel() + inputs["l_orderkey"].numel()
     rows = all_sum(ctx, rows_rank)
     pairs = all_sum(ctx, results["pairs"])

@@ -392,6 +392,12 @@ int qsx_join_table_destroy(qsx_join_table_t *table);
  *   out_dev n int64 on device;  out_exact  host int */
 int qsx_join_key_pack(int ncols, const void *const *cols, const int32_t *types, int64_t n,
                       int64_t *out_dev, int *out_exact, qsx_stream_t stream);
+/* A CHAR(n <= 8) join key attribute as a LONG key: the bytes of the value (up to its first NUL) little-endian, zero behind
+ * them — two CHAR values are equal strings exactly when their keys are equal, so the join tables, qsx_join_key_pack (as a
+ * LONG component of a composite key) and the partition function take it from there.  The reference hashes the string
+ * (types/TypedValue.hpp:626-633) and compares it on lookup; CHAR(n > 8) and VARCHAR keys are not supported. */
+int qsx_join_key_pack_char(const void *col_dev, int width, int64_t n, int64_t *out_dev, qsx_stream_t stream);
+
 /* qsx_join_key_pack over a run of blocks in one launch: the packed keys of all blocks in ONE stripe, block after block
  * (out_dev: sum of block_rows values) — what the run forms of build and probe then take as a single key stripe.
  *   block_cols   host array [b * ncols + k] of device pointers: block b's stripe of key component k */
@@ -575,6 +581,15 @@ typedef struct qsx_pred_term {
 int qsx_eval_expression(int num_columns, const void *const *cols, const int32_t *types, int num_instrs,
                         const qsx_expr_instr_t *instrs, const double *consts, qsx_operand_t result, int64_t n,
                         double *out_dev, qsx_stream_t stream);
+
+/* The same over INT / LONG operands in INTEGER arithmetic — what the reference's ArithmeticBinaryOperators compute for integer
+ * argument types (types/operations/binary_operations/ArithmeticBinaryOperators.hpp:203-340): INT op INT is an INT (32-bit
+ * wrap-around), an operation with a LONG operand a LONG; `/` truncates toward zero, x / 0 gives 0.  consts: host array of
+ * QSX_MAX_CONSTS int64 (a constant that fits 32 bits counts as an INT operand).  out_width 4 or 8: the result stripe holds
+ * INT or LONG values (the caller knows the expression's type by the same rule). */
+int qsx_eval_expression_long(int num_columns, const void *const *cols, const int32_t *types, int num_instrs,
+                             const qsx_expr_instr_t *instrs, const int64_t *consts, qsx_operand_t result, int64_t n, int out_width,
+                             void *out_dev, qsx_stream_t stream);
 
 typedef struct qsx_agg_config {
   int32_t strategy;                       /* qsx_agg_strategy_t */

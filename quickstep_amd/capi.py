@@ -86,6 +86,7 @@ _SIGNATURES = {
     "qsx_join_table_create_dense": (_int, [_int, _i64, _i64, _i64, _i64, _pp]),
     "qsx_join_table_destroy": (_int, [_vp]),
     "qsx_join_key_pack": (_int, [_int, _pp, C.POINTER(_i32), _i64, _vp, C.POINTER(_int), _vp]),
+    "qsx_join_key_pack_char": (_int, [_vp, _int, _i64, _vp, _vp]),
     "qsx_join_table_clear": (_int, [_vp, _vp]),
     "qsx_join_table_size": (_int, [_vp, C.POINTER(_i64), _vp]),
     "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -98,6 +99,7 @@ _SIGNATURES = {
     "qsx_join_probe_count": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "qsx_join_probe_exists": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
     "qsx_eval_expression": (_int, [_int, _pp, C.POINTER(_i32), _int, C.POINTER(T.ExprInstr), C.POINTER(C.c_double), T.Operand, _i64, _vp, _vp]),
+    "qsx_eval_expression_long": (_int, [_int, _pp, C.POINTER(_i32), _int, C.POINTER(T.ExprInstr), C.POINTER(_i64), T.Operand, _i64, _int, _vp, _vp]),
     "qsx_agg_state_create": (_int, [C.POINTER(T.AggConfig), _pp]),
     "qsx_agg_state_destroy": (_int, [_vp]),
     "qsx_select_cmp_sorted_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, _int, _vp, _pp, _pp, _vp, _vp]),
@@ -361,6 +363,19 @@ def eval_expression(cols, instrs, consts, result, stream=None):
     return out
 
 
+def eval_expression_long(cols, instrs, consts, result, out_dtype=torch.int64, stream=None):
+    """The expression program over INT / LONG columns in integer arithmetic (qsx_eval_expression_long)."""
+    n = cols[0].numel()
+    out = torch.empty(n, dtype=out_dtype, device=cols[0].device)
+    ptrs = (C.c_void_p * max(len(cols), 1))(*[c.data_ptr() for c in cols])
+    types = (C.c_int32 * max(len(cols), 1))(*[qsx_type_of(c) for c in cols])
+    prog = (T.ExprInstr * max(len(instrs), 1))(*[T.ExprInstr(op, dst, a, b) for op, dst, a, b in instrs])
+    cs = (C.c_int64 * T.MAX_CONSTS)(*[int(c) for c in consts])
+    _check(_lib.qsx_eval_expression_long(len(cols), ptrs, types, len(instrs), prog, cs, result, n, out.element_size(), _ptr(out),
+                                         _stream(stream)), "qsx_eval_expression_long")
+    return out
+
+
 def select_codes_sorted(codes, op, first, second=0, filter_bitmap=None, stream=None):
     """K1 on the code stripe of a compressed SORT column (ascending codes): binary search instead of a scan."""
     n = codes.numel()
@@ -461,6 +476,14 @@ def join_key_pack(cols, stream=None):
     _check(_lib.qsx_join_key_pack(len(cols), ptrs, types, n, _ptr(out), C.byref(exact), _stream(stream)),
            "qsx_join_key_pack")
     return out, bool(exact.value)
+
+
+def join_key_pack_char(col, stream=None):
+    """CHAR(n <= 8) stripe (uint8 tensor of shape (rows, n)) -> LONG join keys."""
+    n, width = col.shape
+    out = torch.empty(n, dtype=torch.int64, device=col.device)
+    _check(_lib.qsx_join_key_pack_char(_ptr(col), width, n, _ptr(out), _stream(stream)), "qsx_join_key_pack_char")
+    return out
 
 
 def join_key_pack_blocks(blocks, stream=None):

@@ -359,6 +359,53 @@ __global__ __launch_bounds__(kABlock) void eval_expression_kernel(const ExprProg
   }
 }
 
+// The same program over INT / LONG operands in integer arithmetic (ArithmeticBinaryOperators.hpp:203-340 instantiated for
+// integer types: C++ +, -, *, / on the values; INT op INT is an INT, anything with a LONG a LONG).  Evaluated in 64 bits and
+// narrowed at the store: the low 32 bits of a 64-bit +, -, * are those of the 32-bit operation.  x / 0 gives 0 (the
+// reference's division by zero is undefined behaviour).
+struct IntExprProgram {
+  const void *cols[QSX_MAX_COLUMNS];
+  int32_t types[QSX_MAX_COLUMNS];
+  DevInstr instrs[QSX_MAX_INSTRS];
+  long long consts[QSX_MAX_CONSTS];
+  DevOperand result;
+  int32_t num_instrs;
+  int32_t narrow[QSX_MAX_INSTRS];   // instruction k produces an INT (both operands INT): wrap to 32 bits like the reference's int arithmetic
+};
+static_assert(sizeof(IntExprProgram) % 4 == 0, "store_struct_kernel copies words");
+__global__ __launch_bounds__(kABlock) void eval_expression_long_kernel(const IntExprProgram *__restrict__ program, int64_t n, int out_width,
+                                                                      void *__restrict__ out) {
+  const IntExprProgram &p = *program;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * kABlock + threadIdx.x; row < n; row += static_cast<int64_t>(gridDim.x) * kABlock) {
+    long long temps[QSX_MAX_TEMPS];
+    auto operand = [&](const DevOperand &o) -> long long {
+      switch (o.kind) {
+        case QSX_OPD_COLUMN:
+          return p.types[o.index] == QSX_INT ? static_cast<long long>(static_cast<const int32_t *>(p.cols[o.index])[row])
+                                             : static_cast<const long long *>(p.cols[o.index])[row];
+        case QSX_OPD_CONST: return p.consts[o.index];
+        default: return temps[o.index];
+      }
+    };
+    for (int k = 0; k < p.num_instrs; ++k) {
+      const DevInstr in = p.instrs[k];
+      const long long a = operand(in.a), b = operand(in.b);
+      long long r;
+      switch (in.op) {
+        case QSX_EX_ADD: r = static_cast<long long>(static_cast<unsigned long long>(a) + static_cast<unsigned long long>(b)); break;
+        case QSX_EX_SUB: r = static_cast<long long>(static_cast<unsigned long long>(a) - static_cast<unsigned long long>(b)); break;
+        case QSX_EX_MUL: r = static_cast<long long>(static_cast<unsigned long long>(a) * static_cast<unsigned long long>(b)); break;
+        default: r = b == 0 ? 0 : (b == -1 ? static_cast<long long>(0ull - static_cast<unsigned long long>(a)) : a / b); break;
+      }
+      if (p.narrow[k]) r = static_cast<long long>(static_cast<int32_t>(r));
+      temps[in.dst] = r;
+    }
+    const long long value = operand(p.result);
+    if (out_width == 4) static_cast<int32_t *>(out)[row] = static_cast<int32_t>(value);
+    else static_cast<long long *>(out)[row] = value;
+  }
+}
+
 // A wide-key state whose finalize saw MIN != MAX in a key word reports it in the group count (include/qsx.h).
 __global__ void report_collision_kernel(const int *collision, unsigned long long *out_groups) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && *collision != 0) *out_groups = static_cast<unsigned long long>(QSX_GROUPS_HASH_COLLISION);
@@ -1083,7 +1130,12 @@ static const ShapeEntry *find_shape(const qsx_agg_config_t &c) {
 // ---- run-time plan shapes (agg_jit.hpp) ---------------------------------------------------------
 static long long jit_min_rows() {
   const char *e = getenv("QSX_AGG_JIT_MIN_ROWS");   // read per call: tests switch it at run time
-  return e != nullptr ? atoll(e) : 16ll * 1024 * 1024;   // below this the interpreter costs less than the compile
+  // The compile runs on a background thread and its result is kept per process by source text, so what the threshold
+  // guards is a CPU core for 1-2 s per DISTINCT plan shape, not the caller's time: a shape is worth that once a state of
+  // it has seen 2 Mi rows (45 us through the interpreter) — every later state of the shape, however small, then starts on
+  // the compiled kernel as soon as it has seen as many rows itself.  (16 Mi until round 3: a query whose states stayed
+  // below that never left the interpreter.)
+  return e != nullptr ? atoll(e) : 2ll * 1024 * 1024;
 }
 
 // The specialised kernel of this state for the filter variant, compiling it on first use once the state
@@ -2220,6 +2272,68 @@ int qsx_eval_expression(int num_columns, const void *const *cols, const int32_t 
   hipLaunchKernelGGL(store_struct_kernel<ExprProgram>, dim3(1), dim3(64), 0, s, prog, slot);
   QSX_CHECK_LAUNCH();
   hipLaunchKernelGGL(eval_expression_kernel, dim3(grid_for(n, kABlock * kExprRows)), dim3(kABlock), 0, s, slot, n, out_dev);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
+int qsx_eval_expression_long(int num_columns, const void *const *cols, const int32_t *types, int num_instrs,
+                             const qsx_expr_instr_t *instrs, const int64_t *consts, qsx_operand_t result, int64_t n, int out_width,
+                             void *out_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (num_columns < 0 || num_columns > QSX_MAX_COLUMNS || num_instrs < 0 || num_instrs > QSX_MAX_INSTRS || n < 0 ||
+      (num_columns > 0 && (cols == nullptr || types == nullptr)) || (num_instrs > 0 && instrs == nullptr) ||
+      (n > 0 && out_dev == nullptr) || (out_width != 4 && out_width != 8)) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  IntExprProgram prog{};
+  prog.num_instrs = num_instrs;
+  for (int c = 0; c < num_columns; ++c) {
+    if (types[c] != QSX_INT && types[c] != QSX_LONG) return QSX_ERR_UNSUPPORTED;   // FLOAT / DOUBLE operands: qsx_eval_expression
+    if (n > 0 && cols[c] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    prog.cols[c] = cols[c];
+    prog.types[c] = types[c];
+  }
+  int defined = 0;
+  bool temp_is_int[QSX_MAX_TEMPS] = {};
+  auto valid = [&](const qsx_operand_t &o) {
+    switch (o.kind) {
+      case QSX_OPD_COLUMN: return o.index >= 0 && o.index < num_columns;
+      case QSX_OPD_CONST: return o.index >= 0 && o.index < QSX_MAX_CONSTS && consts != nullptr;
+      case QSX_OPD_TEMP: return o.index >= 0 && o.index < QSX_MAX_TEMPS && ((defined >> o.index) & 1) != 0;
+      default: return false;
+    }
+  };
+  // INT unless a LONG is involved (a constant counts as INT when it fits 32 bits)
+  auto is_int = [&](const qsx_operand_t &o) {
+    switch (o.kind) {
+      case QSX_OPD_COLUMN: return types[o.index] == QSX_INT;
+      case QSX_OPD_CONST: return consts[o.index] >= INT32_MIN && consts[o.index] <= INT32_MAX;
+      default: return temp_is_int[o.index];
+    }
+  };
+  for (int k = 0; k < num_instrs; ++k) {
+    const qsx_expr_instr_t &in = instrs[k];
+    if (in.op < QSX_EX_ADD || in.op > QSX_EX_DIV || in.dst < 0 || in.dst >= QSX_MAX_TEMPS || !valid(in.a) || !valid(in.b)) {
+      return QSX_ERR_INVALID_ARGUMENT;
+    }
+    prog.instrs[k].op = in.op;
+    prog.instrs[k].dst = in.dst;
+    prog.instrs[k].a = DevOperand{in.a.kind, in.a.index};
+    prog.instrs[k].b = DevOperand{in.b.kind, in.b.index};
+    prog.narrow[k] = is_int(in.a) && is_int(in.b) ? 1 : 0;
+    temp_is_int[in.dst] = prog.narrow[k] != 0;
+    defined |= 1 << in.dst;
+  }
+  if (!valid(result)) return QSX_ERR_INVALID_ARGUMENT;
+  prog.result = DevOperand{result.kind, result.index};
+  for (int k = 0; k < QSX_MAX_CONSTS; ++k) prog.consts[k] = consts != nullptr ? consts[k] : 0;
+  if (n == 0) return QSX_OK;
+  hipStream_t s = as_stream(stream);
+  IntExprProgram *slot = device_slot<IntExprProgram>(s);
+  if (slot == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  hipLaunchKernelGGL(store_struct_kernel<IntExprProgram>, dim3(1), dim3(64), 0, s, prog, slot);
+  QSX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(eval_expression_long_kernel, dim3(grid_for(n, kABlock * 4)), dim3(kABlock), 0, s, slot, n, out_width, out_dev);
   QSX_CHECK_LAUNCH();
   return QSX_OK;
 }

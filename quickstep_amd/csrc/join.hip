@@ -191,6 +191,18 @@ __global__ __launch_bounds__(kJBlock) void rehash_kernel(int is_long, TableView 
   }
 }
 
+// head[] -> the 3-byte copy the probes read (sealed_pack).  Entries beyond 23 bits cannot occur: the host checks the row
+// and overflow counts first.
+__global__ __launch_bounds__(kJBlock) void dense_pack_kernel(const uint32_t *__restrict__ head, uint64_t range, unsigned char *__restrict__ head3) {
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < range; i += static_cast<uint64_t>(gridDim.x) * kJBlock) {
+    const uint32_t w = head[i];
+    const uint32_t packed = (w & 0x7FFFFFu) | ((w & kChainBit) >> 8);
+    head3[i * 3] = static_cast<unsigned char>(packed);
+    head3[i * 3 + 1] = static_cast<unsigned char>(packed >> 8);
+    head3[i * 3 + 2] = static_cast<unsigned char>(packed >> 16);
+  }
+}
+
 // Every entry of a hashed table into a directly addressed one (seal_table): what dense_build_kernel does per build row.
 __global__ __launch_bounds__(kJBlock) void dense_build_from_slots_kernel(int is_long, TableView src, DenseTableView d) {
   const int64_t cap = static_cast<int64_t>(src.mask) + 1;
@@ -513,6 +525,22 @@ __global__ __launch_bounds__(kJBlock) void key_pack_kernel(KeyPackArgs a, int64_
   }
 }
 
+// A CHAR(n <= 8) join key as a LONG: the bytes up to the first NUL (AsciiStringComparators.hpp:218-251: a value ends
+// there), zero behind it — equal strings give equal keys whatever lies behind the terminator in the stripe.
+__global__ __launch_bounds__(kJBlock) void key_pack_char_kernel(const unsigned char *__restrict__ col, int width, int64_t n,
+                                                               int64_t *__restrict__ out) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kJBlock) {
+    uint64_t key = 0;
+    bool ended = false;
+    for (int b = 0; b < width; ++b) {
+      const unsigned char c = col[i * width + b];
+      ended = ended || c == 0;
+      key |= static_cast<uint64_t>(ended ? 0 : c) << (8 * b);
+    }
+    out[i] = static_cast<int64_t>(key);
+  }
+}
+
 // The composite keys of a run of blocks -> ONE stripe of packed keys, block after block (qsx_join_key_pack_blocks): a wave
 // takes tiles of 512 rows of one block; the blocks' key columns follow the run table at word cols_offset
 // ([block * ncols + component]), the table's `base` is the block's first row in the output.
@@ -556,6 +584,7 @@ struct qsx_join_table {
   void *slots = nullptr;
   unsigned long long *entries_dev = nullptr;
   int64_t reserved = 0;   // host-side upper bound of entries (rows handed to build so far)
+  std::atomic<int64_t> max_tid{-1};   // host-side upper bound of the tuple ids stored so far (base_tid + rows of every build)
   // Builds/probes take it shared, growth takes it exclusive — the role of
   // HashTable::resize_shared_mutex_ (storage/HashTable.hpp:1215).
   std::shared_mutex mutex;
@@ -574,11 +603,15 @@ struct qsx_join_table {
   int stride_shift = 0;
   uint64_t range = 0;
   uint32_t *head = nullptr;
+  unsigned char *head3 = nullptr;   // the probes' 3-byte copy of head[] (sealed_pack); valid while seal_state == 2
+  hipEvent_t pack_event = nullptr;  // recorded behind the pack kernel on pack_stream
+  hipStream_t pack_stream = nullptr;
   uint2 *ov = nullptr;
   unsigned int ov_capacity = 0;
   DenseTableView dense_view() const {
     DenseTableView v;
     v.head = head;
+    v.head3 = seal_state.load(std::memory_order_acquire) == 2 ? head3 : nullptr;
     v.ov = ov;
     v.min_key = min_key;
     v.stride_shift = stride_shift;
@@ -770,6 +803,17 @@ int qsx_join_key_pack(int ncols, const void *const *cols, const int32_t *types, 
   return QSX_OK;
 }
 
+int qsx_join_key_pack_char(const void *col_dev, int width, int64_t n, int64_t *out_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (n < 0 || (n > 0 && (col_dev == nullptr || out_dev == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
+  if (width < 1 || width > 8) return QSX_ERR_UNSUPPORTED;
+  if (n == 0) return QSX_OK;
+  hipLaunchKernelGGL(key_pack_char_kernel, dim3(grid_for(n, kJBlock * 4)), dim3(kJBlock), 0, as_stream(stream),
+                     static_cast<const unsigned char *>(col_dev), width, n, out_dev);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
 int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks, const int64_t *block_rows,
                              const void *const *block_cols, int64_t *out_dev, int *out_exact, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
@@ -827,6 +871,8 @@ int qsx_join_table_destroy(qsx_join_table_t *t) {
   if (t->shadow != nullptr) (void)qsx_join_table_destroy(t->shadow);
   (void)device_free_idle(t->slots);
   (void)device_free_idle(t->head);
+  (void)device_free_idle(t->head3);
+  if (t->pack_event != nullptr) (void)hipEventDestroy(t->pack_event);
   (void)device_free_idle(t->ov);
   (void)device_free_idle(t->entries_dev);
   delete t;
@@ -845,6 +891,7 @@ int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
   const int rc_control = reset_control_words(t->entries_dev, as_stream(stream));
   if (rc_control != QSX_OK) return rc_control;
   t->reserved = 0;
+  t->max_tid.store(-1);
   t->seal_state.store(0);
   return QSX_OK;
 }
@@ -871,6 +918,7 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   int rc = ensure_room(t, n);
   if (rc != QSX_OK) return rc;
   t->seal_state.store(0);
+  for (int64_t seen = t->max_tid.load(); seen < base_tid + n - 1 && !t->max_tid.compare_exchange_weak(seen, base_tid + n - 1);) {}
   std::shared_lock<std::shared_mutex> lock(t->mutex);
   const int grid = grid_for(n, kJBlock * 4);
   if (t->dense) {
@@ -916,6 +964,10 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
   int rc = ensure_room(t, total);
   if (rc != QSX_OK) return rc;
   t->seal_state.store(0);
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    const int64_t last = base[b] + block_rows[b] - 1;
+    for (int64_t seen = t->max_tid.load(); seen < last && !t->max_tid.compare_exchange_weak(seen, last);) {}
+  }
   hipStream_t s = as_stream(stream);
   std::vector<long long> table;
   const long long groups = build_run_table(kBuildTile, num_blocks, block_rows, block_keys,
@@ -1012,6 +1064,53 @@ static bool adaptive_enabled() {
   return e == nullptr || e[0] != '0';
 }
 
+// Directly addressed tables around the size of an XCD's L2: the first probe after the builds packs head[] to 3 bytes per key
+// value when that makes it fit (4-byte words beyond ~3.25 MiB, the packed copy at most 3.6 MiB, every stored number below
+// 2^23).  Builds keep working on head[]; a build or clear drops the copy.
+static void sealed_pack(qsx_join_table *t, hipStream_t stream) {
+  int state = t->seal_state.load(std::memory_order_acquire);
+  if (state == 2) {
+    // packed on another stream a moment ago?  This stream's probe must not overtake the pack kernel.
+    if (t->pack_stream != stream && t->pack_event != nullptr && hipEventQuery(t->pack_event) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamWaitEvent(stream, t->pack_event, 0);
+    }
+    return;
+  }
+  if (state != 0 || !adaptive_enabled()) return;
+  const uint64_t bytes4 = t->range * 4, bytes3 = t->range * 3;
+  // every number a head word can hold — tuple id + 1, overflow entry — stays below 2^23: both bounds are known on the host
+  if (bytes4 <= (13ull << 18) || bytes3 > (36ull << 20) / 10 || t->max_tid.load() >= (1 << 23) - 2 || t->reserved >= (1 << 23) - 1) {
+    return;   // (not marked: the test is four comparisons)
+  }
+  std::lock_guard<std::mutex> lock(t->seal_mutex);
+  if (t->seal_state.load(std::memory_order_acquire) != 0) return;
+  // No host synchronisation: the pack kernel is ordered on the probing stream behind the builds the caller has ordered
+  // before this probe (pipeline breaker), and other streams' probes wait for its event.
+  if (t->head3 == nullptr && device_malloc(&t->head3, static_cast<size_t>(bytes3) + 4) != hipSuccess) {
+    (void)hipGetLastError();
+    t->head3 = nullptr;
+    t->seal_state.store(1, std::memory_order_release);
+    return;
+  }
+  if (t->pack_event == nullptr && hipEventCreateWithFlags(&t->pack_event, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    t->pack_event = nullptr;
+    t->seal_state.store(1, std::memory_order_release);
+    return;
+  }
+  hipLaunchKernelGGL(dense_pack_kernel, dim3(grid_for(static_cast<int64_t>(t->range), kJBlock * 4)), dim3(kJBlock), 0, stream, t->head, t->range,
+                     t->head3);
+  if (hipGetLastError() != hipSuccess || hipEventRecord(t->pack_event, stream) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(stream);
+    t->seal_state.store(1, std::memory_order_release);
+    return;
+  }
+  t->pack_stream = stream;
+  t->seal_state.store(2, std::memory_order_release);
+}
+
 static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream) {
   int state = t->seal_state.load(std::memory_order_acquire);
   if (state == 2) return t->shadow;
@@ -1047,6 +1146,7 @@ static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream) {
     return nullptr;
   }
   shadow->reserved = static_cast<int64_t>(entries);
+  shadow->max_tid.store(t->max_tid.load());
   const TableView src = t->view();
   hipLaunchKernelGGL(dense_build_from_slots_kernel, dim3(grid_for(static_cast<int64_t>(src.mask) + 1, kJBlock * 4)), dim3(kJBlock), 0, stream,
                      t->key_type == QSX_LONG ? 1 : 0, src, shadow->dense_view());
@@ -1078,6 +1178,7 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
   }
   if (out_count != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), stream));
   if (n == 0) return QSX_OK;
+  if (t->dense) sealed_pack(t, stream);
   std::shared_lock<std::shared_mutex> lock(t->mutex);
   if (t->dense) {
     const int64_t tiles = kRuns ? run_tiles : (n + kDenseTile - 1) / kDenseTile;

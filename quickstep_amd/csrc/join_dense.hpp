@@ -38,6 +38,10 @@ constexpr int kDenseSparsePairs = 256;   // a wave with at most this many first-
 
 struct DenseTableView {
   uint32_t *head;
+  // != nullptr: head[] packed to 3 bytes per key value for the probes (join.hip sealed_pack): bits 0-22 = tid + 1 or the
+  // overflow entry, bit 23 = chain.  For ~1 M keys that is 3 MiB instead of 4: what fits an XCD's L2 next to the streamed
+  // keys and pairs (tools/ubench/gather_floor.hip: 100 M lookups + pairs 0.48 ms at 3 MiB, 0.57 ms at 4 MiB).
+  const unsigned char *head3;
   uint2 *ov;
   int64_t min_key;
   int stride_shift;          // keys are min_key + i * 2^stride_shift (one hash partition of a dense key domain)
@@ -53,6 +57,14 @@ __device__ __forceinline__ uint64_t dense_index(const DenseTableView &t, KeyT ke
   const uint64_t d = static_cast<uint64_t>(static_cast<int64_t>(key) - t.min_key);
   const uint64_t idx = d >> t.stride_shift;
   return (idx << t.stride_shift) == d && idx < t.range ? idx : ~0ull;
+}
+
+// The head word of key value idx as the probe kernels read it.
+__device__ __forceinline__ uint32_t dense_head_word(const DenseTableView &t, uint64_t idx) {
+  if (t.head3 == nullptr) return t.head[idx];
+  uint32_t w;
+  __builtin_memcpy(&w, t.head3 + idx * 3, 4);       // (one unaligned 4-byte load; the array has a spare byte at its end)
+  return (w & 0x7FFFFFu) | ((w & 0x800000u) << 8);   // chain bit 23 -> bit 31 (kChainBit)
 }
 
 __device__ __forceinline__ bool dense_row_in_filter(const uint64_t *filter, int64_t row) {
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
       // unconditional read (dead lanes read word 0): a guarded read compiles to branch + load + wait per step, which
       // serialises the 16 reads of a tile (seen in the existence variant: 1.45 ms instead of 0.6 ms per 600 M rows)
       const bool lookup = live && idx != ~0ull;
-      const uint32_t word = t.head[lookup ? idx : 0];
+      const uint32_t word = dense_head_word(t, lookup ? idx : 0);
       h[r] = lookup ? word : 0u;
     }
 #pragma unroll

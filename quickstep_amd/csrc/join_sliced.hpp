@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kSBlock) void sliced_probe_kernel(P policy, const t
       uint32_t h[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const uint32_t word = t.head[(live >> r) & 1u ? entry[r] : static_cast<uint32_t>(policy.lo)];   // unconditional read
+        const uint32_t word = dense_head_word(t, (live >> r) & 1u ? entry[r] : static_cast<uint32_t>(policy.lo));   // unconditional read
         h[r] = (live >> r) & 1u ? word : 0u;
       }
       int total = 0;

@@ -97,6 +97,46 @@ class _Transport:
 xfer = _Transport
 
 
+class _PhaseTimer:
+    """Optional HIP-event brackets around the device phases of a plan (bench.py --config c4 / c5): phase(name) is a context
+    manager that records an event pair on the current stream while `enabled`; read() sums the pairs per phase."""
+    enabled = False
+    _pairs = []
+
+    class _Span:
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            if _PhaseTimer.enabled and torch.cuda.is_available():
+                self.start = torch.cuda.Event(enable_timing=True)
+                self.start.record()
+            return self
+
+        def __exit__(self, *exc):
+            if _PhaseTimer.enabled and torch.cuda.is_available():
+                end = torch.cuda.Event(enable_timing=True)
+                end.record()
+                _PhaseTimer._pairs.append((self.name, self.start, end))
+            return False
+
+    @classmethod
+    def phase(cls, name):
+        return cls._Span(name)
+
+    @classmethod
+    def read(cls):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in cls._pairs:
+            out[name] = out.get(name, 0.0) + a.elapsed_time(b)
+        cls._pairs = []
+        return out
+
+
+phases = _PhaseTimer
+
+
 def exchange_counts(send_counts, group=None):
     """send_counts: int64[P] on the compute device.  Returns int64[P] recv counts."""
     recv = torch.empty_like(send_counts)
@@ -112,17 +152,21 @@ def shuffle_by_key(ops, keys, cols, group=None):
     recv_counts list).  Rows from rank r arrive before rows from rank r + 1 and
     keep their local order (the scatter is stable)."""
     world = dist.get_world_size(group)
-    scattered, offsets = ops.partition_scatter(keys, world, cols)
-    send_counts_dev = offsets[1:] - offsets[:-1]
-    recv_counts_dev = exchange_counts(send_counts_dev, group)
-    send_splits = send_counts_dev.cpu().tolist()          # host sync: all_to_all_single needs host split sizes
-    recv_splits = recv_counts_dev.cpu().tolist()
-    total = int(sum(recv_splits))
-    received = []
-    for col in scattered:
-        out = torch.empty(total, dtype=col.dtype, device=col.device)
-        xfer.all_to_all_single(out, col, output_split_sizes=recv_splits, input_split_sizes=send_splits, group=group)
-        received.append(out)
+    with phases.phase("partition_scatter"):
+        scattered, offsets = ops.partition_scatter(keys, world, cols)
+    with phases.phase("exchange"):
+        send_counts_dev = offsets[1:] - offsets[:-1]
+        recv_counts_dev = exchange_counts(send_counts_dev, group)
+        send_splits = send_counts_dev.cpu().tolist()          # host sync: all_to_all_single needs host split sizes
+        recv_splits = recv_counts_dev.cpu().tolist()
+        total = int(sum(recv_splits))
+        if world == 1:
+            return scattered, recv_splits                      # nothing leaves the rank: the scattered columns are the result
+        received = []
+        for col in scattered:
+            out = torch.empty(total, dtype=col.dtype, device=col.device)
+            xfer.all_to_all_single(out, col, output_split_sizes=recv_splits, input_split_sizes=send_splits, group=group)
+            received.append(out)
     return received, recv_splits
 
 
@@ -183,8 +227,9 @@ class PartitionedHashJoin:
         self.build_keys = rkeys
         self.build_payload = received[2:]
         self.shuffled_bytes = sum(c.numel() * c.element_size() for c in received)
-        self.table.clear()
-        self.table.build(rkeys)
+        with phases.phase("build"):
+            self.table.clear()
+            self.table.build(rkeys)
         return rkeys.numel()
 
     def probe(self, keys, tid_base, capacity=None, payload=()):
@@ -201,7 +246,8 @@ class PartitionedHashJoin:
             capacity = max(int(capacity), rkeys.numel())
         else:
             capacity = max(int(self.table.probe_count(rkeys).item()), 1)
-        out_p, out_b, count = self.table.probe(rkeys, capacity=capacity)
+        with phases.phase("probe"):
+            out_p, out_b, count = self.table.probe(rkeys, capacity=capacity)
         return rtids, self.build_tids, out_p, out_b, count
 
     def materialize_payload(self, out_p, out_b, count):
@@ -210,8 +256,9 @@ class PartitionedHashJoin:
         same columns through ScalarAttribute::getAllValuesForJoin)."""
         k = _checked_count(count, out_p)
         p, b = out_p[:k], out_b[:k]
-        return ([self.ops.gather(self.probe_keys, p)] + [self.ops.gather(c, b) for c in self.build_payload]
-                + [self.ops.gather(c, p) for c in self.probe_payload])
+        with phases.phase("materialise"):
+            return ([self.ops.gather(self.probe_keys, p)] + [self.ops.gather(c, b) for c in self.build_payload]
+                    + [self.ops.gather(c, p) for c in self.probe_payload])
 
     def materialize(self, probe_tids, build_tids, out_p, out_b, count):
         """Global (probe_tid, build_tid) pairs of this partition (K5 gathers)."""

@@ -2019,6 +2019,7 @@ QueryContext::join_hash_table_id QueryContext::addJoinHashTable(TypeID key_type,
                                                                 std::size_t num_partitions,
                                                                 const ExactKeyRange *exact_key_range) {
   std::vector<qsx_join_table_t *> parts(num_partitions, nullptr);
+  if (key_type == kChar) key_type = kLong;   // a CHAR(n <= 8) key travels as the LONG qsx_join_key_pack_char makes of it
   for (std::size_t p = 0; p < num_partitions; ++p) {
     if (exact_key_range != nullptr) {
       // every partition addresses the whole range: the single-node partition function is not a stride of the key
@@ -2534,18 +2535,40 @@ namespace {
 // composite key — the LONG fold of the components (qsx_join_key_pack; the QueryContext creates
 // the table of a composite key with key type kLong).  `exact` is false when the fold is the
 // reference's composite hash and joined pairs still need their components compared.
+// A CHAR(n <= 8) key attribute of `block` as a LONG stripe (qsx_join_key_pack_char); wider strings are not join keys here.
+std::unique_ptr<DeviceBuffer> CharKeyAsLong(const StorageBlock &block, attribute_id a) {
+  const Type &t = block.getRelation().getAttributeType(a);
+  if (t.width > 8) throw ExecutionError("join key CHAR(n): n > 8 is not supported", QSX_ERR_UNSUPPORTED);
+  std::unique_ptr<DeviceBuffer> out(new DeviceBuffer(static_cast<std::size_t>(block.numTuples()) * 8 + 8));
+  CheckStatus(qsx_join_key_pack_char(block.stripe(a), t.width, block.numTuples(), static_cast<std::int64_t *>(out->ptr), CurrentStream()),
+              "qsx_join_key_pack_char");
+  return out;
+}
+
 struct JoinKeys {
   const void *ptr = nullptr;
   bool exact = true;
   std::unique_ptr<DeviceBuffer> packed;
+  std::vector<std::unique_ptr<DeviceBuffer>> char_keys;
   JoinKeys(const StorageBlock &block, const std::vector<attribute_id> &attrs) {
     if (attrs.size() == 1) {
+      if (block.getRelation().getAttributeType(attrs.front()).id == kChar) {
+        char_keys.push_back(CharKeyAsLong(block, attrs.front()));
+        ptr = char_keys.back()->ptr;
+        return;
+      }
       ptr = block.stripe(attrs.front());
       return;
     }
     std::vector<const void *> cols;
     std::vector<std::int32_t> types;
     for (attribute_id a : attrs) {
+      if (block.getRelation().getAttributeType(a).id == kChar) {
+        char_keys.push_back(CharKeyAsLong(block, a));
+        cols.push_back(char_keys.back()->ptr);
+        types.push_back(kLong);
+        continue;
+      }
       cols.push_back(block.stripe(a));
       types.push_back(block.getRelation().getAttributeType(a).id);
     }
@@ -2567,17 +2590,33 @@ struct RunJoinKeys {
   std::vector<const void *> ptr;          // per block
   bool exact = true;
   std::unique_ptr<DeviceBuffer> packed;
+  std::vector<std::unique_ptr<DeviceBuffer>> char_keys;
   RunJoinKeys(const std::vector<BlockReference> &blocks, const std::vector<attribute_id> &attrs, const std::vector<std::int64_t> &rows) {
+    const CatalogRelation &relation = blocks.front()->getRelation();
     if (attrs.size() == 1) {
-      for (const BlockReference &b : blocks) ptr.push_back(b->stripe(attrs.front()));
+      for (const BlockReference &b : blocks) {
+        if (relation.getAttributeType(attrs.front()).id == kChar) {
+          char_keys.push_back(CharKeyAsLong(*b, attrs.front()));
+          ptr.push_back(char_keys.back()->ptr);
+        } else {
+          ptr.push_back(b->stripe(attrs.front()));
+        }
+      }
       return;
     }
     std::vector<const void *> cols;
     std::vector<std::int32_t> types;
-    for (attribute_id a : attrs) types.push_back(blocks.front()->getRelation().getAttributeType(a).id);
+    for (attribute_id a : attrs) types.push_back(relation.getAttributeType(a).id == kChar ? static_cast<std::int32_t>(kLong) : relation.getAttributeType(a).id);
     std::int64_t total = 0;
     for (std::size_t b = 0; b < blocks.size(); ++b) {
-      for (attribute_id a : attrs) cols.push_back(blocks[b]->stripe(a));
+      for (attribute_id a : attrs) {
+        if (relation.getAttributeType(a).id == kChar) {
+          char_keys.push_back(CharKeyAsLong(*blocks[b], a));
+          cols.push_back(char_keys.back()->ptr);
+        } else {
+          cols.push_back(blocks[b]->stripe(a));
+        }
+      }
       total += rows[b];
     }
     packed.reset(new DeviceBuffer(static_cast<std::size_t>(total) * 8 + 8));
@@ -2796,7 +2835,9 @@ bool HashInnerJoinWorkOrder::executeRun() {
   if (join_type_ != JoinType::kInnerJoin && !existence) return false;
   if (residual_predicate_ != nullptr && existence) return false;   // (semi / anti with a residual go through the pairs: block by block)
   int key_bits = 0;
-  for (attribute_id a : join_key_attributes_) key_bits += probe_relation_.getAttributeType(a).width * 8;
+  for (attribute_id a : join_key_attributes_) {   // (a CHAR(n <= 8) component travels as a LONG)
+    key_bits += probe_relation_.getAttributeType(a).id == kChar ? 64 : probe_relation_.getAttributeType(a).width * 8;
+  }
   const bool hashed_key = join_key_attributes_.size() > 1 && key_bits > 64;   // the fold is a hash: pairs need their components compared
   if (hashed_key && existence) return false;
   std::vector<BlockReference> blocks;

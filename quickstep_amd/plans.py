@@ -183,54 +183,63 @@ class DistributedQ3:
         self.t_c.clear(); self.t_o.clear(); self.state.clear()
         if self.use_lip:
             self.lip_c.clear(); self.lip_o.clear()
+        ph = qd.phases.phase
         # customer
-        c_sel, c_cnt = ops.select_cmp(inp["c_mktsegment"], T.EQ, SEG_BUILDING)
-        (c_keys,), _ = ops.compact_gather([inp["c_custkey"]], c_sel, inp["c_custkey"].numel())
-        (all_c,), _ = self._all_gather_rows([c_keys], int(c_cnt.item()))
-        self.t_c.build(all_c)
-        if self.use_lip:
-            self.lip_c.build(inp["c_custkey"], filter_bitmap=c_sel)
-            self._or_filter(self.lip_c)
+        with ph("customer: select + gather + build + LIP"):
+            c_sel, c_cnt = ops.select_cmp(inp["c_mktsegment"], T.EQ, SEG_BUILDING)
+            (c_keys,), _ = ops.compact_gather([inp["c_custkey"]], c_sel, inp["c_custkey"].numel())
+            (all_c,), _ = self._all_gather_rows([c_keys], int(c_cnt.item()))
+            self.t_c.build(all_c)
+            if self.use_lip:
+                self.lip_c.build(inp["c_custkey"], filter_bitmap=c_sel)
+                self._or_filter(self.lip_c)
         # orders
-        o_sel, _ = ops.select_cmp(inp["o_orderdate"], T.LT, DATE_CUT)
-        o_lip = self.lip_c.probe(inp["o_custkey"], in_bitmap=o_sel)[0] if self.use_lip else o_sel
-        o_ok, o_cnt = self.t_c.probe_exists(inp["o_custkey"], filter_bitmap=o_lip)
-        n_o_local = inp["o_orderkey"].numel()
-        (o_keys, o_tids), _ = ops.compact_gather([inp["o_orderkey"], self._tids(n_o_local, tid_base_orders, dev)], o_ok, n_o_local)
-        (all_ok, all_ot), counts = self._all_gather_rows([o_keys, o_tids], int(o_cnt.item()))
-        # the table keeps the position in the gathered list; all_ot turns it into the global orders tuple id
-        self.t_o.build(all_ok)
-        self.qualifying_order_tids = all_ot
-        if self.use_lip:
-            self.lip_o.build(all_ok)           # all ranks hold all qualifying keys already: no OR needed
+        with ph("orders: select + LIP probe + semi probe + gather + build + LIP"):
+            o_sel, _ = ops.select_cmp(inp["o_orderdate"], T.LT, DATE_CUT)
+            o_lip = self.lip_c.probe(inp["o_custkey"], in_bitmap=o_sel)[0] if self.use_lip else o_sel
+            o_ok, o_cnt = self.t_c.probe_exists(inp["o_custkey"], filter_bitmap=o_lip)
+            n_o_local = inp["o_orderkey"].numel()
+            (o_keys, o_tids), _ = ops.compact_gather([inp["o_orderkey"], self._tids(n_o_local, tid_base_orders, dev)], o_ok, n_o_local)
+            (all_ok, all_ot), counts = self._all_gather_rows([o_keys, o_tids], int(o_cnt.item()))
+            # the table keeps the position in the gathered list; all_ot turns it into the global orders tuple id
+            self.t_o.build(all_ok)
+            self.qualifying_order_tids = all_ot
+            if self.use_lip:
+                self.lip_o.build(all_ok)           # all ranks hold all qualifying keys already: no OR needed
         # lineitem
-        l_sel, l_sel_count = ops.select_cmp(inp["l_shipdate"], T.GT, DATE_CUT)
-        if self.use_lip:
-            l_lip, l_live = self.lip_o.probe(inp["l_orderkey"], in_bitmap=l_sel)
-        else:
-            l_lip, l_live = l_sel, l_sel_count
-        p, b, cnt = self.t_o.probe(inp["l_orderkey"], capacity=int(l_live.item()), filter_bitmap=l_lip)
-        total = int(cnt.item())
+        with ph("lineitem: select l_shipdate"):
+            l_sel, l_sel_count = ops.select_cmp(inp["l_shipdate"], T.GT, DATE_CUT)
+        with ph("lineitem: LIP probe"):
+            if self.use_lip:
+                l_lip, l_live = self.lip_o.probe(inp["l_orderkey"], in_bitmap=l_sel)
+            else:
+                l_lip, l_live = l_sel, l_sel_count
+        with ph("lineitem: inner probe"):
+            p, b, cnt = self.t_o.probe(inp["l_orderkey"], capacity=int(l_live.item()), filter_bitmap=l_lip)
+            total = int(cnt.item())
         pt = p[:total]
-        if self.fused:
-            self.state.update_coded([pt, pt, pt], [inp["l_orderkey"], inp["l_extendedprice"], inp["l_discount"]], total)
-        else:
-            self.state.update([ops.gather(inp["l_orderkey"], pt), ops.gather(inp["l_extendedprice"], pt),
-                               ops.gather(inp["l_discount"], pt)], total)
+        with ph("group by l_orderkey (dense state, through the pair list)"):
+            if self.fused:
+                self.state.update_coded([pt, pt, pt], [inp["l_orderkey"], inp["l_extendedprice"], inp["l_discount"]], total)
+            else:
+                self.state.update([ops.gather(inp["l_orderkey"], pt), ops.gather(inp["l_extendedprice"], pt),
+                                   ops.gather(inp["l_discount"], pt)], total)
         # merge + finalize this rank's key range
-        self._merge_state(dev)
-        keys, vals, _, groups = self.state.finalize(dev, partition=self.rank, num_partitions=self.world)
-        g = int(groups.item())
-        k = min(10, g)
-        if k:
-            perm = ops.sort_top_k([vals[0][:g]], k, [True])
-            top_keys, top_rev = ops.gather(keys[0][:g], perm), ops.gather(vals[0][:g], perm)
-        else:
-            top_keys, top_rev = keys[0][:0], vals[0][:0]
-        (all_keys, all_rev), _ = self._all_gather_rows([top_keys, top_rev], k)
-        if all_rev.numel() > 10:
-            perm = ops.sort_top_k([all_rev], 10, [True])
-            all_keys, all_rev = ops.gather(all_keys, perm), ops.gather(all_rev, perm)
+        with ph("merge (reduce-scatter)"):
+            self._merge_state(dev)
+        with ph("finalize + top 10"):
+            keys, vals, _, groups = self.state.finalize(dev, partition=self.rank, num_partitions=self.world)
+            g = int(groups.item())
+            k = min(10, g)
+            if k:
+                perm = ops.sort_top_k([vals[0][:g]], k, [True])
+                top_keys, top_rev = ops.gather(keys[0][:g], perm), ops.gather(vals[0][:g], perm)
+            else:
+                top_keys, top_rev = keys[0][:0], vals[0][:0]
+            (all_keys, all_rev), _ = self._all_gather_rows([top_keys, top_rev], k)
+            if all_rev.numel() > 10:
+                perm = ops.sort_top_k([all_rev], 10, [True])
+                all_keys, all_rev = ops.gather(all_keys, perm), ops.gather(all_rev, perm)
         return {"pairs": total, "groups": g, "top_keys": all_keys, "top_revenue": all_rev,
                 "qualifying_customers": int(all_c.numel()), "qualifying_orders": int(all_ok.numel())}
 

@@ -3,6 +3,7 @@
 // (:516-690), CompositeKeyHashJoinTest (:999-1177), CompositeKeyHashJoinWithResidualPredicateTest (:1187-1375),
 // plus semi/anti/outer variants and a Foreman/Worker run of the same plans.  GPU work orders.
 #include <algorithm>
+#include <cstdio>
 #include <map>
 
 #include "test_util.hpp"
@@ -36,6 +37,14 @@ struct Fixture {
     r->addAttribute("varchar_as_long", Type::Long());
     r->addAttribute("varchar_as_int", Type::Int());
     r->addAttribute("tid_int", Type::Int());
+    r->addAttribute("char", Type::Char(4));              // "100" in every tuple of both tables (:196-270)
+    r->addAttribute("varchar_as_char", Type::Char(8));   // the digits of tid / 2 * 2 (dim) resp. tid (fact), as the reference's VARCHAR column holds them
+  }
+  static void chars(std::int64_t varchar_value, std::vector<char> *c4, std::vector<char> *c8) {
+    char a[4] = {'1', '0', '0', 0}, b[24] = {0};
+    std::snprintf(b, sizeof(b), "%lld", static_cast<long long>(varchar_value));
+    c4->insert(c4->end(), a, a + 4);
+    c8->insert(c8->end(), b, b + 8);
   }
   void loadPartitioned(CatalogRelation *r, tuple_id num_tuples, bool is_dim, bool with_scheme) {
     addAttributes(r);
@@ -44,12 +53,14 @@ struct Fixture {
     for (std::size_t part = 0; part < parts; ++part) {
       std::vector<std::int64_t> l, vl;
       std::vector<std::int32_t> v, vi, ti;
+      std::vector<char> c4, c8;
       for (tuple_id tid = 0; tid < num_tuples; ++tid) {
         if (with_scheme && static_cast<std::size_t>(tid) % kMultiplePartitions != part) continue;
         l.push_back(tid); v.push_back(is_dim ? tid % kBlockSize : tid);
         vl.push_back(is_dim ? tid / 2 * 2 : tid); vi.push_back(is_dim ? tid / 2 * 2 : tid); ti.push_back(tid);
+        chars(is_dim ? tid / 2 * 2 : tid, &c4, &c8);
       }
-      storage.loadBlock(r, {l.data(), v.data(), vl.data(), vi.data(), ti.data()}, static_cast<std::int64_t>(l.size()), part);
+      storage.loadBlock(r, {l.data(), v.data(), vl.data(), vi.data(), ti.data(), c4.data(), c8.data()}, static_cast<std::int64_t>(l.size()), part);
     }
   }
   void loadUnpartitioned() {
@@ -61,16 +72,22 @@ struct Fixture {
     for (tuple_id i = 0; i < kNumDimTuples; i += kBlockSize) {
       std::int64_t l[kBlockSize], vl[kBlockSize];
       std::int32_t v[kBlockSize], vi[kBlockSize], ti[kBlockSize];
+      std::vector<char> c4, c8;
       for (tuple_id t = 0; t < kBlockSize; ++t) {
         l[t] = i + t; v[t] = (i + t) % kBlockSize; vl[t] = (i + t) / 2 * 2; vi[t] = (i + t) / 2 * 2; ti[t] = i + t;
+        chars((i + t) / 2 * 2, &c4, &c8);
       }
-      storage.loadBlock(&dim, {l, v, vl, vi, ti}, kBlockSize);
+      storage.loadBlock(&dim, {l, v, vl, vi, ti, c4.data(), c8.data()}, kBlockSize);
     }
     for (tuple_id i = 0; i < kNumFactTuples; i += kBlockSize) {
       std::int64_t l[kBlockSize], vl[kBlockSize];
       std::int32_t v[kBlockSize], vi[kBlockSize], ti[kBlockSize];
-      for (tuple_id t = 0; t < kBlockSize; ++t) { l[t] = i + t; v[t] = i + t; vl[t] = i + t; vi[t] = i + t; ti[t] = i + t; }
-      storage.loadBlock(&fact, {l, v, vl, vi, ti}, kBlockSize);
+      std::vector<char> c4, c8;
+      for (tuple_id t = 0; t < kBlockSize; ++t) {
+        l[t] = i + t; v[t] = i + t; vl[t] = i + t; vi[t] = i + t; ti[t] = i + t;
+        chars(i + t, &c4, &c8);
+      }
+      storage.loadBlock(&fact, {l, v, vl, vi, ti, c4.data(), c8.data()}, kBlockSize);
     }
   }
 };
@@ -272,6 +289,39 @@ int main() {
       EXPECT_EQ(anti.dim_long.size(), static_cast<std::size_t>(kNumFactTuples - kNumDimTuples));
       for (std::size_t i = 0; i < semi.dim_long.size(); ++i) EXPECT_EQ(semi.dim_long[i], static_cast<std::int64_t>(i));
       for (std::size_t i = 0; i < anti.dim_long.size(); ++i) EXPECT_EQ(anti.dim_long[i], static_cast<std::int64_t>(kNumDimTuples + i));
+    }
+  }
+  // ---- CHAR join keys (carried as the LONG qsx_join_key_pack_char makes of them) ---------------------------------------
+  for (const int variant : {0, 1, 2, 3}) {
+    const bool use_foreman = (variant & 1) != 0;
+    g_exact_stats = false;
+    g_partitioning = 0;
+    g_blocks_per_work_order = variant >= 2 ? 7 : 1;
+    {  // CharKeyCartesianProductHashJoinTest (:692-826): every tuple holds "100": 200 x 300 results, every dim row 300 times
+      Result r;
+      runJoin(5, kChar, use_foreman, HashJoinOperator::JoinType::kInnerJoin, &r);
+      EXPECT_EQ(r.dim_long.size(), static_cast<std::size_t>(kNumDimTuples) * kNumFactTuples);
+      std::vector<int> dim_counts(kNumDimTuples, 0), fact_counts(kNumFactTuples, 0);
+      for (std::size_t i = 0; i < r.dim_long.size(); ++i) {
+        ++dim_counts[r.dim_long[i]];
+        ++fact_counts[r.fact_long[i]];
+      }
+      for (int c : dim_counts) EXPECT_EQ(c, kNumFactTuples);
+      for (int c : fact_counts) EXPECT_EQ(c, kNumDimTuples);
+    }
+    {  // VarCharDuplicateKeyHashJoinTest (:828-997), the strings as CHAR(8): dim holds the digits of tid / 2 * 2, fact of tid —
+       // 200 results, every dim row once, the even fact rows below 200 twice
+      Result r;
+      runJoin(6, kChar, use_foreman, HashJoinOperator::JoinType::kInnerJoin, &r);
+      EXPECT_EQ(r.dim_long.size(), static_cast<std::size_t>(kNumDimTuples));
+      std::vector<int> dim_counts(kNumDimTuples, 0), fact_counts(kNumFactTuples, 0);
+      for (std::size_t i = 0; i < r.dim_long.size(); ++i) {
+        ++dim_counts[r.dim_long[i]];
+        ++fact_counts[r.fact_long[i]];
+        EXPECT_EQ(r.dim_long[i] / 2 * 2, r.fact_long[i]);
+      }
+      for (int c : dim_counts) EXPECT_EQ(c, 1);
+      for (tuple_id i = 0; i < kNumFactTuples; ++i) EXPECT_EQ(fact_counts[i], (i < kNumDimTuples && (i & 1) == 0) ? 2 : 0);
     }
   }
   g_blocks_per_work_order = 1;

@@ -1,7 +1,7 @@
 """Run-time plan shapes (csrc/agg_jit.hip): the aggregation kernel specialised by hipRTC for the state's
 configuration must give the interpreter's results — same body, configuration folded in — on every
 strategy, with filters, predicates, MIN/MAX, and when groups overflow LDS.  QSX_AGG_JIT_MIN_ROWS=0 makes
-the states compile on their first update (the default waits for 16 Mi rows)."""
+the states compile on their first update (the default waits for 2 Mi rows and compiles in the background)."""
 import os
 
 import numpy as np

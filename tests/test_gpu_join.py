@@ -368,6 +368,53 @@ def test_hashed_table_over_a_dense_key_domain_answers_from_its_shadow(capi, orac
         table.close()
 
 
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+def test_dense_table_packs_its_head_words_for_the_probes(capi, oracle, dev, key_type, dtype, monkeypatch):
+    """A directly addressed table of about the size of an XCD's L2 (1 M key values: 4 MiB of head words) is probed through a
+    3-byte copy of its head words (join.hip sealed_pack).  Same pairs / counts / bitmaps with the copy and without
+    (QSX_JOIN_ADAPTIVE=0): duplicate keys (chains), a probe filter, runs of blocks, a further build after a probe, a clear —
+    and tuple ids beyond 2^23 (a large base_tid) must keep the table on its 4-byte words."""
+    rng = np.random.default_rng(17)
+    lo = 7 if dtype == np.int32 else 2**40
+    span, n_build, n_probe = 1_000_000, 300_000, 1_200_003
+    build = (lo + rng.integers(0, span, size=n_build)).astype(dtype)           # ~4 % of the keys twice or more
+    more = (lo + rng.integers(0, span, size=50_000)).astype(dtype)
+    probe = (lo + rng.integers(-100, span + 100, size=n_probe)).astype(dtype)
+    pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.5)
+    dp = to_dev(probe, dev)
+
+    def check(table, blocks, bases):
+        t = oracle.JoinTable(key_type, sum(b.size for b in blocks))
+        for b, base in zip(blocks, bases):
+            t.build(b, base_tid=base)
+        for filt in (None, pf):
+            fdev = None if filt is None else bitmap_dev(filt, dev)
+            rp, rd = t.probe(probe, filter_bitmap=filt)
+            assert int(table.probe_count(dp, filter_bitmap=fdev).item()) == rp.size
+            p, b, cnt = table.probe(dp, capacity=rp.size, filter_bitmap=fdev)
+            assert int(cnt.item()) == rp.size
+            assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rd))
+        bm, c = table.probe_exists(dp)
+        want = np.zeros(n_probe, dtype=bool)
+        want[t.probe(probe)[0]] = True
+        assert np.array_equal(bitmap_np(bm), oracle.bitmap_from_bools(want)) and int(c.item()) == int(want.sum())
+        rp, rd = t.probe(probe)
+        p, b, cnt = table.probe_blocks([dp[:400_001], dp[400_001:]], capacity=rp.size)
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rd))
+
+    for adaptive in ("1", "0"):
+        monkeypatch.setenv("QSX_JOIN_ADAPTIVE", adaptive)
+        table = capi.JoinTable(key_type, n_build, key_range=(lo, lo + span - 1))
+        table.build(to_dev(build, dev))
+        check(table, [build], [0])
+        table.build(to_dev(more, dev), base_tid=n_build)
+        check(table, [build, more], [0, n_build])
+        table.clear()
+        table.build(to_dev(more, dev), base_tid=(1 << 23) + 5)          # tuple ids that do not fit 23 bits
+        check(table, [more], [(1 << 23) + 5])
+        table.close()
+
+
 def hip_composite_join(capi, dev, build_cols, probe_cols):
     """Composite-key inner join through the C ABI: fold the components into one LONG key
     (qsx_join_key_pack), single-key table, and — when the fold is a hash, not an exact packing —
