@@ -1275,6 +1275,26 @@ Type AggResultType(AggregationID id, const Type &argument) {
 }
 }  // namespace
 
+TypeID ScalarResultType(const ScalarPtr &scalar, const CatalogRelation &relation) {
+  if (scalar == nullptr) throw ExecutionError("ScalarResultType: null scalar", QSX_ERR_INVALID_ARGUMENT);
+  switch (scalar->kind) {
+    case Scalar::kAttribute: {
+      const TypeID t = relation.getAttributeType(scalar->attribute).id;
+      if (t != kInt && t != kLong && t != kFloat && t != kDouble) {
+        throw ExecutionError("arithmetic over a non-numeric attribute", QSX_ERR_UNSUPPORTED);
+      }
+      return t == kFloat ? kDouble : t;   // (FLOAT operands are evaluated in double)
+    }
+    case Scalar::kLiteral:
+      return scalar->literal_type;
+    default: {
+      const TypeID l = ScalarResultType(scalar->left, relation), r = ScalarResultType(scalar->right, relation);
+      if (l == kDouble || r == kDouble) return kDouble;
+      return l == kLong || r == kLong ? kLong : kInt;
+    }
+  }
+}
+
 qsx_operand_t ExpressionFlattener::add(const ScalarPtr &scalar) {
   if (scalar == nullptr) throw ExecutionError("ExpressionFlattener: null scalar", QSX_ERR_INVALID_ARGUMENT);
   switch (scalar->kind) {
@@ -2400,11 +2420,26 @@ void SelectWorkOrder::executeBlock(block_id input_block_id) {
       double consts[QSX_MAX_CONSTS] = {};
       for (std::size_t c = 0; c < flattener.consts().size(); ++c) consts[c] = flattener.consts()[c];
       expression_values.emplace_back(new DeviceBuffer(static_cast<std::size_t>(n > 0 ? n : 1) * 8));
-      CheckStatus(qsx_eval_expression(static_cast<int>(attrs.size()), cols, types, static_cast<int>(flattener.instrs().size()),
-                                      flattener.instrs().data(), consts, result, n, static_cast<double *>(expression_values.back()->ptr),
-                                      CurrentStream()), "qsx_eval_expression");
+      const TypeID value_type = ScalarResultType(scalar, block->getRelation());
+      const int value_width = value_type == kInt ? 4 : 8;
+      if (out->getRelation().getAttributeType(static_cast<attribute_id>(i)).width != value_width) {
+        throw ExecutionError("SelectWorkOrder: the output attribute of an expression must have the expression's type "
+                             "(INT op INT is an INT, with a LONG a LONG, with a FLOAT / DOUBLE a DOUBLE)", QSX_ERR_INVALID_ARGUMENT);
+      }
+      if (value_type == kDouble) {
+        CheckStatus(qsx_eval_expression(static_cast<int>(attrs.size()), cols, types, static_cast<int>(flattener.instrs().size()),
+                                        flattener.instrs().data(), consts, result, n, static_cast<double *>(expression_values.back()->ptr),
+                                        CurrentStream()), "qsx_eval_expression");
+      } else {
+        // integer operands: integer arithmetic (ArithmeticBinaryOperators.hpp:203-340 for INT / LONG)
+        std::int64_t int_consts[QSX_MAX_CONSTS] = {};
+        for (std::size_t c = 0; c < flattener.consts().size(); ++c) int_consts[c] = static_cast<std::int64_t>(flattener.consts()[c]);
+        CheckStatus(qsx_eval_expression_long(static_cast<int>(attrs.size()), cols, types, static_cast<int>(flattener.instrs().size()),
+                                             flattener.instrs().data(), int_consts, result, n, value_width, expression_values.back()->ptr,
+                                             CurrentStream()), "qsx_eval_expression_long");
+      }
       src.push_back(expression_values.back()->ptr);
-      widths.push_back(8);
+      widths.push_back(value_width);
       null_sources.push_back(kInvalidAttributeID);
     }
   } else {

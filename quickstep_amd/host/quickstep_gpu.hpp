@@ -394,16 +394,30 @@ class Scalar {
   Kind kind = kAttribute;
   attribute_id attribute = kInvalidAttributeID;
   double literal = 0.0;
+  TypeID literal_type = kDouble;   // kInt / kLong: an integer literal (ScalarLiteral of an INT / LONG TypedValue)
   BinaryOperationID operation = BinaryOperationID::kAdd;
   ScalarPtr left, right;
   static ScalarPtr Attribute(attribute_id a) { auto s = std::make_shared<Scalar>(); s->kind = kAttribute; s->attribute = a; return s; }
   static ScalarPtr Literal(double v) { auto s = std::make_shared<Scalar>(); s->kind = kLiteral; s->literal = v; return s; }
+  // an INT literal when the value fits 32 bits, else LONG (|v| < 2^53: it travels as a double inside the program)
+  static ScalarPtr IntLiteral(std::int64_t v) {
+    auto s = std::make_shared<Scalar>();
+    s->kind = kLiteral;
+    s->literal = static_cast<double>(v);
+    s->literal_type = v >= INT32_MIN && v <= INT32_MAX ? kInt : kLong;
+    return s;
+  }
   static ScalarPtr Binary(BinaryOperationID op, ScalarPtr l, ScalarPtr r) {
     auto s = std::make_shared<Scalar>();
     s->kind = kBinaryExpression; s->operation = op; s->left = std::move(l); s->right = std::move(r);
     return s;
   }
 };
+// The type of a Scalar over `relation` by the reference's rule for arithmetic (BinaryOperation::resultTypeForArgumentTypes,
+// types/operations/binary_operations/ArithmeticBinaryOperation.hpp): DOUBLE as soon as a FLOAT / DOUBLE is involved, else LONG
+// if a LONG is, else INT.  Integer-typed trees are evaluated in integer arithmetic (qsx_eval_expression_long) by the
+// SelectOperator's general form; aggregate arguments are evaluated in double inside the aggregation kernel (exact below 2^53).
+TypeID ScalarResultType(const ScalarPtr &scalar, const CatalogRelation &relation);
 // Scalar trees flattened into one expression program (qsx_expr_instr_t[]): one instruction per distinct binary node —
 // a subexpression shared by several scalars is computed once, the role of the reference's ColumnVectorCache — input
 // attributes mapped to program columns through `column_of`.
@@ -689,7 +703,7 @@ class SelectOperator : public RelationalOperator {
                  QueryContext::predicate_id predicate_index, std::vector<attribute_id> &&selection,
                  bool input_relation_is_stored, bool on_gpu = true);
   // The general form (SelectOperator.hpp:90-98: selection = a group of Scalars): attributes and arithmetic expressions;
-  // an expression's output attribute is DOUBLE.
+  // an expression's output attribute has ScalarResultType(...): INT / LONG for integer operands, else DOUBLE.
   SelectOperator(std::size_t query_id, const CatalogRelation &input_relation, bool has_repartition,
                  const CatalogRelation &output_relation, QueryContext::insert_destination_id output_destination_index,
                  QueryContext::predicate_id predicate_index, std::vector<ScalarPtr> &&selection, bool input_relation_is_stored);

@@ -258,6 +258,70 @@ void runJoinCharResidual(std::size_t blocks_per_order, std::size_t *out_blocks) 
   EXPECT_EQ(g.size(), w.size());
   EXPECT_TRUE(g == w);
 }
+
+// select l_orderkey * 2 + l_quantity [INT], l_orderkey * 5000000000 - l_quantity [LONG], l_quantity / 7 [INT, truncating],
+//        l_extendedprice * l_quantity [DOUBLE] from lineitem where l_quantity < 24 — integer operands in integer arithmetic
+void runTypedExpressions() {
+  StorageManager storage;
+  Lineitem li(&storage, false);
+  CatalogRelation out(2, "projected");
+  out.addAttribute("a", Type::Int());
+  out.addAttribute("b", Type::Long());
+  out.addAttribute("c", Type::Int());
+  out.addAttribute("d", Type::Double());
+  QueryContext ctx;
+  Predicate p;
+  p.conjuncts.push_back(ComparisonPredicate(1, ComparisonID::kLess, TypedLiteral::Int(24)));
+  const auto pred = ctx.addPredicate(p);
+  const auto dest = ctx.addInsertDestination(&out, &storage);
+  using B = BinaryOperationID;
+  std::vector<ScalarPtr> selection = {
+      Scalar::Binary(B::kAdd, Scalar::Binary(B::kMultiply, Scalar::Attribute(0), Scalar::IntLiteral(2)), Scalar::Attribute(1)),
+      Scalar::Binary(B::kSubtract, Scalar::Binary(B::kMultiply, Scalar::Attribute(0), Scalar::IntLiteral(5000000000ll)), Scalar::Attribute(1)),
+      Scalar::Binary(B::kDivide, Scalar::Attribute(1), Scalar::IntLiteral(7)),
+      Scalar::Binary(B::kMultiply, Scalar::Attribute(2), Scalar::Attribute(1))};
+  EXPECT_EQ(ScalarResultType(selection[0], li.rel), kInt);
+  EXPECT_EQ(ScalarResultType(selection[1], li.rel), kLong);
+  EXPECT_EQ(ScalarResultType(selection[3], li.rel), kDouble);
+  SelectOperator op(0, li.rel, false, out, dest, pred, std::move(selection), true);
+  fetchAndExecuteWorkOrders(&op, &ctx, &storage);
+  std::vector<std::int32_t> a, c;
+  std::vector<std::int64_t> b;
+  std::vector<double> d;
+  for (block_id id : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+    BlockReference blk = storage.getBlock(id);
+    const std::size_t at = a.size(), k = static_cast<std::size_t>(blk->numTuples());
+    a.resize(at + k); b.resize(at + k); c.resize(at + k); d.resize(at + k);
+    if (k == 0) continue;
+    blk->copyAttributeToHost(0, a.data() + at); blk->copyAttributeToHost(1, b.data() + at);
+    blk->copyAttributeToHost(2, c.data() + at); blk->copyAttributeToHost(3, d.data() + at);
+  }
+  std::size_t at = 0;
+  bool same = true;
+  for (std::size_t i = 0; i < li.orderkey.size(); ++i) {
+    if (li.quantity[i] >= 24) continue;
+    if (at >= a.size()) { same = false; break; }
+    same = same && a[at] == li.orderkey[i] * 2 + li.quantity[i] &&
+           b[at] == static_cast<std::int64_t>(li.orderkey[i]) * 5000000000ll - li.quantity[i] && c[at] == li.quantity[i] / 7 &&
+           d[at] == li.price[i] * static_cast<double>(li.quantity[i]);
+    ++at;
+  }
+  EXPECT_EQ(at, a.size());
+  EXPECT_TRUE(same);
+  // an output attribute of the wrong type for its expression is refused
+  CatalogRelation wrong(3, "wrong");
+  wrong.addAttribute("a", Type::Double());
+  const auto wrong_dest = ctx.addInsertDestination(&wrong, &storage);
+  SelectOperator bad(0, li.rel, false, wrong, wrong_dest, pred,
+                     std::vector<ScalarPtr>{Scalar::Binary(B::kAdd, Scalar::Attribute(0), Scalar::Attribute(1))}, true);
+  bool threw = false;
+  try {
+    fetchAndExecuteWorkOrders(&bad, &ctx, &storage);
+  } catch (const ExecutionError &e) {
+    threw = e.status() == QSX_ERR_INVALID_ARGUMENT;
+  }
+  EXPECT_TRUE(threw);
+}
 }  // namespace
 
 int main() {
@@ -315,6 +379,7 @@ int main() {
   runJoin(true, 64, &blocks_run, &ms_run, true);
   EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
   std::printf("hash join under a LIP filter: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n", ms_one, ms_run);
+  runTypedExpressions();
   // a CHAR(10) build attribute in the residual predicate and in the projection: both forms
   runJoinCharResidual(1, &blocks_one);
   runJoinCharResidual(64, &blocks_run);
