@@ -2140,9 +2140,7 @@ SelectOperator::SelectOperator(std::size_t query_id, const CatalogRelation &inpu
   }
   for (std::size_t i = 0; i < selection_.size(); ++i) {
     if (selection_[i] == nullptr) throw ExecutionError("SelectOperator: null Scalar", QSX_ERR_INVALID_ARGUMENT);
-    if (selection_[i]->kind != Scalar::kAttribute && output_relation.getAttributeType(static_cast<attribute_id>(i)).id != kDouble) {
-      throw ExecutionError("SelectOperator: an arithmetic expression yields a DOUBLE attribute", QSX_ERR_INVALID_ARGUMENT);
-    }
+    // (an expression's output attribute must have its result type: checked per work order, against the block's relation)
   }
   if (input_relation_is_stored) input_relation_block_ids_ = input_relation.getBlocksSnapshot();
 }
