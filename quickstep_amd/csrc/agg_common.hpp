@@ -252,8 +252,26 @@ struct DirView {
   // The build pass is two launches over the same sample: 0 = key bounds only; 1 = the directory itself — which returns at
   // once when the bounds span a usable box (the accumulate pass will not look anything up).
   int build_step;
+  // Wide keys (DevConfig::wide_words != 0): entries are four words {tag | gid, word 0, word 1, word 2} — tag = the upper
+  // half of the key's hash code, gid in the lower half — and the key words of gid g are words_by_gid[3 g ..].  A lookup
+  // compares all key words, so a gid's accumulators only ever see rows of ITS key: the hidden MIN / MAX accumulators that
+  // prove a wide key elsewhere (DevConfig::wide_words) have no LDS planes in directory mode, the flush writes the key words
+  // into those state columns once per group and workgroup.
+  int wide_words;
+  unsigned long long *words_by_gid;   // [lds_gids][kMaxKeyWords]
 };
 constexpr unsigned long long kSignBias = 1ull << 63;
+
+// 64-bit mixing hash of the words of a wide key: the code the tables are keyed by (DevConfig::wide_words).
+__device__ __forceinline__ unsigned long long wide_key_code(const unsigned long long (&w)[kMaxKeyWords], int wide_words,
+                                                            unsigned long long hash_mask) {
+  unsigned long long h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (int i = 0; i < kMaxKeyWords; ++i) {
+    if (i < wide_words) h = mix64(h ^ w[i]) * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull;
+  }
+  return mix64(h) & hash_mask;
+}
 
 // Position of a row's group inside the key box of the build pass (dense numbering).
 struct KeyBox {
@@ -327,16 +345,88 @@ __device__ __forceinline__ void dir_insert(const DirView &d, unsigned long long 
 }
 
 // gid of `code` (plain cached loads: the directory is read-only in this launch), or -1: not in the directory
-// (full around its home) or without an LDS accumulator.
+// (full around its home) or without an LDS accumulator.  The lookup comes in two halves so that a caller can put other
+// memory operations between the read of the home entry and its use (agg_hash_update.hpp: the next tile's DMA).
+struct DirProbe {
+  unsigned long long s;
+  ulonglong2 a, b;   // the entry at s (b: words 2, 3 of a wide key's entry)
+};
+__device__ __forceinline__ DirProbe dir_first_probe(const DirView &d, unsigned long long code) {
+  DirProbe p;
+  p.s = (mix64(code) * 0x9E3779B97F4A7C15ull) >> d.dshift;
+  if (d.wide_words != 0) {
+    const ulonglong2 *entry = reinterpret_cast<const ulonglong2 *>(d.entries + 4 * p.s);
+    p.a = entry[0];
+    p.b = entry[1];
+  } else {
+    p.a = *reinterpret_cast<const ulonglong2 *>(d.entries + 2 * p.s);
+    p.b = ulonglong2{0, 0};
+  }
+  return p;
+}
+__device__ __forceinline__ int dir_lookup_from(const DirView &d, unsigned long long code, DirProbe p) {
+  for (int probes = 1;; ++probes) {
+    if (p.a.x == code) return p.a.y < d.lds_gids ? static_cast<int>(p.a.y) : -1;
+    if (p.a.x == kEmptyCode || probes >= kDirMaxProbes) return -1;
+    p.s = (p.s + 1) & d.dmask;
+    p.a = *reinterpret_cast<const ulonglong2 *>(d.entries + 2 * p.s);
+  }
+}
 __device__ __forceinline__ int dir_lookup(const DirView &d, unsigned long long code) {
+  return dir_lookup_from(d, code, dir_first_probe(d, code));
+}
+
+// Wide keys.  The directory only accelerates — a key that is not in it is aggregated through the global table, which is
+// always right — so an INSERT may take "an entry with my tag is there" for "my key is there" (another key sharing the 32-bit
+// tag merely stays out), while a LOOKUP answers with a gid only when every key word matches.
+constexpr unsigned long long kDirTagMask = 0xFFFFFFFF00000000ull;
+constexpr unsigned long long kDirGidPending = 0xFFFFFFFEull;   // claimed, gid not published yet (never < lds_gids)
+__device__ __forceinline__ void dir_insert_wide(const DirView &d, unsigned long long code, const unsigned long long (&w)[kMaxKeyWords]) {
+  const unsigned long long tag = code & kDirTagMask;
   unsigned long long s = (mix64(code) * 0x9E3779B97F4A7C15ull) >> d.dshift;
   for (int probes = 0; probes < kDirMaxProbes; ++probes) {
-    const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(d.entries + 2 * s);
-    if (e.x == code) return e.y < d.lds_gids ? static_cast<int>(e.y) : -1;
-    if (e.x == kEmptyCode) return -1;
+    unsigned long long *entry = d.entries + 4 * s;
+    unsigned long long k = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmptyCode) {
+      k = atomicCAS(entry, kEmptyCode, tag | kDirGidPending);
+      if (k == kEmptyCode) {
+        unsigned int g = atomicAdd(d.ngids, 1u);
+        if (g > kDirGidPending - 1) g = static_cast<unsigned int>(kDirGidPending - 1);
+#pragma unroll
+        for (int i = 0; i < kMaxKeyWords; ++i) {
+          __hip_atomic_store(entry + 1 + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (g < d.lds_gids) {
+            __hip_atomic_store(&d.words_by_gid[static_cast<size_t>(g) * kMaxKeyWords + i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        __hip_atomic_store(entry, tag | g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
+    if ((k & kDirTagMask) == tag) return;
     s = (s + 1) & d.dmask;
   }
-  return -1;
+}
+// (one aligned 32-byte read per probe; an entry seen half-written — the words still 0xFF.. behind a published gid cannot
+// happen in program order, but the two halves of the read are not ordered — fails the comparison: global path)
+__device__ __forceinline__ int dir_lookup_wide_from(const DirView &d, unsigned long long code, const unsigned long long (&w)[kMaxKeyWords],
+                                                    DirProbe p) {
+  const unsigned long long tag = code & kDirTagMask;
+  for (int probes = 1;; ++probes) {
+    if (p.a.x == kEmptyCode) return -1;
+    if ((p.a.x & kDirTagMask) == tag) {
+      const unsigned long long gid = p.a.x & ~kDirTagMask;
+      return (gid < d.lds_gids && p.a.y == w[0] && p.b.x == w[1] && p.b.y == w[2]) ? static_cast<int>(gid) : -1;
+    }
+    if (probes >= kDirMaxProbes) return -1;
+    p.s = (p.s + 1) & d.dmask;
+    const ulonglong2 *entry = reinterpret_cast<const ulonglong2 *>(d.entries + 4 * p.s);
+    p.a = entry[0];
+    p.b = entry[1];
+  }
+}
+__device__ __forceinline__ int dir_lookup_wide(const DirView &d, unsigned long long code, const unsigned long long (&w)[kMaxKeyWords]) {
+  return dir_lookup_wide_from(d, code, w, dir_first_probe(d, code));
 }
 
 // ---- LDS table ------------------------------------------------------------------
@@ -402,6 +492,27 @@ __device__ __forceinline__ int lds_find_or_insert(unsigned long long *l_keys, in
     if (k == kEmptyCode) {
       k = atomicCAS(&l_keys[s], kEmptyCode, code);
       if (k == kEmptyCode || k == code) return s;
+    }
+    s = (s + 1) & (S - 1);
+  }
+  return -1;
+}
+
+// The same; *inserted = this call claimed the slot.
+__device__ __forceinline__ int lds_find_or_insert_new(unsigned long long *l_keys, int S, unsigned long long code, bool *inserted) {
+  int s = static_cast<int>(mix64(code) >> 40) & (S - 1);
+  const int limit = S < kLdsMaxProbes ? S : kLdsMaxProbes;
+  *inserted = false;
+  for (int probes = 0; probes < limit; ++probes) {
+    unsigned long long k = __hip_atomic_load(&l_keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == code) return s;
+    if (k == kEmptyCode) {
+      k = atomicCAS(&l_keys[s], kEmptyCode, code);
+      if (k == kEmptyCode) {
+        *inserted = true;
+        return s;
+      }
+      if (k == code) return s;
     }
     s = (s + 1) & (S - 1);
   }

@@ -355,12 +355,10 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
   if (c.wide_words != 0) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      unsigned long long h = 0x9E3779B97F4A7C15ull;
+      unsigned long long words[kMaxKeyWords];
 #pragma unroll
-      for (int w = 0; w < kMaxKeyWords; ++w) {
-        if (w < c.wide_words) h = mix64(h ^ key_word_of(c, tile, w, trow + v * BLOCK)) * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull;
-      }
-      code[v] = mix64(h) & c.wide_hash_mask;
+      for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of(c, tile, w, trow + v * BLOCK) : 0ull;
+      code[v] = wide_key_code(words, c.wide_words, c.wide_hash_mask);
     }
     return;
   }
@@ -499,14 +497,19 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   // (a workgroup sees < 2^32 rows of one group between two flushes: it flushes once, at its end, after < 2^32 rows in all
   // — the launcher bounds the rows per workgroup).
   // Dynamic LDS: tile[nbuf][tile_bytes] | temps | l_sum[NS][S + 64] u64 | l_cnt[S + 64] u32
+  // A wide key's hidden MIN / MAX accumulators (the last 2 x wide_words of c.sums) have no planes here: the directory hands
+  // out a gid only to rows whose key words all match (DirView::wide_words), the flush writes the words into those columns.
+  const int ns_lds = kDir ? NS - 2 * c.wide_words : NS;
   unsigned long long *l_sum = l_keys;
-  unsigned int *l_cnt = reinterpret_cast<unsigned int *>(l_keys + static_cast<size_t>(NS) * plane);
+  unsigned int *l_cnt = reinterpret_cast<unsigned int *>(l_keys + static_cast<size_t>(ns_lds) * plane);
   auto acc_plane_of = [&](int j) { return kDir ? l_sum + static_cast<size_t>(j) * plane : l_acc + static_cast<size_t>(j + 1) * plane; };
+  // kDirBuild with a wide key: the words of the key that claimed set slot i (behind the S codes)
+  unsigned long long *l_set_words = l_keys + S;
 
   if constexpr (kDirBuild) {
     // build pass of the group directory: only the set of key codes this workgroup sees, S slots
     if (dir->build_step == 1) {
-      if (key_box_of(*dir, c.wide_words != 0 ? 0 : c.num_keys).usable) return;   // (uniform) groups will be numbered by their place in the key box
+      if (key_box_of(*dir, c.num_keys).usable) return;   // (uniform) groups will be numbered by their place in the key box
       for (int i = threadIdx.x; i < S; i += BLOCK) l_keys[i] = kEmptyCode;
     }
   } else if constexpr (kDir) {
@@ -517,6 +520,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   }
 #pragma unroll
   for (int j = 0; j < (kDirBuild ? 0 : NS); ++j) {
+    if (j >= ns_lds) break;
     const unsigned long long identity = static_cast<unsigned long long>(acc_identity(c.sums[j].kind));
     unsigned long long *p = acc_plane_of(j);
     for (int i = threadIdx.x; i < plane; i += BLOCK) p[i] = identity;
@@ -543,8 +547,8 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   for (int k = 0; k < QSX_MAX_KEYS; ++k) seen_hi[k] = seen_nlo[k] = 0;
   KeyBox box;
   box.usable = false;
-  // (a wide key's code is a hash: its groups cannot be numbered by position, the directory is looked up)
-  if constexpr (kDir) box = key_box_of(*dir, c.wide_words != 0 ? 0 : c.num_keys);
+  // (the box is one of key FIELDS: a wide key's groups are numbered by position like a narrow key's)
+  if constexpr (kDir) box = key_box_of(*dir, c.num_keys);
   // a run of blocks (agg_common.hpp BlockRunView): the tiles of all blocks, each block with its own stripes
   constexpr bool batched = kRuns;
   BlockRunView run{};
@@ -634,7 +638,9 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       }
     }
   };
-  if (nbuf == 2 && first_tile < num_tiles) {
+  // (directory mode with one tile buffer stages the next tile as soon as the current one has been read, see the loop's end)
+  const bool staged_ahead = nbuf == 2 || kDir;
+  if (staged_ahead && first_tile < num_tiles) {
     const TileSource src = locate(first_tile);
     stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? src.cols : cols, kRuns ? src.filter : filter, tiles, src.row0, src.rows, nulls, &src.bases);
   }
@@ -644,7 +650,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   if (first_tile < num_tiles) carried = locate(first_tile);
   for (int64_t tile_id = first_tile; tile_id < num_tiles; tile_id += tile_step, ++tile_count) {
     const TileSource here = carried;
-    if (nbuf == 1) {
+    if (!staged_ahead) {
       __syncthreads();  // every wave is done reading the previous tile
       stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? here.cols : cols, kRuns ? here.filter : filter, tiles, here.row0, here.rows, nulls, &here.bases);
     }
@@ -737,6 +743,21 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       for (int v = 0; v < V; ++v) {
         if (live[v] && code[v] != kEmptyCode) {
           if (dir->build_step == 1) {
+            if (c.wide_words != 0) {
+              unsigned long long words[kMaxKeyWords];
+#pragma unroll
+              for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of(c, tile, w, trow + v * BLOCK) : 0ull;
+              bool inserted;
+              const int at = lds_find_or_insert_new(l_keys, S, code[v], &inserted);
+              if (at < 0) {
+                dir_insert_wide(*dir, code[v], words);
+              } else if (inserted) {
+                // (another key under the same code finds the slot taken and stays out of the directory: global path)
+#pragma unroll
+                for (int w = 0; w < kMaxKeyWords; ++w) l_set_words[at * kMaxKeyWords + w] = words[w];
+              }
+              continue;
+            }
             if (lds_find_or_insert(l_keys, S, code[v]) < 0) dir_insert(*dir, code[v]);
             continue;
           }
@@ -756,6 +777,10 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     long long global_slot[V];
     bool any_global = false;
     bool run_tail[V];   // kDense: this lane commits the run of equal adjacent keys ending here
+    // kDir: the row's group number (or -2: look it up), its wide key, and the aggregates' arguments until the row is classified
+    int dir_gid = -1;
+    unsigned long long dir_words[kMaxKeyWords] = {};
+    unsigned long long dir_inc[NS > 0 ? NS : 1];
     if constexpr (kDense) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
@@ -773,42 +798,35 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         slot[v] = wave_run_start(run_key);
       }
     } else if constexpr (kDir) {
+      // Directory mode reads everything it needs from the tile first (here: the group's position in the key box, or the
+      // key words the directory entry has to match; below: the aggregates' arguments) and classifies the row afterwards —
+      // with one tile buffer the next tile's DMA then runs under the lookups and the LDS atomics instead of after them.
+      static_assert(!kDir || V == 1, "directory mode: one row per thread");
+      run_tail[0] = false;
+      slot[0] = S + lane_id();   // trash
+      global_slot[0] = -1;
+      dir_gid = -1;              // -2: to be looked up
+      if (live[0] && code[0] != kEmptyCode) {
+        if (box.usable) {
+          // group number = position in the key box of the build pass; a key outside the box (the build pass samples) has none
+          unsigned int cell = 0;
+          bool inside = true;
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        run_tail[v] = false;
-        slot[v] = S + lane_id();   // trash
-        global_slot[v] = -1;
-        int gid = -1;
-        if (live[v] && code[v] != kEmptyCode) {
-          if (box.usable) {
-            // group number = position in the key box of the build pass; a key outside the box (the build pass samples) has none
-            unsigned int cell = 0;
-            bool inside = true;
-#pragma unroll
-            for (int k = 0; k < QSX_MAX_KEYS; ++k) {
-              if (k < c.num_keys) {
-                const unsigned long long d = static_cast<unsigned long long>(key_field(c, tile, k, trow + v * BLOCK) - box.lo[k]);
-                inside = inside && d < box.range[k];
-                cell += static_cast<unsigned int>(d) * box.mult[k];
-              }
+          for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+            if (k < c.num_keys) {
+              const unsigned long long d = static_cast<unsigned long long>(key_field(c, tile, k, trow) - box.lo[k]);
+              inside = inside && d < box.range[k];
+              cell += static_cast<unsigned int>(d) * box.mult[k];
             }
-            gid = inside ? static_cast<int>(cell) : -1;
-          } else {
-            gid = dir_lookup(*dir, code[v]);
+          }
+          dir_gid = inside ? static_cast<int>(cell) : -1;
+        } else {
+          dir_gid = -2;
+          if (c.wide_words != 0) {
+#pragma unroll
+            for (int w = 0; w < kMaxKeyWords; ++w) dir_words[w] = w < c.wide_words ? key_word_of(c, tile, w, trow) : 0ull;
           }
         }
-        if (gid >= 0) {
-          slot[v] = gid;
-          atomicAdd(&l_cnt[gid], 1u);
-        } else if (live[v]) {
-          // no gid with an accumulator here (more groups than the directory was sized for, or the sentinel code)
-          const unsigned long long gs = global_find_or_insert(g, code[v]);
-          if (gs != ~0ull) {
-            global_slot[v] = static_cast<long long>(gs);
-            global_add(g, 0, gs, 1ull, kAccSumI64);
-          }
-        }
-        any_global = any_global || global_slot[v] >= 0;
       }
     } else {
 #pragma unroll
@@ -959,14 +977,49 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
           if (run_tail[v]) global_accumulate(&col[global_slot[v]], run, s.kind);
         }
       } else {
-        unsigned long long *acc_plane = acc_plane_of(j);
+        if constexpr (kDir) {
+          dir_inc[j] = inc[0];
+          continue;
+        }
+        {
+          unsigned long long *acc_plane = acc_plane_of(j);
 #pragma unroll
-        for (int v = 0; v < V; ++v) lds_add(&acc_plane[slot[v]], inc[v], s.kind);  // unconditional (trash slot)
+          for (int v = 0; v < V; ++v) lds_add(&acc_plane[slot[v]], inc[v], s.kind);  // unconditional (trash slot)
+        }
         if (wave_has_global) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             if (global_slot[v] >= 0) global_add(g, j + 1, static_cast<unsigned long long>(global_slot[v]), inc[v], s.kind);
           }
+        }
+      }
+    }
+    if constexpr (kDir) {
+      // every read of this tile is done; the home entry of the row's key is read BEFORE the next tile's DMA is issued —
+      // loads return in order, so waiting for a lookup issued behind the DMA would wait for the tile as well
+      DirProbe probe{};
+      if (dir_gid == -2) probe = dir_first_probe(*dir, code[0]);
+      if (nbuf == 1 && next < num_tiles) {
+        __syncthreads();
+        stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? carried.cols : cols, kRuns ? carried.filter : filter, tiles, carried.row0, carried.rows,
+                                          nulls, &carried.bases);
+      }
+      int gid = dir_gid;
+      if (gid == -2) gid = c.wide_words != 0 ? dir_lookup_wide_from(*dir, code[0], dir_words, probe) : dir_lookup_from(*dir, code[0], probe);
+      if (gid >= 0) {
+        atomicAdd(&l_cnt[gid], 1u);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          if (j < ns_lds) lds_add(&acc_plane_of(j)[gid], dir_inc[j], c.sums[j].kind);
+        }
+      } else if (live[0]) {
+        // no gid with an accumulator here (more groups than the directory was sized for, a group the build pass's sample
+        // missed, the sentinel code): the global table, all accumulators — a wide key's hidden ones included
+        const unsigned long long gs = global_find_or_insert(g, code[0]);
+        if (gs != ~0ull) {
+          global_add(g, 0, gs, 1ull, kAccSumI64);
+#pragma unroll
+          for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, dir_inc[j], c.sums[j].kind);
         }
       }
     }
@@ -977,7 +1030,15 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     if (dir->build_step == 1) {
       for (int i = threadIdx.x; i < S; i += BLOCK) {
         const unsigned long long code = l_keys[i];
-        if (code != kEmptyCode) dir_insert(*dir, code);
+        if (code == kEmptyCode) continue;
+        if (c.wide_words != 0) {
+          unsigned long long words[kMaxKeyWords];
+#pragma unroll
+          for (int w = 0; w < kMaxKeyWords; ++w) words[w] = l_set_words[i * kMaxKeyWords + w];
+          dir_insert_wide(*dir, code, words);
+        } else {
+          dir_insert(*dir, code);
+        }
       }
       return;
     }
@@ -1020,24 +1081,44 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       const unsigned long long cnt = l_cnt[gid];
       if (cnt == 0) continue;
       unsigned long long code;
+      unsigned long long words[kMaxKeyWords] = {};   // the group's key, word by word (narrow key: word 0 = the code)
       if (box.usable) {
-        code = 0;
 #pragma unroll
         for (int k = 0; k < QSX_MAX_KEYS; ++k) {
           if (k < c.num_keys) {
             const unsigned long long field = static_cast<unsigned long long>(
                 box.lo[k] + static_cast<long long>((static_cast<unsigned int>(gid) / box.mult[k]) % box.range[k]));
             const unsigned long long mask = c.key_width[k] >= 8 ? ~0ull : (1ull << (8 * c.key_width[k])) - 1;
-            code |= (field & mask) << c.key_shift[k];
+#pragma unroll
+            for (int w = 0; w < kMaxKeyWords; ++w) {
+              if ((c.wide_words != 0 ? c.key_word[k] : 0) == w) words[w] |= (field & mask) << c.key_shift[k];
+            }
           }
         }
+        code = words[0];
+      } else if (c.wide_words != 0) {
+#pragma unroll
+        for (int w = 0; w < kMaxKeyWords; ++w) {
+          words[w] = __hip_atomic_load(&dir->words_by_gid[static_cast<size_t>(gid) * kMaxKeyWords + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        code = 0;
       } else {
         code = __hip_atomic_load(&dir->codes_by_gid[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (c.wide_words != 0) code = wide_key_code(words, c.wide_words, c.wide_hash_mask);
       const unsigned long long gs = global_find_or_insert(g, code);
       if (gs == ~0ull) continue;
       global_add(g, 0, gs, cnt, kAccSumI64);
-      for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, acc_plane_of(j)[gid], c.sums[j].kind);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        if (j < ns_lds) {
+          global_add(g, j + 1, gs, acc_plane_of(j)[gid], c.sums[j].kind);
+        } else {
+          // hidden MIN / MAX of key word (j - ns_lds) / 2: every row of this gid carried exactly these words
+          const int w = (j - ns_lds) >> 1;
+          global_add(g, j + 1, gs, w == 0 ? words[0] : (w == 1 ? words[1] : words[2]), c.sums[j].kind);
+        }
+      }
     }
     return;
   }

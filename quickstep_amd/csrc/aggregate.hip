@@ -612,6 +612,8 @@ struct qsx_agg_state {
   unsigned long long dir_cap = 0;
   unsigned long long *dir_codes = nullptr;
   int dir_codes_len = 0;
+  unsigned long long *dir_words = nullptr;    // wide keys: the key words of every gid (DirView::words_by_gid)
+  int dir_entry_words = 2;                    // words per directory entry the allocation was made for
   unsigned int *dir_ngids = nullptr;          // [4] counter words, then the key bounds (kDirControlBytes in all)
   std::atomic<unsigned> dir_calls{0};         // rotates the build pass's sample
   // The key bounds belong to ONE update call (build pass writes, accumulate pass reads): calls on the same stream are
@@ -641,6 +643,8 @@ struct qsx_agg_state {
     d.sample_stride = 1;
     d.sample_phase = 0;
     d.build_step = 0;
+    d.wide_words = dev.wide_words;
+    d.words_by_gid = dir_words;
     return d;
   }
   // scratch for ordered dense finalize
@@ -945,6 +949,8 @@ static int dir_grid(int64_t n) {
   const int64_t num_tiles = (n + kDirBlock - 1) / kDirBlock;
   return static_cast<int>(num_tiles < kCUs ? num_tiles : kCUs);
 }
+// num_sums: the accumulators with an LDS plane — a wide key's hidden MIN / MAX accumulators have none (agg_hash_update.hpp)
+static int dir_plane_sums(const DevConfig &dev) { return dev.num_sums - 2 * dev.wide_words; }
 static size_t dir_lds_bytes(int tile_bytes, int temps_bytes, int num_sums, int gids, int nbuf) {
   return static_cast<size_t>(nbuf) * tile_bytes + temps_bytes + static_cast<size_t>(gids + kWave) * (8 * static_cast<size_t>(num_sums) + 4) + 16;
 }
@@ -955,7 +961,7 @@ static int launch_shape_dir(const void *const *cols, int num_columns, int64_t n,
   constexpr Translated T = Shape::translated(kDirBlock);
   static_assert(T.status == QSX_OK, "plan shape does not translate");
   constexpr size_t kMaxLds = 160 * 1024;
-  const size_t lds = dir_lds_bytes(T.dev.tile_bytes, 0, T.num_sums, gids, nbuf);
+  const size_t lds = dir_lds_bytes(T.dev.tile_bytes, 0, T.num_sums - 2 * T.dev.wide_words, gids, nbuf);
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   static PerDeviceOnce attribute_set;
   {
@@ -985,10 +991,12 @@ static int launch_dir_build(DevConfig dc, unsigned key_columns, int64_t n, const
   dc.temps_bytes = 0;
   constexpr size_t kMaxLds = 160 * 1024;
   // LDS set of the workgroup's distinct codes: twice the gids, what the CU has room for at most
+  // (a wide key: its words behind the codes)
+  const size_t slot_bytes = dc.wide_words != 0 ? 8 * (1 + static_cast<size_t>(kMaxKeyWords)) : 8;
   int slots = static_cast<int>(next_pow2(static_cast<uint64_t>(gids) * 2));
   int nbuf = 2;
-  while (slots > 1024 && static_cast<size_t>(nbuf) * dc.tile_bytes + 8 * static_cast<size_t>(slots) + 16 > kMaxLds) slots >>= 1;
-  const size_t lds = static_cast<size_t>(nbuf) * dc.tile_bytes + 8 * static_cast<size_t>(slots) + 16;
+  while (slots > 1024 && static_cast<size_t>(nbuf) * dc.tile_bytes + slot_bytes * static_cast<size_t>(slots) + 16 > kMaxLds) slots >>= 1;
+  const size_t lds = static_cast<size_t>(nbuf) * dc.tile_bytes + slot_bytes * static_cast<size_t>(slots) + 16;
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   static PerDeviceOnce attribute_set;
   {
@@ -1016,7 +1024,7 @@ static int launch_dir(DevConfig dc, unsigned used_columns, int64_t n, const uint
   plan_tile(dc, used_columns, kDirBlock, filter != nullptr);
   plan_interpreter(dc, kDirBlock);
   constexpr size_t kMaxLds = 160 * 1024;
-  const size_t lds = dir_lds_bytes(dc.tile_bytes, dc.temps_bytes, NS, gids, nbuf);
+  const size_t lds = dir_lds_bytes(dc.tile_bytes, dc.temps_bytes, dir_plane_sums(dc), gids, nbuf);
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   static PerDeviceOnce attribute_set;
   {
@@ -1178,7 +1186,7 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
     st->jit_tile_bytes[v] = dev.tile_bytes;
     if (directory) {
       st->jit_geometry[v] = JitGeometry{st->dir_gids, 0, st->dir_nbuf, 1, st->dir_gids};
-      st->jit_lds[v] = dir_lds_bytes(dev.tile_bytes, 0, st->num_sums, st->dir_gids, st->dir_nbuf);
+      st->jit_lds[v] = dir_lds_bytes(dev.tile_bytes, 0, dir_plane_sums(dev), st->dir_gids, st->dir_nbuf);
     } else {
       st->jit_geometry[v] = jit_geometry_for(st, dev.tile_bytes, slots, num_ranges, &st->jit_lds[v]);
       st->jit_geometry[v].runs = runs ? 1 : 0;
@@ -1385,7 +1393,7 @@ static void derive_geometry(qsx_agg_state *st, int64_t est) {
     // (a little head-room: the estimate is an estimate; groups beyond the accumulators take the global path, and the
     // table's growth re-derives the geometry when the estimate was far off)
     const size_t want = (static_cast<size_t>(est) + static_cast<size_t>(est) / 16 + 63) / 64 * 64;
-    const size_t per_gid = 8 * static_cast<size_t>(st->num_sums) + 4;
+    const size_t per_gid = 8 * static_cast<size_t>(dir_plane_sums(st->dev)) + 4;
     for (int nbuf = 2; nbuf >= 1 && st->dir_gids == 0; --nbuf) {
       const size_t fixed = nbuf * tile + dev.temps_bytes + kWave * per_gid + 16;
       if (fixed + want * per_gid <= 160 * 1024) {
@@ -1406,19 +1414,26 @@ static hipError_t ensure_directory(qsx_agg_state *st) {
   const unsigned long long want_cap = next_pow2(static_cast<uint64_t>(st->dir_gids) * 4);
   hipError_t err = hipSuccess;
   if (st->dir_ngids == nullptr) err = device_malloc(reinterpret_cast<void **>(&st->dir_ngids), kDirControlBytes);
-  if (err == hipSuccess && st->dir_cap != want_cap) {
+  const int entry_words = st->dev.wide_words != 0 ? 4 : 2;
+  if (err == hipSuccess && (st->dir_cap != want_cap || st->dir_entry_words != entry_words)) {
     (void)device_free(st->dir_entries);
     st->dir_entries = nullptr;
     st->dir_cap = want_cap;
-    err = device_malloc(reinterpret_cast<void **>(&st->dir_entries), want_cap * 16);
+    st->dir_entry_words = entry_words;
+    err = device_malloc(reinterpret_cast<void **>(&st->dir_entries), want_cap * 8 * entry_words);
   }
   if (err == hipSuccess && st->dir_codes_len < st->dir_gids) {
     (void)device_free(st->dir_codes);
     st->dir_codes = nullptr;
     st->dir_codes_len = st->dir_gids;
     err = device_malloc(reinterpret_cast<void **>(&st->dir_codes), sizeof(unsigned long long) * st->dir_gids);
+    if (err == hipSuccess && st->dev.wide_words != 0) {
+      (void)device_free(st->dir_words);
+      st->dir_words = nullptr;
+      err = device_malloc(reinterpret_cast<void **>(&st->dir_words), sizeof(unsigned long long) * kMaxKeyWords * st->dir_gids);
+    }
   }
-  if (err == hipSuccess) err = hipMemset(st->dir_entries, 0xFF, st->dir_cap * 16);
+  if (err == hipSuccess) err = hipMemset(st->dir_entries, 0xFF, st->dir_cap * 8 * entry_words);
   if (err == hipSuccess) err = hipMemset(st->dir_ngids, 0, kDirControlBytes);
   return err;
 }
@@ -1605,7 +1620,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     set_last_error("qsx_agg_state_create", err);
     (void)device_free(st->image); (void)device_free(st->control); (void)device_free(st->tile_counts); (void)device_free(st->tile_offsets);
     (void)device_free(st->log);
-    (void)device_free(st->dir_entries); (void)device_free(st->dir_codes); (void)device_free(st->dir_ngids);
+    (void)device_free(st->dir_entries); (void)device_free(st->dir_codes); (void)device_free(st->dir_words); (void)device_free(st->dir_ngids);
     if (st->published != nullptr) (void)hipHostFree(st->published);
     delete st;
     return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
@@ -1624,6 +1639,7 @@ int qsx_agg_state_destroy(qsx_agg_state_t *st) {
   (void)device_free_idle(st->log);
   (void)device_free_idle(st->dir_entries);
   (void)device_free_idle(st->dir_codes);
+  (void)device_free_idle(st->dir_words);
   (void)device_free_idle(st->dir_ngids);
   if (st->published != nullptr) (void)hipHostFree(st->published);
   delete st;
@@ -1643,7 +1659,7 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
     __atomic_store_n(&st->published[1], 0ull, __ATOMIC_RELEASE);
   }
   if (st->dir_gids != 0) {
-    QSX_HIP_TRY(hipMemsetAsync(st->dir_entries, 0xFF, st->dir_cap * 16, s));
+    QSX_HIP_TRY(hipMemsetAsync(st->dir_entries, 0xFF, st->dir_cap * 8 * st->dir_entry_words, s));
     QSX_HIP_TRY(hipMemsetAsync(st->dir_ngids, 0, 16, s));
   }
   if (st->dense) {

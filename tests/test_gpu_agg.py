@@ -762,6 +762,55 @@ def test_wide_group_key_hash_collision_is_reported_not_returned(capi, dev, monke
     assert keys[0].size == 40
 
 
+@pytest.mark.parametrize("shape", ["key_box", "looked_up", "three_words"])
+def test_wide_group_keys_through_the_group_directory(capi, oracle, dev, shape, monkeypatch):
+    """Thousands of groups under a key wider than 8 bytes: the group directory carries the key words in its entries, a row
+    gets a group number only when all its key words match, and only the aggregates' own accumulators live in LDS
+    (DirView::wide_words).  key_box: component ranges small enough to number the groups by position; looked_up: components
+    spread (the bench_ops shape); three_words: a 24-byte key.  A sample that misses groups (global path next to the
+    directory), a filter, several blocks, both interpreter and run-time shape; a short hash (collisions) must be reported."""
+    rng = np.random.default_rng(61)
+    n = 600_000
+    k1 = rng.integers(0, 100, size=n).astype(np.int32)
+    k2 = rng.integers(0, 90, size=n).astype(np.int64)
+    if shape == "key_box":
+        layout = [(T.INT, None), (T.LONG, None), (T.INT, None), (T.DOUBLE, None)]
+        cols = [k1 - 50, k2 + 2**40, (k1 & 1).astype(np.int32), rng.normal(size=n)]
+        keys, val = [0, 1, 2], 3
+    elif shape == "looked_up":
+        layout = [(T.INT, None), (T.LONG, None), (T.INT, None), (T.DOUBLE, None)]
+        cols = [k1, k2 << 33, (k1 & 1).astype(np.int32), rng.normal(size=n)]
+        keys, val = [0, 1, 2], 3
+    else:
+        layout = [(T.LONG, None), (T.LONG, None), (T.LONG, None), (T.DOUBLE, None)]
+        cols = [k1.astype(np.int64) * (2**41 + 3), k2 * -(2**35 + 11), (k1 % 3).astype(np.int64) - 2**62, rng.normal(size=n)]
+        keys, val = [0, 1, 2], 3
+    aggs = [(T.AGG_SUM, T.col(val)), (T.AGG_COUNT_STAR, None), (T.AGG_AVG, T.col(val))]
+    keep = oracle.bitmap_from_bools(rng.uniform(size=n) < 0.6)
+    for jit in (False, True):
+        monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if jit else str(1 << 60))
+        for sample in (None, "20000"):
+            if sample is None:
+                monkeypatch.delenv("QSX_AGG_DIR_SAMPLE_ROWS", raising=False)
+            else:
+                monkeypatch.setenv("QSX_AGG_DIR_SAMPLE_ROWS", sample)
+            cfg = T.make_agg_config(T.AGG_GENERIC, layout, keys=keys, aggs=aggs, est_groups=9_500)
+            o = oracle.AggState(cfg)
+            o.update(cols)
+            ref = o.finalize()
+            for blocks in (1, 3):
+                assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols, blocks=blocks), dev), ref)
+            of = oracle.AggState(cfg)
+            of.update(cols, filter_bitmap=keep)
+            assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols, filter_bitmap=keep), dev), of.finalize())
+    monkeypatch.delenv("QSX_AGG_DIR_SAMPLE_ROWS", raising=False)
+    if shape != "key_box":   # (the key box never consults the hash)
+        monkeypatch.setenv("QSX_AGG_WIDE_HASH_BITS", "9")
+        cfg = T.make_agg_config(T.AGG_GENERIC, layout, keys=keys, aggs=aggs, est_groups=9_500)
+        with pytest.raises(RuntimeError, match="QSX_GROUPS_HASH_COLLISION"):
+            finalize_np(run_hip(capi, dev, cfg, cols), dev)
+
+
 def test_wide_group_key_limits(capi):
     """Every key word costs two accumulators of the state: what does not fit is refused at creation."""
     layout = [(T.LONG, None)] * 4 + [(T.DOUBLE, None)]

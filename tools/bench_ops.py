@@ -155,7 +155,7 @@ widecfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.LONG, None), (T.IN
 st = capi.AggState(widecfg)
 k_long, k_bit = k2.long() << 33, k1 & 1
 ms = timed(lambda: st.update([k1, k_long, k_bit, val], na), reps=3)
-report("K8 aggregate 16-byte key (INT, LONG, INT), 10 k groups (hashed words + MIN/MAX proof)", ms, na, 24 * na)
+report("K8 aggregate 16-byte key (INT, LONG, INT), 10 k groups (group directory: entries carry the key words)", ms, na, 24 * na)
 del k_long, k_bit
 # Q3 group-by shape: dense key (orders at SF100: 150 M keys for 600 M lineitems -> 4 rows per key, clustered)
 ne = na // 4
