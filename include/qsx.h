@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
-#define QSX_ABI_VERSION 8
+#define QSX_ABI_VERSION 9
 
 typedef void *qsx_stream_t;
 
@@ -468,6 +468,38 @@ int qsx_join_probe_count(qsx_join_table_t *table, const void *keys_dev, int64_t 
 int qsx_join_probe_blocks(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
                           const int32_t *block_base_tids, const uint64_t *const *block_filters, int32_t *out_probe_tid_dev,
                           int32_t *out_build_tid_dev, int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream);
+
+/* K4 + K5 in one pass: the OUTPUT RELATION of an inner join over a run of probe blocks, written by the probe itself.
+ * HashInnerJoinWorkOrder collects (probe, build) tuple-id pairs and then materialises every output attribute from them
+ * (relational_operators/HashJoinOperator.cpp:494-560: one ValueAccessor pass per build block, ScalarAttribute::
+ * getAllValuesForJoin per attribute); here a matching lane reads the projected attributes of its probe row and of the build
+ * tuple it found and stores them where it would have stored the pair — the pair list is never written, no launch per
+ * attribute.  Output tuple i (i < min(*out_count, capacity)) holds column c at out_columns[c] + i * width[c]; tuples come
+ * out in no particular order (like the pairs), all columns of a tuple at the same position.
+ *   num_columns     1 .. QSX_MAX_PROJECTED output columns; width[c] = 1, 2, 4 or 8 bytes
+ *   on_build[c]     0: column c is a probe-side attribute, its stripe in probe block b is probe_stripes[b * num_columns + c];
+ *                   1: a build-side attribute, stored as num_build_segments blocks in build-tuple-id order: segment s holds
+ *                   the tuples from build_first_tids[s] on (the ids the table was built with: base_tid + row) and its stripe is
+ *                   build_stripes[s * num_columns + c].  Entries of the other side's columns are ignored.
+ * block_rows / block_keys / block_filters, capacity and *out_count_dev as qsx_join_probe_blocks (probe tuple ids are not
+ * reported, so there are no base tids).  Directly addressed tables — and hashed tables whose keys got a directly addressed
+ * shadow — run the fused kernel; any other table is probed into a scratch pair list and gathered from it inside the call
+ * (same result, the unfused cost).  All host arrays are consumed before return. */
+#define QSX_MAX_PROJECTED 16
+typedef struct qsx_join_projection {
+  int32_t num_columns;
+  int32_t width[QSX_MAX_PROJECTED];
+  int32_t on_build[QSX_MAX_PROJECTED];
+  const void *const *probe_stripes;     /* host array [num_blocks * num_columns] of device pointers */
+  int32_t num_build_segments;
+  const int64_t *build_first_tids;      /* host array [num_build_segments], ascending */
+  const void *const *build_stripes;     /* host array [num_build_segments * num_columns] of device pointers */
+  void *const *out_columns;             /* host array [num_columns] of device pointers, capacity values each */
+} qsx_join_projection_t;
+int qsx_join_probe_project_blocks(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows,
+                                  const void *const *block_keys, const uint64_t *const *block_filters,
+                                  const qsx_join_projection_t *projection, int64_t capacity, int64_t *out_count_dev,
+                                  qsx_stream_t stream);
 
 /* qsx_join_probe_count over a run of probe blocks: the number of pairs qsx_join_probe_blocks would emit. */
 int qsx_join_probe_count_blocks(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows,

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "qsx_join_build_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp]),
     "qsx_join_probe_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_probe_count_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _vp, _vp]),
+    "qsx_join_probe_project_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, C.POINTER(T.JoinProjection), _i64, _vp, _vp]),
     "qsx_join_probe_exists_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _int, _pp, _vp, _vp]),
     "qsx_join_probe_count": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "qsx_join_probe_exists": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
@@ -684,6 +685,53 @@ class JoinTable:
         _check(_lib.qsx_join_probe_blocks(self._h, nb, rows, kptr, bptr, fptr, _ptr(out_p), _ptr(out_b), capacity, _ptr(count),
                                           _stream(stream)), "qsx_join_probe_blocks")
         return out_p, out_b, count
+
+    def probe_project_blocks(self, key_blocks, probe_columns, build_columns, build_first_tids=None, capacity=None, filters=None,
+                             stream=None):
+        """K4 + K5 in one pass: the output relation of the inner join over a run of probe blocks.
+        probe_columns: list of per-attribute lists of per-block stripes (probe_columns[a][b]); build_columns: list of
+        per-attribute lists of per-segment stripes (build_columns[a][s]), segment s starting at build tuple id
+        build_first_tids[s].  Returns (output columns — the probe attributes first, then the build attributes —, count)."""
+        nb = len(key_blocks)
+        dev = key_blocks[0].device if nb else torch.device("cuda:0")
+        total = sum(k.numel() for k in key_blocks)
+        capacity = total if capacity is None else capacity
+        sources = [(0, c) for c in probe_columns] + [(1, c) for c in build_columns]
+        nc = len(sources)
+        nseg = len(build_columns[0]) if build_columns else 0
+        if build_first_tids is None:
+            build_first_tids, at = [], 0
+            for sg in range(nseg):
+                build_first_tids.append(at)
+                at += build_columns[0][sg].numel()
+        proj = T.JoinProjection()
+        proj.num_columns = nc
+        outs = []
+        pstripes = (C.c_void_p * max(nb * nc, 1))()
+        bstripes = (C.c_void_p * max(nseg * nc, 1))()
+        for c, (side, stripes) in enumerate(sources):
+            ref = stripes[0]
+            proj.width[c] = ref.element_size()
+            proj.on_build[c] = side
+            outs.append(torch.empty(max(capacity, 1), dtype=ref.dtype, device=dev))
+            for i, stripe in enumerate(stripes):
+                (bstripes if side else pstripes)[i * nc + c] = stripe.data_ptr() if stripe.numel() else None
+        optr = (C.c_void_p * nc)(*[o.data_ptr() for o in outs])
+        first = (C.c_int64 * max(nseg, 1))(*build_first_tids)
+        proj.probe_stripes = C.cast(pstripes, C.POINTER(C.c_void_p))
+        proj.num_build_segments = nseg
+        proj.build_first_tids = C.cast(first, C.POINTER(C.c_int64))
+        proj.build_stripes = C.cast(bstripes, C.POINTER(C.c_void_p))
+        proj.out_columns = C.cast(optr, C.POINTER(C.c_void_p))
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
+        fptr = None
+        if filters is not None:
+            fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        _check(_lib.qsx_join_probe_project_blocks(self._h, nb, rows, kptr, fptr, C.byref(proj), capacity, _ptr(count), _stream(stream)),
+               "qsx_join_probe_project_blocks")
+        return outs, count
 
     def probe_count_blocks(self, key_blocks, filters=None, stream=None):
         nb = len(key_blocks)

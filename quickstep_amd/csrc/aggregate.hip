@@ -696,6 +696,38 @@ struct qsx_agg_state {
   }
 };
 
+// Host-visible control words of growable states: 32 bytes of pinned, mapped memory each.  hipHostMalloc / hipHostFree take
+// 0.1-0.2 ms apiece — on the critical path of every query that creates and destroys an aggregation state — so freed slots
+// are kept (a page holds 128 of them; pages are never returned).
+struct PublishedSlots {
+  std::mutex mutex;
+  std::vector<unsigned long long *> free_slots;
+  unsigned long long *take() {
+    std::lock_guard<std::mutex> lock(mutex);
+    if (free_slots.empty()) {
+      constexpr size_t kSlotsPerPage = 128;
+      unsigned long long *page = nullptr;
+      if (hipHostMalloc(reinterpret_cast<void **>(&page), kSlotsPerPage * 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+      for (size_t i = 0; i < kSlotsPerPage; ++i) free_slots.push_back(page + 4 * i);
+    }
+    unsigned long long *slot = free_slots.back();
+    free_slots.pop_back();
+    return slot;
+  }
+  void give(unsigned long long *slot) {
+    if (slot == nullptr) return;
+    std::lock_guard<std::mutex> lock(mutex);
+    free_slots.push_back(slot);
+  }
+};
+static PublishedSlots &published_slots() {
+  static PublishedSlots *slots = new PublishedSlots;   // (never destroyed: states may outlive static destruction order)
+  return *slots;
+}
+
 // Fills the state from the constexpr-capable translation shared with the AOT plan shapes.
 static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
   const Translated t = translate(c);
@@ -1595,7 +1627,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
   if (err == hipSuccess && !st->dense) err = ensure_directory(st);
   if (err == hipSuccess && st->growable) {
     err = device_malloc(reinterpret_cast<void **>(&st->log), sizeof(unsigned long long) * kLogRecords * (st->num_cols + 1));
-    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void **>(&st->published), 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    if (err == hipSuccess && (st->published = published_slots().take()) == nullptr) err = hipErrorOutOfMemory;
     if (err == hipSuccess) {
       std::memset(st->published, 0, 4 * sizeof(unsigned long long));
       err = hipHostGetDevicePointer(reinterpret_cast<void **>(&st->published_dev), st->published, 0);
@@ -1621,7 +1653,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
     (void)device_free(st->image); (void)device_free(st->control); (void)device_free(st->tile_counts); (void)device_free(st->tile_offsets);
     (void)device_free(st->log);
     (void)device_free(st->dir_entries); (void)device_free(st->dir_codes); (void)device_free(st->dir_words); (void)device_free(st->dir_ngids);
-    if (st->published != nullptr) (void)hipHostFree(st->published);
+    published_slots().give(st->published);
     delete st;
     return err == hipErrorOutOfMemory ? QSX_ERR_OUT_OF_MEMORY : QSX_ERR_HIP;
   }
@@ -1641,7 +1673,7 @@ int qsx_agg_state_destroy(qsx_agg_state_t *st) {
   (void)device_free_idle(st->dir_codes);
   (void)device_free_idle(st->dir_words);
   (void)device_free_idle(st->dir_ngids);
-  if (st->published != nullptr) (void)hipHostFree(st->published);
+  published_slots().give(st->published);
   delete st;
   return QSX_OK;
 }

@@ -69,16 +69,17 @@ struct ProbeTileSource {
   int32_t base_tid;
   const uint64_t *filter;
   uint64_t *out_bitmap;
+  int block;                 // position of the block in the run (0 without a run)
 };
 template <typename KeyT, int kTileRows, bool kRuns>
 __device__ __forceinline__ ProbeTileSource<KeyT> probe_tile_source(const long long *__restrict__ runs, int64_t tile,
                                                                    const KeyT *keys, int64_t n, int32_t base_tid,
                                                                    const uint64_t *filter, uint64_t *out_bitmap) {
-  if (!kRuns) return ProbeTileSource<KeyT>{keys, n, tile * kTileRows, base_tid, filter, out_bitmap};
+  if (!kRuns) return ProbeTileSource<KeyT>{keys, n, tile * kTileRows, base_tid, filter, out_bitmap, 0};
   const RunTile at = run_locate(runs, static_cast<int>(tile));
   return ProbeTileSource<KeyT>{run_in<KeyT>(runs, at.block), run_rows(runs, at.block),
                                static_cast<int64_t>(at.tile_in_block) * kTileRows, static_cast<int32_t>(run_base(runs, at.block)),
-                               run_filter(runs, at.block), run_out<uint64_t>(runs, at.block)};
+                               run_filter(runs, at.block), run_out<uint64_t>(runs, at.block), at.block};
 }
 
 }  // namespace qsx

@@ -35,6 +35,26 @@ __device__ __forceinline__ T *as_global(T *p) {
   return (T *)(__attribute__((address_space(1))) T *)p;
 }
 
+// The same for ONE access, with nothing left to inference: the access itself goes through a global-address-space pointer
+// (as_global() relies on the compiler propagating the cast to the uses, which it does not always do — join_dense.hpp's run
+// kernels kept their flat_load / flat_store through it).
+template <typename T>
+__device__ __forceinline__ T load_global(const T *p) {
+  return *(const __attribute__((address_space(1))) T *)p;
+}
+template <typename T>
+__device__ __forceinline__ T load_global_nt(const T *p) {
+  return __builtin_nontemporal_load((const __attribute__((address_space(1))) T *)p);
+}
+template <typename T>
+__device__ __forceinline__ void store_global(T v, T *p) {
+  *(__attribute__((address_space(1))) T *)p = v;
+}
+template <typename T>
+__device__ __forceinline__ void store_global_nt(T v, T *p) {
+  __builtin_nontemporal_store(v, (__attribute__((address_space(1))) T *)p);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_reduce_add(T v) {
 #pragma unroll

@@ -595,6 +595,18 @@ struct qsx_join_table {
   // 2 = `shadow` answers the probes.
   std::mutex seal_mutex;
   std::atomic<int> seal_state{0};
+  // Covering array of the projection last asked for (join_dense.hpp ProjectionView::cover; directly addressed tables):
+  // cover_sig = what it was built for (column widths, build stripes, segment starts); cover_state 0 = none, 1 = this
+  // projection cannot have one (duplicate keys, entries wider than 16 bytes, an ambiguous entry), 2 = valid.  A build or
+  // clear drops it.  Probes of other streams wait for cover_event.
+  std::mutex cover_mutex;
+  std::vector<long long> cover_sig;
+  void *cover = nullptr;
+  size_t cover_bytes = 0;
+  int cover_entry_bytes = 0;
+  int cover_state = 0;
+  hipEvent_t cover_event = nullptr;
+  hipStream_t cover_stream = nullptr;
   qsx_join_table *shadow = nullptr;
 
   // Directly addressed flavour (join_dense.hpp): head[] + overflow chain entries; `slots` unused.
@@ -634,6 +646,7 @@ struct qsx_join_table {
     return v;
   }
 };
+static void drop_cover(qsx_join_table *t);
 
 // control words behind entries_dev: [0] entries, [1] unused, [2] overflow entries (dense) / duplicate-key flag
 // (hashed), [3] error flag (dense), [4] [5] bounds of the inserted keys (KeyBounds; all ones = none)
@@ -872,6 +885,7 @@ int qsx_join_table_destroy(qsx_join_table_t *t) {
   (void)device_free_idle(t->slots);
   (void)device_free_idle(t->head);
   (void)device_free_idle(t->head3);
+  (void)device_free_idle(t->cover);
   if (t->pack_event != nullptr) (void)hipEventDestroy(t->pack_event);
   (void)device_free_idle(t->ov);
   (void)device_free_idle(t->entries_dev);
@@ -893,6 +907,7 @@ int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
   t->reserved = 0;
   t->max_tid.store(-1);
   t->seal_state.store(0);
+  drop_cover(t);
   return QSX_OK;
 }
 
@@ -918,6 +933,7 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   int rc = ensure_room(t, n);
   if (rc != QSX_OK) return rc;
   t->seal_state.store(0);
+  drop_cover(t);
   for (int64_t seen = t->max_tid.load(); seen < base_tid + n - 1 && !t->max_tid.compare_exchange_weak(seen, base_tid + n - 1);) {}
   std::shared_lock<std::shared_mutex> lock(t->mutex);
   const int grid = grid_for(n, kJBlock * 4);
@@ -964,6 +980,7 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
   int rc = ensure_room(t, total);
   if (rc != QSX_OK) return rc;
   t->seal_state.store(0);
+  drop_cover(t);
   for (int64_t b = 0; b < num_blocks; ++b) {
     const int64_t last = base[b] + block_rows[b] - 1;
     for (int64_t seen = t->max_tid.load(); seen < last && !t->max_tid.compare_exchange_weak(seen, last);) {}
@@ -1048,6 +1065,13 @@ static int launch_sliced(const P &policy, const typename P::Key *keys, int64_t n
                      probe_base_tid, filter, out_probe, out_build, capacity, count, slices, row_bits);
   QSX_CHECK_LAUNCH();
   return QSX_OK;
+}
+
+// A build or clear: the covering array of the last projection describes another table now.
+static void drop_cover(qsx_join_table *t) {
+  std::lock_guard<std::mutex> lock(t->cover_mutex);
+  t->cover_state = 0;
+  t->cover_sig.clear();
 }
 
 // ---- hashed table -> directly addressed shadow ------------------------------------------------------------------------------
@@ -1287,9 +1311,63 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
 
 // The table of a run of probe blocks on the device (staged_upload: stream-ordered, pinned); *rows_total = rows of the run,
 // *any_filter = some block has a filter.  Tuple ids: block_base_tids[b] + row, or run-global row numbers when it is NULL.
+// The covering array of `view`'s build-side columns for table t (directly addressed), built on first use: returns its entry
+// size (4 / 8 / 16) and sets *cover, or 0 — no build-side column, entries wider than 16 bytes, duplicate build keys, an entry
+// that came out all-ones, QSX_JOIN_COVER=0 — and the probe reads head[] and the stripes.  `view.table` must be on the device
+// in stream order (it is the calling probe's own table); the signature says what the array was built from.
+static int cover_for(qsx_join_table *t, const ProjectionView &view, int entry_bytes, bool wanted, const std::vector<long long> &signature,
+                     hipStream_t stream, const void **cover) {
+  const char *env = getenv("QSX_JOIN_COVER");   // (read per call: tests and tools compare the two forms)
+  if (!wanted || entry_bytes <= 0 || (env != nullptr && env[0] == '0') || !adaptive_enabled()) return 0;
+  std::lock_guard<std::mutex> lock(t->cover_mutex);
+  if (t->cover_state != 0 && t->cover_sig == signature) {
+    *cover = t->cover;
+    return t->cover_state == 2 ? t->cover_entry_bytes : 0;
+  }
+  // another projection's array may still be read by probes in flight
+  if (t->cover_state == 2 && hipDeviceSynchronize() != hipSuccess) return 0;
+  t->cover_state = 1;
+  t->cover_sig = signature;
+  const size_t bytes = static_cast<size_t>(t->range) * entry_bytes;
+  if (bytes > (size_t(1) << 30)) return 0;
+  if (t->cover_bytes < bytes) {
+    (void)device_free(t->cover);
+    t->cover = nullptr;
+    t->cover_bytes = 0;
+    if (device_malloc(&t->cover, bytes + 16) != hipSuccess) {
+      (void)hipGetLastError();
+      t->cover = nullptr;
+      return 0;
+    }
+    t->cover_bytes = bytes;
+  }
+  unsigned int *flags = reinterpret_cast<unsigned int *>(static_cast<char *>(t->cover) + bytes);   // (16 spare bytes behind the array)
+  if (hipMemsetAsync(flags, 0, sizeof(unsigned int), stream) != hipSuccess) return 0;
+  const DenseTableView dv = t->dense_view();
+  const unsigned grid = static_cast<unsigned>((t->range + kDBlock - 1) / kDBlock);
+  switch (entry_bytes) {
+    case 4: hipLaunchKernelGGL(cover_build_kernel<uint32_t>, dim3(grid), dim3(kDBlock), 0, stream, dv, view, static_cast<uint32_t *>(t->cover), flags); break;
+    case 8: hipLaunchKernelGGL(cover_build_kernel<unsigned long long>, dim3(grid), dim3(kDBlock), 0, stream, dv, view,
+                               static_cast<unsigned long long *>(t->cover), flags); break;
+    default: hipLaunchKernelGGL(cover_build_kernel<ulonglong2>, dim3(grid), dim3(kDBlock), 0, stream, dv, view, static_cast<ulonglong2 *>(t->cover), flags); break;
+  }
+  unsigned int seen = 0;
+  // (synchronous: once per table and projection; probes of other streams find a finished array)
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess ||
+      hipMemcpy(&seen, flags, sizeof(seen), hipMemcpyDeviceToHost) != hipSuccess || seen != 0) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  t->cover_entry_bytes = entry_bytes;
+  t->cover_state = 2;
+  *cover = t->cover;
+  return entry_bytes;
+}
+
 static int upload_probe_run(int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
                             const int32_t *block_base_tids, const uint64_t *const *block_filters, uint64_t *const *block_out,
-                            hipStream_t stream, const long long **runs_dev, int64_t *tiles, int64_t *rows_total, bool *any_filter) {
+                            hipStream_t stream, const long long **runs_dev, int64_t *tiles, int64_t *rows_total, bool *any_filter,
+                            const std::vector<long long> *extra = nullptr, const long long **extra_dev = nullptr) {
   std::vector<int64_t> base(static_cast<size_t>(num_blocks));
   int64_t total = 0;
   *any_filter = false;
@@ -1307,9 +1385,13 @@ static int upload_probe_run(int64_t num_blocks, const int64_t *block_rows, const
   *rows_total = total;
   if (*tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
   if (*tiles == 0) return QSX_OK;
+  // (a second table of the same call rides behind the run table: one staging buffer per thread and stream)
+  const size_t run_words = table.size();
+  if (extra != nullptr) table.insert(table.end(), extra->begin(), extra->end());
   const size_t bytes = table.size() * sizeof(long long);
   *runs_dev = static_cast<const long long *>(staged_device_buffer(stream, bytes));
   if (*runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  if (extra_dev != nullptr) *extra_dev = *runs_dev + run_words;
   return staged_upload(stream, table.data(), bytes);
 }
 
@@ -1368,6 +1450,163 @@ int qsx_join_probe_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
   const uint64_t *filter_mark = any_filter ? reinterpret_cast<const uint64_t *>(runs_dev) : nullptr;   // only tested against NULL
   return launch_probe<0, true>(t, nullptr, rows, 0, filter_mark, out_probe_tid_dev, out_build_tid_dev, capacity, out_count_dev,
                                nullptr, 0, s, runs_dev, tiles);
+}
+
+int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                  const uint64_t *const *block_filters, const qsx_join_projection_t *proj, int64_t capacity,
+                                  int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || num_blocks < 0 || capacity < 0 || out_count_dev == nullptr || proj == nullptr ||
+      (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr)) || proj->num_columns < 1 ||
+      proj->num_columns > QSX_MAX_PROJECTED || proj->out_columns == nullptr || proj->num_build_segments < 0) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  const int nc = proj->num_columns;
+  bool any_build = false, any_probe = false;
+  for (int c = 0; c < nc; ++c) {
+    const int w = proj->width[c];
+    if (w != 1 && w != 2 && w != 4 && w != 8) return QSX_ERR_INVALID_ARGUMENT;
+    if (capacity > 0 && proj->out_columns[c] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    (proj->on_build[c] != 0 ? any_build : any_probe) = true;
+  }
+  if (any_probe && num_blocks > 0 && proj->probe_stripes == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (any_build && proj->num_build_segments > 0 && (proj->build_first_tids == nullptr || proj->build_stripes == nullptr)) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  for (int sg = 1; sg < proj->num_build_segments; ++sg) {
+    if (proj->build_first_tids[sg] < proj->build_first_tids[sg - 1]) return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  if (capacity == 0 || (any_build && proj->num_build_segments == 0)) {
+    // nowhere to write, or a build side without tuples (nothing can match): the count only
+    return qsx_join_probe_count_blocks(t, num_blocks, block_rows, block_keys, block_filters, out_count_dev, stream);
+  }
+  qsx_join_table *direct = t->dense ? t : sealed_shadow(t, s);
+  if (direct == nullptr) {
+    // No directly addressed form of this table: the pair list after all, in scratch of this call, and one gather per column.
+    int64_t total_rows = 0;
+    for (int64_t b = 0; b < num_blocks; ++b) total_rows += block_rows[b] > 0 ? block_rows[b] : 0;
+    QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+    if (total_rows == 0) return QSX_OK;
+    int32_t *pairs = nullptr;
+    QSX_HIP_TRY(device_malloc(reinterpret_cast<void **>(&pairs), static_cast<size_t>(capacity) * 8 + 16));
+    int32_t *probe_tids = pairs, *build_tids = pairs + capacity;
+    // slots no pair reaches gather tuple 0 of their side (the caller reads *out_count tuples; the rest is unspecified)
+    hipError_t err = hipMemsetAsync(probe_tids, 0, static_cast<size_t>(capacity) * 4, s);
+    const int first_build = proj->num_build_segments > 0 ? static_cast<int>(proj->build_first_tids[0]) : 0;
+    if (err == hipSuccess) err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(build_tids), first_build, static_cast<size_t>(capacity), s);
+    int rc = err == hipSuccess ? QSX_OK : QSX_ERR_HIP;
+    if (rc == QSX_OK) {
+      rc = qsx_join_probe_blocks(t, num_blocks, block_rows, block_keys, nullptr, block_filters, probe_tids, build_tids, capacity, out_count_dev, stream);
+    }
+    std::vector<int64_t> probe_first(static_cast<size_t>(num_blocks));
+    std::vector<const void *> segs;
+    int64_t at = 0;
+    for (int64_t b = 0; b < num_blocks; ++b) {
+      probe_first[static_cast<size_t>(b)] = at;
+      at += block_rows[b];
+    }
+    const int64_t gathered = capacity;
+    for (int c = 0; c < nc && rc == QSX_OK; ++c) {
+      segs.clear();
+      if (proj->on_build[c] != 0) {
+        if (proj->num_build_segments == 0) continue;   // an empty build side: nothing matched
+        for (int sg = 0; sg < proj->num_build_segments; ++sg) segs.push_back(proj->build_stripes[static_cast<size_t>(sg) * nc + c]);
+        rc = qsx_gather_segmented(proj->width[c], proj->num_build_segments, segs.data(), proj->build_first_tids, build_tids, gathered,
+                                  proj->out_columns[c], stream);
+      } else {
+        for (int64_t b = 0; b < num_blocks; ++b) segs.push_back(proj->probe_stripes[static_cast<size_t>(b) * nc + c]);
+        rc = qsx_gather_segmented(proj->width[c], static_cast<int>(num_blocks), segs.data(), probe_first.data(), probe_tids, gathered,
+                                  proj->out_columns[c], stream);
+      }
+    }
+    (void)hipStreamSynchronize(s);   // the pair list is this call's
+    (void)device_free_idle(pairs);
+    return rc;
+  }
+  // the projection's table (join_dense.hpp ProjectionView) rides behind the run table
+  const int nseg = proj->num_build_segments > 0 ? proj->num_build_segments : 1;
+  const size_t head_words = static_cast<size_t>(kProjColumnWords) * nc;
+  std::vector<long long> table(head_words + nseg + static_cast<size_t>(nseg) * nc + static_cast<size_t>(num_blocks) * nc, 0);
+  auto word_of = [](const void *p) { return static_cast<long long>(reinterpret_cast<uintptr_t>(p)); };
+  // entries of the covering array: the build-side columns at their natural alignment, 4 / 8 / 16 bytes in all
+  int cover_bytes = 0;
+  std::vector<long long> signature;
+  for (int c = 0; c < nc; ++c) {
+    table[static_cast<size_t>(c)] = proj->width[c];
+    table[static_cast<size_t>(nc + c)] = proj->on_build[c] != 0 ? 1 : 0;
+    table[static_cast<size_t>(2 * nc + c)] = word_of(proj->out_columns[c]);
+    if (proj->on_build[c] != 0) {
+      cover_bytes = (cover_bytes + proj->width[c] - 1) / proj->width[c] * proj->width[c];
+      table[static_cast<size_t>(3 * nc + c)] = cover_bytes;
+      signature.push_back(proj->width[c]);
+      signature.push_back(cover_bytes);
+      cover_bytes += proj->width[c];
+    }
+  }
+  cover_bytes = cover_bytes == 0 ? 0 : (cover_bytes <= 4 ? 4 : (cover_bytes <= 8 ? 8 : (cover_bytes <= 16 ? 16 : -1)));
+  long long seg_rows = 0;
+  for (int sg = 0; sg < proj->num_build_segments; ++sg) {
+    table[head_words + sg] = proj->build_first_tids[sg];
+    signature.push_back(proj->build_first_tids[sg]);
+    if (sg > 0) {
+      const long long len = proj->build_first_tids[sg] - proj->build_first_tids[sg - 1];
+      if (sg == 1) seg_rows = len;
+      else if (len != seg_rows) seg_rows = -1;
+    }
+    for (int c = 0; c < nc; ++c) {
+      if (proj->on_build[c] != 0) {
+        table[head_words + nseg + static_cast<size_t>(sg) * nc + c] = word_of(proj->build_stripes[static_cast<size_t>(sg) * nc + c]);
+        signature.push_back(table[head_words + nseg + static_cast<size_t>(sg) * nc + c]);
+      }
+    }
+  }
+  if (seg_rows <= 0 || seg_rows > INT32_MAX) seg_rows = 0;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    for (int c = 0; c < nc; ++c) {
+      if (proj->on_build[c] == 0) {
+        const void *stripe = proj->probe_stripes[static_cast<size_t>(b) * nc + c];
+        if (stripe == nullptr && block_rows[b] > 0) return QSX_ERR_INVALID_ARGUMENT;
+        table[head_words + nseg + static_cast<size_t>(nseg) * nc + static_cast<size_t>(b) * nc + c] = word_of(stripe);
+      }
+    }
+  }
+  const long long *runs_dev = nullptr, *proj_dev = nullptr;
+  int64_t tiles = 0, rows = 0;
+  bool any_filter = false;
+  const int rc = upload_probe_run(num_blocks, block_rows, block_keys, nullptr, block_filters, nullptr, s, &runs_dev, &tiles, &rows,
+                                  &any_filter, &table, &proj_dev);
+  if (rc != QSX_OK) return rc;
+  QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+  if (rows == 0) return QSX_OK;
+  sealed_pack(direct, s);
+  ProjectionView view{proj_dev, nc, nseg, static_cast<int>(seg_rows), nullptr};
+  const int cover_entry = cover_for(direct, view, cover_bytes, any_build && proj->num_build_segments > 0, signature, s, &view.cover);
+  std::shared_lock<std::shared_mutex> lock(direct->mutex);
+  const int64_t limit = 8 * kCUs;
+  const int dgrid = static_cast<int>(tiles < limit ? tiles : limit);
+  const uint64_t *filter_mark = any_filter ? reinterpret_cast<const uint64_t *>(runs_dev) : nullptr;   // only tested against NULL
+  unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count_dev);
+  const DenseTableView dv = direct->dense_view();
+  constexpr int kCoverBlock = 1024;
+  const int cgrid = static_cast<int>(tiles < 2 * kCUs ? tiles : 2 * kCUs);
+  auto by_entry = [&](auto key_tag) {
+    using KeyT = decltype(key_tag);
+    switch (cover_entry) {
+      case 4: hipLaunchKernelGGL((cover_probe_kernel<KeyT, uint32_t, kCoverBlock>), dim3(cgrid), dim3(kCoverBlock), 0, s, dv, capacity, count, runs_dev, view); break;
+      case 8: hipLaunchKernelGGL((cover_probe_kernel<KeyT, unsigned long long, kCoverBlock>), dim3(cgrid), dim3(kCoverBlock), 0, s, dv, capacity, count, runs_dev, view); break;
+      case 16: hipLaunchKernelGGL((cover_probe_kernel<KeyT, ulonglong2, kCoverBlock>), dim3(cgrid), dim3(kCoverBlock), 0, s, dv, capacity, count, runs_dev, view); break;
+      default:
+        hipLaunchKernelGGL((dense_probe_kernel<KeyT, 5, true>), dim3(dgrid), dim3(kDBlock), 0, s, dv, static_cast<const KeyT *>(nullptr), rows, 0,
+                           filter_mark, static_cast<int32_t *>(nullptr), static_cast<int32_t *>(nullptr), capacity, count,
+                           static_cast<uint64_t *>(nullptr), 0, static_cast<int32_t *>(nullptr), static_cast<const int64_t *>(nullptr), runs_dev,
+                           view);
+        break;
+    }
+  };
+  if (direct->key_type == QSX_INT) by_entry(int32_t{}); else by_entry(int64_t{});
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
 }
 
 int qsx_join_probe_count_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,

@@ -25,6 +25,8 @@
 #ifndef QSX_CSRC_JOIN_DENSE_HPP_
 #define QSX_CSRC_JOIN_DENSE_HPP_
 
+#include <type_traits>
+
 #include "block_runs.hpp"
 #include "common.hpp"
 
@@ -99,10 +101,10 @@ __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((sw0 + r) << 6) + lane;
-      k[r] = src.keys[row < src.n ? row : src.n - 1];   // clamped, not guarded: no branch around the read
+      k[r] = load_global(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded: no branch around the read
     }
     fw = ~0ull;
-    if (src.filter != nullptr && lane < R && sw0 + lane < ((src.n + 63) >> 6)) fw = src.filter[sw0 + lane];
+    if (src.filter != nullptr && lane < R && sw0 + lane < ((src.n + 63) >> 6)) fw = load_global(&src.filter[sw0 + lane]);
   };
   Source cur = Source(), next = Source();
   int64_t group = wave;
@@ -158,6 +160,116 @@ __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, 
   if (lane == 0 && inserted != 0) atomicAdd(entries, inserted);
 }
 
+// ---- probe + projection in one pass (qsx_join_probe_project_blocks) ------------------------------------------------------
+// The output relation of an inner join — the reference's HashInnerJoinWorkOrder materialises it from the (probe, build)
+// tuple-id pairs it collected (HashJoinOperator.cpp:494-560) — written by the probe itself: a matching lane reads the
+// projected attributes of its probe row (coalesced: lanes are consecutive rows) and of the build tuple it found (random)
+// and stores them at the output position it would have stored the pair at.  The pair list (8 bytes written and read
+// again per match) and one kernel per attribute go away.
+// Device table (8-byte words), kProjColumnWords arrays of nc words first: width | on_build | output stripe | byte offset of the
+// column inside an entry of the covering array (build-side columns, when there is one); then first tuple id of build segment
+// s [nseg] | stripe of column c in build segment s [s * nc + c] | stripe of column c in probe block b [b * nc + c].
+//
+// Covering array (MODE 6 / 7 / 8: entries of 4 / 8 / 16 bytes): the projected build-side values of the tuple under key value
+// k, packed into one entry at cover[k - min_key]; all bits set = no tuple.  Built once per (table, projection) by
+// cover_build_kernel when the build keys are unique; the probe then reads ONE random entry per row — not head[] and then the
+// attribute stripes: both together (3 + 4 MiB for a million keys and one INT attribute) do not share an XCD's L2.
+constexpr int kProjColumnWords = 4;
+struct ProjectionView {
+  const long long *table;
+  int nc;
+  int nseg;
+  int seg_rows;   // > 0: every build segment but the last holds this many tuples — segment of a tuple id by division
+  const void *cover;
+  __device__ __forceinline__ int width(int c) const { return static_cast<int>(table[c]); }
+  __device__ __forceinline__ bool on_build(int c) const { return table[nc + c] != 0; }
+  __device__ __forceinline__ char *out(int c) const { return as_global(reinterpret_cast<char *>(table[2 * nc + c])); }
+  __device__ __forceinline__ int cover_offset(int c) const { return static_cast<int>(table[3 * nc + c]); }
+  __device__ __forceinline__ const long long *first_tids() const { return table + kProjColumnWords * nc; }
+  __device__ __forceinline__ const char *build_stripe(int seg, int c) const {
+    return as_global(reinterpret_cast<const char *>(table[kProjColumnWords * nc + nseg + seg * nc + c]));
+  }
+  __device__ __forceinline__ const char *probe_stripe(int block, int c) const {
+    return as_global(reinterpret_cast<const char *>(table[kProjColumnWords * nc + nseg + nseg * nc + block * nc + c]));
+  }
+};
+__device__ __forceinline__ unsigned long long load_value(const char *src, int width) {
+  switch (width) {
+    case 1: return load_global(reinterpret_cast<const uint8_t *>(src));
+    case 2: return load_global(reinterpret_cast<const uint16_t *>(src));
+    case 4: return load_global(reinterpret_cast<const uint32_t *>(src));
+    default: return load_global(reinterpret_cast<const unsigned long long *>(src));
+  }
+}
+__device__ __forceinline__ void store_value(char *dst, unsigned long long v, int width) {
+  switch (width) {
+    case 1: store_global(static_cast<uint8_t>(v), reinterpret_cast<uint8_t *>(dst)); break;
+    case 2: store_global(static_cast<uint16_t>(v), reinterpret_cast<uint16_t *>(dst)); break;
+    case 4: store_global_nt(static_cast<uint32_t>(v), reinterpret_cast<uint32_t *>(dst)); break;
+    default: store_global_nt(v, reinterpret_cast<unsigned long long *>(dst)); break;
+  }
+}
+// Where column c of build tuple `tid` lives.
+__device__ __forceinline__ const char *projected_build_value(const ProjectionView &p, int c, int width, uint32_t tid) {
+  const long long *first = p.first_tids();
+  int seg = 0;
+  if (p.nseg > 1) {
+    if (p.seg_rows > 0) {
+      seg = static_cast<int>((tid - static_cast<uint32_t>(first[0])) / static_cast<uint32_t>(p.seg_rows));
+      seg = seg < p.nseg ? seg : p.nseg - 1;
+    } else {
+      int lo = 0, hi = p.nseg - 1;   // last segment whose first tuple id <= tid
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= static_cast<long long>(tid)) lo = mid; else hi = mid - 1;
+      }
+      seg = lo;
+    }
+  }
+  return p.build_stripe(seg, c) + static_cast<size_t>(tid - static_cast<uint32_t>(first[seg])) * width;
+}
+// One projected tuple (the duplicate chains' path: one match at a time).
+__device__ __forceinline__ void project_one(const ProjectionView &p, int block, int64_t probe_row, uint32_t tid, unsigned long long o) {
+  for (int c = 0; c < p.nc; ++c) {
+    const int width = p.width(c);
+    const char *src = p.on_build(c) ? projected_build_value(p, c, width, tid) : p.probe_stripe(block, c) + static_cast<size_t>(probe_row) * width;
+    store_value(p.out(c) + o * width, load_value(src, width), width);
+  }
+}
+
+// The covering array of a projection: entry i = the build-side values of the tuple whose key is min_key + i.
+// flags: bit 0 = some key has several tuples (no covering array for this table), bit 1 = a real entry came out all-ones
+// (indistinguishable from "no tuple").
+template <typename EntryT>
+__global__ __launch_bounds__(kDBlock) void cover_build_kernel(DenseTableView t, ProjectionView p, EntryT *__restrict__ cover,
+                                                             unsigned int *__restrict__ flags) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kDBlock + threadIdx.x;
+  if (i >= t.range) return;
+  const uint32_t hw = t.head[i];
+  unsigned long long words[2] = {~0ull, ~0ull};
+  if (hw & kChainBit) {
+    atomicOr(flags, 1u);
+  } else if (hw != 0u) {
+    words[0] = words[1] = 0ull;
+    for (int c = 0; c < p.nc; ++c) {
+      if (!p.on_build(c)) continue;
+      const int width = p.width(c), off = p.cover_offset(c);
+      const unsigned long long v = load_value(projected_build_value(p, c, width, hw - 1u), width);
+      if (off < 8) words[0] |= v << (8 * off); else words[1] |= v << (8 * (off - 8));
+    }
+    const bool ones = sizeof(EntryT) == 4 ? static_cast<uint32_t>(words[0]) == ~0u
+                                          : (sizeof(EntryT) == 8 ? words[0] == ~0ull : (words[0] & words[1]) == ~0ull);
+    if (ones) atomicOr(flags, 2u);
+  }
+  if constexpr (sizeof(EntryT) == 4) {
+    cover[i] = static_cast<uint32_t>(words[0]);
+  } else if constexpr (sizeof(EntryT) == 8) {
+    cover[i] = words[0];
+  } else {
+    cover[i] = EntryT{words[0], words[1]};
+  }
+}
+
 // One wave-aggregated append of the matching lanes straight to the global output.
 __device__ __forceinline__ void dense_emit_direct(bool match, int32_t probe_tid, int32_t build_tid,
                                                   int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build,
@@ -182,17 +294,21 @@ __device__ __forceinline__ void dense_emit_direct(bool match, int32_t probe_tid,
 // ~12 ns each: with sparse matches over clustered keys the one-pass form is bound by them, 146 K tiles = 1.7 ms for
 // 600 M rows) and the pairs come out in probe-row order.
 //
+// MODE 5: MODE 0 with the projected tuples written instead of the pairs (ProjectionView above).
+// (with a covering array of the build-side columns: cover_probe_kernel below)
+//
 // kRuns: the probe side is a run of blocks (qsx_join_probe_blocks, block_runs.hpp) — `runs` is the table, a tile belongs to
 // one block and takes that block's key stripe, row count, filter, base tuple id and (MODE 2) output bitmap; the output
 // pair list and its counter are the run's.
 template <typename KeyT, int MODE, bool kRuns = false>
-__global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
+__global__ __launch_bounds__(kDBlock) __attribute__((amdgpu_waves_per_eu(MODE == 5 ? 3 : 1))) void dense_probe_kernel(
     DenseTableView t, const KeyT *__restrict__ keys, int64_t n, int32_t probe_base_tid,
     const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build,
     int64_t capacity_signed, unsigned long long *__restrict__ out_count, uint64_t *__restrict__ out_bitmap, int anti,
     int32_t *__restrict__ unit_counts = nullptr, const int64_t *__restrict__ unit_offsets = nullptr,
-    const long long *__restrict__ runs = nullptr) {
+    const long long *__restrict__ runs = nullptr, ProjectionView proj = ProjectionView{}) {
   constexpr int R = kDenseRowsPerThread;
+  constexpr bool kProject = MODE == 5;                  // emits projected tuples
   using Source = ProbeTileSource<KeyT>;
   const unsigned long long capacity = static_cast<unsigned long long>(capacity_signed);
   const int64_t num_tiles = kRuns ? runs[2] : (n + kDenseTile - 1) / kDenseTile;
@@ -216,12 +332,12 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = src.base + r * kDBlock + threadIdx.x;
-      k[r] = __builtin_nontemporal_load(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded
+      k[r] = load_global_nt(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded
     }
     words = ~0ull;
     if (src.filter != nullptr && lane < R) {
       const int64_t w = (src.base >> 6) + lane * (kDBlock / kWave) + wave;
-      if (w < ((src.n + 63) >> 6)) words = src.filter[w];
+      if (w < ((src.n + 63) >> 6)) words = load_global(&src.filter[w]);
     }
   };
   Source cur = Source(), next = Source();
@@ -239,6 +355,7 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
     const int64_t n_rows = cur.n;
     const int32_t base_tid = cur.base_tid;
     uint64_t *const tile_bitmap = cur.out_bitmap;
+    const int tile_block = cur.block;
     cur = next;
     // Row r of this thread: tile_base + r * 256 + tid; a wave owns 64 consecutive rows per r (the workgroup reads 1 KiB
     // contiguous per step: the wave-contiguous mapping measured 8 % slower).
@@ -273,7 +390,7 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
       }
       // lane r holds the word of step r: one store instruction per tile and wave
       const int64_t w = (tile_base >> 6) + lane * (kDBlock / kWave) + wave;
-      if (lane < R && w < ((n_rows + 63) >> 6)) tile_bitmap[w] = mine;
+      if (lane < R && w < ((n_rows + 63) >> 6)) store_global(mine, &tile_bitmap[w]);
       continue;
     }
 
@@ -297,7 +414,7 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
         for (int r = 0; r < R; ++r) next[r] = (h[r] & kChainBit) ? t.ov[h[r] & ~kChainBit].y : 0u;
       }
     } else {
-      if (MODE == 0) {
+      if (MODE == 0 || kProject) {
         // s_wave_total is double-buffered by tile parity, s_tile_base is rewritten only after the next
         // tile's first barrier: two barriers per tile suffice.
         if (lane == 0) s_wave_total[parity][wave] = total;
@@ -317,10 +434,74 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
       // Few matches in the wave's 1024 rows (a selective filter in front of the probe): 16 steps of stores with a
       // handful of active lanes each would write 16-byte fragments.  The pairs meet in a wave-private LDS strip and
       // leave as full-wave contiguous stores.
-      const bool sparse = total <= kDenseSparsePairs;   // wave-uniform
+      const bool sparse = !kProject && total <= kDenseSparsePairs;   // wave-uniform
       int staged = 0;
+      if (kProject) {
+        // positions and build tuple ids of the first-level matches, then column by column: the R reads of a column are all
+        // issued before its first store (a store between them would order them: the compiler cannot tell the stripes apart)
+        // (registers: h[r] becomes the matched build tuple id + 1, the output position a 32-bit offset from the wave's base)
+        int off[R];
+        int emitted = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          next[r] = 0u;
+          if (wave_has_chain && (h[r] & kChainBit)) {
+            const uint2 e = t.ov[h[r] & ~kChainBit];
+            h[r] = e.x + 1u;
+            next[r] = e.y;
+          }
+          off[r] = emitted + rank_below(m[r]);
+          emitted += __popcll(m[r]);
+        }
+        const unsigned long long wave_base = base;
+        base += emitted;
+        for (int c = 0; c < proj.nc; ++c) {
+          const int width = proj.width(c);
+          const bool on_build = proj.on_build(c);
+          char *dst = proj.out(c);
+          const char *probe_stripe = proj.probe_stripe(tile_block, c);   // (0 for a build-side column: never read)
+          // (the width is chosen once per column, outside the R reads: a switch per read puts every read into a basic block of
+          // its own and the tile pays R memory round trips per column instead of one — 2.1 instead of 0.8 ms per 100 M rows)
+          auto column = [&](auto tag) __attribute__((always_inline)) {
+            using V = decltype(tag);
+            constexpr int H = R / 2;   // (two half tiles: 16 values and their addresses in registers cost two waves per SIMD)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              V v[H];
+              if (on_build) {
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                  const int r = half * H + i;
+                  // unconditional read, no branch around it: rows without a match read the first word of the output stripe
+                  const char *src = h[r] != 0u ? projected_build_value(proj, c, sizeof(V), h[r] - 1u) : dst;
+                  v[i] = load_global(reinterpret_cast<const V *>(src));
+                }
+              } else {
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                  const int64_t row = tile_base + (half * H + i) * kDBlock + threadIdx.x;
+                  v[i] = load_global_nt(&reinterpret_cast<const V *>(probe_stripe)[row < n_rows ? row : n_rows - 1]);
+                }
+              }
+#pragma unroll
+              for (int i = 0; i < H; ++i) {
+                const int r = half * H + i;
+                const unsigned long long o = wave_base + off[r];
+                if (h[r] != 0u && o < capacity) store_global_nt(v[i], reinterpret_cast<V *>(dst) + o);
+              }
+            }
+          };
+          switch (width) {
+            case 1: column(uint8_t{}); break;
+            case 2: column(uint16_t{}); break;
+            case 4: column(uint32_t{}); break;
+            default: column(static_cast<unsigned long long>(0)); break;
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
+        if (kProject) break;
         const int64_t row = tile_base + r * kDBlock + threadIdx.x;
         uint32_t tid = h[r] - 1u;
         next[r] = 0u;
@@ -377,6 +558,13 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
           } else if (MODE == 0) {
             dense_emit_direct(cur != 0u, static_cast<int32_t>(base_tid + row), static_cast<int32_t>(tid), out_probe,
                               out_build, capacity, out_count);
+          } else if (kProject) {
+            const uint64_t cm = __ballot(cur != 0u);
+            unsigned long long at = 0;
+            const int leader = __ffsll(static_cast<long long>(cm)) - 1;
+            if (lane == leader) at = atomicAdd(out_count, static_cast<unsigned long long>(__popcll(cm)));
+            at = __shfl(at, leader, kWave) + rank_below(cm);
+            if (cur != 0u && at < capacity) project_one(proj, tile_block, row, tid, at);
           } else {   // the wave's run continues behind its first-level matches, in the order the counting pass saw
             const uint64_t cm = __ballot(cur != 0u);
             const unsigned long long o = base + rank_below(cm);
@@ -399,6 +587,138 @@ __global__ __launch_bounds__(kDBlock) void dense_probe_kernel(
   if (MODE == 1 || MODE == 2) {
     local_count = wave_reduce_add(local_count);
     if (lane == 0 && local_count != 0 && out_count != nullptr) atomicAdd(out_count, local_count);
+  }
+}
+
+// Probe + projection through the covering array (ProjectionView::cover), over a run of probe blocks: one random read per
+// probe row brings the match AND the build-side values.  Tiles, reservation (one atomic on the output counter per tile) and
+// output order as dense_probe_kernel MODE 0; unique build keys by construction (cover_build_kernel), so no chains.
+// BLOCK threads take a tile of kDenseTile rows, kDenseTile / BLOCK rows per thread: 512 x 8 instead of the pair kernel's 256 x 16 —
+// the entries and values of 16 rows per thread cost 180 registers, i.e. two workgroups per CU and most of a tile's four memory
+// round trips exposed.
+template <typename KeyT, typename CoverT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void cover_probe_kernel(DenseTableView t, int64_t capacity_signed,
+                                                             unsigned long long *__restrict__ out_count,
+                                                             const long long *__restrict__ runs, ProjectionView proj) {
+  constexpr int R = kDenseTile / BLOCK;
+  static_assert(R * BLOCK == kDenseTile && R <= kWave, "a tile is R steps of BLOCK rows; lane r holds the filter word of step r");
+  const unsigned long long capacity = static_cast<unsigned long long>(capacity_signed);
+  const int64_t num_tiles = runs[2];
+  __shared__ int s_wave_total[2][BLOCK / kWave];
+  __shared__ unsigned long long s_tile_base;
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const CoverT *cover = reinterpret_cast<const CoverT *>(proj.cover);
+  int parity = 0;
+  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, parity ^= 1) {
+    const ProbeTileSource<KeyT> src = probe_tile_source<KeyT, kDenseTile, true>(runs, tile, nullptr, 0, 0, nullptr, nullptr);
+    uint64_t filter_words = ~0ull;
+    if (src.filter != nullptr && lane < R) {
+      const int64_t w = (src.base >> 6) + lane * (BLOCK / kWave) + wave;
+      if (w < ((src.n + 63) >> 6)) filter_words = load_global(&src.filter[w]);
+    }
+    CoverT e[R];
+    {
+      KeyT key[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = src.base + r * BLOCK + threadIdx.x;
+        key[r] = load_global_nt(&src.keys[row < src.n ? row : src.n - 1]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {   // R independent reads in flight per lane; dead rows read entry 0 and are masked below
+        const uint64_t idx = dense_index(t, key[r]);
+        if constexpr (sizeof(CoverT) == 16) {
+          using Pair = unsigned long long __attribute__((ext_vector_type(2)));   // (one 16-byte load; a class type cannot be read through an address-space pointer)
+          const Pair both = load_global(reinterpret_cast<const Pair *>(&cover[idx != ~0ull ? idx : 0]));
+          e[r] = CoverT{both.x, both.y};
+        } else {
+          e[r] = load_global(&cover[idx != ~0ull ? idx : 0]);
+        }
+        if (idx == ~0ull) {
+          if constexpr (sizeof(CoverT) == 16) e[r] = CoverT{~0ull, ~0ull}; else e[r] = static_cast<CoverT>(~static_cast<CoverT>(0));
+        }
+      }
+    }
+    uint64_t m[R];
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = src.base + r * BLOCK + threadIdx.x;
+      const uint64_t filter_word = __shfl(filter_words, r, kWave);
+      bool present;
+      if constexpr (sizeof(CoverT) == 16) present = (e[r].x & e[r].y) != ~0ull; else present = e[r] != static_cast<CoverT>(~static_cast<CoverT>(0));
+      m[r] = __ballot(present && row < src.n && msb_bit(filter_word, lane));
+      total += __popcll(m[r]);
+    }
+    if (lane == 0) s_wave_total[parity][wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int all = 0;
+#pragma unroll
+      for (int w = 0; w < BLOCK / kWave; ++w) all += s_wave_total[parity][w];
+      s_tile_base = all != 0 ? atomicAdd(out_count, static_cast<unsigned long long>(all)) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = s_tile_base;
+    for (int w = 0; w < wave; ++w) base += s_wave_total[parity][w];
+    if (total == 0) continue;   // (wave-uniform; the barriers are behind us)
+    // Per row and column-invariant, in 32 bits (what the compiler hoists out of the column loop stays in registers: 64-bit
+    // positions and row numbers for 16 rows were 64 of them): the row's offset from the wave's first output tuple, its
+    // offset from the tile's first row, and one bit "matched and inside the capacity".
+    int off[R];
+    unsigned int emit_mask = 0;
+    {
+      int at = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        off[r] = at + rank_below(m[r]);
+        if (((m[r] >> lane) & 1ull) && base + static_cast<unsigned long long>(off[r]) < capacity) emit_mask |= 1u << r;
+        at += __popcll(m[r]);
+      }
+    }
+    const int tile_rows = static_cast<int>(src.n - src.base < kDenseTile ? src.n - src.base : kDenseTile);
+    for (int c = 0; c < proj.nc; ++c) {
+      const int width = proj.width(c);
+      const bool on_build = proj.on_build(c);
+      const int shift = 8 * proj.cover_offset(c);
+      auto column = [&](auto tag) __attribute__((always_inline)) {
+        using V = decltype(tag);
+        constexpr int H = R / 2;
+        // (wave-uniform; as_global at the point of use: a pointer that went through a select with nullptr or a struct is
+        // generic again and its accesses become flat_load / flat_store)
+        V *tile_dst = reinterpret_cast<V *>(proj.out(c)) + base;
+        const V *tile_src = reinterpret_cast<const V *>(proj.probe_stripe(src.block, c)) + src.base;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          V v[H];
+#pragma unroll
+          for (int i = 0; i < H; ++i) {
+            const int r = half * H + i;
+            if (on_build) {
+              if constexpr (sizeof(CoverT) == 16) {
+                v[i] = static_cast<V>(shift < 64 ? e[r].x >> shift : e[r].y >> (shift - 64));
+              } else {
+                v[i] = static_cast<V>(static_cast<unsigned long long>(e[r]) >> shift);
+              }
+            } else {
+              const int in_tile = r * BLOCK + static_cast<int>(threadIdx.x);
+              v[i] = load_global_nt(&tile_src[in_tile < tile_rows ? in_tile : tile_rows - 1]);   // (a stream: keep it out of the covering array's L2)
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < H; ++i) {
+            const int r = half * H + i;
+            if ((emit_mask >> r) & 1u) store_global_nt(v[i], &tile_dst[off[r]]);
+          }
+        }
+      };
+      switch (width) {
+        case 1: column(uint8_t{}); break;
+        case 2: column(uint16_t{}); break;
+        case 4: column(uint32_t{}); break;
+        default: column(static_cast<unsigned long long>(0)); break;
+      }
+    }
   }
 }
 

@@ -629,6 +629,12 @@ class WorkOrder {
   virtual ~WorkOrder() {}
   virtual void execute() = 0;                                            // WorkOrder.hpp:251
   const std::vector<int> &getPreferredNUMANodes() const { return preferred_numa_nodes_; }  // :260
+  // The counterpart of the NUMA preference on this device: a work order whose speed depends on a table staying in the XCDs'
+  // L2 (a probe of a table of a few MiB over millions of rows) wants the device to itself — next to a streaming aggregation
+  // the table is evicted continuously and the probe runs at half speed while the aggregation gains nothing.  With
+  // QSX_HOST_EXCLUSIVE_PROBES=1 the Foreman lets such work orders run only among themselves (ForemanSingleNode::workerMain;
+  // off by default: no gain measured on the headline plan, see there).
+  virtual bool prefersExclusiveDevice() const { return false; }
   std::size_t getQueryID() const { return query_id_; }
   partition_id getPartitionId() const { return partition_id_; }
 
@@ -910,6 +916,8 @@ class HashInnerJoinWorkOrder : public WorkOrder {
   void execute() override;  // HashJoinOperator.cpp:450-541 (inner), :680-877 (semi / anti), :960-1099 (outer)
   // A run of probe blocks (HashJoinOperator::setBlocksPerWorkOrder): lookup_block_id is the first of them.
   void setRun(std::vector<block_id> &&probe_block_ids) { run_block_ids_ = std::move(probe_block_ids); }
+  // a probe of millions of rows: its table wants to stay in L2 (called on the Foreman thread when the work order is queued)
+  bool prefersExclusiveDevice() const override;
 
  private:
   void executeBlock(block_id probe_block_id);
@@ -1162,7 +1170,8 @@ class ForemanSingleNode {
   std::mutex mutex_;
   std::condition_variable cv_work_;
   std::condition_variable cv_done_;
-  struct Item { WorkOrder *wo; std::size_t op; };
+  struct Item { WorkOrder *wo; std::size_t op; bool exclusive; };
+  std::size_t exclusive_running_ = 0, shared_running_ = 0;   // work orders on Workers right now, by prefersExclusiveDevice()
   std::deque<Item> ready_;
   std::vector<std::size_t> outstanding_;  // dispatched but unfinished work orders per operator
   std::vector<std::size_t> executing_;    // of those: on a Worker right now

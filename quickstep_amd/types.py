@@ -8,7 +8,7 @@ import ctypes as C
 
 # qsx_type_t (numbering of types/TypeID.hpp:32-43 in the reference)
 ACC_SUM_F64, ACC_SUM_I64, ACC_MIN_I64, ACC_MAX_I64 = 0, 1, 2, 3      # qsx_agg_state_image_layout column kinds
-ABI_VERSION = 8                                                     # QSX_ABI_VERSION of include/qsx.h
+ABI_VERSION = 9                                                     # QSX_ABI_VERSION of include/qsx.h
 INT, LONG, FLOAT, DOUBLE, CHAR = 0, 1, 2, 3, 4
 DATE = 6   # the reference's 8-byte DateLit {int32 year; uint8 month, day; 2 bytes padding}, carried as int64 raw bytes
 # qsx_cmp_t (types/operations/comparisons/ComparisonID.hpp:36-42)
@@ -169,3 +169,13 @@ def agg_output_is_int(cfg, a):
         return False
     arg = cfg.aggs[a].arg
     return arg.kind == OPD_COLUMN and cfg.column_type[arg.index] in (INT, LONG)
+
+
+MAX_PROJECTED = 16                                                  # QSX_MAX_PROJECTED
+
+
+class JoinProjection(C.Structure):                                   # qsx_join_projection_t
+    _fields_ = [("num_columns", C.c_int32), ("width", C.c_int32 * MAX_PROJECTED), ("on_build", C.c_int32 * MAX_PROJECTED),
+                ("probe_stripes", C.POINTER(C.c_void_p)), ("num_build_segments", C.c_int32),
+                ("build_first_tids", C.POINTER(C.c_int64)), ("build_stripes", C.POINTER(C.c_void_p)),
+                ("out_columns", C.POINTER(C.c_void_p))]

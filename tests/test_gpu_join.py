@@ -519,6 +519,84 @@ PROBE_RUNS = {
 }
 
 
+@pytest.mark.parametrize("table_kind", ["dense", "hashed_dense_keys", "hashed_sparse_keys"])
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+@pytest.mark.parametrize("duplicates,cover", [(False, "1"), (False, "0"), (True, "1")])
+def test_probe_writes_the_projected_output_relation(capi, oracle, dev, table_kind, key_type, dtype, duplicates, cover, monkeypatch):
+    """qsx_join_probe_project_blocks: the tuples HashInnerJoinWorkOrder materialises from its pair list
+    (HashJoinOperator.cpp:494-560), written by the probe itself — checked as a multiset of rows against the oracle's pairs
+    joined with the same attributes on the host.  Directly addressed tables and shadows run the fused kernel, a hashed
+    table over spread keys the pair list + gathers inside the call.  Build side in several segments (uniform and ragged),
+    probe side in ragged blocks with an empty one, attribute widths 1 / 2 / 4 / 8, a filter, a capacity below the result.
+    Unique build keys get a covering array of the build-side attributes (entries of 16 bytes for the INT key's projection, 4 or
+    8 for the second one; the LONG key's first projection is too wide for one); QSX_JOIN_COVER=0 keeps head[] + stripes."""
+    monkeypatch.setenv("QSX_JOIN_COVER", cover)
+    rng = np.random.default_rng(97 + duplicates)
+    nbuild = 70_000 if table_kind != "dense" or not duplicates else 9_000
+    spread = table_kind == "hashed_sparse_keys"
+    bkeys = rng.permutation(nbuild).astype(np.int64)
+    if duplicates:
+        bkeys[rng.integers(0, nbuild, size=nbuild // 10)] = bkeys[rng.integers(0, nbuild, size=nbuild // 10)]
+    if spread:
+        bkeys = bkeys * 30_011 - 10**9
+    bkeys = bkeys.astype(dtype)
+    for seg_rows in ([nbuild], [nbuild // 4] * 3 + [nbuild - 3 * (nbuild // 4)], [1000, 0, nbuild - 5000, 4000]):
+        first_tids = [100 + int(x) for x in np.cumsum([0] + seg_rows[:-1])]     # (tuple ids need not start at 0)
+        cuts = np.cumsum([0] + seg_rows)
+        b_long = rng.integers(-2**60, 2**60, size=nbuild)
+        b_short = rng.integers(0, 60000, size=nbuild).astype(np.uint16)
+        key_range = (int(bkeys.min()), int(bkeys.max())) if table_kind == "dense" else None
+        table = capi.JoinTable(key_type, nbuild, key_range=key_range)
+        dsegs = [to_dev(bkeys[a:b], dev) for a, b in zip(cuts[:-1], cuts[1:])]
+        for sg, keys in enumerate(dsegs):
+            if keys.numel():
+                table.build(keys, base_tid=first_tids[sg])
+        rows = [5000, 0, 123, 40_000, 4097]
+        pkeys = [(rng.integers(-5, nbuild + nbuild // 3, size=n) * (30_011 if spread else 1) - (10**9 if spread else 0)).astype(dtype)
+                 for n in rows]
+        p_double = [rng.normal(size=n) for n in rows]
+        p_byte = [rng.integers(0, 250, size=n).astype(np.uint8) for n in rows]
+        p_int = [rng.integers(-2**31, 2**31 - 1, size=n).astype(np.int32) for n in rows]
+        keep = [rng.random(n) < 0.8 for n in rows]
+        for use_filter in (False, True):
+            filters = [bitmap_dev(oracle.bitmap_from_bools(m), dev) if m.size else None for m in keep] if use_filter else None
+            # expected: pairs on the host
+            allp = np.concatenate(pkeys)
+            order = np.argsort(bkeys, kind="stable")
+            lo, hi = np.searchsorted(bkeys[order], allp, "left"), np.searchsorted(bkeys[order], allp, "right")
+            live = np.concatenate(keep) if use_filter else np.ones(allp.size, dtype=bool)
+            counts = np.where(live, hi - lo, 0)
+            probe_rows = np.repeat(np.arange(allp.size), counts)
+            build_rows = order[np.concatenate([np.arange(a, b) for a, b, c in zip(lo, hi, counts) if c > 0])] if counts.sum() else np.zeros(0, dtype=np.int64)
+            want = np.stack([np.concatenate(p_double)[probe_rows].view(np.int64), np.concatenate(p_byte)[probe_rows].astype(np.int64),
+                             np.concatenate(p_int)[probe_rows].astype(np.int64), allp[probe_rows].astype(np.int64),
+                             b_long[build_rows], b_short[build_rows].astype(np.int64), bkeys[build_rows].astype(np.int64)], axis=1)
+            outs, cnt = table.probe_project_blocks(
+                [to_dev(k, dev) for k in pkeys],
+                [[to_dev(x, dev) for x in col] for col in (p_double, p_byte, p_int, pkeys)],
+                [[to_dev(col[a:b], dev) for a, b in zip(cuts[:-1], cuts[1:])] for col in (b_long, b_short, bkeys)],
+                build_first_tids=first_tids, filters=filters)
+            k = int(cnt.item())
+            assert k == want.shape[0]
+            got = np.stack([outs[0][:k].cpu().numpy().view(np.int64)] + [o[:k].cpu().numpy().astype(np.int64) for o in outs[1:]], axis=1)
+            assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+        # a capacity below the result: the count is the full one, what fits is a subset of the result's rows
+        small = max(1, want.shape[0] // 3)
+        outs, cnt = table.probe_project_blocks(
+            [to_dev(k, dev) for k in pkeys], [[to_dev(x, dev) for x in col] for col in (p_int, pkeys)],
+            [[to_dev(col[a:b], dev) for a, b in zip(cuts[:-1], cuts[1:])] for col in (bkeys,)],
+            build_first_tids=first_tids, filters=filters, capacity=small)
+        assert int(cnt.item()) == want.shape[0]
+        got = np.stack([o[:small].cpu().numpy().astype(np.int64) for o in outs], axis=1)
+        assert np.array_equal(got[:, 1], got[:, 2])
+        table.close()
+    # nothing to probe
+    table = capi.JoinTable(key_type, 10)
+    none = to_dev(np.zeros(0, dtype=dtype), dev)
+    outs, cnt = table.probe_project_blocks([none], [[none]], [[none]])
+    assert int(cnt.item()) == 0
+
+
 @pytest.mark.parametrize("shape", sorted(PROBE_RUNS))
 @pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
 @pytest.mark.parametrize("flavour", FLAVOURS)
