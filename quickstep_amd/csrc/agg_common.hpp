@@ -221,7 +221,7 @@ __device__ __forceinline__ void global_add(const HashTableView &g, int col, unsi
                                            unsigned long long inc, int kind) {
   unsigned long long *p = slot <= g.cap ? g.states + static_cast<unsigned long long>(col) * (g.cap + 1) + slot
                                         : g.log + (slot - g.cap - 1) * g.log_stride + 1 + col;
-  global_accumulate(p, inc, kind);
+  global_accumulate(as_global(p), inc, kind);   // (a select of two pointers is generic to the compiler: flat atomics otherwise)
 }
 
 // ---- group directory (mid-size group counts) ---------------------------------------

@@ -305,7 +305,7 @@ __device__ __forceinline__ void expr_operand(const ExprProgram &p, const DevOper
                                              double (&out)[kExprRows]) {
   switch (o.kind) {
     case QSX_OPD_COLUMN: {
-      const void *col = p.cols[o.index];
+      const void *col = as_global(p.cols[o.index]);   // (loaded from the program in device memory)
 #pragma unroll
       for (int v = 0; v < kExprRows; ++v) {
         switch (p.types[o.index]) {
@@ -381,8 +381,8 @@ __global__ __launch_bounds__(kABlock) void eval_expression_long_kernel(const Int
     auto operand = [&](const DevOperand &o) -> long long {
       switch (o.kind) {
         case QSX_OPD_COLUMN:
-          return p.types[o.index] == QSX_INT ? static_cast<long long>(static_cast<const int32_t *>(p.cols[o.index])[row])
-                                             : static_cast<const long long *>(p.cols[o.index])[row];
+          return p.types[o.index] == QSX_INT ? static_cast<long long>(static_cast<const int32_t *>(as_global(p.cols[o.index]))[row])
+                                             : static_cast<const long long *>(as_global(p.cols[o.index]))[row];
         case QSX_OPD_CONST: return p.consts[o.index];
         default: return temps[o.index];
       }

@@ -30,9 +30,13 @@ __device__ __forceinline__ int rank_below(uint64_t mask) {
 // compiler: accesses through it become flat_load / flat_store, which count against the LDS counter as well — next to LDS
 // DMA that serialises a kernel (the Q1 aggregation under a filter: 5.0 instead of 3.4 ms per 600 M rows when the filter
 // pointer travelled through a struct).  This tells the compiler that the pointer is to device memory.
+// (Through an INTEGER: generic -> global -> generic pointer casts are looked through by the address-space inference only
+// when the generic pointer has a known origin; a pointer made from a loaded table word has none, and the round trip through
+// the pointer types left every access of the run kernels a flat_load / flat_store.  integer -> global pointer -> generic is
+// a global pointer by construction.)
 template <typename T>
 __device__ __forceinline__ T *as_global(T *p) {
-  return (T *)(__attribute__((address_space(1))) T *)p;
+  return (T *)(__attribute__((address_space(1))) T *)reinterpret_cast<uintptr_t>(p);
 }
 
 // The same for ONE access, with nothing left to inference: the access itself goes through a global-address-space pointer
