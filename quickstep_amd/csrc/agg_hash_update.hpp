@@ -474,6 +474,11 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
 // ~6 ns per wave instruction per CU, tools/ubench/lds_atomic.hip).
 // kDense: COLLISION_FREE sink — the group of a row is its key value, accumulators are the dense
 // arrays in HBM (DenseView), adjacent equal keys of a wave are combined before the atomics.
+// kDense && kDir: a dense state small enough for ONE workgroup's LDS (S = num_entries accumulators per aggregate, the
+// directory kernels' layout and geometry, no DirView): the group number is the key value, rows accumulate with LDS atomics
+// and the workgroup adds its totals to the dense arrays at its end.  Random global atomics complete at ~24 G/s whatever
+// their scope, target size or slicing by XCD (tools/ubench/atomic_scope.hip) and same-address ones one at a time: a
+// 25-entry state took 290 ms per 100 M rows through the per-row atomics.
 // kRuns: the rows are a run of blocks (agg_common.hpp BlockRunView in `pieces`; cols / filter unused).  A compile-time
 // flavour, not a run-time test: with both sources in one kernel the by-value column table has its address taken and moves
 // to scratch (136 bytes per lane, Q1 3.3 -> 4.9 ms per 600 M rows).
@@ -548,7 +553,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   KeyBox box;
   box.usable = false;
   // (the box is one of key FIELDS: a wide key's groups are numbered by position like a narrow key's)
-  if constexpr (kDir) box = key_box_of(*dir, c.num_keys);
+  if constexpr (kDir && !kDense) box = key_box_of(*dir, c.num_keys);
   // a run of blocks (agg_common.hpp BlockRunView): the tiles of all blocks, each block with its own stripes
   constexpr bool batched = kRuns;
   BlockRunView run{};
@@ -731,7 +736,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     // ---- group of every row ----------------------------------------------------
     unsigned long long code[V];
     key_codes_vec<kStatic, V, BLOCK>(c, tile, trow, code);
-    if (ranges > 1 && !by_piece) {
+    if (ranges > 1 && !by_piece && !(kDense && kDir)) {   // (a dense state in LDS splits by key range, below)
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         live[v] = live[v] && static_cast<int>((mix64(code[v]) >> 20) % static_cast<unsigned>(ranges)) == my_range;
@@ -781,7 +786,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     int dir_gid = -1;
     unsigned long long dir_words[kMaxKeyWords] = {};
     unsigned long long dir_inc[NS > 0 ? NS : 1];
-    if constexpr (kDense) {
+    if constexpr (kDense && !kDir) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         global_slot[v] = -1;
@@ -806,7 +811,22 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       slot[0] = S + lane_id();   // trash
       global_slot[0] = -1;
       dir_gid = -1;              // -2: to be looked up
-      if (live[0] && code[0] != kEmptyCode) {
+      if constexpr (kDense) {
+        // a dense state in LDS: the group number is the key value
+        // (ranges > 1: workgroup family r keeps entries [r S, (r + 1) S) and reads every row, like the hash-range families)
+        const long long loc = static_cast<long long>(tile_int(c, tile, c.key_column[0], trow));
+        const long long lo = static_cast<long long>(my_range) * S;
+        if (live[0]) {
+          if (loc < 0 || loc >= dense.num_entries) {
+            atomicExch(dense.error, 1);  // precondition min >= 0, max < num_entries violated
+            live[0] = false;
+          } else if (loc >= lo && loc < lo + S) {
+            dir_gid = (static_cast<int>(loc - lo) << rep_shift) + lane_col;   // (few entries: up to 64 copies, a lane adds into its own)
+          } else {
+            live[0] = false;             // another family's entry
+          }
+        }
+      } else if (live[0] && code[0] != kEmptyCode) {
         if (box.usable) {
           // group number = position in the key box of the build pass; a key outside the box (the build pass samples) has none
           unsigned int cell = 0;
@@ -838,7 +858,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     }
     const bool wave_has_global = __any(any_global);  // rare: groups that did not fit the LDS table
     if (can_flush && any_global) l_ctl[tile_count % 3] = 1;   // (benign race: everyone stores the same value)
-    if constexpr (kDense) {
+    if constexpr (kDense && !kDir) {
       // existence bit + row count of every run (CollisionFreeVectorTable.hpp:530-645)
 #pragma unroll
       for (int v = 0; v < V; ++v) {
@@ -963,7 +983,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
           if ((nullbits[v] & s.null_mask) != 0) inc[v] = static_cast<unsigned long long>(acc_identity(s.kind));
         }
       }
-      if constexpr (kDense) {
+      if constexpr (kDense && !kDir) {
         unsigned long long *col = dense.states + static_cast<unsigned long long>((dense.has_count ? 1 : 0) + j) * dense.num_entries;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -998,21 +1018,21 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       // every read of this tile is done; the home entry of the row's key is read BEFORE the next tile's DMA is issued —
       // loads return in order, so waiting for a lookup issued behind the DMA would wait for the tile as well
       DirProbe probe{};
-      if (dir_gid == -2) probe = dir_first_probe(*dir, code[0]);
+      if (!kDense && dir_gid == -2) probe = dir_first_probe(*dir, code[0]);
       if (nbuf == 1 && next < num_tiles) {
         __syncthreads();
         stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? carried.cols : cols, kRuns ? carried.filter : filter, tiles, carried.row0, carried.rows,
                                           nulls, &carried.bases);
       }
       int gid = dir_gid;
-      if (gid == -2) gid = c.wide_words != 0 ? dir_lookup_wide_from(*dir, code[0], dir_words, probe) : dir_lookup_from(*dir, code[0], probe);
+      if (!kDense && gid == -2) gid = c.wide_words != 0 ? dir_lookup_wide_from(*dir, code[0], dir_words, probe) : dir_lookup_from(*dir, code[0], probe);
       if (gid >= 0) {
         atomicAdd(&l_cnt[gid], 1u);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
           if (j < ns_lds) lds_add(&acc_plane_of(j)[gid], dir_inc[j], c.sums[j].kind);
         }
-      } else if (live[0]) {
+      } else if (!kDense && live[0]) {
         // no gid with an accumulator here (more groups than the directory was sized for, a group the build pass's sample
         // missed, the sentinel code): the global table, all accumulators — a wide key's hidden ones included
         const unsigned long long gs = global_find_or_insert(g, code[0]);
@@ -1024,8 +1044,39 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       }
     }
   }
-  if constexpr (kDense) return;
+  if constexpr (kDense && !kDir) return;
   __syncthreads();
+  if constexpr (kDense && kDir) {
+    // the workgroup's totals -> the dense arrays: existence bit, row count, one atomic per accumulator and entry it saw
+    const int rep = 1 << rep_shift;
+    const long long first_entry = static_cast<long long>(my_range) * S;   // (S is a multiple of 64 when there are several ranges)
+    for (int base_gid = 0; base_gid < S; base_gid += BLOCK) {
+      const int local = base_gid + static_cast<int>(threadIdx.x);
+      const long long gid = first_entry + local;
+      unsigned long long cnt = 0;
+      if (local < S && gid < dense.num_entries) {
+        for (int r = 0; r < rep; ++r) cnt += l_cnt[(local << rep_shift) + r];
+      }
+      // a wave's 64 entries are one existence word: one atomic per word and workgroup (an atomicOr per entry is 64 same-
+      // address atomics per word from each of 256 workgroups, all in a handful of memory channels: 1.8 ms for 8000 entries)
+      const unsigned long long seen = __ballot(cnt != 0);
+      if (lane_id() == 0 && seen != 0) {
+        unsigned long long *word = &dense.exist[gid >> 6];
+        if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & seen) != seen) atomicOr(word, seen);
+      }
+      if (cnt == 0) continue;
+      if (dense.has_count) atomicAdd(&dense.states[gid], cnt);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int kind = c.sums[j].kind;
+        const unsigned long long *p = acc_plane_of(j) + (local << rep_shift);
+        unsigned long long v = static_cast<unsigned long long>(acc_identity(kind));
+        for (int r = 0; r < rep; ++r) v = acc_combine(v, p[r], kind);
+        global_accumulate(dense.states + static_cast<unsigned long long>((dense.has_count ? 1 : 0) + j) * dense.num_entries + gid, v, kind);
+      }
+    }
+    return;
+  }
   if constexpr (kDirBuild) {
     if (dir->build_step == 1) {
       for (int i = threadIdx.x; i < S; i += BLOCK) {
@@ -1162,6 +1213,17 @@ __global__ __launch_bounds__(kABlock) void agg_dense_update_runs_kernel(DevConfi
                                                                        const long long *__restrict__ block_run) {
   agg_hash_update_body<false, true, NS, V, false, kABlock, false, true>(c, nullptr, nullptr, n, nullptr, HashTableView{}, d, 8, 0, nbuf, 1,
                                                                         block_run, nullptr);
+}
+
+// A dense state in LDS (kDense && kDir of the body): `entries` accumulators per aggregate x 2^rep_shift copies per workgroup;
+// `ranges` families of workgroups split a state of up to ranges x entries entries between them.
+template <int NS, bool kRuns>
+__global__ __launch_bounds__(1024) void agg_dense_lds_kernel(DevConfig c, int64_t n, const uint64_t *__restrict__ filter, DenseView d,
+                                                            int entries, int rep_shift, int nbuf, int ranges,
+                                                            const long long *__restrict__ block_run) {
+  agg_hash_update_body<false, true, NS, 1, true, 1024, false, kRuns>(c, kRuns ? nullptr : c.cols, kRuns ? nullptr : c.dicts, n,
+                                                                    kRuns ? nullptr : filter, HashTableView{}, d, entries, rep_shift, nbuf, ranges,
+                                                                    block_run, kRuns ? nullptr : c.nulls, nullptr);
 }
 
 // Group-directory variant (agg_common.hpp DirView): ONE workgroup of 1024 threads per CU owns the CU's LDS — `gids`

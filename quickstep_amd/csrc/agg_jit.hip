@@ -108,6 +108,19 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
   for (int i = 0; i < dev.num_columns; ++i) any_coded = any_coded || dev.code_width[i] != 0;
   o << kPrelude << kBundle << "\nnamespace qsx {\nconstexpr DevConfig jit_make_dev() {\n  DevConfig d{};\n"
     << emit_dev_config(dev) << "  return d;\n}\n";
+  if (geo.dir_gids != 0 && dense) {
+    // a dense state in LDS (agg_hash_update.hpp, kDense && kDir): the signature of the plain shapes, 1024 threads
+    o << "extern \"C\" __global__ __launch_bounds__(" << kDirBlock << ") void qsx_jit_agg(ColumnPointers cols,\n"
+      << "    const void *const *dicts, int64_t n, const uint64_t *filter, DenseView view,\n"
+      << "    int S, int rep_shift, int nbuf, int ranges, const long long *pieces) {\n"
+      << "  static constexpr DevConfig D = jit_make_dev();\n"
+      << "  (void)S; (void)rep_shift; (void)nbuf; (void)ranges; (void)cols;\n"
+      << "  agg_hash_update_body<true, true, " << num_sums << ", 1, true, " << kDirBlock << ", false, " << (geo.runs != 0 ? "true" : "false")
+      << ">(D, " << (geo.runs != 0 ? "nullptr" : "cols.p") << ", " << (any_coded ? "dicts" : "nullptr") << ", n, "
+      << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", HashTableView{}, view, " << geo.S << ", " << geo.rep_shift << ", " << geo.nbuf
+      << ", " << geo.ranges << ", pieces, nullptr, nullptr);\n}\n}  // namespace qsx\n";
+    return o.str();
+  }
   if (geo.dir_gids != 0) {
     // group-directory variant: the body of agg_dir_update_kernel with the configuration and the geometry as constants
     o << "extern \"C\" __global__ __launch_bounds__(" << kDirBlock << ") void qsx_jit_agg(ColumnPointers cols,\n"
@@ -362,7 +375,7 @@ int jit_request_state(JitRequest *r, const JitKernel **kernel) {
 
 int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
                    const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g,
-                   const DenseView &dense, bool is_dense, int S, int rep_shift, int nbuf, int ranges, const long long *pieces) {
+                   const DenseView &dense, bool is_dense, int S, int rep_shift, int nbuf, int ranges, const long long *pieces, int block) {
   ColumnPointers a_cols = cols;
   const void *const *a_dicts = dict_table_dev;
   int64_t a_n = n;
@@ -372,7 +385,7 @@ int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t s
   const long long *a_pieces = pieces;
   void *view = is_dense ? static_cast<void *>(&a_dense) : static_cast<void *>(&a_g);
   void *args[] = {&a_cols, &a_dicts, &a_n, &a_filter, view, &S, &rep_shift, &nbuf, &ranges, &a_pieces};
-  QSX_HIP_TRY(hipModuleLaunchKernel(k->function, static_cast<unsigned>(grid), 1, 1, kABlock, 1, 1,
+  QSX_HIP_TRY(hipModuleLaunchKernel(k->function, static_cast<unsigned>(grid), 1, 1, static_cast<unsigned>(block), 1, 1,
                                     static_cast<unsigned>(lds_bytes), stream, args, nullptr));
   return QSX_OK;
 }

@@ -40,7 +40,8 @@ int jit_request_state(JitRequest *request, const JitKernel **kernel);
 // Launches it: the argument list of agg_hash_update_body.
 int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
                    const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g,
-                   const DenseView &dense, bool is_dense, int S, int rep_shift, int nbuf, int ranges, const long long *pieces);
+                   const DenseView &dense, bool is_dense, int S, int rep_shift, int nbuf, int ranges, const long long *pieces,
+                   int block = kABlock);   // (1024 for a dense state in LDS: geometry.dir_gids != 0 of a dense state)
 
 // The group-directory variant (geometry.dir_gids != 0): the argument list of agg_dir_update_kernel.
 int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,

@@ -987,6 +987,39 @@ static size_t dir_lds_bytes(int tile_bytes, int temps_bytes, int num_sums, int g
   return static_cast<size_t>(nbuf) * tile_bytes + temps_bytes + static_cast<size_t>(gids + kWave) * (8 * static_cast<size_t>(num_sums) + 4) + 16;
 }
 
+// Dense states of few entries live in LDS during an update (agg_hash_update.hpp, kDense && kDir): entries != 0 when the
+// state qualifies, rep_shift = log2 of the copies per entry (few entries: same-address LDS atomics pile up otherwise).
+// QSX_AGG_DENSE_LDS=0: the per-row global atomics for every dense state.
+struct DenseLdsGeometry {
+  int entries;     // per workgroup (0: the state does not qualify)
+  int rep_shift;
+  int ranges;      // families of workgroups, each reading every row and keeping `entries` consecutive entries
+};
+static DenseLdsGeometry dense_lds_geometry(long long num_entries, int num_sums, size_t tile_and_temps_bytes) {
+  const char *e = getenv("QSX_AGG_DENSE_LDS");   // read per call: tests and tools compare the paths
+  // Up to 8 families: eight reads of the input (~0.45 ms per 100 M rows each) still beat 2 global atomics per row at 24 G/s
+  // (8.9 ms); beyond that they do not.  What a workgroup holds is what one tile buffer leaves of the CU's LDS.
+  constexpr long long kMaxRanges = 8;
+  const size_t per_entry = 8 * static_cast<size_t>(num_sums) + 4;
+  const size_t fixed = tile_and_temps_bytes + kWave * per_entry + 16;
+  if ((e != nullptr && e[0] == '0') || num_entries <= 0 || fixed + 64 * per_entry > 160 * 1024) return DenseLdsGeometry{0, 0, 1};
+  const long long capacity = static_cast<long long>((160 * 1024 - fixed) / per_entry / 64 * 64);
+  if (num_entries > capacity * kMaxRanges) return DenseLdsGeometry{0, 0, 1};
+  if (num_entries > capacity) {
+    const long long ranges = (num_entries + capacity - 1) / capacity;
+    const long long per = ((num_entries + ranges - 1) / ranges + 63) / 64 * 64;   // whole existence words per family
+    return DenseLdsGeometry{static_cast<int>(per), 0, static_cast<int>(ranges)};
+  }
+  int rep_shift = 0;
+  while (rep_shift < 6 && (num_entries << (rep_shift + 1)) <= 2048) ++rep_shift;
+  return DenseLdsGeometry{static_cast<int>(num_entries), rep_shift, 1};
+}
+// One 1024-thread workgroup per CU, a multiple of the families.
+static int dense_lds_grid(int64_t n, int ranges) {
+  int grid = dir_grid(n * ranges) / ranges * ranges;
+  return grid < ranges ? ranges : grid;
+}
+
 template <typename Shape>
 static int launch_shape_dir(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, const DirView &d, int gids,
                             int nbuf, hipStream_t stream) {
@@ -1214,9 +1247,22 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
       return nullptr;
     }
     DevConfig dev = st->dev;
-    plan_tile(dev, st->used_columns, directory ? kDirBlock : kABlock * kJitRowsPerThread, has_filter);
+    DenseLdsGeometry dense_lds{0, 0, 1};
+    if (st->dense) {
+      plan_tile(dev, st->used_columns, kDirBlock, has_filter);
+      dense_lds = dense_lds_geometry(st->config.num_entries, st->num_sums, static_cast<size_t>(dev.tile_bytes));
+    }
+    plan_tile(dev, st->used_columns, directory || dense_lds.entries != 0 ? kDirBlock : kABlock * kJitRowsPerThread, has_filter);
     st->jit_tile_bytes[v] = dev.tile_bytes;
-    if (directory) {
+    if (dense_lds.entries != 0) {
+      // a dense state in LDS (agg_hash_update.hpp, kDense && kDir): the directory kernels' geometry, S = entries
+      const int copies = dense_lds.entries << dense_lds.rep_shift;
+      int nbuf = 2;
+      size_t lds = dir_lds_bytes(dev.tile_bytes, 0, st->num_sums, copies, nbuf);
+      if (lds > 160 * 1024) lds = dir_lds_bytes(dev.tile_bytes, 0, st->num_sums, copies, nbuf = 1);
+      st->jit_geometry[v] = JitGeometry{dense_lds.entries, dense_lds.rep_shift, nbuf, dense_lds.ranges, copies, runs ? 1 : 0};
+      st->jit_lds[v] = lds;
+    } else if (directory) {
       st->jit_geometry[v] = JitGeometry{st->dir_gids, 0, st->dir_nbuf, 1, st->dir_gids};
       st->jit_lds[v] = dir_lds_bytes(dev.tile_bytes, 0, dir_plane_sums(dev), st->dir_gids, st->dir_nbuf);
     } else {
@@ -1266,6 +1312,8 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const 
   int grid = static_cast<int>(num_tiles * ranges < max_grid ? num_tiles * ranges : max_grid);
   grid = grid / ranges * ranges;
   if (grid < ranges) grid = ranges;
+  const bool dense_lds = st->dense && geo.dir_gids != 0;   // one 1024-thread workgroup per CU (state_jit_kernel)
+  if (dense_lds) grid = dense_lds_grid(n, ranges);
   if (getenv("QSX_DEBUG_LAUNCH") != nullptr) {
     std::fprintf(stderr, "[qsx] jit launch grid=%d lds=%zu S=%d rep_shift=%d nbuf=%d ranges=%d tile_bytes=%d n=%lld\n", grid, lds, S,
                  rep_shift, nbuf, ranges, tile_bytes, static_cast<long long>(n));
@@ -1283,7 +1331,8 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const 
     dict_table = slot->p;
   }
   const int rc = jit_agg_launch(k, grid, lds, stream, cp, dict_table, n, filter, st->dense ? HashTableView{} : st->hash_view(),
-                                st->dense ? st->dense_view() : DenseView{}, st->dense, S, rep_shift, nbuf, ranges, pieces);
+                                st->dense ? st->dense_view() : DenseView{}, st->dense, S, rep_shift, nbuf, ranges, pieces,
+                                dense_lds ? kDirBlock : kABlock);
   return rc;
 }
 
@@ -1324,6 +1373,39 @@ static int launch_hash(const DevConfig &dc, unsigned used_columns, int64_t n, co
 template <int NS>
 static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter, const DenseView &d,
                         hipStream_t stream, const long long *block_run = nullptr) {   // block_run: the rows are a run of blocks
+  {
+    // a state of few entries: accumulated in LDS, one workgroup per CU (agg_hash_update.hpp, kDense && kDir)
+    DevConfig lc = dc;
+    plan_tile(lc, used_columns, kDirBlock, filter != nullptr);
+    plan_interpreter(lc, kDirBlock);
+    const DenseLdsGeometry geo = dense_lds_geometry(d.num_entries, NS, static_cast<size_t>(lc.tile_bytes) + lc.temps_bytes);
+    constexpr size_t kMaxLds = 160 * 1024;
+    int nbuf = 2;
+    size_t lds = dir_lds_bytes(lc.tile_bytes, lc.temps_bytes, NS, geo.entries << geo.rep_shift, nbuf);
+    if (lds > kMaxLds) lds = dir_lds_bytes(lc.tile_bytes, lc.temps_bytes, NS, geo.entries << geo.rep_shift, nbuf = 1);
+    if (geo.entries != 0 && lds <= kMaxLds) {
+      static PerDeviceOnce lds_attribute_set;
+      const int rc = once_per_device(lds_attribute_set, [] {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dense_lds_kernel<NS, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+        if (err == hipSuccess) {
+          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dense_lds_kernel<NS, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+        }
+        return err;
+      });
+      if (rc != QSX_OK) return rc;
+      const int grid = dense_lds_grid(n, geo.ranges);
+      if (block_run != nullptr) {
+        hipLaunchKernelGGL((agg_dense_lds_kernel<NS, true>), dim3(grid), dim3(kDirBlock), lds, stream, lc, n, filter, d, geo.entries,
+                           geo.rep_shift, nbuf, geo.ranges, block_run);
+      } else {
+        hipLaunchKernelGGL((agg_dense_lds_kernel<NS, false>), dim3(grid), dim3(kDirBlock), lds, stream, lc, n, filter, d, geo.entries,
+                           geo.rep_shift, nbuf, geo.ranges, block_run);
+      }
+      return QSX_OK;
+    }
+  }
   constexpr int V = 4;
   constexpr int TR = kABlock * V;
   plan_tile(dc, used_columns, TR, filter != nullptr);

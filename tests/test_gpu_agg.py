@@ -235,6 +235,57 @@ def test_collision_free_vector(capi, oracle, dev, num_entries, partitions):
                     assert np.allclose(a, b, rtol=FP_RTOL, atol=0.0)
 
 
+@pytest.mark.parametrize("num_entries", [1, 5, 25, 640, 3000, 16_384, 16_385, 40_000, 65_536, 70_000])
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_small_collision_free_states_in_random_key_order(capi, oracle, dev, num_entries, lds, monkeypatch):
+    """Dense states of few entries are accumulated in LDS (one workgroup per CU, copies of every entry when there are very
+    few, up to eight key-range families of workgroups from 16 Ki entries on) instead of with one global atomic per row and aggregate — same results as the per-row path (QSX_AGG_DENSE_LDS=0)
+    and the oracle: random key order, SUM(double expression) + COUNT + SUM(int) + MIN + MAX, one stripe, several calls, a
+    run of ragged blocks with per-block filters, interpreter and run-time plan shape, a key outside the range."""
+    monkeypatch.setenv("QSX_AGG_DENSE_LDS", lds)
+    rng = np.random.default_rng(num_entries)
+    n = 300_000
+    key = rng.integers(0, num_entries, size=n).astype(np.int32)
+    if num_entries > 100:
+        key[key % 7 == 3] = 0                                 # some entries stay empty, one is hot
+    price = np.round(rng.uniform(900, 105000, size=n), 2)
+    disc = rng.integers(0, 11, size=n) / 100.0
+    qty = rng.integers(-50, 51, size=n).astype(np.int32)
+    layout = [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)]
+    aggs = [(T.AGG_SUM, T.temp(1)), (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(3)), (T.AGG_MIN, T.col(1)), (T.AGG_MAX, T.col(3))]
+    cfg = T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], instrs=[(T.EX_SUB, 0, T.const(0), T.col(2)), (T.EX_MUL, 1, T.col(1), T.temp(0))],
+                            consts=[1.0], aggs=aggs, num_entries=num_entries)
+    cols = [key, price, disc, qty]
+    o = oracle.AggState(cfg)
+    o.update(cols)
+    ref = o.finalize()
+    keep = rng.random(n) < 0.6
+    of = oracle.AggState(cfg)
+    of.update(cols, filter_bitmap=oracle.bitmap_from_bools(keep))
+    ref_filtered = of.finalize()
+    for jit in (False, True):
+        monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if jit else str(1 << 60))
+        for blocks in (1, 4):
+            assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols, blocks=blocks), dev), ref)
+        assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols, filter_bitmap=oracle.bitmap_from_bools(keep)), dev), ref_filtered)
+        # a run of ragged blocks (one empty), per-block filters with a gap
+        cuts = [0, 1000, 1000, 77_777, 200_001, n]
+        dcols = [to_dev(c, dev) for c in cols]
+        run = [[c[a:b] for c in dcols] for a, b in zip(cuts[:-1], cuts[1:])]
+        st = capi.AggState(cfg)
+        st.update_blocks(run)
+        assert_same_groups(finalize_np(st, dev), ref)
+        filters = [bitmap_dev(oracle.bitmap_from_bools(keep[a:b]), dev) if b > a else None for a, b in zip(cuts[:-1], cuts[1:])]
+        st = capi.AggState(cfg)
+        st.update_blocks(run, filters=filters)
+        assert_same_groups(finalize_np(st, dev), ref_filtered)
+    bad = key.copy()
+    bad[12345] = num_entries                                  # precondition violated: reported at finalize, as before
+    st = run_hip(capi, dev, cfg, [bad, price, disc, qty])
+    with pytest.raises(capi.QsxError):
+        st.finalize(dev, capacity=num_entries + 1)
+
+
 def test_merge_and_export_import(capi, oracle, dev):
     """Partial states of two 'GPUs' merged: mergeFrom semantics (ThreadPrivateCompactKeyHashTable.cpp:306-363)."""
     rng = np.random.default_rng(21)
