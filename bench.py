@@ -577,7 +577,7 @@ def run_c4(ctx, args):
     inputs = plans.generate_c4_inputs(dev, n_o, rank)
     n_l = inputs["l_orderkey"].numel()
     torch.cuda.synchronize()
-    pj = plans.PartitionedJoin(capi, n_o * world, n_o, dense=args.join_table == "dense")
+    pj = plans.PartitionedJoin(capi, n_o * world, n_o, dense=args.join_table == "dense", fused=not args.c4_unfused)
     recorded, results = [], {}
 
     def step(timed):
@@ -733,6 +733,7 @@ def operators_leg(args, raw_value):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--c4-unfused", action="store_true", help="config c4: pair list + K5 gathers instead of the projecting probe")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=["headline", "c4", "c5"], default="headline")
@@ -772,9 +773,17 @@ def main():
         raise SystemExit("libqsx.so sees no gfx950 device; there is no CPU path to benchmark")
     # QSX_BENCH_FORCE_DISTRIBUTED=1 runs the multi-GPU code path (RCCL shuffle + merge) even with one rank:
     # used to validate that path on the 1-GPU box (torch.distributed.run --nproc-per-node 1).
-    ctx.distributed = world > 1 or os.environ.get("QSX_BENCH_FORCE_DISTRIBUTED") == "1"
+    # (the partitioned configurations are written against a process group at any N: a plain `python bench.py --config c4`
+    # makes its own group of one rank)
+    ctx.distributed = world > 1 or os.environ.get("QSX_BENCH_FORCE_DISTRIBUTED") == "1" or args.config in ("c4", "c5")
     if ctx.distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1"})
         dist.init_process_group(backend="nccl", device_id=dev)
 
     line = {"headline": run_headline, "c4": run_c4, "c5": run_c5}[args.config](ctx, args)
@@ -791,10 +800,15 @@ def main():
             line["operators"]["fraction_of_raw_abi_with_output_relation"] = raw_ms / line["operators"]["ms_per_step"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "headline":
         line["cpu_baseline"] = cpu_baseline(args)
-    if rank == 0:
-        print(json.dumps(line))
+    # RCCL writes its version banner to the C library's stdout, which a pipe only sees when that buffer is flushed — at
+    # exit, behind anything Python printed.  The JSON line is the last thing this process writes: flush C stdio first.
     if ctx.distributed:
         dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -250,6 +250,32 @@ class PartitionedHashJoin:
             out_p, out_b, count = self.table.probe(rkeys, capacity=capacity)
         return rtids, self.build_tids, out_p, out_b, count
 
+    def probe_output(self, keys, tid_base, payload=()):
+        """probe() + materialize_payload() in one pass where the table offers it (qsx_join_probe_project_blocks: the probe
+        writes (join key, build payload columns..., probe payload columns...) itself — no pair list, no gathers); the pair
+        list and K5 gathers otherwise (the CPU checker of the gloo tests)."""
+        if not hasattr(self.table, "probe_project_blocks"):
+            _, _, out_p, out_b, count = self.probe(keys, tid_base, capacity=0, payload=payload)
+            return self.materialize_payload(out_p, out_b, count)
+        tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
+        received, _ = shuffle_by_key(self.ops, keys, [keys, tids, *payload], self.group)
+        rkeys = received[0]
+        self.probe_keys = rkeys
+        self.probe_payload = received[2:]
+        self.shuffled_bytes += sum(c.numel() * c.element_size() for c in received)
+        with phases.phase("probe"):
+            room = max(rkeys.numel(), 1)
+            for _ in range(2):
+                outs, count = self.table.probe_project_blocks([rkeys], [[rkeys]] + [[c] for c in self.probe_payload],
+                                                              [[c] for c in self.build_payload], capacity=room)
+                k = int(count.item())
+                if k <= room:
+                    break
+                room = k                    # duplicate build keys: once more with the exact capacity
+        npay = len(self.probe_payload)
+        cols = [outs[0]] + outs[1 + npay:] + outs[1:1 + npay]
+        return [c[:k] for c in cols]
+
     def materialize_payload(self, out_p, out_b, count):
         """The join's output relation on this rank: (join key, build payload columns..., probe payload columns...) of
         every pair — K5 gathers on the columns that arrived with the shuffle (HashJoinOperator.cpp:526-541 builds the

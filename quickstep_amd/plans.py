@@ -52,8 +52,10 @@ class PartitionedJoin:
     """BASELINE config 4.  step() = shuffle both sides on the join key, build, probe, materialise
     (key, o_payload, l_payload) for every pair of this rank's partition."""
 
-    def __init__(self, ops, orders_total, est_orders_per_rank, group=None, dense=True):
-        self.ops, self.group = ops, group
+    def __init__(self, ops, orders_total, est_orders_per_rank, group=None, dense=True, fused=True):
+        """fused: the probe writes the output relation itself (PartitionedHashJoin.probe_output) instead of a pair list that
+        K5 gathers materialise."""
+        self.ops, self.group, self.fused = ops, group, fused
         self.join = qd.PartitionedHashJoin(ops, T.INT, est_orders_per_rank, group=group,
                                            key_domain=(1, orders_total) if dense else None)
 
@@ -62,8 +64,11 @@ class PartitionedJoin:
         j.build(inputs["o_orderkey"], tid_base_orders, payload=[inputs["o_payload"]])
         # a lineitem row has exactly one order: the rows that arrive bound the pairs; how many arrive is only known
         # after the counts exchange, so the capacity is left to probe() (rows received)
-        _, _, out_p, out_b, count = j.probe(inputs["l_orderkey"], tid_base_lines, capacity=0, payload=[inputs["l_payload"]])
-        cols = j.materialize_payload(out_p, out_b, count)
+        if self.fused:
+            cols = j.probe_output(inputs["l_orderkey"], tid_base_lines, payload=[inputs["l_payload"]])
+        else:
+            _, _, out_p, out_b, count = j.probe(inputs["l_orderkey"], tid_base_lines, capacity=0, payload=[inputs["l_payload"]])
+            cols = j.materialize_payload(out_p, out_b, count)
         return cols, j.shuffled_bytes
 
     @staticmethod
