@@ -131,6 +131,11 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
       << ", view, DenseView{}, " << geo.dir_gids << ", 0, " << geo.nbuf << ", 1, nullptr, nullptr, &d);\n}\n}  // namespace qsx\n";
     return o.str();
   }
+  // the run-of-blocks flavour of the body takes the same signature (the table arrives as `pieces`) and its stripes from the
+  // table: its template arguments are emitted here, not patched into the text afterwards
+  std::ostringstream body_args;
+  body_args << "true, " << (dense ? "true" : "false") << ", " << num_sums << ", " << kJitRowsPerThread;
+  if (geo.runs != 0) body_args << ", false, " << kABlock << ", false, true";
   o
     // explicit arguments are kept under 256 bytes (one view, the dictionaries behind a pointer): with the 256 hidden
     // bytes a kernarg segment beyond 512 bytes made the same code 2.4x slower (3.5 -> 8.3 ms, Q1 over 600 M rows)
@@ -139,22 +144,11 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
     << "    int S, int rep_shift, int nbuf, int ranges, const long long *pieces) {\n"
     << "  static constexpr DevConfig D = jit_make_dev();\n"
     // the geometry arguments stay in the signature (one launch path for every shape) but the body gets the constants
-    << "  (void)S; (void)rep_shift; (void)nbuf; (void)ranges;\n"
-    << "  agg_hash_update_body<true, " << (dense ? "true" : "false") << ", " << num_sums << ", " << kJitRowsPerThread
-    << ">(D, cols.p, " << (any_coded ? "dicts" : "nullptr") << ", n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", "
+    << "  (void)S; (void)rep_shift; (void)nbuf; (void)ranges; (void)cols;\n"
+    << "  agg_hash_update_body<" << body_args.str() << ">(D, " << (geo.runs != 0 ? "nullptr" : "cols.p") << ", "
+    << (any_coded ? "dicts" : "nullptr") << ", n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", "
     << (dense ? "HashTableView{}, view" : "view, DenseView{}")
     << ", " << geo.S << ", " << geo.rep_shift << ", " << geo.nbuf << ", " << geo.ranges << ", pieces);\n}\n}  // namespace qsx\n";
-  if (geo.runs != 0) {
-    // the run-of-blocks flavour of the body: same signature (the table arrives as `pieces`), stripes from the table
-    std::string src = o.str();
-    const std::string from = "agg_hash_update_body<true, " + std::string(dense ? "true" : "false") + ", " + std::to_string(num_sums) + ", " +
-                             std::to_string(kJitRowsPerThread) + ">(D, cols.p, ";
-    const std::string to = "agg_hash_update_body<true, " + std::string(dense ? "true" : "false") + ", " + std::to_string(num_sums) + ", " +
-                           std::to_string(kJitRowsPerThread) + ", false, " + std::to_string(kABlock) + ", false, true>(D, nullptr, ";
-    const size_t at = src.find(from);
-    if (at != std::string::npos) src.replace(at, from.size(), to);
-    return src;
-  }
   return o.str();
 }
 
@@ -414,10 +408,14 @@ extern "C" int qsx_debug_jit_compile(const qsx_agg_config_t *config, int with_fi
   Translated t = translate(*config);
   if (t.status != QSX_OK) return t.status;
   const bool directory = (with_filter & 2) != 0 && !t.dense;   // bit 1: the group-directory variant
+  const bool runs = (with_filter & 4) != 0;                    // bit 2: the run-of-blocks flavour
+  const bool dense_lds = (with_filter & 8) != 0 && t.dense;    // bit 3: a dense state in LDS
   with_filter &= 1;
-  plan_tile(t.dev, t.used_columns, directory ? kDirBlock : kABlock * kJitRowsPerThread, with_filter != 0);
+  plan_tile(t.dev, t.used_columns, directory || dense_lds ? kDirBlock : kABlock * kJitRowsPerThread, with_filter != 0);
   // a plausible geometry: this hook only checks that the shape compiles
-  const JitGeometry geometry = directory ? JitGeometry{4096, 0, 2, 1, 4096} : JitGeometry{t.dense ? 8 : 16, t.dense ? 0 : 4, 1, 1, 0};
+  JitGeometry geometry = directory ? JitGeometry{4096, 0, 2, 1, 4096, 0} : JitGeometry{t.dense ? 8 : 16, t.dense ? 0 : 4, 1, 1, 0, 0};
+  if (dense_lds) geometry = JitGeometry{4096, 0, 2, 2, 4096, 0};
+  geometry.runs = runs && !directory ? 1 : 0;
   const std::string source = jit_agg_source(t.dev, t.num_sums, t.dense, geometry);
   if (const char *dump = getenv("QSX_JIT_DUMP")) {   // the generated translation unit, for offline inspection with hipcc -S
     if (FILE *f = std::fopen(dump, "w")) {

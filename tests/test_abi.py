@@ -87,6 +87,36 @@ def test_run_time_plan_shape_generator_compiles_without_a_gpu(capi):
         assert size.value > 1000
 
 
+def test_plan_shape_flavours_have_sources_of_their_own(capi, tmp_path, monkeypatch):
+    """The run-of-blocks flavour and the dense-state-in-LDS flavour of a plan shape are generated as such (template
+    arguments emitted, not patched into the text): every flavour compiles and its translation unit differs from the plain
+    one's — a run flavour that silently came out as the single-stripe kernel would read past the first block."""
+    import ctypes as C
+    from quickstep_amd import types as T
+    fn = capi.lib.qsx_debug_jit_compile
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(T.AggConfig), C.c_int, C.POINTER(C.c_size_t)]
+    layout = [(T.INT, None), (T.DOUBLE, None)]
+    aggs = [(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None)]
+    sources = {}
+    for name, cfg, bits in (("hash", T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], aggs=aggs), 0),
+                            ("hash_runs", T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], aggs=aggs), 4),
+                            ("dense", T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], aggs=aggs, num_entries=5000), 0),
+                            ("dense_runs", T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], aggs=aggs, num_entries=5000), 4),
+                            ("dense_lds", T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], aggs=aggs, num_entries=5000), 8),
+                            ("dense_lds_runs", T.make_agg_config(T.AGG_COLLISION_FREE, layout, keys=[0], aggs=aggs, num_entries=5000), 12)):
+        dump = tmp_path / f"{name}.hip"
+        monkeypatch.setenv("QSX_JIT_DUMP", str(dump))
+        size = C.c_size_t(0)
+        assert fn(C.byref(cfg), bits, C.byref(size)) == 0 and size.value > 1000
+        sources[name] = dump.read_text()
+    assert len(set(sources.values())) == len(sources)
+    tail = lambda text: text[text.rindex("agg_hash_update_body<"):]   # noqa: E731
+    assert "false, true>(D, nullptr" in tail(sources["hash_runs"]) and "false, true>(D, nullptr" in tail(sources["dense_runs"])
+    assert "true>(D, nullptr" in tail(sources["dense_lds_runs"]) and "(D, cols.p" in tail(sources["dense_lds"])
+    assert "(D, cols.p" in tail(sources["hash"]) and "(D, cols.p" in tail(sources["dense"])
+
+
 def test_plan_shape_code_objects_are_kept_in_the_cache_directory(capi, tmp_path, monkeypatch):
     """QSX_JIT_CACHE_DIR: the first build of a plan shape leaves one file there (source text + code object), the second
     takes the code object from it (same bytes, no compile); a damaged or foreign file is ignored and replaced."""
