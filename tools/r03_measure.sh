@@ -3,15 +3,18 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r03m
 mkdir -p $out
-timeout 2400 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; tail -5 $out/pytest_gpu.log
-timeout 900 python bench.py --steps 25 --warmup 5 > $out/bench_headline.json 2> $out/bench_headline.err; tail -c 600 $out/bench_headline.json; tail -3 $out/bench_headline.err
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -E " passed| failed|rror" | tail -5 > $out/pytest_gpu.log; cat $out/pytest_gpu.log
+timeout 900 python bench.py --steps 25 --warmup 5 2> $out/bench_headline.err | tail -1 > $out/bench_headline.json; tail -c 400 $out/bench_headline.json; tail -2 $out/bench_headline.err
 for cfg in c4 c5; do
-  QSX_BENCH_FORCE_DISTRIBUTED=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --config $cfg > $out/bench_$cfg.json 2> $out/bench_$cfg.err; tail -c 400 $out/bench_$cfg.json
+  timeout 600 python bench.py --steps 5 --warmup 2 --config $cfg 2> $out/bench_$cfg.err | tail -1 > $out/bench_$cfg.json; tail -c 300 $out/bench_$cfg.json
 done
-QSX_BENCH_FORCE_DISTRIBUTED=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_headline_dist1.json 2> $out/bench_headline_dist1.err; tail -c 300 $out/bench_headline_dist1.json
+QSX_BENCH_FORCE_DISTRIBUTED=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline 2> $out/bench_headline_dist1.err | tail -1 > $out/bench_headline_dist1.json; tail -c 300 $out/bench_headline_dist1.json
 rocprofv3 --kernel-trace --stats -d $out/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-operators > $out/bench_traced.json 2> $out/bench_traced.err
-python3 tools/rocpd_kernel_stats.py "$(find $out/trace -name '*.db' | head -1)" > $out/kernel_stats.txt 2>&1; head -25 $out/kernel_stats.txt
+python3 tools/rocpd_kernel_stats.py "$(find $out/trace -name '*.db' | head -1)" > $out/kernel_stats.txt 2>&1; head -12 $out/kernel_stats.txt
 rm -rf $out/trace
 tools/prof_pmc.sh $out/pmc --no-operators > /dev/null 2>&1
-python3 tools/pmc_summary.py $out/pmc agg_hash dense_probe probe_kernel dense_build build_kernel gather_kernel > $out/pmc_summary.txt 2>&1; head -120 $out/pmc_summary.txt
+python3 tools/pmc_summary.py $out/pmc agg_hash dense_probe probe_kernel dense_build build_kernel gather_kernel cover_probe > $out/pmc_summary.txt 2>&1; grep -A 3 "agg_hash_shape_fixed" $out/pmc_summary.txt | head -8
 find $out/pmc -name '*.csv' -size +1M -delete; find $out/pmc -name '*.db' -delete
+QSX_TEST_PROFILE=1 tests/cpp/bin/headline_operators_bench 1000000 100000000 600000000 25 5 8 256 > $out/operators_profile.txt 2>&1; tail -9 $out/operators_profile.txt | cut -c 1-200
+for t in agg_wide agg_dense_small probe_project; do timeout 300 python tools/$t.py > $out/$t.jsonl 2>/dev/null; done
+timeout 300 python tools/bench_ops.py > $out/bench_ops.jsonl 2>/dev/null; wc -l $out/*.jsonl
