@@ -1562,12 +1562,16 @@ int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const
     }
   }
   if (seg_rows <= 0 || seg_rows > INT32_MAX) seg_rows = 0;
+  const int key_width = direct->key_type == QSX_INT ? 4 : 8;
+  for (int c = 0; c < nc; ++c) table[static_cast<size_t>(4 * nc + c)] = proj->on_build[c] == 0 && proj->width[c] == key_width && num_blocks > 0 ? 1 : 0;
   for (int64_t b = 0; b < num_blocks; ++b) {
     for (int c = 0; c < nc; ++c) {
       if (proj->on_build[c] == 0) {
         const void *stripe = proj->probe_stripes[static_cast<size_t>(b) * nc + c];
         if (stripe == nullptr && block_rows[b] > 0) return QSX_ERR_INVALID_ARGUMENT;
         table[head_words + nseg + static_cast<size_t>(nseg) * nc + static_cast<size_t>(b) * nc + c] = word_of(stripe);
+        // the probe key itself (SELECT ... the join attribute): every block's stripe of the column is its key stripe
+        if (block_rows[b] > 0 && stripe != block_keys[b]) table[static_cast<size_t>(4 * nc + c)] = 0;
       }
     }
   }
@@ -1588,8 +1592,10 @@ int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const
   const uint64_t *filter_mark = any_filter ? reinterpret_cast<const uint64_t *>(runs_dev) : nullptr;   // only tested against NULL
   unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count_dev);
   const DenseTableView dv = direct->dense_view();
-  constexpr int kCoverBlock = 1024;
-  const int cgrid = static_cast<int>(tiles < 2 * kCUs ? tiles : 2 * kCUs);
+  // 512 threads x 8 rows per tile: measured 0.72 ms per 100 M rows (int key + int attribute) against 0.87 at 1024 x 4 and
+  // 0.85 at 256 x 16 (tools/probe_project.py)
+  constexpr int kCoverBlock = 512;
+  const int cgrid = static_cast<int>(tiles < 4 * kCUs ? tiles : 4 * kCUs);
   auto by_entry = [&](auto key_tag) {
     using KeyT = decltype(key_tag);
     switch (cover_entry) {

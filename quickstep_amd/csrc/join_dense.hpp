@@ -167,14 +167,15 @@ __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, 
 // and stores them at the output position it would have stored the pair at.  The pair list (8 bytes written and read
 // again per match) and one kernel per attribute go away.
 // Device table (8-byte words), kProjColumnWords arrays of nc words first: width | on_build | output stripe | byte offset of the
-// column inside an entry of the covering array (build-side columns, when there is one); then first tuple id of build segment
+// column inside an entry of the covering array (build-side columns, when there is one) | 1 when the column is the probe key
+// itself (its stripe in every block is the block's key stripe: the value is in a register already); then first tuple id of build segment
 // s [nseg] | stripe of column c in build segment s [s * nc + c] | stripe of column c in probe block b [b * nc + c].
 //
 // Covering array (MODE 6 / 7 / 8: entries of 4 / 8 / 16 bytes): the projected build-side values of the tuple under key value
 // k, packed into one entry at cover[k - min_key]; all bits set = no tuple.  Built once per (table, projection) by
 // cover_build_kernel when the build keys are unique; the probe then reads ONE random entry per row — not head[] and then the
 // attribute stripes: both together (3 + 4 MiB for a million keys and one INT attribute) do not share an XCD's L2.
-constexpr int kProjColumnWords = 4;
+constexpr int kProjColumnWords = 5;
 struct ProjectionView {
   const long long *table;
   int nc;
@@ -185,6 +186,7 @@ struct ProjectionView {
   __device__ __forceinline__ bool on_build(int c) const { return table[nc + c] != 0; }
   __device__ __forceinline__ char *out(int c) const { return as_global(reinterpret_cast<char *>(table[2 * nc + c])); }
   __device__ __forceinline__ int cover_offset(int c) const { return static_cast<int>(table[3 * nc + c]); }
+  __device__ __forceinline__ bool is_probe_key(int c) const { return table[4 * nc + c] != 0; }
   __device__ __forceinline__ const long long *first_tids() const { return table + kProjColumnWords * nc; }
   __device__ __forceinline__ const char *build_stripe(int seg, int c) const {
     return as_global(reinterpret_cast<const char *>(table[kProjColumnWords * nc + nseg + seg * nc + c]));
@@ -593,9 +595,9 @@ __global__ __launch_bounds__(kDBlock) __attribute__((amdgpu_waves_per_eu(MODE ==
 // Probe + projection through the covering array (ProjectionView::cover), over a run of probe blocks: one random read per
 // probe row brings the match AND the build-side values.  Tiles, reservation (one atomic on the output counter per tile) and
 // output order as dense_probe_kernel MODE 0; unique build keys by construction (cover_build_kernel), so no chains.
-// BLOCK threads take a tile of kDenseTile rows, kDenseTile / BLOCK rows per thread: 512 x 8 instead of the pair kernel's 256 x 16 —
-// the entries and values of 16 rows per thread cost 180 registers, i.e. two workgroups per CU and most of a tile's four memory
-// round trips exposed.
+// BLOCK threads take a tile of kDenseTile rows, kDenseTile / BLOCK rows per thread: launched as 512 x 8 instead of the pair
+// kernel's 256 x 16 — the entries and values of 16 rows per thread cost 180 registers, i.e. two workgroups per CU and most of a
+// tile's dependent memory round trips exposed.
 template <typename KeyT, typename CoverT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void cover_probe_kernel(DenseTableView t, int64_t capacity_signed,
                                                              unsigned long long *__restrict__ out_count,
@@ -617,8 +619,8 @@ __global__ __launch_bounds__(BLOCK) void cover_probe_kernel(DenseTableView t, in
       if (w < ((src.n + 63) >> 6)) filter_words = load_global(&src.filter[w]);
     }
     CoverT e[R];
+    KeyT key[R];   // (kept for projected columns that ARE the probe key)
     {
-      KeyT key[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int64_t row = src.base + r * BLOCK + threadIdx.x;
@@ -681,6 +683,7 @@ __global__ __launch_bounds__(BLOCK) void cover_probe_kernel(DenseTableView t, in
       const int width = proj.width(c);
       const bool on_build = proj.on_build(c);
       const int shift = 8 * proj.cover_offset(c);
+      const bool from_key = proj.is_probe_key(c);   // (host: only for columns as wide as the key)
       auto column = [&](auto tag) __attribute__((always_inline)) {
         using V = decltype(tag);
         constexpr int H = R / 2;
@@ -700,6 +703,8 @@ __global__ __launch_bounds__(BLOCK) void cover_probe_kernel(DenseTableView t, in
               } else {
                 v[i] = static_cast<V>(static_cast<unsigned long long>(e[r]) >> shift);
               }
+            } else if (from_key && sizeof(V) == sizeof(KeyT)) {
+              v[i] = static_cast<V>(key[r]);
             } else {
               const int in_tile = r * BLOCK + static_cast<int>(threadIdx.x);
               v[i] = load_global_nt(&tile_src[in_tile < tile_rows ? in_tile : tile_rows - 1]);   // (a stream: keep it out of the covering array's L2)
