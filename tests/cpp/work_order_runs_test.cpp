@@ -196,6 +196,72 @@ Rows runJoin(bool exact_stats, std::size_t blocks_per_order, std::size_t *out_bl
   return got;
 }
 
+// The same join with every order THREE times in the build relation: three matches per probe tuple, i.e. more output tuples than
+// the projecting probe has room for (one per probe tuple) — the work order must notice (count > room), drop the block it
+// started and produce the result through the pair list.
+void runJoinDuplicateBuildKeys(bool exact_stats, std::size_t blocks_per_order) {
+  StorageManager storage;
+  Lineitem li(&storage, false);
+  CatalogRelation orders(3, "orders");
+  orders.addAttribute("o_orderkey", Type::Int());
+  orders.addAttribute("o_copy", Type::Long());
+  std::vector<std::int32_t> okeys;
+  std::vector<std::int64_t> copies;
+  for (std::int32_t copy = 0; copy < 3; ++copy) {
+    for (std::int32_t k = 0; k < 200000; k += 2) {
+      okeys.push_back(k);
+      copies.push_back(static_cast<std::int64_t>(k) * 10 + copy);
+    }
+  }
+  std::vector<std::size_t> order(okeys.size());
+  for (std::size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::shuffle(order.begin(), order.end(), std::mt19937_64(11));
+  std::vector<std::int32_t> k2(okeys.size());
+  std::vector<std::int64_t> c2(okeys.size());
+  for (std::size_t i = 0; i < order.size(); ++i) {
+    k2[i] = okeys[order[i]];
+    c2[i] = copies[order[i]];
+  }
+  for (std::size_t at = 0; at < k2.size(); at += 7500) storage.loadBlock(&orders, {k2.data() + at, c2.data() + at}, 7500);
+  CatalogRelation out(4, "joined");
+  out.addAttribute("o_copy", Type::Long());
+  out.addAttribute("l_extendedprice", Type::Double());
+  QueryContext ctx;
+  const QueryContext::ExactKeyRange range{0, 199998};
+  const auto table = ctx.addJoinHashTable(kInt, 300000, 1, exact_stats ? &range : nullptr);
+  const auto dest = ctx.addInsertDestination(&out, &storage);
+  const auto selection = ctx.addScalarGroup({1, 2});
+  const std::vector<bool> on_build = {true, false};
+  BuildHashOperator builder(0, orders, true, {0}, false, 1, table);
+  HashJoinOperator prober(0, orders, li.rel, true, {0}, false, 1, false, out, dest, table, QueryContext::kInvalidPredicateId, selection,
+                          &on_build, HashJoinOperator::JoinType::kInnerJoin);
+  prober.setBlocksPerWorkOrder(blocks_per_order);
+  builder.setBlocksPerWorkOrder(blocks_per_order);
+  fetchAndExecuteWorkOrders(&builder, &ctx, &storage);
+  fetchAndExecuteWorkOrders(&prober, &ctx, &storage);
+  std::vector<std::pair<std::int64_t, double>> g, w;
+  for (block_id b : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+    BlockReference blk = storage.getBlock(b);
+    const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+    if (k == 0) continue;
+    std::vector<std::int64_t> copy(k);
+    std::vector<double> price(k);
+    blk->copyAttributeToHost(0, copy.data());
+    blk->copyAttributeToHost(1, price.data());
+    for (std::size_t i = 0; i < k; ++i) g.emplace_back(copy[i], price[i]);
+  }
+  for (std::size_t i = 0; i < li.orderkey.size(); ++i) {
+    if (li.orderkey[i] < 200000 && (li.orderkey[i] & 1) == 0) {
+      for (int copy = 0; copy < 3; ++copy) w.emplace_back(static_cast<std::int64_t>(li.orderkey[i]) * 10 + copy, li.price[i]);
+    }
+  }
+  std::sort(g.begin(), g.end());
+  std::sort(w.begin(), w.end());
+  EXPECT_TRUE(w.size() > 100000);
+  EXPECT_EQ(g.size(), w.size());
+  EXPECT_TRUE(g == w);
+}
+
 // select o_orderkey, l_extendedprice, o_flag from orders join lineitem on o_orderkey = l_orderkey where o_flag = 'KEEP':
 // a CHAR(10) attribute of the build side in the residual predicate (compared on the pair list by qsx_select_cmp_char) and in
 // the projection (gathered byte by byte) — the run form and the block-by-block form
@@ -380,6 +446,11 @@ int main() {
   EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
   std::printf("hash join under a LIP filter: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n", ms_one, ms_run);
   runTypedExpressions();
+  // duplicate build keys: the projecting probe overflows its block and the work order falls back to the pair list
+  for (bool exact_stats : {true, false}) {
+    runJoinDuplicateBuildKeys(exact_stats, 1);
+    runJoinDuplicateBuildKeys(exact_stats, 64);
+  }
   // a CHAR(10) build attribute in the residual predicate and in the projection: both forms
   runJoinCharResidual(1, &blocks_one);
   runJoinCharResidual(64, &blocks_run);
