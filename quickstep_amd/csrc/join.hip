@@ -1491,14 +1491,16 @@ int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const
     int32_t *pairs = nullptr;
     QSX_HIP_TRY(device_malloc(reinterpret_cast<void **>(&pairs), static_cast<size_t>(capacity) * 8 + 16));
     int32_t *probe_tids = pairs, *build_tids = pairs + capacity;
-    // slots no pair reaches gather tuple 0 of their side (the caller reads *out_count tuples; the rest is unspecified)
-    hipError_t err = hipMemsetAsync(probe_tids, 0, static_cast<size_t>(capacity) * 4, s);
-    const int first_build = proj->num_build_segments > 0 ? static_cast<int>(proj->build_first_tids[0]) : 0;
-    if (err == hipSuccess) err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(build_tids), first_build, static_cast<size_t>(capacity), s);
-    int rc = err == hipSuccess ? QSX_OK : QSX_ERR_HIP;
-    if (rc == QSX_OK) {
-      rc = qsx_join_probe_blocks(t, num_blocks, block_rows, block_keys, nullptr, block_filters, probe_tids, build_tids, capacity, out_count_dev, stream);
+    int rc = qsx_join_probe_blocks(t, num_blocks, block_rows, block_keys, nullptr, block_filters, probe_tids, build_tids, capacity,
+                                   out_count_dev, stream);
+    // how many pairs there are to gather (this path synchronises anyway: the pair list is released before it returns)
+    int64_t pairs_found = 0;
+    if (rc == QSX_OK && (hipMemcpyAsync(&pairs_found, out_count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                         hipStreamSynchronize(s) != hipSuccess)) {
+      (void)hipGetLastError();
+      rc = QSX_ERR_HIP;
     }
+    const int64_t gathered = pairs_found < capacity ? pairs_found : capacity;
     std::vector<int64_t> probe_first(static_cast<size_t>(num_blocks));
     std::vector<const void *> segs;
     int64_t at = 0;
@@ -1506,11 +1508,9 @@ int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const
       probe_first[static_cast<size_t>(b)] = at;
       at += block_rows[b];
     }
-    const int64_t gathered = capacity;
-    for (int c = 0; c < nc && rc == QSX_OK; ++c) {
+    for (int c = 0; c < nc && rc == QSX_OK && gathered > 0; ++c) {
       segs.clear();
       if (proj->on_build[c] != 0) {
-        if (proj->num_build_segments == 0) continue;   // an empty build side: nothing matched
         for (int sg = 0; sg < proj->num_build_segments; ++sg) segs.push_back(proj->build_stripes[static_cast<size_t>(sg) * nc + c]);
         rc = qsx_gather_segmented(proj->width[c], proj->num_build_segments, segs.data(), proj->build_first_tids, build_tids, gathered,
                                   proj->out_columns[c], stream);
