@@ -530,6 +530,15 @@ __global__ __launch_bounds__(kABlock) void mark_existence_kernel(const KeyT *__r
   }
 }
 
+// How clustered on the key do the rows arrive?  Counts key[i] == key[i - 1] over the first rows of an input.
+template <typename KeyT>
+__global__ __launch_bounds__(1024) void adjacent_equal_kernel(const KeyT *__restrict__ keys, int rows, unsigned int *__restrict__ out) {
+  unsigned int equal = 0;
+  for (int i = 1 + static_cast<int>(threadIdx.x); i < rows; i += 1024) equal += keys[i] == keys[i - 1] ? 1u : 0u;
+  equal = static_cast<unsigned int>(wave_reduce_add(static_cast<unsigned long long>(equal)));
+  if (lane_id() == 0 && equal != 0) atomicAdd(out, equal);
+}
+
 struct DictTable {
   const void *p[QSX_MAX_COLUMNS];
 };
@@ -585,6 +594,10 @@ struct qsx_agg_state {
   bool has_min_max = false;  // some state column needs a non-zero identity
   bool dense = false;
   bool dense_has_count = false;
+  // A dense state too large for one workgroup's LDS: 0 = not decided, 1 = key-range families of workgroups in LDS (every
+  // family reads every row), 2 = one global atomic per run of equal adjacent keys — decided once, from how clustered the
+  // first rows the state sees are (decide_dense_families).
+  std::atomic<int> dense_families{0};
 
   // one allocation: the image
   unsigned long long *image = nullptr;
@@ -995,7 +1008,7 @@ struct DenseLdsGeometry {
   int rep_shift;
   int ranges;      // families of workgroups, each reading every row and keeping `entries` consecutive entries
 };
-static DenseLdsGeometry dense_lds_geometry(long long num_entries, int num_sums, size_t tile_and_temps_bytes) {
+static DenseLdsGeometry dense_lds_geometry(long long num_entries, int num_sums, size_t tile_and_temps_bytes, bool allow_families) {
   const char *e = getenv("QSX_AGG_DENSE_LDS");   // read per call: tests and tools compare the paths
   // Up to 8 families: eight reads of the input (~0.45 ms per 100 M rows each) still beat 2 global atomics per row at 24 G/s
   // (8.9 ms); beyond that they do not.  What a workgroup holds is what one tile buffer leaves of the CU's LDS.
@@ -1006,6 +1019,8 @@ static DenseLdsGeometry dense_lds_geometry(long long num_entries, int num_sums, 
   const long long capacity = static_cast<long long>((160 * 1024 - fixed) / per_entry / 64 * 64);
   if (num_entries > capacity * kMaxRanges) return DenseLdsGeometry{0, 0, 1};
   if (num_entries > capacity) {
+    // (several reads of the input only pay when the rows do not come clustered on the key: decide_dense_families)
+    if (!allow_families) return DenseLdsGeometry{0, 0, 1};
     const long long ranges = (num_entries + capacity - 1) / capacity;
     const long long per = ((num_entries + ranges - 1) / ranges + 63) / 64 * 64;   // whole existence words per family
     return DenseLdsGeometry{static_cast<int>(per), 0, static_cast<int>(ranges)};
@@ -1250,7 +1265,7 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
     DenseLdsGeometry dense_lds{0, 0, 1};
     if (st->dense) {
       plan_tile(dev, st->used_columns, kDirBlock, has_filter);
-      dense_lds = dense_lds_geometry(st->config.num_entries, st->num_sums, static_cast<size_t>(dev.tile_bytes));
+      dense_lds = dense_lds_geometry(st->config.num_entries, st->num_sums, static_cast<size_t>(dev.tile_bytes), st->dense_families.load() == 1);
     }
     plan_tile(dev, st->used_columns, directory || dense_lds.entries != 0 ? kDirBlock : kABlock * kJitRowsPerThread, has_filter);
     st->jit_tile_bytes[v] = dev.tile_bytes;
@@ -1372,13 +1387,13 @@ static int launch_hash(const DevConfig &dc, unsigned used_columns, int64_t n, co
 }
 template <int NS>
 static int launch_dense(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter, const DenseView &d,
-                        hipStream_t stream, const long long *block_run = nullptr) {   // block_run: the rows are a run of blocks
+                        hipStream_t stream, const long long *block_run, bool allow_families) {   // block_run: the rows are a run of blocks
   {
     // a state of few entries: accumulated in LDS, one workgroup per CU (agg_hash_update.hpp, kDense && kDir)
     DevConfig lc = dc;
     plan_tile(lc, used_columns, kDirBlock, filter != nullptr);
     plan_interpreter(lc, kDirBlock);
-    const DenseLdsGeometry geo = dense_lds_geometry(d.num_entries, NS, static_cast<size_t>(lc.tile_bytes) + lc.temps_bytes);
+    const DenseLdsGeometry geo = dense_lds_geometry(d.num_entries, NS, static_cast<size_t>(lc.tile_bytes) + lc.temps_bytes, allow_families);
     constexpr size_t kMaxLds = 160 * 1024;
     int nbuf = 2;
     size_t lds = dir_lds_bytes(lc.tile_bytes, lc.temps_bytes, NS, geo.entries << geo.rep_shift, nbuf);
@@ -1787,6 +1802,45 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
   return fill_identities(st, s);
 }
 
+// Dense states between one LDS and eight: key-range families read the input `ranges` times (~0.45 ms per 100 M rows and
+// read) and never touch a global atomic per row; the per-row path costs 2 atomics per RUN of equal adjacent keys at 24 G/s
+// (8.4 ms per 100 M runs) but reads once.  Random keys: families win by 2.6-10x; lineitem clustered on l_orderkey (runs of
+// ~4): the per-row path wins.  One sample of the first rows, once per state (one small synchronous read-back).
+static void decide_dense_families(qsx_agg_state *st, const void *key_col, int64_t rows, hipStream_t s) {
+  if (st->dense_families.load() != 0) return;
+  DevConfig dev = st->dev;
+  plan_tile(dev, st->used_columns, kDirBlock, false);
+  const DenseLdsGeometry geo = dense_lds_geometry(st->config.num_entries, st->num_sums, static_cast<size_t>(dev.tile_bytes), true);
+  if (geo.entries == 0 || geo.ranges == 1) {
+    st->dense_families.store(1);   // (nothing to decide: one LDS holds it, or not even eight do)
+    return;
+  }
+  const int key_col_index = st->dev.key_column[0];
+  const int sample = static_cast<int>(std::min<int64_t>(rows, 256 * 1024));
+  if (key_col == nullptr || st->dev.code_width[key_col_index] != 0 || sample < 4096) {
+    if (sample >= 4096 || key_col == nullptr) st->dense_families.store(geo.ranges <= 4 ? 1 : 2);   // (codes: no sample — a middle course)
+    return;                                                                                        // (a small first input: ask again)
+  }
+  CallScratch scratch(s);
+  if (scratch.reserve(CallScratch::padded(sizeof(unsigned int))) != QSX_OK) return;
+  unsigned int *counter = static_cast<unsigned int *>(scratch.take(sizeof(unsigned int)));
+  unsigned int equal = 0;
+  if (hipMemsetAsync(counter, 0, sizeof(unsigned int), s) != hipSuccess) return;
+  if (st->dev.column_type[key_col_index] == QSX_LONG) {
+    hipLaunchKernelGGL(adjacent_equal_kernel<long long>, dim3(1), dim3(1024), 0, s, static_cast<const long long *>(key_col), sample, counter);
+  } else {
+    hipLaunchKernelGGL(adjacent_equal_kernel<int32_t>, dim3(1), dim3(1024), 0, s, static_cast<const int32_t *>(key_col), sample, counter);
+  }
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&equal, counter, sizeof(equal), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  const double runs_per_row = 1.0 - static_cast<double>(equal) / (sample - 1);        // 1 / average run length
+  const double per_row_ms = std::max(1.1, 8.4 * runs_per_row), families_ms = 0.45 * geo.ranges;   // per 100 M rows
+  st->dense_families.store(families_ms < per_row_ms ? 1 : 2);
+}
+
 // One launch of the update kernel over n rows with the given LDS table geometry: AOT plan shape, then the
 // run-time one, then the interpreter (CAPACITY — the tile does not fit LDS next to the group tables — and
 // compile failures fall through).
@@ -1794,10 +1848,14 @@ int qsx_agg_state_clear(qsx_agg_state_t *st, qsx_stream_t stream) {
 // filter_dev then only say which columns and whether a filter exist); it travels in the kernels' `pieces` argument.
 static int update_slice(qsx_agg_state *st, const void *const *cols, const void *const *dicts, int64_t n,
                         const uint64_t *filter_dev, int slots, int ranges, const long long *pieces, hipStream_t s,
-                        const uint64_t *const *nulls = nullptr, const long long *block_run = nullptr) {
+                        const uint64_t *const *nulls = nullptr, const long long *block_run = nullptr, int64_t first_block_rows = 0) {
   const bool partitioned = pieces != nullptr;
   const bool runs = block_run != nullptr;
   if (runs) pieces = block_run;
+  if (st->dense && st->dense_families.load() == 0) {
+    // (a run of blocks: cols are the first block's stripes)
+    decide_dense_families(st, st->dev.num_keys > 0 ? cols[st->dev.key_column[0]] : nullptr, runs ? first_block_rows : n, s);
+  }
   DevConfig dc = st->dev;
   for (int i = 0; i < st->config.num_columns; ++i) {
     dc.cols[i] = cols[i];
@@ -1822,7 +1880,7 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
   if (st->dense) {
     const DenseView d = st->dense_view();
     int rc = QSX_OK;
-    QSX_DISPATCH_NS(st->num_sums, rc = launch_dense, dc, st->used_columns, n, filter_dev, d, s, block_run);
+    QSX_DISPATCH_NS(st->num_sums, rc = launch_dense, dc, st->used_columns, n, filter_dev, d, s, block_run, st->dense_families.load() == 1);
     if (rc != QSX_OK) return rc;
   } else {
     const HashTableView g = st->hash_view();
@@ -2052,7 +2110,7 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   // one launch over the tiles of all blocks.  (The group directory and the partition pass want one stripe per column: a
   // mid-size group count takes the hash-range families here.)
   rc = update_slice(st, first_cols, nullptr, total, any_filter ? first_filter : nullptr, st->lds_slots, st->lds_ranges, nullptr, s, nullptr,
-                    dev_table);
+                    dev_table, rows[0]);
   if (rc != QSX_OK) return rc;
   return publish_control(st, s);
 }
