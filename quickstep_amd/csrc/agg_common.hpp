@@ -212,8 +212,20 @@ __device__ __forceinline__ void global_accumulate(unsigned long long *p, unsigne
     case kAccSumI64:
       if (inc != 0) atomicAdd(p, inc);
       break;
-    case kAccMinI64: atomicMin(reinterpret_cast<long long *>(p), static_cast<long long>(inc)); break;
-    case kAccMaxI64: atomicMax(reinterpret_cast<long long *>(p), static_cast<long long>(inc)); break;
+    // MIN / MAX only ever move one way: a value that cannot move the accumulator any more is not sent (a stale read errs
+    // on the side of sending it).  After a group's first rows that is nearly every row — and every row of a wide key's
+    // hidden MIN / MAX proof, whose value is the same word each time: random global atomics complete at 24 G/s, reads of an
+    // L2-resident line ten times faster (16-byte key, 10^5 groups: 25.5 -> 9 ms per 100 M rows).
+    case kAccMinI64:
+      if (static_cast<long long>(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > static_cast<long long>(inc)) {
+        atomicMin(reinterpret_cast<long long *>(p), static_cast<long long>(inc));
+      }
+      break;
+    case kAccMaxI64:
+      if (static_cast<long long>(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < static_cast<long long>(inc)) {
+        atomicMax(reinterpret_cast<long long *>(p), static_cast<long long>(inc));
+      }
+      break;
     default: atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(inc))); break;
   }
 }
