@@ -118,13 +118,17 @@ def test_partition_test_known_answers_through_the_operators():
 
 
 @pytest.mark.gpu
-def test_headline_workload_through_the_operator_boundary():
+@pytest.mark.parametrize("exclusive_probes,cover", [("0", "1"), ("1", "1"), ("0", "0")])
+def test_headline_workload_through_the_operator_boundary(exclusive_probes, cover):
     """BASELINE configs 2 + 3 as BuildHash / HashJoin / Aggregation / FinalizeAggregation operators under ForemanSingleNode on
     4 MB blocks with work orders over runs of blocks, scaled to 1 M x 20 M + 60 M rows; every step's results are checked
-    (join condition on every output row, COUNT / SUM(qty) exact, sums to 1e-6)."""
+    (join condition on every output row, COUNT / SUM(qty) exact, sums to 1e-6).  Also with probe work orders keeping the
+    device to themselves (QSX_HOST_EXCLUSIVE_PROBES=1: the Foreman's two classes of work orders) and with the projecting
+    probe reading head[] and the stripes instead of a covering array (QSX_JOIN_COVER=0)."""
     _ensure_built()
-    r = subprocess.run([os.path.join(BIN, "headline_operators_bench"), "1000000", "20000000", "60000000", "2", "1", "4", "16"],
-                       capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, QSX_HOST_EXCLUSIVE_PROBES=exclusive_probes, QSX_JOIN_COVER=cover)
+    r = subprocess.run([os.path.join(BIN, "headline_operators_bench"), "1000000", "20000000", "60000000", "3", "1", "4", "16"],
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and '"checked": true' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
