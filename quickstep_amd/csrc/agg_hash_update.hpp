@@ -537,11 +537,9 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   // families; family r walks ALL tiles but only aggregates the groups whose hash falls into
   // range r, so each family's groups fit its LDS tables.  Costs `ranges` reads of the input
   // instead of (NS + 1) global atomics per row.
-  // pieces != nullptr (partitioned aggregation, aggregate.hip): the input was hash-partitioned on the key code into P
-  // pieces and every piece is shared by pieces[0] = R hash-range families (ranges = P x R): family (p, r) walks piece p = rows
-  // [pieces[1 + p], + pieces[1 + P + p]) and keeps the groups whose hash falls into range r of R — R = 1: its groups are its
-  // own by construction, no hash test, every row is read once; R > 1 (more groups than P tables hold): the piece is read R
-  // times, which is still cheaper than NS + 1 global atomics per row.
+  // pieces != nullptr (partitioned aggregation, aggregate.hip): the input was hash-partitioned on the key code into
+  // `ranges` pieces; family r walks only piece r = rows [pieces[r], pieces[r] + pieces[ranges + r]) — its groups are
+  // its own by construction, no hash test, every row is read once.
   const int my_range = ranges > 1 ? static_cast<int>(blockIdx.x % ranges) : 0;
   // (build pass of the group directory: every sample_stride-th tile only)
   const int64_t first_tile = kDirBuild ? static_cast<int64_t>(blockIdx.x) * dir->sample_stride + dir->sample_phase
@@ -561,10 +559,8 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   BlockRunView run{};
   if constexpr (batched) run = block_run_view(pieces, TR);
   const bool by_piece = pieces != nullptr && !batched;
-  const int piece_families = by_piece ? static_cast<int>(pieces[0]) : 1;
-  const int my_piece = my_range / piece_families, my_sub_range = my_range % piece_families;
-  const int64_t row_begin = by_piece ? pieces[1 + my_piece] : 0;
-  const int64_t row_end = by_piece ? row_begin + pieces[1 + ranges / piece_families + my_piece] : n;
+  const int64_t row_begin = by_piece ? pieces[my_range] : 0;
+  const int64_t row_end = by_piece ? row_begin + pieces[ranges + my_range] : n;
   const int64_t num_tiles = batched ? run.first_tile[run.num_blocks] : (row_end - row_begin + TR - 1) / TR;
   auto tile_row0 = [&](int64_t t) { return row_begin + t * TR; };
   auto tile_rows = [&](int64_t t) { return static_cast<int>(row_end - tile_row0(t) < TR ? row_end - tile_row0(t) : TR); };
@@ -744,12 +740,6 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         live[v] = live[v] && static_cast<int>((mix64(code[v]) >> 20) % static_cast<unsigned>(ranges)) == my_range;
-      }
-    }
-    if (by_piece && piece_families > 1) {   // (other bits than the partition pass took: it routes on the hash's top bits)
-#pragma unroll
-      for (int v = 0; v < V; ++v) {
-        live[v] = live[v] && static_cast<int>((mix64(code[v]) >> 20) % static_cast<unsigned>(piece_families)) == my_sub_range;
       }
     }
     if constexpr (kDirBuild) {

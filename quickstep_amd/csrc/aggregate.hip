@@ -672,7 +672,6 @@ struct qsx_agg_state {
   // lds_ranges reads of the whole input at one workgroup per CU.
   int part_count = 1;
   int part_slots = 64;
-  int part_families = 1;   // hash-range families per piece (more groups than part_count tables hold: every piece is read that often)
   unsigned used_columns = 0;
   const struct ShapeEntry *shape = nullptr;  // AOT plan shape matching this configuration, if any
   // Run-time plan shapes (agg_jit.hpp), one per filter variant; compiled once the state has seen enough
@@ -1483,7 +1482,6 @@ static void derive_geometry(qsx_agg_state *st, int64_t est) {
   st->lds_ranges = 1;
   st->part_count = 1;
   st->part_slots = 64;
-  st->part_families = 1;
   // workgroup-private LDS table: up to 512 slots (<= 40 KiB at NS = 8)
   uint64_t s = next_pow2(static_cast<uint64_t>(est) * 2);
   if (s < 8) s = 8;
@@ -1512,12 +1510,6 @@ static void derive_geometry(qsx_agg_state *st, int64_t est) {
       if (ps < 64) ps = 64;
       if (ps > 4096) ps = 4096;
       st->part_slots = static_cast<int>(ps);
-      // More groups per piece than its table holds at half load: the piece's groups are split over up to 8 hash-range
-      // families, each reading the whole piece (64 pieces x 8 families x 2048 groups: a million groups before rows start
-      // paying global atomics; eight reads of 12 B/row cost ~2 ms per 100 M rows, the atomics 8 ms).
-      const uint64_t per_piece = (static_cast<uint64_t>(est) + pieces - 1) / pieces;
-      uint64_t families = (per_piece * 2 + ps - 1) / ps;
-      st->part_families = static_cast<int>(families < 1 ? 1 : (families > 8 ? 8 : families));
     }
   }
   // More groups than the replicated LDS tables hold, but few enough that one CU's LDS holds an accumulator per group
@@ -1919,19 +1911,14 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   const int64_t padded = n + static_cast<int64_t>(kAlignRows) * P;
   // the scratch of this call: piece table, K9 workspace, one partitioned copy of every used column
   const size_t ws_bytes = partition_workspace_bytes(n, P);
-  size_t total = CallScratch::padded(sizeof(int64_t) * (2 * P + 1)) + CallScratch::padded(ws_bytes);
+  size_t total = CallScratch::padded(sizeof(int64_t) * 2 * P) + CallScratch::padded(ws_bytes);
   for (int c = 0; c < ncols; ++c) {
     if ((st->used_columns >> c) & 1u) total += CallScratch::padded(static_cast<size_t>(padded) * st->dev.column_width[c] + 16);
   }
   CallScratch scratch(s);
   int rc = scratch.reserve(total);
   if (rc != QSX_OK) return rc;
-  // the piece table of the update kernel (agg_hash_update.hpp): [0] families per piece, then what K9 writes — first row and
-  // row count of every piece
-  int64_t *pieces = static_cast<int64_t *>(scratch.take(sizeof(int64_t) * (2 * P + 1)));
-  const int families = st->part_families;
-  QSX_HIP_TRY(hipMemsetAsync(pieces, 0, sizeof(int64_t), s));
-  QSX_HIP_TRY(hipMemsetAsync(pieces, families, 1, s));   // (little-endian: the low byte of word 0)
+  int64_t *pieces = static_cast<int64_t *>(scratch.take(sizeof(int64_t) * 2 * P));
   void *ws = scratch.take(ws_bytes);
   const void *src[QSX_MAX_COLUMNS];
   void *dst[QSX_MAX_COLUMNS];
@@ -1952,10 +1939,10 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   const void *key_cols[QSX_MAX_KEYS];
   for (int k = 0; k < st->dev.num_keys; ++k) key_cols[k] = cols[st->dev.key_column[k]];
   rc = partition_scatter_packed_keys(st->dev.num_keys, key_cols, st->dev.key_width, st->dev.key_shift, n, P, moved, src, widths,
-                                     dst, pieces + 1, ws, ws_bytes, s, kAlignRows);
+                                     dst, pieces, ws, ws_bytes, s, kAlignRows);
   if (rc != QSX_OK) return rc;
   // n only sizes the grid here (an upper bound of every piece); the kernel reads its piece from `pieces`
-  return update_slice(st, part_cols, nullptr, n, nullptr, st->part_slots, P * families, reinterpret_cast<const long long *>(pieces), s);
+  return update_slice(st, part_cols, nullptr, n, nullptr, st->part_slots, P, reinterpret_cast<const long long *>(pieces), s);
 }
 
 static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *const *dicts, int64_t n,

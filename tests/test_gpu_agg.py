@@ -862,34 +862,6 @@ def test_wide_group_keys_through_the_group_directory(capi, oracle, dev, shape, m
             finalize_np(run_hip(capi, dev, cfg, cols), dev)
 
 
-@pytest.mark.parametrize("shape", ["narrow", "wide"])
-def test_partitioned_aggregation_shares_a_piece_between_hash_range_families(capi, oracle, dev, shape, monkeypatch):
-    """More groups than the partition pass's 64 pieces hold in their LDS tables (est 300 K: 4 700 per piece, tables of 4 096
-    slots): every piece is read by several hash-range families of workgroups, each keeping its share of the piece's groups —
-    same groups and sums as the oracle; single calls and several, MIN / MAX next to SUM / COUNT, a 16-byte key (its proof
-    columns), interpreter and run-time shape."""
-    monkeypatch.setenv("QSX_AGG_PARTITION_MIN_ROWS", "100000")
-    rng = np.random.default_rng(71)
-    n, groups = 700_000, 300_000
-    k = rng.integers(0, groups, size=n).astype(np.int32)
-    val = rng.normal(size=n)
-    qty = rng.integers(-100, 100, size=n).astype(np.int32)
-    if shape == "narrow":
-        layout, cols, keys, v, q = [(T.INT, None), (T.DOUBLE, None), (T.INT, None)], [k, val, qty], [0], 1, 2
-    else:
-        layout = [(T.INT, None), (T.LONG, None), (T.DOUBLE, None), (T.INT, None)]
-        cols, keys, v, q = [k, k.astype(np.int64) << 21, val, qty], [0, 1], 2, 3
-    aggs = [(T.AGG_SUM, T.col(v)), (T.AGG_COUNT_STAR, None), (T.AGG_MIN, T.col(v)), (T.AGG_MAX, T.col(q))]
-    cfg = T.make_agg_config(T.AGG_GENERIC, layout, keys=keys, aggs=aggs, est_groups=groups)
-    o = oracle.AggState(cfg)
-    o.update(cols)
-    ref = o.finalize()
-    for jit in (False, True):
-        monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if jit else str(1 << 60))
-        for blocks in (1, 3):
-            assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols, blocks=blocks), dev), ref)
-
-
 def test_wide_group_key_limits(capi):
     """Every key word costs two accumulators of the state: what does not fit is refused at creation."""
     layout = [(T.LONG, None)] * 4 + [(T.DOUBLE, None)]
