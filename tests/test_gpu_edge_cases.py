@@ -109,3 +109,65 @@ def test_tuple_id_range_and_argument_errors(capi, dev):
     with pytest.raises(capi.QsxError):
         capi.AggState(T.make_agg_config(T.AGG_COMPACT_KEY, [(T.LONG, None)] * 4, keys=[0, 1, 2, 3], aggs=[]))   # 32-byte key: four words
     capi.AggState(T.make_agg_config(T.AGG_COMPACT_KEY, [(T.LONG, None), (T.LONG, None)], keys=[0, 1], aggs=[])).close()   # 16 bytes: a wide key
+
+
+def test_projecting_probe_argument_errors_and_empty_sides(capi, dev):
+    """qsx_join_probe_project_blocks: what it refuses (column counts, widths, missing stripes, descending segment starts)
+    and what it accepts without touching memory that is not there (no probe rows, a build side without tuples, capacity 0:
+    the count only)."""
+    import ctypes as C
+    keys = torch.arange(1000, dtype=torch.int32, device=dev)
+    t = capi.JoinTable(T.INT, 1000, key_range=(0, 999))
+    t.build(keys)
+    probe = torch.randint(0, 2000, (5000,), dtype=torch.int32, device=dev)
+    expected = int((probe < 1000).sum().item())
+    # capacity 0: the count, nothing written
+    outs, cnt = t.probe_project_blocks([probe], [[probe]], [[keys]], capacity=0)
+    assert int(cnt.item()) == expected
+    # a smaller capacity than the result: the full count, no write past the capacity
+    outs, cnt = t.probe_project_blocks([probe], [[probe]], [[keys]], capacity=7)
+    assert int(cnt.item()) == expected and outs[0].numel() == 7 and bool((outs[0] == outs[1]).all())
+    # no probe rows at all
+    none = torch.empty(0, dtype=torch.int32, device=dev)
+    outs, cnt = t.probe_project_blocks([none, none], [[none, none]], [[keys]])
+    assert int(cnt.item()) == 0
+    # an empty table, its build relation without tuples
+    empty = capi.JoinTable(T.INT, 10, key_range=(0, 9))
+    outs, cnt = empty.probe_project_blocks([probe], [[probe]], [[none]])
+    assert int(cnt.item()) == 0
+    # refused descriptors
+    def call(proj):
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        rows = (C.c_int64 * 1)(probe.numel())
+        kptr = (C.c_void_p * 1)(probe.data_ptr())
+        return capi.lib.qsx_join_probe_project_blocks(t._h, 1, rows, kptr, None, C.byref(proj), 100, C.c_void_p(count.data_ptr()), None)
+    out = torch.empty(100, dtype=torch.int64, device=dev)
+    def descriptor(num_columns=1, width=4, on_build=0, segments=1, first=(0,)):
+        p = T.JoinProjection()
+        p.num_columns = num_columns
+        p.width[0] = width
+        p.on_build[0] = on_build
+        stripes = (C.c_void_p * 1)(probe.data_ptr())
+        bstripes = (C.c_void_p * max(segments, 1))(*([keys.data_ptr()] * max(segments, 1)))
+        firsts = (C.c_int64 * max(segments, 1))(*first)
+        outp = (C.c_void_p * 1)(out.data_ptr())
+        p.probe_stripes = C.cast(stripes, C.POINTER(C.c_void_p))
+        p.num_build_segments = segments
+        p.build_first_tids = C.cast(firsts, C.POINTER(C.c_int64))
+        p.build_stripes = C.cast(bstripes, C.POINTER(C.c_void_p))
+        p.out_columns = C.cast(outp, C.POINTER(C.c_void_p))
+        p._keep = (stripes, bstripes, firsts, outp)
+        return p
+    assert call(descriptor()) == 0
+    assert call(descriptor(num_columns=0)) == T.ERR_INVALID_ARGUMENT
+    assert call(descriptor(num_columns=T.MAX_PROJECTED + 1)) == T.ERR_INVALID_ARGUMENT
+    assert call(descriptor(width=3)) == T.ERR_INVALID_ARGUMENT
+    assert call(descriptor(width=16)) == T.ERR_INVALID_ARGUMENT
+    assert call(descriptor(on_build=1, segments=2, first=(500, 0))) == T.ERR_INVALID_ARGUMENT
+    p = descriptor()
+    p.out_columns = None
+    assert call(p) == T.ERR_INVALID_ARGUMENT
+    p = descriptor()
+    p.probe_stripes = None
+    assert call(p) == T.ERR_INVALID_ARGUMENT
+
