@@ -1229,18 +1229,23 @@ __global__ __launch_bounds__(1024) void agg_dense_lds_kernel(DevConfig c, int64_
 // Group-directory variant (agg_common.hpp DirView): ONE workgroup of 1024 threads per CU owns the CU's LDS — `gids`
 // accumulators per aggregate, unreplicated — and 16 waves hide the directory's L2 round trip.  One row per thread and tile.
 constexpr int kDirBlock = 1024;
-template <int NS>
+// kRuns: the rows are a run of blocks (block_run = the table of agg_common.hpp BlockRunView; stripes, filters and dictionaries
+// come from it).
+template <int NS, bool kRuns>
 __global__ __launch_bounds__(kDirBlock) void agg_dir_update_kernel(DevConfig c, int64_t n, const uint64_t *__restrict__ filter,
-                                                                  HashTableView g, DirView d, int gids, int nbuf) {
-  agg_hash_update_body<false, false, NS, 1, true, kDirBlock>(c, c.cols, c.dicts, n, filter, g, DenseView{}, gids, 0, nbuf, 1, nullptr,
-                                                             c.nulls, &d);
+                                                                  HashTableView g, DirView d, int gids, int nbuf,
+                                                                  const long long *__restrict__ block_run) {
+  agg_hash_update_body<false, false, NS, 1, true, kDirBlock, false, kRuns>(c, kRuns ? nullptr : c.cols, kRuns ? nullptr : c.dicts, n,
+                                                                           kRuns ? nullptr : filter, g, DenseView{}, gids, 0, nbuf, 1, block_run,
+                                                                           kRuns ? nullptr : c.nulls, &d);
 }
 // Build pass: key (and predicate) columns only, `set_slots` LDS slots for the workgroup's distinct codes.
-template <int kUnused>   // (a template only so that the header can be included by several translation units)
+template <bool kRuns>
 __global__ __launch_bounds__(kDirBlock) void agg_dir_build_kernel(DevConfig c, int64_t n, const uint64_t *__restrict__ filter, DirView d,
-                                                                 int set_slots, int nbuf) {
-  agg_hash_update_body<false, false, 0, 1, false, kDirBlock, true>(c, c.cols, c.dicts, n, filter, HashTableView{}, DenseView{}, set_slots, 0,
-                                                                   nbuf, 1, nullptr, c.nulls, &d);
+                                                                 int set_slots, int nbuf, const long long *__restrict__ block_run) {
+  agg_hash_update_body<false, false, 0, 1, false, kDirBlock, true, kRuns>(c, kRuns ? nullptr : c.cols, kRuns ? nullptr : c.dicts, n,
+                                                                          kRuns ? nullptr : filter, HashTableView{}, DenseView{}, set_slots, 0,
+                                                                          nbuf, 1, block_run, kRuns ? nullptr : c.nulls, &d);
 }
 template <typename Shape>
 __global__ __launch_bounds__(kDirBlock) void agg_dir_shape_kernel(ColumnPointers cols, int64_t n, HashTableView g, DirView d, int gids,
@@ -1248,6 +1253,13 @@ __global__ __launch_bounds__(kDirBlock) void agg_dir_shape_kernel(ColumnPointers
   static constexpr Translated T = Shape::translated(kDirBlock);
   agg_hash_update_body<true, false, T.num_sums, 1, true, kDirBlock>(T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, gids, 0, nbuf, 1,
                                                                     nullptr, nullptr, &d);
+}
+template <typename Shape>
+__global__ __launch_bounds__(kDirBlock) void agg_dir_shape_runs_kernel(int64_t n, HashTableView g, DirView d, int gids, int nbuf,
+                                                                      const long long *__restrict__ block_run) {
+  static constexpr Translated T = Shape::translated(kDirBlock);
+  agg_hash_update_body<true, false, T.num_sums, 1, true, kDirBlock, false, true>(T.dev, nullptr, nullptr, n, nullptr, g, DenseView{}, gids, 0,
+                                                                                 nbuf, 1, block_run, nullptr, &d);
 }
 
 

@@ -123,12 +123,15 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
   }
   if (geo.dir_gids != 0) {
     // group-directory variant: the body of agg_dir_update_kernel with the configuration and the geometry as constants
+    // (geo.runs: the rows are a run of blocks, the table arrives as `pieces`)
     o << "extern \"C\" __global__ __launch_bounds__(" << kDirBlock << ") void qsx_jit_agg(ColumnPointers cols,\n"
-      << "    const void *const *dicts, int64_t n, const uint64_t *filter, HashTableView view, DirView d) {\n"
+      << "    const void *const *dicts, int64_t n, const uint64_t *filter, HashTableView view, DirView d, const long long *pieces) {\n"
       << "  static constexpr DevConfig D = jit_make_dev();\n"
-      << "  agg_hash_update_body<true, false, " << num_sums << ", 1, true, " << kDirBlock << ">(D, cols.p, "
-      << (any_coded ? "dicts" : "nullptr") << ", n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr")
-      << ", view, DenseView{}, " << geo.dir_gids << ", 0, " << geo.nbuf << ", 1, nullptr, nullptr, &d);\n}\n}  // namespace qsx\n";
+      << "  (void)cols; (void)pieces;\n"
+      << "  agg_hash_update_body<true, false, " << num_sums << ", 1, true, " << kDirBlock << ", false, " << (geo.runs != 0 ? "true" : "false")
+      << ">(D, " << (geo.runs != 0 ? "nullptr" : "cols.p") << ", " << (any_coded ? "dicts" : "nullptr") << ", n, "
+      << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", view, DenseView{}, " << geo.dir_gids << ", 0, " << geo.nbuf << ", 1, "
+      << (geo.runs != 0 ? "pieces" : "nullptr") << ", nullptr, &d);\n}\n}  // namespace qsx\n";
     return o.str();
   }
   // the run-of-blocks flavour of the body takes the same signature (the table arrives as `pieces`) and its stripes from the
@@ -385,14 +388,16 @@ int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t s
 }
 
 int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
-                       const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d) {
+                       const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d,
+                       const long long *pieces) {
   ColumnPointers a_cols = cols;
   const void *const *a_dicts = dict_table_dev;
   int64_t a_n = n;
   const uint64_t *a_filter = filter;
   HashTableView a_g = g;
   DirView a_d = d;
-  void *args[] = {&a_cols, &a_dicts, &a_n, &a_filter, &a_g, &a_d};
+  const long long *a_pieces = pieces;
+  void *args[] = {&a_cols, &a_dicts, &a_n, &a_filter, &a_g, &a_d, &a_pieces};
   QSX_HIP_TRY(hipModuleLaunchKernel(k->function, static_cast<unsigned>(grid), 1, 1, kDirBlock, 1, 1,
                                     static_cast<unsigned>(lds_bytes), stream, args, nullptr));
   return QSX_OK;
@@ -415,7 +420,7 @@ extern "C" int qsx_debug_jit_compile(const qsx_agg_config_t *config, int with_fi
   // a plausible geometry: this hook only checks that the shape compiles
   JitGeometry geometry = directory ? JitGeometry{4096, 0, 2, 1, 4096, 0} : JitGeometry{t.dense ? 8 : 16, t.dense ? 0 : 4, 1, 1, 0, 0};
   if (dense_lds) geometry = JitGeometry{4096, 0, 2, 2, 4096, 0};
-  geometry.runs = runs && !directory ? 1 : 0;
+  geometry.runs = runs ? 1 : 0;
   const std::string source = jit_agg_source(t.dev, t.num_sums, t.dense, geometry);
   if (const char *dump = getenv("QSX_JIT_DUMP")) {   // the generated translation unit, for offline inspection with hipcc -S
     if (FILE *f = std::fopen(dump, "w")) {

@@ -45,7 +45,8 @@ int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t s
 
 // The group-directory variant (geometry.dir_gids != 0): the argument list of agg_dir_update_kernel.
 int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
-                       const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d);
+                       const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d,
+                       const long long *pieces = nullptr);   // pieces: the run table of a geometry.runs shape
 
 constexpr int kJitRowsPerThread = 4;
 

@@ -574,7 +574,7 @@ using namespace qsx;
 // (a 0.5 M-row block whose groups the estimate missed entirely still fits).
 constexpr unsigned int kLogRecords = 1u << 20;
 
-constexpr int kJitVariants = 8;   // (filter) x (tile path, partitioned path, group directory, run of blocks)
+constexpr int kJitVariants = 10;   // (filter) x (tile path, partitioned path, group directory, run of blocks, directory over a run)
 constexpr int kDirBoundSlots = 32;
 constexpr size_t kDirControlBytes = 16 + sizeof(unsigned long long) * 2 * QSX_MAX_KEYS * kDirBoundSlots;
 struct qsx_agg_state {
@@ -981,7 +981,7 @@ static int agg_rows_per_thread() { return agg_tuning().rows_per_thread; }
 typedef int (*ShapeLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S,
                              int ranges, const long long *pieces, hipStream_t stream, bool runs);
 typedef int (*ShapeDirLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, const DirView &d, int gids,
-                                int nbuf, hipStream_t stream);
+                                int nbuf, hipStream_t stream, const long long *block_run);
 struct ShapeEntry {
   const char *name;
   qsx_agg_config_t config;
@@ -1037,7 +1037,7 @@ static int dense_lds_grid(int64_t n, int ranges) {
 
 template <typename Shape>
 static int launch_shape_dir(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, const DirView &d, int gids,
-                            int nbuf, hipStream_t stream) {
+                            int nbuf, hipStream_t stream, const long long *block_run) {
   constexpr Translated T = Shape::translated(kDirBlock);
   static_assert(T.status == QSX_OK, "plan shape does not translate");
   constexpr size_t kMaxLds = 160 * 1024;
@@ -1051,6 +1051,16 @@ static int launch_shape_dir(const void *const *cols, int num_columns, int64_t n,
     });
     if (rc != QSX_OK) return rc;
   }
+  if (block_run != nullptr) {
+    static PerDeviceOnce runs_attribute_set;
+    const int rc = once_per_device(runs_attribute_set, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_shape_runs_kernel<Shape>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+    });
+    if (rc != QSX_OK) return rc;
+    hipLaunchKernelGGL((agg_dir_shape_runs_kernel<Shape>), dim3(dir_grid(n)), dim3(kDirBlock), lds, stream, n, g, d, gids, nbuf, block_run);
+    return QSX_OK;
+  }
   ColumnPointers cp;
   for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < num_columns ? cols[i] : nullptr;
   hipLaunchKernelGGL((agg_dir_shape_kernel<Shape>), dim3(dir_grid(n)), dim3(kDirBlock), lds, stream, cp, n, g, d, gids, nbuf);
@@ -1059,7 +1069,7 @@ static int launch_shape_dir(const void *const *cols, int num_columns, int64_t n,
 
 // Build pass of the group directory: stages the key and predicate columns only.
 static int launch_dir_build(DevConfig dc, unsigned key_columns, int64_t n, const uint64_t *filter, DirView d, int gids,
-                            unsigned call, hipStream_t stream) {
+                            unsigned call, hipStream_t stream, const long long *block_run) {
   // the sample: every stride-th tile, at least ~4 M rows of a large input (all of a small one), another phase every call
   const char *e = getenv("QSX_AGG_DIR_SAMPLE_ROWS");   // tests shrink the sample
   const int64_t sample_rows = e != nullptr && atoll(e) > 0 ? atoll(e) : (4 << 20);
@@ -1081,8 +1091,13 @@ static int launch_dir_build(DevConfig dc, unsigned key_columns, int64_t n, const
   static PerDeviceOnce attribute_set;
   {
     const int rc = once_per_device(attribute_set, [] {
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_build_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 static_cast<int>(kMaxLds));
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_build_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+      if (err == hipSuccess) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_build_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(kMaxLds));
+      }
+      return err;
     });
     if (rc != QSX_OK) return rc;
   }
@@ -1090,17 +1105,21 @@ static int launch_dir_build(DevConfig dc, unsigned key_columns, int64_t n, const
   // (all CUs: the pass is bound by the LDS compare-and-swaps of the workgroups' code sets — 2.7 us per 1024-row tile —
   // not by the inserts at its end: 64 workgroups took 0.54 ms for the sample that 256 read in 0.32 ms)
   const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(sampled_tiles, kCUs)));
-  d.build_step = 0;
-  hipLaunchKernelGGL(agg_dir_build_kernel<0>, dim3(grid), dim3(kDirBlock), static_cast<size_t>(nbuf) * dc.tile_bytes + 16, stream, dc, n,
-                     filter, d, slots, nbuf);
-  d.build_step = 1;
-  hipLaunchKernelGGL(agg_dir_build_kernel<0>, dim3(grid), dim3(kDirBlock), lds, stream, dc, n, filter, d, slots, nbuf);
+  for (int step = 0; step < 2; ++step) {   // bounds, then the directory itself (agg_common.hpp DirView::build_step)
+    d.build_step = step;
+    const size_t step_lds = step == 0 ? static_cast<size_t>(nbuf) * dc.tile_bytes + 16 : lds;
+    if (block_run != nullptr) {
+      hipLaunchKernelGGL(agg_dir_build_kernel<true>, dim3(grid), dim3(kDirBlock), step_lds, stream, dc, n, filter, d, slots, nbuf, block_run);
+    } else {
+      hipLaunchKernelGGL(agg_dir_build_kernel<false>, dim3(grid), dim3(kDirBlock), step_lds, stream, dc, n, filter, d, slots, nbuf, block_run);
+    }
+  }
   return QSX_OK;
 }
 
 template <int NS>
 static int launch_dir(DevConfig dc, unsigned used_columns, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d,
-                      int gids, int nbuf, hipStream_t stream) {
+                      int gids, int nbuf, hipStream_t stream, const long long *block_run) {
   plan_tile(dc, used_columns, kDirBlock, filter != nullptr);
   plan_interpreter(dc, kDirBlock);
   constexpr size_t kMaxLds = 160 * 1024;
@@ -1109,12 +1128,21 @@ static int launch_dir(DevConfig dc, unsigned used_columns, int64_t n, const uint
   static PerDeviceOnce attribute_set;
   {
     const int rc = once_per_device(attribute_set, [] {
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_update_kernel<NS>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_update_kernel<NS, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+      if (err == hipSuccess) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_update_kernel<NS, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+      }
+      return err;
     });
     if (rc != QSX_OK) return rc;
   }
-  hipLaunchKernelGGL((agg_dir_update_kernel<NS>), dim3(dir_grid(n)), dim3(kDirBlock), lds, stream, dc, n, filter, g, d, gids, nbuf);
+  if (block_run != nullptr) {
+    hipLaunchKernelGGL((agg_dir_update_kernel<NS, true>), dim3(dir_grid(n)), dim3(kDirBlock), lds, stream, dc, n, filter, g, d, gids, nbuf, block_run);
+  } else {
+    hipLaunchKernelGGL((agg_dir_update_kernel<NS, false>), dim3(dir_grid(n)), dim3(kDirBlock), lds, stream, dc, n, filter, g, d, gids, nbuf, block_run);
+  }
   return QSX_OK;
 }
 
@@ -1250,7 +1278,7 @@ static JitGeometry jit_geometry_for(const qsx_agg_state *st, int tile_bytes, int
 static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, bool partitioned, int slots, int num_ranges, int64_t n,
                                          int *variant, bool directory = false, bool runs = false) {
   const long long seen = st->rows_seen.fetch_add(n) + n;
-  const int v = (has_filter ? 1 : 0) + (runs ? 6 : (directory ? 4 : (partitioned ? 2 : 0)));
+  const int v = (has_filter ? 1 : 0) + (runs && directory ? 8 : (runs ? 6 : (directory ? 4 : (partitioned ? 2 : 0))));
   *variant = v;
   std::lock_guard<std::mutex> lock(st->jit_mutex);
   if (st->jit_tried[v]) return st->jit[v];          // settled: ready or given up
@@ -1278,7 +1306,7 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
       st->jit_geometry[v] = JitGeometry{dense_lds.entries, dense_lds.rep_shift, nbuf, dense_lds.ranges, copies, runs ? 1 : 0};
       st->jit_lds[v] = lds;
     } else if (directory) {
-      st->jit_geometry[v] = JitGeometry{st->dir_gids, 0, st->dir_nbuf, 1, st->dir_gids};
+      st->jit_geometry[v] = JitGeometry{st->dir_gids, 0, st->dir_nbuf, 1, st->dir_gids, runs ? 1 : 0};
       st->jit_lds[v] = dir_lds_bytes(dev.tile_bytes, 0, dir_plane_sums(dev), st->dir_gids, st->dir_nbuf);
     } else {
       st->jit_geometry[v] = jit_geometry_for(st, dev.tile_bytes, slots, num_ranges, &st->jit_lds[v]);
@@ -1352,7 +1380,7 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const 
 }
 
 static int launch_jit_dir(qsx_agg_state *st, const JitKernel *k, int variant, const void *const *cols, const void *const *dicts, int64_t n,
-                          const uint64_t *filter, const DirView &dir, hipStream_t stream) {
+                          const uint64_t *filter, const DirView &dir, hipStream_t stream, const long long *block_run) {
   const size_t lds = st->jit_lds[variant];
   if (lds > 160 * 1024) return QSX_ERR_CAPACITY;
   ColumnPointers cp;
@@ -1366,7 +1394,7 @@ static int launch_jit_dir(qsx_agg_state *st, const JitKernel *k, int variant, co
     hipLaunchKernelGGL(store_struct_kernel<DictTable>, dim3(1), dim3(64), 0, stream, host_table, slot);
     dict_table = slot->p;
   }
-  const int rc = jit_agg_launch_dir(k, dir_grid(n), lds, stream, cp, dict_table, n, filter, st->hash_view(), dir);
+  const int rc = jit_agg_launch_dir(k, dir_grid(n), lds, stream, cp, dict_table, n, filter, st->hash_view(), dir, block_run);
   if (rc != QSX_OK || hipGetLastError() != hipSuccess) return QSX_ERR_HIP;
   return QSX_OK;
 }
@@ -1945,6 +1973,52 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   return update_slice(st, part_cols, nullptr, n, nullptr, st->part_slots, P, reinterpret_cast<const long long *>(pieces), s);
 }
 
+// Mid-size group count: group directory + one accumulator per group in LDS (derive_geometry).  Two launches
+// (agg_common.hpp): the distinct key codes of these rows enter the directory, then the rows are aggregated.
+// block_run != nullptr: the rows are a run of blocks (cols = the first block's stripes: only which ones exist matters).
+static int update_directory(qsx_agg_state *st, const void *const *cols, const void *const *dicts, int64_t n, const uint64_t *filter_dev,
+                            const uint64_t *const *nulls, const long long *block_run, int bounds_slot, hipStream_t s) {
+  const bool runs = block_run != nullptr;
+  const DirView dir = st->dir_view(bounds_slot);
+  DevConfig dc = st->dev;
+  for (int i = 0; i < st->config.num_columns; ++i) {
+    dc.cols[i] = cols[i];
+    dc.dicts[i] = (dicts != nullptr && dc.code_width[i] != 0) ? dicts[i] : nullptr;
+  }
+  for (int sl = 0; sl < dc.num_null_cols; ++sl) {
+    dc.nulls[sl] = nulls != nullptr ? reinterpret_cast<const unsigned long long *>(nulls[dc.null_column[sl]]) : nullptr;
+  }
+  unsigned key_columns = 0;
+  for (int k = 0; k < dc.num_keys; ++k) key_columns |= 1u << dc.key_column[k];
+  for (int p = 0; p < dc.num_pred; ++p) key_columns |= 1u << dc.pred[p].column;
+  int rc = launch_dir_build(dc, key_columns, n, filter_dev, dir, st->dir_gids, st->dir_calls.fetch_add(1), s, block_run);
+  if (rc != QSX_OK) return rc;
+  QSX_CHECK_LAUNCH();
+  int variant = 0;
+  const JitKernel *jk = nullptr;
+  if (st->shape != nullptr && filter_dev == nullptr && dc.num_null_cols == 0) {
+    st->rows_seen.fetch_add(n);
+    rc = st->shape->launch_dir(cols, st->config.num_columns, n, st->hash_view(), dir, st->dir_gids, st->dir_nbuf, s, block_run);
+  } else if (dc.num_null_cols == 0 &&
+             (jk = state_jit_kernel(st, filter_dev != nullptr, false, st->dir_gids, 1, n, &variant, true, runs)) != nullptr &&
+             st->jit_geometry[variant].dir_gids == st->dir_gids &&
+             launch_jit_dir(st, jk, variant, cols, dc.dicts, n, filter_dev, dir, s, block_run) == QSX_OK) {
+    rc = QSX_OK;   // run-time plan shape of the directory kernel
+  } else {
+    if (jk != nullptr) {   // the specialised kernel could not be launched: the interpreter from now on
+      (void)hipGetLastError();
+      std::lock_guard<std::mutex> jit_lock(st->jit_mutex);
+      st->jit[variant] = nullptr;
+    } else if (dc.num_null_cols != 0) {
+      st->rows_seen.fetch_add(n);
+    }
+    QSX_DISPATCH_NS(st->num_sums, rc = launch_dir, dc, st->used_columns, n, filter_dev, st->hash_view(), dir, st->dir_gids, st->dir_nbuf, s,
+                    block_run);
+  }
+  if (rc == QSX_OK) QSX_CHECK_LAUNCH();
+  return rc;
+}
+
 static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *const *dicts, int64_t n,
                       const uint64_t *filter_dev, qsx_stream_t stream, const uint64_t *const *nulls = nullptr) {
   QSX_REQUIRE_DEVICE();
@@ -1957,44 +2031,7 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
   // (the partitioned path scatters value columns: states over compressed attributes take the tile path)
   const int bounds_slot = !st->dense && st->dir_gids != 0 ? st->dir_bounds_slot(s) : -1;
   if (bounds_slot >= 0) {
-    // mid-size group count: group directory + one accumulator per group in LDS (derive_geometry)
-    const DirView dir = st->dir_view(bounds_slot);
-    DevConfig dc = st->dev;
-    for (int i = 0; i < st->config.num_columns; ++i) {
-      dc.cols[i] = cols[i];
-      dc.dicts[i] = (dicts != nullptr && dc.code_width[i] != 0) ? dicts[i] : nullptr;
-    }
-    for (int sl = 0; sl < dc.num_null_cols; ++sl) {
-      dc.nulls[sl] = nulls != nullptr ? reinterpret_cast<const unsigned long long *>(nulls[dc.null_column[sl]]) : nullptr;
-    }
-    // two launches (agg_common.hpp): the distinct key codes of these rows enter the directory, then the rows are aggregated
-    unsigned key_columns = 0;
-    for (int k = 0; k < dc.num_keys; ++k) key_columns |= 1u << dc.key_column[k];
-    for (int p = 0; p < dc.num_pred; ++p) key_columns |= 1u << dc.pred[p].column;
-    rc = launch_dir_build(dc, key_columns, n, filter_dev, dir, st->dir_gids, st->dir_calls.fetch_add(1), s);
-    if (rc != QSX_OK) return rc;
-    QSX_CHECK_LAUNCH();
-    int variant = 0;
-    const JitKernel *jk = nullptr;
-    if (st->shape != nullptr && filter_dev == nullptr && dc.num_null_cols == 0) {
-      st->rows_seen.fetch_add(n);
-      rc = st->shape->launch_dir(cols, st->config.num_columns, n, st->hash_view(), dir, st->dir_gids, st->dir_nbuf, s);
-    } else if (dc.num_null_cols == 0 &&
-               (jk = state_jit_kernel(st, filter_dev != nullptr, false, st->dir_gids, 1, n, &variant, true)) != nullptr &&
-               st->jit_geometry[variant].dir_gids == st->dir_gids && launch_jit_dir(st, jk, variant, cols, dc.dicts, n, filter_dev, dir, s) == QSX_OK) {
-      rc = QSX_OK;   // run-time plan shape of the directory kernel
-    } else {
-      if (jk != nullptr) {   // the specialised kernel could not be launched: the interpreter from now on
-        (void)hipGetLastError();
-        std::lock_guard<std::mutex> jit_lock(st->jit_mutex);
-        st->jit[variant] = nullptr;
-      } else if (dc.num_null_cols != 0) {
-        st->rows_seen.fetch_add(n);
-      }
-      QSX_DISPATCH_NS(st->num_sums, rc = launch_dir, dc, st->used_columns, n, filter_dev, st->hash_view(), dir, st->dir_gids,
-                      st->dir_nbuf, s);
-    }
-    if (rc == QSX_OK) QSX_CHECK_LAUNCH();
+    rc = update_directory(st, cols, dicts, n, filter_dev, nulls, nullptr, bounds_slot, s);
   } else
   // (and so do states over nullable columns: a null bitmap cannot be scattered like a value column)
   // (and states with a DATE key: K9 packs the key columns itself and would take the DateLit padding bytes along.  A wide
@@ -2107,8 +2144,14 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   rc = maybe_grow(st);
   if (rc != QSX_OK) return rc;
   std::shared_lock<std::shared_mutex> lock(st->table_mutex);
-  // one launch over the tiles of all blocks.  (The group directory and the partition pass want one stripe per column: a
-  // mid-size group count takes the hash-range families here.)
+  // one launch over the tiles of all blocks (a mid-size group count: the two passes of the group directory; the partition
+  // pass wants one stripe per column, its group counts take the hash-range families here)
+  const int bounds_slot = !st->dense && st->dir_gids != 0 ? st->dir_bounds_slot(s) : -1;
+  if (bounds_slot >= 0) {
+    rc = update_directory(st, first_cols, nullptr, total, any_filter ? first_filter : nullptr, nullptr, dev_table, bounds_slot, s);
+    if (rc != QSX_OK) return rc;
+    return publish_control(st, s);
+  }
   rc = update_slice(st, first_cols, nullptr, total, any_filter ? first_filter : nullptr, st->lds_slots, st->lds_ranges, nullptr, s, nullptr,
                     dev_table, rows[0]);
   if (rc != QSX_OK) return rc;

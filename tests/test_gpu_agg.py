@@ -742,6 +742,17 @@ def test_group_directory_numbering_modes(capi, oracle, dev, layout_kind, run_tim
         ref = o.finalize()
         for blocks in (1, 3):
             assert_same_groups(finalize_np(run_hip(capi, dev, cfg, [k1, k2, val], blocks=blocks), dev), ref)
+        # a run of ragged blocks in one launch pair (qsx_agg_update_blocks: the AOT shape of the COMPACT_KEY configuration,
+        # run-time shape or interpreter of the GENERIC one), then more runs into the same state
+        dcols = [to_dev(c, dev) for c in (k1, k2, val)]
+        cuts = [0, 200_000, 200_000, 777_777, n]
+        st = capi.AggState(cfg)
+        st.update_blocks([[c[a:b] for c in dcols] for a, b in zip(cuts[:-1], cuts[1:])])
+        assert_same_groups(finalize_np(st, dev), ref)
+        st = capi.AggState(cfg)
+        st.update_blocks([[c[:600_000] for c in dcols]])
+        st.update_blocks([[c[600_000:900_000] for c in dcols], [c[900_000:] for c in dcols]])
+        assert_same_groups(finalize_np(st, dev), ref)
 
 
 # ---- group-by keys wider than 8 bytes ---------------------------------------------------------------------------------
@@ -854,6 +865,20 @@ def test_wide_group_keys_through_the_group_directory(capi, oracle, dev, shape, m
             of = oracle.AggState(cfg)
             of.update(cols, filter_bitmap=keep)
             assert_same_groups(finalize_np(run_hip(capi, dev, cfg, cols, filter_bitmap=keep), dev), of.finalize())
+            # the same through ONE launch pair over a run of ragged blocks (the directory's two passes walk the run's tiles),
+            # with and without per-block filters
+            cuts = [0, 70_000, 70_000, 333_333, n]
+            dcols = [to_dev(c, dev) for c in cols]
+            run = [[c[a:b] for c in dcols] for a, b in zip(cuts[:-1], cuts[1:])]
+            st = capi.AggState(cfg)
+            st.update_blocks(run)
+            assert_same_groups(finalize_np(st, dev), ref)
+            keep_bools = oracle.bools_from_bitmap(keep, n) if hasattr(oracle, "bools_from_bitmap") else None
+            if keep_bools is not None:
+                filters = [bitmap_dev(oracle.bitmap_from_bools(keep_bools[a:b]), dev) if b > a else None for a, b in zip(cuts[:-1], cuts[1:])]
+                st = capi.AggState(cfg)
+                st.update_blocks(run, filters=filters)
+                assert_same_groups(finalize_np(st, dev), of.finalize())
     monkeypatch.delenv("QSX_AGG_DIR_SAMPLE_ROWS", raising=False)
     if shape != "key_box":   # (the key box never consults the hash)
         monkeypatch.setenv("QSX_AGG_WIDE_HASH_BITS", "9")
