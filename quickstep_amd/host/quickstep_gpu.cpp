@@ -2876,7 +2876,9 @@ bool HashInnerJoinWorkOrder::executeRun() {
   using JoinType = HashJoinOperator::JoinType;
   const bool existence = join_type_ == JoinType::kLeftSemiJoin || join_type_ == JoinType::kLeftAntiJoin;
   if (join_type_ != JoinType::kInnerJoin && !existence) return false;
-  if (residual_predicate_ != nullptr && existence) return false;   // (semi / anti with a residual go through the pairs: block by block)
+  // semi / anti with a residual predicate: the pairs of the run, the residual on them, then the probe tuples that kept (semi)
+  // or never had (anti) a pair — HashSemiJoinWorkOrder / HashAntiJoinWorkOrder::executeWithResidualPredicate (:680-793, :880-1000)
+  const bool existence_by_pairs = existence && residual_predicate_ != nullptr;
   int key_bits = 0;
   for (attribute_id a : join_key_attributes_) {   // (a CHAR(n <= 8) component travels as a LONG)
     key_bits += probe_relation_.getAttributeType(a).id == kChar ? 64 : probe_relation_.getAttributeType(a).width * 8;
@@ -2898,6 +2900,9 @@ bool HashInnerJoinWorkOrder::executeRun() {
     rows.push_back(b.numTuples());
     first_rows.push_back(total_rows);
     total_rows += b.numTuples();
+    // (the pairs of a semi / anti join end up as ONE bitmap over the run's tuple ids: every block starts at a word boundary,
+    // so that its part of the bitmap is the bitmap of the block)
+    if (existence_by_pairs) total_rows = (total_rows + 63) / 64 * 64;
   }
   if (total_rows > INT32_MAX || blocks.size() > 16384) return false;
   const std::int64_t nb = static_cast<std::int64_t>(blocks.size());
@@ -2931,10 +2936,13 @@ bool HashInnerJoinWorkOrder::executeRun() {
     ~OwnedStorage() { qsx_device_free(ptr); }
   } lip_storage;
   std::vector<const std::uint64_t *> lip_bitmaps;
+  // (anti join with a residual under a LIP filter: the tuples the filter rejects must not come back through the complement;
+  // that combination stays block by block)
+  if (existence_by_pairs && join_type_ == JoinType::kLeftAntiJoin && lip_filter_adaptive_prober_ != nullptr) return false;
   if (lip_filter_adaptive_prober_ != nullptr && !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps)) return false;
   const std::uint64_t *const *lookup = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();
   DeviceBuffer count(8);
-  if (existence) {
+  if (existence && !existence_by_pairs) {
     // HashSemiJoinWorkOrder / HashAntiJoinWorkOrder without residual (:795-816, :860-877): the probe tuples with / without a
     // match, projected on the probe attributes — one existence probe and one compaction over the run
     std::size_t words = 0;
@@ -3021,10 +3029,13 @@ bool HashInnerJoinWorkOrder::executeRun() {
   // once more with the exact capacity.
   JoinedPairs pairs;
   std::int64_t room = total_rows > 0 ? total_rows : 1;
+  std::vector<std::int32_t> base_tids;   // semi / anti by pairs: the word-aligned first tuple id of every block (first_rows)
+  if (existence_by_pairs) base_tids.assign(first_rows.begin(), first_rows.end());
   for (int attempt = 0; attempt < 2; ++attempt) {
     pairs.probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(room) * 4 + 8));
     pairs.build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(room) * 4 + 8));
-    CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), nullptr, lookup, static_cast<std::int32_t *>(pairs.probe_tids->ptr),
+    CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), existence_by_pairs ? base_tids.data() : nullptr, lookup,
+                                      static_cast<std::int32_t *>(pairs.probe_tids->ptr),
                                       static_cast<std::int32_t *>(pairs.build_tids->ptr), room, static_cast<std::int64_t *>(count.ptr),
                                       CurrentStream()), "qsx_join_probe_blocks");
     pairs.count = ReadCount(count.ptr);
@@ -3085,6 +3096,43 @@ bool HashInnerJoinWorkOrder::executeRun() {
       first = false;
     }
     if (!first) CompactPairs(&pairs, cur);
+  }
+  if (existence_by_pairs) {
+    // the probe tuples that kept a pair, as one bitmap over the run's (word-aligned) tuple ids; anti: its complement, block by
+    // block (the complement of a block's part ends at the block's last tuple); then one compaction over the run
+    const std::size_t words = static_cast<std::size_t>(total_rows / 64) + 1;
+    DeviceBuffer bitmap(words * 8 + 8);
+    CheckStatus(qsx_tids_to_bitmap(static_cast<const std::int32_t *>(pairs.probe_tids->ptr), pairs.count, 0, total_rows,
+                                   static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_tids_to_bitmap");
+    std::vector<std::uint64_t *> bitmaps(blocks.size());
+    std::int64_t upper = 0;   // tuples the compaction can select at most
+    for (std::size_t b = 0; b < blocks.size(); ++b) {
+      bitmaps[b] = static_cast<std::uint64_t *>(bitmap.ptr) + first_rows[b] / 64;
+      if (join_type_ == JoinType::kLeftAntiJoin && rows[b] > 0) {
+        CheckStatus(qsx_bitmap_combine(3, bitmaps[b], nullptr, rows[b], bitmaps[b], CurrentStream()), "qsx_bitmap_combine");
+      }
+      upper += rows[b];
+    }
+    if (join_type_ == JoinType::kLeftSemiJoin) upper = std::min<std::int64_t>(upper, pairs.count);
+    block_id out_id;
+    BlockReference out = output_destination_->getBlockForInsertion(upper > 0 ? upper : 1, &out_id);
+    std::vector<const void *> src(blocks.size() * selection_.size());
+    std::vector<void *> dst;
+    std::vector<std::int32_t> widths;
+    for (std::size_t i = 0; i < selection_.size(); ++i) {
+      dst.push_back(out->stripe(static_cast<attribute_id>(i)));
+      widths.push_back(probe_relation_.getAttributeType(selection_[i]).width);
+      for (std::size_t b = 0; b < blocks.size(); ++b) src[b * selection_.size() + i] = blocks[b]->stripe(selection_[i]);
+    }
+    const std::size_t ws_bytes = qsx_compact_blocks_workspace_bytes(nb, rows.data());
+    DeviceBuffer ws(ws_bytes + 8);
+    CheckStatus(qsx_compact_gather_blocks(static_cast<int>(selection_.size()), widths.data(), nb, rows.data(), src.data(),
+                                          reinterpret_cast<const std::uint64_t *const *>(bitmaps.data()), nullptr, dst.data(), nullptr,
+                                          static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
+                "qsx_compact_gather_blocks");
+    const std::int64_t written = ReadCount(count.ptr);
+    output_destination_->returnBlock(out_id, written, getPartitionId());
+    return true;
   }
   const std::int64_t matches = pairs.count;
   DeviceBuffer &probe_tids = *pairs.probe_tids, &build_tids = *pairs.build_tids;

@@ -262,6 +262,59 @@ void runJoinDuplicateBuildKeys(bool exact_stats, std::size_t blocks_per_order) {
   EXPECT_TRUE(g == w);
 }
 
+// select l_orderkey, l_extendedprice from lineitem where [not] exists (select * from orders where o_orderkey = l_orderkey and
+// o_limit > l_quantity): a semi / an anti join with a residual predicate between the two sides — the pairs of the run, the
+// residual on them, the probe tuples that kept (semi) or never had (anti) a pair; every order twice with different limits, so
+// that a probe tuple can keep one pair and lose the other
+void runSemiAntiResidual(bool anti, bool exact_stats, std::size_t blocks_per_order, std::size_t *out_blocks) {
+  StorageManager storage;
+  Lineitem li(&storage, false);
+  CatalogRelation orders(3, "orders");
+  orders.addAttribute("o_orderkey", Type::Int());
+  orders.addAttribute("o_limit", Type::Int());
+  std::vector<std::int32_t> okeys, limits;
+  for (std::int32_t copy = 0; copy < 2; ++copy) {
+    for (std::int32_t k = 0; k < 200000; k += 2) {
+      okeys.push_back(k);
+      limits.push_back(copy == 0 ? k % 50 : (k / 2) % 7);
+    }
+  }
+  for (std::size_t at = 0; at < okeys.size(); at += 5000) storage.loadBlock(&orders, {okeys.data() + at, limits.data() + at}, 5000);
+  CatalogRelation out(4, "kept");
+  out.addAttribute("l_orderkey", Type::Int());
+  out.addAttribute("l_extendedprice", Type::Double());
+  QueryContext ctx;
+  const QueryContext::ExactKeyRange range{0, 199998};
+  const auto table = ctx.addJoinHashTable(kInt, 200000, 1, exact_stats ? &range : nullptr);
+  const auto dest = ctx.addInsertDestination(&out, &storage);
+  const auto selection = ctx.addScalarGroup({0, 2});
+  const std::vector<bool> on_build = {false, false};
+  Predicate residual;   // o_limit (build side) > l_quantity (probe side)
+  residual.conjuncts.push_back(ComparisonPredicate::Attributes(1, true, ComparisonID::kGreater, 1, false));
+  const auto pred = ctx.addPredicate(residual);
+  BuildHashOperator builder(0, orders, true, {0}, false, 1, table);
+  HashJoinOperator prober(0, orders, li.rel, true, {0}, false, 1, false, out, dest, table, pred, selection, &on_build,
+                          anti ? HashJoinOperator::JoinType::kLeftAntiJoin : HashJoinOperator::JoinType::kLeftSemiJoin);
+  prober.setBlocksPerWorkOrder(blocks_per_order);
+  builder.setBlocksPerWorkOrder(blocks_per_order);
+  fetchAndExecuteWorkOrders(&builder, &ctx, &storage);
+  fetchAndExecuteWorkOrders(&prober, &ctx, &storage);
+  Rows got = collect(ctx, dest, storage, out_blocks);
+  std::vector<std::pair<std::int32_t, double>> g, w;
+  for (std::size_t i = 0; i < got.key.size(); ++i) g.emplace_back(got.key[i], got.price[i]);
+  for (std::size_t i = 0; i < li.orderkey.size(); ++i) {
+    const std::int32_t k = li.orderkey[i];
+    const bool has_order = k < 200000 && (k & 1) == 0;
+    const bool kept = has_order && (k % 50 > li.quantity[i] || (k / 2) % 7 > li.quantity[i]);
+    if (kept != anti) w.emplace_back(k, li.price[i]);
+  }
+  std::sort(g.begin(), g.end());
+  std::sort(w.begin(), w.end());
+  EXPECT_TRUE(w.size() > 1000);
+  EXPECT_EQ(g.size(), w.size());
+  EXPECT_TRUE(g == w);
+}
+
 // select o_orderkey, l_extendedprice, o_flag from orders join lineitem on o_orderkey = l_orderkey where o_flag = 'KEEP':
 // a CHAR(10) attribute of the build side in the residual predicate (compared on the pair list by qsx_select_cmp_char) and in
 // the projection (gathered byte by byte) — the run form and the block-by-block form
@@ -446,6 +499,15 @@ int main() {
   EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
   std::printf("hash join under a LIP filter: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n", ms_one, ms_run);
   runTypedExpressions();
+  // semi / anti joins with a residual predicate: block by block and over runs (ragged blocks: word-aligned tuple ids)
+  for (bool anti : {false, true}) {
+    std::size_t one = 0, run = 0;
+    runSemiAntiResidual(anti, true, 1, &one);
+    runSemiAntiResidual(anti, true, 64, &run);
+    runSemiAntiResidual(anti, false, 64, &run);
+    EXPECT_EQ(one, static_cast<std::size_t>(kBlocks));
+    EXPECT_EQ(run, static_cast<std::size_t>((kBlocks + 63) / 64));
+  }
   // duplicate build keys: the projecting probe overflows its block and the work order falls back to the pair list
   for (bool exact_stats : {true, false}) {
     runJoinDuplicateBuildKeys(exact_stats, 1);
