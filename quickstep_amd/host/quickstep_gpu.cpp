@@ -2875,7 +2875,9 @@ void HashInnerJoinWorkOrder::execute() {
 bool HashInnerJoinWorkOrder::executeRun() {
   using JoinType = HashJoinOperator::JoinType;
   const bool existence = join_type_ == JoinType::kLeftSemiJoin || join_type_ == JoinType::kLeftAntiJoin;
-  if (join_type_ != JoinType::kInnerJoin && !existence) return false;
+  const bool outer = join_type_ == JoinType::kLeftOuterJoin;
+  if (join_type_ != JoinType::kInnerJoin && !existence && !outer) return false;
+  if (outer && residual_predicate_ != nullptr) return false;   // (HashOuterJoinWorkOrder takes none either)
   // semi / anti with a residual predicate: the pairs of the run, the residual on them, then the probe tuples that kept (semi)
   // or never had (anti) a pair — HashSemiJoinWorkOrder / HashAntiJoinWorkOrder::executeWithResidualPredicate (:680-793, :880-1000)
   const bool existence_by_pairs = existence && residual_predicate_ != nullptr;
@@ -2902,7 +2904,7 @@ bool HashInnerJoinWorkOrder::executeRun() {
     total_rows += b.numTuples();
     // (the pairs of a semi / anti join end up as ONE bitmap over the run's tuple ids: every block starts at a word boundary,
     // so that its part of the bitmap is the bitmap of the block)
-    if (existence_by_pairs) total_rows = (total_rows + 63) / 64 * 64;
+    if (existence_by_pairs || outer) total_rows = (total_rows + 63) / 64 * 64;
   }
   if (total_rows > INT32_MAX || blocks.size() > 16384) return false;
   const std::int64_t nb = static_cast<std::int64_t>(blocks.size());
@@ -2982,8 +2984,8 @@ bool HashInnerJoinWorkOrder::executeRun() {
   // Nothing is evaluated on the pairs (an exact key, no residual predicate) and every output attribute is a plain value of
   // 1 / 2 / 4 / 8 bytes: the probe writes the output tuples itself (qsx_join_probe_project_blocks) into a block with room for
   // one match per probe tuple.  More matches than that (duplicate build keys) and the work order takes the pair list below.
-  bool projectable = run_keys.exact && residual_predicate_ == nullptr && !selection_.empty() && selection_.size() <= QSX_MAX_PROJECTED &&
-                     total_rows > 0;
+  bool projectable = !outer && run_keys.exact && residual_predicate_ == nullptr && !selection_.empty() &&
+                     selection_.size() <= QSX_MAX_PROJECTED && total_rows > 0;
   for (std::size_t i = 0; i < selection_.size() && projectable; ++i) {
     const Type &t = (is_selection_on_build_[i] ? build_relation_ : probe_relation_).getAttributeType(selection_[i]);
     projectable = !t.nullable && (t.width == 1 || t.width == 2 || t.width == 4 || t.width == 8);
@@ -3030,11 +3032,11 @@ bool HashInnerJoinWorkOrder::executeRun() {
   JoinedPairs pairs;
   std::int64_t room = total_rows > 0 ? total_rows : 1;
   std::vector<std::int32_t> base_tids;   // semi / anti by pairs: the word-aligned first tuple id of every block (first_rows)
-  if (existence_by_pairs) base_tids.assign(first_rows.begin(), first_rows.end());
+  if (existence_by_pairs || outer) base_tids.assign(first_rows.begin(), first_rows.end());
   for (int attempt = 0; attempt < 2; ++attempt) {
     pairs.probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(room) * 4 + 8));
     pairs.build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(room) * 4 + 8));
-    CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), existence_by_pairs ? base_tids.data() : nullptr, lookup,
+    CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), base_tids.empty() ? nullptr : base_tids.data(), lookup,
                                       static_cast<std::int32_t *>(pairs.probe_tids->ptr),
                                       static_cast<std::int32_t *>(pairs.build_tids->ptr), room, static_cast<std::int64_t *>(count.ptr),
                                       CurrentStream()), "qsx_join_probe_blocks");
@@ -3132,6 +3134,75 @@ bool HashInnerJoinWorkOrder::executeRun() {
                 "qsx_compact_gather_blocks");
     const std::int64_t written = ReadCount(count.ptr);
     output_destination_->returnBlock(out_id, written, getPartitionId());
+    return true;
+  }
+  if (outer) {
+    // HashOuterJoinWorkOrder (:1026-1099) over the run: the matched pairs, then the probe tuples without one (the complement of
+    // the matched tuples' bitmap, block by block so that it ends at each block's last tuple, AND the LIP filter's survivors)
+    // with NULL build-side attributes
+    const std::int64_t matches = pairs.count;
+    const std::size_t words = static_cast<std::size_t>(total_rows / 64) + 1;
+    DeviceBuffer bitmap(words * 8 + 8);
+    CheckStatus(qsx_tids_to_bitmap(static_cast<const std::int32_t *>(pairs.probe_tids->ptr), matches, 0, total_rows,
+                                   static_cast<std::uint64_t *>(bitmap.ptr), CurrentStream()), "qsx_tids_to_bitmap");
+    for (std::size_t b = 0; b < blocks.size(); ++b) {
+      if (rows[b] == 0) continue;
+      std::uint64_t *part = static_cast<std::uint64_t *>(bitmap.ptr) + first_rows[b] / 64;
+      CheckStatus(qsx_bitmap_combine(3, part, nullptr, rows[b], part, CurrentStream()), "qsx_bitmap_combine");
+      if (lookup != nullptr && lookup[b] != nullptr) {
+        CheckStatus(qsx_bitmap_combine(0, part, lookup[b], rows[b], part, CurrentStream()), "qsx_bitmap_combine");
+      }
+    }
+    DeviceBuffer unmatched_tids(static_cast<std::size_t>(total_rows) * 4 + 8);
+    const std::size_t ws_bytes = qsx_compact_workspace_bytes(total_rows);
+    DeviceBuffer ws(ws_bytes + 8);
+    CheckStatus(qsx_bitmap_to_tids(static_cast<const std::uint64_t *>(bitmap.ptr), total_rows, 0, static_cast<std::int32_t *>(unmatched_tids.ptr),
+                                   static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()), "qsx_bitmap_to_tids");
+    const std::int64_t unmatched = ReadCount(count.ptr);
+    const std::int64_t total = matches + unmatched;
+    block_id out_id;
+    BlockReference out = output_destination_->getBlockForInsertion(total > 0 ? total : 1, &out_id);
+    std::unique_ptr<DeviceBuffer> padded_build_tids;   // the pairs' build tuple ids, then -1 for every unmatched probe tuple
+    for (std::size_t i = 0; i < selection_.size(); ++i) {
+      char *dst = static_cast<char *>(out->stripe(static_cast<attribute_id>(i)));
+      const bool on_build = is_selection_on_build_[i];
+      const Type &t = (on_build ? build_relation_ : probe_relation_).getAttributeType(selection_[i]);
+      char *tail = dst + static_cast<std::size_t>(matches) * t.width;
+      if (on_build) {
+        std::uint64_t *nulls = out->nullBitmap(static_cast<attribute_id>(i));
+        if (nulls == nullptr) throw ExecutionError("outer join output attribute taken from the build side must be nullable", QSX_ERR_INVALID_ARGUMENT);
+        if (matches > 0) build.gather(selection_[i], t.width, pairs.build_tids->ptr, matches, dst);
+        if (unmatched > 0) CheckStatus(qsx_memset_device(tail, 0, static_cast<std::size_t>(unmatched) * t.width, CurrentStream()), "qsx_memset_device");
+        if (total > 0) {
+          if (padded_build_tids == nullptr) {
+            padded_build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(total) * 4 + 8));
+            if (matches > 0) {
+              CheckStatus(qsx_copy_on_device(padded_build_tids->ptr, pairs.build_tids->ptr, static_cast<std::size_t>(matches) * 4, CurrentStream()),
+                          "qsx_copy_on_device");
+            }
+            if (unmatched > 0) {
+              CheckStatus(qsx_memset_device(static_cast<char *>(padded_build_tids->ptr) + static_cast<std::size_t>(matches) * 4, 0xFF,
+                                            static_cast<std::size_t>(unmatched) * 4, CurrentStream()), "qsx_memset_device");
+            }
+          }
+          build.gatherNulls(selection_[i], padded_build_tids->ptr, total, nulls);
+        }
+      } else {
+        for (std::size_t b = 0; b < blocks.size(); ++b) segments[b] = blocks[b]->stripe(selection_[i]);
+        if (matches > 0) {
+          CheckStatus(qsx_gather_segmented(t.width, static_cast<int>(segments.size()), segments.data(), first_rows.data(),
+                                           static_cast<const std::int32_t *>(pairs.probe_tids->ptr), matches, dst, CurrentStream()),
+                      "qsx_gather_segmented");
+        }
+        if (unmatched > 0) {
+          CheckStatus(qsx_gather_segmented(t.width, static_cast<int>(segments.size()), segments.data(), first_rows.data(),
+                                           static_cast<const std::int32_t *>(unmatched_tids.ptr), unmatched, tail, CurrentStream()),
+                      "qsx_gather_segmented");
+        }
+      }
+    }
+    CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+    output_destination_->returnBlock(out_id, total, getPartitionId());
     return true;
   }
   const std::int64_t matches = pairs.count;

@@ -315,6 +315,80 @@ void runSemiAntiResidual(bool anti, bool exact_stats, std::size_t blocks_per_ord
   EXPECT_TRUE(g == w);
 }
 
+// select l_orderkey, l_extendedprice, o_limit from lineitem left outer join orders on o_orderkey = l_orderkey: every lineitem
+// once, o_limit NULL where the order does not exist (the odd keys and those from 200000 on)
+void runOuterJoin(bool exact_stats, std::size_t blocks_per_order, std::size_t *out_blocks) {
+  StorageManager storage;
+  Lineitem li(&storage, false);
+  CatalogRelation orders(3, "orders");
+  orders.addAttribute("o_orderkey", Type::Int());
+  orders.addAttribute("o_limit", Type::Int());
+  std::vector<std::int32_t> okeys, limits;
+  for (std::int32_t k = 0; k < 200000; k += 2) {
+    okeys.push_back(k);
+    limits.push_back(k % 50 + 1);
+  }
+  std::vector<std::size_t> order(okeys.size());
+  for (std::size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::shuffle(order.begin(), order.end(), std::mt19937_64(13));
+  std::vector<std::int32_t> k2(okeys.size()), l2(okeys.size());
+  for (std::size_t i = 0; i < order.size(); ++i) {
+    k2[i] = okeys[order[i]];
+    l2[i] = limits[order[i]];
+  }
+  for (std::size_t at = 0; at < k2.size(); at += 2500) storage.loadBlock(&orders, {k2.data() + at, l2.data() + at}, 2500);
+  CatalogRelation out(4, "joined");
+  out.addAttribute("l_orderkey", Type::Int());
+  out.addAttribute("l_extendedprice", Type::Double());
+  out.addAttribute("o_limit", Type::Int().getNullableVersion());
+  QueryContext ctx;
+  const QueryContext::ExactKeyRange range{0, 199998};
+  const auto table = ctx.addJoinHashTable(kInt, 100000, 1, exact_stats ? &range : nullptr);
+  const auto dest = ctx.addInsertDestination(&out, &storage);
+  const auto selection = ctx.addScalarGroup({0, 2, 1});
+  const std::vector<bool> on_build = {false, false, true};
+  BuildHashOperator builder(0, orders, true, {0}, false, 1, table);
+  HashJoinOperator prober(0, orders, li.rel, true, {0}, false, 1, false, out, dest, table, QueryContext::kInvalidPredicateId, selection,
+                          &on_build, HashJoinOperator::JoinType::kLeftOuterJoin);
+  prober.setBlocksPerWorkOrder(blocks_per_order);
+  builder.setBlocksPerWorkOrder(blocks_per_order);
+  fetchAndExecuteWorkOrders(&builder, &ctx, &storage);
+  fetchAndExecuteWorkOrders(&prober, &ctx, &storage);
+  struct Row { std::int32_t key; double price; std::int32_t limit; bool null; };
+  std::vector<Row> g, w;
+  const std::vector<block_id> touched = ctx.getInsertDestination(dest)->getTouchedBlocks();
+  *out_blocks = touched.size();
+  for (block_id b : touched) {
+    BlockReference blk = storage.getBlock(b);
+    const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+    if (k == 0) continue;
+    std::vector<std::int32_t> key(k), limit(k);
+    std::vector<double> price(k);
+    std::vector<std::uint64_t> nulls((k + 63) / 64);
+    blk->copyAttributeToHost(0, key.data());
+    blk->copyAttributeToHost(1, price.data());
+    blk->copyAttributeToHost(2, limit.data());
+    EXPECT_TRUE(blk->nullBitmap(2) != nullptr);
+    blk->copyNullBitmapToHost(2, nulls.data());
+    for (std::size_t i = 0; i < k; ++i) {
+      const bool is_null = (nulls[i >> 6] >> (63 - (i & 63))) & 1ull;   // TupleIdSequence order: first tuple = most significant bit
+      g.push_back({key[i], price[i], is_null ? 0 : limit[i], is_null});
+    }
+  }
+  for (std::size_t i = 0; i < li.orderkey.size(); ++i) {
+    const std::int32_t k = li.orderkey[i];
+    const bool has_order = k < 200000 && (k & 1) == 0;
+    w.push_back({k, li.price[i], has_order ? k % 50 + 1 : 0, !has_order});
+  }
+  auto less = [](const Row &a, const Row &b) { return std::tie(a.key, a.price, a.limit, a.null) < std::tie(b.key, b.price, b.limit, b.null); };
+  std::sort(g.begin(), g.end(), less);
+  std::sort(w.begin(), w.end(), less);
+  EXPECT_EQ(g.size(), w.size());
+  bool same = g.size() == w.size();
+  for (std::size_t i = 0; same && i < g.size(); ++i) same = g[i].key == w[i].key && g[i].price == w[i].price && g[i].limit == w[i].limit && g[i].null == w[i].null;
+  EXPECT_TRUE(same);
+}
+
 // select o_orderkey, l_extendedprice, o_flag from orders join lineitem on o_orderkey = l_orderkey where o_flag = 'KEEP':
 // a CHAR(10) attribute of the build side in the residual predicate (compared on the pair list by qsx_select_cmp_char) and in
 // the projection (gathered byte by byte) — the run form and the block-by-block form
@@ -499,6 +573,15 @@ int main() {
   EXPECT_EQ(blocks_run, static_cast<std::size_t>((kBlocks + 63) / 64));
   std::printf("hash join under a LIP filter: one work order per block %.2f ms, per run of 64 blocks %.2f ms\n", ms_one, ms_run);
   runTypedExpressions();
+  // left outer join: block by block and over runs
+  {
+    std::size_t one = 0, run = 0;
+    runOuterJoin(true, 1, &one);
+    runOuterJoin(true, 64, &run);
+    runOuterJoin(false, 64, &run);
+    EXPECT_EQ(one, static_cast<std::size_t>(kBlocks));
+    EXPECT_EQ(run, static_cast<std::size_t>((kBlocks + 63) / 64));
+  }
   // semi / anti joins with a residual predicate: block by block and over runs (ragged blocks: word-aligned tuple ids)
   for (bool anti : {false, true}) {
     std::size_t one = 0, run = 0;
