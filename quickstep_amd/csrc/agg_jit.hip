@@ -7,6 +7,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <cerrno>
+#include <fcntl.h>
+#include <spawn.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <map>
 #include <vector>
@@ -16,6 +20,8 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+
+extern char **environ;
 
 namespace qsx {
 
@@ -205,10 +211,29 @@ void join_compile_threads() {
 // and is only used when that text matches (the file name is a hash); files are written to a temporary name and renamed,
 // so concurrent processes see whole files or none.  Unset (the default): no file is read or written.
 constexpr char kCacheMagic[8] = {'Q', 'S', 'X', 'J', 'I', 'T', '0', '1'};
+// The compiler driver of the ROCm install (hipcc), or empty: QSX_JIT_COMPILER = "hiprtc" (never spawn a compiler), a path, or
+// unset = $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc when one of them is executable.
+std::string compiler_driver() {
+  const char *e = getenv("QSX_JIT_COMPILER");
+  if (e != nullptr && std::strcmp(e, "hiprtc") == 0) return std::string();
+  std::vector<std::string> candidates;
+  if (e != nullptr && e[0] != '\0') {
+    candidates.push_back(e);
+  } else {
+    if (const char *rocm = getenv("ROCM_PATH")) candidates.push_back(std::string(rocm) + "/bin/hipcc");
+    candidates.push_back("/opt/rocm/bin/hipcc");
+  }
+  for (const std::string &c : candidates) {
+    if (access(c.c_str(), X_OK) == 0) return c;
+  }
+  return std::string();
+}
 std::string cache_stamp() {
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
-  return "hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics\n";
+  const std::string driver = compiler_driver();
+  return (driver.empty() ? std::string("hiprtc ") : "driver " + driver + " hip ") + std::to_string(major) + "." + std::to_string(minor) +
+         " gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics\n";
 }
 std::string cache_path(const std::string &stamped_source) {
   const char *dir = getenv("QSX_JIT_CACHE_DIR");
@@ -260,13 +285,87 @@ void store_cached_code(const std::string &source, const std::string &code) {
 
 // Source text -> gfx950 code object: from QSX_JIT_CACHE_DIR when it is there, else hipRTC (and then into the directory).
 // log (optional) receives the compiler's messages on failure.
+// The source through the compiler driver, in a child process: hipRTC's pipeline builds measurably slower code from the same
+// text (Q1's shape: no 128-bit LDS reads, the flush loop not unrolled, scalar registers spilled into vector lanes — 1.31
+// against 1.18 ms per 200 M rows, tools/ab/jit_offline_ab.py; option for option the same as far as hiprtcCompileProgram
+// takes them).  Any failure — no driver, no temporary directory, a non-zero exit — leaves the job to hipRTC.
+bool compile_with_driver(const std::string &source, std::string *code, std::string *log) {
+  const std::string driver = compiler_driver();
+  if (driver.empty()) return false;
+  const char *tmp = getenv("TMPDIR");
+  std::string dir = std::string(tmp != nullptr && tmp[0] != '\0' ? tmp : "/tmp") + "/qsx_jit_XXXXXX";
+  if (mkdtemp(&dir[0]) == nullptr) return false;
+  const std::string src = dir + "/shape.hip", out = dir + "/shape.hsaco", messages = dir + "/messages.txt";
+  bool ok = false;
+  if (FILE *f = std::fopen(src.c_str(), "wb")) {
+    ok = std::fwrite(source.data(), 1, source.size(), f) == source.size();
+    ok = std::fclose(f) == 0 && ok;
+  }
+  if (ok) {
+    // (the prelude's typedefs repeat <cstdint>'s: legal, same types; hip_runtime.h brings what hipRTC has built in)
+    const char *argv[] = {driver.c_str(), "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                          "-munsafe-fp-atomics", "-include", "hip/hip_runtime.h", "-o", "shape.hsaco", "shape.hip", nullptr};
+    posix_spawn_file_actions_t actions;
+    posix_spawn_file_actions_init(&actions);
+    // run inside the directory, on relative names: its random name stays out of the code object (same text, same bytes)
+    posix_spawn_file_actions_addchdir_np(&actions, dir.c_str());
+    posix_spawn_file_actions_addopen(&actions, 1, messages.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    posix_spawn_file_actions_adddup2(&actions, 1, 2);
+    pid_t pid = 0;
+    int status = -1;
+    ok = posix_spawn(&pid, driver.c_str(), &actions, nullptr, const_cast<char *const *>(argv), environ) == 0;
+    posix_spawn_file_actions_destroy(&actions);
+    if (ok) {
+      while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+      }
+      ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
+    }
+  }
+  if (ok) {
+    ok = false;
+    if (FILE *f = std::fopen(out.c_str(), "rb")) {
+      std::fseek(f, 0, SEEK_END);
+      const long size = std::ftell(f);
+      std::fseek(f, 0, SEEK_SET);
+      if (size > 0) {
+        code->assign(static_cast<size_t>(size), '\0');
+        ok = std::fread(&(*code)[0], 1, static_cast<size_t>(size), f) == static_cast<size_t>(size);
+      }
+      std::fclose(f);
+    }
+  } else if (log != nullptr) {
+    if (FILE *f = std::fopen(messages.c_str(), "rb")) {
+      char buf[4096];
+      const size_t got = std::fread(buf, 1, sizeof(buf), f);
+      log->assign(buf, got);
+      std::fclose(f);
+    }
+  }
+  (void)std::remove(src.c_str());
+  (void)std::remove(out.c_str());
+  (void)std::remove(messages.c_str());
+  (void)rmdir(dir.c_str());
+  return ok;
+}
+
 bool compile_to_code(const std::string &source, std::string *code, std::string *log) {
   if (load_cached_code(source, code)) return true;
+  if (compile_with_driver(source, code, log)) {
+    store_cached_code(source, *code);
+    return true;
+  }
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, source.c_str(), "qsx_jit_agg.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
-                        "-mllvm", "-amdgpu-internalize-symbols"};   // the last two: what hipcc passes for device code
-  const hiprtcResult rc = hiprtcCompileProgram(prog, 7, opts);
+  std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
+                                    "-mllvm", "-amdgpu-internalize-symbols"};   // the last two: what hipcc passes for device code
+  // QSX_JIT_OPTIONS: further options, blank-separated (experiments with what hipRTC's pipeline does differently from hipcc's)
+  std::vector<std::string> extra;
+  if (const char *e = getenv("QSX_JIT_OPTIONS")) {
+    std::istringstream words(e);
+    for (std::string w; words >> w;) extra.push_back(w);
+    for (const std::string &w : extra) opts.push_back(w.c_str());
+  }
+  const hiprtcResult rc = hiprtcCompileProgram(prog, static_cast<int>(opts.size()), opts.data());
   if (rc != HIPRTC_SUCCESS) {
     size_t log_size = 0;
     hiprtcGetProgramLogSize(prog, &log_size);

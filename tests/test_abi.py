@@ -151,3 +151,36 @@ def test_plan_shape_code_objects_are_kept_in_the_cache_directory(capi, tmp_path,
     files[0].write_bytes(blob[:len(blob) // 2])
     assert fn(C.byref(cfg), 0, C.byref(size)) == 0 and size.value == first
     assert files[0].read_bytes() == blob
+
+
+def test_plan_shapes_name_their_compiler_in_the_cache(capi, tmp_path, monkeypatch):
+    """Run-time plan shapes go to the ROCm compiler driver (a child process) when one is installed and to hipRTC otherwise
+    (`QSX_JIT_COMPILER`): objects of the two never share a cache file, and a driver that cannot be run
+    leaves the shape to hipRTC instead of failing the state."""
+    import ctypes as C
+    from quickstep_amd import types as T
+    fn = capi.lib.qsx_debug_jit_compile
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(T.AggConfig), C.c_int, C.POINTER(C.c_size_t)]
+    layout = [(T.INT, None), (T.DOUBLE, None)]
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], aggs=[(T.AGG_MAX, T.col(1))])
+    monkeypatch.setenv("QSX_JIT_CACHE_DIR", str(tmp_path))
+    size = C.c_size_t(0)
+    stamps = {}
+    for compiler in ("hiprtc", None, str(tmp_path / "no_such_driver")):
+        if compiler is None:
+            monkeypatch.delenv("QSX_JIT_COMPILER", raising=False)
+        else:
+            monkeypatch.setenv("QSX_JIT_COMPILER", compiler)
+        before = set(tmp_path.iterdir())
+        assert fn(C.byref(cfg), 0, C.byref(size)) == 0 and size.value > 0
+        new = set(tmp_path.iterdir()) - before
+        if compiler is not None and compiler != "hiprtc":
+            assert not new                      # no driver there: the same key as hipRTC's, already in the directory
+            continue
+        assert len(new) == 1
+        blob = new.pop().read_bytes()
+        stamps[compiler] = blob[24:blob.index(b"\n", 24)]
+    assert stamps["hiprtc"].startswith(b"hiprtc ")
+    if os.access(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc"), os.X_OK):
+        assert stamps[None].startswith(b"driver ") and b"hipcc" in stamps[None]

@@ -115,7 +115,7 @@ report("K9 partition_scatter P=8, key + tid", ms, N, 4 * N * 2 + 8 * N * 2, "key
 # ---- aggregation family --------------------------------------------------------------------------------
 na = 2 * N
 cols = gen_q1_columns_gpu(na, dev, 4)
-for label, create_env, update_env in (("AOT plan shape", None, None), ("run-time plan shape (hipRTC)", "1", None),
+for label, create_env, update_env in (("AOT plan shape", None, None), ("run-time plan shape", "1", None),
                                       ("interpreter", "1", "1")):
     # QSX_AGG_NO_SPECIALIZE at creation: no AOT shape; still set at update: no run-time shape either
     if create_env:
