@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
-#define QSX_ABI_VERSION 9
+#define QSX_ABI_VERSION 10
 
 typedef void *qsx_stream_t;
 
@@ -81,6 +81,13 @@ int qsx_abi_version(void);
 size_t qsx_abi_sizeof_agg_config(void);
 /* Number of usable gfx950 devices (0 when there is none). Never fails. */
 int qsx_device_count(void);
+/* One process per GPU is the deployment this library is written for, but nothing in it is bound to device 0: every call
+ * works on the device that is current in the calling thread (HIP's per-thread current device), objects live on the device
+ * they were created on.  An engine that selects its GPU with hipSetDevice rather than HIP_VISIBLE_DEVICES tells threads it
+ * creates itself which device that is through these two (the host layer's Worker threads do: they take the device that was
+ * current in the thread calling ForemanSingleNode::run).  device = an index below qsx_device_count(). */
+int qsx_current_device(int *out_device);
+int qsx_set_current_device(int device);
 /* Text of the last HIP error seen by this thread ("" if none). */
 const char *qsx_last_error(void);
 

@@ -47,6 +47,8 @@ _SIGNATURES = {
     "qsx_abi_version": (_int, []),
     "qsx_abi_sizeof_agg_config": (_sz, []),
     "qsx_device_count": (_int, []),
+    "qsx_current_device": (_int, [C.POINTER(C.c_int)]),
+    "qsx_set_current_device": (_int, [_int]),
     "qsx_last_error": (C.c_char_p, []),
     "qsx_device_alloc": (_int, [_sz, _pp]),
     "qsx_device_free": (_int, [_vp]),
@@ -172,6 +174,17 @@ def trim_scratch():
 
 def device_count():
     return _lib.qsx_device_count()
+
+
+def current_device():
+    """The HIP device current in the calling thread (qsx_current_device): the one every call of this thread works on."""
+    v = C.c_int(-1)
+    _check(_lib.qsx_current_device(C.byref(v)), "qsx_current_device")
+    return v.value
+
+
+def set_current_device(device):
+    _check(_lib.qsx_set_current_device(int(device)), "qsx_set_current_device")
 
 
 def _ptr(t):

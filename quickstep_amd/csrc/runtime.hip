@@ -251,6 +251,22 @@ size_t qsx_abi_sizeof_agg_config(void) { return sizeof(qsx_agg_config_t); }
 
 int qsx_device_count(void) { return qsx::usable_devices(); }
 
+int qsx_current_device(int *out_device) {
+  QSX_REQUIRE_DEVICE();
+  if (out_device == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  QSX_HIP_TRY(hipGetDevice(out_device));
+  return QSX_OK;
+}
+
+int qsx_set_current_device(int device) {
+  QSX_REQUIRE_DEVICE();
+  int count = 0;
+  QSX_HIP_TRY(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) return QSX_ERR_INVALID_ARGUMENT;
+  QSX_HIP_TRY(hipSetDevice(device));
+  return QSX_OK;
+}
+
 const char *qsx_last_error(void) { return qsx::g_last_error.c_str(); }
 
 int qsx_device_alloc(size_t bytes, void **out_dev) {

@@ -3819,9 +3819,21 @@ namespace {
 // The threads are never joined: they sleep on their queues when the process exits.
 class WorkerThreads {
  public:
-  static WorkerThreads &instance() {
-    static WorkerThreads *pool = new WorkerThreads;
+  // The pool of one device (-1: no usable GPU, every work order fails with QSX_ERR_NO_DEVICE anyway).  One process per GPU is
+  // the rule and then there is one pool; a process that drives several GPUs gets Worker threads — and streams — per device.
+  static WorkerThreads &instance(int device) {
+    static std::mutex pools_mutex;
+    static std::map<int, WorkerThreads *> *pools = new std::map<int, WorkerThreads *>;
+    std::lock_guard<std::mutex> lock(pools_mutex);
+    WorkerThreads *&pool = (*pools)[device];
+    if (pool == nullptr) pool = new WorkerThreads(device);
     return *pool;
+  }
+  // The device that is current in the calling thread: the one the caller's blocks, tables and states live on.
+  static int callersDevice() {
+    int device = -1;
+    if (qsx_device_count() == 0 || qsx_current_device(&device) != QSX_OK) device = -1;
+    return device;
   }
   // fn(i) on worker thread i for every i < n; returns when all have returned.
   void run(std::size_t n, const std::function<void(std::size_t)> &fn) {
@@ -3834,7 +3846,7 @@ class WorkerThreads {
       while (slots_.size() < n) {
         slots_.emplace_back(new Slot);
         Slot *slot = slots_.back().get();
-        std::thread([slot]() { threadMain(slot); }).detach();
+        std::thread([slot, device = device_]() { threadMain(slot, device); }).detach();
       }
       for (std::size_t i = 0; i < n; ++i) mine.push_back(slots_[i].get());
     }
@@ -3860,9 +3872,13 @@ class WorkerThreads {
     std::condition_variable cv;
     std::deque<std::function<void()>> tasks;
   };
-  static void threadMain(Slot *slot) {
+  explicit WorkerThreads(int device) : device_(device) {}
+  static void threadMain(Slot *slot, int device) {
     qsx_stream_t stream = nullptr;
-    if (qsx_device_count() > 0 && qsx_stream_create(&stream) != QSX_OK) stream = nullptr;   // (the default stream then)
+    // a new thread starts on device 0: move it to the pool's device before anything is created (stream, scratch, staging)
+    if (device >= 0 && (qsx_set_current_device(device) != QSX_OK || qsx_stream_create(&stream) != QSX_OK)) {
+      stream = nullptr;   // (the default stream then)
+    }
     SetCurrentStream(stream);
     for (;;) {
       std::function<void()> task;
@@ -3875,6 +3891,7 @@ class WorkerThreads {
       task();
     }
   }
+  const int device_;
   std::mutex mutex_;
   std::vector<std::unique_ptr<Slot>> slots_;
 };
@@ -3982,13 +3999,14 @@ void ForemanSingleNode::run() {
   std::vector<bool> done_generating(N, false), finished(N, false);
   std::vector<std::size_t> blocks_fed(N, 0);  // per producer: output blocks already fed downstream
   // the process-wide Worker threads serve this query until it shuts them out again (one more thread drives them and waits)
-  std::thread workers([this]() {
+  const int device = WorkerThreads::callersDevice();
+  std::thread workers([this, device]() {
     if (std::getenv("QSX_HOST_EPHEMERAL_WORKERS") != nullptr) {   // (debugging: threads and streams of this run() only)
       std::vector<std::thread> own;
       for (std::size_t w = 0; w < num_workers_; ++w) {
-        own.emplace_back([this, w]() {
+        own.emplace_back([this, w, device]() {
           qsx_stream_t stream = nullptr;
-          if (qsx_device_count() > 0) (void)qsx_stream_create(&stream);
+          if (device >= 0 && qsx_set_current_device(device) == QSX_OK) (void)qsx_stream_create(&stream);
           SetCurrentStream(stream);
           workerMain(w);
           if (stream != nullptr) qsx_stream_destroy(stream);
@@ -3997,7 +4015,7 @@ void ForemanSingleNode::run() {
       for (auto &t : own) t.join();
       return;
     }
-    WorkerThreads::instance().run(num_workers_, [this](std::size_t w) { workerMain(w); });
+    WorkerThreads::instance(device).run(num_workers_, [this](std::size_t w) { workerMain(w); });
   });
 
   auto shutdown = [&]() {

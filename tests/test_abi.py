@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(capi):
 
 def test_abi_version_and_struct_mirror(capi):
     from quickstep_amd import types as T
-    assert capi.lib.qsx_abi_version() == T.ABI_VERSION == 9
+    assert capi.lib.qsx_abi_version() == T.ABI_VERSION == 10
     header = open(os.path.join(ROOT, "include", "qsx.h")).read()
     assert f"#define QSX_ABI_VERSION {T.ABI_VERSION}" in header
     assert capi.lib.qsx_abi_sizeof_agg_config() == ctypes.sizeof(T.AggConfig)
@@ -184,3 +184,15 @@ def test_plan_shapes_name_their_compiler_in_the_cache(capi, tmp_path, monkeypatc
     assert stamps["hiprtc"].startswith(b"hiprtc ")
     if os.access(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc"), os.X_OK):
         assert stamps[None].startswith(b"driver ") and b"hipcc" in stamps[None]
+
+
+def test_device_selection_needs_a_device(capi):
+    """qsx_current_device / qsx_set_current_device (include/qsx.h): the calling thread's HIP device, for engines that pick
+    their GPU per thread instead of per process; without a GPU both say so."""
+    import ctypes as C
+    from quickstep_amd import types as T
+    if capi.lib.qsx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    device = C.c_int(-7)
+    assert capi.lib.qsx_current_device(C.byref(device)) == T.ERR_NO_DEVICE
+    assert capi.lib.qsx_set_current_device(0) == T.ERR_NO_DEVICE

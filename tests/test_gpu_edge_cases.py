@@ -171,3 +171,25 @@ def test_projecting_probe_argument_errors_and_empty_sides(capi, dev):
     p.probe_stripes = None
     assert call(p) == T.ERR_INVALID_ARGUMENT
 
+
+
+def test_calls_follow_the_calling_threads_device(capi, dev):
+    """Nothing in the library is bound to device 0: a call works on the device current in its thread (include/qsx.h,
+    qsx_current_device / qsx_set_current_device).  A thread the engine creates starts on device 0 whatever the creating
+    thread had selected — it selects explicitly, which is what the host layer's Worker threads do."""
+    import threading
+    assert capi.current_device() == torch.cuda.current_device()
+    count = capi.device_count()
+    for bad in (-1, count):
+        with pytest.raises(capi.QsxError) as e:
+            capi.set_current_device(bad)
+        assert e.value.status == T.ERR_INVALID_ARGUMENT
+    seen = []
+    def worker():
+        capi.set_current_device(count - 1)
+        seen.append(capi.current_device())
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert seen == [count - 1]
+    assert capi.current_device() == torch.cuda.current_device()
