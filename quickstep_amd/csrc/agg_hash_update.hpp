@@ -40,10 +40,16 @@ namespace qsx {
 using lds_ptr_t = __attribute__((address_space(3))) void *;
 using glb_ptr_t = const __attribute__((address_space(1))) void *;
 
+// Cache policy of the tile copies (the aux operand: 0 plain, 1 sc0, 2 nt, 16 sc1).  Non-temporal: the tiles are read once,
+// and a kernel that only reads gets more out of HBM that way — tools/ubench/read_ceiling.hip: six streams side by side
+// 6.8–7.0 TB/s non-temporal against 6.2 plain; the Q1 update over 600 M rows 3.18 against 3.29–3.44 ms on the same box.
+#ifndef QSX_DMA_AUX
+#define QSX_DMA_AUX 2
+#endif
 // One wave instruction: lane l copies 16 bytes from its own global address to
 // (wave-uniform LDS base) + 16 * l.
 __device__ __forceinline__ void dma16(const char *global_lane_addr, char *lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((glb_ptr_t)global_lane_addr, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)global_lane_addr, (lds_ptr_t)lds_wave_base, 16, 0, QSX_DMA_AUX);
 }
 
 // Loop over a configuration-sized range.  kStatic = the configuration is a compile-time

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(kBlock) void select_cmp_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = ((w0 + r) << 6) + lane;
-      v[r] = col[row < n ? row : n - 1];   // clamped, not guarded (rows past n are masked out of the ballot)
-      u[r] = COLS ? rhs[row < n ? row : n - 1] : lit;
+      v[r] = load_global_nt(&col[row < n ? row : n - 1]);   // clamped, not guarded (rows past n are masked out of the ballot)
+      u[r] = COLS ? load_global_nt(&rhs[row < n ? row : n - 1]) : lit;
     }
     uint64_t mine = 0;
 #pragma unroll
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ sr
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t i = i0 + r * stride;
-      t[r] = i < n ? tids[i] : -1;
+      t[r] = i < n ? load_global_nt(&tids[i]) : -1;   // the two streams pass the caches by: what is read again is src
     }
     T v[R];
 #pragma unroll
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ sr
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t i = i0 + r * stride;
-      if (i < n) dst[i] = t[r] < 0 ? T() : v[r];
+      if (i < n) store_global_nt(t[r] < 0 ? T() : v[r], &dst[i]);
     }
   }
 }
@@ -915,7 +915,7 @@ __device__ __forceinline__ void select_packed_group(const T *__restrict__ col, i
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row0 = (l0 + r) * kRowsPerLoad + static_cast<int64_t>(lane) * K;
-      raw[r] = *reinterpret_cast<const uint4 *>(col + row0);
+      raw[r] = stream_load16(col + row0);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -943,7 +943,7 @@ __device__ __forceinline__ void select_packed_group(const T *__restrict__ col, i
     const int64_t row0 = (l0 + r) * kRowsPerLoad + static_cast<int64_t>(lane) * K;
     raw[r] = make_uint4(0, 0, 0, 0);
     if (row0 + K <= n) {
-      raw[r] = *reinterpret_cast<const uint4 *>(col + row0);
+      raw[r] = stream_load16(col + row0);
     } else if (row0 < n) {               // the last, partial 16 bytes of the stripe: element by element
       T tmp[K];
 #pragma unroll
@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void select_char_tile(const unsigned char *__restrict
   if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const int full = bytes & ~15;
     for (int o = threadIdx.x * 16; o < full; o += kBlock * 16) {
-      *reinterpret_cast<uint4 *>(s_tile + o) = *reinterpret_cast<const uint4 *>(src + o);
+      *reinterpret_cast<uint4 *>(s_tile + o) = stream_load16(src + o);
     }
     for (int o = full + threadIdx.x; o < bytes; o += kBlock) s_tile[o] = src[o];
   } else {
@@ -1258,10 +1258,21 @@ __global__ __launch_bounds__(kBlock) void select_char_runs_kernel(const long lon
 template <typename C, typename V>
 __global__ __launch_bounds__(kBlock) void decode_codes_kernel(const C *__restrict__ codes, int64_t n,
                                                              const V *__restrict__ dictionary, V *__restrict__ out) {
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
-       i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const C c = codes[i];
-    out[i] = dictionary != nullptr ? dictionary[c] : static_cast<V>(c);
+  // four coalesced code reads in flight per thread, values written past the caches (both stripes are touched once)
+  constexpr int U = 4;
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * (kBlock * U) + threadIdx.x; i0 < n;
+       i0 += static_cast<int64_t>(gridDim.x) * (kBlock * U)) {
+    C c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * kBlock;
+      c[u] = load_global_nt(&codes[i < n ? i : n - 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * kBlock;
+      if (i < n) store_global_nt(dictionary != nullptr ? dictionary[c[u]] : static_cast<V>(c[u]), &out[i]);
+    }
   }
 }
 
