@@ -79,6 +79,15 @@ class FinalizeAggregationWorkOrder : public WorkOrder {
   AggregationOperationState *state_;
   InsertDestination *dest_;
 };
+class InitializeAggregationWorkOrder : public WorkOrder {
+ public:
+  InitializeAggregationWorkOrder(std::size_t query_id, partition_id part, std::size_t state_partition_id, AggregationOperationState *state)
+      : WorkOrder(query_id, part), state_partition_id_(state_partition_id), state_(state) {}
+  void execute() override { state_->initialize(state_partition_id_); }   // InitializeAggregationOperator.cpp:91-93
+ private:
+  const std::size_t state_partition_id_;
+  AggregationOperationState *state_;
+};
 class DestroyAggregationStateWorkOrder : public WorkOrder {
  public:
   DestroyAggregationStateWorkOrder(std::size_t query_id, QueryContext::aggregation_state_id id, QueryContext *ctx,
@@ -178,6 +187,19 @@ bool FinalizeAggregationOperator::getAllWorkOrders(WorkOrdersContainer *containe
       }
     }
   }
+  return true;
+}
+
+bool InitializeAggregationOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *,
+                                                     const tmb::client_id, tmb::MessageBus *) {
+  if (started_) return true;
+  for (partition_id part = 0; part < num_partitions_; ++part) {
+    AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, part);
+    for (std::size_t p = 0; p < aggr_state_num_init_partitions_; ++p) {
+      container->addNormalWorkOrder(new InitializeAggregationWorkOrder(query_id_, part, p, state), op_index_);
+    }
+  }
+  started_ = true;
   return true;
 }
 

@@ -415,6 +415,16 @@ AggregationOperationState::~AggregationOperationState() {
   if (coded_state_ != nullptr) qsx_agg_state_destroy(coded_state_);
 }
 
+void AggregationOperationState::initialize(std::size_t state_partition_id) {
+  if (config_.strategy != QSX_AGG_COLLISION_FREE) {
+    throw ExecutionError("AggregationOperationState::initialize() is not supported by this aggregation", QSX_ERR_UNSUPPORTED);
+  }
+  if (state_partition_id != 0) return;   // (the fill of slice 0 covers the whole allocation)
+  if (state_ != nullptr) CheckStatus(qsx_agg_state_clear(state_, CurrentStream()), "qsx_agg_state_clear");
+  if (coded_state_ != nullptr) CheckStatus(qsx_agg_state_clear(coded_state_, CurrentStream()), "qsx_agg_state_clear");
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // the aggregation runs on other streams
+}
+
 void AggregationOperationState::aggregateBlock(const StorageBlock &block, const std::uint64_t *lip_filter) {
   const std::int64_t n = block.numTuples();
   if (!distinctify_.empty() && n > 0) {

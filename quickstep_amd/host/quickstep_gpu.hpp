@@ -463,6 +463,11 @@ class AggregationOperationState {
   ~AggregationOperationState();
   // :428-474; lip_filter = TupleIdSequence left by the LIPFilterAdaptiveProber (:440-460), or nullptr
   void aggregateBlock(const StorageBlock &block, const std::uint64_t *lip_filter = nullptr);
+  // :418-426 — slice `state_partition_id` of the collision-free vector table set to its initial values.  The device state is
+  // one allocation zeroed by one fill: slice 0 clears all of it (qsx_agg_state_clear; a state fresh from the constructor
+  // is clear already), the other slices have nothing left to do.  Any other strategy: ExecutionError, as the reference's
+  // LOG(FATAL) "is not supported by this aggregation".
+  void initialize(std::size_t state_partition_id);
   // A run of blocks in one launch where the state allows it (plain, non-nullable attributes, every conjunct inside the
   // kernel, no DISTINCT aggregate); blocks that need the per-block path take it.  lip_filters[i]: block i's filter or nullptr.
   void aggregateBlocks(const std::vector<BlockReference> &blocks, const std::vector<const std::uint64_t *> &lip_filters);
@@ -661,7 +666,7 @@ class WorkOrdersContainer {
 class RelationalOperator {
  public:
   enum OperatorType { kAggregation = 0, kBuildAggregationExistenceMap, kBuildHash, kDestroyAggregationState, kDestroyHash, kFinalizeAggregation,
-                      kInnerJoin, kSelect, kSortMergeRun, kSortRunGeneration, kMockOperator };
+                      kInitializeAggregation, kInnerJoin, kSelect, kSortMergeRun, kSortRunGeneration, kMockOperator };
   virtual ~RelationalOperator() {}
   virtual OperatorType getOperatorType() const = 0;
   virtual std::string getName() const = 0;
@@ -1030,6 +1035,26 @@ class FinalizeAggregationOperator : public RelationalOperator {
   const std::size_t aggr_state_num_partitions_;
   const CatalogRelation &output_relation_;
   const QueryContext::insert_destination_id output_destination_index_;
+  bool started_ = false;
+};
+
+// InitializeAggregationOperator.hpp:52-99: num_partitions x aggr_state_num_init_partitions work orders, each
+// AggregationOperationState::initialize(state_partition_id) (.cpp:38-62, 91-93).  The optimizer adds it in front of an
+// aggregation over a CollisionFreeVectorTable (ExecutionGenerator.cpp:204-208 sizes the slices).
+class InitializeAggregationOperator : public RelationalOperator {
+ public:
+  InitializeAggregationOperator(std::size_t query_id, QueryContext::aggregation_state_id aggr_state_index,
+                                std::size_t num_partitions, std::size_t aggr_state_num_init_partitions)
+      : RelationalOperator(query_id, num_partitions), aggr_state_index_(aggr_state_index),
+        aggr_state_num_init_partitions_(aggr_state_num_init_partitions) {}
+  OperatorType getOperatorType() const override { return kInitializeAggregation; }
+  std::string getName() const override { return "InitializeAggregationOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+
+ private:
+  const QueryContext::aggregation_state_id aggr_state_index_;
+  const std::size_t aggr_state_num_init_partitions_;
   bool started_ = false;
 };
 

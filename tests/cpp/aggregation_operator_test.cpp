@@ -276,7 +276,10 @@ int main() {
     const auto dest = ctx.addInsertDestination(&result, &f.storage);
     if (use_foreman) {
       QueryPlan plan;
+      // InitializeAggregation in front, in 3 slices ("aggr_state_num_init_partitions", ExecutionGenerator.cpp:204-208, 2160-2170)
+      const auto in = plan.addRelationalOperator(new InitializeAggregationOperator(0, state, 1, 3));
       const auto e = plan.addRelationalOperator(new BuildAggregationExistenceMapOperator(0, customer, 0, true, state));
+      plan.addDirectDependency(e, in, true);
       const auto a = plan.addRelationalOperator(new AggregationOperator(0, orders, true, state));
       const auto fz = plan.addRelationalOperator(new FinalizeAggregationOperator(0, state, 1, false, 2, result, dest));
       const auto d = plan.addRelationalOperator(new DestroyAggregationStateOperator(0, state));
@@ -285,8 +288,12 @@ int main() {
       plan.addDirectDependency(d, fz, true);
       ForemanSingleNode foreman(&plan, &ctx, &f.storage, 4);
       foreman.run();
-      EXPECT_EQ(foreman.getWorkOrderProfilingResults().size(), static_cast<std::size_t>(5 + 30 + 2 + 1));
+      EXPECT_EQ(foreman.getWorkOrderProfilingResults().size(), static_cast<std::size_t>(3 + 5 + 30 + 2 + 1));
     } else {
+      InitializeAggregationOperator init(0, state, 1, 2);
+      EXPECT_TRUE(init.getOperatorType() == RelationalOperator::kInitializeAggregation);
+      EXPECT_TRUE(init.getName() == "InitializeAggregationOperator");
+      fetchAndExecuteWorkOrders(&init, &ctx, &f.storage);
       BuildAggregationExistenceMapOperator exist(0, customer, 0, true, state);
       EXPECT_TRUE(exist.getOperatorType() == RelationalOperator::kBuildAggregationExistenceMap);
       AggregationOperator op(0, orders, true, state);
@@ -305,6 +312,52 @@ int main() {
       seen[key] = true;
       EXPECT_EQ(at<std::int64_t>(cols[1], i), want_count[key]);
       EXPECT_EQ(at<std::int64_t>(cols[2], i), want_sum[key]);
+    }
+  }
+  // ---- InitializeAggregation on a state that is not a collision-free vector: the reference's LOG(FATAL)
+  // (AggregationOperationState.cpp:418-426) is an ExecutionError here; re-initialising a USED collision-free state empties it
+  {
+    Fixture f;
+    CatalogRelation keys(113, "keys"), result(114, "result");
+    keys.addAttribute("k", Type::Int());
+    std::int32_t k[kNumTuplesPerBlock];
+    for (tuple_id t = 0; t < kNumTuplesPerBlock; ++t) k[t] = t % 7;
+    f.storage.loadBlock(&keys, {k}, kNumTuplesPerBlock);
+    result.addAttribute("k", Type::Int());
+    result.addAttribute("count", Type::Long());
+    QueryContext ctx;
+    AggregationStateSpec spec;
+    spec.input_relation = &keys;
+    spec.group_by = {0};
+    spec.aggregates = {{AggregationID::kCount, kInvalidAttributeID}};
+    const auto hashed = ctx.addAggregationState(spec);
+    InitializeAggregationOperator bad(0, hashed, 1, 1);
+    bool threw = false;
+    try {
+      fetchAndExecuteWorkOrders(&bad, &ctx, &f.storage);
+    } catch (const ExecutionError &e) {
+      threw = e.status() == QSX_ERR_UNSUPPORTED;
+    }
+    EXPECT_TRUE(threw);
+    spec.strategy = QSX_AGG_COLLISION_FREE;
+    spec.collision_free_num_entries = 7;
+    const auto dense = ctx.addAggregationState(spec);
+    const auto dest = ctx.addInsertDestination(&result, &f.storage);
+    AggregationOperator once(0, keys, true, dense), again(0, keys, true, dense);
+    fetchAndExecuteWorkOrders(&once, &ctx, &f.storage);
+    InitializeAggregationOperator init(0, dense, 1, 4);
+    fetchAndExecuteWorkOrders(&init, &ctx, &f.storage);      // what the first pass counted is gone
+    fetchAndExecuteWorkOrders(&again, &ctx, &f.storage);
+    FinalizeAggregationOperator fin(0, dense, 1, false, 1, result, dest);
+    fetchAndExecuteWorkOrders(&fin, &ctx, &f.storage);
+    std::size_t rows;
+    auto cols = readAll(ctx, dest, f.storage, result, &rows);
+    EXPECT_EQ(rows, static_cast<std::size_t>(7));
+    for (std::size_t i = 0; i < rows; ++i) {
+      const int key = at<std::int32_t>(cols[0], i);
+      std::int64_t want = 0;
+      for (tuple_id t = 0; t < kNumTuplesPerBlock; ++t) want += (t % 7) == key;
+      EXPECT_EQ(at<std::int64_t>(cols[1], i), want);
     }
   }
   // ---- DISTINCT aggregates: query_optimizer/tests/execution_generator/Distinct.test -----------------------------------
