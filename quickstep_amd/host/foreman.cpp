@@ -287,6 +287,7 @@ void ForemanSingleNode::run() {
               blocks_fed[op] == query_context_->getInsertDestination(dest_id)->getTouchedBlocks().size()) {
             finished[op] = true;
             progress = true;
+            producer->updateCatalogOnCompletion();   // QueryManagerBase.cpp:184 (markOperatorFinished)
             for (std::size_t consumer = 0; consumer < N; ++consumer) {
               for (const QueryPlan::Edge &e : plan_->dependencies(consumer)) {
                 if (e.producer == op && !e.breaker) {

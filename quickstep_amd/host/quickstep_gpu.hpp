@@ -688,6 +688,11 @@ class RelationalOperator {
   std::size_t getOperatorIndex() const { return op_index_; }
   std::size_t getQueryID() const { return query_id_; }
   std::size_t getNumPartitions() const { return num_partitions_; }
+  bool hasRepartition() const { return has_repartition_; }                       // :278
+  std::size_t getOutputNumPartitions() const { return output_num_partitions_; }  // :287
+  // :164 — called by the query manager when the operator has finished; none of the operators here touches the catalog
+  // at that point (the reference's overriders are the DDL / load operators)
+  virtual void updateCatalogOnCompletion() {}
 
  protected:
   explicit RelationalOperator(std::size_t query_id, std::size_t num_partitions = 1, bool has_repartition = false,
