@@ -37,6 +37,43 @@ __global__ __launch_bounds__(BLOCK) void read_kernel(const u64x2 *__restrict__ d
   if (acc == 0x1234567ull) atomicAdd(out, acc);   // (keeps the loads)
 }
 
+// The same bytes with every workgroup walking a contiguous chunk of its own (what a stable partition pass does: workgroup b
+// owns rows [b * chunk, (b + 1) * chunk)) instead of the tiles being dealt round-robin: G streams far apart instead of one front.
+template <int BLOCK, int U, bool NT>
+__global__ __launch_bounds__(BLOCK) void read_chunked_kernel(const u64x2 *__restrict__ data, int64_t vecs, unsigned long long *__restrict__ out) {
+  constexpr int kTile = BLOCK * U;
+  const int64_t tiles = vecs / kTile, per_block = (tiles + gridDim.x - 1) / gridDim.x;
+  const int64_t first = blockIdx.x * per_block, last = first + per_block < tiles ? first + per_block : tiles;
+  unsigned long long acc = 0;
+  for (int64_t tile = first; tile < last; ++tile) {
+    u64x2 v[U];
+    const u64x2 *p = data + tile * kTile + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + u * BLOCK) : p[u * BLOCK];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u].x ^ v[u].y;
+  }
+  if (acc == 0x1234567ull) atomicAdd(out, acc);
+}
+
+template <int BLOCK, int U, bool NT>
+static void run_chunked(const u64x2 *data, int64_t vecs, unsigned long long *out, int grid, hipEvent_t a, hipEvent_t b) {
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL((read_chunked_kernel<BLOCK, U, NT>), dim3(grid), dim3(BLOCK), 0, 0, data, vecs, out);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    if (rep > 0 && ms < best) best = ms;
+  }
+  const double bytes = static_cast<double>(vecs / (BLOCK * U)) * (BLOCK * U) * 16.0;
+  printf("{\"chunk_per_workgroup\": true, \"block\": %d, \"loads_in_flight\": %d, \"nontemporal\": %s, \"workgroups\": %d, \"ms\": %.3f, \"GBps\": %.0f}\n",
+         BLOCK, U, NT ? "true" : "false", grid, best, bytes / best / 1e6);
+  fflush(stdout);
+}
+
 template <int BLOCK, int U, int STREAMS, bool NT>
 static void run(const u64x2 *data, int64_t vecs, unsigned long long *out, int per_cu, hipEvent_t a, hipEvent_t b) {
   const int64_t per_stream = vecs / STREAMS;
@@ -69,6 +106,10 @@ int main(int argc, char **argv) {
   hipEvent_t a, b;
   CHECK(hipEventCreate(&a));
   CHECK(hipEventCreate(&b));
+  for (int grid : {256, 512, 1024, 2048, 8192}) {
+    run_chunked<256, 4, false>(data, vecs, out, grid, a, b);
+    run_chunked<256, 4, true>(data, vecs, out, grid, a, b);
+  }
   for (int per_cu : {1, 2, 4, 8}) {
     run<256, 4, 1, false>(data, vecs, out, per_cu, a, b);
     run<256, 4, 1, true>(data, vecs, out, per_cu, a, b);
