@@ -316,9 +316,11 @@ bool compile_with_driver(const std::string &source, std::string *code, std::stri
     ok = posix_spawn(&pid, driver.c_str(), &actions, nullptr, const_cast<char *const *>(argv), environ) == 0;
     posix_spawn_file_actions_destroy(&actions);
     if (ok) {
-      while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+      pid_t waited = -1;
+      while ((waited = waitpid(pid, &status, 0)) < 0 && errno == EINTR) {
       }
-      ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
+      // (a host that ignores SIGCHLD reaps the child itself: no status to read then — whether the code object is there decides)
+      ok = waited < 0 ? errno == ECHILD : (WIFEXITED(status) && WEXITSTATUS(status) == 0);
     }
   }
   if (ok) {
