@@ -120,6 +120,59 @@ __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key
   __syncthreads();
   const int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
   const int64_t end = begin + rows_per_block < n ? begin + rows_per_block : n;
+  if constexpr (kSmallP && std::is_same<Loader, ColumnKey<int32_t>>::value) {
+    // Counts need no row order: four keys per 16-byte read, a thread's counts of the (at most 8) partitions packed into the
+    // bytes of one register and unpacked every 63 reads (252 < 256).  The ranking form below reads 4 bytes per lane and
+    // spends three ballots per 64 rows on ranks nobody asks for here: 0.145 ms per 100 M keys against 0.07.
+    const int32_t *keys = load_key.keys;
+    if ((reinterpret_cast<uintptr_t>(keys) & 15) == 0) {   // (begin is a multiple of the tile: 16-byte aligned with the stripe)
+      unsigned long long packed = 0;
+      unsigned int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      auto unpack = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) cnt[p] += static_cast<unsigned int>(packed >> (8 * p)) & 255u;
+        packed = 0;
+      };
+      // whole 16-byte groups of the chunk (a trailing workgroup's chunk may lie behind the stripe: nothing to count)
+      const int64_t first = begin >> 2, last = begin < end ? end >> 2 : first;
+      int since = 0;
+      constexpr int U = 4;
+      for (int64_t v0 = first + threadIdx.x; v0 < last; v0 += static_cast<int64_t>(kPBlock) * U) {
+        uint4 k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t v = v0 + static_cast<int64_t>(u) * kPBlock;
+          k[u] = reinterpret_cast<const uint4 *>(keys)[v < last ? v : last - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (v0 + static_cast<int64_t>(u) * kPBlock < last) {
+            packed += 1ull << (8 * partition_of<MODE>(k[u].x, P, pow2));
+            packed += 1ull << (8 * partition_of<MODE>(k[u].y, P, pow2));
+            packed += 1ull << (8 * partition_of<MODE>(k[u].z, P, pow2));
+            packed += 1ull << (8 * partition_of<MODE>(k[u].w, P, pow2));
+          }
+        }
+        since += U;
+        if (since + U > 63) {
+          unpack();
+          since = 0;
+        }
+      }
+      for (int64_t row = (last << 2) + threadIdx.x; begin < end && row < end; row += kPBlock) {   // (the stripe's last, partial group)
+        packed += 1ull << (8 * partition_of<MODE>(load_key(row), P, pow2));
+      }
+      unpack();
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const unsigned int total = wave_reduce_add(cnt[p]);
+        if (lane == 0 && total != 0 && p < P) atomicAdd(&s_total[p], static_cast<int>(total));
+      }
+      __syncthreads();
+      if (threadIdx.x < P) hist[static_cast<int64_t>(threadIdx.x) * G + blockIdx.x] = s_total[threadIdx.x];
+      return;
+    }
+  }
   int my_count = 0;  // lane p counts partition p
   for (int64_t tile = begin; tile < end; tile += kPTile) {
     int pid[kPSteps];
