@@ -341,6 +341,169 @@ __global__ __launch_bounds__(kPBlock) void partition_scatter_kernel(Loader load_
   }
 }
 
+// The scatter pass for at most 8 partitions whose columns fit the staging area side by side (the shuffle of a join side
+// across the GPUs of a node: key + a few payload columns into 8).  Same result as partition_scatter_kernel — stable, one
+// contiguous run per partition per tile — with three workgroup barriers per tile instead of 4 + 2 per column: after the
+// cell counts are in LDS every wave derives the offsets of its own rows by itself (lane p walks partition p's 32 cells and
+// the partitions' totals are scanned across 8 lanes), and all columns are staged before the one barrier that precedes the
+// copy-out.  The general kernel spends its time in those barriers, not on bytes (open items).
+struct SmallScatterLayout {
+  int stage_off[QSX_MAX_COLUMNS];   // byte offset of column c's slots in the staging area
+};
+// (PT == 8, the shuffle's form, fits 80 registers without scratch: six waves per SIMD instead of five)
+template <typename Loader, int MODE, int PT = 0>
+__global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8 ? 6 : 4))) void partition_scatter_small_kernel(Loader load_key, int64_t n, int P_arg, int pow2,
+                                                                         int64_t rows_per_block, int64_t G,
+                                                                         const int64_t *__restrict__ starts, ScatterArgs args,
+                                                                         SmallScatterLayout layout, int stage_bytes,
+                                                                         int64_t *__restrict__ out_offsets) {
+  const int P = PT > 0 ? PT : P_arg;
+  extern __shared__ __attribute__((aligned(8))) unsigned char s_dyn[];
+  unsigned char *s_stage = s_dyn;
+  int *s_cnt = reinterpret_cast<int *>(s_dyn + stage_bytes);   // [cell][partition], cell = step * kPWaves + wave: row order
+  __shared__ int s_part_start[kWave + 1];
+  __shared__ long long s_glob[kWave];
+  __shared__ unsigned char s_pid[kPTile];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && out_offsets != nullptr) {
+    if (threadIdx.x < P) out_offsets[threadIdx.x] = starts[static_cast<int64_t>(threadIdx.x) * G];
+    if (threadIdx.x == 0) out_offsets[P] = n;
+  }
+  if (threadIdx.x < P) s_glob[threadIdx.x] = starts[static_cast<int64_t>(threadIdx.x) * G + blockIdx.x];
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  const int64_t end = begin + rows_per_block < n ? begin + rows_per_block : n;
+  using KeyValue = decltype(load_key(static_cast<int64_t>(0)));
+  KeyValue key[kPSteps], next_key[kPSteps];
+#pragma unroll
+  for (int j = 0; j < kPSteps; ++j) {
+    const int64_t r = begin + j * kPBlock + threadIdx.x;
+    key[j] = r < end ? load_key(r) : KeyValue();
+  }
+  for (int64_t tile = begin; tile < end; tile += kPTile) {
+    const int tile_rows = static_cast<int>(end - tile < kPTile ? end - tile : kPTile);
+    int64_t row[kPSteps];
+    int pid[kPSteps], pos[kPSteps];
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
+      const int64_t r = tile + kPTile + j * kPBlock + threadIdx.x;
+      next_key[j] = r < end ? load_key(r) : KeyValue();
+    }
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
+      row[j] = tile + j * kPBlock + threadIdx.x;
+      pid[j] = row[j] < end ? partition_of<MODE>(key[j], P, pow2) : -1;
+      key[j] = next_key[j];
+    }
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
+      int count;
+      step_ranks<true>(pid[j], P, pos[j], count);
+      if (lane < P) s_cnt[(j * kPWaves + wave) * P + lane] = count;
+    }
+    __syncthreads();   // (1) the cell counts
+    {
+      // lane 8 j + p holds (step j, partition p): the four waves' cells of that step, then an exclusive scan over the steps
+      // (lanes 8 apart) — the rows of partition p in front of this wave's cell of step j — and, in the last step's lanes, the
+      // partition's total, scanned over the 8 partitions for their starts.  (Walking a partition's 32 cells in one lane
+      // kept 32 registers in flight: 116 VGPRs, four waves per SIMD.)
+      static_assert(kPSteps == 8 && kPWaves == 4, "the (step, partition) lane layout below");
+      const int cell_step = lane >> 3, cell_part = lane & 7;
+      int in_step_before = 0, step_total = 0;
+#pragma unroll
+      for (int w = 0; w < kPWaves; ++w) {
+        const int c = cell_part < P ? s_cnt[(cell_step * kPWaves + w) * P + cell_part] : 0;
+        if (w == wave) in_step_before = step_total;
+        step_total += c;
+      }
+      int incl = step_total;
+#pragma unroll
+      for (int off = 8; off < kWave; off <<= 1) {
+        const int up = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += up;
+      }
+      const int before_cell = incl - step_total + in_step_before;   // rows of (partition) in front of (step, this wave)
+      // totals: lanes 56 + p
+      int total = __shfl(incl, 56 + cell_part, kWave);
+      int scan = cell_step == 0 ? total : 0;                         // lanes 0..7 scan the 8 totals
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) {
+        const int up = __shfl_up(scan, off, kWave);
+        if (lane >= off && lane < 8) scan += up;
+      }
+      const int start_of_part = __shfl(scan - total, cell_part, kWave);   // exclusive: lane p of the first row of lanes
+      if (wave == 0 && lane < 8) {
+        if (lane < P) s_part_start[lane] = scan - total;
+        if (lane == P - 1) s_part_start[P] = scan;
+      }
+      const int cell_base = start_of_part + before_cell;
+#pragma unroll
+      for (int j = 0; j < kPSteps; ++j) {
+        const int base = __shfl(cell_base, (j << 3) + (pid[j] >= 0 ? pid[j] : 0), kWave);
+        pos[j] += base;
+        if (pid[j] >= 0) s_pid[pos[j]] = static_cast<unsigned char>(pid[j]);
+      }
+    }
+    for (int c = 0; c < args.ncols; ++c) {   // every column into its own part of the staging area: no barrier in between
+      unsigned char *stage = s_stage + layout.stage_off[c];
+      switch (args.width[c]) {
+        case 1: {
+          uint8_t v[kPSteps];
+#pragma unroll
+          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint8_t *>(args.src[c])[row[j]]) : uint8_t(0);
+#pragma unroll
+          for (int j = 0; j < kPSteps; ++j) if (pid[j] >= 0) reinterpret_cast<uint8_t *>(stage)[pos[j]] = v[j];
+          break;
+        }
+        case 2: {
+          uint16_t v[kPSteps];
+#pragma unroll
+          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint16_t *>(args.src[c])[row[j]]) : uint16_t(0);
+#pragma unroll
+          for (int j = 0; j < kPSteps; ++j) if (pid[j] >= 0) reinterpret_cast<uint16_t *>(stage)[pos[j]] = v[j];
+          break;
+        }
+        case 4: {
+          uint32_t v[kPSteps];
+#pragma unroll
+          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint32_t *>(args.src[c])[row[j]]) : 0u;
+#pragma unroll
+          for (int j = 0; j < kPSteps; ++j) if (pid[j] >= 0) reinterpret_cast<uint32_t *>(stage)[pos[j]] = v[j];
+          break;
+        }
+        default: {
+          uint64_t v[kPSteps];
+#pragma unroll
+          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint64_t *>(args.src[c])[row[j]]) : 0ull;
+#pragma unroll
+          for (int j = 0; j < kPSteps; ++j) if (pid[j] >= 0) reinterpret_cast<uint64_t *>(stage)[pos[j]] = v[j];
+          break;
+        }
+      }
+    }
+    __syncthreads();   // (2) slots, their partitions, the partitions' starts
+#pragma unroll
+    for (int j = 0; j < kPSteps; ++j) {
+      const int i = j * kPBlock + threadIdx.x;
+      if (i < tile_rows) {
+        const int p = s_pid[i];
+        const long long at = s_glob[p] + (i - s_part_start[p]);
+        for (int c = 0; c < args.ncols; ++c) {
+          const unsigned char *stage = s_stage + layout.stage_off[c];
+          switch (args.width[c]) {
+            case 1: store_global(reinterpret_cast<const uint8_t *>(stage)[i], &static_cast<uint8_t *>(args.dst[c])[at]); break;
+            case 2: store_global(reinterpret_cast<const uint16_t *>(stage)[i], &static_cast<uint16_t *>(args.dst[c])[at]); break;
+            case 4: store_global(reinterpret_cast<const uint32_t *>(stage)[i], &static_cast<uint32_t *>(args.dst[c])[at]); break;
+            default: store_global(reinterpret_cast<const uint64_t *>(stage)[i], &static_cast<uint64_t *>(args.dst[c])[at]); break;
+          }
+        }
+      }
+    }
+    __syncthreads();   // (3) the staging area and the starts are free again
+    if (threadIdx.x < P) s_glob[threadIdx.x] += s_part_start[threadIdx.x + 1] - s_part_start[threadIdx.x];
+  }
+}
+
 // Internal re-partitioning with aligned pieces: every partition's run starts at a multiple of `align` rows of the
 // output (so that a consumer can DMA 16-byte chunks of any column straight out of a piece); the gaps are never
 // read.  Rewrites the (partition, workgroup) start cells in place and publishes pieces[p] = start row,
@@ -381,10 +544,14 @@ __global__ __launch_bounds__(1024) void align_starts_kernel(int64_t *__restrict_
 static size_t p_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int64_t blocks_for(int64_t n) {
-  // whole 4096-row tiles per workgroup, at most 2048 workgroups
+  // whole tiles per workgroup, at most 4096 workgroups
   int64_t G = (n + kPTile - 1) / kPTile;
   if (G < 1) G = 1;
-  if (G > kMaxGridBlocks) G = kMaxGridBlocks;
+  // 4096 chunks: twice what is resident at most — the second half fills in behind workgroups that finish early (2048, one
+  // chunk per resident workgroup of the lightest kernel, left the tail to the slowest chunk: 0.70 against 0.67 ms per 100 M
+  // rows of (key, tid)); QSX_K9_GRID: sweeps
+  static const int64_t cap = getenv("QSX_K9_GRID") != nullptr && atoll(getenv("QSX_K9_GRID")) > 0 ? atoll(getenv("QSX_K9_GRID")) : 2 * kMaxGridBlocks;
+  if (G > cap) G = cap;
   return G;
 }
 
@@ -422,6 +589,28 @@ static int launch_partition_t(Loader keys, int64_t n, int P, int pow2, const Sca
     hipLaunchKernelGGL(align_starts_kernel, dim3(1), dim3(1024), 0, s, starts, P, G, n, align_rows, out_offsets);
     QSX_CHECK_LAUNCH();
     block0_offsets = nullptr;   // out_offsets holds the pieces (start, count) instead of P + 1 boundaries
+  }
+  if (P <= 8 && args.ncols > 0) {
+    // all columns staged side by side (8-byte aligned parts): up to 48 KiB of staging keeps three workgroups on a CU
+    SmallScatterLayout layout{};
+    int stage_bytes = 0;
+    for (int c = 0; c < args.ncols; ++c) {
+      layout.stage_off[c] = stage_bytes;
+      stage_bytes += (kPTile * args.width[c] + 7) & ~7;
+    }
+    static const bool small_off = getenv("QSX_K9_SMALL") != nullptr && atoi(getenv("QSX_K9_SMALL")) == 0;
+    if (stage_bytes <= 48 * 1024 && !small_off) {
+      const size_t small_lds = static_cast<size_t>(stage_bytes) + sizeof(int) * kPCells * P;
+      if (P == 8) {
+        hipLaunchKernelGGL((partition_scatter_small_kernel<Loader, MODE, 8>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), small_lds, s,
+                           keys, n, P, pow2, rows_per_block, G, starts, args, layout, stage_bytes, block0_offsets);
+      } else {
+        hipLaunchKernelGGL((partition_scatter_small_kernel<Loader, MODE>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), small_lds, s,
+                           keys, n, P, pow2, rows_per_block, G, starts, args, layout, stage_bytes, block0_offsets);
+      }
+      QSX_CHECK_LAUNCH();
+      return QSX_OK;
+    }
   }
   int stage_width = 1;
   for (int c = 0; c < args.ncols; ++c) stage_width = args.width[c] > stage_width ? args.width[c] : stage_width;
