@@ -67,6 +67,24 @@ def test_partition_scatter_is_stable_and_matches_oracle(capi, oracle, dev, dtype
         assert np.array_equal(got.cpu().numpy(), oracle.partition_scatter(keys, P, col) if n else col)
 
 
+@pytest.mark.parametrize("P", [2, 5, 8])
+@pytest.mark.parametrize("num_wide", [0, 7])
+def test_partition_scatter_few_partitions_both_kernels(capi, oracle, dev, P, num_wide):
+    """<= 8 partitions: the scatter kernel that stages all columns side by side (csrc/partition.hip,
+    partition_scatter_small_kernel) while they fit 48 KiB of staging — key + 2-byte + 1-byte columns here — and the general
+    kernel when they do not (seven more 8-byte columns).  Both stable, both equal to the oracle's partition; sizes on both
+    sides of the chunking (one tile, a few thousand chunks, a ragged last tile)."""
+    for n in (1, 2047, 2049, 300_001, 9_000_001):
+        rng = np.random.default_rng(n + P + num_wide)
+        keys = rng.integers(-50, 1 << 30, size=n).astype(np.int32)
+        cols = [keys, rng.integers(0, 65535, size=n).astype(np.uint16), rng.integers(0, 255, size=n).astype(np.uint8)]
+        cols += [rng.integers(0, 2**62, size=n).astype(np.int64) for _ in range(num_wide)]
+        outs, offs = capi.partition_scatter(to_dev(keys, dev), P, [to_dev(c, dev) for c in cols])
+        assert np.array_equal(offs.cpu().numpy(), oracle.partition_offsets(keys, P))
+        for got, col in zip(outs, cols):
+            assert np.array_equal(got.cpu().numpy(), oracle.partition_scatter(keys, P, col))
+
+
 @pytest.mark.parametrize("kind,anti,card", [(T.LIP_BITVECTOR_EXACT, False, 1_000_000), (T.LIP_BITVECTOR_EXACT, True, 999_937),
                                             (T.LIP_SINGLE_IDENTITY_HASH, False, 1_048_573), (T.LIP_BITVECTOR_EXACT, False, 3_000_000)])
 def test_lip_probe_at_scale_lds_resident_filter(capi, oracle, dev, kind, anti, card):
