@@ -120,11 +120,14 @@ __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key
   __syncthreads();
   const int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
   const int64_t end = begin + rows_per_block < n ? begin + rows_per_block : n;
-  if constexpr (kSmallP && std::is_same<Loader, ColumnKey<int32_t>>::value) {
-    // Counts need no row order: four keys per 16-byte read, a thread's counts of the (at most 8) partitions packed into the
-    // bytes of one register and unpacked every 63 reads (252 < 256).  The ranking form below reads 4 bytes per lane and
-    // spends three ballots per 64 rows on ranks nobody asks for here: 0.145 ms per 100 M keys against 0.07.
-    const int32_t *keys = load_key.keys;
+  constexpr bool kIntKeys = std::is_same<Loader, ColumnKey<int32_t>>::value;
+  if constexpr (kSmallP && (kIntKeys || std::is_same<Loader, ColumnKey<int64_t>>::value)) {
+    // Counts need no row order: four (INT) or two (LONG) keys per 16-byte read, a thread's counts of the (at most 8)
+    // partitions packed into the bytes of one register and unpacked every 63 reads (252 < 256).  The ranking form below
+    // reads one key per lane and spends three ballots per 64 rows on ranks nobody asks for here: 0.145 ms per 100 M INT keys
+    // against 0.09.
+    constexpr int kShift = kIntKeys ? 2 : 1;   // log2 of the keys per 16 bytes
+    const auto *keys = load_key.keys;
     if ((reinterpret_cast<uintptr_t>(keys) & 15) == 0) {   // (begin is a multiple of the tile: 16-byte aligned with the stripe)
       unsigned long long packed = 0;
       unsigned int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key
         packed = 0;
       };
       // whole 16-byte groups of the chunk (a trailing workgroup's chunk may lie behind the stripe: nothing to count)
-      const int64_t first = begin >> 2, last = begin < end ? end >> 2 : first;
+      const int64_t first = begin >> kShift, last = begin < end ? end >> kShift : first;
       int since = 0;
       constexpr int U = 4;
       for (int64_t v0 = first + threadIdx.x; v0 < last; v0 += static_cast<int64_t>(kPBlock) * U) {
@@ -147,10 +150,15 @@ __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (v0 + static_cast<int64_t>(u) * kPBlock < last) {
-            packed += 1ull << (8 * partition_of<MODE>(k[u].x, P, pow2));
-            packed += 1ull << (8 * partition_of<MODE>(k[u].y, P, pow2));
-            packed += 1ull << (8 * partition_of<MODE>(k[u].z, P, pow2));
-            packed += 1ull << (8 * partition_of<MODE>(k[u].w, P, pow2));
+            if constexpr (kIntKeys) {
+              packed += 1ull << (8 * partition_of<MODE>(k[u].x, P, pow2));
+              packed += 1ull << (8 * partition_of<MODE>(k[u].y, P, pow2));
+              packed += 1ull << (8 * partition_of<MODE>(k[u].z, P, pow2));
+              packed += 1ull << (8 * partition_of<MODE>(k[u].w, P, pow2));
+            } else {
+              packed += 1ull << (8 * partition_of<MODE>(k[u].x | (static_cast<unsigned long long>(k[u].y) << 32), P, pow2));
+              packed += 1ull << (8 * partition_of<MODE>(k[u].z | (static_cast<unsigned long long>(k[u].w) << 32), P, pow2));
+            }
           }
         }
         since += U;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key
           since = 0;
         }
       }
-      for (int64_t row = (last << 2) + threadIdx.x; begin < end && row < end; row += kPBlock) {   // (the stripe's last, partial group)
+      for (int64_t row = (last << kShift) + threadIdx.x; begin < end && row < end; row += kPBlock) {   // (the stripe's last, partial group)
         packed += 1ull << (8 * partition_of<MODE>(load_key(row), P, pow2));
       }
       unpack();
