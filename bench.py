@@ -35,11 +35,57 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def self_launch():
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves — a CHILD process running
+    torch.distributed.run (one rank per GPU over RCCL), started before this process has imported torch or touched the GPU
+    (never an exec: a GPU-initialised process must not replace its program on this pool) — relay what the ranks print (rank
+    0's JSON line is the last line of stdout) and exit with the launcher's status.  Under torch.distributed.run (WORLD_SIZE
+    set) this is a no-op."""
+    n = 1
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["QSX_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    last_json = None
+    for ln in child.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            last_json = ln           # held back so that it is the LAST line this process prints
+        else:
+            sys.stdout.write(ln)
+    rc = child.wait()
+    sys.stdout.flush()
+    if last_json is not None:
+        sys.stdout.write(last_json)
+        sys.stdout.flush()
+    sys.exit(rc if rc != 0 or last_json is not None else 1)
+
+
+if __name__ == "__main__":
+    self_launch()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
 sys.path.insert(0, ROOT)
 
 import quickstep_amd.capi as capi  # noqa: E402
@@ -451,7 +497,7 @@ def run_headline(ctx, args):
     if distributed and plan == "shuffle":
         moved = join.shuffled_bytes * (world - 1) / max(world, 1)
         sh_s = (phase_ms["shuffle_build"] + phase_ms["shuffle_probe"]) / 1e3
-        line["alltoall"] = {"bytes_per_rank_per_step": moved, "GBps_per_rank_over_shuffle_phases": moved / sh_s / 1e9,
+        line["alltoall"] = {"bytes_per_rank_per_step": moved, "GBps_per_rank": moved / sh_s / 1e9, "GBps_per_rank_over_shuffle_phases": moved / sh_s / 1e9,
                             "peak_GBps_per_rank": XGMI_PEAK_GBS,
                             "note": "phases include K9 scatter, counts exchange, build / probe kernels"}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
@@ -620,7 +666,7 @@ def run_c4(ctx, args):
         "roofline": {"kernel": "whole step (K9 partition_scatter x2, build, probe, K5 gathers)", "bound": "hbm",
                      "achieved": algo / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / step_s / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_step": algo, "traffic": None},
-        "alltoall": {"bytes_sent_per_rank_per_step": moved, "GBps_per_rank_over_step": moved / step_s / 1e9,
+        "alltoall": {"bytes_sent_per_rank_per_step": moved, "GBps_per_rank": moved / step_s / 1e9, "GBps_per_rank_over_step": moved / step_s / 1e9,
                      "peak_GBps_per_rank": XGMI_PEAK_GBS},
         "phases_ms": phase_ms,
     }
@@ -759,6 +805,9 @@ def main():
     ap.add_argument("--no-operators", action="store_true", help="N = 1: skip the leg that runs the workload through the C++ operator layer")
     ap.add_argument("--operator-workers", type=int, default=8)
     ap.add_argument("--blocks-per-work-order", type=int, default=256)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch check without a GPU: the ranks rendezvous over gloo, agree on the world size and rank 0 prints a "
+                         "line with no measurement in it (tests/test_bench_launch.py)")
     args = ap.parse_args()
 
     ctx = Ctx()
@@ -766,7 +815,20 @@ def main():
     ctx.rank = rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} was launched with WORLD_SIZE={world}: the rank count must equal --gpus")
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            seen = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(seen)
+            world_seen = int(seen.item())
+            dist.destroy_process_group()
+        else:
+            world_seen = 1
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "dry_run": True, "n_gpus": args.gpus, "world_size_seen": world_seen,
+                              "self_launched": os.environ.get("QSX_BENCH_SELF_LAUNCHED") == "1", "config": {"workload": args.config}}), flush=True)
+        return
     torch.cuda.set_device(local_rank)
     ctx.dev = dev = torch.device("cuda", local_rank)
     if capi.device_count() < 1:
@@ -787,6 +849,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     line = {"headline": run_headline, "c4": run_c4, "c5": run_c5}[args.config](ctx, args)
+    line["world_size_seen"] = dist.get_world_size() if ctx.distributed else 1      # what the RCCL process group reports
+    line["self_launched"] = os.environ.get("QSX_BENCH_SELF_LAUNCHED") == "1"
     if rank == 0 and world == 1 and args.config == "headline" and not args.no_operators:
         line["operators"] = operators_leg(args, line["value"])
         variants = line.get("probe", {}).get("variants", {})

@@ -1,0 +1,41 @@
+"""bench.py --gpus N started as a plain `python bench.py` (no rank environment) launches its own N ranks as child
+processes (VERDICT r03 missing 2).  --dry-run keeps the GPU out of it: the ranks rendezvous over gloo and rank 0 prints
+the line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"] + extra, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    return json.loads(lines[-1])        # the JSON line is the LAST line of stdout
+
+
+def test_plain_python_bench_launches_its_ranks():
+    for n, cfg in ((2, "headline"), (3, "c4")):
+        line = _run(["--gpus", str(n), "--config", cfg, "--steps", "1", "--warmup", "0"])
+        assert line["n_gpus"] == n and line["world_size_seen"] == n and line["self_launched"] is True
+        assert line["config"]["workload"] == cfg
+
+
+def test_one_gpu_needs_no_launcher():
+    line = _run(["--gpus", "1"])
+    assert line["n_gpus"] == 1 and line["world_size_seen"] == 1 and line["self_launched"] is False
+
+
+def test_under_torch_distributed_run_nothing_is_relaunched():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["world_size_seen"] == 2 and line["self_launched"] is False
