@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
-#define QSX_ABI_VERSION 10
+#define QSX_ABI_VERSION 11
 
 typedef void *qsx_stream_t;
 
@@ -945,6 +945,15 @@ int qsx_bitmap_allreduce_or(qsx_comm_t *comm, uint64_t *words_dev, int64_t num_w
  * else — finalize with qsx_agg_finalize(state, rank, world, ...).  Replaces the shared atomics of
  * CollisionFreeVectorTable (storage/CollisionFreeVectorTable.hpp:530-645) across address spaces. */
 int qsx_agg_reduce_scatter(qsx_comm_t *comm, qsx_agg_state_t *state, qsx_stream_t stream);
+/* The key range [begin, end) that finalize partition `partition` of `num_partitions` owns in a COLLISION_FREE state of
+ * `num_entries` keys (storage/CollisionFreeVectorTable.hpp:192-208: contiguous ranges of ceil(entries / partitions) keys),
+ * the LSB-first existence words [first_word, last_word) covering it (both 0 for an empty range) and the masks that cut the
+ * range out of its first and last word.  qsx_agg_finalize and qsx_agg_reduce_scatter split by this very function; a
+ * caller that moves image ranges itself (quickstep_amd/distributed.py over torch.distributed) takes the split from here
+ * instead of restating it.  Host arithmetic only: needs no device; any out pointer may be NULL. */
+int qsx_agg_dense_partition_range(int64_t num_entries, int num_partitions, int partition, int64_t *out_begin, int64_t *out_end,
+                                  int64_t *out_first_word, int64_t *out_last_word, uint64_t *out_first_mask,
+                                  uint64_t *out_last_mask);
 /* Hash-strategy state: afterwards every rank holds the whole merged table (AggregationOperationState.cpp:925-948's merge
  * of the thread-private tables, across ranks).  Synchronises on `stream`. */
 int qsx_agg_allgather_merge(qsx_comm_t *comm, qsx_agg_state_t *state, qsx_stream_t stream);

@@ -143,6 +143,8 @@ _SIGNATURES = {
     "qsx_bitmap_allreduce_or": (_int, [_vp, _vp, _i64, _vp]),
     "qsx_agg_reduce_scatter": (_int, [_vp, _vp, _vp]),
     "qsx_agg_allgather_merge": (_int, [_vp, _vp, _vp]),
+    "qsx_agg_dense_partition_range": (_int, [_i64, _int, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
+                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "qsx_partition_workspace_bytes": (_sz, [_i64, _int]),
     "qsx_partition_scatter": (_int, [_int, _vp, _i64, _int, _int, _pp, C.POINTER(_i32), _pp, _vp, _vp, _sz, _vp]),
 }
@@ -1013,6 +1015,17 @@ def partition_scatter(keys, num_partitions, cols, stream=None):
 
 
 # --------------------------------------------------------------------------- multi-GPU (RCCL behind the C ABI)
+def dense_partition_range(num_entries, num_partitions, partition):
+    """qsx_agg_dense_partition_range (host arithmetic, needs no device): (begin, end, first_word, last_word, first_mask,
+    last_mask) of finalize partition `partition` of a COLLISION_FREE state — the split qsx_agg_finalize and
+    qsx_agg_reduce_scatter use."""
+    b, e, fw, lw = _i64(), _i64(), _i64(), _i64()
+    fm, lm = C.c_uint64(), C.c_uint64()
+    _check(_lib.qsx_agg_dense_partition_range(num_entries, num_partitions, partition, C.byref(b), C.byref(e), C.byref(fw), C.byref(lw),
+                                              C.byref(fm), C.byref(lm)), "qsx_agg_dense_partition_range")
+    return b.value, e.value, fw.value, lw.value, fm.value, lm.value
+
+
 class Comm:
     """qsx_comm_t: one per rank.  unique_id() on rank 0, carried to the other ranks by the caller's control plane
     (torch.distributed's store, an engine's message bus), then Comm(world, rank, id_bytes) on every rank's own device."""
@@ -1040,16 +1053,21 @@ class Comm:
         _check(_lib.qsx_exchange_counts(self._h, _ptr(send_counts), _ptr(recv), _stream(stream)), "qsx_exchange_counts")
         return recv
 
-    def alltoallv(self, col, send_rows, recv_rows, stream=None):
+    def alltoallv(self, col, send_rows, recv_rows, stream=None, out=None):
         """col: rows for rank 0, then rank 1, ... (qsx_partition_scatter's layout); returns the rows received, in rank order."""
-        out = torch.empty(int(sum(recv_rows)), dtype=col.dtype, device=col.device)
+        if out is None:
+            out = torch.empty(int(sum(recv_rows)), dtype=col.dtype, device=col.device)
+        assert out.numel() == int(sum(recv_rows)) and col.numel() >= int(sum(send_rows)) and out.dtype == col.dtype
+        assert col.is_contiguous() and out.is_contiguous()
         sr = (C.c_int64 * self.world)(*[int(x) for x in send_rows])
         rr = (C.c_int64 * self.world)(*[int(x) for x in recv_rows])
         _check(_lib.qsx_alltoallv(self._h, col.element_size(), _ptr(col), sr, _ptr(out), rr, _stream(stream)), "qsx_alltoallv")
         return out
 
-    def allgather(self, t, stream=None):
-        out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+    def allgather(self, t, stream=None, out=None):
+        if out is None:
+            out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+        assert out.numel() == self.world * t.numel() and out.dtype == t.dtype and out.is_contiguous() and t.is_contiguous()
         _check(_lib.qsx_allgather(self._h, _ptr(t), t.numel() * t.element_size(), _ptr(out), _stream(stream)), "qsx_allgather")
         return out
 

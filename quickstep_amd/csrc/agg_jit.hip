@@ -313,7 +313,21 @@ bool compile_with_driver(const std::string &source, std::string *code, std::stri
     posix_spawn_file_actions_adddup2(&actions, 1, 2);
     pid_t pid = 0;
     int status = -1;
-    ok = posix_spawn(&pid, driver.c_str(), &actions, nullptr, const_cast<char *const *>(argv), environ) == 0;
+    // The child gets the parent's environment MINUS everything that would load a tool library into it: under
+    // `rocprofv3 -- python3 bench.py` the profiler's LD_PRELOAD / HSA_TOOLS_LIB / ROCP* variables would otherwise reach the
+    // driver, whose preloaded library initialises the GPU there — and the driver then hops to clang and lld: a
+    // GPU-initialised process replacing its program, which this pool treats as a hazard (and which, refused, silently turned
+    // every profiled run into hipRTC-built code).  The compiler needs none of them.
+    std::vector<char *> child_env;
+    for (char **e = environ; e != nullptr && *e != nullptr; ++e) {
+      static const char *const kDropped[] = {"LD_PRELOAD=", "HSA_TOOLS_LIB=", "HSA_TOOLS_REPORT_LOAD_FAILURE=", "ROCP_", "ROCPROF", "ROCTRACER_",
+                                             "ROCTX_", "HIP_TOOLS_", "OMPT_TOOL", "ROCM_TOOLS"};
+      bool dropped = false;
+      for (const char *prefix : kDropped) dropped = dropped || std::strncmp(*e, prefix, std::strlen(prefix)) == 0;
+      if (!dropped) child_env.push_back(*e);
+    }
+    child_env.push_back(nullptr);
+    ok = posix_spawn(&pid, driver.c_str(), &actions, nullptr, const_cast<char *const *>(argv), child_env.data()) == 0;
     posix_spawn_file_actions_destroy(&actions);
     if (ok) {
       pid_t waited = -1;

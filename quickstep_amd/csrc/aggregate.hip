@@ -1788,7 +1788,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
 
 int qsx_agg_state_destroy(qsx_agg_state_t *st) {
   if (st == nullptr) return QSX_OK;
-  (void)hipDeviceSynchronize();
+  (void)synchronize_owner_device(st->image);   // the device the state lives on, whichever one the caller is on
   (void)device_free_idle(st->image);
   (void)device_free_idle(st->control);
   (void)device_free_idle(st->tile_counts);
@@ -2282,12 +2282,48 @@ int qsx_agg_merge(qsx_agg_state_t *dst, qsx_agg_state_t *src, qsx_stream_t strea
   return qsx_agg_state_import_merge(dst, src->image, src->image_bytes, stream);
 }
 
+// Key range [begin, end) of partition `part` of `parts` of a dense (CollisionFreeVector) state with `entries` keys
+// (storage/CollisionFreeVectorTable.hpp:192-208: contiguous ranges of ceil(entries / parts) keys, the last ones short or
+// empty), the LSB-first existence words [first_word, last_word) that cover it, and the masks that cut the range out of its
+// first and last word.  The ONE statement of this split: qsx_agg_finalize, qsx_agg_reduce_scatter and — through
+// qsx_agg_dense_partition_range — quickstep_amd/distributed.py all take it from here.
+struct DenseRange {
+  long long begin, end, first_word, last_word;
+  unsigned long long first_mask, last_mask;
+};
+static DenseRange dense_partition_range(long long entries, int parts, int part) {
+  DenseRange r{};
+  const long long length = (entries + parts - 1) / parts;
+  r.begin = static_cast<long long>(part) * length < entries ? static_cast<long long>(part) * length : entries;
+  r.end = r.begin + length < entries ? r.begin + length : entries;
+  if (r.end > r.begin) {
+    r.first_word = r.begin / 64;
+    r.last_word = (r.end + 63) / 64;
+  }
+  r.first_mask = ~0ull << (r.begin & 63);
+  r.last_mask = (r.end & 63) != 0 ? ~0ull >> (64 - (r.end & 63)) : ~0ull;
+  return r;
+}
+
 // ---- partial aggregates across GPUs ------------------------------------------------------------------------------------------
 // Dense (CollisionFreeVector) states: reduce-scatter.  Rank r ends up holding — and finalizes with partition = r,
 // num_partitions = world — the merged groups of key range r (CollisionFreeVectorTable.hpp:192-208's contiguous ranges), and
 // nothing else; per rank this moves 1 / world of what an all-reduce moves.  Every state column is reduced the way its
 // accumulator combines (f64 +, int64 +, MIN, MAX); the existence bits of the owned range are the OR of what every rank holds
 // for it (RCCL has no bitwise reduction: each rank sends every peer the words covering that peer's range).
+int qsx_agg_dense_partition_range(int64_t num_entries, int num_partitions, int partition, int64_t *out_begin, int64_t *out_end,
+                                   int64_t *out_first_word, int64_t *out_last_word, uint64_t *out_first_mask, uint64_t *out_last_mask) {
+  if (num_entries < 0 || num_partitions < 1 || partition < 0 || partition >= num_partitions) return QSX_ERR_INVALID_ARGUMENT;
+  const DenseRange r = dense_partition_range(num_entries, num_partitions, partition);
+  if (out_begin != nullptr) *out_begin = r.begin;
+  if (out_end != nullptr) *out_end = r.end;
+  if (out_first_word != nullptr) *out_first_word = r.first_word;
+  if (out_last_word != nullptr) *out_last_word = r.last_word;
+  if (out_first_mask != nullptr) *out_first_mask = r.first_mask;
+  if (out_last_mask != nullptr) *out_last_mask = r.last_mask;
+  return QSX_OK;
+}
+
 int qsx_agg_reduce_scatter(qsx_comm_t *comm, qsx_agg_state_t *st, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (comm == nullptr || st == nullptr) return QSX_ERR_INVALID_ARGUMENT;
@@ -2299,19 +2335,8 @@ int qsx_agg_reduce_scatter(qsx_comm_t *comm, qsx_agg_state_t *st, qsx_stream_t s
   hipStream_t s = as_stream(stream);
   const long long entries = st->config.num_entries, exist_words = st->exist_words;
   const long long length = (entries + world - 1) / world, padded = length * world;
-  auto range_of = [&](int r, long long *begin, long long *end) {
-    *begin = static_cast<long long>(r) * length < entries ? static_cast<long long>(r) * length : entries;
-    *end = *begin + length < entries ? *begin + length : entries;
-  };
-  auto words_of = [&](int r, long long *first, long long *last) {
-    long long b, e;
-    range_of(r, &b, &e);
-    *first = e > b ? b / 64 : 0;
-    *last = e > b ? (e + 63) / 64 : 0;
-  };
-  long long begin, end, my_first, my_last;
-  range_of(rank, &begin, &end);
-  words_of(rank, &my_first, &my_last);
+  const DenseRange own = dense_partition_range(entries, world, rank);
+  const long long begin = own.begin, end = own.end, my_first = own.first_word, my_last = own.last_word;
   const long long my_words = my_last - my_first;
   CallScratch scratch(s);
   const size_t bytes_send = static_cast<size_t>(padded) * 8, bytes_mine = static_cast<size_t>(length) * 8,
@@ -2354,19 +2379,20 @@ int qsx_agg_reduce_scatter(qsx_comm_t *comm, qsx_agg_state_t *st, qsx_stream_t s
     }
   }
   // existence words of every peer's range -> that peer; the owner ORs them
-  QSX_RCCL_TRY(api->GroupStart(), "ncclGroupStart");
-  for (int p = 0; p < world; ++p) {
-    long long first, last;
-    words_of(p, &first, &last);
-    if (last > first) QSX_RCCL_TRY(api->Send(st->image + first, static_cast<size_t>(last - first), ncclUint64, p, comm->comm, s), "ncclSend");
-    if (my_words > 0) QSX_RCCL_TRY(api->Recv(parts + static_cast<long long>(p) * my_words, static_cast<size_t>(my_words), ncclUint64, p, comm->comm, s), "ncclRecv");
+  {
+    RcclGroup group(api);
+    for (int p = 0; p < world && group.ok(); ++p) {
+      const DenseRange theirs = dense_partition_range(entries, world, p);
+      const long long first = theirs.first_word, last = theirs.last_word;
+      if (last > first) group.add(api->Send(st->image + first, static_cast<size_t>(last - first), ncclUint64, p, comm->comm, s), "ncclSend");
+      if (my_words > 0) group.add(api->Recv(parts + static_cast<long long>(p) * my_words, static_cast<size_t>(my_words), ncclUint64, p, comm->comm, s), "ncclRecv");
+    }
+    rc = group.end();
+    if (rc != QSX_OK) return rc;
   }
-  QSX_RCCL_TRY(api->GroupEnd(), "ncclGroupEnd");
   if (my_words > 0) {
     // LSB-first existence words: keep bits [begin, end) only
-    const unsigned long long first_mask = ~0ull << (begin & 63);
-    const unsigned long long last_mask = (end & 63) != 0 ? ~0ull >> (64 - (end & 63)) : ~0ull;
-    hipLaunchKernelGGL(or_words_kernel, dim3(grid_for(my_words, 256)), dim3(256), 0, s, parts, world, my_words, first_mask, last_mask,
+    hipLaunchKernelGGL(or_words_kernel, dim3(grid_for(my_words, 256)), dim3(256), 0, s, parts, world, my_words, own.first_mask, own.last_mask,
                        reduced + my_first);
     QSX_CHECK_LAUNCH();
   }
@@ -2394,8 +2420,11 @@ int qsx_agg_allgather_merge(qsx_comm_t *comm, qsx_agg_state_t *st, qsx_stream_t 
   unsigned long long *sizes_dev = nullptr;
   QSX_HIP_TRY(device_malloc(&sizes_dev, sizeof(unsigned long long) * (world + 1)));
   const unsigned long long mine_size = my_bytes;
-  QSX_HIP_TRY(hipMemcpyAsync(sizes_dev + world, &mine_size, 8, hipMemcpyHostToDevice, s));
-  int status = rccl_status(api->AllGather(sizes_dev + world, sizes_dev, 1, ncclUint64, comm->comm, s), "ncclAllGather");
+  int status = QSX_OK;
+  if (hipMemcpyAsync(sizes_dev + world, &mine_size, 8, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    status = QSX_ERR_HIP;      // (synchronised: mine_size is a stack word)
+  }
+  if (status == QSX_OK) status = rccl_status(api->AllGather(sizes_dev + world, sizes_dev, 1, ncclUint64, comm->comm, s), "ncclAllGather");
   std::vector<unsigned long long> sizes(static_cast<size_t>(world));
   if (status == QSX_OK && (hipMemcpyAsync(sizes.data(), sizes_dev, 8 * world, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) {
     status = QSX_ERR_HIP;
@@ -2405,7 +2434,7 @@ int qsx_agg_allgather_merge(qsx_comm_t *comm, qsx_agg_state_t *st, qsx_stream_t 
   size_t pad = 0;
   for (unsigned long long v : sizes) pad = v > pad ? static_cast<size_t>(v) : pad;
   unsigned char *gathered = nullptr, *padded_image = nullptr;
-  QSX_HIP_TRY(device_malloc(&gathered, pad * world));
+  if (device_malloc(&gathered, pad * world) != hipSuccess) return QSX_ERR_OUT_OF_MEMORY;
   if (device_malloc(&padded_image, pad) != hipSuccess) {
     (void)device_free(gathered);
     return QSX_ERR_OUT_OF_MEMORY;
@@ -2611,13 +2640,11 @@ int qsx_agg_finalize(qsx_agg_state_t *st, int partition, int num_partitions, voi
                          out_groups);
       break;
     default: {
-      const long long E = st->config.num_entries;
-      const long long len = (E + num_partitions - 1) / num_partitions;
-      const long long begin = static_cast<long long>(partition) * len;
-      const long long end = begin + len < E ? begin + len : E;
+      const DenseRange range = dense_partition_range(st->config.num_entries, num_partitions, partition);
+      const long long begin = range.begin, end = range.end;
       if (begin >= end) return QSX_OK;
-      const long long first_word = begin / 64;
-      const long long num_words = (end + 63) / 64 - first_word;
+      const long long first_word = range.first_word;
+      const long long num_words = range.last_word - first_word;
       const long long num_tiles = (num_words + kDenseTileWords - 1) / kDenseTileWords;
       const DenseView d = st->dense_view();
       // the tile counts / offsets of THIS call: the partitions of a state are finalized by concurrent work orders

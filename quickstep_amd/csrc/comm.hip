@@ -7,7 +7,9 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace qsx {
@@ -19,9 +21,21 @@ const RcclApi *rccl() {
   static bool ok = false;
   static std::once_flag once;
   std::call_once(once, []() {
-    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // the copy the process already holds, if any
-    if (lib == nullptr) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (lib == nullptr) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    // QSX_RCCL_LIBRARY names the library to bind instead (the deployment's own build of RCCL; the tests' loopback
+    // transport, tests/cpp/loopback/loopback_rccl.cpp, which lets several ranks share one GPU).  No fallback from it.
+    void *lib = nullptr;
+    const char *named = std::getenv("QSX_RCCL_LIBRARY");
+    if (named != nullptr && named[0] != 0) {
+      lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+      if (lib == nullptr) {
+        set_last_error_text((std::string("QSX_RCCL_LIBRARY: ") + dlerror()).c_str());
+        return;
+      }
+    } else {
+      lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // the copy the process already holds, if any
+      if (lib == nullptr) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+      if (lib == nullptr) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    }
     if (lib == nullptr) {
       set_last_error_text("librccl.so.1 not found (multi-GPU entry points need RCCL)");
       return;
@@ -114,13 +128,12 @@ int qsx_exchange_counts(qsx_comm_t *c, const int64_t *send_counts_dev, int64_t *
   const RcclApi *api = rccl();
   if (api == nullptr) return QSX_ERR_COMM;
   hipStream_t s = as_stream(stream);
-  QSX_RCCL_TRY(api->GroupStart(), "ncclGroupStart");
-  for (int p = 0; p < c->world; ++p) {
-    QSX_RCCL_TRY(api->Send(send_counts_dev + p, 1, ncclInt64, p, c->comm, s), "ncclSend");
-    QSX_RCCL_TRY(api->Recv(recv_counts_dev + p, 1, ncclInt64, p, c->comm, s), "ncclRecv");
+  RcclGroup group(api);
+  for (int p = 0; p < c->world && group.ok(); ++p) {
+    group.add(api->Send(send_counts_dev + p, 1, ncclInt64, p, c->comm, s), "ncclSend");
+    group.add(api->Recv(recv_counts_dev + p, 1, ncclInt64, p, c->comm, s), "ncclRecv");
   }
-  QSX_RCCL_TRY(api->GroupEnd(), "ncclGroupEnd");
-  return QSX_OK;
+  return group.end();
 }
 
 int qsx_alltoallv(qsx_comm_t *c, int width, const void *send_dev, const int64_t *send_rows, void *recv_dev, const int64_t *recv_rows,
@@ -133,23 +146,18 @@ int qsx_alltoallv(qsx_comm_t *c, int width, const void *send_dev, const int64_t 
   const char *send = static_cast<const char *>(send_dev);
   char *recv = static_cast<char *>(recv_dev);
   int64_t send_at = 0, recv_at = 0;
-  QSX_RCCL_TRY(api->GroupStart(), "ncclGroupStart");
   for (int p = 0; p < c->world; ++p) {
-    if (send_rows[p] < 0 || recv_rows[p] < 0) {
-      (void)api->GroupEnd();
-      return QSX_ERR_INVALID_ARGUMENT;
-    }
-    if (send_rows[p] > 0) {
-      QSX_RCCL_TRY(api->Send(send + send_at * width, static_cast<size_t>(send_rows[p]) * width, ncclUint8, p, c->comm, s), "ncclSend");
-    }
-    if (recv_rows[p] > 0) {
-      QSX_RCCL_TRY(api->Recv(recv + recv_at * width, static_cast<size_t>(recv_rows[p]) * width, ncclUint8, p, c->comm, s), "ncclRecv");
-    }
+    if (send_rows[p] < 0 || recv_rows[p] < 0) return QSX_ERR_INVALID_ARGUMENT;
+    if ((send_rows[p] > 0 && send_dev == nullptr) || (recv_rows[p] > 0 && recv_dev == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+  }
+  RcclGroup group(api);
+  for (int p = 0; p < c->world && group.ok(); ++p) {
+    if (send_rows[p] > 0) group.add(api->Send(send + send_at * width, static_cast<size_t>(send_rows[p]) * width, ncclUint8, p, c->comm, s), "ncclSend");
+    if (recv_rows[p] > 0) group.add(api->Recv(recv + recv_at * width, static_cast<size_t>(recv_rows[p]) * width, ncclUint8, p, c->comm, s), "ncclRecv");
     send_at += send_rows[p];
     recv_at += recv_rows[p];
   }
-  QSX_RCCL_TRY(api->GroupEnd(), "ncclGroupEnd");
-  return QSX_OK;
+  return group.end();
 }
 
 int qsx_allgather(qsx_comm_t *c, const void *send_dev, size_t bytes, void *recv_dev, qsx_stream_t stream) {

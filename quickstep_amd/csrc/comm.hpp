@@ -50,6 +50,41 @@ struct qsx_comm {
   int rank = 0;
 };
 
+namespace qsx {
+// ncclGroupStart ... ncclGroupEnd around a batch of sends / receives.  A call that fails inside the batch must not leave
+// the thread's group open (every later collective would queue into a group that never ends): the first error is kept,
+// nothing more is issued, and ncclGroupEnd always runs — from end() or, on an early return, from the destructor.
+class RcclGroup {
+ public:
+  explicit RcclGroup(const RcclApi *api) : api_(api) {
+    status_ = rccl_status(api_->GroupStart(), "ncclGroupStart");
+    open_ = status_ == QSX_OK;
+  }
+  ~RcclGroup() {
+    if (open_) (void)api_->GroupEnd();
+  }
+  RcclGroup(const RcclGroup &) = delete;
+  RcclGroup &operator=(const RcclGroup &) = delete;
+  bool ok() const { return status_ == QSX_OK; }
+  void add(ncclResult_t r, const char *what) {
+    if (status_ == QSX_OK) status_ = rccl_status(r, what);
+  }
+  int end() {
+    if (open_) {
+      open_ = false;
+      const int rc = rccl_status(api_->GroupEnd(), "ncclGroupEnd");
+      if (status_ == QSX_OK) status_ = rc;
+    }
+    return status_;
+  }
+
+ private:
+  const RcclApi *api_;
+  int status_ = QSX_OK;
+  bool open_ = false;
+};
+}  // namespace qsx
+
 #define QSX_RCCL_TRY(call, what)                              \
   do {                                                         \
     const int rc_rccl__ = qsx::rccl_status((call), what);      \

@@ -87,8 +87,14 @@ inline hipError_t device_malloc(T **ptr, size_t bytes) { return device_malloc(re
 hipError_t device_free(void *ptr);
 hipError_t device_free_idle(void *ptr);
 size_t trim_idle_allocations();
+// Allocations remember the device they were made on (calls follow the calling thread's device; an object stays on the
+// device it was created on): an idle allocation is only handed out again on that device, and a destroy entry point waits
+// for THAT device's queued work — not the caller's current one — before its memory is recycled.
+int device_of_allocation(const void *ptr);              // -1: not a live device_malloc
+hipError_t synchronize_owner_device(const void *ptr);   // hipDeviceSynchronize on the device that owns ptr
 
-// ---- per-(host thread, stream) device resources --------------------------------------------------------------------------
+// ---- per-(host thread, device, stream) device resources ------------------------------------------------------------------
+// (the key includes the calling thread's current device: the null stream is a different queue on every device)
 // Calls issued by one thread on one stream are ordered on the device, so such a pair can own buffers that every call
 // reuses without an allocator on the hot path: a grow-only scratch arena, a pinned + device staging pair for host tables,
 // small device slots for by-value structs.  ONE registry for the whole library (runtime.hip) holds them — per thread, so no
@@ -96,7 +102,9 @@ size_t trim_idle_allocations();
 //   * when the thread exits (the registry's destructor),
 //   * when the stream is destroyed through qsx_stream_destroy (the calling thread's entries for it),
 //   * on qsx_trim_scratch() (everything the calling thread holds; the host layer calls it on its out-of-memory path),
-//   * before a failed allocation inside the library is retried once.
+//   * before a failed allocation inside the library is retried once — then only the entries of the thread's OTHER streams
+//     (trim_thread_resources_sparing): the call that is allocating may already have staged a table into its stream's
+//     StagedBuffer, filled a device slot or carved its arena, and its kernels are about to be launched on them.
 struct ScratchArena {
   void *base = nullptr;
   size_t capacity = 0;
@@ -112,6 +120,7 @@ StagedBuffer &thread_staged_buffer(hipStream_t stream);
 void *&thread_device_slot(hipStream_t stream, const void *type_tag);
 void release_thread_stream(hipStream_t stream);     // this thread's entries for `stream` (the stream is idle or being destroyed)
 size_t trim_thread_resources();                      // everything this thread holds; returns the device bytes released
+size_t trim_thread_resources_sparing(hipStream_t stream);   // everything this thread holds for OTHER (device, stream) pairs
 
 // One device slot per (host thread, stream) for a by-value struct: work on one stream is ordered, so the store of the next
 // call cannot overtake the kernel still reading the slot, and no allocator is involved on the update path.
@@ -122,13 +131,12 @@ static T *device_slot(hipStream_t stream) {
   if (p != nullptr) return static_cast<T *>(p);
   if (device_malloc(&p, sizeof(T)) != hipSuccess) {
     (void)hipGetLastError();
-    (void)trim_thread_resources();
-    void *&q = thread_device_slot(stream, &tag);   // (the trim dropped the entry)
-    if (device_malloc(&q, sizeof(T)) != hipSuccess) {
-      q = nullptr;
+    (void)trim_thread_resources_sparing(stream);   // never this stream's own buffers: the caller may have staged into them
+    if (device_malloc(&p, sizeof(T)) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
       return nullptr;
     }
-    return static_cast<T *>(q);
   }
   return static_cast<T *>(p);
 }
@@ -208,7 +216,7 @@ class CallScratch {
     if (total > kScratchKeepBytes) {
       if (device_malloc(&one_off_, total) != hipSuccess) {
         (void)hipGetLastError();
-        (void)trim_thread_resources();   // what this thread keeps for later calls goes first
+        (void)trim_thread_resources_sparing(stream_);   // what this thread keeps for its other streams goes first
         QSX_HIP_TRY(device_malloc(&one_off_, total));
       }
       base_ = static_cast<char *>(one_off_);
@@ -229,8 +237,7 @@ class CallScratch {
       if (device_malloc(&a->base, cap) != hipSuccess) {
         (void)hipGetLastError();
         a->base = nullptr;
-        (void)trim_thread_resources();
-        a = &thread_scratch_arena(stream_);
+        (void)trim_thread_resources_sparing(stream_);   // (this stream's staged table and slots may belong to this very call)
         QSX_HIP_TRY(device_malloc(&a->base, cap));
       }
       a->capacity = cap;

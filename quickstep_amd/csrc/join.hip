@@ -880,7 +880,7 @@ int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks
 
 int qsx_join_table_destroy(qsx_join_table_t *t) {
   if (t == nullptr) return QSX_OK;
-  (void)hipDeviceSynchronize();
+  (void)synchronize_owner_device(t->slots != nullptr ? static_cast<const void *>(t->slots) : static_cast<const void *>(t->head));
   if (t->shadow != nullptr) (void)qsx_join_table_destroy(t->shadow);
   (void)device_free_idle(t->slots);
   (void)device_free_idle(t->head);

@@ -263,7 +263,7 @@ int qsx_lip_filter_create(int kind, int64_t cardinality, int64_t min_value, int 
 
 int qsx_lip_filter_destroy(qsx_lip_filter_t *f) {
   if (f == nullptr) return QSX_OK;
-  (void)hipDeviceSynchronize();
+  (void)synchronize_owner_device(f->words);
   (void)device_free_idle(f->words);
   delete f;
   return QSX_OK;

@@ -42,12 +42,32 @@ static int usable_devices() {
   return usable;
 }
 
-// ---- the per-(host thread, stream) resources of common.hpp -----------------------------------------------------------------
+// ---- the per-(host thread, device, stream) resources of common.hpp -----------------------------------------------------------
 namespace {
+// Calls follow the calling thread's device (qsx_set_current_device), and the null stream names a different queue on every
+// device: the key of a thread's buffers is (device, stream), never the stream alone.
+int current_device() {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) (void)hipGetLastError();
+  return device;
+}
+// Makes `device` current for a scope (buffers are freed, and their streams waited for, on the device that owns them).
+struct DeviceScope {
+  int previous;
+  bool switched;
+  explicit DeviceScope(int device) : previous(current_device()), switched(false) {
+    if (device != previous && hipSetDevice(device) == hipSuccess) switched = true;
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(previous);
+  }
+};
+using StreamKey = std::pair<int, hipStream_t>;
+
 struct ThreadResources {
-  std::map<hipStream_t, ScratchArena> arenas;
-  std::map<hipStream_t, StagedBuffer> staged;
-  std::map<std::pair<hipStream_t, const void *>, void *> slots;
+  std::map<StreamKey, ScratchArena> arenas;
+  std::map<StreamKey, StagedBuffer> staged;
+  std::map<std::pair<StreamKey, const void *>, void *> slots;
 
   static size_t drop(ScratchArena &a) {
     const size_t bytes = a.capacity;
@@ -66,12 +86,18 @@ struct ThreadResources {
     b = StagedBuffer();
     return bytes;
   }
-  // Entries of `stream` (all streams when match_all).  The stream's queued work still uses them: wait for it first.
-  size_t release(hipStream_t stream, bool match_all) {
+  // Which entries go: those of `key` only, all of them, or all BUT those of `key`.  The stream's queued work still uses them:
+  // wait for it first, on its own device.
+  enum Which { kOnly, kAll, kAllBut };
+  static bool chosen(const StreamKey &entry, const StreamKey &key, Which which) {
+    return which == kAll || (which == kOnly ? entry == key : entry != key);
+  }
+  size_t release(const StreamKey &key, Which which) {
     size_t bytes = 0;
     for (auto it = arenas.begin(); it != arenas.end();) {
-      if (match_all || it->first == stream) {
-        (void)hipStreamSynchronize(it->first);
+      if (chosen(it->first, key, which)) {
+        DeviceScope scope(it->first.first);
+        (void)hipStreamSynchronize(it->first.second);
         bytes += drop(it->second);
         it = arenas.erase(it);
       } else {
@@ -79,8 +105,9 @@ struct ThreadResources {
       }
     }
     for (auto it = staged.begin(); it != staged.end();) {
-      if (match_all || it->first == stream) {
-        (void)hipStreamSynchronize(it->first);
+      if (chosen(it->first, key, which)) {
+        DeviceScope scope(it->first.first);
+        (void)hipStreamSynchronize(it->first.second);
         bytes += drop(it->second);
         it = staged.erase(it);
       } else {
@@ -88,8 +115,9 @@ struct ThreadResources {
       }
     }
     for (auto it = slots.begin(); it != slots.end();) {
-      if (match_all || it->first.first == stream) {
-        (void)hipStreamSynchronize(it->first.first);
+      if (chosen(it->first.first, key, which)) {
+        DeviceScope scope(it->first.first.first);
+        (void)hipStreamSynchronize(it->first.first.second);
         if (it->second != nullptr) (void)device_free(it->second);
         it = slots.erase(it);
       } else {
@@ -99,19 +127,21 @@ struct ThreadResources {
     (void)hipGetLastError();   // (a stream destroyed behind the library's back: its synchronize fails, the buffers still go)
     return bytes;
   }
-  ~ThreadResources() { (void)release(nullptr, true); }   // thread exit
+  ~ThreadResources() { (void)release(StreamKey(), kAll); }   // thread exit
 };
 ThreadResources &thread_resources() {
   thread_local ThreadResources r;
   return r;
 }
+StreamKey key_of(hipStream_t stream) { return StreamKey(current_device(), stream); }
 }  // namespace
 
-ScratchArena &thread_scratch_arena(hipStream_t stream) { return thread_resources().arenas[stream]; }
-StagedBuffer &thread_staged_buffer(hipStream_t stream) { return thread_resources().staged[stream]; }
-void *&thread_device_slot(hipStream_t stream, const void *type_tag) { return thread_resources().slots[std::make_pair(stream, type_tag)]; }
-void release_thread_stream(hipStream_t stream) { (void)thread_resources().release(stream, false); }
-size_t trim_thread_resources() { return thread_resources().release(nullptr, true); }
+ScratchArena &thread_scratch_arena(hipStream_t stream) { return thread_resources().arenas[key_of(stream)]; }
+StagedBuffer &thread_staged_buffer(hipStream_t stream) { return thread_resources().staged[key_of(stream)]; }
+void *&thread_device_slot(hipStream_t stream, const void *type_tag) { return thread_resources().slots[std::make_pair(key_of(stream), type_tag)]; }
+void release_thread_stream(hipStream_t stream) { (void)thread_resources().release(key_of(stream), ThreadResources::kOnly); }
+size_t trim_thread_resources() { return thread_resources().release(StreamKey(), ThreadResources::kAll); }
+size_t trim_thread_resources_sparing(hipStream_t stream) { return thread_resources().release(key_of(stream), ThreadResources::kAllBut); }
 
 namespace {
 std::mutex g_hook_mutex;
@@ -121,10 +151,14 @@ void *g_oom_hook_user = nullptr;
 
 namespace {
 constexpr size_t kIdleKeepBytes = size_t(2) << 30;
+struct Owned {
+  size_t bytes;
+  int device;
+};
 struct Allocations {
   std::mutex mutex;
-  std::map<void *, size_t> size_of;                       // every live device_malloc
-  std::map<size_t, std::vector<void *>> idle;             // given back by device_free_idle, by exact size
+  std::map<void *, Owned> live;                                          // every live device_malloc: its size and its device
+  std::map<std::pair<int, size_t>, std::vector<void *>> idle;             // given back by device_free_idle, by (device, exact size)
   size_t idle_bytes = 0;
 };
 Allocations &allocations() {
@@ -146,8 +180,22 @@ size_t trim_idle_allocations() {
     bytes = a.idle_bytes;
     a.idle_bytes = 0;
   }
-  for (void *p : doomed) (void)hipFree(p);
+  for (void *p : doomed) (void)hipFree(p);   // (hipFree finds the owning device from the pointer)
   return bytes;
+}
+
+int device_of_allocation(const void *ptr) {
+  Allocations &a = allocations();
+  std::lock_guard<std::mutex> lock(a.mutex);
+  auto it = a.live.find(const_cast<void *>(ptr));
+  return it != a.live.end() ? it->second.device : -1;
+}
+
+hipError_t synchronize_owner_device(const void *ptr) {
+  const int owner = ptr != nullptr ? device_of_allocation(ptr) : -1;
+  if (owner < 0) return hipDeviceSynchronize();
+  DeviceScope scope(owner);
+  return hipDeviceSynchronize();
 }
 
 hipError_t device_free(void *ptr) {
@@ -155,7 +203,7 @@ hipError_t device_free(void *ptr) {
   {
     Allocations &a = allocations();
     std::lock_guard<std::mutex> lock(a.mutex);
-    a.size_of.erase(ptr);
+    a.live.erase(ptr);
   }
   return hipFree(ptr);
 }
@@ -165,28 +213,29 @@ hipError_t device_free_idle(void *ptr) {
   {
     Allocations &a = allocations();
     std::lock_guard<std::mutex> lock(a.mutex);
-    auto it = a.size_of.find(ptr);
-    if (it != a.size_of.end() && a.idle_bytes + it->second <= kIdleKeepBytes) {
-      a.idle[it->second].push_back(ptr);
-      a.idle_bytes += it->second;
-      a.size_of.erase(it);
+    auto it = a.live.find(ptr);
+    if (it != a.live.end() && a.idle_bytes + it->second.bytes <= kIdleKeepBytes) {
+      a.idle[std::make_pair(it->second.device, it->second.bytes)].push_back(ptr);
+      a.idle_bytes += it->second.bytes;
+      a.live.erase(it);
       return hipSuccess;
     }
-    if (it != a.size_of.end()) a.size_of.erase(it);
+    if (it != a.live.end()) a.live.erase(it);
   }
   return hipFree(ptr);
 }
 
 hipError_t device_malloc(void **ptr, size_t bytes) {
   Allocations &a = allocations();
+  const int device = current_device();     // an idle allocation is only ever handed back out on the device it lives on
   {
     std::lock_guard<std::mutex> lock(a.mutex);
-    auto it = a.idle.find(bytes);
+    auto it = a.idle.find(std::make_pair(device, bytes));
     if (it != a.idle.end() && !it->second.empty()) {
       *ptr = it->second.back();
       it->second.pop_back();
       a.idle_bytes -= bytes;
-      a.size_of[*ptr] = bytes;
+      a.live[*ptr] = Owned{bytes, device};
       return hipSuccess;
     }
   }
@@ -197,7 +246,7 @@ hipError_t device_malloc(void **ptr, size_t bytes) {
   }
   if (err == hipSuccess) {
     std::lock_guard<std::mutex> lock(a.mutex);
-    a.size_of[*ptr] = bytes;
+    a.live[*ptr] = Owned{bytes, device};
     return err;
   }
   if (err != hipErrorOutOfMemory) return err;
@@ -214,7 +263,7 @@ hipError_t device_malloc(void **ptr, size_t bytes) {
   err = hipMalloc(ptr, bytes);
   if (err == hipSuccess) {
     std::lock_guard<std::mutex> lock(a.mutex);
-    a.size_of[*ptr] = bytes;
+    a.live[*ptr] = Owned{bytes, device};
   }
   return err;
 }

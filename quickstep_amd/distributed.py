@@ -35,13 +35,46 @@ def _splits(offsets_host):
     return [int(offsets_host[i + 1] - offsets_host[i]) for i in range(len(offsets_host) - 1)]
 
 
-class _Transport:
-    """The collectives this file issues, by where the tensors live and what the process group can move.
+class CapiGroup:
+    """The ranks of a job as the C ABI sees them: one qsx_comm_t per rank (quickstep_amd.capi.Comm — RCCL bound inside
+    libqsx.so, or whatever QSX_RCCL_LIBRARY names).  Pass one wherever this module takes `group=` and every exchange goes
+    through the C ABI's own entry points — qsx_exchange_counts, qsx_alltoallv, qsx_allgather, qsx_bitmap_allreduce_or,
+    qsx_agg_reduce_scatter, qsx_agg_allgather_merge: the calls a compiled host makes (quickstep_amd/host) — instead of
+    torch.distributed.  `group=None` / a torch ProcessGroup keeps torch.distributed (backend "nccl" = RCCL)."""
 
-    Product: backend "nccl" (= RCCL over xGMI) on device tensors, handed through unchanged.  A process group that cannot
-    take device memory (gloo) gets *host staging*: device tensor -> host copy -> collective -> device copy.  That is how
-    the rank logic runs with the real kernels when ranks cannot have a GPU each (two rank processes sharing the one GPU
-    of a test box, where RCCL refuses the duplicate device); it moves the same bytes in the same order, only slower."""
+    def __init__(self, comm):
+        self.comm, self.world, self.rank = comm, comm.world, comm.rank
+
+    @classmethod
+    def from_torch_group(cls, ops, device, group=None):
+        """A communicator over the ranks of an initialised torch process group: rank 0 makes the id, the process group's
+        own (host-side) broadcast carries it — torch.distributed is the control plane here, the data goes through the C ABI."""
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [ops.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(ops.Comm(world, rank, box[0]))
+
+
+def world_size(group=None):
+    if isinstance(group, CapiGroup):
+        return group.world
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank_of(group=None):
+    if isinstance(group, CapiGroup):
+        return group.rank
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+class _Transport:
+    """The collectives this file issues, by where the tensors live and what the group can move.
+
+    torch process group, backend "nccl" (= RCCL over xGMI): device tensors handed through unchanged.  A CapiGroup: the C
+    ABI's entry points.  A process group that cannot take device memory (gloo) gets *host staging*: device tensor -> host
+    copy -> collective -> device copy — how the rank logic runs with the real kernels when ranks cannot have a GPU each
+    (rank processes sharing the one GPU of a test box, where RCCL refuses the duplicate device); it moves the same bytes
+    in the same order, only slower."""
 
     @staticmethod
     def _staged(tensor, group):
@@ -49,6 +82,10 @@ class _Transport:
 
     @classmethod
     def all_to_all_single(cls, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        if isinstance(group, CapiGroup):
+            each_in, each_out = inp.numel() // group.world, out.numel() // group.world
+            group.comm.alltoallv(inp, input_split_sizes or [each_in] * group.world, output_split_sizes or [each_out] * group.world, out=out)
+            return
         if not cls._staged(inp, group):
             dist.all_to_all_single(out, inp, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
             return
@@ -58,6 +95,9 @@ class _Transport:
 
     @classmethod
     def all_gather_into_tensor(cls, out, inp, group=None):
+        if isinstance(group, CapiGroup):
+            group.comm.allgather(inp.contiguous(), out=out)
+            return
         if not cls._staged(inp, group):
             dist.all_gather_into_tensor(out, inp, group=group)
             return
@@ -66,17 +106,9 @@ class _Transport:
         out.copy_(host)
 
     @classmethod
-    def all_gather(cls, outs, inp, group=None):
-        if not cls._staged(inp, group):
-            dist.all_gather(outs, inp, group=group)
-            return
-        hosts = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
-        dist.all_gather(hosts, inp.cpu(), group=group)
-        for o, h in zip(outs, hosts):
-            o.copy_(h)
-
-    @classmethod
     def reduce_scatter_tensor(cls, out, inp, op=dist.ReduceOp.SUM, group=None):
+        if isinstance(group, CapiGroup):
+            raise NotImplementedError("the C ABI reduces whole states (qsx_agg_reduce_scatter), not tensors")
         if not cls._staged(inp, group):
             dist.reduce_scatter_tensor(out, inp, op=op, group=group)
             return
@@ -86,6 +118,8 @@ class _Transport:
 
     @classmethod
     def all_reduce(cls, tensor, op=dist.ReduceOp.SUM, group=None):
+        if isinstance(group, CapiGroup):
+            raise NotImplementedError("the C ABI has no tensor all-reduce (bit vectors: qsx_bitmap_allreduce_or)")
         if not cls._staged(tensor, group):
             dist.all_reduce(tensor, op=op, group=group)
             return
@@ -139,6 +173,8 @@ phases = _PhaseTimer
 
 def exchange_counts(send_counts, group=None):
     """send_counts: int64[P] on the compute device.  Returns int64[P] recv counts."""
+    if isinstance(group, CapiGroup):
+        return group.comm.exchange_counts(send_counts)
     recv = torch.empty_like(send_counts)
     xfer.all_to_all_single(recv, send_counts, group=group)
     return recv
@@ -151,7 +187,7 @@ def shuffle_by_key(ops, keys, cols, group=None):
     ``keys`` itself if the receiver needs it).  Returns (received columns,
     recv_counts list).  Rows from rank r arrive before rows from rank r + 1 and
     keep their local order (the scatter is stable)."""
-    world = dist.get_world_size(group)
+    world = world_size(group)
     with phases.phase("partition_scatter"):
         scattered, offsets = ops.partition_scatter(keys, world, cols)
     with phases.phase("exchange"):
@@ -209,8 +245,8 @@ class PartitionedHashJoin:
         flavour (qsx_join_table_create_dense); otherwise the hashed table."""
         self.ops = ops
         self.group = group
-        world = dist.get_world_size(group)
-        rank = dist.get_rank(group)
+        world = world_size(group)
+        rank = rank_of(group)
         progression = rank_progression(key_domain, world, rank)
         if progression is None:
             self.table = ops.JoinTable(key_type, est_build_rows_per_rank)
@@ -255,7 +291,7 @@ class PartitionedHashJoin:
         writes (join key, build payload columns..., probe payload columns...) itself — no pair list, no gathers); the pair
         list and K5 gathers otherwise (the CPU checker of the gloo tests)."""
         if not hasattr(self.table, "probe_project_blocks"):
-            _, _, out_p, out_b, count = self.probe(keys, tid_base, capacity=0, payload=payload)
+            _, _, out_p, out_b, count = self.probe(keys, tid_base, capacity=None, payload=payload)   # counts first: duplicates
             return self.materialize_payload(out_p, out_b, count)
         tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
         received, _ = shuffle_by_key(self.ops, keys, [keys, tids, *payload], self.group)
@@ -306,7 +342,7 @@ class BroadcastHashJoin:
             else ops.JoinTable(key_type, est_build_rows_total)
 
     def build(self, keys, tid_base):
-        world = dist.get_world_size(self.group)
+        world = world_size(self.group)
         # (row count, tid base) of every rank: one collective, one host synchronisation
         mine_meta = torch.tensor([keys.numel(), tid_base], dtype=torch.int64, device=keys.device)
         meta = torch.empty(2 * world, dtype=torch.int64, device=keys.device)
@@ -322,14 +358,14 @@ class BroadcastHashJoin:
             xfer.all_gather_into_tensor(everything, keys.contiguous(), group=self.group)
             self.table.build(everything, base_tid=bases[0])
             return sum(sizes)
-        pad = max(sizes)
+        pad = max(max(sizes), 1)
         mine = torch.zeros(pad, dtype=keys.dtype, device=keys.device)
         mine[:keys.numel()] = keys
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        xfer.all_gather(gathered, mine, group=self.group)
+        gathered = torch.empty(world * pad, dtype=keys.dtype, device=keys.device)
+        xfer.all_gather_into_tensor(gathered, mine, group=self.group)
         for r in range(world):                              # the stored reference is the GLOBAL build tid
             if sizes[r]:
-                self.table.build(gathered[r][:sizes[r]], base_tid=bases[r])
+                self.table.build(gathered[r * pad: r * pad + sizes[r]], base_tid=bases[r])
         return sum(sizes)
 
     def probe(self, keys, tid_base, capacity=None):
@@ -346,8 +382,11 @@ def merge_agg_state_images(ops, state, group=None):
     (counterpart of merging the thread-private tables at finalize,
     storage/AggregationOperationState.cpp:925-948).  Hash-table images are
     all-gathered and merged locally (Q1-sized: a few KiB per rank)."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    if isinstance(group, CapiGroup):
+        group.comm.agg_allgather_merge(state)      # sizes, images and the merges: all inside qsx_agg_allgather_merge
+        return state
+    world = world_size(group)
+    rank = rank_of(group)
     device = state.device if hasattr(state, "device") else None
     image = state.export(device)
     # a table that outgrew its estimate has a bigger image than its peers': exchange the sizes, pad to the largest
@@ -370,6 +409,8 @@ def _allreduce_or(words, group=None):
     """Bit-OR all-reduce of an int64 tensor in place.  RCCL has no bitwise reductions (SUM / PROD / MIN / MAX / AVG only:
     ReduceOp.BOR raises on the "nccl" backend), so there the words are all-gathered and OR-ed locally; the existence map
     of a CollisionFreeVector is 1 bit per key, a sixty-fourth of one state column."""
+    if isinstance(group, CapiGroup):
+        return group.comm.bitmap_allreduce_or(words)
     if dist.get_backend(group) != "nccl":
         xfer.all_reduce(words, op=dist.ReduceOp.BOR, group=group)
         return words
@@ -387,9 +428,15 @@ def _allreduce_or(words, group=None):
 def dense_partition_range(num_entries, world, rank):
     """Key range [begin, end) that finalize partition `rank` of `world` owns in a CollisionFreeVector state
     (CollisionFreeVectorTable.hpp:192-208; qsx_agg_finalize uses the same split)."""
-    length = (num_entries + world - 1) // world
-    begin = min(rank * length, num_entries)
-    return begin, min(begin + length, num_entries)
+    return _dense_split(num_entries, world, rank)[:2]
+
+
+def _dense_split(num_entries, world, rank):
+    """(begin, end, first_word, last_word, first_mask, last_mask) from the C ABI's own statement of the split
+    (qsx_agg_dense_partition_range: host arithmetic, runs without a device) — the torch.distributed path below moves
+    exactly the ranges and applies exactly the masks qsx_agg_reduce_scatter does."""
+    from . import capi
+    return capi.dense_partition_range(num_entries, world, rank)
 
 
 def reduce_scatter_dense_agg_image(image, exist_words, num_entries, int_col_mask, num_cols, group=None, min_max_cols=None):
@@ -402,9 +449,11 @@ def reduce_scatter_dense_agg_image(image, exist_words, num_entries, int_col_mask
 
     image: int64[exist_words + num_cols * num_entries] as exported by the state.  Returns a new image of the same layout
     to be imported into a CLEARED state (state.clear(); state.import_merge(result))."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    length = (num_entries + world - 1) // world
+    if isinstance(group, CapiGroup):
+        raise NotImplementedError("a CapiGroup reduces the state itself: reduce_scatter_dense_state -> qsx_agg_reduce_scatter")
+    world = world_size(group)
+    rank = rank_of(group)
+    length = _dense_split(num_entries, world, 0)[1]          # every range but the last ones: ceil(entries / world) keys
     begin, end = dense_partition_range(num_entries, world, rank)
     out = torch.zeros_like(image)
     padded = world * length
@@ -430,11 +479,9 @@ def reduce_scatter_dense_agg_image(image, exist_words, num_entries, int_col_mask
             full[:begin] = fill
             full[end:] = fill
     # existence words covering every peer's range (the same word may go to two neighbours: their ranges share it)
-    def word_range(r):
-        b, e = dense_partition_range(num_entries, world, r)
-        return (b // 64, (e + 63) // 64) if e > b else (0, 0)
-    splits = [word_range(r)[1] - word_range(r)[0] for r in range(world)]
-    send = torch.cat([image[word_range(r)[0]: word_range(r)[1]] for r in range(world)]) if sum(splits) else image[:0]
+    ranges = [_dense_split(num_entries, world, r) for r in range(world)]
+    splits = [r[3] - r[2] for r in ranges]
+    send = torch.cat([image[r[2]: r[3]] for r in ranges]) if sum(splits) else image[:0]
     my_words = splits[rank]
     recv = torch.empty(world * my_words, dtype=image.dtype, device=image.device)
     xfer.all_to_all_single(recv, send, output_split_sizes=[my_words] * world, input_split_sizes=splits, group=group)
@@ -442,13 +489,12 @@ def reduce_scatter_dense_agg_image(image, exist_words, num_entries, int_col_mask
         acc = recv[:my_words].clone()
         for r in range(1, world):
             acc |= recv[r * my_words: (r + 1) * my_words]
-        first_word, last_word = word_range(rank)
+        _, _, first_word, last_word, first_mask, last_mask = ranges[rank]
         # bits of neighbouring partitions that share the boundary words are dropped: the range is exactly [begin, end)
-        bit = torch.arange(first_word * 64, last_word * 64, device=image.device, dtype=torch.int64)
-        inside = ((bit >= begin) & (bit < end)).view(-1, 64)
-        weights = (torch.ones(64, dtype=torch.int64, device=image.device) << torch.arange(64, device=image.device, dtype=torch.int64))
-        mask = (inside.to(torch.int64) * weights).sum(dim=1)      # LSB-first existence words
-        out[first_word:last_word] = acc & mask
+        signed = lambda m: m - (1 << 64) if m >> 63 else m        # noqa: E731  (uint64 mask as the int64 the image holds)
+        acc[0] &= signed(first_mask)
+        acc[-1] &= signed(last_mask)
+        out[first_word:last_word] = acc
     return out
 
 
@@ -460,7 +506,10 @@ def reduce_scatter_dense_state(state, device, group=None):
     dense, exist_words, entries, kinds = state.image_layout()
     if not dense:
         raise ValueError("reduce_scatter_dense_state needs a COLLISION_FREE state (hash states: merge_agg_state_images)")
-    world = dist.get_world_size(group)
+    world = world_size(group)
+    if isinstance(group, CapiGroup):
+        group.comm.agg_reduce_scatter(state)
+        return (len(kinds) * entries * 8 + exist_words * 8) * (world - 1) // world
     int_mask, min_max = 0, {}
     for c, kind in enumerate(kinds):
         if kind != T.ACC_SUM_F64:

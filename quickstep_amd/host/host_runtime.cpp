@@ -45,7 +45,7 @@ class BlockSlabPool {
     *granted = cls;
     {
       std::lock_guard<std::mutex> lock(mutex_);
-      auto it = free_.find(cls);
+      auto it = free_.find(keyOf(cls));
       if (it != free_.end() && !it->second.empty()) {
         void *p = it->second.back();
         it->second.pop_back();
@@ -60,12 +60,19 @@ class BlockSlabPool {
       (void)qsx_trim_scratch(nullptr);           // and what libqsx.so keeps for this thread between calls
       CheckStatus(qsx_device_alloc(cls, &p), "qsx_device_alloc(block)");
     }
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      owner_[p] = keyOf(cls).first;              // the slab's device: where it may be handed out again
+    }
     return p;
   }
   void trim() {
     std::lock_guard<std::mutex> lock(mutex_);
     for (auto &cls : free_) {
-      for (void *q : cls.second) qsx_device_free(q);
+      for (void *q : cls.second) {
+        owner_.erase(q);
+        qsx_device_free(q);
+      }
       cls.second.clear();
     }
     kept_ = 0;
@@ -74,18 +81,27 @@ class BlockSlabPool {
     if (p == nullptr) return;
     if (granted != 0) {
       std::lock_guard<std::mutex> lock(mutex_);
-      if (kept_ + granted <= kKeepBytes) {
-        free_[granted].push_back(p);
+      auto owner = owner_.find(p);
+      if (owner != owner_.end() && kept_ + granted <= kKeepBytes) {
+        free_[std::make_pair(owner->second, granted)].push_back(p);     // filed under the device it was made on
         kept_ += granted;
         return;
       }
+      if (owner != owner_.end()) owner_.erase(owner);
     }
     qsx_device_free(p);
   }
 
  private:
   std::mutex mutex_;
-  std::map<std::size_t, std::vector<void *>> free_;
+  // slabs by (device, size class): the pool is process-wide, Worker pools are per device
+  static std::pair<int, std::size_t> keyOf(std::size_t cls) {
+    int device = 0;
+    (void)qsx_current_device(&device);
+    return std::make_pair(device, cls);
+  }
+  std::map<std::pair<int, std::size_t>, std::vector<void *>> free_;
+  std::map<void *, int> owner_;                  // every pooled slab, out or in: its device
   std::size_t kept_ = 0;
 };
 

@@ -33,8 +33,15 @@ void GivePooled(void *p, std::size_t granted);
 struct DeviceBuffer {
   static constexpr std::size_t kCacheFrom = 64 * 1024 + 1;
   static constexpr std::size_t kCacheBytes = std::size_t(2) << 30;
+  // (device, size class): a thread that moves to another device (qsx_set_current_device) must not be handed the other
+  // device's memory — Worker threads stay on one device, callers of the layer need not
+  static std::pair<int, std::size_t> classKey(std::size_t size_class) {
+    int device = 0;
+    (void)qsx_current_device(&device);
+    return std::make_pair(device, size_class);
+  }
   struct Cache {
-    std::map<std::size_t, std::vector<void *>> free_by_class;
+    std::map<std::pair<int, std::size_t>, std::vector<void *>> free_by_class;
     std::size_t bytes = 0;
     ~Cache() {
       for (auto &cls : free_by_class) for (void *p : cls.second) qsx_device_free(p);
@@ -74,7 +81,7 @@ struct DeviceBuffer {
       size_class = 128 * 1024;
       while (size_class < bytes) size_class *= 2;
       Cache &c = cache();
-      auto it = c.free_by_class.find(size_class);
+      auto it = c.free_by_class.find(classKey(size_class));
       if (it != c.free_by_class.end() && !it->second.empty()) {
         ptr = it->second.back();
         it->second.pop_back();
@@ -102,7 +109,7 @@ struct DeviceBuffer {
     if (size_class != 0) {
       Cache &c = cache();
       if (c.bytes + size_class <= kCacheBytes) {
-        c.free_by_class[size_class].push_back(ptr);
+        c.free_by_class[classKey(size_class)].push_back(ptr);
         c.bytes += size_class;
         return;
       }

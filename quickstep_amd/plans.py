@@ -14,7 +14,6 @@ Synthetic inputs (no dbgen here): dense keys, every rank owns a contiguous key r
 so `key & (P - 1)` is uniform over a rank's rows and a shuffle really moves (P - 1) / P of them.
 """
 import torch
-import torch.distributed as dist
 
 from . import distributed as qd
 from . import types as T
@@ -24,9 +23,7 @@ SEG_BUILDING = 1
 
 
 def _world_rank(group=None):
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_world_size(group), dist.get_rank(group)
-    return 1, 0
+    return qd.world_size(group), qd.rank_of(group)
 
 
 # ------------------------------------------------------------------------------------------------ C4

@@ -1,7 +1,11 @@
-"""Worker of tests/test_gpu_two_ranks.py: one of TWO rank processes that share the box's single GPU and run the multi-GPU
-rank logic (quickstep_amd/distributed.py, quickstep_amd/plans.py) with the PRODUCT's kernels (ops = quickstep_amd.capi).
-RCCL refuses two ranks on one device, so the process group is gloo and distributed.py stages the device tensors through the
-host (its _Transport) — same bytes, same order, same kernels on either side of every exchange.
+"""Worker of tests/test_gpu_two_ranks.py: one of the rank processes (2 or 3) that share the box's single GPU and run the
+multi-GPU rank logic (quickstep_amd/distributed.py, quickstep_amd/plans.py) with the PRODUCT's kernels (ops =
+quickstep_amd.capi).  RCCL refuses two ranks on one device, so argv[2] picks the transport:
+  gloo  the process group is gloo and distributed.py stages the device tensors through the host (its _Transport) — same
+        bytes, same order, same kernels on either side of every exchange;
+  capi  every exchange goes through the C ABI's multi-GPU entry points (qd.CapiGroup -> qsx_alltoallv, qsx_allgather,
+        qsx_bitmap_allreduce_or, qsx_agg_reduce_scatter, qsx_agg_allgather_merge), libqsx.so bound to the tests' loopback
+        transport instead of RCCL (QSX_RCCL_LIBRARY = tests/cpp/bin/libloopback_rccl.so).
 Every rank writes what it produced to argv[1]; the parent test compares the union with the CPU oracle."""
 import os
 import sys
@@ -34,11 +38,16 @@ def q1_config():
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    out_dir = sys.argv[1]
-    torch.cuda.set_device(0)                      # both ranks: the one GPU of the box
+    out_dir, transport = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "gloo"
+    torch.cuda.set_device(0)                      # all ranks: the one GPU of the box
     dev = torch.device("cuda", 0)
     assert capi.device_count() >= 1
     dist.init_process_group(backend="gloo")
+    group = None
+    if transport == "capi":
+        assert os.environ.get("QSX_RCCL_LIBRARY"), "the capi transport of this test needs the loopback library"
+        group = qd.CapiGroup.from_torch_group(capi, dev)
+        assert (group.world, group.rank) == (world, rank)
     rng = np.random.default_rng(500 + rank)
     save = {}
 
@@ -46,7 +55,7 @@ def main():
     n_build, n_probe = 30_000, 250_000
     bk = rng.integers(-20_000, 20_000, size=n_build).astype(np.int32)
     pk = rng.integers(-25_000, 25_000, size=n_probe).astype(np.int32)
-    join = qd.PartitionedHashJoin(capi, T.INT, 2 * n_build)
+    join = qd.PartitionedHashJoin(capi, T.INT, 2 * n_build, group=group)
     join.build(torch.from_numpy(bk).to(dev), rank * n_build)
     pt, bt, op, ob, cnt = join.probe(torch.from_numpy(pk).to(dev), rank * n_probe)   # counts first: duplicates
     gp, gb = join.materialize(pt, bt, op, ob, cnt)
@@ -55,17 +64,17 @@ def main():
     # ---- BASELINE config 4: partitioned join with payload columns, strided directly addressed tables
     orders_per_rank = 40_000
     c4 = plans.generate_c4_inputs(dev, orders_per_rank, rank)
-    pj = plans.PartitionedJoin(capi, orders_per_rank * world, orders_per_rank, dense=True)
+    pj = plans.PartitionedJoin(capi, orders_per_rank * world, orders_per_rank, group=group, dense=True)
     assert pj.join.table is not None
     cols, moved = pj.step(c4, rank * orders_per_rank, 0)
     assert plans.PartitionedJoin.check(cols)
-    assert bool(((cols[0] & (world - 1)) == rank).all())          # every output row sits on the rank that owns its key
+    assert bool(((cols[0] % world) == rank).all())                # every output row sits on the rank that owns its key
     save.update(c4_o_key=c4["o_orderkey"].cpu().numpy(), c4_l_key=c4["l_orderkey"].cpu().numpy(),
                 c4_l_pay=c4["l_payload"].cpu().numpy(), c4_out_key=cols[0].cpu().numpy(), c4_out_o=cols[1].cpu().numpy(),
                 c4_out_l=cols[2].cpu().numpy(), c4_moved=np.int64(moved))
 
     # ---- broadcast join
-    bj = qd.BroadcastHashJoin(capi, T.INT, n_build * world)
+    bj = qd.BroadcastHashJoin(capi, T.INT, n_build * world, group=group)
     assert bj.build(torch.from_numpy(bk).to(dev), rank * n_build) == n_build * world
     total_b = int(bj.table.probe_count(torch.from_numpy(pk).to(dev)).item())
     _, _, op3, ob3, cnt3 = bj.probe(torch.from_numpy(pk).to(dev), rank * n_probe, capacity=total_b)
@@ -80,7 +89,7 @@ def main():
                rng.integers(0, 11, size=n) / 100.0, rng.integers(0, 9, size=n) / 100.0]
     st = capi.AggState(q1_config())
     st.update([torch.from_numpy(c).to(dev) for c in q1_cols], n)
-    qd.merge_agg_state_images(capi, st)
+    qd.merge_agg_state_images(capi, st, group=group)
     keys, vals, _, groups = st.finalize(dev)
     g = int(groups.item())
     for i, c in enumerate(q1_cols):
@@ -99,11 +108,7 @@ def main():
                              aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1)), (T.AGG_MIN, T.col(1))], num_entries=entries)
     ds = capi.AggState(dcfg)
     ds.update([torch.from_numpy(dkeys).to(dev), torch.from_numpy(dvals).to(dev)], dn)
-    image = ds.export(dev)
-    exist_words = (entries + 63) // 64
-    reduced = qd.reduce_scatter_dense_agg_image(image, exist_words, entries, int_col_mask=0b001, num_cols=3, min_max_cols={2: "min"})
-    ds.clear()
-    ds.import_merge(reduced)
+    qd.reduce_scatter_dense_state(ds, dev, group=group)
     dk, dv, _, dg = ds.finalize(dev, partition=rank, num_partitions=world)
     dg = int(dg.item())
     save.update(d_keys_in=dkeys, d_vals_in=dvals, d_key=dk[0].cpu().numpy()[:dg], d_cnt=dv[0].cpu().numpy()[:dg],
@@ -112,7 +117,7 @@ def main():
     # ---- BASELINE config 5: Q3 with LIP filters, broadcast build sides, reduce-scatter of the dense partial aggregates
     q3_in = plans.generate_q3_inputs(dev, 0.02, rank, world)
     for fused in (True, False):
-        q3 = plans.DistributedQ3(capi, q3_in["customers_total"], q3_in["orders_total"], use_lip=True, fused=fused)
+        q3 = plans.DistributedQ3(capi, q3_in["customers_total"], q3_in["orders_total"], group=group, use_lip=True, fused=fused)
         res = q3.run(q3_in, tid_base_orders=rank * q3_in["o_orderkey"].numel())
         tag = "f" if fused else "g"
         # this rank's groups after the merge (all of them, for the parent's comparison)
@@ -126,9 +131,11 @@ def main():
             save["q3in_" + k] = v.cpu().numpy()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **save)
     torch.cuda.synchronize()
+    if group is not None:
+        group.comm.close()
     dist.barrier()
     dist.destroy_process_group()
-    print(f"TWO_RANKS_OK rank {rank}")
+    print(f"RANKS_OK rank {rank}")
 
 
 if __name__ == "__main__":

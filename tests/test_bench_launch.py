@@ -39,3 +39,12 @@ def test_under_torch_distributed_run_nothing_is_relaunched():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["world_size_seen"] == 2 and line["self_launched"] is False
+
+
+def test_loopback_transport_protocol_selftest():
+    """tests/cpp/loopback: the stand-in for RCCL that lets several ranks share one GPU (QSX_RCCL_LIBRARY) — its rendezvous,
+    grouped send / recv matching, collectives and reductions at world 1, 2, 3, with host memory in place of device memory."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "loopback_selftest")
+    assert os.path.exists(exe), "make -C quickstep_amd/host builds it"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "loopback selftest ok" in r.stdout, r.stdout + r.stderr

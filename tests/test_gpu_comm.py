@@ -48,3 +48,79 @@ def test_single_rank_collectives_through_the_c_abi(capi, dev):
     with pytest.raises(capi.QsxError):
         comm.agg_allgather_merge(dense)
     comm.close()
+
+
+# ---- world 2 and 3 over the loopback transport -----------------------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 3])
+def test_c_abi_collectives_at_world_2_and_3(world, tmp_path):
+    """The N > 1 branches of qsx_exchange_counts / qsx_alltoallv / qsx_allgather / qsx_bitmap_allreduce_or /
+    qsx_agg_reduce_scatter / qsx_agg_allgather_merge (tests/comm_loopback_worker.py: rank processes sharing cuda:0, libqsx.so
+    bound to tests/cpp/bin/libloopback_rccl.so).  The workers assert bit-equality with quickstep_amd/distributed.py's
+    torch.distributed route; here the union of the ranks' results is checked against numpy restatements of the aggregates."""
+    import functools
+    from test_gpu_two_ranks import LOOPBACK, launch_ranks
+    from comm_loopback_worker import DENSE_CASES, dense_inputs, hash_inputs
+    import os
+    assert os.path.exists(LOOPBACK), "tests/cpp/bin/libloopback_rccl.so is not built (make -C quickstep_amd/host)"
+    launch_ranks(world, "comm_loopback_worker.py", [tmp_path], {"QSX_RCCL_LIBRARY": LOOPBACK})
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+
+    want = functools.reduce(np.bitwise_or, [d["or_in"] for d in ranks])
+    for d in ranks:
+        assert np.array_equal(d["or_out"], want)
+
+    def aggregate(kind, keys, values, entries):
+        """numpy restatement per key: (values of present keys, present mask)"""
+        present = np.bincount(keys, minlength=entries) > 0
+        if kind == "count":
+            return np.bincount(keys, minlength=entries), present
+        if kind == "sum":
+            if values.dtype == np.float64:
+                return np.bincount(keys, weights=values, minlength=entries), present     # multiples of 1/64: exact
+            out = np.zeros(entries, dtype=np.int64)
+            np.add.at(out, keys, values)
+            return out, present
+        out = np.full(entries, values.max() if kind == "min" else values.min(), dtype=values.dtype)
+        (np.minimum if kind == "min" else np.maximum).at(out, keys, values)
+        return out, present
+
+    for name, (entries, _, aggs) in DENSE_CASES.items():
+        inputs = [dense_inputs(name, r) for r in range(world)]
+        keys = np.concatenate([i[0] for i in inputs])
+        cols = {1: np.concatenate([i[1] for i in inputs]), 2: np.concatenate([i[2] for i in inputs])}
+        length = (entries + world - 1) // world
+        seen = []
+        for r, d in enumerate(ranks):
+            k = d[f"dense_{name}_key"]
+            assert ((k >= min(r * length, entries)) & (k < min((r + 1) * length, entries))).all(), name   # only its own key range
+            assert (np.diff(k) > 0).all()
+            seen.append(k)
+            for i, (kind, arg) in enumerate(aggs):
+                got = d[f"dense_{name}_val{i}"]
+                if kind == T.AGG_COUNT_STAR:
+                    ref, _ = aggregate("count", keys, None, entries)
+                elif kind == T.AGG_AVG:
+                    s_, _ = aggregate("sum", keys, cols[arg.index], entries)
+                    c_, _ = aggregate("count", keys, None, entries)
+                    ref = s_ / np.maximum(c_, 1)
+                else:
+                    ref, _ = aggregate({T.AGG_SUM: "sum", T.AGG_MIN: "min", T.AGG_MAX: "max"}[kind], keys, cols[arg.index], entries)
+                assert np.array_equal(got, ref[k].astype(got.dtype)), (name, i)
+                assert not d[f"dense_{name}_null{i}"].any()
+        assert np.array_equal(np.concatenate(seen), np.nonzero(np.bincount(keys, minlength=entries))[0]), name   # every group exactly once
+
+    inputs = [hash_inputs(r) for r in range(world)]
+    keys = np.concatenate([i[0] for i in inputs])
+    a = np.concatenate([i[1] for i in inputs])
+    b = np.concatenate([i[2] for i in inputs])
+    uniq, inv = np.unique(keys, return_inverse=True)
+    sums = np.bincount(inv, weights=a)
+    counts = np.bincount(inv)
+    mins = np.full(uniq.size, b.max())
+    np.minimum.at(mins, inv, b)
+    maxs = np.full(uniq.size, a.min())
+    np.maximum.at(maxs, inv, a)
+    for d in ranks:                                  # every rank ends with the whole merged table
+        assert np.array_equal(d["hash_key"], uniq)
+        assert np.array_equal(d["hash_val0"], sums) and np.array_equal(d["hash_val1"], counts)
+        assert np.array_equal(d["hash_val2"], mins) and np.array_equal(d["hash_val3"], maxs)

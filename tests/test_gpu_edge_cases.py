@@ -193,3 +193,40 @@ def test_calls_follow_the_calling_threads_device(capi, dev):
     t.join()
     assert seen == [count - 1]
     assert capi.current_device() == torch.cuda.current_device()
+
+
+def test_idle_allocations_are_reused_on_their_own_device_only(capi, dev):
+    """the idle-allocation cache (a destroyed table's / state's memory kept for the next create of the same
+    size) is keyed by (device, size).  One device: destroy -> create of the same size hands the same memory back.  With a
+    second device in the box: a create issued from a thread on device 1 must NOT receive device 0's memory."""
+    cfg = T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None), (T.DOUBLE, None)], keys=[0], aggs=[(T.AGG_SUM, T.col(1))], num_entries=777_777)
+    st = capi.AggState(cfg)
+    k0 = torch.arange(0, 1000, device=dev, dtype=torch.int32)
+    st.update([k0, torch.ones(1000, device=dev, dtype=torch.float64)], 1000)
+    assert int(st.finalize(dev)[3].item()) == 1000
+    st.close()
+    st2 = capi.AggState(cfg)                   # same size, same device: the idle allocation comes back, cleared
+    assert int(st2.finalize(dev)[3].item()) == 0
+    st2.close()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU in this box: the cross-device half of this test needs two")
+    import threading
+    seen = {}
+
+    def on_device_1():
+        capi.set_current_device(1)
+        d1 = torch.device("cuda", 1)
+        other = capi.AggState(cfg)             # would be handed device 0's idle image if the cache were keyed by size alone
+        k = torch.randint(0, 777_777, (100_000,), device=d1, dtype=torch.int32)
+        v = torch.ones(100_000, device=d1, dtype=torch.float64)
+        other.update([k, v], k.numel())
+        _, vals1, _, g1 = other.finalize(d1)
+        seen["groups"] = int(g1.item())
+        seen["sum"] = float(vals1[0][: seen["groups"]].sum().item())
+        seen["want_groups"] = int(torch.unique(k).numel())
+        other.close()
+
+    t = threading.Thread(target=on_device_1)
+    t.start()
+    t.join()
+    assert seen["groups"] == seen["want_groups"] and seen["sum"] == 100_000.0

@@ -1,7 +1,11 @@
-"""N = 2 with the product's kernels: two rank processes share cuda:0 (tests/dist_worker_gpu.py), ops = quickstep_amd.capi,
-collectives over gloo with host staging.  The union of what the ranks produce must be what one process / the CPU oracle
-produces: shuffle joins (hashed and strided directly addressed tables, payload columns = BASELINE config 4), broadcast join,
-Q1 state merge (all-gather + import-merge), dense state reduce-scatter, and the distributed Q3 plan (BASELINE config 5)."""
+"""N = 2 and 3 with the product's kernels: the rank processes share cuda:0 (tests/dist_worker_gpu.py), ops =
+quickstep_amd.capi.  Transports: "gloo" = torch.distributed collectives with host staging; "capi" = the C ABI's own
+multi-GPU entry points (qsx_alltoallv, qsx_allgather, qsx_bitmap_allreduce_or, qsx_agg_reduce_scatter,
+qsx_agg_allgather_merge) over the tests' loopback stand-in for RCCL, at world 2 and at world 3 (not a power of two:
+hash % P partitions, hashed tables, key ranges that do not divide).  The union of what the ranks produce must be what one
+process / the CPU oracle produces: shuffle joins (hashed and strided directly addressed tables, payload columns =
+BASELINE config 4), broadcast join, Q1 state merge, dense state reduce-scatter, and the distributed Q3 plan (BASELINE
+config 5)."""
 import os
 import socket
 import subprocess
@@ -15,22 +19,32 @@ from helpers import q3_reference_numpy, sorted_pairs
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORLD = 2
+LOOPBACK = os.path.join(ROOT, "tests", "cpp", "bin", "libloopback_rccl.so")
 
 
-@pytest.fixture(scope="module")
-def ranks(tmp_path_factory):
-    out = tmp_path_factory.mktemp("two_ranks")
+def launch_ranks(world, script, args, extra_env=None, timeout=900):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={WORLD}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(out)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", script)] + [str(a) for a in args]
     env = dict(os.environ, OMP_NUM_THREADS="1", QSX_AGG_JIT="0")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0 and r.stdout.count("TWO_RANKS_OK") == WORLD, r.stdout[-3000:] + r.stderr[-6000:]
-    return [np.load(out / f"rank{i}.npz") for i in range(WORLD)]
+    env.update(extra_env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0 and r.stdout.count("RANKS_OK") == world, r.stdout[-3000:] + r.stderr[-6000:]
+
+
+@pytest.fixture(scope="module", params=[(2, "gloo"), (2, "capi"), (3, "capi")], ids=lambda p: f"world{p[0]}-{p[1]}")
+def ranks(request, tmp_path_factory):
+    world, transport = request.param
+    out = tmp_path_factory.mktemp(f"ranks_{world}_{transport}")
+    extra = {}
+    if transport == "capi":
+        assert os.path.exists(LOOPBACK), "tests/cpp/bin/libloopback_rccl.so is not built (make -C quickstep_amd/host)"
+        extra["QSX_RCCL_LIBRARY"] = LOOPBACK
+    launch_ranks(world, "dist_worker_gpu.py", [out, transport], extra)
+    return [np.load(out / f"rank{i}.npz") for i in range(world)]
 
 
 def test_shuffle_join_hashed_tables_equals_oracle_join(ranks, oracle):
@@ -38,7 +52,7 @@ def test_shuffle_join_hashed_tables_equals_oracle_join(ranks, oracle):
     probe = np.concatenate([d["h_probe"] for d in ranks])
     got = np.concatenate([np.stack([d["h_pp"], d["h_pb"]], 1) for d in ranks])
     for i, d in enumerate(ranks):                                     # a pair sits on the rank that owns its key's partition
-        assert ((probe[d["h_pp"]].astype(np.uint32) & (WORLD - 1)) == i).all()
+        assert ((probe[d["h_pp"]].astype(np.uint32) % len(ranks)) == i).all()       # hash = the zero-extended key, pid = h % P
     t = oracle.JoinTable(T.INT, build.size)
     t.build(build)
     p, b = t.probe(probe)
@@ -103,7 +117,8 @@ def test_dense_state_reduce_scatter_gives_every_rank_its_key_range(ranks):
     sm = np.bincount(keys, weights=vals, minlength=entries)
     mn = np.full(entries, np.inf)
     np.minimum.at(mn, keys, vals)
-    length = (entries + WORLD - 1) // WORLD
+    world = len(ranks)
+    length = (entries + world - 1) // world
     seen = []
     for r, d in enumerate(ranks):
         k = d["d_key"]
