@@ -182,6 +182,7 @@ bool FinalizeAggregationOperator::getAllWorkOrders(WorkOrdersContainer *containe
     for (partition_id part = 0; part < num_partitions_; ++part) {
       AggregationOperationState *state = query_context->getAggregationState(aggr_state_index_, part);
       for (std::size_t p = 0; p < aggr_state_num_partitions_; ++p) {
+        if (rank_slice_ >= 0 && p != static_cast<std::size_t>(rank_slice_)) continue;   // the other slices are other ranks'
         container->addNormalWorkOrder(new FinalizeAggregationWorkOrder(query_id_, p, aggr_state_num_partitions_, state, dest),
                                       op_index_);
       }

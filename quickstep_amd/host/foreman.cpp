@@ -251,6 +251,12 @@ void ForemanSingleNode::run() {
             if (e.breaker) blocked = true;
           }
         }
+        if (plan_->getOperator(op)->isCollective()) {
+          // collectives in plan order, one operator at a time: every rank then issues the same sequence
+          for (std::size_t earlier = 0; earlier < op; ++earlier) {
+            if (!finished[earlier] && plan_->getOperator(earlier)->isCollective()) blocked = true;
+          }
+        }
         if (!blocked && !done_generating[op]) {
           // only the Foreman thread ever calls getAllWorkOrders (SURVEY §8b Threading)
           lock.unlock();

@@ -475,6 +475,11 @@ class AggregationOperationState {
   // getCollisionFreeVectorTable()->getExistenceMap()->setBit(key) for every tuple of the block
   // (BuildAggregationExistenceMapOperator.cpp:177-208); the state must use QSX_AGG_COLLISION_FREE
   void buildExistenceMap(const StorageBlock &block, attribute_id build_attribute, const Type &type);
+  // Partial aggregates of every rank -> merged (ExchangeAggregationStatesOperator).  Hash-table states: every rank ends
+  // with the whole merged table (qsx_agg_allgather_merge); CollisionFreeVector states: rank r ends with the merged groups
+  // of key range r (qsx_agg_reduce_scatter) — finalize with (partition = rank, num_partitions = world) either way.
+  // A collective: every rank calls it for the same states in the same order.  DISTINCT aggregates are not supported.
+  void mergeAcrossRanks(qsx_comm_t *comm);
   const AggregationStateSpec &spec() const { return spec_; }
   // blocks aggregated on their code stripes (qsx_agg_update_coded) rather than on decoded values
   std::int64_t numBlocksAggregatedOnCodes() const { return coded_blocks_.load(); }
@@ -666,7 +671,8 @@ class WorkOrdersContainer {
 class RelationalOperator {
  public:
   enum OperatorType { kAggregation = 0, kBuildAggregationExistenceMap, kBuildHash, kDestroyAggregationState, kDestroyHash, kFinalizeAggregation,
-                      kInitializeAggregation, kInnerJoin, kSelect, kSortMergeRun, kSortRunGeneration, kMockOperator };
+                      kInitializeAggregation, kInnerJoin, kSelect, kSortMergeRun, kSortRunGeneration, kMockOperator,
+                      kPartitionExchange, kExchangeAggregationStates };   // (the last two: multi-GPU, no counterpart in the reference)
   virtual ~RelationalOperator() {}
   virtual OperatorType getOperatorType() const = 0;
   virtual std::string getName() const = 0;
@@ -693,6 +699,10 @@ class RelationalOperator {
   // :164 — called by the query manager when the operator has finished; none of the operators here touches the catalog
   // at that point (the reference's overriders are the DDL / load operators)
   virtual void updateCatalogOnCompletion() {}
+  // Multi-GPU: the operator's work order issues collectives (every rank must run it, and all ranks must run such operators
+  // in the same order).  The Foreman lets a collective operator start only when every collective operator with a smaller
+  // plan index has finished — all ranks build the same plan, so all issue the same sequence of collectives.
+  virtual bool isCollective() const { return false; }
 
  protected:
   explicit RelationalOperator(std::size_t query_id, std::size_t num_partitions = 1, bool has_repartition = false,
@@ -1034,12 +1044,17 @@ class FinalizeAggregationOperator : public RelationalOperator {
                         const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
   QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
   relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+  // One process per GPU: after ExchangeAggregationStatesOperator every rank holds the merged state (hash tables) or the
+  // merged groups of its key range (CollisionFreeVector); construct the operator with aggr_state_num_partitions = world and
+  // let rank r emit finalize partition r only — every group leaves the job exactly once.
+  void setRankSlice(std::size_t rank) { rank_slice_ = static_cast<std::int64_t>(rank); }
 
  private:
   const QueryContext::aggregation_state_id aggr_state_index_;
   const std::size_t aggr_state_num_partitions_;
   const CatalogRelation &output_relation_;
   const QueryContext::insert_destination_id output_destination_index_;
+  std::int64_t rank_slice_ = -1;   // >= 0: only this finalize partition of every state
   bool started_ = false;
 };
 
@@ -1150,6 +1165,103 @@ class SortMergeRunOperator : public RelationalOperator {
   const bool input_relation_is_stored_;
   std::mutex mutex_;
   std::vector<block_id> input_relation_block_ids_;
+  bool work_generated_ = false;
+};
+
+// ---------------------------------------------------------------------------
+// Multi-GPU: one process per GPU, every process runs the SAME plan under its own ForemanSingleNode over its own
+// StorageManager and QueryContext; GPU (rank) r owns the partitions p with p % world == r of every hash-partitioned
+// relation.  The reference's partitions share one address space — PartitionAwareInsertDestination routes a tuple to the
+// block of its partition (storage/InsertDestination.hpp:490-660) and the per-partition work orders of BuildHash / HashJoin /
+// Aggregation read them where they lie (BuildHashOperator.cpp:82-91, HashJoinOperator.cpp:220-231,
+// AggregationOperator.cpp:49-61); its distributed mode moves whole blocks between the StorageManagers of its nodes on
+// demand (storage/DataExchangerAsync.cpp, DataExchange.proto:22-34: Pull by block id).  Here a partition that is not this
+// rank's leaves as one exchange step per plan edge: PartitionExchangeOperator behind the repartitioning producer
+// (qsx_exchange_counts + qsx_alltoallv per attribute = RCCL all-to-all over xGMI), and ExchangeAggregationStatesOperator in
+// front of FinalizeAggregation (qsx_agg_reduce_scatter / qsx_agg_allgather_merge).  Collectives are issued by exactly one
+// work order per such operator, and the Foreman runs those operators one after the other in plan order
+// (RelationalOperator::isCollective), so all ranks issue the same sequence of collectives.
+// ---------------------------------------------------------------------------
+class RankGroup {
+ public:
+  // Rank 0 makes the id; the caller's control plane carries the QSX_COMM_ID_BYTES to the other ranks (the reference's
+  // control plane is the TMB; tests use a file).
+  static std::vector<unsigned char> MakeUniqueId();
+  RankGroup(int world, int rank, const void *id_bytes);   // qsx_comm_create on the calling thread's device
+  ~RankGroup();
+  RankGroup(const RankGroup &) = delete;
+  RankGroup &operator=(const RankGroup &) = delete;
+  int world() const { return world_; }
+  int rank() const { return rank_; }
+  qsx_comm_t *comm() const { return comm_; }
+  std::size_t ownerOf(partition_id part) const { return part % static_cast<std::size_t>(world_); }
+  bool owns(partition_id part) const { return ownerOf(part) == static_cast<std::size_t>(rank_); }
+
+ private:
+  int world_, rank_;
+  qsx_comm_t *comm_ = nullptr;
+};
+
+// The blocks of `input_relation` on this rank -> the ranks that own their partitions.
+//   partitioned input (a relation with a partition scheme, filled by a PartitionAwareInsertDestination or stored): the
+//     tuples of partition p go to rank p % world; the output relation has the same attributes and partition scheme, its
+//     blocks — one per owned partition and round, tuples of rank 0 first, every rank's in their local order — are
+//     registered under their partition and streamed to the consumers with it (kDataPipelineMessage's partition id);
+//   unpartitioned input + broadcast = true: every rank receives the tuples of all ranks (rank order) as ONE block of the
+//     (unpartitioned) output relation — the build side of a broadcast join (BuildHashOperator.hpp:99, 146-152).
+// One work order, generated when the input is complete (the operator is a pipeline breaker towards its producer); NULL
+// bitmaps of nullable attributes travel as word-aligned bitmaps per (source rank, partition) and are re-packed on arrival.
+class PartitionExchangeOperator : public RelationalOperator {
+ public:
+  PartitionExchangeOperator(std::size_t query_id, const CatalogRelation &input_relation, bool input_relation_is_stored,
+                            const CatalogRelation &output_relation, QueryContext::insert_destination_id output_destination_index,
+                            RankGroup *ranks, bool broadcast = false);
+  OperatorType getOperatorType() const override { return kPartitionExchange; }
+  bool isCollective() const override { return true; }
+  std::string getName() const override { return "PartitionExchangeOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+  void feedInputBlock(const block_id input_block_id, const relation_id, const partition_id part_id) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    input_.ids.at(broadcast_ ? 0 : part_id).push_back(input_block_id);
+  }
+  QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
+  relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+  // bytes this rank sent to other ranks / received from them (after the work order has run)
+  std::uint64_t bytesSentToPeers() const { return bytes_sent_.load(); }
+
+ private:
+  friend class PartitionExchangeWorkOrder;
+  const CatalogRelation &input_relation_;
+  const bool input_relation_is_stored_;
+  const CatalogRelation &output_relation_;
+  const QueryContext::insert_destination_id output_destination_index_;
+  RankGroup *ranks_;
+  const bool broadcast_;
+  std::mutex mutex_;
+  PartitionedBlockIds input_;
+  std::atomic<std::uint64_t> bytes_sent_{0};
+  bool work_generated_ = false;
+};
+
+// The partial aggregation states of all ranks merged, in front of FinalizeAggregationOperator (a pipeline breaker after
+// the AggregationOperator): one work order, state partitions in order, AggregationOperationState::mergeAcrossRanks each.
+// The counterpart of merging the partitions' / threads' tables at finalize (storage/AggregationOperationState.cpp:831-843,
+// 925-948) when a partition is a GPU.
+class ExchangeAggregationStatesOperator : public RelationalOperator {
+ public:
+  ExchangeAggregationStatesOperator(std::size_t query_id, QueryContext::aggregation_state_id aggr_state_index, std::size_t num_partitions,
+                                    RankGroup *ranks)
+      : RelationalOperator(query_id, num_partitions), aggr_state_index_(aggr_state_index), ranks_(ranks) {}
+  OperatorType getOperatorType() const override { return kExchangeAggregationStates; }
+  bool isCollective() const override { return true; }
+  std::string getName() const override { return "ExchangeAggregationStatesOperator"; }
+  bool getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
+                        const tmb::client_id scheduler_client_id, tmb::MessageBus *bus) override;
+
+ private:
+  const QueryContext::aggregation_state_id aggr_state_index_;
+  RankGroup *ranks_;
   bool work_generated_ = false;
 };
 

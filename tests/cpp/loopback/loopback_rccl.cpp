@@ -77,7 +77,10 @@ struct Comm {
 thread_local int group_depth = 0;
 thread_local std::vector<Op> group_ops;
 thread_local Comm *group_comm = nullptr;
-thread_local Comm *last_comm = nullptr;   // a group this rank put nothing into is still a round of its communicator
+// A group this rank put nothing into is still a round of its communicator: the one this thread used last, else — rank
+// processes issue their collectives from whichever Worker thread runs the work order — the process's communicator.
+thread_local Comm *last_comm = nullptr;
+std::atomic<Comm *> process_comm{nullptr};
 
 double now_seconds() {
   timespec ts;
@@ -314,6 +317,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int r
   if (!barrier(c)) return ncclSystemError;
   *out = reinterpret_cast<ncclComm_t>(c);
   last_comm = c;
+  process_comm.store(c);
   return ncclSuccess;
 }
 
@@ -321,6 +325,8 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm *c = reinterpret_cast<Comm *>(comm);
   if (c == nullptr) return ncclSuccess;
   if (last_comm == c) last_comm = nullptr;
+  Comm *expected = c;
+  process_comm.compare_exchange_strong(expected, nullptr);
   for (int r = 0; r < c->world; ++r) {
     if (c->files[r] >= 0) close(c->files[r]);
   }
@@ -340,7 +346,7 @@ ncclResult_t ncclGroupEnd() {
   if (group_depth <= 0) return ncclInvalidUsage;
   if (--group_depth > 0) return ncclSuccess;
   ncclResult_t result = ncclSuccess;
-  if (group_comm == nullptr) group_comm = last_comm;
+  if (group_comm == nullptr) group_comm = last_comm != nullptr ? last_comm : process_comm.load();
   if (group_comm != nullptr) result = run_group(group_comm, group_ops);
   group_ops.clear();
   group_comm = nullptr;

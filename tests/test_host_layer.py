@@ -15,7 +15,8 @@ def _ensure_built():
                ("select_cpu_workorder_test", "hash_join_operator_test", "aggregation_operator_test",
                 "lip_filter_operator_test", "compressed_block_operator_test", "host_logic_test",
                 "sort_operator_test", "nullable_operator_test", "tpch_types_operator_test", "tpch_q3_plan_test", "work_order_runs_test",
-                "partition_operator_test", "headline_operators_bench", "block_image_test")):
+                "partition_operator_test", "headline_operators_bench", "block_image_test", "partitioned_ranks_test",
+                "libloopback_rccl.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quickstep_amd", "host")], check=True)
 
 
@@ -138,3 +139,14 @@ def test_reference_block_images_are_adopted_in_place():
     [null bitmaps][stripes at max_tuples x width]) copied to device memory as they are: Select / Aggregation / HashJoin over
     the adopted blocks equal the same operators over blocks loaded column by column (nullable and non-nullable relations)."""
     _run("block_image_test")
+
+
+@pytest.mark.gpu
+def test_sharding_from_the_operator_layer_two_and_three_rank_processes():
+    """One process per rank, each with its own StorageManager / QueryContext / ForemanSingleNode running the same plan; rank r
+    owns the partitions p % world == r; PartitionExchangeOperator (qsx_exchange_counts + qsx_alltoallv) moves the tuples of
+    foreign partitions, ExchangeAggregationStatesOperator (qsx_agg_allgather_merge / qsx_agg_reduce_scatter) merges partial
+    states; the ranks share cuda:0 over the loopback stand-in for RCCL.  Partition.test's partitioned / broadcast /
+    repartitioned joins and aggregations and the BASELINE config 4 shape: union over ranks = the single-process operators."""
+    out = _run("partitioned_ranks_test", timeout=900)
+    assert "world 2:" in out and "world 3:" in out
