@@ -358,8 +358,8 @@ def run_headline(ctx, args):
     if distributed:
         def make_join(which):
             if which == "broadcast":
-                return qd.BroadcastHashJoin(capi, T.INT, args.build_rows * world, key_domain=(0, key_space - 1) if dense else None)
-            return qd.PartitionedHashJoin(capi, T.INT, 2 * args.build_rows, key_domain=(0, key_space - 1) if dense else None)
+                return qd.BroadcastHashJoin(capi, T.INT, args.build_rows * world, group=ctx.group, key_domain=(0, key_space - 1) if dense else None)
+            return qd.PartitionedHashJoin(capi, T.INT, 2 * args.build_rows, group=ctx.group, key_domain=(0, key_space - 1) if dense else None)
         join = make_join(plan)
         capacity = int(args.probe_rows * 1.25)
     else:
@@ -382,7 +382,7 @@ def run_headline(ctx, args):
                 state.clear()
                 state.update(agg_cols, args.agg_rows)
                 a1.record()
-                qd.merge_agg_state_images(capi, state)
+                qd.merge_agg_state_images(capi, state, group=ctx.group)
                 fin = state.finalize(dev, capacity=16)
                 a2.record()
             e0, e1, e2 = ev(), ev(), ev()
@@ -623,7 +623,7 @@ def run_c4(ctx, args):
     inputs = plans.generate_c4_inputs(dev, n_o, rank)
     n_l = inputs["l_orderkey"].numel()
     torch.cuda.synchronize()
-    pj = plans.PartitionedJoin(capi, n_o * world, n_o, dense=args.join_table == "dense", fused=not args.c4_unfused)
+    pj = plans.PartitionedJoin(capi, n_o * world, n_o, group=ctx.group, dense=args.join_table == "dense", fused=not args.c4_unfused)
     recorded, results = [], {}
 
     def step(timed):
@@ -678,7 +678,7 @@ def run_c5(ctx, args):
     inputs = plans.generate_q3_inputs(dev, args.c5_sf_per_rank, rank, world)
     torch.cuda.synchronize()
     os.environ.setdefault("QSX_AGG_JIT_MIN_ROWS", "0")
-    q3 = plans.DistributedQ3(capi, inputs["customers_total"], inputs["orders_total"], use_lip=not args.no_lip, fused=True)
+    q3 = plans.DistributedQ3(capi, inputs["customers_total"], inputs["orders_total"], group=ctx.group, use_lip=not args.no_lip, fused=True)
     recorded, results = [], {}
 
     def step(timed):
@@ -805,6 +805,10 @@ def main():
     ap.add_argument("--no-operators", action="store_true", help="N = 1: skip the leg that runs the workload through the C++ operator layer")
     ap.add_argument("--operator-workers", type=int, default=8)
     ap.add_argument("--blocks-per-work-order", type=int, default=256)
+    ap.add_argument("--transport", choices=["torch", "capi"], default="torch",
+                    help="who issues the exchange steps: torch = torch.distributed on the nccl backend (RCCL); capi = the C ABI's own "
+                         "multi-GPU entry points (qsx_alltoallv, qsx_allgather, qsx_agg_reduce_scatter, ...: RCCL bound inside "
+                         "libqsx.so, the calls the C++ operator layer makes — quickstep_amd/host/rank_exchange.cpp)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch check without a GPU: the ranks rendezvous over gloo, agree on the world size and rank 0 prints a "
                          "line with no measurement in it (tests/test_bench_launch.py)")
@@ -847,10 +851,17 @@ def main():
                 port = sock.getsockname()[1]
             os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1"})
         dist.init_process_group(backend="nccl", device_id=dev)
+    ctx.group = None
+    if ctx.distributed and args.transport == "capi":
+        from quickstep_amd import distributed as qd
+        ctx.group = qd.CapiGroup.from_torch_group(capi, dev)
 
     line = {"headline": run_headline, "c4": run_c4, "c5": run_c5}[args.config](ctx, args)
     line["world_size_seen"] = dist.get_world_size() if ctx.distributed else 1      # what the RCCL process group reports
     line["self_launched"] = os.environ.get("QSX_BENCH_SELF_LAUNCHED") == "1"
+    line["transport"] = args.transport if ctx.distributed else None
+    if ctx.group is not None:
+        ctx.group.comm.close()
     if rank == 0 and world == 1 and args.config == "headline" and not args.no_operators:
         line["operators"] = operators_leg(args, line["value"])
         variants = line.get("probe", {}).get("variants", {})

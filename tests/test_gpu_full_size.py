@@ -64,3 +64,28 @@ def test_c3_full_size_q1_aggregates_against_independent_reductions(capi, dev):
     fin2 = state.finalize(dev, capacity=16)
     rows_total = sum(b[0].numel() for b in blocks)
     assert bench.check_q1([c[:rows_total] for c in cols], fin2, rows_total) == 4
+
+
+@pytest.mark.parametrize("transport", ["torch", "capi"])
+@pytest.mark.parametrize("config", ["c4", "c5"])
+def test_c4_c5_at_their_per_rank_full_sizes_over_rccl_one_rank(config, transport):
+    """BASELINE configs 4 and 5 at the sizes ONE rank of the 8-GPU job holds (C4: 18.75 M orders + ~75 M lineitems with
+    payload columns, both sides through K9 and the exchange; C5: TPC-H Q3 at SF 37.5 with LIP filters, broadcast build sides,
+    dense group-by, reduce-scatter) through bench.py's own step and CHECKS — every joined row satisfies the join condition,
+    one output row per lineitem row (C4); joined pairs, group count and the top-10 revenues against an independent torch
+    evaluation of the query (C5, sums to 1e-6) — over RCCL with one rank, exchanges issued by torch.distributed and by the
+    C ABI's own entry points (qsx_alltoallv, qsx_allgather, qsx_agg_reduce_scatter)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", config, "--steps", "2", "--warmup", "1", "--transport", transport],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["world_size_seen"] == 1 and line["transport"] == transport
+    if config == "c4":
+        assert line["config"]["output_rows"] == line["config"]["lineitems"] > 70_000_000
+    else:
+        assert line["config"]["joined_pairs"] > 0 and line["config"]["groups"] > 0
