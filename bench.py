@@ -623,7 +623,8 @@ def run_c4(ctx, args):
     inputs = plans.generate_c4_inputs(dev, n_o, rank)
     n_l = inputs["l_orderkey"].numel()
     torch.cuda.synchronize()
-    pj = plans.PartitionedJoin(capi, n_o * world, n_o, group=ctx.group, dense=args.join_table == "dense", fused=not args.c4_unfused)
+    pj = plans.PartitionedJoin(capi, n_o * world, n_o, group=ctx.group, dense=args.join_table == "dense", fused=not args.c4_unfused,
+                               overlap=not args.c4_no_overlap)
     recorded, results = [], {}
 
     def step(timed):
@@ -780,6 +781,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--c4-unfused", action="store_true", help="config c4: pair list + K5 gathers instead of the projecting probe")
+    ap.add_argument("--c4-no-overlap", action="store_true", help="config c4: the probe side's exchange after the build instead of next to it")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=["headline", "c4", "c5"], default="headline")

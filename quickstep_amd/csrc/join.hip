@@ -44,21 +44,51 @@ struct alignas(16) LongEntry {
   uint32_t pad;
 };
 
+// Two layouts behind one view.
+//   LONG keys: open addressing over LongEntry slots, power-of-two capacity at load <= 0.5, linear probing (mask / shift).
+//   INT keys: BUCKETS of 16 slots.  slots[16 b .. 16 b + 15] = one 128-byte line of {tid:32 | key:32} words (all ones =
+//     empty); fp[16 b .. 16 b + 15] = one aligned 16-byte word of 1-byte fingerprints (0 = empty slot).  A key's home bucket
+//     comes from the high bits of its Fibonacci hash by multiply-shift (any bucket count: the table is sized for load 0.8,
+//     not rounded to a power of two), its fingerprint from a second multiplicative hash.  Slots of a bucket fill in order
+//     and never empty again, a key that finds its bucket full goes on to the next one — so a probe reads ONE fingerprint
+//     word per bucket of its sequence (the plane is a tenth of the table and stays in every XCD's L2), compares sixteen
+//     bytes in registers, touches the table only where a fingerprint matches (a miss almost never does: 16 / 255 per
+//     bucket), and stops at the first bucket that still has an empty byte.  1 M keys: 10 MiB of slots + 1.25 MiB of
+//     fingerprints instead of 16 MiB of half-empty units no L2 holds; a probe that misses costs an L2 hit.
+constexpr int kBucketSlots = 16;
 struct TableView {
-  void *slots;    // uint64_t[capacity] (INT) or LongEntry[capacity] (LONG)
-  uint64_t mask;  // capacity - 1 (entries)
-  int shift;      // 64 - log2(capacity)
+  void *slots;    // uint64_t[16 * buckets] (INT) or LongEntry[capacity] (LONG)
+  unsigned char *fp;   // INT: fingerprint plane, 16 * buckets bytes
+  uint64_t buckets;    // INT
+  uint64_t mask;  // LONG: capacity - 1 (entries)
+  int shift;      // LONG: 64 - log2(capacity)
   unsigned int *dup_flag;  // set when an insert of an INT key met an occupant with the same key: the build side is not unique
+  __device__ __host__ uint64_t num_slots(bool is_long) const { return is_long ? mask + 1 : buckets * kBucketSlots; }
 };
 
-// INT keys: 32-bit multiplicative (Fibonacci) hashing — one v_mul_lo_u32 and a shift; the sliced probe evaluates it for
-// every (key, slice) pair.  capacity <= 2^32 slots for 32-bit keys (at most 2^31 entries, two slots per entry).
-__device__ __forceinline__ uint64_t slot_of(int32_t key, const TableView &t) {
+__device__ __forceinline__ uint64_t home_bucket(int32_t key, const TableView &t) {
   const uint32_t h = static_cast<uint32_t>(key) * 0x9E3779B9u;
-  return t.shift > 32 ? (h >> (t.shift - 32)) : h;
+  return (static_cast<uint64_t>(h) * t.buckets) >> 32;
+}
+__device__ __forceinline__ uint32_t fingerprint(int32_t key) {
+  const uint32_t f = (static_cast<uint32_t>(key) * 0x85EBCA6Bu) >> 24;
+  return f != 0u ? f : 1u;
 }
 __device__ __forceinline__ uint64_t slot_of(int64_t key, const TableView &t) {
   return (mix64(static_cast<uint64_t>(key)) * 0x9E3779B97F4A7C15ull) >> t.shift;
+}
+// 0x80 in every byte of x that is zero (exact: nothing carries from one byte into the next)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); }
+// the four 0x80 flags of a word as bits 0..3
+__device__ __forceinline__ uint32_t flags_to_nibble(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
+// A bucket's fingerprint word against fingerprint f: bits 0..15 = slots holding f, bits 16..31 = empty slots.
+__device__ __forceinline__ uint32_t bucket_masks(const uint4 &w, uint32_t f) {
+  const uint32_t ffff = f * 0x01010101u;
+  const uint32_t same = flags_to_nibble(zero_bytes(w.x ^ ffff)) | flags_to_nibble(zero_bytes(w.y ^ ffff)) << 4 |
+                        flags_to_nibble(zero_bytes(w.z ^ ffff)) << 8 | flags_to_nibble(zero_bytes(w.w ^ ffff)) << 12;
+  const uint32_t empty = flags_to_nibble(zero_bytes(w.x)) | flags_to_nibble(zero_bytes(w.y)) << 4 | flags_to_nibble(zero_bytes(w.z)) << 8 |
+                         flags_to_nibble(zero_bytes(w.w)) << 12;
+  return same | empty << 16;
 }
 
 __device__ __forceinline__ bool row_in_filter(const uint64_t *filter, int64_t row) {
@@ -68,18 +98,31 @@ __device__ __forceinline__ bool row_in_filter(const uint64_t *filter, int64_t ro
 __device__ __forceinline__ void insert_entry(const TableView &t, int32_t key, uint32_t tid) {
   uint64_t *slots = static_cast<uint64_t *>(t.slots);
   const uint64_t packed = (static_cast<uint64_t>(tid) << 32) | static_cast<uint32_t>(key);
-  // Home position = entry 0 of the key's 16-byte unit, so that a probe that
-  // starts at the unit boundary sees the sequence without gaps.
-  const uint64_t home = slot_of(key, t) & ~1ull;
-  uint64_t s = home;
+  const uint32_t f = fingerprint(key);
+  uint64_t b = home_bucket(key, t);
   for (;;) {
-    const unsigned long long old =
-        atomicCAS(reinterpret_cast<unsigned long long *>(&slots[s]), kEmpty64, packed);
-    if (old == kEmpty64) break;
-    // an occupant with this key: probes may no longer stop at their first match (join_sliced.hpp).  Every pair of equal
-    // keys is seen by the later of the two inserts, which walks over the earlier one's slot.
-    if (static_cast<uint32_t>(old) == static_cast<uint32_t>(key)) *t.dup_flag = 1u;
-    s = (s + 1) & t.mask;
+    // The bucket's fingerprints as a HINT (a plain load: this CU's L1 may hold an older line; bytes only ever go 0 -> f):
+    // an occupant under another fingerprint is another key and is skipped; one under this key's fingerprint is looked at
+    // (atomic load: slots are published by compare-and-swap at L2); an apparently empty slot is claimed by compare-and-swap,
+    // and a claim that fails shows the occupant.  Every occupant with this key is therefore seen by the later of the two
+    // inserts — probes of a table whose flag stays clear may stop at their first match.
+    const uint4 w = *reinterpret_cast<const uint4 *>(t.fp + b * kBucketSlots);
+    const uint32_t m = bucket_masks(w, f);
+    for (uint32_t same = m & 0xFFFFu; same != 0u; same &= same - 1u) {
+      const unsigned long long old = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&slots[b * kBucketSlots + (__ffs(same) - 1)]),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (static_cast<uint32_t>(old) == static_cast<uint32_t>(key)) *t.dup_flag = 1u;
+    }
+    const uint32_t empty = m >> 16;
+    for (int c = empty != 0u ? __ffs(empty) - 1 : kBucketSlots; c < kBucketSlots; ++c) {
+      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[b * kBucketSlots + c]), kEmpty64, packed);
+      if (old == kEmpty64) {
+        t.fp[b * kBucketSlots + c] = static_cast<unsigned char>(f);
+        return;
+      }
+      if (static_cast<uint32_t>(old) == static_cast<uint32_t>(key)) *t.dup_flag = 1u;
+    }
+    b = b + 1 == t.buckets ? 0 : b + 1;
   }
 }
 
@@ -176,7 +219,7 @@ __global__ __launch_bounds__(kJBlock) void build_runs_kernel(TableView t, const 
 
 // Re-insert every entry of an old table into a bigger one (resize).
 __global__ __launch_bounds__(kJBlock) void rehash_kernel(int is_long, TableView src, TableView dst) {
-  const int64_t cap = static_cast<int64_t>(src.mask) + 1;
+  const int64_t cap = static_cast<int64_t>(src.num_slots(is_long != 0));
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < cap;
        i += static_cast<int64_t>(gridDim.x) * kJBlock) {
     if (is_long) {
@@ -205,7 +248,7 @@ __global__ __launch_bounds__(kJBlock) void dense_pack_kernel(const uint32_t *__r
 
 // Every entry of a hashed table into a directly addressed one (seal_table): what dense_build_kernel does per build row.
 __global__ __launch_bounds__(kJBlock) void dense_build_from_slots_kernel(int is_long, TableView src, DenseTableView d) {
-  const int64_t cap = static_cast<int64_t>(src.mask) + 1;
+  const int64_t cap = static_cast<int64_t>(src.num_slots(is_long != 0));
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < cap;
        i += static_cast<int64_t>(gridDim.x) * kJBlock) {
     int64_t key;
@@ -253,28 +296,6 @@ struct UnitHits {
   int32_t t0, t1;
 };
 
-struct IntUnits {
-  using Key = int32_t;
-  using Raw = ulonglong2;
-  const ulonglong2 *units;
-  uint64_t unit_mask;
-  __device__ IntUnits(const TableView &t) : units(static_cast<const ulonglong2 *>(t.slots)), unit_mask(t.mask >> 1) {}
-  __device__ __forceinline__ uint64_t first_unit(Key k, const TableView &t) const { return slot_of(k, t) >> 1; }
-  __device__ __forceinline__ Raw load(uint64_t u) const { return units[u]; }
-  __device__ __forceinline__ UnitHits inspect(const Raw &u, Key k) const {
-    UnitHits h;
-    const bool e0 = u.x == kEmpty64;
-    const bool e1 = u.y == kEmpty64;
-    h.m0 = !e0 && static_cast<uint32_t>(u.x) == static_cast<uint32_t>(k);
-    // entry 1 is only part of this key's probe sequence if entry 0 is occupied
-    h.m1 = !e0 && !e1 && static_cast<uint32_t>(u.y) == static_cast<uint32_t>(k);
-    h.end = e0 || e1;
-    h.t0 = static_cast<int32_t>(u.x >> 32);
-    h.t1 = static_cast<int32_t>(u.y >> 32);
-    return h;
-  }
-};
-
 struct LongUnits {
   using Key = int64_t;
   using Raw = LongEntry;
@@ -293,10 +314,6 @@ struct LongUnits {
     return h;
   }
 };
-
-}  // namespace qsx
-#include "join_sliced.hpp"
-namespace qsx {
 
 struct PairSink {
   int32_t *stage_probe;  // LDS
@@ -357,8 +374,7 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
   __shared__ int s_fill;
   __shared__ unsigned long long s_base;
   const Units table(t);
-  // no build key occurs twice (the build compared keys on every failed claim): a probe ends at its first match
-  const bool unique = sizeof(Key) == 4 && *t.dup_flag == 0u;
+  const bool unique = false;   // (LONG keys: the build claims slots through the tid word and never compares keys)
   PairSink sink{s_probe, s_build, &s_fill, out_probe, out_build,
                 static_cast<unsigned long long>(capacity), out_count};
   const int64_t num_tiles = kRuns ? runs[2] : (n + kProbeTile - 1) / kProbeTile;
@@ -488,6 +504,166 @@ __global__ __launch_bounds__(kJBlock) void probe_kernel(
   }
 }
 
+// K4 over the bucketed INT table (TableView): same tiles, sources, modes and pair staging as probe_kernel.
+//   phase 1  the fingerprint word of every row's home bucket: 16 independent 16-byte reads of the L2-resident plane;
+//   phase 2  the slot under the first matching fingerprint: 16 independent 8-byte reads of the table — rows without a
+//            matching fingerprint (nearly every probe that misses) read nothing;
+//   phase 3  key compare + emit; whatever is left — another slot under the same fingerprint (a false positive, or duplicate
+//            build keys), a home bucket without an empty byte (go on in the next bucket) — is walked by a wave-uniform loop.
+template <int MODE, bool kRuns = false>
+__global__ __launch_bounds__(kJBlock) void probe_fp_kernel(
+    TableView t, const int32_t *__restrict__ keys, int64_t n, int32_t probe_base_tid,
+    const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe,
+    int32_t *__restrict__ out_build, int64_t capacity, unsigned long long *__restrict__ out_count,
+    uint64_t *__restrict__ out_bitmap, int anti, const long long *__restrict__ runs = nullptr) {
+  using Key = int32_t;
+  using Source = ProbeTileSource<Key>;
+  __shared__ int32_t s_probe[MODE == 0 ? kStage : 1];
+  __shared__ int32_t s_build[MODE == 0 ? kStage : 1];
+  __shared__ int s_fill;
+  __shared__ unsigned long long s_base;
+  const uint64_t *__restrict__ slots = static_cast<const uint64_t *>(t.slots);
+  const uint4 *__restrict__ fp_words = reinterpret_cast<const uint4 *>(t.fp);
+  // no build key occurs twice (the build looked at every occupant that could be this key): a probe ends at its first match
+  const bool unique = *t.dup_flag == 0u;
+  PairSink sink{s_probe, s_build, &s_fill, out_probe, out_build, static_cast<unsigned long long>(capacity), out_count};
+  const int64_t num_tiles = kRuns ? runs[2] : (n + kProbeTile - 1) / kProbeTile;
+  auto source_of = [&](int64_t tile) {
+    return probe_tile_source<Key, kProbeTile, kRuns>(runs, tile, keys, n, probe_base_tid, filter, out_bitmap);
+  };
+  unsigned long long local_count = 0;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  Key key[kRowsPerThread], next_key[kRowsPerThread];
+  uint64_t filter_words = ~0ull, next_filter_words = ~0ull;
+  auto request = [&](const Source &src, Key (&k)[kRowsPerThread], uint64_t &words) {
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const int64_t row = src.base + r * kJBlock + threadIdx.x;
+      k[r] = __builtin_nontemporal_load(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded; streamed once
+    }
+    words = ~0ull;
+    if (src.filter != nullptr && lane < kRowsPerThread) {
+      const int64_t w = (src.base >> 6) + lane * (kJBlock / kWave) + wave;
+      if (w < ((src.n + 63) >> 6)) words = src.filter[w];
+    }
+  };
+  Source cur = Source(), next = Source();
+  if (static_cast<int64_t>(blockIdx.x) < num_tiles) {
+    cur = source_of(blockIdx.x);
+    request(cur, key, filter_words);
+  }
+  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    if (MODE == 0) {
+      if (threadIdx.x == 0) s_fill = 0;
+      __syncthreads();
+    }
+    if (tile + gridDim.x < num_tiles) {
+      next = source_of(tile + gridDim.x);
+      request(next, next_key, next_filter_words);
+    }
+    const int64_t tile_base = cur.base;
+    const int64_t n_rows = cur.n;
+    const int32_t base_tid = cur.base_tid;
+    uint64_t *const tile_bitmap = cur.out_bitmap;
+    cur = next;
+    bool live[kRowsPerThread];
+    uint64_t exists_word = 0;
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const int64_t row = tile_base + r * kJBlock + threadIdx.x;
+      const uint64_t filter_word = __shfl(filter_words, r, kWave);   // before the branch: every lane takes part
+      live[r] = row < n_rows && msb_bit(filter_word, lane);
+    }
+    // phase 1: fingerprint words (unconditional reads: dead rows read bucket 0)
+    uint32_t bucket[kRowsPerThread], masks[kRowsPerThread];
+    {
+      uint4 w[kRowsPerThread];
+#pragma unroll
+      for (int r = 0; r < kRowsPerThread; ++r) {
+        bucket[r] = static_cast<uint32_t>(home_bucket(key[r], t));
+        w[r] = fp_words[live[r] ? bucket[r] : 0u];
+      }
+#pragma unroll
+      for (int r = 0; r < kRowsPerThread; ++r) masks[r] = live[r] ? bucket_masks(w[r], fingerprint(key[r])) : 0x10000u;   // dead: nothing, "empty seen"
+    }
+    // phase 2: the slot under the first matching fingerprint
+    uint64_t first[kRowsPerThread];
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const uint32_t same = masks[r] & 0xFFFFu;
+      first[r] = slots[same != 0u ? static_cast<uint64_t>(bucket[r]) * kBucketSlots + (__ffs(same) - 1) : 0ull];
+    }
+    // phase 3
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const int64_t row = tile_base + r * kJBlock + threadIdx.x;
+      const int32_t probe_tid = static_cast<int32_t>(base_tid + row);
+      uint32_t same = masks[r] & 0xFFFFu, empty = masks[r] >> 16;
+      bool hit = same != 0u && static_cast<uint32_t>(first[r]) == static_cast<uint32_t>(key[r]);
+      bool found = hit;
+      if (MODE == 0) emit_match(sink, hit, probe_tid, static_cast<int32_t>(first[r] >> 32));
+      if (MODE == 1) local_count += hit ? 1u : 0u;
+      same &= same - 1u;
+      // done: one match of a duplicate-free table (or any match of an existence probe), or nothing else under this
+      // fingerprint and the bucket still has room (its sequence ends here)
+      bool walking = live[r] && !(hit && (unique || MODE == 2)) && !(same == 0u && empty != 0u);
+      uint32_t b = bucket[r];
+      const uint32_t f = fingerprint(key[r]);
+      while (__any(walking)) {   // (wave-uniform: emit_match ballots)
+        if (walking && same == 0u) {   // this bucket is used up and was full: the next one
+          b = b + 1u == static_cast<uint32_t>(t.buckets) ? 0u : b + 1u;
+          const uint32_t m = bucket_masks(fp_words[b], f);
+          same = m & 0xFFFFu;
+          empty = m >> 16;
+        }
+        const bool have = walking && same != 0u;
+        const uint64_t e = slots[have ? static_cast<uint64_t>(b) * kBucketSlots + (__ffs(same) - 1) : 0ull];
+        if (have) same &= same - 1u;
+        hit = have && static_cast<uint32_t>(e) == static_cast<uint32_t>(key[r]);
+        found = found || hit;
+        if (MODE == 0) emit_match(sink, hit, probe_tid, static_cast<int32_t>(e >> 32));
+        if (MODE == 1) local_count += hit ? 1u : 0u;
+        if (hit && (unique || MODE == 2)) walking = false;
+        if (same == 0u && empty != 0u) walking = false;
+      }
+      if (MODE == 2) {
+        const bool bit = live[r] && (found != (anti != 0));
+        const uint64_t word = msb_first(__ballot(bit));
+        if (lane == r) exists_word = word;
+        if (lane == 0) local_count += __popcll(word);
+      }
+    }
+    if (MODE == 2) {   // lane r holds the word of step r: one store instruction per tile and wave
+      const int64_t w = (tile_base >> 6) + lane * (kJBlock / kWave) + wave;
+      if (lane < kRowsPerThread && w < ((n_rows + 63) >> 6)) tile_bitmap[w] = exists_word;
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) key[r] = next_key[r];
+    filter_words = next_filter_words;
+    if (MODE == 0) {
+      __syncthreads();
+      const int produced = s_fill;
+      const int staged = produced < kStage ? produced : kStage;
+      if (threadIdx.x == 0) s_base = atomicAdd(out_count, static_cast<unsigned long long>(staged));
+      __syncthreads();
+      const unsigned long long base = s_base;
+      for (int i = threadIdx.x; i < staged; i += kJBlock) {
+        const unsigned long long o = base + i;
+        if (o < sink.capacity) {
+          __builtin_nontemporal_store(s_probe[i], &out_probe[o]);
+          __builtin_nontemporal_store(s_build[i], &out_build[o]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (MODE != 0) {
+    local_count = wave_reduce_add(local_count);
+    if (lane_id() == 0 && local_count != 0 && out_count != nullptr) atomicAdd(out_count, local_count);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // composite keys -> one LONG key (qsx_join_key_pack)
 // ---------------------------------------------------------------------------
@@ -580,7 +756,7 @@ using namespace qsx;
 // ---------------------------------------------------------------------------
 struct qsx_join_table {
   int key_type = QSX_INT;
-  uint64_t capacity = 0;  // entries, power of two
+  uint64_t capacity = 0;  // slots: LONG a power of two (load <= 0.5); INT 16 x buckets (load <= 0.8), fingerprint plane behind the slots
   void *slots = nullptr;
   unsigned long long *entries_dev = nullptr;
   int64_t reserved = 0;   // host-side upper bound of entries (rows handed to build so far)
@@ -635,14 +811,23 @@ struct qsx_join_table {
   }
 
   size_t entry_bytes() const { return key_type == QSX_INT ? 8 : 16; }
+  // bytes of the table: slots, then (INT) one fingerprint byte per slot
+  size_t table_bytes() const { return capacity * entry_bytes() + (key_type == QSX_INT ? capacity : 0); }
+  // rows the table takes at its load limit
+  uint64_t room() const { return key_type == QSX_INT ? capacity / 5 * 4 : capacity / 2; }
   TableView view() const {
-    TableView v;
+    TableView v{};
     v.slots = slots;
+    v.dup_flag = reinterpret_cast<unsigned int *>(entries_dev + 2);
+    if (key_type == QSX_INT) {
+      v.fp = static_cast<unsigned char *>(slots) + capacity * 8;
+      v.buckets = capacity / kBucketSlots;
+      return v;
+    }
     v.mask = capacity - 1;
     int log2 = 0;
     while ((1ull << log2) < capacity) ++log2;
     v.shift = 64 - log2;
-    v.dup_flag = reinterpret_cast<unsigned int *>(entries_dev + 2);
     return v;
   }
 };
@@ -657,16 +842,25 @@ static int reset_control_words(unsigned long long *control, hipStream_t stream) 
   return QSX_OK;
 }
 
-static uint64_t capacity_for(int64_t entries) {
-  // kHashTableLoadFactor = 2 slots per entry (storage/StorageConstants.hpp:104),
-  // rounded up to a power of two for mask addressing.
-  const uint64_t want = static_cast<uint64_t>(entries < 512 ? 512 : entries) * 2;
-  return next_pow2(want);
+static uint64_t capacity_for(int key_type, int64_t entries) {
+  const uint64_t rows = static_cast<uint64_t>(entries < 512 ? 512 : entries);
+  // INT: buckets of 16 slots at load 0.8 (12.8 rows per bucket), any bucket count
+  if (key_type == QSX_INT) return (rows * 5 + 63) / 64 * kBucketSlots + kBucketSlots;
+  // LONG: kHashTableLoadFactor = 2 slots per entry (storage/StorageConstants.hpp:104), a power of two for mask addressing
+  return next_pow2(rows * 2);
+}
+
+static int fill_empty(const qsx_join_table *t, void *slots, uint64_t capacity, hipStream_t stream) {
+  QSX_HIP_TRY(hipMemsetAsync(slots, 0xFF, capacity * t->entry_bytes(), stream));
+  if (t->key_type == QSX_INT) QSX_HIP_TRY(hipMemsetAsync(static_cast<char *>(slots) + capacity * 8, 0, capacity, stream));
+  return QSX_OK;
 }
 
 static int allocate_slots(qsx_join_table *t, uint64_t capacity, void **out) {
-  QSX_HIP_TRY(device_malloc(out, capacity * t->entry_bytes()));
-  QSX_HIP_TRY(hipMemset(*out, 0xFF, capacity * t->entry_bytes()));
+  QSX_HIP_TRY(device_malloc(out, capacity * t->entry_bytes() + (t->key_type == QSX_INT ? capacity : 0)));
+  const int rc = fill_empty(t, *out, capacity, nullptr);
+  if (rc != QSX_OK) return rc;
+  QSX_HIP_TRY(hipStreamSynchronize(nullptr));
   return QSX_OK;
 }
 
@@ -698,7 +892,7 @@ static int ensure_room_dense(qsx_join_table *t, int64_t additional) {
 static int ensure_room(qsx_join_table *t, int64_t additional) {
   if (t->dense) return ensure_room_dense(t, additional);
   std::unique_lock<std::shared_mutex> lock(t->mutex);
-  if (static_cast<uint64_t>(t->reserved + additional) * 2 <= t->capacity) {
+  if (static_cast<uint64_t>(t->reserved + additional) <= t->room()) {
     t->reserved += additional;
     return QSX_OK;
   }
@@ -707,11 +901,11 @@ static int ensure_room(qsx_join_table *t, int64_t additional) {
   QSX_HIP_TRY(hipMemcpy(&actual, t->entries_dev, sizeof(actual), hipMemcpyDeviceToHost));
   // rows filtered out by a bitmap never became entries: tighten the bound
   t->reserved = static_cast<int64_t>(actual);
-  if (static_cast<uint64_t>(t->reserved + additional) * 2 <= t->capacity) {
+  if (static_cast<uint64_t>(t->reserved + additional) <= t->room()) {
     t->reserved += additional;
     return QSX_OK;
   }
-  const uint64_t new_capacity = capacity_for(2 * (t->reserved + additional));
+  const uint64_t new_capacity = capacity_for(t->key_type, 2 * (t->reserved + additional));
   void *bigger = nullptr;
   int rc = allocate_slots(t, new_capacity, &bigger);
   if (rc != QSX_OK) return rc;
@@ -720,7 +914,7 @@ static int ensure_room(qsx_join_table *t, int64_t additional) {
   t->slots = bigger;
   t->capacity = new_capacity;
   TableView dst = t->view();
-  hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(src.mask + 1, kJBlock)), dim3(kJBlock), 0, nullptr,
+  hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(static_cast<int64_t>(src.num_slots(t->key_type == QSX_LONG)), kJBlock)), dim3(kJBlock), 0, nullptr,
                      t->key_type == QSX_LONG ? 1 : 0, src, dst);
   QSX_CHECK_LAUNCH();
   QSX_HIP_TRY(hipDeviceSynchronize());
@@ -737,7 +931,7 @@ int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **
   if (key_type != QSX_INT && key_type != QSX_LONG) return QSX_ERR_UNSUPPORTED;
   qsx_join_table *t = new qsx_join_table();
   t->key_type = key_type;
-  t->capacity = capacity_for(est_entries);
+  t->capacity = capacity_for(key_type, est_entries);
   int rc = allocate_slots(t, t->capacity, &t->slots);
   if (rc != QSX_OK) { delete t; return rc; }
   hipError_t err = device_malloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
@@ -900,7 +1094,8 @@ int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
   if (t->dense) {
     QSX_HIP_TRY(hipMemsetAsync(t->head, 0, t->range * sizeof(uint32_t), as_stream(stream)));
   } else {
-    QSX_HIP_TRY(hipMemsetAsync(t->slots, 0xFF, t->capacity * t->entry_bytes(), as_stream(stream)));
+    const int rc_fill = fill_empty(t, t->slots, t->capacity, as_stream(stream));
+    if (rc_fill != QSX_OK) return rc_fill;
   }
   const int rc_control = reset_control_words(t->entries_dev, as_stream(stream));
   if (rc_control != QSX_OK) return rc_control;
@@ -1027,46 +1222,6 @@ static bool dense_two_pass(const uint64_t *filter) {
   return filter != nullptr;
 }
 
-// The XCD-sliced, compacting probe (join_sliced.hpp) for tables beyond one XCD's L2: how many slices, 0 = not this call.
-// A slice should stay <= ~3 MiB (the 4 MiB L2 also streams the keys and the pairs); more than 8 slices do not exist (8 XCDs),
-// so beyond 8 x 16 MiB the lookups miss anyway.  OPT-IN (QSX_JOIN_SLICED=1; QSX_JOIN_SLICES=2|4|8 fixes the slice count):
-// every XCD has to pull all probe keys through its own fabric port, and that — about 1.1 ms per 100 M keys at eight slices,
-// whatever the scan costs in instructions — is what the L2 hits save on a 16 MiB hashed table (1.52 ms plain, 1.64 ms
-// sliced) and far more than they save on a selective probe.
-static int sliced_probe_slices(uint64_t table_bytes, uint64_t sliceable_units, int64_t n, const void *keys) {
-  if ((reinterpret_cast<uintptr_t>(keys) & 15u) != 0) return 0;   // the scan reads 16-byte key vectors
-  const char *e = getenv("QSX_JOIN_SLICED");
-  const bool forced = e != nullptr && e[0] == '1';
-  if (e != nullptr && e[0] == '0') return 0;
-  if (!forced) return 0;   // measured (profiles/r03_probe_sliced.jsonl): streaming the keys S times costs what the L2 hits save
-  int slices = 2;
-  while (slices < 8 && table_bytes / slices > (3ull << 20)) slices *= 2;
-  const char *fixed = getenv("QSX_JOIN_SLICES");
-  if (fixed != nullptr && (atoi(fixed) == 2 || atoi(fixed) == 4 || atoi(fixed) == 8)) slices = atoi(fixed);
-  while (slices > 1 && sliceable_units < static_cast<uint64_t>(slices)) slices /= 2;
-  return slices >= 2 ? slices : 0;
-}
-
-template <typename P, int MODE>
-static int launch_sliced(const P &policy, const typename P::Key *keys, int64_t n, int32_t probe_base_tid, const uint64_t *filter,
-                         int32_t *out_probe, int32_t *out_build, int64_t capacity, unsigned long long *count, int slices,
-                         hipStream_t stream) {
-  int per_cu = 0;
-  QSX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sliced_probe_kernel<P, MODE>, kSBlock, 0));
-  if (per_cu < 1) per_cu = 1;
-  const int64_t chunks = (n + kSChunk - 1) / kSChunk;
-  int row_bits = 1;
-  while (row_bits < 32 && (1ll << row_bits) < n) ++row_bits;   // rows of this call fit row_bits bits
-  int64_t grid = static_cast<int64_t>(per_cu) * kCUs;
-  if (grid > chunks * slices) grid = chunks * slices;
-  grid = grid / slices * slices;
-  if (grid < slices) grid = slices;
-  hipLaunchKernelGGL((sliced_probe_kernel<P, MODE>), dim3(static_cast<unsigned>(grid)), dim3(kSBlock), 0, stream, policy, keys, n,
-                     probe_base_tid, filter, out_probe, out_build, capacity, count, slices, row_bits);
-  QSX_CHECK_LAUNCH();
-  return QSX_OK;
-}
-
 // A build or clear: the covering array of the last projection describes another table now.
 static void drop_cover(qsx_join_table *t) {
   std::lock_guard<std::mutex> lock(t->cover_mutex);
@@ -1172,7 +1327,7 @@ static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream) {
   shadow->reserved = static_cast<int64_t>(entries);
   shadow->max_tid.store(t->max_tid.load());
   const TableView src = t->view();
-  hipLaunchKernelGGL(dense_build_from_slots_kernel, dim3(grid_for(static_cast<int64_t>(src.mask) + 1, kJBlock * 4)), dim3(kJBlock), 0, stream,
+  hipLaunchKernelGGL(dense_build_from_slots_kernel, dim3(grid_for(static_cast<int64_t>(src.num_slots(t->key_type == QSX_LONG)), kJBlock * 4)), dim3(kJBlock), 0, stream,
                      t->key_type == QSX_LONG ? 1 : 0, src, shadow->dense_view());
   int error = 0;
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess ||
@@ -1242,23 +1397,6 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
       QSX_CHECK_LAUNCH();
       return QSX_OK;
     }
-    if constexpr (!kRuns && (MODE == 0 || MODE == 1)) {
-      const DenseTableView dv = t->dense_view();
-      const bool min_fits = t->key_type != QSX_INT || (dv.min_key >= INT32_MIN && dv.min_key <= INT32_MAX);
-      const int slices = dcount != nullptr && min_fits ? sliced_probe_slices(dv.range * sizeof(uint32_t), dv.range, n, keys) : 0;
-      if (slices != 0) {
-        if (t->key_type == QSX_INT) {
-          DenseSlices<int32_t> policy;
-          policy.t = dv;
-          return launch_sliced<DenseSlices<int32_t>, MODE>(policy, static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,
-                                                           out_build, capacity, dcount, slices, stream);
-        }
-        DenseSlices<int64_t> policy;
-        policy.t = dv;
-        return launch_sliced<DenseSlices<int64_t>, MODE>(policy, static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe,
-                                                         out_build, capacity, dcount, slices, stream);
-      }
-    }
     if (t->key_type == QSX_INT) {
       hipLaunchKernelGGL((dense_probe_kernel<int32_t, MODE, kRuns>), dim3(dgrid), dim3(kDBlock), 0, stream, t->dense_view(),
                          static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe, out_build, capacity,
@@ -1271,33 +1409,13 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
     QSX_CHECK_LAUNCH();
     return QSX_OK;
   }
-  if constexpr (!kRuns && (MODE == 0 || MODE == 1)) {
-    const TableView hv = t->view();
-    const uint64_t units = t->key_type == QSX_INT ? t->capacity / 2 : t->capacity;
-    const int slices = out_count != nullptr ? sliced_probe_slices(t->capacity * t->entry_bytes(), units, n, keys) : 0;
-    if (slices != 0) {
-      unsigned long long *hcount = reinterpret_cast<unsigned long long *>(out_count);
-      if (t->key_type == QSX_INT) {
-        HashedSlices<IntUnits> policy;
-        policy.t = hv;
-        policy.dup_flag = hv.dup_flag;
-        return launch_sliced<HashedSlices<IntUnits>, MODE>(policy, static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,
-                                                           out_build, capacity, hcount, slices, stream);
-      }
-      HashedSlices<LongUnits> policy;
-      policy.t = hv;
-      policy.dup_flag = hv.dup_flag;
-      return launch_sliced<HashedSlices<LongUnits>, MODE>(policy, static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe,
-                                                          out_build, capacity, hcount, slices, stream);
-    }
-  }
   const int64_t num_tiles = kRuns ? run_tiles : (n + kProbeTile - 1) / kProbeTile;
   // 4 workgroups per CU keep 128 KiB of the 160 KiB LDS busy in pair mode.
   const int64_t max_grid = MODE == 0 ? 4 * kCUs : 8 * kCUs;
   const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
   unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count);
   if (t->key_type == QSX_INT) {
-    hipLaunchKernelGGL((probe_kernel<IntUnits, MODE, kRuns>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
+    hipLaunchKernelGGL((probe_fp_kernel<MODE, kRuns>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
                        static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,
                        out_build, capacity, count, out_bitmap, anti, runs_dev);
   } else {

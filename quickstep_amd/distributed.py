@@ -256,17 +256,41 @@ class PartitionedHashJoin:
     def build(self, keys, tid_base, payload=()):
         """payload: further columns of the build relation that travel with the rows (BASELINE config 4: one 8-byte
         column per side); they end up in self.build_payload, in the order of the rows of this rank's partition."""
-        tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
-        received, _ = shuffle_by_key(self.ops, keys, [keys, tids, *payload], self.group)
-        rkeys, rtids = received[0], received[1]
-        self.build_tids = rtids                            # table stores positions into this column
-        self.build_keys = rkeys
-        self.build_payload = received[2:]
+        self.shuffle_build(keys, tid_base, payload)
+        return self.build_received()
+
+    def shuffle_build(self, keys, tid_base, payload=(), with_tids=True):
+        """The build side's exchange step alone (K9 scatter, counts, all-to-all(v)); build_received() then inserts what
+        arrived.  Split so that a plan can put the probe side's exchange on a second stream next to the build kernel —
+        the build runs at the rate of the atomic units and leaves HBM and the links idle (plans.PartitionedJoin.step).
+        with_tids=False: the global tuple ids do not travel (a plan whose output relation is written by the probe itself
+        never looks at them: 4 of 16 bytes per row less through K9 and over the links)."""
+        cols = [keys, *payload]
+        if with_tids:
+            cols.insert(1, torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device))
+        received, _ = shuffle_by_key(self.ops, keys, cols, self.group)
+        self.build_keys = received[0]
+        self.build_tids = received[1] if with_tids else None   # table stores positions into this column
+        self.build_payload = received[2:] if with_tids else received[1:]
         self.shuffled_bytes = sum(c.numel() * c.element_size() for c in received)
+
+    def build_received(self):
         with phases.phase("build"):
             self.table.clear()
-            self.table.build(rkeys)
-        return rkeys.numel()
+            self.table.build(self.build_keys)
+        return self.build_keys.numel()
+
+    def shuffle_probe(self, keys, tid_base, payload=(), with_tids=True):
+        """The probe side's exchange step alone; probe_output_received() joins what arrived."""
+        cols = [keys, *payload]
+        if with_tids:
+            cols.insert(1, torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device))
+        received, _ = shuffle_by_key(self.ops, keys, cols, self.group)
+        self.probe_keys = received[0]
+        self.probe_tids = received[1] if with_tids else None
+        self.probe_payload = received[2:] if with_tids else received[1:]
+        self.shuffled_bytes += sum(c.numel() * c.element_size() for c in received)
+        return received
 
     def probe(self, keys, tid_base, capacity=None, payload=()):
         tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
@@ -293,12 +317,11 @@ class PartitionedHashJoin:
         if not hasattr(self.table, "probe_project_blocks"):
             _, _, out_p, out_b, count = self.probe(keys, tid_base, capacity=None, payload=payload)   # counts first: duplicates
             return self.materialize_payload(out_p, out_b, count)
-        tids = torch.arange(tid_base, tid_base + keys.numel(), dtype=torch.int32, device=keys.device)
-        received, _ = shuffle_by_key(self.ops, keys, [keys, tids, *payload], self.group)
-        rkeys = received[0]
-        self.probe_keys = rkeys
-        self.probe_payload = received[2:]
-        self.shuffled_bytes += sum(c.numel() * c.element_size() for c in received)
+        self.shuffle_probe(keys, tid_base, payload, with_tids=False)
+        return self.probe_output_received()
+
+    def probe_output_received(self):
+        rkeys = self.probe_keys
         with phases.phase("probe"):
             room = max(rkeys.numel(), 1)
             for _ in range(2):

@@ -49,16 +49,38 @@ class PartitionedJoin:
     """BASELINE config 4.  step() = shuffle both sides on the join key, build, probe, materialise
     (key, o_payload, l_payload) for every pair of this rank's partition."""
 
-    def __init__(self, ops, orders_total, est_orders_per_rank, group=None, dense=True, fused=True):
+    def __init__(self, ops, orders_total, est_orders_per_rank, group=None, dense=True, fused=True, overlap=True):
         """fused: the probe writes the output relation itself (PartitionedHashJoin.probe_output) instead of a pair list that
-        K5 gathers materialise."""
-        self.ops, self.group, self.fused = ops, group, fused
+        K5 gathers materialise.  overlap: the probe side's exchange runs on a second stream under the build kernel."""
+        self.ops, self.group, self.fused, self.overlap = ops, group, fused, overlap
+        self._side = None
         self.join = qd.PartitionedHashJoin(ops, T.INT, est_orders_per_rank, group=group,
                                            key_domain=(1, orders_total) if dense else None)
 
     def step(self, inputs, tid_base_orders=0, tid_base_lines=0):
         j = self.join
-        j.build(inputs["o_orderkey"], tid_base_orders, payload=[inputs["o_payload"]])
+        overlapped = self.fused and self.overlap and inputs["l_orderkey"].is_cuda
+        if overlapped:
+            # The build kernel is one atomic per row (bound by the atomic units: HBM and the links idle), the probe side's
+            # K9 scatter + exchange is HBM- / link-bound: the second runs on a side stream under the first.  The build side's
+            # exchange has finished (its counts were read on the host) before the probe side's starts, so every rank still
+            # issues its collectives in the same order.
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            j.shuffle_build(inputs["o_orderkey"], tid_base_orders, payload=[inputs["o_payload"]], with_tids=False)
+            self._side.wait_stream(main)              # (the inputs are ready; nothing of the build is queued yet)
+            j.table.clear()
+            j.table.build(j.build_keys)               # main stream, asynchronous
+            with torch.cuda.stream(self._side):
+                received = j.shuffle_probe(inputs["l_orderkey"], tid_base_lines, payload=[inputs["l_payload"]], with_tids=False)
+            for t in received:
+                t.record_stream(main)                 # allocated under the side stream, read by the probe on the main one
+            main.wait_stream(self._side)
+            cols = j.probe_output_received()
+            return cols, j.shuffled_bytes
+        j.shuffle_build(inputs["o_orderkey"], tid_base_orders, payload=[inputs["o_payload"]], with_tids=not self.fused)
+        j.build_received()
         # a lineitem row has exactly one order: the rows that arrive bound the pairs; how many arrive is only known
         # after the counts exchange, so the capacity is left to probe() (rows received)
         if self.fused:

@@ -205,93 +205,63 @@ def test_dense_table_over_one_hash_partition(capi, oracle, dev, key_type, dtype)
         table.size()
 
 
-@pytest.mark.parametrize("slices", ["2", "8"])
-@pytest.mark.parametrize("flavour", FLAVOURS)
-@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
-def test_xcd_sliced_probe_matches_oracle(capi, oracle, dev, key_type, dtype, flavour, slices, monkeypatch):
-    """The XCD-sliced, compacting probe (join_sliced.hpp: workgroup b serves table slice b % S, survivors of the key scan
-    meet in an LDS ring, full rounds of lookups) against the oracle, for both table kinds: duplicates (dense: chains; hashed:
-    walks that go back into the ring), a probe filter, keys outside the range, a strided table, a range that does not divide
-    by the slice count, row counts that are not a multiple of the scan chunk, skewed keys (one slice gets nearly every
-    match), and a capacity smaller than the match count."""
-    monkeypatch.setenv("QSX_JOIN_SLICED", "1")
-    monkeypatch.setenv("QSX_JOIN_SLICES", slices)
-    rng = np.random.default_rng(77)
-    for stride, n_build, span, n_probe, hot in ((1, 90_000, 100_003, 700_001, 0.0), (4, 30_000, 200_001, 300_000, 0.0),
-                                                (1, 50_000, 64_000, 600_000, 0.9), (1, 40_000, 1_000_000, 123_457, 0.0)):
-        lo = 1_000 if dtype == np.int32 else 2**40
-        domain = lo + np.arange(0, span * stride, stride)
-        build = rng.choice(domain, size=n_build, replace=span < 500_000).astype(dtype)   # last case: unique build keys
-        probe = (lo + rng.integers(-20, span * stride + 20, size=n_probe)).astype(dtype)
-        if hot:
-            probe[rng.random(n_probe) < hot] = build[7]          # one key range takes nearly all matches
-        if flavour == "dense":
-            table = capi.JoinTable(key_type, n_build, key_range=(int(domain[0]), int(domain[-1])), key_stride=stride)
-        else:
-            table = capi.JoinTable(key_type, n_build)
-        table.build(to_dev(build, dev))
-        dp = to_dev(probe, dev)
-        pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.7)
-        for filt in (None, pf):
-            fdev = None if filt is None else bitmap_dev(filt, dev)
-            _, rp, rd = oracle_join(oracle, key_type, [build], probe, probe_filter=filt)
-            total = int(table.probe_count(dp, filter_bitmap=fdev).item())
-            assert total == rp.size
-            monkeypatch.setenv("QSX_JOIN_TWO_PASS", "0")         # (with a filter the two-pass kernels would take the call)
-            p, b, cnt = table.probe(dp, capacity=total, filter_bitmap=fdev)
-            assert int(cnt.item()) == total
-            assert np.array_equal(sorted_pairs(p.cpu().numpy()[:total], b.cpu().numpy()[:total]), sorted_pairs(rp, rd))
-        p, b, cnt = table.probe(dp, capacity=1000)               # more matches than room: full count, no write past the end
-        assert int(cnt.item()) == int(table.probe_count(dp).item())
-        # a key stripe that does not start on a 16-byte boundary takes the plain kernels: same result
-        _, rp1, rd1 = oracle_join(oracle, key_type, [build], probe[1:])
-        p, b, cnt = table.probe(dp[1:], capacity=rp1.size)
-        assert int(cnt.item()) == rp1.size
-        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp1.size], b.cpu().numpy()[:rp1.size]), sorted_pairs(rp1, rd1))
-        table.close()
+def _int_table_geometry(est_entries):
+    """quickstep_amd/csrc/join.hip capacity_for / home_bucket / fingerprint for INT keys, restated for the test."""
+    rows = max(512, est_entries)
+    buckets = (rows * 5 + 63) // 64 + 1
+    def home(keys):
+        h = (keys.astype(np.uint64) & 0xFFFFFFFF) * 0x9E3779B9 & 0xFFFFFFFF
+        return (h * buckets) >> 32
+    def fingerprint(keys):
+        f = ((keys.astype(np.uint64) & 0xFFFFFFFF) * 0x85EBCA6B & 0xFFFFFFFF) >> 24
+        return np.where(f == 0, 1, f)
+    return buckets, home, fingerprint
 
 
-@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
-def test_xcd_sliced_hashed_probe_walks_hundreds_of_duplicates(capi, oracle, dev, key_type, dtype, monkeypatch):
-    """One build key occurs 1500 times (a walk of 750+ units: beyond the 8-bit displacement a ring entry carries, finished
-    lane by lane), next to ordinary keys."""
-    monkeypatch.setenv("QSX_JOIN_SLICED", "1")
-    rng = np.random.default_rng(78)
-    build = rng.integers(0, 50_000, size=60_000).astype(dtype)
-    build[rng.choice(build.size, size=1500, replace=False)] = 424_242
-    probe = rng.integers(0, 60_000, size=200_003).astype(dtype)
-    probe[rng.choice(probe.size, size=40, replace=False)] = 424_242
-    table = capi.JoinTable(key_type, build.size)
+@pytest.mark.parametrize("unique", [True, False])
+def test_int_table_crowded_buckets_and_shared_fingerprints(capi, oracle, dev, unique, monkeypatch):
+    """The bucketed INT table against its worst inputs (QSX_JOIN_ADAPTIVE=0: no directly addressed shadow): hundreds of
+    distinct keys whose home is ONE bucket (the sequence runs through a dozen full buckets, wrapping at the table's end),
+    keys that share home bucket AND fingerprint (every fingerprint hit but one is a false positive), probes for keys that
+    are absent but share bucket and fingerprint with present ones, and — unique=False — heavy duplicates of such keys."""
+    monkeypatch.setenv("QSX_JOIN_ADAPTIVE", "0")
+    est = 4_000
+    buckets, home, fingerprint = _int_table_geometry(est)
+    pool = np.arange(-3_000_000, 3_000_000, dtype=np.int64)
+    h, f = home(pool), fingerprint(pool)
+    last = pool[h == buckets - 1][:300]                                  # one bucket, the LAST one: the walk wraps around
+    twins = pool[(h == 7) & (f == 99)]                                   # same bucket, same fingerprint
+    assert last.size == 300 and twins.size >= 40
+    rng = np.random.default_rng(5)
+    spread = rng.choice(pool, size=2_500, replace=False)
+    build = np.unique(np.concatenate([last[:200], twins[:20], spread])).astype(np.int32)
+    if not unique:
+        build = np.concatenate([build, np.repeat(twins[:3].astype(np.int32), 40), np.repeat(last[:2].astype(np.int32), 25)])
+    rng.shuffle(build)
+    assert build.size <= est
+    probe = np.concatenate([last, twins[:40], rng.choice(pool, size=50_000), build[:500]]).astype(np.int32)   # present and absent look-alikes
+    rng.shuffle(probe)
+    table = capi.JoinTable(T.INT, est)
     table.build(to_dev(build, dev))
+    assert table.size() == build.size
     dp = to_dev(probe, dev)
-    _, rp, rd = oracle_join(oracle, key_type, [build], probe)
+    _, rp, rd = oracle_join(oracle, T.INT, [build], probe)
     total = int(table.probe_count(dp).item())
     assert total == rp.size
     p, b, cnt = table.probe(dp, capacity=total)
     assert int(cnt.item()) == total
     assert np.array_equal(sorted_pairs(p.cpu().numpy()[:total], b.cpu().numpy()[:total]), sorted_pairs(rp, rd))
-
-
-@pytest.mark.parametrize("flavour", FLAVOURS)
-def test_xcd_sliced_probe_at_scale_properties(capi, dev, monkeypatch, flavour):
-    """8 M-key table (32 MiB of head words — the broadcast join's table at 8 GPUs — or 128 MiB of hashed slots) probed by
-    30 M keys through the sliced kernels (their default at this size) and the plain ones: pairs are a permutation of the
-    probe tids and satisfy the join condition."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(5)
-    n_build, n_probe = 8_000_000, 30_000_000
-    build = torch.randperm(n_build, device=dev, generator=g, dtype=torch.int32)
-    probe = torch.randint(0, n_build, (n_probe,), device=dev, generator=g, dtype=torch.int32)
-    table = capi.JoinTable(T.INT, n_build, key_range=(0, n_build - 1) if flavour == "dense" else None)
-    table.build(build)
-    for sliced in (None, "0"):
-        if sliced is not None:
-            monkeypatch.setenv("QSX_JOIN_SLICED", sliced)
-        p, b, cnt = table.probe(probe)
-        assert int(cnt.item()) == n_probe == int(table.probe_count(probe).item())
-        assert bool((build[b.long()] == probe[p.long()]).all())
-        assert int(p.long().sum().item()) == n_probe * (n_probe - 1) // 2
-        assert int(torch.bincount(p.long(), minlength=n_probe).max().item()) == 1
+    exists, n_exist = table.probe_exists(dp)
+    assert int(n_exist.item()) == np.isin(probe, build).sum()
+    # the table grows (rehash into more buckets) and keeps every entry
+    more = rng.choice(pool, size=30_000, replace=False).astype(np.int32)
+    table.build(to_dev(more, dev), base_tid=build.size)
+    _, rp2, rd2 = oracle_join(oracle, T.INT, [build, more], probe)
+    total2 = int(table.probe_count(dp).item())
+    assert total2 == rp2.size
+    p, b, cnt = table.probe(dp, capacity=total2)
+    assert np.array_equal(sorted_pairs(p.cpu().numpy()[:total2], b.cpu().numpy()[:total2]), sorted_pairs(rp2, rd2))
+    table.close()
 
 
 @pytest.mark.parametrize("flavour", FLAVOURS + ["hashed_no_shadow"])
