@@ -98,6 +98,17 @@ std::string emit_dev_config(const DevConfig &d) {
     std::snprintf(buf, sizeof(buf), "d.sums[%d].arg", j);
     emit_operand(o, buf, d.sums[j].arg);
     o << "  d.sums[" << j << "].is_int = " << d.sums[j].is_int << "; d.sums[" << j << "].kind = " << d.sums[j].kind << ";\n";
+    if (d.sums[j].null_mask != 0 || d.sums[j].count_valid != 0) {
+      o << "  d.sums[" << j << "].null_mask = " << d.sums[j].null_mask << "u; d.sums[" << j << "].count_valid = " << d.sums[j].count_valid << ";\n";
+    }
+  }
+  // nullable columns the plan reads: which, where their null words of a tile are staged, which of them drop the row (the
+  // bitmaps themselves are per call: behind the kernel's `nulls` pointer)
+  if (d.num_null_cols != 0) {
+    o << "  d.num_null_cols = " << d.num_null_cols << "; d.row_null_mask = " << d.row_null_mask << "u;\n";
+    for (int sl = 0; sl < d.num_null_cols; ++sl) {
+      o << "  d.null_column[" << sl << "] = " << d.null_column[sl] << "; d.null_lds_off[" << sl << "] = " << d.null_lds_off[sl] << ";\n";
+    }
   }
   o << "  d.num_pred = " << d.num_pred << ";\n";
   for (int p = 0; p < d.num_pred; ++p) {
@@ -112,32 +123,39 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
   std::ostringstream o;
   bool any_coded = false;   // unused pointers are passed as literals: every live scalar argument costs SGPRs in the tile loop
   for (int i = 0; i < dev.num_columns; ++i) any_coded = any_coded || dev.code_width[i] != 0;
+  // a state over nullable columns: the null bitmaps of a call arrive as a device table of num_null_cols pointers (by null
+  // slot; a null entry = the block has no NULL in that attribute) — the last of the trailing arguments
+  const bool any_nulls = dev.num_null_cols != 0;
+  const char *nulls_param = any_nulls ? ", const unsigned long long *const *nulls" : "";
+  const char *nulls_arg = any_nulls ? "nulls" : "nullptr";
   o << kPrelude << kBundle << "\nnamespace qsx {\nconstexpr DevConfig jit_make_dev() {\n  DevConfig d{};\n"
     << emit_dev_config(dev) << "  return d;\n}\n";
   if (geo.dir_gids != 0 && dense) {
     // a dense state in LDS (agg_hash_update.hpp, kDense && kDir): the signature of the plain shapes, 1024 threads
     o << "extern \"C\" __global__ __launch_bounds__(" << kDirBlock << ") void qsx_jit_agg(ColumnPointers cols, int64_t n,\n"
       << "    DenseView view, const long long *pieces"
-      << (dev.filter_lds_off >= 0 || any_coded ? ", const uint64_t *filter" : "") << (any_coded ? ", const void *const *dicts" : "") << ") {\n"
+      << (dev.filter_lds_off >= 0 || any_coded || any_nulls ? ", const uint64_t *filter" : "") << (any_coded || any_nulls ? ", const void *const *dicts" : "")
+      << nulls_param << ") {\n"
       << "  static constexpr DevConfig D = jit_make_dev();\n"
       << "  (void)cols; (void)pieces;\n"
       << "  agg_hash_update_body<true, true, " << num_sums << ", 1, true, " << kDirBlock << ", false, " << (geo.runs != 0 ? "true" : "false")
       << ">(D, " << (geo.runs != 0 ? "nullptr" : "cols.p") << ", " << (any_coded ? "dicts" : "nullptr") << ", n, "
       << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", HashTableView{}, view, " << geo.S << ", " << geo.rep_shift << ", " << geo.nbuf
-      << ", " << geo.ranges << ", pieces, nullptr, nullptr);\n}\n}  // namespace qsx\n";
+      << ", " << geo.ranges << ", pieces, " << nulls_arg << ", nullptr);\n}\n}  // namespace qsx\n";
     return o.str();
   }
   if (geo.dir_gids != 0) {
     // group-directory variant: the body of agg_dir_update_kernel with the configuration and the geometry as constants
     // (geo.runs: the rows are a run of blocks, the table arrives as `pieces`)
     o << "extern \"C\" __global__ __launch_bounds__(" << kDirBlock << ") void qsx_jit_agg(ColumnPointers cols,\n"
-      << "    const void *const *dicts, int64_t n, const uint64_t *filter, HashTableView view, DirView d, const long long *pieces) {\n"
+      << "    const void *const *dicts, int64_t n, const uint64_t *filter, HashTableView view, DirView d, const long long *pieces"
+      << nulls_param << ") {\n"
       << "  static constexpr DevConfig D = jit_make_dev();\n"
       << "  (void)cols; (void)pieces;\n"
       << "  agg_hash_update_body<true, false, " << num_sums << ", 1, true, " << kDirBlock << ", false, " << (geo.runs != 0 ? "true" : "false")
       << ">(D, " << (geo.runs != 0 ? "nullptr" : "cols.p") << ", " << (any_coded ? "dicts" : "nullptr") << ", n, "
       << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", view, DenseView{}, " << geo.dir_gids << ", 0, " << geo.nbuf << ", 1, "
-      << (geo.runs != 0 ? "pieces" : "nullptr") << ", nullptr, &d);\n}\n}  // namespace qsx\n";
+      << (geo.runs != 0 ? "pieces" : "nullptr") << ", " << nulls_arg << ", &d);\n}\n}  // namespace qsx\n";
     return o.str();
   }
   // the run-of-blocks flavour of the body takes the same signature (the table arrives as `pieces`) and its stripes from the
@@ -155,13 +173,15 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
     // identical launch geometry and arguments: 5 % more instructions in the hipRTC build, cause not established.)
     << "extern \"C\" __global__ __launch_bounds__(" << kABlock << ") void qsx_jit_agg(ColumnPointers cols, int64_t n,\n"
     << "    " << (dense ? "DenseView" : "HashTableView") << " view, const long long *pieces"
-    << (dev.filter_lds_off >= 0 || any_coded ? ", const uint64_t *filter" : "") << (any_coded ? ", const void *const *dicts" : "") << ") {\n"
+    << (dev.filter_lds_off >= 0 || any_coded || any_nulls ? ", const uint64_t *filter" : "") << (any_coded || any_nulls ? ", const void *const *dicts" : "")
+    << nulls_param << ") {\n"
     << "  static constexpr DevConfig D = jit_make_dev();\n"
     << "  (void)cols;\n"
     << "  agg_hash_update_body<" << body_args.str() << ">(D, " << (geo.runs != 0 ? "nullptr" : "cols.p") << ", "
     << (any_coded ? "dicts" : "nullptr") << ", n, " << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", "
     << (dense ? "HashTableView{}, view" : "view, DenseView{}")
-    << ", " << geo.S << ", " << geo.rep_shift << ", " << geo.nbuf << ", " << geo.ranges << ", pieces);\n}\n}  // namespace qsx\n";
+    << ", " << geo.S << ", " << geo.rep_shift << ", " << geo.nbuf << ", " << geo.ranges << ", pieces" << (any_nulls ? ", nulls" : "")
+    << ");\n}\n}  // namespace qsx\n";
   return o.str();
 }
 
@@ -491,8 +511,10 @@ int jit_request_state(JitRequest *r, const JitKernel **kernel) {
 
 int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
                    const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g,
-                   const DenseView &dense, bool is_dense, int S, int rep_shift, int nbuf, int ranges, const long long *pieces, int block) {
+                   const DenseView &dense, bool is_dense, int S, int rep_shift, int nbuf, int ranges, const long long *pieces, int block,
+                   const unsigned long long *const *null_table_dev) {
   ColumnPointers a_cols = cols;
+  const unsigned long long *const *a_nulls = null_table_dev;
   const void *const *a_dicts = dict_table_dev;
   int64_t a_n = n;
   const uint64_t *a_filter = filter;
@@ -501,7 +523,7 @@ int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t s
   const long long *a_pieces = pieces;
   void *view = is_dense ? static_cast<void *>(&a_dense) : static_cast<void *>(&a_g);
   (void)S; (void)rep_shift; (void)nbuf; (void)ranges;   // (constants inside the shape)
-  void *args[] = {&a_cols, &a_n, view, &a_pieces, &a_filter, &a_dicts};   // (a shape declares a prefix of these: make_source)
+  void *args[] = {&a_cols, &a_n, view, &a_pieces, &a_filter, &a_dicts, &a_nulls};   // (a shape declares a prefix of these: make_source)
   QSX_HIP_TRY(hipModuleLaunchKernel(k->function, static_cast<unsigned>(grid), 1, 1, static_cast<unsigned>(block), 1, 1,
                                     static_cast<unsigned>(lds_bytes), stream, args, nullptr));
   return QSX_OK;
@@ -509,15 +531,16 @@ int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t s
 
 int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
                        const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d,
-                       const long long *pieces) {
+                       const long long *pieces, const unsigned long long *const *null_table_dev) {
   ColumnPointers a_cols = cols;
+  const unsigned long long *const *a_nulls = null_table_dev;
   const void *const *a_dicts = dict_table_dev;
   int64_t a_n = n;
   const uint64_t *a_filter = filter;
   HashTableView a_g = g;
   DirView a_d = d;
   const long long *a_pieces = pieces;
-  void *args[] = {&a_cols, &a_dicts, &a_n, &a_filter, &a_g, &a_d, &a_pieces};
+  void *args[] = {&a_cols, &a_dicts, &a_n, &a_filter, &a_g, &a_d, &a_pieces, &a_nulls};
   QSX_HIP_TRY(hipModuleLaunchKernel(k->function, static_cast<unsigned>(grid), 1, 1, kDirBlock, 1, 1,
                                     static_cast<unsigned>(lds_bytes), stream, args, nullptr));
   return QSX_OK;

@@ -41,12 +41,15 @@ int jit_request_state(JitRequest *request, const JitKernel **kernel);
 int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
                    const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g,
                    const DenseView &dense, bool is_dense, int S, int rep_shift, int nbuf, int ranges, const long long *pieces,
-                   int block = kABlock);   // (1024 for a dense state in LDS: geometry.dir_gids != 0 of a dense state)
+                   int block = kABlock,    // (1024 for a dense state in LDS: geometry.dir_gids != 0 of a dense state)
+                   const unsigned long long *const *null_table_dev = nullptr);   // states over nullable columns: the call's null
+                                                                                 // bitmaps by null slot, a table in device memory
 
 // The group-directory variant (geometry.dir_gids != 0): the argument list of agg_dir_update_kernel.
 int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
                        const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d,
-                       const long long *pieces = nullptr);   // pieces: the run table of a geometry.runs shape
+                       const long long *pieces = nullptr,    // pieces: the run table of a geometry.runs shape
+                       const unsigned long long *const *null_table_dev = nullptr);
 
 constexpr int kJitRowsPerThread = 4;
 

@@ -542,6 +542,9 @@ __global__ __launch_bounds__(1024) void adjacent_equal_kernel(const KeyT *__rest
 struct DictTable {
   const void *p[QSX_MAX_COLUMNS];
 };
+struct NullTable {   // the null bitmaps of one call by null slot (DevConfig::null_column), for the run-time plan shapes
+  const unsigned long long *p[QSX_MAX_COLUMNS];
+};
 __global__ __launch_bounds__(kABlock) void popcount_words_kernel(const unsigned long long *__restrict__ words,
                                                                 long long num_words,
                                                                 unsigned long long *__restrict__ out) {
@@ -1248,10 +1251,10 @@ static long long jit_min_rows() {
   const char *e = getenv("QSX_AGG_JIT_MIN_ROWS");   // read per call: tests switch it at run time
   // The compile runs on a background thread and its result is kept per process by source text, so what the threshold
   // guards is a CPU core for 1-2 s per DISTINCT plan shape, not the caller's time: a shape is worth that once a state of
-  // it has seen 2 Mi rows (45 us through the interpreter) — every later state of the shape, however small, then starts on
-  // the compiled kernel as soon as it has seen as many rows itself.  (16 Mi until round 3: a query whose states stayed
-  // below that never left the interpreter.)
-  return e != nullptr ? atoll(e) : 2ll * 1024 * 1024;
+  // it has seen 256 Ki rows (6 us through the interpreter: what keeps the compiler away are states of a few blocks, tests) —
+  // every later state of the shape, however small, then starts on the compiled kernel as soon as it has seen as many rows
+  // itself.  (16 Mi until round 3, 2 Mi in round 3.)
+  return e != nullptr ? atoll(e) : 256ll * 1024;
 }
 
 // The specialised kernel of this state for the filter variant, compiling it on first use once the state
@@ -1335,8 +1338,22 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
   return k;
 }
 
+// The null bitmaps of a call behind a pointer: a device slot per (thread, stream), filled in stream order.
+static int upload_null_table(const DevConfig &dc, hipStream_t stream, const unsigned long long *const **out) {
+  *out = nullptr;
+  if (dc.num_null_cols == 0) return QSX_OK;
+  NullTable host_table{};
+  for (int sl = 0; sl < dc.num_null_cols; ++sl) host_table.p[sl] = dc.nulls[sl];
+  NullTable *slot = device_slot<NullTable>(stream);
+  if (slot == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  hipLaunchKernelGGL(store_struct_kernel<NullTable>, dim3(1), dim3(64), 0, stream, host_table, slot);
+  *out = slot->p;
+  return QSX_OK;
+}
+
 static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const void *const *cols, const void *const *dicts, int64_t n,
-                      const uint64_t *filter, int slots, int num_ranges, const long long *pieces, hipStream_t stream) {
+                      const uint64_t *filter, int slots, int num_ranges, const long long *pieces, hipStream_t stream,
+                      const DevConfig *call_config = nullptr) {
   constexpr int TR = kABlock * kJitRowsPerThread;
   constexpr size_t kMaxLds = 160 * 1024;
   const AggTuning &tune = agg_tuning();
@@ -1373,14 +1390,20 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const 
     hipLaunchKernelGGL(store_struct_kernel<DictTable>, dim3(1), dim3(64), 0, stream, host_table, slot);
     dict_table = slot->p;
   }
+  const unsigned long long *const *null_table = nullptr;
+  if (call_config != nullptr) {
+    const int rc_nulls = upload_null_table(*call_config, stream, &null_table);
+    if (rc_nulls != QSX_OK) return rc_nulls;
+  }
   const int rc = jit_agg_launch(k, grid, lds, stream, cp, dict_table, n, filter, st->dense ? HashTableView{} : st->hash_view(),
                                 st->dense ? st->dense_view() : DenseView{}, st->dense, S, rep_shift, nbuf, ranges, pieces,
-                                dense_lds ? kDirBlock : kABlock);
+                                dense_lds ? kDirBlock : kABlock, null_table);
   return rc;
 }
 
 static int launch_jit_dir(qsx_agg_state *st, const JitKernel *k, int variant, const void *const *cols, const void *const *dicts, int64_t n,
-                          const uint64_t *filter, const DirView &dir, hipStream_t stream, const long long *block_run) {
+                          const uint64_t *filter, const DirView &dir, hipStream_t stream, const long long *block_run,
+                          const DevConfig *call_config = nullptr) {
   const size_t lds = st->jit_lds[variant];
   if (lds > 160 * 1024) return QSX_ERR_CAPACITY;
   ColumnPointers cp;
@@ -1394,7 +1417,12 @@ static int launch_jit_dir(qsx_agg_state *st, const JitKernel *k, int variant, co
     hipLaunchKernelGGL(store_struct_kernel<DictTable>, dim3(1), dim3(64), 0, stream, host_table, slot);
     dict_table = slot->p;
   }
-  const int rc = jit_agg_launch_dir(k, dir_grid(n), lds, stream, cp, dict_table, n, filter, st->hash_view(), dir, block_run);
+  const unsigned long long *const *null_table = nullptr;
+  if (call_config != nullptr) {
+    const int rc_nulls = upload_null_table(*call_config, stream, &null_table);
+    if (rc_nulls != QSX_OK) return rc_nulls;
+  }
+  const int rc = jit_agg_launch_dir(k, dir_grid(n), lds, stream, cp, dict_table, n, filter, st->hash_view(), dir, block_run, null_table);
   if (rc != QSX_OK || hipGetLastError() != hipSuccess) return QSX_ERR_HIP;
   return QSX_OK;
 }
@@ -1894,12 +1922,13 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
   }
   const bool aot = !st->dense && st->shape != nullptr && filter_dev == nullptr && dc.num_null_cols == 0;
   int variant = 0;
-  // (states over nullable columns run the interpreter: the null bitmaps of a call travel in its configuration argument)
-  const JitKernel *jk = (aot || dc.num_null_cols != 0)
+  // (states over nullable columns: the run-time shapes take the null bitmaps of a call behind a pointer — a run of blocks
+  // has one set per block, which the run table does not carry: those stay with the interpreter, block by block)
+  const JitKernel *jk = (aot || (dc.num_null_cols != 0 && runs))
                             ? nullptr
                             : state_jit_kernel(st, filter_dev != nullptr, partitioned, slots, ranges, n, &variant, false, runs);
   if (jk != nullptr) {
-    int rc = launch_jit(st, jk, variant, cols, dc.dicts, n, filter_dev, slots, ranges, pieces, s);
+    int rc = launch_jit(st, jk, variant, cols, dc.dicts, n, filter_dev, slots, ranges, pieces, s, &dc);
     if (rc == QSX_OK && hipGetLastError() == hipSuccess) return QSX_OK;
     // the specialised kernel could not be launched: keep going with the interpreter from now on
     std::lock_guard<std::mutex> lock(st->jit_mutex);
@@ -1999,10 +2028,10 @@ static int update_directory(qsx_agg_state *st, const void *const *cols, const vo
   if (st->shape != nullptr && filter_dev == nullptr && dc.num_null_cols == 0) {
     st->rows_seen.fetch_add(n);
     rc = st->shape->launch_dir(cols, st->config.num_columns, n, st->hash_view(), dir, st->dir_gids, st->dir_nbuf, s, block_run);
-  } else if (dc.num_null_cols == 0 &&
+  } else if ((dc.num_null_cols == 0 || !runs) &&
              (jk = state_jit_kernel(st, filter_dev != nullptr, false, st->dir_gids, 1, n, &variant, true, runs)) != nullptr &&
              st->jit_geometry[variant].dir_gids == st->dir_gids &&
-             launch_jit_dir(st, jk, variant, cols, dc.dicts, n, filter_dev, dir, s, block_run) == QSX_OK) {
+             launch_jit_dir(st, jk, variant, cols, dc.dicts, n, filter_dev, dir, s, block_run, &dc) == QSX_OK) {
     rc = QSX_OK;   // run-time plan shape of the directory kernel
   } else {
     if (jk != nullptr) {   // the specialised kernel could not be launched: the interpreter from now on

@@ -184,6 +184,7 @@ void ForemanSingleNode::workerMain(std::size_t worker_id) {
       --outstanding_[item.op];
       --executing_[item.op];
       --(item.exclusive ? exclusive_running_ : shared_running_);
+      ++events_;
       profile_.push_back(WorkOrderTimeEntry{worker_id, item.op, start, end});
       if (!error.empty() && worker_error_.empty()) worker_error_ = error;
     }
@@ -228,6 +229,23 @@ void ForemanSingleNode::run() {
     WorkerThreads::instance(device).run(num_workers_, [this](std::size_t w) { workerMain(w); });
   });
 
+  // The Foreman sleeps until something happened: a work order finished (workerMain) or an output block was registered with
+  // one of the plan's destinations — the kDataPipelineMessage / kWorkOrderCompleteMessage the reference's Foreman blocks on
+  // (query_execution/ForemanSingleNode.cpp:118-170), in place of a timed poll.
+  std::vector<InsertDestination *> hooked;
+  for (std::size_t op = 0; op < N; ++op) {
+    const QueryContext::insert_destination_id dest_id = plan_->getOperator(op)->getInsertDestinationID();
+    if (dest_id == QueryContext::kInvalidInsertDestinationId) continue;
+    InsertDestination *dest = query_context_->getInsertDestination(dest_id);
+    dest->setBlockReturnedCallback([this]() {
+      {
+        std::lock_guard<std::mutex> lock(mutex_);
+        ++events_;
+      }
+      cv_done_.notify_all();
+    });
+    hooked.push_back(dest);
+  }
   auto shutdown = [&]() {
     {
       std::lock_guard<std::mutex> lock(mutex_);
@@ -235,12 +253,14 @@ void ForemanSingleNode::run() {
     }
     cv_work_.notify_all();
     workers.join();
+    for (InsertDestination *dest : hooked) dest->setBlockReturnedCallback(nullptr);
   };
 
   try {
     for (;;) {
       std::unique_lock<std::mutex> lock(mutex_);
       if (!worker_error_.empty()) throw std::runtime_error("work order failed: " + worker_error_);
+      const std::uint64_t events_seen = events_;   // whatever happens from here on wakes the wait at the end of this pass
       bool progress = false;
       for (std::size_t op = 0; op < N; ++op) {
         if (finished[op]) continue;
@@ -273,14 +293,15 @@ void ForemanSingleNode::run() {
         RelationalOperator *producer = plan_->getOperator(op);
         const QueryContext::insert_destination_id dest_id = producer->getInsertDestinationID();
         if (dest_id != QueryContext::kInvalidInsertDestinationId) {
-          const std::vector<InsertDestination::TouchedBlock> touched = query_context_->getInsertDestination(dest_id)->getTouchedBlocksWithPartitions();
-          for (; blocks_fed[op] < touched.size(); ++blocks_fed[op]) {
+          // (only the blocks that are new since the last pass are copied out of the destination)
+          const std::vector<InsertDestination::TouchedBlock> fresh = query_context_->getInsertDestination(dest_id)->getTouchedBlocksSince(blocks_fed[op]);
+          for (const InsertDestination::TouchedBlock &block : fresh) {
+            ++blocks_fed[op];
             for (std::size_t consumer = 0; consumer < N; ++consumer) {
               for (const QueryPlan::Edge &e : plan_->dependencies(consumer)) {
                 if (e.producer == op && !e.breaker) {
                   // kDataPipelineMessage carries the partition id of the block (InsertDestination.cpp:424-470)
-                  plan_->getOperator(consumer)->feedInputBlock(touched[blocks_fed[op]].id, producer->getOutputRelationID(),
-                                                               touched[blocks_fed[op]].partition);
+                  plan_->getOperator(consumer)->feedInputBlock(block.id, producer->getOutputRelationID(), block.partition);
                   progress = true;
                 }
               }
@@ -290,7 +311,7 @@ void ForemanSingleNode::run() {
         if (done_generating[op] && outstanding_[op] == 0 && producers_finished && container.getNumNormalWorkOrders(op) == 0) {
           // re-check that no block appeared between the scan above and now
           if (dest_id == QueryContext::kInvalidInsertDestinationId ||
-              blocks_fed[op] == query_context_->getInsertDestination(dest_id)->getTouchedBlocks().size()) {
+              blocks_fed[op] == query_context_->getInsertDestination(dest_id)->numTouchedBlocks()) {
             finished[op] = true;
             progress = true;
             producer->updateCatalogOnCompletion();   // QueryManagerBase.cpp:184 (markOperatorFinished)
@@ -310,7 +331,7 @@ void ForemanSingleNode::run() {
         cv_work_.notify_all();
         continue;
       }
-      cv_done_.wait_for(lock, std::chrono::milliseconds(50));
+      cv_done_.wait(lock, [&] { return events_ != events_seen || !worker_error_.empty(); });
     }
   } catch (...) {
     shutdown();

@@ -97,13 +97,16 @@ void InsertDestination::returnBlock(block_id id, std::int64_t num_tuples, partit
   BlockReference block = storage_manager_->getBlock(id);
   block->setNumTuples(num_tuples);
   block->setFirstRow(storage_manager_->reserveRows(relation_->getID(), num_tuples));
-  std::lock_guard<std::mutex> lock(mutex_);
-  touched_.push_back(TouchedBlock{id, input_partition});
-  if (relation_->hasPartitionScheme()) {
-    relation_->addBlockToPartition(id, input_partition);   // the output keeps the input's partitioning (no repartition)
-  } else {
-    relation_->addBlock(id);
+  {
+    std::lock_guard<std::mutex> lock(mutex_);
+    touched_.push_back(TouchedBlock{id, input_partition});
+    if (relation_->hasPartitionScheme()) {
+      relation_->addBlockToPartition(id, input_partition);   // the output keeps the input's partitioning (no repartition)
+    } else {
+      relation_->addBlock(id);
+    }
   }
+  if (block_returned_) block_returned_();
 }
 
 // bulkInsertTuples of a PartitionAwareInsertDestination (storage/InsertDestination.hpp:560-660), on a whole block at once:
@@ -193,11 +196,14 @@ void InsertDestination::repartitionBlock(block_id id, std::int64_t num_tuples) {
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // before the source block goes
   storage_manager_->deleteBlockOrBlobFile(id);
   storage_manager_->deleteBlockOrBlobFile(scattered_id);      // (the views keep the scattered block alive)
-  std::lock_guard<std::mutex> lock(mutex_);
-  for (const auto &m : made) {
-    touched_.push_back(TouchedBlock{m.first, m.second});
-    relation_->addBlockToPartition(m.first, m.second);
+  {
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (const auto &m : made) {
+      touched_.push_back(TouchedBlock{m.first, m.second});
+      relation_->addBlockToPartition(m.first, m.second);
+    }
   }
+  if (block_returned_ && !made.empty()) block_returned_();
 }
 std::vector<block_id> InsertDestination::getTouchedBlocks() const {
   std::lock_guard<std::mutex> lock(mutex_);
@@ -208,6 +214,15 @@ std::vector<block_id> InsertDestination::getTouchedBlocks() const {
 std::vector<InsertDestination::TouchedBlock> InsertDestination::getTouchedBlocksWithPartitions() const {
   std::lock_guard<std::mutex> lock(mutex_);
   return touched_;
+}
+std::vector<InsertDestination::TouchedBlock> InsertDestination::getTouchedBlocksSince(std::size_t from) const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  if (from >= touched_.size()) return {};
+  return std::vector<TouchedBlock>(touched_.begin() + static_cast<std::ptrdiff_t>(from), touched_.end());
+}
+std::size_t InsertDestination::numTouchedBlocks() const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  return touched_.size();
 }
 
 // ---------------------------------------------------------------------------

@@ -210,6 +210,14 @@ class StorageBlock {
   // Replaces attribute a's stripe by its compressed form when CompressedBlockBuilder would (values on the host).
   void compressAttribute(attribute_id a, const void *host_values);
   bool valuesMaterialized(attribute_id a) const { return stripes_.at(a) != nullptr; }
+  // An attribute of a block adopted from a reference CompressedColumnStore image (StorageManager::adoptBlockImage): its
+  // code stripe and dictionary lie in the image (nothing is copied but the dictionary's host copy for the predicate
+  // rewriting); the values are decoded on first use like those of a block this layer compressed itself.
+  void adoptCompressedAttribute(attribute_id a, CompressedAttribute attribute);
+  // The memory an adopted block points into (never freed with the block; what it allocates later — decoded stripes, the
+  // null bitmap made from a dictionary's NULL code — is).
+  void setExternalRange(const void *base, std::size_t bytes) { external_base_ = static_cast<const char *>(base); external_bytes_ = bytes; }
+  void setNullBitmap(attribute_id a, void *bitmap) { null_bitmaps_.at(a) = bitmap; }
   // Sort column of a sorted column store (TupleStorageSubBlockDescription sort_attribute_id; the tuples of the block are
   // in ascending order of it): predicates on it are evaluated by binary search (predicate_cost::kBinarySearch).
   // kInvalidAttributeID = unsorted.  The loader of the block vouches for the order.
@@ -231,6 +239,8 @@ class StorageBlock {
   std::size_t slab_bytes_ = 0, slab_granted_ = 0;   // granted: the pool's size class (0: a plain allocation)
   std::shared_ptr<StorageBlock> view_parent_;    // != nullptr: the stripes belong to it
   bool external_memory_ = false;                 // stripes and null bitmaps belong to the caller (an adopted block image)
+  const char *external_base_ = nullptr;          // ... and lie in [external_base_, external_base_ + external_bytes_)
+  std::size_t external_bytes_ = 0;               //     (0: every pointer of the block is the caller's)
   mutable std::vector<void *> stripes_;          // nullptr: compressed and not decoded yet
   std::vector<void *> null_bitmaps_;
   std::vector<CompressedAttribute> compressed_;  // empty or one per attribute
@@ -251,12 +261,23 @@ struct ReferenceBlockLayout {
   std::int64_t num_tuples = 0, max_tuples = 0;
   attribute_id sort_attribute = kInvalidAttributeID;   // BasicColumnStoreTupleStorageSubBlockDescription::sort_attribute_id
   std::size_t tuple_store_offset = 0, tuple_store_size = 0;
-  std::vector<std::size_t> null_bitmap_offset;          // per attribute; SIZE_MAX: not nullable
+  std::vector<std::size_t> null_bitmap_offset;          // per attribute; SIZE_MAX: not nullable / no bitmap in this block
   std::vector<std::size_t> stripe_offset;               // per attribute
+  // A CompressedColumnStoreTupleStorageSubBlock (storage/CompressedColumnStoreTupleStorageSubBlock.cpp:755-798,
+  // CompressedTupleStorageSubBlock.cpp:281-342): {int32 num_tuples; int32 info bytes; CompressedBlockInfo (protobuf)}, the
+  // dictionaries back to back ({uint32 num_codes; uint32 null_code; values}, compression/CompressionDictionary.hpp:46-58),
+  // a null bitmap of null_bitmap_bits bits per UNCOMPRESSED attribute that has NULLs, then one stripe per attribute at
+  // max_tuples x attribute_size[a] bytes — codes where attribute_size differs from the type's width or a dictionary exists.
+  bool compressed = false;
+  std::vector<std::size_t> attribute_size;              // bytes per tuple in the stripe (compressed stores)
+  std::vector<std::size_t> dictionary_offset;           // per attribute; SIZE_MAX: none.  Offset of the 8-byte dictionary header
+  std::vector<std::size_t> dictionary_bytes;
+  std::size_t null_bitmap_bits = 0;
 };
 // Pure host logic: `prefix` = the first prefix_bytes of the image (the block header and the 8-byte sub-block header must lie
 // inside), image_bytes = its full size.  Throws ExecutionError(QSX_ERR_INVALID_ARGUMENT) for a malformed image
-// (StorageBlock.cpp:108-131 MalformedBlock) and QSX_ERR_UNSUPPORTED for a tuple store that is not a basic column store.
+// (StorageBlock.cpp:108-131 MalformedBlock) and QSX_ERR_UNSUPPORTED for a tuple store that is neither a basic nor a compressed
+// column store (row stores), or a compressed store with a variable-length attribute.
 ReferenceBlockLayout ParseReferenceBlockImage(const CatalogRelation &relation, const void *prefix, std::size_t prefix_bytes,
                                               std::size_t image_bytes);
 
@@ -367,6 +388,12 @@ class InsertDestination {
   std::vector<block_id> getTouchedBlocks() const;
   struct TouchedBlock { block_id id; partition_id partition; };
   std::vector<TouchedBlock> getTouchedBlocksWithPartitions() const;
+  // The blocks returned since the first `from` (what the Foreman feeds downstream each pass: kDataPipelineMessage).
+  std::vector<TouchedBlock> getTouchedBlocksSince(std::size_t from) const;
+  std::size_t numTouchedBlocks() const;
+  // Called (outside the destination's lock) every time a block has been registered — the reference sends the Foreman a
+  // kDataPipelineMessage from here (storage/InsertDestination.cpp:424-470); the Foreman of this layer sleeps until then.
+  void setBlockReturnedCallback(std::function<void()> callback) { block_returned_ = std::move(callback); }
 
  private:
   void repartitionBlock(block_id id, std::int64_t num_tuples);
@@ -376,6 +403,7 @@ class InsertDestination {
   attribute_id partition_attribute_ = kInvalidAttributeID;
   mutable std::mutex mutex_;
   std::vector<TouchedBlock> touched_;
+  std::function<void()> block_returned_;
 };
 typedef InsertDestination PartitionAwareInsertDestination;   // (one class: the second constructor makes it partition-aware)
 
@@ -1315,6 +1343,7 @@ class ForemanSingleNode {
   struct Item { WorkOrder *wo; std::size_t op; bool exclusive; };
   std::size_t exclusive_running_ = 0, shared_running_ = 0;   // work orders on Workers right now, by prefersExclusiveDevice()
   std::deque<Item> ready_;
+  std::uint64_t events_ = 0;              // work orders finished + blocks returned to a destination (what the Foreman sleeps on)
   std::vector<std::size_t> outstanding_;  // dispatched but unfinished work orders per operator
   std::vector<std::size_t> executing_;    // of those: on a Worker right now
   bool shutting_down_ = false;

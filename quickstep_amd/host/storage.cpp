@@ -125,8 +125,19 @@ StorageBlock::StorageBlock(const CatalogRelation &relation, std::int64_t num_tup
 
 StorageBlock::~StorageBlock() {
   if (external_memory_) {
-    for (void *&p : stripes_) p = nullptr;
-    for (void *&p : null_bitmaps_) p = nullptr;
+    // pointers into the adopted image are the caller's; what the block allocated afterwards (a decoded stripe, the null
+    // bitmap made from a dictionary's NULL code) is freed below like any other block's
+    auto foreign = [&](const void *p) {
+      if (external_bytes_ == 0) return true;
+      const char *c = static_cast<const char *>(p);
+      return c >= external_base_ && c < external_base_ + external_bytes_;
+    };
+    for (void *&p : stripes_) if (p != nullptr && foreign(p)) p = nullptr;
+    for (void *&p : null_bitmaps_) if (p != nullptr && foreign(p)) p = nullptr;
+    for (CompressedAttribute &c : compressed_) {
+      if (c.codes != nullptr && foreign(c.codes)) c.codes = nullptr;
+      if (c.dictionary != nullptr && foreign(c.dictionary)) c.dictionary = nullptr;
+    }
   }
   // A block that dies while an exception unwinds a work order may still be the target of kernels that work order has
   // queued: they must finish before its memory goes back to a pool another Worker takes from (the regular path has
@@ -171,6 +182,12 @@ void StorageBlock::copyAttributeToHost(attribute_id a, void *dst) const {
   } else {
     CheckStatus(qsx_copy_to_host(dst, stripe(a), bytes, CurrentStream()), "qsx_copy_to_host");
   }
+}
+
+void StorageBlock::adoptCompressedAttribute(attribute_id a, CompressedAttribute attribute) {
+  if (compressed_.empty()) compressed_.resize(relation_.size());
+  compressed_.at(a) = std::move(attribute);
+  stripes_.at(a) = nullptr;   // decoded on first use (stripe())
 }
 
 void *StorageBlock::stripe(attribute_id a) const {
@@ -649,7 +666,10 @@ ReferenceBlockLayout ParseReferenceBlockImage(const CatalogRelation &relation, c
           while (store.ok && store.at < store.end) {
             const std::uint64_t stag = store.varint();
             if ((stag >> 3) == 1 && (stag & 7) == 0) sub_block_type = store.varint();
-            else if ((stag >> 3) == 64 && (stag & 7) == 0) out.sort_attribute = static_cast<attribute_id>(static_cast<std::int32_t>(store.varint()));
+            // sort_attribute_id: extension 64 of a basic column store, 128 of a compressed one (StorageBlockLayout.proto:38-58);
+            // 129 (compressed_attribute_id, repeated) only says what the builder was ASKED to compress — what it did is in
+            // the sub-block's own CompressedBlockInfo
+            else if (((stag >> 3) == 64 || (stag >> 3) == 128) && (stag & 7) == 0) out.sort_attribute = static_cast<attribute_id>(static_cast<std::int32_t>(store.varint()));
             else store.skip(static_cast<int>(stag & 7));
           }
           if (!store.ok) Malformed("tuple store description");
@@ -666,12 +686,92 @@ ReferenceBlockLayout ParseReferenceBlockImage(const CatalogRelation &relation, c
     }
   }
   if (!header.ok || !have_layout || !have_size || sub_block_type == ~0ull) Malformed("block header");   // !IsInitialized()
-  if (sub_block_type != 0) {   // TupleStorageSubBlockDescription::BASIC_COLUMN_STORE
-    throw ExecutionError("block image: the tuple store is not a BasicColumnStore (compressed / row stores are not adopted in place)", QSX_ERR_UNSUPPORTED);
+  // TupleStorageSubBlockDescription: BASIC_COLUMN_STORE = 0, COMPRESSED_COLUMN_STORE = 2 (the row stores 1 and 3 have no stripes)
+  if (sub_block_type != 0 && sub_block_type != 2) {
+    throw ExecutionError("block image: the tuple store is a row store (only column stores are adopted in place)", QSX_ERR_UNSUPPORTED);
   }
   out.tuple_store_offset = sizeof(std::int32_t) + static_cast<std::size_t>(header_length);
   if (out.tuple_store_offset + out.tuple_store_size > image_bytes) Malformed("sub-block sizes exceed the block");   // :141-143
   if (out.tuple_store_size < 8) Malformed("tuple store smaller than its header");   // BlockMemoryTooSmall
+  if (out.sort_attribute != kInvalidAttributeID && (out.sort_attribute < 0 || static_cast<std::size_t>(out.sort_attribute) >= relation.size())) {
+    Malformed("sort attribute");
+  }
+  if (sub_block_type == 2) {
+    // CompressedTupleStorageSubBlock::initializeCommon (storage/CompressedTupleStorageSubBlock.cpp:281-342) +
+    // CompressedColumnStoreTupleStorageSubBlock::initialize (.cpp:755-798)
+    out.compressed = true;
+    const std::size_t store_end = out.tuple_store_offset + out.tuple_store_size;
+    std::int32_t num_tuples = 0, info_bytes = 0;
+    std::memcpy(&num_tuples, bytes + out.tuple_store_offset, 4);
+    std::memcpy(&info_bytes, bytes + out.tuple_store_offset + 4, 4);
+    if (num_tuples < 0 || info_bytes <= 0 || out.tuple_store_offset + 8 + static_cast<std::size_t>(info_bytes) > std::min(prefix_bytes, store_end)) {
+      Malformed("compressed block info");
+    }
+    WireReader info{bytes + out.tuple_store_offset + 8, bytes + out.tuple_store_offset + 8 + info_bytes};
+    std::vector<std::uint64_t> attribute_size, dictionary_size;
+    std::vector<bool> has_nulls;
+    bool have_bits = false;
+    auto packed_fixed64 = [](WireReader r, std::vector<std::uint64_t> *into) {
+      while (r.ok && r.at < r.end) into->push_back(r.fixed(8));
+      return r.ok;
+    };
+    while (info.ok && info.at < info.end) {   // StorageBlockLayout.proto:128-150
+      const std::uint64_t tag = info.varint();
+      const int field = static_cast<int>(tag >> 3), wire = static_cast<int>(tag & 7);
+      if (field == 1 && wire == 2) { if (!packed_fixed64(info.sub(), &attribute_size)) Malformed("attribute_size"); }
+      else if (field == 1 && wire == 1) attribute_size.push_back(info.fixed(8));          // (unpacked encoding of the same field)
+      else if (field == 2 && wire == 2) { if (!packed_fixed64(info.sub(), &dictionary_size)) Malformed("dictionary_size"); }
+      else if (field == 2 && wire == 1) dictionary_size.push_back(info.fixed(8));
+      else if (field == 3 && wire == 1) { out.null_bitmap_bits = static_cast<std::size_t>(info.fixed(8)); have_bits = true; }
+      else if (field == 4 && wire == 2) { WireReader r = info.sub(); while (r.ok && r.at < r.end) has_nulls.push_back(r.varint() != 0); }
+      else if (field == 4 && wire == 0) has_nulls.push_back(info.varint() != 0);
+      else info.skip(wire);
+    }
+    if (!info.ok || !have_bits || attribute_size.size() != relation.size() || dictionary_size.size() != relation.size()) {
+      Malformed("compressed block info");   // MalformedBlock (:288-291)
+    }
+    std::size_t at = out.tuple_store_offset + 8 + static_cast<std::size_t>(info_bytes), tuple_length = 0;
+    for (std::size_t a = 0; a < relation.size(); ++a) {
+      const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
+      const std::size_t size = static_cast<std::size_t>(attribute_size[a]);
+      out.attribute_size.push_back(size);
+      tuple_length += size;
+      if (dictionary_size[a] > 0) {
+        if (size != 1 && size != 2 && size != 4) Malformed("code width of a dictionary-coded attribute");
+        if (dictionary_size[a] < 8 || at + dictionary_size[a] > store_end) Malformed("dictionary size");
+        out.dictionary_offset.push_back(at);
+        out.dictionary_bytes.push_back(static_cast<std::size_t>(dictionary_size[a]));
+        at += static_cast<std::size_t>(dictionary_size[a]);
+      } else {
+        out.dictionary_offset.push_back(static_cast<std::size_t>(-1));
+        out.dictionary_bytes.push_back(0);
+        if (size != static_cast<std::size_t>(t.width)) {   // truncation: INT / LONG only, to 1 / 2 / 4 bytes (:319-337)
+          if ((t.id != kInt && t.id != kLong) || (size != 1 && size != 2 && size != 4) || size >= static_cast<std::size_t>(t.width)) Malformed("truncated attribute");
+        }
+      }
+    }
+    if (tuple_length == 0) Malformed("relation without attributes");
+    const std::size_t per_bitmap = (out.null_bitmap_bits + 63) / 64 * 8;   // BitVector<false>::BytesNeeded
+    for (std::size_t a = 0; a < relation.size(); ++a) {
+      if (out.null_bitmap_bits > 0 && a < has_nulls.size() && has_nulls[a]) {
+        out.null_bitmap_offset.push_back(at);
+        at += per_bitmap;
+      } else {
+        out.null_bitmap_offset.push_back(static_cast<std::size_t>(-1));
+      }
+    }
+    if (at > store_end) Malformed("dictionaries and null bitmaps exceed the tuple store");
+    const std::size_t max_tuples = (store_end - at) / tuple_length;
+    if (static_cast<std::size_t>(num_tuples) > max_tuples) Malformed("num_tuples");
+    if (out.null_bitmap_bits > 0 && out.null_bitmap_bits < static_cast<std::size_t>(num_tuples)) Malformed("null bitmap shorter than the block");
+    out.num_tuples = num_tuples;
+    out.max_tuples = static_cast<std::int64_t>(max_tuples);
+    for (std::size_t a = 0; a < relation.size(); ++a) {
+      out.stripe_offset.push_back(at);
+      at += max_tuples * out.attribute_size[a];
+    }
+    return out;
+  }
   // BasicColumnStoreTupleStorageSubBlock.cpp:131-147
   std::size_t row_bytes = 0, nullable = 0;
   for (std::size_t a = 0; a < relation.size(); ++a) {
@@ -729,7 +829,63 @@ block_id StorageManager::adoptBlockImage(CatalogRelation *relation, void *image_
     nulls.push_back(layout.null_bitmap_offset[a] == static_cast<std::size_t>(-1) ? nullptr : base + layout.null_bitmap_offset[a]);
   }
   BlockReference block = std::make_shared<StorageBlock>(*relation, layout.num_tuples, stripes, nulls);
+  block->setExternalRange(image_dev, image_bytes);
   block->setSortColumn(layout.sort_attribute);
+  auto fetch = [&](void *dst, std::size_t offset, std::size_t bytes) {
+    if (g_host_memory) std::memcpy(dst, base + offset, bytes);
+    else CheckStatus(qsx_copy_to_host(dst, base + offset, bytes, CurrentStream()), "qsx_copy_to_host(dictionary)");
+  };
+  for (std::size_t a = 0; layout.compressed && a < relation->size(); ++a) {
+    const Type &t = relation->getAttributeType(static_cast<attribute_id>(a));
+    const bool coded = layout.dictionary_offset[a] != static_cast<std::size_t>(-1);
+    if (!coded && layout.attribute_size[a] == static_cast<std::size_t>(t.width)) continue;   // stored as values
+    if (g_host_memory) throw ExecutionError("adoptBlockImage: compressed blocks need device memory", QSX_ERR_UNSUPPORTED);
+    CompressedAttribute c;
+    c.code_width = static_cast<int>(layout.attribute_size[a]);
+    c.codes = base + layout.stripe_offset[a];
+    if (!coded) {
+      c.kind = CompressedAttribute::kTruncated;   // the value itself, zero-extended (CompressedBlockBuilder.cpp:508-566)
+    } else {
+      // {uint32 num_codes; uint32 null_code; num_codes values in ascending order} (compression/CompressionDictionary.hpp:46-58)
+      std::uint32_t head[2] = {0, 0};
+      fetch(head, layout.dictionary_offset[a], 8);
+      const std::size_t value_bytes = static_cast<std::size_t>(head[0]) * static_cast<std::size_t>(t.width);
+      if (8 + value_bytes > layout.dictionary_bytes[a]) {
+        throw ExecutionError("malformed block image: dictionary shorter than its entry count (variable-length dictionaries are not adopted)",
+                             QSX_ERR_INVALID_ARGUMENT);
+      }
+      c.kind = CompressedAttribute::kDictionary;
+      c.num_codes = head[0];
+      c.dictionary = base + layout.dictionary_offset[a] + 8;
+      c.dictionary_host.resize(value_bytes);
+      if (value_bytes != 0) fetch(c.dictionary_host.data(), layout.dictionary_offset[a] + 8, value_bytes);
+      if (t.id == kChar || t.id == kDate) c.value_width = t.width;
+      if (head[1] != 0xFFFFFFFFu && layout.num_tuples > 0) {
+        // a NULL is the code num_codes (CompressionDictionary.hpp:49-52, 114-115): the tuples that carry it become the
+        // attribute's null bitmap, which every operator of this layer already honours — a predicate's match under a NULL
+        // is taken back, a NULL join key or group-by key drops the tuple, aggregates skip NULL arguments; the decoded value
+        // under a NULL (one entry past the dictionary's last) is never looked at
+        const std::size_t words = static_cast<std::size_t>((layout.num_tuples + 63) / 64);
+        void *bitmap = nullptr, *count = nullptr;
+        CheckStatus(qsx_device_alloc(words * 8 + 8, &bitmap), "qsx_device_alloc(null bitmap)");
+        CheckStatus(qsx_device_alloc(8, &count), "qsx_device_alloc(count)");
+        const int rc = qsx_select_codes(c.code_width, c.codes, layout.num_tuples, QSX_CODE_EQ, head[1], 0, nullptr, static_cast<std::uint64_t *>(bitmap),
+                                        static_cast<std::int64_t *>(count), CurrentStream());
+        if (rc == QSX_OK) (void)qsx_stream_synchronize(CurrentStream());
+        qsx_device_free(count);
+        if (rc != QSX_OK) {
+          qsx_device_free(bitmap);
+          CheckStatus(rc, "qsx_select_codes(NULL code)");
+        }
+        if (!t.nullable) {
+          qsx_device_free(bitmap);
+          throw ExecutionError("malformed block image: a NULL code in an attribute the relation declares NOT NULL", QSX_ERR_INVALID_ARGUMENT);
+        }
+        block->setNullBitmap(static_cast<attribute_id>(a), bitmap);
+      }
+    }
+    block->adoptCompressedAttribute(static_cast<attribute_id>(a), std::move(c));
+  }
   block_id id;
   {
     std::lock_guard<std::mutex> lock(mutex_);

@@ -4,7 +4,10 @@
 // block's stripes and null bitmaps point into the image, stripes max_tuples x width apart).  Select, HashJoin and
 // Aggregation over the adopted blocks must give what they give over blocks loaded column by column (loadBlock) from the
 // same values — a non-nullable and a nullable relation, 2 MB and 4 MB blocks, ragged fill, one empty block, work orders per
-// block and per run of blocks.
+// block and per run of blocks.  The same for COMPRESSED column store images (the reference's TPC-H DDL stores lineitem and
+// orders that way, benchmarks/tpch/create.sql:69-121): l_orderkey truncated to 2 bytes and the block's sort column,
+// l_quantity dictionary-coded in one byte — with the NULL code of compression/CompressionDictionary.hpp:49-52 in the nullable
+// relation — l_extendedprice as values with its own null bitmap; codes and dictionaries are used where they lie.
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -37,7 +40,15 @@ Data makeData(int blocks, std::int64_t rows_per_block) {
       qn[i] = rnd() % 13 == 0;
       pn[i] = rnd() % 7 == 0;
     }
-    d.key.push_back(k); d.qty.push_back(q); d.price.push_back(p); d.qty_null.push_back(qn); d.price_null.push_back(pn);
+    // ascending l_orderkey inside a block: what a column store sorted on it holds (the compressed images declare it)
+    std::vector<std::size_t> order(static_cast<std::size_t>(n));
+    for (std::size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](std::size_t x, std::size_t y) { return k[x] < k[y]; });
+    std::vector<std::int32_t> k2(k.size()), q2(q.size());
+    std::vector<double> p2(p.size());
+    std::vector<bool> qn2(qn.size()), pn2(pn.size());
+    for (std::size_t i = 0; i < order.size(); ++i) { k2[i] = k[order[i]]; q2[i] = q[order[i]]; p2[i] = p[order[i]]; qn2[i] = qn[order[i]]; pn2[i] = pn[order[i]]; }
+    d.key.push_back(k2); d.qty.push_back(q2); d.price.push_back(p2); d.qty_null.push_back(qn2); d.price_null.push_back(pn2);
   }
   return d;
 }
@@ -55,15 +66,26 @@ void addAttributes(CatalogRelation *rel, bool nullable) {
   rel->addAttribute("l_extendedprice", nullable ? Type::Double().getNullableVersion() : Type::Double());
 }
 
-void load(Loaded *l, const Data &d, bool nullable, bool as_images, std::size_t block_bytes) {
+// as_images: 0 = loaded column by column, 1 = BasicColumnStore images, 2 = CompressedColumnStore images
+void load(Loaded *l, const Data &d, bool nullable, int as_images, std::size_t block_bytes) {
   addAttributes(&l->rel, nullable);
   for (std::size_t b = 0; b < d.key.size(); ++b) {
     const std::int64_t n = static_cast<std::int64_t>(d.key[b].size());
-    if (as_images) {
+    if (as_images != 0) {
       std::int64_t max_tuples = 0;
-      const std::vector<unsigned char> image = block_image::Build(l->rel, {d.key[b].data(), d.qty[b].data(), d.price[b].data()},
-                                                                  {{}, nullable ? d.qty_null[b] : std::vector<bool>(), nullable ? d.price_null[b] : std::vector<bool>()},
-                                                                  n, block_bytes, -1, &max_tuples);
+      const std::vector<const void *> columns = {d.key[b].data(), d.qty[b].data(), d.price[b].data()};
+      const std::vector<std::vector<bool>> null_flags = {{}, nullable ? d.qty_null[b] : std::vector<bool>(), nullable ? d.price_null[b] : std::vector<bool>()};
+      std::vector<unsigned char> image;
+      if (as_images == 2) {
+        block_image::Coding truncated, dictionary, values;
+        truncated.kind = block_image::Coding::kTruncated;
+        truncated.code_width = 2;
+        dictionary.kind = block_image::Coding::kDictionary;
+        dictionary.code_width = 1;
+        image = block_image::BuildCompressed(l->rel, columns, null_flags, n, block_bytes, 0, {truncated, dictionary, values}, &max_tuples);
+      } else {
+        image = block_image::Build(l->rel, columns, null_flags, n, block_bytes, -1, &max_tuples);
+      }
       EXPECT_TRUE(max_tuples >= n);
       void *dev = nullptr;
       CheckStatus(qsx_device_alloc(image.size(), &dev), "qsx_device_alloc");
@@ -72,6 +94,14 @@ void load(Loaded *l, const Data &d, bool nullable, bool as_images, std::size_t b
       l->images.push_back(dev);
       const block_id id = l->storage.adoptBlockImage(&l->rel, dev, image.size());
       EXPECT_EQ(l->storage.getBlock(id)->numTuples(), n);
+      if (as_images == 2) {   // adopted as codes: nothing decoded yet, the key column is the block's sort column
+        BlockReference blk = l->storage.getBlock(id);
+        EXPECT_TRUE(blk->compressedAttribute(0) != nullptr && blk->compressedAttribute(0)->kind == CompressedAttribute::kTruncated);
+        EXPECT_TRUE(blk->compressedAttribute(1) != nullptr && blk->compressedAttribute(1)->kind == CompressedAttribute::kDictionary);
+        EXPECT_TRUE(blk->compressedAttribute(2) == nullptr);
+        EXPECT_TRUE(!blk->valuesMaterialized(0) && !blk->valuesMaterialized(1));
+        EXPECT_EQ(blk->sortColumn(), 0);
+      }
     } else {
       std::vector<std::uint64_t> qn(static_cast<std::size_t>((n + 63) / 64) + 1, 0), pn(qn.size(), 0);
       for (std::int64_t i = 0; i < n && nullable; ++i) {
@@ -90,7 +120,7 @@ struct Results {
   std::int64_t joined = 0;
 };
 
-Results run(const Data &d, bool nullable, bool as_images, std::size_t block_bytes, std::size_t blocks_per_order) {
+Results run(const Data &d, bool nullable, int as_images, std::size_t block_bytes, std::size_t blocks_per_order) {
   Loaded l;
   load(&l, d, nullable, as_images, block_bytes);
   Results r;
@@ -189,11 +219,13 @@ int main() {
         want_selected += (!(nullable && d.qty_null[b][i]) && d.qty[b][i] < 24) ? 1 : 0;
       }
     }
-    const Results loaded = run(d, nullable, false, block_bytes, 1);
+    const Results loaded = run(d, nullable, 0, block_bytes, 1);
     EXPECT_EQ(loaded.joined, want_joined);
     EXPECT_EQ(static_cast<std::int64_t>(loaded.selected.size()), want_selected);
-    for (const std::size_t per_order : {std::size_t(1), std::size_t(4)}) {
-      const Results adopted = run(d, nullable, true, block_bytes, per_order);
+    for (const int form : {1, 1, 2, 2}) {
+      static int turn = 0;
+      const std::size_t per_order = (turn++ % 2) == 0 ? 1 : 4;
+      const Results adopted = run(d, nullable, form, block_bytes, per_order);
       EXPECT_EQ(adopted.joined, want_joined);
       EXPECT_TRUE(adopted.selected == loaded.selected);
       EXPECT_EQ(adopted.groups.size(), loaded.groups.size());

@@ -171,6 +171,47 @@ void CheckBlockImages() {
     std::memcpy(other.data(), &len, 4);
     std::memcpy(other.data() + 4, split_row.data(), split_row.size());
     EXPECT_TRUE(refused(other, other.size(), QSX_ERR_UNSUPPORTED));
+    // a CompressedColumnStore image of the same relation: k truncated to 2 bytes and the sort column, q dictionary-coded in
+    // one byte with a NULL code, v as values with a null bitmap (CompressedColumnStoreTupleStorageSubBlock.cpp:755-798)
+    {
+      for (std::int64_t i = 0; i < n; ++i) k[i] = i / 4;     // (fits 2 bytes, ascending)
+      block_image::Coding truncated, dictionary, values;
+      truncated.kind = block_image::Coding::kTruncated;
+      truncated.code_width = 2;
+      dictionary.kind = block_image::Coding::kDictionary;
+      dictionary.code_width = 1;
+      std::int64_t cmax = 0;
+      const std::vector<unsigned char> cimage = block_image::BuildCompressed(rel, {k.data(), q.data(), v.data()}, {{}, qn, vn}, n, 2u << 20, 0,
+                                                                             {truncated, dictionary, values}, &cmax);
+      const ReferenceBlockLayout cl = ParseReferenceBlockImage(rel, cimage.data(), 8192, cimage.size());
+      EXPECT_TRUE(cl.compressed);
+      EXPECT_EQ(cl.num_tuples, n);
+      EXPECT_EQ(cl.max_tuples, cmax);
+      EXPECT_EQ(cl.sort_attribute, 0);
+      EXPECT_EQ(cl.attribute_size[0], static_cast<std::size_t>(2));
+      EXPECT_EQ(cl.attribute_size[1], static_cast<std::size_t>(1));
+      EXPECT_EQ(cl.attribute_size[2], static_cast<std::size_t>(8));
+      EXPECT_TRUE(cl.dictionary_offset[0] == static_cast<std::size_t>(-1) && cl.dictionary_offset[2] == static_cast<std::size_t>(-1));
+      EXPECT_EQ(cl.dictionary_bytes[1], static_cast<std::size_t>(8 + 50 * 4));          // {num_codes, null_code} + 50 INT values
+      std::uint32_t head[2];
+      std::memcpy(head, cimage.data() + cl.dictionary_offset[1], 8);
+      EXPECT_EQ(head[0], 50u);
+      EXPECT_EQ(head[1], 50u);                                                             // NULL = the code num_codes
+      EXPECT_EQ(cl.null_bitmap_bits, static_cast<std::size_t>(n));
+      EXPECT_TRUE(cl.null_bitmap_offset[1] == static_cast<std::size_t>(-1));              // q's NULLs are codes, not bits
+      EXPECT_EQ(cl.null_bitmap_offset[2], cl.dictionary_offset[1] + cl.dictionary_bytes[1]);
+      EXPECT_EQ(cl.stripe_offset[0], cl.null_bitmap_offset[2] + static_cast<std::size_t>((n + 63) / 64 * 8));
+      EXPECT_EQ(cl.stripe_offset[1], cl.stripe_offset[0] + static_cast<std::size_t>(cmax) * 2);
+      EXPECT_EQ(cl.stripe_offset[2], cl.stripe_offset[1] + static_cast<std::size_t>(cmax));
+      EXPECT_TRUE(cl.stripe_offset[2] + static_cast<std::size_t>(cmax) * 8 <= cimage.size());
+      std::uint16_t key_at_1000 = 0;
+      std::memcpy(&key_at_1000, cimage.data() + cl.stripe_offset[0] + 2000, 2);
+      EXPECT_EQ(key_at_1000, 250);
+      std::vector<unsigned char> cbad = cimage;
+      const std::int32_t absurd = 1 << 30;
+      std::memcpy(cbad.data() + cl.tuple_store_offset + 4, &absurd, 4);                    // info size beyond the block
+      EXPECT_TRUE(refused(cbad, cbad.size(), QSX_ERR_INVALID_ARGUMENT));
+    }
   }
   UseHostMemoryForBlocks(false);
 }

@@ -87,6 +87,28 @@ def test_run_time_plan_shape_generator_compiles_without_a_gpu(capi):
         assert size.value > 1000
 
 
+def test_plan_shapes_over_nullable_columns_compile(capi, tmp_path, monkeypatch):
+    """A state over nullable columns gets a run-time plan shape too (round 4: the interpreter served them before): the null
+    slots, their LDS offsets and the accumulators' null masks are constants of the shape, the bitmaps of a call arrive
+    behind the `nulls` pointer — plain, filtered, group-directory and dense flavours."""
+    import ctypes as C
+    from quickstep_amd import types as T
+    fn = capi.lib.qsx_debug_jit_compile
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(T.AggConfig), C.c_int, C.POINTER(C.c_size_t)]
+    layout = [(T.INT, None), (T.DOUBLE, None), (T.LONG, None)]
+    aggs = [(T.AGG_SUM, T.col(1)), (T.AGG_COUNT, T.col(2)), (T.AGG_AVG, T.col(1)), (T.AGG_MIN, T.col(2)), (T.AGG_COUNT_STAR, None)]
+    for strategy, extra, bits in ((T.AGG_GENERIC, {}, 0), (T.AGG_GENERIC, {}, 1), (T.AGG_GENERIC, {}, 2),
+                                  (T.AGG_COLLISION_FREE, {"num_entries": 5000}, 0), (T.AGG_COLLISION_FREE, {"num_entries": 5000}, 8)):
+        cfg = T.make_agg_config(strategy, layout, keys=[0], aggs=aggs, nullable=[0, 1, 2], **extra)
+        dump = tmp_path / f"nullable_{strategy}_{bits}.hip"
+        monkeypatch.setenv("QSX_JIT_DUMP", str(dump))
+        size = C.c_size_t(0)
+        assert fn(C.byref(cfg), bits, C.byref(size)) == 0 and size.value > 1000
+        text = dump.read_text()
+        assert "d.num_null_cols = 3" in text and "const unsigned long long *const *nulls" in text and "count_valid = 1" in text
+
+
 def test_plan_shape_flavours_have_sources_of_their_own(capi, tmp_path, monkeypatch):
     """The run-of-blocks flavour and the dense-state-in-LDS flavour of a plan shape are generated as such (template
     arguments emitted, not patched into the text): every flavour compiles and its translation unit differs from the plain

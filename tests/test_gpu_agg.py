@@ -603,11 +603,14 @@ def test_sql_golden_scalar_aggregates_skip_nulls(capi, oracle, dev, golden):
     assert int(vals[0][0]) == 25 and int(vals[5][0]) == 0 and [int(z[0]) for z in flags] == [0, 1, 1, 1, 0, 0]
 
 
+@pytest.mark.parametrize("kernel", ["interpreter", "plan_shape"])
 @pytest.mark.parametrize("strategy", [T.AGG_SINGLE_STATE, T.AGG_COMPACT_KEY, T.AGG_GENERIC, T.AGG_COLLISION_FREE])
-def test_nullable_columns_match_the_oracle(capi, oracle, dev, strategy):
+def test_nullable_columns_match_the_oracle(capi, oracle, dev, strategy, kernel, monkeypatch):
     """NULL group-by keys drop the tuple, NULL predicate operands fail the predicate, every aggregate skips the tuples whose
     argument (or an operand of its expression) is NULL, COUNT(*) does not; groups whose argument was always NULL finalize
-    as NULL.  Blocks with and without bitmaps, with and without a filter."""
+    as NULL.  Blocks with and without bitmaps, with and without a filter — through the interpreter kernel and through the
+    state's run-time plan shape (the null bitmaps of a call behind a pointer; compiled at the first update here)."""
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", "0" if kernel == "plan_shape" else str(1 << 60))
     rng = np.random.default_rng(77 + strategy)
     n = 150_000
     key = rng.integers(0, 300, size=n).astype(np.int32)
@@ -647,6 +650,8 @@ def test_nullable_columns_match_the_oracle(capi, oracle, dev, strategy):
                                filter_bitmap=None if filt is None else bitmap_dev(filt, dev))
         got, ref = finalize_np(st, dev), o.finalize()
         assert_same_groups(got, ref)
+        # which kernel served the state: 1 = its run-time plan shape, -2 = never asked for one
+        assert capi.lib.qsx_debug_agg_jit_state(st._h, 1 if with_filter else 0) == (1 if kernel == "plan_shape" else -2)
         if strategy != T.AGG_SINGLE_STATE:
             row = int(np.nonzero(got[0][0] == 7)[0][0])
             assert [int(z_[row]) for z_ in got[2]] == [0, 0, 1, 0, 1, 1, 0] and int(got[1][1][row]) == 0
