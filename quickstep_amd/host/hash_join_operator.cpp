@@ -169,15 +169,11 @@ bool HashInnerJoinWorkOrder::executeRun() {
   std::vector<BlockReference> blocks;
   std::vector<std::int64_t> rows, first_rows;
   std::int64_t total_rows = 0;
+  bool any_null_key = false;   // some block holds NULLs in a key attribute: those tuples are not looked up
   for (block_id id : run_block_ids_) {
     blocks.push_back(storage_manager_->getBlock(id));
     const StorageBlock &b = *blocks.back();
-    for (attribute_id a : join_key_attributes_) {
-      if (b.nullBitmap(a) != nullptr) return false;   // (compressed key: stripe() decodes once)
-    }
-    for (std::size_t i = 0; i < selection_.size(); ++i) {
-      if (!is_selection_on_build_[i] && b.nullBitmap(selection_[i]) != nullptr) return false;
-    }
+    for (attribute_id a : join_key_attributes_) any_null_key = any_null_key || b.nullBitmap(a) != nullptr;   // (compressed key: stripe() decodes once)
     rows.push_back(b.numTuples());
     first_rows.push_back(total_rows);
     total_rows += b.numTuples();
@@ -221,7 +217,52 @@ bool HashInnerJoinWorkOrder::executeRun() {
   // that combination stays block by block)
   if (existence_by_pairs && join_type_ == JoinType::kLeftAntiJoin && lip_filter_adaptive_prober_ != nullptr) return false;
   if (lip_filter_adaptive_prober_ != nullptr && !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps)) return false;
-  const std::uint64_t *const *lookup = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();
+  // `about` = the tuples this work order is about (the LIP filter's survivors, or all); `lookup` = those of them that are
+  // looked up: a probe tuple with a NULL key component matches nothing (check_for_null_keys, HashTable.hpp:2158-2160,
+  // 1855-1865) — out of an inner / semi join, NULL-padded by an outer join, KEPT by an anti join.  Blocks without NULLs in
+  // their key attributes (no bitmap) cost nothing here.
+  const std::uint64_t *const *about = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();
+  std::vector<std::unique_ptr<DeviceBuffer>> not_null_storage;
+  std::vector<const std::uint64_t *> lookup_bitmaps;
+  if (any_null_key) {
+    for (std::size_t b = 0; b < blocks.size(); ++b) {
+      const std::uint64_t *in = about != nullptr ? about[b] : nullptr;
+      std::unique_ptr<DeviceBuffer> not_null = NotNullFilter(*blocks[b], join_key_attributes_, in);
+      lookup_bitmaps.push_back(not_null != nullptr ? static_cast<const std::uint64_t *>(not_null->ptr) : in);
+      not_null_storage.push_back(std::move(not_null));
+    }
+  }
+  const std::uint64_t *const *lookup = any_null_key ? lookup_bitmaps.data() : about;
+  // nullable probe-side output attributes: their null bits follow the output tuples (qsx_bitmap_gather_segmented over the
+  // blocks' null bitmaps, by the same tuple ids that gather the values)
+  auto gather_probe_nulls = [&](std::size_t i, const void *tids, std::int64_t n, BlockReference &out, std::int64_t out_first_bit) {
+    const Type &t = probe_relation_.getAttributeType(selection_[i]);
+    if (!t.nullable || n == 0) return;
+    bool any = false;
+    std::vector<const std::uint64_t *> segs(blocks.size());
+    for (std::size_t b = 0; b < blocks.size(); ++b) {
+      segs[b] = blocks[b]->nullBitmap(selection_[i]);
+      any = any || segs[b] != nullptr;
+    }
+    std::uint64_t *nulls = out->nullBitmap(static_cast<attribute_id>(i));
+    if (nulls == nullptr) throw ExecutionError("join output of a nullable attribute must be nullable", QSX_ERR_INVALID_ARGUMENT);
+    if (!any) return;   // (the output block's bitmaps start zeroed)
+    if ((out_first_bit & 63) != 0) throw ExecutionError("join output null bits: unaligned tail", QSX_ERR_UNSUPPORTED);
+    // empty blocks share their first row with the next one: the gather wants strictly increasing segment starts
+    std::vector<const std::uint64_t *> used_segs;
+    std::vector<std::int64_t> used_first;
+    for (std::size_t b = 0; b < blocks.size(); ++b) {
+      if (rows[b] == 0) continue;
+      used_segs.push_back(segs[b]);
+      used_first.push_back(first_rows[b]);
+    }
+    CheckStatus(qsx_bitmap_gather_segmented(static_cast<int>(used_segs.size()), used_segs.data(), used_first.data(), static_cast<const std::int32_t *>(tids), n,
+                                            nulls + out_first_bit / 64, CurrentStream()), "qsx_bitmap_gather_segmented");
+  };
+  bool nullable_probe_output = false;
+  for (std::size_t i = 0; i < selection_.size(); ++i) {
+    nullable_probe_output = nullable_probe_output || (!is_selection_on_build_[i] && probe_relation_.getAttributeType(selection_[i]).nullable);
+  }
   DeviceBuffer count(8);
   if (existence && !existence_by_pairs) {
     // HashSemiJoinWorkOrder / HashAntiJoinWorkOrder without residual (:795-816, :860-877): the probe tuples with / without a
@@ -235,10 +276,26 @@ bool HashInnerJoinWorkOrder::executeRun() {
       bitmaps[b] = static_cast<std::uint64_t *>(bitmap_storage.ptr) + at;
       at += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
     }
-    CheckStatus(qsx_join_probe_exists_blocks(hash_table_, nb, rows.data(), keys.data(), lookup, join_type_ == JoinType::kLeftAntiJoin ? 1 : 0,
+    const bool anti = join_type_ == JoinType::kLeftAntiJoin;
+    // (an anti join over NULL keys: the tuples FOUND among those looked up, then "about AND NOT found" block by block — a
+    // tuple that was not looked up was not found and stays)
+    const bool anti_by_complement = anti && any_null_key;
+    CheckStatus(qsx_join_probe_exists_blocks(hash_table_, nb, rows.data(), keys.data(), lookup, anti && !anti_by_complement ? 1 : 0,
                                              bitmaps.data(), static_cast<std::int64_t *>(count.ptr), CurrentStream()),
                 "qsx_join_probe_exists_blocks");
-    const std::int64_t selected = ReadCount(count.ptr);
+    std::int64_t selected = ReadCount(count.ptr);
+    if (anti_by_complement) {
+      selected = 0;
+      for (std::size_t b = 0; b < blocks.size(); ++b) {
+        selected += rows[b];
+        if (rows[b] == 0) continue;
+        if (about != nullptr && about[b] != nullptr) {
+          CheckStatus(qsx_bitmap_combine(2, about[b], bitmaps[b], rows[b], bitmaps[b], CurrentStream()), "qsx_bitmap_combine");
+        } else {
+          CheckStatus(qsx_bitmap_combine(3, bitmaps[b], nullptr, rows[b], bitmaps[b], CurrentStream()), "qsx_bitmap_combine");
+        }
+      }
+    }
     block_id out_id;
     BlockReference out = output_destination_->getBlockForInsertion(selected > 0 ? selected : 1, &out_id);
     std::vector<const void *> src(blocks.size() * selection_.size());
@@ -251,11 +308,16 @@ bool HashInnerJoinWorkOrder::executeRun() {
     }
     const std::size_t ws_bytes = qsx_compact_blocks_workspace_bytes(nb, rows.data());
     DeviceBuffer ws(ws_bytes + 8);
+    std::unique_ptr<DeviceBuffer> out_tids;   // run-global row number of every output tuple (nullable outputs: their null bits)
+    if (nullable_probe_output) out_tids.reset(new DeviceBuffer(static_cast<std::size_t>(selected > 0 ? selected : 1) * 4 + 8));
     CheckStatus(qsx_compact_gather_blocks(static_cast<int>(selection_.size()), widths.data(), nb, rows.data(), src.data(),
-                                          reinterpret_cast<const std::uint64_t *const *>(bitmaps.data()), nullptr, dst.data(), nullptr,
+                                          reinterpret_cast<const std::uint64_t *const *>(bitmaps.data()), nullptr, dst.data(),
+                                          out_tids != nullptr ? static_cast<std::int32_t *>(out_tids->ptr) : nullptr,
                                           static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
                 "qsx_compact_gather_blocks");
     const std::int64_t written = ReadCount(count.ptr);
+    for (std::size_t i = 0; i < selection_.size() && out_tids != nullptr; ++i) gather_probe_nulls(i, out_tids->ptr, written, out, 0);
+    if (out_tids != nullptr) CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
     output_destination_->returnBlock(out_id, written, getPartitionId());
     return true;
   }
@@ -407,11 +469,16 @@ bool HashInnerJoinWorkOrder::executeRun() {
     }
     const std::size_t ws_bytes = qsx_compact_blocks_workspace_bytes(nb, rows.data());
     DeviceBuffer ws(ws_bytes + 8);
+    std::unique_ptr<DeviceBuffer> out_tids;   // the (word-aligned, like the bitmap) tuple id of every output tuple
+    if (nullable_probe_output) out_tids.reset(new DeviceBuffer(static_cast<std::size_t>(upper > 0 ? upper : 1) * 4 + 8));
     CheckStatus(qsx_compact_gather_blocks(static_cast<int>(selection_.size()), widths.data(), nb, rows.data(), src.data(),
-                                          reinterpret_cast<const std::uint64_t *const *>(bitmaps.data()), nullptr, dst.data(), nullptr,
+                                          reinterpret_cast<const std::uint64_t *const *>(bitmaps.data()), out_tids != nullptr ? base_tids.data() : nullptr,
+                                          dst.data(), out_tids != nullptr ? static_cast<std::int32_t *>(out_tids->ptr) : nullptr,
                                           static_cast<std::int64_t *>(count.ptr), ws.ptr, ws_bytes, CurrentStream()),
                 "qsx_compact_gather_blocks");
     const std::int64_t written = ReadCount(count.ptr);
+    for (std::size_t i = 0; i < selection_.size() && out_tids != nullptr; ++i) gather_probe_nulls(i, out_tids->ptr, written, out, 0);
+    if (out_tids != nullptr) CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
     output_destination_->returnBlock(out_id, written, getPartitionId());
     return true;
   }
@@ -428,8 +495,8 @@ bool HashInnerJoinWorkOrder::executeRun() {
       if (rows[b] == 0) continue;
       std::uint64_t *part = static_cast<std::uint64_t *>(bitmap.ptr) + first_rows[b] / 64;
       CheckStatus(qsx_bitmap_combine(3, part, nullptr, rows[b], part, CurrentStream()), "qsx_bitmap_combine");
-      if (lookup != nullptr && lookup[b] != nullptr) {
-        CheckStatus(qsx_bitmap_combine(0, part, lookup[b], rows[b], part, CurrentStream()), "qsx_bitmap_combine");
+      if (about != nullptr && about[b] != nullptr) {   // (NOT `lookup`: a tuple with a NULL key is NULL-padded, not dropped)
+        CheckStatus(qsx_bitmap_combine(0, part, about[b], rows[b], part, CurrentStream()), "qsx_bitmap_combine");
       }
     }
     DeviceBuffer unmatched_tids(static_cast<std::size_t>(total_rows) * 4 + 8);
@@ -442,6 +509,17 @@ bool HashInnerJoinWorkOrder::executeRun() {
     block_id out_id;
     BlockReference out = output_destination_->getBlockForInsertion(total > 0 ? total : 1, &out_id);
     std::unique_ptr<DeviceBuffer> padded_build_tids;   // the pairs' build tuple ids, then -1 for every unmatched probe tuple
+    std::unique_ptr<DeviceBuffer> all_probe_tids;      // the pairs' probe tuple ids, then the unmatched ones: the output's order
+    if (nullable_probe_output && total > 0) {
+      all_probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(total) * 4 + 8));
+      if (matches > 0) {
+        CheckStatus(qsx_copy_on_device(all_probe_tids->ptr, pairs.probe_tids->ptr, static_cast<std::size_t>(matches) * 4, CurrentStream()), "qsx_copy_on_device");
+      }
+      if (unmatched > 0) {
+        CheckStatus(qsx_copy_on_device(static_cast<char *>(all_probe_tids->ptr) + static_cast<std::size_t>(matches) * 4, unmatched_tids.ptr,
+                                       static_cast<std::size_t>(unmatched) * 4, CurrentStream()), "qsx_copy_on_device");
+      }
+    }
     for (std::size_t i = 0; i < selection_.size(); ++i) {
       char *dst = static_cast<char *>(out->stripe(static_cast<attribute_id>(i)));
       const bool on_build = is_selection_on_build_[i];
@@ -478,6 +556,7 @@ bool HashInnerJoinWorkOrder::executeRun() {
                                            static_cast<const std::int32_t *>(unmatched_tids.ptr), unmatched, tail, CurrentStream()),
                       "qsx_gather_segmented");
         }
+        if (all_probe_tids != nullptr) gather_probe_nulls(i, all_probe_tids->ptr, total, out, 0);
       }
     }
     CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
@@ -504,6 +583,7 @@ bool HashInnerJoinWorkOrder::executeRun() {
       CheckStatus(qsx_gather_segmented(t.width, static_cast<int>(segments.size()), segments.data(), first_rows.data(),
                                        static_cast<const std::int32_t *>(probe_tids.ptr), matches, dst, CurrentStream()),
                   "qsx_gather_segmented");
+      gather_probe_nulls(i, probe_tids.ptr, matches, out, 0);
     }
   }
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");

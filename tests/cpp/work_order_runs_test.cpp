@@ -454,6 +454,94 @@ void runJoinCharResidual(std::size_t blocks_per_order, std::size_t *out_blocks) 
 
 // select l_orderkey * 2 + l_quantity [INT], l_orderkey * 5000000000 - l_quantity [LONG], l_quantity / 7 [INT, truncating],
 //        l_extendedprice * l_quantity [DOUBLE] from lineitem where l_quantity < 24 — integer operands in integer arithmetic
+// NULLs on the probe side — what every outer-join chain hands to the next join: a nullable join key (NULL in every 11th row of
+// the odd blocks; the even blocks carry no bitmap at all) and a nullable output attribute (NULL in every 17th row).  A tuple
+// with a NULL key is not looked up (HashTable.hpp:2158-2160): out of an inner / semi join, kept by an anti join, NULL-padded
+// by an outer join; the null bits of the projected probe attribute follow the output tuples.  Tuples as (quantity or -1 for
+// NULL, second attribute or a marker for NULL).
+void runNullableProbeSide(HashJoinOperator::JoinType type, bool exact_stats, std::size_t blocks_per_order, std::size_t *out_blocks) {
+  using JoinType = HashJoinOperator::JoinType;
+  StorageManager storage;
+  CatalogRelation li(1, "lineitem"), orders(3, "orders"), out(4, "joined");
+  li.addAttribute("l_orderkey", Type::Int().getNullableVersion());
+  li.addAttribute("l_quantity", Type::Int().getNullableVersion());
+  li.addAttribute("l_extendedprice", Type::Double());
+  orders.addAttribute("o_orderkey", Type::Int());
+  const bool existence = type == JoinType::kLeftSemiJoin || type == JoinType::kLeftAntiJoin;
+  out.addAttribute("l_quantity", Type::Int().getNullableVersion());
+  if (existence) out.addAttribute("l_extendedprice", Type::Double());
+  else out.addAttribute("o_orderkey", type == JoinType::kLeftOuterJoin ? Type::Int().getNullableVersion() : Type::Int());
+  std::vector<std::pair<std::int64_t, std::int64_t>> want;
+  constexpr std::int64_t kNullMark = -7777777;
+  std::mt19937_64 rng(23);
+  for (int b = 0; b < kBlocks; ++b) {
+    const std::int64_t n = b == 5 ? 0 : kBlockRows - 13 * (b % 7);
+    std::vector<std::int32_t> k(n), q(n);
+    std::vector<double> p(n);
+    std::vector<std::uint64_t> key_nulls(static_cast<std::size_t>((n + 63) / 64) + 1, 0), qty_nulls(key_nulls.size(), 0);
+    for (std::int64_t i = 0; i < n; ++i) {
+      k[i] = static_cast<std::int32_t>(rng() % 300000);
+      q[i] = static_cast<std::int32_t>(rng() % 50) + 1;
+      p[i] = static_cast<double>(rng() % 10000000);
+      const bool key_null = (b & 1) != 0 && i % 11 == 0, qty_null = i % 17 == 0;
+      if (key_null) key_nulls[i >> 6] |= 1ull << (63 - (i & 63));
+      if (qty_null) qty_nulls[i >> 6] |= 1ull << (63 - (i & 63));
+      const bool matched = !key_null && k[i] < 200000 && (k[i] & 1) == 0;
+      const std::int64_t qty = qty_null ? -1 : q[i];
+      switch (type) {
+        case JoinType::kInnerJoin: if (matched) want.emplace_back(qty, k[i]); break;
+        case JoinType::kLeftSemiJoin: if (matched) want.emplace_back(qty, static_cast<std::int64_t>(p[i])); break;
+        case JoinType::kLeftAntiJoin: if (!matched) want.emplace_back(qty, static_cast<std::int64_t>(p[i])); break;
+        default: want.emplace_back(qty, matched ? k[i] : kNullMark); break;
+      }
+    }
+    const std::vector<const std::uint64_t *> null_bitmaps = {(b & 1) != 0 ? key_nulls.data() : nullptr, qty_nulls.data(), nullptr};
+    storage.loadBlock(&li, {k.data(), q.data(), p.data()}, n, 0, nullptr, &null_bitmaps);
+  }
+  std::vector<std::int32_t> okeys;
+  for (std::int32_t k = 0; k < 200000; k += 2) okeys.push_back(k);
+  std::shuffle(okeys.begin(), okeys.end(), std::mt19937_64(3));
+  for (std::size_t at = 0; at < okeys.size(); at += 2500) storage.loadBlock(&orders, {okeys.data() + at}, 2500);
+  QueryContext ctx;
+  const QueryContext::ExactKeyRange range{0, 199998};
+  const auto table = ctx.addJoinHashTable(kInt, 100000, 1, exact_stats ? &range : nullptr);
+  const auto dest = ctx.addInsertDestination(&out, &storage);
+  const auto selection = ctx.addScalarGroup(existence ? std::vector<attribute_id>{1, 2} : std::vector<attribute_id>{1, 0});
+  const std::vector<bool> on_build = existence ? std::vector<bool>{false, false} : std::vector<bool>{false, true};
+  BuildHashOperator builder(0, orders, true, {0}, false, 1, table);
+  HashJoinOperator prober(0, orders, li, true, {0}, true, 1, false, out, dest, table, QueryContext::kInvalidPredicateId, selection, &on_build, type);
+  prober.setBlocksPerWorkOrder(blocks_per_order);
+  fetchAndExecuteWorkOrders(&builder, &ctx, &storage);
+  fetchAndExecuteWorkOrders(&prober, &ctx, &storage);
+  std::vector<std::pair<std::int64_t, std::int64_t>> got;
+  const std::vector<block_id> touched = ctx.getInsertDestination(dest)->getTouchedBlocks();
+  *out_blocks = touched.size();
+  for (block_id id : touched) {
+    BlockReference blk = storage.getBlock(id);
+    const std::size_t n = static_cast<std::size_t>(blk->numTuples());
+    if (n == 0) continue;
+    std::vector<std::int32_t> qty(n), key(n);
+    std::vector<double> price(n);
+    std::vector<std::uint64_t> qn((n + 63) / 64), kn((n + 63) / 64);
+    blk->copyAttributeToHost(0, qty.data());
+    blk->copyNullBitmapToHost(0, qn.data());
+    if (existence) {
+      blk->copyAttributeToHost(1, price.data());
+    } else {
+      blk->copyAttributeToHost(1, key.data());
+      blk->copyNullBitmapToHost(1, kn.data());
+    }
+    for (std::size_t i = 0; i < n; ++i) {
+      const bool qty_null = ((qn[i >> 6] >> (63 - (i & 63))) & 1u) != 0, key_null = ((kn[i >> 6] >> (63 - (i & 63))) & 1u) != 0;
+      got.emplace_back(qty_null ? -1 : qty[i], existence ? static_cast<std::int64_t>(price[i]) : (key_null ? kNullMark : key[i]));
+    }
+  }
+  std::sort(got.begin(), got.end());
+  std::sort(want.begin(), want.end());
+  EXPECT_EQ(got.size(), want.size());
+  EXPECT_TRUE(got == want);
+}
+
 void runTypedExpressions() {
   StorageManager storage;
   Lineitem li(&storage, false);
@@ -590,6 +678,18 @@ int main() {
     runSemiAntiResidual(anti, false, 64, &run);
     EXPECT_EQ(one, static_cast<std::size_t>(kBlocks));
     EXPECT_EQ(run, static_cast<std::size_t>((kBlocks + 63) / 64));
+  }
+  // NULL join keys and a nullable projected attribute on the probe side: every join type, both table kinds, both forms —
+  // the run form covers them (one output block per run), it no longer hands these shapes to the block-by-block path
+  for (const HashJoinOperator::JoinType type : {HashJoinOperator::JoinType::kInnerJoin, HashJoinOperator::JoinType::kLeftSemiJoin,
+                                                HashJoinOperator::JoinType::kLeftAntiJoin, HashJoinOperator::JoinType::kLeftOuterJoin}) {
+    for (const bool exact_stats : {true, false}) {
+      std::size_t one = 0, run = 0;
+      runNullableProbeSide(type, exact_stats, 1, &one);
+      runNullableProbeSide(type, exact_stats, 64, &run);
+      EXPECT_EQ(one, static_cast<std::size_t>(kBlocks));
+      EXPECT_EQ(run, static_cast<std::size_t>((kBlocks + 63) / 64));
+    }
   }
   // duplicate build keys: the projecting probe overflows its block and the work order falls back to the pair list
   for (bool exact_stats : {true, false}) {
