@@ -430,18 +430,6 @@ int qsx_join_table_size(qsx_join_table_t *table, int64_t *out_entries, qsx_strea
 int qsx_join_build(qsx_join_table_t *table, const void *keys_dev, int64_t n,
                    int32_t base_tid, const uint64_t *filter_dev, qsx_stream_t stream);
 
-/* qsx_join_build for a build side whose join is known to project `columns_dev` (num_columns <= 4 stripes of `widths` bytes,
- * n values each, row i belonging to keys[i]): a directly addressed table writes its covering array — key value -> the
- * projected build-side values, what qsx_join_probe_project_blocks reads instead of head words and stripes — while it claims
- * the head words, instead of gathering the values back by tuple id at the first probe.  The first projecting probe whose
- * build side is exactly these stripes (one build segment, first tuple id = base_tid, the same columns in the same order)
- * uses the array when no key took a second tuple; any other probe, projection or table kind behaves as after qsx_join_build.
- * Only the first build of a cleared table writes the array (a later build of any kind drops it).  The reference's
- * BuildHashOperator stores tuple references only (storage/HashTable.hpp:1358-1461); which attributes the probe projects is
- * in the same plan (HashJoinOperator's selection, relational_operators/HashJoinOperator.hpp:126-141). */
-int qsx_join_build_project(qsx_join_table_t *table, const void *keys_dev, int64_t n, int32_t base_tid, const uint64_t *filter_dev,
-                           int num_columns, const void *const *columns_dev, const int32_t *widths, qsx_stream_t stream);
-
 /* K3 over a run of build blocks in one launch: num_blocks calls of qsx_join_build (block b with base_tid =
  * block_base_tids[b], its own key stripe and filter) as one.  BuildHashOperator makes one BuildHashWorkOrder per block
  * (relational_operators/BuildHashOperator.cpp:70-130); how many blocks a work order covers is the operator's decision

@@ -94,7 +94,6 @@ _SIGNATURES = {
     "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_key_pack_blocks": (_int, [_int, C.POINTER(_i32), _i64, C.POINTER(_i64), _pp, _vp, C.POINTER(_int), _vp]),
-    "qsx_join_build_project": (_int, [_vp, _vp, _i64, _i32, _vp, _int, _pp, C.POINTER(_i32), _vp]),
     "qsx_join_build_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp]),
     "qsx_join_probe_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_probe_count_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _vp, _vp]),
@@ -634,14 +633,7 @@ class JoinTable:
         _check(_lib.qsx_join_table_size(self._h, C.byref(v), _stream(stream)), "qsx_join_table_size")
         return v.value
 
-    def build(self, keys, base_tid=0, filter_bitmap=None, stream=None, project=None):
-        """project: the build-side columns (row i = keys[i]) the join's probe will project — qsx_join_build_project: a
-        directly addressed table then writes its covering array during the build."""
-        if project:
-            widths = (C.c_int32 * len(project))(*[c.element_size() for c in project])
-            _check(_lib.qsx_join_build_project(self._h, _ptr(keys), keys.numel(), base_tid, _ptr(filter_bitmap), len(project),
-                                               _ptr_array(project), widths, _stream(stream)), "qsx_join_build_project")
-            return
+    def build(self, keys, base_tid=0, filter_bitmap=None, stream=None):
         _check(_lib.qsx_join_build(self._h, _ptr(keys), keys.numel(), base_tid, _ptr(filter_bitmap),
                                    _stream(stream)), "qsx_join_build")
 

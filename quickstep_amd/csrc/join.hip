@@ -773,9 +773,8 @@ struct qsx_join_table {
   std::atomic<int> seal_state{0};
   // Covering array of the projection last asked for (join_dense.hpp ProjectionView::cover; directly addressed tables):
   // cover_sig = what it was built for (column widths, build stripes, segment starts); cover_state 0 = none, 1 = this
-  // projection cannot have one (duplicate keys, entries wider than 16 bytes, an ambiguous entry), 2 = valid, 3 = written by
-  // the build itself (qsx_join_build_project) and not looked at yet: the first probe with that signature reads its flags.
-  // A build or clear drops it.  Probes of other streams wait for cover_event.
+  // projection cannot have one (duplicate keys, entries wider than 16 bytes, an ambiguous entry), 2 = valid.  A build or
+  // clear drops it.  Probes of other streams wait for cover_event.
   std::mutex cover_mutex;
   std::vector<long long> cover_sig;
   void *cover = nullptr;
@@ -833,7 +832,6 @@ struct qsx_join_table {
   }
 };
 static void drop_cover(qsx_join_table *t);
-static bool adaptive_enabled();
 
 // control words behind entries_dev: [0] entries, [1] unused, [2] overflow entries (dense) / duplicate-key flag
 // (hashed), [3] error flag (dense), [4] [5] bounds of the inserted keys (KeyBounds; all ones = none)
@@ -1157,85 +1155,6 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   return QSX_OK;
 }
 
-int qsx_join_build_project(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t base_tid, const uint64_t *filter_dev,
-                           int num_columns, const void *const *columns_dev, const int32_t *widths, qsx_stream_t stream) {
-  QSX_REQUIRE_DEVICE();
-  if (t == nullptr || n < 0 || base_tid < 0 || num_columns < 0 || (num_columns > 0 && (columns_dev == nullptr || widths == nullptr))) {
-    return QSX_ERR_INVALID_ARGUMENT;
-  }
-  // the packing of cover_for / qsx_join_probe_project_blocks: natural alignment, 4 / 8 / 16 bytes in all
-  BuildCover bc;
-  std::vector<long long> signature;
-  int bytes = 0;
-  bool coverable = t->dense && n > 0 && num_columns >= 1 && num_columns <= kMaxCoverColumns && adaptive_enabled();
-  const char *env = getenv("QSX_JOIN_COVER");
-  if (env != nullptr && env[0] == '0') coverable = false;
-  for (int c = 0; c < num_columns && coverable; ++c) {
-    const int w = widths[c];
-    if ((w != 1 && w != 2 && w != 4 && w != 8) || columns_dev[c] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
-    bytes = (bytes + w - 1) / w * w;
-    bc.column[c] = columns_dev[c];
-    bc.width[c] = w;
-    bc.offset[c] = bytes;
-    signature.push_back(w);
-    signature.push_back(bytes);
-    bytes += w;
-  }
-  bc.num_columns = num_columns;
-  bc.entry_bytes = bytes <= 4 ? 4 : (bytes <= 8 ? 8 : (bytes <= 16 ? 16 : 0));
-  // Only the FIRST build of a cleared table can stand for the whole table, and only when no filter keeps rows out whose
-  // keys a later build might bring (the array holds what THIS call inserts; any later build drops it: drop_cover).
-  {
-    std::shared_lock<std::shared_mutex> lock(t->mutex);
-    coverable = coverable && bc.entry_bytes != 0 && t->reserved == 0 && static_cast<size_t>(t->range) * bc.entry_bytes <= (size_t(1) << 30);
-  }
-  if (!coverable) return qsx_join_build(t, keys_dev, n, base_tid, filter_dev, stream);
-  if (keys_dev == nullptr || static_cast<int64_t>(base_tid) + n > INT32_MAX) return QSX_ERR_INVALID_ARGUMENT;
-  int rc = ensure_room(t, n);
-  if (rc != QSX_OK) return rc;
-  t->seal_state.store(0);
-  for (int64_t seen = t->max_tid.load(); seen < base_tid + n - 1 && !t->max_tid.compare_exchange_weak(seen, base_tid + n - 1);) {}
-  hipStream_t s = as_stream(stream);
-  {
-    std::lock_guard<std::mutex> lock(t->cover_mutex);
-    if (t->cover_state == 2 && hipDeviceSynchronize() != hipSuccess) return QSX_ERR_HIP;   // probes in flight may still read the old array
-    t->cover_state = 0;
-    t->cover_sig.clear();
-    const size_t array_bytes = static_cast<size_t>(t->range) * bc.entry_bytes;
-    if (t->cover_bytes < array_bytes) {
-      (void)device_free(t->cover);
-      t->cover = nullptr;
-      t->cover_bytes = 0;
-      if (device_malloc(&t->cover, array_bytes + 16) != hipSuccess) {
-        (void)hipGetLastError();
-        t->cover = nullptr;
-        return qsx_join_build(t, keys_dev, n, base_tid, filter_dev, stream);   // (reserved twice: harmless, an upper bound)
-      }
-      t->cover_bytes = array_bytes;
-    }
-    bc.cover = t->cover;
-    bc.flags = reinterpret_cast<unsigned int *>(static_cast<char *>(t->cover) + array_bytes);
-    QSX_HIP_TRY(hipMemsetAsync(t->cover, 0xFF, array_bytes, s));   // all bits set = no tuple under this key value
-    QSX_HIP_TRY(hipMemsetAsync(bc.flags, 0, sizeof(unsigned int), s));
-    signature.push_back(base_tid);                                   // one build segment: its first tuple id, its stripes
-    for (int c = 0; c < num_columns; ++c) signature.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(columns_dev[c])));
-    t->cover_sig = signature;
-    t->cover_entry_bytes = bc.entry_bytes;
-    t->cover_state = 3;
-  }
-  std::shared_lock<std::shared_mutex> lock(t->mutex);
-  const int dgrid = grid_for((n + 63) >> 6, (kDBlock / kWave) * kBuildR);
-  if (t->key_type == QSX_INT) {
-    hipLaunchKernelGGL((dense_build_kernel<int32_t, false, true>), dim3(dgrid), dim3(kDBlock), 0, s, t->dense_view(),
-                       static_cast<const int32_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev, static_cast<const long long *>(nullptr), bc);
-  } else {
-    hipLaunchKernelGGL((dense_build_kernel<int64_t, false, true>), dim3(dgrid), dim3(kDBlock), 0, s, t->dense_view(),
-                       static_cast<const int64_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev, static_cast<const long long *>(nullptr), bc);
-  }
-  QSX_CHECK_LAUNCH();
-  return QSX_OK;
-}
-
 int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
                           const int32_t *block_base_tids, const uint64_t *const *block_filters, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
@@ -1519,19 +1438,7 @@ static int cover_for(qsx_join_table *t, const ProjectionView &view, int entry_by
   const char *env = getenv("QSX_JOIN_COVER");   // (read per call: tests and tools compare the two forms)
   if (!wanted || entry_bytes <= 0 || (env != nullptr && env[0] == '0') || !adaptive_enabled()) return 0;
   std::lock_guard<std::mutex> lock(t->cover_mutex);
-  if (t->cover_state == 3 && t->cover_sig == signature && t->cover_entry_bytes == entry_bytes) {
-    // written by the build (qsx_join_build_project): valid when no key took a second tuple and no entry is ambiguous.  The
-    // builds have finished (pipeline breaker) — on whichever stream they ran.
-    unsigned int seen = 1;
-    const unsigned int *flags = reinterpret_cast<const unsigned int *>(static_cast<const char *>(t->cover) + static_cast<size_t>(t->range) * entry_bytes);
-    if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&seen, flags, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess && seen == 0) {
-      t->cover_state = 2;
-    } else {
-      (void)hipGetLastError();
-      t->cover_state = 0;   // (built the ordinary way below — or refused there for the same reason)
-    }
-  }
-  if (t->cover_state != 0 && t->cover_state != 3 && t->cover_sig == signature) {
+  if (t->cover_state != 0 && t->cover_sig == signature) {
     *cover = t->cover;
     return t->cover_state == 2 ? t->cover_entry_bytes : 0;
   }
@@ -1824,14 +1731,6 @@ int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const
   if (direct->key_type == QSX_INT) by_entry(int32_t{}); else by_entry(int64_t{});
   QSX_CHECK_LAUNCH();
   return QSX_OK;
-}
-
-// Test hook (not part of include/qsx.h): the state of the table's covering array — 0 none, 1 refused for the last projection,
-// 2 valid, 3 written by the build and not yet looked at (qsx_join_build_project).
-int qsx_debug_join_cover_state(qsx_join_table_t *t) {
-  if (t == nullptr) return QSX_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lock(t->cover_mutex);
-  return t->cover_state;
 }
 
 int qsx_join_probe_count_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,

@@ -79,27 +79,11 @@ __device__ __forceinline__ bool dense_row_in_filter(const uint64_t *filter, int6
 // row count, filter and base tuple id from the run table.
 constexpr int kBuildR = 8;
 constexpr int kBuildTile = kBuildR * kWave;   // rows of a group
-// The covering array written by the BUILD (qsx_join_build_project): the build-side columns a later projecting probe reads,
-// of the row that claimed a key value, packed like cover_build_kernel packs them.  A build that already knows the join's
-// projection saves the pass that gathers the values back out by tuple id (a random read per build row, 0.37 ms for the
-// 18.75 M orders of BASELINE config 4): the row has its values at hand, coalesced, when it claims its head word.
-// flags (behind the array): bit 0 = a key with several tuples (no covering array), bit 1 = an entry came out all-ones.
-constexpr int kMaxCoverColumns = 4;
-__device__ __forceinline__ unsigned long long load_value(const char *src, int width);   // (below, with the projection)
-struct BuildCover {
-  void *cover = nullptr;            // nullptr: a plain build
-  unsigned int *flags = nullptr;
-  int entry_bytes = 0;              // 4 / 8 / 16
-  int num_columns = 0;
-  const void *column[kMaxCoverColumns] = {};
-  int width[kMaxCoverColumns] = {};
-  int offset[kMaxCoverColumns] = {};
-};
-template <typename KeyT, bool kRuns = false, bool kCover = false>
+template <typename KeyT, bool kRuns = false>
 __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, const KeyT *__restrict__ keys, int64_t n,
                                                              int32_t base_tid_arg, const uint64_t *__restrict__ filter,
                                                              unsigned long long *__restrict__ entries,
-                                                             const long long *__restrict__ runs = nullptr, BuildCover bc = BuildCover()) {
+                                                             const long long *__restrict__ runs = nullptr) {
   constexpr int R = kBuildR;
   using Source = ProbeTileSource<KeyT>;
   const int lane = lane_id();
@@ -155,33 +139,6 @@ __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, 
       if (idx[r] >= ~1ull) continue;
       const int64_t i = ((w0 + r) << 6) + lane;
       const uint32_t tid = static_cast<uint32_t>(base_tid + i);
-      if constexpr (kCover) {
-        if (old[r] != 0u) {
-          atomicOr(bc.flags, 1u);            // a second tuple under this key: the covering array cannot stand for the table
-        } else {
-          unsigned long long words[2] = {0ull, 0ull};
-#pragma unroll
-          for (int c = 0; c < kMaxCoverColumns; ++c) {
-            if (c < bc.num_columns) {
-              const unsigned long long v = load_value(static_cast<const char *>(bc.column[c]) + static_cast<size_t>(i) * bc.width[c], bc.width[c]);
-              if (bc.offset[c] < 8) words[0] |= v << (8 * bc.offset[c]); else words[1] |= v << (8 * (bc.offset[c] - 8));
-            }
-          }
-          char *entry = static_cast<char *>(bc.cover) + idx[r] * static_cast<uint64_t>(bc.entry_bytes);
-          bool ones;
-          if (bc.entry_bytes == 4) {
-            ones = static_cast<uint32_t>(words[0]) == ~0u;
-            *reinterpret_cast<uint32_t *>(entry) = static_cast<uint32_t>(words[0]);
-          } else if (bc.entry_bytes == 8) {
-            ones = words[0] == ~0ull;
-            *reinterpret_cast<unsigned long long *>(entry) = words[0];
-          } else {
-            ones = (words[0] & words[1]) == ~0ull;
-            *reinterpret_cast<ulonglong2 *>(entry) = ulonglong2{words[0], words[1]};
-          }
-          if (ones) atomicOr(bc.flags, 2u);
-        }
-      }
       if (old[r] != 0u) {
         // duplicate key: push an overflow entry in front of whatever the head holds now
         const unsigned int e = atomicAdd(t.ov_count, 1u);

@@ -274,16 +274,10 @@ class PartitionedHashJoin:
         self.build_payload = received[2:] if with_tids else received[1:]
         self.shuffled_bytes = sum(c.numel() * c.element_size() for c in received)
 
-    def build_received(self, project=False):
-        """project: the plan's probe will write the output relation itself with these payload columns on the build side
-        (probe_output): the table is told, and a directly addressed one keeps key -> payload from the build on
-        (qsx_join_build_project)."""
+    def build_received(self):
         with phases.phase("build"):
             self.table.clear()
-            if project and self.build_payload and hasattr(self.table, "probe_project_blocks"):
-                self.table.build(self.build_keys, project=list(self.build_payload))
-            else:
-                self.table.build(self.build_keys)
+            self.table.build(self.build_keys)
         return self.build_keys.numel()
 
     def shuffle_probe(self, keys, tid_base, payload=(), with_tids=True):

@@ -70,7 +70,8 @@ class PartitionedJoin:
                 self._side = torch.cuda.Stream()
             j.shuffle_build(inputs["o_orderkey"], tid_base_orders, payload=[inputs["o_payload"]], with_tids=False)
             self._side.wait_stream(main)              # (the inputs are ready; nothing of the build is queued yet)
-            j.build_received(project=True)            # main stream, asynchronous
+            j.table.clear()
+            j.table.build(j.build_keys)               # main stream, asynchronous
             with torch.cuda.stream(self._side):
                 received = j.shuffle_probe(inputs["l_orderkey"], tid_base_lines, payload=[inputs["l_payload"]], with_tids=False)
             for t in received:
@@ -79,7 +80,7 @@ class PartitionedJoin:
             cols = j.probe_output_received()
             return cols, j.shuffled_bytes
         j.shuffle_build(inputs["o_orderkey"], tid_base_orders, payload=[inputs["o_payload"]], with_tids=not self.fused)
-        j.build_received(project=self.fused)
+        j.build_received()
         # a lineitem row has exactly one order: the rows that arrive bound the pairs; how many arrive is only known
         # after the counts exchange, so the capacity is left to probe() (rows received)
         if self.fused:

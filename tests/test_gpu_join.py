@@ -695,68 +695,3 @@ def test_composite_keys_of_a_run_of_blocks_pack_like_block_by_block(capi, dev, t
     want = torch.cat([capi.join_key_pack(b)[0] for b in blocks if b[0].numel()])
     assert exact == capi.join_key_pack([b for b in blocks if b[0].numel()][0])[1]
     assert torch.equal(packed, want)
-
-
-def test_build_that_knows_the_projection_writes_the_covering_array(capi, oracle, dev):
-    """qsx_join_build_project: a directly addressed table writes key -> projected build values while it claims its head
-    words; the first projecting probe over exactly those stripes uses the array as it is (state 3 -> 2, no gather pass),
-    duplicates / a second build / other stripes make it fall back — the output relation is the same every time."""
-    state = capi.lib.qsx_debug_join_cover_state
-    g = torch.Generator(device=dev)
-    g.manual_seed(12)
-    n_build, n_probe = 200_000, 1_000_000
-    keys = torch.randperm(n_build, device=dev, generator=g, dtype=torch.int32) + 1000
-    pay64 = keys.long() * 7 + 3
-    pay32 = (keys * 3 - 1).to(torch.int32)
-    probe = torch.randint(900, n_build + 1200, (n_probe,), device=dev, generator=g, dtype=torch.int32)
-    probe_pay = torch.arange(n_probe, device=dev, dtype=torch.int64)
-
-    def joined(table):
-        outs, cnt = table.probe_project_blocks([probe], [[probe], [probe_pay]], [[pay64], [pay32]], capacity=n_probe)
-        k = int(cnt.item())
-        rows = torch.stack([outs[0][:k].long(), outs[1][:k], outs[2][:k], outs[3][:k].long()], 1)
-        return rows[torch.argsort(rows[:, 1])]            # probe_pay = the probe row: unique per output row here
-
-    inside = (probe >= 1000) & (probe < 1000 + n_build)
-    want = torch.stack([probe[inside].long(), probe_pay[inside], probe[inside].long() * 7 + 3, probe[inside].long() * 3 - 1], 1)
-    t = capi.JoinTable(T.INT, n_build, key_range=(1000, 1000 + n_build - 1))
-    t.build(keys, project=[pay64, pay32])
-    assert state(t._h) == 3                                # written by the build, not looked at yet
-    assert torch.equal(joined(t), want)
-    assert state(t._h) == 2                                # ... and taken as it is by the first probe
-    # the build's own columns in another order are another projection: the array is rebuilt the ordinary way
-    outs, cnt = t.probe_project_blocks([probe], [[probe]], [[pay32]], capacity=n_probe)
-    assert int(cnt.item()) == int(inside.sum().item()) and bool((outs[1][:int(cnt.item())].long() == outs[0][:int(cnt.item())].long() * 3 - 1).all())
-    # a second build drops what the first one wrote
-    t.clear()
-    half = n_build // 2
-    t.build(keys[:half], project=[pay64[:half], pay32[:half]])
-    assert state(t._h) == 3
-    t.build(keys[half:], base_tid=half)
-    assert state(t._h) == 0
-    outs, cnt = t.probe_project_blocks([probe], [[probe], [probe_pay]], [[pay64], [pay32]], capacity=n_probe)
-    assert int(cnt.item()) == want.shape[0]
-    # duplicate build keys: the flag set by the build sends the probe to the general form (every duplicate pair comes out)
-    t.clear()
-    dup_keys = torch.cat([keys, keys[:1000]])
-    dup64, dup32 = torch.cat([pay64, pay64[:1000]]), torch.cat([pay32, pay32[:1000]])
-    t.build(dup_keys, project=[dup64, dup32])
-    outs, cnt = t.probe_project_blocks([probe], [[probe], [probe_pay]], [[dup64], [dup32]], capacity=2 * n_probe)
-    k = int(cnt.item())
-    twice = torch.isin(probe, keys[:1000])
-    assert k == want.shape[0] + int(twice.sum().item())
-    assert bool((outs[2][:k] == outs[0][:k].long() * 7 + 3).all()) and state(t._h) != 2
-    # a build under a filter: only the selected rows are in the table and in the array
-    t.clear()
-    keep = torch.rand(dup_keys.numel(), device=dev, generator=g) < 0.5
-    keep[n_build:] = False
-    t.build(dup_keys, filter_bitmap=bitmap_dev(oracle.bitmap_from_bools(keep.cpu().numpy()), dev), project=[dup64, dup32])
-    outs, cnt = t.probe_project_blocks([probe], [[probe], [probe_pay]], [[dup64], [dup32]], capacity=n_probe)
-    kept = torch.isin(probe, dup_keys[keep])
-    assert int(cnt.item()) == int(kept.sum().item()) and state(t._h) == 2
-    t.close()
-    # a hashed table has no covering array: the call is qsx_join_build
-    h = capi.JoinTable(T.INT, n_build)
-    h.build(keys, project=[pay64, pay32])
-    assert state(h._h) == 0 and h.size() == n_build
-    h.close()
