@@ -492,6 +492,7 @@ def run_headline(ctx, args):
         "phases_ms": phase_ms,
         "checked": checks,
     }
+    line.setdefault("_probe_traffic", None)
     if other_plan_ms is not None:
         line["join_plan"] = {"used": plan, "other_plan_build_plus_probe_ms": other_plan_ms}
     if distributed and plan == "shuffle":
@@ -508,6 +509,7 @@ def run_headline(ctx, args):
                 if tr.get("kernel_source_digest") in (None, kernel_source_digest()):
                     line["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
                     line["roofline"]["traffic_source"] = tr.get("source")
+                    line["_probe_traffic"] = tr.get("probe")
                 else:
                     line["roofline"]["traffic_source"] = "profiles/traffic.json is for other kernel sources: stale, not quoted"
         except Exception:
@@ -519,15 +521,20 @@ def run_headline(ctx, args):
             "rows_per_s": args.probe_rows / probe_s, "ms": phase_ms["probe"],
             "table": "directly addressed (exact min/max statistics of the build key)" if dense else "hashed",
             "roofline": {"kernel": "dense_probe_kernel<int,0> (qsx_join_probe)" if dense else
-                         "probe_kernel<IntUnits,0> (qsx_join_probe)", "bound": "hbm",
+                         "probe_fp_kernel<0> (qsx_join_probe; bucketed table + fingerprint plane)", "bound": "hbm",
                          "achieved": probe_bytes / probe_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": probe_bytes / probe_s / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes": "4*N_probe + 8*N_match (hash-table traffic excluded)"},
         }
+        probe_traffic = line.pop("_probe_traffic", None)
+        if probe_traffic is not None and dense and args.probe_rows == 100_000_000 and args.build_rows == 1_000_000:
+            line["probe"]["roofline"]["traffic"] = probe_traffic.get("hbm_bytes_per_launch")
+            line["probe"]["roofline"]["traffic_detail"] = probe_traffic
         line["probe"]["variants"] = probe_variants(ctx, args, build_keys, probe_keys, out)
         line["build"] = {"rows_per_s": args.build_rows / (phase_ms["build"] / 1e3), "ms": phase_ms["build"]}
         line["aggregate"] = {"rows_per_s": args.agg_rows / agg_s, "ms": phase_ms["aggregate_update"],
                              "finalize_ms": phase_ms["finalize"]}
+    line.pop("_probe_traffic", None)
     return line
 
 
