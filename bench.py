@@ -530,7 +530,8 @@ def run_headline(ctx, args):
         if probe_traffic is not None and dense and args.probe_rows == 100_000_000 and args.build_rows == 1_000_000:
             line["probe"]["roofline"]["traffic"] = probe_traffic.get("hbm_bytes_per_launch")
             line["probe"]["roofline"]["traffic_detail"] = probe_traffic
-        line["probe"]["variants"] = probe_variants(ctx, args, build_keys, probe_keys, out)
+        if not args.no_probe_variants:
+            line["probe"]["variants"] = probe_variants(ctx, args, build_keys, probe_keys, out)
         line["build"] = {"rows_per_s": args.build_rows / (phase_ms["build"] / 1e3), "ms": phase_ms["build"]}
         line["aggregate"] = {"rows_per_s": args.agg_rows / agg_s, "ms": phase_ms["aggregate_update"],
                              "finalize_ms": phase_ms["finalize"]}
@@ -811,6 +812,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU time budget per operator for the cpu_baseline trials")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the result checks after the timed region")
+    ap.add_argument("--no-probe-variants", action="store_true", help="N = 1: skip the other C2 legs (PMC passes: only the headline's own launches)")
     ap.add_argument("--no-operators", action="store_true", help="N = 1: skip the leg that runs the workload through the C++ operator layer")
     ap.add_argument("--operator-workers", type=int, default=8)
     ap.add_argument("--blocks-per-work-order", type=int, default=256)

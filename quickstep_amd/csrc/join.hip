@@ -44,26 +44,24 @@ struct alignas(16) LongEntry {
   uint32_t pad;
 };
 
-// Two layouts behind one view.
-//   LONG keys: open addressing over LongEntry slots, power-of-two capacity at load <= 0.5, linear probing (mask / shift).
-//   INT keys: BUCKETS of 16 slots.  slots[16 b .. 16 b + 15] = one 128-byte line of {tid:32 | key:32} words (all ones =
-//     empty); fp[16 b .. 16 b + 15] = one aligned 16-byte word of 1-byte fingerprints (0 = empty slot).  A key's home bucket
-//     comes from the high bits of its Fibonacci hash by multiply-shift (any bucket count: the table is sized for load 0.8,
-//     not rounded to a power of two), its fingerprint from a second multiplicative hash.  Slots of a bucket fill in order
-//     and never empty again, a key that finds its bucket full goes on to the next one — so a probe reads ONE fingerprint
-//     word per bucket of its sequence (the plane is a tenth of the table and stays in every XCD's L2), compares sixteen
-//     bytes in registers, touches the table only where a fingerprint matches (a miss almost never does: 16 / 255 per
-//     bucket), and stops at the first bucket that still has an empty byte.  1 M keys: 10 MiB of slots + 1.25 MiB of
-//     fingerprints instead of 16 MiB of half-empty units no L2 holds; a probe that misses costs an L2 hit.
+// BUCKETS of 16 slots, for both key widths.
+//   slots[16 b .. 16 b + 15]: INT keys {tid:32 | key:32} words (one bucket = one 128-byte line, all ones = empty); LONG keys
+//     LongEntry {key, tid, pad} (one bucket = two lines, tid all ones = empty);
+//   fp[16 b .. 16 b + 15] = one aligned 16-byte word of 1-byte fingerprints (0 = empty slot).
+// A key's home bucket comes from the high bits of its hash by multiply-shift (any bucket count: the table is sized for
+// load 0.8, not rounded to a power of two), its fingerprint from other bits of the hash.  Slots of a bucket fill in order
+// and never empty again, a key that finds its bucket full goes on to the next one — so a probe reads ONE fingerprint word
+// per bucket of its sequence (the plane is a tenth / a seventeenth of the table and stays in every XCD's L2), compares
+// sixteen bytes in registers, touches the table only where a fingerprint matches (a miss almost never does: 16 / 255 per
+// bucket), and stops at the first bucket that still has an empty byte.  1 M INT keys: 10 MiB of slots + 1.25 MiB of
+// fingerprints instead of 16 MiB of half-empty units no L2 holds; a probe that misses costs an L2 hit.
 constexpr int kBucketSlots = 16;
 struct TableView {
-  void *slots;    // uint64_t[16 * buckets] (INT) or LongEntry[capacity] (LONG)
-  unsigned char *fp;   // INT: fingerprint plane, 16 * buckets bytes
-  uint64_t buckets;    // INT
-  uint64_t mask;  // LONG: capacity - 1 (entries)
-  int shift;      // LONG: 64 - log2(capacity)
+  void *slots;    // uint64_t[16 * buckets] (INT) or LongEntry[16 * buckets] (LONG)
+  unsigned char *fp;   // fingerprint plane, 16 * buckets bytes
+  uint64_t buckets;
   unsigned int *dup_flag;  // set when an insert of an INT key met an occupant with the same key: the build side is not unique
-  __device__ __host__ uint64_t num_slots(bool is_long) const { return is_long ? mask + 1 : buckets * kBucketSlots; }
+  __device__ __host__ uint64_t num_slots() const { return buckets * kBucketSlots; }
 };
 
 __device__ __forceinline__ uint64_t home_bucket(int32_t key, const TableView &t) {
@@ -74,8 +72,13 @@ __device__ __forceinline__ uint32_t fingerprint(int32_t key) {
   const uint32_t f = (static_cast<uint32_t>(key) * 0x85EBCA6Bu) >> 24;
   return f != 0u ? f : 1u;
 }
-__device__ __forceinline__ uint64_t slot_of(int64_t key, const TableView &t) {
-  return (mix64(static_cast<uint64_t>(key)) * 0x9E3779B97F4A7C15ull) >> t.shift;
+__device__ __forceinline__ uint64_t home_bucket(int64_t key, const TableView &t) {
+  const uint64_t h = mix64(static_cast<uint64_t>(key)) * 0x9E3779B97F4A7C15ull;
+  return ((h >> 32) * t.buckets) >> 32;
+}
+__device__ __forceinline__ uint32_t fingerprint(int64_t key) {
+  const uint32_t f = static_cast<uint32_t>(mix64(static_cast<uint64_t>(key)) * 0x9E3779B97F4A7C15ull) & 0xFFu;   // (low bits: the bucket took the high ones)
+  return f != 0u ? f : 1u;
 }
 // 0x80 in every byte of x that is zero (exact: nothing carries from one byte into the next)
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); }
@@ -128,16 +131,24 @@ __device__ __forceinline__ void insert_entry(const TableView &t, int32_t key, ui
 
 __device__ __forceinline__ void insert_entry(const TableView &t, int64_t key, uint32_t tid) {
   LongEntry *slots = static_cast<LongEntry *>(t.slots);
-  uint64_t s = slot_of(key, t);
+  const uint32_t f = fingerprint(key);
+  uint64_t b = home_bucket(key, t);
   for (;;) {
-    // Claim the slot through its tid word; the key is published with a plain
-    // store and only read by probe kernels launched after the build
-    // (BuildHash -> HashJoin is a pipeline breaker, ExecutionGenerator.cpp:1110-1124).
-    if (atomicCAS(&slots[s].tid, kEmptyTid, tid) == kEmptyTid) {
-      slots[s].key = key;
-      return;
+    // the fingerprints as a hint for where the bucket's first empty slot is (see the INT insert); a slot is claimed through
+    // its tid word, the key is published with a plain store and only read by probe kernels launched after the build
+    // (BuildHash -> HashJoin is a pipeline breaker, ExecutionGenerator.cpp:1110-1124).  Keys are not compared here: probes
+    // of a LONG table always walk on (no "unique" shortcut).
+    const uint4 w = *reinterpret_cast<const uint4 *>(t.fp + b * kBucketSlots);
+    const uint32_t empty = bucket_masks(w, f) >> 16;
+    for (int c = empty != 0u ? __ffs(empty) - 1 : kBucketSlots; c < kBucketSlots; ++c) {
+      LongEntry *e = &slots[b * kBucketSlots + c];
+      if (atomicCAS(&e->tid, kEmptyTid, tid) == kEmptyTid) {
+        e->key = key;
+        t.fp[b * kBucketSlots + c] = static_cast<unsigned char>(f);
+        return;
+      }
     }
-    s = (s + 1) & t.mask;
+    b = b + 1 == t.buckets ? 0 : b + 1;
   }
 }
 
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(kJBlock) void build_runs_kernel(TableView t, const 
 
 // Re-insert every entry of an old table into a bigger one (resize).
 __global__ __launch_bounds__(kJBlock) void rehash_kernel(int is_long, TableView src, TableView dst) {
-  const int64_t cap = static_cast<int64_t>(src.num_slots(is_long != 0));
+  const int64_t cap = static_cast<int64_t>(src.num_slots());
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < cap;
        i += static_cast<int64_t>(gridDim.x) * kJBlock) {
     if (is_long) {
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(kJBlock) void dense_pack_kernel(const uint32_t *__r
 
 // Every entry of a hashed table into a directly addressed one (seal_table): what dense_build_kernel does per build row.
 __global__ __launch_bounds__(kJBlock) void dense_build_from_slots_kernel(int is_long, TableView src, DenseTableView d) {
-  const int64_t cap = static_cast<int64_t>(src.num_slots(is_long != 0));
+  const int64_t cap = static_cast<int64_t>(src.num_slots());
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < cap;
        i += static_cast<int64_t>(gridDim.x) * kJBlock) {
     int64_t key;
@@ -288,32 +299,6 @@ __global__ __launch_bounds__(kJBlock) void dense_build_from_slots_kernel(int is_
 constexpr int kRowsPerThread = 16;
 constexpr int kProbeTile = kJBlock * kRowsPerThread;  // 4096 rows per workgroup tile
 constexpr int kStage = kProbeTile;                    // staged pairs per tile (FK joins never exceed it)
-
-// What one 16-byte probe unit holds for a given key.
-struct UnitHits {
-  bool m0, m1;   // entry 0 / 1 matches
-  bool end;      // an empty slot was seen: the probe sequence stops here
-  int32_t t0, t1;
-};
-
-struct LongUnits {
-  using Key = int64_t;
-  using Raw = LongEntry;
-  const LongEntry *units;
-  uint64_t unit_mask;
-  __device__ LongUnits(const TableView &t) : units(static_cast<const LongEntry *>(t.slots)), unit_mask(t.mask) {}
-  __device__ __forceinline__ uint64_t first_unit(Key k, const TableView &t) const { return slot_of(k, t); }
-  __device__ __forceinline__ Raw load(uint64_t u) const { return units[u]; }
-  __device__ __forceinline__ UnitHits inspect(const Raw &u, Key k) const {
-    UnitHits h;
-    h.end = u.tid == kEmptyTid;
-    h.m0 = !h.end && u.key == k;
-    h.m1 = false;
-    h.t0 = static_cast<int32_t>(u.tid);
-    h.t1 = 0;
-    return h;
-  }
-};
 
 struct PairSink {
   int32_t *stage_probe;  // LDS
@@ -359,173 +344,47 @@ __device__ __forceinline__ void emit_match(const PairSink &sink, bool match, int
   }
 }
 
-// kRuns: the probe side is a run of blocks, as in dense_probe_kernel (join_dense.hpp).
-template <typename Units, int MODE, bool kRuns = false>
-__global__ __launch_bounds__(kJBlock) void probe_kernel(
-    TableView t, const typename Units::Key *__restrict__ keys, int64_t n, int32_t probe_base_tid,
-    const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe,
-    int32_t *__restrict__ out_build, int64_t capacity, unsigned long long *__restrict__ out_count,
-    uint64_t *__restrict__ out_bitmap, int anti, const long long *__restrict__ runs = nullptr) {
-  using Key = typename Units::Key;
-  using Raw = typename Units::Raw;
-  using Source = ProbeTileSource<Key>;
-  __shared__ int32_t s_probe[MODE == 0 ? kStage : 1];
-  __shared__ int32_t s_build[MODE == 0 ? kStage : 1];
-  __shared__ int s_fill;
-  __shared__ unsigned long long s_base;
-  const Units table(t);
-  const bool unique = false;   // (LONG keys: the build claims slots through the tid word and never compares keys)
-  PairSink sink{s_probe, s_build, &s_fill, out_probe, out_build,
-                static_cast<unsigned long long>(capacity), out_count};
-  const int64_t num_tiles = kRuns ? runs[2] : (n + kProbeTile - 1) / kProbeTile;
-  auto source_of = [&](int64_t tile) {
-    return probe_tile_source<Key, kProbeTile, kRuns>(runs, tile, keys, n, probe_base_tid, filter, out_bitmap);
-  };
-  unsigned long long local_count = 0;
-
-  // Row r of a thread in a tile: tile_base + r * 256 + tid.  A wave therefore owns 64 consecutive rows per r:
-  // coalesced key loads, and an existence ballot is exactly one TupleIdSequence word.  The keys and the 16 filter words
-  // (one load, lane r holds word r) of the NEXT tile are requested before the table units of the current one are read.
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  Key key[kRowsPerThread], next_key[kRowsPerThread];
-  uint64_t filter_words = ~0ull, next_filter_words = ~0ull;
-  auto request = [&](const Source &src, Key (&k)[kRowsPerThread], uint64_t &words) {
-#pragma unroll
-    for (int r = 0; r < kRowsPerThread; ++r) {
-      const int64_t row = src.base + r * kJBlock + threadIdx.x;
-      k[r] = src.keys[row < src.n ? row : src.n - 1];   // clamped, not guarded: no branch around the read
-    }
-    words = ~0ull;
-    if (src.filter != nullptr && lane < kRowsPerThread) {
-      const int64_t w = (src.base >> 6) + lane * (kJBlock / kWave) + wave;
-      if (w < ((src.n + 63) >> 6)) words = src.filter[w];
-    }
-  };
-  Source cur = Source(), next = Source();
-  if (static_cast<int64_t>(blockIdx.x) < num_tiles) {
-    cur = source_of(blockIdx.x);
-    request(cur, key, filter_words);
-  }
-
-  for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-    if (MODE == 0) {
-      if (threadIdx.x == 0) s_fill = 0;
-      __syncthreads();
-    }
-    if (tile + gridDim.x < num_tiles) {
-      next = source_of(tile + gridDim.x);
-      request(next, next_key, next_filter_words);
-    }
-    const int64_t tile_base = cur.base;
-    const int64_t n_rows = cur.n;
-    const int32_t base_tid = cur.base_tid;
-    uint64_t *const tile_bitmap = cur.out_bitmap;
-    cur = next;
-    bool live[kRowsPerThread];
-    uint64_t exists_word = 0;
-#pragma unroll
-    for (int r = 0; r < kRowsPerThread; ++r) {
-      const int64_t row = tile_base + r * kJBlock + threadIdx.x;
-      const uint64_t filter_word = __shfl(filter_words, r, kWave);   // before the branch: every lane takes part
-      live[r] = row < n_rows && msb_bit(filter_word, lane);
-    }
-    // First unit of every row: kRowsPerThread independent 16-byte loads in flight.
-    uint64_t unit[kRowsPerThread];
-    Raw first[kRowsPerThread];
-#pragma unroll
-    for (int r = 0; r < kRowsPerThread; ++r) {
-      unit[r] = table.first_unit(key[r], t);
-      first[r] = table.load(live[r] ? unit[r] : 0);
-    }
-#pragma unroll
-    for (int r = 0; r < kRowsPerThread; ++r) {
-      const int64_t row = tile_base + r * kJBlock + threadIdx.x;
-      const int32_t probe_tid = static_cast<int32_t>(base_tid + row);
-      bool walking = live[r];
-      Raw u = first[r];
-      uint64_t cur = unit[r];
-      bool found = false;
-      // Every lane of the wave stays in the loop until all are done, so that
-      // emit_match can use wave-wide ballots.
-      while (__any(walking)) {
-        const UnitHits h = table.inspect(u, key[r]);
-        const bool m0 = walking && h.m0;
-        const bool m1 = walking && h.m1;
-        if (MODE == 0) {
-          emit_match(sink, m0, probe_tid, h.t0);
-          emit_match(sink, m1, probe_tid, h.t1);
-        } else if (MODE == 1) {
-          local_count += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
-        } else {
-          found = found || m0 || m1;
-          if (found) walking = false;  // existence: the first hit is enough
-        }
-        if (h.end || (unique && (m0 || m1))) walking = false;
-        if (walking) {
-          cur = (cur + 1) & table.unit_mask;
-          u = table.load(cur);
-        }
-      }
-      if (MODE == 2) {
-        const bool bit = live[r] && (found != (anti != 0));
-        const uint64_t word = msb_first(__ballot(bit));
-        if (lane == r) exists_word = word;
-        if (lane == 0) local_count += __popcll(word);
-      }
-    }
-    if (MODE == 2) {   // lane r holds the word of step r: one store instruction per tile and wave
-      const int64_t w = (tile_base >> 6) + lane * (kJBlock / kWave) + wave;
-      if (lane < kRowsPerThread && w < ((n_rows + 63) >> 6)) tile_bitmap[w] = exists_word;
-    }
-#pragma unroll
-    for (int r = 0; r < kRowsPerThread; ++r) key[r] = next_key[r];
-    filter_words = next_filter_words;
-    if (MODE == 0) {
-      __syncthreads();
-      const int produced = s_fill;
-      const int staged = produced < kStage ? produced : kStage;
-      if (threadIdx.x == 0) s_base = atomicAdd(out_count, static_cast<unsigned long long>(staged));
-      __syncthreads();
-      const unsigned long long base = s_base;
-      for (int i = threadIdx.x; i < staged; i += kJBlock) {
-        const unsigned long long o = base + i;
-        if (o < sink.capacity) {
-          out_probe[o] = s_probe[i];
-          out_build[o] = s_build[i];
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (MODE != 0) {
-    local_count = wave_reduce_add(local_count);
-    if (lane_id() == 0 && local_count != 0 && out_count != nullptr) atomicAdd(out_count, local_count);
-  }
-}
-
-// K4 over the bucketed INT table (TableView): same tiles, sources, modes and pair staging as probe_kernel.
+// K4 over the bucketed table (TableView).  MODE 0: emit pairs, 1: count only, 2: existence bitmap.  kRuns: the probe side is a
+// run of blocks, as in dense_probe_kernel (join_dense.hpp).
+// One slot of either key width as (key, tuple id).
+template <typename KeyT>
+struct SlotOf;
+template <>
+struct SlotOf<int32_t> {
+  using Raw = uint64_t;
+  __device__ static __forceinline__ bool holds(const Raw &e, int32_t key) { return static_cast<uint32_t>(e) == static_cast<uint32_t>(key); }
+  __device__ static __forceinline__ int32_t tid(const Raw &e) { return static_cast<int32_t>(e >> 32); }
+};
+template <>
+struct SlotOf<int64_t> {
+  using Raw = LongEntry;
+  __device__ static __forceinline__ bool holds(const Raw &e, int64_t key) { return e.key == key; }
+  __device__ static __forceinline__ int32_t tid(const Raw &e) { return static_cast<int32_t>(e.tid); }
+};
 //   phase 1  the fingerprint word of every row's home bucket: 16 independent 16-byte reads of the L2-resident plane;
 //   phase 2  the slot under the first matching fingerprint: 16 independent 8-byte reads of the table — rows without a
 //            matching fingerprint (nearly every probe that misses) read nothing;
 //   phase 3  key compare + emit; whatever is left — another slot under the same fingerprint (a false positive, or duplicate
 //            build keys), a home bucket without an empty byte (go on in the next bucket) — is walked by a wave-uniform loop.
-template <int MODE, bool kRuns = false>
+template <typename KeyT, int MODE, bool kRuns = false>
 __global__ __launch_bounds__(kJBlock) void probe_fp_kernel(
-    TableView t, const int32_t *__restrict__ keys, int64_t n, int32_t probe_base_tid,
+    TableView t, const KeyT *__restrict__ keys, int64_t n, int32_t probe_base_tid,
     const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe,
     int32_t *__restrict__ out_build, int64_t capacity, unsigned long long *__restrict__ out_count,
     uint64_t *__restrict__ out_bitmap, int anti, const long long *__restrict__ runs = nullptr) {
-  using Key = int32_t;
+  using Key = KeyT;
+  using Slot = SlotOf<KeyT>;
+  using Raw = typename Slot::Raw;
   using Source = ProbeTileSource<Key>;
   __shared__ int32_t s_probe[MODE == 0 ? kStage : 1];
   __shared__ int32_t s_build[MODE == 0 ? kStage : 1];
   __shared__ int s_fill;
   __shared__ unsigned long long s_base;
-  const uint64_t *__restrict__ slots = static_cast<const uint64_t *>(t.slots);
+  const Raw *__restrict__ slots = static_cast<const Raw *>(t.slots);
   const uint4 *__restrict__ fp_words = reinterpret_cast<const uint4 *>(t.fp);
-  // no build key occurs twice (the build looked at every occupant that could be this key): a probe ends at its first match
-  const bool unique = *t.dup_flag == 0u;
+  // INT keys: no build key occurs twice (the build looked at every occupant that could be this key) -> a probe ends at its
+  // first match.  LONG keys: the build never compares keys, probes always walk on.
+  const bool unique = sizeof(Key) == 4 && *t.dup_flag == 0u;
   PairSink sink{s_probe, s_build, &s_fill, out_probe, out_build, static_cast<unsigned long long>(capacity), out_count};
   const int64_t num_tiles = kRuns ? runs[2] : (n + kProbeTile - 1) / kProbeTile;
   auto source_of = [&](int64_t tile) {
@@ -588,7 +447,7 @@ __global__ __launch_bounds__(kJBlock) void probe_fp_kernel(
       for (int r = 0; r < kRowsPerThread; ++r) masks[r] = live[r] ? bucket_masks(w[r], fingerprint(key[r])) : 0x10000u;   // dead: nothing, "empty seen"
     }
     // phase 2: the slot under the first matching fingerprint
-    uint64_t first[kRowsPerThread];
+    Raw first[kRowsPerThread];
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
       const uint32_t same = masks[r] & 0xFFFFu;
@@ -600,9 +459,9 @@ __global__ __launch_bounds__(kJBlock) void probe_fp_kernel(
       const int64_t row = tile_base + r * kJBlock + threadIdx.x;
       const int32_t probe_tid = static_cast<int32_t>(base_tid + row);
       uint32_t same = masks[r] & 0xFFFFu, empty = masks[r] >> 16;
-      bool hit = same != 0u && static_cast<uint32_t>(first[r]) == static_cast<uint32_t>(key[r]);
+      bool hit = same != 0u && Slot::holds(first[r], key[r]);
       bool found = hit;
-      if (MODE == 0) emit_match(sink, hit, probe_tid, static_cast<int32_t>(first[r] >> 32));
+      if (MODE == 0) emit_match(sink, hit, probe_tid, Slot::tid(first[r]));
       if (MODE == 1) local_count += hit ? 1u : 0u;
       same &= same - 1u;
       // done: one match of a duplicate-free table (or any match of an existence probe), or nothing else under this
@@ -618,11 +477,11 @@ __global__ __launch_bounds__(kJBlock) void probe_fp_kernel(
           empty = m >> 16;
         }
         const bool have = walking && same != 0u;
-        const uint64_t e = slots[have ? static_cast<uint64_t>(b) * kBucketSlots + (__ffs(same) - 1) : 0ull];
+        const Raw e = slots[have ? static_cast<uint64_t>(b) * kBucketSlots + (__ffs(same) - 1) : 0ull];
         if (have) same &= same - 1u;
-        hit = have && static_cast<uint32_t>(e) == static_cast<uint32_t>(key[r]);
+        hit = have && Slot::holds(e, key[r]);
         found = found || hit;
-        if (MODE == 0) emit_match(sink, hit, probe_tid, static_cast<int32_t>(e >> 32));
+        if (MODE == 0) emit_match(sink, hit, probe_tid, Slot::tid(e));
         if (MODE == 1) local_count += hit ? 1u : 0u;
         if (hit && (unique || MODE == 2)) walking = false;
         if (same == 0u && empty != 0u) walking = false;
@@ -756,7 +615,7 @@ using namespace qsx;
 // ---------------------------------------------------------------------------
 struct qsx_join_table {
   int key_type = QSX_INT;
-  uint64_t capacity = 0;  // slots: LONG a power of two (load <= 0.5); INT 16 x buckets (load <= 0.8), fingerprint plane behind the slots
+  uint64_t capacity = 0;  // slots: 16 x buckets (load <= 0.8), the fingerprint plane behind them
   void *slots = nullptr;
   unsigned long long *entries_dev = nullptr;
   int64_t reserved = 0;   // host-side upper bound of entries (rows handed to build so far)
@@ -811,23 +670,16 @@ struct qsx_join_table {
   }
 
   size_t entry_bytes() const { return key_type == QSX_INT ? 8 : 16; }
-  // bytes of the table: slots, then (INT) one fingerprint byte per slot
-  size_t table_bytes() const { return capacity * entry_bytes() + (key_type == QSX_INT ? capacity : 0); }
+  // bytes of the table: slots, then one fingerprint byte per slot
+  size_t table_bytes() const { return capacity * entry_bytes() + capacity; }
   // rows the table takes at its load limit
-  uint64_t room() const { return key_type == QSX_INT ? capacity / 5 * 4 : capacity / 2; }
+  uint64_t room() const { return capacity / 5 * 4; }
   TableView view() const {
     TableView v{};
     v.slots = slots;
     v.dup_flag = reinterpret_cast<unsigned int *>(entries_dev + 2);
-    if (key_type == QSX_INT) {
-      v.fp = static_cast<unsigned char *>(slots) + capacity * 8;
-      v.buckets = capacity / kBucketSlots;
-      return v;
-    }
-    v.mask = capacity - 1;
-    int log2 = 0;
-    while ((1ull << log2) < capacity) ++log2;
-    v.shift = 64 - log2;
+    v.fp = static_cast<unsigned char *>(slots) + capacity * entry_bytes();
+    v.buckets = capacity / kBucketSlots;
     return v;
   }
 };
@@ -843,21 +695,21 @@ static int reset_control_words(unsigned long long *control, hipStream_t stream) 
 }
 
 static uint64_t capacity_for(int key_type, int64_t entries) {
+  (void)key_type;
   const uint64_t rows = static_cast<uint64_t>(entries < 512 ? 512 : entries);
-  // INT: buckets of 16 slots at load 0.8 (12.8 rows per bucket), any bucket count
-  if (key_type == QSX_INT) return (rows * 5 + 63) / 64 * kBucketSlots + kBucketSlots;
-  // LONG: kHashTableLoadFactor = 2 slots per entry (storage/StorageConstants.hpp:104), a power of two for mask addressing
-  return next_pow2(rows * 2);
+  // buckets of 16 slots at load 0.8 (12.8 rows per bucket), any bucket count — the reference sizes for load 0.5
+  // (kHashTableLoadFactor = 2 slots per entry, storage/StorageConstants.hpp:104); a fingerprint probe does not need the room
+  return (rows * 5 + 63) / 64 * kBucketSlots + kBucketSlots;
 }
 
 static int fill_empty(const qsx_join_table *t, void *slots, uint64_t capacity, hipStream_t stream) {
   QSX_HIP_TRY(hipMemsetAsync(slots, 0xFF, capacity * t->entry_bytes(), stream));
-  if (t->key_type == QSX_INT) QSX_HIP_TRY(hipMemsetAsync(static_cast<char *>(slots) + capacity * 8, 0, capacity, stream));
+  QSX_HIP_TRY(hipMemsetAsync(static_cast<char *>(slots) + capacity * t->entry_bytes(), 0, capacity, stream));
   return QSX_OK;
 }
 
 static int allocate_slots(qsx_join_table *t, uint64_t capacity, void **out) {
-  QSX_HIP_TRY(device_malloc(out, capacity * t->entry_bytes() + (t->key_type == QSX_INT ? capacity : 0)));
+  QSX_HIP_TRY(device_malloc(out, capacity * t->entry_bytes() + capacity));
   const int rc = fill_empty(t, *out, capacity, nullptr);
   if (rc != QSX_OK) return rc;
   QSX_HIP_TRY(hipStreamSynchronize(nullptr));
@@ -914,7 +766,7 @@ static int ensure_room(qsx_join_table *t, int64_t additional) {
   t->slots = bigger;
   t->capacity = new_capacity;
   TableView dst = t->view();
-  hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(static_cast<int64_t>(src.num_slots(t->key_type == QSX_LONG)), kJBlock)), dim3(kJBlock), 0, nullptr,
+  hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(static_cast<int64_t>(src.num_slots()), kJBlock)), dim3(kJBlock), 0, nullptr,
                      t->key_type == QSX_LONG ? 1 : 0, src, dst);
   QSX_CHECK_LAUNCH();
   QSX_HIP_TRY(hipDeviceSynchronize());
@@ -1327,7 +1179,7 @@ static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream) {
   shadow->reserved = static_cast<int64_t>(entries);
   shadow->max_tid.store(t->max_tid.load());
   const TableView src = t->view();
-  hipLaunchKernelGGL(dense_build_from_slots_kernel, dim3(grid_for(static_cast<int64_t>(src.num_slots(t->key_type == QSX_LONG)), kJBlock * 4)), dim3(kJBlock), 0, stream,
+  hipLaunchKernelGGL(dense_build_from_slots_kernel, dim3(grid_for(static_cast<int64_t>(src.num_slots()), kJBlock * 4)), dim3(kJBlock), 0, stream,
                      t->key_type == QSX_LONG ? 1 : 0, src, shadow->dense_view());
   int error = 0;
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess ||
@@ -1415,11 +1267,11 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
   const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
   unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count);
   if (t->key_type == QSX_INT) {
-    hipLaunchKernelGGL((probe_fp_kernel<MODE, kRuns>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
+    hipLaunchKernelGGL((probe_fp_kernel<int32_t, MODE, kRuns>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
                        static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,
                        out_build, capacity, count, out_bitmap, anti, runs_dev);
   } else {
-    hipLaunchKernelGGL((probe_kernel<LongUnits, MODE, kRuns>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
+    hipLaunchKernelGGL((probe_fp_kernel<int64_t, MODE, kRuns>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
                        static_cast<const int64_t *>(keys), n, probe_base_tid, filter, out_probe,
                        out_build, capacity, count, out_bitmap, anti, runs_dev);
   }

@@ -205,47 +205,68 @@ def test_dense_table_over_one_hash_partition(capi, oracle, dev, key_type, dtype)
         table.size()
 
 
-def _int_table_geometry(est_entries):
-    """quickstep_amd/csrc/join.hip capacity_for / home_bucket / fingerprint for INT keys, restated for the test."""
+def _table_geometry(est_entries, key_type):
+    """quickstep_amd/csrc/join.hip capacity_for / home_bucket / fingerprint, restated for the test (INT and LONG keys)."""
     rows = max(512, est_entries)
     buckets = (rows * 5 + 63) // 64 + 1
+    M64 = (1 << 64) - 1
+    if key_type == T.INT:
+        def home(keys):
+            h = (keys.astype(np.uint64) & 0xFFFFFFFF) * 0x9E3779B9 & 0xFFFFFFFF
+            return (h * buckets) >> 32
+        def fingerprint(keys):
+            f = ((keys.astype(np.uint64) & 0xFFFFFFFF) * 0x85EBCA6B & 0xFFFFFFFF) >> 24
+            return np.where(f == 0, 1, f)
+        return buckets, home, fingerprint
+    def hashed(keys):                                   # mix64(k) * 0x9E3779B97F4A7C15 (Python integers: exact modulo 2^64)
+        out = []
+        for k in keys.tolist():
+            k &= M64
+            k ^= k >> 32
+            k = k * 0x9E3779B97F4A7C15 & M64
+            k ^= k >> 29
+            out.append(k * 0x9E3779B97F4A7C15 & M64)
+        return out
     def home(keys):
-        h = (keys.astype(np.uint64) & 0xFFFFFFFF) * 0x9E3779B9 & 0xFFFFFFFF
-        return (h * buckets) >> 32
+        return np.array([((h >> 32) * buckets) >> 32 for h in hashed(keys)], dtype=np.int64)
     def fingerprint(keys):
-        f = ((keys.astype(np.uint64) & 0xFFFFFFFF) * 0x85EBCA6B & 0xFFFFFFFF) >> 24
-        return np.where(f == 0, 1, f)
+        return np.array([(h & 0xFF) or 1 for h in hashed(keys)], dtype=np.int64)
     return buckets, home, fingerprint
 
 
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
 @pytest.mark.parametrize("unique", [True, False])
-def test_int_table_crowded_buckets_and_shared_fingerprints(capi, oracle, dev, unique, monkeypatch):
-    """The bucketed INT table against its worst inputs (QSX_JOIN_ADAPTIVE=0: no directly addressed shadow): hundreds of
+def test_bucketed_table_crowded_buckets_and_shared_fingerprints(capi, oracle, dev, unique, key_type, dtype, monkeypatch):
+    """The bucketed table against its worst inputs (QSX_JOIN_ADAPTIVE=0: no directly addressed shadow): hundreds of
     distinct keys whose home is ONE bucket (the sequence runs through a dozen full buckets, wrapping at the table's end),
     keys that share home bucket AND fingerprint (every fingerprint hit but one is a false positive), probes for keys that
     are absent but share bucket and fingerprint with present ones, and — unique=False — heavy duplicates of such keys."""
     monkeypatch.setenv("QSX_JOIN_ADAPTIVE", "0")
     est = 4_000
-    buckets, home, fingerprint = _int_table_geometry(est)
-    pool = np.arange(-3_000_000, 3_000_000, dtype=np.int64)
+    buckets, home, fingerprint = _table_geometry(est, key_type)
+    pool = np.arange(-3_000_000, 3_000_000, dtype=np.int64) if key_type == T.INT else np.arange(-600_000, 600_000, dtype=np.int64) * 1_000_003
     h, f = home(pool), fingerprint(pool)
     last = pool[h == buckets - 1][:300]                                  # one bucket, the LAST one: the walk wraps around
     twins = pool[(h == 7) & (f == 99)]                                   # same bucket, same fingerprint
-    assert last.size == 300 and twins.size >= 40
+    if twins.size < 40:                                                  # (the smaller LONG pool: any well-filled pair)
+        pairs, counts = np.unique(np.stack([h, f], 1), axis=0, return_counts=True)
+        hb, fb = pairs[np.argmax(counts)]
+        twins = pool[(h == hb) & (f == fb)]
+    assert last.size == 300 and twins.size >= 12
     rng = np.random.default_rng(5)
     spread = rng.choice(pool, size=2_500, replace=False)
-    build = np.unique(np.concatenate([last[:200], twins[:20], spread])).astype(np.int32)
+    build = np.unique(np.concatenate([last[:200], twins[:twins.size // 2], spread])).astype(dtype)
     if not unique:
-        build = np.concatenate([build, np.repeat(twins[:3].astype(np.int32), 40), np.repeat(last[:2].astype(np.int32), 25)])
+        build = np.concatenate([build, np.repeat(twins[:3].astype(dtype), 40), np.repeat(last[:2].astype(dtype), 25)])
     rng.shuffle(build)
     assert build.size <= est
-    probe = np.concatenate([last, twins[:40], rng.choice(pool, size=50_000), build[:500]]).astype(np.int32)   # present and absent look-alikes
+    probe = np.concatenate([last, twins[:40], rng.choice(pool, size=50_000), build[:500]]).astype(dtype)   # present and absent look-alikes
     rng.shuffle(probe)
-    table = capi.JoinTable(T.INT, est)
+    table = capi.JoinTable(key_type, est)
     table.build(to_dev(build, dev))
     assert table.size() == build.size
     dp = to_dev(probe, dev)
-    _, rp, rd = oracle_join(oracle, T.INT, [build], probe)
+    _, rp, rd = oracle_join(oracle, key_type, [build], probe)
     total = int(table.probe_count(dp).item())
     assert total == rp.size
     p, b, cnt = table.probe(dp, capacity=total)
@@ -254,9 +275,9 @@ def test_int_table_crowded_buckets_and_shared_fingerprints(capi, oracle, dev, un
     exists, n_exist = table.probe_exists(dp)
     assert int(n_exist.item()) == np.isin(probe, build).sum()
     # the table grows (rehash into more buckets) and keeps every entry
-    more = rng.choice(pool, size=30_000, replace=False).astype(np.int32)
+    more = rng.choice(pool, size=30_000, replace=False).astype(dtype)
     table.build(to_dev(more, dev), base_tid=build.size)
-    _, rp2, rd2 = oracle_join(oracle, T.INT, [build, more], probe)
+    _, rp2, rd2 = oracle_join(oracle, key_type, [build, more], probe)
     total2 = int(table.probe_count(dp).item())
     assert total2 == rp2.size
     p, b, cnt = table.probe(dp, capacity=total2)
