@@ -159,13 +159,14 @@ bool HashInnerJoinWorkOrder::executeRun() {
   if (outer && residual_predicate_ != nullptr) return false;   // (HashOuterJoinWorkOrder takes none either)
   // semi / anti with a residual predicate: the pairs of the run, the residual on them, then the probe tuples that kept (semi)
   // or never had (anti) a pair — HashSemiJoinWorkOrder / HashAntiJoinWorkOrder::executeWithResidualPredicate (:680-793, :880-1000)
-  const bool existence_by_pairs = existence && residual_predicate_ != nullptr;
   int key_bits = 0;
   for (attribute_id a : join_key_attributes_) {   // (a CHAR(n <= 8) component travels as a LONG)
     key_bits += probe_relation_.getAttributeType(a).id == kChar ? 64 : probe_relation_.getAttributeType(a).width * 8;
   }
   const bool hashed_key = join_key_attributes_.size() > 1 && key_bits > 64;   // the fold is a hash: pairs need their components compared
-  if (hashed_key && existence) return false;
+  // ... and so does a semi / anti join over a hashed composite key: an existence probe would count tuples whose key merely
+  // shares the fold with a build key (compositeKeyCollisionCheck, SeparateChainingHashTable.hpp:1046)
+  const bool existence_by_pairs = existence && (residual_predicate_ != nullptr || hashed_key);
   std::vector<BlockReference> blocks;
   std::vector<std::int64_t> rows, first_rows;
   std::int64_t total_rows = 0;
@@ -213,9 +214,6 @@ bool HashInnerJoinWorkOrder::executeRun() {
     ~OwnedStorage() { qsx_device_free(ptr); }
   } lip_storage;
   std::vector<const std::uint64_t *> lip_bitmaps;
-  // (anti join with a residual under a LIP filter: the tuples the filter rejects must not come back through the complement;
-  // that combination stays block by block)
-  if (existence_by_pairs && join_type_ == JoinType::kLeftAntiJoin && lip_filter_adaptive_prober_ != nullptr) return false;
   if (lip_filter_adaptive_prober_ != nullptr && !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps)) return false;
   // `about` = the tuples this work order is about (the LIP filter's survivors, or all); `lookup` = those of them that are
   // looked up: a probe tuple with a NULL key component matches nothing (check_for_null_keys, HashTable.hpp:2158-2160,
@@ -452,7 +450,13 @@ bool HashInnerJoinWorkOrder::executeRun() {
     for (std::size_t b = 0; b < blocks.size(); ++b) {
       bitmaps[b] = static_cast<std::uint64_t *>(bitmap.ptr) + first_rows[b] / 64;
       if (join_type_ == JoinType::kLeftAntiJoin && rows[b] > 0) {
-        CheckStatus(qsx_bitmap_combine(3, bitmaps[b], nullptr, rows[b], bitmaps[b], CurrentStream()), "qsx_bitmap_combine");
+        // the tuples WITHOUT a surviving pair — among those this work order is about: what a LIP filter rejected must not
+        // come back through the complement
+        if (about != nullptr && about[b] != nullptr) {
+          CheckStatus(qsx_bitmap_combine(2, about[b], bitmaps[b], rows[b], bitmaps[b], CurrentStream()), "qsx_bitmap_combine");
+        } else {
+          CheckStatus(qsx_bitmap_combine(3, bitmaps[b], nullptr, rows[b], bitmaps[b], CurrentStream()), "qsx_bitmap_combine");
+        }
       }
       upper += rows[b];
     }

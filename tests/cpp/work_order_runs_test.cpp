@@ -266,9 +266,10 @@ void runJoinDuplicateBuildKeys(bool exact_stats, std::size_t blocks_per_order) {
 // o_limit > l_quantity): a semi / an anti join with a residual predicate between the two sides — the pairs of the run, the
 // residual on them, the probe tuples that kept (semi) or never had (anti) a pair; every order twice with different limits, so
 // that a probe tuple can keep one pair and lose the other
-void runSemiAntiResidual(bool anti, bool exact_stats, std::size_t blocks_per_order, std::size_t *out_blocks) {
+void runSemiAntiResidual(bool anti, bool exact_stats, std::size_t blocks_per_order, std::size_t *out_blocks, bool with_lip = false) {
   StorageManager storage;
   Lineitem li(&storage, false);
+  CatalogRelation small(7, "small");
   CatalogRelation orders(3, "orders");
   orders.addAttribute("o_orderkey", Type::Int());
   orders.addAttribute("o_limit", Type::Int());
@@ -295,6 +296,9 @@ void runSemiAntiResidual(bool anti, bool exact_stats, std::size_t blocks_per_ord
   BuildHashOperator builder(0, orders, true, {0}, false, 1, table);
   HashJoinOperator prober(0, orders, li.rel, true, {0}, false, 1, false, out, dest, table, pred, selection, &on_build,
                           anti ? HashJoinOperator::JoinType::kLeftAntiJoin : HashJoinOperator::JoinType::kLeftSemiJoin);
+  // under a LIP filter the work order is only ABOUT the tuples the filter lets through: an anti join must not bring the
+  // others back through the complement of the paired tuples
+  if (with_lip) prober.deployLIPFilters(deployLip(&ctx, &storage, &small, blocks_per_order));
   prober.setBlocksPerWorkOrder(blocks_per_order);
   builder.setBlocksPerWorkOrder(blocks_per_order);
   fetchAndExecuteWorkOrders(&builder, &ctx, &storage);
@@ -304,6 +308,7 @@ void runSemiAntiResidual(bool anti, bool exact_stats, std::size_t blocks_per_ord
   for (std::size_t i = 0; i < got.key.size(); ++i) g.emplace_back(got.key[i], got.price[i]);
   for (std::size_t i = 0; i < li.orderkey.size(); ++i) {
     const std::int32_t k = li.orderkey[i];
+    if (with_lip && k >= kLipLimit) continue;
     const bool has_order = k < 200000 && (k & 1) == 0;
     const bool kept = has_order && (k % 50 > li.quantity[i] || (k / 2) % 7 > li.quantity[i]);
     if (kept != anti) w.emplace_back(k, li.price[i]);
@@ -542,6 +547,77 @@ void runNullableProbeSide(HashJoinOperator::JoinType type, bool exact_stats, std
   EXPECT_TRUE(got == want);
 }
 
+// Semi / anti joins over a HASHED composite key: (LONG, LONG) does not fit 8 bytes, the table is keyed by the reference's
+// CombineHashes fold and a tuple only counts as matched when the components of a pair are equal (compositeKeyCollisionCheck,
+// SeparateChainingHashTable.hpp:1046) — so the run form goes through the pair list and the component equalities, not
+// through an existence probe.  Build: (a, b) for a in [0, 400), b = 7 a mod 13 and b + 13 (two rows per a); probe rows pick
+// a in [0, 600) and b in [0, 26): few match by both components.
+void runCompositeSemiAnti(bool anti, std::size_t blocks_per_order, std::size_t *out_blocks) {
+  StorageManager storage;
+  CatalogRelation probe(1, "probe"), build(3, "build"), out(4, "kept");
+  probe.addAttribute("a", Type::Long());
+  probe.addAttribute("b", Type::Long());
+  probe.addAttribute("v", Type::Double());
+  build.addAttribute("a", Type::Long());
+  build.addAttribute("b", Type::Long());
+  out.addAttribute("a", Type::Long());
+  out.addAttribute("v", Type::Double());
+  std::vector<std::pair<std::int64_t, double>> want;
+  std::mt19937_64 rng(29);
+  for (int blk = 0; blk < kBlocks; ++blk) {
+    const std::int64_t n = blk == 5 ? 0 : 4000 - 13 * (blk % 7);
+    std::vector<std::int64_t> a(n), b(n);
+    std::vector<double> v(n);
+    for (std::int64_t i = 0; i < n; ++i) {
+      a[i] = static_cast<std::int64_t>(rng() % 600) * 1000003;       // (wide values: the pair does not pack into 8 bytes)
+      b[i] = static_cast<std::int64_t>(rng() % 26) * 1000003;
+      v[i] = static_cast<double>(rng() % 100000);
+      const std::int64_t ka = a[i] / 1000003, kb = b[i] / 1000003;
+      const bool matched = ka < 400 && (kb == (7 * ka) % 13 || kb == (7 * ka) % 13 + 13);
+      if (matched != anti) want.emplace_back(a[i], v[i]);
+    }
+    storage.loadBlock(&probe, {a.data(), b.data(), v.data()}, n);
+  }
+  std::vector<std::int64_t> ba, bb;
+  for (std::int64_t ka = 0; ka < 400; ++ka) {
+    for (std::int64_t kb : {(7 * ka) % 13, (7 * ka) % 13 + 13}) {
+      ba.push_back(ka * 1000003);
+      bb.push_back(kb * 1000003);
+    }
+  }
+  for (std::size_t at = 0; at < ba.size(); at += 100) storage.loadBlock(&build, {ba.data() + at, bb.data() + at}, 100);
+  QueryContext ctx;
+  const auto table = ctx.addJoinHashTable(kLong, 1000);
+  const auto dest = ctx.addInsertDestination(&out, &storage);
+  const auto selection = ctx.addScalarGroup({0, 2});
+  const std::vector<bool> on_build = {false, false};
+  BuildHashOperator builder(0, build, true, {0, 1}, false, 1, table);
+  HashJoinOperator prober(0, build, probe, true, {0, 1}, false, 1, false, out, dest, table, QueryContext::kInvalidPredicateId, selection, &on_build,
+                          anti ? HashJoinOperator::JoinType::kLeftAntiJoin : HashJoinOperator::JoinType::kLeftSemiJoin);
+  prober.setBlocksPerWorkOrder(blocks_per_order);
+  builder.setBlocksPerWorkOrder(blocks_per_order);
+  fetchAndExecuteWorkOrders(&builder, &ctx, &storage);
+  fetchAndExecuteWorkOrders(&prober, &ctx, &storage);
+  std::vector<std::pair<std::int64_t, double>> got;
+  const std::vector<block_id> touched = ctx.getInsertDestination(dest)->getTouchedBlocks();
+  *out_blocks = touched.size();
+  for (block_id id : touched) {
+    BlockReference blk = storage.getBlock(id);
+    const std::size_t n = static_cast<std::size_t>(blk->numTuples());
+    if (n == 0) continue;
+    std::vector<std::int64_t> a(n);
+    std::vector<double> v(n);
+    blk->copyAttributeToHost(0, a.data());
+    blk->copyAttributeToHost(1, v.data());
+    for (std::size_t i = 0; i < n; ++i) got.emplace_back(a[i], v[i]);
+  }
+  std::sort(got.begin(), got.end());
+  std::sort(want.begin(), want.end());
+  EXPECT_TRUE(want.size() > 1000);
+  EXPECT_EQ(got.size(), want.size());
+  EXPECT_TRUE(got == want);
+}
+
 void runTypedExpressions() {
   StorageManager storage;
   Lineitem li(&storage, false);
@@ -690,6 +766,19 @@ int main() {
       EXPECT_EQ(one, static_cast<std::size_t>(kBlocks));
       EXPECT_EQ(run, static_cast<std::size_t>((kBlocks + 63) / 64));
     }
+  }
+  // an anti / semi join with a residual predicate UNDER A LIP FILTER, and semi / anti joins over a hashed composite key:
+  // run forms since round 4
+  for (bool anti : {false, true}) {
+    std::size_t one = 0, run = 0;
+    runSemiAntiResidual(anti, true, 1, &one, /*with_lip=*/true);
+    runSemiAntiResidual(anti, true, 64, &run, /*with_lip=*/true);
+    EXPECT_EQ(one, static_cast<std::size_t>(kBlocks));
+    EXPECT_EQ(run, static_cast<std::size_t>((kBlocks + 63) / 64));
+    runCompositeSemiAnti(anti, 1, &one);
+    runCompositeSemiAnti(anti, 64, &run);
+    EXPECT_EQ(one, static_cast<std::size_t>(kBlocks));
+    EXPECT_EQ(run, static_cast<std::size_t>((kBlocks + 63) / 64));
   }
   // duplicate build keys: the projecting probe overflows its block and the work order falls back to the pair list
   for (bool exact_stats : {true, false}) {
