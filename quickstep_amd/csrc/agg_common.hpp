@@ -47,6 +47,7 @@ __host__ __device__ constexpr long long ordered_from_bits(long long bits) {
 __host__ __device__ constexpr long long acc_identity(int kind) {
   return kind == kAccMinI64 ? 0x7FFFFFFFFFFFFFFFll : (kind == kAccMaxI64 ? static_cast<long long>(0x8000000000000000ull) : 0ll);
 }
+constexpr int kRegDecoded = -2;   // DevConfig::lds_off of a compressed attribute whose values live in registers (plan_tile)
 struct DevPred {
   int column;
   int op;
@@ -110,7 +111,7 @@ struct DevConfig {
   // LDS staging plan of the hash-strategy update kernel: byte offset of column
   // c inside a staged tile (-1: column not referenced, not staged), of the
   // filter words (-1: no filter) and the size of one tile buffer.
-  int lds_off[QSX_MAX_COLUMNS];
+  int lds_off[QSX_MAX_COLUMNS];   // (-1: column not referenced; kRegDecoded: a compressed attribute decoded into registers)
   int filter_lds_off;
   int tile_bytes;
   // Nullable columns (qsx_agg_config_t::column_nullable) that the plan reads: slot s = column null_column[s]; its

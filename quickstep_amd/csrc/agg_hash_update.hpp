@@ -97,8 +97,9 @@ __device__ __forceinline__ void stage_tile(const DevConfig &c, const void *const
   const int wave = threadIdx.x >> 6;
   auto stage_column = [&](int col, const void *base) __attribute__((always_inline)) {
     const int off = c.lds_off[col];
-    if (off < 0) return;  // column not referenced by keys / predicate / expressions
-    // a compressed attribute is staged as its code stripe (decode_tile_codes fills the value slots afterwards)
+    if (off < 0 && off != kRegDecoded) return;  // column not referenced by keys / predicate / expressions
+    // a compressed attribute is staged as its code stripe (decode_tile_codes fills the value slots afterwards, or
+    // decode_rows the thread's registers: lds_off = kRegDecoded, no slots)
     const bool coded = c.code_width[col] != 0;
     const int w = coded ? c.code_width[col] : c.column_width[col];
     const char *src = static_cast<const char *>(base) + row0 * w;
@@ -190,8 +191,67 @@ __device__ __forceinline__ void decode_tile_codes(const DevConfig &c, const void
   });
 }
 
+// Compressed attributes of a plan shape whose tile holds only the codes (plan_tile reg_decode, lds_off = kRegDecoded): the
+// values of the thread's V rows live in registers — the column's own type, zero-extended into a 64-bit container.  With a
+// static configuration every index below is a constant after unrolling, and only the columns the plan reads survive.
+template <int V>
+struct DecodedRows {
+  unsigned long long raw[QSX_MAX_COLUMNS][V];
+};
+template <int V, int BLOCK = kABlock>
+__device__ __forceinline__ void decode_rows(const DevConfig &c, const void *const *dicts, const char *tile, int trow, int rows,
+                                            DecodedRows<V> &dec) {
+#pragma unroll
+  for (int col = 0; col < QSX_MAX_COLUMNS; ++col) {
+    if (col >= c.num_columns || c.lds_off[col] != kRegDecoded) continue;
+    const char *codes = tile + c.code_off[col];
+    const void *dict = dicts != nullptr ? as_global(dicts[col]) : nullptr;
+    uint32_t code[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int r = trow + v * BLOCK;
+      switch (c.code_width[col]) {
+        case 1: code[v] = reinterpret_cast<const uint8_t *>(codes)[r]; break;
+        case 2: code[v] = reinterpret_cast<const uint16_t *>(codes)[r]; break;
+        default: code[v] = reinterpret_cast<const uint32_t *>(codes)[r]; break;
+      }
+      if (r >= rows) code[v] = 0;   // stale LDS behind a partial tile must not index the dictionary
+    }
+    const bool narrow = c.column_type[col] == QSX_INT || c.column_type[col] == QSX_FLOAT;
+    if (dict != nullptr) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        dec.raw[col][v] = narrow ? static_cast<unsigned long long>(static_cast<const uint32_t *>(dict)[code[v]])
+                                 : static_cast<const unsigned long long *>(dict)[code[v]];
+      }
+    } else {   // truncation: value = code (the conversions of decode_tile_codes)
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        switch (c.column_type[col]) {
+          case QSX_INT: dec.raw[col][v] = code[v]; break;
+          case QSX_FLOAT: dec.raw[col][v] = __float_as_uint(static_cast<float>(code[v])); break;
+          case QSX_LONG: dec.raw[col][v] = code[v]; break;
+          default: dec.raw[col][v] = static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(code[v]))); break;
+        }
+      }
+    }
+  }
+}
+
 // ---- typed reads of a staged column ---------------------------------------------
-__device__ __forceinline__ double tile_double(const DevConfig &c, const char *tile, int col, int r) {
+// (dec / v: the registers of a plan shape's compressed attributes and which of the thread's rows r is; nullptr elsewhere)
+template <int V = 1>
+__device__ __forceinline__ double tile_double(const DevConfig &c, const char *tile, int col, int r, const DecodedRows<V> *dec = nullptr,
+                                              int v = 0) {
+  if (dec != nullptr && c.lds_off[col] == kRegDecoded) {
+    const unsigned long long raw = dec->raw[col][v];
+    switch (c.column_type[col]) {
+      case QSX_INT: return static_cast<double>(static_cast<int32_t>(raw));
+      case QSX_LONG: return static_cast<double>(static_cast<int64_t>(raw));
+      case QSX_FLOAT: return static_cast<double>(__uint_as_float(static_cast<uint32_t>(raw)));
+      default: return __longlong_as_double(static_cast<long long>(raw));
+    }
+  }
   const char *p = tile + c.lds_off[col];
   switch (c.column_type[col]) {
     case QSX_INT: return static_cast<double>(reinterpret_cast<const int32_t *>(p)[r]);
@@ -200,7 +260,13 @@ __device__ __forceinline__ double tile_double(const DevConfig &c, const char *ti
     default: return reinterpret_cast<const double *>(p)[r];
   }
 }
-__device__ __forceinline__ long long tile_int(const DevConfig &c, const char *tile, int col, int r) {
+template <int V = 1>
+__device__ __forceinline__ long long tile_int(const DevConfig &c, const char *tile, int col, int r, const DecodedRows<V> *dec = nullptr,
+                                              int v = 0) {
+  if (dec != nullptr && c.lds_off[col] == kRegDecoded) {
+    const unsigned long long raw = dec->raw[col][v];
+    return c.column_type[col] == QSX_INT ? static_cast<long long>(static_cast<int32_t>(raw)) : static_cast<long long>(raw);
+  }
   const char *p = tile + c.lds_off[col];
   if (c.column_type[col] == QSX_INT) return reinterpret_cast<const int32_t *>(p)[r];
   return reinterpret_cast<const long long *>(p)[r];
@@ -247,11 +313,11 @@ __device__ __forceinline__ void temps_set(Temps<V> &s, int i, const double (&in)
 
 template <int V, int BLOCK = kABlock>
 __device__ __forceinline__ void operand_vec(const DevConfig &c, const DevOperand &o, const Temps<V> &s,
-                                            const char *tile, int trow, double (&out)[V]) {
+                                            const char *tile, int trow, double (&out)[V], const DecodedRows<V> *dec = nullptr) {
   switch (o.kind) {
     case QSX_OPD_COLUMN:
 #pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = tile_double(c, tile, o.index, trow + v * BLOCK);
+      for (int v = 0; v < V; ++v) out[v] = tile_double<V>(c, tile, o.index, trow + v * BLOCK, dec, v);
       break;
     case QSX_OPD_CONST:
 #pragma unroll
@@ -300,9 +366,32 @@ __device__ __forceinline__ void plan_operand_vec(const PlanOperand &o, const cha
 }
 
 template <bool kStatic, int V, int BLOCK = kABlock>
-__device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *tile, int trow, bool (&live)[V]) {
+__device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *tile, int trow, bool (&live)[V],
+                                              const DecodedRows<V> *dec = nullptr) {
   cfg_for<kStatic, QSX_MAX_PRED_TERMS>(c.num_pred, [&](int p) __attribute__((always_inline)) {
     const DevPred term = c.pred[p];
+    if (dec != nullptr && c.lds_off[term.column] == kRegDecoded) {
+      // a compressed attribute of a plan shape: the value is in the thread's registers
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const unsigned long long raw = dec->raw[term.column][v];
+        bool ok;
+        switch (c.column_type[term.column]) {
+          case QSX_INT: ok = compare_op<int32_t>(static_cast<int32_t>(raw), term.op, static_cast<int32_t>(term.literal)); break;
+          case QSX_LONG: ok = compare_op<int64_t>(static_cast<int64_t>(raw), term.op, static_cast<int64_t>(term.literal)); break;
+          case QSX_FLOAT:
+            ok = compare_op<float>(__uint_as_float(static_cast<uint32_t>(raw)), term.op, __uint_as_float(static_cast<uint32_t>(term.literal)));
+            break;
+          case QSX_DATE: ok = compare_op<long long>(date_ordered(raw), term.op, date_ordered(term.literal)); break;
+          default:
+            ok = compare_op<double>(__longlong_as_double(static_cast<long long>(raw)), term.op,
+                                    __longlong_as_double(static_cast<long long>(term.literal)));
+            break;
+        }
+        live[v] = live[v] && ok;
+      }
+      return;
+    }
     const char *base = tile + c.lds_off[term.column];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -334,13 +423,18 @@ __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *ti
 }
 
 // Word w of the packed wide key of tile row r (DevConfig::wide_words).
-__device__ __forceinline__ unsigned long long key_word_of(const DevConfig &c, const char *tile, int w, int r) {
+template <int V = 1>
+__device__ __forceinline__ unsigned long long key_word_of(const DevConfig &c, const char *tile, int w, int r,
+                                                          const DecodedRows<V> *dec = nullptr, int v = 0) {
   unsigned long long word = 0;
 #pragma unroll
   for (int k = 0; k < QSX_MAX_KEYS; ++k) {
     if (k < c.num_keys && c.key_word[k] == w) {
       const char *base = tile + c.lds_off[c.key_column[k]];
       unsigned long long x;
+      if (dec != nullptr && c.lds_off[c.key_column[k]] == kRegDecoded) {
+        x = dec->raw[c.key_column[k]][v];   // (zero-extended in its container: the same bits the stripe would hold)
+      } else
       switch (c.key_width[k]) {
         case 1: x = reinterpret_cast<const uint8_t *>(base)[r]; break;
         case 2: x = reinterpret_cast<const uint16_t *>(base)[r]; break;
@@ -357,13 +451,14 @@ __device__ __forceinline__ unsigned long long key_word_of(const DevConfig &c, co
 // Compact key codes of V rows (ThreadPrivateCompactKeyHashTable.cpp:216-232); for a wide key the 64-bit mixing hash of
 // its words.
 template <bool kStatic, int V, int BLOCK = kABlock>
-__device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *tile, int trow, unsigned long long (&code)[V]) {
+__device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *tile, int trow, unsigned long long (&code)[V],
+                                              const DecodedRows<V> *dec = nullptr) {
   if (c.wide_words != 0) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       unsigned long long words[kMaxKeyWords];
 #pragma unroll
-      for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of(c, tile, w, trow + v * BLOCK) : 0ull;
+      for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of<V>(c, tile, w, trow + v * BLOCK, dec, v) : 0ull;
       code[v] = wide_key_code(words, c.wide_words, c.wide_hash_mask);
     }
     return;
@@ -376,6 +471,9 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
     for (int v = 0; v < V; ++v) {
       const int r = trow + v * BLOCK;
       unsigned long long x;
+      if (dec != nullptr && c.lds_off[c.key_column[k]] == kRegDecoded) {
+        x = dec->raw[c.key_column[k]][v];
+      } else
       switch (c.key_width[k]) {
         case 1: x = reinterpret_cast<const uint8_t *>(base)[r]; break;
         case 2: x = reinterpret_cast<const uint16_t *>(base)[r]; break;
@@ -488,7 +586,16 @@ __device__ __forceinline__ void classify_row(bool live, unsigned long long code,
 // kRuns: the rows are a run of blocks (agg_common.hpp BlockRunView in `pieces`; cols / filter unused).  A compile-time
 // flavour, not a run-time test: with both sources in one kernel the by-value column table has its address taken and moves
 // to scratch (136 bytes per lane, Q1 3.3 -> 4.9 ms per 600 M rows).
-template <bool kStatic, bool kDense, int NS, int V, bool kDir = false, int BLOCK = kABlock, bool kDirBuild = false, bool kRuns = false>
+// REG > 0 (plan shapes over a table sized for a handful of groups; off by default, QSX_AGG_REG_GROUPS=1): every wave keeps
+// the accumulators of the first REG groups it meets in its lanes' REGISTERS — the reference's
+// ThreadPrivateCompactKeyHashTable taken literally — and a row of such a group costs exec-masked VALU adds instead of NS + 1
+// LDS atomics plus the table lookup.  The LDS table stays what it was for every other row (a wave adopts a key only after a
+// row of it found an LDS slot there, and remembers the slot); the lanes add their registers to that slot's planes when the
+// workgroup is done with its tiles, in front of the flush.  Measured: the LDS atomics disappear
+// (SQ_LDS_ADDR_CONFLICT 9e7 -> 4e5 cycles) but every (row, entry) pair executes its block of adds whenever any lane of the
+// wave matches (4x the f64 adds) and the registers cost a workgroup per CU: slower than the atomics it replaces.
+template <bool kStatic, bool kDense, int NS, int V, bool kDir = false, int BLOCK = kABlock, bool kDirBuild = false, bool kRuns = false,
+          int REG = 0>
 __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const void *const *cols, const void *const *dicts, int64_t n,
                                                      const uint64_t *__restrict__ filter, const HashTableView &g,
                                                      const DenseView &dense, int S, int rep_shift, int nbuf,
@@ -587,7 +694,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       if constexpr (kStatic) {
 #pragma unroll
         for (int col = 0; col < QSX_MAX_COLUMNS; ++col) {
-          src.bases.p[col] = (col < c.num_columns && c.lds_off[col] >= 0) ? src.cols[col] : nullptr;
+          src.bases.p[col] = (col < c.num_columns && (c.lds_off[col] >= 0 || c.lds_off[col] == kRegDecoded)) ? src.cols[col] : nullptr;
         }
       }
       src.filter = run.filters != nullptr ? reinterpret_cast<const uint64_t *>(run.filters[b]) : nullptr;
@@ -617,6 +724,24 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   unsigned long long *s_flush_stat = l_ctl + 3;
   if (can_flush && threadIdx.x < kHashCtlWords) l_ctl[threadIdx.x] = 0;
   int tile_count = 0;
+  static_assert(REG == 0 || (kStatic && !kDense && !kDir && !kDirBuild), "register groups: plan shapes of the hash path only");
+  // register groups (REG > 0): key code and LDS table slot per entry (wave-uniform), row count and accumulators per lane
+  constexpr int kRegN = REG > 0 ? REG : 1;
+  unsigned long long reg_key[kRegN];
+  int reg_slot[kRegN];
+  unsigned int reg_cnt[kRegN];
+  unsigned long long reg_acc[kRegN][NS > 0 ? NS : 1];
+  int reg_used = 0;
+  if constexpr (REG > 0) {
+#pragma unroll
+    for (int e = 0; e < REG; ++e) {
+      reg_key[e] = kEmptyCode;
+      reg_slot[e] = 0;
+      reg_cnt[e] = 0;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) reg_acc[e][j] = static_cast<unsigned long long>(acc_identity(c.sums[j].kind));
+    }
+  }
   // LDS -> global table: fold the REP partials, one global atomic per group per accumulator per workgroup
   auto flush_table = [&](bool with_stats) {
     const int rep = 1 << rep_shift;
@@ -663,6 +788,9 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const TileSource here = carried;
     if (!staged_ahead) {
       __syncthreads();  // every wave is done reading the previous tile
+#ifdef QSX_EXP_STAGE_ONCE   // (experiment: every tile works on the first one's bytes — the compute side without HBM traffic)
+      if (tile_count == 0)
+#endif
       stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? here.cols : cols, kRuns ? here.filter : filter, tiles, here.row0, here.rows, nulls, &here.bases);
     }
     // The tile has landed (nbuf == 2: it was staged during the previous iteration and
@@ -707,7 +835,17 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const int rows = here.rows;
 
     const int trow = threadIdx.x;  // this thread's first row of the tile
+#ifdef QSX_EXP_NO_COMPUTE   // (experiment through QSX_JIT_OPTIONS, tools/agg_coded_exp.sh: the tile pipeline alone — staging, waits, barriers)
+    if constexpr (kStatic && !kDense && !kDir && !kDirBuild) continue;
+#endif
     decode_tile_codes<kStatic, V, BLOCK>(c, kRuns ? here.dicts : dicts, tile, trow, rows);
+    // plan shapes whose tile holds only the codes of the compressed attributes: their values, into registers
+    DecodedRows<V> decoded;
+    const DecodedRows<V> *dec = nullptr;
+    if constexpr (kStatic) {
+      decode_rows<V, BLOCK>(c, kRuns ? here.dicts : dicts, tile, trow, rows, decoded);
+      dec = &decoded;
+    }
 
     // ---- which rows are live -------------------------------------------------
     bool live[V];
@@ -737,11 +875,11 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 #pragma unroll
       for (int v = 0; v < V; ++v) live[v] = live[v] && (nullbits[v] & c.row_null_mask) == 0;
     }
-    predicate_vec<kStatic, V, BLOCK>(c, tile, trow, live);
+    predicate_vec<kStatic, V, BLOCK>(c, tile, trow, live, dec);
 
     // ---- group of every row ----------------------------------------------------
     unsigned long long code[V];
-    key_codes_vec<kStatic, V, BLOCK>(c, tile, trow, code);
+    key_codes_vec<kStatic, V, BLOCK>(c, tile, trow, code, dec);
     if (ranges > 1 && !by_piece && !(kDense && kDir)) {   // (a dense state in LDS splits by key range, below)
 #pragma unroll
       for (int v = 0; v < V; ++v) {
@@ -757,7 +895,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
             if (c.wide_words != 0) {
               unsigned long long words[kMaxKeyWords];
 #pragma unroll
-              for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of(c, tile, w, trow + v * BLOCK) : 0ull;
+              for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of<V>(c, tile, w, trow + v * BLOCK, dec, v) : 0ull;
               bool inserted;
               const int at = lds_find_or_insert_new(l_keys, S, code[v], &inserted);
               if (at < 0) {
@@ -787,6 +925,9 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     int slot[V];
     long long global_slot[V];
     bool any_global = false;
+    bool any_lds = false;       // REG: a row of this lane goes through the LDS table
+    int reg_entry[V];           // REG: the register entry of the row's group, -1: none
+    unsigned long long reg_inc[NS > 0 ? NS : 1][V];
     bool run_tail[V];   // kDense: this lane commits the run of equal adjacent keys ending here
     // kDir: the row's group number (or -2: look it up), its wide key, and the aggregates' arguments until the row is classified
     int dir_gid = -1;
@@ -855,14 +996,58 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         }
       }
     } else {
+      if constexpr (REG > 0) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          reg_entry[v] = -1;
+#pragma unroll
+          for (int e = 0; e < REG; ++e) {
+            if (e < reg_used && live[v] && code[v] == reg_key[e]) reg_entry[v] = e;
+          }
+        }
+      }
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        classify_row(live[v], code[v], l_keys, l_acc, S, rep_shift, lane_col, g, slot[v], global_slot[v]);
+        const bool through_lds = live[v] && (REG == 0 || reg_entry[v] < 0);
+        classify_row(through_lds, code[v], l_keys, l_acc, S, rep_shift, lane_col, g, slot[v], global_slot[v]);
         any_global = any_global || global_slot[v] >= 0;
+        any_lds = any_lds || through_lds;
         run_tail[v] = false;
+      }
+      if constexpr (REG > 0) {
+        // a wave with free entries adopts the keys of rows that found an LDS slot (wave-uniform: ballots and readlanes)
+        if (reg_used < REG) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            unsigned long long candidates = __ballot(live[v] && reg_entry[v] < 0 && slot[v] < (S << rep_shift));
+            while (candidates != 0 && reg_used < REG) {
+              const int l = __builtin_ctzll(candidates);
+              // (readlane returns int: without the casts the low half would sign-extend over the high one)
+              const unsigned long long key =
+                  static_cast<unsigned long long>(static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(code[v]), l))) |
+                  (static_cast<unsigned long long>(static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(code[v] >> 32), l))) << 32);
+              candidates &= ~(1ull << l);   // (whatever the comparison below says, this lane is done)
+              const int at = __builtin_amdgcn_readlane(slot[v], l) >> rep_shift;
+              candidates &= ~__ballot(code[v] == key);
+              bool known = false;
+#pragma unroll
+              for (int e = 0; e < REG; ++e) known = known || (e < reg_used && reg_key[e] == key);
+              if (known) continue;   // (adopted from an earlier row of this tile)
+#pragma unroll
+              for (int e = 0; e < REG; ++e) {
+                if (e == reg_used) {
+                  reg_key[e] = key;
+                  reg_slot[e] = at;
+                }
+              }
+              ++reg_used;
+            }
+          }
+        }
       }
     }
     const bool wave_has_global = __any(any_global);  // rare: groups that did not fit the LDS table
+    const bool wave_has_lds = REG == 0 || __any(any_lds);   // (register groups: most waves have no row for the LDS planes)
     if (can_flush && any_global) l_ctl[tile_count % 3] = 1;   // (benign race: everyone stores the same value)
     if constexpr (kDense && !kDir) {
       // existence bit + row count of every run (CollisionFreeVectorTable.hpp:530-645)
@@ -917,8 +1102,8 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     cfg_for<kStatic, QSX_MAX_INSTRS>(kStatic ? c.num_instrs : 0, [&](int k) __attribute__((always_inline)) {
       const DevInstr in = c.instrs[k];
       double a[V], b[V], res[V];
-      operand_vec<V, BLOCK>(c, in.a, temps, tile, trow, a);
-      operand_vec<V, BLOCK>(c, in.b, temps, tile, trow, b);
+      operand_vec<V, BLOCK>(c, in.a, temps, tile, trow, a, dec);
+      operand_vec<V, BLOCK>(c, in.b, temps, tile, trow, b, dec);
       switch (in.op) {
         case QSX_EX_ADD:
 #pragma unroll
@@ -952,12 +1137,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       } else if (s.arg.kind == kOpdKeyWord) {
         // hidden accumulators of a wide key: MIN / MAX of the packed key words (DevConfig::wide_words)
 #pragma unroll
-        for (int v = 0; v < V; ++v) inc[v] = key_word_of(c, tile, s.arg.index, trow + v * BLOCK);
+        for (int v = 0; v < V; ++v) inc[v] = key_word_of<V>(c, tile, s.arg.index, trow + v * BLOCK, dec, v);
       } else if (s.is_int) {
         if constexpr (kStatic) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            inc[v] = static_cast<unsigned long long>(tile_int(c, tile, s.arg.index, trow + v * BLOCK));
+            inc[v] = static_cast<unsigned long long>(tile_int<V>(c, tile, s.arg.index, trow + v * BLOCK, dec, v));
           }
         } else {
           const PlanSum ps = c.plan_sums[j];
@@ -972,7 +1157,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       } else {
         double x[V];
         if constexpr (kStatic) {
-          operand_vec<V, BLOCK>(c, s.arg, temps, tile, trow, x);
+          operand_vec<V, BLOCK>(c, s.arg, temps, tile, trow, x, dec);
         } else {
           plan_operand_vec<V, BLOCK>(c.plan_sums[j].arg, tile, lds_temps, trow, x);
         }
@@ -1007,15 +1192,38 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
           dir_inc[j] = inc[0];
           continue;
         }
-        {
+        if constexpr (REG > 0) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) reg_inc[j][v] = inc[v];
+        }
+#ifndef QSX_EXP_NO_LDS_ADD   // (experiment, tools/agg_coded_exp.sh: what the accumulator atomics cost)
+        if (wave_has_lds) {
           unsigned long long *acc_plane = acc_plane_of(j);
 #pragma unroll
           for (int v = 0; v < V; ++v) lds_add(&acc_plane[slot[v]], inc[v], s.kind);  // unconditional (trash slot)
         }
+#else
+#pragma unroll
+        for (int v = 0; v < V; ++v) asm volatile("" ::"v"(inc[v]), "v"(slot[v]));
+#endif
         if (wave_has_global) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             if (global_slot[v] >= 0) global_add(g, j + 1, static_cast<unsigned long long>(global_slot[v]), inc[v], s.kind);
+          }
+        }
+      }
+    }
+    if constexpr (REG > 0) {
+      // rows of the wave's register groups: one exec-masked block of adds per (row, entry)
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+#pragma unroll
+        for (int e = 0; e < REG; ++e) {
+          if (reg_entry[v] == e) {
+            ++reg_cnt[e];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) reg_acc[e][j] = acc_combine(reg_acc[e][j], reg_inc[j][v], c.sums[j].kind);
           }
         }
       }
@@ -1051,6 +1259,20 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     }
   }
   if constexpr (kDense && !kDir) return;
+  if constexpr (REG > 0) {
+    // the lanes' registers -> the planes of the entry's LDS slot (a lane adds into its own copy)
+#pragma unroll
+    for (int e = 0; e < REG; ++e) {
+      if (e < reg_used) {
+        const int at = (reg_slot[e] << rep_shift) + lane_col;
+        if (reg_cnt[e] != 0) {
+          atomicAdd(&l_acc[at], static_cast<unsigned long long>(reg_cnt[e]));
+#pragma unroll
+          for (int j = 0; j < NS; ++j) lds_add(&acc_plane_of(j)[at], reg_acc[e][j], c.sums[j].kind);
+        }
+      }
+    }
+  }
   __syncthreads();
   if constexpr (kDense && kDir) {
     // the workgroup's totals -> the dense arrays: existence bit, row count, one atomic per accumulator and entry it saw
@@ -1289,21 +1511,31 @@ __global__ __launch_bounds__(kABlock) void agg_hash_shape_runs_kernel(int64_t n,
                                                                                 nbuf, ranges, block_run);
 }
 
-template <typename Shape, int V, int S_, int REP_SHIFT_, int RANGES_>
+// Register groups of a fixed-geometry shape: tables sized for a handful of groups (the launchers' smallest, 16 slots), and
+// accumulators that fit the register file next to the body's own (REG x (2 NS + 1) VGPRs).
+#ifndef QSX_AGG_REG_GROUPS
+#define QSX_AGG_REG_GROUPS 4
+#endif
+constexpr int reg_groups_for(int slots, int num_sums) {
+  return slots <= 16 && num_sums >= 1 && num_sums <= 6 ? QSX_AGG_REG_GROUPS : 0;
+}
+
+template <typename Shape, int V, int S_, int REP_SHIFT_, int RANGES_, bool kRegGroups = false>
 __global__ __launch_bounds__(kABlock) void agg_hash_shape_fixed_runs_kernel(int64_t n, HashTableView g, const long long *__restrict__ block_run) {
   static constexpr Translated T = Shape::translated(kABlock * V);
-  agg_hash_update_body<true, false, T.num_sums, V, false, kABlock, false, true>(T.dev, nullptr, nullptr, n, nullptr, g, DenseView{}, S_, REP_SHIFT_, 1,
-                                                                                RANGES_, block_run);
+  agg_hash_update_body<true, false, T.num_sums, V, false, kABlock, false, true, kRegGroups ? reg_groups_for(S_, T.num_sums) : 0>(
+      T.dev, nullptr, nullptr, n, nullptr, g, DenseView{}, S_, REP_SHIFT_, 1, RANGES_, block_run);
 }
 
 // The same with the launch geometry of the common small-group case (one tile buffer, one workgroup family) as constants:
 // the plane / slot arithmetic of the tile loop folds instead of occupying scalar registers (what made the run-time shapes
 // 10 % faster once they got their geometry as constants).
-template <typename Shape, int V, int S_, int REP_SHIFT_, int RANGES_>
+template <typename Shape, int V, int S_, int REP_SHIFT_, int RANGES_, bool kRegGroups = false>
 __global__ __launch_bounds__(kABlock) void agg_hash_shape_fixed_kernel(ColumnPointers cols, int64_t n, HashTableView g,
                                                                       const long long *__restrict__ pieces) {
   static constexpr Translated T = Shape::translated(kABlock * V);
-  agg_hash_update_body<true, false, T.num_sums, V>(T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, S_, REP_SHIFT_, 1, RANGES_, pieces);
+  agg_hash_update_body<true, false, T.num_sums, V, false, kABlock, false, false, kRegGroups ? reg_groups_for(S_, T.num_sums) : 0>(
+      T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, S_, REP_SHIFT_, 1, RANGES_, pieces);
 }
 
 }  // namespace qsx

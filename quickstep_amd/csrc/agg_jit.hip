@@ -161,8 +161,11 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
   // the run-of-blocks flavour of the body takes the same signature (the table arrives as `pieces`) and its stripes from the
   // table: its template arguments are emitted here, not patched into the text afterwards
   std::ostringstream body_args;
-  body_args << "true, " << (dense ? "true" : "false") << ", " << num_sums << ", " << kJitRowsPerThread;
-  if (geo.runs != 0) body_args << ", false, " << kABlock << ", false, true";
+  body_args << "true, " << (dense ? "true" : "false") << ", " << num_sums << ", " << jit_rows_per_thread();
+  if (geo.runs != 0 || geo.reg_groups != 0) {
+    body_args << ", false, " << kABlock << ", false, " << (geo.runs != 0 ? "true" : "false");
+    if (geo.reg_groups != 0) body_args << ", " << geo.reg_groups;   // per-wave register accumulators (agg_hash_update.hpp, REG)
+  }
   o
     // explicit arguments are kept under 256 bytes (one view, the dictionaries behind a pointer): with the 256 hidden
     // bytes a kernarg segment beyond 512 bytes made the same code 2.4x slower (3.5 -> 8.3 ms, Q1 over 600 M rows)
@@ -529,6 +532,23 @@ int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t s
   return QSX_OK;
 }
 
+int jit_rows_per_thread() {
+  static const int rows = []() {
+    const char *e = getenv("QSX_AGG_JIT_ROWS");
+    return e != nullptr && atoi(e) == 2 ? 2 : 4;
+  }();
+  return rows;
+}
+
+int jit_resident_blocks(const JitKernel *k, int block, size_t lds_bytes) {
+  int blocks = 0;
+  if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k->function, block, lds_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return blocks;
+}
+
 int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t stream, const ColumnPointers &cols,
                        const void *const *dict_table_dev, int64_t n, const uint64_t *filter, const HashTableView &g, const DirView &d,
                        const long long *pieces, const unsigned long long *const *null_table_dev) {
@@ -558,12 +578,15 @@ extern "C" int qsx_debug_jit_compile(const qsx_agg_config_t *config, int with_fi
   const bool directory = (with_filter & 2) != 0 && !t.dense;   // bit 1: the group-directory variant
   const bool runs = (with_filter & 4) != 0;                    // bit 2: the run-of-blocks flavour
   const bool dense_lds = (with_filter & 8) != 0 && t.dense;    // bit 3: a dense state in LDS
+  const bool reg_groups = (with_filter & 16) != 0;             // bit 4: per-wave register accumulators (small hash tables)
   with_filter &= 1;
-  plan_tile(t.dev, t.used_columns, directory || dense_lds ? kDirBlock : kABlock * kJitRowsPerThread, with_filter != 0);
+  plan_tile(t.dev, t.used_columns, directory || dense_lds ? kDirBlock : kABlock * jit_rows_per_thread(), with_filter != 0,
+            /*reg_decode=*/!directory && !t.dense);
   // a plausible geometry: this hook only checks that the shape compiles
   JitGeometry geometry = directory ? JitGeometry{4096, 0, 2, 1, 4096, 0} : JitGeometry{t.dense ? 8 : 16, t.dense ? 0 : 4, 1, 1, 0, 0};
   if (dense_lds) geometry = JitGeometry{4096, 0, 2, 2, 4096, 0};
   geometry.runs = runs ? 1 : 0;
+  if (reg_groups && !directory && !t.dense) geometry.reg_groups = reg_groups_for(geometry.S, t.num_sums);
   const std::string source = jit_agg_source(t.dev, t.num_sums, t.dense, geometry);
   if (const char *dump = getenv("QSX_JIT_DUMP")) {   // the generated translation unit, for offline inspection with hipcc -S
     if (FILE *f = std::fopen(dump, "w")) {

@@ -32,6 +32,7 @@ struct JitGeometry {
   int S, rep_shift, nbuf, ranges;
   int dir_gids;   // != 0: the group-directory variant (agg_common.hpp DirView) with that many LDS accumulators per aggregate
   int runs;       // != 0: the rows are a run of blocks (agg_common.hpp BlockRunView behind the `pieces` argument)
+  int reg_groups; // != 0: that many groups per wave accumulate in registers (agg_hash_update.hpp, REG; small hash tables only)
 };
 JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geometry, bool synchronous);
 // 0: still compiling, 1: ready (*kernel set), -1: failed (hipRTC error: the interpreter stays in use)
@@ -51,7 +52,11 @@ int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream
                        const long long *pieces = nullptr,    // pieces: the run table of a geometry.runs shape
                        const unsigned long long *const *null_table_dev = nullptr);
 
-constexpr int kJitRowsPerThread = 4;
+// Workgroups of `block` threads with lds_bytes of dynamic LDS that one CU keeps resident (registers and LDS); 0: unknown.
+int jit_resident_blocks(const JitKernel *k, int block, size_t lds_bytes);
+
+// Rows of a tile per thread in the run-time shapes of the hash path (tile = 256 x that): 4, or 2 with QSX_AGG_JIT_ROWS=2.
+int jit_rows_per_thread();
 
 }  // namespace qsx
 

@@ -317,13 +317,22 @@ constexpr size_t align16_ce(size_t v) { return (v + 15) & ~static_cast<size_t>(1
 
 // LDS layout of one tile of `tile_rows` rows: referenced columns back to back (16-byte
 // aligned), then the filter words.  Returns the tile size in bytes.
-constexpr int plan_tile(DevConfig &d, unsigned used_columns, int tile_rows, bool has_filter) {
+// reg_decode (plan shapes of the hash path): a compressed attribute gets NO value slots in the tile — lds_off = kRegDecoded,
+// the thread decodes the codes of its rows into registers (agg_hash_update.hpp DecodedRows) — so the tile is as small as
+// the bytes that are read (Q1 over lineitem's codes: 13 instead of 37 KiB per 1024 rows).
+constexpr int plan_tile(DevConfig &d, unsigned used_columns, int tile_rows, bool has_filter, bool reg_decode = false) {
   size_t off = 0;
   for (int col = 0; col < QSX_MAX_COLUMNS; ++col) {
     if (col < d.num_columns && ((used_columns >> col) & 1u)) {
+      d.code_off[col] = -1;
+      if (reg_decode && d.code_width[col] != 0) {
+        d.lds_off[col] = kRegDecoded;
+        d.code_off[col] = static_cast<int>(off);
+        off += align16_ce(static_cast<size_t>(tile_rows) * d.code_width[col]);
+        continue;
+      }
       d.lds_off[col] = static_cast<int>(off);
       off += align16_ce(static_cast<size_t>(tile_rows) * d.column_width[col]);
-      d.code_off[col] = -1;
       if (d.code_width[col] != 0) {   // compressed attribute: the codes are staged, the slots above receive the values
         d.code_off[col] = static_cast<int>(off);
         off += align16_ce(static_cast<size_t>(tile_rows) * d.code_width[col]);

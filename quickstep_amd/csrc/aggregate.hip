@@ -810,13 +810,19 @@ struct AggTuning {
   int acc_kib;           // LDS budget of the replicated accumulators
   int max_blocks_per_cu;
 };
+// Small hash tables of plan shapes: per-wave register accumulators (agg_hash_update.hpp, REG).  Measured slower than the LDS
+// atomics they replace: off unless QSX_AGG_REG_GROUPS=1 (read per call: the parity tests run both).
+static bool reg_groups_enabled() {
+  const char *e = getenv("QSX_AGG_REG_GROUPS");
+  return e != nullptr && atoi(e) != 0;
+}
 static const AggTuning &agg_tuning() {
   static AggTuning t = []() {
     // measured on MI355X (tools/agg_sweep.sh, 600 M Q1 rows): shape kernel V=4, 1 buffer, 16 KiB
     // accumulators, 4 workgroups/CU = 3.47 ms; interpreter V=2 = 10.9 ms
     AggTuning v{2, 4, 1, 16, 4};
     if (const char *e = getenv("QSX_AGG_ROWS_PER_THREAD")) v.rows_per_thread = v.shape_rows_per_thread = atoi(e) == 4 ? 4 : 2;
-    if (const char *e = getenv("QSX_AGG_BUFFERS")) v.buffers = atoi(e) == 2 ? 2 : 1;
+    if (const char *e = getenv("QSX_AGG_BUFFERS")) v.buffers = atoi(e) == 2 ? 2 : (atoi(e) == 0 ? 0 : 1);   // (0: per shape, jit_geometry_for)
     if (const char *e = getenv("QSX_AGG_ACC_KIB")) v.acc_kib = atoi(e) > 0 ? atoi(e) : 12;
     if (const char *e = getenv("QSX_AGG_BLOCKS_PER_CU")) v.max_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 4;
     return v;
@@ -943,7 +949,7 @@ static int launch_hash_v(DevConfig dc, unsigned used_columns, int64_t n, const u
   plan_interpreter(dc, TR);
   // replicate every accumulator as far as the budget allows (64 = one bank column per lane)
   const AggTuning &tune = agg_tuning();
-  const int nbuf = tune.buffers;
+  const int nbuf = tune.buffers == 0 ? 1 : tune.buffers;   // (0 = chosen per run-time shape: jit_geometry_for)
   size_t lds = 0;
   const int rep_shift = choose_replication(NS, S, nbuf * off + dc.temps_bytes, tune, &lds);
   constexpr size_t kMaxLds = 160 * 1024;
@@ -1157,7 +1163,7 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
   static_assert(T.status == QSX_OK, "plan shape does not translate");
   constexpr int NS = T.num_sums;
   const AggTuning &tune = agg_tuning();
-  const int nbuf = tune.buffers;
+  const int nbuf = tune.buffers == 0 ? 1 : tune.buffers;   // (0 = chosen per run-time shape: jit_geometry_for)
   size_t lds = 0;
   const int rep_shift = choose_replication(NS, S, static_cast<size_t>(nbuf) * T.dev.tile_bytes, tune, &lds);
   constexpr size_t kMaxLds = 160 * 1024;
@@ -1186,26 +1192,35 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
   }
   // the two geometries the defaults produce — a handful of groups in one family (Q1), and the partitioned path's 32 pieces
   // with 1024-slot tables (10 k groups) — have kernels with those numbers as constants
-#define QSX_LAUNCH_FIXED(S_, REP_, RANGES_)                                                                                        \
+#define QSX_LAUNCH_FIXED(S_, REP_, RANGES_, REG_)                                                                                  \
   do {                                                                                                                             \
     static PerDeviceOnce fixed_attribute_set;                                                                                      \
     const int attr_rc = once_per_device(fixed_attribute_set, [] {                                                                  \
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_kernel<Shape, V, S_, REP_, RANGES_>),        \
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_kernel<Shape, V, S_, REP_, RANGES_, REG_>),  \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));                          \
     });                                                                                                                            \
     if (attr_rc != QSX_OK) return attr_rc;                                                                                         \
-    hipLaunchKernelGGL((agg_hash_shape_fixed_kernel<Shape, V, S_, REP_, RANGES_>), dim3(grid), dim3(kABlock), lds, stream, cp, n,  \
-                       g, pieces);                                                                                                 \
+    hipLaunchKernelGGL((agg_hash_shape_fixed_kernel<Shape, V, S_, REP_, RANGES_, REG_>), dim3(grid), dim3(kABlock), lds, stream,   \
+                       cp, n, g, pieces);                                                                                          \
     return QSX_OK;                                                                                                                 \
   } while (0)
   if (runs && nbuf == 1 && S == 16 && rep_shift == 4 && ranges == 1) {   // the default small-group geometry as constants (Q1)
     static PerDeviceOnce fixed_runs_attribute_set;
     const int rc = once_per_device(fixed_runs_attribute_set, [] {
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_runs_kernel<Shape, V, 16, 4, 1>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_runs_kernel<Shape, V, 16, 4, 1, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+      if (err == hipSuccess) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_fixed_runs_kernel<Shape, V, 16, 4, 1, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+      }
+      return err;
     });
     if (rc != QSX_OK) return rc;
-    hipLaunchKernelGGL((agg_hash_shape_fixed_runs_kernel<Shape, V, 16, 4, 1>), dim3(grid), dim3(kABlock), lds, stream, n, g, pieces);
+    if (reg_groups_enabled()) {
+      hipLaunchKernelGGL((agg_hash_shape_fixed_runs_kernel<Shape, V, 16, 4, 1, true>), dim3(grid), dim3(kABlock), lds, stream, n, g, pieces);
+    } else {
+      hipLaunchKernelGGL((agg_hash_shape_fixed_runs_kernel<Shape, V, 16, 4, 1, false>), dim3(grid), dim3(kABlock), lds, stream, n, g, pieces);
+    }
     return QSX_OK;
   }
   if (runs) {   // a run of blocks (pieces = its table): stripes come from the table, not from the argument list
@@ -1218,8 +1233,11 @@ static int launch_shape_v(const void *const *cols, int num_columns, int64_t n, c
     hipLaunchKernelGGL((agg_hash_shape_runs_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, n, g, S, rep_shift, nbuf, ranges, pieces);
     return QSX_OK;
   }
-  if (nbuf == 1 && S == 16 && rep_shift == 4 && ranges == 1 && pieces == nullptr) QSX_LAUNCH_FIXED(16, 4, 1);
-  if (nbuf == 1 && S == 1024 && rep_shift == 0 && ranges == 32 && pieces != nullptr) QSX_LAUNCH_FIXED(1024, 0, 32);
+  if (nbuf == 1 && S == 16 && rep_shift == 4 && ranges == 1 && pieces == nullptr) {
+    if (reg_groups_enabled()) QSX_LAUNCH_FIXED(16, 4, 1, true);
+    QSX_LAUNCH_FIXED(16, 4, 1, false);
+  }
+  if (nbuf == 1 && S == 1024 && rep_shift == 0 && ranges == 32 && pieces != nullptr) QSX_LAUNCH_FIXED(1024, 0, 32, false);
 #undef QSX_LAUNCH_FIXED
   hipLaunchKernelGGL((agg_hash_shape_kernel<Shape, V>), dim3(grid), dim3(kABlock), lds, stream, cp, n, g, S, rep_shift, nbuf,
                      ranges, pieces);
@@ -1272,7 +1290,15 @@ static JitGeometry jit_geometry_for(const qsx_agg_state *st, int tile_bytes, int
   g.S = slots;
   g.ranges = num_ranges;
   g.nbuf = tune.buffers;
+  if (tune.buffers == 0) {
+    // auto: a second tile buffer when three workgroups per CU still fit with it (small tiles: code stripes, narrow plans) —
+    // the DMA of tile i + 1 then runs under the compute of tile i inside the workgroup as well
+    size_t with_two = 0;
+    choose_replication(NS, g.S, 2 * static_cast<size_t>(tile_bytes), tune, &with_two);
+    g.nbuf = (with_two + 1023) / 1024 * 1024 * 3 <= 160 * 1024 ? 2 : 1;
+  }
   g.rep_shift = choose_replication(NS, g.S, static_cast<size_t>(g.nbuf) * tile_bytes, tune, lds);
+  g.reg_groups = reg_groups_enabled() && g.ranges == 1 ? reg_groups_for(g.S, NS) : 0;
   return g;
 }
 
@@ -1298,7 +1324,9 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
       plan_tile(dev, st->used_columns, kDirBlock, has_filter);
       dense_lds = dense_lds_geometry(st->config.num_entries, st->num_sums, static_cast<size_t>(dev.tile_bytes), st->dense_families.load() == 1);
     }
-    plan_tile(dev, st->used_columns, directory || dense_lds.entries != 0 ? kDirBlock : kABlock * kJitRowsPerThread, has_filter);
+    // (the hash path's shapes keep only the codes of compressed attributes in the tile: their values live in registers)
+    plan_tile(dev, st->used_columns, directory || dense_lds.entries != 0 ? kDirBlock : kABlock * jit_rows_per_thread(), has_filter,
+              /*reg_decode=*/!directory && !st->dense);
     st->jit_tile_bytes[v] = dev.tile_bytes;
     if (dense_lds.entries != 0) {
       // a dense state in LDS (agg_hash_update.hpp, kDense && kDir): the directory kernels' geometry, S = entries
@@ -1354,7 +1382,7 @@ static int upload_null_table(const DevConfig &dc, hipStream_t stream, const unsi
 static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const void *const *cols, const void *const *dicts, int64_t n,
                       const uint64_t *filter, int slots, int num_ranges, const long long *pieces, hipStream_t stream,
                       const DevConfig *call_config = nullptr) {
-  constexpr int TR = kABlock * kJitRowsPerThread;
+  const int TR = kABlock * jit_rows_per_thread();
   constexpr size_t kMaxLds = 160 * 1024;
   const AggTuning &tune = agg_tuning();
   // the geometry the shape was compiled for (constants inside it); a call with another one cannot use it
@@ -1366,6 +1394,11 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const 
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
   if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
+  {
+    // ... and the registers may admit fewer: workgroups beyond what is resident would run as a second, thinner round
+    const int resident = jit_resident_blocks(k, kABlock, lds);
+    if (resident > 0 && per_cu > resident) per_cu = resident;
+  }
   if (per_cu < 1) per_cu = 1;
   const int64_t num_tiles = (n + TR - 1) / TR;
   const int64_t max_grid = static_cast<int64_t>(kCUs) * per_cu;

@@ -18,6 +18,11 @@ __global__ __launch_bounds__(256) void k(int iters, int slots, double *out) {
     if (MODE == 1) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[slot * 64 + lane]), 3ull);
     if (MODE == 2) atomicAdd(reinterpret_cast<unsigned *>(&acc[slot * 64 + lane]), 3u);
     if (MODE == 3) acc[slot * 64 + lane] += 1.5;  // non-atomic read-modify-write (wrong across waves; rate reference)
+    // how the cost of a wave's atomic scales with its active lanes (an exec-masked add: rows folded away, filtered rows)
+    if (MODE == 4 && lane < 32) unsafeAtomicAdd(&acc[slot * 64 + lane], 1.5);          // lower half of the wave
+    if (MODE == 5 && (s & 0x300) == 0) unsafeAtomicAdd(&acc[slot * 64 + lane], 1.5);    // a random quarter of the lanes
+    if (MODE == 6 && (lane & 15) == 0) unsafeAtomicAdd(&acc[slot * 64 + lane], 1.5);    // 4 lanes
+    if (MODE == 7) unsafeAtomicAdd(&acc[slot * 64 + (lane & 15)], 1.5);                 // 16 copies: 4 lanes per column (rep_shift 4)
   }
   __syncthreads();
   if (threadIdx.x < 64) out[blockIdx.x * 64 + threadIdx.x] = acc[threadIdx.x];
@@ -51,6 +56,10 @@ int main() {
     run<1>("ds_add_u64 (lane columns)", b);
     run<2>("ds_add_u32 (lane columns)", b);
     run<3>("ds rmw f64 non-atomic", b);
+    run<4>("ds_add_f64 32 of 64 lanes", b);
+    run<5>("ds_add_f64 random quarter", b);
+    run<6>("ds_add_f64 4 of 64 lanes", b);
+    run<7>("ds_add_f64 16 copies (4 lanes/col)", b);
   }
   return 0;
 }
