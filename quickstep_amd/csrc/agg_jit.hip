@@ -174,7 +174,9 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
     // Q1 without filter or dictionaries then has the kernarg segment of the AOT kernel (472 bytes; the geometry lives in the
     // shape as constants).  (The run-time Q1 shape still measures 1.26 against the AOT kernel's 1.16 ms per 200 M rows with
     // identical launch geometry and arguments: 5 % more instructions in the hipRTC build, cause not established.)
-    << "extern \"C\" __global__ __launch_bounds__(" << kABlock << ") void qsx_jit_agg(ColumnPointers cols, int64_t n,\n"
+    // (geo.waves_per_eu: the occupancy the launcher wants from the registers — LDS would admit that many workgroups per CU)
+    << "extern \"C\" __global__ __launch_bounds__(" << kABlock << (geo.waves_per_eu != 0 ? ", " + std::to_string(geo.waves_per_eu) : std::string())
+    << ") void qsx_jit_agg(ColumnPointers cols, int64_t n,\n"
     << "    " << (dense ? "DenseView" : "HashTableView") << " view, const long long *pieces"
     << (dev.filter_lds_off >= 0 || any_coded || any_nulls ? ", const uint64_t *filter" : "") << (any_coded || any_nulls ? ", const void *const *dicts" : "")
     << nulls_param << ") {\n"
@@ -449,6 +451,22 @@ JitKernel *load_code(const std::string &code) {
   return k;
 }
 
+// A shape built for a requested occupancy (JitGeometry::waves_per_eu) that had to spill registers to scratch for it is
+// rebuilt from `relaxed` (the same shape without the request): scratch traffic costs more than the workgroup it buys.
+JitKernel *settle(JitKernel *k, const std::string &relaxed) {
+  if (k == nullptr || relaxed.empty()) return k;
+  int scratch = 0;
+  if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->function) != hipSuccess) {
+    (void)hipGetLastError();
+    return k;
+  }
+  if (scratch == 0) return k;
+  (void)hipModuleUnload(k->module);
+  delete k;
+  std::string cached;
+  return load_cached_code(relaxed, &cached) ? load_code(cached) : compile(relaxed);
+}
+
 }  // namespace
 
 // Source text only (tests / offline inspection; needs no device).
@@ -459,6 +477,12 @@ std::string jit_agg_source(const DevConfig &dev, int num_sums, bool dense, const
 JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geometry, bool synchronous) {
   if (!jit_enabled()) return nullptr;
   const std::string source = make_source(dev, num_sums, dense, geometry);   // a filter is part of dev (filter_lds_off)
+  std::string relaxed;
+  if (geometry.waves_per_eu != 0) {
+    JitGeometry without = geometry;
+    without.waves_per_eu = 0;
+    relaxed = make_source(dev, num_sums, dense, without);
+  }
   JitRequest *r = nullptr;
   bool mine = false;
   int device = 0;
@@ -476,7 +500,7 @@ JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, cons
       std::string cached;
       if (!synchronous && load_cached_code(source, &cached)) {
         // on disk (QSX_JIT_CACHE_DIR): a file read and a module load, milliseconds — ready before the first launch
-        JitKernel *k = load_code(cached);
+        JitKernel *k = settle(load_code(cached), relaxed);
         r->kernel = k;
         r->state.store(k != nullptr ? 1 : -1, std::memory_order_release);
         mine = false;
@@ -487,9 +511,9 @@ JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, cons
           std::atexit(join_compile_threads);
           hooked = true;
         }
-        compile_threads().emplace_back([r, source, device]() {
+        compile_threads().emplace_back([r, source, relaxed, device]() {
           (void)hipSetDevice(device);
-          JitKernel *k = compile(source);
+          JitKernel *k = settle(compile(source), relaxed);
           r->kernel = k;
           r->state.store(k != nullptr ? 1 : -1, std::memory_order_release);
         });
@@ -497,7 +521,7 @@ JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, cons
     }
   }
   if (mine && synchronous) {
-    JitKernel *k = compile(source);
+    JitKernel *k = settle(compile(source), relaxed);
     r->kernel = k;
     r->state.store(k != nullptr ? 1 : -1, std::memory_order_release);
   } else if (synchronous) {

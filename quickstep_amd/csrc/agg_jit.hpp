@@ -33,6 +33,8 @@ struct JitGeometry {
   int dir_gids;   // != 0: the group-directory variant (agg_common.hpp DirView) with that many LDS accumulators per aggregate
   int runs;       // != 0: the rows are a run of blocks (agg_common.hpp BlockRunView behind the `pieces` argument)
   int reg_groups; // != 0: that many groups per wave accumulate in registers (agg_hash_update.hpp, REG; small hash tables only)
+  int waves_per_eu;   // != 0: the waves per SIMD the shape is to be built for (LDS admits that many workgroups per CU; a shape
+                      // that spills for it is rebuilt without)
 };
 JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geometry, bool synchronous);
 // 0: still compiling, 1: ready (*kernel set), -1: failed (hipRTC error: the interpreter stays in use)

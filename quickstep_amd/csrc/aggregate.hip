@@ -809,6 +809,7 @@ struct AggTuning {
   int buffers;           // 1 or 2 tile buffers per workgroup
   int acc_kib;           // LDS budget of the replicated accumulators
   int max_blocks_per_cu;
+  int jit_waves_per_eu;  // run-time shapes whose LDS admits >= 5 workgroups per CU are built for this many waves per SIMD (0: do not ask)
 };
 // Small hash tables of plan shapes: per-wave register accumulators (agg_hash_update.hpp, REG).  Measured slower than the LDS
 // atomics they replace: off unless QSX_AGG_REG_GROUPS=1 (read per call: the parity tests run both).
@@ -820,7 +821,8 @@ static const AggTuning &agg_tuning() {
   static AggTuning t = []() {
     // measured on MI355X (tools/agg_sweep.sh, 600 M Q1 rows): shape kernel V=4, 1 buffer, 16 KiB
     // accumulators, 4 workgroups/CU = 3.47 ms; interpreter V=2 = 10.9 ms
-    AggTuning v{2, 4, 1, 16, 4};
+    AggTuning v{2, 4, 1, 16, 4, 5};
+    if (const char *e = getenv("QSX_AGG_JIT_WAVES")) v.jit_waves_per_eu = atoi(e) >= 0 && atoi(e) <= 8 ? atoi(e) : 5;
     if (const char *e = getenv("QSX_AGG_ROWS_PER_THREAD")) v.rows_per_thread = v.shape_rows_per_thread = atoi(e) == 4 ? 4 : 2;
     if (const char *e = getenv("QSX_AGG_BUFFERS")) v.buffers = atoi(e) == 2 ? 2 : (atoi(e) == 0 ? 0 : 1);   // (0: per shape, jit_geometry_for)
     if (const char *e = getenv("QSX_AGG_ACC_KIB")) v.acc_kib = atoi(e) > 0 ? atoi(e) : 12;
@@ -1299,6 +1301,11 @@ static JitGeometry jit_geometry_for(const qsx_agg_state *st, int tile_bytes, int
   }
   g.rep_shift = choose_replication(NS, g.S, static_cast<size_t>(g.nbuf) * tile_bytes, tune, lds);
   g.reg_groups = reg_groups_enabled() && g.ranges == 1 ? reg_groups_for(g.S, NS) : 0;
+  // Small tiles (code stripes, narrow plans): LDS admits five or more workgroups per CU, the shape's ~100 registers four.
+  // The kernel's phases (tile copy, argument reads, LDS atomics) overlap across workgroups only, so one more resident
+  // workgroup is worth asking the register allocator for (Q1 over codes: 107 -> 96 registers without spilling).
+  const int by_lds = static_cast<int>(160 * 1024 / ((*lds + 1023) / 1024 * 1024));
+  g.waves_per_eu = by_lds >= 5 && g.reg_groups == 0 && tune.jit_waves_per_eu != 0 ? tune.jit_waves_per_eu : 0;
   return g;
 }
 
@@ -1393,7 +1400,8 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const 
   const int tile_bytes = st->jit_tile_bytes[variant];
   if (lds > kMaxLds) return QSX_ERR_CAPACITY;
   int per_cu = static_cast<int>(kMaxLds / ((lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
-  if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
+  const int most = geo.waves_per_eu > tune.max_blocks_per_cu ? geo.waves_per_eu : tune.max_blocks_per_cu;
+  if (per_cu > most) per_cu = most;
   {
     // ... and the registers may admit fewer: workgroups beyond what is resident would run as a second, thinner round
     const int resident = jit_resident_blocks(k, kABlock, lds);
