@@ -844,6 +844,15 @@ def main():
             print(json.dumps({"metric": METRIC, "value": None, "dry_run": True, "n_gpus": args.gpus, "world_size_seen": world_seen,
                               "self_launched": os.environ.get("QSX_BENCH_SELF_LAUNCHED") == "1", "config": {"workload": args.config}}), flush=True)
         return
+    # QSX_BENCH_SHARED_GPU=1: a rehearsal of the N > 1 path on a box with ONE GPU — every rank works on cuda:0, the process
+    # group is gloo (barriers, the max over ranks, the checks) and the exchange steps go through the C ABI over the loopback
+    # stand-in for RCCL (QSX_RCCL_LIBRARY=tests/cpp/bin/libloopback_rccl.so, --transport capi).  It executes every line of the
+    # multi-rank code with the product's kernels; its throughput says nothing about scaling, and the line says so.
+    shared_gpu = os.environ.get("QSX_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        if args.transport != "capi" or not os.environ.get("QSX_RCCL_LIBRARY"):
+            raise SystemExit("QSX_BENCH_SHARED_GPU=1 needs --transport capi and QSX_RCCL_LIBRARY (the loopback library)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     ctx.dev = dev = torch.device("cuda", local_rank)
     if capi.device_count() < 1:
@@ -861,7 +870,10 @@ def main():
                 sock.bind(("127.0.0.1", 0))
                 port = sock.getsockname()[1]
             os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1"})
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     ctx.group = None
     if ctx.distributed and args.transport == "capi":
         from quickstep_amd import distributed as qd
@@ -871,6 +883,8 @@ def main():
     line["world_size_seen"] = dist.get_world_size() if ctx.distributed else 1      # what the RCCL process group reports
     line["self_launched"] = os.environ.get("QSX_BENCH_SELF_LAUNCHED") == "1"
     line["transport"] = args.transport if ctx.distributed else None
+    if shared_gpu:
+        line["rehearsal"] = "ranks share cuda:0 over the loopback transport: the N > 1 code path, not a scaling number"
     if ctx.group is not None:
         ctx.group.comm.close()
     if rank == 0 and world == 1 and args.config == "headline" and not args.no_operators:

@@ -48,3 +48,26 @@ def test_loopback_transport_protocol_selftest():
     assert os.path.exists(exe), "make -C quickstep_amd/host builds it"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "loopback selftest ok" in r.stdout, r.stdout + r.stderr
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["headline", "c4", "c5"])
+def test_two_ranks_rehearsal_on_one_gpu(config):
+    """`python bench.py --gpus 2` end to end on the one GPU of the test box: the self-launch, two rank processes, the
+    product's kernels, every exchange step of the configuration through the C ABI over the loopback stand-in for RCCL
+    (QSX_BENCH_SHARED_GPU=1: both ranks on cuda:0, gloo for barriers and checks).  bench.py checks the results of every
+    configuration itself (pair lists, group counts, Q3's top 10 against a torch evaluation) and exits non-zero otherwise."""
+    lib = os.path.join(ROOT, "tests", "cpp", "bin", "libloopback_rccl.so")
+    assert os.path.exists(lib), "make -C quickstep_amd/host builds it"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"QSX_BENCH_SHARED_GPU": "1", "QSX_RCCL_LIBRARY": lib})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "capi", "--config", config,
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric')][-1])
+    assert line["n_gpus"] == 2 and line["world_size_seen"] == 2 and line["self_launched"] is True
+    assert line["transport"] == "capi" and "rehearsal" in line and line["value"] > 0
+    assert line["roofline"]["frac"] > 0 and line["scaling"] == "weak"
