@@ -484,7 +484,7 @@ def run_headline(ctx, args):
                                      else "join-key all-to-all shuffle of both sides") + " + partial-aggregate all-gather merge"),
         },
         "roofline": {
-            "kernel": "agg_hash_shape_fixed_kernel<ShapeTpchQ1,4,16,4,1> (qsx_agg_update; AOT plan shape of the Q1 aggregation with its launch geometry as constants, same body as the interpreter kernel)", "bound": "hbm",
+            "kernel": "agg_hash_shape_fixed_kernel<ShapeTpchQ1,4,16,4,1,false> (qsx_agg_update; AOT plan shape of the Q1 aggregation with its launch geometry as constants, same body as the interpreter kernel)", "bound": "hbm",
             "achieved": agg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg_gbs / HBM_PEAK_GBS,
             "algorithmic_bytes_per_row": Q1_BYTES_PER_ROW, "rows_per_launch": args.agg_rows,
             "avg_launch_ms": phase_ms["aggregate_update"], "traffic": None,

@@ -74,7 +74,12 @@ res["coded_without_dictionaries_ms"] = timed(run_truncated)
 ck, cv, _, cg = coded.finalize(dev, capacity=16)
 qty, disc, tax = qty_d[qty_c.long()], disc_d[disc_c.long()], tax_d[tax_c.long()]
 del qty_c, disc_c, tax_c
+# QSX_PROBE_PLAIN_RUNTIME_SHAPE=1: the plain state takes its run-time shape instead of the AOT one (so that QSX_JIT_OPTIONS
+# reach it: tools/agg_coded_exp.sh)
+if os.environ.get("QSX_PROBE_PLAIN_RUNTIME_SHAPE") == "1":
+    os.environ["QSX_AGG_NO_SPECIALIZE"] = "1"
 plain = capi.AggState(plain_cfg)
+os.environ.pop("QSX_AGG_NO_SPECIALIZE", None)
 cols_p = [k1, k2, qty, price, disc, tax]
 
 

@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNEL = "agg_hash_shape_fixed_kernel<qsx::ShapeTpchQ1, 4, 16, 4, 1>"
+KERNEL = "agg_hash_shape_fixed_kernel<qsx::ShapeTpchQ1, 4, 16, 4, 1, false>"   # (the last argument: no per-wave register groups)
 PROBE_KERNEL = "dense_probe_kernel<int, 0, false>"
 
 
