@@ -98,6 +98,18 @@ __device__ __forceinline__ bool row_in_filter(const uint64_t *filter, int64_t ro
   return filter == nullptr || ((filter[row >> 6] >> (63 - (row & 63))) & 1u);
 }
 
+// A bucket's 16 fingerprints for an INSERT: read at L2 (two relaxed agent-scope loads), not through this CU's L1.  A plain
+// load keeps serving the line the CU read first — eight buckets, mostly empty then — while the other CUs fill them: at
+// load 0.8 every later insert from this CU started its compare-and-swaps at a slot long taken and walked the bucket one
+// failed atomic at a time (1 M keys: 0.35 ms, eight times the atomic units' rate).  Still a hint: a slot claimed between this
+// read and the claim below costs one failed compare-and-swap, as before.
+__device__ __forceinline__ uint4 load_fingerprints_fresh(const unsigned char *bucket_fp) {
+  const unsigned long long *p = reinterpret_cast<const unsigned long long *>(bucket_fp);
+  const unsigned long long lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return uint4{static_cast<uint32_t>(lo), static_cast<uint32_t>(lo >> 32), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
+}
+
 __device__ __forceinline__ void insert_entry(const TableView &t, int32_t key, uint32_t tid) {
   uint64_t *slots = static_cast<uint64_t *>(t.slots);
   const uint64_t packed = (static_cast<uint64_t>(tid) << 32) | static_cast<uint32_t>(key);
@@ -109,7 +121,7 @@ __device__ __forceinline__ void insert_entry(const TableView &t, int32_t key, ui
     // (atomic load: slots are published by compare-and-swap at L2); an apparently empty slot is claimed by compare-and-swap,
     // and a claim that fails shows the occupant.  Every occupant with this key is therefore seen by the later of the two
     // inserts — probes of a table whose flag stays clear may stop at their first match.
-    const uint4 w = *reinterpret_cast<const uint4 *>(t.fp + b * kBucketSlots);
+    const uint4 w = load_fingerprints_fresh(t.fp + b * kBucketSlots);
     const uint32_t m = bucket_masks(w, f);
     for (uint32_t same = m & 0xFFFFu; same != 0u; same &= same - 1u) {
       const unsigned long long old = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&slots[b * kBucketSlots + (__ffs(same) - 1)]),
@@ -138,7 +150,7 @@ __device__ __forceinline__ void insert_entry(const TableView &t, int64_t key, ui
     // its tid word, the key is published with a plain store and only read by probe kernels launched after the build
     // (BuildHash -> HashJoin is a pipeline breaker, ExecutionGenerator.cpp:1110-1124).  Keys are not compared here: probes
     // of a LONG table always walk on (no "unique" shortcut).
-    const uint4 w = *reinterpret_cast<const uint4 *>(t.fp + b * kBucketSlots);
+    const uint4 w = load_fingerprints_fresh(t.fp + b * kBucketSlots);
     const uint32_t empty = bucket_masks(w, f) >> 16;
     for (int c = empty != 0u ? __ffs(empty) - 1 : kBucketSlots; c < kBucketSlots; ++c) {
       LongEntry *e = &slots[b * kBucketSlots + c];
@@ -165,16 +177,33 @@ struct KeyBounds {
     lo = u < lo ? u : lo;
     hi_inv = ~u < hi_inv ? ~u : hi_inv;
   }
-  __device__ __forceinline__ void publish(unsigned long long *control) {
+  // The workgroup's bounds and its count of inserted rows go to the control words ONCE per workgroup, and a bound only when
+  // it still moves the word (a relaxed read first: both words only shrink, a stale read errs towards sending).  Same-address
+  // atomics complete one at a time device-wide, ~12 ns each: three per wave were 0.14 of the 0.31 ms a 1 M-key build took.
+  __device__ __forceinline__ void publish(unsigned long long *control, unsigned long long inserted) {
+    __shared__ unsigned long long wg[3];   // count, min, ~max
+    if (threadIdx.x == 0) {
+      wg[0] = 0;
+      wg[1] = wg[2] = ~0ull;
+    }
+    __syncthreads();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned long long a = __shfl_xor(lo, o, kWave), b = __shfl_xor(hi_inv, o, kWave);
       lo = a < lo ? a : lo;
       hi_inv = b < hi_inv ? b : hi_inv;
     }
-    if (lane_id() == 0 && lo != ~0ull) {
-      atomicMin(control + 4, lo);
-      atomicMin(control + 5, hi_inv);
+    inserted = wave_reduce_add(inserted);
+    if (lane_id() == 0 && inserted != 0) {
+      atomicAdd(&wg[0], inserted);
+      atomicMin(&wg[1], lo);
+      atomicMin(&wg[2], hi_inv);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && wg[0] != 0) {
+      atomicAdd(control, wg[0]);
+      if (wg[1] < __hip_atomic_load(control + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(control + 4, wg[1]);
+      if (wg[2] < __hip_atomic_load(control + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(control + 5, wg[2]);
     }
   }
 };
@@ -194,9 +223,7 @@ __global__ __launch_bounds__(kJBlock) void build_kernel(TableView t, const KeyT 
     bounds.add(key);
     ++inserted;
   }
-  inserted = wave_reduce_add(inserted);
-  if (lane_id() == 0 && inserted != 0) atomicAdd(entries, inserted);
-  bounds.publish(entries);
+  bounds.publish(entries, inserted);
 }
 // The build side as a run of blocks (qsx_join_build_blocks): a wave takes groups of kBuildTile rows of ONE block.
 template <typename KeyT>
@@ -223,9 +250,7 @@ __global__ __launch_bounds__(kJBlock) void build_runs_kernel(TableView t, const 
       ++inserted;
     }
   }
-  inserted = wave_reduce_add(inserted);
-  if (lane == 0 && inserted != 0) atomicAdd(entries, inserted);
-  bounds.publish(entries);
+  bounds.publish(entries, inserted);
 }
 
 // Re-insert every entry of an old table into a bigger one (resize).
