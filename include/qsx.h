@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
-#define QSX_ABI_VERSION 11
+#define QSX_ABI_VERSION 12
 
 typedef void *qsx_stream_t;
 
@@ -743,6 +743,14 @@ int qsx_agg_update_nullable(qsx_agg_state_t *state, const void *const *cols, con
  * relational_operators/HashJoinOperator.cpp:529-541, followed by aggregateBlock). */
 int qsx_agg_update_coded(qsx_agg_state_t *state, const void *const *cols, const void *const *dictionaries_dev,
                          int64_t n, const uint64_t *filter_dev, qsx_stream_t stream);
+
+/* qsx_agg_update_coded with the dictionaries' sizes: dictionary_entries[c] = number of entries of dictionaries_dev[c] (0 or a
+ * NULL array: unknown — the call behaves exactly like qsx_agg_update_coded).  A reference block knows them
+ * (compression/CompressionDictionary.hpp:46-58: the dictionary begins with its number of codes).  With the size in hand the
+ * plan shapes copy dictionaries of up to 64 entries into LDS once per workgroup and decode from there instead of through the
+ * vector memory path (Q1 over lineitem: quantity 50, discount 11, tax 9 entries). */
+int qsx_agg_update_coded_sized(qsx_agg_state_t *state, const void *const *cols, const void *const *dictionaries_dev,
+                               const int32_t *dictionary_entries, int64_t n, const uint64_t *filter_dev, qsx_stream_t stream);
 
 /* BuildAggregationExistenceMapWorkOrder::execute (relational_operators/
  * BuildAggregationExistenceMapOperator.cpp:50-67, 177-208): sets the existence bit of every (selected)

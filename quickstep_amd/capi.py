@@ -118,6 +118,7 @@ _SIGNATURES = {
     "qsx_agg_update_coded_blocks": (_int, [_vp, _int, C.POINTER(_i64), _pp, _pp, _pp, _vp]),
     "qsx_agg_mark_existence": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "qsx_agg_update_coded": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
+    "qsx_agg_update_coded_sized": (_int, [_vp, _pp, _pp, C.POINTER(C.c_int32), _i64, _vp, _vp]),
     "qsx_agg_update_nullable": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
     "qsx_agg_merge": (_int, [_vp, _vp, _vp]),
     "qsx_agg_state_export_bytes": (_int, [_vp, C.POINTER(_sz), _vp]),
@@ -846,11 +847,16 @@ class AggState:
         _check(_lib.qsx_agg_update_nullable(self._h, _ptr_array(cols), nulls, n, _ptr(filter_bitmap), _stream(stream)),
                "qsx_agg_update_nullable")
 
-    def update_coded(self, cols, dictionaries, n=None, filter_bitmap=None, stream=None):
+    def update_coded(self, cols, dictionaries, n=None, filter_bitmap=None, stream=None, sized=True):
         """cols[c] = code stripe for columns with column_code_width != 0; dictionaries[c] = dictionary tensor or None."""
         if n is None:
             n = cols[0].numel()
         dicts = (C.c_void_p * len(cols))(*[d.data_ptr() if d is not None else None for d in dictionaries])
+        if sized:      # the dictionaries' sizes travel with the call (small ones are then decoded from LDS)
+            entries = (C.c_int32 * len(cols))(*[d.numel() if d is not None else 0 for d in dictionaries])
+            _check(_lib.qsx_agg_update_coded_sized(self._h, _ptr_array(cols), dicts, entries, n, _ptr(filter_bitmap), _stream(stream)),
+                   "qsx_agg_update_coded_sized")
+            return
         _check(_lib.qsx_agg_update_coded(self._h, _ptr_array(cols), dicts, n, _ptr(filter_bitmap), _stream(stream)),
                "qsx_agg_update_coded")
 

@@ -194,16 +194,28 @@ __device__ __forceinline__ void decode_tile_codes(const DevConfig &c, const void
 // Compressed attributes of a plan shape whose tile holds only the codes (plan_tile reg_decode, lds_off = kRegDecoded): the
 // values of the thread's V rows live in registers — the column's own type, zero-extended into a 64-bit container.  With a
 // static configuration every index below is a constant after unrolling, and only the columns the plan reads survive.
+// Dictionaries of up to kDictLdsEntries entries whose size the caller named (qsx_agg_update_coded_sized) are copied into LDS
+// once per workgroup (plan shapes of the hash path, one launch over one set of stripes) and read from there: the three
+// 8-byte gathers per row of Q1 over lineitem's codes cost 0.3 ms per 600 M rows through the vector memory path.
+constexpr int kDictLdsEntries = 64;
+// (the sizes sit right behind the QSX_MAX_COLUMNS dictionary pointers of the call's table: aggregate.hip DictTable)
+__device__ __forceinline__ int dict_entries_behind(const void *const *dicts, int col) {
+  return reinterpret_cast<const int *>(as_global(dicts) + QSX_MAX_COLUMNS)[col];
+}
 template <int V>
 struct DecodedRows {
   unsigned long long raw[QSX_MAX_COLUMNS][V];
 };
+// l_dict / dict_in_lds: the LDS copies (kDictLdsEntries 8-byte entries per decoded column, in column order) and which
+// decoded columns have one (bit k = the k-th decoded column); nullptr / 0: every dictionary is read from memory.
 template <int V, int BLOCK = kABlock>
 __device__ __forceinline__ void decode_rows(const DevConfig &c, const void *const *dicts, const char *tile, int trow, int rows,
-                                            DecodedRows<V> &dec) {
+                                            DecodedRows<V> &dec, const unsigned long long *l_dict = nullptr, unsigned dict_in_lds = 0) {
+  int k = -1;   // (a constant per column after unrolling)
 #pragma unroll
   for (int col = 0; col < QSX_MAX_COLUMNS; ++col) {
     if (col >= c.num_columns || c.lds_off[col] != kRegDecoded) continue;
+    ++k;
     const char *codes = tile + c.code_off[col];
     const void *dict = dicts != nullptr ? as_global(dicts[col]) : nullptr;
     uint32_t code[V];
@@ -218,7 +230,10 @@ __device__ __forceinline__ void decode_rows(const DevConfig &c, const void *cons
       if (r >= rows) code[v] = 0;   // stale LDS behind a partial tile must not index the dictionary
     }
     const bool narrow = c.column_type[col] == QSX_INT || c.column_type[col] == QSX_FLOAT;
-    if (dict != nullptr) {
+    if (((dict_in_lds >> k) & 1u) != 0) {   // (wave-uniform)
+#pragma unroll
+      for (int v = 0; v < V; ++v) dec.raw[col][v] = l_dict[k * kDictLdsEntries + (code[v] < kDictLdsEntries ? code[v] : 0u)];
+    } else if (dict != nullptr) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         dec.raw[col][v] = narrow ? static_cast<unsigned long long>(static_cast<const uint32_t *>(dict)[code[v]])
@@ -723,6 +738,28 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
   unsigned long long *l_ctl = l_acc + static_cast<size_t>(NS + 1) * plane;
   unsigned long long *s_flush_stat = l_ctl + 3;
   if (can_flush && threadIdx.x < kHashCtlWords) l_ctl[threadIdx.x] = 0;
+  // small dictionaries of known size -> LDS, behind the control words (the first barrier of the tile loop publishes them)
+  unsigned long long *l_dict = l_ctl + kHashCtlWords;
+  unsigned dict_in_lds = 0;
+  if constexpr (kStatic && !kDense && !kDir && !kDirBuild && !kRuns) {
+    if (dicts != nullptr) {
+      int k = -1;
+#pragma unroll
+      for (int col = 0; col < QSX_MAX_COLUMNS; ++col) {
+        if (col >= c.num_columns || c.lds_off[col] != kRegDecoded) continue;
+        ++k;
+        const void *dict = as_global(dicts[col]);
+        const int entries = __builtin_amdgcn_readfirstlane(dict_entries_behind(dicts, col));
+        if (dict == nullptr || entries <= 0 || entries > kDictLdsEntries) continue;
+        dict_in_lds |= 1u << k;
+        const bool narrow = c.column_type[col] == QSX_INT || c.column_type[col] == QSX_FLOAT;
+        for (int i = threadIdx.x; i < entries; i += BLOCK) {
+          l_dict[k * kDictLdsEntries + i] = narrow ? static_cast<unsigned long long>(static_cast<const uint32_t *>(dict)[i])
+                                                   : static_cast<const unsigned long long *>(dict)[i];
+        }
+      }
+    }
+  }
   int tile_count = 0;
   static_assert(REG == 0 || (kStatic && !kDense && !kDir && !kDirBuild), "register groups: plan shapes of the hash path only");
   // register groups (REG > 0): key code and LDS table slot per entry (wave-uniform), row count and accumulators per lane
@@ -843,7 +880,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     DecodedRows<V> decoded;
     const DecodedRows<V> *dec = nullptr;
     if constexpr (kStatic) {
-      decode_rows<V, BLOCK>(c, kRuns ? here.dicts : dicts, tile, trow, rows, decoded);
+      decode_rows<V, BLOCK>(c, kRuns ? here.dicts : dicts, tile, trow, rows, decoded, l_dict, dict_in_lds);
       dec = &decoded;
     }
 

@@ -541,7 +541,12 @@ __global__ __launch_bounds__(1024) void adjacent_equal_kernel(const KeyT *__rest
 
 struct DictTable {
   const void *p[QSX_MAX_COLUMNS];
+  int entries[QSX_MAX_COLUMNS];   // entries of p[c] when the caller said so (qsx_agg_update_coded_sized), else 0; read by the plan
+                                  // shapes right behind the pointers (agg_hash_update.hpp dict_entries_behind)
 };
+// The dictionary sizes of the call in progress on this thread (qsx_agg_update_coded_sized sets them around agg_update, which
+// enqueues its launches before it returns; the launchers copy them into the call's DictTable).
+static thread_local const int32_t *tl_dictionary_entries = nullptr;
 struct NullTable {   // the null bitmaps of one call by null slot (DevConfig::null_column), for the run-time plan shapes
   const unsigned long long *p[QSX_MAX_COLUMNS];
 };
@@ -1292,14 +1297,21 @@ static JitGeometry jit_geometry_for(const qsx_agg_state *st, int tile_bytes, int
   g.S = slots;
   g.ranges = num_ranges;
   g.nbuf = tune.buffers;
+  // (room for the dictionaries the shape keeps in LDS: kDictLdsEntries 8-byte entries per compressed attribute it decodes
+  // into registers, behind the control words — agg_hash_update.hpp)
+  int decoded_columns = 0;
+  for (int col = 0; col < st->dev.num_columns; ++col) {
+    decoded_columns += st->dev.code_width[col] != 0 && ((st->used_columns >> col) & 1u) != 0 ? 1 : 0;
+  }
+  const size_t dict_bytes = static_cast<size_t>(decoded_columns) * kDictLdsEntries * 8;
   if (tune.buffers == 0) {
     // auto: a second tile buffer when three workgroups per CU still fit with it (small tiles: code stripes, narrow plans) —
     // the DMA of tile i + 1 then runs under the compute of tile i inside the workgroup as well
     size_t with_two = 0;
-    choose_replication(NS, g.S, 2 * static_cast<size_t>(tile_bytes), tune, &with_two);
+    choose_replication(NS, g.S, 2 * static_cast<size_t>(tile_bytes) + dict_bytes, tune, &with_two);
     g.nbuf = (with_two + 1023) / 1024 * 1024 * 3 <= 160 * 1024 ? 2 : 1;
   }
-  g.rep_shift = choose_replication(NS, g.S, static_cast<size_t>(g.nbuf) * tile_bytes, tune, lds);
+  g.rep_shift = choose_replication(NS, g.S, static_cast<size_t>(g.nbuf) * tile_bytes + dict_bytes, tune, lds);
   g.reg_groups = reg_groups_enabled() && g.ranges == 1 ? reg_groups_for(g.S, NS) : 0;
   // Small tiles (code stripes, narrow plans): LDS admits five or more workgroups per CU, the shape's ~100 registers four.
   // The kernel's phases (tile copy, argument reads, LDS atomics) overlap across workgroups only, so one more resident
@@ -1425,7 +1437,10 @@ static int launch_jit(qsx_agg_state *st, const JitKernel *k, int variant, const 
   const void **dict_table = nullptr;
   if (st->has_coded_columns) {
     DictTable host_table;
-    for (int i = 0; i < QSX_MAX_COLUMNS; ++i) host_table.p[i] = i < st->config.num_columns ? dicts[i] : nullptr;
+    for (int i = 0; i < QSX_MAX_COLUMNS; ++i) {
+      host_table.p[i] = i < st->config.num_columns ? dicts[i] : nullptr;
+      host_table.entries[i] = i < st->config.num_columns && tl_dictionary_entries != nullptr && dicts[i] != nullptr ? tl_dictionary_entries[i] : 0;
+    }
     DictTable *slot = device_slot<DictTable>(stream);
     if (slot == nullptr) return QSX_ERR_OUT_OF_MEMORY;
     hipLaunchKernelGGL(store_struct_kernel<DictTable>, dim3(1), dim3(64), 0, stream, host_table, slot);
@@ -1452,7 +1467,10 @@ static int launch_jit_dir(qsx_agg_state *st, const JitKernel *k, int variant, co
   const void **dict_table = nullptr;
   if (st->has_coded_columns) {
     DictTable host_table;
-    for (int i = 0; i < QSX_MAX_COLUMNS; ++i) host_table.p[i] = i < st->config.num_columns ? dicts[i] : nullptr;
+    for (int i = 0; i < QSX_MAX_COLUMNS; ++i) {
+      host_table.p[i] = i < st->config.num_columns ? dicts[i] : nullptr;
+      host_table.entries[i] = i < st->config.num_columns && tl_dictionary_entries != nullptr && dicts[i] != nullptr ? tl_dictionary_entries[i] : 0;
+    }
     DictTable *slot = device_slot<DictTable>(stream);
     if (slot == nullptr) return QSX_ERR_OUT_OF_MEMORY;
     hipLaunchKernelGGL(store_struct_kernel<DictTable>, dim3(1), dim3(64), 0, stream, host_table, slot);
@@ -2243,6 +2261,19 @@ int qsx_agg_update_coded_blocks(qsx_agg_state_t *st, int num_blocks, const int64
 int qsx_agg_update_coded(qsx_agg_state_t *st, const void *const *cols, const void *const *dictionaries_dev, int64_t n,
                          const uint64_t *filter_dev, qsx_stream_t stream) {
   return agg_update(st, cols, dictionaries_dev, n, filter_dev, stream);
+}
+
+int qsx_agg_update_coded_sized(qsx_agg_state_t *st, const void *const *cols, const void *const *dictionaries_dev,
+                               const int32_t *dictionary_entries, int64_t n, const uint64_t *filter_dev, qsx_stream_t stream) {
+  if (st != nullptr && dictionary_entries != nullptr) {
+    for (int i = 0; i < st->config.num_columns; ++i) {
+      if (dictionary_entries[i] < 0) return QSX_ERR_INVALID_ARGUMENT;
+    }
+  }
+  tl_dictionary_entries = dictionaries_dev != nullptr ? dictionary_entries : nullptr;
+  const int rc = agg_update(st, cols, dictionaries_dev, n, filter_dev, stream);
+  tl_dictionary_entries = nullptr;
+  return rc;
 }
 
 // Test hook (not part of include/qsx.h): where the run-time plan shape of a state stands.

@@ -553,12 +553,15 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
     if (use_coded) {
       const void *cols[QSX_MAX_COLUMNS];
       const void *dicts[QSX_MAX_COLUMNS];
+      std::int32_t dict_entries[QSX_MAX_COLUMNS] = {};
       for (std::size_t i = 0; i < column_attr_.size(); ++i) {
         const CompressedAttribute *ca = code_width[i] != 0 ? block.compressedAttribute(column_attr_[i]) : nullptr;
         cols[i] = ca != nullptr ? ca->codes : block.stripe(column_attr_[i]);
         dicts[i] = ca != nullptr && ca->kind == CompressedAttribute::kDictionary ? ca->dictionary : nullptr;
+        dict_entries[i] = dicts[i] != nullptr ? static_cast<std::int32_t>(ca->num_codes) : 0;
       }
-      CheckStatus(qsx_agg_update_coded(coded_state_, cols, dicts, n, lip_filter, CurrentStream()), "qsx_agg_update_coded");
+      CheckStatus(qsx_agg_update_coded_sized(coded_state_, cols, dicts, dict_entries, n, lip_filter, CurrentStream()),
+                  "qsx_agg_update_coded_sized");
       ++coded_blocks_;
       CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
       return;

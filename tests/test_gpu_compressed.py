@@ -173,13 +173,15 @@ def test_q1_over_compressed_attributes_matches_oracle(capi, oracle, dev, jit, mo
         st.update([to_dev(c[:10], dev) for c in code_cols], 10)
 
 
-@pytest.mark.parametrize("kernel", ["interpreter", "plan_shape", "plan_shape_register_groups"])
+@pytest.mark.parametrize("kernel", ["interpreter", "plan_shape", "plan_shape_unsized_dictionaries", "plan_shape_register_groups"])
 def test_group_by_compressed_keys_matches_oracle(capi, oracle, dev, kernel, monkeypatch):
     """Hash-strategy states whose GROUP BY attributes themselves arrive as codes (a dictionary-coded INT, a truncated LONG)
     next to coded arguments: the plan shapes keep only the code stripes in the tile and decode a thread's rows into
     registers (agg_hash_update.hpp DecodedRows) — key packing, the predicate and the aggregates' arguments all read them
     there; the interpreter decodes into LDS slots.  Also with per-wave register accumulators (QSX_AGG_REG_GROUPS=1), a
-    handful of groups and then more groups than the registers keep."""
+    handful of groups and then more groups than the registers keep.  The dictionaries' sizes travel with the call
+    (qsx_agg_update_coded_sized): those of up to 64 entries are decoded from LDS (k1, quantity), the 150-entry one and — in
+    the unsized variant, plain qsx_agg_update_coded — all of them through memory."""
     monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", str(1 << 60) if kernel == "interpreter" else "0")
     monkeypatch.setenv("QSX_AGG_REG_GROUPS", "1" if kernel == "plan_shape_register_groups" else "0")
     rng = np.random.default_rng(91)
@@ -191,17 +193,20 @@ def test_group_by_compressed_keys_matches_oracle(capi, oracle, dev, kernel, monk
         qty = rng.integers(1, 51, size=n).astype(np.float64)
         cnt = rng.integers(0, 200, size=n).astype(np.int32)
         price = np.round(rng.uniform(900, 105000, size=n), 2)
-        cols = [k1, k2, qty, cnt, price]
-        comp = [oracle.CompressedColumn(c) for c in cols[:4]] + [None]
+        steps = rng.integers(0, 150, size=n) * 0.5 - 7.0                                                         # a 150-entry dictionary
+        cols = [k1, k2, qty, cnt, price, steps]
+        comp = [oracle.CompressedColumn(c) for c in cols[:4]] + [None, oracle.CompressedColumn(steps)]
         widths = [c.code_width if c is not None and c.kind != 0 else 0 for c in comp]
         assert widths[0] == 1 and comp[0].dictionary is not None and widths[1] == 1 and comp[1].dictionary is None and widths[4] == 0
-        layout = [(T.INT, None), (T.LONG, None), (T.DOUBLE, None), (T.INT, None), (T.DOUBLE, None)]
+        assert widths[5] == 1 and comp[5].dictionary is not None and comp[5].dictionary.size == 150 and comp[2].dictionary.size == 50
+        layout = [(T.INT, None), (T.LONG, None), (T.DOUBLE, None), (T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None)]
         kw = dict(keys=[0, 1], instrs=[(T.EX_MUL, 0, T.col(2), T.col(4))],
-                  aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.col(3)), (T.AGG_SUM, T.temp(0)), (T.AGG_MIN, T.col(4)), (T.AGG_COUNT_STAR, None)],
+                  aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.temp(0)), (T.AGG_MIN, T.col(4)), (T.AGG_COUNT_STAR, None),
+                        (T.AGG_SUM, T.col(5))],      # (+ the four hidden accumulators of the 12-byte key: the state's eight)
                   pred=[(3, T.GE, 20), (0, T.NE, 5)], est_groups=4)
         cfg = T.make_agg_config(T.AGG_GENERIC, layout, code_widths=widths, **kw)
-        code_cols = [cols[i] if widths[i] == 0 else comp[i].codes for i in range(5)]
-        dicts = [None if widths[i] == 0 else comp[i].dictionary for i in range(5)]
+        code_cols = [cols[i] if widths[i] == 0 else comp[i].codes for i in range(6)]
+        dicts = [None if widths[i] == 0 else comp[i].dictionary for i in range(6)]
         st = capi.AggState(cfg)
         o = oracle.AggState(cfg)
         filt = oracle.bitmap_from_bools(rng.random(n) < 0.6)
@@ -209,7 +214,7 @@ def test_group_by_compressed_keys_matches_oracle(capi, oracle, dev, kernel, monk
             f = oracle.bitmap_from_bools(oracle.bools_from_bitmap(filt, n)[lo:hi]) if use_filter else None
             st.update_coded([to_dev(np.ascontiguousarray(c[lo:hi]), dev) for c in code_cols],
                             [None if d is None else to_dev(d, dev) for d in dicts], hi - lo,
-                            filter_bitmap=None if f is None else bitmap_dev(f, dev))
+                            filter_bitmap=None if f is None else bitmap_dev(f, dev), sized=kernel != "plan_shape_unsized_dictionaries")
             o.update_coded([np.ascontiguousarray(c[lo:hi]) for c in code_cols], dicts, hi - lo, filter_bitmap=f)
         assert_same_groups(finalize_np(st, dev), o.finalize())
         if kernel != "interpreter":
