@@ -518,43 +518,47 @@ __device__ __forceinline__ long long key_field(const DevConfig &c, const char *t
   }
 }
 
-// Runs of equal ADJACENT keys inside a wave (clustered / sorted inputs, e.g. lineitem on
-// l_orderkey): run_start = lane where the run containing this lane begins (max-scan over the
-// head flags); the segmented sums below add lane (i - off) only while it is still inside the
-// run, so equal keys that are not adjacent are never merged.  The last lane of a run ends up
-// with the whole run's sum.
-__device__ __forceinline__ int wave_run_start(long long key) {
+// Runs of equal ADJACENT keys inside a wave (clustered / sorted inputs, e.g. lineitem on l_orderkey).  One shuffle (the
+// predecessor's key) and one ballot describe them all: a lane heads a run when its key differs from its predecessor's, the
+// run a lane belongs to starts at the highest head at or below it (a count of leading zeros on the ballot), it ends where
+// the next lane is a head, and the longest run says how many doubling steps the segmented sums need — two for the four
+// lineitems of an order, not six.  (Round 4: the six-step max-scan for the run starts, a six-step scan for the row counts
+// and six steps per aggregate were 32 ds_bpermute per wave row; the compute side of K7 took 1.17 ms per 200 M rows with
+// nothing read from HBM and no atomic issued — tools/agg_dense_exp.sh.)  Equal keys that are not adjacent are never merged.
+struct WaveRuns {
+  int start;    // lane where the run containing this lane begins
+  bool tail;    // this lane is the last of its run (it ends up with the run's sums)
+  int steps;    // doubling steps that cover the longest run of the wave (wave-uniform)
+};
+__device__ __forceinline__ WaveRuns wave_runs(long long key) {
+  const int lane = lane_id();
   const long long prev = __shfl_up(key, 1, kWave);
-  int start = (lane_id() == 0 || prev != key) ? lane_id() : 0;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const int up = __shfl_up(start, off, kWave);
-    if (lane_id() >= off && up > start) start = up;
-  }
-  return start;
+  const unsigned long long heads = __ballot(lane == 0 || prev != key);   // (bit 0 is always set)
+  WaveRuns r;
+  r.start = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
+  r.tail = lane == kWave - 1 || ((heads >> (lane + 1)) & 1ull) != 0;
+  const int back = lane - r.start;
+  r.steps = 0;
+  while (r.steps < 6 && __any(back >= (1 << r.steps))) ++r.steps;
+  return r;
 }
-__device__ __forceinline__ unsigned long long segmented_run_sum_u64(int run_start, unsigned long long v) {
+// The segmented sums add lane (i - off) only while it is still inside the run; the run's last lane ends up with the whole sum.
+__device__ __forceinline__ double segmented_run_sum_f64(const WaveRuns &runs, double v) {
 #pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const unsigned long long v2 = __shfl_up(v, off, kWave);
-    if (lane_id() - off >= run_start) v += v2;
-  }
-  return v;
-}
-__device__ __forceinline__ double segmented_run_sum_f64(int run_start, double v) {
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const double v2 = __shfl_up(v, off, kWave);
-    if (lane_id() - off >= run_start) v += v2;
+  for (int s = 0; s < 6; ++s) {
+    if (s >= runs.steps) break;   // (wave-uniform)
+    const double v2 = __shfl_up(v, 1 << s, kWave);
+    if (lane_id() - (1 << s) >= runs.start) v += v2;
   }
   return v;
 }
 // Same scan with the accumulator's own combine (MIN / MAX / integer SUM); dead lanes carry the identity.
-__device__ __forceinline__ unsigned long long segmented_run_combine(int run_start, unsigned long long v, int kind) {
+__device__ __forceinline__ unsigned long long segmented_run_combine(const WaveRuns &runs, unsigned long long v, int kind) {
 #pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const unsigned long long v2 = __shfl_up(v, off, kWave);
-    if (lane_id() - off >= run_start) v = acc_combine(v, v2, kind);
+  for (int s = 0; s < 6; ++s) {
+    if (s >= runs.steps) break;
+    const unsigned long long v2 = __shfl_up(v, 1 << s, kWave);
+    if (lane_id() - (1 << s) >= runs.start) v = acc_combine(v, v2, kind);
   }
   return v;
 }
@@ -873,7 +877,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 
     const int trow = threadIdx.x;  // this thread's first row of the tile
 #ifdef QSX_EXP_NO_COMPUTE   // (experiment through QSX_JIT_OPTIONS, tools/agg_coded_exp.sh: the tile pipeline alone — staging, waits, barriers)
-    if constexpr (kStatic && !kDense && !kDir && !kDirBuild) continue;
+    if constexpr (kStatic && !kDir && !kDirBuild) continue;   // (hash path and the dense per-row path)
 #endif
     decode_tile_codes<kStatic, V, BLOCK>(c, kRuns ? here.dicts : dicts, tile, trow, rows);
     // plan shapes whose tile holds only the codes of the compressed attributes: their values, into registers
@@ -966,6 +970,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     int reg_entry[V];           // REG: the register entry of the row's group, -1: none
     unsigned long long reg_inc[NS > 0 ? NS : 1][V];
     bool run_tail[V];   // kDense: this lane commits the run of equal adjacent keys ending here
+    WaveRuns runs[V];   // kDense: the runs of equal adjacent keys of the wave, per row of the thread
     // kDir: the row's group number (or -2: look it up), its wide key, and the aggregates' arguments until the row is classified
     int dir_gid = -1;
     unsigned long long dir_words[kMaxKeyWords] = {};
@@ -981,10 +986,10 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         }
         // dead rows get a key no neighbour shares so that they never join a run
         const long long run_key = live[v] ? loc : -1 - static_cast<long long>(lane_id());
-        const long long next_key = __shfl_down(run_key, 1, kWave);
-        run_tail[v] = live[v] && (lane_id() == kWave - 1 || next_key != run_key);
+        runs[v] = wave_runs(run_key);
+        run_tail[v] = live[v] && runs[v].tail;
         global_slot[v] = live[v] ? loc : -1;
-        slot[v] = wave_run_start(run_key);
+        slot[v] = runs[v].start;
       }
     } else if constexpr (kDir) {
       // Directory mode reads everything it needs from the tile first (here: the group's position in the key box, or the
@@ -1090,8 +1095,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       // existence bit + row count of every run (CollisionFreeVectorTable.hpp:530-645)
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        unsigned long long run_len = live[v] ? 1ull : 0ull;
-        run_len = segmented_run_sum_u64(slot[v], run_len);
+        const unsigned long long run_len = static_cast<unsigned long long>(lane_id() - runs[v].start + 1);   // (at the run's tail: its
+                                                                                  // length — a dead row is a run of its own)
+#ifdef QSX_EXP_NO_DENSE_ATOMICS   // (experiment, tools/agg_dense_exp.sh: the dense per-row path without its global atomics)
+        asm volatile("" ::"v"(run_len));
+        continue;
+#endif
         if (run_tail[v]) {
           const long long loc = global_slot[v];
           const unsigned long long bit = 1ull << (loc & 63);
@@ -1218,10 +1227,14 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
           unsigned long long run;
           if (s.kind == kAccSumF64) {
             run = static_cast<unsigned long long>(__double_as_longlong(segmented_run_sum_f64(
-                slot[v], live[v] ? __longlong_as_double(static_cast<long long>(inc[v])) : 0.0)));
+                runs[v], live[v] ? __longlong_as_double(static_cast<long long>(inc[v])) : 0.0)));
           } else {
-            run = segmented_run_combine(slot[v], live[v] ? inc[v] : static_cast<unsigned long long>(acc_identity(s.kind)), s.kind);
+            run = segmented_run_combine(runs[v], live[v] ? inc[v] : static_cast<unsigned long long>(acc_identity(s.kind)), s.kind);
           }
+#ifdef QSX_EXP_NO_DENSE_ATOMICS
+          asm volatile("" ::"v"(run));
+          continue;
+#endif
           if (run_tail[v]) global_accumulate(&col[global_slot[v]], run, s.kind);
         }
       } else {
