@@ -868,8 +868,10 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const int64_t next = tile_id + tile_step;
     if (next < num_tiles) carried = locate(next);
     if (nbuf == 2 && next < num_tiles) {
+#ifndef QSX_EXP_STAGE_ONCE
       stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? carried.cols : cols, kRuns ? carried.filter : filter, tiles + (buf ^ 1) * c.tile_bytes,
                                         carried.row0, carried.rows, nulls, &carried.bases);
+#endif
     }
     char *tile = tiles + buf * c.tile_bytes;
     if (nbuf == 2) buf ^= 1;
@@ -878,6 +880,14 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     const int trow = threadIdx.x;  // this thread's first row of the tile
 #ifdef QSX_EXP_NO_COMPUTE   // (experiment through QSX_JIT_OPTIONS, tools/agg_coded_exp.sh: the tile pipeline alone — staging, waits, barriers)
     if constexpr (kStatic && !kDir && !kDirBuild) continue;   // (hash path and the dense per-row path)
+    if constexpr (kStatic && kDir) {                          // (directory kernels: their one buffer is staged behind the reads)
+      if (nbuf == 1 && next < num_tiles) {
+        __syncthreads();
+        stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? carried.cols : cols, kRuns ? carried.filter : filter, tiles, carried.row0, carried.rows,
+                                          nulls, &carried.bases);
+      }
+      continue;
+    }
 #endif
     decode_tile_codes<kStatic, V, BLOCK>(c, kRuns ? here.dicts : dicts, tile, trow, rows);
     // plan shapes whose tile holds only the codes of the compressed attributes: their values, into registers
@@ -1285,8 +1295,10 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       if (!kDense && dir_gid == -2) probe = dir_first_probe(*dir, code[0]);
       if (nbuf == 1 && next < num_tiles) {
         __syncthreads();
+#ifndef QSX_EXP_STAGE_ONCE
         stage_tile<kStatic, BLOCK, kRuns>(c, kRuns ? carried.cols : cols, kRuns ? carried.filter : filter, tiles, carried.row0, carried.rows,
                                           nulls, &carried.bases);
+#endif
       }
       int gid = dir_gid;
       if (!kDense && gid == -2) gid = c.wide_words != 0 ? dir_lookup_wide_from(*dir, code[0], dir_words, probe) : dir_lookup_from(*dir, code[0], probe);
