@@ -48,8 +48,23 @@ using glb_ptr_t = const __attribute__((address_space(1))) void *;
 #endif
 // One wave instruction: lane l copies 16 bytes from its own global address to
 // (wave-uniform LDS base) + 16 * l.
+// QSX_DMA_ASM=1 (experiment, through QSX_JIT_OPTIONS): the copy as an asm statement instead of the builtin.  hipcc counts the
+// builtin's DMA like a store to LDS it cannot tell from any other and drains it (`s_waitcnt vmcnt(0)`) in front of the next
+// LDS read and of every barrier, so a tile staged AHEAD of the work on the current one runs under nothing; an asm statement
+// is absent from that bookkeeping (the tile loop has its own `s_waitcnt vmcnt(0)` + barrier before a tile is read).
+#ifndef QSX_DMA_ASM
+#define QSX_DMA_ASM 0
+#endif
 __device__ __forceinline__ void dma16(const char *global_lane_addr, char *lds_wave_base) {
+#if QSX_DMA_ASM
+  const unsigned lds_at = __builtin_amdgcn_readfirstlane(
+      static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char *)lds_wave_base)));
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(global_lane_addr), "s"(lds_at) : "memory");
+#else
   __builtin_amdgcn_global_load_lds((glb_ptr_t)global_lane_addr, (lds_ptr_t)lds_wave_base, 16, 0, QSX_DMA_AUX);
+#endif
 }
 
 // Loop over a configuration-sized range.  kStatic = the configuration is a compile-time
