@@ -997,9 +997,9 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     bool run_tail[V];   // kDense: this lane commits the run of equal adjacent keys ending here
     WaveRuns runs[V];   // kDense: the runs of equal adjacent keys of the wave, per row of the thread
     // kDir: the row's group number (or -2: look it up), its wide key, and the aggregates' arguments until the row is classified
-    int dir_gid = -1;
-    unsigned long long dir_words[kMaxKeyWords] = {};
-    unsigned long long dir_inc[NS > 0 ? NS : 1];
+    int dir_gid[V];
+    unsigned long long dir_words[V][kMaxKeyWords];
+    unsigned long long dir_inc[NS > 0 ? NS : 1][V];
     if constexpr (kDense && !kDir) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
@@ -1020,45 +1020,52 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       // Directory mode reads everything it needs from the tile first (here: the group's position in the key box, or the
       // key words the directory entry has to match; below: the aggregates' arguments) and classifies the row afterwards —
       // with one tile buffer the next tile's DMA then runs under the lookups and the LDS atomics instead of after them.
-      static_assert(!kDir || V == 1, "directory mode: one row per thread");
-      run_tail[0] = false;
-      slot[0] = S + lane_id();   // trash
-      global_slot[0] = -1;
-      dir_gid = -1;              // -2: to be looked up
-      if constexpr (kDense) {
-        // a dense state in LDS: the group number is the key value
-        // (ranges > 1: workgroup family r keeps entries [r S, (r + 1) S) and reads every row, like the hash-range families)
-        const long long loc = static_cast<long long>(tile_int(c, tile, c.key_column[0], trow));
-        const long long lo = static_cast<long long>(my_range) * S;
-        if (live[0]) {
-          if (loc < 0 || loc >= dense.num_entries) {
-            atomicExch(dense.error, 1);  // precondition min >= 0, max < num_entries violated
-            live[0] = false;
-          } else if (loc >= lo && loc < lo + S) {
-            dir_gid = (static_cast<int>(loc - lo) << rep_shift) + lane_col;   // (few entries: up to 64 copies, a lane adds into its own)
-          } else {
-            live[0] = false;             // another family's entry
-          }
-        }
-      } else if (live[0] && code[0] != kEmptyCode) {
-        if (box.usable) {
-          // group number = position in the key box of the build pass; a key outside the box (the build pass samples) has none
-          unsigned int cell = 0;
-          bool inside = true;
+      // (V rows per thread: the plan shapes take two — the accumulators leave room for one 2048-row tile where the one-row
+      // form kept two 1024-row buffers, and with ONE workgroup per CU the bytes in flight per CU are the tile)
 #pragma unroll
-          for (int k = 0; k < QSX_MAX_KEYS; ++k) {
-            if (k < c.num_keys) {
-              const unsigned long long d = static_cast<unsigned long long>(key_field(c, tile, k, trow) - box.lo[k]);
-              inside = inside && d < box.range[k];
-              cell += static_cast<unsigned int>(d) * box.mult[k];
+      for (int v = 0; v < V; ++v) {
+        const int r = trow + v * BLOCK;
+        run_tail[v] = false;
+        slot[v] = S + lane_id();   // trash
+        global_slot[v] = -1;
+        dir_gid[v] = -1;           // -2: to be looked up
+#pragma unroll
+        for (int w = 0; w < kMaxKeyWords; ++w) dir_words[v][w] = 0ull;
+        if constexpr (kDense) {
+          // a dense state in LDS: the group number is the key value
+          // (ranges > 1: workgroup family r keeps entries [r S, (r + 1) S) and reads every row, like the hash-range families)
+          const long long loc = static_cast<long long>(tile_int(c, tile, c.key_column[0], r));
+          const long long lo = static_cast<long long>(my_range) * S;
+          if (live[v]) {
+            if (loc < 0 || loc >= dense.num_entries) {
+              atomicExch(dense.error, 1);  // precondition min >= 0, max < num_entries violated
+              live[v] = false;
+            } else if (loc >= lo && loc < lo + S) {
+              dir_gid[v] = (static_cast<int>(loc - lo) << rep_shift) + lane_col;   // (few entries: up to 64 copies, a lane adds into its own)
+            } else {
+              live[v] = false;             // another family's entry
             }
           }
-          dir_gid = inside ? static_cast<int>(cell) : -1;
-        } else {
-          dir_gid = -2;
-          if (c.wide_words != 0) {
+        } else if (live[v] && code[v] != kEmptyCode) {
+          if (box.usable) {
+            // group number = position in the key box of the build pass; a key outside the box (the build pass samples) has none
+            unsigned int cell = 0;
+            bool inside = true;
 #pragma unroll
-            for (int w = 0; w < kMaxKeyWords; ++w) dir_words[w] = w < c.wide_words ? key_word_of(c, tile, w, trow) : 0ull;
+            for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+              if (k < c.num_keys) {
+                const unsigned long long d = static_cast<unsigned long long>(key_field(c, tile, k, r) - box.lo[k]);
+                inside = inside && d < box.range[k];
+                cell += static_cast<unsigned int>(d) * box.mult[k];
+              }
+            }
+            dir_gid[v] = inside ? static_cast<int>(cell) : -1;
+          } else {
+            dir_gid[v] = -2;
+            if (c.wide_words != 0) {
+#pragma unroll
+              for (int w = 0; w < kMaxKeyWords; ++w) dir_words[v][w] = w < c.wide_words ? key_word_of(c, tile, w, r) : 0ull;
+            }
           }
         }
       }
@@ -1264,7 +1271,8 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         }
       } else {
         if constexpr (kDir) {
-          dir_inc[j] = inc[0];
+#pragma unroll
+          for (int v = 0; v < V; ++v) dir_inc[j][v] = inc[v];
           continue;
         }
         if constexpr (REG > 0) {
@@ -1306,8 +1314,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     if constexpr (kDir) {
       // every read of this tile is done; the home entry of the row's key is read BEFORE the next tile's DMA is issued —
       // loads return in order, so waiting for a lookup issued behind the DMA would wait for the tile as well
-      DirProbe probe{};
-      if (!kDense && dir_gid == -2) probe = dir_first_probe(*dir, code[0]);
+      DirProbe probe[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        probe[v] = DirProbe{};
+        if (!kDense && dir_gid[v] == -2) probe[v] = dir_first_probe(*dir, code[v]);
+      }
       if (nbuf == 1 && next < num_tiles) {
         __syncthreads();
 #ifndef QSX_EXP_STAGE_ONCE
@@ -1315,22 +1327,27 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
                                           nulls, &carried.bases);
 #endif
       }
-      int gid = dir_gid;
-      if (!kDense && gid == -2) gid = c.wide_words != 0 ? dir_lookup_wide_from(*dir, code[0], dir_words, probe) : dir_lookup_from(*dir, code[0], probe);
-      if (gid >= 0) {
-        atomicAdd(&l_cnt[gid], 1u);
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          if (j < ns_lds) lds_add(&acc_plane_of(j)[gid], dir_inc[j], c.sums[j].kind);
+      for (int v = 0; v < V; ++v) {
+        int gid = dir_gid[v];
+        if (!kDense && gid == -2) {
+          gid = c.wide_words != 0 ? dir_lookup_wide_from(*dir, code[v], dir_words[v], probe[v]) : dir_lookup_from(*dir, code[v], probe[v]);
         }
-      } else if (!kDense && live[0]) {
-        // no gid with an accumulator here (more groups than the directory was sized for, a group the build pass's sample
-        // missed, the sentinel code): the global table, all accumulators — a wide key's hidden ones included
-        const unsigned long long gs = global_find_or_insert(g, code[0]);
-        if (gs != ~0ull) {
-          global_add(g, 0, gs, 1ull, kAccSumI64);
+        if (gid >= 0) {
+          atomicAdd(&l_cnt[gid], 1u);
 #pragma unroll
-          for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, dir_inc[j], c.sums[j].kind);
+          for (int j = 0; j < NS; ++j) {
+            if (j < ns_lds) lds_add(&acc_plane_of(j)[gid], dir_inc[j][v], c.sums[j].kind);
+          }
+        } else if (!kDense && live[v]) {
+          // no gid with an accumulator here (more groups than the directory was sized for, a group the build pass's sample
+          // missed, the sentinel code): the global table, all accumulators — a wide key's hidden ones included
+          const unsigned long long gs = global_find_or_insert(g, code[v]);
+          if (gs != ~0ull) {
+            global_add(g, 0, gs, 1ull, kAccSumI64);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) global_add(g, j + 1, gs, dir_inc[j][v], c.sums[j].kind);
+          }
         }
       }
     }

@@ -152,7 +152,8 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
       << nulls_param << ") {\n"
       << "  static constexpr DevConfig D = jit_make_dev();\n"
       << "  (void)cols; (void)pieces;\n"
-      << "  agg_hash_update_body<true, false, " << num_sums << ", 1, true, " << kDirBlock << ", false, " << (geo.runs != 0 ? "true" : "false")
+      << "  agg_hash_update_body<true, false, " << num_sums << ", " << (geo.dir_rows == 2 ? 2 : 1) << ", true, " << kDirBlock << ", false, "
+      << (geo.runs != 0 ? "true" : "false")
       << ">(D, " << (geo.runs != 0 ? "nullptr" : "cols.p") << ", " << (any_coded ? "dicts" : "nullptr") << ", n, "
       << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", view, DenseView{}, " << geo.dir_gids << ", 0, " << geo.nbuf << ", 1, "
       << (geo.runs != 0 ? "pieces" : "nullptr") << ", " << nulls_arg << ", &d);\n}\n}  // namespace qsx\n";

@@ -818,6 +818,12 @@ struct AggTuning {
 };
 // Small hash tables of plan shapes: per-wave register accumulators (agg_hash_update.hpp, REG).  Measured slower than the LDS
 // atomics they replace: off unless QSX_AGG_REG_GROUPS=1 (read per call: the parity tests run both).
+// Rows per thread of the group-directory plan shapes (2: one 2048-row tile instead of two 1024-row buffers); QSX_AGG_DIR_ROWS=1
+// keeps the one-row form.
+static int dir_rows_per_thread() {
+  const char *e = getenv("QSX_AGG_DIR_ROWS");
+  return e != nullptr && atoi(e) == 1 ? 1 : 2;
+}
 static bool reg_groups_enabled() {
   const char *e = getenv("QSX_AGG_REG_GROUPS");
   return e != nullptr && atoi(e) != 0;
@@ -1358,6 +1364,16 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
     } else if (directory) {
       st->jit_geometry[v] = JitGeometry{st->dir_gids, 0, st->dir_nbuf, 1, st->dir_gids, runs ? 1 : 0};
       st->jit_lds[v] = dir_lds_bytes(dev.tile_bytes, 0, dir_plane_sums(dev), st->dir_gids, st->dir_nbuf);
+      // Where the accumulators left room for two 1024-row buffers the shape takes ONE 2048-row tile, two rows per thread —
+      // the same LDS.  The directory kernels run one workgroup per CU, and the copies of a tile do not run under that
+      // workgroup's own LDS work: what a CU has in flight is one tile, so the tile is made as large as fits.
+      if (dir_rows_per_thread() == 2 && st->dir_nbuf == 2 && !runs) {
+        plan_tile(dev, st->used_columns, 2 * kDirBlock, has_filter);
+        st->jit_tile_bytes[v] = dev.tile_bytes;
+        st->jit_geometry[v].nbuf = 1;
+        st->jit_geometry[v].dir_rows = 2;
+        st->jit_lds[v] = dir_lds_bytes(dev.tile_bytes, 0, dir_plane_sums(dev), st->dir_gids, 1);
+      }
     } else {
       st->jit_geometry[v] = jit_geometry_for(st, dev.tile_bytes, slots, num_ranges, &st->jit_lds[v]);
       st->jit_geometry[v].runs = runs ? 1 : 0;
