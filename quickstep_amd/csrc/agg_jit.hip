@@ -138,7 +138,8 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
       << nulls_param << ") {\n"
       << "  static constexpr DevConfig D = jit_make_dev();\n"
       << "  (void)cols; (void)pieces;\n"
-      << "  agg_hash_update_body<true, true, " << num_sums << ", 1, true, " << kDirBlock << ", false, " << (geo.runs != 0 ? "true" : "false")
+      << "  agg_hash_update_body<true, true, " << num_sums << ", " << (geo.dir_rows > 1 ? geo.dir_rows : 1) << ", true, " << kDirBlock << ", false, "
+      << (geo.runs != 0 ? "true" : "false")
       << ">(D, " << (geo.runs != 0 ? "nullptr" : "cols.p") << ", " << (any_coded ? "dicts" : "nullptr") << ", n, "
       << (dev.filter_lds_off >= 0 ? "filter" : "nullptr") << ", HashTableView{}, view, " << geo.S << ", " << geo.rep_shift << ", " << geo.nbuf
       << ", " << geo.ranges << ", pieces, " << nulls_arg << ", nullptr);\n}\n}  // namespace qsx\n";

@@ -33,7 +33,8 @@ struct JitGeometry {
   int dir_gids;   // != 0: the group-directory variant (agg_common.hpp DirView) with that many LDS accumulators per aggregate
   int runs;       // != 0: the rows are a run of blocks (agg_common.hpp BlockRunView behind the `pieces` argument)
   int reg_groups; // != 0: that many groups per wave accumulate in registers (agg_hash_update.hpp, REG; small hash tables only)
-  int dir_rows;       // group directory: rows per thread (0 = 1); 2 = one 2048-row tile in the LDS two 1024-row buffers would take
+  int dir_rows;       // group directory / dense state in LDS: rows per thread (0 = 1); 2 = one 2048-row tile in the LDS two 1024-row
+                      // buffers would take (dense states of few entries: 4)
   int waves_per_eu;   // != 0: the waves per SIMD the shape is to be built for (LDS admits that many workgroups per CU; a shape
                       // that spills for it is rebuilt without)
 };

@@ -1361,6 +1361,21 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
       if (lds > 160 * 1024) lds = dir_lds_bytes(dev.tile_bytes, 0, st->num_sums, copies, nbuf = 1);
       st->jit_geometry[v] = JitGeometry{dense_lds.entries, dense_lds.rep_shift, nbuf, dense_lds.ranges, copies, runs ? 1 : 0};
       st->jit_lds[v] = lds;
+      if (dir_rows_per_thread() == 2 && nbuf == 2 && !runs) {
+        // one tile of 2048 rows instead of two buffers (see the directory below) — or of 4096 where few entries leave the room
+        for (int rows_per_thread = 4; rows_per_thread >= 2; rows_per_thread >>= 1) {
+          DevConfig wide = dev;
+          plan_tile(wide, st->used_columns, rows_per_thread * kDirBlock, has_filter);
+          const size_t wide_lds = dir_lds_bytes(wide.tile_bytes, 0, st->num_sums, copies, 1);
+          if (wide_lds > 160 * 1024) continue;
+          dev = wide;
+          st->jit_tile_bytes[v] = dev.tile_bytes;
+          st->jit_geometry[v].nbuf = 1;
+          st->jit_geometry[v].dir_rows = rows_per_thread;
+          st->jit_lds[v] = wide_lds;
+          break;
+        }
+      }
     } else if (directory) {
       st->jit_geometry[v] = JitGeometry{st->dir_gids, 0, st->dir_nbuf, 1, st->dir_gids, runs ? 1 : 0};
       st->jit_lds[v] = dir_lds_bytes(dev.tile_bytes, 0, dir_plane_sums(dev), st->dir_gids, st->dir_nbuf);
