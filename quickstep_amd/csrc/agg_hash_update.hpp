@@ -1576,6 +1576,13 @@ __global__ __launch_bounds__(kDirBlock) void agg_dir_shape_kernel(ColumnPointers
   agg_hash_update_body<true, false, T.num_sums, 1, true, kDirBlock>(T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, gids, 0, nbuf, 1,
                                                                     nullptr, nullptr, &d);
 }
+// The same with one 2048-row tile, two rows per thread, in the LDS the two 1024-row buffers take (nbuf = 1 in the body).
+template <typename Shape>
+__global__ __launch_bounds__(kDirBlock) void agg_dir_shape_wide_kernel(ColumnPointers cols, int64_t n, HashTableView g, DirView d, int gids) {
+  static constexpr Translated T = Shape::translated(2 * kDirBlock);
+  agg_hash_update_body<true, false, T.num_sums, 2, true, kDirBlock>(T.dev, cols.p, nullptr, n, nullptr, g, DenseView{}, gids, 0, 1, 1,
+                                                                    nullptr, nullptr, &d);
+}
 template <typename Shape>
 __global__ __launch_bounds__(kDirBlock) void agg_dir_shape_runs_kernel(int64_t n, HashTableView g, DirView d, int gids, int nbuf,
                                                                       const long long *__restrict__ block_run) {

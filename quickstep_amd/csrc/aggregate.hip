@@ -1085,6 +1085,21 @@ static int launch_shape_dir(const void *const *cols, int num_columns, int64_t n,
   }
   ColumnPointers cp;
   for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < num_columns ? cols[i] : nullptr;
+  if (nbuf == 2 && dir_rows_per_thread() == 2) {
+    // (two buffers fit: one 2048-row tile in their place, two rows per thread — see state_jit_kernel)
+    constexpr Translated W = Shape::translated(2 * kDirBlock);
+    const size_t wide_lds = dir_lds_bytes(W.dev.tile_bytes, 0, W.num_sums - 2 * W.dev.wide_words, gids, 1);
+    if (wide_lds <= kMaxLds) {
+      static PerDeviceOnce wide_attribute_set;
+      const int rc = once_per_device(wide_attribute_set, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_dir_shape_wide_kernel<Shape>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+      });
+      if (rc != QSX_OK) return rc;
+      hipLaunchKernelGGL((agg_dir_shape_wide_kernel<Shape>), dim3(dir_grid(n)), dim3(kDirBlock), wide_lds, stream, cp, n, g, d, gids);
+      return QSX_OK;
+    }
+  }
   hipLaunchKernelGGL((agg_dir_shape_kernel<Shape>), dim3(dir_grid(n)), dim3(kDirBlock), lds, stream, cp, n, g, d, gids, nbuf);
   return QSX_OK;
 }
