@@ -270,10 +270,13 @@ __device__ __forceinline__ void decode_rows(const DevConfig &c, const void *cons
 
 // ---- typed reads of a staged column ---------------------------------------------
 // (dec / v: the registers of a plan shape's compressed attributes and which of the thread's rows r is; nullptr elsewhere)
-template <int V = 1>
+// (kDec, not a null test on dec: a comparison of the register struct's address with the null pointer of another address space
+// does not fold, counts as a use of the address and keeps the whole struct in scratch — found in round 4 on a shape with a
+// decoded INT column: 520 bytes of scratch per lane, and wrong sums from the hipRTC build of it)
+template <int V = 1, bool kDec = false>
 __device__ __forceinline__ double tile_double(const DevConfig &c, const char *tile, int col, int r, const DecodedRows<V> *dec = nullptr,
                                               int v = 0) {
-  if (dec != nullptr && c.lds_off[col] == kRegDecoded) {
+  if (kDec && c.lds_off[col] == kRegDecoded) {
     const unsigned long long raw = dec->raw[col][v];
     switch (c.column_type[col]) {
       case QSX_INT: return static_cast<double>(static_cast<int32_t>(raw));
@@ -290,10 +293,10 @@ __device__ __forceinline__ double tile_double(const DevConfig &c, const char *ti
     default: return reinterpret_cast<const double *>(p)[r];
   }
 }
-template <int V = 1>
+template <int V = 1, bool kDec = false>
 __device__ __forceinline__ long long tile_int(const DevConfig &c, const char *tile, int col, int r, const DecodedRows<V> *dec = nullptr,
                                               int v = 0) {
-  if (dec != nullptr && c.lds_off[col] == kRegDecoded) {
+  if (kDec && c.lds_off[col] == kRegDecoded) {
     const unsigned long long raw = dec->raw[col][v];
     return c.column_type[col] == QSX_INT ? static_cast<long long>(static_cast<int32_t>(raw)) : static_cast<long long>(raw);
   }
@@ -341,13 +344,13 @@ __device__ __forceinline__ void temps_set(Temps<V> &s, int i, const double (&in)
 #undef QSX_TS
 }
 
-template <int V, int BLOCK = kABlock>
+template <int V, int BLOCK = kABlock, bool kDec = false>
 __device__ __forceinline__ void operand_vec(const DevConfig &c, const DevOperand &o, const Temps<V> &s,
                                             const char *tile, int trow, double (&out)[V], const DecodedRows<V> *dec = nullptr) {
   switch (o.kind) {
     case QSX_OPD_COLUMN:
 #pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = tile_double<V>(c, tile, o.index, trow + v * BLOCK, dec, v);
+      for (int v = 0; v < V; ++v) out[v] = tile_double<V, kDec>(c, tile, o.index, trow + v * BLOCK, dec, v);
       break;
     case QSX_OPD_CONST:
 #pragma unroll
@@ -400,7 +403,7 @@ __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *ti
                                               const DecodedRows<V> *dec = nullptr) {
   cfg_for<kStatic, QSX_MAX_PRED_TERMS>(c.num_pred, [&](int p) __attribute__((always_inline)) {
     const DevPred term = c.pred[p];
-    if (dec != nullptr && c.lds_off[term.column] == kRegDecoded) {
+    if (kStatic && c.lds_off[term.column] == kRegDecoded) {
       // a compressed attribute of a plan shape: the value is in the thread's registers
 #pragma unroll
       for (int v = 0; v < V; ++v) {
@@ -453,7 +456,7 @@ __device__ __forceinline__ void predicate_vec(const DevConfig &c, const char *ti
 }
 
 // Word w of the packed wide key of tile row r (DevConfig::wide_words).
-template <int V = 1>
+template <int V = 1, bool kDec = false>
 __device__ __forceinline__ unsigned long long key_word_of(const DevConfig &c, const char *tile, int w, int r,
                                                           const DecodedRows<V> *dec = nullptr, int v = 0) {
   unsigned long long word = 0;
@@ -462,7 +465,7 @@ __device__ __forceinline__ unsigned long long key_word_of(const DevConfig &c, co
     if (k < c.num_keys && c.key_word[k] == w) {
       const char *base = tile + c.lds_off[c.key_column[k]];
       unsigned long long x;
-      if (dec != nullptr && c.lds_off[c.key_column[k]] == kRegDecoded) {
+      if (kDec && c.lds_off[c.key_column[k]] == kRegDecoded) {
         x = dec->raw[c.key_column[k]][v];   // (zero-extended in its container: the same bits the stripe would hold)
       } else
       switch (c.key_width[k]) {
@@ -488,7 +491,7 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
     for (int v = 0; v < V; ++v) {
       unsigned long long words[kMaxKeyWords];
 #pragma unroll
-      for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of<V>(c, tile, w, trow + v * BLOCK, dec, v) : 0ull;
+      for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of<V, kStatic>(c, tile, w, trow + v * BLOCK, dec, v) : 0ull;
       code[v] = wide_key_code(words, c.wide_words, c.wide_hash_mask);
     }
     return;
@@ -501,7 +504,7 @@ __device__ __forceinline__ void key_codes_vec(const DevConfig &c, const char *ti
     for (int v = 0; v < V; ++v) {
       const int r = trow + v * BLOCK;
       unsigned long long x;
-      if (dec != nullptr && c.lds_off[c.key_column[k]] == kRegDecoded) {
+      if (kStatic && c.lds_off[c.key_column[k]] == kRegDecoded) {
         x = dec->raw[c.key_column[k]][v];
       } else
       switch (c.key_width[k]) {
@@ -961,7 +964,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
             if (c.wide_words != 0) {
               unsigned long long words[kMaxKeyWords];
 #pragma unroll
-              for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of<V>(c, tile, w, trow + v * BLOCK, dec, v) : 0ull;
+              for (int w = 0; w < kMaxKeyWords; ++w) words[w] = w < c.wide_words ? key_word_of<V, kStatic>(c, tile, w, trow + v * BLOCK, dec, v) : 0ull;
               bool inserted;
               const int at = lds_find_or_insert_new(l_keys, S, code[v], &inserted);
               if (at < 0) {
@@ -1180,8 +1183,8 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
     cfg_for<kStatic, QSX_MAX_INSTRS>(kStatic ? c.num_instrs : 0, [&](int k) __attribute__((always_inline)) {
       const DevInstr in = c.instrs[k];
       double a[V], b[V], res[V];
-      operand_vec<V, BLOCK>(c, in.a, temps, tile, trow, a, dec);
-      operand_vec<V, BLOCK>(c, in.b, temps, tile, trow, b, dec);
+      operand_vec<V, BLOCK, kStatic>(c, in.a, temps, tile, trow, a, dec);
+      operand_vec<V, BLOCK, kStatic>(c, in.b, temps, tile, trow, b, dec);
       switch (in.op) {
         case QSX_EX_ADD:
 #pragma unroll
@@ -1215,12 +1218,12 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       } else if (s.arg.kind == kOpdKeyWord) {
         // hidden accumulators of a wide key: MIN / MAX of the packed key words (DevConfig::wide_words)
 #pragma unroll
-        for (int v = 0; v < V; ++v) inc[v] = key_word_of<V>(c, tile, s.arg.index, trow + v * BLOCK, dec, v);
+        for (int v = 0; v < V; ++v) inc[v] = key_word_of<V, kStatic>(c, tile, s.arg.index, trow + v * BLOCK, dec, v);
       } else if (s.is_int) {
         if constexpr (kStatic) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            inc[v] = static_cast<unsigned long long>(tile_int<V>(c, tile, s.arg.index, trow + v * BLOCK, dec, v));
+            inc[v] = static_cast<unsigned long long>(tile_int<V, kStatic>(c, tile, s.arg.index, trow + v * BLOCK, dec, v));
           }
         } else {
           const PlanSum ps = c.plan_sums[j];
@@ -1235,7 +1238,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
       } else {
         double x[V];
         if constexpr (kStatic) {
-          operand_vec<V, BLOCK>(c, s.arg, temps, tile, trow, x, dec);
+          operand_vec<V, BLOCK, kStatic>(c, s.arg, temps, tile, trow, x, dec);
         } else {
           plan_operand_vec<V, BLOCK>(c.plan_sums[j].arg, tile, lds_temps, trow, x);
         }

@@ -119,6 +119,8 @@ std::string emit_dev_config(const DevConfig &d) {
   return o.str();
 }
 
+std::string compiler_driver();   // (below: who compiles the shapes — empty = hipRTC)
+
 std::string make_source(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geo) {
   std::ostringstream o;
   bool any_coded = false;   // unused pointers are passed as literals: every live scalar argument costs SGPRs in the tile loop
@@ -176,8 +178,10 @@ std::string make_source(const DevConfig &dev, int num_sums, bool dense, const Ji
     // Q1 without filter or dictionaries then has the kernarg segment of the AOT kernel (472 bytes; the geometry lives in the
     // shape as constants).  (The run-time Q1 shape still measures 1.26 against the AOT kernel's 1.16 ms per 200 M rows with
     // identical launch geometry and arguments: 5 % more instructions in the hipRTC build, cause not established.)
-    // (geo.waves_per_eu: the occupancy the launcher wants from the registers — LDS would admit that many workgroups per CU)
-    << "extern \"C\" __global__ __launch_bounds__(" << kABlock << (geo.waves_per_eu != 0 ? ", " + std::to_string(geo.waves_per_eu) : std::string())
+    // (geo.waves_per_eu: the occupancy the launcher wants from the registers — LDS would admit that many workgroups per CU.
+    // Only asked of the compiler driver: hipRTC's pipeline spills for it, and a second in-process compile on a background
+    // thread for the fallback crashed a short-lived host test)
+    << "extern \"C\" __global__ __launch_bounds__(" << kABlock << (geo.waves_per_eu != 0 && !compiler_driver().empty() ? ", " + std::to_string(geo.waves_per_eu) : std::string())
     << ") void qsx_jit_agg(ColumnPointers cols, int64_t n,\n"
     << "    " << (dense ? "DenseView" : "HashTableView") << " view, const long long *pieces"
     << (dev.filter_lds_off >= 0 || any_coded || any_nulls ? ", const uint64_t *filter" : "") << (any_coded || any_nulls ? ", const void *const *dicts" : "")
@@ -453,20 +457,30 @@ JitKernel *load_code(const std::string &code) {
   return k;
 }
 
-// A shape built for a requested occupancy (JitGeometry::waves_per_eu) that had to spill registers to scratch for it is
-// rebuilt from `relaxed` (the same shape without the request): scratch traffic costs more than the workgroup it buys.
-JitKernel *settle(JitKernel *k, const std::string &relaxed) {
-  if (k == nullptr || relaxed.empty()) return k;
+// Plan shapes run without scratch memory (their state lives in registers and LDS: DESIGN.md §4).  A shape built for a
+// requested occupancy (JitGeometry::waves_per_eu) that had to spill for it is rebuilt from `relaxed` (the same shape without
+// the request: scratch traffic costs more than the workgroup it buys); a shape that needs scratch even then is not used at all
+// — the interpreter kernel serves its state (the one such build of round 4, a register struct kept in memory by a pointer
+// comparison, also produced wrong sums through hipRTC).
+int scratch_bytes_of(const JitKernel *k) {
   int scratch = 0;
   if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->function) != hipSuccess) {
     (void)hipGetLastError();
-    return k;
+    return 0;
   }
-  if (scratch == 0) return k;
-  (void)hipModuleUnload(k->module);
+  return scratch;
+}
+JitKernel *settle(JitKernel *k, const std::string &relaxed) {
+  if (k == nullptr || scratch_bytes_of(k) == 0) return k;
+  // (the rejected module stays loaded: a few KiB, once per shape — unloading it from a compile thread while other threads
+  // launch is not worth the risk)
   delete k;
+  if (relaxed.empty()) {
+    std::fprintf(stderr, "[qsx] run-time plan shape: the build needs scratch memory; the interpreter kernel is used.\n");
+    return nullptr;
+  }
   std::string cached;
-  return load_cached_code(relaxed, &cached) ? load_code(cached) : compile(relaxed);
+  return settle(load_cached_code(relaxed, &cached) ? load_code(cached) : compile(relaxed), std::string());
 }
 
 }  // namespace
@@ -478,9 +492,14 @@ std::string jit_agg_source(const DevConfig &dev, int num_sums, bool dense, const
 
 JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, const JitGeometry &geometry, bool synchronous) {
   if (!jit_enabled()) return nullptr;
+  // Without a compiler driver the shape is built by hipRTC IN this process — then in the calling thread: a process that exits
+  // while a background thread is inside hiprtcCompileProgram tears LLVM's statics down under it (they are registered at
+  // hipRTC's first use, after this file's exit hook, and so destroyed before it runs: a short-lived host test crashed that
+  // way).  The driver's compile is a child process; its thread only waits.
+  synchronous = synchronous || compiler_driver().empty();
   const std::string source = make_source(dev, num_sums, dense, geometry);   // a filter is part of dev (filter_lds_off)
   std::string relaxed;
-  if (geometry.waves_per_eu != 0) {
+  if (geometry.waves_per_eu != 0 && !compiler_driver().empty()) {
     JitGeometry without = geometry;
     without.waves_per_eu = 0;
     relaxed = make_source(dev, num_sums, dense, without);

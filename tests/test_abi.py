@@ -218,3 +218,42 @@ def test_device_selection_needs_a_device(capi):
     device = C.c_int(-7)
     assert capi.lib.qsx_current_device(C.byref(device)) == T.ERR_NO_DEVICE
     assert capi.lib.qsx_set_current_device(0) == T.ERR_NO_DEVICE
+
+
+def test_plan_shapes_over_code_stripes_use_no_scratch(capi, tmp_path, monkeypatch):
+    """Plan shapes keep their state in registers and LDS.  The values of compressed attributes decoded into registers
+    (DecodedRows) once sat in 520 bytes of scratch per lane — a null test on the struct's address kept it in memory — and the
+    hipRTC build of that shape produced wrong sums: every flavour of a shape over code stripes (a narrow decoded column in
+    the predicate and in an integer SUM included) must come out of both compilers without a private segment."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from quickstep_amd import types as T
+    readelf, bundler = "/opt/rocm/lib/llvm/bin/llvm-readelf", "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    if not (os.path.exists(readelf) and os.path.exists(bundler)):
+        pytest.skip("no llvm-readelf / clang-offload-bundler in this image")
+    fn = capi.lib.qsx_debug_jit_compile
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(T.AggConfig), C.c_int, C.POINTER(C.c_size_t)]
+    layout = [(T.CHAR, 1), (T.CHAR, 1), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)]
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=[0, 0, 1, 0, 1, 1, 1], keys=[0, 1],
+                            instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0))], consts=[1.0],
+                            aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.temp(1)), (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(6)),
+                                  (T.AGG_MAX, T.col(5))], pred=[(6, T.LT, 7)], est_groups=6)
+    for compiler in ("", "hiprtc"):
+        if compiler:
+            monkeypatch.setenv("QSX_JIT_COMPILER", compiler)
+        else:
+            monkeypatch.delenv("QSX_JIT_COMPILER", raising=False)
+        for bits in (0, 1, 4, 16):          # plain, filtered, run of blocks, register groups
+            code = tmp_path / f"shape_{compiler or 'driver'}_{bits}.co"
+            monkeypatch.setenv("QSX_JIT_DUMP_CODE", str(code))
+            size = C.c_size_t(0)
+            assert fn(C.byref(cfg), bits, C.byref(size)) == 0 and size.value > 1000
+            elf = tmp_path / "shape.elf"
+            r = subprocess.run([bundler, "--unbundle", "--type=o", f"--input={code}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                f"--output={elf}"], capture_output=True)
+            if r.returncode != 0:           # (hipRTC hands out the bare code object)
+                shutil.copy(code, elf)
+            notes = subprocess.run([readelf, "--notes", str(elf)], capture_output=True, text=True).stdout
+            assert ".private_segment_fixed_size: 0" in notes, (compiler, bits, [ln for ln in notes.splitlines() if "private_segment" in ln])

@@ -1,5 +1,7 @@
 """GPU parity for compressed attributes: code-stripe scans and decode through the C ABI
 against the oracle's restatement of CompressedColumnStoreTupleStorageSubBlock / CompressedStoreUtil."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -379,3 +381,18 @@ def test_code_stripe_scans_over_runs_of_blocks(capi, oracle, dev):
                     if n:
                         assert np.array_equal(bitmap_np(outs[b])[:want.size], want), (width, shift, b, n, ops[b])
                     assert int(counts[b].item()) == oracle.bitmap_count(want, n)
+
+
+def test_coded_plan_shapes_built_by_hiprtc_match_too():
+    """The in-process compiler (QSX_JIT_COMPILER=hiprtc: what builds the shapes on a host without hipcc) produces code of its
+    own; the coded aggregation tests of this file — decoded columns in keys, predicates, integer and floating sums — once
+    passed with the driver's build and returned garbage with hipRTC's (a register struct in scratch).  Run them again in a
+    process that only has hipRTC."""
+    import subprocess
+    import sys
+    env = dict(os.environ, QSX_JIT_COMPILER="hiprtc")
+    nodes = ["test_q1_over_compressed_attributes_matches_oracle", "test_group_by_compressed_keys_matches_oracle",
+             "test_q1_over_a_run_of_compressed_blocks"]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", " or ".join(nodes)],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
