@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         global_slot[v] = -1;
-        const long long loc = static_cast<long long>(tile_int(c, tile, c.key_column[0], trow + v * BLOCK));
+        const long long loc = static_cast<long long>(tile_int<V, kStatic>(c, tile, c.key_column[0], trow + v * BLOCK, dec, v));
         if (live[v] && (loc < 0 || loc >= dense.num_entries)) {
           atomicExch(dense.error, 1);  // precondition min >= 0, max < num_entries violated
           live[v] = false;

@@ -626,7 +626,7 @@ extern "C" int qsx_debug_jit_compile(const qsx_agg_config_t *config, int with_fi
   const bool reg_groups = (with_filter & 16) != 0;             // bit 4: per-wave register accumulators (small hash tables)
   with_filter &= 1;
   plan_tile(t.dev, t.used_columns, directory || dense_lds ? kDirBlock : kABlock * jit_rows_per_thread(), with_filter != 0,
-            /*reg_decode=*/!directory && !t.dense);
+            /*reg_decode=*/!directory && !dense_lds);
   // a plausible geometry: this hook only checks that the shape compiles
   JitGeometry geometry = directory ? JitGeometry{4096, 0, 2, 1, 4096, 0} : JitGeometry{t.dense ? 8 : 16, t.dense ? 0 : 4, 1, 1, 0, 0};
   if (dense_lds) geometry = JitGeometry{4096, 0, 2, 2, 4096, 0};

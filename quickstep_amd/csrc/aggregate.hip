@@ -1364,9 +1364,10 @@ static const JitKernel *state_jit_kernel(qsx_agg_state *st, bool has_filter, boo
       plan_tile(dev, st->used_columns, kDirBlock, has_filter);
       dense_lds = dense_lds_geometry(st->config.num_entries, st->num_sums, static_cast<size_t>(dev.tile_bytes), st->dense_families.load() == 1);
     }
-    // (the hash path's shapes keep only the codes of compressed attributes in the tile: their values live in registers)
+    // (the shapes of the hash path and of the dense per-row path keep only the codes of compressed attributes in the tile:
+    // their values live in registers; the directory and dense-in-LDS shapes decode into LDS slots)
     plan_tile(dev, st->used_columns, directory || dense_lds.entries != 0 ? kDirBlock : kABlock * jit_rows_per_thread(), has_filter,
-              /*reg_decode=*/!directory && !st->dense);
+              /*reg_decode=*/!directory && dense_lds.entries == 0);
     st->jit_tile_bytes[v] = dev.tile_bytes;
     if (dense_lds.entries != 0) {
       // a dense state in LDS (agg_hash_update.hpp, kDense && kDir): the directory kernels' geometry, S = entries

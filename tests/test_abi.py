@@ -240,16 +240,24 @@ def test_plan_shapes_over_code_stripes_use_no_scratch(capi, tmp_path, monkeypatc
                             instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0))], consts=[1.0],
                             aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.temp(1)), (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(6)),
                                   (T.AGG_MAX, T.col(5))], pred=[(6, T.LT, 7)], est_groups=6)
+    # (and the dense per-row path reading everything through a pair list: 4-byte "codes" = row numbers)
+    dense = T.make_agg_config(T.AGG_COLLISION_FREE, [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None)], keys=[0],
+                              instrs=[(T.EX_SUB, 0, T.const(0), T.col(2)), (T.EX_MUL, 1, T.col(1), T.temp(0))], consts=[1.0],
+                              aggs=[(T.AGG_SUM, T.temp(1)), (T.AGG_COUNT_STAR, None)], num_entries=60_000_000, code_widths=[4, 4, 4])
     for compiler in ("", "hiprtc"):
         if compiler:
             monkeypatch.setenv("QSX_JIT_COMPILER", compiler)
         else:
             monkeypatch.delenv("QSX_JIT_COMPILER", raising=False)
-        for bits in (0, 1, 4, 16):          # plain, filtered, run of blocks, register groups
+        for bits in (0, 1, 4, 16, 32, 33):          # plain, filtered, run of blocks, register groups; dense plain, filtered
+            if bits >= 32:
+                cfg_used, bits = dense, bits - 32
+            else:
+                cfg_used = cfg
             code = tmp_path / f"shape_{compiler or 'driver'}_{bits}.co"
             monkeypatch.setenv("QSX_JIT_DUMP_CODE", str(code))
             size = C.c_size_t(0)
-            assert fn(C.byref(cfg), bits, C.byref(size)) == 0 and size.value > 1000
+            assert fn(C.byref(cfg_used), bits, C.byref(size)) == 0 and size.value > 1000
             elf = tmp_path / "shape.elf"
             r = subprocess.run([bundler, "--unbundle", "--type=o", f"--input={code}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                                 f"--output={elf}"], capture_output=True)
