@@ -24,6 +24,11 @@ Per-rank sizes are fixed, so one rank on the 1-GPU box runs the same code path (
 After the timed region the results of the last step are CHECKED (pair validity, permutation of the probe rows, COUNT /
 SUM values against independent torch reductions) — a wrong result fails the run instead of printing a number.
 
+With one GPU the headline line also carries `secondary`: the other BASELINE configurations under the same clock — Q1 over
+code stripes (the reference's own lineitem layout, benchmarks/tpch/create.sql:69-121), the C3 minimal variant, C4 and C5 at
+their per-rank sizes — each with its time, roofline, result check and an oracle cpu_baseline on a bounded sample
+(--no-secondary skips them).
+
 The line carries `roofline` for the dominant kernel with its duration measured by HIP events on the launch stream, and
 `cpu_baseline`: the CPU oracle (a port of the reference algorithms, oracle/) timed on this host's cores on a bounded sample
 of the same workload — 5 trials, mean of trials 2-4 in run order (benchmarks/tpch/process.py:11-45).
@@ -536,6 +541,8 @@ def run_headline(ctx, args):
         line["aggregate"] = {"rows_per_s": args.agg_rows / agg_s, "ms": phase_ms["aggregate_update"],
                              "finalize_ms": phase_ms["finalize"]}
     line.pop("_probe_traffic", None)
+    if getattr(ctx, "keep_headline", False):
+        ctx.headline = {"agg_cols": agg_cols, "fin": results["fin"]}
     return line
 
 
@@ -675,6 +682,7 @@ def run_c4(ctx, args):
         "roofline": {"kernel": "whole step (K9 partition_scatter x2, build, probe, K5 gathers)", "bound": "hbm",
                      "achieved": algo / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / step_s / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_step": algo, "traffic": None},
+        "checked": not args.no_check,
         "alltoall": {"bytes_sent_per_rank_per_step": moved, "GBps_per_rank": moved / step_s / 1e9, "GBps_per_rank_over_step": moved / step_s / 1e9,
                      "peak_GBps_per_rank": XGMI_PEAK_GBS},
         "phases_ms": phase_ms,
@@ -751,10 +759,322 @@ def run_c5(ctx, args):
         "roofline": {"kernel": "whole query (K1 selects, LIP, K3/K4 joins, K7 dense aggregation through the pair list, K10, top-k)",
                      "bound": "hbm", "achieved": algo / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": algo / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": algo, "traffic": None},
+        "checked": not args.no_check,
         "collectives": {"bytes_per_rank_per_step": q3.comm_bytes, "GBps_per_rank_over_step": q3.comm_bytes / step_s / 1e9,
                         "peak_GBps_per_rank": XGMI_PEAK_GBS},
         "phases_ms": phase_ms,
     }
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# secondary: the other BASELINE configurations under the driver's clock (N = 1, headline config)
+def launches_ms(fn, reps=5, warm=2):
+    """Average duration of one launch of `fn` by HIP events on the launch stream (capi launches on torch's current stream)."""
+    for _ in range(warm):
+        fn()
+    total = 0.0
+    for _ in range(reps):
+        a, b = ev(), ev()
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        total += a.elapsed_time(b)
+    return total / reps
+
+
+def hbm_roofline(kernel, bytes_per_launch, ms, **extra):
+    gbs = bytes_per_launch / ms / 1e6
+    out = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": ms}
+    out.update(extra)
+    return out
+
+
+def sized_sample(run_small, small_units, seconds_per_trial, lo, hi):
+    """Rows (orders, scale factor ...) for one trial of about `seconds_per_trial`, from one calibration run."""
+    secs = max(run_small(), 1e-6)
+    return int(min(hi, max(lo, small_units / secs * seconds_per_trial)))
+
+
+def q1_coded_config():
+    cfg = q1_config()
+    for c in (2, 4, 5):                      # l_quantity, l_discount, l_tax: 1-byte dictionary codes (create.sql:69-121)
+        cfg.column_code_width[c] = 1
+    return cfg
+
+
+def minimal_config():
+    return T.make_agg_config(T.AGG_COMPACT_KEY, [(T.INT, None), (T.INT, None), (T.DOUBLE, None)], keys=[0, 1],
+                             aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None), (T.AGG_AVG, T.col(2))], est_groups=9)
+
+
+def secondary_q1_coded(ctx, args, threads):
+    """C3 over lineitem as the reference's DDL stores it: CompressedColumnStore, l_quantity / l_discount / l_tax as 1-byte
+    dictionary codes, the keys CHAR(1), l_extendedprice a plain DOUBLE stripe: 1 + 1 + 1 + 8 + 1 + 1 = 13 B/row.  The
+    columns are the headline's (codes of the same values), so the result must equal the headline's."""
+    dev, n = ctx.dev, args.agg_rows
+    k1, k2, qty, price, disc, tax = ctx.headline["agg_cols"]
+    qty_c = (qty - 1.0).to(torch.uint8)
+    disc_c = (disc * 100.0).round().to(torch.uint8)
+    tax_c = (tax * 100.0).round().to(torch.uint8)
+    dicts = [None, None, torch.arange(1, 51, device=dev, dtype=torch.float64), None,
+             torch.arange(0, 11, device=dev, dtype=torch.float64) / 100, torch.arange(0, 9, device=dev, dtype=torch.float64) / 100]
+    cols = [k1, k2, qty_c, price, disc_c, tax_c]
+    jit_env = os.environ.get("QSX_AGG_JIT_MIN_ROWS")
+    os.environ["QSX_AGG_JIT_MIN_ROWS"] = "0"      # the plan shape is built in the calling thread before the first launch
+    st = capi.AggState(q1_coded_config())
+    st.clear()
+    st.update_coded(cols, dicts, n)               # first use: the shape's compile (or its load from QSX_JIT_CACHE_DIR)
+    torch.cuda.synchronize()
+    if jit_env is None:
+        os.environ.pop("QSX_AGG_JIT_MIN_ROWS")
+    else:
+        os.environ["QSX_AGG_JIT_MIN_ROWS"] = jit_env
+
+    def one():
+        st.clear()
+        st.update_coded(cols, dicts, n)
+    ms_clear_update = launches_ms(one)
+    ms = launches_ms(lambda: st.update_coded(cols, dicts, n), warm=0)
+    st.clear()
+    st.update_coded(cols, dicts, n)
+    ck, cv, _, cg = st.finalize(dev, capacity=16)
+    checked = False
+    if not args.no_check:
+        hk, hv, _, hg = ctx.headline["fin"]
+        g = int(hg.item())
+        assert int(cg.item()) == g, "groups over code stripes differ from the plain columns'"
+        oc = torch.argsort(ck[0][:g].long() * 256 + ck[1][:g].long())
+        oh = torch.argsort(hk[0][:g].long() * 256 + hk[1][:g].long())
+        for a in range(len(hv)):
+            x, y = cv[a][:g][oc], hv[a][:g][oh]
+            if a in (0, 7):      # SUM(l_quantity) (integer-valued doubles) and COUNT(*): exact
+                assert bool((x == y).all()), f"aggregate {a} over code stripes is not exact"
+            else:
+                assert bool(torch.allclose(x.double(), y.double(), rtol=1e-9, atol=0.0)), f"aggregate {a} over code stripes differs"
+        checked = True
+    st.close()
+    out = {"workload": f"C3 Q1 aggregation over CompressedColumnStore lineitem: {n} rows, 13 B/row (l_quantity / l_discount / "
+                       "l_tax 1-byte dictionary codes decoded in the kernel)",
+           "ms": ms, "ms_with_clear": ms_clear_update, "rows_per_s": n / ms * 1e3,
+           "roofline": hbm_roofline("qsx_jit_agg (qsx_agg_update_coded_sized; run-time plan shape of the Q1 aggregation over code stripes)",
+                                    13 * n, ms, algorithmic_bytes_per_row=13),
+           "checked": checked}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_q1_coded(args, threads)
+    return out
+
+
+def cpu_baseline_q1_coded(args, threads):
+    from oracle import pyoracle as O
+    cfg = q1_coded_config()
+    block = 4 * 1024 * 1024 // 13
+    rng = np.random.default_rng(4)
+
+    def gen(n):
+        combo = rng.choice(4, size=n, p=[0.2466, 0.0065, 0.5005, 0.2464])
+        return [np.frombuffer(b"ANNR", dtype=np.uint8)[combo], np.frombuffer(b"FFOF", dtype=np.uint8)[combo],
+                rng.integers(0, 50, size=n).astype(np.uint8), np.round(rng.uniform(900, 105000, size=n), 2),
+                rng.integers(0, 11, size=n).astype(np.uint8), rng.integers(0, 9, size=n).astype(np.uint8)]
+    dicts = [None, None, np.arange(1, 51, dtype=np.float64), None, np.arange(11) / 100.0, np.arange(9) / 100.0]
+
+    def run(cols, n):
+        secs, st = O.bench_agg_coded(cfg, cols, dicts, n, block, threads)
+        st.close()
+        return secs
+    small = gen(1_000_000)
+    n = sized_sample(lambda: run(small, 1_000_000), 1_000_000, args.secondary_cpu_seconds / 5.0, 2_000_000, 40_000_000)
+    cols = gen(n)
+    secs, trials = trials_2_to_4(lambda: run(cols, n))
+    return {"value": n / secs, "unit": "rows/s", "cores": threads, "kind": "port", "trials_s": trials,
+            "sample": f"oracle: ThreadPrivateCompactKey aggregation over CompressedColumnStore blocks (per-value dictionary decode, "
+                      f"CompressedColumnStoreValueAccessor.hpp:90-150), {n} rows in 4 MB blocks, {threads} worker threads; 5 trials, mean of 2-4"}
+
+
+def secondary_c3_minimal(ctx, args, threads):
+    """BASELINE config 3 as its one-line description reads: SUM / COUNT / AVG GROUP BY 2 keys — two INT keys (3 x 3 groups)
+    and one DOUBLE, 16 B/row (SURVEY.md §8(d) "minimal variant")."""
+    dev, n = ctx.dev, args.agg_rows
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    k1 = torch.randint(0, 3, (n,), device=dev, generator=g, dtype=torch.int32)
+    k2 = torch.randint(0, 3, (n,), device=dev, generator=g, dtype=torch.int32)
+    val = torch.rand(n, device=dev, generator=g, dtype=torch.float64)
+    st = capi.AggState(minimal_config())
+    cols = [k1, k2, val]
+
+    def one():
+        st.clear()
+        st.update(cols, n)
+    ms_clear_update = launches_ms(one)
+    ms = launches_ms(lambda: st.update(cols, n), warm=0)
+    st.clear()
+    st.update(cols, n)
+    keys, vals, _, groups = st.finalize(dev, capacity=16)
+    checked = False
+    if not args.no_check:
+        gcount = int(groups.item())
+        assert gcount == 9, gcount
+        combo = keys[0][:gcount].long() * 3 + keys[1][:gcount].long()
+        want_count = torch.bincount(k1.long() * 3 + k2.long(), minlength=9)
+        assert bool((vals[1][:gcount] == want_count[combo]).all()), "COUNT(*) per group differs from a bincount of the keys"
+        for i in range(gcount):
+            mask = (k1 == keys[0][i]) & (k2 == keys[1][i])
+            ref = torch.where(mask, val, torch.zeros((), dtype=torch.float64, device=dev)).sum().item()
+            assert abs(vals[0][i].item() - ref) <= 1e-6 * abs(ref), "SUM per group differs from a torch reduction"
+            assert abs(vals[2][i].item() - ref / want_count[combo[i]].item()) <= 1e-6 * abs(ref), "AVG per group differs"
+            del mask
+        checked = True
+    st.close()
+    out = {"workload": f"C3 minimal variant: SUM / COUNT / AVG GROUP BY 2 INT keys over {n} rows, 16 B/row",
+           "ms": ms, "ms_with_clear": ms_clear_update, "rows_per_s": n / ms * 1e3,
+           "roofline": hbm_roofline("agg_hash_shape_fixed_kernel<ShapeTwoIntKeysSumCountAvg,...> (qsx_agg_update; AOT plan shape)",
+                                    16 * n, ms, algorithmic_bytes_per_row=16),
+           "checked": checked}
+    del k1, k2, val
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as O
+        cfg = minimal_config()
+        rng = np.random.default_rng(9)
+
+        def gen(m):
+            return [rng.integers(0, 3, size=m).astype(np.int32), rng.integers(0, 3, size=m).astype(np.int32), rng.random(m)]
+
+        def run(c, m):
+            secs, s_ = O.bench_agg(cfg, c, m, 4 * 1024 * 1024 // 16, threads)
+            s_.close()
+            return secs
+        small = gen(1_000_000)
+        m = sized_sample(lambda: run(small, 1_000_000), 1_000_000, args.secondary_cpu_seconds / 5.0, 2_000_000, 60_000_000)
+        c = gen(m)
+        secs, trials = trials_2_to_4(lambda: run(c, m))
+        out["cpu_baseline"] = {"value": m / secs, "unit": "rows/s", "cores": threads, "kind": "port", "trials_s": trials,
+                               "sample": f"oracle: ThreadPrivateCompactKey aggregation, {m} rows in 4 MB blocks, {threads} worker threads; 5 trials, mean of 2-4"}
+    return out
+
+
+def condensed(line):
+    """What a partitioned configuration's own line (--config c4 | c5) contributes to `secondary`."""
+    return {"workload": line["config"]["workload"], "ms": line["ms_per_step"], "rows_per_s": line["value"],
+            "roofline": line["roofline"], "checked": line["checked"], "phases_ms": line["phases_ms"],
+            "config": {k: v for k, v in line["config"].items() if k != "workload"}}
+
+
+def secondary_c4(ctx, args, threads):
+    from quickstep_amd import plans
+    sub = argparse.Namespace(**vars(args))
+    sub.steps, sub.warmup = args.secondary_steps, 2
+    out = condensed(run_c4(ctx, sub))
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as O
+        P, block = 8, 4 * 1024 * 1024 // 12      # SF100 over 8 partitions; 4 MB blocks of (INT key, 8-byte payload)
+
+        def host(n_o):
+            inp = plans.generate_c4_inputs(ctx.dev, n_o, 0)
+            return [inp[k].cpu().numpy() for k in ("o_orderkey", "o_payload", "l_orderkey", "l_payload")]
+
+        def run(cols):
+            r = O.bench_partitioned_join(cols[0], cols[1], cols[2], cols[3], P, block, threads)
+            assert r["violations"] == 0 and r["output_rows"] == cols[2].size
+            return r["repartition_seconds"] + r["build_seconds"] + r["probe_seconds"], r
+        small = host(500_000)
+        n_o = sized_sample(lambda: run(small)[0], 500_000, args.secondary_cpu_seconds / 5.0, 1_000_000, args.c4_orders_per_rank)
+        cols = host(n_o)
+        last = {}
+
+        def trial():
+            secs, r = run(cols)
+            last.update(r)
+            return secs
+        secs, trials = trials_2_to_4(trial)
+        rows = cols[0].size + cols[2].size
+        out["cpu_baseline"] = {"value": rows / secs, "unit": "rows/s", "cores": threads, "kind": "port", "trials_s": trials,
+                               "phases_s": {k: last[k] for k in ("repartition_seconds", "build_seconds", "probe_seconds")},
+                               "sample": f"oracle: both relations through a repartitioning Select into {P} hash partitions "
+                                         f"(PartitionSchemeHeader.hpp:200-214), per-partition SimpleScalarSeparateChaining build + probe + "
+                                         f"materialised (key, o_payload, l_payload) (HashJoinOperator.cpp:220-231, 450-541), one address "
+                                         f"space; {cols[0].size} orders + {cols[2].size} lineitems, {threads} worker threads; 5 trials, mean of 2-4"}
+    return out
+
+
+def secondary_c5(ctx, args, threads):
+    from quickstep_amd import plans
+    sub = argparse.Namespace(**vars(args))
+    sub.steps, sub.warmup = args.secondary_steps, 2
+    out = condensed(run_c5(ctx, sub))
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as O
+
+        def host(sf):
+            inp = plans.generate_q3_inputs(ctx.dev, sf, 0, 1)
+            return {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in inp.items()}
+
+        def run(inp):
+            r = O.bench_q3(inp, plans.SEG_BUILDING, plans.DATE_CUT, 262144, threads)
+            return r["total_seconds"], r
+        small = host(0.5)
+        sf = sized_sample(lambda: run(small)[0], 500, args.secondary_cpu_seconds / 5.0, 1000, int(args.c5_sf_per_rank * 1000)) / 1000.0
+        inp = host(sf)
+        last = {}
+
+        def trial():
+            secs, r = run(inp)
+            last.update(r)
+            return secs
+        secs, trials = trials_2_to_4(trial)
+        rows = inp["c_custkey"].size + inp["o_orderkey"].size + inp["l_orderkey"].size
+        out["cpu_baseline"] = {"value": rows / secs, "unit": "rows/s", "cores": threads, "kind": "port", "trials_s": trials,
+                               "phases_s": {k: last[k] for k in ("customer_seconds", "orders_seconds", "lineitem_seconds", "finalize_seconds")},
+                               "groups": last["groups"], "pairs": last["pairs"],
+                               "sample": f"oracle: Q3 in one process at SF {sf} ({rows} input rows): selects, exact LIP bit vectors on "
+                                         f"custkey / orderkey, two SimpleScalarSeparateChaining joins, CollisionFreeVector SUM on l_orderkey, "
+                                         f"top 10; block-at-a-time, {threads} worker threads; 5 trials, mean of 2-4"}
+    return out
+
+
+def secondary_block(ctx, args):
+    """Runs after the headline's timed region and checks, in the same process: the driver's clock covers it."""
+    t_start = time.perf_counter()
+    threads = usable_cores()
+    out = {}
+    legs = [("q1_coded", secondary_q1_coded), ("c3_minimal", secondary_c3_minimal)]
+    for name, fn in legs:
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn(ctx, args, threads)
+        except Exception as exc:  # noqa: BLE001  (a secondary leg never takes the headline line down; its failure is in the line)
+            out[name] = {"error": repr(exc)[:400], "checked": False}
+        out[name]["wall_s"] = time.perf_counter() - t0
+    ctx.headline = None          # the 20 GB of Q1 columns are not needed any more
+    torch.cuda.empty_cache()
+    # C4 / C5 are written against a process group at any N: one rank over RCCL here
+    group_made = False
+    try:
+        if not dist.is_initialized():
+            import socket
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1"})
+            dist.init_process_group(backend="nccl", device_id=ctx.dev)
+            group_made = True
+        sub = Ctx()
+        sub.dev, sub.rank, sub.world, sub.distributed, sub.group = ctx.dev, 0, 1, True, None
+        for name, fn in (("c4", secondary_c4), ("c5", secondary_c5)):
+            t0 = time.perf_counter()
+            try:
+                out[name] = fn(sub, args, threads)
+            except Exception as exc:  # noqa: BLE001
+                out[name] = {"error": repr(exc)[:400], "checked": False}
+            out[name]["wall_s"] = time.perf_counter() - t0
+            torch.cuda.empty_cache()
+    finally:
+        if group_made:
+            dist.destroy_process_group()
+    out["wall_s"] = time.perf_counter() - t_start
+    return out
 
 
 def operators_leg(args, raw_value):
@@ -813,6 +1133,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the result checks after the timed region")
     ap.add_argument("--no-probe-variants", action="store_true", help="N = 1: skip the other C2 legs (PMC passes: only the headline's own launches)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1: skip the `secondary` block (Q1 over code stripes, C3 minimal, C4, C5 with their cpu baselines)")
+    ap.add_argument("--secondary-steps", type=int, default=5, help="timed steps of the C4 / C5 legs of `secondary`")
+    ap.add_argument("--secondary-cpu-seconds", type=float, default=4.0, help="CPU time budget per `secondary` cpu_baseline (5 trials in all)")
     ap.add_argument("--no-operators", action="store_true", help="N = 1: skip the leg that runs the workload through the C++ operator layer")
     ap.add_argument("--operator-workers", type=int, default=8)
     ap.add_argument("--blocks-per-work-order", type=int, default=256)
@@ -879,7 +1203,11 @@ def main():
         from quickstep_amd import distributed as qd
         ctx.group = qd.CapiGroup.from_torch_group(capi, dev)
 
+    want_secondary = rank == 0 and world == 1 and args.config == "headline" and not args.no_secondary and not ctx.distributed
+    ctx.keep_headline = want_secondary
     line = {"headline": run_headline, "c4": run_c4, "c5": run_c5}[args.config](ctx, args)
+    if want_secondary:
+        line["secondary"] = secondary_block(ctx, args)
     line["world_size_seen"] = dist.get_world_size() if ctx.distributed else 1      # what the RCCL process group reports
     line["self_launched"] = os.environ.get("QSX_BENCH_SELF_LAUNCHED") == "1"
     line["transport"] = args.transport if ctx.distributed else None

@@ -44,6 +44,25 @@ class JoinBenchResult(C.Structure):
                 ("checksum", C.c_uint64)]
 
 
+class PartitionedJoinResult(C.Structure):
+    _fields_ = [("repartition_seconds", C.c_double), ("build_seconds", C.c_double), ("probe_seconds", C.c_double),
+                ("output_rows", C.c_int64), ("violations", C.c_int64), ("checksum", C.c_uint64)]
+
+
+class Q3Inputs(C.Structure):
+    _fields_ = [("c_custkey", C.c_void_p), ("c_mktsegment", C.c_void_p), ("n_customer", C.c_int64),
+                ("o_orderkey", C.c_void_p), ("o_custkey", C.c_void_p), ("o_orderdate", C.c_void_p), ("n_orders", C.c_int64),
+                ("l_orderkey", C.c_void_p), ("l_shipdate", C.c_void_p), ("l_extendedprice", C.c_void_p),
+                ("l_discount", C.c_void_p), ("n_lineitem", C.c_int64), ("customers_total", C.c_int64),
+                ("orders_total", C.c_int64), ("segment", C.c_int32), ("date_cut", C.c_int32)]
+
+
+class Q3Result(C.Structure):
+    _fields_ = [("customer_seconds", C.c_double), ("orders_seconds", C.c_double), ("lineitem_seconds", C.c_double),
+                ("finalize_seconds", C.c_double), ("total_seconds", C.c_double), ("qualifying_orders", C.c_int64),
+                ("pairs", C.c_int64), ("groups", C.c_int64), ("top_revenue", C.c_double * 10), ("top_orderkey", C.c_int32 * 10)]
+
+
 for _name, _res, _args in [
     ("qso_sizeof_agg_config", _sz, []),
     ("qso_hash_scalar", _u64, [_int, _vp]),
@@ -96,6 +115,9 @@ for _name, _res, _args in [
     ("qso_bench_join", None, [_int, _vp, _i64, _vp, _i64, _i64, _int, C.POINTER(JoinBenchResult)]),
     ("qso_bench_agg", C.c_double, [C.POINTER(T.AggConfig), _pp, _i64, _i64, _int, _pp]),
     ("qso_bench_select", C.c_double, [_int, _vp, _i64, _int, _vp, _i64, _int, _vp, C.POINTER(_i64)]),
+    ("qso_bench_agg_coded", C.c_double, [C.POINTER(T.AggConfig), _pp, _pp, _i64, _i64, _int, _pp]),
+    ("qso_bench_partitioned_join", None, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _i64, _int, C.POINTER(PartitionedJoinResult)]),
+    ("qso_bench_q3", None, [C.POINTER(Q3Inputs), _i64, _int, C.POINTER(Q3Result)]),
 ]:
     _f = getattr(_lib, _name)
     _f.restype = _res
@@ -544,3 +566,40 @@ def bench_select(col, op, literal, block_rows, num_threads):
     secs = _lib.qso_bench_select(qtype(col), _p(col), col.size, op, C.byref(lit), block_rows, num_threads, _p(out),
                                  C.byref(rows))
     return secs, out[:rows.value]
+
+
+def bench_agg_coded(config, cols, dictionaries, n, block_rows, num_threads):
+    """cols: code stripes for the columns with column_code_width != 0, plain stripes otherwise; dictionaries: one per column or None."""
+    h = C.c_void_p()
+    secs = _lib.qso_bench_agg_coded(C.byref(config), _ptr_array(cols), _ptr_array(dictionaries), n, block_rows, num_threads, C.byref(h))
+    return secs, AggState(config, handle=h)
+
+
+def bench_partitioned_join(o_key, o_payload, l_key, l_payload, num_partitions, block_rows, num_threads):
+    """BASELINE config 4 in one process (repartition both sides, per-partition build / probe / materialise)."""
+    assert o_key.dtype == np.int32 and l_key.dtype == np.int32 and o_payload.dtype == np.int64 and l_payload.dtype == np.int64
+    r = PartitionedJoinResult()
+    _lib.qso_bench_partitioned_join(_p(o_key), _p(o_payload), o_key.size, _p(l_key), _p(l_payload), l_key.size,
+                                    num_partitions, block_rows, num_threads, C.byref(r))
+    return {f: getattr(r, f) for f, _ in PartitionedJoinResult._fields_}
+
+
+def bench_q3(inputs, segment, date_cut, block_rows, num_threads):
+    """BASELINE config 5 in one process.  inputs: dict of numpy columns (int32 keys / dates / segment codes, float64 price and
+    discount) plus customers_total, orders_total."""
+    a = Q3Inputs()
+    keep = []
+    for name, dt in (("c_custkey", np.int32), ("c_mktsegment", np.int32), ("o_orderkey", np.int32), ("o_custkey", np.int32),
+                     ("o_orderdate", np.int32), ("l_orderkey", np.int32), ("l_shipdate", np.int32),
+                     ("l_extendedprice", np.float64), ("l_discount", np.float64)):
+        arr = np.ascontiguousarray(inputs[name], dtype=dt)
+        keep.append(arr)
+        setattr(a, name, arr.ctypes.data)
+    a.n_customer, a.n_orders, a.n_lineitem = inputs["c_custkey"].size, inputs["o_orderkey"].size, inputs["l_orderkey"].size
+    a.customers_total, a.orders_total = int(inputs["customers_total"]), int(inputs["orders_total"])
+    a.segment, a.date_cut = int(segment), int(date_cut)
+    r = Q3Result()
+    _lib.qso_bench_q3(C.byref(a), block_rows, num_threads, C.byref(r))
+    out = {f: getattr(r, f) for f, _ in Q3Result._fields_}
+    out["top_revenue"], out["top_orderkey"] = list(r.top_revenue), list(r.top_orderkey)
+    return out

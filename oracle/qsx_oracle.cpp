@@ -1508,6 +1508,359 @@ double qso_bench_agg(const qsx_agg_config_t *config, const void *const *cols, in
   return elapsed;
 }
 
+double qso_bench_agg_coded(const qsx_agg_config_t *config, const void *const *cols, const void *const *dictionaries,
+                           int64_t n, int64_t block_rows, int num_threads, qso_agg_state_t **out_state) {
+  // AggregationWorkOrder over CompressedColumnStore blocks: the accessor hands out dictionary[code] / the widened code
+  // per value (storage/CompressedColumnStoreValueAccessor.hpp:90-150); the rest is qso_bench_agg (per-worker tables
+  // from the pool, merged at finalize).
+  const int64_t blocks = (n + block_rows - 1) / block_rows;
+  std::vector<qso_agg_state_t *> priv(num_threads, nullptr);
+  for (int t = 0; t < num_threads; ++t) priv[t] = qso_agg_state_create(config);
+  Clock::time_point t0 = Clock::now();
+  run_work_orders(blocks, num_threads, [&](int64_t b, int t) {
+    const int64_t begin = b * block_rows, rows = std::min(block_rows, n - begin);
+    const void *block_cols[QSX_MAX_COLUMNS];
+    for (int c = 0; c < config->num_columns; ++c) {
+      const int w = config->column_code_width[c] != 0 ? config->column_code_width[c] : config->column_width[c];
+      block_cols[c] = static_cast<const char *>(cols[c]) + begin * w;
+    }
+    qso_agg_update_coded(priv[t], block_cols, dictionaries, rows, nullptr);
+  });
+  for (int t = 1; t < num_threads; ++t) priv[0]->merge_from(*priv[t]);
+  const double elapsed = seconds_since(t0);
+  for (int t = 1; t < num_threads; ++t) qso_agg_state_destroy(priv[t]);
+  if (out_state != nullptr) *out_state = priv[0]; else qso_agg_state_destroy(priv[0]);
+  return elapsed;
+}
+
+}  // extern "C"
+
+namespace {
+
+// One relation of (INT key, 8-byte payload) kept as blocks: what a PartitionAwareInsertDestination leaves behind for one
+// partition (storage/InsertDestination.hpp:490-660) — a list of blocks, each filled up to `block_rows` tuples.
+struct KeyPayloadBlock {
+  std::vector<std::int32_t> key;
+  std::vector<std::int64_t> payload;
+};
+struct PartitionBlocks {
+  std::mutex mutex;                       // available_block_refs_ / done_block_ids_ are guarded per partition (:640-660)
+  std::vector<KeyPayloadBlock> blocks;    // the last one is the partially filled block
+};
+
+// Select with has_repartition (relational_operators/SelectOperator.cpp:161-195 -> PartitionAwareInsertDestination::
+// bulkInsertTuples, storage/InsertDestination.cpp:560-640): per input block the partition id of every tuple
+// (HashPartitionSchemeHeader::getPartitionId, catalog/PartitionSchemeHeader.hpp:200-214), then one bulk insert per
+// partition into that partition's current block(s).
+void repartition_relation(const std::int32_t *key, const std::int64_t *payload, std::int64_t n, int num_partitions,
+                          std::int64_t block_rows, int num_threads, std::vector<PartitionBlocks> *parts) {
+  const std::int64_t blocks = (n + block_rows - 1) / block_rows;
+  run_work_orders(blocks, num_threads, [&](std::int64_t b, int) {
+    const std::int64_t begin = b * block_rows, rows = std::min(block_rows, n - begin);
+    std::vector<std::vector<std::int32_t>> membership(num_partitions);     // tuple ids per partition (:575-590)
+    for (std::int64_t i = 0; i < rows; ++i) {
+      const std::uint64_t h = hash_int(key[begin + i]);
+      membership[partition_id(h, num_partitions)].push_back(static_cast<std::int32_t>(i));
+    }
+    for (int p = 0; p < num_partitions; ++p) {
+      const std::vector<std::int32_t> &mine = membership[p];
+      std::size_t done = 0;
+      while (done < mine.size()) {
+        // getBlockForInsertionInPartition: take the partition's partially filled block out of the pool under its mutex,
+        // fill it outside the lock, return it (:600-640)
+        KeyPayloadBlock blk;
+        {
+          std::lock_guard<std::mutex> lock((*parts)[p].mutex);
+          std::vector<KeyPayloadBlock> &list = (*parts)[p].blocks;
+          if (!list.empty() && static_cast<std::int64_t>(list.back().key.size()) < block_rows) {
+            blk = std::move(list.back());
+            list.pop_back();
+          }
+        }
+        const std::size_t room = static_cast<std::size_t>(block_rows) - blk.key.size();
+        const std::size_t take = std::min(room, mine.size() - done);
+        for (std::size_t j = 0; j < take; ++j) {
+          blk.key.push_back(key[begin + mine[done + j]]);
+          blk.payload.push_back(payload[begin + mine[done + j]]);
+        }
+        done += take;
+        std::lock_guard<std::mutex> lock((*parts)[p].mutex);
+        std::vector<KeyPayloadBlock> &list = (*parts)[p].blocks;
+        // keep the invariant "only the last block may be partially filled"
+        if (!list.empty() && static_cast<std::int64_t>(list.back().key.size()) < block_rows &&
+            static_cast<std::int64_t>(blk.key.size()) == block_rows) {
+          list.insert(list.end() - 1, std::move(blk));
+        } else {
+          list.push_back(std::move(blk));
+        }
+      }
+    }
+  });
+}
+
+inline void atomic_or_bit(std::atomic<std::uint64_t> *words, std::uint64_t bit) {
+  // BarrieredReadWriteConcurrentBitVector::setBit (utility/BarrieredReadWriteConcurrentBitVector.hpp): fetch_or, relaxed
+  words[bit >> 6].fetch_or(static_cast<std::uint64_t>(1) << (bit & 63), std::memory_order_relaxed);
+}
+inline bool test_bit(const std::atomic<std::uint64_t> *words, std::uint64_t bit) {
+  return (words[bit >> 6].load(std::memory_order_relaxed) >> (bit & 63)) & 1u;
+}
+
+}  // namespace
+
+extern "C" {
+
+void qso_bench_partitioned_join(const int32_t *o_key, const int64_t *o_payload, int64_t n_o, const int32_t *l_key,
+                                const int64_t *l_payload, int64_t n_l, int num_partitions, int64_t block_rows,
+                                int num_threads, qso_partitioned_join_result_t *out) {
+  // BASELINE config 4 the way one reference process runs it (all partitions in one address space): both relations pass
+  // a repartitioning Select, then per partition BuildHashWorkOrders (BuildHashOperator.cpp:82-91, 162-207) and
+  // HashInnerJoinWorkOrders (HashJoinOperator.cpp:220-231, 450-541) over that partition's blocks and table.
+  std::vector<PartitionBlocks> o_parts(num_partitions), l_parts(num_partitions);
+  Clock::time_point t0 = Clock::now();
+  repartition_relation(o_key, o_payload, n_o, num_partitions, block_rows, num_threads, &o_parts);
+  repartition_relation(l_key, l_payload, n_l, num_partitions, block_rows, num_threads, &l_parts);
+  out->repartition_seconds = seconds_since(t0);
+
+  // one JoinHashTable per partition, sized by the optimizer's estimate of the partition (ExecutionGenerator.cpp:903-904)
+  std::vector<qso_join_table_t *> tables(num_partitions);
+  struct Unit { int part; std::int64_t block; };
+  std::vector<Unit> build_units, probe_units;
+  for (int p = 0; p < num_partitions; ++p) {
+    tables[p] = qso_join_table_create(QSX_INT, std::max<std::int64_t>(1, n_o / num_partitions));
+    for (std::size_t b = 0; b < o_parts[p].blocks.size(); ++b) build_units.push_back({p, static_cast<std::int64_t>(b)});
+    for (std::size_t b = 0; b < l_parts[p].blocks.size(); ++b) probe_units.push_back({p, static_cast<std::int64_t>(b)});
+  }
+  t0 = Clock::now();
+  run_work_orders(static_cast<std::int64_t>(build_units.size()), num_threads, [&](std::int64_t u, int) {
+    const Unit &unit = build_units[u];
+    const KeyPayloadBlock &blk = o_parts[unit.part].blocks[unit.block];
+    tables[unit.part]->put_block(blk.key.data(), static_cast<std::int64_t>(blk.key.size()),
+                                 static_cast<std::uint64_t>(unit.block), 0, nullptr);
+  });
+  out->build_seconds = seconds_since(t0);
+
+  std::vector<std::int64_t> rows_out(num_threads, 0);
+  std::vector<std::uint64_t> checks(num_threads, 0);
+  std::vector<std::int64_t> violations(num_threads, 0);
+  t0 = Clock::now();
+  run_work_orders(static_cast<std::int64_t>(probe_units.size()), num_threads, [&](std::int64_t u, int t) {
+    const Unit &unit = probe_units[u];
+    const KeyPayloadBlock &probe = l_parts[unit.part].blocks[unit.block];
+    const qso_join_table_t *table = tables[unit.part];
+    // collect (probe_tid, build_tid) per build block (HashJoinOperator.cpp:76-102) ...
+    std::unordered_map<std::uint64_t, std::vector<std::pair<std::int32_t, std::int32_t>>> joined;
+    const std::int64_t rows = static_cast<std::int64_t>(probe.key.size());
+    for (std::int64_t i = 0; i < rows; ++i) {
+      const std::uint64_t hash = hash_int(probe.key[i]);
+      std::uint64_t entry = table->st.slots[hash % table->st.num_slots].load(std::memory_order_relaxed);
+      while (entry != 0) {
+        const Bucket &bucket = table->st.buckets[entry - 1];
+        entry = bucket.next.load(std::memory_order_relaxed);
+        if (bucket.hash == hash) joined[bucket.value.block].emplace_back(static_cast<std::int32_t>(i), bucket.value.tuple);
+      }
+    }
+    // ... then one output ColumnVector per attribute and build block, bulk-inserted (:494-540): (key, o_payload, l_payload)
+    for (const auto &kv : joined) {
+      const KeyPayloadBlock &build = o_parts[unit.part].blocks[kv.first];
+      const std::size_t m = kv.second.size();
+      std::vector<std::int32_t> out_key(m);
+      std::vector<std::int64_t> out_o(m), out_l(m);
+      for (std::size_t j = 0; j < m; ++j) out_key[j] = probe.key[kv.second[j].first];
+      for (std::size_t j = 0; j < m; ++j) out_o[j] = build.payload[kv.second[j].second];
+      for (std::size_t j = 0; j < m; ++j) out_l[j] = probe.payload[kv.second[j].first];
+      for (std::size_t j = 0; j < m; ++j) {
+        checks[t] += static_cast<std::uint64_t>(out_o[j]) * 1000003ULL + static_cast<std::uint64_t>(out_l[j]) +
+                     static_cast<std::uint32_t>(out_key[j]);
+        violations[t] += build.key[kv.second[j].second] != out_key[j];
+      }
+      rows_out[t] += static_cast<std::int64_t>(m);
+    }
+  });
+  out->probe_seconds = seconds_since(t0);
+  out->output_rows = 0;
+  out->checksum = 0;
+  out->violations = 0;
+  for (int t = 0; t < num_threads; ++t) {
+    out->output_rows += rows_out[t];
+    out->checksum += checks[t];
+    out->violations += violations[t];
+  }
+  for (int p = 0; p < num_partitions; ++p) qso_join_table_destroy(tables[p]);
+}
+
+void qso_bench_q3(const qso_q3_inputs_t *in, int64_t block_rows, int num_threads, qso_q3_result_t *out) {
+  // BASELINE config 5 as one reference process runs TPC-H Q3 (benchmarks/tpch/queries/03.sql) with LIP filters attached
+  // (query_optimizer/rules/AttachLIPFilters.cpp:131-164: exact bit vectors on custkey and orderkey) and the
+  // CollisionFreeVector aggregation on l_orderkey (StarSchemaSimpleCostModel.cpp:614-776).  Every operator is
+  // block-at-a-time work orders over num_threads workers; an operator starts when its producer has finished.
+  const std::int64_t n_c = in->n_customer, n_o = in->n_orders, n_l = in->n_lineitem;
+  const std::int64_t c_words = (in->customers_total + 1 + 63) / 64, o_words = (in->orders_total + 1 + 63) / 64;
+  std::unique_ptr<std::atomic<std::uint64_t>[]> lip_c(new std::atomic<std::uint64_t>[c_words]);
+  std::unique_ptr<std::atomic<std::uint64_t>[]> lip_o(new std::atomic<std::uint64_t>[o_words]);
+  std::unique_ptr<std::atomic<std::uint64_t>[]> exist(new std::atomic<std::uint64_t>[o_words]);
+  std::unique_ptr<std::atomic<double>[]> revenue(new std::atomic<double>[in->orders_total + 1]);
+  Clock::time_point t_all = Clock::now();
+  // InitializeAggregationWorkOrders zero the state in partitions (CollisionFreeVectorTable.hpp:136-143): part of the query
+  run_work_orders(num_threads, num_threads, [&](std::int64_t p, int) {
+    const std::int64_t per = (in->orders_total + 1 + num_threads - 1) / num_threads;
+    const std::int64_t a = p * per, b = std::min<std::int64_t>(in->orders_total + 1, a + per);
+    for (std::int64_t i = a; i < b; ++i) revenue[i].store(0.0, std::memory_order_relaxed);
+    const std::int64_t wper = (o_words + num_threads - 1) / num_threads;
+    for (std::int64_t i = p * wper; i < std::min(o_words, (p + 1) * wper); ++i) {
+      lip_o[i].store(0, std::memory_order_relaxed);
+      exist[i].store(0, std::memory_order_relaxed);
+    }
+    const std::int64_t cper = (c_words + num_threads - 1) / num_threads;
+    for (std::int64_t i = p * cper; i < std::min(c_words, (p + 1) * cper); ++i) lip_c[i].store(0, std::memory_order_relaxed);
+  });
+
+  // customer: BuildHashWorkOrder under the predicate c_mktsegment = 'BUILDING', with its LIPFilterBuilder
+  // (BuildHashOperator.cpp:162-207)
+  qso_join_table_t *t_c = qso_join_table_create(QSX_INT, std::max<std::int64_t>(1, n_c / 5));
+  Clock::time_point t0 = Clock::now();
+  run_work_orders((n_c + block_rows - 1) / block_rows, num_threads, [&](std::int64_t b, int) {
+    const std::int64_t begin = b * block_rows, rows = std::min(block_rows, n_c - begin);
+    std::vector<std::uint64_t> sel(bitmap_words(rows));
+    qso_select_cmp(QSX_INT, in->c_mktsegment + begin, rows, QSX_EQ, &in->segment, nullptr, sel.data());
+    for (std::int64_t i = 0; i < rows; ++i) {
+      if (bit_get(sel.data(), i)) atomic_or_bit(lip_c.get(), static_cast<std::uint64_t>(in->c_custkey[begin + i]));
+    }
+    t_c->put_block(in->c_custkey + begin, rows, static_cast<std::uint64_t>(b), 0, sel.data());
+  });
+  out->customer_seconds = seconds_since(t0);
+
+  // orders: HashInnerJoinWorkOrder probing the customer table under o_orderdate < DATE and the LIP filter on o_custkey;
+  // output relation (o_orderkey) into temporary blocks (one per work order here)
+  struct OrdersOut { std::vector<std::int32_t> orderkey; };
+  const std::int64_t o_blocks = (n_o + block_rows - 1) / block_rows;
+  std::vector<OrdersOut> o_out(o_blocks);
+  t0 = Clock::now();
+  run_work_orders(o_blocks, num_threads, [&](std::int64_t b, int) {
+    const std::int64_t begin = b * block_rows, rows = std::min(block_rows, n_o - begin);
+    std::vector<std::uint64_t> sel(bitmap_words(rows));
+    qso_select_cmp(QSX_INT, in->o_orderdate + begin, rows, QSX_LT, &in->date_cut, nullptr, sel.data());
+    // LIPFilterAdaptiveProber::filterValueAccessor (utility/lip_filter/LIPFilterAdaptiveProber.hpp:113-228)
+    std::vector<std::int32_t> live;
+    for (std::int64_t i = 0; i < rows; ++i) {
+      if (!bit_get(sel.data(), i)) continue;
+      const std::int32_t ck = in->o_custkey[begin + i];
+      if (ck < 0 || ck > in->customers_total || !test_bit(lip_c.get(), static_cast<std::uint64_t>(ck))) continue;
+      live.push_back(static_cast<std::int32_t>(i));
+    }
+    std::unordered_map<std::uint64_t, std::vector<std::pair<std::int32_t, std::int32_t>>> joined;
+    for (std::int32_t i : live) {
+      const std::uint64_t hash = hash_int(in->o_custkey[begin + i]);
+      std::uint64_t entry = t_c->st.slots[hash % t_c->st.num_slots].load(std::memory_order_relaxed);
+      while (entry != 0) {
+        const Bucket &bucket = t_c->st.buckets[entry - 1];
+        entry = bucket.next.load(std::memory_order_relaxed);
+        if (bucket.hash == hash) joined[bucket.value.block].emplace_back(i, bucket.value.tuple);
+      }
+    }
+    for (const auto &kv : joined) {
+      for (const auto &pr : kv.second) o_out[b].orderkey.push_back(in->o_orderkey[begin + pr.first]);
+    }
+  });
+  // BuildHashWorkOrder over the join's output blocks, LIP filter on orderkey built alongside
+  std::int64_t qualifying = 0;
+  for (const OrdersOut &o : o_out) qualifying += static_cast<std::int64_t>(o.orderkey.size());
+  qso_join_table_t *t_o = qso_join_table_create(QSX_INT, std::max<std::int64_t>(1, qualifying));
+  run_work_orders(o_blocks, num_threads, [&](std::int64_t b, int) {
+    const std::vector<std::int32_t> &keys = o_out[b].orderkey;
+    for (std::int32_t k : keys) atomic_or_bit(lip_o.get(), static_cast<std::uint64_t>(k));
+    t_o->put_block(keys.data(), static_cast<std::int64_t>(keys.size()), static_cast<std::uint64_t>(b), 0, nullptr);
+  });
+  out->orders_seconds = seconds_since(t0);
+
+  // lineitem: HashInnerJoinWorkOrder under l_shipdate > DATE and the LIP filter on l_orderkey, output (l_orderkey,
+  // l_extendedprice, l_discount) into a temporary block; AggregationWorkOrder on that block: revenue[l_orderkey] +=
+  // l_extendedprice * (1 - l_discount) (CollisionFreeVectorTable.hpp:530-645: fetch_or of the existence bit, a
+  // compare-exchange loop on the atomic<double>, :640-643)
+  std::vector<std::int64_t> pairs(num_threads, 0);
+  t0 = Clock::now();
+  run_work_orders((n_l + block_rows - 1) / block_rows, num_threads, [&](std::int64_t b, int t) {
+    const std::int64_t begin = b * block_rows, rows = std::min(block_rows, n_l - begin);
+    std::vector<std::uint64_t> sel(bitmap_words(rows));
+    qso_select_cmp(QSX_INT, in->l_shipdate + begin, rows, QSX_GT, &in->date_cut, nullptr, sel.data());
+    std::vector<std::int32_t> live;
+    for (std::int64_t i = 0; i < rows; ++i) {
+      if (!bit_get(sel.data(), i)) continue;
+      const std::int32_t ok = in->l_orderkey[begin + i];
+      if (ok < 0 || ok > in->orders_total || !test_bit(lip_o.get(), static_cast<std::uint64_t>(ok))) continue;
+      live.push_back(static_cast<std::int32_t>(i));
+    }
+    std::unordered_map<std::uint64_t, std::vector<std::pair<std::int32_t, std::int32_t>>> joined;
+    for (std::int32_t i : live) {
+      const std::uint64_t hash = hash_int(in->l_orderkey[begin + i]);
+      std::uint64_t entry = t_o->st.slots[hash % t_o->st.num_slots].load(std::memory_order_relaxed);
+      while (entry != 0) {
+        const Bucket &bucket = t_o->st.buckets[entry - 1];
+        entry = bucket.next.load(std::memory_order_relaxed);
+        if (bucket.hash == hash) joined[bucket.value.block].emplace_back(i, bucket.value.tuple);
+      }
+    }
+    std::vector<std::int32_t> j_key;
+    std::vector<double> j_price, j_disc;
+    for (const auto &kv : joined) {
+      for (const auto &pr : kv.second) j_key.push_back(in->l_orderkey[begin + pr.first]);
+      for (const auto &pr : kv.second) j_price.push_back(in->l_extendedprice[begin + pr.first]);
+      for (const auto &pr : kv.second) j_disc.push_back(in->l_discount[begin + pr.first]);
+    }
+    pairs[t] += static_cast<std::int64_t>(j_key.size());
+    // ScalarBinaryExpression::getAllValues: one temporary vector per node (expressions/scalar/ScalarBinaryExpression.cpp:100-195)
+    std::vector<double> one_minus(j_key.size()), value(j_key.size());
+    for (std::size_t j = 0; j < j_key.size(); ++j) one_minus[j] = 1.0 - j_disc[j];
+    for (std::size_t j = 0; j < j_key.size(); ++j) value[j] = j_price[j] * one_minus[j];
+    for (std::size_t j = 0; j < j_key.size(); ++j) {
+      const std::uint64_t loc = static_cast<std::uint64_t>(j_key[j]);
+      atomic_or_bit(exist.get(), loc);
+      double seen = revenue[loc].load(std::memory_order_relaxed);
+      while (!revenue[loc].compare_exchange_weak(seen, seen + value[j], std::memory_order_relaxed)) {}
+    }
+  });
+  out->lineitem_seconds = seconds_since(t0);
+
+  // FinalizeAggregationWorkOrders over key ranges (CollisionFreeVectorTable.hpp:647-727), then ORDER BY revenue DESC LIMIT 10
+  t0 = Clock::now();
+  std::vector<std::vector<std::pair<double, std::int32_t>>> tops(num_threads);
+  std::vector<std::int64_t> groups(num_threads, 0);
+  const std::int64_t fin_parts = std::max<std::int64_t>(1, std::min<std::int64_t>((in->orders_total + 1) / 4096, 2 * num_threads));
+  run_work_orders(fin_parts, num_threads, [&](std::int64_t p, int t) {
+    const std::int64_t len = (in->orders_total + 1 + fin_parts - 1) / fin_parts;
+    const std::int64_t a = p * len, b = std::min<std::int64_t>(in->orders_total + 1, a + len);
+    std::vector<std::pair<double, std::int32_t>> &top = tops[t];
+    for (std::int64_t loc = a; loc < b; ++loc) {
+      if (!test_bit(exist.get(), static_cast<std::uint64_t>(loc))) continue;
+      ++groups[t];
+      top.emplace_back(revenue[loc].load(std::memory_order_relaxed), static_cast<std::int32_t>(loc));
+      if (top.size() >= 4096) {
+        std::partial_sort(top.begin(), top.begin() + 10, top.end(), std::greater<std::pair<double, std::int32_t>>());
+        top.resize(10);
+      }
+    }
+  });
+  std::vector<std::pair<double, std::int32_t>> all;
+  out->groups = 0;
+  for (int t = 0; t < num_threads; ++t) {
+    all.insert(all.end(), tops[t].begin(), tops[t].end());
+    out->groups += groups[t];
+  }
+  const std::size_t k = std::min<std::size_t>(10, all.size());
+  std::partial_sort(all.begin(), all.begin() + k, all.end(), std::greater<std::pair<double, std::int32_t>>());
+  for (std::size_t i = 0; i < 10; ++i) {
+    out->top_revenue[i] = i < k ? all[i].first : 0.0;
+    out->top_orderkey[i] = i < k ? all[i].second : -1;
+  }
+  out->finalize_seconds = seconds_since(t0);
+  out->total_seconds = seconds_since(t_all);
+  out->pairs = 0;
+  for (int t = 0; t < num_threads; ++t) out->pairs += pairs[t];
+  out->qualifying_orders = qualifying;
+  qso_join_table_destroy(t_c);
+  qso_join_table_destroy(t_o);
+}
+
 double qso_bench_select(int type, const void *col, int64_t n, int op, const void *literal,
                         int64_t block_rows, int num_threads, void *out_col, int64_t *out_rows) {
   // SelectWorkOrder::execute (relational_operators/SelectOperator.cpp:161-195):
