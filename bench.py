@@ -58,17 +58,14 @@ def self_launch():
             n = int(a.split("=", 1)[1])
     if n <= 1 or "WORLD_SIZE" in os.environ:
         return
-    import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
     env["QSX_BENCH_SELF_LAUNCHED"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # --standalone: the launcher binds its own rendezvous port (no bind-then-close race between benches started together)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + argv
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     last_json = None
     for ln in child.stdout:
@@ -1170,12 +1167,12 @@ def main():
         return
     # QSX_BENCH_SHARED_GPU=1: a rehearsal of the N > 1 path on a box with ONE GPU — every rank works on cuda:0, the process
     # group is gloo (barriers, the max over ranks, the checks) and the exchange steps go through the C ABI over the loopback
-    # stand-in for RCCL (QSX_RCCL_LIBRARY=tests/cpp/bin/libloopback_rccl.so, --transport capi).  It executes every line of the
+    # stand-in for RCCL (QSX_ALLOW_TEST_TRANSPORT=1 QSX_RCCL_LIBRARY=tests/cpp/bin/libloopback_rccl.so, --transport capi).  It executes every line of the
     # multi-rank code with the product's kernels; its throughput says nothing about scaling, and the line says so.
     shared_gpu = os.environ.get("QSX_BENCH_SHARED_GPU") == "1"
     if shared_gpu:
-        if args.transport != "capi" or not os.environ.get("QSX_RCCL_LIBRARY"):
-            raise SystemExit("QSX_BENCH_SHARED_GPU=1 needs --transport capi and QSX_RCCL_LIBRARY (the loopback library)")
+        if args.transport != "capi" or not os.environ.get("QSX_RCCL_LIBRARY") or os.environ.get("QSX_ALLOW_TEST_TRANSPORT") != "1":
+            raise SystemExit("QSX_BENCH_SHARED_GPU=1 needs --transport capi, QSX_RCCL_LIBRARY (the loopback library) and QSX_ALLOW_TEST_TRANSPORT=1")
         local_rank = 0
     torch.cuda.set_device(local_rank)
     ctx.dev = dev = torch.device("cuda", local_rank)

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
-#define QSX_ABI_VERSION 12
+#define QSX_ABI_VERSION 13
 
 typedef void *qsx_stream_t;
 
@@ -748,7 +748,10 @@ int qsx_agg_update_coded(qsx_agg_state_t *state, const void *const *cols, const 
  * NULL array: unknown — the call behaves exactly like qsx_agg_update_coded).  A reference block knows them
  * (compression/CompressionDictionary.hpp:46-58: the dictionary begins with its number of codes).  With the size in hand the
  * plan shapes copy dictionaries of up to 64 entries into LDS once per workgroup and decode from there instead of through the
- * vector memory path (Q1 over lineitem: quantity 50, discount 11, tax 9 entries). */
+ * vector memory path (Q1 over lineitem: quantity 50, discount 11, tax 9 entries).  A code >= dictionary_entries[c] is
+ * outside the contract (the unsized call would read past the dictionary): it decodes to 0 from the LDS copy.  A dictionary
+ * with a NULL code (= num_codes, compression/CompressionDictionary.hpp:49-52) is passed with num_codes entries and the
+ * attribute's NULL rows masked by its null bitmap / the filter, as the host layer does. */
 int qsx_agg_update_coded_sized(qsx_agg_state_t *state, const void *const *cols, const void *const *dictionaries_dev,
                                const int32_t *dictionary_entries, int64_t n, const uint64_t *filter_dev, qsx_stream_t stream);
 
@@ -939,6 +942,19 @@ int qsx_comm_unique_id(void *out_id_bytes);
 int qsx_comm_create(int world, int rank, const void *id_bytes, qsx_comm_t **out);
 int qsx_comm_destroy(qsx_comm_t *comm);
 int qsx_comm_rank(const qsx_comm_t *comm, int *out_world, int *out_rank);
+/* Failure agreement.  A rank that fails on its own between two collectives (an allocation, a validation) must not leave
+ * its peers inside a collective nobody else will enter: before the first collective of a step every rank contributes the
+ * status of its local preparation, and ALL ranks get the same verdict — QSX_OK when every rank contributed QSX_OK, else
+ * the rank's own status when that is the failure, QSX_ERR_COMM ("rank r failed ...", qsx_last_error) on the others.  A
+ * collective itself (one word per rank through a buffer the communicator owns: nothing is allocated); synchronises.
+ * qsx_agg_reduce_scatter, qsx_agg_allgather_merge and qsx_bitmap_allreduce_or agree this way on their own scratch. */
+int qsx_comm_agree(qsx_comm_t *comm, int local_status, qsx_stream_t stream);
+/* Wait for `stream` under the communicator's watchdog (QSX_COMM_TIMEOUT_MS, default 600 000; 0 = wait for ever): a
+ * collective whose peers never arrive does not block the caller indefinitely — at the deadline the communicator is
+ * aborted (ncclCommAbort) and QSX_ERR_COMM returned; every later call on it returns QSX_ERR_COMM at once. */
+int qsx_comm_synchronize(qsx_comm_t *comm, qsx_stream_t stream);
+/* Abort the communicator (a rank that failed inside a step tells RCCL to give up instead of waiting in its kernels). */
+int qsx_comm_abort(qsx_comm_t *comm);
 /* recv_counts_dev[p] = send_counts_dev[p] of rank p's call (int64[world] device arrays): the row counts of a shuffle */
 int qsx_exchange_counts(qsx_comm_t *comm, const int64_t *send_counts_dev, int64_t *recv_counts_dev, qsx_stream_t stream);
 /* Rows of `width` bytes: send_rows[p] rows go to rank p (taken back to back from send_dev in rank order — the layout

@@ -26,7 +26,7 @@ class QsxError(RuntimeError):
         self.status = status
         msg = _lib.qsx_status_string(status).decode()
         detail = _lib.qsx_last_error().decode()
-        super().__init__(f"{where}: {msg} ({status})" + (f" — {detail}" if detail and status == T.ERR_HIP else ""))
+        super().__init__(f"{where}: {msg} ({status})" + (f" — {detail}" if detail and status in (T.ERR_HIP, T.ERR_COMM) else ""))
 
 
 def _load():
@@ -138,6 +138,9 @@ _SIGNATURES = {
     "qsx_comm_create": (_int, [_int, _int, _vp, _pp]),
     "qsx_comm_destroy": (_int, [_vp]),
     "qsx_comm_rank": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    "qsx_comm_agree": (_int, [_vp, _int, _vp]),
+    "qsx_comm_synchronize": (_int, [_vp, _vp]),
+    "qsx_comm_abort": (_int, [_vp]),
     "qsx_exchange_counts": (_int, [_vp, _vp, _vp, _vp]),
     "qsx_alltoallv": (_int, [_vp, _int, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _vp]),
     "qsx_allgather": (_int, [_vp, _vp, _sz, _vp, _vp]),
@@ -1053,6 +1056,17 @@ class Comm:
         if self._h is not None:
             _lib.qsx_comm_destroy(self._h)
             self._h = None
+
+    def agree(self, local_status=0, stream=None):
+        """Failure agreement before a collective step: raises on EVERY rank when any rank contributed a non-zero status."""
+        _check(_lib.qsx_comm_agree(self._h, int(local_status), _stream(stream)), "qsx_comm_agree")
+
+    def synchronize(self, stream=None):
+        """Wait for the stream under the communicator's watchdog (QSX_COMM_TIMEOUT_MS)."""
+        _check(_lib.qsx_comm_synchronize(self._h, _stream(stream)), "qsx_comm_synchronize")
+
+    def abort(self):
+        _check(_lib.qsx_comm_abort(self._h), "qsx_comm_abort")
 
     def exchange_counts(self, send_counts, stream=None):
         recv = torch.empty_like(send_counts)

@@ -775,9 +775,14 @@ __device__ __forceinline__ void agg_hash_update_body(const DevConfig &c, const v
         if (dict == nullptr || entries <= 0 || entries > kDictLdsEntries) continue;
         dict_in_lds |= 1u << k;
         const bool narrow = c.column_type[col] == QSX_INT || c.column_type[col] == QSX_FLOAT;
-        for (int i = threadIdx.x; i < entries; i += BLOCK) {
-          l_dict[k * kDictLdsEntries + i] = narrow ? static_cast<unsigned long long>(static_cast<const uint32_t *>(dict)[i])
-                                                   : static_cast<const unsigned long long *>(dict)[i];
+        // (the slots behind `entries` are zeroed: decode_rows clamps a code to the LDS copy's size, not to `entries` — a code
+        // beyond the dictionary, e.g. a reference block's NULL code = num_codes, then decodes to 0 whatever the LDS held)
+        for (int i = threadIdx.x; i < kDictLdsEntries; i += BLOCK) {
+          unsigned long long word = 0;
+          if (i < entries) {
+            word = narrow ? static_cast<unsigned long long>(static_cast<const uint32_t *>(dict)[i]) : static_cast<const unsigned long long *>(dict)[i];
+          }
+          l_dict[k * kDictLdsEntries + i] = word;
         }
       }
     }

@@ -472,8 +472,9 @@ int scratch_bytes_of(const JitKernel *k) {
 }
 JitKernel *settle(JitKernel *k, const std::string &relaxed) {
   if (k == nullptr || scratch_bytes_of(k) == 0) return k;
-  // (the rejected module stays loaded: a few KiB, once per shape — unloading it from a compile thread while other threads
-  // launch is not worth the risk)
+  // (nothing was ever launched from the rejected module — it was loaded to read its attributes only — so it is unloaded
+  // here, by the thread that loaded it)
+  if (k->module != nullptr) (void)hipModuleUnload(k->module);
   delete k;
   if (relaxed.empty()) {
     std::fprintf(stderr, "[qsx] run-time plan shape: the build needs scratch memory; the interpreter kernel is used.\n");
@@ -576,6 +577,8 @@ int jit_agg_launch(const JitKernel *k, int grid, size_t lds_bytes, hipStream_t s
                                     static_cast<unsigned>(lds_bytes), stream, args, nullptr));
   return QSX_OK;
 }
+
+bool jit_compiles_out_of_process() { return !compiler_driver().empty(); }
 
 int jit_rows_per_thread() {
   static const int rows = []() {

@@ -61,6 +61,9 @@ int jit_resident_blocks(const JitKernel *k, int block, size_t lds_bytes);
 
 // Rows of a tile per thread in the run-time shapes of the hash path (tile = 256 x that): 4, or 2 with QSX_AGG_JIT_ROWS=2.
 int jit_rows_per_thread();
+// true: shapes are built by the compiler driver in a child process (the calling thread never waits for a compile);
+// false: by hipRTC inside this process, in the calling thread
+bool jit_compiles_out_of_process();
 
 }  // namespace qsx
 

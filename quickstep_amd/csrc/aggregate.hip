@@ -1300,7 +1300,11 @@ static long long jit_min_rows() {
   // it has seen 256 Ki rows (6 us through the interpreter: what keeps the compiler away are states of a few blocks, tests) —
   // every later state of the shape, however small, then starts on the compiled kernel as soon as it has seen as many rows
   // itself.  (16 Mi until round 3, 2 Mi in round 3.)
-  return e != nullptr ? atoll(e) : 256ll * 1024;
+  // Without a compiler driver the shape is built by hipRTC in the CALLING thread (agg_jit.hip: a background hipRTC compile
+  // does not survive process exit): a Worker's update then stalls 1-2 s per distinct plan shape, which only a state of
+  // round 3's 2 Mi rows is worth.
+  if (e != nullptr) return atoll(e);
+  return jit_compiles_out_of_process() ? 256ll * 1024 : 2048ll * 1024;
 }
 
 // The specialised kernel of this state for the filter variant, compiling it on first use once the state
@@ -2492,8 +2496,9 @@ int qsx_agg_reduce_scatter(qsx_comm_t *comm, qsx_agg_state_t *st, qsx_stream_t s
   CallScratch scratch(s);
   const size_t bytes_send = static_cast<size_t>(padded) * 8, bytes_mine = static_cast<size_t>(length) * 8,
                bytes_parts = static_cast<size_t>(my_words > 0 ? my_words : 1) * 8 * world;
-  int rc = scratch.reserve(CallScratch::padded(bytes_send) + CallScratch::padded(bytes_mine) + CallScratch::padded(bytes_parts) +
-                           CallScratch::padded(st->image_bytes));
+  // (a rank that cannot get its scratch must not leave the others inside the first reduce-scatter: agree on it first)
+  int rc = comm_agree(comm, scratch.reserve(CallScratch::padded(bytes_send) + CallScratch::padded(bytes_mine) + CallScratch::padded(bytes_parts) +
+                                            CallScratch::padded(st->image_bytes)), s);
   if (rc != QSX_OK) return rc;
   unsigned long long *send = static_cast<unsigned long long *>(scratch.take(bytes_send));
   unsigned long long *mine = static_cast<unsigned long long *>(scratch.take(bytes_mine));
@@ -2564,40 +2569,41 @@ int qsx_agg_allgather_merge(qsx_comm_t *comm, qsx_agg_state_t *st, qsx_stream_t 
   const RcclApi *api = rccl();
   if (api == nullptr) return QSX_ERR_COMM;
   hipStream_t s = as_stream(stream);
+  // Every step that can fail on one rank alone (the size query, the allocations, the export) happens BETWEEN collectives
+  // and is followed by an agreement (comm_agree: one word per rank through the communicator's own buffer): either all
+  // ranks go on to the next collective or all of them give the call up — none is left waiting for a peer that returned.
   size_t my_bytes = 0;
-  int rc = qsx_agg_state_export_bytes(st, &my_bytes, stream);
+  int rc = comm_agree(comm, qsx_agg_state_export_bytes(st, &my_bytes, stream), s);
   if (rc != QSX_OK) return rc;
-  // sizes: through device memory (one word per rank)
-  unsigned long long *sizes_dev = nullptr;
-  QSX_HIP_TRY(device_malloc(&sizes_dev, sizeof(unsigned long long) * (world + 1)));
-  const unsigned long long mine_size = my_bytes;
-  int status = QSX_OK;
-  if (hipMemcpyAsync(sizes_dev + world, &mine_size, 8, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-    status = QSX_ERR_HIP;      // (synchronised: mine_size is a stack word)
-  }
-  if (status == QSX_OK) status = rccl_status(api->AllGather(sizes_dev + world, sizes_dev, 1, ncclUint64, comm->comm, s), "ncclAllGather");
+  // sizes: the agreement's buffer carries them (one word per rank, nothing allocated)
   std::vector<unsigned long long> sizes(static_cast<size_t>(world));
-  if (status == QSX_OK && (hipMemcpyAsync(sizes.data(), sizes_dev, 8 * world, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) {
-    status = QSX_ERR_HIP;
-  }
-  (void)device_free(sizes_dev);
-  if (status != QSX_OK) return status;
+  comm->status_host[world] = static_cast<long long>(my_bytes);
+  int status = QSX_OK;
+  if (hipMemcpyAsync(comm->status_dev + world, comm->status_host + world, 8, hipMemcpyHostToDevice, s) != hipSuccess) status = QSX_ERR_HIP;
+  const int gathered_sizes = rccl_status(api->AllGather(comm->status_dev + world, comm->status_dev, 1, ncclInt64, comm->comm, s), "ncclAllGather(sizes)");
+  if (gathered_sizes != QSX_OK) return gathered_sizes;
+  if (hipMemcpyAsync(comm->status_host, comm->status_dev, 8 * static_cast<size_t>(world), hipMemcpyDeviceToHost, s) != hipSuccess) status = QSX_ERR_HIP;
+  const int waited = comm_wait(comm, s);
+  if (waited != QSX_OK) return waited;
   size_t pad = 0;
-  for (unsigned long long v : sizes) pad = v > pad ? static_cast<size_t>(v) : pad;
-  unsigned char *gathered = nullptr, *padded_image = nullptr;
-  if (device_malloc(&gathered, pad * world) != hipSuccess) return QSX_ERR_OUT_OF_MEMORY;
-  if (device_malloc(&padded_image, pad) != hipSuccess) {
-    (void)device_free(gathered);
-    return QSX_ERR_OUT_OF_MEMORY;
+  for (int r = 0; r < world; ++r) {
+    sizes[static_cast<size_t>(r)] = static_cast<unsigned long long>(comm->status_host[r]);
+    pad = sizes[static_cast<size_t>(r)] > pad ? static_cast<size_t>(sizes[static_cast<size_t>(r)]) : pad;
   }
-  status = qsx_agg_state_export(st, padded_image, my_bytes, stream);
+  unsigned char *gathered = nullptr, *padded_image = nullptr;
+  if (status == QSX_OK && device_malloc(&gathered, pad * world) != hipSuccess) status = QSX_ERR_OUT_OF_MEMORY;
+  if (status == QSX_OK && device_malloc(&padded_image, pad) != hipSuccess) status = QSX_ERR_OUT_OF_MEMORY;
+  if (status == QSX_OK) status = qsx_agg_state_export(st, padded_image, my_bytes, stream);
+  status = comm_agree(comm, status, s);
   if (status == QSX_OK) status = rccl_status(api->AllGather(padded_image, gathered, pad, ncclUint8, comm->comm, s), "ncclAllGather");
+  if (status == QSX_OK) status = comm_wait(comm, s);
+  // (from here on a failure is this rank's alone and no collective follows it)
   for (int r = 0; r < world && status == QSX_OK; ++r) {
-    if (r != rank) status = qsx_agg_state_import_merge(st, gathered + static_cast<size_t>(r) * pad, static_cast<size_t>(sizes[r]), stream);
+    if (r != rank) status = qsx_agg_state_import_merge(st, gathered + static_cast<size_t>(r) * pad, static_cast<size_t>(sizes[static_cast<size_t>(r)]), stream);
   }
   if (hipStreamSynchronize(s) != hipSuccess && status == QSX_OK) status = QSX_ERR_HIP;
-  (void)device_free(gathered);
-  (void)device_free(padded_image);
+  if (gathered != nullptr) (void)device_free(gathered);
+  if (padded_image != nullptr) (void)device_free(padded_image);
   return status;
 }
 

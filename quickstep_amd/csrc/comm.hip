@@ -7,8 +7,10 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -21,11 +23,19 @@ const RcclApi *rccl() {
   static bool ok = false;
   static std::once_flag once;
   std::call_once(once, []() {
-    // QSX_RCCL_LIBRARY names the library to bind instead (the deployment's own build of RCCL; the tests' loopback
-    // transport, tests/cpp/loopback/loopback_rccl.cpp, which lets several ranks share one GPU).  No fallback from it.
+    // QSX_RCCL_LIBRARY names the library to bind instead — a TEST HOOK (the tests' loopback transport,
+    // tests/cpp/loopback/loopback_rccl.cpp, which lets several ranks share one GPU).  An environment variable must not be
+    // able to put another library under a production process's collectives by itself: it is honoured only together with
+    // QSX_ALLOW_TEST_TRANSPORT=1, and without that switch a process that carries it gets NO transport at all (every
+    // multi-GPU entry point fails with QSX_ERR_COMM) rather than a silent fall-back to the real RCCL.
     void *lib = nullptr;
     const char *named = std::getenv("QSX_RCCL_LIBRARY");
     if (named != nullptr && named[0] != 0) {
+      const char *allow = std::getenv("QSX_ALLOW_TEST_TRANSPORT");
+      if (allow == nullptr || std::string(allow) != "1") {
+        set_last_error_text("QSX_RCCL_LIBRARY is set but QSX_ALLOW_TEST_TRANSPORT=1 is not: refusing to bind a substitute for RCCL");
+        return;
+      }
       lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
       if (lib == nullptr) {
         set_last_error_text((std::string("QSX_RCCL_LIBRARY: ") + dlerror()).c_str());
@@ -56,6 +66,9 @@ const RcclApi *rccl() {
     bind(api.ReduceScatter, "ncclReduceScatter");
     bind(api.AllReduce, "ncclAllReduce");
     bind(api.GetErrorString, "ncclGetErrorString");
+    const bool required = all;
+    bind(api.CommAbort, "ncclCommAbort");          // optional
+    all = required;
     if (!all) set_last_error_text("librccl.so.1 lacks a symbol the multi-GPU entry points need");
     ok = all;
   });
@@ -68,6 +81,65 @@ int rccl_status(ncclResult_t r, const char *what) {
   std::string text = std::string(what) + ": " + (api != nullptr ? api->GetErrorString(r) : "RCCL error");
   set_last_error_text(text.c_str());
   return QSX_ERR_COMM;
+}
+
+// hipStreamSynchronize with a deadline: a collective whose peers never arrive must not hold the caller for ever.
+int comm_wait(::qsx_comm *c, hipStream_t s) {
+  if (c->aborted.load(std::memory_order_acquire)) {
+    set_last_error_text("the communicator was aborted");
+    return QSX_ERR_COMM;
+  }
+  if (c->world == 1 || c->timeout_ms <= 0) {
+    QSX_HIP_TRY(hipStreamSynchronize(s));
+    return QSX_OK;
+  }
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(c->timeout_ms);
+  int spins = 0;
+  for (;;) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return QSX_OK;
+    if (q != hipErrorNotReady) {
+      set_last_error("hipStreamQuery", q);
+      return QSX_ERR_HIP;
+    }
+    if (std::chrono::steady_clock::now() > deadline) {
+      set_last_error_text("a collective did not finish before QSX_COMM_TIMEOUT_MS: a peer rank is not issuing the same calls; communicator aborted");
+      (void)qsx_comm_abort(c);
+      return QSX_ERR_COMM;
+    }
+    if (++spins < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+
+int comm_agree(::qsx_comm *c, int local_status, hipStream_t s) {
+  if (c->aborted.load(std::memory_order_acquire)) {
+    set_last_error_text("the communicator was aborted");
+    return local_status != QSX_OK ? local_status : QSX_ERR_COMM;
+  }
+  if (c->world == 1) return local_status;
+  const RcclApi *api = rccl();
+  if (api == nullptr) return QSX_ERR_COMM;
+  const int world = c->world;
+  c->status_host[world] = local_status;
+  int rc = QSX_OK;
+  if (hipMemcpyAsync(c->status_dev + world, c->status_host + world, 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = QSX_ERR_HIP;
+  // (a rank that cannot even stage its word still enters the collective: its peers are waiting there)
+  const int gathered = rccl_status(api->AllGather(c->status_dev + world, c->status_dev, 1, ncclInt64, c->comm, s), "ncclAllGather(status)");
+  if (gathered != QSX_OK) return local_status != QSX_OK ? local_status : gathered;
+  if (hipMemcpyAsync(c->status_host, c->status_dev, 8 * static_cast<size_t>(world), hipMemcpyDeviceToHost, s) != hipSuccess) rc = QSX_ERR_HIP;
+  const int waited = comm_wait(c, s);
+  if (waited != QSX_OK) return local_status != QSX_OK ? local_status : waited;
+  if (local_status != QSX_OK) return local_status;
+  if (rc != QSX_OK) return rc;
+  for (int r = 0; r < world; ++r) {
+    if (c->status_host[r] != QSX_OK) {
+      const std::string text = "rank " + std::to_string(r) + " failed before a collective step (its status " + std::to_string(c->status_host[r]) +
+                               "): every rank gives the step up";
+      set_last_error_text(text.c_str());
+      return QSX_ERR_COMM;
+    }
+  }
+  return QSX_OK;
 }
 
 }  // namespace qsx
@@ -98,8 +170,17 @@ int qsx_comm_create(int world, int rank, const void *id_bytes, qsx_comm_t **out)
   qsx_comm *c = new qsx_comm;
   c->world = world;
   c->rank = rank;
+  if (const char *t = std::getenv("QSX_COMM_TIMEOUT_MS")) c->timeout_ms = std::atoll(t);
+  if (hipMalloc(reinterpret_cast<void **>(&c->status_dev), 8 * static_cast<size_t>(world + 1)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void **>(&c->status_host), 8 * static_cast<size_t>(world + 1), hipHostMallocDefault) != hipSuccess) {
+    if (c->status_dev != nullptr) (void)hipFree(c->status_dev);
+    delete c;
+    return QSX_ERR_OUT_OF_MEMORY;
+  }
   const int rc = rccl_status(api->CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
   if (rc != QSX_OK) {
+    (void)hipFree(c->status_dev);
+    (void)hipHostFree(c->status_host);
     delete c;
     return rc;
   }
@@ -110,9 +191,32 @@ int qsx_comm_create(int world, int rank, const void *id_bytes, qsx_comm_t **out)
 int qsx_comm_destroy(qsx_comm_t *c) {
   if (c == nullptr) return QSX_OK;
   const RcclApi *api = rccl();
-  if (api != nullptr && c->comm != nullptr) (void)api->CommDestroy(c->comm);
+  // (an aborted communicator was already given back to RCCL by ncclCommAbort)
+  if (api != nullptr && c->comm != nullptr && !(c->aborted.load() && api->CommAbort != nullptr)) (void)api->CommDestroy(c->comm);
+  if (c->status_dev != nullptr) (void)hipFree(c->status_dev);
+  if (c->status_host != nullptr) (void)hipHostFree(c->status_host);
   delete c;
   return QSX_OK;
+}
+
+int qsx_comm_abort(qsx_comm_t *c) {
+  if (c == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  if (c->aborted.exchange(true)) return QSX_OK;
+  const RcclApi *api = rccl();
+  if (api != nullptr && api->CommAbort != nullptr && c->comm != nullptr) (void)api->CommAbort(c->comm);
+  return QSX_OK;
+}
+
+int qsx_comm_agree(qsx_comm_t *c, int local_status, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (c == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  return comm_agree(c, local_status, as_stream(stream));
+}
+
+int qsx_comm_synchronize(qsx_comm_t *c, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (c == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  return comm_wait(c, as_stream(stream));
 }
 
 int qsx_comm_rank(const qsx_comm_t *c, int *out_world, int *out_rank) {
@@ -180,7 +284,9 @@ int qsx_bitmap_allreduce_or(qsx_comm_t *c, uint64_t *words_dev, int64_t num_word
   hipStream_t s = as_stream(stream);
   CallScratch scratch(s);
   const size_t bytes = static_cast<size_t>(num_words) * 8 * c->world;
-  const int rc = scratch.reserve(CallScratch::padded(bytes));
+  // (the scratch is this rank's own business: agree on it before the all-gather, or a rank without memory leaves the
+  // others waiting in it)
+  const int rc = comm_agree(c, scratch.reserve(CallScratch::padded(bytes)), s);
   if (rc != QSX_OK) return rc;
   unsigned long long *all = static_cast<unsigned long long *>(scratch.take(bytes));
   QSX_RCCL_TRY(api->AllGather(words_dev, all, static_cast<size_t>(num_words), ncclUint64, c->comm, s), "ncclAllGather");

@@ -6,7 +6,11 @@
 
 #include <rccl/rccl.h>
 
+#include <atomic>
+
 #include "common.hpp"
+
+struct qsx_comm;
 
 namespace qsx {
 
@@ -22,11 +26,16 @@ struct RcclApi {
   decltype(&ncclReduceScatter) ReduceScatter = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;   // optional: absent from a transport that cannot abort
 };
 // nullptr (and qsx_last_error set) when the library or one of the symbols is missing.
 const RcclApi *rccl();
 int rccl_status(ncclResult_t r, const char *what);   // QSX_OK or QSX_ERR_COMM with qsx_last_error set
 void set_last_error_text(const char *text);
+// The failure agreement of qsx_comm_agree for callers inside the library (csrc/comm.hip).
+int comm_agree(::qsx_comm *c, int local_status, hipStream_t s);
+// hipStreamSynchronize under the communicator's watchdog (qsx_comm_synchronize).
+int comm_wait(::qsx_comm *c, hipStream_t s);
 
 // out[w] = OR over r of parts[r * words + w], AND mask of the first / last word (bits of the neighbouring key ranges that
 // share a boundary word are dropped)
@@ -48,6 +57,12 @@ struct qsx_comm {
   ncclComm_t comm = nullptr;
   int world = 1;
   int rank = 0;
+  // the agreement's buffers, allocated once with the communicator: [world] gathered words + 1 contributed word on the
+  // device, the same in pinned host memory — a status exchange never allocates
+  long long *status_dev = nullptr;
+  long long *status_host = nullptr;
+  std::atomic<bool> aborted{false};
+  long long timeout_ms = 600000;
 };
 
 namespace qsx {

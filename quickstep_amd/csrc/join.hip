@@ -735,10 +735,19 @@ static int fill_empty(const qsx_join_table *t, void *slots, uint64_t capacity, h
 
 static int allocate_slots(qsx_join_table *t, uint64_t capacity, void **out) {
   QSX_HIP_TRY(device_malloc(out, capacity * t->entry_bytes() + capacity));
-  const int rc = fill_empty(t, *out, capacity, nullptr);
-  if (rc != QSX_OK) return rc;
-  QSX_HIP_TRY(hipStreamSynchronize(nullptr));
-  return QSX_OK;
+  int rc = fill_empty(t, *out, capacity, nullptr);
+  if (rc == QSX_OK) {
+    const hipError_t waited = hipStreamSynchronize(nullptr);
+    if (waited != hipSuccess) {
+      set_last_error("hipStreamSynchronize(nullptr)", waited);
+      rc = QSX_ERR_HIP;
+    }
+  }
+  if (rc != QSX_OK) {        // the callers drop *out on failure: give the allocation back here
+    (void)device_free(*out);
+    *out = nullptr;
+  }
+  return rc;
 }
 
 // Make room for `additional` more rows.  Counterpart of HashTable::resize

@@ -1224,6 +1224,16 @@ class RankGroup {
   qsx_comm_t *comm() const { return comm_; }
   std::size_t ownerOf(partition_id part) const { return part % static_cast<std::size_t>(world_); }
   bool owns(partition_id part) const { return ownerOf(part) == static_cast<std::size_t>(rank_); }
+  // Failure agreement (qsx_comm_agree).  `prepare` is this rank's own, collective-free part of a step — the work that can
+  // fail on one rank alone (fetching blocks, allocating the output block and the send buffers, validating what arrived).
+  // Either it succeeded on EVERY rank and agreeOn returns on every rank, or it throws on every rank (the rank whose
+  // preparation threw rethrows that exception, the others an ExecutionError with QSX_ERR_COMM): no rank walks into a
+  // collective its peers will never enter.  A collective itself: all ranks call it at the same point of the step.
+  void agreeOn(const std::function<void()> &prepare, const char *where);
+  // Wait for the calling thread's stream under the communicator's watchdog (qsx_comm_synchronize, QSX_COMM_TIMEOUT_MS).
+  void synchronize();
+  // A rank that failed INSIDE a step's collectives gives the communicator up: its peers' collectives end with an error.
+  void abort() noexcept;
 
  private:
   int world_, rank_;

@@ -60,6 +60,7 @@ struct DeviceBuffer {
     c.bytes = 0;
   }
   void *ptr = nullptr;
+  std::pair<int, std::size_t> class_key{0, 0};   // (device the buffer was allocated on, size class): where a release files it
   std::size_t size_class = 0;   // 0: a plain allocation of its own
   std::size_t pooled = 0;       // != 0: from the shared pool (its size class there)
   static constexpr std::size_t kSharedFrom = std::size_t(32) << 20;
@@ -81,7 +82,10 @@ struct DeviceBuffer {
       size_class = 128 * 1024;
       while (size_class < bytes) size_class *= 2;
       Cache &c = cache();
-      auto it = c.free_by_class.find(classKey(size_class));
+      // (the key is taken once, here: a thread that changes its device between constructor and destructor must still file
+      // the buffer under the device that owns the memory)
+      class_key = classKey(size_class);
+      auto it = c.free_by_class.find(class_key);
       if (it != c.free_by_class.end() && !it->second.empty()) {
         ptr = it->second.back();
         it->second.pop_back();
@@ -109,7 +113,7 @@ struct DeviceBuffer {
     if (size_class != 0) {
       Cache &c = cache();
       if (c.bytes + size_class <= kCacheBytes) {
-        c.free_by_class[classKey(size_class)].push_back(ptr);
+        c.free_by_class[class_key].push_back(ptr);
         c.bytes += size_class;
         return;
       }

@@ -18,24 +18,60 @@ RankGroup::RankGroup(int world, int rank, const void *id_bytes) : world_(world),
 }
 RankGroup::~RankGroup() { qsx_comm_destroy(comm_); }
 
-void AggregationOperationState::mergeAcrossRanks(qsx_comm_t *comm) {
-  if (!distinctify_.empty()) {
-    throw ExecutionError("AggregationOperationState::mergeAcrossRanks: DISTINCT aggregates are not merged across ranks", QSX_ERR_UNSUPPORTED);
+void RankGroup::agreeOn(const std::function<void()> &prepare, const char *where) {
+  std::exception_ptr mine;
+  int status = QSX_OK;
+  try {
+    prepare();
+  } catch (const ExecutionError &e) {
+    mine = std::current_exception();
+    status = e.status() != QSX_OK ? e.status() : QSX_ERR_INVALID_ARGUMENT;
+  } catch (const std::bad_alloc &) {
+    mine = std::current_exception();
+    status = QSX_ERR_OUT_OF_MEMORY;
+  } catch (...) {
+    mine = std::current_exception();
+    status = QSX_ERR_INVALID_ARGUMENT;
   }
-  {   // the state fed by compressed blocks joins the other one first (as finalizeAggregate does)
+  const int verdict = qsx_comm_agree(comm_, status, CurrentStream());
+  if (mine != nullptr) std::rethrow_exception(mine);
+  CheckStatus(verdict, where);
+}
+void RankGroup::synchronize() { CheckStatus(qsx_comm_synchronize(comm_, CurrentStream()), "qsx_comm_synchronize"); }
+void RankGroup::abort() noexcept { (void)qsx_comm_abort(comm_); }
+
+void AggregationOperationState::mergeAcrossRanks(qsx_comm_t *comm) {
+  // The local part first, and its outcome agreed on with the peers (qsx_comm_agree): a rank that fails here must not leave
+  // the others inside the merge's collectives.  (The collectives agree on their own scratch the same way, csrc/aggregate.hip.)
+  int status = QSX_OK;
+  std::exception_ptr mine;
+  try {
+    if (!distinctify_.empty()) {
+      throw ExecutionError("AggregationOperationState::mergeAcrossRanks: DISTINCT aggregates are not merged across ranks", QSX_ERR_UNSUPPORTED);
+    }
+    // the state fed by compressed blocks joins the other one first (as finalizeAggregate does)
     std::lock_guard<std::mutex> lock(coded_mutex_);
     if (coded_state_ != nullptr && !coded_merged_) {
       CheckStatus(qsx_agg_merge(state_, coded_state_, CurrentStream()), "qsx_agg_merge");
       CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
     }
     coded_merged_ = true;
+  } catch (const ExecutionError &e) {
+    mine = std::current_exception();
+    status = e.status() != QSX_OK ? e.status() : QSX_ERR_INVALID_ARGUMENT;
+  } catch (...) {
+    mine = std::current_exception();
+    status = QSX_ERR_INVALID_ARGUMENT;
   }
+  const int verdict = qsx_comm_agree(comm, status, CurrentStream());
+  if (mine != nullptr) std::rethrow_exception(mine);
+  CheckStatus(verdict, "AggregationOperationState::mergeAcrossRanks");
   if (config_.strategy == QSX_AGG_COLLISION_FREE) {
     CheckStatus(qsx_agg_reduce_scatter(comm, state_, CurrentStream()), "qsx_agg_reduce_scatter");
   } else {
     CheckStatus(qsx_agg_allgather_merge(comm, state_, CurrentStream()), "qsx_agg_allgather_merge");
   }
-  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+  CheckStatus(qsx_comm_synchronize(comm, CurrentStream()), "qsx_comm_synchronize");
 }
 
 namespace {
@@ -91,13 +127,21 @@ class PartitionExchangeWorkOrder : public WorkOrder {
       : WorkOrder(query_id), op_(op), blocks_(std::move(blocks)), dest_(dest), storage_manager_(storage_manager) {}
 
   void execute() override {
-    if (op_->broadcast_) {
-      broadcastAll();
-      return;
+    try {
+      if (op_->broadcast_) {
+        broadcastAll();
+        return;
+      }
+      const std::size_t world = static_cast<std::size_t>(op_->ranks_->world());
+      const std::size_t parts = blocks_.size();
+      for (std::size_t first = 0; first < parts; first += world) exchangeRound(first);
+    } catch (...) {
+      // A failure every rank agreed on (RankGroup::agreeOn) is thrown by all of them between collectives: nothing is in
+      // flight.  Anything else happened on this rank alone while a step's collectives were being issued — the peers are
+      // inside them, or about to be: the communicator is given up so that they end with QSX_ERR_COMM instead of waiting.
+      if (in_collectives_) op_->ranks_->abort();
+      throw;
     }
-    const std::size_t world = static_cast<std::size_t>(op_->ranks_->world());
-    const std::size_t parts = blocks_.size();
-    for (std::size_t first = 0; first < parts; first += world) exchangeRound(first);
   }
 
  private:
@@ -107,56 +151,73 @@ class PartitionExchangeWorkOrder : public WorkOrder {
   };
 
   // Partitions first .. first + world - 1: partition first + r goes to rank r.
+  // Order of a round: everything that can fail on this rank alone — fetching the blocks, validating what is
+  // about to arrive, the output block, every send buffer — happens BEFORE the first data collective and its outcome is
+  // agreed on with the peers (RankGroup::agreeOn); behind the agreement only copies and collectives are issued.
   void exchangeRound(std::size_t first) {
     RankGroup *ranks = op_->ranks_;
     const std::size_t world = static_cast<std::size_t>(ranks->world()), me = static_cast<std::size_t>(ranks->rank());
     const CatalogRelation &relation = op_->output_relation_;
     std::vector<Piece> pieces(world);
     std::vector<std::int64_t> send_rows(world, 0);
-    for (std::size_t r = 0; r < world; ++r) {
-      if (first + r >= blocks_.size()) continue;
-      for (block_id id : blocks_[first + r]) {
-        BlockReference b = storage_manager_->getBlock(id);
-        if (b->numTuples() == 0) continue;
-        pieces[r].blocks.push_back(b);
-        pieces[r].rows += b->numTuples();
+    ranks->agreeOn([&]() {
+      for (std::size_t r = 0; r < world; ++r) {
+        if (first + r >= blocks_.size()) continue;
+        for (block_id id : blocks_[first + r]) {
+          BlockReference b = storage_manager_->getBlock(id);
+          if (b->numTuples() == 0) continue;
+          pieces[r].blocks.push_back(b);
+          pieces[r].rows += b->numTuples();
+        }
+        send_rows[r] = pieces[r].rows;
       }
-      send_rows[r] = pieces[r].rows;
-    }
+    }, "PartitionExchangeOperator: a rank could not collect its blocks");
+    in_collectives_ = true;
     const std::vector<std::int64_t> recv_rows = exchangeCounts(send_rows);
+    in_collectives_ = false;
     const std::int64_t total_send = Sum(send_rows), total_recv = Sum(recv_rows);
-    const bool owns_one = first + me < blocks_.size();
-    if (!owns_one && total_recv != 0) throw ExecutionError("PartitionExchangeOperator: tuples arrived for a partition that does not exist", QSX_ERR_INVALID_ARGUMENT);
     block_id out_id = 0;
     BlockReference out;
-    if (total_recv > 0) out = dest_->getBlockForInsertion(total_recv, &out_id);
     std::unique_ptr<DeviceBuffer> row_numbers;
+    std::vector<std::unique_ptr<DeviceBuffer>> send(relation.size()), send_bits(relation.size()), recv_bits(relation.size());
+    std::vector<std::int64_t> send_words(world), recv_words(world);
+    ranks->agreeOn([&]() {
+      const bool owns_one = first + me < blocks_.size();
+      if (!owns_one && total_recv != 0) throw ExecutionError("PartitionExchangeOperator: tuples arrived for a partition that does not exist", QSX_ERR_INVALID_ARGUMENT);
+      if (total_recv > 0) out = dest_->getBlockForInsertion(total_recv, &out_id);
+      std::int64_t max_rows = total_recv;
+      for (std::size_t r = 0; r < world; ++r) {
+        send_words[r] = WordsOf(send_rows[r]);
+        recv_words[r] = WordsOf(recv_rows[r]);
+        max_rows = std::max(max_rows, send_rows[r]);
+      }
+      for (std::size_t a = 0; a < relation.size(); ++a) {
+        const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
+        send[a].reset(new DeviceBuffer(static_cast<std::size_t>(total_send) * t.width + 8));
+        if (t.nullable) {
+          if (row_numbers == nullptr) row_numbers = RowNumbers(max_rows);
+          send_bits[a].reset(new DeviceBuffer(static_cast<std::size_t>(Sum(send_words)) * 8 + 8));
+          recv_bits[a].reset(new DeviceBuffer(static_cast<std::size_t>(Sum(recv_words)) * 8 + 8));
+        }
+      }
+    }, "PartitionExchangeOperator: a rank could not prepare its side of the exchange");
+    in_collectives_ = true;
     for (std::size_t a = 0; a < relation.size(); ++a) {
       const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
       // values: the pieces back to back in rank order -> all-to-all(v) straight into the output block's stripe
-      DeviceBuffer send(static_cast<std::size_t>(total_send) * t.width + 8);
       std::int64_t at = 0;
       for (const Piece &piece : pieces) {
         for (const BlockReference &b : piece.blocks) {
-          CheckStatus(qsx_copy_on_device(static_cast<char *>(send.ptr) + at * t.width, b->stripe(static_cast<attribute_id>(a)),
+          CheckStatus(qsx_copy_on_device(static_cast<char *>(send[a]->ptr) + at * t.width, b->stripe(static_cast<attribute_id>(a)),
                                          static_cast<std::size_t>(b->numTuples()) * t.width, CurrentStream()), "qsx_copy_on_device");
           at += b->numTuples();
         }
       }
-      CheckStatus(qsx_alltoallv(ranks->comm(), t.width, send.ptr, send_rows.data(), out != nullptr ? out->stripe(static_cast<attribute_id>(a)) : nullptr,
+      CheckStatus(qsx_alltoallv(ranks->comm(), t.width, send[a]->ptr, send_rows.data(), out != nullptr ? out->stripe(static_cast<attribute_id>(a)) : nullptr,
                                 recv_rows.data(), CurrentStream()), "qsx_alltoallv");
       op_->bytes_sent_ += static_cast<std::uint64_t>(total_send - send_rows[me]) * t.width;
       if (t.nullable) {
         // null bits: one word-aligned bitmap per (this rank, destination) and per (source, this rank)
-        std::vector<std::int64_t> send_words(world), recv_words(world);
-        std::int64_t max_rows = total_recv;
-        for (std::size_t r = 0; r < world; ++r) {
-          send_words[r] = WordsOf(send_rows[r]);
-          recv_words[r] = WordsOf(recv_rows[r]);
-          max_rows = std::max(max_rows, send_rows[r]);
-        }
-        if (row_numbers == nullptr) row_numbers = RowNumbers(max_rows);
-        DeviceBuffer send_bits(static_cast<std::size_t>(Sum(send_words)) * 8 + 8), recv_bits(static_cast<std::size_t>(Sum(recv_words)) * 8 + 8);
         std::int64_t word_at = 0;
         for (std::size_t r = 0; r < world; ++r) {
           std::vector<const std::uint64_t *> bitmaps;
@@ -165,24 +226,24 @@ class PartitionExchangeWorkOrder : public WorkOrder {
             bitmaps.push_back(b->nullBitmap(static_cast<attribute_id>(a)));
             rows.push_back(b->numTuples());
           }
-          PackNullBits(bitmaps, rows, *row_numbers, static_cast<std::uint64_t *>(send_bits.ptr) + word_at);
+          PackNullBits(bitmaps, rows, *row_numbers, static_cast<std::uint64_t *>(send_bits[a]->ptr) + word_at);
           word_at += send_words[r];
         }
-        CheckStatus(qsx_alltoallv(ranks->comm(), 8, send_bits.ptr, send_words.data(), recv_bits.ptr, recv_words.data(), CurrentStream()),
+        CheckStatus(qsx_alltoallv(ranks->comm(), 8, send_bits[a]->ptr, send_words.data(), recv_bits[a]->ptr, recv_words.data(), CurrentStream()),
                     "qsx_alltoallv(null bits)");
         if (out != nullptr) {
           std::vector<const std::uint64_t *> bitmaps;
           word_at = 0;
           for (std::size_t r = 0; r < world; ++r) {
-            bitmaps.push_back(static_cast<const std::uint64_t *>(recv_bits.ptr) + word_at);
+            bitmaps.push_back(static_cast<const std::uint64_t *>(recv_bits[a]->ptr) + word_at);
             word_at += recv_words[r];
           }
           PackNullBits(bitmaps, recv_rows, *row_numbers, out->nullBitmap(static_cast<attribute_id>(a)));
         }
-        CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // (send_bits / recv_bits go out of scope)
       }
-      CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");     // (send goes out of scope)
+      ranks->synchronize();       // (the watchdog's wait: a peer that never arrives ends the round with QSX_ERR_COMM)
     }
+    in_collectives_ = false;
     if (out != nullptr) dest_->returnBlock(out_id, total_recv, first + me);
   }
 
@@ -192,24 +253,40 @@ class PartitionExchangeWorkOrder : public WorkOrder {
     const std::size_t world = static_cast<std::size_t>(ranks->world()), me = static_cast<std::size_t>(ranks->rank());
     const CatalogRelation &relation = op_->output_relation_;
     Piece mine;
-    for (block_id id : blocks_.at(0)) {
-      BlockReference b = storage_manager_->getBlock(id);
-      if (b->numTuples() == 0) continue;
-      mine.blocks.push_back(b);
-      mine.rows += b->numTuples();
-    }
+    ranks->agreeOn([&]() {
+      for (block_id id : blocks_.at(0)) {
+        BlockReference b = storage_manager_->getBlock(id);
+        if (b->numTuples() == 0) continue;
+        mine.blocks.push_back(b);
+        mine.rows += b->numTuples();
+      }
+    }, "PartitionExchangeOperator: a rank could not collect its blocks");
+    in_collectives_ = true;
     const std::vector<std::int64_t> rows = exchangeCounts(std::vector<std::int64_t>(world, mine.rows));   // rows[r] = rank r's tuples
+    in_collectives_ = false;
     const std::int64_t total = Sum(rows);
     if (total == 0) return;
     std::int64_t pad = 1;
     for (std::int64_t r : rows) pad = std::max(pad, r);
     block_id out_id = 0;
-    BlockReference out = dest_->getBlockForInsertion(total, &out_id);
+    BlockReference out;
     std::unique_ptr<DeviceBuffer> row_numbers;
+    std::vector<std::unique_ptr<DeviceBuffer>> send_of(relation.size()), gathered_of(relation.size());
+    ranks->agreeOn([&]() {      // the output block and every buffer before the first all-gather (see exchangeRound)
+      out = dest_->getBlockForInsertion(total, &out_id);
+      for (std::size_t a = 0; a < relation.size(); ++a) {
+        const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
+        const std::size_t piece_bytes = static_cast<std::size_t>(pad) * t.width;
+        send_of[a].reset(new DeviceBuffer(piece_bytes + 8));
+        gathered_of[a].reset(new DeviceBuffer(piece_bytes * world + 8));
+        if (t.nullable && row_numbers == nullptr) row_numbers = RowNumbers(total);
+      }
+    }, "PartitionExchangeOperator: a rank could not prepare its side of the broadcast");
+    in_collectives_ = true;
     for (std::size_t a = 0; a < relation.size(); ++a) {
       const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
       const std::size_t piece_bytes = static_cast<std::size_t>(pad) * t.width;
-      DeviceBuffer send(piece_bytes + 8), gathered(piece_bytes * world + 8);
+      DeviceBuffer &send = *send_of[a], &gathered = *gathered_of[a];
       std::int64_t at = 0;
       for (const BlockReference &b : mine.blocks) {
         CheckStatus(qsx_copy_on_device(static_cast<char *>(send.ptr) + at * t.width, b->stripe(static_cast<attribute_id>(a)),
@@ -227,7 +304,6 @@ class PartitionExchangeWorkOrder : public WorkOrder {
         at += rows[r];
       }
       if (t.nullable) {
-        if (row_numbers == nullptr) row_numbers = RowNumbers(total);
         const std::int64_t pad_words = WordsOf(pad);
         DeviceBuffer send_bits(static_cast<std::size_t>(pad_words) * 8 + 8), all_bits(static_cast<std::size_t>(pad_words) * 8 * world + 8);
         CheckStatus(qsx_memset_device(send_bits.ptr, 0, static_cast<std::size_t>(pad_words) * 8, CurrentStream()), "qsx_memset_device");
@@ -243,8 +319,9 @@ class PartitionExchangeWorkOrder : public WorkOrder {
         for (std::size_t r = 0; r < world; ++r) bitmaps.push_back(static_cast<const std::uint64_t *>(all_bits.ptr) + static_cast<std::int64_t>(r) * pad_words);
         PackNullBits(bitmaps, rows, *row_numbers, out->nullBitmap(static_cast<attribute_id>(a)));
       }
-      CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+      ranks->synchronize();
     }
+    in_collectives_ = false;
     (void)me;
     dest_->returnBlock(out_id, total, 0);
   }
@@ -257,11 +334,12 @@ class PartitionExchangeWorkOrder : public WorkOrder {
                                     CurrentStream()), "qsx_exchange_counts");
     std::vector<std::int64_t> recv(world);
     CheckStatus(qsx_copy_to_host(recv.data(), recv_dev.ptr, world * 8, CurrentStream()), "qsx_copy_to_host");
-    CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
+    op_->ranks_->synchronize();
     return recv;
   }
 
   PartitionExchangeOperator *op_;
+  bool in_collectives_ = false;                 // a failure now is this rank's alone: execute() aborts the communicator
   std::vector<std::vector<block_id>> blocks_;   // per partition (broadcast: all in [0])
   InsertDestination *dest_;
   StorageManager *storage_manager_;

@@ -142,6 +142,49 @@ def main():
     for i, v in enumerate(results[0][1:]):
         save[f"hash_val{i}"] = v.cpu().numpy()
 
+    # ---- failure agreement (qsx_comm_agree): one rank contributes a failure, EVERY rank gets an error, and the communicator
+    # is still in step afterwards — no rank is left inside a collective the failing one never entered
+    comm.agree(0)                                                     # all fine: returns on every rank
+    failing = world - 1
+    try:
+        comm.agree(T.ERR_OUT_OF_MEMORY if rank == failing else 0)
+    except capi.QsxError as e:
+        if rank == failing:
+            assert e.status == T.ERR_OUT_OF_MEMORY, e
+        else:
+            assert e.status == T.ERR_COMM and f"rank {failing} failed" in str(e), e
+    else:
+        raise AssertionError("an agreed failure must raise on every rank")
+    comm.agree(0)
+    assert comm.allgather(mine).tolist() == [r + 1 for r in range(world) for _ in range(5)]
+    comm.synchronize()
+
+    # ---- the watchdog (qsx_comm_synchronize): a stream that does not drain before QSX_COMM_TIMEOUT_MS — what a collective
+    # whose peer never arrives looks like — ends the wait with QSX_ERR_COMM and aborts the communicator
+    import time
+    os.environ["QSX_COMM_TIMEOUT_MS"] = "150"
+    short = qd.CapiGroup.from_torch_group(capi, dev).comm
+    os.environ.pop("QSX_COMM_TIMEOUT_MS")
+    short.agree(0)
+    torch.cuda._sleep(int(4e9))                                      # ~2 s of device time on the current stream
+    t0 = time.perf_counter()
+    try:
+        short.synchronize()
+    except capi.QsxError as e:
+        assert e.status == T.ERR_COMM and "QSX_COMM_TIMEOUT_MS" in str(e), e
+    else:
+        raise AssertionError("the watchdog did not fire")
+    assert time.perf_counter() - t0 < 1.5, "the watchdog waited for the stream instead of its deadline"
+    try:
+        short.agree(0)
+    except capi.QsxError as e:
+        assert e.status == T.ERR_COMM and "aborted" in str(e), e
+    else:
+        raise AssertionError("an aborted communicator must refuse further calls")
+    short.close()
+    torch.cuda.synchronize()
+    dist.barrier()
+
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **save)
     torch.cuda.synchronize()
     comm.close()

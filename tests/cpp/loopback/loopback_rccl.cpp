@@ -43,7 +43,8 @@ namespace {
 
 constexpr uint32_t kMagic = 0x51534c42;   // "QSLB"
 constexpr int kMaxWorld = 16;
-constexpr double kTimeoutSeconds = 120.0;
+// LOOPBACK_RCCL_TIMEOUT_S shortens the wait for a peer that never arrives (tests of the failure paths)
+const double kTimeoutSeconds = std::getenv("LOOPBACK_RCCL_TIMEOUT_S") != nullptr ? std::atof(std::getenv("LOOPBACK_RCCL_TIMEOUT_S")) : 120.0;
 
 struct Control {
   std::atomic<uint32_t> magic;
@@ -335,6 +336,15 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   munmap(c->control, sizeof(Control));
   delete c;
   return ncclSuccess;
+}
+
+// A rank that gives a step up: its peers leave their barriers with an error (the control block's `failed` word) instead of
+// waiting for it; the communicator's files are released like ncclCommDestroy does.
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+  Comm *c = reinterpret_cast<Comm *>(comm);
+  if (c == nullptr) return ncclSuccess;
+  c->control->failed.store(1, std::memory_order_relaxed);
+  return ncclCommDestroy(comm);
 }
 
 ncclResult_t ncclGroupStart() {

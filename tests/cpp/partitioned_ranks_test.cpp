@@ -461,6 +461,68 @@ void runMergedAggregation(const Ranks &ranks, int slices, Lines *out) {
   }
 }
 
+// One rank loses a block between plan construction and the exchange (a rank-local failure between collectives
+// used to leave every other rank inside the all-to-all for ever).  The round must end with an error on EVERY rank, promptly
+// — the failing rank with its own error, the healthy ones with QSX_ERR_COMM naming the rank that failed
+// (RankGroup::agreeOn -> qsx_comm_agree) — and the communicator must still be in step afterwards.
+void runFailingExchange(const Ranks &ranks) {
+  StorageManager storage;
+  CatalogRelation scattered(1, "scattered"), arrived(2, "arrived");
+  addDimAttributes(&scattered);
+  scattered.setPartitionScheme(4, 0);
+  addDimAttributes(&arrived);
+  arrived.setPartitionScheme(4, 0);
+  std::vector<block_id> mine;
+  for (std::size_t p = 0; p < 4; ++p) {       // every rank holds a piece of EVERY partition: the exchange really moves tuples
+    std::vector<std::int32_t> id;
+    std::vector<char> text;
+    int dealt = 0;
+    for (const TestRow &r : testTable()) {
+      if (r.int_null || r.int_col == 0 || pid(r.int_col, 4) != p) continue;
+      if ((dealt++ % ranks.world) != ranks.rank) continue;
+      id.push_back(r.int_col);
+      text.insert(text.end(), r.char_col, r.char_col + 20);
+    }
+    if (!id.empty()) mine.push_back(storage.loadBlock(&scattered, {id.data(), text.data()}, static_cast<std::int64_t>(id.size()), p));
+  }
+  QueryContext ctx;
+  const auto d_arrived = ctx.addInsertDestination(&arrived, &storage);
+  QueryPlan plan;
+  plan.addRelationalOperator(new PartitionExchangeOperator(0, scattered, true, arrived, d_arrived, ranks.group));
+  const int failing = ranks.world - 1;
+  if (ranks.rank == failing) {
+    EXPECT_TRUE(!mine.empty());
+    if (!mine.empty()) storage.deleteBlockOrBlobFile(mine.front());
+  }
+  bool threw = false;
+  std::string what;
+  const auto t0 = std::chrono::steady_clock::now();
+  try {
+    ForemanSingleNode foreman(&plan, &ctx, &storage, 2);
+    foreman.run();
+  } catch (const std::exception &e) {
+    threw = true;
+    what = e.what();
+  }
+  const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  EXPECT_TRUE(threw);
+  EXPECT_TRUE(seconds < 30.0);
+  if (ranks.rank == failing) {
+    EXPECT_TRUE(what.find("unknown block") != std::string::npos);
+  } else {
+    EXPECT_TRUE(what.find("rank " + std::to_string(failing) + " failed") != std::string::npos);
+  }
+  std::printf("rank %d: the failed round ended after %.2f s with '%s'\n", ranks.rank, seconds, what.c_str());
+  bool in_step = true;
+  try {
+    ranks.group->agreeOn([]() {}, "after the failed round");
+  } catch (const std::exception &e) {
+    in_step = false;
+    std::fprintf(stderr, "rank %d: the communicator is out of step after the failed round: %s\n", ranks.rank, e.what());
+  }
+  EXPECT_TRUE(in_step);
+}
+
 void runAll(const Ranks &ranks, int slices, Lines *out) {
   runTestTableJoin("partitioned_join", DimKind::kPartitioned4, ranks, out);
   runTestTableJoin("broadcast_join", DimKind::kUnpartitionedBroadcast, ranks, out);
@@ -502,8 +564,16 @@ int rankMain(int world, int rank, const std::string &dir) {
   ranks.world = world;
   ranks.rank = rank;
   ranks.group = &group;
-  Lines lines;
+  Lines lines, lines_again;
   runAll(ranks, world, &lines);
+  runFailingExchange(ranks);
+  runAll(ranks, world, &lines_again);      // ... and every plan still runs on the same communicator afterwards
+  {
+    Lines a = lines, b = lines_again;            // (row order depends on which Worker returns its block first)
+    std::sort(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    EXPECT_TRUE(a == b);
+  }
   std::ofstream out(dir + "/w" + std::to_string(world) + "_r" + std::to_string(rank) + ".txt");
   for (const std::string &l : lines) out << l << "\n";
   out.close();
@@ -518,6 +588,7 @@ bool startRanks(int world, const std::string &dir, const std::string &loopback) 
     if (std::strncmp(*e, "QSX_RCCL_LIBRARY=", 17) != 0) env_text.push_back(*e);
   }
   env_text.push_back("QSX_RCCL_LIBRARY=" + loopback);
+  env_text.push_back("QSX_ALLOW_TEST_TRANSPORT=1");
   std::vector<char *> envp;
   for (std::string &s : env_text) envp.push_back(&s[0]);
   envp.push_back(nullptr);

@@ -63,9 +63,9 @@ def test_two_ranks_rehearsal_on_one_gpu(config):
     lib = os.path.join(ROOT, "tests", "cpp", "bin", "libloopback_rccl.so")
     assert os.path.exists(lib), "make -C quickstep_amd/host builds it"
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update({"QSX_BENCH_SHARED_GPU": "1", "QSX_RCCL_LIBRARY": lib})
+    env.update({"QSX_BENCH_SHARED_GPU": "1", "QSX_RCCL_LIBRARY": lib, "QSX_ALLOW_TEST_TRANSPORT": "1"})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "capi", "--config", config,
-                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric')][-1])
     assert line["n_gpus"] == 2 and line["world_size_seen"] == 2 and line["self_launched"] is True

@@ -62,7 +62,7 @@ def test_c_abi_collectives_at_world_2_and_3(world, tmp_path):
     from comm_loopback_worker import DENSE_CASES, dense_inputs, hash_inputs
     import os
     assert os.path.exists(LOOPBACK), "tests/cpp/bin/libloopback_rccl.so is not built (make -C quickstep_amd/host)"
-    launch_ranks(world, "comm_loopback_worker.py", [tmp_path], {"QSX_RCCL_LIBRARY": LOOPBACK})
+    launch_ranks(world, "comm_loopback_worker.py", [tmp_path], {"QSX_RCCL_LIBRARY": LOOPBACK, "QSX_ALLOW_TEST_TRANSPORT": "1"})
     ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
 
     want = functools.reduce(np.bitwise_or, [d["or_in"] for d in ranks])
@@ -124,3 +124,19 @@ def test_c_abi_collectives_at_world_2_and_3(world, tmp_path):
         assert np.array_equal(d["hash_key"], uniq)
         assert np.array_equal(d["hash_val0"], sums) and np.array_equal(d["hash_val1"], counts)
         assert np.array_equal(d["hash_val2"], mins) and np.array_equal(d["hash_val3"], maxs)
+
+
+def test_the_test_transport_is_refused_without_its_switch():
+    """QSX_RCCL_LIBRARY alone must not put another library under the collectives (csrc/comm.hip): a process that carries it
+    without QSX_ALLOW_TEST_TRANSPORT=1 gets no transport at all — QSX_ERR_COMM — instead of the substitute or a silent fall-back."""
+    import os
+    import subprocess
+    import sys
+    from test_gpu_two_ranks import LOOPBACK
+    code = ("import quickstep_amd.capi as capi\n"
+            "try:\n    capi.Comm.unique_id()\nexcept capi.QsxError as e:\n    print('refused:', e)\nelse:\n    print('bound')\n")
+    env = dict(os.environ, QSX_RCCL_LIBRARY=LOOPBACK)
+    env.pop("QSX_ALLOW_TEST_TRANSPORT", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert "refused:" in r.stdout and "QSX_ALLOW_TEST_TRANSPORT" in r.stdout, r.stdout + r.stderr

@@ -43,6 +43,7 @@ def ranks(request, tmp_path_factory):
     if transport == "capi":
         assert os.path.exists(LOOPBACK), "tests/cpp/bin/libloopback_rccl.so is not built (make -C quickstep_amd/host)"
         extra["QSX_RCCL_LIBRARY"] = LOOPBACK
+        extra["QSX_ALLOW_TEST_TRANSPORT"] = "1"
     launch_ranks(world, "dist_worker_gpu.py", [out, transport], extra)
     return [np.load(out / f"rank{i}.npz") for i in range(world)]
 

@@ -13,7 +13,7 @@ for cfg in c4 c5; do
 done
 # two ranks on this one GPU (rehearsal: loopback transport, gloo control plane): the N > 1 path of every configuration, self-launched
 for cfg in headline c4 c5; do
-  QSX_BENCH_SHARED_GPU=1 QSX_RCCL_LIBRARY=$PWD/tests/cpp/bin/libloopback_rccl.so timeout 600 python bench.py --gpus 2 --transport capi --config $cfg --steps 3 --warmup 1 --no-cpu-baseline 2> $out/bench_${cfg}_2ranks_shared_gpu.err | tail -1 > $out/bench_${cfg}_2ranks_shared_gpu.json; tail -c 200 $out/bench_${cfg}_2ranks_shared_gpu.json; echo
+  QSX_BENCH_SHARED_GPU=1 QSX_ALLOW_TEST_TRANSPORT=1 QSX_RCCL_LIBRARY=$PWD/tests/cpp/bin/libloopback_rccl.so timeout 600 python bench.py --gpus 2 --transport capi --config $cfg --steps 3 --warmup 1 --no-cpu-baseline 2> $out/bench_${cfg}_2ranks_shared_gpu.err | tail -1 > $out/bench_${cfg}_2ranks_shared_gpu.json; tail -c 200 $out/bench_${cfg}_2ranks_shared_gpu.json; echo
 done
 QSX_BENCH_FORCE_DISTRIBUTED=1 timeout 600 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --transport capi 2> $out/bench_headline_dist1_capi.err | tail -1 > $out/bench_headline_dist1_capi.json; tail -c 200 $out/bench_headline_dist1_capi.json; echo
 rocprofv3 --kernel-trace --stats -d $out/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-operators > $out/bench_traced.json 2> $out/bench_traced.err
