@@ -24,6 +24,7 @@
 
 #include "common.hpp"
 #include "join_dense.hpp"
+#include "join_lds.hpp"
 #include "scan.hpp"
 
 #include <atomic>
@@ -547,6 +548,10 @@ __global__ __launch_bounds__(kJBlock) void probe_fp_kernel(
     if (lane_id() == 0 && local_count != 0 && out_count != nullptr) atomicAdd(out_count, local_count);
   }
 }
+
+}  // namespace qsx
+#include "join_lds_bucket.hpp"
+namespace qsx {
 
 // ---------------------------------------------------------------------------
 // composite keys -> one LONG key (qsx_join_key_pack)
@@ -1100,6 +1105,12 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
 
 }  // extern "C"
 
+// Tables the probe kernels copy into LDS (join_lds.hpp); QSX_JOIN_LDS=0 keeps every lookup in HBM / L2.
+static bool lds_tables_enabled() {
+  const char *e = getenv("QSX_JOIN_LDS");
+  return e == nullptr || e[0] != '0';
+}
+
 // The two-pass dense probe pays a second read of the keys and wins when the lookups are cheap and the tiles many: with
 // a filter (LIP / predicate bitmap: few live rows) by default; QSX_JOIN_TWO_PASS=1 / 0 forces it on / off.
 static bool dense_two_pass(const uint64_t *filter) {
@@ -1176,10 +1187,15 @@ static void sealed_pack(qsx_join_table *t, hipStream_t stream) {
   t->seal_state.store(2, std::memory_order_release);
 }
 
-static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream) {
+// probe_rows: the rows of the probe that asks (0: unknown).  A build side below kAdaptiveMinRows is only worth the look
+// (a device synchronisation, a copy of the control words) in front of a probe of a million rows or more — and then its
+// shadow, when the keys turn out dense, is a table the probe kernels hold in LDS (join_lds.hpp).
+static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream, int64_t probe_rows = 0) {
   int state = t->seal_state.load(std::memory_order_acquire);
   if (state == 2) return t->shadow;
-  if (state == 1 || t->reserved < kAdaptiveMinRows || !adaptive_enabled()) return nullptr;
+  if (state == 1 || !adaptive_enabled()) return nullptr;
+  const bool small_build = t->reserved < kAdaptiveMinRows;
+  if (small_build && (probe_rows < (1 << 20) || t->reserved < 1 || !lds_tables_enabled())) return nullptr;
   std::lock_guard<std::mutex> lock(t->seal_mutex);
   state = t->seal_state.load(std::memory_order_acquire);
   if (state != 0) return state == 2 ? t->shadow : nullptr;
@@ -1190,8 +1206,10 @@ static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream) {
   const uint64_t entries = v[0];
   const int64_t lo = static_cast<int64_t>(v[4] ^ 0x8000000000000000ull), hi = static_cast<int64_t>(~v[5] ^ 0x8000000000000000ull);
   const uint64_t span = static_cast<uint64_t>(hi) - static_cast<uint64_t>(lo);
-  if (v[4] == ~0ull || entries < static_cast<uint64_t>(kAdaptiveMinRows) || span >= 8 * entries || span >= (1ull << 32) ||
-      entries > 0x7FFFFFFFull) {
+  // (a small build side: only when the whole key range fits the LDS table of the probe kernels)
+  const bool fits_lds = small_build && entries >= 1 && span < static_cast<uint64_t>(kLdsDenseMaxWords);
+  if (v[4] == ~0ull || (entries < static_cast<uint64_t>(kAdaptiveMinRows) && !fits_lds) || (span >= 8 * entries && !fits_lds) ||
+      span >= (1ull << 32) || entries > 0x7FFFFFFFull) {
     t->seal_state.store(1, std::memory_order_release);
     return nullptr;
   }
@@ -1225,6 +1243,29 @@ static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream) {
   return shadow;
 }
 
+// The LDS-resident form of the dense probe (join_lds.hpp): one workgroup of 1024 threads per CU, the table in its LDS.
+template <int MODE, bool kRuns>
+static int launch_lds_dense_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_t probe_base_tid, const uint64_t *filter,
+                                  int32_t *out_probe, int32_t *out_build, int64_t capacity, unsigned long long *count,
+                                  uint64_t *out_bitmap, int anti, hipStream_t stream, const long long *runs_dev, int64_t tiles) {
+  const size_t table_bytes = (static_cast<size_t>(t->range) * 4 + 15) & ~static_cast<size_t>(15);
+  auto launch = [&](auto key_tag) -> int {
+    using KeyT = decltype(key_tag);
+    auto kernel = &lds_dense_probe_kernel<KeyT, MODE, kRuns>;
+    if (table_bytes > 48 * 1024) {
+      // (a property of (kernel, device); setting it again is a cheap host call)
+      QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLdsStaticBytes));
+    }
+    const int64_t units = (tiles + kLdsSub - 1) / kLdsSub;
+    const int grid = static_cast<int>(units < kCUs ? units : kCUs);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kLdsBlock), table_bytes, stream, t->dense_view(), static_cast<const KeyT *>(keys), n, probe_base_tid,
+                       filter, out_probe, out_build, capacity, count, out_bitmap, anti, runs_dev);
+    QSX_CHECK_LAUNCH();
+    return QSX_OK;
+  };
+  return t->key_type == QSX_INT ? launch(int32_t{}) : launch(int64_t{});
+}
+
 // kRuns: the probe side is a run of blocks — runs_dev is its table (block_runs.hpp, tiles of 4096 rows), run_tiles its tile
 // count, n the rows of all blocks together and `filter` non-NULL when any block has one; keys / probe_base_tid /
 // out_bitmap come from the table.
@@ -1235,7 +1276,7 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
                         hipStream_t stream, const long long *runs_dev = nullptr, int64_t run_tiles = 0) {
   static_assert(kDenseTile == kProbeTile, "one run table serves both table kinds");
   if (!t->dense && n != 0) {
-    qsx_join_table *shadow = sealed_shadow(t, stream);
+    qsx_join_table *shadow = sealed_shadow(t, stream, n);
     if (shadow != nullptr) {
       return launch_probe<MODE, kRuns>(shadow, keys, n, probe_base_tid, filter, out_probe, out_build, capacity, out_count, out_bitmap,
                                        anti, stream, runs_dev, run_tiles);
@@ -1250,6 +1291,16 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
     const int64_t limit = 8 * kCUs;  // no LDS: 8 workgroups (32 waves) per CU
     const int dgrid = static_cast<int>(tiles < limit ? tiles : limit);
     unsigned long long *dcount = reinterpret_cast<unsigned long long *>(out_count);
+    if constexpr (MODE == 0 || MODE == 1 || MODE == 2) {
+      // A table of a few ten thousand key values: every workgroup holds it in LDS (join_lds.hpp).  Worth it when the probe
+      // is long against the copies (a workgroup copies range words once and then walks its tiles).
+      const bool two_pass = MODE == 0 && dense_two_pass(filter);
+      if (!two_pass && lds_tables_enabled() && t->range <= static_cast<uint64_t>(kLdsDenseMaxWords) && n >= 32 * static_cast<int64_t>(t->range) &&
+          n >= (1 << 18)) {
+        return launch_lds_dense_probe<MODE, kRuns>(t, keys, n, probe_base_tid, filter, out_probe, out_build, capacity, dcount, out_bitmap, anti,
+                                                   stream, runs_dev, tiles);
+      }
+    }
     if (MODE == 0 && dense_two_pass(filter)) {
       // count per (tile, wave) -> scan -> write: see join_dense.hpp
       const int64_t units = tiles * (kDBlock / kWave);
@@ -1296,6 +1347,27 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
     return QSX_OK;
   }
   const int64_t num_tiles = kRuns ? run_tiles : (n + kProbeTile - 1) / kProbeTile;
+  if constexpr (MODE == 0 || MODE == 1 || MODE == 2) {
+    // a bucketed table of a few thousand keys: fingerprint plane and slots copied into every workgroup's LDS
+    // (join_lds_bucket.hpp), for a probe that is long against the copies
+    if (lds_tables_enabled() && t->table_bytes() <= kLdsBucketMaxBytes && n >= (1 << 18) && n >= 8 * static_cast<int64_t>(t->capacity)) {
+      const size_t table_bytes = (t->table_bytes() + 15) & ~static_cast<size_t>(15);
+      auto launch = [&](auto key_tag) -> int {
+        using KeyT = decltype(key_tag);
+        auto kernel = &lds_bucket_probe_kernel<KeyT, MODE, kRuns>;
+        if (table_bytes > 48 * 1024) {
+          QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLdsStaticBytes));
+        }
+        const int64_t units = (num_tiles + kLdsSub - 1) / kLdsSub;
+        const int lgrid = static_cast<int>(units < kCUs ? units : kCUs);
+        hipLaunchKernelGGL(kernel, dim3(lgrid), dim3(kLdsBlock), table_bytes, stream, t->view(), static_cast<const KeyT *>(keys), n, probe_base_tid, filter,
+                           out_probe, out_build, capacity, reinterpret_cast<unsigned long long *>(out_count), out_bitmap, anti, runs_dev);
+        QSX_CHECK_LAUNCH();
+        return QSX_OK;
+      };
+      return t->key_type == QSX_INT ? launch(int32_t{}) : launch(int64_t{});
+    }
+  }
   // 4 workgroups per CU keep 128 KiB of the 160 KiB LDS busy in pair mode.
   const int64_t max_grid = MODE == 0 ? 4 * kCUs : 8 * kCUs;
   const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);

@@ -716,3 +716,109 @@ def test_composite_keys_of_a_run_of_blocks_pack_like_block_by_block(capi, dev, t
     want = torch.cat([capi.join_key_pack(b)[0] for b in blocks if b[0].numel()])
     assert exact == capi.join_key_pack([b for b in blocks if b[0].numel()][0])[1]
     assert torch.equal(packed, want)
+
+
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+@pytest.mark.parametrize("key_range", [1, 7, 2_000, 11_000, 20_000, 36 * 1024, 36 * 1024 + 1])
+@pytest.mark.parametrize("flavour", ["dense", "hashed"])
+def test_small_build_sides_are_probed_from_lds(capi, oracle, dev, key_type, dtype, key_range, flavour, monkeypatch):
+    """csrc/join_lds.hpp: a directly addressed table of up to 36 Ki key values (or the shadow of a hashed table over such a
+    domain) is copied into LDS by every workgroup of a long probe.  Key ranges that make one, two and four workgroups per
+    CU (1024 / 512 / 256 threads), the largest range the LDS takes and the first one it does not; duplicate build keys
+    (chains through the overflow list), probe keys outside the range, a probe filter (NULL probe keys reach the kernels as
+    one), count / pairs / existence / anti, a run of blocks — all equal to the oracle, and to the same calls with
+    QSX_JOIN_LDS=0."""
+    rng = np.random.default_rng(1000 + key_range)
+    lo = -77 if dtype == np.int32 else 2**40
+    n_probe = max(300_000, 40 * key_range)
+    n_build = max(1, int(key_range * 1.2)) if key_range < 30_000 else key_range // 2
+    build = (lo + rng.integers(0, key_range, size=n_build)).astype(dtype)     # duplicates (1.2 rows per key value) or holes
+    build[0], build[-1] = lo, lo + key_range - 1                              # the whole range is in use
+    probe = (lo + rng.integers(-key_range // 10 - 3, key_range + key_range // 10 + 3, size=n_probe)).astype(dtype)
+    pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.7)
+    dp = to_dev(probe, dev)
+    results = {}
+    for lds in ("1", "0"):
+        monkeypatch.setenv("QSX_JOIN_LDS", lds)
+        table = capi.JoinTable(key_type, n_build, key_range=(lo, lo + key_range - 1) if flavour == "dense" else None)
+        table.build(to_dev(build, dev))
+        got = []
+        for filt in (None, pf):
+            fdev = None if filt is None else bitmap_dev(filt, dev)
+            _, rp, rd = oracle_join(oracle, key_type, [build], probe, probe_filter=filt)
+            assert int(table.probe_count(dp, filter_bitmap=fdev).item()) == rp.size
+            p, b, cnt = table.probe(dp, capacity=rp.size, filter_bitmap=fdev)
+            assert int(cnt.item()) == rp.size
+            pairs = sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size])
+            assert np.array_equal(pairs, sorted_pairs(rp, rd))
+            want = np.zeros(n_probe, dtype=bool)
+            want[rp] = True
+            live = np.ones(n_probe, dtype=bool) if filt is None else oracle.bools_from_bitmap(filt, n_probe)
+            for anti in (False, True):
+                bm, c = table.probe_exists(dp, anti=anti, filter_bitmap=fdev)
+                ref = (want != anti) & live
+                assert np.array_equal(bitmap_np(bm), oracle.bitmap_from_bools(ref)) and int(c.item()) == int(ref.sum())
+            got.append(pairs)
+        cuts = [0, 4096, 4096, 123_457, n_probe]
+        blocks = [dp[a:b_] for a, b_ in zip(cuts[:-1], cuts[1:])]
+        _, rp, rd = oracle_join(oracle, key_type, [build], probe)
+        p, b, cnt = table.probe_blocks(blocks, capacity=rp.size)
+        assert int(cnt.item()) == rp.size
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rd))
+        results[lds] = got
+        table.close()
+    for a, b in zip(results["1"], results["0"]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+@pytest.mark.parametrize("n_keys,duplicates", [(1, False), (40, True), (3_000, False), (3_000, True), (6_000, False), (12_500, False), (14_000, False)])
+def test_small_bucketed_tables_are_probed_from_lds(capi, oracle, dev, key_type, dtype, n_keys, duplicates, monkeypatch):
+    """csrc/join_lds_bucket.hpp: a bucketed table (sparse keys: no shadow) whose slots and fingerprint plane fit 144 KiB is
+    copied into LDS by every workgroup of a long probe — INT tables up to ~13 K keys, LONG tables up to ~6.5 K; the sizes
+    beyond stay in L2.  Unique and duplicate build keys (a duplicate-free INT table ends a probe at its first match), keys
+    that are absent, a probe filter, count / pairs / existence / anti and a run of blocks: equal to the oracle and to the
+    same calls with QSX_JOIN_LDS=0."""
+    rng = np.random.default_rng(7000 + n_keys + (1 if duplicates else 0))
+    info = np.iinfo(dtype)
+    distinct = rng.choice(np.arange(-2**30, 2**30, dtype=np.int64) if dtype == np.int32 else rng.integers(info.min // 2, info.max // 2, size=4 * n_keys + 8),
+                          size=max(2, 2 * n_keys), replace=False).astype(dtype)
+    present, absent = distinct[:n_keys], distinct[n_keys:]
+    build = np.concatenate([present, rng.choice(present, size=n_keys // 2)]) if duplicates else present.copy()
+    rng.shuffle(build)
+    n_probe = 400_000
+    probe = np.where(rng.random(n_probe) < 0.7, rng.choice(present, size=n_probe), rng.choice(absent, size=n_probe)).astype(dtype)
+    pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.8)
+    dp = to_dev(probe, dev)
+    results = {}
+    for lds in ("1", "0"):
+        monkeypatch.setenv("QSX_JOIN_LDS", lds)
+        table = capi.JoinTable(key_type, build.size)
+        table.build(to_dev(build, dev))
+        got = []
+        for filt in (None, pf):
+            fdev = None if filt is None else bitmap_dev(filt, dev)
+            _, rp, rd = oracle_join(oracle, key_type, [build], probe, probe_filter=filt)
+            assert int(table.probe_count(dp, filter_bitmap=fdev).item()) == rp.size
+            p, b, cnt = table.probe(dp, capacity=rp.size, filter_bitmap=fdev)
+            assert int(cnt.item()) == rp.size
+            pairs = sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size])
+            assert np.array_equal(pairs, sorted_pairs(rp, rd))
+            want = np.zeros(n_probe, dtype=bool)
+            want[rp] = True
+            live = np.ones(n_probe, dtype=bool) if filt is None else oracle.bools_from_bitmap(filt, n_probe)
+            for anti in (False, True):
+                bm, c = table.probe_exists(dp, anti=anti, filter_bitmap=fdev)
+                ref = (want != anti) & live
+                assert np.array_equal(bitmap_np(bm), oracle.bitmap_from_bools(ref)) and int(c.item()) == int(ref.sum())
+            got.append(pairs)
+        cuts = [0, 4096, 4096, 123_457, n_probe]
+        blocks = [dp[a:b_] for a, b_ in zip(cuts[:-1], cuts[1:])]
+        _, rp, rd = oracle_join(oracle, key_type, [build], probe)
+        p, b, cnt = table.probe_blocks(blocks, capacity=rp.size)
+        assert int(cnt.item()) == rp.size
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rd))
+        results[lds] = got
+        table.close()
+    for a, b in zip(results["1"], results["0"]):
+        assert np.array_equal(a, b)
