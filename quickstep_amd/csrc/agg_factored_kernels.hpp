@@ -1,0 +1,572 @@
+// agg_factored_kernels.hpp — device code of the factored aggregation (agg_factored.hpp has the story); included by
+// agg_factored.hip only.
+#ifndef QSX_CSRC_AGG_FACTORED_KERNELS_HPP_
+#define QSX_CSRC_AGG_FACTORED_KERNELS_HPP_
+
+#include "agg_factored.hpp"
+#include "agg_hash_update.hpp"
+
+namespace qsx {
+
+__device__ inline double factored_dict_value(const DevConfig &c, int col, int code) {
+  const void *d = as_global(c.dicts[col]);
+  switch (c.column_type[col]) {
+    case QSX_INT: return static_cast<double>(static_cast<const int32_t *>(d)[code]);
+    case QSX_LONG: return static_cast<double>(static_cast<const long long *>(d)[code]);
+    case QSX_FLOAT: return static_cast<double>(static_cast<const float *>(d)[code]);
+    default: return static_cast<const double *>(d)[code];
+  }
+}
+__device__ inline long long factored_dict_int(const DevConfig &c, int col, int code) {
+  const void *d = as_global(c.dicts[col]);
+  return c.column_type[col] == QSX_INT ? static_cast<long long>(static_cast<const int32_t *>(d)[code]) : static_cast<const long long *>(d)[code];
+}
+// The expression program over one assignment of column values (every node rounded on its own, like the row-wise
+// evaluation: -ffp-contract=off); returns the value of `arg`.
+__device__ inline double factored_eval(const DevConfig &c, const double (&vals)[QSX_MAX_COLUMNS], const DevOperand &arg) {
+  double temps[QSX_MAX_TEMPS];
+  for (int t = 0; t < QSX_MAX_TEMPS; ++t) temps[t] = 0.0;
+  auto value = [&](const DevOperand &o) -> double {
+    if (o.kind == QSX_OPD_COLUMN) return vals[o.index];
+    if (o.kind == QSX_OPD_CONST) return c.consts[o.index];
+    return temps[o.index];
+  };
+  for (int k = 0; k < c.num_instrs; ++k) {
+    const double a = value(c.instrs[k].a), b = value(c.instrs[k].b);
+    double r;
+    switch (c.instrs[k].op) {
+      case QSX_EX_ADD: r = a + b; break;
+      case QSX_EX_SUB: r = a - b; break;
+      case QSX_EX_MUL: r = a * b; break;
+      default: r = a / b; break;
+    }
+    temps[c.instrs[k].dst] = r;
+  }
+  return value(arg);
+}
+__global__ __launch_bounds__(kABlock) void factored_coef_kernel(DevConfig c, FactoredCoefArgs a) {
+  const int per_sum = a.cells + kFacMaxDict;
+  const int i = blockIdx.x * kABlock + threadIdx.x;
+  if (i >= a.nsums * per_sum) return;
+  const int j = i / per_sum, at = i % per_sum;
+  const bool is_int = c.sums[j].kind == kAccSumI64;
+  double vals[QSX_MAX_COLUMNS];
+  for (int col = 0; col < QSX_MAX_COLUMNS; ++col) vals[col] = 0.0;
+  if (at >= a.cells) {     // the histogram coefficients of sum j: H[j][code]
+    const int code = at - a.cells;
+    unsigned long long word = 0;
+    const int h = a.sum_hist[j];
+    if (h >= 0 && code < a.hist_size[h]) {
+      const int col = a.hist_col[h];
+      if (is_int) {
+        word = static_cast<unsigned long long>(factored_dict_int(c, col, code));
+      } else {
+        vals[col] = factored_dict_value(c, col, code);
+        word = static_cast<unsigned long long>(__double_as_longlong(factored_eval(c, vals, c.sums[j].arg)));
+      }
+    }
+    a.hcoef[j * kFacMaxDict + code] = word;
+    return;
+  }
+  const int cell = at;
+  unsigned long long *out = a.coef + static_cast<size_t>(j) * (1 + a.ncar) * a.cells;
+  if (a.sum_hist[j] >= 0) {   // depends on a histogram column only: nothing comes from the cells
+    for (int k = 0; k <= a.ncar; ++k) out[static_cast<size_t>(k) * a.cells + cell] = 0;
+    return;
+  }
+  int cell_code[kFacMaxCell] = {};
+  for (int q = 0; q < a.ncell; ++q) {
+    cell_code[q] = (cell / a.cell_stride[q]) % a.cell_radix[q];
+    vals[a.cell_col[q]] = factored_dict_value(c, a.cell_col[q], cell_code[q]);
+  }
+  if (is_int) {
+    // SUM over an INT / LONG column: the cell's integer dictionary value times its count (a plain integer column is a
+    // carrier with an i64 plane and needs no coefficient, FactoredArgs::sum_car_int); COUNT-like sums of the constant: 1
+    long long v = 1;
+    if (c.sums[j].arg.kind == QSX_OPD_COLUMN) {
+      v = 0;
+      for (int q = 0; q < a.ncell; ++q) {
+        if (a.cell_col[q] == c.sums[j].arg.index) v = factored_dict_int(c, a.cell_col[q], cell_code[q]);
+      }
+    }
+    out[cell] = static_cast<unsigned long long>(v);
+    for (int k = 1; k <= a.ncar; ++k) out[static_cast<size_t>(k) * a.cells + cell] = 0;
+    return;
+  }
+  const double a0 = factored_eval(c, vals, c.sums[j].arg);      // every carrier 0: the part that multiplies the count
+  out[cell] = static_cast<unsigned long long>(__double_as_longlong(a0));
+  for (int k = 0; k < a.ncar; ++k) {
+    vals[a.car_col[k]] = 1.0;
+    const double ak = factored_eval(c, vals, c.sums[j].arg) - a0;
+    vals[a.car_col[k]] = 0.0;
+    out[static_cast<size_t>(k + 1) * a.cells + cell] = static_cast<unsigned long long>(__double_as_longlong(ak));
+  }
+}
+
+// ---- accumulate ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long factored_read(const char *tile, int off, int width, int row) {
+  switch (width) {
+    case 1: return reinterpret_cast<const uint8_t *>(tile + off)[row];
+    case 2: return reinterpret_cast<const uint16_t *>(tile + off)[row];
+    case 4: return reinterpret_cast<const uint32_t *>(tile + off)[row];
+    default: return reinterpret_cast<const unsigned long long *>(tile + off)[row];
+  }
+}
+__device__ __forceinline__ unsigned long long factored_carrier_word(unsigned long long raw, int type, bool as_int) {
+  if (as_int) return type == QSX_INT ? static_cast<unsigned long long>(static_cast<long long>(static_cast<int32_t>(raw))) : raw;
+  double v;
+  switch (type) {
+    case QSX_INT: v = static_cast<double>(static_cast<int32_t>(raw)); break;
+    case QSX_LONG: v = static_cast<double>(static_cast<long long>(raw)); break;
+    case QSX_FLOAT: v = static_cast<double>(__uint_as_float(static_cast<uint32_t>(raw))); break;
+    default: v = __longlong_as_double(static_cast<long long>(raw)); break;
+  }
+  return static_cast<unsigned long long>(__double_as_longlong(v));
+}
+
+// The workgroup's cells -> the state: a wave per group slot; every accumulator of the state is a dot product over the slot's
+// cells (coefficients from this call's dictionaries, factored_coef_kernel).
+__device__ __forceinline__ void factored_flush(const FactoredArgs &a, const unsigned long long *l_keys, const unsigned long long *l_plane,
+                                               const unsigned int *l_cnt, const unsigned int *l_hist, const HashTableView &g) {
+  const int S = a.S, cells = a.cells;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  for (int s = wave; s < S; s += kABlock / kWave) {
+    const unsigned long long code = l_keys[s];
+    if (code == kEmptyCode) continue;
+    unsigned long long gs = 0;
+    if (lane == 0) gs = global_find_or_insert(g, code);
+    gs = __shfl(gs, 0, kWave);
+    if (gs == ~0ull) continue;
+    const unsigned int *cnt = l_cnt + static_cast<size_t>(s) * cells;
+    unsigned long long rows_in_group = 0;
+    for (int c = lane; c < cells; c += kWave) rows_in_group += cnt[c];
+    rows_in_group = wave_reduce_add(rows_in_group);
+    if (lane == 0) global_add(g, 0, gs, rows_in_group, kAccSumI64);
+    for (int j = 0; j < a.nsums; ++j) {
+      const unsigned long long *cj = a.coef + static_cast<size_t>(j) * (1 + a.ncar) * cells;
+      if (a.sum_kind[j] == kAccSumI64) {
+        long long acc = 0;
+        if (a.sum_car_int[j] >= 0) {
+          const unsigned long long *plane = l_plane + static_cast<size_t>(a.sum_car_int[j]) * S * cells + static_cast<size_t>(s) * cells;
+          for (int c = lane; c < cells; c += kWave) acc += static_cast<long long>(plane[c]);
+        } else if (a.sum_hist[j] >= 0) {
+          const int h = a.sum_hist[j];
+          const unsigned int *hist = l_hist + s * a.hist_words + a.hist_off[h];
+          for (int c = lane; c < a.hist_size[h]; c += kWave) acc += static_cast<long long>(a.hcoef[j * kFacMaxDict + c]) * static_cast<long long>(hist[c]);
+        } else {
+          for (int c = lane; c < cells; c += kWave) acc += static_cast<long long>(cj[c]) * static_cast<long long>(cnt[c]);
+        }
+        const unsigned long long total = wave_reduce_add(static_cast<unsigned long long>(acc));
+        if (lane == 0) global_add(g, j + 1, gs, total, kAccSumI64);
+      } else {
+        double acc = 0.0;
+        if (a.sum_hist[j] >= 0) {
+          const int h = a.sum_hist[j];
+          const unsigned int *hist = l_hist + s * a.hist_words + a.hist_off[h];
+          for (int c = lane; c < a.hist_size[h]; c += kWave) {
+            acc += __longlong_as_double(static_cast<long long>(a.hcoef[j * kFacMaxDict + c])) * static_cast<double>(hist[c]);
+          }
+        } else {
+          for (int c = lane; c < cells; c += kWave) {
+            if (cnt[c] == 0u) continue;
+            double term = __longlong_as_double(static_cast<long long>(cj[c])) * static_cast<double>(cnt[c]);
+            for (int k = 0; k < a.ncar; ++k) {
+              if (a.car_int[k] != 0) continue;
+              const unsigned long long *plane = l_plane + static_cast<size_t>(k) * S * cells + static_cast<size_t>(s) * cells;
+              term += __longlong_as_double(static_cast<long long>(cj[static_cast<size_t>(k + 1) * cells + c])) * __longlong_as_double(static_cast<long long>(plane[c]));
+            }
+            acc += term;
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+        if (lane == 0) global_add(g, j + 1, gs, static_cast<unsigned long long>(__double_as_longlong(acc)), kAccSumF64);
+      }
+    }
+  }
+}
+
+// One row that found no slot in the workgroup's table: its terms go straight to the state's table (a group the optimizer's
+// estimate did not foresee; slow and exact).  hist_code[h]: the row's code of histogram column h.
+__device__ __forceinline__ void factored_spill_row(const FactoredArgs &a, const HashTableView &g, unsigned long long code, int cell,
+                                                   const int (&hist_code)[kFacMaxHist], unsigned long long car0, unsigned long long car1) {
+  const int cells = a.cells;
+  const unsigned long long gs = global_find_or_insert(g, code);
+  if (gs == ~0ull) return;
+  global_add(g, 0, gs, 1ull, kAccSumI64);
+  for (int j = 0; j < a.nsums; ++j) {
+    const unsigned long long *cj = a.coef + static_cast<size_t>(j) * (1 + a.ncar) * cells;
+    const int h = a.sum_hist[j];
+    int hc = 0;
+    if (h >= 0) {
+      hc = h == 0 ? hist_code[0] : (h == 1 ? hist_code[1] : (h == 2 ? hist_code[2] : hist_code[3]));
+      hc = hc < a.hist_size[h] ? hc : a.hist_size[h] - 1;
+    }
+    if (a.sum_kind[j] == kAccSumI64) {
+      long long inc = 0;
+      if (a.sum_car_int[j] >= 0) inc = static_cast<long long>(a.sum_car_int[j] == 0 ? car0 : car1);
+      else if (h >= 0) inc = static_cast<long long>(a.hcoef[j * kFacMaxDict + hc]);
+      else inc = static_cast<long long>(cj[cell]);
+      global_add(g, j + 1, gs, static_cast<unsigned long long>(inc), kAccSumI64);
+    } else {
+      double inc = 0.0;
+      if (h >= 0) {
+        inc = __longlong_as_double(static_cast<long long>(a.hcoef[j * kFacMaxDict + hc]));
+      } else {
+        inc = __longlong_as_double(static_cast<long long>(cj[cell]));
+        if (a.ncar > 0 && a.car_int[0] == 0) {
+          inc += __longlong_as_double(static_cast<long long>(cj[static_cast<size_t>(1) * cells + cell])) * __longlong_as_double(static_cast<long long>(car0));
+        }
+        if (a.ncar > 1 && a.car_int[1] == 0) {
+          inc += __longlong_as_double(static_cast<long long>(cj[static_cast<size_t>(2) * cells + cell])) * __longlong_as_double(static_cast<long long>(car1));
+        }
+      }
+      global_add(g, j + 1, gs, static_cast<unsigned long long>(__double_as_longlong(inc)), kAccSumF64);
+    }
+  }
+}
+
+// The group's slot in the workgroup's table (bounded linear probing); -1: the sentinel code, or the table is full.
+__device__ __forceinline__ int factored_group_slot(unsigned long long *l_keys, int S, unsigned long long code) {
+  if (code == kEmptyCode) return -1;
+  // (the table is private to the workgroup: any hash will do, so a cheap one — one 32-bit multiply)
+  int s = static_cast<int>(((static_cast<uint32_t>(code) ^ static_cast<uint32_t>(code >> 32)) * 0x9E3779B9u) >> 16) & (S - 1);
+  for (int probes = 0; probes < S; ++probes) {
+    unsigned long long k = l_keys[s];
+    if (k == kEmptyCode) k = atomicCAS(&l_keys[s], kEmptyCode, code);
+    if (k == kEmptyCode || k == code) return s;
+    s = (s + 1) & (S - 1);
+  }
+  return -1;
+}
+
+template <bool kFilter>
+__global__ __launch_bounds__(kABlock) void agg_factored_kernel(FactoredArgs a, int64_t n, const uint64_t *__restrict__ filter, HashTableView g) {
+  extern __shared__ __align__(16) char lds[];
+  const int S = a.S, cells = a.cells;
+  unsigned long long *l_keys = reinterpret_cast<unsigned long long *>(lds);
+  unsigned long long *l_plane = l_keys + S;                                          // [ncar][S * cells]
+  unsigned int *l_cnt = reinterpret_cast<unsigned int *>(l_plane + static_cast<size_t>(a.ncar) * S * cells);   // [S * cells]
+  unsigned int *l_hist = l_cnt + static_cast<size_t>(S) * cells;                     // [S * hist_words]
+  const size_t table_bytes = (static_cast<size_t>(S) * 8 + static_cast<size_t>(a.ncar) * S * cells * 8 + static_cast<size_t>(S) * cells * 4 +
+                              static_cast<size_t>(S) * a.hist_words * 4 + 15) & ~static_cast<size_t>(15);
+  char *tile = lds + table_bytes;
+  for (int i = threadIdx.x; i < S; i += kABlock) l_keys[i] = kEmptyCode;
+  for (int i = threadIdx.x; i < a.ncar * S * cells; i += kABlock) l_plane[i] = 0;
+  for (int i = threadIdx.x; i < S * cells + S * a.hist_words; i += kABlock) l_cnt[i] = 0;   // (counts and histograms are contiguous)
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int64_t num_tiles = (n + kFacTileRows - 1) / kFacTileRows;
+  // The plan's descriptors, read ONCE: indexed from the kernel argument inside the row loop they are chains of dependent
+  // scalar loads per row (the first version of this kernel: 6.6 ms per 600 M rows of Q1 against 1.5 for the hand-written
+  // prototype).  Fixed-size locals under unrolled loops stay in scalar registers (or their spill lanes).
+  int k_off[QSX_MAX_KEYS], k_w[QSX_MAX_KEYS], k_sh[QSX_MAX_KEYS];
+#pragma unroll
+  for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+    const int q = k < a.nkeys ? a.key_slot[k] : 0;
+    k_off[k] = a.off[q];
+    k_w[k] = a.width[q];
+    k_sh[k] = a.key_shift[k];
+  }
+  int c_off[kFacMaxCell], c_w[kFacMaxCell], c_stride[kFacMaxCell], c_radix[kFacMaxCell];
+#pragma unroll
+  for (int q = 0; q < kFacMaxCell; ++q) {
+    const int sl = q < a.ncell ? a.cell_slot[q] : 0;
+    c_off[q] = a.off[sl];
+    c_w[q] = a.width[sl];
+    c_stride[q] = a.cell_stride[q];
+    c_radix[q] = a.cell_radix[q];
+  }
+  int h_off[kFacMaxHist], h_w[kFacMaxHist], h_at[kFacMaxHist], h_size[kFacMaxHist];
+#pragma unroll
+  for (int h = 0; h < kFacMaxHist; ++h) {
+    const int sl = h < a.nhist ? a.hist_slot[h] : 0;
+    h_off[h] = a.off[sl];
+    h_w[h] = a.width[sl];
+    h_at[h] = a.hist_off[h];
+    h_size[h] = a.hist_size[h];
+  }
+  int r_off[kFacMaxCarriers], r_w[kFacMaxCarriers], r_type[kFacMaxCarriers], r_int[kFacMaxCarriers];
+#pragma unroll
+  for (int k = 0; k < kFacMaxCarriers; ++k) {
+    const int sl = k < a.ncar ? a.car_slot[k] : 0;
+    r_off[k] = a.off[sl];
+    r_w[k] = a.width[sl];
+    r_type[k] = a.car_type[k];
+    r_int[k] = a.car_int[k];
+  }
+  const int nkeys = a.nkeys, ncell = a.ncell, nhist = a.nhist, ncar = a.ncar, hist_words = a.hist_words, filter_off = a.filter_off;
+  for (int64_t t = blockIdx.x; t < num_tiles; t += gridDim.x) {
+    __syncthreads();   // the previous tile has been read (first pass: the tables are initialised)
+    const int64_t row0 = t * kFacTileRows;
+    const int rows = static_cast<int>(n - row0 < kFacTileRows ? n - row0 : kFacTileRows);
+    for (int q = 0; q < a.nstaged; ++q) {
+      const int w = a.width[q];
+      const char *src = static_cast<const char *>(a.col[q]) + row0 * w;
+      char *dst = tile + a.off[q];
+      const int bytes = rows * w;
+      if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int full = bytes & ~15;
+        const int chunks = (full + 1023) >> 10;
+        for (int k = wave; k < chunks; k += kABlock / kWave) {
+          const int o = (k << 10) + (lane << 4);
+          if (o < full) dma16(src + o, dst + (k << 10));
+        }
+        if (full != bytes) copy_elements_to_lds<kABlock>(src + full, dst + full, (bytes - full) / w, w);
+      } else {
+        copy_elements_to_lds<kABlock>(src, dst, rows, w);
+      }
+    }
+    if (kFilter) copy_elements_to_lds<kABlock>(reinterpret_cast<const char *>(filter + (row0 >> 6)), tile + filter_off, (rows + 63) >> 6, 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // column by column over the thread's V rows: the reads of a column are independent and in flight together
+    bool live[kFacV];
+    unsigned long long code[kFacV];
+    int cell[kFacV], slot[kFacV];
+#pragma unroll
+    for (int v = 0; v < kFacV; ++v) {
+      const int row = v * kABlock + threadIdx.x;
+      live[v] = row < rows;
+      if (kFilter && live[v]) live[v] = msb_bit(reinterpret_cast<const uint64_t *>(tile + filter_off)[row >> 6], row & 63);
+      code[v] = 0;
+      cell[v] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < QSX_MAX_KEYS; ++k) {
+      if (k >= nkeys) break;
+#pragma unroll
+      for (int v = 0; v < kFacV; ++v) code[v] |= factored_read(tile, k_off[k], k_w[k], live[v] ? v * kABlock + threadIdx.x : 0) << k_sh[k];
+    }
+#pragma unroll
+    for (int q = 0; q < kFacMaxCell; ++q) {
+      if (q >= ncell) break;
+#pragma unroll
+      for (int v = 0; v < kFacV; ++v) {
+        int cc = static_cast<int>(factored_read(tile, c_off[q], c_w[q], live[v] ? v * kABlock + threadIdx.x : 0));
+        cc = cc < c_radix[q] ? cc : c_radix[q] - 1;   // (a code beyond the dictionary is outside the contract: stay inside the table)
+        cell[v] += cc * c_stride[q];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < kFacV; ++v) slot[v] = live[v] ? factored_group_slot(l_keys, S, code[v]) : -1;
+    unsigned long long car[kFacMaxCarriers][kFacV];
+#pragma unroll
+    for (int k = 0; k < kFacMaxCarriers; ++k) {
+#pragma unroll
+      for (int v = 0; v < kFacV; ++v) car[k][v] = 0;
+      if (k >= ncar) continue;
+#pragma unroll
+      for (int v = 0; v < kFacV; ++v) {
+        car[k][v] = factored_carrier_word(factored_read(tile, r_off[k], r_w[k], live[v] ? v * kABlock + threadIdx.x : 0), r_type[k], r_int[k] != 0);
+      }
+    }
+    bool any_overflow = false;
+#pragma unroll
+    for (int v = 0; v < kFacV; ++v) {
+      if (!live[v]) continue;
+      if (slot[v] < 0) {
+        any_overflow = true;
+        continue;
+      }
+      const int at = slot[v] * cells + cell[v];
+      atomicAdd(&l_cnt[at], 1u);
+#pragma unroll
+      for (int k = 0; k < kFacMaxCarriers; ++k) {
+        if (k >= ncar) break;
+        unsigned long long *p = l_plane + static_cast<size_t>(k) * S * cells + at;
+        if (r_int[k] != 0) atomicAdd(p, car[k][v]);
+        else unsafeAtomicAdd(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(car[k][v])));
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < kFacMaxHist; ++h) {
+      if (h >= nhist) break;
+#pragma unroll
+      for (int v = 0; v < kFacV; ++v) {
+        int hc = static_cast<int>(factored_read(tile, h_off[h], h_w[h], live[v] ? v * kABlock + threadIdx.x : 0));
+        hc = hc < h_size[h] ? hc : h_size[h] - 1;
+        if (live[v] && slot[v] >= 0) atomicAdd(&l_hist[slot[v] * hist_words + h_at[h] + hc], 1u);
+      }
+    }
+    if (__any(any_overflow)) {
+      // more groups than the table holds (the optimizer's estimate was far off): those rows' terms go straight to the state
+      // (unrolled: live / slot / code / cell / car indexed by a loop variable would live in scratch)
+#pragma unroll
+      for (int v = 0; v < kFacV; ++v) {
+        if (!live[v] || slot[v] >= 0) continue;
+        const int row = v * kABlock + threadIdx.x;
+        int hist_code[kFacMaxHist] = {};
+#pragma unroll
+        for (int h = 0; h < kFacMaxHist; ++h) {
+          if (h < nhist) hist_code[h] = static_cast<int>(factored_read(tile, h_off[h], h_w[h], row));
+        }
+        factored_spill_row(a, g, code[v], cell[v], hist_code, car[0][v], car[1][v]);
+      }
+    }
+  }
+  __syncthreads();
+  factored_flush(a, l_keys, l_plane, l_cnt, l_hist, g);
+}
+
+// ---- the common signatures without LDS staging ------------------------------------------------------------------------
+// Rows reach the lanes by direct loads — a thread owns 8 consecutive rows: 8 bytes of every 1-byte column (the codes of a
+// dictionary of <= 64 entries ARE one byte), 32 bytes of an INT key, 64 bytes of a DOUBLE carrier — with the next tile
+// requested before the current one is consumed, no barrier and no wait for a DMA in the tile loop: what the prototype
+// (tools/ubench/q1_factored.hip) measured at 1.48 ms per 600 M rows of Q1 against 4.5 ms for the staged kernel above, whose
+// waves sit out every tile's copy.  Instantiated for the signatures that cover star-schema aggregations over dictionary
+// columns: one or two keys of one width (CHAR(1) or INT), one or two cell columns, at most one histogram column, at most
+// one DOUBLE carrier; everything else keeps the other kernels.
+template <int KEYW, int NK, int NC, int NH, bool kCar>
+struct FactoredDirectTile {
+  unsigned long long key8[KEYW == 1 ? NK : 1];   // 1-byte keys: 8 rows in 8 bytes
+  uint4 key32[KEYW == 4 ? NK : 1][2];            // 4-byte keys: 8 rows in 32 bytes
+  unsigned long long cell[NC];
+  unsigned long long hist[NH > 0 ? NH : 1];
+  uint4 car[kCar ? 4 : 1];
+  unsigned int live;                         // bit r: row r of the thread is inside the stripe and selected by the filter
+};
+template <bool kFilter, int KEYW, int NK, int NC, int NH, bool kCar>
+__global__ __launch_bounds__(kABlock) void agg_factored_direct_kernel(const FactoredArgs *__restrict__ a_dev, FactoredDirectArgs d, int64_t n,
+                                                                     const uint64_t *__restrict__ filter, HashTableView g) {
+  static_assert((KEYW == 1 || KEYW == 4) && NK >= 1 && NK <= 2 && NC >= 1 && NC <= 2 && NH >= 0 && NH <= 1, "instantiated signatures");
+  extern __shared__ __align__(16) char lds[];
+  const int S = d.S, cells = d.cells;
+  unsigned long long *l_keys = reinterpret_cast<unsigned long long *>(lds);
+  unsigned long long *l_plane = l_keys + S;                                        // [kCar][S * cells]
+  unsigned int *l_cnt = reinterpret_cast<unsigned int *>(l_plane + (kCar ? static_cast<size_t>(S) * cells : 0));
+  unsigned int *l_hist = l_cnt + static_cast<size_t>(S) * cells;
+  for (int i = threadIdx.x; i < S; i += kABlock) l_keys[i] = kEmptyCode;
+  if (kCar) for (int i = threadIdx.x; i < S * cells; i += kABlock) l_plane[i] = 0;
+  for (int i = threadIdx.x; i < S * cells + S * d.hist_words; i += kABlock) l_cnt[i] = 0;
+  __syncthreads();
+  using Tile = FactoredDirectTile<KEYW, NK, NC, NH, kCar>;
+  const int64_t full_tiles = n / kFacDirectTile;          // the tail (< one tile) goes row by row below
+  auto request = [&](int64_t tile, Tile &x) {
+    const int64_t row = tile * kFacDirectTile + static_cast<int64_t>(threadIdx.x) * kFacDirectRows;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      if constexpr (KEYW == 1) {
+        x.key8[k] = load_global_nt(reinterpret_cast<const unsigned long long *>(static_cast<const unsigned char *>(d.key[k]) + row));
+      } else {
+        x.key32[k][0] = stream_load16(static_cast<const uint32_t *>(d.key[k]) + row);
+        x.key32[k][1] = stream_load16(static_cast<const uint32_t *>(d.key[k]) + row + 4);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) x.cell[q] = load_global_nt(reinterpret_cast<const unsigned long long *>(d.cellc[q] + row));
+    if constexpr (NH > 0) x.hist[0] = load_global_nt(reinterpret_cast<const unsigned long long *>(d.histc + row));
+    if constexpr (kCar) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x.car[j] = stream_load16(d.carrier + row + 2 * j);
+    }
+    x.live = 0xFFu;
+    if (kFilter) {   // rows row .. row + 7 sit in one word (row is a multiple of 8): bit 63 - (row & 63) is the first of them
+      const uint64_t w = load_global(&filter[row >> 6]);
+      x.live = __brev(static_cast<unsigned int>((w >> (56 - (row & 63))) & 0xFFu)) >> 24;   // MSB-first -> bit r = row + r
+    }
+  };
+  auto byte_of = [](unsigned long long v, int r) -> unsigned int { return static_cast<unsigned int>(v >> (r * 8)) & 0xFFu; };
+  unsigned long long last_code = kEmptyCode;   // the previous row's group: with a handful of groups every other row repeats it
+  int last_slot = -1;
+  auto consume = [&](const Tile &x, int64_t tile) {
+#pragma unroll
+    for (int r = 0; r < kFacDirectRows; ++r) {
+      if (((x.live >> r) & 1u) == 0u) continue;
+      unsigned long long code = 0;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        unsigned long long kv;
+        if constexpr (KEYW == 1) {
+          kv = byte_of(x.key8[k], r);
+        } else {
+          const uint4 &w = x.key32[k][r >> 2];
+          kv = (r & 3) == 0 ? w.x : ((r & 3) == 1 ? w.y : ((r & 3) == 2 ? w.z : w.w));
+        }
+        code |= kv << d.key_shift[k];
+      }
+      int cell = 0;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        int cc = static_cast<int>(byte_of(x.cell[q], r));
+        cc = cc < d.cell_radix[q] ? cc : d.cell_radix[q] - 1;
+        cell += cc * d.cell_stride[q];
+      }
+      int hc = 0;
+      if constexpr (NH > 0) {
+        hc = static_cast<int>(byte_of(x.hist[0], r));
+        hc = hc < d.hist_size ? hc : d.hist_size - 1;
+      }
+      unsigned long long carw = 0;
+      if constexpr (kCar) {
+        const uint4 &pw = x.car[r >> 1];
+        carw = (static_cast<unsigned long long>((r & 1) ? pw.w : pw.y) << 32) | ((r & 1) ? pw.z : pw.x);
+      }
+      if (code != last_code) {
+        last_slot = factored_group_slot(l_keys, S, code);
+        last_code = code;
+      }
+      const int slot = last_slot;
+      if (slot >= 0) {
+        const int at = slot * cells + cell;
+        atomicAdd(&l_cnt[at], 1u);
+        if constexpr (kCar) unsafeAtomicAdd(reinterpret_cast<double *>(l_plane) + at, __longlong_as_double(static_cast<long long>(carw)));
+        if constexpr (NH > 0) atomicAdd(&l_hist[slot * d.hist_words + hc], 1u);
+      } else {
+        const int hist_code[kFacMaxHist] = {hc, 0, 0, 0};
+        factored_spill_row(*a_dev, g, code, cell, hist_code, carw, 0ull);
+      }
+    }
+    (void)tile;
+  };
+  Tile cur, nxt;
+  int64_t tile = blockIdx.x;
+  if (tile < full_tiles) request(tile, cur);
+  for (; tile < full_tiles; tile += gridDim.x) {
+    if (tile + gridDim.x < full_tiles) request(tile + gridDim.x, nxt);
+    consume(cur, tile);
+    cur = nxt;
+  }
+  // the tail of the stripe: fewer than kFacDirectTile rows, one per thread and step, by the workgroup that would own that tile
+  if (static_cast<int64_t>(blockIdx.x) == full_tiles % gridDim.x) {
+    for (int64_t row = full_tiles * kFacDirectTile + threadIdx.x; row < n; row += kABlock) {
+      if (kFilter && !msb_bit(load_global(&filter[row >> 6]), static_cast<int>(row & 63))) continue;
+      unsigned long long code = 0;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const unsigned long long kv = KEYW == 1 ? static_cast<unsigned long long>(load_global(static_cast<const unsigned char *>(d.key[k]) + row))
+                                                : static_cast<unsigned long long>(load_global(static_cast<const uint32_t *>(d.key[k]) + row));
+        code |= kv << d.key_shift[k];
+      }
+      int cell = 0;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        int cc = load_global(d.cellc[q] + row);
+        cc = cc < d.cell_radix[q] ? cc : d.cell_radix[q] - 1;
+        cell += cc * d.cell_stride[q];
+      }
+      int hc = 0;
+      if constexpr (NH > 0) {
+        hc = load_global(d.histc + row);
+        hc = hc < d.hist_size ? hc : d.hist_size - 1;
+      }
+      unsigned long long carw = 0;
+      if constexpr (kCar) carw = static_cast<unsigned long long>(__double_as_longlong(load_global(d.carrier + row)));
+      const int slot = factored_group_slot(l_keys, S, code);
+      if (slot >= 0) {
+        const int at = slot * cells + cell;
+        atomicAdd(&l_cnt[at], 1u);
+        if constexpr (kCar) unsafeAtomicAdd(reinterpret_cast<double *>(l_plane) + at, __longlong_as_double(static_cast<long long>(carw)));
+        if constexpr (NH > 0) atomicAdd(&l_hist[slot * d.hist_words + hc], 1u);
+      } else {
+        const int hist_code[kFacMaxHist] = {hc, 0, 0, 0};
+        factored_spill_row(*a_dev, g, code, cell, hist_code, carw, 0ull);
+      }
+    }
+  }
+  __syncthreads();
+  factored_flush(*a_dev, l_keys, l_plane, l_cnt, l_hist, g);
+}
+
+}  // namespace qsx
+
+#endif  // QSX_CSRC_AGG_FACTORED_KERNELS_HPP_

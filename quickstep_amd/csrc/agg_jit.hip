@@ -1,6 +1,8 @@
 // agg_jit.hip — see agg_jit.hpp.
 #include "agg_jit.hpp"
 
+#include <dlfcn.h>
+
 #include <hip/hiprtc.h>
 
 #include <cstdio>
@@ -266,22 +268,48 @@ std::string cache_stamp() {
   return (driver.empty() ? std::string("hiprtc ") : "driver " + driver + " hip ") + std::to_string(major) + "." + std::to_string(minor) +
          " gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics\n";
 }
-std::string cache_path(const std::string &stamped_source) {
-  const char *dir = getenv("QSX_JIT_CACHE_DIR");
-  if (dir == nullptr || dir[0] == '\0') return std::string();
+std::string cache_file_name(const std::string &text) {
   unsigned long long h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;   // two FNV-1a walks with different offsets
-  for (unsigned char c : stamped_source) {
+  for (unsigned char c : text) {
     h1 = (h1 ^ c) * 0x100000001b3ull;
     h2 = (h2 ^ (c + 0x9Eu)) * 0x100000001b3ull;
   }
   char name[64];
-  std::snprintf(name, sizeof(name), "/qsx_%016llx%016llx.hsaco", h1, h2);
-  return std::string(dir) + name;
+  std::snprintf(name, sizeof(name), "/qsx_%016llx%016llx", h1, h2);
+  return name;
 }
+// The directory code objects are WRITTEN to: QSX_JIT_CACHE_DIR, or none.
+std::string cache_path(const std::string &stamped_source) {
+  const char *dir = getenv("QSX_JIT_CACHE_DIR");
+  if (dir == nullptr || dir[0] == '\0') return std::string();
+  return std::string(dir) + cache_file_name(stamped_source) + ".hsaco";
+}
+// The code objects that ship with the library: <directory of libqsx.so>/jit_cache, filled by the build for the plan shapes
+// listed under csrc/jit_shapes/ (__graft_entry__.build -> qsx_jit_warm).  Read-only, looked at after QSX_JIT_CACHE_DIR: an
+// installation starts with the shapes its tests and benchmarks use already compiled, and nothing is ever written next to the
+// library at run time.  QSX_JIT_SHIPPED_CACHE=0 ignores it (tests of the compile path).
+std::string shipped_cache_dir() {
+  const char *e = getenv("QSX_JIT_SHIPPED_CACHE");   // (read per call: tests switch it)
+  if (e != nullptr && e[0] == '0') return std::string();
+  static const std::string dir = []() {
+    Dl_info info{};
+    if (dladdr(reinterpret_cast<const void *>(&shipped_cache_dir), &info) == 0 || info.dli_fname == nullptr) return std::string();
+    std::string path(info.dli_fname);
+    const size_t slash = path.rfind('/');
+    if (slash == std::string::npos) return std::string();
+    return path.substr(0, slash) + "/jit_cache";
+  }();
+  return !dir.empty() && access(dir.c_str(), R_OK | X_OK) == 0 ? dir : std::string();
+}
+bool read_cache_file(const std::string &path, const std::string &stamped, std::string *code);
 bool load_cached_code(const std::string &source, std::string *code) {
   const std::string stamped = cache_stamp() + source;
-  const std::string path = cache_path(stamped);
-  if (path.empty()) return false;
+  const std::string own = cache_path(stamped);
+  if (!own.empty() && read_cache_file(own, stamped, code)) return true;
+  const std::string shipped = shipped_cache_dir();
+  return !shipped.empty() && read_cache_file(shipped + cache_file_name(stamped) + ".hsaco", stamped, code);
+}
+bool read_cache_file(const std::string &path, const std::string &stamped, std::string *code) {
   FILE *f = std::fopen(path.c_str(), "rb");
   if (f == nullptr) return false;
   bool ok = false;
@@ -297,10 +325,14 @@ bool load_cached_code(const std::string &source, std::string *code) {
   std::fclose(f);
   return ok;
 }
+void write_cache_file(const std::string &path, const std::string &stamped, const std::string &code);
 void store_cached_code(const std::string &source, const std::string &code) {
   const std::string stamped = cache_stamp() + source;
   const std::string path = cache_path(stamped);
   if (path.empty()) return;
+  write_cache_file(path, stamped, code);
+}
+void write_cache_file(const std::string &path, const std::string &stamped, const std::string &code) {
   char suffix[48];
   std::snprintf(suffix, sizeof(suffix), ".tmp.%ld.%llx", static_cast<long>(getpid()),
                 static_cast<unsigned long long>(std::hash<std::thread::id>()(std::this_thread::get_id())));
@@ -395,7 +427,28 @@ bool compile_with_driver(const std::string &source, std::string *code, std::stri
   return ok;
 }
 
+// QSX_JIT_RECORD_DIR: every plan shape this process asks for leaves its text there — the part behind the bundled kernel
+// sources: the translated configuration and the entry point, a few KiB — as qsx_<hash>.shape.  That is how csrc/jit_shapes/
+// is made (tools/record_jit_shapes.sh runs the GPU suite and the benchmarks with it): the build compiles what it lists.
+size_t bundle_prefix_length() { return std::strlen(kPrelude) + std::strlen(kBundle); }
+void record_shape(const std::string &source) {
+  const char *dir = getenv("QSX_JIT_RECORD_DIR");
+  if (dir == nullptr || dir[0] == '\0' || source.size() <= bundle_prefix_length()) return;
+  const std::string tail = source.substr(bundle_prefix_length());
+  const std::string path = std::string(dir) + cache_file_name(tail) + ".shape";
+  if (access(path.c_str(), F_OK) == 0) return;
+  char suffix[48];
+  std::snprintf(suffix, sizeof(suffix), ".tmp.%ld.%llx", static_cast<long>(getpid()),
+                static_cast<unsigned long long>(std::hash<std::thread::id>()(std::this_thread::get_id())));
+  const std::string tmp = path + suffix;
+  FILE *f = std::fopen(tmp.c_str(), "wb");
+  if (f == nullptr) return;
+  const bool ok = std::fwrite(tail.data(), 1, tail.size(), f) == tail.size();
+  if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+
 bool compile_to_code(const std::string &source, std::string *code, std::string *log) {
+  record_shape(source);
   if (load_cached_code(source, code)) return true;
   if (compile_with_driver(source, code, log)) {
     store_cached_code(source, *code);
@@ -520,6 +573,7 @@ JitRequest *jit_agg_request(const DevConfig &dev, int num_sums, bool dense, cons
       cache().emplace(key, r);
       mine = true;
       std::string cached;
+      if (!synchronous) record_shape(source);
       if (!synchronous && load_cached_code(source, &cached)) {
         // on disk (QSX_JIT_CACHE_DIR): a file read and a module load, milliseconds — ready before the first launch
         JitKernel *k = settle(load_code(cached), relaxed);
@@ -615,6 +669,26 @@ int jit_agg_launch_dir(const JitKernel *k, int grid, size_t lds_bytes, hipStream
 }
 
 }  // namespace qsx
+
+// Build step (not part of include/qsx.h; called by __graft_entry__.build for every file of csrc/jit_shapes/): compile the plan
+// shape whose recorded text is `tail` with the compiler driver and keep the code object in out_dir under the name the
+// run-time lookup computes (shipped_cache_dir).  1: already there, 0: compiled, < 0: a status.  Needs no GPU.
+extern "C" int qsx_jit_warm(const char *tail, size_t tail_bytes, const char *out_dir) {
+  using namespace qsx;
+  if (tail == nullptr || out_dir == nullptr || tail_bytes == 0) return QSX_ERR_INVALID_ARGUMENT;
+  const std::string source = std::string(kPrelude) + kBundle + std::string(tail, tail_bytes);
+  const std::string stamped = cache_stamp() + source;
+  const std::string path = std::string(out_dir) + cache_file_name(stamped) + ".hsaco";
+  std::string code, log;
+  if (read_cache_file(path, stamped, &code)) return 1;
+  if (compiler_driver().empty()) return QSX_ERR_UNSUPPORTED;     // (a hipRTC build would carry another stamp: nothing to ship)
+  if (!compile_with_driver(source, &code, &log)) {
+    std::fprintf(stderr, "qsx_jit_warm: %.2000s\n", log.c_str());
+    return QSX_ERR_HIP;
+  }
+  write_cache_file(path, stamped, code);
+  return 0;
+}
 
 // Test hook (not part of include/qsx.h): compiles the plan shape of a configuration with hipRTC and
 // reports whether that worked — runs without a GPU, so the CPU test suite covers the generator.

@@ -33,6 +33,7 @@
 #include "agg_common.hpp"
 #include "agg_translate.hpp"
 #include "agg_hash_update.hpp"
+#include "agg_factored.hpp"
 #include "agg_shapes.hpp"
 #include "agg_jit.hpp"
 #include "comm.hpp"
@@ -588,6 +589,7 @@ constexpr size_t kDirControlBytes = 16 + sizeof(unsigned long long) * 2 * QSX_MA
 struct qsx_agg_state {
   qsx_agg_config_t config;
   bool has_coded_columns = false;   // some column arrives as codes of a compressed attribute
+  FactoredStatic factored;          // the plan seen through its dictionary columns (agg_factored.hpp); ok = it factors
   bool has_date_key = false;        // a group-by key is a DATE: its padding bytes are masked when the key is packed
   // run-time plan shapes asked for, owned by the cache: index = (filter ? 1 : 0) + (partitioned input ? 2 : 0)
   JitRequest *jit_request[kJitVariants] = {};
@@ -771,6 +773,7 @@ static int translate_config(const qsx_agg_config_t &c, qsx_agg_state *st) {
   for (int k = 0; k < t.dev.num_keys; ++k) st->has_date_key = st->has_date_key || t.dev.column_type[t.dev.key_column[k]] == QSX_DATE;
   st->dense = t.dense;
   st->dense_has_count = t.dense_has_count;
+  if (st->has_coded_columns) st->factored = factored_analyse(t.dev, t.dense);
   return QSX_OK;
 }
 
@@ -2066,6 +2069,169 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
   return QSX_OK;
 }
 
+// ---- aggregates factored through the dictionary codes (agg_factored.hpp) ------------------------------------------------
+static std::atomic<long long> g_factored_launches{0};
+// Test hook (not part of include/qsx.h): update calls this process has issued through the factored kernels.
+extern "C" long long qsx_debug_agg_factored_launches(void) { return g_factored_launches.load(std::memory_order_relaxed); }
+static bool factored_enabled() {
+  const char *e = getenv("QSX_AGG_FACTORED");
+  return e == nullptr || e[0] != '0';
+}
+static long long factored_min_rows() {
+  const char *e = getenv("QSX_AGG_FACTORED_MIN_ROWS");
+  return e != nullptr ? atoll(e) : 256ll * 1024;
+}
+// QSX_OK = the call was issued through the factored kernels; QSX_ERR_UNSUPPORTED = not this call (dictionary sizes unknown or
+// too large, the cells do not fit LDS): the caller goes on with the decoding kernels; anything else is an error.
+static int update_factored(qsx_agg_state *st, const void *const *cols, const void *const *dicts, const int32_t *entries, int64_t n,
+                           const uint64_t *filter_dev, hipStream_t s) {
+  const FactoredStatic &f = st->factored;
+  if (!f.ok || !factored_enabled() || dicts == nullptr || entries == nullptr || n < factored_min_rows()) return QSX_ERR_UNSUPPORTED;
+  const DevConfig &d = st->dev;
+  const int S = st->lds_slots;
+  if (S < 1 || S > 64 || (S & (S - 1)) != 0 || st->lds_ranges != 1) return QSX_ERR_UNSUPPORTED;
+  FactoredArgs a{};
+  FactoredCoefArgs ca{};
+  size_t tile = 0;
+  auto stage = [&](int col) {
+    const int q = a.nstaged++;
+    a.col[q] = cols[col];
+    a.width[q] = d.code_width[col] != 0 ? d.code_width[col] : d.column_width[col];
+    a.off[q] = static_cast<int>(tile);
+    tile += align16(static_cast<size_t>(kFacTileRows) * a.width[q]);
+    return q;
+  };
+  for (int col = 0; col < d.num_columns; ++col) {
+    if (((st->used_columns >> col) & 1u) != 0 && cols[col] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  }
+  a.nkeys = d.num_keys;
+  for (int k = 0; k < d.num_keys; ++k) {
+    a.key_slot[k] = stage(d.key_column[k]);
+    a.key_shift[k] = d.key_shift[k];
+  }
+  long long cells = 1;
+  a.ncell = ca.ncell = f.ncell;
+  for (int q = 0; q < f.ncell; ++q) {
+    const int col = f.cell_col[q], radix = entries[col];
+    if (dicts[col] == nullptr || radix < 1 || radix > kFacMaxDict) return QSX_ERR_UNSUPPORTED;
+    a.cell_slot[q] = stage(col);
+    a.cell_stride[q] = ca.cell_stride[q] = static_cast<int>(cells);
+    a.cell_radix[q] = ca.cell_radix[q] = radix;
+    ca.cell_col[q] = col;
+    cells *= radix;
+    if (cells > kFacMaxCells) return QSX_ERR_UNSUPPORTED;
+  }
+  a.cells = ca.cells = static_cast<int>(cells);
+  a.nhist = ca.nhist = f.nhist;
+  for (int h = 0; h < f.nhist; ++h) {
+    const int col = f.hist_col[h], size = entries[col];
+    if (dicts[col] == nullptr || size < 1 || size > kFacMaxDict) return QSX_ERR_UNSUPPORTED;
+    a.hist_slot[h] = stage(col);
+    a.hist_off[h] = a.hist_words;
+    a.hist_size[h] = ca.hist_size[h] = size;
+    ca.hist_col[h] = col;
+    a.hist_words += size;
+  }
+  a.ncar = ca.ncar = f.ncar;
+  for (int k = 0; k < f.ncar; ++k) {
+    a.car_slot[k] = stage(f.car_col[k]);
+    a.car_type[k] = d.column_type[f.car_col[k]];
+    a.car_int[k] = f.car_int[k];
+    ca.car_col[k] = f.car_col[k];
+  }
+  a.filter_off = static_cast<int>(tile);
+  if (filter_dev != nullptr) tile += align16(kFacTileRows / 64 * 8);
+  a.tile_bytes = static_cast<int>(tile);
+  a.S = S;
+  a.nsums = ca.nsums = d.num_sums;
+  for (int j = 0; j < d.num_sums; ++j) {
+    a.sum_kind[j] = d.sums[j].kind;
+    a.sum_hist[j] = ca.sum_hist[j] = f.sum_hist[j];
+    a.sum_car_int[j] = f.sum_car_int[j];
+  }
+  const size_t table_bytes = align16(static_cast<size_t>(S) * 8 + static_cast<size_t>(a.ncar) * S * cells * 8 + static_cast<size_t>(S) * cells * 4 +
+                                     static_cast<size_t>(S) * a.hist_words * 4);
+  const size_t lds_bytes = table_bytes + tile;
+  if (lds_bytes > 64 * 1024) return QSX_ERR_UNSUPPORTED;     // (at least two workgroups per CU, or the tile copies run under nothing)
+  // coefficients: this call's dictionaries through the state's expression program
+  CallScratch scratch(s);
+  const size_t coef_bytes = static_cast<size_t>(d.num_sums) * (1 + a.ncar) * cells * 8, hcoef_bytes = static_cast<size_t>(d.num_sums) * kFacMaxDict * 8;
+  int rc = scratch.reserve(CallScratch::padded(coef_bytes) + CallScratch::padded(hcoef_bytes));
+  if (rc != QSX_OK) return rc;
+  ca.coef = static_cast<unsigned long long *>(scratch.take(coef_bytes));
+  ca.hcoef = static_cast<unsigned long long *>(scratch.take(hcoef_bytes));
+  a.coef = ca.coef;
+  a.hcoef = ca.hcoef;
+  DevConfig dc = d;
+  for (int i = 0; i < d.num_columns; ++i) dc.dicts[i] = d.code_width[i] != 0 ? dicts[i] : nullptr;
+  rc = launch_factored_coef(dc, ca, s);
+  if (rc != QSX_OK) return rc;
+  const HashTableView g = st->hash_view();
+  // ---- the common signatures: rows by direct loads, no staging (agg_factored_direct_kernel) ----
+  {
+    bool direct = a.nkeys >= 1 && a.nkeys <= 2 && a.ncell >= 1 && a.ncell <= 2 && a.nhist <= 1 && a.ncar <= 1;
+    const int keyw = a.width[a.key_slot[0]];
+    direct = direct && (keyw == 1 || keyw == 4);
+    auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    for (int k = 0; k < a.nkeys && direct; ++k) direct = a.width[a.key_slot[k]] == keyw && aligned16(a.col[a.key_slot[k]]);
+    for (int q = 0; q < a.ncell && direct; ++q) direct = a.width[a.cell_slot[q]] == 1 && aligned16(a.col[a.cell_slot[q]]);
+    for (int h = 0; h < a.nhist && direct; ++h) direct = a.width[a.hist_slot[h]] == 1 && aligned16(a.col[a.hist_slot[h]]);
+    if (a.ncar == 1) direct = direct && a.car_type[0] == QSX_DOUBLE && a.car_int[0] == 0 && aligned16(a.col[a.car_slot[0]]);
+    const size_t direct_lds = table_bytes;
+    if (direct && direct_lds <= 60 * 1024) {
+      FactoredDirectArgs da{};
+      for (int k = 0; k < a.nkeys; ++k) {
+        da.key[k] = a.col[a.key_slot[k]];
+        da.key_shift[k] = a.key_shift[k];
+      }
+      for (int q = 0; q < a.ncell; ++q) {
+        da.cellc[q] = static_cast<const unsigned char *>(a.col[a.cell_slot[q]]);
+        da.cell_stride[q] = a.cell_stride[q];
+        da.cell_radix[q] = a.cell_radix[q];
+      }
+      if (a.nhist == 1) {
+        da.histc = static_cast<const unsigned char *>(a.col[a.hist_slot[0]]);
+        da.hist_size = a.hist_size[0];
+      }
+      if (a.ncar == 1) da.carrier = static_cast<const double *>(a.col[a.car_slot[0]]);
+      da.S = S;
+      da.cells = a.cells;
+      da.hist_words = a.hist_words;
+      // the flush and the spill path read the whole plan: behind a pointer (a kernarg segment beyond 512 bytes has cost this
+      // code base a factor before, DESIGN.md "Kernel arguments")
+      const FactoredArgs *a_dev = static_cast<const FactoredArgs *>(staged_device_buffer(s, sizeof(FactoredArgs)));
+      if (a_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+      rc = staged_upload(s, &a, sizeof(FactoredArgs));
+      if (rc != QSX_OK) return rc;
+      int per_cu = static_cast<int>((160 * 1024) / (direct_lds + 512));
+      per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);   // (measured on Q1: 3 / 4 / 5 / 6 workgroups per CU 1.78 / 1.73 / 1.79 / 1.86 ms per 600 M rows)
+      if (const char *e = getenv("QSX_AGG_FACTORED_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+      const int64_t tiles = (n + kFacDirectTile - 1) / kFacDirectTile;
+      const int grid = static_cast<int>(tiles < static_cast<int64_t>(per_cu) * kCUs ? tiles : static_cast<int64_t>(per_cu) * kCUs);
+      const bool launched = launch_factored_direct(a, a_dev, da, keyw, direct_lds, grid, n, filter_dev, g, s);
+      if (launched) {
+        QSX_CHECK_LAUNCH();
+        g_factored_launches.fetch_add(1, std::memory_order_relaxed);
+        return QSX_OK;
+      }
+    }
+  }
+  // ---- any other signature: the staged kernel.  Slower than the decoding plan shapes as it stands (4.5 against 2.1 ms per
+  // 600 M rows of Q1: its waves sit out every tile's copy and read their descriptors at run time), so it answers only when
+  // asked (QSX_AGG_FACTORED_GENERIC=1: the tests keep it exact for the day it is made fast). ----
+  {
+    const char *e = getenv("QSX_AGG_FACTORED_GENERIC");
+    if (e == nullptr || e[0] != '1') return QSX_ERR_UNSUPPORTED;
+  }
+  int per_cu = static_cast<int>((160 * 1024) / (lds_bytes + 512));
+  per_cu = per_cu > 8 ? 8 : per_cu;
+  if (const char *e = getenv("QSX_AGG_FACTORED_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+  rc = launch_factored_staged(a, lds_bytes, per_cu, n, filter_dev, g, s);
+  if (rc != QSX_OK) return rc;
+  g_factored_launches.fetch_add(1, std::memory_order_relaxed);
+  return QSX_OK;
+}
+
 static long long partition_min_rows() {
   const char *e = getenv("QSX_AGG_PARTITION_MIN_ROWS");
   return e != nullptr ? atoll(e) : 4ll * 1024 * 1024;
@@ -2172,6 +2338,13 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
   std::shared_lock<std::shared_mutex> lock(st->table_mutex);
   // (the partitioned path scatters value columns: states over compressed attributes take the tile path)
   const int bounds_slot = !st->dense && st->dir_gids != 0 ? st->dir_bounds_slot(s) : -1;
+  // a state over dictionary-coded attributes whose aggregates factor through the codes (agg_factored.hpp), and a call that
+  // brought the dictionaries' sizes (qsx_agg_update_coded_sized)
+  if (st->factored.ok && nulls == nullptr && bounds_slot < 0) {
+    rc = update_factored(st, cols, dicts, tl_dictionary_entries, n, filter_dev, s);
+    if (rc == QSX_OK) return publish_control(st, s);
+    if (rc != QSX_ERR_UNSUPPORTED) return rc;
+  }
   if (bounds_slot >= 0) {
     rc = update_directory(st, cols, dicts, n, filter_dev, nulls, nullptr, bounds_slot, s);
   } else

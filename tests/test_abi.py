@@ -151,6 +151,7 @@ def test_plan_shape_code_objects_are_kept_in_the_cache_directory(capi, tmp_path,
     layout = [(T.INT, None), (T.DOUBLE, None)]
     cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None)])
     monkeypatch.setenv("QSX_JIT_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("QSX_JIT_SHIPPED_CACHE", "0")               # (the code objects that ship with the library would answer first)
     size = C.c_size_t(0)
     t0 = time.perf_counter()
     assert fn(C.byref(cfg), 0, C.byref(size)) == 0
@@ -187,6 +188,7 @@ def test_plan_shapes_name_their_compiler_in_the_cache(capi, tmp_path, monkeypatc
     layout = [(T.INT, None), (T.DOUBLE, None)]
     cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0], aggs=[(T.AGG_MAX, T.col(1))])
     monkeypatch.setenv("QSX_JIT_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("QSX_JIT_SHIPPED_CACHE", "0")
     size = C.c_size_t(0)
     stamps = {}
     for compiler in ("hiprtc", None, str(tmp_path / "no_such_driver")):
@@ -265,3 +267,64 @@ def test_plan_shapes_over_code_stripes_use_no_scratch(capi, tmp_path, monkeypatc
                 shutil.copy(code, elf)
             notes = subprocess.run([readelf, "--notes", str(elf)], capture_output=True, text=True).stdout
             assert ".private_segment_fixed_size: 0" in notes, (compiler, bits, [ln for ln in notes.splitlines() if "private_segment" in ln])
+
+
+def test_recorded_plan_shapes_are_compiled_at_build_time_and_found_at_run_time(capi, tmp_path, monkeypatch):
+    """The shipped code objects (csrc/agg_jit.hip: QSX_JIT_RECORD_DIR -> csrc/jit_shapes/*.shape -> qsx_jit_warm at build time
+    -> <library directory>/jit_cache at run time): a process that asks for a plan shape leaves its text in the record
+    directory; qsx_jit_warm compiles that text into a directory under the name the run-time lookup computes (a second call
+    finds it there: 1); and the library directory's jit_cache answers a later request without a compile and without writing
+    anything.  No GPU involved: hipcc cross-compiles."""
+    import ctypes as C
+    import os
+    import shutil
+    import time
+    from quickstep_amd import types as T
+    fn = capi.lib.qsx_debug_jit_compile
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(T.AggConfig), C.c_int, C.POINTER(C.c_size_t)]
+    warm = capi.lib.qsx_jit_warm
+    warm.restype = C.c_int
+    warm.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+    if not os.access("/opt/rocm/bin/hipcc", os.X_OK):
+        pytest.skip("no compiler driver: nothing is shipped from a hipRTC-only installation")
+    layout = [(T.INT, None), (T.LONG, None), (T.DOUBLE, None)]
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0, 1], aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_MAX, T.col(2)), (T.AGG_COUNT_STAR, None)])
+    record, built = tmp_path / "record", tmp_path / "built"
+    record.mkdir()
+    built.mkdir()
+    monkeypatch.setenv("QSX_JIT_RECORD_DIR", str(record))
+    monkeypatch.setenv("QSX_JIT_SHIPPED_CACHE", "0")
+    monkeypatch.delenv("QSX_JIT_CACHE_DIR", raising=False)
+    size = C.c_size_t(0)
+    assert fn(C.byref(cfg), 0, C.byref(size)) == 0
+    shapes = sorted(record.iterdir())
+    assert len(shapes) == 1 and shapes[0].suffix == ".shape"
+    text = shapes[0].read_bytes()
+    assert b"jit_make_dev" in text and b"qsx_jit_agg" in text and len(text) < 64 * 1024      # the configuration and the entry point, not the kernel sources
+    assert fn(C.byref(cfg), 0, C.byref(size)) == 0 and sorted(record.iterdir()) == shapes      # recorded once
+    monkeypatch.delenv("QSX_JIT_RECORD_DIR")
+    assert warm(text, len(text), str(built).encode()) == 0
+    objects = sorted(built.iterdir())
+    assert len(objects) == 1 and objects[0].suffix == ".hsaco" and objects[0].read_bytes()[:8] == b"QSXJIT01"
+    assert warm(text, len(text), str(built).encode()) == 1                                      # already there
+    # the run-time side: the same object under <library directory>/jit_cache is found (no compile: an order of magnitude faster)
+    shipped = os.path.join(os.path.dirname(capi.LIB_PATH), "jit_cache")
+    made = not os.path.isdir(shipped)
+    os.makedirs(shipped, exist_ok=True)
+    target = os.path.join(shipped, objects[0].name)
+    present = os.path.exists(target)
+    try:
+        if not present:
+            shutil.copy(objects[0], target)
+        monkeypatch.setenv("QSX_JIT_SHIPPED_CACHE", "1")
+        before = sorted(os.listdir(shipped))
+        t0 = time.perf_counter()
+        assert fn(C.byref(cfg), 0, C.byref(size)) == 0 and size.value > 0
+        assert time.perf_counter() - t0 < 0.5, "the shipped code object was not used"
+        assert sorted(os.listdir(shipped)) == before                                            # nothing is written next to the library
+    finally:
+        if not present:
+            os.remove(target)
+        if made:
+            shutil.rmtree(shipped, ignore_errors=True)

@@ -396,3 +396,157 @@ def test_coded_plan_shapes_built_by_hiprtc_match_too():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", " or ".join(nodes)],
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _factored_launches(capi):
+    import ctypes
+    fn = capi.lib.qsx_debug_agg_factored_launches
+    fn.restype = ctypes.c_longlong
+    return fn()
+
+
+def _coded(oracle, values, dtype=None):
+    """(codes, dictionary) of a column as CompressedBlockBuilder stores it when it picks a dictionary."""
+    col = oracle.CompressedColumn(values if dtype is None else values.astype(dtype))
+    assert col.dictionary is not None, "the test wants a dictionary-coded column"
+    return col
+
+
+_FACTORED_PLANS = {
+    # TPC-H Q1 (benchmarks/tpch/queries/01.sql) over lineitem's code stripes: cells (disc, tax), a histogram for quantity
+    "q1": dict(instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0)), (T.EX_ADD, 2, T.const(0), T.col(5)),
+                       (T.EX_MUL, 3, T.temp(1), T.temp(2))], consts=[1.0],
+               aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.col(3)), (T.AGG_SUM, T.temp(1)), (T.AGG_SUM, T.temp(3)), (T.AGG_AVG, T.col(2)),
+                     (T.AGG_AVG, T.col(3)), (T.AGG_AVG, T.col(4)), (T.AGG_COUNT_STAR, None)], factored=True),
+    # affine forms: price + disc, disc * tax (two dictionary columns, no plain one), price / (1 + tax), a constant-free product
+    "affine": dict(instrs=[(T.EX_ADD, 0, T.col(3), T.col(4)), (T.EX_MUL, 1, T.col(4), T.col(5)), (T.EX_ADD, 2, T.const(0), T.col(5)),
+                           (T.EX_DIV, 3, T.col(3), T.temp(2)), (T.EX_SUB, 4, T.temp(3), T.col(6))], consts=[1.0],
+                   aggs=[(T.AGG_SUM, T.temp(0)), (T.AGG_SUM, T.temp(1)), (T.AGG_SUM, T.temp(3)), (T.AGG_AVG, T.temp(4)), (T.AGG_COUNT_STAR, None)],
+                   factored=True),
+    # integer sums: over a dictionary-coded INT column (histogram, exact), over a plain INT column (an i64 plane), next to a double sum
+    "integers": dict(instrs=[(T.EX_MUL, 0, T.col(3), T.col(4))], consts=[],
+                     aggs=[(T.AGG_SUM, T.col(7)), (T.AGG_SUM, T.col(8)), (T.AGG_SUM, T.temp(0)), (T.AGG_AVG, T.col(7)), (T.AGG_COUNT_STAR, None)], factored=True),
+    # two plain columns (price and a FLOAT) times dictionary factors
+    "two_carriers": dict(instrs=[(T.EX_MUL, 0, T.col(3), T.col(4)), (T.EX_MUL, 1, T.col(6), T.col(5)), (T.EX_ADD, 2, T.temp(0), T.temp(1))], consts=[],
+                         aggs=[(T.AGG_SUM, T.temp(2)), (T.AGG_SUM, T.col(6)), (T.AGG_COUNT_STAR, None)], factored=True),
+    # not affine in the plain column: the decoding kernels answer
+    "square": dict(instrs=[(T.EX_MUL, 0, T.col(3), T.col(3)), (T.EX_MUL, 1, T.temp(0), T.col(4))], consts=[],
+                   aggs=[(T.AGG_SUM, T.temp(1)), (T.AGG_COUNT_STAR, None)], factored=False),
+    # MIN / MAX do not factor
+    "minmax": dict(instrs=[], consts=[], aggs=[(T.AGG_SUM, T.col(4)), (T.AGG_MAX, T.col(3)), (T.AGG_COUNT_STAR, None)], factored=False),
+}
+
+
+@pytest.mark.parametrize("plan", sorted(_FACTORED_PLANS))
+@pytest.mark.parametrize("groups,est", [(4, 6), (40, 2)])
+def test_aggregates_factored_through_dictionary_codes_match_the_oracle(capi, oracle, dev, plan, groups, est, monkeypatch):
+    """csrc/agg_factored.hpp: a state over dictionary-coded attributes whose aggregate arguments are affine in the plain
+    columns adds every row to the CELL (group, codes of the dictionary columns) — carrier sums and a count — and to a
+    histogram per stand-alone dictionary column; the state's accumulators are dot products of the cells with coefficients made
+    from the call's dictionaries.  Against the oracle (which decodes every value, like the reference's accessor): COUNT and
+    integer sums exact, SUM over an integer-valued dictionary column exact, the rest to 1e-6 (north_star) — under a filter,
+    over a tail that is not a multiple of the tile, with more groups than the workgroup's table holds (est = 2: the rows of
+    the other groups take the per-row path), and for plans that do NOT factor (answered by the decoding kernels)."""
+    monkeypatch.setenv("QSX_AGG_FACTORED_MIN_ROWS", "0")
+    monkeypatch.setenv("QSX_AGG_FACTORED_GENERIC", "1")            # keys of two widths: none of the direct-load signatures, the staged kernel answers
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", str(1 << 60))        # (the fall-back, when it is taken, is the interpreter: no compile in this test)
+    rng = np.random.default_rng(500 + groups)
+    n = 300_007
+    k1 = rng.integers(0, groups, size=n).astype(np.int32) * 7 - 3
+    k2 = rng.choice(np.frombuffer(b"FO", dtype=np.uint8), size=n)
+    qty = rng.integers(1, 51, size=n).astype(np.float64)
+    price = np.round(rng.uniform(900, 105000, size=n), 2)
+    disc = rng.integers(0, 11, size=n) / 100.0
+    tax = rng.integers(0, 9, size=n) / 100.0
+    weight = rng.uniform(-2, 2, size=n).astype(np.float32)
+    size_code = (rng.integers(0, 40, size=n) * 1000 - 7000).astype(np.int32)      # a dictionary-coded INT (negative values: no truncation)
+    plain_int = rng.integers(-10**6, 10**6, size=n).astype(np.int32)
+    cols = [k1, k2, qty, price, disc, tax, weight, size_code, plain_int]
+    comp = {2: _coded(oracle, qty), 4: _coded(oracle, disc), 5: _coded(oracle, tax), 7: _coded(oracle, size_code)}
+    widths = [comp[i].code_width if i in comp else 0 for i in range(len(cols))]
+    assert widths[2] == widths[4] == widths[5] == widths[7] == 1
+    layout = [(T.INT, None), (T.CHAR, 1), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.FLOAT, None), (T.INT, None), (T.INT, None)]
+    spec = _FACTORED_PLANS[plan]
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0, 1], instrs=spec["instrs"], consts=spec["consts"], aggs=spec["aggs"],
+                            est_groups=est, code_widths=widths)
+    code_cols = [comp[i].codes if i in comp else cols[i] for i in range(len(cols))]
+    dicts = [comp[i].dictionary if i in comp else None for i in range(len(cols))]
+    filt = oracle.bitmap_from_bools(rng.random(n) < 0.75)
+    before = _factored_launches(capi)
+    st, o = capi.AggState(cfg), oracle.AggState(cfg)
+    cut = 131_072 + 5
+    for lo, hi, use_filter in ((0, cut, False), (cut, n, True)):
+        f = oracle.bitmap_from_bools(oracle.bools_from_bitmap(filt, n)[lo:hi]) if use_filter else None
+        st.update_coded([to_dev(np.ascontiguousarray(c[lo:hi]), dev) for c in code_cols], [None if d is None else to_dev(d, dev) for d in dicts],
+                        hi - lo, filter_bitmap=None if f is None else bitmap_dev(f, dev))
+        o.update_coded([np.ascontiguousarray(c[lo:hi]) for c in code_cols], dicts, hi - lo, filter_bitmap=f)
+    assert (_factored_launches(capi) - before == 2) == spec["factored"], "the plan took the other path"
+    from test_gpu_agg import assert_same_groups, finalize_np
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+    # a call without the dictionaries' sizes cannot factor (the cells' extent is unknown): same groups from the decoding kernels
+    st2 = capi.AggState(cfg)
+    st2.update_coded([to_dev(c, dev) for c in code_cols], [None if d is None else to_dev(d, dev) for d in dicts], n, sized=False)
+    o2 = oracle.AggState(cfg)
+    o2.update_coded(code_cols, dicts, n)
+    assert_same_groups(finalize_np(st2, dev), o2.finalize())
+
+
+@pytest.mark.parametrize("key_kind", ["char", "int"])
+@pytest.mark.parametrize("shape", ["q1", "one_cell_no_histogram", "two_cells_no_carrier"])
+@pytest.mark.parametrize("groups,est", [(3, 6), (50, 2)])
+def test_factored_aggregation_by_direct_loads_matches_the_oracle(capi, oracle, dev, key_kind, shape, groups, est, monkeypatch):
+    """agg_factored_direct_kernel (csrc/agg_factored_kernels.hpp): the signatures answered without LDS staging — one or two
+    keys of one width (CHAR(1) or INT), one or two cell columns, at most one histogram column, at most one DOUBLE carrier;
+    8 consecutive rows per thread by 8- / 16-byte loads, the stripe's tail row by row.  Q1 over lineitem's codes is the
+    first of them (benchmarks/tpch/queries/01.sql over create.sql:69-121).  Against the oracle, with and without a filter, a
+    row count that is no multiple of anything, a slice that starts at an odd tile, and more groups than the table holds."""
+    monkeypatch.setenv("QSX_AGG_FACTORED_MIN_ROWS", "0")
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", str(1 << 60))
+    monkeypatch.delenv("QSX_AGG_FACTORED_GENERIC", raising=False)
+    rng = np.random.default_rng(900 + groups)
+    n = 2048 * 37 + 1234                                              # 37 full tiles of the direct kernel and a tail
+    if key_kind == "char":
+        letters = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", dtype=np.uint8)
+        k1, k2 = rng.choice(letters[:max(1, groups // 2)], size=n), rng.choice(letters[:2], size=n)
+        key_layout = [(T.CHAR, 1), (T.CHAR, 1)]
+    else:
+        k1 = (rng.integers(0, max(1, groups // 2), size=n) * 1009 - 5).astype(np.int32)
+        k2 = rng.integers(0, 2, size=n).astype(np.int32)
+        key_layout = [(T.INT, None), (T.INT, None)]
+    qty = rng.integers(1, 51, size=n).astype(np.float64)
+    price = np.round(rng.uniform(900, 105000, size=n), 2)
+    disc = rng.integers(0, 11, size=n) / 100.0
+    tax = rng.integers(0, 9, size=n) / 100.0
+    cols = [k1, k2, qty, price, disc, tax]
+    comp = {2: _coded(oracle, qty), 4: _coded(oracle, disc), 5: _coded(oracle, tax)}
+    widths = [comp[i].code_width if i in comp else 0 for i in range(len(cols))]
+    layout = key_layout + [(T.DOUBLE, None)] * 4
+    if shape == "q1":
+        spec = _FACTORED_PLANS["q1"]
+        keys = [0, 1]
+    elif shape == "one_cell_no_histogram":     # SUM(price * (1 - disc)), AVG(disc): one key, one cell column, one carrier
+        spec = dict(instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0))], consts=[1.0],
+                    aggs=[(T.AGG_SUM, T.temp(1)), (T.AGG_AVG, T.col(4)), (T.AGG_COUNT_STAR, None)])
+        keys = [0]
+    else:                                      # SUM(disc * tax), SUM(qty): two cell columns, a histogram, no plain column at all
+        spec = dict(instrs=[(T.EX_MUL, 0, T.col(4), T.col(5))], consts=[], aggs=[(T.AGG_SUM, T.temp(0)), (T.AGG_SUM, T.col(2)), (T.AGG_COUNT_STAR, None)])
+        keys = [0, 1]
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=keys, instrs=spec["instrs"], consts=spec["consts"], aggs=spec["aggs"],
+                            est_groups=est, code_widths=widths)
+    code_cols = [comp[i].codes if i in comp else cols[i] for i in range(len(cols))]
+    dicts = [comp[i].dictionary if i in comp else None for i in range(len(cols))]
+    filt = oracle.bitmap_from_bools(rng.random(n) < 0.7)
+    dev_cols = [to_dev(c, dev) for c in code_cols]
+    dev_dicts = [None if d is None else to_dev(d, dev) for d in dicts]
+    before = _factored_launches(capi)
+    st, o = capi.AggState(cfg), oracle.AggState(cfg)
+    st.update_coded(dev_cols, dev_dicts, n)
+    o.update_coded(code_cols, dicts, n)
+    st.update_coded(dev_cols, dev_dicts, n, filter_bitmap=bitmap_dev(filt, dev))
+    o.update_coded(code_cols, dicts, n, filter_bitmap=filt)
+    lo = 2048 * 3                                                     # a slice (16-byte aligned for every column width)
+    st.update_coded([c[lo:] for c in dev_cols], dev_dicts, n - lo)
+    o.update_coded([np.ascontiguousarray(c[lo:]) for c in code_cols], dicts, n - lo)
+    assert _factored_launches(capi) - before == 3, "the signature did not take the direct-load kernel"
+    from test_gpu_agg import assert_same_groups, finalize_np
+    assert_same_groups(finalize_np(st, dev), o.finalize())

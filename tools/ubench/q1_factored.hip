@@ -1,0 +1,152 @@
+// Prototype: TPC-H Q1 over code stripes with the aggregates FACTORED through the dictionary codes (priced
+// before building it into the plan shapes).  13 B/row: k1, k2 CHAR(1); quantity, discount, tax 1-byte codes; price DOUBLE.
+//   per row: cell = (group, discount code, tax code)  ->  SUM(price) f64 + COUNT u32 atomics into the cell, u32 into the
+//   group's quantity histogram: 3 LDS atomics instead of 6, no dictionary decode, no expression per row;
+//   per workgroup at its end: SUM(price*(1-d)) = sum over cells of (1-d) * cell sum, ... -> the six accumulators per group.
+// Rows reach the lanes by direct 8 / 16-byte loads (8 consecutive rows per thread), next tile requested before the current
+// one is consumed.  build: hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -ffp-contract=off tools/ubench/q1_factored.hip -o /tmp/q1_factored
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+constexpr int kBlock = 256;
+constexpr int kRows = 8;                    // rows per thread and tile
+constexpr int kTile = kBlock * kRows;       // 2048 rows
+constexpr int kGroups = 8;                  // slots of the (k1, k2) table
+constexpr int kD = 11, kT = 9, kQ = 50;
+constexpr int kCells = kGroups * kD * kT;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+__device__ __forceinline__ T ldg_nt(const T *p) { return __builtin_nontemporal_load((const __attribute__((address_space(1))) T *)p); }
+
+__device__ __forceinline__ int group_of(unsigned k1, unsigned k2) { return ((k1 >> 2) & 7) ^ ((k2 & 1) << 0) ^ 0; }   // A,F=0 N,F=3 N,O=2 R,F=4 (distinct)
+
+struct Tile {
+  u32x2 k1, k2, q, d, t;
+  u32x4 p[4];
+};
+
+__global__ __launch_bounds__(kBlock) void q1_factored(const unsigned char *__restrict__ k1, const unsigned char *__restrict__ k2,
+                                                     const unsigned char *__restrict__ qc, const double *__restrict__ price,
+                                                     const unsigned char *__restrict__ dc, const unsigned char *__restrict__ tc,
+                                                     const double *__restrict__ qdict, const double *__restrict__ ddict,
+                                                     const double *__restrict__ tdict, long long n, double *__restrict__ out /* [kGroups][6] */) {
+  __shared__ double s_sum[kCells];
+  __shared__ unsigned s_cnt[kCells];
+  __shared__ unsigned s_hq[kGroups * kQ];
+  for (int i = threadIdx.x; i < kCells; i += kBlock) { s_sum[i] = 0.0; s_cnt[i] = 0u; }
+  for (int i = threadIdx.x; i < kGroups * kQ; i += kBlock) s_hq[i] = 0u;
+  __syncthreads();
+  const long long tiles = n / kTile;          // (prototype: n is a multiple of the tile)
+  auto request = [&](long long tile, Tile &x) {
+    const long long row = tile * kTile + static_cast<long long>(threadIdx.x) * kRows;
+    x.k1 = ldg_nt(reinterpret_cast<const u32x2 *>(k1 + row));
+    x.k2 = ldg_nt(reinterpret_cast<const u32x2 *>(k2 + row));
+    x.q = ldg_nt(reinterpret_cast<const u32x2 *>(qc + row));
+    x.d = ldg_nt(reinterpret_cast<const u32x2 *>(dc + row));
+    x.t = ldg_nt(reinterpret_cast<const u32x2 *>(tc + row));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x.p[j] = ldg_nt(reinterpret_cast<const u32x4 *>(price + row) + j);
+  };
+  Tile cur, nxt;
+  long long tile = blockIdx.x;
+  if (tile < tiles) request(tile, cur);
+  for (; tile < tiles; tile += gridDim.x) {
+    if (tile + gridDim.x < tiles) request(tile + gridDim.x, nxt);
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const unsigned sh = (r & 3) * 8;
+      const unsigned a = (r < 4 ? cur.k1.x : cur.k1.y) >> sh & 0xFF, b = (r < 4 ? cur.k2.x : cur.k2.y) >> sh & 0xFF;
+      const unsigned q = (r < 4 ? cur.q.x : cur.q.y) >> sh & 0xFF, d = (r < 4 ? cur.d.x : cur.d.y) >> sh & 0xFF, t = (r < 4 ? cur.t.x : cur.t.y) >> sh & 0xFF;
+      const u32x4 pw = cur.p[r >> 1];
+      const double p = __hiloint2double((r & 1) ? pw.w : pw.y, (r & 1) ? pw.z : pw.x);
+      const int g = group_of(a, b);
+      const int cell = (g * kD + d) * kT + t;
+      unsafeAtomicAdd(&s_sum[cell], p);
+      atomicAdd(&s_cnt[cell], 1u);
+      atomicAdd(&s_hq[g * kQ + q], 1u);
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  // flush: the six accumulators of every group from the cells (one thread per (group, accumulator) would do; here a wave per group)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int g = wave; g < kGroups; g += kBlock / 64) {
+    double a_price = 0, a_disc_price = 0, a_charge = 0, a_disc = 0, a_qty = 0, a_cnt = 0;
+    for (int c = lane; c < kD * kT; c += 64) {
+      const int d = c / kT, t = c % kT;
+      const double s = s_sum[g * kD * kT + c], k = s_cnt[g * kD * kT + c];
+      const double one_minus = 1.0 - ddict[d], one_plus = 1.0 + tdict[t];
+      a_price += s;
+      a_disc_price += s * one_minus;
+      a_charge += s * one_minus * one_plus;
+      a_disc += k * ddict[d];
+      a_cnt += k;
+    }
+    for (int c = lane; c < kQ; c += 64) a_qty += s_hq[g * kQ + c] * qdict[c];
+    for (int o = 32; o > 0; o >>= 1) {
+      a_price += __shfl_xor(a_price, o); a_disc_price += __shfl_xor(a_disc_price, o); a_charge += __shfl_xor(a_charge, o);
+      a_disc += __shfl_xor(a_disc, o); a_qty += __shfl_xor(a_qty, o); a_cnt += __shfl_xor(a_cnt, o);
+    }
+    if (lane == 0 && a_cnt != 0) {
+      unsafeAtomicAdd(&out[g * 6 + 0], a_qty); unsafeAtomicAdd(&out[g * 6 + 1], a_price); unsafeAtomicAdd(&out[g * 6 + 2], a_disc_price);
+      unsafeAtomicAdd(&out[g * 6 + 3], a_charge); unsafeAtomicAdd(&out[g * 6 + 4], a_disc); unsafeAtomicAdd(&out[g * 6 + 5], a_cnt);
+    }
+  }
+}
+
+__global__ void fill(unsigned char *k1, unsigned char *k2, unsigned char *q, double *p, unsigned char *d, unsigned char *t, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    unsigned s = static_cast<unsigned>(i) * 2654435761u + 12345u;
+    s = s * 1664525u + 1013904223u;
+    const unsigned r = (s >> 8) & 0xFFFFFF;
+    const int g = r < 4137000u ? 0 : (r < 4246000u ? 1 : (r < 12643000u ? 2 : 3));
+    k1[i] = "ANNR"[g]; k2[i] = "FFOF"[g];
+    s = s * 1664525u + 1013904223u;
+    q[i] = (s >> 8) % 50; d[i] = (s >> 14) % 11; t[i] = (s >> 20) % 9;
+    s = s * 1664525u + 1013904223u;
+    p[i] = 900.0 + (s >> 8) % 10410000 / 100.0;
+  }
+}
+
+int main(int argc, char **argv) {
+  const long long n = (argc > 1 ? atoll(argv[1]) : 600) * 1000000ll / kTile * kTile;
+  unsigned char *k1, *k2, *q, *d, *t;
+  double *p, *out, *qd, *dd, *td;
+  hipMalloc(&k1, n); hipMalloc(&k2, n); hipMalloc(&q, n); hipMalloc(&d, n); hipMalloc(&t, n); hipMalloc(&p, n * 8);
+  hipMalloc(&out, kGroups * 6 * 8); hipMalloc(&qd, 50 * 8); hipMalloc(&dd, 11 * 8); hipMalloc(&td, 9 * 8);
+  std::vector<double> hq(50), hd(11), ht(9);
+  for (int i = 0; i < 50; ++i) hq[i] = i + 1;
+  for (int i = 0; i < 11; ++i) hd[i] = i / 100.0;
+  for (int i = 0; i < 9; ++i) ht[i] = i / 100.0;
+  hipMemcpy(qd, hq.data(), 400, hipMemcpyHostToDevice); hipMemcpy(dd, hd.data(), 88, hipMemcpyHostToDevice); hipMemcpy(td, ht.data(), 72, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, k1, k2, q, p, d, t, n);
+  hipDeviceSynchronize();
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  for (int per_cu : {2, 3, 4, 5, 6, 8}) {
+    const int grid = 256 * per_cu;
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipMemset(out, 0, kGroups * 6 * 8);
+      hipEventRecord(a);
+      hipLaunchKernelGGL(q1_factored, dim3(grid), dim3(kBlock), 0, 0, k1, k2, q, p, d, t, qd, dd, td, n, out);
+      hipEventRecord(b);
+      hipEventSynchronize(b);
+      float ms;
+      hipEventElapsedTime(&ms, a, b);
+      if (rep > 0 && ms < best) best = ms;
+    }
+    double h[kGroups * 6];
+    hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    double cnt = 0;
+    for (int g = 0; g < kGroups; ++g) cnt += h[g * 6 + 5];
+    printf("workgroups/CU %d: %.3f ms per %lld M rows = %.2f TB/s of 13 B/row (%.3f of 8 TB/s); COUNT total %.0f (%s), SUM(qty) g0 %.0f, SUM(charge) g2 %.6e\n", per_cu, best,
+           n / 1000000, 13.0 * n / best / 1e9, 13.0 * n / best / 1e9 / 8.0, cnt, cnt == double(n) ? "ok" : "WRONG", h[0], h[2 * 6 + 3]);
+  }
+  return 0;
+}
