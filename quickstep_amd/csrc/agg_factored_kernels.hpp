@@ -44,7 +44,16 @@ __device__ inline double factored_eval(const DevConfig &c, const double (&vals)[
   }
   return value(arg);
 }
-__global__ __launch_bounds__(kABlock) void factored_coef_kernel(DevConfig c, FactoredCoefArgs a) {
+__global__ __launch_bounds__(kABlock) void factored_coef_kernel(DevConfig c_arg, FactoredCoefArgs a) {
+  // (the configuration is indexed by thread-dependent values: from the kernel argument that is a private copy of all of it per
+  // lane — 2.7 KB of scratch, 32 us for 600 threads; from LDS it is a handful of ds_reads)
+  __shared__ DevConfig c;
+  {
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(&c_arg);
+    unsigned int *dst = reinterpret_cast<unsigned int *>(&c);
+    for (int i = threadIdx.x; i < static_cast<int>(sizeof(DevConfig) / 4); i += kABlock) dst[i] = src[i];
+  }
+  __syncthreads();
   const int per_sum = a.cells + kFacMaxDict;
   const int i = blockIdx.x * kABlock + threadIdx.x;
   if (i >= a.nsums * per_sum) return;
@@ -226,11 +235,14 @@ __device__ __forceinline__ void factored_spill_row(const FactoredArgs &a, const 
   }
 }
 
+// (the table is private to the workgroup: any hash will do, so a cheap one — one 32-bit multiply)
+__device__ __forceinline__ int factored_home_slot(unsigned long long code, int S) {
+  return static_cast<int>(((static_cast<uint32_t>(code) ^ static_cast<uint32_t>(code >> 32)) * 0x9E3779B9u) >> 16) & (S - 1);
+}
 // The group's slot in the workgroup's table (bounded linear probing); -1: the sentinel code, or the table is full.
 __device__ __forceinline__ int factored_group_slot(unsigned long long *l_keys, int S, unsigned long long code) {
   if (code == kEmptyCode) return -1;
-  // (the table is private to the workgroup: any hash will do, so a cheap one — one 32-bit multiply)
-  int s = static_cast<int>(((static_cast<uint32_t>(code) ^ static_cast<uint32_t>(code >> 32)) * 0x9E3779B9u) >> 16) & (S - 1);
+  int s = factored_home_slot(code, S);
   for (int probes = 0; probes < S; ++probes) {
     unsigned long long k = l_keys[s];
     if (k == kEmptyCode) k = atomicCAS(&l_keys[s], kEmptyCode, code);
@@ -466,13 +478,17 @@ __global__ __launch_bounds__(kABlock) void agg_factored_direct_kernel(const Fact
     }
   };
   auto byte_of = [](unsigned long long v, int r) -> unsigned int { return static_cast<unsigned int>(v >> (r * 8)) & 0xFFu; };
-  unsigned long long last_code = kEmptyCode;   // the previous row's group: with a handful of groups every other row repeats it
-  int last_slot = -1;
+  // A tile's rows in three sweeps, so that the eight group lookups of a thread are in flight together (row by row — hash,
+  // ds_read, compare, atomics, next row — every row waited out its own LDS round trip: 1.61 ms per 600 M rows of Q1):
+  // (1) key code, cell, histogram code, carrier of every row from the registers; (2) the home slot of every code read from
+  // the table, compared; a code that is not at home yet (first sight, or a collision) goes through the probing insert;
+  // (3) the atomics.
   auto consume = [&](const Tile &x, int64_t tile) {
+    unsigned long long code[kFacDirectRows];
+    int cell[kFacDirectRows], hcode[kFacDirectRows], home[kFacDirectRows], slot[kFacDirectRows];
 #pragma unroll
     for (int r = 0; r < kFacDirectRows; ++r) {
-      if (((x.live >> r) & 1u) == 0u) continue;
-      unsigned long long code = 0;
+      code[r] = 0;
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         unsigned long long kv;
@@ -482,38 +498,46 @@ __global__ __launch_bounds__(kABlock) void agg_factored_direct_kernel(const Fact
           const uint4 &w = x.key32[k][r >> 2];
           kv = (r & 3) == 0 ? w.x : ((r & 3) == 1 ? w.y : ((r & 3) == 2 ? w.z : w.w));
         }
-        code |= kv << d.key_shift[k];
+        code[r] |= kv << d.key_shift[k];
       }
-      int cell = 0;
+      cell[r] = 0;
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
         int cc = static_cast<int>(byte_of(x.cell[q], r));
         cc = cc < d.cell_radix[q] ? cc : d.cell_radix[q] - 1;
-        cell += cc * d.cell_stride[q];
+        cell[r] += cc * d.cell_stride[q];
       }
-      int hc = 0;
+      hcode[r] = 0;
       if constexpr (NH > 0) {
-        hc = static_cast<int>(byte_of(x.hist[0], r));
-        hc = hc < d.hist_size ? hc : d.hist_size - 1;
+        hcode[r] = static_cast<int>(byte_of(x.hist[0], r));
+        hcode[r] = hcode[r] < d.hist_size ? hcode[r] : d.hist_size - 1;
       }
+      home[r] = factored_home_slot(code[r], S);
+    }
+    unsigned long long at_home[kFacDirectRows];
+#pragma unroll
+    for (int r = 0; r < kFacDirectRows; ++r) at_home[r] = l_keys[home[r]];
+#pragma unroll
+    for (int r = 0; r < kFacDirectRows; ++r) {
+      const bool live = ((x.live >> r) & 1u) != 0u;
+      slot[r] = !live ? -2 : ((at_home[r] == code[r] && code[r] != kEmptyCode) ? home[r] : factored_group_slot(l_keys, S, code[r]));
+    }
+#pragma unroll
+    for (int r = 0; r < kFacDirectRows; ++r) {
+      if (slot[r] == -2) continue;
       unsigned long long carw = 0;
       if constexpr (kCar) {
         const uint4 &pw = x.car[r >> 1];
         carw = (static_cast<unsigned long long>((r & 1) ? pw.w : pw.y) << 32) | ((r & 1) ? pw.z : pw.x);
       }
-      if (code != last_code) {
-        last_slot = factored_group_slot(l_keys, S, code);
-        last_code = code;
-      }
-      const int slot = last_slot;
-      if (slot >= 0) {
-        const int at = slot * cells + cell;
+      if (slot[r] >= 0) {
+        const int at = slot[r] * cells + cell[r];
         atomicAdd(&l_cnt[at], 1u);
         if constexpr (kCar) unsafeAtomicAdd(reinterpret_cast<double *>(l_plane) + at, __longlong_as_double(static_cast<long long>(carw)));
-        if constexpr (NH > 0) atomicAdd(&l_hist[slot * d.hist_words + hc], 1u);
+        if constexpr (NH > 0) atomicAdd(&l_hist[slot[r] * d.hist_words + hcode[r]], 1u);
       } else {
-        const int hist_code[kFacMaxHist] = {hc, 0, 0, 0};
-        factored_spill_row(*a_dev, g, code, cell, hist_code, carw, 0ull);
+        const int hist_code[kFacMaxHist] = {hcode[r], 0, 0, 0};
+        factored_spill_row(*a_dev, g, code[r], cell[r], hist_code, carw, 0ull);
       }
     }
     (void)tile;

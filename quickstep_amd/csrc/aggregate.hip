@@ -2073,6 +2073,20 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
 static std::atomic<long long> g_factored_launches{0};
 // Test hook (not part of include/qsx.h): update calls this process has issued through the factored kernels.
 extern "C" long long qsx_debug_agg_factored_launches(void) { return g_factored_launches.load(std::memory_order_relaxed); }
+// Test hook (not part of include/qsx.h; needs no GPU): how factored_analyse() sees a configuration — out[0] = factors (0 / 1),
+// out[1..3] = cell columns, histogram columns, carriers; out[4 + j] = histogram column of sum j or -1.
+extern "C" int qsx_debug_agg_factored_plan(const qsx_agg_config_t *config, int32_t *out, int out_len) {
+  if (config == nullptr || out == nullptr || out_len < 4 + kMaxSums) return QSX_ERR_INVALID_ARGUMENT;
+  const Translated t = translate(*config);
+  if (t.status != QSX_OK) return t.status;
+  const FactoredStatic f = factored_analyse(t.dev, t.dense);
+  out[0] = f.ok ? 1 : 0;
+  out[1] = f.ncell;
+  out[2] = f.nhist;
+  out[3] = f.ncar;
+  for (int j = 0; j < kMaxSums; ++j) out[4 + j] = j < t.num_sums ? f.sum_hist[j] : -1;
+  return QSX_OK;
+}
 static bool factored_enabled() {
   const char *e = getenv("QSX_AGG_FACTORED");
   return e == nullptr || e[0] != '0';

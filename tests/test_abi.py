@@ -328,3 +328,43 @@ def test_recorded_plan_shapes_are_compiled_at_build_time_and_found_at_run_time(c
             os.remove(target)
         if made:
             shutil.rmtree(shipped, ignore_errors=True)
+
+
+def test_which_plans_factor_through_their_dictionary_columns(capi):
+    """csrc/agg_factored.hpp factored_analyse (host logic, no GPU): an aggregation over dictionary-coded attributes factors when
+    every aggregate argument is affine in the plain columns once the dictionary columns are fixed.  TPC-H Q1 over lineitem's
+    codes: cells over (discount, tax), a histogram for quantity, one carrier (extendedprice)."""
+    import ctypes as C
+    from quickstep_amd import types as T
+    fn = capi.lib.qsx_debug_agg_factored_plan
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(T.AggConfig), C.POINTER(C.c_int32), C.c_int]
+
+    def plan(cfg):
+        out = (C.c_int32 * 16)()
+        assert fn(C.byref(cfg), out, 16) == 0
+        return list(out)
+    layout = [(T.CHAR, 1), (T.CHAR, 1), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.DOUBLE, None)]
+    q1 = dict(keys=[0, 1], instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0)), (T.EX_ADD, 2, T.const(0), T.col(5)),
+                                   (T.EX_MUL, 3, T.temp(1), T.temp(2))], consts=[1.0],
+              aggs=[(T.AGG_SUM, T.col(2)), (T.AGG_SUM, T.col(3)), (T.AGG_SUM, T.temp(1)), (T.AGG_SUM, T.temp(3)), (T.AGG_AVG, T.col(4)), (T.AGG_COUNT_STAR, None)],
+              est_groups=6)
+    coded = [0, 0, 1, 0, 1, 1]
+    got = plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, **q1))
+    assert got[:4] == [1, 2, 1, 1]                     # factors; cells (disc, tax); histogram (qty); carrier (price)
+    assert got[4] == 0 and got[5:9] == [-1, -1, -1, -1]   # SUM(qty) reads the histogram, the others the cells
+    # the same plan over plain columns has nothing to factor through
+    assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, **q1))[0] == 0
+    # price * price is not affine; MIN / MAX do not factor; a predicate inside the state keeps the decoding kernels
+    square = dict(q1, instrs=[(T.EX_MUL, 0, T.col(3), T.col(3)), (T.EX_MUL, 1, T.temp(0), T.col(4))], aggs=[(T.AGG_SUM, T.temp(1))])
+    assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, **square))[0] == 0
+    minmax = dict(q1, aggs=[(T.AGG_SUM, T.col(4)), (T.AGG_MAX, T.col(3))])
+    assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, **minmax))[0] == 0
+    assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, pred=[(3, T.LT, 1000.0)], **q1))[0] == 0
+    # price + disc is affine (the constant part multiplies the cell's count); price / (1 + tax) divides by a dictionary-only term
+    affine = dict(q1, instrs=[(T.EX_ADD, 0, T.col(3), T.col(4)), (T.EX_ADD, 1, T.const(0), T.col(5)), (T.EX_DIV, 2, T.col(3), T.temp(1))],
+                  aggs=[(T.AGG_SUM, T.temp(0)), (T.AGG_SUM, T.temp(2))])
+    assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, **affine))[:4] == [1, 2, 0, 1]
+    # ... a dictionary column in the numerator's place is fine, a plain column in the denominator is not
+    bad_div = dict(q1, instrs=[(T.EX_DIV, 0, T.col(4), T.col(3))], aggs=[(T.AGG_SUM, T.temp(0))])
+    assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, **bad_div))[0] == 0
