@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
-#define QSX_ABI_VERSION 13
+#define QSX_ABI_VERSION 14
 
 typedef void *qsx_stream_t;
 
@@ -860,6 +860,19 @@ int qsx_lip_probe_blocks(const qsx_lip_filter_t *filter, int key_type, int64_t n
 
 /* Raw bit array (for all-reduce(OR) across GPUs): 64-bit words, LSB-first. */
 int qsx_lip_filter_words(qsx_lip_filter_t *f, uint64_t **out_words_dev, int64_t *out_num_words);
+
+/* qsx_join_probe with the work order's LIP filters tested INSIDE the probe: HashInnerJoinWorkOrder::execute runs its
+ * LIPFilterAdaptiveProber over the probe accessor first and probes the hash table with the survivors
+ * (relational_operators/HashJoinOperator.cpp:450-470, utility/lip_filter/LIPFilterAdaptiveProber.hpp:113-228).  A row is probed
+ * when it is set in filter_dev (NULL: every row) AND every filter reports a hit for its key; the pairs are those of
+ * qsx_lip_probe (per filter) + qsx_join_probe under the resulting bitmap — from one pass over the keys when the table is
+ * directly addressed (or answers from its shadow) and num_lip <= 2, else from exactly that sequence inside the call.
+ *   lip_filters   host array of num_lip filters over the probe key (QSX_LIP_*; built before the probe: pipeline breaker) */
+int qsx_join_probe_lip(qsx_join_table_t *table, const void *keys_dev, int64_t n, int32_t probe_base_tid,
+                       const uint64_t *filter_dev, int num_lip, const qsx_lip_filter_t *const *lip_filters,
+                       int32_t *out_probe_tid_dev, int32_t *out_build_tid_dev, int64_t capacity,
+                       int64_t *out_count_dev, qsx_stream_t stream);
+
 
 /* ======================================================================
  * Hash partitioning (multi-GPU shuffle, partitioned aggregation)

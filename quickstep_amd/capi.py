@@ -93,6 +93,7 @@ _SIGNATURES = {
     "qsx_join_table_size": (_int, [_vp, C.POINTER(_i64), _vp]),
     "qsx_join_build": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_join_probe_lip": (_int, [_vp, _vp, _i64, _i32, _vp, _int, _pp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_key_pack_blocks": (_int, [_int, C.POINTER(_i32), _i64, C.POINTER(_i64), _pp, _vp, C.POINTER(_int), _vp]),
     "qsx_join_build_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp]),
     "qsx_join_probe_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
@@ -665,6 +666,22 @@ class JoinTable:
             capacity = out_p.numel() if capacity is None else capacity
         _check(_lib.qsx_join_probe(self._h, _ptr(keys), n, probe_base_tid, _ptr(filter_bitmap), _ptr(out_p),
                                    _ptr(out_b), capacity, _ptr(count), _stream(stream)), "qsx_join_probe")
+        return out_p, out_b, count
+
+    def probe_lip(self, keys, lip_filters, capacity=None, probe_base_tid=0, filter_bitmap=None, out=None, stream=None):
+        """qsx_join_probe_lip: the probe with the work order's LIP filters (LipFilter objects over the probe key) tested inside."""
+        n = keys.numel()
+        if out is None:
+            capacity = n if capacity is None else capacity
+            out_p = torch.empty(max(capacity, 1), dtype=torch.int32, device=keys.device)
+            out_b = torch.empty(max(capacity, 1), dtype=torch.int32, device=keys.device)
+            count = torch.zeros(1, dtype=torch.int64, device=keys.device)
+        else:
+            out_p, out_b, count = out
+            capacity = out_p.numel() if capacity is None else capacity
+        handles = (C.c_void_p * max(len(lip_filters), 1))(*[f._h for f in lip_filters])
+        _check(_lib.qsx_join_probe_lip(self._h, _ptr(keys), n, probe_base_tid, _ptr(filter_bitmap), len(lip_filters), handles, _ptr(out_p),
+                                       _ptr(out_b), capacity, _ptr(count), _stream(stream)), "qsx_join_probe_lip")
         return out_p, out_b, count
 
     def probe_count(self, keys, filter_bitmap=None, stream=None):

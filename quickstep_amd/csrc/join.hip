@@ -1243,15 +1243,17 @@ static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream, int6
   return shadow;
 }
 
-// The LDS-resident form of the dense probe (join_lds.hpp): one workgroup of 1024 threads per CU, the table in its LDS.
-template <int MODE, bool kRuns>
+// The big-tile form of the dense probe (join_lds.hpp): one workgroup of 1024 threads per CU, one output reservation per 16 K
+// rows; kLds: the table copied into the workgroup's LDS, else looked up where it lies; NLIP: LIP filters tested in the kernel.
+template <int MODE, bool kRuns, bool kLds = true, int NLIP = 0>
 static int launch_lds_dense_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_t probe_base_tid, const uint64_t *filter,
                                   int32_t *out_probe, int32_t *out_build, int64_t capacity, unsigned long long *count,
-                                  uint64_t *out_bitmap, int anti, hipStream_t stream, const long long *runs_dev, int64_t tiles) {
-  const size_t table_bytes = (static_cast<size_t>(t->range) * 4 + 15) & ~static_cast<size_t>(15);
+                                  uint64_t *out_bitmap, int anti, hipStream_t stream, const long long *runs_dev, int64_t tiles,
+                                  const LipViews &lips = LipViews{}) {
+  const size_t table_bytes = kLds ? ((static_cast<size_t>(t->range) * 4 + 15) & ~static_cast<size_t>(15)) : 0;
   auto launch = [&](auto key_tag) -> int {
     using KeyT = decltype(key_tag);
-    auto kernel = &lds_dense_probe_kernel<KeyT, MODE, kRuns>;
+    auto kernel = &lds_dense_probe_kernel<KeyT, MODE, kRuns, kLds, NLIP>;
     if (table_bytes > 48 * 1024) {
       // (a property of (kernel, device); setting it again is a cheap host call)
       QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLdsStaticBytes));
@@ -1259,11 +1261,18 @@ static int launch_lds_dense_probe(qsx_join_table_t *t, const void *keys, int64_t
     const int64_t units = (tiles + kLdsSub - 1) / kLdsSub;
     const int grid = static_cast<int>(units < kCUs ? units : kCUs);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kLdsBlock), table_bytes, stream, t->dense_view(), static_cast<const KeyT *>(keys), n, probe_base_tid,
-                       filter, out_probe, out_build, capacity, count, out_bitmap, anti, runs_dev);
+                       filter, out_probe, out_build, capacity, count, out_bitmap, anti, runs_dev, lips);
     QSX_CHECK_LAUNCH();
     return QSX_OK;
   };
   return t->key_type == QSX_INT ? launch(int32_t{}) : launch(int64_t{});
+}
+
+// A pair-emitting probe under a filter in ONE pass (join_lds.hpp, kLds = false) instead of count / scan / write;
+// QSX_JOIN_ONE_PASS=0 keeps the two passes.
+static bool one_pass_enabled() {
+  const char *e = getenv("QSX_JOIN_ONE_PASS");
+  return e == nullptr || e[0] != '0';
 }
 
 // kRuns: the probe side is a run of blocks — runs_dev is its table (block_runs.hpp, tiles of 4096 rows), run_tiles its tile
@@ -1299,6 +1308,12 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
           n >= (1 << 18)) {
         return launch_lds_dense_probe<MODE, kRuns>(t, keys, n, probe_base_tid, filter, out_probe, out_build, capacity, dcount, out_bitmap, anti,
                                                    stream, runs_dev, tiles);
+      }
+    }
+    if constexpr (MODE == 0) {
+      if (dense_two_pass(filter) && one_pass_enabled() && n >= (1 << 20)) {
+        return launch_lds_dense_probe<0, kRuns, false>(t, keys, n, probe_base_tid, filter, out_probe, out_build, capacity, dcount, out_bitmap, anti,
+                                                       stream, runs_dev, tiles);
       }
     }
     if (MODE == 0 && dense_two_pass(filter)) {
@@ -1484,6 +1499,55 @@ int qsx_join_probe(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   if (static_cast<int64_t>(probe_base_tid) + n > INT32_MAX) return QSX_ERR_INVALID_ARGUMENT;
   return launch_probe<0>(t, keys_dev, n, probe_base_tid, filter_dev, out_probe_tid_dev,
                          out_build_tid_dev, capacity, out_count_dev, nullptr, 0, as_stream(stream));
+}
+
+int qsx_join_probe_lip(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t probe_base_tid, const uint64_t *filter_dev,
+                       int num_lip, const qsx_lip_filter_t *const *lip_filters, int32_t *out_probe_tid_dev, int32_t *out_build_tid_dev,
+                       int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || n < 0 || capacity < 0 || out_count_dev == nullptr || num_lip < 0 || (num_lip > 0 && lip_filters == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (keys_dev == nullptr || (capacity > 0 && (out_probe_tid_dev == nullptr || out_build_tid_dev == nullptr)))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (static_cast<int64_t>(probe_base_tid) + n > INT32_MAX) return QSX_ERR_INVALID_ARGUMENT;
+  for (int f = 0; f < num_lip; ++f) {
+    if (lip_filters[f] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  if (num_lip == 0) {
+    return launch_probe<0>(t, keys_dev, n, probe_base_tid, filter_dev, out_probe_tid_dev, out_build_tid_dev, capacity, out_count_dev, nullptr, 0, s);
+  }
+  // the table the probe will really read: a directly addressed one (or a hashed table's shadow) takes the filters into its kernel
+  qsx_join_table *direct = t->dense ? t : (n != 0 ? sealed_shadow(t, s, n) : nullptr);
+  if (direct != nullptr && num_lip <= kMaxFusedLip && n >= (1 << 16) && one_pass_enabled()) {
+    QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+    sealed_pack(direct, s);
+    std::shared_lock<std::shared_mutex> lock(direct->mutex);
+    LipViews lips{};
+    for (int f = 0; f < num_lip; ++f) lips.f[f] = lip_filter_view(lip_filters[f]);
+    const int64_t tiles = (n + kDenseTile - 1) / kDenseTile;
+    unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count_dev);
+    if (num_lip == 1) {
+      return launch_lds_dense_probe<0, false, false, 1>(direct, keys_dev, n, probe_base_tid, filter_dev, out_probe_tid_dev, out_build_tid_dev, capacity, count,
+                                                        nullptr, 0, s, nullptr, tiles, lips);
+    }
+    return launch_lds_dense_probe<0, false, false, 2>(direct, keys_dev, n, probe_base_tid, filter_dev, out_probe_tid_dev, out_build_tid_dev, capacity, count,
+                                                      nullptr, 0, s, nullptr, tiles, lips);
+  }
+  // any other table (or more filters than the kernel takes): the filters one after the other into a bitmap of the call, then
+  // the probe under it — what the separate entry points do
+  CallScratch scratch(s);
+  const size_t words = static_cast<size_t>((n + 63) / 64 + 1);
+  int rc = scratch.reserve(CallScratch::padded(words * 8) * 2);
+  if (rc != QSX_OK) return rc;
+  uint64_t *bitmaps[2] = {static_cast<uint64_t *>(scratch.take(words * 8)), static_cast<uint64_t *>(scratch.take(words * 8))};
+  const uint64_t *in = filter_dev;
+  for (int f = 0; f < num_lip; ++f) {
+    rc = qsx_lip_probe(lip_filters[f], t->key_type, keys_dev, n, in, bitmaps[f & 1], nullptr, stream);
+    if (rc != QSX_OK) return rc;
+    in = bitmaps[f & 1];
+  }
+  return launch_probe<0>(t, keys_dev, n, probe_base_tid, in, out_probe_tid_dev, out_build_tid_dev, capacity, out_count_dev, nullptr, 0, s);
 }
 
 int qsx_join_probe_count(qsx_join_table_t *t, const void *keys_dev, int64_t n,

@@ -23,6 +23,7 @@
 #define QSX_CSRC_JOIN_LDS_HPP_
 
 #include "join_dense.hpp"
+#include "lip_view.hpp"
 
 namespace qsx {
 
@@ -38,15 +39,28 @@ constexpr int kLdsStaticBytes = 1024;                     // what the kernels' s
 // that take 0.5 ms, the whole kernel once the lookups are ds_reads (first version: 0.33 ms whatever the table).  Per
 // 16 K rows it is 0.07 ms and hides under the streams.  A sub-tile is a tile of the run tables (block_runs.hpp): each has
 // its own stripe, row count, filter and base tuple id, looked up from the table when it is needed (scalar loads).
+//
+// kLds = false: the same kernel over a table that stays in HBM / L2 (head words through dense_head_word) — the ONE-PASS form
+// of a pair-emitting probe under a filter.  With a reservation per 4096-row tile that probe had to run in two passes (count
+// per unit, scan, write: the keys are read twice) because 146 K same-address atomics cost 1.7 ms per 600 M rows; one
+// reservation per 16 K rows makes it 37 K = 0.4 ms, hidden under the streams, and the keys are read once.
+// NLIP > 0: LIP filters tested inside the probe, between the input bitmap and the table lookup — what
+// HashInnerJoinWorkOrder::execute does with its LIPFilterAdaptiveProber before it probes
+// (relational_operators/HashJoinOperator.cpp:450-470, utility/lip_filter/LIPFilterAdaptiveProber.hpp:113-228): no bitmap
+// pass of its own, no second read of the keys.
 constexpr int kLdsBlock = 1024;
 constexpr int kLdsSub = 4;
-template <typename KeyT, int MODE, bool kRuns = false>
+constexpr int kMaxFusedLip = 2;
+struct LipViews {
+  LipView f[kMaxFusedLip];
+};
+template <typename KeyT, int MODE, bool kRuns = false, bool kLds = true, int NLIP = 0>
 __global__ __launch_bounds__(kLdsBlock) void lds_dense_probe_kernel(DenseTableView t, const KeyT *__restrict__ keys, int64_t n,
                                                                    int32_t probe_base_tid, const uint64_t *__restrict__ filter,
                                                                    int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build,
                                                                    int64_t capacity_signed, unsigned long long *__restrict__ out_count,
                                                                    uint64_t *__restrict__ out_bitmap, int anti,
-                                                                   const long long *__restrict__ runs = nullptr) {
+                                                                   const long long *__restrict__ runs = nullptr, LipViews lips = LipViews{}) {
   constexpr int BLOCK = kLdsBlock, S = kLdsSub;
   constexpr int R = kLdsTile / BLOCK;
   constexpr int kWaves = BLOCK / kWave;
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_dense_probe_kernel(DenseTableVi
   };
   // the first super tile's keys are requested before the table is copied: both travel together
   if (static_cast<int64_t>(blockIdx.x) < num_super) request(blockIdx.x, key, filter_words);
-  {
+  if constexpr (kLds) {
     // head[] -> LDS, 16 bytes per lane and step (a device allocation: 256-byte aligned; the tail goes word by word)
     const int range = static_cast<int>(t.range);
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -114,15 +128,40 @@ __global__ __launch_bounds__(kLdsBlock) void lds_dense_probe_kernel(DenseTableVi
       const bool present = tile < num_tiles;
       const Source src = present ? source_of(tile) : Source();
       const int64_t n_rows = present ? src.n : 0;
+      bool live[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int64_t row = src.base + r * BLOCK + threadIdx.x;
         const uint64_t filter_word = __shfl(filter_words[s], r, kWave);   // before any branch: every lane takes part
-        const bool live = row < n_rows && msb_bit(filter_word, lane);
-        live_mask |= live ? (1u << (s * R + r)) : 0u;
+        live[r] = row < n_rows && msb_bit(filter_word, lane);
+      }
+      if constexpr (NLIP > 0) {
+        // the filter bits of the sub-tile's live rows: independent reads, issued together (dead rows read word 0)
+#pragma unroll
+        for (int f = 0; f < NLIP; ++f) {
+          long long bit[R];
+          unsigned long long w[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            bit[r] = live[r] ? lip_bit_index(lips.f[f], static_cast<long long>(key[s][r])) : -2;
+            w[r] = load_global(&lips.f[f].words[bit[r] >= 0 ? bit[r] >> 6 : 0]);
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const bool set = bit[r] >= 0 && ((w[r] >> (bit[r] & 63)) & 1ull) != 0;
+            // (outside an exact filter's range: a miss — a hit for an anti filter, BitVectorExactFilter.hpp:158-172)
+            live[r] = live[r] && (bit[r] == -1 ? lips.f[f].is_anti != 0 : (set != (lips.f[f].is_anti != 0)));
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        live_mask |= live[r] ? (1u << (s * R + r)) : 0u;
         const uint64_t idx = dense_index(t, key[s][r]);
-        const bool lookup = live && idx != ~0ull;
-        const uint32_t word = l_head[lookup ? static_cast<int>(idx) : 0];   // unconditional ds_read (dead lanes read word 0)
+        const bool lookup = live[r] && idx != ~0ull;
+        uint32_t word;
+        if constexpr (kLds) word = l_head[lookup ? static_cast<int>(idx) : 0];   // unconditional ds_read (dead lanes read word 0)
+        else word = dense_head_word(t, lookup ? idx : 0);
         h[s][r] = lookup ? word : 0u;
       }
     }

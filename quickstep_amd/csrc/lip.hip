@@ -10,20 +10,13 @@
 
 #include "common.hpp"
 #include "block_runs.hpp"
+#include "lip_view.hpp"
 
 #include <vector>
 
 namespace qsx {
 
 constexpr int kLBlock = 256;
-
-struct LipView {
-  unsigned long long *words;  // LSB-first bit array
-  long long cardinality;
-  long long min_value;
-  int exact;
-  int is_anti;
-};
 
 // A wave owns groups of R x 64 rows; the R filter words of a group come with one load (lane r holds word r) and the
 // keys of the next group are requested before the bits of the current one are set (as in lip_probe_kernel below).
@@ -96,16 +89,6 @@ __global__ __launch_bounds__(kLBlock) void lip_build_kernel(LipView f, const Key
     for (int r = 0; r < R; ++r) key[r] = next_key[r];
     words = next_words;
   }
-}
-
-// Filter membership of one key: index of the filter bit, or -1 when the key is outside an exact
-// filter's range (then `out_of_range_hit` decides, BitVectorExactFilter.hpp:158-172).
-__device__ __forceinline__ long long lip_bit_index(const LipView &f, long long v) {
-  if (f.exact) {
-    const long long off = v - f.min_value;
-    return (off < 0 || off >= f.cardinality) ? -1 : off;
-  }
-  return static_cast<long long>(static_cast<unsigned long long>(v) % static_cast<unsigned long long>(f.cardinality));
 }
 
 // R bitmap words (64-row groups) per wave iteration: R independent key loads, then R independent
@@ -234,6 +217,10 @@ struct qsx_lip_filter {
     return v;
   }
 };
+
+namespace qsx {
+LipView lip_filter_view(const qsx_lip_filter *f) { return f->view(); }
+}  // namespace qsx
 
 extern "C" {
 

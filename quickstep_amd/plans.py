@@ -233,14 +233,21 @@ class DistributedQ3:
         # lineitem
         with ph("lineitem: select l_shipdate"):
             l_sel, l_sel_count = ops.select_cmp(inp["l_shipdate"], T.GT, DATE_CUT)
-        with ph("lineitem: LIP probe"):
-            if self.use_lip:
-                l_lip, l_live = self.lip_o.probe(inp["l_orderkey"], in_bitmap=l_sel)
-            else:
-                l_lip, l_live = l_sel, l_sel_count
-        with ph("lineitem: inner probe"):
-            p, b, cnt = self.t_o.probe(inp["l_orderkey"], capacity=int(l_live.item()), filter_bitmap=l_lip)
-            total = int(cnt.item())
+        if self.use_lip and self.fused and hasattr(self.t_o, "probe_lip"):
+            # the join work order's own LIP prober (HashJoinOperator.cpp:450-470): filter bit and table word from one pass over
+            # l_orderkey; the rows that pass the predicate bound the pairs (an order is unique), so nothing is counted first
+            with ph("lineitem: LIP + inner probe (one pass)"):
+                p, b, cnt = self.t_o.probe_lip(inp["l_orderkey"], [self.lip_o], capacity=int(l_sel_count.item()), filter_bitmap=l_sel)
+                total = int(cnt.item())
+        else:
+            with ph("lineitem: LIP probe"):
+                if self.use_lip:
+                    l_lip, l_live = self.lip_o.probe(inp["l_orderkey"], in_bitmap=l_sel)
+                else:
+                    l_lip, l_live = l_sel, l_sel_count
+            with ph("lineitem: inner probe"):
+                p, b, cnt = self.t_o.probe(inp["l_orderkey"], capacity=int(l_live.item()), filter_bitmap=l_lip)
+                total = int(cnt.item())
         pt = p[:total]
         with ph("group by l_orderkey (dense state, through the pair list)"):
             if self.fused:

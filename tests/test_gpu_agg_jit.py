@@ -161,7 +161,9 @@ def test_plan_shape_from_the_cache_directory_serves_the_first_update(tmp_path):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, QSX_JIT_CACHE_DIR=str(tmp_path), QSX_AGG_JIT_MIN_ROWS="1000")
+    # (QSX_JIT_SHIPPED_CACHE=0: this shape is among the recorded ones — the code object that ships with the library would
+    # answer the first process before it compiled or wrote anything)
+    env = dict(os.environ, QSX_JIT_CACHE_DIR=str(tmp_path), QSX_AGG_JIT_MIN_ROWS="1000", QSX_JIT_SHIPPED_CACHE="0")
     env.pop("QSX_AGG_JIT_SYNC", None)
     env.pop("QSX_AGG_NO_SPECIALIZE", None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -176,3 +178,28 @@ def test_plan_shape_from_the_cache_directory_serves_the_first_update(tmp_path):
     assert runs[1]["after_first_update"] == 1, "the cached code object was not picked up before the first update returned"
     assert len([p for p in tmp_path.iterdir() if p.suffix == ".hsaco"]) >= 1
     assert runs[0]["keys"] == runs[1]["keys"] == list(range(23)) and runs[0]["sums"] == runs[1]["sums"]
+
+
+def test_a_recorded_plan_shape_is_served_by_the_shipped_code_object(tmp_path):
+    """quickstep_amd/lib/jit_cache (filled by __graft_entry__.build from csrc/jit_shapes/): the FIRST process that asks for a
+    recorded shape gets it before its first update returns — no compiler, no interpreter, nothing written — where the
+    same process with QSX_JIT_SHIPPED_CACHE=0 starts on the interpreter and compiles."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shipped = os.path.join(root, "quickstep_amd", "lib", "jit_cache")
+    if not os.path.isdir(shipped) or not any(f.endswith(".hsaco") for f in os.listdir(shipped)):
+        pytest.skip("no shipped code objects (build() has not run its warm step)")
+    env = dict(os.environ, QSX_AGG_JIT_MIN_ROWS="1000")
+    for name in ("QSX_JIT_CACHE_DIR", "QSX_AGG_JIT_SYNC", "QSX_AGG_NO_SPECIALIZE", "QSX_JIT_SHIPPED_CACHE", "QSX_JIT_RECORD_DIR"):
+        env.pop(name, None)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    before = sorted(os.listdir(shipped))
+    r = subprocess.run([sys.executable, "-c", _CACHE_SCRIPT], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = json.loads(r.stdout.strip().splitlines()[-1])
+    assert run["after_first_update"] == 1 and run["final"] == 1, "the shipped code object did not serve the first update (re-record csrc/jit_shapes?)"
+    assert sorted(os.listdir(shipped)) == before
+    assert run["keys"] == list(range(23))

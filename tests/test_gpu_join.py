@@ -822,3 +822,62 @@ def test_small_bucketed_tables_are_probed_from_lds(capi, oracle, dev, key_type, 
         table.close()
     for a, b in zip(results["1"], results["0"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+@pytest.mark.parametrize("table_kind", ["dense", "hashed_dense_keys", "hashed_sparse_keys"])
+@pytest.mark.parametrize("filters", [["exact"], ["hash"], ["exact", "hash"], ["anti"], ["exact", "hash", "exact"]])
+def test_probe_with_lip_filters_inside_equals_filter_then_probe(capi, oracle, dev, key_type, dtype, table_kind, filters, monkeypatch):
+    """qsx_join_probe_lip: HashInnerJoinWorkOrder's LIP filters tested inside the probe (one pass over the keys for directly
+    addressed tables and shadows; the filter-then-probe sequence inside the call for every other table and for more than two
+    filters).  Pairs = the oracle's LIP probes chained into a bitmap + its join under that bitmap: exact, hash and anti
+    filters, keys outside an exact filter's range, an input bitmap, duplicate build keys; and the one-pass probe under a
+    plain filter (QSX_JOIN_ONE_PASS) against the two-pass form."""
+    rng = np.random.default_rng(4242 + len(filters))
+    n_build, n_probe, domain = 60_000, 1_300_003, 150_000
+    lo = -1000 if dtype == np.int32 else 2**40
+    keys = lo + rng.integers(0, domain, size=n_build)
+    if table_kind == "hashed_sparse_keys":
+        keys = lo + (rng.integers(0, domain, size=n_build) * 7919)
+    build = keys.astype(dtype)                                          # duplicates
+    span = int(build.max()) - lo + 1
+    probe = (lo + rng.integers(-span // 20, span + span // 20, size=n_probe)).astype(dtype)
+    if table_kind == "hashed_sparse_keys":
+        probe = np.where(rng.random(n_probe) < 0.6, rng.choice(build, size=n_probe), probe).astype(dtype)
+    in_filter = oracle.bitmap_from_bools(rng.random(n_probe) < 0.8)
+    table = capi.JoinTable(key_type, n_build, key_range=(int(build.min()), int(build.max())) if table_kind == "dense" else None)
+    table.build(to_dev(build, dev))
+    otable = oracle.JoinTable(key_type, n_build)
+    otable.build(build)
+    members = build[rng.random(n_build) < 0.5]                           # what the filters were built on
+    lips, olips = [], []
+    for kind in filters:
+        if kind == "hash":
+            args = (T.LIP_SINGLE_IDENTITY_HASH, 8 * members.size, 0, False)
+        else:      # exact filters cover only part of the probe keys' range: out-of-range keys miss (hit for the anti filter)
+            args = (T.LIP_BITVECTOR_EXACT, span, lo, kind == "anti")
+        f, of = capi.LipFilter(*args), oracle.LipFilter(*args)
+        subset = members[members >= lo] if kind == "hash" else members
+        f.build(to_dev(subset.astype(dtype), dev))
+        of.build(subset.astype(dtype))
+        lips.append(f)
+        olips.append(of)
+    dp = to_dev(probe, dev)
+    for filt in (None, in_filter):
+        bitmap = filt
+        for of in olips:
+            bitmap = of.probe(probe, in_bitmap=bitmap)
+        rp, rd = otable.probe(probe, filter_bitmap=bitmap)
+        p, b, cnt = table.probe_lip(dp, lips, capacity=rp.size, filter_bitmap=None if filt is None else bitmap_dev(filt, dev))
+        assert int(cnt.item()) == rp.size
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rd))
+    # the probe under a plain filter: one pass (one reservation per 16 K rows) = two passes (count / scan / write)
+    rp, rd = otable.probe(probe, filter_bitmap=in_filter)
+    for one_pass in ("1", "0"):
+        monkeypatch.setenv("QSX_JOIN_ONE_PASS", one_pass)
+        p, b, cnt = table.probe(dp, capacity=rp.size, filter_bitmap=bitmap_dev(in_filter, dev))
+        assert int(cnt.item()) == rp.size
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rd))
+    for f in lips:
+        f.close()
+    table.close()
