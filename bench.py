@@ -855,7 +855,8 @@ def secondary_q1_coded(ctx, args, threads):
     out = {"workload": f"C3 Q1 aggregation over CompressedColumnStore lineitem: {n} rows, 13 B/row (l_quantity / l_discount / "
                        "l_tax 1-byte dictionary codes decoded in the kernel)",
            "ms": ms, "ms_with_clear": ms_clear_update, "rows_per_s": n / ms * 1e3,
-           "roofline": hbm_roofline("qsx_jit_agg (qsx_agg_update_coded_sized; run-time plan shape of the Q1 aggregation over code stripes)",
+           "roofline": hbm_roofline("agg_factored_direct_kernel<false,1,2,2,1,true> (qsx_agg_update_coded_sized: the aggregates factored through the "
+                                    "dictionary codes, csrc/agg_factored.hpp; the call also launches factored_coef_kernel, ~10 us)",
                                     13 * n, ms, algorithmic_bytes_per_row=13),
            "checked": checked}
     if not args.no_cpu_baseline:
@@ -951,6 +952,50 @@ def secondary_c3_minimal(ctx, args, threads):
     return out
 
 
+def secondary_join_small_build(ctx, args, threads):
+    """C2 with a build side that fits LDS (a dimension table: 25 K keys — nation / region / a filtered dimension / one partition
+    of a radix split): north_star's "LDS-staged hash tables".  Every workgroup copies the table into its LDS and answers its
+    probe rows from there (csrc/join_lds.hpp); algorithmic bytes 4 N + 8 M as for C2."""
+    dev = ctx.dev
+    n_build, n = 25_000, args.probe_rows
+    g = torch.Generator(device=dev)
+    g.manual_seed(12)
+    build = torch.randperm(n_build, device=dev, generator=g, dtype=torch.int32)
+    probe = torch.randint(0, n_build, (n,), device=dev, generator=g, dtype=torch.int32)
+    out = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
+    res = {}
+    for name, key_range in (("dense", (0, n_build - 1)), ("hashed", None)):
+        t = capi.JoinTable(T.INT, n_build, key_range=key_range)
+        t.build(build)
+        ms = launches_ms(lambda: t.probe(probe, capacity=n, out=out))
+        k = int(out[2].item())
+        checked = False
+        if not args.no_check:
+            check_pairs(probe, build, out[0], out[1], k, n_build)
+            assert k == n
+            checked = True
+        res[name] = {"ms": ms, "checked": checked}
+        t.close()
+    ms = res["dense"]["ms"]
+    out_line = {"workload": f"C2 with a build side that fits LDS: {n_build} x {n} INTEGER inner equi-join, match rate 1.0",
+                "ms": ms, "rows_per_s": n / ms * 1e3, "hashed_table_ms": res["hashed"]["ms"],
+                "roofline": hbm_roofline("lds_dense_probe_kernel<int,0> (qsx_join_probe: the table copied into every workgroup's LDS)", 12 * n, ms,
+                                         algorithmic_bytes="4*N_probe + 8*N_match"),
+                "checked": res["dense"]["checked"] and res["hashed"]["checked"]}
+    del out, probe
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as O
+        rng = np.random.default_rng(12)
+        b = rng.permutation(n_build).astype(np.int32)
+        small = rng.integers(0, n_build, size=2_000_000).astype(np.int32)
+        m = sized_sample(lambda: O.bench_join(b, small, 1_048_576, threads)["probe_seconds"], 2_000_000, args.secondary_cpu_seconds / 5.0, 4_000_000, n)
+        p = rng.integers(0, n_build, size=m).astype(np.int32)
+        secs, trials = trials_2_to_4(lambda: O.bench_join(b, p, 1_048_576, threads)["probe_seconds"])
+        out_line["cpu_baseline"] = {"value": m / secs, "unit": "rows/s", "cores": threads, "kind": "port", "trials_s": trials,
+                                    "sample": f"oracle: SimpleScalarSeparateChaining probe, {n_build} x {m} rows in 4 MB blocks, {threads} worker threads; 5 trials, mean of 2-4"}
+    return out_line
+
+
 def condensed(line):
     """What a partitioned configuration's own line (--config c4 | c5) contributes to `secondary`."""
     return {"workload": line["config"]["workload"], "ms": line["ms_per_step"], "rows_per_s": line["value"],
@@ -1035,7 +1080,7 @@ def secondary_block(ctx, args):
     t_start = time.perf_counter()
     threads = usable_cores()
     out = {}
-    legs = [("q1_coded", secondary_q1_coded), ("c3_minimal", secondary_c3_minimal)]
+    legs = [("q1_coded", secondary_q1_coded), ("c3_minimal", secondary_c3_minimal), ("join_small_build", secondary_join_small_build)]
     for name, fn in legs:
         t0 = time.perf_counter()
         try:
@@ -1203,8 +1248,6 @@ def main():
     want_secondary = rank == 0 and world == 1 and args.config == "headline" and not args.no_secondary and not ctx.distributed
     ctx.keep_headline = want_secondary
     line = {"headline": run_headline, "c4": run_c4, "c5": run_c5}[args.config](ctx, args)
-    if want_secondary:
-        line["secondary"] = secondary_block(ctx, args)
     line["world_size_seen"] = dist.get_world_size() if ctx.distributed else 1      # what the RCCL process group reports
     line["self_launched"] = os.environ.get("QSX_BENCH_SELF_LAUNCHED") == "1"
     line["transport"] = args.transport if ctx.distributed else None
@@ -1223,6 +1266,8 @@ def main():
             # like for like: the raw step with its probe writing the operators' output relation instead of the pair list
             raw_ms = line["ms_per_step"] - line["phases_ms"]["probe"] + variants["dense_m1.0_projected_int_attributes"]["ms"]
             line["operators"]["fraction_of_raw_abi_with_output_relation"] = raw_ms / line["operators"]["ms_per_step"]
+    if want_secondary:     # (behind the operators leg: that child process is timed next to an otherwise idle parent, as in round 4)
+        line["secondary"] = secondary_block(ctx, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "headline":
         line["cpu_baseline"] = cpu_baseline(args)
     # RCCL writes its version banner to the C library's stdout, which a pipe only sees when that buffer is flushed — at

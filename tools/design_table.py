@@ -42,6 +42,18 @@ def main():
         if "ms_per_step" in op:
             rows.append(("the step through the operator layer", "8 Workers, 256 blocks per work order", f"{op['ms_per_step']:.2f} ms",
                          f"{op['rows_per_s'] / 1e9:.0f} G rows/s", "—", f"{100 * op['fraction_of_raw_abi_value']:.0f} % of the raw step"))
+        for name, v in (line.get("secondary") or {}).items():      # (round 5: the other BASELINE configurations in the same line)
+            if isinstance(v, dict) and "ms" in v and "roofline" in v:
+                rows.append((f"`secondary.{name}` — `{v['roofline']['kernel'].split(' ')[0]}`", v["workload"][:90] + "…", f"{v['ms']:.3f} ms",
+                             f"{v['rows_per_s'] / 1e9:.0f} G rows/s", f"{v['roofline']['achieved'] / 1e3:.2f} TB/s", f"{100 * v['roofline']['frac']:.0f} %"))
+    for s in load_lines(os.path.join(prof, f"{tag}_probe_small_tables.jsonl")):
+        if s["build_keys"] not in (25000, 8000) or (s["table"] == "hashed_sparse" and s["build_keys"] > 13000):   # (25 K sparse keys: 250 KB of buckets, not an LDS table)
+            continue
+        for k, label in (("pairs_ms_lds", "pairs, table in LDS"), ("pairs_ms_l2", "pairs, table in L2 (`QSX_JOIN_LDS=0`)")):
+            if k in s:
+                byts = (12 if k.startswith("pairs") else 4) * s["probe_rows"]
+                rows.append((f"K4 small build side ({s['table']}): {label}", f"{s['build_keys']} keys x {s['probe_rows'] // 1_000_000} M, m = 1.0", f"{s[k]:.3f} ms",
+                             f"{s['probe_rows'] / s[k] / 1e6:.0f} G rows/s", f"{byts / s[k] / 1e9:.2f} TB/s", f"{100 * byts / s[k] / 1e6 / 8000:.0f} %"))
     for cfg in ("c4", "c5"):
         c = (load_lines(os.path.join(prof, f"{tag}_bench_{cfg}.json")) or [None])[0]
         if c is not None:
@@ -60,7 +72,9 @@ def main():
                          ("plain_ms (34 B/row)", "Q1 over plain stripes (34 B/row)")):
             if k in s:
                 b = 13 if "13" in label or "codes" in label else 34
-                rows.append((label, f"{s['rows'] // 1_000_000} M rows, run-time plan shape", f"{s[k]:.2f} ms", f"{s['rows'] / s[k] / 1e6:.0f} G rows/s",
+                how = ("factored through the codes, clear included" if k.startswith("coded_ms") and tag >= "r05" else
+                       ("decoding plan shape" if tag >= "r05" and "codes" in label else "plan shape"))
+                rows.append((label, f"{s['rows'] // 1_000_000} M rows, {how}", f"{s[k]:.2f} ms", f"{s['rows'] / s[k] / 1e6:.0f} G rows/s",
                              f"{b * s['rows'] / s[k] / 1e9:.2f} TB/s", f"{100 * b * s['rows'] / s[k] / 1e6 / 8000:.0f} %"))
     for o in load_lines(os.path.join(prof, f"{tag}_bench_ops.jsonl")):
         rows.append((o["op"], f"{o['rows'] // 1_000_000} M rows" + (f" ({o['note']})" if o.get("note") else ""), f"{o['ms']:.3f} ms",

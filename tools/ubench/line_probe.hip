@@ -17,7 +17,8 @@ __global__ void fill_keys(uint32_t *keys, int64_t n, uint32_t range, uint64_t se
   }
 }
 
-// MODE 0: plane + slots, 1: in-line, 2: a single 8-byte read of the 10 MiB array (the floor of one random line)
+// MODE 0: plane + slots, 1: in-line, 2: a single 8-byte read of the 10 MiB array (the floor of one random line),
+// 3: plane + a 4-byte slot of an array HALF the size (64-byte buckets of 16 4-byte slots: the "compact slot" of open item 12)
 template <int MODE, int R>
 __global__ __launch_bounds__(256) void probe(const uint32_t *__restrict__ keys, int64_t n, const uint4 *__restrict__ plane,
                                              const unsigned long long *__restrict__ lines, uint32_t buckets, int32_t *__restrict__ out_a,
@@ -36,13 +37,16 @@ __global__ __launch_bounds__(256) void probe(const uint32_t *__restrict__ keys, 
     } else {
       uint4 w[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) w[r] = MODE == 0 ? plane[b[r]] : reinterpret_cast<const uint4 *>(lines + (uint64_t)b[r] * 16)[7];
+      for (int r = 0; r < R; ++r) w[r] = (MODE == 0 || MODE == 3) ? plane[b[r]] : reinterpret_cast<const uint4 *>(lines + (uint64_t)b[r] * 16)[7];
 #pragma unroll
       for (int r = 0; r < R; ++r) pick[r] = (w[r].x ^ w[r].y ^ w[r].z ^ w[r].w ^ b[r]) % 14;
     }
     unsigned long long e[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) e[r] = lines[(uint64_t)b[r] * 16 + pick[r]];
+    for (int r = 0; r < R; ++r) {
+      if (MODE == 3) e[r] = reinterpret_cast<const uint32_t *>(lines)[(uint64_t)b[r] * 16 + pick[r]];
+      else e[r] = lines[(uint64_t)b[r] * 16 + pick[r]];
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = tile * kTile + r * 256 + threadIdx.x;
@@ -86,6 +90,7 @@ int main(int argc, char **argv) {
     run<0, 16>("plane (16 B, L2) then slot line (8 B)", keys, n, plane, lines, buckets, oa, ob, sum, per_cu);
     run<1, 16>("in-line: 16 B then 8 B of the same line", keys, n, plane, lines, buckets, oa, ob, sum, per_cu);
     run<1, 8>("in-line: 16 B then 8 B of the same line", keys, n, plane, lines, buckets, oa, ob, sum, per_cu);
+    run<3, 16>("plane then a 4-byte slot of a 5 MiB array", keys, n, plane, lines, buckets, oa, ob, sum, per_cu);
   }
   return 0;
 }
