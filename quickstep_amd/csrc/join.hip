@@ -1258,8 +1258,9 @@ static int launch_lds_dense_probe(qsx_join_table_t *t, const void *keys, int64_t
       // (a property of (kernel, device); setting it again is a cheap host call)
       QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLdsStaticBytes));
     }
-    const int64_t units = (tiles + kLdsSub - 1) / kLdsSub;
-    const int grid = static_cast<int>(units < kCUs ? units : kCUs);
+    const int sub = kLds ? kLdsSub : kLdsSubGlobal, per_cu = kLds ? 1 : 2;
+    const int64_t units = (tiles + sub - 1) / sub;
+    const int grid = static_cast<int>(units < static_cast<int64_t>(per_cu) * kCUs ? units : static_cast<int64_t>(per_cu) * kCUs);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kLdsBlock), table_bytes, stream, t->dense_view(), static_cast<const KeyT *>(keys), n, probe_base_tid,
                        filter, out_probe, out_build, capacity, count, out_bitmap, anti, runs_dev, lips);
     QSX_CHECK_LAUNCH();

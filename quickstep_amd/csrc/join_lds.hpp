@@ -54,14 +54,17 @@ constexpr int kMaxFusedLip = 2;
 struct LipViews {
   LipView f[kMaxFusedLip];
 };
+// (a table that stays in HBM takes units of 2 sub-tiles: 8 rows per thread fit 64 registers, so two workgroups share a CU and
+// twice as many lookups are in flight — what a latency-bound probe wants; the LDS table admits one workgroup per CU anyway)
+constexpr int kLdsSubGlobal = 2;
 template <typename KeyT, int MODE, bool kRuns = false, bool kLds = true, int NLIP = 0>
-__global__ __launch_bounds__(kLdsBlock) void lds_dense_probe_kernel(DenseTableView t, const KeyT *__restrict__ keys, int64_t n,
+__global__ __launch_bounds__(kLdsBlock, kLds ? 1 : 8) void lds_dense_probe_kernel(DenseTableView t, const KeyT *__restrict__ keys, int64_t n,
                                                                    int32_t probe_base_tid, const uint64_t *__restrict__ filter,
                                                                    int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build,
                                                                    int64_t capacity_signed, unsigned long long *__restrict__ out_count,
                                                                    uint64_t *__restrict__ out_bitmap, int anti,
                                                                    const long long *__restrict__ runs = nullptr, LipViews lips = LipViews{}) {
-  constexpr int BLOCK = kLdsBlock, S = kLdsSub;
+  constexpr int BLOCK = kLdsBlock, S = kLds ? kLdsSub : kLdsSubGlobal;
   constexpr int R = kLdsTile / BLOCK;
   constexpr int kWaves = BLOCK / kWave;
   static_assert(R * BLOCK == kLdsTile && R <= kWave, "a tile is R steps of BLOCK rows; lane r holds the filter word of step r");
