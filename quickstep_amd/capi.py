@@ -117,6 +117,7 @@ _SIGNATURES = {
     "qsx_agg_update": (_int, [_vp, _pp, _i64, _vp, _vp]),
     "qsx_agg_update_blocks": (_int, [_vp, _int, C.POINTER(_i64), _pp, _pp, _vp]),
     "qsx_agg_update_coded_blocks": (_int, [_vp, _int, C.POINTER(_i64), _pp, _pp, _pp, _vp]),
+    "qsx_agg_update_coded_blocks_sized": (_int, [_vp, _int, C.POINTER(_i64), _pp, _pp, C.POINTER(C.c_int32), _pp, _vp]),
     "qsx_agg_mark_existence": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "qsx_agg_update_coded": (_int, [_vp, _pp, _pp, _i64, _vp, _vp]),
     "qsx_agg_update_coded_sized": (_int, [_vp, _pp, _pp, C.POINTER(C.c_int32), _i64, _vp, _vp]),
@@ -843,8 +844,9 @@ class AggState:
             fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None else None for f in filters])
         _check(_lib.qsx_agg_update_blocks(self._h, nb, rows, ptrs, fptr, _stream(stream)), "qsx_agg_update_blocks")
 
-    def update_coded_blocks(self, blocks, dictionaries, filters=None, stream=None):
-        """qsx_agg_update_coded over a run of blocks: blocks[b][c] = code / value stripe, dictionaries[b][c] = dictionary or None."""
+    def update_coded_blocks(self, blocks, dictionaries, filters=None, stream=None, sized=True):
+        """qsx_agg_update_coded over a run of blocks: blocks[b][c] = code / value stripe, dictionaries[b][c] = dictionary or None.
+        sized: every block's dictionary sizes travel with the call (qsx_agg_update_coded_blocks_sized)."""
         nb, ncols = len(blocks), self.config.num_columns
         rows = (C.c_int64 * max(nb, 1))(*[b[0].numel() if b else 0 for b in blocks])
         ptrs = (C.c_void_p * max(nb * ncols, 1))()
@@ -857,6 +859,15 @@ class AggState:
         fptr = None
         if filters is not None:
             fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None else None for f in filters])
+        if sized:
+            entries = (C.c_int32 * max(nb * ncols, 1))()
+            for i in range(nb):
+                for c in range(ncols):
+                    d = dictionaries[i][c] if c < len(dictionaries[i]) else None
+                    entries[i * ncols + c] = d.numel() if d is not None else 0
+            _check(_lib.qsx_agg_update_coded_blocks_sized(self._h, nb, rows, ptrs, dptr, entries, fptr, _stream(stream)),
+                   "qsx_agg_update_coded_blocks_sized")
+            return
         _check(_lib.qsx_agg_update_coded_blocks(self._h, nb, rows, ptrs, dptr, fptr, _stream(stream)), "qsx_agg_update_coded_blocks")
 
     def update_nullable(self, cols, null_bitmaps, n=None, filter_bitmap=None, stream=None):

@@ -1,5 +1,5 @@
 // agg_factored.hip — the kernels of the factored aggregation over code stripes (agg_factored.hpp) and their launchers, in a
-// translation unit of their own: the direct-load kernel is instantiated per signature (64 code objects), which aggregate.hip's
+// translation unit of their own: the direct-load kernel is instantiated per signature (128 code objects), which aggregate.hip's
 // already long compile should not wait for.
 // Reference loops: storage/AggregationOperationState.cpp:428-474, storage/ThreadPrivateCompactKeyHashTable.cpp:216-304 over
 // storage/CompressedColumnStoreValueAccessor.hpp:90-150.
@@ -10,9 +10,16 @@
 
 namespace qsx {
 
-int launch_factored_coef(const DevConfig &dc, const FactoredCoefArgs &ca, hipStream_t s) {
-  const int threads = ca.nsums * (ca.cells + kFacMaxDict);
-  hipLaunchKernelGGL(factored_coef_kernel, dim3((threads + kABlock - 1) / kABlock), dim3(kABlock), 0, s, dc, ca);
+int launch_factored_coef(const DevConfig &dc, const FactoredCoefArgs &ca_in, hipStream_t s, int num_blocks) {
+  FactoredCoefArgs ca = ca_in;
+  ca.num_blocks = num_blocks;
+  const int threads = ca.cells + kFacMaxDict;   // a thread per cell and per dictionary code
+  const int across = (threads + kABlock - 1) / kABlock;
+  // (a block's tables are ~10 us of dependent loads and interpreted arithmetic whatever the grid: as many workgroups as fit the
+  // device at once — eight per CU — and each walks its share of the blocks; 1860 blocks: 2 per CU 0.29 ms, one per block 0.19 ms)
+  const int fit = 8 * kCUs / across + 1;
+  const int rows = num_blocks < fit ? num_blocks : fit;
+  hipLaunchKernelGGL(factored_coef_kernel, dim3(across, rows), dim3(kABlock), 0, s, dc, ca);
   QSX_CHECK_LAUNCH();
   return QSX_OK;
 }
@@ -43,12 +50,17 @@ int launch_factored_staged(const FactoredArgs &a, size_t lds_bytes, int per_cu, 
 }
 
 bool launch_factored_direct(const FactoredArgs &a, const FactoredArgs *a_dev, const FactoredDirectArgs &da, int key_width, size_t lds_bytes, int grid, int64_t n,
-                            const uint64_t *filter_dev, const HashTableView &g, hipStream_t s) {
+                            const uint64_t *filter_dev, const HashTableView &g, hipStream_t s, const FactoredRunArgs *runs) {
   if (a.nkeys < 1 || a.nkeys > 2 || a.ncell < 1 || a.ncell > 2 || a.nhist > 1 || a.ncar > 1 || (key_width != 1 && key_width != 4)) return false;
   auto launch = [&](auto filt, auto kw, auto nk, auto nc, auto nh, auto car) {
     constexpr bool F = decltype(filt)::value, CAR = decltype(car)::value;
     constexpr int KW = decltype(kw)::value, NK = decltype(nk)::value, NC = decltype(nc)::value, NH = decltype(nh)::value;
-    hipLaunchKernelGGL((agg_factored_direct_kernel<F, KW, NK, NC, NH, CAR>), dim3(grid), dim3(kABlock), lds_bytes, s, a_dev, da, n, filter_dev, g);
+    if (runs != nullptr) {   // (a run of blocks: F = some block has a filter)
+      hipLaunchKernelGGL((agg_factored_direct_kernel<F, KW, NK, NC, NH, CAR, true>), dim3(grid), dim3(kABlock), lds_bytes, s, a_dev, da, n, nullptr, g, *runs);
+    } else {
+      hipLaunchKernelGGL((agg_factored_direct_kernel<F, KW, NK, NC, NH, CAR, false>), dim3(grid), dim3(kABlock), lds_bytes, s, a_dev, da, n, filter_dev, g,
+                         FactoredRunArgs{});
+    }
   };
   using std::integral_constant;
   auto by_car = [&](auto filt, auto kw, auto nk, auto nc, auto nh) {

@@ -78,6 +78,13 @@ struct FactoredCoefArgs {
   int ncar, car_col[kFacMaxCarriers];
   int nsums, sum_hist[kMaxSums];
   unsigned long long *coef, *hcoef;
+  // a run of blocks (grid.y = block): the dictionaries of block b at run_dicts[b * QSX_MAX_COLUMNS + column], their entry counts at
+  // run_entries[...] (a block's dictionary may be shorter than the radix the cells are laid out for); block b's coefficients at
+  // coef + b * coef_words, hcoef + b * hcoef_words.  nullptr: one stripe, the dictionaries of the DevConfig.
+  const long long *run_dicts;
+  const int *run_entries;
+  long long coef_words, hcoef_words;
+  int num_blocks;   // (1 for one stripe)
 };
 constexpr int kFacDirectRows = 8;
 constexpr int kFacDirectTile = kABlock * kFacDirectRows;
@@ -91,12 +98,25 @@ struct FactoredDirectArgs {
   const double *carrier;
   int S, cells, hist_words;
 };
+// A run of blocks through the direct kernel (qsx_agg_update_coded_blocks_sized): every block has its own stripes, filter and
+// DICTIONARIES (the reference builds one per block, storage/CompressedBlockBuilder.cpp:300-368), so the cells of a workgroup
+// mean something else in every block: a workgroup takes a CONTIGUOUS range of the run's tiles and flushes its cells with the
+// block's coefficients whenever it moves on to another block (1-3 flushes per workgroup at 4 workgroups per CU over 2 K blocks).
+struct FactoredRunArgs {
+  const long long *run;          // the call's block run table (agg_common.hpp BlockRunView: rows, stripes, filters)
+  const long long *first_tile;   // [num_blocks + 1]: direct tiles before block b — rows / kFacDirectTile full ones and one for a tail
+  long long total_tiles;
+  int num_blocks;
+  int key_col[2], cell_col[2], hist_col, car_col;   // the state's column behind every stripe the kernel reads
+  const unsigned long long *coef, *hcoef;           // block b: coef + b * coef_words, hcoef + b * hcoef_words
+  long long coef_words, hcoef_words;
+};
 // Launchers (agg_factored.hip: the kernels live in a translation unit of their own).
-int launch_factored_coef(const DevConfig &dc, const FactoredCoefArgs &ca, hipStream_t s);
+int launch_factored_coef(const DevConfig &dc, const FactoredCoefArgs &ca, hipStream_t s, int num_blocks = 1);
 int launch_factored_staged(const FactoredArgs &a, size_t lds_bytes, int per_cu, int64_t n, const uint64_t *filter_dev, const HashTableView &g, hipStream_t s);
 // false: the signature is not one of the instantiated ones (nothing was launched)
 bool launch_factored_direct(const FactoredArgs &a, const FactoredArgs *a_dev, const FactoredDirectArgs &da, int key_width, size_t lds_bytes, int grid, int64_t n,
-                            const uint64_t *filter_dev, const HashTableView &g, hipStream_t s);
+                            const uint64_t *filter_dev, const HashTableView &g, hipStream_t s, const FactoredRunArgs *runs = nullptr);
 
 #ifndef __HIPCC_RTC__
 // ---- host: is the plan affine in its plain columns once the dictionary columns are fixed? ------------------------------

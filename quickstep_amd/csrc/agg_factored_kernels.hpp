@@ -21,18 +21,34 @@ __device__ inline long long factored_dict_int(const DevConfig &c, int col, int c
   const void *d = as_global(c.dicts[col]);
   return c.column_type[col] == QSX_INT ? static_cast<long long>(static_cast<const int32_t *>(d)[code]) : static_cast<const long long *>(d)[code];
 }
+// Element i of a small array that lives in registers: a chain of selects (indexing it with i would put the array into scratch
+// memory — the first form of the coefficient kernel moved ~2 KB of scratch per thread and block: 0.2 ms for 1860 blocks).
+template <int N>
+__device__ __forceinline__ double reg_pick(const double (&a)[N], int i) {
+  double r = a[0];
+#pragma unroll
+  for (int k = 1; k < N; ++k) r = i == k ? a[k] : r;
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void reg_put(double (&a)[N], int i, double v) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) a[k] = i == k ? v : a[k];
+}
 // The expression program over one assignment of column values (every node rounded on its own, like the row-wise
-// evaluation: -ffp-contract=off); returns the value of `arg`.
-__device__ inline double factored_eval(const DevConfig &c, const double (&vals)[QSX_MAX_COLUMNS], const DevOperand &arg) {
-  double temps[QSX_MAX_TEMPS];
+// evaluation: -ffp-contract=off): all temporaries at once — every aggregate argument is then one operand read.
+// c: the configuration in LDS.
+__device__ __forceinline__ double factored_operand(const DevConfig &c, const double (&vals)[QSX_MAX_COLUMNS], const double (&temps)[QSX_MAX_TEMPS],
+                                                   const DevOperand &o) {
+  if (o.kind == QSX_OPD_COLUMN) return reg_pick(vals, o.index);
+  if (o.kind == QSX_OPD_CONST) return c.consts[o.index];
+  return reg_pick(temps, o.index);
+}
+__device__ inline void factored_eval_all(const DevConfig &c, const double (&vals)[QSX_MAX_COLUMNS], double (&temps)[QSX_MAX_TEMPS]) {
+#pragma unroll
   for (int t = 0; t < QSX_MAX_TEMPS; ++t) temps[t] = 0.0;
-  auto value = [&](const DevOperand &o) -> double {
-    if (o.kind == QSX_OPD_COLUMN) return vals[o.index];
-    if (o.kind == QSX_OPD_CONST) return c.consts[o.index];
-    return temps[o.index];
-  };
   for (int k = 0; k < c.num_instrs; ++k) {
-    const double a = value(c.instrs[k].a), b = value(c.instrs[k].b);
+    const double a = factored_operand(c, vals, temps, c.instrs[k].a), b = factored_operand(c, vals, temps, c.instrs[k].b);
     double r;
     switch (c.instrs[k].op) {
       case QSX_EX_ADD: r = a + b; break;
@@ -40,75 +56,127 @@ __device__ inline double factored_eval(const DevConfig &c, const double (&vals)[
       case QSX_EX_MUL: r = a * b; break;
       default: r = a / b; break;
     }
-    temps[c.instrs[k].dst] = r;
+    reg_put(temps, c.instrs[k].dst, r);
   }
-  return value(arg);
 }
-__global__ __launch_bounds__(kABlock) void factored_coef_kernel(DevConfig c_arg, FactoredCoefArgs a) {
+__global__ __launch_bounds__(kABlock) void factored_coef_kernel(DevConfig c_arg, FactoredCoefArgs a_all) {
   // (the configuration is indexed by thread-dependent values: from the kernel argument that is a private copy of all of it per
   // lane — 2.7 KB of scratch, 32 us for 600 threads; from LDS it is a handful of ds_reads)
   __shared__ DevConfig c;
+  __shared__ FactoredCoefArgs a_lds;           // (indexed by thread-dependent values like the configuration)
+  __shared__ int s_entries[QSX_MAX_COLUMNS];   // entries of this block's dictionaries (a run of blocks); kFacMaxDict otherwise
   {
     const unsigned int *src = reinterpret_cast<const unsigned int *>(&c_arg);
     unsigned int *dst = reinterpret_cast<unsigned int *>(&c);
     for (int i = threadIdx.x; i < static_cast<int>(sizeof(DevConfig) / 4); i += kABlock) dst[i] = src[i];
+    static_assert(sizeof(FactoredCoefArgs) % 4 == 0, "copied word by word");
+    const unsigned int *asrc = reinterpret_cast<const unsigned int *>(&a_all);
+    unsigned int *adst = reinterpret_cast<unsigned int *>(&a_lds);
+    for (int i = threadIdx.x; i < static_cast<int>(sizeof(FactoredCoefArgs) / 4); i += kABlock) adst[i] = asrc[i];
   }
   __syncthreads();
-  const int per_sum = a.cells + kFacMaxDict;
-  const int i = blockIdx.x * kABlock + threadIdx.x;
-  if (i >= a.nsums * per_sum) return;
-  const int j = i / per_sum, at = i % per_sum;
-  const bool is_int = c.sums[j].kind == kAccSumI64;
-  double vals[QSX_MAX_COLUMNS];
-  for (int col = 0; col < QSX_MAX_COLUMNS; ++col) vals[col] = 0.0;
-  if (at >= a.cells) {     // the histogram coefficients of sum j: H[j][code]
-    const int code = at - a.cells;
-    unsigned long long word = 0;
-    const int h = a.sum_hist[j];
-    if (h >= 0 && code < a.hist_size[h]) {
-      const int col = a.hist_col[h];
-      if (is_int) {
-        word = static_cast<unsigned long long>(factored_dict_int(c, col, code));
-      } else {
-        vals[col] = factored_dict_value(c, col, code);
-        word = static_cast<unsigned long long>(__double_as_longlong(factored_eval(c, vals, c.sums[j].arg)));
+  // (a code beyond the block's own dictionary does not occur in the block; its coefficient is that of the last entry)
+  auto clamped = [&](int col, int code) { return code < s_entries[col] ? code : s_entries[col] - 1; };
+  // One block's tables.  A run of blocks: workgroup row y takes blocks y, y + gridDim.y, ... — the configuration is copied to LDS
+  // once per workgroup, not once per block (a workgroup per block: 0.19 ms for the 1860 blocks of 600 M lineitems).
+  // A thread per cell and per dictionary code: the program runs once per assignment (plus once per carrier) and serves every
+  // sum of the state (a thread per (sum, cell) ran it eight times over for Q1).
+  auto one_block = [&](int blk) {
+    const FactoredCoefArgs &a = a_lds;
+    unsigned long long *const coef_b = a_all.coef + static_cast<size_t>(blk) * a_all.coef_words;
+    unsigned long long *const hcoef_b = a_all.hcoef + static_cast<size_t>(blk) * a_all.hcoef_words;
+    const int i = blockIdx.x * kABlock + threadIdx.x;
+    if (i >= a.cells + kFacMaxDict) return;
+    double vals[QSX_MAX_COLUMNS], temps[QSX_MAX_TEMPS];
+#pragma unroll
+    for (int col = 0; col < QSX_MAX_COLUMNS; ++col) vals[col] = 0.0;
+    if (i >= a.cells) {     // the histogram coefficients of every sum: H[j][code]
+      const int code = i - a.cells;
+      for (int j = 0; j < a.nsums; ++j) if (a.sum_hist[j] < 0) hcoef_b[j * kFacMaxDict + code] = 0;
+      for (int h = 0; h < a.nhist; ++h) {
+        const int col = a.hist_col[h];
+        const bool in_range = code < a.hist_size[h];
+        const double v = factored_dict_value(c, col, clamped(col, code));
+        reg_put(vals, col, v);
+        factored_eval_all(c, vals, temps);
+        for (int j = 0; j < a.nsums; ++j) {
+          if (a.sum_hist[j] != h) continue;
+          unsigned long long word;
+          if (c.sums[j].kind == kAccSumI64) {
+            word = static_cast<unsigned long long>(factored_dict_int(c, col, clamped(col, code)));
+          } else {
+            word = static_cast<unsigned long long>(__double_as_longlong(factored_operand(c, vals, temps, c.sums[j].arg)));
+          }
+          hcoef_b[j * kFacMaxDict + code] = in_range ? word : 0ull;
+        }
+        reg_put(vals, col, 0.0);
+      }
+      return;
+    }
+    const int cell = i;
+    int cell_code[kFacMaxCell] = {};
+#pragma unroll
+    for (int q = 0; q < kFacMaxCell; ++q) {
+      if (q >= a.ncell) break;
+      cell_code[q] = clamped(a.cell_col[q], (cell / a.cell_stride[q]) % a.cell_radix[q]);
+      reg_put(vals, a.cell_col[q], factored_dict_value(c, a.cell_col[q], cell_code[q]));
+    }
+    // every carrier 0: the part that multiplies the count; then one carrier at 1 and the others at 0
+    double temps_car[kFacMaxCarriers][QSX_MAX_TEMPS];
+    factored_eval_all(c, vals, temps);
+#pragma unroll
+    for (int k = 0; k < kFacMaxCarriers; ++k) {
+      if (k >= a.ncar) break;
+      reg_put(vals, a.car_col[k], 1.0);
+      factored_eval_all(c, vals, temps_car[k]);
+      reg_put(vals, a.car_col[k], 0.0);
+    }
+    for (int j = 0; j < a.nsums; ++j) {
+      unsigned long long *out = coef_b + static_cast<size_t>(j) * (1 + a.ncar) * a.cells;
+      if (a.sum_hist[j] >= 0) {   // depends on a histogram column only: nothing comes from the cells
+        for (int k = 0; k <= a.ncar; ++k) out[static_cast<size_t>(k) * a.cells + cell] = 0;
+        continue;
+      }
+      const DevOperand arg = c.sums[j].arg;
+      if (c.sums[j].kind == kAccSumI64) {
+        // SUM over an INT / LONG column: the cell's integer dictionary value times its count (a plain integer column is a
+        // carrier with an i64 plane and needs no coefficient, FactoredArgs::sum_car_int); COUNT-like sums of the constant: 1
+        long long v = 1;
+        if (arg.kind == QSX_OPD_COLUMN) {
+          v = 0;
+#pragma unroll
+          for (int q = 0; q < kFacMaxCell; ++q) {
+            if (q < a.ncell && a.cell_col[q] == arg.index) v = factored_dict_int(c, a.cell_col[q], cell_code[q]);
+          }
+        }
+        out[cell] = static_cast<unsigned long long>(v);
+        for (int k = 1; k <= a.ncar; ++k) out[static_cast<size_t>(k) * a.cells + cell] = 0;
+        continue;
+      }
+      const double a0 = factored_operand(c, vals, temps, arg);
+      out[cell] = static_cast<unsigned long long>(__double_as_longlong(a0));
+#pragma unroll
+      for (int k = 0; k < kFacMaxCarriers; ++k) {
+        if (k >= a.ncar) break;
+        // (the argument itself may be the carrier column: its value in this evaluation is 1)
+        const double with_k = arg.kind == QSX_OPD_COLUMN ? (arg.index == a.car_col[k] ? 1.0 : reg_pick(vals, arg.index))
+                                                         : factored_operand(c, vals, temps_car[k], arg);
+        out[static_cast<size_t>(k + 1) * a.cells + cell] = static_cast<unsigned long long>(__double_as_longlong(with_k - a0));
       }
     }
-    a.hcoef[j * kFacMaxDict + code] = word;
-    return;
-  }
-  const int cell = at;
-  unsigned long long *out = a.coef + static_cast<size_t>(j) * (1 + a.ncar) * a.cells;
-  if (a.sum_hist[j] >= 0) {   // depends on a histogram column only: nothing comes from the cells
-    for (int k = 0; k <= a.ncar; ++k) out[static_cast<size_t>(k) * a.cells + cell] = 0;
-    return;
-  }
-  int cell_code[kFacMaxCell] = {};
-  for (int q = 0; q < a.ncell; ++q) {
-    cell_code[q] = (cell / a.cell_stride[q]) % a.cell_radix[q];
-    vals[a.cell_col[q]] = factored_dict_value(c, a.cell_col[q], cell_code[q]);
-  }
-  if (is_int) {
-    // SUM over an INT / LONG column: the cell's integer dictionary value times its count (a plain integer column is a
-    // carrier with an i64 plane and needs no coefficient, FactoredArgs::sum_car_int); COUNT-like sums of the constant: 1
-    long long v = 1;
-    if (c.sums[j].arg.kind == QSX_OPD_COLUMN) {
-      v = 0;
-      for (int q = 0; q < a.ncell; ++q) {
-        if (a.cell_col[q] == c.sums[j].arg.index) v = factored_dict_int(c, a.cell_col[q], cell_code[q]);
+  };
+  for (int blk = blockIdx.y; blk < a_all.num_blocks; blk += gridDim.y) {
+    __syncthreads();   // the previous block's readers are done with the dictionary pointers
+    if (threadIdx.x < QSX_MAX_COLUMNS) {
+      s_entries[threadIdx.x] = kFacMaxDict;
+      if (a_all.run_dicts != nullptr) {
+        const size_t at = static_cast<size_t>(blk) * QSX_MAX_COLUMNS + threadIdx.x;
+        c.dicts[threadIdx.x] = reinterpret_cast<const void *>(static_cast<uintptr_t>(a_all.run_dicts[at]));
+        s_entries[threadIdx.x] = a_all.run_entries[at] > 0 ? a_all.run_entries[at] : 1;
       }
     }
-    out[cell] = static_cast<unsigned long long>(v);
-    for (int k = 1; k <= a.ncar; ++k) out[static_cast<size_t>(k) * a.cells + cell] = 0;
-    return;
-  }
-  const double a0 = factored_eval(c, vals, c.sums[j].arg);      // every carrier 0: the part that multiplies the count
-  out[cell] = static_cast<unsigned long long>(__double_as_longlong(a0));
-  for (int k = 0; k < a.ncar; ++k) {
-    vals[a.car_col[k]] = 1.0;
-    const double ak = factored_eval(c, vals, c.sums[j].arg) - a0;
-    vals[a.car_col[k]] = 0.0;
-    out[static_cast<size_t>(k + 1) * a.cells + cell] = static_cast<unsigned long long>(__double_as_longlong(ak));
+    __syncthreads();
+    one_block(blk);
   }
 }
 
@@ -136,7 +204,8 @@ __device__ __forceinline__ unsigned long long factored_carrier_word(unsigned lon
 // The workgroup's cells -> the state: a wave per group slot; every accumulator of the state is a dot product over the slot's
 // cells (coefficients from this call's dictionaries, factored_coef_kernel).
 __device__ __forceinline__ void factored_flush(const FactoredArgs &a, const unsigned long long *l_keys, const unsigned long long *l_plane,
-                                               const unsigned int *l_cnt, const unsigned int *l_hist, const HashTableView &g) {
+                                               const unsigned int *l_cnt, const unsigned int *l_hist, const HashTableView &g,
+                                               const unsigned long long *coef, const unsigned long long *hcoef) {
   const int S = a.S, cells = a.cells;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   for (int s = wave; s < S; s += kABlock / kWave) {
@@ -152,7 +221,7 @@ __device__ __forceinline__ void factored_flush(const FactoredArgs &a, const unsi
     rows_in_group = wave_reduce_add(rows_in_group);
     if (lane == 0) global_add(g, 0, gs, rows_in_group, kAccSumI64);
     for (int j = 0; j < a.nsums; ++j) {
-      const unsigned long long *cj = a.coef + static_cast<size_t>(j) * (1 + a.ncar) * cells;
+      const unsigned long long *cj = coef + static_cast<size_t>(j) * (1 + a.ncar) * cells;
       if (a.sum_kind[j] == kAccSumI64) {
         long long acc = 0;
         if (a.sum_car_int[j] >= 0) {
@@ -161,7 +230,7 @@ __device__ __forceinline__ void factored_flush(const FactoredArgs &a, const unsi
         } else if (a.sum_hist[j] >= 0) {
           const int h = a.sum_hist[j];
           const unsigned int *hist = l_hist + s * a.hist_words + a.hist_off[h];
-          for (int c = lane; c < a.hist_size[h]; c += kWave) acc += static_cast<long long>(a.hcoef[j * kFacMaxDict + c]) * static_cast<long long>(hist[c]);
+          for (int c = lane; c < a.hist_size[h]; c += kWave) acc += static_cast<long long>(hcoef[j * kFacMaxDict + c]) * static_cast<long long>(hist[c]);
         } else {
           for (int c = lane; c < cells; c += kWave) acc += static_cast<long long>(cj[c]) * static_cast<long long>(cnt[c]);
         }
@@ -173,7 +242,7 @@ __device__ __forceinline__ void factored_flush(const FactoredArgs &a, const unsi
           const int h = a.sum_hist[j];
           const unsigned int *hist = l_hist + s * a.hist_words + a.hist_off[h];
           for (int c = lane; c < a.hist_size[h]; c += kWave) {
-            acc += __longlong_as_double(static_cast<long long>(a.hcoef[j * kFacMaxDict + c])) * static_cast<double>(hist[c]);
+            acc += __longlong_as_double(static_cast<long long>(hcoef[j * kFacMaxDict + c])) * static_cast<double>(hist[c]);
           }
         } else {
           for (int c = lane; c < cells; c += kWave) {
@@ -198,13 +267,14 @@ __device__ __forceinline__ void factored_flush(const FactoredArgs &a, const unsi
 // One row that found no slot in the workgroup's table: its terms go straight to the state's table (a group the optimizer's
 // estimate did not foresee; slow and exact).  hist_code[h]: the row's code of histogram column h.
 __device__ __forceinline__ void factored_spill_row(const FactoredArgs &a, const HashTableView &g, unsigned long long code, int cell,
-                                                   const int (&hist_code)[kFacMaxHist], unsigned long long car0, unsigned long long car1) {
+                                                   const int (&hist_code)[kFacMaxHist], unsigned long long car0, unsigned long long car1,
+                                                   const unsigned long long *coef, const unsigned long long *hcoef) {
   const int cells = a.cells;
   const unsigned long long gs = global_find_or_insert(g, code);
   if (gs == ~0ull) return;
   global_add(g, 0, gs, 1ull, kAccSumI64);
   for (int j = 0; j < a.nsums; ++j) {
-    const unsigned long long *cj = a.coef + static_cast<size_t>(j) * (1 + a.ncar) * cells;
+    const unsigned long long *cj = coef + static_cast<size_t>(j) * (1 + a.ncar) * cells;
     const int h = a.sum_hist[j];
     int hc = 0;
     if (h >= 0) {
@@ -214,13 +284,13 @@ __device__ __forceinline__ void factored_spill_row(const FactoredArgs &a, const 
     if (a.sum_kind[j] == kAccSumI64) {
       long long inc = 0;
       if (a.sum_car_int[j] >= 0) inc = static_cast<long long>(a.sum_car_int[j] == 0 ? car0 : car1);
-      else if (h >= 0) inc = static_cast<long long>(a.hcoef[j * kFacMaxDict + hc]);
+      else if (h >= 0) inc = static_cast<long long>(hcoef[j * kFacMaxDict + hc]);
       else inc = static_cast<long long>(cj[cell]);
       global_add(g, j + 1, gs, static_cast<unsigned long long>(inc), kAccSumI64);
     } else {
       double inc = 0.0;
       if (h >= 0) {
-        inc = __longlong_as_double(static_cast<long long>(a.hcoef[j * kFacMaxDict + hc]));
+        inc = __longlong_as_double(static_cast<long long>(hcoef[j * kFacMaxDict + hc]));
       } else {
         inc = __longlong_as_double(static_cast<long long>(cj[cell]));
         if (a.ncar > 0 && a.car_int[0] == 0) {
@@ -412,12 +482,12 @@ __global__ __launch_bounds__(kABlock) void agg_factored_kernel(FactoredArgs a, i
         for (int h = 0; h < kFacMaxHist; ++h) {
           if (h < nhist) hist_code[h] = static_cast<int>(factored_read(tile, h_off[h], h_w[h], row));
         }
-        factored_spill_row(a, g, code[v], cell[v], hist_code, car[0][v], car[1][v]);
+        factored_spill_row(a, g, code[v], cell[v], hist_code, car[0][v], car[1][v], a.coef, a.hcoef);
       }
     }
   }
   __syncthreads();
-  factored_flush(a, l_keys, l_plane, l_cnt, l_hist, g);
+  factored_flush(a, l_keys, l_plane, l_cnt, l_hist, g, a.coef, a.hcoef);
 }
 
 // ---- the common signatures without LDS staging ------------------------------------------------------------------------
@@ -437,9 +507,12 @@ struct FactoredDirectTile {
   uint4 car[kCar ? 4 : 1];
   unsigned int live;                         // bit r: row r of the thread is inside the stripe and selected by the filter
 };
-template <bool kFilter, int KEYW, int NK, int NC, int NH, bool kCar>
-__global__ __launch_bounds__(kABlock) void agg_factored_direct_kernel(const FactoredArgs *__restrict__ a_dev, FactoredDirectArgs d, int64_t n,
-                                                                     const uint64_t *__restrict__ filter, HashTableView g) {
+// kRuns: the rows are a run of blocks (FactoredRunArgs); d's stripe pointers, `n` and `filter` then change from block to block
+// (kFilter says whether ANY block has a filter; a block's own pointer may be null).
+// (four waves per SIMD = four workgroups per CU: 128 registers; the single-stripe forms fit by themselves, the run forms are held to it)
+template <bool kFilter, int KEYW, int NK, int NC, int NH, bool kCar, bool kRuns = false>
+__global__ __launch_bounds__(kABlock, 4) void agg_factored_direct_kernel(const FactoredArgs *__restrict__ a_dev, FactoredDirectArgs d, int64_t n,
+                                                                     const uint64_t *__restrict__ filter, HashTableView g, FactoredRunArgs runs) {
   static_assert((KEYW == 1 || KEYW == 4) && NK >= 1 && NK <= 2 && NC >= 1 && NC <= 2 && NH >= 0 && NH <= 1, "instantiated signatures");
   extern __shared__ __align__(16) char lds[];
   const int S = d.S, cells = d.cells;
@@ -448,11 +521,14 @@ __global__ __launch_bounds__(kABlock) void agg_factored_direct_kernel(const Fact
   unsigned int *l_cnt = reinterpret_cast<unsigned int *>(l_plane + (kCar ? static_cast<size_t>(S) * cells : 0));
   unsigned int *l_hist = l_cnt + static_cast<size_t>(S) * cells;
   for (int i = threadIdx.x; i < S; i += kABlock) l_keys[i] = kEmptyCode;
-  if (kCar) for (int i = threadIdx.x; i < S * cells; i += kABlock) l_plane[i] = 0;
-  for (int i = threadIdx.x; i < S * cells + S * d.hist_words; i += kABlock) l_cnt[i] = 0;
+  auto clear_cells = [&]() {
+    if (kCar) for (int i = threadIdx.x; i < S * cells; i += kABlock) l_plane[i] = 0;
+    for (int i = threadIdx.x; i < S * cells + S * d.hist_words; i += kABlock) l_cnt[i] = 0;
+  };
+  clear_cells();
   __syncthreads();
+  const unsigned long long *coef = kRuns ? runs.coef : a_dev->coef, *hcoef = kRuns ? runs.hcoef : a_dev->hcoef;
   using Tile = FactoredDirectTile<KEYW, NK, NC, NH, kCar>;
-  const int64_t full_tiles = n / kFacDirectTile;          // the tail (< one tile) goes row by row below
   auto request = [&](int64_t tile, Tile &x) {
     const int64_t row = tile * kFacDirectTile + static_cast<int64_t>(threadIdx.x) * kFacDirectRows;
 #pragma unroll
@@ -472,7 +548,7 @@ __global__ __launch_bounds__(kABlock) void agg_factored_direct_kernel(const Fact
       for (int j = 0; j < 4; ++j) x.car[j] = stream_load16(d.carrier + row + 2 * j);
     }
     x.live = 0xFFu;
-    if (kFilter) {   // rows row .. row + 7 sit in one word (row is a multiple of 8): bit 63 - (row & 63) is the first of them
+    if (kFilter && (!kRuns || filter != nullptr)) {   // rows row .. row + 7 sit in one word (row is a multiple of 8): bit 63 - (row & 63) is the first of them
       const uint64_t w = load_global(&filter[row >> 6]);
       x.live = __brev(static_cast<unsigned int>((w >> (56 - (row & 63))) & 0xFFu)) >> 24;   // MSB-first -> bit r = row + r
     }
@@ -483,7 +559,7 @@ __global__ __launch_bounds__(kABlock) void agg_factored_direct_kernel(const Fact
   // (1) key code, cell, histogram code, carrier of every row from the registers; (2) the home slot of every code read from
   // the table, compared; a code that is not at home yet (first sight, or a collision) goes through the probing insert;
   // (3) the atomics.
-  auto consume = [&](const Tile &x, int64_t tile) {
+  auto consume = [&](const Tile &x) {
     unsigned long long code[kFacDirectRows];
     int cell[kFacDirectRows], hcode[kFacDirectRows], home[kFacDirectRows], slot[kFacDirectRows];
 #pragma unroll
@@ -537,23 +613,14 @@ __global__ __launch_bounds__(kABlock) void agg_factored_direct_kernel(const Fact
         if constexpr (NH > 0) atomicAdd(&l_hist[slot[r] * d.hist_words + hcode[r]], 1u);
       } else {
         const int hist_code[kFacMaxHist] = {hcode[r], 0, 0, 0};
-        factored_spill_row(*a_dev, g, code[r], cell[r], hist_code, carw, 0ull);
+        factored_spill_row(*a_dev, g, code[r], cell[r], hist_code, carw, 0ull, coef, hcoef);
       }
     }
-    (void)tile;
   };
-  Tile cur, nxt;
-  int64_t tile = blockIdx.x;
-  if (tile < full_tiles) request(tile, cur);
-  for (; tile < full_tiles; tile += gridDim.x) {
-    if (tile + gridDim.x < full_tiles) request(tile + gridDim.x, nxt);
-    consume(cur, tile);
-    cur = nxt;
-  }
-  // the tail of the stripe: fewer than kFacDirectTile rows, one per thread and step, by the workgroup that would own that tile
-  if (static_cast<int64_t>(blockIdx.x) == full_tiles % gridDim.x) {
-    for (int64_t row = full_tiles * kFacDirectTile + threadIdx.x; row < n; row += kABlock) {
-      if (kFilter && !msb_bit(load_global(&filter[row >> 6]), static_cast<int>(row & 63))) continue;
+  // rows [first, n) of the stripe, one per thread and step (the tail behind the stripe's last full tile)
+  auto row_by_row = [&](int64_t first) {
+    for (int64_t row = first + threadIdx.x; row < n; row += kABlock) {
+      if (kFilter && (!kRuns || filter != nullptr) && !msb_bit(load_global(&filter[row >> 6]), static_cast<int>(row & 63))) continue;
       unsigned long long code = 0;
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
@@ -583,12 +650,71 @@ __global__ __launch_bounds__(kABlock) void agg_factored_direct_kernel(const Fact
         if constexpr (NH > 0) atomicAdd(&l_hist[slot * d.hist_words + hc], 1u);
       } else {
         const int hist_code[kFacMaxHist] = {hc, 0, 0, 0};
-        factored_spill_row(*a_dev, g, code, cell, hist_code, carw, 0ull);
+        factored_spill_row(*a_dev, g, code, cell, hist_code, carw, 0ull, coef, hcoef);
       }
     }
+  };
+  // tiles lo, lo + step, ... below hi of the current stripe, the next one requested before the current one is consumed
+  auto full_tiles_of = [&](int64_t lo, int64_t hi, int64_t step) {
+    Tile cur, nxt;
+    int64_t tile = lo;
+    if (tile < hi) request(tile, cur);
+    for (; tile < hi; tile += step) {
+      if (tile + step < hi) request(tile + step, nxt);
+      consume(cur);
+      cur = nxt;
+    }
+  };
+  if constexpr (!kRuns) {
+    const int64_t full_tiles = n / kFacDirectTile;          // the tail (< one tile) goes row by row
+    full_tiles_of(blockIdx.x, full_tiles, gridDim.x);
+    if (static_cast<int64_t>(blockIdx.x) == full_tiles % gridDim.x) row_by_row(full_tiles * kFacDirectTile);   // by the workgroup that would own that tile
+    __syncthreads();
+    factored_flush(*a_dev, l_keys, l_plane, l_cnt, l_hist, g, coef, hcoef);
+  } else {
+    // this workgroup's share of the run: tiles [t0, t1) of the run's tile sequence, block by block
+    const BlockRunView run = block_run_view(runs.run, 1024);
+    int64_t t0 = runs.total_tiles * blockIdx.x / gridDim.x;
+    const int64_t t1 = runs.total_tiles * (blockIdx.x + 1) / gridDim.x;
+    long long b = 0;
+    {
+      long long lo = 0, hi = runs.num_blocks;   // first_tile[lo] <= t0 < first_tile[hi]
+      while (hi - lo > 1) {
+        const long long mid = (lo + hi) >> 1;
+        if (runs.first_tile[mid] <= t0) lo = mid; else hi = mid;
+      }
+      b = static_cast<long long>(wave_broadcast_first(static_cast<uint64_t>(lo)));
+    }
+    for (; t0 < t1; ++b) {
+      const int64_t block_first = static_cast<int64_t>(wave_broadcast_first(static_cast<uint64_t>(runs.first_tile[b]))),
+                    block_end = static_cast<int64_t>(wave_broadcast_first(static_cast<uint64_t>(runs.first_tile[b + 1])));
+      if (block_end <= t0) continue;   // (a block without tiles)
+      // (the block's stripes, filter, row count and coefficient tables are the same for every lane: in scalar registers — as
+      // loaded they sit in 2 vector registers each, 162 instead of 125 registers and a wave less per SIMD)
+      auto uniform = [](const void *p) { return reinterpret_cast<const void *>(static_cast<uintptr_t>(wave_broadcast_first(reinterpret_cast<uintptr_t>(p)))); };
+      const void *const *cols = run.cols + b * QSX_MAX_COLUMNS;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) d.key[k] = uniform(cols[runs.key_col[k]]);
+#pragma unroll
+      for (int q = 0; q < NC; ++q) d.cellc[q] = static_cast<const unsigned char *>(uniform(cols[runs.cell_col[q]]));
+      if constexpr (NH > 0) d.histc = static_cast<const unsigned char *>(uniform(cols[runs.hist_col]));
+      if constexpr (kCar) d.carrier = static_cast<const double *>(uniform(cols[runs.car_col]));
+      filter = kFilter && run.filters != nullptr ? static_cast<const uint64_t *>(uniform(run.filters[b])) : nullptr;
+      n = static_cast<int64_t>(wave_broadcast_first(static_cast<uint64_t>(run.rows[b])));
+      coef = runs.coef + b * runs.coef_words;
+      hcoef = runs.hcoef + b * runs.hcoef_words;
+      const int64_t lo = t0 - block_first, hi = (t1 < block_end ? t1 : block_end) - block_first;
+      const int64_t full_tiles = n / kFacDirectTile;
+      full_tiles_of(lo, hi < full_tiles ? hi : full_tiles, 1);
+      if (hi > full_tiles) row_by_row(full_tiles * kFacDirectTile);   // the block's tail tile is one of this workgroup's
+      __syncthreads();
+      factored_flush(*a_dev, l_keys, l_plane, l_cnt, l_hist, g, coef, hcoef);
+      __syncthreads();
+      clear_cells();       // the group codes stay: the next block's rows find their groups where they are
+      __syncthreads();
+      t0 = block_first + hi;
+    }
   }
-  __syncthreads();
-  factored_flush(*a_dev, l_keys, l_plane, l_cnt, l_hist, g);
 }
 
 }  // namespace qsx

@@ -2095,17 +2095,25 @@ static long long factored_min_rows() {
   const char *e = getenv("QSX_AGG_FACTORED_MIN_ROWS");
   return e != nullptr ? atoll(e) : 256ll * 1024;
 }
-// QSX_OK = the call was issued through the factored kernels; QSX_ERR_UNSUPPORTED = not this call (dictionary sizes unknown or
-// too large, the cells do not fit LDS): the caller goes on with the decoding kernels; anything else is an error.
-static int update_factored(qsx_agg_state *st, const void *const *cols, const void *const *dicts, const int32_t *entries, int64_t n,
-                           const uint64_t *filter_dev, hipStream_t s) {
+// The plan of a call through the factored kernels: everything but the coefficient tables' addresses.
+struct FactoredPlan {
+  FactoredArgs a{};
+  FactoredCoefArgs ca{};
+  FactoredDirectArgs da{};
+  size_t tile_bytes = 0, table_bytes = 0;
+  bool direct = false;   // one of the direct-load kernel's signatures (stripe alignment is the caller's to check)
+  int keyw = 0;
+};
+// cols / dicts: the stripes of the call (a run of blocks: of its first block); entries[column]: the radix of every dictionary
+// column (a run of blocks: the largest dictionary of the run).  QSX_ERR_UNSUPPORTED: not a call for these kernels.
+static int factored_plan(const qsx_agg_state *st, const void *const *cols, const void *const *dicts, const int32_t *entries, bool has_filter,
+                         FactoredPlan *plan) {
   const FactoredStatic &f = st->factored;
-  if (!f.ok || !factored_enabled() || dicts == nullptr || entries == nullptr || n < factored_min_rows()) return QSX_ERR_UNSUPPORTED;
   const DevConfig &d = st->dev;
   const int S = st->lds_slots;
   if (S < 1 || S > 64 || (S & (S - 1)) != 0 || st->lds_ranges != 1) return QSX_ERR_UNSUPPORTED;
-  FactoredArgs a{};
-  FactoredCoefArgs ca{};
+  FactoredArgs &a = plan->a;
+  FactoredCoefArgs &ca = plan->ca;
   size_t tile = 0;
   auto stage = [&](int col) {
     const int q = a.nstaged++;
@@ -2154,7 +2162,7 @@ static int update_factored(qsx_agg_state *st, const void *const *cols, const voi
     ca.car_col[k] = f.car_col[k];
   }
   a.filter_off = static_cast<int>(tile);
-  if (filter_dev != nullptr) tile += align16(kFacTileRows / 64 * 8);
+  if (has_filter) tile += align16(kFacTileRows / 64 * 8);
   a.tile_bytes = static_cast<int>(tile);
   a.S = S;
   a.nsums = ca.nsums = d.num_sums;
@@ -2163,14 +2171,80 @@ static int update_factored(qsx_agg_state *st, const void *const *cols, const voi
     a.sum_hist[j] = ca.sum_hist[j] = f.sum_hist[j];
     a.sum_car_int[j] = f.sum_car_int[j];
   }
-  const size_t table_bytes = align16(static_cast<size_t>(S) * 8 + static_cast<size_t>(a.ncar) * S * cells * 8 + static_cast<size_t>(S) * cells * 4 +
-                                     static_cast<size_t>(S) * a.hist_words * 4);
-  const size_t lds_bytes = table_bytes + tile;
-  if (lds_bytes > 64 * 1024) return QSX_ERR_UNSUPPORTED;     // (at least two workgroups per CU, or the tile copies run under nothing)
+  plan->tile_bytes = tile;
+  plan->table_bytes = align16(static_cast<size_t>(S) * 8 + static_cast<size_t>(a.ncar) * S * cells * 8 + static_cast<size_t>(S) * cells * 4 +
+                              static_cast<size_t>(S) * a.hist_words * 4);
+  // the direct-load kernel's signatures (agg_factored_direct_kernel)
+  bool direct = a.nkeys >= 1 && a.nkeys <= 2 && a.ncell >= 1 && a.ncell <= 2 && a.nhist <= 1 && a.ncar <= 1;
+  const int keyw = a.width[a.key_slot[0]];
+  direct = direct && (keyw == 1 || keyw == 4);
+  for (int k = 0; k < a.nkeys && direct; ++k) direct = a.width[a.key_slot[k]] == keyw;
+  for (int q = 0; q < a.ncell && direct; ++q) direct = a.width[a.cell_slot[q]] == 1;
+  for (int h = 0; h < a.nhist && direct; ++h) direct = a.width[a.hist_slot[h]] == 1;
+  if (a.ncar == 1) direct = direct && a.car_type[0] == QSX_DOUBLE && a.car_int[0] == 0;
+  plan->direct = direct && plan->table_bytes <= 60 * 1024;
+  plan->keyw = keyw;
+  FactoredDirectArgs &da = plan->da;
+  if (plan->direct) {
+    for (int k = 0; k < a.nkeys; ++k) {
+      da.key[k] = a.col[a.key_slot[k]];
+      da.key_shift[k] = a.key_shift[k];
+    }
+    for (int q = 0; q < a.ncell; ++q) {
+      da.cellc[q] = static_cast<const unsigned char *>(a.col[a.cell_slot[q]]);
+      da.cell_stride[q] = a.cell_stride[q];
+      da.cell_radix[q] = a.cell_radix[q];
+    }
+    if (a.nhist == 1) {
+      da.histc = static_cast<const unsigned char *>(a.col[a.hist_slot[0]]);
+      da.hist_size = a.hist_size[0];
+    }
+    if (a.ncar == 1) da.carrier = static_cast<const double *>(a.col[a.car_slot[0]]);
+    da.S = S;
+    da.cells = a.cells;
+    da.hist_words = a.hist_words;
+  }
+  return QSX_OK;
+}
+static int factored_workgroups_per_cu(size_t lds_bytes) {
+  int per_cu = static_cast<int>((160 * 1024) / (lds_bytes + 512));
+  per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);   // (measured on Q1: 3 / 4 / 5 / 6 workgroups per CU 1.78 / 1.73 / 1.79 / 1.86 ms per 600 M rows)
+  if (const char *e = getenv("QSX_AGG_FACTORED_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+  return per_cu;
+}
+// the stripes a direct-load kernel reads of one block: 16-byte aligned?
+static bool factored_direct_aligned(const FactoredPlan &plan, const qsx_agg_state *st, const void *const *cols) {
+  const FactoredStatic &f = st->factored;
+  auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  bool ok = true;
+  for (int k = 0; k < st->dev.num_keys; ++k) ok = ok && aligned16(cols[st->dev.key_column[k]]);
+  for (int q = 0; q < f.ncell; ++q) ok = ok && aligned16(cols[f.cell_col[q]]);
+  for (int h = 0; h < f.nhist; ++h) ok = ok && aligned16(cols[f.hist_col[h]]);
+  for (int k = 0; k < f.ncar; ++k) ok = ok && aligned16(cols[f.car_col[k]]);
+  (void)plan;
+  return ok;
+}
+
+// QSX_OK = the call was issued through the factored kernels; QSX_ERR_UNSUPPORTED = not this call (dictionary sizes unknown or
+// too large, the cells do not fit LDS): the caller goes on with the decoding kernels; anything else is an error.
+static int update_factored(qsx_agg_state *st, const void *const *cols, const void *const *dicts, const int32_t *entries, int64_t n,
+                           const uint64_t *filter_dev, hipStream_t s) {
+  const FactoredStatic &f = st->factored;
+  if (!f.ok || !factored_enabled() || dicts == nullptr || entries == nullptr || n < factored_min_rows()) return QSX_ERR_UNSUPPORTED;
+  const DevConfig &d = st->dev;
+  FactoredPlan plan;
+  int rc = factored_plan(st, cols, dicts, entries, filter_dev != nullptr, &plan);
+  if (rc != QSX_OK) return rc;
+  FactoredArgs &a = plan.a;
+  FactoredCoefArgs &ca = plan.ca;
+  const long long cells = a.cells;
+  const size_t lds_bytes = plan.table_bytes + plan.tile_bytes;
+  const bool direct = plan.direct && factored_direct_aligned(plan, st, cols);
+  if (!direct && lds_bytes > 64 * 1024) return QSX_ERR_UNSUPPORTED;     // (the staged kernel: at least two workgroups per CU, or the tile copies run under nothing)
   // coefficients: this call's dictionaries through the state's expression program
   CallScratch scratch(s);
   const size_t coef_bytes = static_cast<size_t>(d.num_sums) * (1 + a.ncar) * cells * 8, hcoef_bytes = static_cast<size_t>(d.num_sums) * kFacMaxDict * 8;
-  int rc = scratch.reserve(CallScratch::padded(coef_bytes) + CallScratch::padded(hcoef_bytes));
+  rc = scratch.reserve(CallScratch::padded(coef_bytes) + CallScratch::padded(hcoef_bytes));
   if (rc != QSX_OK) return rc;
   ca.coef = static_cast<unsigned long long *>(scratch.take(coef_bytes));
   ca.hcoef = static_cast<unsigned long long *>(scratch.take(hcoef_bytes));
@@ -2182,52 +2256,22 @@ static int update_factored(qsx_agg_state *st, const void *const *cols, const voi
   if (rc != QSX_OK) return rc;
   const HashTableView g = st->hash_view();
   // ---- the common signatures: rows by direct loads, no staging (agg_factored_direct_kernel) ----
-  {
-    bool direct = a.nkeys >= 1 && a.nkeys <= 2 && a.ncell >= 1 && a.ncell <= 2 && a.nhist <= 1 && a.ncar <= 1;
-    const int keyw = a.width[a.key_slot[0]];
-    direct = direct && (keyw == 1 || keyw == 4);
-    auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    for (int k = 0; k < a.nkeys && direct; ++k) direct = a.width[a.key_slot[k]] == keyw && aligned16(a.col[a.key_slot[k]]);
-    for (int q = 0; q < a.ncell && direct; ++q) direct = a.width[a.cell_slot[q]] == 1 && aligned16(a.col[a.cell_slot[q]]);
-    for (int h = 0; h < a.nhist && direct; ++h) direct = a.width[a.hist_slot[h]] == 1 && aligned16(a.col[a.hist_slot[h]]);
-    if (a.ncar == 1) direct = direct && a.car_type[0] == QSX_DOUBLE && a.car_int[0] == 0 && aligned16(a.col[a.car_slot[0]]);
-    const size_t direct_lds = table_bytes;
-    if (direct && direct_lds <= 60 * 1024) {
-      FactoredDirectArgs da{};
-      for (int k = 0; k < a.nkeys; ++k) {
-        da.key[k] = a.col[a.key_slot[k]];
-        da.key_shift[k] = a.key_shift[k];
-      }
-      for (int q = 0; q < a.ncell; ++q) {
-        da.cellc[q] = static_cast<const unsigned char *>(a.col[a.cell_slot[q]]);
-        da.cell_stride[q] = a.cell_stride[q];
-        da.cell_radix[q] = a.cell_radix[q];
-      }
-      if (a.nhist == 1) {
-        da.histc = static_cast<const unsigned char *>(a.col[a.hist_slot[0]]);
-        da.hist_size = a.hist_size[0];
-      }
-      if (a.ncar == 1) da.carrier = static_cast<const double *>(a.col[a.car_slot[0]]);
-      da.S = S;
-      da.cells = a.cells;
-      da.hist_words = a.hist_words;
-      // the flush and the spill path read the whole plan: behind a pointer (a kernarg segment beyond 512 bytes has cost this
-      // code base a factor before, DESIGN.md "Kernel arguments")
-      const FactoredArgs *a_dev = static_cast<const FactoredArgs *>(staged_device_buffer(s, sizeof(FactoredArgs)));
-      if (a_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
-      rc = staged_upload(s, &a, sizeof(FactoredArgs));
-      if (rc != QSX_OK) return rc;
-      int per_cu = static_cast<int>((160 * 1024) / (direct_lds + 512));
-      per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);   // (measured on Q1: 3 / 4 / 5 / 6 workgroups per CU 1.78 / 1.73 / 1.79 / 1.86 ms per 600 M rows)
-      if (const char *e = getenv("QSX_AGG_FACTORED_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-      const int64_t tiles = (n + kFacDirectTile - 1) / kFacDirectTile;
-      const int grid = static_cast<int>(tiles < static_cast<int64_t>(per_cu) * kCUs ? tiles : static_cast<int64_t>(per_cu) * kCUs);
-      const bool launched = launch_factored_direct(a, a_dev, da, keyw, direct_lds, grid, n, filter_dev, g, s);
-      if (launched) {
-        QSX_CHECK_LAUNCH();
-        g_factored_launches.fetch_add(1, std::memory_order_relaxed);
-        return QSX_OK;
-      }
+  if (direct) {
+    const size_t direct_lds = plan.table_bytes;
+    // the flush and the spill path read the whole plan: behind a pointer (a kernarg segment beyond 512 bytes has cost this
+    // code base a factor before, DESIGN.md "Kernel arguments")
+    const FactoredArgs *a_dev = static_cast<const FactoredArgs *>(staged_device_buffer(s, sizeof(FactoredArgs)));
+    if (a_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+    rc = staged_upload(s, &a, sizeof(FactoredArgs));
+    if (rc != QSX_OK) return rc;
+    const int per_cu = factored_workgroups_per_cu(direct_lds);
+    const int64_t tiles = (n + kFacDirectTile - 1) / kFacDirectTile;
+    const int grid = static_cast<int>(tiles < static_cast<int64_t>(per_cu) * kCUs ? tiles : static_cast<int64_t>(per_cu) * kCUs);
+    const bool launched = launch_factored_direct(a, a_dev, plan.da, plan.keyw, direct_lds, grid, n, filter_dev, g, s);
+    if (launched) {
+      QSX_CHECK_LAUNCH();
+      g_factored_launches.fetch_add(1, std::memory_order_relaxed);
+      return QSX_OK;
     }
   }
   // ---- any other signature: the staged kernel.  Slower than the decoding plan shapes as it stands (4.5 against 2.1 ms per
@@ -2235,7 +2279,7 @@ static int update_factored(qsx_agg_state *st, const void *const *cols, const voi
   // asked (QSX_AGG_FACTORED_GENERIC=1: the tests keep it exact for the day it is made fast). ----
   {
     const char *e = getenv("QSX_AGG_FACTORED_GENERIC");
-    if (e == nullptr || e[0] != '1') return QSX_ERR_UNSUPPORTED;
+    if (e == nullptr || e[0] != '1' || lds_bytes > 64 * 1024) return QSX_ERR_UNSUPPORTED;
   }
   int per_cu = static_cast<int>((160 * 1024) / (lds_bytes + 512));
   per_cu = per_cu > 8 ? 8 : per_cu;
@@ -2396,7 +2440,8 @@ int qsx_agg_update_nullable(qsx_agg_state_t *st, const void *const *cols, const 
 
 // block_dicts: the dictionaries of a state over compressed attributes, [block * num_columns + column] (nullptr otherwise).
 static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
-                             const void *const *block_dicts, const uint64_t *const *block_filters, qsx_stream_t stream) {
+                             const void *const *block_dicts, const uint64_t *const *block_filters, qsx_stream_t stream,
+                             const int32_t *block_entries = nullptr) {
   QSX_REQUIRE_DEVICE();
   if (st == nullptr || num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_cols == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
   // (nullable inputs carry per-block null bitmaps: one call per block, qsx_agg_update_nullable)
@@ -2439,9 +2484,74 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   tiles1024.push_back(tiles1024.back() + (rows.back() + 1023) / 1024);
   tiles512.push_back(tiles512.back() + (rows.back() + 511) / 512);
   const size_t nb = rows.size();
+  hipStream_t s = as_stream(stream);
+  int rc = maybe_grow(st);
+  if (rc != QSX_OK) return rc;
+  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
+  const int bounds_slot = !st->dense && st->dir_gids != 0 ? st->dir_bounds_slot(s) : -1;
+  // ---- aggregates factored through the dictionary codes (agg_factored.hpp), block by block: the caller brought every block's
+  // dictionary sizes, the plan is one of the direct-load kernel's signatures and every stripe is 16-byte aligned ----
+  FactoredPlan fplan;
+  bool factored = false;
+  std::vector<long long> fac_first_tile;
+  std::vector<int32_t> fac_entries;
+  if (block_entries != nullptr && block_dicts != nullptr && st->factored.ok && bounds_slot < 0 && factored_enabled() && total >= factored_min_rows()) {
+    const FactoredStatic &f = st->factored;
+    int32_t radix[QSX_MAX_COLUMNS] = {};
+    const void *first_dicts[QSX_MAX_COLUMNS] = {};
+    fac_entries.assign(nb * QSX_MAX_COLUMNS, 0);
+    factored = true;
+    size_t at = 0;
+    for (int b = 0; b < num_blocks && factored; ++b) {
+      if (block_rows[b] == 0) continue;
+      const void *const *bc = block_cols + static_cast<size_t>(b) * ncols;
+      auto dictionary_column = [&](int col) {
+        const int32_t e = block_entries[static_cast<size_t>(b) * ncols + col];
+        const void *dict = block_dicts[static_cast<size_t>(b) * ncols + col];
+        if (e < 0) rc = QSX_ERR_INVALID_ARGUMENT;
+        if (dict == nullptr || e < 1 || e > kFacMaxDict) factored = false;
+        radix[col] = e > radix[col] ? e : radix[col];
+        if (first_dicts[col] == nullptr) first_dicts[col] = dict;
+        fac_entries[at * QSX_MAX_COLUMNS + col] = e;
+      };
+      for (int q = 0; q < f.ncell; ++q) dictionary_column(f.cell_col[q]);
+      for (int h = 0; h < f.nhist; ++h) dictionary_column(f.hist_col[h]);
+      factored = factored && factored_direct_aligned(fplan, st, bc);
+      const uint64_t *bf = block_filters != nullptr ? block_filters[b] : nullptr;
+      factored = factored && (reinterpret_cast<uintptr_t>(bf) & 7) == 0;
+      ++at;
+    }
+    if (rc != QSX_OK) return rc;
+    if (factored) {
+      rc = factored_plan(st, first_cols, first_dicts, radix, any_filter, &fplan);
+      if (rc != QSX_OK && rc != QSX_ERR_UNSUPPORTED) return rc;
+      factored = rc == QSX_OK && fplan.direct;
+    }
+    if (factored) {
+      fac_first_tile.push_back(0);
+      for (size_t b = 0; b < nb; ++b) fac_first_tile.push_back(fac_first_tile.back() + (rows[b] + kFacDirectTile - 1) / kFacDirectTile);
+    }
+  }
+  // the coefficient tables of every block
+  CallScratch fac_scratch(s);
+  const size_t coef_words = factored ? static_cast<size_t>(st->dev.num_sums) * (1 + fplan.a.ncar) * fplan.a.cells : 0,
+               hcoef_words = factored ? static_cast<size_t>(st->dev.num_sums) * kFacMaxDict : 0;
+  if (factored && nb * (coef_words + hcoef_words) * 8 > (size_t(256) << 20)) factored = false;   // (a run of very many blocks over very many cells)
+  if (factored) {
+    rc = fac_scratch.reserve(CallScratch::padded(nb * coef_words * 8) + CallScratch::padded(nb * hcoef_words * 8));
+    if (rc != QSX_OK) return rc;
+    fplan.ca.coef = static_cast<unsigned long long *>(fac_scratch.take(nb * coef_words * 8));
+    fplan.ca.hcoef = static_cast<unsigned long long *>(fac_scratch.take(nb * hcoef_words * 8));
+    fplan.a.coef = fplan.ca.coef;      // (block 0's: the kernel takes every block's from FactoredRunArgs)
+    fplan.a.hcoef = fplan.ca.hcoef;
+  }
   const size_t off1024 = kBlockRunHeaderWords, off512 = off1024 + nb + 1, off_rows = off512 + nb + 1, off_cols = off_rows + nb,
                off_filters = off_cols + nb * QSX_MAX_COLUMNS, off_dicts = off_filters + nb,
-               words = off_dicts + (block_dicts != nullptr ? nb * QSX_MAX_COLUMNS : 0);
+               off_fac_tiles = off_dicts + (block_dicts != nullptr ? nb * QSX_MAX_COLUMNS : 0),
+               off_fac_entries = off_fac_tiles + (factored ? nb + 1 : 0),
+               off_fac_args = off_fac_entries + (factored ? nb * QSX_MAX_COLUMNS / 2 : 0),
+               words = off_fac_args + (factored ? (sizeof(FactoredArgs) + 7) / 8 : 0);
+  static_assert(QSX_MAX_COLUMNS % 2 == 0, "two int32 dictionary sizes per table word");
   table.resize(words);
   std::copy(dicts.begin(), dicts.end(), table.begin() + off_dicts);
   std::copy(tiles1024.begin(), tiles1024.end(), table.begin() + off1024);
@@ -2449,7 +2559,11 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   std::copy(rows.begin(), rows.end(), table.begin() + off_rows);
   std::copy(cols.begin(), cols.end(), table.begin() + off_cols);
   std::copy(filters.begin(), filters.end(), table.begin() + off_filters);
-  hipStream_t s = as_stream(stream);
+  if (factored) {
+    std::copy(fac_first_tile.begin(), fac_first_tile.end(), table.begin() + off_fac_tiles);
+    std::memcpy(&table[off_fac_entries], fac_entries.data(), fac_entries.size() * sizeof(int32_t));
+    std::memcpy(&table[off_fac_args], &fplan.a, sizeof(FactoredArgs));
+  }
   long long *dev_table = static_cast<long long *>(staged_device_buffer(s, words * sizeof(long long)));
   if (dev_table == nullptr) return QSX_ERR_OUT_OF_MEMORY;
   table[0] = kBlockRunMagic;
@@ -2468,14 +2582,45 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
     if (uniform && nb > 1 && (rows[nb - 1] + 1023) / 1024 > per_block) uniform = false;
     if (uniform) table[7] = per_block;
   }
-  int rc = staged_upload(s, table.data(), words * sizeof(long long));
+  rc = staged_upload(s, table.data(), words * sizeof(long long));
   if (rc != QSX_OK) return rc;
-  rc = maybe_grow(st);
-  if (rc != QSX_OK) return rc;
-  std::shared_lock<std::shared_mutex> lock(st->table_mutex);
+  if (factored) {
+    // (one staged table per call and stream: the run table, the kernel's tile index, the dictionary sizes and the plan travel together)
+    fplan.ca.run_dicts = dev_table + off_dicts;
+    fplan.ca.run_entries = reinterpret_cast<const int *>(dev_table + off_fac_entries);
+    fplan.ca.coef_words = static_cast<long long>(coef_words);
+    fplan.ca.hcoef_words = static_cast<long long>(hcoef_words);
+    rc = launch_factored_coef(st->dev, fplan.ca, s, static_cast<int>(nb));
+    if (rc != QSX_OK) return rc;
+    const FactoredStatic &f = st->factored;
+    FactoredRunArgs ra{};
+    ra.run = dev_table;
+    ra.first_tile = dev_table + off_fac_tiles;
+    ra.total_tiles = fac_first_tile.back();
+    ra.num_blocks = static_cast<int>(nb);
+    for (int k = 0; k < st->dev.num_keys && k < 2; ++k) ra.key_col[k] = st->dev.key_column[k];
+    for (int q = 0; q < f.ncell && q < 2; ++q) ra.cell_col[q] = f.cell_col[q];
+    ra.hist_col = f.nhist > 0 ? f.hist_col[0] : 0;
+    ra.car_col = f.ncar > 0 ? f.car_col[0] : 0;
+    ra.coef = fplan.ca.coef;
+    ra.hcoef = fplan.ca.hcoef;
+    ra.coef_words = static_cast<long long>(coef_words);
+    ra.hcoef_words = static_cast<long long>(hcoef_words);
+    const int per_cu = factored_workgroups_per_cu(fplan.table_bytes);
+    // (a workgroup flushes its cells once per block it touches: no more workgroups than tiles / 4)
+    const int64_t want = ra.total_tiles / 4 > 0 ? ra.total_tiles / 4 : 1;
+    const int grid = static_cast<int>(want < static_cast<int64_t>(per_cu) * kCUs ? want : static_cast<int64_t>(per_cu) * kCUs);
+    const FactoredArgs *a_dev = reinterpret_cast<const FactoredArgs *>(dev_table + off_fac_args);
+    // (kFilter of the kernel = some block of the run has a filter: any non-null pointer says so)
+    const uint64_t *filter_flag = any_filter ? first_filter : nullptr;
+    if (launch_factored_direct(fplan.a, a_dev, fplan.da, fplan.keyw, fplan.table_bytes, grid, total, filter_flag, st->hash_view(), s, &ra)) {
+      QSX_CHECK_LAUNCH();
+      g_factored_launches.fetch_add(1, std::memory_order_relaxed);
+      return publish_control(st, s);
+    }
+  }
   // one launch over the tiles of all blocks (a mid-size group count: the two passes of the group directory; the partition
   // pass wants one stripe per column, its group counts take the hash-range families here)
-  const int bounds_slot = !st->dense && st->dir_gids != 0 ? st->dir_bounds_slot(s) : -1;
   if (bounds_slot >= 0) {
     rc = update_directory(st, first_cols, nullptr, total, any_filter ? first_filter : nullptr, nullptr, dev_table, bounds_slot, s);
     if (rc != QSX_OK) return rc;
@@ -2497,6 +2642,15 @@ int qsx_agg_update_coded_blocks(qsx_agg_state_t *st, int num_blocks, const int64
   if (num_blocks > 0 && block_dictionaries == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   static const void *const no_dictionaries[1] = {nullptr};
   return agg_update_blocks(st, num_blocks, block_rows, block_cols, num_blocks > 0 ? block_dictionaries : no_dictionaries, block_filters, stream);
+}
+
+int qsx_agg_update_coded_blocks_sized(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
+                                      const void *const *block_dictionaries, const int32_t *block_dictionary_entries,
+                                      const uint64_t *const *block_filters, qsx_stream_t stream) {
+  if (num_blocks > 0 && block_dictionaries == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  static const void *const no_dictionaries[1] = {nullptr};
+  return agg_update_blocks(st, num_blocks, block_rows, block_cols, num_blocks > 0 ? block_dictionaries : no_dictionaries, block_filters, stream,
+                           num_blocks > 0 ? block_dictionary_entries : nullptr);
 }
 
 int qsx_agg_update_coded(qsx_agg_state_t *st, const void *const *cols, const void *const *dictionaries_dev, int64_t n,

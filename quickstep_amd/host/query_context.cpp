@@ -585,6 +585,7 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
   bool any_filter = false;
   std::vector<std::int64_t> coded_rows;
   std::vector<const void *> coded_cols, coded_dicts;
+  std::vector<std::int32_t> coded_entries;   // every block's dictionary sizes (the reference builds a dictionary per block)
   std::vector<const std::uint64_t *> coded_filters;
   bool any_coded_filter = false;
   const bool state_allows = state_ != nullptr && distinctify_.empty() && external_predicate_.conjuncts.empty();
@@ -628,6 +629,7 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
         const CompressedAttribute *ca = code_width[c] != 0 ? block.compressedAttribute(column_attr_[c]) : nullptr;
         coded_cols.push_back(ca != nullptr ? ca->codes : block.stripe(column_attr_[c]));
         coded_dicts.push_back(ca != nullptr && ca->kind == CompressedAttribute::kDictionary ? ca->dictionary : nullptr);
+        coded_entries.push_back(coded_dicts.back() != nullptr ? static_cast<std::int32_t>(ca->num_codes) : 0);
       }
       coded_filters.push_back(filter);
       any_coded_filter = any_coded_filter || filter != nullptr;
@@ -643,9 +645,10 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
     any_filter = any_filter || filter != nullptr;
   }
   if (!coded_rows.empty()) {
-    CheckStatus(qsx_agg_update_coded_blocks(coded_state_, static_cast<int>(coded_rows.size()), coded_rows.data(), coded_cols.data(),
-                                            coded_dicts.data(), any_coded_filter ? coded_filters.data() : nullptr, CurrentStream()),
-                "qsx_agg_update_coded_blocks");
+    CheckStatus(qsx_agg_update_coded_blocks_sized(coded_state_, static_cast<int>(coded_rows.size()), coded_rows.data(), coded_cols.data(),
+                                                  coded_dicts.data(), coded_entries.data(), any_coded_filter ? coded_filters.data() : nullptr,
+                                                  CurrentStream()),
+                "qsx_agg_update_coded_blocks_sized");
     coded_blocks_ += static_cast<int>(coded_rows.size());
     CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
   }

@@ -5,6 +5,7 @@
 // (truncation for small non-negative integers, dictionaries for few distinct values: CompressedBlockBuilder's choice).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "test_util.hpp"
@@ -147,6 +148,143 @@ Output run(const Lineitem &li, bool compressed, bool use_foreman) {
   }
   return out;
 }
+
+// ---- TPC-H Q1's shape over compressed blocks: aggregates factored through the dictionary codes, block by block ----------------
+// (csrc/agg_factored.hpp; benchmarks/tpch/queries/01.sql over create.sql:69-121).  Plain CHAR(1) keys, l_quantity and
+// l_discount dictionary-coded with a dictionary of ITS OWN in every block (storage/CompressedBlockBuilder.cpp:300-368): the
+// blocks draw their discounts from different value sets, so one code means different discounts from block to block.
+extern "C" long long qsx_debug_agg_factored_launches(void);   // test hook of libqsx.so (aggregate.hip)
+
+struct Q1Rows {
+  std::vector<char> flag, status;
+  std::vector<double> quantity, price, discount;
+  Q1Rows() {
+    std::uint64_t x = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (std::int64_t i = 0; i < kRows; ++i) {
+      const std::int64_t block = i / kBlockRows;
+      flag.push_back("ANR"[rnd() % 3]);
+      status.push_back("FO"[rnd() % 2]);
+      quantity.push_back(static_cast<double>(rnd() % (20 + 10 * block) + 1));                        // 20 / 30 / 40 / 50 entries
+      discount.push_back(static_cast<double>(rnd() % (4 + 2 * block) + static_cast<std::uint64_t>(block)) / 100.0);   // shifted value sets
+      price.push_back(900.0 + static_cast<double>(rnd() % 10000000) / 100.0);
+    }
+  }
+};
+struct Q1Group {
+  std::int64_t count = 0;
+  double sum_qty = 0, sum_price = 0, sum_disc_price = 0, avg_disc = 0;
+};
+
+std::vector<Q1Group> runQ1(const Q1Rows &rows, bool compressed, std::size_t blocks_per_work_order, bool use_foreman) {
+  CatalogRelation lineitem(1, "lineitem"), result(2, "result");
+  StorageManager storage;
+  lineitem.addAttribute("l_returnflag", Type::Char(1));
+  lineitem.addAttribute("l_linestatus", Type::Char(1));
+  for (const char *name : {"l_quantity", "l_extendedprice", "l_discount"}) lineitem.addAttribute(name, Type::Double());
+  const std::vector<bool> all(5, true);
+  for (std::int64_t at = 0; at < kRows; at += kBlockRows) {
+    storage.loadBlock(&lineitem, {rows.flag.data() + at, rows.status.data() + at, rows.quantity.data() + at, rows.price.data() + at,
+                                  rows.discount.data() + at}, kBlockRows, 0, compressed ? &all : nullptr);
+  }
+  if (compressed) {   // every block its own dictionaries
+    const auto ids = lineitem.getBlocksSnapshot();
+    BlockReference first = storage.getBlock(ids.front()), last = storage.getBlock(ids.back());
+    EXPECT_TRUE(first->compressedAttribute(2) != nullptr && first->compressedAttribute(2)->num_codes == 20);
+    EXPECT_TRUE(last->compressedAttribute(2) != nullptr && last->compressedAttribute(2)->num_codes == 50);
+    EXPECT_TRUE(first->compressedAttribute(4) != nullptr && first->compressedAttribute(4)->num_codes == 4);
+    EXPECT_TRUE(last->compressedAttribute(4) != nullptr && last->compressedAttribute(4)->num_codes == 10);
+    EXPECT_TRUE(first->compressedAttribute(3) == nullptr);
+  }
+  result.addAttribute("l_returnflag", Type::Char(1));
+  result.addAttribute("l_linestatus", Type::Char(1));
+  for (const char *name : {"sum_qty", "sum_price", "sum_disc_price", "avg_disc"}) result.addAttribute(name, Type::Double());
+  result.addAttribute("count", Type::Long());
+  QueryContext ctx;
+  const auto dest = ctx.addInsertDestination(&result, &storage);
+  AggregationStateSpec spec;
+  spec.input_relation = &lineitem;
+  spec.group_by = {0, 1};
+  const ScalarPtr disc_price = Scalar::Binary(BinaryOperationID::kMultiply, Scalar::Attribute(3),
+                                              Scalar::Binary(BinaryOperationID::kSubtract, Scalar::Literal(1.0), Scalar::Attribute(4)));
+  spec.aggregates = {AggregateSpec(AggregationID::kSum, 2), AggregateSpec(AggregationID::kSum, 3), AggregateSpec(AggregationID::kSum, disc_price),
+                     AggregateSpec(AggregationID::kAvg, 4), AggregateSpec(AggregationID::kCount, kInvalidAttributeID)};
+  spec.strategy = QSX_AGG_COMPACT_KEY;
+  spec.estimated_num_groups = 6;
+  const auto state = ctx.addAggregationState(spec);
+  auto *aggregate = new AggregationOperator(0, lineitem, true, state);
+  auto *finalize = new FinalizeAggregationOperator(0, state, 1, false, 1, result, dest);
+  aggregate->setBlocksPerWorkOrder(blocks_per_work_order);
+  const long long launches_before = qsx_debug_agg_factored_launches();
+  std::vector<std::unique_ptr<RelationalOperator>> owned;
+  if (use_foreman) {
+    QueryPlan plan;
+    const auto a = plan.addRelationalOperator(aggregate);
+    const auto z = plan.addRelationalOperator(finalize);
+    plan.addDirectDependency(z, a, true);
+    ForemanSingleNode foreman(&plan, &ctx, &storage, 4);
+    foreman.run();
+  } else {
+    for (RelationalOperator *op : {static_cast<RelationalOperator *>(aggregate), static_cast<RelationalOperator *>(finalize)}) {
+      owned.emplace_back(op);
+      fetchAndExecuteWorkOrders(op, &ctx, &storage);
+    }
+  }
+  const long long launches = qsx_debug_agg_factored_launches() - launches_before;
+  if (compressed) {
+    const long long work_orders = static_cast<long long>((kRows / kBlockRows + blocks_per_work_order - 1) / blocks_per_work_order);
+    EXPECT_EQ(launches, work_orders);           // every work order — a block, or a run of blocks — through the factored kernel
+    EXPECT_TRUE(ctx.getAggregationState(state, 0)->numBlocksAggregatedOnCodes() == kRows / kBlockRows);
+  } else {
+    EXPECT_EQ(launches, 0ll);
+  }
+  std::vector<Q1Group> out(6);
+  for (block_id b : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+    BlockReference blk = storage.getBlock(b);
+    const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+    std::vector<char> f(k), st(k);
+    std::vector<double> q(k), p(k), dp(k), ad(k);
+    std::vector<std::int64_t> cnt(k);
+    blk->copyAttributeToHost(0, f.data()); blk->copyAttributeToHost(1, st.data());
+    blk->copyAttributeToHost(2, q.data()); blk->copyAttributeToHost(3, p.data());
+    blk->copyAttributeToHost(4, dp.data()); blk->copyAttributeToHost(5, ad.data());
+    blk->copyAttributeToHost(6, cnt.data());
+    for (std::size_t i = 0; i < k; ++i) {
+      const std::size_t g = (f[i] == 'A' ? 0 : (f[i] == 'N' ? 1 : 2)) * 2 + (st[i] == 'F' ? 0 : 1);
+      out[g].count = cnt[i]; out[g].sum_qty = q[i]; out[g].sum_price = p[i]; out[g].sum_disc_price = dp[i]; out[g].avg_disc = ad[i];
+    }
+  }
+  return out;
+}
+
+void testQ1OverCompressedBlocks() {
+  setenv("QSX_AGG_FACTORED_MIN_ROWS", "0", 1);   // (a test relation of 200 K rows: the default keeps calls below 256 Ki rows on the decoding kernels)
+  const Q1Rows rows;
+  std::vector<Q1Group> want(6);
+  std::vector<double> disc_sum(6, 0.0);
+  for (std::int64_t i = 0; i < kRows; ++i) {
+    const std::size_t g = (rows.flag[i] == 'A' ? 0 : (rows.flag[i] == 'N' ? 1 : 2)) * 2 + (rows.status[i] == 'F' ? 0 : 1);
+    ++want[g].count;
+    want[g].sum_qty += rows.quantity[i];
+    want[g].sum_price += rows.price[i];
+    want[g].sum_disc_price += rows.price[i] * (1.0 - rows.discount[i]);
+    disc_sum[g] += rows.discount[i];
+  }
+  for (const int variant : {0, 1, 2, 3, 4, 5}) {
+    const bool compressed = variant != 0;
+    const std::size_t per_work_order = variant <= 1 ? 1 : (variant <= 3 ? 3 : 4);
+    const bool use_foreman = variant == 3 || variant == 5;
+    const std::vector<Q1Group> got = runQ1(rows, compressed, per_work_order, use_foreman);
+    for (std::size_t g = 0; g < 6; ++g) {
+      EXPECT_EQ(got[g].count, want[g].count);
+      EXPECT_TRUE(got[g].sum_qty == want[g].sum_qty);                       // integer-valued doubles: exact
+      EXPECT_NEAR(got[g].sum_price, want[g].sum_price, 1e-9 * want[g].sum_price);
+      EXPECT_NEAR(got[g].sum_disc_price, want[g].sum_disc_price, 1e-9 * want[g].sum_disc_price);
+      EXPECT_NEAR(got[g].avg_disc, disc_sum[g] / static_cast<double>(want[g].count), 1e-9);
+    }
+  }
+  unsetenv("QSX_AGG_FACTORED_MIN_ROWS");
+}
 }  // namespace
 
 int main() {
@@ -187,5 +325,6 @@ int main() {
       }
     }
   }
+  testQ1OverCompressedBlocks();
   return finish("compressed_block_operator_test");
 }

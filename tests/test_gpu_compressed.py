@@ -550,3 +550,75 @@ def test_factored_aggregation_by_direct_loads_matches_the_oracle(capi, oracle, d
     assert _factored_launches(capi) - before == 3, "the signature did not take the direct-load kernel"
     from test_gpu_agg import assert_same_groups, finalize_np
     assert_same_groups(finalize_np(st, dev), o.finalize())
+
+
+@pytest.mark.parametrize("key_kind", ["char", "int"])
+@pytest.mark.parametrize("shape", ["q1", "one_cell_no_histogram"])
+@pytest.mark.parametrize("groups,est", [(3, 6), (50, 2)])
+def test_factored_aggregation_over_a_run_of_blocks_with_their_own_dictionaries(capi, oracle, dev, key_kind, shape, groups, est, monkeypatch):
+    """qsx_agg_update_coded_blocks_sized: the reference compresses block by block (storage/CompressedBlockBuilder.cpp:300-368), so
+    one attribute's codes mean other values in every block — here every block draws its discounts, taxes and quantities from a
+    different subset, its dictionaries differ in size and content.  The factored kernel (agg_factored_direct_kernel, run form)
+    walks a contiguous range of the run's tiles per workgroup and settles its per-code cells with the block's coefficient
+    tables at every block boundary.  Blocks of fewer rows than a tile, of exactly whole tiles, with tails that are no multiple
+    of 8; filters on some blocks only; more groups than the workgroup's table holds.  Against the oracle block by block."""
+    monkeypatch.setenv("QSX_AGG_FACTORED_MIN_ROWS", "0")
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", str(1 << 60))
+    monkeypatch.delenv("QSX_AGG_FACTORED_GENERIC", raising=False)
+    rng = np.random.default_rng(1300 + groups)
+    sizes = [2048 * 3 + 5, 300, 2048 * 9, 70_001, 517, 2048, 33_333, 2048 * 2 + 2047]
+    layout = ([(T.CHAR, 1), (T.CHAR, 1)] if key_kind == "char" else [(T.INT, None), (T.INT, None)]) + [(T.DOUBLE, None)] * 4
+    if shape == "q1":
+        spec, keys = _FACTORED_PLANS["q1"], [0, 1]
+    else:
+        spec = dict(instrs=[(T.EX_SUB, 0, T.const(0), T.col(4)), (T.EX_MUL, 1, T.col(3), T.temp(0))], consts=[1.0],
+                    aggs=[(T.AGG_SUM, T.temp(1)), (T.AGG_AVG, T.col(4)), (T.AGG_COUNT_STAR, None)])
+        keys = [0]
+    blocks, block_dicts, filters, host = [], [], [], []
+    widths = None
+    for b, n in enumerate(sizes):
+        if key_kind == "char":
+            letters = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", dtype=np.uint8)
+            k1, k2 = rng.choice(letters[:max(1, groups // 2)], size=n), rng.choice(letters[:2], size=n)
+        else:
+            k1 = (rng.integers(0, max(1, groups // 2), size=n) * 1009 - 5).astype(np.int32)
+            k2 = rng.integers(0, 2, size=n).astype(np.int32)
+        # every block its own subsets: dictionaries of 2 .. 50 / 11 / 9 entries whose code i is another value from block to block
+        qty_values = rng.choice(np.arange(1, 51), size=int(rng.integers(2, 51)), replace=False).astype(np.float64)
+        disc_values = rng.choice(np.arange(0, 11), size=int(rng.integers(2, 12)), replace=False) / 100.0
+        tax_values = rng.choice(np.arange(0, 9), size=int(rng.integers(2, 10)), replace=False) / 100.0
+        qty, disc, tax = rng.choice(qty_values, size=n), rng.choice(disc_values, size=n), rng.choice(tax_values, size=n)
+        price = np.round(rng.uniform(900, 105000, size=n), 2)
+        cols = [k1, k2, qty, price, disc, tax]
+        comp = {2: _coded(oracle, qty), 4: _coded(oracle, disc), 5: _coded(oracle, tax)}
+        w = [comp[i].code_width if i in comp else 0 for i in range(len(cols))]
+        widths = widths or w
+        assert w == widths
+        code_cols = [comp[i].codes if i in comp else cols[i] for i in range(len(cols))]
+        dicts = [comp[i].dictionary if i in comp else None for i in range(len(cols))]
+        filt = oracle.bitmap_from_bools(rng.random(n) < 0.6) if b % 3 == 1 else None
+        host.append((code_cols, dicts, n, filt))
+        blocks.append([to_dev(c, dev) for c in code_cols])
+        block_dicts.append([None if d is None else to_dev(d, dev) for d in dicts])
+        filters.append(None if filt is None else bitmap_dev(filt, dev))
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=keys, instrs=spec["instrs"], consts=spec["consts"], aggs=spec["aggs"],
+                            est_groups=est, code_widths=widths)
+    from test_gpu_agg import assert_same_groups, finalize_np
+    before = _factored_launches(capi)
+    st, o = capi.AggState(cfg), oracle.AggState(cfg)
+    st.update_coded_blocks(blocks, block_dicts, filters)               # some blocks filtered
+    st.update_coded_blocks(blocks[2:5], block_dicts[2:5])              # no filter at all
+    for code_cols, dicts, n, filt in host:
+        o.update_coded(code_cols, dicts, n, filter_bitmap=filt)
+    for code_cols, dicts, n, filt in host[2:5]:
+        o.update_coded(code_cols, dicts, n)
+    assert _factored_launches(capi) - before == 2, "the run did not take the factored kernel"
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+    # without the sizes the decoding kernels answer: same groups
+    st2 = capi.AggState(cfg)
+    st2.update_coded_blocks(blocks, block_dicts, filters, sized=False)
+    assert _factored_launches(capi) - before == 2
+    o2 = oracle.AggState(cfg)
+    for code_cols, dicts, n, filt in host:
+        o2.update_coded(code_cols, dicts, n, filter_bitmap=filt)
+    assert_same_groups(finalize_np(st2, dev), o2.finalize())

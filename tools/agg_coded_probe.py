@@ -71,6 +71,54 @@ def run_truncated():
 
 
 res["coded_without_dictionaries_ms"] = timed(run_truncated)
+# the same rows as the operators hand them over: a run of 4 MiB blocks (322 640 rows of 13 B), every block with dictionaries
+# of its own (qsx_agg_update_coded_blocks_sized; the reference compresses block by block)
+block_rows = int(os.environ.get("QSX_PROBE_BLOCK_ROWS", "322640"))
+run_blocks, run_dicts = [], []
+for lo in range(0, n, block_rows):
+    hi = min(n, lo + block_rows)
+    run_blocks.append([c[lo:hi] for c in cols_c])
+    run_dicts.append([None, None, qty_d.clone(), None, disc_d.clone(), tax_d.clone()])
+blocks_state = capi.AggState(coded_cfg)
+
+
+# (the argument arrays are built once: filling 1860 x 6 ctypes slots per call costs Python more than the launch takes)
+import ctypes as C  # noqa: E402
+nb, ncols = len(run_blocks), 6
+arg_rows = (C.c_int64 * nb)(*[b[0].numel() for b in run_blocks])
+arg_cols, arg_dicts, arg_entries = (C.c_void_p * (nb * ncols))(), (C.c_void_p * (nb * ncols))(), (C.c_int32 * (nb * ncols))()
+for i in range(nb):
+    for c in range(ncols):
+        arg_cols[i * ncols + c] = run_blocks[i][c].data_ptr()
+        d = run_dicts[i][c]
+        arg_dicts[i * ncols + c] = d.data_ptr() if d is not None else None
+        arg_entries[i * ncols + c] = d.numel() if d is not None else 0
+
+
+def update_run(state):
+    rc = capi.lib.qsx_agg_update_coded_blocks_sized(state._h, nb, arg_rows, arg_cols, arg_dicts, arg_entries, None, None)
+    assert rc == 0, rc
+
+
+def run_coded_blocks():
+    blocks_state.clear()
+    update_run(blocks_state)
+
+
+res["blocks"] = len(run_blocks)
+res["coded_blocks_ms"] = timed(run_coded_blocks)
+os.environ["QSX_AGG_FACTORED"] = "0"
+decoding_blocks = capi.AggState(coded_cfg)
+
+
+def run_decoding_blocks():
+    decoding_blocks.clear()
+    update_run(decoding_blocks)
+
+
+res["coded_blocks_decoding_kernels_ms"] = timed(run_decoding_blocks)
+os.environ.pop("QSX_AGG_FACTORED")
+bk, bv, _, bg = blocks_state.finalize(dev, capacity=16)
 ck, cv, _, cg = coded.finalize(dev, capacity=16)
 qty, disc, tax = qty_d[qty_c.long()], disc_d[disc_c.long()], tax_d[tax_c.long()]
 del qty_c, disc_c, tax_c
@@ -97,6 +145,12 @@ for a in range(len(pv)):
     order_x, order_y = torch.argsort(ck[0][:groups].long() * 256 + ck[1][:groups].long()), torch.argsort(pk[0][:groups].long() * 256 + pk[1][:groups].long())
     same = same and bool(torch.allclose(x[order_x], y[order_y], rtol=1e-9, atol=0))
 res["same_result_as_plain"] = same
+same_blocks = int(bg.item()) == groups
+for a in range(len(pv)):
+    x, y = bv[a][:groups].double(), pv[a][:groups].double()
+    order_x, order_y = torch.argsort(bk[0][:groups].long() * 256 + bk[1][:groups].long()), torch.argsort(pk[0][:groups].long() * 256 + pk[1][:groups].long())
+    same_blocks = same_blocks and bool(torch.allclose(x[order_x], y[order_y], rtol=1e-9, atol=0))
+res["blocks_same_result_as_plain"] = same_blocks
 res["coded_GBps_of_codes"] = 13 * n / res["coded_ms (13 B/row)"] / 1e6
 res["coded_rows_per_s"] = n / res["coded_ms (13 B/row)"] * 1e3
 res["plain_rows_per_s"] = n / res["plain_ms (34 B/row)"] * 1e3
