@@ -852,9 +852,10 @@ def secondary_q1_coded(ctx, args, threads):
                 assert bool(torch.allclose(x.double(), y.double(), rtol=1e-9, atol=0.0)), f"aggregate {a} over code stripes differs"
         checked = True
     st.close()
+    blocks = q1_coded_as_blocks(ctx, args, cols, dicts, (ck, cv, cg))
     out = {"workload": f"C3 Q1 aggregation over CompressedColumnStore lineitem: {n} rows, 13 B/row (l_quantity / l_discount / "
                        "l_tax 1-byte dictionary codes decoded in the kernel)",
-           "ms": ms, "ms_with_clear": ms_clear_update, "rows_per_s": n / ms * 1e3,
+           "ms": ms, "ms_with_clear": ms_clear_update, "rows_per_s": n / ms * 1e3, "blocks": blocks,
            "roofline": hbm_roofline("agg_factored_direct_kernel<false,1,2,2,1,true> (qsx_agg_update_coded_sized: the aggregates factored through the "
                                     "dictionary codes, csrc/agg_factored.hpp; the call also launches factored_coef_kernel, ~10 us)",
                                     13 * n, ms, algorithmic_bytes_per_row=13),
@@ -862,6 +863,57 @@ def secondary_q1_coded(ctx, args, threads):
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_q1_coded(args, threads)
     return out
+
+
+def q1_coded_as_blocks(ctx, args, cols, dicts, single):
+    """The same rows as the operators hand them over: a run of 4 MiB blocks (322 640 rows of 13 B), every block with dictionaries of
+    its own (the reference compresses block by block, storage/CompressedBlockBuilder.cpp:300-368) — one
+    qsx_agg_update_coded_blocks_sized call; the result must equal the single stripe's."""
+    import ctypes as C
+    dev, n = ctx.dev, args.agg_rows
+    rows_per_block = 322_640
+    starts = list(range(0, n, rows_per_block))
+    nb, ncols = len(starts), len(cols)
+    own = [[None if d is None else d.clone() for d in dicts] for _ in starts]
+    # (the argument arrays are built once: filling them is Python's time, not the call's)
+    a_rows = (C.c_int64 * nb)(*[min(n, lo + rows_per_block) - lo for lo in starts])
+    a_cols, a_dicts, a_entries = (C.c_void_p * (nb * ncols))(), (C.c_void_p * (nb * ncols))(), (C.c_int32 * (nb * ncols))()
+    for b, lo in enumerate(starts):
+        for c in range(ncols):
+            a_cols[b * ncols + c] = cols[c].data_ptr() + lo * cols[c].element_size()
+            d = own[b][c]
+            a_dicts[b * ncols + c] = d.data_ptr() if d is not None else None
+            a_entries[b * ncols + c] = d.numel() if d is not None else 0
+    st = capi.AggState(q1_coded_config())
+
+    def update():
+        rc = capi.lib.qsx_agg_update_coded_blocks_sized(st._h, nb, a_rows, a_cols, a_dicts, a_entries, None, None)
+        assert rc == 0, f"qsx_agg_update_coded_blocks_sized: {rc}"
+    st.clear()
+    update()
+    torch.cuda.synchronize()
+    ms = launches_ms(update, warm=1)
+    st.clear()
+    update()
+    bk, bv, _, bg = st.finalize(dev, capacity=16)
+    checked = False
+    if not args.no_check:
+        ck, cv, cg = single
+        g = int(cg.item())
+        assert int(bg.item()) == g, "groups of the run of blocks differ from the single stripe's"
+        ob = torch.argsort(bk[0][:g].long() * 256 + bk[1][:g].long())
+        oc = torch.argsort(ck[0][:g].long() * 256 + ck[1][:g].long())
+        for a in range(len(cv)):
+            x, y = bv[a][:g][ob], cv[a][:g][oc]
+            if a in (0, 7):
+                assert bool((x == y).all()), f"aggregate {a} over the run of blocks is not exact"
+            else:
+                assert bool(torch.allclose(x.double(), y.double(), rtol=1e-9, atol=0.0)), f"aggregate {a} over the run of blocks differs"
+        checked = True
+    st.close()
+    return {"blocks": nb, "rows_per_block": rows_per_block, "ms": ms, "frac": 13 * n / (ms * 1e-3) / 8e12, "checked": checked,
+            "call": "qsx_agg_update_coded_blocks_sized: one launch of factored_coef_kernel (every block's coefficient tables) and one of "
+                    "agg_factored_direct_kernel<...,runs>"}
 
 
 def cpu_baseline_q1_coded(args, threads):
@@ -1128,16 +1180,26 @@ def operators_leg(args, raw_value):
     exe = os.path.join(ROOT, "tests", "cpp", "bin", "headline_operators_bench")
     if not os.path.exists(exe):
         return {"error": "tests/cpp/bin/headline_operators_bench is not built (make -C quickstep_amd/host)"}
-    cmd = [exe, str(args.build_rows), str(args.probe_rows), str(args.agg_rows), str(args.steps), str(max(args.warmup, 4)),
-           str(args.operator_workers), str(args.blocks_per_work_order)]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    except subprocess.TimeoutExpired:
-        return {"error": "timed out"}
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if r.returncode != 0 or not lines:
-        return {"error": f"exit code {r.returncode}", "stderr": r.stderr[-1500:]}
-    out = json.loads(lines[-1])
+    def child(lineitem_store):
+        cmd = [exe, str(args.build_rows), str(args.probe_rows), str(args.agg_rows), str(args.steps), str(max(args.warmup, 4)),
+               str(args.operator_workers), str(args.blocks_per_work_order), str(lineitem_store)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        except subprocess.TimeoutExpired:
+            return {"error": "timed out"}
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"exit code {r.returncode}", "stderr": r.stderr[-1500:]}
+        return json.loads(lines[-1])
+    out = child(0)
+    if "error" in out:
+        return out
+    # the same step with lineitem as the reference's DDL stores it: CompressedColumnStore block images in the reference's layout,
+    # adopted in place; the aggregation reads 13 B/row and its aggregates are factored through every block's own dictionaries
+    coded = child(1)
+    if "rows_per_s" in coded:
+        coded["fraction_of_raw_abi_value"] = coded["rows_per_s"] / raw_value
+    out["compressed_lineitem"] = coded
     out["fraction_of_raw_abi_value"] = out["rows_per_s"] / raw_value
     out["note"] = ("the operators' join produces its output relation (one INT attribute from each side, written by the probe: "
                    "qsx_join_probe_project_blocks) where the raw-ABI step stops at the (probe_tid, build_tid) pairs: "

@@ -2212,10 +2212,16 @@ static int factored_workgroups_per_cu(size_t lds_bytes) {
   if (const char *e = getenv("QSX_AGG_FACTORED_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
   return per_cu;
 }
-// the stripes a direct-load kernel reads of one block: 16-byte aligned?
+// The stripes a direct-load kernel reads of one block.  The kernel reads 8 rows per thread with one 8- or 16-byte load per
+// stripe at whatever address the stripe starts: a reference block image keeps its stripes at offsets that are multiples of
+// the block's tuple capacity (storage/CompressedColumnStoreTupleStorageSubBlock.cpp:71-160), aligned to nothing.  gfx950 under
+// this stack serves unaligned global loads (tools/unaligned_probe.py: a DOUBLE stripe 1 byte off, code stripes 3 or 5
+// bytes off — same groups, 0.34-0.36 instead of 0.33 ms per 100 M Q1 rows).  QSX_AGG_FACTORED_ALIGNED_ONLY=1 restores the
+// 16-byte requirement (misaligned blocks then take the decoding kernels).
 static bool factored_direct_aligned(const FactoredPlan &plan, const qsx_agg_state *st, const void *const *cols) {
   const FactoredStatic &f = st->factored;
-  auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  static const bool aligned_only = [] { const char *e = getenv("QSX_AGG_FACTORED_ALIGNED_ONLY"); return e != nullptr && e[0] == '1'; }();
+  auto aligned16 = [](const void *p) { return !aligned_only || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   bool ok = true;
   for (int k = 0; k < st->dev.num_keys; ++k) ok = ok && aligned16(cols[st->dev.key_column[k]]);
   for (int q = 0; q < f.ncell; ++q) ok = ok && aligned16(cols[f.cell_col[q]]);
@@ -2452,6 +2458,15 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   std::vector<long long> table(kBlockRunHeaderWords);
   std::vector<long long> tiles1024, tiles512, rows, filters;
   std::vector<long long> cols, dicts;
+  {   // (a run of a few thousand blocks: the table is ~35 words per block; growing the vectors word by word showed in the call's time)
+    const size_t nb_max = static_cast<size_t>(num_blocks);
+    tiles1024.reserve(nb_max + 1);
+    tiles512.reserve(nb_max + 1);
+    rows.reserve(nb_max);
+    filters.reserve(nb_max);
+    cols.reserve(nb_max * QSX_MAX_COLUMNS);
+    if (block_dicts != nullptr) dicts.reserve(nb_max * QSX_MAX_COLUMNS);
+  }
   int64_t total = 0;
   bool any_filter = false;
   const void *first_cols[QSX_MAX_COLUMNS] = {};

@@ -13,7 +13,13 @@
 // The blocks are loaded from a handful of host templates (no 20 GB host copy of lineitem): every template block recurs
 // n / templates times, so the expected result of any number of blocks is known exactly (counts) or to rounding (sums).
 //
-// usage: headline_operators_bench [build_rows probe_rows agg_rows [steps warmup workers blocks_per_work_order]]
+// lineitem_store = 1: lineitem arrives as the reference stores it (benchmarks/tpch/create.sql:69-121): CompressedColumnStore blocks
+// sorted on l_shipdate, l_quantity / l_discount / l_tax as 1-byte dictionary codes with a dictionary per block — block IMAGES in
+// the reference's own layout (tests/cpp/block_image_util.hpp) adopted where they lie in device memory
+// (StorageManager::adoptBlockImage), the stripes at whatever byte offsets the layout gives them.  The aggregation then reads
+// 13 instead of 34 bytes per row and its aggregates are factored through the dictionary codes (csrc/agg_factored.hpp).
+//
+// usage: headline_operators_bench [build_rows probe_rows agg_rows [steps warmup workers blocks_per_work_order [lineitem_store]]]
 // prints one JSON line {"rows_per_s": ..., "ms_per_step": ..., ...}; exit code 0 only when every step's results check out.
 #include <algorithm>
 #include <chrono>
@@ -23,9 +29,12 @@
 #include <map>
 #include <tuple>
 
+#include "block_image_util.hpp"
 #include "test_util.hpp"
 
 using namespace quickstep;
+
+extern "C" long long qsx_debug_agg_factored_launches(void);   // test hook of libqsx.so (aggregate.hip)
 
 namespace {
 constexpr std::int64_t kBlockBytes = 4ll << 20;
@@ -55,6 +64,7 @@ int main(int argc, char **argv) {
   const int steps = argc > 4 ? std::atoi(argv[4]) : 5, warmup = argc > 5 ? std::atoi(argv[5]) : 2;
   const std::size_t workers = argc > 6 ? static_cast<std::size_t>(std::atoi(argv[6])) : 4;
   const std::size_t run_blocks = argc > 7 ? static_cast<std::size_t>(std::atoi(argv[7])) : 64;
+  const bool compressed_lineitem = argc > 8 && std::atoi(argv[8]) == 1;
 
   StorageManager storage;
   CatalogRelation customer(1, "customer"), orders(2, "orders"), lineitem(3, "lineitem");
@@ -63,6 +73,7 @@ int main(int argc, char **argv) {
   lineitem.addAttribute("l_returnflag", Type::Char(1));
   lineitem.addAttribute("l_linestatus", Type::Char(1));
   for (const char *n : {"l_quantity", "l_extendedprice", "l_discount", "l_tax"}) lineitem.addAttribute(n, Type::Double());
+  if (compressed_lineitem) lineitem.addAttribute("l_shipdate", Type::Int());   // the block's sort column (create.sql: SORT l_shipdate)
 
   // ---- customer: a permutation of [0, build_rows) in 4 MB blocks ----------------------------------------------------------
   const std::int64_t int_block = kBlockBytes / 4;
@@ -85,8 +96,27 @@ int main(int argc, char **argv) {
       storage.loadBlock(&orders, {tmpl[b % kTemplates].data()}, std::min(int_block, probe_rows - at));
     }
   }
-  // ---- lineitem: Q1 attributes, 4 MB = 123 361 rows of 34 bytes ---------------------------------------------------------------
-  const std::int64_t q1_block = kBlockBytes / 34;
+  // ---- lineitem: Q1 attributes, 4 MB = 123 361 rows of 34 bytes (plain) -----------------------------------------------------
+  // compressed: the rows a 4 MB CompressedColumnStore block holds at 13 + 4 bytes per tuple behind its header and dictionaries
+  std::vector<block_image::Coding> coding(7);
+  for (int a : {2, 4, 5}) {
+    coding[a].kind = block_image::Coding::kDictionary;
+    coding[a].code_width = 1;
+  }
+  std::int64_t q1_block = kBlockBytes / 34;
+  std::vector<void *> device_images;
+  if (compressed_lineitem) {   // (the capacity depends on the dictionaries' sizes only: ask the builder with a small block)
+    Q1Template t;
+    std::vector<std::int32_t> shipdate;
+    for (int i = 0; i < 4000; ++i) {
+      t.flag.push_back('A'); t.status.push_back('F'); t.qty.push_back(1.0 + i % 50); t.price.push_back(1000.0 + i);
+      t.disc.push_back((i % 11) / 100.0); t.tax.push_back((i % 9) / 100.0); shipdate.push_back(i);
+    }
+    std::int64_t capacity = 0;
+    (void)block_image::BuildCompressed(lineitem, {t.flag.data(), t.status.data(), t.qty.data(), t.price.data(), t.disc.data(), t.tax.data(), shipdate.data()},
+                                       std::vector<std::vector<bool>>(7), 4000, kBlockBytes, 6, coding, &capacity);
+    q1_block = capacity;
+  }
   std::vector<Q1Template> q1(kTemplates);
   std::vector<std::int64_t> q1_uses(kTemplates, 0);
   std::int64_t last_block_rows = 0;
@@ -106,17 +136,56 @@ int main(int argc, char **argv) {
         t.tax.push_back(static_cast<double>(rng.next() % 9) / 100.0);
       }
     }
+    // compressed: one image per template in device memory; every block of the relation is a device copy of its template's
+    std::vector<void *> template_images;
+    std::vector<std::int32_t> shipdate(static_cast<std::size_t>(q1_block));
+    for (std::int64_t i = 0; i < q1_block; ++i) shipdate[i] = static_cast<std::int32_t>(19920101 + i / 128);   // ascending: the sort column
+    auto build_image = [&](const Q1Template &t, std::int64_t rows) {
+      std::int64_t capacity = 0;
+      const std::vector<unsigned char> image = block_image::BuildCompressed(
+          lineitem, {t.flag.data(), t.status.data(), t.qty.data(), t.price.data(), t.disc.data(), t.tax.data(), shipdate.data()},
+          std::vector<std::vector<bool>>(7), rows, kBlockBytes, 6, coding, &capacity);
+      EXPECT_TRUE(capacity >= rows);
+      void *dev = nullptr;
+      CheckStatus(qsx_device_alloc(image.size(), &dev), "qsx_device_alloc");
+      CheckStatus(qsx_copy_to_device(dev, image.data(), image.size(), nullptr), "qsx_copy_to_device");
+      CheckStatus(qsx_stream_synchronize(nullptr), "qsx_stream_synchronize");
+      return dev;
+    };
+    if (compressed_lineitem) for (const Q1Template &t : q1) template_images.push_back(build_image(t, q1_block));
     int b = 0;
     for (std::int64_t at = 0; at < agg_rows; at += q1_block, ++b) {
       const Q1Template &t = q1[b % kTemplates];
       const std::int64_t rows = std::min(q1_block, agg_rows - at);
-      storage.loadBlock(&lineitem, {t.flag.data(), t.status.data(), t.qty.data(), t.price.data(), t.disc.data(), t.tax.data()}, rows);
+      if (compressed_lineitem) {
+        void *dev = nullptr;
+        if (rows == q1_block) {
+          CheckStatus(qsx_device_alloc(static_cast<std::size_t>(kBlockBytes), &dev), "qsx_device_alloc");
+          CheckStatus(qsx_copy_on_device(dev, template_images[b % kTemplates], static_cast<std::size_t>(kBlockBytes), nullptr), "qsx_copy_on_device");
+        } else {
+          dev = build_image(t, rows);
+        }
+        device_images.push_back(dev);
+        const block_id id = storage.adoptBlockImage(&lineitem, dev, static_cast<std::size_t>(kBlockBytes));
+        EXPECT_EQ(storage.getBlock(id)->numTuples(), rows);
+      } else {
+        storage.loadBlock(&lineitem, {t.flag.data(), t.status.data(), t.qty.data(), t.price.data(), t.disc.data(), t.tax.data()}, rows);
+      }
       if (rows == q1_block) {
         ++q1_uses[b % kTemplates];
       } else {
         last_block_rows = rows;
         last_template = b % kTemplates;
       }
+    }
+    CheckStatus(qsx_stream_synchronize(nullptr), "qsx_stream_synchronize");
+    for (void *p : template_images) qsx_device_free(p);
+    if (compressed_lineitem) {
+      BlockReference first = storage.getBlock(lineitem.getBlocksSnapshot().front());
+      EXPECT_TRUE(first->compressedAttribute(2) != nullptr && first->compressedAttribute(2)->kind == CompressedAttribute::kDictionary &&
+                  first->compressedAttribute(2)->num_codes == 50 && first->compressedAttribute(4) != nullptr &&
+                  first->compressedAttribute(4)->num_codes == 11 && first->compressedAttribute(5) != nullptr && first->compressedAttribute(5)->num_codes == 9);
+      EXPECT_TRUE(first->compressedAttribute(3) == nullptr && first->sortColumn() == 6);
     }
   }
   // expected Q1 groups from the templates
@@ -155,6 +224,7 @@ int main(int argc, char **argv) {
 
   double total_ms = 0.0, best_ms = 1e30;
   std::size_t work_orders = 0;
+  const long long factored_before = qsx_debug_agg_factored_launches();
   for (int it = 0; it < warmup + steps; ++it) {
     const auto t0 = std::chrono::steady_clock::now();
     QueryContext ctx;
@@ -267,10 +337,14 @@ int main(int argc, char **argv) {
   std::printf("{\"path\": \"operators (BuildHash / HashJoin / Aggregation / FinalizeAggregation under ForemanSingleNode)\", "
               "\"rows_per_s\": %.6g, \"ms_per_step\": %.4f, \"best_ms\": %.4f, \"steps\": %d, \"warmup\": %d, \"workers\": %zu, "
               "\"blocks_per_work_order\": %zu, \"block_bytes\": %lld, \"probe_blocks\": %lld, \"aggregate_blocks\": %lld, \"work_orders_per_step\": %zu, "
-              "\"build_rows\": %lld, \"probe_rows\": %lld, \"aggregate_rows\": %lld, \"checked\": %s}\n",
+              "\"build_rows\": %lld, \"probe_rows\": %lld, \"aggregate_rows\": %lld, \"lineitem_store\": \"%s\", \"lineitem_rows_per_block\": %lld, "
+              "\"factored_aggregation_launches_per_step\": %.1f, \"checked\": %s}\n",
               static_cast<double>(probe_rows + agg_rows) / (ms_per_step / 1e3), ms_per_step, best_ms, steps, warmup, workers, run_blocks,
               static_cast<long long>(kBlockBytes), static_cast<long long>((probe_rows + int_block - 1) / int_block),
               static_cast<long long>((agg_rows + q1_block - 1) / q1_block), work_orders, static_cast<long long>(build_rows),
-              static_cast<long long>(probe_rows), static_cast<long long>(agg_rows), g_failures == 0 ? "true" : "false");
+              static_cast<long long>(probe_rows), static_cast<long long>(agg_rows),
+              compressed_lineitem ? "CompressedColumnStore images (13 B/row aggregated, per-block dictionaries)" : "plain column stripes (34 B/row)",
+              static_cast<long long>(q1_block), static_cast<double>(qsx_debug_agg_factored_launches() - factored_before) / (warmup + steps),
+              g_failures == 0 ? "true" : "false");
   return g_failures == 0 ? 0 : 1;
 }

@@ -622,3 +622,61 @@ def test_factored_aggregation_over_a_run_of_blocks_with_their_own_dictionaries(c
     for code_cols, dicts, n, filt in host:
         o2.update_coded(code_cols, dicts, n, filter_bitmap=filt)
     assert_same_groups(finalize_np(st2, dev), o2.finalize())
+
+
+class _StripeAt:
+    """A stripe at an arbitrary byte address inside a device buffer (what a reference block image holds: offsets that are
+    multiples of the block's tuple capacity, aligned to nothing)."""
+
+    def __init__(self, values, shift, dev):
+        raw = np.ascontiguousarray(values).view(np.uint8).reshape(-1)
+        self.buffer = torch.zeros(raw.size + 64, dtype=torch.uint8, device=dev)
+        self.buffer[shift:shift + raw.size] = torch.from_numpy(raw.copy()).to(dev)
+        self.shift, self.rows = shift, len(values)
+
+    def data_ptr(self):
+        return self.buffer.data_ptr() + self.shift
+
+    def numel(self):
+        return self.rows
+
+
+@pytest.mark.parametrize("shifts", [(1, 3, 5, 7, 9, 11), (0, 0, 13, 4, 0, 6), (16, 8, 2, 1, 3, 15)])
+def test_factored_aggregation_reads_stripes_at_any_byte_address(capi, oracle, dev, shifts, monkeypatch):
+    """A reference CompressedColumnStore block keeps attribute stripes back to back at multiples of its tuple capacity
+    (storage/CompressedColumnStoreTupleStorageSubBlock.cpp:71-160): a DOUBLE stripe can start at an odd address.  The direct-load
+    factored kernel reads 8 rows per thread with 8- and 16-byte loads at whatever address that is — one stripe and a run of
+    blocks, every stripe shifted by another number of bytes.  Against the oracle."""
+    monkeypatch.setenv("QSX_AGG_FACTORED_MIN_ROWS", "0")
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", str(1 << 60))
+    rng = np.random.default_rng(77)
+    spec = _FACTORED_PLANS["q1"]
+    layout = [(T.CHAR, 1), (T.CHAR, 1)] + [(T.DOUBLE, None)] * 4
+    from test_gpu_agg import assert_same_groups, finalize_np
+    cfg = None
+    st = o = None
+    before = _factored_launches(capi)
+    blocks, block_dicts, keep = [], [], []
+    for n in (2048 * 5 + 77, 40_001, 2048 * 2):
+        letters = np.frombuffer(b"ANR", dtype=np.uint8)
+        cols = [rng.choice(letters, size=n), rng.choice(np.frombuffer(b"FO", dtype=np.uint8), size=n), rng.integers(1, 51, size=n).astype(np.float64),
+                np.round(rng.uniform(900, 105000, size=n), 2), rng.integers(0, 11, size=n) / 100.0, rng.integers(0, 9, size=n) / 100.0]
+        comp = {2: _coded(oracle, cols[2]), 4: _coded(oracle, cols[4]), 5: _coded(oracle, cols[5])}
+        widths = [comp[i].code_width if i in comp else 0 for i in range(6)]
+        if cfg is None:
+            cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0, 1], instrs=spec["instrs"], consts=spec["consts"], aggs=spec["aggs"],
+                                    est_groups=6, code_widths=widths)
+            st, o = capi.AggState(cfg), oracle.AggState(cfg)
+        code_cols = [comp[i].codes if i in comp else cols[i] for i in range(6)]
+        dicts = [comp[i].dictionary if i in comp else None for i in range(6)]
+        shifted = [_StripeAt(c, sh, dev) for c, sh in zip(code_cols, shifts)]
+        dev_dicts = [None if d is None else to_dev(d, dev) for d in dicts]
+        keep.append(shifted)
+        st.update_coded(shifted, dev_dicts, n)                       # one stripe
+        o.update_coded(code_cols, dicts, n)
+        blocks.append(shifted)
+        block_dicts.append(dev_dicts)
+        o.update_coded(code_cols, dicts, n)                          # (and once more as part of the run below)
+    st.update_coded_blocks(blocks, block_dicts)
+    assert _factored_launches(capi) - before == 4, "misaligned stripes did not take the factored kernel"
+    assert_same_groups(finalize_np(st, dev), o.finalize())

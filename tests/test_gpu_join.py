@@ -881,3 +881,41 @@ def test_probe_with_lip_filters_inside_equals_filter_then_probe(capi, oracle, de
     for f in lips:
         f.close()
     table.close()
+
+
+def test_first_probes_from_several_streams_wait_for_the_packed_table(capi, dev):
+    """A directly addressed table around the size of an XCD's L2 is packed to 3 bytes per key value by its FIRST probe
+    (join.hip sealed_pack), on that probe's stream.  Probes that other host threads issue at the same moment on their own
+    streams — the Workers' first HashJoin work orders behind a BuildHash (relational_operators/HashJoinOperator.cpp:220-231,
+    one work order per probe block) — must run behind the pack kernel whichever way they learn of it: seeing the table
+    already marked packed, or finding it packed when they get the mutex they waited for (that second way once let a probe
+    read the packed copy while it was being written: half a work order's rows were lost — seen once in some twenty runs of
+    twenty concurrent single-block work orders; the window is the first prober's critical section, so this test exercises
+    the path without promising to hit it)."""
+    import threading
+    n_build, n_probe, threads = 1_000_000, 1 << 20, 8
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    build = torch.randperm(n_build, device=dev, generator=g).to(torch.int32)
+    probes = [torch.randint(0, n_build, (n_probe,), device=dev, generator=g, dtype=torch.int32) for _ in range(threads)]
+    for _ in range(10):
+        table = capi.JoinTable(T.INT, n_build, key_range=(0, n_build - 1))
+        table.build(build)
+        torch.cuda.synchronize()                  # the pipeline breaker between BuildHash and HashJoin
+        start = threading.Barrier(threads)
+        counts = [None] * threads
+
+        def work(i):
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                start.wait()
+                c = table.probe_count(probes[i])
+                stream.synchronize()
+                counts[i] = int(c.item())
+        pool = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in pool:
+            t.start()
+        for t in pool:
+            t.join()
+        assert counts == [n_probe] * threads, counts
+        table.close()

@@ -134,6 +134,26 @@ def test_headline_workload_through_the_operator_boundary(exclusive_probes, cover
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("blocks_per_work_order", ["1", "16"])
+def test_headline_workload_over_compressed_lineitem_images(blocks_per_work_order):
+    """The same step with lineitem as the reference's TPC-H DDL stores it (benchmarks/tpch/create.sql:69-121): 4 MB
+    CompressedColumnStore block images in the reference's layout, sorted on l_shipdate, quantity / discount / tax as 1-byte
+    dictionary codes with a dictionary per block, adopted in place — stripes at whatever byte offsets the layout gives them.
+    The AggregationOperator's work orders (single blocks and runs of 16) all go through the factored kernels
+    (csrc/agg_factored.hpp); every step's groups are checked like the plain store's."""
+    import json
+    _ensure_built()
+    r = subprocess.run([os.path.join(BIN, "headline_operators_bench"), "1000000", "20000000", "60000000", "3", "1", "4", blocks_per_work_order, "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '"checked": true' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "CompressedColumnStore" in line["lineitem_store"]
+    work_orders = -(-line["aggregate_blocks"] // int(blocks_per_work_order))
+    # (a single block of 246 K rows stays below the factored kernels' default threshold of 256 Ki rows)
+    assert line["factored_aggregation_launches_per_step"] == (float(work_orders) if blocks_per_work_order != "1" else 0.0)
+
+
+@pytest.mark.gpu
 def test_reference_block_images_are_adopted_in_place():
     """Block images in the reference's layout ([int32 header length][StorageBlockHeader][{num_tuples, nulls_in_sort_column}]
     [null bitmaps][stripes at max_tuples x width]) copied to device memory as they are: Select / Aggregation / HashJoin over
