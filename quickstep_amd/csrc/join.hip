@@ -32,6 +32,7 @@
 #include <vector>
 #include <mutex>
 #include <shared_mutex>
+#include <type_traits>
 
 namespace qsx {
 
@@ -93,6 +94,31 @@ __device__ __forceinline__ uint32_t bucket_masks(const uint4 &w, uint32_t f) {
   const uint32_t empty = flags_to_nibble(zero_bytes(w.x)) | flags_to_nibble(zero_bytes(w.y)) << 4 | flags_to_nibble(zero_bytes(w.z)) << 8 |
                          flags_to_nibble(zero_bytes(w.w)) << 12;
   return same | empty << 16;
+}
+
+// ---- the COMPACT plane of a sealed bucketed table over INT keys (round 5) ------------------------------------------------------
+// What a probe that hits pays for is the slot line: 8-byte slots make 1 M keys a 10 MiB table no L2 holds.  The slot is 8
+// bytes because it stores the whole key — but the key's hash h = key * odd is a bijection of 32 bits, the bucket index is
+// hi32(h * buckets), and what is left of h inside a bucket, lo32(h * buckets), steps by `buckets` from one h to the next: with
+// more than 65 536 buckets id = lo32 * 65024 >> 32 (16 bits, < 65024) is different for every key of a bucket.  The first
+// probe after the builds (seal) therefore writes, slot for slot, a second plane: fingerprint byte = (id >> 8) + 1 (1..254;
+// 0 = empty, 255 = a key whose home is an earlier bucket), 4-byte slot = {id & 255 : 8, tuple id : 24} — bucket, fingerprint
+// and slot together ARE the key.  5 MiB + 1.25 MiB for 1 M keys.  A probe reads its home bucket there; a key that is not in
+// its home bucket although the bucket is full was displaced by the build: the probe walks on in the 8-byte table from the
+// next bucket, as before.  Only for tables without duplicate keys, tuple ids below 2^24, at least kCompactMinBuckets buckets.
+constexpr uint64_t kCompactMinBuckets = 66053;   // buckets * 65024 >= 2^32: ids of one bucket's keys differ
+struct CompactView {
+  const uint32_t *slots;        // [16 * buckets]
+  const unsigned char *fp;      // [16 * buckets]
+};
+struct CompactId {
+  uint32_t bucket, fp, low;
+};
+__device__ __forceinline__ CompactId compact_id(int32_t key, uint64_t buckets) {
+  const uint32_t h = static_cast<uint32_t>(key) * 0x9E3779B9u;   // (home_bucket's hash)
+  const uint64_t p = static_cast<uint64_t>(h) * buckets;
+  const uint32_t id = static_cast<uint32_t>((static_cast<uint64_t>(static_cast<uint32_t>(p)) * 65024ull) >> 32);
+  return CompactId{static_cast<uint32_t>(p >> 32), (id >> 8) + 1u, id & 0xFFu};
 }
 
 __device__ __forceinline__ bool row_in_filter(const uint64_t *filter, int64_t row) {
@@ -271,6 +297,26 @@ __global__ __launch_bounds__(kJBlock) void rehash_kernel(int is_long, TableView 
   }
 }
 
+// The compact plane from the sealed table, slot for slot (no atomics: slot s of the plane describes slot s of the table).
+__global__ __launch_bounds__(kJBlock) void compact_build_kernel(TableView t, uint32_t *__restrict__ cslots, unsigned char *__restrict__ cfp) {
+  const uint64_t s = static_cast<uint64_t>(blockIdx.x) * kJBlock + threadIdx.x;
+  if (s >= t.num_slots()) return;
+  unsigned char f = 0;
+  uint32_t packed = 0xFFFFFFFFu;
+  if (t.fp[s] != 0) {
+    const uint64_t e = static_cast<const uint64_t *>(t.slots)[s];
+    const CompactId id = compact_id(static_cast<int32_t>(static_cast<uint32_t>(e)), t.buckets);
+    if (id.bucket == static_cast<uint32_t>(s / kBucketSlots)) {
+      f = static_cast<unsigned char>(id.fp);
+      packed = (id.low << 24) | (static_cast<uint32_t>(e >> 32) & 0xFFFFFFu);
+    } else {
+      f = 0xFFu;     // a key displaced from an earlier bucket: occupies the slot, matches nothing
+    }
+  }
+  cfp[s] = f;
+  cslots[s] = packed;
+}
+
 // head[] -> the 3-byte copy the probes read (sealed_pack).  Entries beyond 23 bits cannot occur: the host checks the row
 // and overflow counts first.
 __global__ __launch_bounds__(kJBlock) void dense_pack_kernel(const uint32_t *__restrict__ head, uint64_t range, unsigned char *__restrict__ head3) {
@@ -392,12 +438,15 @@ struct SlotOf<int64_t> {
 //            matching fingerprint (nearly every probe that misses) read nothing;
 //   phase 3  key compare + emit; whatever is left — another slot under the same fingerprint (a false positive, or duplicate
 //            build keys), a home bucket without an empty byte (go on in the next bucket) — is walked by a wave-uniform loop.
-template <typename KeyT, int MODE, bool kRuns = false>
+// kCompact (INT keys): the home bucket is looked up in the table's compact plane (CompactView, above); whatever is not settled
+// there — a key displaced by the build — is walked in the 8-byte table from the next bucket on.
+template <typename KeyT, int MODE, bool kRuns = false, bool kCompact = false>
 __global__ __launch_bounds__(kJBlock) void probe_fp_kernel(
     TableView t, const KeyT *__restrict__ keys, int64_t n, int32_t probe_base_tid,
     const uint64_t *__restrict__ filter, int32_t *__restrict__ out_probe,
     int32_t *__restrict__ out_build, int64_t capacity, unsigned long long *__restrict__ out_count,
-    uint64_t *__restrict__ out_bitmap, int anti, const long long *__restrict__ runs = nullptr) {
+    uint64_t *__restrict__ out_bitmap, int anti, const long long *__restrict__ runs = nullptr, CompactView cv = CompactView{}) {
+  static_assert(!kCompact || sizeof(KeyT) == 4, "the compact plane is for INT keys");
   using Key = KeyT;
   using Slot = SlotOf<KeyT>;
   using Raw = typename Slot::Raw;
@@ -464,56 +513,125 @@ __global__ __launch_bounds__(kJBlock) void probe_fp_kernel(
     uint32_t bucket[kRowsPerThread], masks[kRowsPerThread];
     {
       uint4 w[kRowsPerThread];
+      const uint4 *__restrict__ plane = kCompact ? reinterpret_cast<const uint4 *>(cv.fp) : fp_words;
 #pragma unroll
       for (int r = 0; r < kRowsPerThread; ++r) {
-        bucket[r] = static_cast<uint32_t>(home_bucket(key[r], t));
-        w[r] = fp_words[live[r] ? bucket[r] : 0u];
+        if constexpr (kCompact) bucket[r] = compact_id(key[r], t.buckets).bucket; else bucket[r] = static_cast<uint32_t>(home_bucket(key[r], t));
+        w[r] = plane[live[r] ? bucket[r] : 0u];
       }
 #pragma unroll
-      for (int r = 0; r < kRowsPerThread; ++r) masks[r] = live[r] ? bucket_masks(w[r], fingerprint(key[r])) : 0x10000u;   // dead: nothing, "empty seen"
+      for (int r = 0; r < kRowsPerThread; ++r) {
+        uint32_t f;
+        if constexpr (kCompact) f = compact_id(key[r], t.buckets).fp; else f = fingerprint(key[r]);
+        masks[r] = live[r] ? bucket_masks(w[r], f) : 0x10000u;   // dead: nothing, "empty seen"
+      }
     }
     // phase 2: the slot under the first matching fingerprint
-    Raw first[kRowsPerThread];
+    using First = typename std::conditional<kCompact, uint32_t, Raw>::type;
+    First first[kRowsPerThread];
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
       const uint32_t same = masks[r] & 0xFFFFu;
-      first[r] = slots[same != 0u ? static_cast<uint64_t>(bucket[r]) * kBucketSlots + (__ffs(same) - 1) : 0ull];
+      const uint64_t at = same != 0u ? static_cast<uint64_t>(bucket[r]) * kBucketSlots + (__ffs(same) - 1) : 0ull;
+      if constexpr (kCompact) first[r] = cv.slots[at]; else first[r] = slots[at];
     }
-    // phase 3
+    // phase 3: the first candidate of every row
+    uint32_t walking = 0, found = 0;                    // bit r: row r of this thread
+    uint32_t in_plane = kCompact ? 0xFFFFu : 0u;        // bit r: still among the home bucket's entries of the compact plane
+    auto tid_of_row = [&](int r) { return static_cast<int32_t>(base_tid + tile_base + r * kJBlock + threadIdx.x); };
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
-      const int64_t row = tile_base + r * kJBlock + threadIdx.x;
-      const int32_t probe_tid = static_cast<int32_t>(base_tid + row);
-      uint32_t same = masks[r] & 0xFFFFu, empty = masks[r] >> 16;
-      bool hit = same != 0u && Slot::holds(first[r], key[r]);
-      bool found = hit;
-      if (MODE == 0) emit_match(sink, hit, probe_tid, Slot::tid(first[r]));
+      uint32_t same = masks[r] & 0xFFFFu;
+      const uint32_t empty = masks[r] >> 16;
+      bool hit;
+      int32_t hit_tid;
+      if constexpr (kCompact) {
+        hit = same != 0u && (first[r] >> 24) == compact_id(key[r], t.buckets).low;
+        hit_tid = static_cast<int32_t>(first[r] & 0xFFFFFFu);
+      } else {
+        hit = same != 0u && Slot::holds(first[r], key[r]);
+        hit_tid = Slot::tid(first[r]);
+      }
+      if (MODE == 0) emit_match(sink, hit, tid_of_row(r), hit_tid);
       if (MODE == 1) local_count += hit ? 1u : 0u;
+      found |= hit ? (1u << r) : 0u;
       same &= same - 1u;
+      masks[r] = same | (empty << 16);
       // done: one match of a duplicate-free table (or any match of an existence probe), or nothing else under this
       // fingerprint and the bucket still has room (its sequence ends here)
-      bool walking = live[r] && !(hit && (unique || MODE == 2)) && !(same == 0u && empty != 0u);
-      uint32_t b = bucket[r];
-      const uint32_t f = fingerprint(key[r]);
-      while (__any(walking)) {   // (wave-uniform: emit_match ballots)
-        if (walking && same == 0u) {   // this bucket is used up and was full: the next one
-          b = b + 1u == static_cast<uint32_t>(t.buckets) ? 0u : b + 1u;
-          const uint32_t m = bucket_masks(fp_words[b], f);
-          same = m & 0xFFFFu;
-          empty = m >> 16;
+      const bool more = live[r] && !(hit && (unique || MODE == 2)) && !(same == 0u && empty != 0u);
+      walking |= more ? (1u << r) : 0u;
+    }
+    // Whatever is left — another slot under the same fingerprint (a false positive, or duplicate build keys), a bucket without
+    // an empty byte (go on in the next bucket; a compact plane: a key the build displaced) — in ROUNDS over all rows of the
+    // thread: the fingerprint words of every row that moves on are read together, then the next candidate slots of every row.
+    // (Row by row — a wave-uniform loop per row — nearly every wave walked at least once per row, for one lane in twenty, and
+    // waited out two dependent reads each time: 16 x 2 round trips per tile instead of ~2 x 2.)
+    while (__any(walking != 0u)) {
+      uint32_t advance = 0;    // rows whose bucket is used up (and was full)
+#pragma unroll
+      for (int r = 0; r < kRowsPerThread; ++r) advance |= (((walking >> r) & 1u) != 0u && (masks[r] & 0xFFFFu) == 0u) ? (1u << r) : 0u;
+#pragma unroll
+      for (int half = 0; half < kRowsPerThread; half += 8) {
+        uint4 w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = half + j;
+          const bool adv = ((advance >> r) & 1u) != 0u;
+          if (adv) bucket[r] = bucket[r] + 1u == static_cast<uint32_t>(t.buckets) ? 0u : bucket[r] + 1u;
+          w[j] = fp_words[adv ? bucket[r] : 0u];
         }
-        const bool have = walking && same != 0u;
-        const Raw e = slots[have ? static_cast<uint64_t>(b) * kBucketSlots + (__ffs(same) - 1) : 0ull];
-        if (have) same &= same - 1u;
-        hit = have && Slot::holds(e, key[r]);
-        found = found || hit;
-        if (MODE == 0) emit_match(sink, hit, probe_tid, Slot::tid(e));
-        if (MODE == 1) local_count += hit ? 1u : 0u;
-        if (hit && (unique || MODE == 2)) walking = false;
-        if (same == 0u && empty != 0u) walking = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = half + j;
+          if (((advance >> r) & 1u) != 0u) masks[r] = bucket_masks(w[j], fingerprint(key[r]));
+        }
       }
-      if (MODE == 2) {
-        const bool bit = live[r] && (found != (anti != 0));
+      in_plane &= ~advance;    // (the next bucket is the 8-byte table's)
+#pragma unroll
+      for (int half = 0; half < kRowsPerThread; half += 8) {
+        Raw e[8];
+        uint32_t e4[kCompact ? 8 : 1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = half + j;
+          const uint32_t same = masks[r] & 0xFFFFu;
+          const bool have = ((walking >> r) & 1u) != 0u && same != 0u;
+          const bool plane_row = kCompact && ((in_plane >> r) & 1u) != 0u;
+          const uint64_t at = have ? static_cast<uint64_t>(bucket[r]) * kBucketSlots + (__ffs(same) - 1) : 0ull;
+          e[j] = slots[plane_row ? 0ull : at];
+          if constexpr (kCompact) e4[j] = cv.slots[plane_row ? at : 0ull];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = half + j;
+          uint32_t same = masks[r] & 0xFFFFu;
+          const uint32_t empty = masks[r] >> 16;
+          const bool is_walking = ((walking >> r) & 1u) != 0u;
+          const bool have = is_walking && same != 0u;
+          bool hit;
+          int32_t hit_tid;
+          if (kCompact && ((in_plane >> r) & 1u) != 0u) {
+            hit = have && (e4[kCompact ? j : 0] >> 24) == compact_id(key[r], t.buckets).low;
+            hit_tid = static_cast<int32_t>(e4[kCompact ? j : 0] & 0xFFFFFFu);
+          } else {
+            hit = have && Slot::holds(e[j], key[r]);
+            hit_tid = Slot::tid(e[j]);
+          }
+          if (have) same &= same - 1u;
+          masks[r] = same | (empty << 16);
+          found |= hit ? (1u << r) : 0u;
+          if (MODE == 0) emit_match(sink, hit, tid_of_row(r), hit_tid);
+          if (MODE == 1) local_count += hit ? 1u : 0u;
+          const bool done = (hit && (unique || MODE == 2)) || (same == 0u && empty != 0u);
+          if (is_walking && done) walking &= ~(1u << r);
+        }
+      }
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int r = 0; r < kRowsPerThread; ++r) {
+        const bool bit = live[r] && ((((found >> r) & 1u) != 0u) != (anti != 0));
         const uint64_t word = msb_first(__ballot(bit));
         if (lane == r) exists_word = word;
         if (lane == 0) local_count += __popcll(word);
@@ -658,8 +776,14 @@ struct qsx_join_table {
   // Hashed flavour: a directly addressed shadow of the entries, made by the first probe after the builds when the keys
   // turned out to span a small range (seal_table).  0 = not looked at since the last build / clear, 1 = stays hashed,
   // 2 = `shadow` answers the probes.
+  // 3 = stays hashed AND `compact` (the 4-byte plane of the slots, CompactView) is valid.
   std::mutex seal_mutex;
   std::atomic<int> seal_state{0};
+  void *compact = nullptr;          // [capacity] 4-byte slots, then [capacity] fingerprint bytes
+  uint64_t compact_capacity = 0;
+  CompactView compact_view() const {
+    return CompactView{static_cast<const uint32_t *>(compact), static_cast<const unsigned char *>(compact) + compact_capacity * 4};
+  }
   // Covering array of the projection last asked for (join_dense.hpp ProjectionView::cover; directly addressed tables):
   // cover_sig = what it was built for (column widths, build stripes, segment starts); cover_state 0 = none, 1 = this
   // projection cannot have one (duplicate keys, entries wider than 16 bytes, an ambiguous entry), 2 = valid.  A build or
@@ -970,6 +1094,7 @@ int qsx_join_table_destroy(qsx_join_table_t *t) {
   (void)device_free_idle(t->slots);
   (void)device_free_idle(t->head);
   (void)device_free_idle(t->head3);
+  (void)device_free_idle(t->compact);
   (void)device_free_idle(t->cover);
   if (t->pack_event != nullptr) (void)hipEventDestroy(t->pack_event);
   (void)device_free_idle(t->ov);
@@ -1106,6 +1231,9 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
 }  // extern "C"
 
 // Tables the probe kernels copy into LDS (join_lds.hpp); QSX_JOIN_LDS=0 keeps every lookup in HBM / L2.
+static std::atomic<long long> g_compact_probes{0};
+// Test hook (not part of include/qsx.h): probe launches this process has issued against a table's compact plane.
+extern "C" long long qsx_debug_join_compact_probes(void) { return g_compact_probes.load(std::memory_order_relaxed); }
 static bool lds_tables_enabled() {
   const char *e = getenv("QSX_JOIN_LDS");
   return e == nullptr || e[0] != '0';
@@ -1197,13 +1325,45 @@ static void sealed_pack(qsx_join_table *t, hipStream_t stream) {
   t->seal_state.store(2, std::memory_order_release);
 }
 
+static bool compact_enabled() {
+  const char *e = getenv("QSX_JOIN_COMPACT");   // (read per call: tests and tools compare the two forms)
+  return e == nullptr || e[0] != '0';
+}
+// The compact plane of a sealed bucketed table (CompactView; called under seal_mutex with the device idle): true = built.
+static bool seal_compact(qsx_join_table *t, bool duplicate_keys, hipStream_t stream) {
+  const uint64_t buckets = t->capacity / kBucketSlots;
+  if (!compact_enabled() || t->key_type != QSX_INT || duplicate_keys || buckets < kCompactMinBuckets || buckets > 0xFFFFFFFFull ||
+      t->max_tid.load() >= (1 << 24)) {
+    return false;
+  }
+  if (t->compact_capacity != t->capacity) {
+    (void)device_free(t->compact);
+    t->compact = nullptr;
+    t->compact_capacity = 0;
+    if (device_malloc(&t->compact, static_cast<size_t>(t->capacity) * 5 + 16) != hipSuccess) {
+      (void)hipGetLastError();
+      t->compact = nullptr;
+      return false;
+    }
+    t->compact_capacity = t->capacity;
+  }
+  hipLaunchKernelGGL(compact_build_kernel, dim3(static_cast<unsigned>((t->capacity + kJBlock - 1) / kJBlock)), dim3(kJBlock), 0, stream, t->view(),
+                     static_cast<uint32_t *>(t->compact), static_cast<unsigned char *>(t->compact) + t->capacity * 4);
+  // (synchronous: once per sealed table; probes of other streams find a finished plane)
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return true;
+}
+
 // probe_rows: the rows of the probe that asks (0: unknown).  A build side below kAdaptiveMinRows is only worth the look
 // (a device synchronisation, a copy of the control words) in front of a probe of a million rows or more — and then its
 // shadow, when the keys turn out dense, is a table the probe kernels hold in LDS (join_lds.hpp).
 static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream, int64_t probe_rows = 0) {
   int state = t->seal_state.load(std::memory_order_acquire);
   if (state == 2) return t->shadow;
-  if (state == 1 || !adaptive_enabled()) return nullptr;
+  if (state == 1 || state == 3 || !adaptive_enabled()) return nullptr;
   const bool small_build = t->reserved < kAdaptiveMinRows;
   if (small_build && (probe_rows < (1 << 20) || t->reserved < 1 || !lds_tables_enabled())) return nullptr;
   std::lock_guard<std::mutex> lock(t->seal_mutex);
@@ -1220,7 +1380,8 @@ static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream, int6
   const bool fits_lds = small_build && entries >= 1 && span < static_cast<uint64_t>(kLdsDenseMaxWords);
   if (v[4] == ~0ull || (entries < static_cast<uint64_t>(kAdaptiveMinRows) && !fits_lds) || (span >= 8 * entries && !fits_lds) ||
       span >= (1ull << 32) || entries > 0x7FFFFFFFull) {
-    t->seal_state.store(1, std::memory_order_release);
+    // stays hashed — behind the compact plane of its slots when the table is one that has it (v[2]: the duplicate-key flag)
+    t->seal_state.store(seal_compact(t, v[2] != 0, stream) ? 3 : 1, std::memory_order_release);
     return nullptr;
   }
   qsx_join_table *shadow = t->shadow;
@@ -1398,6 +1559,16 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
   const int64_t max_grid = MODE == 0 ? 4 * kCUs : 8 * kCUs;
   const int grid = static_cast<int>(num_tiles < max_grid ? num_tiles : max_grid);
   unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count);
+  if constexpr (MODE == 0 || MODE == 1 || MODE == 2) {
+    if (t->key_type == QSX_INT && t->seal_state.load(std::memory_order_acquire) == 3 && compact_enabled()) {
+      g_compact_probes.fetch_add(1, std::memory_order_relaxed);
+      hipLaunchKernelGGL((probe_fp_kernel<int32_t, MODE, kRuns, true>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
+                         static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,
+                         out_build, capacity, count, out_bitmap, anti, runs_dev, t->compact_view());
+      QSX_CHECK_LAUNCH();
+      return QSX_OK;
+    }
+  }
   if (t->key_type == QSX_INT) {
     hipLaunchKernelGGL((probe_fp_kernel<int32_t, MODE, kRuns>), dim3(grid), dim3(kJBlock), 0, stream, t->view(),
                        static_cast<const int32_t *>(keys), n, probe_base_tid, filter, out_probe,

@@ -919,3 +919,65 @@ def test_first_probes_from_several_streams_wait_for_the_packed_table(capi, dev):
             t.join()
         assert counts == [n_probe] * threads, counts
         table.close()
+
+
+def _compact_probes(capi):
+    import ctypes
+    capi.lib.qsx_debug_join_compact_probes.restype = ctypes.c_longlong
+    return capi.lib.qsx_debug_join_compact_probes()
+
+
+@pytest.mark.parametrize("case", ["unique", "duplicates", "large_tuple_ids", "too_few_buckets"])
+def test_big_bucketed_tables_are_probed_through_their_compact_plane(capi, oracle, dev, case, monkeypatch):
+    """join.hip CompactView: a sealed bucketed table over INT keys without a dense domain, without duplicate keys, with tuple
+    ids below 2^24 and more than 65 536 buckets gets a second plane of 4-byte slots {8 identity bits, tuple id} behind
+    fingerprints that are identity bits too — bucket + fingerprint + slot ARE the key (the hash is a bijection).  Probes read
+    their home bucket there and walk on in the 8-byte table only for keys the build displaced (3-4 % at load 0.8).
+    getAllFromValueAccessor's contract (storage/HashTable.hpp:2145-2181): pairs, counts, existence / anti, under a filter and
+    over a run of blocks — equal to the oracle, and to the same calls with QSX_JOIN_COMPACT=0.  Tables that must NOT take it
+    (duplicate keys, tuple ids of 2^24 and more, too few buckets) answer from the 8-byte slots as before."""
+    rng = np.random.default_rng(4100)
+    n_build = 900_000 if case != "too_few_buckets" else 700_000
+    keys = rng.choice(np.arange(-2**31, 2**31, 2311, dtype=np.int64), size=n_build, replace=False).astype(np.int32)   # sparse: no dense shadow
+    if case == "duplicates":
+        keys[1000:1010] = keys[:10]
+    base_tid = (1 << 24) if case == "large_tuple_ids" else 0
+    n_probe = 1_200_007
+    probe = np.where(rng.random(n_probe) < 0.6, rng.choice(keys, size=n_probe), rng.integers(-2**31, 2**31, size=n_probe)).astype(np.int32)
+    pf = oracle.bitmap_from_bools(rng.random(n_probe) < 0.7)
+    ot = oracle.JoinTable(T.INT, n_build)
+    ot.build(keys, block_id=0, base_tid=base_tid)
+    dp = to_dev(probe, dev)
+    answers = {}
+    for compact in ("1", "0"):
+        monkeypatch.setenv("QSX_JOIN_COMPACT", compact)
+        before = _compact_probes(capi)
+        table = capi.JoinTable(T.INT, n_build)
+        table.build(to_dev(keys, dev), base_tid=base_tid)
+        got = []
+        for filt in (None, pf):
+            fdev = None if filt is None else bitmap_dev(filt, dev)
+            rp, rb = ot.probe(probe, filter_bitmap=filt)
+            assert int(table.probe_count(dp, filter_bitmap=fdev).item()) == rp.size
+            p, b, cnt = table.probe(dp, capacity=rp.size, filter_bitmap=fdev)
+            assert int(cnt.item()) == rp.size
+            pairs = sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size])
+            assert np.array_equal(pairs, sorted_pairs(rp, rb))
+            want = np.zeros(n_probe, dtype=bool)
+            want[rp] = True
+            live = np.ones(n_probe, dtype=bool) if filt is None else oracle.bools_from_bitmap(filt, n_probe)
+            for anti in (False, True):
+                bm, c = table.probe_exists(dp, anti=anti, filter_bitmap=fdev)
+                ref = (want != anti) & live
+                assert np.array_equal(bitmap_np(bm), oracle.bitmap_from_bools(ref)) and int(c.item()) == int(ref.sum())
+            got.append(pairs)
+        cuts = [0, 4096, 300_001, n_probe]
+        blocks = [dp[a:b_] for a, b_ in zip(cuts[:-1], cuts[1:])]
+        rp, rb = ot.probe(probe)
+        assert int(table.probe_count_blocks(blocks).item()) == rp.size
+        launches = _compact_probes(capi) - before
+        assert (launches > 0) == (compact == "1" and case == "unique"), (case, compact, launches)
+        answers[compact] = got
+        table.close()
+    for a, b in zip(answers["1"], answers["0"]):
+        assert np.array_equal(a, b)
