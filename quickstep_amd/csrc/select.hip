@@ -1099,10 +1099,19 @@ static int dispatch_select_runs(int op, const long long *runs_dev, long long til
 // literal the way AsciiStringUncheckedComparator::strcmpHelper does (AsciiStringComparators.hpp:218-251): C strings
 // ending at the first NUL or at their maximum length, unsigned bytes, a proper prefix is smaller.
 // ---------------------------------------------------------------------------
+constexpr int kCharUnroll = 4;
+constexpr int kCharStripWords = 16 * 16 + 8;   // a wave's strip for one bitmap word of CHAR(16) rows, and the spare word
+constexpr size_t kCharDirectLds = static_cast<size_t>(kWavesPerBlock) * kCharUnroll * kCharStripWords * 4;
 struct CharLiteral {
   unsigned char bytes[QSX_MAX_CHAR_LITERAL];
   int length;   // bytes before the first NUL
 };
+// All ones up to (not including) the first zero byte of x (byte 0 = the lowest), all ones when there is none.  (The classic
+// zero-byte test flags bytes ABOVE a zero byte by mistake now and then; its lowest flag is always a true one.)
+__device__ __forceinline__ unsigned long long up_to_first_zero_byte(unsigned long long x) {
+  const unsigned long long z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+  return z != 0ull ? ((z & (0ull - z)) - 1ull) : ~0ull;
+}
 // One tile (rows [row0, row0 + tile_rows) of a stripe) of the CHAR comparison; lane 0 of every wave adds its words' bits to count.
 __device__ __forceinline__ void select_char_tile(const unsigned char *__restrict__ col, int width, int64_t n, int op, const CharLiteral &lit,
                                                  const uint64_t *__restrict__ filter, uint64_t *__restrict__ out, int64_t row0,
@@ -1111,58 +1120,104 @@ __device__ __forceinline__ void select_char_tile(const unsigned char *__restrict
   const int wave = threadIdx.x >> 6;
   const int rows = static_cast<int>(n - row0 < tile_rows ? n - row0 : tile_rows);
   if (width <= 16 && lit.length <= 16 && (reinterpret_cast<uintptr_t>(col) & 3) == 0) {
-    // short fields (c_mktsegment CHAR(10), l_shipmode CHAR(10), flags): no staging — a lane reads the 16 bytes from its row's
-    // first byte on as five aligned 4-byte loads straight from the stripe (neighbouring lanes share cache lines) and compares
-    // in registers.  Through LDS a workgroup pays load -> store -> barrier -> a byte-at-a-time walk per tile: 0.236 ms per
-    // 25 M CHAR(10) rows.
+    // short fields (c_mktsegment CHAR(10), l_shipmode CHAR(10), flags): no workgroup-wide staging, no barrier — wave by wave
+    // (below); a row is compared in registers, 16 bytes from its first byte on.  Through a tile in LDS a workgroup pays load ->
+    // store -> barrier -> a byte-at-a-time walk per tile: 0.236 ms per 25 M CHAR(10) rows.
     const uint32_t *stripe_words = reinterpret_cast<const uint32_t *>(col);
     const long long last_word = ((n * width + 3) >> 2) - 1;
-    constexpr int kUnroll = 4;   // bitmap words per wave and step: the loads of four rows per lane are in flight together
-    for (int w0 = wave * kUnroll; w0 * 64 < rows; w0 += kWavesPerBlock * kUnroll) {
-      uint32_t x[kUnroll][5];
-      int shift[kUnroll];
+    constexpr int kUnroll = kCharUnroll;   // bitmap words per wave and step: the loads of four rows per lane are in flight together
+    // The 64 rows of a bitmap word are 64 * width contiguous bytes from a 64-byte aligned offset of the stripe: the wave reads them
+    // with coalesced 4-byte loads (16 * width words: every cache line once) into a strip of LDS of its own and every lane
+    // picks its row's five words from there.  (Five 4-byte loads per lane straight from the stripe, at a lane stride of `width`
+    // bytes, touched every line five times over: 0.153 ms per 25 M CHAR(10) rows, a fifth of the HBM peak.)
+    uint32_t *const strips = reinterpret_cast<uint32_t *>(s_tile) + static_cast<size_t>(wave) * kUnroll * kCharStripWords;
+    const int strip_words = 16 * width + 1;   // (+ 1: a row's fifth word may lie behind the last row)
+    const unsigned long long width_mask_lo = width >= 8 ? ~0ull : ((1ull << (8 * width)) - 1ull);
+    const unsigned long long width_mask_hi = width >= 16 ? ~0ull : (width > 8 ? ((1ull << (8 * (width - 8))) - 1ull) : 0ull);
+    unsigned long long lit_first = 0, lit_second = 0;   // the literal's first / second eight bytes, big-endian, zero-padded
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const int r = (w0 + u) * 64 + lane;
-        const long long first_byte = (row0 + (r < rows ? r : 0)) * width;   // (a valid row either way; masked by r < rows below)
-        const long long w_at = first_byte >> 2;
-        shift[u] = static_cast<int>(first_byte & 3) * 8;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) x[u][k] = stripe_words[w_at + k <= last_word ? w_at + k : last_word];   // clamped: bytes past the row are masked
-      }
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const int w = w0 + u;
-        if (w * 64 >= rows) break;   // wave-uniform
-        const int r = w * 64 + lane;
-        const unsigned long long q0 = x[u][0] | (static_cast<unsigned long long>(x[u][1]) << 32), q1 = x[u][2] | (static_cast<unsigned long long>(x[u][3]) << 32);
-        const unsigned long long lo = shift[u] != 0 ? (q0 >> shift[u]) | (q1 << (64 - shift[u])) : q0;
-        const unsigned long long hi = shift[u] != 0 ? (q1 >> shift[u]) | (static_cast<unsigned long long>(x[u][4]) << (64 - shift[u])) : q1;
-        int res = 0;
-        bool decided = false;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const unsigned char a = i < width ? static_cast<unsigned char>((i < 8 ? lo : hi) >> (8 * (i & 7))) : 0;
-          const unsigned char b = i < lit.length ? lit.bytes[i] : 0;
-          if (!decided) {
-            if (a != b) {
-              res = a < b ? -1 : 1;
-              decided = true;
-            } else if (a == 0) {
-              decided = true;
+    for (int i = 0; i < 8; ++i) {
+      lit_first |= static_cast<unsigned long long>(i < lit.length ? lit.bytes[i] : 0) << (8 * (7 - i));
+      lit_second |= static_cast<unsigned long long>(8 + i < lit.length ? lit.bytes[8 + i] : 0) << (8 * (7 - i));
+    }
+    // words a row can touch from its first byte's word on: 2 (width <= 4), 3 (<= 8), 5 (<= 16) — also the rounds of 64 lanes
+    // that load a bitmap word's rows
+    auto rows_of_wave = [&](auto kw_tag) {
+      constexpr int KW = decltype(kw_tag)::value;
+      for (int w0 = wave * kUnroll; w0 * 64 < rows; w0 += kWavesPerBlock * kUnroll) {
+        uint32_t x[kUnroll][KW];
+        int shift[kUnroll];
+        {
+          uint32_t g[kUnroll][KW];   // strip_words <= 64 (KW - 1) + 1: KW rounds of 64 lanes
+  #pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            const long long w_base = ((row0 + static_cast<long long>(w0 + u) * 64) * width) >> 2;
+  #pragma unroll
+            for (int k = 0; k < KW; ++k) {
+              const long long at = w_base + k * 64 + lane;
+              g[u][k] = k * 64 + lane < strip_words ? stripe_words[at <= last_word ? at : last_word] : 0u;   // clamped: bytes past the stripe are masked
+            }
+          }
+  #pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+  #pragma unroll
+            for (int k = 0; k < KW; ++k) {
+              if (k * 64 + lane < strip_words) strips[u * kCharStripWords + k * 64 + lane] = g[u][k];
             }
           }
         }
-        const bool pred = r < rows && compare_op<int>(res, op, 0);
-        uint64_t word = msb_first(__ballot(pred));
-        const int64_t word_index = (row0 >> 6) + w;
-        if (filter != nullptr) word &= filter[word_index];
-        if (lane == 0) {
-          out[word_index] = word;
-          count += __popcll(word);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  #pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int first_byte = lane * width;   // inside the strip
+          shift[u] = (first_byte & 3) * 8;
+  #pragma unroll
+          for (int k = 0; k < KW; ++k) x[u][k] = strips[u * kCharStripWords + (first_byte >> 2) + k];
+        }
+        __builtin_amdgcn_wave_barrier();   // the strips are rewritten by the next step
+  #pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int w = w0 + u;
+          if (w * 64 >= rows) break;   // wave-uniform
+          const int r = w * 64 + lane;
+          const unsigned long long q0 = x[u][0] | (static_cast<unsigned long long>(x[u][1]) << 32);
+          unsigned long long lo, hi = 0;
+          if constexpr (KW == 5) {
+            const unsigned long long q1 = x[u][2] | (static_cast<unsigned long long>(x[u][3]) << 32);
+            lo = shift[u] != 0 ? (q0 >> shift[u]) | (q1 << (64 - shift[u])) : q0;
+            hi = shift[u] != 0 ? (q1 >> shift[u]) | (static_cast<unsigned long long>(x[u][4]) << (64 - shift[u])) : q1;
+          } else if constexpr (KW == 3) {   // width <= 8: the row ends inside the third word
+            lo = shift[u] != 0 ? (q0 >> shift[u]) | (static_cast<unsigned long long>(x[u][2]) << (64 - shift[u])) : q0;
+          } else {                          // width <= 4: inside the second
+            lo = q0 >> shift[u];
+          }
+          // strcmp on zero-padded 16-byte strings = an unsigned compare of their bytes read as one big-endian number: bytes from
+          // the field's width on and everything behind its first NUL are cleared (the literal's were, by the host), then two
+          // 64-bit compares.  (A byte-at-a-time walk with a "decided" flag was ~130 instructions per row: the kernel took
+          // 0.11 ms per 25 M rows whatever the width — CHAR(1) included.)
+          const unsigned long long a_lo = lo & width_mask_lo, a_hi = hi & width_mask_hi;
+          const unsigned long long keep_lo = up_to_first_zero_byte(a_lo);
+          const unsigned long long s_lo = a_lo & keep_lo;
+          unsigned long long s_hi = 0;
+          if constexpr (KW == 5) s_hi = keep_lo == ~0ull ? (a_hi & up_to_first_zero_byte(a_hi)) : 0ull;
+          const unsigned long long x_first = __builtin_bswap64(s_lo), x_second = __builtin_bswap64(s_hi);
+          const int res = x_first != lit_first ? (x_first < lit_first ? -1 : 1) : (x_second != lit_second ? (x_second < lit_second ? -1 : 1) : 0);
+          const bool pred = r < rows && compare_op<int>(res, op, 0);
+          uint64_t word = msb_first(__ballot(pred));
+          const int64_t word_index = (row0 >> 6) + w;
+          if (filter != nullptr) word &= filter[word_index];
+          if (lane == 0) {
+            out[word_index] = word;
+            count += __popcll(word);
+          }
         }
       }
-    }
+    };
+    if (width <= 4) rows_of_wave(std::integral_constant<int, 2>{});
+    else if (width <= 8) rows_of_wave(std::integral_constant<int, 3>{});
+    else rows_of_wave(std::integral_constant<int, 5>{});
     return;
   }
   const unsigned char *src = col + row0 * width;
@@ -1373,7 +1428,7 @@ int qsx_select_cmp_char(const void *col_dev, int width, int64_t n, int op, const
   if (direct) tile_rows = 4096;
   const int64_t tiles = (n + tile_rows - 1) / tile_rows;
   const int grid = static_cast<int>(tiles < 8 * kCUs ? tiles : 8 * kCUs);
-  const size_t lds = direct ? 64 : (static_cast<size_t>(tile_rows) * width + 15) / 16 * 16;
+  const size_t lds = direct ? kCharDirectLds : (static_cast<size_t>(tile_rows) * width + 15) / 16 * 16;
   hipLaunchKernelGGL(select_char_kernel, dim3(grid), dim3(kBlock), lds, s, static_cast<const unsigned char *>(col_dev), width, n, op,
                      lit, filter_dev, out_bitmap_dev, reinterpret_cast<unsigned long long *>(out_count_dev), tile_rows);
   QSX_CHECK_LAUNCH();
@@ -1418,7 +1473,7 @@ int qsx_select_cmp_char_blocks(int width, int64_t num_blocks, const int64_t *blo
   const int rc = staged_upload(s, table.data(), bytes);
   if (rc != QSX_OK) return rc;
   const int grid = static_cast<int>(tiles < 8 * kCUs ? tiles : 8 * kCUs);
-  const size_t lds = direct ? 64 : (static_cast<size_t>(tile_rows) * width + 15) / 16 * 16;
+  const size_t lds = direct ? kCharDirectLds : (static_cast<size_t>(tile_rows) * width + 15) / 16 * 16;
   hipLaunchKernelGGL(select_char_runs_kernel, dim3(grid), dim3(kBlock), lds, s, runs_dev, width, op, lit,
                      reinterpret_cast<unsigned long long *>(out_counts_dev), tile_rows);
   QSX_CHECK_LAUNCH();
