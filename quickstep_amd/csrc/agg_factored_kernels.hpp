@@ -529,23 +529,32 @@ __global__ __launch_bounds__(kABlock, 4) void agg_factored_direct_kernel(const F
   __syncthreads();
   const unsigned long long *coef = kRuns ? runs.coef : a_dev->coef, *hcoef = kRuns ? runs.hcoef : a_dev->hcoef;
   using Tile = FactoredDirectTile<KEYW, NK, NC, NH, kCar>;
+  // (plain loads, not the non-temporal ones of the scans: a thread owns 8 CONSECUTIVE rows, so a 128-byte line of the DOUBLE
+  // carrier is read by four instructions of the wave (two lanes each) — under the non-temporal hint the line did not outlive
+  // the first of them and came back from L2 / HBM for the others: tools/ubench/q1_factored.hip 1.63 ms with the hint, 1.33 ms
+  // without it, and 1.56 ms with or without any LDS atomic at all: the load path was the whole bound)
+  auto load16 = [](const void *p) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = load_global(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
   auto request = [&](int64_t tile, Tile &x) {
     const int64_t row = tile * kFacDirectTile + static_cast<int64_t>(threadIdx.x) * kFacDirectRows;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       if constexpr (KEYW == 1) {
-        x.key8[k] = load_global_nt(reinterpret_cast<const unsigned long long *>(static_cast<const unsigned char *>(d.key[k]) + row));
+        x.key8[k] = load_global(reinterpret_cast<const unsigned long long *>(static_cast<const unsigned char *>(d.key[k]) + row));
       } else {
-        x.key32[k][0] = stream_load16(static_cast<const uint32_t *>(d.key[k]) + row);
-        x.key32[k][1] = stream_load16(static_cast<const uint32_t *>(d.key[k]) + row + 4);
+        x.key32[k][0] = load16(static_cast<const uint32_t *>(d.key[k]) + row);
+        x.key32[k][1] = load16(static_cast<const uint32_t *>(d.key[k]) + row + 4);
       }
     }
 #pragma unroll
-    for (int q = 0; q < NC; ++q) x.cell[q] = load_global_nt(reinterpret_cast<const unsigned long long *>(d.cellc[q] + row));
-    if constexpr (NH > 0) x.hist[0] = load_global_nt(reinterpret_cast<const unsigned long long *>(d.histc + row));
+    for (int q = 0; q < NC; ++q) x.cell[q] = load_global(reinterpret_cast<const unsigned long long *>(d.cellc[q] + row));
+    if constexpr (NH > 0) x.hist[0] = load_global(reinterpret_cast<const unsigned long long *>(d.histc + row));
     if constexpr (kCar) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x.car[j] = stream_load16(d.carrier + row + 2 * j);
+      for (int j = 0; j < 4; ++j) x.car[j] = load16(d.carrier + row + 2 * j);
     }
     x.live = 0xFFu;
     if (kFilter && (!kRuns || filter != nullptr)) {   // rows row .. row + 7 sit in one word (row is a multiple of 8): bit 63 - (row & 63) is the first of them

@@ -2208,7 +2208,7 @@ static int factored_plan(const qsx_agg_state *st, const void *const *cols, const
 }
 static int factored_workgroups_per_cu(size_t lds_bytes) {
   int per_cu = static_cast<int>((160 * 1024) / (lds_bytes + 512));
-  per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);   // (measured on Q1: 3 / 4 / 5 / 6 workgroups per CU 1.78 / 1.73 / 1.79 / 1.86 ms per 600 M rows)
+  per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);   // (measured on Q1, clear included: 2 / 3 / 4 / 5 / 6 workgroups per CU 1.51 / 1.43 / 1.45 / 1.49 / 1.44 ms per 600 M rows)
   if (const char *e = getenv("QSX_AGG_FACTORED_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
   return per_cu;
 }

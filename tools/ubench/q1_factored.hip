@@ -6,12 +6,21 @@
 // Rows reach the lanes by direct 8 / 16-byte loads (8 consecutive rows per thread), next tile requested before the current
 // one is consumed.  build: hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -ffp-contract=off tools/ubench/q1_factored.hip -o /tmp/q1_factored
 #include <hip/hip_runtime.h>
+#ifndef JOINT
+#define JOINT 0
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 constexpr int kBlock = 256;
-constexpr int kRows = 8;                    // rows per thread and tile
+#ifndef KROWS
+#define KROWS 8
+#endif
+#ifndef NT
+#define NT 1
+#endif
+constexpr int kRows = KROWS;                // rows per thread and tile (8: 8-byte loads of the code stripes; 16: 16-byte loads)
 constexpr int kTile = kBlock * kRows;       // 2048 rows
 constexpr int kGroups = 8;                  // slots of the (k1, k2) table
 constexpr int kD = 11, kT = 9, kQ = 50;
@@ -21,13 +30,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 template <typename T>
-__device__ __forceinline__ T ldg_nt(const T *p) { return __builtin_nontemporal_load((const __attribute__((address_space(1))) T *)p); }
+__device__ __forceinline__ T ldg_nt(const T *p) {
+#if NT
+  return __builtin_nontemporal_load((const __attribute__((address_space(1))) T *)p);
+#else
+  return *(const __attribute__((address_space(1))) T *)p;
+#endif
+}
+#if KROWS == 16
+typedef u32x4 codes_t;
+#else
+typedef u32x2 codes_t;
+#endif
 
 __device__ __forceinline__ int group_of(unsigned k1, unsigned k2) { return ((k1 >> 2) & 7) ^ ((k2 & 1) << 0) ^ 0; }   // A,F=0 N,F=3 N,O=2 R,F=4 (distinct)
 
 struct Tile {
-  u32x2 k1, k2, q, d, t;
-  u32x4 p[4];
+  codes_t k1, k2, q, d, t;
+  u32x4 p[kRows / 2];
 };
 
 __global__ __launch_bounds__(kBlock) void q1_factored(const unsigned char *__restrict__ k1, const unsigned char *__restrict__ k2,
@@ -38,21 +58,28 @@ __global__ __launch_bounds__(kBlock) void q1_factored(const unsigned char *__res
   __shared__ double s_sum[kCells];
   __shared__ unsigned s_cnt[kCells];
   __shared__ unsigned s_hq[kGroups * kQ];
+#if JOINT
+  // round 5, second look: ONE count atomic per row — the joint histogram of the dictionary columns the carrier-free sums
+  // depend on (quantity x discount: 550 per group) instead of a count per cell and a quantity histogram
+  __shared__ unsigned s_joint[kGroups * kQ * kD];
+  for (int i = threadIdx.x; i < kGroups * kQ * kD; i += kBlock) s_joint[i] = 0u;
+#endif
   for (int i = threadIdx.x; i < kCells; i += kBlock) { s_sum[i] = 0.0; s_cnt[i] = 0u; }
   for (int i = threadIdx.x; i < kGroups * kQ; i += kBlock) s_hq[i] = 0u;
   __syncthreads();
   const long long tiles = n / kTile;          // (prototype: n is a multiple of the tile)
   auto request = [&](long long tile, Tile &x) {
     const long long row = tile * kTile + static_cast<long long>(threadIdx.x) * kRows;
-    x.k1 = ldg_nt(reinterpret_cast<const u32x2 *>(k1 + row));
-    x.k2 = ldg_nt(reinterpret_cast<const u32x2 *>(k2 + row));
-    x.q = ldg_nt(reinterpret_cast<const u32x2 *>(qc + row));
-    x.d = ldg_nt(reinterpret_cast<const u32x2 *>(dc + row));
-    x.t = ldg_nt(reinterpret_cast<const u32x2 *>(tc + row));
+    x.k1 = ldg_nt(reinterpret_cast<const codes_t *>(k1 + row));
+    x.k2 = ldg_nt(reinterpret_cast<const codes_t *>(k2 + row));
+    x.q = ldg_nt(reinterpret_cast<const codes_t *>(qc + row));
+    x.d = ldg_nt(reinterpret_cast<const codes_t *>(dc + row));
+    x.t = ldg_nt(reinterpret_cast<const codes_t *>(tc + row));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x.p[j] = ldg_nt(reinterpret_cast<const u32x4 *>(price + row) + j);
+    for (int j = 0; j < kRows / 2; ++j) x.p[j] = ldg_nt(reinterpret_cast<const u32x4 *>(price + row) + j);
   };
   Tile cur, nxt;
+  double sink_value = 0;
   long long tile = blockIdx.x;
   if (tile < tiles) request(tile, cur);
   for (; tile < tiles; tile += gridDim.x) {
@@ -60,18 +87,29 @@ __global__ __launch_bounds__(kBlock) void q1_factored(const unsigned char *__res
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
       const unsigned sh = (r & 3) * 8;
-      const unsigned a = (r < 4 ? cur.k1.x : cur.k1.y) >> sh & 0xFF, b = (r < 4 ? cur.k2.x : cur.k2.y) >> sh & 0xFF;
-      const unsigned q = (r < 4 ? cur.q.x : cur.q.y) >> sh & 0xFF, d = (r < 4 ? cur.d.x : cur.d.y) >> sh & 0xFF, t = (r < 4 ? cur.t.x : cur.t.y) >> sh & 0xFF;
+      const unsigned a = cur.k1[r >> 2] >> sh & 0xFF, b = cur.k2[r >> 2] >> sh & 0xFF;
+      const unsigned q = cur.q[r >> 2] >> sh & 0xFF, d = cur.d[r >> 2] >> sh & 0xFF, t = cur.t[r >> 2] >> sh & 0xFF;
       const u32x4 pw = cur.p[r >> 1];
       const double p = __hiloint2double((r & 1) ? pw.w : pw.y, (r & 1) ? pw.z : pw.x);
       const int g = group_of(a, b);
       const int cell = (g * kD + d) * kT + t;
+#if JOINT == 3
+      sink_value += p + cell;   // (no LDS atomic at all: what the loads and the per-row arithmetic alone take; results wrong)
+#else
       unsafeAtomicAdd(&s_sum[cell], p);
+#endif
+#if JOINT == 1
+      atomicAdd(&s_joint[(g * kQ + q) * kD + d], 1u);
+#elif JOINT >= 2
+      (void)q;   // (no count atomics at all: the floor of the plane atomic alone; results wrong)
+#else
       atomicAdd(&s_cnt[cell], 1u);
       atomicAdd(&s_hq[g * kQ + q], 1u);
+#endif
     }
     cur = nxt;
   }
+  if (sink_value == 1.2345e-300) out[0] = sink_value;
   __syncthreads();
   // flush: the six accumulators of every group from the cells (one thread per (group, accumulator) would do; here a wave per group)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -87,7 +125,17 @@ __global__ __launch_bounds__(kBlock) void q1_factored(const unsigned char *__res
       a_disc += k * ddict[d];
       a_cnt += k;
     }
+#if JOINT == 1
+    a_disc = 0; a_cnt = 0;
+    for (int c = lane; c < kQ * kD; c += 64) {
+      const double k = s_joint[g * kQ * kD + c];
+      a_qty += k * qdict[c / kD];
+      a_disc += k * ddict[c % kD];
+      a_cnt += k;
+    }
+#else
     for (int c = lane; c < kQ; c += 64) a_qty += s_hq[g * kQ + c] * qdict[c];
+#endif
     for (int o = 32; o > 0; o >>= 1) {
       a_price += __shfl_xor(a_price, o); a_disc_price += __shfl_xor(a_disc_price, o); a_charge += __shfl_xor(a_charge, o);
       a_disc += __shfl_xor(a_disc, o); a_qty += __shfl_xor(a_qty, o); a_cnt += __shfl_xor(a_cnt, o);
