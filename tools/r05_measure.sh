@@ -4,7 +4,7 @@
 # the LDS-resident probe), the per-topic tools.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r05m
-mkdir -p $out $out/jit_shapes $out/pmc_coded $out/pmc_lds_probe
+mkdir -p $out $out/jit_shapes $out/pmc_coded $out/pmc_lds_probe $out/pmc_sparse
 export QSX_JIT_RECORD_DIR=$PWD/$out/jit_shapes
 t0=$(date +%s)
 timeout 1800 python -m pytest tests -m gpu -x -q --durations=25 > $out/pytest_gpu_full.log 2>&1
@@ -42,9 +42,18 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/pmc_coded/pass$i" -o p -- python3 tools/agg_coded_probe.py > "$out/pmc_coded/pass$i.json" 2> "$out/pmc_coded/pass$i.err"
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/pmc_lds_probe/pass$i" -o p -- python3 tools/probe_small_tables.py 100 > "$out/pmc_lds_probe/pass$i.json" 2> "$out/pmc_lds_probe/pass$i.err"
 done
+# the bucketed table over sparse keys behind its compact plane (probe_fp_kernel<..., kCompact>)
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS TCC_REQ"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/pmc_sparse/pass$i" -o p -- python3 tools/probe_hashed_sparse.py > "$out/pmc_sparse/pass$i.json" 2> "$out/pmc_sparse/pass$i.err"
+done
+python3 tools/pmc_summary.py $out/pmc_sparse probe_fp build_kernel compact_build > $out/pmc_summary_sparse_probe.txt 2>&1; head -12 $out/pmc_summary_sparse_probe.txt
+find $out/pmc_sparse -name '*.csv' -size +1M -delete; find $out/pmc_sparse -name '*.db' -delete
+bash tools/r05_blocks_trace.sh > $out/blocks_trace.txt 2>&1; cp gpurun_out/prof_blocks/run_kernel_stats.csv $out/blocks_kernel_stats.csv; grep -E "coef|factored_direct" $out/blocks_trace.txt | cut -c1-200
 python3 tools/pmc_summary.py $out/pmc_coded agg_factored qsx_jit_agg agg_hash > $out/pmc_summary_coded.txt 2>&1; head -14 $out/pmc_summary_coded.txt
 python3 tools/pmc_summary.py $out/pmc_lds_probe lds_dense lds_bucket dense_probe probe_fp > $out/pmc_summary_lds_probe.txt 2>&1; head -14 $out/pmc_summary_lds_probe.txt
 find $out/pmc_coded $out/pmc_lds_probe -name '*.csv' -size +1M -delete; find $out/pmc_coded $out/pmc_lds_probe -name '*.db' -delete
-for t in probe_hashed_sparse agg_coded_probe probe_small_tables agg_dir_probe agg_dense_probe; do timeout 300 python tools/$t.py > $out/$t.jsonl 2>/dev/null; done
+for t in probe_hashed_sparse agg_coded_probe probe_small_tables agg_dir_probe agg_dense_probe select_char_probe; do timeout 300 python tools/$t.py > $out/$t.jsonl 2>/dev/null; done
 timeout 400 python tools/bench_ops.py > $out/bench_ops.jsonl 2>/dev/null; wc -l $out/*.jsonl
 ls $out/jit_shapes | wc -l
