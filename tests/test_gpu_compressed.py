@@ -607,7 +607,9 @@ def test_factored_aggregation_over_a_run_of_blocks_with_their_own_dictionaries(c
     before = _factored_launches(capi)
     st, o = capi.AggState(cfg), oracle.AggState(cfg)
     st.update_coded_blocks(blocks, block_dicts, filters)               # some blocks filtered
-    st.update_coded_blocks(blocks[2:5], block_dicts[2:5])              # no filter at all
+    # no filter at all, and a block without tuples in the middle of the run (it has stripes and dictionaries, and no rows)
+    empty = [c[:0] for c in blocks[0]]
+    st.update_coded_blocks([blocks[2], blocks[3], empty, blocks[4]], [block_dicts[2], block_dicts[3], block_dicts[0], block_dicts[4]])
     for code_cols, dicts, n, filt in host:
         o.update_coded(code_cols, dicts, n, filter_bitmap=filt)
     for code_cols, dicts, n, filt in host[2:5]:

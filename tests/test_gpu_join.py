@@ -981,3 +981,43 @@ def test_big_bucketed_tables_are_probed_through_their_compact_plane(capi, oracle
         table.close()
     for a, b in zip(answers["1"], answers["0"]):
         assert np.array_equal(a, b)
+
+
+def test_compact_plane_follows_builds_growth_and_clear(capi, oracle, dev):
+    """The compact plane belongs to ONE sealed state of the table: a build behind the first probes drops it (the next probe
+    seals again — over a table that has grown by rehash in between, with another bucket count and so other identities), a
+    clear empties the table under it.  Every probe equals the oracle's."""
+    rng = np.random.default_rng(77)
+    universe = np.arange(-2**31, 2**31, 1777, dtype=np.int64)
+    keys = rng.choice(universe, size=1_900_000, replace=False).astype(np.int32)
+    first, second = keys[:900_000], keys[900_000:]
+    probe = np.where(rng.random(800_003) < 0.7, rng.choice(keys, size=800_003), rng.integers(-2**31, 2**31, size=800_003)).astype(np.int32)
+    dp = to_dev(probe, dev)
+    before = _compact_probes(capi)
+    table = capi.JoinTable(T.INT, first.size)          # sized for the first build only: the second one makes it grow
+    ot = oracle.JoinTable(T.INT, keys.size)
+    table.build(to_dev(first, dev))
+    ot.build(first, block_id=0, base_tid=0)
+
+    def same_as_oracle():
+        rp, rb = ot.probe(probe)
+        p, b, cnt = table.probe(dp, capacity=max(rp.size, 1))
+        assert int(cnt.item()) == rp.size
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rb))
+    same_as_oracle()
+    table.build(to_dev(second, dev), base_tid=first.size)
+    ot.build(second, block_id=1, base_tid=first.size)
+    same_as_oracle()
+    same_as_oracle()                                   # (sealed: straight through the plane)
+    assert _compact_probes(capi) - before == 3
+    table.clear()
+    p, b, cnt = table.probe(dp, capacity=16)
+    assert int(cnt.item()) == 0
+    table.build(to_dev(second, dev))
+    ot2 = oracle.JoinTable(T.INT, second.size)
+    ot2.build(second, block_id=0, base_tid=0)
+    rp, rb = ot2.probe(probe)
+    p, b, cnt = table.probe(dp, capacity=max(rp.size, 1))
+    assert int(cnt.item()) == rp.size
+    assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rb))
+    table.close()
