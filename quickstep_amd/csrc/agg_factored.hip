@@ -24,6 +24,13 @@ int launch_factored_coef(const DevConfig &dc, const FactoredCoefArgs &ca_in, hip
   return QSX_OK;
 }
 
+int launch_factored_predicate(const FactoredPredArgs &pa, long long tiles, hipStream_t s) {
+  const long long groups = (tiles + kABlock / kWave - 1) / (kABlock / kWave), limit = 8ll * kCUs;   // a wave per tile
+  hipLaunchKernelGGL(factored_predicate_kernel, dim3(static_cast<unsigned>(groups < limit ? groups : limit)), dim3(kABlock), 0, s, pa, tiles);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
+}
+
 int launch_factored_staged(const FactoredArgs &a, size_t lds_bytes, int per_cu, int64_t n, const uint64_t *filter_dev, const HashTableView &g, hipStream_t s) {
   static std::mutex attr_mutex;
   static bool attr_set[2][16] = {};

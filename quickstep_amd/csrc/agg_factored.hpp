@@ -49,6 +49,7 @@ struct FactoredStatic {
   int ncar = 0, car_col[kFacMaxCarriers] = {}, car_int[kFacMaxCarriers] = {};   // car_int: an i64 plane (SUM(int column))
   int sum_hist[kMaxSums] = {};      // >= 0: the sum's argument depends on that histogram column only
   int sum_car_int[kMaxSums] = {};   // >= 0: SUM of a plain INT / LONG column = that carrier's i64 plane, coefficient 1
+  bool prepass = false;             // the state has predicate terms: a pass of its own turns them into the call's filter bitmap
 };
 
 // Kernel argument of the accumulate kernel (< 512 bytes).
@@ -111,6 +112,28 @@ struct FactoredRunArgs {
   const unsigned long long *coef, *hcoef;           // block b: coef + b * coef_words, hcoef + b * hcoef_words
   long long coef_words, hcoef_words;
 };
+// The state's predicate (AggregationOperationState's predicate_: TPC-H Q1's l_shipdate <= DATE, storage/
+// AggregationOperationState.cpp:428-440) in front of the factored kernels: one pass over the predicate's columns — values, or
+// codes through the block's dictionary — writes the TupleIdSequence the accumulate kernel then takes as its filter (AND the
+// caller's own filter).  One workgroup per 1024 rows; a run of blocks: the tiles of the call's run table, bitmap of block b at
+// out + 16 * first_tile[b] words.
+struct FactoredPredArgs {
+  int num_pred;
+  DevPred pred[QSX_MAX_PRED_TERMS];
+  int type[QSX_MAX_PRED_TERMS];        // the column's type
+  int width[QSX_MAX_PRED_TERMS];       // bytes per row of the stripe (the code width of a compressed attribute)
+  int coded[QSX_MAX_PRED_TERMS];       // != 0: a compressed attribute (through its dictionary when it has one, else value = code)
+  // one stripe
+  const void *col[QSX_MAX_PRED_TERMS];
+  const void *dict[QSX_MAX_PRED_TERMS];
+  const unsigned long long *filter_in;
+  long long n;
+  // a run of blocks (run != nullptr)
+  const long long *run;
+  const long long *filters_in;          // [num_blocks] addresses of the caller's filters (0: none), or nullptr
+  unsigned long long *out;
+};
+int launch_factored_predicate(const FactoredPredArgs &pa, long long tiles, hipStream_t s);
 // Launchers (agg_factored.hip: the kernels live in a translation unit of their own).
 int launch_factored_coef(const DevConfig &dc, const FactoredCoefArgs &ca, hipStream_t s, int num_blocks = 1);
 int launch_factored_staged(const FactoredArgs &a, size_t lds_bytes, int per_cu, int64_t n, const uint64_t *filter_dev, const HashTableView &g, hipStream_t s);
@@ -123,7 +146,7 @@ bool launch_factored_direct(const FactoredArgs &a, const FactoredArgs *a_dev, co
 inline FactoredStatic factored_analyse(const DevConfig &d, bool dense) {
   FactoredStatic f;
   for (int j = 0; j < kMaxSums; ++j) f.sum_hist[j] = f.sum_car_int[j] = -1;
-  if (dense || d.wide_words != 0 || d.num_pred != 0 || d.num_null_cols != 0 || d.num_keys < 1 || d.num_sums < 1) return f;
+  if (dense || d.wide_words != 0 || d.num_null_cols != 0 || d.num_keys < 1 || d.num_sums < 1) return f;
   unsigned key_mask = 0;
   for (int k = 0; k < d.num_keys; ++k) {
     const int c = d.key_column[k];
@@ -196,6 +219,7 @@ inline FactoredStatic factored_analyse(const DevConfig &d, bool dense) {
       for (int k = 0; k < f.ncar; ++k) if (of_sum[j].cmask == (1u << f.car_col[k])) f.sum_car_int[j] = k;
     }
   }
+  f.prepass = d.num_pred != 0;
   f.ok = true;
   return f;
 }

@@ -2231,6 +2231,33 @@ static bool factored_direct_aligned(const FactoredPlan &plan, const qsx_agg_stat
   return ok;
 }
 
+// How a factored state's predicate becomes the call's filter: 1 = every term is on a plain stripe -> the tuned K1 kernels
+// (qsx_select_cmp / _blocks, chained through the bitmap: ~6 TB/s of the terms' columns); 2 = some term is on a compressed
+// attribute -> factored_predicate_kernel, which compares dictionary VALUES (540 G rows/s: slower than what the factored kernels
+// save, so only with QSX_AGG_FACTORED_CODED_PREDICATES=1 — the tests keep it exact); 0 = that case by default: the decoding
+// kernels keep the state.
+static int factored_predicate_route(const DevConfig &d) {
+  bool all_plain = true;
+  for (int p = 0; p < d.num_pred; ++p) all_plain = all_plain && d.code_width[d.pred[p].column] == 0;
+  if (all_plain) return 1;
+  const char *e = getenv("QSX_AGG_FACTORED_CODED_PREDICATES");
+  return e != nullptr && e[0] == '1' ? 2 : 0;
+}
+
+// The static part of the predicate pass's arguments (FactoredPredArgs): the state's terms, the type / width / coding of their columns.
+static FactoredPredArgs factored_predicate_terms(const DevConfig &d) {
+  FactoredPredArgs pa{};
+  pa.num_pred = d.num_pred;
+  for (int p = 0; p < d.num_pred; ++p) {
+    const int col = d.pred[p].column;
+    pa.pred[p] = d.pred[p];
+    pa.type[p] = d.column_type[col];
+    pa.width[p] = d.code_width[col] != 0 ? d.code_width[col] : d.column_width[col];
+    pa.coded[p] = d.code_width[col] != 0 ? 1 : 0;
+  }
+  return pa;
+}
+
 // QSX_OK = the call was issued through the factored kernels; QSX_ERR_UNSUPPORTED = not this call (dictionary sizes unknown or
 // too large, the cells do not fit LDS): the caller goes on with the decoding kernels; anything else is an error.
 static int update_factored(qsx_agg_state *st, const void *const *cols, const void *const *dicts, const int32_t *entries, int64_t n,
@@ -2238,8 +2265,10 @@ static int update_factored(qsx_agg_state *st, const void *const *cols, const voi
   const FactoredStatic &f = st->factored;
   if (!f.ok || !factored_enabled() || dicts == nullptr || entries == nullptr || n < factored_min_rows()) return QSX_ERR_UNSUPPORTED;
   const DevConfig &d = st->dev;
+  const int pred_route = f.prepass ? factored_predicate_route(d) : 0;
+  if (f.prepass && pred_route == 0) return QSX_ERR_UNSUPPORTED;
   FactoredPlan plan;
-  int rc = factored_plan(st, cols, dicts, entries, filter_dev != nullptr, &plan);
+  int rc = factored_plan(st, cols, dicts, entries, filter_dev != nullptr || f.prepass, &plan);
   if (rc != QSX_OK) return rc;
   FactoredArgs &a = plan.a;
   FactoredCoefArgs &ca = plan.ca;
@@ -2250,10 +2279,35 @@ static int update_factored(qsx_agg_state *st, const void *const *cols, const voi
   // coefficients: this call's dictionaries through the state's expression program
   CallScratch scratch(s);
   const size_t coef_bytes = static_cast<size_t>(d.num_sums) * (1 + a.ncar) * cells * 8, hcoef_bytes = static_cast<size_t>(d.num_sums) * kFacMaxDict * 8;
-  rc = scratch.reserve(CallScratch::padded(coef_bytes) + CallScratch::padded(hcoef_bytes));
+  const long long pred_tiles = (n + 1023) / 1024;
+  const size_t pred_bytes = f.prepass ? static_cast<size_t>(pred_tiles) * 16 * 8 : 0;
+  rc = scratch.reserve(CallScratch::padded(coef_bytes) + CallScratch::padded(hcoef_bytes) + CallScratch::padded(pred_bytes));
   if (rc != QSX_OK) return rc;
   ca.coef = static_cast<unsigned long long *>(scratch.take(coef_bytes));
   ca.hcoef = static_cast<unsigned long long *>(scratch.take(hcoef_bytes));
+  if (f.prepass) {   // the state's predicate -> this call's filter
+    uint64_t *bitmap = static_cast<uint64_t *>(scratch.take(pred_bytes));
+    if (pred_route == 1) {
+      for (int p = 0; p < d.num_pred; ++p) {
+        const unsigned long long literal = d.pred[p].literal;   // (raw bits typed like the column: what qsx_select_cmp reads behind the pointer)
+        rc = qsx_select_cmp(d.column_type[d.pred[p].column], cols[d.pred[p].column], n, d.pred[p].op, &literal, p == 0 ? filter_dev : bitmap, bitmap,
+                            nullptr, reinterpret_cast<qsx_stream_t>(s));
+        if (rc != QSX_OK) return rc;
+      }
+    } else {
+      FactoredPredArgs pa = factored_predicate_terms(d);
+      for (int p = 0; p < d.num_pred; ++p) {
+        pa.col[p] = cols[d.pred[p].column];
+        pa.dict[p] = d.code_width[d.pred[p].column] != 0 ? dicts[d.pred[p].column] : nullptr;
+      }
+      pa.filter_in = reinterpret_cast<const unsigned long long *>(filter_dev);
+      pa.n = n;
+      pa.out = reinterpret_cast<unsigned long long *>(bitmap);
+      rc = launch_factored_predicate(pa, pred_tiles, s);
+      if (rc != QSX_OK) return rc;
+    }
+    filter_dev = bitmap;
+  }
   a.coef = ca.coef;
   a.hcoef = ca.hcoef;
   DevConfig dc = d;
@@ -2510,7 +2564,9 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   bool factored = false;
   std::vector<long long> fac_first_tile;
   std::vector<int32_t> fac_entries;
-  if (block_entries != nullptr && block_dicts != nullptr && st->factored.ok && bounds_slot < 0 && factored_enabled() && total >= factored_min_rows()) {
+  const int pred_route = st->factored.ok && st->factored.prepass ? factored_predicate_route(st->dev) : 0;
+  if (block_entries != nullptr && block_dicts != nullptr && st->factored.ok && bounds_slot < 0 && factored_enabled() && total >= factored_min_rows() &&
+      !(st->factored.prepass && pred_route == 0)) {
     const FactoredStatic &f = st->factored;
     int32_t radix[QSX_MAX_COLUMNS] = {};
     const void *first_dicts[QSX_MAX_COLUMNS] = {};
@@ -2538,7 +2594,7 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
     }
     if (rc != QSX_OK) return rc;
     if (factored) {
-      rc = factored_plan(st, first_cols, first_dicts, radix, any_filter, &fplan);
+      rc = factored_plan(st, first_cols, first_dicts, radix, any_filter || f.prepass, &fplan);
       if (rc != QSX_OK && rc != QSX_ERR_UNSUPPORTED) return rc;
       factored = rc == QSX_OK && fplan.direct;
     }
@@ -2552,11 +2608,16 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   const size_t coef_words = factored ? static_cast<size_t>(st->dev.num_sums) * (1 + fplan.a.ncar) * fplan.a.cells : 0,
                hcoef_words = factored ? static_cast<size_t>(st->dev.num_sums) * kFacMaxDict : 0;
   if (factored && nb * (coef_words + hcoef_words) * 8 > (size_t(256) << 20)) factored = false;   // (a run of very many blocks over very many cells)
+  // the state's predicate becomes every block's filter bitmap first (FactoredPredArgs): 16 words per 1024-row tile of the run
+  const bool prepass = factored && st->factored.prepass;
+  const size_t pred_bytes = prepass ? static_cast<size_t>(tiles1024.back()) * 16 * 8 : 0;
+  unsigned long long *pred_bitmaps = nullptr;
   if (factored) {
-    rc = fac_scratch.reserve(CallScratch::padded(nb * coef_words * 8) + CallScratch::padded(nb * hcoef_words * 8));
+    rc = fac_scratch.reserve(CallScratch::padded(nb * coef_words * 8) + CallScratch::padded(nb * hcoef_words * 8) + CallScratch::padded(pred_bytes));
     if (rc != QSX_OK) return rc;
     fplan.ca.coef = static_cast<unsigned long long *>(fac_scratch.take(nb * coef_words * 8));
     fplan.ca.hcoef = static_cast<unsigned long long *>(fac_scratch.take(nb * hcoef_words * 8));
+    if (prepass) pred_bitmaps = static_cast<unsigned long long *>(fac_scratch.take(pred_bytes));
     fplan.a.coef = fplan.ca.coef;      // (block 0's: the kernel takes every block's from FactoredRunArgs)
     fplan.a.hcoef = fplan.ca.hcoef;
   }
@@ -2565,7 +2626,8 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
                off_fac_tiles = off_dicts + (block_dicts != nullptr ? nb * QSX_MAX_COLUMNS : 0),
                off_fac_entries = off_fac_tiles + (factored ? nb + 1 : 0),
                off_fac_args = off_fac_entries + (factored ? nb * QSX_MAX_COLUMNS / 2 : 0),
-               words = off_fac_args + (factored ? (sizeof(FactoredArgs) + 7) / 8 : 0);
+               off_fac_infilters = off_fac_args + (factored ? (sizeof(FactoredArgs) + 7) / 8 : 0),
+               words = off_fac_infilters + (prepass && any_filter ? nb : 0);
   static_assert(QSX_MAX_COLUMNS % 2 == 0, "two int32 dictionary sizes per table word");
   table.resize(words);
   std::copy(dicts.begin(), dicts.end(), table.begin() + off_dicts);
@@ -2574,10 +2636,37 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   std::copy(rows.begin(), rows.end(), table.begin() + off_rows);
   std::copy(cols.begin(), cols.end(), table.begin() + off_cols);
   std::copy(filters.begin(), filters.end(), table.begin() + off_filters);
+  if (prepass) {   // the accumulate kernel's filters are the predicate pass's bitmaps; the caller's own go to that pass
+    if (any_filter) std::copy(filters.begin(), filters.end(), table.begin() + off_fac_infilters);
+    for (size_t b = 0; b < nb; ++b) {
+      table[off_filters + b] = static_cast<long long>(reinterpret_cast<uintptr_t>(pred_bitmaps + static_cast<size_t>(tiles1024[b]) * 16));
+    }
+  }
   if (factored) {
     std::copy(fac_first_tile.begin(), fac_first_tile.end(), table.begin() + off_fac_tiles);
     std::memcpy(&table[off_fac_entries], fac_entries.data(), fac_entries.size() * sizeof(int32_t));
     std::memcpy(&table[off_fac_args], &fplan.a, sizeof(FactoredArgs));
+  }
+  if (prepass && pred_route == 1) {
+    // every term on a plain stripe: the K1 run kernels, chained through the blocks' bitmaps — BEFORE this call's own table goes
+    // into the stream's staging buffer (they stage theirs there)
+    std::vector<int64_t> rows64(rows.begin(), rows.end());
+    std::vector<const void *> term_cols(nb);
+    std::vector<const uint64_t *> in_filters(nb);
+    std::vector<uint64_t *> out_bitmaps(nb);
+    for (size_t b = 0; b < nb; ++b) {
+      in_filters[b] = reinterpret_cast<const uint64_t *>(static_cast<uintptr_t>(filters[b]));
+      out_bitmaps[b] = reinterpret_cast<uint64_t *>(pred_bitmaps + static_cast<size_t>(tiles1024[b]) * 16);
+    }
+    for (int p = 0; p < st->dev.num_pred; ++p) {
+      const int col = st->dev.pred[p].column;
+      for (size_t b = 0; b < nb; ++b) term_cols[b] = reinterpret_cast<const void *>(static_cast<uintptr_t>(cols[b * QSX_MAX_COLUMNS + col]));
+      const unsigned long long literal = st->dev.pred[p].literal;
+      rc = qsx_select_cmp_blocks(st->dev.column_type[col], static_cast<int64_t>(nb), rows64.data(), term_cols.data(), st->dev.pred[p].op, &literal,
+                                 p == 0 ? (any_filter ? in_filters.data() : nullptr) : const_cast<const uint64_t *const *>(out_bitmaps.data()),
+                                 out_bitmaps.data(), nullptr, stream);
+      if (rc != QSX_OK) return rc;
+    }
   }
   long long *dev_table = static_cast<long long *>(staged_device_buffer(s, words * sizeof(long long)));
   if (dev_table == nullptr) return QSX_ERR_OUT_OF_MEMORY;
@@ -2587,7 +2676,7 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   table[3] = static_cast<long long>(off512);
   table[4] = static_cast<long long>(off_rows);
   table[5] = static_cast<long long>(off_cols);
-  table[6] = any_filter ? static_cast<long long>(off_filters) : 0;
+  table[6] = any_filter || prepass ? static_cast<long long>(off_filters) : 0;
   table[7] = 0;
   table[8] = block_dicts != nullptr ? static_cast<long long>(off_dicts) : 0;
   {   // equal-sized blocks (a relation's blocks all hold the same number of tuples but the last): no search per tile
@@ -2607,6 +2696,14 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
     fplan.ca.hcoef_words = static_cast<long long>(hcoef_words);
     rc = launch_factored_coef(st->dev, fplan.ca, s, static_cast<int>(nb));
     if (rc != QSX_OK) return rc;
+    if (prepass && pred_route == 2) {
+      FactoredPredArgs pa = factored_predicate_terms(st->dev);
+      pa.run = dev_table;
+      pa.filters_in = any_filter ? dev_table + off_fac_infilters : nullptr;
+      pa.out = pred_bitmaps;
+      rc = launch_factored_predicate(pa, tiles1024.back(), s);
+      if (rc != QSX_OK) return rc;
+    }
     const FactoredStatic &f = st->factored;
     FactoredRunArgs ra{};
     ra.run = dev_table;
@@ -2627,7 +2724,7 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
     const int grid = static_cast<int>(want < static_cast<int64_t>(per_cu) * kCUs ? want : static_cast<int64_t>(per_cu) * kCUs);
     const FactoredArgs *a_dev = reinterpret_cast<const FactoredArgs *>(dev_table + off_fac_args);
     // (kFilter of the kernel = some block of the run has a filter: any non-null pointer says so)
-    const uint64_t *filter_flag = any_filter ? first_filter : nullptr;
+    const uint64_t *filter_flag = prepass ? reinterpret_cast<const uint64_t *>(pred_bitmaps) : (any_filter ? first_filter : nullptr);
     if (launch_factored_direct(fplan.a, a_dev, fplan.da, fplan.keyw, fplan.table_bytes, grid, total, filter_flag, st->hash_view(), s, &ra)) {
       QSX_CHECK_LAUNCH();
       g_factored_launches.fetch_add(1, std::memory_order_relaxed);

@@ -176,7 +176,14 @@ struct Q1Group {
   double sum_qty = 0, sum_price = 0, sum_disc_price = 0, avg_disc = 0;
 };
 
-std::vector<Q1Group> runQ1(const Q1Rows &rows, bool compressed, std::size_t blocks_per_work_order, bool use_foreman) {
+// with_predicate: a predicate inside the aggregation (Q1's l_shipdate <= DATE is such a predicate_ of the operator).
+//   1: 20000 <= l_extendedprice < 95000 — two terms on a plain attribute (the K1 kernels make the filter);
+//   2: l_quantity < 24 AND l_extendedprice >= 20000 — a term on a dictionary-coded attribute (factored_predicate_kernel, on request).
+bool Q1RowPasses(const Q1Rows &rows, std::int64_t i, int with_predicate) {
+  return with_predicate == 1 ? rows.price[i] >= 20000.0 && rows.price[i] < 95000.0 : rows.quantity[i] < 24.0 && rows.price[i] >= 20000.0;
+}
+
+std::vector<Q1Group> runQ1(const Q1Rows &rows, bool compressed, std::size_t blocks_per_work_order, bool use_foreman, int with_predicate = 0) {
   CatalogRelation lineitem(1, "lineitem"), result(2, "result");
   StorageManager storage;
   lineitem.addAttribute("l_returnflag", Type::Char(1));
@@ -211,6 +218,17 @@ std::vector<Q1Group> runQ1(const Q1Rows &rows, bool compressed, std::size_t bloc
                      AggregateSpec(AggregationID::kAvg, 4), AggregateSpec(AggregationID::kCount, kInvalidAttributeID)};
   spec.strategy = QSX_AGG_COMPACT_KEY;
   spec.estimated_num_groups = 6;
+  if (with_predicate != 0) {
+    Predicate pred;
+    if (with_predicate == 1) {
+      pred.conjuncts.push_back({3, ComparisonID::kGreaterOrEqual, TypedLiteral::Double(20000.0)});
+      pred.conjuncts.push_back({3, ComparisonID::kLess, TypedLiteral::Double(95000.0)});
+    } else {
+      pred.conjuncts.push_back({2, ComparisonID::kLess, TypedLiteral::Double(24.0)});
+      pred.conjuncts.push_back({3, ComparisonID::kGreaterOrEqual, TypedLiteral::Double(20000.0)});
+    }
+    spec.predicate = ctx.getPredicate(ctx.addPredicate(pred));
+  }
   const auto state = ctx.addAggregationState(spec);
   auto *aggregate = new AggregationOperator(0, lineitem, true, state);
   auto *finalize = new FinalizeAggregationOperator(0, state, 1, false, 1, result, dest);
@@ -270,20 +288,39 @@ void testQ1OverCompressedBlocks() {
     want[g].sum_disc_price += rows.price[i] * (1.0 - rows.discount[i]);
     disc_sum[g] += rows.discount[i];
   }
-  for (const int variant : {0, 1, 2, 3, 4, 5}) {
-    const bool compressed = variant != 0;
-    const std::size_t per_work_order = variant <= 1 ? 1 : (variant <= 3 ? 3 : 4);
-    const bool use_foreman = variant == 3 || variant == 5;
-    const std::vector<Q1Group> got = runQ1(rows, compressed, per_work_order, use_foreman);
+  // the same under a predicate inside the aggregation
+  std::vector<Q1Group> want_pred[3] = {std::vector<Q1Group>(6), std::vector<Q1Group>(6), std::vector<Q1Group>(6)};
+  std::vector<double> disc_sum_pred[3] = {std::vector<double>(6, 0.0), std::vector<double>(6, 0.0), std::vector<double>(6, 0.0)};
+  for (int kind = 1; kind <= 2; ++kind) {
+    for (std::int64_t i = 0; i < kRows; ++i) {
+      if (!Q1RowPasses(rows, i, kind)) continue;
+      const std::size_t g = (rows.flag[i] == 'A' ? 0 : (rows.flag[i] == 'N' ? 1 : 2)) * 2 + (rows.status[i] == 'F' ? 0 : 1);
+      ++want_pred[kind][g].count;
+      want_pred[kind][g].sum_qty += rows.quantity[i];
+      want_pred[kind][g].sum_price += rows.price[i];
+      want_pred[kind][g].sum_disc_price += rows.price[i] * (1.0 - rows.discount[i]);
+      disc_sum_pred[kind][g] += rows.discount[i];
+    }
+  }
+  for (const int variant : {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10}) {
+    const int with_predicate = variant < 6 ? 0 : (variant <= 8 ? 1 : 2);
+    const bool compressed = variant != 0 && variant != 6;
+    const std::size_t per_work_order = variant <= 1 || variant == 6 ? 1 : (variant <= 3 || variant == 9 ? 3 : 4);
+    const bool use_foreman = variant == 3 || variant == 5 || variant == 8;
+    if (with_predicate == 2) setenv("QSX_AGG_FACTORED_CODED_PREDICATES", "1", 1); else unsetenv("QSX_AGG_FACTORED_CODED_PREDICATES");
+    const std::vector<Q1Group> got = runQ1(rows, compressed, per_work_order, use_foreman, with_predicate);
+    const std::vector<Q1Group> &expect = with_predicate != 0 ? want_pred[with_predicate] : want;
+    const std::vector<double> &expect_disc = with_predicate != 0 ? disc_sum_pred[with_predicate] : disc_sum;
     for (std::size_t g = 0; g < 6; ++g) {
-      EXPECT_EQ(got[g].count, want[g].count);
-      EXPECT_TRUE(got[g].sum_qty == want[g].sum_qty);                       // integer-valued doubles: exact
-      EXPECT_NEAR(got[g].sum_price, want[g].sum_price, 1e-9 * want[g].sum_price);
-      EXPECT_NEAR(got[g].sum_disc_price, want[g].sum_disc_price, 1e-9 * want[g].sum_disc_price);
-      EXPECT_NEAR(got[g].avg_disc, disc_sum[g] / static_cast<double>(want[g].count), 1e-9);
+      EXPECT_EQ(got[g].count, expect[g].count);
+      EXPECT_TRUE(got[g].sum_qty == expect[g].sum_qty);                       // integer-valued doubles: exact
+      EXPECT_NEAR(got[g].sum_price, expect[g].sum_price, 1e-9 * expect[g].sum_price);
+      EXPECT_NEAR(got[g].sum_disc_price, expect[g].sum_disc_price, 1e-9 * expect[g].sum_disc_price);
+      EXPECT_NEAR(got[g].avg_disc, expect_disc[g] / static_cast<double>(expect[g].count), 1e-9);
     }
   }
   unsetenv("QSX_AGG_FACTORED_MIN_ROWS");
+  unsetenv("QSX_AGG_FACTORED_CODED_PREDICATES");
 }
 }  // namespace
 

@@ -355,12 +355,13 @@ def test_which_plans_factor_through_their_dictionary_columns(capi):
     assert got[4] == 0 and got[5:9] == [-1, -1, -1, -1]   # SUM(qty) reads the histogram, the others the cells
     # the same plan over plain columns has nothing to factor through
     assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, **q1))[0] == 0
-    # price * price is not affine; MIN / MAX do not factor; a predicate inside the state keeps the decoding kernels
+    # price * price is not affine; MIN / MAX do not factor; a predicate inside the state does not stand in the way (a pass of
+    # its own turns it into the call's filter)
     square = dict(q1, instrs=[(T.EX_MUL, 0, T.col(3), T.col(3)), (T.EX_MUL, 1, T.temp(0), T.col(4))], aggs=[(T.AGG_SUM, T.temp(1))])
     assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, **square))[0] == 0
     minmax = dict(q1, aggs=[(T.AGG_SUM, T.col(4)), (T.AGG_MAX, T.col(3))])
     assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, **minmax))[0] == 0
-    assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, pred=[(3, T.LT, 1000.0)], **q1))[0] == 0
+    assert plan(T.make_agg_config(T.AGG_COMPACT_KEY, layout, code_widths=coded, pred=[(3, T.LT, 1000.0)], **q1))[:4] == [1, 2, 1, 1]
     # price + disc is affine (the constant part multiplies the cell's count); price / (1 + tax) divides by a dictionary-only term
     affine = dict(q1, instrs=[(T.EX_ADD, 0, T.col(3), T.col(4)), (T.EX_ADD, 1, T.const(0), T.col(5)), (T.EX_DIV, 2, T.col(3), T.temp(1))],
                   aggs=[(T.AGG_SUM, T.temp(0)), (T.AGG_SUM, T.temp(2))])

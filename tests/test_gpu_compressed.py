@@ -682,3 +682,73 @@ def test_factored_aggregation_reads_stripes_at_any_byte_address(capi, oracle, de
     st.update_coded_blocks(blocks, block_dicts)
     assert _factored_launches(capi) - before == 4, "misaligned stripes did not take the factored kernel"
     assert_same_groups(finalize_np(st, dev), o.finalize())
+
+
+@pytest.mark.parametrize("pred_kind", ["plain_int", "coded_double", "two_terms", "date"])
+def test_factored_aggregation_under_the_states_predicate(capi, oracle, dev, pred_kind, monkeypatch):
+    """TPC-H Q1 as the reference runs it has its predicate inside the aggregation (l_shipdate <= DATE: the operator's
+    predicate_, storage/AggregationOperationState.cpp:428-440).  A state that factors through the dictionary codes keeps doing
+    so: a pass of its own (factored_predicate_kernel) evaluates the terms — on plain values, or on codes through the block's
+    dictionary — into the filter bitmap of the call, ANDed with the caller's own filter.  One stripe and a run of blocks with
+    per-block dictionaries, against the oracle (which evaluates the predicate row by row like the reference)."""
+    monkeypatch.setenv("QSX_AGG_FACTORED_MIN_ROWS", "0")
+    monkeypatch.setenv("QSX_AGG_JIT_MIN_ROWS", str(1 << 60))
+    # terms on plain stripes go through the K1 kernels, chained through the bitmap; a term on a compressed attribute takes
+    # factored_predicate_kernel (values through the dictionary), which a state only does when asked to
+    if pred_kind in ("coded_double", "two_terms"):
+        monkeypatch.setenv("QSX_AGG_FACTORED_CODED_PREDICATES", "1")
+    else:
+        monkeypatch.delenv("QSX_AGG_FACTORED_CODED_PREDICATES", raising=False)
+    rng = np.random.default_rng(2100)
+    spec = _FACTORED_PLANS["q1"]
+    date_type = (T.DATE, None) if pred_kind == "date" else (T.INT, None)
+    layout = [(T.CHAR, 1), (T.CHAR, 1)] + [(T.DOUBLE, None)] * 4 + [date_type]
+    if pred_kind == "plain_int":
+        pred = [(6, T.LE, 19980902)]
+    elif pred_kind == "coded_double":
+        pred = [(4, T.GE, 0.045)]                       # l_discount >= 0.045: a dictionary column, between two of its values
+    elif pred_kind == "two_terms":
+        pred = [(6, T.LE, 19980902), (2, T.LT, 24.0)]   # and l_quantity < 24 (a dictionary column)
+    else:
+        pred = [(6, T.LE, T.date_raw(1998, 9, 2))]
+    from test_gpu_agg import assert_same_groups, finalize_np
+    cfg = None
+    st = o = None
+    before = _factored_launches(capi)
+    blocks, block_dicts, filters, host = [], [], [], []
+    for b, n in enumerate((2048 * 4 + 9, 51_003, 700, 2048 * 3)):
+        letters = np.frombuffer(b"ANR", dtype=np.uint8)
+        qty = rng.choice(rng.choice(np.arange(1, 51), size=int(rng.integers(20, 51)), replace=False).astype(np.float64), size=n)
+        disc = rng.choice(rng.choice(np.arange(0, 11), size=int(rng.integers(3, 12)), replace=False) / 100.0, size=n)
+        if pred_kind == "date":
+            years, months, days = rng.integers(1996, 2001, size=n), rng.integers(1, 13, size=n), rng.integers(1, 29, size=n)
+            ship = ((years.astype(np.int64) & 0xFFFFFFFF) | (months.astype(np.int64) << 32) | (days.astype(np.int64) << 40) |
+                    (rng.integers(0, 1 << 16, size=n).astype(np.int64) << 48)).astype(np.int64)     # (the padding bytes are never looked at)
+        else:
+            ship = (19980101 + rng.integers(0, 1200, size=n)).astype(np.int32)
+        cols = [rng.choice(letters, size=n), rng.choice(np.frombuffer(b"FO", dtype=np.uint8), size=n), qty,
+                np.round(rng.uniform(900, 105000, size=n), 2), disc, rng.integers(0, 9, size=n) / 100.0, ship]
+        comp = {2: _coded(oracle, cols[2]), 4: _coded(oracle, cols[4]), 5: _coded(oracle, cols[5])}
+        widths = [comp[i].code_width if i in comp else 0 for i in range(7)]
+        if cfg is None:
+            cfg = T.make_agg_config(T.AGG_COMPACT_KEY, layout, keys=[0, 1], instrs=spec["instrs"], consts=spec["consts"], aggs=spec["aggs"],
+                                    est_groups=6, code_widths=widths, pred=pred)
+            st, o = capi.AggState(cfg), oracle.AggState(cfg)
+        code_cols = [comp[i].codes if i in comp else cols[i] for i in range(7)]
+        dicts = [comp[i].dictionary if i in comp else None for i in range(7)]
+        filt = oracle.bitmap_from_bools(rng.random(n) < 0.8) if b % 2 == 1 else None
+        dev_cols = [to_dev(c, dev) for c in code_cols]
+        dev_dicts = [None if d is None else to_dev(d, dev) for d in dicts]
+        st.update_coded(dev_cols, dev_dicts, n, filter_bitmap=None if filt is None else bitmap_dev(filt, dev))     # one stripe
+        o.update_coded(code_cols, dicts, n, filter_bitmap=filt)
+        o.update_coded(code_cols, dicts, n, filter_bitmap=filt)                                                   # (and in the run below)
+        blocks.append(dev_cols)
+        block_dicts.append(dev_dicts)
+        filters.append(None if filt is None else bitmap_dev(filt, dev))
+        host.append((code_cols, dicts, n))
+    st.update_coded_blocks(blocks, block_dicts, filters)
+    st.update_coded_blocks(blocks[::2], block_dicts[::2])          # no filter of the caller's at all
+    for i in (0, 2):
+        o.update_coded(host[i][0], host[i][1], host[i][2])
+    assert _factored_launches(capi) - before == 6, "a state with a predicate did not take the factored kernels"
+    assert_same_groups(finalize_np(st, dev), o.finalize())
