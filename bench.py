@@ -1200,6 +1200,13 @@ def operators_leg(args, raw_value):
     if "rows_per_s" in coded:
         coded["fraction_of_raw_abi_value"] = coded["rows_per_s"] / raw_value
     out["compressed_lineitem"] = coded
+    # and with TPC-H Q1's WHERE l_shipdate <= DATE inside the aggregation, l_shipdate one more dictionary-coded attribute (2-byte
+    # codes, a dictionary per block) of images sorted on l_orderkey: the predicate is scanned on the code stripes, rewritten on
+    # every block's own dictionary
+    with_predicate = child(2)
+    if "rows_per_s" in with_predicate:
+        with_predicate["fraction_of_raw_abi_value"] = with_predicate["rows_per_s"] / raw_value
+    out["compressed_lineitem_q1_predicate"] = with_predicate
     out["fraction_of_raw_abi_value"] = out["rows_per_s"] / raw_value
     out["note"] = ("the operators' join produces its output relation (one INT attribute from each side, written by the probe: "
                    "qsx_join_probe_project_blocks) where the raw-ABI step stops at the (probe_tid, build_tid) pairs: "

@@ -1066,7 +1066,14 @@ static int launch_select_packed(const void *col, int64_t n, Pred pred, const uin
   return QSX_OK;
 }
 
-static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// May a stripe that starts at p take the kernels that read 16 bytes per lane?  Any stripe may: gfx950 under this stack serves
+// unaligned 16-byte global loads (tools/unaligned_probe.py), and the stripes of a reference block image start at multiples of the
+// block's tuple capacity, aligned to nothing — a run of 2726 adopted lineitem blocks took 2726 row-per-lane launches per term
+// before (10 ms per 600 M rows instead of 0.3).  QSX_SELECT_ALIGNED_ONLY=1 restores the 16-byte requirement.
+static bool aligned16(const void *p) {
+  static const bool strict = [] { const char *e = getenv("QSX_SELECT_ALIGNED_ONLY"); return e != nullptr && e[0] == '1'; }();
+  return !strict || (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
 
 template <typename T, int OP>
 static int launch_select_runs(const long long *runs_dev, long long tiles, const void *literal, int64_t *out_counts, hipStream_t stream) {

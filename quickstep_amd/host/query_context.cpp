@@ -83,6 +83,139 @@ void *Predicate::getMatchesForBlock(const StorageBlock &block, std::int64_t *num
 }
 
 // ---------------------------------------------------------------------------
+// A predicate over a RUN of blocks (the SelectOperator's work orders over runs; the aggregation over runs of compressed blocks)
+// ---------------------------------------------------------------------------
+// Can the run forms evaluate `predicate` over these blocks in one launch per term?  Terms against a literal on attributes
+// without NULLs, every block coding and ordering a term's attribute like the first non-empty one.
+bool RunPredicateCovers(const Predicate &predicate, const std::vector<BlockReference> &blocks) {
+  const StorageBlock *reference_block = nullptr;   // the first non-empty block: what the others have to agree with
+  for (const BlockReference &block : blocks) {
+    const StorageBlock &b = *block;
+    for (const ComparisonPredicate &term : predicate.conjuncts) {
+      const Type &t = b.getRelation().getAttributeType(term.attribute);
+      if (term.rhs_attribute != kInvalidAttributeID || b.nullBitmap(term.attribute) != nullptr) return false;
+      if (b.numTuples() == 0) continue;                 // (an empty block has neither codes nor an order to agree on)
+      // a term on the blocks' sort column is a per-block binary search (also on the code stripe of a compressed sort column), a
+      // term on a compressed attribute a scan of the code stripes with the comparison rewritten per block
+      if (t.id == kChar && b.compressedAttribute(term.attribute) == nullptr && term.attribute == b.sortColumn()) return false;
+      if (reference_block == nullptr) reference_block = &b;
+      const StorageBlock &f = *reference_block;
+      if ((term.attribute == b.sortColumn()) != (term.attribute == f.sortColumn())) return false;
+      const CompressedAttribute *cb = b.compressedAttribute(term.attribute), *cf = f.compressedAttribute(term.attribute);
+      if ((cb != nullptr) != (cf != nullptr) || (cb != nullptr && cb->code_width != cf->code_width)) return false;
+    }
+  }
+  return true;
+}
+
+// The TupleIdSequences of the run's blocks under `predicate` (RunPredicateCovers said yes), every term one launch over the run,
+// chained like a conjunction behind `in_filters` (per block, entries may be null; or nullptr): out->bitmaps[b] is block b's
+// bitmap, out->counts the per-block match counts of the last term (device memory).
+void RunPredicateMatches(const Predicate &predicate, const std::vector<BlockReference> &blocks, const std::vector<std::int64_t> &rows,
+                         const std::uint64_t *const *in_filters, RunMatches *out) {
+  const std::size_t nb = blocks.size();
+  std::size_t bitmap_words = 0;
+  const StorageBlock *reference_block = blocks.empty() ? nullptr : blocks.front().get();
+  for (std::size_t b = 0; b < nb; ++b) {
+    bitmap_words += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
+    if (reference_block != nullptr && reference_block->numTuples() == 0 && blocks[b]->numTuples() != 0) reference_block = blocks[b].get();
+  }
+  // two sets of per-block bitmaps in two allocations, the terms ping-pong between them
+  out->set_a.reset(new DeviceBuffer(bitmap_words * 8 + 8));
+  out->set_b.reset(new DeviceBuffer(bitmap_words * 8 + 8));
+  out->counts.reset(new DeviceBuffer(nb * 8 + 8));
+  std::vector<std::uint64_t *> cur(nb), nxt(nb);
+  std::size_t at = 0;
+  for (std::size_t b = 0; b < nb; ++b) {
+    cur[b] = static_cast<std::uint64_t *>(out->set_a->ptr) + at;
+    nxt[b] = static_cast<std::uint64_t *>(out->set_b->ptr) + at;
+    at += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
+  }
+  std::vector<const void *> stripes(nb);
+  bool first = true;
+  for (const ComparisonPredicate &term : predicate.conjuncts) {
+    const Type &t = blocks.front()->getRelation().getAttributeType(term.attribute);
+    const StorageBlock &ref = *reference_block;
+    if (ref.compressedAttribute(term.attribute) == nullptr) {   // (a compressed sort column is searched on its codes)
+      for (std::size_t b = 0; b < nb; ++b) stripes[b] = blocks[b]->stripe(term.attribute);
+    }
+    const std::uint64_t *const *in = first ? in_filters : reinterpret_cast<const std::uint64_t *const *>(cur.data());
+    const bool on_sort_column = term.attribute == ref.sortColumn();
+    if (on_sort_column && ref.compressedAttribute(term.attribute) != nullptr) {
+      // the sort column of compressed blocks: the comparison rewritten on every block's own codes
+      // (CompressedTupleStorageSubBlock::getMatchesForPredicate), then one search per block on the code stripes
+      std::vector<std::int32_t> ops(nb);
+      std::vector<std::uint32_t> firsts(nb), seconds(nb);
+      for (std::size_t b = 0; b < nb; ++b) {
+        const CompressedAttribute *c = blocks[b]->compressedAttribute(term.attribute);
+        if (c == nullptr) {   // an empty block
+          stripes[b] = nullptr;
+          ops[b] = QSX_CODE_LT;
+          firsts[b] = seconds[b] = 0;
+          continue;
+        }
+        const PredicateTransformResult r = TransformPredicateOnCompressedAttribute(*c, t.id, term.comparison, term.literal);
+        stripes[b] = c->codes;
+        if (r.type == PredicateTransformResult::kAll || r.type == PredicateTransformResult::kNone) {
+          ops[b] = r.type == PredicateTransformResult::kAll ? QSX_CODE_GE : QSX_CODE_LT;   // every code / no code
+          firsts[b] = seconds[b] = 0;
+        } else {
+          ops[b] = r.comp;
+          firsts[b] = r.first_literal;
+          seconds[b] = r.second_literal;
+        }
+      }
+      CheckStatus(qsx_select_codes_sorted_blocks(ref.compressedAttribute(term.attribute)->code_width, static_cast<std::int64_t>(nb),
+                                                 rows.data(), stripes.data(), ops.data(), firsts.data(), seconds.data(), in, nxt.data(),
+                                                 static_cast<std::int64_t *>(out->counts->ptr), CurrentStream()), "qsx_select_codes_sorted_blocks");
+    } else if (ref.compressedAttribute(term.attribute) != nullptr) {
+      // a compressed attribute: every block's code stripe scanned with the comparison rewritten on that block's codes
+      std::vector<std::int32_t> ops(nb);
+      std::vector<std::uint32_t> firsts(nb), seconds(nb);
+      for (std::size_t b = 0; b < nb; ++b) {
+        const CompressedAttribute *c = blocks[b]->compressedAttribute(term.attribute);
+        if (c == nullptr) {   // an empty block
+          stripes[b] = nullptr;
+          ops[b] = QSX_CODE_LT;
+          firsts[b] = seconds[b] = 0;
+          continue;
+        }
+        const PredicateTransformResult r = TransformPredicateOnCompressedAttribute(*c, t.id, term.comparison, term.literal);
+        stripes[b] = c->codes;
+        if (r.type == PredicateTransformResult::kAll || r.type == PredicateTransformResult::kNone) {
+          ops[b] = r.type == PredicateTransformResult::kAll ? QSX_CODE_GE : QSX_CODE_LT;
+          firsts[b] = seconds[b] = 0;
+        } else {
+          ops[b] = r.comp;
+          firsts[b] = r.first_literal;
+          seconds[b] = r.second_literal;
+        }
+      }
+      CheckStatus(qsx_select_codes_blocks(ref.compressedAttribute(term.attribute)->code_width, static_cast<std::int64_t>(nb), rows.data(),
+                                          stripes.data(), ops.data(), firsts.data(), seconds.data(), in, nxt.data(),
+                                          static_cast<std::int64_t *>(out->counts->ptr), CurrentStream()), "qsx_select_codes_blocks");
+    } else if (t.id == kChar) {
+      // CHAR(n) OP string literal on plain stripes (AsciiStringUncheckedComparator, AsciiStringComparators.hpp:218-251)
+      CheckStatus(qsx_select_cmp_char_blocks(t.width, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
+                                             term.literal.text.data(), static_cast<int>(term.literal.text.size()), in, nxt.data(),
+                                             static_cast<std::int64_t *>(out->counts->ptr), CurrentStream()), "qsx_select_cmp_char_blocks");
+    } else if (on_sort_column) {
+      // SortColumnPredicateEvaluator (storage/ColumnStoreUtil.cpp:40-280), one search per block
+      CheckStatus(qsx_select_cmp_sorted_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
+                                               &term.literal.v, in, nxt.data(), static_cast<std::int64_t *>(out->counts->ptr), CurrentStream()),
+                  "qsx_select_cmp_sorted_blocks");
+    } else {
+      CheckStatus(qsx_select_cmp_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
+                                        &term.literal.v, in, nxt.data(), static_cast<std::int64_t *>(out->counts->ptr), CurrentStream()),
+                  "qsx_select_cmp_blocks");
+    }
+    std::swap(cur, nxt);
+    first = false;
+  }
+  out->bitmaps = cur;
+}
+
+// ---------------------------------------------------------------------------
 // InsertDestination
 // ---------------------------------------------------------------------------
 BlockReference InsertDestination::getBlockForInsertion(std::int64_t capacity, block_id *id) {
@@ -543,6 +676,7 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
       if (coded_state_ == nullptr && !coded_merged_) {
         coded_config_ = config_;
         for (std::size_t i = 0; i < column_attr_.size(); ++i) coded_config_.column_code_width[i] = code_width[i];
+        externalizeCodedPredicate();
         CheckStatus(qsx_agg_state_create(&coded_config_, &coded_state_), "qsx_agg_state_create");
       }
       if (coded_state_ != nullptr && !coded_merged_) {
@@ -560,7 +694,14 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
         dicts[i] = ca != nullptr && ca->kind == CompressedAttribute::kDictionary ? ca->dictionary : nullptr;
         dict_entries[i] = dicts[i] != nullptr ? static_cast<std::int32_t>(ca->num_codes) : 0;
       }
-      CheckStatus(qsx_agg_update_coded_sized(coded_state_, cols, dicts, dict_entries, n, lip_filter, CurrentStream()),
+      OwnedBitmap predicate_matches;
+      const std::uint64_t *coded_filter = lip_filter;
+      if (coded_predicate_external_) {   // the state over code stripes leaves its predicate to the scans on codes (externalizeCodedPredicate)
+        std::int64_t matches = 0;
+        predicate_matches.ptr = spec_.predicate->getMatchesForBlock(block, &matches, lip_filter);
+        coded_filter = static_cast<const std::uint64_t *>(predicate_matches.ptr);
+      }
+      CheckStatus(qsx_agg_update_coded_sized(coded_state_, cols, dicts, dict_entries, n, coded_filter, CurrentStream()),
                   "qsx_agg_update_coded_sized");
       ++coded_blocks_;
       CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
@@ -577,6 +718,18 @@ void AggregationOperationState::aggregateBlock(const StorageBlock &block, const 
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
 }
 
+// The state over code stripes leaves a predicate that the kernel would have evaluated on DECODED values to the scans on codes
+// instead (Predicate::getMatchesForBlock / RunPredicateMatches: the comparison rewritten on every block's own dictionary,
+// storage/CompressedStoreUtil.cpp:51-140 — a code stripe is an eighth of the column) and takes the resulting TupleIdSequence as
+// its filter.  The state then has no predicate of its own, which also lets its aggregates factor through the dictionary codes
+// (csrc/agg_factored.hpp): TPC-H Q1's l_shipdate <= DATE over lineitem's compressed blocks.  Called with coded_mutex_ held.
+void AggregationOperationState::externalizeCodedPredicate() {
+  if (coded_config_.num_pred_terms > 0 && spec_.predicate != nullptr && external_predicate_.conjuncts.empty()) {
+    coded_config_.num_pred_terms = 0;
+    coded_predicate_external_ = true;
+  }
+}
+
 void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference> &blocks,
                                                 const std::vector<const std::uint64_t *> &lip_filters) {
   std::vector<std::int64_t> rows;
@@ -587,6 +740,7 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
   std::vector<const void *> coded_cols, coded_dicts;
   std::vector<std::int32_t> coded_entries;   // every block's dictionary sizes (the reference builds a dictionary per block)
   std::vector<const std::uint64_t *> coded_filters;
+  std::vector<BlockReference> coded_refs;
   bool any_coded_filter = false;
   const bool state_allows = state_ != nullptr && distinctify_.empty() && external_predicate_.conjuncts.empty();
   for (std::size_t i = 0; i < blocks.size(); ++i) {
@@ -613,6 +767,7 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
         if (coded_state_ == nullptr && !coded_merged_) {
           coded_config_ = config_;
           for (std::size_t c = 0; c < column_attr_.size(); ++c) coded_config_.column_code_width[c] = code_width[c];
+          externalizeCodedPredicate();
           CheckStatus(qsx_agg_state_create(&coded_config_, &coded_state_), "qsx_agg_state_create");
         }
         if (coded_state_ != nullptr && !coded_merged_) {
@@ -625,6 +780,7 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
         continue;
       }
       coded_rows.push_back(block.numTuples());
+      coded_refs.push_back(blocks[i]);
       for (std::size_t c = 0; c < column_attr_.size(); ++c) {
         const CompressedAttribute *ca = code_width[c] != 0 ? block.compressedAttribute(column_attr_[c]) : nullptr;
         coded_cols.push_back(ca != nullptr ? ca->codes : block.stripe(column_attr_[c]));
@@ -643,6 +799,19 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
     for (std::size_t c = 0; c < column_attr_.size(); ++c) cols.push_back(block.stripe(column_attr_[c]));
     filters.push_back(filter);
     any_filter = any_filter || filter != nullptr;
+  }
+  RunMatches coded_matches;
+  if (!coded_rows.empty() && coded_predicate_external_) {
+    // the predicate over the run's code stripes: every term one launch, rewritten on every block's own codes
+    // (RunPredicateMatches); a run the run forms do not cover goes block by block
+    if (!RunPredicateCovers(*spec_.predicate, coded_refs)) {
+      for (std::size_t b = 0; b < coded_refs.size(); ++b) aggregateBlock(*coded_refs[b], coded_filters[b]);
+      coded_rows.clear();
+    } else {
+      RunPredicateMatches(*spec_.predicate, coded_refs, coded_rows, any_coded_filter ? coded_filters.data() : nullptr, &coded_matches);
+      for (std::size_t b = 0; b < coded_refs.size(); ++b) coded_filters[b] = coded_matches.bitmaps[b];
+      any_coded_filter = true;
+    }
   }
   if (!coded_rows.empty()) {
     CheckStatus(qsx_agg_update_coded_blocks_sized(coded_state_, static_cast<int>(coded_rows.size()), coded_rows.data(), coded_cols.data(),

@@ -521,6 +521,8 @@ class AggregationOperationState {
   // block, blocks coded differently take the value path; merged into state_ before the first finalize.
   qsx_agg_state_t *coded_state_ = nullptr;
   qsx_agg_config_t coded_config_;
+  bool coded_predicate_external_ = false;   // the coded state takes the predicate as a filter (externalizeCodedPredicate)
+  void externalizeCodedPredicate();
   bool coded_merged_ = false;
   std::mutex coded_mutex_;
   std::atomic<std::int64_t> coded_blocks_{0};

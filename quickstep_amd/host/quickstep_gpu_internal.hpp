@@ -239,6 +239,15 @@ using namespace host_internal;   // (this header is included by the layer's own 
 
 void CheckRepartition(const char *op, bool has_repartition, const InsertDestination *dest);   // (query_context.cpp)
 
+// A predicate over a run of blocks (query_context.cpp): per-block TupleIdSequences in two device allocations.
+struct RunMatches {
+  std::unique_ptr<DeviceBuffer> set_a, set_b, counts;
+  std::vector<std::uint64_t *> bitmaps;   // block b's bitmap under the whole conjunction
+};
+bool RunPredicateCovers(const Predicate &predicate, const std::vector<BlockReference> &blocks);
+void RunPredicateMatches(const Predicate &predicate, const std::vector<BlockReference> &blocks, const std::vector<std::int64_t> &rows,
+                         const std::uint64_t *const *in_filters, RunMatches *out);
+
 }  // namespace quickstep
 
 #endif  // QUICKSTEP_GPU_INTERNAL_HPP_

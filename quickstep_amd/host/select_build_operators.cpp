@@ -102,23 +102,9 @@ bool SelectWorkOrder::executeRun() {
   std::vector<std::int64_t> rows;
   std::int64_t total_rows = 0;
   std::size_t bitmap_words = 0;
-  const StorageBlock *reference_block = nullptr;   // the first non-empty block: what the others have to agree with
   for (block_id id : run_block_ids_) {
     blocks.push_back(storage_manager_->getBlock(id));
     const StorageBlock &b = *blocks.back();
-    for (const ComparisonPredicate &term : predicate.conjuncts) {
-      const Type &t = b.getRelation().getAttributeType(term.attribute);
-      if (term.rhs_attribute != kInvalidAttributeID || b.nullBitmap(term.attribute) != nullptr) return false;
-      if (b.numTuples() == 0) continue;                 // (an empty block has neither codes nor an order to agree on)
-      // a term on the blocks' sort column is a per-block binary search (also on the code stripe of a compressed sort column), a
-      // term on a compressed attribute a scan of the code stripes with the comparison rewritten per block
-      if (t.id == kChar && b.compressedAttribute(term.attribute) == nullptr && term.attribute == b.sortColumn()) return false;
-      if (reference_block == nullptr) reference_block = &b;
-      const StorageBlock &f = *reference_block;
-      if ((term.attribute == b.sortColumn()) != (term.attribute == f.sortColumn())) return false;
-      const CompressedAttribute *cb = b.compressedAttribute(term.attribute), *cf = f.compressedAttribute(term.attribute);
-      if ((cb != nullptr) != (cf != nullptr) || (cb != nullptr && cb->code_width != cf->code_width)) return false;
-    }
     for (attribute_id a : selection) {
       if (b.nullBitmap(a) != nullptr) return false;   // (projected values of a compressed attribute: stripe() decodes once)
     }
@@ -126,17 +112,8 @@ bool SelectWorkOrder::executeRun() {
     total_rows += b.numTuples();
     bitmap_words += static_cast<std::size_t>((b.numTuples() + 63) / 64) + 1;
   }
+  if (!RunPredicateCovers(predicate, blocks)) return false;
   const std::size_t nb = blocks.size();
-  // two sets of per-block bitmaps in two allocations, the terms ping-pong between them
-  DeviceBuffer set_a(bitmap_words * 8 + 8), set_b(bitmap_words * 8 + 8), counts(nb * 8 + 8);
-  std::vector<std::uint64_t *> cur(nb), nxt(nb);
-  std::size_t at = 0;
-  for (std::size_t b = 0; b < nb; ++b) {
-    cur[b] = static_cast<std::uint64_t *>(set_a.ptr) + at;
-    nxt[b] = static_cast<std::uint64_t *>(set_b.ptr) + at;
-    at += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
-  }
-  std::vector<const void *> stripes(nb);
   // SelectOperator.cpp:161-195: predicate matches, then the LIP filters on what is left — here the filters run first and
   // the predicate only looks at their survivors (the same conjunction, as in the single-block form)
   struct OwnedStorage {
@@ -149,96 +126,17 @@ bool SelectWorkOrder::executeRun() {
       !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps, has_terms ? nullptr : &lip_hits)) {
     return false;
   }
-  bool first = true;
-  for (const ComparisonPredicate &term : predicate.conjuncts) {
-    const Type &t = blocks.front()->getRelation().getAttributeType(term.attribute);
-    const StorageBlock &ref = reference_block != nullptr ? *reference_block : *blocks.front();
-    if (ref.compressedAttribute(term.attribute) == nullptr) {   // (a compressed sort column is searched on its codes)
-      for (std::size_t b = 0; b < nb; ++b) stripes[b] = blocks[b]->stripe(term.attribute);
-    }
-    const std::uint64_t *const *in = first ? (lip_bitmaps.empty() ? nullptr : lip_bitmaps.data())
-                                           : reinterpret_cast<const std::uint64_t *const *>(cur.data());
-    const bool on_sort_column = term.attribute == ref.sortColumn();
-    if (on_sort_column && ref.compressedAttribute(term.attribute) != nullptr) {
-      // the sort column of compressed blocks: the comparison rewritten on every block's own codes
-      // (CompressedTupleStorageSubBlock::getMatchesForPredicate), then one search per block on the code stripes
-      std::vector<std::int32_t> ops(nb);
-      std::vector<std::uint32_t> firsts(nb), seconds(nb);
-      for (std::size_t b = 0; b < nb; ++b) {
-        const CompressedAttribute *c = blocks[b]->compressedAttribute(term.attribute);
-        if (c == nullptr) {   // an empty block
-          stripes[b] = nullptr;
-          ops[b] = QSX_CODE_LT;
-          firsts[b] = seconds[b] = 0;
-          continue;
-        }
-        const PredicateTransformResult r = TransformPredicateOnCompressedAttribute(*c, t.id, term.comparison, term.literal);
-        stripes[b] = c->codes;
-        if (r.type == PredicateTransformResult::kAll || r.type == PredicateTransformResult::kNone) {
-          ops[b] = r.type == PredicateTransformResult::kAll ? QSX_CODE_GE : QSX_CODE_LT;   // every code / no code
-          firsts[b] = seconds[b] = 0;
-        } else {
-          ops[b] = r.comp;
-          firsts[b] = r.first_literal;
-          seconds[b] = r.second_literal;
-        }
-      }
-      CheckStatus(qsx_select_codes_sorted_blocks(ref.compressedAttribute(term.attribute)->code_width, static_cast<std::int64_t>(nb),
-                                                 rows.data(), stripes.data(), ops.data(), firsts.data(), seconds.data(), in, nxt.data(),
-                                                 static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_codes_sorted_blocks");
-    } else if (ref.compressedAttribute(term.attribute) != nullptr) {
-      // a compressed attribute: every block's code stripe scanned with the comparison rewritten on that block's codes
-      std::vector<std::int32_t> ops(nb);
-      std::vector<std::uint32_t> firsts(nb), seconds(nb);
-      for (std::size_t b = 0; b < nb; ++b) {
-        const CompressedAttribute *c = blocks[b]->compressedAttribute(term.attribute);
-        if (c == nullptr) {   // an empty block
-          stripes[b] = nullptr;
-          ops[b] = QSX_CODE_LT;
-          firsts[b] = seconds[b] = 0;
-          continue;
-        }
-        const PredicateTransformResult r = TransformPredicateOnCompressedAttribute(*c, t.id, term.comparison, term.literal);
-        stripes[b] = c->codes;
-        if (r.type == PredicateTransformResult::kAll || r.type == PredicateTransformResult::kNone) {
-          ops[b] = r.type == PredicateTransformResult::kAll ? QSX_CODE_GE : QSX_CODE_LT;
-          firsts[b] = seconds[b] = 0;
-        } else {
-          ops[b] = r.comp;
-          firsts[b] = r.first_literal;
-          seconds[b] = r.second_literal;
-        }
-      }
-      CheckStatus(qsx_select_codes_blocks(ref.compressedAttribute(term.attribute)->code_width, static_cast<std::int64_t>(nb), rows.data(),
-                                          stripes.data(), ops.data(), firsts.data(), seconds.data(), in, nxt.data(),
-                                          static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_codes_blocks");
-    } else if (t.id == kChar) {
-      // CHAR(n) OP string literal on plain stripes (AsciiStringUncheckedComparator, AsciiStringComparators.hpp:218-251)
-      CheckStatus(qsx_select_cmp_char_blocks(t.width, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
-                                             term.literal.text.data(), static_cast<int>(term.literal.text.size()), in, nxt.data(),
-                                             static_cast<std::int64_t *>(counts.ptr), CurrentStream()), "qsx_select_cmp_char_blocks");
-    } else if (on_sort_column) {
-      // SortColumnPredicateEvaluator (storage/ColumnStoreUtil.cpp:40-280), one search per block
-      CheckStatus(qsx_select_cmp_sorted_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
-                                               &term.literal.v, in, nxt.data(), static_cast<std::int64_t *>(counts.ptr), CurrentStream()),
-                  "qsx_select_cmp_sorted_blocks");
-    } else {
-      CheckStatus(qsx_select_cmp_blocks(t.id, static_cast<std::int64_t>(nb), rows.data(), stripes.data(), static_cast<int>(term.comparison),
-                                        &term.literal.v, in, nxt.data(), static_cast<std::int64_t *>(counts.ptr), CurrentStream()),
-                  "qsx_select_cmp_blocks");
-    }
-    std::swap(cur, nxt);
-    first = false;
-  }
+  RunMatches run_matches;
+  if (has_terms) RunPredicateMatches(predicate, blocks, rows, lip_bitmaps.empty() ? nullptr : lip_bitmaps.data(), &run_matches);
   std::int64_t matches = lip_hits;
   const std::uint64_t *const *selected = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();   // only LIP filters: their bitmaps
   if (has_terms) {
     std::vector<std::int64_t> block_matches(nb);
-    CheckStatus(qsx_copy_to_host(block_matches.data(), counts.ptr, nb * 8, CurrentStream()), "qsx_copy_to_host");
+    CheckStatus(qsx_copy_to_host(block_matches.data(), run_matches.counts->ptr, nb * 8, CurrentStream()), "qsx_copy_to_host");
     CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
     matches = 0;
     for (std::int64_t m : block_matches) matches += m;
-    selected = reinterpret_cast<const std::uint64_t *const *>(cur.data());
+    selected = reinterpret_cast<const std::uint64_t *const *>(run_matches.bitmaps.data());
   }
   block_id out_id;
   BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);

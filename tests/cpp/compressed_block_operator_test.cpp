@@ -176,9 +176,12 @@ struct Q1Group {
   double sum_qty = 0, sum_price = 0, sum_disc_price = 0, avg_disc = 0;
 };
 
-// with_predicate: a predicate inside the aggregation (Q1's l_shipdate <= DATE is such a predicate_ of the operator).
-//   1: 20000 <= l_extendedprice < 95000 — two terms on a plain attribute (the K1 kernels make the filter);
-//   2: l_quantity < 24 AND l_extendedprice >= 20000 — a term on a dictionary-coded attribute (factored_predicate_kernel, on request).
+// with_predicate: a predicate inside the aggregation (Q1's l_shipdate <= DATE is such a predicate_ of the operator).  The state
+// over code stripes leaves it to the scans (AggregationOperationState::externalizeCodedPredicate): terms on compressed attributes
+// are rewritten on every block's own codes and scanned on the code stripes, the state takes the TupleIdSequence as its filter
+// and keeps factoring.
+//   1: 20000 <= l_extendedprice < 95000 — two terms on a plain attribute;
+//   2: l_quantity < 24 AND l_extendedprice >= 20000 — a term on a dictionary-coded attribute.
 bool Q1RowPasses(const Q1Rows &rows, std::int64_t i, int with_predicate) {
   return with_predicate == 1 ? rows.price[i] >= 20000.0 && rows.price[i] < 95000.0 : rows.quantity[i] < 24.0 && rows.price[i] >= 20000.0;
 }
@@ -307,7 +310,6 @@ void testQ1OverCompressedBlocks() {
     const bool compressed = variant != 0 && variant != 6;
     const std::size_t per_work_order = variant <= 1 || variant == 6 ? 1 : (variant <= 3 || variant == 9 ? 3 : 4);
     const bool use_foreman = variant == 3 || variant == 5 || variant == 8;
-    if (with_predicate == 2) setenv("QSX_AGG_FACTORED_CODED_PREDICATES", "1", 1); else unsetenv("QSX_AGG_FACTORED_CODED_PREDICATES");
     const std::vector<Q1Group> got = runQ1(rows, compressed, per_work_order, use_foreman, with_predicate);
     const std::vector<Q1Group> &expect = with_predicate != 0 ? want_pred[with_predicate] : want;
     const std::vector<double> &expect_disc = with_predicate != 0 ? disc_sum_pred[with_predicate] : disc_sum;
@@ -320,7 +322,6 @@ void testQ1OverCompressedBlocks() {
     }
   }
   unsetenv("QSX_AGG_FACTORED_MIN_ROWS");
-  unsetenv("QSX_AGG_FACTORED_CODED_PREDICATES");
 }
 }  // namespace
 

@@ -64,7 +64,13 @@ int main(int argc, char **argv) {
   const int steps = argc > 4 ? std::atoi(argv[4]) : 5, warmup = argc > 5 ? std::atoi(argv[5]) : 2;
   const std::size_t workers = argc > 6 ? static_cast<std::size_t>(std::atoi(argv[6])) : 4;
   const std::size_t run_blocks = argc > 7 ? static_cast<std::size_t>(std::atoi(argv[7])) : 64;
-  const bool compressed_lineitem = argc > 8 && std::atoi(argv[8]) == 1;
+  const int lineitem_store = argc > 8 ? std::atoi(argv[8]) : 0;
+  const bool compressed_lineitem = lineitem_store == 1 || lineitem_store == 2;
+  // lineitem_store = 2: the block's sort column is l_orderkey, l_shipdate is one more dictionary-coded attribute (2-byte codes, a
+  // dictionary per block: COMPRESS ALL) and Q1's predicate l_shipdate <= DATE sits inside the aggregation, as in the reference's
+  // plan — scanned on the code stripes (rewritten on every block's own dictionary), the aggregation takes the TupleIdSequence.
+  const bool q1_predicate = lineitem_store == 2;
+  const std::int32_t shipdate_cutoff = 19920101 + 2475;   // of 19920101 .. 19920101 + 2525: ~98 % of the tuples, as in Q1
 
   StorageManager storage;
   CatalogRelation customer(1, "customer"), orders(2, "orders"), lineitem(3, "lineitem");
@@ -73,7 +79,8 @@ int main(int argc, char **argv) {
   lineitem.addAttribute("l_returnflag", Type::Char(1));
   lineitem.addAttribute("l_linestatus", Type::Char(1));
   for (const char *n : {"l_quantity", "l_extendedprice", "l_discount", "l_tax"}) lineitem.addAttribute(n, Type::Double());
-  if (compressed_lineitem) lineitem.addAttribute("l_shipdate", Type::Int());   // the block's sort column (create.sql: SORT l_shipdate)
+  if (compressed_lineitem) lineitem.addAttribute("l_shipdate", Type::Int());   // store 1: the block's sort column
+  if (q1_predicate) lineitem.addAttribute("l_orderkey", Type::Int());          // store 2: the block's sort column (create.sql: SORT l_orderkey)
 
   // ---- customer: a permutation of [0, build_rows) in 4 MB blocks ----------------------------------------------------------
   const std::int64_t int_block = kBlockBytes / 4;
@@ -98,26 +105,35 @@ int main(int argc, char **argv) {
   }
   // ---- lineitem: Q1 attributes, 4 MB = 123 361 rows of 34 bytes (plain) -----------------------------------------------------
   // compressed: the rows a 4 MB CompressedColumnStore block holds at 13 + 4 bytes per tuple behind its header and dictionaries
-  std::vector<block_image::Coding> coding(7);
+  const int image_attrs = q1_predicate ? 8 : 7, sort_attr = q1_predicate ? 7 : 6;
+  std::vector<block_image::Coding> coding(static_cast<std::size_t>(image_attrs));
   for (int a : {2, 4, 5}) {
     coding[a].kind = block_image::Coding::kDictionary;
     coding[a].code_width = 1;
+  }
+  if (q1_predicate) {
+    coding[6].kind = block_image::Coding::kDictionary;
+    coding[6].code_width = 2;
   }
   std::int64_t q1_block = kBlockBytes / 34;
   std::vector<void *> device_images;
   if (compressed_lineitem) {   // (the capacity depends on the dictionaries' sizes only: ask the builder with a small block)
     Q1Template t;
-    std::vector<std::int32_t> shipdate;
+    std::vector<std::int32_t> shipdate, orderkey;
     for (int i = 0; i < 4000; ++i) {
       t.flag.push_back('A'); t.status.push_back('F'); t.qty.push_back(1.0 + i % 50); t.price.push_back(1000.0 + i);
-      t.disc.push_back((i % 11) / 100.0); t.tax.push_back((i % 9) / 100.0); shipdate.push_back(i);
+      t.disc.push_back((i % 11) / 100.0); t.tax.push_back((i % 9) / 100.0); shipdate.push_back(q1_predicate ? 19920101 + i % 2526 : i);
+      orderkey.push_back(i);
     }
     std::int64_t capacity = 0;
-    (void)block_image::BuildCompressed(lineitem, {t.flag.data(), t.status.data(), t.qty.data(), t.price.data(), t.disc.data(), t.tax.data(), shipdate.data()},
-                                       std::vector<std::vector<bool>>(7), 4000, kBlockBytes, 6, coding, &capacity);
+    std::vector<const void *> columns = {t.flag.data(), t.status.data(), t.qty.data(), t.price.data(), t.disc.data(), t.tax.data(), shipdate.data()};
+    if (q1_predicate) columns.push_back(orderkey.data());
+    (void)block_image::BuildCompressed(lineitem, columns, std::vector<std::vector<bool>>(static_cast<std::size_t>(image_attrs)), 4000, kBlockBytes, sort_attr,
+                                       coding, &capacity);
     q1_block = capacity;
   }
   std::vector<Q1Template> q1(kTemplates);
+  std::vector<std::int32_t> shipdate_of_row;   // l_shipdate of row i of every block (the templates share the column)
   std::vector<std::int64_t> q1_uses(kTemplates, 0);
   std::int64_t last_block_rows = 0;
   int last_template = 0;
@@ -138,13 +154,22 @@ int main(int argc, char **argv) {
     }
     // compressed: one image per template in device memory; every block of the relation is a device copy of its template's
     std::vector<void *> template_images;
-    std::vector<std::int32_t> shipdate(static_cast<std::size_t>(q1_block));
-    for (std::int64_t i = 0; i < q1_block; ++i) shipdate[i] = static_cast<std::int32_t>(19920101 + i / 128);   // ascending: the sort column
+    std::vector<std::int32_t> shipdate(static_cast<std::size_t>(q1_block)), orderkey(static_cast<std::size_t>(q1_block));
+    {
+      Xorshift dates(9);
+      for (std::int64_t i = 0; i < q1_block; ++i) {
+        // store 1: ascending, the sort column; store 2: any of 2526 days (a 2-byte dictionary), the order keys ascend instead
+        shipdate[i] = q1_predicate ? static_cast<std::int32_t>(19920101 + dates.next() % 2526) : static_cast<std::int32_t>(19920101 + i / 128);
+        orderkey[i] = static_cast<std::int32_t>(i / 4);
+      }
+    }
+    shipdate_of_row = shipdate;
     auto build_image = [&](const Q1Template &t, std::int64_t rows) {
       std::int64_t capacity = 0;
+      std::vector<const void *> columns = {t.flag.data(), t.status.data(), t.qty.data(), t.price.data(), t.disc.data(), t.tax.data(), shipdate.data()};
+      if (q1_predicate) columns.push_back(orderkey.data());
       const std::vector<unsigned char> image = block_image::BuildCompressed(
-          lineitem, {t.flag.data(), t.status.data(), t.qty.data(), t.price.data(), t.disc.data(), t.tax.data(), shipdate.data()},
-          std::vector<std::vector<bool>>(7), rows, kBlockBytes, 6, coding, &capacity);
+          lineitem, columns, std::vector<std::vector<bool>>(static_cast<std::size_t>(image_attrs)), rows, kBlockBytes, sort_attr, coding, &capacity);
       EXPECT_TRUE(capacity >= rows);
       void *dev = nullptr;
       CheckStatus(qsx_device_alloc(image.size(), &dev), "qsx_device_alloc");
@@ -185,7 +210,11 @@ int main(int argc, char **argv) {
       EXPECT_TRUE(first->compressedAttribute(2) != nullptr && first->compressedAttribute(2)->kind == CompressedAttribute::kDictionary &&
                   first->compressedAttribute(2)->num_codes == 50 && first->compressedAttribute(4) != nullptr &&
                   first->compressedAttribute(4)->num_codes == 11 && first->compressedAttribute(5) != nullptr && first->compressedAttribute(5)->num_codes == 9);
-      EXPECT_TRUE(first->compressedAttribute(3) == nullptr && first->sortColumn() == 6);
+      EXPECT_TRUE(first->compressedAttribute(3) == nullptr && first->sortColumn() == sort_attr);
+      if (q1_predicate) {
+        EXPECT_TRUE(first->compressedAttribute(6) != nullptr && first->compressedAttribute(6)->kind == CompressedAttribute::kDictionary &&
+                    first->compressedAttribute(6)->code_width == 2);
+      }
     }
   }
   // expected Q1 groups from the templates
@@ -197,6 +226,7 @@ int main(int argc, char **argv) {
       std::map<std::pair<char, char>, std::int64_t> c;
       std::map<std::pair<char, char>, double> sq, sp, sd;
       for (std::int64_t i = 0; i < rows; ++i) {
+        if (q1_predicate && shipdate_of_row[static_cast<std::size_t>(i)] > shipdate_cutoff) continue;
         const auto k = std::make_pair(t.flag[i], t.status[i]);
         c[k] += 1;
         sq[k] += t.qty[i];
@@ -245,6 +275,11 @@ int main(int argc, char **argv) {
                        AggregateSpec(AggregationID::kAvg, 4), AggregateSpec(AggregationID::kCount, kInvalidAttributeID)};
     spec.strategy = QSX_AGG_COMPACT_KEY;
     spec.estimated_num_groups = 6;
+    if (q1_predicate) {   // WHERE l_shipdate <= DATE: the aggregation operator's own predicate (benchmarks/tpch/queries/01.sql)
+      Predicate where;
+      where.conjuncts.push_back({6, ComparisonID::kLessOrEqual, TypedLiteral::Int(shipdate_cutoff)});
+      spec.predicate = ctx.getPredicate(ctx.addPredicate(where));
+    }
     const auto state = ctx.addAggregationState(spec);
 
     QueryPlan plan;
@@ -343,7 +378,8 @@ int main(int argc, char **argv) {
               static_cast<long long>(kBlockBytes), static_cast<long long>((probe_rows + int_block - 1) / int_block),
               static_cast<long long>((agg_rows + q1_block - 1) / q1_block), work_orders, static_cast<long long>(build_rows),
               static_cast<long long>(probe_rows), static_cast<long long>(agg_rows),
-              compressed_lineitem ? "CompressedColumnStore images (13 B/row aggregated, per-block dictionaries)" : "plain column stripes (34 B/row)",
+              q1_predicate ? "CompressedColumnStore images sorted on l_orderkey, l_shipdate 2-byte dictionary codes; Q1's l_shipdate <= DATE inside the aggregation (13 + 2 B/row)"
+                           : (compressed_lineitem ? "CompressedColumnStore images (13 B/row aggregated, per-block dictionaries)" : "plain column stripes (34 B/row)"),
               static_cast<long long>(q1_block), static_cast<double>(qsx_debug_agg_factored_launches() - factored_before) / (warmup + steps),
               g_failures == 0 ? "true" : "false");
   return g_failures == 0 ? 0 : 1;

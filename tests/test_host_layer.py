@@ -154,6 +154,23 @@ def test_headline_workload_over_compressed_lineitem_images(blocks_per_work_order
 
 
 @pytest.mark.gpu
+def test_headline_workload_with_q1s_predicate_over_coded_shipdate():
+    """lineitem_store = 2 of the operators bench: block images sorted on l_orderkey, l_shipdate a dictionary-coded attribute
+    (2-byte codes, per-block dictionaries) and TPC-H Q1's l_shipdate <= DATE inside the AggregationOperator.  The state over
+    code stripes leaves the predicate to the scans on codes (one qsx_select_codes_blocks per work order, the comparison
+    rewritten on every block's own dictionary, stripes at whatever addresses the images give them) and keeps factoring its
+    aggregates; groups checked against the rows that pass."""
+    import json
+    _ensure_built()
+    r = subprocess.run([os.path.join(BIN, "headline_operators_bench"), "1000000", "20000000", "60000000", "3", "1", "4", "16", "2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '"checked": true' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "l_shipdate" in line["lineitem_store"]
+    assert line["factored_aggregation_launches_per_step"] == float(-(-line["aggregate_blocks"] // 16))
+
+
+@pytest.mark.gpu
 def test_reference_block_images_are_adopted_in_place():
     """Block images in the reference's layout ([int32 header length][StorageBlockHeader][{num_tuples, nulls_in_sort_column}]
     [null bitmaps][stripes at max_tuples x width]) copied to device memory as they are: Select / Aggregation / HashJoin over
