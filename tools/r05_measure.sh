@@ -54,6 +54,6 @@ bash tools/r05_blocks_trace.sh > $out/blocks_trace.txt 2>&1; cp gpurun_out/prof_
 python3 tools/pmc_summary.py $out/pmc_coded agg_factored qsx_jit_agg agg_hash > $out/pmc_summary_coded.txt 2>&1; head -14 $out/pmc_summary_coded.txt
 python3 tools/pmc_summary.py $out/pmc_lds_probe lds_dense lds_bucket dense_probe probe_fp > $out/pmc_summary_lds_probe.txt 2>&1; head -14 $out/pmc_summary_lds_probe.txt
 find $out/pmc_coded $out/pmc_lds_probe -name '*.csv' -size +1M -delete; find $out/pmc_coded $out/pmc_lds_probe -name '*.db' -delete
-for t in probe_hashed_sparse agg_coded_probe probe_small_tables agg_dir_probe agg_dense_probe select_char_probe; do timeout 300 python tools/$t.py > $out/$t.jsonl 2>/dev/null; done
+for t in probe_hashed_sparse agg_coded_probe probe_small_tables agg_dir_probe agg_dense_probe select_char_probe q1_predicate_probe; do timeout 300 python tools/$t.py > $out/$t.jsonl 2>/dev/null; done
 timeout 400 python tools/bench_ops.py > $out/bench_ops.jsonl 2>/dev/null; wc -l $out/*.jsonl
 ls $out/jit_shapes | wc -l
