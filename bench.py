@@ -1181,8 +1181,11 @@ def operators_leg(args, raw_value):
     if not os.path.exists(exe):
         return {"error": "tests/cpp/bin/headline_operators_bench is not built (make -C quickstep_amd/host)"}
     def child(lineitem_store):
+        # (the compressed relations take twice the blocks per work order: five or six aggregation work orders per step instead
+        # of ten — every one of them scans its predicate, builds its coefficient tables and settles its cells once)
+        blocks = args.blocks_per_work_order * (2 if lineitem_store != 0 else 1)
         cmd = [exe, str(args.build_rows), str(args.probe_rows), str(args.agg_rows), str(args.steps), str(max(args.warmup, 4)),
-               str(args.operator_workers), str(args.blocks_per_work_order), str(lineitem_store)]
+               str(args.operator_workers), str(blocks), str(lineitem_store)]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         except subprocess.TimeoutExpired:
