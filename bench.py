@@ -1184,7 +1184,9 @@ def operators_leg(args, raw_value):
         # (the compressed relations take twice the blocks per work order: five or six aggregation work orders per step instead
         # of ten — every one of them scans its predicate, builds its coefficient tables and settles its cells once)
         blocks = args.blocks_per_work_order * (2 if lineitem_store != 0 else 1)
-        cmd = [exe, str(args.build_rows), str(args.probe_rows), str(args.agg_rows), str(args.steps), str(max(args.warmup, 4)),
+        # (ten untimed steps at least: every Worker thread keeps a cache of device scratch of its own, which is warm only once
+        # the thread has executed each kind of work order — the first handful of steps carry 6-9 ms of allocations now and then)
+        cmd = [exe, str(args.build_rows), str(args.probe_rows), str(args.agg_rows), str(args.steps), str(max(args.warmup, 10)),
                str(args.operator_workers), str(blocks), str(lineitem_store)]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)

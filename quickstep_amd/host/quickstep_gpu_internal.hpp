@@ -31,7 +31,11 @@ void TrimBlockSlabPool();   // (host_runtime.cpp, BlockSlabPool)
 void *TakePooled(std::size_t bytes, std::size_t *granted);
 void GivePooled(void *p, std::size_t granted);
 struct DeviceBuffer {
-  static constexpr std::size_t kCacheFrom = 64 * 1024 + 1;
+  // Every scratch buffer is cached per thread, the 8-byte count words of a work order included: a plain allocation is a
+  // hipMalloc + hipFree pair, and hipFree waits for everything queued on the device — with eight Workers in flight a step of
+  // the operators' bench stalled 6-9 ms on one of them every few steps (366 hipFree calls in 28 steps, 0.65 ms on average,
+  // 9 ms at worst: rocprofv3 --hip-trace).  (Until round 5 only buffers above 64 KiB were cached.)
+  static constexpr std::size_t kCacheFrom = 1;
   static constexpr std::size_t kCacheBytes = std::size_t(2) << 30;
   // (device, size class): a thread that moves to another device (qsx_set_current_device) must not be handed the other
   // device's memory — Worker threads stay on one device, callers of the layer need not
@@ -79,7 +83,7 @@ struct DeviceBuffer {
       return;
     }
     if (bytes >= kCacheFrom && cacheEnabled()) {
-      size_class = 128 * 1024;
+      size_class = bytes <= 64 * 1024 ? 256 : 128 * 1024;   // (small ones in classes of their own: 256 B, 512 B, ...)
       while (size_class < bytes) size_class *= 2;
       Cache &c = cache();
       // (the key is taken once, here: a thread that changes its device between constructor and destructor must still file

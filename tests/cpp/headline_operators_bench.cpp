@@ -307,6 +307,7 @@ int main(int argc, char **argv) {
       total_ms += ms;
       best_ms = std::min(best_ms, ms);
     }
+    if (std::getenv("QSX_BENCH_STEP_TIMES") != nullptr) std::fprintf(stderr, "step %d%s: %.3f ms\n", it, it < warmup ? " (warmup)" : "", ms);
     work_orders = foreman.getWorkOrderProfilingResults().size();
     if (std::getenv("QSX_TEST_PROFILE") != nullptr && it == warmup + steps - 1) {   // --profile_and_report_workorder_perf
       const std::uint64_t t0_us = static_cast<std::uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(t0.time_since_epoch()).count());
