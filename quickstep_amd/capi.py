@@ -87,6 +87,7 @@ _SIGNATURES = {
     "qsx_join_table_create": (_int, [_int, _i64, _pp]),
     "qsx_join_table_create_dense": (_int, [_int, _i64, _i64, _i64, _i64, _pp]),
     "qsx_join_table_destroy": (_int, [_vp]),
+    "qsx_join_table_release": (_int, [_vp]),
     "qsx_join_key_pack": (_int, [_int, _pp, C.POINTER(_i32), _i64, _vp, C.POINTER(_int), _vp]),
     "qsx_join_key_pack_char": (_int, [_vp, _int, _i64, _vp, _vp]),
     "qsx_join_table_clear": (_int, [_vp, _vp]),
@@ -623,6 +624,12 @@ class JoinTable:
     def close(self):
         if self._h is not None:
             _lib.qsx_join_table_destroy(self._h)
+            self._h = None
+
+    def release(self):
+        """qsx_join_table_release: destroy without the wait for the device (every stream that used the table has been synchronised)."""
+        if self._h is not None:
+            _check(_lib.qsx_join_table_release(self._h), "qsx_join_table_release")
             self._h = None
 
     def __del__(self):

@@ -1087,10 +1087,12 @@ int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks
   return QSX_OK;
 }
 
-int qsx_join_table_destroy(qsx_join_table_t *t) {
+static int destroy_table(qsx_join_table_t *t, bool wait_for_device) {
   if (t == nullptr) return QSX_OK;
-  (void)synchronize_owner_device(t->slots != nullptr ? static_cast<const void *>(t->slots) : static_cast<const void *>(t->head));
-  if (t->shadow != nullptr) (void)qsx_join_table_destroy(t->shadow);
+  if (wait_for_device) {
+    (void)synchronize_owner_device(t->slots != nullptr ? static_cast<const void *>(t->slots) : static_cast<const void *>(t->head));
+  }
+  if (t->shadow != nullptr) (void)destroy_table(t->shadow, wait_for_device);
   (void)device_free_idle(t->slots);
   (void)device_free_idle(t->head);
   (void)device_free_idle(t->head3);
@@ -1102,6 +1104,8 @@ int qsx_join_table_destroy(qsx_join_table_t *t) {
   delete t;
   return QSX_OK;
 }
+int qsx_join_table_destroy(qsx_join_table_t *t) { return destroy_table(t, true); }
+int qsx_join_table_release(qsx_join_table_t *t) { return destroy_table(t, false); }
 
 int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();

@@ -1226,7 +1226,9 @@ QueryContext::join_hash_table_id QueryContext::addJoinHashTable(TypeID key_type,
   return static_cast<join_hash_table_id>(join_tables_.size() - 1);
 }
 void QueryContext::destroyJoinHashTable(join_hash_table_id id, partition_id part) {
-  qsx_join_table_destroy(join_tables_.at(id).at(part));
+  // (DestroyHashOperator runs behind the last HashJoin work order, and every work order waits for its stream before it returns:
+  // nothing queued uses the table — no wait for the other operators' kernels, qsx_join_table_release)
+  qsx_join_table_release(join_tables_.at(id).at(part));
   join_tables_.at(id).at(part) = nullptr;
 }
 QueryContext::aggregation_state_id QueryContext::addAggregationState(const AggregationStateSpec &spec,

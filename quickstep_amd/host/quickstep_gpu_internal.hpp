@@ -67,7 +67,9 @@ struct DeviceBuffer {
   std::pair<int, std::size_t> class_key{0, 0};   // (device the buffer was allocated on, size class): where a release files it
   std::size_t size_class = 0;   // 0: a plain allocation of its own
   std::size_t pooled = 0;       // != 0: from the shared pool (its size class there)
-  static constexpr std::size_t kSharedFrom = std::size_t(32) << 20;
+  // (1 MiB, 32 MiB until late in round 5: the per-block bitmaps of a run — two sets of 16 MiB — were cached per thread, and every
+  // Worker paid ~7 ms of first allocations the first time a work order of that kind came its way, thirty steps into a run at times)
+  static constexpr std::size_t kSharedFrom = std::size_t(1) << 20;
   static bool cacheEnabled() {   // QSX_HOST_SCRATCH_CACHE=0: every buffer a plain allocation (debugging)
     static const bool on = []() {
       const char *e = std::getenv("QSX_HOST_SCRATCH_CACHE");

@@ -309,7 +309,8 @@ int main(int argc, char **argv) {
     }
     if (std::getenv("QSX_BENCH_STEP_TIMES") != nullptr) std::fprintf(stderr, "step %d%s: %.3f ms\n", it, it < warmup ? " (warmup)" : "", ms);
     work_orders = foreman.getWorkOrderProfilingResults().size();
-    if (std::getenv("QSX_TEST_PROFILE") != nullptr && it == warmup + steps - 1) {   // --profile_and_report_workorder_perf
+    if ((std::getenv("QSX_TEST_PROFILE") != nullptr && it == warmup + steps - 1) ||
+        (std::getenv("QSX_BENCH_STEP_TIMES") != nullptr && it >= warmup && ms > 8.0)) {   // --profile_and_report_workorder_perf; a slow step
       const std::uint64_t t0_us = static_cast<std::uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(t0.time_since_epoch()).count());
       std::map<std::size_t, std::tuple<double, int, std::uint64_t, std::uint64_t>> per_op;
       for (const WorkOrderTimeEntry &e : foreman.getWorkOrderProfilingResults()) {
@@ -319,6 +320,12 @@ int main(int argc, char **argv) {
         std::get<1>(p) += 1;
         std::get<2>(p) = std::min(std::get<2>(p), e.start_us);
         std::get<3>(p) = std::max(std::get<3>(p), e.end_us);
+      }
+      if (ms > 8.0) {
+        for (const WorkOrderTimeEntry &e : foreman.getWorkOrderProfilingResults()) {
+          std::fprintf(stderr, "    op %zu worker %zu: %+8.3f .. %+8.3f ms\n", e.operator_index, e.worker_id,
+                       (static_cast<double>(e.start_us) - static_cast<double>(t0_us)) / 1e3, (static_cast<double>(e.end_us) - static_cast<double>(t0_us)) / 1e3);
+        }
       }
       for (const auto &kv : per_op) {
         std::fprintf(stderr, "  %-34s %3d work orders, %7.3f ms summed, first start %+8.3f ms, last end %+8.3f ms\n",

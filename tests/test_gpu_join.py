@@ -1021,3 +1021,23 @@ def test_compact_plane_follows_builds_growth_and_clear(capi, oracle, dev):
     assert int(cnt.item()) == rp.size
     assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rb))
     table.close()
+
+
+@pytest.mark.parametrize("flavour", ["dense", "hashed"])
+def test_released_tables_hand_their_memory_to_the_next_one(capi, oracle, dev, flavour):
+    """qsx_join_table_release (DestroyHashOperator behind the last HashJoin work order): no wait for the device; the table's
+    allocations go to the library's idle list and the next table of the same size takes them — its probes must see its own
+    keys only."""
+    rng = np.random.default_rng(31)
+    n = 300_000
+    for round_ in range(4):
+        build = rng.permutation(n).astype(np.int32) * 3 + round_          # another key set every round
+        probe = rng.integers(0, 3 * n + 3, size=500_001).astype(np.int32)
+        table = capi.JoinTable(T.INT, n, key_range=(0, 3 * n + 2) if flavour == "dense" else None)
+        table.build(to_dev(build, dev))
+        _, rp, rb = oracle_join(oracle, T.INT, [build], probe)
+        p, b, cnt = table.probe(to_dev(probe, dev), capacity=max(rp.size, 1))
+        assert int(cnt.item()) == rp.size
+        assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rb))
+        torch.cuda.synchronize()              # what the caller of qsx_join_table_release promises
+        table.release()
