@@ -1254,7 +1254,10 @@ def main():
     ap.add_argument("--secondary-steps", type=int, default=5, help="timed steps of the C4 / C5 legs of `secondary`")
     ap.add_argument("--secondary-cpu-seconds", type=float, default=4.0, help="CPU time budget per `secondary` cpu_baseline (5 trials in all)")
     ap.add_argument("--no-operators", action="store_true", help="N = 1: skip the leg that runs the workload through the C++ operator layer")
-    ap.add_argument("--operator-workers", type=int, default=8)
+    ap.add_argument("--operator-workers", type=int, default=4,
+                    help="Worker threads of the operators legs (8 until late in round 5: every Worker spins in its stream wait, and on a box "
+                         "that grants 16 cores by cgroup quota eight of them next to the runtime's own threads got the process throttled — "
+                         "6-7 ms standstills every few steps; four do the same work in the same or less time)")
     ap.add_argument("--blocks-per-work-order", type=int, default=256)
     ap.add_argument("--transport", choices=["torch", "capi"], default="torch",
                     help="who issues the exchange steps: torch = torch.distributed on the nccl backend (RCCL); capi = the C ABI's own "
