@@ -40,7 +40,7 @@ def main():
                     rows.append((f"probe variant `{name}`", "C2", f"{v:.3f} ms", "—", "—", "—"))
         op = line.get("operators", {})
         if "ms_per_step" in op:
-            rows.append(("the step through the operator layer", "8 Workers, 256 blocks per work order", f"{op['ms_per_step']:.2f} ms",
+            rows.append(("the step through the operator layer", f"{op.get('workers', 8)} Workers, {op.get('blocks_per_work_order', 256)} blocks per work order", f"{op['ms_per_step']:.2f} ms",
                          f"{op['rows_per_s'] / 1e9:.0f} G rows/s", "—", f"{100 * op['fraction_of_raw_abi_value']:.0f} % of the raw step"))
         for name, v in (line.get("secondary") or {}).items():      # (round 5: the other BASELINE configurations in the same line)
             if isinstance(v, dict) and "ms" in v and "roofline" in v:
