@@ -1221,6 +1221,58 @@ def operators_leg(args, raw_value):
     return out
 
 
+def capi_leg_under_deadline(ctx, args, run_config, torch_line, legs):
+    """The second leg of --transport both: the same configuration with every exchange step through the C ABI's collectives.
+    Returns the line to print: the capi leg's when it completed and checked on EVERY rank, else the torch leg's with the reason.
+    A stall (a rank inside a collective its peers never enter) ends at the deadline: rank 0 prints the torch line from the
+    watchdog thread and every rank leaves with status 0 — os._exit, because a process stuck in a collective cannot unwind."""
+    import threading
+    from quickstep_amd import distributed as qd
+    os.environ.setdefault("QSX_COMM_TIMEOUT_MS", str(int(args.capi_leg_deadline * 500)))   # the library's own watchdog: half the deadline
+    done = threading.Event()
+
+    def fallback(reason):
+        legs["capi"] = {"error": reason}
+        torch_line["transport_legs"] = legs
+        torch_line["world_size_seen"] = ctx.world
+        torch_line["self_launched"] = os.environ.get("QSX_BENCH_SELF_LAUNCHED") == "1"
+        return torch_line
+
+    def watchdog():
+        if done.wait(args.capi_leg_deadline):
+            return
+        if ctx.rank == 0:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(fallback(f"the C ABI leg did not finish within {args.capi_leg_deadline} s")), flush=True)
+        os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    ok, error, line = 1, None, None
+    try:
+        broken = os.environ.get("QSX_BENCH_BREAK_CAPI_LEG")     # tests: "all" = every rank fails alike; "last" = one rank fails, its peers stall
+        if broken == "all" or (broken == "last" and ctx.rank == ctx.world - 1):
+            raise RuntimeError("QSX_BENCH_BREAK_CAPI_LEG")
+        ctx.group = qd.CapiGroup.from_torch_group(capi, ctx.dev)
+        line = run_config(ctx, args)
+    except BaseException as exc:  # noqa: BLE001  (this leg never takes the run down)
+        ok, error = 0, repr(exc)[:400]
+    try:
+        if ctx.group is not None:
+            ctx.group.comm.close()
+    except Exception:  # noqa: BLE001
+        pass
+    ctx.group = None
+    flag = torch.tensor([ok], dtype=torch.int32, device=ctx.dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    everywhere = ok == 1 and int(flag.item()) == 1
+    done.set()
+    if not everywhere:
+        return fallback(error or "the C ABI leg failed on another rank")
+    line["transport"] = "capi"
+    legs["capi"] = {k: line.get(k) for k in ("value", "ms_per_step") if k in line}
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1259,10 +1311,14 @@ def main():
                          "that grants 16 cores by cgroup quota eight of them next to the runtime's own threads got the process throttled — "
                          "6-7 ms standstills every few steps; four do the same work in the same or less time)")
     ap.add_argument("--blocks-per-work-order", type=int, default=256)
-    ap.add_argument("--transport", choices=["torch", "capi"], default="torch",
+    ap.add_argument("--transport", choices=["auto", "torch", "capi", "both"], default="auto",
                     help="who issues the exchange steps: torch = torch.distributed on the nccl backend (RCCL); capi = the C ABI's own "
                          "multi-GPU entry points (qsx_alltoallv, qsx_allgather, qsx_agg_reduce_scatter, ...: RCCL bound inside "
-                         "libqsx.so, the calls the C++ operator layer makes — quickstep_amd/host/rank_exchange.cpp)")
+                         "libqsx.so, the calls the C++ operator layer makes — quickstep_amd/host/rank_exchange.cpp); both = the torch leg, "
+                         "then the capi leg under a deadline, the line's value from the capi leg when it completed on every rank; "
+                         "auto = both at N > 1, torch with one rank")
+    ap.add_argument("--capi-leg-deadline", type=float, default=240.0,
+                    help="--transport both: seconds the C ABI leg may take before the line falls back to the torch leg")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch check without a GPU: the ranks rendezvous over gloo, agree on the world size and rank 0 prints a "
                          "line with no measurement in it (tests/test_bench_launch.py)")
@@ -1293,8 +1349,9 @@ def main():
     # multi-rank code with the product's kernels; its throughput says nothing about scaling, and the line says so.
     shared_gpu = os.environ.get("QSX_BENCH_SHARED_GPU") == "1"
     if shared_gpu:
-        if args.transport != "capi" or not os.environ.get("QSX_RCCL_LIBRARY") or os.environ.get("QSX_ALLOW_TEST_TRANSPORT") != "1":
-            raise SystemExit("QSX_BENCH_SHARED_GPU=1 needs --transport capi, QSX_RCCL_LIBRARY (the loopback library) and QSX_ALLOW_TEST_TRANSPORT=1")
+        if args.transport == "torch" or not os.environ.get("QSX_RCCL_LIBRARY") or os.environ.get("QSX_ALLOW_TEST_TRANSPORT") != "1":
+            raise SystemExit("QSX_BENCH_SHARED_GPU=1 needs --transport capi (or both: the torch leg then stages through the host over gloo), "
+                             "QSX_RCCL_LIBRARY (the loopback library) and QSX_ALLOW_TEST_TRANSPORT=1")
         local_rank = 0
     torch.cuda.set_device(local_rank)
     ctx.dev = dev = torch.device("cuda", local_rank)
@@ -1318,16 +1375,34 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
     ctx.group = None
-    if ctx.distributed and args.transport == "capi":
-        from quickstep_amd import distributed as qd
-        ctx.group = qd.CapiGroup.from_torch_group(capi, dev)
-
     want_secondary = rank == 0 and world == 1 and args.config == "headline" and not args.no_secondary and not ctx.distributed
     ctx.keep_headline = want_secondary
-    line = {"headline": run_headline, "c4": run_c4, "c5": run_c5}[args.config](ctx, args)
+    run_config = {"headline": run_headline, "c4": run_c4, "c5": run_c5}[args.config]
+    # Who issues the exchange steps.  auto: one rank -> torch.distributed (nothing is exchanged); N > 1 -> BOTH legs, the C ABI's own
+    # collectives (csrc/comm.hip: what a compiled host and the C++ operator layer call) as the line's value and the
+    # torch.distributed leg beside it (`transport_legs`).  The torch leg runs first and is kept; the C ABI leg runs under a
+    # deadline: RCCL with more than one rank under comm.hip cannot be rehearsed on a one-GPU box, so if that leg raises on any
+    # rank or stalls, the line falls back to the torch leg and says why — never a lost run.
+    transport = args.transport
+    if transport == "auto":
+        transport = "capi" if shared_gpu else ("both" if world > 1 else "torch")
+    legs = {}
+    if transport == "both":
+        line = run_config(ctx, args)
+        line["transport"] = "torch"
+        legs["torch"] = {k: line.get(k) for k in ("value", "ms_per_step", "phases_ms", "alltoall", "collectives") if k in line}
+        torch.cuda.empty_cache()
+        line = capi_leg_under_deadline(ctx, args, run_config, line, legs)
+    else:
+        if ctx.distributed and transport == "capi":
+            from quickstep_amd import distributed as qd
+            ctx.group = qd.CapiGroup.from_torch_group(capi, dev)
+        line = run_config(ctx, args)
+        line["transport"] = transport if ctx.distributed else None
+    if legs:
+        line["transport_legs"] = legs
     line["world_size_seen"] = dist.get_world_size() if ctx.distributed else 1      # what the RCCL process group reports
     line["self_launched"] = os.environ.get("QSX_BENCH_SELF_LAUNCHED") == "1"
-    line["transport"] = args.transport if ctx.distributed else None
     if shared_gpu:
         line["rehearsal"] = "ranks share cuda:0 over the loopback transport: the N > 1 code path, not a scaling number"
     if ctx.group is not None:

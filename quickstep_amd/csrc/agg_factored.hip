@@ -56,9 +56,13 @@ int launch_factored_staged(const FactoredArgs &a, size_t lds_bytes, int per_cu, 
   return QSX_OK;
 }
 
+bool factored_direct_signature(const FactoredArgs &a, int key_width) {
+  return !(a.nkeys < 1 || a.nkeys > 2 || a.ncell < 1 || a.ncell > 2 || a.nhist > 1 || a.ncar > 1 || (key_width != 1 && key_width != 4));
+}
+
 bool launch_factored_direct(const FactoredArgs &a, const FactoredArgs *a_dev, const FactoredDirectArgs &da, int key_width, size_t lds_bytes, int grid, int64_t n,
                             const uint64_t *filter_dev, const HashTableView &g, hipStream_t s, const FactoredRunArgs *runs) {
-  if (a.nkeys < 1 || a.nkeys > 2 || a.ncell < 1 || a.ncell > 2 || a.nhist > 1 || a.ncar > 1 || (key_width != 1 && key_width != 4)) return false;
+  if (!factored_direct_signature(a, key_width)) return false;
   auto launch = [&](auto filt, auto kw, auto nk, auto nc, auto nh, auto car) {
     constexpr bool F = decltype(filt)::value, CAR = decltype(car)::value;
     constexpr int KW = decltype(kw)::value, NK = decltype(nk)::value, NC = decltype(nc)::value, NH = decltype(nh)::value;

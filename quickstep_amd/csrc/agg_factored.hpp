@@ -138,6 +138,8 @@ int launch_factored_predicate(const FactoredPredArgs &pa, long long tiles, hipSt
 int launch_factored_coef(const DevConfig &dc, const FactoredCoefArgs &ca, hipStream_t s, int num_blocks = 1);
 int launch_factored_staged(const FactoredArgs &a, size_t lds_bytes, int per_cu, int64_t n, const uint64_t *filter_dev, const HashTableView &g, hipStream_t s);
 // false: the signature is not one of the instantiated ones (nothing was launched)
+// Whether launch_factored_direct has a kernel for this plan (asked BEFORE a call pays for its predicate pass and coefficients).
+bool factored_direct_signature(const FactoredArgs &a, int key_width);
 bool launch_factored_direct(const FactoredArgs &a, const FactoredArgs *a_dev, const FactoredDirectArgs &da, int key_width, size_t lds_bytes, int grid, int64_t n,
                             const uint64_t *filter_dev, const HashTableView &g, hipStream_t s, const FactoredRunArgs *runs = nullptr);
 

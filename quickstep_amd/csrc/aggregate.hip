@@ -2258,6 +2258,11 @@ static FactoredPredArgs factored_predicate_terms(const DevConfig &d) {
   return pa;
 }
 
+static bool factored_generic_enabled() {
+  const char *e = getenv("QSX_AGG_FACTORED_GENERIC");
+  return e != nullptr && e[0] == '1';
+}
+
 // QSX_OK = the call was issued through the factored kernels; QSX_ERR_UNSUPPORTED = not this call (dictionary sizes unknown or
 // too large, the cells do not fit LDS): the caller goes on with the decoding kernels; anything else is an error.
 static int update_factored(qsx_agg_state *st, const void *const *cols, const void *const *dicts, const int32_t *entries, int64_t n,
@@ -2274,8 +2279,11 @@ static int update_factored(qsx_agg_state *st, const void *const *cols, const voi
   FactoredCoefArgs &ca = plan.ca;
   const long long cells = a.cells;
   const size_t lds_bytes = plan.table_bytes + plan.tile_bytes;
-  const bool direct = plan.direct && factored_direct_aligned(plan, st, cols);
-  if (!direct && lds_bytes > 64 * 1024) return QSX_ERR_UNSUPPORTED;     // (the staged kernel: at least two workgroups per CU, or the tile copies run under nothing)
+  const bool direct = plan.direct && factored_direct_aligned(plan, st, cols) && factored_direct_signature(a, plan.keyw);
+  // Who serves the call is decided HERE, before the predicate pass, the coefficient launch and the scratch (a state
+  // whose plan is no direct-load signature paid for all three on every update and then handed the call to the decoding kernels,
+  // which evaluate the predicate again).  The staged kernel needs at least two workgroups per CU, or its tile copies run under nothing.
+  if (!direct && (!factored_generic_enabled() || lds_bytes > 64 * 1024)) return QSX_ERR_UNSUPPORTED;
   // coefficients: this call's dictionaries through the state's expression program
   CallScratch scratch(s);
   const size_t coef_bytes = static_cast<size_t>(d.num_sums) * (1 + a.ncar) * cells * 8, hcoef_bytes = static_cast<size_t>(d.num_sums) * kFacMaxDict * 8;
@@ -2327,20 +2335,14 @@ static int update_factored(qsx_agg_state *st, const void *const *cols, const voi
     const int per_cu = factored_workgroups_per_cu(direct_lds);
     const int64_t tiles = (n + kFacDirectTile - 1) / kFacDirectTile;
     const int grid = static_cast<int>(tiles < static_cast<int64_t>(per_cu) * kCUs ? tiles : static_cast<int64_t>(per_cu) * kCUs);
-    const bool launched = launch_factored_direct(a, a_dev, plan.da, plan.keyw, direct_lds, grid, n, filter_dev, g, s);
-    if (launched) {
-      QSX_CHECK_LAUNCH();
-      g_factored_launches.fetch_add(1, std::memory_order_relaxed);
-      return QSX_OK;
-    }
+    if (!launch_factored_direct(a, a_dev, plan.da, plan.keyw, direct_lds, grid, n, filter_dev, g, s)) return QSX_ERR_UNSUPPORTED;   // (cannot happen: the signature was checked above)
+    QSX_CHECK_LAUNCH();
+    g_factored_launches.fetch_add(1, std::memory_order_relaxed);
+    return QSX_OK;
   }
   // ---- any other signature: the staged kernel.  Slower than the decoding plan shapes as it stands (4.5 against 2.1 ms per
   // 600 M rows of Q1: its waves sit out every tile's copy and read their descriptors at run time), so it answers only when
-  // asked (QSX_AGG_FACTORED_GENERIC=1: the tests keep it exact for the day it is made fast). ----
-  {
-    const char *e = getenv("QSX_AGG_FACTORED_GENERIC");
-    if (e == nullptr || e[0] != '1' || lds_bytes > 64 * 1024) return QSX_ERR_UNSUPPORTED;
-  }
+  // asked (QSX_AGG_FACTORED_GENERIC=1, checked before any work of the call: the tests keep it exact for the day it is made fast). ----
   int per_cu = static_cast<int>((160 * 1024) / (lds_bytes + 512));
   per_cu = per_cu > 8 ? 8 : per_cu;
   if (const char *e = getenv("QSX_AGG_FACTORED_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;

@@ -108,6 +108,12 @@ hipError_t synchronize_owner_device(const void *ptr);   // hipDeviceSynchronize 
 struct ScratchArena {
   void *base = nullptr;
   size_t capacity = 0;
+  // Reservations of calls that are still on the host's stack (an entry point that calls another entry point's launcher
+  // while it holds scratch of its own: the LIP bitmaps of qsx_join_probe_lip under launch_probe's two-pass scratch).
+  // `floor` = first byte no live reservation has handed out; a nested reservation is carved above it and the arena is
+  // neither grown nor freed while `live` > 0.
+  size_t floor = 0;
+  int live = 0;
 };
 struct StagedBuffer {
   void *pinned = nullptr;
@@ -201,19 +207,26 @@ class CallScratch {
   explicit CallScratch(hipStream_t stream) : stream_(stream) {}
   CallScratch(const CallScratch &) = delete;
   CallScratch &operator=(const CallScratch &) = delete;
-  ~CallScratch() {
-    if (one_off_ != nullptr) {
-      (void)hipStreamSynchronize(stream_);
-      (void)device_free(one_off_);
-    }
-  }
+  ~CallScratch() { release(); }
   // Bytes a take() of `bytes` consumes of the reservation.
   static size_t padded(size_t bytes) { return (bytes + 255) / 256 * 256; }
-  // All the scratch of the call at once (sum of padded() sizes); QSX_OK or an error status.
+  // All the scratch of the call at once (sum of padded() sizes); QSX_OK or an error status.  Reservations nest: a
+  // CallScratch opened on the same (thread, stream) while another is alive gets the arena's bytes ABOVE what the live ones
+  // hold — never their bytes, and never a grown (freed and reallocated) arena; when the arena has no room left for it the
+  // nested reservation is a one-off allocation released when its call's work has finished.
   int reserve(size_t total) {
+    release();
     total = padded(total ? total : 1);
     used_ = 0;
-    if (total > kScratchKeepBytes) {
+    ScratchArena *a = total > kScratchKeepBytes ? nullptr : &thread_scratch_arena(stream_);
+    if (a != nullptr && a->live > 0) {
+      if (a->capacity - a->floor >= total) {
+        attach(a, a->floor, total);
+        return QSX_OK;
+      }
+      a = nullptr;   // an outer reservation is live: the arena stays where and what it is
+    }
+    if (a == nullptr) {
       if (device_malloc(&one_off_, total) != hipSuccess) {
         (void)hipGetLastError();
         (void)trim_thread_resources_sparing(stream_);   // what this thread keeps for its other streams goes first
@@ -223,7 +236,6 @@ class CallScratch {
       capacity_ = total;
       return QSX_OK;
     }
-    ScratchArena *a = &thread_scratch_arena(stream_);
     if (a->capacity < total) {
       if (a->base != nullptr) {
         QSX_HIP_TRY(hipStreamSynchronize(stream_));   // kernels of earlier calls may still use the old arena
@@ -242,8 +254,7 @@ class CallScratch {
       }
       a->capacity = cap;
     }
-    base_ = static_cast<char *>(a->base);
-    capacity_ = a->capacity;
+    attach(a, 0, total);
     return QSX_OK;
   }
   // The next piece of the reservation (256-byte aligned), nullptr when the reservation is exhausted.
@@ -256,7 +267,31 @@ class CallScratch {
   }
 
  private:
+  void attach(ScratchArena *a, size_t offset, size_t total) {
+    arena_ = a;
+    saved_floor_ = a->floor;
+    a->floor = offset + total;
+    a->live += 1;
+    base_ = static_cast<char *>(a->base) + offset;
+    capacity_ = total;
+  }
+  void release() {
+    if (arena_ != nullptr) {
+      arena_->floor = saved_floor_;
+      arena_->live -= 1;
+      arena_ = nullptr;
+    }
+    if (one_off_ != nullptr) {
+      (void)hipStreamSynchronize(stream_);
+      (void)device_free(one_off_);
+      one_off_ = nullptr;
+    }
+    base_ = nullptr;
+    capacity_ = used_ = 0;
+  }
   hipStream_t stream_;
+  ScratchArena *arena_ = nullptr;
+  size_t saved_floor_ = 0;
   void *one_off_ = nullptr;
   char *base_ = nullptr;
   size_t capacity_ = 0, used_ = 0;

@@ -483,6 +483,14 @@ void runFailingExchange(const Ranks &ranks) {
       id.push_back(r.int_col);
       text.insert(text.end(), r.char_col, r.char_col + 20);
     }
+    // (the test table has fewer rows per partition than eight ranks: one row of the rank's own, so that every rank — the one
+    // that is about to lose a block included — holds something)
+    if (pid(1000 + ranks.rank, 4) == p) {
+      char own[20] = {};
+      std::snprintf(own, sizeof(own), "rank %d", ranks.rank);
+      id.push_back(1000 + ranks.rank);
+      text.insert(text.end(), own, own + 20);
+    }
     if (!id.empty()) mine.push_back(storage.loadBlock(&scattered, {id.data(), text.data()}, static_cast<std::int64_t>(id.size()), p));
   }
   QueryContext ctx;
@@ -527,7 +535,11 @@ void runAll(const Ranks &ranks, int slices, Lines *out) {
   runTestTableJoin("partitioned_join", DimKind::kPartitioned4, ranks, out);
   runTestTableJoin("broadcast_join", DimKind::kUnpartitionedBroadcast, ranks, out);
   runTestTableJoin("repartitioned_join", DimKind::kPartitioned2Repartitioned, ranks, out);
-  runC4(ranks, slices, 20'000, 4, out);
+  // C4: P = the partition count of the machine this is for (world 8: pid = h & 7, catalog/PartitionSchemeHeader.hpp:207-214, one
+  // exchange round) and a scheme with more partitions than ranks (two rounds at world 2, 3 and 4; at world 8: 16 partitions)
+  const std::size_t parts = slices <= 4 ? 4 : 8;
+  runC4(ranks, slices, slices <= 4 ? 20'000 : 6'000, parts, out);
+  if (slices >= 4) runC4(ranks, slices, 3'000, 2 * static_cast<std::size_t>(slices), out);
   runPartitionedAggregation(ranks, out);
   runMergedAggregation(ranks, slices, out);
 }
@@ -637,7 +649,18 @@ int main(int argc, char **argv) {
   if (dir == nullptr) return 3;
   const std::string self = selfPath();
   const std::string loopback = self.substr(0, self.rfind('/')) + "/libloopback_rccl.so";
-  const std::vector<int> worlds = {2, 3};
+  // 2 and 3 (not a power of two: h % P), 4, and 8 = the node this is built for (QSX_RANKS_TEST_WORLDS="2,3": a subset)
+  std::vector<int> worlds = {2, 3, 4, 8};
+  if (const char *e = std::getenv("QSX_RANKS_TEST_WORLDS")) {
+    worlds.clear();
+    for (const char *p = e; *p != 0;) {
+      char *end = nullptr;
+      const long w = std::strtol(p, &end, 10);
+      if (end == p) break;
+      if (w >= 2 && w <= 16) worlds.push_back(static_cast<int>(w));
+      p = *end == ',' ? end + 1 : end;
+    }
+  }
   std::map<int, bool> ran;
   for (int world : worlds) ran[world] = startRanks(world, dir, loopback);
   if (qsx_device_count() < 1) {
@@ -672,7 +695,7 @@ int main(int argc, char **argv) {
       join_rows += l.compare(0, 17, "partitioned_join|") == 0;
     }
     EXPECT_EQ(join_rows, static_cast<std::size_t>(10));            // Partition.test:75-92: ten joined rows
-    EXPECT_TRUE(c4_rows > static_cast<std::size_t>(world) * 20'000);   // one output row per lineitem row
+    EXPECT_TRUE(c4_rows > static_cast<std::size_t>(world) * (world <= 4 ? 20'000 : 6'000));   // one output row per lineitem row
     std::printf("world %d: %zu result rows over the ranks = the single-process operators' (%zu joined C4 rows)\n", world, have.size(), c4_rows);
   }
   return finish("partitioned_ranks_test");

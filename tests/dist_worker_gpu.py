@@ -49,7 +49,10 @@ def main():
         group = qd.CapiGroup.from_torch_group(capi, dev)
         assert (group.world, group.rank) == (world, rank)
     rng = np.random.default_rng(500 + rank)
-    save = {}
+    seen = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(seen)
+    save = {"world_size_seen": np.int64(group.world if group is not None else int(seen.item()))}
+    assert int(seen.item()) == world
 
     # ---- shuffle join, hashed tables: keys collide across ranks, negatives included, duplicates on the build side
     n_build, n_probe = 30_000, 250_000

@@ -50,9 +50,9 @@ def test_single_rank_collectives_through_the_c_abi(capi, dev):
     comm.close()
 
 
-# ---- world 2 and 3 over the loopback transport -----------------------------------------------------------------------
-@pytest.mark.parametrize("world", [2, 3])
-def test_c_abi_collectives_at_world_2_and_3(world, tmp_path):
+# ---- world 2, 3, 4 and 8 over the loopback transport ------------------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_c_abi_collectives_at_world_2_to_8(world, tmp_path):
     """The N > 1 branches of qsx_exchange_counts / qsx_alltoallv / qsx_allgather / qsx_bitmap_allreduce_or /
     qsx_agg_reduce_scatter / qsx_agg_allgather_merge (tests/comm_loopback_worker.py: rank processes sharing cuda:0, libqsx.so
     bound to tests/cpp/bin/libloopback_rccl.so).  The workers assert bit-equality with quickstep_amd/distributed.py's

@@ -828,13 +828,31 @@ def test_small_bucketed_tables_are_probed_from_lds(capi, oracle, dev, key_type, 
 @pytest.mark.parametrize("table_kind", ["dense", "hashed_dense_keys", "hashed_sparse_keys"])
 @pytest.mark.parametrize("filters", [["exact"], ["hash"], ["exact", "hash"], ["anti"], ["exact", "hash", "exact"]])
 def test_probe_with_lip_filters_inside_equals_filter_then_probe(capi, oracle, dev, key_type, dtype, table_kind, filters, monkeypatch):
+    _probe_lip_case(capi, oracle, dev, key_type, dtype, table_kind, filters, monkeypatch, n_probe=1_300_003)
+
+
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+@pytest.mark.parametrize("table_kind", ["dense", "hashed_dense_keys"])
+@pytest.mark.parametrize("filters", [["exact"], ["exact", "hash"], ["exact", "hash", "exact"]])
+@pytest.mark.parametrize("n_probe,one_pass", [(50_021, None), (3_001, None), (700_001, "0"), (700_001, None)])
+def test_probe_lip_whose_probe_takes_the_two_pass_form(capi, oracle, dev, key_type, dtype, table_kind, filters, n_probe, one_pass, monkeypatch):
+    """qsx_join_probe_lip's filter-then-probe fallback holds its LIP bitmaps in the call's scratch and
+    then runs launch_probe, whose two-pass form (n < 64 Ki rows on a directly addressed table, any n with
+    QSX_JOIN_ONE_PASS=0, three filters and n < 1 Mi) reserves scratch on the same stream: the inner reservation must not
+    hand out the bytes of the bitmaps the probe is reading."""
+    if one_pass is not None:
+        monkeypatch.setenv("QSX_JOIN_ONE_PASS", one_pass)
+    _probe_lip_case(capi, oracle, dev, key_type, dtype, table_kind, filters, monkeypatch, n_probe=n_probe, plain_filter_legs=False)
+
+
+def _probe_lip_case(capi, oracle, dev, key_type, dtype, table_kind, filters, monkeypatch, n_probe, plain_filter_legs=True):
     """qsx_join_probe_lip: HashInnerJoinWorkOrder's LIP filters tested inside the probe (one pass over the keys for directly
     addressed tables and shadows; the filter-then-probe sequence inside the call for every other table and for more than two
     filters).  Pairs = the oracle's LIP probes chained into a bitmap + its join under that bitmap: exact, hash and anti
     filters, keys outside an exact filter's range, an input bitmap, duplicate build keys; and the one-pass probe under a
     plain filter (QSX_JOIN_ONE_PASS) against the two-pass form."""
     rng = np.random.default_rng(4242 + len(filters))
-    n_build, n_probe, domain = 60_000, 1_300_003, 150_000
+    n_build, domain = 60_000, 150_000
     lo = -1000 if dtype == np.int32 else 2**40
     keys = lo + rng.integers(0, domain, size=n_build)
     if table_kind == "hashed_sparse_keys":
@@ -873,7 +891,7 @@ def test_probe_with_lip_filters_inside_equals_filter_then_probe(capi, oracle, de
         assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rd))
     # the probe under a plain filter: one pass (one reservation per 16 K rows) = two passes (count / scan / write)
     rp, rd = otable.probe(probe, filter_bitmap=in_filter)
-    for one_pass in ("1", "0"):
+    for one_pass in ("1", "0") if plain_filter_legs else ():
         monkeypatch.setenv("QSX_JOIN_ONE_PASS", one_pass)
         p, b, cnt = table.probe(dp, capacity=rp.size, filter_bitmap=bitmap_dev(in_filter, dev))
         assert int(cnt.item()) == rp.size

@@ -1,8 +1,9 @@
-"""N = 2 and 3 with the product's kernels: the rank processes share cuda:0 (tests/dist_worker_gpu.py), ops =
+"""N = 2, 3, 4 and 8 with the product's kernels: the rank processes share cuda:0 (tests/dist_worker_gpu.py), ops =
 quickstep_amd.capi.  Transports: "gloo" = torch.distributed collectives with host staging; "capi" = the C ABI's own
 multi-GPU entry points (qsx_alltoallv, qsx_allgather, qsx_bitmap_allreduce_or, qsx_agg_reduce_scatter,
-qsx_agg_allgather_merge) over the tests' loopback stand-in for RCCL, at world 2 and at world 3 (not a power of two:
-hash % P partitions, hashed tables, key ranges that do not divide).  The union of what the ranks produce must be what one
+qsx_agg_allgather_merge) over the tests' loopback stand-in for RCCL, at world 2, at world 3 (not a power of two:
+hash % P partitions, hashed tables, key ranges that do not divide), at world 4 and at world 8 — the partition count of the
+node this is built for (pid = h & 7, catalog/PartitionSchemeHeader.hpp:207-214).  The union of what the ranks produce must be what one
 process / the CPU oracle produces: shuffle joins (hashed and strided directly addressed tables, payload columns =
 BASELINE config 4), broadcast join, Q1 state merge, dense state reduce-scatter, and the distributed Q3 plan (BASELINE
 config 5)."""
@@ -35,7 +36,7 @@ def launch_ranks(world, script, args, extra_env=None, timeout=900):
     assert r.returncode == 0 and r.stdout.count("RANKS_OK") == world, r.stdout[-3000:] + r.stderr[-6000:]
 
 
-@pytest.fixture(scope="module", params=[(2, "gloo"), (2, "capi"), (3, "capi")], ids=lambda p: f"world{p[0]}-{p[1]}")
+@pytest.fixture(scope="module", params=[(2, "gloo"), (2, "capi"), (3, "capi"), (4, "capi"), (8, "capi")], ids=lambda p: f"world{p[0]}-{p[1]}")
 def ranks(request, tmp_path_factory):
     world, transport = request.param
     out = tmp_path_factory.mktemp(f"ranks_{world}_{transport}")
@@ -45,7 +46,9 @@ def ranks(request, tmp_path_factory):
         extra["QSX_RCCL_LIBRARY"] = LOOPBACK
         extra["QSX_ALLOW_TEST_TRANSPORT"] = "1"
     launch_ranks(world, "dist_worker_gpu.py", [out, transport], extra)
-    return [np.load(out / f"rank{i}.npz") for i in range(world)]
+    loaded = [np.load(out / f"rank{i}.npz") for i in range(world)]
+    assert all(int(d["world_size_seen"]) == world for d in loaded)        # what the communicator itself reported on every rank
+    return loaded
 
 
 def test_shuffle_join_hashed_tables_equals_oracle_join(ranks, oracle):
