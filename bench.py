@@ -911,7 +911,7 @@ def q1_coded_as_blocks(ctx, args, cols, dicts, single):
                 assert bool(torch.allclose(x.double(), y.double(), rtol=1e-9, atol=0.0)), f"aggregate {a} over the run of blocks differs"
         checked = True
     st.close()
-    return {"blocks": nb, "rows_per_block": rows_per_block, "ms": ms, "frac": 13 * n / (ms * 1e-3) / 8e12, "checked": checked,
+    return {"blocks": nb, "rows_per_block": rows_per_block, "ms": ms, "frac": hbm_roofline("", 13 * n, ms)["frac"], "checked": checked,
             "call": "qsx_agg_update_coded_blocks_sized: one launch of factored_coef_kernel (every block's coefficient tables) and one of "
                     "agg_factored_direct_kernel<...,runs>"}
 

@@ -981,7 +981,9 @@ int qsx_comm_rank(const qsx_comm_t *comm, int *out_world, int *out_rank);
 int qsx_comm_agree(qsx_comm_t *comm, int local_status, qsx_stream_t stream);
 /* Wait for `stream` under the communicator's watchdog (QSX_COMM_TIMEOUT_MS, default 600 000; 0 = wait for ever): a
  * collective whose peers never arrive does not block the caller indefinitely — at the deadline the communicator is
- * aborted (ncclCommAbort) and QSX_ERR_COMM returned; every later call on it returns QSX_ERR_COMM at once. */
+ * aborted (ncclCommAbort) and QSX_ERR_COMM returned; every later call on it returns QSX_ERR_COMM at once.  A transport
+ * that has no ncclCommAbort gets no watchdog (as with 0): without the abort the stalled kernels stay on the stream and the
+ * deadline would only move the stall into the next wait. */
 int qsx_comm_synchronize(qsx_comm_t *comm, qsx_stream_t stream);
 /* Abort the communicator (a rank that failed inside a step tells RCCL to give up instead of waiting in its kernels). */
 int qsx_comm_abort(qsx_comm_t *comm);

@@ -245,7 +245,7 @@ void join_compile_threads() {
 // so concurrent processes see whole files or none.  Unset (the default): no file is read or written.
 constexpr char kCacheMagic[8] = {'Q', 'S', 'X', 'J', 'I', 'T', '0', '1'};
 // The compiler driver of the ROCm install (hipcc), or empty: QSX_JIT_COMPILER = "hiprtc" (never spawn a compiler), a path, or
-// unset = $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc when one of them is executable.
+// unset = $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc, then hipcc on PATH — the first that is executable.
 std::string compiler_driver() {
   const char *e = getenv("QSX_JIT_COMPILER");
   if (e != nullptr && std::strcmp(e, "hiprtc") == 0) return std::string();
@@ -255,6 +255,16 @@ std::string compiler_driver() {
   } else {
     if (const char *rocm = getenv("ROCM_PATH")) candidates.push_back(std::string(rocm) + "/bin/hipcc");
     candidates.push_back("/opt/rocm/bin/hipcc");
+    if (const char *path = getenv("PATH")) {   // (a host whose Makefile found hipcc on PATH finds it here too)
+      const std::string dirs(path);
+      for (size_t at = 0; at <= dirs.size();) {
+        const size_t end = dirs.find(':', at);
+        const std::string dir = dirs.substr(at, end == std::string::npos ? std::string::npos : end - at);
+        if (!dir.empty()) candidates.push_back(dir + "/hipcc");
+        if (end == std::string::npos) break;
+        at = end + 1;
+      }
+    }
   }
   for (const std::string &c : candidates) {
     if (access(c.c_str(), X_OK) == 0) return c;
@@ -265,7 +275,9 @@ std::string cache_stamp() {
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
   const std::string driver = compiler_driver();
-  return (driver.empty() ? std::string("hiprtc ") : "driver " + driver + " hip ") + std::to_string(major) + "." + std::to_string(minor) +
+  // (the driver's KIND and the HIP version, not its path: code objects shipped with the library stay valid on a box whose
+  // hipcc lives elsewhere)
+  return (driver.empty() ? std::string("hiprtc ") : std::string("driver hipcc hip ")) + std::to_string(major) + "." + std::to_string(minor) +
          " gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics\n";
 }
 std::string cache_file_name(const std::string &text) {

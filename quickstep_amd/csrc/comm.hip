@@ -171,6 +171,11 @@ int qsx_comm_create(int world, int rank, const void *id_bytes, qsx_comm_t **out)
   c->world = world;
   c->rank = rank;
   if (const char *t = std::getenv("QSX_COMM_TIMEOUT_MS")) c->timeout_ms = std::atoll(t);
+  // The watchdog's promise — no wait on this communicator outlasts the deadline — needs ncclCommAbort to take the stalled
+  // collective's kernels off the stream: the waits behind comm_wait (the scratch's and the pooled buffers' stream
+  // synchronisations) would block on them otherwise.  A transport without it gets NO watchdog (plain waits, as with
+  // QSX_COMM_TIMEOUT_MS=0) instead of a deadline that only moves the stall into the next wait.
+  if (api->CommAbort == nullptr) c->timeout_ms = 0;
   if (hipMalloc(reinterpret_cast<void **>(&c->status_dev), 8 * static_cast<size_t>(world + 1)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void **>(&c->status_host), 8 * static_cast<size_t>(world + 1), hipHostMallocDefault) != hipSuccess) {
     if (c->status_dev != nullptr) (void)hipFree(c->status_dev);

@@ -52,6 +52,7 @@ struct alignas(16) LongEntry {
 //   fp[16 b .. 16 b + 15] = one aligned 16-byte word of 1-byte fingerprints (0 = empty slot).
 // A key's home bucket comes from the high bits of its hash by multiply-shift (any bucket count: the table is sized for
 // load 0.8, not rounded to a power of two), its fingerprint from other bits of the hash.  Slots of a bucket fill in order
+// (slot number = what a fetch-add on the bucket's fill counter returned: fill[buckets], behind the fingerprint plane)
 // and never empty again, a key that finds its bucket full goes on to the next one — so a probe reads ONE fingerprint word
 // per bucket of its sequence (the plane is a tenth / a seventeenth of the table and stays in every XCD's L2), compares
 // sixteen bytes in registers, touches the table only where a fingerprint matches (a miss almost never does: 16 / 255 per
@@ -62,7 +63,8 @@ struct TableView {
   void *slots;    // uint64_t[16 * buckets] (INT) or LongEntry[16 * buckets] (LONG)
   unsigned char *fp;   // fingerprint plane, 16 * buckets bytes
   uint64_t buckets;
-  unsigned int *dup_flag;  // set when an insert of an INT key met an occupant with the same key: the build side is not unique
+  unsigned int *dup_flag;  // set by seal_scan_kernel (the first probe after the builds) when two entries of an INT table share a key
+  unsigned int *fill;      // [buckets] slots handed out per bucket (may count past 16: claims that found the bucket full)
   __device__ __host__ uint64_t num_slots() const { return buckets * kBucketSlots; }
 };
 
@@ -125,112 +127,123 @@ __device__ __forceinline__ bool row_in_filter(const uint64_t *filter, int64_t ro
   return filter == nullptr || ((filter[row >> 6] >> (63 - (row & 63))) & 1u);
 }
 
-// A bucket's 16 fingerprints for an INSERT: read at L2 (two relaxed agent-scope loads), not through this CU's L1.  A plain
-// load keeps serving the line the CU read first — eight buckets, mostly empty then — while the other CUs fill them: at
-// load 0.8 every later insert from this CU started its compare-and-swaps at a slot long taken and walked the bucket one
-// failed atomic at a time (1 M keys: 0.35 ms, eight times the atomic units' rate).  Still a hint: a slot claimed between this
-// read and the claim below costs one failed compare-and-swap, as before.
-__device__ __forceinline__ uint4 load_fingerprints_fresh(const unsigned char *bucket_fp) {
-  const unsigned long long *p = reinterpret_cast<const unsigned long long *>(bucket_fp);
-  const unsigned long long lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return uint4{static_cast<uint32_t>(lo), static_cast<uint32_t>(lo >> 32), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
+// An insert claims its slot with ONE returning fetch-add on the bucket's fill counter and writes the slot with a plain store —
+// nothing is read, and the fingerprint plane is not touched: the first probe after the builds writes it, slot for slot, from
+// the keys (seal_scan_kernel: coalesced, 1.25 MB for a million keys, instead of a million scattered byte stores that each
+// pull a line into L2).  (Until round 6 an insert read the bucket's fingerprint word at agent scope and claimed the first slot
+// that looked empty by compare-and-swap: on this part an agent-scope load is served by the memory side, not by the XCD's L2,
+// at 3-4 G loads/s — build_kernel took 238 us per 1 M keys, a sixth of the atomic units' rate.)  What the compare-and-swap
+// also did — the later of two inserts of one INT key saw the earlier — is done by the same scan.  Slots and fingerprints are
+// only read by kernels launched after the builds (BuildHash -> HashJoin is a pipeline breaker,
+// ExecutionGenerator.cpp:1110-1124).
+__device__ __forceinline__ void store_entry(const TableView &t, uint64_t slot, int32_t key, uint32_t tid) {
+  static_cast<uint64_t *>(t.slots)[slot] = (static_cast<uint64_t>(tid) << 32) | static_cast<uint32_t>(key);
 }
-
-__device__ __forceinline__ void insert_entry(const TableView &t, int32_t key, uint32_t tid) {
-  uint64_t *slots = static_cast<uint64_t *>(t.slots);
-  const uint64_t packed = (static_cast<uint64_t>(tid) << 32) | static_cast<uint32_t>(key);
-  const uint32_t f = fingerprint(key);
-  uint64_t b = home_bucket(key, t);
-  for (;;) {
-    // The bucket's fingerprints as a HINT (a plain load: this CU's L1 may hold an older line; bytes only ever go 0 -> f):
-    // an occupant under another fingerprint is another key and is skipped; one under this key's fingerprint is looked at
-    // (atomic load: slots are published by compare-and-swap at L2); an apparently empty slot is claimed by compare-and-swap,
-    // and a claim that fails shows the occupant.  Every occupant with this key is therefore seen by the later of the two
-    // inserts — probes of a table whose flag stays clear may stop at their first match.
-    const uint4 w = load_fingerprints_fresh(t.fp + b * kBucketSlots);
-    const uint32_t m = bucket_masks(w, f);
-    for (uint32_t same = m & 0xFFFFu; same != 0u; same &= same - 1u) {
-      const unsigned long long old = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&slots[b * kBucketSlots + (__ffs(same) - 1)]),
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (static_cast<uint32_t>(old) == static_cast<uint32_t>(key)) *t.dup_flag = 1u;
-    }
-    const uint32_t empty = m >> 16;
-    for (int c = empty != 0u ? __ffs(empty) - 1 : kBucketSlots; c < kBucketSlots; ++c) {
-      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[b * kBucketSlots + c]), kEmpty64, packed);
-      if (old == kEmpty64) {
-        t.fp[b * kBucketSlots + c] = static_cast<unsigned char>(f);
-        return;
-      }
-      if (static_cast<uint32_t>(old) == static_cast<uint32_t>(key)) *t.dup_flag = 1u;
-    }
+__device__ __forceinline__ void store_entry(const TableView &t, uint64_t slot, int64_t key, uint32_t tid) {
+  LongEntry e;
+  e.key = key;
+  e.tid = tid;
+  e.pad = 0;
+  static_cast<LongEntry *>(t.slots)[slot] = e;
+}
+// The claim behind fetch-add result `c` on bucket b (c < 16: the slot is this entry's; else the bucket was full: walk on).
+template <typename KeyT>
+__device__ __forceinline__ void finish_insert(const TableView &t, KeyT key, uint32_t tid, uint64_t b, unsigned int c) {
+  while (c >= static_cast<unsigned int>(kBucketSlots)) {
     b = b + 1 == t.buckets ? 0 : b + 1;
+    c = atomicAdd(&t.fill[b], 1u);
   }
+  store_entry(t, b * kBucketSlots + c, key, tid);
+}
+template <typename KeyT>
+__device__ __forceinline__ void insert_entry(const TableView &t, KeyT key, uint32_t tid) {
+  const uint64_t b = home_bucket(key, t);
+  finish_insert(t, key, tid, b, atomicAdd(&t.fill[b], 1u));
 }
 
-__device__ __forceinline__ void insert_entry(const TableView &t, int64_t key, uint32_t tid) {
-  LongEntry *slots = static_cast<LongEntry *>(t.slots);
-  const uint32_t f = fingerprint(key);
-  uint64_t b = home_bucket(key, t);
-  for (;;) {
-    // the fingerprints as a hint for where the bucket's first empty slot is (see the INT insert); a slot is claimed through
-    // its tid word, the key is published with a plain store and only read by probe kernels launched after the build
-    // (BuildHash -> HashJoin is a pipeline breaker, ExecutionGenerator.cpp:1110-1124).  Keys are not compared here: probes
-    // of a LONG table always walk on (no "unique" shortcut).
-    const uint4 w = load_fingerprints_fresh(t.fp + b * kBucketSlots);
-    const uint32_t empty = bucket_masks(w, f) >> 16;
-    for (int c = empty != 0u ? __ffs(empty) - 1 : kBucketSlots; c < kBucketSlots; ++c) {
-      LongEntry *e = &slots[b * kBucketSlots + c];
-      if (atomicCAS(&e->tid, kEmptyTid, tid) == kEmptyTid) {
-        e->key = key;
-        t.fp[b * kBucketSlots + c] = static_cast<unsigned char>(f);
-        return;
-      }
+// Launched by the first probe after the builds (plain cached loads: the builds' kernels have finished), one thread per slot:
+//  * the slot's fingerprint byte, from its key (0 for an empty slot) — the whole plane is written here;
+//  * INT tables: the build side's "some key occurs twice" flag (control word 2).  A thread looks at the entries in FRONT of
+//    its own on its key's walk — its home bucket up to its own bucket, there only the slots before its own; every pair of
+//    equal keys is seen by the later of the two.  Probes of a table whose flag stays clear stop at their first match.
+template <typename KeyT>
+__global__ __launch_bounds__(kJBlock) void seal_scan_kernel(TableView t) {
+  const uint64_t s = static_cast<uint64_t>(blockIdx.x) * kJBlock + threadIdx.x;
+  if (s >= t.num_slots()) return;
+  if constexpr (sizeof(KeyT) == 8) {
+    const LongEntry e = static_cast<const LongEntry *>(t.slots)[s];
+    t.fp[s] = e.tid == kEmptyTid ? static_cast<unsigned char>(0) : static_cast<unsigned char>(fingerprint(e.key));
+  } else {
+    const uint64_t *slots = static_cast<const uint64_t *>(t.slots);
+    const uint64_t e = slots[s];
+    if (e == kEmpty64) {
+      t.fp[s] = 0;
+      return;
     }
-    b = b + 1 == t.buckets ? 0 : b + 1;
+    const uint32_t key = static_cast<uint32_t>(e);
+    t.fp[s] = static_cast<unsigned char>(fingerprint(static_cast<int32_t>(key)));
+    const uint64_t own = s / kBucketSlots;
+    uint64_t b = home_bucket(static_cast<int32_t>(key), t);
+    for (;;) {   // (the buckets in front of `own` on the walk are full; a bucket's sixteen slots are one line)
+      const int end = b == own ? static_cast<int>(s % kBucketSlots) : kBucketSlots;
+      for (int j = 0; j < end; ++j) {
+        if (static_cast<uint32_t>(slots[b * kBucketSlots + j]) == key) {
+          *t.dup_flag = 1u;
+          return;
+        }
+      }
+      if (b == own) return;
+      b = b + 1 == t.buckets ? 0 : b + 1;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------
 // K3 build
 // ---------------------------------------------------------------------------
-// Bounds of the inserted keys, kept next to the entry count: [4] = min (key + 2^63 as unsigned), [5] = ~(max + 2^63) — both
-// shrink under atomicMin and both start from all ones (one memset).  The first probe reads them: a build side whose keys
-// span a small range gets a directly addressed shadow (seal_table).
+// The control words of a table come in kControlReplicas copies, each on a cache line of its own: [0] entries, [2] duplicate-key
+// flag (hashed) / overflow entries (dense), [3] error flag (dense) — both only in copy 0 —, [4] [5] bounds of the inserted keys:
+// max of ~(key + 2^63) and max of (key + 2^63) as unsigned words, all zero = none (one memset clears a table's words).  A
+// workgroup adds to copy blockIdx & 31; readers (the host) sum / max over the copies.  One copy made every workgroup's three
+// atomics same-address atomics, which complete one at a time device-wide: 977 workgroups cost 44 of a 1 M-key build's 116 us,
+// 3 907 workgroups 0.29 ms (tools/hashed_build_exp.py).
+constexpr int kControlReplicas = 32;
+constexpr int kControlStride = 16;   // words between two copies (128 bytes)
+constexpr int kControlWords = 6;
+static_assert(kControlReplicas == 32 && kControlStride == 16, "join_dense.hpp's dense_build_kernel picks its copy with the same numbers");
+__device__ __forceinline__ unsigned long long *control_replica(unsigned long long *control, unsigned int who) {
+  return control + static_cast<size_t>(who & (kControlReplicas - 1)) * kControlStride;
+}
 struct KeyBounds {
-  unsigned long long lo = ~0ull, hi_inv = ~0ull;
+  unsigned long long lo_inv = 0ull, hi = 0ull;
   __device__ __forceinline__ void add(int64_t key) {
     const unsigned long long u = static_cast<unsigned long long>(key) ^ 0x8000000000000000ull;
-    lo = u < lo ? u : lo;
-    hi_inv = ~u < hi_inv ? ~u : hi_inv;
+    lo_inv = ~u > lo_inv ? ~u : lo_inv;
+    hi = u > hi ? u : hi;
   }
-  // The workgroup's bounds and its count of inserted rows go to the control words ONCE per workgroup, and a bound only when
-  // it still moves the word (a relaxed read first: both words only shrink, a stale read errs towards sending).  Same-address
-  // atomics complete one at a time device-wide, ~12 ns each: three per wave were 0.14 of the 0.31 ms a 1 M-key build took.
+  // The workgroup's bounds and its count of inserted rows go to its copy of the control words once per workgroup.
   __device__ __forceinline__ void publish(unsigned long long *control, unsigned long long inserted) {
-    __shared__ unsigned long long wg[3];   // count, min, ~max
-    if (threadIdx.x == 0) {
-      wg[0] = 0;
-      wg[1] = wg[2] = ~0ull;
-    }
+    __shared__ unsigned long long wg[3];   // count, ~min, max
+    if (threadIdx.x == 0) wg[0] = wg[1] = wg[2] = 0ull;
     __syncthreads();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long a = __shfl_xor(lo, o, kWave), b = __shfl_xor(hi_inv, o, kWave);
-      lo = a < lo ? a : lo;
-      hi_inv = b < hi_inv ? b : hi_inv;
+      const unsigned long long a = __shfl_xor(lo_inv, o, kWave), b = __shfl_xor(hi, o, kWave);
+      lo_inv = a > lo_inv ? a : lo_inv;
+      hi = b > hi ? b : hi;
     }
     inserted = wave_reduce_add(inserted);
     if (lane_id() == 0 && inserted != 0) {
       atomicAdd(&wg[0], inserted);
-      atomicMin(&wg[1], lo);
-      atomicMin(&wg[2], hi_inv);
+      atomicMax(&wg[1], lo_inv);
+      atomicMax(&wg[2], hi);
     }
     __syncthreads();
     if (threadIdx.x == 0 && wg[0] != 0) {
-      atomicAdd(control, wg[0]);
-      if (wg[1] < __hip_atomic_load(control + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(control + 4, wg[1]);
-      if (wg[2] < __hip_atomic_load(control + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(control + 5, wg[2]);
+      unsigned long long *mine = control_replica(control, blockIdx.x);
+      atomicAdd(mine, wg[0]);
+      atomicMax(mine + 4, wg[1]);
+      atomicMax(mine + 5, wg[2]);
     }
   }
 };
@@ -240,15 +253,33 @@ __global__ __launch_bounds__(kJBlock) void build_kernel(TableView t, const KeyT 
                                                        int64_t n, int32_t base_tid,
                                                        const uint64_t *__restrict__ filter,
                                                        unsigned long long *__restrict__ entries) {
+  constexpr int R = 4;   // a lane's rows of one round: their fetch-adds are all issued before the first result is used
   unsigned long long inserted = 0;
   KeyBounds bounds;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i < n;
-       i += static_cast<int64_t>(gridDim.x) * kJBlock) {
-    if (!row_in_filter(filter, i)) continue;
-    const KeyT key = keys[i];
-    insert_entry(t, key, static_cast<uint32_t>(base_tid + i));
-    bounds.add(key);
-    ++inserted;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kJBlock;
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * kJBlock + threadIdx.x; i0 < n; i0 += stride * R) {
+    KeyT key[R];
+    uint64_t b[R];
+    unsigned int c[R];
+    bool live[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t i = i0 + r * stride;
+      live[r] = i < n && row_in_filter(filter, i);
+      key[r] = live[r] ? keys[i] : KeyT(0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      b[r] = home_bucket(key[r], t);
+      c[r] = live[r] ? atomicAdd(&t.fill[b[r]], 1u) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!live[r]) continue;
+      finish_insert(t, key[r], static_cast<uint32_t>(base_tid + i0 + r * stride), b[r], c[r]);
+      bounds.add(key[r]);
+      ++inserted;
+    }
   }
   bounds.publish(entries, inserted);
 }
@@ -779,6 +810,16 @@ struct qsx_join_table {
   // 3 = stays hashed AND `compact` (the 4-byte plane of the slots, CompactView) is valid.
   std::mutex seal_mutex;
   std::atomic<int> seal_state{0};
+  // What the first probe waits for instead of the whole device: one event per stream that cleared or built this (hashed)
+  // table, re-recorded behind every such call (mark_stream); the probing stream is made to wait for them, reads the control
+  // words into control_host behind them and only that stream is synchronised.  seal_event / seal_stream: recorded behind the
+  // kernels that make the shadow or the compact plane — probes of OTHER streams wait for it (like pack_event).
+  std::atomic<bool> scanned{false};   // seal_scan_kernel has been issued since the last build (seal_event orders probes behind it)
+  std::mutex marks_mutex;
+  std::vector<std::pair<hipStream_t, hipEvent_t>> marks;
+  unsigned long long *control_host = nullptr;   // pinned, kControlBytes
+  hipEvent_t seal_event = nullptr;
+  hipStream_t seal_stream = nullptr;
   void *compact = nullptr;          // [capacity] 4-byte slots, then [capacity] fingerprint bytes
   uint64_t compact_capacity = 0;
   CompactView compact_view() const {
@@ -826,6 +867,8 @@ struct qsx_join_table {
   size_t entry_bytes() const { return key_type == QSX_INT ? 8 : 16; }
   // bytes of the table: slots, then one fingerprint byte per slot
   size_t table_bytes() const { return capacity * entry_bytes() + capacity; }
+  // ... and behind them the buckets' fill counters (only the builds touch them)
+  static size_t alloc_bytes(size_t entry, uint64_t cap) { return cap * entry + cap + cap / kBucketSlots * sizeof(unsigned int); }
   // rows the table takes at its load limit
   uint64_t room() const { return capacity / 5 * 4; }
   TableView view() const {
@@ -834,18 +877,68 @@ struct qsx_join_table {
     v.dup_flag = reinterpret_cast<unsigned int *>(entries_dev + 2);
     v.fp = static_cast<unsigned char *>(slots) + capacity * entry_bytes();
     v.buckets = capacity / kBucketSlots;
+    v.fill = reinterpret_cast<unsigned int *>(v.fp + capacity);
     return v;
   }
 };
 static void drop_cover(qsx_join_table *t);
 
-// control words behind entries_dev: [0] entries, [1] unused, [2] overflow entries (dense) / duplicate-key flag
-// (hashed), [3] error flag (dense), [4] [5] bounds of the inserted keys (KeyBounds; all ones = none)
-constexpr int kControlWords = 6;
+// control words behind entries_dev: kControlReplicas copies (see KeyBounds).
+constexpr size_t kControlBytes = static_cast<size_t>(kControlReplicas) * kControlStride * sizeof(unsigned long long);
 static int reset_control_words(unsigned long long *control, hipStream_t stream) {
-  QSX_HIP_TRY(hipMemsetAsync(control, 0, 4 * sizeof(unsigned long long), stream));
-  QSX_HIP_TRY(hipMemsetAsync(control + 4, 0xFF, 2 * sizeof(unsigned long long), stream));
+  QSX_HIP_TRY(hipMemsetAsync(control, 0, kControlBytes, stream));
   return QSX_OK;
+}
+// The copies folded into one set of words: v[0] entries, v[2], v[3] as they are, v[4] = min key + 2^63, v[5] = max key + 2^63
+// (unsigned images); returns false when no key was ever inserted.
+static bool fold_control_words(const unsigned long long *copies, unsigned long long *v) {
+  unsigned long long entries = 0, lo_inv = 0, hi = 0;
+  for (int r = 0; r < kControlReplicas; ++r) {
+    const unsigned long long *c = copies + static_cast<size_t>(r) * kControlStride;
+    entries += c[0];
+    lo_inv = c[4] > lo_inv ? c[4] : lo_inv;
+    hi = c[5] > hi ? c[5] : hi;
+  }
+  v[0] = entries;
+  v[1] = 0;
+  v[2] = copies[2];
+  v[3] = copies[3];
+  v[4] = ~lo_inv;
+  v[5] = hi;
+  return !(lo_inv == 0 && hi == 0);
+}
+// (host waits for `stream`, or for the null stream's ordering when the copy is synchronous)
+static int copy_control_words(const unsigned long long *control_dev, hipStream_t stream, unsigned long long *v, bool *any_key = nullptr) {
+  unsigned long long copies[kControlReplicas * kControlStride];
+  QSX_HIP_TRY(hipMemcpyAsync(copies, control_dev, kControlBytes, hipMemcpyDeviceToHost, stream));
+  QSX_HIP_TRY(hipStreamSynchronize(stream));
+  const bool any = fold_control_words(copies, v);
+  if (any_key != nullptr) *any_key = any;
+  return QSX_OK;
+}
+
+// Behind a clear or build of a hashed table on `stream` (see qsx_join_table::marks).  A failure to record only costs the
+// first probe its shortcut: it then waits for the device (sealed_shadow).
+static void mark_stream(qsx_join_table *t, hipStream_t stream) {
+  if (t->dense) return;
+  std::lock_guard<std::mutex> lock(t->marks_mutex);
+  for (auto &m : t->marks) {
+    if (m.first == stream) {
+      if (m.second != nullptr && hipEventRecord(m.second, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipEventDestroy(m.second);
+        m.second = nullptr;
+      }
+      return;
+    }
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, stream) != hipSuccess) {
+    (void)hipGetLastError();
+    if (e != nullptr) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  t->marks.emplace_back(stream, e);
 }
 
 static uint64_t capacity_for(int key_type, int64_t entries) {
@@ -858,12 +951,13 @@ static uint64_t capacity_for(int key_type, int64_t entries) {
 
 static int fill_empty(const qsx_join_table *t, void *slots, uint64_t capacity, hipStream_t stream) {
   QSX_HIP_TRY(hipMemsetAsync(slots, 0xFF, capacity * t->entry_bytes(), stream));
-  QSX_HIP_TRY(hipMemsetAsync(static_cast<char *>(slots) + capacity * t->entry_bytes(), 0, capacity, stream));
+  // (the fingerprint plane is written whole by seal_scan_kernel in front of the first probe: only the fill counters behind it)
+  QSX_HIP_TRY(hipMemsetAsync(static_cast<char *>(slots) + capacity * t->entry_bytes() + capacity, 0, capacity / kBucketSlots * sizeof(unsigned int), stream));
   return QSX_OK;
 }
 
 static int allocate_slots(qsx_join_table *t, uint64_t capacity, void **out) {
-  QSX_HIP_TRY(device_malloc(out, capacity * t->entry_bytes() + capacity));
+  QSX_HIP_TRY(device_malloc(out, qsx_join_table::alloc_bytes(t->entry_bytes(), capacity)));
   int rc = fill_empty(t, *out, capacity, nullptr);
   if (rc == QSX_OK) {
     const hipError_t waited = hipStreamSynchronize(nullptr);
@@ -912,8 +1006,10 @@ static int ensure_room(qsx_join_table *t, int64_t additional) {
     return QSX_OK;
   }
   QSX_HIP_TRY(hipDeviceSynchronize());  // drain in-flight builds on every stream
-  unsigned long long actual = 0;
-  QSX_HIP_TRY(hipMemcpy(&actual, t->entries_dev, sizeof(actual), hipMemcpyDeviceToHost));
+  unsigned long long words[kControlWords];
+  const int rc_words = copy_control_words(t->entries_dev, nullptr, words);
+  if (rc_words != QSX_OK) return rc_words;
+  const unsigned long long actual = words[0];
   // rows filtered out by a bitmap never became entries: tighten the bound
   t->reserved = static_cast<int64_t>(actual);
   if (static_cast<uint64_t>(t->reserved + additional) <= t->room()) {
@@ -949,9 +1045,8 @@ int qsx_join_table_create(int key_type, int64_t est_entries, qsx_join_table_t **
   t->capacity = capacity_for(key_type, est_entries);
   int rc = allocate_slots(t, t->capacity, &t->slots);
   if (rc != QSX_OK) { delete t; return rc; }
-  hipError_t err = device_malloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, 4 * sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemset(t->entries_dev + 4, 0xFF, 2 * sizeof(unsigned long long));
+  hipError_t err = device_malloc(reinterpret_cast<void **>(&t->entries_dev), kControlBytes);
+  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, kControlBytes);
   if (err != hipSuccess) {
     set_last_error("device_malloc(entries)", err);
     (void)device_free(t->slots);
@@ -984,9 +1079,8 @@ int qsx_join_table_create_dense(int key_type, int64_t min_key, int64_t max_key, 
   hipError_t err = device_malloc(reinterpret_cast<void **>(&t->head), range * sizeof(uint32_t));
   if (err == hipSuccess) err = hipMemset(t->head, 0, range * sizeof(uint32_t));
   if (err == hipSuccess) err = device_malloc(reinterpret_cast<void **>(&t->ov), static_cast<size_t>(t->ov_capacity) * sizeof(uint2));
-  if (err == hipSuccess) err = device_malloc(reinterpret_cast<void **>(&t->entries_dev), kControlWords * sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, 4 * sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemset(t->entries_dev + 4, 0xFF, 2 * sizeof(unsigned long long));
+  if (err == hipSuccess) err = device_malloc(reinterpret_cast<void **>(&t->entries_dev), kControlBytes);
+  if (err == hipSuccess) err = hipMemset(t->entries_dev, 0, kControlBytes);
   if (err != hipSuccess) {
     set_last_error("device_malloc(dense join table)", err);
     (void)device_free(t->head);
@@ -1099,6 +1193,11 @@ static int destroy_table(qsx_join_table_t *t, bool wait_for_device) {
   (void)device_free_idle(t->compact);
   (void)device_free_idle(t->cover);
   if (t->pack_event != nullptr) (void)hipEventDestroy(t->pack_event);
+  if (t->seal_event != nullptr) (void)hipEventDestroy(t->seal_event);
+  for (auto &m : t->marks) {
+    if (m.second != nullptr) (void)hipEventDestroy(m.second);
+  }
+  if (t->control_host != nullptr) (void)hipHostFree(t->control_host);
   (void)device_free_idle(t->ov);
   (void)device_free_idle(t->entries_dev);
   delete t;
@@ -1122,7 +1221,9 @@ int qsx_join_table_clear(qsx_join_table_t *t, qsx_stream_t stream) {
   t->reserved = 0;
   t->max_tid.store(-1);
   t->seal_state.store(0);
+  t->scanned.store(false);
   drop_cover(t);
+  mark_stream(t, as_stream(stream));
   return QSX_OK;
 }
 
@@ -1130,8 +1231,8 @@ int qsx_join_table_size(qsx_join_table_t *t, int64_t *out_entries, qsx_stream_t 
   QSX_REQUIRE_DEVICE();
   if (t == nullptr || out_entries == nullptr) return QSX_ERR_INVALID_ARGUMENT;
   unsigned long long v[kControlWords] = {0, 0, 0, 0, 0, 0};
-  QSX_HIP_TRY(hipMemcpyAsync(v, t->entries_dev, sizeof(v), hipMemcpyDeviceToHost, as_stream(stream)));
-  QSX_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  const int rc_words = copy_control_words(t->entries_dev, as_stream(stream), v);
+  if (rc_words != QSX_OK) return rc_words;
   *out_entries = static_cast<int64_t>(v[0]);
   // dense flavour: a build key outside [min_key, max_key] was skipped — the caller's statistics were not exact
   if (t->dense && static_cast<int>(v[3] & 0xFFFFFFFFu) != 0) return QSX_ERR_INVALID_ARGUMENT;
@@ -1148,6 +1249,7 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   int rc = ensure_room(t, n);
   if (rc != QSX_OK) return rc;
   t->seal_state.store(0);
+  t->scanned.store(false);
   drop_cover(t);
   for (int64_t seen = t->max_tid.load(); seen < base_tid + n - 1 && !t->max_tid.compare_exchange_weak(seen, base_tid + n - 1);) {}
   std::shared_lock<std::shared_mutex> lock(t->mutex);
@@ -1172,6 +1274,7 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
                        static_cast<const int64_t *>(keys_dev), n, base_tid, filter_dev, t->entries_dev);
   }
   QSX_CHECK_LAUNCH();
+  mark_stream(t, as_stream(stream));
   return QSX_OK;
 }
 
@@ -1195,6 +1298,7 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
   int rc = ensure_room(t, total);
   if (rc != QSX_OK) return rc;
   t->seal_state.store(0);
+  t->scanned.store(false);
   drop_cover(t);
   for (int64_t b = 0; b < num_blocks; ++b) {
     const int64_t last = base[b] + block_rows[b] - 1;
@@ -1229,6 +1333,7 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
     }
   }
   QSX_CHECK_LAUNCH();
+  mark_stream(t, s);
   return QSX_OK;
 }
 
@@ -1334,12 +1439,13 @@ static bool compact_enabled() {
   return e == nullptr || e[0] != '0';
 }
 // The compact plane of a sealed bucketed table (CompactView; called under seal_mutex with the device idle): true = built.
-static bool seal_compact(qsx_join_table *t, bool duplicate_keys, hipStream_t stream) {
+// What the host knows without the duplicate-key flag.
+static bool compact_possible(const qsx_join_table *t) {
   const uint64_t buckets = t->capacity / kBucketSlots;
-  if (!compact_enabled() || t->key_type != QSX_INT || duplicate_keys || buckets < kCompactMinBuckets || buckets > 0xFFFFFFFFull ||
-      t->max_tid.load() >= (1 << 24)) {
-    return false;
-  }
+  return compact_enabled() && t->key_type == QSX_INT && buckets >= kCompactMinBuckets && buckets <= 0xFFFFFFFFull && t->max_tid.load() < (1 << 24);
+}
+static bool seal_compact(qsx_join_table *t, bool duplicate_keys, hipStream_t stream) {
+  if (!compact_possible(t) || duplicate_keys) return false;
   if (t->compact_capacity != t->capacity) {
     (void)device_free(t->compact);
     t->compact = nullptr;
@@ -1353,39 +1459,149 @@ static bool seal_compact(qsx_join_table *t, bool duplicate_keys, hipStream_t str
   }
   hipLaunchKernelGGL(compact_build_kernel, dim3(static_cast<unsigned>((t->capacity + kJBlock - 1) / kJBlock)), dim3(kJBlock), 0, stream, t->view(),
                      static_cast<uint32_t *>(t->compact), static_cast<unsigned char *>(t->compact) + t->capacity * 4);
-  // (synchronous: once per sealed table; probes of other streams find a finished plane)
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+  // (no host wait: the plane is ordered on the sealing stream, probes of other streams wait for seal_event)
+  if (hipGetLastError() != hipSuccess) return false;
+  return true;
+}
+
+static bool seal_verify_enabled() {
+  const char *e = getenv("QSX_JOIN_SEAL_VERIFY");   // tests: wait for the shadow's build and look at its error word
+  return e != nullptr && e[0] == '1';
+}
+// Put `stream` behind every stream's last clear / build of this table (mark_stream; the calls themselves have returned:
+// pipeline breaker) — device-side waits only.  false: some event could not be made or waited for.
+static bool wait_for_builds(qsx_join_table *t, hipStream_t stream) {
+  bool marked = true;
+  std::lock_guard<std::mutex> lock(t->marks_mutex);
+  for (const auto &m : t->marks) {
+    if (m.second == nullptr) marked = false;
+    else if (m.first != stream && hipStreamWaitEvent(stream, m.second, 0) != hipSuccess) marked = false;
+  }
+  if (!marked) (void)hipGetLastError();
+  return marked;
+}
+// The control words of a hashed table as the builds (and the scan) left them, WITHOUT waiting for the device: `stream` is
+// behind the builds (wait_for_builds), the words are copied behind them into pinned memory, and only that stream is
+// synchronised — other Workers' streams keep running.
+static bool read_control_words(qsx_join_table *t, hipStream_t stream, unsigned long long *v, bool *any_key) {
+  if (t->control_host == nullptr && hipHostMalloc(reinterpret_cast<void **>(&t->control_host), kControlBytes, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
+    t->control_host = nullptr;
+  }
+  if (t->control_host == nullptr) return copy_control_words(t->entries_dev, stream, v, any_key) == QSX_OK;
+  if (hipMemcpyAsync(t->control_host, t->entries_dev, kControlBytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess) {
     return false;
   }
+  *any_key = fold_control_words(t->control_host, v);
+  return true;
+}
+// A probe on `stream` is about to read what another stream's seal made (shadow / compact plane): run behind its kernels.
+static void behind_the_seal(qsx_join_table *t, hipStream_t stream) {
+  if (t->seal_stream != stream && t->seal_event != nullptr && hipEventQuery(t->seal_event) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamWaitEvent(stream, t->seal_event, 0);
+  }
+}
+// Record seal_event behind what `stream` has queued for this table (scan, shadow, compact plane); false = no event and the
+// stream could not be waited for either.
+static bool record_seal(qsx_join_table *t, hipStream_t stream) {
+  if (t->seal_event == nullptr && hipEventCreateWithFlags(&t->seal_event, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    t->seal_event = nullptr;
+  }
+  if (t->seal_event == nullptr || hipEventRecord(t->seal_event, stream) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipStreamSynchronize(stream) != hipSuccess) return false;
+    t->seal_stream = nullptr;      // (finished: nobody has to wait)
+    if (t->seal_event != nullptr) {
+      (void)hipEventDestroy(t->seal_event);
+      t->seal_event = nullptr;
+    }
+  } else {
+    t->seal_stream = stream;
+  }
+  return true;
+}
+// Publish `state` behind the seal's kernels on `stream`.
+static bool publish_seal(qsx_join_table *t, hipStream_t stream, int state) {
+  if (!record_seal(t, stream)) return false;
+  t->seal_state.store(state, std::memory_order_release);
   return true;
 }
 
 // probe_rows: the rows of the probe that asks (0: unknown).  A build side below kAdaptiveMinRows is only worth the look
-// (a device synchronisation, a copy of the control words) in front of a probe of a million rows or more — and then its
+// (a wait for the builds, a copy of the control words) in front of a probe of a million rows or more — and then its
 // shadow, when the keys turn out dense, is a table the probe kernels hold in LDS (join_lds.hpp).
 static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream, int64_t probe_rows = 0) {
   int state = t->seal_state.load(std::memory_order_acquire);
-  if (state == 2) return t->shadow;
-  if (state == 1 || state == 3 || !adaptive_enabled()) return nullptr;
+  if (state != 0) {
+    behind_the_seal(t, stream);
+    return state == 2 ? t->shadow : nullptr;
+  }
   const bool small_build = t->reserved < kAdaptiveMinRows;
-  if (small_build && (probe_rows < (1 << 20) || t->reserved < 1 || !lds_tables_enabled())) return nullptr;
+  const bool not_worth_a_look = small_build && (probe_rows < (1 << 20) || t->reserved < 1 || !lds_tables_enabled());
+  if (not_worth_a_look && t->scanned.load(std::memory_order_acquire)) {   // (the short probes of a small table: no mutex)
+    behind_the_seal(t, stream);
+    return nullptr;
+  }
   std::lock_guard<std::mutex> lock(t->seal_mutex);
   state = t->seal_state.load(std::memory_order_acquire);
-  if (state != 0) return state == 2 ? t->shadow : nullptr;
-  // probes start after every build work order has finished (pipeline breaker); builds issued on other streams included
-  if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+  if (state != 0) {
+    behind_the_seal(t, stream);
+    return state == 2 ? t->shadow : nullptr;
+  }
+  // The first probe since the last build: probes start after every build work order has finished (pipeline breaker), builds
+  // issued on other streams included — this stream is put behind them (device-side waits), and every later probe (any stream)
+  // runs behind seal_event.  A table that stays hashed gets its scan (fingerprint plane, duplicate keys) here, once; a table
+  // that gets a directly addressed shadow needs neither.
+  bool behind_builds = t->scanned.load(std::memory_order_acquire);
+  if (behind_builds) behind_the_seal(t, stream);
+  auto put_behind_builds = [&]() -> bool {
+    if (behind_builds) return true;
+    if (!wait_for_builds(t, stream) && hipDeviceSynchronize() != hipSuccess) return false;
+    behind_builds = true;
+    return true;
+  };
+  auto ensure_scanned = [&]() -> bool {
+    if (t->scanned.load(std::memory_order_acquire)) return true;
+    if (!put_behind_builds()) return false;
+    const unsigned scan_grid = static_cast<unsigned>((t->capacity + kJBlock - 1) / kJBlock);
+    if (t->key_type == QSX_INT) {
+      hipLaunchKernelGGL(seal_scan_kernel<int32_t>, dim3(scan_grid), dim3(kJBlock), 0, stream, t->view());
+    } else {
+      hipLaunchKernelGGL(seal_scan_kernel<int64_t>, dim3(scan_grid), dim3(kJBlock), 0, stream, t->view());
+    }
+    if (hipGetLastError() != hipSuccess || !record_seal(t, stream)) return false;
+    t->scanned.store(true, std::memory_order_release);
+    return true;
+  };
+  auto stays_hashed = [&]() -> qsx_join_table * {   // (state 1 behind the scan; a failed scan leaves the table undecided and the probe fails)
+    if (ensure_scanned()) t->seal_state.store(1, std::memory_order_release);
+    return nullptr;
+  };
+  if (!adaptive_enabled()) return stays_hashed();
+  // (undecided, not "stays hashed": a longer probe may still be worth the look)
+  if (not_worth_a_look) {
+    (void)ensure_scanned();
+    return nullptr;
+  }
   unsigned long long v[kControlWords];
-  if (hipMemcpy(v, t->entries_dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+  bool any_key = false;
+  if (!put_behind_builds() || !read_control_words(t, stream, v, &any_key)) return stays_hashed();
   const uint64_t entries = v[0];
-  const int64_t lo = static_cast<int64_t>(v[4] ^ 0x8000000000000000ull), hi = static_cast<int64_t>(~v[5] ^ 0x8000000000000000ull);
+  const int64_t lo = static_cast<int64_t>(v[4] ^ 0x8000000000000000ull), hi = static_cast<int64_t>(v[5] ^ 0x8000000000000000ull);
   const uint64_t span = static_cast<uint64_t>(hi) - static_cast<uint64_t>(lo);
   // (a small build side: only when the whole key range fits the LDS table of the probe kernels)
   const bool fits_lds = small_build && entries >= 1 && span < static_cast<uint64_t>(kLdsDenseMaxWords);
-  if (v[4] == ~0ull || (entries < static_cast<uint64_t>(kAdaptiveMinRows) && !fits_lds) || (span >= 8 * entries && !fits_lds) ||
+  if (!any_key || (entries < static_cast<uint64_t>(kAdaptiveMinRows) && !fits_lds) || (span >= 8 * entries && !fits_lds) ||
       span >= (1ull << 32) || entries > 0x7FFFFFFFull) {
-    // stays hashed — behind the compact plane of its slots when the table is one that has it (v[2]: the duplicate-key flag)
-    t->seal_state.store(seal_compact(t, v[2] != 0, stream) ? 3 : 1, std::memory_order_release);
+    // stays hashed — behind the compact plane of its slots when the table is one that can have it and the scan found no key twice
+    // (the flag is the scan's: one more look at the control words, on this stream only)
+    if (!ensure_scanned()) return nullptr;
+    if (!compact_possible(t) || !read_control_words(t, stream, v, &any_key) || !seal_compact(t, v[2] != 0, stream) || !publish_seal(t, stream, 3)) {
+      t->seal_state.store(1, std::memory_order_release);
+    }
     return nullptr;
   }
   qsx_join_table *shadow = t->shadow;
@@ -1396,25 +1612,30 @@ static qsx_join_table *sealed_shadow(qsx_join_table *t, hipStream_t stream, int6
   if (shadow == nullptr) {
     if (qsx_join_table_create_dense(t->key_type, lo, hi, 1, static_cast<int64_t>(entries), &shadow) != QSX_OK) {
       (void)hipGetLastError();
-      t->seal_state.store(1, std::memory_order_release);   // no room for the shadow: the hashed table answers
-      return nullptr;
+      return stays_hashed();   // no room for the shadow: the hashed table answers
     }
     t->shadow = shadow;
   } else if (qsx_join_table_clear(shadow, reinterpret_cast<qsx_stream_t>(stream)) != QSX_OK) {
-    return nullptr;
+    return stays_hashed();
   }
   shadow->reserved = static_cast<int64_t>(entries);
   shadow->max_tid.store(t->max_tid.load());
   const TableView src = t->view();
   hipLaunchKernelGGL(dense_build_from_slots_kernel, dim3(grid_for(static_cast<int64_t>(src.num_slots()), kJBlock * 4)), dim3(kJBlock), 0, stream,
                      t->key_type == QSX_LONG ? 1 : 0, src, shadow->dense_view());
-  int error = 0;
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess ||
-      hipMemcpy(&error, shadow->entries_dev + 3, sizeof(error), hipMemcpyDeviceToHost) != hipSuccess || error != 0) {
-    t->seal_state.store(1, std::memory_order_release);
-    return nullptr;
+  if (hipGetLastError() != hipSuccess) return stays_hashed();
+  // The copy cannot fail on the device: the range is the exact min / max of the entries and the overflow list has room for
+  // every one of them — so nobody waits for it on the host (QSX_JOIN_SEAL_VERIFY=1: the tests do, and read the error word).
+  if (seal_verify_enabled()) {
+    int error = 0;
+    if (hipStreamSynchronize(stream) != hipSuccess ||
+        hipMemcpy(&error, shadow->entries_dev + 3, sizeof(error), hipMemcpyDeviceToHost) != hipSuccess || error != 0) {
+      set_last_error("QSX_JOIN_SEAL_VERIFY: the shadow's build reported an error", hipErrorUnknown);
+      return stays_hashed();
+    }
   }
-  t->seal_state.store(2, std::memory_order_release);   // other threads' probes (their own streams) may use it from here on
+  // other threads' probes (their own streams) may use it from here on, behind seal_event
+  if (!publish_seal(t, stream, 2)) return stays_hashed();
   return shadow;
 }
 
@@ -1465,6 +1686,11 @@ static int launch_probe(qsx_join_table_t *t, const void *keys, int64_t n, int32_
     if (shadow != nullptr) {
       return launch_probe<MODE, kRuns>(shadow, keys, n, probe_base_tid, filter, out_probe, out_build, capacity, out_count, out_bitmap,
                                        anti, stream, runs_dev, run_tiles);
+    }
+    // the hashed kernels read the fingerprint plane, which the scan of the first probe writes: no scan, no probe
+    if (!t->scanned.load(std::memory_order_acquire)) {
+      set_last_error("the scan in front of a hashed table's first probe could not be issued", hipErrorUnknown);
+      return QSX_ERR_HIP;
     }
   }
   if (out_count != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), stream));

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, 
     words = next_words;
   }
   inserted = wave_reduce_add(inserted);
-  if (lane == 0 && inserted != 0) atomicAdd(entries, inserted);
+  // (the wave's copy of the control words, join.hip kControlReplicas x kControlStride: not one address for every wave)
+  if (lane == 0 && inserted != 0) atomicAdd(entries + static_cast<size_t>(wave & 31) * 16, inserted);
 }
 
 // ---- probe + projection in one pass (qsx_join_probe_project_blocks) ------------------------------------------------------

@@ -939,6 +939,62 @@ def test_first_probes_from_several_streams_wait_for_the_packed_table(capi, dev):
         table.close()
 
 
+@pytest.mark.parametrize("keys_kind,n_build", [("dense", 1_000_000), ("sparse", 900_000), ("sparse_duplicates", 900_000), ("small", 20_000)])
+@pytest.mark.parametrize("verify", ["0", "1"])
+def test_first_probes_of_a_hashed_table_from_several_streams(capi, dev, keys_kind, n_build, verify, monkeypatch):
+    """The first probe after the builds of a hashed table (join.hip sealed_shadow) no longer waits for the device: the probing
+    stream is put behind the event of every stream that cleared or built the table, reads the control words behind them,
+    then either copies the entries into a directly addressed shadow (dense keys) or runs the scan that writes the
+    fingerprint plane and finds duplicate keys (builds write neither any more) and, for big tables of unique sparse keys, the
+    compact plane.  Builds from TWO streams, then eight Worker-like threads probing at once on their own streams — the first
+    HashJoin work orders behind a BuildHash (relational_operators/HashJoinOperator.cpp:220-231) — must all see the complete
+    table: whoever seals, the others run behind its event.  Ten build / probe rounds per table (clear in between), with
+    QSX_JOIN_SEAL_VERIFY=1 (the sealing thread waits for the shadow and reads its error word) and without."""
+    import threading
+    monkeypatch.setenv("QSX_JOIN_SEAL_VERIFY", verify)
+    n_probe, threads = 1 << 20, 8
+    g = torch.Generator(device=dev)
+    g.manual_seed(17)
+    build = torch.randperm(n_build, device=dev, generator=g).to(torch.int32)
+    if keys_kind.startswith("sparse"):
+        build = (build.long() * 2039 % (2**31 - 1)).to(torch.int32)               # a bijection: unique keys without a dense domain
+    per_key = 1
+    if keys_kind == "sparse_duplicates":
+        build[n_build // 2:] = build[:n_build - n_build // 2]                     # every key twice
+        per_key = 2
+    half = n_build // 2
+    probes = [build[torch.randint(0, n_build, (n_probe,), device=dev, generator=g)] for _ in range(threads)]
+    misses = torch.full((n_probe,), 2**31 - 1, dtype=torch.int32, device=dev)      # not a build key
+    table = capi.JoinTable(T.INT, n_build)
+    side = torch.cuda.Stream(device=dev)
+    for _ in range(10):
+        table.clear()
+        table.build(build[:half], base_tid=0)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            table.build(build[half:], base_tid=half)                               # a second BuildHash work order, on its own stream
+        # (no synchronisation here: the pipeline breaker is the builds' calls having returned, not the device being idle)
+        start = threading.Barrier(threads)
+        counts, missed = [None] * threads, [None] * threads
+
+        def work(i):
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                start.wait()
+                c = table.probe_count(probes[i])
+                m = table.probe_count(misses)
+                stream.synchronize()
+                counts[i], missed[i] = int(c.item()), int(m.item())
+        pool = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in pool:
+            t.start()
+        for t in pool:
+            t.join()
+        assert counts == [n_probe * per_key] * threads and missed == [0] * threads, (counts, missed)
+        torch.cuda.synchronize()
+    table.close()
+
+
 def _compact_probes(capi):
     import ctypes
     capi.lib.qsx_debug_join_compact_probes.restype = ctypes.c_longlong
