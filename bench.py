@@ -1055,11 +1055,35 @@ def condensed(line):
             "config": {k: v for k, v in line["config"].items() if k != "workload"}}
 
 
+def partitioned_operators_leg(args, config, size, twin_ms):
+    """BASELINE config 4 / 5 through the operator boundary: the plan's DAG as RelationalOperators under ForemanSingleNode + Workers, the
+    exchange steps issued by PartitionExchangeOperator / ExchangeAggregationStatesOperator over a one-rank RankGroup on RCCL
+    (tests/cpp/partitioned_operators_bench.cpp, a child process with its own copy of the relations, result-checked every step)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "partitioned_operators_bench")
+    if not os.path.exists(exe):
+        return {"error": "tests/cpp/bin/partitioned_operators_bench is not built (make -C quickstep_amd/host)"}
+    cmd = [exe, config, str(size), str(args.secondary_steps), "3", str(args.operator_workers), str(args.partitioned_blocks_per_work_order)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"exit code {r.returncode}", "stderr": r.stderr[-1500:]}
+    out = json.loads(lines[-1])
+    out["ms_over_the_raw_abi_plan"] = out["ms_per_step"] / twin_ms
+    return out
+
+
 def secondary_c4(ctx, args, threads):
     from quickstep_amd import plans
     sub = argparse.Namespace(**vars(args))
     sub.steps, sub.warmup = args.secondary_steps, 2
     out = condensed(run_c4(ctx, sub))
+    if not args.no_operators:
+        torch.cuda.empty_cache()
+        out["operators"] = partitioned_operators_leg(args, "c4", args.c4_orders_per_rank, out["ms"])
     if not args.no_cpu_baseline:
         from oracle import pyoracle as O
         P, block = 8, 4 * 1024 * 1024 // 12      # SF100 over 8 partitions; 4 MB blocks of (INT key, 8-byte payload)
@@ -1097,6 +1121,9 @@ def secondary_c5(ctx, args, threads):
     sub = argparse.Namespace(**vars(args))
     sub.steps, sub.warmup = args.secondary_steps, 2
     out = condensed(run_c5(ctx, sub))
+    if not args.no_operators:
+        torch.cuda.empty_cache()
+        out["operators"] = partitioned_operators_leg(args, "c5", args.c5_sf_per_rank, out["ms"])
     if not args.no_cpu_baseline:
         from oracle import pyoracle as O
 
@@ -1311,6 +1338,9 @@ def main():
                          "that grants 16 cores by cgroup quota eight of them next to the runtime's own threads got the process throttled — "
                          "6-7 ms standstills every few steps; four do the same work in the same or less time)")
     ap.add_argument("--blocks-per-work-order", type=int, default=256)
+    ap.add_argument("--partitioned-blocks-per-work-order", type=int, default=1024,
+                    help="blocks per work order of the C4 / C5 operators legs (their work orders stream: every one ends in a count the host "
+                         "reads, so fewer and longer ones)")
     ap.add_argument("--transport", choices=["auto", "torch", "capi", "both"], default="auto",
                     help="who issues the exchange steps: torch = torch.distributed on the nccl backend (RCCL); capi = the C ABI's own "
                          "multi-GPU entry points (qsx_alltoallv, qsx_allgather, qsx_agg_reduce_scatter, ...: RCCL bound inside "

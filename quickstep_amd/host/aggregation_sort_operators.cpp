@@ -305,7 +305,7 @@ bool SortRunGenerationOperator::getAllWorkOrders(WorkOrdersContainer *container,
   std::lock_guard<std::mutex> lock(mutex_);
   while (num_workorders_generated_ < input_relation_block_ids_.size()) {   // one sorted run per input block
     container->addNormalWorkOrder(new SortWorkOrder(query_id_, {input_relation_block_ids_[num_workorders_generated_]}, input_relation_,
-                                                    config, 0, dest, storage_manager), op_index_);
+                                                    config, top_k_, dest, storage_manager), op_index_);
     ++num_workorders_generated_;
   }
   return input_relation_is_stored_ || done_feeding_input_relation_;

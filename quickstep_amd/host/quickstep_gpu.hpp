@@ -1150,6 +1150,9 @@ class SortRunGenerationOperator : public RelationalOperator {
   }
   QueryContext::insert_destination_id getInsertDestinationID() const override { return output_destination_index_; }
   relation_id getOutputRelationID() const override { return output_relation_.getID(); }
+  // ORDER BY ... LIMIT k: the merge behind this operator keeps k tuples (SortMergeRunOperator's top_k), so no run needs more than
+  // its first k — a run is then a selection of k tuples (qsx_sort_top_k) instead of a sort of the whole block.  0 = whole runs.
+  void setTopK(std::size_t top_k) { top_k_ = top_k; }
 
  private:
   const CatalogRelation &input_relation_;
@@ -1157,6 +1160,7 @@ class SortRunGenerationOperator : public RelationalOperator {
   const QueryContext::insert_destination_id output_destination_index_;
   const QueryContext::sort_config_id sort_config_index_;
   const bool input_relation_is_stored_;
+  std::size_t top_k_ = 0;
   std::mutex mutex_;
   std::vector<block_id> input_relation_block_ids_;
   std::size_t num_workorders_generated_ = 0;
@@ -1249,8 +1253,10 @@ class RankGroup {
 //     registered under their partition and streamed to the consumers with it (kDataPipelineMessage's partition id);
 //   unpartitioned input + broadcast = true: every rank receives the tuples of all ranks (rank order) as ONE block of the
 //     (unpartitioned) output relation — the build side of a broadcast join (BuildHashOperator.hpp:99, 146-152).
-// One work order, generated when the input is complete (the operator is a pipeline breaker towards its producer); NULL
-// bitmaps of nullable attributes travel as word-aligned bitmaps per (source rank, partition) and are re-packed on arrival.
+// One work order at a time, each over the blocks that have arrived since the last (a ROUND of collectives: the producer keeps
+// filling blocks under it, and the whole shuffled relation never has to be held at once); every rank runs the same number of
+// rounds — the counts exchange carries "more of mine will follow", and the round in which no rank says so is the last everywhere.
+// NULL bitmaps of nullable attributes travel as word-aligned bitmaps per (source rank, partition) and are re-packed on arrival.
 class PartitionExchangeOperator : public RelationalOperator {
  public:
   PartitionExchangeOperator(std::size_t query_id, const CatalogRelation &input_relation, bool input_relation_is_stored,
@@ -1269,6 +1275,7 @@ class PartitionExchangeOperator : public RelationalOperator {
   relation_id getOutputRelationID() const override { return output_relation_.getID(); }
   // bytes this rank sent to other ranks / received from them (after the work order has run)
   std::uint64_t bytesSentToPeers() const { return bytes_sent_.load(); }
+  std::size_t numRounds() const { return rounds_; }
 
  private:
   friend class PartitionExchangeWorkOrder;
@@ -1278,10 +1285,13 @@ class PartitionExchangeOperator : public RelationalOperator {
   const QueryContext::insert_destination_id output_destination_index_;
   RankGroup *ranks_;
   const bool broadcast_;
+  void roundFinished(bool last);   // by the round's work order: the next one may be issued / the operator is done
   std::mutex mutex_;
   PartitionedBlockIds input_;
+  std::vector<std::size_t> consumed_;     // per partition: blocks of input_ the rounds so far have taken
   std::atomic<std::uint64_t> bytes_sent_{0};
-  bool work_generated_ = false;
+  bool round_in_flight_ = false, finished_ = false;
+  std::size_t rounds_ = 0;
 };
 
 // The partial aggregation states of all ranks merged, in front of FinalizeAggregationOperator (a pipeline breaker after

@@ -122,20 +122,25 @@ void PackNullBits(const std::vector<const std::uint64_t *> &bitmaps, const std::
 // (not in the anonymous namespace: PartitionExchangeOperator names it as a friend)
 class PartitionExchangeWorkOrder : public WorkOrder {
  public:
-  PartitionExchangeWorkOrder(std::size_t query_id, PartitionExchangeOperator *op, std::vector<std::vector<block_id>> &&blocks,
+  // more_to_come: this rank's input is not complete yet — another work order of the operator follows (see
+  // PartitionExchangeOperator::getAllWorkOrders); the flag travels with the round's first counts exchange, and the round in which
+  // no rank has more to come is the operator's last on every rank.
+  PartitionExchangeWorkOrder(std::size_t query_id, PartitionExchangeOperator *op, std::vector<std::vector<block_id>> &&blocks, bool more_to_come,
                              InsertDestination *dest, StorageManager *storage_manager)
-      : WorkOrder(query_id), op_(op), blocks_(std::move(blocks)), dest_(dest), storage_manager_(storage_manager) {}
+      : WorkOrder(query_id), op_(op), blocks_(std::move(blocks)), more_to_come_(more_to_come), dest_(dest), storage_manager_(storage_manager) {}
 
   void execute() override {
     try {
       if (op_->broadcast_) {
         broadcastAll();
-        return;
+      } else {
+        const std::size_t world = static_cast<std::size_t>(op_->ranks_->world());
+        const std::size_t parts = blocks_.size();
+        for (std::size_t first = 0; first < parts; first += world) exchangeRound(first);
       }
-      const std::size_t world = static_cast<std::size_t>(op_->ranks_->world());
-      const std::size_t parts = blocks_.size();
-      for (std::size_t first = 0; first < parts; first += world) exchangeRound(first);
+      op_->roundFinished(!any_rank_has_more_);
     } catch (...) {
+      op_->roundFinished(true);   // (the query is over: the Foreman rethrows)
       // A failure every rank agreed on (RankGroup::agreeOn) is thrown by all of them between collectives: nothing is in
       // flight.  Anything else happened on this rank alone while a step's collectives were being issued — the peers are
       // inside them, or about to be: the communicator is given up so that they end with QSX_ERR_COMM instead of waiting.
@@ -173,7 +178,7 @@ class PartitionExchangeWorkOrder : public WorkOrder {
       }
     }, "PartitionExchangeOperator: a rank could not collect its blocks");
     in_collectives_ = true;
-    const std::vector<std::int64_t> recv_rows = exchangeCounts(send_rows);
+    const std::vector<std::int64_t> recv_rows = exchangeCounts(send_rows, /*with_flag=*/first == 0);
     in_collectives_ = false;
     const std::int64_t total_send = Sum(send_rows), total_recv = Sum(recv_rows);
     block_id out_id = 0;
@@ -202,19 +207,37 @@ class PartitionExchangeWorkOrder : public WorkOrder {
       }
     }, "PartitionExchangeOperator: a rank could not prepare its side of the exchange");
     in_collectives_ = true;
+    // This rank's own partition needs no transport: its tuples are copied from their blocks straight to the END of the output
+    // block (behind what the peers sent, in rank order), and only the pieces bound for other ranks are staged and exchanged —
+    // one copy of 1 / world of the relation instead of a staging copy and a trip through the transport.  (With a nullable
+    // attribute everything takes the transport, in rank order: the null bits of a block are packed per source rank.)
+    bool any_nullable = false;
+    for (std::size_t a = 0; a < relation.size(); ++a) any_nullable = any_nullable || relation.getAttributeType(static_cast<attribute_id>(a)).nullable;
+    const bool self_direct = !any_nullable;
+    std::vector<std::int64_t> wire_send = send_rows, wire_recv = recv_rows;
+    if (self_direct) wire_send[me] = wire_recv[me] = 0;
     for (std::size_t a = 0; a < relation.size(); ++a) {
       const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
       // values: the pieces back to back in rank order -> all-to-all(v) straight into the output block's stripe
       std::int64_t at = 0;
-      for (const Piece &piece : pieces) {
-        for (const BlockReference &b : piece.blocks) {
+      for (std::size_t r = 0; r < world; ++r) {
+        if (self_direct && r == me) continue;
+        for (const BlockReference &b : pieces[r].blocks) {
           CheckStatus(qsx_copy_on_device(static_cast<char *>(send[a]->ptr) + at * t.width, b->stripe(static_cast<attribute_id>(a)),
                                          static_cast<std::size_t>(b->numTuples()) * t.width, CurrentStream()), "qsx_copy_on_device");
           at += b->numTuples();
         }
       }
-      CheckStatus(qsx_alltoallv(ranks->comm(), t.width, send[a]->ptr, send_rows.data(), out != nullptr ? out->stripe(static_cast<attribute_id>(a)) : nullptr,
-                                recv_rows.data(), CurrentStream()), "qsx_alltoallv");
+      CheckStatus(qsx_alltoallv(ranks->comm(), t.width, send[a]->ptr, wire_send.data(), out != nullptr ? out->stripe(static_cast<attribute_id>(a)) : nullptr,
+                                wire_recv.data(), CurrentStream()), "qsx_alltoallv");
+      if (self_direct && out != nullptr) {
+        std::int64_t to = total_recv - recv_rows[me];
+        for (const BlockReference &b : pieces[me].blocks) {
+          CheckStatus(qsx_copy_on_device(static_cast<char *>(out->stripe(static_cast<attribute_id>(a))) + to * t.width, b->stripe(static_cast<attribute_id>(a)),
+                                         static_cast<std::size_t>(b->numTuples()) * t.width, CurrentStream()), "qsx_copy_on_device");
+          to += b->numTuples();
+        }
+      }
       op_->bytes_sent_ += static_cast<std::uint64_t>(total_send - send_rows[me]) * t.width;
       if (t.nullable) {
         // null bits: one word-aligned bitmap per (this rank, destination) and per (source, this rank)
@@ -262,7 +285,7 @@ class PartitionExchangeWorkOrder : public WorkOrder {
       }
     }, "PartitionExchangeOperator: a rank could not collect its blocks");
     in_collectives_ = true;
-    const std::vector<std::int64_t> rows = exchangeCounts(std::vector<std::int64_t>(world, mine.rows));   // rows[r] = rank r's tuples
+    const std::vector<std::int64_t> rows = exchangeCounts(std::vector<std::int64_t>(world, mine.rows), /*with_flag=*/true);   // rows[r] = rank r's tuples
     in_collectives_ = false;
     const std::int64_t total = Sum(rows);
     if (total == 0) return;
@@ -326,21 +349,35 @@ class PartitionExchangeWorkOrder : public WorkOrder {
     dest_->returnBlock(out_id, total, 0);
   }
 
-  std::vector<std::int64_t> exchangeCounts(const std::vector<std::int64_t> &send) {
+  // with_flag: bit 62 of every count this rank sends says "more tuples of mine will follow in a later round"; what arrives tells
+  // the same of every peer (any_rank_has_more_).
+  std::vector<std::int64_t> exchangeCounts(const std::vector<std::int64_t> &send, bool with_flag) {
+    constexpr std::int64_t kMoreBit = std::int64_t(1) << 62;
     const std::size_t world = send.size();
+    std::vector<std::int64_t> tagged = send;
+    if (with_flag && more_to_come_) {
+      for (std::int64_t &v : tagged) v |= kMoreBit;
+    }
     DeviceBuffer send_dev(world * 8 + 8), recv_dev(world * 8 + 8);
-    CheckStatus(qsx_copy_to_device(send_dev.ptr, send.data(), world * 8, CurrentStream()), "qsx_copy_to_device");
+    CheckStatus(qsx_copy_to_device(send_dev.ptr, tagged.data(), world * 8, CurrentStream()), "qsx_copy_to_device");
     CheckStatus(qsx_exchange_counts(op_->ranks_->comm(), static_cast<const std::int64_t *>(send_dev.ptr), static_cast<std::int64_t *>(recv_dev.ptr),
                                     CurrentStream()), "qsx_exchange_counts");
     std::vector<std::int64_t> recv(world);
     CheckStatus(qsx_copy_to_host(recv.data(), recv_dev.ptr, world * 8, CurrentStream()), "qsx_copy_to_host");
     op_->ranks_->synchronize();
+    for (std::int64_t &v : recv) {
+      if (with_flag && (v & kMoreBit) != 0) any_rank_has_more_ = true;
+      v &= ~kMoreBit;
+    }
+    if (with_flag && more_to_come_) any_rank_has_more_ = true;
     return recv;
   }
 
   PartitionExchangeOperator *op_;
   bool in_collectives_ = false;                 // a failure now is this rank's alone: execute() aborts the communicator
-  std::vector<std::vector<block_id>> blocks_;   // per partition (broadcast: all in [0])
+  std::vector<std::vector<block_id>> blocks_;   // per partition (broadcast: all in [0]): what arrived since the last round
+  const bool more_to_come_;
+  bool any_rank_has_more_ = false;
   InsertDestination *dest_;
   StorageManager *storage_manager_;
 };
@@ -352,6 +389,7 @@ PartitionExchangeOperator::PartitionExchangeOperator(std::size_t query_id, const
       input_relation_is_stored_(input_relation_is_stored), output_relation_(output_relation),
       output_destination_index_(output_destination_index), ranks_(ranks), broadcast_(broadcast),
       input_(broadcast ? 1 : input_relation.getNumPartitions()) {
+  consumed_.assign(input_.ids.size(), 0);
   if (ranks == nullptr) throw ExecutionError("PartitionExchangeOperator: no RankGroup", QSX_ERR_INVALID_ARGUMENT);
   if (input_relation.size() != output_relation.size()) {
     throw ExecutionError("PartitionExchangeOperator: input and output relation differ in their attributes", QSX_ERR_INVALID_ARGUMENT);
@@ -380,18 +418,43 @@ PartitionExchangeOperator::PartitionExchangeOperator(std::size_t query_id, const
   }
 }
 
+// Rounds.  The reference's consumers take a producer's blocks as they are filled (streaming edges, kDataPipelineMessage); an
+// exchange that waited for its whole local input would be a pipeline breaker and hold the whole shuffled relation at once.  So
+// the operator issues ONE work order at a time, each over the blocks that have arrived since the last one: a round of
+// collectives (counts, then the attributes).  Every rank runs the same number of rounds: the counts carry "more of mine will
+// follow", and the round in which no rank says so is the last everywhere; a rank that has nothing new while a peer still has
+// takes part with empty pieces.  (A rank waits for new blocks — or the end of its input — before it issues its next round; its
+// peers wait for it inside theirs.)
 bool PartitionExchangeOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryContext *query_context, StorageManager *storage_manager,
                                                  const tmb::client_id, tmb::MessageBus *) {
   std::lock_guard<std::mutex> lock(mutex_);
-  if (work_generated_) return true;
-  if (!input_relation_is_stored_ && !done_feeding_input_relation_) return false;   // a collective needs the whole local input
+  if (finished_) return true;
+  if (round_in_flight_) return false;
+  const bool input_done = input_relation_is_stored_ || done_feeding_input_relation_;
+  std::vector<std::vector<block_id>> fresh(input_.ids.size());
+  std::size_t fresh_blocks = 0;
+  for (std::size_t p = 0; p < input_.ids.size(); ++p) {
+    fresh[p].assign(input_.ids[p].begin() + static_cast<std::ptrdiff_t>(consumed_.at(p)), input_.ids[p].end());
+    fresh_blocks += fresh[p].size();
+  }
+  // (a round that must not end the operator needs something to carry — except when the peers are waiting for this rank's part in
+  // a round of theirs: rounds_ > 0 and the last one did not end it)
+  if (!input_done && fresh_blocks == 0) return false;
   InsertDestination *dest = query_context->getInsertDestination(output_destination_index_);
   if (dest->isPartitionAware()) {
     throw ExecutionError("PartitionExchangeOperator: the output destination must not repartition (the tuples arrive partitioned)", QSX_ERR_INVALID_ARGUMENT);
   }
-  container->addNormalWorkOrder(new PartitionExchangeWorkOrder(query_id_, this, std::vector<std::vector<block_id>>(input_.ids), dest, storage_manager), op_index_);
-  work_generated_ = true;
-  return true;
+  for (std::size_t p = 0; p < input_.ids.size(); ++p) consumed_[p] = input_.ids[p].size();
+  container->addNormalWorkOrder(new PartitionExchangeWorkOrder(query_id_, this, std::move(fresh), /*more_to_come=*/!input_done, dest, storage_manager), op_index_);
+  round_in_flight_ = true;
+  ++rounds_;
+  return false;      // (finished only when a round has ended it: roundFinished)
+}
+
+void PartitionExchangeOperator::roundFinished(bool last) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  round_in_flight_ = false;
+  if (last) finished_ = true;
 }
 
 namespace {

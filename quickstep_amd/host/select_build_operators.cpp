@@ -85,7 +85,10 @@ void SelectWorkOrder::execute() {
 // — what consecutive SelectWorkOrders do to an InsertDestination's current block (InsertDestination.cpp:222-260).
 bool SelectWorkOrder::executeRun() {
   const bool has_terms = predicate_ != nullptr && !predicate_->conjuncts.empty();
-  if (!has_terms && lip_filter_adaptive_prober_ == nullptr) return false;   // a plain copy: block by block
+  // (no predicate and no filter: a projection of every tuple — the repartitioning Select in front of a partitioned join,
+  // ExecutionGenerator's build / probe side "needs repartition" — takes the run form too: one compaction under all-ones
+  // TupleIdSequences instead of a block allocation, a copy and a wait per 4 MB block)
+  const bool plain_copy = !has_terms && lip_filter_adaptive_prober_ == nullptr;
   static const Predicate no_terms;
   const Predicate &predicate = has_terms ? *predicate_ : no_terms;
   std::vector<attribute_id> selection;
@@ -130,6 +133,36 @@ bool SelectWorkOrder::executeRun() {
   if (has_terms) RunPredicateMatches(predicate, blocks, rows, lip_bitmaps.empty() ? nullptr : lip_bitmaps.data(), &run_matches);
   std::int64_t matches = lip_hits;
   const std::uint64_t *const *selected = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();   // only LIP filters: their bitmaps
+  // every tuple: one all-ones TupleIdSequence per distinct block size of the run (a relation's blocks hold the same number of
+  // tuples but the last), trailing bits zero
+  std::vector<std::unique_ptr<DeviceBuffer>> ones_storage;
+  std::vector<const std::uint64_t *> ones_of_block;
+  if (plain_copy) {
+    std::vector<std::pair<std::int64_t, const std::uint64_t *>> made;
+    for (std::size_t b = 0; b < nb; ++b) {
+      const std::uint64_t *bits = nullptr;
+      for (const auto &m : made) if (m.first == rows[b]) bits = m.second;
+      if (bits == nullptr && rows[b] > 0) {
+        const std::size_t words = static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
+        ones_storage.emplace_back(new DeviceBuffer(words * 8));
+        DeviceBuffer zero(words * 8);
+        CheckStatus(qsx_memset_device(zero.ptr, 0, words * 8, CurrentStream()), "qsx_memset_device");
+        CheckStatus(qsx_bitmap_combine(3, static_cast<const std::uint64_t *>(zero.ptr), nullptr, rows[b], static_cast<std::uint64_t *>(ones_storage.back()->ptr),
+                                       CurrentStream()), "qsx_bitmap_combine");
+        CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // (zero goes out of scope)
+        bits = static_cast<const std::uint64_t *>(ones_storage.back()->ptr);
+        made.emplace_back(rows[b], bits);
+      }
+      ones_of_block.push_back(bits != nullptr ? bits : static_cast<const std::uint64_t *>(nullptr));
+    }
+    // (an empty block of the run needs a non-null pointer: any of the others', or a word of its own)
+    const std::uint64_t *any = nullptr;
+    for (const std::uint64_t *p : ones_of_block) if (p != nullptr) any = p;
+    if (any == nullptr) return false;
+    for (const std::uint64_t *&p : ones_of_block) if (p == nullptr) p = any;
+    selected = ones_of_block.data();
+    matches = total_rows;
+  }
   if (has_terms) {
     std::vector<std::int64_t> block_matches(nb);
     CheckStatus(qsx_copy_to_host(block_matches.data(), run_matches.counts->ptr, nb * 8, CurrentStream()), "qsx_copy_to_host");

@@ -59,8 +59,9 @@ std::vector<Row> readRows(const std::vector<block_id> &blocks, StorageManager &s
   return out;
 }
 
+// limit_runs: the LIMIT is handed to the run generation too (SortRunGenerationOperator::setTopK): runs of at most top_k tuples
 void runCase(const std::vector<Row> &rows, const std::vector<attribute_id> &order_by, const std::vector<bool> &ordering,
-             std::size_t top_k, bool use_foreman) {
+             std::size_t top_k, bool use_foreman, bool limit_runs = false) {
   CatalogRelation input(1, "input"), runs(2, "runs"), output(3, "output");
   StorageManager storage;
   for (CatalogRelation *r : {&input, &runs, &output}) {
@@ -79,6 +80,7 @@ void runCase(const std::vector<Row> &rows, const std::vector<attribute_id> &orde
   const auto run_dest = ctx.addInsertDestination(&runs, &storage);
   const auto out_dest = ctx.addInsertDestination(&output, &storage);
   auto *generate = new SortRunGenerationOperator(0, input, runs, run_dest, config, true);
+  if (limit_runs) generate->setTopK(top_k);
   auto *merge = new SortMergeRunOperator(0, runs, output, out_dest, runs, run_dest, config, /*merge_factor=*/4, top_k, false);
   std::unique_ptr<RelationalOperator> g, m;
   if (use_foreman) {
@@ -98,8 +100,11 @@ void runCase(const std::vector<Row> &rows, const std::vector<attribute_id> &orde
   // every run is sorted (SortRunGenerationOperator_unittest: checkOutput per block)
   std::vector<std::size_t> run_sizes;
   const std::vector<Row> run_rows = readRows(ctx.getInsertDestination(run_dest)->getTouchedBlocks(), storage, &run_sizes);
-  EXPECT_EQ(run_rows.size(), static_cast<std::size_t>(kRows));
+  if (!limit_runs || top_k == 0) EXPECT_EQ(run_rows.size(), static_cast<std::size_t>(kRows));
   EXPECT_EQ(run_sizes.size(), static_cast<std::size_t>((kRows + kBlockRows - 1) / kBlockRows));
+  if (limit_runs && top_k != 0) {
+    for (std::size_t sz : run_sizes) EXPECT_TRUE(sz <= top_k);
+  }
   std::size_t at = 0;
   for (std::size_t sz : run_sizes) {
     for (std::size_t i = at + 1; i < at + sz; ++i) EXPECT_TRUE(!Before(run_rows[i], run_rows[i - 1], order_by, ordering));
@@ -141,6 +146,8 @@ int main() {
       runCase(rows, {2, 0, 1}, {true, true, true}, top_k, use_foreman);        // 3Column_NonNull_Asc[_TopK]
       runCase(rows, {2, 1, 0}, {false, false, false}, top_k, use_foreman);     // 3Column_NonNull_Desc[_TopK]
       runCase(rows, {0, 2, 1}, {true, false, true}, top_k, use_foreman);       // mixed ordering (:754-800 without NULLs)
+      runCase(rows, {1}, {false}, top_k, use_foreman, /*limit_runs=*/true);    // ORDER BY b DESC LIMIT k with the limit in the runs
+      runCase(rows, {2, 0, 1}, {true, false, true}, top_k, use_foreman, true);
     }
   }
   // ---- predicates on the sort column of a sorted block: binary search (qsx_select_cmp_sorted) == scan ----------------
