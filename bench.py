@@ -1048,6 +1048,55 @@ def secondary_join_small_build(ctx, args, threads):
     return out_line
 
 
+def secondary_c1_select(ctx, args, threads):
+    """BASELINE config 1: SelectOperator over a 10 M-row INTEGER column, predicate col < K.  The reference's own CPU-runnable case is
+    the headline there (rows/s through the CPU WorkOrder path: quickstep_amd/host's on_gpu = false work orders under Foreman + Workers,
+    tests/cpp/select_cpu_workorder_test — plumbing, no GPU); beside it the same selects on the device: K1 (bitmap) + K2 (compaction)
+    through the C ABI on the same column shape, algorithmic bytes 4 N read + 4 sigma N written."""
+    import re
+    import subprocess
+    dev, n = ctx.dev, 10_000_000
+    out = {"workload": f"C1 SelectOperator: {n}-row INTEGER column, predicate col < K at selectivities 0.01 / 0.1 / 0.5"}
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "select_cpu_workorder_test")
+    workers = min(threads, 16)
+    cpu = {}
+    if os.path.exists(exe):
+        r = subprocess.run([exe, str(n), str(workers)], capture_output=True, text=True, timeout=600)
+        for m in re.finditer(r"select col < (\d+): \d+ rows, (\d+) selected, \d+ workers, ([0-9.]+) ms", r.stdout):
+            cpu[round(int(m.group(2)) / n, 2)] = {"ms": float(m.group(3)), "rows_per_s": n / float(m.group(3)) * 1e3, "selected": int(m.group(2))}
+        out["cpu_workorder_path"] = {"workers": workers, "checked": r.returncode == 0 and "[  PASSED  ]" in r.stdout, "by_selectivity": cpu,
+                                     "what": "SelectWorkOrder::executeOnHost over 1 Mi-row blocks under ForemanSingleNode + Workers (BASELINE.md C1: plumbing, no GPU)"}
+    else:
+        out["cpu_workorder_path"] = {"error": "tests/cpp/bin/select_cpu_workorder_test is not built"}
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    col = torch.randint(0, 2**31 - 1, (n,), device=dev, generator=g, dtype=torch.int32)
+    gpu = {}
+    checked = True
+    for sel in (0.01, 0.1, 0.5):
+        k = int(sel * (2**31 - 1))
+
+        def one():
+            bm, _ = capi.select_cmp(col, T.LT, k)
+            return capi.compact_gather([col], bm, n)
+        ms = launches_ms(one)
+        (vals,), cnt = one()
+        c = int(cnt.item())
+        if not args.no_check:
+            want = col[col < k]
+            checked = checked and c == want.numel() and bool((vals[:c] == want).all())
+        gpu[sel] = {"ms": ms, "rows_per_s": n / ms * 1e3, "selected": c,
+                    "roofline": hbm_roofline("select_cmp_kernel + compact_gather kernels (qsx_select_cmp, qsx_compact_gather)", 4 * n + 4 * c, ms,
+                                             algorithmic_bytes="4 N + 4 sigma N")}
+    out.update({"gpu_k1_k2": gpu, "ms": gpu[0.1]["ms"], "roofline": gpu[0.1]["roofline"], "checked": checked and out["cpu_workorder_path"].get("checked", False),
+                "note": "10 M rows are 40 MB: three launches of a few microseconds each; the rate is launch-bound at this size, the kernels' own "
+                        "rates at 100 M rows are in profiles/r05_bench_ops.jsonl"})
+    if cpu:
+        out["cpu_baseline"] = {"value": cpu.get(0.1, next(iter(cpu.values())))["rows_per_s"], "unit": "rows/s", "cores": workers, "kind": "port",
+                               "sample": f"the whole configuration: {n} rows through the CPU SelectWorkOrder path, selectivity 0.1"}
+    return out
+
+
 def condensed(line):
     """What a partitioned configuration's own line (--config c4 | c5) contributes to `secondary`."""
     return {"workload": line["config"]["workload"], "ms": line["ms_per_step"], "rows_per_s": line["value"],
@@ -1159,7 +1208,8 @@ def secondary_block(ctx, args):
     t_start = time.perf_counter()
     threads = usable_cores()
     out = {}
-    legs = [("q1_coded", secondary_q1_coded), ("c3_minimal", secondary_c3_minimal), ("join_small_build", secondary_join_small_build)]
+    legs = [("c1_select", secondary_c1_select), ("q1_coded", secondary_q1_coded), ("c3_minimal", secondary_c3_minimal),
+            ("join_small_build", secondary_join_small_build)]
     for name, fn in legs:
         t0 = time.perf_counter()
         try:

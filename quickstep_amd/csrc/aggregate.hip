@@ -35,6 +35,7 @@
 #include "agg_hash_update.hpp"
 #include "agg_factored.hpp"
 #include "agg_shapes.hpp"
+#include "agg_family.hpp"
 #include "agg_jit.hpp"
 #include "comm.hpp"
 #include "partition.hpp"
@@ -684,6 +685,11 @@ struct qsx_agg_state {
   int part_slots = 64;
   unsigned used_columns = 0;
   const struct ShapeEntry *shape = nullptr;  // AOT plan shape matching this configuration, if any
+  // ... or the member of the AOT family (agg_family.hpp) whose canonical configuration is this plan up to the numbering of its
+  // columns: family_cols[c] = the state's column behind canonical column c
+  const FamilyEntry *family = nullptr;
+  int family_num_columns = 0;
+  int family_cols[QSX_MAX_COLUMNS] = {};
   // Run-time plan shapes (agg_jit.hpp), one per filter variant; compiled once the state has seen enough
   // rows to pay for the 1-2 s of hipRTC.
   std::mutex jit_mutex;
@@ -1282,6 +1288,51 @@ static int launch_shape(const void *const *cols, int num_columns, int64_t n, con
   return launch_shape_v<Shape, 2>(cols, num_columns, n, g, S, ranges, pieces, stream, runs);
 }
 
+// The numbers launch_shape_v derives, for the family's launchers (agg_family_part.hip).
+int qsx::shape_launch_geometry(int NS, int S, int tile_bytes, ShapeGeometry *out) {
+  const AggTuning &tune = agg_tuning();
+  out->nbuf = tune.buffers == 0 ? 1 : tune.buffers;
+  out->rep_shift = choose_replication(NS, S, static_cast<size_t>(out->nbuf) * tile_bytes, tune, &out->lds);
+  constexpr size_t kMaxLds = 160 * 1024;
+  if (out->lds > kMaxLds) return QSX_ERR_CAPACITY;
+  int per_cu = static_cast<int>(kMaxLds / ((out->lds + 1023) / 1024 * 1024));   // LDS is granted in 1 KiB steps
+  if (per_cu > tune.max_blocks_per_cu) per_cu = tune.max_blocks_per_cu;
+  out->per_cu = per_cu < 1 ? 1 : per_cu;
+  return QSX_OK;
+}
+
+// The family member that serves this state's plan (agg_family.hpp), with the state's column behind every canonical column; nullptr:
+// the plan is not of the family.  Decided on the TRANSLATED plan: what the kernel body sees.
+static const FamilyEntry *find_family(const qsx_agg_config_t &c, const DevConfig &d, int num_sums, int *num_columns, int *cols) {
+  if (getenv("QSX_AGG_NO_SPECIALIZE") != nullptr && atoi(getenv("QSX_AGG_NO_SPECIALIZE")) != 0) return nullptr;
+  if (getenv("QSX_AGG_FAMILY") != nullptr && atoi(getenv("QSX_AGG_FAMILY")) == 0) return nullptr;
+  if (c.strategy != QSX_AGG_COMPACT_KEY && c.strategy != QSX_AGG_GENERIC) return nullptr;
+  if (d.num_keys < 1 || d.num_keys > 2 || d.wide_words != 0 || d.num_instrs != 0 || d.num_pred != 0 || d.num_null_cols != 0) return nullptr;
+  if (num_sums < 1 || num_sums > kFamilyMaxSums) return nullptr;
+  int kt[2] = {0, 0}, n = 0;
+  for (int k = 0; k < d.num_keys; ++k) {
+    const int col = d.key_column[k], type = d.column_type[col];
+    if (d.code_width[col] != 0 || c.column_nullable[col] != 0) return nullptr;
+    if (!((type == QSX_CHAR && d.column_width[col] == 1) || type == QSX_INT || type == QSX_LONG)) return nullptr;
+    kt[k] = d.column_width[col];
+    cols[n++] = col;
+  }
+  for (int j = 0; j < num_sums; ++j) {
+    const DevSum &sum = d.sums[j];
+    if (sum.kind != kAccSumF64 || sum.count_valid != 0 || sum.null_mask != 0 || sum.is_int != 0 || sum.arg.kind != QSX_OPD_COLUMN) return nullptr;
+    const int col = sum.arg.index;
+    if (d.column_type[col] != QSX_DOUBLE || d.code_width[col] != 0 || c.column_nullable[col] != 0) return nullptr;
+    cols[n++] = col;
+  }
+  const FamilyEntry *e = find_family_entry(kt[0], kt[1], num_sums);
+  if (e != nullptr) *num_columns = n;
+  return e;
+}
+
+static std::atomic<long long> g_family_launches{0};
+// Test hook (not part of include/qsx.h): update calls this process has issued through a kernel of the AOT family.
+extern "C" long long qsx_debug_agg_family_launches(void) { return g_family_launches.load(std::memory_order_relaxed); }
+
 static const ShapeEntry *find_shape(const qsx_agg_config_t &c) {
   static const ShapeEntry table[] = {
       {"tpch_q1", ShapeTpchQ1::config(), &launch_shape<ShapeTpchQ1>, &launch_shape_dir<ShapeTpchQ1>},
@@ -1878,6 +1929,7 @@ int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) 
   int rc = translate_config(*config, st);
   if (rc != QSX_OK) { delete st; return rc; }
   if (!st->dense) st->shape = find_shape(*config);
+  if (!st->dense && st->shape == nullptr) st->family = find_family(*config, st->dev, st->num_sums, &st->family_num_columns, st->family_cols);
   if (st->dense) {
     st->exist_words = (config->num_entries + 63) / 64;
     st->image_bytes = sizeof(unsigned long long) * (st->exist_words + static_cast<size_t>(st->num_cols) * config->num_entries);
@@ -2037,10 +2089,12 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
     dc.nulls[sl] = nulls != nullptr ? reinterpret_cast<const unsigned long long *>(nulls[dc.null_column[sl]]) : nullptr;
   }
   const bool aot = !st->dense && st->shape != nullptr && filter_dev == nullptr && dc.num_null_cols == 0;
+  // (the family's kernels take one stripe per column, in canonical order: no run of blocks, whose table is numbered like the state)
+  const bool family = !aot && !st->dense && st->family != nullptr && filter_dev == nullptr && dc.num_null_cols == 0 && !runs;
   int variant = 0;
   // (states over nullable columns: the run-time shapes take the null bitmaps of a call behind a pointer — a run of blocks
   // has one set per block, which the run table does not carry: those stay with the interpreter, block by block)
-  const JitKernel *jk = (aot || (dc.num_null_cols != 0 && runs))
+  const JitKernel *jk = (aot || family || (dc.num_null_cols != 0 && runs))
                             ? nullptr
                             : state_jit_kernel(st, filter_dev != nullptr, partitioned, slots, ranges, n, &variant, false, runs);
   if (jk != nullptr) {
@@ -2060,6 +2114,11 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
     int rc = QSX_OK;
     if (aot) {
       rc = st->shape->launch(cols, st->config.num_columns, n, g, slots, ranges, pieces, s, runs);
+    } else if (family) {
+      const void *canonical[QSX_MAX_COLUMNS] = {};
+      for (int i = 0; i < st->family_num_columns; ++i) canonical[i] = cols[st->family_cols[i]];
+      rc = st->family->launch(canonical, st->family_num_columns, n, g, slots, ranges, pieces, s);
+      if (rc == QSX_OK) g_family_launches.fetch_add(1, std::memory_order_relaxed);
     } else {
       QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, slots, ranges, pieces, s, runs);
     }

@@ -420,6 +420,96 @@ def test_plan_shape_and_interpreter_agree(capi, oracle, dev):
         assert_same_groups(results[0], results[1])
 
 
+def _family_launches(capi):
+    import ctypes
+    capi.lib.qsx_debug_agg_family_launches.restype = ctypes.c_longlong
+    return capi.lib.qsx_debug_agg_family_launches()
+
+
+FAMILY_KEYS = {"char": (T.CHAR, 1, np.uint8), "int": (T.INT, None, np.int32), "long": (T.LONG, None, np.int64)}
+
+
+@pytest.mark.parametrize("keys", [("char",), ("int",), ("long",), ("char", "char"), ("char", "int"), ("int", "char"), ("int", "int")])
+@pytest.mark.parametrize("num_sums", [1, 3, 6])
+@pytest.mark.parametrize("strategy", [T.AGG_COMPACT_KEY, T.AGG_GENERIC])
+def test_plans_of_the_aot_family_never_meet_the_interpreter(capi, oracle, dev, keys, num_sums, strategy, monkeypatch):
+    """csrc/agg_family.hpp: a GROUP BY of one or two CHAR(1) / INT / LONG keys (packed into 8 bytes) with one to six SUM / AVG over plain
+    DOUBLE columns and COUNT(*) — whatever the order of its columns and aggregates — is served by an ahead-of-time kernel of the
+    family on its FIRST update, in a process that may not compile anything (QSX_AGG_JIT=0) and holds no recording of the plan:
+    the reference's update loop is one template instantiation whatever the plan (storage/AggregationOperationState.cpp:428-474).
+    The plans here put their summed columns IN FRONT of the keys, interleave an unused column, repeat a column under SUM and
+    AVG and ask for COUNT(*) twice; results against the oracle, and against the interpreter (QSX_AGG_FAMILY=0)."""
+    if strategy == T.AGG_GENERIC and "char" in keys:
+        pytest.skip("CHAR group-by keys under the GENERIC strategy are out of scope (DESIGN.md §8)")
+    monkeypatch.setenv("QSX_AGG_JIT", "0")
+    rng = np.random.default_rng(910 + num_sums + len(keys))
+    n = 300_007
+    columns, cols, key_idx = [], [], []
+    value_idx = []
+    for j in range(num_sums):                      # the DOUBLE columns first
+        columns.append((T.DOUBLE, None))
+        cols.append(rng.normal(size=n) * (j + 1))
+        value_idx.append(len(columns) - 1)
+    columns.append((T.INT, None))                 # a column the plan never reads
+    cols.append(rng.integers(0, 9, size=n).astype(np.int32))
+    for k in keys[::-1]:                           # the keys last, in reverse
+        ty, width, dtype = FAMILY_KEYS[k]
+        columns.append((ty, width))
+        if k == "char":
+            cols.append(rng.choice(np.frombuffer(b"ABCDEFG", dtype=np.uint8), size=n))
+        elif k == "int":
+            cols.append(rng.integers(-40, 40, size=n).astype(np.int32))
+        else:
+            cols.append((rng.integers(-20, 20, size=n) * 1_000_000_007).astype(np.int64))
+        key_idx.insert(0, len(columns) - 1)
+    aggs = [(T.AGG_COUNT_STAR, None)]
+    for j in reversed(range(num_sums)):            # accumulators in an order of their own
+        aggs.append((T.AGG_SUM if j % 2 == 0 else T.AGG_AVG, T.col(value_idx[j])))
+    aggs.append((T.AGG_AVG, T.col(value_idx[0])))  # the same column again: one accumulator (ReuseAggregateExpressions)
+    aggs.append((T.AGG_COUNT_STAR, None))
+    if len(aggs) > 8:
+        aggs = aggs[:8]
+    cfg = T.make_agg_config(strategy, columns, keys=key_idx, aggs=aggs, est_groups=64)
+    before = _family_launches(capi)
+    st = run_hip(capi, dev, cfg, cols, blocks=2)
+    assert _family_launches(capi) == before + 2, "the plan did not reach a kernel of the family"
+    got = finalize_np(st, dev)
+    o = oracle.AggState(cfg)
+    o.update(cols, n)
+    assert_same_groups(got, o.finalize())
+    monkeypatch.setenv("QSX_AGG_FAMILY", "0")     # (read at state creation)
+    st2 = run_hip(capi, dev, cfg, cols, blocks=2)
+    assert _family_launches(capi) == before + 2
+    assert_same_groups(finalize_np(st2, dev), got)
+
+
+def test_plans_outside_the_aot_family_keep_their_kernels(capi, oracle, dev, monkeypatch):
+    """An expression under an aggregate, an INT sum, a predicate inside the state, three keys: not of the family (agg_family.hpp)."""
+    monkeypatch.setenv("QSX_AGG_JIT", "0")
+    rng = np.random.default_rng(5)
+    n = 100_000
+    k = rng.integers(0, 30, size=n).astype(np.int32)
+    x, y = rng.normal(size=n), rng.normal(size=n)
+    z = rng.integers(0, 100, size=n).astype(np.int32)
+    plans = [
+        T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)], keys=[0],
+                          instrs=[(T.EX_MUL, 0, T.col(1), T.col(2))], aggs=[(T.AGG_SUM, T.temp(0))], est_groups=64),
+        T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)], keys=[0],
+                          aggs=[(T.AGG_SUM, T.col(3)), (T.AGG_SUM, T.col(1))], est_groups=64),
+        T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)], keys=[0],
+                          aggs=[(T.AGG_SUM, T.col(1))], pred=[(3, T.LT, 50)], est_groups=64),
+        T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)], keys=[0, 3],
+                          aggs=[(T.AGG_MIN, T.col(1))], est_groups=64),
+    ]
+    before = _family_launches(capi)
+    for cfg in plans:
+        st = run_hip(capi, dev, cfg, [k, x, y, z])
+        o = oracle.AggState(cfg)
+        o.update([k, x, y, z], n)
+        assert_same_groups(finalize_np(st, dev), o.finalize())
+    assert _family_launches(capi) == before
+
+
 # ---- MIN / MAX (AggregationHandleMin/Max; AggregationOperator_unittest.cpp:675-712, :1550-1680) -----------------
 @pytest.mark.parametrize("with_pred", [False, True])
 def test_golden_scalar_min_max(capi, dev, golden, with_pred):
