@@ -11,9 +11,12 @@
 // the keys as columns 0 .. K-1 and the summed columns behind them in accumulator order.  A state whose translated plan
 // (agg_translate.hpp) has that form is served by the member's kernel with its stripes handed over in canonical order — the state
 // image (key codes, accumulator columns) is the same either way, so finalize, merge and export do not know the difference.
-// 7 key signatures x 6 = 42 members, one translation unit per key signature (agg_family_part.hip, -DQSX_FAMILY_PART=n).
-// Not covered (they keep the run-time shapes / the interpreter): predicates inside the state, filter bitmaps, nullable or
-// compressed columns, expressions, INT / LONG sums, MIN / MAX, keys wider than 8 packed bytes, runs of blocks.
+// 7 key signatures x 6 = 42 members, each with and without a filter bitmap, over one stripe per column or a run of blocks (168
+// kernels), one translation unit per key signature (agg_family_part.hip, -DQSX_FAMILY_PART=n: ~20 s each).  A state's own
+// predicate (attribute OP literal terms on plain columns) becomes the call's filter by a K1 pass in front of the update
+// (one stripe per column; a run of blocks with a predicate keeps the other kernels).
+// Not covered (they keep the run-time shapes / the interpreter): nullable or compressed columns, expressions, INT / LONG sums,
+// MIN / MAX, keys wider than 8 packed bytes, the group directory's mid-size group counts.
 #ifndef QSX_CSRC_AGG_FAMILY_HPP_
 #define QSX_CSRC_AGG_FAMILY_HPP_
 
@@ -45,9 +48,11 @@ struct ShapeFamily : ShapeBase<ShapeFamily<KT0, KT1, NS>> {
   }
 };
 
-// Same signature as aggregate.hip's ShapeLauncher; cols in CANONICAL order.
-typedef int (*FamilyLauncher)(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S, int ranges,
-                              const long long *pieces, hipStream_t stream);
+// cols in CANONICAL order.  filter: the call's TupleIdSequence (nullptr: every row).  runs: the rows are a run of blocks —
+// `pieces` is its table (agg_common.hpp BlockRunView) with the stripes of every block in CANONICAL order, cols is not read, and
+// `filter` only says whether some block has a filter (the table carries them).
+typedef int (*FamilyLauncher)(const void *const *cols, int num_columns, int64_t n, const uint64_t *filter, const HashTableView &g, int S, int ranges,
+                              const long long *pieces, hipStream_t stream, bool runs);
 struct FamilyEntry {
   int kt0, kt1, ns;
   FamilyLauncher launch;

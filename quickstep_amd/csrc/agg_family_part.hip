@@ -1,8 +1,11 @@
 // agg_family_part.hip — one key signature of the ahead-of-time plan-shape family (agg_family.hpp), compiled once per part with
-// -DQSX_FAMILY_PART=0..6: six kernels (one to six DOUBLE sums) of agg_hash_shape_kernel over the canonical configuration.
+// -DQSX_FAMILY_PART=0..6: for one to six DOUBLE sums the update body over the canonical configuration — one stripe per column or a run
+// of blocks, with or without a filter bitmap: 24 kernels.
 // Part 0 also holds the lookup over all parts.
 #include "agg_family.hpp"
 #include "agg_hash_update.hpp"
+
+#include <type_traits>
 
 #ifndef QSX_FAMILY_PART
 #error "compile with -DQSX_FAMILY_PART=<0..6>"
@@ -14,37 +17,76 @@ namespace {
 constexpr int kPart = QSX_FAMILY_PART;
 constexpr int kKT0 = kFamilyKeySignatures[kPart][0], kKT1 = kFamilyKeySignatures[kPart][1];
 constexpr int kV = 4;   // rows per thread of a tile: what the registered shapes run with by default
+}  // namespace
 
+// The member's configuration planned with or without a filter word per 64 rows of the tile.
+template <typename Shape, bool kFilter>
+struct Planned {
+  static constexpr Translated get() {
+    Translated t = translate(Shape::config());
+    plan_tile(t.dev, t.used_columns, kABlock * kV, kFilter);
+    return t;
+  }
+};
+template <typename Shape, bool kFilter>
+__global__ __launch_bounds__(kABlock) void family_kernel(ColumnPointers cols, int64_t n, const uint64_t *__restrict__ filter, HashTableView g, int S,
+                                                        int rep_shift, int nbuf, int ranges, const long long *__restrict__ pieces) {
+  static constexpr Translated T = Planned<Shape, kFilter>::get();
+  agg_hash_update_body<true, false, T.num_sums, kV>(T.dev, cols.p, nullptr, n, kFilter ? filter : nullptr, g, DenseView{}, S, rep_shift, nbuf, ranges, pieces);
+}
+template <typename Shape, bool kFilter>
+__global__ __launch_bounds__(kABlock) void family_runs_kernel(int64_t n, HashTableView g, int S, int rep_shift, int nbuf, int ranges,
+                                                             const long long *__restrict__ block_run) {
+  static constexpr Translated T = Planned<Shape, kFilter>::get();
+  agg_hash_update_body<true, false, T.num_sums, kV, false, kABlock, false, true>(T.dev, nullptr, nullptr, n, nullptr, g, DenseView{}, S, rep_shift, nbuf, ranges,
+                                                                                  block_run);
+}
+
+namespace {
 template <int NS>
-int launch_member(const void *const *cols, int num_columns, int64_t n, const HashTableView &g, int S, int ranges, const long long *pieces,
-                  hipStream_t stream) {
+int launch_member(const void *const *cols, int num_columns, int64_t n, const uint64_t *filter, const HashTableView &g, int S, int ranges,
+                  const long long *pieces, hipStream_t stream, bool runs) {
   using Shape = ShapeFamily<kKT0, kKT1, NS>;
   constexpr int TR = kABlock * kV;
-  constexpr Translated T = Shape::translated(TR);
+  constexpr Translated T = Planned<Shape, false>::get(), TF = Planned<Shape, true>::get();
   static_assert(T.status == QSX_OK && T.num_sums == NS, "the canonical configuration translates to NS accumulators");
+  const bool filtered = filter != nullptr;
   ShapeGeometry geo{};
-  const int rc = shape_launch_geometry(NS, S, T.dev.tile_bytes, &geo);
+  const int rc = shape_launch_geometry(NS, S, filtered ? TF.dev.tile_bytes : T.dev.tile_bytes, &geo);
   if (rc != QSX_OK) return rc;
-  // (a property of (kernel, device); setting it again is a cheap host call)
-  QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_hash_shape_kernel<Shape, kV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int64_t num_tiles = (n + TR - 1) / TR;
   const int64_t max_grid = static_cast<int64_t>(kCUs) * geo.per_cu;
   int grid = static_cast<int>(num_tiles * ranges < max_grid ? num_tiles * ranges : max_grid);
   grid = grid / ranges * ranges;
   if (grid < ranges) grid = ranges;
   ColumnPointers cp;
-  for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = i < num_columns ? cols[i] : nullptr;
-  hipLaunchKernelGGL((agg_hash_shape_kernel<Shape, kV>), dim3(grid), dim3(kABlock), geo.lds, stream, cp, n, g, S, geo.rep_shift, geo.nbuf, ranges, pieces);
-  return QSX_OK;
+  for (int i = 0; i < QSX_MAX_COLUMNS; ++i) cp.p[i] = (!runs && i < num_columns) ? cols[i] : nullptr;
+  // (hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device); setting it again is a cheap host call)
+  auto go = [&](auto filt) -> int {
+    constexpr bool F = decltype(filt)::value;
+    if (runs) {
+      QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&family_runs_kernel<Shape, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL((family_runs_kernel<Shape, F>), dim3(grid), dim3(kABlock), geo.lds, stream, n, g, S, geo.rep_shift, geo.nbuf, ranges, pieces);
+    } else {
+      QSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&family_kernel<Shape, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL((family_kernel<Shape, F>), dim3(grid), dim3(kABlock), geo.lds, stream, cp, n, filter, g, S, geo.rep_shift, geo.nbuf, ranges, pieces);
+    }
+    return QSX_OK;
+  };
+  return filtered ? go(std::true_type{}) : go(std::false_type{});
 }
 }  // namespace
 
-// the six kernels, instantiated in BOTH compilation passes (the table below is host code: the device pass would not ask for them)
-#define QSX_FAMILY_KERNEL(NS)                                                                                                            \
-  template __global__ void agg_hash_shape_kernel<ShapeFamily<kKT0, kKT1, NS>, kV>(ColumnPointers, int64_t, HashTableView, int, int, int, int, \
-                                                                                  const long long *__restrict__);
-QSX_FAMILY_KERNEL(1) QSX_FAMILY_KERNEL(2) QSX_FAMILY_KERNEL(3) QSX_FAMILY_KERNEL(4) QSX_FAMILY_KERNEL(5) QSX_FAMILY_KERNEL(6)
-#undef QSX_FAMILY_KERNEL
+// the kernels, instantiated in BOTH compilation passes (the table below is host code: the device pass would not ask for them)
+#define QSX_FAMILY_KERNELS(NS)                                                                                                                       \
+  template __global__ void family_kernel<ShapeFamily<kKT0, kKT1, NS>, false>(ColumnPointers, int64_t, const uint64_t *__restrict__, HashTableView, int, int, \
+                                                                             int, int, const long long *__restrict__);                                     \
+  template __global__ void family_kernel<ShapeFamily<kKT0, kKT1, NS>, true>(ColumnPointers, int64_t, const uint64_t *__restrict__, HashTableView, int, int,  \
+                                                                            int, int, const long long *__restrict__);                                      \
+  template __global__ void family_runs_kernel<ShapeFamily<kKT0, kKT1, NS>, false>(int64_t, HashTableView, int, int, int, int, const long long *__restrict__); \
+  template __global__ void family_runs_kernel<ShapeFamily<kKT0, kKT1, NS>, true>(int64_t, HashTableView, int, int, int, int, const long long *__restrict__);
+QSX_FAMILY_KERNELS(1) QSX_FAMILY_KERNELS(2) QSX_FAMILY_KERNELS(3) QSX_FAMILY_KERNELS(4) QSX_FAMILY_KERNELS(5) QSX_FAMILY_KERNELS(6)
+#undef QSX_FAMILY_KERNELS
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 #define QSX_FAMILY_TABLE_NAME_(p) kFamilyPart##p

@@ -1307,7 +1307,12 @@ static const FamilyEntry *find_family(const qsx_agg_config_t &c, const DevConfig
   if (getenv("QSX_AGG_NO_SPECIALIZE") != nullptr && atoi(getenv("QSX_AGG_NO_SPECIALIZE")) != 0) return nullptr;
   if (getenv("QSX_AGG_FAMILY") != nullptr && atoi(getenv("QSX_AGG_FAMILY")) == 0) return nullptr;
   if (c.strategy != QSX_AGG_COMPACT_KEY && c.strategy != QSX_AGG_GENERIC) return nullptr;
-  if (d.num_keys < 1 || d.num_keys > 2 || d.wide_words != 0 || d.num_instrs != 0 || d.num_pred != 0 || d.num_null_cols != 0) return nullptr;
+  if (d.num_keys < 1 || d.num_keys > 2 || d.wide_words != 0 || d.num_instrs != 0 || d.num_null_cols != 0) return nullptr;
+  for (int p = 0; p < d.num_pred; ++p) {   // the state's own predicate: a K1 pass per term in front of the update (family_filter)
+    const int col = d.pred[p].column, type = d.column_type[col];
+    if (d.code_width[col] != 0 || c.column_nullable[col] != 0) return nullptr;
+    if (type != QSX_INT && type != QSX_LONG && type != QSX_FLOAT && type != QSX_DOUBLE && type != QSX_DATE) return nullptr;
+  }
   if (num_sums < 1 || num_sums > kFamilyMaxSums) return nullptr;
   int kt[2] = {0, 0}, n = 0;
   for (int k = 0; k < d.num_keys; ++k) {
@@ -1329,6 +1334,9 @@ static const FamilyEntry *find_family(const qsx_agg_config_t &c, const DevConfig
   return e;
 }
 
+// A run of blocks of this state goes to the family's run kernels (agg_update_blocks then numbers the run table canonically):
+// a hash state of the family without a predicate of its own, outside the group directory's mid-size group counts.
+static bool family_serves_runs(const qsx_agg_state *st) { return st->family != nullptr && !st->dense && st->dev.num_pred == 0 && st->dir_gids == 0; }
 static std::atomic<long long> g_family_launches{0};
 // Test hook (not part of include/qsx.h): update calls this process has issued through a kernel of the AOT family.
 extern "C" long long qsx_debug_agg_family_launches(void) { return g_family_launches.load(std::memory_order_relaxed); }
@@ -2089,8 +2097,10 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
     dc.nulls[sl] = nulls != nullptr ? reinterpret_cast<const unsigned long long *>(nulls[dc.null_column[sl]]) : nullptr;
   }
   const bool aot = !st->dense && st->shape != nullptr && filter_dev == nullptr && dc.num_null_cols == 0;
-  // (the family's kernels take one stripe per column, in canonical order: no run of blocks, whose table is numbered like the state)
-  const bool family = !aot && !st->dense && st->family != nullptr && filter_dev == nullptr && dc.num_null_cols == 0 && !runs;
+  // (a run of blocks: agg_update_blocks numbered the table canonically for exactly these states — family_serves_runs; a state with
+  // a predicate of its own gets it as a filter from a K1 pass here, over one stripe per column and outside the partitioned path)
+  const bool family = !aot && !st->dense && st->family != nullptr && dc.num_null_cols == 0 &&
+                      (runs ? family_serves_runs(st) : (dc.num_pred == 0 || pieces == nullptr));
   int variant = 0;
   // (states over nullable columns: the run-time shapes take the null bitmaps of a call behind a pointer — a run of blocks
   // has one set per block, which the run table does not carry: those stay with the interpreter, block by block)
@@ -2117,7 +2127,22 @@ static int update_slice(qsx_agg_state *st, const void *const *cols, const void *
     } else if (family) {
       const void *canonical[QSX_MAX_COLUMNS] = {};
       for (int i = 0; i < st->family_num_columns; ++i) canonical[i] = cols[st->family_cols[i]];
-      rc = st->family->launch(canonical, st->family_num_columns, n, g, slots, ranges, pieces, s);
+      const uint64_t *family_filter = filter_dev;
+      CallScratch pred_scratch(s);
+      if (!runs && dc.num_pred != 0) {   // the state's predicate -> this call's filter: the tuned K1 kernels, chained through the bitmap
+        const size_t words = static_cast<size_t>((n + 63) / 64) + 1;
+        rc = pred_scratch.reserve(CallScratch::padded(words * 8));
+        if (rc != QSX_OK) return rc;
+        uint64_t *bitmap = static_cast<uint64_t *>(pred_scratch.take(words * 8));
+        for (int p = 0; p < dc.num_pred; ++p) {
+          const unsigned long long literal = dc.pred[p].literal;   // (raw bits typed like the column: what qsx_select_cmp reads behind the pointer)
+          rc = qsx_select_cmp(dc.column_type[dc.pred[p].column], cols[dc.pred[p].column], n, dc.pred[p].op, &literal, p == 0 ? filter_dev : bitmap, bitmap,
+                              nullptr, reinterpret_cast<qsx_stream_t>(s));
+          if (rc != QSX_OK) return rc;
+        }
+        family_filter = bitmap;
+      }
+      rc = st->family->launch(canonical, st->family_num_columns, n, family_filter, g, slots, ranges, pieces, s, runs);
       if (rc == QSX_OK) g_family_launches.fetch_add(1, std::memory_order_relaxed);
     } else {
       QSX_DISPATCH_NS(st->num_sums, rc = launch_hash, dc, st->used_columns, n, filter_dev, g, slots, ranges, pieces, s, runs);
@@ -2586,6 +2611,7 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   bool any_filter = false;
   const void *first_cols[QSX_MAX_COLUMNS] = {};
   const uint64_t *first_filter = nullptr;
+  const bool canonical_table = block_dicts == nullptr && family_serves_runs(st);   // (the same test the update makes: one decision)
   for (int b = 0; b < num_blocks; ++b) {
     if (block_rows[b] < 0) return QSX_ERR_INVALID_ARGUMENT;
     if (block_rows[b] == 0) continue;
@@ -2596,8 +2622,10 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
     tiles512.push_back(tiles512.empty() ? 0 : tiles512.back() + (rows.back() + 511) / 512);
     rows.push_back(block_rows[b]);
     for (int c = 0; c < QSX_MAX_COLUMNS; ++c) {
-      const void *p = c < ncols ? block_cols[static_cast<size_t>(b) * ncols + c] : nullptr;
-      if (c < ncols && ((st->used_columns >> c) & 1u) != 0 && p == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+      // (a state served by the AOT family: the table's column c is the family's canonical column c, agg_family.hpp)
+      const int from = canonical_table ? (c < st->family_num_columns ? st->family_cols[c] : -1) : (c < ncols ? c : -1);
+      const void *p = from >= 0 ? block_cols[static_cast<size_t>(b) * ncols + from] : nullptr;
+      if (from >= 0 && ((st->used_columns >> from) & 1u) != 0 && p == nullptr) return QSX_ERR_INVALID_ARGUMENT;
       cols.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(p)));
       if (block_dicts != nullptr) {
         const void *d = c < ncols && st->dev.code_width[c] != 0 ? block_dicts[static_cast<size_t>(b) * ncols + c] : nullptr;

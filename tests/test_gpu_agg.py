@@ -483,8 +483,50 @@ def test_plans_of_the_aot_family_never_meet_the_interpreter(capi, oracle, dev, k
     assert_same_groups(finalize_np(st2, dev), got)
 
 
+@pytest.mark.parametrize("form", ["filter", "state_predicate", "filter_and_predicate", "run_of_blocks", "run_of_blocks_with_filters"])
+def test_the_aot_family_under_filters_predicates_and_runs_of_blocks(capi, oracle, dev, form, monkeypatch):
+    """The family's kernels come with and without a filter bitmap, over one stripe per column and over a run of blocks (the
+    operators' work orders: every block its own stripes, the run table numbered canonically); a state's own predicate becomes the
+    call's filter by a K1 pass per term (csrc/aggregate.hip family_filter).  No compiler (QSX_AGG_JIT=0); against the oracle."""
+    monkeypatch.setenv("QSX_AGG_JIT", "0")
+    rng = np.random.default_rng(31)
+    n = 400_003
+    x, y = rng.normal(size=n), rng.uniform(0, 100, size=n)
+    unused = rng.integers(0, 5, size=n).astype(np.int64)
+    k1 = rng.integers(-9, 9, size=n).astype(np.int32)
+    k0 = rng.choice(np.frombuffer(b"NRA", dtype=np.uint8), size=n)
+    d = rng.integers(19920101, 19981231, size=n).astype(np.int32)
+    columns = [(T.DOUBLE, None), (T.LONG, None), (T.INT, None), (T.DOUBLE, None), (T.CHAR, 1), (T.INT, None)]
+    cols = [x, unused, k1, y, k0, d]
+    pred = [(5, T.LE, 19980902), (3, T.GT, 7.5)] if "predicate" in form else []
+    cfg = T.make_agg_config(T.AGG_COMPACT_KEY, columns, keys=[4, 2], aggs=[(T.AGG_AVG, T.col(3)), (T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(0))],
+                            pred=pred, est_groups=128)
+    filt = oracle.bitmap_from_bools(rng.random(n) < 0.6) if "filter" in form else None
+    before = _family_launches(capi)
+    st = capi.AggState(cfg)
+    dcols = [to_dev(c, dev) for c in cols]
+    o = oracle.AggState(cfg)
+    if form.startswith("run_of_blocks"):
+        cuts = [0, 1, 4096, 4096, 70_001, 300_000, n]          # a one-row block, an empty block, blocks that end inside a tile
+        blocks = [[c[a:b] for c in dcols] for a, b in zip(cuts[:-1], cuts[1:])]
+        filters = None
+        if form.endswith("filters"):
+            masks = [rng.random(b - a) < 0.5 if i % 2 == 0 else None for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
+            filters = [None if m is None or m.size == 0 else bitmap_dev(oracle.bitmap_from_bools(m), dev) for m in masks]
+            keep = np.concatenate([np.ones(b - a, dtype=bool) if m is None else m for m, (a, b) in zip(masks, zip(cuts[:-1], cuts[1:]))])
+            o.update(cols, n, filter_bitmap=oracle.bitmap_from_bools(keep))
+        else:
+            o.update(cols, n)
+        st.update_blocks(blocks, filters)
+    else:
+        st.update(dcols, n, filter_bitmap=None if filt is None else bitmap_dev(filt, dev))
+        o.update(cols, n, filter_bitmap=filt)
+    assert _family_launches(capi) == before + 1, "the call did not reach a kernel of the family"
+    assert_same_groups(finalize_np(st, dev), o.finalize())
+
+
 def test_plans_outside_the_aot_family_keep_their_kernels(capi, oracle, dev, monkeypatch):
-    """An expression under an aggregate, an INT sum, a predicate inside the state, three keys: not of the family (agg_family.hpp)."""
+    """An expression under an aggregate, an INT sum, MIN over two keys: not of the family (agg_family.hpp)."""
     monkeypatch.setenv("QSX_AGG_JIT", "0")
     rng = np.random.default_rng(5)
     n = 100_000
@@ -496,8 +538,6 @@ def test_plans_outside_the_aot_family_keep_their_kernels(capi, oracle, dev, monk
                           instrs=[(T.EX_MUL, 0, T.col(1), T.col(2))], aggs=[(T.AGG_SUM, T.temp(0))], est_groups=64),
         T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)], keys=[0],
                           aggs=[(T.AGG_SUM, T.col(3)), (T.AGG_SUM, T.col(1))], est_groups=64),
-        T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)], keys=[0],
-                          aggs=[(T.AGG_SUM, T.col(1))], pred=[(3, T.LT, 50)], est_groups=64),
         T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None), (T.DOUBLE, None), (T.INT, None)], keys=[0, 3],
                           aggs=[(T.AGG_MIN, T.col(1))], est_groups=64),
     ]
