@@ -36,6 +36,7 @@
 #include "agg_factored.hpp"
 #include "agg_shapes.hpp"
 #include "agg_family.hpp"
+#include "agg_pieces.hpp"
 #include "agg_jit.hpp"
 #include "comm.hpp"
 #include "partition.hpp"
@@ -687,6 +688,7 @@ struct qsx_agg_state {
   const struct ShapeEntry *shape = nullptr;  // AOT plan shape matching this configuration, if any
   // ... or the member of the AOT family (agg_family.hpp) whose canonical configuration is this plan up to the numbering of its
   // columns: family_cols[c] = the state's column behind canonical column c
+  std::atomic<int> two_level_mode{0};   // the two-level partitioned aggregation for this state's keys: 0 = not decided, 1 = yes, 2 = the one-pass path (decide_two_level)
   const FamilyEntry *family = nullptr;
   int family_num_columns = 0;
   int family_cols[QSX_MAX_COLUMNS] = {};
@@ -2485,6 +2487,136 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
   return update_slice(st, part_cols, nullptr, n, nullptr, st->part_slots, P, reinterpret_cast<const long long *>(pieces), s);
 }
 
+// More groups than one partition pass brings into LDS (agg_pieces.hpp): two K9 passes on digits of the mixing hash, then 4096
+// pieces of disjoint groups, each through a workgroup's LDS table.  For the plans the consumer serves (two_level_plan).
+// Per 100 M rows of an INT key and a DOUBLE, random keys, one pass / two levels: 10^5 groups 4.1 / 3.7 ms, 3 x 10^5 5.9 / 3.7,
+// 10^6 9.6 / 3.6, 3 x 10^6 13.2 / 3.9, 10^7 20.9 / 5.1 (tools/agg_large_groups.py; profiles/README.md round 6).
+static long long two_level_min_groups() {
+  const char *e = getenv("QSX_AGG_TWO_LEVEL_MIN_GROUPS");   // 0 = never
+  return e != nullptr ? atoll(e) : 100000ll;
+}
+// Clustered keys up to this many groups stay on the one-pass path (decide_two_level): 3.4-3.9 ms up to 10^6 groups against
+// 4.7-4.8 through two levels (runs of one key are runs of one partition: the scatter's LDS counters take a wave's 64 adds
+// one after the other); level at 3 x 10^6 (5.1 / 4.9), and 10.8 against 5.2 at 10^7.
+constexpr long long kTwoLevelWhateverTheOrder = 4000000;
+static bool two_level_plan(const qsx_agg_state *st) {
+  const DevConfig &d = st->dev;
+  if (st->dense || d.wide_words != 0 || d.num_instrs != 0 || d.num_pred != 0 || d.num_null_cols != 0 || st->has_coded_columns || st->has_date_key) return false;
+  if (d.num_keys < 1) return false;
+  for (int j = 0; j < st->num_sums; ++j) {
+    const DevSum &sum = d.sums[j];
+    if (sum.count_valid != 0 || sum.null_mask != 0 || sum.arg.kind != QSX_OPD_COLUMN) return false;
+    const int type = d.column_type[sum.arg.index];
+    if (!((sum.kind == kAccSumF64 && type == QSX_DOUBLE) || (sum.kind == kAccSumI64 && (type == QSX_INT || type == QSX_LONG)))) return false;
+  }
+  return true;
+}
+// Slots of a piece's LDS table for `est` groups in all (load <= 1/3 when it fits), and whether a piece's groups fit it at all —
+// a table that is full makes every further row of the piece walk it before it takes the global path.
+static int two_level_slots(const qsx_agg_state *st, bool *fits) {
+  const uint64_t per_piece = static_cast<uint64_t>(st->geometry_est) / kNumPieces + 1;
+  uint64_t slots = next_pow2(per_piece * 3);
+  if (slots < 64) slots = 64;
+  while (slots > 64 && slots * 8 * (static_cast<uint64_t>(st->num_sums) + 2) > 128 * 1024) slots >>= 1;
+  *fits = per_piece * 10 <= slots * 7;
+  return static_cast<int>(slots);
+}
+// Clustered keys (lineitem on l_orderkey) are the one-pass path's best case — its LDS table works as a write-combining cache —
+// and random keys its worst: decided once per state from how often the leading key repeats among the first 256 K rows it sees
+// (1 = two levels, 2 = one pass; kTwoLevelWhateverTheOrder for the numbers).
+static int decide_two_level(qsx_agg_state *st, const void *const *cols, int64_t n, hipStream_t s) {
+  int mode = st->two_level_mode.load();
+  if (mode != 0) return mode;
+  const int col = st->dev.key_column[0], width = st->dev.key_width[0];
+  const int sample = static_cast<int>(std::min<int64_t>(n, 256 * 1024));
+  mode = 1;
+  static const bool sampling = []() { const char *e = std::getenv("QSX_AGG_TWO_LEVEL_SAMPLE"); return e == nullptr || std::atoi(e) != 0; }();
+  if (sampling && (width == 4 || width == 8) && cols[col] != nullptr && sample >= 4096) {
+    CallScratch scratch(s);
+    unsigned int equal = 0;
+    if (scratch.reserve(CallScratch::padded(sizeof(unsigned int))) == QSX_OK) {
+      unsigned int *counter = static_cast<unsigned int *>(scratch.take(sizeof(unsigned int)));
+      bool ok = hipMemsetAsync(counter, 0, sizeof(unsigned int), s) == hipSuccess;
+      if (ok && width == 8) hipLaunchKernelGGL(adjacent_equal_kernel<long long>, dim3(1), dim3(1024), 0, s, static_cast<const long long *>(cols[col]), sample, counter);
+      if (ok && width == 4) hipLaunchKernelGGL(adjacent_equal_kernel<int32_t>, dim3(1), dim3(1024), 0, s, static_cast<const int32_t *>(cols[col]), sample, counter);
+      ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(&equal, counter, sizeof(equal), hipMemcpyDeviceToHost, s) == hipSuccess &&
+           hipStreamSynchronize(s) == hipSuccess;
+      if (ok && static_cast<double>(equal) / (sample - 1) > 0.5) mode = 2;   // runs of two and more rows on average
+      if (!ok) (void)hipGetLastError();
+    }
+  }
+  st->two_level_mode.store(mode);
+  return mode;
+}
+static std::atomic<long long> g_two_level_updates{0};
+// Test hook (not part of include/qsx.h): update calls this process has served through the two-level partitioned aggregation.
+extern "C" long long qsx_debug_agg_two_level_updates(void) { return g_two_level_updates.load(std::memory_order_relaxed); }
+
+static int update_two_level(qsx_agg_state *st, const void *const *cols, int64_t n, hipStream_t s) {
+  const int ncols = st->config.num_columns;
+  const size_t ws_bytes = partition_workspace_bytes(n, kWave);
+  size_t total = CallScratch::padded(sizeof(int64_t) * (kWave + 1)) + CallScratch::padded(sizeof(long long) * (kNumPieces + 1)) + CallScratch::padded(ws_bytes);
+  for (int c = 0; c < ncols; ++c) {
+    if ((st->used_columns >> c) & 1u) total += 2 * CallScratch::padded(static_cast<size_t>(n) * st->dev.column_width[c] + 16);
+  }
+  CallScratch scratch(s);
+  int rc = scratch.reserve(total);
+  if (rc != QSX_OK) return rc;
+  int64_t *offsets = static_cast<int64_t *>(scratch.take(sizeof(int64_t) * (kWave + 1)));
+  long long *bounds = static_cast<long long *>(scratch.take(sizeof(long long) * (kNumPieces + 1)));
+  void *ws = scratch.take(ws_bytes);
+  const void *src[QSX_MAX_COLUMNS];
+  void *first[QSX_MAX_COLUMNS], *second[QSX_MAX_COLUMNS], *first_of[QSX_MAX_COLUMNS] = {}, *second_of[QSX_MAX_COLUMNS] = {};
+  int32_t widths[QSX_MAX_COLUMNS];
+  int moved = 0;
+  for (int c = 0; c < ncols; ++c) {
+    if (!((st->used_columns >> c) & 1u)) continue;
+    const size_t bytes = static_cast<size_t>(n) * st->dev.column_width[c] + 16;
+    first_of[c] = scratch.take(bytes);
+    second_of[c] = scratch.take(bytes);
+    if (first_of[c] == nullptr || second_of[c] == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+    src[moved] = cols[c];
+    first[moved] = first_of[c];
+    second[moved] = second_of[c];
+    widths[moved] = st->dev.column_width[c];
+    ++moved;
+  }
+  // the routing key is the packed key code, computed from the key columns inside K9 (never materialised): the low digit of
+  // the top 12 hash bits first, then — stable — the high digit
+  const void *key_cols[QSX_MAX_KEYS];
+  for (int k = 0; k < st->dev.num_keys; ++k) key_cols[k] = cols[st->dev.key_column[k]];
+  rc = partition_scatter_packed_digit(st->dev.num_keys, key_cols, st->dev.key_width, st->dev.key_shift, n, 64 - kPieceBits, false, moved, src, widths, first, offsets,
+                                      ws, ws_bytes, s);
+  if (rc != QSX_OK) return rc;
+  for (int k = 0; k < st->dev.num_keys; ++k) key_cols[k] = first_of[st->dev.key_column[k]];
+  const void *first_const[QSX_MAX_COLUMNS];
+  for (int i = 0; i < moved; ++i) first_const[i] = first[i];
+  rc = partition_scatter_packed_digit(st->dev.num_keys, key_cols, st->dev.key_width, st->dev.key_shift, n, 64 - kPieceBits + 6, true, moved, first_const, widths, second,
+                                      offsets, ws, ws_bytes, s);
+  if (rc != QSX_OK) return rc;
+  PieceArgs a{};
+  a.num_keys = st->dev.num_keys;
+  for (int k = 0; k < st->dev.num_keys; ++k) {
+    a.key_col[k] = second_of[st->dev.key_column[k]];
+    a.key_width[k] = st->dev.key_width[k];
+    a.key_shift[k] = st->dev.key_shift[k];
+  }
+  a.num_sums = st->num_sums;
+  for (int j = 0; j < st->num_sums; ++j) {
+    const int col = st->dev.sums[j].arg.index;
+    a.sum_col[j] = second_of[col];
+    a.sum_type[j] = st->dev.column_type[col];
+    a.sum_kind[j] = st->dev.sums[j].kind;
+  }
+  a.bounds = bounds;
+  a.n = n;
+  bool fits = false;
+  a.S = two_level_slots(st, &fits);
+  rc = launch_agg_pieces(a, st->hash_view(), s);
+  if (rc == QSX_OK) g_two_level_updates.fetch_add(1, std::memory_order_relaxed);
+  return rc;
+}
+
 // Mid-size group count: group directory + one accumulator per group in LDS (derive_geometry).  Two launches
 // (agg_common.hpp): the distinct key codes of these rows enter the directory, then the rows are aggregated.
 // block_run != nullptr: the rows are a run of blocks (cols = the first block's stripes: only which ones exist matters).
@@ -2558,7 +2690,14 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
   // pieces have to guarantee; the per-piece tables are keyed by the hashed code like everything else)
   if (!st->dense && st->part_count > 1 && filter_dev == nullptr && !st->has_coded_columns && st->dev.num_null_cols == 0 &&
       !st->has_date_key && n >= partition_min_rows()) {
-    rc = update_partitioned(st, cols, n, s);
+    const long long two_level_from = two_level_min_groups();
+    bool pieces_fit = false;
+    if (two_level_from > 0 && st->geometry_est >= two_level_from && n >= 2 * partition_min_rows() && two_level_plan(st) &&
+        (two_level_slots(st, &pieces_fit), pieces_fit) && (st->geometry_est >= kTwoLevelWhateverTheOrder || decide_two_level(st, cols, n, s) == 1)) {
+      rc = update_two_level(st, cols, n, s);
+    } else {
+      rc = update_partitioned(st, cols, n, s);
+    }
   } else {
     rc = update_slice(st, cols, dicts, n, filter_dev, st->lds_slots, st->lds_ranges, nullptr, s, nulls);
   }

@@ -25,6 +25,14 @@ int partition_scatter_packed_keys(int num_keys, const void *const *key_cols, con
                                   void *const *out_cols, int64_t *out_offsets_dev, void *workspace_dev, size_t workspace_bytes,
                                   hipStream_t stream, int align_rows);
 
+// One pass (stable or not: the first pass has no earlier order to keep) of an LSD ordering by the MIXING hash of the key code packed on the fly (the hash that addresses the aggregation's
+// global table): 64 buckets by the digit (hash >> shift) & 63.  Two passes (shift 52, then 58) order the rows by the hash's top
+// 12 bits — 4096 pieces whose groups are disjoint (the two-level partitioned aggregation).  out_offsets_dev: 65 int64.
+// Workspace: partition_workspace_bytes(n, 64).
+int partition_scatter_packed_digit(int num_keys, const void *const *key_cols, const int *key_widths, const int *key_shifts, int64_t n,
+                                   int shift, bool stable, int ncols, const void *const *cols, const int32_t *widths, void *const *out_cols,
+                                   int64_t *out_offsets_dev, void *workspace_dev, size_t workspace_bytes, hipStream_t stream);
+
 // One stable LSD radix-sort pass over 64-bit keys: 64 buckets by the digit (key >> shift) & 63, ties keep their order.
 // out_offsets_dev: 65 int64.  Workspace: partition_workspace_bytes(n, 64).
 int partition_scatter_digit(const unsigned long long *keys64_dev, int64_t n, int shift, int ncols, const void *const *cols,

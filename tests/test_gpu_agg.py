@@ -525,6 +525,76 @@ def test_the_aot_family_under_filters_predicates_and_runs_of_blocks(capi, oracle
     assert_same_groups(finalize_np(st, dev), o.finalize())
 
 
+def _two_level_updates(capi):
+    import ctypes
+    capi.lib.qsx_debug_agg_two_level_updates.restype = ctypes.c_longlong
+    return capi.lib.qsx_debug_agg_two_level_updates()
+
+
+@pytest.mark.parametrize("groups,keys_kind", [(1_000_000, "int"), (300_000, "int_and_char"), (3_000_000, "int_clustered"), (8_000_000, "int_underestimated")])
+def test_two_level_partitioned_aggregation_for_large_group_counts(capi, dev, groups, keys_kind, monkeypatch):
+    """csrc/agg_pieces.hpp: more groups than one partition pass brings into LDS (est_groups >= 100 K): two stable K9 passes on
+    digits of the mixing hash order the rows by its top 12 bits, then 4096 pieces of disjoint groups go through workgroup-private
+    LDS tables (the partitioned aggregation of storage/AggregationOperationState.cpp:548-614 with partition = piece).  COUNT(*),
+    SUM over a DOUBLE, a LONG and an INT column, AVG; groups compared one by one with numpy (COUNT and the integer sums exact);
+    the same plan through the one-pass path (QSX_AGG_TWO_LEVEL_MIN_GROUPS=0) gives the same groups; two update calls, the
+    second one over rows of groups the first has not seen."""
+    rng = np.random.default_rng(groups % 1000 + 7)
+    n = 17_000_017                                                              # two calls of 8.5 M rows: each one beyond the path's row threshold
+    if keys_kind == "int_clustered":
+        gid = (np.arange(n, dtype=np.int64) * groups // n)                     # sorted: long runs inside every piece
+    else:
+        gid = rng.integers(0, groups, size=n)
+    a = rng.integers(-1000, 1000, size=n) / 8.0                                 # multiples of 1/8: sums are exact in any order
+    b = rng.integers(-2**40, 2**40, size=n).astype(np.int64)
+    c = rng.integers(-100, 100, size=n).astype(np.int32)
+    if keys_kind == "int_and_char":                                             # (a 40-bit packed code: a LONG next to it would make the key a wide one)
+        k0 = ((gid // 5) * 1_003 - 17).astype(np.int32)
+        k1 = np.frombuffer(b"VWXYZ", dtype=np.uint8)[gid % 5]
+        columns = [(T.INT, None), (T.CHAR, 1), (T.DOUBLE, None), (T.LONG, None), (T.INT, None)]
+        cols, key_idx, strategy = [k0, k1, a, b, c], [0, 1], T.AGG_COMPACT_KEY
+    else:
+        k0 = (gid * 7 - 3).astype(np.int32)
+        columns = [(T.INT, None), (T.DOUBLE, None), (T.LONG, None), (T.INT, None)]
+        cols, key_idx, strategy = [k0, a, b, c], [0], T.AGG_GENERIC
+    v = len(key_idx)
+    cfg = T.make_agg_config(strategy, columns, keys=key_idx,
+                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(v)), (T.AGG_SUM, T.col(v + 1)), (T.AGG_SUM, T.col(v + 2)), (T.AGG_AVG, T.col(v))],
+                            est_groups=groups if keys_kind != "int_underestimated" else 3_000_000)   # (1953 groups a piece for tables of 2048 slots: the probe bound sends rows down the global path)
+    dcols = [to_dev(x, dev) for x in cols]
+    half = n // 2 + 3
+    results = []
+    for two_level in (True, False):
+        monkeypatch.setenv("QSX_AGG_TWO_LEVEL_MIN_GROUPS", "100000" if two_level else "0")
+        before = _two_level_updates(capi)
+        st = capi.AggState(cfg)
+        st.update([x[:half] for x in dcols], half)
+        st.update([x[half:] for x in dcols], n - half)
+        # (clustered keys: the state samples its leading key and keeps the one-pass path, whose LDS table combines the runs)
+        assert _two_level_updates(capi) == before + (2 if two_level and keys_kind != "int_clustered" else 0)
+        results.append(finalize_np(st, dev))
+        st.close()
+    gk, gv, gn = results[0]
+    # numpy, by group number
+    cnt = np.bincount(gid, minlength=groups)
+    present = np.nonzero(cnt)[0]
+    sum_a = np.bincount(gid, weights=a, minlength=groups)
+    sum_b = np.zeros(groups, dtype=np.int64)
+    np.add.at(sum_b, gid, b)
+    sum_c = np.bincount(gid, weights=c.astype(np.float64), minlength=groups).astype(np.int64)
+    if keys_kind == "int_and_char":
+        got_gid = (gk[0].astype(np.int64) + 17) // 1_003 * 5 + (gk[1].reshape(gk[1].shape[0], -1)[:, 0].astype(np.int64) - ord("V"))
+    else:
+        got_gid = (gk[0].astype(np.int64) + 3) // 7
+    assert got_gid.size == present.size and np.array_equal(np.sort(got_gid), present)
+    assert np.array_equal(gv[0], cnt[got_gid])
+    assert np.array_equal(gv[1], sum_a[got_gid])
+    assert np.array_equal(gv[2], sum_b[got_gid])
+    assert np.array_equal(gv[3], sum_c[got_gid])
+    assert np.allclose(gv[4], sum_a[got_gid] / cnt[got_gid], rtol=1e-12, atol=0.0)
+    assert_same_groups(results[0], results[1])
+
+
 def test_plans_outside_the_aot_family_keep_their_kernels(capi, oracle, dev, monkeypatch):
     """An expression under an aggregate, an INT sum, MIN over two keys: not of the family (agg_family.hpp)."""
     monkeypatch.setenv("QSX_AGG_JIT", "0")

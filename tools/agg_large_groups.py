@@ -19,7 +19,7 @@ n = 100_000_000
 val = torch.rand(n, device=dev, generator=g, dtype=torch.float64)
 
 
-def timed(fn, reps=3):
+def timed(fn, reps=10):
     fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,10 +31,13 @@ def timed(fn, reps=3):
     return a.elapsed_time(b) / reps
 
 
-for groups in (100_000, 1_000_000, 10_000_000):
+only_random_generic = len(sys.argv) > 1 and sys.argv[1] == "random-generic"   # (the profile of the two-level path's kernels)
+for groups in (100_000, 300_000, 1_000_000, 3_000_000, 10_000_000) if not only_random_generic else (1_000_000, 10_000_000):
     for label, keys in (("random keys", torch.randint(0, groups, (n,), device=dev, generator=g, dtype=torch.int32)),
                         ("clustered keys (sorted)", (torch.arange(n, device=dev, dtype=torch.int64) * groups // n).to(torch.int32))):
-        for strategy, name in ((T.AGG_GENERIC, "GENERIC (hash table)"), (T.AGG_COLLISION_FREE, "COLLISION_FREE (dense arrays)")):
+        if only_random_generic and label != "random keys":
+            continue
+        for strategy, name in ((T.AGG_GENERIC, "GENERIC (hash table)"), (T.AGG_COLLISION_FREE, "COLLISION_FREE (dense arrays)"))[:1 if only_random_generic else 2]:
             cfg = T.make_agg_config(strategy, [(T.INT, None), (T.DOUBLE, None)], keys=[0], aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None)],
                                     est_groups=groups, num_entries=groups)
             st = capi.AggState(cfg)
