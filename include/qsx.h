@@ -538,6 +538,41 @@ int qsx_join_probe_exists_blocks(qsx_join_table_t *table, int64_t num_blocks, co
                                  const void *const *block_keys, const uint64_t *const *block_filters, int anti,
                                  uint64_t *const *block_out_bitmaps, int64_t *out_count_dev, qsx_stream_t stream);
 
+/* The block forms over COMPRESSED key stripes.  A CompressedColumnStore block stores an INT / LONG attribute as values, as
+ * truncated values of 1 / 2 / 4 bytes, or as 1 / 2 / 4-byte codes into the block's own sorted dictionary — each block decides
+ * for itself (storage/CompressedBlockBuilder.cpp:508-566, 590-650) — and the reference's join reads the key through
+ * CompressedTupleStorageSubBlock::getAttributeValue (storage/CompressedTupleStorageSubBlock.hpp:225-300: dictionary lookup
+ * or widening, per tuple).  These forms take the stripes as they lie: block_keys[b] is block b's stripe of
+ * coding->block_code_width[b]-byte codes (0: the stripe holds values of the table's key type, as in the plain forms) and
+ * coding->block_dictionaries[b] the block's dictionary of key-type values on the device (NULL entry or NULL array: the codes
+ * are truncated values, widened without sign).  coding == NULL or all widths 0: exactly the plain form.  No qsx_decode_codes
+ * pass, no decoded stripe: the key costs its code width in HBM traffic.
+ * qsx_join_probe_project_blocks_coded: a probe-side output column whose stripe pointers are the blocks' key stripes IS the
+ * join key and comes out as its value (the column's width must be the key type's); on a table without a directly addressed
+ * form such a column returns QSX_ERR_UNSUPPORTED (present its decoded stripe instead). */
+typedef struct qsx_key_coding {
+  const int32_t *block_code_width;        /* host array [num_blocks]: 0, 1, 2 or 4 */
+  const void *const *block_dictionaries;  /* NULL, or host array [num_blocks] of device pointers (NULL entries: truncation) */
+} qsx_key_coding_t;
+int qsx_join_build_blocks_coded(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                const qsx_key_coding_t *coding, const int32_t *block_base_tids, const uint64_t *const *block_filters,
+                                qsx_stream_t stream);
+int qsx_join_probe_blocks_coded(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                const qsx_key_coding_t *coding, const int32_t *block_base_tids, const uint64_t *const *block_filters,
+                                int32_t *out_probe_tid_dev, int32_t *out_build_tid_dev, int64_t capacity, int64_t *out_count_dev,
+                                qsx_stream_t stream);
+int qsx_join_probe_project_blocks_coded(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows,
+                                        const void *const *block_keys, const qsx_key_coding_t *coding,
+                                        const uint64_t *const *block_filters, const qsx_join_projection_t *projection,
+                                        int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream);
+int qsx_join_probe_count_blocks_coded(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows,
+                                      const void *const *block_keys, const qsx_key_coding_t *coding,
+                                      const uint64_t *const *block_filters, int64_t *out_count_dev, qsx_stream_t stream);
+int qsx_join_probe_exists_blocks_coded(qsx_join_table_t *table, int64_t num_blocks, const int64_t *block_rows,
+                                       const void *const *block_keys, const qsx_key_coding_t *coding,
+                                       const uint64_t *const *block_filters, int anti, uint64_t *const *block_out_bitmaps,
+                                       int64_t *out_count_dev, qsx_stream_t stream);
+
 /* ======================================================================
  * Aggregation
  * ====================================================================== */
@@ -874,6 +909,14 @@ int qsx_lip_build_blocks(qsx_lip_filter_t *filter, int key_type, int64_t num_blo
 int qsx_lip_probe_blocks(const qsx_lip_filter_t *filter, int key_type, int64_t num_blocks, const int64_t *block_rows,
                          const void *const *block_keys, const uint64_t *const *block_in_bitmaps,
                          uint64_t *const *block_out_bitmaps, int64_t *out_count_dev, qsx_stream_t stream);
+
+/* qsx_lip_build_blocks / qsx_lip_probe_blocks over compressed key stripes (qsx_key_coding_t, above). */
+int qsx_lip_build_blocks_coded(qsx_lip_filter_t *filter, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                               const void *const *block_keys, const qsx_key_coding_t *coding, const uint64_t *const *block_filters,
+                               qsx_stream_t stream);
+int qsx_lip_probe_blocks_coded(const qsx_lip_filter_t *filter, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                               const void *const *block_keys, const qsx_key_coding_t *coding, const uint64_t *const *block_in_bitmaps,
+                               uint64_t *const *block_out_bitmaps, int64_t *out_count_dev, qsx_stream_t stream);
 
 /* Raw bit array (for all-reduce(OR) across GPUs): 64-bit words, LSB-first. */
 int qsx_lip_filter_words(qsx_lip_filter_t *f, uint64_t **out_words_dev, int64_t *out_num_words);

@@ -101,6 +101,11 @@ _SIGNATURES = {
     "qsx_join_probe_count_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _vp, _vp]),
     "qsx_join_probe_project_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, C.POINTER(T.JoinProjection), _i64, _vp, _vp]),
     "qsx_join_probe_exists_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _int, _pp, _vp, _vp]),
+    "qsx_join_build_blocks_coded": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _vp, C.POINTER(_i32), _pp, _vp]),
+    "qsx_join_probe_blocks_coded": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _vp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
+    "qsx_join_probe_count_blocks_coded": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _vp, _pp, _vp, _vp]),
+    "qsx_join_probe_project_blocks_coded": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _vp, _pp, C.POINTER(T.JoinProjection), _i64, _vp, _vp]),
+    "qsx_join_probe_exists_blocks_coded": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _vp, _pp, _int, _pp, _vp, _vp]),
     "qsx_join_probe_count": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "qsx_join_probe_exists": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
     "qsx_eval_expression": (_int, [_int, _pp, C.POINTER(_i32), _int, C.POINTER(T.ExprInstr), C.POINTER(C.c_double), T.Operand, _i64, _vp, _vp]),
@@ -136,6 +141,8 @@ _SIGNATURES = {
     "qsx_lip_probe": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     "qsx_lip_build_blocks": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _pp, _vp]),
     "qsx_lip_probe_blocks": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _pp, _pp, _vp, _vp]),
+    "qsx_lip_build_blocks_coded": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _vp, _pp, _vp]),
+    "qsx_lip_probe_blocks_coded": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _vp, _pp, _pp, _vp, _vp]),
     "qsx_lip_filter_words": (_int, [_vp, _pp, C.POINTER(_i64)]),
     "qsx_comm_unique_id": (_int, [_vp]),
     "qsx_comm_create": (_int, [_int, _int, _vp, _pp]),
@@ -409,9 +416,10 @@ def select_codes_sorted(codes, op, first, second=0, filter_bitmap=None, stream=N
     return out_bitmap, out_count
 
 
-def decode_codes(codes, dictionary, value_dtype, stream=None):
+def decode_codes(codes, dictionary, value_dtype, stream=None, out=None):
     """codes -> values: dictionary lookup, or zero-extension when dictionary is None (truncated attribute)."""
-    out = torch.empty(codes.numel(), dtype=value_dtype, device=codes.device)
+    if out is None:
+        out = torch.empty(codes.numel(), dtype=value_dtype, device=codes.device)
     _check(_lib.qsx_decode_codes(codes.element_size(), _ptr(codes), codes.numel(), _ptr(dictionary), out.element_size(),
                                  _ptr(out), _stream(stream)), "qsx_decode_codes")
     return out
@@ -604,6 +612,29 @@ def bitmap_gather_segmented(segment_bitmaps, first_rows, tids, stream=None):
 
 
 # --------------------------------------------------------------------------- join
+class KeyCoding(C.Structure):
+    """qsx_key_coding_t (include/qsx.h)."""
+    _fields_ = [("block_code_width", C.POINTER(C.c_int32)), ("block_dictionaries", C.POINTER(C.c_void_p))]
+
+
+def _key_coding(coding, nb):
+    """coding: None, or one (code_width, dictionary tensor or None) per block -> (pointer for the call, keep-alive)."""
+    if coding is None:
+        return None, None
+    assert len(coding) == nb
+    widths = (C.c_int32 * max(nb, 1))(*[w for w, _ in coding])
+    dicts = (C.c_void_p * max(nb, 1))(*[d.data_ptr() if d is not None else None for _, d in coding])
+    kc = KeyCoding(C.cast(widths, C.POINTER(C.c_int32)), C.cast(dicts, C.POINTER(C.c_void_p)))
+    return C.byref(kc), (kc, widths, dicts)
+
+
+def _rows_of(key_blocks, coding):
+    """Rows per block: a plain stripe's elements, or a code stripe's bytes over its code width."""
+    if coding is None:
+        return [k.numel() for k in key_blocks]
+    return [k.numel() if w == 0 else k.numel() * k.element_size() // w for k, (w, _) in zip(key_blocks, coding)]
+
+
 class JoinTable:
     """JoinHashTable handle (qsx_join_table_t)."""
 
@@ -650,15 +681,20 @@ class JoinTable:
         _check(_lib.qsx_join_build(self._h, _ptr(keys), keys.numel(), base_tid, _ptr(filter_bitmap),
                                    _stream(stream)), "qsx_join_build")
 
-    def build_blocks(self, key_blocks, base_tids, filters=None, stream=None):
-        """K3 over a run of build blocks in one launch."""
+    def build_blocks(self, key_blocks, base_tids, filters=None, stream=None, coding=None):
+        """K3 over a run of build blocks in one launch.  coding: one (code_width, dictionary or None) per block — the key
+        stripes as a CompressedColumnStore holds them (qsx_join_build_blocks_coded)."""
         nb = len(key_blocks)
-        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        rows = (C.c_int64 * max(nb, 1))(*_rows_of(key_blocks, coding))
         kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
         bptr = (C.c_int32 * max(nb, 1))(*base_tids)
         fptr = None
         if filters is not None:
             fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        if coding is not None:
+            cptr, keep = _key_coding(coding, nb)
+            _check(_lib.qsx_join_build_blocks_coded(self._h, nb, rows, kptr, cptr, bptr, fptr, _stream(stream)), "qsx_join_build_blocks_coded")
+            return
         _check(_lib.qsx_join_build_blocks(self._h, nb, rows, kptr, bptr, fptr, _stream(stream)), "qsx_join_build_blocks")
 
     def probe(self, keys, capacity=None, probe_base_tid=0, filter_bitmap=None, out=None, stream=None):
@@ -706,12 +742,12 @@ class JoinTable:
                                           _ptr(count), _stream(stream)), "qsx_join_probe_exists")
         return out, count
 
-    def probe_blocks(self, key_blocks, capacity=None, base_tids=None, filters=None, out=None, stream=None):
+    def probe_blocks(self, key_blocks, capacity=None, base_tids=None, filters=None, out=None, stream=None, coding=None):
         """K4 over a run of probe blocks in one launch: key_blocks = one key stripe per block.  Probe tids are
-        base_tids[b] + row, or run-global row numbers when base_tids is None."""
+        base_tids[b] + row, or run-global row numbers when base_tids is None.  coding: as in build_blocks."""
         nb = len(key_blocks)
         dev = key_blocks[0].device if nb else torch.device("cuda:0")
-        total = sum(k.numel() for k in key_blocks)
+        total = sum(_rows_of(key_blocks, coding))
         if out is None:
             capacity = total if capacity is None else capacity
             out_p = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
@@ -720,25 +756,30 @@ class JoinTable:
         else:
             out_p, out_b, count = out
             capacity = out_p.numel() if capacity is None else capacity
-        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        rows = (C.c_int64 * max(nb, 1))(*_rows_of(key_blocks, coding))
         kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
         bptr = None if base_tids is None else (C.c_int32 * max(nb, 1))(*base_tids)
         fptr = None
         if filters is not None:
             fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        if coding is not None:
+            cptr, keep = _key_coding(coding, nb)
+            _check(_lib.qsx_join_probe_blocks_coded(self._h, nb, rows, kptr, cptr, bptr, fptr, _ptr(out_p), _ptr(out_b), capacity, _ptr(count),
+                                                    _stream(stream)), "qsx_join_probe_blocks_coded")
+            return out_p, out_b, count
         _check(_lib.qsx_join_probe_blocks(self._h, nb, rows, kptr, bptr, fptr, _ptr(out_p), _ptr(out_b), capacity, _ptr(count),
                                           _stream(stream)), "qsx_join_probe_blocks")
         return out_p, out_b, count
 
     def probe_project_blocks(self, key_blocks, probe_columns, build_columns, build_first_tids=None, capacity=None, filters=None,
-                             stream=None):
+                             stream=None, coding=None, key_dtype=None):
         """K4 + K5 in one pass: the output relation of the inner join over a run of probe blocks.
         probe_columns: list of per-attribute lists of per-block stripes (probe_columns[a][b]); build_columns: list of
         per-attribute lists of per-segment stripes (build_columns[a][s]), segment s starting at build tuple id
         build_first_tids[s].  Returns (output columns — the probe attributes first, then the build attributes —, count)."""
         nb = len(key_blocks)
         dev = key_blocks[0].device if nb else torch.device("cuda:0")
-        total = sum(k.numel() for k in key_blocks)
+        total = sum(_rows_of(key_blocks, coding))
         capacity = total if capacity is None else capacity
         sources = [(0, c) for c in probe_columns] + [(1, c) for c in build_columns]
         nc = len(sources)
@@ -755,9 +796,12 @@ class JoinTable:
         bstripes = (C.c_void_p * max(nseg * nc, 1))()
         for c, (side, stripes) in enumerate(sources):
             ref = stripes[0]
-            proj.width[c] = ref.element_size()
+            # (coded runs: a probe column given as the key stripes themselves is the join key, emitted as its value)
+            is_key = coding is not None and side == 0 and all(a is b for a, b in zip(stripes, key_blocks))
+            dtype = key_dtype if is_key else ref.dtype
+            proj.width[c] = torch.empty(0, dtype=dtype).element_size()
             proj.on_build[c] = side
-            outs.append(torch.empty(max(capacity, 1), dtype=ref.dtype, device=dev))
+            outs.append(torch.empty(max(capacity, 1), dtype=dtype, device=dev))
             for i, stripe in enumerate(stripes):
                 (bstripes if side else pstripes)[i * nc + c] = stripe.data_ptr() if stripe.numel() else None
         optr = (C.c_void_p * nc)(*[o.data_ptr() for o in outs])
@@ -768,39 +812,54 @@ class JoinTable:
         proj.build_stripes = C.cast(bstripes, C.POINTER(C.c_void_p))
         proj.out_columns = C.cast(optr, C.POINTER(C.c_void_p))
         count = torch.zeros(1, dtype=torch.int64, device=dev)
-        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        rows = (C.c_int64 * max(nb, 1))(*_rows_of(key_blocks, coding))
         kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
         fptr = None
         if filters is not None:
             fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        if coding is not None:
+            cptr, keep = _key_coding(coding, nb)
+            _check(_lib.qsx_join_probe_project_blocks_coded(self._h, nb, rows, kptr, cptr, fptr, C.byref(proj), capacity, _ptr(count),
+                                                            _stream(stream)), "qsx_join_probe_project_blocks_coded")
+            return outs, count
         _check(_lib.qsx_join_probe_project_blocks(self._h, nb, rows, kptr, fptr, C.byref(proj), capacity, _ptr(count), _stream(stream)),
                "qsx_join_probe_project_blocks")
         return outs, count
 
-    def probe_count_blocks(self, key_blocks, filters=None, stream=None):
+    def probe_count_blocks(self, key_blocks, filters=None, stream=None, coding=None):
         nb = len(key_blocks)
         dev = key_blocks[0].device if nb else torch.device("cuda:0")
         count = torch.zeros(1, dtype=torch.int64, device=dev)
-        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        rows = (C.c_int64 * max(nb, 1))(*_rows_of(key_blocks, coding))
         kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
         fptr = None
         if filters is not None:
             fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        if coding is not None:
+            cptr, keep = _key_coding(coding, nb)
+            _check(_lib.qsx_join_probe_count_blocks_coded(self._h, nb, rows, kptr, cptr, fptr, _ptr(count), _stream(stream)),
+                   "qsx_join_probe_count_blocks_coded")
+            return count
         _check(_lib.qsx_join_probe_count_blocks(self._h, nb, rows, kptr, fptr, _ptr(count), _stream(stream)), "qsx_join_probe_count_blocks")
         return count
 
-    def probe_exists_blocks(self, key_blocks, anti=False, filters=None, out_bitmaps=None, stream=None):
+    def probe_exists_blocks(self, key_blocks, anti=False, filters=None, out_bitmaps=None, stream=None, coding=None):
         """Semi / anti probe over a run of blocks: returns (per-block bitmaps, total count int64[1])."""
         nb = len(key_blocks)
         dev = key_blocks[0].device if nb else torch.device("cuda:0")
-        outs = out_bitmaps if out_bitmaps is not None else [new_bitmap(k.numel(), dev) for k in key_blocks]
+        outs = out_bitmaps if out_bitmaps is not None else [new_bitmap(r, dev) for r in _rows_of(key_blocks, coding)]
         count = torch.zeros(1, dtype=torch.int64, device=dev)
-        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        rows = (C.c_int64 * max(nb, 1))(*_rows_of(key_blocks, coding))
         kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
         optr = (C.c_void_p * max(nb, 1))(*[o.data_ptr() if o.numel() else None for o in outs])
         fptr = None
         if filters is not None:
             fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        if coding is not None:
+            cptr, keep = _key_coding(coding, nb)
+            _check(_lib.qsx_join_probe_exists_blocks_coded(self._h, nb, rows, kptr, cptr, fptr, 1 if anti else 0, optr, _ptr(count),
+                                                           _stream(stream)), "qsx_join_probe_exists_blocks_coded")
+            return outs, count
         _check(_lib.qsx_join_probe_exists_blocks(self._h, nb, rows, kptr, fptr, 1 if anti else 0, optr, _ptr(count),
                                                  _stream(stream)), "qsx_join_probe_exists_blocks")
         return outs, count
@@ -989,29 +1048,38 @@ class LipFilter:
                                   _stream(stream)), "qsx_lip_probe")
         return out, count
 
-    def build_blocks(self, key_blocks, filters=None, stream=None):
-        """qsx_lip_build over a run of blocks in one launch."""
+    def build_blocks(self, key_blocks, filters=None, stream=None, coding=None, key_type=None):
+        """qsx_lip_build over a run of blocks in one launch (coding / key_type: compressed key stripes, JoinTable.build_blocks)."""
         nb = len(key_blocks)
-        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        rows = (C.c_int64 * max(nb, 1))(*_rows_of(key_blocks, coding))
         kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
         fptr = None
         if filters is not None:
             fptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in filters])
+        if coding is not None:
+            cptr, keep = _key_coding(coding, nb)
+            _check(_lib.qsx_lip_build_blocks_coded(self._h, key_type, nb, rows, kptr, cptr, fptr, _stream(stream)), "qsx_lip_build_blocks_coded")
+            return
         _check(_lib.qsx_lip_build_blocks(self._h, qsx_type_of(key_blocks[0]) if nb else T.INT, nb, rows, kptr, fptr, _stream(stream)),
                "qsx_lip_build_blocks")
 
-    def probe_blocks(self, key_blocks, in_bitmaps=None, stream=None):
+    def probe_blocks(self, key_blocks, in_bitmaps=None, stream=None, coding=None, key_type=None):
         """qsx_lip_probe over a run of blocks in one launch: (per-block output bitmaps, total count int64[1])."""
         nb = len(key_blocks)
         dev = key_blocks[0].device if nb else torch.device("cuda:0")
-        outs = [new_bitmap(k.numel(), dev) for k in key_blocks]
+        outs = [new_bitmap(r, dev) for r in _rows_of(key_blocks, coding)]
         count = torch.zeros(1, dtype=torch.int64, device=dev)
-        rows = (C.c_int64 * max(nb, 1))(*[k.numel() for k in key_blocks])
+        rows = (C.c_int64 * max(nb, 1))(*_rows_of(key_blocks, coding))
         kptr = (C.c_void_p * max(nb, 1))(*[k.data_ptr() if k.numel() else None for k in key_blocks])
         optr = (C.c_void_p * max(nb, 1))(*[o.data_ptr() if o.numel() else None for o in outs])
         iptr = None
         if in_bitmaps is not None:
             iptr = (C.c_void_p * max(nb, 1))(*[f.data_ptr() if f is not None and f.numel() else None for f in in_bitmaps])
+        if coding is not None:
+            cptr, keep = _key_coding(coding, nb)
+            _check(_lib.qsx_lip_probe_blocks_coded(self._h, key_type, nb, rows, kptr, cptr, iptr, optr, _ptr(count), _stream(stream)),
+                   "qsx_lip_probe_blocks_coded")
+            return outs, count
         _check(_lib.qsx_lip_probe_blocks(self._h, qsx_type_of(key_blocks[0]) if nb else T.INT, nb, rows, kptr, iptr, optr, _ptr(count),
                                          _stream(stream)), "qsx_lip_probe_blocks")
         return outs, count

@@ -1,11 +1,15 @@
 // agg_pieces.hpp — the consumer of the TWO-LEVEL partitioned aggregation: more groups than one partition pass brings into LDS
 // (one K9 pass makes 64 pieces: beyond ~10^5 groups a piece's groups no longer fit a workgroup's table and the rows pay
-// NS + 1 global atomics each, at the atomic units' 23.7 G/s: COUNT + SUM 7.9 ms per 100 M rows at 10^6 groups).  Two stable K9
-// passes on digits of the mixing hash (partition.hpp partition_scatter_packed_digit) order the rows by the hash's top 12
-// bits: 4096 pieces with disjoint groups — a few hundred to a few thousand groups each — and, because the global table is
+// NS + 1 global atomics each, at the atomic units' 23.7 G/s: COUNT + SUM 9.6 ms per 100 M rows at 10^6 groups, 20.9 at 10^7).
+// Two K9 passes on digits of the mixing hash (partition.hpp partition_scatter_packed_digit: the low digit in any order, then
+// the high digit keeping the first pass's order) order the rows by the hash's top 12 bits: 4096 pieces with disjoint groups — a few hundred to a few thousand groups each — and, because the global table is
 // addressed by the same hash (agg_common.hpp code_slot), piece p's groups are one contiguous 1/4096 of the table.  A workgroup
 // takes a piece at a time: its rows once through a workgroup-private LDS table (direct loads: a piece starts at any row),
-// then one global update per group and accumulator.
+// then one global update per group and accumulator.  3.4 ms at 10^6 groups, 5.0 at 10^7 (two scatters 0.86 + 1.01, two
+// histograms 0.18 + 0.16, this kernel 0.53 / 1.78; tools/agg_large_groups.py, profiles/r06_two_level_kernel_stats.csv).
+// A piece's table holds est_groups / 4096 groups at load <= 1/3 where LDS allows (128 KB), never beyond 0.7 (the path is not
+// taken then: aggregate.hip two_level_slots); a row whose group finds no slot within 48 probes — an estimate that was too
+// low — goes to the global table directly, like every row of the one-pass path does.
 // Reference loops: storage/AggregationOperationState.cpp:548-614 (the partitioned aggregation), storage/
 // PackedPayloadHashTable.hpp:838-909 (upsert per row).
 // Plans it serves: hash states with a key code of <= 8 bytes, SUM / AVG / COUNT over plain DOUBLE, INT or LONG columns (and

@@ -298,11 +298,15 @@ __global__ __launch_bounds__(kJBlock) void build_runs_kernel(TableView t, const 
     const uint64_t *filter = run_filter(runs, at.block);
     const int64_t n = run_rows(runs, at.block);
     const uint32_t base_tid = static_cast<uint32_t>(run_base(runs, at.block));
+    // (a compressed key stripe, block_runs.hpp: read as it lies)
+    const bool coded = run_has_coding(runs);
+    const ProbeTileSource<KeyT> src{keys, n, 0, 0, filter, nullptr, at.block, coded ? run_code_width(runs, at.block) : 0,
+                                    coded ? run_dictionary(runs, at.block) : nullptr};
 #pragma unroll 2
     for (int r = 0; r < kBuildR; ++r) {
       const int64_t i = static_cast<int64_t>(at.tile_in_block) * kBuildTile + r * kWave + lane;
       if (i >= n || !row_in_filter(filter, i)) continue;
-      const KeyT key = keys[i];
+      const KeyT key = src.code_width != 0 ? coded_key(src, i) : keys[i];
       insert_entry(t, key, base_tid + static_cast<uint32_t>(i));
       bounds.add(key);
       ++inserted;
@@ -502,10 +506,17 @@ __global__ __launch_bounds__(kJBlock) void probe_fp_kernel(
   Key key[kRowsPerThread], next_key[kRowsPerThread];
   uint64_t filter_words = ~0ull, next_filter_words = ~0ull;
   auto request = [&](const Source &src, Key (&k)[kRowsPerThread], uint64_t &words) {
+    if (kRuns && src.code_width != 0) {   // a compressed key stripe (block_runs.hpp): read as it lies
+      coded_keys(src, k, [&](int r) {
+        const int64_t row = src.base + r * kJBlock + threadIdx.x;
+        return row < src.n ? row : src.n - 1;
+      });
+    } else {
 #pragma unroll
-    for (int r = 0; r < kRowsPerThread; ++r) {
-      const int64_t row = src.base + r * kJBlock + threadIdx.x;
-      k[r] = __builtin_nontemporal_load(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded; streamed once
+      for (int r = 0; r < kRowsPerThread; ++r) {
+        const int64_t row = src.base + r * kJBlock + threadIdx.x;
+        k[r] = __builtin_nontemporal_load(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded; streamed once
+      }
     }
     words = ~0ull;
     if (src.filter != nullptr && lane < kRowsPerThread) {
@@ -1278,12 +1289,31 @@ int qsx_join_build(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t
   return QSX_OK;
 }
 
-int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
-                          const int32_t *block_base_tids, const uint64_t *const *block_filters, qsx_stream_t stream) {
+// A run's key coding as the kernels take it (block_runs.hpp): nullptr when there is none to speak of.
+static int check_key_coding(const qsx_key_coding_t **coding, int64_t num_blocks) {
+  if (*coding == nullptr) return QSX_OK;
+  if ((*coding)->block_code_width == nullptr) {
+    *coding = nullptr;
+    return QSX_OK;
+  }
+  bool any = false;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    const int w = (*coding)->block_code_width[b];
+    if (w != 0 && w != 1 && w != 2 && w != 4) return QSX_ERR_INVALID_ARGUMENT;
+    if (w == 0 && (*coding)->block_dictionaries != nullptr && (*coding)->block_dictionaries[b] != nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    any = any || w != 0;
+  }
+  if (!any) *coding = nullptr;   // every stripe holds values: the plain run
+  return QSX_OK;
+}
+
+static int join_build_blocks_impl(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                          const int32_t *block_base_tids, const uint64_t *const *block_filters, const qsx_key_coding_t *coding, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (t == nullptr || num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr || block_base_tids == nullptr))) {
     return QSX_ERR_INVALID_ARGUMENT;
   }
+  if (check_key_coding(&coding, num_blocks) != QSX_OK) return QSX_ERR_INVALID_ARGUMENT;
   std::vector<int64_t> base(static_cast<size_t>(num_blocks));
   int64_t total = 0;
   for (int64_t b = 0; b < num_blocks; ++b) {
@@ -1307,7 +1337,9 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
   hipStream_t s = as_stream(stream);
   std::vector<long long> table;
   const long long groups = build_run_table(kBuildTile, num_blocks, block_rows, block_keys,
-                                           reinterpret_cast<const void *const *>(block_filters), nullptr, base.data(), &table);
+                                           reinterpret_cast<const void *const *>(block_filters), nullptr, base.data(), &table,
+                                           coding != nullptr ? coding->block_code_width : nullptr,
+                                           coding != nullptr ? coding->block_dictionaries : nullptr);
   if (groups < 0) return QSX_ERR_INVALID_ARGUMENT;
   const size_t bytes = table.size() * sizeof(long long);
   const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
@@ -1335,6 +1367,16 @@ int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
   QSX_CHECK_LAUNCH();
   mark_stream(t, s);
   return QSX_OK;
+}
+
+int qsx_join_build_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                          const int32_t *block_base_tids, const uint64_t *const *block_filters, qsx_stream_t stream) {
+  return join_build_blocks_impl(t, num_blocks, block_rows, block_keys, block_base_tids, block_filters, nullptr, stream);
+}
+int qsx_join_build_blocks_coded(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                const qsx_key_coding_t *coding, const int32_t *block_base_tids, const uint64_t *const *block_filters,
+                                qsx_stream_t stream) {
+  return join_build_blocks_impl(t, num_blocks, block_rows, block_keys, block_base_tids, block_filters, coding, stream);
 }
 
 }  // extern "C"
@@ -1870,7 +1912,8 @@ static int cover_for(qsx_join_table *t, const ProjectionView &view, int entry_by
 static int upload_probe_run(int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
                             const int32_t *block_base_tids, const uint64_t *const *block_filters, uint64_t *const *block_out,
                             hipStream_t stream, const long long **runs_dev, int64_t *tiles, int64_t *rows_total, bool *any_filter,
-                            const std::vector<long long> *extra = nullptr, const long long **extra_dev = nullptr) {
+                            const std::vector<long long> *extra = nullptr, const long long **extra_dev = nullptr,
+                            const qsx_key_coding_t *coding = nullptr) {
   std::vector<int64_t> base(static_cast<size_t>(num_blocks));
   int64_t total = 0;
   *any_filter = false;
@@ -1884,7 +1927,8 @@ static int upload_probe_run(int64_t num_blocks, const int64_t *block_rows, const
   }
   std::vector<long long> table;
   *tiles = build_run_table(kDenseTile, num_blocks, block_rows, block_keys, reinterpret_cast<const void *const *>(block_filters),
-                           reinterpret_cast<void *const *>(block_out), base.data(), &table);
+                           reinterpret_cast<void *const *>(block_out), base.data(), &table,
+                           coding != nullptr ? coding->block_code_width : nullptr, coding != nullptr ? coding->block_dictionaries : nullptr);
   *rows_total = total;
   if (*tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
   if (*tiles == 0) return QSX_OK;
@@ -1983,9 +2027,9 @@ int qsx_join_probe_exists(qsx_join_table_t *t, const void *keys_dev, int64_t n,
                          out_bitmap_dev, anti, as_stream(stream));
 }
 
-int qsx_join_probe_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+static int join_probe_blocks_impl(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
                           const int32_t *block_base_tids, const uint64_t *const *block_filters, int32_t *out_probe_tid_dev,
-                          int32_t *out_build_tid_dev, int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream) {
+                          int32_t *out_build_tid_dev, int64_t capacity, int64_t *out_count_dev, const qsx_key_coding_t *coding, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (t == nullptr || num_blocks < 0 || capacity < 0 || out_count_dev == nullptr ||
       (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr)) ||
@@ -1996,17 +2040,20 @@ int qsx_join_probe_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t
   const long long *runs_dev = nullptr;
   int64_t tiles = 0, rows = 0;
   bool any_filter = false;
+  if (check_key_coding(&coding, num_blocks) != QSX_OK) return QSX_ERR_INVALID_ARGUMENT;
   const int rc = upload_probe_run(num_blocks, block_rows, block_keys, block_base_tids, block_filters, nullptr, s, &runs_dev, &tiles,
-                                  &rows, &any_filter);
+                                  &rows, &any_filter, nullptr, nullptr, coding);
   if (rc != QSX_OK) return rc;
   const uint64_t *filter_mark = any_filter ? reinterpret_cast<const uint64_t *>(runs_dev) : nullptr;   // only tested against NULL
   return launch_probe<0, true>(t, nullptr, rows, 0, filter_mark, out_probe_tid_dev, out_build_tid_dev, capacity, out_count_dev,
                                nullptr, 0, s, runs_dev, tiles);
 }
 
-int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+static int join_probe_count_blocks_impl(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                        const uint64_t *const *block_filters, int64_t *out_count_dev, const qsx_key_coding_t *coding, qsx_stream_t stream);
+static int join_probe_project_blocks_impl(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
                                   const uint64_t *const *block_filters, const qsx_join_projection_t *proj, int64_t capacity,
-                                  int64_t *out_count_dev, qsx_stream_t stream) {
+                                  int64_t *out_count_dev, const qsx_key_coding_t *coding, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (t == nullptr || num_blocks < 0 || capacity < 0 || out_count_dev == nullptr || proj == nullptr ||
       (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr)) || proj->num_columns < 1 ||
@@ -2031,9 +2078,18 @@ int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const
   hipStream_t s = as_stream(stream);
   if (capacity == 0 || (any_build && proj->num_build_segments == 0)) {
     // nowhere to write, or a build side without tuples (nothing can match): the count only
-    return qsx_join_probe_count_blocks(t, num_blocks, block_rows, block_keys, block_filters, out_count_dev, stream);
+    return join_probe_count_blocks_impl(t, num_blocks, block_rows, block_keys, block_filters, out_count_dev, coding, stream);
   }
+  if (check_key_coding(&coding, num_blocks) != QSX_OK) return QSX_ERR_INVALID_ARGUMENT;
   qsx_join_table *direct = t->dense ? t : sealed_shadow(t, s);
+  if (direct == nullptr && coding != nullptr) {
+    // (the gather below reads values: a projected column that IS a coded key stripe has none — the caller presents the decoded stripe)
+    for (int64_t b = 0; b < num_blocks; ++b) {
+      for (int c = 0; c < nc && coding->block_code_width[b] != 0 && block_rows[b] > 0; ++c) {
+        if (proj->on_build[c] == 0 && proj->probe_stripes[static_cast<size_t>(b) * nc + c] == block_keys[b]) return QSX_ERR_UNSUPPORTED;
+      }
+    }
+  }
   if (direct == nullptr) {
     // No directly addressed form of this table: the pair list after all, in scratch of this call, and one gather per column.
     int64_t total_rows = 0;
@@ -2043,8 +2099,8 @@ int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const
     int32_t *pairs = nullptr;
     QSX_HIP_TRY(device_malloc(reinterpret_cast<void **>(&pairs), static_cast<size_t>(capacity) * 8 + 16));
     int32_t *probe_tids = pairs, *build_tids = pairs + capacity;
-    int rc = qsx_join_probe_blocks(t, num_blocks, block_rows, block_keys, nullptr, block_filters, probe_tids, build_tids, capacity,
-                                   out_count_dev, stream);
+    int rc = join_probe_blocks_impl(t, num_blocks, block_rows, block_keys, nullptr, block_filters, probe_tids, build_tids, capacity,
+                                    out_count_dev, coding, stream);
     // how many pairs there are to gather (this path synchronises anyway: the pair list is released before it returns)
     int64_t pairs_found = 0;
     if (rc == QSX_OK && (hipMemcpyAsync(&pairs_found, out_count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -2131,7 +2187,7 @@ int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const
   int64_t tiles = 0, rows = 0;
   bool any_filter = false;
   const int rc = upload_probe_run(num_blocks, block_rows, block_keys, nullptr, block_filters, nullptr, s, &runs_dev, &tiles, &rows,
-                                  &any_filter, &table, &proj_dev);
+                                  &any_filter, &table, &proj_dev, coding);
   if (rc != QSX_OK) return rc;
   QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
   if (rows == 0) return QSX_OK;
@@ -2167,8 +2223,8 @@ int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const
   return QSX_OK;
 }
 
-int qsx_join_probe_count_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
-                                const uint64_t *const *block_filters, int64_t *out_count_dev, qsx_stream_t stream) {
+static int join_probe_count_blocks_impl(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                const uint64_t *const *block_filters, int64_t *out_count_dev, const qsx_key_coding_t *coding, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (t == nullptr || num_blocks < 0 || out_count_dev == nullptr || (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr))) {
     return QSX_ERR_INVALID_ARGUMENT;
@@ -2177,15 +2233,16 @@ int qsx_join_probe_count_blocks(qsx_join_table_t *t, int64_t num_blocks, const i
   const long long *runs_dev = nullptr;
   int64_t tiles = 0, rows = 0;
   bool any_filter = false;
+  if (check_key_coding(&coding, num_blocks) != QSX_OK) return QSX_ERR_INVALID_ARGUMENT;
   const int rc = upload_probe_run(num_blocks, block_rows, block_keys, nullptr, block_filters, nullptr, s, &runs_dev, &tiles, &rows,
-                                  &any_filter);
+                                  &any_filter, nullptr, nullptr, coding);
   if (rc != QSX_OK) return rc;
   return launch_probe<1, true>(t, nullptr, rows, 0, nullptr, nullptr, nullptr, 0, out_count_dev, nullptr, 0, s, runs_dev, tiles);
 }
 
-int qsx_join_probe_exists_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+static int join_probe_exists_blocks_impl(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
                                  const uint64_t *const *block_filters, int anti, uint64_t *const *block_out_bitmaps,
-                                 int64_t *out_count_dev, qsx_stream_t stream) {
+                                 int64_t *out_count_dev, const qsx_key_coding_t *coding, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (t == nullptr || num_blocks < 0 ||
       (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr || block_out_bitmaps == nullptr))) {
@@ -2195,10 +2252,54 @@ int qsx_join_probe_exists_blocks(qsx_join_table_t *t, int64_t num_blocks, const 
   const long long *runs_dev = nullptr;
   int64_t tiles = 0, rows = 0;
   bool any_filter = false;
+  if (check_key_coding(&coding, num_blocks) != QSX_OK) return QSX_ERR_INVALID_ARGUMENT;
   const int rc = upload_probe_run(num_blocks, block_rows, block_keys, nullptr, block_filters, block_out_bitmaps, s, &runs_dev,
-                                  &tiles, &rows, &any_filter);
+                                  &tiles, &rows, &any_filter, nullptr, nullptr, coding);
   if (rc != QSX_OK) return rc;
   return launch_probe<2, true>(t, nullptr, rows, 0, nullptr, nullptr, nullptr, 0, out_count_dev, nullptr, anti, s, runs_dev, tiles);
+}
+
+int qsx_join_probe_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                          const int32_t *block_base_tids, const uint64_t *const *block_filters, int32_t *out_probe_tid_dev,
+                          int32_t *out_build_tid_dev, int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream) {
+  return join_probe_blocks_impl(t, num_blocks, block_rows, block_keys, block_base_tids, block_filters, out_probe_tid_dev, out_build_tid_dev,
+                                capacity, out_count_dev, nullptr, stream);
+}
+int qsx_join_probe_blocks_coded(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                const qsx_key_coding_t *coding, const int32_t *block_base_tids, const uint64_t *const *block_filters,
+                                int32_t *out_probe_tid_dev, int32_t *out_build_tid_dev, int64_t capacity, int64_t *out_count_dev,
+                                qsx_stream_t stream) {
+  return join_probe_blocks_impl(t, num_blocks, block_rows, block_keys, block_base_tids, block_filters, out_probe_tid_dev, out_build_tid_dev,
+                                capacity, out_count_dev, coding, stream);
+}
+int qsx_join_probe_project_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                  const uint64_t *const *block_filters, const qsx_join_projection_t *proj, int64_t capacity,
+                                  int64_t *out_count_dev, qsx_stream_t stream) {
+  return join_probe_project_blocks_impl(t, num_blocks, block_rows, block_keys, block_filters, proj, capacity, out_count_dev, nullptr, stream);
+}
+int qsx_join_probe_project_blocks_coded(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                        const qsx_key_coding_t *coding, const uint64_t *const *block_filters,
+                                        const qsx_join_projection_t *proj, int64_t capacity, int64_t *out_count_dev, qsx_stream_t stream) {
+  return join_probe_project_blocks_impl(t, num_blocks, block_rows, block_keys, block_filters, proj, capacity, out_count_dev, coding, stream);
+}
+int qsx_join_probe_count_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                const uint64_t *const *block_filters, int64_t *out_count_dev, qsx_stream_t stream) {
+  return join_probe_count_blocks_impl(t, num_blocks, block_rows, block_keys, block_filters, out_count_dev, nullptr, stream);
+}
+int qsx_join_probe_count_blocks_coded(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                      const qsx_key_coding_t *coding, const uint64_t *const *block_filters, int64_t *out_count_dev,
+                                      qsx_stream_t stream) {
+  return join_probe_count_blocks_impl(t, num_blocks, block_rows, block_keys, block_filters, out_count_dev, coding, stream);
+}
+int qsx_join_probe_exists_blocks(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                 const uint64_t *const *block_filters, int anti, uint64_t *const *block_out_bitmaps,
+                                 int64_t *out_count_dev, qsx_stream_t stream) {
+  return join_probe_exists_blocks_impl(t, num_blocks, block_rows, block_keys, block_filters, anti, block_out_bitmaps, out_count_dev, nullptr, stream);
+}
+int qsx_join_probe_exists_blocks_coded(qsx_join_table_t *t, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                       const qsx_key_coding_t *coding, const uint64_t *const *block_filters, int anti,
+                                       uint64_t *const *block_out_bitmaps, int64_t *out_count_dev, qsx_stream_t stream) {
+  return join_probe_exists_blocks_impl(t, num_blocks, block_rows, block_keys, block_filters, anti, block_out_bitmaps, out_count_dev, coding, stream);
 }
 
 }  // extern "C"

@@ -98,10 +98,17 @@ __global__ __launch_bounds__(kDBlock) void dense_build_kernel(DenseTableView t, 
   };
   auto request = [&](const Source &src, KeyT (&k)[R], uint64_t &fw) {
     const int64_t sw0 = src.base >> 6;
+    if (kRuns && src.code_width != 0) {   // a compressed key stripe (block_runs.hpp): read as it lies
+      coded_keys(src, k, [&](int r) {
+        const int64_t row = ((sw0 + r) << 6) + lane;
+        return row < src.n ? row : src.n - 1;
+      });
+    } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t row = ((sw0 + r) << 6) + lane;
-      k[r] = load_global(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded: no branch around the read
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = ((sw0 + r) << 6) + lane;
+        k[r] = load_global(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded: no branch around the read
+      }
     }
     fw = ~0ull;
     if (src.filter != nullptr && lane < R && sw0 + lane < ((src.n + 63) >> 6)) fw = load_global(&src.filter[sw0 + lane]);
@@ -232,10 +239,17 @@ __device__ __forceinline__ const char *projected_build_value(const ProjectionVie
   return p.build_stripe(seg, c) + static_cast<size_t>(tid - static_cast<uint32_t>(first[seg])) * width;
 }
 // One projected tuple (the duplicate chains' path: one match at a time).
-__device__ __forceinline__ void project_one(const ProjectionView &p, int block, int64_t probe_row, uint32_t tid, unsigned long long o) {
+// (tile: the probe tile's source — a projected column that is the coded key stripe itself comes out as the key's value)
+template <typename KeyT>
+__device__ __forceinline__ void project_one(const ProjectionView &p, const ProbeTileSource<KeyT> &tile, int64_t probe_row, uint32_t tid,
+                                            unsigned long long o) {
   for (int c = 0; c < p.nc; ++c) {
     const int width = p.width(c);
-    const char *src = p.on_build(c) ? projected_build_value(p, c, width, tid) : p.probe_stripe(block, c) + static_cast<size_t>(probe_row) * width;
+    if (!p.on_build(c) && tile.code_width != 0 && p.is_probe_key(c)) {
+      store_value(p.out(c) + o * width, static_cast<unsigned long long>(coded_key(tile, probe_row)), width);
+      continue;
+    }
+    const char *src = p.on_build(c) ? projected_build_value(p, c, width, tid) : p.probe_stripe(tile.block, c) + static_cast<size_t>(probe_row) * width;
     store_value(p.out(c) + o * width, load_value(src, width), width);
   }
 }
@@ -332,10 +346,17 @@ __global__ __launch_bounds__(kDBlock) __attribute__((amdgpu_waves_per_eu(MODE ==
   KeyT key[R], next_key[R];
   uint64_t filter_words = ~0ull, next_filter_words = ~0ull;
   auto request = [&](const Source &src, KeyT (&k)[R], uint64_t &words) {
+    if (kRuns && src.code_width != 0) {   // a compressed key stripe (block_runs.hpp): read as it lies
+      coded_keys(src, k, [&](int r) {
+        const int64_t row = src.base + r * kDBlock + threadIdx.x;
+        return row < src.n ? row : src.n - 1;
+      });
+    } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t row = src.base + r * kDBlock + threadIdx.x;
-      k[r] = load_global_nt(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = src.base + r * kDBlock + threadIdx.x;
+        k[r] = load_global_nt(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded
+      }
     }
     words = ~0ull;
     if (src.filter != nullptr && lane < R) {
@@ -359,6 +380,7 @@ __global__ __launch_bounds__(kDBlock) __attribute__((amdgpu_waves_per_eu(MODE ==
     const int32_t base_tid = cur.base_tid;
     uint64_t *const tile_bitmap = cur.out_bitmap;
     const int tile_block = cur.block;
+    const Source tile_src = cur;   // (MODE 5: a projected column that IS a coded key stripe is read through the tile's coding)
     cur = next;
     // Row r of this thread: tile_base + r * 256 + tid; a wave owns 64 consecutive rows per r (the workgroup reads 1 KiB
     // contiguous per step: the wave-contiguous mapping measured 8 % slower).
@@ -479,6 +501,14 @@ __global__ __launch_bounds__(kDBlock) __attribute__((amdgpu_waves_per_eu(MODE ==
                   const char *src = h[r] != 0u ? projected_build_value(proj, c, sizeof(V), h[r] - 1u) : dst;
                   v[i] = load_global(reinterpret_cast<const V *>(src));
                 }
+              } else if (kRuns && sizeof(V) == sizeof(KeyT) && tile_src.code_width != 0 && proj.is_probe_key(c)) {
+                // the join attribute itself over a block that holds it compressed (qsx_join_probe_project_blocks_coded): the
+                // column's stripe is the key's code stripe, the value what the code stands for
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                  const int64_t row = tile_base + (half * H + i) * kDBlock + threadIdx.x;
+                  v[i] = static_cast<V>(coded_key(tile_src, row < n_rows ? row : n_rows - 1));
+                }
               } else {
 #pragma unroll
                 for (int i = 0; i < H; ++i) {
@@ -567,7 +597,7 @@ __global__ __launch_bounds__(kDBlock) __attribute__((amdgpu_waves_per_eu(MODE ==
             const int leader = __ffsll(static_cast<long long>(cm)) - 1;
             if (lane == leader) at = atomicAdd(out_count, static_cast<unsigned long long>(__popcll(cm)));
             at = __shfl(at, leader, kWave) + rank_below(cm);
-            if (cur != 0u && at < capacity) project_one(proj, tile_block, row, tid, at);
+            if (cur != 0u && at < capacity) project_one(proj, tile_src, row, tid, at);
           } else {   // the wave's run continues behind its first-level matches, in the order the counting pass saw
             const uint64_t cm = __ballot(cur != 0u);
             const unsigned long long o = base + rank_below(cm);
@@ -622,10 +652,17 @@ __global__ __launch_bounds__(BLOCK) void cover_probe_kernel(DenseTableView t, in
     CoverT e[R];
     KeyT key[R];   // (kept for projected columns that ARE the probe key)
     {
+      if (src.code_width != 0) {   // a compressed key stripe (block_runs.hpp): read as it lies
+        coded_keys(src, key, [&](int r) {
+          const int64_t row = src.base + r * BLOCK + threadIdx.x;
+          return row < src.n ? row : src.n - 1;
+        });
+      } else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t row = src.base + r * BLOCK + threadIdx.x;
-        key[r] = load_global_nt(&src.keys[row < src.n ? row : src.n - 1]);
+        for (int r = 0; r < R; ++r) {
+          const int64_t row = src.base + r * BLOCK + threadIdx.x;
+          key[r] = load_global_nt(&src.keys[row < src.n ? row : src.n - 1]);
+        }
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {   // R independent reads in flight per lane; dead rows read entry 0 and are masked below

@@ -62,10 +62,17 @@ __global__ __launch_bounds__(kLdsBlock) void lds_bucket_probe_kernel(TableView t
         continue;
       }
       const Source src = source_of(tile);
+      if (kRuns && src.code_width != 0) {   // a compressed key stripe (block_runs.hpp): read as it lies
+        coded_keys(src, k[s], [&](int r) {
+          const int64_t row = src.base + r * BLOCK + threadIdx.x;
+          return row < src.n ? row : src.n - 1;
+        });
+      } else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t row = src.base + r * BLOCK + threadIdx.x;
-        k[s][r] = load_global_nt(&src.keys[row < src.n ? row : src.n - 1]);
+        for (int r = 0; r < R; ++r) {
+          const int64_t row = src.base + r * BLOCK + threadIdx.x;
+          k[s][r] = load_global_nt(&src.keys[row < src.n ? row : src.n - 1]);
+        }
       }
       if (src.filter != nullptr && lane < R) {
         const int64_t w = (src.base >> 6) + lane * kWaves + wave;

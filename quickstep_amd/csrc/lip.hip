@@ -34,10 +34,17 @@ __global__ __launch_bounds__(kLBlock) void lip_build_kernel(LipView f, const Key
   auto source_of = [&](int64_t group) { return probe_tile_source<KeyT, R * kWave, kRuns>(runs, group, keys, n_arg, 0, filter, nullptr); };
   auto request = [&](const Source &src, KeyT (&k)[R], uint64_t &fw) {
     const int64_t sw0 = src.base >> 6;
+    if (kRuns && src.code_width != 0) {   // a compressed key stripe (block_runs.hpp): read as it lies
+      coded_keys(src, k, [&](int r) {
+        const int64_t row = ((sw0 + r) << 6) + lane;
+        return row < src.n ? row : src.n - 1;
+      });
+    } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t row = ((sw0 + r) << 6) + lane;
-      k[r] = src.keys[row < src.n ? row : src.n - 1];   // clamped, not guarded: no branch around the read
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = ((sw0 + r) << 6) + lane;
+        k[r] = src.keys[row < src.n ? row : src.n - 1];   // clamped, not guarded: no branch around the read
+      }
     }
     fw = ~0ull;
     if (src.filter != nullptr && lane < R && sw0 + lane < ((src.n + 63) >> 6)) fw = src.filter[sw0 + lane];
@@ -128,10 +135,17 @@ __global__ __launch_bounds__(kInLds ? 1024 : kLBlock) void lip_probe_kernel(LipV
     return probe_tile_source<KeyT, kTileRows, kRuns>(runs, tile, keys, n_arg, 0, in_bitmap_arg, out_bitmap_arg);
   };
   auto request = [&](const Source &src, KeyT (&k)[R], uint64_t &words) {
+    if (kRuns && src.code_width != 0) {   // a compressed key stripe (block_runs.hpp): read as it lies
+      coded_keys(src, k, [&](int r) {
+        const int64_t row = src.base + static_cast<int64_t>(r) * blockDim.x + threadIdx.x;
+        return row < src.n ? row : src.n - 1;
+      });
+    } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t row = src.base + static_cast<int64_t>(r) * blockDim.x + threadIdx.x;
-      k[r] = __builtin_nontemporal_load(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = src.base + static_cast<int64_t>(r) * blockDim.x + threadIdx.x;
+        k[r] = __builtin_nontemporal_load(&src.keys[row < src.n ? row : src.n - 1]);   // clamped, not guarded
+      }
     }
     words = ~0ull;
     if (src.filter != nullptr && lane < R) {
@@ -324,7 +338,16 @@ int qsx_lip_probe(const qsx_lip_filter_t *f, int key_type, const void *keys_dev,
 // The table of a run (block_runs.hpp) on the device; *tiles = its tile count (0: nothing to do).
 static int upload_lip_run(long long tile_rows, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
                           const uint64_t *const *block_in, uint64_t *const *block_out, hipStream_t s, const long long **runs_dev,
-                          long long *tiles) {
+                          long long *tiles, const qsx_key_coding_t *coding = nullptr) {
+  const int32_t *code_widths = coding != nullptr ? coding->block_code_width : nullptr;
+  bool any_coded = false;
+  for (int64_t b = 0; b < num_blocks && code_widths != nullptr; ++b) {
+    const int w = code_widths[b];
+    if (w != 0 && w != 1 && w != 2 && w != 4) return QSX_ERR_INVALID_ARGUMENT;
+    if (w == 0 && coding->block_dictionaries != nullptr && coding->block_dictionaries[b] != nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    any_coded = any_coded || w != 0;
+  }
+  if (!any_coded) code_widths = nullptr;   // every stripe holds values: the plain run
   for (int64_t b = 0; b < num_blocks; ++b) {
     if (block_rows[b] < 0 || (block_rows[b] > 0 && (block_keys[b] == nullptr || (block_out != nullptr && block_out[b] == nullptr)))) {
       return QSX_ERR_INVALID_ARGUMENT;
@@ -332,7 +355,8 @@ static int upload_lip_run(long long tile_rows, int64_t num_blocks, const int64_t
   }
   std::vector<long long> table;
   *tiles = build_run_table(tile_rows, num_blocks, block_rows, block_keys, reinterpret_cast<const void *const *>(block_in),
-                           reinterpret_cast<void *const *>(block_out), nullptr, &table);
+                           reinterpret_cast<void *const *>(block_out), nullptr, &table, code_widths,
+                           code_widths != nullptr ? coding->block_dictionaries : nullptr);
   if (*tiles < 0) return QSX_ERR_INVALID_ARGUMENT;
   if (*tiles == 0) return QSX_OK;
   const size_t bytes = table.size() * sizeof(long long);
@@ -341,15 +365,16 @@ static int upload_lip_run(long long tile_rows, int64_t num_blocks, const int64_t
   return staged_upload(s, table.data(), bytes);
 }
 
-int qsx_lip_build_blocks(qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
-                         const void *const *block_keys, const uint64_t *const *block_filters, qsx_stream_t stream) {
+static int lip_build_blocks_impl(qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                                 const void *const *block_keys, const uint64_t *const *block_filters, const qsx_key_coding_t *coding,
+                                 qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (f == nullptr || num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
   if (key_type != QSX_INT && key_type != QSX_LONG) return QSX_ERR_UNSUPPORTED;
   hipStream_t s = as_stream(stream);
   const long long *runs_dev = nullptr;
   long long groups = 0;
-  const int rc = upload_lip_run(8 * kWave, num_blocks, block_rows, block_keys, block_filters, nullptr, s, &runs_dev, &groups);
+  const int rc = upload_lip_run(8 * kWave, num_blocks, block_rows, block_keys, block_filters, nullptr, s, &runs_dev, &groups, coding);
   if (rc != QSX_OK || groups == 0) return rc;
   const int grid = grid_for(groups, kLBlock / kWave);
   if (key_type == QSX_INT) {
@@ -363,9 +388,19 @@ int qsx_lip_build_blocks(qsx_lip_filter_t *f, int key_type, int64_t num_blocks, 
   return QSX_OK;
 }
 
-int qsx_lip_probe_blocks(const qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
-                         const void *const *block_keys, const uint64_t *const *block_in_bitmaps, uint64_t *const *block_out_bitmaps,
-                         int64_t *out_count_dev, qsx_stream_t stream) {
+int qsx_lip_build_blocks(qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                         const void *const *block_keys, const uint64_t *const *block_filters, qsx_stream_t stream) {
+  return lip_build_blocks_impl(f, key_type, num_blocks, block_rows, block_keys, block_filters, nullptr, stream);
+}
+int qsx_lip_build_blocks_coded(qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                               const void *const *block_keys, const qsx_key_coding_t *coding, const uint64_t *const *block_filters,
+                               qsx_stream_t stream) {
+  return lip_build_blocks_impl(f, key_type, num_blocks, block_rows, block_keys, block_filters, coding, stream);
+}
+
+static int lip_probe_blocks_impl(const qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                                 const void *const *block_keys, const uint64_t *const *block_in_bitmaps, uint64_t *const *block_out_bitmaps,
+                                 int64_t *out_count_dev, const qsx_key_coding_t *coding, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (f == nullptr || num_blocks < 0 || (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr || block_out_bitmaps == nullptr))) {
     return QSX_ERR_INVALID_ARGUMENT;
@@ -382,7 +417,7 @@ int qsx_lip_probe_blocks(const qsx_lip_filter_t *f, int key_type, int64_t num_bl
   const long long *runs_dev = nullptr;
   long long tiles = 0;
   const int rc = upload_lip_run(static_cast<long long>(R) * (in_lds ? 1024 : kLBlock), num_blocks, block_rows, block_keys, block_in_bitmaps,
-                                block_out_bitmaps, s, &runs_dev, &tiles);
+                                block_out_bitmaps, s, &runs_dev, &tiles, coding);
   if (rc != QSX_OK || tiles == 0) return rc;
   if (in_lds) {
     const size_t lds = static_cast<size_t>(words32) * 4;
@@ -414,6 +449,16 @@ int qsx_lip_probe_blocks(const qsx_lip_filter_t *f, int key_type, int64_t num_bl
   }
   QSX_CHECK_LAUNCH();
   return QSX_OK;
+}
+int qsx_lip_probe_blocks(const qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                         const void *const *block_keys, const uint64_t *const *block_in_bitmaps, uint64_t *const *block_out_bitmaps,
+                         int64_t *out_count_dev, qsx_stream_t stream) {
+  return lip_probe_blocks_impl(f, key_type, num_blocks, block_rows, block_keys, block_in_bitmaps, block_out_bitmaps, out_count_dev, nullptr, stream);
+}
+int qsx_lip_probe_blocks_coded(const qsx_lip_filter_t *f, int key_type, int64_t num_blocks, const int64_t *block_rows,
+                               const void *const *block_keys, const qsx_key_coding_t *coding, const uint64_t *const *block_in_bitmaps,
+                               uint64_t *const *block_out_bitmaps, int64_t *out_count_dev, qsx_stream_t stream) {
+  return lip_probe_blocks_impl(f, key_type, num_blocks, block_rows, block_keys, block_in_bitmaps, block_out_bitmaps, out_count_dev, coding, stream);
 }
 
 int qsx_lip_filter_words(qsx_lip_filter_t *f, uint64_t **out_words_dev, int64_t *out_num_words) {

@@ -278,8 +278,9 @@ bool HashInnerJoinWorkOrder::executeRun() {
     // (an anti join over NULL keys: the tuples FOUND among those looked up, then "about AND NOT found" block by block — a
     // tuple that was not looked up was not found and stays)
     const bool anti_by_complement = anti && any_null_key;
-    CheckStatus(qsx_join_probe_exists_blocks(hash_table_, nb, rows.data(), keys.data(), lookup, anti && !anti_by_complement ? 1 : 0,
-                                             bitmaps.data(), static_cast<std::int64_t *>(count.ptr), CurrentStream()),
+    CheckStatus(qsx_join_probe_exists_blocks_coded(hash_table_, nb, rows.data(), keys.data(), run_keys.coding(), lookup,
+                                                   anti && !anti_by_complement ? 1 : 0, bitmaps.data(),
+                                                   static_cast<std::int64_t *>(count.ptr), CurrentStream()),
                 "qsx_join_probe_exists_blocks");
     std::int64_t selected = ReadCount(count.ptr);
     if (anti_by_complement) {
@@ -335,6 +336,7 @@ bool HashInnerJoinWorkOrder::executeRun() {
     proj.num_columns = static_cast<std::int32_t>(nc);
     std::vector<const void *> probe_stripes(blocks.size() * nc, nullptr), build_stripes(nseg * nc, nullptr);
     std::vector<void *> out_columns(nc);
+    bool coded_key_projected = false;
     block_id out_id;
     BlockReference out = output_destination_->getBlockForInsertion(total_rows, &out_id);
     for (std::size_t i = 0; i < nc; ++i) {
@@ -345,7 +347,13 @@ bool HashInnerJoinWorkOrder::executeRun() {
       if (on_build) {
         for (std::size_t sg = 0; sg < nseg; ++sg) build_stripes[sg * nc + i] = build.refs[sg]->stripe(selection_[i]);
       } else {
-        for (std::size_t b = 0; b < blocks.size(); ++b) probe_stripes[b * nc + i] = blocks[b]->stripe(selection_[i]);
+        // (the join attribute itself over blocks that hold it compressed: given as the key stripes, the probe emits its value —
+        // qsx_join_probe_project_blocks_coded — and the attribute is not decoded for the sake of this column)
+        const bool is_coded_key = run_keys.coded && join_key_attributes_.size() == 1 && selection_[i] == join_key_attributes_.front();
+        coded_key_projected = coded_key_projected || is_coded_key;
+        for (std::size_t b = 0; b < blocks.size(); ++b) {
+          probe_stripes[b * nc + i] = is_coded_key ? keys[b] : blocks[b]->stripe(selection_[i]);
+        }
       }
     }
     proj.probe_stripes = probe_stripes.data();
@@ -353,9 +361,18 @@ bool HashInnerJoinWorkOrder::executeRun() {
     proj.build_first_tids = build.first_rows.data();
     proj.build_stripes = build_stripes.data();
     proj.out_columns = out_columns.data();
-    CheckStatus(qsx_join_probe_project_blocks(hash_table_, nb, rows.data(), keys.data(), lookup, &proj, total_rows,
-                                              static_cast<std::int64_t *>(count.ptr), CurrentStream()),
-                "qsx_join_probe_project_blocks");
+    int project_status = qsx_join_probe_project_blocks_coded(hash_table_, nb, rows.data(), keys.data(), run_keys.coding(), lookup, &proj,
+                                                             total_rows, static_cast<std::int64_t *>(count.ptr), CurrentStream());
+    if (project_status == QSX_ERR_UNSUPPORTED && coded_key_projected) {
+      // a table without a directly addressed form gathers the output from the stripes: the key column as decoded values then
+      for (std::size_t i = 0; i < nc; ++i) {
+        if (is_selection_on_build_[i] || selection_[i] != join_key_attributes_.front()) continue;
+        for (std::size_t b = 0; b < blocks.size(); ++b) probe_stripes[b * nc + i] = blocks[b]->stripe(selection_[i]);
+      }
+      project_status = qsx_join_probe_project_blocks_coded(hash_table_, nb, rows.data(), keys.data(), run_keys.coding(), lookup, &proj,
+                                                           total_rows, static_cast<std::int64_t *>(count.ptr), CurrentStream());
+    }
+    CheckStatus(project_status, "qsx_join_probe_project_blocks");
     const std::int64_t matches = ReadCount(count.ptr);   // (synchronises the stream: the block's tuples are written)
     if (matches <= total_rows) {
       output_destination_->returnBlock(out_id, matches, getPartitionId());
@@ -375,8 +392,9 @@ bool HashInnerJoinWorkOrder::executeRun() {
   for (int attempt = 0; attempt < 2; ++attempt) {
     pairs.probe_tids.reset(new DeviceBuffer(static_cast<std::size_t>(room) * 4 + 8));
     pairs.build_tids.reset(new DeviceBuffer(static_cast<std::size_t>(room) * 4 + 8));
-    CheckStatus(qsx_join_probe_blocks(hash_table_, nb, rows.data(), keys.data(), base_tids.empty() ? nullptr : base_tids.data(), lookup,
-                                      static_cast<std::int32_t *>(pairs.probe_tids->ptr),
+    CheckStatus(qsx_join_probe_blocks_coded(hash_table_, nb, rows.data(), keys.data(), run_keys.coding(),
+                                            base_tids.empty() ? nullptr : base_tids.data(), lookup,
+                                            static_cast<std::int32_t *>(pairs.probe_tids->ptr),
                                       static_cast<std::int32_t *>(pairs.build_tids->ptr), room, static_cast<std::int64_t *>(count.ptr),
                                       CurrentStream()), "qsx_join_probe_blocks");
     pairs.count = ReadCount(count.ptr);

@@ -1095,16 +1095,17 @@ void LIPFilterBuilder::insertValueAccessor(const StorageBlock &block, const std:
 bool LIPFilterBuilder::insertBlocks(const std::vector<BlockReference> &blocks) const {
   for (const auto &e : entries_) {
     for (const BlockReference &b : blocks) {
-      if (b->nullBitmap(e.second) != nullptr) return false;   // (a compressed attribute is read through stripe(): decoded once)
+      if (b->nullBitmap(e.second) != nullptr) return false;   // (a compressed attribute is read as it lies: RunJoinKeys)
     }
   }
   std::vector<std::int64_t> rows;
   for (const BlockReference &b : blocks) rows.push_back(b->numTuples());
-  std::vector<const void *> keys(blocks.size());
   for (const auto &e : entries_) {
-    for (std::size_t b = 0; b < blocks.size(); ++b) keys[b] = blocks[b]->stripe(e.second);
-    CheckStatus(qsx_lip_build_blocks(e.first, blocks.front()->getRelation().getAttributeType(e.second).id,
-                                     static_cast<std::int64_t>(blocks.size()), rows.data(), keys.data(), nullptr, CurrentStream()),
+    // (INT / LONG attributes — the key types of a LIP filter — that a block holds compressed are read as they lie)
+    const RunJoinKeys keys(blocks, {e.second}, rows);
+    CheckStatus(qsx_lip_build_blocks_coded(e.first, blocks.front()->getRelation().getAttributeType(e.second).id,
+                                           static_cast<std::int64_t>(blocks.size()), rows.data(), keys.ptr.data(), keys.coding(), nullptr,
+                                           CurrentStream()),
                 "qsx_lip_build_blocks");
   }
   return true;
@@ -1142,7 +1143,7 @@ bool LIPFilterAdaptiveProber::filterBlocks(const std::vector<BlockReference> &bl
   *storage = nullptr;
   for (const auto &e : entries_) {
     for (const BlockReference &b : blocks) {
-      if (b->nullBitmap(e.second) != nullptr) return false;   // (a compressed attribute is read through stripe(): decoded once)
+      if (b->nullBitmap(e.second) != nullptr) return false;   // (a compressed attribute is read as it lies: RunJoinKeys)
     }
   }
   const std::size_t nb = blocks.size();
@@ -1161,14 +1162,14 @@ bool LIPFilterAdaptiveProber::filterBlocks(const std::vector<BlockReference> &bl
     nxt[b] = static_cast<std::uint64_t *>(*storage) + words + at;
     at += static_cast<std::size_t>((rows[b] + 63) / 64) + 1;
   }
-  std::vector<const void *> keys(nb);
   DeviceBuffer count(8);
   bool first = true;
   for (const auto &e : entries_) {
-    for (std::size_t b = 0; b < nb; ++b) keys[b] = blocks[b]->stripe(e.second);
-    CheckStatus(qsx_lip_probe_blocks(e.first, blocks.front()->getRelation().getAttributeType(e.second).id, static_cast<std::int64_t>(nb),
-                                     rows.data(), keys.data(), first ? nullptr : reinterpret_cast<const std::uint64_t *const *>(cur.data()),
-                                     nxt.data(), static_cast<std::int64_t *>(count.ptr), CurrentStream()), "qsx_lip_probe_blocks");
+    const RunJoinKeys keys(blocks, {e.second}, rows);   // (a compressed INT / LONG attribute: its code stripes, as they lie)
+    CheckStatus(qsx_lip_probe_blocks_coded(e.first, blocks.front()->getRelation().getAttributeType(e.second).id, static_cast<std::int64_t>(nb),
+                                           rows.data(), keys.ptr.data(), keys.coding(),
+                                           first ? nullptr : reinterpret_cast<const std::uint64_t *const *>(cur.data()), nxt.data(),
+                                           static_cast<std::int64_t *>(count.ptr), CurrentStream()), "qsx_lip_probe_blocks");
     std::swap(cur, nxt);
     first = false;
   }

@@ -193,22 +193,43 @@ struct JoinKeys {
 
 // The key stripes of a run of blocks as the join table sees them: the attribute's stripes, or — composite key — one stripe of
 // packed keys for the whole run (qsx_join_key_pack_blocks), block b's keys at row first_rows[b] of it.
+//
+// A single INT / LONG key attribute that a block holds COMPRESSED (CompressedColumnStore: truncated values or dictionary codes,
+// each block its own choice) is presented as it lies — ptr[b] = the code stripe, code_width[b] / dictionary[b] its coding — for
+// the *_blocks_coded entry points (include/qsx.h qsx_key_coding_t): the kernels widen or look up the codes themselves, the
+// attribute is never decoded into a stripe of values (StorageBlock::stripe would on first use).  coding() is nullptr when no
+// block of the run is compressed in its key.
 struct RunJoinKeys {
   std::vector<const void *> ptr;          // per block
+  std::vector<std::int32_t> code_width;   // per block: 0 = values
+  std::vector<const void *> dictionary;   // per block: nullptr = values / truncated values
+  bool coded = false;
   bool exact = true;
   std::unique_ptr<DeviceBuffer> packed;
   std::vector<std::unique_ptr<DeviceBuffer>> char_keys;
+  qsx_key_coding_t coding_{nullptr, nullptr};
+  const qsx_key_coding_t *coding() const { return coded ? &coding_ : nullptr; }
   RunJoinKeys(const std::vector<BlockReference> &blocks, const std::vector<attribute_id> &attrs, const std::vector<std::int64_t> &rows) {
     const CatalogRelation &relation = blocks.front()->getRelation();
     if (attrs.size() == 1) {
+      const TypeID key_type = relation.getAttributeType(attrs.front()).id;
       for (const BlockReference &b : blocks) {
-        if (relation.getAttributeType(attrs.front()).id == kChar) {
+        const CompressedAttribute *c = (key_type == kInt || key_type == kLong) ? b->compressedAttribute(attrs.front()) : nullptr;
+        if (key_type == kChar) {
           char_keys.push_back(CharKeyAsLong(*b, attrs.front()));
           ptr.push_back(char_keys.back()->ptr);
+        } else if (c != nullptr && b->numTuples() > 0) {
+          ptr.push_back(c->codes);
+          coded = true;
         } else {
           ptr.push_back(b->stripe(attrs.front()));
+          c = nullptr;
         }
+        code_width.push_back(c != nullptr && key_type != kChar ? c->code_width : 0);
+        dictionary.push_back(c != nullptr && key_type != kChar && c->kind == CompressedAttribute::kDictionary ? c->dictionary : nullptr);
       }
+      coding_.block_code_width = code_width.data();
+      coding_.block_dictionaries = dictionary.data();
       return;
     }
     std::vector<const void *> cols;

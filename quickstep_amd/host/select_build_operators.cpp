@@ -405,7 +405,7 @@ bool BuildHashWorkOrder::executeRun() {
     blocks.push_back(storage_manager_->getBlock(id));
     const StorageBlock &b = *blocks.back();
     for (attribute_id a : join_key_attributes_) {
-      if (b.nullBitmap(a) != nullptr) return false;   // (compressed key: stripe() decodes once)
+      if (b.nullBitmap(a) != nullptr) return false;   // (compressed key: read as it lies, RunJoinKeys)
     }
     if (b.firstRow() + b.numTuples() > INT32_MAX) return false;
     rows.push_back(b.numTuples());
@@ -414,8 +414,8 @@ bool BuildHashWorkOrder::executeRun() {
   if (lip_filter_builder_ != nullptr && !lip_filter_builder_->insertBlocks(blocks)) return false;   // BuildHashOperator.cpp:187-190
   const RunJoinKeys run_keys(blocks, join_key_attributes_, rows);
   const std::vector<const void *> &keys = run_keys.ptr;
-  CheckStatus(qsx_join_build_blocks(hash_table_, static_cast<std::int64_t>(blocks.size()), rows.data(), keys.data(), bases.data(), nullptr,
-                                    CurrentStream()), "qsx_join_build_blocks");
+  CheckStatus(qsx_join_build_blocks_coded(hash_table_, static_cast<std::int64_t>(blocks.size()), rows.data(), keys.data(), run_keys.coding(),
+                                          bases.data(), nullptr, CurrentStream()), "qsx_join_build_blocks");
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
   return true;
 }

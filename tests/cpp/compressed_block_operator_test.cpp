@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <tuple>
 
 #include "test_util.hpp"
 
@@ -323,6 +324,170 @@ void testQ1OverCompressedBlocks() {
   }
   unsetenv("QSX_AGG_FACTORED_MIN_ROWS");
 }
+
+// ---- joins directly on compressed key stripes ------------------------------------------------------------------------------------
+// (csrc/block_runs.hpp "Coded key stripes", include/qsx.h qsx_key_coding_t.)  BuildHash and HashJoin work orders over runs of
+// CompressedColumnStore blocks hand the join attribute to the kernels as it lies — per block: 2- or 4-byte truncated values,
+// 1-byte dictionary codes — where the reference reads it through CompressedTupleStorageSubBlock::getAttributeValue
+// (storage/CompressedTupleStorageSubBlock.hpp:225-300).  Same output as over plain blocks, and no block's key attribute is
+// ever decoded into a stripe of values (valuesMaterialized stays false) — neither by the build, the probe, the LIP filters,
+// nor by the projection of the join attribute itself.
+constexpr std::int64_t kDimRows = 120000, kDimBlock = 40000, kFactRows = 250000, kFactBlock = 50000;
+struct JoinRows {
+  std::vector<std::int64_t> d_key, f_key;
+  std::vector<double> d_val;
+  std::vector<std::int32_t> f_qty;
+  JoinRows() {
+    std::uint64_t x = 0x2545F4914F6CDD1Dull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (std::int64_t i = 0; i < kDimRows; ++i) {
+      d_key.push_back(i);                       // block 0: < 2^16, truncated to 2 bytes; blocks 1, 2: 17 bits, 4 bytes
+      d_val.push_back(0.5 * static_cast<double>(i) + 7.0);
+    }
+    std::vector<std::int64_t> few;
+    for (int i = 0; i < 200; ++i) few.push_back(static_cast<std::int64_t>(rnd() % 150000));
+    for (std::int64_t i = 0; i < kFactRows; ++i) {
+      const std::int64_t block = i / kFactBlock;
+      // blocks 1 and 3 draw from 200 keys (1-byte dictionary codes), the others from 0 .. 149999 (4-byte truncation; a fifth misses)
+      f_key.push_back(block % 2 == 1 ? few[rnd() % few.size()] : static_cast<std::int64_t>(rnd() % 150000));
+      f_qty.push_back(static_cast<std::int32_t>(rnd() % 50));
+    }
+  }
+};
+struct JoinOut {
+  std::vector<std::int64_t> key;
+  std::vector<std::int32_t> qty;
+  std::vector<double> val;
+};
+JoinOut runCompressedJoin(const JoinRows &rows, bool compressed, bool exact_stats, std::size_t per_work_order, bool use_foreman,
+                          HashJoinOperator::JoinType join_type, bool with_lip) {
+  CatalogRelation dim(1, "dim"), fact(2, "fact"), result(3, "result");
+  StorageManager storage;
+  dim.addAttribute("d_key", Type::Long());
+  dim.addAttribute("d_val", Type::Double());
+  fact.addAttribute("f_key", Type::Long());
+  fact.addAttribute("f_qty", Type::Int());
+  const std::vector<bool> both(2, true);
+  for (std::int64_t at = 0; at < kDimRows; at += kDimBlock) {
+    storage.loadBlock(&dim, {rows.d_key.data() + at, rows.d_val.data() + at}, kDimBlock, 0, compressed ? &both : nullptr);
+  }
+  for (std::int64_t at = 0; at < kFactRows; at += kFactBlock) {
+    storage.loadBlock(&fact, {rows.f_key.data() + at, rows.f_qty.data() + at}, kFactBlock, 0, compressed ? &both : nullptr);
+  }
+  if (compressed) {
+    const auto d = dim.getBlocksSnapshot(), f = fact.getBlocksSnapshot();
+    const CompressedAttribute *d0 = storage.getBlock(d[0])->compressedAttribute(0), *d2 = storage.getBlock(d[2])->compressedAttribute(0);
+    const CompressedAttribute *f0 = storage.getBlock(f[0])->compressedAttribute(0), *f1 = storage.getBlock(f[1])->compressedAttribute(0);
+    EXPECT_TRUE(d0 != nullptr && d0->kind == CompressedAttribute::kTruncated && d0->code_width == 2);
+    EXPECT_TRUE(d2 != nullptr && d2->kind == CompressedAttribute::kTruncated && d2->code_width == 4);
+    EXPECT_TRUE(f0 != nullptr && f0->kind == CompressedAttribute::kTruncated && f0->code_width == 4);
+    EXPECT_TRUE(f1 != nullptr && f1->kind == CompressedAttribute::kDictionary && f1->code_width == 1);
+  }
+  const bool inner = join_type == HashJoinOperator::JoinType::kInnerJoin;
+  QueryContext ctx;
+  const QueryContext::ExactKeyRange range{0, kDimRows - 1};
+  const auto table = ctx.addJoinHashTable(kLong, kDimRows, 1, exact_stats ? &range : nullptr);
+  const auto dest = ctx.addInsertDestination(&result, &storage);
+  std::vector<bool> on_build;
+  QueryContext::scalar_group_id selection;
+  if (inner) {
+    result.addAttribute("f_key", Type::Long());
+    result.addAttribute("f_qty", Type::Int());
+    result.addAttribute("d_val", Type::Double());
+    selection = ctx.addScalarGroup({0, 1, 1});      // the join attribute itself, a probe attribute, a build attribute
+    on_build = {false, false, true};
+  } else {
+    // (a semi / anti join that projected f_key would decode it for the OUTPUT — the compaction copies values; the join does not)
+    result.addAttribute("f_qty", Type::Int());
+    selection = ctx.addScalarGroup({1});
+    on_build = {false};
+  }
+  auto *builder = new BuildHashOperator(0, dim, true, {0}, false, 1, table);
+  auto *prober = new HashJoinOperator(0, dim, fact, true, {0}, false, 1, false, result, dest, table, QueryContext::kInvalidPredicateId,
+                                      selection, &on_build, join_type);
+  auto *cleaner = new DestroyHashOperator(0, 1, table);
+  if (with_lip) {   // a LIP filter on the join attribute: built from the dim's key stripes, probed with the fact's
+    // (the anti join probes no filter: a LIP filter drops the tuples it is after)
+    const auto lip = ctx.addLIPFilter(QSX_LIP_BITVECTOR_EXACT, kDimRows, 0);
+    QueryContext::LIPFilterDeployment build_dep, probe_dep;
+    build_dep.build_entries.push_back({lip, 0});
+    probe_dep.probe_entries.push_back({lip, 0});
+    builder->deployLIPFilters(ctx.addLIPDeployment(build_dep));
+    if (join_type != HashJoinOperator::JoinType::kLeftAntiJoin) prober->deployLIPFilters(ctx.addLIPDeployment(probe_dep));
+  }
+  builder->setBlocksPerWorkOrder(per_work_order);
+  prober->setBlocksPerWorkOrder(per_work_order);
+  std::vector<std::unique_ptr<RelationalOperator>> owned;
+  if (use_foreman) {
+    QueryPlan plan;
+    const auto b = plan.addRelationalOperator(builder);
+    const auto pr = plan.addRelationalOperator(prober);
+    const auto c = plan.addRelationalOperator(cleaner);
+    plan.addDirectDependency(pr, b, true);
+    plan.addDirectDependency(c, pr, true);
+    ForemanSingleNode foreman(&plan, &ctx, &storage, 4);
+    foreman.run();
+  } else {
+    owned.emplace_back(builder); owned.emplace_back(prober); owned.emplace_back(cleaner);
+    fetchAndExecuteWorkOrders(builder, &ctx, &storage);
+    fetchAndExecuteWorkOrders(prober, &ctx, &storage);
+  }
+  JoinOut out;
+  for (block_id b : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+    BlockReference blk = storage.getBlock(b);
+    const std::size_t at = out.key.size(), k = static_cast<std::size_t>(blk->numTuples());
+    out.key.resize(at + k, 0); out.qty.resize(at + k);
+    blk->copyAttributeToHost(inner ? 1 : 0, out.qty.data() + at);
+    if (inner) {
+      out.val.resize(at + k);
+      blk->copyAttributeToHost(0, out.key.data() + at);
+      blk->copyAttributeToHost(2, out.val.data() + at);
+    }
+  }
+  if (!use_foreman) fetchAndExecuteWorkOrders(cleaner, &ctx, &storage);
+  if (compressed && per_work_order > 1) {   // (a work order over ONE block takes the per-block entry points, which read values)
+    int decoded_dim = 0, decoded_fact = 0;
+    for (block_id b : dim.getBlocksSnapshot()) decoded_dim += storage.getBlock(b)->valuesMaterialized(0) ? 1 : 0;
+    for (block_id b : fact.getBlocksSnapshot()) decoded_fact += storage.getBlock(b)->valuesMaterialized(0) ? 1 : 0;
+    if (decoded_dim != 0 || decoded_fact != 0) {
+      std::fprintf(stderr, "join type %d, exact_stats %d, per work order %zu, foreman %d, lip %d: %d dim and %d fact key stripes were decoded\n",
+                   static_cast<int>(join_type), exact_stats ? 1 : 0, per_work_order, use_foreman ? 1 : 0, with_lip ? 1 : 0, decoded_dim, decoded_fact);
+    }
+    EXPECT_EQ(decoded_dim, 0);
+    EXPECT_EQ(decoded_fact, 0);
+  }
+  return out;
+}
+
+void testJoinsOverCompressedKeys() {
+  const JoinRows rows;
+  for (const auto join_type : {HashJoinOperator::JoinType::kInnerJoin, HashJoinOperator::JoinType::kLeftSemiJoin,
+                               HashJoinOperator::JoinType::kLeftAntiJoin}) {
+    const bool inner = join_type == HashJoinOperator::JoinType::kInnerJoin;
+    // expected: (f_key, f_qty[, d_val]) of the fact rows with / without a partner, as sorted triples
+    std::vector<std::tuple<std::int64_t, std::int32_t, double>> want;
+    for (std::int64_t i = 0; i < kFactRows; ++i) {
+      const bool found = rows.f_key[i] < kDimRows;
+      if (found == (join_type != HashJoinOperator::JoinType::kLeftAntiJoin)) {
+        want.emplace_back(inner ? rows.f_key[i] : 0, rows.f_qty[i], inner ? rows.d_val[rows.f_key[i]] : 0.0);
+      }
+    }
+    std::sort(want.begin(), want.end());
+    for (const int variant : {0, 1, 2, 3, 4, 5, 6}) {
+      const bool compressed = variant != 0;
+      const bool exact_stats = variant == 2 || variant == 4 || variant == 6;
+      const std::size_t per_work_order = variant == 5 ? 1 : (variant <= 2 ? 3 : 8);
+      const bool use_foreman = variant == 3 || variant == 4;
+      const bool with_lip = variant == 6 || variant == 3;
+      const JoinOut got = runCompressedJoin(rows, compressed, exact_stats, per_work_order, use_foreman, join_type, with_lip);
+      std::vector<std::tuple<std::int64_t, std::int32_t, double>> have;
+      for (std::size_t i = 0; i < got.key.size(); ++i) have.emplace_back(got.key[i], got.qty[i], inner ? got.val[i] : 0.0);
+      std::sort(have.begin(), have.end());
+      EXPECT_EQ(have.size(), want.size());
+      EXPECT_TRUE(have == want);
+    }
+  }
+}
 }  // namespace
 
 int main() {
@@ -364,5 +529,6 @@ int main() {
     }
   }
   testQ1OverCompressedBlocks();
+  testJoinsOverCompressedKeys();
   return finish("compressed_block_operator_test");
 }

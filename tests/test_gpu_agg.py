@@ -532,13 +532,13 @@ def _two_level_updates(capi):
 
 
 @pytest.mark.parametrize("groups,keys_kind", [(1_000_000, "int"), (300_000, "int_and_char"), (3_000_000, "int_clustered"), (8_000_000, "int_underestimated")])
-def test_two_level_partitioned_aggregation_for_large_group_counts(capi, dev, groups, keys_kind, monkeypatch):
-    """csrc/agg_pieces.hpp: more groups than one partition pass brings into LDS (est_groups >= 100 K): two stable K9 passes on
+def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, dev, groups, keys_kind, monkeypatch):
+    """csrc/agg_pieces.hpp: more groups than one partition pass brings into LDS (est_groups >= 100 K): two K9 passes on
     digits of the mixing hash order the rows by its top 12 bits, then 4096 pieces of disjoint groups go through workgroup-private
     LDS tables (the partitioned aggregation of storage/AggregationOperationState.cpp:548-614 with partition = piece).  COUNT(*),
     SUM over a DOUBLE, a LONG and an INT column, AVG; groups compared one by one with numpy (COUNT and the integer sums exact);
-    the same plan through the one-pass path (QSX_AGG_TWO_LEVEL_MIN_GROUPS=0) gives the same groups; two update calls, the
-    second one over rows of groups the first has not seen."""
+    the same plan through the one-pass path (QSX_AGG_TWO_LEVEL_MIN_GROUPS=0) and through the oracle gives the same groups;
+    two update calls, the second one over rows of groups the first has not seen."""
     rng = np.random.default_rng(groups % 1000 + 7)
     n = 17_000_017                                                              # two calls of 8.5 M rows: each one beyond the path's row threshold
     if keys_kind == "int_clustered":
@@ -593,6 +593,10 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, dev, gro
     assert np.array_equal(gv[3], sum_c[got_gid])
     assert np.allclose(gv[4], sum_a[got_gid] / cnt[got_gid], rtol=1e-12, atol=0.0)
     assert_same_groups(results[0], results[1])
+    o = oracle.AggState(cfg)                                                    # (the oracle's hash table: seconds at these sizes)
+    o.update([x[:half] for x in cols], half)
+    o.update([x[half:] for x in cols], n - half)
+    assert_same_groups(results[0], o.finalize())
 
 
 def test_plans_outside_the_aot_family_keep_their_kernels(capi, oracle, dev, monkeypatch):

@@ -752,3 +752,207 @@ def test_factored_aggregation_under_the_states_predicate(capi, oracle, dev, pred
         o.update_coded(host[i][0], host[i][1], host[i][2])
     assert _factored_launches(capi) - before == 6, "a state with a predicate did not take the factored kernels"
     assert_same_groups(finalize_np(st, dev), o.finalize())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Joins and LIP filters directly on compressed key stripes (qsx_*_blocks_coded, include/qsx.h)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _key_blocks_of_every_kind(rng, dtype, rows, lo=0):
+    """Blocks of one key attribute the way a CompressedColumnStore holds them: every block compressed on its own
+    (oracle.CompressedColumn = CompressedBlockBuilder's decision), so that the run mixes dictionary codes of 1 and 2 bytes,
+    truncated values of 1 / 2 / 4 bytes and plain values — and an empty block."""
+    makers = [
+        lambda n: rng.choice(rng.integers(lo, lo + 60_000, size=180), size=n),                    # few distinct values: 1-byte dictionary codes
+        lambda n: rng.permutation(60_000)[:n] if n <= 60_000 else rng.integers(0, 60_000, size=n),  # < 2^16, many distinct: 2-byte truncation
+        lambda n: rng.integers(-50, 90_000, size=n),                                              # negative values: never truncated
+        lambda n: rng.choice(rng.integers(lo + 66_000, lo + 90_000, size=600), size=n),             # 600 distinct 17-bit values: 2-byte dictionary codes
+        lambda n: rng.integers(0, 250, size=n),                                                   # < 2^8: 1-byte truncation (or dictionary)
+        lambda n: rng.integers(70_000, 95_000, size=n),                                           # 17 bits: 4-byte truncation for a LONG
+    ]
+    blocks = []
+    for i, n in enumerate(rows):
+        values = makers[i % len(makers)](n).astype(dtype) if n else np.zeros(0, dtype=dtype)
+        blocks.append(values)
+    return blocks
+
+
+def _coded_run(oracle, blocks, dev):
+    """(device stripes as they lie, coding for the *_coded calls, the kinds seen)."""
+    stripes, coding, kinds = [], [], set()
+    for values in blocks:
+        if values.size == 0:
+            stripes.append(to_dev(values, dev))
+            coding.append((0, None))
+            continue
+        col = oracle.CompressedColumn(values)
+        assert np.array_equal(col.decode(), values)
+        kinds.add((col.kind, col.code_width if col.kind else 0))
+        if col.kind == 0:
+            stripes.append(to_dev(values, dev))
+            coding.append((0, None))
+        else:
+            stripes.append(codes_dev(col, dev))
+            coding.append((col.code_width, None if col.dictionary is None else to_dev(col.dictionary, dev)))
+    return stripes, coding, kinds
+
+
+@pytest.mark.parametrize("flavour", ["hashed", "dense"])
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+def test_joins_read_compressed_key_stripes_as_they_lie(capi, oracle, dev, flavour, key_type, dtype):
+    """qsx_join_build_blocks_coded / qsx_join_probe_blocks_coded / _count_ / _exists_ / _project_: build and probe over runs of
+    blocks whose key attribute lies as CompressedBlockBuilder left it (per block: values, truncated values, dictionary codes) —
+    the reference reads such a key through CompressedTupleStorageSubBlock::getAttributeValue (storage/
+    CompressedTupleStorageSubBlock.hpp:225-300) — give the pairs, counts, bitmaps and output tuples of the same calls over the
+    decoded stripes, and of the oracle's join."""
+    from test_gpu_join import sorted_pairs
+    rng = np.random.default_rng(7 if flavour == "dense" else 8)
+    build_rows = [5_000, 4_099, 7_000, 3_000, 2_500, 6_001, 0, 1_200]
+    probe_rows = [9_000, 70_001, 20_000, 4_097, 33_000, 12_345, 0, 1, 777]
+    build_blocks = _key_blocks_of_every_kind(rng, dtype, build_rows)
+    probe_blocks = _key_blocks_of_every_kind(rng, dtype, probe_rows, lo=20_000)
+    b_stripes, b_coding, b_kinds = _coded_run(oracle, build_blocks, dev)
+    p_stripes, p_coding, p_kinds = _coded_run(oracle, probe_blocks, dev)
+    want_kinds = {(0, 0), (1, 1), (1, 2), (2, 1), (2, 2)} | ({(1, 4)} if key_type == T.LONG else set())
+    assert want_kinds <= (b_kinds | p_kinds), (b_kinds, p_kinds)                       # the run really mixes the forms
+    n_build = sum(build_rows)
+    key_range = (-50, 95_000) if flavour == "dense" else None
+    bases = [int(x) for x in np.cumsum([0] + build_rows[:-1])]
+    table = capi.JoinTable(key_type, n_build, key_range=key_range)
+    table.build_blocks(b_stripes, bases, coding=b_coding)
+    plain = capi.JoinTable(key_type, n_build, key_range=key_range)                      # the same joins over decoded stripes
+    plain.build_blocks([to_dev(b, dev) for b in build_blocks], bases)
+    ot = oracle.JoinTable(key_type, n_build)
+    for b, blk in enumerate(build_blocks):
+        ot.build(blk, block_id=0, base_tid=bases[b])
+    assert table.size() == n_build
+    d_probe = [to_dev(b, dev) for b in probe_blocks]
+    filters = [oracle.bitmap_from_bools(rng.random(n) < 0.6) if (i % 3 != 1 and n) else None for i, n in enumerate(probe_rows)]
+    dfilters = [None if f is None else bitmap_dev(f, dev) for f in filters]
+    for use_filters in (False, True):
+        f_arg = dfilters if use_filters else None
+        want_p, want_b, start = [], [], 0
+        for i, blk in enumerate(probe_blocks):
+            rp, rb = ot.probe(blk, filter_bitmap=filters[i] if use_filters else None)
+            want_p.append(rp + start)
+            want_b.append(rb)
+            start += blk.size
+        want_p, want_b = np.concatenate(want_p), np.concatenate(want_b)
+        for tbl, stripes, coding in ((table, p_stripes, p_coding), (table, d_probe, None), (plain, p_stripes, p_coding)):
+            p, b, cnt = tbl.probe_blocks(stripes, capacity=want_p.size + 3, filters=f_arg, coding=coding)
+            k = int(cnt.item())
+            assert k == want_p.size
+            assert np.array_equal(sorted_pairs(p.cpu().numpy()[:k], b.cpu().numpy()[:k]), sorted_pairs(want_p, want_b))
+            assert int(tbl.probe_count_blocks(stripes, filters=f_arg, coding=coding).item()) == k
+        for anti in (False, True):
+            outs, cnt = table.probe_exists_blocks(p_stripes, anti=anti, filters=f_arg, coding=p_coding)
+            total = 0
+            for i, blk in enumerate(probe_blocks):
+                ref = ot.probe_exists(blk, anti=anti, filter_bitmap=filters[i] if use_filters else None)
+                if blk.size:
+                    assert np.array_equal(bitmap_np(outs[i]), ref), (i, anti, use_filters)
+                total += oracle.bitmap_count(ref, blk.size)
+            assert int(cnt.item()) == total
+    # code stripes at any byte address (a reference block image adopted in place, StorageManager::adoptBlockImage: the stripes
+    # lie back to back behind the header, 2- and 4-byte codes at odd addresses)
+    shifted = []
+    for i, (stripe, (w, _)) in enumerate(zip(p_stripes, p_coding)):
+        if w == 0 or stripe.numel() == 0:
+            shifted.append(stripe)
+            continue
+        raw = stripe.view(torch.uint8)
+        buf = torch.zeros(raw.numel() + 16, dtype=torch.uint8, device=dev)
+        off = 1 + 2 * (i % 3)
+        buf[off:off + raw.numel()] = raw
+        shifted.append(buf[off:off + raw.numel()])
+    p, b, cnt = table.probe_blocks(shifted, capacity=want_p.size + 3, filters=dfilters, coding=p_coding)
+    assert int(cnt.item()) == want_p.size
+    assert np.array_equal(sorted_pairs(p.cpu().numpy()[:want_p.size], b.cpu().numpy()[:want_p.size]), sorted_pairs(want_p, want_b))
+    # the output relation written by the probe: the join key itself (given as the key stripes: emitted as its value), a probe
+    # attribute and a build attribute.  Unique build keys here (one match per probe tuple at most).
+    uniq = rng.permutation(95_000)[:n_build].astype(dtype)
+    u_blocks = [np.sort(uniq[a:a + n]) if i % 2 else uniq[a:a + n] for i, (a, n) in enumerate(zip(bases, build_rows))]
+    u_stripes, u_coding, _ = _coded_run(oracle, u_blocks, dev)
+    utable = capi.JoinTable(key_type, n_build, key_range=(0, 95_000) if flavour == "dense" else None)
+    utable.build_blocks(u_stripes, bases, coding=u_coding)
+    payload = rng.integers(-2**40, 2**40, size=n_build).astype(np.int64)               # build attribute, by build tid
+    probe_attr = [rng.integers(0, 1000, size=n).astype(np.int32) for n in probe_rows]
+    try:
+        outs, cnt = utable.probe_project_blocks(p_stripes, [p_stripes, [to_dev(a, dev) for a in probe_attr]], [[to_dev(payload, dev)]],
+                                                coding=p_coding, key_dtype=torch.int32 if key_type == T.INT else torch.int64)
+    except capi.QsxError as e:   # a hashed table that got no directly addressed shadow: the documented refusal
+        assert flavour == "hashed" and e.status == T.ERR_UNSUPPORTED
+        return
+    k = int(cnt.item())
+    all_keys = np.concatenate(probe_blocks)
+    all_attr = np.concatenate(probe_attr)
+    # (probe-side columns only — SELECT the join attribute of a semi-join-like inner join: the kernel without a covering array)
+    outs2, cnt2 = utable.probe_project_blocks(p_stripes, [p_stripes, [to_dev(a, dev) for a in probe_attr]], [], coding=p_coding,
+                                              key_dtype=torch.int32 if key_type == T.INT else torch.int64)
+    k2 = int(cnt2.item())
+    got2 = np.stack([outs2[0].cpu().numpy()[:k2].astype(np.int64), outs2[1].cpu().numpy()[:k2].astype(np.int64)], axis=1)
+    where = {int(v): i for i, v in enumerate(np.concatenate(u_blocks))}
+    hit = np.array([int(v) in where for v in all_keys])
+    assert k == int(hit.sum())
+    got = np.stack([outs[0].cpu().numpy()[:k].astype(np.int64), outs[1].cpu().numpy()[:k].astype(np.int64), outs[2].cpu().numpy()[:k]], axis=1)
+    want = np.stack([all_keys[hit].astype(np.int64), all_attr[hit].astype(np.int64),
+                     payload[[where[int(v)] for v in all_keys[hit]]]], axis=1)
+    assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+    assert k2 == k
+    assert np.array_equal(got2[np.lexsort(got2.T[::-1])], want[:, :2][np.lexsort(want[:, :2].T[::-1])])
+
+
+@pytest.mark.parametrize("key_type,dtype", [(T.INT, np.int32), (T.LONG, np.int64)])
+def test_lip_filters_over_compressed_key_stripes(capi, oracle, dev, key_type, dtype):
+    """qsx_lip_build_blocks_coded / qsx_lip_probe_blocks_coded equal the plain forms over the decoded stripes, bit for bit."""
+    rng = np.random.default_rng(21)
+    build_blocks = _key_blocks_of_every_kind(rng, dtype, [5_000, 3_000, 2_000, 900, 1_500, 800, 0, 3])
+    probe_blocks = _key_blocks_of_every_kind(rng, dtype, [40_000, 8_193, 30_000, 2_000, 5_000, 6_000, 0, 1], lo=10_000)
+    b_stripes, b_coding, _ = _coded_run(oracle, build_blocks, dev)
+    p_stripes, p_coding, _ = _coded_run(oracle, probe_blocks, dev)
+    for kind, cardinality in ((T.LIP_BITVECTOR_EXACT, 95_051), (T.LIP_SINGLE_IDENTITY_HASH, 4_001)):
+        coded = capi.LipFilter(kind, cardinality, min_value=-50)
+        plain = capi.LipFilter(kind, cardinality, min_value=-50)
+        coded.build_blocks(b_stripes, coding=b_coding, key_type=key_type)
+        plain.build_blocks([to_dev(b, dev) for b in build_blocks if b.size])
+        assert torch.equal(coded.export(dev), plain.export(dev))
+        in_bitmaps = [bitmap_dev(oracle.bitmap_from_bools(rng.random(b.size) < 0.7), dev) if (i % 2 and b.size) else None
+                      for i, b in enumerate(probe_blocks)]
+        for ins in (None, in_bitmaps):
+            outs, cnt = coded.probe_blocks(p_stripes, in_bitmaps=ins, coding=p_coding, key_type=key_type)
+            ref, ref_cnt = plain.probe_blocks([to_dev(b, dev) for b in probe_blocks], in_bitmaps=ins)
+            assert int(cnt.item()) == int(ref_cnt.item())
+            for i, b in enumerate(probe_blocks):
+                if b.size:
+                    assert torch.equal(outs[i], ref[i]), (kind, i)
+
+
+@pytest.mark.parametrize("key_range", [None, (0, 4_999)])
+def test_small_build_side_probed_with_sorted_truncated_keys(capi, oracle, dev, key_range):
+    """A dimension of a few thousand keys (its directly addressed form fits LDS) probed with runs of blocks sorted on the join
+    attribute and truncated to 2 bytes — tests/cpp/block_image_test.cpp's join over adopted CompressedColumnStore images — through
+    every coded probe form; the projection is the join attribute alone."""
+    rng = np.random.default_rng(5)
+    dim = np.arange(0, 5_000, 3, dtype=np.int32)
+    table = capi.JoinTable(T.INT, dim.size, key_range=key_range)
+    table.build(to_dev(dim, dev))
+    rows = [120_000, 118_991, 0, 116_973, 40_001]
+    blocks = [np.sort(rng.integers(0, 5_000, size=n)).astype(np.int32) for n in rows]
+    stripes, coding, kinds = _coded_run(oracle, blocks, dev)
+    assert kinds == {(1, 2)}
+    want = int(sum((b % 3 == 0).sum() for b in blocks))
+    assert int(table.probe_count_blocks(stripes, coding=coding).item()) == want
+    p, b, cnt = table.probe_blocks(stripes, coding=coding)
+    assert int(cnt.item()) == want
+    all_keys = np.concatenate(blocks)
+    pk = p.cpu().numpy()[:want]
+    assert np.array_equal(np.sort(all_keys[pk]), np.sort(all_keys[all_keys % 3 == 0]))
+    assert np.array_equal(dim[b.cpu().numpy()[:want]], all_keys[pk])
+    outs, cnt = table.probe_exists_blocks(stripes, coding=coding)
+    assert int(cnt.item()) == want
+    try:
+        outs, cnt = table.probe_project_blocks(stripes, [stripes], [], coding=coding, key_dtype=torch.int32)
+    except capi.QsxError as e:
+        assert e.status == T.ERR_UNSUPPORTED and key_range is None
+        outs, cnt = table.probe_project_blocks(stripes, [[to_dev(x, dev) for x in blocks]], [], coding=coding, key_dtype=torch.int32)
+    assert int(cnt.item()) == want
+    assert np.array_equal(np.sort(outs[0].cpu().numpy()[:want]), np.sort(all_keys[all_keys % 3 == 0]))
