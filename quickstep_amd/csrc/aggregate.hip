@@ -1929,6 +1929,23 @@ static int settle(qsx_agg_state *st, hipStream_t stream) {
   return QSX_OK;
 }
 
+// (update_run_end_to_end, below)
+constexpr int kConcatChunk = 16 * 1024;
+template <typename V>
+__global__ __launch_bounds__(256) void concat_segments_kernel(const long long *__restrict__ segments, int first_segment) {
+  const long long *seg = segments + 3 * static_cast<size_t>(first_segment + blockIdx.y);
+  const V *src = as_global(reinterpret_cast<const V *>(seg[0]));
+  V *dst = as_global(reinterpret_cast<V *>(seg[1]));
+  const long long n = seg[2];
+  for (long long chunk = blockIdx.x; chunk * kConcatChunk < n; chunk += gridDim.x) {
+    const long long base = chunk * kConcatChunk;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < kConcatChunk; i += 256) {
+      if (base + i < n) store_global_nt(load_global_nt(&src[base + i]), &dst[base + i]);
+    }
+  }
+}
+
 extern "C" {
 
 int qsx_agg_state_create(const qsx_agg_config_t *config, qsx_agg_state_t **out) {
@@ -2723,6 +2740,90 @@ int qsx_agg_update_nullable(qsx_agg_state_t *st, const void *const *cols, const 
   return agg_update(st, cols, nullptr, n, filter_dev, stream, null_bitmaps_dev);
 }
 
+// A run of blocks for a state whose groups need the partition passes (update_partitioned / update_two_level scatter whole
+// columns): the run's used columns are laid end to end in scratch of the call first — one launch, 2 x the columns' bytes, 0.5 ms
+// per 100 M rows of a 4-byte key and an 8-byte value — and take the stripe form from there.  Without it every row of a run paid
+// NS + 1 global atomics: the operators hand the state runs of 1 M-row blocks (AggregationOperator::setBlocksPerWorkOrder), never
+// a stripe long enough for the partition passes.
+// segments: {source, destination, elements} per (block, used column); blockIdx.y = segment, blockIdx.x = its 16 Ki-element chunks.
+static bool run_takes_partition_passes(const qsx_agg_state *st, int64_t total, bool any_filter, bool coded) {
+  if (st->dense || st->part_count <= 1 || any_filter || coded || st->has_coded_columns || st->dev.num_null_cols != 0 || st->has_date_key) return false;
+  if (st->dir_gids != 0 || st->factored.ok) return false;
+  static const bool enabled = []() { const char *e = getenv("QSX_AGG_RUN_PARTITIONED"); return e == nullptr || atoi(e) != 0; }();
+  return enabled && total >= partition_min_rows();
+}
+static std::atomic<long long> g_run_concats{0};
+// Test hook (not part of include/qsx.h): runs of blocks that were laid end to end for the partition passes.
+extern "C" long long qsx_debug_agg_run_concats(void) { return g_run_concats.load(std::memory_order_relaxed); }
+static int update_run_end_to_end(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols, int64_t total,
+                                 qsx_stream_t stream) {
+  hipStream_t s = as_stream(stream);
+  const int ncols = st->config.num_columns;
+  size_t bytes = 0;
+  int used = 0;
+  for (int c = 0; c < ncols; ++c) {
+    if ((st->used_columns >> c) & 1u) {
+      bytes += CallScratch::padded(static_cast<size_t>(total) * st->dev.column_width[c] + 16);
+      ++used;
+    }
+  }
+  std::vector<long long> segments;   // grouped by element width: one launch per width that occurs
+  int first_of_width[5] = {0, 0, 0, 0, 0};
+  const int widths[4] = {1, 2, 4, 8};
+  CallScratch scratch(s);
+  int rc = scratch.reserve(bytes);
+  if (rc != QSX_OK) return rc;
+  const void *stripes[QSX_MAX_COLUMNS] = {};
+  char *stripe_of[QSX_MAX_COLUMNS] = {};
+  for (int c = 0; c < ncols; ++c) {
+    if (!((st->used_columns >> c) & 1u)) continue;
+    stripe_of[c] = static_cast<char *>(scratch.take(static_cast<size_t>(total) * st->dev.column_width[c] + 16));
+    if (stripe_of[c] == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+    stripes[c] = stripe_of[c];
+  }
+  long long widest_segment = 0;
+  for (int wi = 0; wi < 4; ++wi) {
+    first_of_width[wi] = static_cast<int>(segments.size() / 3);
+    for (int c = 0; c < ncols; ++c) {
+      if (!((st->used_columns >> c) & 1u) || st->dev.column_width[c] != widths[wi]) continue;
+      int64_t at = 0;
+      for (int b = 0; b < num_blocks; ++b) {
+        if (block_rows[b] == 0) continue;
+        const void *src = block_cols[static_cast<size_t>(b) * ncols + c];
+        if (src == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+        segments.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(src)));
+        segments.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(stripe_of[c] + static_cast<size_t>(at) * widths[wi])));
+        segments.push_back(block_rows[b]);
+        widest_segment = std::max<long long>(widest_segment, block_rows[b]);
+        at += block_rows[b];
+      }
+    }
+  }
+  first_of_width[4] = static_cast<int>(segments.size() / 3);
+  const size_t table_bytes = segments.size() * sizeof(long long);
+  const long long *segments_dev = static_cast<const long long *>(staged_device_buffer(s, table_bytes));
+  if (segments_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  rc = staged_upload(s, segments.data(), table_bytes);
+  if (rc != QSX_OK) return rc;
+  const unsigned chunks = static_cast<unsigned>(std::min<long long>((widest_segment + kConcatChunk - 1) / kConcatChunk, 64));
+  for (int wi = 0; wi < 4; ++wi) {
+    for (int first = first_of_width[wi]; first < first_of_width[wi + 1]; first += 65535) {
+      const unsigned count = static_cast<unsigned>(std::min(first_of_width[wi + 1] - first, 65535));
+      const dim3 grid(chunks, count);
+      switch (widths[wi]) {
+        case 1: hipLaunchKernelGGL(concat_segments_kernel<uint8_t>, grid, dim3(256), 0, s, segments_dev, first); break;
+        case 2: hipLaunchKernelGGL(concat_segments_kernel<uint16_t>, grid, dim3(256), 0, s, segments_dev, first); break;
+        case 4: hipLaunchKernelGGL(concat_segments_kernel<uint32_t>, grid, dim3(256), 0, s, segments_dev, first); break;
+        default: hipLaunchKernelGGL(concat_segments_kernel<unsigned long long>, grid, dim3(256), 0, s, segments_dev, first); break;
+      }
+      QSX_CHECK_LAUNCH();
+    }
+  }
+  g_run_concats.fetch_add(1, std::memory_order_relaxed);
+  (void)used;
+  return agg_update(st, stripes, nullptr, total, nullptr, stream, nullptr);
+}
+
 // block_dicts: the dictionaries of a state over compressed attributes, [block * num_columns + column] (nullptr otherwise).
 static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
                              const void *const *block_dicts, const uint64_t *const *block_filters, qsx_stream_t stream,
@@ -2778,6 +2879,9 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
     total += block_rows[b];
   }
   if (rows.empty()) return QSX_OK;
+  if (run_takes_partition_passes(st, total, any_filter, block_dicts != nullptr)) {
+    return update_run_end_to_end(st, num_blocks, block_rows, block_cols, total, stream);
+  }
   tiles1024.push_back(tiles1024.back() + (rows.back() + 1023) / 1024);
   tiles512.push_back(tiles512.back() + (rows.back() + 511) / 512);
   const size_t nb = rows.size();

@@ -593,6 +593,20 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
     assert np.array_equal(gv[3], sum_c[got_gid])
     assert np.allclose(gv[4], sum_a[got_gid] / cnt[got_gid], rtol=1e-12, atol=0.0)
     assert_same_groups(results[0], results[1])
+    # the operators' form: a run of 1 M-row blocks (ragged at the end, an empty one inside) in one call — laid end to end in scratch
+    # of the call and through the same partition passes (aggregate.hip update_run_end_to_end)
+    import ctypes
+    capi.lib.qsx_debug_agg_run_concats.restype = ctypes.c_longlong
+    monkeypatch.setenv("QSX_AGG_TWO_LEVEL_MIN_GROUPS", "100000")
+    before, concats = _two_level_updates(capi), capi.lib.qsx_debug_agg_run_concats()
+    st = capi.AggState(cfg)
+    edges = list(range(0, n, 1_000_000)) + [n]
+    edges.insert(5, edges[5])
+    st.update_blocks([[x[a:b] for x in dcols] for a, b in zip(edges[:-1], edges[1:])])
+    assert capi.lib.qsx_debug_agg_run_concats() == concats + 1
+    assert _two_level_updates(capi) == before + (1 if keys_kind != "int_clustered" else 0)
+    assert_same_groups(finalize_np(st, dev), results[0])
+    st.close()
     o = oracle.AggState(cfg)                                                    # (the oracle's hash table: seconds at these sizes)
     o.update([x[:half] for x in cols], half)
     o.update([x[half:] for x in cols], n - half)
