@@ -2506,16 +2506,16 @@ static int update_partitioned(qsx_agg_state *st, const void *const *cols, int64_
 
 // More groups than one partition pass brings into LDS (agg_pieces.hpp): two K9 passes on digits of the mixing hash, then 4096
 // pieces of disjoint groups, each through a workgroup's LDS table.  For the plans the consumer serves (two_level_plan).
-// Per 100 M rows of an INT key and a DOUBLE, random keys, one pass / two levels: 10^5 groups 4.1 / 3.7 ms, 3 x 10^5 5.9 / 3.7,
-// 10^6 9.6 / 3.6, 3 x 10^6 13.2 / 3.9, 10^7 20.9 / 5.1 (tools/agg_large_groups.py; profiles/README.md round 6).
+// Per 100 M rows of an INT key and a DOUBLE, random keys, one pass / two levels: 10^5 groups 4.1 / 3.0 ms, 3 x 10^5 5.9 / 3.0,
+// 10^6 9.6 / 3.0, 3 x 10^6 13.2 / 3.4, 10^7 20.9 / 4.9 (tools/agg_large_groups.py; profiles/README.md round 6).
 static long long two_level_min_groups() {
   const char *e = getenv("QSX_AGG_TWO_LEVEL_MIN_GROUPS");   // 0 = never
   return e != nullptr ? atoll(e) : 100000ll;
 }
-// Clustered keys up to this many groups stay on the one-pass path (decide_two_level): 3.4-3.9 ms up to 10^6 groups against
-// 4.7-4.8 through two levels (runs of one key are runs of one partition: the scatter's LDS counters take a wave's 64 adds
-// one after the other); level at 3 x 10^6 (5.1 / 4.9), and 10.8 against 5.2 at 10^7.
-constexpr long long kTwoLevelWhateverTheOrder = 4000000;
+// Clustered keys up to this many groups stay on the one-pass path (decide_two_level): 2.8 / 3.0 / 3.4 ms at 10^5 / 3 x 10^5 /
+// 10^6 groups against 3.5 through two levels (a wave whose 64 rows are one partition's takes its places in the scatter with one
+// LDS add — partition.hip — or the gap was a millisecond); 4.9 against 4.3 at 3 x 10^6, 10.8 against 4.9 at 10^7.
+constexpr long long kTwoLevelWhateverTheOrder = 2000000;
 static bool two_level_plan(const qsx_agg_state *st) {
   const DevConfig &d = st->dev;
   if (st->dense || d.wide_words != 0 || d.num_instrs != 0 || d.num_pred != 0 || d.num_null_cols != 0 || st->has_coded_columns || st->has_date_key) return false;

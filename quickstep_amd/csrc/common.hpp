@@ -199,7 +199,7 @@ static int staged_upload(hipStream_t stream, const void *host_src, size_t bytes)
 // Instead every (host thread, stream) owns one grow-only arena: calls issued by one thread on one stream are ordered on
 // the device, so the next call may reuse the arena while the previous call's kernels are still queued.  An arena is a
 // power of two up to 256 MiB and the request rounded to 64 MiB beyond (a 2.1 GB request keeps 2.1 GB, not 4 GiB); requests
-// beyond kScratchKeepBytes are one-off plain allocations, released when the call's work has finished.
+// beyond kScratchKeepBytes are one-off allocations, handed to the idle pool (device_free_idle) when the call's work has finished.
 constexpr size_t kScratchKeepBytes = size_t(1) << 30;
 constexpr size_t kScratchPow2Bytes = size_t(256) << 20;
 class CallScratch {
@@ -283,7 +283,7 @@ class CallScratch {
     }
     if (one_off_ != nullptr) {
       (void)hipStreamSynchronize(stream_);
-      (void)device_free(one_off_);
+      (void)device_free_idle(one_off_);   // (kept for the next request of its size: runtime.hip kIdleKeepBytes)
       one_off_ = nullptr;
     }
     base_ = nullptr;

@@ -203,7 +203,15 @@ __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key
       // internal re-partitioning needs no row order (and a count never does): one LDS atomic per row instead of the ranking loop
 #pragma unroll
       for (int j = 0; j < kPSteps; ++j) {
-        if (pid[j] >= 0) atomicAdd(&s_total[pid[j]], 1);
+        // (clustered keys: a wave's 64 rows are one partition's — 64 adds to one LDS word go one after the other; one add then)
+        const uint64_t live = __ballot(pid[j] >= 0);
+        if (live == 0) continue;
+        const int first = __builtin_amdgcn_readlane(pid[j], __ffsll(static_cast<long long>(live)) - 1);
+        if (__ballot(pid[j] == first) == live) {
+          if (lane == 0) atomicAdd(&s_total[first], static_cast<int>(__popcll(live)));
+        } else if (pid[j] >= 0) {
+          atomicAdd(&s_total[pid[j]], 1);
+        }
       }
     } else {
 #pragma unroll
@@ -321,7 +329,22 @@ __global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(MODE ==
       if (threadIdx.x < P) s_cnt[threadIdx.x] = 0;
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < kPSteps; ++j) pos[j] = pid[j] >= 0 ? atomicAdd(&s_cnt[pid[j]], 1) : 0;
+      for (int j = 0; j < kPSteps; ++j) {
+        // (a wave whose 64 rows are one partition's — clustered keys — takes its 64 places with one add: 64 adds to one LDS word
+        // go one after the other)
+        const uint64_t live = __ballot(pid[j] >= 0);
+        pos[j] = 0;
+        if (live == 0) continue;
+        const int leader = __ffsll(static_cast<long long>(live)) - 1;
+        const int first = __builtin_amdgcn_readlane(pid[j], leader);
+        if (__ballot(pid[j] == first) == live) {
+          int base = 0;
+          if (lane == leader) base = atomicAdd(&s_cnt[first], static_cast<int>(__popcll(live)));
+          pos[j] = __builtin_amdgcn_readlane(base, leader) + rank_below(live);
+        } else if (pid[j] >= 0) {
+          pos[j] = atomicAdd(&s_cnt[pid[j]], 1);
+        }
+      }
       __syncthreads();
       if (threadIdx.x < P) s_part_start[threadIdx.x + 1] = s_cnt[threadIdx.x];
     } else {

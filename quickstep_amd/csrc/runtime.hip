@@ -150,7 +150,10 @@ void *g_oom_hook_user = nullptr;
 }  // namespace
 
 namespace {
-constexpr size_t kIdleKeepBytes = size_t(2) << 30;
+// (16 GiB of a 288 GB device: a call's scratch beyond what its arena keeps — the partition passes over 100 M rows take 2.5 GB —
+// comes from here too, and a hipMalloc / hipFree pair of that size costs anything between 0.2 and 140 ms, by the state the
+// driver's address space is in: tools/agg_large_groups.py saw both within one process)
+constexpr size_t kIdleKeepBytes = size_t(16) << 30;
 struct Owned {
   size_t bytes;
   int device;
@@ -210,19 +213,32 @@ hipError_t device_free(void *ptr) {
 
 hipError_t device_free_idle(void *ptr) {
   if (ptr == nullptr) return hipSuccess;
+  std::vector<void *> evicted;
+  bool kept = false;
   {
     Allocations &a = allocations();
     std::lock_guard<std::mutex> lock(a.mutex);
     auto it = a.live.find(ptr);
-    if (it != a.live.end() && a.idle_bytes + it->second.bytes <= kIdleKeepBytes) {
+    if (it != a.live.end() && it->second.bytes <= kIdleKeepBytes) {
+      // room for the newcomer: idle allocations go back to the runtime first, the largest classes first — a size nobody asks
+      // for again must not keep the pool full for good
+      while (a.idle_bytes + it->second.bytes > kIdleKeepBytes && !a.idle.empty()) {
+        auto cls = std::prev(a.idle.end());
+        if (!cls->second.empty()) {
+          evicted.push_back(cls->second.back());
+          cls->second.pop_back();
+          a.idle_bytes -= cls->first.second;
+        }
+        if (cls->second.empty()) a.idle.erase(cls);
+      }
       a.idle[std::make_pair(it->second.device, it->second.bytes)].push_back(ptr);
       a.idle_bytes += it->second.bytes;
-      a.live.erase(it);
-      return hipSuccess;
+      kept = true;
     }
     if (it != a.live.end()) a.live.erase(it);
   }
-  return hipFree(ptr);
+  for (void *p : evicted) (void)hipFree(p);
+  return kept ? hipSuccess : hipFree(ptr);
 }
 
 hipError_t device_malloc(void **ptr, size_t bytes) {

@@ -531,7 +531,7 @@ def _two_level_updates(capi):
     return capi.lib.qsx_debug_agg_two_level_updates()
 
 
-@pytest.mark.parametrize("groups,keys_kind", [(1_000_000, "int"), (300_000, "int_and_char"), (3_000_000, "int_clustered"), (8_000_000, "int_underestimated")])
+@pytest.mark.parametrize("groups,keys_kind", [(1_000_000, "int"), (300_000, "int_and_char"), (1_500_000, "int_clustered"), (8_000_000, "int_underestimated")])
 def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, dev, groups, keys_kind, monkeypatch):
     """csrc/agg_pieces.hpp: more groups than one partition pass brings into LDS (est_groups >= 100 K): two K9 passes on
     digits of the mixing hash order the rows by its top 12 bits, then 4096 pieces of disjoint groups go through workgroup-private

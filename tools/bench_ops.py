@@ -150,6 +150,25 @@ st = capi.AggState(gencfg)
 ms = timed(lambda: st.update([k1, k2, val], na), reps=3)
 os.environ.pop("QSX_AGG_DIRECTORY")
 report("K8 the same without the group directory (K9 on the key code + per-piece tables: round 1)", ms, na, 16 * na)
+# the reference's default group-by path at scale (PackedPayloadHashTable): 10^6 and 10^7 groups, random keys — two partition passes on
+# hash digits, then 4096 pieces through LDS tables (csrc/agg_pieces.hpp); and the one-pass path it replaced
+for many in (1_000_000, 10_000_000):
+    big = torch.randint(0, many, (na,), device=dev, generator=g, dtype=torch.int32)
+    bigcfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None)], keys=[0], aggs=[(T.AGG_SUM, T.col(1)), (T.AGG_COUNT_STAR, None)],
+                               est_groups=many)
+    for env, label in ((None, "two partition passes + LDS pieces"), ("0", "one partition pass, then global atomics: round 5")):
+        if env is not None:
+            os.environ["QSX_AGG_TWO_LEVEL_MIN_GROUPS"] = env
+        st = capi.AggState(bigcfg)
+
+        def many_groups():
+            st.clear()
+            st.update([big, val], na)
+        ms = timed(many_groups, reps=3)
+        os.environ.pop("QSX_AGG_TWO_LEVEL_MIN_GROUPS", None)
+        report(f"K8 aggregate GENERIC INT key, {many:,} groups, SUM + COUNT ({label})", ms, na, 12 * na, "state cleared inside the timed call")
+        del st
+    del big
 widecfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.LONG, None), (T.INT, None), (T.DOUBLE, None)], keys=[0, 1, 2],
                             aggs=[(T.AGG_SUM, T.col(3)), (T.AGG_COUNT_STAR, None)], est_groups=10_000)
 st = capi.AggState(widecfg)
