@@ -43,7 +43,7 @@ def main():
             rows.append(("the step through the operator layer", f"{op.get('workers', 8)} Workers, {op.get('blocks_per_work_order', 256)} blocks per work order", f"{op['ms_per_step']:.2f} ms",
                          f"{op['rows_per_s'] / 1e9:.0f} G rows/s", "—", f"{100 * op['fraction_of_raw_abi_value']:.0f} % of the raw step"))
         for name, v in (line.get("secondary") or {}).items():      # (round 5: the other BASELINE configurations in the same line)
-            if isinstance(v, dict) and "ms" in v and "roofline" in v:
+            if isinstance(v, dict) and "ms" in v and "roofline" in v and "rows_per_s" in v and "workload" in v:
                 rows.append((f"`secondary.{name}` — `{v['roofline']['kernel'].split(' ')[0]}`", v["workload"][:90] + "…", f"{v['ms']:.3f} ms",
                              f"{v['rows_per_s'] / 1e9:.0f} G rows/s", f"{v['roofline']['achieved'] / 1e3:.2f} TB/s", f"{100 * v['roofline']['frac']:.0f} %"))
     for s in load_lines(os.path.join(prof, f"{tag}_probe_small_tables.jsonl")):
