@@ -71,6 +71,7 @@ _SIGNATURES = {
     "qsx_bitmap_combine": (_int, [_int, _vp, _vp, _i64, _vp, _vp]),
     "qsx_bitmap_count": (_int, [_vp, _i64, _vp, _vp]),
     "qsx_compact_workspace_bytes": (_sz, [_i64]),
+    "qsx_copy_segments": (_int, [_i64, _pp, _pp, C.POINTER(_i64), _vp]),
     "qsx_compact_blocks_workspace_bytes": (_sz, [_i64, C.POINTER(_i64)]),
     "qsx_compact_gather_blocks": (_int, [_int, C.POINTER(_i32), _i64, C.POINTER(_i64), _pp, _pp, C.POINTER(_i32), _pp, _vp, _vp, _vp,
                                          _sz, _vp]),
@@ -414,6 +415,15 @@ def select_codes_sorted(codes, op, first, second=0, filter_bitmap=None, stream=N
     _check(_lib.qsx_select_codes_sorted(codes.element_size(), _ptr(codes), n, op, first, second, _ptr(filter_bitmap),
                                         _ptr(out_bitmap), _ptr(out_count), _stream(stream)), "qsx_select_codes_sorted")
     return out_bitmap, out_count
+
+
+def copy_segments(srcs, dsts, stream=None):
+    """qsx_copy_segments: srcs[i] -> dsts[i] (flat tensors of equal byte size), one launch."""
+    n = len(srcs)
+    sp = (C.c_void_p * max(n, 1))(*[s.data_ptr() if s.numel() else None for s in srcs])
+    dp = (C.c_void_p * max(n, 1))(*[d.data_ptr() if d.numel() else None for d in dsts])
+    nbytes = (C.c_int64 * max(n, 1))(*[s.numel() * s.element_size() for s in srcs])
+    _check(_lib.qsx_copy_segments(n, sp, dp, nbytes, _stream(stream)), "qsx_copy_segments")
 
 
 def decode_codes(codes, dictionary, value_dtype, stream=None, out=None):

@@ -71,7 +71,9 @@ namespace qsx {
 // nothing more is issued, and ncclGroupEnd always runs — from end() or, on an early return, from the destructor.
 class RcclGroup {
  public:
+  // api == nullptr: a batch that turned out to hold nothing for the transport (every piece was the rank's own): no group
   explicit RcclGroup(const RcclApi *api) : api_(api) {
+    if (api_ == nullptr) return;
     status_ = rccl_status(api_->GroupStart(), "ncclGroupStart");
     open_ = status_ == QSX_OK;
   }

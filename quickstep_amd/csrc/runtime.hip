@@ -292,6 +292,32 @@ int device_ready() {
 
 }  // namespace qsx
 
+namespace qsx {
+// qsx_copy_segments: blockIdx.y = segment, blockIdx.x strides over its chunks of kCopyChunk units.
+constexpr int kCopyChunk = 4096;
+typedef unsigned int CopyUnit16 __attribute__((ext_vector_type(4)));
+template <typename V>
+__global__ __launch_bounds__(256) void copy_segments_kernel(const long long *__restrict__ segments) {
+  const long long *seg = segments + 3 * static_cast<size_t>(blockIdx.y);
+  const V *src = as_global(reinterpret_cast<const V *>(seg[0]));
+  V *dst = as_global(reinterpret_cast<V *>(seg[1]));
+  const long long n = seg[2];
+  for (long long base = static_cast<long long>(blockIdx.x) * kCopyChunk; base < n; base += static_cast<long long>(gridDim.x) * kCopyChunk) {
+    V v[kCopyChunk / 256];
+#pragma unroll
+    for (int i = 0; i < kCopyChunk / 256; ++i) {
+      const long long at = base + i * 256 + threadIdx.x;
+      v[i] = load_global(&src[at < n ? at : n - 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < kCopyChunk / 256; ++i) {
+      const long long at = base + i * 256 + threadIdx.x;
+      if (at < n) store_global(v[i], &dst[at]);
+    }
+  }
+}
+}  // namespace qsx
+
 extern "C" {
 
 const char *qsx_status_string(int status) {
@@ -368,6 +394,48 @@ int qsx_copy_on_device(void *dst_dev, const void *src_dev, size_t bytes, qsx_str
   QSX_REQUIRE_DEVICE();
   if (bytes == 0) return QSX_OK;
   QSX_HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, qsx::as_stream(stream)));
+  return QSX_OK;
+}
+
+int qsx_copy_segments(int64_t num_segments, const void *const *src_dev, void *const *dst_dev, const int64_t *bytes, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (num_segments < 0 || (num_segments > 0 && (src_dev == nullptr || dst_dev == nullptr || bytes == nullptr))) return QSX_ERR_INVALID_ARGUMENT;
+  hipStream_t s = qsx::as_stream(stream);
+  // segments whose two ends and length are 16-byte multiples go 16 bytes a lane, the others byte by byte (a stripe of an adopted
+  // block image lies at any byte address); {source, destination, units} per segment, grouped by unit
+  std::vector<long long> wide, narrow;
+  long long widest[2] = {0, 0};
+  for (int64_t i = 0; i < num_segments; ++i) {
+    if (bytes[i] < 0) return QSX_ERR_INVALID_ARGUMENT;
+    if (bytes[i] == 0) continue;
+    if (src_dev[i] == nullptr || dst_dev[i] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(src_dev[i]), b = reinterpret_cast<uintptr_t>(dst_dev[i]);
+    const bool is_wide = ((a | b | static_cast<uintptr_t>(bytes[i])) & 15u) == 0;
+    std::vector<long long> &v = is_wide ? wide : narrow;
+    v.push_back(static_cast<long long>(a));
+    v.push_back(static_cast<long long>(b));
+    v.push_back(is_wide ? bytes[i] / 16 : bytes[i]);
+    widest[is_wide ? 0 : 1] = std::max<long long>(widest[is_wide ? 0 : 1], v.back());
+  }
+  if (wide.empty() && narrow.empty()) return QSX_OK;
+  const size_t wide_words = wide.size();
+  wide.insert(wide.end(), narrow.begin(), narrow.end());
+  const size_t table_bytes = wide.size() * sizeof(long long);
+  const long long *table = static_cast<const long long *>(qsx::staged_device_buffer(s, table_bytes));
+  if (table == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  const int rc = qsx::staged_upload(s, wide.data(), table_bytes);
+  if (rc != QSX_OK) return rc;
+  for (int kind = 0; kind < 2; ++kind) {
+    const long long count = static_cast<long long>(kind == 0 ? wide_words : wide.size() - wide_words) / 3;
+    const long long *first = table + (kind == 0 ? 0 : wide_words);
+    const unsigned chunks = static_cast<unsigned>(std::min<long long>((widest[kind] + qsx::kCopyChunk - 1) / qsx::kCopyChunk, 256));
+    for (long long at = 0; at < count; at += 65535) {
+      const dim3 grid(chunks, static_cast<unsigned>(std::min<long long>(count - at, 65535)));
+      if (kind == 0) hipLaunchKernelGGL(qsx::copy_segments_kernel<qsx::CopyUnit16>, grid, dim3(256), 0, s, first + 3 * at);
+      else hipLaunchKernelGGL(qsx::copy_segments_kernel<unsigned char>, grid, dim3(256), 0, s, first + 3 * at);
+      QSX_CHECK_LAUNCH();
+    }
+  }
   return QSX_OK;
 }
 

@@ -65,7 +65,9 @@ bool HashJoinOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCon
                                      query_context->getPredicate(residual_predicate_index_), selection, is_selection_on_build_,
                                      join_type_, table, dest, storage_manager, part,
                                      CreateLIPFilterAdaptiveProberHelper(lip_deployment_index_, query_context));
-      if (take > 1) {
+      // (an operator told to work on runs gives a lone block the run form too — the probe that writes the output relation
+      // itself, the coded key stripes — e.g. the one block a PartitionExchangeOperator delivers per round)
+      if (take > 1 || blocks_per_work_order_ > 1) {
         order->setRun(std::vector<block_id>(probe_.ids[part].begin() + static_cast<std::ptrdiff_t>(probe_.generated[part]),
                                             probe_.ids[part].begin() + static_cast<std::ptrdiff_t>(probe_.generated[part] + take)));
       }

@@ -219,24 +219,35 @@ class PartitionExchangeWorkOrder : public WorkOrder {
     for (std::size_t a = 0; a < relation.size(); ++a) {
       const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
       // values: the pieces back to back in rank order -> all-to-all(v) straight into the output block's stripe
+      // (every block's piece in ONE launch per direction: qsx_copy_segments, not a copy call per block)
+      std::vector<const void *> from;
+      std::vector<void *> to_where;
+      std::vector<std::int64_t> piece_bytes;
       std::int64_t at = 0;
       for (std::size_t r = 0; r < world; ++r) {
         if (self_direct && r == me) continue;
         for (const BlockReference &b : pieces[r].blocks) {
-          CheckStatus(qsx_copy_on_device(static_cast<char *>(send[a]->ptr) + at * t.width, b->stripe(static_cast<attribute_id>(a)),
-                                         static_cast<std::size_t>(b->numTuples()) * t.width, CurrentStream()), "qsx_copy_on_device");
+          from.push_back(b->stripe(static_cast<attribute_id>(a)));
+          to_where.push_back(static_cast<char *>(send[a]->ptr) + at * t.width);
+          piece_bytes.push_back(b->numTuples() * t.width);
           at += b->numTuples();
         }
       }
+      CheckStatus(qsx_copy_segments(static_cast<std::int64_t>(from.size()), from.data(), to_where.data(), piece_bytes.data(), CurrentStream()),
+                  "qsx_copy_segments");
       CheckStatus(qsx_alltoallv(ranks->comm(), t.width, send[a]->ptr, wire_send.data(), out != nullptr ? out->stripe(static_cast<attribute_id>(a)) : nullptr,
                                 wire_recv.data(), CurrentStream()), "qsx_alltoallv");
       if (self_direct && out != nullptr) {
+        from.clear(); to_where.clear(); piece_bytes.clear();
         std::int64_t to = total_recv - recv_rows[me];
         for (const BlockReference &b : pieces[me].blocks) {
-          CheckStatus(qsx_copy_on_device(static_cast<char *>(out->stripe(static_cast<attribute_id>(a))) + to * t.width, b->stripe(static_cast<attribute_id>(a)),
-                                         static_cast<std::size_t>(b->numTuples()) * t.width, CurrentStream()), "qsx_copy_on_device");
+          from.push_back(b->stripe(static_cast<attribute_id>(a)));
+          to_where.push_back(static_cast<char *>(out->stripe(static_cast<attribute_id>(a))) + to * t.width);
+          piece_bytes.push_back(b->numTuples() * t.width);
           to += b->numTuples();
         }
+        CheckStatus(qsx_copy_segments(static_cast<std::int64_t>(from.size()), from.data(), to_where.data(), piece_bytes.data(), CurrentStream()),
+                    "qsx_copy_segments");
       }
       op_->bytes_sent_ += static_cast<std::uint64_t>(total_send - send_rows[me]) * t.width;
       if (t.nullable) {

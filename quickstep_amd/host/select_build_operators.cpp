@@ -375,7 +375,7 @@ bool BuildHashOperator::getAllWorkOrders(WorkOrdersContainer *container, QueryCo
                                                          input_.ids[part][input_.generated[part]], predicate, table,
                                                          storage_manager, part,
                                                          CreateLIPFilterBuilderHelper(lip_deployment_index_, query_context));
-      if (take > 1) {
+      if (take > 1 || blocks_per_work_order_ > 1) {   // (run mode: a lone block takes the run form too — its key stripe as it lies)
         order->setRun(std::vector<block_id>(input_.ids[part].begin() + static_cast<std::ptrdiff_t>(input_.generated[part]),
                                             input_.ids[part].begin() + static_cast<std::ptrdiff_t>(input_.generated[part] + take)));
       }

@@ -230,3 +230,27 @@ def test_idle_allocations_are_reused_on_their_own_device_only(capi, dev):
     t.start()
     t.join()
     assert seen["groups"] == seen["want_groups"] and seen["sum"] == 100_000.0
+
+
+def test_copy_segments_equals_a_copy_per_segment(capi, dev):
+    """qsx_copy_segments: many device-to-device copies in one launch — 16-byte aligned pieces (16 bytes a lane), pieces at odd
+    addresses and of odd lengths (byte by byte), empty pieces, more pieces than one grid dimension takes."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    pool = torch.randint(0, 256, (9_000_000,), device=dev, generator=g, dtype=torch.uint8)
+    out = torch.zeros_like(pool)
+    cuts = [0, 16, 16, 4096 * 16 + 32, 1_000_003, 1_000_003 + 7, 3_000_000, 3_000_016, 8_999_999, 9_000_000]
+    srcs = [pool[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    dsts = [out[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    capi.copy_segments(srcs, dsts)
+    assert torch.equal(out, pool)
+    # 70 000 small pieces, shuffled destinations
+    n, piece = 70_000, 48
+    src = pool[: n * piece].view(n, piece)
+    perm = torch.randperm(n, device=dev, generator=g)
+    dst = torch.zeros(n, piece, dtype=torch.uint8, device=dev)
+    p = perm.cpu().tolist()
+    capi.copy_segments([src[i] for i in range(n)], [dst[p[i]] for i in range(n)])
+    assert torch.equal(dst[perm], src)
+    capi.copy_segments([], [])
