@@ -1004,6 +1004,71 @@ def secondary_c3_minimal(ctx, args, threads):
     return out
 
 
+def secondary_agg_many_groups(ctx, args, threads):
+    """The reference's default group-by path at scale (PackedPayloadHashTable behind AggregationOperationState's partitioned
+    aggregation, storage/AggregationOperationState.cpp:548-614): COUNT(*) + SUM(double) GROUP BY one INT key with 10^6 distinct
+    random keys, 100 M rows, 12 B/row.  Two partition passes on digits of the mixing hash, then 4096 pieces through workgroup-private
+    LDS tables (csrc/agg_pieces.hpp); `one_pass_ms` = round 5's path (one partition pass, then NS + 1 global atomics per row)."""
+    dev, n, groups = ctx.dev, 100_000_000, 1_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(17)
+    key = torch.randint(0, groups, (n,), device=dev, generator=g, dtype=torch.int32)
+    val = torch.randint(0, 1 << 20, (n,), device=dev, generator=g, dtype=torch.int32).double() / 64.0    # (sums exact in any order)
+    cfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1))],
+                            est_groups=groups)
+    res = {}
+    for name, env in (("two_level", None), ("one_pass", "0")):
+        if env is not None:
+            os.environ["QSX_AGG_TWO_LEVEL_MIN_GROUPS"] = env
+        st = capi.AggState(cfg)
+
+        def one():
+            st.clear()
+            st.update([key, val], n)
+        res[name] = launches_ms(one)
+        os.environ.pop("QSX_AGG_TWO_LEVEL_MIN_GROUPS", None)
+        if name == "two_level":
+            checked = False
+            if not args.no_check:
+                keys, vals, _, found = st.finalize(dev)
+                k = int(found.item())
+                want_count = torch.bincount(key.long(), minlength=groups)
+                want_sum = torch.zeros(groups, dtype=torch.float64, device=dev).index_add_(0, key.long(), val)
+                assert k == int((want_count > 0).sum().item()), "number of groups differs from the distinct keys"
+                gk = keys[0][:k].long()
+                assert bool((vals[0][:k] == want_count[gk]).all()), "COUNT(*) per group differs from a bincount of the keys"
+                assert bool((vals[1][:k] == want_sum[gk]).all()), "SUM per group differs from an index_add of the values"
+                checked = True
+                del want_count, want_sum, keys, vals
+        st.close()
+    ms = res["two_level"]
+    out = {"workload": f"COUNT(*) + SUM(double) GROUP BY one INT key, {groups} random groups over {n} rows, 12 B/row (state cleared inside the timed call)",
+           "ms": ms, "one_pass_ms": res["one_pass"], "rows_per_s": n / ms * 1e3,
+           "roofline": hbm_roofline("partition_scatter_kernel<PackedKey,4|3> x 2 + agg_pieces_kernel<1> (qsx_agg_update: two partition passes, "
+                                    "4096 pieces through LDS tables)", 12 * n, ms, algorithmic_bytes_per_row=12,
+                                    note="three kernels move the rows: 5 x the algorithmic bytes cross HBM (12 read + 12 written per pass, 12 read by the pieces)"),
+           "checked": checked}
+    del key, val
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as O
+        rng = np.random.default_rng(17)
+
+        def gen(m):
+            return [rng.integers(0, groups, size=m).astype(np.int32), rng.integers(0, 1 << 20, size=m).astype(np.float64) / 64.0]
+
+        def run(c, m):
+            secs, s_ = O.bench_agg(cfg, c, m, 4 * 1024 * 1024 // 12, threads)
+            s_.close()
+            return secs
+        small = gen(1_000_000)
+        m = sized_sample(lambda: run(small, 1_000_000), 1_000_000, args.secondary_cpu_seconds / 5.0, 2_000_000, 40_000_000)
+        c = gen(m)
+        secs, trials = trials_2_to_4(lambda: run(c, m))
+        out["cpu_baseline"] = {"value": m / secs, "unit": "rows/s", "cores": threads, "kind": "port", "trials_s": trials,
+                               "sample": f"oracle: PackedPayloadHashTable aggregation, {groups} groups, {m} rows in 4 MB blocks, {threads} worker threads; 5 trials, mean of 2-4"}
+    return out
+
+
 def secondary_join_small_build(ctx, args, threads):
     """C2 with a build side that fits LDS (a dimension table: 25 K keys — nation / region / a filtered dimension / one partition
     of a radix split): north_star's "LDS-staged hash tables".  Every workgroup copies the table into its LDS and answers its
@@ -1209,7 +1274,7 @@ def secondary_block(ctx, args):
     threads = usable_cores()
     out = {}
     legs = [("c1_select", secondary_c1_select), ("q1_coded", secondary_q1_coded), ("c3_minimal", secondary_c3_minimal),
-            ("join_small_build", secondary_join_small_build)]
+            ("join_small_build", secondary_join_small_build), ("agg_many_groups", secondary_agg_many_groups)]
     for name, fn in legs:
         t0 = time.perf_counter()
         try:

@@ -196,9 +196,13 @@ class PartitionExchangeWorkOrder : public WorkOrder {
         recv_words[r] = WordsOf(recv_rows[r]);
         max_rows = std::max(max_rows, send_rows[r]);
       }
+      bool nullable_attribute = false;
+      for (std::size_t a = 0; a < relation.size(); ++a) nullable_attribute = nullable_attribute || relation.getAttributeType(static_cast<attribute_id>(a)).nullable;
+      // (the rank's own piece is copied straight into the output block unless null bits travel: nothing is staged for it)
+      const std::int64_t staged_rows = nullable_attribute ? total_send : total_send - send_rows[me];
       for (std::size_t a = 0; a < relation.size(); ++a) {
         const Type &t = relation.getAttributeType(static_cast<attribute_id>(a));
-        send[a].reset(new DeviceBuffer(static_cast<std::size_t>(total_send) * t.width + 8));
+        send[a].reset(new DeviceBuffer(static_cast<std::size_t>(staged_rows) * t.width + 8));
         if (t.nullable) {
           if (row_numbers == nullptr) row_numbers = RowNumbers(max_rows);
           send_bits[a].reset(new DeviceBuffer(static_cast<std::size_t>(Sum(send_words)) * 8 + 8));
@@ -275,8 +279,8 @@ class PartitionExchangeWorkOrder : public WorkOrder {
           PackNullBits(bitmaps, recv_rows, *row_numbers, out->nullBitmap(static_cast<attribute_id>(a)));
         }
       }
-      ranks->synchronize();       // (the watchdog's wait: a peer that never arrives ends the round with QSX_ERR_COMM)
     }
+    ranks->synchronize();         // (the watchdog's wait: a peer that never arrives ends the round with QSX_ERR_COMM)
     in_collectives_ = false;
     if (out != nullptr) dest_->returnBlock(out_id, total_recv, first + me);
   }
