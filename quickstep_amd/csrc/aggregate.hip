@@ -2711,7 +2711,20 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
     bool pieces_fit = false;
     if (two_level_from > 0 && st->geometry_est >= two_level_from && n >= 2 * partition_min_rows() && two_level_plan(st) &&
         (two_level_slots(st, &pieces_fit), pieces_fit) && (st->geometry_est >= kTwoLevelWhateverTheOrder || decide_two_level(st, cols, n, s) == 1)) {
-      rc = update_two_level(st, cols, n, s);
+      // the passes ping-pong the used columns through scratch (2 x their bytes): a call whose columns would take more than
+      // 8 GiB of it goes slice by slice — every slice flushes its groups into the state like a call of its own
+      size_t row_bytes = 0;
+      for (int c = 0; c < st->config.num_columns; ++c) row_bytes += ((st->used_columns >> c) & 1u) ? st->dev.column_width[c] : 0;
+      static const long long forced = []() { const char *e = getenv("QSX_AGG_TWO_LEVEL_SLICE_ROWS"); return e != nullptr ? atoll(e) : 0ll; }();
+      const int64_t slice = forced > 0 ? forced : static_cast<int64_t>((size_t(8) << 30) / (2 * (row_bytes ? row_bytes : 1)));
+      rc = QSX_OK;
+      for (int64_t at = 0; at < n && rc == QSX_OK; at += slice) {
+        const void *from[QSX_MAX_COLUMNS];
+        for (int c = 0; c < st->config.num_columns; ++c) {
+          from[c] = cols[c] != nullptr ? static_cast<const char *>(cols[c]) + static_cast<size_t>(at) * st->dev.column_width[c] : nullptr;
+        }
+        rc = update_two_level(st, at == 0 ? cols : from, std::min<int64_t>(slice, n - at), s);
+      }
     } else {
       rc = update_partitioned(st, cols, n, s);
     }

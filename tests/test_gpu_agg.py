@@ -608,6 +608,21 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
     assert_same_groups(finalize_np(st, dev), results[0])
     st.close()
     o = oracle.AggState(cfg)                                                    # (the oracle's hash table: seconds at these sizes)
+    # (a call whose columns would not fit 8 GiB of scratch goes slice by slice; forced here: a child process, the variable is read once)
+    if keys_kind == "int":
+        import subprocess, sys, os
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import quickstep_amd.capi as capi; from quickstep_amd import types as T;"
+                "n, groups = 17_000_017, 1_000_000; g = torch.Generator(device='cuda:0'); g.manual_seed(3);"
+                "k = torch.randint(0, groups, (n,), device='cuda:0', generator=g, dtype=torch.int32); v = torch.randint(0, 1000, (n,), device='cuda:0', generator=g).double();"
+                "cfg = T.make_agg_config(T.AGG_GENERIC, [(T.INT, None), (T.DOUBLE, None)], keys=[0], aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(1))], est_groups=groups);"
+                "st = capi.AggState(cfg); st.update([k, v], n); keys, vals, _, found = st.finalize(torch.device('cuda:0')); f = int(found.item());"
+                "wc = torch.bincount(k.long(), minlength=groups); ws = torch.zeros(groups, dtype=torch.float64, device='cuda:0').index_add_(0, k.long(), v);"
+                "gk = keys[0][:f].long(); assert f == int((wc > 0).sum()); assert bool((vals[0][:f] == wc[gk]).all()) and bool((vals[1][:f] == ws[gk]).all());"
+                "capi.lib.qsx_debug_agg_two_level_updates.restype = __import__('ctypes').c_longlong; assert capi.lib.qsx_debug_agg_two_level_updates() == 4; print('sliced ok')"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, QSX_AGG_TWO_LEVEL_SLICE_ROWS="5000000", QSX_AGG_TWO_LEVEL_MIN_GROUPS="100000"))
+        assert r.returncode == 0 and "sliced ok" in r.stdout, r.stderr[-2000:]
     o.update([x[:half] for x in cols], half)
     o.update([x[half:] for x in cols], n - half)
     assert_same_groups(results[0], o.finalize())
