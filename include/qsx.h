@@ -422,6 +422,12 @@ int qsx_join_key_pack_char(const void *col_dev, int width, int64_t n, int64_t *o
  *   block_cols   host array [b * ncols + k] of device pointers: block b's stripe of key component k */
 int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks, const int64_t *block_rows,
                              const void *const *block_cols, int64_t *out_dev, int *out_exact, qsx_stream_t stream);
+/* The same over blocks that hold some components COMPRESSED (see qsx_key_coding_t below): block_code_widths[b * ncols + k] =
+ * 0 (block_cols holds values), 1, 2 or 4 (it holds codes that wide), block_dictionaries[b * ncols + k] = the block's dictionary
+ * of that component on the device, or NULL: truncated values.  Either array may be NULL (no component is compressed). */
+int qsx_join_key_pack_blocks_coded(int ncols, const int32_t *types, int64_t num_blocks, const int64_t *block_rows,
+                                   const void *const *block_cols, const int32_t *block_code_widths, const void *const *block_dictionaries,
+                                   int64_t *out_dev, int *out_exact, qsx_stream_t stream);
 
 /* Drop every entry, keep the allocation (a new query re-using the table;
  * counterpart of DestroyHashOperator + re-creation, relational_operators/

@@ -97,6 +97,7 @@ _SIGNATURES = {
     "qsx_join_probe": (_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_probe_lip": (_int, [_vp, _vp, _i64, _i32, _vp, _int, _pp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_key_pack_blocks": (_int, [_int, C.POINTER(_i32), _i64, C.POINTER(_i64), _pp, _vp, C.POINTER(_int), _vp]),
+    "qsx_join_key_pack_blocks_coded": (_int, [_int, C.POINTER(_i32), _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp, C.POINTER(_int), _vp]),
     "qsx_join_build_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp]),
     "qsx_join_probe_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_probe_count_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _vp, _vp]),
@@ -541,6 +542,30 @@ def join_key_pack_blocks(blocks, stream=None):
     types = (C.c_int32 * ncols)(*[qsx_type_of(c) for c in blocks[0]])
     exact = C.c_int(0)
     _check(_lib.qsx_join_key_pack_blocks(ncols, types, nb, rows, ptrs, _ptr(out), C.byref(exact), _stream(stream)), "qsx_join_key_pack_blocks")
+    return out[:total], bool(exact.value)
+
+
+def join_key_pack_blocks_coded(blocks, coding, types, stream=None):
+    """qsx_join_key_pack_blocks_coded: blocks[b][k] = block b's stripe of component k as it lies, coding[b][k] = (code width or 0,
+    dictionary or None), types[k] = T.INT / T.LONG of the component."""
+    nb, ncols = len(blocks), len(types)
+    rows_of = [(b[0].numel() if coding[i][0][0] == 0 else b[0].numel() * b[0].element_size() // coding[i][0][0]) for i, b in enumerate(blocks)]
+    total = sum(rows_of)
+    dev = blocks[0][0].device
+    out = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    rows = (C.c_int64 * max(nb, 1))(*rows_of)
+    ptrs = (C.c_void_p * max(nb * ncols, 1))()
+    widths = (C.c_int32 * max(nb * ncols, 1))()
+    dicts = (C.c_void_p * max(nb * ncols, 1))()
+    for i, b in enumerate(blocks):
+        for k in range(ncols):
+            ptrs[i * ncols + k] = b[k].data_ptr() if b[k].numel() else None
+            widths[i * ncols + k] = coding[i][k][0]
+            dicts[i * ncols + k] = coding[i][k][1].data_ptr() if coding[i][k][1] is not None else None
+    tarr = (C.c_int32 * ncols)(*types)
+    exact = C.c_int(0)
+    _check(_lib.qsx_join_key_pack_blocks_coded(ncols, tarr, nb, rows, ptrs, widths, dicts, _ptr(out), C.byref(exact), _stream(stream)),
+           "qsx_join_key_pack_blocks_coded")
     return out[:total], bool(exact.value)
 
 

@@ -769,8 +769,10 @@ __global__ __launch_bounds__(kJBlock) void key_pack_char_kernel(const unsigned c
 // The composite keys of a run of blocks -> ONE stripe of packed keys, block after block (qsx_join_key_pack_blocks): a wave
 // takes tiles of 512 rows of one block; the blocks' key columns follow the run table at word cols_offset
 // ([block * ncols + component]), the table's `base` is the block's first row in the output.
+// coded != 0: behind the column pointers lie, per (block, component), a code width (0 = values) and a dictionary address — the
+// component of a block that holds it compressed is read as it lies (block_runs.hpp "Coded key stripes").
 __global__ __launch_bounds__(kJBlock) void key_pack_runs_kernel(KeyPackArgs a, const long long *__restrict__ runs, long long cols_offset,
-                                                               int64_t *__restrict__ out) {
+                                                               int64_t *__restrict__ out, int coded) {
   constexpr int kTileRows = 512;
   const int lane = lane_id();
   const int num_tiles = static_cast<int>(runs[2]);
@@ -780,14 +782,25 @@ __global__ __launch_bounds__(kJBlock) void key_pack_runs_kernel(KeyPackArgs a, c
     const long long n = run_rows(runs, at.block);
     const long long out_first = run_base(runs, at.block);
     const long long *cols = runs + cols_offset + static_cast<long long>(at.block) * a.ncols;
+    const long long total_entries = runs[0] * a.ncols;
+    const long long *widths = cols + total_entries, *dicts = widths + total_entries;   // (only read when coded)
     for (int r = lane; r < kTileRows; r += kWave) {
       const long long i = static_cast<long long>(at.tile_in_block) * kTileRows + r;
       if (i >= n) break;
       uint64_t acc = 0;
       for (int k = 0; k < a.ncols; ++k) {
         const void *col = as_global(reinterpret_cast<const void *>(cols[k]));
-        const uint64_t v = a.is_long[k] ? static_cast<uint64_t>(static_cast<const int64_t *>(col)[i])
-                                        : static_cast<uint64_t>(static_cast<const uint32_t *>(col)[i]);
+        const int code_width = coded != 0 ? static_cast<int>(widths[k]) : 0;
+        uint64_t v;
+        if (code_width == 0) {
+          v = a.is_long[k] ? static_cast<uint64_t>(static_cast<const int64_t *>(col)[i]) : static_cast<uint64_t>(static_cast<const uint32_t *>(col)[i]);
+        } else {
+          const uint32_t code = code_width == 1 ? static_cast<const uint8_t *>(col)[i]
+                                                : (code_width == 2 ? static_cast<const uint16_t *>(col)[i] : static_cast<const uint32_t *>(col)[i]);
+          const void *dict = as_global(reinterpret_cast<const void *>(dicts[k]));
+          if (dict == nullptr) v = code;   // a truncated value (never negative): as wide as it gets
+          else v = a.is_long[k] ? static_cast<uint64_t>(static_cast<const int64_t *>(dict)[code]) : static_cast<uint64_t>(static_cast<const uint32_t *>(dict)[code]);
+        }
         if (a.exact) acc |= v << a.shift[k];
         else acc = k == 0 ? v : combine_hashes(acc, v);
       }
@@ -1141,8 +1154,9 @@ int qsx_join_key_pack_char(const void *col_dev, int width, int64_t n, int64_t *o
   return QSX_OK;
 }
 
-int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks, const int64_t *block_rows,
-                             const void *const *block_cols, int64_t *out_dev, int *out_exact, qsx_stream_t stream) {
+static int join_key_pack_blocks_impl(int ncols, const int32_t *types, int64_t num_blocks, const int64_t *block_rows,
+                                     const void *const *block_cols, const int32_t *block_code_widths, const void *const *block_dictionaries,
+                                     int64_t *out_dev, int *out_exact, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();
   if (ncols < 1 || ncols > QSX_MAX_KEYS || types == nullptr || num_blocks < 0 || out_exact == nullptr ||
       (num_blocks > 0 && (block_rows == nullptr || block_cols == nullptr))) {
@@ -1181,15 +1195,38 @@ int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks
       table.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(col)));
     }
   }
+  bool coded = false;
+  for (int64_t e = 0; block_code_widths != nullptr && e < num_blocks * ncols; ++e) {
+    const int w = block_code_widths[e];
+    if (w != 0 && w != 1 && w != 2 && w != 4) return QSX_ERR_INVALID_ARGUMENT;
+    coded = coded || w != 0;
+  }
+  if (coded) {
+    for (int64_t e = 0; e < num_blocks * ncols; ++e) table.push_back(block_code_widths[e]);
+    for (int64_t e = 0; e < num_blocks * ncols; ++e) {
+      const void *d = block_dictionaries != nullptr && block_code_widths[e] != 0 ? block_dictionaries[e] : nullptr;
+      table.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(d)));
+    }
+  }
   hipStream_t s = as_stream(stream);
   const size_t bytes = table.size() * sizeof(long long);
   const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
   if (runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
   const int rc = staged_upload(s, table.data(), bytes);
   if (rc != QSX_OK) return rc;
-  hipLaunchKernelGGL(key_pack_runs_kernel, dim3(grid_for(tiles, kJBlock / kWave)), dim3(kJBlock), 0, s, a, runs_dev, cols_offset, out_dev);
+  hipLaunchKernelGGL(key_pack_runs_kernel, dim3(grid_for(tiles, kJBlock / kWave)), dim3(kJBlock), 0, s, a, runs_dev, cols_offset, out_dev, coded ? 1 : 0);
   QSX_CHECK_LAUNCH();
   return QSX_OK;
+}
+
+int qsx_join_key_pack_blocks(int ncols, const int32_t *types, int64_t num_blocks, const int64_t *block_rows,
+                             const void *const *block_cols, int64_t *out_dev, int *out_exact, qsx_stream_t stream) {
+  return join_key_pack_blocks_impl(ncols, types, num_blocks, block_rows, block_cols, nullptr, nullptr, out_dev, out_exact, stream);
+}
+int qsx_join_key_pack_blocks_coded(int ncols, const int32_t *types, int64_t num_blocks, const int64_t *block_rows,
+                                   const void *const *block_cols, const int32_t *block_code_widths, const void *const *block_dictionaries,
+                                   int64_t *out_dev, int *out_exact, qsx_stream_t stream) {
+  return join_key_pack_blocks_impl(ncols, types, num_blocks, block_rows, block_cols, block_code_widths, block_dictionaries, out_dev, out_exact, stream);
 }
 
 static int destroy_table(qsx_join_table_t *t, bool wait_for_device) {

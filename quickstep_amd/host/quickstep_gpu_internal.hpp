@@ -235,22 +235,32 @@ struct RunJoinKeys {
     std::vector<const void *> cols;
     std::vector<std::int32_t> types;
     for (attribute_id a : attrs) types.push_back(relation.getAttributeType(a).id == kChar ? static_cast<std::int32_t>(kLong) : relation.getAttributeType(a).id);
+    // (a component that a block holds compressed is packed from its code stripe: qsx_join_key_pack_blocks_coded)
+    std::vector<std::int32_t> widths;
+    std::vector<const void *> dicts;
     std::int64_t total = 0;
     for (std::size_t b = 0; b < blocks.size(); ++b) {
       for (attribute_id a : attrs) {
-        if (relation.getAttributeType(a).id == kChar) {
+        const TypeID id = relation.getAttributeType(a).id;
+        const CompressedAttribute *c = (id == kInt || id == kLong) && blocks[b]->numTuples() > 0 ? blocks[b]->compressedAttribute(a) : nullptr;
+        if (id == kChar) {
           char_keys.push_back(CharKeyAsLong(*blocks[b], a));
           cols.push_back(char_keys.back()->ptr);
+        } else if (c != nullptr) {
+          cols.push_back(c->codes);
         } else {
           cols.push_back(blocks[b]->stripe(a));
         }
+        widths.push_back(c != nullptr ? c->code_width : 0);
+        dicts.push_back(c != nullptr && c->kind == CompressedAttribute::kDictionary ? c->dictionary : nullptr);
       }
       total += rows[b];
     }
     packed.reset(new DeviceBuffer(static_cast<std::size_t>(total) * 8 + 8));
     int is_exact = 0;
-    CheckStatus(qsx_join_key_pack_blocks(static_cast<int>(attrs.size()), types.data(), static_cast<std::int64_t>(blocks.size()), rows.data(),
-                                         cols.data(), static_cast<std::int64_t *>(packed->ptr), &is_exact, CurrentStream()),
+    CheckStatus(qsx_join_key_pack_blocks_coded(static_cast<int>(attrs.size()), types.data(), static_cast<std::int64_t>(blocks.size()), rows.data(),
+                                               cols.data(), widths.data(), dicts.data(), static_cast<std::int64_t *>(packed->ptr), &is_exact,
+                                               CurrentStream()),
                 "qsx_join_key_pack_blocks");
     exact = is_exact != 0;
     std::int64_t at = 0;

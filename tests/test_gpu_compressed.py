@@ -956,3 +956,29 @@ def test_small_build_side_probed_with_sorted_truncated_keys(capi, oracle, dev, k
         outs, cnt = table.probe_project_blocks(stripes, [[to_dev(x, dev) for x in blocks]], [], coding=coding, key_dtype=torch.int32)
     assert int(cnt.item()) == want
     assert np.array_equal(np.sort(outs[0].cpu().numpy()[:want]), np.sort(all_keys[all_keys % 3 == 0]))
+
+
+@pytest.mark.parametrize("types,dtypes", [((T.INT, T.INT), (np.int32, np.int32)), ((T.INT, T.LONG, T.INT), (np.int32, np.int64, np.int32))])
+def test_composite_keys_packed_from_compressed_components(capi, oracle, dev, types, dtypes):
+    """qsx_join_key_pack_blocks_coded: the packed (exact, <= 64 bits) or folded (wider) composite key of a run of blocks whose
+    components lie compressed per block equals qsx_join_key_pack_blocks over the decoded stripes, bit for bit."""
+    rows = [5_000, 1, 0, 7_003, 2_500, 4_097, 513]
+    comps = [_key_blocks_of_every_kind(np.random.default_rng(11 + k), dt, rows, lo=1000 * k) for k, dt in enumerate(dtypes)]
+    blocks, coding, plain = [], [], []
+    for b in range(len(rows)):
+        stripes, cods, vals = [], [], []
+        for k in range(len(types)):
+            values = comps[k][(b + 2 * k) % len(rows)]
+            values = np.resize(values, rows[b]).astype(dtypes[k]) if rows[b] else np.zeros(0, dtype=dtypes[k])
+            (s,), (c,), _ = _coded_run(oracle, [values], dev)
+            stripes.append(s)
+            cods.append(c)
+            vals.append(to_dev(values, dev))
+        blocks.append(stripes)
+        coding.append(cods)
+        plain.append(vals)
+    got, exact = capi.join_key_pack_blocks_coded(blocks, coding, list(types))
+    want, want_exact = capi.join_key_pack_blocks([p for p in plain])
+    assert exact == want_exact == (sum(32 if t == T.INT else 64 for t in types) <= 64)
+    assert torch.equal(got, want)
+    assert any(c[0] != 0 for cs in coding for c in cs), "no component of any block was compressed"
