@@ -254,3 +254,46 @@ def test_copy_segments_equals_a_copy_per_segment(capi, dev):
     capi.copy_segments([src[i] for i in range(n)], [dst[p[i]] for i in range(n)])
     assert torch.equal(dst[perm], src)
     capi.copy_segments([], [])
+
+
+def test_coded_block_forms_argument_errors_and_plain_equivalence(capi, dev):
+    """qsx_*_blocks_coded: a coding with a width other than 0 / 1 / 2 / 4, or a dictionary for a block that holds values, is an
+    invalid argument; a NULL coding and a coding of all zeros ARE the plain forms; empty runs do nothing."""
+    import ctypes as C
+    import torch
+    from quickstep_amd import types as T
+    lib = capi.lib
+    keys = torch.arange(1000, dtype=torch.int32, device=dev)
+    table = capi.JoinTable(T.INT, 1000, key_range=(0, 999))
+    table.build_blocks([keys[:400], keys[400:]], [0, 400], coding=[(0, None), (0, None)])       # all zeros: the plain form
+    assert table.size() == 1000
+    probe = torch.randint(0, 2000, (5000,), device=dev, dtype=torch.int32)
+    want = int(table.probe_count_blocks([probe]).item())
+    assert int(table.probe_count_blocks([probe], coding=[(0, None)]).item()) == want
+    with pytest.raises(capi.QsxError) as e:
+        table.probe_count_blocks([probe], coding=[(3, None)])
+    assert e.value.status == T.ERR_INVALID_ARGUMENT
+    d = torch.zeros(4, dtype=torch.int32, device=dev)
+    with pytest.raises(capi.QsxError) as e:
+        table.probe_count_blocks([probe], coding=[(0, d)])                                          # a dictionary without codes
+    assert e.value.status == T.ERR_INVALID_ARGUMENT
+    with pytest.raises(capi.QsxError) as e:
+        table.build_blocks([keys], [0], coding=[(8, None)])
+    assert e.value.status == T.ERR_INVALID_ARGUMENT
+    # NULL coding struct / NULL width array through the raw entry point
+    rows = (C.c_int64 * 1)(probe.numel())
+    kptr = (C.c_void_p * 1)(probe.data_ptr())
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    assert lib.qsx_join_probe_count_blocks_coded(table._h, 1, rows, kptr, None, None, C.c_void_p(count.data_ptr()), None) == 0
+    assert int(count.item()) == want
+    empty = capi.KeyCoding(None, None)
+    assert lib.qsx_join_probe_count_blocks_coded(table._h, 1, rows, kptr, C.byref(empty), None, C.c_void_p(count.data_ptr()), None) == 0
+    assert int(count.item()) == want
+    assert int(table.probe_count_blocks([], coding=[]).item()) == 0
+    lip = capi.LipFilter(T.LIP_BITVECTOR_EXACT, 2000, min_value=0)
+    with pytest.raises(capi.QsxError) as e:
+        lip.build_blocks([keys], coding=[(5, None)], key_type=T.INT)
+    assert e.value.status == T.ERR_INVALID_ARGUMENT
+    with pytest.raises(capi.QsxError) as e:
+        capi.join_key_pack_blocks_coded([[keys, keys]], [[(0, None), (7, None)]], [T.INT, T.INT])
+    assert e.value.status == T.ERR_INVALID_ARGUMENT
