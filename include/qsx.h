@@ -943,6 +943,12 @@ int qsx_join_probe_lip(qsx_join_table_t *table, const void *keys_dev, int64_t n,
                        const uint64_t *filter_dev, int num_lip, const qsx_lip_filter_t *const *lip_filters,
                        int32_t *out_probe_tid_dev, int32_t *out_build_tid_dev, int64_t capacity,
                        int64_t *out_count_dev, qsx_stream_t stream);
+/* The semi join's form of qsx_join_probe_lip: out_bitmap bit i = filter[i] AND every LIP filter passes key i AND key i is in
+ * the table (HashSemiJoinWorkOrder under its LIPFilterAdaptiveProber, relational_operators/HashJoinOperator.cpp:795-816 with
+ * :462-470) — one pass over the key stripe where qsx_lip_probe + qsx_join_probe_exists make two. */
+int qsx_join_probe_exists_lip(qsx_join_table_t *table, const void *keys_dev, int64_t n, const uint64_t *filter_dev, int num_lip,
+                              const qsx_lip_filter_t *const *lip_filters, uint64_t *out_bitmap_dev, int64_t *out_count_dev,
+                              qsx_stream_t stream);
 
 
 /* ======================================================================

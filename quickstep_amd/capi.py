@@ -103,6 +103,7 @@ _SIGNATURES = {
     "qsx_join_probe_count_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _vp, _vp]),
     "qsx_join_probe_project_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, C.POINTER(T.JoinProjection), _i64, _vp, _vp]),
     "qsx_join_probe_exists_blocks": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _pp, _int, _pp, _vp, _vp]),
+    "qsx_join_probe_exists_lip": (_int, [_vp, _vp, _i64, _vp, _int, _pp, _vp, _vp, _vp]),
     "qsx_join_build_blocks_coded": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _vp, C.POINTER(_i32), _pp, _vp]),
     "qsx_join_probe_blocks_coded": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _vp, C.POINTER(_i32), _pp, _vp, _vp, _i64, _vp, _vp]),
     "qsx_join_probe_count_blocks_coded": (_int, [_vp, _i64, C.POINTER(_i64), _pp, _vp, _pp, _vp, _vp]),
@@ -746,6 +747,16 @@ class JoinTable:
         _check(_lib.qsx_join_probe(self._h, _ptr(keys), n, probe_base_tid, _ptr(filter_bitmap), _ptr(out_p),
                                    _ptr(out_b), capacity, _ptr(count), _stream(stream)), "qsx_join_probe")
         return out_p, out_b, count
+
+    def probe_exists_lip(self, keys, lip_filters, filter_bitmap=None, stream=None):
+        """qsx_join_probe_exists_lip: the semi probe with the work order's LIP filters tested inside: (bitmap, count int64[1])."""
+        n = keys.numel()
+        out = new_bitmap(n, keys.device)
+        count = torch.zeros(1, dtype=torch.int64, device=keys.device)
+        fptr = (C.c_void_p * max(len(lip_filters), 1))(*[f._h for f in lip_filters])
+        _check(_lib.qsx_join_probe_exists_lip(self._h, _ptr(keys), n, _ptr(filter_bitmap), len(lip_filters), fptr, _ptr(out), _ptr(count),
+                                              _stream(stream)), "qsx_join_probe_exists_lip")
+        return out, count
 
     def probe_lip(self, keys, lip_filters, capacity=None, probe_base_tid=0, filter_bitmap=None, out=None, stream=None):
         """qsx_join_probe_lip: the probe with the work order's LIP filters (LipFilter objects over the probe key) tested inside."""

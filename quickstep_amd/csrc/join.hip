@@ -2043,6 +2043,46 @@ int qsx_join_probe_lip(qsx_join_table_t *t, const void *keys_dev, int64_t n, int
   return launch_probe<0>(t, keys_dev, n, probe_base_tid, in, out_probe_tid_dev, out_build_tid_dev, capacity, out_count_dev, nullptr, 0, s);
 }
 
+int qsx_join_probe_exists_lip(qsx_join_table_t *t, const void *keys_dev, int64_t n, const uint64_t *filter_dev, int num_lip,
+                              const qsx_lip_filter_t *const *lip_filters, uint64_t *out_bitmap_dev, int64_t *out_count_dev, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (t == nullptr || n < 0 || num_lip < 0 || (num_lip > 0 && lip_filters == nullptr) || (n > 0 && (keys_dev == nullptr || out_bitmap_dev == nullptr))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  for (int f = 0; f < num_lip; ++f) {
+    if (lip_filters[f] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = as_stream(stream);
+  if (num_lip == 0) return launch_probe<2>(t, keys_dev, n, 0, filter_dev, nullptr, nullptr, 0, out_count_dev, out_bitmap_dev, 0, s);
+  qsx_join_table *direct = t->dense ? t : (n != 0 ? sealed_shadow(t, s, n) : nullptr);
+  if (direct != nullptr && num_lip <= kMaxFusedLip && n >= (1 << 16) && one_pass_enabled()) {
+    if (out_count_dev != nullptr) QSX_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), s));
+    sealed_pack(direct, s);
+    std::shared_lock<std::shared_mutex> lock(direct->mutex);
+    LipViews lips{};
+    for (int f = 0; f < num_lip; ++f) lips.f[f] = lip_filter_view(lip_filters[f]);
+    const int64_t tiles = (n + kDenseTile - 1) / kDenseTile;
+    unsigned long long *count = reinterpret_cast<unsigned long long *>(out_count_dev);
+    if (num_lip == 1) {
+      return launch_lds_dense_probe<2, false, false, 1>(direct, keys_dev, n, 0, filter_dev, nullptr, nullptr, 0, count, out_bitmap_dev, 0, s, nullptr, tiles, lips);
+    }
+    return launch_lds_dense_probe<2, false, false, 2>(direct, keys_dev, n, 0, filter_dev, nullptr, nullptr, 0, count, out_bitmap_dev, 0, s, nullptr, tiles, lips);
+  }
+  // any other table: the filters one after the other into a bitmap of the call, then the existence probe under it
+  CallScratch scratch(s);
+  const size_t words = static_cast<size_t>((n + 63) / 64 + 1);
+  int rc = scratch.reserve(CallScratch::padded(words * 8) * 2);
+  if (rc != QSX_OK) return rc;
+  uint64_t *bitmaps[2] = {static_cast<uint64_t *>(scratch.take(words * 8)), static_cast<uint64_t *>(scratch.take(words * 8))};
+  const uint64_t *in = filter_dev;
+  for (int f = 0; f < num_lip; ++f) {
+    rc = qsx_lip_probe(lip_filters[f], t->key_type, keys_dev, n, in, bitmaps[f & 1], nullptr, stream);
+    if (rc != QSX_OK) return rc;
+    in = bitmaps[f & 1];
+  }
+  return launch_probe<2>(t, keys_dev, n, 0, in, nullptr, nullptr, 0, out_count_dev, out_bitmap_dev, 0, s);
+}
+
 int qsx_join_probe_count(qsx_join_table_t *t, const void *keys_dev, int64_t n,
                          const uint64_t *filter_dev, int64_t *out_count_dev, qsx_stream_t stream) {
   QSX_REQUIRE_DEVICE();

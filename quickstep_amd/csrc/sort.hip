@@ -52,6 +52,38 @@ __global__ __launch_bounds__(kSBlock) void sort_keys_kernel(const T *__restrict_
   }
 }
 
+// Up to kSmallSort (key image, row number) pairs sorted by ONE workgroup in LDS — a bitonic network on (key, position), so
+// equal keys keep their order — instead of 6-11 radix passes of three launches each: the candidates of an ORDER BY ... LIMIT k
+// (qsx_sort_top_k: k rows and the population of one histogram bin), the runs of a few hundred groups of a finalize.
+// out[i] = tids[position of the i-th smallest key].
+constexpr int kSmallSort = 2048;
+__global__ __launch_bounds__(1024) void small_sort_kernel(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ tids, int n,
+                                                         int32_t *__restrict__ out) {
+  __shared__ unsigned long long s_key[kSmallSort];
+  __shared__ unsigned short s_pos[kSmallSort];
+  for (int i = threadIdx.x; i < kSmallSort; i += 1024) {
+    s_key[i] = i < n ? keys[i] : ~0ull;     // (padding sorts behind every real pair: an all-ones key of a real row has the smaller position)
+    s_pos[i] = static_cast<unsigned short>(i);
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  for (int k = 2; k <= kSmallSort; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo + j;
+      const bool ascending = (lo & k) == 0;
+      const unsigned long long ka = s_key[lo], kb = s_key[hi];
+      const unsigned short pa = s_pos[lo], pb = s_pos[hi];
+      const bool a_behind_b = ka > kb || (ka == kb && pa > pb);
+      if (a_behind_b == ascending) {
+        s_key[lo] = kb; s_key[hi] = ka;
+        s_pos[lo] = pb; s_pos[hi] = pa;
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += 1024) out[i] = tids[s_pos[i]];
+}
+
 // ---- top-k: threshold selection on the most significant key -------------------------------------------------------
 // LIMIT k after ORDER BY needs the k first rows only.  A 4096-bin histogram of the leading 12 bits of the first key's
 // image locates the bin in which the k-th row falls; the rows up to that bin (k + one bin's population, in input
@@ -230,6 +262,12 @@ static int sort_tids(int nkeys, const void *const *key_cols, const int32_t *key_
                          static_cast<const unsigned long long *>(key_cols[k]), tids_a, n, type, desc, keys_a);
     }
     QSX_CHECK_LAUNCH();
+    if (n <= kSmallSort) {   // one workgroup, one launch
+      hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(1024), 0, s, keys_a, tids_a, static_cast<int>(n), tids_b);
+      QSX_CHECK_LAUNCH();
+      int32_t *tt = tids_a; tids_a = tids_b; tids_b = tt;
+      continue;
+    }
     const int bits = type == QSX_CHAR ? 8 : ((type == QSX_INT || type == QSX_FLOAT) ? 32 : 64);
     for (int shift = 0; shift < bits; shift += 6) {
       const void *src[2] = {keys_a, tids_a};
@@ -298,7 +336,9 @@ int qsx_sort_top_k(int nkeys, const void *const *key_cols, const int32_t *key_ty
     const bool narrow = type == QSX_INT || type == QSX_FLOAT;
     const int width = narrow ? 32 : 64;
     const int grid = grid_for(n, kSBlock * 8);
-    const int64_t good_enough = std::max<int64_t>(std::max<int64_t>(4 * k, 65536), n / 1024);
+    // (candidates that fit one workgroup's LDS sort are worth another histogram level — 60 us — against the radix passes'
+    // 11 x 3 launches; a bin of very many equal keys ends the refinement at 60 bits either way)
+    const int64_t good_enough = 4 * k <= kSmallSort ? kSmallSort : std::max<int64_t>(std::max<int64_t>(4 * k, 65536), n / 1024);
     int prefix_bits = 0;
     unsigned long long prefix = 0;
     long long below = 0;

@@ -220,10 +220,20 @@ class DistributedQ3:
         # orders
         with ph("orders: select + LIP probe + semi probe + gather + build + LIP"):
             o_sel, _ = ops.select_cmp(inp["o_orderdate"], T.LT, DATE_CUT)
-            o_lip = self.lip_c.probe(inp["o_custkey"], in_bitmap=o_sel)[0] if self.use_lip else o_sel
-            o_ok, o_cnt = self.t_c.probe_exists(inp["o_custkey"], filter_bitmap=o_lip)
+            if self.use_lip and self.fused and hasattr(self.t_c, "probe_exists_lip"):
+                # (the semi join's own LIP prober: filter bit and table word from one pass over o_custkey)
+                o_ok, o_cnt = self.t_c.probe_exists_lip(inp["o_custkey"], [self.lip_c], filter_bitmap=o_sel)
+            else:
+                o_lip = self.lip_c.probe(inp["o_custkey"], in_bitmap=o_sel)[0] if self.use_lip else o_sel
+                o_ok, o_cnt = self.t_c.probe_exists(inp["o_custkey"], filter_bitmap=o_lip)
             n_o_local = inp["o_orderkey"].numel()
-            (o_keys, o_tids), _ = ops.compact_gather([inp["o_orderkey"], self._tids(n_o_local, tid_base_orders, dev)], o_ok, n_o_local)
+            # the qualifying orders' keys and their tuple ids: the ids come from the bitmap itself (no row-number column is
+            # written and gathered: 56 M x 4 bytes out and in again per step)
+            (o_keys,), _ = ops.compact_gather([inp["o_orderkey"]], o_ok, n_o_local)
+            if hasattr(ops, "bitmap_to_tids"):
+                o_tids, _ = ops.bitmap_to_tids(o_ok, n_o_local, tid_base_orders)
+            else:
+                (o_tids,), _ = ops.compact_gather([self._tids(n_o_local, tid_base_orders, dev)], o_ok, n_o_local)
             (all_ok, all_ot), counts = self._all_gather_rows([o_keys, o_tids], int(o_cnt.item()))
             # the table keeps the position in the gathered list; all_ot turns it into the global orders tuple id
             self.t_o.build(all_ok)

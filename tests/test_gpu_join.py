@@ -1115,3 +1115,32 @@ def test_released_tables_hand_their_memory_to_the_next_one(capi, oracle, dev, fl
         assert np.array_equal(sorted_pairs(p.cpu().numpy()[:rp.size], b.cpu().numpy()[:rp.size]), sorted_pairs(rp, rb))
         torch.cuda.synchronize()              # what the caller of qsx_join_table_release promises
         table.release()
+
+
+@pytest.mark.parametrize("flavour", ["dense", "hashed", "hashed_sparse"])
+@pytest.mark.parametrize("n", [1_000, 70_001, 1_200_007])
+def test_semi_probe_with_lip_filters_inside_equals_the_two_passes(capi, oracle, dev, flavour, n):
+    """qsx_join_probe_exists_lip: the existence bitmap and count of qsx_lip_probe followed by qsx_join_probe_exists — one or two
+    LIP filters, with and without an input bitmap, directly addressed tables (the fused kernel from 64 Ki rows), hashed tables
+    with and without a directly addressed shadow (the two passes inside the call)."""
+    rng = np.random.default_rng(n + len(flavour))
+    spread = 1 if flavour != "hashed_sparse" else 1_000
+    build = (rng.permutation(40_000)[:25_000] * spread).astype(np.int32)
+    probe = (rng.integers(0, 50_000, size=n) * spread).astype(np.int32)
+    table = capi.JoinTable(T.INT, build.size, key_range=(0, 39_999) if flavour == "dense" else None)
+    table.build(to_dev(build, dev))
+    lip_a = capi.LipFilter(T.LIP_BITVECTOR_EXACT, 50_000 * spread, min_value=0)
+    lip_a.build(to_dev(build[build % 3 != 0], dev))
+    lip_b = capi.LipFilter(T.LIP_SINGLE_IDENTITY_HASH, 8_191, min_value=0)
+    lip_b.build(to_dev(build[build % 5 != 0], dev))
+    d_probe = to_dev(probe, dev)
+    filt = bitmap_dev(oracle.bitmap_from_bools(rng.random(n) < 0.7), dev)
+    for lips in ([lip_a], [lip_a, lip_b], []):
+        for f in (None, filt):
+            got, cnt = table.probe_exists_lip(d_probe, lips, filter_bitmap=f)
+            cur = f
+            for lip in lips:
+                cur = lip.probe(d_probe, in_bitmap=cur)[0]
+            want, want_cnt = table.probe_exists(d_probe, filter_bitmap=cur)
+            assert torch.equal(got, want), (flavour, n, len(lips), f is not None)
+            assert int(cnt.item()) == int(want_cnt.item())
