@@ -135,6 +135,30 @@ bool SelectWorkOrder::executeRun() {
   const std::uint64_t *const *selected = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();   // only LIP filters: their bitmaps
   // every tuple: one all-ones TupleIdSequence per distinct block size of the run (a relation's blocks hold the same number of
   // tuples but the last), trailing bits zero
+  if (plain_copy && total_rows > 0) {
+    // every tuple, projected on plain attributes: the selected stripes of the run laid end to end in the output block — one
+    // qsx_copy_segments launch for all attributes (no TupleIdSequences, no compaction, no count to read back)
+    block_id copy_id;
+    BlockReference copy = output_destination_->getBlockForInsertion(total_rows, &copy_id);
+    std::vector<const void *> from;
+    std::vector<void *> to;
+    std::vector<std::int64_t> bytes;
+    for (std::size_t i = 0; i < selection.size(); ++i) {
+      const std::int64_t width = blocks.front()->getRelation().getAttributeType(selection[i]).width;
+      std::int64_t at = 0;
+      for (std::size_t b = 0; b < nb; ++b) {
+        if (rows[b] == 0) continue;
+        from.push_back(blocks[b]->stripe(selection[i]));
+        to.push_back(static_cast<char *>(copy->stripe(static_cast<attribute_id>(i))) + at * width);
+        bytes.push_back(rows[b] * width);
+        at += rows[b];
+      }
+    }
+    CheckStatus(qsx_copy_segments(static_cast<std::int64_t>(from.size()), from.data(), to.data(), bytes.data(), CurrentStream()), "qsx_copy_segments");
+    CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // (the work order's wait, like the reference's execute())
+    output_destination_->returnBlock(copy_id, total_rows, getPartitionId());
+    return true;
+  }
   std::vector<std::unique_ptr<DeviceBuffer>> ones_storage;
   std::vector<const std::uint64_t *> ones_of_block;
   if (plain_copy) {

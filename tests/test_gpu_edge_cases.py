@@ -254,6 +254,13 @@ def test_copy_segments_equals_a_copy_per_segment(capi, dev):
     capi.copy_segments([src[i] for i in range(n)], [dst[p[i]] for i in range(n)])
     assert torch.equal(dst[perm], src)
     capi.copy_segments([], [])
+    # pieces whose addresses and lengths are multiples of 8, 4 and 2 bytes only (a stripe of 349 525 INTs: 4-byte units)
+    out.zero_()
+    pieces = [(8, 8 + 16 * 1000 + 8), (40_004, 40_004 + 4 * 349_525), (2_000_002, 2_000_002 + 2 * 77_777), (3_000_001, 3_000_001 + 12_345)]
+    capi.copy_segments([pool[a:b] for a, b in pieces], [out[a + 16:b + 16] for a, b in pieces])      # (the same residues: + 16)
+    for a, b in pieces:
+        assert torch.equal(out[a + 16:b + 16], pool[a:b])
+    assert int(out.count_nonzero().item()) <= sum(b - a for a, b in pieces)
 
 
 def test_coded_block_forms_argument_errors_and_plain_equivalence(capi, dev):
