@@ -34,7 +34,9 @@ extern "C" {
 #endif
 
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
-#define QSX_ABI_VERSION 16
+/* 17: the block forms over compressed key stripes (qsx_key_coding_t, qsx_join_*_blocks_coded, qsx_lip_*_blocks_coded,
+ *     qsx_join_key_pack_blocks_coded), qsx_join_probe_exists_lip, qsx_copy_segments; nothing older changed its signature */
+#define QSX_ABI_VERSION 17
 
 typedef void *qsx_stream_t;
 
