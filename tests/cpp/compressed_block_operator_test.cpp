@@ -337,6 +337,7 @@ struct JoinRows {
   std::vector<std::int64_t> d_key, f_key;
   std::vector<double> d_val;
   std::vector<std::int32_t> f_qty;
+  std::vector<std::int32_t> d_lo, d_hi, f_lo, f_hi;   // key % 5 and key / 5: a composite key (INT, INT) that joins like the key itself
   JoinRows() {
     std::uint64_t x = 0x2545F4914F6CDD1Dull;
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
@@ -352,6 +353,8 @@ struct JoinRows {
       f_key.push_back(block % 2 == 1 ? few[rnd() % few.size()] : static_cast<std::int64_t>(rnd() % 150000));
       f_qty.push_back(static_cast<std::int32_t>(rnd() % 50));
     }
+    for (std::int64_t k : d_key) { d_lo.push_back(static_cast<std::int32_t>(k % 5)); d_hi.push_back(static_cast<std::int32_t>(k / 5)); }
+    for (std::int64_t k : f_key) { f_lo.push_back(static_cast<std::int32_t>(k % 5)); f_hi.push_back(static_cast<std::int32_t>(k / 5)); }
   }
 };
 struct JoinOut {
@@ -359,20 +362,28 @@ struct JoinOut {
   std::vector<std::int32_t> qty;
   std::vector<double> val;
 };
+// composite: the join key is (lo, hi) = (key % 5, key / 5) — two INT attributes, both compressed (1-byte and 2-byte truncation):
+// the packed key of a run is made from the code stripes (qsx_join_key_pack_blocks_coded).
 JoinOut runCompressedJoin(const JoinRows &rows, bool compressed, bool exact_stats, std::size_t per_work_order, bool use_foreman,
-                          HashJoinOperator::JoinType join_type, bool with_lip) {
+                          HashJoinOperator::JoinType join_type, bool with_lip, bool composite = false) {
   CatalogRelation dim(1, "dim"), fact(2, "fact"), result(3, "result");
   StorageManager storage;
   dim.addAttribute("d_key", Type::Long());
   dim.addAttribute("d_val", Type::Double());
   fact.addAttribute("f_key", Type::Long());
   fact.addAttribute("f_qty", Type::Int());
-  const std::vector<bool> both(2, true);
+  for (CatalogRelation *r : {&dim, &fact}) {
+    r->addAttribute("lo", Type::Int());
+    r->addAttribute("hi", Type::Int());
+  }
+  const std::vector<bool> both(4, true);
   for (std::int64_t at = 0; at < kDimRows; at += kDimBlock) {
-    storage.loadBlock(&dim, {rows.d_key.data() + at, rows.d_val.data() + at}, kDimBlock, 0, compressed ? &both : nullptr);
+    storage.loadBlock(&dim, {rows.d_key.data() + at, rows.d_val.data() + at, rows.d_lo.data() + at, rows.d_hi.data() + at}, kDimBlock, 0,
+                      compressed ? &both : nullptr);
   }
   for (std::int64_t at = 0; at < kFactRows; at += kFactBlock) {
-    storage.loadBlock(&fact, {rows.f_key.data() + at, rows.f_qty.data() + at}, kFactBlock, 0, compressed ? &both : nullptr);
+    storage.loadBlock(&fact, {rows.f_key.data() + at, rows.f_qty.data() + at, rows.f_lo.data() + at, rows.f_hi.data() + at}, kFactBlock, 0,
+                      compressed ? &both : nullptr);
   }
   if (compressed) {
     const auto d = dim.getBlocksSnapshot(), f = fact.getBlocksSnapshot();
@@ -402,8 +413,9 @@ JoinOut runCompressedJoin(const JoinRows &rows, bool compressed, bool exact_stat
     selection = ctx.addScalarGroup({1});
     on_build = {false};
   }
-  auto *builder = new BuildHashOperator(0, dim, true, {0}, false, 1, table);
-  auto *prober = new HashJoinOperator(0, dim, fact, true, {0}, false, 1, false, result, dest, table, QueryContext::kInvalidPredicateId,
+  const std::vector<attribute_id> key_attrs = composite ? std::vector<attribute_id>{2, 3} : std::vector<attribute_id>{0};
+  auto *builder = new BuildHashOperator(0, dim, true, key_attrs, false, 1, table);
+  auto *prober = new HashJoinOperator(0, dim, fact, true, key_attrs, false, 1, false, result, dest, table, QueryContext::kInvalidPredicateId,
                                       selection, &on_build, join_type);
   auto *cleaner = new DestroyHashOperator(0, 1, table);
   if (with_lip) {   // a LIP filter on the join attribute: built from the dim's key stripes, probed with the fact's
@@ -447,8 +459,10 @@ JoinOut runCompressedJoin(const JoinRows &rows, bool compressed, bool exact_stat
   if (!use_foreman) fetchAndExecuteWorkOrders(cleaner, &ctx, &storage);
   if (compressed && per_work_order > 1) {   // (a work order over ONE block takes the per-block entry points, which read values)
     int decoded_dim = 0, decoded_fact = 0;
-    for (block_id b : dim.getBlocksSnapshot()) decoded_dim += storage.getBlock(b)->valuesMaterialized(0) ? 1 : 0;
-    for (block_id b : fact.getBlocksSnapshot()) decoded_fact += storage.getBlock(b)->valuesMaterialized(0) ? 1 : 0;
+    for (attribute_id a : key_attrs) {
+      for (block_id b : dim.getBlocksSnapshot()) decoded_dim += storage.getBlock(b)->valuesMaterialized(a) ? 1 : 0;
+      for (block_id b : fact.getBlocksSnapshot()) decoded_fact += storage.getBlock(b)->valuesMaterialized(a) ? 1 : 0;
+    }
     if (decoded_dim != 0 || decoded_fact != 0) {
       std::fprintf(stderr, "join type %d, exact_stats %d, per work order %zu, foreman %d, lip %d: %d dim and %d fact key stripes were decoded\n",
                    static_cast<int>(join_type), exact_stats ? 1 : 0, per_work_order, use_foreman ? 1 : 0, with_lip ? 1 : 0, decoded_dim, decoded_fact);
@@ -473,13 +487,14 @@ void testJoinsOverCompressedKeys() {
       }
     }
     std::sort(want.begin(), want.end());
-    for (const int variant : {0, 1, 2, 3, 4, 5, 6}) {
+    for (const int variant : {0, 1, 2, 3, 4, 5, 6, 7}) {
       const bool compressed = variant != 0;
+      const bool composite = variant == 7;
       const bool exact_stats = variant == 2 || variant == 4 || variant == 6;
       const std::size_t per_work_order = variant == 5 ? 1 : (variant <= 2 ? 3 : 8);
       const bool use_foreman = variant == 3 || variant == 4;
       const bool with_lip = variant == 6 || variant == 3;
-      const JoinOut got = runCompressedJoin(rows, compressed, exact_stats, per_work_order, use_foreman, join_type, with_lip);
+      const JoinOut got = runCompressedJoin(rows, compressed, exact_stats, per_work_order, use_foreman, join_type, with_lip, composite);
       std::vector<std::tuple<std::int64_t, std::int32_t, double>> have;
       for (std::size_t i = 0; i < got.key.size(); ++i) have.emplace_back(got.key[i], got.qty[i], inner ? got.val[i] : 0.0);
       std::sort(have.begin(), have.end());
