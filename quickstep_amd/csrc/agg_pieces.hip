@@ -94,6 +94,10 @@ __device__ __forceinline__ void load_piece_row(const PieceArgs &a, int64_t row, 
       case QSX_LONG: r.val[j] = static_cast<unsigned long long>(load_global(&static_cast<const long long *>(a.sum_col[j])[row])); break;
       default: r.val[j] = load_global(&static_cast<const unsigned long long *>(a.sum_col[j])[row]); break;   // the DOUBLE's bits
     }
+    // MIN / MAX combine as int64 (agg_common.hpp AccKind): a DOUBLE through the order-preserving map
+    if (a.sum_kind[j] >= kAccMinI64 && a.sum_type[j] == QSX_DOUBLE) {
+      r.val[j] = static_cast<unsigned long long>(ordered_from_bits(static_cast<long long>(r.val[j])));
+    }
   }
 }
 template <int NS>
@@ -106,7 +110,8 @@ __device__ __forceinline__ void add_piece_row(const PieceArgs &a, const HashTabl
     for (int j = 0; j < NS; ++j) {
       unsigned long long *p = &l_acc[static_cast<size_t>(j + 1) * S + slot];
       if (a.sum_kind[j] == kAccSumI64) atomicAdd(p, r.val[j]);
-      else atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(r.val[j])));
+      else if (a.sum_kind[j] == kAccSumF64) atomic_add_f64(reinterpret_cast<double *>(p), __longlong_as_double(static_cast<long long>(r.val[j])));
+      else lds_add(p, r.val[j], a.sum_kind[j]);   // MIN / MAX
     }
   } else {   // the sentinel code, or more groups in this piece than the table holds: straight to the state
     const unsigned long long gs = piece_global_slot(g, r.code, fresh);
@@ -130,7 +135,12 @@ __global__ __launch_bounds__(kPMaxBlockThreads) void agg_pieces_kernel(PieceArgs
     const int64_t lo = a.bounds[piece], hi = a.bounds[piece + 1];
     if (lo >= hi) continue;   // (wave-uniform: the bounds are the same for every thread)
     for (int i = threadIdx.x; i < S; i += threads) l_keys[i] = kEmptyCode;
-    for (int i = threadIdx.x; i < (NS + 1) * S; i += threads) l_acc[i] = 0;
+    for (int i = threadIdx.x; i < S; i += threads) l_acc[i] = 0;   // the row counts
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {   // every accumulator starts from its kind's identity (0 for the sums)
+      const unsigned long long identity = static_cast<unsigned long long>(acc_identity(a.sum_kind[j]));
+      for (int i = threadIdx.x; i < S; i += threads) l_acc[static_cast<size_t>(j + 1) * S + i] = identity;
+    }
     __syncthreads();
     int64_t row = lo + threadIdx.x;
     for (; row + threads < hi; row += 2 * threads) {   // two rows' loads in flight: a wave waits for its loads and little else

@@ -12,8 +12,8 @@
 // low — goes to the global table directly, like every row of the one-pass path does.
 // Reference loops: storage/AggregationOperationState.cpp:548-614 (the partitioned aggregation), storage/
 // PackedPayloadHashTable.hpp:838-909 (upsert per row).
-// Plans it serves: hash states with a key code of <= 8 bytes, SUM / AVG / COUNT over plain DOUBLE, INT or LONG columns (and
-// COUNT(*)); no predicate, expression, NULLs or codes — the other plans keep the one-pass path.
+// Plans it serves: hash states with a key code of <= 8 bytes, SUM / AVG / COUNT / MIN / MAX over plain DOUBLE, INT or LONG columns
+// (and COUNT(*)); no predicate, expression, NULLs or codes — the other plans keep the one-pass path.
 #ifndef QSX_CSRC_AGG_PIECES_HPP_
 #define QSX_CSRC_AGG_PIECES_HPP_
 
@@ -32,7 +32,7 @@ struct PieceArgs {
   int num_sums;
   const void *sum_col[kMaxSums];
   int sum_type[kMaxSums];     // QSX_DOUBLE / QSX_INT / QSX_LONG: the argument column's type
-  int sum_kind[kMaxSums];     // kAccSumF64 / kAccSumI64
+  int sum_kind[kMaxSums];     // AccKind: kAccSumF64 / kAccSumI64 / kAccMinI64 / kAccMaxI64
   long long *bounds;          // [kNumPieces + 1]: first row of every piece (written by the bounds kernel)
   int64_t n;
   int S;                      // slots of a workgroup's table (power of two)

@@ -2524,7 +2524,12 @@ static bool two_level_plan(const qsx_agg_state *st) {
     const DevSum &sum = d.sums[j];
     if (sum.count_valid != 0 || sum.null_mask != 0 || sum.arg.kind != QSX_OPD_COLUMN) return false;
     const int type = d.column_type[sum.arg.index];
-    if (!((sum.kind == kAccSumF64 && type == QSX_DOUBLE) || (sum.kind == kAccSumI64 && (type == QSX_INT || type == QSX_LONG)))) return false;
+    const bool integer = type == QSX_INT || type == QSX_LONG;
+    const bool min_max = sum.kind == kAccMinI64 || sum.kind == kAccMaxI64;
+    if (!((sum.kind == kAccSumF64 && type == QSX_DOUBLE) || (sum.kind == kAccSumI64 && integer) ||
+          (min_max && (integer ? sum.is_int != 0 : (type == QSX_DOUBLE && sum.is_int == 0))))) {
+      return false;
+    }
   }
   return true;
 }

@@ -536,7 +536,7 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
     """csrc/agg_pieces.hpp: more groups than one partition pass brings into LDS (est_groups >= 100 K): two K9 passes on
     digits of the mixing hash order the rows by its top 12 bits, then 4096 pieces of disjoint groups go through workgroup-private
     LDS tables (the partitioned aggregation of storage/AggregationOperationState.cpp:548-614 with partition = piece).  COUNT(*),
-    SUM over a DOUBLE, a LONG and an INT column, AVG; groups compared one by one with numpy (COUNT and the integer sums exact);
+    SUM over a DOUBLE, a LONG and an INT column, AVG, MIN over the LONG and the INT, MAX over the DOUBLE; groups compared one by one with numpy (COUNT and the integer sums exact);
     the same plan through the one-pass path (QSX_AGG_TWO_LEVEL_MIN_GROUPS=0) and through the oracle gives the same groups;
     two update calls, the second one over rows of groups the first has not seen."""
     rng = np.random.default_rng(groups % 1000 + 7)
@@ -559,7 +559,8 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
         cols, key_idx, strategy = [k0, a, b, c], [0], T.AGG_GENERIC
     v = len(key_idx)
     cfg = T.make_agg_config(strategy, columns, keys=key_idx,
-                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(v)), (T.AGG_SUM, T.col(v + 1)), (T.AGG_SUM, T.col(v + 2)), (T.AGG_AVG, T.col(v))],
+                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(v)), (T.AGG_SUM, T.col(v + 1)), (T.AGG_SUM, T.col(v + 2)), (T.AGG_AVG, T.col(v)),
+                                  (T.AGG_MIN, T.col(v + 1)), (T.AGG_MAX, T.col(v)), (T.AGG_MIN, T.col(v + 2))],
                             est_groups=groups if keys_kind != "int_underestimated" else 3_000_000)   # (1953 groups a piece for tables of 2048 slots: the probe bound sends rows down the global path)
     dcols = [to_dev(x, dev) for x in cols]
     half = n // 2 + 3
@@ -592,6 +593,13 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
     assert np.array_equal(gv[2], sum_b[got_gid])
     assert np.array_equal(gv[3], sum_c[got_gid])
     assert np.allclose(gv[4], sum_a[got_gid] / cnt[got_gid], rtol=1e-12, atol=0.0)
+    min_b = np.full(groups, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(min_b, gid, b)
+    max_a = np.full(groups, -np.inf)
+    np.maximum.at(max_a, gid, a)
+    min_c = np.full(groups, np.iinfo(np.int32).max, dtype=np.int64)
+    np.minimum.at(min_c, gid, c.astype(np.int64))
+    assert np.array_equal(gv[5], min_b[got_gid]) and np.array_equal(gv[6], max_a[got_gid]) and np.array_equal(gv[7].astype(np.int64), min_c[got_gid])
     assert_same_groups(results[0], results[1])
     # the operators' form: a run of 1 M-row blocks (ragged at the end, an empty one inside) in one call — laid end to end in scratch
     # of the call and through the same partition passes (aggregate.hip update_run_end_to_end)
