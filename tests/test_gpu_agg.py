@@ -615,6 +615,29 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
     assert _two_level_updates(capi) == before + (1 if keys_kind != "int_clustered" else 0)
     assert_same_groups(finalize_np(st, dev), results[0])
     st.close()
+    if keys_kind in ("int", "int_and_char"):
+        # under a filter bitmap (a predicate's / LIP filter's TupleIdSequence): many rows survive -> the used columns are compacted
+        # under the filter and the survivors take the partition passes (aggregate.hip update_filtered_end_to_end); against the oracle
+        capi.lib.qsx_debug_agg_filtered_compactions.restype = ctypes.c_longlong
+        keep = rng.random(n) < 0.7
+        fbits = oracle.bitmap_from_bools(keep)
+        before, compactions = _two_level_updates(capi), capi.lib.qsx_debug_agg_filtered_compactions()
+        st = capi.AggState(cfg)
+        st.update(dcols, n, filter_bitmap=bitmap_dev(fbits, dev))
+        assert capi.lib.qsx_debug_agg_filtered_compactions() == compactions + 1
+        assert _two_level_updates(capi) == before + 1
+        of = oracle.AggState(cfg)
+        of.update(cols, n, filter_bitmap=fbits)
+        assert_same_groups(finalize_np(st, dev), of.finalize())
+        st.close()
+        few = oracle.bitmap_from_bools(rng.random(n) < 0.01)                      # few survivors: compacted too, then the tile kernels on what is left
+        st = capi.AggState(cfg)
+        st.update(dcols, n, filter_bitmap=bitmap_dev(few, dev))
+        assert capi.lib.qsx_debug_agg_filtered_compactions() == compactions + 2
+        of = oracle.AggState(cfg)
+        of.update(cols, n, filter_bitmap=few)
+        assert_same_groups(finalize_np(st, dev), of.finalize())
+        st.close()
     o = oracle.AggState(cfg)                                                    # (the oracle's hash table: seconds at these sizes)
     # (a call whose columns would not fit 8 GiB of scratch goes slice by slice; forced here: a child process, the variable is read once)
     if keys_kind == "int":
