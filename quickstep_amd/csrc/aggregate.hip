@@ -2907,6 +2907,62 @@ static int update_run_end_to_end(qsx_agg_state_t *st, int num_blocks, const int6
   return agg_update(st, stripes, nullptr, total, nullptr, stream, nullptr);
 }
 
+// The same for a run whose blocks all come with a filter (an AggregationWorkOrder under a predicate or LIP filter over a run): the
+// survivors of the whole run compacted into one stripe per used column (K2 over the run), then the stripe form.
+static int update_filtered_run_end_to_end(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
+                                          const uint64_t *const *block_filters, int64_t total, qsx_stream_t stream) {
+  hipStream_t s = as_stream(stream);
+  const int ncols = st->config.num_columns;
+  int32_t widths[QSX_MAX_COLUMNS];
+  int column_of[QSX_MAX_COLUMNS];
+  int used = 0;
+  size_t bytes = CallScratch::padded(16);
+  for (int c = 0; c < ncols; ++c) {
+    if (!((st->used_columns >> c) & 1u)) continue;
+    widths[used] = st->dev.column_width[c];
+    column_of[used] = c;
+    bytes += CallScratch::padded(static_cast<size_t>(total) * st->dev.column_width[c] + 16);
+    ++used;
+  }
+  if (used == 0) return QSX_ERR_UNSUPPORTED;
+  std::vector<int64_t> rows;
+  std::vector<const void *> cols;
+  std::vector<const uint64_t *> filters;
+  for (int b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] == 0) continue;
+    rows.push_back(block_rows[b]);
+    filters.push_back(block_filters[b]);
+    for (int i = 0; i < used; ++i) {
+      const void *p = block_cols[static_cast<size_t>(b) * ncols + column_of[i]];
+      if (p == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+      cols.push_back(p);
+    }
+  }
+  const int64_t nb = static_cast<int64_t>(rows.size());
+  const size_t ws_bytes = qsx_compact_blocks_workspace_bytes(nb, rows.data()) + 16;
+  bytes += CallScratch::padded(ws_bytes);
+  CallScratch scratch(s);
+  int rc = scratch.reserve(bytes);
+  if (rc != QSX_OK) return rc;
+  int64_t *count_dev = static_cast<int64_t *>(scratch.take(16));
+  void *ws = scratch.take(ws_bytes);
+  void *out_cols[QSX_MAX_COLUMNS];
+  const void *stripes[QSX_MAX_COLUMNS] = {};
+  for (int i = 0; i < used; ++i) {
+    out_cols[i] = scratch.take(static_cast<size_t>(total) * widths[i] + 16);
+    if (out_cols[i] == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+    stripes[column_of[i]] = out_cols[i];
+  }
+  rc = qsx_compact_gather_blocks(used, widths, nb, rows.data(), cols.data(), filters.data(), nullptr, out_cols, nullptr, count_dev, ws, ws_bytes, stream);
+  if (rc != QSX_OK) return rc;
+  int64_t survivors = 0;
+  QSX_HIP_TRY(hipMemcpyAsync(&survivors, count_dev, sizeof(survivors), hipMemcpyDeviceToHost, s));
+  QSX_HIP_TRY(hipStreamSynchronize(s));
+  g_filtered_compactions.fetch_add(1, std::memory_order_relaxed);
+  if (survivors == 0) return QSX_OK;
+  return agg_update(st, stripes, nullptr, survivors, nullptr, stream, nullptr);
+}
+
 // block_dicts: the dictionaries of a state over compressed attributes, [block * num_columns + column] (nullptr otherwise).
 static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t *block_rows, const void *const *block_cols,
                              const void *const *block_dicts, const uint64_t *const *block_filters, qsx_stream_t stream,
@@ -2964,6 +3020,12 @@ static int agg_update_blocks(qsx_agg_state_t *st, int num_blocks, const int64_t 
   if (rows.empty()) return QSX_OK;
   if (run_takes_partition_passes(st, total, any_filter, block_dicts != nullptr)) {
     return update_run_end_to_end(st, num_blocks, block_rows, block_cols, total, stream);
+  }
+  if (any_filter && total >= 2 * partition_min_rows() && run_takes_partition_passes(st, total, false, block_dicts != nullptr)) {
+    bool every_block_filtered = true;
+    for (int b = 0; b < num_blocks; ++b) every_block_filtered = every_block_filtered && (block_rows[b] == 0 || block_filters[b] != nullptr);
+    static const bool compact = []() { const char *e = getenv("QSX_AGG_FILTER_COMPACT"); return e == nullptr || atoi(e) != 0; }();
+    if (every_block_filtered && compact) return update_filtered_run_end_to_end(st, num_blocks, block_rows, block_cols, block_filters, total, stream);
   }
   tiles1024.push_back(tiles1024.back() + (rows.back() + 1023) / 1024);
   tiles512.push_back(tiles512.back() + (rows.back() + 511) / 512);

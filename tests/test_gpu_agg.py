@@ -630,6 +630,15 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
         of.update(cols, n, filter_bitmap=fbits)
         assert_same_groups(finalize_np(st, dev), of.finalize())
         st.close()
+        # the same filter over a run of blocks (an AggregationWorkOrder over a run under its predicate): K2 over the run, then the stripe form
+        st = capi.AggState(cfg)
+        fedges = list(range(0, n, 2_000_000)) + [n]
+        st.update_blocks([[x[a:b] for x in dcols] for a, b in zip(fedges[:-1], fedges[1:])],
+                         filters=[bitmap_dev(oracle.bitmap_from_bools(keep[a:b]), dev) for a, b in zip(fedges[:-1], fedges[1:])])
+        assert capi.lib.qsx_debug_agg_filtered_compactions() == compactions + 2
+        assert_same_groups(finalize_np(st, dev), of.finalize())
+        st.close()
+        compactions += 1
         few = oracle.bitmap_from_bools(rng.random(n) < 0.01)                      # few survivors: compacted too, then the tile kernels on what is left
         st = capi.AggState(cfg)
         st.update(dcols, n, filter_bitmap=bitmap_dev(few, dev))
