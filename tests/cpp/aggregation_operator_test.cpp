@@ -76,6 +76,90 @@ T at(const std::vector<unsigned char> &col, std::size_t i) {
   std::memcpy(&v, col.data() + i * sizeof(T), sizeof(T));
   return v;
 }
+
+// ---- a group-by with many groups through the operators ------------------------------------------------------------------------
+// 24 M rows in 1 M-row blocks, 500 000 random groups, COUNT / SUM / MIN / MAX — AggregationWorkOrders over runs of 12 blocks on four
+// Workers: each run is laid end to end and takes the two partition passes and the per-piece LDS tables (csrc/agg_pieces.hpp);
+// with a predicate on a plain attribute the state filters inside its kernels after one partition pass.  Against the same
+// aggregation computed on the host.
+extern "C" long long qsx_debug_agg_run_concats(void);
+extern "C" long long qsx_debug_agg_two_level_updates(void);
+void testManyGroupsThroughRuns() {
+  constexpr std::int64_t kRows = 24000000, kBlock = 1000000;
+  constexpr std::int32_t kGroups = 500000;
+  std::vector<std::int32_t> key(kRows);
+  std::vector<double> val(kRows);
+  std::vector<std::int64_t> qty(kRows);
+  std::uint64_t x = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  for (std::int64_t i = 0; i < kRows; ++i) {
+    key[i] = static_cast<std::int32_t>(rnd() % kGroups) * 3 - 7;
+    val[i] = static_cast<double>(static_cast<std::int64_t>(rnd() % 200001) - 100000) / 8.0;   // multiples of 1/8: sums exact in any order
+    qty[i] = static_cast<std::int64_t>(rnd() % 1000003) - 500000;
+  }
+  for (const int with_predicate : {0, 1}) {
+    struct G { std::int64_t count = 0; double sum = 0; std::int64_t min_q = INT64_MAX; double max_v = -1e300; };
+    std::vector<G> want(kGroups);
+    for (std::int64_t i = 0; i < kRows; ++i) {
+      if (with_predicate && !(qty[i] < 250000)) continue;
+      G &g = want[(key[i] + 7) / 3];
+      ++g.count; g.sum += val[i]; g.min_q = std::min(g.min_q, qty[i]); g.max_v = std::max(g.max_v, val[i]);
+    }
+    CatalogRelation rel(200, "many_groups"), result(201, "result");
+    StorageManager storage;
+    rel.addAttribute("k", Type::Int());
+    rel.addAttribute("v", Type::Double());
+    rel.addAttribute("q", Type::Long());
+    for (std::int64_t at = 0; at < kRows; at += kBlock) storage.loadBlock(&rel, {key.data() + at, val.data() + at, qty.data() + at}, kBlock);
+    result.addAttribute("k", Type::Int());
+    result.addAttribute("count", Type::Long());
+    result.addAttribute("sum", Type::Double().getNullableVersion());
+    result.addAttribute("min_q", Type::Long().getNullableVersion());
+    result.addAttribute("max_v", Type::Double().getNullableVersion());
+    QueryContext ctx;
+    Predicate pred;
+    pred.conjuncts.push_back({2, ComparisonID::kLess, TypedLiteral::Long(250000)});
+    const auto pred_id = ctx.addPredicate(pred);
+    AggregationStateSpec spec;
+    spec.input_relation = &rel;
+    spec.group_by = {0};
+    spec.aggregates = {{AggregationID::kCount, kInvalidAttributeID}, {AggregationID::kSum, 1}, {AggregationID::kMin, 2}, {AggregationID::kMax, 1}};
+    spec.predicate = with_predicate ? ctx.getPredicate(pred_id) : nullptr;
+    spec.strategy = QSX_AGG_GENERIC;
+    spec.estimated_num_groups = kGroups;
+    const auto state = ctx.addAggregationState(spec);
+    const auto dest = ctx.addInsertDestination(&result, &storage);
+    auto *aggregate = new AggregationOperator(0, rel, true, state);
+    auto *finalize = new FinalizeAggregationOperator(0, state, 1, false, 1, result, dest);
+    aggregate->setBlocksPerWorkOrder(12);
+    const long long concats = qsx_debug_agg_run_concats(), two_level = qsx_debug_agg_two_level_updates();
+    QueryPlan plan;
+    const auto a = plan.addRelationalOperator(aggregate);
+    const auto z = plan.addRelationalOperator(finalize);
+    plan.addDirectDependency(z, a, true);
+    ForemanSingleNode foreman(&plan, &ctx, &storage, 4);
+    foreman.run();
+    if (!with_predicate) {
+      EXPECT_EQ(qsx_debug_agg_run_concats() - concats, 2ll);          // two work orders, each a run laid end to end
+      EXPECT_EQ(qsx_debug_agg_two_level_updates() - two_level, 2ll);
+    }
+    std::size_t rows = 0;
+    auto cols = readAll(ctx, dest, storage, result, &rows);
+    std::size_t present = 0;
+    for (const G &g : want) present += g.count != 0 ? 1 : 0;
+    EXPECT_EQ(rows, present);
+    std::size_t wrong = 0;
+    for (std::size_t i = 0; i < rows; ++i) {
+      const std::int32_t k = at<std::int32_t>(cols[0], i);
+      const G &g = want[static_cast<std::size_t>((k + 7) / 3)];
+      if ((k + 7) % 3 != 0 || at<std::int64_t>(cols[1], i) != g.count || at<double>(cols[2], i) != g.sum || at<std::int64_t>(cols[3], i) != g.min_q ||
+          at<double>(cols[4], i) != g.max_v) {
+        ++wrong;
+      }
+    }
+    EXPECT_EQ(wrong, static_cast<std::size_t>(0));
+  }
+}
 }  // namespace
 
 #include <cstring>
@@ -583,5 +667,6 @@ int main() {
     }
     EXPECT_EQ(matched, want.size());
   }
+  testManyGroupsThroughRuns();
   return finish("aggregation_operator_test");
 }
