@@ -2516,9 +2516,15 @@ static long long two_level_min_groups() {
 // 10^6 groups against 3.5 through two levels (a wave whose 64 rows are one partition's takes its places in the scatter with one
 // LDS add — partition.hip — or the gap was a millisecond); 4.9 against 4.3 at 3 x 10^6, 10.8 against 4.9 at 10^7.
 constexpr long long kTwoLevelWhateverTheOrder = 2000000;
+// The rows of the call in progress have been through the state's predicate already (update_filtered_end_to_end behind the K1
+// prepass of agg_update): the consumer of the pieces, which evaluates none, may serve them.
+static thread_local bool tl_predicate_applied = false;
 static bool two_level_plan(const qsx_agg_state *st) {
   const DevConfig &d = st->dev;
-  if (st->dense || d.wide_words != 0 || d.num_instrs != 0 || d.num_pred != 0 || d.num_null_cols != 0 || st->has_coded_columns || st->has_date_key) return false;
+  if (st->dense || d.wide_words != 0 || d.num_instrs != 0 || (d.num_pred != 0 && !tl_predicate_applied) || d.num_null_cols != 0 || st->has_coded_columns ||
+      st->has_date_key) {
+    return false;
+  }
   if (d.num_keys < 1) return false;
   for (int j = 0; j < st->num_sums; ++j) {
     const DevSum &sum = d.sums[j];
@@ -2696,12 +2702,14 @@ extern "C" long long qsx_debug_agg_filtered_compactions(void) { return g_filtere
 // used columns are compacted under the filter (K2) and the survivors take the stripe form — per 100 M rows at 10^6 groups
 // (tools/agg_filtered_groups.py): selectivity 0.9 9.1 -> 3.2 ms, 0.5 6.2 -> 2.0, 0.1 5.9 -> 0.9.  Returns QSX_ERR_UNSUPPORTED
 // when the call should go on as it came.
-static int update_filtered_end_to_end(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev, qsx_stream_t stream) {
+static bool filtered_call_compacts(const qsx_agg_state *st, int64_t n) {
   static const bool enabled = []() { const char *e = getenv("QSX_AGG_FILTER_COMPACT"); return e == nullptr || atoi(e) != 0; }();
-  if (!enabled || st->dense || st->part_count <= 1 || st->has_coded_columns || st->dev.num_null_cols != 0 || st->has_date_key || st->dir_gids != 0 ||
-      st->factored.ok || n < 2 * partition_min_rows()) {
-    return QSX_ERR_UNSUPPORTED;
-  }
+  return enabled && !st->dense && st->part_count > 1 && !st->has_coded_columns && st->dev.num_null_cols == 0 && !st->has_date_key && st->dir_gids == 0 &&
+         !st->factored.ok && n >= 2 * partition_min_rows();
+}
+static int update_filtered_end_to_end(qsx_agg_state_t *st, const void *const *cols, int64_t n, const uint64_t *filter_dev, qsx_stream_t stream,
+                                      bool predicate_applied = false) {
+  if (!filtered_call_compacts(st, n)) return QSX_ERR_UNSUPPORTED;
   hipStream_t s = as_stream(stream);
   const int ncols = st->config.num_columns;
   const void *used_cols[QSX_MAX_COLUMNS];
@@ -2743,7 +2751,31 @@ static int update_filtered_end_to_end(qsx_agg_state_t *st, const void *const *co
   rc = qsx_compact_gather(used, used_cols, widths, filter_dev, n, out_cols, count_dev, ws, ws_bytes, stream);
   if (rc != QSX_OK) return rc;
   g_filtered_compactions.fetch_add(1, std::memory_order_relaxed);
-  return agg_update(st, stripes, nullptr, survivors, nullptr, stream, nullptr);
+  const bool outer = tl_predicate_applied;
+  tl_predicate_applied = predicate_applied;
+  rc = agg_update(st, stripes, nullptr, survivors, nullptr, stream, nullptr);
+  tl_predicate_applied = outer;
+  return rc;
+}
+// The state's own predicate (plain INT / LONG / FLOAT / DOUBLE columns against literals) as a TupleIdSequence: a K1 pass per term,
+// chained through the bitmap (and behind the call's filter) — what update_slice does in front of the family's kernels.
+static int predicate_bitmap(const qsx_agg_state *st, const void *const *cols, int64_t n, const uint64_t *filter_dev, uint64_t *bitmap, qsx_stream_t stream) {
+  const DevConfig &d = st->dev;
+  for (int p = 0; p < d.num_pred; ++p) {
+    const unsigned long long literal = d.pred[p].literal;
+    const int rc = qsx_select_cmp(d.column_type[d.pred[p].column], cols[d.pred[p].column], n, d.pred[p].op, &literal, p == 0 ? filter_dev : bitmap, bitmap,
+                                  nullptr, stream);
+    if (rc != QSX_OK) return rc;
+  }
+  return QSX_OK;
+}
+static bool predicate_is_plain(const qsx_agg_state *st, const void *const *cols) {
+  const DevConfig &d = st->dev;
+  for (int p = 0; p < d.num_pred; ++p) {
+    const int c = d.pred[p].column, type = d.column_type[c];
+    if (cols[c] == nullptr || d.code_width[c] != 0 || (type != QSX_INT && type != QSX_LONG && type != QSX_FLOAT && type != QSX_DOUBLE)) return false;
+  }
+  return d.num_pred != 0;
 }
 
 static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *const *dicts, int64_t n,
@@ -2752,8 +2784,20 @@ static int agg_update(qsx_agg_state_t *st, const void *const *cols, const void *
   if (st == nullptr || n < 0 || (n > 0 && st->config.num_columns > 0 && cols == nullptr)) return QSX_ERR_INVALID_ARGUMENT;
   if (n == 0) return QSX_OK;
   hipStream_t s = as_stream(stream);
-  if (filter_dev != nullptr && dicts == nullptr && nulls == nullptr) {
-    const int rc_filtered = update_filtered_end_to_end(st, cols, n, filter_dev, stream);
+  if (dicts == nullptr && nulls == nullptr && !tl_predicate_applied && filtered_call_compacts(st, n) && predicate_is_plain(st, cols)) {
+    // a state that filters inside its kernels AND partitions its input: the predicate becomes a bitmap first, the survivors are
+    // compacted and — past their predicate — may take the two partition passes
+    CallScratch pred_scratch(s);
+    const size_t words = static_cast<size_t>((n + 63) / 64) + 1;
+    int rc_pred = pred_scratch.reserve(CallScratch::padded(words * 8));
+    if (rc_pred != QSX_OK) return rc_pred;
+    uint64_t *bitmap = static_cast<uint64_t *>(pred_scratch.take(words * 8));
+    rc_pred = predicate_bitmap(st, cols, n, filter_dev, bitmap, stream);
+    if (rc_pred != QSX_OK) return rc_pred;
+    rc_pred = update_filtered_end_to_end(st, cols, n, bitmap, stream, true);
+    if (rc_pred != QSX_ERR_UNSUPPORTED) return rc_pred;
+  } else if (filter_dev != nullptr && dicts == nullptr && nulls == nullptr) {
+    const int rc_filtered = update_filtered_end_to_end(st, cols, n, filter_dev, stream, tl_predicate_applied);
     if (rc_filtered != QSX_ERR_UNSUPPORTED) return rc_filtered;
   }
   int rc = maybe_grow(st);

@@ -639,6 +639,21 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
         assert_same_groups(finalize_np(st, dev), of.finalize())
         st.close()
         compactions += 1
+        # the STATE's own predicate (a conjunction on the DOUBLE and the INT column, with the call's filter on top): a K1 pass per term
+        # makes the bitmap, the survivors are compacted and — past their predicate — take the two partition passes
+        pcfg = T.make_agg_config(strategy, columns, keys=key_idx,
+                                 aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(v)), (T.AGG_SUM, T.col(v + 1)), (T.AGG_MIN, T.col(v + 2))],
+                                 pred=[(v, T.GT, -100.0), (v + 2, T.LT, 60)], est_groups=groups)
+        for filt in (None, fbits):
+            before, comps = _two_level_updates(capi), capi.lib.qsx_debug_agg_filtered_compactions()
+            st = capi.AggState(pcfg)
+            st.update(dcols, n, filter_bitmap=None if filt is None else bitmap_dev(filt, dev))
+            assert capi.lib.qsx_debug_agg_filtered_compactions() == comps + 1 and _two_level_updates(capi) == before + 1
+            op = oracle.AggState(pcfg)
+            op.update(cols, n, filter_bitmap=filt)
+            assert_same_groups(finalize_np(st, dev), op.finalize())
+            st.close()
+        compactions = capi.lib.qsx_debug_agg_filtered_compactions() - 1
         few = oracle.bitmap_from_bools(rng.random(n) < 0.01)                      # few survivors: compacted too, then the tile kernels on what is left
         st = capi.AggState(cfg)
         st.update(dcols, n, filter_bitmap=bitmap_dev(few, dev))
