@@ -12,8 +12,9 @@
 // low — goes to the global table directly, like every row of the one-pass path does.
 // Reference loops: storage/AggregationOperationState.cpp:548-614 (the partitioned aggregation), storage/
 // PackedPayloadHashTable.hpp:838-909 (upsert per row).
-// Plans it serves: hash states with a key code of <= 8 bytes, SUM / AVG / COUNT / MIN / MAX over plain DOUBLE, INT or LONG columns
-// (and COUNT(*)); no predicate, expression, NULLs or codes — the other plans keep the one-pass path.
+// Plans it serves (aggregate.hip two_level_plan): hash states with a key code of <= 8 bytes, SUM / AVG / COUNT / MIN / MAX over
+// plain DOUBLE, INT or LONG columns and over DOUBLE expressions (their values arrive as a stripe), COUNT(*); rows past the
+// state's predicate (agg_update's K1 prepass + compaction); no NULLs or codes — the other plans keep the one-pass path.
 #ifndef QSX_CSRC_AGG_PIECES_HPP_
 #define QSX_CSRC_AGG_PIECES_HPP_
 

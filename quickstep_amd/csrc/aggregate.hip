@@ -2521,14 +2521,19 @@ constexpr long long kTwoLevelWhateverTheOrder = 2000000;
 static thread_local bool tl_predicate_applied = false;
 static bool two_level_plan(const qsx_agg_state *st) {
   const DevConfig &d = st->dev;
-  if (st->dense || d.wide_words != 0 || d.num_instrs != 0 || (d.num_pred != 0 && !tl_predicate_applied) || d.num_null_cols != 0 || st->has_coded_columns ||
-      st->has_date_key) {
+  if (st->dense || d.wide_words != 0 || (d.num_pred != 0 && !tl_predicate_applied) || d.num_null_cols != 0 || st->has_coded_columns || st->has_date_key) {
     return false;
   }
   if (d.num_keys < 1) return false;
   for (int j = 0; j < st->num_sums; ++j) {
     const DevSum &sum = d.sums[j];
-    if (sum.count_valid != 0 || sum.null_mask != 0 || sum.arg.kind != QSX_OPD_COLUMN) return false;
+    if (sum.count_valid != 0 || sum.null_mask != 0) return false;
+    if (sum.arg.kind == QSX_OPD_TEMP) {
+      // an expression (DOUBLE arithmetic): its values become a stripe in front of the passes (update_two_level)
+      if (sum.is_int != 0 || sum.kind == kAccSumI64 || sum.arg.index < 0 || sum.arg.index >= QSX_MAX_TEMPS) return false;
+      continue;
+    }
+    if (sum.arg.kind != QSX_OPD_COLUMN) return false;
     const int type = d.column_type[sum.arg.index];
     const bool integer = type == QSX_INT || type == QSX_LONG;
     const bool min_max = sum.kind == kAccMinI64 || sum.kind == kAccMaxI64;
@@ -2582,59 +2587,113 @@ extern "C" long long qsx_debug_agg_two_level_updates(void) { return g_two_level_
 
 static int update_two_level(qsx_agg_state *st, const void *const *cols, int64_t n, hipStream_t s) {
   const int ncols = st->config.num_columns;
-  const size_t ws_bytes = partition_workspace_bytes(n, kWave);
-  size_t total = CallScratch::padded(sizeof(int64_t) * (kWave + 1)) + CallScratch::padded(sizeof(long long) * (kNumPieces + 1)) + CallScratch::padded(ws_bytes);
-  for (int c = 0; c < ncols; ++c) {
-    if ((st->used_columns >> c) & 1u) total += 2 * CallScratch::padded(static_cast<size_t>(n) * st->dev.column_width[c] + 16);
+  const DevConfig &d = st->dev;
+  // What travels through the two passes: the key columns, the columns the aggregates read directly, and — for an aggregate over
+  // an expression — ONE stripe of the expression's values, computed in front of the passes by the K11 evaluator
+  // (qsx_eval_expression: the same program, the same arithmetic as the fused form) instead of its operand columns.
+  struct Moved {
+    const void *src;
+    int width;
+    void *first, *second;
+  };
+  Moved items[QSX_MAX_COLUMNS + kMaxSums] = {};
+  int moved = 0, item_of_column[QSX_MAX_COLUMNS], item_of_temp[QSX_MAX_TEMPS], item_of_sum[kMaxSums];
+  for (int &v : item_of_column) v = -1;
+  for (int &v : item_of_temp) v = -1;
+  auto need_column = [&](int c) {
+    if (item_of_column[c] < 0) {
+      items[moved] = Moved{cols[c], d.column_width[c], nullptr, nullptr};
+      item_of_column[c] = moved++;
+    }
+    return item_of_column[c];
+  };
+  for (int k = 0; k < d.num_keys; ++k) (void)need_column(d.key_column[k]);
+  int num_temps = 0;
+  for (int j = 0; j < st->num_sums; ++j) {
+    const DevOperand &arg = d.sums[j].arg;
+    if (arg.kind == QSX_OPD_COLUMN) {
+      item_of_sum[j] = need_column(arg.index);
+    } else {   // QSX_OPD_TEMP (two_level_plan)
+      if (item_of_temp[arg.index] < 0) {
+        items[moved] = Moved{nullptr, 8, nullptr, nullptr};
+        item_of_temp[arg.index] = moved++;
+        ++num_temps;
+      }
+      item_of_sum[j] = item_of_temp[arg.index];
+    }
   }
+  if (moved > QSX_MAX_COLUMNS) return QSX_ERR_UNSUPPORTED;
+  const size_t ws_bytes = partition_workspace_bytes(n, kWave);
+  size_t total = CallScratch::padded(sizeof(int64_t) * (kWave + 1)) + CallScratch::padded(sizeof(long long) * (kNumPieces + 1)) + CallScratch::padded(ws_bytes) +
+                 static_cast<size_t>(num_temps) * CallScratch::padded(static_cast<size_t>(n) * 8 + 16);
+  for (int i = 0; i < moved; ++i) total += 2 * CallScratch::padded(static_cast<size_t>(n) * items[i].width + 16);
   CallScratch scratch(s);
   int rc = scratch.reserve(total);
   if (rc != QSX_OK) return rc;
   int64_t *offsets = static_cast<int64_t *>(scratch.take(sizeof(int64_t) * (kWave + 1)));
   long long *bounds = static_cast<long long *>(scratch.take(sizeof(long long) * (kNumPieces + 1)));
   void *ws = scratch.take(ws_bytes);
-  const void *src[QSX_MAX_COLUMNS];
-  void *first[QSX_MAX_COLUMNS], *second[QSX_MAX_COLUMNS], *first_of[QSX_MAX_COLUMNS] = {}, *second_of[QSX_MAX_COLUMNS] = {};
+  if (num_temps != 0) {
+    // (columns the program cannot name — a CHAR key — stand in as INT stripes it never reads)
+    const void *eval_cols[QSX_MAX_COLUMNS];
+    int32_t eval_types[QSX_MAX_COLUMNS];
+    const void *any = cols[d.key_column[0]];
+    for (int c = 0; c < ncols; ++c) {
+      const int type = st->config.column_type[c];
+      const bool numeric = type == QSX_INT || type == QSX_LONG || type == QSX_FLOAT || type == QSX_DOUBLE;
+      eval_cols[c] = numeric && cols[c] != nullptr ? cols[c] : any;
+      eval_types[c] = numeric && cols[c] != nullptr ? type : QSX_INT;
+    }
+    for (int t = 0; t < QSX_MAX_TEMPS; ++t) {
+      if (item_of_temp[t] < 0) continue;
+      double *values = static_cast<double *>(scratch.take(static_cast<size_t>(n) * 8 + 16));
+      if (values == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+      qsx_operand_t result{};
+      result.kind = QSX_OPD_TEMP;
+      result.index = t;
+      rc = qsx_eval_expression(ncols, eval_cols, eval_types, st->config.num_instrs, st->config.instrs, st->config.consts, result, n, values,
+                               reinterpret_cast<qsx_stream_t>(s));
+      if (rc != QSX_OK) return rc;
+      items[item_of_temp[t]].src = values;
+    }
+  }
+  const void *src[QSX_MAX_COLUMNS], *first_const[QSX_MAX_COLUMNS];
+  void *first[QSX_MAX_COLUMNS], *second[QSX_MAX_COLUMNS];
   int32_t widths[QSX_MAX_COLUMNS];
-  int moved = 0;
-  for (int c = 0; c < ncols; ++c) {
-    if (!((st->used_columns >> c) & 1u)) continue;
-    const size_t bytes = static_cast<size_t>(n) * st->dev.column_width[c] + 16;
-    first_of[c] = scratch.take(bytes);
-    second_of[c] = scratch.take(bytes);
-    if (first_of[c] == nullptr || second_of[c] == nullptr) return QSX_ERR_OUT_OF_MEMORY;
-    src[moved] = cols[c];
-    first[moved] = first_of[c];
-    second[moved] = second_of[c];
-    widths[moved] = st->dev.column_width[c];
-    ++moved;
+  for (int i = 0; i < moved; ++i) {
+    const size_t bytes = static_cast<size_t>(n) * items[i].width + 16;
+    items[i].first = scratch.take(bytes);
+    items[i].second = scratch.take(bytes);
+    if (items[i].first == nullptr || items[i].second == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+    src[i] = items[i].src;
+    first[i] = items[i].first;
+    first_const[i] = items[i].first;
+    second[i] = items[i].second;
+    widths[i] = items[i].width;
   }
   // the routing key is the packed key code, computed from the key columns inside K9 (never materialised): the low digit of
-  // the top 12 hash bits first, then — stable — the high digit
+  // the top 12 hash bits first (any order), then the high digit keeping that order
   const void *key_cols[QSX_MAX_KEYS];
-  for (int k = 0; k < st->dev.num_keys; ++k) key_cols[k] = cols[st->dev.key_column[k]];
-  rc = partition_scatter_packed_digit(st->dev.num_keys, key_cols, st->dev.key_width, st->dev.key_shift, n, 64 - kPieceBits, false, moved, src, widths, first, offsets,
+  for (int k = 0; k < d.num_keys; ++k) key_cols[k] = cols[d.key_column[k]];
+  rc = partition_scatter_packed_digit(d.num_keys, key_cols, d.key_width, d.key_shift, n, 64 - kPieceBits, false, moved, src, widths, first, offsets,
                                       ws, ws_bytes, s);
   if (rc != QSX_OK) return rc;
-  for (int k = 0; k < st->dev.num_keys; ++k) key_cols[k] = first_of[st->dev.key_column[k]];
-  const void *first_const[QSX_MAX_COLUMNS];
-  for (int i = 0; i < moved; ++i) first_const[i] = first[i];
-  rc = partition_scatter_packed_digit(st->dev.num_keys, key_cols, st->dev.key_width, st->dev.key_shift, n, 64 - kPieceBits + 6, true, moved, first_const, widths, second,
+  for (int k = 0; k < d.num_keys; ++k) key_cols[k] = items[item_of_column[d.key_column[k]]].first;
+  rc = partition_scatter_packed_digit(d.num_keys, key_cols, d.key_width, d.key_shift, n, 64 - kPieceBits + 6, true, moved, first_const, widths, second,
                                       offsets, ws, ws_bytes, s);
   if (rc != QSX_OK) return rc;
   PieceArgs a{};
-  a.num_keys = st->dev.num_keys;
-  for (int k = 0; k < st->dev.num_keys; ++k) {
-    a.key_col[k] = second_of[st->dev.key_column[k]];
-    a.key_width[k] = st->dev.key_width[k];
-    a.key_shift[k] = st->dev.key_shift[k];
+  a.num_keys = d.num_keys;
+  for (int k = 0; k < d.num_keys; ++k) {
+    a.key_col[k] = items[item_of_column[d.key_column[k]]].second;
+    a.key_width[k] = d.key_width[k];
+    a.key_shift[k] = d.key_shift[k];
   }
   a.num_sums = st->num_sums;
   for (int j = 0; j < st->num_sums; ++j) {
-    const int col = st->dev.sums[j].arg.index;
-    a.sum_col[j] = second_of[col];
-    a.sum_type[j] = st->dev.column_type[col];
-    a.sum_kind[j] = st->dev.sums[j].kind;
+    a.sum_col[j] = items[item_of_sum[j]].second;
+    a.sum_type[j] = d.sums[j].arg.kind == QSX_OPD_COLUMN ? d.column_type[d.sums[j].arg.index] : QSX_DOUBLE;
+    a.sum_kind[j] = d.sums[j].kind;
   }
   a.bounds = bounds;
   a.n = n;

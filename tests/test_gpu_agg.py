@@ -536,7 +536,8 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
     """csrc/agg_pieces.hpp: more groups than one partition pass brings into LDS (est_groups >= 100 K): two K9 passes on
     digits of the mixing hash order the rows by its top 12 bits, then 4096 pieces of disjoint groups go through workgroup-private
     LDS tables (the partitioned aggregation of storage/AggregationOperationState.cpp:548-614 with partition = piece).  COUNT(*),
-    SUM over a DOUBLE, a LONG and an INT column, AVG, MIN over the LONG and the INT, MAX over the DOUBLE; groups compared one by one with numpy (COUNT and the integer sums exact);
+    SUM over a DOUBLE and a LONG column, AVG, MIN over the LONG, MAX over the DOUBLE, SUM and MAX over an expression (its values
+    become a stripe in front of the passes), MIN over the INT column under the state's predicate further down; groups compared one by one with numpy (COUNT and the integer sums exact);
     the same plan through the one-pass path (QSX_AGG_TWO_LEVEL_MIN_GROUPS=0) and through the oracle gives the same groups;
     two update calls, the second one over rows of groups the first has not seen."""
     rng = np.random.default_rng(groups % 1000 + 7)
@@ -559,8 +560,10 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
         cols, key_idx, strategy = [k0, a, b, c], [0], T.AGG_GENERIC
     v = len(key_idx)
     cfg = T.make_agg_config(strategy, columns, keys=key_idx,
-                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(v)), (T.AGG_SUM, T.col(v + 1)), (T.AGG_SUM, T.col(v + 2)), (T.AGG_AVG, T.col(v)),
-                                  (T.AGG_MIN, T.col(v + 1)), (T.AGG_MAX, T.col(v)), (T.AGG_MIN, T.col(v + 2))],
+                            aggs=[(T.AGG_COUNT_STAR, None), (T.AGG_SUM, T.col(v)), (T.AGG_SUM, T.col(v + 1)), (T.AGG_AVG, T.col(v)),
+                                  (T.AGG_MIN, T.col(v + 1)), (T.AGG_MAX, T.col(v)),
+                                  (T.AGG_SUM, T.temp(1)), (T.AGG_MAX, T.temp(1))],                # over the expression (1 - a) * a
+                            instrs=[(T.EX_SUB, 0, T.const(0), T.col(v)), (T.EX_MUL, 1, T.temp(0), T.col(v))], consts=[1.0],
                             est_groups=groups if keys_kind != "int_underestimated" else 3_000_000)   # (1953 groups a piece for tables of 2048 slots: the probe bound sends rows down the global path)
     dcols = [to_dev(x, dev) for x in cols]
     half = n // 2 + 3
@@ -582,7 +585,6 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
     sum_a = np.bincount(gid, weights=a, minlength=groups)
     sum_b = np.zeros(groups, dtype=np.int64)
     np.add.at(sum_b, gid, b)
-    sum_c = np.bincount(gid, weights=c.astype(np.float64), minlength=groups).astype(np.int64)
     if keys_kind == "int_and_char":
         got_gid = (gk[0].astype(np.int64) + 17) // 1_003 * 5 + (gk[1].reshape(gk[1].shape[0], -1)[:, 0].astype(np.int64) - ord("V"))
     else:
@@ -591,15 +593,17 @@ def test_two_level_partitioned_aggregation_for_large_group_counts(capi, oracle, 
     assert np.array_equal(gv[0], cnt[got_gid])
     assert np.array_equal(gv[1], sum_a[got_gid])
     assert np.array_equal(gv[2], sum_b[got_gid])
-    assert np.array_equal(gv[3], sum_c[got_gid])
-    assert np.allclose(gv[4], sum_a[got_gid] / cnt[got_gid], rtol=1e-12, atol=0.0)
+    assert np.allclose(gv[3], sum_a[got_gid] / cnt[got_gid], rtol=1e-12, atol=0.0)
     min_b = np.full(groups, np.iinfo(np.int64).max, dtype=np.int64)
     np.minimum.at(min_b, gid, b)
     max_a = np.full(groups, -np.inf)
     np.maximum.at(max_a, gid, a)
-    min_c = np.full(groups, np.iinfo(np.int32).max, dtype=np.int64)
-    np.minimum.at(min_c, gid, c.astype(np.int64))
-    assert np.array_equal(gv[5], min_b[got_gid]) and np.array_equal(gv[6], max_a[got_gid]) and np.array_equal(gv[7].astype(np.int64), min_c[got_gid])
+    assert np.array_equal(gv[4], min_b[got_gid]) and np.array_equal(gv[5], max_a[got_gid])
+    expr = (1.0 - a) * a                                                        # (multiples of 1/64: exact, and their sums too)
+    sum_e = np.bincount(gid, weights=expr, minlength=groups)
+    max_e = np.full(groups, -np.inf)
+    np.maximum.at(max_e, gid, expr)
+    assert np.array_equal(gv[6], sum_e[got_gid]) and np.array_equal(gv[7], max_e[got_gid])
     assert_same_groups(results[0], results[1])
     # the operators' form: a run of 1 M-row blocks (ragged at the end, an empty one inside) in one call — laid end to end in scratch
     # of the call and through the same partition passes (aggregate.hip update_run_end_to_end)
