@@ -36,7 +36,8 @@ extern "C" {
 /* 6: the entry points over runs of blocks (qsx_*_blocks); nothing older changed its signature */
 /* 17: the block forms over compressed key stripes (qsx_key_coding_t, qsx_join_*_blocks_coded, qsx_lip_*_blocks_coded,
  *     qsx_join_key_pack_blocks_coded), qsx_join_probe_exists_lip, qsx_copy_segments; nothing older changed its signature */
-#define QSX_ABI_VERSION 17
+/* 18: qsx_partition_scatter_blocks (K9 reading a run of blocks where they lie); nothing older changed its signature */
+#define QSX_ABI_VERSION 18
 
 typedef void *qsx_stream_t;
 
@@ -972,6 +973,19 @@ int qsx_partition_scatter(int key_type, const void *keys_dev, int64_t n, int num
                           int ncols, const void *const *cols, const int32_t *widths,
                           void *const *out_cols, int64_t *out_offsets_dev,
                           void *workspace_dev, size_t workspace_bytes, qsx_stream_t stream);
+
+/* K9 over a run of storage blocks: what qsx_partition_scatter leaves for the blocks' rows laid end to end (block 0's rows, then
+ * block 1's, ...) without laying them so — the repartitioning Select in front of a partitioned join reads a stored relation
+ * (SelectOperator.cpp:83-150 one work order per block, every tuple routed by PartitionAwareInsertDestination::bulkInsertTuples,
+ * storage/InsertDestination.hpp:560-660); here a work order takes a run of blocks and the scatter reads every block's stripes
+ * where they lie.  block_keys[b]: the key stripe of block b (INT / LONG values); block_cols[b * ncols + c]: column c's stripe of
+ * block b; out_cols[c]: one stripe with room for all rows.  Blocks without rows are skipped (their pointers are not looked at).
+ * Workspace: qsx_partition_blocks_workspace_bytes(all rows, num_blocks, num_partitions). */
+size_t qsx_partition_blocks_workspace_bytes(int64_t n, int64_t num_blocks, int num_partitions);
+int qsx_partition_scatter_blocks(int key_type, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                 int num_partitions, int ncols, const void *const *block_cols, const int32_t *widths,
+                                 void *const *out_cols, int64_t *out_offsets_dev, void *workspace_dev, size_t workspace_bytes,
+                                 qsx_stream_t stream);
 
 /* ======================================================================
  * ORDER BY (the step after the aggregate in Q1 / Q3)

@@ -164,6 +164,8 @@ _SIGNATURES = {
                                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "qsx_partition_workspace_bytes": (_sz, [_i64, _int]),
     "qsx_partition_scatter": (_int, [_int, _vp, _i64, _int, _int, _pp, C.POINTER(_i32), _pp, _vp, _vp, _sz, _vp]),
+    "qsx_partition_blocks_workspace_bytes": (_sz, [_i64, _i64, _int]),
+    "qsx_partition_scatter_blocks": (_int, [_int, _i64, C.POINTER(_i64), _pp, _int, _int, _pp, C.POINTER(_i32), _pp, _vp, _vp, _sz, _vp]),
 }
 
 # every symbol include/qsx.h declares must resolve (tests/test_abi.py checks the header against this table)
@@ -1169,6 +1171,28 @@ def partition_scatter(keys, num_partitions, cols, stream=None):
     _check(_lib.qsx_partition_scatter(qsx_type_of(keys), _ptr(keys), n, num_partitions, len(cols), _ptr_array(cols),
                                       widths, _ptr_array(out_cols), _ptr(offsets), _ptr(ws), ws_bytes,
                                       _stream(stream)), "qsx_partition_scatter")
+    return out_cols, offsets
+
+
+def partition_scatter_blocks(block_keys, num_partitions, block_cols, stream=None):
+    """K9 over a run of blocks (qsx_partition_scatter_blocks): block_keys[b] the key stripe of block b, block_cols[b][c] column c's
+    stripe of block b.  Returns (scattered columns over all rows, offsets int64[P+1] on device) — what partition_scatter returns for
+    the blocks' rows laid end to end."""
+    nb = len(block_keys)
+    assert nb > 0 and len(block_cols) == nb
+    device = block_keys[0].device
+    ncols = len(block_cols[0])
+    rows = [k.numel() for k in block_keys]
+    n = sum(rows)
+    out_cols = [torch.empty(n, dtype=block_cols[0][c].dtype, device=device) for c in range(ncols)]
+    widths = (C.c_int32 * max(ncols, 1))(*[block_cols[0][c].element_size() for c in range(ncols)])
+    flat = [block_cols[b][c] for b in range(nb) for c in range(ncols)]
+    ws_bytes = _lib.qsx_partition_blocks_workspace_bytes(n, nb, num_partitions)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    offsets = torch.zeros(num_partitions + 1, dtype=torch.int64, device=device)
+    _check(_lib.qsx_partition_scatter_blocks(qsx_type_of(block_keys[0]), nb, (C.c_int64 * nb)(*rows), _ptr_array(block_keys), num_partitions,
+                                             ncols, _ptr_array(flat), widths, _ptr_array(out_cols), _ptr(offsets), _ptr(ws), ws_bytes,
+                                             _stream(stream)), "qsx_partition_scatter_blocks")
     return out_cols, offsets
 
 

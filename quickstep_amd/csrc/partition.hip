@@ -19,10 +19,12 @@
 // Limits: at most 64 partitions (lane p owns partition p).
 
 #include "common.hpp"
+#include "block_runs.hpp"
 #include "partition.hpp"
 #include "scan.hpp"
 
 #include <type_traits>
+#include <vector>
 
 namespace qsx {
 
@@ -40,6 +42,7 @@ constexpr int kPCells = kPSteps * kPWaves;        // 32 (step, wave) cells per t
 template <typename KeyT>
 struct ColumnKey {
   const KeyT *keys;
+  __device__ __forceinline__ void rebase(const void *stripe) { keys = static_cast<const KeyT *>(stripe); }
   __device__ __forceinline__ unsigned long long operator()(int64_t row) const {
     if (sizeof(KeyT) == 4) return static_cast<uint32_t>(keys[row]);
     return static_cast<unsigned long long>(keys[row]);
@@ -111,6 +114,25 @@ __device__ __forceinline__ void step_ranks(int pid, int P, int &rank, int &count
   count_in_lane = lane < P ? __popcll(mine) : 0;
 }
 
+// ---- a run of storage blocks as K9's input (qsx_partition_scatter_blocks) ---------------------------------------------
+// The repartitioning Select of a partitioned join reads a stored relation: tens to hundreds of blocks, every one with its own
+// stripes.  Laid end to end first (one qsx_copy_segments launch) the rows cross HBM twice more than the scatter needs; here a
+// workgroup's chunk of rows lies inside ONE block — the run table of block_runs.hpp with a chunk as its "tile", in[b] = the key
+// stripe of block b, and behind it one more array of nb words per column: the column's stripe in every block — so a workgroup
+// looks its block up once (scalar loads) and walks block-local rows.  Chunks follow each other in row order: the (partition,
+// workgroup) cells scan to the same places as over the concatenation and the scatter stays stable.
+template <bool kRuns>
+struct ChunkSource {
+  int block;
+  long long cols_at;   // word of the table where column 0's array starts
+  long long nb;
+};
+template <bool kRuns>
+__device__ __forceinline__ const void *chunk_column(const long long *__restrict__ runs, const ChunkSource<kRuns> &at, const void *plain, int c) {
+  if constexpr (kRuns) return as_global(reinterpret_cast<const unsigned char *>(runs[at.cols_at + static_cast<long long>(c) * at.nb + at.block]));
+  return plain;
+}
+
 struct ScatterArgs {
   int ncols;
   int width[QSX_MAX_COLUMNS];
@@ -119,16 +141,21 @@ struct ScatterArgs {
 };
 
 // PT > 0: the partition count as a constant (8 = one partition per GPU of a node, the shuffle's case); 0 = run-time P.
-template <typename Loader, int MODE, bool kSmallP, int PT = 0>
-__global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key, int64_t n, int P_arg,
-                                                                int pow2, int64_t rows_per_block, int64_t G,
-                                                                int32_t *__restrict__ hist) {
+template <typename Loader, int MODE, bool kSmallP, int PT, bool kRuns>
+__device__ __forceinline__ void partition_hist_body(Loader load_key, int64_t n, int P_arg, int pow2, int64_t rows_per_block, int64_t G,
+                                                    int32_t *__restrict__ hist, const long long *__restrict__ runs) {
   const int P = PT > 0 ? PT : P_arg;
   __shared__ int s_total[kWave];
   const int lane = lane_id();
   if (threadIdx.x < kWave) s_total[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  if constexpr (kRuns) {   // this workgroup's chunk of its block (rows are block-local from here on)
+    const RunTile at = run_locate(runs, static_cast<int>(blockIdx.x));
+    begin = static_cast<int64_t>(at.tile_in_block) * rows_per_block;
+    n = run_rows(runs, at.block);
+    load_key.rebase(run_in<unsigned char>(runs, at.block));
+  }
   const int64_t end = begin + rows_per_block < n ? begin + rows_per_block : n;
   constexpr bool kIntKeys = std::is_same<Loader, ColumnKey<int32_t>>::value;
   if constexpr (kSmallP && (kIntKeys || std::is_same<Loader, ColumnKey<int64_t>>::value)) {
@@ -226,6 +253,18 @@ __global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key
   __syncthreads();
   if (threadIdx.x < P) hist[static_cast<int64_t>(threadIdx.x) * G + blockIdx.x] = s_total[threadIdx.x];
 }
+template <typename Loader, int MODE, bool kSmallP, int PT = 0>
+__global__ __launch_bounds__(kPBlock) void partition_hist_kernel(Loader load_key, int64_t n, int P_arg,
+                                                                int pow2, int64_t rows_per_block, int64_t G,
+                                                                int32_t *__restrict__ hist) {
+  partition_hist_body<Loader, MODE, kSmallP, PT, false>(load_key, n, P_arg, pow2, rows_per_block, G, hist, nullptr);
+}
+template <typename Loader, int MODE, bool kSmallP, int PT = 0>
+__global__ __launch_bounds__(kPBlock) void partition_hist_runs_kernel(Loader load_key, const long long *__restrict__ runs, int P_arg,
+                                                                     int pow2, int64_t rows_per_block, int64_t G,
+                                                                     int32_t *__restrict__ hist) {
+  partition_hist_body<Loader, MODE, kSmallP, PT, true>(load_key, 0, P_arg, pow2, rows_per_block, G, hist, runs);
+}
 
 template <int W>
 __device__ __forceinline__ void stage_and_copy(const void *src, void *dst, unsigned char *stage, const int64_t (&row)[kPSteps],
@@ -253,12 +292,10 @@ __device__ __forceinline__ void stage_and_copy(const void *src, void *dst, unsig
   __syncthreads();
 }
 
-template <typename Loader, int MODE, bool kSmallP, int PT = 0>
-__global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(MODE == 3 && !kSmallP ? 4 : 1))) void partition_scatter_kernel(Loader load_key, int64_t n, int P_arg,
-                                                                   int pow2, int64_t rows_per_block, int64_t G,
-                                                                   const int64_t *__restrict__ starts,
-                                                                   ScatterArgs args, int stage_width,
-                                                                   int64_t *__restrict__ out_offsets) {
+template <typename Loader, int MODE, bool kSmallP, int PT, bool kRuns>
+__device__ __forceinline__ void partition_scatter_body(Loader load_key, int64_t n, int P_arg, int pow2, int64_t rows_per_block, int64_t G,
+                                                       const int64_t *__restrict__ starts, const ScatterArgs &args, int stage_width,
+                                                       int64_t *__restrict__ out_offsets, const long long *__restrict__ runs) {
   // dynamic LDS: stage[kPTile * widest column] | cnt[kPCells * P] — sized by the launch so that small
   // P / narrow columns leave room for more workgroups per CU (the tile loop is a chain of
   // load -> LDS -> barrier -> store phases: occupancy is what hides their latencies)
@@ -276,7 +313,17 @@ __global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(MODE ==
     if (threadIdx.x == 0) out_offsets[P] = n;
   }
   if (threadIdx.x < P) s_glob[threadIdx.x] = starts[static_cast<int64_t>(threadIdx.x) * G + blockIdx.x];
-  const int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  ChunkSource<kRuns> chunk{0, 0, 0};
+  if constexpr (kRuns) {   // (n, the rows of the whole run, is out_offsets[P] above; from here on: of this workgroup's block)
+    const RunTile at = run_locate(runs, static_cast<int>(blockIdx.x));
+    chunk.block = at.block;
+    chunk.nb = runs[0];
+    chunk.cols_at = kRunHeaderWords + (chunk.nb + 1) + 5 * chunk.nb;
+    begin = static_cast<int64_t>(at.tile_in_block) * rows_per_block;
+    n = run_rows(runs, at.block);
+    load_key.rebase(run_in<unsigned char>(runs, at.block));
+  }
   const int64_t end = begin + rows_per_block < n ? begin + rows_per_block : n;
   // the keys of the NEXT tile are requested before the current tile goes through its rank / stage / copy phases (each
   // of them ends in a barrier): one exposed round trip less per tile
@@ -391,16 +438,33 @@ __global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(MODE ==
     }
     __syncthreads();
     for (int c = 0; c < args.ncols; ++c) {
+      const void *src = chunk_column<kRuns>(runs, chunk, args.src[c], c);
       switch (args.width[c]) {
-        case 1: stage_and_copy<1>(args.src[c], args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
-        case 2: stage_and_copy<2>(args.src[c], args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
-        case 4: stage_and_copy<4>(args.src[c], args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
-        default: stage_and_copy<8>(args.src[c], args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
+        case 1: stage_and_copy<1>(src, args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
+        case 2: stage_and_copy<2>(src, args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
+        case 4: stage_and_copy<4>(src, args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
+        default: stage_and_copy<8>(src, args.dst[c], s_stage, row, pos, pid, s_pid, s_part_start, s_glob, tile_rows); break;
       }
     }
     if (threadIdx.x < P) s_glob[threadIdx.x] += s_part_start[threadIdx.x + 1] - s_part_start[threadIdx.x];
     __syncthreads();
   }
+}
+template <typename Loader, int MODE, bool kSmallP, int PT = 0>
+__global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(MODE == 3 && !kSmallP ? 4 : 1))) void partition_scatter_kernel(Loader load_key, int64_t n, int P_arg,
+                                                                   int pow2, int64_t rows_per_block, int64_t G,
+                                                                   const int64_t *__restrict__ starts,
+                                                                   ScatterArgs args, int stage_width,
+                                                                   int64_t *__restrict__ out_offsets) {
+  partition_scatter_body<Loader, MODE, kSmallP, PT, false>(load_key, n, P_arg, pow2, rows_per_block, G, starts, args, stage_width, out_offsets, nullptr);
+}
+template <typename Loader, int MODE, bool kSmallP, int PT = 0>
+__global__ __launch_bounds__(kPBlock) void partition_scatter_runs_kernel(Loader load_key, int64_t n, const long long *__restrict__ runs, int P_arg,
+                                                                        int pow2, int64_t rows_per_block, int64_t G,
+                                                                        const int64_t *__restrict__ starts,
+                                                                        ScatterArgs args, int stage_width,
+                                                                        int64_t *__restrict__ out_offsets) {
+  partition_scatter_body<Loader, MODE, kSmallP, PT, true>(load_key, n, P_arg, pow2, rows_per_block, G, starts, args, stage_width, out_offsets, runs);
 }
 
 // The scatter pass for at most 8 partitions whose columns fit the staging area side by side (the shuffle of a join side
@@ -413,12 +477,11 @@ struct SmallScatterLayout {
   int stage_off[QSX_MAX_COLUMNS];   // byte offset of column c's slots in the staging area
 };
 // (PT == 8, the shuffle's form, fits 80 registers without scratch: six waves per SIMD instead of five)
-template <typename Loader, int MODE, int PT = 0>
-__global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8 ? 6 : 4))) void partition_scatter_small_kernel(Loader load_key, int64_t n, int P_arg, int pow2,
-                                                                         int64_t rows_per_block, int64_t G,
-                                                                         const int64_t *__restrict__ starts, ScatterArgs args,
-                                                                         SmallScatterLayout layout, int stage_bytes,
-                                                                         int64_t *__restrict__ out_offsets) {
+template <typename Loader, int MODE, int PT, bool kRuns>
+__device__ __forceinline__ void partition_scatter_small_body(Loader load_key, int64_t n, int P_arg, int pow2, int64_t rows_per_block, int64_t G,
+                                                             const int64_t *__restrict__ starts, const ScatterArgs &args,
+                                                             const SmallScatterLayout &layout, int stage_bytes,
+                                                             int64_t *__restrict__ out_offsets, const long long *__restrict__ runs) {
   const int P = PT > 0 ? PT : P_arg;
   extern __shared__ __attribute__((aligned(8))) unsigned char s_dyn[];
   unsigned char *s_stage = s_dyn;
@@ -433,7 +496,17 @@ __global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8
     if (threadIdx.x == 0) out_offsets[P] = n;
   }
   if (threadIdx.x < P) s_glob[threadIdx.x] = starts[static_cast<int64_t>(threadIdx.x) * G + blockIdx.x];
-  const int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  int64_t begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  ChunkSource<kRuns> chunk{0, 0, 0};
+  if constexpr (kRuns) {
+    const RunTile at = run_locate(runs, static_cast<int>(blockIdx.x));
+    chunk.block = at.block;
+    chunk.nb = runs[0];
+    chunk.cols_at = kRunHeaderWords + (chunk.nb + 1) + 5 * chunk.nb;
+    begin = static_cast<int64_t>(at.tile_in_block) * rows_per_block;
+    n = run_rows(runs, at.block);
+    load_key.rebase(run_in<unsigned char>(runs, at.block));
+  }
   const int64_t end = begin + rows_per_block < n ? begin + rows_per_block : n;
   using KeyValue = decltype(load_key(static_cast<int64_t>(0)));
   KeyValue key[kPSteps], next_key[kPSteps];
@@ -508,11 +581,12 @@ __global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8
     }
     for (int c = 0; c < args.ncols; ++c) {   // every column into its own part of the staging area: no barrier in between
       unsigned char *stage = s_stage + layout.stage_off[c];
+      const void *src = chunk_column<kRuns>(runs, chunk, args.src[c], c);
       switch (args.width[c]) {
         case 1: {
           uint8_t v[kPSteps];
 #pragma unroll
-          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint8_t *>(args.src[c])[row[j]]) : uint8_t(0);
+          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint8_t *>(src)[row[j]]) : uint8_t(0);
 #pragma unroll
           for (int j = 0; j < kPSteps; ++j) if (pid[j] >= 0) reinterpret_cast<uint8_t *>(stage)[pos[j]] = v[j];
           break;
@@ -520,7 +594,7 @@ __global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8
         case 2: {
           uint16_t v[kPSteps];
 #pragma unroll
-          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint16_t *>(args.src[c])[row[j]]) : uint16_t(0);
+          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint16_t *>(src)[row[j]]) : uint16_t(0);
 #pragma unroll
           for (int j = 0; j < kPSteps; ++j) if (pid[j] >= 0) reinterpret_cast<uint16_t *>(stage)[pos[j]] = v[j];
           break;
@@ -528,7 +602,7 @@ __global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8
         case 4: {
           uint32_t v[kPSteps];
 #pragma unroll
-          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint32_t *>(args.src[c])[row[j]]) : 0u;
+          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint32_t *>(src)[row[j]]) : 0u;
 #pragma unroll
           for (int j = 0; j < kPSteps; ++j) if (pid[j] >= 0) reinterpret_cast<uint32_t *>(stage)[pos[j]] = v[j];
           break;
@@ -536,7 +610,7 @@ __global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8
         default: {
           uint64_t v[kPSteps];
 #pragma unroll
-          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint64_t *>(args.src[c])[row[j]]) : 0ull;
+          for (int j = 0; j < kPSteps; ++j) v[j] = pid[j] >= 0 ? load_global(&static_cast<const uint64_t *>(src)[row[j]]) : 0ull;
 #pragma unroll
           for (int j = 0; j < kPSteps; ++j) if (pid[j] >= 0) reinterpret_cast<uint64_t *>(stage)[pos[j]] = v[j];
           break;
@@ -564,6 +638,22 @@ __global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8
     __syncthreads();   // (3) the staging area and the starts are free again
     if (threadIdx.x < P) s_glob[threadIdx.x] += s_part_start[threadIdx.x + 1] - s_part_start[threadIdx.x];
   }
+}
+template <typename Loader, int MODE, int PT = 0>
+__global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8 ? 6 : 4))) void partition_scatter_small_kernel(Loader load_key, int64_t n, int P_arg, int pow2,
+                                                                         int64_t rows_per_block, int64_t G,
+                                                                         const int64_t *__restrict__ starts, ScatterArgs args,
+                                                                         SmallScatterLayout layout, int stage_bytes,
+                                                                         int64_t *__restrict__ out_offsets) {
+  partition_scatter_small_body<Loader, MODE, PT, false>(load_key, n, P_arg, pow2, rows_per_block, G, starts, args, layout, stage_bytes, out_offsets, nullptr);
+}
+template <typename Loader, int MODE, int PT = 0>
+__global__ __launch_bounds__(kPBlock) __attribute__((amdgpu_waves_per_eu(PT == 8 ? 6 : 4))) void partition_scatter_small_runs_kernel(Loader load_key, int64_t n, const long long *__restrict__ runs,
+                                                                         int P_arg, int pow2, int64_t rows_per_block, int64_t G,
+                                                                         const int64_t *__restrict__ starts, ScatterArgs args,
+                                                                         SmallScatterLayout layout, int stage_bytes,
+                                                                         int64_t *__restrict__ out_offsets) {
+  partition_scatter_small_body<Loader, MODE, PT, true>(load_key, n, P_arg, pow2, rows_per_block, G, starts, args, layout, stage_bytes, out_offsets, runs);
 }
 
 // Internal re-partitioning with aligned pieces: every partition's run starts at a multiple of `align` rows of the
@@ -623,18 +713,52 @@ size_t partition_workspace_bytes(int64_t n, int num_partitions) {
          scan_workspace_words(cells) * sizeof(int64_t);
 }
 
+// The rows a workgroup takes: whole tiles, blocks_for(n) chunks over one stripe.
+static int64_t chunk_rows_for(int64_t n) {
+  const int64_t G = blocks_for(n);
+  const int64_t rows_per_block = (n + G - 1) / G;
+  return (rows_per_block + kPTile - 1) / kPTile * kPTile;
+}
+
+// A run of blocks (ChunkSource above): chunks of chunk_rows_for(all rows) rows that never straddle two blocks — at most one
+// chunk per block more than over the concatenation.
+size_t partition_blocks_workspace_bytes(int64_t n, int64_t num_blocks, int num_partitions) {
+  const int64_t cells = (blocks_for(n) + num_blocks) * num_partitions;
+  return p_align_up(sizeof(int64_t) * (cells + 1), 256) + p_align_up(sizeof(int32_t) * cells, 256) +
+         scan_workspace_words(cells) * sizeof(int64_t);
+}
+
+// runs_dev != nullptr: the run form — G_runs chunks of rows_runs rows, the keys and columns found through the table.
 template <typename Loader, int MODE>
 static int launch_partition_t(Loader keys, int64_t n, int P, int pow2, const ScatterArgs &args, int64_t *out_offsets,
-                              void *workspace, int align_rows, hipStream_t s) {
-  const int64_t G = blocks_for(n);
-  int64_t rows_per_block = (n + G - 1) / G;
-  rows_per_block = (rows_per_block + kPTile - 1) / kPTile * kPTile;
+                              void *workspace, int align_rows, hipStream_t s, const long long *runs_dev = nullptr,
+                              int64_t G_runs = 0, int64_t rows_runs = 0) {
+  constexpr bool kRunForms = MODE == 0 && !std::is_same<Loader, PackedKey>::value;   // (the C ABI's partition function only)
+  if (runs_dev != nullptr && !kRunForms) return QSX_ERR_UNSUPPORTED;
+  const int64_t G = runs_dev != nullptr ? G_runs : blocks_for(n);
+  const int64_t rows_per_block = runs_dev != nullptr ? rows_runs : chunk_rows_for(n);
   const int64_t cells = G * P;
   int64_t *starts = static_cast<int64_t *>(workspace);
   char *after = static_cast<char *>(workspace) + p_align_up(sizeof(int64_t) * (cells + 1), 256);
   int32_t *hist = reinterpret_cast<int32_t *>(after);
   int64_t *scan_ws = reinterpret_cast<int64_t *>(after + p_align_up(sizeof(int32_t) * cells, 256));
-  if (P == 8) {
+  if constexpr (kRunForms) {
+    if (runs_dev != nullptr) {
+      if (P == 8) {
+        hipLaunchKernelGGL((partition_hist_runs_kernel<Loader, MODE, true, 8>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys,
+                           runs_dev, P, pow2, rows_per_block, G, hist);
+      } else if (P <= 8) {
+        hipLaunchKernelGGL((partition_hist_runs_kernel<Loader, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys,
+                           runs_dev, P, pow2, rows_per_block, G, hist);
+      } else {
+        hipLaunchKernelGGL((partition_hist_runs_kernel<Loader, MODE, false>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys,
+                           runs_dev, P, pow2, rows_per_block, G, hist);
+      }
+    }
+  }
+  if (runs_dev != nullptr) {
+    // (launched above)
+  } else if (P == 8) {
     hipLaunchKernelGGL((partition_hist_kernel<Loader, MODE, true, 8>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), 0, s, keys, n, P,
                        pow2, rows_per_block, G, hist);
   } else if (P <= 8) {
@@ -663,6 +787,19 @@ static int launch_partition_t(Loader keys, int64_t n, int P, int pow2, const Sca
     static const bool small_off = getenv("QSX_K9_SMALL") != nullptr && atoi(getenv("QSX_K9_SMALL")) == 0;
     if (stage_bytes <= 48 * 1024 && !small_off) {
       const size_t small_lds = static_cast<size_t>(stage_bytes) + sizeof(int) * kPCells * P;
+      if constexpr (kRunForms) {
+        if (runs_dev != nullptr) {
+          if (P == 8) {
+            hipLaunchKernelGGL((partition_scatter_small_runs_kernel<Loader, MODE, 8>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), small_lds,
+                               s, keys, n, runs_dev, P, pow2, rows_per_block, G, starts, args, layout, stage_bytes, block0_offsets);
+          } else {
+            hipLaunchKernelGGL((partition_scatter_small_runs_kernel<Loader, MODE>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), small_lds,
+                               s, keys, n, runs_dev, P, pow2, rows_per_block, G, starts, args, layout, stage_bytes, block0_offsets);
+          }
+          QSX_CHECK_LAUNCH();
+          return QSX_OK;
+        }
+      }
       if (P == 8) {
         hipLaunchKernelGGL((partition_scatter_small_kernel<Loader, MODE, 8>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), small_lds, s,
                            keys, n, P, pow2, rows_per_block, G, starts, args, layout, stage_bytes, block0_offsets);
@@ -677,6 +814,22 @@ static int launch_partition_t(Loader keys, int64_t n, int P, int pow2, const Sca
   int stage_width = 1;
   for (int c = 0; c < args.ncols; ++c) stage_width = args.width[c] > stage_width ? args.width[c] : stage_width;
   const size_t lds = static_cast<size_t>(kPTile) * stage_width + sizeof(int) * kPCells * P;
+  if constexpr (kRunForms) {
+    if (runs_dev != nullptr) {
+      if (P == 8) {
+        hipLaunchKernelGGL((partition_scatter_runs_kernel<Loader, MODE, true, 8>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
+                           n, runs_dev, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
+      } else if (P <= 8) {
+        hipLaunchKernelGGL((partition_scatter_runs_kernel<Loader, MODE, true>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
+                           n, runs_dev, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
+      } else {
+        hipLaunchKernelGGL((partition_scatter_runs_kernel<Loader, MODE, false>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
+                           n, runs_dev, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
+      }
+      QSX_CHECK_LAUNCH();
+      return QSX_OK;
+    }
+  }
   if (P == 8) {
     hipLaunchKernelGGL((partition_scatter_kernel<Loader, MODE, true, 8>), dim3(static_cast<unsigned>(G)), dim3(kPBlock), lds, s, keys,
                        n, P, pow2, rows_per_block, G, starts, args, stage_width, block0_offsets);
@@ -827,6 +980,79 @@ int qsx_partition_scatter(int key_type, const void *keys_dev, int64_t n, int num
   QSX_REQUIRE_DEVICE();
   return partition_scatter_impl(0, key_type, keys_dev, n, num_partitions, ncols, cols, widths, out_cols, out_offsets_dev,
                                 workspace_dev, workspace_bytes, as_stream(stream), 0);
+}
+
+size_t qsx_partition_blocks_workspace_bytes(int64_t n, int64_t num_blocks, int num_partitions) {
+  return partition_blocks_workspace_bytes(n, num_blocks < 0 ? 0 : num_blocks, num_partitions);
+}
+
+// K9 over a run of blocks: the result of qsx_partition_scatter over the blocks' rows laid end to end, without laying them so.
+int qsx_partition_scatter_blocks(int key_type, int64_t num_blocks, const int64_t *block_rows, const void *const *block_keys,
+                                 int num_partitions, int ncols, const void *const *block_cols, const int32_t *widths,
+                                 void *const *out_cols, int64_t *out_offsets_dev, void *workspace_dev, size_t workspace_bytes,
+                                 qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (num_blocks < 0 || num_partitions < 1 || ncols < 0 || ncols > QSX_MAX_COLUMNS || out_offsets_dev == nullptr ||
+      (num_blocks > 0 && (block_rows == nullptr || block_keys == nullptr)) ||
+      (ncols > 0 && (widths == nullptr || out_cols == nullptr || (num_blocks > 0 && block_cols == nullptr)))) {
+    return QSX_ERR_INVALID_ARGUMENT;
+  }
+  if (num_partitions > kWave) return QSX_ERR_UNSUPPORTED;
+  if (key_type != QSX_INT && key_type != QSX_LONG) return QSX_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  ScatterArgs args;
+  args.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) {
+    if (widths[c] != 1 && widths[c] != 2 && widths[c] != 4 && widths[c] != 8) return QSX_ERR_UNSUPPORTED;
+    args.width[c] = widths[c];
+    args.src[c] = nullptr;
+    args.dst[c] = out_cols[c];
+  }
+  // the blocks that hold rows
+  std::vector<int64_t> rows;
+  std::vector<const void *> keys;
+  std::vector<int64_t> which;
+  int64_t n = 0;
+  for (int64_t b = 0; b < num_blocks; ++b) {
+    if (block_rows[b] < 0) return QSX_ERR_INVALID_ARGUMENT;
+    if (block_rows[b] == 0) continue;
+    if (block_keys[b] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    for (int c = 0; c < ncols; ++c) {
+      if (block_cols[b * ncols + c] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+    }
+    rows.push_back(block_rows[b]);
+    keys.push_back(block_keys[b]);
+    which.push_back(b);
+    n += block_rows[b];
+  }
+  if (n == 0) {
+    QSX_HIP_TRY(hipMemsetAsync(out_offsets_dev, 0, sizeof(int64_t) * (num_partitions + 1), s));
+    return QSX_OK;
+  }
+  const int64_t nb = static_cast<int64_t>(rows.size());
+  if (workspace_dev == nullptr || workspace_bytes < partition_blocks_workspace_bytes(n, num_blocks, num_partitions)) return QSX_ERR_CAPACITY;
+  for (int c = 0; c < ncols; ++c) {
+    if (out_cols[c] == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  }
+  const int64_t chunk_rows = chunk_rows_for(n);
+  std::vector<long long> table;
+  const long long chunks = build_run_table(chunk_rows, nb, rows.data(), keys.data(), nullptr, nullptr, nullptr, &table);
+  if (chunks <= 0) return QSX_ERR_INVALID_ARGUMENT;
+  for (int c = 0; c < ncols; ++c) {   // (ChunkSource::cols_at: right behind the table's five arrays)
+    for (int64_t i = 0; i < nb; ++i) table.push_back(static_cast<long long>(reinterpret_cast<uintptr_t>(block_cols[which[i] * ncols + c])));
+  }
+  const size_t bytes = table.size() * sizeof(long long);
+  const long long *runs_dev = static_cast<const long long *>(staged_device_buffer(s, bytes));
+  if (runs_dev == nullptr) return QSX_ERR_OUT_OF_MEMORY;
+  const int rc = staged_upload(s, table.data(), bytes);
+  if (rc != QSX_OK) return rc;
+  const bool is_pow2 = (num_partitions & (num_partitions - 1)) == 0;
+  if (key_type == QSX_INT) {
+    return launch_partition_t<ColumnKey<int32_t>, 0>(ColumnKey<int32_t>{nullptr}, n, num_partitions, is_pow2 ? 1 : 0, args, out_offsets_dev,
+                                                     workspace_dev, 0, s, runs_dev, chunks, chunk_rows);
+  }
+  return launch_partition_t<ColumnKey<int64_t>, 0>(ColumnKey<int64_t>{nullptr}, n, num_partitions, is_pow2 ? 1 : 0, args, out_offsets_dev,
+                                                   workspace_dev, 0, s, runs_dev, chunks, chunk_rows);
 }
 
 }  // extern "C"

@@ -242,6 +242,66 @@ void InsertDestination::returnBlock(block_id id, std::int64_t num_tuples, partit
   if (block_returned_) block_returned_();
 }
 
+// bulkInsertTuples of a PartitionAwareInsertDestination over every tuple of a run of input blocks: one K9 pass that finds the
+// blocks' stripes through a table — against a copy of the run into one block (two more trips through HBM) and K9 over that.
+bool InsertDestination::insertRunRepartitioned(const std::vector<BlockReference> &blocks, const std::vector<attribute_id> &attributes) {
+  if (!isPartitionAware() || blocks.empty() || attributes.size() != relation_->size() || attributes.size() > QSX_MAX_COLUMNS) return false;
+  const std::size_t P = num_partitions_;
+  const Type &key_type = relation_->getAttributeType(partition_attribute_);
+  if ((key_type.id != kInt && key_type.id != kLong) || P > 64) return false;   // (repartitionBlock reports these)
+  for (std::size_t a = 0; a < relation_->size(); ++a) {
+    const Type &t = relation_->getAttributeType(static_cast<attribute_id>(a));
+    if (t.nullable || (t.width != 1 && t.width != 2 && t.width != 4 && t.width != 8)) return false;
+  }
+  std::vector<std::int64_t> rows;
+  std::vector<const void *> keys, cols;
+  std::vector<std::int32_t> widths;
+  std::int64_t total = 0;
+  for (const BlockReference &b : blocks) {
+    for (attribute_id a : attributes) {
+      if (b->nullBitmap(a) != nullptr) return false;
+    }
+    rows.push_back(b->numTuples());
+    total += b->numTuples();
+    keys.push_back(b->numTuples() > 0 ? b->stripe(attributes[partition_attribute_]) : nullptr);
+    for (attribute_id a : attributes) cols.push_back(b->numTuples() > 0 ? b->stripe(a) : nullptr);
+  }
+  if (total == 0) return true;
+  for (std::size_t a = 0; a < relation_->size(); ++a) widths.push_back(relation_->getAttributeType(static_cast<attribute_id>(a)).width);
+  block_id scattered_id;
+  BlockReference scattered = getBlockForInsertion(total, &scattered_id);
+  scattered->setNumTuples(total);
+  std::vector<void *> outs;
+  for (std::size_t a = 0; a < relation_->size(); ++a) outs.push_back(scattered->stripe(static_cast<attribute_id>(a)));
+  const std::size_t ws_bytes = qsx_partition_blocks_workspace_bytes(total, static_cast<std::int64_t>(blocks.size()), static_cast<int>(P));
+  DeviceBuffer ws(ws_bytes + 8), offsets_dev((P + 1) * 8);
+  CheckStatus(qsx_partition_scatter_blocks(key_type.id, static_cast<std::int64_t>(blocks.size()), rows.data(), keys.data(), static_cast<int>(P),
+                                           static_cast<int>(widths.size()), cols.data(), widths.data(), outs.data(),
+                                           static_cast<std::int64_t *>(offsets_dev.ptr), ws.ptr, ws_bytes, CurrentStream()),
+              "qsx_partition_scatter_blocks");
+  std::vector<std::int64_t> offsets(P + 1);
+  CheckStatus(qsx_copy_to_host(offsets.data(), offsets_dev.ptr, (P + 1) * 8, CurrentStream()), "qsx_copy_to_host");
+  CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");   // (the work order's wait; ws goes out of scope)
+  std::vector<std::pair<block_id, partition_id>> made;
+  for (std::size_t p = 0; p < P; ++p) {
+    const std::int64_t first = offsets[p], rows_p = offsets[p + 1] - offsets[p];
+    if (rows_p == 0) continue;
+    const block_id view_id = storage_manager_->createViewBlock(scattered_id, first, rows_p);
+    storage_manager_->getBlock(view_id)->setFirstRow(storage_manager_->reserveRows(relation_->getID(), rows_p));
+    made.emplace_back(view_id, p);
+  }
+  storage_manager_->deleteBlockOrBlobFile(scattered_id);      // (the views keep the scattered block alive)
+  {
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (const auto &m : made) {
+      touched_.push_back(TouchedBlock{m.first, m.second});
+      relation_->addBlockToPartition(m.first, m.second);
+    }
+  }
+  if (block_returned_ && !made.empty()) block_returned_();
+  return true;
+}
+
 // bulkInsertTuples of a PartitionAwareInsertDestination (storage/InsertDestination.hpp:560-660), on a whole block at once:
 // K9 scatters the columns of 1 / 2 / 4 / 8 bytes and a row-number column by the partition of the partition attribute; wider
 // columns (CHAR(n)) and the null bits follow through the scattered row numbers; the scattered block is then cut into one

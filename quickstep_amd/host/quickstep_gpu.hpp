@@ -385,6 +385,11 @@ class InsertDestination {
   // input_partition: the partition of the work order that filled the block — the partition of the output block when the
   // destination does not repartition (the output relation keeps the input's scheme, RelationalOperator.hpp:311-320).
   void returnBlock(block_id id, std::int64_t num_tuples, partition_id input_partition = 0);
+  // A partition-aware destination fed by a projection of EVERY tuple of a run of blocks (the repartitioning Select in front of a
+  // partitioned join): output attribute i = attribute attributes[i] of the blocks.  K9 reads the blocks' stripes where they lie
+  // (qsx_partition_scatter_blocks) — no output block filled first, then scattered.  false: not this case (a destination that
+  // does not repartition, nullable attributes, attributes wider than 8 bytes) — nothing was done, fill a block and return it.
+  bool insertRunRepartitioned(const std::vector<BlockReference> &blocks, const std::vector<attribute_id> &attributes);
   std::vector<block_id> getTouchedBlocks() const;
   struct TouchedBlock { block_id id; partition_id partition; };
   std::vector<TouchedBlock> getTouchedBlocksWithPartitions() const;

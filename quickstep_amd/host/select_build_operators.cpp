@@ -138,6 +138,8 @@ bool SelectWorkOrder::executeRun() {
   if (plain_copy && total_rows > 0) {
     // every tuple, projected on plain attributes: the selected stripes of the run laid end to end in the output block — one
     // qsx_copy_segments launch for all attributes (no TupleIdSequences, no compaction, no count to read back)
+    // (into a partition-aware destination: K9 reads the run where it lies — no copy in front of the scatter)
+    if (output_destination_->insertRunRepartitioned(blocks, selection)) return true;
     block_id copy_id;
     BlockReference copy = output_destination_->getBlockForInsertion(total_rows, &copy_id);
     std::vector<const void *> from;

@@ -193,6 +193,58 @@ void runMembership() {
   EXPECT_EQ(total, static_cast<std::size_t>(22));
 }
 
+// The repartitioning Select over runs of blocks: with attributes K9 moves by itself (1 / 2 / 4 / 8 bytes, not nullable) the
+// scatter reads the stored blocks where they lie (InsertDestination::insertRunRepartitioned, qsx_partition_scatter_blocks) — the
+// partitions hold what the block-at-a-time work orders leave: every tuple once, in input order, projected and reordered
+// (the partition attribute is output attribute 1, input attribute 2).  A relation with an attribute the scatter cannot move
+// (CHAR(20)) or NULLs keeps the copy-then-scatter path: runMembership / runNullsThroughRepartition with runs below.
+void runRepartitionOverRuns(std::size_t parts, std::size_t blocks_per_work_order) {
+  StorageManager storage;
+  CatalogRelation src(1, "lineitem_like"), dst(2, "by_orderkey");
+  src.addAttribute("payload", Type::Long());
+  src.addAttribute("unused", Type::Double());
+  src.addAttribute("orderkey", Type::Int());
+  dst.addAttribute("payload", Type::Long());
+  dst.addAttribute("orderkey", Type::Int());
+  dst.setPartitionScheme(parts, 1);
+  const std::vector<std::int64_t> block_rows = {30000, 30000, 30000, 0, 30000, 30000, 30000, 30000, 1234, 1};
+  std::vector<std::vector<std::pair<std::int64_t, std::int32_t>>> want(parts);
+  std::uint64_t state = 88172645463325252ull;
+  std::int64_t serial = 0;
+  for (const std::int64_t rows : block_rows) {
+    std::vector<std::int64_t> payload(rows);
+    std::vector<double> unused(rows, 1.5);
+    std::vector<std::int32_t> key(rows);
+    for (std::int64_t i = 0; i < rows; ++i) {
+      state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+      key[i] = static_cast<std::int32_t>(state % 1000003) - 500;           // (negative keys: the zero-extended bit pattern)
+      payload[i] = serial++;
+      const std::uint64_t h = static_cast<std::uint32_t>(key[i]);
+      const std::size_t p = (parts & (parts - 1)) == 0 ? h & (parts - 1) : (h >= parts ? h % parts : h);
+      want[p].emplace_back(payload[i], key[i]);
+    }
+    storage.loadBlock(&src, {payload.data(), unused.data(), key.data()}, rows, 0);
+  }
+  QueryContext ctx;
+  const auto dest = ctx.addPartitionAwareInsertDestination(&dst, &storage);
+  SelectOperator op(0, src, /*has_repartition=*/true, dst, dest, QueryContext::kInvalidPredicateId, std::vector<attribute_id>{0, 2}, true);
+  op.setBlocksPerWorkOrder(blocks_per_work_order);
+  fetchAndExecuteWorkOrders(&op, &ctx, &storage);
+  for (std::size_t p = 0; p < parts; ++p) {
+    std::vector<std::pair<std::int64_t, std::int32_t>> got;
+    for (block_id b : dst.getBlocksInPartition(p)) {
+      BlockReference blk = storage.getBlock(b);
+      const std::size_t k = static_cast<std::size_t>(blk->numTuples());
+      std::vector<std::int64_t> payload(k);
+      std::vector<std::int32_t> key(k);
+      blk->copyAttributeToHost(0, payload.data());
+      blk->copyAttributeToHost(1, key.data());
+      for (std::size_t i = 0; i < k; ++i) got.emplace_back(payload[i], key[i]);
+    }
+    EXPECT_TRUE(got == want[p]);
+  }
+}
+
 // NULL bits follow their tuples through the scatter; an empty work-order output leaves no block behind
 void runNullsThroughRepartition() {
   StorageManager storage;
@@ -340,6 +392,9 @@ int main() {
   }
   runMembership();
   runNullsThroughRepartition();
+  for (const std::size_t parts : {std::size_t(1), std::size_t(4), std::size_t(5), std::size_t(8), std::size_t(64)}) {
+    for (const std::size_t blocks : {std::size_t(1), std::size_t(3), std::size_t(100)}) runRepartitionOverRuns(parts, blocks);
+  }
   for (const bool use_foreman : {false, true}) {
     runJoin(4, false, use_foreman);    // partitioned hash join
     runJoin(1, false, use_foreman);    // broadcast build

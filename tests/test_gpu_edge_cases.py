@@ -263,6 +263,49 @@ def test_copy_segments_equals_a_copy_per_segment(capi, dev):
     assert int(out.count_nonzero().item()) <= sum(b - a for a, b in pieces)
 
 
+def test_partition_scatter_blocks_argument_errors_and_empty_runs(capi, dev):
+    """qsx_partition_scatter_blocks: no blocks / only empty blocks leave P + 1 zero offsets; a block with rows and no key stripe, a
+    negative row count, a column width K9 does not move, more than 64 partitions and a workspace that is too small are refused."""
+    import ctypes as C
+    import torch
+    from quickstep_amd import types as T
+    lib = capi.lib
+    P = 4
+    offs = torch.full((P + 1,), 7, dtype=torch.int64, device=dev)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    keys = torch.arange(5000, dtype=torch.int32, device=dev)
+    out = torch.empty_like(keys)
+
+    def call(rows, key_ptrs, col_ptrs, widths=(4,), parts=P, ws_bytes=ws.numel(), key_type=T.INT):
+        nb = len(rows)
+        return lib.qsx_partition_scatter_blocks(key_type, nb, (C.c_int64 * max(nb, 1))(*rows), (C.c_void_p * max(nb, 1))(*key_ptrs), parts,
+                                                len(widths), (C.c_void_p * max(len(col_ptrs), 1))(*col_ptrs), (C.c_int32 * len(widths))(*widths),
+                                                (C.c_void_p * len(widths))(*([out.data_ptr()] * len(widths))), C.c_void_p(offs.data_ptr()),
+                                                C.c_void_p(ws.data_ptr()), ws_bytes, None)
+
+    assert call([], [], []) == T.OK
+    torch.cuda.synchronize()
+    assert offs.tolist() == [0] * (P + 1)
+    offs.fill_(7)
+    assert call([0, 0], [None, None], [None, None]) == T.OK                       # empty blocks: their pointers are not looked at
+    torch.cuda.synchronize()
+    assert offs.tolist() == [0] * (P + 1)
+    k = keys.data_ptr()
+    assert call([5000], [None], [k]) == T.ERR_INVALID_ARGUMENT
+    assert call([5000], [k], [None]) == T.ERR_INVALID_ARGUMENT
+    assert call([-1], [k], [k]) == T.ERR_INVALID_ARGUMENT
+    assert call([5000], [k], [k], widths=(3,)) == T.ERR_UNSUPPORTED
+    assert call([5000], [k], [k], parts=65) == T.ERR_UNSUPPORTED
+    assert call([5000], [k], [k], parts=0) == T.ERR_INVALID_ARGUMENT
+    assert call([5000], [k], [k], key_type=T.DOUBLE) == T.ERR_UNSUPPORTED
+    assert call([5000], [k], [k], ws_bytes=8) == T.ERR_CAPACITY
+    assert lib.qsx_partition_blocks_workspace_bytes(5000, 1, P) <= ws.numel()
+    assert call([2000, 0, 3000], [k, None, k + 4 * 2000], [k, None, k + 4 * 2000]) == T.OK   # the same rows as two blocks around an empty one
+    torch.cuda.synchronize()
+    (want,), want_offs = capi.partition_scatter(keys, P, [keys])
+    assert torch.equal(out, want) and torch.equal(offs, want_offs)
+
+
 def test_coded_block_forms_argument_errors_and_plain_equivalence(capi, dev):
     """qsx_*_blocks_coded: a coding with a width other than 0 / 1 / 2 / 4, or a dictionary for a block that holds values, is an
     invalid argument; a NULL coding and a coding of all zeros ARE the plain forms; empty runs do nothing."""

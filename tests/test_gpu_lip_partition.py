@@ -85,6 +85,30 @@ def test_partition_scatter_few_partitions_both_kernels(capi, oracle, dev, P, num
             assert np.array_equal(got.cpu().numpy(), oracle.partition_scatter(keys, P, col))
 
 
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("P,num_wide", [(1, 0), (2, 0), (3, 7), (8, 0), (8, 7), (41, 0), (64, 1)])
+def test_partition_scatter_over_a_run_of_blocks(capi, oracle, dev, dtype, P, num_wide):
+    """qsx_partition_scatter_blocks: the scatter reads every block's stripes where they lie and leaves what qsx_partition_scatter
+    leaves for the rows laid end to end — equal to the oracle's stable partition of the concatenation.  Runs of equal blocks with
+    a shorter last one (a stored relation), ragged runs with empty blocks, a lone block, blocks shorter than a tile and blocks
+    longer than a workgroup's chunk (so that one block is many chunks and a chunk never straddles two blocks); all three
+    scatter kernels (side-by-side staging for <= 8 partitions and narrow rows, the general kernel with and without ranks)."""
+    shapes = [[349_525] * 6 + [12_345], [5, 0, 2047, 2048, 2049, 0, 70_001, 1], [1], [3_000_001, 17, 1_200_000], [0, 0], []]
+    for rows in shapes:
+        rng = np.random.default_rng(sum(rows) + P + num_wide)
+        keys = [rng.integers(-1000, 1 << 30, size=r).astype(dtype) for r in rows]
+        cols = [[k, rng.integers(0, 65535, size=k.size).astype(np.uint16), rng.integers(0, 255, size=k.size).astype(np.uint8)] +
+                [rng.integers(0, 2**62, size=k.size).astype(np.int64) for _ in range(num_wide)] for k in keys]
+        if not rows:
+            continue   # (the Python mirror asks for one block at least; the C entry point with no blocks: test_gpu_edge_cases)
+        outs, offs = capi.partition_scatter_blocks([to_dev(k, dev) for k in keys], P, [[to_dev(c, dev) for c in b] for b in cols])
+        all_keys = np.concatenate(keys)
+        assert np.array_equal(offs.cpu().numpy(), oracle.partition_offsets(all_keys, P))
+        for c, got in enumerate(outs):
+            col = np.concatenate([b[c] for b in cols])
+            assert np.array_equal(got.cpu().numpy(), oracle.partition_scatter(all_keys, P, col) if all_keys.size else col)
+
+
 @pytest.mark.parametrize("kind,anti,card", [(T.LIP_BITVECTOR_EXACT, False, 1_000_000), (T.LIP_BITVECTOR_EXACT, True, 999_937),
                                             (T.LIP_SINGLE_IDENTITY_HASH, False, 1_048_573), (T.LIP_BITVECTOR_EXACT, False, 3_000_000)])
 def test_lip_probe_at_scale_lds_resident_filter(capi, oracle, dev, kind, anti, card):
