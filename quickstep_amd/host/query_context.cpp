@@ -820,7 +820,7 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
     }
     if (in_run && any_coded) {
       // compressed blocks: one run through the state over code stripes (created by the first such block, which fixes the code
-      // widths; a block that compressed differently goes block by block)
+      // widths; blocks that compressed differently go with the run of plain stripes)
       bool use_coded = false;
       {
         std::lock_guard<std::mutex> lock(coded_mutex_);
@@ -836,7 +836,12 @@ void AggregationOperationState::aggregateBlocks(const std::vector<BlockReference
         }
       }
       if (!use_coded) {
-        aggregateBlock(block, filter);
+        // a block that compressed an operand differently than the block the coded state was created for (another code width, or
+        // not at all): its values — stripe() decodes them once — join the run of plain stripes instead of a call of their own
+        rows.push_back(block.numTuples());
+        for (std::size_t c = 0; c < column_attr_.size(); ++c) cols.push_back(block.stripe(column_attr_[c]));
+        filters.push_back(filter);
+        any_filter = any_filter || filter != nullptr;
         continue;
       }
       coded_rows.push_back(block.numTuples());

@@ -325,6 +325,77 @@ void testQ1OverCompressedBlocks() {
   unsetenv("QSX_AGG_FACTORED_MIN_ROWS");
 }
 
+// ---- a run whose blocks compressed an operand differently ------------------------------------------------------------------------
+// The reference compresses every block on its own (storage/CompressedBlockBuilder.cpp:300-368): one attribute may be 1-byte
+// dictionary codes in most blocks, 2-byte codes in a block with more distinct values and plain in a block where compression does
+// not pay.  The state over code stripes is created for the first block's widths; the blocks that agree with it make one run on
+// their codes, the others join the work order's run of plain stripes (decoded once) — two launches per work order, not one per
+// odd block — and both states are merged at finalization.
+void testAggregationOverBlocksThatCompressedDifferently() {
+  const std::int64_t blocks = 6;
+  std::vector<std::int32_t> key;
+  std::vector<double> value;
+  std::uint64_t x = 0x2545F4914F6CDD1Dull;
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  std::vector<std::int64_t> want_count(5, 0);
+  std::vector<double> want_sum(5, 0.0);
+  for (std::int64_t i = 0; i < blocks * kBlockRows; ++i) {
+    const std::int64_t b = i / kBlockRows;
+    key.push_back(static_cast<std::int32_t>(rnd() % 5));
+    value.push_back(static_cast<double>(b == 2 ? rnd() % 1000 : (b == 5 ? rnd() % 5000000 : rnd() % 50)));
+    ++want_count[key.back()];
+    want_sum[key.back()] += value.back();
+  }
+  for (const std::size_t per_work_order : {std::size_t(1), std::size_t(4), std::size_t(6)}) {
+    CatalogRelation rel(1, "r"), result(2, "result");
+    StorageManager storage;
+    rel.addAttribute("k", Type::Int());
+    rel.addAttribute("v", Type::Double());
+    const std::vector<bool> all(2, true);
+    for (std::int64_t at = 0; at < blocks * kBlockRows; at += kBlockRows) storage.loadBlock(&rel, {key.data() + at, value.data() + at}, kBlockRows, 0, &all);
+    const auto ids = rel.getBlocksSnapshot();
+    EXPECT_TRUE(storage.getBlock(ids[0])->compressedAttribute(1) != nullptr && storage.getBlock(ids[0])->compressedAttribute(1)->code_width == 1);
+    EXPECT_TRUE(storage.getBlock(ids[2])->compressedAttribute(1) != nullptr && storage.getBlock(ids[2])->compressedAttribute(1)->code_width == 2);
+    EXPECT_TRUE(storage.getBlock(ids[5])->compressedAttribute(1) == nullptr);
+    result.addAttribute("k", Type::Int());
+    result.addAttribute("sum_v", Type::Double());
+    result.addAttribute("count", Type::Long());
+    QueryContext ctx;
+    const auto dest = ctx.addInsertDestination(&result, &storage);
+    AggregationStateSpec spec;
+    spec.input_relation = &rel;
+    spec.group_by = {0};
+    spec.aggregates = {AggregateSpec(AggregationID::kSum, 1), AggregateSpec(AggregationID::kCount, kInvalidAttributeID)};
+    spec.strategy = QSX_AGG_COMPACT_KEY;
+    spec.estimated_num_groups = 5;
+    const auto state = ctx.addAggregationState(spec);
+    AggregationOperator aggregate(0, rel, true, state);
+    FinalizeAggregationOperator finalize(0, state, 1, false, 1, result, dest);
+    aggregate.setBlocksPerWorkOrder(per_work_order);
+    fetchAndExecuteWorkOrders(&aggregate, &ctx, &storage);
+    fetchAndExecuteWorkOrders(&finalize, &ctx, &storage);
+    EXPECT_TRUE(ctx.getAggregationState(state, 0)->numBlocksAggregatedOnCodes() == 4);   // blocks 0, 1, 3, 4: the first block's coding
+    std::vector<std::int64_t> got_count(5, -1);
+    std::vector<double> got_sum(5, -1.0);
+    for (block_id b : ctx.getInsertDestination(dest)->getTouchedBlocks()) {
+      BlockReference blk = storage.getBlock(b);
+      const std::size_t n = static_cast<std::size_t>(blk->numTuples());
+      std::vector<std::int32_t> k(n);
+      std::vector<double> sum(n);
+      std::vector<std::int64_t> cnt(n);
+      blk->copyAttributeToHost(0, k.data());
+      blk->copyAttributeToHost(1, sum.data());
+      blk->copyAttributeToHost(2, cnt.data());
+      for (std::size_t i = 0; i < n; ++i) {
+        got_sum[k[i]] = sum[i];
+        got_count[k[i]] = cnt[i];
+      }
+    }
+    EXPECT_TRUE(got_count == want_count);
+    EXPECT_TRUE(got_sum == want_sum);     // integer-valued doubles below 2^53: exact in any order
+  }
+}
+
 // ---- joins directly on compressed key stripes ------------------------------------------------------------------------------------
 // (csrc/block_runs.hpp "Coded key stripes", include/qsx.h qsx_key_coding_t.)  BuildHash and HashJoin work orders over runs of
 // CompressedColumnStore blocks hand the join attribute to the kernels as it lies — per block: 2- or 4-byte truncated values,
@@ -510,6 +581,7 @@ int main() {
     std::fprintf(stderr, "compressed_block_operator_test needs an MI355X: %s\n", qsx_status_string(QSX_ERR_NO_DEVICE));
     return 2;
   }
+  testAggregationOverBlocksThatCompressedDifferently();
   const Lineitem li;
   // expected, straight from the host columns
   std::vector<std::int64_t> want_count(8, 0);
