@@ -87,10 +87,26 @@ __global__ __launch_bounds__(kLBlock) void lip_build_kernel(LipView f, const Key
     unsigned long long have[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) have[r] = __hip_atomic_load(&f.words[bit[r] >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Neighbouring lanes that set bits of the SAME word hand their bits up the wave and the last lane of the run sets them with
+    // one atomic: a build side in key order (o_orderkey of the qualifying orders, c_custkey under a filter) puts 6 - 13 keys
+    // into a 64-bit word, and the device retires 23.7 G atomics/s whatever they carry (5.5 M keys: 0.25 ms one by one).  Bits
+    // handed to a lane whose word merely repeats further down the wave are set twice, which an OR does not mind.
+    const bool merge = f.cardinality <= (1ll << 37);   // (word numbers are compared as 32-bit values)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const unsigned long long mask = 1ull << (bit[r] & 63);
-      if (set_it[r] && (have[r] & mask) == 0) atomicOr(&f.words[bit[r] >> 6], mask);
+      unsigned long long mask = set_it[r] ? 1ull << (bit[r] & 63) : 0ull;
+      if (merge) {
+        const unsigned int word = set_it[r] ? static_cast<unsigned int>(bit[r] >> 6) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+          const unsigned int word_below = __shfl_up(word, off, kWave);
+          const unsigned long long mask_below = __shfl_up(mask, off, kWave);
+          if (lane >= off && word_below == word) mask |= mask_below;
+        }
+        const unsigned int word_above = __shfl_down(word, 1, kWave);
+        if (lane != kWave - 1 && word_above == word) mask = 0;   // the lane above carries these bits on
+      }
+      if (mask != 0 && (have[r] & mask) != mask) atomicOr(&f.words[bit[r] >> 6], mask);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) key[r] = next_key[r];

@@ -54,6 +54,38 @@ def test_golden_partition_membership(capi, dev, golden):
 
 
 @pytest.mark.parametrize("dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("kind", [T.LIP_BITVECTOR_EXACT, T.LIP_SINGLE_IDENTITY_HASH])
+def test_lip_build_over_keys_in_order_merges_its_atomics_and_matches_oracle(capi, oracle, dev, dtype, kind):
+    """A build side in key order (what dbgen writes): neighbouring lanes that set bits of one filter word hand them up the wave and
+    one lane sets them (csrc/lip.hip lip_build_kernel).  Same filter words as the oracle for keys in order at every density —
+    every key of the range (64 lanes, one word), one in ten, duplicates next to each other, runs that cross wave and group
+    borders, holes punched by a filter bitmap, both ends of the declared range, and a word that repeats further down the wave
+    (ascending runs laid side by side)."""
+    rng = np.random.default_rng(11)
+    card, mn = (300_000, 100) if kind == T.LIP_BITVECTOR_EXACT else (65_521, 0)
+    cases = {
+        "every key": np.arange(mn, mn + 250_000),
+        "one in ten": np.sort(rng.choice(np.arange(mn, mn + 290_000), size=29_000, replace=False)),
+        "duplicates": np.repeat(np.arange(mn + 5, mn + 40_005), 3),
+        "both ends of the declared range": np.concatenate([np.arange(mn, mn + 700), np.arange(mn + card - 700, mn + card)]),
+        "runs side by side": np.concatenate([np.arange(mn + o, mn + 200_000, 4) for o in (0, 1, 2, 3)]),
+        "seventy keys": np.arange(mn + 130, mn + 200),
+    }
+    for name, k in cases.items():
+        keys = k.astype(dtype)
+        for filt in (None, oracle.bitmap_from_bools(rng.random(keys.size) < 0.6)):
+            f = capi.LipFilter(kind, card, mn)
+            o = oracle.LipFilter(kind, card, mn)
+            f.build(to_dev(keys, dev), filter_bitmap=None if filt is None else bitmap_dev(filt, dev))
+            o.build(keys, filter_bitmap=filt)
+            probe = np.arange(mn - 50, mn + card + 50).astype(dtype)
+            bm, cnt = f.probe(to_dev(probe, dev))
+            ref = o.probe(probe)
+            assert np.array_equal(bitmap_np(bm), ref), name
+            assert int(cnt.item()) == oracle.bitmap_count(ref, probe.size), name
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
 @pytest.mark.parametrize("P", [1, 2, 3, 8, 41, 64])
 @pytest.mark.parametrize("n", [0, 1, 1000, 777_777])
 def test_partition_scatter_is_stable_and_matches_oracle(capi, oracle, dev, dtype, P, n):

@@ -11,7 +11,7 @@ for c in c4 c5; do
   grep '^{' $m/operators_$c.json | tail -1 > profiles/r06_operators_$c.json
 done
 cp $m/pmc_summary.txt profiles/r06_pmc_summary.txt
-for f in agg_large_groups agg_large_groups_one_pass agg_large_groups_two_levels_always join_coded_probe hashed_cycle k9_probe k9_blocks_probe agg_filtered_groups agg_family_probe probe_hashed_sparse agg_coded_probe probe_small_tables agg_dir_probe agg_dense_probe bench_ops; do
+for f in agg_large_groups agg_large_groups_one_pass agg_large_groups_two_levels_always join_coded_probe hashed_cycle k9_probe k9_blocks_probe lip_build_probe agg_filtered_groups agg_family_probe probe_hashed_sparse agg_coded_probe probe_small_tables agg_dir_probe agg_dense_probe bench_ops; do
   cp $m/$f.jsonl profiles/r06_$f.jsonl
 done
 cp $m/two_level_kernel_stats.csv profiles/r06_two_level_kernel_stats.csv

@@ -49,7 +49,7 @@ for f in agg_large_groups agg_large_groups_one_pass agg_large_groups_two_levels_
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$out/trace_two_level" -o two_level -- python3 "$GRAFT_REPO_ROOT/tools/agg_large_groups.py" random-generic > /dev/null 2>&1)
 cp "$(find $out/trace_two_level -name '*kernel_stats.csv' | head -1)" $out/two_level_kernel_stats.csv; rm -rf $out/trace_two_level; head -9 $out/two_level_kernel_stats.csv | cut -c1-170
 timeout 600 python tools/join_coded_probe.py > $out/join_coded_probe.jsonl 2>/dev/null; cat $out/join_coded_probe.jsonl
-for t in hashed_cycle k9_probe k9_blocks_probe agg_family_probe probe_hashed_sparse agg_coded_probe probe_small_tables agg_dir_probe agg_dense_probe; do timeout 300 python tools/$t.py > $out/$t.jsonl 2>/dev/null; done
+for t in hashed_cycle k9_probe k9_blocks_probe lip_build_probe agg_family_probe probe_hashed_sparse agg_coded_probe probe_small_tables agg_dir_probe agg_dense_probe; do timeout 300 python tools/$t.py > $out/$t.jsonl 2>/dev/null; done
 timeout 300 python tools/agg_filtered_groups.py > $out/agg_filtered_groups.jsonl 2>/dev/null; QSX_AGG_FILTER_COMPACT=0 timeout 300 python tools/agg_filtered_groups.py >> $out/agg_filtered_groups.jsonl 2>/dev/null
 timeout 600 python tools/bench_ops.py > $out/bench_ops.jsonl 2>/dev/null; wc -l $out/*.jsonl | tail -20
 grep "1,000,000\|10,000,000" $out/bench_ops.jsonl | cut -c1-260
