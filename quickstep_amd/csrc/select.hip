@@ -1338,24 +1338,77 @@ __global__ __launch_bounds__(kBlock) void decode_codes_kernel(const C *__restric
   }
 }
 
-template <typename C>
-static int launch_decode(const void *codes, int64_t n, const void *dictionary, int value_width, void *out, hipStream_t s) {
-  const int grid = grid_for(n, kBlock * 4);
-  switch (value_width) {
-    case 4:
-      hipLaunchKernelGGL((decode_codes_kernel<C, uint32_t>), dim3(grid), dim3(kBlock), 0, s, static_cast<const C *>(codes), n,
-                         static_cast<const uint32_t *>(dictionary), static_cast<uint32_t *>(out));
-      break;
-    case 8:
-      hipLaunchKernelGGL((decode_codes_kernel<C, uint64_t>), dim3(grid), dim3(kBlock), 0, s, static_cast<const C *>(codes), n,
-                         static_cast<const uint64_t *>(dictionary), static_cast<uint64_t *>(out));
-      break;
-    default: return QSX_ERR_UNSUPPORTED;
+// The same with 16 bytes of values per lane and store (K = 2 DOUBLE / LONG or 4 INT / FLOAT values): the K codes come with one
+// read of K * sizeof(C) bytes.  A decode is nine tenths writing; 8-byte stores of a lane reach 3.5 TB/s here, 16-byte stores
+// what a copy writes at.  Needs the code stripe aligned to its K-code groups and the value stripe to 16 bytes; the rows behind
+// the last whole group (fewer than K) are the scalar kernel's.
+template <typename C, typename V>
+__global__ __launch_bounds__(kBlock) void decode_codes_packed_kernel(const C *__restrict__ codes, int64_t groups,
+                                                                    const V *__restrict__ dictionary, V *__restrict__ out) {
+  constexpr int K = 16 / static_cast<int>(sizeof(V));
+  constexpr int kCodeBytes = K * static_cast<int>(sizeof(C));   // 2 .. 16
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int U = 4;
+  for (int64_t g0 = static_cast<int64_t>(blockIdx.x) * (kBlock * U) + threadIdx.x; g0 < groups;
+       g0 += static_cast<int64_t>(gridDim.x) * (kBlock * U)) {
+    C c[U][K];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t g = g0 + u * kBlock < groups ? g0 + u * kBlock : groups - 1;
+      const unsigned char *at = reinterpret_cast<const unsigned char *>(codes) + g * kCodeBytes;
+      if constexpr (kCodeBytes == 16) {
+        const uint4 bits = stream_load16(at);
+        __builtin_memcpy(&c[u][0], &bits, 16);
+      } else {
+        typedef typename BitsOfSize<kCodeBytes>::type Bits;
+        const Bits bits = load_global_nt(reinterpret_cast<const Bits *>(at));
+        __builtin_memcpy(&c[u][0], &bits, kCodeBytes);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t g = g0 + u * kBlock;
+      if (g >= groups) continue;
+      V v[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) v[k] = dictionary != nullptr ? dictionary[c[u][k]] : static_cast<V>(c[u][k]);
+      u32x4 bits;
+      __builtin_memcpy(&bits, &v[0], 16);
+      __builtin_nontemporal_store(bits, (__attribute__((address_space(1))) u32x4 *)reinterpret_cast<uintptr_t>(out + g * K));
+    }
   }
-  QSX_CHECK_LAUNCH();
-  return QSX_OK;
 }
 
+template <typename C, typename V>
+static void launch_decode_t(const C *codes, int64_t n, const V *dictionary, V *out, hipStream_t s) {
+  constexpr int K = 16 / static_cast<int>(sizeof(V));
+  static const bool packed_off = getenv("QSX_DECODE_PACKED") != nullptr && atoi(getenv("QSX_DECODE_PACKED")) == 0;
+  int64_t done = 0;
+  if (!packed_off && n >= K && (reinterpret_cast<uintptr_t>(codes) % (K * sizeof(C))) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int64_t groups = n / K;
+    hipLaunchKernelGGL((decode_codes_packed_kernel<C, V>), dim3(grid_for(groups, kBlock * 4)), dim3(kBlock), 0, s, codes, groups, dictionary, out);
+    done = groups * K;
+  }
+  if (done < n) {
+    hipLaunchKernelGGL((decode_codes_kernel<C, V>), dim3(grid_for(n - done, kBlock * 4)), dim3(kBlock), 0, s, codes + done, n - done, dictionary,
+                       out + done);
+  }
+}
+
+template <typename C>
+static int launch_decode(const void *codes, int64_t n, const void *dictionary, int value_width, void *out, hipStream_t s) {
+  switch (value_width) {
+    case 4:
+      launch_decode_t<C, uint32_t>(static_cast<const C *>(codes), n, static_cast<const uint32_t *>(dictionary), static_cast<uint32_t *>(out), s);
+      QSX_CHECK_LAUNCH();
+      return QSX_OK;
+    case 8:
+      launch_decode_t<C, uint64_t>(static_cast<const C *>(codes), n, static_cast<const uint64_t *>(dictionary), static_cast<uint64_t *>(out), s);
+      QSX_CHECK_LAUNCH();
+      return QSX_OK;
+    default: return QSX_ERR_UNSUPPORTED;
+  }
+}
 // tuple-id list -> TupleIdSequence (bit = tid - base): one atomicOr per tid, skipped when the bit is already set
 __global__ __launch_bounds__(kBlock) void tids_to_bitmap_kernel(const int32_t *__restrict__ tids, int64_t n, int32_t base_tid,
                                                                int64_t num_bits, unsigned long long *__restrict__ out) {

@@ -89,6 +89,33 @@ def test_compressed_columns_select_and_decode(capi, oracle, dev):
                     assert torch.equal(got, want) and int(cnt.item()) == int(want_cnt.item()), (name, op, lit)
 
 
+@pytest.mark.parametrize("code_dtype", [np.uint8, np.uint16, np.uint32])
+@pytest.mark.parametrize("value_dtype", [np.int32, np.int64, np.float32, np.float64])
+def test_decode_codes_every_width_length_and_alignment(capi, dev, code_dtype, value_dtype):
+    """qsx_decode_codes: dictionary lookup and zero-extension for 1 / 2 / 4-byte codes into 4 / 8-byte values — the kernel that
+    writes 16 bytes per lane (two or four values from one read of their codes) for the whole groups of an aligned stripe, the
+    one-value kernel for the rows behind the last group and for stripes that start at odd addresses.  Lengths on both sides of a
+    group, a workgroup's share and the grid; equal to numpy's `dictionary[codes]` / `codes.astype`."""
+    rng = np.random.default_rng(5)
+    entries = min(int(np.iinfo(code_dtype).max) + 1, 40_000)
+    if np.issubdtype(value_dtype, np.integer):
+        dictionary = np.sort(rng.choice(np.arange(-10**6, 10**6), size=entries, replace=False)).astype(value_dtype)
+    else:
+        dictionary = np.sort(rng.standard_normal(entries)).astype(value_dtype)
+    d_dict = to_dev(dictionary, dev)
+    for n in (1, 2, 3, 4, 5, 1023, 4096, 4099, 1_048_577, 3_000_001):
+        for skew in (0, 1, 3):                         # rows by which the stripes start behind an aligned address
+            pool = rng.integers(0, entries, size=n + skew).astype(code_dtype)
+            d_pool = to_dev(pool.view({1: np.uint8, 2: np.int16, 4: np.int32}[pool.itemsize]), dev)   # (the bits are what travels)
+            out_pool = torch.zeros(n + skew + 4, dtype=d_dict.dtype, device=dev)
+            got = capi.decode_codes(d_pool[skew:], d_dict, out_pool.dtype, out=out_pool[skew:skew + n])
+            assert np.array_equal(got.cpu().numpy(), dictionary[pool[skew:]]), (n, skew)
+            assert not out_pool[:skew].any() and not out_pool[skew + n:].any(), (n, skew)   # nothing written outside the stripe
+            if np.issubdtype(value_dtype, np.integer):   # truncated values: zero-extension
+                got = capi.decode_codes(d_pool[skew:], None, out_pool.dtype)
+                assert np.array_equal(got.cpu().numpy(), pool[skew:].astype(value_dtype)), (n, skew)
+
+
 def test_q1_style_aggregation_over_decoded_dictionary_columns(capi, oracle, dev):
     """lineitem in the reference's TPC-H DDL is a compressed column store (benchmarks/tpch/create.sql:69-121): l_discount,
     l_tax, l_quantity are dictionary-coded.  Predicate on the l_quantity codes, decode the arguments, aggregate."""
