@@ -37,7 +37,8 @@ extern "C" {
 /* 17: the block forms over compressed key stripes (qsx_key_coding_t, qsx_join_*_blocks_coded, qsx_lip_*_blocks_coded,
  *     qsx_join_key_pack_blocks_coded), qsx_join_probe_exists_lip, qsx_copy_segments; nothing older changed its signature */
 /* 18: qsx_partition_scatter_blocks (K9 reading a run of blocks where they lie); nothing older changed its signature */
-#define QSX_ABI_VERSION 18
+/* 19: qsx_lip_build_from_join_table; nothing older changed its signature */
+#define QSX_ABI_VERSION 19
 
 typedef void *qsx_stream_t;
 
@@ -931,6 +932,15 @@ int qsx_lip_build_blocks_coded(qsx_lip_filter_t *filter, int key_type, int64_t n
 int qsx_lip_probe_blocks_coded(const qsx_lip_filter_t *filter, int key_type, int64_t num_blocks, const int64_t *block_rows,
                                const void *const *block_keys, const qsx_key_coding_t *coding, const uint64_t *const *block_in_bitmaps,
                                uint64_t *const *block_out_bitmaps, int64_t *out_count_dev, qsx_stream_t stream);
+
+/* An EXACT filter over the key a directly addressed join table was built on, taken from the table: the filter of a BuildHash work
+ * order is built from the same keys as its table (relational_operators/BuildHashOperator.cpp:187-203), and such a table is an
+ * existence map of its key range already — the bits are read off its head words (4 bytes streamed per key value of the range)
+ * instead of one atomic per key.  Sets the bit of EVERY key the table holds by the time the stream gets here (a bit set twice does
+ * no harm).  num_new_keys: how many keys the caller would hand qsx_lip_build instead (< 0: do it whatever it costs).
+ * QSX_ERR_UNSUPPORTED — nothing was done, call qsx_lip_build — for a hashed table, a table over a strided key domain, a filter
+ * that is not LIP_BITVECTOR_EXACT, or when reading the range costs more than num_new_keys atomics would. */
+int qsx_lip_build_from_join_table(qsx_lip_filter_t *filter, qsx_join_table_t *table, int64_t num_new_keys, qsx_stream_t stream);
 
 /* Raw bit array (for all-reduce(OR) across GPUs): 64-bit words, LSB-first. */
 int qsx_lip_filter_words(qsx_lip_filter_t *f, uint64_t **out_words_dev, int64_t *out_num_words);

@@ -141,6 +141,7 @@ _SIGNATURES = {
     "qsx_lip_filter_create": (_int, [_int, _i64, _i64, _int, _pp]),
     "qsx_lip_filter_destroy": (_int, [_vp]),
     "qsx_lip_build": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
+    "qsx_lip_build_from_join_table": (_int, [_vp, _vp, _i64, _vp]),
     "qsx_lip_probe": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     "qsx_lip_build_blocks": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _pp, _vp]),
     "qsx_lip_probe_blocks": (_int, [_vp, _int, _i64, C.POINTER(_i64), _pp, _pp, _pp, _vp, _vp]),
@@ -1087,6 +1088,16 @@ class LipFilter:
     def build(self, keys, filter_bitmap=None, stream=None):
         _check(_lib.qsx_lip_build(self._h, qsx_type_of(keys), _ptr(keys), keys.numel(), _ptr(filter_bitmap),
                                   _stream(stream)), "qsx_lip_build")
+
+    def build_from_table(self, table, num_new_keys=-1, stream=None):
+        """qsx_lip_build_from_join_table: the bits of every key a directly addressed JoinTable holds, read off the table.  False —
+        nothing done, call build() — when the table / filter are not of those kinds or reading the key range would cost more
+        than num_new_keys atomics (< 0: whatever it costs)."""
+        rc = _lib.qsx_lip_build_from_join_table(self._h, table._h, num_new_keys, _stream(stream))
+        if rc == T.ERR_UNSUPPORTED:
+            return False
+        _check(rc, "qsx_lip_build_from_join_table")
+        return True
 
     def probe(self, keys, in_bitmap=None, stream=None):
         n = keys.numel()

@@ -1979,6 +1979,45 @@ static int upload_probe_run(int64_t num_blocks, const int64_t *block_rows, const
   return staged_upload(stream, table.data(), bytes);
 }
 
+namespace qsx {
+// ---- an exact LIP filter from a directly addressed table (qsx_lip_build_from_join_table) ------------------------------------------
+// The filter of a BuildHash work order is built over the very keys the table was (BuildHashOperator.cpp:187-203), and a
+// directly addressed table already IS an existence map of its key range: head[k - min] != 0.  A wave reads 64 consecutive
+// head words (coalesced), ballots "taken" into the filter word they stand for and ORs it in — 4 bytes streamed per key VALUE
+// of the range instead of one atomic per key: Q3's 5.56 M qualifying orders in a range of 56 M: 0.05 ms against 0.25.
+constexpr int kLipFromTableWords = kWave;   // filter words per wave and turn: lane r ends up holding word r's bits
+__global__ __launch_bounds__(256) void lip_from_dense_kernel(DenseTableView t, LipView f, long long delta, long long first_word,
+                                                             long long end_word) {
+  const int lane = lane_id();
+  const long long wave = static_cast<long long>(blockIdx.x) * (256 / kWave) + (threadIdx.x >> 6);
+  const long long num_waves = static_cast<long long>(gridDim.x) * (256 / kWave);
+  for (long long w0 = first_word + wave * kLipFromTableWords; w0 < end_word; w0 += num_waves * kLipFromTableWords) {
+    // 64 words a turn, eight head reads in flight at a time; the ballot of word r stays in lane r, and ONE atomic instruction
+    // of the wave sets all 64 words (a lane that looked its word up first and set it then kept every wave waiting on two
+    // dependent round trips per word: 0.44 ms for 56 M key values; this way 0.06)
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int r0 = 0; r0 < kLipFromTableWords; r0 += 8) {
+      uint32_t head[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long word = w0 + r0 + u;
+        const long long bit = (word << 6) + lane;                 // bit of the filter = key - f.min_value
+        const long long idx = bit - delta;                        // head word of that key: key - t.min_key
+        const bool inside = word < end_word && bit < f.cardinality && idx >= 0 && idx < static_cast<long long>(t.range);
+        head[u] = inside ? load_global_nt(&t.head[idx]) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned long long mask = __ballot(head[u] != 0u);  // lane i <-> bit i of the word: the filter is LSB-first
+        if (lane == r0 + u) mine = mask;
+      }
+    }
+    if (mine != 0ull) atomicOr(&f.words[w0 + lane], mine);        // (a word behind end_word has no bits: nothing inside it was read)
+  }
+}
+}  // namespace qsx
+
 extern "C" {
 
 int qsx_join_probe(qsx_join_table_t *t, const void *keys_dev, int64_t n, int32_t probe_base_tid,
@@ -2377,6 +2416,29 @@ int qsx_join_probe_exists_blocks_coded(qsx_join_table_t *t, int64_t num_blocks, 
                                        const qsx_key_coding_t *coding, const uint64_t *const *block_filters, int anti,
                                        uint64_t *const *block_out_bitmaps, int64_t *out_count_dev, qsx_stream_t stream) {
   return join_probe_exists_blocks_impl(t, num_blocks, block_rows, block_keys, block_filters, anti, block_out_bitmaps, out_count_dev, coding, stream);
+}
+
+int qsx_lip_build_from_join_table(qsx_lip_filter_t *filter, qsx_join_table_t *t, int64_t num_new_keys, qsx_stream_t stream) {
+  QSX_REQUIRE_DEVICE();
+  if (filter == nullptr || t == nullptr) return QSX_ERR_INVALID_ARGUMENT;
+  const LipView f = lip_filter_view(filter);
+  std::shared_lock<std::shared_mutex> lock(t->mutex);
+  if (!t->dense || t->stride_shift != 0 || !f.exact || f.cardinality <= 0 || t->range == 0) return QSX_ERR_UNSUPPORTED;
+  const DenseTableView view = t->dense_view();
+  // the filter words that stand for key values of the table's range
+  const long long delta = static_cast<long long>(t->min_key) - f.min_value;            // bit = head index + delta
+  const long long first_bit = delta > 0 ? delta : 0;
+  const long long end_bit = delta + static_cast<long long>(view.range) < f.cardinality ? delta + static_cast<long long>(view.range) : f.cardinality;
+  if (end_bit <= first_bit) return QSX_OK;                                             // no key of the table can be in the filter
+  const long long first_word = first_bit >> 6, end_word = (end_bit + 63) >> 6;
+  // worth it?  (end_bit - first_bit) head words of 4 bytes at ~4 TB/s against num_new_keys atomics at 23.7 G/s
+  if (num_new_keys >= 0 && static_cast<double>(end_bit - first_bit) * 4.0 / 4.0e12 > static_cast<double>(num_new_keys) / 23.7e9) return QSX_ERR_UNSUPPORTED;
+  const long long turns = (end_word - first_word + kLipFromTableWords - 1) / kLipFromTableWords;
+  const long long want = (turns + (256 / kWave) - 1) / (256 / kWave);
+  const int grid = static_cast<int>(want < 16 * kCUs ? (want > 0 ? want : 1) : 16 * kCUs);
+  hipLaunchKernelGGL(lip_from_dense_kernel, dim3(grid), dim3(256), 0, as_stream(stream), view, f, delta, first_word, end_word);
+  QSX_CHECK_LAUNCH();
+  return QSX_OK;
 }
 
 }  // extern "C"

@@ -1157,15 +1157,30 @@ void LIPFilterBuilder::insertValueAccessor(const StorageBlock &block, const std:
     if (not_null != nullptr) CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
   }
 }
-bool LIPFilterBuilder::insertBlocks(const std::vector<BlockReference> &blocks) const {
+bool LIPFilterBuilder::coversBlocks(const std::vector<BlockReference> &blocks) const {
   for (const auto &e : entries_) {
     for (const BlockReference &b : blocks) {
       if (b->nullBitmap(e.second) != nullptr) return false;   // (a compressed attribute is read as it lies: RunJoinKeys)
     }
   }
+  return true;
+}
+bool LIPFilterBuilder::insertBlocks(const std::vector<BlockReference> &blocks, qsx_join_table_t *built_table, attribute_id table_key) const {
+  if (!coversBlocks(blocks)) return false;
   std::vector<std::int64_t> rows;
-  for (const BlockReference &b : blocks) rows.push_back(b->numTuples());
+  std::int64_t total_rows = 0;
+  for (const BlockReference &b : blocks) {
+    rows.push_back(b->numTuples());
+    total_rows += b->numTuples();
+  }
   for (const auto &e : entries_) {
+    if (built_table != nullptr && e.second == table_key) {
+      // the table holds these keys already: its head words are the filter's bits (QSX_ERR_UNSUPPORTED: not that kind of table
+      // or filter, or the run is too short for a pass over the key range to pay — the keys one by one then)
+      const int rc = qsx_lip_build_from_join_table(e.first, built_table, total_rows, CurrentStream());
+      if (rc == QSX_OK) continue;
+      if (rc != QSX_ERR_UNSUPPORTED) CheckStatus(rc, "qsx_lip_build_from_join_table");
+    }
     // (INT / LONG attributes — the key types of a LIP filter — that a block holds compressed are read as they lie)
     const RunJoinKeys keys(blocks, {e.second}, rows);
     CheckStatus(qsx_lip_build_blocks_coded(e.first, blocks.front()->getRelation().getAttributeType(e.second).id,

@@ -640,7 +640,13 @@ class LIPFilterBuilder {
   void insertValueAccessor(const StorageBlock &block, const std::uint64_t *filter) const;
   // A run of blocks, one launch per filter (qsx_lip_build_blocks); false when an inserted attribute is nullable or
   // compressed in one of the blocks (nothing inserted: the caller goes block by block).
-  bool insertBlocks(const std::vector<BlockReference> &blocks) const;
+  // built_table != nullptr: the join table the caller has just put these blocks' tuples into (same stream), keyed on
+  // attribute table_key — an exact filter over that attribute takes its bits from the table where that is cheaper than an
+  // atomic per key (qsx_lip_build_from_join_table).
+  bool insertBlocks(const std::vector<BlockReference> &blocks, qsx_join_table_t *built_table = nullptr,
+                    attribute_id table_key = kInvalidAttributeID) const;
+  // What insertBlocks would answer, without inserting anything.
+  bool coversBlocks(const std::vector<BlockReference> &blocks) const;
  private:
   std::vector<std::pair<qsx_lip_filter_t *, attribute_id>> entries_;
 };

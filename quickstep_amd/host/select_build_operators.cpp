@@ -437,11 +437,16 @@ bool BuildHashWorkOrder::executeRun() {
     rows.push_back(b.numTuples());
     bases.push_back(static_cast<std::int32_t>(b.firstRow()));   // the stored reference: relation-global row number
   }
-  if (lip_filter_builder_ != nullptr && !lip_filter_builder_->insertBlocks(blocks)) return false;   // BuildHashOperator.cpp:187-190
+  if (lip_filter_builder_ != nullptr && !lip_filter_builder_->coversBlocks(blocks)) return false;
   const RunJoinKeys run_keys(blocks, join_key_attributes_, rows);
   const std::vector<const void *> &keys = run_keys.ptr;
   CheckStatus(qsx_join_build_blocks_coded(hash_table_, static_cast<std::int64_t>(blocks.size()), rows.data(), keys.data(), run_keys.coding(),
                                           bases.data(), nullptr, CurrentStream()), "qsx_join_build_blocks");
+  // BuildHashOperator.cpp:187-190 builds the LIP filters in front of the table; behind it (same stream) a filter over the join
+  // key can read its bits off the table
+  if (lip_filter_builder_ != nullptr) {
+    lip_filter_builder_->insertBlocks(blocks, hash_table_, join_key_attributes_.size() == 1 ? join_key_attributes_.front() : kInvalidAttributeID);
+  }
   CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
   return true;
 }

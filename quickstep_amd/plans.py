@@ -212,11 +212,14 @@ class DistributedQ3:
         with ph("customer: select + gather + build + LIP"):
             c_sel, c_cnt = ops.select_cmp(inp["c_mktsegment"], T.EQ, SEG_BUILDING)
             (c_keys,), _ = ops.compact_gather([inp["c_custkey"]], c_sel, inp["c_custkey"].numel())
-            (all_c,), _ = self._all_gather_rows([c_keys], int(c_cnt.item()))
+            n_c_sel = int(c_cnt.item())
+            (all_c,), _ = self._all_gather_rows([c_keys], n_c_sel)
             self.t_c.build(all_c)
             if self.use_lip:
-                self.lip_c.build(inp["c_custkey"], filter_bitmap=c_sel)
-                self._or_filter(self.lip_c)
+                # (the table holds every rank's qualifying customers: read off it, the filter needs no OR across the ranks)
+                if not (hasattr(self.lip_c, "build_from_table") and self.lip_c.build_from_table(self.t_c, n_c_sel)):
+                    self.lip_c.build(inp["c_custkey"], filter_bitmap=c_sel)
+                    self._or_filter(self.lip_c)
         # orders
         with ph("orders: select + LIP probe + semi probe + gather + build + LIP"):
             o_sel, _ = ops.select_cmp(inp["o_orderdate"], T.LT, DATE_CUT)
@@ -239,7 +242,10 @@ class DistributedQ3:
             self.t_o.build(all_ok)
             self.qualifying_order_tids = all_ot
             if self.use_lip:
-                self.lip_o.build(all_ok)           # all ranks hold all qualifying keys already: no OR needed
+                # all ranks hold all qualifying keys already: no OR needed.  The table is an existence map of the orders' key range:
+                # the filter's bits are read off it (qsx_lip_build_from_join_table) where that beats one atomic per key
+                if not (hasattr(self.lip_o, "build_from_table") and self.lip_o.build_from_table(self.t_o, int(all_ok.numel()))):
+                    self.lip_o.build(all_ok)
         # lineitem
         with ph("lineitem: select l_shipdate"):
             l_sel, l_sel_count = ops.select_cmp(inp["l_shipdate"], T.GT, DATE_CUT)

@@ -8,7 +8,7 @@ import ctypes as C
 
 # qsx_type_t (numbering of types/TypeID.hpp:32-43 in the reference)
 ACC_SUM_F64, ACC_SUM_I64, ACC_MIN_I64, ACC_MAX_I64 = 0, 1, 2, 3      # qsx_agg_state_image_layout column kinds
-ABI_VERSION = 18                                                    # QSX_ABI_VERSION of include/qsx.h
+ABI_VERSION = 19                                                    # QSX_ABI_VERSION of include/qsx.h
 INT, LONG, FLOAT, DOUBLE, CHAR = 0, 1, 2, 3, 4
 DATE = 6   # the reference's 8-byte DateLit {int32 year; uint8 month, day; 2 bytes padding}, carried as int64 raw bytes
 # qsx_cmp_t (types/operations/comparisons/ComparisonID.hpp:36-42)

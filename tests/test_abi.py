@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(capi):
 
 def test_abi_version_and_struct_mirror(capi):
     from quickstep_amd import types as T
-    assert capi.lib.qsx_abi_version() == T.ABI_VERSION == 18
+    assert capi.lib.qsx_abi_version() == T.ABI_VERSION == 19
     header = open(os.path.join(ROOT, "include", "qsx.h")).read()
     assert f"#define QSX_ABI_VERSION {T.ABI_VERSION}" in header
     assert capi.lib.qsx_abi_sizeof_agg_config() == ctypes.sizeof(T.AggConfig)

@@ -54,6 +54,44 @@ def test_golden_partition_membership(capi, dev, golden):
 
 
 @pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_exact_lip_filter_read_off_a_directly_addressed_join_table(capi, oracle, dev, dtype):
+    """qsx_lip_build_from_join_table: the filter of a BuildHash work order is built from the keys its table was built from, and a
+    directly addressed table is an existence map of its key range — the filter read off the table's head words has the words of
+    the filter built key by key (and of the oracle's).  Filters whose range starts before / inside / at the table's (offsets that
+    are no multiple of 64), narrower and wider than it; duplicate keys (overflow chains), a build under a filter bitmap, two
+    builds one after the other; a hashed table, an identity-hash filter and a run too short to pay are declined (nothing set)."""
+    rng = np.random.default_rng(21)
+    lo, hi = 1000, 1000 + 700_000
+    keys = rng.integers(lo, hi, size=200_000).astype(dtype)                  # duplicates among them
+    keep = oracle.bitmap_from_bools(rng.random(keys.size) < 0.7)
+    more = rng.integers(lo, hi, size=50_000).astype(dtype)
+    table = capi.JoinTable(T.INT if dtype == np.int32 else T.LONG, keys.size + more.size, key_range=(lo, hi - 1))
+    table.build(to_dev(keys, dev), filter_bitmap=bitmap_dev(keep, dev))
+    table.build(to_dev(more, dev), base_tid=keys.size)
+    probe = np.arange(lo - 300, hi + 300).astype(dtype)
+    for mn, card in ((lo, hi - lo), (lo - 131, hi - lo + 500), (lo + 77, 300_000), (lo - 64, 64 * 5000), (lo + 640_000, 200_000),
+                     (hi + 5, 1000), (0, lo)):
+        f = capi.LipFilter(T.LIP_BITVECTOR_EXACT, card, mn)
+        assert f.build_from_table(table)
+        o = oracle.LipFilter(T.LIP_BITVECTOR_EXACT, card, mn)
+        inside = lambda k: k[(k >= mn) & (k < mn + card)]                     # (the reference's builder is handed keys of the range only)
+        o.build(inside(keys), filter_bitmap=oracle.bitmap_from_bools(oracle.bools_from_bitmap(keep, keys.size)[(keys >= mn) & (keys < mn + card)]))
+        o.build(inside(more))
+        bm, cnt = f.probe(to_dev(probe, dev))
+        ref = o.probe(probe)
+        assert np.array_equal(bitmap_np(bm), ref), (mn, card)
+        assert int(cnt.item()) == oracle.bitmap_count(ref, probe.size)
+    f = capi.LipFilter(T.LIP_BITVECTOR_EXACT, hi - lo, lo)
+    assert not f.build_from_table(table, num_new_keys=100)                    # 700 000 head words against 100 atomics: declined
+    assert not capi.LipFilter(T.LIP_SINGLE_IDENTITY_HASH, 65_521, 0).build_from_table(table)
+    hashed = capi.JoinTable(T.INT if dtype == np.int32 else T.LONG, keys.size)
+    hashed.build(to_dev(keys, dev))
+    assert not f.build_from_table(hashed)
+    bm, cnt = f.probe(to_dev(probe, dev))
+    assert int(cnt.item()) == 0                                               # the declined calls set nothing
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
 @pytest.mark.parametrize("kind", [T.LIP_BITVECTOR_EXACT, T.LIP_SINGLE_IDENTITY_HASH])
 def test_lip_build_over_keys_in_order_merges_its_atomics_and_matches_oracle(capi, oracle, dev, dtype, kind):
     """A build side in key order (what dbgen writes): neighbouring lanes that set bits of one filter word hand them up the wave and
