@@ -21,9 +21,11 @@ class OracleJoinTable:
         self.key_type, self.est = key_type, est
         self.key_range, self.key_stride = key_range, key_stride
         self.t = O.JoinTable(key_type, est)
+        self.live_keys = []          # what the builds inserted (ExactLipFilter.build_from_table reads them off the table)
 
     def clear(self):
         self.t = O.JoinTable(self.key_type, self.est)
+        self.live_keys = []
 
     def build(self, keys, base_tid=0, filter_bitmap=None):
         k = keys.numpy()
@@ -34,6 +36,7 @@ class OracleJoinTable:
                 assert live.min() >= self.key_range[0] and live.max() <= self.key_range[1]
                 assert ((live.astype(np.int64) - self.key_range[0]) % self.key_stride == 0).all()
         self.t.build(k, base_tid=base_tid, filter_bitmap=_bm_in(filter_bitmap))
+        self.live_keys.append(k if filter_bitmap is None else k[O.bools_from_bitmap(_bm_in(filter_bitmap), k.size)])
 
     def probe_count(self, keys, filter_bitmap=None):
         return torch.tensor([self.t.probe(keys.numpy(), filter_bitmap=_bm_in(filter_bitmap))[0].size], dtype=torch.int64)
@@ -64,6 +67,14 @@ class ExactLipFilter:
             k = k[O.bools_from_bitmap(_bm_in(filter_bitmap), k.size)]
         k = k[(k >= 0) & (k < self.card)]
         np.bitwise_or.at(self.bits, k >> 6, np.uint64(1) << (k & 63).astype(np.uint64))
+
+    def build_from_table(self, table, num_new_keys=-1):
+        """The mirror of qsx_lip_build_from_join_table: every key a directly addressed table holds; declined for a hashed one."""
+        if table.key_range is None or table.key_stride != 1:
+            return False
+        for k in table.live_keys:
+            self.build(torch.from_numpy(np.ascontiguousarray(k)))
+        return True
 
     def probe(self, keys, in_bitmap=None):
         k = keys.numpy().astype(np.int64) - self.min
