@@ -1219,7 +1219,8 @@ void *LIPFilterAdaptiveProber::filterValueAccessor(const StorageBlock &block, co
   return current;
 }
 bool LIPFilterAdaptiveProber::filterBlocks(const std::vector<BlockReference> &blocks, void **storage,
-                                           std::vector<const std::uint64_t *> *bitmaps, std::int64_t *num_hits) const {
+                                           std::vector<const std::uint64_t *> *bitmaps, std::int64_t *num_hits,
+                                           const std::uint64_t *const *in_bitmaps) const {
   *storage = nullptr;
   for (const auto &e : entries_) {
     for (const BlockReference &b : blocks) {
@@ -1248,7 +1249,7 @@ bool LIPFilterAdaptiveProber::filterBlocks(const std::vector<BlockReference> &bl
     const RunJoinKeys keys(blocks, {e.second}, rows);   // (a compressed INT / LONG attribute: its code stripes, as they lie)
     CheckStatus(qsx_lip_probe_blocks_coded(e.first, blocks.front()->getRelation().getAttributeType(e.second).id, static_cast<std::int64_t>(nb),
                                            rows.data(), keys.ptr.data(), keys.coding(),
-                                           first ? nullptr : reinterpret_cast<const std::uint64_t *const *>(cur.data()), nxt.data(),
+                                           first ? in_bitmaps : reinterpret_cast<const std::uint64_t *const *>(cur.data()), nxt.data(),
                                            static_cast<std::int64_t *>(count.ptr), CurrentStream()), "qsx_lip_probe_blocks");
     std::swap(cur, nxt);
     first = false;
@@ -1261,7 +1262,11 @@ bool LIPFilterAdaptiveProber::filterBlocks(const std::vector<BlockReference> &bl
       *num_hits = ReadCount(count.ptr);
     }
   }
-  if (first) {   // no filter attached: every tuple
+  if (first && in_bitmaps != nullptr) {   // no filter attached: what came in
+    for (std::size_t b = 0; b < nb; ++b) {
+      if (rows[b] > 0) CheckStatus(qsx_bitmap_combine(0, in_bitmaps[b], in_bitmaps[b], rows[b], cur[b], CurrentStream()), "qsx_bitmap_combine");
+    }
+  } else if (first) {   // no filter attached: every tuple
     for (std::size_t b = 0; b < nb; ++b) {
       CheckStatus(qsx_memset_device(nxt[b], 0xFF, static_cast<std::size_t>((rows[b] + 63) / 64) * 8, CurrentStream()), "qsx_memset_device");
       if (rows[b] > 0) {

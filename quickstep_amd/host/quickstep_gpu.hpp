@@ -662,8 +662,11 @@ class LIPFilterAdaptiveProber {
   // The same for a run of blocks, one launch per filter (qsx_lip_probe_blocks): bitmaps[b] receives block b's TupleIdSequence.
   // All bitmaps live in *storage (a device allocation owned by the caller: qsx_device_free).  Returns false — nothing
   // allocated — when a probed attribute is nullable or compressed in one of the blocks (the caller goes block by block).
+  // in_bitmaps: block b's TupleIdSequence so far (the predicate's matches: SelectOperator.cpp:161-195 filters what the
+  // predicate left) — only those tuples are looked up.
   bool filterBlocks(const std::vector<BlockReference> &blocks, void **storage, std::vector<const std::uint64_t *> *bitmaps,
-                    std::int64_t *num_hits = nullptr) const;   // num_hits: tuples of the run that pass (synchronises)
+                    std::int64_t *num_hits = nullptr,   // num_hits: tuples of the run that pass (synchronises)
+                    const std::uint64_t *const *in_bitmaps = nullptr) const;
  private:
   std::vector<std::pair<qsx_lip_filter_t *, attribute_id>> entries_;
 };

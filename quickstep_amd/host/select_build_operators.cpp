@@ -117,20 +117,22 @@ bool SelectWorkOrder::executeRun() {
   }
   if (!RunPredicateCovers(predicate, blocks)) return false;
   const std::size_t nb = blocks.size();
-  // SelectOperator.cpp:161-195: predicate matches, then the LIP filters on what is left — here the filters run first and
-  // the predicate only looks at their survivors (the same conjunction, as in the single-block form)
+  // SelectOperator.cpp:161-195: predicate matches, then the LIP filters on what is left (a filter looks a tuple up at a random
+  // place of its bit vector; a tuple the predicate dropped costs it nothing: Q3's lineitem Select loses 46 % of its lookups)
   struct OwnedStorage {
     void *ptr = nullptr;
     ~OwnedStorage() { qsx_device_free(ptr); }
   } lip_storage;
   std::vector<const std::uint64_t *> lip_bitmaps;
   std::int64_t lip_hits = 0;
+  RunMatches run_matches;
+  if (has_terms) RunPredicateMatches(predicate, blocks, rows, nullptr, &run_matches);
+  const bool lip_after_predicate = has_terms && lip_filter_adaptive_prober_ != nullptr;
   if (lip_filter_adaptive_prober_ != nullptr &&
-      !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps, has_terms ? nullptr : &lip_hits)) {
+      !lip_filter_adaptive_prober_->filterBlocks(blocks, &lip_storage.ptr, &lip_bitmaps, &lip_hits,
+                                                 has_terms ? reinterpret_cast<const std::uint64_t *const *>(run_matches.bitmaps.data()) : nullptr)) {
     return false;
   }
-  RunMatches run_matches;
-  if (has_terms) RunPredicateMatches(predicate, blocks, rows, lip_bitmaps.empty() ? nullptr : lip_bitmaps.data(), &run_matches);
   std::int64_t matches = lip_hits;
   const std::uint64_t *const *selected = lip_bitmaps.empty() ? nullptr : lip_bitmaps.data();   // only LIP filters: their bitmaps
   // every tuple: one all-ones TupleIdSequence per distinct block size of the run (a relation's blocks hold the same number of
@@ -189,7 +191,7 @@ bool SelectWorkOrder::executeRun() {
     selected = ones_of_block.data();
     matches = total_rows;
   }
-  if (has_terms) {
+  if (has_terms && !lip_after_predicate) {
     std::vector<std::int64_t> block_matches(nb);
     CheckStatus(qsx_copy_to_host(block_matches.data(), run_matches.counts->ptr, nb * 8, CurrentStream()), "qsx_copy_to_host");
     CheckStatus(qsx_stream_synchronize(CurrentStream()), "qsx_stream_synchronize");
