@@ -89,6 +89,11 @@ def test_exact_lip_filter_read_off_a_directly_addressed_join_table(capi, oracle,
     assert not f.build_from_table(hashed)
     bm, cnt = f.probe(to_dev(probe, dev))
     assert int(cnt.item()) == 0                                               # the declined calls set nothing
+    assert capi.lib.qsx_lip_build_from_join_table(None, table._h, -1, None) == T.ERR_INVALID_ARGUMENT
+    assert capi.lib.qsx_lip_build_from_join_table(f._h, None, -1, None) == T.ERR_INVALID_ARGUMENT
+    strided = capi.JoinTable(T.INT if dtype == np.int32 else T.LONG, 1000, key_range=(0, 7992), key_stride=8)   # one hash partition of a dense domain
+    strided.build(to_dev((np.arange(1000) * 8).astype(dtype), dev))
+    assert not f.build_from_table(strided)
 
 
 @pytest.mark.parametrize("dtype", [np.int32, np.int64])
