@@ -225,13 +225,13 @@ void SelectWorkOrder::executeBlock(block_id input_block_id) {
   const std::int64_t n = block->numTuples();
   std::int64_t matches = 0;
   Predicate all;
-  // SelectOperator.cpp:161-195: predicate matches, then the LIP filters on what is left; the filters run
-  // first here and the predicate only evaluates their survivors (same conjunction)
-  void *lip = nullptr;
-  if (lip_filter_adaptive_prober_ != nullptr) lip = lip_filter_adaptive_prober_->filterValueAccessor(*block, nullptr, nullptr);
-  void *bitmap = (predicate_ != nullptr ? predicate_ : &all)
-                     ->getMatchesForBlock(*block, &matches, static_cast<const std::uint64_t *>(lip));  // getMatchesForPredicate
-  qsx_device_free(lip);
+  // SelectOperator.cpp:161-195: predicate matches, then the LIP filters on what is left
+  void *bitmap = (predicate_ != nullptr ? predicate_ : &all)->getMatchesForBlock(*block, &matches, nullptr);  // getMatchesForPredicate
+  if (lip_filter_adaptive_prober_ != nullptr) {
+    void *filtered = lip_filter_adaptive_prober_->filterValueAccessor(*block, static_cast<const std::uint64_t *>(bitmap), &matches);
+    qsx_device_free(bitmap);
+    bitmap = filtered;
+  }
   block_id out_id;
   BlockReference out = output_destination_->getBlockForInsertion(matches > 0 ? matches : 1, &out_id);
   // block->selectSimple(simple_selection_, matches, output_destination_) (StorageBlock.cpp:390-399), or block->select(
